@@ -1,0 +1,369 @@
+#!/usr/bin/env python3
+"""
+tests/golden/make_golden.py -- generates the committed golden vectors.
+
+Runs ONLY in the build container (needs /root/reference). It imports the reference's own
+Python (inStrain v1.9.1) under a stub importer for the five third-party roots that are not
+installed here (pysam, h5py, Bio, seaborn, lmfit), feeds duck-typed pileup columns to
+  inStrain.profile.profile_utilities.process_bam_sites / shrink_basewise
+  inStrain.profile.snv_utilities.generate_snp_model / generate_snp_table
+  inStrain.profile.linkage.calc_mm_SNV_linkage_network / calculate_ld
+and stores INPUTS + the reference's OUTPUTS as .npz / .csv.gz fixtures next to this file.
+Nothing of the reference's source text is stored -- only data.
+
+Also copies the data files the reference's own tests hold for this path:
+  test/test_data/sars_cov_2_*.sorted.bam, SmallScaffold.fa(.sorted.bam), and the stored
+  golden tables of the sars_cov_2 .IS run.
+
+usage: python tests/golden/make_golden.py [--skip-sars]
+"""
+import gzip
+import importlib.abc
+import importlib.machinery
+import os
+import shutil
+import sys
+import types
+from collections import defaultdict
+from unittest.mock import MagicMock
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    ROOTS = {"pysam", "h5py", "Bio", "seaborn", "lmfit"}
+
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in self.ROOTS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = MagicMock(name=spec.name)
+        m.__path__ = []
+        m.__name__ = spec.name
+        m.__spec__ = spec
+        m.__loader__ = self
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def import_reference():
+    sys.meta_path.insert(0, _StubFinder())
+    sys.path.insert(0, REF)
+    import inStrain.profile.profile_utilities as pu
+    import inStrain.profile.snv_utilities as su
+    import inStrain.profile.linkage as lk
+    import inStrain.profile.fasta as fa
+    return pu, su, lk, fa
+
+
+# ---- duck-typed pileup objects ---------------------------------------------------------
+class _Aln:
+    __slots__ = ("query_name", "query_sequence")
+
+
+class _PRead:
+    __slots__ = ("is_del", "is_refskip", "query_position", "alignment")
+
+
+class _Col:
+    __slots__ = ("pos", "pileups")
+
+
+CH = "ACTGN"
+
+
+def columns_from_obs(pos, base, pair_names):
+    """obs in arrival order -> list of pileup columns (ascending pos, arrival order kept)."""
+    order = np.argsort(pos, kind="stable")
+    cols = []
+    cur = None
+    for i in order:
+        p = int(pos[i])
+        if cur is None or cur.pos != p:
+            cur = _Col()
+            cur.pos = p
+            cur.pileups = []
+            cols.append(cur)
+        a = _Aln()
+        a.query_name = pair_names[i]
+        a.query_sequence = CH[base[i]]
+        r = _PRead()
+        r.is_del = False
+        r.is_refskip = False
+        r.query_position = 0
+        r.alignment = a
+        cur.pileups.append(r)
+    return cols
+
+
+def run_reference_split(mods, scaffold, seq, start, pos, base, mm, pair, nm, skip_mm=False,
+                        min_cov=5, min_freq=0.05, min_snp=20, rarefied_coverage=50):
+    """The body of profile_split (profile_utilities.py:158-192) on duck-typed columns."""
+    pu, su, lk, fa = mods
+    names = ["r%d" % p for p in pair]
+    if skip_mm:
+        R2M = set(names)
+    else:
+        R2M = {n: int(m) for n, m in zip(names, mm)}
+    sel = (pos >= start) & (pos < start + len(seq))
+    cols = columns_from_obs(pos[sel], base[sel], [n for n, s in zip(names, sel) if s])
+    mLen = len(seq)
+    covT, clonT, clonTR, p2c = {}, {}, {}, {}
+    read_to_snvs = defaultdict(pu._dlist)
+    snv2mm2counts = {}
+    Stable = defaultdict(list)
+    np.random.seed(0)
+    pu.process_bam_sites(scaffold, seq, iter(cols), covT, clonT, clonTR, p2c, read_to_snvs,
+                         snv2mm2counts, Stable, None, mLen, nm, R2M, start=start,
+                         min_cov=min_cov, min_freq=min_freq, rarefied_coverage=rarefied_coverage,
+                         min_snp=min_snp)
+    covT = pu.shrink_basewise(covT, "coverage", start=start, len=mLen)
+    clonT = pu.shrink_basewise(clonT, "clonality", start=start, len=mLen)
+    S = su.generate_snp_table(Stable, scaffold, p2c)
+    if len(S) > 0:
+        S["position"] = S["position"] + start
+    G = lk.calc_mm_SNV_linkage_network(read_to_snvs, scaff=scaffold)
+    L = lk.calculate_ld(G, min_snp, snv2mm2counts=snv2mm2counts, scaffold=scaffold)
+    if len(L) > 0:
+        for p in ["position_A", "position_B"]:
+            L[p] = L[p] + start
+    return covT, clonT, S, L, G.number_of_edges()
+
+
+def pack_expected(covT, clonT, S, L, n_edges):
+    """reference outputs -> flat arrays for an .npz"""
+    out = {}
+    cp, cm, cv = [], [], []
+    for m, ser in covT.items():
+        cp.append(ser.index.values.astype(np.int64)); cm.append(np.full(len(ser), m)); cv.append(ser.values.astype(np.int64))
+    out["cov_pos"] = np.concatenate(cp) if cp else np.zeros(0, np.int64)
+    out["cov_mm"] = np.concatenate(cm) if cm else np.zeros(0, np.int64)
+    out["cov_val"] = np.concatenate(cv) if cv else np.zeros(0, np.int64)
+    cp, cm, cv = [], [], []
+    for m, ser in clonT.items():
+        cp.append(ser.index.values.astype(np.int64)); cm.append(np.full(len(ser), m)); cv.append(ser.values.astype(np.float32))
+    out["clon_pos"] = np.concatenate(cp) if cp else np.zeros(0, np.int64)
+    out["clon_mm"] = np.concatenate(cm) if cm else np.zeros(0, np.int64)
+    out["clon_val"] = np.concatenate(cv) if cv else np.zeros(0, np.float32)
+    snv_cols = ["position", "mm", "A", "C", "T", "G", "allele_count", "position_coverage"]
+    if len(S) > 0:
+        S = S.sort_values(["position", "mm"], kind="stable")
+        for c in snv_cols:
+            out["snv_" + c] = S[c].values.astype(np.int64)
+        for c in ["ref_base", "con_base", "var_base", "class"]:
+            out["snv_" + c] = S[c].values.astype(str)
+        out["snv_cryptic"] = S["cryptic"].values.astype(bool)
+    else:
+        for c in snv_cols:
+            out["snv_" + c] = np.zeros(0, np.int64)
+        for c in ["ref_base", "con_base", "var_base", "class"]:
+            out["snv_" + c] = np.zeros(0, dtype="<U1")
+        out["snv_cryptic"] = np.zeros(0, bool)
+    ld_int = ["position_A", "position_B", "mm", "distance", "total", "countAB", "countAb", "countaB", "countab"]
+    if len(L) > 0:
+        L = L.sort_values(["position_A", "position_B", "mm"], kind="stable")
+        for c in ld_int:
+            out["ld_" + c] = L[c].values.astype(np.int64)
+        for c in ["allele_A", "allele_a", "allele_B", "allele_b"]:
+            out["ld_" + c] = L[c].values.astype(str)
+        for c in ["r2", "d_prime"]:
+            out["ld_" + c] = L[c].values.astype(np.float64)
+    else:
+        for c in ld_int:
+            out["ld_" + c] = np.zeros(0, np.int64)
+        for c in ["allele_A", "allele_a", "allele_B", "allele_b"]:
+            out["ld_" + c] = np.zeros(0, dtype="<U1")
+        for c in ["r2", "d_prime"]:
+            out["ld_" + c] = np.zeros(0, np.float64)
+    out["n_edges"] = np.array(n_edges)
+    return out
+
+
+# ---- synthetic cases -------------------------------------------------------------------
+def synth_case(seed, mLen=400, start=0, depth=30, read_len=60, n_sites=12, mm_levels=4,
+               p_other=0.01, ref_ambig=0, self_pairs=0.05, err=0.01, af_lo=0.1, af_hi=0.5,
+               hot_col=0):
+    """Small split with planted bi/tri-allelic sites, sequencing error, non-ACGT bases,
+    non-ACGT reference characters, mate overlaps that leave BOTH mates visible at a column
+    (-> self pairs), and optionally one very deep column (coverage >= 10000 -> LUT fallback)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ref = rng.integers(0, 4, mLen)
+    seq = np.array(list("ACTG"))[ref]
+    for p in rng.choice(mLen, ref_ambig, replace=False):
+        seq[p] = "N"
+    sites = np.sort(rng.choice(np.arange(5, mLen - 5), n_sites, replace=False))
+    alt = (ref[sites] + rng.integers(1, 4, n_sites)) % 4
+    alt2 = (ref[sites] + rng.integers(1, 4, n_sites)) % 4
+    af = rng.uniform(af_lo, af_hi, n_sites)
+    n_pairs = int(depth * mLen / (2 * read_len))
+    hap = rng.integers(0, 2, n_pairs)       # two haplotype backgrounds -> non-trivial LD
+    P, B, M, R = [], [], [], []
+    for pid in range(n_pairs):
+        mm = int(rng.integers(0, mm_levels))
+        s1 = int(rng.integers(-read_len // 2, mLen - read_len // 2))
+        gap = int(rng.integers(-read_len // 2, read_len)) if rng.random() < self_pairs * 4 else int(rng.integers(0, read_len))
+        s2 = s1 + read_len + gap
+        for s in (s1, s2):
+            pp = np.arange(s, s + read_len)
+            pp = pp[(pp >= 0) & (pp < mLen)]
+            if s == s2 and gap < 0 and rng.random() > self_pairs:
+                pp = pp[pp >= s1 + read_len]            # overlap resolved: one mate visible
+            keep = rng.random(len(pp)) > 0.1            # base-quality drop-outs
+            pp = pp[keep]
+            b = ref[pp].copy()
+            for k, sp in enumerate(sites):
+                hit = pp == sp
+                if hit.any():
+                    carries = (rng.random() < af[k] * (1.6 if hap[pid] else 0.4))
+                    if carries:
+                        b[hit] = alt[k] if rng.random() < 0.85 else alt2[k]
+            e = rng.random(len(pp)) < err
+            b[e] = rng.integers(0, 4, e.sum())
+            o = rng.random(len(pp)) < p_other
+            b[o] = 4
+            P.append(pp + start); B.append(b); M.append(np.full(len(pp), mm)); R.append(np.full(len(pp), pid))
+    if hot_col:
+        hp = int(sites[0])
+        bb = np.where(rng.random(hot_col) < 0.3, alt[0], ref[hp])
+        P.append(np.full(hot_col, hp + start)); B.append(bb); M.append(rng.integers(0, mm_levels, hot_col))
+        R.append(np.arange(n_pairs, n_pairs + hot_col))
+    pos = np.concatenate(P).astype(np.int64)
+    base = np.concatenate(B).astype(np.uint8)
+    mm = np.concatenate(M).astype(np.int64)
+    pair = np.concatenate(R).astype(np.int64)
+    # pair -> mm must be a function of the pair (R2M)
+    return "".join(seq), pos, base, mm, pair
+
+
+SYNTH = {
+    "synth_mm4": dict(seed=11, mm_levels=4),
+    "synth_m1": dict(seed=12, mm_levels=1),
+    "synth_skipmm": dict(seed=13, mm_levels=3, skip_mm=True),
+    "synth_ambig": dict(seed=14, mm_levels=6, p_other=0.06, ref_ambig=20),
+    "synth_lowcov": dict(seed=15, depth=7, mm_levels=3),
+    "synth_offset": dict(seed=16, start=20000, mm_levels=5, depth=60),
+    "synth_selfpairs": dict(seed=17, self_pairs=0.6, mm_levels=3, depth=80, n_sites=25),
+    "synth_deep": dict(seed=18, mm_levels=3, hot_col=12000, depth=40),
+    "synth_dense": dict(seed=19, mm_levels=8, depth=150, n_sites=60, mLen=600, af_lo=0.2),
+    "synth_minsnp5": dict(seed=20, mm_levels=2, depth=25, min_snp=5, min_cov=3, min_freq=0.1),
+}
+
+
+def main():
+    mods = import_reference()
+    pu, su, lk, fa = mods
+    from oracle import bam_py
+
+    nm = su.generate_snp_model(REF + "/inStrain/helper_files/NullModel.txt", fdr=1e-6)
+    lut = np.full(10001, -1, dtype=np.int32)
+    for k, v in nm.items():
+        if k >= 0:
+            lut[k] = v
+    np.savez_compressed(os.path.join(HERE, "null_model_fdr1e-6.npz"), lut=lut, fallback=np.array(nm[-1]))
+
+    # iterate_splits sweep (profile/fasta.py:56-73)
+    lens = [1, 2, 126, 999, 1000, 1001, 9999, 10000, 10001, 19999, 20000, 29879, 30000, 123457, 5000000]
+    rows = []
+    for L in lens:
+        for W in (1000, 10000):
+            for i, (s, e) in enumerate(fa.iterate_splits(L, W)):
+                rows.append((L, W, i, s, e))
+    np.save(os.path.join(HERE, "iterate_splits.npy"), np.array(rows, dtype=np.int64))
+
+    # synthetic splits through the reference's own functions
+    for name, kw in SYNTH.items():
+        kw = dict(kw)
+        skip_mm = kw.pop("skip_mm", False)
+        params = dict(min_cov=kw.pop("min_cov", 5), min_freq=kw.pop("min_freq", 0.05), min_snp=kw.pop("min_snp", 20))
+        start = kw.get("start", 0)
+        seq, pos, base, mm, pair = synth_case(**kw)
+        covT, clonT, S, L, ne = run_reference_split(mods, "scaf", seq, start, pos, base, mm, pair, nm,
+                                                    skip_mm=skip_mm, **params)
+        exp = pack_expected(covT, clonT, S, L, ne)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), seq=np.array(seq), start=np.array(start),
+                            pos=pos.astype(np.int32), base=base, mm=(mm * (0 if skip_mm else 1)).astype(np.int32),
+                            pair=pair.astype(np.int32), **{"p_" + k: np.array(v) for k, v in params.items()}, **exp)
+        print(name, "obs", len(pos), "snv rows", len(S), "ld rows", len(L), "edges", ne)
+
+    if "--skip-sars" in sys.argv:
+        return
+
+    # ---- the reference's stored golden run (sars_cov_2) ----
+    td = REF + "/test/test_data/"
+    bam = td + "sars_cov_2_MT039887.1.fasta.bt2-vs-SRR11140750.sorted.bam"
+    isd = td + "sars_cov_2_MT039887.1.fasta.bt2-vs-SRR11140750.sam.IS/raw_data/"
+    shutil.copy(bam, os.path.join(HERE, "sars_cov_2.sorted.bam"))
+    shutil.copy(td + "SmallScaffold.fa.sorted.bam", os.path.join(HERE, "SmallScaffold.fa.sorted.bam"))
+    shutil.copy(td + "SmallScaffold.fa", os.path.join(HERE, "SmallScaffold.fa"))
+    for f in ["raw_snp_table", "raw_linkage_table", "cumulative_scaffold_table", "read_report"]:
+        shutil.copy(isd + f + ".csv.gz", os.path.join(HERE, "sars_cov_2_" + f + ".csv.gz"))
+    for f in os.listdir(HERE):
+        os.chmod(os.path.join(HERE, f), 0o644)
+    # reference sequence from the GenBank record (ORIGIN block) -> FASTA (data)
+    seq = []
+    on = False
+    for line in open(td + "sars_cov_2_MT039887.1.gb"):
+        if line.startswith("ORIGIN"):
+            on = True
+            continue
+        if line.startswith("//"):
+            on = False
+        if on:
+            seq.append("".join(line.split()[1:]))
+    seq = "".join(seq).upper()
+    with open(os.path.join(HERE, "sars_cov_2_MT039887.1.fasta"), "w") as f:
+        f.write(">MT039887.1\n")
+        for i in range(0, len(seq), 70):
+            f.write(seq[i:i + 70] + "\n")
+
+    # reference code on the fixture (pileup by oracle/bam_py) vs stored golden
+    refs, reads = bam_py.read_bam(bam)
+    assert refs[0][1] == len(seq), (refs, len(seq))
+    p2i = bam_py.get_paired_reads(reads, 0)
+    r2m, tallies = bam_py.filter_pairs({refs[0][0]: p2i})
+    r2m = r2m[refs[0][0]]
+    print("filtered pairs", len(r2m), tallies)
+    bam_py.resolve_overlaps(reads, 0)
+    pos, base, mm, pair, name2id = bam_py.expand_observations(reads, 0, r2m)
+    np.savez_compressed(os.path.join(HERE, "sars_cov_2_obs.npz"), pos=pos.astype(np.int32), base=base,
+                        mm=mm.astype(np.int32), pair=pair.astype(np.int32))
+    Ss, Ls = [], []
+    cov = defaultdict(list)
+    for i, (s, e) in enumerate(fa.iterate_splits(len(seq), 10000)):
+        covT, clonT, S, L, ne = run_reference_split(mods, refs[0][0], seq[s:e + 1], s, pos, base, mm, pair, nm)
+        Ss.append(S); Ls.append(L)
+        print("split", i, s, e, len(S), len(L), ne)
+    S = pd.concat(Ss).reset_index(drop=True)
+    L = pd.concat(Ls).reset_index(drop=True)
+    gS = pd.read_csv(isd + "raw_snp_table.csv.gz").rename(columns={"refBase": "ref_base", "conBase": "con_base",
+                     "varBase": "var_base", "baseCoverage": "position_coverage"})
+    gL = pd.read_csv(isd + "raw_linkage_table.csv.gz")
+    S = S.sort_values(["position", "mm"]).reset_index(drop=True)
+    gS = gS.sort_values(["position", "mm"]).reset_index(drop=True)
+    bad = 0
+    assert len(S) == len(gS), (len(S), len(gS))
+    for c in ["position", "mm", "A", "C", "T", "G", "ref_base", "con_base", "var_base", "allele_count", "cryptic", "position_coverage"]:
+        bad += int((S[c].values != gS[c].values).sum())
+    L = L.sort_values(["position_A", "position_B", "mm"]).reset_index(drop=True)
+    gL = gL.sort_values(["position_A", "position_B", "mm"]).reset_index(drop=True)
+    assert len(L) == len(gL), (len(L), len(gL))
+    for c in ["position_A", "position_B", "mm", "total", "countAB", "countAb", "countaB", "countab", "allele_A", "allele_a", "allele_B", "allele_b", "distance"]:
+        bad += int((L[c].values != gL[c].values).sum())
+    dr2 = np.nanmax(np.abs(L["r2"].values - gL["r2"].values))
+    print("reference-on-our-pileup vs stored golden: mismatches", bad, "max|dr2|", dr2)
+    assert bad == 0
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""Pins the C oracle (oracle/oracle_core.c) against golden vectors produced by the
+reference's own Python (tests/golden/make_golden.py) -- CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import util
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(util.GOLD, "synth_*.npz")))
+
+
+def run_oracle_case(g, lut, fb):
+    return oracle.profile_split(g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]),
+                                lut, fb, min_cov=int(g["p_min_cov"]), min_freq=float(g["p_min_freq"]),
+                                min_snp=int(g["p_min_snp"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_vectors(name):
+    lut, fb = util.load_lut()
+    g = util.load_case(name)
+    res = run_oracle_case(g, lut, fb)
+    got = util.canon_from_struct(res)
+    exp = util.canon_from_golden(g)
+    util.assert_same(got, exp, float_tol=0.0, what=name)     # same IEEE ops in the same order -> identical
+    assert res["n_edges"] == int(g["n_edges"])
+
+
+def test_cases_exist():
+    assert len(CASES) >= 8
+
+
+# ---------------------------------------------------------------------------------------
+# The reference's stored golden run (sars_cov_2 .IS folder, inStrain 1.2.4 + real pysam)
+# ---------------------------------------------------------------------------------------
+def iterate_splits(sLen, W):
+    """profile/fasta.py:56-73"""
+    n = sLen // W + 1
+    cl = int(sLen / n)
+    out, s, e = [], 0, 0
+    for i in range(n):
+        if i + 1 == n:
+            out.append((s, sLen - 1))
+        else:
+            e += cl
+            out.append((s, e - 1))
+            s += cl
+    return out
+
+
+def read_fasta(path):
+    return "".join(l.strip() for l in open(path) if not l.startswith(">")).upper()
+
+
+def sars_golden_tables():
+    import pandas as pd
+    S = pd.read_csv(os.path.join(util.GOLD, "sars_cov_2_raw_snp_table.csv.gz")).rename(
+        columns={"refBase": "ref_base", "conBase": "con_base", "varBase": "var_base",
+                 "baseCoverage": "position_coverage"})      # test/tests/test_utils.py:165-195
+    L = pd.read_csv(os.path.join(util.GOLD, "sars_cov_2_raw_linkage_table.csv.gz"))
+    return (S.sort_values(["position", "mm"]).reset_index(drop=True),
+            L.sort_values(["position_A", "position_B", "mm"]).reset_index(drop=True))
+
+
+def check_against_sars_golden(snv, ld, float_tol):
+    """snv / ld: concatenated structured arrays (oracle field names), absolute positions."""
+    S, L = sars_golden_tables()
+    o = np.lexsort((snv["mm"], snv["pos"]))
+    snv = snv[o]
+    assert len(snv) == len(S) == 707
+    assert (snv["pos"] == S["position"].values).all() and (snv["mm"] == S["mm"].values).all()
+    for i, b in enumerate("ACTG"):
+        assert (snv["cnt"][:, i] == S[b].values).all(), b
+    assert (util.BASES[snv["con_base"]] == S["con_base"].values).all()
+    assert (util.BASES[snv["var_base"]] == S["var_base"].values).all()
+    assert (util.BASES[snv["ref_base"]] == S["ref_base"].values).all()
+    assert (snv["allele_count"] == S["allele_count"].values).all()
+    assert (snv["cryptic"].astype(bool) == S["cryptic"].values).all()
+    assert (snv["position_coverage"] == S["position_coverage"].values).all()
+    o = np.lexsort((ld["mm"], ld["pos_b"], ld["pos_a"]))
+    ld = ld[o]
+    assert len(ld) == len(L) == 2228
+    for a, b in [("pos_a", "position_A"), ("pos_b", "position_B"), ("mm", "mm"), ("distance", "distance"),
+                 ("total", "total"), ("cAB", "countAB"), ("cAb", "countAb"), ("caB", "countaB"), ("cab", "countab")]:
+        assert (ld[a] == L[b].values).all(), b
+    for k in ["allele_A", "allele_a", "allele_B", "allele_b"]:
+        assert (util.BASES[ld[k]] == L[k].values).all(), k
+    for a, b in [("r2", "r2"), ("d_prime", "d_prime")]:
+        x, y = ld[a], L[b].values.astype(float)
+        assert (np.isnan(x) == np.isnan(y)).all(), b
+        m = ~np.isnan(x)
+        assert np.max(np.abs(x[m] - y[m])) <= float_tol, (b, np.max(np.abs(x[m] - y[m])))
+    assert (ld["distance"] == 0).sum() == 16        # self pairs are real
+
+
+def test_oracle_vs_stored_sars_golden():
+    lut, fb = util.load_lut()
+    z = np.load(os.path.join(util.GOLD, "sars_cov_2_obs.npz"))
+    seq = read_fasta(os.path.join(util.GOLD, "sars_cov_2_MT039887.1.fasta"))
+    snv, ld = [], []
+    for s, e in iterate_splits(len(seq), 10000):
+        r = oracle.profile_split(z["pos"], z["base"], z["mm"], z["pair"], seq[s:e + 1], s, lut, fb,
+                                 min_cov=5, min_freq=0.05, min_snp=20)
+        snv.append(r["snv"]); ld.append(r["ld"])
+    check_against_sars_golden(np.concatenate(snv), np.concatenate(ld), float_tol=1e-9)
+
+
+def test_iterate_splits_sweep():
+    rows = np.load(os.path.join(util.GOLD, "iterate_splits.npy"))
+    for L in np.unique(rows[:, 0]):
+        for W in (1000, 10000):
+            exp = rows[(rows[:, 0] == L) & (rows[:, 1] == W)][:, 3:5]
+            got = np.array(iterate_splits(int(L), W))
+            assert (got == exp).all(), (L, W)
+
+
+def test_bam_py_reproduces_sars_observations():
+    """BGZF/BAM decode + read filter + htslib-1.9 overlap rules (oracle/bam_py.py) regenerate the
+    committed packed observations; read-filter tallies equal the stored read_report."""
+    import pandas as pd
+    from oracle import bam_py
+    refs, reads = bam_py.read_bam(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"))
+    assert refs == [("MT039887.1", 29879)] and len(reads) == 28913
+    p2i = bam_py.get_paired_reads(reads, 0)
+    r2m, tallies = bam_py.filter_pairs({"MT039887.1": p2i})
+    t = tallies["MT039887.1"]
+    rr = pd.read_csv(os.path.join(util.GOLD, "sars_cov_2_read_report.csv.gz"), comment="#")
+    row = rr[rr["scaffold"] == "MT039887.1"].iloc[0]
+    assert t["filtered_pairs"] == int(row["filtered_pairs"]) == 13124
+    assert t["unfiltered_pairs"] == int(row["unfiltered_pairs"])
+    assert t["median_insert"] == 267.0
+    bam_py.resolve_overlaps(reads, 0)
+    pos, base, mm, pair, _ = bam_py.expand_observations(reads, 0, r2m["MT039887.1"])
+    z = np.load(os.path.join(util.GOLD, "sars_cov_2_obs.npz"))
+    assert len(pos) == len(z["pos"]) == 3717600
+    assert (pos == z["pos"]).all() and (base == z["base"]).all() and (mm == z["mm"]).all() and (pair == z["pair"]).all()
