@@ -1,0 +1,213 @@
+/*
+ * instrain_amd.h -- C ABI of libinstrain_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the `inStrain profile` hot path.  The reference has no FFI layer
+ * (it is pure Python); the seam this library replaces is
+ *
+ *   profile_split(samfile, scaffold, start, end, split_number, seq, R2M, null_model, **kw)
+ *       -> SplitObject          /root/reference/inStrain/profile/profile_utilities.py:115-216
+ *
+ * called once per split from split_profile_wrapper_groups (profile_utilities.py:92-112).
+ * Here MANY splits are profiled by one call: a "batch" is a set of splits laid out in one
+ * flat position space (flat position = split offset + position inside the split), so the
+ * device sees one long, position-clustered observation stream and >>256 workgroups.
+ *
+ * Plain C types only; no torch / HIP types cross this boundary.  Every function returns
+ * ISX_OK (0) or a negative error code; isx_last_error() gives the message (thread-local).
+ * One isx_ctx per GPU; a ctx is not thread-safe, different ctxs are independent.
+ *
+ * What each group of entry points replaces in the reference:
+ *   isx_set_null_model      snv_utilities.py:14-38   generate_snp_model (the dict handed to
+ *                                                    every profile_split call)
+ *   isx_batch_create        profile_utilities.py:150-153 + 268-286: the pileup iterator's
+ *                           visits, already filtered to reads in R2M, as packed records
+ *                           (decoded on the host -- isx_bam_* below -- or by the caller)
+ *   isx_batch_run           profile_utilities.py:218-266 process_bam_sites (get_base_counts_mm,
+ *                           update_covT, snv_utilities.update_snp_table 40-145, call_snv_site,
+ *                           calculate_clonality, calc_snp_class), linkage.update_linked_reads
+ *                           254-283, calc_mm_SNV_linkage_network 14-44, calculate_ld 46-240
+ *   isx_batch_fetch_*       the SplitObject fields (profile_utilities.py:195-211): covT / clonT
+ *                           (entries), raw_snp_table (snv rows), raw_linkage_table (ld rows)
+ *   isx_bam_*               pysam.AlignmentFile + samfile.pileup(...) with the htslib-1.9 rules
+ *                           of profile_utilities.py:150-153, and filter_reads.get_paired_reads /
+ *                           filter_scaff2pair2info (filter_reads.py:885-956, 201-260)
+ */
+#ifndef INSTRAIN_AMD_H
+#define INSTRAIN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISX_OK 0
+#define ISX_ERR_ARG (-1)        /* bad argument */
+#define ISX_ERR_HIP (-2)        /* HIP runtime error / no gfx950 device */
+#define ISX_ERR_CAPACITY (-3)   /* an output table outgrew its device buffer */
+#define ISX_ERR_MM_RANGE (-4)   /* an observation's mm level >= n_mm_bins */
+#define ISX_ERR_IO (-5)         /* BAM / file error */
+#define ISX_ERR_STATE (-6)      /* call out of order (e.g. fetch before run) */
+
+#define ISX_ABI_VERSION 1
+
+/* Base codes everywhere: 0=A 1=C 2=T 3=G (P2C order, profile_utilities.py:34), 4 = anything else. */
+
+typedef struct isx_ctx isx_ctx;
+typedef struct isx_batch isx_batch;
+
+/* One packed pileup observation = one (pileup column, pileup read) visit on which the
+ * reference touches its count table.  8 bytes. */
+typedef struct {
+    uint32_t gpos;      /* flat position in the batch */
+    uint16_t mm;        /* R2M[read name]; 0 when mm profiling is skipped */
+    uint8_t base;       /* 0..4 */
+    uint8_t flags;      /* reserved, 0 */
+} isx_obs;
+
+typedef struct {
+    int32_t min_cov;            /* -c, default 5   (profile_utilities.py:142) */
+    int32_t min_snp;            /* --min_snp, default 20 at the CLI (argumentParser.py:164) */
+    double min_freq;            /* -f, default 0.05 */
+    int32_t rarefied_coverage;  /* --rarefied_coverage, default 50 */
+    int32_t n_mm_bins;          /* mm levels 0..n_mm_bins-1 may occur; 1 = --skip_mm_profiling */
+    int32_t enable_linkage;     /* 0: pileup / SNV only */
+    int32_t linkage_mode;       /* 0 auto, 1 sparse pair-increment path, 2 dense int8 MFMA path */
+    int32_t window;             /* 0 = auto; positions per workgroup window (power of two) */
+    uint64_t seed;              /* counter-based RNG seed for the rarefied outputs */
+} isx_params;
+
+/* (position, mm)-present entry: one per mm level present at a position, ascending mm.
+ * 28 bytes.  cnt = counts of THIS level; covT[mm][pos] = sum(cnt); clon = clonT[mm][pos]
+ * (float32 of the cumulative-<=mm clonality) or NaN when cumulative coverage < min_cov. */
+typedef struct {
+    uint32_t gpos;
+    uint16_t mm;
+    uint16_t flags;
+    uint32_t cnt[4];
+    float clon;
+} isx_entry;
+
+/* raw_snp_table row (snv_utilities.py:118-127, 274-290).  28 bytes. */
+typedef struct {
+    uint32_t gpos;
+    uint16_t mm;
+    uint8_t con_base, var_base;
+    uint8_t allele_count;       /* "morphia" */
+    uint8_t cls;                /* 0 AmbiguousReference 1 DivergentSite 2 SNS 3 SNV 4 con_SNV 5 pop_SNV */
+    uint8_t cryptic;
+    uint8_t ref_base;           /* 0..4 */
+    uint32_t cnt[4];            /* cumulative over levels <= mm; position_coverage = sum */
+} isx_snv;
+
+/* raw_linkage_table row (linkage.py:230-237 + 67-71), random *_normalized columns excluded. */
+typedef struct {
+    uint32_t gpos_a, gpos_b;    /* flat positions, gpos_a <= gpos_b */
+    uint16_t mm;
+    uint8_t allele_A, allele_a, allele_B, allele_b;
+    uint16_t pad;
+    uint32_t total, countAB, countAb, countaB, countab;
+    uint32_t pad2;
+    double r2, d_prime;
+} isx_ld;
+
+/* sizes of the result tables of a batch after isx_batch_run */
+typedef struct {
+    int64_t n_entries;      /* 0 when n_mm_bins == 1 (dense counts/clon arrays instead) */
+    int64_t n_snv;
+    int64_t n_sites;        /* positions with anySNP (snv_utilities.py:129-133) */
+    int64_t n_allele_obs;   /* update_linked_reads appends */
+    int64_t n_increments;   /* calc_mm_SNV_linkage_network pair increments */
+    int64_t n_edges;        /* graph edges (distinct site pairs, self pairs included) */
+    int64_t n_ld;
+} isx_sizes;
+
+/* per-kernel device time of the last isx_batch_run, milliseconds (HIP events on the ctx stream) */
+typedef struct {
+    float pileup_ms;        /* k_pileup_call: window histogram + SNV call epilogue */
+    float sites_ms;         /* site table sort / rank */
+    float allele_ms;        /* k_allele_obs: second pass over the observations */
+    float group_ms;         /* group allele observations by pair */
+    float incr_ms;          /* pair increments -> keys, sort, run-length */
+    float ld_ms;            /* LD rows */
+    float total_ms;
+    int32_t pileup_blocks, pileup_threads, pileup_lds_bytes, pad;
+} isx_timings;
+
+const char *isx_last_error(void);
+int isx_abi_version(void);
+
+int isx_ctx_create(int device_id, isx_ctx **out);
+void isx_ctx_destroy(isx_ctx *ctx);
+
+/* lut[c] = minimum count for a base to be "present" at coverage c, or < 0 when the
+ * coverage is missing from the model; fallback = model[-1]. */
+int isx_set_null_model(isx_ctx *ctx, const int32_t *lut, int64_t n, int32_t fallback);
+
+/*
+ * Make a batch resident on the device.
+ *   n_pos         flat positions; ref[n_pos] reference base codes (0..4)
+ *   split_bounds  [n_splits+1] ascending flat offsets, split_bounds[0]=0, [n_splits]=n_pos;
+ *                 linkage never crosses a bound (profile_utilities.py:164,188-189)
+ *   obs[n_obs]    packed observations in BAM arrival order (position-clustered)
+ *   pair[n_obs]   dense read-pair id of each observation (both mates share it); may be NULL
+ *                 when enable_linkage == 0
+ * Host buffers may be freed after the call returns.
+ */
+int isx_batch_create(isx_ctx *ctx, const isx_params *params, int64_t n_pos, const uint8_t *ref,
+                     int32_t n_splits, const int64_t *split_bounds, int64_t n_obs,
+                     const isx_obs *obs, const uint32_t *pair, isx_batch **out);
+void isx_batch_destroy(isx_batch *b);
+
+/* One pass of the hot path over the resident batch (blocking). Re-runnable. */
+int isx_batch_run(isx_batch *b);
+int isx_batch_sizes(const isx_batch *b, isx_sizes *out);
+int isx_batch_timings(const isx_batch *b, isx_timings *out);
+
+/* Results -> caller-allocated host buffers sized from isx_batch_sizes. Tables come back in
+ * canonical order: entries (gpos, mm); snv (gpos, mm); ld (gpos_a, gpos_b, mm). */
+int isx_batch_fetch_entries(isx_batch *b, isx_entry *out);
+int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts /* [n_pos][4] */, float *clon /* [n_pos] */);
+int isx_batch_fetch_snv(isx_batch *b, isx_snv *out);
+int isx_batch_fetch_ld(isx_batch *b, isx_ld *out);
+
+/* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ---- */
+typedef struct isx_bam isx_bam;
+
+typedef struct {
+    double min_read_ani;        /* -l, 0.95 */
+    int32_t min_mapq;           /* -1 */
+    double max_insert_relative; /* 3 */
+    int32_t min_insert;         /* 50 */
+    int32_t min_base_quality;   /* 30 (profile_utilities.py:153) */
+    int32_t skip_mm;            /* --skip_mm_profiling */
+    int32_t window_length;      /* 10000 (fasta.py:56-73 iterate_splits) */
+    int32_t pad;
+} isx_bam_params;
+
+typedef struct {
+    int32_t n_refs;
+    int32_t n_splits;
+    int64_t n_reads;
+    int64_t n_pos;              /* sum of reference lengths = flat space */
+    int64_t n_obs;
+    int64_t n_pairs;            /* dense pair ids handed out */
+    int64_t unfiltered_pairs, filtered_pairs;
+    int64_t filtered_bases;     /* sum of query lengths of filtered pairs ("Gbp profiled" numerator) */
+    double median_insert;
+    int32_t max_mm;
+    int32_t pad;
+} isx_bam_info;
+
+int isx_bam_open(const char *path, isx_bam **out);
+void isx_bam_close(isx_bam *bam);
+/* filter + overlap resolution + expansion of every reference of the file */
+int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info);
+int isx_bam_ref(const isx_bam *bam, int32_t i, const char **name, int64_t *length, int64_t *flat_offset);
+/* copy out: obs[n_obs], pair[n_obs], split_bounds[n_splits+1], split_ref[n_splits] */
+int isx_bam_copy(const isx_bam *bam, isx_obs *obs, uint32_t *pair, int64_t *split_bounds, int32_t *split_ref);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

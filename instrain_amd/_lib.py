@@ -1,0 +1,107 @@
+"""ctypes binding of libinstrain_amd.so (include/instrain_amd.h).
+
+There is NO CPU fallback: if the HIP extension is missing or no MI355X is visible the calls
+raise IsxError.  Nothing here imports `oracle/`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinstrain_amd.so")
+
+OBS_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("base", "u1"), ("flags", "u1")])
+ENTRY_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("flags", "<u2"), ("cnt", "<u4", (4,)), ("clon", "<f4")])
+SNV_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("con_base", "u1"), ("var_base", "u1"),
+                   ("allele_count", "u1"), ("cls", "u1"), ("cryptic", "u1"), ("ref_base", "u1"),
+                   ("cnt", "<u4", (4,))])
+LD_DT = np.dtype([("gpos_a", "<u4"), ("gpos_b", "<u4"), ("mm", "<u2"), ("allele_A", "u1"), ("allele_a", "u1"),
+                  ("allele_B", "u1"), ("allele_b", "u1"), ("pad", "<u2"), ("total", "<u4"), ("countAB", "<u4"),
+                  ("countAb", "<u4"), ("countaB", "<u4"), ("countab", "<u4"), ("pad2", "<u4"),
+                  ("r2", "<f8"), ("d_prime", "<f8")])
+assert OBS_DT.itemsize == 8 and ENTRY_DT.itemsize == 28 and SNV_DT.itemsize == 28 and LD_DT.itemsize == 56
+
+
+class Params(C.Structure):
+    _fields_ = [("min_cov", C.c_int32), ("min_snp", C.c_int32), ("min_freq", C.c_double),
+                ("rarefied_coverage", C.c_int32), ("n_mm_bins", C.c_int32), ("enable_linkage", C.c_int32),
+                ("linkage_mode", C.c_int32), ("window", C.c_int32), ("seed", C.c_uint64)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_entries", "n_snv", "n_sites", "n_allele_obs", "n_increments",
+                                         "n_edges", "n_ld")]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("pileup_ms", "sites_ms", "allele_ms", "group_ms", "incr_ms", "ld_ms",
+                                         "total_ms")] + \
+               [(n, C.c_int32) for n in ("pileup_blocks", "pileup_threads", "pileup_lds_bytes", "pad")]
+
+
+class BamParams(C.Structure):
+    _fields_ = [("min_read_ani", C.c_double), ("min_mapq", C.c_int32), ("max_insert_relative", C.c_double),
+                ("min_insert", C.c_int32), ("min_base_quality", C.c_int32), ("skip_mm", C.c_int32),
+                ("window_length", C.c_int32), ("pad", C.c_int32)]
+
+
+class BamInfo(C.Structure):
+    _fields_ = [("n_refs", C.c_int32), ("n_splits", C.c_int32), ("n_reads", C.c_int64), ("n_pos", C.c_int64),
+                ("n_obs", C.c_int64), ("n_pairs", C.c_int64), ("unfiltered_pairs", C.c_int64),
+                ("filtered_pairs", C.c_int64), ("filtered_bases", C.c_int64), ("median_insert", C.c_double),
+                ("max_mm", C.c_int32), ("pad", C.c_int32)]
+
+
+class IsxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libinstrain_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destroy", "isx_set_null_model",
+           "isx_batch_create", "isx_batch_destroy", "isx_batch_run", "isx_batch_sizes", "isx_batch_timings",
+           "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
+           "isx_bam_open", "isx_bam_close", "isx_bam_expand", "isx_bam_ref", "isx_bam_copy"]
+
+_lib = None
+
+
+def load():
+    """Load the in-tree shared library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IsxError(-2, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.isx_last_error.restype = C.c_char_p
+    lib.isx_abi_version.restype = C.c_int
+    lib.isx_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.isx_ctx_destroy.argtypes = [vp]
+    lib.isx_ctx_destroy.restype = None
+    lib.isx_set_null_model.argtypes = [vp, vp, i64, i32]
+    lib.isx_batch_create.argtypes = [vp, C.POINTER(Params), i64, vp, i32, vp, i64, vp, vp, C.POINTER(vp)]
+    lib.isx_batch_destroy.argtypes = [vp]
+    lib.isx_batch_destroy.restype = None
+    lib.isx_batch_run.argtypes = [vp]
+    lib.isx_batch_sizes.argtypes = [vp, C.POINTER(Sizes)]
+    lib.isx_batch_timings.argtypes = [vp, C.POINTER(Timings)]
+    for f in ("isx_batch_fetch_entries", "isx_batch_fetch_snv", "isx_batch_fetch_ld"):
+        getattr(lib, f).argtypes = [vp, vp]
+    lib.isx_batch_fetch_dense.argtypes = [vp, vp, vp]
+    lib.isx_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.isx_bam_close.argtypes = [vp]
+    lib.isx_bam_close.restype = None
+    lib.isx_bam_expand.argtypes = [vp, C.POINTER(BamParams), C.POINTER(BamInfo)]
+    lib.isx_bam_ref.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64)]
+    lib.isx_bam_copy.argtypes = [vp, vp, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IsxError(rc, load().isx_last_error().decode(errors="replace"))

@@ -1,0 +1,533 @@
+// bam_front.cpp -- host side of the hot path: BGZF/BAM decode, read-pair filter and the
+// htslib-1.9 pileup rules, producing the packed observation stream the kernels consume.
+//
+// Replaces (host side, C++; the reference reaches all of this through pysam -> htslib, which
+// is not vendored under /root/reference):
+//   pysam.AlignmentFile(bam) / samfile.fetch      /root/reference/inStrain/profile/profile_utilities.py:56
+//   get_paired_reads                              /root/reference/inStrain/filter_reads.py:885-956
+//   paired_read_filter ('paired_only')            filter_reads.py:471-532
+//   filter_scaff2pair2info / evaluate_pair        filter_reads.py:201-260, 388-426
+//   samfile.pileup(..., stepper='nofilter', ignore_overlaps=True, min_base_quality=30, ...)
+//                                                 profile_utilities.py:150-153
+//       = htslib 1.9 bam_plp: default flag mask UNMAP|SECONDARY|QCFAIL|DUP, overlap_push /
+//         tweak_overlap_quality / cigar_iref2iseq_set/next (sam.c), and pysam's
+//         `qual >= min_base_quality` test when listing PileupColumn.pileups
+//   iterate_splits                                /root/reference/inStrain/profile/fasta.py:56-73
+//
+// No device code here; it is linked into libinstrain_amd.so so that the whole path sits behind
+// one C ABI.  Inflate of the BGZF blocks is multi-threaded (blocks are independent).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/instrain_amd.h"
+
+void isx_set_error(const std::string &msg);
+
+namespace {
+
+enum { CM = 0, CI, CD, CN, CS, CH, CP, CEQ, CX };
+constexpr uint16_t FPROPER = 0x2, FUNMAP = 0x4, FMUNMAP = 0x8, FSECONDARY = 0x100, FQCFAIL = 0x200, FDUP = 0x400;
+constexpr uint16_t DEF_MASK = FUNMAP | FSECONDARY | FQCFAIL | FDUP;
+
+// 4-bit BAM code -> inStrain base index (A,C,T,G = 0..3; everything else 4)
+const uint8_t CODE2IDX[16] = {4, 0, 1, 4, 3, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4};
+
+struct Read {
+    int32_t tid, pos, isize, l_seq, nm;
+    uint16_t flag, n_cigar;
+    uint8_t mapq;
+    bool has_nm;
+    uint32_t name_off, name_len;
+    uint64_t cigar_off, seq_off, qual_off;
+};
+
+struct Cursor {     // htslib sam.c cigar_iref2iseq_* state
+    const uint32_t *cig; int n; int k, icig, iseq, iref;
+};
+
+int cur_set(Cursor &c, int pos)
+{
+    if (pos < 0) return -1;
+    c.k = 0; c.icig = 0; c.iseq = 0; c.iref = 0;
+    while (c.k < c.n) {
+        const int op = c.cig[c.k] & 15, n = (int)(c.cig[c.k] >> 4);
+        if (op == CS) { c.k++; c.iseq += n; c.icig = 0; continue; }
+        if (op == CH || op == CP) { c.k++; c.icig = 0; continue; }
+        if (op == CM || op == CEQ || op == CX) {
+            pos -= n;
+            if (pos < 0) { c.icig = n + pos; c.iseq += c.icig; c.iref += c.icig; return 0; }
+            c.k++; c.iseq += n; c.icig = 0; c.iref += n;
+            continue;
+        }
+        if (op == CI) { c.k++; c.iseq += n; c.icig = 0; continue; }
+        if (op == CD || op == CN) {
+            pos -= n;
+            if (pos < 0) pos = 0;
+            c.k++; c.icig = 0; c.iref += n;
+            continue;
+        }
+        return -2;
+    }
+    c.iseq = -1;
+    return -1;
+}
+
+int cur_next(Cursor &c)
+{
+    while (c.k < c.n) {
+        const int op = c.cig[c.k] & 15, n = (int)(c.cig[c.k] >> 4);
+        if (op == CM || op == CEQ || op == CX) {
+            if (c.icig >= n - 1) { c.icig = 0; c.k++; continue; }
+            c.iseq++; c.icig++; c.iref++;
+            return 0;
+        }
+        if (op == CD || op == CN) { c.k++; c.iref += n; c.icig = 0; continue; }
+        if (op == CI || op == CS) { c.k++; c.iseq += n; c.icig = 0; continue; }
+        if (op == CH || op == CP) { c.k++; c.icig = 0; continue; }
+        return -2;
+    }
+    c.iseq = -1; c.iref = -1;
+    return -1;
+}
+
+struct PairInfo {       // filter_reads.py i2o order
+    int64_t nm, insert, mapq, length, reads, start, stop;
+    bool pass;
+    uint32_t pair_id;
+};
+
+}  // namespace
+
+struct isx_bam {
+    std::vector<std::string> ref_name;
+    std::vector<int64_t> ref_len, ref_off;
+    std::vector<Read> reads;
+    std::vector<char> names;
+    std::vector<uint32_t> cigars;
+    std::vector<uint8_t> seqs;      // one code per base (unpacked)
+    std::vector<uint8_t> quals;     // mutated by overlap resolution
+    // results of expand
+    std::vector<isx_obs> obs;
+    std::vector<uint32_t> pair;
+    std::vector<int64_t> split_bounds;
+    std::vector<int32_t> split_ref;
+    bool expanded = false;
+};
+
+namespace {
+
+bool inflate_block(const uint8_t *src, size_t n_src, uint8_t *dst, size_t n_dst)
+{
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = (uInt)n_src;
+    zs.next_out = dst; zs.avail_out = (uInt)n_dst;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = (rc == Z_STREAM_END) && zs.total_out == n_dst;
+    inflateEnd(&zs);
+    return ok;
+}
+
+int load_file(const char *path, std::vector<uint8_t> &out)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { isx_set_error(std::string("cannot open ") + path); return ISX_ERR_IO; }
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> raw((size_t)n);
+    if (n && fread(raw.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); isx_set_error("short read"); return ISX_ERR_IO; }
+    fclose(f);
+    // index the BGZF blocks
+    struct Blk { size_t src, n_src, dst, n_dst; };
+    std::vector<Blk> blks;
+    size_t off = 0, total = 0;
+    while (off + 18 <= raw.size()) {
+        const uint8_t *h = raw.data() + off;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { isx_set_error("not a BGZF file"); return ISX_ERR_IO; }
+        const size_t xlen = h[10] | (h[11] << 8);
+        size_t bsize = 0;
+        for (size_t x = 12; x + 4 <= 12 + xlen;) {
+            const size_t slen = h[x + 2] | (h[x + 3] << 8);
+            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || off + bsize > raw.size()) { isx_set_error("corrupt BGZF block"); return ISX_ERR_IO; }
+        const uint8_t *t = h + bsize - 4;
+        const size_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((size_t)t[3] << 24);
+        blks.push_back({off + 12 + xlen, bsize - 12 - xlen - 8, total, isize});
+        total += isize;
+        off += bsize;
+    }
+    out.resize(total);
+    const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    std::vector<int> ok(nt, 1);
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t]() {
+            for (size_t i = t; i < blks.size(); i += nt)
+                if (blks[i].n_dst && !inflate_block(raw.data() + blks[i].src, blks[i].n_src, out.data() + blks[i].dst, blks[i].n_dst))
+                    ok[t] = 0;
+        });
+    for (auto &x : th) x.join();
+    for (int v : ok) if (!v) { isx_set_error("BGZF inflate failed"); return ISX_ERR_IO; }
+    return ISX_OK;
+}
+
+inline int32_t rd32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
+
+int parse_nm(const uint8_t *p, const uint8_t *end, bool &has, int32_t &nm)
+{
+    has = false;
+    while (p + 3 <= end) {
+        const bool is_nm = (p[0] == 'N' && p[1] == 'M');
+        const char t = (char)p[2];
+        p += 3;
+        int64_t v = 0;
+        bool num = true;
+        switch (t) {
+        case 'A': v = *p; p += 1; num = false; break;
+        case 'c': v = (int8_t)*p; p += 1; break;
+        case 'C': v = *p; p += 1; break;
+        case 's': { int16_t x; memcpy(&x, p, 2); v = x; p += 2; break; }
+        case 'S': { uint16_t x; memcpy(&x, p, 2); v = x; p += 2; break; }
+        case 'i': { int32_t x; memcpy(&x, p, 4); v = x; p += 4; break; }
+        case 'I': { uint32_t x; memcpy(&x, p, 4); v = x; p += 4; break; }
+        case 'f': p += 4; num = false; break;
+        case 'Z': case 'H': while (p < end && *p) p++; p++; num = false; break;
+        case 'B': {
+            const char sub = (char)p[0];
+            const int32_t cnt = rd32(p + 1);
+            const int sz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            p += 5 + (size_t)cnt * sz;
+            num = false;
+            break;
+        }
+        default: return -1;
+        }
+        if (is_nm && num) { has = true; nm = (int32_t)v; }
+    }
+    return 0;
+}
+
+int parse_bam(const std::vector<uint8_t> &buf, isx_bam &B)
+{
+    if (buf.size() < 12 || memcmp(buf.data(), "BAM\1", 4) != 0) { isx_set_error("not a BAM file"); return ISX_ERR_IO; }
+    size_t off = 8 + (size_t)rd32(buf.data() + 4);
+    const int32_t n_ref = rd32(buf.data() + off);
+    off += 4;
+    int64_t flat = 0;
+    for (int i = 0; i < n_ref; i++) {
+        const int32_t l_name = rd32(buf.data() + off);
+        B.ref_name.emplace_back(reinterpret_cast<const char *>(buf.data() + off + 4), (size_t)l_name - 1);
+        const int32_t l_ref = rd32(buf.data() + off + 4 + l_name);
+        B.ref_len.push_back(l_ref);
+        B.ref_off.push_back(flat);
+        flat += l_ref;
+        off += 8 + (size_t)l_name;
+    }
+    while (off + 36 <= buf.size()) {
+        const uint8_t *p = buf.data() + off;
+        const int32_t block = rd32(p);
+        if (off + 4 + (size_t)block > buf.size()) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
+        Read r{};
+        r.tid = rd32(p + 4); r.pos = rd32(p + 8);
+        const uint8_t l_name = p[12];
+        r.mapq = p[13];
+        uint16_t ncig, flag;
+        memcpy(&ncig, p + 16, 2); memcpy(&flag, p + 18, 2);
+        r.n_cigar = ncig; r.flag = flag;
+        r.l_seq = rd32(p + 20);
+        r.isize = rd32(p + 32);
+        const uint8_t *q = p + 36;
+        r.name_off = (uint32_t)B.names.size(); r.name_len = (uint32_t)l_name - 1;
+        B.names.insert(B.names.end(), q, q + l_name - 1);
+        q += l_name;
+        r.cigar_off = B.cigars.size();
+        B.cigars.resize(B.cigars.size() + ncig);
+        memcpy(B.cigars.data() + r.cigar_off, q, (size_t)ncig * 4);
+        q += (size_t)ncig * 4;
+        r.seq_off = B.seqs.size();
+        B.seqs.resize(B.seqs.size() + (size_t)r.l_seq);
+        for (int32_t i = 0; i < r.l_seq; i++) {
+            const uint8_t byte = q[i >> 1];
+            B.seqs[r.seq_off + i] = (i & 1) ? (byte & 15) : (byte >> 4);
+        }
+        q += ((size_t)r.l_seq + 1) / 2;
+        r.qual_off = B.quals.size();
+        B.quals.insert(B.quals.end(), q, q + r.l_seq);
+        q += r.l_seq;
+        if (parse_nm(q, p + 4 + block, r.has_nm, r.nm) != 0) { isx_set_error("bad aux field"); return ISX_ERR_IO; }
+        B.reads.push_back(r);
+        off += 4 + (size_t)block;
+    }
+    return ISX_OK;
+}
+
+// htslib sam.c tweak_overlap_quality
+void tweak_overlap(isx_bam &B, const Read &a, const Read &b)
+{
+    Cursor ca{B.cigars.data() + a.cigar_off, a.n_cigar, 0, 0, 0, 0};
+    Cursor cb{B.cigars.data() + b.cigar_off, b.n_cigar, 0, 0, 0, 0};
+    uint8_t *aq = B.quals.data() + a.qual_off, *bq = B.quals.data() + b.qual_off;
+    const uint8_t *as = B.seqs.data() + a.seq_off, *bs = B.seqs.data() + b.seq_off;
+    int iref = b.pos;
+    int a_ret = cur_set(ca, iref - a.pos);
+    if (a_ret < 0) return;
+    int b_ret = cur_set(cb, iref - b.pos);
+    if (b_ret < 0) return;
+    for (;;) {
+        while (ca.iref >= 0 && ca.iref < iref - a.pos) a_ret = cur_next(ca);
+        if (a_ret < 0) break;
+        if (iref < ca.iref + a.pos) iref = ca.iref + a.pos;
+        while (cb.iref >= 0 && cb.iref < iref - b.pos) b_ret = cur_next(cb);
+        if (b_ret < 0) break;
+        if (iref < cb.iref + b.pos) iref = cb.iref + b.pos;
+        iref++;
+        if (ca.iref + a.pos != cb.iref + b.pos) continue;
+        const int qa = aq[ca.iseq], qb = bq[cb.iseq];
+        if (as[ca.iseq] == bs[cb.iseq]) {
+            const int q = qa + qb;
+            aq[ca.iseq] = (uint8_t)(q > 200 ? 200 : q);
+            bq[cb.iseq] = 0;
+        } else if (qa >= qb) {
+            aq[ca.iseq] = (uint8_t)(0.8 * qa);
+            bq[cb.iseq] = 0;
+        } else {
+            bq[cb.iseq] = (uint8_t)(0.8 * qb);
+            aq[ca.iseq] = 0;
+        }
+    }
+}
+
+struct RefSpan { int64_t first, last, end; int64_t qlen; bool any; };
+
+RefSpan span_of(const isx_bam &B, const Read &r)
+{
+    RefSpan s{0, 0, r.pos, 0, false};
+    int64_t ref = r.pos;
+    for (int k = 0; k < r.n_cigar; k++) {
+        const uint32_t c = B.cigars[r.cigar_off + k];
+        const int op = c & 15;
+        const int64_t n = c >> 4;
+        if (op == CM || op == CEQ || op == CX) {
+            if (n > 0) {
+                if (!s.any) { s.first = ref; s.any = true; }
+                s.last = ref + n - 1;
+            }
+            ref += n;
+        } else if (op == CD || op == CN) ref += n;
+        if (op == CM || op == CI || op == CS || op == CEQ || op == CX) s.qlen += n;
+    }
+    s.end = ref;
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int isx_bam_open(const char *path, isx_bam **out)
+{
+    if (!path || !out) { isx_set_error("isx_bam_open: bad argument"); return ISX_ERR_ARG; }
+    *out = nullptr;
+    std::vector<uint8_t> buf;
+    int rc = load_file(path, buf);
+    if (rc != ISX_OK) return rc;
+    isx_bam *B = new isx_bam();
+    rc = parse_bam(buf, *B);
+    if (rc != ISX_OK) { delete B; return rc; }
+    *out = B;
+    return ISX_OK;
+}
+
+void isx_bam_close(isx_bam *bam) { delete bam; }
+
+int isx_bam_ref(const isx_bam *bam, int32_t i, const char **name, int64_t *length, int64_t *flat_offset)
+{
+    if (!bam || i < 0 || (size_t)i >= bam->ref_name.size()) { isx_set_error("isx_bam_ref: bad index"); return ISX_ERR_ARG; }
+    if (name) *name = bam->ref_name[(size_t)i].c_str();
+    if (length) *length = bam->ref_len[(size_t)i];
+    if (flat_offset) *flat_offset = bam->ref_off[(size_t)i];
+    return ISX_OK;
+}
+
+int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
+{
+    if (!bam || !p || !info) { isx_set_error("isx_bam_expand: bad argument"); return ISX_ERR_ARG; }
+    if (bam->expanded) { isx_set_error("isx_bam_expand: already expanded (qualities were rewritten)"); return ISX_ERR_STATE; }
+    isx_bam &B = *bam;
+    memset(info, 0, sizeof(*info));
+    const size_t n_ref = B.ref_name.size();
+    auto name_of = [&](const Read &r) { return std::string_view(B.names.data() + r.name_off, r.name_len); };
+
+    // ---- get_paired_reads per scaffold (filter_reads.py:885-956) ----
+    std::vector<std::unordered_map<std::string_view, uint32_t>> idx(n_ref);
+    std::vector<PairInfo> pinfo;
+    std::vector<int32_t> read_pi(B.reads.size(), -1);
+    for (size_t ri = 0; ri < B.reads.size(); ri++) {
+        const Read &r = B.reads[ri];
+        if (r.tid < 0 || (size_t)r.tid >= n_ref) continue;
+        if (r.flag & FUNMAP) continue;
+        const RefSpan s = span_of(B, r);
+        if (!s.any) continue;                       // get_reference_positions() == []
+        if (!r.has_nm) { isx_set_error("read without NM tag: " + std::string(name_of(r))); return ISX_ERR_IO; }
+        auto &m = idx[(size_t)r.tid];
+        auto it = m.find(name_of(r));
+        if (it == m.end()) {
+            m.emplace(name_of(r), (uint32_t)pinfo.size());
+            read_pi[ri] = (int32_t)pinfo.size();
+            pinfo.push_back(PairInfo{r.nm, -1, r.mapq, s.qlen, 1, s.first, s.last, false, 0});
+        } else {
+            PairInfo &i = pinfo[it->second];
+            read_pi[ri] = (int32_t)it->second;
+            i.nm += r.nm;
+            i.reads += 1;
+            i.length += s.qlen;
+            i.mapq = std::max<int64_t>(i.mapq, r.mapq);
+            if (i.reads == 2) {
+                if (s.last > i.start) i.insert = s.last - i.start;
+                else i.insert = i.stop - s.first;
+            } else {
+                i.insert = -1;
+            }
+            i.start = 0; i.stop = 0;
+        }
+    }
+    // ---- paired_only + filter_scaff2pair2info (filter_reads.py:201-260, 471-532) ----
+    std::vector<int64_t> ins;
+    for (const PairInfo &i : pinfo) if (i.reads == 2) { ins.push_back(i.insert); info->unfiltered_pairs++; }
+    double median = NAN;
+    if (!ins.empty()) {                             // np.median
+        std::sort(ins.begin(), ins.end());
+        const size_t n = ins.size();
+        median = (n & 1) ? (double)ins[n / 2] : ((double)ins[n / 2 - 1] + (double)ins[n / 2]) / 2.0;
+    }
+    info->median_insert = median;
+    const double max_insert = median * p->max_insert_relative;
+    int32_t max_mm = 0;
+    for (PairInfo &i : pinfo) {
+        if (i.reads != 2) continue;                 // pairing_filter == paired_only
+        const double pid = 1 - ((double)i.nm / (double)i.length);       // evaluate_pair :406
+        bool ok = pid > p->min_read_ani;
+        ok = ok && (i.mapq > p->min_mapq);
+        if (i.insert != -1) ok = ok && ((double)i.insert > (double)p->min_insert) && ((double)i.insert < max_insert);
+        i.pass = ok;
+        if (ok) {
+            info->filtered_pairs++;
+            info->filtered_bases += i.length;
+            if (i.nm > max_mm) max_mm = (int32_t)i.nm;
+        }
+    }
+    info->max_mm = p->skip_mm ? 0 : max_mm;
+    if (max_mm > 65535) { isx_set_error("mm level > 65535"); return ISX_ERR_ARG; }
+
+    // ---- overlap_push in file order (htslib-1.9 rule |isize| < 2*l_qseq) ----
+    {
+        std::vector<std::unordered_map<std::string_view, size_t>> H(n_ref);
+        for (size_t ri = 0; ri < B.reads.size(); ri++) {
+            const Read &r = B.reads[ri];
+            if (r.tid < 0 || (size_t)r.tid >= n_ref || (r.flag & DEF_MASK)) continue;
+            if ((r.flag & FMUNMAP) || !(r.flag & FPROPER)) continue;
+            if (std::abs((int64_t)r.isize) >= 2 * (int64_t)r.l_seq) continue;
+            auto &h = H[(size_t)r.tid];
+            auto it = h.find(name_of(r));
+            if (it != h.end() && span_of(B, B.reads[it->second]).end <= r.pos) { h.erase(it); it = h.end(); }
+            if (it == h.end()) h.emplace(name_of(r), ri);
+            else {
+                const size_t ai = it->second;
+                h.erase(it);
+                tweak_overlap(B, B.reads[ai], r);
+            }
+        }
+    }
+
+    // ---- expansion: the visits on which get_base_counts_mm touches `table` ----
+    uint32_t next_pair = 0;
+    for (PairInfo &i : pinfo) i.pair_id = 0xFFFFFFFFu;
+    B.obs.clear(); B.pair.clear();
+    for (size_t ri = 0; ri < B.reads.size(); ri++) {
+        const Read &r = B.reads[ri];
+        if (r.tid < 0 || (size_t)r.tid >= n_ref || (r.flag & DEF_MASK)) continue;
+        // R2M membership is by NAME on this scaffold (get_base_counts_mm looks up query_name)
+        auto &m = idx[(size_t)r.tid];
+        auto it = m.find(name_of(r));
+        if (it == m.end()) continue;
+        PairInfo &pi = pinfo[it->second];
+        if (!pi.pass) continue;
+        if (pi.pair_id == 0xFFFFFFFFu) pi.pair_id = next_pair++;
+        const uint16_t mm = p->skip_mm ? 0 : (uint16_t)pi.nm;
+        const int64_t base_off = B.ref_off[(size_t)r.tid];
+        int64_t ref = r.pos, q = 0;
+        for (int k = 0; k < r.n_cigar; k++) {
+            const uint32_t c = B.cigars[r.cigar_off + k];
+            const int op = c & 15;
+            const int64_t n = c >> 4;
+            if (op == CM || op == CEQ || op == CX) {
+                for (int64_t j = 0; j < n; j++) {
+                    if (B.quals[r.qual_off + q + j] >= p->min_base_quality) {
+                        isx_obs o;
+                        o.gpos = (uint32_t)(base_off + ref + j);
+                        o.mm = mm;
+                        o.base = CODE2IDX[B.seqs[r.seq_off + q + j]];
+                        o.flags = 0;
+                        B.obs.push_back(o);
+                        B.pair.push_back(pi.pair_id);
+                    }
+                }
+                q += n; ref += n;
+            } else if (op == CI || op == CS) q += n;
+            else if (op == CD || op == CN) ref += n;
+        }
+    }
+
+    // ---- iterate_splits (fasta.py:56-73) on the flat space ----
+    B.split_bounds.clear(); B.split_ref.clear();
+    const int64_t W = p->window_length > 0 ? p->window_length : 10000;
+    for (size_t t = 0; t < n_ref; t++) {
+        const int64_t sLen = B.ref_len[t];
+        if (sLen <= 0) continue;
+        const int64_t n_chunks = sLen / W + 1;
+        const int64_t chunk = (int64_t)((double)sLen / (double)n_chunks);
+        int64_t start = 0;
+        for (int64_t i = 0; i < n_chunks; i++) {
+            B.split_bounds.push_back(B.ref_off[t] + start);
+            B.split_ref.push_back((int32_t)t);
+            if (i + 1 < n_chunks) start += chunk;
+        }
+    }
+    int64_t n_pos = 0;
+    for (int64_t l : B.ref_len) n_pos += l;
+    B.split_bounds.push_back(n_pos);
+    B.expanded = true;
+
+    info->n_refs = (int32_t)n_ref;
+    info->n_splits = (int32_t)B.split_ref.size();
+    info->n_reads = (int64_t)B.reads.size();
+    info->n_pos = n_pos;
+    info->n_obs = (int64_t)B.obs.size();
+    info->n_pairs = next_pair;
+    return ISX_OK;
+}
+
+int isx_bam_copy(const isx_bam *bam, isx_obs *obs, uint32_t *pair, int64_t *split_bounds, int32_t *split_ref)
+{
+    if (!bam || !bam->expanded) { isx_set_error("isx_bam_copy: expand first"); return ISX_ERR_STATE; }
+    if (obs && !bam->obs.empty()) memcpy(obs, bam->obs.data(), bam->obs.size() * sizeof(isx_obs));
+    if (pair && !bam->pair.empty()) memcpy(pair, bam->pair.data(), bam->pair.size() * sizeof(uint32_t));
+    if (split_bounds) memcpy(split_bounds, bam->split_bounds.data(), bam->split_bounds.size() * sizeof(int64_t));
+    if (split_ref && !bam->split_ref.empty()) memcpy(split_ref, bam->split_ref.data(), bam->split_ref.size() * sizeof(int32_t));
+    return ISX_OK;
+}
+
+}  // extern "C"

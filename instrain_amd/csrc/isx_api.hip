@@ -1,0 +1,420 @@
+// isx_api.hip -- C ABI of libinstrain_amd.so: context, resident batches, run, fetch.
+// (see include/instrain_amd.h for what each entry point replaces in the reference)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "isx_internal.h"
+#include "isx_linkage.h"
+
+static thread_local std::string g_err;
+void isx_set_error(const std::string &msg) { g_err = msg; }
+
+struct isx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *d_lut = nullptr;
+    int32_t lut_n = 0, fallback = 0;
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+};
+
+struct isx_batch {
+    isx_ctx *ctx = nullptr;
+    isx_params prm{};
+    int64_t n_pos = 0, n_obs = 0;
+    uint64_t n_rec = 0;         // padded
+    uint64_t n_pairs = 0;
+    int32_t n_splits = 0;
+    int W = 0, logW = 0, M = 1, n_win = 0, block = 512;
+    size_t lds = 0;
+    // device
+    uint2 *d_rec = nullptr;
+    uint32_t *d_pair = nullptr;
+    uint8_t *d_ref = nullptr;
+    uint2 *d_win = nullptr;
+    int64_t *d_bounds = nullptr;
+    uint4 *d_counts = nullptr;
+    float *d_clon = nullptr;
+    isx_entry *d_entries = nullptr;
+    isx_snv *d_snv = nullptr;
+    isx_site *d_sites = nullptr;
+    uint8_t *d_site_mask = nullptr;
+    uint32_t *d_cursors = nullptr, *d_flags = nullptr;
+    size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
+    LinkageBuffers L;
+    hipEvent_t ev[8] = {};
+    bool ran = false;
+    isx_sizes sizes{};
+    isx_timings tim{};
+};
+
+// host -> device through the two pinned staging buffers (hipMemcpyAsync, double-buffered);
+// `fill(dst, first, count)` writes `count` elements starting at element `first` into dst.
+template <class T, class F>
+static int staged_upload(isx_ctx *c, T *d_dst, uint64_t n, F fill)
+{
+    const uint64_t per = c->pin_bytes / sizeof(T);
+    int k = 0;
+    for (uint64_t off = 0; off < n; off += per, k ^= 1) {
+        const uint64_t cnt = std::min<uint64_t>(per, n - off);
+        HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        fill(reinterpret_cast<T *>(c->pin[k]), off, cnt);
+        HIP_TRY(hipMemcpyAsync(d_dst + off, c->pin[k], cnt * sizeof(T), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream));
+    }
+    return ISX_OK;
+}
+
+extern "C" {
+
+const char *isx_last_error(void) { return g_err.c_str(); }
+int isx_abi_version(void) { return ISX_ABI_VERSION; }
+
+int isx_ctx_create(int device_id, isx_ctx **out)
+{
+    if (!out) { isx_set_error("isx_ctx_create: out is NULL"); return ISX_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        isx_set_error("no HIP device visible: libinstrain_amd has no CPU fallback");
+        return ISX_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= n) { isx_set_error("bad device id"); return ISX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        isx_set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return ISX_ERR_HIP;
+    }
+    isx_ctx *c = new isx_ctx();
+    c->device = device_id;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->pin_bytes = (size_t)64 << 20;
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipHostMalloc(&c->pin[i], c->pin_bytes, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+    }
+    *out = c;
+    return ISX_OK;
+}
+
+void isx_ctx_destroy(isx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    for (int i = 0; i < 2; i++) {
+        if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+        if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int isx_set_null_model(isx_ctx *c, const int32_t *lut, int64_t n, int32_t fallback)
+{
+    if (!c || !lut || n <= 0) { isx_set_error("isx_set_null_model: bad argument"); return ISX_ERR_ARG; }
+    if (fallback < 0 || fallback >= 255) { isx_set_error("null model fallback out of range"); return ISX_ERR_ARG; }
+    std::vector<uint8_t> h((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        if (lut[i] >= 255) { isx_set_error("null model value >= 255"); return ISX_ERR_ARG; }
+        h[(size_t)i] = lut[i] < 0 ? 255 : (uint8_t)lut[i];
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->d_lut) { (void)hipFree(c->d_lut); c->d_lut = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_lut, (size_t)n));
+    HIP_TRY(hipMemcpy(c->d_lut, h.data(), (size_t)n, hipMemcpyHostToDevice));
+    c->lut_n = (int32_t)n;
+    c->fallback = fallback;
+    return ISX_OK;
+}
+
+void isx_batch_destroy(isx_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    void *ps[] = {b->d_rec, b->d_pair, b->d_ref, b->d_win, b->d_bounds, b->d_counts, b->d_clon, b->d_entries,
+                  b->d_snv, b->d_sites, b->d_site_mask, b->d_cursors, b->d_flags};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    b->L.release();
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uint8_t *ref, int32_t n_splits,
+                     const int64_t *split_bounds, int64_t n_obs, const isx_obs *obs, const uint32_t *pair,
+                     isx_batch **out)
+{
+    if (!c || !prm || !out || !ref || !split_bounds || n_pos <= 0 || n_splits <= 0 || n_obs < 0 || (n_obs && !obs)) {
+        isx_set_error("isx_batch_create: bad argument");
+        return ISX_ERR_ARG;
+    }
+    *out = nullptr;
+    if (!c->d_lut) { isx_set_error("isx_batch_create: call isx_set_null_model first"); return ISX_ERR_STATE; }
+    if (prm->enable_linkage && n_obs && !pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
+    if (prm->n_mm_bins < 1 || prm->n_mm_bins > 128) { isx_set_error("n_mm_bins must be in [1, 128]"); return ISX_ERR_ARG; }
+    if (n_pos >= (int64_t)0xFFFF0000ll) { isx_set_error("flat position space must be < 2^32 - 65536"); return ISX_ERR_ARG; }
+    if (split_bounds[0] != 0 || split_bounds[n_splits] != n_pos) { isx_set_error("split_bounds must span [0, n_pos]"); return ISX_ERR_ARG; }
+    for (int i = 0; i < n_splits; i++)
+        if (split_bounds[i + 1] <= split_bounds[i]) { isx_set_error("split_bounds must be strictly ascending"); return ISX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+
+    isx_batch *b = new isx_batch();
+    b->ctx = c; b->prm = *prm; b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits;
+    b->M = prm->n_mm_bins;
+    int W = prm->window;
+    if (W <= 0) {
+        if (b->M == 1) W = 4096;
+        else { W = 64; while (W * 2 * b->M * 16 <= 128 * 1024 && W < 4096) W *= 2; }
+    }
+    if (W < 64 || (W & (W - 1))) { delete b; isx_set_error("window must be a power of two >= 64"); return ISX_ERR_ARG; }
+    b->W = W;
+    b->logW = 0;
+    while ((1 << b->logW) < W) b->logW++;
+    b->lds = pileup_lds_bytes(W, b->M);
+    if (b->lds > 160 * 1024) { delete b; isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
+    b->n_win = (int)((n_pos + W - 1) / W);
+    b->block = 512;
+    b->n_rec = std::max<uint64_t>(ISX_CHUNK, ((uint64_t)n_obs + ISX_CHUNK - 1) / ISX_CHUNK * ISX_CHUNK);
+    if (b->n_rec >= 0xFFFFFFFFull) { delete b; isx_set_error("more than 2^32 observations in one batch"); return ISX_ERR_ARG; }
+
+#define BT(expr) do { int _rc = (expr); if (_rc != ISX_OK) { isx_batch_destroy(b); return _rc; } } while (0)
+#define BH(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { isx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); isx_batch_destroy(b); return ISX_ERR_HIP; } } while (0)
+    for (auto &e : b->ev) BH(hipEventCreate(&e));
+    BH(hipMalloc(&b->d_rec, b->n_rec * sizeof(uint2)));
+    BH(hipMalloc(&b->d_ref, (size_t)n_pos));
+    BH(hipMalloc(&b->d_win, (size_t)b->n_win * sizeof(uint2)));
+    BH(hipMalloc(&b->d_bounds, (size_t)(n_splits + 1) * sizeof(int64_t)));
+    BH(hipMalloc(&b->d_site_mask, (size_t)n_pos));
+    BH(hipMalloc(&b->d_cursors, CUR_N * sizeof(uint32_t)));
+    BH(hipMalloc(&b->d_flags, 4 * sizeof(uint32_t)));
+    const uint64_t npm = (uint64_t)n_pos * b->M;
+    if (b->M == 1) {
+        BH(hipMalloc(&b->d_counts, (size_t)n_pos * sizeof(uint4)));
+        BH(hipMalloc(&b->d_clon, (size_t)n_pos * sizeof(float)));
+    } else {
+        b->cap_entries = (size_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)n_obs, 1), npm);
+        BH(hipMalloc(&b->d_entries, b->cap_entries * sizeof(isx_entry)));
+    }
+    b->cap_snv = (size_t)std::min<uint64_t>(npm, std::max<uint64_t>((uint64_t)n_pos / 2, 1u << 20));
+    b->cap_sites = (size_t)std::min<uint64_t>((uint64_t)n_pos, std::max<uint64_t>((uint64_t)n_pos / 4, 1u << 20));
+    b->cap_ao = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_obs, std::max<uint64_t>((uint64_t)n_obs / 4, 1u << 20)));
+    BH(hipMalloc(&b->d_snv, b->cap_snv * sizeof(isx_snv)));
+    BH(hipMalloc(&b->d_sites, b->cap_sites * sizeof(isx_site)));
+
+    // ---- observation stream: pinned, double-buffered upload + per-chunk min/max directory ----
+    const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
+    std::vector<uint32_t> cmin(n_chunks, 0xFFFFFFFFu), cmax(n_chunks, 0u);
+    std::vector<uint8_t> cany(n_chunks, 0);
+    bool bad_pos = false;
+    BT(staged_upload(c, b->d_rec, b->n_rec, [&](uint2 *dst, uint64_t first, uint64_t cnt) {
+        for (uint64_t i = 0; i < cnt; i++) {
+            const uint64_t g = first + i;
+            if (g < (uint64_t)n_obs) {
+                const isx_obs &o = obs[g];
+                if ((int64_t)o.gpos >= n_pos) bad_pos = true;
+                dst[i] = make_uint2(o.gpos, (uint32_t)o.mm | ((uint32_t)o.base << 16) | ((uint32_t)o.flags << 24));
+                const uint64_t ch = g / ISX_CHUNK;
+                cmin[ch] = std::min(cmin[ch], o.gpos);
+                cmax[ch] = std::max(cmax[ch], o.gpos);
+                cany[ch] = 1;
+            } else {
+                dst[i] = make_uint2(ISX_SENTINEL, 0);
+            }
+        }
+    }));
+    if (bad_pos) { isx_batch_destroy(b); isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
+    if (prm->enable_linkage) {
+        BH(hipMalloc(&b->d_pair, b->n_rec * sizeof(uint32_t)));
+        uint32_t maxp = 0;
+        BT(staged_upload(c, b->d_pair, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
+            for (uint64_t i = 0; i < cnt; i++) {
+                const uint64_t g = first + i;
+                dst[i] = g < (uint64_t)n_obs ? pair[g] : 0u;
+                if (g < (uint64_t)n_obs) maxp = std::max(maxp, pair[g]);
+            }
+        }));
+        b->n_pairs = (uint64_t)maxp + 1;
+    }
+    BT(staged_upload(c, b->d_ref, (uint64_t)n_pos, [&](uint8_t *dst, uint64_t first, uint64_t cnt) {
+        memcpy(dst, ref + first, cnt);
+    }));
+
+    // ---- window -> record range: prefix-max / suffix-min over the chunk directory ----
+    {
+        std::vector<uint32_t> pmax(n_chunks), smin(n_chunks);
+        uint32_t run = 0;
+        for (uint64_t i = 0; i < n_chunks; i++) { if (cany[i]) run = std::max(run, cmax[i]); pmax[i] = run; }
+        run = 0xFFFFFFFFu;
+        for (uint64_t i = n_chunks; i-- > 0;) { if (cany[i]) run = std::min(run, cmin[i]); smin[i] = run; }
+        std::vector<uint2> win((size_t)b->n_win);
+        uint64_t lo = 0, hi = 0;
+        for (int w = 0; w < b->n_win; w++) {
+            const uint64_t w0 = (uint64_t)w * W, w1 = w0 + W;
+            while (lo < n_chunks && (uint64_t)pmax[lo] < w0) lo++;       // chunks before lo: every gpos < w0
+            if (hi < lo) hi = lo;
+            while (hi < n_chunks && (uint64_t)smin[hi] < w1) hi++;       // chunks from hi on: every gpos >= w1
+            win[(size_t)w] = make_uint2((uint32_t)(lo * ISX_CHUNK), (uint32_t)(hi * ISX_CHUNK));
+        }
+        BH(hipMemcpyAsync(b->d_win, win.data(), win.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+        BH(hipMemcpyAsync(b->d_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        BH(hipStreamSynchronize(c->stream));
+    }
+#undef BT
+#undef BH
+    *out = b;
+    return ISX_OK;
+}
+
+static float ev_ms(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+    return ms;
+}
+
+int isx_batch_run(isx_batch *b)
+{
+    if (!b) { isx_set_error("isx_batch_run: NULL batch"); return ISX_ERR_ARG; }
+    isx_ctx *c = b->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    b->ran = false;
+    HIP_TRY(hipMemsetAsync(b->d_cursors, 0, CUR_N * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(b->d_flags, 0, 4 * sizeof(uint32_t), s));
+
+    PileupArgs a{};
+    a.rec = b->d_rec; a.win_range = b->d_win; a.ref = b->d_ref;
+    a.lut = c->d_lut; a.lut_n = c->lut_n; a.fallback = c->fallback;
+    a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
+    a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
+    a.counts = b->d_counts; a.clon = b->d_clon;
+    a.entries = b->d_entries; a.cap_entries = (uint32_t)std::min<size_t>(b->cap_entries, 0xFFFFFFFFu);
+    a.snv = b->d_snv; a.cap_snv = (uint32_t)std::min<size_t>(b->cap_snv, 0xFFFFFFFFu);
+    a.sites = b->d_sites; a.cap_sites = (uint32_t)std::min<size_t>(b->cap_sites, 0xFFFFFFFFu);
+    a.site_mask = b->d_site_mask; a.cursors = b->d_cursors; a.flags = b->d_flags;
+
+    HIP_TRY(hipEventRecord(b->ev[0], s));
+    launch_pileup(a, b->block, b->lds, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev[1], s));
+    uint32_t cur[CUR_N] = {0}, flags = 0;
+    HIP_TRY(hipMemcpyAsync(cur, b->d_cursors, sizeof(cur), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&flags, b->d_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (flags & ISX_FLAG_MM_RANGE) { isx_set_error("an observation has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
+    if (flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES)) {
+        isx_set_error("output table capacity exceeded (flags " + std::to_string(flags) + ")");
+        return ISX_ERR_CAPACITY;
+    }
+    b->sizes = isx_sizes{};
+    b->sizes.n_entries = cur[CUR_ENTRIES];
+    b->sizes.n_snv = cur[CUR_SNV];
+    b->sizes.n_sites = cur[CUR_SITES];
+    b->tim = isx_timings{};
+    b->tim.pileup_ms = ev_ms(b->ev[0], b->ev[1]);
+    b->tim.pileup_blocks = ((b->n_win + 7) / 8) * 8;
+    b->tim.pileup_threads = b->block;
+    b->tim.pileup_lds_bytes = (int32_t)b->lds;
+
+    if (b->prm.enable_linkage) {
+        LinkageIn in{};
+        in.stream = s; in.ev = &b->ev[2];
+        in.rec = b->d_rec; in.pair = b->d_pair; in.n_rec = b->n_rec; in.n_pairs = b->n_pairs;
+        in.site_mask = b->d_site_mask; in.sites = b->d_sites; in.n_sites = cur[CUR_SITES];
+        in.entries = b->d_entries; in.counts = b->d_counts;
+        in.split_bounds = b->d_bounds; in.n_splits = b->n_splits; in.M = b->M; in.min_snp = b->prm.min_snp;
+        in.cap_ao = b->cap_ao; in.cursors = b->d_cursors; in.flags = b->d_flags;
+        LinkageOut lo;
+        int rc = run_linkage(in, b->L, lo);
+        if (rc != ISX_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(s));
+        b->sizes.n_allele_obs = (int64_t)lo.n_ao;
+        b->sizes.n_increments = (int64_t)lo.n_increments;
+        b->sizes.n_edges = (int64_t)lo.n_edges;
+        b->sizes.n_ld = (int64_t)lo.n_ld;
+        b->tim.sites_ms = ev_ms(b->ev[2], b->ev[3]);
+        b->tim.allele_ms = ev_ms(b->ev[3], b->ev[4]);
+        b->tim.group_ms = ev_ms(b->ev[4], b->ev[5]);
+        b->tim.incr_ms = ev_ms(b->ev[5], b->ev[6]);
+        b->tim.ld_ms = ev_ms(b->ev[6], b->ev[7]);
+        b->tim.total_ms = ev_ms(b->ev[0], b->ev[7]);
+    } else {
+        b->tim.total_ms = b->tim.pileup_ms;
+    }
+    b->ran = true;
+    return ISX_OK;
+}
+
+int isx_batch_sizes(const isx_batch *b, isx_sizes *out)
+{
+    if (!b || !out) { isx_set_error("isx_batch_sizes: bad argument"); return ISX_ERR_ARG; }
+    if (!b->ran) { isx_set_error("isx_batch_sizes: run the batch first"); return ISX_ERR_STATE; }
+    *out = b->sizes;
+    return ISX_OK;
+}
+
+int isx_batch_timings(const isx_batch *b, isx_timings *out)
+{
+    if (!b || !out) { isx_set_error("isx_batch_timings: bad argument"); return ISX_ERR_ARG; }
+    if (!b->ran) { isx_set_error("isx_batch_timings: run the batch first"); return ISX_ERR_STATE; }
+    *out = b->tim;
+    return ISX_OK;
+}
+
+#define NEED_RUN(b, out)                                                                       \
+    if (!(b) || ((out) == nullptr)) { isx_set_error("fetch: bad argument"); return ISX_ERR_ARG; } \
+    if (!(b)->ran) { isx_set_error("fetch: run the batch first"); return ISX_ERR_STATE; }        \
+    HIP_TRY(hipSetDevice((b)->ctx->device));
+
+int isx_batch_fetch_entries(isx_batch *b, isx_entry *out)
+{
+    NEED_RUN(b, out);
+    if (b->M == 1) { isx_set_error("n_mm_bins == 1: use isx_batch_fetch_dense"); return ISX_ERR_STATE; }
+    const size_t n = (size_t)b->sizes.n_entries;
+    if (!n) return ISX_OK;
+    HIP_TRY(hipMemcpy(out, b->d_entries, n * sizeof(isx_entry), hipMemcpyDeviceToHost));
+    std::sort(out, out + n, [](const isx_entry &x, const isx_entry &y) {
+        return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm;
+    });
+    return ISX_OK;
+}
+
+int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts, float *clon)
+{
+    NEED_RUN(b, counts);
+    if (b->M != 1) { isx_set_error("n_mm_bins > 1: use isx_batch_fetch_entries"); return ISX_ERR_STATE; }
+    HIP_TRY(hipMemcpy(counts, b->d_counts, (size_t)b->n_pos * sizeof(uint4), hipMemcpyDeviceToHost));
+    if (clon) HIP_TRY(hipMemcpy(clon, b->d_clon, (size_t)b->n_pos * sizeof(float), hipMemcpyDeviceToHost));
+    return ISX_OK;
+}
+
+int isx_batch_fetch_snv(isx_batch *b, isx_snv *out)
+{
+    NEED_RUN(b, out);
+    const size_t n = (size_t)b->sizes.n_snv;
+    if (!n) return ISX_OK;
+    HIP_TRY(hipMemcpy(out, b->d_snv, n * sizeof(isx_snv), hipMemcpyDeviceToHost));
+    std::sort(out, out + n, [](const isx_snv &x, const isx_snv &y) {
+        return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm;
+    });
+    return ISX_OK;
+}
+
+int isx_batch_fetch_ld(isx_batch *b, isx_ld *out)
+{
+    NEED_RUN(b, out);
+    const size_t n = (size_t)b->sizes.n_ld;
+    if (!n) return ISX_OK;
+    // rows are produced in (site1, site2, mm) order == (gpos_a, gpos_b, mm) order
+    HIP_TRY(hipMemcpy(out, b->L.ld.p, n * sizeof(isx_ld), hipMemcpyDeviceToHost));
+    return ISX_OK;
+}
+
+}  // extern "C"

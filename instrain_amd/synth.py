@@ -1,0 +1,111 @@
+"""Synthetic workloads of the BASELINE.json / SURVEY section 8(d) shapes (seeded, numpy PCG64).
+
+Generates the POST-pileup packed observation stream directly (what the host BAM front end
+would emit for such reads): reads in BAM order (sorted by start), per read its kept bases
+(quality >= 30 with probability `p_keep`), planted biallelic sites on two haplotype
+backgrounds so linkage is non-trivial, uniform sequencing error, mm = mismatches of the pair.
+Inserts are clipped at 2 x read length, i.e. mates never overlap (config C2: "no mate overlap
+at insert 350").
+"""
+import numpy as np
+
+from ._lib import OBS_DT
+
+
+def iterate_splits(sLen, window_length=10000):
+    """Split geometry of the reference (inStrain/profile/fasta.py:56-73): 0-based, double
+    inclusive; numberChunks = sLen // W + 1; the last split absorbs the remainder."""
+    n = sLen // window_length + 1
+    chunk = int(sLen / n)
+    out = []
+    start = 0
+    end = 0
+    for i in range(n):
+        if i + 1 == n:
+            out.append((start, sLen - 1))
+        else:
+            end += chunk
+            out.append((start, end - 1))
+            start += chunk
+    return out
+
+
+def split_bounds_for(lengths, window_length=10000):
+    """flat split bounds for scaffolds laid end to end"""
+    b = []
+    off = 0
+    for L in lengths:
+        for s, _ in iterate_splits(int(L), window_length):
+            b.append(off + s)
+        off += int(L)
+    b.append(off)
+    return np.asarray(b, dtype=np.int64)
+
+
+def make_workload(genome_len=5_000_000, coverage=20, read_len=150, insert_mean=350.0, insert_sd=30.0,
+                  n_sites=5000, err=0.001, p_keep=0.90, seed=2, skip_mm=True, window_length=10000,
+                  af_lo=0.05, af_hi=0.5, n_scaffolds=1, max_mm=14):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    G = int(genome_len)
+    ref = rng.integers(0, 4, G, dtype=np.uint8)
+    n_pairs = int(G * coverage / (2 * read_len))
+    ins = np.maximum(rng.normal(insert_mean, insert_sd, n_pairs), 2 * read_len).astype(np.int64)
+    s1 = rng.integers(0, max(1, G - int(ins.max()) - 1), n_pairs)
+    s2 = s1 + ins - read_len
+    starts = np.concatenate([s1, s2])
+    pid = np.concatenate([np.arange(n_pairs), np.arange(n_pairs)]).astype(np.uint32)
+    order = np.argsort(starts, kind="stable")            # BAM order
+    starts, pid = starts[order], pid[order]
+    n_reads = len(starts)
+
+    # planted sites, two haplotype backgrounds
+    sites = np.sort(rng.choice(G, size=min(n_sites, G), replace=False))
+    site_of = np.full(G, -1, dtype=np.int32)
+    site_of[sites] = np.arange(len(sites), dtype=np.int32)
+    alt = ((ref[sites].astype(np.int64) + rng.integers(1, 4, len(sites))) % 4).astype(np.uint8)
+    af = rng.uniform(af_lo, af_hi, len(sites))
+    hap = rng.integers(0, 2, n_pairs).astype(np.uint8)
+
+    mm_pair = np.zeros(n_pairs, dtype=np.int64)
+    obs_parts, pair_parts = [], []
+    CH = 1 << 16                                        # reads per chunk keeps temporaries small
+    for c0 in range(0, n_reads, CH):
+        st = starts[c0:c0 + CH]
+        pp = pid[c0:c0 + CH]
+        pos = (st[:, None] + np.arange(read_len)[None, :])
+        b = ref[pos]
+        si = site_of[pos]
+        at = si >= 0
+        if at.any():
+            h = np.broadcast_to(hap[pp][:, None], pos.shape)[at]
+            p_alt = af[si[at]] * np.where(h == 1, 1.6, 0.4)
+            carries = rng.random(at.sum()) < p_alt
+            bb = b[at]
+            bb[carries] = alt[si[at]][carries]
+            b[at] = bb
+        e = rng.random(pos.shape) < err
+        if e.any():
+            b[e] = rng.integers(0, 4, int(e.sum()), dtype=np.uint8)
+        np.add.at(mm_pair, pp, (b != ref[pos]).sum(axis=1))
+        keep = rng.random(pos.shape) < p_keep
+        o = np.empty(int(keep.sum()), dtype=OBS_DT)
+        o["gpos"] = pos[keep]
+        o["base"] = b[keep]
+        o["mm"] = 0
+        o["flags"] = 0
+        obs_parts.append(o)
+        pair_parts.append(np.broadcast_to(pp[:, None], pos.shape)[keep])
+    obs = np.concatenate(obs_parts)
+    pair = np.concatenate(pair_parts).astype(np.uint32)
+    if not skip_mm:
+        obs["mm"] = np.minimum(mm_pair, max_mm)[pair]
+    # scaffolds: equal cuts of the flat space (reads crossing a cut are simply kept; the
+    # kernels only see the flat stream, linkage never crosses a split bound)
+    lens = [G // n_scaffolds] * n_scaffolds
+    lens[-1] += G - sum(lens)
+    return {
+        "ref_codes": ref, "split_bounds": split_bounds_for(lens, window_length), "obs": obs, "pair": pair,
+        "n_pairs": n_pairs, "n_obs": len(obs), "n_pos": G, "n_sites_planted": len(sites),
+        "profiled_bases": int(n_pairs) * 2 * read_len,       # "Gbp profiled" numerator (controller.py:309-310)
+        "n_mm_bins": 1 if skip_mm else int(obs["mm"].max()) + 1,
+    }

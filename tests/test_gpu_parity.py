@@ -1,0 +1,167 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI vs
+(a) golden vectors from the reference's own Python, (b) the reference's stored sars_cov_2 run,
+(c) the C oracle on seeded random inputs, (d) size-independent properties.
+
+Bars: integer / categorical tables bit-exact; clonality float32 bit-exact; r2 / D' within 1e-6
+(north_star) -- in practice identical, the same IEEE fp64 operations run in the same order."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(util.GOLD, "synth_*.npz")))
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from instrain_amd import engine
+    c = engine.Context(0)
+    lut, fb = util.load_lut()
+    c.set_null_model(lut, fb)
+    yield c
+    c.close()
+
+
+def _params(g):
+    return dict(min_cov=int(g["p_min_cov"]), min_freq=float(g["p_min_freq"]), min_snp=int(g["p_min_snp"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_vectors(ctx, name):
+    from tests import prod
+    g = util.load_case(name)
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), **_params(g))
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name)
+    assert res["n_edges"] == int(g["n_edges"])
+
+
+@pytest.mark.parametrize("name", ["synth_m1", "synth_skipmm"])
+def test_dense_path_equals_mm_path(ctx, name):
+    """n_mm_bins == 1 (dense output) and n_mm_bins == 4 with all mm == 0 give identical tables."""
+    from tests import prod
+    g = util.load_case(name)
+    a = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), n_mm_bins=1, **_params(g))
+    b = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), n_mm_bins=4, **_params(g))
+    util.assert_same(util.canon_from_struct(a), util.canon_from_struct(b), float_tol=0.0, what=name)
+
+
+@pytest.mark.parametrize("window", [64, 128, 1024])
+def test_window_size_invariance(ctx, window):
+    from tests import prod
+    g = util.load_case("synth_dense")
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), window=window, **_params(g))
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what="window%d" % window)
+
+
+def test_stored_sars_golden_from_bam(ctx):
+    """BAM -> C++ front end -> kernels -> tables == the reference's stored run (3 splits in one batch)."""
+    from instrain_amd import engine
+    from tests import prod
+    from tests.test_oracle_golden import check_against_sars_golden, read_fasta
+    bam = engine.BamFile(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"))
+    obs, pair, bounds, sref = bam.expand()
+    assert bam.info["filtered_pairs"] == 13124 and bam.info["n_obs"] == 3717600
+    seq = read_fasta(os.path.join(util.GOLD, "sars_cov_2_MT039887.1.fasta"))
+    b = engine.Batch(ctx, engine.encode_seq(seq), bounds, obs, pair, n_mm_bins=bam.info["max_mm"] + 1,
+                     min_cov=5, min_freq=0.05, min_snp=20)
+    b.run()
+    res = prod.to_oracle_layout(b.fetch(), lambda g: g.astype(np.int64))
+    sizes = b.sizes()
+    b.close()
+    bam.close()
+    check_against_sars_golden(res["snv"], res["ld"], float_tol=TOL)
+    assert sizes["n_edges"] == 963 and sizes["n_increments"] == 23319
+
+
+def _random_split(seed, mLen, depth, mm_levels, n_sites):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(util.GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)         # only its synthetic generator is used (no reference import)
+    return mg.synth_case(seed=seed, mLen=mLen, depth=depth, mm_levels=mm_levels, n_sites=n_sites,
+                         p_other=0.02, ref_ambig=5, self_pairs=0.2)
+
+
+@pytest.mark.parametrize("seed,mLen,depth,mm_levels,n_sites", [(101, 3000, 60, 6, 120), (102, 9000, 25, 1, 200),
+                                                                (103, 1500, 300, 12, 100), (104, 5000, 40, 33, 150)])
+def test_random_splits_vs_oracle(ctx, seed, mLen, depth, mm_levels, n_sites):
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    seq, pos, base, mm, pair = _random_split(seed, mLen, depth, mm_levels, n_sites)
+    exp = oracle.profile_split(pos, base, mm, pair, seq, 0, lut, fb)
+    got = prod.run_split(ctx, pos, base, mm, pair, seq, 0)
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="seed%d" % seed)
+    assert got["n_edges"] == exp["n_edges"] and got["sizes"]["n_increments"] == exp["n_increments"]
+
+
+def test_multi_split_batch_vs_per_split_oracle(ctx):
+    """Several splits in one flat batch: linkage must not cross split bounds; pair ids shared across bounds."""
+    from instrain_amd import engine
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    seq, pos, base, mm, pair = _random_split(77, 6000, 50, 4, 240)
+    bounds = np.array([0, 1500, 1501, 4000, 6000])
+    b = engine.Batch(ctx, engine.encode_seq(seq), bounds, engine.pack_obs(pos.astype(np.uint32), base, mm),
+                     pair.astype(np.uint32), n_mm_bins=4)
+    b.run()
+    got = prod.to_oracle_layout(b.fetch(), lambda g: g.astype(np.int64))
+    b.close()
+    exp = {"entries": [], "snv": [], "ld": []}
+    for s, e in zip(bounds[:-1], bounds[1:]):
+        r = oracle.profile_split(pos, base, mm, pair, seq[s:e], int(s), lut, fb)
+        for k in exp:
+            exp[k].append(r[k])
+    exp = {k: np.concatenate(v) for k, v in exp.items()}
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="multi")
+
+
+def test_empty_and_ragged(ctx):
+    from instrain_amd import engine
+    from tests import prod
+    z = np.zeros(0, dtype=np.int64)
+    res = prod.run_split(ctx, z, z.astype(np.uint8), z, z, "ACGTACGTNN", 0, n_mm_bins=3)
+    assert len(res["entries"]) == 0 and len(res["snv"]) == 0 and len(res["ld"]) == 0
+    # a single deep column at the last position of a 1-position-short window
+    n = 70000
+    pos = np.full(n, 130)
+    base = (np.arange(n) % 3 == 0).astype(np.uint8)       # A / C mix
+    res = prod.run_split(ctx, pos, base, np.zeros(n, int), np.arange(n), "A" * 131, 0, n_mm_bins=1, window=64)
+    assert len(res["entries"]) == 1 and res["entries"]["cnt"][0].sum() == n
+    assert len(res["snv"]) == 1 and res["snv"]["allele_count"][0] == 2
+
+
+def test_mm_out_of_range_is_loud(ctx):
+    from instrain_amd import engine
+    obs = engine.pack_obs(np.array([1, 2], dtype=np.uint32), np.array([0, 1], dtype=np.uint8), np.array([0, 9]))
+    b = engine.Batch(ctx, engine.encode_seq("ACGTACGT"), [0, 8], obs, np.array([0, 1], dtype=np.uint32), n_mm_bins=4)
+    with pytest.raises(engine.IsxError) as e:
+        b.run()
+    assert e.value.code == -4
+    b.close()
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config-2-shaped batch (reduced to 1 Mbp to keep the suite short): properties that do
+    not need the oracle -- sum of level counts == number of ACGT observations; re-run idempotence;
+    covT vs SNV-table coverage consistency (reference test_profile_13)."""
+    from instrain_amd import engine, synth
+    w = synth.make_workload(genome_len=1_000_000, coverage=20, n_sites=1000, seed=2, skip_mm=True)
+    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1)
+    b.run()
+    r1 = b.fetch()
+    b.run()
+    r2 = b.fetch()
+    b.close()
+    assert int(r1["counts"].sum()) == int((w["obs"]["base"] < 4).sum())
+    for k in r1:
+        assert r1[k].tobytes() == r2[k].tobytes(), k
+    cov = r1["counts"].sum(axis=1)
+    assert (r1["snv"]["cnt"].sum(axis=1) == cov[r1["snv"]["gpos"]]).all()
