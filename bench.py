@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the `inStrain profile` hot path on MI355X.
+
+A "step" = one pass of the hot path (isx_batch_run) over one resident batch of synthetic
+observations.  At N=1 the workload is BASELINE.json configs[1] (C2: one 5 Mbp genome, 20x,
+2x150 bp, --skip_mm_profiling, linkage off).  For N>1 every rank profiles its own C2 genome
+(scaffolds shard embarrassingly; weak scaling; no data-path collective; one final RCCL gather of
+the SNV tables after the timed region, reported separately).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
+`roofline` (dominant kernel k_pileup_call vs the HBM roof) and `cpu_baseline` (the oracle's C
+restatement of the reference loop, 1 core, same workload; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def c2_workload(seed, scale=1.0):
+    from instrain_amd import synth
+    return synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale),
+                               seed=seed, skip_mm=True)
+
+
+def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense):
+    """SURVEY 8(d) / DESIGN.md: 8 B per observation in, 1 B/pos reference in, and out
+    dense (M==1): 16 B counts + 4 B clonality + 1 B site mask per position;
+    mm path: 28 B per present (pos, mm) entry + 1 B/pos site mask."""
+    b = n_obs * 8 + n_pos * 1
+    b += n_pos * (16 + 4 + 1) if dense else n_entries * 28 + n_pos
+    return b
+
+
+def split_obs_ranges(obs_gpos, bounds, chunk=1024):
+    """record range that can touch each split (same prefix-max / suffix-min directory as the library)"""
+    n = len(obs_gpos)
+    nch = (n + chunk - 1) // chunk
+    pad = np.full(nch * chunk, obs_gpos[-1] if n else 0, dtype=np.int64)
+    pad[:n] = obs_gpos
+    m = pad.reshape(nch, chunk)
+    pmax = np.maximum.accumulate(m.max(axis=1))
+    smin = np.minimum.accumulate(m.min(axis=1)[::-1])[::-1]
+    lo = np.searchsorted(pmax, bounds[:-1], side="left") * chunk
+    hi = np.searchsorted(smin, bounds[1:], side="left") * chunk
+    return np.minimum(lo, n), np.minimum(hi, n)
+
+
+def cpu_baseline(w, budget_s=25.0, min_s=10.0):
+    """The oracle's C port of the reference per-column loop (oracle/oracle_core.c), one core,
+    split by split exactly like profile_split, on as many splits of the SAME workload as fit
+    the time budget."""
+    from oracle import oracle
+    from tests import util
+    lut, fb = util.load_lut()
+    obs, pair, bounds = w["obs"], w["pair"], w["split_bounds"]
+    gpos = obs["gpos"].astype(np.int64)
+    lo, hi = split_obs_ranges(gpos, bounds)
+    letters = np.array(list("ACTGN"))
+    done_pos = 0
+    done_obs = 0
+    n_done = 0
+    n_splits = len(bounds) - 1
+    t0 = time.perf_counter()
+    i = 0
+    while True:                                   # wrap around the workload until >= min_s of CPU work
+        j = i % n_splits
+        s, e = int(bounds[j]), int(bounds[j + 1])
+        sl = slice(int(lo[j]), int(hi[j]))
+        seq = "".join(letters[w["ref_codes"][s:e]])
+        oracle.profile_split(gpos[sl].astype(np.int32), obs["base"][sl], obs["mm"][sl].astype(np.int32),
+                             pair[sl].astype(np.int32), seq, s, lut, fb, min_cov=5, min_freq=0.05, min_snp=20)
+        done_pos += e - s
+        done_obs += int(((gpos[sl] >= s) & (gpos[sl] < e)).sum())
+        n_done += 1
+        i += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or (el > min_s and i % n_splits == 0):
+            break
+    dt = time.perf_counter() - t0
+    frac = done_pos / float(bounds[-1])
+    gbp = w["profiled_bases"] * frac / 1e9
+    return {"value": gbp / dt, "unit": "Gbp/s", "cores": 1, "kind": "port",
+            "sample": "%d split profiles (the workload's %d splits, wrapped around; %.2f Mbp, %d kept observations) in %.1f s; "
+                      "oracle/oracle_core.c, single thread, pileup+SNV call+linkage"
+                      % (n_done, len(bounds) - 1, done_pos / 1e6, done_obs, dt)}
+
+
+def linkage_leg(ctx, seed=3):
+    """Secondary metric: SNV pairs linked / s on a C3-shaped slice (200x, 1 SNV site / 100 bp)."""
+    from instrain_amd import engine, synth
+    w = synth.make_workload(genome_len=250_000, coverage=200, n_sites=2500, seed=seed, skip_mm=True,
+                            af_lo=0.2, af_hi=0.5)
+    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1, enable_linkage=True)
+    for _ in range(2):
+        b.run()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        b.run()
+        ts.append(time.perf_counter() - t0)
+    s, t = b.sizes(), b.timings()
+    b.close()
+    dt = float(np.median(ts))
+    return {"workload": "C3 slice: 250 kbp, 200x, 2500 SNV sites, skip_mm, linkage on",
+            "snv_pairs_linked_per_s": s["n_edges"] / dt, "edges": s["n_edges"], "ld_rows": s["n_ld"],
+            "pair_increments": s["n_increments"], "ms_per_step": dt * 1e3,
+            "kernel_ms": {k: round(v, 4) for k, v in t.items() if k.endswith("_ms")},
+            "gbp_per_s": w["profiled_bases"] / 1e9 / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the C2 genome (debug only; reported in config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-linkage-leg", action="store_true")
+    ap.add_argument("--window", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from instrain_amd import dist as idist
+    from instrain_amd import engine
+    from tests import util        # only for the committed null-model LUT fixture (data, not oracle code)
+
+    rank, local, world = idist.init_from_env()
+    assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ctx = engine.Context(local)
+    lut, fb = util.load_lut()
+    ctx.set_null_model(lut, fb)
+
+    w = c2_workload(seed=2 + rank, scale=args.scale)
+    batch = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], None, n_mm_bins=1,
+                         enable_linkage=False, window=args.window)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local])
+
+    for _ in range(args.warmup):
+        batch.run()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k_ms = 0.0
+    for _ in range(args.steps):
+        batch.run()                              # blocking: kernels + size readback
+        k_ms += batch.timings()["pileup_ms"]     # HIP events on the library's own stream
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        u = torch.tensor([float(w["profiled_bases"])], dtype=torch.float64, device=dev)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        units = float(u.item())
+    else:
+        units = float(w["profiled_bases"])
+    sizes, tim = batch.sizes(), batch.timings()
+
+    # the one collective of the path: final gather of the SNV tables to rank 0 (outside the timed steps)
+    gather_ms = None
+    if world > 1:
+        res = batch.fetch()
+        torch.cuda.synchronize()
+        barrier()
+        g0 = time.perf_counter()
+        idist.gather_tables({"snv": res["snv"]}, dst=0)
+        torch.cuda.synchronize()
+        barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        k_avg_ms = k_ms / args.steps
+        abytes = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], sizes["n_entries"], dense=True)
+        achieved = abytes / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("c2_pileup_bytes_per_launch") if args.scale == 1.0 else None
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Gbp profiled/s", "value": units * args.steps / dt / 1e9, "unit": "Gbp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "C2: one 5 Mbp genome per GPU, 20x, 2x150 bp pairs, insert N(350,30), "
+                                   "--skip_mm_profiling (1 mm bin), linkage off; pileup + SNV call",
+                       "genome_bp": int(w["n_pos"]), "kept_observations": int(w["n_obs"]),
+                       "profiled_bases_per_gpu": int(w["profiled_bases"]), "splits": int(len(w["split_bounds"]) - 1),
+                       "window": tim["pileup_window"], "parallelism": "scaffold-sharded x%d" % world,
+                       "scale": args.scale},
+            "roofline": {"bound": "hbm", "kernel": "k_pileup_call<false>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": k_avg_ms,
+                         "blocks": tim["pileup_blocks"], "threads": tim["pileup_threads"],
+                         "lds_bytes": tim["pileup_lds_bytes"]},
+            "snv_rows": sizes["n_snv"], "snp_sites": sizes["n_sites"],
+        }
+        if gather_ms is not None:
+            out["final_gather_ms"] = gather_ms
+        if world == 1 and not args.no_linkage_leg:
+            out["linkage"] = linkage_leg(ctx)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out), flush=True)
+    batch.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

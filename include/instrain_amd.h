@@ -73,7 +73,7 @@ typedef struct {
     int32_t n_mm_bins;          /* mm levels 0..n_mm_bins-1 may occur; 1 = --skip_mm_profiling */
     int32_t enable_linkage;     /* 0: pileup / SNV only */
     int32_t linkage_mode;       /* 0 auto, 1 sparse pair-increment path, 2 dense int8 MFMA path */
-    int32_t window;             /* 0 = auto; positions per workgroup window (power of two) */
+    int32_t window;             /* 0 = auto; positions per workgroup window (multiple of 64) */
     uint64_t seed;              /* counter-based RNG seed for the rarefied outputs */
 } isx_params;
 
@@ -131,7 +131,7 @@ typedef struct {
     float incr_ms;          /* pair increments -> keys, sort, run-length */
     float ld_ms;            /* LD rows */
     float total_ms;
-    int32_t pileup_blocks, pileup_threads, pileup_lds_bytes, pad;
+    int32_t pileup_blocks, pileup_threads, pileup_lds_bytes, pileup_window;
 } isx_timings;
 
 const char *isx_last_error(void);

@@ -37,7 +37,7 @@ class Sizes(C.Structure):
 class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("pileup_ms", "sites_ms", "allele_ms", "group_ms", "incr_ms", "ld_ms",
                                          "total_ms")] + \
-               [(n, C.c_int32) for n in ("pileup_blocks", "pileup_threads", "pileup_lds_bytes", "pad")]
+               [(n, C.c_int32) for n in ("pileup_blocks", "pileup_threads", "pileup_lds_bytes", "pileup_window")]
 
 
 class BamParams(C.Structure):

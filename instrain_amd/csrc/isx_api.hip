@@ -2,6 +2,7 @@
 // (see include/instrain_amd.h for what each entry point replaces in the reference)
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,6 +17,7 @@ struct isx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     uint8_t *d_lut = nullptr;
+    std::vector<int32_t> h_lut;
     int32_t lut_n = 0, fallback = 0;
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
@@ -29,13 +31,15 @@ struct isx_batch {
     uint64_t n_rec = 0;         // padded
     uint64_t n_pairs = 0;
     int32_t n_splits = 0;
-    int W = 0, logW = 0, M = 1, n_win = 0, block = 512;
+    int W = 0, logW = 0, M = 1, n_win = 0, block = 512, grid_dense = 0;
     size_t lds = 0;
     // device
     uint2 *d_rec = nullptr;
     uint32_t *d_pair = nullptr;
     uint8_t *d_ref = nullptr;
     uint2 *d_win = nullptr;
+    uint16_t *d_thr = nullptr;
+    int qcap = 1024;
     int64_t *d_bounds = nullptr;
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
@@ -43,7 +47,8 @@ struct isx_batch {
     isx_snv *d_snv = nullptr;
     isx_site *d_sites = nullptr;
     uint8_t *d_site_mask = nullptr;
-    uint32_t *d_cursors = nullptr, *d_flags = nullptr;
+    uint32_t *d_cursors = nullptr, *d_flags = nullptr;   // one allocation: cursors[CUR_N] | flags[4]
+    uint32_t *h_state = nullptr;                          // pinned mirror of the above
     size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
     LinkageBuffers L;
     hipEvent_t ev[8] = {};
@@ -67,6 +72,26 @@ static int staged_upload(isx_ctx *c, T *d_dst, uint64_t n, F fill)
         HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream));
     }
     return ISX_OK;
+}
+
+// call_snv_site's per-base test (snv_utilities.py:179) is
+//     c >= null_model[total]  and  float(c) / total >= min_freq
+// For every coverage below lut_n both parts are monotone in c, so they fold into one exact
+// integer threshold: thr[total] = max(null_model[total], min{c : (double)c / (double)total >= min_freq}),
+// found here with the SAME IEEE fp64 division the reference performs (no rounding shortcuts).
+static std::vector<uint16_t> build_thresholds(const std::vector<int32_t> &lut, int32_t fallback, double min_freq)
+{
+    std::vector<uint16_t> thr(lut.size(), 65535);
+    for (size_t t = 1; t < lut.size(); t++) {
+        const int64_t mb = lut[t] >= 0 ? lut[t] : fallback;
+        int64_t c = (int64_t)std::floor(min_freq * (double)t) - 2;
+        if (c < 0) c = 0;
+        while (c <= (int64_t)t && !((double)c / (double)t >= min_freq)) c++;
+        while (c > 0 && ((double)(c - 1) / (double)t >= min_freq)) c--;
+        const int64_t v = std::max<int64_t>(mb, c);        // c == t + 1: no count can reach min_freq
+        thr[t] = (uint16_t)std::min<int64_t>(v, 65535);
+    }
+    return thr;
 }
 
 extern "C" {
@@ -119,6 +144,7 @@ void isx_ctx_destroy(isx_ctx *c)
 int isx_set_null_model(isx_ctx *c, const int32_t *lut, int64_t n, int32_t fallback)
 {
     if (!c || !lut || n <= 0) { isx_set_error("isx_set_null_model: bad argument"); return ISX_ERR_ARG; }
+    if (n > 65535) { isx_set_error("null model longer than 65535 coverages"); return ISX_ERR_ARG; }
     if (fallback < 0 || fallback >= 255) { isx_set_error("null model fallback out of range"); return ISX_ERR_ARG; }
     std::vector<uint8_t> h((size_t)n);
     for (int64_t i = 0; i < n; i++) {
@@ -131,6 +157,7 @@ int isx_set_null_model(isx_ctx *c, const int32_t *lut, int64_t n, int32_t fallba
     HIP_TRY(hipMemcpy(c->d_lut, h.data(), (size_t)n, hipMemcpyHostToDevice));
     c->lut_n = (int32_t)n;
     c->fallback = fallback;
+    c->h_lut.assign(lut, lut + n);
     return ISX_OK;
 }
 
@@ -139,8 +166,9 @@ void isx_batch_destroy(isx_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_rec, b->d_pair, b->d_ref, b->d_win, b->d_bounds, b->d_counts, b->d_clon, b->d_entries,
-                  b->d_snv, b->d_sites, b->d_site_mask, b->d_cursors, b->d_flags};
+    void *ps[] = {b->d_rec, b->d_pair, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_entries,
+                  b->d_snv, b->d_sites, b->d_site_mask, b->d_cursors};
+    if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
     b->L.release();
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
@@ -169,19 +197,33 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     b->ctx = c; b->prm = *prm; b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits;
     b->M = prm->n_mm_bins;
     int W = prm->window;
+    const bool dense = b->M == 1;
+    b->block = dense ? 1024 : 512;
+    if (const char *e = getenv("ISX_BLOCK")) b->block = atoi(e);       // tuning only
+    if (b->block < 64 || b->block > 1024 || (b->block & 63)) { delete b; isx_set_error("ISX_BLOCK must be a multiple of 64 in [64, 1024]"); return ISX_ERR_ARG; }
     if (W <= 0) {
-        if (b->M == 1) W = 4096;
-        else { W = 64; while (W * 2 * b->M * 16 <= 128 * 1024 && W < 4096) W *= 2; }
+        if (dense) W = 2560;                    // measured best on MI355X (tools/tune_pileup.py, profiles/)
+        else {
+            // largest window whose counters fit half of the 160 KiB LDS (2 workgroups per CU)
+            const int bytes_per_pos = b->M * 16 + ((b->M + 31) / 32) * 4;
+            int wmax = ((78 * 1024 - 8 * b->qcap - 2048) / bytes_per_pos) / 64 * 64;
+            W = std::min(std::max(wmax, 64), 4096);
+        }
     }
-    if (W < 64 || (W & (W - 1))) { delete b; isx_set_error("window must be a power of two >= 64"); return ISX_ERR_ARG; }
+    if (W < 64 || (W & 63) || W > 8192) { delete b; isx_set_error("window must be a multiple of 64 in [64, 8192]"); return ISX_ERR_ARG; }
     b->W = W;
     b->logW = 0;
-    while ((1 << b->logW) < W) b->logW++;
-    b->lds = pileup_lds_bytes(W, b->M);
+    b->lds = dense ? pileup_dense_lds_bytes(W) : pileup_lds_bytes(W, b->M, b->qcap);
     if (b->lds > 160 * 1024) { delete b; isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
     b->n_win = (int)((n_pos + W - 1) / W);
-    b->block = 512;
-    b->n_rec = std::max<uint64_t>(ISX_CHUNK, ((uint64_t)n_obs + ISX_CHUNK - 1) / ISX_CHUNK * ISX_CHUNK);
+    {   // persistent dense kernel: as many workgroups as stay resident on the 256 CUs
+        const int per_cu = std::max(1, std::min((int)(160 * 1024 / b->lds), 2048 / b->block));
+        int g = 256 * per_cu;
+        if (const char *e = getenv("ISX_GRID")) g = atoi(e);            // tuning only
+        g = std::min(g, b->n_win);
+        b->grid_dense = std::max(8, (g + 7) / 8 * 8);
+    }
+    b->n_rec = std::max<uint64_t>(ISX_PAD, ((uint64_t)n_obs + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
     if (b->n_rec >= 0xFFFFFFFFull) { delete b; isx_set_error("more than 2^32 observations in one batch"); return ISX_ERR_ARG; }
 
 #define BT(expr) do { int _rc = (expr); if (_rc != ISX_OK) { isx_batch_destroy(b); return _rc; } } while (0)
@@ -192,8 +234,14 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     BH(hipMalloc(&b->d_win, (size_t)b->n_win * sizeof(uint2)));
     BH(hipMalloc(&b->d_bounds, (size_t)(n_splits + 1) * sizeof(int64_t)));
     BH(hipMalloc(&b->d_site_mask, (size_t)n_pos));
-    BH(hipMalloc(&b->d_cursors, CUR_N * sizeof(uint32_t)));
-    BH(hipMalloc(&b->d_flags, 4 * sizeof(uint32_t)));
+    BH(hipMalloc(&b->d_cursors, (CUR_N + 4) * sizeof(uint32_t)));
+    b->d_flags = b->d_cursors + CUR_N;
+    BH(hipHostMalloc(&b->h_state, (CUR_N + 4) * sizeof(uint32_t), hipHostMallocDefault));
+    {   // folded presence threshold per coverage (see build_thresholds)
+        std::vector<uint16_t> thr = build_thresholds(c->h_lut, c->fallback, prm->min_freq);
+        BH(hipMalloc(&b->d_thr, thr.size() * sizeof(uint16_t)));
+        BH(hipMemcpy(b->d_thr, thr.data(), thr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     const uint64_t npm = (uint64_t)n_pos * b->M;
     if (b->M == 1) {
         BH(hipMalloc(&b->d_counts, (size_t)n_pos * sizeof(uint4)));
@@ -286,14 +334,14 @@ int isx_batch_run(isx_batch *b)
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     b->ran = false;
-    HIP_TRY(hipMemsetAsync(b->d_cursors, 0, CUR_N * sizeof(uint32_t), s));
-    HIP_TRY(hipMemsetAsync(b->d_flags, 0, 4 * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(b->d_cursors, 0, (CUR_N + 4) * sizeof(uint32_t), s));
 
     PileupArgs a{};
     a.rec = b->d_rec; a.win_range = b->d_win; a.ref = b->d_ref;
-    a.lut = c->d_lut; a.lut_n = c->lut_n; a.fallback = c->fallback;
+    a.lut = c->d_lut; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
+    if (const char *e = getenv("ISX_DEBUG_MODE")) a.debug_mode = atoi(e);     // ablation only
     a.counts = b->d_counts; a.clon = b->d_clon;
     a.entries = b->d_entries; a.cap_entries = (uint32_t)std::min<size_t>(b->cap_entries, 0xFFFFFFFFu);
     a.snv = b->d_snv; a.cap_snv = (uint32_t)std::min<size_t>(b->cap_snv, 0xFFFFFFFFu);
@@ -301,13 +349,13 @@ int isx_batch_run(isx_batch *b)
     a.site_mask = b->d_site_mask; a.cursors = b->d_cursors; a.flags = b->d_flags;
 
     HIP_TRY(hipEventRecord(b->ev[0], s));
-    launch_pileup(a, b->block, b->lds, s);
+    launch_pileup(a, b->block, b->lds, b->grid_dense, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[1], s));
-    uint32_t cur[CUR_N] = {0}, flags = 0;
-    HIP_TRY(hipMemcpyAsync(cur, b->d_cursors, sizeof(cur), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&flags, b->d_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(b->h_state, b->d_cursors, (CUR_N + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t *cur = b->h_state;
+    const uint32_t flags = b->h_state[CUR_N];
     if (flags & ISX_FLAG_MM_RANGE) { isx_set_error("an observation has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
     if (flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES)) {
         isx_set_error("output table capacity exceeded (flags " + std::to_string(flags) + ")");
@@ -319,9 +367,10 @@ int isx_batch_run(isx_batch *b)
     b->sizes.n_sites = cur[CUR_SITES];
     b->tim = isx_timings{};
     b->tim.pileup_ms = ev_ms(b->ev[0], b->ev[1]);
-    b->tim.pileup_blocks = ((b->n_win + 7) / 8) * 8;
+    b->tim.pileup_blocks = b->M == 1 ? b->grid_dense : ((b->n_win + 7) / 8) * 8;
     b->tim.pileup_threads = b->block;
     b->tim.pileup_lds_bytes = (int32_t)b->lds;
+    b->tim.pileup_window = b->W;
 
     if (b->prm.enable_linkage) {
         LinkageIn in{};

@@ -7,6 +7,7 @@
 #include "../../include/instrain_amd.h"
 
 #define ISX_CHUNK 1024              // observation directory granule (records)
+#define ISX_PAD 2048                // the record stream is padded to a multiple of this (k_allele_obs tile)
 #define ISX_SENTINEL 0xFFFFFFFFu    // gpos of padding records (never inside a window)
 
 void isx_set_error(const std::string &msg);
@@ -57,11 +58,14 @@ struct PileupArgs {
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK)
     const uint8_t *ref;
     const uint8_t *lut;         // lut_n entries; 255 = coverage missing -> fallback
+    const uint16_t *thr;        // lut_n entries: folded presence threshold per coverage (build_thresholds)
     int32_t lut_n, fallback;
     uint32_t n_pos;
     int32_t W, logW, M;
     int32_t n_win;
     int32_t min_cov;
+    int32_t debug_mode;
+    int32_t qcap;               // deferred-clonality queue capacity (entries)
     double min_freq;
     // outputs
     uint4 *counts;              // dense path (M == 1): [n_pos]
@@ -77,7 +81,8 @@ struct PileupArgs {
     uint32_t *flags;
 };
 
-void launch_pileup(const PileupArgs &a, int block, size_t lds, hipStream_t s);
-size_t pileup_lds_bytes(int W, int M);
+void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid_dense, hipStream_t s);
+size_t pileup_dense_lds_bytes(int W);
+size_t pileup_lds_bytes(int W, int M, int qcap);
 
 struct LinkageBuffers;      // defined in isx_linkage.hip

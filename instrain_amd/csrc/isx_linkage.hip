@@ -19,6 +19,7 @@
 //   5 radix sort + run-length encode of the keys                      -> mm2combo2counts
 //   6 k_ld_rows      one lane per edge: ascending mm on the edge, cumulative combo counts,
 //                    site counts <= mm, gates, r2 / D' in fp64 in the reference's order.
+#include <algorithm>
 #include <cstring>
 #include <string.h>
 #include <rocprim/rocprim.hpp>
@@ -59,44 +60,73 @@ __global__ void k_site_split(const isx_site *sites, uint32_t n, const int64_t *b
 }
 
 // update_linked_reads (linkage.py:254-283): `if val in bases: read_to_snvs[mm][name].append(...)`
-__global__ void __launch_bounds__(256) k_allele_obs(const uint2 *rec, const uint32_t *pair, uint64_t n_rec,
-                                                    const uint8_t *site_mask, const uint32_t *site_gpos,
-                                                    uint32_t n_sites, isx_ao *ao, uint32_t *ao_key,
-                                                    uint32_t cap, uint32_t *cursors, uint32_t *flags)
+// One block = tiles of AO_TILE records; hits of a tile are compacted with LDS counters and ONE
+// global atomic per tile (a single contended device-scope word saturates near 88 atomics/us).
+#define AO_THREADS 256
+#define AO_PER 4                                    // uint4 loads (2 records each) per lane per tile
+#define AO_TILE (AO_THREADS * AO_PER * 2)
+__global__ void __launch_bounds__(AO_THREADS) k_allele_obs(const uint2 *rec, const uint32_t *pair, uint64_t n_rec,
+                                                           const uint8_t *site_mask, const uint32_t *site_gpos,
+                                                           uint32_t n_sites, isx_ao *ao, uint32_t *ao_key,
+                                                           uint32_t cap, uint32_t *cursors, uint32_t *flags)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += stride) {
-        const uint2 r = rec[i];
-        bool hit = false;
-        uint32_t base = 0;
-        if (r.x != ISX_SENTINEL) {
-            base = (r.y >> 16) & 0xFFu;
-            const uint32_t m = site_mask[r.x];
-            hit = (base < 4) && ((m >> base) & 1u);
+    __shared__ uint32_t s_cnt, s_base;
+    const uint4 *rec4 = reinterpret_cast<const uint4 *>(rec);
+    const uint64_t n_tiles = n_rec / AO_TILE;       // n_rec is a multiple of ISX_CHUNK == AO_TILE / 2 ... see host
+    const int lane = threadIdx.x & 63;
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        uint32_t g[AO_PER * 2], at[AO_PER * 2], slot[AO_PER * 2];
+        uint32_t hits = 0;
+#pragma unroll
+        for (int k = 0; k < AO_PER; k++) {
+            const uint64_t j = t * (AO_TILE / 2) + (uint64_t)k * AO_THREADS + threadIdx.x;
+            const uint4 v = rec4[j];
+            g[2 * k] = v.x; at[2 * k] = v.y; g[2 * k + 1] = v.z; at[2 * k + 1] = v.w;
         }
-        // wave-aggregated slot allocation
-        const unsigned long long ballot = __ballot(hit);
-        if (ballot == 0) continue;
-        const int lane = threadIdx.x & 63;
-        uint32_t slot0 = 0;
-        const int leader = __ffsll((long long)ballot) - 1;
-        if (lane == leader) slot0 = atomicAdd(&cursors[CUR_AO], (uint32_t)__popcll(ballot));
-        slot0 = __shfl(slot0, leader);
-        if (hit) {
-            const uint32_t slot = slot0 + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-            if (slot >= cap) { atomicOr(flags, ISX_FLAG_CAP_AO); continue; }
-            // rank of the site = index in the position-sorted site table
-            uint32_t lo = 0, hi = n_sites;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (site_gpos[mid] < r.x) lo = mid + 1; else hi = mid;
+#pragma unroll
+        for (int q = 0; q < AO_PER * 2; q++) {
+            bool hit = false;
+            if (g[q] != ISX_SENTINEL) {
+                const uint32_t base = (at[q] >> 16) & 0xFFu;
+                const uint32_t m = site_mask[g[q]];
+                hit = (base < 4) && ((m >> base) & 1u);
             }
-            isx_ao a;
-            a.pair = pair[i]; a.site = lo; a.obs_idx = (uint32_t)i;
-            a.mm = (uint16_t)(r.y & 0xFFFFu); a.base = (uint8_t)base; a.pad = 0;
-            ao[slot] = a;
-            ao_key[slot] = a.pair;
+            const unsigned long long ballot = __ballot(hit);
+            uint32_t wbase = 0;
+            if (ballot) {
+                const int leader = __ffsll((long long)ballot) - 1;
+                if (lane == leader) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(ballot));
+                wbase = __shfl(wbase, leader);
+            }
+            slot[q] = wbase + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+            hits |= hit ? (1u << q) : 0u;
         }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&cursors[CUR_AO], s_cnt) : 0u;
+        __syncthreads();
+        const uint32_t gbase = s_base;
+        if (hits) {
+#pragma unroll
+            for (int q = 0; q < AO_PER * 2; q++) {
+                if (!((hits >> q) & 1u)) continue;
+                const uint32_t o = gbase + slot[q];
+                if (o >= cap) { atomicOr(flags, ISX_FLAG_CAP_AO); continue; }
+                uint32_t lo = 0, hi = n_sites;          // rank of the site in the position-sorted table
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (site_gpos[mid] < g[q]) lo = mid + 1; else hi = mid;
+                }
+                const uint64_t i = t * AO_TILE + (uint64_t)(q >> 1) * (2 * AO_THREADS) + 2 * threadIdx.x + (q & 1);
+                isx_ao a;
+                a.pair = pair[i]; a.site = lo; a.obs_idx = (uint32_t)i;
+                a.mm = (uint16_t)(at[q] & 0xFFFFu); a.base = (uint8_t)((at[q] >> 16) & 0xFFu); a.pad = 0;
+                ao[o] = a;
+                ao_key[o] = a.pair;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -329,8 +359,9 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     if ((rc = ensure(B.ao, in.cap_ao)) || (rc = ensure(B.ao_key, in.cap_ao)) || (rc = ensure(B.ao2, in.cap_ao)) ||
         (rc = ensure(B.ao_key2, in.cap_ao))) return rc;
     {
-        const int grid = 256 * 8;
-        hipLaunchKernelGGL(k_allele_obs, dim3(grid), dim3(256), 0, s, in.rec, in.pair, in.n_rec, in.site_mask,
+        const uint64_t n_tiles = in.n_rec / AO_TILE;
+        const int grid = (int)std::min<uint64_t>(n_tiles, 256 * 8);
+        hipLaunchKernelGGL(k_allele_obs, dim3(grid), dim3(AO_THREADS), 0, s, in.rec, in.pair, in.n_rec, in.site_mask,
                            B.site_gpos.p, n_sites, B.ao.p, B.ao_key.p, (uint32_t)in.cap_ao, in.cursors, in.flags);
     }
     uint32_t n_ao = 0;

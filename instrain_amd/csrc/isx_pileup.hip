@@ -31,6 +31,8 @@ namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#define THR_LDS 1024        // coverages below this read their folded threshold from LDS
+
 __device__ __forceinline__ int lut_min_bases(const uint8_t *lut, int lut_n, int fallback, uint32_t total)
 {
     // snv_utilities.py:174-177 / readComparer.py:311-314
@@ -102,25 +104,45 @@ __device__ __forceinline__ int xcd_window(int b, int nb)
 }
 
 template <bool MM>
-__global__ void __launch_bounds__(512) k_pileup_call(const PileupArgs a)
+__global__ void __launch_bounds__(1024) k_pileup_call(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int w = xcd_window(blockIdx.x, gridDim.x);
     if (w >= a.n_win) return;
     const int W = a.W, M = MM ? a.M : 1;
-    const uint32_t w0 = (uint32_t)w << a.logW;
+    const uint32_t w0 = (uint32_t)w * (uint32_t)a.W;
     const int n_cnt = M * 4 * W;
     const int pres_words = MM ? ((M + 31) >> 5) : 0;
     uint32_t *cnt = lds;
     uint32_t *pres = lds + n_cnt;
-    uint32_t *scratch = pres + pres_words * W;      // [0] entry total, [1] entry base
+    uint32_t *scratch = pres + pres_words * W;      // [0] entry total, [1] entry base, [2] queue length, [4..] queue
+    uint16_t *thr_lds = reinterpret_cast<uint16_t *>(scratch + 4 + 2 * a.qcap);
 
     {   // zero the window
         uint4 *z = reinterpret_cast<uint4 *>(lds);
         const int n4 = (n_cnt + pres_words * W) >> 2;       // W is a multiple of 64
         for (int i = tid; i < n4; i += nthr) z[i] = make_uint4(0, 0, 0, 0);
         if (tid < 4) scratch[tid] = 0;
+    }
+    // Issued now, consumed only in the epilogue (the waits land after the streaming loop): this
+    // lane's slice of the folded-threshold table and the reference bases of its positions, so the
+    // epilogue has no dependent global load on its common path.
+    uint32_t thr_stage[4];
+    const int n_thr32 = min(THR_LDS, a.lut_n & ~1) >> 1;
+    {
+        const uint32_t *t32 = reinterpret_cast<const uint32_t *>(a.thr);
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int i = tid + it * nthr;
+            thr_stage[it] = (i < n_thr32) ? t32[i] : 0u;
+        }
+    }
+    uint8_t ref_raw[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const uint32_t gp = w0 + tid + it * nthr;
+        ref_raw[it] = (tid + it * nthr < W && gp < a.n_pos) ? a.ref[gp] : (uint8_t)4;
     }
     __syncthreads();
 
@@ -129,8 +151,11 @@ __global__ void __launch_bounds__(512) k_pileup_call(const PileupArgs a)
     const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(a.rec);
     const uint32_t lo = rng.x >> 1, hi = rng.y >> 1;
     uint32_t bad_mm = 0;
+    const int dbg = a.debug_mode;                   // ablation switches (tools/tune_pileup.py), 0 in production
+    uint32_t sink = 0;
     auto visit = [&](uint32_t gpos, uint32_t attr) {
         const uint32_t rel = gpos - w0;
+        if (dbg & 1) { sink ^= gpos + attr; return; }
         if (rel < (uint32_t)W) {
             const uint32_t base = (attr >> 16) & 0xFFu;
             if (MM) {
@@ -143,7 +168,7 @@ __global__ void __launch_bounds__(512) k_pileup_call(const PileupArgs a)
             }
         }
     };
-    for (uint32_t i = lo + tid; i < hi; i += 4 * nthr) {
+    for (uint32_t i = lo + tid; i < ((dbg & 4) ? lo : hi); i += 4 * nthr) {
         u32x4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -155,9 +180,27 @@ __global__ void __launch_bounds__(512) k_pileup_call(const PileupArgs a)
         for (int u = 0; u < 4; u++) { visit(v[u].x, v[u].y); visit(v[u].z, v[u].w); }
     }
     if (bad_mm) atomicOr(a.flags, ISX_FLAG_MM_RANGE);
+    if ((dbg & 1) && sink == 0x12345678u) atomicOr(a.flags + 1, 1u);     // keep the loads alive
+    {
+        uint32_t *t32 = reinterpret_cast<uint32_t *>(thr_lds);
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int i = tid + it * nthr;
+            if (i < n_thr32) t32[i] = thr_stage[it];
+        }
+    }
     __syncthreads();
+    if (dbg & 2) return;
 
     // ---- epilogue: one lane per position, straight out of LDS ----
+    // Integer-only on the common path: for coverage < lut_n the two per-base tests of
+    // call_snv_site (c >= null_model[total] and float(c)/total >= min_freq, snv_utilities.py:179)
+    // are folded on the host into ONE exact threshold thr[total] (isx_api.hip build_thresholds);
+    // clonality is exactly 1.0 when a single base is present, otherwise the (pos, level) is queued
+    // in LDS and the fp64 divisions run densely packed afterwards (no divergent lanes idling).
+    uint32_t *qn = scratch + 2;                          // queue length
+    uint32_t *queue = scratch + 4;                       // [QCAP][2]: target index, (mm << 16) | p
+    const uint32_t QCAP = (uint32_t)a.qcap;
     uint32_t e_off = 0;
     if (MM) {
         uint32_t my_e = 0;
@@ -180,15 +223,22 @@ __global__ void __launch_bounds__(512) k_pileup_call(const PileupArgs a)
         }
     }
 
-    for (int p = tid; p < W; p += nthr) {
+    int ep_it = 0;
+    for (int p = tid; p < W; p += nthr, ep_it++) {
         const uint32_t gpos = w0 + p;
         if (gpos >= a.n_pos) break;
-        const int ref_base = a.ref[gpos];
+        int ref_base;
+        if (ep_it == 0) ref_base = ref_raw[0];
+        else if (ep_it == 1) ref_base = ref_raw[1];
+        else if (ep_it == 2) ref_base = ref_raw[2];
+        else if (ep_it == 3) ref_base = ref_raw[3];
+        else ref_base = a.ref[gpos];
         uint32_t cum[4] = {0, 0, 0, 0};
         int anySNP = 0, cryptic = 0, nrows = 0, nlev = 0;
         uint32_t mask = 0;
         const uint32_t first_entry = e_off;
         float clon_last = __builtin_nanf("");
+        bool clon_deferred = false;
 
         // one pass of update_snp_table's `for mm in sorted(MMcounts)`; EMIT writes SNV rows
         auto levels = [&](bool emit, uint32_t row_base) {
@@ -204,13 +254,41 @@ __global__ void __launch_bounds__(512) k_pileup_call(const PileupArgs a)
 #pragma unroll
                 for (int k = 0; k < 4; k++) cum[k] += l[k];
                 const uint32_t total = cum[0] + cum[1] + cum[2] + cum[3];
-                const int min_bases = ((int64_t)total >= (int64_t)a.min_cov) ? lut_min_bases(a.lut, a.lut_n, a.fallback, total) : 0;
-                int morphia;
-                const int snp = call_snv_site(cum, total, ref_base, min_bases, a.min_cov, a.min_freq, morphia);
+                const bool counted = (int64_t)total >= (int64_t)a.min_cov;
+                const bool fast = total < (uint32_t)a.lut_n;           // folded threshold available
+                int morphia = 0, snp = -2, min_bases = 0;
+                uint32_t thr = 0;
+                if (counted) {
+                    if (fast) {
+                        thr = (total < THR_LDS && nthr >= 128) ? (uint32_t)thr_lds[total] : (uint32_t)a.thr[total];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) morphia += (cum[k] >= thr) ? 1 : 0;
+                        const int am = argmax4(cum);
+                        snp = (morphia > 1) ? am : (morphia == 1 ? (am != ref_base ? am : -1) : am);
+                    } else {                                           // coverage >= lut_n: the reference's own arithmetic
+                        min_bases = a.fallback;
+                        snp = call_snv_site(cum, total, ref_base, min_bases, a.min_cov, a.min_freq, morphia);
+                    }
+                }
                 if (!emit) {
                     float cl = __builtin_nanf("");
-                    if ((int64_t)total >= (int64_t)a.min_cov) cl = (float)clonality(cum, total);
+                    bool defer = false;
+                    if (counted) {
+                        const uint32_t mx = max(max(cum[0], cum[1]), max(cum[2], cum[3]));
+                        if (mx == total) cl = 1.0f;                    // (s/s)^2 + 0 + 0 + 0
+                        else {
+                            const uint32_t slot = atomicAdd(qn, 1u);
+                            if (slot < QCAP) {
+                                defer = true;
+                                queue[slot * 2 + 0] = MM ? e_off : gpos;
+                                queue[slot * 2 + 1] = ((uint32_t)m << 16) | (uint32_t)p;
+                            } else {
+                                cl = (float)clonality(cum, total);     // queue full: inline
+                            }
+                        }
+                    }
                     clon_last = cl;
+                    clon_deferred = defer;
                     if (MM) {
                         isx_entry e;
                         e.gpos = gpos; e.mm = (uint16_t)m; e.flags = 0;
@@ -224,14 +302,29 @@ __global__ void __launch_bounds__(512) k_pileup_call(const PileupArgs a)
                 if (snp == -2) continue;
                 if (snp != -1) {
                     uint32_t tmp[4] = {cum[0], cum[1], cum[2], cum[3]};
-                    tmp[snp] = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) tmp[k] = (k == snp) ? 0u : tmp[k];
                     const int var = argmax4(tmp);
                     if (emit) {
+                        int cls;
+                        if (fast) {                                    // calc_snp_class with is_present folded into thr
+                            uint32_t cref = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) cref = (k == ref_base) ? cum[k] : cref;
+                            if (ref_base > 3) cls = 0;
+                            else if (morphia == 0) cls = 1;
+                            else if (morphia == 1) cls = 2;
+                            else if (ref_base == snp) cls = 3;
+                            else if (ref_base == var) cls = 4;
+                            else cls = (cref >= thr) ? 4 : 5;
+                        } else {
+                            cls = snp_class(snp, ref_base, var, cum, total, morphia, min_bases, a.min_freq);
+                        }
                         isx_snv r;
                         r.gpos = gpos; r.mm = (uint16_t)m;
                         r.con_base = (uint8_t)snp; r.var_base = (uint8_t)var;
                         r.allele_count = (uint8_t)morphia;
-                        r.cls = (uint8_t)snp_class(snp, ref_base, var, cum, total, morphia, min_bases, a.min_freq);
+                        r.cls = (uint8_t)cls;
                         r.cryptic = (uint8_t)cryptic;       // position-level flag from the first pass (p2c map)
                         r.ref_base = (uint8_t)ref_base;
                         r.cnt[0] = cum[0]; r.cnt[1] = cum[1]; r.cnt[2] = cum[2]; r.cnt[3] = cum[3];
@@ -247,12 +340,12 @@ __global__ void __launch_bounds__(512) k_pileup_call(const PileupArgs a)
             anySNP = any; cryptic = cry; nrows = rows;
         };
 
-        levels(false, 0);
-        if (!MM) {
+        if (!(dbg & 16)) levels(false, 0);
+        if (!MM && !(dbg & 8)) {
             a.counts[gpos] = make_uint4(cum[0], cum[1], cum[2], cum[3]);
-            a.clon[gpos] = clon_last;
+            if (!clon_deferred) a.clon[gpos] = clon_last;
         }
-        a.site_mask[gpos] = anySNP ? (uint8_t)mask : (uint8_t)0;
+        if (!(dbg & 8) && !(dbg & 32)) a.site_mask[gpos] = anySNP ? (uint8_t)mask : (uint8_t)0;
         if (nrows) {
             const uint32_t row_base = atomicAdd(&a.cursors[CUR_SNV], (uint32_t)nrows);
             if (row_base + nrows > a.cap_snv) atomicOr(a.flags, ISX_FLAG_CAP_SNV);
@@ -269,26 +362,257 @@ __global__ void __launch_bounds__(512) k_pileup_call(const PileupArgs a)
             }
         }
     }
+    __syncthreads();
+    // ---- deferred clonalities: calculate_clonality (snv_utilities.py:225-231) in fp64, densely packed ----
+    const uint32_t nq = min(*qn, QCAP);
+    for (uint32_t q = tid; q < nq; q += nthr) {
+        const uint32_t pm = queue[q * 2 + 1];
+        const int p = (int)(pm & 0xFFFFu), mq = (int)(pm >> 16);
+        uint32_t c[4] = {0, 0, 0, 0};
+        for (int m = 0; m <= mq; m++) {                 // mm_counts_to_counts(MMcounts, mm)
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[k] += cnt[(m * 4 + k) * W + p];
+        }
+        const float cl = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+        if (MM) a.entries[queue[q * 2]].clon = cl;
+        else a.clon[queue[q * 2]] = cl;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// k_pileup_dense: the n_mm_bins == 1 (--skip_mm_profiling / --database_mode) specialisation.
+// Persistent workgroups: each walks windows slot, slot + grid, ... so the per-window fixed costs
+// (launch, threshold staging, dependent global latencies of the epilogue) are paid behind the
+// NEXT window's first loads, which are issued before the epilogue starts.  SNV rows / SNP sites
+// are allocated with ONE global atomic per window (LDS-aggregated), clonality divisions and row
+// emission run densely packed from an LDS queue.
+// LDS: cnt[4][W] | queue[W] | thr_lds[THR_LDS] | scratch[8]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int W = a.W;
+    uint32_t *cnt = lds;
+    uint32_t *queue = lds + 4 * W;
+    uint32_t *scratch = queue + W;              // [0] queue length [1] rows [2] sites [3] row base [4] site base
+    uint16_t *thr_lds = reinterpret_cast<uint16_t *>(scratch + 8);
+    const int grid = gridDim.x, per = grid >> 3;
+    const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
+    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(a.rec);
+    const int dbg = a.debug_mode;
+
+    {   // once per workgroup: folded thresholds of the low coverages
+        const int n = min(THR_LDS, a.lut_n);
+        for (int i = tid; i < n; i += nthr) thr_lds[i] = a.thr[i];
+    }
+
+    u32x4 v[4];
+    uint32_t lo = 0, hi = 0;
+    auto issue = [&](uint32_t i0) {             // 4 coalesced 16-byte loads per lane (2 records each)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t j = i0 + tid + u * nthr;
+            if (j < hi) v[u] = __builtin_nontemporal_load(&rec4[j]);
+            else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
+        }
+    };
+    if (slot < a.n_win) {
+        const uint2 rng = a.win_range[slot];
+        lo = rng.x >> 1; hi = rng.y >> 1;
+        if (lo < hi) issue(lo);
+    }
+
+    for (int w = slot; w < a.n_win; w += grid) {
+        const uint32_t w0 = (uint32_t)w * (uint32_t)W;
+        {   // zero the window's counters
+            uint4 *z = reinterpret_cast<uint4 *>(cnt);
+            for (int i = tid; i < W; i += nthr) z[i] = make_uint4(0, 0, 0, 0);
+            if (tid < 8) scratch[tid] = 0;
+        }
+        uint8_t ref_raw[2];
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const uint32_t gp = w0 + tid + it * nthr;
+            ref_raw[it] = (tid + it * nthr < W && gp < a.n_pos) ? a.ref[gp] : (uint8_t)4;
+        }
+        __syncthreads();
+
+        // ---- get_base_counts_mm (profile_utilities.py:268-286) over the window's slice ----
+        for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t g0 = v[u].x, a0 = v[u].y, g1 = v[u].z, a1 = v[u].w;
+                const uint32_t r0 = g0 - w0, r1 = g1 - w0;
+                const uint32_t b0 = (a0 >> 16) & 0xFFu, b1 = (a1 >> 16) & 0xFFu;
+                if (r0 < (uint32_t)W && b0 < 4) atomicAdd(&cnt[b0 * W + r0], 1u);
+                if (r1 < (uint32_t)W && b1 < 4) atomicAdd(&cnt[b1 * W + r1], 1u);
+            }
+            const uint32_t nxt = i0 + 4 * nthr;
+            if (nxt < hi) issue(nxt);
+        }
+        __syncthreads();
+
+        // ---- first loads of the NEXT window go out before the epilogue ----
+        {
+            const int wn = w + grid;
+            lo = hi = 0;
+            if (wn < a.n_win) {
+                const uint2 rng = a.win_range[wn];
+                lo = rng.x >> 1; hi = rng.y >> 1;
+                if (lo < hi) issue(lo);
+            }
+        }
+
+        // ---- epilogue pass 1: integer only (update_snp_table / call_snv_site, single mm level) ----
+        int ep_it = 0;
+        for (int p = tid; p < ((dbg & 2) ? 0 : W); p += nthr, ep_it++) {
+            const uint32_t gpos = w0 + p;
+            if (gpos >= a.n_pos) break;
+            const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
+            const uint32_t total = c[0] + c[1] + c[2] + c[3];
+            a.counts[gpos] = make_uint4(c[0], c[1], c[2], c[3]);
+            uint32_t mask = 0;
+            float cl = __builtin_nanf("");
+            bool defer = false;
+            if ((int64_t)total >= (int64_t)a.min_cov) {
+                const int ref_base = ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : a.ref[gpos]);
+                int morphia = 0, snp;
+                if (total < (uint32_t)a.lut_n) {
+                    const uint32_t thr = total < THR_LDS ? (uint32_t)thr_lds[total] : (uint32_t)a.thr[total];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) morphia += (c[k] >= thr) ? 1 : 0;
+                    const int am = argmax4(c);
+                    snp = (morphia > 1) ? am : (morphia == 1 ? (am != ref_base ? am : -1) : am);
+                } else {
+                    snp = call_snv_site(c, total, ref_base, a.fallback, a.min_cov, a.min_freq, morphia);
+                }
+                const uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
+                if (mx == total) cl = 1.0f; else defer = true;
+                uint32_t entry = (uint32_t)p;
+                if (defer) entry |= 1u << 13;
+                if (snp != -1) {
+                    entry |= 1u << 14;
+                    atomicAdd(&scratch[1], 1u);
+                    if (morphia >= 2) {
+                        uint32_t tmp[4] = {c[0], c[1], c[2], c[3]};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) tmp[k] = (k == snp) ? 0u : tmp[k];
+                        mask = (1u << snp) | (1u << argmax4(tmp));
+                        entry |= (atomicAdd(&scratch[2], 1u) + 1u) << 16;
+                    }
+                }
+                if (entry != (uint32_t)p) queue[atomicAdd(&scratch[0], 1u)] = entry;
+            }
+            if (!defer) a.clon[gpos] = cl;
+            a.site_mask[gpos] = (uint8_t)mask;
+        }
+        __syncthreads();
+        const uint32_t nq = scratch[0], nrows = scratch[1], nsites = scratch[2];
+        if (tid == 0 && nrows) scratch[3] = atomicAdd(&a.cursors[CUR_SNV], nrows);
+        if (tid == 32 && nsites) scratch[4] = atomicAdd(&a.cursors[CUR_SITES], nsites);
+        // ---- deferred clonalities (snv_utilities.py:225-231), densely packed ----
+        for (uint32_t q = tid; q < nq; q += nthr) {
+            const uint32_t e = queue[q];
+            if (!(e & (1u << 13))) continue;
+            const int p = (int)(e & 0x1FFFu);
+            const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
+            a.clon[w0 + p] = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+        }
+        if (nrows) __syncthreads();             // uniform: scratch[3..4] from the two atomics above
+        // ---- SNV rows / SNP sites (snv_utilities.py:107-133) ----
+        const uint32_t row_base = scratch[3], site_base = scratch[4];
+        bool emit_rows = nrows != 0;
+        if (emit_rows && (row_base + nrows > a.cap_snv || site_base + nsites > a.cap_sites)) {
+            if (tid == 0) atomicOr(a.flags, row_base + nrows > a.cap_snv ? ISX_FLAG_CAP_SNV : ISX_FLAG_CAP_SITES);
+            emit_rows = false;
+        }
+        uint32_t my_row = 0;                    // rank among the row entries (LDS counter)
+        for (uint32_t q0 = 0; q0 < (emit_rows ? nq : 0u); q0 += nthr) {
+            const uint32_t q = q0 + tid;
+            const uint32_t e = q < nq ? queue[q] : 0u;
+            const bool is_row = (e >> 14) & 1u;
+            if (is_row) my_row = atomicAdd(&scratch[5], 1u);
+            if (!is_row) continue;
+            const int p = (int)(e & 0x1FFFu);
+            const uint32_t gpos = w0 + p;
+            const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
+            const uint32_t total = c[0] + c[1] + c[2] + c[3];
+            const int ref_base = a.ref[gpos];
+            int morphia = 0, snp, cls;
+            const bool fast = total < (uint32_t)a.lut_n;
+            uint32_t thr = 0;
+            if (fast) {
+                thr = a.thr[total];
+#pragma unroll
+                for (int k = 0; k < 4; k++) morphia += (c[k] >= thr) ? 1 : 0;
+                const int am = argmax4(c);
+                snp = (morphia > 1) ? am : (morphia == 1 ? (am != ref_base ? am : -1) : am);
+            } else {
+                snp = call_snv_site(c, total, ref_base, a.fallback, a.min_cov, a.min_freq, morphia);
+            }
+            uint32_t tmp[4] = {c[0], c[1], c[2], c[3]};
+#pragma unroll
+            for (int k = 0; k < 4; k++) tmp[k] = (k == snp) ? 0u : tmp[k];
+            const int var = argmax4(tmp);
+            if (fast) {
+                uint32_t cref = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) cref = (k == ref_base) ? c[k] : cref;
+                if (ref_base > 3) cls = 0;
+                else if (morphia == 0) cls = 1;
+                else if (morphia == 1) cls = 2;
+                else if (ref_base == snp) cls = 3;
+                else if (ref_base == var) cls = 4;
+                else cls = (cref >= thr) ? 4 : 5;
+            } else {
+                cls = snp_class(snp, ref_base, var, c, total, morphia, a.fallback, a.min_freq);
+            }
+            isx_snv r;
+            r.gpos = gpos; r.mm = 0;
+            r.con_base = (uint8_t)snp; r.var_base = (uint8_t)var;
+            r.allele_count = (uint8_t)morphia; r.cls = (uint8_t)cls;
+            r.cryptic = 0;                      // a single mm level cannot turn cryptic (snv_utilities.py:135-140)
+            r.ref_base = (uint8_t)ref_base;
+            r.cnt[0] = c[0]; r.cnt[1] = c[1]; r.cnt[2] = c[2]; r.cnt[3] = c[3];
+            a.snv[row_base + my_row] = r;
+            const uint32_t ss = e >> 16;
+            if (ss) {
+                isx_site st;
+                st.gpos = gpos; st.entry_off = 0; st.n_levels = 1;
+                st.mask = (uint8_t)((1u << snp) | (1u << var)); st.pad = 0;
+                a.sites[site_base + ss - 1] = st;
+            }
+        }
+        // the zeroing + barrier at the top of the next window protect cnt / queue / scratch
+        __syncthreads();
+    }
 }
 
 }  // namespace
 
-size_t pileup_lds_bytes(int W, int M)
+size_t pileup_lds_bytes(int W, int M, int qcap)
 {
     const size_t pres_words = M > 1 ? (size_t)((M + 31) / 32) : 0;
-    return ((size_t)M * 4 * W + pres_words * W + 4) * sizeof(uint32_t);
+    return ((size_t)M * 4 * W + pres_words * W + 4 + (size_t)qcap * 2) * sizeof(uint32_t) + THR_LDS * sizeof(uint16_t);
 }
 
-void launch_pileup(const PileupArgs &a, int block, size_t lds, hipStream_t s)
+size_t pileup_dense_lds_bytes(int W)
 {
-    const int grid = ((a.n_win + 7) / 8) * 8;
+    return ((size_t)5 * W + 8) * sizeof(uint32_t) + THR_LDS * sizeof(uint16_t);
+}
+
+void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid_dense, hipStream_t s)
+{
     if (a.M > 1) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_call<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int grid = ((a.n_win + 7) / 8) * 8;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_call<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_pileup_call<true>, dim3(grid), dim3(block), lds, s, a);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_call<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_pileup_call<false>, dim3(grid), dim3(block), lds, s, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_dense),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_pileup_dense, dim3(grid_dense), dim3(block), lds, s, a);
     }
 }

@@ -1,0 +1,75 @@
+"""Multi-GPU layer: one process per GPU, scaffolds sharded across ranks, no data-path collective;
+a single final gather of the (small) SNV / linkage tables to rank 0 over RCCL (xGMI).
+
+Replaces the reference's process-level data parallelism over splits
+(/root/reference/inStrain/profile/profile_controller.py:157-193 queues, :243-271 spawn workers,
+:441 per-scaffold cost estimate).  The split is the independent unit (linkage never crosses a
+split bound, profile_utilities.py:164,188-189; merge is concatenation :785-792), scaffolds are
+kept whole on one rank so per-scaffold summaries stay local.
+"""
+import os
+
+import numpy as np
+
+
+def lpt_shards(costs, world):
+    """Longest-processing-time bin packing: costs[i] = estimated work of scaffold i (the reference
+    uses filtered read pairs, profile_controller.py:460-465). Returns list of index lists."""
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.argsort(-costs, kind="stable")
+    load = np.zeros(world)
+    shards = [[] for _ in range(world)]
+    for i in order:
+        r = int(np.argmin(load))
+        shards[r].append(int(i))
+        load[r] += costs[i]
+    return [sorted(s) for s in shards]
+
+
+def init_from_env(backend=None):
+    """torch.distributed init from the torchrun environment; returns (rank, local_rank, world)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" IS RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def gather_tables(tables, dst=0, device=None):
+    """tables: {name: numpy structured array}. Rank `dst` gets {name: concatenation over ranks in
+    rank order}; other ranks get None.  One all_gather of sizes + one padded gather per table."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return tables
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    names = sorted(tables)
+    sizes = torch.tensor([tables[n].nbytes for n in names], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = torch.stack(all_sizes).cpu().numpy()
+    out = {} if rank == dst else None
+    for j, n in enumerate(names):
+        mx = int(all_sizes[:, j].max())
+        buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=device)
+        raw = np.frombuffer(np.ascontiguousarray(tables[n]).tobytes(), dtype=np.uint8)
+        if len(raw):
+            buf[:len(raw)] = torch.from_numpy(raw.copy()).to(device)
+        recv = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, recv, dst=dst)
+        if rank == dst:
+            parts = [np.frombuffer(recv[r].cpu().numpy().tobytes()[:int(all_sizes[r, j])], dtype=tables[n].dtype)
+                     for r in range(world)]
+            out[n] = np.concatenate(parts)
+    return out
