@@ -34,10 +34,9 @@ def c2_workload(seed, scale=1.0):
 
 def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense):
     """SURVEY 8(d) / DESIGN.md: 8 B per observation in, 1 B/pos reference in, and out
-    dense (M==1): 16 B counts + 4 B clonality + 1 B site mask per position;
-    mm path: 28 B per present (pos, mm) entry + 1 B/pos site mask."""
+    dense (M==1): 16 B counts + 4 B clonality per position; mm path: 28 B per present (pos, mm) entry."""
     b = n_obs * 8 + n_pos * 1
-    b += n_pos * (16 + 4 + 1) if dense else n_entries * 28 + n_pos
+    b += n_pos * (16 + 4) if dense else n_entries * 28
     return b
 
 
@@ -208,7 +207,7 @@ def main():
                        "profiled_bases_per_gpu": int(w["profiled_bases"]), "splits": int(len(w["split_bounds"]) - 1),
                        "window": tim["pileup_window"], "parallelism": "scaffold-sharded x%d" % world,
                        "scale": args.scale},
-            "roofline": {"bound": "hbm", "kernel": "k_pileup_call<false>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_pileup_dense", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": k_avg_ms,
                          "blocks": tim["pileup_blocks"], "threads": tim["pileup_threads"],

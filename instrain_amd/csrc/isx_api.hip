@@ -46,7 +46,7 @@ struct isx_batch {
     isx_entry *d_entries = nullptr;
     isx_snv *d_snv = nullptr;
     isx_site *d_sites = nullptr;
-    uint8_t *d_site_mask = nullptr;
+    isx_ao *d_ao = nullptr;
     uint32_t *d_cursors = nullptr, *d_flags = nullptr;   // one allocation: cursors[CUR_N] | flags[4]
     uint32_t *h_state = nullptr;                          // pinned mirror of the above
     size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
@@ -167,7 +167,7 @@ void isx_batch_destroy(isx_batch *b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     void *ps[] = {b->d_rec, b->d_pair, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_entries,
-                  b->d_snv, b->d_sites, b->d_site_mask, b->d_cursors};
+                  b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
     b->L.release();
@@ -202,10 +202,15 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     if (const char *e = getenv("ISX_BLOCK")) b->block = atoi(e);       // tuning only
     if (b->block < 64 || b->block > 1024 || (b->block & 63)) { delete b; isx_set_error("ISX_BLOCK must be a multiple of 64 in [64, 1024]"); return ISX_ERR_ARG; }
     if (W <= 0) {
-        if (dense) W = 2560;                    // measured best on MI355X (tools/tune_pileup.py, profiles/)
+        if (dense) {
+            // 2560 measured best on MI355X for batches that fill the chip (tools/tune_pileup.py);
+            // small batches get smaller windows so that every CU still owns >= 2 of them
+            int64_t w = (n_pos / 1024 + 63) / 64 * 64;
+            W = (int)std::min<int64_t>(2560, std::max<int64_t>(512, w));
+        }
         else {
             // largest window whose counters fit half of the 160 KiB LDS (2 workgroups per CU)
-            const int bytes_per_pos = b->M * 16 + ((b->M + 31) / 32) * 4;
+            const int bytes_per_pos = b->M * 16 + ((b->M + 31) / 32) * 4 + 5;
             int wmax = ((78 * 1024 - 8 * b->qcap - 2048) / bytes_per_pos) / 64 * 64;
             W = std::min(std::max(wmax, 64), 4096);
         }
@@ -213,7 +218,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     if (W < 64 || (W & 63) || W > 8192) { delete b; isx_set_error("window must be a multiple of 64 in [64, 8192]"); return ISX_ERR_ARG; }
     b->W = W;
     b->logW = 0;
-    b->lds = dense ? pileup_dense_lds_bytes(W) : pileup_lds_bytes(W, b->M, b->qcap);
+    b->lds = pileup_lds_bytes(W, b->M, b->qcap, prm->enable_linkage);
     if (b->lds > 160 * 1024) { delete b; isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
     b->n_win = (int)((n_pos + W - 1) / W);
     {   // persistent dense kernel: as many workgroups as stay resident on the 256 CUs
@@ -233,7 +238,6 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     BH(hipMalloc(&b->d_ref, (size_t)n_pos));
     BH(hipMalloc(&b->d_win, (size_t)b->n_win * sizeof(uint2)));
     BH(hipMalloc(&b->d_bounds, (size_t)(n_splits + 1) * sizeof(int64_t)));
-    BH(hipMalloc(&b->d_site_mask, (size_t)n_pos));
     BH(hipMalloc(&b->d_cursors, (CUR_N + 4) * sizeof(uint32_t)));
     b->d_flags = b->d_cursors + CUR_N;
     BH(hipHostMalloc(&b->h_state, (CUR_N + 4) * sizeof(uint32_t), hipHostMallocDefault));
@@ -255,6 +259,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     b->cap_ao = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_obs, std::max<uint64_t>((uint64_t)n_obs / 4, 1u << 20)));
     BH(hipMalloc(&b->d_snv, b->cap_snv * sizeof(isx_snv)));
     BH(hipMalloc(&b->d_sites, b->cap_sites * sizeof(isx_site)));
+    if (prm->enable_linkage) BH(hipMalloc(&b->d_ao, b->cap_ao * sizeof(isx_ao)));
 
     // ---- observation stream: pinned, double-buffered upload + per-chunk min/max directory ----
     const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
@@ -338,7 +343,7 @@ int isx_batch_run(isx_batch *b)
 
     PileupArgs a{};
     a.rec = b->d_rec; a.win_range = b->d_win; a.ref = b->d_ref;
-    a.lut = c->d_lut; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap;
+    a.pair = b->d_pair; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
     if (const char *e = getenv("ISX_DEBUG_MODE")) a.debug_mode = atoi(e);     // ablation only
@@ -346,7 +351,8 @@ int isx_batch_run(isx_batch *b)
     a.entries = b->d_entries; a.cap_entries = (uint32_t)std::min<size_t>(b->cap_entries, 0xFFFFFFFFu);
     a.snv = b->d_snv; a.cap_snv = (uint32_t)std::min<size_t>(b->cap_snv, 0xFFFFFFFFu);
     a.sites = b->d_sites; a.cap_sites = (uint32_t)std::min<size_t>(b->cap_sites, 0xFFFFFFFFu);
-    a.site_mask = b->d_site_mask; a.cursors = b->d_cursors; a.flags = b->d_flags;
+    a.ao = b->d_ao; a.cap_ao = (uint32_t)std::min<size_t>(b->cap_ao, 0xFFFFFFFFu); a.enable_linkage = b->prm.enable_linkage;
+    a.cursors = b->d_cursors; a.flags = b->d_flags;
 
     HIP_TRY(hipEventRecord(b->ev[0], s));
     launch_pileup(a, b->block, b->lds, b->grid_dense, s);
@@ -357,7 +363,7 @@ int isx_batch_run(isx_batch *b)
     const uint32_t *cur = b->h_state;
     const uint32_t flags = b->h_state[CUR_N];
     if (flags & ISX_FLAG_MM_RANGE) { isx_set_error("an observation has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
-    if (flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES)) {
+    if (flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES | ISX_FLAG_CAP_AO)) {
         isx_set_error("output table capacity exceeded (flags " + std::to_string(flags) + ")");
         return ISX_ERR_CAPACITY;
     }
@@ -375,11 +381,10 @@ int isx_batch_run(isx_batch *b)
     if (b->prm.enable_linkage) {
         LinkageIn in{};
         in.stream = s; in.ev = &b->ev[2];
-        in.rec = b->d_rec; in.pair = b->d_pair; in.n_rec = b->n_rec; in.n_pairs = b->n_pairs;
-        in.site_mask = b->d_site_mask; in.sites = b->d_sites; in.n_sites = cur[CUR_SITES];
+        in.n_pairs = b->n_pairs; in.ao = b->d_ao; in.n_ao = cur[CUR_AO];
+        in.sites = b->d_sites; in.n_sites = cur[CUR_SITES];
         in.entries = b->d_entries; in.counts = b->d_counts;
         in.split_bounds = b->d_bounds; in.n_splits = b->n_splits; in.M = b->M; in.min_snp = b->prm.min_snp;
-        in.cap_ao = b->cap_ao; in.cursors = b->d_cursors; in.flags = b->d_flags;
         LinkageOut lo;
         int rc = run_linkage(in, b->L, lo);
         if (rc != ISX_OK) return rc;

@@ -46,7 +46,8 @@ struct isx_site {
 // allele observation = one update_linked_reads append (linkage.py:281)
 struct isx_ao {
     uint32_t pair;
-    uint32_t site;          // rank of the site in the position-sorted site table
+    uint32_t site;          // flat position when written by the pileup kernel; then the rank of the
+                            // site in the position-sorted site table (k_ao_rank)
     uint32_t obs_idx;       // arrival order (orders the two mates of a self pair)
     uint16_t mm;
     uint8_t base;
@@ -57,7 +58,7 @@ struct PileupArgs {
     const uint2 *rec;           // packed isx_obs, padded to a multiple of ISX_CHUNK with sentinels
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK)
     const uint8_t *ref;
-    const uint8_t *lut;         // lut_n entries; 255 = coverage missing -> fallback
+    const uint32_t *pair;       // read-pair id per record (linkage only)
     const uint16_t *thr;        // lut_n entries: folded presence threshold per coverage (build_thresholds)
     int32_t lut_n, fallback;
     uint32_t n_pos;
@@ -76,13 +77,14 @@ struct PileupArgs {
     uint32_t cap_snv;
     isx_site *sites;
     uint32_t cap_sites;
-    uint8_t *site_mask;         // [n_pos] `bases` mask, 0 = not a SNP site
+    isx_ao *ao;                 // allele observations, exactly sized slabs per SNP site
+    uint32_t cap_ao;
+    int32_t enable_linkage;
     uint32_t *cursors;
     uint32_t *flags;
 };
 
 void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid_dense, hipStream_t s);
-size_t pileup_dense_lds_bytes(int W);
-size_t pileup_lds_bytes(int W, int M, int qcap);
+size_t pileup_lds_bytes(int W, int M, int qcap, int linkage);
 
 struct LinkageBuffers;      // defined in isx_linkage.hip

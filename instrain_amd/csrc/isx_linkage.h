@@ -11,7 +11,7 @@ struct DevBuf {
 struct LinkageBuffers {
     DevBuf<uint32_t> site_keys, site_keys2, site_gpos, site_split;
     DevBuf<isx_site> sites_sorted;
-    DevBuf<isx_ao> ao, ao2;
+    DevBuf<isx_ao> ao2;
     DevBuf<uint32_t> ao_key, ao_key2;
     DevBuf<uint32_t> incr_cnt, incr_off;
     DevBuf<uint64_t> keys, keys2, ukeys;
@@ -24,11 +24,9 @@ struct LinkageBuffers {
 struct LinkageIn {
     hipStream_t stream;
     hipEvent_t *ev;             // 6 events: start, sites, allele, group, incr, ld
-    const uint2 *rec;
-    const uint32_t *pair;
-    uint64_t n_rec;             // padded record count
     uint64_t n_pairs;           // 0 = unknown
-    const uint8_t *site_mask;
+    isx_ao *ao;                 // written by the pileup kernel (site field = flat position)
+    uint32_t n_ao;
     const isx_site *sites;      // unsorted, from k_pileup_call
     uint32_t n_sites;
     const isx_entry *entries;   // mm path
@@ -37,9 +35,6 @@ struct LinkageIn {
     int n_splits;
     int M;
     int min_snp;
-    size_t cap_ao;
-    uint32_t *cursors;
-    uint32_t *flags;
 };
 
 struct LinkageOut {

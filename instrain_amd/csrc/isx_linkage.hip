@@ -1,7 +1,8 @@
 // isx_linkage.hip -- pairwise SNV linkage on the device (sparse pair-increment path).
 //
 // Replaces
-//   update_linked_reads           /root/reference/inStrain/profile/linkage.py:254-283
+//   update_linked_reads           /root/reference/inStrain/profile/linkage.py:254-283 (consumer side;
+//                                 the producer is allele_pass in isx_pileup.hip)
 //   calc_mm_SNV_linkage_network   linkage.py:14-44
 //   calculate_ld                  linkage.py:46-75
 //   _iterator_ld_sites            linkage.py:78-131
@@ -11,8 +12,9 @@
 //
 // Pipeline (all on the ctx stream; sorts/scans are rocPRIM device primitives):
 //   1 sort the SNP-site records emitted by k_pileup_call by position  -> site rank
-//   2 k_allele_obs   second pass over the observation stream (12 B/obs + 1 B site-mask gather):
-//                    keep observations at SNP sites whose base is in the site's `bases` set
+//   2 (isx_pileup.hip allele_pass, fused into the pileup kernels) observations at SNP sites whose
+//     base is in the site's `bases` set, in exactly sized per-site slabs; k_ao_rank maps their
+//     position to the site rank
 //   3 radix sort of the allele observations by read-pair id           -> read_to_snvs[mm][name]
 //   4 k_pair_incr    every i<j combination inside a pair (same split) -> 64-bit key
 //                    (site1, site2, mm, b1, b2), oriented by (position, arrival order)
@@ -59,75 +61,21 @@ __global__ void k_site_split(const isx_site *sites, uint32_t n, const int64_t *b
     site_split[i] = (uint32_t)lo;
 }
 
-// update_linked_reads (linkage.py:254-283): `if val in bases: read_to_snvs[mm][name].append(...)`
-// One block = tiles of AO_TILE records; hits of a tile are compacted with LDS counters and ONE
-// global atomic per tile (a single contended device-scope word saturates near 88 atomics/us).
-#define AO_THREADS 256
-#define AO_PER 4                                    // uint4 loads (2 records each) per lane per tile
-#define AO_TILE (AO_THREADS * AO_PER * 2)
-__global__ void __launch_bounds__(AO_THREADS) k_allele_obs(const uint2 *rec, const uint32_t *pair, uint64_t n_rec,
-                                                           const uint8_t *site_mask, const uint32_t *site_gpos,
-                                                           uint32_t n_sites, isx_ao *ao, uint32_t *ao_key,
-                                                           uint32_t cap, uint32_t *cursors, uint32_t *flags)
+// The pileup kernel leaves the flat position in isx_ao::site; replace it by the rank of the site
+// in the position-sorted site table and emit the grouping key (read-pair id).
+__global__ void __launch_bounds__(256) k_ao_rank(isx_ao *ao, uint32_t n, const uint32_t *site_gpos, uint32_t n_sites,
+                                                 uint32_t *ao_key)
 {
-    __shared__ uint32_t s_cnt, s_base;
-    const uint4 *rec4 = reinterpret_cast<const uint4 *>(rec);
-    const uint64_t n_tiles = n_rec / AO_TILE;       // n_rec is a multiple of ISX_CHUNK == AO_TILE / 2 ... see host
-    const int lane = threadIdx.x & 63;
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        uint32_t g[AO_PER * 2], at[AO_PER * 2], slot[AO_PER * 2];
-        uint32_t hits = 0;
-#pragma unroll
-        for (int k = 0; k < AO_PER; k++) {
-            const uint64_t j = t * (AO_TILE / 2) + (uint64_t)k * AO_THREADS + threadIdx.x;
-            const uint4 v = rec4[j];
-            g[2 * k] = v.x; at[2 * k] = v.y; g[2 * k + 1] = v.z; at[2 * k + 1] = v.w;
-        }
-#pragma unroll
-        for (int q = 0; q < AO_PER * 2; q++) {
-            bool hit = false;
-            if (g[q] != ISX_SENTINEL) {
-                const uint32_t base = (at[q] >> 16) & 0xFFu;
-                const uint32_t m = site_mask[g[q]];
-                hit = (base < 4) && ((m >> base) & 1u);
-            }
-            const unsigned long long ballot = __ballot(hit);
-            uint32_t wbase = 0;
-            if (ballot) {
-                const int leader = __ffsll((long long)ballot) - 1;
-                if (lane == leader) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(ballot));
-                wbase = __shfl(wbase, leader);
-            }
-            slot[q] = wbase + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-            hits |= hit ? (1u << q) : 0u;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&cursors[CUR_AO], s_cnt) : 0u;
-        __syncthreads();
-        const uint32_t gbase = s_base;
-        if (hits) {
-#pragma unroll
-            for (int q = 0; q < AO_PER * 2; q++) {
-                if (!((hits >> q) & 1u)) continue;
-                const uint32_t o = gbase + slot[q];
-                if (o >= cap) { atomicOr(flags, ISX_FLAG_CAP_AO); continue; }
-                uint32_t lo = 0, hi = n_sites;          // rank of the site in the position-sorted table
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (site_gpos[mid] < g[q]) lo = mid + 1; else hi = mid;
-                }
-                const uint64_t i = t * AO_TILE + (uint64_t)(q >> 1) * (2 * AO_THREADS) + 2 * threadIdx.x + (q & 1);
-                isx_ao a;
-                a.pair = pair[i]; a.site = lo; a.obs_idx = (uint32_t)i;
-                a.mm = (uint16_t)(at[q] & 0xFFFFu); a.base = (uint8_t)((at[q] >> 16) & 0xFFu); a.pad = 0;
-                ao[o] = a;
-                ao_key[o] = a.pair;
-            }
-        }
-        __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = ao[i].site;
+    uint32_t lo = 0, hi = n_sites;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (site_gpos[mid] < g) lo = mid + 1; else hi = mid;
     }
+    ao[i].site = lo;
+    ao_key[i] = ao[i].pair;
 }
 
 // calc_mm_SNV_linkage_network (linkage.py:26-42): itertools.combinations(snvs, 2) per (mm, read).
@@ -319,7 +267,7 @@ inline int bits_for(uint64_t n)
 
 void LinkageBuffers::release()
 {
-    void *ps[] = {site_keys.p, site_keys2.p, sites_sorted.p, site_gpos.p, site_split.p, ao.p, ao_key.p, ao2.p,
+    void *ps[] = {site_keys.p, site_keys2.p, sites_sorted.p, site_gpos.p, site_split.p, ao_key.p, ao2.p,
                   ao_key2.p, incr_cnt.p, incr_off.p, keys.p, keys2.p, ukeys.p, ucnt.p, n_runs.p, rows_per.p,
                   row_off.p, ld.p, temp.p};
     for (void *p : ps) if (p) (void)hipFree(p);
@@ -355,30 +303,22 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
                        in.split_bounds, in.n_splits, B.site_gpos.p, B.site_split.p);
     EV(1);
 
-    // ---- 2. allele observations ----
-    if ((rc = ensure(B.ao, in.cap_ao)) || (rc = ensure(B.ao_key, in.cap_ao)) || (rc = ensure(B.ao2, in.cap_ao)) ||
-        (rc = ensure(B.ao_key2, in.cap_ao))) return rc;
-    {
-        const uint64_t n_tiles = in.n_rec / AO_TILE;
-        const int grid = (int)std::min<uint64_t>(n_tiles, 256 * 8);
-        hipLaunchKernelGGL(k_allele_obs, dim3(grid), dim3(AO_THREADS), 0, s, in.rec, in.pair, in.n_rec, in.site_mask,
-                           B.site_gpos.p, n_sites, B.ao.p, B.ao_key.p, (uint32_t)in.cap_ao, in.cursors, in.flags);
-    }
-    uint32_t n_ao = 0;
-    HIP_TRY(hipMemcpyAsync(&n_ao, in.cursors + CUR_AO, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    EV(2);
-    HIP_TRY(hipStreamSynchronize(s));
-    if (n_ao > in.cap_ao) { isx_set_error("allele-observation buffer overflow"); return ISX_ERR_CAPACITY; }
+    // ---- 2. allele observations (produced by the pileup kernel): position -> site rank ----
+    const uint32_t n_ao = in.n_ao;
     out.n_ao = n_ao;
-    if (n_ao == 0) { EV(3); EV(4); EV(5); return ISX_OK; }
+    if (n_ao == 0) { EV(2); EV(3); EV(4); EV(5); return ISX_OK; }
+    if ((rc = ensure(B.ao_key, n_ao)) || (rc = ensure(B.ao2, n_ao)) || (rc = ensure(B.ao_key2, n_ao))) return rc;
+    hipLaunchKernelGGL(k_ao_rank, dim3((n_ao + 255) / 256), dim3(256), 0, s, in.ao, n_ao, B.site_gpos.p, n_sites,
+                       B.ao_key.p);
+    EV(2);
 
     // ---- 3. group by pair ----
     tb = 0;
     const int pair_bits = bits_for(in.n_pairs ? in.n_pairs : 0xFFFFFFFFull);
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, B.ao_key.p, B.ao_key2.p, B.ao.p, B.ao2.p, n_ao, 0, pair_bits, s));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, B.ao_key.p, B.ao_key2.p, in.ao, B.ao2.p, n_ao, 0, pair_bits, s));
     if ((rc = ensure_temp(B.temp, tb))) return rc;
     tb = B.temp.cap;
-    HIP_TRY(rocprim::radix_sort_pairs(B.temp.p, tb, B.ao_key.p, B.ao_key2.p, B.ao.p, B.ao2.p, n_ao, 0, pair_bits, s));
+    HIP_TRY(rocprim::radix_sort_pairs(B.temp.p, tb, B.ao_key.p, B.ao_key2.p, in.ao, B.ao2.p, n_ao, 0, pair_bits, s));
     EV(3);
 
     // ---- 4. pair increments ----

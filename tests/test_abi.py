@@ -1,0 +1,68 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/instrain_amd.h declares;
+struct layouts used by the ctypes binding match the header; no compute calls."""
+import ctypes as C
+import os
+import re
+
+from instrain_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    h = open(os.path.join(REPO, "include", "instrain_amd.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(isx_[a-z_0-9]+)\s*\(", h)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(syms) == sorted(_lib.SYMBOLS)
+
+
+def test_abi_version_and_error_string():
+    lib = _lib.load()
+    assert lib.isx_abi_version() == 1
+    assert isinstance(lib.isx_last_error(), bytes)
+
+
+def test_struct_sizes_match_header(tmp_path):
+    """sizeof() of every ABI struct as the C compiler sees the header == the ctypes / numpy mirror."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "instrain_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(isx_params),sizeof(isx_sizes),sizeof(isx_timings),sizeof(isx_bam_params),sizeof(isx_bam_info),'
+                   'sizeof(isx_obs),sizeof(isx_entry),sizeof(isx_snv),sizeof(isx_ld));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    c_sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    py_sizes = [C.sizeof(_lib.Params), C.sizeof(_lib.Sizes), C.sizeof(_lib.Timings), C.sizeof(_lib.BamParams),
+                C.sizeof(_lib.BamInfo), _lib.OBS_DT.itemsize, _lib.ENTRY_DT.itemsize, _lib.SNV_DT.itemsize,
+                _lib.LD_DT.itemsize]
+    assert c_sizes == py_sizes, (c_sizes, py_sizes)
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    """Without a visible MI355X, context creation must fail (there is no CPU path in the product)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.isx_ctx_create(0, C.byref(h))
+    assert rc != 0 and not h.value
+    assert b"device" in lib.isx_last_error().lower() or b"hip" in lib.isx_last_error().lower()
+
+
+def test_product_never_imports_oracle():
+    import glob
+    for f in glob.glob(os.path.join(REPO, "instrain_amd", "**", "*.py"), recursive=True):
+        src = open(f).read()
+        assert "import oracle" not in src and "from oracle" not in src, f
+    for f in glob.glob(os.path.join(REPO, "instrain_amd", "csrc", "*")):
+        if f.endswith((".hip", ".cpp", ".h")):
+            assert "oracle" not in open(f).read(), f

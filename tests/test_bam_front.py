@@ -1,0 +1,64 @@
+"""CPU-only: the product's C++ BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9
+overlap rules, expansion) against the oracle's pure-Python restatement and the committed golden
+observations; host code only, no GPU."""
+import os
+
+import numpy as np
+
+from instrain_amd import engine
+from tests import util
+
+
+def test_sars_bam_matches_committed_observations():
+    bam = engine.BamFile(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"))
+    assert bam.refs() == [("MT039887.1", 29879, 0)]
+    obs, pair, bounds, sref = bam.expand()
+    i = bam.info
+    assert (i["n_reads"], i["unfiltered_pairs"], i["filtered_pairs"], i["median_insert"], i["max_mm"]) == \
+           (28913, 13925, 13124, 267.0, 25)
+    z = np.load(os.path.join(util.GOLD, "sars_cov_2_obs.npz"))
+    assert len(obs) == len(z["pos"]) == 3717600
+    assert (obs["gpos"] == z["pos"]).all() and (obs["base"] == z["base"]).all()
+    assert (obs["mm"] == z["mm"]).all() and (pair == z["pair"]).all()
+    assert list(bounds) == [0, 9959, 19918, 29879] and list(sref) == [0, 0, 0]      # iterate_splits(29879, 10000)
+    bam.close()
+
+
+def test_small_scaffold_matches_oracle_python():
+    """second BAM fixture of the reference's tests (126 bp scaffold, 751 reads): C++ == oracle/bam_py"""
+    from oracle import bam_py
+    path = os.path.join(util.GOLD, "SmallScaffold.fa.sorted.bam")
+    refs, reads = bam_py.read_bam(path)
+    p2i = {r[0]: bam_py.get_paired_reads(reads, t) for t, r in enumerate(refs)}
+    r2m, tallies = bam_py.filter_pairs(p2i)
+    bam = engine.BamFile(path)
+    obs, pair, bounds, sref = bam.expand()
+    assert [(n, l) for n, l, _ in bam.refs()] == refs
+    assert bam.info["filtered_pairs"] == sum(t["filtered_pairs"] for t in tallies.values())
+    P, B, M = [], [], []
+    off = 0
+    for t, (name, ln) in enumerate(refs):
+        bam_py.resolve_overlaps(reads, t)
+        pos, base, mm, pr, _ = bam_py.expand_observations(reads, t, r2m[name])
+        P.append(pos + off); B.append(base); M.append(mm)
+        off += ln
+    assert (obs["gpos"] == np.concatenate(P)).all()
+    assert (obs["base"] == np.concatenate(B)).all() and (obs["mm"] == np.concatenate(M)).all()
+    bam.close()
+
+
+def test_skip_mm_and_errors():
+    bam = engine.BamFile(os.path.join(util.GOLD, "SmallScaffold.fa.sorted.bam"))
+    obs, pair, bounds, sref = bam.expand(skip_mm=True)
+    assert (obs["mm"] == 0).all() and bam.info["max_mm"] == 0
+    try:
+        bam.expand()
+        assert False, "second expand must be refused (qualities were rewritten)"
+    except engine.IsxError as e:
+        assert e.code == -6
+    bam.close()
+    try:
+        engine.BamFile("/nonexistent.bam")
+        assert False
+    except engine.IsxError as e:
+        assert e.code == -5
