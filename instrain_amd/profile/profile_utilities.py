@@ -1,0 +1,172 @@
+"""Mirror of inStrain/profile/profile_utilities.py for the hot path: profile_split's result
+carrier (SplitObject, profile_utilities.py:823-858 and the fields set at :195-211) and the batch
+driver that replaces the split worker pool (profile_controller.py:157-271)."""
+import logging
+import time
+import traceback
+
+import numpy as np
+import pandas as pd
+
+from .. import engine
+from .snv_utilities import C2P, CLASSES, null_model_lut
+
+BASES = np.array(["A", "C", "T", "G", "N"])
+LD_COLUMNS = ['r2', 'd_prime', 'r2_normalized', 'd_prime_normalized', 'total', 'countAB', 'countAb', 'countaB',
+              'countab', 'allele_A', 'allele_a', 'allele_B', 'allele_b', 'distance', 'position_A', 'position_B',
+              'mm', 'scaffold']          # linkage.py:230-249 + calculate_ld :67-71
+SNP_COLUMNS = ['scaffold', 'position', 'ref_base', 'A', 'C', 'T', 'G', 'con_base', 'var_base', 'mm',
+               'allele_count', 'class', 'cryptic', 'position_coverage']   # snv_utilities.py:118-127, 274-290
+
+
+class SplitObject():
+    '''Holds the profile of an individual split (same attributes as the reference's SplitObject).'''
+
+    def __init__(self):
+        pass
+
+
+def _series_by_mm(pos, mm, val, dtype):
+    """shrink_basewise (profile_utilities.py:337-350): dict mm -> sparse pd.Series indexed by position"""
+    out = {}
+    if len(pos) == 0:
+        return out
+    order = np.lexsort((pos, mm))
+    pos, mm, val = pos[order], mm[order], val[order]
+    cuts = np.flatnonzero(np.diff(mm)) + 1
+    for s, e in zip(np.r_[0, cuts], np.r_[cuts, len(mm)]):
+        out[int(mm[s])] = pd.Series(val[s:e].astype(dtype), index=pos[s:e].astype(np.int64))
+    return out
+
+
+def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_offset, split_seq_len, min_freq,
+                     bam_name=None):
+    """Batch result (engine.Batch.fetch()) -> list of SplitObject, one per split, in split order."""
+    if "entries" in res:
+        e = res["entries"]
+    else:
+        e = engine.dense_to_entries(res["counts"], res["clon"])
+    snv, ld = res["snv"], res["ld"]
+    n = len(split_bounds) - 1
+    e_cut = np.searchsorted(e["gpos"], split_bounds)
+    s_cut = np.searchsorted(snv["gpos"], split_bounds)
+    l_cut = np.searchsorted(ld["gpos_a"], split_bounds)
+    out = []
+    for i in range(n):
+        scaff = split_scaffold[i]
+        off = scaffold_offset[i]
+        S = SplitObject()
+        S.scaffold = scaff
+        S.split_number = int(split_number[i])
+        S.bam = bam_name
+        S.length = int(split_seq_len[i])
+        S.min_freq = min_freq
+        ee = e[e_cut[i]:e_cut[i + 1]]
+        pos = ee["gpos"].astype(np.int64) - off
+        lvl = ee["cnt"].sum(axis=1)
+        k = lvl > 0
+        S.covT = _series_by_mm(pos[k], ee["mm"][k], lvl[k], "int32")
+        k = ~np.isnan(ee["clon"])
+        S.clonT = _series_by_mm(pos[k], ee["mm"][k], ee["clon"][k], "float32")
+        S.clonTR = {}       # rarefied clonality is unseeded-random in the reference; not produced yet
+        ss = snv[s_cut[i]:s_cut[i + 1]]
+        S.raw_snp_table = pd.DataFrame({
+            'scaffold': scaff, 'position': ss["gpos"].astype(np.int64) - off, 'ref_base': BASES[ss["ref_base"]],
+            'A': ss["cnt"][:, 0].astype(np.int64), 'C': ss["cnt"][:, 1].astype(np.int64),
+            'T': ss["cnt"][:, 2].astype(np.int64), 'G': ss["cnt"][:, 3].astype(np.int64),
+            'con_base': BASES[ss["con_base"]], 'var_base': BASES[ss["var_base"]], 'mm': ss["mm"].astype(np.int64),
+            'allele_count': ss["allele_count"].astype(np.int64), 'class': np.array(CLASSES)[ss["cls"]],
+            'cryptic': ss["cryptic"].astype(bool), 'position_coverage': ss["cnt"].sum(axis=1).astype(np.int64),
+        }, columns=SNP_COLUMNS) if len(ss) else pd.DataFrame()
+        ll = ld[l_cut[i]:l_cut[i + 1]]
+        if len(ll):
+            pa = ll["gpos_a"].astype(np.int64) - off
+            pb = ll["gpos_b"].astype(np.int64) - off
+            S.raw_linkage_table = pd.DataFrame({
+                'r2': ll["r2"], 'd_prime': ll["d_prime"], 'r2_normalized': np.nan, 'd_prime_normalized': np.nan,
+                'total': ll["total"].astype(np.int64), 'countAB': ll["countAB"].astype(np.int64),
+                'countAb': ll["countAb"].astype(np.int64), 'countaB': ll["countaB"].astype(np.int64),
+                'countab': ll["countab"].astype(np.int64), 'allele_A': BASES[ll["allele_A"]],
+                'allele_a': BASES[ll["allele_a"]], 'allele_B': BASES[ll["allele_B"]], 'allele_b': BASES[ll["allele_b"]],
+                'distance': np.abs(pb - pa), 'position_A': pa, 'position_B': pb, 'mm': ll["mm"].astype(np.int64),
+                'scaffold': scaff}, columns=LD_COLUMNS)
+        else:
+            S.raw_linkage_table = pd.DataFrame()
+        S.log = ""
+        out.append(S)
+    return out
+
+
+def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, window_length=10000, bam_name=None,
+                   **kwargs):
+    """Profile every split of `scaffolds` in ONE device batch.
+
+    scaffolds / sequences: names and upper-cased sequences laid end to end in the flat space (in the
+    order the observations' gpos assume); obs / pair: packed observations (engine.OBS_DT) and pair ids.
+    kwargs as the reference's profile_split: min_cov, min_freq, min_snp, rarefied_coverage.
+    Returns {"{scaffold}.{split}": SplitObject} like Sprofile_dict (profile_utilities.py:85).
+    """
+    from ..synth import iterate_splits
+    min_cov = int(kwargs.get('min_cov', 5))
+    min_freq = float(kwargs.get('min_freq', .05))
+    min_snp = int(kwargs.get('min_snp', 10))
+    lut, fb = null_model_lut(null_model)
+    ctx.set_null_model(lut, fb)
+    bounds, s_scaff, s_num, s_off, s_len = [], [], [], [], []
+    off = 0
+    for name, seq in zip(scaffolds, sequences):
+        for i, (s, e) in enumerate(iterate_splits(len(seq), window_length)):
+            bounds.append(off + s)
+            s_scaff.append(name); s_num.append(i); s_off.append(off); s_len.append(e - s + 1)
+        off += len(seq)
+    bounds.append(off)
+    ref = np.concatenate([engine.encode_seq(s) for s in sequences])
+    b = engine.Batch(ctx, ref, bounds, obs, pair, min_cov=min_cov, min_freq=min_freq, min_snp=min_snp,
+                     n_mm_bins=n_mm_bins, enable_linkage=True)
+    try:
+        b.run()
+        res = b.fetch()
+    finally:
+        b.close()
+    splits = tables_to_splits(res, np.asarray(bounds), s_scaff, s_num, s_off, s_len, min_freq, bam_name)
+    return {"{0}.{1}".format(S.scaffold, S.split_number): S for S in splits}
+
+
+def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
+    """Mirror of inStrain.profile.profile_bam (profile/__init__.py:7-18).
+
+    bam: path of a sorted BAM; kwargs: the CLI's flags (min_cov, min_freq, min_snp, min_read_ani,
+    min_mapq, max_insert_relative, min_insert, skip_mm_profiling, window_length) plus `s2s`
+    (scaffold -> upper-cased sequence, controller.py:337) and `null_model` (dict, snv_utilities.py:14-38).
+    fasta_db / sR2M are accepted for signature compatibility: split geometry and the read-pair filter
+    are recomputed by the C++ front end with the reference's rules (filter_reads.py:885-956, 201-260).
+    Returns {"scaffold.split": SplitObject}; a failing batch follows the reference's convention
+    (profile_utilities.py:104-111): the exception is logged and the splits are dropped."""
+    s2s = kwargs['s2s']
+    null_model = kwargs['null_model']
+    device = int(kwargs.get('device', 0))
+    t = time.strftime('%m-%d %H:%M')
+    try:
+        ctx = kwargs.get('ctx') or engine.Context(device)
+        bf = engine.BamFile(bam)
+        obs, pair, bounds, sref = bf.expand(min_read_ani=kwargs.get('min_read_ani', 0.95),
+                                            min_mapq=kwargs.get('min_mapq', -1),
+                                            max_insert_relative=kwargs.get('max_insert_relative', 3),
+                                            min_insert=kwargs.get('min_insert', 50),
+                                            skip_mm=bool(kwargs.get('skip_mm_profiling', False)),
+                                            window_length=int(kwargs.get('window_length', 10000)))
+        refs = bf.refs()
+        names = [r[0] for r in refs]
+        for n, ln, _ in refs:
+            if n not in s2s or len(s2s[n]) != ln:
+                raise ValueError("scaffold {0} is not in the .fasta / length differs from the .bam header".format(n))
+        n_mm = bf.info["max_mm"] + 1
+        bf.close()
+        kw = {k: v for k, v in kwargs.items() if k in ('min_cov', 'min_freq', 'min_snp', 'rarefied_coverage')}
+        return profile_splits(ctx, names, [str(s2s[n]).upper() for n in names], obs, pair, null_model, n_mm,
+                              window_length=int(kwargs.get('window_length', 10000)), bam_name=bam, **kw)
+    except Exception as e:
+        print(e)
+        traceback.print_exc()
+        logging.error("\n{1} DEBUG FAILURE SplitException {0} batch\n".format(bam, t))
+        return {}

@@ -1,0 +1,90 @@
+"""GPU tests written the way the reference's own tests read (test/tests/test_profile.py): run the
+profile entry point on a BAM + FASTA, then assert on DataFrames."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sars_profile():
+    import instrain_amd.profile as prof
+    from tests.test_oracle_golden import read_fasta
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    seq = read_fasta(os.path.join(util.GOLD, "sars_cov_2_MT039887.1.fasta"))
+    splits = prof.profile_bam(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"), s2s={"MT039887.1": seq},
+                              null_model=model, min_cov=5, min_freq=0.05, min_snp=20, min_read_ani=0.95)
+    assert sorted(splits) == ["MT039887.1.0", "MT039887.1.1", "MT039887.1.2"]
+    return splits
+
+
+def test_split_objects_have_the_reference_fields(sars_profile):
+    S = sars_profile["MT039887.1.1"]
+    for att in ["scaffold", "split_number", "bam", "length", "raw_snp_table", "raw_linkage_table", "covT", "clonT",
+                "clonTR", "min_freq", "log"]:       # profile_utilities.py:195-214
+        assert hasattr(S, att), att
+    assert S.length == 9959 and S.split_number == 1
+    assert list(S.raw_snp_table.columns) == ['scaffold', 'position', 'ref_base', 'A', 'C', 'T', 'G', 'con_base',
+                                              'var_base', 'mm', 'allele_count', 'class', 'cryptic', 'position_coverage']
+    assert S.covT[0].dtype == np.int32 and S.clonT[0].dtype == np.float32      # shrink_basewise dtypes
+
+
+def test_tables_equal_stored_golden(sars_profile):
+    """like test_profile_16: every row of raw_snp_table / raw_linkage_table vs the stored run
+    (random *_normalized columns excluded, test_profile.py:896-900)"""
+    from tests.test_oracle_golden import sars_golden_tables
+    gS, gL = sars_golden_tables()
+    S = pd.concat([s.raw_snp_table for s in sars_profile.values()]).sort_values(["position", "mm"]).reset_index(drop=True)
+    L = pd.concat([s.raw_linkage_table for s in sars_profile.values()]).sort_values(["position_A", "position_B", "mm"]).reset_index(drop=True)
+    assert len(S) == len(gS) and len(L) == len(gL)
+    for c in ["scaffold", "position", "ref_base", "A", "C", "T", "G", "con_base", "var_base", "mm", "allele_count",
+              "cryptic", "position_coverage"]:
+        assert (S[c].values == gS[c].values).all(), c
+    for c in ["total", "countAB", "countAb", "countaB", "countab", "allele_A", "allele_a", "allele_B", "allele_b",
+              "distance", "position_A", "position_B", "mm", "scaffold"]:
+        assert (L[c].values == gL[c].values).all(), c
+    for c in ["r2", "d_prime"]:
+        a, b = L[c].values.astype(float), gL[c].values.astype(float)
+        assert (np.isnan(a) == np.isnan(b)).all() and np.nanmax(np.abs(a - b)) <= 1e-6, c
+
+
+def test_covT_vs_snv_table_coverage(sars_profile):
+    """the reference's test_profile_13 (test_profile.py:726-750): cumulative covT == position_coverage"""
+    for S in sars_profile.values():
+        for _, row in S.raw_snp_table.iterrows():
+            cov = sum(int(ser.get(row["position"], 0)) for mm, ser in S.covT.items() if mm <= row["mm"])
+            assert cov == row["position_coverage"], (row["position"], row["mm"])
+
+
+def test_coverage_summary_equals_stored_cumulative_table(sars_profile):
+    """per-mm mean coverage / breadth recomputed from covT == the stored cumulative_scaffold_table"""
+    g = pd.read_csv(os.path.join(util.GOLD, "sars_cov_2_cumulative_scaffold_table.csv.gz"))
+    L = 29879
+    dense = {}
+    for S in sars_profile.values():
+        for mm, ser in S.covT.items():
+            dense.setdefault(mm, np.zeros(L, dtype=np.int64))[ser.index.values] += ser.values
+    cum = np.zeros(L, dtype=np.int64)
+    for mm in sorted(dense):
+        cum = cum + dense[mm]
+        row = g[g["mm"] == mm].iloc[0]
+        assert abs(cum.mean() - row["coverage"]) < 1e-9
+        assert abs((cum > 0).sum() / L - row["breadth"]) < 1e-12
+        assert int(np.median(cum)) == int(row["median_cov"])
+
+
+def test_missing_scaffold_follows_failure_convention():
+    """like test_profile_17 / profile_utilities.py:104-111: a failing batch is logged and dropped"""
+    import instrain_amd.profile as prof
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    out = prof.profile_bam(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"), s2s={"other": "ACGT"}, null_model=model)
+    assert out == {}
