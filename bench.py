@@ -134,10 +134,14 @@ def main():
     from instrain_amd import engine
     from tests import util        # only for the committed null-model LUT fixture (data, not oracle code)
 
-    rank, local, world = idist.init_from_env()
+    # ISX_DIST_BACKEND=gloo + ISX_DEVICE=0 let the N>1 control flow be exercised on a 1-GPU box (tests only)
+    rank, local, world = idist.init_from_env(backend=os.environ.get("ISX_DIST_BACKEND"))
     assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
+    if "ISX_DEVICE" in os.environ:
+        local = int(os.environ["ISX_DEVICE"])
+    use_nccl = world > 1 and dist.get_backend() == "nccl"
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local) if (world == 1 or use_nccl) else torch.device("cpu")
     ctx = engine.Context(local)
     lut, fb = util.load_lut()
     ctx.set_null_model(lut, fb)
@@ -148,7 +152,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if use_nccl:
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
 
     for _ in range(args.warmup):
         batch.run()
@@ -180,7 +187,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         g0 = time.perf_counter()
-        idist.gather_tables({"snv": res["snv"]}, dst=0)
+        idist.gather_tables({"snv": res["snv"]}, dst=0, device=dev)
         torch.cuda.synchronize()
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
@@ -224,7 +231,7 @@ def main():
     batch.close()
     ctx.close()
     if world > 1:
-        dist.barrier(device_ids=[local])
+        barrier()
         dist.destroy_process_group()
 
 

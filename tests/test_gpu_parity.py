@@ -165,3 +165,24 @@ def test_full_size_properties(ctx):
         assert r1[k].tobytes() == r2[k].tobytes(), k
     cov = r1["counts"].sum(axis=1)
     assert (r1["snv"]["cnt"].sum(axis=1) == cov[r1["snv"]["gpos"]]).all()
+
+
+def test_bench_two_ranks_control_flow(tmp_path):
+    """bench.py under torch.distributed.run with 2 ranks (both on GPU 0, gloo) -- the N>1 code path
+    (per-rank workload, barrier, MAX-reduce of the time, SUM of units, final gather) runs and prints
+    one JSON line whose value is the whole-job aggregate."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(util.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
+    env = dict(os.environ, ISX_DIST_BACKEND="gloo", ISX_DEVICE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(repo, "bench.py"),
+                        "--gpus", "2", "--steps", "5", "--warmup", "1", "--scale", "0.05"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and "final_gather_ms" in j
+    assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j
