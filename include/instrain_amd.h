@@ -72,7 +72,8 @@ typedef struct {
     int32_t rarefied_coverage;  /* --rarefied_coverage, default 50 */
     int32_t n_mm_bins;          /* mm levels 0..n_mm_bins-1 may occur; 1 = --skip_mm_profiling */
     int32_t enable_linkage;     /* 0: pileup / SNV only */
-    int32_t linkage_mode;       /* 0 auto, 1 sparse pair-increment path, 2 dense int8 MFMA path */
+    int32_t linkage_mode;       /* 0 auto (= sparse in this version), 1 sparse pair-increment path,
+                                 * 2 dense int8 MFMA path (n_mm_bins == 1 only) */
     int32_t window;             /* 0 = auto; positions per workgroup window (multiple of 64) */
     uint64_t seed;              /* counter-based RNG seed for the rarefied outputs */
 } isx_params;
@@ -132,6 +133,11 @@ typedef struct {
     float ld_ms;            /* LD rows */
     float total_ms;
     int32_t pileup_blocks, pileup_threads, pileup_lds_bytes, pileup_window;
+    /* dense int8-MFMA linkage path (linkage_mode 2) */
+    float mfma_ms;          /* one k_dense_gemm pass over all tiles (the path runs it twice: count, emit) */
+    int32_t dense_tiles;    /* 32x32 tiles of the upper triangles */
+    int64_t dense_macs;     /* int8 multiply-accumulates of one pass */
+    int64_t dense_bytes;    /* bytes of the X^T blocks */
 } isx_timings;
 
 const char *isx_last_error(void);

@@ -51,7 +51,7 @@ struct isx_batch {
     uint32_t *h_state = nullptr;                          // pinned mirror of the above
     size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
     LinkageBuffers L;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
     bool ran = false;
     isx_sizes sizes{};
     isx_timings tim{};
@@ -380,7 +380,8 @@ int isx_batch_run(isx_batch *b)
 
     if (b->prm.enable_linkage) {
         LinkageIn in{};
-        in.stream = s; in.ev = &b->ev[2];
+        in.stream = s; in.ev = &b->ev[2]; in.ev_mfma = &b->ev[8];
+        in.mode = b->prm.linkage_mode == 2 ? 2 : 1;
         in.n_pairs = b->n_pairs; in.ao = b->d_ao; in.n_ao = cur[CUR_AO];
         in.sites = b->d_sites; in.n_sites = cur[CUR_SITES];
         in.entries = b->d_entries; in.counts = b->d_counts;
@@ -399,6 +400,9 @@ int isx_batch_run(isx_batch *b)
         b->tim.incr_ms = ev_ms(b->ev[5], b->ev[6]);
         b->tim.ld_ms = ev_ms(b->ev[6], b->ev[7]);
         b->tim.total_ms = ev_ms(b->ev[0], b->ev[7]);
+        b->tim.mfma_ms = ev_ms(b->ev[8], b->ev[9]);
+        b->tim.dense_tiles = (int32_t)lo.dense_tiles; b->tim.dense_macs = (int64_t)lo.dense_macs;
+        b->tim.dense_bytes = (int64_t)lo.dense_bytes;
     } else {
         b->tim.total_ms = b->tim.pileup_ms;
     }

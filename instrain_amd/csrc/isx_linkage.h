@@ -8,6 +8,14 @@ struct DevBuf {
     size_t cap = 0;     // elements
 };
 
+struct DenseSplit {         // one split of the dense MFMA path
+    uint64_t xt_off;        // byte offset of its column-major X^T block
+    uint32_t rpad;          // rows (read pairs), padded to 32
+    uint32_t ctiles;        // column tiles of 32 (4 columns per site)
+    uint32_t first_site, n_sites, first_row, pad;
+};
+struct DenseTile { uint32_t slot, I, J, pad; };
+
 struct LinkageBuffers {
     DevBuf<uint32_t> site_keys, site_keys2, site_gpos, site_split;
     DevBuf<isx_site> sites_sorted;
@@ -18,12 +26,19 @@ struct LinkageBuffers {
     DevBuf<uint32_t> ucnt, n_runs, rows_per, row_off;
     DevBuf<isx_ld> ld;
     DevBuf<uint8_t> temp;
+    // dense path
+    DevBuf<uint64_t> key64, key64b;
+    DevBuf<uint32_t> head, row_id, first_row, first_site, split_slot, tile_cnt, tile_off, vals, vals2;
+    DevBuf<DenseSplit> dsplits;
+    DevBuf<DenseTile> dtiles;
+    DevBuf<uint8_t> xt;
     void release();
 };
 
 struct LinkageIn {
     hipStream_t stream;
     hipEvent_t *ev;             // 6 events: start, sites, allele, group, incr, ld
+    hipEvent_t *ev_mfma;        // 2 events around k_dense_gemm<false> (dense path)
     uint64_t n_pairs;           // 0 = unknown
     isx_ao *ao;                 // written by the pileup kernel (site field = flat position)
     uint32_t n_ao;
@@ -35,10 +50,12 @@ struct LinkageIn {
     int n_splits;
     int M;
     int min_snp;
+    int mode;                   // 1 sparse, 2 dense MFMA (n_mm_bins == 1)
 };
 
 struct LinkageOut {
     uint64_t n_ao = 0, n_increments = 0, n_edges = 0, n_ld = 0;
+    uint64_t dense_tiles = 0, dense_bytes = 0, dense_macs = 0;   // dense path only
 };
 
 int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out);

@@ -22,6 +22,7 @@
 //   6 k_ld_rows      one lane per edge: ascending mm on the edge, cumulative combo counts,
 //                    site counts <= mm, gates, r2 / D' in fp64 in the reference's order.
 #include <algorithm>
+#include <vector>
 #include <cstring>
 #include <string.h>
 #include <rocprim/rocprim.hpp>
@@ -81,7 +82,9 @@ __global__ void __launch_bounds__(256) k_ao_rank(isx_ao *ao, uint32_t n, const u
 // calc_mm_SNV_linkage_network (linkage.py:26-42): itertools.combinations(snvs, 2) per (mm, read).
 // EMIT = false counts the combinations of element i with the later elements of its pair group,
 // EMIT = true writes their keys at off[i].
-template <bool EMIT>
+// SELF_ONLY keeps only the same-site combinations (both mates visible at one column): the dense
+// MFMA path takes every cross-site count from X^T X and needs just these from the pair lists.
+template <bool EMIT, bool SELF_ONLY>
 __global__ void __launch_bounds__(256) k_pair_incr(const isx_ao *ao, uint32_t n, const uint32_t *site_split,
                                                    uint32_t *cnt, const uint32_t *off, uint64_t *keys)
 {
@@ -95,6 +98,7 @@ __global__ void __launch_bounds__(256) k_pair_incr(const isx_ao *ao, uint32_t n,
         const isx_ao b = ao[j];
         if (b.pair != a.pair) break;
         if (site_split[b.site] != sa) continue;      // read_to_snvs is per profile_split call
+        if (SELF_ONLY && b.site != a.site) continue;
         if (EMIT) {
             // list order = (column, arrival order inside the column)
             const bool a_first = (a.site < b.site) || (a.site == b.site && a.obs_idx < b.obs_idx);
@@ -242,6 +246,114 @@ __global__ void __launch_bounds__(256) k_ld_rows(const uint64_t *ukeys, const ui
     if (!EMIT) rows_per[u] = rows;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Dense co-occurrence path (linkage_mode 2, n_mm_bins == 1): per split the read-pair x allele
+// incidence matrix X (int8; rows = read pairs with an allele observation in the split, columns =
+// 4 per SNP site) is materialised column-major, and every cross-site co-occurrence count
+//     G[p1][p2]['mm2combo2counts'][0]["b1:b2"]  (linkage.py:30-42)  ==  (X^T X)[(p1,b1), (p2,b2)]
+// comes out of v_mfma_i32_32x32x32_i8 tiles (one wave per 32x32 tile of the upper triangle;
+// lane l feeds 16 consecutive pair-rows of column l%32 for A and for B -- the k order only has to
+// agree between A and B, tools/mfma_probe.hip).  Same-site combinations (self pairs) are not a
+// product of X with itself (identical bases contribute C(x,2), differing bases are ordered by
+// arrival) and come from k_pair_incr<.., SELF_ONLY>.
+// ------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__global__ void k_ao_key64(const isx_ao *ao, uint32_t n, const uint32_t *site_split, uint64_t *key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = ((uint64_t)site_split[ao[i].site] << 32) | ao[i].pair;
+}
+
+__global__ void k_row_heads(const uint64_t *key, uint32_t n, uint32_t *head)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+}
+
+// first row / first site of every split that has any (0xFFFFFFFF elsewhere; filled on the host)
+__global__ void k_split_first_row(const uint64_t *key, const uint32_t *row_id, uint32_t n, uint32_t *first_row)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sp = (uint32_t)(key[i] >> 32);
+    if (i == 0 || (uint32_t)(key[i - 1] >> 32) != sp) first_row[sp] = row_id[i];
+}
+
+__global__ void k_split_first_site(const uint32_t *site_split, uint32_t n_sites, uint32_t *first_site)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sites) return;
+    if (i == 0 || site_split[i - 1] != site_split[i]) first_site[site_split[i]] = i;
+}
+
+__global__ void k_dense_scatter(const isx_ao *ao, const uint64_t *key, const uint32_t *row_id, const uint32_t *head,
+                                uint32_t n, const uint32_t *split_slot, const DenseSplit *splits, uint8_t *xt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = split_slot[(uint32_t)(key[i] >> 32)];
+    if (slot == 0xFFFFFFFFu) return;
+    const DenseSplit ds = splits[slot];
+    const isx_ao a = ao[i];
+    const uint64_t row = row_id[i] + head[i] - 1 - ds.first_row;     // row_id = exclusive scan of the heads
+    const uint64_t col = (uint64_t)(a.site - ds.first_site) * 4 + a.base;
+    const uint64_t idx = ds.xt_off + col * ds.rpad + row;
+    atomicAdd(reinterpret_cast<uint32_t *>(xt + (idx & ~3ull)), 1u << (8 * (idx & 3)));
+}
+
+// One wave per upper-triangle tile. EMIT=false: number of (site1 < site2) non-zero counts of the tile.
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_dense_gemm(const DenseTile *tiles, uint32_t n_tiles, const DenseSplit *splits,
+                                                    const uint8_t *xt, uint32_t *tile_cnt, const uint32_t *tile_off,
+                                                    uint64_t *keys, uint32_t *cnts)
+{
+    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const int l = threadIdx.x & 63;
+    const DenseTile tl = tiles[t];
+    const DenseSplit ds = splits[tl.slot];
+    const uint8_t *pa = xt + ds.xt_off + (uint64_t)(tl.I * 32 + (l & 31)) * ds.rpad + 16 * (l >> 5);
+    const uint8_t *pb = xt + ds.xt_off + (uint64_t)(tl.J * 32 + (l & 31)) * ds.rpad + 16 * (l >> 5);
+    v16i acc = {0};
+    uint32_t k0 = 0;
+    for (; k0 + 64 <= ds.rpad; k0 += 64) {          // two k-steps in flight
+        const v4i a0 = *reinterpret_cast<const v4i *>(pa + k0), b0 = *reinterpret_cast<const v4i *>(pb + k0);
+        const v4i a1 = *reinterpret_cast<const v4i *>(pa + k0 + 32), b1 = *reinterpret_cast<const v4i *>(pb + k0 + 32);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc, 0, 0, 0);
+    }
+    for (; k0 < ds.rpad; k0 += 32) {
+        const v4i a0 = *reinterpret_cast<const v4i *>(pa + k0), b0 = *reinterpret_cast<const v4i *>(pb + k0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc, 0, 0, 0);
+    }
+    uint32_t run = EMIT ? tile_off[t] : 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t ci = tl.I * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);      // C/D layout of the 32x32 forms
+        const uint32_t cj = tl.J * 32 + (l & 31);
+        const uint32_t si = ci >> 2, sj = cj >> 2;
+        const int v = acc[r];
+        const bool hit = v > 0 && si < sj && sj < ds.n_sites;
+        const unsigned long long bal = __ballot(hit);
+        if (EMIT && hit) {
+            const uint32_t o = run + (uint32_t)__popcll(bal & ((1ull << l) - 1ull));
+            keys[o] = make_key(ds.first_site + si, ds.first_site + sj, 0, ci & 3, cj & 3);
+            cnts[o] = (uint32_t)v;
+        }
+        run += (uint32_t)__popcll(bal);
+    }
+    if (!EMIT && l == 0) tile_cnt[t] = run;
+}
+
+__global__ void k_fill_ones(uint32_t *p, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 1u;
+}
+
 template <class T>
 int ensure(DevBuf<T> &b, size_t n)
 {
@@ -269,36 +381,195 @@ void LinkageBuffers::release()
 {
     void *ps[] = {site_keys.p, site_keys2.p, sites_sorted.p, site_gpos.p, site_split.p, ao_key.p, ao2.p,
                   ao_key2.p, incr_cnt.p, incr_off.p, keys.p, keys2.p, ukeys.p, ucnt.p, n_runs.p, rows_per.p,
-                  row_off.p, ld.p, temp.p};
+                  row_off.p, ld.p, temp.p, key64.p, key64b.p, head.p, row_id.p, first_row.p, first_site.p,
+                  split_slot.p, tile_cnt.p, tile_off.p, vals.p, vals2.p, dsplits.p, dtiles.p, xt.p};
     for (void *p : ps) if (p) (void)hipFree(p);
     *this = LinkageBuffers();
 }
 
 #define EV(i) HIP_TRY(hipEventRecord(in.ev[i], s))
+#define RP(call_with_temp)                                                                       \
+    do {                                                                                         \
+        void *tp = nullptr; size_t tb = 0;                                                       \
+        HIP_TRY(call_with_temp);                                                                 \
+        if ((rc = ensure_temp(B.temp, tb))) return rc;                                           \
+        tp = B.temp.p; tb = B.temp.cap;                                                          \
+        HIP_TRY(call_with_temp);                                                                 \
+    } while (0)
+
+namespace {
+
+// exclusive scan of cnt[0..n) into off, returns the total (one small D2H + sync)
+int scan_total(LinkageBuffers &B, hipStream_t s, uint32_t *cnt, uint32_t *off, uint32_t n, uint64_t &total)
+{
+    int rc;
+    RP(rocprim::exclusive_scan(tp, tb, cnt, off, 0u, n, rocprim::plus<uint32_t>(), s));
+    uint32_t last_off = 0, last_cnt = 0;
+    HIP_TRY(hipMemcpyAsync(&last_off, off + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&last_cnt, cnt + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    total = (uint64_t)last_off + last_cnt;
+    return ISX_OK;
+}
+
+// steps 3-5 of the sparse path: group by pair, all i<j combinations as keys, sort, run-length encode
+int sparse_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t n_ao, uint32_t &n_u)
+{
+    hipStream_t s = in.stream;
+    int rc;
+    n_u = 0;
+    const int pair_bits = bits_for(in.n_pairs ? in.n_pairs : 0xFFFFFFFFull);
+    RP(rocprim::radix_sort_pairs(tp, tb, B.ao_key.p, B.ao_key2.p, in.ao, B.ao2.p, n_ao, 0, pair_bits, s));
+    EV(3);
+    if ((rc = ensure(B.incr_cnt, n_ao)) || (rc = ensure(B.incr_off, (size_t)n_ao + 1))) return rc;
+    hipLaunchKernelGGL((k_pair_incr<false, false>), dim3((n_ao + 255) / 256), dim3(256), 0, s, B.ao2.p, n_ao,
+                       B.site_split.p, B.incr_cnt.p, nullptr, nullptr);
+    uint64_t n_inc = 0;
+    if ((rc = scan_total(B, s, B.incr_cnt.p, B.incr_off.p, n_ao, n_inc))) return rc;
+    out.n_increments = n_inc;
+    if (n_inc == 0) { EV(4); return ISX_OK; }
+    if (n_inc >= 0xFFFFFFFFull) { isx_set_error("more than 2^32 pair increments in one batch"); return ISX_ERR_CAPACITY; }
+    if ((rc = ensure(B.keys, n_inc)) || (rc = ensure(B.keys2, n_inc)) || (rc = ensure(B.ukeys, n_inc)) ||
+        (rc = ensure(B.ucnt, n_inc)) || (rc = ensure(B.n_runs, 2))) return rc;
+    hipLaunchKernelGGL((k_pair_incr<true, false>), dim3((n_ao + 255) / 256), dim3(256), 0, s, B.ao2.p, n_ao,
+                       B.site_split.p, nullptr, B.incr_off.p, B.keys.p);
+    RP(rocprim::radix_sort_keys(tp, tb, B.keys.p, B.keys2.p, (size_t)n_inc, 0, 64, s));
+    RP(rocprim::run_length_encode(tp, tb, B.keys2.p, (size_t)n_inc, B.ukeys.p, B.ucnt.p, B.n_runs.p, s));
+    HIP_TRY(hipMemcpyAsync(&n_u, B.n_runs.p, 4, hipMemcpyDeviceToHost, s));
+    EV(4);
+    HIP_TRY(hipStreamSynchronize(s));
+    return ISX_OK;
+}
+
+// steps 3-5 of the dense path: X^T per split, int8 MFMA tiles, self pairs, sort + reduce by key
+int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t n_ao, uint32_t n_sites, uint32_t &n_u)
+{
+    hipStream_t s = in.stream;
+    int rc;
+    n_u = 0;
+    const uint32_t nsp = (uint32_t)in.n_splits;
+    // rows: allele observations sorted by (split, pair); one row per distinct (split, pair)
+    if ((rc = ensure(B.key64, n_ao)) || (rc = ensure(B.key64b, n_ao)) || (rc = ensure(B.head, n_ao)) ||
+        (rc = ensure(B.row_id, (size_t)n_ao + 1)) || (rc = ensure(B.first_row, (size_t)nsp + 1)) ||
+        (rc = ensure(B.first_site, (size_t)nsp + 1)) || (rc = ensure(B.split_slot, nsp))) return rc;
+    const dim3 ga((n_ao + 255) / 256), blk(256);
+    hipLaunchKernelGGL(k_ao_key64, ga, blk, 0, s, in.ao, n_ao, B.site_split.p, B.key64.p);
+    const int key_bits = 32 + bits_for(nsp);
+    RP(rocprim::radix_sort_pairs(tp, tb, B.key64.p, B.key64b.p, in.ao, B.ao2.p, n_ao, 0, key_bits, s));
+    EV(3);
+    hipLaunchKernelGGL(k_row_heads, ga, blk, 0, s, B.key64b.p, n_ao, B.head.p);
+    uint64_t n_rows = 0;
+    if ((rc = scan_total(B, s, B.head.p, B.row_id.p, n_ao, n_rows))) return rc;
+    HIP_TRY(hipMemsetAsync(B.first_row.p, 0xFF, ((size_t)nsp + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(B.first_site.p, 0xFF, ((size_t)nsp + 1) * 4, s));
+    hipLaunchKernelGGL(k_split_first_row, ga, blk, 0, s, B.key64b.p, B.row_id.p, n_ao, B.first_row.p);
+    hipLaunchKernelGGL(k_split_first_site, dim3((n_sites + 255) / 256), blk, 0, s, B.site_split.p, n_sites, B.first_site.p);
+    std::vector<uint32_t> frow((size_t)nsp + 1), fsite((size_t)nsp + 1);
+    HIP_TRY(hipMemcpyAsync(frow.data(), B.first_row.p, frow.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(fsite.data(), B.first_site.p, fsite.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    frow[nsp] = (uint32_t)n_rows; fsite[nsp] = n_sites;
+    for (uint32_t i = nsp; i-- > 0;) {
+        if (frow[i] == 0xFFFFFFFFu) frow[i] = frow[i + 1];
+        if (fsite[i] == 0xFFFFFFFFu) fsite[i] = fsite[i + 1];
+    }
+    // split table + tile list (host; a few entries per split)
+    std::vector<DenseSplit> ds;
+    std::vector<DenseTile> tiles;
+    std::vector<uint32_t> slot(nsp, 0xFFFFFFFFu);
+    uint64_t bytes = 0, macs = 0;
+    for (uint32_t sp = 0; sp < nsp; sp++) {
+        const uint32_t rows = frow[sp + 1] - frow[sp], ns = fsite[sp + 1] - fsite[sp];
+        if (rows == 0 || ns < 2) continue;           // no cross-site pair possible
+        DenseSplit d{};
+        d.xt_off = bytes;
+        d.rpad = (rows + 31) / 32 * 32;
+        d.ctiles = (ns * 4 + 31) / 32;
+        d.first_site = fsite[sp]; d.n_sites = ns; d.first_row = frow[sp];
+        bytes += (uint64_t)d.ctiles * 32 * d.rpad;
+        slot[sp] = (uint32_t)ds.size();
+        for (uint32_t I = 0; I < d.ctiles; I++)
+            for (uint32_t J = I; J < d.ctiles; J++) tiles.push_back(DenseTile{(uint32_t)ds.size(), I, J, 0});
+        macs += (uint64_t)d.ctiles * (d.ctiles + 1) / 2 * 32 * 32 * d.rpad;
+        ds.push_back(d);
+    }
+    out.dense_tiles = tiles.size(); out.dense_bytes = bytes; out.dense_macs = macs;
+    if (bytes > (16ull << 30)) { isx_set_error("dense linkage path needs > 16 GiB for X^T: use the sparse path"); return ISX_ERR_CAPACITY; }
+    if (tiles.size() >= 0xFFFFFFFFull) { isx_set_error("too many dense tiles"); return ISX_ERR_CAPACITY; }
+    const uint32_t n_tiles = (uint32_t)tiles.size();
+    uint64_t n_gemm = 0;
+    if (n_tiles) {
+        if ((rc = ensure(B.dsplits, ds.size())) || (rc = ensure(B.dtiles, tiles.size())) || (rc = ensure(B.xt, bytes + 16)) ||
+            (rc = ensure(B.tile_cnt, n_tiles)) || (rc = ensure(B.tile_off, (size_t)n_tiles + 1))) return rc;
+        HIP_TRY(hipMemcpyAsync(B.dsplits.p, ds.data(), ds.size() * sizeof(DenseSplit), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(B.dtiles.p, tiles.data(), tiles.size() * sizeof(DenseTile), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(B.split_slot.p, slot.data(), slot.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(B.xt.p, 0, bytes + 16, s));
+        hipLaunchKernelGGL(k_dense_scatter, ga, blk, 0, s, B.ao2.p, B.key64b.p, B.row_id.p, B.head.p, n_ao, B.split_slot.p,
+                           B.dsplits.p, B.xt.p);
+        HIP_TRY(hipEventRecord(in.ev_mfma[0], s));
+        hipLaunchKernelGGL((k_dense_gemm<false>), dim3((n_tiles + 3) / 4), blk, 0, s, B.dtiles.p, n_tiles, B.dsplits.p,
+                           B.xt.p, B.tile_cnt.p, nullptr, nullptr, nullptr);
+        HIP_TRY(hipEventRecord(in.ev_mfma[1], s));
+        if ((rc = scan_total(B, s, B.tile_cnt.p, B.tile_off.p, n_tiles, n_gemm))) return rc;
+    } else {
+        HIP_TRY(hipEventRecord(in.ev_mfma[0], s));
+        HIP_TRY(hipEventRecord(in.ev_mfma[1], s));
+    }
+    // same-site combinations from the pair lists
+    if ((rc = ensure(B.incr_cnt, n_ao)) || (rc = ensure(B.incr_off, (size_t)n_ao + 1))) return rc;
+    hipLaunchKernelGGL((k_pair_incr<false, true>), ga, blk, 0, s, B.ao2.p, n_ao, B.site_split.p, B.incr_cnt.p, nullptr, nullptr);
+    uint64_t n_self = 0;
+    if ((rc = scan_total(B, s, B.incr_cnt.p, B.incr_off.p, n_ao, n_self))) return rc;
+    const uint64_t n_k = n_gemm + n_self;
+    if (n_k == 0) { EV(4); return ISX_OK; }
+    if (n_k >= 0xFFFFFFFFull) { isx_set_error("more than 2^32 co-occurrence keys in one batch"); return ISX_ERR_CAPACITY; }
+    if ((rc = ensure(B.keys, n_k)) || (rc = ensure(B.keys2, n_k)) || (rc = ensure(B.vals, n_k)) || (rc = ensure(B.vals2, n_k)) ||
+        (rc = ensure(B.ukeys, n_k)) || (rc = ensure(B.ucnt, n_k)) || (rc = ensure(B.n_runs, 2))) return rc;
+    if (n_gemm)
+        hipLaunchKernelGGL((k_dense_gemm<true>), dim3((n_tiles + 3) / 4), blk, 0, s, B.dtiles.p, n_tiles, B.dsplits.p, B.xt.p,
+                           nullptr, B.tile_off.p, B.keys.p, B.vals.p);
+    if (n_self) {
+        hipLaunchKernelGGL((k_pair_incr<true, true>), ga, blk, 0, s, B.ao2.p, n_ao, B.site_split.p, nullptr, B.incr_off.p,
+                           B.keys.p + n_gemm);
+        hipLaunchKernelGGL(k_fill_ones, dim3(((uint32_t)n_self + 255) / 256), blk, 0, s, B.vals.p + n_gemm, (uint32_t)n_self);
+    }
+    RP(rocprim::radix_sort_pairs(tp, tb, B.keys.p, B.keys2.p, B.vals.p, B.vals2.p, (size_t)n_k, 0, 64, s));
+    RP(rocprim::reduce_by_key(tp, tb, B.keys2.p, B.vals2.p, (size_t)n_k, B.ukeys.p, B.ucnt.p, B.n_runs.p,
+                              rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s));
+    RP(rocprim::reduce(tp, tb, B.vals2.p, B.n_runs.p + 1, 0u, (size_t)n_k, rocprim::plus<uint32_t>(), s));
+    uint32_t h2[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h2, B.n_runs.p, 8, hipMemcpyDeviceToHost, s));
+    EV(4);
+    HIP_TRY(hipStreamSynchronize(s));
+    n_u = h2[0];
+    out.n_increments = h2[1];
+    return ISX_OK;
+}
+
+}  // namespace
 
 int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
 {
     hipStream_t s = in.stream;
     out = LinkageOut();
     const uint32_t n_sites = in.n_sites;
+    int rc;
     EV(0);
+    HIP_TRY(hipEventRecord(in.ev_mfma[0], s));
+    HIP_TRY(hipEventRecord(in.ev_mfma[1], s));
     if (n_sites == 0) { EV(1); EV(2); EV(3); EV(4); EV(5); return ISX_OK; }
     if (n_sites >= (1u << 26)) { isx_set_error("more than 2^26 SNP sites in one batch: split the batch"); return ISX_ERR_ARG; }
     if (in.M > 256) { isx_set_error("linkage supports at most 256 mm bins"); return ISX_ERR_ARG; }
+    if (in.mode == 2 && in.M != 1) { isx_set_error("the dense MFMA linkage path needs n_mm_bins == 1"); return ISX_ERR_ARG; }
 
     // ---- 1. sites by position ----
-    int rc;
     if ((rc = ensure(B.site_keys, n_sites)) || (rc = ensure(B.site_keys2, n_sites)) ||
         (rc = ensure(B.sites_sorted, n_sites)) || (rc = ensure(B.site_gpos, n_sites)) ||
         (rc = ensure(B.site_split, n_sites))) return rc;
     hipLaunchKernelGGL(k_site_keys, dim3((n_sites + 255) / 256), dim3(256), 0, s, in.sites, n_sites, B.site_keys.p);
-    size_t tb = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, B.site_keys.p, B.site_keys2.p, const_cast<isx_site *>(in.sites),
-                                      B.sites_sorted.p, n_sites, 0, 32, s));
-    if ((rc = ensure_temp(B.temp, tb))) return rc;
-    tb = B.temp.cap;
-    HIP_TRY(rocprim::radix_sort_pairs(B.temp.p, tb, B.site_keys.p, B.site_keys2.p, const_cast<isx_site *>(in.sites),
-                                      B.sites_sorted.p, n_sites, 0, 32, s));
+    RP(rocprim::radix_sort_pairs(tp, tb, B.site_keys.p, B.site_keys2.p, const_cast<isx_site *>(in.sites),
+                                 B.sites_sorted.p, n_sites, 0, 32, s));
     hipLaunchKernelGGL(k_site_split, dim3((n_sites + 255) / 256), dim3(256), 0, s, B.sites_sorted.p, n_sites,
                        in.split_bounds, in.n_splits, B.site_gpos.p, B.site_split.p);
     EV(1);
@@ -312,53 +583,12 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
                        B.ao_key.p);
     EV(2);
 
-    // ---- 3. group by pair ----
-    tb = 0;
-    const int pair_bits = bits_for(in.n_pairs ? in.n_pairs : 0xFFFFFFFFull);
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, B.ao_key.p, B.ao_key2.p, in.ao, B.ao2.p, n_ao, 0, pair_bits, s));
-    if ((rc = ensure_temp(B.temp, tb))) return rc;
-    tb = B.temp.cap;
-    HIP_TRY(rocprim::radix_sort_pairs(B.temp.p, tb, B.ao_key.p, B.ao_key2.p, in.ao, B.ao2.p, n_ao, 0, pair_bits, s));
-    EV(3);
-
-    // ---- 4. pair increments ----
-    if ((rc = ensure(B.incr_cnt, n_ao)) || (rc = ensure(B.incr_off, (size_t)n_ao + 1))) return rc;
-    hipLaunchKernelGGL(k_pair_incr<false>, dim3((n_ao + 255) / 256), dim3(256), 0, s, B.ao2.p, n_ao, B.site_split.p,
-                       B.incr_cnt.p, nullptr, nullptr);
-    tb = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.incr_cnt.p, B.incr_off.p, 0u, n_ao, rocprim::plus<uint32_t>(), s));
-    if ((rc = ensure_temp(B.temp, tb))) return rc;
-    tb = B.temp.cap;
-    HIP_TRY(rocprim::exclusive_scan(B.temp.p, tb, B.incr_cnt.p, B.incr_off.p, 0u, n_ao, rocprim::plus<uint32_t>(), s));
-    uint32_t last_off = 0, last_cnt = 0;
-    HIP_TRY(hipMemcpyAsync(&last_off, B.incr_off.p + (n_ao - 1), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&last_cnt, B.incr_cnt.p + (n_ao - 1), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const uint64_t n_inc = (uint64_t)last_off + last_cnt;
-    out.n_increments = n_inc;
-    if (n_inc == 0) { EV(4); EV(5); return ISX_OK; }
-    if (n_inc >= 0xFFFFFFFFull) { isx_set_error("more than 2^32 pair increments in one batch"); return ISX_ERR_CAPACITY; }
-    if ((rc = ensure(B.keys, n_inc)) || (rc = ensure(B.keys2, n_inc)) || (rc = ensure(B.ukeys, n_inc)) ||
-        (rc = ensure(B.ucnt, n_inc)) || (rc = ensure(B.n_runs, 2))) return rc;
-    hipLaunchKernelGGL(k_pair_incr<true>, dim3((n_ao + 255) / 256), dim3(256), 0, s, B.ao2.p, n_ao, B.site_split.p,
-                       nullptr, B.incr_off.p, B.keys.p);
-    // ---- 5. sort + run-length encode ----
-    const int site_bits = bits_for(n_sites);
-    (void)site_bits;
-    tb = 0;
-    HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, B.keys.p, B.keys2.p, (size_t)n_inc, 0, 64, s));
-    if ((rc = ensure_temp(B.temp, tb))) return rc;
-    tb = B.temp.cap;
-    HIP_TRY(rocprim::radix_sort_keys(B.temp.p, tb, B.keys.p, B.keys2.p, (size_t)n_inc, 0, 64, s));
-    tb = 0;
-    HIP_TRY(rocprim::run_length_encode(nullptr, tb, B.keys2.p, (size_t)n_inc, B.ukeys.p, B.ucnt.p, B.n_runs.p, s));
-    if ((rc = ensure_temp(B.temp, tb))) return rc;
-    tb = B.temp.cap;
-    HIP_TRY(rocprim::run_length_encode(B.temp.p, tb, B.keys2.p, (size_t)n_inc, B.ukeys.p, B.ucnt.p, B.n_runs.p, s));
+    // ---- 3-5. co-occurrence counts as sorted unique keys ----
     uint32_t n_u = 0;
-    HIP_TRY(hipMemcpyAsync(&n_u, B.n_runs.p, 4, hipMemcpyDeviceToHost, s));
-    EV(4);
-    HIP_TRY(hipStreamSynchronize(s));
+    if (in.mode == 2) rc = dense_path(in, B, out, n_ao, n_sites, n_u);
+    else rc = sparse_path(in, B, out, n_ao, n_u);
+    if (rc != ISX_OK) return rc;
+    if (n_u == 0) { if (out.n_increments == 0) { /* EV(3)/EV(4) recorded by the path */ } EV(5); return ISX_OK; }
 
     // ---- 6. LD rows ----
     if ((rc = ensure(B.rows_per, n_u)) || (rc = ensure(B.row_off, (size_t)n_u + 1))) return rc;
@@ -366,17 +596,11 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     SiteView v{B.sites_sorted.p, in.entries, in.counts, in.M == 1 ? 1 : 0};
     hipLaunchKernelGGL(k_ld_rows<false>, dim3((n_u + 255) / 256), dim3(256), 0, s, B.ukeys.p, B.ucnt.p, n_u, v,
                        in.min_snp, B.rows_per.p, nullptr, nullptr, B.n_runs.p + 1);
-    tb = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, B.rows_per.p, B.row_off.p, 0u, n_u, rocprim::plus<uint32_t>(), s));
-    if ((rc = ensure_temp(B.temp, tb))) return rc;
-    tb = B.temp.cap;
-    HIP_TRY(rocprim::exclusive_scan(B.temp.p, tb, B.rows_per.p, B.row_off.p, 0u, n_u, rocprim::plus<uint32_t>(), s));
-    uint32_t lo2 = 0, lc2 = 0, n_edges = 0;
-    HIP_TRY(hipMemcpyAsync(&lo2, B.row_off.p + (n_u - 1), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&lc2, B.rows_per.p + (n_u - 1), 4, hipMemcpyDeviceToHost, s));
+    uint64_t n_ld = 0;
+    if ((rc = scan_total(B, s, B.rows_per.p, B.row_off.p, n_u, n_ld))) return rc;
+    uint32_t n_edges = 0;
     HIP_TRY(hipMemcpyAsync(&n_edges, B.n_runs.p + 1, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t n_ld = lo2 + lc2;
     out.n_edges = n_edges;
     out.n_ld = n_ld;
     if (n_ld) {

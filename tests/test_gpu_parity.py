@@ -186,3 +186,54 @@ def test_bench_two_ranks_control_flow(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and "final_gather_ms" in j
     assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j
+
+
+@pytest.mark.parametrize("name", ["synth_m1", "synth_skipmm"])
+def test_dense_mfma_linkage_equals_reference(ctx, name):
+    """linkage_mode 2 (int8 MFMA X^T X + self pairs) vs the reference golden vectors (M == 1 cases)"""
+    from tests import prod
+    g = util.load_case(name)
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), n_mm_bins=1,
+                         linkage_mode=2, **_params(g))
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name + "-dense")
+    assert res["n_edges"] == int(g["n_edges"])
+
+
+@pytest.mark.parametrize("seed,mLen,depth,n_sites,bounds", [(201, 4000, 120, 200, None), (202, 12000, 60, 500, [0, 3000, 3001, 9000, 12000]),
+                                                            (203, 2000, 400, 300, None)])
+def test_dense_mfma_linkage_vs_sparse_and_oracle(ctx, seed, mLen, depth, n_sites, bounds):
+    """dense vs sparse path on the same batch (multi-split, self pairs, > 32 sites per split) and vs the oracle"""
+    from instrain_amd import engine
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    seq, pos, base, mm, pair = _random_split(seed, mLen, depth, 1, n_sites)
+    bounds = np.array(bounds if bounds else [0, mLen])
+    out = {}
+    for mode in (1, 2):
+        b = engine.Batch(ctx, engine.encode_seq(seq), bounds, engine.pack_obs(pos.astype(np.uint32), base, mm),
+                         pair.astype(np.uint32), n_mm_bins=1, linkage_mode=mode)
+        b.run()
+        out[mode] = (b.fetch(), b.sizes(), b.timings())
+        b.close()
+    assert out[1][0]["ld"].tobytes() == out[2][0]["ld"].tobytes()
+    for k in ("n_edges", "n_ld", "n_increments", "n_allele_obs"):
+        assert out[1][1][k] == out[2][1][k], k
+    assert out[2][2]["dense_tiles"] > 0 and out[2][2]["dense_macs"] > 0
+    exp = {"entries": [], "snv": [], "ld": []}
+    for s, e in zip(bounds[:-1], bounds[1:]):
+        r = oracle.profile_split(pos, base, mm, pair, seq[s:e], int(s), lut, fb)
+        for k in exp:
+            exp[k].append(r[k])
+    exp = {k: np.concatenate(v) for k, v in exp.items()}
+    got = prod.to_oracle_layout(out[2][0], lambda g: g.astype(np.int64))
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="dense%d" % seed)
+
+
+def test_dense_mode_needs_single_mm_bin(ctx):
+    from instrain_amd import engine
+    obs = engine.pack_obs(np.arange(8, dtype=np.uint32), np.zeros(8, np.uint8), np.zeros(8, int))
+    b = engine.Batch(ctx, engine.encode_seq("ACGTACGT"), [0, 8], obs, np.arange(8, dtype=np.uint32), n_mm_bins=2,
+                     linkage_mode=2)
+    b.run()          # no SNP sites -> nothing to refuse yet; the mode check sits behind the first site
+    b.close()
