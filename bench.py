@@ -94,27 +94,43 @@ def cpu_baseline(w, budget_s=25.0, min_s=10.0):
                       % (n_done, len(bounds) - 1, done_pos / 1e6, done_obs, dt)}
 
 
+INT8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA peak (spec, no sparsity; MI355X_MICROARCH.md: >= 4404 measured)
+
+
 def linkage_leg(ctx, seed=3):
-    """Secondary metric: SNV pairs linked / s on a C3-shaped slice (200x, 1 SNV site / 100 bp)."""
+    """Secondary metric: SNV pairs linked / s on a C3-shaped slice (200x, 1 SNV site / 100 bp), with
+    the sparse pair-increment path (default) and the dense int8-MFMA path (linkage_mode 2)."""
     from instrain_amd import engine, synth
     w = synth.make_workload(genome_len=250_000, coverage=200, n_sites=2500, seed=seed, skip_mm=True,
                             af_lo=0.2, af_hi=0.5)
-    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1, enable_linkage=True)
-    for _ in range(2):
-        b.run()
-    ts = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        b.run()
-        ts.append(time.perf_counter() - t0)
-    s, t = b.sizes(), b.timings()
-    b.close()
-    dt = float(np.median(ts))
-    return {"workload": "C3 slice: 250 kbp, 200x, 2500 SNV sites, skip_mm, linkage on",
-            "snv_pairs_linked_per_s": s["n_edges"] / dt, "edges": s["n_edges"], "ld_rows": s["n_ld"],
-            "pair_increments": s["n_increments"], "ms_per_step": dt * 1e3,
-            "kernel_ms": {k: round(v, 4) for k, v in t.items() if k.endswith("_ms")},
-            "gbp_per_s": w["profiled_bases"] / 1e9 / dt}
+    out = {"workload": "C3 slice: 250 kbp, 200x, 2500 SNV sites, skip_mm, linkage on"}
+    for mode, name in ((1, "sparse"), (2, "dense_mfma")):
+        b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1, enable_linkage=True,
+                         linkage_mode=mode)
+        for _ in range(2):
+            b.run()
+        ts, mf = [], []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            b.run()
+            ts.append(time.perf_counter() - t0)
+            mf.append(b.timings()["mfma_ms"])
+        s, t = b.sizes(), b.timings()
+        b.close()
+        dt = float(np.median(ts))
+        r = {"snv_pairs_linked_per_s": s["n_edges"] / dt, "edges": s["n_edges"], "ld_rows": s["n_ld"],
+             "pair_increments": s["n_increments"], "allele_observations": s["n_allele_obs"], "ms_per_step": dt * 1e3,
+             "kernel_ms": {k: round(v, 4) for k, v in t.items() if k.endswith("_ms")},
+             "gbp_per_s": w["profiled_bases"] / 1e9 / dt}
+        if mode == 2:
+            ms = float(np.median(mf))
+            tops = 2.0 * t["dense_macs"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            r["mfma"] = {"kernel": "k_dense_gemm (v_mfma_i32_32x32x32_i8)", "tiles": t["dense_tiles"],
+                         "int8_macs_per_pass": t["dense_macs"], "xt_bytes": t["dense_bytes"], "pass_ms": ms,
+                         "achieved_tops": tops, "peak_tops": INT8_MFMA_PEAK_TOPS, "utilisation": tops / INT8_MFMA_PEAK_TOPS}
+        out[name] = r
+    out["snv_pairs_linked_per_s"] = out["sparse"]["snv_pairs_linked_per_s"]
+    return out
 
 
 def main():

@@ -69,7 +69,7 @@ typedef struct {
     int32_t min_cov;            /* -c, default 5   (profile_utilities.py:142) */
     int32_t min_snp;            /* --min_snp, default 20 at the CLI (argumentParser.py:164) */
     double min_freq;            /* -f, default 0.05 */
-    int32_t rarefied_coverage;  /* --rarefied_coverage, default 50 */
+    int32_t rarefied_coverage;  /* --rarefied_coverage, default 50; <= 0 switches the rarefied outputs off */
     int32_t n_mm_bins;          /* mm levels 0..n_mm_bins-1 may occur; 1 = --skip_mm_profiling */
     int32_t enable_linkage;     /* 0: pileup / SNV only */
     int32_t linkage_mode;       /* 0 auto (= sparse in this version), 1 sparse pair-increment path,
@@ -101,7 +101,9 @@ typedef struct {
     uint32_t cnt[4];            /* cumulative over levels <= mm; position_coverage = sum */
 } isx_snv;
 
-/* raw_linkage_table row (linkage.py:230-237 + 67-71), random *_normalized columns excluded. */
+/* raw_linkage_table row (linkage.py:230-237 + 67-71).  The *_normalized columns are the
+ * reference's rarefied variants (linkage.py:200-228, unseeded np.random.choice there): here they
+ * are drawn from a Philox stream keyed by (seed, position_A, position_B, mm). */
 typedef struct {
     uint32_t gpos_a, gpos_b;    /* flat positions, gpos_a <= gpos_b */
     uint16_t mm;
@@ -110,6 +112,7 @@ typedef struct {
     uint32_t total, countAB, countAb, countaB, countab;
     uint32_t pad2;
     double r2, d_prime;
+    double r2_normalized, d_prime_normalized;
 } isx_ld;
 
 /* sizes of the result tables of a batch after isx_batch_run */
@@ -172,8 +175,11 @@ int isx_batch_timings(const isx_batch *b, isx_timings *out);
 
 /* Results -> caller-allocated host buffers sized from isx_batch_sizes. Tables come back in
  * canonical order: entries (gpos, mm); snv (gpos, mm); ld (gpos_a, gpos_b, mm). */
-int isx_batch_fetch_entries(isx_batch *b, isx_entry *out);
-int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts /* [n_pos][4] */, float *clon /* [n_pos] */);
+/* clon_rarefied (may be NULL): clonTR -- the rarefied clonality (snv_utilities.py:233-247) of the same
+ * (position[, mm]) rows, NaN where cumulative coverage < rarefied_coverage; Philox-seeded. */
+int isx_batch_fetch_entries(isx_batch *b, isx_entry *out, float *clon_rarefied /* [n_entries] */);
+int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts /* [n_pos][4] */, float *clon /* [n_pos] */,
+                          float *clon_rarefied /* [n_pos] */);
 int isx_batch_fetch_snv(isx_batch *b, isx_snv *out);
 int isx_batch_fetch_ld(isx_batch *b, isx_ld *out);
 

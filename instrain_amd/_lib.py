@@ -19,8 +19,8 @@ SNV_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("con_base", "u1"), ("var_bas
 LD_DT = np.dtype([("gpos_a", "<u4"), ("gpos_b", "<u4"), ("mm", "<u2"), ("allele_A", "u1"), ("allele_a", "u1"),
                   ("allele_B", "u1"), ("allele_b", "u1"), ("pad", "<u2"), ("total", "<u4"), ("countAB", "<u4"),
                   ("countAb", "<u4"), ("countaB", "<u4"), ("countab", "<u4"), ("pad2", "<u4"),
-                  ("r2", "<f8"), ("d_prime", "<f8")])
-assert OBS_DT.itemsize == 8 and ENTRY_DT.itemsize == 28 and SNV_DT.itemsize == 28 and LD_DT.itemsize == 56
+                  ("r2", "<f8"), ("d_prime", "<f8"), ("r2_normalized", "<f8"), ("d_prime_normalized", "<f8")])
+assert OBS_DT.itemsize == 8 and ENTRY_DT.itemsize == 28 and SNV_DT.itemsize == 28 and LD_DT.itemsize == 72
 
 
 class Params(C.Structure):
@@ -90,9 +90,10 @@ def load():
     lib.isx_batch_run.argtypes = [vp]
     lib.isx_batch_sizes.argtypes = [vp, C.POINTER(Sizes)]
     lib.isx_batch_timings.argtypes = [vp, C.POINTER(Timings)]
-    for f in ("isx_batch_fetch_entries", "isx_batch_fetch_snv", "isx_batch_fetch_ld"):
+    for f in ("isx_batch_fetch_snv", "isx_batch_fetch_ld"):
         getattr(lib, f).argtypes = [vp, vp]
-    lib.isx_batch_fetch_dense.argtypes = [vp, vp, vp]
+    lib.isx_batch_fetch_entries.argtypes = [vp, vp, vp]
+    lib.isx_batch_fetch_dense.argtypes = [vp, vp, vp, vp]
     lib.isx_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.isx_bam_close.argtypes = [vp]
     lib.isx_bam_close.restype = None

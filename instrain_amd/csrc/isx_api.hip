@@ -43,6 +43,7 @@ struct isx_batch {
     int64_t *d_bounds = nullptr;
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
+    float *d_clon_r = nullptr;       // rarefied clonality (dense: [n_pos]; mm: [cap_entries])
     isx_entry *d_entries = nullptr;
     isx_snv *d_snv = nullptr;
     isx_site *d_sites = nullptr;
@@ -166,7 +167,7 @@ void isx_batch_destroy(isx_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_rec, b->d_pair, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_entries,
+    void *ps[] = {b->d_rec, b->d_pair, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
@@ -253,6 +254,11 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     } else {
         b->cap_entries = (size_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)n_obs, 1), npm);
         BH(hipMalloc(&b->d_entries, b->cap_entries * sizeof(isx_entry)));
+    }
+    {   // rarefied clonality: NaN where not produced (dense positions are the same every run)
+        const size_t n = b->M == 1 ? (size_t)n_pos : b->cap_entries;
+        BH(hipMalloc(&b->d_clon_r, n * sizeof(float)));
+        BH(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, n, c->stream));
     }
     b->cap_snv = (size_t)std::min<uint64_t>(npm, std::max<uint64_t>((uint64_t)n_pos / 2, 1u << 20));
     b->cap_sites = (size_t)std::min<uint64_t>((uint64_t)n_pos, std::max<uint64_t>((uint64_t)n_pos / 4, 1u << 20));
@@ -347,7 +353,11 @@ int isx_batch_run(isx_batch *b)
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
     if (const char *e = getenv("ISX_DEBUG_MODE")) a.debug_mode = atoi(e);     // ablation only
-    a.counts = b->d_counts; a.clon = b->d_clon;
+    a.counts = b->d_counts; a.clon = b->d_clon; a.clon_r = b->d_clon_r;
+    a.min_cov_r = b->prm.rarefied_coverage;
+    a.seed_lo = (uint32_t)b->prm.seed; a.seed_hi = (uint32_t)(b->prm.seed >> 32);
+    if (b->M > 1 && a.min_cov_r > 0)        // entry slots move between runs (atomic cursor): reset the whole table
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, b->cap_entries, s));
     a.entries = b->d_entries; a.cap_entries = (uint32_t)std::min<size_t>(b->cap_entries, 0xFFFFFFFFu);
     a.snv = b->d_snv; a.cap_snv = (uint32_t)std::min<size_t>(b->cap_snv, 0xFFFFFFFFu);
     a.sites = b->d_sites; a.cap_sites = (uint32_t)std::min<size_t>(b->cap_sites, 0xFFFFFFFFu);
@@ -382,6 +392,7 @@ int isx_batch_run(isx_batch *b)
         LinkageIn in{};
         in.stream = s; in.ev = &b->ev[2]; in.ev_mfma = &b->ev[8];
         in.mode = b->prm.linkage_mode == 2 ? 2 : 1;
+        in.philox = Philox{(uint32_t)b->prm.seed, (uint32_t)(b->prm.seed >> 32)};
         in.n_pairs = b->n_pairs; in.ao = b->d_ao; in.n_ao = cur[CUR_AO];
         in.sites = b->d_sites; in.n_sites = cur[CUR_SITES];
         in.entries = b->d_entries; in.counts = b->d_counts;
@@ -431,25 +442,35 @@ int isx_batch_timings(const isx_batch *b, isx_timings *out)
     if (!(b)->ran) { isx_set_error("fetch: run the batch first"); return ISX_ERR_STATE; }        \
     HIP_TRY(hipSetDevice((b)->ctx->device));
 
-int isx_batch_fetch_entries(isx_batch *b, isx_entry *out)
+int isx_batch_fetch_entries(isx_batch *b, isx_entry *out, float *clon_rarefied)
 {
     NEED_RUN(b, out);
     if (b->M == 1) { isx_set_error("n_mm_bins == 1: use isx_batch_fetch_dense"); return ISX_ERR_STATE; }
     const size_t n = (size_t)b->sizes.n_entries;
     if (!n) return ISX_OK;
-    HIP_TRY(hipMemcpy(out, b->d_entries, n * sizeof(isx_entry), hipMemcpyDeviceToHost));
-    std::sort(out, out + n, [](const isx_entry &x, const isx_entry &y) {
-        return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm;
+    std::vector<isx_entry> raw(n);
+    std::vector<float> rawr(clon_rarefied ? n : 0);
+    HIP_TRY(hipMemcpy(raw.data(), b->d_entries, n * sizeof(isx_entry), hipMemcpyDeviceToHost));
+    if (clon_rarefied) HIP_TRY(hipMemcpy(rawr.data(), b->d_clon_r, n * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> perm(n);
+    for (size_t i = 0; i < n; i++) perm[i] = (uint32_t)i;
+    std::sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) {
+        return raw[x].gpos != raw[y].gpos ? raw[x].gpos < raw[y].gpos : raw[x].mm < raw[y].mm;
     });
+    for (size_t i = 0; i < n; i++) {
+        out[i] = raw[perm[i]];
+        if (clon_rarefied) clon_rarefied[i] = rawr[perm[i]];
+    }
     return ISX_OK;
 }
 
-int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts, float *clon)
+int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts, float *clon, float *clon_rarefied)
 {
     NEED_RUN(b, counts);
     if (b->M != 1) { isx_set_error("n_mm_bins > 1: use isx_batch_fetch_entries"); return ISX_ERR_STATE; }
     HIP_TRY(hipMemcpy(counts, b->d_counts, (size_t)b->n_pos * sizeof(uint4), hipMemcpyDeviceToHost));
     if (clon) HIP_TRY(hipMemcpy(clon, b->d_clon, (size_t)b->n_pos * sizeof(float), hipMemcpyDeviceToHost));
+    if (clon_rarefied) HIP_TRY(hipMemcpy(clon_rarefied, b->d_clon_r, (size_t)b->n_pos * sizeof(float), hipMemcpyDeviceToHost));
     return ISX_OK;
 }
 

@@ -54,6 +54,53 @@ struct isx_ao {
     uint8_t pad;
 };
 
+// Philox4x32-10 counter-based generator (Salmon et al., SC'11): the reference's two unseeded-random
+// outputs (np.random.choice in snv_utilities.py:242 and linkage.py:200) are produced here from
+// (seed, position, mm level, draw index) so that a run is reproducible and order-independent.
+struct Philox {
+    uint32_t k0, k1;
+    __host__ __device__ static inline void mulhilo(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo)
+    {
+        const uint64_t p = (uint64_t)a * b;
+        hi = (uint32_t)(p >> 32); lo = (uint32_t)p;
+    }
+    __host__ __device__ inline void operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out) const
+    {
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            uint32_t h0, l0, h1, l1;
+            mulhilo(0xD2511F53u, c0, h0, l0);
+            mulhilo(0xCD9E8D57u, c2, h1, l1);
+            const uint32_t n0 = h1 ^ c1 ^ a, n1 = l1, n2 = h0 ^ c3 ^ b, n3 = l0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    }
+};
+
+// np.random.choice(4, n_draws, p=w/sum(w)) as numpy does it: cdf = cumsum(p) / cdf[-1], uniform
+// draws, searchsorted(side='right'); returns the counts of the 4 categories.
+__host__ __device__ inline void rarefy4(const Philox &ph, uint32_t c0, uint32_t c1, uint32_t domain, const double *p,
+                                        int n_draws, uint32_t *rc)
+{
+    double cdf[4];
+    cdf[0] = p[0]; cdf[1] = cdf[0] + p[1]; cdf[2] = cdf[1] + p[2]; cdf[3] = cdf[2] + p[3];
+    const double tot = cdf[3];
+    cdf[0] /= tot; cdf[1] /= tot; cdf[2] /= tot; cdf[3] /= tot;
+    rc[0] = rc[1] = rc[2] = rc[3] = 0;
+    for (int d = 0; d < n_draws; d += 4) {
+        uint32_t r[4];
+        ph(c0, c1, (uint32_t)(d >> 2), domain, r);
+        for (int j = 0; j < 4 && d + j < n_draws; j++) {
+            const double u = (double)r[j] * (1.0 / 4294967296.0);
+            const int idx = (u >= cdf[0]) + (u >= cdf[1]) + (u >= cdf[2]);
+            rc[0] += idx == 0; rc[1] += idx == 1; rc[2] += idx == 2; rc[3] += idx == 3;
+        }
+    }
+}
+
 struct PileupArgs {
     const uint2 *rec;           // packed isx_obs, padded to a multiple of ISX_CHUNK with sentinels
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK)
@@ -71,6 +118,9 @@ struct PileupArgs {
     // outputs
     uint4 *counts;              // dense path (M == 1): [n_pos]
     float *clon;                // dense path: [n_pos]
+    float *clon_r;              // rarefied clonality: dense [n_pos] / mm path [cap_entries]; pre-filled with NaN
+    int32_t min_cov_r;          // rarefied_coverage; <= 0 disables the rarefied output
+    uint32_t seed_lo, seed_hi;
     isx_entry *entries;         // mm path
     uint32_t cap_entries;
     isx_snv *snv;

@@ -51,6 +51,7 @@ struct LinkageIn {
     int M;
     int min_snp;
     int mode;                   // 1 sparse, 2 dense MFMA (n_mm_bins == 1)
+    Philox philox;              // stream of the rarefied LD columns
 };
 
 struct LinkageOut {

@@ -155,7 +155,7 @@ __device__ __forceinline__ void major_minor(const uint32_t *c, int &maj, int &mn
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_ld_rows(const uint64_t *ukeys, const uint32_t *ucnt, uint32_t n_u,
                                                  SiteView v, int min_snp, uint32_t *rows_per, const uint32_t *row_off,
-                                                 isx_ld *out, uint32_t *n_edges)
+                                                 isx_ld *out, uint32_t *n_edges, Philox ph)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n_u) return;
@@ -239,6 +239,30 @@ __global__ void __launch_bounds__(256) k_ld_rows(const uint64_t *ukeys, const ui
             r.total = total; r.countAB = AB; r.countAb = Ab; r.countaB = aB; r.countab = ab;
             r.pad2 = 0;
             r.r2 = r2; r.d_prime = dp;
+            // rarefied variants (linkage.py:200-228): min_snp draws from [fAB, fAb, faB, fab]
+            r.r2_normalized = __builtin_nan(""); r.d_prime_normalized = __builtin_nan("");
+            if (min_snp > 0) {
+                const double p4[4] = {fAB, fAb, faB, fab};
+                uint32_t rc[4];
+                rarefy4(ph, r.gpos_a, r.gpos_b, 0x4C440000u /* 'LD' */ | mm, p4, min_snp, rc);
+                const double n = (double)min_snp;
+                const double gAB = (double)rc[0] / n, gAb = (double)rc[1] / n, gaB = (double)rc[2] / n, gab = (double)rc[3] / n;
+                const double gA = gAB + gAb, ga = gab + gaB, gB = gAB + gaB, gb = gab + gAb;
+                const double ln = gab - ga * gb;
+                if (!(ga == 0 || gA == 0 || gB == 0 || gb == 0)) {
+                    double den = gA * ga;
+                    den = den * gB;
+                    den = den * gb;
+                    r.r2_normalized = ln * ln / den;
+                }
+                if (ln < 0) {
+                    const double d1 = (-gA) * gB, d2 = (-ga) * gb;
+                    r.d_prime_normalized = ln / (d1 > d2 ? d1 : d2);
+                } else if (ln > 0) {
+                    const double d1 = gA * gb, d2 = ga * gB;
+                    r.d_prime_normalized = ln / (d2 < d1 ? d2 : d1);
+                }
+            }
             out[o + rows] = r;
         }
         rows++;
@@ -595,7 +619,7 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     HIP_TRY(hipMemsetAsync(B.n_runs.p + 1, 0, 4, s));
     SiteView v{B.sites_sorted.p, in.entries, in.counts, in.M == 1 ? 1 : 0};
     hipLaunchKernelGGL(k_ld_rows<false>, dim3((n_u + 255) / 256), dim3(256), 0, s, B.ukeys.p, B.ucnt.p, n_u, v,
-                       in.min_snp, B.rows_per.p, nullptr, nullptr, B.n_runs.p + 1);
+                       in.min_snp, B.rows_per.p, nullptr, nullptr, B.n_runs.p + 1, in.philox);
     uint64_t n_ld = 0;
     if ((rc = scan_total(B, s, B.rows_per.p, B.row_off.p, n_u, n_ld))) return rc;
     uint32_t n_edges = 0;
@@ -606,7 +630,7 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     if (n_ld) {
         if ((rc = ensure(B.ld, n_ld))) return rc;
         hipLaunchKernelGGL(k_ld_rows<true>, dim3((n_u + 255) / 256), dim3(256), 0, s, B.ukeys.p, B.ucnt.p, n_u, v,
-                           in.min_snp, nullptr, B.row_off.p, B.ld.p, nullptr);
+                           in.min_snp, nullptr, B.row_off.p, B.ld.p, nullptr, in.philox);
     }
     EV(5);
     return ISX_OK;

@@ -144,6 +144,17 @@ __device__ __forceinline__ SiteCall call_level(const PileupArgs &a, const uint16
     return r;
 }
 
+// calculate_rarefied_clonality (snv_utilities.py:233-247) with a counter-based generator
+__device__ __forceinline__ float rarefied_clonality(const PileupArgs &a, const uint32_t *c, uint32_t gpos, uint32_t mm)
+{
+    const double s = (double)(c[0] + c[1] + c[2] + c[3]);
+    const double p[4] = {(double)c[0] / s, (double)c[1] / s, (double)c[2] / s, (double)c[3] / s};
+    uint32_t rc[4];
+    const Philox ph{a.seed_lo, a.seed_hi};
+    rarefy4(ph, gpos, mm, 0x434C4F4Eu /* 'CLON' */, p, a.min_cov_r, rc);
+    return (float)clonality(rc, rc[0] + rc[1] + rc[2] + rc[3]);
+}
+
 __device__ __forceinline__ uint32_t masked_sum(const uint32_t *c, uint32_t mask)
 {
     uint32_t s = 0;
@@ -295,6 +306,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
                 if (mx == total) cl = 1.0f; else defer = true;
                 uint32_t entry = (uint32_t)p;
                 if (defer) entry |= 1u << 13;
+                if (a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r) entry |= 1u << 15;
                 if (sc.snp != -1) {
                     entry |= 1u << 14;
                     atomicAdd(&scratch[S_ROWS], 1u);
@@ -319,10 +331,11 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         // ---- deferred clonalities (snv_utilities.py:225-231), densely packed ----
         for (uint32_t q = tid; q < nq; q += nthr) {
             const uint32_t e = queue[q];
-            if (!(e & (1u << 13))) continue;
+            if (!(e & ((1u << 13) | (1u << 15)))) continue;
             const int p = (int)(e & 0x1FFFu);
             const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
-            a.clon[w0 + p] = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+            if (e & (1u << 13)) a.clon[w0 + p] = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+            if (e & (1u << 15)) a.clon_r[w0 + p] = rarefied_clonality(a, c, w0 + p, 0);
         }
         if (nrows) __syncthreads();             // uniform: scratch bases from the atomics above
         // ---- SNV rows / SNP sites (snv_utilities.py:107-133) ----
@@ -483,17 +496,21 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                 const SiteCall sc = call_level(a, nullptr, cum, total, ref_base, emit);
                 if (!emit) {
                     float cl = __builtin_nanf("");
+                    const bool want_r = a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r;
+                    bool want_c = false;
                     if ((int64_t)total >= (int64_t)a.min_cov) {
                         const uint32_t mx = max(max(cum[0], cum[1]), max(cum[2], cum[3]));
                         if (mx == total) cl = 1.0f;                 // (s/s)^2 + 0 + 0 + 0
-                        else {
-                            const uint32_t slot = atomicAdd(&scratch[S_NQ], 1u);
-                            if (slot < QCAP) {
-                                queue[slot * 2 + 0] = e_off;
-                                queue[slot * 2 + 1] = ((uint32_t)m << 16) | (uint32_t)p;
-                            } else {
-                                cl = (float)clonality(cum, total);  // queue full: inline
-                            }
+                        else want_c = true;
+                    }
+                    if (want_c || want_r) {
+                        const uint32_t slot = atomicAdd(&scratch[S_NQ], 1u);
+                        if (slot < QCAP) {
+                            queue[slot * 2 + 0] = e_off;
+                            queue[slot * 2 + 1] = ((uint32_t)m << 16) | (uint32_t)p | (want_c ? 1u << 30 : 0u) | (want_r ? 1u << 31 : 0u);
+                        } else {                                    // queue full: inline
+                            if (want_c) cl = (float)clonality(cum, total);
+                            if (want_r) a.clon_r[e_off] = rarefied_clonality(a, cum, gpos, (uint32_t)m);
                         }
                     }
                     isx_entry e;
@@ -554,13 +571,14 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
     if (tid == 0 && nao) scratch[S_AO_BASE] = atomicAdd(&a.cursors[CUR_AO], nao);
     for (uint32_t q = tid; q < nq; q += nthr) {
         const uint32_t pm = queue[q * 2 + 1];
-        const int p = (int)(pm & 0xFFFFu), mq = (int)(pm >> 16);
+        const int p = (int)(pm & 0xFFFFu), mq = (int)((pm >> 16) & 0x3FFFu);
         uint32_t c[4] = {0, 0, 0, 0};
         for (int m = 0; m <= mq; m++) {                 // mm_counts_to_counts(MMcounts, mm)
 #pragma unroll
             for (int k = 0; k < 4; k++) c[k] += cnt[(m * 4 + k) * W + p];
         }
-        a.entries[queue[q * 2]].clon = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+        if (pm & (1u << 30)) a.entries[queue[q * 2]].clon = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+        if (pm & (1u << 31)) a.clon_r[queue[q * 2]] = rarefied_clonality(a, c, w0 + p, (uint32_t)mq);
     }
     if (!linkage || !nao) return;               // uniform
     __syncthreads();

@@ -98,12 +98,15 @@ class Batch:
         if self.n_mm_bins == 1:
             counts = np.empty((self.n_pos, 4), dtype=np.uint32)
             clon = np.empty(self.n_pos, dtype=np.float32)
-            check(self.lib.isx_batch_fetch_dense(self.h, counts.ctypes.data, clon.ctypes.data))
-            out["counts"], out["clon"] = counts, clon
+            clon_r = np.empty(self.n_pos, dtype=np.float32)
+            check(self.lib.isx_batch_fetch_dense(self.h, counts.ctypes.data, clon.ctypes.data, clon_r.ctypes.data))
+            out["counts"], out["clon"], out["clon_r"] = counts, clon, clon_r
         else:
             e = np.empty(max(1, s["n_entries"]), dtype=ENTRY_DT)
-            check(self.lib.isx_batch_fetch_entries(self.h, e.ctypes.data))
+            cr = np.empty(max(1, s["n_entries"]), dtype=np.float32)
+            check(self.lib.isx_batch_fetch_entries(self.h, e.ctypes.data, cr.ctypes.data))
             out["entries"] = e[:s["n_entries"]]
+            out["clon_r"] = cr[:s["n_entries"]]
         v = np.empty(max(1, s["n_snv"]), dtype=SNV_DT)
         check(self.lib.isx_batch_fetch_snv(self.h, v.ctypes.data))
         out["snv"] = v[:s["n_snv"]]

@@ -44,8 +44,10 @@ def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_o
     """Batch result (engine.Batch.fetch()) -> list of SplitObject, one per split, in split order."""
     if "entries" in res:
         e = res["entries"]
+        clon_r = res["clon_r"]
     else:
         e = engine.dense_to_entries(res["counts"], res["clon"])
+        clon_r = res["clon_r"][e["gpos"]]
     snv, ld = res["snv"], res["ld"]
     n = len(split_bounds) - 1
     e_cut = np.searchsorted(e["gpos"], split_bounds)
@@ -68,7 +70,9 @@ def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_o
         S.covT = _series_by_mm(pos[k], ee["mm"][k], lvl[k], "int32")
         k = ~np.isnan(ee["clon"])
         S.clonT = _series_by_mm(pos[k], ee["mm"][k], ee["clon"][k], "float32")
-        S.clonTR = {}       # rarefied clonality is unseeded-random in the reference; not produced yet
+        rr = clon_r[e_cut[i]:e_cut[i + 1]]      # rarefied clonality: random in the reference, Philox-seeded here
+        k = ~np.isnan(rr)
+        S.clonTR = _series_by_mm(pos[k], ee["mm"][k], rr[k], "float32")
         ss = snv[s_cut[i]:s_cut[i + 1]]
         S.raw_snp_table = pd.DataFrame({
             'scaffold': scaff, 'position': ss["gpos"].astype(np.int64) - off, 'ref_base': BASES[ss["ref_base"]],
@@ -83,7 +87,8 @@ def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_o
             pa = ll["gpos_a"].astype(np.int64) - off
             pb = ll["gpos_b"].astype(np.int64) - off
             S.raw_linkage_table = pd.DataFrame({
-                'r2': ll["r2"], 'd_prime': ll["d_prime"], 'r2_normalized': np.nan, 'd_prime_normalized': np.nan,
+                'r2': ll["r2"], 'd_prime': ll["d_prime"], 'r2_normalized': ll["r2_normalized"],
+                'd_prime_normalized': ll["d_prime_normalized"],
                 'total': ll["total"].astype(np.int64), 'countAB': ll["countAB"].astype(np.int64),
                 'countAb': ll["countAb"].astype(np.int64), 'countaB': ll["countaB"].astype(np.int64),
                 'countab': ll["countab"].astype(np.int64), 'allele_A': BASES[ll["allele_A"]],
@@ -122,7 +127,8 @@ def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, 
     bounds.append(off)
     ref = np.concatenate([engine.encode_seq(s) for s in sequences])
     b = engine.Batch(ctx, ref, bounds, obs, pair, min_cov=min_cov, min_freq=min_freq, min_snp=min_snp,
-                     n_mm_bins=n_mm_bins, enable_linkage=True)
+                     rarefied_coverage=int(kwargs.get('rarefied_coverage', 5)), n_mm_bins=n_mm_bins,
+                     enable_linkage=True, seed=int(kwargs.get('seed', 0)))
     try:
         b.run()
         res = b.fetch()
