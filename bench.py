@@ -26,10 +26,20 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
-def c2_workload(seed, scale=1.0):
+def c2_workload(seed, scale=1.0, with_mm=False):
+    """C2 of SURVEY 8(d). One generation serves both runs: `obs` has mm = 0 (the headline
+    --skip_mm_profiling run), `obs_mm` (with_mm) carries the pairs' mismatch counts (mm profiling on)."""
     from instrain_amd import synth
-    return synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale),
-                               seed=seed, skip_mm=True)
+    w = synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale),
+                            seed=seed, skip_mm=not with_mm)
+    if with_mm:
+        w["obs_mm"] = w["obs"]
+        w["n_mm_bins_mm"] = w["n_mm_bins"]
+        o = w["obs"].copy()
+        o["mm"] = 0
+        w["obs"] = o
+        w["n_mm_bins"] = 1
+    return w
 
 
 def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense):
@@ -101,9 +111,10 @@ def linkage_leg(ctx, seed=3):
     """Secondary metric: SNV pairs linked / s on a C3-shaped slice (200x, 1 SNV site / 100 bp), with
     the sparse pair-increment path (default) and the dense int8-MFMA path (linkage_mode 2)."""
     from instrain_amd import engine, synth
-    w = synth.make_workload(genome_len=250_000, coverage=200, n_sites=2500, seed=seed, skip_mm=True,
+    w = synth.make_workload(genome_len=1_000_000, coverage=200, n_sites=10_000, seed=seed, skip_mm=True,
                             af_lo=0.2, af_hi=0.5)
-    out = {"workload": "C3 slice: 250 kbp, 200x, 2500 SNV sites, skip_mm, linkage on"}
+    out = {"workload": "C3 slice: 1 Mbp of the 5 Mbp genome, 200x, 10000 SNV sites (1 / 100 bp), skip_mm, linkage on",
+           "kept_observations": int(w["n_obs"]), "read_pairs": int(w["n_pairs"])}
     for mode, name in ((1, "sparse"), (2, "dense_mfma")):
         b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1, enable_linkage=True,
                          linkage_mode=mode)
@@ -133,6 +144,31 @@ def linkage_leg(ctx, seed=3):
     return out
 
 
+def mm_leg(ctx, w, steps=10):
+    """C2 again with mm profiling ON (the reference's default): k_pileup_mm, sparse (pos, mm) entries."""
+    from instrain_amd import engine
+    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs_mm"], None, n_mm_bins=w["n_mm_bins_mm"],
+                     enable_linkage=False)
+    for _ in range(3):
+        b.run()
+    ts, ks = [], []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        b.run()
+        ts.append(time.perf_counter() - t0)
+        ks.append(b.timings()["pileup_ms"])
+    s, t = b.sizes(), b.timings()
+    b.close()
+    dt, k = float(np.median(ts)), float(np.mean(ks))
+    ab = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], s["n_entries"], dense=False)
+    return {"workload": "C2 with mm profiling on (%d mm bins)" % w["n_mm_bins_mm"], "gbp_per_s": w["profiled_bases"] / 1e9 / dt,
+            "ms_per_step": dt * 1e3, "entries": s["n_entries"], "snv_rows": s["n_snv"],
+            "roofline": {"bound": "hbm", "kernel": "k_pileup_mm", "achieved": ab / (k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ab / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
+                         "kernel_ms_avg": k, "blocks": t["pileup_blocks"], "threads": t["pileup_threads"],
+                         "lds_bytes": t["pileup_lds_bytes"], "window": t["pileup_window"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +177,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the C2 genome (debug only; reported in config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-linkage-leg", action="store_true")
+    ap.add_argument("--no-mm-leg", action="store_true")
     ap.add_argument("--window", type=int, default=0)
     args = ap.parse_args()
 
@@ -162,7 +199,8 @@ def main():
     lut, fb = util.load_lut()
     ctx.set_null_model(lut, fb)
 
-    w = c2_workload(seed=2 + rank, scale=args.scale)
+    want_mm = world == 1 and not args.no_mm_leg
+    w = c2_workload(seed=2 + rank, scale=args.scale, with_mm=want_mm)
     batch = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], None, n_mm_bins=1,
                          enable_linkage=False, window=args.window)
 
@@ -239,6 +277,8 @@ def main():
         }
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
+        if want_mm:
+            out["mm_on"] = mm_leg(ctx, w)
         if world == 1 and not args.no_linkage_leg:
             out["linkage"] = linkage_leg(ctx)
         if world == 1 and not args.no_cpu_baseline:

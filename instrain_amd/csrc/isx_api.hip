@@ -31,7 +31,7 @@ struct isx_batch {
     uint64_t n_rec = 0;         // padded
     uint64_t n_pairs = 0;
     int32_t n_splits = 0;
-    int W = 0, logW = 0, M = 1, n_win = 0, block = 512, grid_dense = 0;
+    int W = 0, logW = 0, M = 1, n_win = 0, block = 1024, grid = 0, packed = 0;
     size_t lds = 0;
     // device
     uint2 *d_rec = nullptr;
@@ -39,7 +39,7 @@ struct isx_batch {
     uint8_t *d_ref = nullptr;
     uint2 *d_win = nullptr;
     uint16_t *d_thr = nullptr;
-    int qcap = 1024;
+    int qcap = 1024, rqcap = 0;
     int64_t *d_bounds = nullptr;
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
@@ -197,38 +197,25 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     isx_batch *b = new isx_batch();
     b->ctx = c; b->prm = *prm; b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits;
     b->M = prm->n_mm_bins;
-    int W = prm->window;
     const bool dense = b->M == 1;
-    b->block = dense ? 1024 : 512;
+    b->block = 1024;
     if (const char *e = getenv("ISX_BLOCK")) b->block = atoi(e);       // tuning only
     if (b->block < 64 || b->block > 1024 || (b->block & 63)) { delete b; isx_set_error("ISX_BLOCK must be a multiple of 64 in [64, 1024]"); return ISX_ERR_ARG; }
-    if (W <= 0) {
+    if (prm->window && (prm->window < 64 || (prm->window & 63) || prm->window > 8192)) { delete b; isx_set_error("window must be a multiple of 64 in [64, 8192]"); return ISX_ERR_ARG; }
+    // window size: explicit, or (dense) 2560 measured best on MI355X for batches that fill the chip
+    // (tools/tune_pileup.py), smaller for small batches so every CU still owns >= 2 windows; (mm) the
+    // largest multiple of 64 whose counters fit the LDS of ONE resident 1024-lane workgroup per CU (the
+    // mm kernel needs > 64 VGPRs, so two would not be resident anyway), at most 2 positions per lane
+    auto window_for = [&](bool packed) -> int {
+        if (prm->window > 0) return prm->window;
         if (dense) {
-            // 2560 measured best on MI355X for batches that fill the chip (tools/tune_pileup.py);
-            // small batches get smaller windows so that every CU still owns >= 2 of them
-            int64_t w = (n_pos / 1024 + 63) / 64 * 64;
-            W = (int)std::min<int64_t>(2560, std::max<int64_t>(512, w));
+            const int64_t w = (n_pos / 1024 + 63) / 64 * 64;
+            return (int)std::min<int64_t>(2560, std::max<int64_t>(512, w));
         }
-        else {
-            // largest window whose counters fit half of the 160 KiB LDS (2 workgroups per CU)
-            const int bytes_per_pos = b->M * 16 + ((b->M + 31) / 32) * 4 + 5;
-            int wmax = ((78 * 1024 - 8 * b->qcap - 2048) / bytes_per_pos) / 64 * 64;
-            W = std::min(std::max(wmax, 64), 4096);
-        }
-    }
-    if (W < 64 || (W & 63) || W > 8192) { delete b; isx_set_error("window must be a multiple of 64 in [64, 8192]"); return ISX_ERR_ARG; }
-    b->W = W;
-    b->logW = 0;
-    b->lds = pileup_lds_bytes(W, b->M, b->qcap, prm->enable_linkage);
-    if (b->lds > 160 * 1024) { delete b; isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
-    b->n_win = (int)((n_pos + W - 1) / W);
-    {   // persistent dense kernel: as many workgroups as stay resident on the 256 CUs
-        const int per_cu = std::max(1, std::min((int)(160 * 1024 / b->lds), 2048 / b->block));
-        int g = 256 * per_cu;
-        if (const char *e = getenv("ISX_GRID")) g = atoi(e);            // tuning only
-        g = std::min(g, b->n_win);
-        b->grid_dense = std::max(8, (g + 7) / 8 * 8);
-    }
+        const int bytes_per_pos = b->M * (packed ? 8 : 16) + ((b->M + 31) / 32) * 4 + 5;
+        const int wmax = ((150 * 1024 - 8 * b->qcap - 8192 - 2048 - 256) / bytes_per_pos) / 64 * 64;
+        return std::min(std::max(wmax, 64), 2 * b->block);
+    };
     b->n_rec = std::max<uint64_t>(ISX_PAD, ((uint64_t)n_obs + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
     if (b->n_rec >= 0xFFFFFFFFull) { delete b; isx_set_error("more than 2^32 observations in one batch"); return ISX_ERR_ARG; }
 
@@ -237,7 +224,6 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     for (auto &e : b->ev) BH(hipEventCreate(&e));
     BH(hipMalloc(&b->d_rec, b->n_rec * sizeof(uint2)));
     BH(hipMalloc(&b->d_ref, (size_t)n_pos));
-    BH(hipMalloc(&b->d_win, (size_t)b->n_win * sizeof(uint2)));
     BH(hipMalloc(&b->d_bounds, (size_t)(n_splits + 1) * sizeof(int64_t)));
     BH(hipMalloc(&b->d_cursors, (CUR_N + 4) * sizeof(uint32_t)));
     b->d_flags = b->d_cursors + CUR_N;
@@ -312,15 +298,43 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
         for (uint64_t i = 0; i < n_chunks; i++) { if (cany[i]) run = std::max(run, cmax[i]); pmax[i] = run; }
         run = 0xFFFFFFFFu;
         for (uint64_t i = n_chunks; i-- > 0;) { if (cany[i]) run = std::min(run, cmin[i]); smin[i] = run; }
-        std::vector<uint2> win((size_t)b->n_win);
-        uint64_t lo = 0, hi = 0;
-        for (int w = 0; w < b->n_win; w++) {
-            const uint64_t w0 = (uint64_t)w * W, w1 = w0 + W;
-            while (lo < n_chunks && (uint64_t)pmax[lo] < w0) lo++;       // chunks before lo: every gpos < w0
-            if (hi < lo) hi = lo;
-            while (hi < n_chunks && (uint64_t)smin[hi] < w1) hi++;       // chunks from hi on: every gpos >= w1
-            win[(size_t)w] = make_uint2((uint32_t)(lo * ISX_CHUNK), (uint32_t)(hi * ISX_CHUNK));
+        std::vector<uint2> win;
+        auto build = [&](int W) -> uint64_t {           // returns the longest record range of a window
+            const int n_win = (int)((n_pos + W - 1) / W);
+            win.assign((size_t)n_win, make_uint2(0, 0));
+            uint64_t lo = 0, hi = 0, longest = 0;
+            for (int w = 0; w < n_win; w++) {
+                const uint64_t w0 = (uint64_t)w * W, w1 = w0 + W;
+                while (lo < n_chunks && (uint64_t)pmax[lo] < w0) lo++;       // chunks before lo: every gpos < w0
+                if (hi < lo) hi = lo;
+                while (hi < n_chunks && (uint64_t)smin[hi] < w1) hi++;       // chunks from hi on: every gpos >= w1
+                win[(size_t)w] = make_uint2((uint32_t)(lo * ISX_CHUNK), (uint32_t)(hi * ISX_CHUNK));
+                longest = std::max(longest, (hi - lo) * ISX_CHUNK);
+            }
+            return longest;
+        };
+        b->packed = 0;
+        int W = window_for(false);
+        if (!dense) {
+            // u16-packed counters are legal when no window streams >= 65536 records
+            const int Wp = window_for(true);
+            if (getenv("ISX_NO_PACKED") == nullptr && build(Wp) < 65536) { b->packed = 1; W = Wp; }
         }
+        if (!b->packed) build(W);
+        if (!dense && W > 2 * b->block) { isx_batch_destroy(b); isx_set_error("mm path: window must be <= 2 x block"); return ISX_ERR_ARG; }
+        b->W = W;
+        b->rqcap = dense ? 0 : std::min(W, 512);     // positions with SNV rows per window (overflow: per-position atomics)
+        b->lds = pileup_lds_bytes(W, b->M, b->qcap, b->rqcap, prm->enable_linkage, b->packed);
+        if (b->lds > 160 * 1024) { isx_batch_destroy(b); isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
+        b->n_win = (int)win.size();
+        {   // persistent kernels: as many workgroups as stay resident on the 256 CUs
+            const int per_cu = std::max(1, std::min((int)(160 * 1024 / b->lds), 2048 / b->block));
+            int g = 256 * per_cu;
+            if (const char *e = getenv("ISX_GRID")) g = atoi(e);            // tuning only
+            g = std::min(g, b->n_win);
+            b->grid = std::max(8, (g + 7) / 8 * 8);
+        }
+        BH(hipMalloc(&b->d_win, win.size() * sizeof(uint2)));
         BH(hipMemcpyAsync(b->d_win, win.data(), win.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
         BH(hipMemcpyAsync(b->d_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
         BH(hipStreamSynchronize(c->stream));
@@ -349,7 +363,7 @@ int isx_batch_run(isx_batch *b)
 
     PileupArgs a{};
     a.rec = b->d_rec; a.win_range = b->d_win; a.ref = b->d_ref;
-    a.pair = b->d_pair; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap;
+    a.pair = b->d_pair; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
     if (const char *e = getenv("ISX_DEBUG_MODE")) a.debug_mode = atoi(e);     // ablation only
@@ -365,7 +379,7 @@ int isx_batch_run(isx_batch *b)
     a.cursors = b->d_cursors; a.flags = b->d_flags;
 
     HIP_TRY(hipEventRecord(b->ev[0], s));
-    launch_pileup(a, b->block, b->lds, b->grid_dense, s);
+    launch_pileup(a, b->block, b->lds, b->grid, b->packed, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[1], s));
     HIP_TRY(hipMemcpyAsync(b->h_state, b->d_cursors, (CUR_N + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -383,7 +397,7 @@ int isx_batch_run(isx_batch *b)
     b->sizes.n_sites = cur[CUR_SITES];
     b->tim = isx_timings{};
     b->tim.pileup_ms = ev_ms(b->ev[0], b->ev[1]);
-    b->tim.pileup_blocks = b->M == 1 ? b->grid_dense : ((b->n_win + 7) / 8) * 8;
+    b->tim.pileup_blocks = b->grid;
     b->tim.pileup_threads = b->block;
     b->tim.pileup_lds_bytes = (int32_t)b->lds;
     b->tim.pileup_window = b->W;

@@ -114,6 +114,7 @@ struct PileupArgs {
     int32_t min_cov;
     int32_t debug_mode;
     int32_t qcap;               // deferred-clonality queue capacity (entries)
+    int32_t rqcap;              // mm path: row-queue capacity (positions with SNV rows per window)
     double min_freq;
     // outputs
     uint4 *counts;              // dense path (M == 1): [n_pos]
@@ -134,7 +135,7 @@ struct PileupArgs {
     uint32_t *flags;
 };
 
-void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid_dense, hipStream_t s);
-size_t pileup_lds_bytes(int W, int M, int qcap, int linkage);
+void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s);
+size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed);
 
 struct LinkageBuffers;      // defined in isx_linkage.hip

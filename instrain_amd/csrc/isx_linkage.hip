@@ -34,10 +34,11 @@
 
 namespace {
 
-// key layout: site1:26 | site2:26 | mm:8 | b1:2 | b2:2
-__device__ __forceinline__ uint64_t make_key(uint32_t s1, uint32_t s2, uint32_t mm, uint32_t b1, uint32_t b2)
+// key layout: site1:sb | site2:sb | mm:8 | b1:2 | b2:2 with sb = bits needed for the site ranks of
+// this batch (<= 26), so the radix sorts only walk 2*sb + 12 bits
+__device__ __forceinline__ uint64_t make_key(int sb, uint32_t s1, uint32_t s2, uint32_t mm, uint32_t b1, uint32_t b2)
 {
-    return ((uint64_t)s1 << 38) | ((uint64_t)s2 << 12) | ((uint64_t)mm << 4) | (b1 << 2) | b2;
+    return ((uint64_t)s1 << (12 + sb)) | ((uint64_t)s2 << 12) | ((uint64_t)mm << 4) | (b1 << 2) | b2;
 }
 
 __global__ void k_site_keys(const isx_site *sites, uint32_t n, uint32_t *keys)
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(256) k_ao_rank(isx_ao *ao, uint32_t n, const u
 // MFMA path takes every cross-site count from X^T X and needs just these from the pair lists.
 template <bool EMIT, bool SELF_ONLY>
 __global__ void __launch_bounds__(256) k_pair_incr(const isx_ao *ao, uint32_t n, const uint32_t *site_split,
-                                                   uint32_t *cnt, const uint32_t *off, uint64_t *keys)
+                                                   uint32_t *cnt, const uint32_t *off, uint64_t *keys, int sb)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -102,8 +103,8 @@ __global__ void __launch_bounds__(256) k_pair_incr(const isx_ao *ao, uint32_t n,
         if (EMIT) {
             // list order = (column, arrival order inside the column)
             const bool a_first = (a.site < b.site) || (a.site == b.site && a.obs_idx < b.obs_idx);
-            keys[o + c] = a_first ? make_key(a.site, b.site, a.mm, a.base, b.base)
-                                  : make_key(b.site, a.site, a.mm, b.base, a.base);
+            keys[o + c] = a_first ? make_key(sb, a.site, b.site, a.mm, a.base, b.base)
+                                  : make_key(sb, b.site, a.site, a.mm, b.base, a.base);
         }
         c++;
     }
@@ -155,7 +156,7 @@ __device__ __forceinline__ void major_minor(const uint32_t *c, int &maj, int &mn
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_ld_rows(const uint64_t *ukeys, const uint32_t *ucnt, uint32_t n_u,
                                                  SiteView v, int min_snp, uint32_t *rows_per, const uint32_t *row_off,
-                                                 isx_ld *out, uint32_t *n_edges, Philox ph)
+                                                 isx_ld *out, uint32_t *n_edges, Philox ph, int sb)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n_u) return;
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(256) k_ld_rows(const uint64_t *ukeys, const ui
     const bool head = (u == 0) || ((ukeys[u - 1] >> 12) != edge);
     if (!head) { if (!EMIT) rows_per[u] = 0; return; }
     if (!EMIT) atomicAdd(n_edges, 1u);
-    const uint32_t s1 = (uint32_t)(k0 >> 38), s2 = (uint32_t)((k0 >> 12) & 0x3FFFFFFu);
+    const uint32_t s1 = (uint32_t)(k0 >> (12 + sb)), s2 = (uint32_t)((k0 >> 12) & ((1u << sb) - 1u));
     uint32_t combo[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) combo[i] = 0;
@@ -332,7 +333,7 @@ __global__ void k_dense_scatter(const isx_ao *ao, const uint64_t *key, const uin
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_dense_gemm(const DenseTile *tiles, uint32_t n_tiles, const DenseSplit *splits,
                                                     const uint8_t *xt, uint32_t *tile_cnt, const uint32_t *tile_off,
-                                                    uint64_t *keys, uint32_t *cnts)
+                                                    uint64_t *keys, uint32_t *cnts, int sb)
 {
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= n_tiles) return;
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(256) k_dense_gemm(const DenseTile *tiles, uint
         const unsigned long long bal = __ballot(hit);
         if (EMIT && hit) {
             const uint32_t o = run + (uint32_t)__popcll(bal & ((1ull << l) - 1ull));
-            keys[o] = make_key(ds.first_site + si, ds.first_site + sj, 0, ci & 3, cj & 3);
+            keys[o] = make_key(sb, ds.first_site + si, ds.first_site + sj, 0, ci & 3, cj & 3);
             cnts[o] = (uint32_t)v;
         }
         run += (uint32_t)__popcll(bal);
@@ -441,13 +442,14 @@ int sparse_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_
 {
     hipStream_t s = in.stream;
     int rc;
+    const int sb = bits_for(in.n_sites);
     n_u = 0;
     const int pair_bits = bits_for(in.n_pairs ? in.n_pairs : 0xFFFFFFFFull);
     RP(rocprim::radix_sort_pairs(tp, tb, B.ao_key.p, B.ao_key2.p, in.ao, B.ao2.p, n_ao, 0, pair_bits, s));
     EV(3);
     if ((rc = ensure(B.incr_cnt, n_ao)) || (rc = ensure(B.incr_off, (size_t)n_ao + 1))) return rc;
     hipLaunchKernelGGL((k_pair_incr<false, false>), dim3((n_ao + 255) / 256), dim3(256), 0, s, B.ao2.p, n_ao,
-                       B.site_split.p, B.incr_cnt.p, nullptr, nullptr);
+                       B.site_split.p, B.incr_cnt.p, nullptr, nullptr, sb);
     uint64_t n_inc = 0;
     if ((rc = scan_total(B, s, B.incr_cnt.p, B.incr_off.p, n_ao, n_inc))) return rc;
     out.n_increments = n_inc;
@@ -456,8 +458,8 @@ int sparse_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_
     if ((rc = ensure(B.keys, n_inc)) || (rc = ensure(B.keys2, n_inc)) || (rc = ensure(B.ukeys, n_inc)) ||
         (rc = ensure(B.ucnt, n_inc)) || (rc = ensure(B.n_runs, 2))) return rc;
     hipLaunchKernelGGL((k_pair_incr<true, false>), dim3((n_ao + 255) / 256), dim3(256), 0, s, B.ao2.p, n_ao,
-                       B.site_split.p, nullptr, B.incr_off.p, B.keys.p);
-    RP(rocprim::radix_sort_keys(tp, tb, B.keys.p, B.keys2.p, (size_t)n_inc, 0, 64, s));
+                       B.site_split.p, nullptr, B.incr_off.p, B.keys.p, sb);
+    RP(rocprim::radix_sort_keys(tp, tb, B.keys.p, B.keys2.p, (size_t)n_inc, 0, 2 * sb + 12, s));
     RP(rocprim::run_length_encode(tp, tb, B.keys2.p, (size_t)n_inc, B.ukeys.p, B.ucnt.p, B.n_runs.p, s));
     HIP_TRY(hipMemcpyAsync(&n_u, B.n_runs.p, 4, hipMemcpyDeviceToHost, s));
     EV(4);
@@ -471,6 +473,7 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
     hipStream_t s = in.stream;
     int rc;
     n_u = 0;
+    const int sb = bits_for(n_sites);
     const uint32_t nsp = (uint32_t)in.n_splits;
     // rows: allele observations sorted by (split, pair); one row per distinct (split, pair)
     if ((rc = ensure(B.key64, n_ao)) || (rc = ensure(B.key64b, n_ao)) || (rc = ensure(B.head, n_ao)) ||
@@ -533,7 +536,7 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
                            B.dsplits.p, B.xt.p);
         HIP_TRY(hipEventRecord(in.ev_mfma[0], s));
         hipLaunchKernelGGL((k_dense_gemm<false>), dim3((n_tiles + 3) / 4), blk, 0, s, B.dtiles.p, n_tiles, B.dsplits.p,
-                           B.xt.p, B.tile_cnt.p, nullptr, nullptr, nullptr);
+                           B.xt.p, B.tile_cnt.p, nullptr, nullptr, nullptr, sb);
         HIP_TRY(hipEventRecord(in.ev_mfma[1], s));
         if ((rc = scan_total(B, s, B.tile_cnt.p, B.tile_off.p, n_tiles, n_gemm))) return rc;
     } else {
@@ -542,7 +545,7 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
     }
     // same-site combinations from the pair lists
     if ((rc = ensure(B.incr_cnt, n_ao)) || (rc = ensure(B.incr_off, (size_t)n_ao + 1))) return rc;
-    hipLaunchKernelGGL((k_pair_incr<false, true>), ga, blk, 0, s, B.ao2.p, n_ao, B.site_split.p, B.incr_cnt.p, nullptr, nullptr);
+    hipLaunchKernelGGL((k_pair_incr<false, true>), ga, blk, 0, s, B.ao2.p, n_ao, B.site_split.p, B.incr_cnt.p, nullptr, nullptr, sb);
     uint64_t n_self = 0;
     if ((rc = scan_total(B, s, B.incr_cnt.p, B.incr_off.p, n_ao, n_self))) return rc;
     const uint64_t n_k = n_gemm + n_self;
@@ -552,13 +555,13 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
         (rc = ensure(B.ukeys, n_k)) || (rc = ensure(B.ucnt, n_k)) || (rc = ensure(B.n_runs, 2))) return rc;
     if (n_gemm)
         hipLaunchKernelGGL((k_dense_gemm<true>), dim3((n_tiles + 3) / 4), blk, 0, s, B.dtiles.p, n_tiles, B.dsplits.p, B.xt.p,
-                           nullptr, B.tile_off.p, B.keys.p, B.vals.p);
+                           nullptr, B.tile_off.p, B.keys.p, B.vals.p, sb);
     if (n_self) {
         hipLaunchKernelGGL((k_pair_incr<true, true>), ga, blk, 0, s, B.ao2.p, n_ao, B.site_split.p, nullptr, B.incr_off.p,
-                           B.keys.p + n_gemm);
+                           B.keys.p + n_gemm, sb);
         hipLaunchKernelGGL(k_fill_ones, dim3(((uint32_t)n_self + 255) / 256), blk, 0, s, B.vals.p + n_gemm, (uint32_t)n_self);
     }
-    RP(rocprim::radix_sort_pairs(tp, tb, B.keys.p, B.keys2.p, B.vals.p, B.vals2.p, (size_t)n_k, 0, 64, s));
+    RP(rocprim::radix_sort_pairs(tp, tb, B.keys.p, B.keys2.p, B.vals.p, B.vals2.p, (size_t)n_k, 0, 2 * sb + 12, s));
     RP(rocprim::reduce_by_key(tp, tb, B.keys2.p, B.vals2.p, (size_t)n_k, B.ukeys.p, B.ucnt.p, B.n_runs.p,
                               rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s));
     RP(rocprim::reduce(tp, tb, B.vals2.p, B.n_runs.p + 1, 0u, (size_t)n_k, rocprim::plus<uint32_t>(), s));
@@ -615,11 +618,12 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     if (n_u == 0) { if (out.n_increments == 0) { /* EV(3)/EV(4) recorded by the path */ } EV(5); return ISX_OK; }
 
     // ---- 6. LD rows ----
+    const int sb = bits_for(n_sites);
     if ((rc = ensure(B.rows_per, n_u)) || (rc = ensure(B.row_off, (size_t)n_u + 1))) return rc;
     HIP_TRY(hipMemsetAsync(B.n_runs.p + 1, 0, 4, s));
     SiteView v{B.sites_sorted.p, in.entries, in.counts, in.M == 1 ? 1 : 0};
     hipLaunchKernelGGL(k_ld_rows<false>, dim3((n_u + 255) / 256), dim3(256), 0, s, B.ukeys.p, B.ucnt.p, n_u, v,
-                       in.min_snp, B.rows_per.p, nullptr, nullptr, B.n_runs.p + 1, in.philox);
+                       in.min_snp, B.rows_per.p, nullptr, nullptr, B.n_runs.p + 1, in.philox, sb);
     uint64_t n_ld = 0;
     if ((rc = scan_total(B, s, B.rows_per.p, B.row_off.p, n_u, n_ld))) return rc;
     uint32_t n_edges = 0;
@@ -630,7 +634,7 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     if (n_ld) {
         if ((rc = ensure(B.ld, n_ld))) return rc;
         hipLaunchKernelGGL(k_ld_rows<true>, dim3((n_u + 255) / 256), dim3(256), 0, s, B.ukeys.p, B.ucnt.p, n_u, v,
-                           in.min_snp, nullptr, B.row_off.p, B.ld.p, nullptr, in.philox);
+                           in.min_snp, nullptr, B.row_off.p, B.ld.p, nullptr, in.philox, sb);
     }
     EV(5);
     return ISX_OK;

@@ -383,118 +383,156 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_pileup_mm: n_mm_bins > 1.  One workgroup per window (grid = #windows, XCD-aware order).
-// LDS: cnt[M*4][W] | pres[ceil(M/32)][W] | scratch[16] | queue[QCAP][2] | slabc[W] | maskl[W bytes]
+// k_pileup_mm: n_mm_bins > 1 (mm profiling on, the reference's default).  Persistent workgroups
+// like k_pileup_dense.  PACKED: two u16 counters per LDS word ((A,C) and (T,G) of a level) -- legal
+// when no window streams >= 65536 records (no counter can overflow), halves the LDS per position
+// and so doubles the window (less over-scan).  All table slots (entries, SNV rows, SNP sites,
+// allele slabs) come from ONE global atomic each per window: pass A runs update_snp_table's level
+// loop to size everything, pass B runs it again to write.
+// LDS: cnt[M*(PACKED?2:4)][W] | pres[ceil(M/32)][W] | scratch[16] | queue[QCAP][2] | rowq[RQCAP][4] | thr_lds |
+//      (linkage) slabc[W] | maskl[W bytes]
 // pres = levels made present by a non-ACGT base only (profile_utilities.py:279-285 creates
 // table[mm] before the KeyError), a presence the SNV loop must see.
 // ---------------------------------------------------------------------------------------------
+template <bool PACKED>
 __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int nb = gridDim.x;
-    const int w = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);       // grid is a multiple of 8
-    if (w >= a.n_win) return;
     const int W = a.W, M = a.M;
-    const uint32_t w0 = (uint32_t)w * (uint32_t)W;
-    const int n_cnt = M * 4 * W;
+    const int n_cnt = M * (PACKED ? 2 : 4) * W;
     const int pres_words = (M + 31) >> 5;
     uint32_t *cnt = lds;
     uint32_t *pres = lds + n_cnt;
     uint32_t *scratch = pres + pres_words * W;
-    uint32_t *queue = scratch + S_N;                    // [QCAP][2]: entry index, (mm << 16) | p
-    uint32_t *slabc = queue + 2 * a.qcap;
+    uint32_t *queue = scratch + S_N;                    // [QCAP][2]: entry index, flags | (mm << 16) | p
+    uint16_t *thr_lds = reinterpret_cast<uint16_t *>(queue + 2 * a.qcap + 4 * a.rqcap);
+    uint32_t *slabc = queue + 2 * a.qcap + 4 * a.rqcap + THR_LDS / 2;
     uint8_t *maskl = reinterpret_cast<uint8_t *>(slabc + W);
     const uint32_t QCAP = (uint32_t)a.qcap;
     const bool linkage = a.enable_linkage != 0;
-
-    {   // zero the window
-        uint4 *z = reinterpret_cast<uint4 *>(lds);
-        const int n4 = (n_cnt + pres_words * W) >> 2;   // W is a multiple of 64
-        for (int i = tid; i < n4; i += nthr) z[i] = make_uint4(0, 0, 0, 0);
-        if (linkage) {
-            uint4 *zm = reinterpret_cast<uint4 *>(maskl);
-            for (int i = tid; i < (W >> 4); i += nthr) zm[i] = make_uint4(0, 0, 0, 0);
-        }
-        if (tid < S_N) scratch[tid] = 0;
-    }
-    __syncthreads();
-
-    // ---- get_base_counts_mm over the window's slice of the stream ----
-    const uint2 rng = a.win_range[w];
+    const int grid = gridDim.x, per = grid >> 3;
+    const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
     const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(a.rec);
-    const uint32_t lo = rng.x >> 1, hi = rng.y >> 1;
-    uint32_t bad_mm = 0;
-    for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
-        u32x4 v[4];
+    {   // once per workgroup: folded thresholds of the low coverages
+        const int n = min(THR_LDS, a.lut_n);
+        for (int i = tid; i < n; i += nthr) thr_lds[i] = a.thr[i];
+    }
+
+    auto rd = [&](int m, int k, int p) -> uint32_t {    // count of base k at level m, position p
+        if (PACKED) {
+            const uint32_t w = cnt[(m * 2 + (k >> 1)) * W + p];
+            return (k & 1) ? (w >> 16) : (w & 0xFFFFu);
+        }
+        return cnt[(m * 4 + k) * W + p];
+    };
+
+    u32x4 v[4];
+    uint32_t lo = 0, hi = 0;
+    auto issue = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t j = i0 + tid + u * nthr;
             if (j < hi) v[u] = __builtin_nontemporal_load(&rec4[j]);
             else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
         }
+    };
+    auto prefetch_window = [&](int wn) {
+        lo = hi = 0;
+        if (wn < a.n_win) {
+            const uint2 rng = a.win_range[wn];
+            lo = rng.x >> 1; hi = rng.y >> 1;
+            if (lo < hi) issue(lo);
+        }
+    };
+    prefetch_window(slot);
+
+    for (int w = slot; w < a.n_win; w += grid) {
+        const uint32_t w0 = (uint32_t)w * (uint32_t)W;
+        const uint32_t cur_lo = lo, cur_hi = hi;
+        {   // zero the window
+            uint4 *z = reinterpret_cast<uint4 *>(lds);
+            const int n4 = (n_cnt + pres_words * W) >> 2;   // W is a multiple of 64
+            for (int i = tid; i < n4; i += nthr) z[i] = make_uint4(0, 0, 0, 0);
+            if (linkage) {
+                uint4 *zm = reinterpret_cast<uint4 *>(maskl);
+                for (int i = tid; i < (W >> 4); i += nthr) zm[i] = make_uint4(0, 0, 0, 0);
+            }
+            if (tid < S_N) scratch[tid] = 0;
+        }
+        __syncthreads();
+
+        // ---- get_base_counts_mm over the window's slice of the stream ----
+        uint32_t bad_mm = 0;
+        for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 4; u++) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t g = h ? v[u].z : v[u].x, at = h ? v[u].w : v[u].y;
-                const uint32_t rel = g - w0;
-                if (rel >= (uint32_t)W) continue;
-                const uint32_t base = (at >> 16) & 0xFFu, mm = at & 0xFFFFu;
-                if (mm >= (uint32_t)M) { bad_mm = 1; continue; }
-                if (base < 4) atomicAdd(&cnt[(mm * 4 + base) * W + rel], 1u);
-                else atomicOr(&pres[(mm >> 5) * W + rel], 1u << (mm & 31));
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t g = h ? v[u].z : v[u].x, at = h ? v[u].w : v[u].y;
+                    const uint32_t rel = g - w0;
+                    if (rel >= (uint32_t)W) continue;
+                    const uint32_t base = (at >> 16) & 0xFFu, mm = at & 0xFFFFu;
+                    if (mm >= (uint32_t)M) { bad_mm = 1; continue; }
+                    if (base < 4) {
+                        if (PACKED) atomicAdd(&cnt[(mm * 2 + (base >> 1)) * W + rel], 1u << (16 * (base & 1)));
+                        else atomicAdd(&cnt[(mm * 4 + base) * W + rel], 1u);
+                    } else {
+                        atomicOr(&pres[(mm >> 5) * W + rel], 1u << (mm & 31));
+                    }
+                }
+            }
+            const uint32_t nxt = i0 + 4 * nthr;
+            if (nxt < hi) issue(nxt);
+        }
+        if (bad_mm) atomicOr(a.flags, ISX_FLAG_MM_RANGE);
+        __syncthreads();
+        if (!linkage) prefetch_window(w + grid);
+        const int dbg = a.debug_mode;           // ablation switches (tools/ablate_mm.py), 0 in production
+
+        // ---- entry slots: count the present levels, one global atomic per window ----
+        uint32_t e_off[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int p = tid + j * nthr;
+            if (p < W && w0 + p < a.n_pos && !(dbg & 2)) {
+                uint32_t n = 0;
+                for (int m = 0; m < M; m++) {
+                    const uint32_t any = PACKED ? (cnt[(m * 2) * W + p] | cnt[(m * 2 + 1) * W + p])
+                                                : (cnt[(m * 4) * W + p] | cnt[(m * 4 + 1) * W + p] | cnt[(m * 4 + 2) * W + p] | cnt[(m * 4 + 3) * W + p]);
+                    n += (any | ((pres[(m >> 5) * W + p] >> (m & 31)) & 1u)) ? 1u : 0u;
+                }
+                if (n) e_off[j] = atomicAdd(&scratch[S_ENT_TOT], n);
             }
         }
-    }
-    if (bad_mm) atomicOr(a.flags, ISX_FLAG_MM_RANGE);
-    __syncthreads();
+        __syncthreads();
+        const uint32_t n_ent = scratch[S_ENT_TOT];
+        if (tid == 0 && n_ent) scratch[S_ENT_BASE] = atomicAdd(&a.cursors[CUR_ENTRIES], n_ent);
+        __syncthreads();
+        const uint32_t ent_base = scratch[S_ENT_BASE];
+        bool ok = true;
+        if (ent_base + n_ent > a.cap_entries) { if (tid == 0) atomicOr(a.flags, ISX_FLAG_CAP_ENTRIES); ok = false; }
 
-    // ---- entry allocation: one global atomic per window ----
-    uint32_t my_e = 0;
-    for (int p = tid; p < W; p += nthr) {
-        if (w0 + p >= a.n_pos) break;
-        for (int m = 0; m < M; m++) {
-            const uint32_t any = cnt[(m * 4 + 0) * W + p] | cnt[(m * 4 + 1) * W + p] | cnt[(m * 4 + 2) * W + p] |
-                                 cnt[(m * 4 + 3) * W + p] | ((pres[(m >> 5) * W + p] >> (m & 31)) & 1u);
-            my_e += any ? 1u : 0u;
-        }
-    }
-    const uint32_t my_off = atomicAdd(&scratch[S_ENT_TOT], my_e);
-    __syncthreads();
-    if (tid == 0) scratch[S_ENT_BASE] = atomicAdd(&a.cursors[CUR_ENTRIES], scratch[S_ENT_TOT]);
-    __syncthreads();
-    uint32_t e_off = scratch[S_ENT_BASE] + my_off;
-    if (scratch[S_ENT_BASE] + scratch[S_ENT_TOT] > a.cap_entries) {
-        if (tid == 0) atomicOr(a.flags, ISX_FLAG_CAP_ENTRIES);
-        return;
-    }
-
-    // ---- update_snp_table: `for mm in sorted(MMcounts)` per position ----
-    for (int p = tid; p < W; p += nthr) {
-        const uint32_t gpos = w0 + p;
-        if (gpos >= a.n_pos) break;
-        const int ref_base = a.ref[gpos];
-        uint32_t cum[4] = {0, 0, 0, 0};
-        int anySNP = 0, cryptic = 0, nrows = 0, nlev = 0;
-        uint32_t mask = 0;
-        const uint32_t first_entry = e_off;
-
-        // EMIT = false: entries, clonality, row count; EMIT = true: write the SNV rows
-        auto levels = [&](bool emit, uint32_t row_base) {
-            cum[0] = cum[1] = cum[2] = cum[3] = 0;
-            int any = 0, cry = 0, rows = 0;
+        // ---- update_snp_table's `for mm in sorted(MMcounts)`; up to two positions per lane ----
+        // mode 0: entries + clonality, and sizes rows / sites / hits (positions with rows go to rowq);
+        // mode 1 (rare, queued positions only): write the SNV rows
+        auto levels = [&](int p, uint32_t gpos, uint32_t e0, int mode, uint32_t row_at, uint32_t cry_in, uint32_t &out_rows,
+                          uint32_t &out_any, uint32_t &out_cry, uint32_t &out_mask, uint32_t &out_nlev, uint32_t &out_hits) {
+            const int ref_base = a.ref[gpos];
+            uint32_t cum[4] = {0, 0, 0, 0};
+            uint32_t any = 0, cry = 0, rows = 0, nlev = 0, mask = 0;
             for (int m = 0; m < M; m++) {
                 uint32_t l[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) l[k] = cnt[(m * 4 + k) * W + p];
+                for (int k = 0; k < 4; k++) l[k] = rd(m, k, p);
                 const uint32_t present = l[0] | l[1] | l[2] | l[3] | ((pres[(m >> 5) * W + p] >> (m & 31)) & 1u);
                 if (!present) continue;
 #pragma unroll
                 for (int k = 0; k < 4; k++) cum[k] += l[k];         // mm_counts_to_counts(MMcounts, mm)
                 const uint32_t total = cum[0] + cum[1] + cum[2] + cum[3];
-                const SiteCall sc = call_level(a, nullptr, cum, total, ref_base, emit);
-                if (!emit) {
+                const SiteCall sc = call_level(a, thr_lds, cum, total, ref_base, mode == 1);
+                if (mode == 0) {
+                    const uint32_t ei = ent_base + e0 + nlev;
                     float cl = __builtin_nanf("");
                     const bool want_r = a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r;
                     bool want_c = false;
@@ -504,34 +542,33 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                         else want_c = true;
                     }
                     if (want_c || want_r) {
-                        const uint32_t slot = atomicAdd(&scratch[S_NQ], 1u);
-                        if (slot < QCAP) {
-                            queue[slot * 2 + 0] = e_off;
-                            queue[slot * 2 + 1] = ((uint32_t)m << 16) | (uint32_t)p | (want_c ? 1u << 30 : 0u) | (want_r ? 1u << 31 : 0u);
+                        const uint32_t qs = atomicAdd(&scratch[S_NQ], 1u);
+                        if (qs < QCAP) {
+                            queue[qs * 2 + 0] = ei;
+                            queue[qs * 2 + 1] = ((uint32_t)m << 16) | (uint32_t)p | (want_c ? 1u << 30 : 0u) | (want_r ? 1u << 31 : 0u);
                         } else {                                    // queue full: inline
                             if (want_c) cl = (float)clonality(cum, total);
-                            if (want_r) a.clon_r[e_off] = rarefied_clonality(a, cum, gpos, (uint32_t)m);
+                            if (want_r) a.clon_r[ei] = rarefied_clonality(a, cum, gpos, (uint32_t)m);
                         }
                     }
                     isx_entry e;
                     e.gpos = gpos; e.mm = (uint16_t)m; e.flags = 0;
                     e.cnt[0] = l[0]; e.cnt[1] = l[1]; e.cnt[2] = l[2]; e.cnt[3] = l[3];
                     e.clon = cl;
-                    a.entries[e_off] = e;
-                    e_off++;
-                    nlev++;
+                    if (!(a.debug_mode & 64)) a.entries[ei] = e;
                 }
+                nlev++;
                 if (sc.snp == -2) continue;
                 if (sc.snp != -1) {
-                    if (emit) {
+                    if (mode == 1) {
                         isx_snv r;
                         r.gpos = gpos; r.mm = (uint16_t)m;
                         r.con_base = (uint8_t)sc.snp; r.var_base = (uint8_t)sc.var;
                         r.allele_count = (uint8_t)sc.morphia; r.cls = (uint8_t)sc.cls;
-                        r.cryptic = (uint8_t)cryptic;               // position-level flag from the first pass (p2c map)
+                        r.cryptic = (uint8_t)cry_in;                // position-level flag from mode 0 (p2c map)
                         r.ref_base = (uint8_t)ref_base;
                         r.cnt[0] = cum[0]; r.cnt[1] = cum[1]; r.cnt[2] = cum[2]; r.cnt[3] = cum[3];
-                        a.snv[row_base + rows] = r;
+                        a.snv[row_at + rows] = r;
                     }
                     rows++;
                     if (sc.morphia >= 2) { any = 1; mask |= (1u << sc.snp) | (1u << sc.var); }
@@ -540,75 +577,129 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                     cry = 1;
                 }
             }
-            anySNP = any; cryptic = cry; nrows = rows;
+            out_rows = rows; out_any = any; out_cry = cry; out_mask = mask; out_nlev = nlev;
+            out_hits = any ? masked_sum(cum, mask) : 0u;            // cum == counts over ALL levels here
         };
-
-        levels(false, 0);
-        const uint32_t all[4] = {cum[0], cum[1], cum[2], cum[3]};   // counts over ALL levels
-        if (nrows) {
-            const uint32_t row_base = atomicAdd(&a.cursors[CUR_SNV], (uint32_t)nrows);
-            if (row_base + nrows > a.cap_snv) atomicOr(a.flags, ISX_FLAG_CAP_SNV);
-            else levels(true, row_base);
-        }
-        if (anySNP) {
-            const uint32_t s = atomicAdd(&a.cursors[CUR_SITES], 1u);
-            if (s >= a.cap_sites) atomicOr(a.flags, ISX_FLAG_CAP_SITES);
-            else {
-                isx_site st;
-                st.gpos = gpos; st.entry_off = first_entry; st.n_levels = (uint16_t)nlev;
-                st.mask = (uint8_t)mask; st.pad = 0;
-                a.sites[s] = st;
-            }
-            if (linkage) {
-                maskl[p] = (uint8_t)mask;
-                slabc[p] = atomicAdd(&scratch[S_NAO], masked_sum(all, mask));
-            }
-        }
-    }
-    __syncthreads();
-    // ---- deferred clonalities: calculate_clonality (snv_utilities.py:225-231) in fp64, densely packed ----
-    const uint32_t nq = min(scratch[S_NQ], QCAP), nao = scratch[S_NAO];
-    if (tid == 0 && nao) scratch[S_AO_BASE] = atomicAdd(&a.cursors[CUR_AO], nao);
-    for (uint32_t q = tid; q < nq; q += nthr) {
-        const uint32_t pm = queue[q * 2 + 1];
-        const int p = (int)(pm & 0xFFFFu), mq = (int)((pm >> 16) & 0x3FFFu);
-        uint32_t c[4] = {0, 0, 0, 0};
-        for (int m = 0; m <= mq; m++) {                 // mm_counts_to_counts(MMcounts, mm)
+        // row queue (positions with SNV rows; rare): rowq[4 * i] = p | any << 16 | cry << 17 | mask << 20,
+        // row offset, site offset, entry offset | nlev << 24 ... kept in 4 words per entry
+        uint32_t *rowq = queue + 2 * QCAP;
+        if (ok && !(dbg & 130)) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) c[k] += cnt[(m * 4 + k) * W + p];
+            for (int j = 0; j < 2; j++) {
+                const int p = tid + j * nthr;
+                if (p < W && w0 + p < a.n_pos) {
+                    uint32_t rows, any, cry, mask, nlev, hits;
+                    levels(p, w0 + p, e_off[j], 0, 0, 0, rows, any, cry, mask, nlev, hits);
+                    if (rows) {
+                        if (any && linkage) {
+                            maskl[p] = (uint8_t)mask;
+                            slabc[p] = atomicAdd(&scratch[S_NAO], hits);
+                        }
+                        const uint32_t qi = atomicAdd(&scratch[S_ROW_RANK], 1u);
+                        if (qi < (uint32_t)a.rqcap) {
+                            const uint32_t r_off = atomicAdd(&scratch[S_ROWS], rows);
+                            const uint32_t s_off = any ? atomicAdd(&scratch[S_SITES], 1u) : 0u;
+                            rowq[qi * 4 + 0] = (uint32_t)p | (any << 16) | (cry << 17) | (mask << 20);
+                            rowq[qi * 4 + 1] = r_off;
+                            rowq[qi * 4 + 2] = s_off;
+                            rowq[qi * 4 + 3] = e_off[j] | (nlev << 24);
+                        } else {                                    // row queue full: this position allocates by itself
+                            const uint32_t row_at = atomicAdd(&a.cursors[CUR_SNV], rows);
+                            if (row_at + rows > a.cap_snv) atomicOr(a.flags, ISX_FLAG_CAP_SNV);
+                            else {
+                                uint32_t r1, r2, r3, r4, r5, r6;
+                                levels(p, w0 + p, 0, 1, row_at, cry, r1, r2, r3, r4, r5, r6);
+                            }
+                            if (any) {
+                                const uint32_t sa = atomicAdd(&a.cursors[CUR_SITES], 1u);
+                                if (sa >= a.cap_sites) atomicOr(a.flags, ISX_FLAG_CAP_SITES);
+                                else {
+                                    isx_site ss;
+                                    ss.gpos = w0 + p; ss.entry_off = ent_base + e_off[j]; ss.n_levels = (uint16_t)nlev;
+                                    ss.mask = (uint8_t)mask; ss.pad = 0;
+                                    a.sites[sa] = ss;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
         }
-        if (pm & (1u << 30)) a.entries[queue[q * 2]].clon = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
-        if (pm & (1u << 31)) a.clon_r[queue[q * 2]] = rarefied_clonality(a, c, w0 + p, (uint32_t)mq);
+        __syncthreads();
+        const uint32_t nrows = scratch[S_ROWS], nsites = scratch[S_SITES], nao = scratch[S_NAO], nrq = scratch[S_ROW_RANK];
+        if (tid == 64 && nrows) scratch[S_ROW_BASE] = atomicAdd(&a.cursors[CUR_SNV], nrows);
+        if (tid == 128 && nsites) scratch[S_SITE_BASE] = atomicAdd(&a.cursors[CUR_SITES], nsites);
+        if (tid == 192 && nao) scratch[S_AO_BASE] = atomicAdd(&a.cursors[CUR_AO], nao);
+        // ---- deferred clonalities: calculate_clonality (snv_utilities.py:225-231) in fp64, densely packed ----
+        const uint32_t nq = min(scratch[S_NQ], QCAP);
+        for (uint32_t q = tid; q < nq; q += nthr) {
+            const uint32_t pm = queue[q * 2 + 1];
+            const int p = (int)(pm & 0xFFFFu), mq = (int)((pm >> 16) & 0x3FFFu);
+            uint32_t c[4] = {0, 0, 0, 0};
+            for (int m = 0; m <= mq; m++) {             // mm_counts_to_counts(MMcounts, mm)
+#pragma unroll
+                for (int k = 0; k < 4; k++) c[k] += rd(m, k, p);
+            }
+            if (pm & (1u << 30)) a.entries[queue[q * 2]].clon = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+            if (pm & (1u << 31)) a.clon_r[queue[q * 2]] = rarefied_clonality(a, c, w0 + p, (uint32_t)mq);
+        }
+        if (nrows) __syncthreads();             // uniform: bases from the atomics above
+        const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE], ao_base = scratch[S_AO_BASE];
+        if (ok && nrows && (row_base + nrows > a.cap_snv || site_base + nsites > a.cap_sites || ao_base + nao > a.cap_ao)) {
+            if (tid == 0) atomicOr(a.flags, row_base + nrows > a.cap_snv ? ISX_FLAG_CAP_SNV
+                                            : site_base + nsites > a.cap_sites ? ISX_FLAG_CAP_SITES : ISX_FLAG_CAP_AO);
+            ok = false;
+        }
+        // ---- SNV rows / SNP sites of the queued positions (snv_utilities.py:107-133) ----
+        for (uint32_t q = tid; q < (ok ? min(nrq, (uint32_t)a.rqcap) : 0u); q += nthr) {
+            const uint32_t w0q = rowq[q * 4 + 0];
+            const int p = (int)(w0q & 0xFFFFu);
+            const uint32_t any = (w0q >> 16) & 1u, cry = (w0q >> 17) & 1u, mask = (w0q >> 20) & 0xFu;
+            uint32_t r1, r2, r3, r4, r5, r6;
+            levels(p, w0 + p, 0, 1, row_base + rowq[q * 4 + 1], cry, r1, r2, r3, r4, r5, r6);
+            if (any) {
+                isx_site ss;
+                ss.gpos = w0 + p; ss.entry_off = ent_base + (rowq[q * 4 + 3] & 0xFFFFFFu);
+                ss.n_levels = (uint16_t)(rowq[q * 4 + 3] >> 24);
+                ss.mask = (uint8_t)mask; ss.pad = 0;
+                a.sites[site_base + rowq[q * 4 + 2]] = ss;
+            }
+        }
+        if (linkage) {
+            if (ok && nao) allele_pass(a, rec4, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, tid, nthr);
+            prefetch_window(w + grid);
+        }
+        __syncthreads();
     }
-    if (!linkage || !nao) return;               // uniform
-    __syncthreads();
-    const uint32_t ao_base = scratch[S_AO_BASE];
-    if (ao_base + nao > a.cap_ao) { if (tid == 0) atomicOr(a.flags, ISX_FLAG_CAP_AO); return; }
-    allele_pass(a, rec4, lo, hi, w0, W, maskl, slabc, ao_base, tid, nthr);
 }
 
 }  // namespace
 
-size_t pileup_lds_bytes(int W, int M, int qcap, int linkage)
+size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed)
 {
     size_t words;
     if (M == 1) words = (size_t)5 * W + S_N + THR_LDS / 2;
-    else words = (size_t)M * 4 * W + (size_t)((M + 31) / 32) * W + S_N + (size_t)qcap * 2;
+    else words = (size_t)M * (packed ? 2 : 4) * W + (size_t)((M + 31) / 32) * W + S_N + (size_t)qcap * 2 + (size_t)rqcap * 4 + THR_LDS / 2;
     size_t bytes = words * sizeof(uint32_t);
     if (linkage) bytes += (size_t)W * 5;        // slabc[W] + maskl[W]
     return bytes;
 }
 
-void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid_dense, hipStream_t s)
+void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s)
 {
     if (a.M > 1) {
-        const int grid = ((a.n_win + 7) / 8) * 8;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_mm),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_pileup_mm, dim3(grid), dim3(block), lds, s, a);
+        if (packed) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_mm<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_pileup_mm<true>, dim3(grid), dim3(block), lds, s, a);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_mm<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_pileup_mm<false>, dim3(grid), dim3(block), lds, s, a);
+        }
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_dense),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_pileup_dense, dim3(grid_dense), dim3(block), lds, s, a);
+        hipLaunchKernelGGL(k_pileup_dense, dim3(grid), dim3(block), lds, s, a);
     }
 }

@@ -68,33 +68,39 @@ def make_workload(genome_len=5_000_000, coverage=20, read_len=150, insert_mean=3
 
     mm_pair = np.zeros(n_pairs, dtype=np.int64)
     obs_parts, pair_parts = [], []
+    ref_rows = np.lib.stride_tricks.sliding_window_view(np.concatenate([ref, np.zeros(read_len, np.uint8)]), read_len)
+    site_rows = np.lib.stride_tricks.sliding_window_view(np.concatenate([site_of, np.full(read_len, -1, np.int32)]), read_len)
+    offs = np.arange(read_len, dtype=np.int32)
     CH = 1 << 16                                        # reads per chunk keeps temporaries small
     for c0 in range(0, n_reads, CH):
         st = starts[c0:c0 + CH]
         pp = pid[c0:c0 + CH]
-        pos = (st[:, None] + np.arange(read_len)[None, :])
-        b = ref[pos]
-        si = site_of[pos]
+        rb = ref_rows[st]                               # (reads, read_len) reference bases, row gathers
+        b = rb.copy()
+        si = site_rows[st]
         at = si >= 0
         if at.any():
-            h = np.broadcast_to(hap[pp][:, None], pos.shape)[at]
-            p_alt = af[si[at]] * np.where(h == 1, 1.6, 0.4)
-            carries = rng.random(at.sum()) < p_alt
+            sia = si[at]
+            h = np.broadcast_to(hap[pp][:, None], b.shape)[at]
+            p_alt = af[sia] * np.where(h == 1, 1.6, 0.4)
+            carries = rng.random(len(sia)) < p_alt
             bb = b[at]
-            bb[carries] = alt[si[at]][carries]
+            bb[carries] = alt[sia][carries]
             b[at] = bb
-        e = rng.random(pos.shape) < err
-        if e.any():
-            b[e] = rng.integers(0, 4, int(e.sum()), dtype=np.uint8)
-        np.add.at(mm_pair, pp, (b != ref[pos]).sum(axis=1))
-        keep = rng.random(pos.shape) < p_keep
-        o = np.empty(int(keep.sum()), dtype=OBS_DT)
-        o["gpos"] = pos[keep]
+        n_err = rng.binomial(b.size, err)               # sparse errors: positions drawn directly
+        if n_err:
+            fi = rng.integers(0, b.size, n_err)
+            b.reshape(-1)[fi] = rng.integers(0, 4, n_err, dtype=np.uint8)
+        mm_pair += np.bincount(pp, weights=(b != rb).sum(axis=1), minlength=n_pairs).astype(np.int64)
+        keep = rng.random(b.shape, dtype=np.float32) < np.float32(p_keep)
+        nk = int(keep.sum())
+        o = np.empty(nk, dtype=OBS_DT)
+        o["gpos"] = (st[:, None].astype(np.int32) + offs[None, :])[keep]
         o["base"] = b[keep]
         o["mm"] = 0
         o["flags"] = 0
         obs_parts.append(o)
-        pair_parts.append(np.broadcast_to(pp[:, None], pos.shape)[keep])
+        pair_parts.append(np.broadcast_to(pp[:, None], b.shape)[keep])
     obs = np.concatenate(obs_parts)
     pair = np.concatenate(pair_parts).astype(np.uint32)
     if not skip_mm:
