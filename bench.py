@@ -44,9 +44,9 @@ def c2_workload(seed, scale=1.0, with_mm=False):
 
 def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense):
     """SURVEY 8(d) / DESIGN.md: 8 B per observation in, 1 B/pos reference in, and out
-    dense (M==1): 16 B counts + 4 B clonality per position; mm path: 28 B per present (pos, mm) entry."""
+    dense (M==1): 16 B counts + 4 B clonality per position; mm path: 32 B per present (pos, mm) entry."""
     b = n_obs * 8 + n_pos * 1
-    b += n_pos * (16 + 4) if dense else n_entries * 28
+    b += n_pos * (16 + 4) if dense else n_entries * 32
     return b
 
 

@@ -79,14 +79,17 @@ typedef struct {
 } isx_params;
 
 /* (position, mm)-present entry: one per mm level present at a position, ascending mm.
- * 28 bytes.  cnt = counts of THIS level; covT[mm][pos] = sum(cnt); clon = clonT[mm][pos]
- * (float32 of the cumulative-<=mm clonality) or NaN when cumulative coverage < min_cov. */
+ * 32 bytes (two aligned 16-byte device stores).  cnt = counts of THIS level; covT[mm][pos] = sum(cnt);
+ * clon = clonT[mm][pos] (float32 of the cumulative-<=mm clonality) or NaN when cumulative coverage
+ * < min_cov; clon_rarefied = clonTR[mm][pos] (snv_utilities.py:233-247; Philox-seeded) or NaN when
+ * cumulative coverage < rarefied_coverage. */
 typedef struct {
     uint32_t gpos;
     uint16_t mm;
     uint16_t flags;
     uint32_t cnt[4];
     float clon;
+    float clon_rarefied;
 } isx_entry;
 
 /* raw_snp_table row (snv_utilities.py:118-127, 274-290).  28 bytes. */
@@ -175,9 +178,8 @@ int isx_batch_timings(const isx_batch *b, isx_timings *out);
 
 /* Results -> caller-allocated host buffers sized from isx_batch_sizes. Tables come back in
  * canonical order: entries (gpos, mm); snv (gpos, mm); ld (gpos_a, gpos_b, mm). */
-/* clon_rarefied (may be NULL): clonTR -- the rarefied clonality (snv_utilities.py:233-247) of the same
- * (position[, mm]) rows, NaN where cumulative coverage < rarefied_coverage; Philox-seeded. */
-int isx_batch_fetch_entries(isx_batch *b, isx_entry *out, float *clon_rarefied /* [n_entries] */);
+int isx_batch_fetch_entries(isx_batch *b, isx_entry *out);
+/* clon_rarefied (may be NULL): clonTR of the dense path, NaN where coverage < rarefied_coverage */
 int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts /* [n_pos][4] */, float *clon /* [n_pos] */,
                           float *clon_rarefied /* [n_pos] */);
 int isx_batch_fetch_snv(isx_batch *b, isx_snv *out);

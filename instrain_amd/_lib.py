@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinstrain_amd.so")
 
 OBS_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("base", "u1"), ("flags", "u1")])
-ENTRY_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("flags", "<u2"), ("cnt", "<u4", (4,)), ("clon", "<f4")])
+ENTRY_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("flags", "<u2"), ("cnt", "<u4", (4,)), ("clon", "<f4"),
+                     ("clon_rarefied", "<f4")])
 SNV_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("con_base", "u1"), ("var_base", "u1"),
                    ("allele_count", "u1"), ("cls", "u1"), ("cryptic", "u1"), ("ref_base", "u1"),
                    ("cnt", "<u4", (4,))])
@@ -20,7 +21,7 @@ LD_DT = np.dtype([("gpos_a", "<u4"), ("gpos_b", "<u4"), ("mm", "<u2"), ("allele_
                   ("allele_B", "u1"), ("allele_b", "u1"), ("pad", "<u2"), ("total", "<u4"), ("countAB", "<u4"),
                   ("countAb", "<u4"), ("countaB", "<u4"), ("countab", "<u4"), ("pad2", "<u4"),
                   ("r2", "<f8"), ("d_prime", "<f8"), ("r2_normalized", "<f8"), ("d_prime_normalized", "<f8")])
-assert OBS_DT.itemsize == 8 and ENTRY_DT.itemsize == 28 and SNV_DT.itemsize == 28 and LD_DT.itemsize == 72
+assert OBS_DT.itemsize == 8 and ENTRY_DT.itemsize == 32 and SNV_DT.itemsize == 28 and LD_DT.itemsize == 72
 
 
 class Params(C.Structure):
@@ -90,9 +91,8 @@ def load():
     lib.isx_batch_run.argtypes = [vp]
     lib.isx_batch_sizes.argtypes = [vp, C.POINTER(Sizes)]
     lib.isx_batch_timings.argtypes = [vp, C.POINTER(Timings)]
-    for f in ("isx_batch_fetch_snv", "isx_batch_fetch_ld"):
+    for f in ("isx_batch_fetch_entries", "isx_batch_fetch_snv", "isx_batch_fetch_ld"):
         getattr(lib, f).argtypes = [vp, vp]
-    lib.isx_batch_fetch_entries.argtypes = [vp, vp, vp]
     lib.isx_batch_fetch_dense.argtypes = [vp, vp, vp, vp]
     lib.isx_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.isx_bam_close.argtypes = [vp]

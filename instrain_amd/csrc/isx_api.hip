@@ -43,8 +43,12 @@ struct isx_batch {
     int64_t *d_bounds = nullptr;
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
-    float *d_clon_r = nullptr;       // rarefied clonality (dense: [n_pos]; mm: [cap_entries])
-    isx_entry *d_entries = nullptr;
+    float *d_clon_r = nullptr;       // rarefied clonality of the dense path [n_pos]
+    isx_entry *d_entries = nullptr;  // mm path: [n_win][slab] slabs, then cap_ovf overflow entries
+    uint32_t *d_win_nent = nullptr;
+    isx_slev *d_slev = nullptr;
+    uint32_t slab = 0;
+    size_t cap_ovf = 0, cap_slev = 0;
     isx_snv *d_snv = nullptr;
     isx_site *d_sites = nullptr;
     isx_ao *d_ao = nullptr;
@@ -54,6 +58,7 @@ struct isx_batch {
     LinkageBuffers L;
     hipEvent_t ev[10] = {};
     bool ran = false;
+    uint32_t n_ovf = 0;
     isx_sizes sizes{};
     isx_timings tim{};
 };
@@ -167,7 +172,7 @@ void isx_batch_destroy(isx_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_rec, b->d_pair, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries,
+    void *ps[] = {b->d_rec, b->d_pair, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
@@ -198,14 +203,14 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     b->ctx = c; b->prm = *prm; b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits;
     b->M = prm->n_mm_bins;
     const bool dense = b->M == 1;
-    b->block = 1024;
+    b->block = dense ? 1024 : 512;       // mm kernel: > 64 VGPRs, two 512-lane workgroups per CU overlap their phases
     if (const char *e = getenv("ISX_BLOCK")) b->block = atoi(e);       // tuning only
     if (b->block < 64 || b->block > 1024 || (b->block & 63)) { delete b; isx_set_error("ISX_BLOCK must be a multiple of 64 in [64, 1024]"); return ISX_ERR_ARG; }
     if (prm->window && (prm->window < 64 || (prm->window & 63) || prm->window > 8192)) { delete b; isx_set_error("window must be a multiple of 64 in [64, 8192]"); return ISX_ERR_ARG; }
     // window size: explicit, or (dense) 2560 measured best on MI355X for batches that fill the chip
     // (tools/tune_pileup.py), smaller for small batches so every CU still owns >= 2 windows; (mm) the
-    // largest multiple of 64 whose counters fit the LDS of ONE resident 1024-lane workgroup per CU (the
-    // mm kernel needs > 64 VGPRs, so two would not be resident anyway), at most 2 positions per lane
+    // largest multiple of 64 whose counters fit half of the 160 KiB LDS (two resident workgroups per CU),
+    // at most 2 positions per lane
     auto window_for = [&](bool packed) -> int {
         if (prm->window > 0) return prm->window;
         if (dense) {
@@ -213,7 +218,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
             return (int)std::min<int64_t>(2560, std::max<int64_t>(512, w));
         }
         const int bytes_per_pos = b->M * (packed ? 8 : 16) + ((b->M + 31) / 32) * 4 + 5;
-        const int wmax = ((150 * 1024 - 8 * b->qcap - 8192 - 2048 - 256) / bytes_per_pos) / 64 * 64;
+        const int wmax = ((78 * 1024 - 8 * b->qcap - 8192 - 2048 - 256) / bytes_per_pos) / 64 * 64;
         return std::min(std::max(wmax, 64), 2 * b->block);
     };
     b->n_rec = std::max<uint64_t>(ISX_PAD, ((uint64_t)n_obs + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
@@ -238,13 +243,11 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
         BH(hipMalloc(&b->d_counts, (size_t)n_pos * sizeof(uint4)));
         BH(hipMalloc(&b->d_clon, (size_t)n_pos * sizeof(float)));
     } else {
-        b->cap_entries = (size_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)n_obs, 1), npm);
-        BH(hipMalloc(&b->d_entries, b->cap_entries * sizeof(isx_entry)));
+        // entries / site-level tables are sized once the window geometry is known (below)
     }
-    {   // rarefied clonality: NaN where not produced (dense positions are the same every run)
-        const size_t n = b->M == 1 ? (size_t)n_pos : b->cap_entries;
-        BH(hipMalloc(&b->d_clon_r, n * sizeof(float)));
-        BH(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, n, c->stream));
+    if (b->M == 1) {   // rarefied clonality: NaN where not produced (the positions are the same every run)
+        BH(hipMalloc(&b->d_clon_r, (size_t)n_pos * sizeof(float)));
+        BH(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)n_pos, c->stream));
     }
     b->cap_snv = (size_t)std::min<uint64_t>(npm, std::max<uint64_t>((uint64_t)n_pos / 2, 1u << 20));
     b->cap_sites = (size_t)std::min<uint64_t>((uint64_t)n_pos, std::max<uint64_t>((uint64_t)n_pos / 4, 1u << 20));
@@ -334,6 +337,18 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
             g = std::min(g, b->n_win);
             b->grid = std::max(8, (g + 7) / 8 * 8);
         }
+        if (!dense) {
+            // entry slabs: min(M, 4) levels per position fit without overflow; the rest spills
+            b->slab = (uint32_t)W * (uint32_t)std::min(b->M, 4);
+            b->cap_ovf = b->M <= 4 ? 16 : (size_t)std::max<uint64_t>(1u << 20, std::min<uint64_t>((uint64_t)n_obs, npm) / 4);
+            const uint64_t tot = (uint64_t)b->n_win * b->slab + b->cap_ovf;
+            if (tot >= 0xFFFFFFFFull) { isx_batch_destroy(b); isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_ARG; }
+            b->cap_entries = (size_t)tot;
+            BH(hipMalloc(&b->d_entries, b->cap_entries * sizeof(isx_entry)));
+            BH(hipMalloc(&b->d_win_nent, (size_t)b->n_win * sizeof(uint32_t)));
+            b->cap_slev = b->cap_sites * (size_t)std::min(b->M, 8);
+            BH(hipMalloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
+        }
         BH(hipMalloc(&b->d_win, win.size() * sizeof(uint2)));
         BH(hipMemcpyAsync(b->d_win, win.data(), win.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
         BH(hipMemcpyAsync(b->d_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
@@ -370,9 +385,9 @@ int isx_batch_run(isx_batch *b)
     a.counts = b->d_counts; a.clon = b->d_clon; a.clon_r = b->d_clon_r;
     a.min_cov_r = b->prm.rarefied_coverage;
     a.seed_lo = (uint32_t)b->prm.seed; a.seed_hi = (uint32_t)(b->prm.seed >> 32);
-    if (b->M > 1 && a.min_cov_r > 0)        // entry slots move between runs (atomic cursor): reset the whole table
-        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, b->cap_entries, s));
-    a.entries = b->d_entries; a.cap_entries = (uint32_t)std::min<size_t>(b->cap_entries, 0xFFFFFFFFu);
+    a.entries = b->d_entries; a.slab = b->slab; a.cap_ovf = (uint32_t)b->cap_ovf;
+    a.ovf0 = (uint64_t)b->n_win * b->slab; a.win_nent = b->d_win_nent;
+    a.slev = b->d_slev; a.cap_slev = (uint32_t)std::min<size_t>(b->cap_slev, 0xFFFFFFFFu);
     a.snv = b->d_snv; a.cap_snv = (uint32_t)std::min<size_t>(b->cap_snv, 0xFFFFFFFFu);
     a.sites = b->d_sites; a.cap_sites = (uint32_t)std::min<size_t>(b->cap_sites, 0xFFFFFFFFu);
     a.ao = b->d_ao; a.cap_ao = (uint32_t)std::min<size_t>(b->cap_ao, 0xFFFFFFFFu); a.enable_linkage = b->prm.enable_linkage;
@@ -387,12 +402,14 @@ int isx_batch_run(isx_batch *b)
     const uint32_t *cur = b->h_state;
     const uint32_t flags = b->h_state[CUR_N];
     if (flags & ISX_FLAG_MM_RANGE) { isx_set_error("an observation has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
+    if (b->M > 1 && cur[CUR_ENTRIES] > b->cap_ovf) { isx_set_error("entry overflow region exhausted"); return ISX_ERR_CAPACITY; }
     if (flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES | ISX_FLAG_CAP_AO)) {
         isx_set_error("output table capacity exceeded (flags " + std::to_string(flags) + ")");
         return ISX_ERR_CAPACITY;
     }
     b->sizes = isx_sizes{};
-    b->sizes.n_entries = cur[CUR_ENTRIES];
+    b->sizes.n_entries = cur[CUR_ENT_TOTAL];
+    b->n_ovf = cur[CUR_ENTRIES];
     b->sizes.n_snv = cur[CUR_SNV];
     b->sizes.n_sites = cur[CUR_SITES];
     b->tim = isx_timings{};
@@ -409,7 +426,7 @@ int isx_batch_run(isx_batch *b)
         in.philox = Philox{(uint32_t)b->prm.seed, (uint32_t)(b->prm.seed >> 32)};
         in.n_pairs = b->n_pairs; in.ao = b->d_ao; in.n_ao = cur[CUR_AO];
         in.sites = b->d_sites; in.n_sites = cur[CUR_SITES];
-        in.entries = b->d_entries; in.counts = b->d_counts;
+        in.slev = b->d_slev; in.counts = b->d_counts;
         in.split_bounds = b->d_bounds; in.n_splits = b->n_splits; in.M = b->M; in.min_snp = b->prm.min_snp;
         LinkageOut lo;
         int rc = run_linkage(in, b->L, lo);
@@ -456,25 +473,29 @@ int isx_batch_timings(const isx_batch *b, isx_timings *out)
     if (!(b)->ran) { isx_set_error("fetch: run the batch first"); return ISX_ERR_STATE; }        \
     HIP_TRY(hipSetDevice((b)->ctx->device));
 
-int isx_batch_fetch_entries(isx_batch *b, isx_entry *out, float *clon_rarefied)
+int isx_batch_fetch_entries(isx_batch *b, isx_entry *out)
 {
     NEED_RUN(b, out);
     if (b->M == 1) { isx_set_error("n_mm_bins == 1: use isx_batch_fetch_dense"); return ISX_ERR_STATE; }
     const size_t n = (size_t)b->sizes.n_entries;
     if (!n) return ISX_OK;
-    std::vector<isx_entry> raw(n);
-    std::vector<float> rawr(clon_rarefied ? n : 0);
-    HIP_TRY(hipMemcpy(raw.data(), b->d_entries, n * sizeof(isx_entry), hipMemcpyDeviceToHost));
-    if (clon_rarefied) HIP_TRY(hipMemcpy(rawr.data(), b->d_clon_r, n * sizeof(float), hipMemcpyDeviceToHost));
-    std::vector<uint32_t> perm(n);
-    for (size_t i = 0; i < n; i++) perm[i] = (uint32_t)i;
-    std::sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) {
-        return raw[x].gpos != raw[y].gpos ? raw[x].gpos < raw[y].gpos : raw[x].mm < raw[y].mm;
-    });
-    for (size_t i = 0; i < n; i++) {
-        out[i] = raw[perm[i]];
-        if (clon_rarefied) clon_rarefied[i] = rawr[perm[i]];
+    // the device table is one slab per window (used prefix = win_nent[w]) + the overflow region
+    std::vector<uint32_t> nent((size_t)b->n_win);
+    HIP_TRY(hipMemcpy(nent.data(), b->d_win_nent, nent.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const size_t total = (size_t)b->n_win * b->slab + b->n_ovf;
+    std::vector<isx_entry> raw(total);
+    HIP_TRY(hipMemcpy(raw.data(), b->d_entries, total * sizeof(isx_entry), hipMemcpyDeviceToHost));
+    size_t k = 0;
+    for (int w = 0; w < b->n_win; w++) {
+        const isx_entry *src = raw.data() + (size_t)w * b->slab;
+        for (uint32_t i = 0; i < nent[(size_t)w]; i++) { if (k < n) out[k] = src[i]; k++; }
     }
+    const isx_entry *ov = raw.data() + (size_t)b->n_win * b->slab;
+    for (uint32_t i = 0; i < b->n_ovf; i++) { if (k < n) out[k] = ov[i]; k++; }
+    if (k != n) { isx_set_error("entry table inconsistent: " + std::to_string(k) + " gathered vs " + std::to_string(n)); return ISX_ERR_STATE; }
+    std::sort(out, out + n, [](const isx_entry &x, const isx_entry &y) {
+        return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm;
+    });
     return ISX_OK;
 }
 

@@ -31,16 +31,23 @@ void isx_set_error(const std::string &msg);
 #define ISX_FLAG_CAP_LD 64u
 
 // cursors (dev_cursors[i], uint32)
-enum { CUR_ENTRIES = 0, CUR_SNV = 1, CUR_SITES = 2, CUR_AO = 3, CUR_N = 8 };
+enum { CUR_ENTRIES = 0 /* mm path: overflow entries */, CUR_SNV = 1, CUR_SITES = 2, CUR_AO = 3, CUR_SLEV = 4,
+       CUR_ENT_TOTAL = 5, CUR_N = 8 };
 
 // SNP site record: a position where update_snp_table returned anySNP (snv_utilities.py:129-133).
 // Holds what linkage needs later: the `bases` set and where the per-level counts live.
 struct isx_site {
     uint32_t gpos;
-    uint32_t entry_off;     // mm path: index of the first entry of this position; dense path: unused
-    uint16_t n_levels;      // mm path: number of entries (levels present)
+    uint32_t entry_off;     // mm path: index of the site's first isx_slev row; dense path: unused
+    uint16_t n_levels;      // mm path: number of levels present
     uint8_t mask;           // `bases` set, bit b = base b
     uint8_t pad;
+};
+
+// per-level counts of a SNP site (snv2mm2counts[pos], profile_utilities.py:266), mm path
+struct isx_slev {
+    uint16_t mm, pad;
+    uint32_t cnt[4];
 };
 
 // allele observation = one update_linked_reads append (linkage.py:281)
@@ -122,8 +129,13 @@ struct PileupArgs {
     float *clon_r;              // rarefied clonality: dense [n_pos] / mm path [cap_entries]; pre-filled with NaN
     int32_t min_cov_r;          // rarefied_coverage; <= 0 disables the rarefied output
     uint32_t seed_lo, seed_hi;
-    isx_entry *entries;         // mm path
-    uint32_t cap_entries;
+    isx_entry *entries;         // mm path: per-window slabs [n_win][slab] then the overflow region
+    uint32_t slab;              // entries per window slab
+    uint32_t cap_ovf;           // overflow capacity
+    uint64_t ovf0;              // index of the overflow region = n_win * slab
+    uint32_t *win_nent;         // [n_win] entries used in each slab
+    isx_slev *slev;             // per-level counts of the SNP sites
+    uint32_t cap_slev;
     isx_snv *snv;
     uint32_t cap_snv;
     isx_site *sites;

@@ -44,7 +44,7 @@ struct LinkageIn {
     uint32_t n_ao;
     const isx_site *sites;      // unsorted, from k_pileup_call
     uint32_t n_sites;
-    const isx_entry *entries;   // mm path
+    const isx_slev *slev;       // mm path: per-level counts of the SNP sites
     const uint4 *counts;        // dense path
     const int64_t *split_bounds;
     int n_splits;

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_pair_incr(const isx_ao *ao, uint32_t n,
 // cumulative counts over levels <= mm at a SNP site (mm_counts_to_counts on snv2mm2counts[p])
 struct SiteView {
     const isx_site *sites;
-    const isx_entry *entries;   // mm path
+    const isx_slev *slev;       // mm path: per-level counts of the sites
     const uint4 *counts;        // dense path
     int dense;
 };
@@ -131,7 +131,7 @@ __device__ __forceinline__ void site_cum(const SiteView &v, uint32_t s, uint32_t
     out[0] = out[1] = out[2] = out[3] = 0;
     has_mm = false;
     for (uint32_t k = 0; k < st.n_levels; k++) {
-        const isx_entry e = v.entries[st.entry_off + k];
+        const isx_slev e = v.slev[st.entry_off + k];
         if (e.mm == mm) has_mm = true;
         if (e.mm <= mm) { out[0] += e.cnt[0]; out[1] += e.cnt[1]; out[2] += e.cnt[2]; out[3] += e.cnt[3]; }
     }
@@ -621,7 +621,7 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     const int sb = bits_for(n_sites);
     if ((rc = ensure(B.rows_per, n_u)) || (rc = ensure(B.row_off, (size_t)n_u + 1))) return rc;
     HIP_TRY(hipMemsetAsync(B.n_runs.p + 1, 0, 4, s));
-    SiteView v{B.sites_sorted.p, in.entries, in.counts, in.M == 1 ? 1 : 0};
+    SiteView v{B.sites_sorted.p, in.slev, in.counts, in.M == 1 ? 1 : 0};
     hipLaunchKernelGGL(k_ld_rows<false>, dim3((n_u + 255) / 256), dim3(256), 0, s, B.ukeys.p, B.ucnt.p, n_u, v,
                        in.min_snp, B.rows_per.p, nullptr, nullptr, B.n_runs.p + 1, in.philox, sb);
     uint64_t n_ld = 0;

@@ -46,7 +46,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define THR_LDS 1024        // coverages below this read their folded threshold from LDS
 
 // scratch words (LDS)
-enum { S_NQ = 0, S_ROWS, S_SITES, S_ROW_BASE, S_SITE_BASE, S_ROW_RANK, S_NAO, S_AO_BASE, S_ENT_TOT, S_ENT_BASE, S_N = 16 };
+enum { S_NQ = 0, S_ROWS, S_SITES, S_ROW_BASE, S_SITE_BASE, S_ROW_RANK, S_NAO, S_AO_BASE, S_ENT_TOT, S_ENT_BASE, S_SLEV, S_SLEV_BASE, S_N = 16 };
 
 __device__ __forceinline__ int argmax4(const uint32_t *c)
 {
@@ -429,6 +429,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 
     u32x4 v[4];
     uint32_t lo = 0, hi = 0;
+    uint32_t my_entries = 0;                    // thread 0: entries of all windows of this workgroup
     auto issue = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -489,38 +490,21 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         __syncthreads();
         if (!linkage) prefetch_window(w + grid);
         const int dbg = a.debug_mode;           // ablation switches (tools/ablate_mm.py), 0 in production
+        const uint32_t CW = (uint32_t)a.slab;   // entry slab of this window: [w * CW, (w + 1) * CW)
+        const uint64_t slab0 = (uint64_t)w * CW;
+        const int lane = tid & 63;
 
-        // ---- entry slots: count the present levels, one global atomic per window ----
-        uint32_t e_off[2] = {0, 0};
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int p = tid + j * nthr;
-            if (p < W && w0 + p < a.n_pos && !(dbg & 2)) {
-                uint32_t n = 0;
-                for (int m = 0; m < M; m++) {
-                    const uint32_t any = PACKED ? (cnt[(m * 2) * W + p] | cnt[(m * 2 + 1) * W + p])
-                                                : (cnt[(m * 4) * W + p] | cnt[(m * 4 + 1) * W + p] | cnt[(m * 4 + 2) * W + p] | cnt[(m * 4 + 3) * W + p]);
-                    n += (any | ((pres[(m >> 5) * W + p] >> (m & 31)) & 1u)) ? 1u : 0u;
-                }
-                if (n) e_off[j] = atomicAdd(&scratch[S_ENT_TOT], n);
-            }
-        }
-        __syncthreads();
-        const uint32_t n_ent = scratch[S_ENT_TOT];
-        if (tid == 0 && n_ent) scratch[S_ENT_BASE] = atomicAdd(&a.cursors[CUR_ENTRIES], n_ent);
-        __syncthreads();
-        const uint32_t ent_base = scratch[S_ENT_BASE];
-        bool ok = true;
-        if (ent_base + n_ent > a.cap_entries) { if (tid == 0) atomicOr(a.flags, ISX_FLAG_CAP_ENTRIES); ok = false; }
-
-        // ---- update_snp_table's `for mm in sorted(MMcounts)`; up to two positions per lane ----
-        // mode 0: entries + clonality, and sizes rows / sites / hits (positions with rows go to rowq);
-        // mode 1 (rare, queued positions only): write the SNV rows
-        auto levels = [&](int p, uint32_t gpos, uint32_t e0, int mode, uint32_t row_at, uint32_t cry_in, uint32_t &out_rows,
-                          uint32_t &out_any, uint32_t &out_cry, uint32_t &out_mask, uint32_t &out_nlev, uint32_t &out_hits) {
+        // ---- update_snp_table's `for mm in sorted(MMcounts)`, level-major across the wave ----
+        // Every lane owns a position; all lanes walk the mm levels together, so the entries of one
+        // level are ballot-compacted into CONSECUTIVE slots of the window's slab (coalesced 32-byte
+        // entry stores, no per-position entry count pass, no global atomic).  Positions with SNV rows
+        // (rare) go to the row queue and are finished after the window-level allocations.
+        uint32_t *rowq = queue + 2 * QCAP;      // [rqcap][4]: p | any<<16 | cry<<17 | mask<<20, row off, site off | nlev<<24, slev off
+        // mode 1 (rare, queued positions only): write the SNV rows and the site's level rows
+        auto emit_rows = [&](int p, uint32_t gpos, uint32_t row_at, uint32_t cry_in, uint32_t slev_at) {
             const int ref_base = a.ref[gpos];
             uint32_t cum[4] = {0, 0, 0, 0};
-            uint32_t any = 0, cry = 0, rows = 0, nlev = 0, mask = 0;
+            uint32_t rows = 0, nl = 0;
             for (int m = 0; m < M; m++) {
                 uint32_t l[4];
 #pragma unroll
@@ -528,48 +512,90 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                 const uint32_t present = l[0] | l[1] | l[2] | l[3] | ((pres[(m >> 5) * W + p] >> (m & 31)) & 1u);
                 if (!present) continue;
 #pragma unroll
+                for (int k = 0; k < 4; k++) cum[k] += l[k];
+                if (slev_at != 0xFFFFFFFFu) {
+                    isx_slev sl;
+                    sl.mm = (uint16_t)m; sl.pad = 0;
+                    sl.cnt[0] = l[0]; sl.cnt[1] = l[1]; sl.cnt[2] = l[2]; sl.cnt[3] = l[3];
+                    a.slev[slev_at + nl] = sl;
+                }
+                nl++;
+                const uint32_t total = cum[0] + cum[1] + cum[2] + cum[3];
+                const SiteCall sc = call_level(a, thr_lds, cum, total, ref_base, true);
+                if (sc.snp < 0) continue;
+                isx_snv r;
+                r.gpos = gpos; r.mm = (uint16_t)m;
+                r.con_base = (uint8_t)sc.snp; r.var_base = (uint8_t)sc.var;
+                r.allele_count = (uint8_t)sc.morphia; r.cls = (uint8_t)sc.cls;
+                r.cryptic = (uint8_t)cry_in;                        // position-level flag (p2c map)
+                r.ref_base = (uint8_t)ref_base;
+                r.cnt[0] = cum[0]; r.cnt[1] = cum[1]; r.cnt[2] = cum[2]; r.cnt[3] = cum[3];
+                a.snv[row_at + rows] = r;
+                rows++;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int p = tid + j * nthr;
+            const uint32_t gpos = w0 + p;
+            const bool valid = p < W && gpos < a.n_pos && !(dbg & 2);
+            const int ref_base = valid ? (int)a.ref[gpos] : 4;
+            uint32_t cum[4] = {0, 0, 0, 0};
+            uint32_t any = 0, cry = 0, rows = 0, nlev = 0, mask = 0;
+            for (int m = 0; m < M; m++) {
+                uint32_t l[4] = {0, 0, 0, 0};
+                bool present = false;
+                if (valid) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) l[k] = rd(m, k, p);
+                    present = (l[0] | l[1] | l[2] | l[3] | ((pres[(m >> 5) * W + p] >> (m & 31)) & 1u)) != 0;
+                }
+                const unsigned long long bal = __ballot(present);
+                if (bal == 0) continue;                             // wave-uniform
+                uint32_t wbase = 0;
+                const int first = __ffsll((long long)bal) - 1;
+                if (lane == first) wbase = atomicAdd(&scratch[S_ENT_TOT], (uint32_t)__popcll(bal));
+                wbase = __shfl(wbase, first);
+                if (!present) continue;
+                const uint32_t slot_w = wbase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                uint64_t ei;
+                if (slot_w < CW) ei = slab0 + slot_w;
+                else {                                              // slab full (more than CW / W levels per position on average)
+                    const uint32_t o = atomicAdd(&a.cursors[CUR_ENTRIES], 1u);
+                    if (o >= a.cap_ovf) { atomicOr(a.flags, ISX_FLAG_CAP_ENTRIES); continue; }
+                    ei = a.ovf0 + o;
+                }
+#pragma unroll
                 for (int k = 0; k < 4; k++) cum[k] += l[k];         // mm_counts_to_counts(MMcounts, mm)
                 const uint32_t total = cum[0] + cum[1] + cum[2] + cum[3];
-                const SiteCall sc = call_level(a, thr_lds, cum, total, ref_base, mode == 1);
-                if (mode == 0) {
-                    const uint32_t ei = ent_base + e0 + nlev;
-                    float cl = __builtin_nanf("");
-                    const bool want_r = a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r;
-                    bool want_c = false;
-                    if ((int64_t)total >= (int64_t)a.min_cov) {
-                        const uint32_t mx = max(max(cum[0], cum[1]), max(cum[2], cum[3]));
-                        if (mx == total) cl = 1.0f;                 // (s/s)^2 + 0 + 0 + 0
-                        else want_c = true;
+                const SiteCall sc = call_level(a, thr_lds, cum, total, ref_base, false);
+                float cl = __builtin_nanf("");
+                const bool want_r = a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r;
+                bool want_c = false;
+                if ((int64_t)total >= (int64_t)a.min_cov) {
+                    const uint32_t mx = max(max(cum[0], cum[1]), max(cum[2], cum[3]));
+                    if (mx == total) cl = 1.0f;                     // (s/s)^2 + 0 + 0 + 0
+                    else want_c = true;
+                }
+                float clr = __builtin_nanf("");
+                if (want_c || want_r) {
+                    const uint32_t qs = atomicAdd(&scratch[S_NQ], 1u);
+                    if (qs < QCAP && ei < 0xFFFFFFFFull) {
+                        queue[qs * 2 + 0] = (uint32_t)ei;
+                        queue[qs * 2 + 1] = ((uint32_t)m << 16) | (uint32_t)p | (want_c ? 1u << 30 : 0u) | (want_r ? 1u << 31 : 0u);
+                    } else {                                        // queue full: inline
+                        if (want_c) cl = (float)clonality(cum, total);
+                        if (want_r) clr = rarefied_clonality(a, cum, gpos, (uint32_t)m);
                     }
-                    if (want_c || want_r) {
-                        const uint32_t qs = atomicAdd(&scratch[S_NQ], 1u);
-                        if (qs < QCAP) {
-                            queue[qs * 2 + 0] = ei;
-                            queue[qs * 2 + 1] = ((uint32_t)m << 16) | (uint32_t)p | (want_c ? 1u << 30 : 0u) | (want_r ? 1u << 31 : 0u);
-                        } else {                                    // queue full: inline
-                            if (want_c) cl = (float)clonality(cum, total);
-                            if (want_r) a.clon_r[ei] = rarefied_clonality(a, cum, gpos, (uint32_t)m);
-                        }
-                    }
-                    isx_entry e;
-                    e.gpos = gpos; e.mm = (uint16_t)m; e.flags = 0;
-                    e.cnt[0] = l[0]; e.cnt[1] = l[1]; e.cnt[2] = l[2]; e.cnt[3] = l[3];
-                    e.clon = cl;
-                    if (!(a.debug_mode & 64)) a.entries[ei] = e;
+                }
+                if (!(dbg & 64)) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(&a.entries[ei]);
+                    dst[0] = make_uint4(gpos, (uint32_t)m, l[0], l[1]);                     // gpos | mm,flags | cnt[0..1]
+                    dst[1] = make_uint4(l[2], l[3], __float_as_uint(cl), __float_as_uint(clr));
                 }
                 nlev++;
                 if (sc.snp == -2) continue;
                 if (sc.snp != -1) {
-                    if (mode == 1) {
-                        isx_snv r;
-                        r.gpos = gpos; r.mm = (uint16_t)m;
-                        r.con_base = (uint8_t)sc.snp; r.var_base = (uint8_t)sc.var;
-                        r.allele_count = (uint8_t)sc.morphia; r.cls = (uint8_t)sc.cls;
-                        r.cryptic = (uint8_t)cry_in;                // position-level flag from mode 0 (p2c map)
-                        r.ref_base = (uint8_t)ref_base;
-                        r.cnt[0] = cum[0]; r.cnt[1] = cum[1]; r.cnt[2] = cum[2]; r.cnt[3] = cum[3];
-                        a.snv[row_at + rows] = r;
-                    }
                     rows++;
                     if (sc.morphia >= 2) { any = 1; mask |= (1u << sc.snp) | (1u << sc.var); }
                     else if (sc.morphia == 1 && any) cry = 1;
@@ -577,59 +603,51 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                     cry = 1;
                 }
             }
-            out_rows = rows; out_any = any; out_cry = cry; out_mask = mask; out_nlev = nlev;
-            out_hits = any ? masked_sum(cum, mask) : 0u;            // cum == counts over ALL levels here
-        };
-        // row queue (positions with SNV rows; rare): rowq[4 * i] = p | any << 16 | cry << 17 | mask << 20,
-        // row offset, site offset, entry offset | nlev << 24 ... kept in 4 words per entry
-        uint32_t *rowq = queue + 2 * QCAP;
-        if (ok && !(dbg & 130)) {
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int p = tid + j * nthr;
-                if (p < W && w0 + p < a.n_pos) {
-                    uint32_t rows, any, cry, mask, nlev, hits;
-                    levels(p, w0 + p, e_off[j], 0, 0, 0, rows, any, cry, mask, nlev, hits);
-                    if (rows) {
-                        if (any && linkage) {
-                            maskl[p] = (uint8_t)mask;
-                            slabc[p] = atomicAdd(&scratch[S_NAO], hits);
-                        }
-                        const uint32_t qi = atomicAdd(&scratch[S_ROW_RANK], 1u);
-                        if (qi < (uint32_t)a.rqcap) {
-                            const uint32_t r_off = atomicAdd(&scratch[S_ROWS], rows);
-                            const uint32_t s_off = any ? atomicAdd(&scratch[S_SITES], 1u) : 0u;
-                            rowq[qi * 4 + 0] = (uint32_t)p | (any << 16) | (cry << 17) | (mask << 20);
-                            rowq[qi * 4 + 1] = r_off;
-                            rowq[qi * 4 + 2] = s_off;
-                            rowq[qi * 4 + 3] = e_off[j] | (nlev << 24);
-                        } else {                                    // row queue full: this position allocates by itself
-                            const uint32_t row_at = atomicAdd(&a.cursors[CUR_SNV], rows);
-                            if (row_at + rows > a.cap_snv) atomicOr(a.flags, ISX_FLAG_CAP_SNV);
-                            else {
-                                uint32_t r1, r2, r3, r4, r5, r6;
-                                levels(p, w0 + p, 0, 1, row_at, cry, r1, r2, r3, r4, r5, r6);
-                            }
-                            if (any) {
-                                const uint32_t sa = atomicAdd(&a.cursors[CUR_SITES], 1u);
-                                if (sa >= a.cap_sites) atomicOr(a.flags, ISX_FLAG_CAP_SITES);
-                                else {
-                                    isx_site ss;
-                                    ss.gpos = w0 + p; ss.entry_off = ent_base + e_off[j]; ss.n_levels = (uint16_t)nlev;
-                                    ss.mask = (uint8_t)mask; ss.pad = 0;
-                                    a.sites[sa] = ss;
-                                }
-                            }
+            if (rows) {
+                if (any && linkage) {                               // cum == counts over ALL levels here
+                    maskl[p] = (uint8_t)mask;
+                    slabc[p] = atomicAdd(&scratch[S_NAO], masked_sum(cum, mask));
+                }
+                const uint32_t qi = atomicAdd(&scratch[S_ROW_RANK], 1u);
+                if (qi < (uint32_t)a.rqcap) {
+                    const uint32_t r_off = atomicAdd(&scratch[S_ROWS], rows);
+                    const uint32_t s_off = any ? atomicAdd(&scratch[S_SITES], 1u) : 0u;
+                    const uint32_t v_off = any ? atomicAdd(&scratch[S_SLEV], nlev) : 0u;
+                    rowq[qi * 4 + 0] = (uint32_t)p | (any << 16) | (cry << 17) | (mask << 20);
+                    rowq[qi * 4 + 1] = r_off;
+                    rowq[qi * 4 + 2] = s_off | (nlev << 24);
+                    rowq[qi * 4 + 3] = v_off;
+                } else {                                            // row queue full: this position allocates by itself
+                    const uint32_t row_at = atomicAdd(&a.cursors[CUR_SNV], rows);
+                    uint32_t slev_at = 0xFFFFFFFFu;
+                    bool fine = row_at + rows <= a.cap_snv;
+                    if (!fine) atomicOr(a.flags, ISX_FLAG_CAP_SNV);
+                    if (any && fine) {
+                        const uint32_t sa = atomicAdd(&a.cursors[CUR_SITES], 1u);
+                        slev_at = atomicAdd(&a.cursors[CUR_SLEV], nlev);
+                        if (sa >= a.cap_sites || slev_at + nlev > a.cap_slev) { atomicOr(a.flags, ISX_FLAG_CAP_SITES); fine = false; }
+                        else {
+                            isx_site ss;
+                            ss.gpos = gpos; ss.entry_off = slev_at; ss.n_levels = (uint16_t)nlev;
+                            ss.mask = (uint8_t)mask; ss.pad = 0;
+                            a.sites[sa] = ss;
                         }
                     }
+                    if (fine) emit_rows(p, gpos, row_at, cry, slev_at);
                 }
             }
         }
         __syncthreads();
-        const uint32_t nrows = scratch[S_ROWS], nsites = scratch[S_SITES], nao = scratch[S_NAO], nrq = scratch[S_ROW_RANK];
+        const uint32_t n_ent = scratch[S_ENT_TOT], nrows = scratch[S_ROWS], nsites = scratch[S_SITES], nao = scratch[S_NAO],
+                       nslev = scratch[S_SLEV], nrq = min(scratch[S_ROW_RANK], (uint32_t)a.rqcap);
+        if (tid == 0) {
+            a.win_nent[w] = min(n_ent, CW);
+            my_entries += n_ent;                                    // per-workgroup total, published once at the end
+        }
         if (tid == 64 && nrows) scratch[S_ROW_BASE] = atomicAdd(&a.cursors[CUR_SNV], nrows);
         if (tid == 128 && nsites) scratch[S_SITE_BASE] = atomicAdd(&a.cursors[CUR_SITES], nsites);
         if (tid == 192 && nao) scratch[S_AO_BASE] = atomicAdd(&a.cursors[CUR_AO], nao);
+        if (tid == 256 % nthr && nslev) scratch[S_SLEV_BASE] = atomicAdd(&a.cursors[CUR_SLEV], nslev);
         // ---- deferred clonalities: calculate_clonality (snv_utilities.py:225-231) in fp64, densely packed ----
         const uint32_t nq = min(scratch[S_NQ], QCAP);
         for (uint32_t q = tid; q < nq; q += nthr) {
@@ -641,28 +659,31 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                 for (int k = 0; k < 4; k++) c[k] += rd(m, k, p);
             }
             if (pm & (1u << 30)) a.entries[queue[q * 2]].clon = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
-            if (pm & (1u << 31)) a.clon_r[queue[q * 2]] = rarefied_clonality(a, c, w0 + p, (uint32_t)mq);
+            if (pm & (1u << 31)) a.entries[queue[q * 2]].clon_rarefied = rarefied_clonality(a, c, w0 + p, (uint32_t)mq);
         }
         if (nrows) __syncthreads();             // uniform: bases from the atomics above
-        const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE], ao_base = scratch[S_AO_BASE];
-        if (ok && nrows && (row_base + nrows > a.cap_snv || site_base + nsites > a.cap_sites || ao_base + nao > a.cap_ao)) {
+        const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE], ao_base = scratch[S_AO_BASE],
+                       slev_base = scratch[S_SLEV_BASE];
+        bool ok = true;
+        if (nrows && (row_base + nrows > a.cap_snv || site_base + nsites > a.cap_sites || ao_base + nao > a.cap_ao ||
+                      slev_base + nslev > a.cap_slev)) {
             if (tid == 0) atomicOr(a.flags, row_base + nrows > a.cap_snv ? ISX_FLAG_CAP_SNV
-                                            : site_base + nsites > a.cap_sites ? ISX_FLAG_CAP_SITES : ISX_FLAG_CAP_AO);
+                                            : ao_base + nao > a.cap_ao ? ISX_FLAG_CAP_AO : ISX_FLAG_CAP_SITES);
             ok = false;
         }
         // ---- SNV rows / SNP sites of the queued positions (snv_utilities.py:107-133) ----
-        for (uint32_t q = tid; q < (ok ? min(nrq, (uint32_t)a.rqcap) : 0u); q += nthr) {
+        for (uint32_t q = tid; q < (ok ? nrq : 0u); q += nthr) {
             const uint32_t w0q = rowq[q * 4 + 0];
             const int p = (int)(w0q & 0xFFFFu);
             const uint32_t any = (w0q >> 16) & 1u, cry = (w0q >> 17) & 1u, mask = (w0q >> 20) & 0xFu;
-            uint32_t r1, r2, r3, r4, r5, r6;
-            levels(p, w0 + p, 0, 1, row_base + rowq[q * 4 + 1], cry, r1, r2, r3, r4, r5, r6);
+            const uint32_t slev_at = any ? slev_base + rowq[q * 4 + 3] : 0xFFFFFFFFu;
+            emit_rows(p, w0 + p, row_base + rowq[q * 4 + 1], cry, slev_at);
             if (any) {
                 isx_site ss;
-                ss.gpos = w0 + p; ss.entry_off = ent_base + (rowq[q * 4 + 3] & 0xFFFFFFu);
-                ss.n_levels = (uint16_t)(rowq[q * 4 + 3] >> 24);
+                ss.gpos = w0 + p; ss.entry_off = slev_at;
+                ss.n_levels = (uint16_t)(rowq[q * 4 + 2] >> 24);
                 ss.mask = (uint8_t)mask; ss.pad = 0;
-                a.sites[site_base + rowq[q * 4 + 2]] = ss;
+                a.sites[site_base + (rowq[q * 4 + 2] & 0xFFFFFFu)] = ss;
             }
         }
         if (linkage) {
@@ -671,6 +692,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         }
         __syncthreads();
     }
+    if (tid == 0 && my_entries) atomicAdd(&a.cursors[CUR_ENT_TOTAL], my_entries);
 }
 
 }  // namespace

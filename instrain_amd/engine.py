@@ -103,10 +103,9 @@ class Batch:
             out["counts"], out["clon"], out["clon_r"] = counts, clon, clon_r
         else:
             e = np.empty(max(1, s["n_entries"]), dtype=ENTRY_DT)
-            cr = np.empty(max(1, s["n_entries"]), dtype=np.float32)
-            check(self.lib.isx_batch_fetch_entries(self.h, e.ctypes.data, cr.ctypes.data))
+            check(self.lib.isx_batch_fetch_entries(self.h, e.ctypes.data))
             out["entries"] = e[:s["n_entries"]]
-            out["clon_r"] = cr[:s["n_entries"]]
+            out["clon_r"] = out["entries"]["clon_rarefied"]
         v = np.empty(max(1, s["n_snv"]), dtype=SNV_DT)
         check(self.lib.isx_batch_fetch_snv(self.h, v.ctypes.data))
         out["snv"] = v[:s["n_snv"]]
@@ -135,6 +134,7 @@ def dense_to_entries(counts, clon):
     e["gpos"] = k
     e["cnt"] = counts[k]
     e["clon"] = clon[k]
+    e["clon_rarefied"] = np.nan
     return e
 
 
