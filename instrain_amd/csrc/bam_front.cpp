@@ -374,12 +374,15 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
     // ---- get_paired_reads per scaffold (filter_reads.py:885-956) ----
     std::vector<std::unordered_map<std::string_view, uint32_t>> idx(n_ref);
     std::vector<PairInfo> pinfo;
-    std::vector<int32_t> read_pi(B.reads.size(), -1);
+    std::vector<int32_t> read_pi(B.reads.size(), -1);      // read -> index of its (scaffold, name) entry
+    std::vector<RefSpan> spans(B.reads.size());
+    for (size_t t = 0; t < n_ref; t++) idx[t].reserve(1024);
     for (size_t ri = 0; ri < B.reads.size(); ri++) {
         const Read &r = B.reads[ri];
         if (r.tid < 0 || (size_t)r.tid >= n_ref) continue;
+        spans[ri] = span_of(B, r);
         if (r.flag & FUNMAP) continue;
-        const RefSpan s = span_of(B, r);
+        const RefSpan &s = spans[ri];
         if (!s.any) continue;                       // get_reference_positions() == []
         if (!r.has_nm) { isx_set_error("read without NM tag: " + std::string(name_of(r))); return ISX_ERR_IO; }
         auto &m = idx[(size_t)r.tid];
@@ -434,19 +437,26 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
 
     // ---- overlap_push in file order (htslib-1.9 rule |isize| < 2*l_qseq) ----
     {
-        std::vector<std::unordered_map<std::string_view, size_t>> H(n_ref);
+        std::vector<int64_t> pending(pinfo.size(), -1);     // per (scaffold, name): read waiting for its mate
         for (size_t ri = 0; ri < B.reads.size(); ri++) {
             const Read &r = B.reads[ri];
             if (r.tid < 0 || (size_t)r.tid >= n_ref || (r.flag & DEF_MASK)) continue;
             if ((r.flag & FMUNMAP) || !(r.flag & FPROPER)) continue;
             if (std::abs((int64_t)r.isize) >= 2 * (int64_t)r.l_seq) continue;
-            auto &h = H[(size_t)r.tid];
-            auto it = h.find(name_of(r));
-            if (it != h.end() && span_of(B, B.reads[it->second]).end <= r.pos) { h.erase(it); it = h.end(); }
-            if (it == h.end()) h.emplace(name_of(r), ri);
+            int32_t pi = read_pi[ri];
+            if (pi < 0) {                                   // aligned-base-free read: still hashed by name in htslib
+                auto &m = idx[(size_t)r.tid];
+                auto it = m.find(name_of(r));
+                if (it == m.end()) { m.emplace(name_of(r), (uint32_t)pinfo.size()); pi = (int32_t)pinfo.size();
+                                     pinfo.push_back(PairInfo{0, -1, 0, 0, 0, 0, 0, false, 0}); pending.push_back(-1); }
+                else pi = (int32_t)it->second;
+            }
+            int64_t &slot = pending[(size_t)pi];
+            if (slot >= 0 && spans[(size_t)slot].end <= r.pos) slot = -1;    // earlier read already left the buffer
+            if (slot < 0) slot = (int64_t)ri;
             else {
-                const size_t ai = it->second;
-                h.erase(it);
+                const size_t ai = (size_t)slot;
+                slot = -1;
                 tweak_overlap(B, B.reads[ai], r);
             }
         }
@@ -455,34 +465,41 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
     // ---- expansion: the visits on which get_base_counts_mm touches `table` ----
     uint32_t next_pair = 0;
     for (PairInfo &i : pinfo) i.pair_id = 0xFFFFFFFFu;
-    B.obs.clear(); B.pair.clear();
+    size_t max_obs = 0;
+    for (size_t ri = 0; ri < B.reads.size(); ri++) {
+        const int32_t pi = read_pi[ri];
+        if (pi >= 0 && pinfo[(size_t)pi].pass && !(B.reads[ri].flag & DEF_MASK)) max_obs += (size_t)B.reads[ri].l_seq;
+    }
+    B.obs.resize(max_obs); B.pair.resize(max_obs);
+    isx_obs *po = B.obs.data();
+    uint32_t *pp = B.pair.data();
+    size_t n_out = 0;
+    const uint8_t minq = (uint8_t)std::min(255, std::max(0, p->min_base_quality));
     for (size_t ri = 0; ri < B.reads.size(); ri++) {
         const Read &r = B.reads[ri];
         if (r.tid < 0 || (size_t)r.tid >= n_ref || (r.flag & DEF_MASK)) continue;
         // R2M membership is by NAME on this scaffold (get_base_counts_mm looks up query_name)
-        auto &m = idx[(size_t)r.tid];
-        auto it = m.find(name_of(r));
-        if (it == m.end()) continue;
-        PairInfo &pi = pinfo[it->second];
+        const int32_t pidx = read_pi[ri];
+        if (pidx < 0) continue;
+        PairInfo &pi = pinfo[(size_t)pidx];
         if (!pi.pass) continue;
         if (pi.pair_id == 0xFFFFFFFFu) pi.pair_id = next_pair++;
         const uint16_t mm = p->skip_mm ? 0 : (uint16_t)pi.nm;
         const int64_t base_off = B.ref_off[(size_t)r.tid];
+        const uint8_t *ql = B.quals.data() + r.qual_off, *sq = B.seqs.data() + r.seq_off;
         int64_t ref = r.pos, q = 0;
         for (int k = 0; k < r.n_cigar; k++) {
             const uint32_t c = B.cigars[r.cigar_off + k];
             const int op = c & 15;
             const int64_t n = c >> 4;
             if (op == CM || op == CEQ || op == CX) {
+                const uint32_t g0 = (uint32_t)(base_off + ref);
                 for (int64_t j = 0; j < n; j++) {
-                    if (B.quals[r.qual_off + q + j] >= p->min_base_quality) {
-                        isx_obs o;
-                        o.gpos = (uint32_t)(base_off + ref + j);
-                        o.mm = mm;
-                        o.base = CODE2IDX[B.seqs[r.seq_off + q + j]];
-                        o.flags = 0;
-                        B.obs.push_back(o);
-                        B.pair.push_back(pi.pair_id);
+                    if (ql[q + j] >= minq) {
+                        isx_obs &o = po[n_out];
+                        o.gpos = g0 + (uint32_t)j; o.mm = mm; o.base = CODE2IDX[sq[q + j]]; o.flags = 0;
+                        pp[n_out] = pi.pair_id;
+                        n_out++;
                     }
                 }
                 q += n; ref += n;
@@ -490,6 +507,7 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
             else if (op == CD || op == CN) ref += n;
         }
     }
+    B.obs.resize(n_out); B.pair.resize(n_out);
 
     // ---- iterate_splits (fasta.py:56-73) on the flat space ----
     B.split_bounds.clear(); B.split_ref.clear();

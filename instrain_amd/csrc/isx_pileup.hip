@@ -331,11 +331,19 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         // ---- deferred clonalities (snv_utilities.py:225-231), densely packed ----
         for (uint32_t q = tid; q < nq; q += nthr) {
             const uint32_t e = queue[q];
-            if (!(e & ((1u << 13) | (1u << 15)))) continue;
+            if (!(e & (1u << 13))) continue;
             const int p = (int)(e & 0x1FFFu);
             const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
-            if (e & (1u << 13)) a.clon[w0 + p] = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
-            if (e & (1u << 15)) a.clon_r[w0 + p] = rarefied_clonality(a, c, w0 + p, 0);
+            a.clon[w0 + p] = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+        }
+        if (a.min_cov_r > 0) {                  // rarefied clonality (snv_utilities.py:233-247), own loop: fewer live registers
+            for (uint32_t q = tid; q < nq; q += nthr) {
+                const uint32_t e = queue[q];
+                if (!(e & (1u << 15))) continue;
+                const int p = (int)(e & 0x1FFFu);
+                const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
+                a.clon_r[w0 + p] = rarefied_clonality(a, c, w0 + p, 0);
+            }
         }
         if (nrows) __syncthreads();             // uniform: scratch bases from the atomics above
         // ---- SNV rows / SNP sites (snv_utilities.py:107-133) ----

@@ -237,3 +237,47 @@ def test_dense_mode_needs_single_mm_bin(ctx):
                      linkage_mode=2)
     b.run()          # no SNP sites -> nothing to refuse yet; the mode check sits behind the first site
     b.close()
+
+
+@pytest.mark.parametrize("n_mm", [1, 5])
+def test_divergent_reference_rows_everywhere(ctx, n_mm):
+    """every position differs from the reference (SNS rows at each covered position): overflows the
+    per-window row queue of the mm kernel and stresses row allocation of both kernels"""
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    seq, pos, base, mm, pair = _random_split(301, 2500, 40, n_mm, 60)
+    rot = {"A": "C", "C": "T", "T": "G", "G": "A", "N": "N"}
+    seq2 = "".join(rot[c] for c in seq)                      # a reference that matches (almost) nowhere
+    exp = oracle.profile_split(pos, base, mm, pair, seq2, 0, lut, fb)
+    assert len(exp["snv"]) > 2000
+    got = prod.run_split(ctx, pos, base, mm, pair, seq2, 0, n_mm_bins=n_mm)
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="divergent")
+
+
+def test_unpacked_counter_variant(ctx, monkeypatch):
+    """the u32-counter variant of the mm kernel (taken automatically when a window streams >= 65536
+    records) forced through ISX_NO_PACKED, against the same golden vectors"""
+    from tests import prod
+    monkeypatch.setenv("ISX_NO_PACKED", "1")
+    for name in ("synth_mm4", "synth_dense", "synth_selfpairs"):
+        g = util.load_case(name)
+        res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), **_params(g))
+        util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name + "-u32")
+
+
+def test_deep_window_takes_unpacked_automatically(ctx):
+    """> 65535 records in one window: the packed variant is illegal; counts stay exact"""
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    n = 140000
+    rng = np.random.Generator(np.random.PCG64(5))
+    pos = rng.integers(0, 3, n)                              # three very deep columns
+    base = rng.choice(4, n, p=[0.55, 0.25, 0.15, 0.05]).astype(np.uint8)
+    mm = rng.integers(0, 3, n)
+    pair = np.arange(n)
+    exp = oracle.profile_split(pos, base, mm, pair, "AAAC", 0, lut, fb)
+    got = prod.run_split(ctx, pos, base, mm, pair, "AAAC", 0, n_mm_bins=3)
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="deep")
+    assert got["entries"]["cnt"].sum() == n

@@ -10,12 +10,12 @@ ctx = engine.Context(0)
 lut, fb = util.load_lut()
 ctx.set_null_model(lut, fb)
 w = bench.c2_workload(2, scale=float(os.environ.get("SCALE", "1.0")), with_mm=True)
-for env in ({"ISX_BLOCK": "512"},):
+for env in ({"ISX_BLOCK": "512"}, {"ISX_BLOCK": "1024"}, {"ISX_BLOCK": "256"}, {"ISX_BLOCK": "512", "ISX_NO_PACKED": "1"}):
     for k in ("ISX_NO_PACKED", "ISX_BLOCK"):
         os.environ.pop(k, None)
     os.environ.update(env)
     b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs_mm"], None, n_mm_bins=w["n_mm_bins_mm"], enable_linkage=False)
-    for mode, name in ((0, "full"), (64, "no entry stores"), (128, "stream+count"), (2, "stream only")):
+    for mode, name in ((0, "full"), (2, "stream only")):
         os.environ["ISX_DEBUG_MODE"] = str(mode)
         ts = []
         for i in range(12):
