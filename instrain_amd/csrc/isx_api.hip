@@ -214,8 +214,21 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     auto window_for = [&](bool packed) -> int {
         if (prm->window > 0) return prm->window;
         if (dense) {
-            const int64_t w = (n_pos / 1024 + 63) / 64 * 64;
-            return (int)std::min<int64_t>(2560, std::max<int64_t>(512, w));
+            // small batches: every CU should still own >= 2 windows
+            const int64_t wsmall = (n_pos / 1024 + 63) / 64 * 64;
+            if (wsmall < 2048) return (int)std::max<int64_t>(512, wsmall);
+            // otherwise the multiple of 64 in [2048, 3904] (two 1024-lane workgroups per CU fit their LDS)
+            // that wastes least: whole rounds of the 512 persistent workgroups x stream over-scan of a
+            // window (~ one read length + one directory chunk on each side)
+            int best = 2560;
+            double best_eff = 0.0;
+            for (int w = 2048; w <= 3904; w += 64) {
+                const double n_win = std::ceil((double)n_pos / w);
+                const double rounds = n_win / 512.0;
+                const double eff = rounds / std::ceil(rounds) * (w / (w + 200.0));
+                if (eff > best_eff + 1e-9) { best_eff = eff; best = w; }
+            }
+            return best;
         }
         const int bytes_per_pos = b->M * (packed ? 8 : 16) + ((b->M + 31) / 32) * 4 + 5;
         const int wmax = ((78 * 1024 - 8 * b->qcap - 8192 - 2048 - 256) / bytes_per_pos) / 64 * 64;

@@ -15,7 +15,7 @@ ctx.set_null_model(lut, fb)
 scale = float(os.environ.get("SCALE", "1.0"))
 w = bench.c2_workload(2, scale=scale)
 abytes = bench.pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], 0, True)
-combos = [(0, 1024)] + [(W, B) for W in (1024, 1536, 2048, 2560, 3072, 4096) for B in (512, 1024)]
+combos = [(0, 1024)] + [(W, 1024) for W in (2560, 3008, 3264, 3328, 3904)]
 for W, B in combos:
     os.environ["ISX_BLOCK"] = str(B)
     try:
