@@ -185,6 +185,27 @@ int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts /* [n_pos][4] */, float
 int isx_batch_fetch_snv(isx_batch *b, isx_snv *out);
 int isx_batch_fetch_ld(isx_batch *b, isx_ld *out);
 
+/* ---- per-scaffold merge summaries (make_coverage_table, profile_utilities.py:425-506) ----
+ * One row per (scaffold, mm level): the position-sized aggregates of the cumulative coverage over
+ * levels <= mm (mm_counts_to_counts_shrunk :508-532) and of the clonalities of the highest level
+ * <= mm (get_basewise_clons :534-546).  `present` = the level has coverage on this scaffold (it is
+ * a key of covT).  The SNV-table columns (SNS/SNV counts, ANI) are table-sized and stay on the host. */
+typedef struct {
+    int64_t nonzero;                /* positions with cumulative coverage > 0 (breadth * length) */
+    uint64_t sum_cov, sumsq_cov;    /* exact integer sums -> mean / std / SEM */
+    double median_cov;              /* np.median(covs) over ALL positions of the scaffold */
+    int64_t counted;                /* positions with a clonality (breadth_minCov * length) */
+    double sum_clon, median_clon;   /* nucl_diversity = 1 - sum_clon / counted; ..._median = 1 - median_clon */
+    int64_t counted_rarefied;
+    double sum_clon_rarefied, median_clon_rarefied;
+    int32_t mm, present;
+} isx_scaffold_level;
+
+/* out[n_scaffolds][n_mm_bins]; scaffold_bounds[n_scaffolds + 1] ascending flat offsets spanning [0, n_pos].
+ * Needs a completed isx_batch_run. device_ms (may be NULL) = device time of the pass. */
+int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, isx_scaffold_level *out,
+                        float *device_ms);
+
 /* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ---- */
 typedef struct isx_bam isx_bam;
 

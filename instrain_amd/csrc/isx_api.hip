@@ -9,6 +9,7 @@
 
 #include "isx_internal.h"
 #include "isx_linkage.h"
+#include "isx_summary.h"
 
 static thread_local std::string g_err;
 void isx_set_error(const std::string &msg) { g_err = msg; }
@@ -56,6 +57,8 @@ struct isx_batch {
     uint32_t *h_state = nullptr;                          // pinned mirror of the above
     size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
     LinkageBuffers L;
+    SummaryBuffers S;
+    hipEvent_t ev_sum[2] = {};
     hipEvent_t ev[10] = {};
     bool ran = false;
     uint32_t n_ovf = 0;
@@ -177,6 +180,8 @@ void isx_batch_destroy(isx_batch *b)
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
     b->L.release();
+    b->S.release();
+    for (auto &e : b->ev_sum) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
@@ -240,6 +245,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
 #define BT(expr) do { int _rc = (expr); if (_rc != ISX_OK) { isx_batch_destroy(b); return _rc; } } while (0)
 #define BH(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { isx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); isx_batch_destroy(b); return ISX_ERR_HIP; } } while (0)
     for (auto &e : b->ev) BH(hipEventCreate(&e));
+    for (auto &e : b->ev_sum) BH(hipEventCreate(&e));
     BH(hipMalloc(&b->d_rec, b->n_rec * sizeof(uint2)));
     BH(hipMalloc(&b->d_ref, (size_t)n_pos));
     BH(hipMalloc(&b->d_bounds, (size_t)(n_splits + 1) * sizeof(int64_t)));
@@ -520,6 +526,25 @@ int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts, float *clon, float *cl
     if (clon) HIP_TRY(hipMemcpy(clon, b->d_clon, (size_t)b->n_pos * sizeof(float), hipMemcpyDeviceToHost));
     if (clon_rarefied) HIP_TRY(hipMemcpy(clon_rarefied, b->d_clon_r, (size_t)b->n_pos * sizeof(float), hipMemcpyDeviceToHost));
     return ISX_OK;
+}
+
+int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, isx_scaffold_level *out,
+                        float *device_ms)
+{
+    NEED_RUN(b, out);
+    if (n_scaffolds <= 0 || !scaffold_bounds || scaffold_bounds[0] != 0 || scaffold_bounds[n_scaffolds] != b->n_pos) {
+        isx_set_error("isx_batch_summarize: scaffold_bounds must span [0, n_pos]");
+        return ISX_ERR_ARG;
+    }
+    for (int i = 0; i < n_scaffolds; i++)
+        if (scaffold_bounds[i + 1] <= scaffold_bounds[i]) { isx_set_error("scaffold_bounds must be strictly ascending"); return ISX_ERR_ARG; }
+    SummaryIn in{};
+    in.stream = b->ctx->stream; in.ev = b->ev_sum;
+    in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
+    in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
+    in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
+    in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
+    return run_summary(in, b->S, out, device_ms);
 }
 
 int isx_batch_fetch_snv(isx_batch *b, isx_snv *out)

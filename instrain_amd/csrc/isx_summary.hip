@@ -1,0 +1,241 @@
+// isx_summary.hip -- per-scaffold merge summaries on the device.
+//
+// Replaces the position-sized part of
+//   make_coverage_table          /root/reference/inStrain/profile/profile_utilities.py:425-506
+//   mm_counts_to_counts_shrunk   profile_utilities.py:508-532   (cumulative coverage over levels <= mm)
+//   get_basewise_clons           profile_utilities.py:534-546   (per position the clonality of the highest
+//                                                                 level <= mm that has one)
+// i.e. for every (scaffold, mm): number of covered positions, sum / sum of squares / median of the
+// cumulative coverage, count / sum / median of the clonalities (and of the rarefied ones).  The
+// table-sized rest (SNP counts from the SNV table, ANI, expected breadth, column naming) stays on
+// the host (instrain_amd/profile/profile_utilities.py make_coverage_table).
+//
+// Levels are applied in ascending order onto three flat per-position arrays that stay on the
+// device; per level one pass of segmented reductions (register partials, one set of atomics per
+// lane) and three rocPRIM segmented radix sorts for the medians.
+#include <algorithm>
+#include <vector>
+#include <cstring>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
+#include "isx_internal.h"
+#include "isx_summary.h"
+
+namespace {
+
+struct Acc {
+    unsigned long long nonzero, sum, sumsq, counted, counted_r;
+    double sum_clon, sum_clon_r;
+    unsigned int present, pad;
+};
+
+__device__ __forceinline__ int find_seg(const int64_t *bounds, int n_seg, uint32_t g)
+{
+    int lo = 0, hi = n_seg;             // bounds[lo] <= g < bounds[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bounds[mid] <= (int64_t)g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// dense path (one level): counts / clonalities are already per position
+__global__ void k_level_dense(const uint4 *counts, const float *clon, const float *clon_r, uint32_t n_pos,
+                              uint32_t *cov, float *cv, float *cr)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pos) return;
+    const uint4 c = counts[i];
+    cov[i] = c.x + c.y + c.z + c.w;
+    cv[i] = clon[i];
+    cr[i] = clon_r[i];
+}
+
+// mm path: add level `mm` of the entry table (window slabs + overflow) onto the running arrays.
+// Every (position, level) occurs once, so plain read-modify-writes are race free.
+__global__ void k_level_apply(const isx_entry *entries, const uint32_t *win_nent, uint32_t slab, uint32_t n_win,
+                              uint64_t ovf0, uint32_t n_ovf, uint32_t mm, uint32_t *cov, float *cv, float *cr,
+                              const int64_t *bounds, int n_seg, Acc *acc)
+{
+    const uint64_t total = ovf0 + n_ovf;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        if (i < ovf0) {
+            const uint32_t w = (uint32_t)(i / slab);
+            if ((uint32_t)(i - (uint64_t)w * slab) >= win_nent[w]) continue;
+        }
+        const isx_entry e = entries[i];
+        if (e.mm != mm) continue;
+        const uint32_t s = e.cnt[0] + e.cnt[1] + e.cnt[2] + e.cnt[3];
+        if (s) {
+            cov[e.gpos] += s;
+            Acc *a = &acc[find_seg(bounds, n_seg, e.gpos)];
+            if (!a->present) a->present = 1;        // covT has this level on this scaffold (shrink_basewise)
+        }
+        if (e.clon == e.clon) cv[e.gpos] = e.clon;
+        if (e.clon_rarefied == e.clon_rarefied) cr[e.gpos] = e.clon_rarefied;
+    }
+}
+
+// segmented reductions: each lane walks a contiguous tile, keeps partials while the scaffold stays
+// the same and flushes them with atomics when it changes / at the end
+__global__ void __launch_bounds__(256) k_seg_reduce(const uint32_t *cov, const float *cv, const float *cr, uint32_t n_pos,
+                                                    const int64_t *bounds, int n_seg, Acc *acc, int dense)
+{
+    const uint32_t TILE = 64;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p0 = t * TILE;
+    if (p0 >= n_pos) return;
+    const uint32_t p1 = (uint32_t)min((uint64_t)n_pos, p0 + TILE);
+    int seg = find_seg(bounds, n_seg, (uint32_t)p0);
+    unsigned long long nz = 0, sum = 0, sq = 0, cn = 0, cnr = 0;
+    double sc = 0.0, scr = 0.0;
+    auto flush = [&]() {
+        Acc *a = &acc[seg];
+        if (nz) atomicAdd(&a->nonzero, nz);
+        if (sum) atomicAdd(&a->sum, sum);
+        if (sq) atomicAdd(&a->sumsq, sq);
+        if (cn) { atomicAdd(&a->counted, cn); atomicAdd(&a->sum_clon, sc); }
+        if (cnr) { atomicAdd(&a->counted_r, cnr); atomicAdd(&a->sum_clon_r, scr); }
+        if (dense && nz && !a->present) a->present = 1;
+        nz = sum = sq = cn = cnr = 0; sc = scr = 0.0;
+    };
+    for (uint32_t p = (uint32_t)p0; p < p1; p++) {
+        if ((int64_t)p >= bounds[seg + 1]) { flush(); seg = find_seg(bounds, n_seg, p); }
+        const unsigned long long c = cov[p];
+        nz += c ? 1 : 0; sum += c; sq += c * c;
+        const float v = cv[p], r = cr[p];
+        if (v == v) { cn++; sc += (double)v; }
+        if (r == r) { cnr++; scr += (double)r; }
+    }
+    flush();
+}
+
+// np.median over each segment of the sorted keys: the first `n` values of the segment count
+// (n = segment length for coverage, = number of non-NaN values for the clonalities; NaN sorts last)
+template <class T>
+__global__ void k_pick_median(const T *sorted, const uint32_t *seg_off, int n_seg, const Acc *acc, int which, double *out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const uint32_t b = seg_off[s];
+    uint64_t n = seg_off[s + 1] - b;
+    if (which == 1) n = acc[s].counted;
+    if (which == 2) n = acc[s].counted_r;
+    double m = __builtin_nan("");
+    if (n) {
+        const uint64_t h = n >> 1;
+        m = (n & 1) ? (double)sorted[b + h] : ((double)sorted[b + h - 1] + (double)sorted[b + h]) / 2.0;
+    }
+    out[s] = m;
+}
+
+__global__ void k_pack_rows(const Acc *acc, const double *med_cov, const double *med_c, const double *med_r, int n_seg,
+                            int mm, int M, isx_scaffold_level *out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const Acc a = acc[s];
+    isx_scaffold_level r;
+    r.nonzero = (int64_t)a.nonzero; r.sum_cov = a.sum; r.sumsq_cov = a.sumsq; r.median_cov = med_cov[s];
+    r.counted = (int64_t)a.counted; r.sum_clon = a.sum_clon; r.median_clon = med_c[s];
+    r.counted_rarefied = (int64_t)a.counted_r; r.sum_clon_rarefied = a.sum_clon_r; r.median_clon_rarefied = med_r[s];
+    r.mm = mm; r.present = (int32_t)a.present;
+    out[(size_t)s * M + mm] = r;
+}
+
+__global__ void k_reset_acc(Acc *acc, int n_seg)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    Acc z;
+    z.nonzero = z.sum = z.sumsq = z.counted = z.counted_r = 0; z.sum_clon = z.sum_clon_r = 0.0; z.present = 0; z.pad = 0;
+    acc[s] = z;
+}
+
+template <class T>
+int dev_alloc(T **p, size_t n)
+{
+    if (*p) return ISX_OK;
+    HIP_TRY(hipMalloc(p, std::max<size_t>(n, 1) * sizeof(T)));
+    return ISX_OK;
+}
+
+}  // namespace
+
+void SummaryBuffers::release()
+{
+    void *ps[] = {cov, cv, cr, k_u32, k_f32, seg_off, bounds, acc, med, rows, temp};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    *this = SummaryBuffers();
+}
+
+int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host_out, float *ms)
+{
+    hipStream_t s = in.stream;
+    const uint32_t n_pos = in.n_pos;
+    const int n_seg = in.n_scaffolds, M = in.M;
+    int rc;
+    if ((rc = dev_alloc(&B.cov, n_pos)) || (rc = dev_alloc(&B.cv, n_pos)) || (rc = dev_alloc(&B.cr, n_pos)) ||
+        (rc = dev_alloc(&B.k_u32, n_pos)) || (rc = dev_alloc(&B.k_f32, n_pos))) return rc;
+    if (B.n_seg != n_seg) {
+        void *ps[] = {B.seg_off, B.bounds, B.acc, B.med, B.rows};
+        for (void *p : ps) if (p) (void)hipFree(p);
+        B.seg_off = nullptr; B.bounds = nullptr; B.acc = nullptr; B.med = nullptr; B.rows = nullptr;
+        B.n_seg = n_seg;
+    }
+    if ((rc = dev_alloc(&B.seg_off, (size_t)n_seg + 1)) || (rc = dev_alloc(&B.bounds, (size_t)n_seg + 1)) ||
+        (rc = dev_alloc(reinterpret_cast<Acc **>(&B.acc), (size_t)n_seg)) || (rc = dev_alloc(&B.med, (size_t)n_seg * 3)) ||
+        (rc = dev_alloc(&B.rows, (size_t)n_seg * M))) return rc;
+    std::vector<uint32_t> off((size_t)n_seg + 1);
+    for (int i = 0; i <= n_seg; i++) off[(size_t)i] = (uint32_t)in.scaffold_bounds[i];
+    HIP_TRY(hipMemcpyAsync(B.seg_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(B.bounds, in.scaffold_bounds, ((size_t)n_seg + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(in.ev[0], s));
+    Acc *acc = reinterpret_cast<Acc *>(B.acc);
+    const dim3 blk(256), gpos((n_pos + 255) / 256), gseg((n_seg + 255) / 256);
+    if (M > 1) {
+        HIP_TRY(hipMemsetAsync(B.cov, 0, (size_t)n_pos * 4, s));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(B.cv), 0x7FC00000, n_pos, s));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(B.cr), 0x7FC00000, n_pos, s));
+    }
+    size_t tb = 0;
+    HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb, B.cov, B.k_u32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
+    size_t tb2 = 0;
+    HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb2, B.cv, B.k_f32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
+    tb = std::max(tb, tb2);
+    if (B.temp_bytes < tb) {
+        if (B.temp) (void)hipFree(B.temp);
+        B.temp = nullptr;
+        HIP_TRY(hipMalloc(&B.temp, tb + 256));
+        B.temp_bytes = tb + 256;
+    }
+    for (int mm = 0; mm < M; mm++) {
+        hipLaunchKernelGGL(k_reset_acc, gseg, blk, 0, s, acc, n_seg);
+        if (M == 1) {
+            hipLaunchKernelGGL(k_level_dense, gpos, blk, 0, s, in.counts, in.clon, in.clon_r, n_pos, B.cov, B.cv, B.cr);
+        } else {
+            hipLaunchKernelGGL(k_level_apply, dim3(2048), blk, 0, s, in.entries, in.win_nent, in.slab, in.n_win, in.ovf0,
+                               in.n_ovf, (uint32_t)mm, B.cov, B.cv, B.cr, B.bounds, n_seg, acc);
+        }
+        const uint32_t tiles = (n_pos + 63) / 64;
+        hipLaunchKernelGGL(k_seg_reduce, dim3((tiles + 255) / 256), blk, 0, s, B.cov, B.cv, B.cr, n_pos, B.bounds, n_seg, acc,
+                           M == 1 ? 1 : 0);
+        size_t t = B.temp_bytes;
+        HIP_TRY(rocprim::segmented_radix_sort_keys(B.temp, t, B.cov, B.k_u32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
+        hipLaunchKernelGGL(k_pick_median<uint32_t>, gseg, blk, 0, s, B.k_u32, B.seg_off, n_seg, acc, 0, B.med);
+        t = B.temp_bytes;
+        HIP_TRY(rocprim::segmented_radix_sort_keys(B.temp, t, B.cv, B.k_f32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
+        hipLaunchKernelGGL(k_pick_median<float>, gseg, blk, 0, s, B.k_f32, B.seg_off, n_seg, acc, 1, B.med + n_seg);
+        t = B.temp_bytes;
+        HIP_TRY(rocprim::segmented_radix_sort_keys(B.temp, t, B.cr, B.k_f32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
+        hipLaunchKernelGGL(k_pick_median<float>, gseg, blk, 0, s, B.k_f32, B.seg_off, n_seg, acc, 2, B.med + 2 * n_seg);
+        hipLaunchKernelGGL(k_pack_rows, gseg, blk, 0, s, acc, B.med, B.med + n_seg, B.med + 2 * n_seg, n_seg, mm, M, B.rows);
+    }
+    HIP_TRY(hipEventRecord(in.ev[1], s));
+    HIP_TRY(hipMemcpyAsync(host_out, B.rows, (size_t)n_seg * M * sizeof(isx_scaffold_level), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ms) { float v = 0.f; (void)hipEventElapsedTime(&v, in.ev[0], in.ev[1]); *ms = v; }
+    return ISX_OK;
+}

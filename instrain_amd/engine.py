@@ -114,6 +114,14 @@ class Batch:
         out["ld"] = l[:s["n_ld"]]
         return out
 
+    def summarize(self, scaffold_bounds):
+        """per-(scaffold, mm) aggregates of make_coverage_table -> (structured array [n_scaffolds, n_mm_bins], device ms)"""
+        sb = np.ascontiguousarray(scaffold_bounds, dtype=np.int64)
+        out = np.zeros((len(sb) - 1, self.n_mm_bins), dtype=_lib.SCAFFOLD_LEVEL_DT)
+        ms = C.c_float(0)
+        check(self.lib.isx_batch_summarize(self.h, len(sb) - 1, sb.ctypes.data, out.ctypes.data, C.byref(ms)))
+        return out, ms.value
+
     def close(self):
         if self.h:
             self.lib.isx_batch_destroy(self.h)

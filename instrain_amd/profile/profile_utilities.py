@@ -102,6 +102,63 @@ def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_o
     return out
 
 
+def estimate_breadth(coverage):
+    """profile_utilities.py:548-555"""
+    return (-1) * np.exp(-1 * ((0.883) * coverage)) + 1
+
+
+def calc_snps(Odb, mm):
+    """snv_utilities.py:249-272 on a raw_snp_table DataFrame"""
+    if len(Odb) == 0:
+        return [0, 0, 0, 0, 0]
+    db = Odb[Odb['mm'] <= mm].sort_values('mm').drop_duplicates(subset=['position'], keep='last')
+    return [len(db[(db['allele_count'] == 1)]), len(db[db['allele_count'] > 1]), len(db),
+            len(db[db['class'].isin(['SNS', 'con_SNV', 'pop_SNV'])]), len(db[db['class'].isin(['SNS', 'pop_SNV'])])]
+
+
+def make_coverage_table(levels, lengt, scaff, SNPTable):
+    """Mirror of make_coverage_table (profile_utilities.py:425-506): `levels` = this scaffold's row of
+    Batch.summarize() (device aggregates per mm); the SNV-table columns are computed here."""
+    table = {k: [] for k in ['scaffold', 'length', 'breadth', 'coverage', 'coverage_median', 'coverage_std',
+                             'coverage_SEM', 'nucl_diversity', 'nucl_diversity_median', 'nucl_diversity_rarefied',
+                             'nucl_diversity_rarefied_median', 'breadth_minCov', 'breadth_rarefied', 'breadth_expected',
+                             'divergent_site_count', 'SNS_count', 'SNV_count', 'consensus_divergent_sites',
+                             'population_divergent_sites', 'conANI_reference', 'popANI_reference', 'mm']}
+    n = float(lengt)
+    for r in levels:
+        if not r['present']:
+            continue                                    # not a key of covT for this scaffold
+        mm = int(r['mm'])
+        s1, s2 = float(r['sum_cov']), float(r['sumsq_cov'])
+        mean = s1 / n
+        var = max(s2 / n - mean * mean, 0.0)
+        counted, rare = int(r['counted']), int(r['counted_rarefied'])
+        SNS_count, SNV_count, div_site_count, con_snps, pop_snps = calc_snps(SNPTable, mm)
+        table['scaffold'].append(scaff)
+        table['length'].append(lengt)
+        table['breadth'].append(int(r['nonzero']) / lengt)
+        table['coverage'].append(mean)
+        table['coverage_median'].append(int(r['median_cov']))
+        table['coverage_std'].append(np.sqrt(var))
+        table['coverage_SEM'].append(np.sqrt(var * n / (n - 1)) / np.sqrt(n) if lengt > 1 else np.nan)
+        table['nucl_diversity'].append(1 - r['sum_clon'] / counted if counted else np.nan)
+        table['nucl_diversity_median'].append(1 - r['median_clon'] if counted else np.nan)
+        table['nucl_diversity_rarefied'].append(1 - r['sum_clon_rarefied'] / rare if rare else np.nan)
+        table['nucl_diversity_rarefied_median'].append(1 - r['median_clon_rarefied'] if rare else np.nan)
+        table['breadth_minCov'].append(counted / lengt)
+        table['breadth_rarefied'].append(rare / lengt)
+        table['breadth_expected'].append(estimate_breadth(mean))
+        table['divergent_site_count'].append(div_site_count)
+        table['SNS_count'].append(SNS_count)
+        table['SNV_count'].append(SNV_count)
+        table['consensus_divergent_sites'].append(con_snps)
+        table['population_divergent_sites'].append(pop_snps)
+        table['conANI_reference'].append((counted - con_snps) / counted if counted else 0)
+        table['popANI_reference'].append((counted - pop_snps) / counted if counted else 0)
+        table['mm'].append(mm)
+    return pd.DataFrame(table)
+
+
 def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, window_length=10000, bam_name=None,
                    **kwargs):
     """Profile every split of `scaffolds` in ONE device batch.
@@ -132,10 +189,18 @@ def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, 
     try:
         b.run()
         res = b.fetch()
+        scaff_bounds = np.r_[0, np.cumsum([len(q) for q in sequences])]
+        levels, _ = b.summarize(scaff_bounds)
     finally:
         b.close()
     splits = tables_to_splits(res, np.asarray(bounds), s_scaff, s_num, s_off, s_len, min_freq, bam_name)
-    return {"{0}.{1}".format(S.scaffold, S.split_number): S for S in splits}
+    out = {"{0}.{1}".format(S.scaffold, S.split_number): S for S in splits}
+    if kwargs.get('scaffold_tables') is not None:       # cumulative_scaffold_table per scaffold (merge step)
+        for i, name in enumerate(scaffolds):
+            snp = [S.raw_snp_table for S in splits if S.scaffold == name and len(S.raw_snp_table)]
+            snp = pd.concat(snp) if snp else pd.DataFrame()
+            kwargs['scaffold_tables'][name] = make_coverage_table(levels[i], len(sequences[i]), name, snp)
+    return out
 
 
 def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
@@ -168,7 +233,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                 raise ValueError("scaffold {0} is not in the .fasta / length differs from the .bam header".format(n))
         n_mm = bf.info["max_mm"] + 1
         bf.close()
-        kw = {k: v for k, v in kwargs.items() if k in ('min_cov', 'min_freq', 'min_snp', 'rarefied_coverage')}
+        kw = {k: v for k, v in kwargs.items() if k in ('min_cov', 'min_freq', 'min_snp', 'rarefied_coverage', 'scaffold_tables', 'seed')}
         return profile_splits(ctx, names, [str(s2s[n]).upper() for n in names], obs, pair, null_model, n_mm,
                               window_length=int(kwargs.get('window_length', 10000)), bam_name=bam, **kw)
     except Exception as e:

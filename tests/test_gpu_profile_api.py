@@ -88,3 +88,75 @@ def test_missing_scaffold_follows_failure_convention():
     model[-1] = fb
     out = prof.profile_bam(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"), s2s={"other": "ACGT"}, null_model=model)
     assert out == {}
+
+
+def test_device_coverage_table_equals_stored_golden():
+    """make_coverage_table with the device aggregates (isx_batch_summarize) vs all 26 rows of the
+    reference's stored cumulative_scaffold_table"""
+    import instrain_amd.profile as prof
+    from tests.test_oracle_golden import check_coverage_table_vs_sars_golden, read_fasta
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    seq = read_fasta(os.path.join(util.GOLD, "sars_cov_2_MT039887.1.fasta"))
+    tabs = {}
+    prof.profile_bam(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"), s2s={"MT039887.1": seq}, null_model=model,
+                     min_cov=5, min_freq=0.05, min_snp=20, scaffold_tables=tabs)
+    t = tabs["MT039887.1"]
+    assert list(t["mm"]) == list(range(26))
+    check_coverage_table_vs_sars_golden(t.to_dict("records"), float_tol=1e-9)
+
+
+@pytest.mark.parametrize("mm_levels", [1, 5])
+def test_device_summary_vs_oracle_multi_scaffold(mm_levels):
+    """three scaffolds of unequal length in one batch: every aggregate vs oracle/summary.py"""
+    from instrain_amd import engine
+    from oracle import oracle, summary
+    from tests.test_gpu_parity import _random_split
+    lut, fb = util.load_lut()
+    ctx = engine.Context(0)
+    ctx.set_null_model(lut, fb)
+    seq, pos, base, mm, pair = _random_split(400 + mm_levels, 9000, 45, mm_levels, 200)
+    sb = np.array([0, 2500, 2700, 9000])
+    b = engine.Batch(ctx, engine.encode_seq(seq), sb, engine.pack_obs(pos.astype(np.uint32), base, mm), pair.astype(np.uint32),
+                     n_mm_bins=mm_levels, rarefied_coverage=30, seed=9)
+    b.run()
+    res = b.fetch()
+    lv, ms = b.summarize(sb)
+    b.close()
+    ctx.close()
+    assert ms > 0
+    ent_all = res["entries"] if mm_levels > 1 else engine.dense_to_entries(res["counts"], res["clon"])
+    clon_r_all = res["clon_r"] if mm_levels > 1 else res["clon_r"][ent_all["gpos"]]
+    for i, (s, e) in enumerate(zip(sb[:-1], sb[1:])):
+        r = oracle.profile_split(pos, base, mm, pair, seq[s:e], int(s), lut, fb)
+        k = (ent_all["gpos"] >= s) & (ent_all["gpos"] < e)
+        cr = np.full(len(r["entries"]), np.nan, dtype=np.float32)
+        # the rarefied values are the product's own (random in the reference): align them by (pos, mm)
+        key = lambda p, m: p.astype(np.int64) * 1000 + m
+        idx = {kk: j for j, kk in enumerate(key(r["entries"]["pos"], r["entries"]["mm"]))}
+        for kk, v in zip(key(ent_all["gpos"][k], ent_all["mm"][k]), clon_r_all[k]):
+            cr[idx[kk]] = v
+        e_rel = r["entries"].copy()
+        e_rel["pos"] -= int(s)
+        s_rel = r["snv"].copy()
+        s_rel["pos"] -= int(s)
+        rows = {row["mm"]: row for row in summary.coverage_table(e_rel, s_rel, int(e - s), clon_r=cr)}
+        L = float(e - s)
+        for m in range(mm_levels):
+            d = lv[i, m]
+            assert bool(d["present"]) == (m in rows), (i, m)
+            if m not in rows:
+                continue
+            o = rows[m]
+            assert d["nonzero"] == round(o["breadth"] * L) and d["counted"] == round(o["breadth_minCov"] * L)
+            assert abs(d["sum_cov"] / L - o["coverage"]) < 1e-9 and int(d["median_cov"]) == o["coverage_median"]
+            var = d["sumsq_cov"] / L - (d["sum_cov"] / L) ** 2
+            assert abs(np.sqrt(var) - o["coverage_std"]) < 1e-8
+            if d["counted"]:
+                assert abs((1 - d["sum_clon"] / d["counted"]) - o["nucl_diversity"]) < 1e-9
+                assert abs((1 - d["median_clon"]) - o["nucl_diversity_median"]) < 1e-9
+            assert d["counted_rarefied"] == round(o["breadth_rarefied"] * L)
+            if d["counted_rarefied"]:
+                assert abs((1 - d["sum_clon_rarefied"] / d["counted_rarefied"]) - o["nucl_diversity_rarefied"]) < 1e-9
+                assert abs((1 - d["median_clon_rarefied"]) - o["nucl_diversity_rarefied_median"]) < 1e-9

@@ -137,3 +137,44 @@ def test_bam_py_reproduces_sars_observations():
     z = np.load(os.path.join(util.GOLD, "sars_cov_2_obs.npz"))
     assert len(pos) == len(z["pos"]) == 3717600
     assert (pos == z["pos"]).all() and (base == z["base"]).all() and (mm == z["mm"]).all() and (pair == z["pair"]).all()
+
+
+# mapping of the stored v1.2.4 column names to the current ones (test/tests/test_utils.py:160-195)
+OLD2NEW = {"median_cov": "coverage_median", "std_cov": "coverage_std", "mean_microdiversity": "nucl_diversity",
+           "median_microdiversity": "nucl_diversity_median", "unmaskedBreadth": "breadth_minCov",
+           "expected_breadth": "breadth_expected", "SNPs": "divergent_site_count", "Reference_SNPs": "SNS_count",
+           "consensus_SNPs": "consensus_divergent_sites", "population_SNPs": "population_divergent_sites",
+           "conANI": "conANI_reference", "popANI": "popANI_reference"}
+
+
+def check_coverage_table_vs_sars_golden(rows, float_tol):
+    """rows: list of dicts with the CURRENT column names, one per mm level (any order)."""
+    import pandas as pd
+    g = pd.read_csv(os.path.join(util.GOLD, "sars_cov_2_cumulative_scaffold_table.csv.gz")).rename(columns=OLD2NEW)
+    got = pd.DataFrame(rows).sort_values("mm").reset_index(drop=True)
+    g = g.sort_values("mm").reset_index(drop=True)
+    assert len(got) == len(g) == 26 and (got["mm"].values == g["mm"].values).all()
+    for c in ["length", "coverage_median", "divergent_site_count", "SNS_count", "consensus_divergent_sites",
+              "population_divergent_sites"]:
+        assert (got[c].values.astype(np.int64) == g[c].values.astype(np.int64)).all(), c
+    assert (got["SNV_count"].values == (g["BiAllelic_SNPs"] + g["MultiAllelic_SNPs"]).values).all()
+    assert ((got["length"] - (got["breadth"] * got["length"]).round().astype(int)).values == g["bases_w_0_coverage"].values).all()
+    for c in ["breadth", "coverage", "coverage_std", "nucl_diversity", "nucl_diversity_median", "breadth_minCov",
+              "breadth_expected", "conANI_reference", "popANI_reference"]:
+        a, b = got[c].values.astype(float), g[c].values.astype(float)
+        assert np.max(np.abs(a - b)) <= float_tol * max(1.0, np.max(np.abs(b))), (c, np.max(np.abs(a - b)))
+
+
+def test_oracle_coverage_table_vs_stored_golden():
+    """oracle/summary.py (make_coverage_table restatement) on the oracle's own tables == the 26 rows
+    of the reference's stored cumulative_scaffold_table"""
+    from oracle import summary
+    lut, fb = util.load_lut()
+    z = np.load(os.path.join(util.GOLD, "sars_cov_2_obs.npz"))
+    seq = read_fasta(os.path.join(util.GOLD, "sars_cov_2_MT039887.1.fasta"))
+    ent, snv = [], []
+    for s, e in iterate_splits(len(seq), 10000):
+        r = oracle.profile_split(z["pos"], z["base"], z["mm"], z["pair"], seq[s:e + 1], s, lut, fb)
+        ent.append(r["entries"]); snv.append(r["snv"])
+    rows = summary.coverage_table(np.concatenate(ent), np.concatenate(snv), len(seq))
+    check_coverage_table_vs_sars_golden(rows, float_tol=1e-12)
