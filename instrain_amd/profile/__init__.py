@@ -6,5 +6,5 @@
 Same names, argument meaning and failure convention; the work is done by libinstrain_amd.so
 (one batch of splits per call instead of one process per split).
 """
-from .profile_utilities import SplitObject, profile_bam, profile_splits  # noqa: F401
+from .profile_utilities import SplitObject, make_coverage_table, profile_bam, profile_splits  # noqa: F401
 from .snv_utilities import generate_snp_model, null_model_lut  # noqa: F401

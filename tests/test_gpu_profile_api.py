@@ -160,3 +160,29 @@ def test_device_summary_vs_oracle_multi_scaffold(mm_levels):
             if d["counted_rarefied"]:
                 assert abs((1 - d["sum_clon_rarefied"] / d["counted_rarefied"]) - o["nucl_diversity_rarefied"]) < 1e-9
                 assert abs((1 - d["median_clon_rarefied"]) - o["nucl_diversity_rarefied_median"]) < 1e-9
+
+
+def test_snv_pooling_repileup_counts():
+    """extract_SNVS_from_bam (polymorpher.py:275-316): counts over all mm levels at a position list
+    == the oracle's level counts summed over mm, zeros for uncovered positions"""
+    from instrain_amd.profile import polymorpher
+    from oracle import oracle
+    from tests.test_oracle_golden import iterate_splits, read_fasta, sars_golden_tables
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    gS, _ = sars_golden_tables()
+    positions = sorted(set(int(p) for p in gS["position"])) + [0, 29878]
+    got = polymorpher.extract_SNVS_from_bam(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"), None, positions,
+                                            "MT039887.1", null_model=model)
+    z = np.load(os.path.join(util.GOLD, "sars_cov_2_obs.npz"))
+    exp = np.zeros((29879, 4), dtype=np.int64)
+    k = z["base"] < 4
+    np.add.at(exp, (z["pos"][k], z["base"][k]), 1)
+    assert set(got) == set(positions)
+    for p in positions:
+        assert (got[p] == exp[p]).all(), p
+    # the highest-mm golden row of a position can never exceed the pooled counts
+    top = gS.sort_values("mm").drop_duplicates("position", keep="last")
+    for _, r in top.iterrows():
+        assert (np.array([r["A"], r["C"], r["T"], r["G"]]) <= got[int(r["position"])]).all()
