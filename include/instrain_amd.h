@@ -206,6 +206,20 @@ typedef struct {
 int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, isx_scaffold_level *out,
                         float *device_ms);
 
+/* ---- compare: coverage overlap of two samples (readComparer.py:145-191 calc_mm2overlap) ----
+ * Two batches over the SAME flat space (same scaffolds laid out identically, same ctx).  One row per
+ * (scaffold, mm): positions where both / either sample reach min_cov in the coverage cumulated over
+ * levels <= mm; present_x = the level is a key of that sample's covT on the scaffold (the reference
+ * evaluates the union of both key sets). */
+typedef struct {
+    int64_t both, either;
+    int32_t mm, present_a, present_b, pad;
+} isx_compare_level;
+
+/* out[n_scaffolds][max(n_mm_bins_a, n_mm_bins_b)] */
+int isx_compare_coverage(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, int32_t min_cov,
+                         isx_compare_level *out, float *device_ms);
+
 /* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ---- */
 typedef struct isx_bam isx_bam;
 

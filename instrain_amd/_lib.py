@@ -62,6 +62,10 @@ SCAFFOLD_LEVEL_DT = np.dtype([("nonzero", "<i8"), ("sum_cov", "<u8"), ("sumsq_co
 assert SCAFFOLD_LEVEL_DT.itemsize == 88
 
 
+COMPARE_LEVEL_DT = np.dtype([("both", "<i8"), ("either", "<i8"), ("mm", "<i4"), ("present_a", "<i4"),
+                             ("present_b", "<i4"), ("pad", "<i4")])
+
+
 class IsxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libinstrain_amd error %d: %s" % (code, msg))
@@ -71,7 +75,7 @@ class IsxError(RuntimeError):
 SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destroy", "isx_set_null_model",
            "isx_batch_create", "isx_batch_destroy", "isx_batch_run", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
-           "isx_batch_summarize",
+           "isx_batch_summarize", "isx_compare_coverage",
            "isx_bam_open", "isx_bam_close", "isx_bam_expand", "isx_bam_ref", "isx_bam_copy"]
 
 _lib = None
@@ -103,6 +107,7 @@ def load():
         getattr(lib, f).argtypes = [vp, vp]
     lib.isx_batch_fetch_dense.argtypes = [vp, vp, vp, vp]
     lib.isx_batch_summarize.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_float)]
+    lib.isx_compare_coverage.argtypes = [vp, vp, i32, vp, i32, vp, C.POINTER(C.c_float)]
     lib.isx_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.isx_bam_close.argtypes = [vp]
     lib.isx_bam_close.restype = None

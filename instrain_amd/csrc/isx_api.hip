@@ -58,6 +58,7 @@ struct isx_batch {
     size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
     LinkageBuffers L;
     SummaryBuffers S;
+    CompareBuffers C;
     hipEvent_t ev_sum[2] = {};
     hipEvent_t ev[10] = {};
     bool ran = false;
@@ -181,6 +182,7 @@ void isx_batch_destroy(isx_batch *b)
     for (void *p : ps) if (p) (void)hipFree(p);
     b->L.release();
     b->S.release();
+    b->C.release();
     for (auto &e : b->ev_sum) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
@@ -545,6 +547,31 @@ int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffo
     in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
     in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
     return run_summary(in, b->S, out, device_ms);
+}
+
+static void fill_summary_in(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, SummaryIn &in)
+{
+    in.stream = b->ctx->stream; in.ev = b->ev_sum;
+    in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
+    in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
+    in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
+    in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
+}
+
+int isx_compare_coverage(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, int32_t min_cov,
+                         isx_compare_level *out, float *device_ms)
+{
+    NEED_RUN(a, out);
+    if (!b || !b->ran) { isx_set_error("isx_compare_coverage: run both batches first"); return ISX_ERR_STATE; }
+    if (a->ctx != b->ctx || a->n_pos != b->n_pos) { isx_set_error("isx_compare_coverage: batches must share ctx and flat space"); return ISX_ERR_ARG; }
+    if (n_scaffolds <= 0 || !scaffold_bounds || scaffold_bounds[0] != 0 || scaffold_bounds[n_scaffolds] != a->n_pos) {
+        isx_set_error("isx_compare_coverage: scaffold_bounds must span [0, n_pos]");
+        return ISX_ERR_ARG;
+    }
+    SummaryIn ia{}, ib{};
+    fill_summary_in(a, n_scaffolds, scaffold_bounds, ia);
+    fill_summary_in(b, n_scaffolds, scaffold_bounds, ib);
+    return run_compare(ia, ib, (uint32_t)std::max(min_cov, 0), a->C, out, device_ms);
 }
 
 int isx_batch_fetch_snv(isx_batch *b, isx_snv *out)

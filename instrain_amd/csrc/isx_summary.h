@@ -35,3 +35,15 @@ struct SummaryIn {
 };
 
 int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host_out, float *ms);
+
+struct CompareBuffers {
+    uint32_t *cov_a = nullptr, *cov_b = nullptr;
+    float *scratch_f = nullptr;
+    int64_t *bounds = nullptr;
+    void *acc_a = nullptr, *acc_b = nullptr;
+    unsigned long long *both = nullptr;
+    isx_compare_level *rows = nullptr;
+    void release();
+};
+
+int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, CompareBuffers &B, isx_compare_level *host_out, float *ms);

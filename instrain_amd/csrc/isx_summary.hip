@@ -154,6 +154,54 @@ __global__ void k_reset_acc(Acc *acc, int n_seg)
     acc[s] = z;
 }
 
+// compare (readComparer.py:145-191 calc_mm2overlap): positions where BOTH / EITHER sample has
+// cumulative coverage >= min_cov, per scaffold
+__global__ void __launch_bounds__(256) k_overlap_reduce(const uint32_t *cov_a, const uint32_t *cov_b, uint32_t n_pos,
+                                                        uint32_t min_cov, const int64_t *bounds, int n_seg,
+                                                        unsigned long long *both, unsigned long long *either)
+{
+    const uint32_t TILE = 64;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p0 = t * TILE;
+    if (p0 >= n_pos) return;
+    const uint32_t p1 = (uint32_t)min((uint64_t)n_pos, p0 + TILE);
+    int seg = find_seg(bounds, n_seg, (uint32_t)p0);
+    unsigned long long nb = 0, ne = 0;
+    for (uint32_t p = (uint32_t)p0; p < p1; p++) {
+        if ((int64_t)p >= bounds[seg + 1]) {
+            if (nb) atomicAdd(&both[seg], nb);
+            if (ne) atomicAdd(&either[seg], ne);
+            nb = ne = 0;
+            seg = find_seg(bounds, n_seg, p);
+        }
+        const bool a = cov_a[p] >= min_cov, b = cov_b[p] >= min_cov;
+        nb += (a && b) ? 1 : 0;
+        ne += (a || b) ? 1 : 0;
+    }
+    if (nb) atomicAdd(&both[seg], nb);
+    if (ne) atomicAdd(&either[seg], ne);
+}
+
+__global__ void k_pack_compare(const Acc *acc_a, const Acc *acc_b, const unsigned long long *both,
+                               const unsigned long long *either, int n_seg, int mm, int M, isx_compare_level *out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    isx_compare_level r;
+    r.both = (int64_t)both[s]; r.either = (int64_t)either[s];
+    r.mm = mm; r.present_a = (int32_t)acc_a[s].present; r.present_b = (int32_t)acc_b[s].present; r.pad = 0;
+    out[(size_t)s * M + mm] = r;
+}
+
+// dense path: a level is "present" on a scaffold when it has any coverage there
+__global__ void __launch_bounds__(256) k_present_dense(const uint32_t *cov, uint32_t n_pos, const int64_t *bounds, int n_seg, Acc *acc)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pos || cov[p] == 0) return;
+    Acc *a = &acc[find_seg(bounds, n_seg, p)];
+    if (!a->present) a->present = 1;
+}
+
 template <class T>
 int dev_alloc(T **p, size_t n)
 {
@@ -237,5 +285,56 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
     HIP_TRY(hipMemcpyAsync(host_out, B.rows, (size_t)n_seg * M * sizeof(isx_scaffold_level), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (ms) { float v = 0.f; (void)hipEventElapsedTime(&v, in.ev[0], in.ev[1]); *ms = v; }
+    return ISX_OK;
+}
+
+void CompareBuffers::release()
+{
+    void *ps[] = {cov_a, cov_b, scratch_f, bounds, acc_a, acc_b, both, rows};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    *this = CompareBuffers();
+}
+
+int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, CompareBuffers &B, isx_compare_level *host_out, float *ms)
+{
+    hipStream_t s = a.stream;
+    const uint32_t n_pos = a.n_pos;
+    const int n_seg = a.n_scaffolds, M = std::max(a.M, b.M);
+    int rc;
+    if ((rc = dev_alloc(&B.cov_a, n_pos)) || (rc = dev_alloc(&B.cov_b, n_pos)) || (rc = dev_alloc(&B.scratch_f, (size_t)n_pos * 2)) ||
+        (rc = dev_alloc(&B.bounds, (size_t)n_seg + 1)) || (rc = dev_alloc(reinterpret_cast<Acc **>(&B.acc_a), (size_t)n_seg)) ||
+        (rc = dev_alloc(reinterpret_cast<Acc **>(&B.acc_b), (size_t)n_seg)) || (rc = dev_alloc(&B.both, (size_t)n_seg * 2)) ||
+        (rc = dev_alloc(&B.rows, (size_t)n_seg * M))) return rc;
+    HIP_TRY(hipMemcpyAsync(B.bounds, a.scaffold_bounds, ((size_t)n_seg + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(a.ev[0], s));
+    HIP_TRY(hipMemsetAsync(B.cov_a, 0, (size_t)n_pos * 4, s));
+    HIP_TRY(hipMemsetAsync(B.cov_b, 0, (size_t)n_pos * 4, s));
+    Acc *acc_a = reinterpret_cast<Acc *>(B.acc_a), *acc_b = reinterpret_cast<Acc *>(B.acc_b);
+    const dim3 blk(256), gpos((n_pos + 255) / 256), gseg((n_seg + 255) / 256);
+    float *f0 = B.scratch_f, *f1 = B.scratch_f + n_pos;
+    auto apply = [&](const SummaryIn &in, int mm, uint32_t *cov, Acc *acc) {
+        hipLaunchKernelGGL(k_reset_acc, gseg, blk, 0, s, acc, n_seg);
+        if (mm >= in.M) return;                 // no such level in this sample: coverage carries over
+        if (in.M == 1) {
+            hipLaunchKernelGGL(k_level_dense, gpos, blk, 0, s, in.counts, in.clon, in.clon_r, n_pos, cov, f0, f1);
+            hipLaunchKernelGGL(k_present_dense, gpos, blk, 0, s, cov, n_pos, B.bounds, n_seg, acc);
+        } else {
+            hipLaunchKernelGGL(k_level_apply, dim3(2048), blk, 0, s, in.entries, in.win_nent, in.slab, in.n_win, in.ovf0, in.n_ovf,
+                               (uint32_t)mm, cov, f0, f1, B.bounds, n_seg, acc);
+        }
+    };
+    for (int mm = 0; mm < M; mm++) {
+        apply(a, mm, B.cov_a, acc_a);
+        apply(b, mm, B.cov_b, acc_b);
+        HIP_TRY(hipMemsetAsync(B.both, 0, (size_t)n_seg * 2 * sizeof(unsigned long long), s));
+        const uint32_t tiles = (n_pos + 63) / 64;
+        hipLaunchKernelGGL(k_overlap_reduce, dim3((tiles + 255) / 256), blk, 0, s, B.cov_a, B.cov_b, n_pos, min_cov, B.bounds, n_seg,
+                           B.both, B.both + n_seg);
+        hipLaunchKernelGGL(k_pack_compare, gseg, blk, 0, s, acc_a, acc_b, B.both, B.both + n_seg, n_seg, mm, M, B.rows);
+    }
+    HIP_TRY(hipEventRecord(a.ev[1], s));
+    HIP_TRY(hipMemcpyAsync(host_out, B.rows, (size_t)n_seg * M * sizeof(isx_compare_level), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ms) { float v = 0.f; (void)hipEventElapsedTime(&v, a.ev[0], a.ev[1]); *ms = v; }
     return ISX_OK;
 }

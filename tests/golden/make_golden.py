@@ -296,6 +296,25 @@ def main():
                             pair=pair.astype(np.int32), **{"p_" + k: np.array(v) for k, v in params.items()}, **exp)
         print(name, "obs", len(pos), "snv rows", len(S), "ld rows", len(L), "edges", ne)
 
+    # ---- compare: coverage overlap of two samples on the same scaffold (readComparer.py:145-191) ----
+    import inStrain.readComparer as rc
+    for name, kwa, kwb in [("compare_a", dict(seed=31, mm_levels=5, depth=30, mLen=1500), dict(seed=32, mm_levels=3, depth=12, mLen=1500)),
+                           ("compare_b", dict(seed=33, mm_levels=1, depth=9, mLen=900), dict(seed=34, mm_levels=7, depth=40, mLen=900))]:
+        seq, posa, basea, mma, paira = synth_case(**kwa)
+        _, posb, baseb, mmb, pairb = synth_case(**kwb)
+        # sample B is piled up on sample A's scaffold: only coverage matters for calc_mm2overlap
+        covA, _, SA, _, _ = run_reference_split(mods, "scaf", seq, 0, posa, basea, mma, paira, nm)
+        covB, _, SB, _, _ = run_reference_split(mods, "scaf", seq, 0, posb, baseb, mmb, pairb, nm)
+        mm2overlap, mm2coverage = rc.calc_mm2overlap(covA, covB, min_cov=5)
+        mms = sorted(mm2overlap)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), seq=np.array(seq),
+                            a_pos=posa.astype(np.int32), a_base=basea, a_mm=mma.astype(np.int32), a_pair=paira.astype(np.int32),
+                            b_pos=posb.astype(np.int32), b_base=baseb, b_mm=mmb.astype(np.int32), b_pair=pairb.astype(np.int32),
+                            mm=np.array(mms), both=np.array([len(mm2overlap[m]) for m in mms]),
+                            coverage=np.array([mm2coverage[m] for m in mms], dtype=np.float64),
+                            pos_in_both_last=np.array(sorted(mm2overlap[mms[-1]]), dtype=np.int64))
+        print(name, "levels", mms, "both", [len(mm2overlap[m]) for m in mms])
+
     if "--skip-sars" in sys.argv:
         return
 

@@ -178,3 +178,19 @@ def test_oracle_coverage_table_vs_stored_golden():
         ent.append(r["entries"]); snv.append(r["snv"])
     rows = summary.coverage_table(np.concatenate(ent), np.concatenate(snv), len(seq))
     check_coverage_table_vs_sars_golden(rows, float_tol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["compare_a", "compare_b"])
+def test_oracle_compare_overlap_vs_reference_vectors(name):
+    """oracle/compare.py vs outputs of the reference's own calc_mm2overlap (readComparer.py:145-191)"""
+    from oracle import compare
+    lut, fb = util.load_lut()
+    g = util.load_case(name)
+    seq = str(g["seq"])
+    ea = oracle.profile_split(g["a_pos"], g["a_base"], g["a_mm"], g["a_pair"], seq, 0, lut, fb)["entries"]
+    eb = oracle.profile_split(g["b_pos"], g["b_base"], g["b_mm"], g["b_pair"], seq, 0, lut, fb)["entries"]
+    o, c = compare.calc_mm2overlap(ea, eb, len(seq), min_cov=5)
+    assert sorted(o) == list(g["mm"])
+    assert [len(o[m]) for m in g["mm"]] == list(g["both"])
+    assert np.max(np.abs(np.array([c[m] for m in g["mm"]]) - g["coverage"])) == 0.0
+    assert sorted(o[int(g["mm"][-1])]) == list(g["pos_in_both_last"])
