@@ -2,6 +2,7 @@
 // (see include/instrain_amd.h for what each entry point replaces in the reference)
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -54,7 +55,10 @@ struct isx_batch {
     isx_site *d_sites = nullptr;
     isx_ao *d_ao = nullptr;
     uint32_t *d_cursors = nullptr, *d_flags = nullptr;   // one allocation: cursors[CUR_N] | flags[4]
-    uint32_t *h_state = nullptr;                          // pinned mirror of the above
+    uint32_t *h_state = nullptr;                          // mapped pinned mirror, written by k_publish_state
+    uint32_t *d_host_state = nullptr;                     // device address of h_state
+    uint32_t base[CUR_N] = {};                            // cursor values at the start of the next run
+    uint32_t epoch = 0;                                   // run counter, echoed by k_publish_state
     size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
     LinkageBuffers L;
     SummaryBuffers S;
@@ -253,7 +257,10 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     BH(hipMalloc(&b->d_bounds, (size_t)(n_splits + 1) * sizeof(int64_t)));
     BH(hipMalloc(&b->d_cursors, (CUR_N + 4) * sizeof(uint32_t)));
     b->d_flags = b->d_cursors + CUR_N;
-    BH(hipHostMalloc(&b->h_state, (CUR_N + 4) * sizeof(uint32_t), hipHostMallocDefault));
+    BH(hipHostMalloc(&b->h_state, (CUR_N + 8) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(b->h_state, 0, (CUR_N + 8) * sizeof(uint32_t));
+    BH(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_host_state), b->h_state, 0));
+    BH(hipMemsetAsync(b->d_cursors, 0, (CUR_N + 4) * sizeof(uint32_t), c->stream));
     {   // folded presence threshold per coverage (see build_thresholds)
         std::vector<uint16_t> thr = build_thresholds(c->h_lut, c->fallback, prm->min_freq);
         BH(hipMalloc(&b->d_thr, thr.size() * sizeof(uint16_t)));
@@ -395,7 +402,8 @@ int isx_batch_run(isx_batch *b)
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     b->ran = false;
-    HIP_TRY(hipMemsetAsync(b->d_cursors, 0, (CUR_N + 4) * sizeof(uint32_t), s));
+    // no per-run memset / copy: the cursors run on (slots are relative to `base`), and the last
+    // one-wave kernel k_publish_state copies them to mapped pinned memory right behind the pileup kernel
 
     PileupArgs a{};
     a.rec = b->d_rec; a.win_range = b->d_win; a.ref = b->d_ref;
@@ -412,16 +420,33 @@ int isx_batch_run(isx_batch *b)
     a.snv = b->d_snv; a.cap_snv = (uint32_t)std::min<size_t>(b->cap_snv, 0xFFFFFFFFu);
     a.sites = b->d_sites; a.cap_sites = (uint32_t)std::min<size_t>(b->cap_sites, 0xFFFFFFFFu);
     a.ao = b->d_ao; a.cap_ao = (uint32_t)std::min<size_t>(b->cap_ao, 0xFFFFFFFFu); a.enable_linkage = b->prm.enable_linkage;
-    a.cursors = b->d_cursors; a.flags = b->d_flags;
+    a.cursors = b->d_cursors; a.flags = b->d_flags; a.host_state = b->d_host_state;
+    memcpy(a.base, b->base, sizeof(a.base));
 
     HIP_TRY(hipEventRecord(b->ev[0], s));
     launch_pileup(a, b->block, b->lds, b->grid, b->packed, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[1], s));
-    HIP_TRY(hipMemcpyAsync(b->h_state, b->d_cursors, (CUR_N + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t *cur = b->h_state;
+    launch_publish_state(a, ++b->epoch, s);
+    {   // spin on the epoch word for a while (no interrupt latency), then fall back to a stream wait
+        volatile uint32_t *ep = b->h_state + CUR_N + 4;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (;;) {
+            if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == b->epoch) { seen = true; break; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipEventSynchronize(b->ev[1]));
+    }
+    uint32_t cur[CUR_N];
+    for (int i = 0; i < CUR_N; i++) { cur[i] = b->h_state[i] - b->base[i]; b->base[i] = b->h_state[i]; }
     const uint32_t flags = b->h_state[CUR_N];
+    if (flags) {        // error path: start the next run from a clean slate
+        HIP_TRY(hipMemsetAsync(b->d_cursors, 0, (CUR_N + 4) * sizeof(uint32_t), s));
+        HIP_TRY(hipStreamSynchronize(s));
+        memset(b->base, 0, sizeof(b->base));
+    }
     if (flags & ISX_FLAG_MM_RANGE) { isx_set_error("an observation has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
     if (b->M > 1 && cur[CUR_ENTRIES] > b->cap_ovf) { isx_set_error("entry overflow region exhausted"); return ISX_ERR_CAPACITY; }
     if (flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES | ISX_FLAG_CAP_AO)) {

@@ -143,11 +143,14 @@ struct PileupArgs {
     isx_ao *ao;                 // allele observations, exactly sized slabs per SNP site
     uint32_t cap_ao;
     int32_t enable_linkage;
-    uint32_t *cursors;
+    uint32_t *cursors;          // monotonic across runs: slot = atomicAdd(...) - base[...] (no per-run memset)
     uint32_t *flags;
+    uint32_t base[CUR_N];       // cursor values when this run started (host copy of the last read-back)
+    uint32_t *host_state;       // mapped pinned [CUR_N + 4]: k_publish_state copies cursors | flags here
 };
 
 void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s);
+void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s);
 size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed);
 
 struct LinkageBuffers;      // defined in isx_linkage.hip

@@ -48,6 +48,32 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // scratch words (LDS)
 enum { S_NQ = 0, S_ROWS, S_SITES, S_ROW_BASE, S_SITE_BASE, S_ROW_RANK, S_NAO, S_AO_BASE, S_ENT_TOT, S_ENT_BASE, S_SLEV, S_SLEV_BASE, S_N = 16 };
 
+// table cursors run on across launches; a run's slots are relative to the values it started from
+__device__ __forceinline__ uint32_t cur_add(const PileupArgs &a, int which, uint32_t n)
+{
+    return atomicAdd(&a.cursors[which], n) - a.base[which];
+}
+
+// error flags: the returned value is consumed so the atomic is complete before the workgroup's ticket
+__device__ __forceinline__ void flag_or(const PileupArgs &a, uint32_t bit)
+{
+    if (atomicOr(a.flags, bit) == 0xFFFFFFFFu) a.flags[3] = 1;
+}
+
+// After the pileup kernel a one-wave kernel copies cursors | flags to mapped pinned host memory: the
+// host then needs no copy, only the stream synchronisation it does anyway.  (A last-workgroup ticket
+// inside the pileup kernel was tried: 512 returning atomics on one word at the kernel's tail cost
+// more than this extra kernel boundary.)
+__global__ void k_publish_state(const uint32_t *cursors, uint32_t *host_state, uint32_t epoch)
+{
+    const int i = threadIdx.x;
+    if (i < CUR_N + 4) host_state[i] = __hip_atomic_load(&cursors[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    // the host spins on this word (coherent pinned memory) instead of sleeping in a stream wait
+    if (i == 0) __hip_atomic_store(&host_state[CUR_N + 4], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ int argmax4(const uint32_t *c)
 {
     int b = 0;
@@ -325,9 +351,9 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         }
         __syncthreads();
         const uint32_t nq = scratch[S_NQ], nrows = scratch[S_ROWS], nsites = scratch[S_SITES], nao = scratch[S_NAO];
-        if (tid == 0 && nrows) scratch[S_ROW_BASE] = atomicAdd(&a.cursors[CUR_SNV], nrows);
-        if (tid == 64 && nsites) scratch[S_SITE_BASE] = atomicAdd(&a.cursors[CUR_SITES], nsites);
-        if (tid == 128 && nao) scratch[S_AO_BASE] = atomicAdd(&a.cursors[CUR_AO], nao);
+        if (tid == 0 && nrows) scratch[S_ROW_BASE] = cur_add(a, CUR_SNV, nrows);
+        if (tid == 64 && nsites) scratch[S_SITE_BASE] = cur_add(a, CUR_SITES, nsites);
+        if (tid == 128 && nao) scratch[S_AO_BASE] = cur_add(a, CUR_AO, nao);
         // ---- deferred clonalities (snv_utilities.py:225-231), densely packed ----
         for (uint32_t q = tid; q < nq; q += nthr) {
             const uint32_t e = queue[q];
@@ -350,7 +376,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE], ao_base = scratch[S_AO_BASE];
         bool ok = nrows != 0;
         if (ok && (row_base + nrows > a.cap_snv || site_base + nsites > a.cap_sites || ao_base + nao > a.cap_ao)) {
-            if (tid == 0) atomicOr(a.flags, row_base + nrows > a.cap_snv ? ISX_FLAG_CAP_SNV
+            if (tid == 0) flag_or(a, row_base + nrows > a.cap_snv ? ISX_FLAG_CAP_SNV
                                             : (site_base + nsites > a.cap_sites ? ISX_FLAG_CAP_SITES : ISX_FLAG_CAP_AO));
             ok = false;
         }
@@ -494,7 +520,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
             const uint32_t nxt = i0 + 4 * nthr;
             if (nxt < hi) issue(nxt);
         }
-        if (bad_mm) atomicOr(a.flags, ISX_FLAG_MM_RANGE);
+        if (bad_mm) flag_or(a, ISX_FLAG_MM_RANGE);
         __syncthreads();
         if (!linkage) prefetch_window(w + grid);
         const int dbg = a.debug_mode;           // ablation switches (tools/ablate_mm.py), 0 in production
@@ -569,8 +595,8 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                 uint64_t ei;
                 if (slot_w < CW) ei = slab0 + slot_w;
                 else {                                              // slab full (more than CW / W levels per position on average)
-                    const uint32_t o = atomicAdd(&a.cursors[CUR_ENTRIES], 1u);
-                    if (o >= a.cap_ovf) { atomicOr(a.flags, ISX_FLAG_CAP_ENTRIES); continue; }
+                    const uint32_t o = cur_add(a, CUR_ENTRIES, 1u);
+                    if (o >= a.cap_ovf) { flag_or(a, ISX_FLAG_CAP_ENTRIES); continue; }
                     ei = a.ovf0 + o;
                 }
 #pragma unroll
@@ -626,14 +652,14 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                     rowq[qi * 4 + 2] = s_off | (nlev << 24);
                     rowq[qi * 4 + 3] = v_off;
                 } else {                                            // row queue full: this position allocates by itself
-                    const uint32_t row_at = atomicAdd(&a.cursors[CUR_SNV], rows);
+                    const uint32_t row_at = cur_add(a, CUR_SNV, rows);
                     uint32_t slev_at = 0xFFFFFFFFu;
                     bool fine = row_at + rows <= a.cap_snv;
-                    if (!fine) atomicOr(a.flags, ISX_FLAG_CAP_SNV);
+                    if (!fine) flag_or(a, ISX_FLAG_CAP_SNV);
                     if (any && fine) {
-                        const uint32_t sa = atomicAdd(&a.cursors[CUR_SITES], 1u);
-                        slev_at = atomicAdd(&a.cursors[CUR_SLEV], nlev);
-                        if (sa >= a.cap_sites || slev_at + nlev > a.cap_slev) { atomicOr(a.flags, ISX_FLAG_CAP_SITES); fine = false; }
+                        const uint32_t sa = cur_add(a, CUR_SITES, 1u);
+                        slev_at = cur_add(a, CUR_SLEV, nlev);
+                        if (sa >= a.cap_sites || slev_at + nlev > a.cap_slev) { flag_or(a, ISX_FLAG_CAP_SITES); fine = false; }
                         else {
                             isx_site ss;
                             ss.gpos = gpos; ss.entry_off = slev_at; ss.n_levels = (uint16_t)nlev;
@@ -652,10 +678,10 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
             a.win_nent[w] = min(n_ent, CW);
             my_entries += n_ent;                                    // per-workgroup total, published once at the end
         }
-        if (tid == 64 && nrows) scratch[S_ROW_BASE] = atomicAdd(&a.cursors[CUR_SNV], nrows);
-        if (tid == 128 && nsites) scratch[S_SITE_BASE] = atomicAdd(&a.cursors[CUR_SITES], nsites);
-        if (tid == 192 && nao) scratch[S_AO_BASE] = atomicAdd(&a.cursors[CUR_AO], nao);
-        if (tid == 256 % nthr && nslev) scratch[S_SLEV_BASE] = atomicAdd(&a.cursors[CUR_SLEV], nslev);
+        if (tid == 64 && nrows) scratch[S_ROW_BASE] = cur_add(a, CUR_SNV, nrows);
+        if (tid == 128 && nsites) scratch[S_SITE_BASE] = cur_add(a, CUR_SITES, nsites);
+        if (tid == 192 && nao) scratch[S_AO_BASE] = cur_add(a, CUR_AO, nao);
+        if (tid == 256 % nthr && nslev) scratch[S_SLEV_BASE] = cur_add(a, CUR_SLEV, nslev);
         // ---- deferred clonalities: calculate_clonality (snv_utilities.py:225-231) in fp64, densely packed ----
         const uint32_t nq = min(scratch[S_NQ], QCAP);
         for (uint32_t q = tid; q < nq; q += nthr) {
@@ -675,7 +701,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         bool ok = true;
         if (nrows && (row_base + nrows > a.cap_snv || site_base + nsites > a.cap_sites || ao_base + nao > a.cap_ao ||
                       slev_base + nslev > a.cap_slev)) {
-            if (tid == 0) atomicOr(a.flags, row_base + nrows > a.cap_snv ? ISX_FLAG_CAP_SNV
+            if (tid == 0) flag_or(a, row_base + nrows > a.cap_snv ? ISX_FLAG_CAP_SNV
                                             : ao_base + nao > a.cap_ao ? ISX_FLAG_CAP_AO : ISX_FLAG_CAP_SITES);
             ok = false;
         }
@@ -700,7 +726,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         }
         __syncthreads();
     }
-    if (tid == 0 && my_entries) atomicAdd(&a.cursors[CUR_ENT_TOTAL], my_entries);
+    if (tid == 0 && my_entries) cur_add(a, CUR_ENT_TOTAL, my_entries);
 }
 
 }  // namespace
@@ -732,4 +758,9 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_pileup_dense, dim3(grid), dim3(block), lds, s, a);
     }
+}
+
+void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, s, a.cursors, a.host_state, epoch);
 }

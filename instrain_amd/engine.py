@@ -91,6 +91,13 @@ class Batch:
         check(self.lib.isx_batch_timings(self.h, C.byref(t)))
         return {n: getattr(t, n) for n, _ in Timings._fields_}
 
+    def pileup_ms(self):
+        """device time of the pileup kernel of the last run (cheap accessor for timing loops)"""
+        if not hasattr(self, "_tim"):
+            self._tim = Timings()
+        check(self.lib.isx_batch_timings(self.h, C.byref(self._tim)))
+        return self._tim.pileup_ms
+
     def fetch(self):
         """-> dict(entries | (counts, clon), snv, ld) as numpy structured arrays (canonical order)."""
         s = self.sizes()
