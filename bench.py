@@ -161,10 +161,15 @@ def mm_leg(ctx, w, steps=10):
     b.close()
     dt, k = float(np.median(ts)), float(np.mean(ks))
     ab = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], s["n_entries"], dense=False)
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get("c2_mm_pileup_bytes_per_launch")
+    except Exception:
+        pass
     return {"workload": "C2 with mm profiling on (%d mm bins)" % w["n_mm_bins_mm"], "gbp_per_s": w["profiled_bases"] / 1e9 / dt,
             "ms_per_step": dt * 1e3, "entries": s["n_entries"], "snv_rows": s["n_snv"],
             "roofline": {"bound": "hbm", "kernel": "k_pileup_mm", "achieved": ab / (k * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ab / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
+                         "unit": "GB/s", "frac": ab / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ab,
                          "kernel_ms_avg": k, "blocks": t["pileup_blocks"], "threads": t["pileup_threads"],
                          "lds_bytes": t["pileup_lds_bytes"], "window": t["pileup_window"]}}
 
