@@ -494,7 +494,10 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
             const int64_t n = c >> 4;
             if (op == CM || op == CEQ || op == CX) {
                 const uint32_t g0 = (uint32_t)(base_off + ref);
+                const int64_t ref_len = B.ref_len[(size_t)r.tid];
                 for (int64_t j = 0; j < n; j++) {
+                    // the reference's pileups are truncated to [0, scaffold length) (profile_utilities.py:150-153)
+                    if (ref + j < 0 || ref + j >= ref_len) continue;
                     if (ql[q + j] >= minq) {
                         isx_obs &o = po[n_out];
                         o.gpos = g0 + (uint32_t)j; o.mm = mm; o.base = CODE2IDX[sq[q + j]]; o.flags = 0;

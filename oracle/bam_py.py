@@ -355,7 +355,7 @@ def resolve_overlaps(reads, tid):
             tweak_overlap_quality(a, r)
 
 
-def expand_observations(reads, tid, r2m, min_base_quality=30, skip_mm=False):
+def expand_observations(reads, tid, r2m, min_base_quality=30, skip_mm=False, ref_len=None):
     """Packed per-base observations of the reads kept by R2M, in file order then
     query order: (pos, base_idx[A,C,T,G,other], mm, pair_id).  This is exactly the set
     of (column, pileupread) visits on which get_base_counts_mm (profile_utilities.py:268-286)
@@ -374,7 +374,11 @@ def expand_observations(reads, tid, r2m, min_base_quality=30, skip_mm=False):
         for op, n in r.cigar:
             if op in (CM, CEQ, CX):
                 qs = r.qual[q:q + n]
-                keep = np.nonzero(qs >= min_base_quality)[0]
+                ok = qs >= min_base_quality
+                if ref_len is not None:      # pileups are truncated to the scaffold (truncate=True, stop=end+1)
+                    rp = ref + np.arange(n)
+                    ok = ok & (rp >= 0) & (rp < ref_len)
+                keep = np.nonzero(ok)[0]
                 if len(keep):
                     P.append(ref + keep)
                     B.append(_CODE2IDX[r.seq[q:q + n][keep]])

@@ -62,3 +62,38 @@ def test_skip_mm_and_errors():
         assert False
     except engine.IsxError as e:
         assert e.code == -5
+
+
+def test_random_messy_bam_cpp_equals_oracle_python(tmp_path):
+    """synthetic BAMs with indels / clips / ref-skips / =X / overlapping disagreeing mates / flag zoo /
+    aux tags of every type: product C++ front end == oracle/bam_py.py, observation for observation"""
+    from oracle import bam_py
+    from tests import bamwriter
+    refs = [("scafA", 4000), ("scafB", 900), ("scafC", 12500)]
+    for seed in (1, 2, 3):
+        path = str(tmp_path / ("r%d.bam" % seed))
+        reads = bamwriter.random_reads(seed, refs, 1500)
+        bamwriter.write_bam(path, refs, reads)
+        rrefs, rr = bam_py.read_bam(path)
+        assert rrefs == refs and len(rr) == len(reads)
+        p2i = {r[0]: bam_py.get_paired_reads(rr, t) for t, r in enumerate(refs)}
+        r2m, tallies = bam_py.filter_pairs(p2i, min_read_ani=0.9)
+        bam = engine.BamFile(path)
+        obs, pair, bounds, sref = bam.expand(min_read_ani=0.9, window_length=1000)
+        assert bam.info["filtered_pairs"] == sum(t["filtered_pairs"] for t in tallies.values()) > 300
+        assert bam.info["unfiltered_pairs"] == sum(t["unfiltered_pairs"] for t in tallies.values())
+        P, B, M, R = [], [], [], []
+        off = 0
+        nid = 0
+        for t, (name, ln) in enumerate(refs):
+            bam_py.resolve_overlaps(rr, t)
+            pos, base, mm, pr, n2i = bam_py.expand_observations(rr, t, r2m[name], ref_len=ln)
+            P.append(pos + off); B.append(base); M.append(mm); R.append(pr + nid)
+            off += ln
+            nid += len(n2i)
+        assert len(obs) == sum(len(x) for x in P) > 20000
+        assert (obs["gpos"] == np.concatenate(P)).all() and (obs["base"] == np.concatenate(B)).all()
+        assert (obs["mm"] == np.concatenate(M)).all() and (pair == np.concatenate(R)).all()
+        from instrain_amd import synth
+        assert list(bounds) == list(synth.split_bounds_for([r[1] for r in refs], 1000))
+        bam.close()

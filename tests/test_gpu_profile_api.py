@@ -186,3 +186,65 @@ def test_snv_pooling_repileup_counts():
     top = gS.sort_values("mm").drop_duplicates("position", keep="last")
     for _, r in top.iterrows():
         assert (np.array([r["A"], r["C"], r["T"], r["G"]]) <= got[int(r["position"])]).all()
+
+
+def test_end_to_end_messy_bam_vs_oracle(tmp_path):
+    """BAM with indels / clips / overlapping mates / three scaffolds -> profile_bam (C++ front end + HIP
+    kernels) == oracle (Python front end + C oracle), split by split"""
+    import instrain_amd.profile as prof
+    from oracle import bam_py, oracle
+    from tests import bamwriter, prod
+    from tests.test_oracle_golden import iterate_splits
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    refs = [("scafA", 2500), ("scafB", 700), ("scafC", 3100)]
+    rng = np.random.Generator(np.random.PCG64(77))
+    seqs = {n: "".join(rng.choice(list("ACGT"), ln)) for n, ln in refs}
+    path = str(tmp_path / "messy.bam")
+    reads = bamwriter.random_reads(9, refs, 4000)
+    bamwriter.write_bam(path, refs, reads)
+    splits = prof.profile_bam(path, s2s=seqs, null_model=model, min_cov=5, min_freq=0.05, min_snp=10, min_read_ani=0.9,
+                              window_length=1000)
+    rrefs, rr = bam_py.read_bam(path)
+    p2i = {r[0]: bam_py.get_paired_reads(rr, t) for t, r in enumerate(refs)}
+    r2m, _ = bam_py.filter_pairs(p2i, min_read_ani=0.9)
+    n_rows = n_ld = 0
+    for t, (name, ln) in enumerate(refs):
+        bam_py.resolve_overlaps(rr, t)
+        pos, base, mm, pr, _ = bam_py.expand_observations(rr, t, r2m[name])
+        for i, (s, e) in enumerate(iterate_splits(ln, 1000)):
+            exp = oracle.profile_split(pos, base, mm, pr, seqs[name][s:e + 1], s, lut, fb, min_cov=5, min_freq=0.05, min_snp=10)
+            S = splits["%s.%d" % (name, i)]
+            assert S.length == e - s + 1
+            got_snv = S.raw_snp_table
+            o = np.lexsort((exp["snv"]["mm"], exp["snv"]["pos"]))
+            es = exp["snv"][o]
+            assert len(got_snv) == len(es)
+            if len(es):
+                g = got_snv.sort_values(["position", "mm"])
+                assert (g["position"].values == es["pos"]).all() and (g["mm"].values == es["mm"]).all()
+                for k, b in enumerate("ACTG"):
+                    assert (g[b].values == es["cnt"][:, k]).all()
+                assert (g["con_base"].values == util.BASES[es["con_base"]]).all()
+                assert (g["class"].values == util.CLASSES[es["cls"]]).all()
+                assert (g["cryptic"].values == es["cryptic"].astype(bool)).all()
+            L = S.raw_linkage_table
+            o = np.lexsort((exp["ld"]["mm"], exp["ld"]["pos_b"], exp["ld"]["pos_a"]))
+            el = exp["ld"][o]
+            assert len(L) == len(el)
+            if len(el):
+                L = L.sort_values(["position_A", "position_B", "mm"])
+                assert (L["position_A"].values == el["pos_a"]).all() and (L["total"].values == el["total"]).all()
+                assert (L["countAB"].values == el["cAB"]).all() and (L["countab"].values == el["cab"]).all()
+                a, b = L["r2"].values.astype(float), el["r2"]
+                assert (np.isnan(a) == np.isnan(b)).all() and (np.nanmax(np.abs(a - b)) if (~np.isnan(a)).any() else 0) <= 1e-6
+            # covT per mm
+            lv = exp["entries"]["cnt"].sum(axis=1)
+            for m in set(int(x) for x in exp["entries"]["mm"][lv > 0]):
+                k = (exp["entries"]["mm"] == m) & (lv > 0)
+                ser = S.covT[m].sort_index()
+                assert (ser.index.values == np.sort(exp["entries"]["pos"][k])).all()
+                assert (ser.values == lv[k][np.argsort(exp["entries"]["pos"][k])]).all()
+            n_rows += len(es); n_ld += len(el)
+    assert n_rows > 50
