@@ -108,6 +108,18 @@ static std::vector<uint16_t> build_thresholds(const std::vector<int32_t> &lut, i
     return thr;
 }
 
+template <class T>
+static int regrow(T **p, size_t *cap, size_t hard_max, size_t elem_pad = 0)
+{
+    if (*cap >= hard_max) { isx_set_error("output table is at its hard bound and still too small"); return ISX_ERR_CAPACITY; }
+    const size_t want = std::min(hard_max, std::max<size_t>(*cap * 4, 1024));
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    HIP_TRY(hipMalloc(p, (want + elem_pad) * sizeof(T)));
+    *cap = want;
+    return ISX_OK;
+}
+
 extern "C" {
 
 const char *isx_last_error(void) { return g_err.c_str(); }
@@ -395,9 +407,10 @@ static float ev_ms(hipEvent_t a, hipEvent_t b)
     return ms;
 }
 
-int isx_batch_run(isx_batch *b)
+// one pass; *cap_flags receives the ISX_FLAG_CAP_* bits of tables that were too small (the caller grows them)
+static int run_once(isx_batch *b, uint32_t *cap_flags)
 {
-    if (!b) { isx_set_error("isx_batch_run: NULL batch"); return ISX_ERR_ARG; }
+    *cap_flags = 0;
     isx_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -448,10 +461,9 @@ int isx_batch_run(isx_batch *b)
         memset(b->base, 0, sizeof(b->base));
     }
     if (flags & ISX_FLAG_MM_RANGE) { isx_set_error("an observation has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
-    if (b->M > 1 && cur[CUR_ENTRIES] > b->cap_ovf) { isx_set_error("entry overflow region exhausted"); return ISX_ERR_CAPACITY; }
     if (flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES | ISX_FLAG_CAP_AO)) {
-        isx_set_error("output table capacity exceeded (flags " + std::to_string(flags) + ")");
-        return ISX_ERR_CAPACITY;
+        *cap_flags = flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES | ISX_FLAG_CAP_AO);
+        return ISX_OK;
     }
     b->sizes = isx_sizes{};
     b->sizes.n_entries = cur[CUR_ENT_TOTAL];
@@ -496,6 +508,46 @@ int isx_batch_run(isx_batch *b)
     }
     b->ran = true;
     return ISX_OK;
+}
+
+int isx_batch_run(isx_batch *b)
+{
+    if (!b) { isx_set_error("isx_batch_run: NULL batch"); return ISX_ERR_ARG; }
+    // Output tables start from generous estimates; a table that turns out too small (e.g. SNS rows at
+    // every position of a divergent reference) is grown x4 up to its hard bound and the pass repeated.
+    const uint64_t npm = (uint64_t)b->n_pos * b->M;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        uint32_t cf = 0;
+        int rc = run_once(b, &cf);
+        if (rc != ISX_OK) return rc;
+        if (!cf) return ISX_OK;
+        HIP_TRY(hipSetDevice(b->ctx->device));
+        if (cf & ISX_FLAG_CAP_SNV) { if ((rc = regrow(&b->d_snv, &b->cap_snv, (size_t)npm))) return rc; }
+        if (cf & ISX_FLAG_CAP_SITES) {
+            if ((rc = regrow(&b->d_sites, &b->cap_sites, (size_t)b->n_pos))) return rc;
+            if (b->M > 1) {
+                if (b->d_slev) (void)hipFree(b->d_slev);
+                b->d_slev = nullptr;
+                b->cap_slev = b->cap_sites * (size_t)b->M;
+                HIP_TRY(hipMalloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
+            }
+        }
+        if (cf & ISX_FLAG_CAP_AO) { if ((rc = regrow(&b->d_ao, &b->cap_ao, (size_t)std::max<int64_t>(b->n_obs, 1)))) return rc; }
+        if (cf & ISX_FLAG_CAP_ENTRIES) {
+            const size_t slabs = (size_t)b->n_win * b->slab;
+            size_t cap = b->cap_ovf;
+            isx_entry *dummy = nullptr;
+            if ((rc = regrow(&dummy, &cap, (size_t)npm))) return rc;      // size check only
+            (void)hipFree(dummy);
+            if (slabs + cap >= 0xFFFFFFFFull) { isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_CAPACITY; }
+            if (b->d_entries) (void)hipFree(b->d_entries);
+            b->d_entries = nullptr;
+            HIP_TRY(hipMalloc(&b->d_entries, (slabs + cap) * sizeof(isx_entry)));
+            b->cap_ovf = cap; b->cap_entries = slabs + cap;
+        }
+    }
+    isx_set_error("output tables still too small after 8 growth steps");
+    return ISX_ERR_CAPACITY;
 }
 
 int isx_batch_sizes(const isx_batch *b, isx_sizes *out)

@@ -281,3 +281,20 @@ def test_deep_window_takes_unpacked_automatically(ctx):
     got = prod.run_split(ctx, pos, base, mm, pair, "AAAC", 0, n_mm_bins=3)
     util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="deep")
     assert got["entries"]["cnt"].sum() == n
+
+
+def test_tables_grow_when_estimates_are_too_small(ctx, monkeypatch):
+    """rows at every position of a >1 Mbp divergent reference exceed the initial SNV-row estimate
+    (max(n_pos / 2, 2^20)): the library grows the table and repeats the pass instead of failing"""
+    from instrain_amd import engine
+    n_pos, depth = 1_300_000, 6
+    pos = np.repeat(np.arange(n_pos, dtype=np.uint32), depth)
+    base = np.ones(len(pos), dtype=np.uint8)                  # every read says C ...
+    obs = engine.pack_obs(pos, base, np.zeros(len(pos), int))
+    b = engine.Batch(ctx, np.zeros(n_pos, np.uint8), [0, n_pos], obs, np.arange(len(pos), dtype=np.uint32) // depth,
+                     n_mm_bins=1, enable_linkage=False)          # ... the reference says A: SNS everywhere
+    b.run()
+    s = b.sizes()
+    snv = b.fetch()["snv"]
+    b.close()
+    assert s["n_snv"] == n_pos and (snv["cls"] == 2).all() and (snv["gpos"] == np.arange(n_pos)).all()
