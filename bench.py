@@ -206,8 +206,10 @@ def main():
 
     want_mm = world == 1 and not args.no_mm_leg
     w = c2_workload(seed=2 + rank, scale=args.scale, with_mm=want_mm)
+    t_up = time.perf_counter()
     batch = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], None, n_mm_bins=1,
                          enable_linkage=False, window=args.window)
+    upload_s = time.perf_counter() - t_up          # allocations + pinned double-buffered H2D + window directory
 
     def barrier():
         if world > 1:
@@ -279,6 +281,10 @@ def main():
                          "blocks": tim["pileup_blocks"], "threads": tim["pileup_threads"],
                          "lds_bytes": tim["pileup_lds_bytes"]},
             "snv_rows": sizes["n_snv"], "snp_sites": sizes["n_sites"],
+            # host -> device hand-over of the batch (never part of `value`): isx_batch_create wall time
+            "upload": {"ms": upload_s * 1e3, "bytes": int(w["n_obs"]) * 8 + int(w["n_pos"]),
+                       "gb_per_s": (int(w["n_obs"]) * 8 + int(w["n_pos"])) / upload_s / 1e9,
+                       "gbp_per_s_including_upload": units / world / 1e9 / (upload_s + dt / args.steps)},
         }
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms

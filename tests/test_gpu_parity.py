@@ -149,11 +149,11 @@ def test_mm_out_of_range_is_loud(ctx):
 
 
 def test_full_size_properties(ctx):
-    """BASELINE config-2-shaped batch (reduced to 1 Mbp to keep the suite short): properties that do
-    not need the oracle -- sum of level counts == number of ACGT observations; re-run idempotence;
-    covT vs SNV-table coverage consistency (reference test_profile_13)."""
+    """BASELINE configs[1] at FULL size (5 Mbp, 20x, 9e7 observations): properties that do not need the
+    oracle -- sum of level counts == number of ACGT observations (a checksum of checksums: also per
+    split); re-run idempotence; covT vs SNV-table coverage consistency (reference test_profile_13)."""
     from instrain_amd import engine, synth
-    w = synth.make_workload(genome_len=1_000_000, coverage=20, n_sites=1000, seed=2, skip_mm=True)
+    w = synth.make_workload(genome_len=5_000_000, coverage=20, n_sites=5000, seed=2, skip_mm=True)
     b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1)
     b.run()
     r1 = b.fetch()
@@ -161,6 +161,10 @@ def test_full_size_properties(ctx):
     r2 = b.fetch()
     b.close()
     assert int(r1["counts"].sum()) == int((w["obs"]["base"] < 4).sum())
+    per_split = np.add.reduceat(r1["counts"].sum(axis=1).astype(np.int64), w["split_bounds"][:-1])
+    exp_split = np.bincount(np.searchsorted(w["split_bounds"], w["obs"]["gpos"][w["obs"]["base"] < 4], side="right") - 1,
+                            minlength=len(w["split_bounds"]) - 1)
+    assert (per_split == exp_split).all()
     for k in r1:
         assert r1[k].tobytes() == r2[k].tobytes(), k
     cov = r1["counts"].sum(axis=1)
