@@ -206,19 +206,44 @@ typedef struct {
 int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, isx_scaffold_level *out,
                         float *device_ms);
 
-/* ---- compare: coverage overlap of two samples (readComparer.py:145-191 calc_mm2overlap) ----
+/* ---- compare: two samples on the same scaffolds (readComparer.py:35-143 compare_scaffold, one pair) ----
  * Two batches over the SAME flat space (same scaffolds laid out identically, same ctx).  One row per
  * (scaffold, mm): positions where both / either sample reach min_cov in the coverage cumulated over
- * levels <= mm; present_x = the level is a key of that sample's covT on the scaffold (the reference
- * evaluates the union of both key sets). */
+ * levels <= mm (readComparer.py:145-191 calc_mm2overlap); present_x = the level is a key of that
+ * sample's covT on the scaffold (the reference evaluates the union of both key sets).
+ * consensus_snps / population_snps: rows of the reference's Mdb at that mm with the flag set
+ * (readComparer.py:205-290 _calc_SNP_count_alternate, :437-502 _update_overlap_table); -1 when the SNP
+ * half was not run (isx_compare_coverage), -2 when the reference itself fails on this scaffold (a SNP row
+ * with an N reference base that the other sample lacks makes it look up the column 'N_1' -> KeyError). */
 typedef struct {
     int64_t both, either;
     int32_t mm, present_a, present_b, pad;
+    int64_t consensus_snps, population_snps;
 } isx_compare_level;
 
-/* out[n_scaffolds][max(n_mm_bins_a, n_mm_bins_b)] */
+/* One row of the reference's Mdb (readComparer.py:221-225 OUT_COLUMNS): a position covered by both
+ * samples at `mm` whose highest-mm SNP rows differ in consensus (consensus_snp) and / or share no
+ * detectable allele (population_snp).  has_x = sample x has a SNP row there (else its columns are NaN
+ * in the reference, 0 here); bases 0..3 = A,C,T,G, 4 = N; position_coverage_x = sum of cnt_x. */
+typedef struct {
+    uint32_t gpos;
+    uint16_t mm;
+    uint8_t consensus_snp, population_snp;
+    uint8_t has_a, has_b;
+    uint8_t con_a, ref_a, var_a, con_b, ref_b, var_b;
+    uint32_t cnt_a[4], cnt_b[4];
+} isx_compare_snp;
+
+/* out[n_scaffolds][max(n_mm_bins_a, n_mm_bins_b)]; coverage half only */
 int isx_compare_coverage(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, int32_t min_cov,
                          isx_compare_level *out, float *device_ms);
+
+/* Coverage half + SNP-table half.  min_freq and the ctx's null model play the roles of compare's
+ * --min_freq / --fdr (is_present, readComparer.py:306-315).  *n_snp_rows = rows isx_compare_fetch_snps
+ * will deliver (sorted by mm, gpos); they stay with batch `a` until its next compare call. */
+int isx_compare_scaffolds(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, int32_t min_cov,
+                          double min_freq, isx_compare_level *out, int64_t *n_snp_rows, float *device_ms);
+int isx_compare_fetch_snps(isx_batch *a, isx_compare_snp *out);
 
 /* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ---- */
 typedef struct isx_bam isx_bam;

@@ -63,7 +63,12 @@ assert SCAFFOLD_LEVEL_DT.itemsize == 88
 
 
 COMPARE_LEVEL_DT = np.dtype([("both", "<i8"), ("either", "<i8"), ("mm", "<i4"), ("present_a", "<i4"),
-                             ("present_b", "<i4"), ("pad", "<i4")])
+                             ("present_b", "<i4"), ("pad", "<i4"), ("consensus_snps", "<i8"), ("population_snps", "<i8")])
+assert COMPARE_LEVEL_DT.itemsize == 48
+COMPARE_SNP_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("consensus_snp", "u1"), ("population_snp", "u1"),
+                           ("has_a", "u1"), ("has_b", "u1"), ("con_a", "u1"), ("ref_a", "u1"), ("var_a", "u1"),
+                           ("con_b", "u1"), ("ref_b", "u1"), ("var_b", "u1"), ("cnt_a", "<u4", (4,)), ("cnt_b", "<u4", (4,))])
+assert COMPARE_SNP_DT.itemsize == 48
 
 
 class IsxError(RuntimeError):
@@ -75,7 +80,7 @@ class IsxError(RuntimeError):
 SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destroy", "isx_set_null_model",
            "isx_batch_create", "isx_batch_destroy", "isx_batch_run", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
-           "isx_batch_summarize", "isx_compare_coverage",
+           "isx_batch_summarize", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
            "isx_bam_open", "isx_bam_close", "isx_bam_expand", "isx_bam_ref", "isx_bam_copy"]
 
 _lib = None
@@ -108,6 +113,8 @@ def load():
     lib.isx_batch_fetch_dense.argtypes = [vp, vp, vp, vp]
     lib.isx_batch_summarize.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_float)]
     lib.isx_compare_coverage.argtypes = [vp, vp, i32, vp, i32, vp, C.POINTER(C.c_float)]
+    lib.isx_compare_scaffolds.argtypes = [vp, vp, i32, vp, i32, C.c_double, vp, C.POINTER(i64), C.POINTER(C.c_float)]
+    lib.isx_compare_fetch_snps.argtypes = [vp, vp]
     lib.isx_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.isx_bam_close.argtypes = [vp]
     lib.isx_bam_close.restype = None

@@ -663,7 +663,42 @@ int isx_compare_coverage(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const 
     SummaryIn ia{}, ib{};
     fill_summary_in(a, n_scaffolds, scaffold_bounds, ia);
     fill_summary_in(b, n_scaffolds, scaffold_bounds, ib);
-    return run_compare(ia, ib, (uint32_t)std::max(min_cov, 0), a->C, out, device_ms);
+    return run_compare(ia, ib, (uint32_t)std::max(min_cov, 0), CompareSnpIn(), a->C, out, device_ms);
+}
+
+int isx_compare_scaffolds(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, int32_t min_cov,
+                          double min_freq, isx_compare_level *out, int64_t *n_snp_rows, float *device_ms)
+{
+    NEED_RUN(a, out);
+    if (!b || !b->ran) { isx_set_error("isx_compare_scaffolds: run both batches first"); return ISX_ERR_STATE; }
+    if (a->ctx != b->ctx || a->n_pos != b->n_pos) { isx_set_error("isx_compare_scaffolds: batches must share ctx and flat space"); return ISX_ERR_ARG; }
+    if (n_scaffolds <= 0 || !scaffold_bounds || scaffold_bounds[0] != 0 || scaffold_bounds[n_scaffolds] != a->n_pos) {
+        isx_set_error("isx_compare_scaffolds: scaffold_bounds must span [0, n_pos]");
+        return ISX_ERR_ARG;
+    }
+    if (!a->ctx->d_lut) { isx_set_error("isx_compare_scaffolds: set the null model first"); return ISX_ERR_STATE; }
+    SummaryIn ia{}, ib{};
+    fill_summary_in(a, n_scaffolds, scaffold_bounds, ia);
+    fill_summary_in(b, n_scaffolds, scaffold_bounds, ib);
+    CompareSnpIn sn;
+    sn.lut = a->ctx->d_lut; sn.lut_n = a->ctx->lut_n; sn.fallback = a->ctx->fallback; sn.min_freq = min_freq;
+    sn.snv_a = a->d_snv; sn.n_a = (uint32_t)a->sizes.n_snv;
+    sn.snv_b = b->d_snv; sn.n_b = (uint32_t)b->sizes.n_snv;
+    const int rc = run_compare(ia, ib, (uint32_t)std::max(min_cov, 0), sn, a->C, out, device_ms);
+    if (n_snp_rows) *n_snp_rows = rc == ISX_OK ? (int64_t)a->C.n_snp_rows : 0;
+    return rc;
+}
+
+int isx_compare_fetch_snps(isx_batch *a, isx_compare_snp *out)
+{
+    NEED_RUN(a, out);
+    const size_t n = a->C.n_snp_rows;
+    if (!n) return ISX_OK;
+    HIP_TRY(hipMemcpy(out, a->C.snp_rows, n * sizeof(isx_compare_snp), hipMemcpyDeviceToHost));
+    std::sort(out, out + n, [](const isx_compare_snp &x, const isx_compare_snp &y) {
+        return x.mm != y.mm ? x.mm < y.mm : x.gpos < y.gpos;
+    });
+    return ISX_OK;
 }
 
 int isx_batch_fetch_snv(isx_batch *b, isx_snv *out)

@@ -41,9 +41,28 @@ struct CompareBuffers {
     float *scratch_f = nullptr;
     int64_t *bounds = nullptr;
     void *acc_a = nullptr, *acc_b = nullptr;
-    unsigned long long *both = nullptr;
+    unsigned long long *both = nullptr;     // [4 * n_seg]: both, either, consensus SNPs, population SNPs
     isx_compare_level *rows = nullptr;
+    // SNP-table half (readComparer.py:205-290)
+    uint64_t *keys = nullptr;               // [4 * cap_snv]: sorted A, sorted B, 2 x sort input
+    uint32_t *idx = nullptr;                // same layout
+    void *cand = nullptr;                   // candidate rows (mm independent verdicts)
+    isx_compare_snp *snp_rows = nullptr;    // emitted (position, mm) rows
+    uint32_t *cursors = nullptr;            // [0] n_cand, [1] n_snp_rows, [2..2+n_seg) scaffold failed
+    void *temp = nullptr;
+    size_t temp_bytes = 0;
+    size_t cap_pos = 0, cap_seg = 0, cap_rows = 0, cap_snv = 0, cap_snp_rows = 0;
+    uint32_t n_snp_rows = 0;                // rows of the last isx_compare_scaffolds
     void release();
 };
 
-int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, CompareBuffers &B, isx_compare_level *host_out, float *ms);
+struct CompareSnpIn {                       // nullptr lut = coverage half only
+    const uint8_t *lut = nullptr;           // 255 = coverage not in the null model -> fallback
+    int32_t lut_n = 0, fallback = 0;
+    double min_freq = 0.05;
+    const isx_snv *snv_a = nullptr, *snv_b = nullptr;
+    uint32_t n_a = 0, n_b = 0;
+};
+
+int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, const CompareSnpIn &snp, CompareBuffers &B,
+                isx_compare_level *host_out, float *ms);

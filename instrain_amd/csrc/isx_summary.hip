@@ -183,13 +183,16 @@ __global__ void __launch_bounds__(256) k_overlap_reduce(const uint32_t *cov_a, c
 }
 
 __global__ void k_pack_compare(const Acc *acc_a, const Acc *acc_b, const unsigned long long *both,
-                               const unsigned long long *either, int n_seg, int mm, int M, isx_compare_level *out)
+                               const unsigned long long *either, const unsigned long long *n_con, const unsigned long long *n_pop,
+                               const uint32_t *failed, int n_seg, int mm, int M, isx_compare_level *out)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
     isx_compare_level r;
     r.both = (int64_t)both[s]; r.either = (int64_t)either[s];
     r.mm = mm; r.present_a = (int32_t)acc_a[s].present; r.present_b = (int32_t)acc_b[s].present; r.pad = 0;
+    r.consensus_snps = failed ? (failed[s] ? -2 : (int64_t)n_con[s]) : -1;
+    r.population_snps = failed ? (failed[s] ? -2 : (int64_t)n_pop[s]) : -1;
     out[(size_t)s * M + mm] = r;
 }
 
@@ -200,6 +203,122 @@ __global__ void __launch_bounds__(256) k_present_dense(const uint32_t *cov, uint
     if (p >= n_pos || cov[p] == 0) return;
     Acc *a = &acc[find_seg(bounds, n_seg, p)];
     if (!a->present) a->present = 1;
+}
+
+// ---- compare, SNP-table half (readComparer.py:205-290 _calc_SNP_count_alternate) ----
+// compare sorts each sample's cumulative_snv_table by mm (compare_utils.py:124-138) and keeps, at EVERY
+// compared mm, the LAST row of a position (drop_duplicates keep='last', no mm filter), i.e. the row of
+// its highest level.  The consensus / population verdict of a position is therefore independent of the
+// compared mm; only the covered-in-both mask changes.  So: one candidate pass, then per mm a mask pass.
+struct SnpCand {
+    uint32_t gpos;
+    uint32_t row_a, row_b;          // index into the samples' SNV tables, 0xFFFFFFFF = no row
+    uint32_t flags;                 // 1 consensus_SNP, 2 population_SNP
+};
+
+__global__ void k_snv_keys(const isx_snv *snv, uint32_t n, uint64_t *keys, uint32_t *idx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = ((uint64_t)snv[i].gpos << 16) | snv[i].mm;
+    idx[i] = i;
+}
+
+// index of the highest-mm row of gpos in a (gpos, mm)-sorted key list, or -1
+__device__ __forceinline__ int64_t last_row_of(const uint64_t *keys, uint32_t n, uint32_t gpos)
+{
+    const uint64_t hi = ((uint64_t)gpos << 16) | 0xFFFFull;
+    uint32_t lo = 0, up = n;                         // first index with key > hi
+    while (lo < up) {
+        const uint32_t mid = (lo + up) >> 1;
+        if (keys[mid] <= hi) lo = mid + 1; else up = mid;
+    }
+    if (lo == 0 || (uint32_t)(keys[lo - 1] >> 16) != gpos) return -1;
+    return (int64_t)lo - 1;
+}
+
+// readComparer.py:306-315 is_present
+__device__ __forceinline__ bool is_present(uint32_t count, uint32_t total, const uint8_t *lut, int32_t lut_n, int32_t fallback,
+                                           double min_freq)
+{
+    int32_t min_bases = fallback;
+    if (total < (uint32_t)lut_n && lut[total] != 255) min_bases = lut[total];
+    return (int64_t)count >= (int64_t)min_bases && ((double)count / (double)total) >= min_freq;
+}
+
+__global__ void __launch_bounds__(256) k_snp_candidates(const uint64_t *keys_a, const uint32_t *idx_a, uint32_t n_a, const isx_snv *snv_a,
+                                                        const uint64_t *keys_b, const uint32_t *idx_b, uint32_t n_b, const isx_snv *snv_b,
+                                                        const uint8_t *lut, int32_t lut_n, int32_t fallback, double min_freq,
+                                                        const int64_t *bounds, int n_seg, SnpCand *cand, uint32_t *cursors)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_a + n_b) return;
+    const bool from_a = t < n_a;
+    const uint64_t *kx = from_a ? keys_a : keys_b;
+    const uint32_t nx = from_a ? n_a : n_b, i = from_a ? t : t - n_a;
+    const uint32_t gpos = (uint32_t)(kx[i] >> 16);
+    if (i + 1 < nx && (uint32_t)(kx[i + 1] >> 16) == gpos) return;          // not the position's last row
+    const int64_t j = from_a ? last_row_of(keys_b, n_b, gpos) : last_row_of(keys_a, n_a, gpos);
+    if (!from_a && j >= 0) return;                                          // shared rows are judged from A's side
+    SnpCand c;
+    c.gpos = gpos;
+    bool con, pop;
+    if (j < 0) {                            // the row exists in one sample only (the other's columns are NaN)
+        const uint32_t r = (from_a ? idx_a : idx_b)[i];
+        const isx_snv x = (from_a ? snv_a : snv_b)[r];
+        c.row_a = from_a ? r : 0xFFFFFFFFu;
+        c.row_b = from_a ? 0xFFFFFFFFu : r;
+        con = x.con_base != x.ref_base;                                     // call_con_snps :296-301
+        if (x.ref_base > 3) {               // '{ref_base}_2' with ref_base N: the reference raises KeyError
+            atomicOr(&cursors[2 + find_seg(bounds, n_seg, gpos)], 1u);
+            return;
+        }
+        const uint32_t total = x.cnt[0] + x.cnt[1] + x.cnt[2] + x.cnt[3];
+        pop = !is_present(x.cnt[x.ref_base], total, lut, lut_n, fallback, min_freq);   // call_pop_snps :329-344
+    } else {
+        const uint32_t ra = idx_a[i], rb = idx_b[j];
+        const isx_snv a = snv_a[ra], b = snv_b[rb];
+        c.row_a = ra; c.row_b = rb;
+        con = a.con_base != b.con_base;                                     // :304
+        const uint32_t ta = a.cnt[0] + a.cnt[1] + a.cnt[2] + a.cnt[3], tb = b.cnt[0] + b.cnt[1] + b.cnt[2] + b.cnt[3];
+        if (!con) pop = false;                                                              // :325
+        else if (is_present(b.cnt[a.con_base & 3], tb, lut, lut_n, fallback, min_freq)) pop = false;   // :349-355
+        else if (is_present(a.cnt[b.con_base & 3], ta, lut, lut_n, fallback, min_freq)) pop = false;   // :358-361
+        else if (a.allele_count > 1 && b.allele_count > 1 && a.var_base == b.var_base) pop = false;   // :364-367
+        else pop = true;
+    }
+    if (!con && !pop) return;                                               // "Only keep SNPs" :281
+    c.flags = (con ? 1u : 0u) | (pop ? 2u : 0u);
+    cand[atomicAdd(&cursors[0], 1u)] = c;
+}
+
+__global__ void __launch_bounds__(256) k_snp_apply(const SnpCand *cand, uint32_t *cursors, const uint32_t *cov_a, const uint32_t *cov_b,
+                                                   uint32_t min_cov, const int64_t *bounds, int n_seg, unsigned long long *n_con,
+                                                   unsigned long long *n_pop, const isx_snv *snv_a, const isx_snv *snv_b, uint32_t mm,
+                                                   isx_compare_snp *rows)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cursors[0]) return;
+    const SnpCand c = cand[t];
+    if (cov_a[c.gpos] < min_cov || cov_b[c.gpos] < min_cov) return;         // position not in mm2overlap[mm]
+    const int seg = find_seg(bounds, n_seg, c.gpos);
+    if (c.flags & 1u) atomicAdd(&n_con[seg], 1ull);
+    if (c.flags & 2u) atomicAdd(&n_pop[seg], 1ull);
+    isx_compare_snp r;
+    memset(&r, 0, sizeof(r));
+    r.gpos = c.gpos; r.mm = (uint16_t)mm;
+    r.consensus_snp = c.flags & 1u; r.population_snp = (c.flags >> 1) & 1u;
+    if (c.row_a != 0xFFFFFFFFu) {
+        const isx_snv a = snv_a[c.row_a];
+        r.has_a = 1; r.con_a = a.con_base; r.ref_a = a.ref_base; r.var_a = a.var_base;
+        for (int k = 0; k < 4; k++) r.cnt_a[k] = a.cnt[k];
+    }
+    if (c.row_b != 0xFFFFFFFFu) {
+        const isx_snv b = snv_b[c.row_b];
+        r.has_b = 1; r.con_b = b.con_base; r.ref_b = b.ref_base; r.var_b = b.var_base;
+        for (int k = 0; k < 4; k++) r.cnt_b[k] = b.cnt[k];
+    }
+    rows[atomicAdd(&cursors[1], 1u)] = r;
 }
 
 template <class T>
@@ -290,28 +409,81 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
 
 void CompareBuffers::release()
 {
-    void *ps[] = {cov_a, cov_b, scratch_f, bounds, acc_a, acc_b, both, rows};
+    void *ps[] = {cov_a, cov_b, scratch_f, bounds, acc_a, acc_b, both, rows, keys, idx, cand, snp_rows, cursors, temp};
     for (void *p : ps) if (p) (void)hipFree(p);
     *this = CompareBuffers();
 }
 
-int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, CompareBuffers &B, isx_compare_level *host_out, float *ms)
+template <class T>
+static int ensure(T **p, size_t have, size_t want)
+{
+    if (*p && have >= want) return ISX_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    HIP_TRY(hipMalloc(p, std::max<size_t>(want, 1) * sizeof(T)));
+    return ISX_OK;
+}
+
+int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, const CompareSnpIn &snp, CompareBuffers &B,
+                isx_compare_level *host_out, float *ms)
 {
     hipStream_t s = a.stream;
     const uint32_t n_pos = a.n_pos;
     const int n_seg = a.n_scaffolds, M = std::max(a.M, b.M);
+    const bool do_snp = snp.lut != nullptr;
+    const size_t n_snv = do_snp ? std::max<size_t>(snp.n_a, snp.n_b) : 0, n_ab = do_snp ? (size_t)snp.n_a + snp.n_b : 0;
     int rc;
-    if ((rc = dev_alloc(&B.cov_a, n_pos)) || (rc = dev_alloc(&B.cov_b, n_pos)) || (rc = dev_alloc(&B.scratch_f, (size_t)n_pos * 2)) ||
-        (rc = dev_alloc(&B.bounds, (size_t)n_seg + 1)) || (rc = dev_alloc(reinterpret_cast<Acc **>(&B.acc_a), (size_t)n_seg)) ||
-        (rc = dev_alloc(reinterpret_cast<Acc **>(&B.acc_b), (size_t)n_seg)) || (rc = dev_alloc(&B.both, (size_t)n_seg * 2)) ||
-        (rc = dev_alloc(&B.rows, (size_t)n_seg * M))) return rc;
+    if ((rc = ensure(&B.cov_a, B.cap_pos, n_pos)) || (rc = ensure(&B.cov_b, B.cap_pos, n_pos)) ||
+        (rc = ensure(&B.scratch_f, B.cap_pos * 2, (size_t)n_pos * 2))) return rc;
+    B.cap_pos = std::max<size_t>(B.cap_pos, n_pos);
+    if ((rc = ensure(&B.bounds, B.cap_seg + 1, (size_t)n_seg + 1)) ||
+        (rc = ensure(reinterpret_cast<Acc **>(&B.acc_a), B.cap_seg, (size_t)n_seg)) ||
+        (rc = ensure(reinterpret_cast<Acc **>(&B.acc_b), B.cap_seg, (size_t)n_seg)) ||
+        (rc = ensure(&B.both, B.cap_seg * 4, (size_t)n_seg * 4)) ||
+        (rc = ensure(&B.cursors, B.cap_seg + 2, (size_t)n_seg + 2))) return rc;
+    B.cap_seg = std::max<size_t>(B.cap_seg, (size_t)n_seg);
+    if ((rc = ensure(&B.rows, B.cap_rows, (size_t)n_seg * M))) return rc;
+    B.cap_rows = std::max(B.cap_rows, (size_t)n_seg * M);
+    if (do_snp) {
+        if ((rc = ensure(&B.keys, B.cap_snv * 4, n_snv * 4)) || (rc = ensure(&B.idx, B.cap_snv * 4, n_snv * 4)) ||
+            (rc = ensure(reinterpret_cast<SnpCand **>(&B.cand), B.cap_snv * 2, n_snv * 2))) return rc;
+        B.cap_snv = std::max(B.cap_snv, n_snv);
+        if ((rc = ensure(&B.snp_rows, B.cap_snp_rows, n_ab * M))) return rc;
+        B.cap_snp_rows = std::max(B.cap_snp_rows, n_ab * M);
+        size_t tb = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, B.keys, B.keys, B.idx, B.idx, std::max<size_t>(n_snv, 1), 0, 48, s));
+        if (B.temp_bytes < tb) {
+            if (B.temp) (void)hipFree(B.temp);
+            B.temp = nullptr;
+            HIP_TRY(hipMalloc(&B.temp, tb + 256));
+            B.temp_bytes = tb + 256;
+        }
+    }
+    B.n_snp_rows = 0;
     HIP_TRY(hipMemcpyAsync(B.bounds, a.scaffold_bounds, ((size_t)n_seg + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(a.ev[0], s));
     HIP_TRY(hipMemsetAsync(B.cov_a, 0, (size_t)n_pos * 4, s));
     HIP_TRY(hipMemsetAsync(B.cov_b, 0, (size_t)n_pos * 4, s));
+    HIP_TRY(hipMemsetAsync(B.cursors, 0, ((size_t)n_seg + 2) * 4, s));
     Acc *acc_a = reinterpret_cast<Acc *>(B.acc_a), *acc_b = reinterpret_cast<Acc *>(B.acc_b);
     const dim3 blk(256), gpos((n_pos + 255) / 256), gseg((n_seg + 255) / 256);
     float *f0 = B.scratch_f, *f1 = B.scratch_f + n_pos;
+    uint64_t *keys_a = B.keys, *keys_b = B.keys + n_snv, *keys_in = B.keys + 2 * n_snv;
+    uint32_t *idx_a = B.idx, *idx_b = B.idx + n_snv, *idx_in = B.idx + 2 * n_snv;
+    SnpCand *cand = reinterpret_cast<SnpCand *>(B.cand);
+    const dim3 gab((unsigned)((n_ab + 255) / 256));
+    if (do_snp && n_ab) {
+        auto sorted = [&](const isx_snv *snv, uint32_t n, uint64_t *keys, uint32_t *idx) -> int {
+            if (!n) return ISX_OK;
+            hipLaunchKernelGGL(k_snv_keys, dim3((n + 255) / 256), blk, 0, s, snv, n, keys_in, idx_in);
+            size_t t = B.temp_bytes;
+            HIP_TRY(rocprim::radix_sort_pairs(B.temp, t, keys_in, keys, idx_in, idx, n, 0, 48, s));
+            return ISX_OK;
+        };
+        if ((rc = sorted(snp.snv_a, snp.n_a, keys_a, idx_a)) || (rc = sorted(snp.snv_b, snp.n_b, keys_b, idx_b))) return rc;
+        hipLaunchKernelGGL(k_snp_candidates, gab, blk, 0, s, keys_a, idx_a, snp.n_a, snp.snv_a, keys_b, idx_b, snp.n_b, snp.snv_b,
+                           snp.lut, snp.lut_n, snp.fallback, snp.min_freq, B.bounds, n_seg, cand, B.cursors);
+    }
     auto apply = [&](const SummaryIn &in, int mm, uint32_t *cov, Acc *acc) {
         hipLaunchKernelGGL(k_reset_acc, gseg, blk, 0, s, acc, n_seg);
         if (mm >= in.M) return;                 // no such level in this sample: coverage carries over
@@ -323,18 +495,26 @@ int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, Compar
                                (uint32_t)mm, cov, f0, f1, B.bounds, n_seg, acc);
         }
     };
+    unsigned long long *both = B.both, *either = B.both + n_seg, *n_con = B.both + 2 * (size_t)n_seg, *n_pop = B.both + 3 * (size_t)n_seg;
     for (int mm = 0; mm < M; mm++) {
         apply(a, mm, B.cov_a, acc_a);
         apply(b, mm, B.cov_b, acc_b);
-        HIP_TRY(hipMemsetAsync(B.both, 0, (size_t)n_seg * 2 * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(B.both, 0, (size_t)n_seg * 4 * sizeof(unsigned long long), s));
         const uint32_t tiles = (n_pos + 63) / 64;
         hipLaunchKernelGGL(k_overlap_reduce, dim3((tiles + 255) / 256), blk, 0, s, B.cov_a, B.cov_b, n_pos, min_cov, B.bounds, n_seg,
-                           B.both, B.both + n_seg);
-        hipLaunchKernelGGL(k_pack_compare, gseg, blk, 0, s, acc_a, acc_b, B.both, B.both + n_seg, n_seg, mm, M, B.rows);
+                           both, either);
+        if (do_snp && n_ab)
+            hipLaunchKernelGGL(k_snp_apply, gab, blk, 0, s, cand, B.cursors, B.cov_a, B.cov_b, min_cov, B.bounds, n_seg, n_con, n_pop,
+                               snp.snv_a, snp.snv_b, (uint32_t)mm, B.snp_rows);
+        hipLaunchKernelGGL(k_pack_compare, gseg, blk, 0, s, acc_a, acc_b, both, either, n_con, n_pop,
+                           do_snp ? B.cursors + 2 : (const uint32_t *)nullptr, n_seg, mm, M, B.rows);
     }
     HIP_TRY(hipEventRecord(a.ev[1], s));
     HIP_TRY(hipMemcpyAsync(host_out, B.rows, (size_t)n_seg * M * sizeof(isx_compare_level), hipMemcpyDeviceToHost, s));
+    uint32_t cur[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(cur, B.cursors, sizeof(cur), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    B.n_snp_rows = cur[1];
     if (ms) { float v = 0.f; (void)hipEventElapsedTime(&v, a.ev[0], a.ev[1]); *ms = v; }
     return ISX_OK;
 }

@@ -298,8 +298,14 @@ def main():
 
     # ---- compare: coverage overlap of two samples on the same scaffold (readComparer.py:145-191) ----
     import inStrain.readComparer as rc
+    # compare_c / compare_d: the same strain mixture sequenced twice (same reference, same planted sites,
+    # other depths / allele frequencies) -> rows shared by both samples' SNP tables
     for name, kwa, kwb in [("compare_a", dict(seed=31, mm_levels=5, depth=30, mLen=1500), dict(seed=32, mm_levels=3, depth=12, mLen=1500)),
-                           ("compare_b", dict(seed=33, mm_levels=1, depth=9, mLen=900), dict(seed=34, mm_levels=7, depth=40, mLen=900))]:
+                           ("compare_b", dict(seed=33, mm_levels=1, depth=9, mLen=900), dict(seed=34, mm_levels=7, depth=40, mLen=900)),
+                           ("compare_c", dict(seed=35, mm_levels=4, depth=60, mLen=1200, n_sites=40, af_lo=0.05, af_hi=0.95),
+                            dict(seed=35, mm_levels=4, depth=35, mLen=1200, n_sites=40, af_lo=0.3, af_hi=0.6)),
+                           ("compare_d", dict(seed=36, mm_levels=3, depth=25, mLen=800, n_sites=60, af_lo=0.0, af_hi=1.0, ref_ambig=15),
+                            dict(seed=36, mm_levels=6, depth=90, mLen=800, n_sites=60, af_lo=0.5, af_hi=1.0, ref_ambig=15, err=0.03))]:
         seq, posa, basea, mma, paira = synth_case(**kwa)
         _, posb, baseb, mmb, pairb = synth_case(**kwb)
         # sample B is piled up on sample A's scaffold: only coverage matters for calc_mm2overlap
@@ -307,7 +313,35 @@ def main():
         covB, _, SB, _, _ = run_reference_split(mods, "scaf", seq, 0, posb, baseb, mmb, pairb, nm)
         mm2overlap, mm2coverage = rc.calc_mm2overlap(covA, covB, min_cov=5)
         mms = sorted(mm2overlap)
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), seq=np.array(seq),
+        # SNP-table half of compare_scaffold (readComparer.py:205-290, 437-502); tables as
+        # compare_controller.load_cache / compare_utils.hash_SNP_table hand them over
+        def as_loaded(S):
+            if len(S) == 0:
+                return pd.DataFrame()
+            S = S.copy()
+            S["scaffold"] = S["scaffold"].astype(str)
+            return S.sort_values(["scaffold", "mm"])
+        snp = {}
+        try:
+            Mdb = rc._calc_SNP_count_alternate(as_loaded(SA), as_loaded(SB), mm2overlap, nm, min_freq=0.05)
+            table = rc._update_overlap_table(defaultdict(list), "scaf", mm2overlap, mm2coverage, Mdb, "a", "b", len(seq))
+            T = pd.DataFrame(table).sort_values("mm")
+            assert list(T["mm"]) == mms
+            Mdb = Mdb.sort_values(["mm", "position"])
+            snp = dict(t_consensus_SNPs=T["consensus_SNPs"].values.astype(np.int64),
+                       t_population_SNPs=T["population_SNPs"].values.astype(np.int64),
+                       t_conANI=T["conANI"].values.astype(np.float64), t_popANI=T["popANI"].values.astype(np.float64),
+                       t_percent_genome_compared=T["percent_genome_compared"].values.astype(np.float64),
+                       m_position=Mdb["position"].values.astype(np.int64), m_mm=Mdb["mm"].values.astype(np.int64),
+                       m_consensus_SNP=Mdb["consensus_SNP"].values.astype(bool),
+                       m_population_SNP=Mdb["population_SNP"].values.astype(bool))
+            print(name, "Mdb rows", len(Mdb), "con", list(snp["t_consensus_SNPs"]), "pop", list(snp["t_population_SNPs"]))
+        except KeyError as e:
+            # a SNP row whose reference base is N and that is absent from the other sample makes the
+            # reference look up the column 'N_1' / 'N_2' -> KeyError (whole scaffold fails)
+            print(name, "reference raised KeyError", e)
+            snp = dict(snp_keyerror=np.array(True))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), seq=np.array(seq), **snp,
                             a_pos=posa.astype(np.int32), a_base=basea, a_mm=mma.astype(np.int32), a_pair=paira.astype(np.int32),
                             b_pos=posb.astype(np.int32), b_base=baseb, b_mm=mmb.astype(np.int32), b_pair=pairb.astype(np.int32),
                             mm=np.array(mms), both=np.array([len(mm2overlap[m]) for m in mms]),

@@ -180,17 +180,27 @@ def test_oracle_coverage_table_vs_stored_golden():
     check_coverage_table_vs_sars_golden(rows, float_tol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["compare_a", "compare_b"])
+@pytest.mark.parametrize("name", ["compare_a", "compare_b", "compare_c", "compare_d"])
 def test_oracle_compare_overlap_vs_reference_vectors(name):
-    """oracle/compare.py vs outputs of the reference's own calc_mm2overlap (readComparer.py:145-191)"""
+    """oracle/compare.py vs outputs of the reference's own calc_mm2overlap (readComparer.py:145-191),
+    _calc_SNP_count_alternate (:205-290) and _update_overlap_table (:437-502)"""
     from oracle import compare
     lut, fb = util.load_lut()
     g = util.load_case(name)
     seq = str(g["seq"])
-    ea = oracle.profile_split(g["a_pos"], g["a_base"], g["a_mm"], g["a_pair"], seq, 0, lut, fb)["entries"]
-    eb = oracle.profile_split(g["b_pos"], g["b_base"], g["b_mm"], g["b_pair"], seq, 0, lut, fb)["entries"]
+    ra = oracle.profile_split(g["a_pos"], g["a_base"], g["a_mm"], g["a_pair"], seq, 0, lut, fb)
+    rb = oracle.profile_split(g["b_pos"], g["b_base"], g["b_mm"], g["b_pair"], seq, 0, lut, fb)
+    ea, eb = ra["entries"], rb["entries"]
     o, c = compare.calc_mm2overlap(ea, eb, len(seq), min_cov=5)
     assert sorted(o) == list(g["mm"])
     assert [len(o[m]) for m in g["mm"]] == list(g["both"])
     assert np.max(np.abs(np.array([c[m] for m in g["mm"]]) - g["coverage"])) == 0.0
     assert sorted(o[int(g["mm"][-1])]) == list(g["pos_in_both_last"])
+    rows = compare.compare_snp_tables(ra["snv"], rb["snv"], o, lut, fb, min_freq=0.05)
+    assert [r[0] for r in rows] == list(g["m_mm"]) and [r[1] for r in rows] == list(g["m_position"])
+    assert [r[2] for r in rows] == list(g["m_consensus_SNP"]) and [r[3] for r in rows] == list(g["m_population_SNP"])
+    t = compare.overlap_table(o, c, rows, len(seq))
+    assert [r["consensus_SNPs"] for r in t] == list(g["t_consensus_SNPs"])
+    assert [r["population_SNPs"] for r in t] == list(g["t_population_SNPs"])
+    for k in ("conANI", "popANI", "percent_genome_compared"):
+        np.testing.assert_array_equal(np.array([r[k] for r in t], dtype=np.float64), g["t_" + k])
