@@ -42,7 +42,7 @@ struct isx_batch {
     uint8_t *d_ref = nullptr;
     uint2 *d_win = nullptr;
     uint16_t *d_thr = nullptr;
-    int qcap = 1024, rqcap = 0;
+    int qcap = 1024, rqcap = 0, stage_off = 0;
     int64_t *d_bounds = nullptr;
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
@@ -382,7 +382,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
         if (!dense && W > 2 * b->block) { isx_batch_destroy(b); isx_set_error("mm path: window must be <= 2 x block"); return ISX_ERR_ARG; }
         b->W = W;
         b->rqcap = dense ? 0 : std::min(W, 512);     // positions with SNV rows per window (overflow: per-position atomics)
-        b->lds = pileup_lds_bytes(W, b->M, b->qcap, b->rqcap, prm->enable_linkage, b->packed);
+        b->lds = pileup_lds_bytes(W, b->M, b->qcap, b->rqcap, prm->enable_linkage, b->packed, b->block, &b->stage_off);
         if (b->lds > 160 * 1024) { isx_batch_destroy(b); isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
         b->n_win = (int)win.size();
         {   // persistent kernels: as many workgroups as stay resident on the 256 CUs
@@ -435,7 +435,7 @@ static int run_once(isx_batch *b, uint32_t *cap_flags)
 
     PileupArgs a{};
     a.rec = b->d_rec; a.win_range = b->d_win; a.ref = b->d_ref;
-    a.pair = b->d_pair; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap;
+    a.pair = b->d_pair; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
     if (const char *e = getenv("ISX_DEBUG_MODE")) a.debug_mode = atoi(e);     // ablation only

@@ -122,6 +122,7 @@ struct PileupArgs {
     int32_t debug_mode;
     int32_t qcap;               // deferred-clonality queue capacity (entries)
     int32_t rqcap;              // mm path: row-queue capacity (positions with SNV rows per window)
+    int32_t stage_off;          // allele pass: LDS word offset of the per-wave hit stage (0 = aliases the counters)
     double min_freq;
     // outputs
     uint4 *counts;              // dense path (M == 1): [n_pos]
@@ -151,6 +152,6 @@ struct PileupArgs {
 
 void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s);
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s);
-size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed);
+size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int *stage_off);
 
 struct LinkageBuffers;      // defined in isx_linkage.hip

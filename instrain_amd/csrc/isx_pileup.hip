@@ -191,10 +191,36 @@ __device__ __forceinline__ uint32_t masked_sum(const uint32_t *c, uint32_t mask)
 
 // update_linked_reads (linkage.py:254-283): re-stream the window's records; an observation at a
 // SNP site whose base is in the site's `bases` set goes to the next free slot of the site's slab.
+// Hits are rare (about one per 100 records) but nearly every wave-wide step has one, and a hit costs a
+// dependent global load (the pair id) + a scattered 16-byte store: handled in place, every step of
+// every wave would wait on that latency with one lane alive.  So hits are compacted (ballot + mbcnt)
+// into a per-wave LDS stage of 64 entries and drained with all lanes busy.  `stage` = 128 words per
+// wave of LDS that is dead during this pass (the window's counters; the caller has a barrier before).
+__device__ __forceinline__ void allele_drain(const PileupArgs &a, const uint32_t *st, uint32_t n, uint32_t w0,
+                                             uint32_t *slabc, uint32_t ao_base, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if ((uint32_t)lane < n) {
+        const uint32_t i = st[2 * lane], pk = st[2 * lane + 1];
+        const uint32_t rel = pk & 0x3FFFu, base = (pk >> 14) & 3u;
+        const uint32_t slot = atomicAdd(&slabc[rel], 1u);
+        isx_ao o;
+        o.pair = a.pair[i]; o.site = w0 + rel; o.obs_idx = i;
+        o.mm = (uint16_t)(pk >> 16); o.base = (uint8_t)base; o.pad = 0;
+        a.ao[ao_base + slot] = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void allele_pass(const PileupArgs &a, const u32x4 *rec4, uint32_t lo, uint32_t hi,
                                             uint32_t w0, int W, const uint8_t *maskl, uint32_t *slabc,
-                                            uint32_t ao_base, int tid, int nthr)
+                                            uint32_t ao_base, uint32_t *stage, int tid, int nthr)
 {
+    const int lane = tid & 63;
+    uint32_t *st = stage + (tid >> 6) * 128;
+    uint32_t nst = 0;                           // wave-uniform fill of the stage
     for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
         u32x4 v[4];
 #pragma unroll
@@ -209,20 +235,23 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, const u32x4 *re
             for (int h = 0; h < 2; h++) {
                 const uint32_t g = h ? v[u].z : v[u].x, at = h ? v[u].w : v[u].y;
                 const uint32_t rel = g - w0;
-                if (rel >= (uint32_t)W) continue;
                 const uint32_t base = (at >> 16) & 0xFFu;
-                const uint32_t m = maskl[rel];
-                if (base < 4 && ((m >> base) & 1u)) {
-                    const uint32_t slot = atomicAdd(&slabc[rel], 1u);
-                    const uint32_t i = 2u * (i0 + tid + u * nthr) + (uint32_t)h;
-                    isx_ao o;
-                    o.pair = a.pair[i]; o.site = g; o.obs_idx = i;
-                    o.mm = (uint16_t)(at & 0xFFFFu); o.base = (uint8_t)base; o.pad = 0;
-                    a.ao[ao_base + slot] = o;
+                bool hit = false;
+                if (rel < (uint32_t)W && base < 4) hit = (maskl[rel] >> base) & 1u;
+                const uint64_t bal = __ballot(hit);
+                if (bal == 0) continue;                             // wave-uniform
+                const uint32_t n = (uint32_t)__popcll(bal);
+                if (nst + n > 64u) { allele_drain(a, st, nst, w0, slabc, ao_base, lane); nst = 0; }
+                if (hit) {
+                    const uint32_t r = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    st[2 * r] = 2u * (i0 + tid + u * nthr) + (uint32_t)h;
+                    st[2 * r + 1] = rel | (base << 14) | (at << 16);
                 }
+                nst += n;
             }
         }
     }
+    if (nst) allele_drain(a, st, nst, w0, slabc, ao_base, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,7 +437,10 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
             }
         }
         if (linkage) {
-            if (ok && nao) allele_pass(a, rec4, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, tid, nthr);
+            if (ok && nao) {
+                __syncthreads();                // every wave is done with cnt: it becomes the allele pass's stage
+                allele_pass(a, rec4, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+            }
             prefetch_window(w + grid);
         }
         // the zeroing + barrier at the top of the next window protect cnt / queue / scratch
@@ -721,7 +753,10 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
             }
         }
         if (linkage) {
-            if (ok && nao) allele_pass(a, rec4, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, tid, nthr);
+            if (ok && nao) {
+                __syncthreads();                // every wave is done with the counters: they become the stage
+                allele_pass(a, rec4, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+            }
             prefetch_window(w + grid);
         }
         __syncthreads();
@@ -731,13 +766,25 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 
 }  // namespace
 
-size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed)
+size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int *stage_off)
 {
-    size_t words;
-    if (M == 1) words = (size_t)5 * W + S_N + THR_LDS / 2;
-    else words = (size_t)M * (packed ? 2 : 4) * W + (size_t)((M + 31) / 32) * W + S_N + (size_t)qcap * 2 + (size_t)rqcap * 4 + THR_LDS / 2;
+    size_t words, cnt_words;
+    if (M == 1) { cnt_words = (size_t)4 * W; words = (size_t)5 * W + S_N + THR_LDS / 2; }
+    else {
+        cnt_words = (size_t)M * (packed ? 2 : 4) * W;
+        words = cnt_words + (size_t)((M + 31) / 32) * W + S_N + (size_t)qcap * 2 + (size_t)rqcap * 4 + THR_LDS / 2;
+    }
     size_t bytes = words * sizeof(uint32_t);
-    if (linkage) bytes += (size_t)W * 5;        // slabc[W] + maskl[W]
+    if (stage_off) *stage_off = 0;
+    if (linkage) {
+        bytes += (size_t)W * 5;                 // slabc[W] + maskl[W]
+        const size_t stage_words = (size_t)(block / 64) * 128;      // allele pass: 64 two-word entries per wave
+        if (cnt_words < stage_words) {          // small windows: the counters cannot host the stage
+            bytes = (bytes + 15) & ~(size_t)15;
+            if (stage_off) *stage_off = (int)(bytes / 4);
+            bytes += stage_words * 4;
+        }
+    }
     return bytes;
 }
 
