@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinstrain_amd.so")
+if os.environ.get("ISX_LIB"):            # A/B timing of two in-tree builds (tools/); never a fallback
+    LIB_PATH = os.path.abspath(os.environ["ISX_LIB"])
 
 OBS_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("base", "u1"), ("flags", "u1")])
 ENTRY_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("flags", "<u2"), ("cnt", "<u4", (4,)), ("clon", "<f4"),

@@ -244,9 +244,11 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
             // otherwise the multiple of 64 in [2048, 3904] (two 1024-lane workgroups per CU fit their LDS)
             // that wastes least: whole rounds of the 512 persistent workgroups x stream over-scan of a
             // window (~ one read length + one directory chunk on each side)
+            // (with linkage a position also carries slabc + maskl: 25 bytes, so two workgroups fit up to 3136)
             int best = 2560;
             double best_eff = 0.0;
-            for (int w = 2048; w <= 3904; w += 64) {
+            const int wtop = prm->enable_linkage ? 3136 : 3904;
+            for (int w = 2048; w <= wtop; w += 64) {
                 const double n_win = std::ceil((double)n_pos / w);
                 const double rounds = n_win / 512.0;
                 const double eff = rounds / std::ceil(rounds) * (w / (w + 200.0));
@@ -303,7 +305,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     std::vector<uint8_t> cany(n_chunks, 0);
     bool bad_pos = false;
     // isx_obs already has the device record layout (gpos | mm, base << 16, flags << 24): plain copy into
-    // the pinned buffer, then one vectorisable sweep per 1024-record chunk for the min/max directory
+    // the pinned buffer, then one vectorisable sweep per ISX_CHUNK-record chunk for the min/max directory
     static_assert(sizeof(isx_obs) == sizeof(uint2), "isx_obs must be the 8-byte device record");
     BT(staged_upload(c, b->d_rec, b->n_rec, [&](uint2 *dst, uint64_t first, uint64_t cnt) {
         // a few host threads fill the pinned buffer (a single core copies at ~10 GB/s, PCIe Gen5 takes 63)

@@ -263,6 +263,7 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, const u32x4 *re
 // clonality divisions and row emission run densely packed from an LDS queue.
 // LDS: cnt[4][W] | queue[W] | scratch[16] | thr_lds[THR_LDS] | (linkage) slabc[W] | maskl[W bytes]
 // ---------------------------------------------------------------------------------------------
+template <bool LINKAGE>
 __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
     uint16_t *thr_lds = reinterpret_cast<uint16_t *>(scratch + S_N);
     uint32_t *slabc = scratch + S_N + THR_LDS / 2;
     uint8_t *maskl = reinterpret_cast<uint8_t *>(slabc + W);
-    const bool linkage = a.enable_linkage != 0;
+    constexpr bool linkage = LINKAGE;            // compile-time: the linkage-off kernels carry none of the allele pass
     const int grid = gridDim.x, per = grid >> 3;
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
     const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(a.rec);
@@ -460,7 +461,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
 // pres = levels made present by a non-ACGT base only (profile_utilities.py:279-285 creates
 // table[mm] before the KeyError), a presence the SNV loop must see.
 // ---------------------------------------------------------------------------------------------
-template <bool PACKED>
+template <bool PACKED, bool LINKAGE>
 __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -476,7 +477,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
     uint32_t *slabc = queue + 2 * a.qcap + 4 * a.rqcap + THR_LDS / 2;
     uint8_t *maskl = reinterpret_cast<uint8_t *>(slabc + W);
     const uint32_t QCAP = (uint32_t)a.qcap;
-    const bool linkage = a.enable_linkage != 0;
+    constexpr bool linkage = LINKAGE;            // compile-time: the linkage-off kernels carry none of the allele pass
     const int grid = gridDim.x, per = grid >> 3;
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
     const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(a.rec);
@@ -555,7 +556,8 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         if (bad_mm) flag_or(a, ISX_FLAG_MM_RANGE);
         __syncthreads();
         if (!linkage) prefetch_window(w + grid);
-        const int dbg = a.debug_mode;           // ablation switches (tools/ablate_mm.py), 0 in production
+        const int dbg = a.debug_mode;
+        const int Mw = (dbg & 512) ? M : __builtin_amdgcn_readfirstlane((int)scratch[S_MAXMM]) + 1;           // levels above the window's highest mm are empty everywhere           // ablation switches (tools/ablate_mm.py), 0 in production
         const uint32_t CW = (uint32_t)a.slab;   // entry slab of this window: [w * CW, (w + 1) * CW)
         const uint64_t slab0 = (uint64_t)w * CW;
         const int lane = tid & 63;
@@ -788,22 +790,21 @@ size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int pack
     return bytes;
 }
 
+template <class K>
+static void launch_one(K kernel, const PileupArgs &a, int block, size_t lds, int grid, hipStream_t s)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, a);
+}
+
 void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s)
 {
+    const bool link = a.enable_linkage != 0;
     if (a.M > 1) {
-        if (packed) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_mm<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_pileup_mm<true>, dim3(grid), dim3(block), lds, s, a);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_mm<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_pileup_mm<false>, dim3(grid), dim3(block), lds, s, a);
-        }
+        if (packed) { if (link) launch_one(k_pileup_mm<true, true>, a, block, lds, grid, s); else launch_one(k_pileup_mm<true, false>, a, block, lds, grid, s); }
+        else        { if (link) launch_one(k_pileup_mm<false, true>, a, block, lds, grid, s); else launch_one(k_pileup_mm<false, false>, a, block, lds, grid, s); }
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pileup_dense),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_pileup_dense, dim3(grid), dim3(block), lds, s, a);
+        if (link) launch_one(k_pileup_dense<true>, a, block, lds, grid, s); else launch_one(k_pileup_dense<false>, a, block, lds, grid, s);
     }
 }
 
