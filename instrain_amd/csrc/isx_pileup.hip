@@ -556,8 +556,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         if (bad_mm) flag_or(a, ISX_FLAG_MM_RANGE);
         __syncthreads();
         if (!linkage) prefetch_window(w + grid);
-        const int dbg = a.debug_mode;
-        const int Mw = (dbg & 512) ? M : __builtin_amdgcn_readfirstlane((int)scratch[S_MAXMM]) + 1;           // levels above the window's highest mm are empty everywhere           // ablation switches (tools/ablate_mm.py), 0 in production
+        const int dbg = a.debug_mode;           // ablation switches (tools/ablate_mm.py), 0 in production
         const uint32_t CW = (uint32_t)a.slab;   // entry slab of this window: [w * CW, (w + 1) * CW)
         const uint64_t slab0 = (uint64_t)w * CW;
         const int lane = tid & 63;
