@@ -173,6 +173,16 @@ void isx_batch_destroy(isx_batch *b);
 
 /* One pass of the hot path over the resident batch (blocking). Re-runnable. */
 int isx_batch_run(isx_batch *b);
+
+/* The same pass split for pipelining: isx_batch_launch enqueues the pileup / SNV-calling kernel on the
+ * context's stream and returns at once; isx_batch_wait blocks until it is done, runs the linkage stages
+ * (they need the table sizes on the host) and makes sizes / fetch available.  isx_batch_run == launch +
+ * wait.  Several batches of one context may be in flight (they execute in launch order), so the next
+ * shard's pass is queued behind the current one -- what the reference does with its worker pool
+ * (profile_controller.py:243-271), without a launch gap between shards.  A batch has at most one pass in
+ * flight; fetch / sizes refuse (ISX_ERR_STATE) until isx_batch_wait has returned. */
+int isx_batch_launch(isx_batch *b);
+int isx_batch_wait(isx_batch *b);
 int isx_batch_sizes(const isx_batch *b, isx_sizes *out);
 int isx_batch_timings(const isx_batch *b, isx_timings *out);
 

@@ -80,7 +80,7 @@ class IsxError(RuntimeError):
 
 
 SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destroy", "isx_set_null_model",
-           "isx_batch_create", "isx_batch_destroy", "isx_batch_run", "isx_batch_sizes", "isx_batch_timings",
+           "isx_batch_create", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
            "isx_batch_summarize", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
            "isx_bam_open", "isx_bam_close", "isx_bam_expand", "isx_bam_ref", "isx_bam_copy"]
@@ -108,6 +108,8 @@ def load():
     lib.isx_batch_destroy.argtypes = [vp]
     lib.isx_batch_destroy.restype = None
     lib.isx_batch_run.argtypes = [vp]
+    lib.isx_batch_launch.argtypes = [vp]
+    lib.isx_batch_wait.argtypes = [vp]
     lib.isx_batch_sizes.argtypes = [vp, C.POINTER(Sizes)]
     lib.isx_batch_timings.argtypes = [vp, C.POINTER(Timings)]
     for f in ("isx_batch_fetch_entries", "isx_batch_fetch_snv", "isx_batch_fetch_ld"):

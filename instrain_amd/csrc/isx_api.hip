@@ -43,6 +43,7 @@ struct isx_batch {
     uint2 *d_win = nullptr;
     uint16_t *d_thr = nullptr;
     int qcap = 1024, rqcap = 0, stage_off = 0;
+    bool in_flight = false;
     int64_t *d_bounds = nullptr;
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
@@ -424,10 +425,9 @@ static float ev_ms(hipEvent_t a, hipEvent_t b)
     return ms;
 }
 
-// one pass; *cap_flags receives the ISX_FLAG_CAP_* bits of tables that were too small (the caller grows them)
-static int run_once(isx_batch *b, uint32_t *cap_flags)
+// enqueue one pass (pileup kernel + state publication) on the context's stream; no host wait
+static int launch_pass(isx_batch *b)
 {
-    *cap_flags = 0;
     isx_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -458,6 +458,19 @@ static int run_once(isx_batch *b, uint32_t *cap_flags)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[1], s));
     launch_publish_state(a, ++b->epoch, s);
+    b->in_flight = true;
+    return ISX_OK;
+}
+
+// wait for the pass enqueued by launch_pass and collect it (linkage stages run here: they need the
+// table sizes on the host); *cap_flags receives the ISX_FLAG_CAP_* bits of tables that were too small
+static int finish_pass(isx_batch *b, uint32_t *cap_flags)
+{
+    *cap_flags = 0;
+    isx_ctx *c = b->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    b->in_flight = false;
     {   // spin on the epoch word for a while (no interrupt latency), then fall back to a stream wait
         volatile uint32_t *ep = b->h_state + CUR_N + 4;
         const auto t0 = std::chrono::steady_clock::now();
@@ -527,15 +540,25 @@ static int run_once(isx_batch *b, uint32_t *cap_flags)
     return ISX_OK;
 }
 
-int isx_batch_run(isx_batch *b)
+int isx_batch_launch(isx_batch *b)
 {
-    if (!b) { isx_set_error("isx_batch_run: NULL batch"); return ISX_ERR_ARG; }
+    if (!b) { isx_set_error("isx_batch_launch: NULL batch"); return ISX_ERR_ARG; }
+    if (b->in_flight) { isx_set_error("isx_batch_launch: the batch already has a pass in flight (isx_batch_wait first)"); return ISX_ERR_STATE; }
+    return launch_pass(b);
+}
+
+int isx_batch_wait(isx_batch *b)
+{
+    if (!b) { isx_set_error("isx_batch_wait: NULL batch"); return ISX_ERR_ARG; }
+    if (!b->in_flight) { isx_set_error("isx_batch_wait: no pass in flight"); return ISX_ERR_STATE; }
     // Output tables start from generous estimates; a table that turns out too small (e.g. SNS rows at
     // every position of a divergent reference) is grown x4 up to its hard bound and the pass repeated.
     const uint64_t npm = (uint64_t)b->n_pos * b->M;
     for (int attempt = 0; attempt < 8; attempt++) {
         uint32_t cf = 0;
-        int rc = run_once(b, &cf);
+        int rc = ISX_OK;
+        if (attempt > 0 && (rc = launch_pass(b)) != ISX_OK) return rc;
+        rc = finish_pass(b, &cf);
         if (rc != ISX_OK) return rc;
         if (!cf) return ISX_OK;
         HIP_TRY(hipSetDevice(b->ctx->device));
@@ -565,6 +588,12 @@ int isx_batch_run(isx_batch *b)
     }
     isx_set_error("output tables still too small after 8 growth steps");
     return ISX_ERR_CAPACITY;
+}
+
+int isx_batch_run(isx_batch *b)
+{
+    const int rc = isx_batch_launch(b);
+    return rc != ISX_OK ? rc : isx_batch_wait(b);
 }
 
 int isx_batch_sizes(const isx_batch *b, isx_sizes *out)

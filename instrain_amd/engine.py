@@ -81,6 +81,13 @@ class Batch:
     def run(self):
         check(self.lib.isx_batch_run(self.h))
 
+    def launch(self):
+        """enqueue one pass without waiting (isx_batch_launch); pair with wait()"""
+        check(self.lib.isx_batch_launch(self.h))
+
+    def wait(self):
+        check(self.lib.isx_batch_wait(self.h))
+
     def sizes(self):
         s = Sizes()
         check(self.lib.isx_batch_sizes(self.h, C.byref(s)))

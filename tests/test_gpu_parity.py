@@ -148,6 +148,42 @@ def test_mm_out_of_range_is_loud(ctx):
     b.close()
 
 
+def test_pipelined_launch_wait_equals_run(ctx):
+    """isx_batch_launch / isx_batch_wait: two batches in flight give what blocking runs give; state errors are loud"""
+    from instrain_amd import engine
+    from tests import prod
+    cases = []
+    for seed, mml, link in ((201, 1, True), (202, 5, False), (203, 3, True)):
+        seq, pos, base, mm, pair = _random_split(seed, 4000, 40, mml, 160)
+        b = engine.Batch(ctx, engine.encode_seq(seq), [0, len(seq)], engine.pack_obs(pos.astype(np.uint32), base, mm),
+                         pair.astype(np.uint32), n_mm_bins=mml, enable_linkage=link)
+        b.run()
+        cases.append((b, b.fetch(), b.sizes()))
+    for rep in range(3):
+        for b, _, _ in cases:
+            b.launch()
+        with pytest.raises(engine.IsxError) as e:
+            cases[0][0].launch()                                 # one pass in flight per batch
+        assert e.value.code == -6
+        with pytest.raises(engine.IsxError):
+            cases[1][0].sizes()                                  # nothing to read before wait
+        for b, exp, sz in reversed(cases):                       # collected in another order than launched
+            b.wait()
+            got = b.fetch()
+            assert b.sizes() == sz
+            for k in exp:
+                if exp[k].dtype.names:
+                    for f in exp[k].dtype.names:
+                        np.testing.assert_array_equal(got[k][f], exp[k][f], err_msg="%s.%s" % (k, f))
+                else:
+                    np.testing.assert_array_equal(got[k], exp[k], err_msg=k)
+    with pytest.raises(engine.IsxError) as e:
+        cases[0][0].wait()
+    assert e.value.code == -6
+    for b, _, _ in cases:
+        b.close()
+
+
 def test_full_size_properties(ctx):
     """BASELINE configs[1] at FULL size (5 Mbp, 20x, 9e7 observations): properties that do not need the
     oracle -- sum of level counts == number of ACGT observations (a checksum of checksums: also per
