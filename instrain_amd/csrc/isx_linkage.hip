@@ -340,19 +340,29 @@ __global__ void __launch_bounds__(256) k_dense_gemm(const DenseTile *tiles, uint
     const int l = threadIdx.x & 63;
     const DenseTile tl = tiles[t];
     const DenseSplit ds = splits[tl.slot];
-    const uint8_t *pa = xt + ds.xt_off + (uint64_t)(tl.I * 32 + (l & 31)) * ds.rpad + 16 * (l >> 5);
-    const uint8_t *pb = xt + ds.xt_off + (uint64_t)(tl.J * 32 + (l & 31)) * ds.rpad + 16 * (l >> 5);
+    // Operand layout of v_mfma_i32_32x32x32_i8: lane l holds row (l & 31) and 16 k-values of half (l >> 5).
+    // Which k-values a (half, step) slot carries is free as long as A and B agree (a dot product has no
+    // order), so a lane streams 64 CONTIGUOUS bytes of its row per round -- the wave reads whole 128-byte
+    // lines of 32 rows, each exactly once -- and feeds them to four MFMAs.  rpad is a multiple of 128.
+    const uint8_t *pa = xt + ds.xt_off + (uint64_t)(tl.I * 32 + (l & 31)) * ds.rpad + 64 * (l >> 5);
+    const uint8_t *pb = xt + ds.xt_off + (uint64_t)(tl.J * 32 + (l & 31)) * ds.rpad + 64 * (l >> 5);
     v16i acc = {0};
-    uint32_t k0 = 0;
-    for (; k0 + 64 <= ds.rpad; k0 += 64) {          // two k-steps in flight
-        const v4i a0 = *reinterpret_cast<const v4i *>(pa + k0), b0 = *reinterpret_cast<const v4i *>(pb + k0);
-        const v4i a1 = *reinterpret_cast<const v4i *>(pa + k0 + 32), b1 = *reinterpret_cast<const v4i *>(pb + k0 + 32);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc, 0, 0, 0);
-    }
-    for (; k0 < ds.rpad; k0 += 32) {
-        const v4i a0 = *reinterpret_cast<const v4i *>(pa + k0), b0 = *reinterpret_cast<const v4i *>(pb + k0);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc, 0, 0, 0);
+    v4i a[4], b[4];
+    auto load = [&](uint32_t k0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            a[q] = *reinterpret_cast<const v4i *>(pa + k0 + 16 * q);
+            b[q] = *reinterpret_cast<const v4i *>(pb + k0 + 16 * q);
+        }
+    };
+    if (ds.rpad) load(0);
+    for (uint32_t k0 = 0; k0 < ds.rpad; k0 += 128) {
+        v4i ca[4], cb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { ca[q] = a[q]; cb[q] = b[q]; }
+        if (k0 + 128 < ds.rpad) load(k0 + 128);        // next round in flight behind the MFMAs
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[q], cb[q], acc, 0, 0, 0);
     }
     uint32_t run = EMIT ? tile_off[t] : 0;
 #pragma unroll
@@ -510,7 +520,7 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
         if (rows == 0 || ns < 2) continue;           // no cross-site pair possible
         DenseSplit d{};
         d.xt_off = bytes;
-        d.rpad = (rows + 31) / 32 * 32;
+        d.rpad = (rows + 127) / 128 * 128;
         d.ctiles = (ns * 4 + 31) / 32;
         d.first_site = fsite[sp]; d.n_sites = ns; d.first_row = frow[sp];
         bytes += (uint64_t)d.ctiles * 32 * d.rpad;
