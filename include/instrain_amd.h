@@ -290,6 +290,9 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info);
 int isx_bam_ref(const isx_bam *bam, int32_t i, const char **name, int64_t *length, int64_t *flat_offset);
 /* copy out: obs[n_obs], pair[n_obs], split_bounds[n_splits+1], split_ref[n_splits] */
 int isx_bam_copy(const isx_bam *bam, isx_obs *obs, uint32_t *pair, int64_t *split_bounds, int32_t *split_ref);
+/* Zero-copy alternative to isx_bam_copy for the two large arrays: pointers into the handle, valid until
+ * isx_bam_close (isx_batch_create copies from them, so the handle can be closed right after). */
+int isx_bam_view(const isx_bam *bam, const isx_obs **obs, const uint32_t **pair);
 
 #ifdef __cplusplus
 }

@@ -83,7 +83,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_batch_create", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
            "isx_batch_summarize", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
-           "isx_bam_open", "isx_bam_close", "isx_bam_expand", "isx_bam_ref", "isx_bam_copy"]
+           "isx_bam_open", "isx_bam_close", "isx_bam_expand", "isx_bam_ref", "isx_bam_copy", "isx_bam_view"]
 
 _lib = None
 
@@ -125,6 +125,7 @@ def load():
     lib.isx_bam_expand.argtypes = [vp, C.POINTER(BamParams), C.POINTER(BamInfo)]
     lib.isx_bam_ref.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64)]
     lib.isx_bam_copy.argtypes = [vp, vp, vp, vp, vp]
+    lib.isx_bam_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     _lib = lib
     return lib
 

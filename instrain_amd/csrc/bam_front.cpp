@@ -25,6 +25,9 @@
 #include <string>
 #include <string_view>
 #include <thread>
+#include <chrono>
+#include <cstdio>
+#include <memory>
 #include <unordered_map>
 #include <vector>
 
@@ -115,9 +118,10 @@ struct isx_bam {
     std::vector<uint32_t> cigars;
     std::vector<uint8_t> seqs;      // one code per base (unpacked)
     std::vector<uint8_t> quals;     // mutated by overlap resolution
-    // results of expand
-    std::vector<isx_obs> obs;
-    std::vector<uint32_t> pair;
+    // results of expand (plain arrays: no zero fill of what is written once)
+    std::unique_ptr<isx_obs[]> obs;
+    std::unique_ptr<uint32_t[]> pair;
+    size_t n_obs = 0;
     std::vector<int64_t> split_bounds;
     std::vector<int32_t> split_ref;
     bool expanded = false;
@@ -236,41 +240,77 @@ int parse_bam(const std::vector<uint8_t> &buf, isx_bam &B)
         flat += l_ref;
         off += 8 + (size_t)l_name;
     }
+    // pass 1 (sequential, a few words per record): record boundaries and the sizes of the side arrays
+    std::vector<size_t> rec_off;
+    size_t n_names = 0, n_cig = 0, n_seq = 0;
     while (off + 36 <= buf.size()) {
         const uint8_t *p = buf.data() + off;
         const int32_t block = rd32(p);
-        if (off + 4 + (size_t)block > buf.size()) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
-        Read r{};
-        r.tid = rd32(p + 4); r.pos = rd32(p + 8);
-        const uint8_t l_name = p[12];
-        r.mapq = p[13];
-        uint16_t ncig, flag;
-        memcpy(&ncig, p + 16, 2); memcpy(&flag, p + 18, 2);
-        r.n_cigar = ncig; r.flag = flag;
-        r.l_seq = rd32(p + 20);
-        r.isize = rd32(p + 32);
-        const uint8_t *q = p + 36;
-        r.name_off = (uint32_t)B.names.size(); r.name_len = (uint32_t)l_name - 1;
-        B.names.insert(B.names.end(), q, q + l_name - 1);
-        q += l_name;
-        r.cigar_off = B.cigars.size();
-        B.cigars.resize(B.cigars.size() + ncig);
-        memcpy(B.cigars.data() + r.cigar_off, q, (size_t)ncig * 4);
-        q += (size_t)ncig * 4;
-        r.seq_off = B.seqs.size();
-        B.seqs.resize(B.seqs.size() + (size_t)r.l_seq);
-        for (int32_t i = 0; i < r.l_seq; i++) {
-            const uint8_t byte = q[i >> 1];
-            B.seqs[r.seq_off + i] = (i & 1) ? (byte & 15) : (byte >> 4);
-        }
-        q += ((size_t)r.l_seq + 1) / 2;
-        r.qual_off = B.quals.size();
-        B.quals.insert(B.quals.end(), q, q + r.l_seq);
-        q += r.l_seq;
-        if (parse_nm(q, p + 4 + block, r.has_nm, r.nm) != 0) { isx_set_error("bad aux field"); return ISX_ERR_IO; }
-        B.reads.push_back(r);
+        if (block < 32 || off + 4 + (size_t)block > buf.size()) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
+        rec_off.push_back(off);
         off += 4 + (size_t)block;
     }
+    const size_t n = rec_off.size();
+    B.reads.resize(n);
+    std::vector<size_t> name_at(n + 1), cig_at(n + 1), seq_at(n + 1);
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *p = buf.data() + rec_off[i];
+        uint16_t ncig;
+        memcpy(&ncig, p + 16, 2);
+        const int32_t l_seq = rd32(p + 20);
+        const size_t need = 32 + (size_t)p[12] + (size_t)ncig * 4 + ((size_t)std::max(l_seq, 0) + 1) / 2 + (size_t)std::max(l_seq, 0);
+        if (l_seq < 0 || p[12] == 0 || need > (size_t)rd32(p)) { isx_set_error("corrupt BAM record"); return ISX_ERR_IO; }
+        name_at[i] = n_names; cig_at[i] = n_cig; seq_at[i] = n_seq;
+        n_names += (size_t)p[12] - 1; n_cig += ncig; n_seq += (size_t)l_seq;
+    }
+    name_at[n] = n_names; cig_at[n] = n_cig; seq_at[n] = n_seq;
+    B.names.resize(n_names); B.cigars.resize(n_cig); B.seqs.resize(n_seq); B.quals.resize(n_seq);
+    // pass 2 (threads over record ranges): field extraction, nibble unpack, aux walk for NM
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n / 4096 + 1));
+    std::vector<int> bad(nt, 0);
+    auto work = [&](unsigned t) {
+        const size_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+        for (size_t i = i0; i < i1; i++) {
+            const uint8_t *p = buf.data() + rec_off[i];
+            const int32_t block = rd32(p);
+            Read r{};
+            r.tid = rd32(p + 4); r.pos = rd32(p + 8);
+            const uint8_t l_name = p[12];
+            r.mapq = p[13];
+            uint16_t ncig, flag;
+            memcpy(&ncig, p + 16, 2); memcpy(&flag, p + 18, 2);
+            r.n_cigar = ncig; r.flag = flag;
+            r.l_seq = rd32(p + 20);
+            r.isize = rd32(p + 32);
+            const uint8_t *q = p + 36;
+            r.name_off = (uint32_t)name_at[i]; r.name_len = (uint32_t)l_name - 1;
+            memcpy(B.names.data() + name_at[i], q, (size_t)l_name - 1);
+            q += l_name;
+            r.cigar_off = cig_at[i];
+            memcpy(B.cigars.data() + cig_at[i], q, (size_t)ncig * 4);
+            q += (size_t)ncig * 4;
+            r.seq_off = seq_at[i];
+            uint8_t *sq = B.seqs.data() + seq_at[i];
+            for (int32_t k = 0; k < r.l_seq; k++) {
+                const uint8_t byte = q[k >> 1];
+                sq[k] = (k & 1) ? (byte & 15) : (byte >> 4);
+            }
+            q += ((size_t)r.l_seq + 1) / 2;
+            r.qual_off = seq_at[i];
+            memcpy(B.quals.data() + seq_at[i], q, (size_t)r.l_seq);
+            q += r.l_seq;
+            if (parse_nm(q, p + 4 + block, r.has_nm, r.nm) != 0) bad[t] = 1;
+            B.reads[i] = r;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (int v : bad) if (v) { isx_set_error("bad aux field"); return ISX_ERR_IO; }
+    if (n_names >= 0xFFFFFFFFull) { isx_set_error("read names exceed 4 GiB"); return ISX_ERR_IO; }
     return ISX_OK;
 }
 
@@ -369,6 +409,14 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
     isx_bam &B = *bam;
     memset(info, 0, sizeof(*info));
     const size_t n_ref = B.ref_name.size();
+    const bool timing = getenv("ISX_BAM_TIMING") != nullptr;       // tuning aid: stage times on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[isx_bam_expand] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     auto name_of = [&](const Read &r) { return std::string_view(B.names.data() + r.name_off, r.name_len); };
 
     // ---- get_paired_reads per scaffold (filter_reads.py:885-956) ----
@@ -407,6 +455,7 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
             i.start = 0; i.stop = 0;
         }
     }
+    stage("pair table (by name)");
     // ---- paired_only + filter_scaff2pair2info (filter_reads.py:201-260, 471-532) ----
     std::vector<int64_t> ins;
     for (const PairInfo &i : pinfo) if (i.reads == 2) { ins.push_back(i.insert); info->unfiltered_pairs++; }
@@ -435,6 +484,7 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
     info->max_mm = p->skip_mm ? 0 : max_mm;
     if (max_mm > 65535) { isx_set_error("mm level > 65535"); return ISX_ERR_ARG; }
 
+    stage("pair filter");
     // ---- overlap_push in file order (htslib-1.9 rule |isize| < 2*l_qseq) ----
     {
         std::vector<int64_t> pending(pinfo.size(), -1);     // per (scaffold, name): read waiting for its mate
@@ -462,20 +512,15 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
         }
     }
 
+    stage("overlap resolution");
     // ---- expansion: the visits on which get_base_counts_mm touches `table` ----
+    // pair ids in order of first appearance (serial, one word per read); then per read the number of
+    // visits it contributes (threads), a prefix sum, and the writes (threads) -- file order is kept
     uint32_t next_pair = 0;
     for (PairInfo &i : pinfo) i.pair_id = 0xFFFFFFFFu;
-    size_t max_obs = 0;
-    for (size_t ri = 0; ri < B.reads.size(); ri++) {
-        const int32_t pi = read_pi[ri];
-        if (pi >= 0 && pinfo[(size_t)pi].pass && !(B.reads[ri].flag & DEF_MASK)) max_obs += (size_t)B.reads[ri].l_seq;
-    }
-    B.obs.resize(max_obs); B.pair.resize(max_obs);
-    isx_obs *po = B.obs.data();
-    uint32_t *pp = B.pair.data();
-    size_t n_out = 0;
-    const uint8_t minq = (uint8_t)std::min(255, std::max(0, p->min_base_quality));
-    for (size_t ri = 0; ri < B.reads.size(); ri++) {
+    const size_t n_reads = B.reads.size();
+    std::vector<uint8_t> emit(n_reads, 0);
+    for (size_t ri = 0; ri < n_reads; ri++) {
         const Read &r = B.reads[ri];
         if (r.tid < 0 || (size_t)r.tid >= n_ref || (r.flag & DEF_MASK)) continue;
         // R2M membership is by NAME on this scaffold (get_base_counts_mm looks up query_name)
@@ -484,24 +529,35 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
         PairInfo &pi = pinfo[(size_t)pidx];
         if (!pi.pass) continue;
         if (pi.pair_id == 0xFFFFFFFFu) pi.pair_id = next_pair++;
+        emit[ri] = 1;
+    }
+    const uint8_t minq = (uint8_t)std::min(255, std::max(0, p->min_base_quality));
+    std::vector<uint64_t> out_at(n_reads + 1, 0);
+    // one walk of a read's CIGAR; WRITE = false only counts
+    auto walk = [&](size_t ri, bool write, isx_obs *po, uint32_t *pp) -> uint64_t {
+        const Read &r = B.reads[ri];
+        const PairInfo &pi = pinfo[(size_t)read_pi[ri]];
         const uint16_t mm = p->skip_mm ? 0 : (uint16_t)pi.nm;
         const int64_t base_off = B.ref_off[(size_t)r.tid];
+        const int64_t ref_len = B.ref_len[(size_t)r.tid];
         const uint8_t *ql = B.quals.data() + r.qual_off, *sq = B.seqs.data() + r.seq_off;
         int64_t ref = r.pos, q = 0;
+        uint64_t n_out = 0;
         for (int k = 0; k < r.n_cigar; k++) {
             const uint32_t c = B.cigars[r.cigar_off + k];
             const int op = c & 15;
             const int64_t n = c >> 4;
             if (op == CM || op == CEQ || op == CX) {
+                // the reference's pileups are truncated to [0, scaffold length) (profile_utilities.py:150-153)
+                const int64_t j0 = std::max<int64_t>(0, -ref), j1 = std::min<int64_t>(n, ref_len - ref);
                 const uint32_t g0 = (uint32_t)(base_off + ref);
-                const int64_t ref_len = B.ref_len[(size_t)r.tid];
-                for (int64_t j = 0; j < n; j++) {
-                    // the reference's pileups are truncated to [0, scaffold length) (profile_utilities.py:150-153)
-                    if (ref + j < 0 || ref + j >= ref_len) continue;
+                for (int64_t j = j0; j < j1; j++) {
                     if (ql[q + j] >= minq) {
-                        isx_obs &o = po[n_out];
-                        o.gpos = g0 + (uint32_t)j; o.mm = mm; o.base = CODE2IDX[sq[q + j]]; o.flags = 0;
-                        pp[n_out] = pi.pair_id;
+                        if (write) {
+                            isx_obs &o = po[n_out];
+                            o.gpos = g0 + (uint32_t)j; o.mm = mm; o.base = CODE2IDX[sq[q + j]]; o.flags = 0;
+                            pp[n_out] = pi.pair_id;
+                        }
                         n_out++;
                     }
                 }
@@ -509,9 +565,30 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
             } else if (op == CI || op == CS) q += n;
             else if (op == CD || op == CN) ref += n;
         }
-    }
-    B.obs.resize(n_out); B.pair.resize(n_out);
+        return n_out;
+    };
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_reads / 4096 + 1));
+    auto run_threads = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(fn, t);
+        fn(0u);
+        for (auto &x : th) x.join();
+    };
+    run_threads([&](unsigned t) {
+        for (size_t ri = n_reads * t / nt; ri < n_reads * (t + 1) / nt; ri++)
+            if (emit[ri]) out_at[ri + 1] = walk(ri, false, nullptr, nullptr);
+    });
+    for (size_t ri = 0; ri < n_reads; ri++) out_at[ri + 1] += out_at[ri];
+    const size_t n_out = (size_t)out_at[n_reads];
+    B.obs.reset(new isx_obs[std::max<size_t>(n_out, 1)]);
+    B.pair.reset(new uint32_t[std::max<size_t>(n_out, 1)]);
+    B.n_obs = n_out;
+    run_threads([&](unsigned t) {
+        for (size_t ri = n_reads * t / nt; ri < n_reads * (t + 1) / nt; ri++)
+            if (emit[ri]) walk(ri, true, B.obs.get() + out_at[ri], B.pair.get() + out_at[ri]);
+    });
 
+    stage("expansion");
     // ---- iterate_splits (fasta.py:56-73) on the flat space ----
     B.split_bounds.clear(); B.split_ref.clear();
     const int64_t W = p->window_length > 0 ? p->window_length : 10000;
@@ -536,7 +613,7 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
     info->n_splits = (int32_t)B.split_ref.size();
     info->n_reads = (int64_t)B.reads.size();
     info->n_pos = n_pos;
-    info->n_obs = (int64_t)B.obs.size();
+    info->n_obs = (int64_t)B.n_obs;
     info->n_pairs = next_pair;
     return ISX_OK;
 }
@@ -544,10 +621,19 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
 int isx_bam_copy(const isx_bam *bam, isx_obs *obs, uint32_t *pair, int64_t *split_bounds, int32_t *split_ref)
 {
     if (!bam || !bam->expanded) { isx_set_error("isx_bam_copy: expand first"); return ISX_ERR_STATE; }
-    if (obs && !bam->obs.empty()) memcpy(obs, bam->obs.data(), bam->obs.size() * sizeof(isx_obs));
-    if (pair && !bam->pair.empty()) memcpy(pair, bam->pair.data(), bam->pair.size() * sizeof(uint32_t));
+    if (obs && bam->n_obs) memcpy(obs, bam->obs.get(), bam->n_obs * sizeof(isx_obs));
+    if (pair && bam->n_obs) memcpy(pair, bam->pair.get(), bam->n_obs * sizeof(uint32_t));
     if (split_bounds) memcpy(split_bounds, bam->split_bounds.data(), bam->split_bounds.size() * sizeof(int64_t));
     if (split_ref && !bam->split_ref.empty()) memcpy(split_ref, bam->split_ref.data(), bam->split_ref.size() * sizeof(int32_t));
+    return ISX_OK;
+}
+
+/* zero-copy access to what isx_bam_copy copies; valid until isx_bam_close */
+int isx_bam_view(const isx_bam *bam, const isx_obs **obs, const uint32_t **pair)
+{
+    if (!bam || !bam->expanded) { isx_set_error("isx_bam_view: expand first"); return ISX_ERR_STATE; }
+    if (obs) *obs = bam->obs.get();
+    if (pair) *pair = bam->pair.get();
     return ISX_OK;
 }
 

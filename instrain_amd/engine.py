@@ -171,17 +171,26 @@ class BamFile:
         self.info = None
 
     def expand(self, min_read_ani=0.95, min_mapq=-1, max_insert_relative=3, min_insert=50,
-               min_base_quality=30, skip_mm=False, window_length=10000):
+               min_base_quality=30, skip_mm=False, window_length=10000, copy=True):
+        """-> (obs, pair, split_bounds, split_ref).  copy=False: obs / pair are views of the handle's own
+        arrays (isx_bam_view), valid until close() -- enough to build a Batch from them."""
         p = BamParams(float(min_read_ani), int(min_mapq), float(max_insert_relative), int(min_insert),
                       int(min_base_quality), 1 if skip_mm else 0, int(window_length), 0)
         info = BamInfo()
         check(self.lib.isx_bam_expand(self.h, C.byref(p), C.byref(info)))
         self.info = {n: getattr(info, n) for n, _ in BamInfo._fields_ if n != "pad"}
-        obs = np.empty(info.n_obs, dtype=OBS_DT)
-        pair = np.empty(info.n_obs, dtype=np.uint32)
         bounds = np.empty(info.n_splits + 1, dtype=np.int64)
         sref = np.empty(info.n_splits, dtype=np.int32)
-        check(self.lib.isx_bam_copy(self.h, obs.ctypes.data, pair.ctypes.data, bounds.ctypes.data, sref.ctypes.data))
+        if copy or info.n_obs == 0:
+            obs = np.empty(info.n_obs, dtype=OBS_DT)
+            pair = np.empty(info.n_obs, dtype=np.uint32)
+            check(self.lib.isx_bam_copy(self.h, obs.ctypes.data, pair.ctypes.data, bounds.ctypes.data, sref.ctypes.data))
+        else:
+            check(self.lib.isx_bam_copy(self.h, None, None, bounds.ctypes.data, sref.ctypes.data))
+            po, pp = C.c_void_p(), C.c_void_p()
+            check(self.lib.isx_bam_view(self.h, C.byref(po), C.byref(pp)))
+            obs = np.frombuffer((C.c_uint8 * (info.n_obs * OBS_DT.itemsize)).from_address(po.value), dtype=OBS_DT)
+            pair = np.frombuffer((C.c_uint32 * info.n_obs).from_address(pp.value), dtype=np.uint32)
         return obs, pair, bounds, sref
 
     def refs(self):

@@ -225,17 +225,19 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                                             max_insert_relative=kwargs.get('max_insert_relative', 3),
                                             min_insert=kwargs.get('min_insert', 50),
                                             skip_mm=bool(kwargs.get('skip_mm_profiling', False)),
-                                            window_length=int(kwargs.get('window_length', 10000)))
+                                            window_length=int(kwargs.get('window_length', 10000)), copy=False)
         refs = bf.refs()
         names = [r[0] for r in refs]
         for n, ln, _ in refs:
             if n not in s2s or len(s2s[n]) != ln:
                 raise ValueError("scaffold {0} is not in the .fasta / length differs from the .bam header".format(n))
         n_mm = bf.info["max_mm"] + 1
-        bf.close()
         kw = {k: v for k, v in kwargs.items() if k in ('min_cov', 'min_freq', 'min_snp', 'rarefied_coverage', 'scaffold_tables', 'seed')}
-        return profile_splits(ctx, names, [str(s2s[n]).upper() for n in names], obs, pair, null_model, n_mm,
-                              window_length=int(kwargs.get('window_length', 10000)), bam_name=bam, **kw)
+        try:                # obs / pair are views of the front end's arrays: keep it open until the batch is built
+            return profile_splits(ctx, names, [str(s2s[n]).upper() for n in names], obs, pair, null_model, n_mm,
+                                  window_length=int(kwargs.get('window_length', 10000)), bam_name=bam, **kw)
+        finally:
+            bf.close()
     except Exception as e:
         print(e)
         traceback.print_exc()

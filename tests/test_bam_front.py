@@ -24,6 +24,16 @@ def test_sars_bam_matches_committed_observations():
     bam.close()
 
 
+def test_zero_copy_view_equals_copy():
+    a = engine.BamFile(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"))
+    b = engine.BamFile(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"))
+    o1, p1, b1, s1 = a.expand()
+    o2, p2, b2, s2 = b.expand(copy=False)               # views of the handle's arrays (isx_bam_view)
+    assert o2.dtype == o1.dtype and len(o2) == len(o1) == 3717600
+    assert (o1 == o2).all() and (p1 == p2).all() and (b1 == b2).all() and (s1 == s2).all()
+    a.close(); b.close()
+
+
 def test_small_scaffold_matches_oracle_python():
     """second BAM fixture of the reference's tests (126 bp scaffold, 751 reads): C++ == oracle/bam_py"""
     from oracle import bam_py
