@@ -108,14 +108,14 @@ INT8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA peak (spec, no sparsity; MI35
 
 
 def linkage_leg(ctx, seed=3):
-    """Secondary metric: SNV pairs linked / s on a C3-shaped slice (200x, 1 SNV site / 100 bp), with
+    """Secondary metric: SNV pairs linked / s on BASELINE configs[2] (C3: 5 Mbp, 200x, 50 000 SNV sites), with
     the sparse pair-increment path (default) and the dense int8-MFMA path (linkage_mode 2)."""
     from instrain_amd import engine, synth
-    glen = int(os.environ.get("ISX_BENCH_C3_BP", 1_000_000))        # 5_000_000 = the full configs[2]
+    glen = int(os.environ.get("ISX_BENCH_C3_BP", 5_000_000))        # configs[2] in full; smaller = a slice of it (debug)
     w = synth.make_workload(genome_len=glen, coverage=200, n_sites=glen // 100, seed=seed, skip_mm=True,
                             af_lo=0.2, af_hi=0.5)
-    out = {"workload": "C3 slice: %.1f Mbp of the 5 Mbp genome, 200x, %d SNV sites (1 / 100 bp), skip_mm, linkage on"
-                       % (glen / 1e6, glen // 100),
+    out = {"workload": "C3%s: %.1f Mbp genome, 200x, %d SNV sites (1 / 100 bp, two haplotype backgrounds), skip_mm, linkage on"
+                       % ("" if glen == 5_000_000 else " slice", glen / 1e6, glen // 100),
            "kept_observations": int(w["n_obs"]), "read_pairs": int(w["n_pairs"])}
     for mode, name in ((1, "sparse"), (2, "dense_mfma")):
         b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1, enable_linkage=True,
