@@ -10,11 +10,12 @@ struct DevBuf {
 
 struct DenseSplit {         // one split of the dense MFMA path
     uint64_t xt_off;        // byte offset of its column-major X^T block
-    uint32_t rpad;          // rows (read pairs), padded to 32
+    uint32_t rpad;          // rows (read pairs), padded to 128
     uint32_t ctiles;        // column tiles of 32 (4 columns per site)
-    uint32_t first_site, n_sites, first_row, pad;
+    uint32_t first_site, n_sites, first_row;
+    uint32_t tile0;         // index of its tile (0, 0) in the tile counters (tiles ordered I, then J >= I)
 };
-struct DenseTile { uint32_t slot, I, J, pad; };
+struct DenseTile { uint32_t slot, I, J, pad; };     // a 128 x 128 column block (I <= J, units of 4 tiles)
 
 struct LinkageBuffers {
     DevBuf<uint32_t> site_keys, site_keys2, site_gpos, site_split;

@@ -329,58 +329,124 @@ __global__ void k_dense_scatter(const isx_ao *ao, const uint64_t *key, const uin
     atomicAdd(reinterpret_cast<uint32_t *>(xt + (idx & ~3ull)), 1u << (8 * (idx & 3)));
 }
 
-// One wave per upper-triangle tile. EMIT=false: number of (site1 < site2) non-zero counts of the tile.
+// X^T X on the matrix cores.  A workgroup (4 waves) owns a 128 x 128 block of allele columns (I <= J) and
+// walks the rows (read pairs) in chunks of 128: both 128 x 128-byte operand panels go global -> registers
+// -> LDS (double buffered, 16-byte pieces XOR-swizzled by the row so that the b128 reads of 32 different
+// rows spread over all banks), every wave computes a 64 x 64 sub-block = 2 x 2 tiles of
+// v_mfma_i32_32x32x32_i8, so each operand fragment read from LDS feeds two MFMAs and each byte of X^T is
+// fetched from L2 once per 128 columns instead of once per 32.
+// Operand layout: lane l holds row (l & 31) and 16 k-values of half (l >> 5); which k-values a (half,
+// step) slot carries is free as long as A and B agree (a dot product has no order).
+// EMIT=false: per 32 x 32 tile the number of (site1 < site2) non-zero counts; EMIT=true: keys + counts.
+constexpr int DG_LDS_BYTES = 2 * 2 * 128 * 128;
+
 template <bool EMIT>
-__global__ void __launch_bounds__(256) k_dense_gemm(const DenseTile *tiles, uint32_t n_tiles, const DenseSplit *splits,
-                                                    const uint8_t *xt, uint32_t *tile_cnt, const uint32_t *tile_off,
-                                                    uint64_t *keys, uint32_t *cnts, int sb)
+__global__ void __launch_bounds__(256) k_dense_gemm(const DenseTile *blocks, const DenseSplit *splits, const uint8_t *xt,
+                                                    uint32_t *tile_cnt, const uint32_t *tile_off, uint64_t *keys,
+                                                    uint32_t *cnts, int sb)
 {
-    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (t >= n_tiles) return;
-    const int l = threadIdx.x & 63;
-    const DenseTile tl = tiles[t];
-    const DenseSplit ds = splits[tl.slot];
-    // Operand layout of v_mfma_i32_32x32x32_i8: lane l holds row (l & 31) and 16 k-values of half (l >> 5).
-    // Which k-values a (half, step) slot carries is free as long as A and B agree (a dot product has no
-    // order), so a lane streams 64 CONTIGUOUS bytes of its row per round -- the wave reads whole 128-byte
-    // lines of 32 rows, each exactly once -- and feeds them to four MFMAs.  rpad is a multiple of 128.
-    const uint8_t *pa = xt + ds.xt_off + (uint64_t)(tl.I * 32 + (l & 31)) * ds.rpad + 64 * (l >> 5);
-    const uint8_t *pb = xt + ds.xt_off + (uint64_t)(tl.J * 32 + (l & 31)) * ds.rpad + 64 * (l >> 5);
-    v16i acc = {0};
-    v4i a[4], b[4];
-    auto load = [&](uint32_t k0) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dg_lds[];
+    const DenseTile bl = blocks[blockIdx.x];
+    const DenseSplit ds = splits[bl.slot];
+    const int tid = threadIdx.x, l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wi = wave >> 1, wj = wave & 1;
+    const uint32_t ncols = ds.ctiles * 32;
+    const bool diag = bl.I == bl.J;
+    // which of this wave's 2 x 2 tiles exist (inside the matrix, upper triangle incl. the diagonal tile)
+    bool use[2][2];
+    uint32_t tI[2], tJ[2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            a[q] = *reinterpret_cast<const v4i *>(pa + k0 + 16 * q);
-            b[q] = *reinterpret_cast<const v4i *>(pb + k0 + 16 * q);
+    for (int a = 0; a < 2; a++) { tI[a] = bl.I * 4 + wi * 2 + a; tJ[a] = bl.J * 4 + wj * 2 + a; }
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) { use[a][b] = tI[a] < ds.ctiles && tJ[b] < ds.ctiles && tJ[b] >= tI[a]; any |= use[a][b]; }
+
+    // global -> register staging: thread handles pieces tid + 256 u (u < 4) of a 128-row x 8-piece panel
+    const uint8_t *src_a[4], *src_b[4];
+    uint32_t dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t idx = (uint32_t)tid + 256u * u, row = idx >> 3, piece = idx & 7;
+        const uint32_t ra = min(bl.I * 128 + row, ncols - 1), rb = min(bl.J * 128 + row, ncols - 1);   // clamp: padding rows are masked at the output
+        src_a[u] = xt + ds.xt_off + (uint64_t)ra * ds.rpad + piece * 16;
+        src_b[u] = xt + ds.xt_off + (uint64_t)rb * ds.rpad + piece * 16;
+        dst[u] = row * 128 + ((piece ^ (row & 7)) << 4);
+    }
+    v4i ga[4], gb[4];
+    auto gload = [&](uint32_t k0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            ga[u] = *reinterpret_cast<const v4i *>(src_a[u] + k0);
+            if (!diag) gb[u] = *reinterpret_cast<const v4i *>(src_b[u] + k0);
         }
     };
-    if (ds.rpad) load(0);
-    for (uint32_t k0 = 0; k0 < ds.rpad; k0 += 128) {
-        v4i ca[4], cb[4];
+    auto lstore = [&](int buf) {
+        uint8_t *pa = dg_lds + buf * (2 * 128 * 128), *pb = pa + 128 * 128;
 #pragma unroll
-        for (int q = 0; q < 4; q++) { ca[q] = a[q]; cb[q] = b[q]; }
-        if (k0 + 128 < ds.rpad) load(k0 + 128);        // next round in flight behind the MFMAs
-#pragma unroll
-        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ca[q], cb[q], acc, 0, 0, 0);
-    }
-    uint32_t run = EMIT ? tile_off[t] : 0;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const uint32_t ci = tl.I * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);      // C/D layout of the 32x32 forms
-        const uint32_t cj = tl.J * 32 + (l & 31);
-        const uint32_t si = ci >> 2, sj = cj >> 2;
-        const int v = acc[r];
-        const bool hit = v > 0 && si < sj && sj < ds.n_sites;
-        const unsigned long long bal = __ballot(hit);
-        if (EMIT && hit) {
-            const uint32_t o = run + (uint32_t)__popcll(bal & ((1ull << l) - 1ull));
-            keys[o] = make_key(sb, ds.first_site + si, ds.first_site + sj, 0, ci & 3, cj & 3);
-            cnts[o] = (uint32_t)v;
+        for (int u = 0; u < 4; u++) {
+            *reinterpret_cast<v4i *>(pa + dst[u]) = ga[u];
+            if (!diag) *reinterpret_cast<v4i *>(pb + dst[u]) = gb[u];
         }
-        run += (uint32_t)__popcll(bal);
+    };
+    v16i acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = v16i{0};
+    const uint32_t n_chunks = ds.rpad / 128;
+    if (n_chunks) { gload(0); lstore(0); }
+    __syncthreads();
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        if (c + 1 < n_chunks) gload((c + 1) * 128);             // in flight behind this chunk's MFMAs
+        const uint8_t *pa = dg_lds + (c & 1) * (2 * 128 * 128), *pb = diag ? pa : pa + 128 * 128;
+        if (any) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t piece = 2 * q + (l >> 5);
+                v4i fa[2], fb[2];
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const uint32_t ra = wi * 64 + a * 32 + (l & 31), rb = wj * 64 + a * 32 + (l & 31);
+                    fa[a] = *reinterpret_cast<const v4i *>(pa + ra * 128 + ((piece ^ (ra & 7)) << 4));
+                    fb[a] = *reinterpret_cast<const v4i *>(pb + rb * 128 + ((piece ^ (rb & 7)) << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+                        if (use[a][b]) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (c + 1 < n_chunks) lstore((c + 1) & 1);              // that buffer was last read in round c - 1
+        __syncthreads();
     }
-    if (!EMIT && l == 0) tile_cnt[t] = run;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            if (!use[a][b]) continue;                           // wave-uniform
+            const uint32_t I = tI[a], J = tJ[b];
+            const uint32_t t = ds.tile0 + I * ds.ctiles - (I * (I - 1)) / 2 + (J - I);
+            uint32_t run = EMIT ? tile_off[t] : 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t ci = I * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);      // C/D layout of the 32x32 forms
+                const uint32_t cj = J * 32 + (l & 31);
+                const uint32_t si = ci >> 2, sj = cj >> 2;
+                const int v = acc[a][b][r];
+                const bool hit = v > 0 && si < sj && sj < ds.n_sites;
+                const unsigned long long bal = __ballot(hit);
+                if (EMIT && hit) {
+                    const uint32_t o = run + (uint32_t)__popcll(bal & ((1ull << l) - 1ull));
+                    keys[o] = make_key(sb, ds.first_site + si, ds.first_site + sj, 0, ci & 3, cj & 3);
+                    cnts[o] = (uint32_t)v;
+                }
+                run += (uint32_t)__popcll(bal);
+            }
+            if (!EMIT && l == 0) tile_cnt[t] = run;
+        }
+    }
 }
 
 __global__ void k_fill_ones(uint32_t *p, uint32_t n)
@@ -512,9 +578,9 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
     }
     // split table + tile list (host; a few entries per split)
     std::vector<DenseSplit> ds;
-    std::vector<DenseTile> tiles;
+    std::vector<DenseTile> blocks;
     std::vector<uint32_t> slot(nsp, 0xFFFFFFFFu);
-    uint64_t bytes = 0, macs = 0;
+    uint64_t bytes = 0, macs = 0, n_tiles64 = 0;
     for (uint32_t sp = 0; sp < nsp; sp++) {
         const uint32_t rows = frow[sp + 1] - frow[sp], ns = fsite[sp + 1] - fsite[sp];
         if (rows == 0 || ns < 2) continue;           // no cross-site pair possible
@@ -523,29 +589,34 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
         d.rpad = (rows + 127) / 128 * 128;
         d.ctiles = (ns * 4 + 31) / 32;
         d.first_site = fsite[sp]; d.n_sites = ns; d.first_row = frow[sp];
+        d.tile0 = (uint32_t)n_tiles64;
         bytes += (uint64_t)d.ctiles * 32 * d.rpad;
         slot[sp] = (uint32_t)ds.size();
-        for (uint32_t I = 0; I < d.ctiles; I++)
-            for (uint32_t J = I; J < d.ctiles; J++) tiles.push_back(DenseTile{(uint32_t)ds.size(), I, J, 0});
-        macs += (uint64_t)d.ctiles * (d.ctiles + 1) / 2 * 32 * 32 * d.rpad;
+        const uint32_t nb = (d.ctiles + 3) / 4;
+        for (uint32_t I = 0; I < nb; I++)
+            for (uint32_t J = I; J < nb; J++) blocks.push_back(DenseTile{(uint32_t)ds.size(), I, J, 0});
+        n_tiles64 += (uint64_t)d.ctiles * (d.ctiles + 1) / 2;
+        macs += (uint64_t)d.ctiles * (d.ctiles + 1) / 2 * 32 * 32 * d.rpad;       // useful tiles only (no block padding)
         ds.push_back(d);
     }
-    out.dense_tiles = tiles.size(); out.dense_bytes = bytes; out.dense_macs = macs;
+    out.dense_tiles = n_tiles64; out.dense_bytes = bytes; out.dense_macs = macs;
     if (bytes > (16ull << 30)) { isx_set_error("dense linkage path needs > 16 GiB for X^T: use the sparse path"); return ISX_ERR_CAPACITY; }
-    if (tiles.size() >= 0xFFFFFFFFull) { isx_set_error("too many dense tiles"); return ISX_ERR_CAPACITY; }
-    const uint32_t n_tiles = (uint32_t)tiles.size();
+    if (n_tiles64 >= 0xFFFFFFFFull || blocks.size() >= 0x7FFFFFFFull) { isx_set_error("too many dense tiles"); return ISX_ERR_CAPACITY; }
+    const uint32_t n_tiles = (uint32_t)n_tiles64, n_blocks = (uint32_t)blocks.size();
     uint64_t n_gemm = 0;
     if (n_tiles) {
-        if ((rc = ensure(B.dsplits, ds.size())) || (rc = ensure(B.dtiles, tiles.size())) || (rc = ensure(B.xt, bytes + 16)) ||
+        if ((rc = ensure(B.dsplits, ds.size())) || (rc = ensure(B.dtiles, blocks.size())) || (rc = ensure(B.xt, bytes + 16)) ||
             (rc = ensure(B.tile_cnt, n_tiles)) || (rc = ensure(B.tile_off, (size_t)n_tiles + 1))) return rc;
         HIP_TRY(hipMemcpyAsync(B.dsplits.p, ds.data(), ds.size() * sizeof(DenseSplit), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(B.dtiles.p, tiles.data(), tiles.size() * sizeof(DenseTile), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(B.dtiles.p, blocks.data(), blocks.size() * sizeof(DenseTile), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(B.split_slot.p, slot.data(), slot.size() * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(B.xt.p, 0, bytes + 16, s));
         hipLaunchKernelGGL(k_dense_scatter, ga, blk, 0, s, B.ao2.p, B.key64b.p, B.row_id.p, B.head.p, n_ao, B.split_slot.p,
                            B.dsplits.p, B.xt.p);
         HIP_TRY(hipEventRecord(in.ev_mfma[0], s));
-        hipLaunchKernelGGL((k_dense_gemm<false>), dim3((n_tiles + 3) / 4), blk, 0, s, B.dtiles.p, n_tiles, B.dsplits.p,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_gemm<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_gemm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_BYTES);
+        hipLaunchKernelGGL((k_dense_gemm<false>), dim3(n_blocks), blk, DG_LDS_BYTES, s, B.dtiles.p, B.dsplits.p,
                            B.xt.p, B.tile_cnt.p, nullptr, nullptr, nullptr, sb);
         HIP_TRY(hipEventRecord(in.ev_mfma[1], s));
         if ((rc = scan_total(B, s, B.tile_cnt.p, B.tile_off.p, n_tiles, n_gemm))) return rc;
@@ -564,7 +635,7 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
     if ((rc = ensure(B.keys, n_k)) || (rc = ensure(B.keys2, n_k)) || (rc = ensure(B.vals, n_k)) || (rc = ensure(B.vals2, n_k)) ||
         (rc = ensure(B.ukeys, n_k)) || (rc = ensure(B.ucnt, n_k)) || (rc = ensure(B.n_runs, 2))) return rc;
     if (n_gemm)
-        hipLaunchKernelGGL((k_dense_gemm<true>), dim3((n_tiles + 3) / 4), blk, 0, s, B.dtiles.p, n_tiles, B.dsplits.p, B.xt.p,
+        hipLaunchKernelGGL((k_dense_gemm<true>), dim3(n_blocks), blk, DG_LDS_BYTES, s, B.dtiles.p, B.dsplits.p, B.xt.p,
                            nullptr, B.tile_off.p, B.keys.p, B.vals.p, sb);
     if (n_self) {
         hipLaunchKernelGGL((k_pair_incr<true, true>), ga, blk, 0, s, B.ao2.p, n_ao, B.site_split.p, nullptr, B.incr_off.p,
