@@ -80,9 +80,9 @@ def test_random_messy_bam_cpp_equals_oracle_python(tmp_path):
     from oracle import bam_py
     from tests import bamwriter
     refs = [("scafA", 4000), ("scafB", 900), ("scafC", 12500)]
-    for seed in (1, 2, 3):
+    for seed, n_pairs in ((1, 1500), (2, 1500), (3, 7000)):       # > 4096 reads: the threaded extraction / expansion paths
         path = str(tmp_path / ("r%d.bam" % seed))
-        reads = bamwriter.random_reads(seed, refs, 1500)
+        reads = bamwriter.random_reads(seed, refs, n_pairs)
         bamwriter.write_bam(path, refs, reads)
         rrefs, rr = bam_py.read_bam(path)
         assert rrefs == refs and len(rr) == len(reads)

@@ -101,6 +101,46 @@ def test_random_splits_vs_oracle(ctx, seed, mLen, depth, mm_levels, n_sites):
     assert got["n_edges"] == exp["n_edges"] and got["sizes"]["n_increments"] == exp["n_increments"]
 
 
+def test_randomized_parameter_sweep_vs_oracle(ctx):
+    """48 random small splits with random thresholds, depths, mm-level counts, non-ACGT rates, windows and
+    linkage modes: every table must equal the oracle's (integers exact, floats to TOL)."""
+    import importlib.util
+    from oracle import oracle
+    from tests import prod
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(util.GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    lut, fb = util.load_lut()
+    rng = np.random.Generator(np.random.PCG64(20250927))
+    n_rows = 0
+    for case in range(48):
+        mLen = int(rng.choice([37, 64, 130, 500, 1200, 3000]))
+        depth = int(rng.choice([3, 8, 20, 60, 200]))
+        mml = int(rng.choice([1, 1, 2, 5, 12, 40]))
+        kw = dict(seed=1000 + case, mLen=mLen, start=int(rng.choice([0, 17, 123456])), depth=depth,
+                  read_len=int(rng.choice([20, 60, 150])), n_sites=int(min(mLen // 6, rng.choice([0, 3, 20, 120]))),
+                  mm_levels=mml, p_other=float(rng.choice([0.0, 0.02, 0.25])), ref_ambig=int(rng.choice([0, 0, 5])),
+                  self_pairs=float(rng.choice([0.05, 0.5])), err=float(rng.choice([0.0, 0.01, 0.08])),
+                  af_lo=float(rng.choice([0.02, 0.2])), af_hi=float(rng.choice([0.5, 1.0])))
+        kw["read_len"] = min(kw["read_len"], max(8, mLen // 2))
+        kw["ref_ambig"] = min(kw["ref_ambig"], mLen // 8)
+        par = dict(min_cov=int(rng.choice([1, 3, 5, 10])), min_freq=float(rng.choice([0.01, 0.05, 0.2, 0.5])),
+                   min_snp=int(rng.choice([2, 5, 20])))
+        seq, pos, base, mm, pair = mg.synth_case(**kw)
+        if len(pos) == 0:
+            continue
+        exp = oracle.profile_split(pos, base, mm, pair, seq, kw["start"], lut, fb, **par)
+        extra = dict(window=int(rng.choice([0, 64, 192])))
+        if mml == 1 and rng.random() < 0.5:
+            extra["linkage_mode"] = 2                                  # dense MFMA path
+        got = prod.run_split(ctx, pos, base, mm, pair, seq, kw["start"], n_mm_bins=mml, **par, **extra)
+        what = "case %d %r %r %r" % (case, kw, par, extra)
+        util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what=what)
+        assert got["n_edges"] == exp["n_edges"] and got["sizes"]["n_increments"] == exp["n_increments"], what
+        n_rows += len(exp["snv"]) + len(exp["ld"])
+    assert n_rows > 2000
+
+
 def test_multi_split_batch_vs_per_split_oracle(ctx):
     """Several splits in one flat batch: linkage must not cross split bounds; pair ids shared across bounds."""
     from instrain_amd import engine
