@@ -38,7 +38,8 @@ struct isx_batch {
     size_t lds = 0;
     // device
     uint2 *d_rec = nullptr;
-    uint32_t *d_pair = nullptr;
+    uint32_t *d_pair = nullptr, *d_gpos = nullptr, *d_cbase = nullptr;
+    uint16_t *d_gpos16 = nullptr;
     uint8_t *d_ref = nullptr;
     uint2 *d_win = nullptr;
     uint16_t *d_thr = nullptr;
@@ -194,7 +195,7 @@ void isx_batch_destroy(isx_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_rec, b->d_pair, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
+    void *ps[] = {b->d_rec, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
@@ -338,6 +339,20 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     if (bad_pos) { isx_batch_destroy(b); isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
     if (prm->enable_linkage) {
         BH(hipMalloc(&b->d_pair, b->n_rec * sizeof(uint32_t)));
+        // the allele pass streams positions only: 2-byte deltas to the chunk's lowest position when every
+        // chunk spans < 65535 positions (any real BAM), else the 4-byte positions
+        bool narrow = true;
+        for (uint64_t i = 0; i < n_chunks; i++) if (cany[i] && cmax[i] - cmin[i] >= 65535u) { narrow = false; break; }
+        if (narrow) {
+            for (uint64_t i = 0; i < n_chunks; i++) if (!cany[i]) cmin[i] = 0;
+            BH(hipMalloc(&b->d_gpos16, b->n_rec * sizeof(uint16_t)));
+            BH(hipMalloc(&b->d_cbase, std::max<uint64_t>(n_chunks, 1) * sizeof(uint32_t)));
+            BH(hipMemcpyAsync(b->d_cbase, cmin.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        } else {
+            BH(hipMalloc(&b->d_gpos, b->n_rec * sizeof(uint32_t)));
+        }
+        launch_extract_gpos(b->d_rec, b->d_gpos, b->d_gpos16, b->d_cbase, b->n_rec, c->stream);
+        BH(hipStreamSynchronize(c->stream));                                  // cmin is a local
         uint32_t maxp = 0;
         BT(staged_upload(c, b->d_pair, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
             for (uint64_t i = 0; i < cnt; i++) {
@@ -437,7 +452,7 @@ static int launch_pass(isx_batch *b)
 
     PileupArgs a{};
     a.rec = b->d_rec; a.win_range = b->d_win; a.ref = b->d_ref;
-    a.pair = b->d_pair; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
+    a.pair = b->d_pair; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_cbase; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
     if (const char *e = getenv("ISX_DEBUG_MODE")) a.debug_mode = atoi(e);     // ablation only

@@ -189,69 +189,103 @@ __device__ __forceinline__ uint32_t masked_sum(const uint32_t *c, uint32_t mask)
     return s;
 }
 
-// update_linked_reads (linkage.py:254-283): re-stream the window's records; an observation at a
-// SNP site whose base is in the site's `bases` set goes to the next free slot of the site's slab.
-// Hits are rare (about one per 100 records) but nearly every wave-wide step has one, and a hit costs a
-// dependent global load (the pair id) + a scattered 16-byte store: handled in place, every step of
-// every wave would wait on that latency with one lane alive.  So hits are compacted (ballot + mbcnt)
-// into a per-wave LDS stage of 64 entries and drained with all lanes busy.  `stage` = 128 words per
-// wave of LDS that is dead during this pass (the window's counters; the caller has a barrier before).
+// update_linked_reads (linkage.py:254-283): an observation at a SNP site whose base is in the site's
+// `bases` set goes to the next free slot of the site's slab.  The window's records are streamed a
+// second time, but only their positions (a.gpos, 4 of the 8 bytes; the full record and the pair id are
+// fetched for the ~1 % of records that sit on a site).  Those candidates are rare but nearly every
+// wave-wide step has one, and a candidate costs dependent global loads + a scattered 16-byte store:
+// handled in place, every step of every wave would wait on that latency with one lane alive.  So they
+// are compacted (ballot + mbcnt) into a per-wave LDS stage of 64 entries and drained with all lanes
+// busy.  `stage` = 128 words per wave of LDS that is dead during this pass (the window's counters; the
+// caller has a barrier before).
 __device__ __forceinline__ void allele_drain(const PileupArgs &a, const uint32_t *st, uint32_t n, uint32_t w0,
-                                             uint32_t *slabc, uint32_t ao_base, int lane)
+                                             const uint8_t *maskl, uint32_t *slabc, uint32_t ao_base, int lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if ((uint32_t)lane < n) {
-        const uint32_t i = st[2 * lane], pk = st[2 * lane + 1];
-        const uint32_t rel = pk & 0x3FFFu, base = (pk >> 14) & 3u;
-        const uint32_t slot = atomicAdd(&slabc[rel], 1u);
-        isx_ao o;
-        o.pair = a.pair[i]; o.site = w0 + rel; o.obs_idx = i;
-        o.mm = (uint16_t)(pk >> 16); o.base = (uint8_t)base; o.pad = 0;
-        a.ao[ao_base + slot] = o;
+        const uint32_t i = st[2 * lane], rel = st[2 * lane + 1];
+        const uint32_t at = a.rec[i].y;
+        const uint32_t base = (at >> 16) & 0xFFu;
+        if (base < 4 && ((maskl[rel] >> base) & 1u)) {
+            const uint32_t slot = atomicAdd(&slabc[rel], 1u);
+            isx_ao o;
+            o.pair = a.pair[i]; o.site = w0 + rel; o.obs_idx = i;
+            o.mm = (uint16_t)(at & 0xFFFFu); o.base = (uint8_t)base; o.pad = 0;
+            a.ao[ao_base + slot] = o;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void allele_pass(const PileupArgs &a, const u32x4 *rec4, uint32_t lo, uint32_t hi,
+// lo, hi: the window's record range in units of TWO records (as the counting pass uses them); multiples of 512
+__device__ __forceinline__ void allele_pass(const PileupArgs &a, uint32_t lo, uint32_t hi,
                                             uint32_t w0, int W, const uint8_t *maskl, uint32_t *slabc,
                                             uint32_t ao_base, uint32_t *stage, int tid, int nthr)
 {
     const int lane = tid & 63;
     uint32_t *st = stage + (tid >> 6) * 128;
     uint32_t nst = 0;                           // wave-uniform fill of the stage
-    for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
-        u32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t j = i0 + tid + u * nthr;
-            if (j < hi) v[u] = rec4[j];
-            else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
+    auto consider = [&](uint32_t rel, uint32_t idx) {               // called by all lanes of the wave together
+        bool cand = false;
+        if (rel < (uint32_t)W) cand = maskl[rel] != 0;
+        const uint64_t bal = __ballot(cand);
+        if (bal == 0) return;                                       // wave-uniform
+        const uint32_t n = (uint32_t)__popcll(bal);
+        if (nst + n > 64u) { allele_drain(a, st, nst, w0, maskl, slabc, ao_base, lane); nst = 0; }
+        if (cand) {
+            const uint32_t r = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            st[2 * r] = idx;
+            st[2 * r + 1] = rel;
         }
+        nst += n;
+    };
+    if (a.gpos16) {                             // 2-byte deltas: 8 records per 16-byte load
+        const u32x4 *g8 = reinterpret_cast<const u32x4 *>(a.gpos16);
+        const uint32_t q_lo = lo >> 2, q_hi = hi >> 2;              // units of EIGHT records
+        for (uint32_t i0 = q_lo; i0 < q_hi; i0 += 2 * nthr) {
+            u32x4 v[2];
+            uint32_t cb[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 2; u++) {
+                const uint32_t j = i0 + tid + u * nthr;
+                if (j < q_hi) { v[u] = __builtin_nontemporal_load(&g8[j]); cb[u] = a.chunk_base[j / (ISX_CHUNK / 8)]; }
+                else { v[u].x = v[u].y = v[u].z = v[u].w = 0xFFFFFFFFu; cb[u] = 0; }
+            }
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t g = h ? v[u].z : v[u].x, at = h ? v[u].w : v[u].y;
-                const uint32_t rel = g - w0;
-                const uint32_t base = (at >> 16) & 0xFFu;
-                bool hit = false;
-                if (rel < (uint32_t)W && base < 4) hit = (maskl[rel] >> base) & 1u;
-                const uint64_t bal = __ballot(hit);
-                if (bal == 0) continue;                             // wave-uniform
-                const uint32_t n = (uint32_t)__popcll(bal);
-                if (nst + n > 64u) { allele_drain(a, st, nst, w0, slabc, ao_base, lane); nst = 0; }
-                if (hit) {
-                    const uint32_t r = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    st[2 * r] = 2u * (i0 + tid + u * nthr) + (uint32_t)h;
-                    st[2 * r + 1] = rel | (base << 14) | (at << 16);
+            for (int u = 0; u < 2; u++) {
+#pragma unroll
+                for (int h = 0; h < 8; h++) {
+                    const uint32_t word = (h >> 1) == 0 ? v[u].x : ((h >> 1) == 1 ? v[u].y : ((h >> 1) == 2 ? v[u].z : v[u].w));
+                    const uint32_t d = (h & 1) ? (word >> 16) : (word & 0xFFFFu);
+                    const uint32_t rel = d == 0xFFFFu ? 0xFFFFFFFFu : cb[u] + d - w0;
+                    consider(rel, 8u * (i0 + tid + u * nthr) + (uint32_t)h);
                 }
-                nst += n;
+            }
+        }
+    } else {
+        const u32x4 *g4 = reinterpret_cast<const u32x4 *>(a.gpos);
+        const uint32_t q_lo = lo >> 1, q_hi = hi >> 1;              // units of FOUR records
+        for (uint32_t i0 = q_lo; i0 < q_hi; i0 += 4 * nthr) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = i0 + tid + u * nthr;
+                if (j < q_hi) v[u] = __builtin_nontemporal_load(&g4[j]);
+                else { v[u].x = ISX_SENTINEL; v[u].y = ISX_SENTINEL; v[u].z = ISX_SENTINEL; v[u].w = ISX_SENTINEL; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t g = h == 0 ? v[u].x : (h == 1 ? v[u].y : (h == 2 ? v[u].z : v[u].w));
+                    consider(g - w0, 4u * (i0 + tid + u * nthr) + (uint32_t)h);
+                }
             }
         }
     }
-    if (nst) allele_drain(a, st, nst, w0, slabc, ao_base, lane);
+    if (nst) allele_drain(a, st, nst, w0, maskl, slabc, ao_base, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -440,7 +474,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         if (linkage) {
             if (ok && nao) {
                 __syncthreads();                // every wave is done with cnt: it becomes the allele pass's stage
-                allele_pass(a, rec4, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                allele_pass(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
             prefetch_window(w + grid);
         }
@@ -756,7 +790,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         if (linkage) {
             if (ok && nao) {
                 __syncthreads();                // every wave is done with the counters: they become the stage
-                allele_pass(a, rec4, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                allele_pass(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
             prefetch_window(w + grid);
         }
@@ -805,6 +839,20 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
     } else {
         if (link) launch_one(k_pileup_dense<true>, a, block, lds, grid, s); else launch_one(k_pileup_dense<false>, a, block, lds, grid, s);
     }
+}
+
+__global__ void k_extract_gpos(const uint2 *rec, uint32_t *gpos, uint16_t *gpos16, const uint32_t *chunk_base, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = rec[i].x;
+    if (gpos16) gpos16[i] = g == ISX_SENTINEL ? (uint16_t)0xFFFFu : (uint16_t)(g - chunk_base[i / ISX_CHUNK]);
+    else gpos[i] = g;
+}
+
+void launch_extract_gpos(const uint2 *rec, uint32_t *gpos, uint16_t *gpos16, const uint32_t *chunk_base, uint64_t n_rec, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_extract_gpos, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, s, rec, gpos, gpos16, chunk_base, n_rec);
 }
 
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s)

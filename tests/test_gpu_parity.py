@@ -163,6 +163,38 @@ def test_multi_split_batch_vs_per_split_oracle(ctx):
     util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="multi")
 
 
+@pytest.mark.parametrize("mml", [1, 3])
+def test_wide_chunk_takes_the_4_byte_position_stream(ctx, mml):
+    """two islands of reads 250 kbp apart: the 1024-record chunk that holds both spans >= 65535 positions, so the
+    allele pass cannot use 2-byte position deltas and must stream the 4-byte positions; results unchanged"""
+    from instrain_amd import engine
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    seq1, p1, b1, m1, r1 = _random_split(301, 700, 40, mml, 40)
+    seq2, p2, b2, m2, r2 = _random_split(302, 900, 40, mml, 50)
+    n1 = len(p1) - (len(p1) % 1024) - 200                     # the boundary falls inside a chunk
+    p1, b1, m1, r1 = p1[:n1], b1[:n1], m1[:n1], r1[:n1]
+    gap = 250_000
+    seq = seq1 + "A" * (gap - len(seq1)) + seq2
+    pos = np.concatenate([p1, p2 + gap]); base = np.concatenate([b1, b2]); mm = np.concatenate([m1, m2])
+    pair = np.concatenate([r1, r2 + int(r1.max()) + 1])
+    bounds = np.array([0, len(seq1), gap, len(seq)])
+    b = engine.Batch(ctx, engine.encode_seq(seq), bounds, engine.pack_obs(pos.astype(np.uint32), base, mm),
+                     pair.astype(np.uint32), n_mm_bins=mml)
+    b.run()
+    got = prod.to_oracle_layout(b.fetch(), lambda g: g.astype(np.int64))
+    b.close()
+    exp = {"entries": [], "snv": [], "ld": []}
+    for s, e in zip(bounds[:-1], bounds[1:]):
+        r = oracle.profile_split(pos, base, mm, pair, seq[s:e], int(s), lut, fb)
+        for k in exp:
+            exp[k].append(r[k])
+    exp = {k: np.concatenate(v) for k, v in exp.items()}
+    assert len(exp["ld"]) > 50
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="wide chunk")
+
+
 def test_empty_and_ragged(ctx):
     from instrain_amd import engine
     from tests import prod
