@@ -7,7 +7,7 @@ struct SummaryBuffers {
     float *cv = nullptr, *cr = nullptr;     // clonality / rarefied clonality of the highest level <= mm
     uint32_t *k_u32 = nullptr;
     float *k_f32 = nullptr;
-    uint32_t *seg_off = nullptr;
+    uint32_t *seg_off = nullptr, *seg_be = nullptr;
     int64_t *bounds = nullptr;
     void *acc = nullptr;
     double *med = nullptr;

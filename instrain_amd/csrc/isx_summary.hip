@@ -333,7 +333,7 @@ int dev_alloc(T **p, size_t n)
 
 void SummaryBuffers::release()
 {
-    void *ps[] = {cov, cv, cr, k_u32, k_f32, seg_off, bounds, acc, med, rows, temp};
+    void *ps[] = {cov, cv, cr, k_u32, k_f32, seg_off, seg_be, bounds, acc, med, rows, temp};
     for (void *p : ps) if (p) (void)hipFree(p);
     *this = SummaryBuffers();
 }
@@ -347,9 +347,9 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
     if ((rc = dev_alloc(&B.cov, n_pos)) || (rc = dev_alloc(&B.cv, n_pos)) || (rc = dev_alloc(&B.cr, n_pos)) ||
         (rc = dev_alloc(&B.k_u32, n_pos)) || (rc = dev_alloc(&B.k_f32, n_pos))) return rc;
     if (B.n_seg != n_seg) {
-        void *ps[] = {B.seg_off, B.bounds, B.acc, B.med, B.rows};
+        void *ps[] = {B.seg_off, B.seg_be, B.bounds, B.acc, B.med, B.rows};
         for (void *p : ps) if (p) (void)hipFree(p);
-        B.seg_off = nullptr; B.bounds = nullptr; B.acc = nullptr; B.med = nullptr; B.rows = nullptr;
+        B.seg_off = nullptr; B.seg_be = nullptr; B.bounds = nullptr; B.acc = nullptr; B.med = nullptr; B.rows = nullptr;
         B.n_seg = n_seg;
     }
     if ((rc = dev_alloc(&B.seg_off, (size_t)n_seg + 1)) || (rc = dev_alloc(&B.bounds, (size_t)n_seg + 1)) ||
@@ -358,6 +358,26 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
     std::vector<uint32_t> off((size_t)n_seg + 1);
     for (int i = 0; i <= n_seg; i++) off[(size_t)i] = (uint32_t)in.scaffold_bounds[i];
     HIP_TRY(hipMemcpyAsync(B.seg_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
+    // Medians come from sorted copies.  rocPRIM's segmented sort gives one workgroup to a segment, which
+    // is right for thousands of contigs and hopeless for a 5 Mbp genome, so segments above BIG_SEG are
+    // sorted one by one with the device-wide radix sort (into the same output array) and handed to the
+    // segmented sort as empty ranges.
+    constexpr uint32_t BIG_SEG = 1u << 17;
+    std::vector<uint32_t> seg_b((size_t)n_seg), seg_e((size_t)n_seg);
+    std::vector<int> big;
+    uint32_t longest = 1;
+    for (int i = 0; i < n_seg; i++) {
+        seg_b[(size_t)i] = off[(size_t)i]; seg_e[(size_t)i] = off[(size_t)i + 1];
+        if (seg_e[(size_t)i] - seg_b[(size_t)i] > BIG_SEG) {
+            big.push_back(i);
+            longest = std::max(longest, seg_e[(size_t)i] - seg_b[(size_t)i]);
+            seg_e[(size_t)i] = seg_b[(size_t)i];
+        }
+    }
+    if ((rc = dev_alloc(&B.seg_be, (size_t)n_seg * 2))) return rc;
+    HIP_TRY(hipMemcpyAsync(B.seg_be, seg_b.data(), (size_t)n_seg * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(B.seg_be + n_seg, seg_e.data(), (size_t)n_seg * 4, hipMemcpyHostToDevice, s));
+    const bool any_small = (int)big.size() < n_seg;
     HIP_TRY(hipMemcpyAsync(B.bounds, in.scaffold_bounds, ((size_t)n_seg + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(in.ev[0], s));
     Acc *acc = reinterpret_cast<Acc *>(B.acc);
@@ -367,17 +387,40 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(B.cv), 0x7FC00000, n_pos, s));
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(B.cr), 0x7FC00000, n_pos, s));
     }
-    size_t tb = 0;
-    HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb, B.cov, B.k_u32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
-    size_t tb2 = 0;
-    HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb2, B.cv, B.k_f32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
+    size_t tb = 0, tb2 = 0;
+    HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb, B.cov, B.k_u32, n_pos, (unsigned)n_seg, B.seg_be, B.seg_be + n_seg, 0, 32, s));
+    HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb2, B.cv, B.k_f32, n_pos, (unsigned)n_seg, B.seg_be, B.seg_be + n_seg, 0, 32, s));
     tb = std::max(tb, tb2);
+    if (!big.empty()) {
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tb2, B.cov, B.k_u32, (size_t)longest, 0, 32, s));
+        tb = std::max(tb, tb2);
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tb2, B.cv, B.k_f32, (size_t)longest, 0, 32, s));
+        tb = std::max(tb, tb2);
+    }
     if (B.temp_bytes < tb) {
         if (B.temp) (void)hipFree(B.temp);
         B.temp = nullptr;
         HIP_TRY(hipMalloc(&B.temp, tb + 256));
         B.temp_bytes = tb + 256;
     }
+    auto sort_u32 = [&](const uint32_t *src, uint32_t *dst) -> int {
+        size_t t = B.temp_bytes;
+        if (any_small) HIP_TRY(rocprim::segmented_radix_sort_keys(B.temp, t, src, dst, n_pos, (unsigned)n_seg, B.seg_be, B.seg_be + n_seg, 0, 32, s));
+        for (int i : big) {
+            t = B.temp_bytes;
+            HIP_TRY(rocprim::radix_sort_keys(B.temp, t, src + off[(size_t)i], dst + off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i]), 0, 32, s));
+        }
+        return ISX_OK;
+    };
+    auto sort_f32 = [&](const float *src, float *dst) -> int {
+        size_t t = B.temp_bytes;
+        if (any_small) HIP_TRY(rocprim::segmented_radix_sort_keys(B.temp, t, src, dst, n_pos, (unsigned)n_seg, B.seg_be, B.seg_be + n_seg, 0, 32, s));
+        for (int i : big) {
+            t = B.temp_bytes;
+            HIP_TRY(rocprim::radix_sort_keys(B.temp, t, src + off[(size_t)i], dst + off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i]), 0, 32, s));
+        }
+        return ISX_OK;
+    };
     for (int mm = 0; mm < M; mm++) {
         hipLaunchKernelGGL(k_reset_acc, gseg, blk, 0, s, acc, n_seg);
         if (M == 1) {
@@ -389,14 +432,11 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
         const uint32_t tiles = (n_pos + 63) / 64;
         hipLaunchKernelGGL(k_seg_reduce, dim3((tiles + 255) / 256), blk, 0, s, B.cov, B.cv, B.cr, n_pos, B.bounds, n_seg, acc,
                            M == 1 ? 1 : 0);
-        size_t t = B.temp_bytes;
-        HIP_TRY(rocprim::segmented_radix_sort_keys(B.temp, t, B.cov, B.k_u32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
+        if ((rc = sort_u32(B.cov, B.k_u32))) return rc;
         hipLaunchKernelGGL(k_pick_median<uint32_t>, gseg, blk, 0, s, B.k_u32, B.seg_off, n_seg, acc, 0, B.med);
-        t = B.temp_bytes;
-        HIP_TRY(rocprim::segmented_radix_sort_keys(B.temp, t, B.cv, B.k_f32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
+        if ((rc = sort_f32(B.cv, B.k_f32))) return rc;
         hipLaunchKernelGGL(k_pick_median<float>, gseg, blk, 0, s, B.k_f32, B.seg_off, n_seg, acc, 1, B.med + n_seg);
-        t = B.temp_bytes;
-        HIP_TRY(rocprim::segmented_radix_sort_keys(B.temp, t, B.cr, B.k_f32, n_pos, (unsigned)n_seg, B.seg_off, B.seg_off + 1, 0, 32, s));
+        if ((rc = sort_f32(B.cr, B.k_f32))) return rc;
         hipLaunchKernelGGL(k_pick_median<float>, gseg, blk, 0, s, B.k_f32, B.seg_off, n_seg, acc, 2, B.med + 2 * n_seg);
         hipLaunchKernelGGL(k_pack_rows, gseg, blk, 0, s, acc, B.med, B.med + n_seg, B.med + 2 * n_seg, n_seg, mm, M, B.rows);
     }

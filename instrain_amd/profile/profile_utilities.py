@@ -189,8 +189,10 @@ def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, 
     try:
         b.run()
         res = b.fetch()
-        scaff_bounds = np.r_[0, np.cumsum([len(q) for q in sequences])]
-        levels, _ = b.summarize(scaff_bounds)
+        levels = None
+        if kwargs.get('scaffold_tables') is not None:   # only the merge step's cumulative tables need the device summaries
+            scaff_bounds = np.r_[0, np.cumsum([len(q) for q in sequences])]
+            levels, _ = b.summarize(scaff_bounds)
     finally:
         b.close()
     splits = tables_to_splits(res, np.asarray(bounds), s_scaff, s_num, s_off, s_len, min_freq, bam_name)

@@ -107,6 +107,51 @@ def test_device_coverage_table_equals_stored_golden():
     check_coverage_table_vs_sars_golden(t.to_dict("records"), float_tol=1e-9)
 
 
+@pytest.mark.parametrize("skip_mm", [True, False])
+def test_device_summary_big_and_small_scaffolds(skip_mm):
+    """a 200 kbp scaffold (sorted by the device-wide radix sort) next to small ones (segmented sort):
+    medians / sums per (scaffold, mm) vs plain numpy on the fetched tables"""
+    from instrain_amd import engine, synth
+    lut, fb = util.load_lut()
+    ctx = engine.Context(0)
+    ctx.set_null_model(lut, fb)
+    w = synth.make_workload(genome_len=300_000, coverage=14, n_sites=600, seed=21, skip_mm=skip_mm, err=0.004)
+    M = w["n_mm_bins"]
+    sb = np.array([0, 200_000, 200_500, 300_000])
+    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=M, rarefied_coverage=12, seed=4)
+    b.run()
+    res = b.fetch()
+    lv, _ = b.summarize(sb)
+    b.close()
+    ctx.close()
+    n_pos = 300_000
+    if M == 1:
+        ent = engine.dense_to_entries(res["counts"], res["clon"])
+        ent["clon_rarefied"] = res["clon_r"][ent["gpos"]]
+    else:
+        ent = res["entries"]
+    cov = np.zeros(n_pos, dtype=np.int64)
+    cv = np.full(n_pos, np.nan); cr = np.full(n_pos, np.nan)
+    assert M >= (1 if skip_mm else 3)
+    for m in range(M):
+        e = ent[ent["mm"] == m]
+        cov[e["gpos"]] += e["cnt"].sum(axis=1).astype(np.int64)
+        k = ~np.isnan(e["clon"]); cv[e["gpos"][k]] = e["clon"][k].astype(np.float64)
+        k = ~np.isnan(e["clon_rarefied"]); cr[e["gpos"][k]] = e["clon_rarefied"][k].astype(np.float64)
+        for i, (s0, s1) in enumerate(zip(sb[:-1], sb[1:])):
+            d = lv[i, m]
+            c = cov[s0:s1]
+            assert d["nonzero"] == np.count_nonzero(c) and d["sum_cov"] == c.sum() and d["sumsq_cov"] == (c * c).sum()
+            assert d["median_cov"] == np.median(c), (i, m)
+            for vals, cnt, med, sm in ((cv[s0:s1], "counted", "median_clon", "sum_clon"),
+                                       (cr[s0:s1], "counted_rarefied", "median_clon_rarefied", "sum_clon_rarefied")):
+                v = vals[~np.isnan(vals)]
+                assert d[cnt] == len(v), (i, m, cnt)
+                if len(v):
+                    assert d[med] == np.median(v.astype(np.float32)).astype(np.float64) or abs(d[med] - np.median(v)) < 1e-7, (i, m, med)
+                    assert abs(d[sm] - v.sum()) < 1e-6 * max(1.0, len(v))
+
+
 @pytest.mark.parametrize("mm_levels", [1, 5])
 def test_device_summary_vs_oracle_multi_scaffold(mm_levels):
     """three scaffolds of unequal length in one batch: every aggregate vs oracle/summary.py"""
