@@ -639,23 +639,7 @@ int isx_batch_fetch_entries(isx_batch *b, isx_entry *out)
     const size_t n = (size_t)b->sizes.n_entries;
     if (!n) return ISX_OK;
     // the device table is one slab per window (used prefix = win_nent[w]) + the overflow region
-    std::vector<uint32_t> nent((size_t)b->n_win);
-    HIP_TRY(hipMemcpy(nent.data(), b->d_win_nent, nent.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    const size_t total = (size_t)b->n_win * b->slab + b->n_ovf;
-    std::vector<isx_entry> raw(total);
-    HIP_TRY(hipMemcpy(raw.data(), b->d_entries, total * sizeof(isx_entry), hipMemcpyDeviceToHost));
-    size_t k = 0;
-    for (int w = 0; w < b->n_win; w++) {
-        const isx_entry *src = raw.data() + (size_t)w * b->slab;
-        for (uint32_t i = 0; i < nent[(size_t)w]; i++) { if (k < n) out[k] = src[i]; k++; }
-    }
-    const isx_entry *ov = raw.data() + (size_t)b->n_win * b->slab;
-    for (uint32_t i = 0; i < b->n_ovf; i++) { if (k < n) out[k] = ov[i]; k++; }
-    if (k != n) { isx_set_error("entry table inconsistent: " + std::to_string(k) + " gathered vs " + std::to_string(n)); return ISX_ERR_STATE; }
-    std::sort(out, out + n, [](const isx_entry &x, const isx_entry &y) {
-        return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm;
-    });
-    return ISX_OK;
+    return fetch_entries_sorted(b->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, (uint32_t)b->n_win, b->n_ovf, n, out);
 }
 
 int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts, float *clon, float *clon_rarefied)

@@ -66,3 +66,7 @@ struct CompareSnpIn {                       // nullptr lut = coverage half only
 
 int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, const CompareSnpIn &snp, CompareBuffers &B,
                 isx_compare_level *host_out, float *ms);
+
+// the mm path's entry table (window slabs + overflow) compacted and ordered by (gpos, mm) on the device
+int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t *win_nent, uint32_t slab, uint32_t n_win,
+                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out);

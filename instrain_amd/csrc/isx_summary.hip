@@ -331,6 +331,84 @@ int dev_alloc(T **p, size_t n)
 
 }  // namespace
 
+// ---- isx_batch_fetch_entries: the used prefixes of the window slabs + the overflow region, in
+// (gpos, mm) order, gathered on the device so that only the entries themselves cross PCIe ----
+namespace {
+__global__ void __launch_bounds__(256) k_entry_keys(const isx_entry *entries, const uint32_t *win_nent, uint32_t slab, uint64_t ovf0,
+                                                    uint32_t n_ovf, uint64_t *keys, uint32_t *idx, uint32_t *cursor, uint32_t cap)
+{
+    const uint64_t total = ovf0 + n_ovf;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const uint64_t rounds = (total + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; r++) {                         // whole waves stay in the loop (ballot below)
+        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        bool ok = i < total;
+        if (ok && i < ovf0) {
+            const uint32_t w = (uint32_t)(i / slab);
+            ok = (uint32_t)(i - (uint64_t)w * slab) < win_nent[w];
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (!bal) continue;
+        uint32_t base = 0;
+        const int first = __ffsll((long long)bal) - 1;
+        if (lane == first) base = atomicAdd(cursor, (uint32_t)__popcll(bal));   // one atomic per wave
+        base = __shfl(base, first);
+        if (!ok) continue;
+        const uint32_t k = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (k >= cap) continue;
+        keys[k] = ((uint64_t)entries[i].gpos << 16) | entries[i].mm;
+        idx[k] = (uint32_t)i;
+    }
+}
+
+__global__ void k_gather_entries(const isx_entry *entries, const uint32_t *idx, uint32_t n, isx_entry *out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(&entries[idx[k]]);
+    uint4 *dst = reinterpret_cast<uint4 *>(&out[k]);
+    dst[0] = src[0]; dst[1] = src[1];
+}
+}  // namespace
+
+int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t *win_nent, uint32_t slab, uint32_t n_win,
+                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out)
+{
+    const uint64_t ovf0 = (uint64_t)n_win * slab;
+    if (ovf0 + n_ovf >= 0xFFFFFFFFull || n_entries >= 0xFFFFFFFFull) { isx_set_error("entry table too large to fetch in one piece"); return ISX_ERR_CAPACITY; }
+    const uint32_t n = (uint32_t)n_entries;
+    uint64_t *keys = nullptr;
+    uint32_t *idx = nullptr, *cursor = nullptr;
+    isx_entry *out = nullptr;
+    void *temp = nullptr;
+    int rc = ISX_OK;
+    auto done = [&](int code) {
+        void *ps[] = {keys, idx, cursor, out, temp};
+        for (void *p : ps) if (p) (void)hipFree(p);
+        return code;
+    };
+#define FE_TRY(expr) do { if ((expr) != hipSuccess) { isx_set_error(std::string("HIP error in fetch_entries: ") + #expr); return done(ISX_ERR_HIP); } } while (0)
+    FE_TRY(hipMalloc(&keys, (size_t)n * 2 * sizeof(uint64_t)));
+    FE_TRY(hipMalloc(&idx, (size_t)n * 2 * sizeof(uint32_t)));
+    FE_TRY(hipMalloc(&cursor, 4));
+    FE_TRY(hipMalloc(&out, (size_t)n * sizeof(isx_entry)));
+    FE_TRY(hipMemsetAsync(cursor, 0, 4, s));
+    hipLaunchKernelGGL(k_entry_keys, dim3(2048), dim3(256), 0, s, entries, win_nent, slab, ovf0, n_ovf, keys, idx, cursor, n);
+    size_t tb = 0;
+    FE_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys, keys + n, idx, idx + n, (size_t)n, 0, 48, s));
+    FE_TRY(hipMalloc(&temp, tb + 256));
+    FE_TRY(rocprim::radix_sort_pairs(temp, tb, keys, keys + n, idx, idx + n, (size_t)n, 0, 48, s));
+    hipLaunchKernelGGL(k_gather_entries, dim3((n + 255) / 256), dim3(256), 0, s, entries, idx + n, n, out);
+    uint32_t got = 0;
+    FE_TRY(hipMemcpyAsync(&got, cursor, 4, hipMemcpyDeviceToHost, s));
+    FE_TRY(hipMemcpyAsync(host_out, out, (size_t)n * sizeof(isx_entry), hipMemcpyDeviceToHost, s));
+    FE_TRY(hipStreamSynchronize(s));
+#undef FE_TRY
+    if (got != n) { isx_set_error("entry table inconsistent: " + std::to_string(got) + " gathered vs " + std::to_string(n)); rc = ISX_ERR_STATE; }
+    return done(rc);
+}
+
 void SummaryBuffers::release()
 {
     void *ps[] = {cov, cv, cr, k_u32, k_f32, seg_off, seg_be, bounds, acc, med, rows, temp};

@@ -53,6 +53,34 @@ def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_o
     e_cut = np.searchsorted(e["gpos"], split_bounds)
     s_cut = np.searchsorted(snv["gpos"], split_bounds)
     l_cut = np.searchsorted(ld["gpos_a"], split_bounds)
+    # the two row tables are built once for the whole batch (vectorised) and cut per split
+    split_of_snv = np.searchsorted(split_bounds, snv["gpos"], side="right") - 1
+    split_of_ld = np.searchsorted(split_bounds, ld["gpos_a"], side="right") - 1
+    scaff_arr = np.asarray(split_scaffold, dtype=object)
+    off_arr = np.asarray(scaffold_offset, dtype=np.int64)
+    big_snv = pd.DataFrame({
+        'scaffold': scaff_arr[split_of_snv], 'position': snv["gpos"].astype(np.int64) - off_arr[split_of_snv],
+        'ref_base': BASES[snv["ref_base"]],
+        'A': snv["cnt"][:, 0].astype(np.int64), 'C': snv["cnt"][:, 1].astype(np.int64),
+        'T': snv["cnt"][:, 2].astype(np.int64), 'G': snv["cnt"][:, 3].astype(np.int64),
+        'con_base': BASES[snv["con_base"]], 'var_base': BASES[snv["var_base"]], 'mm': snv["mm"].astype(np.int64),
+        'allele_count': snv["allele_count"].astype(np.int64), 'class': np.array(CLASSES)[snv["cls"]],
+        'cryptic': snv["cryptic"].astype(bool), 'position_coverage': snv["cnt"].sum(axis=1).astype(np.int64),
+    }, columns=SNP_COLUMNS) if len(snv) else None
+    if len(ld):
+        pa = ld["gpos_a"].astype(np.int64) - off_arr[split_of_ld]
+        pb = ld["gpos_b"].astype(np.int64) - off_arr[split_of_ld]
+        big_ld = pd.DataFrame({
+            'r2': ld["r2"], 'd_prime': ld["d_prime"], 'r2_normalized': ld["r2_normalized"],
+            'd_prime_normalized': ld["d_prime_normalized"],
+            'total': ld["total"].astype(np.int64), 'countAB': ld["countAB"].astype(np.int64),
+            'countAb': ld["countAb"].astype(np.int64), 'countaB': ld["countaB"].astype(np.int64),
+            'countab': ld["countab"].astype(np.int64), 'allele_A': BASES[ld["allele_A"]],
+            'allele_a': BASES[ld["allele_a"]], 'allele_B': BASES[ld["allele_B"]], 'allele_b': BASES[ld["allele_b"]],
+            'distance': np.abs(pb - pa), 'position_A': pa, 'position_B': pb, 'mm': ld["mm"].astype(np.int64),
+            'scaffold': scaff_arr[split_of_ld]}, columns=LD_COLUMNS)
+    else:
+        big_ld = None
     out = []
     for i in range(n):
         scaff = split_scaffold[i]
@@ -73,28 +101,12 @@ def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_o
         rr = clon_r[e_cut[i]:e_cut[i + 1]]      # rarefied clonality: random in the reference, Philox-seeded here
         k = ~np.isnan(rr)
         S.clonTR = _series_by_mm(pos[k], ee["mm"][k], rr[k], "float32")
-        ss = snv[s_cut[i]:s_cut[i + 1]]
-        S.raw_snp_table = pd.DataFrame({
-            'scaffold': scaff, 'position': ss["gpos"].astype(np.int64) - off, 'ref_base': BASES[ss["ref_base"]],
-            'A': ss["cnt"][:, 0].astype(np.int64), 'C': ss["cnt"][:, 1].astype(np.int64),
-            'T': ss["cnt"][:, 2].astype(np.int64), 'G': ss["cnt"][:, 3].astype(np.int64),
-            'con_base': BASES[ss["con_base"]], 'var_base': BASES[ss["var_base"]], 'mm': ss["mm"].astype(np.int64),
-            'allele_count': ss["allele_count"].astype(np.int64), 'class': np.array(CLASSES)[ss["cls"]],
-            'cryptic': ss["cryptic"].astype(bool), 'position_coverage': ss["cnt"].sum(axis=1).astype(np.int64),
-        }, columns=SNP_COLUMNS) if len(ss) else pd.DataFrame()
-        ll = ld[l_cut[i]:l_cut[i + 1]]
-        if len(ll):
-            pa = ll["gpos_a"].astype(np.int64) - off
-            pb = ll["gpos_b"].astype(np.int64) - off
-            S.raw_linkage_table = pd.DataFrame({
-                'r2': ll["r2"], 'd_prime': ll["d_prime"], 'r2_normalized': ll["r2_normalized"],
-                'd_prime_normalized': ll["d_prime_normalized"],
-                'total': ll["total"].astype(np.int64), 'countAB': ll["countAB"].astype(np.int64),
-                'countAb': ll["countAb"].astype(np.int64), 'countaB': ll["countaB"].astype(np.int64),
-                'countab': ll["countab"].astype(np.int64), 'allele_A': BASES[ll["allele_A"]],
-                'allele_a': BASES[ll["allele_a"]], 'allele_B': BASES[ll["allele_B"]], 'allele_b': BASES[ll["allele_b"]],
-                'distance': np.abs(pb - pa), 'position_A': pa, 'position_B': pb, 'mm': ll["mm"].astype(np.int64),
-                'scaffold': scaff}, columns=LD_COLUMNS)
+        if s_cut[i + 1] > s_cut[i]:
+            S.raw_snp_table = big_snv.iloc[s_cut[i]:s_cut[i + 1]].reset_index(drop=True)
+        else:
+            S.raw_snp_table = pd.DataFrame()
+        if l_cut[i + 1] > l_cut[i]:
+            S.raw_linkage_table = big_ld.iloc[l_cut[i]:l_cut[i + 1]].reset_index(drop=True)
         else:
             S.raw_linkage_table = pd.DataFrame()
         S.log = ""
