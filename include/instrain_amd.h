@@ -131,9 +131,9 @@ typedef struct {
 
 /* per-kernel device time of the last isx_batch_run, milliseconds (HIP events on the ctx stream) */
 typedef struct {
-    float pileup_ms;        /* k_pileup_call: window histogram + SNV call epilogue */
+    float pileup_ms;        /* k_pileup_dense / k_pileup_mm: window histogram + SNV call epilogue (+ allele pass with linkage) */
     float sites_ms;         /* site table sort / rank */
-    float allele_ms;        /* k_allele_obs: second pass over the observations */
+    float allele_ms;        /* k_ao_rank: allele observations -> site ranks */
     float group_ms;         /* group allele observations by pair */
     float incr_ms;          /* pair increments -> keys, sort, run-length */
     float ld_ms;            /* LD rows */
@@ -141,8 +141,8 @@ typedef struct {
     int32_t pileup_blocks, pileup_threads, pileup_lds_bytes, pileup_window;
     /* dense int8-MFMA linkage path (linkage_mode 2) */
     float mfma_ms;          /* one k_dense_gemm pass over all tiles (the path runs it twice: count, emit) */
-    int32_t dense_tiles;    /* 32x32 tiles of the upper triangles */
-    int64_t dense_macs;     /* int8 multiply-accumulates of one pass */
+    int32_t dense_tiles;    /* useful 32x32 tiles of the upper triangles */
+    int64_t dense_macs;     /* int8 multiply-accumulates of those tiles in one pass */
     int64_t dense_bytes;    /* bytes of the X^T blocks */
 } isx_timings;
 

@@ -7,7 +7,7 @@
 #include "../../include/instrain_amd.h"
 
 #define ISX_CHUNK 1024              // observation directory granule (records)
-#define ISX_PAD 2048                // the record stream is padded to a multiple of this (k_allele_obs tile)
+#define ISX_PAD 2048                // the record stream is padded to a multiple of this (whole directory chunks, 16-byte loads)
 #define ISX_SENTINEL 0xFFFFFFFFu    // gpos of padding records (never inside a window)
 
 void isx_set_error(const std::string &msg);
