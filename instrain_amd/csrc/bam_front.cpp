@@ -110,14 +110,25 @@ struct PairInfo {       // filter_reads.py i2o order
 
 }  // namespace
 
+template <class T>
+struct RawBuf {                 // sized once, written once: no value initialisation (vector::resize would memset)
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void resize(size_t m) { p.reset(new T[std::max<size_t>(m, 1)]); n = m; }
+    T *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+    const T &operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+};
+
 struct isx_bam {
     std::vector<std::string> ref_name;
     std::vector<int64_t> ref_len, ref_off;
     std::vector<Read> reads;
-    std::vector<char> names;
-    std::vector<uint32_t> cigars;
-    std::vector<uint8_t> seqs;      // one code per base (unpacked)
-    std::vector<uint8_t> quals;     // mutated by overlap resolution
+    RawBuf<char> names;
+    RawBuf<uint32_t> cigars;
+    RawBuf<uint8_t> seqs;           // one code per base (unpacked)
+    RawBuf<uint8_t> quals;          // mutated by overlap resolution
     // results of expand (plain arrays: no zero fill of what is written once)
     std::unique_ptr<isx_obs[]> obs;
     std::unique_ptr<uint32_t[]> pair;
@@ -174,7 +185,7 @@ int load_file(const char *path, std::vector<uint8_t> &out)
         off += bsize;
     }
     out.resize(total);
-    const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     std::vector<std::thread> th;
     std::vector<int> ok(nt, 1);
     for (unsigned t = 0; t < nt; t++)
@@ -266,7 +277,7 @@ int parse_bam(const std::vector<uint8_t> &buf, isx_bam &B)
     name_at[n] = n_names; cig_at[n] = n_cig; seq_at[n] = n_seq;
     B.names.resize(n_names); B.cigars.resize(n_cig); B.seqs.resize(n_seq); B.quals.resize(n_seq);
     // pass 2 (threads over record ranges): field extraction, nibble unpack, aux walk for NM
-    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n / 4096 + 1));
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(64u, std::max(1u, std::thread::hardware_concurrency())), n / 4096 + 1));
     std::vector<int> bad(nt, 0);
     auto work = [&](unsigned t) {
         const size_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
@@ -382,10 +393,16 @@ int isx_bam_open(const char *path, isx_bam **out)
     if (!path || !out) { isx_set_error("isx_bam_open: bad argument"); return ISX_ERR_ARG; }
     *out = nullptr;
     std::vector<uint8_t> buf;
+    const bool timing = getenv("ISX_BAM_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = load_file(path, buf);
     if (rc != ISX_OK) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     isx_bam *B = new isx_bam();
     rc = parse_bam(buf, *B);
+    if (timing) fprintf(stderr, "[isx_bam_open] read + inflate %.1f ms, record extraction %.1f ms\n",
+                        std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     if (rc != ISX_OK) { delete B; return rc; }
     *out = B;
     return ISX_OK;
@@ -424,7 +441,12 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
     std::vector<PairInfo> pinfo;
     std::vector<int32_t> read_pi(B.reads.size(), -1);      // read -> index of its (scaffold, name) entry
     std::vector<RefSpan> spans(B.reads.size());
-    for (size_t t = 0; t < n_ref; t++) idx[t].reserve(1024);
+    {   // size the per-scaffold name tables up front (no rehash while they fill)
+        std::vector<size_t> per_ref(n_ref, 0);
+        for (const Read &r : B.reads) if (r.tid >= 0 && (size_t)r.tid < n_ref) per_ref[(size_t)r.tid]++;
+        for (size_t t = 0; t < n_ref; t++) idx[t].reserve(per_ref[t] / 2 + 16);
+        pinfo.reserve(B.reads.size() / 2 + 16);
+    }
     for (size_t ri = 0; ri < B.reads.size(); ri++) {
         const Read &r = B.reads[ri];
         if (r.tid < 0 || (size_t)r.tid >= n_ref) continue;
@@ -567,7 +589,7 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
         }
         return n_out;
     };
-    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_reads / 4096 + 1));
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(64u, std::max(1u, std::thread::hardware_concurrency())), n_reads / 4096 + 1));
     auto run_threads = [&](auto &&fn) {
         std::vector<std::thread> th;
         for (unsigned t = 1; t < nt; t++) th.emplace_back(fn, t);
