@@ -144,6 +144,8 @@ typedef struct {
     int32_t dense_tiles;    /* useful 32x32 tiles of the upper triangles */
     int64_t dense_macs;     /* int8 multiply-accumulates of those tiles in one pass */
     int64_t dense_bytes;    /* bytes of the X^T blocks */
+    int32_t record_bytes;   /* resident observation stream: 4 (compact records) or 8 (isx_obs as is) bytes per record */
+    int32_t pad;
 } isx_timings;
 
 const char *isx_last_error(void);

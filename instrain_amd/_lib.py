@@ -41,7 +41,8 @@ class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("pileup_ms", "sites_ms", "allele_ms", "group_ms", "incr_ms", "ld_ms",
                                          "total_ms")] + \
                [(n, C.c_int32) for n in ("pileup_blocks", "pileup_threads", "pileup_lds_bytes", "pileup_window")] + \
-               [("mfma_ms", C.c_float), ("dense_tiles", C.c_int32), ("dense_macs", C.c_int64), ("dense_bytes", C.c_int64)]
+               [("mfma_ms", C.c_float), ("dense_tiles", C.c_int32), ("dense_macs", C.c_int64), ("dense_bytes", C.c_int64),
+                ("record_bytes", C.c_int32), ("pad", C.c_int32)]
 
 
 class BamParams(C.Structure):

@@ -1,6 +1,7 @@
 // isx_api.hip -- C ABI of libinstrain_amd.so: context, resident batches, run, fetch.
 // (see include/instrain_amd.h for what each entry point replaces in the reference)
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstdlib>
@@ -37,7 +38,8 @@ struct isx_batch {
     int W = 0, logW = 0, M = 1, n_win = 0, block = 1024, grid = 0, packed = 0;
     size_t lds = 0;
     // device
-    uint2 *d_rec = nullptr;
+    uint2 *d_rec = nullptr;             // wide stream (8-byte isx_obs) -- or:
+    uint32_t *d_rec32 = nullptr, *d_gbase = nullptr;    // compact stream (4-byte records + one position base per 256)
     uint32_t *d_pair = nullptr, *d_gpos = nullptr, *d_cbase = nullptr;
     uint16_t *d_gpos16 = nullptr;
     uint8_t *d_ref = nullptr;
@@ -195,7 +197,7 @@ void isx_batch_destroy(isx_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_rec, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
+    void *ps[] = {b->d_rec, b->d_rec32, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
@@ -269,7 +271,6 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
 #define BH(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { isx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); isx_batch_destroy(b); return ISX_ERR_HIP; } } while (0)
     for (auto &e : b->ev) BH(hipEventCreate(&e));
     for (auto &e : b->ev_sum) BH(hipEventCreate(&e));
-    BH(hipMalloc(&b->d_rec, b->n_rec * sizeof(uint2)));
     BH(hipMalloc(&b->d_ref, (size_t)n_pos));
     BH(hipMalloc(&b->d_bounds, (size_t)(n_splits + 1) * sizeof(int64_t)));
     BH(hipMalloc(&b->d_cursors, (CUR_N + 4) * sizeof(uint32_t)));
@@ -306,36 +307,90 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     std::vector<uint32_t> cmin(n_chunks, 0xFFFFFFFFu), cmax(n_chunks, 0u);
     std::vector<uint8_t> cany(n_chunks, 0);
     bool bad_pos = false;
-    // isx_obs already has the device record layout (gpos | mm, base << 16, flags << 24): plain copy into
-    // the pinned buffer, then one vectorisable sweep per ISX_CHUNK-record chunk for the min/max directory
+    // Compact stream (the normal case): 4 bytes per record -- a 16-bit delta to the lowest position of the
+    // record's group of 256, the mm level in 8 bits, the base code -- encoded by a few host threads while
+    // they fill the pinned buffer (half the PCIe and half the HBM bytes of the 8-byte isx_obs).  It needs
+    // every group to span < 65535 positions and mm < 256; the first record that does not fit makes the
+    // upload start over with the wide stream (isx_obs as is).
     static_assert(sizeof(isx_obs) == sizeof(uint2), "isx_obs must be the 8-byte device record");
-    BT(staged_upload(c, b->d_rec, b->n_rec, [&](uint2 *dst, uint64_t first, uint64_t cnt) {
+    const uint64_t n_groups = b->n_rec / ISX_GROUP;
+    std::vector<uint32_t> gbase(n_groups, 0u);
+    std::atomic<int> too_wide{getenv("ISX_WIDE_RECORDS") ? 1 : 0};      // env: force the wide stream (tests / A-B)
+    auto fill_threads = [&](uint64_t cnt, auto &&work) {
         // a few host threads fill the pinned buffer (a single core copies at ~10 GB/s, PCIe Gen5 takes 63)
         const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, cnt / (64 * ISX_CHUNK)));
         const uint64_t per_t = ((cnt + nt - 1) / nt + ISX_CHUNK - 1) / ISX_CHUNK * ISX_CHUNK;
         std::vector<std::thread> th;
         std::vector<int> bad(nt, 0);
-        auto work = [&](unsigned t) {
+        auto run = [&](unsigned t) {
             const uint64_t a0 = std::min<uint64_t>(cnt, (uint64_t)t * per_t), a1 = std::min<uint64_t>(cnt, a0 + per_t);
-            for (uint64_t i0 = a0; i0 < a1; i0 += ISX_CHUNK) {              // `first` and a0 are multiples of ISX_CHUNK
-                const uint64_t i1 = std::min<uint64_t>(a1, i0 + ISX_CHUNK);
-                const uint64_t g0 = first + i0;
-                const uint64_t n_real = g0 < (uint64_t)n_obs ? std::min<uint64_t>(i1 - i0, (uint64_t)n_obs - g0) : 0;
-                if (n_real) memcpy(dst + i0, obs + g0, n_real * sizeof(uint2));
-                for (uint64_t i = i0 + n_real; i < i1; i++) dst[i] = make_uint2(ISX_SENTINEL, 0);
-                if (!n_real) continue;
-                uint32_t lo = 0xFFFFFFFFu, hi = 0;
-                for (uint64_t i = i0; i < i0 + n_real; i++) { const uint32_t g = dst[i].x; lo = g < lo ? g : lo; hi = g > hi ? g : hi; }
-                const uint64_t ch = g0 / ISX_CHUNK;
-                cmin[ch] = lo; cmax[ch] = hi; cany[ch] = 1;
-                if ((int64_t)hi >= n_pos) bad[t] = 1;
-            }
+            work(a0, a1, bad[t]);
         };
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
-        work(0);
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(run, t);
+        run(0);
         for (auto &x : th) x.join();
         for (int v : bad) if (v) bad_pos = true;
-    }));
+    };
+    if (!too_wide.load()) {
+        BH(hipMalloc(&b->d_rec32, b->n_rec * sizeof(uint32_t)));
+        BT(staged_upload(c, b->d_rec32, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
+            if (too_wide.load()) return;
+            fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
+                for (uint64_t i0 = a0; i0 < a1; i0 += ISX_GROUP) {          // `first`, a0, a1 are multiples of ISX_CHUNK
+                    const uint64_t g0 = first + i0;
+                    const uint64_t n_real = g0 < (uint64_t)n_obs ? std::min<uint64_t>(ISX_GROUP, (uint64_t)n_obs - g0) : 0;
+                    const isx_obs *src = obs + g0;
+                    uint32_t lo = 0xFFFFFFFFu, hi = 0, mmax = 0;
+                    for (uint64_t i = 0; i < n_real; i++) {
+                        const uint32_t g = src[i].gpos;
+                        lo = g < lo ? g : lo; hi = g > hi ? g : hi; mmax = src[i].mm > mmax ? src[i].mm : mmax;
+                    }
+                    if (n_real) {
+                        if (hi - lo >= 65535u || mmax >= 256u) { too_wide.store(1); return; }
+                        if ((int64_t)hi >= n_pos) bad = 1;
+                        const uint64_t ch = g0 / ISX_CHUNK;     // the 4 groups of a chunk belong to one thread
+                        cmin[ch] = std::min(cmin[ch], lo); cmax[ch] = std::max(cmax[ch], hi); cany[ch] = 1;
+                        gbase[g0 / ISX_GROUP] = lo;
+                    }
+                    for (uint64_t i = 0; i < n_real; i++)
+                        dst[i0 + i] = (src[i].gpos - lo) | ((uint32_t)src[i].mm << 16) | ((uint32_t)(src[i].base > 4 ? 4 : src[i].base) << 24);
+                    for (uint64_t i = n_real; i < ISX_GROUP; i++) dst[i0 + i] = ISX_PAD32;
+                }
+            });
+        }));
+        if (too_wide.load()) {
+            BH(hipStreamSynchronize(c->stream));
+            (void)hipFree(b->d_rec32);
+            b->d_rec32 = nullptr;
+            std::fill(cmin.begin(), cmin.end(), 0xFFFFFFFFu); std::fill(cmax.begin(), cmax.end(), 0u); std::fill(cany.begin(), cany.end(), 0);
+            bad_pos = false;
+        } else {
+            BH(hipMalloc(&b->d_gbase, std::max<uint64_t>(n_groups, 1) * sizeof(uint32_t)));
+            BH(hipMemcpy(b->d_gbase, gbase.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    }
+    if (!b->d_rec32) {
+        // wide stream: isx_obs already has the device record layout (gpos | mm, base << 16, flags << 24): plain
+        // copy into the pinned buffer, then one vectorisable sweep per chunk for the min/max directory
+        BH(hipMalloc(&b->d_rec, b->n_rec * sizeof(uint2)));
+        BT(staged_upload(c, b->d_rec, b->n_rec, [&](uint2 *dst, uint64_t first, uint64_t cnt) {
+            fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
+                for (uint64_t i0 = a0; i0 < a1; i0 += ISX_CHUNK) {
+                    const uint64_t i1 = std::min<uint64_t>(a1, i0 + ISX_CHUNK);
+                    const uint64_t g0 = first + i0;
+                    const uint64_t n_real = g0 < (uint64_t)n_obs ? std::min<uint64_t>(i1 - i0, (uint64_t)n_obs - g0) : 0;
+                    if (n_real) memcpy(dst + i0, obs + g0, n_real * sizeof(uint2));
+                    for (uint64_t i = i0 + n_real; i < i1; i++) dst[i] = make_uint2(ISX_SENTINEL, 0);
+                    if (!n_real) continue;
+                    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+                    for (uint64_t i = i0; i < i0 + n_real; i++) { const uint32_t g = dst[i].x; lo = g < lo ? g : lo; hi = g > hi ? g : hi; }
+                    const uint64_t ch = g0 / ISX_CHUNK;
+                    cmin[ch] = lo; cmax[ch] = hi; cany[ch] = 1;
+                    if ((int64_t)hi >= n_pos) bad = 1;
+                }
+            });
+        }));
+    }
     if (bad_pos) { isx_batch_destroy(b); isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
     if (prm->enable_linkage) {
         BH(hipMalloc(&b->d_pair, b->n_rec * sizeof(uint32_t)));
@@ -351,7 +406,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
         } else {
             BH(hipMalloc(&b->d_gpos, b->n_rec * sizeof(uint32_t)));
         }
-        launch_extract_gpos(b->d_rec, b->d_gpos, b->d_gpos16, b->d_cbase, b->n_rec, c->stream);
+        launch_extract_gpos(b->d_rec, b->d_rec32, b->d_gbase, b->d_gpos, b->d_gpos16, b->d_cbase, b->n_rec, c->stream);
         BH(hipStreamSynchronize(c->stream));                                  // cmin is a local
         uint32_t maxp = 0;
         BT(staged_upload(c, b->d_pair, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
@@ -451,7 +506,7 @@ static int launch_pass(isx_batch *b)
     // one-wave kernel k_publish_state copies them to mapped pinned memory right behind the pileup kernel
 
     PileupArgs a{};
-    a.rec = b->d_rec; a.win_range = b->d_win; a.ref = b->d_ref;
+    a.rec = b->d_rec; a.rec32 = b->d_rec32; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref;
     a.pair = b->d_pair; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_cbase; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
@@ -521,6 +576,7 @@ static int finish_pass(isx_batch *b, uint32_t *cap_flags)
     b->tim.pileup_threads = b->block;
     b->tim.pileup_lds_bytes = (int32_t)b->lds;
     b->tim.pileup_window = b->W;
+    b->tim.record_bytes = b->d_rec32 ? 4 : 8;
 
     if (b->prm.enable_linkage) {
         LinkageIn in{};

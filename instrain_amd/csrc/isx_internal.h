@@ -6,6 +6,8 @@
 
 #include "../../include/instrain_amd.h"
 
+#define ISX_PAD32 0x0700FFFFu          // compact padding record: base code 7 (never counted), mm 0
+#define ISX_GROUP 256                // compact stream: records per position base (one wave-wide 16-byte load)
 #define ISX_CHUNK 1024              // observation directory granule (records)
 #define ISX_PAD 2048                // the record stream is padded to a multiple of this (whole directory chunks, 16-byte loads)
 #define ISX_SENTINEL 0xFFFFFFFFu    // gpos of padding records (never inside a window)
@@ -109,7 +111,9 @@ __host__ __device__ inline void rarefy4(const Philox &ph, uint32_t c0, uint32_t 
 }
 
 struct PileupArgs {
-    const uint2 *rec;           // packed isx_obs, padded to a multiple of ISX_CHUNK with sentinels
+    const uint2 *rec;           // wide stream: packed isx_obs, padded to a multiple of ISX_PAD with sentinels; or ...
+    const uint32_t *rec32;      // ... compact stream (rec == NULL): delta:16 | mm:8 | base:3 per record, position =
+    const uint32_t *gbase;      //     gbase[record / 256] + delta; padding records are ISX_PAD32
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK)
     const uint8_t *ref;
     const uint32_t *pair;       // read-pair id per record (linkage only)
@@ -153,9 +157,10 @@ struct PileupArgs {
     uint32_t *host_state;       // mapped pinned [CUR_N + 4]: k_publish_state copies cursors | flags here
 };
 
-void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s);
+void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s);   // compact when a.rec32
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s);
-void launch_extract_gpos(const uint2 *rec, uint32_t *gpos, uint16_t *gpos16, const uint32_t *chunk_base, uint64_t n_rec, hipStream_t s);
+void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
+                         const uint32_t *chunk_base, uint64_t n_rec, hipStream_t s);
 size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int *stage_off);
 
 struct LinkageBuffers;      // defined in isx_linkage.hip

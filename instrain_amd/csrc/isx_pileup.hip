@@ -205,13 +205,14 @@ __device__ __forceinline__ void allele_drain(const PileupArgs &a, const uint32_t
     __builtin_amdgcn_wave_barrier();
     if ((uint32_t)lane < n) {
         const uint32_t i = st[2 * lane], rel = st[2 * lane + 1];
-        const uint32_t at = a.rec[i].y;
-        const uint32_t base = (at >> 16) & 0xFFu;
+        uint32_t base, mm;
+        if (a.rec32) { const uint32_t x = a.rec32[i]; base = (x >> 24) & 7u; mm = (x >> 16) & 0xFFu; }
+        else { const uint32_t at = a.rec[i].y; base = (at >> 16) & 0xFFu; mm = at & 0xFFFFu; }
         if (base < 4 && ((maskl[rel] >> base) & 1u)) {
             const uint32_t slot = atomicAdd(&slabc[rel], 1u);
             isx_ao o;
             o.pair = a.pair[i]; o.site = w0 + rel; o.obs_idx = i;
-            o.mm = (uint16_t)(at & 0xFFFFu); o.base = (uint8_t)base; o.pad = 0;
+            o.mm = (uint16_t)mm; o.base = (uint8_t)base; o.pad = 0;
             a.ao[ao_base + slot] = o;
         }
     }
@@ -297,7 +298,7 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, uint32_t lo, ui
 // clonality divisions and row emission run densely packed from an LDS queue.
 // LDS: cnt[4][W] | queue[W] | scratch[16] | thr_lds[THR_LDS] | (linkage) slabc[W] | maskl[W bytes]
 // ---------------------------------------------------------------------------------------------
-template <bool LINKAGE>
+template <bool LINKAGE, bool COMPACT>
 __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -312,7 +313,10 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
     constexpr bool linkage = LINKAGE;            // compile-time: the linkage-off kernels carry none of the allele pass
     const int grid = gridDim.x, per = grid >> 3;
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
-    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(a.rec);
+    // COMPACT: 4-byte records (4 per 16-byte load); a wave-wide load covers exactly one ISX_GROUP of 256
+    // records, so the group's position base is a scalar load.  Otherwise the 8-byte isx_obs (2 per load).
+    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(COMPACT ? (const void *)a.rec32 : (const void *)a.rec);
+    constexpr int RSH = COMPACT ? 2 : 1;        // record index -> 16-byte load index
     const int dbg = a.debug_mode;               // ablation switches (tools/), 0 in production
 
     {   // once per workgroup: folded thresholds of the low coverages
@@ -321,12 +325,16 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
     }
 
     u32x4 v[4];
+    uint32_t gb[4] = {0, 0, 0, 0};              // COMPACT: position base of each load's group (wave-uniform)
     uint32_t lo = 0, hi = 0;
-    auto issue = [&](uint32_t i0) {             // 4 coalesced 16-byte loads per lane (2 records each)
+    auto issue = [&](uint32_t i0) {             // 4 coalesced 16-byte loads per lane
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t j = i0 + tid + u * nthr;
-            if (j < hi) v[u] = __builtin_nontemporal_load(&rec4[j]);
+            if (j < hi) {
+                v[u] = __builtin_nontemporal_load(&rec4[j]);
+                if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
+            } else if (COMPACT) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
             else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
         }
     };
@@ -334,7 +342,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
-            lo = rng.x >> 1; hi = rng.y >> 1;
+            lo = rng.x >> RSH; hi = rng.y >> RSH;
             if (lo < hi) issue(lo);
         }
     };
@@ -364,11 +372,21 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t g0 = v[u].x, a0 = v[u].y, g1 = v[u].z, a1 = v[u].w;
-                const uint32_t r0 = g0 - w0, r1 = g1 - w0;
-                const uint32_t b0 = (a0 >> 16) & 0xFFu, b1 = (a1 >> 16) & 0xFFu;
-                if (r0 < (uint32_t)W && b0 < 4) atomicAdd(&cnt[b0 * W + r0], 1u);
-                if (r1 < (uint32_t)W && b1 < 4) atomicAdd(&cnt[b1 * W + r1], 1u);
+                if (COMPACT) {
+                    const uint32_t bw = gb[u] - w0;
+                    const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const uint32_t r = (x[h] & 0xFFFFu) + bw, bb = (x[h] >> 24) & 7u;
+                        if (r < (uint32_t)W && bb < 4) atomicAdd(&cnt[bb * W + r], 1u);
+                    }
+                } else {
+                    const uint32_t g0 = v[u].x, a0 = v[u].y, g1 = v[u].z, a1 = v[u].w;
+                    const uint32_t r0 = g0 - w0, r1 = g1 - w0;
+                    const uint32_t b0 = (a0 >> 16) & 0xFFu, b1 = (a1 >> 16) & 0xFFu;
+                    if (r0 < (uint32_t)W && b0 < 4) atomicAdd(&cnt[b0 * W + r0], 1u);
+                    if (r1 < (uint32_t)W && b1 < 4) atomicAdd(&cnt[b1 * W + r1], 1u);
+                }
             }
             const uint32_t nxt = i0 + 4 * nthr;
             if (nxt < hi) issue(nxt);
@@ -474,7 +492,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         if (linkage) {
             if (ok && nao) {
                 __syncthreads();                // every wave is done with cnt: it becomes the allele pass's stage
-                allele_pass(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
             prefetch_window(w + grid);
         }
@@ -495,7 +513,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
 // pres = levels made present by a non-ACGT base only (profile_utilities.py:279-285 creates
 // table[mm] before the KeyError), a presence the SNV loop must see.
 // ---------------------------------------------------------------------------------------------
-template <bool PACKED, bool LINKAGE>
+template <bool PACKED, bool LINKAGE, bool COMPACT>
 __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -514,7 +532,8 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
     constexpr bool linkage = LINKAGE;            // compile-time: the linkage-off kernels carry none of the allele pass
     const int grid = gridDim.x, per = grid >> 3;
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
-    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(a.rec);
+    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(COMPACT ? (const void *)a.rec32 : (const void *)a.rec);
+    constexpr int RSH = COMPACT ? 2 : 1;        // record index -> 16-byte load index (see k_pileup_dense)
     {   // once per workgroup: folded thresholds of the low coverages
         const int n = min(THR_LDS, a.lut_n);
         for (int i = tid; i < n; i += nthr) thr_lds[i] = a.thr[i];
@@ -529,13 +548,17 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
     };
 
     u32x4 v[4];
+    uint32_t gb[4] = {0, 0, 0, 0};
     uint32_t lo = 0, hi = 0;
     uint32_t my_entries = 0;                    // thread 0: entries of all windows of this workgroup
     auto issue = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t j = i0 + tid + u * nthr;
-            if (j < hi) v[u] = __builtin_nontemporal_load(&rec4[j]);
+            if (j < hi) {
+                v[u] = __builtin_nontemporal_load(&rec4[j]);
+                if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
+            } else if (COMPACT) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
             else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
         }
     };
@@ -543,7 +566,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
-            lo = rng.x >> 1; hi = rng.y >> 1;
+            lo = rng.x >> RSH; hi = rng.y >> RSH;
             if (lo < hi) issue(lo);
         }
     };
@@ -569,17 +592,18 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
+                const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t g = h ? v[u].z : v[u].x, at = h ? v[u].w : v[u].y;
-                    const uint32_t rel = g - w0;
+                for (int h = 0; h < (COMPACT ? 4 : 2); h++) {
+                    uint32_t rel, base, mm;
+                    if (COMPACT) { rel = (x[h] & 0xFFFFu) + (gb[u] - w0); base = (x[h] >> 24) & 7u; mm = (x[h] >> 16) & 0xFFu; }
+                    else { rel = x[2 * h] - w0; base = (x[2 * h + 1] >> 16) & 0xFFu; mm = x[2 * h + 1] & 0xFFFFu; }
                     if (rel >= (uint32_t)W) continue;
-                    const uint32_t base = (at >> 16) & 0xFFu, mm = at & 0xFFFFu;
                     if (mm >= (uint32_t)M) { bad_mm = 1; continue; }
                     if (base < 4) {
                         if (PACKED) atomicAdd(&cnt[(mm * 2 + (base >> 1)) * W + rel], 1u << (16 * (base & 1)));
                         else atomicAdd(&cnt[(mm * 4 + base) * W + rel], 1u);
-                    } else {
+                    } else if (!COMPACT || base != 7u) {            // 7 = padding record of the compact stream
                         atomicOr(&pres[(mm >> 5) * W + rel], 1u << (mm & 31));
                     }
                 }
@@ -790,7 +814,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         if (linkage) {
             if (ok && nao) {
                 __syncthreads();                // every wave is done with the counters: they become the stage
-                allele_pass(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
             prefetch_window(w + grid);
         }
@@ -832,27 +856,45 @@ static void launch_one(K kernel, const PileupArgs &a, int block, size_t lds, int
 
 void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s)
 {
-    const bool link = a.enable_linkage != 0;
+    const int sel = (a.enable_linkage != 0 ? 1 : 0) | (a.rec32 ? 2 : 0) | (packed ? 4 : 0);
     if (a.M > 1) {
-        if (packed) { if (link) launch_one(k_pileup_mm<true, true>, a, block, lds, grid, s); else launch_one(k_pileup_mm<true, false>, a, block, lds, grid, s); }
-        else        { if (link) launch_one(k_pileup_mm<false, true>, a, block, lds, grid, s); else launch_one(k_pileup_mm<false, false>, a, block, lds, grid, s); }
+        switch (sel) {
+        case 0: launch_one(k_pileup_mm<false, false, false>, a, block, lds, grid, s); break;
+        case 1: launch_one(k_pileup_mm<false, true, false>, a, block, lds, grid, s); break;
+        case 2: launch_one(k_pileup_mm<false, false, true>, a, block, lds, grid, s); break;
+        case 3: launch_one(k_pileup_mm<false, true, true>, a, block, lds, grid, s); break;
+        case 4: launch_one(k_pileup_mm<true, false, false>, a, block, lds, grid, s); break;
+        case 5: launch_one(k_pileup_mm<true, true, false>, a, block, lds, grid, s); break;
+        case 6: launch_one(k_pileup_mm<true, false, true>, a, block, lds, grid, s); break;
+        default: launch_one(k_pileup_mm<true, true, true>, a, block, lds, grid, s); break;
+        }
     } else {
-        if (link) launch_one(k_pileup_dense<true>, a, block, lds, grid, s); else launch_one(k_pileup_dense<false>, a, block, lds, grid, s);
+        switch (sel & 3) {
+        case 0: launch_one(k_pileup_dense<false, false>, a, block, lds, grid, s); break;
+        case 1: launch_one(k_pileup_dense<true, false>, a, block, lds, grid, s); break;
+        case 2: launch_one(k_pileup_dense<false, true>, a, block, lds, grid, s); break;
+        default: launch_one(k_pileup_dense<true, true>, a, block, lds, grid, s); break;
+        }
     }
 }
 
-__global__ void k_extract_gpos(const uint2 *rec, uint32_t *gpos, uint16_t *gpos16, const uint32_t *chunk_base, uint64_t n)
+__global__ void k_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
+                               const uint32_t *chunk_base, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t g = rec[i].x;
+    uint32_t g;
+    if (rec32) { const uint32_t x = rec32[i]; g = x == ISX_PAD32 ? ISX_SENTINEL : gbase[i / ISX_GROUP] + (x & 0xFFFFu); }
+    else g = rec[i].x;
     if (gpos16) gpos16[i] = g == ISX_SENTINEL ? (uint16_t)0xFFFFu : (uint16_t)(g - chunk_base[i / ISX_CHUNK]);
     else gpos[i] = g;
 }
 
-void launch_extract_gpos(const uint2 *rec, uint32_t *gpos, uint16_t *gpos16, const uint32_t *chunk_base, uint64_t n_rec, hipStream_t s)
+void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
+                         const uint32_t *chunk_base, uint64_t n_rec, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_extract_gpos, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, s, rec, gpos, gpos16, chunk_base, n_rec);
+    hipLaunchKernelGGL(k_extract_gpos, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, s, rec, rec32, gbase, gpos, gpos16,
+                       chunk_base, n_rec);
 }
 
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s)

@@ -183,6 +183,7 @@ def test_wide_chunk_takes_the_4_byte_position_stream(ctx, mml):
     b = engine.Batch(ctx, engine.encode_seq(seq), bounds, engine.pack_obs(pos.astype(np.uint32), base, mm),
                      pair.astype(np.uint32), n_mm_bins=mml)
     b.run()
+    assert b.timings()["record_bytes"] == 8               # ... and the record stream itself stays 8-byte isx_obs
     got = prod.to_oracle_layout(b.fetch(), lambda g: g.astype(np.int64))
     b.close()
     exp = {"entries": [], "snv": [], "ld": []}
@@ -193,6 +194,36 @@ def test_wide_chunk_takes_the_4_byte_position_stream(ctx, mml):
     exp = {k: np.concatenate(v) for k, v in exp.items()}
     assert len(exp["ld"]) > 50
     util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="wide chunk")
+
+
+@pytest.mark.parametrize("name", ["synth_mm4", "synth_m1", "synth_dense", "synth_ambig"])
+def test_wide_record_stream_equals_golden(ctx, name, monkeypatch):
+    """ISX_WIDE_RECORDS forces the 8-byte stream (isx_obs as is) that the library otherwise only falls back to"""
+    from tests import prod
+    monkeypatch.setenv("ISX_WIDE_RECORDS", "1")
+    g = util.load_case(name)
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), **_params(g))
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name)
+
+
+def test_record_stream_choice(ctx):
+    """compact 4-byte records normally; the 8-byte stream when a record does not fit (here: an mm level >= 256,
+    which is also out of range for any legal n_mm_bins <= 128 and must stay a loud error)"""
+    from instrain_amd import engine
+    seq, pos, base, mm, pair = _random_split(321, 1500, 30, 3, 60)
+    b = engine.Batch(ctx, engine.encode_seq(seq), [0, len(seq)], engine.pack_obs(pos.astype(np.uint32), base, mm),
+                     pair.astype(np.uint32), n_mm_bins=3)
+    b.run()
+    assert b.timings()["record_bytes"] == 4
+    b.close()
+    mm2 = mm.copy()
+    mm2[::97] = 300
+    b = engine.Batch(ctx, engine.encode_seq(seq), [0, len(seq)], engine.pack_obs(pos.astype(np.uint32), base, mm2),
+                     pair.astype(np.uint32), n_mm_bins=3)
+    with pytest.raises(engine.IsxError) as e:
+        b.run()
+    assert e.value.code == -4
+    b.close()
 
 
 def test_empty_and_ragged(ctx):
