@@ -318,7 +318,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     std::atomic<int> too_wide{getenv("ISX_WIDE_RECORDS") ? 1 : 0};      // env: force the wide stream (tests / A-B)
     auto fill_threads = [&](uint64_t cnt, auto &&work) {
         // a few host threads fill the pinned buffer (a single core copies at ~10 GB/s, PCIe Gen5 takes 63)
-        const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, cnt / (64 * ISX_CHUNK)));
+        const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(16, cnt / (64 * ISX_CHUNK)));
         const uint64_t per_t = ((cnt + nt - 1) / nt + ISX_CHUNK - 1) / ISX_CHUNK * ISX_CHUNK;
         std::vector<std::thread> th;
         std::vector<int> bad(nt, 0);
