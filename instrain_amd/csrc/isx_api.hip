@@ -42,6 +42,7 @@ struct isx_batch {
     uint32_t *d_rec32 = nullptr, *d_gbase = nullptr;    // compact stream (4-byte records + one position base per 256)
     uint32_t *d_pair = nullptr, *d_gpos = nullptr, *d_cbase = nullptr;
     uint16_t *d_gpos16 = nullptr;
+    int gpos16_shift = 7;
     uint8_t *d_ref = nullptr;
     uint2 *d_win = nullptr;
     uint16_t *d_thr = nullptr;
@@ -303,19 +304,22 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     if (prm->enable_linkage) BH(hipMalloc(&b->d_ao, b->cap_ao * sizeof(isx_ao)));
 
     // ---- observation stream: pinned, double-buffered upload + per-chunk min/max directory ----
-    const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
+    uint64_t n_chunks = b->n_rec / ISX_CHUNK;
     std::vector<uint32_t> cmin(n_chunks, 0xFFFFFFFFu), cmax(n_chunks, 0u);
     std::vector<uint8_t> cany(n_chunks, 0);
     bool bad_pos = false;
     // Compact stream (the normal case): 4 bytes per record -- a 16-bit delta to the lowest position of the
     // record's group of 256, the mm level in 8 bits, the base code -- encoded by a few host threads while
-    // they fill the pinned buffer (half the PCIe and half the HBM bytes of the 8-byte isx_obs).  It needs
-    // every group to span < 65535 positions and mm < 256; the first record that does not fit makes the
-    // upload start over with the wide stream (isx_obs as is).
+    // they fill the pinned buffer (half the PCIe and half the HBM bytes of the 8-byte isx_obs).
+    // A group must span < 65535 positions.  Where the stream jumps further (an uncovered stretch, the next
+    // genome of a database), the group is closed early and padded, so device record i is no longer input
+    // record i: `og_start / og_count` map every device group to its run of input records (built only when
+    // a jump exists; the pair ids follow the same map).  mm >= 256 (legal for no n_mm_bins) -> wide stream.
     static_assert(sizeof(isx_obs) == sizeof(uint2), "isx_obs must be the 8-byte device record");
-    const uint64_t n_groups = b->n_rec / ISX_GROUP;
-    std::vector<uint32_t> gbase(n_groups, 0u);
+    std::vector<uint64_t> og_start;                 // empty = identity (device group g starts at input record 256 g)
+    std::vector<uint16_t> og_count;
     std::atomic<int> too_wide{getenv("ISX_WIDE_RECORDS") ? 1 : 0};      // env: force the wide stream (tests / A-B)
+    std::atomic<int> has_jump{0};
     auto fill_threads = [&](uint64_t cnt, auto &&work) {
         // a few host threads fill the pinned buffer (a single core copies at ~10 GB/s, PCIe Gen5 takes 63)
         const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(16, cnt / (64 * ISX_CHUNK)));
@@ -331,43 +335,107 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
         for (auto &x : th) x.join();
         for (int v : bad) if (v) bad_pos = true;
     };
-    if (!too_wide.load()) {
-        BH(hipMalloc(&b->d_rec32, b->n_rec * sizeof(uint32_t)));
-        BT(staged_upload(c, b->d_rec32, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
-            if (too_wide.load()) return;
+    auto input_run = [&](uint64_t dev_group, const isx_obs *&src) -> uint64_t {     // records of a device group
+        if (og_start.empty()) {
+            const uint64_t g0 = dev_group * ISX_GROUP;
+            src = obs + g0;
+            return g0 < (uint64_t)n_obs ? std::min<uint64_t>(ISX_GROUP, (uint64_t)n_obs - g0) : 0;
+        }
+        if (dev_group >= og_start.size()) { src = obs; return 0; }
+        src = obs + og_start[dev_group];
+        return og_count[dev_group];
+    };
+    std::vector<uint32_t> gbase;
+    auto upload_compact = [&]() -> int {            // ISX_OK, or 1 = start over (jump found / too wide)
+        const uint64_t n_groups = b->n_rec / ISX_GROUP;
+        gbase.assign(n_groups, 0u);
+        HIP_TRY(hipMalloc(&b->d_rec32, b->n_rec * sizeof(uint32_t)));
+        int rc = staged_upload(c, b->d_rec32, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
+            if (too_wide.load() || has_jump.load()) return;
             fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
                 for (uint64_t i0 = a0; i0 < a1; i0 += ISX_GROUP) {          // `first`, a0, a1 are multiples of ISX_CHUNK
-                    const uint64_t g0 = first + i0;
-                    const uint64_t n_real = g0 < (uint64_t)n_obs ? std::min<uint64_t>(ISX_GROUP, (uint64_t)n_obs - g0) : 0;
-                    const isx_obs *src = obs + g0;
+                    const uint64_t dg = (first + i0) / ISX_GROUP;
+                    const isx_obs *src;
+                    const uint64_t n_real = input_run(dg, src);
                     uint32_t lo = 0xFFFFFFFFu, hi = 0, mmax = 0;
                     for (uint64_t i = 0; i < n_real; i++) {
                         const uint32_t g = src[i].gpos;
                         lo = g < lo ? g : lo; hi = g > hi ? g : hi; mmax = src[i].mm > mmax ? src[i].mm : mmax;
                     }
                     if (n_real) {
-                        if (hi - lo >= 65535u || mmax >= 256u) { too_wide.store(1); return; }
+                        if (mmax >= 256u) { too_wide.store(1); return; }
+                        if (hi - lo >= 65535u) { has_jump.store(1); return; }          // identity layout only: the map has none
                         if ((int64_t)hi >= n_pos) bad = 1;
-                        const uint64_t ch = g0 / ISX_CHUNK;     // the 4 groups of a chunk belong to one thread
+                        const uint64_t ch = (first + i0) / ISX_CHUNK;  // the 4 groups of a chunk belong to one thread
                         cmin[ch] = std::min(cmin[ch], lo); cmax[ch] = std::max(cmax[ch], hi); cany[ch] = 1;
-                        gbase[g0 / ISX_GROUP] = lo;
+                        gbase[dg] = lo;
                     }
                     for (uint64_t i = 0; i < n_real; i++)
                         dst[i0 + i] = (src[i].gpos - lo) | ((uint32_t)src[i].mm << 16) | ((uint32_t)(src[i].base > 4 ? 4 : src[i].base) << 24);
                     for (uint64_t i = n_real; i < ISX_GROUP; i++) dst[i0 + i] = ISX_PAD32;
                 }
             });
-        }));
-        if (too_wide.load()) {
-            BH(hipStreamSynchronize(c->stream));
+        });
+        if (rc != ISX_OK) return rc;
+        if (too_wide.load() || has_jump.load()) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
             (void)hipFree(b->d_rec32);
             b->d_rec32 = nullptr;
-            std::fill(cmin.begin(), cmin.end(), 0xFFFFFFFFu); std::fill(cmax.begin(), cmax.end(), 0u); std::fill(cany.begin(), cany.end(), 0);
-            bad_pos = false;
-        } else {
-            BH(hipMalloc(&b->d_gbase, std::max<uint64_t>(n_groups, 1) * sizeof(uint32_t)));
-            BH(hipMemcpy(b->d_gbase, gbase.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
+            return 1;
         }
+        HIP_TRY(hipMalloc(&b->d_gbase, std::max<uint64_t>(n_groups, 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(b->d_gbase, gbase.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return ISX_OK;
+    };
+    auto reset_directory = [&]() {
+        n_chunks = b->n_rec / ISX_CHUNK;
+        cmin.assign(n_chunks, 0xFFFFFFFFu); cmax.assign(n_chunks, 0u); cany.assign(n_chunks, 0);
+        bad_pos = false;
+    };
+    if (!too_wide.load()) {
+        int rc = upload_compact();
+        if (rc < 0) { isx_batch_destroy(b); return rc; }
+        if (rc == 1 && has_jump.load() && !too_wide.load()) {
+            // the stream jumps: cut the input into runs that fit a group (greedy, arrival order), per input
+            // group of 256 in parallel, then lay the runs out one device group each
+            const uint64_t n_in = ((uint64_t)n_obs + ISX_GROUP - 1) / ISX_GROUP;
+            const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(16, n_in / 4096 + 1));
+            std::vector<std::vector<std::pair<uint64_t, uint16_t>>> parts(nt);
+            std::vector<std::thread> th;
+            auto cut = [&](unsigned t) {
+                auto &out = parts[t];
+                for (uint64_t g = n_in * t / nt; g < n_in * (t + 1) / nt; g++) {
+                    const uint64_t s0 = g * ISX_GROUP, s1 = std::min<uint64_t>((uint64_t)n_obs, s0 + ISX_GROUP);
+                    uint64_t run0 = s0;
+                    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+                    for (uint64_t i = s0; i < s1; i++) {
+                        const uint32_t p = obs[i].gpos;
+                        const uint32_t nlo = p < lo ? p : lo, nhi = p > hi ? p : hi;
+                        if (i > run0 && nhi - nlo >= 65535u) {
+                            out.emplace_back(run0, (uint16_t)(i - run0));
+                            run0 = i; lo = hi = p;
+                        } else { lo = nlo; hi = nhi; }
+                    }
+                    if (s1 > run0) out.emplace_back(run0, (uint16_t)(s1 - run0));
+                }
+            };
+            for (unsigned t = 1; t < nt; t++) th.emplace_back(cut, t);
+            cut(0);
+            for (auto &x : th) x.join();
+            size_t total = 0;
+            for (auto &v : parts) total += v.size();
+            og_start.reserve(total); og_count.reserve(total);
+            for (auto &v : parts) for (auto &r : v) { og_start.push_back(r.first); og_count.push_back(r.second); }
+            const uint64_t want = (uint64_t)og_start.size() * ISX_GROUP;
+            b->n_rec = std::max<uint64_t>(ISX_PAD, (want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
+            if (b->n_rec >= 0xFFFFFFFFull) { isx_batch_destroy(b); isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
+            reset_directory();
+            has_jump.store(0);
+            rc = upload_compact();
+            if (rc < 0) { isx_batch_destroy(b); return rc; }
+            if (rc == 1 && !too_wide.load()) { isx_batch_destroy(b); isx_set_error("internal: a cut run still spans >= 65535 positions"); return ISX_ERR_STATE; }
+        }
+        if (!b->d_rec32) { og_start.clear(); og_count.clear(); b->n_rec = std::max<uint64_t>(ISX_PAD, ((uint64_t)n_obs + ISX_PAD - 1) / ISX_PAD * ISX_PAD); reset_directory(); }
     }
     if (!b->d_rec32) {
         // wide stream: isx_obs already has the device record layout (gpos | mm, base << 16, flags << 24): plain
@@ -394,26 +462,43 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     if (bad_pos) { isx_batch_destroy(b); isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
     if (prm->enable_linkage) {
         BH(hipMalloc(&b->d_pair, b->n_rec * sizeof(uint32_t)));
-        // the allele pass streams positions only: 2-byte deltas to the chunk's lowest position when every
-        // chunk spans < 65535 positions (any real BAM), else the 4-byte positions
+        // the allele pass streams positions only: 2-byte deltas -- to the group base with the compact stream
+        // (always possible), to the chunk's lowest position with the wide one when every chunk spans < 65535
+        // positions -- else the 4-byte positions
         bool narrow = true;
-        for (uint64_t i = 0; i < n_chunks; i++) if (cany[i] && cmax[i] - cmin[i] >= 65535u) { narrow = false; break; }
+        if (!b->d_rec32) for (uint64_t i = 0; i < n_chunks; i++) if (cany[i] && cmax[i] - cmin[i] >= 65535u) { narrow = false; break; }
+        std::vector<uint32_t> cb;
         if (narrow) {
-            for (uint64_t i = 0; i < n_chunks; i++) if (!cany[i]) cmin[i] = 0;
             BH(hipMalloc(&b->d_gpos16, b->n_rec * sizeof(uint16_t)));
-            BH(hipMalloc(&b->d_cbase, std::max<uint64_t>(n_chunks, 1) * sizeof(uint32_t)));
-            BH(hipMemcpyAsync(b->d_cbase, cmin.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            if (b->d_rec32) { b->gpos16_shift = 5; }                 // base per ISX_GROUP = 32 loads of 8 records
+            else {
+                cb.assign(cmin.begin(), cmin.end());
+                for (uint64_t i = 0; i < n_chunks; i++) if (!cany[i]) cb[i] = 0;
+                BH(hipMalloc(&b->d_cbase, std::max<uint64_t>(n_chunks, 1) * sizeof(uint32_t)));
+                BH(hipMemcpyAsync(b->d_cbase, cb.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                b->gpos16_shift = 7;                                 // base per ISX_CHUNK = 128 loads
+            }
         } else {
             BH(hipMalloc(&b->d_gpos, b->n_rec * sizeof(uint32_t)));
         }
-        launch_extract_gpos(b->d_rec, b->d_rec32, b->d_gbase, b->d_gpos, b->d_gpos16, b->d_cbase, b->n_rec, c->stream);
-        BH(hipStreamSynchronize(c->stream));                                  // cmin is a local
+        launch_extract_gpos(b->d_rec, b->d_rec32, b->d_gbase, b->d_gpos, b->d_gpos16, b->d_rec32 ? b->d_gbase : b->d_cbase,
+                            b->d_rec32 ? ISX_GROUP : ISX_CHUNK, b->n_rec, c->stream);
+        BH(hipStreamSynchronize(c->stream));                                  // cb is a local
         uint32_t maxp = 0;
         BT(staged_upload(c, b->d_pair, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
-            for (uint64_t i = 0; i < cnt; i++) {
-                const uint64_t g = first + i;
-                dst[i] = g < (uint64_t)n_obs ? pair[g] : 0u;
-                if (g < (uint64_t)n_obs) maxp = std::max(maxp, pair[g]);
+            if (og_start.empty()) {
+                for (uint64_t i = 0; i < cnt; i++) {
+                    const uint64_t g = first + i;
+                    dst[i] = g < (uint64_t)n_obs ? pair[g] : 0u;
+                    if (g < (uint64_t)n_obs) maxp = std::max(maxp, pair[g]);
+                }
+            } else {                                                          // device group -> run of input records
+                for (uint64_t i0 = 0; i0 < cnt; i0 += ISX_GROUP) {
+                    const uint64_t dg = (first + i0) / ISX_GROUP;
+                    const uint64_t n_real = dg < og_start.size() ? og_count[dg] : 0;
+                    for (uint64_t i = 0; i < n_real; i++) { dst[i0 + i] = pair[og_start[dg] + i]; maxp = std::max(maxp, dst[i0 + i]); }
+                    for (uint64_t i = n_real; i < ISX_GROUP; i++) dst[i0 + i] = 0u;
+                }
             }
         }));
         b->n_pairs = (uint64_t)maxp + 1;
@@ -507,7 +592,7 @@ static int launch_pass(isx_batch *b)
 
     PileupArgs a{};
     a.rec = b->d_rec; a.rec32 = b->d_rec32; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref;
-    a.pair = b->d_pair; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_cbase; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
+    a.pair = b->d_pair; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_rec32 ? b->d_gbase : b->d_cbase; a.gpos16_shift = b->gpos16_shift; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
     if (const char *e = getenv("ISX_DEBUG_MODE")) a.debug_mode = atoi(e);     // ablation only

@@ -119,7 +119,8 @@ struct PileupArgs {
     const uint32_t *pair;       // read-pair id per record (linkage only)
     const uint32_t *gpos;       // positions alone, 4 B per record (linkage only): what the allele pass streams ...
     const uint16_t *gpos16;     // ... or, when every 1024-record chunk spans < 65535 positions, 2 B deltas to
-    const uint32_t *chunk_base; //     the chunk's lowest position (0xFFFF = padding record); gpos is NULL then
+    const uint32_t *chunk_base; //     the chunk's / group's lowest position (0xFFFF = padding record); gpos is NULL then
+    int32_t gpos16_shift;       //     log2(16-byte loads of 8 deltas per base): 7 = per ISX_CHUNK, 5 = per ISX_GROUP
     const uint16_t *thr;        // lut_n entries: folded presence threshold per coverage (build_thresholds)
     int32_t lut_n, fallback;
     uint32_t n_pos;
@@ -160,7 +161,7 @@ struct PileupArgs {
 void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s);   // compact when a.rec32
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s);
 void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
-                         const uint32_t *chunk_base, uint64_t n_rec, hipStream_t s);
+                         const uint32_t *base16, uint32_t base16_records, uint64_t n_rec, hipStream_t s);
 size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int *stage_off);
 
 struct LinkageBuffers;      // defined in isx_linkage.hip

@@ -251,7 +251,7 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, uint32_t lo, ui
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const uint32_t j = i0 + tid + u * nthr;
-                if (j < q_hi) { v[u] = __builtin_nontemporal_load(&g8[j]); cb[u] = a.chunk_base[j / (ISX_CHUNK / 8)]; }
+                if (j < q_hi) { v[u] = __builtin_nontemporal_load(&g8[j]); cb[u] = a.chunk_base[j >> a.gpos16_shift]; }
                 else { v[u].x = v[u].y = v[u].z = v[u].w = 0xFFFFFFFFu; cb[u] = 0; }
             }
 #pragma unroll
@@ -879,22 +879,22 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
 }
 
 __global__ void k_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
-                               const uint32_t *chunk_base, uint64_t n)
+                               const uint32_t *base16, uint32_t base16_records, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t g;
     if (rec32) { const uint32_t x = rec32[i]; g = x == ISX_PAD32 ? ISX_SENTINEL : gbase[i / ISX_GROUP] + (x & 0xFFFFu); }
     else g = rec[i].x;
-    if (gpos16) gpos16[i] = g == ISX_SENTINEL ? (uint16_t)0xFFFFu : (uint16_t)(g - chunk_base[i / ISX_CHUNK]);
+    if (gpos16) gpos16[i] = g == ISX_SENTINEL ? (uint16_t)0xFFFFu : (uint16_t)(g - base16[i / base16_records]);
     else gpos[i] = g;
 }
 
 void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
-                         const uint32_t *chunk_base, uint64_t n_rec, hipStream_t s)
+                         const uint32_t *base16, uint32_t base16_records, uint64_t n_rec, hipStream_t s)
 {
     hipLaunchKernelGGL(k_extract_gpos, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, s, rec, rec32, gbase, gpos, gpos16,
-                       chunk_base, n_rec);
+                       base16, base16_records, n_rec);
 }
 
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s)

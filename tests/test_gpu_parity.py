@@ -163,10 +163,13 @@ def test_multi_split_batch_vs_per_split_oracle(ctx):
     util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="multi")
 
 
-@pytest.mark.parametrize("mml", [1, 3])
-def test_wide_chunk_takes_the_4_byte_position_stream(ctx, mml):
-    """two islands of reads 250 kbp apart: the 1024-record chunk that holds both spans >= 65535 positions, so the
-    allele pass cannot use 2-byte position deltas and must stream the 4-byte positions; results unchanged"""
+@pytest.mark.parametrize("mml,wide", [(1, False), (3, False), (1, True), (3, True)])
+def test_stream_with_a_jump(ctx, mml, wide, monkeypatch):
+    """two islands of reads 250 kbp apart.  Compact stream: the group of 256 records that would hold both is cut
+    and padded (device record index != input record index from there on; pair ids follow).  Wide stream
+    (forced): the 1024-record chunk spans >= 65535 positions, so the allele pass streams 4-byte positions."""
+    if wide:
+        monkeypatch.setenv("ISX_WIDE_RECORDS", "1")
     from instrain_amd import engine
     from oracle import oracle
     from tests import prod
@@ -183,7 +186,7 @@ def test_wide_chunk_takes_the_4_byte_position_stream(ctx, mml):
     b = engine.Batch(ctx, engine.encode_seq(seq), bounds, engine.pack_obs(pos.astype(np.uint32), base, mm),
                      pair.astype(np.uint32), n_mm_bins=mml)
     b.run()
-    assert b.timings()["record_bytes"] == 8               # ... and the record stream itself stays 8-byte isx_obs
+    assert b.timings()["record_bytes"] == (8 if wide else 4)
     got = prod.to_oracle_layout(b.fetch(), lambda g: g.astype(np.int64))
     b.close()
     exp = {"entries": [], "snv": [], "ld": []}
@@ -194,6 +197,45 @@ def test_wide_chunk_takes_the_4_byte_position_stream(ctx, mml):
     exp = {k: np.concatenate(v) for k, v in exp.items()}
     assert len(exp["ld"]) > 50
     util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="wide chunk")
+
+
+def test_database_like_stream_with_many_jumps(ctx):
+    """7 copies of one profiled region 100 kbp apart in the flat space (a database of genomes, most of it
+    uncovered): every copy's tables must equal the oracle's for the region; the compact stream is cut at every
+    jump (threaded cut pass: > 4096 input groups)"""
+    from instrain_amd import engine
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    seq, pos, base, mm, pair = _random_split(401, 3000, 60, 3, 150)
+    K, step = 7, 100_000
+    n_pairs = int(pair.max()) + 1
+    P = np.concatenate([pos + k * step for k in range(K)])
+    B = np.tile(base, K); M = np.tile(mm, K)
+    R = np.concatenate([pair + k * n_pairs for k in range(K)])
+    assert len(P) > 4096 * 256
+    ref = np.zeros(K * step, dtype=np.uint8)
+    bounds = []
+    for k in range(K):
+        ref[k * step:k * step + len(seq)] = engine.encode_seq(seq)
+        bounds += [k * step, k * step + len(seq)]
+    bounds.append(K * step)
+    b = engine.Batch(ctx, ref, np.array(bounds), engine.pack_obs(P.astype(np.uint32), B, M), R.astype(np.uint32), n_mm_bins=3)
+    b.run()
+    assert b.timings()["record_bytes"] == 4
+    got = prod.to_oracle_layout(b.fetch(), lambda g: g.astype(np.int64))
+    b.close()
+    exp = oracle.profile_split(pos, base, mm, pair, seq, 0, lut, fb)
+    ce = util.canon_from_struct(exp)
+    assert len(exp["ld"]) > 100
+    for k in range(K):
+        sub = {}
+        for name, key in (("entries", "pos"), ("snv", "pos"), ("ld", "pos_a")):
+            t = got[name][(got[name][key] >= k * step) & (got[name][key] < (k + 1) * step)].copy()
+            for f in (("pos",) if name != "ld" else ("pos_a", "pos_b")):
+                t[f] -= k * step
+            sub[name] = t
+        util.assert_same(util.canon_from_struct(sub), ce, float_tol=TOL, what="copy %d" % k)
 
 
 @pytest.mark.parametrize("name", ["synth_mm4", "synth_m1", "synth_dense", "synth_ambig"])
