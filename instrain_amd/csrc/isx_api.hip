@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "isx_internal.h"
@@ -40,6 +41,7 @@ struct isx_batch {
     // device
     uint2 *d_rec = nullptr;             // wide stream (8-byte isx_obs) -- or:
     uint32_t *d_rec32 = nullptr, *d_gbase = nullptr;    // compact stream (4-byte records + one position base per 256)
+    uint16_t *d_rec16 = nullptr;                        // short stream (n_mm_bins == 1: 2-byte records, base per 512)
     uint32_t *d_pair = nullptr, *d_gpos = nullptr, *d_cbase = nullptr;
     uint16_t *d_gpos16 = nullptr;
     int gpos16_shift = 7;
@@ -198,7 +200,7 @@ void isx_batch_destroy(isx_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_rec, b->d_rec32, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
+    void *ps[] = {b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
@@ -335,52 +337,72 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
         for (auto &x : th) x.join();
         for (int v : bad) if (v) bad_pos = true;
     };
+    // stream format: 2-byte records when there is one mm bin (delta:13 | base:3, groups of 512), else 4-byte
+    const bool want16 = b->M == 1 && !getenv("ISX_NO_SHORT_RECORDS");
+    const uint64_t G = want16 ? ISX_GROUP16 : ISX_GROUP;             // records per position base
+    const uint32_t SPAN = want16 ? 8191u : 65535u;                   // a group must span less than this
     auto input_run = [&](uint64_t dev_group, const isx_obs *&src) -> uint64_t {     // records of a device group
         if (og_start.empty()) {
-            const uint64_t g0 = dev_group * ISX_GROUP;
+            const uint64_t g0 = dev_group * G;
             src = obs + g0;
-            return g0 < (uint64_t)n_obs ? std::min<uint64_t>(ISX_GROUP, (uint64_t)n_obs - g0) : 0;
+            return g0 < (uint64_t)n_obs ? std::min<uint64_t>(G, (uint64_t)n_obs - g0) : 0;
         }
         if (dev_group >= og_start.size()) { src = obs; return 0; }
         src = obs + og_start[dev_group];
         return og_count[dev_group];
     };
     std::vector<uint32_t> gbase;
+    // one group: directory + base + encoded records (T = uint32_t compact / uint16_t short)
+    auto encode_group = [&](auto *dst, uint64_t dev_first, int &bad) -> bool {
+        const uint64_t dg = dev_first / G;
+        const isx_obs *src;
+        const uint64_t n_real = input_run(dg, src);
+        uint32_t lo = 0xFFFFFFFFu, hi = 0, mmax = 0;
+        for (uint64_t i = 0; i < n_real; i++) {
+            const uint32_t g = src[i].gpos;
+            lo = g < lo ? g : lo; hi = g > hi ? g : hi; mmax = src[i].mm > mmax ? src[i].mm : mmax;
+        }
+        using T = std::remove_reference_t<decltype(*dst)>;
+        if (n_real) {
+            if (mmax >= 256u) { too_wide.store(1); return false; }
+            if (hi - lo >= SPAN) { has_jump.store(1); return false; }              // identity layout only: the map has none
+            if ((int64_t)hi >= n_pos) bad = 1;
+            const uint64_t ch = dev_first / ISX_CHUNK;             // the groups of a chunk belong to one thread
+            cmin[ch] = std::min(cmin[ch], lo); cmax[ch] = std::max(cmax[ch], hi); cany[ch] = 1;
+            gbase[dg] = lo;
+        }
+        for (uint64_t i = 0; i < n_real; i++) {
+            const uint32_t bc = src[i].base > 4 ? 4u : (uint32_t)src[i].base;
+            if (sizeof(T) == 2) dst[i] = (T)((src[i].gpos - lo) | (bc << 13));
+            else dst[i] = (T)((src[i].gpos - lo) | ((uint32_t)src[i].mm << 16) | (bc << 24));
+        }
+        for (uint64_t i = n_real; i < G; i++) dst[i] = sizeof(T) == 2 ? (T)0xFFFFu : (T)ISX_PAD32;
+        return true;
+    };
     auto upload_compact = [&]() -> int {            // ISX_OK, or 1 = start over (jump found / too wide)
-        const uint64_t n_groups = b->n_rec / ISX_GROUP;
+        const uint64_t n_groups = b->n_rec / G;
         gbase.assign(n_groups, 0u);
-        HIP_TRY(hipMalloc(&b->d_rec32, b->n_rec * sizeof(uint32_t)));
-        int rc = staged_upload(c, b->d_rec32, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
+        int rc;
+        auto fill = [&](auto *dst, uint64_t first, uint64_t cnt) {
             if (too_wide.load() || has_jump.load()) return;
             fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
-                for (uint64_t i0 = a0; i0 < a1; i0 += ISX_GROUP) {          // `first`, a0, a1 are multiples of ISX_CHUNK
-                    const uint64_t dg = (first + i0) / ISX_GROUP;
-                    const isx_obs *src;
-                    const uint64_t n_real = input_run(dg, src);
-                    uint32_t lo = 0xFFFFFFFFu, hi = 0, mmax = 0;
-                    for (uint64_t i = 0; i < n_real; i++) {
-                        const uint32_t g = src[i].gpos;
-                        lo = g < lo ? g : lo; hi = g > hi ? g : hi; mmax = src[i].mm > mmax ? src[i].mm : mmax;
-                    }
-                    if (n_real) {
-                        if (mmax >= 256u) { too_wide.store(1); return; }
-                        if (hi - lo >= 65535u) { has_jump.store(1); return; }          // identity layout only: the map has none
-                        if ((int64_t)hi >= n_pos) bad = 1;
-                        const uint64_t ch = (first + i0) / ISX_CHUNK;  // the 4 groups of a chunk belong to one thread
-                        cmin[ch] = std::min(cmin[ch], lo); cmax[ch] = std::max(cmax[ch], hi); cany[ch] = 1;
-                        gbase[dg] = lo;
-                    }
-                    for (uint64_t i = 0; i < n_real; i++)
-                        dst[i0 + i] = (src[i].gpos - lo) | ((uint32_t)src[i].mm << 16) | ((uint32_t)(src[i].base > 4 ? 4 : src[i].base) << 24);
-                    for (uint64_t i = n_real; i < ISX_GROUP; i++) dst[i0 + i] = ISX_PAD32;
-                }
+                for (uint64_t i0 = a0; i0 < a1; i0 += G)                   // `first`, a0, a1 are multiples of ISX_CHUNK
+                    if (!encode_group(dst + i0, first + i0, bad)) return;
             });
-        });
+        };
+        if (want16) {
+            HIP_TRY(hipMalloc(&b->d_rec16, b->n_rec * sizeof(uint16_t)));
+            rc = staged_upload(c, b->d_rec16, b->n_rec, [&](uint16_t *dst, uint64_t first, uint64_t cnt) { fill(dst, first, cnt); });
+        } else {
+            HIP_TRY(hipMalloc(&b->d_rec32, b->n_rec * sizeof(uint32_t)));
+            rc = staged_upload(c, b->d_rec32, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) { fill(dst, first, cnt); });
+        }
         if (rc != ISX_OK) return rc;
         if (too_wide.load() || has_jump.load()) {
             HIP_TRY(hipStreamSynchronize(c->stream));
-            (void)hipFree(b->d_rec32);
-            b->d_rec32 = nullptr;
+            if (b->d_rec32) (void)hipFree(b->d_rec32);
+            if (b->d_rec16) (void)hipFree(b->d_rec16);
+            b->d_rec32 = nullptr; b->d_rec16 = nullptr;
             return 1;
         }
         HIP_TRY(hipMalloc(&b->d_gbase, std::max<uint64_t>(n_groups, 1) * sizeof(uint32_t)));
@@ -397,21 +419,21 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
         if (rc < 0) { isx_batch_destroy(b); return rc; }
         if (rc == 1 && has_jump.load() && !too_wide.load()) {
             // the stream jumps: cut the input into runs that fit a group (greedy, arrival order), per input
-            // group of 256 in parallel, then lay the runs out one device group each
-            const uint64_t n_in = ((uint64_t)n_obs + ISX_GROUP - 1) / ISX_GROUP;
+            // group in parallel, then lay the runs out one device group each
+            const uint64_t n_in = ((uint64_t)n_obs + G - 1) / G;
             const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(16, n_in / 4096 + 1));
             std::vector<std::vector<std::pair<uint64_t, uint16_t>>> parts(nt);
             std::vector<std::thread> th;
             auto cut = [&](unsigned t) {
                 auto &out = parts[t];
                 for (uint64_t g = n_in * t / nt; g < n_in * (t + 1) / nt; g++) {
-                    const uint64_t s0 = g * ISX_GROUP, s1 = std::min<uint64_t>((uint64_t)n_obs, s0 + ISX_GROUP);
+                    const uint64_t s0 = g * G, s1 = std::min<uint64_t>((uint64_t)n_obs, s0 + G);
                     uint64_t run0 = s0;
                     uint32_t lo = 0xFFFFFFFFu, hi = 0;
                     for (uint64_t i = s0; i < s1; i++) {
                         const uint32_t p = obs[i].gpos;
                         const uint32_t nlo = p < lo ? p : lo, nhi = p > hi ? p : hi;
-                        if (i > run0 && nhi - nlo >= 65535u) {
+                        if (i > run0 && nhi - nlo >= SPAN) {
                             out.emplace_back(run0, (uint16_t)(i - run0));
                             run0 = i; lo = hi = p;
                         } else { lo = nlo; hi = nhi; }
@@ -426,18 +448,18 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
             for (auto &v : parts) total += v.size();
             og_start.reserve(total); og_count.reserve(total);
             for (auto &v : parts) for (auto &r : v) { og_start.push_back(r.first); og_count.push_back(r.second); }
-            const uint64_t want = (uint64_t)og_start.size() * ISX_GROUP;
+            const uint64_t want = (uint64_t)og_start.size() * G;
             b->n_rec = std::max<uint64_t>(ISX_PAD, (want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
             if (b->n_rec >= 0xFFFFFFFFull) { isx_batch_destroy(b); isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
             reset_directory();
             has_jump.store(0);
             rc = upload_compact();
             if (rc < 0) { isx_batch_destroy(b); return rc; }
-            if (rc == 1 && !too_wide.load()) { isx_batch_destroy(b); isx_set_error("internal: a cut run still spans >= 65535 positions"); return ISX_ERR_STATE; }
+            if (rc == 1 && !too_wide.load()) { isx_batch_destroy(b); isx_set_error("internal: a cut run still spans too many positions"); return ISX_ERR_STATE; }
         }
-        if (!b->d_rec32) { og_start.clear(); og_count.clear(); b->n_rec = std::max<uint64_t>(ISX_PAD, ((uint64_t)n_obs + ISX_PAD - 1) / ISX_PAD * ISX_PAD); reset_directory(); }
+        if (!b->d_rec32 && !b->d_rec16) { og_start.clear(); og_count.clear(); b->n_rec = std::max<uint64_t>(ISX_PAD, ((uint64_t)n_obs + ISX_PAD - 1) / ISX_PAD * ISX_PAD); reset_directory(); }
     }
-    if (!b->d_rec32) {
+    if (!b->d_rec32 && !b->d_rec16) {
         // wide stream: isx_obs already has the device record layout (gpos | mm, base << 16, flags << 24): plain
         // copy into the pinned buffer, then one vectorisable sweep per chunk for the min/max directory
         BH(hipMalloc(&b->d_rec, b->n_rec * sizeof(uint2)));
@@ -468,22 +490,26 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
         bool narrow = true;
         if (!b->d_rec32) for (uint64_t i = 0; i < n_chunks; i++) if (cany[i] && cmax[i] - cmin[i] >= 65535u) { narrow = false; break; }
         std::vector<uint32_t> cb;
-        if (narrow) {
-            BH(hipMalloc(&b->d_gpos16, b->n_rec * sizeof(uint16_t)));
-            if (b->d_rec32) { b->gpos16_shift = 5; }                 // base per ISX_GROUP = 32 loads of 8 records
-            else {
-                cb.assign(cmin.begin(), cmin.end());
-                for (uint64_t i = 0; i < n_chunks; i++) if (!cany[i]) cb[i] = 0;
-                BH(hipMalloc(&b->d_cbase, std::max<uint64_t>(n_chunks, 1) * sizeof(uint32_t)));
-                BH(hipMemcpyAsync(b->d_cbase, cb.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-                b->gpos16_shift = 7;                                 // base per ISX_CHUNK = 128 loads
-            }
+        if (b->d_rec16) {
+            // short stream: the allele pass reads the 2-byte records themselves
         } else {
-            BH(hipMalloc(&b->d_gpos, b->n_rec * sizeof(uint32_t)));
+            if (narrow) {
+                BH(hipMalloc(&b->d_gpos16, b->n_rec * sizeof(uint16_t)));
+                if (b->d_rec32) { b->gpos16_shift = 5; }                 // base per ISX_GROUP = 32 loads of 8 records
+                else {
+                    cb.assign(cmin.begin(), cmin.end());
+                    for (uint64_t i = 0; i < n_chunks; i++) if (!cany[i]) cb[i] = 0;
+                    BH(hipMalloc(&b->d_cbase, std::max<uint64_t>(n_chunks, 1) * sizeof(uint32_t)));
+                    BH(hipMemcpyAsync(b->d_cbase, cb.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                    b->gpos16_shift = 7;                                 // base per ISX_CHUNK = 128 loads
+                }
+            } else {
+                BH(hipMalloc(&b->d_gpos, b->n_rec * sizeof(uint32_t)));
+            }
+            launch_extract_gpos(b->d_rec, b->d_rec32, b->d_gbase, b->d_gpos, b->d_gpos16, b->d_rec32 ? b->d_gbase : b->d_cbase,
+                                b->d_rec32 ? ISX_GROUP : ISX_CHUNK, b->n_rec, c->stream);
+            BH(hipStreamSynchronize(c->stream));                              // cb is a local
         }
-        launch_extract_gpos(b->d_rec, b->d_rec32, b->d_gbase, b->d_gpos, b->d_gpos16, b->d_rec32 ? b->d_gbase : b->d_cbase,
-                            b->d_rec32 ? ISX_GROUP : ISX_CHUNK, b->n_rec, c->stream);
-        BH(hipStreamSynchronize(c->stream));                                  // cb is a local
         uint32_t maxp = 0;
         BT(staged_upload(c, b->d_pair, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
             if (og_start.empty()) {
@@ -493,11 +519,11 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
                     if (g < (uint64_t)n_obs) maxp = std::max(maxp, pair[g]);
                 }
             } else {                                                          // device group -> run of input records
-                for (uint64_t i0 = 0; i0 < cnt; i0 += ISX_GROUP) {
-                    const uint64_t dg = (first + i0) / ISX_GROUP;
+                for (uint64_t i0 = 0; i0 < cnt; i0 += G) {
+                    const uint64_t dg = (first + i0) / G;
                     const uint64_t n_real = dg < og_start.size() ? og_count[dg] : 0;
                     for (uint64_t i = 0; i < n_real; i++) { dst[i0 + i] = pair[og_start[dg] + i]; maxp = std::max(maxp, dst[i0 + i]); }
-                    for (uint64_t i = n_real; i < ISX_GROUP; i++) dst[i0 + i] = 0u;
+                    for (uint64_t i = n_real; i < G; i++) dst[i0 + i] = 0u;
                 }
             }
         }));
@@ -591,7 +617,7 @@ static int launch_pass(isx_batch *b)
     // one-wave kernel k_publish_state copies them to mapped pinned memory right behind the pileup kernel
 
     PileupArgs a{};
-    a.rec = b->d_rec; a.rec32 = b->d_rec32; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref;
+    a.rec = b->d_rec; a.rec32 = b->d_rec32; a.rec16 = b->d_rec16; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref;
     a.pair = b->d_pair; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_rec32 ? b->d_gbase : b->d_cbase; a.gpos16_shift = b->gpos16_shift; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
@@ -661,7 +687,7 @@ static int finish_pass(isx_batch *b, uint32_t *cap_flags)
     b->tim.pileup_threads = b->block;
     b->tim.pileup_lds_bytes = (int32_t)b->lds;
     b->tim.pileup_window = b->W;
-    b->tim.record_bytes = b->d_rec32 ? 4 : 8;
+    b->tim.record_bytes = b->d_rec16 ? 2 : (b->d_rec32 ? 4 : 8);
 
     if (b->prm.enable_linkage) {
         LinkageIn in{};

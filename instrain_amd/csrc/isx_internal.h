@@ -7,6 +7,7 @@
 #include "../../include/instrain_amd.h"
 
 #define ISX_PAD32 0x0700FFFFu          // compact padding record: base code 7 (never counted), mm 0
+#define ISX_GROUP16 512              // short stream: records per position base (one wave-wide 16-byte load of 8 records per lane)
 #define ISX_GROUP 256                // compact stream: records per position base (one wave-wide 16-byte load)
 #define ISX_CHUNK 1024              // observation directory granule (records)
 #define ISX_PAD 2048                // the record stream is padded to a multiple of this (whole directory chunks, 16-byte loads)
@@ -113,7 +114,9 @@ __host__ __device__ inline void rarefy4(const Philox &ph, uint32_t c0, uint32_t 
 struct PileupArgs {
     const uint2 *rec;           // wide stream: packed isx_obs, padded to a multiple of ISX_PAD with sentinels; or ...
     const uint32_t *rec32;      // ... compact stream (rec == NULL): delta:16 | mm:8 | base:3 per record, position =
-    const uint32_t *gbase;      //     gbase[record / 256] + delta; padding records are ISX_PAD32
+    const uint32_t *gbase;      //     gbase[record / 256] + delta; padding records are ISX_PAD32; or ...
+    const uint16_t *rec16;      // ... short stream (n_mm_bins == 1 only; rec, rec32 == NULL): delta:13 | base:3 per record,
+                                //     position = gbase[record / 512] + delta; padding records are 0xFFFF
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK)
     const uint8_t *ref;
     const uint32_t *pair;       // read-pair id per record (linkage only)

@@ -206,7 +206,8 @@ __device__ __forceinline__ void allele_drain(const PileupArgs &a, const uint32_t
     if ((uint32_t)lane < n) {
         const uint32_t i = st[2 * lane], rel = st[2 * lane + 1];
         uint32_t base, mm;
-        if (a.rec32) { const uint32_t x = a.rec32[i]; base = (x >> 24) & 7u; mm = (x >> 16) & 0xFFu; }
+        if (a.rec16) { base = (uint32_t)a.rec16[i] >> 13; mm = 0; }
+        else if (a.rec32) { const uint32_t x = a.rec32[i]; base = (x >> 24) & 7u; mm = (x >> 16) & 0xFFu; }
         else { const uint32_t at = a.rec[i].y; base = (at >> 16) & 0xFFu; mm = at & 0xFFFFu; }
         if (base < 4 && ((maskl[rel] >> base) & 1u)) {
             const uint32_t slot = atomicAdd(&slabc[rel], 1u);
@@ -242,7 +243,32 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, uint32_t lo, ui
         }
         nst += n;
     };
-    if (a.gpos16) {                             // 2-byte deltas: 8 records per 16-byte load
+    if (a.rec16) {                              // short stream: the records themselves are 2 bytes, base included
+        const u32x4 *g8 = reinterpret_cast<const u32x4 *>(a.rec16);
+        const uint32_t q_lo = lo >> 2, q_hi = hi >> 2;              // units of EIGHT records
+        for (uint32_t i0 = q_lo; i0 < q_hi; i0 += 2 * nthr) {
+            u32x4 v[2];
+            uint32_t bw[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t j = i0 + tid + u * nthr;
+                if (j < q_hi) { v[u] = __builtin_nontemporal_load(&g8[j]); bw[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)] - w0; }
+                else { v[u].x = v[u].y = v[u].z = v[u].w = 0xFFFFFFFFu; bw[u] = 0; }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+#pragma unroll
+                for (int h = 0; h < 8; h++) {
+                    const uint32_t word = (h >> 1) == 0 ? v[u].x : ((h >> 1) == 1 ? v[u].y : ((h >> 1) == 2 ? v[u].z : v[u].w));
+                    const uint32_t d = (h & 1) ? (word >> 16) : (word & 0xFFFFu);
+                    const uint32_t bb = d >> 13;
+                    uint32_t rel = (d & 0x1FFFu) + bw[u];
+                    if (bb >= 4 || rel >= (uint32_t)W || !((maskl[rel] >> bb) & 1u)) rel = 0xFFFFFFFFu;   // not an allele of a site
+                    consider(rel, 8u * (i0 + tid + u * nthr) + (uint32_t)h);
+                }
+            }
+        }
+    } else if (a.gpos16) {                      // 2-byte deltas: 8 records per 16-byte load
         const u32x4 *g8 = reinterpret_cast<const u32x4 *>(a.gpos16);
         const uint32_t q_lo = lo >> 2, q_hi = hi >> 2;              // units of EIGHT records
         for (uint32_t i0 = q_lo; i0 < q_hi; i0 += 2 * nthr) {
@@ -298,7 +324,7 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, uint32_t lo, ui
 // clonality divisions and row emission run densely packed from an LDS queue.
 // LDS: cnt[4][W] | queue[W] | scratch[16] | thr_lds[THR_LDS] | (linkage) slabc[W] | maskl[W bytes]
 // ---------------------------------------------------------------------------------------------
-template <bool LINKAGE, bool COMPACT>
+template <bool LINKAGE, int FMT>          // FMT = bytes per resident record: 8 (isx_obs), 4 (compact), 2 (short)
 __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -315,8 +341,9 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
     // COMPACT: 4-byte records (4 per 16-byte load); a wave-wide load covers exactly one ISX_GROUP of 256
     // records, so the group's position base is a scalar load.  Otherwise the 8-byte isx_obs (2 per load).
-    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(COMPACT ? (const void *)a.rec32 : (const void *)a.rec);
-    constexpr int RSH = COMPACT ? 2 : 1;        // record index -> 16-byte load index
+    constexpr bool COMPACT = FMT != 8;
+    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(FMT == 2 ? (const void *)a.rec16 : (FMT == 4 ? (const void *)a.rec32 : (const void *)a.rec));
+    constexpr int RSH = FMT == 2 ? 3 : (FMT == 4 ? 2 : 1);         // record index -> 16-byte load index
     const int dbg = a.debug_mode;               // ablation switches (tools/), 0 in production
 
     {   // once per workgroup: folded thresholds of the low coverages
@@ -334,7 +361,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
             if (j < hi) {
                 v[u] = __builtin_nontemporal_load(&rec4[j]);
                 if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
-            } else if (COMPACT) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
+            } else if (FMT == 2) { v[u].x = v[u].y = v[u].z = v[u].w = 0xFFFFFFFFu; }
+            else if (FMT == 4) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
             else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
         }
     };
@@ -372,7 +400,16 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (COMPACT) {
+                if (FMT == 2) {
+                    const uint32_t bw = gb[u] - w0;
+                    const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int h = 0; h < 8; h++) {
+                        const uint32_t d = (h & 1) ? (x[h >> 1] >> 16) : (x[h >> 1] & 0xFFFFu);
+                        const uint32_t r = (d & 0x1FFFu) + bw, bb = d >> 13;
+                        if (r < (uint32_t)W && bb < 4) atomicAdd(&cnt[bb * W + r], 1u);
+                    }
+                } else if (FMT == 4) {
                     const uint32_t bw = gb[u] - w0;
                     const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -869,12 +906,10 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
         default: launch_one(k_pileup_mm<true, true, true>, a, block, lds, grid, s); break;
         }
     } else {
-        switch (sel & 3) {
-        case 0: launch_one(k_pileup_dense<false, false>, a, block, lds, grid, s); break;
-        case 1: launch_one(k_pileup_dense<true, false>, a, block, lds, grid, s); break;
-        case 2: launch_one(k_pileup_dense<false, true>, a, block, lds, grid, s); break;
-        default: launch_one(k_pileup_dense<true, true>, a, block, lds, grid, s); break;
-        }
+        const bool link = a.enable_linkage != 0;
+        if (a.rec16) { if (link) launch_one(k_pileup_dense<true, 2>, a, block, lds, grid, s); else launch_one(k_pileup_dense<false, 2>, a, block, lds, grid, s); }
+        else if (a.rec32) { if (link) launch_one(k_pileup_dense<true, 4>, a, block, lds, grid, s); else launch_one(k_pileup_dense<false, 4>, a, block, lds, grid, s); }
+        else { if (link) launch_one(k_pileup_dense<true, 8>, a, block, lds, grid, s); else launch_one(k_pileup_dense<false, 8>, a, block, lds, grid, s); }
     }
 }
 

@@ -186,7 +186,7 @@ def test_stream_with_a_jump(ctx, mml, wide, monkeypatch):
     b = engine.Batch(ctx, engine.encode_seq(seq), bounds, engine.pack_obs(pos.astype(np.uint32), base, mm),
                      pair.astype(np.uint32), n_mm_bins=mml)
     b.run()
-    assert b.timings()["record_bytes"] == (8 if wide else 4)
+    assert b.timings()["record_bytes"] == (8 if wide else (2 if mml == 1 else 4))      # one mm bin: 2-byte records
     got = prod.to_oracle_layout(b.fetch(), lambda g: g.astype(np.int64))
     b.close()
     exp = {"entries": [], "snv": [], "ld": []}
@@ -248,6 +248,18 @@ def test_wide_record_stream_equals_golden(ctx, name, monkeypatch):
     util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name)
 
 
+@pytest.mark.parametrize("name", ["synth_m1", "synth_skipmm"])
+def test_one_mm_bin_with_4_byte_records_equals_golden(ctx, name, monkeypatch):
+    """n_mm_bins == 1 normally takes the 2-byte stream; ISX_NO_SHORT_RECORDS keeps the 4-byte one (k_pileup_dense<*, 4>)"""
+    from instrain_amd import engine
+    from tests import prod
+    monkeypatch.setenv("ISX_NO_SHORT_RECORDS", "1")
+    g = util.load_case(name)
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"] * 0, g["pair"], str(g["seq"]), int(g["start"]), n_mm_bins=1, **_params(g))
+    assert res["sizes"]["n_snv"] > 0
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name)
+
+
 def test_record_stream_choice(ctx):
     """compact 4-byte records normally; the 8-byte stream when a record does not fit (here: an mm level >= 256,
     which is also out of range for any legal n_mm_bins <= 128 and must stay a loud error)"""
@@ -257,6 +269,11 @@ def test_record_stream_choice(ctx):
                      pair.astype(np.uint32), n_mm_bins=3)
     b.run()
     assert b.timings()["record_bytes"] == 4
+    b.close()
+    b = engine.Batch(ctx, engine.encode_seq(seq), [0, len(seq)], engine.pack_obs(pos.astype(np.uint32), base, mm * 0),
+                     pair.astype(np.uint32), n_mm_bins=1)
+    b.run()
+    assert b.timings()["record_bytes"] == 2               # one mm bin: delta:13 | base:3
     b.close()
     mm2 = mm.copy()
     mm2[::97] = 300
