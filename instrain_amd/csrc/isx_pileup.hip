@@ -379,6 +379,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
     for (int w = slot; w < a.n_win; w += grid) {
         const uint32_t w0 = (uint32_t)w * (uint32_t)W;
         const uint32_t cur_lo = lo, cur_hi = hi;
+        const uint32_t dummy = 4u * (uint32_t)W + (uint32_t)(tid & 63);     // see the stream loop
         {   // zero the window's counters
             uint4 *z = reinterpret_cast<uint4 *>(cnt);
             for (int i = tid; i < W; i += nthr) z[i] = make_uint4(0, 0, 0, 0);
@@ -400,22 +401,25 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
+                // Branch-free: a record outside the window / without an A,C,T,G base adds to a per-lane dummy word
+                // (the queue region, idle during the stream) -- no exec-mask juggling per record, and the
+                // counter index is a 24-bit mad (v_mul_lo_u32 is quarter rate).
                 if (FMT == 2) {
                     const uint32_t bw = gb[u] - w0;
                     const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                     for (int h = 0; h < 8; h++) {
-                        const uint32_t d = (h & 1) ? (x[h >> 1] >> 16) : (x[h >> 1] & 0xFFFFu);
-                        const uint32_t r = (d & 0x1FFFu) + bw, bb = d >> 13;
-                        if (r < (uint32_t)W && bb < 4) atomicAdd(&cnt[bb * W + r], 1u);
+                        const uint32_t r = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1), 13) + bw;
+                        const uint32_t bb = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1) + 13, 3);
+                        atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u);
                     }
                 } else if (FMT == 4) {
                     const uint32_t bw = gb[u] - w0;
                     const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                     for (int h = 0; h < 4; h++) {
-                        const uint32_t r = (x[h] & 0xFFFFu) + bw, bb = (x[h] >> 24) & 7u;
-                        if (r < (uint32_t)W && bb < 4) atomicAdd(&cnt[bb * W + r], 1u);
+                        const uint32_t r = (x[h] & 0xFFFFu) + bw, bb = __builtin_amdgcn_ubfe(x[h], 24, 3);
+                        atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u);
                     }
                 } else {
                     const uint32_t g0 = v[u].x, a0 = v[u].y, g1 = v[u].z, a1 = v[u].w;
@@ -638,10 +642,10 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                     if (rel >= (uint32_t)W) continue;
                     if (mm >= (uint32_t)M) { bad_mm = 1; continue; }
                     if (base < 4) {
-                        if (PACKED) atomicAdd(&cnt[(mm * 2 + (base >> 1)) * W + rel], 1u << (16 * (base & 1)));
-                        else atomicAdd(&cnt[(mm * 4 + base) * W + rel], 1u);
+                        if (PACKED) atomicAdd(&cnt[__umul24(mm * 2 + (base >> 1), (uint32_t)W) + rel], 1u << (16 * (base & 1)));
+                        else atomicAdd(&cnt[__umul24(mm * 4 + base, (uint32_t)W) + rel], 1u);
                     } else if (!COMPACT || base != 7u) {            // 7 = padding record of the compact stream
-                        atomicOr(&pres[(mm >> 5) * W + rel], 1u << (mm & 31));
+                        atomicOr(&pres[__umul24(mm >> 5, (uint32_t)W) + rel], 1u << (mm & 31));
                     }
                 }
             }
