@@ -21,6 +21,7 @@ void isx_set_error(const std::string &msg) { g_err = msg; }
 struct isx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    struct isx_batch *unpublished = nullptr;   // batch whose last pass has no publication enqueued yet (see launch_pass)
     uint8_t *d_lut = nullptr;
     std::vector<int32_t> h_lut;
     int32_t lut_n = 0, fallback = 0;
@@ -49,7 +50,7 @@ struct isx_batch {
     uint2 *d_win = nullptr;
     uint16_t *d_thr = nullptr;
     int qcap = 1024, rqcap = 0, stage_off = 0;
-    bool in_flight = false;
+    bool in_flight = false, publish_enqueued = true;
     int64_t *d_bounds = nullptr;
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
@@ -198,6 +199,7 @@ int isx_set_null_model(isx_ctx *c, const int32_t *lut, int64_t n, int32_t fallba
 void isx_batch_destroy(isx_batch *b)
 {
     if (!b) return;
+    if (b->ctx->unpublished == b) b->ctx->unpublished = nullptr;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     void *ps[] = {b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
@@ -634,11 +636,22 @@ static int launch_pass(isx_batch *b)
     a.cursors = b->d_cursors; a.flags = b->d_flags; a.host_state = b->d_host_state;
     memcpy(a.base, b->base, sizeof(a.base));
 
+    // Publication of the cursors (k_publish_state) is deferred: if another pass follows on the stream, its
+    // kernel publishes this one's state as it starts (one kernel per step, no extra boundary); otherwise
+    // isx_batch_wait enqueues the one-wave kernel itself.
+    if (c->unpublished && c->unpublished != b) {
+        isx_batch *u = c->unpublished;
+        a.pub_cursors = u->d_cursors; a.pub_host_state = u->d_host_state; a.pub_epoch = u->epoch;
+        u->publish_enqueued = true;
+        c->unpublished = nullptr;
+    }
     HIP_TRY(hipEventRecord(b->ev[0], s));
     launch_pileup(a, b->block, b->lds, b->grid, b->packed, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[1], s));
-    launch_publish_state(a, ++b->epoch, s);
+    ++b->epoch;
+    b->publish_enqueued = false;
+    c->unpublished = b;
     b->in_flight = true;
     return ISX_OK;
 }
@@ -652,6 +665,13 @@ static int finish_pass(isx_batch *b, uint32_t *cap_flags)
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     b->in_flight = false;
+    if (!b->publish_enqueued) {
+        PileupArgs pa{};
+        pa.cursors = b->d_cursors; pa.host_state = b->d_host_state;
+        launch_publish_state(pa, b->epoch, s);
+        b->publish_enqueued = true;
+        if (c->unpublished == b) c->unpublished = nullptr;
+    }
     {   // spin on the epoch word for a while (no interrupt latency), then fall back to a stream wait
         volatile uint32_t *ep = b->h_state + CUR_N + 4;
         const auto t0 = std::chrono::steady_clock::now();

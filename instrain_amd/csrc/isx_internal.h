@@ -159,6 +159,11 @@ struct PileupArgs {
     uint32_t *flags;
     uint32_t base[CUR_N];       // cursor values when this run started (host copy of the last read-back)
     uint32_t *host_state;       // mapped pinned [CUR_N + 4]: k_publish_state copies cursors | flags here
+    // deferred publication of the PREVIOUS pass on this stream (pipelined launches): workgroup 0 copies that
+    // pass's cursors to its host state before it starts -- one kernel per step instead of two
+    const uint32_t *pub_cursors;
+    uint32_t *pub_host_state;
+    uint32_t pub_epoch;
 };
 
 void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s);   // compact when a.rec32

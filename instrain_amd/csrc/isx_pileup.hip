@@ -74,6 +74,17 @@ __global__ void k_publish_state(const uint32_t *cursors, uint32_t *host_state, u
     if (i == 0) __hip_atomic_store(&host_state[CUR_N + 4], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the same publication from inside a pileup kernel (first wave of workgroup 0): the state of the pass that
+// ran before this kernel on the stream, complete at this point by stream order
+__device__ __forceinline__ void publish_previous(const PileupArgs &a, int tid)
+{
+    if (a.pub_cursors == nullptr || blockIdx.x != 0 || tid >= 64) return;
+    if (tid < CUR_N + 4) a.pub_host_state[tid] = __hip_atomic_load(&a.pub_cursors[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (tid == 0) __hip_atomic_store(&a.pub_host_state[CUR_N + 4], a.pub_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ int argmax4(const uint32_t *c)
 {
     int b = 0;
@@ -329,6 +340,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
+    publish_previous(a, tid);
     const int W = a.W;
     uint32_t *cnt = lds;
     uint32_t *queue = lds + 4 * W;
@@ -559,6 +571,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
+    publish_previous(a, tid);
     const int W = a.W, M = a.M;
     const int n_cnt = M * (PACKED ? 2 : 4) * W;
     const int pres_words = (M + 31) >> 5;
