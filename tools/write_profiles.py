@@ -21,7 +21,7 @@ open('profiles/r01_c2_kernel_stats.md', 'w').write(f'''# Round 1 — rocprofv3 -
 
 Command (tools/make_profiles.sh): `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python bench.py --steps 30 --warmup 4 --no-cpu-baseline --no-linkage-leg --no-mm-leg`
 
-k_pileup_dense<false, true> (linkage off, compact 4-byte record stream) average {avg:.1f} us (rocprof) vs {ev:.1f} us (HIP events inside the
+k_pileup_dense<false, 2> (linkage off, 2-byte record stream) average {avg:.1f} us (rocprof) vs {ev:.1f} us (HIP events inside the
 un-profiled bench.py run of the same box, profiles/r01_bench_n1.json): agree within {abs(avg - ev) / avg * 100:.1f} %.
 (44 calls = 4 warm-up + 10 blocking + 30 timed steps.)
 
@@ -43,7 +43,7 @@ am = j['mm_on']['roofline']['algorithmic_bytes_per_launch']
 open('profiles/r01_c2_pmc.md', 'w').write(f'''# Round 1 — HBM traffic of the pileup kernels on C2 (separate --pmc passes, bench.py --steps 5 --no-linkage-leg)
 
 FETCH_SIZE / WRITE_SIZE are in KiB. gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced streaming reads, so read bytes = FETCH_SIZE x 1024 x 2.
-Algorithmic bytes are priced on the resident layout: {j["roofline"]["record_bytes"]} bytes per observation (compact records), 1 B/pos reference, 20 B/pos (dense) or 32 B/entry (mm) out.
+Algorithmic bytes are priced on the resident layout: {j["roofline"]["record_bytes"]} bytes per observation for one mm bin, 4 with mm profiling on, 1 B/pos reference, 20 B/pos (dense) or 32 B/entry (mm) out.
 
 * k_pileup_dense (C2, skip-mm, W = {j["config"]["window"]}): read {rd/1e6:.1f} MB + written {wr/1e6:.1f} MB = **{(rd+wr)/1e6:.1f} MB per launch** vs {ad/1e6:.1f} MB algorithmic = {(rd+wr)/ad:.2f}x (window over-scan of the record stream).
 * k_pileup_mm (C2, mm on, W = {j["mm_on"]["roofline"]["window"]}): read {rm/1e6:.1f} MB + written {wmm/1e6:.1f} MB = {(rm+wmm)/1e6:.1f} MB vs {am/1e6:.1f} MB algorithmic = {(rm+wmm)/am:.2f}x.
