@@ -166,7 +166,10 @@ int isx_set_null_model(isx_ctx *ctx, const int32_t *lut, int64_t n, int32_t fall
  *   obs[n_obs]    packed observations in BAM arrival order (position-clustered)
  *   pair[n_obs]   dense read-pair id of each observation (both mates share it); may be NULL
  *                 when enable_linkage == 0
- * Host buffers may be freed after the call returns.
+ * Host buffers may be freed after the call returns.  The observations are re-encoded while they are staged
+ * for the upload: 2 bytes per record on the device when n_mm_bins == 1, 4 bytes otherwise (a position delta
+ * to the base of the record's group, mm, base code; isx_timings.record_bytes tells which), so a pass reads a
+ * quarter / half of what isx_obs occupies on the host.
  */
 int isx_batch_create(isx_ctx *ctx, const isx_params *params, int64_t n_pos, const uint8_t *ref,
                      int32_t n_splits, const int64_t *split_bounds, int64_t n_obs,
