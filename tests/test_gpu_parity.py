@@ -238,6 +238,48 @@ def test_database_like_stream_with_many_jumps(ctx):
         util.assert_same(util.canon_from_struct(sub), ce, float_tol=TOL, what="copy %d" % k)
 
 
+@pytest.mark.parametrize("skip_mm", [True, False])
+def test_jumpy_stream_all_formats_agree(ctx, skip_mm, monkeypatch):
+    """a 240 kbp workload torn into 3 kbp islands 9-70 kbp apart (jumps in most record groups, some below and
+    some above the 13-bit / 16-bit delta limits): the 2-byte / 4-byte streams with their cut-and-pad layout
+    must give exactly what the plain 8-byte stream gives"""
+    from instrain_amd import engine, synth
+    w = synth.make_workload(genome_len=240_000, coverage=40, n_sites=2400, seed=31, skip_mm=skip_mm, err=0.003, af_lo=0.2)
+    rng = np.random.Generator(np.random.PCG64(7))
+    isl = 3000
+    gaps = rng.choice([0, 9_000, 70_000], size=240_000 // isl)
+    shift = np.cumsum(gaps) - gaps[0]
+    obs = w["obs"].copy()
+    obs["gpos"] = obs["gpos"] + shift[obs["gpos"] // isl].astype(np.uint32)
+    n_pos = int(240_000 + shift[-1])
+    ref = np.zeros(n_pos, dtype=np.uint8)
+    idx = np.arange(240_000)
+    ref[idx + shift[idx // isl]] = w["ref_codes"]
+    bounds = np.unique(np.r_[0, (np.arange(0, 240_000, isl) + shift), n_pos])
+    M = w["n_mm_bins"]
+    res = {}
+    for name, env in (("compact", {}), ("wide", {"ISX_WIDE_RECORDS": "1"}), ("four", {"ISX_NO_SHORT_RECORDS": "1"})):
+        for k in ("ISX_WIDE_RECORDS", "ISX_NO_SHORT_RECORDS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        b = engine.Batch(ctx, ref, bounds, obs, w["pair"], n_mm_bins=M, seed=3, min_snp=5)
+        b.run()
+        res[name] = (b.timings()["record_bytes"], b.fetch(), b.sizes())
+        b.close()
+    assert res["compact"][0] == (2 if M == 1 else 4) and res["wide"][0] == 8 and res["four"][0] == 4
+    assert res["wide"][2]["n_ld"] > 200 and res["wide"][2]["n_snv"] > 500
+    for name in ("compact", "four"):
+        assert res[name][2] == res["wide"][2]
+        for k, a in res["wide"][1].items():
+            g = res[name][1][k]
+            if a.dtype.names:
+                for f in a.dtype.names:
+                    np.testing.assert_array_equal(g[f], a[f], err_msg="%s %s.%s" % (name, k, f))
+            else:
+                np.testing.assert_array_equal(g, a, err_msg="%s %s" % (name, k))
+
+
 @pytest.mark.parametrize("name", ["synth_mm4", "synth_m1", "synth_dense", "synth_ambig"])
 def test_wide_record_stream_equals_golden(ctx, name, monkeypatch):
     """ISX_WIDE_RECORDS forces the 8-byte stream (isx_obs as is) that the library otherwise only falls back to"""
