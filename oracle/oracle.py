@@ -90,7 +90,7 @@ def generate_snp_model(model_file, fdr=1e-6):
 
 
 def profile_split(pos, base, mm, pair, seq, start, lut, fallback, min_cov=5, min_freq=0.05,
-                  min_snp=20):
+                  min_snp=20, convert=True):
     """Run the C oracle on one split's packed observations. Returns dict of structured arrays
     (positions absolute) + n_edges / n_increments."""
     lib = _lib()
@@ -103,6 +103,11 @@ def profile_split(pos, base, mm, pair, seq, start, lut, fallback, min_cov=5, min
     r = lib.orc_profile_split(len(pos), pos.ctypes.data, base.ctypes.data, mm.ctypes.data,
                               pair.ctypes.data, seqb, len(seqb), int(start), lut.ctypes.data,
                               len(lut), int(fallback), int(min_cov), float(min_freq), int(min_snp))
+    if not convert:             # timing only (bench.py's cpu_baseline): sizes, no table copies
+        rc = r.contents
+        out = {"n_entries": int(rc.n_entries), "n_snv": int(rc.n_snv), "n_ld": int(rc.n_ld)}
+        lib.orc_free(r)
+        return out
     try:
         rc = r.contents
         out = {"entries": _copy(rc.entries, rc.n_entries, ENTRY_DT),
