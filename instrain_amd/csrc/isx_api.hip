@@ -129,6 +129,279 @@ static int regrow(T **p, size_t *cap, size_t hard_max, size_t elem_pad = 0)
     return ISX_OK;
 }
 
+// The resident observation stream of a batch: built from the caller's isx_obs while they are staged for
+// the upload (pinned, double buffered), together with the per-1024-record min/max directory the window
+// ranges come from.
+//   short stream    2 bytes per record (delta:13 | base:3, groups of 512)      n_mm_bins == 1
+//   compact stream  4 bytes per record (delta:16 | mm:8 | base:3, groups of 256) mm profiling on
+//   wide stream     isx_obs as is (8 bytes)   only for an mm level >= 256 (legal for no n_mm_bins) or when forced
+// A group must span less than the delta range.  Where the stream jumps further (an uncovered stretch, the
+// next genome of a database) the group is closed early and padded, so device record i is no longer input
+// record i: og_start / og_count map every device group to its run of input records (built only when a
+// jump exists; the pair ids follow the same map).
+struct ObsStream {
+    isx_ctx *c;
+    isx_batch *b;
+    const isx_obs *obs;
+    const uint32_t *pair;
+    const int64_t n_obs, n_pos;
+    uint64_t n_chunks = 0;                          // directory: per ISX_CHUNK device records
+    std::vector<uint32_t> cmin, cmax;
+    std::vector<uint8_t> cany;
+    std::vector<uint64_t> og_start;                 // empty = identity (device group g starts at input record G g)
+    std::vector<uint16_t> og_count;
+    std::vector<uint32_t> gbase;
+    uint64_t G = ISX_GROUP;                         // records per position base
+    uint32_t SPAN = 65535u;                         // a group must span less than this
+    bool want16 = false, bad_pos = false;
+    std::atomic<int> too_wide{0}, has_jump{0};
+
+    ObsStream(isx_ctx *c_, isx_batch *b_, const isx_obs *obs_, const uint32_t *pair_, int64_t n_obs_, int64_t n_pos_)
+        : c(c_), b(b_), obs(obs_), pair(pair_), n_obs(n_obs_), n_pos(n_pos_)
+    {
+        static_assert(sizeof(isx_obs) == sizeof(uint2), "isx_obs must be the 8-byte device record");
+        want16 = b->M == 1 && !getenv("ISX_NO_SHORT_RECORDS");
+        G = want16 ? ISX_GROUP16 : ISX_GROUP;
+        SPAN = want16 ? 8191u : 65535u;
+        too_wide.store(getenv("ISX_WIDE_RECORDS") ? 1 : 0);         // env: force the wide stream (tests / A-B)
+        reset_directory();
+    }
+
+    void reset_directory()
+    {
+        n_chunks = b->n_rec / ISX_CHUNK;
+        cmin.assign(n_chunks, 0xFFFFFFFFu); cmax.assign(n_chunks, 0u); cany.assign(n_chunks, 0);
+        bad_pos = false;
+    }
+
+    // a few host threads fill the pinned buffer (a single core copies at ~10 GB/s, PCIe Gen5 takes 63);
+    // work(a0, a1, bad): element range of the piece, multiples of ISX_CHUNK
+    template <class W>
+    void fill_threads(uint64_t cnt, W &&work)
+    {
+        const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(16, cnt / (64 * ISX_CHUNK)));
+        const uint64_t per_t = ((cnt + nt - 1) / nt + ISX_CHUNK - 1) / ISX_CHUNK * ISX_CHUNK;
+        std::vector<std::thread> th;
+        std::vector<int> bad(nt, 0);
+        auto run = [&](unsigned t) {
+            const uint64_t a0 = std::min<uint64_t>(cnt, (uint64_t)t * per_t), a1 = std::min<uint64_t>(cnt, a0 + per_t);
+            work(a0, a1, bad[t]);
+        };
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(run, t);
+        run(0);
+        for (auto &x : th) x.join();
+        for (int v : bad) if (v) bad_pos = true;
+    }
+
+    uint64_t input_run(uint64_t dev_group, const isx_obs *&src) const      // records of a device group
+    {
+        if (og_start.empty()) {
+            const uint64_t g0 = dev_group * G;
+            src = obs + g0;
+            return g0 < (uint64_t)n_obs ? std::min<uint64_t>(G, (uint64_t)n_obs - g0) : 0;
+        }
+        if (dev_group >= og_start.size()) { src = obs; return 0; }
+        src = obs + og_start[dev_group];
+        return og_count[dev_group];
+    }
+
+    // one group: directory + base + encoded records (T = uint32_t compact / uint16_t short)
+    template <class T>
+    bool encode_group(T *dst, uint64_t dev_first, int &bad)
+    {
+        const uint64_t dg = dev_first / G;
+        const isx_obs *src;
+        const uint64_t n_real = input_run(dg, src);
+        uint32_t lo = 0xFFFFFFFFu, hi = 0, mmax = 0;
+        for (uint64_t i = 0; i < n_real; i++) {
+            const uint32_t g = src[i].gpos;
+            lo = g < lo ? g : lo; hi = g > hi ? g : hi; mmax = src[i].mm > mmax ? src[i].mm : mmax;
+        }
+        if (n_real) {
+            if (mmax >= 256u) { too_wide.store(1); return false; }
+            if (hi - lo >= SPAN) { has_jump.store(1); return false; }              // identity layout only: the map has none
+            if ((int64_t)hi >= n_pos) bad = 1;
+            const uint64_t ch = dev_first / ISX_CHUNK;             // the groups of a chunk belong to one thread
+            cmin[ch] = std::min(cmin[ch], lo); cmax[ch] = std::max(cmax[ch], hi); cany[ch] = 1;
+            gbase[dg] = lo;
+        }
+        for (uint64_t i = 0; i < n_real; i++) {
+            const uint32_t bc = src[i].base > 4 ? 4u : (uint32_t)src[i].base;
+            if (sizeof(T) == 2) dst[i] = (T)((src[i].gpos - lo) | (bc << 13));
+            else dst[i] = (T)((src[i].gpos - lo) | ((uint32_t)src[i].mm << 16) | (bc << 24));
+        }
+        for (uint64_t i = n_real; i < G; i++) dst[i] = sizeof(T) == 2 ? (T)0xFFFFu : (T)ISX_PAD32;
+        return true;
+    }
+
+    template <class T>
+    int upload_encoded(T **d_dst)
+    {
+        HIP_TRY(hipMalloc(d_dst, b->n_rec * sizeof(T)));
+        return staged_upload(c, *d_dst, b->n_rec, [&](T *dst, uint64_t first, uint64_t cnt) {
+            if (too_wide.load() || has_jump.load()) return;
+            fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
+                for (uint64_t i0 = a0; i0 < a1; i0 += G)                   // `first`, a0, a1 are multiples of ISX_CHUNK
+                    if (!encode_group(dst + i0, first + i0, bad)) return;
+            });
+        });
+    }
+
+    int upload_compact()                            // ISX_OK, or 1 = start over (jump found / too wide)
+    {
+        const uint64_t n_groups = b->n_rec / G;
+        gbase.assign(n_groups, 0u);
+        const int rc = want16 ? upload_encoded(&b->d_rec16) : upload_encoded(&b->d_rec32);
+        if (rc != ISX_OK) return rc;
+        if (too_wide.load() || has_jump.load()) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (b->d_rec32) (void)hipFree(b->d_rec32);
+            if (b->d_rec16) (void)hipFree(b->d_rec16);
+            b->d_rec32 = nullptr; b->d_rec16 = nullptr;
+            return 1;
+        }
+        HIP_TRY(hipMalloc(&b->d_gbase, std::max<uint64_t>(n_groups, 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(b->d_gbase, gbase.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return ISX_OK;
+    }
+
+    // the stream jumps: cut the input into runs that fit a group (greedy, arrival order), per input group in
+    // parallel, then lay the runs out one device group each
+    int cut_at_jumps()
+    {
+        const uint64_t n_in = ((uint64_t)n_obs + G - 1) / G;
+        const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(16, n_in / 4096 + 1));
+        std::vector<std::vector<std::pair<uint64_t, uint16_t>>> parts(nt);
+        std::vector<std::thread> th;
+        auto cut = [&](unsigned t) {
+            auto &out = parts[t];
+            for (uint64_t g = n_in * t / nt; g < n_in * (t + 1) / nt; g++) {
+                const uint64_t s0 = g * G, s1 = std::min<uint64_t>((uint64_t)n_obs, s0 + G);
+                uint64_t run0 = s0;
+                uint32_t lo = 0xFFFFFFFFu, hi = 0;
+                for (uint64_t i = s0; i < s1; i++) {
+                    const uint32_t p = obs[i].gpos;
+                    const uint32_t nlo = p < lo ? p : lo, nhi = p > hi ? p : hi;
+                    if (i > run0 && nhi - nlo >= SPAN) {
+                        out.emplace_back(run0, (uint16_t)(i - run0));
+                        run0 = i; lo = hi = p;
+                    } else { lo = nlo; hi = nhi; }
+                }
+                if (s1 > run0) out.emplace_back(run0, (uint16_t)(s1 - run0));
+            }
+        };
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(cut, t);
+        cut(0);
+        for (auto &x : th) x.join();
+        size_t total = 0;
+        for (auto &v : parts) total += v.size();
+        og_start.reserve(total); og_count.reserve(total);
+        for (auto &v : parts) for (auto &r : v) { og_start.push_back(r.first); og_count.push_back(r.second); }
+        const uint64_t want = (uint64_t)og_start.size() * G;
+        b->n_rec = std::max<uint64_t>(ISX_PAD, (want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
+        if (b->n_rec >= 0xFFFFFFFFull) { isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
+        return ISX_OK;
+    }
+
+    // wide stream: isx_obs already has the device record layout (gpos | mm, base << 16, flags << 24): plain
+    // copy into the pinned buffer, then one vectorisable sweep per chunk for the min/max directory
+    int upload_wide()
+    {
+        HIP_TRY(hipMalloc(&b->d_rec, b->n_rec * sizeof(uint2)));
+        return staged_upload(c, b->d_rec, b->n_rec, [&](uint2 *dst, uint64_t first, uint64_t cnt) {
+            fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
+                for (uint64_t i0 = a0; i0 < a1; i0 += ISX_CHUNK) {
+                    const uint64_t i1 = std::min<uint64_t>(a1, i0 + ISX_CHUNK);
+                    const uint64_t g0 = first + i0;
+                    const uint64_t n_real = g0 < (uint64_t)n_obs ? std::min<uint64_t>(i1 - i0, (uint64_t)n_obs - g0) : 0;
+                    if (n_real) memcpy(dst + i0, obs + g0, n_real * sizeof(uint2));
+                    for (uint64_t i = i0 + n_real; i < i1; i++) dst[i] = make_uint2(ISX_SENTINEL, 0);
+                    if (!n_real) continue;
+                    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+                    for (uint64_t i = i0; i < i0 + n_real; i++) { const uint32_t g = dst[i].x; lo = g < lo ? g : lo; hi = g > hi ? g : hi; }
+                    const uint64_t ch = g0 / ISX_CHUNK;
+                    cmin[ch] = lo; cmax[ch] = hi; cany[ch] = 1;
+                    if ((int64_t)hi >= n_pos) bad = 1;
+                }
+            });
+        });
+    }
+
+    int upload_records()
+    {
+        int rc;
+        if (!too_wide.load()) {
+            rc = upload_compact();
+            if (rc < 0) return rc;
+            if (rc == 1 && has_jump.load() && !too_wide.load()) {
+                if ((rc = cut_at_jumps()) != ISX_OK) return rc;
+                reset_directory();
+                has_jump.store(0);
+                rc = upload_compact();
+                if (rc < 0) return rc;
+                if (rc == 1 && !too_wide.load()) { isx_set_error("internal: a cut run still spans too many positions"); return ISX_ERR_STATE; }
+            }
+            if (!b->d_rec32 && !b->d_rec16) {       // mm >= 256 somewhere: back to the plain layout
+                og_start.clear(); og_count.clear();
+                b->n_rec = std::max<uint64_t>(ISX_PAD, ((uint64_t)n_obs + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
+                reset_directory();
+            }
+        }
+        if (!b->d_rec32 && !b->d_rec16 && (rc = upload_wide()) != ISX_OK) return rc;
+        if (bad_pos) { isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
+        return ISX_OK;
+    }
+
+    // linkage: pair ids in device record order; positions alone for the allele pass -- 2-byte deltas to the
+    // group base with the compact stream (always possible), to the chunk's lowest position with the wide one
+    // when every chunk spans < 65535 positions, else the 4-byte positions; the short stream is read itself
+    int upload_linkage_arrays()
+    {
+        HIP_TRY(hipMalloc(&b->d_pair, b->n_rec * sizeof(uint32_t)));
+        if (!b->d_rec16) {
+            bool narrow = true;
+            if (!b->d_rec32) for (uint64_t i = 0; i < n_chunks; i++) if (cany[i] && cmax[i] - cmin[i] >= 65535u) { narrow = false; break; }
+            std::vector<uint32_t> cb;
+            if (narrow) {
+                HIP_TRY(hipMalloc(&b->d_gpos16, b->n_rec * sizeof(uint16_t)));
+                if (b->d_rec32) { b->gpos16_shift = 5; }                 // base per ISX_GROUP = 32 loads of 8 records
+                else {
+                    cb.assign(cmin.begin(), cmin.end());
+                    for (uint64_t i = 0; i < n_chunks; i++) if (!cany[i]) cb[i] = 0;
+                    HIP_TRY(hipMalloc(&b->d_cbase, std::max<uint64_t>(n_chunks, 1) * sizeof(uint32_t)));
+                    HIP_TRY(hipMemcpyAsync(b->d_cbase, cb.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                    b->gpos16_shift = 7;                                 // base per ISX_CHUNK = 128 loads
+                }
+            } else {
+                HIP_TRY(hipMalloc(&b->d_gpos, b->n_rec * sizeof(uint32_t)));
+            }
+            launch_extract_gpos(b->d_rec, b->d_rec32, b->d_gbase, b->d_gpos, b->d_gpos16, b->d_rec32 ? b->d_gbase : b->d_cbase,
+                                b->d_rec32 ? ISX_GROUP : ISX_CHUNK, b->n_rec, c->stream);
+            HIP_TRY(hipStreamSynchronize(c->stream));                     // cb is a local
+        }
+        uint32_t maxp = 0;
+        const int rc = staged_upload(c, b->d_pair, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
+            if (og_start.empty()) {
+                for (uint64_t i = 0; i < cnt; i++) {
+                    const uint64_t g = first + i;
+                    dst[i] = g < (uint64_t)n_obs ? pair[g] : 0u;
+                    if (g < (uint64_t)n_obs) maxp = std::max(maxp, pair[g]);
+                }
+            } else {                                                      // device group -> run of input records
+                for (uint64_t i0 = 0; i0 < cnt; i0 += G) {
+                    const uint64_t dg = (first + i0) / G;
+                    const uint64_t n_real = dg < og_start.size() ? og_count[dg] : 0;
+                    for (uint64_t i = 0; i < n_real; i++) { dst[i0 + i] = pair[og_start[dg] + i]; maxp = std::max(maxp, dst[i0 + i]); }
+                    for (uint64_t i = n_real; i < G; i++) dst[i0 + i] = 0u;
+                }
+            }
+        });
+        b->n_pairs = (uint64_t)maxp + 1;
+        return rc;
+    }
+};
+
+
 extern "C" {
 
 const char *isx_last_error(void) { return g_err.c_str(); }
@@ -307,230 +580,16 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     BH(hipMalloc(&b->d_sites, b->cap_sites * sizeof(isx_site)));
     if (prm->enable_linkage) BH(hipMalloc(&b->d_ao, b->cap_ao * sizeof(isx_ao)));
 
-    // ---- observation stream: pinned, double-buffered upload + per-chunk min/max directory ----
-    uint64_t n_chunks = b->n_rec / ISX_CHUNK;
-    std::vector<uint32_t> cmin(n_chunks, 0xFFFFFFFFu), cmax(n_chunks, 0u);
-    std::vector<uint8_t> cany(n_chunks, 0);
-    bool bad_pos = false;
-    // Compact stream (the normal case): 4 bytes per record -- a 16-bit delta to the lowest position of the
-    // record's group of 256, the mm level in 8 bits, the base code -- encoded by a few host threads while
-    // they fill the pinned buffer (half the PCIe and half the HBM bytes of the 8-byte isx_obs).
-    // A group must span < 65535 positions.  Where the stream jumps further (an uncovered stretch, the next
-    // genome of a database), the group is closed early and padded, so device record i is no longer input
-    // record i: `og_start / og_count` map every device group to its run of input records (built only when
-    // a jump exists; the pair ids follow the same map).  mm >= 256 (legal for no n_mm_bins) -> wide stream.
-    static_assert(sizeof(isx_obs) == sizeof(uint2), "isx_obs must be the 8-byte device record");
-    std::vector<uint64_t> og_start;                 // empty = identity (device group g starts at input record 256 g)
-    std::vector<uint16_t> og_count;
-    std::atomic<int> too_wide{getenv("ISX_WIDE_RECORDS") ? 1 : 0};      // env: force the wide stream (tests / A-B)
-    std::atomic<int> has_jump{0};
-    auto fill_threads = [&](uint64_t cnt, auto &&work) {
-        // a few host threads fill the pinned buffer (a single core copies at ~10 GB/s, PCIe Gen5 takes 63)
-        const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(16, cnt / (64 * ISX_CHUNK)));
-        const uint64_t per_t = ((cnt + nt - 1) / nt + ISX_CHUNK - 1) / ISX_CHUNK * ISX_CHUNK;
-        std::vector<std::thread> th;
-        std::vector<int> bad(nt, 0);
-        auto run = [&](unsigned t) {
-            const uint64_t a0 = std::min<uint64_t>(cnt, (uint64_t)t * per_t), a1 = std::min<uint64_t>(cnt, a0 + per_t);
-            work(a0, a1, bad[t]);
-        };
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(run, t);
-        run(0);
-        for (auto &x : th) x.join();
-        for (int v : bad) if (v) bad_pos = true;
-    };
-    // stream format: 2-byte records when there is one mm bin (delta:13 | base:3, groups of 512), else 4-byte
-    const bool want16 = b->M == 1 && !getenv("ISX_NO_SHORT_RECORDS");
-    const uint64_t G = want16 ? ISX_GROUP16 : ISX_GROUP;             // records per position base
-    const uint32_t SPAN = want16 ? 8191u : 65535u;                   // a group must span less than this
-    auto input_run = [&](uint64_t dev_group, const isx_obs *&src) -> uint64_t {     // records of a device group
-        if (og_start.empty()) {
-            const uint64_t g0 = dev_group * G;
-            src = obs + g0;
-            return g0 < (uint64_t)n_obs ? std::min<uint64_t>(G, (uint64_t)n_obs - g0) : 0;
-        }
-        if (dev_group >= og_start.size()) { src = obs; return 0; }
-        src = obs + og_start[dev_group];
-        return og_count[dev_group];
-    };
-    std::vector<uint32_t> gbase;
-    // one group: directory + base + encoded records (T = uint32_t compact / uint16_t short)
-    auto encode_group = [&](auto *dst, uint64_t dev_first, int &bad) -> bool {
-        const uint64_t dg = dev_first / G;
-        const isx_obs *src;
-        const uint64_t n_real = input_run(dg, src);
-        uint32_t lo = 0xFFFFFFFFu, hi = 0, mmax = 0;
-        for (uint64_t i = 0; i < n_real; i++) {
-            const uint32_t g = src[i].gpos;
-            lo = g < lo ? g : lo; hi = g > hi ? g : hi; mmax = src[i].mm > mmax ? src[i].mm : mmax;
-        }
-        using T = std::remove_reference_t<decltype(*dst)>;
-        if (n_real) {
-            if (mmax >= 256u) { too_wide.store(1); return false; }
-            if (hi - lo >= SPAN) { has_jump.store(1); return false; }              // identity layout only: the map has none
-            if ((int64_t)hi >= n_pos) bad = 1;
-            const uint64_t ch = dev_first / ISX_CHUNK;             // the groups of a chunk belong to one thread
-            cmin[ch] = std::min(cmin[ch], lo); cmax[ch] = std::max(cmax[ch], hi); cany[ch] = 1;
-            gbase[dg] = lo;
-        }
-        for (uint64_t i = 0; i < n_real; i++) {
-            const uint32_t bc = src[i].base > 4 ? 4u : (uint32_t)src[i].base;
-            if (sizeof(T) == 2) dst[i] = (T)((src[i].gpos - lo) | (bc << 13));
-            else dst[i] = (T)((src[i].gpos - lo) | ((uint32_t)src[i].mm << 16) | (bc << 24));
-        }
-        for (uint64_t i = n_real; i < G; i++) dst[i] = sizeof(T) == 2 ? (T)0xFFFFu : (T)ISX_PAD32;
-        return true;
-    };
-    auto upload_compact = [&]() -> int {            // ISX_OK, or 1 = start over (jump found / too wide)
-        const uint64_t n_groups = b->n_rec / G;
-        gbase.assign(n_groups, 0u);
-        int rc;
-        auto fill = [&](auto *dst, uint64_t first, uint64_t cnt) {
-            if (too_wide.load() || has_jump.load()) return;
-            fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
-                for (uint64_t i0 = a0; i0 < a1; i0 += G)                   // `first`, a0, a1 are multiples of ISX_CHUNK
-                    if (!encode_group(dst + i0, first + i0, bad)) return;
-            });
-        };
-        if (want16) {
-            HIP_TRY(hipMalloc(&b->d_rec16, b->n_rec * sizeof(uint16_t)));
-            rc = staged_upload(c, b->d_rec16, b->n_rec, [&](uint16_t *dst, uint64_t first, uint64_t cnt) { fill(dst, first, cnt); });
-        } else {
-            HIP_TRY(hipMalloc(&b->d_rec32, b->n_rec * sizeof(uint32_t)));
-            rc = staged_upload(c, b->d_rec32, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) { fill(dst, first, cnt); });
-        }
-        if (rc != ISX_OK) return rc;
-        if (too_wide.load() || has_jump.load()) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (b->d_rec32) (void)hipFree(b->d_rec32);
-            if (b->d_rec16) (void)hipFree(b->d_rec16);
-            b->d_rec32 = nullptr; b->d_rec16 = nullptr;
-            return 1;
-        }
-        HIP_TRY(hipMalloc(&b->d_gbase, std::max<uint64_t>(n_groups, 1) * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(b->d_gbase, gbase.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
-        return ISX_OK;
-    };
-    auto reset_directory = [&]() {
-        n_chunks = b->n_rec / ISX_CHUNK;
-        cmin.assign(n_chunks, 0xFFFFFFFFu); cmax.assign(n_chunks, 0u); cany.assign(n_chunks, 0);
-        bad_pos = false;
-    };
-    if (!too_wide.load()) {
-        int rc = upload_compact();
-        if (rc < 0) { isx_batch_destroy(b); return rc; }
-        if (rc == 1 && has_jump.load() && !too_wide.load()) {
-            // the stream jumps: cut the input into runs that fit a group (greedy, arrival order), per input
-            // group in parallel, then lay the runs out one device group each
-            const uint64_t n_in = ((uint64_t)n_obs + G - 1) / G;
-            const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(16, n_in / 4096 + 1));
-            std::vector<std::vector<std::pair<uint64_t, uint16_t>>> parts(nt);
-            std::vector<std::thread> th;
-            auto cut = [&](unsigned t) {
-                auto &out = parts[t];
-                for (uint64_t g = n_in * t / nt; g < n_in * (t + 1) / nt; g++) {
-                    const uint64_t s0 = g * G, s1 = std::min<uint64_t>((uint64_t)n_obs, s0 + G);
-                    uint64_t run0 = s0;
-                    uint32_t lo = 0xFFFFFFFFu, hi = 0;
-                    for (uint64_t i = s0; i < s1; i++) {
-                        const uint32_t p = obs[i].gpos;
-                        const uint32_t nlo = p < lo ? p : lo, nhi = p > hi ? p : hi;
-                        if (i > run0 && nhi - nlo >= SPAN) {
-                            out.emplace_back(run0, (uint16_t)(i - run0));
-                            run0 = i; lo = hi = p;
-                        } else { lo = nlo; hi = nhi; }
-                    }
-                    if (s1 > run0) out.emplace_back(run0, (uint16_t)(s1 - run0));
-                }
-            };
-            for (unsigned t = 1; t < nt; t++) th.emplace_back(cut, t);
-            cut(0);
-            for (auto &x : th) x.join();
-            size_t total = 0;
-            for (auto &v : parts) total += v.size();
-            og_start.reserve(total); og_count.reserve(total);
-            for (auto &v : parts) for (auto &r : v) { og_start.push_back(r.first); og_count.push_back(r.second); }
-            const uint64_t want = (uint64_t)og_start.size() * G;
-            b->n_rec = std::max<uint64_t>(ISX_PAD, (want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
-            if (b->n_rec >= 0xFFFFFFFFull) { isx_batch_destroy(b); isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
-            reset_directory();
-            has_jump.store(0);
-            rc = upload_compact();
-            if (rc < 0) { isx_batch_destroy(b); return rc; }
-            if (rc == 1 && !too_wide.load()) { isx_batch_destroy(b); isx_set_error("internal: a cut run still spans too many positions"); return ISX_ERR_STATE; }
-        }
-        if (!b->d_rec32 && !b->d_rec16) { og_start.clear(); og_count.clear(); b->n_rec = std::max<uint64_t>(ISX_PAD, ((uint64_t)n_obs + ISX_PAD - 1) / ISX_PAD * ISX_PAD); reset_directory(); }
+    // ---- observation stream (+ pair ids / allele-pass positions with linkage): see ObsStream ----
+    ObsStream st(c, b, obs, pair, n_obs, n_pos);
+    {
+        int rc = st.upload_records();
+        if (rc == ISX_OK && prm->enable_linkage) rc = st.upload_linkage_arrays();
+        if (rc != ISX_OK) { isx_batch_destroy(b); return rc; }
     }
-    if (!b->d_rec32 && !b->d_rec16) {
-        // wide stream: isx_obs already has the device record layout (gpos | mm, base << 16, flags << 24): plain
-        // copy into the pinned buffer, then one vectorisable sweep per chunk for the min/max directory
-        BH(hipMalloc(&b->d_rec, b->n_rec * sizeof(uint2)));
-        BT(staged_upload(c, b->d_rec, b->n_rec, [&](uint2 *dst, uint64_t first, uint64_t cnt) {
-            fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
-                for (uint64_t i0 = a0; i0 < a1; i0 += ISX_CHUNK) {
-                    const uint64_t i1 = std::min<uint64_t>(a1, i0 + ISX_CHUNK);
-                    const uint64_t g0 = first + i0;
-                    const uint64_t n_real = g0 < (uint64_t)n_obs ? std::min<uint64_t>(i1 - i0, (uint64_t)n_obs - g0) : 0;
-                    if (n_real) memcpy(dst + i0, obs + g0, n_real * sizeof(uint2));
-                    for (uint64_t i = i0 + n_real; i < i1; i++) dst[i] = make_uint2(ISX_SENTINEL, 0);
-                    if (!n_real) continue;
-                    uint32_t lo = 0xFFFFFFFFu, hi = 0;
-                    for (uint64_t i = i0; i < i0 + n_real; i++) { const uint32_t g = dst[i].x; lo = g < lo ? g : lo; hi = g > hi ? g : hi; }
-                    const uint64_t ch = g0 / ISX_CHUNK;
-                    cmin[ch] = lo; cmax[ch] = hi; cany[ch] = 1;
-                    if ((int64_t)hi >= n_pos) bad = 1;
-                }
-            });
-        }));
-    }
-    if (bad_pos) { isx_batch_destroy(b); isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
-    if (prm->enable_linkage) {
-        BH(hipMalloc(&b->d_pair, b->n_rec * sizeof(uint32_t)));
-        // the allele pass streams positions only: 2-byte deltas -- to the group base with the compact stream
-        // (always possible), to the chunk's lowest position with the wide one when every chunk spans < 65535
-        // positions -- else the 4-byte positions
-        bool narrow = true;
-        if (!b->d_rec32) for (uint64_t i = 0; i < n_chunks; i++) if (cany[i] && cmax[i] - cmin[i] >= 65535u) { narrow = false; break; }
-        std::vector<uint32_t> cb;
-        if (b->d_rec16) {
-            // short stream: the allele pass reads the 2-byte records themselves
-        } else {
-            if (narrow) {
-                BH(hipMalloc(&b->d_gpos16, b->n_rec * sizeof(uint16_t)));
-                if (b->d_rec32) { b->gpos16_shift = 5; }                 // base per ISX_GROUP = 32 loads of 8 records
-                else {
-                    cb.assign(cmin.begin(), cmin.end());
-                    for (uint64_t i = 0; i < n_chunks; i++) if (!cany[i]) cb[i] = 0;
-                    BH(hipMalloc(&b->d_cbase, std::max<uint64_t>(n_chunks, 1) * sizeof(uint32_t)));
-                    BH(hipMemcpyAsync(b->d_cbase, cb.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-                    b->gpos16_shift = 7;                                 // base per ISX_CHUNK = 128 loads
-                }
-            } else {
-                BH(hipMalloc(&b->d_gpos, b->n_rec * sizeof(uint32_t)));
-            }
-            launch_extract_gpos(b->d_rec, b->d_rec32, b->d_gbase, b->d_gpos, b->d_gpos16, b->d_rec32 ? b->d_gbase : b->d_cbase,
-                                b->d_rec32 ? ISX_GROUP : ISX_CHUNK, b->n_rec, c->stream);
-            BH(hipStreamSynchronize(c->stream));                              // cb is a local
-        }
-        uint32_t maxp = 0;
-        BT(staged_upload(c, b->d_pair, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
-            if (og_start.empty()) {
-                for (uint64_t i = 0; i < cnt; i++) {
-                    const uint64_t g = first + i;
-                    dst[i] = g < (uint64_t)n_obs ? pair[g] : 0u;
-                    if (g < (uint64_t)n_obs) maxp = std::max(maxp, pair[g]);
-                }
-            } else {                                                          // device group -> run of input records
-                for (uint64_t i0 = 0; i0 < cnt; i0 += G) {
-                    const uint64_t dg = (first + i0) / G;
-                    const uint64_t n_real = dg < og_start.size() ? og_count[dg] : 0;
-                    for (uint64_t i = 0; i < n_real; i++) { dst[i0 + i] = pair[og_start[dg] + i]; maxp = std::max(maxp, dst[i0 + i]); }
-                    for (uint64_t i = n_real; i < G; i++) dst[i0 + i] = 0u;
-                }
-            }
-        }));
-        b->n_pairs = (uint64_t)maxp + 1;
-    }
+    const uint64_t n_chunks = st.n_chunks;
+    const std::vector<uint32_t> &cmin = st.cmin, &cmax = st.cmax;
+    const std::vector<uint8_t> &cany = st.cany;
     BT(staged_upload(c, b->d_ref, (uint64_t)n_pos, [&](uint8_t *dst, uint64_t first, uint64_t cnt) {
         memcpy(dst, ref + first, cnt);
     }));
