@@ -437,46 +437,83 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
     auto name_of = [&](const Read &r) { return std::string_view(B.names.data() + r.name_off, r.name_len); };
 
     // ---- get_paired_reads per scaffold (filter_reads.py:885-956) ----
-    std::vector<std::unordered_map<std::string_view, uint32_t>> idx(n_ref);
-    std::vector<PairInfo> pinfo;
-    std::vector<int32_t> read_pi(B.reads.size(), -1);      // read -> index of its (scaffold, name) entry
-    std::vector<RefSpan> spans(B.reads.size());
-    {   // size the per-scaffold name tables up front (no rehash while they fill)
-        std::vector<size_t> per_ref(n_ref, 0);
-        for (const Read &r : B.reads) if (r.tid >= 0 && (size_t)r.tid < n_ref) per_ref[(size_t)r.tid]++;
-        for (size_t t = 0; t < n_ref; t++) idx[t].reserve(per_ref[t] / 2 + 16);
-        pinfo.reserve(B.reads.size() / 2 + 16);
-    }
-    for (size_t ri = 0; ri < B.reads.size(); ri++) {
-        const Read &r = B.reads[ri];
-        if (r.tid < 0 || (size_t)r.tid >= n_ref) continue;
-        spans[ri] = span_of(B, r);
-        if (r.flag & FUNMAP) continue;
-        const RefSpan &s = spans[ri];
-        if (!s.any) continue;                       // get_reference_positions() == []
-        if (!r.has_nm) { isx_set_error("read without NM tag: " + std::string(name_of(r))); return ISX_ERR_IO; }
-        auto &m = idx[(size_t)r.tid];
-        auto it = m.find(name_of(r));
-        if (it == m.end()) {
-            m.emplace(name_of(r), (uint32_t)pinfo.size());
-            read_pi[ri] = (int32_t)pinfo.size();
-            pinfo.push_back(PairInfo{r.nm, -1, r.mapq, s.qlen, 1, s.first, s.last, false, 0});
-        } else {
-            PairInfo &i = pinfo[it->second];
-            read_pi[ri] = (int32_t)it->second;
-            i.nm += r.nm;
-            i.reads += 1;
-            i.length += s.qlen;
-            i.mapq = std::max<int64_t>(i.mapq, r.mapq);
-            if (i.reads == 2) {
-                if (s.last > i.start) i.insert = s.last - i.start;
-                else i.insert = i.stop - s.first;
-            } else {
-                i.insert = -1;
-            }
-            i.start = 0; i.stop = 0;
+    // The (scaffold, read name) -> pair table is hash-partitioned over a few threads: every thread walks all
+    // reads in file order (so a pair's reads meet in file order) but owns only the names that hash to it.
+    struct NameKey {
+        int32_t tid; std::string_view name;
+        bool operator==(const NameKey &o) const { return tid == o.tid && name == o.name; }
+    };
+    struct NameKeyHash {
+        size_t operator()(const NameKey &k) const { return std::hash<std::string_view>()(k.name) * 1000003u ^ (size_t)(uint32_t)k.tid; }
+    };
+    const size_t n_reads_all = B.reads.size();
+    const unsigned NT = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_reads_all / 8192 + 1));
+    std::vector<std::unordered_map<NameKey, uint32_t, NameKeyHash>> maps(NT);      // value: index local to the partition
+    std::vector<std::vector<PairInfo>> part_info(NT);
+    std::vector<int32_t> read_pi(n_reads_all, -1);         // read -> index of its (scaffold, name) entry
+    std::vector<RefSpan> spans(n_reads_all);
+    std::vector<uint8_t> part_of(n_reads_all, 0xFF);       // partition of the read's name (0xFF: not in the table)
+    std::vector<std::string> no_nm(NT);
+    auto run_nt = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < NT; t++) th.emplace_back(fn, t);
+        fn(0u);
+        for (auto &x : th) x.join();
+    };
+    run_nt([&](unsigned t) {                                // spans + partition of every read (read ranges)
+        for (size_t ri = n_reads_all * t / NT; ri < n_reads_all * (t + 1) / NT; ri++) {
+            const Read &r = B.reads[ri];
+            if (r.tid < 0 || (size_t)r.tid >= n_ref) continue;
+            spans[ri] = span_of(B, r);
+            if ((r.flag & FUNMAP) || !spans[ri].any) continue;          // get_reference_positions() == []
+            part_of[ri] = (uint8_t)(NameKeyHash()(NameKey{r.tid, name_of(r)}) % NT);
         }
-    }
+    });
+    run_nt([&](unsigned t) {                                // the tables (name partitions)
+        auto &m = maps[t];
+        auto &pi = part_info[t];
+        m.reserve(n_reads_all / (2 * NT) + 16);
+        pi.reserve(n_reads_all / (2 * NT) + 16);
+        for (size_t ri = 0; ri < n_reads_all; ri++) {
+            if (part_of[ri] != t) continue;
+            const Read &r = B.reads[ri];
+            const RefSpan &s = spans[ri];
+            if (!r.has_nm) { if (no_nm[t].empty()) no_nm[t] = std::string(name_of(r)); continue; }
+            const NameKey key{r.tid, name_of(r)};
+            auto it = m.find(key);
+            if (it == m.end()) {
+                m.emplace(key, (uint32_t)pi.size());
+                read_pi[ri] = (int32_t)pi.size();
+                pi.push_back(PairInfo{r.nm, -1, r.mapq, s.qlen, 1, s.first, s.last, false, 0});
+            } else {
+                PairInfo &i = pi[it->second];
+                read_pi[ri] = (int32_t)it->second;
+                i.nm += r.nm;
+                i.reads += 1;
+                i.length += s.qlen;
+                i.mapq = std::max<int64_t>(i.mapq, r.mapq);
+                if (i.reads == 2) {
+                    if (s.last > i.start) i.insert = s.last - i.start;
+                    else i.insert = i.stop - s.first;
+                } else {
+                    i.insert = -1;
+                }
+                i.start = 0; i.stop = 0;
+            }
+        }
+    });
+    for (unsigned t = 0; t < NT; t++)
+        if (!no_nm[t].empty()) { isx_set_error("read without NM tag: " + no_nm[t]); return ISX_ERR_IO; }
+    // one table: partition t's entries start at part_base[t]
+    std::vector<uint32_t> part_base(NT + 1, 0);
+    for (unsigned t = 0; t < NT; t++) part_base[t + 1] = part_base[t] + (uint32_t)part_info[t].size();
+    std::vector<PairInfo> pinfo;
+    pinfo.reserve(part_base[NT] + 16);
+    for (unsigned t = 0; t < NT; t++) { pinfo.insert(pinfo.end(), part_info[t].begin(), part_info[t].end()); std::vector<PairInfo>().swap(part_info[t]); }
+    run_nt([&](unsigned t) {
+        for (size_t ri = n_reads_all * t / NT; ri < n_reads_all * (t + 1) / NT; ri++)
+            if (read_pi[ri] >= 0) read_pi[ri] += (int32_t)part_base[part_of[ri]];
+    });
     stage("pair table (by name)");
     // ---- paired_only + filter_scaff2pair2info (filter_reads.py:201-260, 471-532) ----
     std::vector<int64_t> ins;
@@ -517,11 +554,15 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
             if (std::abs((int64_t)r.isize) >= 2 * (int64_t)r.l_seq) continue;
             int32_t pi = read_pi[ri];
             if (pi < 0) {                                   // aligned-base-free read: still hashed by name in htslib
-                auto &m = idx[(size_t)r.tid];
-                auto it = m.find(name_of(r));
-                if (it == m.end()) { m.emplace(name_of(r), (uint32_t)pinfo.size()); pi = (int32_t)pinfo.size();
-                                     pinfo.push_back(PairInfo{0, -1, 0, 0, 0, 0, 0, false, 0}); pending.push_back(-1); }
-                else pi = (int32_t)it->second;
+                const NameKey key{r.tid, name_of(r)};
+                const unsigned t = (unsigned)(NameKeyHash()(key) % NT);
+                auto &m = maps[t];
+                auto it = m.find(key);
+                if (it == m.end()) {                        // new entries live behind the partitions: global index as value
+                    m.emplace(key, 0x80000000u | (uint32_t)pinfo.size());
+                    pi = (int32_t)pinfo.size();
+                    pinfo.push_back(PairInfo{0, -1, 0, 0, 0, 0, 0, false, 0}); pending.push_back(-1);
+                } else pi = (it->second & 0x80000000u) ? (int32_t)(it->second & 0x7FFFFFFFu) : (int32_t)(part_base[t] + it->second);
             }
             int64_t &slot = pending[(size_t)pi];
             if (slot >= 0 && spans[(size_t)slot].end <= r.pos) slot = -1;    // earlier read already left the buffer
