@@ -261,6 +261,8 @@ int parse_bam(const std::vector<uint8_t> &buf, isx_bam &B)
         rec_off.push_back(off);
         off += 4 + (size_t)block;
     }
+    const bool ptiming = getenv("ISX_BAM_TIMING") != nullptr;
+    const auto pt0 = std::chrono::steady_clock::now();
     const size_t n = rec_off.size();
     B.reads.resize(n);
     std::vector<size_t> name_at(n + 1), cig_at(n + 1), seq_at(n + 1);
@@ -275,7 +277,9 @@ int parse_bam(const std::vector<uint8_t> &buf, isx_bam &B)
         n_names += (size_t)p[12] - 1; n_cig += ncig; n_seq += (size_t)l_seq;
     }
     name_at[n] = n_names; cig_at[n] = n_cig; seq_at[n] = n_seq;
+    const auto pt1 = std::chrono::steady_clock::now();
     B.names.resize(n_names); B.cigars.resize(n_cig); B.seqs.resize(n_seq); B.quals.resize(n_seq);
+    const auto pt2 = std::chrono::steady_clock::now();
     // pass 2 (threads over record ranges): field extraction, nibble unpack, aux walk for NM
     const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(64u, std::max(1u, std::thread::hardware_concurrency())), n / 4096 + 1));
     std::vector<int> bad(nt, 0);
@@ -320,6 +324,7 @@ int parse_bam(const std::vector<uint8_t> &buf, isx_bam &B)
         work(0);
         for (auto &x : th) x.join();
     }
+    if (ptiming) fprintf(stderr, "[parse_bam] sizes %.1f ms, alloc %.1f ms, fill %.1f ms (%u threads)\n", std::chrono::duration<double, std::milli>(pt1 - pt0).count(), std::chrono::duration<double, std::milli>(pt2 - pt1).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pt2).count(), nt);
     for (int v : bad) if (v) { isx_set_error("bad aux field"); return ISX_ERR_IO; }
     if (n_names >= 0xFFFFFFFFull) { isx_set_error("read names exceed 4 GiB"); return ISX_ERR_IO; }
     return ISX_OK;
