@@ -50,7 +50,7 @@ struct isx_batch {
     uint2 *d_win = nullptr;
     uint16_t *d_thr = nullptr;
     int qcap = 1024, rqcap = 0, stage_off = 0;
-    bool in_flight = false, publish_enqueued = true;
+    bool in_flight = false, publish_enqueued = true, tim_pending = false;
     int64_t *d_bounds = nullptr;
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
@@ -704,10 +704,8 @@ static int launch_pass(isx_batch *b)
         u->publish_enqueued = true;
         c->unpublished = nullptr;
     }
-    HIP_TRY(hipEventRecord(b->ev[0], s));
-    launch_pileup(a, b->block, b->lds, b->grid, b->packed, s);
+    launch_pileup(a, b->block, b->lds, b->grid, b->packed, s, b->ev[0], b->ev[1]);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b->ev[1], s));
     ++b->epoch;
     b->publish_enqueued = false;
     c->unpublished = b;
@@ -740,7 +738,6 @@ static int finish_pass(isx_batch *b, uint32_t *cap_flags)
             if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
         }
         if (!seen) HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipEventSynchronize(b->ev[1]));
     }
     uint32_t cur[CUR_N];
     for (int i = 0; i < CUR_N; i++) { cur[i] = b->h_state[i] - b->base[i]; b->base[i] = b->h_state[i]; }
@@ -761,7 +758,7 @@ static int finish_pass(isx_batch *b, uint32_t *cap_flags)
     b->sizes.n_snv = cur[CUR_SNV];
     b->sizes.n_sites = cur[CUR_SITES];
     b->tim = isx_timings{};
-    b->tim.pileup_ms = ev_ms(b->ev[0], b->ev[1]);
+    b->tim_pending = true;                  // the kernel's own time stamps are read when somebody asks (isx_batch_timings)
     b->tim.pileup_blocks = b->grid;
     b->tim.pileup_threads = b->block;
     b->tim.pileup_lds_bytes = (int32_t)b->lds;
@@ -795,7 +792,7 @@ static int finish_pass(isx_batch *b, uint32_t *cap_flags)
         b->tim.dense_tiles = (int32_t)lo.dense_tiles; b->tim.dense_macs = (int64_t)lo.dense_macs;
         b->tim.dense_bytes = (int64_t)lo.dense_bytes;
     } else {
-        b->tim.total_ms = b->tim.pileup_ms;
+        b->tim.total_ms = 0.f;
     }
     b->ran = true;
     return ISX_OK;
@@ -869,6 +866,13 @@ int isx_batch_timings(const isx_batch *b, isx_timings *out)
 {
     if (!b || !out) { isx_set_error("isx_batch_timings: bad argument"); return ISX_ERR_ARG; }
     if (!b->ran) { isx_set_error("isx_batch_timings: run the batch first"); return ISX_ERR_STATE; }
+    if (b->tim_pending) {
+        isx_batch *m = const_cast<isx_batch *>(b);
+        HIP_TRY(hipEventSynchronize(b->ev[1]));
+        m->tim.pileup_ms = ev_ms(b->ev[0], b->ev[1]);
+        if (!b->prm.enable_linkage) m->tim.total_ms = m->tim.pileup_ms;
+        m->tim_pending = false;
+    }
     *out = b->tim;
     return ISX_OK;
 }

@@ -166,7 +166,8 @@ struct PileupArgs {
     uint32_t pub_epoch;
 };
 
-void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s);   // compact when a.rec32
+void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s, hipEvent_t ev_start,
+                   hipEvent_t ev_stop);        // record format from a.rec16 / a.rec32 / a.rec; the events bracket the dispatch
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s);
 void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
                          const uint32_t *base16, uint32_t base16_records, uint64_t n_rec, hipStream_t s);

@@ -35,6 +35,7 @@
 // sized slab of the allele-observation table (one global atomic per WINDOW); the workgroup then
 // re-streams its record range and drops each qualifying observation into its site's slab
 // through a per-position LDS cursor.
+#include <hip/hip_ext.h>
 #include "isx_internal.h"
 
 #pragma clang fp contract(off)
@@ -901,32 +902,38 @@ size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int pack
     return bytes;
 }
 
+// ev_start / ev_stop bracket exactly this dispatch (hipExtLaunchKernel: the packet's own start / end time
+// stamps, what rocprofv3 reports too) -- no separate event-record packets around the kernel
+struct LaunchCfg { int block; size_t lds; int grid; hipStream_t s; hipEvent_t ev_start, ev_stop; };
+
 template <class K>
-static void launch_one(K kernel, const PileupArgs &a, int block, size_t lds, int grid, hipStream_t s)
+static void launch_one(K kernel, const PileupArgs &a, const LaunchCfg &l)
 {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds);
+    hipExtLaunchKernelGGL(kernel, dim3(l.grid), dim3(l.block), (uint32_t)l.lds, l.s, l.ev_start, l.ev_stop, 0u, a);
 }
 
-void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s)
+void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s, hipEvent_t ev_start,
+                   hipEvent_t ev_stop)
 {
+    const LaunchCfg l{block, lds, grid, s, ev_start, ev_stop};
     const int sel = (a.enable_linkage != 0 ? 1 : 0) | (a.rec32 ? 2 : 0) | (packed ? 4 : 0);
     if (a.M > 1) {
         switch (sel) {
-        case 0: launch_one(k_pileup_mm<false, false, false>, a, block, lds, grid, s); break;
-        case 1: launch_one(k_pileup_mm<false, true, false>, a, block, lds, grid, s); break;
-        case 2: launch_one(k_pileup_mm<false, false, true>, a, block, lds, grid, s); break;
-        case 3: launch_one(k_pileup_mm<false, true, true>, a, block, lds, grid, s); break;
-        case 4: launch_one(k_pileup_mm<true, false, false>, a, block, lds, grid, s); break;
-        case 5: launch_one(k_pileup_mm<true, true, false>, a, block, lds, grid, s); break;
-        case 6: launch_one(k_pileup_mm<true, false, true>, a, block, lds, grid, s); break;
-        default: launch_one(k_pileup_mm<true, true, true>, a, block, lds, grid, s); break;
+        case 0: launch_one(k_pileup_mm<false, false, false>, a, l); break;
+        case 1: launch_one(k_pileup_mm<false, true, false>, a, l); break;
+        case 2: launch_one(k_pileup_mm<false, false, true>, a, l); break;
+        case 3: launch_one(k_pileup_mm<false, true, true>, a, l); break;
+        case 4: launch_one(k_pileup_mm<true, false, false>, a, l); break;
+        case 5: launch_one(k_pileup_mm<true, true, false>, a, l); break;
+        case 6: launch_one(k_pileup_mm<true, false, true>, a, l); break;
+        default: launch_one(k_pileup_mm<true, true, true>, a, l); break;
         }
     } else {
         const bool link = a.enable_linkage != 0;
-        if (a.rec16) { if (link) launch_one(k_pileup_dense<true, 2>, a, block, lds, grid, s); else launch_one(k_pileup_dense<false, 2>, a, block, lds, grid, s); }
-        else if (a.rec32) { if (link) launch_one(k_pileup_dense<true, 4>, a, block, lds, grid, s); else launch_one(k_pileup_dense<false, 4>, a, block, lds, grid, s); }
-        else { if (link) launch_one(k_pileup_dense<true, 8>, a, block, lds, grid, s); else launch_one(k_pileup_dense<false, 8>, a, block, lds, grid, s); }
+        if (a.rec16) { if (link) launch_one(k_pileup_dense<true, 2>, a, l); else launch_one(k_pileup_dense<false, 2>, a, l); }
+        else if (a.rec32) { if (link) launch_one(k_pileup_dense<true, 4>, a, l); else launch_one(k_pileup_dense<false, 4>, a, l); }
+        else { if (link) launch_one(k_pileup_dense<true, 8>, a, l); else launch_one(k_pileup_dense<false, 8>, a, l); }
     }
 }
 
