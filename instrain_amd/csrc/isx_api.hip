@@ -21,7 +21,12 @@ void isx_set_error(const std::string &msg) { g_err = msg; }
 struct isx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    struct isx_batch *unpublished = nullptr;   // batch whose last pass has no publication enqueued yet (see launch_pass)
+    // passes (pileup kernel + cursor publication) run on one of two streams, alternating by batch: consecutive
+    // batches' kernels are in different queues, so the next one's workgroups move in as the current one's retire
+    // (no kernel-boundary gap); everything else of a batch runs on `stream` after its pass is known to be complete
+    hipStream_t pstream[2] = {nullptr, nullptr};
+    struct isx_batch *unpublished[2] = {nullptr, nullptr};   // per pass stream: batch whose last pass has no publication enqueued yet
+    unsigned n_created = 0;
     uint8_t *d_lut = nullptr;
     std::vector<int32_t> h_lut;
     int32_t lut_n = 0, fallback = 0;
@@ -51,6 +56,7 @@ struct isx_batch {
     uint16_t *d_thr = nullptr;
     int qcap = 1024, rqcap = 0, stage_off = 0;
     bool in_flight = false, publish_enqueued = true, tim_pending = false;
+    int ps = 0;                                           // which pass stream of the context
     int64_t *d_bounds = nullptr;
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
@@ -427,6 +433,7 @@ int isx_ctx_create(int device_id, isx_ctx **out)
     isx_ctx *c = new isx_ctx();
     c->device = device_id;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&c->pstream[i], hipStreamNonBlocking));
     c->pin_bytes = (size_t)64 << 20;
     for (int i = 0; i < 2; i++) {
         HIP_TRY(hipHostMalloc(&c->pin[i], c->pin_bytes, hipHostMallocDefault));
@@ -446,6 +453,7 @@ void isx_ctx_destroy(isx_ctx *c)
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i < 2; i++) if (c->pstream[i]) (void)hipStreamDestroy(c->pstream[i]);
     delete c;
 }
 
@@ -472,7 +480,10 @@ int isx_set_null_model(isx_ctx *c, const int32_t *lut, int64_t n, int32_t fallba
 void isx_batch_destroy(isx_batch *b)
 {
     if (!b) return;
-    if (b->ctx->unpublished == b) b->ctx->unpublished = nullptr;
+    for (int i = 0; i < 2; i++) {
+        if (b->ctx->unpublished[i] == b) b->ctx->unpublished[i] = nullptr;
+        if (b->ctx->pstream[i]) (void)hipStreamSynchronize(b->ctx->pstream[i]);
+    }
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     void *ps[] = {b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
@@ -506,6 +517,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     HIP_TRY(hipSetDevice(c->device));
 
     isx_batch *b = new isx_batch();
+    b->ps = (int)(c->n_created++ & 1u);
     b->ctx = c; b->prm = *prm; b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits;
     b->M = prm->n_mm_bins;
     const bool dense = b->M == 1;
@@ -672,7 +684,7 @@ static int launch_pass(isx_batch *b)
 {
     isx_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
+    hipStream_t s = c->pstream[b->ps];
     b->ran = false;
     // no per-run memset / copy: the cursors run on (slots are relative to `base`), and the last
     // one-wave kernel k_publish_state copies them to mapped pinned memory right behind the pileup kernel
@@ -698,17 +710,17 @@ static int launch_pass(isx_batch *b)
     // Publication of the cursors (k_publish_state) is deferred: if another pass follows on the stream, its
     // kernel publishes this one's state as it starts (one kernel per step, no extra boundary); otherwise
     // isx_batch_wait enqueues the one-wave kernel itself.
-    if (c->unpublished && c->unpublished != b) {
-        isx_batch *u = c->unpublished;
+    if (c->unpublished[b->ps] && c->unpublished[b->ps] != b) {
+        isx_batch *u = c->unpublished[b->ps];
         a.pub_cursors = u->d_cursors; a.pub_host_state = u->d_host_state; a.pub_epoch = u->epoch;
         u->publish_enqueued = true;
-        c->unpublished = nullptr;
+        c->unpublished[b->ps] = nullptr;
     }
     launch_pileup(a, b->block, b->lds, b->grid, b->packed, s, b->ev[0], b->ev[1]);
     HIP_TRY(hipGetLastError());
     ++b->epoch;
     b->publish_enqueued = false;
-    c->unpublished = b;
+    c->unpublished[b->ps] = b;
     b->in_flight = true;
     return ISX_OK;
 }
@@ -725,9 +737,9 @@ static int finish_pass(isx_batch *b, uint32_t *cap_flags)
     if (!b->publish_enqueued) {
         PileupArgs pa{};
         pa.cursors = b->d_cursors; pa.host_state = b->d_host_state;
-        launch_publish_state(pa, b->epoch, s);
+        launch_publish_state(pa, b->epoch, c->pstream[b->ps]);
         b->publish_enqueued = true;
-        if (c->unpublished == b) c->unpublished = nullptr;
+        if (c->unpublished[b->ps] == b) c->unpublished[b->ps] = nullptr;
     }
     {   // spin on the epoch word for a while (no interrupt latency), then fall back to a stream wait
         volatile uint32_t *ep = b->h_state + CUR_N + 4;
@@ -737,7 +749,7 @@ static int finish_pass(isx_batch *b, uint32_t *cap_flags)
             if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == b->epoch) { seen = true; break; }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
         }
-        if (!seen) HIP_TRY(hipStreamSynchronize(s));
+        if (!seen) HIP_TRY(hipStreamSynchronize(c->pstream[b->ps]));
     }
     uint32_t cur[CUR_N];
     for (int i = 0; i < CUR_N; i++) { cur[i] = b->h_state[i] - b->base[i]; b->base[i] = b->h_state[i]; }
