@@ -243,9 +243,12 @@ def main():
     for i in range(args.warmup):
         ring[i % 2].run()
     t0 = time.perf_counter()
+    k_alone = 0.0
     for _ in range(10):
-        batch.run()
+        batch.run()                              # blocking: the kernel has the GPU to itself
+        k_alone += batch.pileup_ms()
     sync_ms = (time.perf_counter() - t0) * 1e3 / 10
+    k_alone /= 10
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -285,7 +288,12 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
 
     if rank == 0:
-        k_avg_ms = k_ms / args.steps
+        # Kernel duration for the roofline: the dispatch's own time stamps on the 10 blocking steps right before the
+        # timed region, where the kernel runs alone (what rocprofv3 reports for it as well).  In the timed region
+        # consecutive passes sit in two queues and overlap at their tails, so a launch's duration there includes the
+        # time it shares the GPU with its neighbour (kernel_ms_avg_overlapped; the sum exceeds the wall time).
+        k_avg_ms = k_alone
+        k_overlapped_ms = k_ms / max(args.steps, 1)
         # the roofline is priced on the bytes the resident layout needs (4 B compact records); the same launch
         # against SURVEY 8(d)'s 8 B/observation model is reported next to it
         abytes = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], sizes["n_entries"], dense=True, record_bytes=tim["record_bytes"])
@@ -312,12 +320,11 @@ def main():
                        "scale": args.scale},
             "roofline": {"bound": "hbm", "kernel": "k_pileup_dense", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # consecutive passes run in two queues and overlap at their tails (the next kernel's workgroups
-                         # move in as the current one's retire), so a launch's own duration includes the time it shares the
-                         # GPU: the sum of the durations exceeds the wall time.  Bytes over wall time of the timed region:
+                         # bytes over the wall time of the timed region (overlapping passes, see above):
                          "achieved_over_wall": abytes / (dt / args.steps) / 1e9, "frac_over_wall": abytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": abytes, "record_bytes": tim["record_bytes"],
                          "gbs_at_8_bytes_per_observation": abytes8 / (k_avg_ms * 1e-3) / 1e9, "kernel_ms_avg": k_avg_ms,
+                         "kernel_ms_avg_overlapped": k_overlapped_ms,
                          "blocks": tim["pileup_blocks"], "threads": tim["pileup_threads"],
                          "lds_bytes": tim["pileup_lds_bytes"]},
             "snv_rows": sizes["n_snv"], "snp_sites": sizes["n_sites"],

@@ -182,8 +182,8 @@ int isx_batch_run(isx_batch *b);
 /* The same pass split for pipelining: isx_batch_launch enqueues the pileup / SNV-calling kernel on the
  * context's stream and returns at once; isx_batch_wait blocks until it is done, runs the linkage stages
  * (they need the table sizes on the host) and makes sizes / fetch available.  isx_batch_run == launch +
- * wait.  Several batches of one context may be in flight (they execute in launch order), so the next
- * shard's pass is queued behind the current one -- what the reference does with its worker pool
+ * wait.  Several batches of one context may be in flight (a context keeps two queues and alternates its
+ * batches between them), so the next shard's pass is queued next to the current one -- what the reference does with its worker pool
  * (profile_controller.py:243-271), without a launch gap between shards.  A batch has at most one pass in
  * flight; fetch / sizes refuse (ISX_ERR_STATE) until isx_batch_wait has returned. */
 int isx_batch_launch(isx_batch *b);

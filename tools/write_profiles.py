@@ -21,9 +21,11 @@ open('profiles/r01_c2_kernel_stats.md', 'w').write(f'''# Round 1 — rocprofv3 -
 
 Command (tools/make_profiles.sh): `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python bench.py --steps 30 --warmup 4 --no-cpu-baseline --no-linkage-leg --no-mm-leg`
 
-k_pileup_dense<false, 2> (linkage off, 2-byte record stream) average {avg:.1f} us (rocprof) vs {ev:.1f} us (HIP events inside the
-un-profiled bench.py run of the same box, profiles/r01_bench_n1.json): agree within {abs(avg - ev) / avg * 100:.1f} %.
-(44 calls = 4 warm-up + 10 blocking + 30 timed steps.)
+k_pileup_dense<false, 2> (linkage off, 2-byte record stream) average {avg:.1f} us (rocprof, all 44 calls) vs {ev:.1f} us (the dispatch's own time stamps on the 10
+blocking steps of the un-profiled bench.py run of the same box, profiles/r01_bench_n1.json, roofline.kernel_ms_avg): agree
+within {abs(avg - ev) / avg * 100:.1f} %.  (44 calls = 4 warm-up + 10 blocking + 30 timed steps; in the timed region consecutive passes
+run in two queues and overlap at their tails -- MaxNs below, roofline.kernel_ms_avg_overlapped in the bench line -- and the
+one-wave k_publish_state then waits for a free slot next to the other queue's pileup kernel.)
 
 ''' + summ(R + '/trace_c2'))
 cf = pd.read_csv(R + '/pmc_fetch/%s_counter_collection.csv' % tag)
