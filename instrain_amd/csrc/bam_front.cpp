@@ -251,32 +251,31 @@ int parse_bam(const std::vector<uint8_t> &buf, isx_bam &B)
         flat += l_ref;
         off += 8 + (size_t)l_name;
     }
-    // pass 1 (sequential, a few words per record): record boundaries and the sizes of the side arrays
-    std::vector<size_t> rec_off;
+    // pass 1 (sequential, one walk, a few words per record): record boundaries and where each record's
+    // name / CIGAR / bases go in the side arrays
+    const bool ptiming = getenv("ISX_BAM_TIMING") != nullptr;
+    const auto pt0 = std::chrono::steady_clock::now();
+    std::vector<size_t> rec_off, name_at, cig_at, seq_at;
+    {
+        const size_t guess = (buf.size() - off) / 160 + 16;        // a 2 x 150 bp record is ~ 240 bytes
+        rec_off.reserve(guess); name_at.reserve(guess); cig_at.reserve(guess); seq_at.reserve(guess);
+    }
     size_t n_names = 0, n_cig = 0, n_seq = 0;
     while (off + 36 <= buf.size()) {
         const uint8_t *p = buf.data() + off;
         const int32_t block = rd32(p);
         if (block < 32 || off + 4 + (size_t)block > buf.size()) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
-        rec_off.push_back(off);
-        off += 4 + (size_t)block;
-    }
-    const bool ptiming = getenv("ISX_BAM_TIMING") != nullptr;
-    const auto pt0 = std::chrono::steady_clock::now();
-    const size_t n = rec_off.size();
-    B.reads.resize(n);
-    std::vector<size_t> name_at(n + 1), cig_at(n + 1), seq_at(n + 1);
-    for (size_t i = 0; i < n; i++) {
-        const uint8_t *p = buf.data() + rec_off[i];
         uint16_t ncig;
         memcpy(&ncig, p + 16, 2);
         const int32_t l_seq = rd32(p + 20);
         const size_t need = 32 + (size_t)p[12] + (size_t)ncig * 4 + ((size_t)std::max(l_seq, 0) + 1) / 2 + (size_t)std::max(l_seq, 0);
-        if (l_seq < 0 || p[12] == 0 || need > (size_t)rd32(p)) { isx_set_error("corrupt BAM record"); return ISX_ERR_IO; }
-        name_at[i] = n_names; cig_at[i] = n_cig; seq_at[i] = n_seq;
+        if (l_seq < 0 || p[12] == 0 || need > (size_t)block) { isx_set_error("corrupt BAM record"); return ISX_ERR_IO; }
+        rec_off.push_back(off); name_at.push_back(n_names); cig_at.push_back(n_cig); seq_at.push_back(n_seq);
         n_names += (size_t)p[12] - 1; n_cig += ncig; n_seq += (size_t)l_seq;
+        off += 4 + (size_t)block;
     }
-    name_at[n] = n_names; cig_at[n] = n_cig; seq_at[n] = n_seq;
+    const size_t n = rec_off.size();
+    B.reads.resize(n);
     const auto pt1 = std::chrono::steady_clock::now();
     B.names.resize(n_names); B.cigars.resize(n_cig); B.seqs.resize(n_seq); B.quals.resize(n_seq);
     const auto pt2 = std::chrono::steady_clock::now();
