@@ -153,14 +153,15 @@ bool inflate_block(const uint8_t *src, size_t n_src, uint8_t *dst, size_t n_dst)
     return ok;
 }
 
-int load_file(const char *path, std::vector<uint8_t> &out)
+int load_file(const char *path, RawBuf<uint8_t> &out)
 {
     FILE *f = fopen(path, "rb");
     if (!f) { isx_set_error(std::string("cannot open ") + path); return ISX_ERR_IO; }
     fseek(f, 0, SEEK_END);
     const long n = ftell(f);
     fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> raw((size_t)n);
+    RawBuf<uint8_t> raw;
+    raw.resize((size_t)n);
     if (n && fread(raw.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); isx_set_error("short read"); return ISX_ERR_IO; }
     fclose(f);
     // index the BGZF blocks
@@ -235,7 +236,7 @@ int parse_nm(const uint8_t *p, const uint8_t *end, bool &has, int32_t &nm)
     return 0;
 }
 
-int parse_bam(const std::vector<uint8_t> &buf, isx_bam &B)
+int parse_bam(const RawBuf<uint8_t> &buf, isx_bam &B)
 {
     if (buf.size() < 12 || memcmp(buf.data(), "BAM\1", 4) != 0) { isx_set_error("not a BAM file"); return ISX_ERR_IO; }
     size_t off = 8 + (size_t)rd32(buf.data() + 4);
@@ -396,7 +397,7 @@ int isx_bam_open(const char *path, isx_bam **out)
 {
     if (!path || !out) { isx_set_error("isx_bam_open: bad argument"); return ISX_ERR_ARG; }
     *out = nullptr;
-    std::vector<uint8_t> buf;
+    RawBuf<uint8_t> buf;
     const bool timing = getenv("ISX_BAM_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     int rc = load_file(path, buf);
