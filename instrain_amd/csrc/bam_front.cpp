@@ -524,10 +524,11 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
     std::vector<int64_t> ins;
     for (const PairInfo &i : pinfo) if (i.reads == 2) { ins.push_back(i.insert); info->unfiltered_pairs++; }
     double median = NAN;
-    if (!ins.empty()) {                             // np.median
-        std::sort(ins.begin(), ins.end());
+    if (!ins.empty()) {                             // np.median (selection, not a full sort)
         const size_t n = ins.size();
-        median = (n & 1) ? (double)ins[n / 2] : ((double)ins[n / 2 - 1] + (double)ins[n / 2]) / 2.0;
+        std::nth_element(ins.begin(), ins.begin() + n / 2, ins.end());
+        const double hi = (double)ins[n / 2];
+        median = (n & 1) ? hi : ((double)*std::max_element(ins.begin(), ins.begin() + n / 2) + hi) / 2.0;
     }
     info->median_insert = median;
     const double max_insert = median * p->max_insert_relative;
