@@ -452,7 +452,7 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
         size_t operator()(const NameKey &k) const { return std::hash<std::string_view>()(k.name) * 1000003u ^ (size_t)(uint32_t)k.tid; }
     };
     const size_t n_reads_all = B.reads.size();
-    const unsigned NT = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_reads_all / 8192 + 1));
+    const unsigned NT = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), n_reads_all / 8192 + 1));
     std::vector<std::unordered_map<NameKey, uint32_t, NameKeyHash>> maps(NT);      // value: index local to the partition
     std::vector<std::vector<PairInfo>> part_info(NT);
     std::vector<int32_t> read_pi(n_reads_all, -1);         // read -> index of its (scaffold, name) entry
