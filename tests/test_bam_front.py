@@ -4,6 +4,7 @@ observations; host code only, no GPU."""
 import os
 
 import numpy as np
+import pytest
 
 from instrain_amd import engine
 from tests import util
@@ -107,3 +108,37 @@ def test_random_messy_bam_cpp_equals_oracle_python(tmp_path):
         from instrain_amd import synth
         assert list(bounds) == list(synth.split_bounds_for([r[1] for r in refs], 1000))
         bam.close()
+
+
+def test_error_paths_and_empty_inputs(tmp_path):
+    """truncated file, a read without NM, a BAM with no reads at all: loud errors / empty outputs"""
+    from tests import bamwriter
+    refs = [("s", 500)]
+    reads = bamwriter.random_reads(5, refs, 40)
+    good = str(tmp_path / "good.bam")
+    bamwriter.write_bam(good, refs, reads)
+    raw = open(good, "rb").read()
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(engine.IsxError) as e:
+        engine.BamFile(cut)
+    assert e.value.code == -5
+    nonm = str(tmp_path / "nonm.bam")
+    rr = [dict(r) for r in reads]
+    for r in rr:
+        r["nm"] = None
+        r["extra_tags"] = False
+    bamwriter.write_bam(nonm, refs, rr)
+    b = engine.BamFile(nonm)
+    with pytest.raises(engine.IsxError) as e:
+        b.expand()
+    assert e.value.code == -5 and "NM" in str(e.value)
+    b.close()
+    empty = str(tmp_path / "empty.bam")
+    bamwriter.write_bam(empty, refs, [])
+    b = engine.BamFile(empty)
+    obs, pair, bounds, sref = b.expand()
+    assert len(obs) == 0 and len(pair) == 0 and list(bounds) == [0, 500] and b.info["filtered_pairs"] == 0
+    o2, p2, _, _ = engine.BamFile(empty).expand(copy=False)
+    assert len(o2) == 0 and len(p2) == 0
+    b.close()
