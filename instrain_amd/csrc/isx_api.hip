@@ -834,7 +834,12 @@ int isx_batch_wait(isx_batch *b)
         HIP_TRY(hipSetDevice(b->ctx->device));
         if (cf & ISX_FLAG_CAP_SNV) { if ((rc = regrow(&b->d_snv, &b->cap_snv, (size_t)npm))) return rc; }
         if (cf & ISX_FLAG_CAP_SITES) {
-            if ((rc = regrow(&b->d_sites, &b->cap_sites, (size_t)b->n_pos))) return rc;
+            // the flag covers the site table and (mm path) the per-site level rows, first sized for 8 levels a
+            // site: with the site table already at its bound only the level rows are short
+            const bool slev_short = b->M > 1 && b->cap_slev < b->cap_sites * (size_t)b->M;
+            if (b->cap_sites < (size_t)b->n_pos || !slev_short) {
+                if ((rc = regrow(&b->d_sites, &b->cap_sites, (size_t)b->n_pos))) return rc;
+            }
             if (b->M > 1) {
                 if (b->d_slev) (void)hipFree(b->d_slev);
                 b->d_slev = nullptr;

@@ -327,6 +327,19 @@ def test_record_stream_choice(ctx):
     b.close()
 
 
+def test_many_levels_per_site_grow_the_level_rows(ctx):
+    """100 mm bins, deep, SNP sites at one position in six: the per-site level rows (first sized for 8 levels a
+    site) overflow while the site table is already at its bound -- only the level rows must grow"""
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    seq, pos, base, mm, pair = _random_split(611, 500, 500, 100, 80)
+    exp = oracle.profile_split(pos, base, mm, pair, seq, 0, lut, fb)
+    got = prod.run_split(ctx, pos, base, mm, pair, seq, 0, n_mm_bins=100)
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="levels")
+    assert len(exp["snv"]) > 4000
+
+
 def test_empty_and_ragged(ctx):
     from instrain_amd import engine
     from tests import prod
