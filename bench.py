@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- headline measurement of the `inStrain profile` hot path on MI355X.
 
-A "step" = one pass of the hot path (isx_batch_run) over one resident batch of synthetic
-observations.  At N=1 the workload is BASELINE.json configs[1] (C2: one 5 Mbp genome, 20x,
-2x150 bp, --skip_mm_profiling, linkage off).  For N>1 every rank profiles its own C2 genome
-(scaffolds shard embarrassingly; weak scaling; no data-path collective; one final RCCL gather of
-the SNV tables after the timed region, reported separately).
+A "step" = one batch of synthetic observations profiled ONCE, the way production does it: the batch is
+handed over from host memory (isx_pipe_submit: 8-byte isx_obs encoded to 2-byte records into pinned
+staging by the pipe's host threads, hipMemcpyAsync in), profiled (k_pileup_dense) and its tables copied
+back to pinned host memory (isx_pipe_collect).  The K timed steps stream K batches through the pipe with
+copy-in / pass / copy-out of consecutive batches overlapping; the batches are distinct (up to 32 variants
+of the workload, see instrain_amd.synth.shifted_variant; cycled beyond that).  At N=1 the workload is
+BASELINE.json configs[1] (C2: one 5 Mbp genome, 20x, 2x150 bp, --skip_mm_profiling, linkage off).  For
+N>1 every rank streams its own C2 genomes (scaffolds shard embarrassingly; weak scaling; no data-path
+collective; one final RCCL gather of the SNV tables after the timed region, reported separately).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
-`roofline` (dominant kernel k_pileup_call vs the HBM roof) and `cpu_baseline` (the oracle's C
-restatement of the reference loop, 1 core, same workload; rank 0, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects `roofline`
+(dominant kernel k_pileup_dense vs the HBM roof, kernel durations from the timed region), `roofline_pcie`
+(the hand-over vs the PCIe Gen5 x16 link), `resident` (the same kernel re-run over a resident batch: the
+kernel-only ceiling, not what production does) and `cpu_baseline` (the oracle's C restatement of the
+reference loop on the host cores, same workload; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -24,6 +30,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+PCIE_PEAK_GBS = 64.0        # PCIe Gen5 x16, one direction (raw; ~57 measured with hipMemcpyAsync on the GPU box)
 
 
 def c2_workload(seed, scale=1.0, with_mm=False):
@@ -64,6 +71,29 @@ def split_obs_ranges(obs_gpos, bounds, chunk=1024):
     lo = np.searchsorted(pmax, bounds[:-1], side="left") * chunk
     hi = np.searchsorted(smin, bounds[1:], side="left") * chunk
     return np.minimum(lo, n), np.minimum(hi, n)
+
+
+def cgroup_cpus():
+    """cpus this container may use on average (cgroup v2 cpu.max), None when unlimited"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(q) // int(p))
+    except Exception:
+        return None
+
+
+def host_cpus():
+    return cgroup_cpus() or os.cpu_count() or 1
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(w, budget_s=25.0, min_s=10.0):
@@ -107,10 +137,11 @@ def cpu_baseline(w, budget_s=25.0, min_s=10.0):
         dt = time.perf_counter() - t0
         return w["profiled_bases"] * (done_pos / float(bounds[-1])) / 1e9 / dt, n_done, done_pos, done_obs, dt
 
-    T = max(1, min(32, (os.cpu_count() or 1)))
+    T = max(1, min(32, host_cpus()))
     v1, n1, _, _, dt1 = run(1, min_s / 2)
     vT, nT, posT, obsT, dtT = run(T, min_s)
     return {"value": vT, "unit": "Gbp/s", "cores": T, "kind": "port", "single_core_value": v1,
+            "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": cgroup_cpus(),
             "sample": "%d split profiles on %d threads in %.1f s (the workload's %d splits, wrapped around; %.1f Mbp, "
                       "%d kept observations) after %d on one thread in %.1f s; oracle/oracle_core.c, pileup+SNV call+linkage"
                       % (nT, T, dtT, n_splits, posT / 1e6, obsT, n1, dt1)}
@@ -188,15 +219,85 @@ def mm_leg(ctx, w, steps=10):
                          "lds_bytes": t["pileup_lds_bytes"], "window": t["pileup_window"]}}
 
 
+def resident_leg(ctx, w, window, steps=30):
+    """The kernel-only ceiling: two resident copies of the batch passed over alternately (the next pass is queued
+    before the current one is collected).  Nothing is handed over or fetched -- NOT what production does; kept
+    because it isolates the pileup kernel (10 blocking runs give the kernel alone, as rocprofv3 sees it)."""
+    from instrain_amd import engine
+    ring = [engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], None, n_mm_bins=1, enable_linkage=False, window=window)
+            for _ in range(2)]
+    for i in range(4):
+        ring[i % 2].run()
+    k_alone = 0.0
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ring[0].run()
+        k_alone += ring[0].pileup_ms()
+    sync_ms = (time.perf_counter() - t0) * 1e3 / 10
+    k_alone /= 10
+    t0 = time.perf_counter()
+    ring[0].launch()
+    for i in range(steps):
+        if i + 1 < steps:
+            ring[(i + 1) % 2].launch()
+        ring[i % 2].wait()
+    dt = time.perf_counter() - t0
+    tim = ring[0].timings()
+    for b in ring:
+        b.close()
+    return {"gbp_per_s": w["profiled_bases"] * steps / dt / 1e9, "ms_per_step": dt / steps * 1e3, "sync_ms_per_step": sync_ms,
+            "kernel_ms_alone": k_alone, "steps": steps, "window": tim["pileup_window"], "blocks": tim["pileup_blocks"],
+            "threads": tim["pileup_threads"], "lds_bytes": tim["pileup_lds_bytes"],
+            "note": "resident re-run of one batch (no hand-over, no fetch): kernel-only ceiling"}
+
+
+def make_variants(w, n):
+    """n distinct batches of w's shape (synth.shifted_variant), built on a few threads"""
+    from concurrent.futures import ThreadPoolExecutor
+    from instrain_amd import synth
+    with ThreadPoolExecutor(max_workers=max(1, min(8, host_cpus()))) as ex:
+        return list(ex.map(lambda k: synth.shifted_variant(w, k), range(n)))
+
+
+def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False):
+    """n_steps batches through the pipe, at most `depth` in flight; returns the last collected result"""
+    tickets, done, last = [], 0, None
+    for i in range(n_steps):
+        if len(tickets) - done == depth:
+            r = pipe.collect(tickets[done], want_ld=False)
+            if stats is not None:
+                stats.append((r["stats"], r["sizes"]))
+            if keep_last and done == n_steps - 1:
+                last = {"snv": r["snv"].copy()}
+            pipe.release(tickets[done])
+            done += 1
+        v = variants[i % len(variants)]
+        tickets.append(pipe.submit(v["ref_codes"], v["split_bounds"], v["obs"], None))
+    while done < len(tickets):
+        r = pipe.collect(tickets[done], want_ld=False)
+        if stats is not None:
+            stats.append((r["stats"], r["sizes"]))
+        if keep_last and done == n_steps - 1:
+            last = {"snv": r["snv"].copy()}
+        pipe.release(tickets[done])
+        done += 1
+    return last
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the C2 genome (debug only; reported in config)")
+    ap.add_argument("--variants", type=int, default=32, help="distinct batches cycled through the timed steps")
+    ap.add_argument("--depth", type=int, default=4, help="pipe slots")
+    ap.add_argument("--host-threads", type=int, default=0, help="encoder threads of the pipe (0 = the cpus this rank may use)")
+    ap.add_argument("--no-pin", action="store_true", help="do not spread the encoder threads over the GPU's L3 domains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-linkage-leg", action="store_true")
     ap.add_argument("--no-mm-leg", action="store_true")
+    ap.add_argument("--no-resident-leg", action="store_true")
     ap.add_argument("--window", type=int, default=0)
     args = ap.parse_args()
 
@@ -220,10 +321,12 @@ def main():
 
     want_mm = world == 1 and not args.no_mm_leg
     w = c2_workload(seed=2 + rank, scale=args.scale, with_mm=want_mm)
-    t_up = time.perf_counter()
-    batch = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], None, n_mm_bins=1,
-                         enable_linkage=False, window=args.window)
-    upload_s = time.perf_counter() - t_up          # allocations + pinned double-buffered H2D + window directory
+    n_var = max(1, min(args.variants, args.steps))
+    variants = make_variants(w, n_var)
+    host_threads = args.host_threads or max(2, min(32, host_cpus() // world))
+    pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=int(w["n_obs"]),
+                       max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
+                       pin_threads=not args.no_pin, n_mm_bins=1, enable_linkage=False, window=args.window)
 
     def barrier():
         if world > 1:
@@ -232,38 +335,17 @@ def main():
             else:
                 dist.barrier()
 
-    # Two resident copies of the rank's shard are passed over alternately, the next pass queued
-    # (isx_batch_launch) before the current one is collected (isx_batch_wait): shards in production
-    # follow each other the same way, so the GPU sees no launch gap between steps.  Every step is one
-    # full pass over one resident batch; `sync_ms_per_step` below is the unpipelined (blocking
-    # isx_batch_run) figure for comparison.
-    batch2 = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], None, n_mm_bins=1,
-                          enable_linkage=False, window=args.window)
-    ring = [batch, batch2]
-    for i in range(args.warmup):
-        ring[i % 2].run()
-    t0 = time.perf_counter()
-    k_alone = 0.0
-    for _ in range(10):
-        batch.run()                              # blocking: the kernel has the GPU to itself
-        k_alone += batch.pileup_ms()
-    sync_ms = (time.perf_counter() - t0) * 1e3 / 10
-    k_alone /= 10
+    # Every step hands one batch over from host memory, profiles it once and brings its tables back;
+    # consecutive batches overlap in the pipe's three queues.
+    stream(pipe, variants, args.warmup, args.depth)
     barrier()
     torch.cuda.synchronize()
+    stats = []
     t0 = time.perf_counter()
-    k_ms = 0.0
-    if args.steps > 0:
-        ring[0].launch()
-    for i in range(args.steps):
-        if i + 1 < args.steps:
-            ring[(i + 1) % 2].launch()
-        ring[i % 2].wait()                       # collects the pass: table sizes on the host
-        k_ms += ring[i % 2].pileup_ms()          # HIP events on the library's own stream
+    last = stream(pipe, variants[args.warmup % n_var:] + variants[:args.warmup % n_var], args.steps, args.depth, stats, keep_last=world > 1)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    batch2.close()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -273,32 +355,26 @@ def main():
         units = float(u.item())
     else:
         units = float(w["profiled_bases"])
-    sizes, tim = batch.sizes(), batch.timings()
 
     # the one collective of the path: final gather of the SNV tables to rank 0 (outside the timed steps)
     gather_ms = None
     if world > 1:
-        res = batch.fetch()
         torch.cuda.synchronize()
         barrier()
         g0 = time.perf_counter()
-        idist.gather_tables({"snv": res["snv"]}, dst=0, device=dev)
+        idist.gather_tables({"snv": last["snv"]}, dst=0, device=dev)
         torch.cuda.synchronize()
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
     if rank == 0:
-        # Kernel duration for the roofline: the dispatch's own time stamps on the 10 blocking steps right before the
-        # timed region, where the kernel runs alone (what rocprofv3 reports for it as well).  In the timed region
-        # consecutive passes sit in two queues and overlap at their tails, so a launch's duration there includes the
-        # time it shares the GPU with its neighbour (kernel_ms_avg_overlapped; the sum exceeds the wall time).
-        k_avg_ms = k_alone
-        k_overlapped_ms = k_ms / max(args.steps, 1)
-        # the roofline is priced on the bytes the resident layout needs (4 B compact records); the same launch
-        # against SURVEY 8(d)'s 8 B/observation model is reported next to it
-        abytes = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], sizes["n_entries"], dense=True, record_bytes=tim["record_bytes"])
-        abytes8 = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], sizes["n_entries"], dense=True, record_bytes=8)
-        achieved = abytes / (k_avg_ms * 1e-3) / 1e9
+        st = [s for s, _ in stats]
+        mean = lambda k: float(np.mean([s[k] for s in st])) if st else 0.0
+        k_ms = mean("kernel_ms")                 # dispatch time stamps of every pass of the timed region
+        n_pos_v = int(np.mean([v["n_pos"] for v in variants]))
+        abytes = pileup_algorithmic_bytes(w["n_obs"], n_pos_v, 0, dense=True, record_bytes=st[0]["record_bytes"] if st else 2)
+        abytes8 = pileup_algorithmic_bytes(w["n_obs"], n_pos_v, 0, dense=True, record_bytes=8)
+        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -306,35 +382,42 @@ def main():
                 traffic = json.load(open(pmc)).get("c2_pileup_bytes_per_launch") if args.scale == 1.0 else None
             except Exception:
                 traffic = None
+        ms_step = dt / args.steps * 1e3
+        h2d_b, d2h_b = mean("h2d_bytes"), mean("d2h_bytes")
         out = {
             "metric": "Gbp profiled/s", "value": units * args.steps / dt / 1e9, "unit": "Gbp/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "sync_ms_per_step": sync_ms,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "C2: one 5 Mbp genome per GPU, 20x, 2x150 bp pairs, insert N(350,30), "
-                                   "--skip_mm_profiling (1 mm bin), linkage off; pileup + SNV call",
+            "config": {"workload": "C2 streamed: one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, 2x150 bp pairs, insert N(350,30), "
+                                   "--skip_mm_profiling (1 mm bin), linkage off; every batch handed over from host memory "
+                                   "(8-byte records -> 2-byte records -> pinned hipMemcpyAsync), profiled once (pileup + SNV call), "
+                                   "tables copied back; %d distinct batches" % n_var,
                        "genome_bp": int(w["n_pos"]), "kept_observations": int(w["n_obs"]),
-                       "profiled_bases_per_gpu": int(w["profiled_bases"]), "splits": int(len(w["split_bounds"]) - 1),
-                       "window": tim["pileup_window"], "parallelism": "scaffold-sharded x%d" % world,
-                       "scale": args.scale},
+                       "profiled_bases_per_batch": int(w["profiled_bases"]), "splits": int(len(variants[0]["split_bounds"]) - 1),
+                       "distinct_batches": n_var, "pipe_depth": args.depth, "host_threads": host_threads,
+                       "parallelism": "scaffold-sharded x%d" % world, "scale": args.scale},
             "roofline": {"bound": "hbm", "kernel": "k_pileup_dense", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # bytes over the wall time of the timed region (overlapping passes, see above):
-                         "achieved_over_wall": abytes / (dt / args.steps) / 1e9, "frac_over_wall": abytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": abytes, "record_bytes": tim["record_bytes"],
-                         "gbs_at_8_bytes_per_observation": abytes8 / (k_avg_ms * 1e-3) / 1e9, "kernel_ms_avg": k_avg_ms,
-                         "kernel_ms_avg_overlapped": k_overlapped_ms,
-                         "blocks": tim["pileup_blocks"], "threads": tim["pileup_threads"],
-                         "lds_bytes": tim["pileup_lds_bytes"]},
-            "snv_rows": sizes["n_snv"], "snp_sites": sizes["n_sites"],
-            # host -> device hand-over of the batch (never part of `value`): isx_batch_create wall time
-            "upload": {"ms": upload_s * 1e3, "bytes": int(w["n_obs"]) * 8 + int(w["n_pos"]),
-                       "gb_per_s": (int(w["n_obs"]) * 8 + int(w["n_pos"])) / upload_s / 1e9,
-                       "gbp_per_s_including_upload": units / world / 1e9 / (upload_s + dt / args.steps)},
+                         "algorithmic_bytes_per_launch": abytes, "record_bytes": st[0]["record_bytes"] if st else 2,
+                         "gbs_at_8_bytes_per_observation": abytes8 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+                         "kernel_ms_avg": k_ms, "launches": len(st),
+                         "note": "durations = the dispatches' own time stamps inside the timed (streamed) region"},
+            "roofline_pcie": {"bound": "pcie", "direction": "host->device", "achieved": h2d_b / (ms_step * 1e-3) / 1e9,
+                              "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": h2d_b / (ms_step * 1e-3) / 1e9 / PCIE_PEAK_GBS,
+                              "bytes_per_step": h2d_b, "copy_ms_avg": mean("h2d_ms"),
+                              "during_copy_gbs": h2d_b / (mean("h2d_ms") * 1e-3) / 1e9 if mean("h2d_ms") > 0 else 0.0,
+                              "device_to_host": {"bytes_per_step": d2h_b, "copy_ms_avg": mean("d2h_ms"),
+                                                 "achieved": d2h_b / (ms_step * 1e-3) / 1e9}},
+            "stages_ms": {"host_encode": mean("encode_ms"), "copy_in": mean("h2d_ms"), "kernel": k_ms, "copy_out": mean("d2h_ms"),
+                          "collect_wait": mean("collect_wait_ms"), "step": ms_step,
+                          "host_bytes_read_per_step": int(w["n_obs"]) * 8 + n_pos_v},
+            "snv_rows": int(stats[-1][1]["n_snv"]) if stats else 0, "snp_sites": int(stats[-1][1]["n_sites"]) if stats else 0,
         }
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
+        if world == 1 and not args.no_resident_leg:
+            out["resident"] = resident_leg(ctx, w, args.window)
         if want_mm:
             out["mm_on"] = mm_leg(ctx, w)
         if world == 1 and not args.no_linkage_leg:
@@ -342,7 +425,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)
-    batch.close()
+    pipe.close()
     ctx.close()
     if world > 1:
         barrier()

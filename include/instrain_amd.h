@@ -49,7 +49,7 @@ extern "C" {
 #define ISX_ERR_IO (-5)         /* BAM / file error */
 #define ISX_ERR_STATE (-6)      /* call out of order (e.g. fetch before run) */
 
-#define ISX_ABI_VERSION 1
+#define ISX_ABI_VERSION 2
 
 /* Base codes everywhere: 0=A 1=C 2=T 3=G (P2C order, profile_utilities.py:34), 4 = anything else. */
 
@@ -76,7 +76,14 @@ typedef struct {
                                  * 2 dense int8 MFMA path (n_mm_bins == 1 only) */
     int32_t window;             /* 0 = auto; positions per workgroup window (multiple of 64) */
     uint64_t seed;              /* counter-based RNG seed for the rarefied outputs */
+    int32_t layout;             /* 0 = automatic (production).  ISX_LAYOUT_* bits force one of the resident layouts the
+                                 * library otherwise picks itself; every layout gives identical results (tests, A/B timing) */
+    int32_t reserved;           /* 0 */
 } isx_params;
+
+#define ISX_LAYOUT_WIDE_RECORDS 1       /* 8-byte records (isx_obs as is) instead of the 2- / 4-byte stream */
+#define ISX_LAYOUT_NO_SHORT_RECORDS 2   /* n_mm_bins == 1: 4-byte instead of 2-byte records */
+#define ISX_LAYOUT_NO_PACKED_COUNTERS 4 /* mm path: u32 instead of packed u16 LDS counters */
 
 /* (position, mm)-present entry: one per mm level present at a position, ascending mm.
  * 32 bytes (two aligned 16-byte device stores).  cnt = counts of THIS level; covT[mm][pos] = sum(cnt);
@@ -259,6 +266,69 @@ int isx_compare_coverage(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const 
 int isx_compare_scaffolds(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, int32_t min_cov,
                           double min_freq, isx_compare_level *out, int64_t *n_snp_rows, float *device_ms);
 int isx_compare_fetch_snps(isx_batch *a, isx_compare_snp *out);
+
+/* ---- streaming hand-over: profile a stream of batches, each exactly once ----
+ * What production does (the reference's analogue is the command / result queue pair around its worker pool,
+ * profile_controller.py:157-193, 243-271): batches arrive from the host, are profiled once and their tables go
+ * back.  A pipe owns `depth` resident slots sized for the largest batch, pinned staging for both directions, a
+ * persistent pool of host threads and three queues, so that at any time
+ *     batch k+1 is encoded into pinned staging by the host threads (8-byte isx_obs -> 2- / 4-byte records),
+ *     batch k   is copied in (hipMemcpyAsync) and profiled,
+ *     batch k-1's tables are copied out (hipMemcpyAsync) / read by the caller.
+ * isx_pipe_submit returns once the batch is encoded and everything else is enqueued (the caller's buffers may be
+ * reused); isx_pipe_collect blocks until that batch's results are on the host; isx_pipe_release gives the slot
+ * back.  Tickets count from 0 in submission order; at most `depth` batches may be submitted and not yet released
+ * (isx_pipe_submit then returns ISX_ERR_STATE).  Not thread-safe: one caller thread per pipe. */
+typedef struct isx_pipe isx_pipe;
+
+typedef struct {
+    int64_t max_pos;            /* largest n_pos of a batch */
+    int64_t max_obs;            /* largest n_obs of a batch */
+    int32_t max_splits;
+    int32_t depth;              /* resident slots, >= 2 (4 is a good default) */
+    int32_t host_threads;       /* encoder threads incl. the caller; 0 = automatic (the cpus this process may use, at most 32) */
+    int32_t pin_threads;        /* 1: spread the threads over the L3 domains of the GPU's NUMA node (sched_setaffinity) */
+    double jump_slack;          /* device records set aside for streams that jump between far-apart positions
+                                 * (next contig / genome of a database), as a fraction of max_obs; 0 = 0.25 */
+} isx_pipe_params;
+
+typedef struct {
+    int64_t ticket;
+    int64_t n_pos, n_obs;
+    isx_sizes sizes;
+    /* n_mm_bins == 1: dense tables in pinned host memory, valid until isx_pipe_release */
+    const uint32_t *counts;     /* [n_pos][4] */
+    const float *clon;          /* [n_pos] */
+    const float *clon_rarefied; /* [n_pos], NULL when rarefied_coverage <= 0 */
+    const isx_snv *snv;         /* [sizes.n_snv], canonical (gpos, mm) order; both modes */
+    /* the slot itself: isx_batch_fetch_entries / isx_batch_fetch_ld / isx_batch_summarize / isx_compare_* may be
+     * called on it until isx_pipe_release (n_mm_bins > 1: the entry table is fetched this way) */
+    isx_batch *batch;
+    /* where the time of this batch went, milliseconds */
+    float encode_ms;            /* host threads: isx_obs -> records in pinned staging */
+    float h2d_ms, kernel_ms, d2h_ms;    /* device-side durations (HIP events) */
+    float collect_wait_ms;      /* host time isx_pipe_collect spent waiting */
+    int32_t record_bytes;       /* 2 or 4 */
+    int32_t encode_passes;      /* 1; 2 when the stream jumped more often than the slot's slack allowed */
+    int64_t h2d_bytes, d2h_bytes;
+} isx_pipe_result;
+
+int isx_pipe_create(isx_ctx *ctx, const isx_params *params, const isx_pipe_params *pp, isx_pipe **out);
+void isx_pipe_destroy(isx_pipe *p);
+/* same arguments as isx_batch_create */
+int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                    int64_t n_obs, const isx_obs *obs, const uint32_t *pair, int64_t *ticket);
+int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out);
+int isx_pipe_release(isx_pipe *p, int64_t ticket);
+
+/* The pipe's host-side encoder on its own (no GPU needed): obs[n_obs] -> resident record stream.
+ *   record_bytes 2: delta:13 | base:3, groups of 512 records; 4: delta:16 | mm:8 | base:3 (<< 24), groups of 256;
+ *   position = gbase[record / group] + delta; padding records 0xFFFF / 0x0700FFFF; a group never spans
+ *   >= 8191 / 65535 positions (the stream is cut and padded where it jumps), *n_rec is a multiple of 2048.
+ * rec / gbase / pair_out (NULL with pair == NULL) hold cap_rec records / cap_rec / group bases / cap_rec ids. */
+int isx_encode_obs(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int64_t n_pos, int32_t record_bytes,
+                   int32_t host_threads, double slack, int64_t cap_rec, void *rec, uint32_t *gbase, uint32_t *pair_out,
+                   int64_t *n_rec, int32_t *passes);
 
 /* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ---- */
 typedef struct isx_bam isx_bam;

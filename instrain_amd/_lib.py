@@ -29,7 +29,16 @@ assert OBS_DT.itemsize == 8 and ENTRY_DT.itemsize == 32 and SNV_DT.itemsize == 2
 class Params(C.Structure):
     _fields_ = [("min_cov", C.c_int32), ("min_snp", C.c_int32), ("min_freq", C.c_double),
                 ("rarefied_coverage", C.c_int32), ("n_mm_bins", C.c_int32), ("enable_linkage", C.c_int32),
-                ("linkage_mode", C.c_int32), ("window", C.c_int32), ("seed", C.c_uint64)]
+                ("linkage_mode", C.c_int32), ("window", C.c_int32), ("seed", C.c_uint64), ("layout", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+LAYOUT_WIDE_RECORDS, LAYOUT_NO_SHORT_RECORDS, LAYOUT_NO_PACKED_COUNTERS = 1, 2, 4
+
+
+class PipeParams(C.Structure):
+    _fields_ = [("max_pos", C.c_int64), ("max_obs", C.c_int64), ("max_splits", C.c_int32), ("depth", C.c_int32),
+                ("host_threads", C.c_int32), ("pin_threads", C.c_int32), ("jump_slack", C.c_double)]
 
 
 class Sizes(C.Structure):
@@ -43,6 +52,15 @@ class Timings(C.Structure):
                [(n, C.c_int32) for n in ("pileup_blocks", "pileup_threads", "pileup_lds_bytes", "pileup_window")] + \
                [("mfma_ms", C.c_float), ("dense_tiles", C.c_int32), ("dense_macs", C.c_int64), ("dense_bytes", C.c_int64),
                 ("record_bytes", C.c_int32), ("pad", C.c_int32)]
+
+
+class PipeResult(C.Structure):
+    _fields_ = [("ticket", C.c_int64), ("n_pos", C.c_int64), ("n_obs", C.c_int64), ("sizes", Sizes),
+                ("counts", C.c_void_p), ("clon", C.c_void_p), ("clon_rarefied", C.c_void_p), ("snv", C.c_void_p),
+                ("batch", C.c_void_p),
+                ("encode_ms", C.c_float), ("h2d_ms", C.c_float), ("kernel_ms", C.c_float), ("d2h_ms", C.c_float),
+                ("collect_wait_ms", C.c_float), ("record_bytes", C.c_int32), ("encode_passes", C.c_int32),
+                ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64)]
 
 
 class BamParams(C.Structure):
@@ -84,6 +102,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_batch_create", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
            "isx_batch_summarize", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
+           "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_collect", "isx_pipe_release", "isx_encode_obs",
            "isx_bam_open", "isx_bam_close", "isx_bam_expand", "isx_bam_ref", "isx_bam_copy", "isx_bam_view"]
 
 _lib = None
@@ -120,6 +139,13 @@ def load():
     lib.isx_compare_coverage.argtypes = [vp, vp, i32, vp, i32, vp, C.POINTER(C.c_float)]
     lib.isx_compare_scaffolds.argtypes = [vp, vp, i32, vp, i32, C.c_double, vp, C.POINTER(i64), C.POINTER(C.c_float)]
     lib.isx_compare_fetch_snps.argtypes = [vp, vp]
+    lib.isx_pipe_create.argtypes = [vp, C.POINTER(Params), C.POINTER(PipeParams), C.POINTER(vp)]
+    lib.isx_pipe_destroy.argtypes = [vp]
+    lib.isx_pipe_destroy.restype = None
+    lib.isx_pipe_submit.argtypes = [vp, i64, vp, i32, vp, i64, vp, vp, C.POINTER(i64)]
+    lib.isx_pipe_collect.argtypes = [vp, i64, C.POINTER(PipeResult)]
+    lib.isx_pipe_release.argtypes = [vp, i64]
+    lib.isx_encode_obs.argtypes = [vp, vp, i64, i64, i32, i32, C.c_double, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
     lib.isx_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.isx_bam_close.argtypes = [vp]
     lib.isx_bam_close.restype = None

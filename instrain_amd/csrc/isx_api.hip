@@ -11,80 +11,10 @@
 #include <type_traits>
 #include <vector>
 
-#include "isx_internal.h"
-#include "isx_linkage.h"
-#include "isx_summary.h"
+#include "isx_batch.h"
 
 static thread_local std::string g_err;
 void isx_set_error(const std::string &msg) { g_err = msg; }
-
-struct isx_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    // passes (pileup kernel + cursor publication) run on one of two streams, alternating by batch: consecutive
-    // batches' kernels are in different queues, so the next one's workgroups move in as the current one's retire
-    // (no kernel-boundary gap); everything else of a batch runs on `stream` after its pass is known to be complete
-    hipStream_t pstream[2] = {nullptr, nullptr};
-    struct isx_batch *unpublished[2] = {nullptr, nullptr};   // per pass stream: batch whose last pass has no publication enqueued yet
-    unsigned n_created = 0;
-    uint8_t *d_lut = nullptr;
-    std::vector<int32_t> h_lut;
-    int32_t lut_n = 0, fallback = 0;
-    void *pin[2] = {nullptr, nullptr};
-    hipEvent_t pin_ev[2] = {nullptr, nullptr};
-    size_t pin_bytes = 0;
-};
-
-struct isx_batch {
-    isx_ctx *ctx = nullptr;
-    isx_params prm{};
-    int64_t n_pos = 0, n_obs = 0;
-    uint64_t n_rec = 0;         // padded
-    uint64_t n_pairs = 0;
-    int32_t n_splits = 0;
-    int W = 0, logW = 0, M = 1, n_win = 0, block = 1024, grid = 0, packed = 0;
-    size_t lds = 0;
-    // device
-    uint2 *d_rec = nullptr;             // wide stream (8-byte isx_obs) -- or:
-    uint32_t *d_rec32 = nullptr, *d_gbase = nullptr;    // compact stream (4-byte records + one position base per 256)
-    uint16_t *d_rec16 = nullptr;                        // short stream (n_mm_bins == 1: 2-byte records, base per 512)
-    uint32_t *d_pair = nullptr, *d_gpos = nullptr, *d_cbase = nullptr;
-    uint16_t *d_gpos16 = nullptr;
-    int gpos16_shift = 7;
-    uint8_t *d_ref = nullptr;
-    uint2 *d_win = nullptr;
-    uint16_t *d_thr = nullptr;
-    int qcap = 1024, rqcap = 0, stage_off = 0;
-    bool in_flight = false, publish_enqueued = true, tim_pending = false;
-    int ps = 0;                                           // which pass stream of the context
-    int64_t *d_bounds = nullptr;
-    uint4 *d_counts = nullptr;
-    float *d_clon = nullptr;
-    float *d_clon_r = nullptr;       // rarefied clonality of the dense path [n_pos]
-    isx_entry *d_entries = nullptr;  // mm path: [n_win][slab] slabs, then cap_ovf overflow entries
-    uint32_t *d_win_nent = nullptr;
-    isx_slev *d_slev = nullptr;
-    uint32_t slab = 0;
-    size_t cap_ovf = 0, cap_slev = 0;
-    isx_snv *d_snv = nullptr;
-    isx_site *d_sites = nullptr;
-    isx_ao *d_ao = nullptr;
-    uint32_t *d_cursors = nullptr, *d_flags = nullptr;   // one allocation: cursors[CUR_N] | flags[4]
-    uint32_t *h_state = nullptr;                          // mapped pinned mirror, written by k_publish_state
-    uint32_t *d_host_state = nullptr;                     // device address of h_state
-    uint32_t base[CUR_N] = {};                            // cursor values at the start of the next run
-    uint32_t epoch = 0;                                   // run counter, echoed by k_publish_state
-    size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
-    LinkageBuffers L;
-    SummaryBuffers S;
-    CompareBuffers C;
-    hipEvent_t ev_sum[2] = {};
-    hipEvent_t ev[10] = {};
-    bool ran = false;
-    uint32_t n_ovf = 0;
-    isx_sizes sizes{};
-    isx_timings tim{};
-};
 
 // host -> device through the two pinned staging buffers (hipMemcpyAsync, double-buffered);
 // `fill(dst, first, count)` writes `count` elements starting at element `first` into dst.
@@ -108,7 +38,7 @@ static int staged_upload(isx_ctx *c, T *d_dst, uint64_t n, F fill)
 // For every coverage below lut_n both parts are monotone in c, so they fold into one exact
 // integer threshold: thr[total] = max(null_model[total], min{c : (double)c / (double)total >= min_freq}),
 // found here with the SAME IEEE fp64 division the reference performs (no rounding shortcuts).
-static std::vector<uint16_t> build_thresholds(const std::vector<int32_t> &lut, int32_t fallback, double min_freq)
+std::vector<uint16_t> build_thresholds(const std::vector<int32_t> &lut, int32_t fallback, double min_freq)
 {
     std::vector<uint16_t> thr(lut.size(), 65535);
     for (size_t t = 1; t < lut.size(); t++) {
@@ -166,10 +96,10 @@ struct ObsStream {
         : c(c_), b(b_), obs(obs_), pair(pair_), n_obs(n_obs_), n_pos(n_pos_)
     {
         static_assert(sizeof(isx_obs) == sizeof(uint2), "isx_obs must be the 8-byte device record");
-        want16 = b->M == 1 && !getenv("ISX_NO_SHORT_RECORDS");
+        want16 = b->M == 1 && !(b->prm.layout & (ISX_LAYOUT_NO_SHORT_RECORDS | ISX_LAYOUT_WIDE_RECORDS));
         G = want16 ? ISX_GROUP16 : ISX_GROUP;
         SPAN = want16 ? 8191u : 65535u;
-        too_wide.store(getenv("ISX_WIDE_RECORDS") ? 1 : 0);         // env: force the wide stream (tests / A-B)
+        too_wide.store((b->prm.layout & ISX_LAYOUT_WIDE_RECORDS) ? 1 : 0);   // forced wide stream (tests / A-B)
         reset_directory();
     }
 
@@ -408,6 +338,88 @@ struct ObsStream {
 };
 
 
+// window size: explicit, or (dense) the multiple of 64 that wastes least on MI355X for batches that fill the
+// chip (tools/tune_pileup.py), smaller for small batches so every CU still owns >= 2 windows; (mm) the
+// largest multiple of 64 whose counters fit half of the 160 KiB LDS (two resident workgroups per CU),
+// at most 2 positions per lane
+int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed)
+{
+    const isx_params *prm = &b->prm;
+    if (prm->window > 0) return prm->window;
+    if (b->M == 1) {
+        // small batches: every CU should still own >= 2 windows
+        const int64_t wsmall = (n_pos / 1024 + 63) / 64 * 64;
+        if (wsmall < 2048) return (int)std::max<int64_t>(512, wsmall);
+        // otherwise the multiple of 64 in [2048, 3904] (two 1024-lane workgroups per CU fit their LDS)
+        // that wastes least: whole rounds of the 512 persistent workgroups x stream over-scan of a
+        // window (~ one read length + one directory chunk on each side)
+        // (with linkage a position also carries slabc + maskl: 25 bytes, so two workgroups fit up to 3136)
+        int best = 2560;
+        double best_eff = 0.0;
+        const int wtop = prm->enable_linkage ? 3136 : 3904;
+        for (int w = 2048; w <= wtop; w += 64) {
+            const double n_win = std::ceil((double)n_pos / w);
+            const double rounds = n_win / 512.0;
+            const double eff = rounds / std::ceil(rounds) * (w / (w + 200.0));
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = w; }
+        }
+        return best;
+    }
+    const int bytes_per_pos = b->M * (packed ? 8 : 16) + ((b->M + 31) / 32) * 4 + 5;
+    const int wmax = ((78 * 1024 - 8 * b->qcap - 8192 - 2048 - 256) / bytes_per_pos) / 64 * 64;
+    return std::min(std::max(wmax, 64), 2 * b->block);
+}
+
+uint64_t build_window_directory(const uint32_t *cmin, const uint32_t *cmax, const uint8_t *cany, uint64_t n_chunks, int W,
+                                int64_t n_pos, std::vector<uint2> &win)
+{
+    std::vector<uint32_t> pmax(n_chunks), smin(n_chunks);
+    uint32_t run = 0;
+    for (uint64_t i = 0; i < n_chunks; i++) { if (cany[i]) run = std::max(run, cmax[i]); pmax[i] = run; }
+    run = 0xFFFFFFFFu;
+    for (uint64_t i = n_chunks; i-- > 0;) { if (cany[i]) run = std::min(run, cmin[i]); smin[i] = run; }
+    const int n_win = (int)((n_pos + W - 1) / W);
+    win.assign((size_t)n_win, make_uint2(0, 0));
+    uint64_t lo = 0, hi = 0, longest = 0;
+    for (int w = 0; w < n_win; w++) {
+        const uint64_t w0 = (uint64_t)w * W, w1 = w0 + W;
+        while (lo < n_chunks && (uint64_t)pmax[lo] < w0) lo++;       // chunks before lo: every gpos < w0
+        if (hi < lo) hi = lo;
+        while (hi < n_chunks && (uint64_t)smin[hi] < w1) hi++;       // chunks from hi on: every gpos >= w1
+        win[(size_t)w] = make_uint2((uint32_t)(lo * ISX_CHUNK), (uint32_t)(hi * ISX_CHUNK));
+        longest = std::max(longest, (hi - lo) * ISX_CHUNK);
+    }
+    return longest;
+}
+
+int batch_set_geometry(isx_batch *b)
+{
+    const bool dense = b->M == 1;
+    if (!dense && b->W > 2 * b->block) { isx_set_error("mm path: window must be <= 2 x block"); return ISX_ERR_ARG; }
+    b->rqcap = dense ? 0 : std::min(b->W, 512);     // positions with SNV rows per window (overflow: per-position atomics)
+    b->lds = pileup_lds_bytes(b->W, b->M, b->qcap, b->rqcap, b->prm.enable_linkage, b->packed, b->block, &b->stage_off);
+    if (b->lds > 160 * 1024) { isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
+    {   // persistent kernels: as many workgroups as stay resident on the 256 CUs
+        const int per_cu = std::max(1, std::min((int)(160 * 1024 / b->lds), 2048 / b->block));
+        int g = 256 * per_cu;
+#ifdef ISX_TUNING
+        if (const char *e = getenv("ISX_GRID")) g = std::max(8, atoi(e));       // tuning builds only
+#endif
+        g = std::min(g, b->n_win);
+        b->grid = std::max(8, (g + 7) / 8 * 8);
+    }
+    if (!dense) {
+        // entry slabs: min(M, 4) levels per position fit without overflow; the rest spills
+        b->slab = (uint32_t)b->W * (uint32_t)std::min(b->M, 4);
+        if (!b->cap_ovf) {
+            const uint64_t npm = (uint64_t)b->n_pos * b->M;
+            b->cap_ovf = b->M <= 4 ? 16 : (size_t)std::max<uint64_t>(1u << 20, std::min<uint64_t>((uint64_t)b->n_obs, npm) / 4);
+        }
+    }
+    return ISX_OK;
+}
+
+
 extern "C" {
 
 const char *isx_last_error(void) { return g_err.c_str(); }
@@ -522,38 +534,11 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     b->M = prm->n_mm_bins;
     const bool dense = b->M == 1;
     b->block = dense ? 1024 : 512;       // mm kernel: > 64 VGPRs, two 512-lane workgroups per CU overlap their phases
-    if (const char *e = getenv("ISX_BLOCK")) b->block = atoi(e);       // tuning only
+#ifdef ISX_TUNING
+    if (const char *e = getenv("ISX_BLOCK")) b->block = atoi(e);       // tuning builds only (make tuning)
+#endif
     if (b->block < 64 || b->block > 1024 || (b->block & 63)) { delete b; isx_set_error("ISX_BLOCK must be a multiple of 64 in [64, 1024]"); return ISX_ERR_ARG; }
     if (prm->window && (prm->window < 64 || (prm->window & 63) || prm->window > 8192)) { delete b; isx_set_error("window must be a multiple of 64 in [64, 8192]"); return ISX_ERR_ARG; }
-    // window size: explicit, or (dense) 2560 measured best on MI355X for batches that fill the chip
-    // (tools/tune_pileup.py), smaller for small batches so every CU still owns >= 2 windows; (mm) the
-    // largest multiple of 64 whose counters fit half of the 160 KiB LDS (two resident workgroups per CU),
-    // at most 2 positions per lane
-    auto window_for = [&](bool packed) -> int {
-        if (prm->window > 0) return prm->window;
-        if (dense) {
-            // small batches: every CU should still own >= 2 windows
-            const int64_t wsmall = (n_pos / 1024 + 63) / 64 * 64;
-            if (wsmall < 2048) return (int)std::max<int64_t>(512, wsmall);
-            // otherwise the multiple of 64 in [2048, 3904] (two 1024-lane workgroups per CU fit their LDS)
-            // that wastes least: whole rounds of the 512 persistent workgroups x stream over-scan of a
-            // window (~ one read length + one directory chunk on each side)
-            // (with linkage a position also carries slabc + maskl: 25 bytes, so two workgroups fit up to 3136)
-            int best = 2560;
-            double best_eff = 0.0;
-            const int wtop = prm->enable_linkage ? 3136 : 3904;
-            for (int w = 2048; w <= wtop; w += 64) {
-                const double n_win = std::ceil((double)n_pos / w);
-                const double rounds = n_win / 512.0;
-                const double eff = rounds / std::ceil(rounds) * (w / (w + 200.0));
-                if (eff > best_eff + 1e-9) { best_eff = eff; best = w; }
-            }
-            return best;
-        }
-        const int bytes_per_pos = b->M * (packed ? 8 : 16) + ((b->M + 31) / 32) * 4 + 5;
-        const int wmax = ((78 * 1024 - 8 * b->qcap - 8192 - 2048 - 256) / bytes_per_pos) / 64 * 64;
-        return std::min(std::max(wmax, 64), 2 * b->block);
-    };
     b->n_rec = std::max<uint64_t>(ISX_PAD, ((uint64_t)n_obs + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
     if (b->n_rec >= 0xFFFFFFFFull) { delete b; isx_set_error("more than 2^32 observations in one batch"); return ISX_ERR_ARG; }
 
@@ -608,51 +593,20 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
 
     // ---- window -> record range: prefix-max / suffix-min over the chunk directory ----
     {
-        std::vector<uint32_t> pmax(n_chunks), smin(n_chunks);
-        uint32_t run = 0;
-        for (uint64_t i = 0; i < n_chunks; i++) { if (cany[i]) run = std::max(run, cmax[i]); pmax[i] = run; }
-        run = 0xFFFFFFFFu;
-        for (uint64_t i = n_chunks; i-- > 0;) { if (cany[i]) run = std::min(run, cmin[i]); smin[i] = run; }
         std::vector<uint2> win;
-        auto build = [&](int W) -> uint64_t {           // returns the longest record range of a window
-            const int n_win = (int)((n_pos + W - 1) / W);
-            win.assign((size_t)n_win, make_uint2(0, 0));
-            uint64_t lo = 0, hi = 0, longest = 0;
-            for (int w = 0; w < n_win; w++) {
-                const uint64_t w0 = (uint64_t)w * W, w1 = w0 + W;
-                while (lo < n_chunks && (uint64_t)pmax[lo] < w0) lo++;       // chunks before lo: every gpos < w0
-                if (hi < lo) hi = lo;
-                while (hi < n_chunks && (uint64_t)smin[hi] < w1) hi++;       // chunks from hi on: every gpos >= w1
-                win[(size_t)w] = make_uint2((uint32_t)(lo * ISX_CHUNK), (uint32_t)(hi * ISX_CHUNK));
-                longest = std::max(longest, (hi - lo) * ISX_CHUNK);
-            }
-            return longest;
-        };
         b->packed = 0;
-        int W = window_for(false);
+        int W = batch_window_for(b, n_pos, false);
         if (!dense) {
             // u16-packed counters are legal when no window streams >= 65536 records
-            const int Wp = window_for(true);
-            if (getenv("ISX_NO_PACKED") == nullptr && build(Wp) < 65536) { b->packed = 1; W = Wp; }
+            const int Wp = batch_window_for(b, n_pos, true);
+            if (!(prm->layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
+                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win) < 65536) { b->packed = 1; W = Wp; }
         }
-        if (!b->packed) build(W);
-        if (!dense && W > 2 * b->block) { isx_batch_destroy(b); isx_set_error("mm path: window must be <= 2 x block"); return ISX_ERR_ARG; }
+        if (!b->packed) build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win);
         b->W = W;
-        b->rqcap = dense ? 0 : std::min(W, 512);     // positions with SNV rows per window (overflow: per-position atomics)
-        b->lds = pileup_lds_bytes(W, b->M, b->qcap, b->rqcap, prm->enable_linkage, b->packed, b->block, &b->stage_off);
-        if (b->lds > 160 * 1024) { isx_batch_destroy(b); isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
         b->n_win = (int)win.size();
-        {   // persistent kernels: as many workgroups as stay resident on the 256 CUs
-            const int per_cu = std::max(1, std::min((int)(160 * 1024 / b->lds), 2048 / b->block));
-            int g = 256 * per_cu;
-            if (const char *e = getenv("ISX_GRID")) g = atoi(e);            // tuning only
-            g = std::min(g, b->n_win);
-            b->grid = std::max(8, (g + 7) / 8 * 8);
-        }
+        BT(batch_set_geometry(b));
         if (!dense) {
-            // entry slabs: min(M, 4) levels per position fit without overflow; the rest spills
-            b->slab = (uint32_t)W * (uint32_t)std::min(b->M, 4);
-            b->cap_ovf = b->M <= 4 ? 16 : (size_t)std::max<uint64_t>(1u << 20, std::min<uint64_t>((uint64_t)n_obs, npm) / 4);
             const uint64_t tot = (uint64_t)b->n_win * b->slab + b->cap_ovf;
             if (tot >= 0xFFFFFFFFull) { isx_batch_destroy(b); isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_ARG; }
             b->cap_entries = (size_t)tot;
@@ -680,7 +634,7 @@ static float ev_ms(hipEvent_t a, hipEvent_t b)
 }
 
 // enqueue one pass (pileup kernel + state publication) on the context's stream; no host wait
-static int launch_pass(isx_batch *b)
+int launch_pass(isx_batch *b)
 {
     isx_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
@@ -694,7 +648,9 @@ static int launch_pass(isx_batch *b)
     a.pair = b->d_pair; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_rec32 ? b->d_gbase : b->d_cbase; a.gpos16_shift = b->gpos16_shift; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;
-    if (const char *e = getenv("ISX_DEBUG_MODE")) a.debug_mode = atoi(e);     // ablation only
+#ifdef ISX_TUNING
+    if (const char *e = getenv("ISX_DEBUG_MODE")) a.debug_mode = atoi(e);     // ablation, tuning builds only: skips parts of the kernel
+#endif
     a.counts = b->d_counts; a.clon = b->d_clon; a.clon_r = b->d_clon_r;
     a.min_cov_r = b->prm.rarefied_coverage;
     a.seed_lo = (uint32_t)b->prm.seed; a.seed_hi = (uint32_t)(b->prm.seed >> 32);
@@ -727,7 +683,7 @@ static int launch_pass(isx_batch *b)
 
 // wait for the pass enqueued by launch_pass and collect it (linkage stages run here: they need the
 // table sizes on the host); *cap_flags receives the ISX_FLAG_CAP_* bits of tables that were too small
-static int finish_pass(isx_batch *b, uint32_t *cap_flags)
+int finish_pass(isx_batch *b, uint32_t *cap_flags)
 {
     *cap_flags = 0;
     isx_ctx *c = b->ctx;
@@ -810,6 +766,48 @@ static int finish_pass(isx_batch *b, uint32_t *cap_flags)
     return ISX_OK;
 }
 
+int batch_grow_tables(isx_batch *b, uint32_t cap_flags)
+{
+    // hard bounds come from the positions / observations the device buffers were sized for (a pipe slot
+    // outlives its batches: cap_pos / cap_obs; a plain batch: its own n_pos / n_obs)
+    const uint64_t pos_bound = (uint64_t)(b->cap_pos ? b->cap_pos : b->n_pos);
+    const uint64_t obs_bound = (uint64_t)std::max<int64_t>(b->cap_obs ? b->cap_obs : b->n_obs, 1);
+    const uint64_t npm = pos_bound * b->M;
+    int rc = ISX_OK;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    if (cap_flags & ISX_FLAG_CAP_SNV) { if ((rc = regrow(&b->d_snv, &b->cap_snv, (size_t)npm))) return rc; }
+    if (cap_flags & ISX_FLAG_CAP_SITES) {
+        // the flag covers the site table and (mm path) the per-site level rows, first sized for 8 levels a
+        // site: with the site table already at its bound only the level rows are short
+        const bool slev_short = b->M > 1 && b->cap_slev < b->cap_sites * (size_t)b->M;
+        if (b->cap_sites < (size_t)pos_bound || !slev_short) {
+            if ((rc = regrow(&b->d_sites, &b->cap_sites, (size_t)pos_bound))) return rc;
+        }
+        if (b->M > 1) {
+            if (b->d_slev) (void)hipFree(b->d_slev);
+            b->d_slev = nullptr;
+            b->cap_slev = b->cap_sites * (size_t)b->M;
+            HIP_TRY(hipMalloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
+        }
+    }
+    if (cap_flags & ISX_FLAG_CAP_AO) { if ((rc = regrow(&b->d_ao, &b->cap_ao, (size_t)obs_bound))) return rc; }
+    if (cap_flags & ISX_FLAG_CAP_ENTRIES) {
+        const size_t used_slabs = (size_t)b->n_win * b->slab;
+        const size_t slabs = b->slab_region ? b->slab_region : used_slabs;      // entries set aside for the window slabs
+        size_t cap = b->cap_entries - slabs;
+        isx_entry *dummy = nullptr;
+        if ((rc = regrow(&dummy, &cap, (size_t)npm))) return rc;      // size check only
+        (void)hipFree(dummy);
+        if (slabs + cap >= 0xFFFFFFFFull) { isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_CAPACITY; }
+        if (b->d_entries) (void)hipFree(b->d_entries);
+        b->d_entries = nullptr;
+        HIP_TRY(hipMalloc(&b->d_entries, (slabs + cap) * sizeof(isx_entry)));
+        b->cap_entries = slabs + cap;
+        b->cap_ovf = b->cap_entries - used_slabs;
+    }
+    return ISX_OK;
+}
+
 int isx_batch_launch(isx_batch *b)
 {
     if (!b) { isx_set_error("isx_batch_launch: NULL batch"); return ISX_ERR_ARG; }
@@ -823,7 +821,6 @@ int isx_batch_wait(isx_batch *b)
     if (!b->in_flight) { isx_set_error("isx_batch_wait: no pass in flight"); return ISX_ERR_STATE; }
     // Output tables start from generous estimates; a table that turns out too small (e.g. SNS rows at
     // every position of a divergent reference) is grown x4 up to its hard bound and the pass repeated.
-    const uint64_t npm = (uint64_t)b->n_pos * b->M;
     for (int attempt = 0; attempt < 8; attempt++) {
         uint32_t cf = 0;
         int rc = ISX_OK;
@@ -831,35 +828,7 @@ int isx_batch_wait(isx_batch *b)
         rc = finish_pass(b, &cf);
         if (rc != ISX_OK) return rc;
         if (!cf) return ISX_OK;
-        HIP_TRY(hipSetDevice(b->ctx->device));
-        if (cf & ISX_FLAG_CAP_SNV) { if ((rc = regrow(&b->d_snv, &b->cap_snv, (size_t)npm))) return rc; }
-        if (cf & ISX_FLAG_CAP_SITES) {
-            // the flag covers the site table and (mm path) the per-site level rows, first sized for 8 levels a
-            // site: with the site table already at its bound only the level rows are short
-            const bool slev_short = b->M > 1 && b->cap_slev < b->cap_sites * (size_t)b->M;
-            if (b->cap_sites < (size_t)b->n_pos || !slev_short) {
-                if ((rc = regrow(&b->d_sites, &b->cap_sites, (size_t)b->n_pos))) return rc;
-            }
-            if (b->M > 1) {
-                if (b->d_slev) (void)hipFree(b->d_slev);
-                b->d_slev = nullptr;
-                b->cap_slev = b->cap_sites * (size_t)b->M;
-                HIP_TRY(hipMalloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
-            }
-        }
-        if (cf & ISX_FLAG_CAP_AO) { if ((rc = regrow(&b->d_ao, &b->cap_ao, (size_t)std::max<int64_t>(b->n_obs, 1)))) return rc; }
-        if (cf & ISX_FLAG_CAP_ENTRIES) {
-            const size_t slabs = (size_t)b->n_win * b->slab;
-            size_t cap = b->cap_ovf;
-            isx_entry *dummy = nullptr;
-            if ((rc = regrow(&dummy, &cap, (size_t)npm))) return rc;      // size check only
-            (void)hipFree(dummy);
-            if (slabs + cap >= 0xFFFFFFFFull) { isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_CAPACITY; }
-            if (b->d_entries) (void)hipFree(b->d_entries);
-            b->d_entries = nullptr;
-            HIP_TRY(hipMalloc(&b->d_entries, (slabs + cap) * sizeof(isx_entry)));
-            b->cap_ovf = cap; b->cap_entries = slabs + cap;
-        }
+        if ((rc = batch_grow_tables(b, cf)) != ISX_OK) return rc;
     }
     isx_set_error("output tables still too small after 8 growth steps");
     return ISX_ERR_CAPACITY;

@@ -1,0 +1,103 @@
+// isx_batch.h -- the context / resident-batch objects behind the C ABI, shared by isx_api.hip (create / run /
+// fetch) and isx_pipe.hip (the streaming hand-over: reusable batch slots fed through pinned staging).
+#pragma once
+#include <vector>
+
+#include "isx_internal.h"
+#include "isx_linkage.h"
+#include "isx_summary.h"
+
+namespace isxenc { class HostPool; }
+
+struct isx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // passes (pileup kernel + cursor publication) run on one of two streams, alternating by batch: consecutive
+    // batches' kernels are in different queues, so the next one's workgroups move in as the current one's retire
+    // (no kernel-boundary gap); everything else of a batch runs on `stream` after its pass is known to be complete
+    hipStream_t pstream[2] = {nullptr, nullptr};
+    struct isx_batch *unpublished[2] = {nullptr, nullptr};   // per pass stream: batch whose last pass has no publication enqueued yet
+    unsigned n_created = 0;
+    uint8_t *d_lut = nullptr;
+    std::vector<int32_t> h_lut;
+    int32_t lut_n = 0, fallback = 0;
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+};
+
+struct isx_batch {
+    isx_ctx *ctx = nullptr;
+    isx_params prm{};
+    int64_t n_pos = 0, n_obs = 0;
+    int64_t cap_pos = 0, cap_obs = 0;   // pipe slots: what the device buffers were sized for (0 = this batch's own n_pos / n_obs)
+    size_t slab_region = 0;             // pipe slots, mm path: entries set aside for the window slabs (0 = n_win * slab)
+    bool arena = false;                 // pipe slots: the input arrays live in the slot's arena, not in own allocations
+    uint64_t n_rec = 0;         // padded
+    uint64_t n_pairs = 0;
+    int32_t n_splits = 0;
+    int W = 0, logW = 0, M = 1, n_win = 0, block = 1024, grid = 0, packed = 0;
+    size_t lds = 0;
+    // device
+    uint2 *d_rec = nullptr;             // wide stream (8-byte isx_obs) -- or:
+    uint32_t *d_rec32 = nullptr, *d_gbase = nullptr;    // compact stream (4-byte records + one position base per 256)
+    uint16_t *d_rec16 = nullptr;                        // short stream (n_mm_bins == 1: 2-byte records, base per 512)
+    uint32_t *d_pair = nullptr, *d_gpos = nullptr, *d_cbase = nullptr;
+    uint16_t *d_gpos16 = nullptr;
+    int gpos16_shift = 7;
+    uint8_t *d_ref = nullptr;
+    uint2 *d_win = nullptr;
+    uint16_t *d_thr = nullptr;
+    int qcap = 1024, rqcap = 0, stage_off = 0;
+    bool in_flight = false, publish_enqueued = true, tim_pending = false;
+    int ps = 0;                                           // which pass stream of the context
+    int64_t *d_bounds = nullptr;
+    uint4 *d_counts = nullptr;
+    float *d_clon = nullptr;
+    float *d_clon_r = nullptr;       // rarefied clonality of the dense path [n_pos]
+    isx_entry *d_entries = nullptr;  // mm path: [n_win][slab] slabs, then cap_ovf overflow entries
+    uint32_t *d_win_nent = nullptr;
+    isx_slev *d_slev = nullptr;
+    uint32_t slab = 0;
+    size_t cap_ovf = 0, cap_slev = 0;
+    isx_snv *d_snv = nullptr;
+    isx_site *d_sites = nullptr;
+    isx_ao *d_ao = nullptr;
+    uint32_t *d_cursors = nullptr, *d_flags = nullptr;   // one allocation: cursors[CUR_N] | flags[4]
+    uint32_t *h_state = nullptr;                          // mapped pinned mirror, written by k_publish_state
+    uint32_t *d_host_state = nullptr;                     // device address of h_state
+    uint32_t base[CUR_N] = {};                            // cursor values at the start of the next run
+    uint32_t epoch = 0;                                   // run counter, echoed by k_publish_state
+    size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
+    LinkageBuffers L;
+    SummaryBuffers S;
+    CompareBuffers C;
+    hipEvent_t ev_sum[2] = {};
+    hipEvent_t ev[10] = {};
+    bool ran = false;
+    uint32_t n_ovf = 0;
+    isx_sizes sizes{};
+    isx_timings tim{};
+};
+
+
+// ---- shared between isx_api.hip and isx_pipe.hip ----
+std::vector<uint16_t> build_thresholds(const std::vector<int32_t> &lut, int32_t fallback, double min_freq);
+
+// window size of a batch of n_pos positions (0 = params.window unset -> auto), see isx_batch_create
+int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed);
+
+// window -> record range directory from the per-chunk position ranges (prefix-max / suffix-min); returns
+// the longest record range of a window
+uint64_t build_window_directory(const uint32_t *cmin, const uint32_t *cmax, const uint8_t *cany, uint64_t n_chunks, int W,
+                                int64_t n_pos, std::vector<uint2> &win);
+
+// derived launch geometry (LDS bytes, persistent grid, row-queue capacity, entry slab) once b->W / b->packed are set
+int batch_set_geometry(isx_batch *b);
+
+extern "C" {
+int launch_pass(isx_batch *b);
+int finish_pass(isx_batch *b, uint32_t *cap_flags);
+// grow the tables named by cap_flags (x4 up to their hard bounds); the pass must then be repeated
+int batch_grow_tables(isx_batch *b, uint32_t cap_flags);
+}

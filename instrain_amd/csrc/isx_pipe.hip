@@ -1,0 +1,499 @@
+// isx_pipe.hip -- streaming hand-over: a stream of batches, each profiled exactly once (isx_pipe_* of the C ABI).
+//
+// Reference analogue: the command queue / result queue pair around the split workers
+// (/root/reference/inStrain/profile/profile_controller.py:157-193 make_profile_queues, :243-271
+// spawn_profile_workers, :273-314 recieve_profile_results): splits go in, SplitObjects come back, every split
+// is profiled once.  Here the unit is a batch of splits and the three stages run on different engines:
+//
+//   host threads   isx_obs (8 B) -> resident records (2 / 4 B) straight into the slot's pinned input arena
+//   copy-in queue  ONE contiguous arena: split bounds | window directory | reference codes | group bases |
+//                  records | pair ids  -> the slot's device arena of the same layout (hipMemcpyAsync)
+//   pass queue     k_pileup_dense / k_pileup_mm (+ the cursor publication) once the copy-in event has fired
+//   copy-out queue counts | clonality | rarefied clonality | first SNV rows -> the slot's pinned result block
+//
+// A slot is a complete isx_batch whose device tables are sized once for the pipe's largest batch, so a
+// submit allocates nothing and everything isx_batch_* offers (linkage stages, entry fetch, summaries,
+// compare) works on a collected slot unchanged.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "isx_batch.h"
+#include "obs_encode.h"
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Slot {
+    isx_batch *b = nullptr;
+    uint8_t *h_in = nullptr, *d_in = nullptr;
+    size_t in_bytes = 0;
+    size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_rec = 0, off_pair = 0;
+    uint8_t *h_out = nullptr;
+    size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0;
+    std::vector<uint32_t> cmin, cmax;
+    std::vector<uint8_t> cany;
+    std::vector<uint2> win;
+    std::vector<isx_snv> snv_big;           // more SNV rows than the pinned block holds (rare)
+    hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_pass = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
+    int64_t ticket = -1;
+    int state = 0;                          // 0 free, 1 submitted, 2 collected
+    float encode_ms = 0.f;
+    int encode_passes = 0;
+    int64_t h2d_bytes = 0, d2h_bytes = 0;
+    uint16_t *d_gpos16 = nullptr;           // compact stream + linkage: positions alone for the allele pass
+};
+
+int cgroup_cpus()
+{
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        long period = 0;
+        const int n = fscanf(f, "%63s %ld", q, &period);
+        fclose(f);
+        if (n == 2 && period > 0 && strcmp(q, "max") != 0) return (int)std::max<long>(1, atol(q) / period);
+    }
+    return 0;
+}
+
+int gpu_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) return -1;
+    std::string id(bus);
+    std::transform(id.begin(), id.end(), id.begin(), [](unsigned char ch) { return (char)std::tolower(ch); });
+    int node = -1;
+    if (FILE *f = fopen(("/sys/bus/pci/devices/" + id + "/numa_node").c_str(), "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    return node;
+}
+
+}  // namespace
+
+struct isx_pipe {
+    isx_ctx *ctx = nullptr;
+    isx_params prm{};
+    isx_pipe_params pp{};
+    std::unique_ptr<isxenc::HostPool> pool;
+    std::vector<Slot> slots;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    int64_t next_ticket = 0;
+    int64_t cap_rec = 0;
+    int rb = 2;                             // record bytes
+    uint32_t G = ISX_GROUP16;
+    size_t snv_prefix = 0;                  // SNV rows copied out with the dense tables
+    double slack = 0.0;                     // learned: extra device groups per input group of the last jumping batch
+};
+
+static void pipe_free(isx_pipe *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
+    if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
+    for (int i = 0; i < 2; i++) if (p->ctx->pstream[i]) (void)hipStreamSynchronize(p->ctx->pstream[i]);
+    for (Slot &s : p->slots) {
+        if (s.b) {
+            isx_batch *b = s.b;             // the input arrays belong to the arena, not to the batch
+            b->d_rec = nullptr; b->d_rec32 = nullptr; b->d_rec16 = nullptr; b->d_gbase = nullptr; b->d_pair = nullptr;
+            b->d_gpos = nullptr; b->d_gpos16 = nullptr; b->d_cbase = nullptr; b->d_ref = nullptr; b->d_win = nullptr;
+            b->d_bounds = nullptr;
+            isx_batch_destroy(b);
+        }
+        if (s.d_gpos16) (void)hipFree(s.d_gpos16);
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_pass, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
+    }
+    if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
+    if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
+    delete p;
+}
+
+// device tables of a slot, sized for the pipe's capacities (the allocation half of isx_batch_create)
+static int slot_batch_create(isx_pipe *p, Slot &s, int index)
+{
+    isx_ctx *c = p->ctx;
+    const isx_params *prm = &p->prm;
+    isx_batch *b = new isx_batch();
+    s.b = b;
+    b->ctx = c; b->prm = *prm; b->M = prm->n_mm_bins;
+    b->ps = index & 1;
+    b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true;
+    b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
+    const bool dense = b->M == 1;
+    b->block = dense ? 1024 : 512;
+    const int64_t cap_pos = p->pp.max_pos;
+    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : b->ev_sum) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipMalloc(&b->d_cursors, (CUR_N + 4) * sizeof(uint32_t)));
+    b->d_flags = b->d_cursors + CUR_N;
+    HIP_TRY(hipHostMalloc(&b->h_state, (CUR_N + 8) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(b->h_state, 0, (CUR_N + 8) * sizeof(uint32_t));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_host_state), b->h_state, 0));
+    HIP_TRY(hipMemset(b->d_cursors, 0, (CUR_N + 4) * sizeof(uint32_t)));
+    {
+        std::vector<uint16_t> thr = build_thresholds(c->h_lut, c->fallback, prm->min_freq);
+        HIP_TRY(hipMalloc(&b->d_thr, thr.size() * sizeof(uint16_t)));
+        HIP_TRY(hipMemcpy(b->d_thr, thr.data(), thr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    const uint64_t npm = (uint64_t)cap_pos * b->M;
+    const uint64_t cap_obs = (uint64_t)std::max<int64_t>(p->pp.max_obs, 1);
+    if (dense) {
+        HIP_TRY(hipMalloc(&b->d_counts, (size_t)cap_pos * sizeof(uint4)));
+        HIP_TRY(hipMalloc(&b->d_clon, (size_t)cap_pos * sizeof(float)));
+        HIP_TRY(hipMalloc(&b->d_clon_r, (size_t)cap_pos * sizeof(float)));
+    } else {
+        b->slab_region = (size_t)(cap_pos + 2 * b->block) * (size_t)std::min(b->M, 4);
+        const size_t ovf = b->M <= 4 ? 16 : (size_t)std::max<uint64_t>(1u << 20, std::min<uint64_t>(cap_obs, npm) / 4);
+        if (b->slab_region + ovf >= 0xFFFFFFFFull) { isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_ARG; }
+        b->cap_entries = b->slab_region + ovf;
+        HIP_TRY(hipMalloc(&b->d_entries, b->cap_entries * sizeof(isx_entry)));
+        HIP_TRY(hipMalloc(&b->d_win_nent, ((size_t)cap_pos / 64 + 2) * sizeof(uint32_t)));
+    }
+    b->cap_snv = (size_t)std::min<uint64_t>(npm, std::max<uint64_t>((uint64_t)cap_pos / 2, 1u << 20));
+    b->cap_sites = (size_t)std::min<uint64_t>((uint64_t)cap_pos, std::max<uint64_t>((uint64_t)cap_pos / 4, 1u << 20));
+    b->cap_ao = (size_t)std::max<uint64_t>(1, std::min<uint64_t>(cap_obs, std::max<uint64_t>(cap_obs / 4, 1u << 20)));
+    HIP_TRY(hipMalloc(&b->d_snv, b->cap_snv * sizeof(isx_snv)));
+    HIP_TRY(hipMalloc(&b->d_sites, b->cap_sites * sizeof(isx_site)));
+    if (prm->enable_linkage) HIP_TRY(hipMalloc(&b->d_ao, b->cap_ao * sizeof(isx_ao)));
+    if (!dense) {
+        b->cap_slev = b->cap_sites * (size_t)std::min(b->M, 8);
+        HIP_TRY(hipMalloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
+    }
+    // input arena: one layout for the pinned staging block and its device twin
+    size_t o = 0;
+    s.off_bounds = o; o = up(o + (size_t)(p->pp.max_splits + 1) * sizeof(int64_t));
+    s.off_win = o; o = up(o + ((size_t)cap_pos / 64 + 2) * sizeof(uint2));
+    s.off_ref = o; o = up(o + (size_t)cap_pos);
+    s.off_gbase = o; o = up(o + (size_t)(p->cap_rec / p->G) * sizeof(uint32_t));
+    s.off_rec = o; o = up(o + (size_t)p->cap_rec * p->rb);
+    s.off_pair = o; if (prm->enable_linkage) o = up(o + (size_t)p->cap_rec * sizeof(uint32_t));
+    s.in_bytes = o;
+    HIP_TRY(hipHostMalloc(&s.h_in, s.in_bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&s.d_in, s.in_bytes));
+    if (prm->enable_linkage && p->rb == 4) HIP_TRY(hipMalloc(&s.d_gpos16, (size_t)p->cap_rec * sizeof(uint16_t)));
+    // pinned result block
+    o = 0;
+    s.o_snv = o; o = up(o + p->snv_prefix * sizeof(isx_snv));
+    if (dense) {
+        s.o_counts = o; o = up(o + (size_t)cap_pos * 16);
+        s.o_clon = o; o = up(o + (size_t)cap_pos * 4);
+        s.o_clonr = o; if (prm->rarefied_coverage > 0) o = up(o + (size_t)cap_pos * 4);
+    }
+    s.out_bytes = o;
+    HIP_TRY(hipHostMalloc(&s.h_out, s.out_bytes, hipHostMallocDefault));
+    for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_pass, &s.ev_d2h0, &s.ev_d2h1}) HIP_TRY(hipEventCreate(e));
+    const size_t n_chunks = (size_t)(p->cap_rec / ISX_CHUNK) + 2;
+    s.cmin.resize(n_chunks); s.cmax.resize(n_chunks); s.cany.resize(n_chunks);
+    return ISX_OK;
+}
+
+extern "C" {
+
+int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp, isx_pipe **out)
+{
+    if (!c || !prm || !pp || !out) { isx_set_error("isx_pipe_create: bad argument"); return ISX_ERR_ARG; }
+    *out = nullptr;
+    if (!c->d_lut) { isx_set_error("isx_pipe_create: call isx_set_null_model first"); return ISX_ERR_STATE; }
+    if (prm->n_mm_bins < 1 || prm->n_mm_bins > 128) { isx_set_error("n_mm_bins must be in [1, 128]"); return ISX_ERR_ARG; }
+    if (pp->max_pos <= 0 || pp->max_obs < 0 || pp->max_splits <= 0 || pp->depth < 2 || pp->depth > 64) {
+        isx_set_error("isx_pipe_create: max_pos > 0, max_obs >= 0, max_splits > 0, 2 <= depth <= 64");
+        return ISX_ERR_ARG;
+    }
+    if (pp->max_pos >= (int64_t)0xFFFF0000ll) { isx_set_error("flat position space must be < 2^32 - 65536"); return ISX_ERR_ARG; }
+    if (prm->window && (prm->window < 64 || (prm->window & 63) || prm->window > 8192)) { isx_set_error("window must be a multiple of 64 in [64, 8192]"); return ISX_ERR_ARG; }
+    if (prm->layout & ISX_LAYOUT_WIDE_RECORDS) { isx_set_error("a pipe streams 2- / 4-byte records only"); return ISX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    isx_pipe *p = new isx_pipe();
+    p->ctx = c; p->prm = *prm; p->pp = *pp;
+    p->rb = (prm->n_mm_bins == 1 && !(prm->layout & ISX_LAYOUT_NO_SHORT_RECORDS)) ? 2 : 4;
+    p->G = p->rb == 2 ? ISX_GROUP16 : ISX_GROUP;
+    const double js = pp->jump_slack > 0 ? pp->jump_slack : 0.25;
+    const uint64_t want = (uint64_t)((double)pp->max_obs * (1.0 + js)) + 4 * ISX_PAD;
+    p->cap_rec = (int64_t)((want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
+    if ((uint64_t)p->cap_rec >= 0xFFFFFFFFull) { delete p; isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
+    p->snv_prefix = (size_t)std::min<int64_t>(std::max<int64_t>(pp->max_pos / 64, 1 << 16), 1 << 22);
+    int nt = pp->host_threads;
+    if (nt <= 0) {
+        const int q = cgroup_cpus();
+        nt = q > 0 ? q : (int)std::thread::hardware_concurrency();
+        nt = std::max(1, std::min(nt, 32));
+    }
+    p->pool.reset(new isxenc::HostPool(nt, gpu_numa_node(c->device), pp->pin_threads != 0));
+    int rc = ISX_OK;
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking)) != hipSuccess) {
+        isx_set_error(std::string("isx_pipe_create: ") + hipGetErrorString(e));
+        pipe_free(p);
+        return ISX_ERR_HIP;
+    }
+    p->slots.resize((size_t)pp->depth);
+    for (int i = 0; i < pp->depth && rc == ISX_OK; i++) rc = slot_batch_create(p, p->slots[(size_t)i], i);
+    if (rc != ISX_OK) { pipe_free(p); return rc; }
+    *out = p;
+    return ISX_OK;
+}
+
+void isx_pipe_destroy(isx_pipe *p) { pipe_free(p); }
+
+int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                    int64_t n_obs, const isx_obs *obs, const uint32_t *pair, int64_t *ticket)
+{
+    if (!p || !ref || !split_bounds || !ticket || n_pos <= 0 || n_splits <= 0 || n_obs < 0 || (n_obs && !obs)) {
+        isx_set_error("isx_pipe_submit: bad argument");
+        return ISX_ERR_ARG;
+    }
+    if (n_pos > p->pp.max_pos || n_obs > p->pp.max_obs || n_splits > p->pp.max_splits) {
+        isx_set_error("isx_pipe_submit: batch larger than the pipe was created for");
+        return ISX_ERR_CAPACITY;
+    }
+    if (p->prm.enable_linkage && n_obs && !pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
+    if (split_bounds[0] != 0 || split_bounds[n_splits] != n_pos) { isx_set_error("split_bounds must span [0, n_pos]"); return ISX_ERR_ARG; }
+    for (int i = 0; i < n_splits; i++)
+        if (split_bounds[i + 1] <= split_bounds[i]) { isx_set_error("split_bounds must be strictly ascending"); return ISX_ERR_ARG; }
+    Slot &s = p->slots[(size_t)(p->next_ticket % (int64_t)p->slots.size())];
+    if (s.state != 0) { isx_set_error("isx_pipe_submit: every slot is in use (collect + release the oldest batch first)"); return ISX_ERR_STATE; }
+    isx_ctx *c = p->ctx;
+    isx_batch *b = s.b;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool dense = b->M == 1, linkage = p->prm.enable_linkage != 0;
+
+    // ---- host threads: records + group bases (+ pair ids) into the pinned arena, reference codes, bounds ----
+    const double t0 = now_ms();
+    isxenc::EncodeJob J;
+    J.obs = obs; J.pair = linkage ? pair : nullptr; J.n_obs = n_obs; J.n_pos = n_pos; J.record_bytes = p->rb;
+    J.rec = s.h_in + s.off_rec; J.gbase = reinterpret_cast<uint32_t *>(s.h_in + s.off_gbase);
+    J.pair_out = linkage ? reinterpret_cast<uint32_t *>(s.h_in + s.off_pair) : nullptr;
+    J.cmin = s.cmin.data(); J.cmax = s.cmax.data(); J.cany = s.cany.data();
+    J.cap_rec = p->cap_rec; J.slack = p->slack;
+    const int erc = isxenc::encode_obs(*p->pool, J);
+    if (erc == isxenc::ENC_CAPACITY) { isx_set_error("isx_pipe_submit: the stream jumps too often for the pipe's record capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
+    if (erc == isxenc::ENC_MM_RANGE) { isx_set_error("an observation has mm >= 256"); return ISX_ERR_MM_RANGE; }
+    if (erc == isxenc::ENC_BAD_POS) { isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
+    if (J.passes > 1 && J.n_groups_in > 0)            // remember how jumpy this stream is: the next batch gets its slack up front
+        p->slack = std::max(p->slack, 1.25 * ((double)J.n_groups_real / (double)J.n_groups_in - 1.0) + 0.01);
+    {
+        const int64_t piece = (int64_t)4 << 20;
+        const int n_tasks = (int)((n_pos + piece - 1) / piece);
+        uint8_t *dst = s.h_in + s.off_ref;
+        auto cp = [&](int t) {
+            const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
+            memcpy(dst + a, ref + a, (size_t)(e - a));
+        };
+        if (n_tasks > 1) p->pool->run(n_tasks, cp); else cp(0);
+    }
+    memcpy(s.h_in + s.off_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t));
+
+    // ---- this batch's geometry ----
+    b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits; b->n_rec = (uint64_t)J.n_rec;
+    b->n_pairs = (uint64_t)J.max_pair + 1;
+    const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
+    b->packed = 0;
+    int W = batch_window_for(b, n_pos, false);
+    if (!dense) {
+        const int Wp = batch_window_for(b, n_pos, true);
+        if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
+            build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win) < 65536) { b->packed = 1; W = Wp; }
+    }
+    if (!b->packed) build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, W, n_pos, s.win);
+    b->W = W;
+    b->n_win = (int)s.win.size();
+    if (s.win.size() > (size_t)p->pp.max_pos / 64 + 2) { isx_set_error("internal: window directory larger than the arena"); return ISX_ERR_STATE; }
+    int rc = batch_set_geometry(b);
+    if (rc != ISX_OK) return rc;
+    if (!dense) {
+        const size_t used = (size_t)b->n_win * b->slab;
+        if (used > b->slab_region) { isx_set_error("internal: entry slabs larger than the slot's region"); return ISX_ERR_STATE; }
+        b->cap_ovf = b->cap_entries - used;
+    }
+    memcpy(s.h_in + s.off_win, s.win.data(), s.win.size() * sizeof(uint2));
+    b->d_bounds = reinterpret_cast<int64_t *>(s.d_in + s.off_bounds);
+    b->d_win = reinterpret_cast<uint2 *>(s.d_in + s.off_win);
+    b->d_ref = s.d_in + s.off_ref;
+    b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
+    b->d_rec16 = p->rb == 2 ? reinterpret_cast<uint16_t *>(s.d_in + s.off_rec) : nullptr;
+    b->d_rec32 = p->rb == 4 ? reinterpret_cast<uint32_t *>(s.d_in + s.off_rec) : nullptr;
+    b->d_pair = linkage ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pair) : nullptr;
+    b->d_gpos16 = s.d_gpos16; b->gpos16_shift = 5;
+    s.encode_ms = (float)(now_ms() - t0);
+    s.encode_passes = J.passes;
+
+    // ---- copy-in queue ----
+    hipStream_t ps = c->pstream[b->ps];
+    HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+    const size_t head = s.off_ref + (size_t)n_pos;                         // bounds | windows | reference codes
+    const size_t gb_bytes = (size_t)(b->n_rec / p->G) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * p->rb;
+    HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, head, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
+    if (linkage) {
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pair, s.h_in + s.off_pair, (size_t)b->n_rec * 4, hipMemcpyHostToDevice, p->s_h2d));
+        s.h2d_bytes += (int64_t)b->n_rec * 4;
+    }
+    HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
+
+    // ---- pass queue ----
+    HIP_TRY(hipStreamWaitEvent(ps, s.ev_h2d1, 0));
+    if (dense && p->prm.rarefied_coverage > 0)
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)n_pos, ps));
+    if (linkage && p->rb == 4)
+        launch_extract_gpos(nullptr, b->d_rec32, b->d_gbase, nullptr, b->d_gpos16, b->d_gbase, ISX_GROUP, b->n_rec, ps);
+    if ((rc = launch_pass(b)) != ISX_OK) return rc;
+    {   // cursors -> mapped host state right behind the kernel: the copy-out below needs no host round trip
+        PileupArgs pa{};
+        pa.cursors = b->d_cursors; pa.host_state = b->d_host_state;
+        launch_publish_state(pa, b->epoch, ps);
+        b->publish_enqueued = true;
+        if (c->unpublished[b->ps] == b) c->unpublished[b->ps] = nullptr;
+    }
+    HIP_TRY(hipEventRecord(s.ev_pass, ps));
+
+    // ---- copy-out queue ----
+    HIP_TRY(hipStreamWaitEvent(p->s_d2h, s.ev_pass, 0));
+    HIP_TRY(hipEventRecord(s.ev_d2h0, p->s_d2h));
+    const size_t snv_rows = std::min(p->snv_prefix, b->cap_snv);
+    HIP_TRY(hipMemcpyAsync(s.h_out + s.o_snv, b->d_snv, snv_rows * sizeof(isx_snv), hipMemcpyDeviceToHost, p->s_d2h));
+    s.d2h_bytes = (int64_t)(snv_rows * sizeof(isx_snv));
+    if (dense) {
+        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_counts, b->d_counts, (size_t)n_pos * 16, hipMemcpyDeviceToHost, p->s_d2h));
+        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clon, b->d_clon, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
+        s.d2h_bytes += (int64_t)n_pos * 20;
+        if (p->prm.rarefied_coverage > 0) {
+            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clonr, b->d_clon_r, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
+            s.d2h_bytes += (int64_t)n_pos * 4;
+        }
+    }
+    HIP_TRY(hipEventRecord(s.ev_d2h1, p->s_d2h));
+    s.ticket = p->next_ticket++;
+    s.state = 1;
+    *ticket = s.ticket;
+    return ISX_OK;
+}
+
+int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
+{
+    if (!p || !out || ticket < 0) { isx_set_error("isx_pipe_collect: bad argument"); return ISX_ERR_ARG; }
+    Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
+    if (s.ticket != ticket || s.state == 0) { isx_set_error("isx_pipe_collect: unknown or already released ticket"); return ISX_ERR_STATE; }
+    isx_ctx *c = p->ctx;
+    isx_batch *b = s.b;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool dense = b->M == 1;
+    *out = isx_pipe_result{};
+    if (s.state == 1) {
+        const double t0 = now_ms();
+        HIP_TRY(hipEventSynchronize(s.ev_d2h1));
+        out->collect_wait_ms = (float)(now_ms() - t0);
+        hipStream_t ps = c->pstream[b->ps];
+        bool redo = false;
+        for (int attempt = 0;; attempt++) {
+            uint32_t cf = 0;
+            int rc = finish_pass(b, &cf);           // sizes from the published cursors; linkage stages when enabled
+            if (rc != ISX_OK) { s.state = 2; return rc; }
+            if (!cf) break;
+            if (attempt == 7) { isx_set_error("output tables still too small after 8 growth steps"); s.state = 2; return ISX_ERR_CAPACITY; }
+            // a table was too small for this batch: grow it and repeat the pass (the slot still holds its input)
+            if ((rc = batch_grow_tables(b, cf)) != ISX_OK) { s.state = 2; return rc; }
+            if (!dense) b->cap_ovf = b->cap_entries - (size_t)b->n_win * b->slab;
+            if (dense && p->prm.rarefied_coverage > 0)
+                HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)b->n_pos, ps));
+            if ((rc = launch_pass(b)) != ISX_OK) { s.state = 2; return rc; }
+            redo = true;
+        }
+        if (redo && dense) {                        // the copied-out tables predate the repeated pass
+            HIP_TRY(hipMemcpy(s.h_out + s.o_counts, b->d_counts, (size_t)b->n_pos * 16, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+            if (p->prm.rarefied_coverage > 0)
+                HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+        }
+        const size_t n_snv = (size_t)b->sizes.n_snv;
+        isx_snv *rows = reinterpret_cast<isx_snv *>(s.h_out + s.o_snv);
+        if (n_snv > p->snv_prefix || redo) {
+            if (n_snv > p->snv_prefix) { s.snv_big.resize(n_snv); rows = s.snv_big.data(); }
+            if (n_snv) HIP_TRY(hipMemcpy(rows, b->d_snv, n_snv * sizeof(isx_snv), hipMemcpyDeviceToHost));
+        }
+        std::sort(rows, rows + n_snv, [](const isx_snv &x, const isx_snv &y) { return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm; });
+        s.state = 2;
+    }
+    out->ticket = ticket;
+    out->n_pos = b->n_pos; out->n_obs = b->n_obs;
+    out->sizes = b->sizes;
+    out->snv = (size_t)b->sizes.n_snv > p->snv_prefix ? s.snv_big.data() : reinterpret_cast<const isx_snv *>(s.h_out + s.o_snv);
+    if (dense) {
+        out->counts = reinterpret_cast<const uint32_t *>(s.h_out + s.o_counts);
+        out->clon = reinterpret_cast<const float *>(s.h_out + s.o_clon);
+        out->clon_rarefied = p->prm.rarefied_coverage > 0 ? reinterpret_cast<const float *>(s.h_out + s.o_clonr) : nullptr;
+    }
+    out->batch = b;
+    out->encode_ms = s.encode_ms;
+    out->encode_passes = s.encode_passes;
+    out->record_bytes = p->rb;
+    out->h2d_bytes = s.h2d_bytes; out->d2h_bytes = s.d2h_bytes;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.ev_h2d0, s.ev_h2d1) == hipSuccess) out->h2d_ms = ms;
+    if (hipEventElapsedTime(&ms, s.ev_d2h0, s.ev_d2h1) == hipSuccess) out->d2h_ms = ms;
+    isx_timings t{};
+    if (isx_batch_timings(b, &t) == ISX_OK) out->kernel_ms = t.pileup_ms;
+    return ISX_OK;
+}
+
+int isx_pipe_release(isx_pipe *p, int64_t ticket)
+{
+    if (!p || ticket < 0) { isx_set_error("isx_pipe_release: bad argument"); return ISX_ERR_ARG; }
+    Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
+    if (s.ticket != ticket || s.state == 0) { isx_set_error("isx_pipe_release: unknown or already released ticket"); return ISX_ERR_STATE; }
+    if (s.state == 1) {                             // never collected: let its queued work drain before the slot is reused
+        HIP_TRY(hipSetDevice(p->ctx->device));
+        HIP_TRY(hipEventSynchronize(s.ev_d2h1));
+        uint32_t cf = 0;
+        (void)finish_pass(s.b, &cf);
+    }
+    s.state = 0;
+    return ISX_OK;
+}
+
+int isx_encode_obs(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int64_t n_pos, int32_t record_bytes,
+                   int32_t host_threads, double slack, int64_t cap_rec, void *rec, uint32_t *gbase, uint32_t *pair_out,
+                   int64_t *n_rec, int32_t *passes)
+{
+    if ((n_obs && !obs) || n_obs < 0 || n_pos <= 0 || (record_bytes != 2 && record_bytes != 4) || !rec || !gbase || !n_rec ||
+        cap_rec < ISX_PAD || (cap_rec % ISX_PAD) || (pair && !pair_out)) {
+        isx_set_error("isx_encode_obs: bad argument");
+        return ISX_ERR_ARG;
+    }
+    isxenc::HostPool pool(std::max(1, host_threads), -1, false);
+    const size_t n_chunks = (size_t)(cap_rec / ISX_CHUNK) + 2;
+    std::vector<uint32_t> cmin(n_chunks), cmax(n_chunks);
+    std::vector<uint8_t> cany(n_chunks);
+    isxenc::EncodeJob J;
+    J.obs = obs; J.pair = pair; J.n_obs = n_obs; J.n_pos = n_pos; J.record_bytes = record_bytes;
+    J.rec = rec; J.gbase = gbase; J.pair_out = pair ? pair_out : nullptr;
+    J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data();
+    J.cap_rec = cap_rec; J.slack = slack;
+    const int erc = isxenc::encode_obs(pool, J);
+    if (erc == isxenc::ENC_CAPACITY) { isx_set_error("isx_encode_obs: cap_rec too small for this stream"); return ISX_ERR_CAPACITY; }
+    if (erc == isxenc::ENC_MM_RANGE) { isx_set_error("an observation has mm >= 256"); return ISX_ERR_MM_RANGE; }
+    if (erc == isxenc::ENC_BAD_POS) { isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
+    *n_rec = J.n_rec;
+    if (passes) *passes = J.passes;
+    return ISX_OK;
+}
+
+}  // extern "C"

@@ -57,7 +57,7 @@ class Batch:
     """A set of splits resident on the device (isx_batch_*)."""
 
     def __init__(self, ctx, ref_codes, split_bounds, obs, pair=None, min_cov=5, min_freq=0.05, min_snp=20,
-                 rarefied_coverage=50, n_mm_bins=1, enable_linkage=True, linkage_mode=0, window=0, seed=0):
+                 rarefied_coverage=50, n_mm_bins=1, enable_linkage=True, linkage_mode=0, window=0, seed=0, layout=0):
         self.ctx = ctx
         self.lib = ctx.lib
         ref_codes = np.ascontiguousarray(ref_codes, dtype=np.uint8)
@@ -70,7 +70,7 @@ class Batch:
         self.n_obs = len(obs)
         self.n_mm_bins = int(n_mm_bins)
         p = Params(int(min_cov), int(min_snp), float(min_freq), int(rarefied_coverage), int(n_mm_bins),
-                   1 if enable_linkage else 0, int(linkage_mode), int(window), int(seed))
+                   1 if enable_linkage else 0, int(linkage_mode), int(window), int(seed), int(layout), 0)
         h = C.c_void_p()
         check(self.lib.isx_batch_create(ctx.h, C.byref(p), self.n_pos, ref_codes.ctypes.data,
                                         len(split_bounds) - 1, split_bounds.ctypes.data, self.n_obs,
@@ -146,6 +146,123 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class _SlotBatch(Batch):
+    """A collected pipe slot seen as a Batch (fetch of entries / ld rows, summaries); owned by the pipe."""
+
+    def __init__(self, ctx, handle, n_pos, n_obs, n_mm_bins):
+        self.ctx, self.lib, self.h = ctx, ctx.lib, C.c_void_p(handle)
+        self.n_pos, self.n_obs, self.n_mm_bins = int(n_pos), int(n_obs), int(n_mm_bins)
+
+    def close(self):
+        self.h = None
+
+
+class Pipe:
+    """Streaming hand-over (isx_pipe_*): submit batches, collect each one's tables once.
+
+    submit() encodes the batch into pinned staging on the pipe's host threads and enqueues copy-in, the
+    pass and copy-out; collect() blocks until that batch's tables are on the host and returns them as
+    numpy views of the slot's pinned result block (valid until release())."""
+
+    def __init__(self, ctx, max_pos, max_obs, max_splits, depth=4, host_threads=0, pin_threads=True, jump_slack=0.0,
+                 min_cov=5, min_freq=0.05, min_snp=20, rarefied_coverage=50, n_mm_bins=1, enable_linkage=False,
+                 linkage_mode=0, window=0, seed=0, layout=0):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.n_mm_bins = int(n_mm_bins)
+        self.enable_linkage = bool(enable_linkage)
+        p = Params(int(min_cov), int(min_snp), float(min_freq), int(rarefied_coverage), int(n_mm_bins),
+                   1 if enable_linkage else 0, int(linkage_mode), int(window), int(seed), int(layout), 0)
+        pp = _lib.PipeParams(int(max_pos), int(max_obs), int(max_splits), int(depth), int(host_threads),
+                             1 if pin_threads else 0, float(jump_slack))
+        h = C.c_void_p()
+        check(self.lib.isx_pipe_create(ctx.h, C.byref(p), C.byref(pp), C.byref(h)))
+        self.h = h
+
+    def submit(self, ref_codes, split_bounds, obs, pair=None):
+        """-> ticket.  Arrays must be C-contiguous uint8 / int64 / OBS_DT / uint32 (no copies are made here)."""
+        ref_codes = np.ascontiguousarray(ref_codes, dtype=np.uint8)
+        split_bounds = np.ascontiguousarray(split_bounds, dtype=np.int64)
+        obs = np.ascontiguousarray(obs, dtype=OBS_DT)
+        if pair is not None:
+            pair = np.ascontiguousarray(pair, dtype=np.uint32)
+        t = C.c_int64(-1)
+        check(self.lib.isx_pipe_submit(self.h, len(ref_codes), ref_codes.ctypes.data, len(split_bounds) - 1,
+                                       split_bounds.ctypes.data, len(obs), obs.ctypes.data if len(obs) else None,
+                                       pair.ctypes.data if pair is not None and len(obs) else None, C.byref(t)))
+        return t.value
+
+    def collect(self, ticket, want_ld=True):
+        """-> dict like Batch.fetch() (+ 'sizes', 'stats'); the dense arrays / snv rows are views of pinned memory."""
+        r = _lib.PipeResult()
+        check(self.lib.isx_pipe_collect(self.h, int(ticket), C.byref(r)))
+        sz = {n: getattr(r.sizes, n) for n, _ in Sizes._fields_}
+        out = {"sizes": sz, "ticket": r.ticket,
+               "stats": {k: getattr(r, k) for k in ("encode_ms", "h2d_ms", "kernel_ms", "d2h_ms", "collect_wait_ms",
+                                                    "record_bytes", "encode_passes", "h2d_bytes", "d2h_bytes")}}
+        n_pos = int(r.n_pos)
+
+        def view(addr, dtype, n):
+            if not n:
+                return np.empty(0, dtype=dtype)
+            return np.frombuffer((C.c_uint8 * (n * np.dtype(dtype).itemsize)).from_address(addr), dtype=dtype)
+
+        slot = _SlotBatch(self.ctx, r.batch, n_pos, r.n_obs, self.n_mm_bins)
+        if self.n_mm_bins == 1:
+            out["counts"] = view(r.counts, np.uint32, n_pos * 4).reshape(n_pos, 4)
+            out["clon"] = view(r.clon, np.float32, n_pos)
+            out["clon_r"] = view(r.clon_rarefied, np.float32, n_pos) if r.clon_rarefied else np.full(n_pos, np.nan, np.float32)
+        else:
+            e = np.empty(max(1, sz["n_entries"]), dtype=ENTRY_DT)
+            check(self.lib.isx_batch_fetch_entries(slot.h, e.ctypes.data))
+            out["entries"] = e[:sz["n_entries"]]
+            out["clon_r"] = out["entries"]["clon_rarefied"]
+        out["snv"] = view(r.snv, SNV_DT, sz["n_snv"])
+        if want_ld and self.enable_linkage:
+            l = np.empty(max(1, sz["n_ld"]), dtype=LD_DT)
+            check(self.lib.isx_batch_fetch_ld(slot.h, l.ctypes.data))
+            out["ld"] = l[:sz["n_ld"]]
+        else:
+            out["ld"] = np.empty(0, dtype=LD_DT)
+        out["slot"] = slot
+        return out
+
+    def release(self, ticket):
+        check(self.lib.isx_pipe_release(self.h, int(ticket)))
+
+    def close(self):
+        if self.h:
+            self.lib.isx_pipe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def encode_obs(obs, pair=None, n_pos=None, record_bytes=2, threads=1, slack=0.0, cap_rec=None):
+    """isx_encode_obs (host only): -> (rec, gbase, pair_out | None, passes)"""
+    lib = _lib.load()
+    obs = np.ascontiguousarray(obs, dtype=OBS_DT)
+    G = 512 if record_bytes == 2 else 256
+    if cap_rec is None:
+        cap_rec = (int(len(obs) * 1.5) + 4 * 2048 + 2047) // 2048 * 2048
+    if n_pos is None:
+        n_pos = int(obs["gpos"].max()) + 1 if len(obs) else 1
+    rec = np.empty(cap_rec, dtype=np.uint16 if record_bytes == 2 else np.uint32)
+    gbase = np.empty(cap_rec // G, dtype=np.uint32)
+    pout = np.empty(cap_rec, dtype=np.uint32) if pair is not None else None
+    if pair is not None:
+        pair = np.ascontiguousarray(pair, dtype=np.uint32)
+    n_rec, passes = C.c_int64(0), C.c_int32(0)
+    check(lib.isx_encode_obs(obs.ctypes.data if len(obs) else None, pair.ctypes.data if pair is not None else None, len(obs),
+                             int(n_pos), int(record_bytes), int(threads), float(slack), int(cap_rec), rec.ctypes.data,
+                             gbase.ctypes.data, pout.ctypes.data if pout is not None else None, C.byref(n_rec), C.byref(passes)))
+    n = n_rec.value
+    return rec[:n], gbase[:n // G], (pout[:n] if pout is not None else None), passes.value
 
 
 def dense_to_entries(counts, clon):

@@ -115,3 +115,29 @@ def make_workload(genome_len=5_000_000, coverage=20, read_len=150, insert_mean=3
         "profiled_bases": int(n_pairs) * 2 * read_len,       # "Gbp profiled" numerator (controller.py:309-310)
         "n_mm_bins": 1 if skip_mm else int(obs["mm"].max()) + 1,
     }
+
+
+def shifted_variant(w, k, max_shift=65536):
+    """A distinct batch of the same shape from workload `w` (cheap: a few passes over the packed records):
+    every position moves up by a k-dependent offset inside a flat space `max_shift` positions longer, and
+    the base alphabet is rotated by k (reference and reads alike), so positions, reference codes and the
+    SNV tables all differ between variants while depth, error rate and site density stay those of `w`.
+    Used to stream many distinct batches through the pipe without generating each from scratch."""
+    rng = np.random.Generator(np.random.PCG64(1000 + k))
+    s = int(rng.integers(0, max_shift)) if k else 0
+    r = k & 3
+    rec = np.ascontiguousarray(w["obs"]).view(np.uint64).copy()
+    rec += np.uint64(s)                                     # gpos is the low 32 bits; no carry: gpos + s < 2^32
+    if r:
+        b = (rec >> np.uint64(48)) & np.uint64(0xFF)
+        nb = np.where(b < 4, (b + np.uint64(r)) & np.uint64(3), b)
+        rec += (nb - b) << np.uint64(48)                    # wraps modulo 2^64 when nb < b: same as subtracting
+    G = int(w["n_pos"])
+    n_pos = G + max_shift
+    ref = np.zeros(n_pos, dtype=np.uint8)
+    rc = w["ref_codes"]
+    ref[s:s + G] = np.where(rc < 4, (rc + r) & 3, rc)
+    out = dict(w)
+    out.update({"obs": rec.view(OBS_DT), "ref_codes": ref, "n_pos": n_pos,
+                "split_bounds": split_bounds_for([n_pos], 10000), "variant": k, "shift": s, "rotation": r})
+    return out

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.isx_abi_version() == 1
+    assert lib.isx_abi_version() == 2
     assert isinstance(lib.isx_last_error(), bytes)
 
 
@@ -34,16 +34,16 @@ def test_struct_sizes_match_header(tmp_path):
     """sizeof() of every ABI struct as the C compiler sees the header == the ctypes / numpy mirror."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "instrain_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "instrain_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(isx_params),sizeof(isx_sizes),sizeof(isx_timings),sizeof(isx_bam_params),sizeof(isx_bam_info),'
-                   'sizeof(isx_obs),sizeof(isx_entry),sizeof(isx_snv),sizeof(isx_ld),sizeof(isx_scaffold_level),sizeof(isx_compare_level),sizeof(isx_compare_snp));return 0;}\n')
+                   'sizeof(isx_obs),sizeof(isx_entry),sizeof(isx_snv),sizeof(isx_ld),sizeof(isx_scaffold_level),sizeof(isx_compare_level),sizeof(isx_compare_snp),sizeof(isx_pipe_params),sizeof(isx_pipe_result));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
     c_sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     py_sizes = [C.sizeof(_lib.Params), C.sizeof(_lib.Sizes), C.sizeof(_lib.Timings), C.sizeof(_lib.BamParams),
                 C.sizeof(_lib.BamInfo), _lib.OBS_DT.itemsize, _lib.ENTRY_DT.itemsize, _lib.SNV_DT.itemsize,
                 _lib.LD_DT.itemsize, _lib.SCAFFOLD_LEVEL_DT.itemsize, _lib.COMPARE_LEVEL_DT.itemsize,
-                _lib.COMPARE_SNP_DT.itemsize]
+                _lib.COMPARE_SNP_DT.itemsize, C.sizeof(_lib.PipeParams), C.sizeof(_lib.PipeResult)]
     assert c_sizes == py_sizes, (c_sizes, py_sizes)
 
 

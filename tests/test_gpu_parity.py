@@ -168,8 +168,7 @@ def test_stream_with_a_jump(ctx, mml, wide, monkeypatch):
     """two islands of reads 250 kbp apart.  Compact stream: the group of 256 records that would hold both is cut
     and padded (device record index != input record index from there on; pair ids follow).  Wide stream
     (forced): the 1024-record chunk spans >= 65535 positions, so the allele pass streams 4-byte positions."""
-    if wide:
-        monkeypatch.setenv("ISX_WIDE_RECORDS", "1")
+    layout = 1 if wide else 0            # ISX_LAYOUT_WIDE_RECORDS
     from instrain_amd import engine
     from oracle import oracle
     from tests import prod
@@ -184,7 +183,7 @@ def test_stream_with_a_jump(ctx, mml, wide, monkeypatch):
     pair = np.concatenate([r1, r2 + int(r1.max()) + 1])
     bounds = np.array([0, len(seq1), gap, len(seq)])
     b = engine.Batch(ctx, engine.encode_seq(seq), bounds, engine.pack_obs(pos.astype(np.uint32), base, mm),
-                     pair.astype(np.uint32), n_mm_bins=mml)
+                     pair.astype(np.uint32), n_mm_bins=mml, layout=layout)
     b.run()
     assert b.timings()["record_bytes"] == (8 if wide else (2 if mml == 1 else 4))      # one mm bin: 2-byte records
     got = prod.to_oracle_layout(b.fetch(), lambda g: g.astype(np.int64))
@@ -258,12 +257,8 @@ def test_jumpy_stream_all_formats_agree(ctx, skip_mm, monkeypatch):
     bounds = np.unique(np.r_[0, (np.arange(0, 240_000, isl) + shift), n_pos])
     M = w["n_mm_bins"]
     res = {}
-    for name, env in (("compact", {}), ("wide", {"ISX_WIDE_RECORDS": "1"}), ("four", {"ISX_NO_SHORT_RECORDS": "1"})):
-        for k in ("ISX_WIDE_RECORDS", "ISX_NO_SHORT_RECORDS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        b = engine.Batch(ctx, ref, bounds, obs, w["pair"], n_mm_bins=M, seed=3, min_snp=5)
+    for name, layout in (("compact", 0), ("wide", 1), ("four", 2)):      # ISX_LAYOUT_WIDE_RECORDS / _NO_SHORT_RECORDS
+        b = engine.Batch(ctx, ref, bounds, obs, w["pair"], n_mm_bins=M, seed=3, min_snp=5, layout=layout)
         b.run()
         res[name] = (b.timings()["record_bytes"], b.fetch(), b.sizes())
         b.close()
@@ -282,22 +277,20 @@ def test_jumpy_stream_all_formats_agree(ctx, skip_mm, monkeypatch):
 
 @pytest.mark.parametrize("name", ["synth_mm4", "synth_m1", "synth_dense", "synth_ambig"])
 def test_wide_record_stream_equals_golden(ctx, name, monkeypatch):
-    """ISX_WIDE_RECORDS forces the 8-byte stream (isx_obs as is) that the library otherwise only falls back to"""
+    """ISX_LAYOUT_WIDE_RECORDS forces the 8-byte stream (isx_obs as is) that the library otherwise only falls back to"""
     from tests import prod
-    monkeypatch.setenv("ISX_WIDE_RECORDS", "1")
     g = util.load_case(name)
-    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), **_params(g))
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), layout=1, **_params(g))
     util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name)
 
 
 @pytest.mark.parametrize("name", ["synth_m1", "synth_skipmm"])
 def test_one_mm_bin_with_4_byte_records_equals_golden(ctx, name, monkeypatch):
-    """n_mm_bins == 1 normally takes the 2-byte stream; ISX_NO_SHORT_RECORDS keeps the 4-byte one (k_pileup_dense<*, 4>)"""
+    """n_mm_bins == 1 normally takes the 2-byte stream; ISX_LAYOUT_NO_SHORT_RECORDS keeps the 4-byte one (k_pileup_dense<*, 4>)"""
     from instrain_amd import engine
     from tests import prod
-    monkeypatch.setenv("ISX_NO_SHORT_RECORDS", "1")
     g = util.load_case(name)
-    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"] * 0, g["pair"], str(g["seq"]), int(g["start"]), n_mm_bins=1, **_params(g))
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"] * 0, g["pair"], str(g["seq"]), int(g["start"]), n_mm_bins=1, layout=2, **_params(g))
     assert res["sizes"]["n_snv"] > 0
     util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name)
 
@@ -514,12 +507,11 @@ def test_divergent_reference_rows_everywhere(ctx, n_mm):
 
 def test_unpacked_counter_variant(ctx, monkeypatch):
     """the u32-counter variant of the mm kernel (taken automatically when a window streams >= 65536
-    records) forced through ISX_NO_PACKED, against the same golden vectors"""
+    records) forced through ISX_LAYOUT_NO_PACKED_COUNTERS, against the same golden vectors"""
     from tests import prod
-    monkeypatch.setenv("ISX_NO_PACKED", "1")
     for name in ("synth_mm4", "synth_dense", "synth_selfpairs"):
         g = util.load_case(name)
-        res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), **_params(g))
+        res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), layout=4, **_params(g))
         util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name + "-u32")
 
 

@@ -1,0 +1,228 @@
+"""GPU: the streaming hand-over (isx_pipe_*).  Every batch of a stream must come back with exactly the
+tables the one-shot path (isx_batch_create / run / fetch, itself pinned against the oracle and the golden
+vectors in test_gpu_parity.py) gives for the same input -- and directly against the oracle for a sample."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from instrain_amd import engine
+    c = engine.Context(0)
+    lut, fb = util.load_lut()
+    c.set_null_model(lut, fb)
+    yield c
+    c.close()
+
+
+def small_workload(seed, genome_len, coverage, skip_mm, n_sites=None):
+    from instrain_amd import synth
+    return synth.make_workload(genome_len=genome_len, coverage=coverage, n_sites=n_sites or genome_len // 200, seed=seed,
+                               skip_mm=skip_mm, af_lo=0.2, af_hi=0.5)
+
+
+def one_shot(ctx, w, **kw):
+    from instrain_amd import engine
+    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=w["n_mm_bins"], **kw)
+    b.run()
+    res, sizes = b.fetch(), b.sizes()
+    b.close()
+    return res, sizes
+
+
+def same_tables(got, exp, what):
+    for k in ("counts", "clon", "clon_r", "entries", "snv", "ld"):
+        if k not in exp:
+            continue
+        a, e = got[k], exp[k]
+        assert a.shape == e.shape, (what, k, a.shape, e.shape)
+        if a.dtype.names:
+            for f in a.dtype.names:
+                x, y = a[f], e[f]
+                if x.dtype.kind == "f":
+                    assert (x.view("u%d" % x.dtype.itemsize) == y.view("u%d" % y.dtype.itemsize)).all(), (what, k, f)
+                else:
+                    assert (x == y).all(), (what, k, f)
+        elif a.dtype.kind == "f":
+            assert (a.view(np.uint32) == e.view(np.uint32)).all(), (what, k)
+        else:
+            assert (a == e).all(), (what, k)
+
+
+@pytest.mark.parametrize("linkage", [False, True])
+def test_stream_of_distinct_batches_dense(ctx, linkage):
+    """one mm bin (2-byte records): 7 distinct batches of different sizes through 3 slots, collected in
+    order while later ones are in flight; bit-identical to the one-shot path"""
+    from instrain_amd import engine
+    ws = [small_workload(100 + i, 60_000 + 17_000 * (i % 3), 25 + 5 * (i % 2), True) for i in range(7)]
+    kw = dict(enable_linkage=linkage, min_snp=5, seed=11, rarefied_coverage=20)
+    exp = [one_shot(ctx, w, **kw) for w in ws]
+    pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
+                       max_splits=max(len(w["split_bounds"]) for w in ws), depth=3, host_threads=4, n_mm_bins=1, **kw)
+    tickets = []
+    done = 0
+    for i, w in enumerate(ws):
+        if len(tickets) - done == 3:                      # every slot busy: collect the oldest first
+            r = pipe.collect(tickets[done])
+            same_tables(r, exp[done][0], "batch %d" % done)
+            assert r["sizes"] == exp[done][1]
+            assert r["stats"]["record_bytes"] == 2 and r["stats"]["encode_passes"] == 1
+            pipe.release(tickets[done])
+            done += 1
+        tickets.append(pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], w["pair"] if linkage else None))
+    while done < len(ws):
+        r = pipe.collect(tickets[done])
+        same_tables(r, exp[done][0], "batch %d" % done)
+        assert r["sizes"] == exp[done][1]
+        if linkage:
+            assert r["sizes"]["n_ld"] > 0
+        pipe.release(tickets[done])
+        done += 1
+    assert tickets == list(range(7))
+    pipe.close()
+
+
+def test_stream_mm_profiling_with_linkage(ctx):
+    """mm profiling on (4-byte records, entry table) + linkage through the pipe == one-shot path"""
+    from instrain_amd import engine
+    ws = [small_workload(200 + i, 50_000 + 9_000 * i, 30, False) for i in range(4)]
+    M = max(w["n_mm_bins"] for w in ws)
+    for w in ws:
+        w["n_mm_bins"] = M
+    kw = dict(enable_linkage=True, min_snp=5, seed=5, rarefied_coverage=20)
+    exp = [one_shot(ctx, w, **kw) for w in ws]
+    pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
+                       max_splits=max(len(w["split_bounds"]) for w in ws), depth=2, host_threads=3, n_mm_bins=M, **kw)
+    for rnd in range(2):                                  # slots are reused: second round through the same slots
+        t0 = pipe.submit(ws[2 * rnd]["ref_codes"], ws[2 * rnd]["split_bounds"], ws[2 * rnd]["obs"], ws[2 * rnd]["pair"])
+        t1 = pipe.submit(ws[2 * rnd + 1]["ref_codes"], ws[2 * rnd + 1]["split_bounds"], ws[2 * rnd + 1]["obs"], ws[2 * rnd + 1]["pair"])
+        for t, i in ((t0, 2 * rnd), (t1, 2 * rnd + 1)):
+            r = pipe.collect(t)
+            assert r["stats"]["record_bytes"] == 4
+            same_tables(r, exp[i][0], "mm batch %d" % i)
+            assert r["sizes"] == exp[i][1] and r["sizes"]["n_entries"] > 0 and r["sizes"]["n_ld"] > 0
+            pipe.release(t)
+    pipe.close()
+
+
+def test_pipe_against_oracle(ctx):
+    """a pipe batch directly against the C oracle, split by split"""
+    from instrain_amd import engine
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    w = small_workload(300, 45_000, 40, False)
+    pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=w["n_obs"], max_splits=len(w["split_bounds"]), depth=2,
+                       host_threads=2, n_mm_bins=w["n_mm_bins"], enable_linkage=True, min_snp=5)
+    t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], w["pair"])
+    r = pipe.collect(t)
+    got = prod.to_oracle_layout(r, lambda g: g.astype(np.int64))
+    pipe.release(t)
+    pipe.close()
+    letters = np.array(list("ACTGN"))
+    exp = {"entries": [], "snv": [], "ld": []}
+    b = w["split_bounds"]
+    for s, e in zip(b[:-1], b[1:]):
+        o = oracle.profile_split(w["obs"]["gpos"].astype(np.int64), w["obs"]["base"], w["obs"]["mm"].astype(np.int64),
+                                 w["pair"].astype(np.int64), "".join(letters[w["ref_codes"][s:e]]), int(s), lut, fb, min_snp=5)
+        for k in exp:
+            exp[k].append(o[k])
+    exp = {k: np.concatenate(v) for k, v in exp.items()}
+    assert len(exp["ld"]) > 20 and len(exp["snv"]) > 50
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=1e-6, what="pipe vs oracle")
+
+
+def test_jumping_stream_learns_its_slack(ctx):
+    """a database-like batch (islands of reads 100 kbp apart): the first submit needs the second, exact
+    layout; the pipe then sets slack aside and the same stream goes through in one pass"""
+    from instrain_amd import engine
+    w = small_workload(400, 30_000, 30, True)
+    K, step = 6, 100_000
+    n_pairs = int(w["pair"].max()) + 1
+    obs = np.concatenate([w["obs"]] * K)
+    obs["gpos"] = np.concatenate([w["obs"]["gpos"] + k * step for k in range(K)])
+    pair = np.concatenate([w["pair"] + k * n_pairs for k in range(K)]).astype(np.uint32)
+    n_pos = (K - 1) * step + w["n_pos"]
+    ref = np.zeros(n_pos, np.uint8)
+    bounds = [0]
+    for k in range(K):
+        ref[k * step:k * step + w["n_pos"]] = w["ref_codes"]
+        bounds += [k * step + int(x) for x in w["split_bounds"][1:]]
+        if k + 1 < K:
+            bounds.append((k + 1) * step)
+    bounds = np.unique(bounds)
+    big = {"ref_codes": ref, "split_bounds": bounds, "obs": obs, "pair": pair, "n_mm_bins": 1}
+    exp, sizes = one_shot(ctx, big, enable_linkage=True, min_snp=5)
+    pipe = engine.Pipe(ctx, max_pos=n_pos, max_obs=len(obs), max_splits=len(bounds), depth=2, host_threads=4,
+                       n_mm_bins=1, enable_linkage=True, min_snp=5)
+    passes = []
+    for _ in range(3):
+        t = pipe.submit(ref, bounds, obs, pair)
+        r = pipe.collect(t)
+        same_tables(r, exp, "jumping")
+        assert r["sizes"] == sizes
+        passes.append(r["stats"]["encode_passes"])
+        pipe.release(t)
+    assert passes[0] == 2 and passes[-1] == 1, passes
+    pipe.close()
+
+
+def test_tables_grow_inside_a_slot(ctx):
+    """SNS rows at every position outgrow the slot's SNV table: collect grows it, repeats the pass and still
+    returns the right tables; the next batch in the same slot is unaffected"""
+    from instrain_amd import engine
+    n_pos, depth = 1_200_000, 6
+    pos = np.repeat(np.arange(n_pos, dtype=np.uint32), depth)
+    obs = engine.pack_obs(pos, np.ones(len(pos), np.uint8), np.zeros(len(pos), int))
+    ref = np.zeros(n_pos, np.uint8)
+    pipe = engine.Pipe(ctx, max_pos=n_pos, max_obs=len(obs), max_splits=4, depth=2, host_threads=4, n_mm_bins=1,
+                       enable_linkage=False)
+    t = pipe.submit(ref, [0, n_pos], obs)
+    r = pipe.collect(t)
+    assert r["sizes"]["n_snv"] == n_pos and (r["snv"]["cls"] == 2).all() and (r["snv"]["gpos"] == np.arange(n_pos)).all()
+    assert (r["counts"][:, 1] == depth).all() and (r["counts"][:, [0, 2, 3]] == 0).all()
+    pipe.release(t)
+    w = small_workload(500, 40_000, 20, True)
+    exp, sizes = one_shot(ctx, w, enable_linkage=False)
+    t2 = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+    t3 = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+    for t in (t2, t3):
+        r = pipe.collect(t)
+        for k in ("counts", "clon", "snv"):
+            same_tables({k: r[k]}, {k: exp[k]}, "after growth")
+        pipe.release(t)
+    pipe.close()
+
+
+def test_pipe_errors(ctx):
+    from instrain_amd import engine
+    from instrain_amd._lib import IsxError
+    w = small_workload(600, 20_000, 10, True)
+    pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=w["n_obs"], max_splits=len(w["split_bounds"]), depth=2, host_threads=2)
+    t0 = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+    t1 = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+    with pytest.raises(IsxError) as e:                    # both slots busy
+        pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+    assert e.value.code == -6
+    with pytest.raises(IsxError):
+        pipe.collect(5)
+    pipe.release(t0)                                      # release without collect is allowed
+    r = pipe.collect(t1)
+    assert r["sizes"]["n_snv"] >= 0
+    pipe.release(t1)
+    with pytest.raises(IsxError):
+        pipe.release(t1)
+    big = small_workload(601, 40_000, 10, True)
+    with pytest.raises(IsxError) as e:
+        pipe.submit(big["ref_codes"], big["split_bounds"], big["obs"])
+    assert e.value.code == -3
+    # an empty batch is legal
+    t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"][:0])
+    r = pipe.collect(t)
+    assert r["sizes"]["n_snv"] == 0 and (r["counts"] == 0).all() and np.isnan(r["clon"]).all()
+    pipe.release(t)
+    pipe.close()
