@@ -251,6 +251,68 @@ def resident_leg(ctx, w, window, steps=30):
             "note": "resident re-run of one batch (no hand-over, no fetch): kernel-only ceiling"}
 
 
+def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=3, with_cpu=True):
+    """BASELINE.json configs[4]: 1000-genome database, 10 Gbp of reads, --database_mode (one mm
+    bin; genomes below 1x dropped like fasta.py:110-136 does).  The kept genomes are LPT-sharded 8 ways on the
+    reference's own cost estimate (read pairs, profile_controller.py:460-465); rank r streams shard r through its
+    pipe in batches (one batch = a few genomes), every batch handed over, profiled once, tables copied back.
+    N=1: the per-GPU shard (1/8 of C5); N=8: the whole configuration."""
+    from instrain_amd import dist as idist
+    from instrain_amd import engine, synth
+    meta = synth.Metagenome(1000, total_read_bp=10e9, seed=5, threads=max(2, host_threads))
+    kept = meta.kept_genomes()
+    shards = idist.lpt_shards(meta.pairs[kept], 8)
+    mine = kept[shards[rank % 8]]
+    est = (meta.pairs[mine] * 2 * meta.read_len * 0.92).astype(np.int64)
+    batches = idist.pack_batches(meta.length[mine], est, 40_000_000, 150_000_000)
+    t0 = time.perf_counter()
+    ws = [meta.generate(mine[b]) for b in batches]
+    gen_s = time.perf_counter() - t0
+    pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
+                       max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
+                       pin_threads=False, n_mm_bins=1, enable_linkage=False, jump_slack=0.5)
+    stream(pipe, ws, min(2, len(ws)), depth)                 # warm-up (also teaches the pipe this stream's jump slack)
+    barrier()
+    stats = []
+    t0 = time.perf_counter()
+    last = stream(pipe, ws, len(ws), depth, stats, keep_last=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    pipe.close()
+    bases = float(sum(w["profiled_bases"] for w in ws))
+    dt_max, bases_all, gather_ms = dist_info(dt, bases, last)
+    st = [s for s, _ in stats]
+    tot = lambda k: float(np.sum([s[k] for s in st]))
+    n_obs = int(sum(w["n_obs"] for w in ws))
+    n_pos = int(sum(w["n_pos"] for w in ws))
+    abytes = pileup_algorithmic_bytes(n_obs, n_pos, 0, dense=True, record_bytes=2)
+    k_ms = tot("kernel_ms")
+    out = {"workload": "C5 shard %d of 8 per GPU: %d of the %d kept genomes (of 1000; %.2f Gbp of positions, %.2f Gbp of reads on this rank), "
+                       "--database_mode, streamed in %d batches" % (rank % 8, len(mine), len(kept), n_pos / 1e9, bases / 1e9, len(ws)),
+           "gbp_per_s": bases_all / dt_max / 1e9, "seconds": dt_max, "n_gpus": world,
+           "genomes_kept": int(len(kept)), "genomes_total": 1000, "positions": n_pos, "kept_observations": n_obs,
+           "mean_depth": n_obs / max(n_pos, 1), "snv_rows": int(sum(z["n_snv"] for _, z in stats)),
+           "load_imbalance": float(max(meta.pairs[kept[s]].sum() for s in shards) / np.mean([meta.pairs[kept[s]].sum() for s in shards])),
+           "generate_s": gen_s,
+           "stages_ms_total": {"host_encode": tot("encode_ms"), "copy_in": tot("h2d_ms"), "kernel": k_ms, "copy_out": tot("d2h_ms"),
+                               "wall": dt * 1e3},
+           "roofline": {"bound": "hbm", "kernel": "k_pileup_dense", "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
+                        "algorithmic_bytes": abytes, "kernel_ms_total": k_ms, "launches": len(st), "traffic": None},
+           "roofline_pcie": {"bound": "pcie", "direction": "device->host", "achieved": tot("d2h_bytes") / dt / 1e9, "peak": PCIE_PEAK_GBS,
+                             "unit": "GB/s", "frac": tot("d2h_bytes") / dt / 1e9 / PCIE_PEAK_GBS, "bytes": tot("d2h_bytes"),
+                             "host_to_device_bytes": tot("h2d_bytes")}}
+    if gather_ms is not None:
+        out["final_gather_ms"] = gather_ms
+    if with_cpu:
+        big = max(ws, key=lambda w: w["n_obs"])
+        cb = cpu_baseline(big, budget_s=14.0, min_s=7.0)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_port"] = out["gbp_per_s"] / cb["value"] if cb["value"] else None
+    return out
+
+
+
 def make_variants(w, n):
     """n distinct batches of w's shape (synth.shifted_variant), built on a few threads"""
     from concurrent.futures import ThreadPoolExecutor
@@ -293,11 +355,14 @@ def main():
     ap.add_argument("--variants", type=int, default=32, help="distinct batches cycled through the timed steps")
     ap.add_argument("--depth", type=int, default=4, help="pipe slots")
     ap.add_argument("--host-threads", type=int, default=0, help="encoder threads of the pipe (0 = the cpus this rank may use)")
-    ap.add_argument("--no-pin", action="store_true", help="do not spread the encoder threads over the GPU's L3 domains")
+    ap.add_argument("--pin", action="store_true", help="bind the encoder threads to the L3 domains of the GPU's NUMA node (pays off when "
+                                                       "the caller's buffers live on that node; tools/bench_pipe.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-linkage-leg", action="store_true")
     ap.add_argument("--no-mm-leg", action="store_true")
     ap.add_argument("--no-resident-leg", action="store_true")
+    ap.add_argument("--no-c5-leg", action="store_true")
+    ap.add_argument("--only-c5", action="store_true", help="skip the C2 legs' extras (debug)")
     ap.add_argument("--window", type=int, default=0)
     args = ap.parse_args()
 
@@ -323,10 +388,10 @@ def main():
     w = c2_workload(seed=2 + rank, scale=args.scale, with_mm=want_mm)
     n_var = max(1, min(args.variants, args.steps))
     variants = make_variants(w, n_var)
-    host_threads = args.host_threads or max(2, min(32, host_cpus() // world))
+    host_threads = args.host_threads or max(2, min(48, host_cpus() * 3 // 2 // world))    # measured best: 1.5 x the cpu quota
     pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=int(w["n_obs"]),
                        max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
-                       pin_threads=not args.no_pin, n_mm_bins=1, enable_linkage=False, window=args.window)
+                       pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window)
 
     def barrier():
         if world > 1:
@@ -366,6 +431,27 @@ def main():
         torch.cuda.synchronize()
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+
+    # configs[4] (C5) sharded over the ranks: every rank streams its shard; rank 0 reports
+    c5 = None
+    if not args.no_c5_leg:
+        def dist_info(dt_c5, bases, last_c5):
+            g_ms = None
+            if world > 1:
+                t = torch.tensor([dt_c5], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                u = torch.tensor([bases], dtype=torch.float64, device=dev)
+                dist.all_reduce(u, op=dist.ReduceOp.SUM)
+                barrier()
+                g0 = time.perf_counter()
+                idist.gather_tables({"snv": last_c5["snv"]}, dst=0, device=dev)
+                torch.cuda.synchronize()
+                barrier()
+                g_ms = (time.perf_counter() - g0) * 1e3
+                return float(t.item()), float(u.item()), g_ms
+            return dt_c5, bases, g_ms
+        pipe.close()
+        c5 = c5_leg(ctx, rank, world, host_threads, barrier, dist_info, with_cpu=(world == 1 and not args.no_cpu_baseline))
 
     if rank == 0:
         st = [s for s, _ in stats]
@@ -416,6 +502,11 @@ def main():
         }
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
+        if c5 is not None:
+            out["c5"] = c5
+        if args.only_c5:
+            args.no_resident_leg = args.no_mm_leg = args.no_linkage_leg = args.no_cpu_baseline = True
+            want_mm = False
         if world == 1 and not args.no_resident_leg:
             out["resident"] = resident_leg(ctx, w, args.window)
         if want_mm:

@@ -1,0 +1,258 @@
+// synth_gen.cpp -- fast generator of the synthetic metagenome workloads of SURVEY.md section 8(d) (C4 / C5) and of
+// single-genome workloads of the C2 / C3 shape: the POST-pileup packed observation stream a BAM of such
+// reads would expand to (what isx_bam_expand emits), produced directly, multi-threaded and deterministic
+// in (seed, genome) whatever the thread count.  Bench / test infrastructure (libisx_synth.so), not part of
+// the product library; there is no reference counterpart (the reference has no workload generator).
+//
+// Model (same as instrain_amd/synth.py make_workload, per contig): uniform random reference; biallelic
+// sites at density `site_frac` with allele frequency U(af_lo, af_hi) on two haplotype backgrounds (a
+// pair carries the alternative allele with probability af * 1.6 / 0.4 depending on its haplotype, so
+// linkage is non-trivial); read pairs 2 x read_len, insert N(mean, sd) clipped at 2 x read_len (mates
+// never overlap), start uniform in the contig; per-base error `err` (uniform substitute); a base is kept
+// (quality >= 30) with probability p_keep; mm of a pair = its mismatches to the reference (capped), 0 when
+// with_mm == 0 (--skip_mm_profiling / --database_mode).  Genome sizes U(len_lo, len_hi), cut into
+// `contigs` scaffolds; abundances log-normal(sigma); coverage_g * len_g sums to total_read_bp.  Genomes
+// below min_genome_coverage are dropped like the reference's filter_fasta does in --database_mode
+// (/root/reference/inStrain/profile/fasta.py:110-136, controller.py:211-214).
+#include <stdint.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Rng {        // xoshiro256++ seeded by splitmix64
+    uint64_t s[4];
+    static uint64_t sm(uint64_t &x) { uint64_t z = (x += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    explicit Rng(uint64_t seed) { for (auto &v : s) v = sm(seed); }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        const uint64_t r = rotl(s[0] + s[3], 23) + s[0], t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    uint64_t below(uint64_t n) { return (uint64_t)(((unsigned __int128)next() * n) >> 64); }
+    double normal() { double u1 = uni(), u2 = uni(); if (u1 < 1e-300) u1 = 1e-300; return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2); }
+};
+
+uint64_t mix(uint64_t a, uint64_t b, uint64_t c) { uint64_t x = a * 0x9E3779B97F4A7C15ull ^ (b + 0x7F4A7C15ull) * 0xBF58476D1CE4E5B9ull ^ (c + 0x1CE4E5B9ull) * 0x94D049BB133111EBull; return Rng::sm(x); }
+
+}  // namespace
+
+extern "C" {
+
+typedef struct {
+    int32_t n_genomes, contigs;
+    int64_t len_lo, len_hi;
+    double total_read_bp;           // sum over genomes of coverage * length (nominal read bases)
+    double abundance_sigma;         // 0 = equal coverage
+    double min_genome_coverage;     // genomes below are dropped (database_mode: 1); 0 keeps all
+    double site_frac, af_lo, af_hi, err, p_keep;
+    int32_t read_len;
+    double insert_mean, insert_sd;
+    int32_t with_mm, max_mm, threads, pad;
+    uint64_t seed;
+} isx_synth_params;
+
+typedef struct { uint32_t gpos; uint16_t mm; uint8_t base, flags; } synth_obs;
+
+// per-genome plan: length, coverage, kept flag, read pairs it will get (estimate = coverage * len / (2 read_len))
+int isx_synth_plan(const isx_synth_params *p, int64_t *length, double *coverage, int32_t *kept, int64_t *pairs)
+{
+    if (!p || p->n_genomes <= 0 || p->contigs <= 0 || p->len_lo <= 0 || p->len_hi < p->len_lo) return -1;
+    std::vector<double> w((size_t)p->n_genomes);
+    double wl = 0;
+    for (int g = 0; g < p->n_genomes; g++) {
+        Rng r(mix(p->seed, (uint64_t)g, 1));
+        length[g] = p->len_lo + (int64_t)r.below((uint64_t)(p->len_hi - p->len_lo + 1));
+        w[(size_t)g] = p->abundance_sigma > 0 ? std::exp(p->abundance_sigma * r.normal()) : 1.0;
+        wl += w[(size_t)g] * (double)length[g];
+    }
+    for (int g = 0; g < p->n_genomes; g++) {
+        coverage[g] = p->total_read_bp * w[(size_t)g] / wl;
+        kept[g] = coverage[g] >= p->min_genome_coverage ? 1 : 0;
+        pairs[g] = (int64_t)(coverage[g] * (double)length[g] / (2.0 * p->read_len));
+    }
+    return 0;
+}
+
+typedef struct {
+    int64_t n_pos, n_obs, n_pairs, n_scaffolds;
+    int64_t profiled_bases;         // pairs * 2 * read_len
+    int64_t n_sites;
+    uint8_t *ref;                   // [n_pos] base codes
+    synth_obs *obs;                 // [n_obs], BAM order (scaffold, read start)
+    uint32_t *pair;                 // [n_obs]
+    int64_t *scaffold_bounds;       // [n_scaffolds + 1]
+    int32_t *scaffold_genome;       // [n_scaffolds] index into the caller's genome list
+} isx_synth_out;
+
+void isx_synth_free(isx_synth_out *o)
+{
+    if (!o) return;
+    free(o->ref); free(o->obs); free(o->pair); free(o->scaffold_bounds); free(o->scaffold_genome);
+    memset(o, 0, sizeof *o);
+}
+
+// generate the genomes genome_sel[0..n_sel) (indices of the plan), laid end to end in that order
+int isx_synth_generate(const isx_synth_params *p, const int32_t *genome_sel, int32_t n_sel, const int64_t *length,
+                       const double *coverage, isx_synth_out *out)
+{
+    if (!p || !genome_sel || n_sel <= 0 || !out) return -1;
+    memset(out, 0, sizeof *out);
+    const int RL = p->read_len, C = p->contigs;
+    const int64_t n_sc = (int64_t)n_sel * C;
+    struct Contig { int64_t off, len, n_pairs, obs_off, obs_cap, obs_n, pair0; int genome; uint64_t seed; };
+    std::vector<Contig> cs((size_t)n_sc);
+    int64_t off = 0, obs_cap = 0, pair0 = 0;
+    const int64_t min_ins = 2 * (int64_t)RL;
+    for (int i = 0; i < n_sel; i++) {
+        const int g = genome_sel[i];
+        Rng r(mix(p->seed, (uint64_t)g, 2));
+        // contig lengths: exponential weights, every contig >= 1000 positions
+        std::vector<double> w((size_t)C);
+        double ws = 0;
+        for (auto &x : w) { x = -std::log(1.0 - r.uni()) + 0.05; ws += x; }
+        const int64_t L = length[g], spare = std::max<int64_t>(0, L - 1000 * (int64_t)C);
+        int64_t used = 0;
+        for (int c = 0; c < C; c++) {
+            int64_t len = 1000 + (int64_t)((double)spare * w[(size_t)c] / ws);
+            if (c == C - 1) len = std::max<int64_t>(1, L - used);
+            used += len;
+            Contig &k = cs[(size_t)i * C + c];
+            k.off = off; k.len = len; k.genome = i; k.seed = mix(p->seed, (uint64_t)g, 100 + (uint64_t)c);
+            const double want = coverage[g] * (double)len / (2.0 * RL);
+            k.n_pairs = len >= min_ins + 8 ? (int64_t)(want + r.uni()) : 0;
+            k.obs_off = obs_cap; k.obs_cap = k.n_pairs * 2 * RL; k.pair0 = pair0;
+            obs_cap += k.obs_cap; pair0 += k.n_pairs; off += len;
+        }
+    }
+    if (off >= (int64_t)0xFFFF0000ll || pair0 >= (int64_t)0xFFFFFFFFll) return -2;
+    out->n_pos = off; out->n_pairs = pair0; out->n_scaffolds = n_sc;
+    out->profiled_bases = pair0 * 2 * RL;
+    out->ref = (uint8_t *)malloc((size_t)std::max<int64_t>(off, 1));
+    out->obs = (synth_obs *)malloc((size_t)std::max<int64_t>(obs_cap, 1) * sizeof(synth_obs));
+    out->pair = (uint32_t *)malloc((size_t)std::max<int64_t>(obs_cap, 1) * sizeof(uint32_t));
+    out->scaffold_bounds = (int64_t *)malloc((size_t)(n_sc + 1) * sizeof(int64_t));
+    out->scaffold_genome = (int32_t *)malloc((size_t)n_sc * sizeof(int32_t));
+    if (!out->ref || !out->obs || !out->pair || !out->scaffold_bounds || !out->scaffold_genome) { isx_synth_free(out); return -3; }
+    for (int64_t i = 0; i < n_sc; i++) { out->scaffold_bounds[i] = cs[(size_t)i].off; out->scaffold_genome[i] = cs[(size_t)i].genome; }
+    out->scaffold_bounds[n_sc] = off;
+
+    std::atomic<int64_t> next{0}, n_sites{0};
+    const uint32_t keep_thr = (uint32_t)std::min(65535.0, std::max(0.0, p->p_keep * 65536.0));
+    auto work = [&]() {
+        std::vector<int32_t> site_of;
+        std::vector<uint8_t> alt, bases, hap;
+        std::vector<float> af;
+        std::vector<int64_t> rstart;
+        std::vector<uint32_t> order;
+        std::vector<uint16_t> mmv;
+        for (;;) {
+            const int64_t ci = next.fetch_add(1);
+            if (ci >= n_sc) break;
+            Contig &k = cs[(size_t)ci];
+            Rng r(k.seed);
+            uint8_t *ref = out->ref + k.off;
+            for (int64_t i = 0; i < k.len; i += 32) {                  // 2 bits per base
+                uint64_t x = r.next();
+                const int64_t e = std::min<int64_t>(k.len, i + 32);
+                for (int64_t j = i; j < e; j++, x >>= 2) ref[j] = (uint8_t)(x & 3);
+            }
+            k.obs_n = 0;
+            if (!k.n_pairs) continue;
+            // variable sites
+            site_of.assign((size_t)k.len, -1);
+            const int64_t ns = (int64_t)((double)k.len * p->site_frac + r.uni());
+            alt.clear(); af.clear();
+            for (int64_t s = 0; s < ns; s++) {
+                const int64_t pos = (int64_t)r.below((uint64_t)k.len);
+                if (site_of[(size_t)pos] >= 0) continue;
+                site_of[(size_t)pos] = (int32_t)alt.size();
+                alt.push_back((uint8_t)((ref[pos] + 1 + r.below(3)) & 3));
+                af.push_back((float)(p->af_lo + (p->af_hi - p->af_lo) * r.uni()));
+            }
+            n_sites.fetch_add((int64_t)alt.size());
+            // read starts (pair j: mates 2j, 2j+1), BAM order = by start
+            const int64_t np = k.n_pairs, nr = 2 * np;
+            rstart.resize((size_t)nr); hap.resize((size_t)np); mmv.assign((size_t)np, 0);
+            for (int64_t j = 0; j < np; j++) {
+                int64_t ins = (int64_t)(p->insert_mean + p->insert_sd * r.normal());
+                ins = std::min<int64_t>(std::max<int64_t>(ins, min_ins), k.len - 1);
+                const int64_t s1 = (int64_t)r.below((uint64_t)(k.len - ins));
+                rstart[(size_t)(2 * j)] = s1; rstart[(size_t)(2 * j + 1)] = s1 + ins - RL;
+                hap[(size_t)j] = (uint8_t)(r.next() & 1);
+            }
+            order.resize((size_t)nr);
+            for (int64_t i = 0; i < nr; i++) order[(size_t)i] = (uint32_t)i;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rstart[a] < rstart[b]; });
+            // read bases (in read-id order so mm is known before anything is emitted)
+            bases.resize((size_t)nr * RL);
+            int64_t next_err = p->err > 0 ? (int64_t)(std::log(1.0 - r.uni()) / std::log(1.0 - p->err)) : (int64_t)1 << 62;
+            for (int64_t i = 0; i < nr; i++) {
+                const int64_t st = rstart[(size_t)i];
+                uint8_t *b = bases.data() + (size_t)i * RL;
+                int mm = 0;
+                for (int q = 0; q < RL; q++) {
+                    uint8_t v = ref[st + q];
+                    const int32_t si = site_of[(size_t)(st + q)];
+                    if (si >= 0 && r.uni() < (double)af[(size_t)si] * (hap[(size_t)(i >> 1)] ? 1.6 : 0.4)) v = alt[(size_t)si];
+                    if (next_err-- == 0) {
+                        v = (uint8_t)r.below(4);
+                        next_err = (int64_t)(std::log(1.0 - r.uni()) / std::log(1.0 - p->err));
+                    }
+                    mm += v != ref[st + q];
+                    b[q] = v;
+                }
+                mmv[(size_t)(i >> 1)] = (uint16_t)std::min<int>(65535, mmv[(size_t)(i >> 1)] + mm);
+            }
+            // emit in BAM order; a base is kept with probability p_keep (16 random bits each)
+            synth_obs *o = out->obs + k.obs_off;
+            uint32_t *pr = out->pair + k.obs_off;
+            int64_t n = 0;
+            for (int64_t oi = 0; oi < nr; oi++) {
+                const uint32_t i = order[(size_t)oi];
+                const int64_t st = rstart[i];
+                const uint8_t *b = bases.data() + (size_t)i * RL;
+                const uint16_t mm = p->with_mm ? (uint16_t)std::min<int>(p->max_mm, mmv[i >> 1]) : (uint16_t)0;
+                const uint32_t pid = (uint32_t)(k.pair0 + (i >> 1));
+                uint64_t bits = 0;
+                for (int q = 0; q < RL; q++) {
+                    if ((q & 3) == 0) bits = r.next();
+                    const uint32_t u = (uint32_t)(bits & 0xFFFF);
+                    bits >>= 16;
+                    if (u >= keep_thr) continue;
+                    o[n].gpos = (uint32_t)(k.off + st + q); o[n].mm = mm; o[n].base = b[q]; o[n].flags = 0;
+                    pr[n] = pid;
+                    n++;
+                }
+            }
+            k.obs_n = n;
+        }
+    };
+    const int nt = std::max(1, p->threads);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    // close the gaps between the contigs' blocks
+    int64_t w = 0;
+    for (auto &k : cs) {
+        if (k.obs_n && w != k.obs_off) {
+            memmove(out->obs + w, out->obs + k.obs_off, (size_t)k.obs_n * sizeof(synth_obs));
+            memmove(out->pair + w, out->pair + k.obs_off, (size_t)k.obs_n * sizeof(uint32_t));
+        }
+        w += k.obs_n;
+    }
+    out->n_obs = w;
+    out->n_sites = n_sites.load();
+    return 0;
+}
+
+}  // extern "C"

@@ -73,3 +73,21 @@ def gather_tables(tables, dst=0, device=None):
                      for r in range(world)]
             out[n] = np.concatenate(parts)
     return out
+
+
+def pack_batches(n_pos, n_obs, max_pos, max_obs):
+    """Cut a rank's scaffolds / genomes (in the given order) into batches for one pipe: consecutive items are
+    taken while the flat positions stay <= max_pos and the (estimated) observations <= max_obs.  The reference
+    groups its profile commands the same way, by estimated seconds (profile_controller.py:397-457).  An item
+    larger than a cap gets a batch of its own (the caller sizes the pipe from the largest batch)."""
+    out, cur, p, o = [], [], 0, 0
+    for i, (a, b) in enumerate(zip(n_pos, n_obs)):
+        if cur and (p + a > max_pos or o + b > max_obs):
+            out.append(cur)
+            cur, p, o = [], 0, 0
+        cur.append(i)
+        p += int(a)
+        o += int(b)
+    if cur:
+        out.append(cur)
+    return out

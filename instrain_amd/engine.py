@@ -36,6 +36,11 @@ class Context:
         check(self.lib.isx_ctx_create(int(device), C.byref(h)))
         self.h = h
         self.device = device
+        self._children = []         # weak references to live Batch / Pipe objects: closed before the context
+
+    def _adopt(self, obj):
+        import weakref
+        self._children.append(weakref.ref(obj))
 
     def set_null_model(self, lut, fallback):
         lut = np.ascontiguousarray(lut, dtype=np.int32)
@@ -43,6 +48,11 @@ class Context:
 
     def close(self):
         if self.h:
+            for r in self._children:
+                o = r()
+                if o is not None:
+                    o.close()
+            self._children = []
             self.lib.isx_ctx_destroy(self.h)
             self.h = None
 
@@ -77,6 +87,7 @@ class Batch:
                                         obs.ctypes.data if self.n_obs else None,
                                         pair.ctypes.data if pair is not None and self.n_obs else None, C.byref(h)))
         self.h = h
+        ctx._adopt(self)
 
     def run(self):
         check(self.lib.isx_batch_run(self.h))
@@ -179,6 +190,7 @@ class Pipe:
         h = C.c_void_p()
         check(self.lib.isx_pipe_create(ctx.h, C.byref(p), C.byref(pp), C.byref(h)))
         self.h = h
+        ctx._adopt(self)
 
     def submit(self, ref_codes, split_bounds, obs, pair=None):
         """-> ticket.  Arrays must be C-contiguous uint8 / int64 / OBS_DT / uint32 (no copies are made here)."""

@@ -141,3 +141,122 @@ def shifted_variant(w, k, max_shift=65536):
     out.update({"obs": rec.view(OBS_DT), "ref_codes": ref, "n_pos": n_pos,
                 "split_bounds": split_bounds_for([n_pos], 10000), "variant": k, "shift": s, "rotation": r})
     return out
+
+
+# ---- metagenome workloads (C4 = 100 genomes x 50x, C5 = 1000 genomes / 10 Gbp of reads) ----
+# generated by instrain_amd/csrc/synth_gen.cpp (libisx_synth.so: multi-threaded, deterministic in (seed, genome))
+import ctypes as _C
+import os as _os
+
+
+class _SynthParams(_C.Structure):
+    _fields_ = [("n_genomes", _C.c_int32), ("contigs", _C.c_int32), ("len_lo", _C.c_int64), ("len_hi", _C.c_int64),
+                ("total_read_bp", _C.c_double), ("abundance_sigma", _C.c_double), ("min_genome_coverage", _C.c_double),
+                ("site_frac", _C.c_double), ("af_lo", _C.c_double), ("af_hi", _C.c_double), ("err", _C.c_double),
+                ("p_keep", _C.c_double), ("read_len", _C.c_int32), ("insert_mean", _C.c_double), ("insert_sd", _C.c_double),
+                ("with_mm", _C.c_int32), ("max_mm", _C.c_int32), ("threads", _C.c_int32), ("pad", _C.c_int32),
+                ("seed", _C.c_uint64)]
+
+
+class _SynthOut(_C.Structure):
+    _fields_ = [("n_pos", _C.c_int64), ("n_obs", _C.c_int64), ("n_pairs", _C.c_int64), ("n_scaffolds", _C.c_int64),
+                ("profiled_bases", _C.c_int64), ("n_sites", _C.c_int64), ("ref", _C.c_void_p), ("obs", _C.c_void_p),
+                ("pair", _C.c_void_p), ("scaffold_bounds", _C.c_void_p), ("scaffold_genome", _C.c_void_p)]
+
+
+_synth_lib = None
+
+
+def _synth():
+    global _synth_lib
+    if _synth_lib is None:
+        path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libisx_synth.so")
+        if not _os.path.exists(path):
+            raise RuntimeError("%s not built (make -C instrain_amd/csrc)" % path)
+        lib = _C.CDLL(path)
+        lib.isx_synth_plan.argtypes = [_C.POINTER(_SynthParams), _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_void_p]
+        lib.isx_synth_generate.argtypes = [_C.POINTER(_SynthParams), _C.c_void_p, _C.c_int32, _C.c_void_p, _C.c_void_p,
+                                           _C.POINTER(_SynthOut)]
+        lib.isx_synth_free.argtypes = [_C.POINTER(_SynthOut)]
+        lib.isx_synth_free.restype = None
+        _synth_lib = lib
+    return _synth_lib
+
+
+class _SynthOwner:
+    def __init__(self, out):
+        self.out = out
+
+    def __del__(self):
+        try:
+            _synth().isx_synth_free(_C.byref(self.out))
+        except Exception:
+            pass
+
+
+class Metagenome:
+    """Plan of a synthetic metagenome: genome lengths U(len_lo, len_hi) in `contigs` scaffolds each, log-normal
+    abundances scaled so that the nominal read bases sum to total_read_bp; genomes whose coverage is below
+    min_genome_coverage are dropped the way --database_mode drops them (fasta.py:110-136).  generate(sel)
+    produces the packed observation stream of a subset of the kept genomes (one GPU's shard, one batch)."""
+
+    def __init__(self, n_genomes, total_read_bp=None, mean_coverage=None, seed=4, contigs=50, len_lo=2_000_000,
+                 len_hi=6_000_000, abundance_sigma=1.0, min_genome_coverage=1.0, site_frac=0.005, af_lo=0.05, af_hi=0.5,
+                 err=0.001, p_keep=0.90, read_len=150, insert_mean=350.0, insert_sd=30.0, with_mm=False, max_mm=14,
+                 threads=0):
+        if threads <= 0:
+            threads = max(1, min(32, len(_os.sched_getaffinity(0))))
+        self.p = _SynthParams(int(n_genomes), int(contigs), int(len_lo), int(len_hi), 0.0, float(abundance_sigma),
+                              float(min_genome_coverage), float(site_frac), float(af_lo), float(af_hi), float(err),
+                              float(p_keep), int(read_len), float(insert_mean), float(insert_sd), 1 if with_mm else 0,
+                              int(max_mm), int(threads), 0, int(seed))
+        n = int(n_genomes)
+        self.length = np.zeros(n, np.int64)
+        self.coverage = np.zeros(n, np.float64)
+        self.kept = np.zeros(n, np.int32)
+        self.pairs = np.zeros(n, np.int64)
+        if total_read_bp is None:               # mean coverage over the whole community (read bases / genome bases)
+            self.p.total_read_bp = 1.0
+            self._plan()
+            total_read_bp = float(mean_coverage) * float(self.length.sum())
+        self.p.total_read_bp = float(total_read_bp)
+        self._plan()
+        self.read_len = int(read_len)
+        self.contigs = int(contigs)
+
+    def _plan(self):
+        rc = _synth().isx_synth_plan(_C.byref(self.p), self.length.ctypes.data, self.coverage.ctypes.data,
+                                     self.kept.ctypes.data, self.pairs.ctypes.data)
+        if rc != 0:
+            raise ValueError("isx_synth_plan: bad parameters")
+
+    def kept_genomes(self):
+        return np.flatnonzero(self.kept)
+
+    def generate(self, genome_sel, window_length=10000):
+        """-> workload dict like make_workload's (+ scaffold_bounds, scaffold_genome, genomes)"""
+        sel = np.ascontiguousarray(genome_sel, dtype=np.int32)
+        out = _SynthOut()
+        rc = _synth().isx_synth_generate(_C.byref(self.p), sel.ctypes.data, len(sel), self.length.ctypes.data,
+                                         self.coverage.ctypes.data, _C.byref(out))
+        if rc != 0:
+            raise ValueError("isx_synth_generate failed (%d): shard too large for one flat space?" % rc)
+        owner = _SynthOwner(out)            # the C buffers live as long as any array below does (no copies)
+
+        def arr(addr, dtype, n):
+            if not n:
+                return np.empty(0, dtype=dtype)
+            buf = (_C.c_uint8 * (n * np.dtype(dtype).itemsize)).from_address(addr)
+            buf._owner = owner
+            return np.frombuffer(buf, dtype=dtype)
+        sb = arr(out.scaffold_bounds, np.int64, out.n_scaffolds + 1).copy()
+        w = {"ref_codes": arr(out.ref, np.uint8, out.n_pos), "obs": arr(out.obs, OBS_DT, out.n_obs),
+             "pair": arr(out.pair, np.uint32, out.n_obs), "scaffold_bounds": sb,
+             "scaffold_genome": sel[arr(out.scaffold_genome, np.int32, out.n_scaffolds)],
+             "genomes": sel.copy(), "n_pairs": int(out.n_pairs), "n_obs": int(out.n_obs), "n_pos": int(out.n_pos),
+             "n_sites_planted": int(out.n_sites), "profiled_bases": int(out.profiled_bases),
+             "n_mm_bins": 1 if not self.p.with_mm else None}
+        w["split_bounds"] = split_bounds_for(np.diff(sb), window_length)
+        if self.p.with_mm:
+            w["n_mm_bins"] = int(w["obs"]["mm"].max()) + 1 if len(w["obs"]) else 1
+        return w

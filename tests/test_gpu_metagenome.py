@@ -1,0 +1,128 @@
+"""GPU: the metagenome configurations (BASELINE.json configs[3] / configs[4]; SURVEY.md 8(d) C4 / C5:
+--database_mode, i.e. one mm bin, genomes below 1x dropped).
+  * a slice (small genomes, same generator and shape) against the C oracle split by split, through both the
+    one-shot path and the pipe;
+  * the full per-GPU shard of C5 (1/8 of the kept genomes, LPT) streamed through the pipe, checked through
+    size-independent properties: per-scaffold sums of counts == observations handed over, a position-weighted
+    checksum of the counts against numpy, SNV rows consistent with the count table, idempotence."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from instrain_amd import engine
+    c = engine.Context(0)
+    lut, fb = util.load_lut()
+    c.set_null_model(lut, fb)
+    yield c
+    c.close()
+
+
+def test_metagenome_slice_vs_oracle(ctx):
+    from instrain_amd import engine, synth
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    meta = synth.Metagenome(14, mean_coverage=9, seed=44, contigs=4, len_lo=30_000, len_hi=70_000, threads=4)
+    kept = meta.kept_genomes()
+    assert 3 <= len(kept) < 14                                # some genomes fall below 1x and are dropped
+    w = meta.generate(kept)
+    kw = dict(min_cov=5, min_freq=0.05, min_snp=10)
+    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1, enable_linkage=True, **kw)
+    b.run()
+    res = b.fetch()
+    got = prod.to_oracle_layout(res, lambda g: g.astype(np.int64))
+    b.close()
+    letters = np.array(list("ACTGN"))
+    gpos = w["obs"]["gpos"].astype(np.int64)
+    exp = {"entries": [], "snv": [], "ld": []}
+    sb = w["split_bounds"]
+    for s, e in zip(sb[:-1], sb[1:]):
+        o = oracle.profile_split(gpos, w["obs"]["base"], w["obs"]["mm"].astype(np.int64), w["pair"].astype(np.int64),
+                                 "".join(letters[w["ref_codes"][s:e]]), int(s), lut, fb, **kw)
+        for k in exp:
+            exp[k].append(o[k])
+    exp = {k: np.concatenate(v) for k, v in exp.items()}
+    assert len(exp["snv"]) > 100 and len(exp["ld"]) > 20
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=1e-6, what="metagenome slice")
+    # the same batch through the pipe (the stream jumps at every uncovered stretch / contig end)
+    pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=w["n_obs"], max_splits=len(sb), depth=2, host_threads=4,
+                       n_mm_bins=1, enable_linkage=True, **kw)
+    t = pipe.submit(w["ref_codes"], sb, w["obs"], w["pair"])
+    r = pipe.collect(t)
+    for k in ("counts", "clon", "snv", "ld"):
+        a, e = r[k], res[k]
+        assert a.shape == e.shape
+        if a.dtype.names:
+            for f in a.dtype.names:
+                assert (a[f].view("u%d" % a[f].dtype.itemsize) == e[f].view("u%d" % e[f].dtype.itemsize)).all(), (k, f)
+        else:
+            assert (a.view(np.uint32) == e.view(np.uint32)).all(), k
+    pipe.release(t)
+    pipe.close()
+
+
+def test_c5_per_gpu_shard_properties(ctx):
+    """configs[4]: 1000 genomes, 10 Gbp of reads, --database_mode; rank 0's shard of 8, streamed in batches"""
+    from instrain_amd import dist as idist
+    from instrain_amd import engine, synth
+    meta = synth.Metagenome(1000, total_read_bp=10e9, seed=5)
+    kept = meta.kept_genomes()
+    assert 600 < len(kept) < 760 and abs(meta.length.sum() / 1e9 - 4.0) < 0.3
+    shard = kept[idist.lpt_shards(meta.pairs[kept], 8)[0]]
+    est_obs = (meta.pairs[shard] * 2 * meta.read_len * 0.92).astype(np.int64)
+    batches = idist.pack_batches(meta.length[shard], est_obs, 40_000_000, 150_000_000)
+    assert len(batches) >= 4
+    ws = [meta.generate(shard[b]) for b in batches]
+    total_bases = sum(w["profiled_bases"] for w in ws)
+    assert 0.9e9 < total_bases < 1.4e9                        # ~ 10 Gbp x (kept share) / 8
+    pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
+                       max_splits=max(len(w["split_bounds"]) for w in ws), depth=3, n_mm_bins=1, enable_linkage=False,
+                       jump_slack=0.5)
+    tickets = [None] * len(ws)
+
+    def check(i, r, first):
+        w = ws[i]
+        counts = r["counts"]
+        sb = w["scaffold_bounds"]
+        o = w["obs"]
+        assert counts.shape == (w["n_pos"], 4)
+        # every observation carries an A,C,T,G base here: per-scaffold sums == observations handed over
+        per_scaf = np.add.reduceat(counts.sum(axis=1, dtype=np.int64), sb[:-1])
+        exp = np.bincount(np.searchsorted(sb, o["gpos"], side="right") - 1, minlength=len(sb) - 1)
+        assert (per_scaf == exp).all()
+        # position- and base-weighted checksum of the whole table against numpy on the raw records
+        wgt = (np.arange(w["n_pos"], dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+        chk_dev = sum(int((counts[:, k].astype(np.uint64) * (wgt + np.uint64(k * 977))).sum()) for k in range(4))
+        g = o["gpos"].astype(np.uint64)
+        chk_host = int((((g * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) + o["base"].astype(np.uint64) * np.uint64(977)).sum())
+        assert chk_dev == chk_host
+        snv = r["snv"]
+        assert len(snv) == r["sizes"]["n_snv"] > 0
+        assert (snv["cnt"] == counts[snv["gpos"]]).all() and (np.diff(snv["gpos"].astype(np.int64)) > 0).all()
+        cov = counts.sum(axis=1)
+        assert np.isnan(r["clon"][cov < 5]).all() and not np.isnan(r["clon"][cov >= 5]).any()
+        return (chk_dev, len(snv), int(snv["gpos"].astype(np.int64).sum()))
+
+    sig = []
+    for rnd in range(2):                                      # idempotence: the same stream twice, same tables
+        out = []
+        done = 0
+        for i, w in enumerate(ws):
+            if i - done == 3:
+                out.append(check(done, pipe.collect(tickets[done]), rnd == 0))
+                pipe.release(tickets[done])
+                done += 1
+            tickets[i] = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+        while done < len(ws):
+            out.append(check(done, pipe.collect(tickets[done]), rnd == 0))
+            pipe.release(tickets[done])
+            done += 1
+        sig.append(out)
+    assert sig[0] == sig[1]
+    pipe.close()

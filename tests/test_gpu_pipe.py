@@ -179,7 +179,7 @@ def test_tables_grow_inside_a_slot(ctx):
     pos = np.repeat(np.arange(n_pos, dtype=np.uint32), depth)
     obs = engine.pack_obs(pos, np.ones(len(pos), np.uint8), np.zeros(len(pos), int))
     ref = np.zeros(n_pos, np.uint8)
-    pipe = engine.Pipe(ctx, max_pos=n_pos, max_obs=len(obs), max_splits=4, depth=2, host_threads=4, n_mm_bins=1,
+    pipe = engine.Pipe(ctx, max_pos=n_pos, max_obs=len(obs), max_splits=16, depth=2, host_threads=4, n_mm_bins=1,
                        enable_linkage=False)
     t = pipe.submit(ref, [0, n_pos], obs)
     r = pipe.collect(t)
