@@ -86,6 +86,29 @@ def host_cpus():
     return cgroup_cpus() or os.cpu_count() or 1
 
 
+def bind_to_gpu_numa_node(torch, local):
+    """One process per GPU, bound to the cpus of the NUMA node the GPU hangs off: the buffers this rank hands over are
+    then first touched next to the GPU and the pipe's encoder threads read local memory (tools/bench_pipe.py: a remote
+    hand-over costs up to 2x).  Returns the node (or None when sysfs does not tell)."""
+    try:
+        p = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:
+        pass
+    return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -357,6 +380,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="encoder threads of the pipe (0 = the cpus this rank may use)")
     ap.add_argument("--pin", action="store_true", help="bind the encoder threads to the L3 domains of the GPU's NUMA node (pays off when "
                                                        "the caller's buffers live on that node; tools/bench_pipe.py)")
+    ap.add_argument("--no-bind", action="store_true", help="do not bind the process to the GPU's NUMA node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-linkage-leg", action="store_true")
     ap.add_argument("--no-mm-leg", action="store_true")
@@ -380,6 +404,7 @@ def main():
     use_nccl = world > 1 and dist.get_backend() == "nccl"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local) if (world == 1 or use_nccl) else torch.device("cpu")
+    numa_node = None if args.no_bind else bind_to_gpu_numa_node(torch, local)
     ctx = engine.Context(local)
     lut, fb = util.load_lut()
     ctx.set_null_model(lut, fb)
@@ -482,6 +507,7 @@ def main():
                        "genome_bp": int(w["n_pos"]), "kept_observations": int(w["n_obs"]),
                        "profiled_bases_per_batch": int(w["profiled_bases"]), "splits": int(len(variants[0]["split_bounds"]) - 1),
                        "distinct_batches": n_var, "pipe_depth": args.depth, "host_threads": host_threads,
+                       "process_bound_to_numa_node": numa_node,
                        "parallelism": "scaffold-sharded x%d" % world, "scale": args.scale},
             "roofline": {"bound": "hbm", "kernel": "k_pileup_dense", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -257,6 +257,12 @@ SYNTH = {
     "synth_deep": dict(seed=18, mm_levels=3, hot_col=12000, depth=40),
     "synth_dense": dict(seed=19, mm_levels=8, depth=150, n_sites=60, mLen=600, af_lo=0.2),
     "synth_minsnp5": dict(seed=20, mm_levels=2, depth=25, min_snp=5, min_cov=3, min_freq=0.1),
+    # round 2: enough SNP sites x depth for hundreds / thousands of LD rows from the reference itself
+    # (the dense int8-MFMA linkage path and the one-mm-bin kernels are compared with these directly)
+    "synth_m1_ld": dict(seed=21, mm_levels=1, depth=140, n_sites=160, mLen=3000, read_len=100, af_lo=0.25, self_pairs=0.02),
+    "synth_skipmm_ld": dict(seed=22, mm_levels=3, skip_mm=True, depth=120, n_sites=120, mLen=2400, read_len=100, af_lo=0.25),
+    "synth_mm4_deep": dict(seed=23, mm_levels=4, depth=130, n_sites=45, mLen=900, af_lo=0.2),
+    "synth_ambig_deep": dict(seed=24, mm_levels=6, p_other=0.06, ref_ambig=20, depth=130, n_sites=45, mLen=900, af_lo=0.2),
 }
 
 
@@ -295,6 +301,22 @@ def main():
                             pos=pos.astype(np.int32), base=base, mm=(mm * (0 if skip_mm else 1)).astype(np.int32),
                             pair=pair.astype(np.int32), **{"p_" + k: np.array(v) for k, v in params.items()}, **exp)
         print(name, "obs", len(pos), "snv rows", len(S), "ld rows", len(L), "edges", ne)
+
+    # ---- one split of the bench's C3 generator (configs[2]: 200x, 1 SNV site / 100 bp, one mm bin) ----
+    if "--skip-c3" not in sys.argv:
+        from instrain_amd import synth
+        w = synth.make_workload(genome_len=9_999, coverage=200, n_sites=100, seed=3, skip_mm=True, af_lo=0.2, af_hi=0.5)
+        assert len(w["split_bounds"]) == 2
+        seq = "".join(np.array(list("ACTG"))[w["ref_codes"]])
+        pos = w["obs"]["gpos"].astype(np.int64); base = w["obs"]["base"].copy(); pair = w["pair"].astype(np.int64)
+        mm = np.zeros(len(pos), np.int64)
+        params = dict(min_cov=5, min_freq=0.05, min_snp=20)
+        covT, clonT, S, L, ne = run_reference_split(mods, "scaf", seq, 0, pos, base, mm, pair, nm, skip_mm=True, **params)
+        exp = pack_expected(covT, clonT, S, L, ne)
+        np.savez_compressed(os.path.join(HERE, "c3_split.npz"), seq=np.array(seq), start=np.array(0),
+                            pos=pos.astype(np.int32), base=base, mm=mm.astype(np.int32), pair=pair.astype(np.int32),
+                            **{"p_" + k: np.array(v) for k, v in params.items()}, **exp)
+        print("c3_split obs", len(pos), "snv rows", len(S), "ld rows", len(L), "edges", ne)
 
     # ---- compare: coverage overlap of two samples on the same scaffold (readComparer.py:145-191) ----
     import inStrain.readComparer as rc

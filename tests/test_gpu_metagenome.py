@@ -28,7 +28,7 @@ def test_metagenome_slice_vs_oracle(ctx):
     from oracle import oracle
     from tests import prod
     lut, fb = util.load_lut()
-    meta = synth.Metagenome(14, mean_coverage=9, seed=44, contigs=4, len_lo=30_000, len_hi=70_000, threads=4)
+    meta = synth.Metagenome(14, mean_coverage=5, seed=44, contigs=4, len_lo=30_000, len_hi=70_000, threads=4)
     kept = meta.kept_genomes()
     assert 3 <= len(kept) < 14                                # some genomes fall below 1x and are dropped
     w = meta.generate(kept)

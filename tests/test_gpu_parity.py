@@ -438,15 +438,100 @@ def test_bench_two_ranks_control_flow(tmp_path):
     assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j
 
 
-@pytest.mark.parametrize("name", ["synth_m1", "synth_skipmm"])
+@pytest.mark.parametrize("name", ["synth_m1", "synth_skipmm", "synth_m1_ld", "synth_skipmm_ld", "c3_split"])
 def test_dense_mfma_linkage_equals_reference(ctx, name):
-    """linkage_mode 2 (int8 MFMA X^T X + self pairs) vs the reference golden vectors (M == 1 cases)"""
+    """linkage_mode 2 (int8 MFMA X^T X + self pairs) vs the reference golden vectors (M == 1 cases; synth_m1_ld /
+    synth_skipmm_ld / c3_split carry 1 714 / 1 141 / 302 LD rows produced by the reference itself)"""
     from tests import prod
     g = util.load_case(name)
     res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), n_mm_bins=1,
                          linkage_mode=2, **_params(g))
     util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name + "-dense")
     assert res["n_edges"] == int(g["n_edges"])
+    if name.endswith("_ld"):
+        assert len(res["ld"]) > 1000
+
+
+def test_c3_split_golden_sparse_path(ctx):
+    """one split of the bench's C3 generator (200x, 1 site / 100 bp): tables from the reference's own Python"""
+    from tests import prod
+    g = util.load_case("c3_split")
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), n_mm_bins=1, **_params(g))
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what="c3_split")
+    assert res["n_edges"] == int(g["n_edges"]) and len(res["ld"]) == 302
+
+
+def test_c3_slice_vs_oracle_and_dense_equals_sparse(ctx):
+    """BASELINE configs[2] (C3): a 200 kbp slice of the exact bench generator (200x, 1 SNV site / 100 bp) against the
+    oracle split by split; the dense int8-MFMA linkage path must equal the sparse one byte for byte"""
+    from instrain_amd import engine, synth
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    w = synth.make_workload(genome_len=200_000, coverage=200, n_sites=2000, seed=3, skip_mm=True, af_lo=0.2, af_hi=0.5)
+    out = {}
+    for mode in (1, 2):
+        b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1, enable_linkage=True,
+                         linkage_mode=mode)
+        b.run()
+        out[mode] = (b.fetch(), b.sizes())
+        b.close()
+    assert out[1][1] == out[2][1] and out[1][1]["n_ld"] > 3000
+    for k in ("counts", "clon", "snv", "ld"):
+        a, e = out[1][0][k], out[2][0][k]
+        assert a.tobytes() == e.tobytes(), k
+    got = prod.to_oracle_layout(out[2][0], lambda g: g.astype(np.int64))
+    letters = np.array(list("ACTGN"))
+    gpos = w["obs"]["gpos"].astype(np.int64)
+    exp = {"entries": [], "snv": [], "ld": []}
+    sb = w["split_bounds"]
+    for s, e in zip(sb[:-1], sb[1:]):
+        o = oracle.profile_split(gpos, w["obs"]["base"], w["obs"]["mm"].astype(np.int64), w["pair"].astype(np.int64),
+                                 "".join(letters[w["ref_codes"][s:e]]), int(s), lut, fb)
+        for k in exp:
+            exp[k].append(o[k])
+    exp = {k: np.concatenate(v) for k, v in exp.items()}
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=TOL, what="C3 slice")
+
+
+def test_c3_full_size_properties(ctx):
+    """configs[2] in full (5 Mbp x 200x, 50 000 planted sites, 0.9 G observations): size-independent properties.
+    Sum of counts == observations; every SNV row's counts == the count table; LD rows stay inside their split,
+    position_A <= position_B, counts sum to `total`; sparse and dense linkage agree on every size; a second run
+    of the same batch gives identical tables (idempotence)."""
+    from instrain_amd import engine, synth
+    meta = synth.Metagenome(1, total_read_bp=200 * 5_000_000, seed=3, contigs=1, len_lo=5_000_000, len_hi=5_000_000,
+                            abundance_sigma=0.0, min_genome_coverage=0.0, site_frac=0.01, af_lo=0.2, af_hi=0.5)
+    w = meta.generate([0])
+    assert w["n_pos"] == 5_000_000 and w["n_obs"] > 850_000_000
+    sizes, tabs = {}, {}
+    for mode in (1, 2):
+        b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"], n_mm_bins=1, enable_linkage=True,
+                         linkage_mode=mode)
+        b.run()
+        sizes[mode] = b.sizes()
+        f = b.fetch()
+        if mode == 1:
+            b.run()
+            f2 = b.fetch()
+            for k in ("counts", "clon", "snv", "ld"):
+                cols = [c for c in (f[k].dtype.names or [None]) if c not in ("r2_normalized", "d_prime_normalized")]
+                for c in cols:
+                    x, y = (f[k][c], f2[k][c]) if c else (f[k], f2[k])
+                    assert x.tobytes() == y.tobytes(), ("idempotence", k, c)
+        tabs[mode] = f
+        b.close()
+    assert sizes[1] == sizes[2] and sizes[1]["n_ld"] > 100_000 and sizes[1]["n_snv"] > 45_000
+    f = tabs[1]
+    assert int(f["counts"].sum(dtype=np.int64)) == w["n_obs"]
+    assert (f["snv"]["cnt"] == f["counts"][f["snv"]["gpos"]]).all()
+    ld = f["ld"]
+    sb = w["split_bounds"]
+    sa = np.searchsorted(sb, ld["gpos_a"], side="right")
+    assert (sa == np.searchsorted(sb, ld["gpos_b"], side="right")).all() and (ld["gpos_a"] <= ld["gpos_b"]).all()
+    assert (ld["countAB"].astype(np.int64) + ld["countAb"] + ld["countaB"] + ld["countab"] == ld["total"]).all()
+    for c in ("gpos_a", "gpos_b", "total", "countAB", "countAb", "countaB", "countab", "r2", "d_prime"):
+        assert tabs[1]["ld"][c].tobytes() == tabs[2]["ld"][c].tobytes(), c
 
 
 @pytest.mark.parametrize("seed,mLen,depth,n_sites,bounds", [(201, 4000, 120, 200, None), (202, 12000, 60, 500, [0, 3000, 3001, 9000, 12000]),

@@ -9,7 +9,7 @@ import pytest
 from oracle import oracle
 from tests import util
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(util.GOLD, "synth_*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(util.GOLD, "synth_*.npz"))) + ["c3_split"]
 
 
 def run_oracle_case(g, lut, fb):
