@@ -290,16 +290,32 @@ typedef struct {
     int32_t pin_threads;        /* 1: spread the threads over the L3 domains of the GPU's NUMA node (sched_setaffinity) */
     double jump_slack;          /* device records set aside for streams that jump between far-apart positions
                                  * (next contig / genome of a database), as a fraction of max_obs; 0 = 0.25 */
+    int32_t want_counts;        /* n_mm_bins == 1: 1 = also hand back the per-base count table and the dense clonTR array
+                                 * (16 + 4 more bytes per position over PCIe: the reference keeps them only with
+                                 * --store_everything, profile_utilities.py:205-211); 0 = the shrunk tables below */
+    int32_t reserved;
 } isx_pipe_params;
+
+/* one entry of the sparse clonTR table (positions whose coverage reaches rarefied_coverage) */
+typedef struct {
+    uint32_t gpos;
+    float clon_rarefied;
+} isx_rare;
 
 typedef struct {
     int64_t ticket;
     int64_t n_pos, n_obs;
     isx_sizes sizes;
-    /* n_mm_bins == 1: dense tables in pinned host memory, valid until isx_pipe_release */
-    const uint32_t *counts;     /* [n_pos][4] */
-    const float *clon;          /* [n_pos] */
-    const float *clon_rarefied; /* [n_pos], NULL when rarefied_coverage <= 0 */
+    /* n_mm_bins == 1: tables in pinned host memory, valid until isx_pipe_release.  What shrink_basewise keeps
+     * (profile_utilities.py:337-350) is coverage, clonality and the few rarefied clonalities, so that is what
+     * crosses PCIe: 6 bytes per position instead of 24. */
+    const uint16_t *coverage16; /* [n_pos] covT = min(sum of the four counts, 65535); n_saturated positions hold 65535
+                                 * (their exact counts: isx_batch_fetch_dense on `batch`, or want_counts) */
+    const float *clon;          /* [n_pos] clonT, NaN below min_cov */
+    const isx_rare *rare;       /* [n_rare] clonTR as a sparse table, ascending gpos */
+    int64_t n_rare, n_saturated;
+    const uint32_t *counts;     /* [n_pos][4], NULL unless want_counts */
+    const float *clon_rarefied; /* [n_pos] dense clonTR, NULL unless want_counts */
     const isx_snv *snv;         /* [sizes.n_snv], canonical (gpos, mm) order; both modes */
     /* the slot itself: isx_batch_fetch_entries / isx_batch_fetch_ld / isx_batch_summarize / isx_compare_* may be
      * called on it until isx_pipe_release (n_mm_bins > 1: the entry table is fetched this way) */

@@ -38,7 +38,11 @@ LAYOUT_WIDE_RECORDS, LAYOUT_NO_SHORT_RECORDS, LAYOUT_NO_PACKED_COUNTERS = 1, 2, 
 
 class PipeParams(C.Structure):
     _fields_ = [("max_pos", C.c_int64), ("max_obs", C.c_int64), ("max_splits", C.c_int32), ("depth", C.c_int32),
-                ("host_threads", C.c_int32), ("pin_threads", C.c_int32), ("jump_slack", C.c_double)]
+                ("host_threads", C.c_int32), ("pin_threads", C.c_int32), ("jump_slack", C.c_double),
+                ("want_counts", C.c_int32), ("reserved", C.c_int32)]
+
+
+RARE_DT = np.dtype([("gpos", "<u4"), ("clon_rarefied", "<f4")])
 
 
 class Sizes(C.Structure):
@@ -56,7 +60,8 @@ class Timings(C.Structure):
 
 class PipeResult(C.Structure):
     _fields_ = [("ticket", C.c_int64), ("n_pos", C.c_int64), ("n_obs", C.c_int64), ("sizes", Sizes),
-                ("counts", C.c_void_p), ("clon", C.c_void_p), ("clon_rarefied", C.c_void_p), ("snv", C.c_void_p),
+                ("coverage16", C.c_void_p), ("clon", C.c_void_p), ("rare", C.c_void_p), ("n_rare", C.c_int64),
+                ("n_saturated", C.c_int64), ("counts", C.c_void_p), ("clon_rarefied", C.c_void_p), ("snv", C.c_void_p),
                 ("batch", C.c_void_p),
                 ("encode_ms", C.c_float), ("h2d_ms", C.c_float), ("kernel_ms", C.c_float), ("d2h_ms", C.c_float),
                 ("collect_wait_ms", C.c_float), ("record_bytes", C.c_int32), ("encode_passes", C.c_int32),

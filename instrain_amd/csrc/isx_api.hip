@@ -498,7 +498,7 @@ void isx_batch_destroy(isx_batch *b)
     }
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_entries, b->d_win_nent, b->d_slev,
+    void *ps[] = {b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
@@ -653,6 +653,7 @@ int launch_pass(isx_batch *b)
 #endif
     a.counts = b->d_counts; a.clon = b->d_clon; a.clon_r = b->d_clon_r;
     a.min_cov_r = b->prm.rarefied_coverage;
+    a.cov16 = b->d_cov16; a.rare = b->d_rare; a.cap_rare = (uint32_t)std::min<size_t>(b->cap_rare, 0xFFFFFFFFu);
     a.seed_lo = (uint32_t)b->prm.seed; a.seed_hi = (uint32_t)(b->prm.seed >> 32);
     a.entries = b->d_entries; a.slab = b->slab; a.cap_ovf = (uint32_t)b->cap_ovf;
     a.ovf0 = (uint64_t)b->n_win * b->slab; a.win_nent = b->d_win_nent;
@@ -725,6 +726,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags)
     b->n_ovf = cur[CUR_ENTRIES];
     b->sizes.n_snv = cur[CUR_SNV];
     b->sizes.n_sites = cur[CUR_SITES];
+    b->n_rare = cur[CUR_RARE]; b->n_sat = cur[CUR_SAT];
     b->tim = isx_timings{};
     b->tim_pending = true;                  // the kernel's own time stamps are read when somebody asks (isx_batch_timings)
     b->tim.pileup_blocks = b->grid;

@@ -55,6 +55,10 @@ struct isx_batch {
     uint4 *d_counts = nullptr;
     float *d_clon = nullptr;
     float *d_clon_r = nullptr;       // rarefied clonality of the dense path [n_pos]
+    uint16_t *d_cov16 = nullptr;     // pipe slots (dense path): coverage per position for the shrunk hand-back
+    uint2 *d_rare = nullptr;         // pipe slots (dense path): sparse clonTR list
+    size_t cap_rare = 0;
+    uint32_t n_rare = 0, n_sat = 0;  // of the last pass: list entries (may exceed cap_rare: list unusable), saturated positions
     isx_entry *d_entries = nullptr;  // mm path: [n_win][slab] slabs, then cap_ovf overflow entries
     uint32_t *d_win_nent = nullptr;
     isx_slev *d_slev = nullptr;

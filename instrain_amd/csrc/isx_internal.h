@@ -35,7 +35,8 @@ void isx_set_error(const std::string &msg);
 
 // cursors (dev_cursors[i], uint32)
 enum { CUR_ENTRIES = 0 /* mm path: overflow entries */, CUR_SNV = 1, CUR_SITES = 2, CUR_AO = 3, CUR_SLEV = 4,
-       CUR_ENT_TOTAL = 5, CUR_N = 8 };
+       CUR_ENT_TOTAL = 5, CUR_RARE = 6 /* dense path: entries of the sparse clonTR list */,
+       CUR_SAT = 7 /* dense path: positions whose coverage saturates the 16-bit hand-back */, CUR_N = 8 };
 
 // SNP site record: a position where update_snp_table returned anySNP (snv_utilities.py:129-133).
 // Holds what linkage needs later: the `bases` set and where the per-level counts live.
@@ -139,6 +140,9 @@ struct PileupArgs {
     uint4 *counts;              // dense path (M == 1): [n_pos]
     float *clon;                // dense path: [n_pos]
     float *clon_r;              // rarefied clonality: dense [n_pos] / mm path [cap_entries]; pre-filled with NaN
+    uint16_t *cov16;            // dense path, pipe slots: min(coverage, 65535) per position (NULL = not wanted)
+    uint2 *rare;                // dense path, pipe slots: (gpos, float bits of clonTR) of the positions that have one, unordered
+    uint32_t cap_rare;
     int32_t min_cov_r;          // rarefied_coverage; <= 0 disables the rarefied output
     uint32_t seed_lo, seed_hi;
     isx_entry *entries;         // mm path: per-window slabs [n_win][slab] then the overflow region

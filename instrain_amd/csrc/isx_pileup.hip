@@ -47,7 +47,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define THR_LDS 1024        // coverages below this read their folded threshold from LDS
 
 // scratch words (LDS)
-enum { S_NQ = 0, S_ROWS, S_SITES, S_ROW_BASE, S_SITE_BASE, S_ROW_RANK, S_NAO, S_AO_BASE, S_ENT_TOT, S_ENT_BASE, S_SLEV, S_SLEV_BASE, S_N = 16 };
+enum { S_NQ = 0, S_ROWS, S_SITES, S_ROW_BASE, S_SITE_BASE, S_ROW_RANK, S_NAO, S_AO_BASE, S_ENT_TOT, S_ENT_BASE, S_SLEV, S_SLEV_BASE, S_NRARE, S_RARE_BASE, S_RARE_RANK, S_N = 16 };
 
 // table cursors run on across launches; a run's slots are relative to the values it started from
 __device__ __forceinline__ uint32_t cur_add(const PileupArgs &a, int which, uint32_t n)
@@ -459,16 +459,19 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
             const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
             const uint32_t total = c[0] + c[1] + c[2] + c[3];
             a.counts[gpos] = make_uint4(c[0], c[1], c[2], c[3]);
+            if (a.cov16) {                      // shrunk hand-back of a pipe slot: coverage alone, 2 bytes per position
+                a.cov16[gpos] = (uint16_t)min(total, 65535u);
+                if (total >= 65535u) cur_add(a, CUR_SAT, 1u);
+            }
             float cl = __builtin_nanf("");
             bool defer = false;
+            uint32_t entry = (uint32_t)p;
             if ((int64_t)total >= (int64_t)a.min_cov) {
                 const int ref_base = ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : a.ref[gpos]);
                 const SiteCall sc = call_level(a, thr_lds, c, total, ref_base, false);
                 const uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
                 if (mx == total) cl = 1.0f; else defer = true;
-                uint32_t entry = (uint32_t)p;
                 if (defer) entry |= 1u << 13;
-                if (a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r) entry |= 1u << 15;
                 if (sc.snp != -1) {
                     entry |= 1u << 14;
                     atomicAdd(&scratch[S_ROWS], 1u);
@@ -481,8 +484,10 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
                         }
                     }
                 }
-                if (entry != (uint32_t)p) queue[atomicAdd(&scratch[S_NQ], 1u)] = entry;
             }
+            // clonTR is gated on rarefied_coverage alone (snv_utilities.py:100-102), also below min_cov
+            if (a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r) { entry |= 1u << 15; if (a.rare) atomicAdd(&scratch[S_NRARE], 1u); }
+            if (entry != (uint32_t)p) queue[atomicAdd(&scratch[S_NQ], 1u)] = entry;
             if (!defer) a.clon[gpos] = cl;
         }
         __syncthreads();
@@ -490,6 +495,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         if (tid == 0 && nrows) scratch[S_ROW_BASE] = cur_add(a, CUR_SNV, nrows);
         if (tid == 64 && nsites) scratch[S_SITE_BASE] = cur_add(a, CUR_SITES, nsites);
         if (tid == 128 && nao) scratch[S_AO_BASE] = cur_add(a, CUR_AO, nao);
+        const uint32_t nrare = a.rare ? scratch[S_NRARE] : 0u;
+        if (tid == 192 && nrare) scratch[S_RARE_BASE] = cur_add(a, CUR_RARE, nrare);
         // ---- deferred clonalities (snv_utilities.py:225-231), densely packed ----
         for (uint32_t q = tid; q < nq; q += nthr) {
             const uint32_t e = queue[q];
@@ -498,16 +505,20 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
             const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
             a.clon[w0 + p] = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
         }
+        if (nrows | nrare) __syncthreads();     // uniform: scratch bases from the atomics above
         if (a.min_cov_r > 0) {                  // rarefied clonality (snv_utilities.py:233-247), own loop: fewer live registers
+            const uint32_t rare_base = scratch[S_RARE_BASE];
+            const bool list = nrare && rare_base + nrare <= a.cap_rare;      // else the host reads the dense array
             for (uint32_t q = tid; q < nq; q += nthr) {
                 const uint32_t e = queue[q];
                 if (!(e & (1u << 15))) continue;
                 const int p = (int)(e & 0x1FFFu);
                 const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
-                a.clon_r[w0 + p] = rarefied_clonality(a, c, w0 + p, 0);
+                const float v = rarefied_clonality(a, c, w0 + p, 0);
+                a.clon_r[w0 + p] = v;
+                if (list) a.rare[rare_base + atomicAdd(&scratch[S_RARE_RANK], 1u)] = make_uint2(w0 + p, __float_as_uint(v));
             }
         }
-        if (nrows) __syncthreads();             // uniform: scratch bases from the atomics above
         // ---- SNV rows / SNP sites (snv_utilities.py:107-133) ----
         const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE], ao_base = scratch[S_AO_BASE];
         bool ok = nrows != 0;

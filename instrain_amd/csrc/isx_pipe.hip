@@ -41,7 +41,8 @@ struct Slot {
     size_t in_bytes = 0;
     size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_rec = 0, off_pair = 0;
     uint8_t *h_out = nullptr;
-    size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0;
+    size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0, o_cov16 = 0, o_rare = 0;
+    std::vector<isx_rare> rare_big;         // more clonTR entries than the pinned block holds / the device list overflowed
     std::vector<uint32_t> cmin, cmax;
     std::vector<uint8_t> cany;
     std::vector<uint2> win;
@@ -95,6 +96,7 @@ struct isx_pipe {
     int rb = 2;                             // record bytes
     uint32_t G = ISX_GROUP16;
     size_t snv_prefix = 0;                  // SNV rows copied out with the dense tables
+    size_t rare_prefix = 0, cap_rare = 0;   // clonTR entries copied out with them / the device list's capacity
     double slack = 0.0;                     // learned: extra device groups per input group of the last jumping batch
 };
 
@@ -157,6 +159,11 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
         HIP_TRY(hipMalloc(&b->d_counts, (size_t)cap_pos * sizeof(uint4)));
         HIP_TRY(hipMalloc(&b->d_clon, (size_t)cap_pos * sizeof(float)));
         HIP_TRY(hipMalloc(&b->d_clon_r, (size_t)cap_pos * sizeof(float)));
+        HIP_TRY(hipMalloc(&b->d_cov16, (size_t)cap_pos * sizeof(uint16_t)));
+        if (prm->rarefied_coverage > 0) {
+            b->cap_rare = p->cap_rare;
+            HIP_TRY(hipMalloc(&b->d_rare, b->cap_rare * sizeof(uint2)));
+        }
     } else {
         b->slab_region = (size_t)(cap_pos + 2 * b->block) * (size_t)std::min(b->M, 4);
         const size_t ovf = b->M <= 4 ? 16 : (size_t)std::max<uint64_t>(1u << 20, std::min<uint64_t>(cap_obs, npm) / 4);
@@ -191,9 +198,13 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     o = 0;
     s.o_snv = o; o = up(o + p->snv_prefix * sizeof(isx_snv));
     if (dense) {
-        s.o_counts = o; o = up(o + (size_t)cap_pos * 16);
+        s.o_cov16 = o; o = up(o + (size_t)cap_pos * 2);
         s.o_clon = o; o = up(o + (size_t)cap_pos * 4);
-        s.o_clonr = o; if (prm->rarefied_coverage > 0) o = up(o + (size_t)cap_pos * 4);
+        s.o_rare = o; if (prm->rarefied_coverage > 0) o = up(o + p->rare_prefix * sizeof(isx_rare));
+        if (p->pp.want_counts) {
+            s.o_counts = o; o = up(o + (size_t)cap_pos * 16);
+            s.o_clonr = o; if (prm->rarefied_coverage > 0) o = up(o + (size_t)cap_pos * 4);
+        }
     }
     s.out_bytes = o;
     HIP_TRY(hipHostMalloc(&s.h_out, s.out_bytes, hipHostMallocDefault));
@@ -228,6 +239,10 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     p->cap_rec = (int64_t)((want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
     if ((uint64_t)p->cap_rec >= 0xFFFFFFFFull) { delete p; isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
     p->snv_prefix = (size_t)std::min<int64_t>(std::max<int64_t>(pp->max_pos / 64, 1 << 16), 1 << 22);
+    // clonTR list: the device list can hold every position; a sixteenth of that travels with every batch, the
+    // rest only when a batch really has that many (deep samples)
+    p->cap_rare = (size_t)std::max<int64_t>(pp->max_pos, 1 << 16);
+    p->rare_prefix = (size_t)std::max<int64_t>(pp->max_pos / 16, 1 << 16);
     int nt = pp->host_threads;
     if (nt <= 0) {
         const int q = cgroup_cpus();
@@ -372,12 +387,21 @@ int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_sp
     HIP_TRY(hipMemcpyAsync(s.h_out + s.o_snv, b->d_snv, snv_rows * sizeof(isx_snv), hipMemcpyDeviceToHost, p->s_d2h));
     s.d2h_bytes = (int64_t)(snv_rows * sizeof(isx_snv));
     if (dense) {
-        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_counts, b->d_counts, (size_t)n_pos * 16, hipMemcpyDeviceToHost, p->s_d2h));
+        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_cov16, b->d_cov16, (size_t)n_pos * 2, hipMemcpyDeviceToHost, p->s_d2h));
         HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clon, b->d_clon, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
-        s.d2h_bytes += (int64_t)n_pos * 20;
+        s.d2h_bytes += (int64_t)n_pos * 6;
         if (p->prm.rarefied_coverage > 0) {
-            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clonr, b->d_clon_r, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
-            s.d2h_bytes += (int64_t)n_pos * 4;
+            const size_t n = std::min(p->rare_prefix, std::min(p->cap_rare, (size_t)n_pos));
+            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_rare, b->d_rare, n * sizeof(isx_rare), hipMemcpyDeviceToHost, p->s_d2h));
+            s.d2h_bytes += (int64_t)(n * sizeof(isx_rare));
+        }
+        if (p->pp.want_counts) {
+            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_counts, b->d_counts, (size_t)n_pos * 16, hipMemcpyDeviceToHost, p->s_d2h));
+            s.d2h_bytes += (int64_t)n_pos * 16;
+            if (p->prm.rarefied_coverage > 0) {
+                HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clonr, b->d_clon_r, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
+                s.d2h_bytes += (int64_t)n_pos * 4;
+            }
         }
     }
     HIP_TRY(hipEventRecord(s.ev_d2h1, p->s_d2h));
@@ -418,10 +442,30 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
             redo = true;
         }
         if (redo && dense) {                        // the copied-out tables predate the repeated pass
-            HIP_TRY(hipMemcpy(s.h_out + s.o_counts, b->d_counts, (size_t)b->n_pos * 16, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
-            if (p->prm.rarefied_coverage > 0)
-                HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+            if (p->pp.want_counts) {
+                HIP_TRY(hipMemcpy(s.h_out + s.o_counts, b->d_counts, (size_t)b->n_pos * 16, hipMemcpyDeviceToHost));
+                if (p->prm.rarefied_coverage > 0)
+                    HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+            }
+        }
+        if (dense && p->prm.rarefied_coverage > 0) {        // the sparse clonTR table, ascending positions
+            const size_t n_rare = b->n_rare;
+            isx_rare *rr = reinterpret_cast<isx_rare *>(s.h_out + s.o_rare);
+            s.rare_big.clear();
+            if (n_rare > p->cap_rare) {                     // the device list overflowed: rebuild it from the dense array
+                std::vector<float> dense_r((size_t)b->n_pos);
+                HIP_TRY(hipMemcpy(dense_r.data(), b->d_clon_r, dense_r.size() * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < dense_r.size(); i++)
+                    if (!std::isnan(dense_r[i])) s.rare_big.push_back(isx_rare{(uint32_t)i, dense_r[i]});
+            } else {
+                if (n_rare > p->rare_prefix || redo) {
+                    if (n_rare > p->rare_prefix) { s.rare_big.resize(n_rare); rr = s.rare_big.data(); }
+                    if (n_rare) HIP_TRY(hipMemcpy(rr, b->d_rare, n_rare * sizeof(isx_rare), hipMemcpyDeviceToHost));
+                }
+                std::sort(rr, rr + n_rare, [](const isx_rare &x, const isx_rare &y) { return x.gpos < y.gpos; });
+            }
         }
         const size_t n_snv = (size_t)b->sizes.n_snv;
         isx_snv *rows = reinterpret_cast<isx_snv *>(s.h_out + s.o_snv);
@@ -437,9 +481,17 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
     out->sizes = b->sizes;
     out->snv = (size_t)b->sizes.n_snv > p->snv_prefix ? s.snv_big.data() : reinterpret_cast<const isx_snv *>(s.h_out + s.o_snv);
     if (dense) {
-        out->counts = reinterpret_cast<const uint32_t *>(s.h_out + s.o_counts);
+        out->coverage16 = reinterpret_cast<const uint16_t *>(s.h_out + s.o_cov16);
         out->clon = reinterpret_cast<const float *>(s.h_out + s.o_clon);
-        out->clon_rarefied = p->prm.rarefied_coverage > 0 ? reinterpret_cast<const float *>(s.h_out + s.o_clonr) : nullptr;
+        out->n_saturated = b->n_sat;
+        if (p->prm.rarefied_coverage > 0) {
+            out->rare = s.rare_big.empty() ? reinterpret_cast<const isx_rare *>(s.h_out + s.o_rare) : s.rare_big.data();
+            out->n_rare = s.rare_big.empty() ? (int64_t)b->n_rare : (int64_t)s.rare_big.size();
+        }
+        if (p->pp.want_counts) {
+            out->counts = reinterpret_cast<const uint32_t *>(s.h_out + s.o_counts);
+            out->clon_rarefied = p->prm.rarefied_coverage > 0 ? reinterpret_cast<const float *>(s.h_out + s.o_clonr) : nullptr;
+        }
     }
     out->batch = b;
     out->encode_ms = s.encode_ms;

@@ -179,14 +179,15 @@ class Pipe:
 
     def __init__(self, ctx, max_pos, max_obs, max_splits, depth=4, host_threads=0, pin_threads=True, jump_slack=0.0,
                  min_cov=5, min_freq=0.05, min_snp=20, rarefied_coverage=50, n_mm_bins=1, enable_linkage=False,
-                 linkage_mode=0, window=0, seed=0, layout=0):
+                 linkage_mode=0, window=0, seed=0, layout=0, want_counts=False):
         self.ctx, self.lib = ctx, ctx.lib
         self.n_mm_bins = int(n_mm_bins)
+        self.want_counts = bool(want_counts)
         self.enable_linkage = bool(enable_linkage)
         p = Params(int(min_cov), int(min_snp), float(min_freq), int(rarefied_coverage), int(n_mm_bins),
                    1 if enable_linkage else 0, int(linkage_mode), int(window), int(seed), int(layout), 0)
         pp = _lib.PipeParams(int(max_pos), int(max_obs), int(max_splits), int(depth), int(host_threads),
-                             1 if pin_threads else 0, float(jump_slack))
+                             1 if pin_threads else 0, float(jump_slack), 1 if want_counts else 0, 0)
         h = C.c_void_p()
         check(self.lib.isx_pipe_create(ctx.h, C.byref(p), C.byref(pp), C.byref(h)))
         self.h = h
@@ -222,9 +223,14 @@ class Pipe:
 
         slot = _SlotBatch(self.ctx, r.batch, n_pos, r.n_obs, self.n_mm_bins)
         if self.n_mm_bins == 1:
-            out["counts"] = view(r.counts, np.uint32, n_pos * 4).reshape(n_pos, 4)
+            # the shrunk tables (what shrink_basewise keeps): coverage, clonality, sparse rarefied clonality
+            out["cov16"] = view(r.coverage16, np.uint16, n_pos)
             out["clon"] = view(r.clon, np.float32, n_pos)
-            out["clon_r"] = view(r.clon_rarefied, np.float32, n_pos) if r.clon_rarefied else np.full(n_pos, np.nan, np.float32)
+            out["rare"] = view(r.rare, _lib.RARE_DT, int(r.n_rare)) if r.rare else np.empty(0, dtype=_lib.RARE_DT)
+            out["n_saturated"] = int(r.n_saturated)
+            if r.counts:                            # want_counts: the full tables as Batch.fetch() returns them
+                out["counts"] = view(r.counts, np.uint32, n_pos * 4).reshape(n_pos, 4)
+                out["clon_r"] = view(r.clon_rarefied, np.float32, n_pos) if r.clon_rarefied else np.full(n_pos, np.nan, np.float32)
         else:
             e = np.empty(max(1, sz["n_entries"]), dtype=ENTRY_DT)
             check(self.lib.isx_batch_fetch_entries(slot.h, e.ctypes.data))

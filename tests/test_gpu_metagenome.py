@@ -52,7 +52,7 @@ def test_metagenome_slice_vs_oracle(ctx):
     util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=1e-6, what="metagenome slice")
     # the same batch through the pipe (the stream jumps at every uncovered stretch / contig end)
     pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=w["n_obs"], max_splits=len(sb), depth=2, host_threads=4,
-                       n_mm_bins=1, enable_linkage=True, **kw)
+                       n_mm_bins=1, enable_linkage=True, want_counts=True, **kw)
     t = pipe.submit(w["ref_codes"], sb, w["obs"], w["pair"])
     r = pipe.collect(t)
     for k in ("counts", "clon", "snv", "ld"):
@@ -83,7 +83,7 @@ def test_c5_per_gpu_shard_properties(ctx):
     assert 0.9e9 < total_bases < 1.4e9                        # ~ 10 Gbp x (kept share) / 8
     pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
                        max_splits=max(len(w["split_bounds"]) for w in ws), depth=3, n_mm_bins=1, enable_linkage=False,
-                       jump_slack=0.5)
+                       jump_slack=0.5, want_counts=True)
     tickets = [None] * len(ws)
 
     def check(i, r, first):
@@ -107,6 +107,9 @@ def test_c5_per_gpu_shard_properties(ctx):
         assert (snv["cnt"] == counts[snv["gpos"]]).all() and (np.diff(snv["gpos"].astype(np.int64)) > 0).all()
         cov = counts.sum(axis=1)
         assert np.isnan(r["clon"][cov < 5]).all() and not np.isnan(r["clon"][cov >= 5]).any()
+        # the shrunk tables that travel by default: coverage16, and clonTR exactly where coverage >= 50
+        assert (r["cov16"] == np.minimum(cov, 65535)).all()
+        assert (r["rare"]["gpos"] == np.flatnonzero(cov >= 50)).all() and not np.isnan(r["rare"]["clon_rarefied"]).any()
         return (chk_dev, len(snv), int(snv["gpos"].astype(np.int64).sum()))
 
     sig = []

@@ -632,3 +632,24 @@ def test_tables_grow_when_estimates_are_too_small(ctx, monkeypatch):
     snv = b.fetch()["snv"]
     b.close()
     assert s["n_snv"] == n_pos and (snv["cls"] == 2).all() and (snv["gpos"] == np.arange(n_pos)).all()
+
+
+def test_rarefied_gate_independent_of_min_cov(ctx):
+    """clonTR exists wherever cumulative coverage >= rarefied_coverage (snv_utilities.py:100-102), also where it is
+    below min_cov: with rarefied_coverage < min_cov the dense and the mm kernels must mark the same positions"""
+    from instrain_amd import engine
+    seq, pos, base, mm, pair = _random_split(77, 1500, 14, 1, 20)
+    obs = engine.pack_obs(pos.astype(np.uint32), base, mm * 0)
+    out = {}
+    for M in (1, 3):
+        b = engine.Batch(ctx, engine.encode_seq(seq), [0, len(seq)], obs, pair.astype(np.uint32), n_mm_bins=M,
+                         min_cov=12, rarefied_coverage=6, seed=9)
+        b.run()
+        out[M] = b.fetch()
+        b.close()
+    cov = out[1]["counts"].sum(axis=1)
+    have = ~np.isnan(out[1]["clon_r"])
+    assert ((cov >= 6) == have).all() and ((cov >= 6) & (cov < 12)).sum() > 50
+    e = out[3]["entries"]
+    assert (e["gpos"][~np.isnan(e["clon_rarefied"])] == np.flatnonzero(have)).all()
+    assert (np.isnan(out[1]["clon"]) == (cov < 12)).all()

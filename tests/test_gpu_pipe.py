@@ -34,9 +34,22 @@ def one_shot(ctx, w, **kw):
     return res, sizes
 
 
+def check_shrunk(got, exp, what):
+    """the shrunk hand-back (coverage16 + clonality + sparse rarefied clonality) against the full tables"""
+    cov = exp["counts"].sum(axis=1, dtype=np.int64)
+    assert (got["cov16"] == np.minimum(cov, 65535)).all(), (what, "cov16")
+    assert got["n_saturated"] == int((cov >= 65535).sum())
+    assert (got["clon"].view(np.uint32) == exp["clon"].view(np.uint32)).all(), (what, "clon")
+    k = np.flatnonzero(~np.isnan(exp["clon_r"]))
+    assert len(got["rare"]) == len(k) and (got["rare"]["gpos"] == k).all(), (what, "rare positions")
+    assert (got["rare"]["clon_rarefied"].view(np.uint32) == exp["clon_r"][k].view(np.uint32)).all(), (what, "rare values")
+
+
 def same_tables(got, exp, what):
+    if "counts" in exp and "cov16" in got:
+        check_shrunk(got, exp, what)
     for k in ("counts", "clon", "clon_r", "entries", "snv", "ld"):
-        if k not in exp:
+        if k not in exp or k not in got:
             continue
         a, e = got[k], exp[k]
         assert a.shape == e.shape, (what, k, a.shape, e.shape)
@@ -62,7 +75,8 @@ def test_stream_of_distinct_batches_dense(ctx, linkage):
     kw = dict(enable_linkage=linkage, min_snp=5, seed=11, rarefied_coverage=20)
     exp = [one_shot(ctx, w, **kw) for w in ws]
     pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
-                       max_splits=max(len(w["split_bounds"]) for w in ws), depth=3, host_threads=4, n_mm_bins=1, **kw)
+                       max_splits=max(len(w["split_bounds"]) for w in ws), depth=3, host_threads=4, n_mm_bins=1,
+                       want_counts=linkage, **kw)           # once with the full tables, once with the shrunk ones only
     tickets = []
     done = 0
     for i, w in enumerate(ws):
@@ -184,7 +198,8 @@ def test_tables_grow_inside_a_slot(ctx):
     t = pipe.submit(ref, [0, n_pos], obs)
     r = pipe.collect(t)
     assert r["sizes"]["n_snv"] == n_pos and (r["snv"]["cls"] == 2).all() and (r["snv"]["gpos"] == np.arange(n_pos)).all()
-    assert (r["counts"][:, 1] == depth).all() and (r["counts"][:, [0, 2, 3]] == 0).all()
+    assert (r["snv"]["cnt"][:, 1] == depth).all() and (r["snv"]["cnt"][:, [0, 2, 3]] == 0).all()
+    assert (r["cov16"] == depth).all() and (r["clon"] == 1.0).all() and len(r["rare"]) == 0
     pipe.release(t)
     w = small_workload(500, 40_000, 20, True)
     exp, sizes = one_shot(ctx, w, enable_linkage=False)
@@ -192,8 +207,7 @@ def test_tables_grow_inside_a_slot(ctx):
     t3 = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
     for t in (t2, t3):
         r = pipe.collect(t)
-        for k in ("counts", "clon", "snv"):
-            same_tables({k: r[k]}, {k: exp[k]}, "after growth")
+        same_tables(r, exp, "after growth")
         pipe.release(t)
     pipe.close()
 
@@ -223,6 +237,6 @@ def test_pipe_errors(ctx):
     # an empty batch is legal
     t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"][:0])
     r = pipe.collect(t)
-    assert r["sizes"]["n_snv"] == 0 and (r["counts"] == 0).all() and np.isnan(r["clon"]).all()
+    assert r["sizes"]["n_snv"] == 0 and (r["cov16"] == 0).all() and np.isnan(r["clon"]).all() and len(r["rare"]) == 0
     pipe.release(t)
     pipe.close()
