@@ -346,7 +346,16 @@ int isx_encode_obs(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int6
                    int32_t host_threads, double slack, int64_t cap_rec, void *rec, uint32_t *gbase, uint32_t *pair_out,
                    int64_t *n_rec, int32_t *passes);
 
-/* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ---- */
+/* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ----
+ * Two passes over the (memory-mapped, compressed) file, like the reference, none of which holds the file's reads:
+ *   isx_bam_scan         filter_reads.get_paired_reads for every reference (filter_reads.py:885-956): per
+ *                        (scaffold, read name) the NM sum / mapq / length / insert record; per read 4 bytes
+ *   isx_bam_filter       paired_read_filter + filter_scaff2pair2info (filter_reads.py:471-532, 201-260) with the
+ *                        file's own median insert -- or a median handed in (one sample spread over several files)
+ *   isx_bam_set_r2m      instead: the controller's own sR2M[scaffold] (profile_controller.py:415-433)
+ *   isx_bam_expand_refs  samfile.pileup(...) of profile_utilities.py:150-153 for a SUBSET of the references (one
+ *                        batch / one GPU's shard): only the BGZF blocks holding them are inflated again
+ * isx_bam_expand = all three over the whole file. */
 typedef struct isx_bam isx_bam;
 
 typedef struct {
@@ -357,14 +366,14 @@ typedef struct {
     int32_t min_base_quality;   /* 30 (profile_utilities.py:153) */
     int32_t skip_mm;            /* --skip_mm_profiling */
     int32_t window_length;      /* 10000 (fasta.py:56-73 iterate_splits) */
-    int32_t pad;
+    int32_t pairing_filter;     /* 0 paired_only (default), 1 non_discordant, 2 all_reads (filter_reads.py:499-525) */
 } isx_bam_params;
 
 typedef struct {
-    int32_t n_refs;
+    int32_t n_refs;             /* references of the file (scan / filter) or of the batch (expand) */
     int32_t n_splits;
     int64_t n_reads;
-    int64_t n_pos;              /* sum of reference lengths = flat space */
+    int64_t n_pos;              /* sum of reference lengths = flat space (of the file / of the batch) */
     int64_t n_obs;
     int64_t n_pairs;            /* dense pair ids handed out */
     int64_t unfiltered_pairs, filtered_pairs;
@@ -372,17 +381,35 @@ typedef struct {
     double median_insert;
     int32_t max_mm;
     int32_t pad;
+    int64_t unfiltered_reads, unfiltered_singletons, filtered_singletons;   /* read_report tallies (filter_reads.py:487-495, 372-377) */
 } isx_bam_info;
 
-int isx_bam_open(const char *path, isx_bam **out);
+int isx_bam_open(const char *path, isx_bam **out);     /* header + BGZF block index; nothing else is inflated */
 void isx_bam_close(isx_bam *bam);
-/* filter + overlap resolution + expansion of every reference of the file */
-int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info);
+int isx_bam_set_threads(isx_bam *bam, int32_t threads); /* 0 = automatic (2 x the container's cpu quota, at most 64) */
 int isx_bam_ref(const isx_bam *bam, int32_t i, const char **name, int64_t *length, int64_t *flat_offset);
+/* names[offs[i] .. offs[i+1]) = i-th priority read (--priority_reads, filter_reads.py:428-469); used by the next isx_bam_filter */
+int isx_bam_set_priority_reads(isx_bam *bam, int64_t n, const char *names, const int64_t *offs);
+int isx_bam_scan(isx_bam *bam, isx_bam_info *info /* may be NULL */);
+/* insert sizes of the two-read pairs: out may be NULL to ask for *n only (a median across files / ranks) */
+int isx_bam_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n);
+int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert /* NaN = this file's own */, isx_bam_info *info);
+int isx_bam_set_r2m(isx_bam *bam, int32_t ref, int64_t n, const char *names, const int64_t *offs, const int32_t *mm /* NULL = 0 */);
+/* the reference's Rdic[scaffold] as the filter left it (read pair -> mm, controller.py:274-281): sizes first (names NULL),
+ * then names[name_bytes], offs[n + 1], mm[n] */
+int isx_bam_r2m(const isx_bam *bam, int32_t ref, int64_t *n, int64_t *name_bytes, char *names, int64_t *offs, int32_t *mm);
+int isx_bam_drop_names(isx_bam *bam);                   /* frees the read names (no filter / set_r2m call may follow) */
+/* per reference: records in the file, pairs that passed the filter (the reference's s2p, profile_controller.py:441) */
+int isx_bam_ref_counts(const isx_bam *bam, int64_t *reads, int64_t *filtered_pairs);
+/* overlap resolution + expansion of the given references (ascending ids = file order), laid end to end (the batch's
+ * flat space); results stay in the handle until the next expand (isx_bam_copy / isx_bam_view) */
+int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info);
+/* scan + filter + expansion of every reference of the file */
+int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info);
 /* copy out: obs[n_obs], pair[n_obs], split_bounds[n_splits+1], split_ref[n_splits] */
 int isx_bam_copy(const isx_bam *bam, isx_obs *obs, uint32_t *pair, int64_t *split_bounds, int32_t *split_ref);
-/* Zero-copy alternative to isx_bam_copy for the two large arrays: pointers into the handle, valid until
- * isx_bam_close (isx_batch_create copies from them, so the handle can be closed right after). */
+/* Zero-copy alternative to isx_bam_copy for the two large arrays: pointers into the handle, valid until the next
+ * expand / isx_bam_close (isx_batch_create / isx_pipe_submit copy from them). */
 int isx_bam_view(const isx_bam *bam, const isx_obs **obs, const uint32_t **pair);
 
 #ifdef __cplusplus

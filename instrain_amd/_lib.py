@@ -71,14 +71,18 @@ class PipeResult(C.Structure):
 class BamParams(C.Structure):
     _fields_ = [("min_read_ani", C.c_double), ("min_mapq", C.c_int32), ("max_insert_relative", C.c_double),
                 ("min_insert", C.c_int32), ("min_base_quality", C.c_int32), ("skip_mm", C.c_int32),
-                ("window_length", C.c_int32), ("pad", C.c_int32)]
+                ("window_length", C.c_int32), ("pairing_filter", C.c_int32)]
+
+
+PAIRING_FILTERS = {"paired_only": 0, "non_discordant": 1, "all_reads": 2}
 
 
 class BamInfo(C.Structure):
     _fields_ = [("n_refs", C.c_int32), ("n_splits", C.c_int32), ("n_reads", C.c_int64), ("n_pos", C.c_int64),
                 ("n_obs", C.c_int64), ("n_pairs", C.c_int64), ("unfiltered_pairs", C.c_int64),
                 ("filtered_pairs", C.c_int64), ("filtered_bases", C.c_int64), ("median_insert", C.c_double),
-                ("max_mm", C.c_int32), ("pad", C.c_int32)]
+                ("max_mm", C.c_int32), ("pad", C.c_int32), ("unfiltered_reads", C.c_int64),
+                ("unfiltered_singletons", C.c_int64), ("filtered_singletons", C.c_int64)]
 
 
 SCAFFOLD_LEVEL_DT = np.dtype([("nonzero", "<i8"), ("sum_cov", "<u8"), ("sumsq_cov", "<u8"), ("median_cov", "<f8"),
@@ -108,7 +112,9 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
            "isx_batch_summarize", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
            "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_collect", "isx_pipe_release", "isx_encode_obs",
-           "isx_bam_open", "isx_bam_close", "isx_bam_expand", "isx_bam_ref", "isx_bam_copy", "isx_bam_view"]
+           "isx_bam_open", "isx_bam_close", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan",
+           "isx_bam_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_ref_counts",
+           "isx_bam_expand_refs", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
 
 _lib = None
 
@@ -155,6 +161,16 @@ def load():
     lib.isx_bam_close.argtypes = [vp]
     lib.isx_bam_close.restype = None
     lib.isx_bam_expand.argtypes = [vp, C.POINTER(BamParams), C.POINTER(BamInfo)]
+    lib.isx_bam_set_threads.argtypes = [vp, i32]
+    lib.isx_bam_set_priority_reads.argtypes = [vp, i64, C.c_char_p, vp]
+    lib.isx_bam_scan.argtypes = [vp, C.POINTER(BamInfo)]
+    lib.isx_bam_insert_sizes.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    lib.isx_bam_filter.argtypes = [vp, C.POINTER(BamParams), C.c_double, C.POINTER(BamInfo)]
+    lib.isx_bam_set_r2m.argtypes = [vp, i32, i64, C.c_char_p, vp, vp]
+    lib.isx_bam_drop_names.argtypes = [vp]
+    lib.isx_bam_r2m.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), vp, vp, vp]
+    lib.isx_bam_ref_counts.argtypes = [vp, vp, vp]
+    lib.isx_bam_expand_refs.argtypes = [vp, C.POINTER(BamParams), vp, i32, C.POINTER(BamInfo)]
     lib.isx_bam_ref.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64)]
     lib.isx_bam_copy.argtypes = [vp, vp, vp, vp, vp]
     lib.isx_bam_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

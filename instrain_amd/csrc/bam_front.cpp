@@ -5,7 +5,7 @@
 // is not vendored under /root/reference):
 //   pysam.AlignmentFile(bam) / samfile.fetch      /root/reference/inStrain/profile/profile_utilities.py:56
 //   get_paired_reads                              /root/reference/inStrain/filter_reads.py:885-956
-//   paired_read_filter ('paired_only')            filter_reads.py:471-532
+//   paired_read_filter                            filter_reads.py:471-532 (paired_only / non_discordant / all_reads, priority reads)
 //   filter_scaff2pair2info / evaluate_pair        filter_reads.py:201-260, 388-426
 //   samfile.pileup(..., stepper='nofilter', ignore_overlaps=True, min_base_quality=30, ...)
 //                                                 profile_utilities.py:150-153
@@ -14,24 +14,40 @@
 //         `qual >= min_base_quality` test when listing PileupColumn.pileups
 //   iterate_splits                                /root/reference/inStrain/profile/fasta.py:56-73
 //
-// No device code here; it is linked into libinstrain_amd.so so that the whole path sits behind
-// one C ABI.  Inflate of the BGZF blocks is multi-threaded (blocks are independent).
+// Two passes over the file, like the reference (filter_reads scans the BAM, then profile piles it up), none of
+// which keeps the file's reads in memory:
+//   scan    (isx_bam_scan)        every BGZF block is inflated once, in waves of segments that bound the memory in
+//                                 flight; per read only name, flag, NM, mapq and the reference span are kept
+//                                 (~70 bytes a read, freed when the pair tables are built); per (scaffold, name) the
+//                                 pair record of get_paired_reads; per read the index of its pair (4 bytes).
+//   filter  (isx_bam_filter)      median insert over the whole file, evaluate_pair per pair -- or the controller's
+//                                 own R2M (isx_bam_set_r2m).
+//   expand  (isx_bam_expand_refs) for a SUBSET of the references (one batch, one GPU's shard): only the segments
+//                                 holding them are inflated again; overlap resolution and expansion run on that
+//                                 batch's reads alone.
+// No device code here; it is linked into libinstrain_amd.so so that the whole path sits behind one C ABI.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <thread>
-#include <chrono>
-#include <cstdio>
-#include <memory>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/instrain_amd.h"
+#include "obs_encode.h"
 
 void isx_set_error(const std::string &msg);
 
@@ -44,13 +60,12 @@ constexpr uint16_t DEF_MASK = FUNMAP | FSECONDARY | FQCFAIL | FDUP;
 // 4-bit BAM code -> inStrain base index (A,C,T,G = 0..3; everything else 4)
 const uint8_t CODE2IDX[16] = {4, 0, 1, 4, 3, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4};
 
-struct Read {
-    int32_t tid, pos, isize, l_seq, nm;
+struct Read {           // a read of the batch being expanded
+    int32_t tid, pos, isize, l_seq;
     uint16_t flag, n_cigar;
-    uint8_t mapq;
-    bool has_nm;
-    uint32_t name_off, name_len;
-    uint64_t cigar_off, seq_off, qual_off;
+    uint32_t pair_idx;          // index into isx_bam::pairs, 0xFFFFFFFF = not in any table
+    uint64_t cigar_off, seq_off;
+    int64_t ref_end;            // reference position after the last CIGAR op (bam_endpos)
 };
 
 struct Cursor {     // htslib sam.c cigar_iref2iseq_* state
@@ -102,11 +117,147 @@ int cur_next(Cursor &c)
     return -1;
 }
 
-struct PairInfo {       // filter_reads.py i2o order
+struct PairInfo {       // filter_reads.py i2o order (+ what the filter decided)
     int64_t nm, insert, mapq, length, reads, start, stop;
-    bool pass;
-    uint32_t pair_id;
+    uint32_t name_seg, name_off;    // where the name lives (segment blob) -- valid until the scan data is dropped
+    uint16_t name_len;
+    bool pass, in_filter;           // in_filter: survived paired_read_filter (evaluated at all)
+    uint8_t pad;
+    int32_t mm;                     // R2M value when pass (nm, or the controller's)
 };
+
+// what the scan keeps of a read until the pair tables are built
+struct ReadLite {
+    int32_t tid, pos, isize, l_seq, nm, qlen;
+    int64_t first, last;            // first / last aligned reference position
+    uint64_t h64;                   // hash of the name
+    uint32_t name_off;
+    uint16_t name_len, flag;
+    uint8_t mapq, has_nm, any, pad;
+};
+
+struct Block { uint64_t coff; uint32_t csize, hdr, isize; uint64_t ioff; };
+
+struct Segment {
+    uint32_t b0 = 0, b1 = 0;        // blocks [b0, b1)
+    uint64_t ioff0 = 0, ioff1 = 0;  // inflated byte range
+    uint64_t first_rec = 0;         // inflated offset of the first record that STARTS in the segment (== ioff1: none)
+    uint64_t read0 = 0;             // ordinal of that record
+    uint32_t n_reads = 0;
+};
+
+// ---- inflate: libdeflate when the image has it (2-3x zlib), zlib otherwise ----
+struct Deflate {
+    void *lib = nullptr;
+    void *(*alloc)() = nullptr;
+    int (*decomp)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    Deflate()
+    {
+        for (const char *n : {"libdeflate.so.0", "libdeflate.so"}) {
+            lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return;
+        alloc = reinterpret_cast<void *(*)()>(dlsym(lib, "libdeflate_alloc_decompressor"));
+        decomp = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *)>(dlsym(lib, "libdeflate_deflate_decompress"));
+        release = reinterpret_cast<void (*)(void *)>(dlsym(lib, "libdeflate_free_decompressor"));
+        if (!alloc || !decomp || !release) { alloc = nullptr; decomp = nullptr; release = nullptr; }
+    }
+};
+const Deflate &deflate_lib() { static Deflate d; return d; }
+
+struct Inflater {       // one per thread
+    void *ld = nullptr;
+    Inflater() { if (deflate_lib().alloc) ld = deflate_lib().alloc(); }
+    ~Inflater() { if (ld) deflate_lib().release(ld); }
+    bool run(const uint8_t *src, size_t n_src, uint8_t *dst, size_t n_dst)
+    {
+        if (!n_dst) return true;
+        if (ld) {
+            size_t got = 0;
+            return deflate_lib().decomp(ld, src, n_src, dst, n_dst, &got) == 0 && got == n_dst;
+        }
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = (uInt)n_src;
+        zs.next_out = dst; zs.avail_out = (uInt)n_dst;
+        const int rc = inflate(&zs, Z_FINISH);
+        const bool ok = (rc == Z_STREAM_END) && zs.total_out == n_dst;
+        inflateEnd(&zs);
+        return ok;
+    }
+};
+
+inline int32_t rd32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+// aux fields of a record: the NM tag; every read is checked against `end`
+int parse_nm(const uint8_t *p, const uint8_t *end, bool &has, int32_t &nm)
+{
+    has = false;
+    while (p + 3 <= end) {
+        const bool is_nm = (p[0] == 'N' && p[1] == 'M');
+        const char t = (char)p[2];
+        p += 3;
+        int64_t v = 0;
+        bool num = true;
+        size_t need = 0;
+        switch (t) {
+        case 'A': case 'c': case 'C': need = 1; break;
+        case 's': case 'S': need = 2; break;
+        case 'i': case 'I': case 'f': need = 4; break;
+        case 'Z': case 'H': case 'B': break;
+        default: return -1;
+        }
+        if ((size_t)(end - p) < need) return -1;
+        switch (t) {
+        case 'A': v = *p; p += 1; num = false; break;
+        case 'c': v = (int8_t)*p; p += 1; break;
+        case 'C': v = *p; p += 1; break;
+        case 's': { int16_t x; memcpy(&x, p, 2); v = x; p += 2; break; }
+        case 'S': { uint16_t x; memcpy(&x, p, 2); v = x; p += 2; break; }
+        case 'i': { int32_t x; memcpy(&x, p, 4); v = x; p += 4; break; }
+        case 'I': { uint32_t x; memcpy(&x, p, 4); v = x; p += 4; break; }
+        case 'f': p += 4; num = false; break;
+        case 'Z': case 'H':
+            while (p < end && *p) p++;
+            if (p >= end) return -1;
+            p++; num = false; break;
+        case 'B': {
+            if (end - p < 5) return -1;
+            const char sub = (char)p[0];
+            const int32_t cnt = rd32(p + 1);
+            int sz;
+            switch (sub) {
+            case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            default: return -1;
+            }
+            if (cnt < 0 || (uint64_t)cnt * sz > (uint64_t)(end - p - 5)) return -1;
+            p += 5 + (size_t)cnt * sz;
+            num = false;
+            break;
+        }
+        }
+        if (is_nm && num) { has = true; nm = (int32_t)v; }
+    }
+    return p == end ? 0 : -1;
+}
+
+uint64_t hash_name(const uint8_t *s, size_t n)
+{
+    uint64_t h = 0xcbf29ce484222325ull ^ (n * 0x9E3779B97F4A7C15ull);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, s + i, 8); h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; }
+    uint64_t w = 0;
+    memcpy(&w, s + i, n - i);
+    h = (h ^ w) * 0x100000001b3ull;
+    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+    return h;
+}
 
 }  // namespace
 
@@ -118,225 +269,291 @@ struct RawBuf {                 // sized once, written once: no value initialisa
     T *data() { return p.get(); }
     const T *data() const { return p.get(); }
     const T &operator[](size_t i) const { return p[i]; }
+    T &operator[](size_t i) { return p[i]; }
     size_t size() const { return n; }
 };
 
 struct isx_bam {
+    int fd = -1;
+    const uint8_t *map = nullptr;
+    size_t map_len = 0;
+    std::vector<Block> blocks;
+    std::vector<Segment> segs;
+    uint64_t total_inflated = 0, first_rec = 0;
     std::vector<std::string> ref_name;
     std::vector<int64_t> ref_len, ref_off;
-    std::vector<Read> reads;
-    RawBuf<char> names;
-    RawBuf<uint32_t> cigars;
-    RawBuf<uint8_t> seqs;           // one code per base (unpacked)
-    RawBuf<uint8_t> quals;          // mutated by overlap resolution
-    // results of expand (plain arrays: no zero fill of what is written once)
+    int threads = 0;
+    std::unique_ptr<isxenc::HostPool> pool;
+    // ---- scan products ----
+    bool scanned = false, filtered = false;
+    uint64_t n_reads = 0;
+    std::vector<uint32_t> read_pair;                // per read ordinal
+    std::vector<PairInfo> pairs;
+    std::vector<PairInfo> pairs_scan;               // what the scan found, kept once all_reads has rewritten entries (_merge_info)
+    std::vector<uint64_t> ref_pair0;                // [n_ref + 1] pairs of a reference are contiguous
+    std::vector<uint32_t> ref_seg0, ref_seg1;       // segments holding records of the reference: [seg0, seg1]
+    std::vector<std::vector<char>> seg_names;       // name blobs, dropped after the filter (or kept for set_r2m)
+    std::vector<std::vector<ReadLite>> seg_reads;   // dropped after the pair tables are built
+    std::vector<uint8_t> priority;                  // per pair: its name is a priority read
+    std::vector<std::string> priority_names;
+    isx_bam_info totals{};
+    std::vector<int64_t> ref_filtered_pairs, ref_reads;
+    // ---- results of the last expand ----
     std::unique_ptr<isx_obs[]> obs;
     std::unique_ptr<uint32_t[]> pair;
     size_t n_obs = 0;
     std::vector<int64_t> split_bounds;
     std::vector<int32_t> split_ref;
     bool expanded = false;
+
+    ~isx_bam()
+    {
+        if (map) munmap(const_cast<uint8_t *>(map), map_len);
+        if (fd >= 0) close(fd);
+    }
 };
 
 namespace {
 
-bool inflate_block(const uint8_t *src, size_t n_src, uint8_t *dst, size_t n_dst)
+int n_threads_default()
 {
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, -15) != Z_OK) return false;
-    zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = (uInt)n_src;
-    zs.next_out = dst; zs.avail_out = (uInt)n_dst;
-    const int rc = inflate(&zs, Z_FINISH);
-    const bool ok = (rc == Z_STREAM_END) && zs.total_out == n_dst;
-    inflateEnd(&zs);
-    return ok;
+    int n = (int)std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {           // a container's cpu quota, when there is one
+        char q[64] = {0};
+        long period = 0;
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) n = std::min<int>(n, (int)std::max<long>(1, 2 * atol(q) / period));
+        fclose(f);
+    }
+    return std::max(1, std::min(n, 64));
 }
 
-int load_file(const char *path, RawBuf<uint8_t> &out)
+isxenc::HostPool &pool_of(isx_bam &B)
 {
-    FILE *f = fopen(path, "rb");
-    if (!f) { isx_set_error(std::string("cannot open ") + path); return ISX_ERR_IO; }
-    fseek(f, 0, SEEK_END);
-    const long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    RawBuf<uint8_t> raw;
-    raw.resize((size_t)n);
-    if (n && fread(raw.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); isx_set_error("short read"); return ISX_ERR_IO; }
-    fclose(f);
-    // index the BGZF blocks
-    struct Blk { size_t src, n_src, dst, n_dst; };
-    std::vector<Blk> blks;
-    size_t off = 0, total = 0;
-    while (off + 18 <= raw.size()) {
-        const uint8_t *h = raw.data() + off;
+    if (!B.pool) B.pool.reset(new isxenc::HostPool(B.threads > 0 ? B.threads : n_threads_default(), -1, false));
+    return *B.pool;
+}
+
+// inflate blocks [b0, b1) into dst (dst[0] = inflated offset blocks[b0].ioff); false on a corrupt block
+bool inflate_range(const isx_bam &B, Inflater &inf, uint32_t b0, uint32_t b1, uint8_t *dst)
+{
+    const uint64_t base = B.blocks[b0].ioff;
+    for (uint32_t b = b0; b < b1; b++) {
+        const Block &k = B.blocks[b];
+        if (!inf.run(B.map + k.coff + k.hdr, k.csize - k.hdr - 8, dst + (k.ioff - base), k.isize)) return false;
+    }
+    return true;
+}
+
+// A segment's inflated bytes plus as much of the following blocks as its last record needs.
+struct SegBuf {
+    std::vector<uint8_t> data;      // data[0] = inflated offset seg.ioff0
+    uint32_t b_end = 0;             // blocks inflated so far: [seg.b0, b_end)
+};
+
+bool seg_inflate(const isx_bam &B, Inflater &inf, const Segment &s, SegBuf &out)
+{
+    out.data.resize((size_t)(s.ioff1 - s.ioff0));
+    out.b_end = s.b1;
+    return inflate_range(B, inf, s.b0, s.b1, out.data.data());
+}
+
+// make sure [off, off + n) of the segment's inflated stream is there (a record may run into the next blocks)
+bool seg_need(const isx_bam &B, Inflater &inf, const Segment &s, SegBuf &buf, uint64_t off, uint64_t n)
+{
+    while (off + n > s.ioff0 + buf.data.size()) {
+        if (buf.b_end >= B.blocks.size()) return false;
+        const Block &k = B.blocks[buf.b_end];
+        const size_t old = buf.data.size();
+        buf.data.resize(old + k.isize);
+        if (!inf.run(B.map + k.coff + k.hdr, k.csize - k.hdr - 8, buf.data.data() + old, k.isize)) return false;
+        buf.b_end++;
+    }
+    return true;
+}
+
+// record starts of a segment: walks the block_size fields from `first`; returns the offset after the last
+// record that starts before s.ioff1 (= first record of the next segment).  rec_off gets inflated offsets.
+int seg_hop(const isx_bam &B, Inflater &inf, const Segment &s, SegBuf &buf, uint64_t first, std::vector<uint64_t> &rec_off,
+            uint64_t &next_first)
+{
+    uint64_t off = first;
+    rec_off.clear();
+    while (off < s.ioff1) {
+        if (off + 4 > B.total_inflated) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
+        if (!seg_need(B, inf, s, buf, off, 4)) { isx_set_error("BGZF inflate failed"); return ISX_ERR_IO; }
+        const int32_t block = rd32(buf.data.data() + (off - s.ioff0));
+        if (block < 32 || off + 4 + (uint64_t)block > B.total_inflated) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
+        if (!seg_need(B, inf, s, buf, off, 4 + (uint64_t)block)) { isx_set_error("BGZF inflate failed"); return ISX_ERR_IO; }
+        rec_off.push_back(off);
+        off += 4 + (uint64_t)block;
+    }
+    next_first = off;
+    return ISX_OK;
+}
+
+struct RecView {        // validated fixed part of a record
+    const uint8_t *p;   // at block_size
+    int32_t block, tid, pos, l_seq, isize;
+    uint16_t n_cigar, flag;
+    uint8_t l_name, mapq;
+    const uint8_t *name, *cigar, *seq, *qual, *aux, *end;
+};
+
+bool rec_view(const uint8_t *p, RecView &r)
+{
+    r.p = p;
+    r.block = rd32(p);
+    r.tid = rd32(p + 4); r.pos = rd32(p + 8);
+    r.l_name = p[12]; r.mapq = p[13];
+    r.n_cigar = rd16(p + 16); r.flag = rd16(p + 18);
+    r.l_seq = rd32(p + 20);
+    r.isize = rd32(p + 32);
+    if (r.l_seq < 0 || r.l_name == 0) return false;
+    const uint64_t need = 32 + (uint64_t)r.l_name + (uint64_t)r.n_cigar * 4 + ((uint64_t)r.l_seq + 1) / 2 + (uint64_t)r.l_seq;
+    if (need > (uint64_t)r.block) return false;
+    r.name = p + 36;
+    r.cigar = r.name + r.l_name;
+    r.seq = r.cigar + (size_t)r.n_cigar * 4;
+    r.qual = r.seq + ((size_t)r.l_seq + 1) / 2;
+    r.aux = r.qual + r.l_seq;
+    r.end = p + 4 + r.block;
+    return true;
+}
+
+struct RefSpan { int64_t first, last, end; int64_t qlen; bool any; };
+
+RefSpan span_of(const uint8_t *cigar, int n_cigar, int32_t pos)
+{
+    RefSpan s{0, 0, pos, 0, false};
+    int64_t ref = pos;
+    for (int k = 0; k < n_cigar; k++) {
+        uint32_t c;
+        memcpy(&c, cigar + 4 * (size_t)k, 4);
+        const int op = c & 15;
+        const int64_t n = c >> 4;
+        if (op == CM || op == CEQ || op == CX) {
+            if (n > 0) {
+                if (!s.any) { s.first = ref; s.any = true; }
+                s.last = ref + n - 1;
+            }
+            ref += n;
+        } else if (op == CD || op == CN) ref += n;
+        if (op == CM || op == CI || op == CS || op == CEQ || op == CX) s.qlen += n;
+    }
+    s.end = ref;
+    return s;
+}
+
+// a record whose real CIGAR sits in the CG tag (> 65535 operations) is not supported: say so instead of piling
+// up the placeholder
+bool is_long_cigar_placeholder(const RecView &r)
+{
+    if (r.n_cigar != 2) return false;
+    uint32_t c0, c1;
+    memcpy(&c0, r.cigar, 4); memcpy(&c1, r.cigar + 4, 4);
+    return (c0 & 15) == CS && (int32_t)(c0 >> 4) == r.l_seq && (c1 & 15) == CN;
+}
+
+int open_file(const char *path, isx_bam &B)
+{
+    B.fd = open(path, O_RDONLY);
+    if (B.fd < 0) { isx_set_error(std::string("cannot open ") + path); return ISX_ERR_IO; }
+    struct stat st;
+    if (fstat(B.fd, &st) != 0) { isx_set_error("fstat failed"); return ISX_ERR_IO; }
+    B.map_len = (size_t)st.st_size;
+    if (B.map_len < 28) { isx_set_error("not a BGZF file"); return ISX_ERR_IO; }
+    void *m = mmap(nullptr, B.map_len, PROT_READ, MAP_PRIVATE, B.fd, 0);
+    if (m == MAP_FAILED) { isx_set_error("mmap failed"); return ISX_ERR_IO; }
+    B.map = static_cast<const uint8_t *>(m);
+    (void)madvise(m, B.map_len, MADV_SEQUENTIAL);
+    // ---- index of the BGZF blocks (headers only, nothing is inflated) ----
+    size_t off = 0;
+    uint64_t total = 0;
+    while (off < B.map_len) {
+        if (off + 18 > B.map_len) { isx_set_error("corrupt BGZF block"); return ISX_ERR_IO; }
+        const uint8_t *h = B.map + off;
         if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { isx_set_error("not a BGZF file"); return ISX_ERR_IO; }
         const size_t xlen = h[10] | (h[11] << 8);
+        if (off + 12 + xlen > B.map_len) { isx_set_error("corrupt BGZF block"); return ISX_ERR_IO; }
         size_t bsize = 0;
         for (size_t x = 12; x + 4 <= 12 + xlen;) {
             const size_t slen = h[x + 2] | (h[x + 3] << 8);
-            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
+            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
             x += 4 + slen;
         }
-        if (!bsize || off + bsize > raw.size()) { isx_set_error("corrupt BGZF block"); return ISX_ERR_IO; }
+        if (bsize < 12 + xlen + 8 || off + bsize > B.map_len) { isx_set_error("corrupt BGZF block"); return ISX_ERR_IO; }
         const uint8_t *t = h + bsize - 4;
-        const size_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((size_t)t[3] << 24);
-        blks.push_back({off + 12 + xlen, bsize - 12 - xlen - 8, total, isize});
+        const uint32_t isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (isize > 65536) { isx_set_error("corrupt BGZF block"); return ISX_ERR_IO; }
+        B.blocks.push_back(Block{off, (uint32_t)bsize, (uint32_t)(12 + xlen), isize, total});
         total += isize;
         off += bsize;
     }
-    out.resize(total);
-    const unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-    std::vector<std::thread> th;
-    std::vector<int> ok(nt, 1);
-    for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([&, t]() {
-            for (size_t i = t; i < blks.size(); i += nt)
-                if (blks[i].n_dst && !inflate_block(raw.data() + blks[i].src, blks[i].n_src, out.data() + blks[i].dst, blks[i].n_dst))
-                    ok[t] = 0;
-        });
-    for (auto &x : th) x.join();
-    for (int v : ok) if (!v) { isx_set_error("BGZF inflate failed"); return ISX_ERR_IO; }
-    return ISX_OK;
-}
-
-inline int32_t rd32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
-
-int parse_nm(const uint8_t *p, const uint8_t *end, bool &has, int32_t &nm)
-{
-    has = false;
-    while (p + 3 <= end) {
-        const bool is_nm = (p[0] == 'N' && p[1] == 'M');
-        const char t = (char)p[2];
-        p += 3;
-        int64_t v = 0;
-        bool num = true;
-        switch (t) {
-        case 'A': v = *p; p += 1; num = false; break;
-        case 'c': v = (int8_t)*p; p += 1; break;
-        case 'C': v = *p; p += 1; break;
-        case 's': { int16_t x; memcpy(&x, p, 2); v = x; p += 2; break; }
-        case 'S': { uint16_t x; memcpy(&x, p, 2); v = x; p += 2; break; }
-        case 'i': { int32_t x; memcpy(&x, p, 4); v = x; p += 4; break; }
-        case 'I': { uint32_t x; memcpy(&x, p, 4); v = x; p += 4; break; }
-        case 'f': p += 4; num = false; break;
-        case 'Z': case 'H': while (p < end && *p) p++; p++; num = false; break;
-        case 'B': {
-            const char sub = (char)p[0];
-            const int32_t cnt = rd32(p + 1);
-            const int sz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-            p += 5 + (size_t)cnt * sz;
-            num = false;
-            break;
+    B.total_inflated = total;
+    // ---- header: magic, text, references (inflate block by block until it is complete) ----
+    Inflater inf;
+    std::vector<uint8_t> head;
+    uint32_t nb = 0;
+    auto more = [&](size_t need) -> bool {
+        while (head.size() < need) {
+            if (nb >= B.blocks.size()) return false;
+            const Block &k = B.blocks[nb++];
+            const size_t old = head.size();
+            head.resize(old + k.isize);
+            if (!inf.run(B.map + k.coff + k.hdr, k.csize - k.hdr - 8, head.data() + old, k.isize)) return false;
         }
-        default: return -1;
-        }
-        if (is_nm && num) { has = true; nm = (int32_t)v; }
-    }
-    return 0;
-}
-
-int parse_bam(const RawBuf<uint8_t> &buf, isx_bam &B)
-{
-    if (buf.size() < 12 || memcmp(buf.data(), "BAM\1", 4) != 0) { isx_set_error("not a BAM file"); return ISX_ERR_IO; }
-    size_t off = 8 + (size_t)rd32(buf.data() + 4);
-    const int32_t n_ref = rd32(buf.data() + off);
-    off += 4;
+        return true;
+    };
+    if (!more(12) || memcmp(head.data(), "BAM\1", 4) != 0) { isx_set_error("not a BAM file"); return ISX_ERR_IO; }
+    const int32_t l_text = rd32(head.data() + 4);
+    if (l_text < 0 || !more(12 + (size_t)l_text)) { isx_set_error("truncated BAM header"); return ISX_ERR_IO; }
+    size_t o = 8 + (size_t)l_text;
+    const int32_t n_ref = rd32(head.data() + o);
+    o += 4;
+    if (n_ref < 0) { isx_set_error("corrupt BAM header"); return ISX_ERR_IO; }
     int64_t flat = 0;
     for (int i = 0; i < n_ref; i++) {
-        const int32_t l_name = rd32(buf.data() + off);
-        B.ref_name.emplace_back(reinterpret_cast<const char *>(buf.data() + off + 4), (size_t)l_name - 1);
-        const int32_t l_ref = rd32(buf.data() + off + 4 + l_name);
+        if (!more(o + 4)) { isx_set_error("truncated BAM header"); return ISX_ERR_IO; }
+        const int32_t l_name = rd32(head.data() + o);
+        if (l_name <= 0 || !more(o + 8 + (size_t)l_name)) { isx_set_error("truncated BAM header"); return ISX_ERR_IO; }
+        B.ref_name.emplace_back(reinterpret_cast<const char *>(head.data() + o + 4), (size_t)l_name - 1);
+        const int32_t l_ref = rd32(head.data() + o + 4 + l_name);
+        if (l_ref < 0) { isx_set_error("corrupt BAM header"); return ISX_ERR_IO; }
         B.ref_len.push_back(l_ref);
         B.ref_off.push_back(flat);
         flat += l_ref;
-        off += 8 + (size_t)l_name;
+        o += 8 + (size_t)l_name;
     }
-    // pass 1 (sequential, one walk, a few words per record): record boundaries and where each record's
-    // name / CIGAR / bases go in the side arrays
-    const bool ptiming = getenv("ISX_BAM_TIMING") != nullptr;
-    const auto pt0 = std::chrono::steady_clock::now();
-    std::vector<size_t> rec_off, name_at, cig_at, seq_at;
-    {
-        const size_t guess = (buf.size() - off) / 160 + 16;        // a 2 x 150 bp record is ~ 240 bytes
-        rec_off.reserve(guess); name_at.reserve(guess); cig_at.reserve(guess); seq_at.reserve(guess);
-    }
-    size_t n_names = 0, n_cig = 0, n_seq = 0;
-    while (off + 36 <= buf.size()) {
-        const uint8_t *p = buf.data() + off;
-        const int32_t block = rd32(p);
-        if (block < 32 || off + 4 + (size_t)block > buf.size()) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
-        uint16_t ncig;
-        memcpy(&ncig, p + 16, 2);
-        const int32_t l_seq = rd32(p + 20);
-        const size_t need = 32 + (size_t)p[12] + (size_t)ncig * 4 + ((size_t)std::max(l_seq, 0) + 1) / 2 + (size_t)std::max(l_seq, 0);
-        if (l_seq < 0 || p[12] == 0 || need > (size_t)block) { isx_set_error("corrupt BAM record"); return ISX_ERR_IO; }
-        rec_off.push_back(off); name_at.push_back(n_names); cig_at.push_back(n_cig); seq_at.push_back(n_seq);
-        n_names += (size_t)p[12] - 1; n_cig += ncig; n_seq += (size_t)l_seq;
-        off += 4 + (size_t)block;
-    }
-    const size_t n = rec_off.size();
-    B.reads.resize(n);
-    const auto pt1 = std::chrono::steady_clock::now();
-    B.names.resize(n_names); B.cigars.resize(n_cig); B.seqs.resize(n_seq); B.quals.resize(n_seq);
-    const auto pt2 = std::chrono::steady_clock::now();
-    // pass 2 (threads over record ranges): field extraction, nibble unpack, aux walk for NM
-    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(64u, std::max(1u, std::thread::hardware_concurrency())), n / 4096 + 1));
-    std::vector<int> bad(nt, 0);
-    auto work = [&](unsigned t) {
-        const size_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
-        for (size_t i = i0; i < i1; i++) {
-            const uint8_t *p = buf.data() + rec_off[i];
-            const int32_t block = rd32(p);
-            Read r{};
-            r.tid = rd32(p + 4); r.pos = rd32(p + 8);
-            const uint8_t l_name = p[12];
-            r.mapq = p[13];
-            uint16_t ncig, flag;
-            memcpy(&ncig, p + 16, 2); memcpy(&flag, p + 18, 2);
-            r.n_cigar = ncig; r.flag = flag;
-            r.l_seq = rd32(p + 20);
-            r.isize = rd32(p + 32);
-            const uint8_t *q = p + 36;
-            r.name_off = (uint32_t)name_at[i]; r.name_len = (uint32_t)l_name - 1;
-            memcpy(B.names.data() + name_at[i], q, (size_t)l_name - 1);
-            q += l_name;
-            r.cigar_off = cig_at[i];
-            memcpy(B.cigars.data() + cig_at[i], q, (size_t)ncig * 4);
-            q += (size_t)ncig * 4;
-            r.seq_off = seq_at[i];
-            uint8_t *sq = B.seqs.data() + seq_at[i];
-            for (int32_t k = 0; k < r.l_seq; k++) {
-                const uint8_t byte = q[k >> 1];
-                sq[k] = (k & 1) ? (byte & 15) : (byte >> 4);
-            }
-            q += ((size_t)r.l_seq + 1) / 2;
-            r.qual_off = seq_at[i];
-            memcpy(B.quals.data() + seq_at[i], q, (size_t)r.l_seq);
-            q += r.l_seq;
-            if (parse_nm(q, p + 4 + block, r.has_nm, r.nm) != 0) bad[t] = 1;
-            B.reads[i] = r;
+    B.first_rec = o;
+    // ---- segments: runs of blocks of ~32 MiB inflated ----
+    const uint64_t SEG = (uint64_t)32 << 20;
+    Segment cur;
+    cur.b0 = 0; cur.ioff0 = 0;
+    for (uint32_t b = 0; b < B.blocks.size(); b++) {
+        const uint64_t end = B.blocks[b].ioff + B.blocks[b].isize;
+        if (end - cur.ioff0 >= SEG || b + 1 == B.blocks.size()) {
+            cur.b1 = b + 1; cur.ioff1 = end;
+            if (cur.ioff1 > cur.ioff0 || B.segs.empty()) B.segs.push_back(cur);
+            cur = Segment();
+            cur.b0 = b + 1; cur.ioff0 = end;
         }
-    };
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
     }
-    if (ptiming) fprintf(stderr, "[parse_bam] sizes %.1f ms, alloc %.1f ms, fill %.1f ms (%u threads)\n", std::chrono::duration<double, std::milli>(pt1 - pt0).count(), std::chrono::duration<double, std::milli>(pt2 - pt1).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pt2).count(), nt);
-    for (int v : bad) if (v) { isx_set_error("bad aux field"); return ISX_ERR_IO; }
-    if (n_names >= 0xFFFFFFFFull) { isx_set_error("read names exceed 4 GiB"); return ISX_ERR_IO; }
     return ISX_OK;
 }
 
-// htslib sam.c tweak_overlap_quality
-void tweak_overlap(isx_bam &B, const Read &a, const Read &b)
+// htslib sam.c tweak_overlap_quality on two reads of the batch
+struct Batch {
+    std::vector<Read> reads;
+    RawBuf<uint32_t> cigars;
+    RawBuf<uint8_t> seqs, quals;
+};
+
+void tweak_overlap(Batch &S, const Read &a, const Read &b)
 {
-    Cursor ca{B.cigars.data() + a.cigar_off, a.n_cigar, 0, 0, 0, 0};
-    Cursor cb{B.cigars.data() + b.cigar_off, b.n_cigar, 0, 0, 0, 0};
-    uint8_t *aq = B.quals.data() + a.qual_off, *bq = B.quals.data() + b.qual_off;
-    const uint8_t *as = B.seqs.data() + a.seq_off, *bs = B.seqs.data() + b.seq_off;
+    Cursor ca{S.cigars.data() + a.cigar_off, a.n_cigar, 0, 0, 0, 0};
+    Cursor cb{S.cigars.data() + b.cigar_off, b.n_cigar, 0, 0, 0, 0};
+    uint8_t *aq = S.quals.data() + a.seq_off, *bq = S.quals.data() + b.seq_off;
+    const uint8_t *as = S.seqs.data() + a.seq_off, *bs = S.seqs.data() + b.seq_off;
     int iref = b.pos;
     int a_ret = cur_set(ca, iref - a.pos);
     if (a_ret < 0) return;
@@ -366,28 +583,54 @@ void tweak_overlap(isx_bam &B, const Read &a, const Read &b)
     }
 }
 
-struct RefSpan { int64_t first, last, end; int64_t qlen; bool any; };
-
-RefSpan span_of(const isx_bam &B, const Read &r)
+// ---- scan: one segment's records -> ReadLite + names ----
+int scan_segment(isx_bam &B, uint32_t si, const SegBuf &buf, const std::vector<uint64_t> &rec_off, std::string &err)
 {
-    RefSpan s{0, 0, r.pos, 0, false};
-    int64_t ref = r.pos;
-    for (int k = 0; k < r.n_cigar; k++) {
-        const uint32_t c = B.cigars[r.cigar_off + k];
-        const int op = c & 15;
-        const int64_t n = c >> 4;
-        if (op == CM || op == CEQ || op == CX) {
-            if (n > 0) {
-                if (!s.any) { s.first = ref; s.any = true; }
-                s.last = ref + n - 1;
-            }
-            ref += n;
-        } else if (op == CD || op == CN) ref += n;
-        if (op == CM || op == CI || op == CS || op == CEQ || op == CX) s.qlen += n;
+    const Segment &s = B.segs[si];
+    std::vector<ReadLite> &out = B.seg_reads[si];
+    std::vector<char> &names = B.seg_names[si];
+    out.resize(rec_off.size());
+    size_t name_bytes = 0;
+    const int n_ref = (int)B.ref_name.size();
+    for (size_t i = 0; i < rec_off.size(); i++) name_bytes += buf.data[(size_t)(rec_off[i] - s.ioff0) + 12];
+    names.resize(name_bytes);
+    size_t at = 0;
+    for (size_t i = 0; i < rec_off.size(); i++) {
+        RecView r;
+        if (!rec_view(buf.data.data() + (rec_off[i] - s.ioff0), r)) { err = "corrupt BAM record"; return ISX_ERR_IO; }
+        if (r.tid >= n_ref) { err = "corrupt BAM record (reference id)"; return ISX_ERR_IO; }
+        ReadLite L{};
+        L.tid = r.tid; L.pos = r.pos; L.isize = r.isize; L.l_seq = r.l_seq; L.flag = r.flag; L.mapq = r.mapq;
+        L.name_off = (uint32_t)at; L.name_len = (uint16_t)(r.l_name - 1);
+        memcpy(names.data() + at, r.name, (size_t)r.l_name - 1);
+        at += (size_t)r.l_name - 1;
+        L.h64 = hash_name(r.name, (size_t)r.l_name - 1);
+        bool has = false;
+        int32_t nm = 0;
+        if (parse_nm(r.aux, r.end, has, nm) != 0) { err = "bad aux field"; return ISX_ERR_IO; }
+        L.has_nm = has; L.nm = nm;
+        if (r.tid >= 0 && is_long_cigar_placeholder(r)) { err = "record with its CIGAR in the CG tag (> 65535 operations) is not supported"; return ISX_ERR_IO; }
+        const RefSpan sp = span_of(r.cigar, r.n_cigar, r.pos);
+        L.first = sp.first; L.last = sp.last; L.qlen = (int32_t)sp.qlen; L.any = sp.any;
+        out[i] = L;
     }
-    s.end = ref;
-    return s;
+    names.resize(at);
+    return ISX_OK;
 }
+
+// open-addressing (hash of name) -> local pair index
+struct NameTable {
+    std::vector<uint64_t> key;
+    std::vector<uint32_t> val;
+    uint64_t mask = 0;
+    void init(size_t n)
+    {
+        size_t cap = 16;
+        while (cap < 2 * n + 8) cap <<= 1;
+        key.assign(cap, 0); val.assign(cap, 0xFFFFFFFFu);
+        mask = cap - 1;
+    }
+};
 
 }  // namespace
 
@@ -397,23 +640,22 @@ int isx_bam_open(const char *path, isx_bam **out)
 {
     if (!path || !out) { isx_set_error("isx_bam_open: bad argument"); return ISX_ERR_ARG; }
     *out = nullptr;
-    RawBuf<uint8_t> buf;
-    const bool timing = getenv("ISX_BAM_TIMING") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    int rc = load_file(path, buf);
+    std::unique_ptr<isx_bam> B(new isx_bam());
+    const int rc = open_file(path, *B);
     if (rc != ISX_OK) return rc;
-    const auto t1 = std::chrono::steady_clock::now();
-    isx_bam *B = new isx_bam();
-    rc = parse_bam(buf, *B);
-    if (timing) fprintf(stderr, "[isx_bam_open] read + inflate %.1f ms, record extraction %.1f ms\n",
-                        std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
-    if (rc != ISX_OK) { delete B; return rc; }
-    *out = B;
+    *out = B.release();
     return ISX_OK;
 }
 
 void isx_bam_close(isx_bam *bam) { delete bam; }
+
+int isx_bam_set_threads(isx_bam *bam, int32_t threads)
+{
+    if (!bam || threads < 0) { isx_set_error("isx_bam_set_threads: bad argument"); return ISX_ERR_ARG; }
+    bam->threads = threads;
+    bam->pool.reset();
+    return ISX_OK;
+}
 
 int isx_bam_ref(const isx_bam *bam, int32_t i, const char **name, int64_t *length, int64_t *flat_offset)
 {
@@ -424,196 +666,532 @@ int isx_bam_ref(const isx_bam *bam, int32_t i, const char **name, int64_t *lengt
     return ISX_OK;
 }
 
-int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
+int isx_bam_set_priority_reads(isx_bam *bam, int64_t n, const char *names, const int64_t *offs)
 {
-    if (!bam || !p || !info) { isx_set_error("isx_bam_expand: bad argument"); return ISX_ERR_ARG; }
-    if (bam->expanded) { isx_set_error("isx_bam_expand: already expanded (qualities were rewritten)"); return ISX_ERR_STATE; }
+    if (!bam || n < 0 || (n && (!names || !offs))) { isx_set_error("isx_bam_set_priority_reads: bad argument"); return ISX_ERR_ARG; }
+    bam->priority_names.clear();
+    for (int64_t i = 0; i < n; i++) bam->priority_names.emplace_back(names + offs[i], (size_t)(offs[i + 1] - offs[i]));
+    return ISX_OK;
+}
+
+// ---- pass 1: get_paired_reads for every reference (filter_reads.py:885-956) ----
+int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
+{
+    if (!bam) { isx_set_error("isx_bam_scan: bad argument"); return ISX_ERR_ARG; }
     isx_bam &B = *bam;
-    memset(info, 0, sizeof(*info));
+    if (B.scanned) { if (info) *info = B.totals; return ISX_OK; }
+    isxenc::HostPool &pool = pool_of(B);
+    const size_t n_ref = B.ref_name.size(), n_seg = B.segs.size();
+    B.seg_reads.assign(n_seg, {}); B.seg_names.assign(n_seg, {});
+    // waves of segments: inflate (parallel) -> record boundaries (serial walk over block_size fields) -> field
+    // extraction (parallel).  At most one wave of inflated data is alive.
+    const size_t wave = (size_t)std::max(2, pool.size());
+    uint64_t first = B.first_rec, read_ord = 0;
+    std::vector<std::string> errs(n_seg);
+    for (size_t w0 = 0; w0 < n_seg; w0 += wave) {
+        const size_t w1 = std::min(n_seg, w0 + wave);
+        std::vector<SegBuf> bufs(w1 - w0);
+        std::vector<std::vector<uint64_t>> recs(w1 - w0);
+        std::atomic<int> bad{0};
+        pool.run((int)(w1 - w0), [&](int i) {
+            Inflater inf;
+            if (!seg_inflate(B, inf, B.segs[w0 + (size_t)i], bufs[(size_t)i])) bad.store(1);
+        });
+        if (bad.load()) { isx_set_error("BGZF inflate failed"); return ISX_ERR_IO; }
+        Inflater inf;
+        for (size_t si = w0; si < w1; si++) {
+            Segment &s = B.segs[si];
+            s.first_rec = std::max(first, s.ioff0);
+            if (first > s.ioff1) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; continue; }    // a record spans the whole segment
+            uint64_t next = first;
+            const int rc = seg_hop(B, inf, s, bufs[si - w0], s.first_rec, recs[si - w0], next);
+            if (rc != ISX_OK) return rc;
+            s.read0 = read_ord; s.n_reads = (uint32_t)recs[si - w0].size();
+            read_ord += s.n_reads;
+            first = next;
+        }
+        std::atomic<int> rc_any{0};
+        pool.run((int)(w1 - w0), [&](int i) {
+            const int rc = scan_segment(B, (uint32_t)(w0 + (size_t)i), bufs[(size_t)i], recs[(size_t)i], errs[w0 + (size_t)i]);
+            if (rc != ISX_OK) rc_any.store(rc);
+        });
+        if (rc_any.load()) { for (auto &e : errs) if (!e.empty()) { isx_set_error(e); break; } return rc_any.load(); }
+    }
+    if (first != B.total_inflated) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
+    B.n_reads = read_ord;
+
+    // ---- reference -> the run of reads that belongs to it (the file is sorted: a reference's reads are contiguous) ----
+    struct Run { uint32_t seg; uint32_t i0, i1; };
+    std::vector<std::vector<Run>> runs(n_ref);
+    B.ref_seg0.assign(n_ref, 0xFFFFFFFFu); B.ref_seg1.assign(n_ref, 0);
+    B.ref_reads.assign(n_ref, 0);
+    {
+        int32_t last_tid = -2;
+        bool unsorted = false;
+        std::vector<uint8_t> closed(n_ref, 0);
+        for (uint32_t si = 0; si < n_seg; si++) {
+            const auto &rs = B.seg_reads[si];
+            size_t i = 0;
+            while (i < rs.size()) {
+                const int32_t t = rs[i].tid;
+                size_t j = i;
+                while (j < rs.size() && rs[j].tid == t) j++;
+                if (t >= 0) {
+                    if (t != last_tid && closed[(size_t)t]) unsorted = true;
+                    runs[(size_t)t].push_back(Run{si, (uint32_t)i, (uint32_t)j});
+                    B.ref_seg0[(size_t)t] = std::min(B.ref_seg0[(size_t)t], si);
+                    B.ref_seg1[(size_t)t] = std::max(B.ref_seg1[(size_t)t], si);
+                    B.ref_reads[(size_t)t] += (int64_t)(j - i);
+                }
+                if (last_tid >= 0 && t != last_tid) closed[(size_t)last_tid] = 1;
+                last_tid = t;
+                i = j;
+            }
+        }
+        if (unsorted) { isx_set_error("BAM is not sorted by reference: the reads of a reference must be contiguous"); return ISX_ERR_IO; }
+    }
+
+    // ---- pair tables: one task per (reference, name-hash partition) ----
+    struct Part { uint32_t ref, p, P; std::vector<PairInfo> info; std::string no_nm; };
+    std::vector<Part> parts;
+    for (size_t t = 0; t < n_ref; t++) {
+        if (!B.ref_reads[t]) continue;
+        const uint32_t P = (uint32_t)std::min<int64_t>(64, B.ref_reads[t] / 262144 + 1);
+        for (uint32_t p = 0; p < P; p++) parts.push_back(Part{(uint32_t)t, p, P, {}, {}});
+    }
+    B.read_pair.assign((size_t)B.n_reads, 0xFFFFFFFFu);
+    pool.run((int)parts.size(), [&](int pi) {
+        Part &pt = parts[(size_t)pi];
+        NameTable tab;
+        size_t mine = 0;
+        for (const Run &r : runs[pt.ref]) {
+            const auto &rs = B.seg_reads[r.seg];
+            for (uint32_t i = r.i0; i < r.i1; i++) mine += (pt.P == 1 || (rs[i].h64 >> 40) % pt.P == pt.p);
+        }
+        tab.init(mine);
+        pt.info.reserve(mine / 2 + 8);
+        for (const Run &r : runs[pt.ref]) {
+            const auto &rs = B.seg_reads[r.seg];
+            const char *names = B.seg_names[r.seg].data();
+            const uint64_t ord0 = B.segs[r.seg].read0;
+            for (uint32_t i = r.i0; i < r.i1; i++) {
+                const ReadLite &L = rs[i];
+                if (pt.P > 1 && (L.h64 >> 40) % pt.P != pt.p) continue;
+                // get_paired_reads skips unmapped reads and reads without aligned bases (get_reference_positions() == []);
+                // the latter still take part in htslib's overlap bookkeeping by name, so they get an entry that counts nothing
+                const bool counted = !(L.flag & FUNMAP) && L.any;
+                if (L.flag & FUNMAP) continue;
+                if (counted && !L.has_nm) { if (pt.no_nm.empty()) pt.no_nm.assign(names + L.name_off, L.name_len); continue; }
+                uint64_t slot = L.h64 & tab.mask;
+                const uint64_t hk = L.h64 | 1;              // 0 marks an empty slot
+                uint32_t idx = 0xFFFFFFFFu;
+                for (;;) {
+                    if (tab.key[slot] == 0) break;
+                    if (tab.key[slot] == hk) {
+                        const PairInfo &e = pt.info[tab.val[slot]];
+                        if (e.name_len == L.name_len && memcmp(B.seg_names[e.name_seg].data() + e.name_off, names + L.name_off, L.name_len) == 0) { idx = tab.val[slot]; break; }
+                    }
+                    slot = (slot + 1) & tab.mask;
+                }
+                if (idx == 0xFFFFFFFFu) {
+                    idx = (uint32_t)pt.info.size();
+                    tab.key[slot] = hk; tab.val[slot] = idx;
+                    PairInfo e{};
+                    e.name_seg = r.seg; e.name_off = L.name_off; e.name_len = L.name_len;
+                    e.insert = -1;
+                    if (counted) { e.nm = L.nm; e.mapq = L.mapq; e.length = L.qlen; e.reads = 1; e.start = L.first; e.stop = L.last; }
+                    pt.info.push_back(e);
+                } else if (counted) {
+                    PairInfo &e = pt.info[idx];
+                    if (e.reads == 0) { e.nm = L.nm; e.mapq = L.mapq; e.length = L.qlen; e.reads = 1; e.start = L.first; e.stop = L.last; e.insert = -1; }
+                    else {
+                        e.nm += L.nm;
+                        e.reads += 1;
+                        e.length += L.qlen;
+                        e.mapq = std::max<int64_t>(e.mapq, L.mapq);
+                        if (e.reads == 2) {
+                            if (L.last > e.start) e.insert = L.last - e.start;
+                            else e.insert = e.stop - L.first;
+                        } else e.insert = -1;
+                        e.start = 0; e.stop = 0;
+                    }
+                }
+                B.read_pair[(size_t)(ord0 + i)] = idx;       // local index for now
+            }
+        }
+    });
+    for (auto &pt : parts) if (!pt.no_nm.empty()) { isx_set_error("read without NM tag: " + pt.no_nm); return ISX_ERR_IO; }
+    // one table: a reference's partitions follow each other
+    std::vector<uint64_t> part_base(parts.size() + 1, 0);
+    for (size_t i = 0; i < parts.size(); i++) part_base[i + 1] = part_base[i] + parts[i].info.size();
+    if (part_base.back() >= 0xFFFFFFFFull) { isx_set_error("more than 2^32 read names"); return ISX_ERR_ARG; }
+    B.pairs.resize((size_t)part_base.back());
+    B.ref_pair0.assign(n_ref + 1, 0);
+    {
+        std::vector<size_t> first_part(n_ref + 1, parts.size());
+        for (size_t i = parts.size(); i-- > 0;) first_part[parts[i].ref] = i;
+        uint64_t run = part_base.back();
+        for (size_t t = n_ref; t-- > 0;) { if (first_part[t] < parts.size()) run = part_base[first_part[t]]; B.ref_pair0[t] = run; }
+        B.ref_pair0[n_ref] = part_base.back();
+    }
+    pool.run((int)parts.size(), [&](int pi) {
+        Part &pt = parts[(size_t)pi];
+        std::copy(pt.info.begin(), pt.info.end(), B.pairs.begin() + (ptrdiff_t)part_base[(size_t)pi]);
+        const uint32_t base = (uint32_t)part_base[(size_t)pi];
+        for (const Run &r : runs[pt.ref]) {
+            const auto &rs = B.seg_reads[r.seg];
+            const uint64_t ord0 = B.segs[r.seg].read0;
+            for (uint32_t i = r.i0; i < r.i1; i++) {
+                if (pt.P > 1 && (rs[i].h64 >> 40) % pt.P != pt.p) continue;
+                uint32_t &v = B.read_pair[(size_t)(ord0 + i)];
+                if (v != 0xFFFFFFFFu) v += base;
+            }
+        }
+        std::vector<PairInfo>().swap(pt.info);
+    });
+    for (auto &v : B.seg_reads) std::vector<ReadLite>().swap(v);     // names stay until the filter has run (set_r2m / priority reads / cross-scaffold filters)
+    B.totals = isx_bam_info{};
+    B.totals.n_refs = (int32_t)n_ref;
+    B.totals.n_reads = (int64_t)B.n_reads;
+    for (int64_t l : B.ref_len) B.totals.n_pos += l;
+    B.scanned = true;
+    if (info) *info = B.totals;
+    return ISX_OK;
+}
+
+int isx_bam_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n)
+{
+    if (!bam || !n) { isx_set_error("isx_bam_insert_sizes: bad argument"); return ISX_ERR_ARG; }
+    if (!bam->scanned) { isx_set_error("isx_bam_insert_sizes: scan first"); return ISX_ERR_STATE; }
+    int64_t k = 0;
+    for (const PairInfo &i : bam->pairs) if (i.reads == 2) { if (out && k < cap) out[k] = i.insert; k++; }
+    *n = k;
+    return ISX_OK;
+}
+
+// ---- paired_read_filter + filter_scaff2pair2info (filter_reads.py:471-532, 201-260) ----
+int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, isx_bam_info *info)
+{
+    if (!bam || !p) { isx_set_error("isx_bam_filter: bad argument"); return ISX_ERR_ARG; }
+    if (!bam->scanned) { isx_set_error("isx_bam_filter: scan first"); return ISX_ERR_STATE; }
+    if (p->pairing_filter < 0 || p->pairing_filter > 2) { isx_set_error("pairing_filter must be 0 (paired_only), 1 (non_discordant) or 2 (all_reads)"); return ISX_ERR_ARG; }
+    isx_bam &B = *bam;
     const size_t n_ref = B.ref_name.size();
-    const bool timing = getenv("ISX_BAM_TIMING") != nullptr;       // tuning aid: stage times on stderr
+    auto name_of = [&](const PairInfo &e) { return std::string_view(B.seg_names[e.name_seg].data() + e.name_off, e.name_len); };
+    if (B.seg_names.empty() && !B.pairs.empty()) { isx_set_error("isx_bam_filter: the read names were already dropped (filter runs once per scan)"); return ISX_ERR_STATE; }
+    // priority reads: by name
+    B.priority.assign(B.pairs.size(), 0);
+    if (!B.priority_names.empty()) {
+        std::unordered_map<std::string_view, int> pr;
+        for (const std::string &s : B.priority_names) pr.emplace(std::string_view(s), 1);
+        for (size_t i = 0; i < B.pairs.size(); i++) if (pr.count(name_of(B.pairs[i]))) B.priority[i] = 1;
+    }
+    isx_bam_info T = B.totals;
+    T.unfiltered_pairs = T.unfiltered_singletons = T.unfiltered_reads = 0;
+    T.filtered_pairs = T.filtered_singletons = T.filtered_bases = 0;
+    if (!B.pairs_scan.empty()) B.pairs = B.pairs_scan;          // an earlier all_reads run merged entries in place
+    else if (p->pairing_filter == 2) B.pairs_scan = B.pairs;
+    for (PairInfo &e : B.pairs) { e.pass = false; e.in_filter = false; }
+    // paired_read_filter: scaffolds in header order, names in order of first appearance
+    std::vector<PairInfo> merged;       // all_reads: entries rewritten by _merge_info
+    if (p->pairing_filter == 0) {
+        for (size_t i = 0; i < B.pairs.size(); i++) {
+            PairInfo &e = B.pairs[i];
+            if (e.reads == 0) continue;
+            T.unfiltered_reads += e.reads; T.unfiltered_pairs += e.reads == 2; T.unfiltered_singletons += e.reads == 1;
+            e.in_filter = e.reads == 2 || B.priority[i];
+        }
+    } else {
+        // names are looked up across scaffolds (pair2scaffold)
+        std::unordered_map<std::string_view, uint32_t> seen;        // name -> index of the entry that holds it now
+        seen.reserve(B.pairs.size());
+        for (size_t i = 0; i < B.pairs.size(); i++) {
+            PairInfo &e = B.pairs[i];
+            if (e.reads == 0) continue;
+            T.unfiltered_reads += e.reads; T.unfiltered_pairs += e.reads == 2; T.unfiltered_singletons += e.reads == 1;
+            auto it = seen.find(name_of(e));
+            if (p->pairing_filter == 1) {               // non_discordant
+                if (it == seen.end() || B.priority[i]) { e.in_filter = true; seen[name_of(e)] = (uint32_t)i; }
+                else {
+                    PairInfo &o = B.pairs[it->second];
+                    if (!o.in_filter) { isx_set_error("non_discordant: a read name occurs on three scaffolds (the reference fails with KeyError here)"); return ISX_ERR_ARG; }
+                    o.in_filter = false;                // mapped to two scaffolds: discordant, gone from the first
+                }
+            } else {                                    // all_reads
+                if (it == seen.end()) { e.in_filter = true; seen.emplace(name_of(e), (uint32_t)i); }
+                else {
+                    PairInfo &o = B.pairs[it->second];
+                    PairInfo m = e;                     // _merge_info(i, stored)
+                    m.nm = e.nm + o.nm; m.insert = -2; m.mapq = e.mapq + o.mapq; m.length = e.length + o.length;
+                    m.reads = e.reads + o.reads; m.start = -1; m.stop = -1;
+                    const PairInfo keep_e = e, keep_o = o;
+                    e = m; e.name_seg = keep_e.name_seg; e.name_off = keep_e.name_off; e.name_len = keep_e.name_len; e.in_filter = true;
+                    o = m; o.name_seg = keep_o.name_seg; o.name_off = keep_o.name_off; o.name_len = keep_o.name_len; o.in_filter = true;
+                }
+            }
+        }
+    }
+    // median insert of the pairs that went through (reads == 2)
+    double median = median_insert;
+    if (std::isnan(median)) {
+        std::vector<int64_t> ins;
+        for (const PairInfo &e : B.pairs) if (e.in_filter && e.reads == 2) ins.push_back(e.insert);
+        if (!ins.empty()) {                             // np.median (selection, not a full sort)
+            const size_t n = ins.size();
+            std::nth_element(ins.begin(), ins.begin() + (ptrdiff_t)(n / 2), ins.end());
+            const double hi = (double)ins[n / 2];
+            median = (n & 1) ? hi : ((double)*std::max_element(ins.begin(), ins.begin() + (ptrdiff_t)(n / 2)) + hi) / 2.0;
+        }
+    }
+    T.median_insert = median;
+    const double max_insert = median * p->max_insert_relative;
+    int64_t max_mm = 0;
+    B.ref_filtered_pairs.assign(n_ref, 0);
+    for (size_t t = 0; t < n_ref; t++) {
+        for (uint64_t i = B.ref_pair0[t]; i < B.ref_pair0[t + 1]; i++) {
+            PairInfo &e = B.pairs[(size_t)i];
+            if (!e.in_filter) continue;
+            const double pid = 1 - ((double)e.nm / (double)e.length);        // evaluate_pair :406
+            bool ok = pid > p->min_read_ani;
+            ok = ok && (e.mapq > p->min_mapq);
+            if (e.reads == 2 && e.insert != -1) ok = ok && ((double)e.insert > (double)p->min_insert) && ((double)e.insert < max_insert);
+            e.pass = ok;
+            if (ok) {
+                e.mm = (int32_t)e.nm;
+                T.filtered_pairs++; T.filtered_bases += e.length; T.filtered_singletons += e.reads == 1;
+                B.ref_filtered_pairs[t]++;
+                if (e.nm > max_mm) max_mm = e.nm;
+            }
+        }
+    }
+    if (max_mm > 65535) { isx_set_error("mm level > 65535"); return ISX_ERR_ARG; }
+    T.max_mm = p->skip_mm ? 0 : (int32_t)max_mm;
+    B.totals = T;
+    B.filtered = true;
+    if (info) *info = T;
+    return ISX_OK;
+}
+
+// The controller's own R2M for one reference (profile_controller.py:415-433 hands sR2M[scaffold] to every split):
+// exactly the named pairs pass, with the given mm.  Replaces what isx_bam_filter decided for that reference.
+int isx_bam_set_r2m(isx_bam *bam, int32_t ref, int64_t n, const char *names, const int64_t *offs, const int32_t *mm)
+{
+    if (!bam || ref < 0 || (size_t)ref >= bam->ref_name.size() || n < 0 || (n && (!names || !offs))) { isx_set_error("isx_bam_set_r2m: bad argument"); return ISX_ERR_ARG; }
+    isx_bam &B = *bam;
+    if (!B.scanned) { isx_set_error("isx_bam_set_r2m: scan first"); return ISX_ERR_STATE; }
+    if (B.seg_names.empty() && !B.pairs.empty()) { isx_set_error("isx_bam_set_r2m: the read names were already dropped (isx_bam_drop_names)"); return ISX_ERR_STATE; }
+    std::unordered_map<std::string_view, int32_t> want;
+    want.reserve((size_t)n * 2);
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t v = mm ? mm[i] : 0;
+        if (v < 0 || v > 65535) { isx_set_error("isx_bam_set_r2m: mm out of range"); return ISX_ERR_ARG; }
+        want.emplace(std::string_view(names + offs[i], (size_t)(offs[i + 1] - offs[i])), v);
+    }
+    int64_t kept = 0, max_mm = B.totals.max_mm;
+    for (uint64_t i = B.ref_pair0[(size_t)ref]; i < B.ref_pair0[(size_t)ref + 1]; i++) {
+        PairInfo &e = B.pairs[(size_t)i];
+        auto it = want.find(std::string_view(B.seg_names[e.name_seg].data() + e.name_off, e.name_len));
+        e.pass = it != want.end();
+        if (e.pass) { e.mm = it->second; kept++; max_mm = std::max<int64_t>(max_mm, e.mm); }
+    }
+    if (B.ref_filtered_pairs.size() != B.ref_name.size()) B.ref_filtered_pairs.assign(B.ref_name.size(), 0);
+    B.ref_filtered_pairs[(size_t)ref] = kept;
+    B.totals.max_mm = (int32_t)max_mm;
+    B.filtered = true;
+    return ISX_OK;
+}
+
+// What the filter decided for one reference: the reference's Rdic[scaffold] (pair name -> mm; controller.py:274-281
+// stores it with the profile).  Call with names == NULL to get the sizes first.
+int isx_bam_r2m(const isx_bam *bam, int32_t ref, int64_t *n, int64_t *name_bytes, char *names, int64_t *offs, int32_t *mm)
+{
+    if (!bam || ref < 0 || (size_t)ref >= bam->ref_name.size() || !n || !name_bytes) { isx_set_error("isx_bam_r2m: bad argument"); return ISX_ERR_ARG; }
+    const isx_bam &B = *bam;
+    if (!B.filtered) { isx_set_error("isx_bam_r2m: filter first"); return ISX_ERR_STATE; }
+    if (B.seg_names.empty() && !B.pairs.empty()) { isx_set_error("isx_bam_r2m: the read names were already dropped"); return ISX_ERR_STATE; }
+    int64_t k = 0, nb = 0;
+    for (uint64_t i = B.ref_pair0[(size_t)ref]; i < B.ref_pair0[(size_t)ref + 1]; i++) {
+        const PairInfo &e = B.pairs[(size_t)i];
+        if (!e.pass || e.reads == 0) continue;
+        if (names && offs && mm) {
+            offs[k] = nb;
+            memcpy(names + nb, B.seg_names[e.name_seg].data() + e.name_off, e.name_len);
+            mm[k] = e.mm;
+        }
+        nb += e.name_len; k++;
+    }
+    if (names && offs) offs[k] = nb;
+    *n = k; *name_bytes = nb;
+    return ISX_OK;
+}
+
+// free the read names once no isx_bam_set_r2m / isx_bam_filter call will follow (they are the bulk of what the scan keeps)
+int isx_bam_drop_names(isx_bam *bam)
+{
+    if (!bam) { isx_set_error("isx_bam_drop_names: bad argument"); return ISX_ERR_ARG; }
+    std::vector<std::vector<char>>().swap(bam->seg_names);
+    return ISX_OK;
+}
+
+int isx_bam_ref_counts(const isx_bam *bam, int64_t *reads, int64_t *filtered_pairs)
+{
+    if (!bam || !bam->scanned) { isx_set_error("isx_bam_ref_counts: scan first"); return ISX_ERR_STATE; }
+    const size_t n = bam->ref_name.size();
+    for (size_t t = 0; t < n; t++) {
+        if (reads) reads[t] = bam->ref_reads[t];
+        if (filtered_pairs) filtered_pairs[t] = bam->ref_filtered_pairs.size() == n ? bam->ref_filtered_pairs[t] : 0;
+    }
+    return ISX_OK;
+}
+
+// ---- pass 2: overlap resolution + expansion of a subset of the references ----
+int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info)
+{
+    if (!bam || !p || n_refs < 0 || (n_refs && !refs)) { isx_set_error("isx_bam_expand_refs: bad argument"); return ISX_ERR_ARG; }
+    isx_bam &B = *bam;
+    if (!B.scanned || !B.filtered) { isx_set_error("isx_bam_expand_refs: scan and filter first"); return ISX_ERR_STATE; }
+    const size_t n_ref_all = B.ref_name.size();
+    isxenc::HostPool &pool = pool_of(B);
+    const bool timing = getenv("ISX_BAM_TIMING") != nullptr;       // tuning aid: stage times on stderr (no effect on results)
     auto t_last = std::chrono::steady_clock::now();
     auto stage = [&](const char *what) {
         if (!timing) return;
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[isx_bam_expand] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        fprintf(stderr, "[isx_bam_expand_refs] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    auto name_of = [&](const Read &r) { return std::string_view(B.names.data() + r.name_off, r.name_len); };
+    // flat space of the batch: its references laid end to end in the order given
+    std::vector<int64_t> boff(n_ref_all, -1);
+    int64_t n_pos = 0;
+    std::vector<uint8_t> seg_wanted(B.segs.size(), 0);
+    for (int32_t i = 0; i < n_refs; i++) {
+        const int32_t t = refs[i];
+        if (t < 0 || (size_t)t >= n_ref_all || (i > 0 && t <= refs[i - 1])) { isx_set_error("isx_bam_expand_refs: reference ids must be valid and ascending (file order: the stream stays position-clustered)"); return ISX_ERR_ARG; }
+        boff[(size_t)t] = n_pos;
+        n_pos += B.ref_len[(size_t)t];
+        if (B.ref_reads[(size_t)t])
+            for (uint32_t s = B.ref_seg0[(size_t)t]; s <= B.ref_seg1[(size_t)t]; s++) seg_wanted[s] = 1;
+    }
+    if (n_pos >= (int64_t)0xFFFF0000ll) { isx_set_error("isx_bam_expand_refs: the batch's flat space must be < 2^32 - 65536 positions"); return ISX_ERR_ARG; }
+    std::vector<uint32_t> seg_list;
+    for (uint32_t s = 0; s < B.segs.size(); s++) if (seg_wanted[s]) seg_list.push_back(s);
 
-    // ---- get_paired_reads per scaffold (filter_reads.py:885-956) ----
-    // The (scaffold, read name) -> pair table is hash-partitioned over a few threads: every thread walks all
-    // reads in file order (so a pair's reads meet in file order) but owns only the names that hash to it.
-    struct NameKey {
-        int32_t tid; std::string_view name;
-        bool operator==(const NameKey &o) const { return tid == o.tid && name == o.name; }
-    };
-    struct NameKeyHash {
-        size_t operator()(const NameKey &k) const { return std::hash<std::string_view>()(k.name) * 1000003u ^ (size_t)(uint32_t)k.tid; }
-    };
-    const size_t n_reads_all = B.reads.size();
-    const unsigned NT = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), n_reads_all / 8192 + 1));
-    std::vector<std::unordered_map<NameKey, uint32_t, NameKeyHash>> maps(NT);      // value: index local to the partition
-    std::vector<std::vector<PairInfo>> part_info(NT);
-    std::vector<int32_t> read_pi(n_reads_all, -1);         // read -> index of its (scaffold, name) entry
-    std::vector<RefSpan> spans(n_reads_all);
-    std::vector<uint8_t> part_of(n_reads_all, 0xFF);       // partition of the read's name (0xFF: not in the table)
-    std::vector<std::string> no_nm(NT);
-    auto run_nt = [&](auto &&fn) {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < NT; t++) th.emplace_back(fn, t);
-        fn(0u);
-        for (auto &x : th) x.join();
-    };
-    run_nt([&](unsigned t) {                                // spans + partition of every read (read ranges)
-        for (size_t ri = n_reads_all * t / NT; ri < n_reads_all * (t + 1) / NT; ri++) {
-            const Read &r = B.reads[ri];
-            if (r.tid < 0 || (size_t)r.tid >= n_ref) continue;
-            spans[ri] = span_of(B, r);
-            if ((r.flag & FUNMAP) || !spans[ri].any) continue;          // get_reference_positions() == []
-            part_of[ri] = (uint8_t)(NameKeyHash()(NameKey{r.tid, name_of(r)}) % NT);
+    // ---- load the batch's reads: inflate + walk + count per segment, then fill ----
+    struct SegWork { SegBuf buf; std::vector<uint64_t> rec; std::vector<uint32_t> keep; uint64_t n_cig = 0, n_seq = 0; std::string err; };
+    std::vector<SegWork> sw(seg_list.size());
+    std::atomic<int> rc_any{0};
+    pool.run((int)seg_list.size(), [&](int k) {
+        const Segment &s = B.segs[seg_list[(size_t)k]];
+        SegWork &w = sw[(size_t)k];
+        Inflater inf;
+        uint64_t next = 0;
+        if (!seg_inflate(B, inf, s, w.buf)) { w.err = "BGZF inflate failed"; rc_any.store(ISX_ERR_IO); return; }
+        if (s.n_reads == 0) return;
+        if (seg_hop(B, inf, s, w.buf, s.first_rec, w.rec, next) != ISX_OK || w.rec.size() != s.n_reads) { w.err = "BAM changed between scan and expand"; rc_any.store(ISX_ERR_IO); return; }
+        for (uint32_t i = 0; i < s.n_reads; i++) {
+            const uint8_t *q = w.buf.data.data() + (w.rec[i] - s.ioff0);
+            const int32_t tid = rd32(q + 4);
+            if (tid < 0 || (size_t)tid >= n_ref_all || boff[(size_t)tid] < 0) continue;
+            if (rd16(q + 18) & DEF_MASK) continue;                     // htslib's pileup never sees these
+            w.keep.push_back(i);
+            w.n_cig += rd16(q + 16);
+            w.n_seq += (uint64_t)std::max(rd32(q + 20), 0);
         }
     });
-    run_nt([&](unsigned t) {                                // the tables (name partitions)
-        auto &m = maps[t];
-        auto &pi = part_info[t];
-        m.reserve(n_reads_all / (2 * NT) + 16);
-        pi.reserve(n_reads_all / (2 * NT) + 16);
-        for (size_t ri = 0; ri < n_reads_all; ri++) {
-            if (part_of[ri] != t) continue;
-            const Read &r = B.reads[ri];
-            const RefSpan &s = spans[ri];
-            if (!r.has_nm) { if (no_nm[t].empty()) no_nm[t] = std::string(name_of(r)); continue; }
-            const NameKey key{r.tid, name_of(r)};
-            auto it = m.find(key);
-            if (it == m.end()) {
-                m.emplace(key, (uint32_t)pi.size());
-                read_pi[ri] = (int32_t)pi.size();
-                pi.push_back(PairInfo{r.nm, -1, r.mapq, s.qlen, 1, s.first, s.last, false, 0});
-            } else {
-                PairInfo &i = pi[it->second];
-                read_pi[ri] = (int32_t)it->second;
-                i.nm += r.nm;
-                i.reads += 1;
-                i.length += s.qlen;
-                i.mapq = std::max<int64_t>(i.mapq, r.mapq);
-                if (i.reads == 2) {
-                    if (s.last > i.start) i.insert = s.last - i.start;
-                    else i.insert = i.stop - s.first;
-                } else {
-                    i.insert = -1;
-                }
-                i.start = 0; i.stop = 0;
+    if (rc_any.load()) { for (auto &w : sw) if (!w.err.empty()) { isx_set_error(w.err); break; } return rc_any.load(); }
+    std::vector<uint64_t> r_at(sw.size() + 1, 0), c_at(sw.size() + 1, 0), s_at(sw.size() + 1, 0);
+    for (size_t k = 0; k < sw.size(); k++) { r_at[k + 1] = r_at[k] + sw[k].keep.size(); c_at[k + 1] = c_at[k] + sw[k].n_cig; s_at[k + 1] = s_at[k] + sw[k].n_seq; }
+    Batch S;
+    S.reads.resize((size_t)r_at.back());
+    S.cigars.resize((size_t)c_at.back()); S.seqs.resize((size_t)s_at.back()); S.quals.resize((size_t)s_at.back());
+    pool.run((int)sw.size(), [&](int k) {
+        const Segment &s = B.segs[seg_list[(size_t)k]];
+        SegWork &w = sw[(size_t)k];
+        uint64_t ci = c_at[(size_t)k], qi = s_at[(size_t)k];
+        for (size_t j = 0; j < w.keep.size(); j++) {
+            RecView r;
+            if (!rec_view(w.buf.data.data() + (w.rec[w.keep[j]] - s.ioff0), r)) { w.err = "corrupt BAM record"; rc_any.store(ISX_ERR_IO); return; }
+            Read R{};
+            R.tid = r.tid; R.pos = r.pos; R.isize = r.isize; R.l_seq = r.l_seq; R.flag = r.flag; R.n_cigar = r.n_cigar;
+            R.pair_idx = B.read_pair[(size_t)(s.read0 + w.keep[j])];
+            R.cigar_off = ci; R.seq_off = qi;
+            memcpy(S.cigars.data() + ci, r.cigar, (size_t)r.n_cigar * 4);
+            uint8_t *sq = S.seqs.data() + qi;
+            for (int32_t x = 0; x < r.l_seq; x++) {
+                const uint8_t byte = r.seq[x >> 1];
+                sq[x] = (x & 1) ? (byte & 15) : (byte >> 4);
             }
+            memcpy(S.quals.data() + qi, r.qual, (size_t)r.l_seq);
+            R.ref_end = span_of(r.cigar, r.n_cigar, r.pos).end;
+            S.reads[(size_t)(r_at[(size_t)k] + j)] = R;
+            ci += r.n_cigar; qi += (uint64_t)r.l_seq;
         }
+        SegBuf().data.swap(w.buf.data);
     });
-    for (unsigned t = 0; t < NT; t++)
-        if (!no_nm[t].empty()) { isx_set_error("read without NM tag: " + no_nm[t]); return ISX_ERR_IO; }
-    // one table: partition t's entries start at part_base[t]
-    std::vector<uint32_t> part_base(NT + 1, 0);
-    for (unsigned t = 0; t < NT; t++) part_base[t + 1] = part_base[t] + (uint32_t)part_info[t].size();
-    std::vector<PairInfo> pinfo;
-    pinfo.reserve(part_base[NT] + 16);
-    for (unsigned t = 0; t < NT; t++) { pinfo.insert(pinfo.end(), part_info[t].begin(), part_info[t].end()); std::vector<PairInfo>().swap(part_info[t]); }
-    run_nt([&](unsigned t) {
-        for (size_t ri = n_reads_all * t / NT; ri < n_reads_all * (t + 1) / NT; ri++)
-            if (read_pi[ri] >= 0) read_pi[ri] += (int32_t)part_base[part_of[ri]];
-    });
-    stage("pair table (by name)");
-    // ---- paired_only + filter_scaff2pair2info (filter_reads.py:201-260, 471-532) ----
-    std::vector<int64_t> ins;
-    for (const PairInfo &i : pinfo) if (i.reads == 2) { ins.push_back(i.insert); info->unfiltered_pairs++; }
-    double median = NAN;
-    if (!ins.empty()) {                             // np.median (selection, not a full sort)
-        const size_t n = ins.size();
-        std::nth_element(ins.begin(), ins.begin() + n / 2, ins.end());
-        const double hi = (double)ins[n / 2];
-        median = (n & 1) ? hi : ((double)*std::max_element(ins.begin(), ins.begin() + n / 2) + hi) / 2.0;
-    }
-    info->median_insert = median;
-    const double max_insert = median * p->max_insert_relative;
-    int32_t max_mm = 0;
-    for (PairInfo &i : pinfo) {
-        if (i.reads != 2) continue;                 // pairing_filter == paired_only
-        const double pid = 1 - ((double)i.nm / (double)i.length);       // evaluate_pair :406
-        bool ok = pid > p->min_read_ani;
-        ok = ok && (i.mapq > p->min_mapq);
-        if (i.insert != -1) ok = ok && ((double)i.insert > (double)p->min_insert) && ((double)i.insert < max_insert);
-        i.pass = ok;
-        if (ok) {
-            info->filtered_pairs++;
-            info->filtered_bases += i.length;
-            if (i.nm > max_mm) max_mm = (int32_t)i.nm;
-        }
-    }
-    info->max_mm = p->skip_mm ? 0 : max_mm;
-    if (max_mm > 65535) { isx_set_error("mm level > 65535"); return ISX_ERR_ARG; }
+    if (rc_any.load()) { for (auto &w : sw) if (!w.err.empty()) { isx_set_error(w.err); break; } return rc_any.load(); }
+    sw.clear();
+    stage("load reads");
 
-    stage("pair filter");
-    // ---- overlap_push in file order (htslib-1.9 rule |isize| < 2*l_qseq) ----
+    // ---- overlap_push in file order (htslib-1.9 rule |isize| < 2*l_qseq), partitioned by pair: a pair's two reads
+    //      only ever touch each other's qualities ----
+    const size_t n_reads = S.reads.size();
     {
-        std::vector<int64_t> pending(pinfo.size(), -1);     // per (scaffold, name): read waiting for its mate
-        for (size_t ri = 0; ri < B.reads.size(); ri++) {
-            const Read &r = B.reads[ri];
-            if (r.tid < 0 || (size_t)r.tid >= n_ref || (r.flag & DEF_MASK)) continue;
-            if ((r.flag & FMUNMAP) || !(r.flag & FPROPER)) continue;
-            if (std::abs((int64_t)r.isize) >= 2 * (int64_t)r.l_seq) continue;
-            int32_t pi = read_pi[ri];
-            if (pi < 0) {                                   // aligned-base-free read: still hashed by name in htslib
-                const NameKey key{r.tid, name_of(r)};
-                const unsigned t = (unsigned)(NameKeyHash()(key) % NT);
-                auto &m = maps[t];
-                auto it = m.find(key);
-                if (it == m.end()) {                        // new entries live behind the partitions: global index as value
-                    m.emplace(key, 0x80000000u | (uint32_t)pinfo.size());
-                    pi = (int32_t)pinfo.size();
-                    pinfo.push_back(PairInfo{0, -1, 0, 0, 0, 0, 0, false, 0}); pending.push_back(-1);
-                } else pi = (it->second & 0x80000000u) ? (int32_t)(it->second & 0x7FFFFFFFu) : (int32_t)(part_base[t] + it->second);
+        const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 2, n_reads / 16384 + 1));
+        pool.run(P, [&](int part) {
+            std::unordered_map<uint32_t, int64_t> pending;      // pair -> read waiting for its mate
+            pending.reserve(n_reads / (size_t)P / 4 + 16);
+            for (size_t ri = 0; ri < n_reads; ri++) {
+                const Read &r = S.reads[ri];
+                if (r.pair_idx == 0xFFFFFFFFu || (int)(r.pair_idx % (uint32_t)P) != part) continue;
+                if ((r.flag & FMUNMAP) || !(r.flag & FPROPER)) continue;
+                if (std::abs((int64_t)r.isize) >= 2 * (int64_t)r.l_seq) continue;
+                auto it = pending.find(r.pair_idx);
+                if (it != pending.end() && S.reads[(size_t)it->second].ref_end <= r.pos) { pending.erase(it); it = pending.end(); }   // earlier read already left the buffer
+                if (it == pending.end()) pending.emplace(r.pair_idx, (int64_t)ri);
+                else {
+                    const size_t ai = (size_t)it->second;
+                    pending.erase(it);
+                    tweak_overlap(S, S.reads[ai], r);
+                }
             }
-            int64_t &slot = pending[(size_t)pi];
-            if (slot >= 0 && spans[(size_t)slot].end <= r.pos) slot = -1;    // earlier read already left the buffer
-            if (slot < 0) slot = (int64_t)ri;
-            else {
-                const size_t ai = (size_t)slot;
-                slot = -1;
-                tweak_overlap(B, B.reads[ai], r);
-            }
-        }
+        });
     }
-
     stage("overlap resolution");
+
     // ---- expansion: the visits on which get_base_counts_mm touches `table` ----
-    // pair ids in order of first appearance (serial, one word per read); then per read the number of
+    // dense pair ids in order of first appearance (serial, one word per read); then per read the number of
     // visits it contributes (threads), a prefix sum, and the writes (threads) -- file order is kept
-    uint32_t next_pair = 0;
-    for (PairInfo &i : pinfo) i.pair_id = 0xFFFFFFFFu;
-    const size_t n_reads = B.reads.size();
     std::vector<uint8_t> emit(n_reads, 0);
+    std::vector<uint64_t> slot0(n_ref_all, 0);              // the batch's pair entries, reference after reference
+    uint64_t n_slots = 0;
+    for (int32_t i = 0; i < n_refs; i++) { slot0[(size_t)refs[i]] = n_slots; n_slots += B.ref_pair0[(size_t)refs[i] + 1] - B.ref_pair0[(size_t)refs[i]]; }
+    std::vector<uint32_t> dense((size_t)n_slots, 0xFFFFFFFFu);
+    std::vector<uint32_t> pid(n_reads, 0);
+    uint32_t next_pair = 0;
     for (size_t ri = 0; ri < n_reads; ri++) {
-        const Read &r = B.reads[ri];
-        if (r.tid < 0 || (size_t)r.tid >= n_ref || (r.flag & DEF_MASK)) continue;
+        const Read &r = S.reads[ri];
         // R2M membership is by NAME on this scaffold (get_base_counts_mm looks up query_name)
-        const int32_t pidx = read_pi[ri];
-        if (pidx < 0) continue;
-        PairInfo &pi = pinfo[(size_t)pidx];
-        if (!pi.pass) continue;
-        if (pi.pair_id == 0xFFFFFFFFu) pi.pair_id = next_pair++;
+        if (r.pair_idx == 0xFFFFFFFFu) continue;
+        const PairInfo &pi = B.pairs[r.pair_idx];
+        if (!pi.pass || pi.reads == 0) continue;
+        uint32_t &d = dense[(size_t)(slot0[(size_t)r.tid] + (r.pair_idx - B.ref_pair0[(size_t)r.tid]))];
+        if (d == 0xFFFFFFFFu) d = next_pair++;
+        pid[ri] = d;
         emit[ri] = 1;
     }
     const uint8_t minq = (uint8_t)std::min(255, std::max(0, p->min_base_quality));
     std::vector<uint64_t> out_at(n_reads + 1, 0);
-    // one walk of a read's CIGAR; WRITE = false only counts
     auto walk = [&](size_t ri, bool write, isx_obs *po, uint32_t *pp) -> uint64_t {
-        const Read &r = B.reads[ri];
-        const PairInfo &pi = pinfo[(size_t)read_pi[ri]];
-        const uint16_t mm = p->skip_mm ? 0 : (uint16_t)pi.nm;
-        const int64_t base_off = B.ref_off[(size_t)r.tid];
+        const Read &r = S.reads[ri];
+        const PairInfo &pi = B.pairs[r.pair_idx];
+        const uint16_t mm = p->skip_mm ? 0 : (uint16_t)pi.mm;
+        const int64_t base_off = boff[(size_t)r.tid];
         const int64_t ref_len = B.ref_len[(size_t)r.tid];
-        const uint8_t *ql = B.quals.data() + r.qual_off, *sq = B.seqs.data() + r.seq_off;
+        const uint8_t *ql = S.quals.data() + r.seq_off, *sq = S.seqs.data() + r.seq_off;
         int64_t ref = r.pos, q = 0;
         uint64_t n_out = 0;
         for (int k = 0; k < r.n_cigar; k++) {
-            const uint32_t c = B.cigars[r.cigar_off + k];
+            const uint32_t c = S.cigars[r.cigar_off + (uint64_t)k];
             const int op = c & 15;
             const int64_t n = c >> 4;
             if (op == CM || op == CEQ || op == CX) {
@@ -625,7 +1203,7 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
                         if (write) {
                             isx_obs &o = po[n_out];
                             o.gpos = g0 + (uint32_t)j; o.mm = mm; o.base = CODE2IDX[sq[q + j]]; o.flags = 0;
-                            pp[n_out] = pi.pair_id;
+                            pp[n_out] = pid[ri];
                         }
                         n_out++;
                     }
@@ -636,55 +1214,63 @@ int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
         }
         return n_out;
     };
-    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(64u, std::max(1u, std::thread::hardware_concurrency())), n_reads / 4096 + 1));
-    auto run_threads = [&](auto &&fn) {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(fn, t);
-        fn(0u);
-        for (auto &x : th) x.join();
-    };
-    run_threads([&](unsigned t) {
-        for (size_t ri = n_reads * t / nt; ri < n_reads * (t + 1) / nt; ri++)
+    const int n_tasks = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n_reads / 2048 + 1));
+    pool.run(n_tasks, [&](int t) {
+        for (size_t ri = n_reads * (size_t)t / (size_t)n_tasks; ri < n_reads * ((size_t)t + 1) / (size_t)n_tasks; ri++)
             if (emit[ri]) out_at[ri + 1] = walk(ri, false, nullptr, nullptr);
     });
     for (size_t ri = 0; ri < n_reads; ri++) out_at[ri + 1] += out_at[ri];
     const size_t n_out = (size_t)out_at[n_reads];
+    if (n_out >= 0xFFFFFFFFull) { isx_set_error("isx_bam_expand_refs: more than 2^32 observations in one batch (expand fewer references at a time)"); return ISX_ERR_ARG; }
     B.obs.reset(new isx_obs[std::max<size_t>(n_out, 1)]);
     B.pair.reset(new uint32_t[std::max<size_t>(n_out, 1)]);
     B.n_obs = n_out;
-    run_threads([&](unsigned t) {
-        for (size_t ri = n_reads * t / nt; ri < n_reads * (t + 1) / nt; ri++)
+    pool.run(n_tasks, [&](int t) {
+        for (size_t ri = n_reads * (size_t)t / (size_t)n_tasks; ri < n_reads * ((size_t)t + 1) / (size_t)n_tasks; ri++)
             if (emit[ri]) walk(ri, true, B.obs.get() + out_at[ri], B.pair.get() + out_at[ri]);
     });
-
     stage("expansion");
-    // ---- iterate_splits (fasta.py:56-73) on the flat space ----
+
+    // ---- iterate_splits (fasta.py:56-73) on the batch's flat space ----
     B.split_bounds.clear(); B.split_ref.clear();
     const int64_t W = p->window_length > 0 ? p->window_length : 10000;
-    for (size_t t = 0; t < n_ref; t++) {
+    for (int32_t i = 0; i < n_refs; i++) {
+        const size_t t = (size_t)refs[i];
         const int64_t sLen = B.ref_len[t];
         if (sLen <= 0) continue;
         const int64_t n_chunks = sLen / W + 1;
         const int64_t chunk = (int64_t)((double)sLen / (double)n_chunks);
         int64_t start = 0;
-        for (int64_t i = 0; i < n_chunks; i++) {
-            B.split_bounds.push_back(B.ref_off[t] + start);
+        for (int64_t c = 0; c < n_chunks; c++) {
+            B.split_bounds.push_back(boff[t] + start);
             B.split_ref.push_back((int32_t)t);
-            if (i + 1 < n_chunks) start += chunk;
+            if (c + 1 < n_chunks) start += chunk;
         }
     }
-    int64_t n_pos = 0;
-    for (int64_t l : B.ref_len) n_pos += l;
     B.split_bounds.push_back(n_pos);
     B.expanded = true;
-
-    info->n_refs = (int32_t)n_ref;
-    info->n_splits = (int32_t)B.split_ref.size();
-    info->n_reads = (int64_t)B.reads.size();
-    info->n_pos = n_pos;
-    info->n_obs = (int64_t)B.n_obs;
-    info->n_pairs = next_pair;
+    if (info) {
+        *info = B.totals;
+        info->n_refs = n_refs;
+        info->n_splits = (int32_t)B.split_ref.size();
+        info->n_pos = n_pos;
+        info->n_obs = (int64_t)B.n_obs;
+        info->n_pairs = next_pair;
+        info->max_mm = p->skip_mm ? 0 : B.totals.max_mm;
+    }
     return ISX_OK;
+}
+
+// scan + filter + expansion of every reference of the file
+int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info)
+{
+    if (!bam || !p || !info) { isx_set_error("isx_bam_expand: bad argument"); return ISX_ERR_ARG; }
+    int rc = isx_bam_scan(bam, nullptr);
+    if (rc != ISX_OK) return rc;
+    if ((rc = isx_bam_filter(bam, p, NAN, nullptr)) != ISX_OK) return rc;
+    std::vector<int32_t> all(bam->ref_name.size());
+    for (size_t i = 0; i < all.size(); i++) all[i] = (int32_t)i;
+    return isx_bam_expand_refs(bam, p, all.data(), (int32_t)all.size(), info);
 }
 
 int isx_bam_copy(const isx_bam *bam, isx_obs *obs, uint32_t *pair, int64_t *split_bounds, int32_t *split_ref)
@@ -697,7 +1283,7 @@ int isx_bam_copy(const isx_bam *bam, isx_obs *obs, uint32_t *pair, int64_t *spli
     return ISX_OK;
 }
 
-/* zero-copy access to what isx_bam_copy copies; valid until isx_bam_close */
+/* zero-copy access to what isx_bam_copy copies; valid until the next expand / isx_bam_close */
 int isx_bam_view(const isx_bam *bam, const isx_obs **obs, const uint32_t **pair)
 {
     if (!bam || !bam->expanded) { isx_set_error("isx_bam_view: expand first"); return ISX_ERR_STATE; }

@@ -295,25 +295,96 @@ def dense_to_entries(counts, clon):
     return e
 
 
-class BamFile:
-    """Host BAM front end (isx_bam_*): BGZF/BAM decode + read-pair filter + htslib-1.9 pileup rules."""
+def _name_blob(names):
+    """list of str -> (bytes blob, int64 offsets[n + 1])"""
+    enc = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+    offs = np.zeros(len(enc) + 1, dtype=np.int64)
+    if enc:
+        offs[1:] = np.cumsum([len(e) for e in enc])
+    return b"".join(enc), offs
 
-    def __init__(self, path):
+
+class BamFile:
+    """Host BAM front end (isx_bam_*): BGZF/BAM decode + read-pair filter + htslib-1.9 pileup rules.
+
+    scan() / filter() / expand_refs() are the three passes (see include/instrain_amd.h); expand() runs all of
+    them over the whole file."""
+
+    def __init__(self, path, threads=0):
         self.lib = _lib.load()
         h = C.c_void_p()
         check(self.lib.isx_bam_open(path.encode(), C.byref(h)))
         self.h = h
         self.info = None
+        self._refs = None
+        if threads:
+            check(self.lib.isx_bam_set_threads(self.h, int(threads)))
 
-    def expand(self, min_read_ani=0.95, min_mapq=-1, max_insert_relative=3, min_insert=50,
-               min_base_quality=30, skip_mm=False, window_length=10000, copy=True):
-        """-> (obs, pair, split_bounds, split_ref).  copy=False: obs / pair are views of the handle's own
-        arrays (isx_bam_view), valid until close() -- enough to build a Batch from them."""
-        p = BamParams(float(min_read_ani), int(min_mapq), float(max_insert_relative), int(min_insert),
-                      int(min_base_quality), 1 if skip_mm else 0, int(window_length), 0)
-        info = BamInfo()
-        check(self.lib.isx_bam_expand(self.h, C.byref(p), C.byref(info)))
+    @staticmethod
+    def _params(min_read_ani=0.95, min_mapq=-1, max_insert_relative=3, min_insert=50, min_base_quality=30,
+                skip_mm=False, window_length=10000, pairing_filter="paired_only"):
+        pf = _lib.PAIRING_FILTERS[pairing_filter] if isinstance(pairing_filter, str) else int(pairing_filter)
+        return BamParams(float(min_read_ani), int(min_mapq), float(max_insert_relative), int(min_insert),
+                         int(min_base_quality), 1 if skip_mm else 0, int(window_length), pf)
+
+    def _info(self, info):
         self.info = {n: getattr(info, n) for n, _ in BamInfo._fields_ if n != "pad"}
+        return self.info
+
+    def scan(self):
+        """pass 1: pair tables of every reference (get_paired_reads)"""
+        info = BamInfo()
+        check(self.lib.isx_bam_scan(self.h, C.byref(info)))
+        return self._info(info)
+
+    def insert_sizes(self):
+        n = C.c_int64(0)
+        check(self.lib.isx_bam_insert_sizes(self.h, None, 0, C.byref(n)))
+        out = np.empty(max(1, n.value), dtype=np.int64)
+        check(self.lib.isx_bam_insert_sizes(self.h, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def set_priority_reads(self, names):
+        blob, offs = _name_blob(list(names))
+        check(self.lib.isx_bam_set_priority_reads(self.h, len(offs) - 1, blob, offs.ctypes.data))
+
+    def filter(self, median_insert=None, **kw):
+        """paired_read_filter + filter_scaff2pair2info; kw as _params"""
+        info = BamInfo()
+        p = self._params(**kw)
+        check(self.lib.isx_bam_filter(self.h, C.byref(p), float("nan") if median_insert is None else float(median_insert),
+                                      C.byref(info)))
+        return self._info(info)
+
+    def set_r2m(self, ref, names, mm=None):
+        """the controller's own R2M for reference index `ref`: exactly these read pairs, with these mm values"""
+        blob, offs = _name_blob(list(names))
+        mmv = None if mm is None else np.ascontiguousarray(mm, dtype=np.int32)
+        check(self.lib.isx_bam_set_r2m(self.h, int(ref), len(offs) - 1, blob, offs.ctypes.data,
+                                       mmv.ctypes.data if mmv is not None else None))
+
+    def r2m(self, ref):
+        """the filter's decision for reference index `ref` as the reference stores it: {pair name: mm}"""
+        n, nb = C.c_int64(0), C.c_int64(0)
+        check(self.lib.isx_bam_r2m(self.h, int(ref), C.byref(n), C.byref(nb), None, None, None))
+        names = C.create_string_buffer(max(1, nb.value))
+        offs = np.zeros(n.value + 1, dtype=np.int64)
+        mm = np.zeros(max(1, n.value), dtype=np.int32)
+        check(self.lib.isx_bam_r2m(self.h, int(ref), C.byref(n), C.byref(nb), names, offs.ctypes.data, mm.ctypes.data))
+        raw = names.raw
+        return {raw[offs[i]:offs[i + 1]].decode(): int(mm[i]) for i in range(n.value)}
+
+    def drop_names(self):
+        check(self.lib.isx_bam_drop_names(self.h))
+
+    def ref_counts(self):
+        """-> (records per reference, filtered pairs per reference)"""
+        n = len(self.refs())
+        reads, pairs = np.zeros(n, np.int64), np.zeros(n, np.int64)
+        check(self.lib.isx_bam_ref_counts(self.h, reads.ctypes.data, pairs.ctypes.data))
+        return reads, pairs
+
+    def _results(self, info, copy):
         bounds = np.empty(info.n_splits + 1, dtype=np.int64)
         sref = np.empty(info.n_splits, dtype=np.int32)
         if copy or info.n_obs == 0:
@@ -328,16 +399,36 @@ class BamFile:
             pair = np.frombuffer((C.c_uint32 * info.n_obs).from_address(pp.value), dtype=np.uint32)
         return obs, pair, bounds, sref
 
+    def expand_refs(self, refs, copy=True, **kw):
+        """pass 2 for the reference indices `refs` (laid end to end in that order): -> (obs, pair, split_bounds,
+        split_ref).  copy=False: obs / pair are views of the handle's arrays, valid until the next expand."""
+        refs = np.ascontiguousarray(refs, dtype=np.int32)
+        info = BamInfo()
+        p = self._params(**kw)
+        check(self.lib.isx_bam_expand_refs(self.h, C.byref(p), refs.ctypes.data, len(refs), C.byref(info)))
+        self._info(info)
+        return self._results(info, copy)
+
+    def expand(self, copy=True, **kw):
+        """scan + filter + expansion of every reference -> (obs, pair, split_bounds, split_ref)"""
+        info = BamInfo()
+        p = self._params(**kw)
+        check(self.lib.isx_bam_expand(self.h, C.byref(p), C.byref(info)))
+        self._info(info)
+        return self._results(info, copy)
+
     def refs(self):
-        out = []
-        i = 0
-        while True:
-            name, ln, off = C.c_char_p(), C.c_int64(), C.c_int64()
-            if self.lib.isx_bam_ref(self.h, i, C.byref(name), C.byref(ln), C.byref(off)) != 0:
-                break
-            out.append((name.value.decode(), ln.value, off.value))
-            i += 1
-        return out
+        if self._refs is None:
+            out = []
+            i = 0
+            while True:
+                name, ln, off = C.c_char_p(), C.c_int64(), C.c_int64()
+                if self.lib.isx_bam_ref(self.h, i, C.byref(name), C.byref(ln), C.byref(off)) != 0:
+                    break
+                out.append((name.value.decode(), ln.value, off.value))
+                i += 1
+            self._refs = out
+        return self._refs
 
     def close(self):
         if self.h:

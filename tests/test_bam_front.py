@@ -62,11 +62,8 @@ def test_skip_mm_and_errors():
     bam = engine.BamFile(os.path.join(util.GOLD, "SmallScaffold.fa.sorted.bam"))
     obs, pair, bounds, sref = bam.expand(skip_mm=True)
     assert (obs["mm"] == 0).all() and bam.info["max_mm"] == 0
-    try:
-        bam.expand()
-        assert False, "second expand must be refused (qualities were rewritten)"
-    except engine.IsxError as e:
-        assert e.code == -6
+    o2, p2, _, _ = bam.expand()                       # a second pass re-reads the file: same visits, now with mm
+    assert (o2["gpos"] == obs["gpos"]).all() and (o2["base"] == obs["base"]).all() and (p2 == pair).all() and o2["mm"].max() > 0
     bam.close()
     try:
         engine.BamFile("/nonexistent.bam")
@@ -142,3 +139,130 @@ def test_error_paths_and_empty_inputs(tmp_path):
     o2, p2, _, _ = engine.BamFile(empty).expand(copy=False)
     assert len(o2) == 0 and len(p2) == 0
     b.close()
+
+
+def test_pairing_filter_modes_match_the_reference():
+    """paired_only / non_discordant / all_reads, with and without --priority_reads: the scaffold -> {pair: mm}
+    dictionaries and read-report tallies that the reference's own paired_read_filter + filter_scaff2pair2info
+    produce (tests/golden/make_filter_golden.py) on filter_modes.bam"""
+    import json
+    g = json.load(open(os.path.join(util.GOLD, "filter_modes.json")))
+    bam = engine.BamFile(os.path.join(util.GOLD, "filter_modes.bam"))
+    assert [(n, l) for n, l, _ in bam.refs()] == [tuple(r) for r in g["refs"]]
+    bam.scan()
+    seen = set()
+    for case in g["cases"]:
+        assert not case.get("keyerror")
+        bam.set_priority_reads(g["priority"] if case["priority"] else [])
+        info = bam.filter(pairing_filter=case["mode"], **case["params"])
+        for k, v in case["tallies"].items():
+            assert info[k] == v, (case["mode"], case["priority"], k, info[k], v)
+        assert info["median_insert"] == case["median_insert"]
+        for t, (name, _, _) in enumerate(bam.refs()):
+            assert bam.r2m(t) == case["r2m"].get(name, {}), (case["mode"], case["priority"], name)
+        seen.add((case["mode"], case["priority"]))
+    assert len(seen) == 6
+    # the modes really differ on this file
+    by = {(c["mode"], c["priority"]): sum(len(d) for d in c["r2m"].values()) for c in g["cases"]}
+    assert by[("paired_only", False)] < by[("paired_only", True)] < by[("non_discordant", False)]
+    bam.close()
+
+
+def test_expand_refs_subsets_and_controller_r2m(tmp_path):
+    """pass 2 on subsets of the references == the whole-file expansion cut per reference; and the controller's own
+    R2M (isx_bam_set_r2m) instead of the built-in filter: exactly the named pairs, with the given mm"""
+    from oracle import bam_py
+    from tests import bamwriter
+    refs = [("scafA", 4000), ("scafB", 900), ("scafC", 12500), ("empty", 700)]
+    path = str(tmp_path / "m.bam")
+    reads = bamwriter.random_reads(11, refs[:3], 6000)
+    bamwriter.write_bam(path, refs, reads)
+    whole = engine.BamFile(path)
+    obs, pair, bounds, sref = whole.expand(min_read_ani=0.9, window_length=1000)
+    offs = np.r_[0, np.cumsum([r[1] for r in refs])]
+    bam = engine.BamFile(path, threads=3)
+    bam.scan()
+    bam.filter(min_read_ani=0.9)
+    reads_per_ref, pairs_per_ref = bam.ref_counts()
+    assert reads_per_ref[3] == 0 and pairs_per_ref.sum() == bam.info["filtered_pairs"] == whole.info["filtered_pairs"]
+    with pytest.raises(engine.IsxError):
+        bam.expand_refs([1, 0])                          # file order only
+    for sel in ([2], [0, 1], [3], [0, 1, 2, 3], [2, 3], [0, 2]):
+        o, p, b, s = bam.expand_refs(sel, min_read_ani=0.9, window_length=1000)
+        exp_parts, at = [], 0
+        for t in sel:
+            k = (obs["gpos"] >= offs[t]) & (obs["gpos"] < offs[t + 1])
+            e = obs[k].copy()
+            e["gpos"] = e["gpos"] - offs[t] + at
+            exp_parts.append((e, pair[k]))
+            at += refs[t][1]
+        e = np.concatenate([x[0] for x in exp_parts])
+        assert len(o) == len(e) and (o == e).all(), sel
+        # pair ids: dense in order of first appearance inside the batch -> same partition of the observations
+        ep = np.concatenate([x[1] + 10_000_000 * i for i, x in enumerate(exp_parts)])
+        _, a = np.unique(p, return_inverse=True)
+        _, c = np.unique(ep, return_inverse=True)
+        first_a = np.full(a.max() + 1 if len(a) else 0, -1); first_c = np.full(c.max() + 1 if len(c) else 0, -1)
+        assert len(first_a) == len(first_c)
+        for arr, first in ((a, first_a), (c, first_c)):
+            idx = np.arange(len(arr))[::-1]
+            first[arr[::-1]] = idx
+        assert (first_a[a] == first_c[c]).all(), sel
+        assert b[-1] == at and list(s) == [t for t in sel for _ in range(refs[t][1] // 1000 + 1)]
+    # controller-supplied R2M: the oracle's filter result with every mm raised by 2, half of scafC's pairs only
+    rrefs, rr = bam_py.read_bam(path)
+    p2i = {r[0]: bam_py.get_paired_reads(rr, t) for t, r in enumerate(rrefs)}
+    r2m, _ = bam_py.filter_pairs(p2i, min_read_ani=0.9)
+    assert bam.r2m(2) == r2m["scafC"] and bam.r2m(0) == r2m["scafA"]
+    keep = dict(list(r2m["scafC"].items())[::2])
+    bam.set_r2m(2, list(keep), [m + 2 for m in keep.values()])
+    o, p, b, s = bam.expand_refs([2], min_read_ani=0.9)
+    bam_py.resolve_overlaps(rr, 2)
+    pos, base, mm, pr, _ = bam_py.expand_observations(rr, 2, {n: m + 2 for n, m in keep.items()}, ref_len=12500)
+    assert len(o) == len(pos) > 1000 and (o["gpos"] == pos).all() and (o["base"] == base).all() and (o["mm"] == mm).all()
+    assert bam.info["max_mm"] >= max(keep.values()) + 2
+    whole.close(); bam.close()
+
+
+def test_corrupt_inputs_are_errors_not_crashes(tmp_path):
+    """truncated / corrupted inflated streams: bounds-checked, reported as ISX_ERR_IO"""
+    import struct, zlib
+    from tests import bamwriter
+    refs = [("s", 3000)]
+    reads = bamwriter.random_reads(9, refs, 300)
+    good = str(tmp_path / "g.bam")
+    bamwriter.write_bam(good, refs, reads)
+    import gzip
+    raw = gzip.open(good).read()
+
+    def rewrite(data, name):
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            for i in range(0, len(data), 60000):
+                f.write(bamwriter._bgzf_block(data[i:i + 60000]))
+            f.write(bamwriter._bgzf_block(b""))
+        return path
+
+    hdr_end = 12 + struct.unpack("<i", raw[4:8])[0]
+    hdr_end += 4 + 8 + struct.unpack("<i", raw[hdr_end + 4:hdr_end + 8])[0]
+    cases = {"tail.bam": raw[:-11],                                                  # last record cut short
+             "badlen.bam": raw[:hdr_end] + struct.pack("<i", 10_000_000) + raw[hdr_end + 4:],       # block_size beyond the file
+             "neglen.bam": raw[:hdr_end] + struct.pack("<i", -5) + raw[hdr_end + 4:],
+             "lseq.bam": raw[:hdr_end + 20] + struct.pack("<i", 1 << 30) + raw[hdr_end + 24:],       # l_seq beyond the record
+             "refs.bam": raw[:8 + struct.unpack("<i", raw[4:8])[0]] + struct.pack("<i", 1 << 28)}    # n_ref without references
+    for name, data in cases.items():
+        path = rewrite(data, name)
+        with pytest.raises(engine.IsxError) as e:
+            engine.BamFile(path).expand()
+        assert e.value.code == -5, name
+    # an aux field that runs past its record
+    r2 = [dict(r) for r in reads[:40]]
+    path = str(tmp_path / "aux.bam")
+    bamwriter.write_bam(path, refs, r2)
+    data = bytearray(gzip.open(path).read())
+    i = data.find(b"XSZhello")
+    assert i > 0
+    data[i + 3:i + 9] = b"hellox"                      # the Z string loses its terminator inside the record
+    with pytest.raises(engine.IsxError) as e:
+        engine.BamFile(rewrite(bytes(data), "aux2.bam")).expand()
+    assert e.value.code == -5
