@@ -285,7 +285,7 @@ typedef struct {
     int64_t max_pos;            /* largest n_pos of a batch */
     int64_t max_obs;            /* largest n_obs of a batch */
     int32_t max_splits;
-    int32_t depth;              /* resident slots, >= 2 (4 is a good default) */
+    int32_t depth;              /* resident slots: 1 = no overlap between batches, 4 is a good default for a stream */
     int32_t host_threads;       /* encoder threads incl. the caller; 0 = automatic (the cpus this process may use, at most 32) */
     int32_t pin_threads;        /* 1: spread the threads over the L3 domains of the GPU's NUMA node (sched_setaffinity) */
     double jump_slack;          /* device records set aside for streams that jump between far-apart positions

@@ -222,8 +222,8 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     *out = nullptr;
     if (!c->d_lut) { isx_set_error("isx_pipe_create: call isx_set_null_model first"); return ISX_ERR_STATE; }
     if (prm->n_mm_bins < 1 || prm->n_mm_bins > 128) { isx_set_error("n_mm_bins must be in [1, 128]"); return ISX_ERR_ARG; }
-    if (pp->max_pos <= 0 || pp->max_obs < 0 || pp->max_splits <= 0 || pp->depth < 2 || pp->depth > 64) {
-        isx_set_error("isx_pipe_create: max_pos > 0, max_obs >= 0, max_splits > 0, 2 <= depth <= 64");
+    if (pp->max_pos <= 0 || pp->max_obs < 0 || pp->max_splits <= 0 || pp->depth < 1 || pp->depth > 64) {
+        isx_set_error("isx_pipe_create: max_pos > 0, max_obs >= 0, max_splits > 0, 1 <= depth <= 64");
         return ISX_ERR_ARG;
     }
     if (pp->max_pos >= (int64_t)0xFFFF0000ll) { isx_set_error("flat position space must be < 2^32 - 65536"); return ISX_ERR_ARG; }

@@ -1,6 +1,16 @@
-"""Mirror of inStrain/profile/profile_utilities.py for the hot path: profile_split's result
-carrier (SplitObject, profile_utilities.py:823-858 and the fields set at :195-211) and the batch
-driver that replaces the split worker pool (profile_controller.py:157-271)."""
+"""Mirror of inStrain/profile/profile_utilities.py for the hot path: profile_split's result carrier
+(SplitObject, profile_utilities.py:823-858 and the fields set at :195-211), the scaffold_profile the merge
+step builds from it (:860-896), and the batch driver that replaces the split worker pool
+(profile_controller.py:157-271, 397-457).
+
+profile_bam keeps the reference's contract (profile/__init__.py:7-18):
+  * `fasta_db` (scaffold, split_number, start, end) decides which scaffolds / splits are profiled
+    (profile_controller.py:415-433); without it every reference of the BAM that has a sequence is;
+  * `sR2M` (scaffold -> {pair: mm} or set of pairs, controller.py:274-281) decides which read pairs count and
+    with which mm; without it the built-in read filter (filter_reads.py) runs with the flags in kwargs;
+  * a scaffold that cannot be profiled (not in the BAM, no / wrong sequence, a failing batch) is logged with the
+    reference's "SplitException" line and dropped -- the others go on (profile_utilities.py:100-111, 154-156).
+"""
 import logging
 import time
 import traceback
@@ -8,8 +18,9 @@ import traceback
 import numpy as np
 import pandas as pd
 
+from .. import dist as idist
 from .. import engine
-from .snv_utilities import C2P, CLASSES, null_model_lut
+from .snv_utilities import CLASSES, null_model_lut
 
 BASES = np.array(["A", "C", "T", "G", "N"])
 LD_COLUMNS = ['r2', 'd_prime', 'r2_normalized', 'd_prime_normalized', 'total', 'countAB', 'countAb', 'countaB',
@@ -17,101 +28,271 @@ LD_COLUMNS = ['r2', 'd_prime', 'r2_normalized', 'd_prime_normalized', 'total', '
               'mm', 'scaffold']          # linkage.py:230-249 + calculate_ld :67-71
 SNP_COLUMNS = ['scaffold', 'position', 'ref_base', 'A', 'C', 'T', 'G', 'con_base', 'var_base', 'mm',
                'allele_count', 'class', 'cryptic', 'position_coverage']   # snv_utilities.py:118-127, 274-290
+COVERAGE_COLUMNS = ['scaffold', 'length', 'breadth', 'coverage', 'coverage_median', 'coverage_std', 'coverage_SEM',
+                    'nucl_diversity', 'nucl_diversity_median', 'nucl_diversity_rarefied', 'nucl_diversity_rarefied_median',
+                    'breadth_minCov', 'breadth_rarefied', 'breadth_expected', 'divergent_site_count', 'SNS_count',
+                    'SNV_count', 'consensus_divergent_sites', 'population_divergent_sites', 'conANI_reference',
+                    'popANI_reference', 'mm']
+
+
+def iterate_splits(sLen, window_length=10000):
+    """fasta.py:56-73"""
+    from ..synth import iterate_splits as it
+    return it(sLen, window_length)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# result carriers
+# ---------------------------------------------------------------------------------------------------------
+def _own(a):
+    """a numpy array that stays valid after the pipe slot it may point into is released"""
+    return a if (a.flags.owndata or isinstance(a.base, np.ndarray) and a.base.flags.owndata) else np.array(a)
+
+
+class _BatchTables:
+    """The tables of one device batch, cut per split on demand (shrink_basewise / generate_snp_table /
+    calculate_ld outputs of every split of the batch).  Built once per batch from numpy arrays; the pandas
+    objects of a split are only made when somebody reads them."""
+
+    def __init__(self, res, split_bounds, split_scaffold, scaffold_offset):
+        self.bounds = np.asarray(split_bounds, dtype=np.int64)
+        self.scaffold = split_scaffold
+        self.offset = np.asarray(scaffold_offset, dtype=np.int64)
+        self.snv, self.ld = _own(res["snv"]), _own(res["ld"])
+        self.s_cut = np.searchsorted(self.snv["gpos"], self.bounds)
+        self.l_cut = np.searchsorted(self.ld["gpos_a"], self.bounds)
+        if "entries" in res:                        # mm profiling on: (position, mm) entries
+            self.entries = res["entries"]
+            self.e_cut = np.searchsorted(self.entries["gpos"], self.bounds)
+        else:                                       # one mm bin: coverage per position, clonality, sparse clonTR
+            self.entries = None
+            if "cov16" in res and not res.get("n_saturated"):
+                self.cov = _own(res["cov16"])
+            else:
+                self.cov = res["counts"].sum(axis=1, dtype=np.int64)
+            self.clon = _own(res["clon"])
+            if "rare" in res:
+                self.rare_pos = res["rare"]["gpos"].astype(np.int64)
+                self.rare_val = np.array(res["rare"]["clon_rarefied"])
+            else:
+                k = np.flatnonzero(~np.isnan(res["clon_r"]))
+                self.rare_pos, self.rare_val = k.astype(np.int64), np.array(res["clon_r"][k])
+            self.r_cut = np.searchsorted(self.rare_pos, self.bounds)
+        self.pileup_counts = _own(res["counts"]) if "counts" in res and self.entries is None else None
+
+    # -- shrink_basewise (profile_utilities.py:337-350): dict mm -> sparse Series; a level that occurs in the split keeps
+    #    its key even when its Series is empty (the reference deletes nothing but zeros / NaNs) --
+    def _by_mm(self, pos, mm, val, dtype, all_mm):
+        out = {int(m): pd.Series(np.zeros(0, dtype=dtype), index=np.zeros(0, dtype=np.int64)) for m in all_mm}
+        if len(pos):
+            order = np.lexsort((pos, mm))
+            pos, mm, val = pos[order], mm[order], val[order]
+            cuts = np.flatnonzero(np.diff(mm)) + 1
+            for s, e in zip(np.r_[0, cuts], np.r_[cuts, len(mm)]):
+                out[int(mm[s])] = pd.Series(val[s:e].astype(dtype), index=pos[s:e].astype(np.int64))
+        return out
+
+    def basewise(self, i):
+        """-> covT, clonT, clonTR of split i"""
+        off = self.offset[i]
+        if self.entries is not None:
+            ee = self.entries[self.e_cut[i]:self.e_cut[i + 1]]
+            pos = ee["gpos"].astype(np.int64) - off
+            all_mm = np.unique(ee["mm"])
+            lvl = ee["cnt"].sum(axis=1)
+            k = lvl > 0
+            covT = self._by_mm(pos[k], ee["mm"][k], lvl[k], "int32", all_mm)
+            k = ~np.isnan(ee["clon"])
+            clonT = self._by_mm(pos[k], ee["mm"][k], ee["clon"][k], "float32", all_mm)
+            k = ~np.isnan(ee["clon_rarefied"])
+            clonTR = self._by_mm(pos[k], ee["mm"][k], ee["clon_rarefied"][k], "float32", all_mm)
+            return covT, clonT, clonTR
+        s, e = int(self.bounds[i]), int(self.bounds[i + 1])
+        cov = self.cov[s:e]
+        k = np.flatnonzero(cov)
+        if len(k) == 0:
+            return {}, {}, {}                       # no read reached the split: no mm level was ever created
+        covT = {0: pd.Series(cov[k].astype("int32"), index=k + (s - off))}
+        cl = self.clon[s:e]
+        k = np.flatnonzero(~np.isnan(cl))
+        clonT = {0: pd.Series(cl[k].astype("float32"), index=k + (s - off))}
+        r0, r1 = self.r_cut[i], self.r_cut[i + 1]
+        clonTR = {0: pd.Series(self.rare_val[r0:r1].astype("float32"), index=self.rare_pos[r0:r1] - off)}
+        return covT, clonT, clonTR
+
+    def snp_table(self, i):
+        snv = self.snv[self.s_cut[i]:self.s_cut[i + 1]]
+        if not len(snv):
+            return pd.DataFrame()
+        cnt = snv["cnt"].astype(np.int64)
+        return pd.DataFrame({
+            'scaffold': self.scaffold[i], 'position': snv["gpos"].astype(np.int64) - self.offset[i],
+            'ref_base': BASES[snv["ref_base"]], 'A': cnt[:, 0], 'C': cnt[:, 1], 'T': cnt[:, 2], 'G': cnt[:, 3],
+            'con_base': BASES[snv["con_base"]], 'var_base': BASES[snv["var_base"]], 'mm': snv["mm"].astype(np.int64),
+            'allele_count': snv["allele_count"].astype(np.int64), 'class': np.array(CLASSES)[snv["cls"]],
+            'cryptic': snv["cryptic"].astype(bool), 'position_coverage': cnt.sum(axis=1)}, columns=SNP_COLUMNS)
+
+    def linkage_table(self, i):
+        ld = self.ld[self.l_cut[i]:self.l_cut[i + 1]]
+        if not len(ld):
+            return pd.DataFrame()
+        pa = ld["gpos_a"].astype(np.int64) - self.offset[i]
+        pb = ld["gpos_b"].astype(np.int64) - self.offset[i]
+        return pd.DataFrame({
+            'r2': ld["r2"], 'd_prime': ld["d_prime"], 'r2_normalized': ld["r2_normalized"],
+            'd_prime_normalized': ld["d_prime_normalized"], 'total': ld["total"].astype(np.int64),
+            'countAB': ld["countAB"].astype(np.int64), 'countAb': ld["countAb"].astype(np.int64),
+            'countaB': ld["countaB"].astype(np.int64), 'countab': ld["countab"].astype(np.int64),
+            'allele_A': BASES[ld["allele_A"]], 'allele_a': BASES[ld["allele_a"]], 'allele_B': BASES[ld["allele_B"]],
+            'allele_b': BASES[ld["allele_b"]], 'distance': np.abs(pb - pa), 'position_A': pa, 'position_B': pb,
+            'mm': ld["mm"].astype(np.int64), 'scaffold': self.scaffold[i]}, columns=LD_COLUMNS)
 
 
 class SplitObject():
-    '''Holds the profile of an individual split (same attributes as the reference's SplitObject).'''
+    '''Holds the profile of an individual split (same attributes as the reference's SplitObject,
+    profile_utilities.py:823-858).  covT / clonT / clonTR / raw_snp_table / raw_linkage_table are cut out of the
+    batch's tables the first time they are read.'''
+    _LAZY = ('covT', 'clonT', 'clonTR', 'raw_snp_table', 'raw_linkage_table', 'pileup_counts')
 
     def __init__(self):
         pass
 
+    def __getattr__(self, name):                    # only reached when the attribute is not set yet
+        src = self.__dict__.get('_src')
+        if src is None or name not in SplitObject._LAZY:
+            raise AttributeError(name)
+        tables, i = src
+        if name in ('covT', 'clonT', 'clonTR'):
+            self.covT, self.clonT, self.clonTR = tables.basewise(i)
+        elif name == 'raw_snp_table':
+            self.raw_snp_table = tables.snp_table(i)
+        elif name == 'raw_linkage_table':
+            self.raw_linkage_table = tables.linkage_table(i)
+        elif name == 'pileup_counts':               # --store_everything (profile_utilities.py:205-211)
+            if tables.pileup_counts is None:
+                raise AttributeError(name)
+            self.pileup_counts = tables.pileup_counts[int(tables.bounds[i]):int(tables.bounds[i + 1])].astype(np.int64)
+        return self.__dict__[name]
 
-def _series_by_mm(pos, mm, val, dtype):
-    """shrink_basewise (profile_utilities.py:337-350): dict mm -> sparse pd.Series indexed by position"""
-    out = {}
-    if len(pos) == 0:
-        return out
-    order = np.lexsort((pos, mm))
-    pos, mm, val = pos[order], mm[order], val[order]
-    cuts = np.flatnonzero(np.diff(mm)) + 1
-    for s, e in zip(np.r_[0, cuts], np.r_[cuts, len(mm)]):
-        out[int(mm[s])] = pd.Series(val[s:e].astype(dtype), index=pos[s:e].astype(np.int64))
-    return out
+    def materialize(self):
+        for a in ('covT', 'raw_snp_table', 'raw_linkage_table'):
+            getattr(self, a)
+        self.__dict__.pop('_src', None)
+        return self
+
+    def merge_single_profile(self, ScaffoldSplitObject):
+        '''Convert self into a scaffold_profile object (profile_utilities.py:831-858)'''
+        Sprofile = _scaffold_profile_class()()
+        Sprofile.scaffold = self.scaffold
+        Sprofile.null_model = ScaffoldSplitObject.null_model
+        Sprofile.bam = self.bam
+        Sprofile.length = self.length
+        Sprofile.raw_snp_table = self.raw_snp_table
+        Sprofile.raw_linkage_table = self.raw_linkage_table
+        Sprofile.covT = self.covT
+        Sprofile.clonT = self.clonT
+        Sprofile.clonTR = self.clonTR
+        Sprofile.min_freq = self.min_freq
+        for att in ['read_to_snvs', 'mm_to_position_graph', 'pileup_counts'] + ['profile_genes', 'gene_database', 'gene2sequence']:
+            if att in self.__dict__ or (att == 'pileup_counts' and hasattr(self, att)):
+                setattr(Sprofile, att, getattr(self, att))
+        for att in ['profile_genes', 'gene_database', 'gene2sequence']:
+            if hasattr(ScaffoldSplitObject, att):
+                setattr(Sprofile, att, getattr(ScaffoldSplitObject, att))
+        Sprofile.make_cumulative_tables()
+        return Sprofile
 
 
-def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_offset, split_seq_len, min_freq,
-                     bam_name=None):
-    """Batch result (engine.Batch.fetch()) -> list of SplitObject, one per split, in split order."""
-    if "entries" in res:
-        e = res["entries"]
-        clon_r = res["clon_r"]
+def _scaffold_profile_class():
+    """inside the reference's process its own scaffold_profile is used (the merge worker and everything after it
+    expect that class); standalone, the mirror below"""
+    try:
+        from inStrain.profile.profile_utilities import scaffold_profile as ref_cls
+        return ref_cls
+    except Exception:
+        return scaffold_profile
+
+
+def merge_basewise(mm2array_list):
+    """profile_utilities.py:408-419"""
+    mms = set()
+    for d in mm2array_list:
+        mms |= set(d.keys())
+    return {mm: pd.concat([d[mm] for d in mm2array_list if mm in d], verify_integrity=True) for mm in mms}
+
+
+class scaffold_profile():
+    '''Profile of a single scaffold (profile_utilities.py:860-896): what ScaffoldSplitObject.merge assembles'''
+
+    def __init__(self, **kwargs):
+        self.version = "instrain_amd"
+
+    @classmethod
+    def from_splits(cls, splits, null_model=None):
+        """ScaffoldSplitObject.merge (profile_utilities.py:752-814) for an ordered list of SplitObjects"""
+        if len(splits) == 1:
+            class _Holder:
+                pass
+            h = _Holder()
+            h.null_model = null_model
+            P = cls()
+            S = splits[0]
+            for att in ['scaffold', 'bam', 'length', 'raw_snp_table', 'raw_linkage_table', 'covT', 'clonT', 'clonTR', 'min_freq']:
+                setattr(P, att, getattr(S, att))
+            P.null_model = null_model
+            P.make_cumulative_tables()
+            return P
+        P = cls()
+        P.null_model = null_model
+        for att in ['scaffold', 'bam', 'min_freq']:
+            vals = set(getattr(S, att) for S in splits)
+            assert len(vals) == 1, vals
+            setattr(P, att, list(vals)[0])
+        P.length = sum(S.length for S in splits)
+        for att in ['raw_snp_table', 'raw_linkage_table']:
+            setattr(P, att, pd.concat([getattr(S, att) for S in splits]).reset_index(drop=True))
+        for att in ['covT', 'clonT', 'clonTR']:
+            setattr(P, att, merge_basewise([getattr(S, att) for S in splits]))
+        P.make_cumulative_tables()
+        return P
+
+    def make_cumulative_tables(self):
+        if self.raw_snp_table is not None:
+            self.cumulative_snv_table = _parse_Sdb(_make_snp_table(self.raw_snp_table))
+        self.cumulative_scaffold_table = make_coverage_table_host(self.covT, self.clonT, self.clonTR, self.length,
+                                                                  self.scaffold, self.raw_snp_table)
+
+
+def _make_snp_table(Stable):
+    """profile_utilities.py:576-596"""
+    if Stable is not False:
+        try:
+            Sdb = pd.DataFrame(Stable)
+            Sdb['scaffold'] = Sdb['scaffold'].astype('category')
+            Sdb['con_base'] = Sdb['con_base'].astype('category')
+        except KeyError:
+            Sdb = pd.DataFrame()
     else:
-        e = engine.dense_to_entries(res["counts"], res["clon"])
-        clon_r = res["clon_r"][e["gpos"]]
-    snv, ld = res["snv"], res["ld"]
-    n = len(split_bounds) - 1
-    e_cut = np.searchsorted(e["gpos"], split_bounds)
-    s_cut = np.searchsorted(snv["gpos"], split_bounds)
-    l_cut = np.searchsorted(ld["gpos_a"], split_bounds)
-    # the two row tables are built once for the whole batch (vectorised) and cut per split
-    split_of_snv = np.searchsorted(split_bounds, snv["gpos"], side="right") - 1
-    split_of_ld = np.searchsorted(split_bounds, ld["gpos_a"], side="right") - 1
-    scaff_arr = np.asarray(split_scaffold, dtype=object)
-    off_arr = np.asarray(scaffold_offset, dtype=np.int64)
-    big_snv = pd.DataFrame({
-        'scaffold': scaff_arr[split_of_snv], 'position': snv["gpos"].astype(np.int64) - off_arr[split_of_snv],
-        'ref_base': BASES[snv["ref_base"]],
-        'A': snv["cnt"][:, 0].astype(np.int64), 'C': snv["cnt"][:, 1].astype(np.int64),
-        'T': snv["cnt"][:, 2].astype(np.int64), 'G': snv["cnt"][:, 3].astype(np.int64),
-        'con_base': BASES[snv["con_base"]], 'var_base': BASES[snv["var_base"]], 'mm': snv["mm"].astype(np.int64),
-        'allele_count': snv["allele_count"].astype(np.int64), 'class': np.array(CLASSES)[snv["cls"]],
-        'cryptic': snv["cryptic"].astype(bool), 'position_coverage': snv["cnt"].sum(axis=1).astype(np.int64),
-    }, columns=SNP_COLUMNS) if len(snv) else None
-    if len(ld):
-        pa = ld["gpos_a"].astype(np.int64) - off_arr[split_of_ld]
-        pb = ld["gpos_b"].astype(np.int64) - off_arr[split_of_ld]
-        big_ld = pd.DataFrame({
-            'r2': ld["r2"], 'd_prime': ld["d_prime"], 'r2_normalized': ld["r2_normalized"],
-            'd_prime_normalized': ld["d_prime_normalized"],
-            'total': ld["total"].astype(np.int64), 'countAB': ld["countAB"].astype(np.int64),
-            'countAb': ld["countAb"].astype(np.int64), 'countaB': ld["countaB"].astype(np.int64),
-            'countab': ld["countab"].astype(np.int64), 'allele_A': BASES[ld["allele_A"]],
-            'allele_a': BASES[ld["allele_a"]], 'allele_B': BASES[ld["allele_B"]], 'allele_b': BASES[ld["allele_b"]],
-            'distance': np.abs(pb - pa), 'position_A': pa, 'position_B': pb, 'mm': ld["mm"].astype(np.int64),
-            'scaffold': scaff_arr[split_of_ld]}, columns=LD_COLUMNS)
-    else:
-        big_ld = None
-    out = []
-    for i in range(n):
-        scaff = split_scaffold[i]
-        off = scaffold_offset[i]
-        S = SplitObject()
-        S.scaffold = scaff
-        S.split_number = int(split_number[i])
-        S.bam = bam_name
-        S.length = int(split_seq_len[i])
-        S.min_freq = min_freq
-        ee = e[e_cut[i]:e_cut[i + 1]]
-        pos = ee["gpos"].astype(np.int64) - off
-        lvl = ee["cnt"].sum(axis=1)
-        k = lvl > 0
-        S.covT = _series_by_mm(pos[k], ee["mm"][k], lvl[k], "int32")
-        k = ~np.isnan(ee["clon"])
-        S.clonT = _series_by_mm(pos[k], ee["mm"][k], ee["clon"][k], "float32")
-        rr = clon_r[e_cut[i]:e_cut[i + 1]]      # rarefied clonality: random in the reference, Philox-seeded here
-        k = ~np.isnan(rr)
-        S.clonTR = _series_by_mm(pos[k], ee["mm"][k], rr[k], "float32")
-        if s_cut[i + 1] > s_cut[i]:
-            S.raw_snp_table = big_snv.iloc[s_cut[i]:s_cut[i + 1]].reset_index(drop=True)
-        else:
-            S.raw_snp_table = pd.DataFrame()
-        if l_cut[i + 1] > l_cut[i]:
-            S.raw_linkage_table = big_ld.iloc[l_cut[i]:l_cut[i + 1]].reset_index(drop=True)
-        else:
-            S.raw_linkage_table = pd.DataFrame()
-        S.log = ""
-        out.append(S)
-    return out
+        Sdb = pd.DataFrame()
+    return Sdb
+
+
+def _parse_Sdb(sdb):
+    """profile_utilities.py:598-612: var_freq / con_freq / ref_freq (count of the base / position_coverage)"""
+    if len(sdb) == 0:
+        return sdb
+    cnt = np.stack([sdb[b].values.astype(np.float64) for b in "ACTG"], axis=1)
+    cov = sdb['position_coverage'].values.astype(np.float64)
+    col = {b: i for i, b in enumerate("ACTG")}
+    rows = np.arange(len(sdb))
+    for out, src in (('var_freq', 'var_base'), ('con_freq', 'con_base')):
+        idx = np.array([col[v] for v in sdb[src].values])
+        sdb[out] = cnt[rows, idx] / cov
+    ref = sdb['ref_base'].values
+    ok = np.array([v in col for v in ref])
+    idx = np.array([col.get(v, 0) for v in ref])
+    sdb['ref_freq'] = np.where(ok, cnt[rows, idx] / cov, np.nan)
+    return sdb
 
 
 def estimate_breadth(coverage):
@@ -120,22 +301,80 @@ def estimate_breadth(coverage):
 
 
 def calc_snps(Odb, mm):
-    """snv_utilities.py:249-272 on a raw_snp_table DataFrame"""
+    """snv_utilities.py:249-272 on a raw_snp_table: numpy pass (highest mm <= mm per position)"""
     if len(Odb) == 0:
         return [0, 0, 0, 0, 0]
-    db = Odb[Odb['mm'] <= mm].sort_values('mm').drop_duplicates(subset=['position'], keep='last')
-    return [len(db[(db['allele_count'] == 1)]), len(db[db['allele_count'] > 1]), len(db),
-            len(db[db['class'].isin(['SNS', 'con_SNV', 'pop_SNV'])]), len(db[db['class'].isin(['SNS', 'pop_SNV'])])]
+    m = Odb['mm'].values
+    k = m <= mm
+    if not k.any():
+        return [0, 0, 0, 0, 0]
+    pos, mmv = Odb['position'].values[k], m[k]
+    ac, cls = Odb['allele_count'].values[k], Odb['class'].values[k]
+    order = np.lexsort((mmv, pos))
+    last = np.r_[pos[order][1:] != pos[order][:-1], True]          # last (highest-mm) row of every position
+    sel = order[last]
+    ac, cls = ac[sel], cls[sel]
+    con = np.isin(cls, ['SNS', 'con_SNV', 'pop_SNV'])
+    pop = np.isin(cls, ['SNS', 'pop_SNV'])
+    return [int((ac == 1).sum()), int((ac > 1).sum()), int(len(sel)), int(con.sum()), int(pop.sum())]
+
+
+def make_coverage_table_host(covT, clonT, clonTR, lengt, scaff, SNPTable):
+    """make_coverage_table (profile_utilities.py:425-506) from the shrunk per-mm Series, in numpy: one row per mm key
+    of covT; coverage cumulated over levels <= mm, clonalities of the highest level <= mm per position."""
+    table = {k: [] for k in COVERAGE_COLUMNS}
+    lengt = int(lengt)
+    cov = np.zeros(lengt, dtype=np.float64)
+    cl = {}
+    clr = {}
+    snp = SNPTable if SNPTable is not None else pd.DataFrame()
+    done = set()
+    for mm in sorted(covT.keys()):
+        for m2 in sorted(k for k in covT.keys() if k <= mm and k not in done):
+            ser = covT[m2]
+            cov[ser.index.values] += ser.values
+            done.add(m2)
+        for src, dst in ((clonT, cl), (clonTR, clr)):
+            for m2 in sorted(int(k) for k in src.keys() if int(k) <= int(mm) and ('d', int(k), id(src)) not in done):
+                dst.update(src[m2].to_dict())
+                done.add(('d', m2, id(src)))
+        clons = list(cl.values())
+        Rclons = list(clr.values())
+        counted, rare = len(clons), len(Rclons)
+        SNS_count, SNV_count, div_site_count, con_snps, pop_snps = calc_snps(snp, mm)
+        table['scaffold'].append(scaff)
+        table['length'].append(lengt)
+        table['breadth'].append(np.count_nonzero(cov) / lengt)
+        table['coverage'].append(np.mean(cov))
+        table['coverage_median'].append(int(np.median(cov)))
+        table['coverage_std'].append(np.std(cov))
+        table['coverage_SEM'].append(np.std(cov, ddof=1) / np.sqrt(lengt) if lengt > 1 else np.nan)
+        for vals, a, b in ((clons, 'nucl_diversity', 'nucl_diversity_median'),
+                           (Rclons, 'nucl_diversity_rarefied', 'nucl_diversity_rarefied_median')):
+            if len(vals) > 0:
+                table[a].append(1 - np.mean(vals))
+                table[b].append(1 - np.median(vals))
+            else:
+                table[a].append(np.nan)
+                table[b].append(np.nan)
+        table['breadth_minCov'].append(counted / lengt)
+        table['breadth_rarefied'].append(rare / lengt)
+        table['breadth_expected'].append(estimate_breadth(table['coverage'][-1]))
+        table['divergent_site_count'].append(div_site_count)
+        table['SNS_count'].append(SNS_count)
+        table['SNV_count'].append(SNV_count)
+        table['consensus_divergent_sites'].append(con_snps)
+        table['population_divergent_sites'].append(pop_snps)
+        table['conANI_reference'].append((counted - con_snps) / counted if counted else 0)
+        table['popANI_reference'].append((counted - pop_snps) / counted if counted else 0)
+        table['mm'].append(mm)
+    return pd.DataFrame(table, columns=COVERAGE_COLUMNS)
 
 
 def make_coverage_table(levels, lengt, scaff, SNPTable):
     """Mirror of make_coverage_table (profile_utilities.py:425-506): `levels` = this scaffold's row of
     Batch.summarize() (device aggregates per mm); the SNV-table columns are computed here."""
-    table = {k: [] for k in ['scaffold', 'length', 'breadth', 'coverage', 'coverage_median', 'coverage_std',
-                             'coverage_SEM', 'nucl_diversity', 'nucl_diversity_median', 'nucl_diversity_rarefied',
-                             'nucl_diversity_rarefied_median', 'breadth_minCov', 'breadth_rarefied', 'breadth_expected',
-                             'divergent_site_count', 'SNS_count', 'SNV_count', 'consensus_divergent_sites',
-                             'population_divergent_sites', 'conANI_reference', 'popANI_reference', 'mm']}
+    table = {k: [] for k in COVERAGE_COLUMNS}
     n = float(lengt)
     for r in levels:
         if not r['present']:
@@ -168,7 +407,25 @@ def make_coverage_table(levels, lengt, scaff, SNPTable):
         table['conANI_reference'].append((counted - con_snps) / counted if counted else 0)
         table['popANI_reference'].append((counted - pop_snps) / counted if counted else 0)
         table['mm'].append(mm)
-    return pd.DataFrame(table)
+    return pd.DataFrame(table, columns=COVERAGE_COLUMNS)
+
+
+def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_offset, split_seq_len, min_freq,
+                     bam_name=None):
+    """Batch result (engine.Batch.fetch() / Pipe.collect()) -> list of SplitObject, one per split, in split order."""
+    tables = _BatchTables(res, split_bounds, split_scaffold, scaffold_offset)
+    out = []
+    for i in range(len(split_bounds) - 1):
+        S = SplitObject()
+        S.scaffold = split_scaffold[i]
+        S.split_number = int(split_number[i])
+        S.bam = bam_name
+        S.length = int(split_seq_len[i])
+        S.min_freq = min_freq
+        S.log = ""
+        S._src = (tables, i)
+        out.append(S)
+    return out
 
 
 def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, window_length=10000, bam_name=None,
@@ -180,7 +437,6 @@ def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, 
     kwargs as the reference's profile_split: min_cov, min_freq, min_snp, rarefied_coverage.
     Returns {"{scaffold}.{split}": SplitObject} like Sprofile_dict (profile_utilities.py:85).
     """
-    from ..synth import iterate_splits
     min_cov = int(kwargs.get('min_cov', 5))
     min_freq = float(kwargs.get('min_freq', .05))
     min_snp = int(kwargs.get('min_snp', 10))
@@ -217,43 +473,184 @@ def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, 
     return out
 
 
+def _failure_log(scaffold, split_number):
+    t = time.strftime('%m-%d %H:%M')
+    return "\n{1} DEBUG FAILURE SplitException {0} {2}\n".format(scaffold, t, split_number)   # profile_utilities.py:108-110
+
+
+def _scaffold_splits(fasta_db, name, length, window_length):
+    """(split_number, start, end) of a scaffold: fasta_db's rows when given (fasta.py:33-40), else iterate_splits"""
+    if fasta_db is not None:
+        db = fasta_db[fasta_db['scaffold'] == name].sort_values('start')
+        rows = [(int(r.split_number), int(r.start), int(r.end)) for r in db.itertuples()]
+        # _validate_splits (fasta.py:75-85): 0-based, double inclusive, covering the scaffold
+        if not rows or rows[0][1] != 0 or rows[-1][2] != length - 1 or any(a[2] + 1 != b[1] for a, b in zip(rows, rows[1:])):
+            raise ValueError("fasta_db splits of {0} do not tile [0, {1})".format(name, length))
+        return rows
+    return [(i, s, e) for i, (s, e) in enumerate(iterate_splits(length, window_length))]
+
+
 def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
     """Mirror of inStrain.profile.profile_bam (profile/__init__.py:7-18).
 
-    bam: path of a sorted BAM; kwargs: the CLI's flags (min_cov, min_freq, min_snp, min_read_ani,
-    min_mapq, max_insert_relative, min_insert, skip_mm_profiling, window_length) plus `s2s`
-    (scaffold -> upper-cased sequence, controller.py:337) and `null_model` (dict, snv_utilities.py:14-38).
-    fasta_db / sR2M are accepted for signature compatibility: split geometry and the read-pair filter
-    are recomputed by the C++ front end with the reference's rules (filter_reads.py:885-956, 201-260).
-    Returns {"scaffold.split": SplitObject}; a failing batch follows the reference's convention
-    (profile_utilities.py:104-111): the exception is logged and the splits are dropped."""
+    bam: path of a sorted BAM.  kwargs: the CLI's flags (min_cov, min_freq, min_snp, rarefied_coverage, min_read_ani,
+    min_mapq, max_insert_relative, min_insert, pairing_filter, skip_mm_profiling, window_length, store_everything)
+    plus `s2s` (scaffold -> upper-cased sequence, controller.py:337), `null_model` (dict, snv_utilities.py:14-38),
+    optionally `ctx` (an engine.Context to reuse), `device`, `scaffold_tables` (dict that receives every scaffold's
+    cumulative_scaffold_table from the device summaries), `logs` (list that receives the failure lines),
+    `batch_positions` / `batch_observations` (size of a device batch).
+    Returns {"scaffold.split": SplitObject} = Sprofile_dict (profile_utilities.py:85)."""
     s2s = kwargs['s2s']
     null_model = kwargs['null_model']
-    device = int(kwargs.get('device', 0))
-    t = time.strftime('%m-%d %H:%M')
+    logs = kwargs.get('logs')
+    W = int(kwargs.get('window_length', 10000))
+    skip_mm = bool(kwargs.get('skip_mm_profiling', False))
+    min_freq = float(kwargs.get('min_freq', .05))
+    store_everything = bool(kwargs.get('store_everything', False))
+    out = {}
+
+    def fail(scaffold, split_numbers, exc=None):
+        if exc is not None:
+            print(exc)
+            traceback.print_exc()
+        for n in split_numbers:
+            line = _failure_log(scaffold, n)
+            logging.error(line)
+            if logs is not None:
+                logs.append(line)
+
+    own_ctx = kwargs.get('ctx') is None
+    ctx = bf = pipe = None
     try:
-        ctx = kwargs.get('ctx') or engine.Context(device)
-        bf = engine.BamFile(bam)
-        obs, pair, bounds, sref = bf.expand(min_read_ani=kwargs.get('min_read_ani', 0.95),
-                                            min_mapq=kwargs.get('min_mapq', -1),
-                                            max_insert_relative=kwargs.get('max_insert_relative', 3),
-                                            min_insert=kwargs.get('min_insert', 50),
-                                            skip_mm=bool(kwargs.get('skip_mm_profiling', False)),
-                                            window_length=int(kwargs.get('window_length', 10000)), copy=False)
+        ctx = kwargs.get('ctx') or engine.Context(int(kwargs.get('device', 0)))
+        lut, fb = null_model_lut(null_model)
+        ctx.set_null_model(lut, fb)
+        bf = engine.BamFile(bam, threads=int(kwargs.get('host_threads', 0)))
         refs = bf.refs()
-        names = [r[0] for r in refs]
-        for n, ln, _ in refs:
-            if n not in s2s or len(s2s[n]) != ln:
-                raise ValueError("scaffold {0} is not in the .fasta / length differs from the .bam header".format(n))
-        n_mm = bf.info["max_mm"] + 1
-        kw = {k: v for k, v in kwargs.items() if k in ('min_cov', 'min_freq', 'min_snp', 'rarefied_coverage', 'scaffold_tables', 'seed')}
-        try:                # obs / pair are views of the front end's arrays: keep it open until the batch is built
-            return profile_splits(ctx, names, [str(s2s[n]).upper() for n in names], obs, pair, null_model, n_mm,
-                                  window_length=int(kwargs.get('window_length', 10000)), bam_name=bam, **kw)
-        finally:
-            bf.close()
+        tid_of = {n: i for i, (n, _, _) in enumerate(refs)}
+        wanted = list(dict.fromkeys(fasta_db['scaffold'])) if fasta_db is not None else [n for n, _, _ in refs if n in s2s]
+        # ---- which scaffolds can be profiled at all ----
+        plan = []                                    # (tid, name, [(split_number, start, end)])
+        for name in wanted:
+            try:
+                if name not in tid_of:               # samfile.pileup raises ValueError -> (None, log) (profile_utilities.py:154-156)
+                    raise ValueError("scaffold {0} is not in the .bam file {1}!".format(name, bam))
+                ln = refs[tid_of[name]][1]
+                if name not in s2s or len(s2s[name]) != ln:
+                    raise ValueError("scaffold {0} has no sequence / its length differs from the .bam header".format(name))
+                plan.append((tid_of[name], name, _scaffold_splits(fasta_db, name, ln, W)))
+            except Exception as e:
+                n_splits = len(fasta_db[fasta_db['scaffold'] == name]) if fasta_db is not None else 1
+                fail(name, range(n_splits), e)
+        plan.sort()                                  # file order: the record stream stays position-clustered
+        if not plan:
+            return out
+        # ---- read pairs: the controller's R2M, or the built-in filter ----
+        bf.scan()
+        fkw = dict(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
+                   max_insert_relative=kwargs.get('max_insert_relative', 3), min_insert=kwargs.get('min_insert', 50),
+                   pairing_filter=kwargs.get('pairing_filter', 'paired_only'))
+        ekw = dict(fkw, skip_mm=skip_mm, window_length=W)
+        if sR2M is None:
+            if kwargs.get('priority_reads'):
+                bf.set_priority_reads(kwargs['priority_reads'])
+            bf.filter(**fkw)
+        else:
+            for tid, name, _ in plan:
+                r2m = sR2M.get(name, {})
+                if isinstance(r2m, (set, frozenset, list, tuple)):       # --skip_mm_profiling: a set of pair names
+                    bf.set_r2m(tid, list(r2m), None)
+                else:
+                    bf.set_r2m(tid, list(r2m.keys()), [0 if skip_mm else int(v) for v in r2m.values()])
+        info = dict(bf.info) if bf.info else {}
+        n_mm = 1 if skip_mm else int(bf.info["max_mm"]) + 1
+        if 's2p' in kwargs and isinstance(kwargs['s2p'], dict):
+            pass
+        reads_per_ref, pairs_per_ref = bf.ref_counts()
+        bf.drop_names()
+        # ---- batches of whole scaffolds under a position / observation budget ----
+        mean_pair = (info.get("filtered_bases", 0) / info["filtered_pairs"]) if info.get("filtered_pairs") else 300.0
+        est_obs = [int(pairs_per_ref[tid] * mean_pair) + 1024 for tid, _, _ in plan]
+        max_pos = int(kwargs.get('batch_positions', 64_000_000))
+        max_obs = int(kwargs.get('batch_observations', 256_000_000))
+        groups = idist.pack_batches([refs[tid][1] for tid, _, _ in plan], est_obs, max_pos, max_obs)
+
+        def run_group(items, depth_hint):
+            """one batch through expand -> device -> SplitObjects; raises on failure"""
+            nonlocal pipe
+            tids = [plan[k][0] for k in items]
+            obs, pair, _, _ = bf.expand_refs(tids, copy=False, **ekw)
+            bounds, s_scaff, s_num, s_off, s_len, seqs = [], [], [], [], [], []
+            off = 0
+            for k in items:
+                tid, name, splits = plan[k]
+                for (num, s, e) in splits:
+                    bounds.append(off + s)
+                    s_scaff.append(name); s_num.append(num); s_off.append(off); s_len.append(e - s + 1)
+                seqs.append(engine.encode_seq(str(s2s[name]).upper()))
+                off += refs[tid][1]
+            bounds.append(off)
+            ref = np.concatenate(seqs) if len(seqs) > 1 else seqs[0]
+            need = (off, len(obs), len(bounds))
+            if pipe is None or need[0] > pipe.cap[0] or need[1] > pipe.cap[1] or need[2] > pipe.cap[2]:
+                if pipe is not None:
+                    pipe.close()
+                cap = (max(need[0], min(max_pos, 1 << 16)), max(need[1], 1 << 16), max(need[2], 64))
+                pipe = engine.Pipe(ctx, max_pos=cap[0], max_obs=cap[1], max_splits=cap[2], depth=1,
+                                   host_threads=int(kwargs.get('host_threads', 0)), pin_threads=False, jump_slack=0.5,
+                                   min_cov=int(kwargs.get('min_cov', 5)), min_freq=min_freq, min_snp=int(kwargs.get('min_snp', 10)),
+                                   rarefied_coverage=int(kwargs.get('rarefied_coverage', 5)), n_mm_bins=n_mm,
+                                   enable_linkage=True, seed=int(kwargs.get('seed', 0)), want_counts=store_everything)
+                pipe.cap = cap
+            t = pipe.submit(ref, bounds, obs, pair)
+            try:
+                res = pipe.collect(t)
+                if res.get("n_saturated"):           # coverage beyond the 16-bit hand-back: take the exact counts
+                    full = res["slot"].fetch()
+                    res["counts"] = full["counts"]
+                splits = tables_to_splits(res, np.asarray(bounds), s_scaff, s_num, s_off, s_len, min_freq, bam)
+                if kwargs.get('scaffold_tables') is not None:
+                    sb = np.r_[0, np.cumsum([refs[plan[k][0]][1] for k in items])]
+                    levels, _ = res["slot"].summarize(sb)
+                    for j, k in enumerate(items):
+                        name = plan[k][1]
+                        snp = [S.raw_snp_table for S in splits if S.scaffold == name and len(S.raw_snp_table)]
+                        snp = pd.concat(snp) if snp else pd.DataFrame()
+                        kwargs['scaffold_tables'][name] = make_coverage_table(levels[j], refs[plan[k][0]][1], name, snp)
+            finally:
+                pipe.release(t)
+            return splits
+
+        for items in groups:
+            try:
+                for S in run_group(items, len(groups)):
+                    out["{0}.{1}".format(S.scaffold, S.split_number)] = S
+            except Exception as e:
+                if len(items) == 1:
+                    fail(plan[items[0]][1], [s[0] for s in plan[items[0]][2]], e)
+                    continue
+                print(e)
+                traceback.print_exc()
+                for k in items:                      # find the scaffold that breaks the batch: the others still count
+                    try:
+                        for S in run_group([k], 1):
+                            out["{0}.{1}".format(S.scaffold, S.split_number)] = S
+                    except Exception as e2:
+                        fail(plan[k][1], [s[0] for s in plan[k][2]], e2)
+        return out
     except Exception as e:
         print(e)
         traceback.print_exc()
-        logging.error("\n{1} DEBUG FAILURE SplitException {0} batch\n".format(bam, t))
-        return {}
+        t = time.strftime('%m-%d %H:%M')
+        line = "\n{1} DEBUG FAILURE SplitException {0} batch\n".format(bam, t)
+        logging.error(line)
+        if logs is not None:
+            logs.append(line)
+        return out
+    finally:
+        if pipe is not None:
+            pipe.close()
+        if bf is not None:
+            bf.close()
+        if own_ctx and ctx is not None:
+            ctx.close()

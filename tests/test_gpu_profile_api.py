@@ -81,13 +81,151 @@ def test_coverage_summary_equals_stored_cumulative_table(sars_profile):
 
 
 def test_missing_scaffold_follows_failure_convention():
-    """like test_profile_17 / profile_utilities.py:104-111: a failing batch is logged and dropped"""
+    """like test_profile_17 / profile_utilities.py:104-111, 154-156: a scaffold that cannot be profiled is logged with
+    the reference's SplitException line and dropped"""
     import instrain_amd.profile as prof
     lut, fb = util.load_lut()
     model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
     model[-1] = fb
-    out = prof.profile_bam(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"), s2s={"other": "ACGT"}, null_model=model)
-    assert out == {}
+    logs = []
+    fdb = pd.DataFrame({"scaffold": ["other"], "split_number": [0], "start": [0], "end": [3]})
+    out = prof.profile_bam(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"), fdb, None, None, s2s={"other": "ACGT"},
+                           null_model=model, logs=logs)
+    assert out == {} and len(logs) == 1 and "FAILURE SplitException other 0" in logs[0]
+
+
+def _messy(tmp_path, seed=9, n_pairs=4000):
+    from tests import bamwriter
+    refs = [("scafA", 2500), ("scafB", 700), ("scafC", 3100), ("scafD", 1500)]
+    rng = np.random.Generator(np.random.PCG64(77))
+    seqs = {n: "".join(rng.choice(list("ACGT"), ln)) for n, ln in refs}
+    path = str(tmp_path / "messy.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(seed, refs, n_pairs))
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    return refs, seqs, path, model
+
+
+def _same_split(a, b):
+    for att in ("scaffold", "split_number", "length"):
+        assert getattr(a, att) == getattr(b, att)
+    for att in ("raw_snp_table", "raw_linkage_table"):
+        x, y = getattr(a, att), getattr(b, att)
+        assert len(x) == len(y)
+        if len(x):
+            cols = [c for c in x.columns if not c.endswith("_normalized")]
+            pd.testing.assert_frame_equal(x[cols].reset_index(drop=True), y[cols].reset_index(drop=True))
+    for att in ("covT", "clonT"):
+        x, y = getattr(a, att), getattr(b, att)
+        assert sorted(x) == sorted(y), att
+        for m in x:
+            pd.testing.assert_series_equal(x[m], y[m])
+
+
+def test_profile_bam_honours_fasta_db_and_per_scaffold_failures(tmp_path):
+    """fasta_db picks the scaffolds and their splits (profile_controller.py:415-433); a scaffold without a usable sequence
+    is dropped with its SplitException lines while the others are profiled (profile_utilities.py:100-111); small batch
+    budgets cut the run into several device batches with identical results"""
+    import instrain_amd.profile as prof
+    refs, seqs, path, model = _messy(tmp_path)
+    kw = dict(null_model=model, min_cov=5, min_freq=0.05, min_snp=10, min_read_ani=0.9, window_length=1000)
+    full = prof.profile_bam(path, s2s=seqs, **kw)
+    assert len(full) == sum(ln // 1000 + 1 for _, ln in refs)
+    # (a) subset + custom splits of scafC (two uneven splits instead of iterate_splits' four)
+    fdb = pd.DataFrame({"scaffold": ["scafA"] * 3 + ["scafC"] * 2, "split_number": [0, 1, 2, 0, 1],
+                        "start": [0, 833, 1666, 0, 1000], "end": [832, 1665, 2499, 999, 3099]})
+    sub = prof.profile_bam(path, fdb, None, None, s2s=seqs, **kw)
+    assert sorted(sub) == ["scafA.0", "scafA.1", "scafA.2", "scafC.0", "scafC.1"]
+    for k in ("scafA.0", "scafA.1", "scafA.2"):
+        _same_split(sub[k], full[k])
+    assert sub["scafC.1"].length == 2100
+    n_full = sum(len(full["scafC.%d" % i].raw_snp_table) for i in range(4))
+    assert len(sub["scafC.0"].raw_snp_table) + len(sub["scafC.1"].raw_snp_table) == n_full        # SNV rows do not depend on the cut
+    cov_full = sum(int(s.sum()) for i in range(4) for s in full["scafC.%d" % i].covT.values())
+    assert sum(int(s.sum()) for i in range(2) for s in sub["scafC.%d" % i].covT.values()) == cov_full
+    # (b) scafB has no sequence, scafD's differs in length: both dropped with their lines, A and C unaffected
+    logs = []
+    bad = dict(seqs)
+    del bad["scafB"]
+    bad["scafD"] = bad["scafD"][:-1]
+    fdb_all = pd.DataFrame([(n, i, s, e) for n, ln in refs for i, (s, e) in enumerate(prof.profile_utilities.iterate_splits(ln, 1000))],
+                           columns=["scaffold", "split_number", "start", "end"])
+    part = prof.profile_bam(path, fdb_all, None, None, s2s=bad, logs=logs, **kw)
+    assert sorted(part) == sorted(k for k in full if k.startswith(("scafA", "scafC")))
+    assert len(logs) == 1 + 2 and sum("scafB" in l for l in logs) == 1 and sum("scafD" in l for l in logs) == 2
+    for k in part:
+        _same_split(part[k], full[k])
+    # (c) tiny budgets: one scaffold per batch, the pipe grows as needed
+    many = prof.profile_bam(path, s2s=seqs, batch_positions=3000, batch_observations=10_000, **kw)
+    assert sorted(many) == sorted(full)
+    for k in full:
+        _same_split(many[k], full[k])
+
+
+def test_profile_bam_honours_the_controllers_r2m(tmp_path):
+    """sR2M as the controller hands it over (controller.py:274-281): the built-in filter's own R2M gives the same
+    profile; a reduced / re-levelled R2M gives exactly the profile of those read pairs; sets mean skip_mm_profiling"""
+    import instrain_amd.profile as prof
+    from instrain_amd import engine
+    from oracle import bam_py, oracle
+    from tests.test_oracle_golden import iterate_splits
+    refs, seqs, path, model = _messy(tmp_path, seed=12)
+    lut, fb = util.load_lut()
+    kw = dict(null_model=model, min_cov=5, min_freq=0.05, min_snp=10, window_length=1000)
+    full = prof.profile_bam(path, s2s=seqs, min_read_ani=0.9, **kw)
+    bam = engine.BamFile(path)
+    bam.scan(); bam.filter(min_read_ani=0.9)
+    r2m = {name: bam.r2m(t) for t, (name, _, _) in enumerate(bam.refs())}
+    bam.close()
+    same = prof.profile_bam(path, None, r2m, None, s2s=seqs, **kw)
+    assert sorted(same) == sorted(full)
+    for k in full:
+        _same_split(same[k], full[k])
+    # half of scafC's pairs, every mm + 1, nothing on the other scaffolds -> oracle on exactly those pairs
+    keep = {n: m + 1 for n, m in list(r2m["scafC"].items())[::2]}
+    fdb = pd.DataFrame([("scafC", i, s, e) for i, (s, e) in enumerate(iterate_splits(3100, 1000))],
+                       columns=["scaffold", "split_number", "start", "end"])
+    got = prof.profile_bam(path, fdb, {"scafC": keep}, None, s2s=seqs, **kw)
+    rrefs, rr = bam_py.read_bam(path)
+    bam_py.resolve_overlaps(rr, 2)
+    pos, base, mm, pr, _ = bam_py.expand_observations(rr, 2, keep, ref_len=3100)
+    n_rows = 0
+    for i, (s, e) in enumerate(iterate_splits(3100, 1000)):
+        exp = oracle.profile_split(pos, base, mm, pr, seqs["scafC"][s:e + 1], s, lut, fb, min_cov=5, min_freq=0.05, min_snp=10)
+        S = got["scafC.%d" % i]
+        o = np.lexsort((exp["snv"]["mm"], exp["snv"]["pos"]))
+        es = exp["snv"][o]
+        g = S.raw_snp_table.sort_values(["position", "mm"]) if len(S.raw_snp_table) else S.raw_snp_table
+        assert len(g) == len(es)
+        if len(es):
+            assert (g["position"].values == es["pos"]).all() and (g["mm"].values == es["mm"]).all()
+            assert (g[["A", "C", "T", "G"]].values == es["cnt"]).all()
+        lv = exp["entries"]["cnt"].sum(axis=1)
+        for m in set(int(x) for x in exp["entries"]["mm"]):
+            k = (exp["entries"]["mm"] == m) & (lv > 0)
+            ser = S.covT[m].sort_index()
+            assert (ser.index.values == np.sort(exp["entries"]["pos"][k])).all()
+        assert min(S.covT) >= 1                                # every level was raised by one
+        n_rows += len(es)
+    assert n_rows > 10
+    # a set of names = --skip_mm_profiling
+    got = prof.profile_bam(path, fdb, {"scafC": set(keep)}, None, s2s=seqs, skip_mm_profiling=True, **kw)
+    assert all(list(S.covT) == [0] for S in got.values())
+    tot = sum(int(S.covT[0].sum()) for S in got.values())
+    assert tot == int((base < 4).sum()) or tot == len(pos) - int((base >= 4).sum())
+
+
+def test_store_everything_keeps_the_count_table(tmp_path):
+    import instrain_amd.profile as prof
+    refs, seqs, path, model = _messy(tmp_path, seed=13, n_pairs=1500)
+    S = prof.profile_bam(path, s2s=seqs, null_model=model, min_read_ani=0.9, window_length=1000, skip_mm_profiling=True,
+                         store_everything=True)["scafA.1"]
+    pc = S.pileup_counts                                       # profile_utilities.py:205-211
+    assert pc.shape == (S.length, 4)
+    cov = pc.sum(axis=1)
+    ser = S.covT[0]
+    assert (cov[ser.index.values - 833] == ser.values).all() and (cov > 0).sum() == len(ser)
 
 
 def test_device_coverage_table_equals_stored_golden():
