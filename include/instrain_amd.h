@@ -55,6 +55,9 @@ extern "C" {
 
 typedef struct isx_ctx isx_ctx;
 typedef struct isx_batch isx_batch;
+typedef struct isx_bam isx_bam;                /* host BAM front end, see the end of this header */
+struct isx_bam_params_s;
+struct isx_bam_info_s;
 
 /* One packed pileup observation = one (pileup column, pileup read) visit on which the
  * reference touches its count table.  8 bytes. */
@@ -334,6 +337,13 @@ void isx_pipe_destroy(isx_pipe *p);
 /* same arguments as isx_batch_create */
 int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
                     int64_t n_obs, const isx_obs *obs, const uint32_t *pair, int64_t *ticket);
+/* The same, fed by the BAM front end (isx_bam_* below; the file must be scanned and filtered): references `refs`
+ * (ascending ids) are expanded straight into the slot's pinned staging -- the 8-byte records of the batch never
+ * exist as a whole.  split_bounds == NULL: the front end's own iterate_splits geometry.  ref[n_pos] = base codes of
+ * the batch's references laid end to end.  info (may be NULL) receives the batch's counts. */
+int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s *bp, const int32_t *refs, int32_t n_refs,
+                        const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds, struct isx_bam_info_s *info,
+                        int64_t *ticket);
 int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out);
 int isx_pipe_release(isx_pipe *p, int64_t ticket);
 
@@ -356,9 +366,7 @@ int isx_encode_obs(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int6
  *   isx_bam_expand_refs  samfile.pileup(...) of profile_utilities.py:150-153 for a SUBSET of the references (one
  *                        batch / one GPU's shard): only the BGZF blocks holding them are inflated again
  * isx_bam_expand = all three over the whole file. */
-typedef struct isx_bam isx_bam;
-
-typedef struct {
+typedef struct isx_bam_params_s {
     double min_read_ani;        /* -l, 0.95 */
     int32_t min_mapq;           /* -1 */
     double max_insert_relative; /* 3 */
@@ -369,7 +377,7 @@ typedef struct {
     int32_t pairing_filter;     /* 0 paired_only (default), 1 non_discordant, 2 all_reads (filter_reads.py:499-525) */
 } isx_bam_params;
 
-typedef struct {
+typedef struct isx_bam_info_s {
     int32_t n_refs;             /* references of the file (scan / filter) or of the batch (expand) */
     int32_t n_splits;
     int64_t n_reads;

@@ -1045,9 +1045,87 @@ int isx_bam_ref_counts(const isx_bam *bam, int64_t *reads, int64_t *filtered_pai
 }
 
 // ---- pass 2: overlap resolution + expansion of a subset of the references ----
-int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info)
+}  // extern "C"
+
+// A batch of references loaded, overlap-resolved and counted: any range of its observation stream can then be
+// produced on demand (isx_bam_expand_refs writes all of it into the handle; isx_pipe_submit_bam lets the pipe's
+// encoder pull it group by group, so the 8-byte records of a batch never exist as a whole).
+struct BamBatch {
+    isx_bam *B = nullptr;
+    isx_bam_params prm{};
+    Batch S;
+    std::vector<uint8_t> emit;
+    std::vector<uint32_t> pid;              // dense pair id per read
+    std::vector<uint64_t> out_at;           // [n_reads + 1] first observation of every read
+    std::vector<int64_t> boff;              // per reference of the file: offset in the batch's flat space, -1 = not in the batch
+    int64_t n_pos = 0;
+    uint32_t next_pair = 0;
+    uint8_t minq = 30;
+    std::vector<int64_t> split_bounds;
+    std::vector<int32_t> split_ref;
+
+    // observations [skip, skip + limit) of read ri -> po / pp (pp may be NULL); returns how many the read has in all when
+    // po == NULL (count only)
+    uint64_t walk(size_t ri, uint64_t skip, uint64_t limit, isx_obs *po, uint32_t *pp) const
+    {
+        const Read &r = S.reads[ri];
+        const PairInfo &pi = B->pairs[r.pair_idx];
+        const uint16_t mm = prm.skip_mm ? 0 : (uint16_t)pi.mm;
+        const int64_t base_off = boff[(size_t)r.tid];
+        const int64_t ref_len = B->ref_len[(size_t)r.tid];
+        const uint8_t *ql = S.quals.data() + r.seq_off, *sq = S.seqs.data() + r.seq_off;
+        int64_t ref = r.pos, q = 0;
+        uint64_t n_out = 0, written = 0;
+        for (int k = 0; k < r.n_cigar; k++) {
+            const uint32_t c = S.cigars[r.cigar_off + (uint64_t)k];
+            const int op = c & 15;
+            const int64_t n = c >> 4;
+            if (op == CM || op == CEQ || op == CX) {
+                // the reference's pileups are truncated to [0, scaffold length) (profile_utilities.py:150-153)
+                const int64_t j0 = std::max<int64_t>(0, -ref), j1 = std::min<int64_t>(n, ref_len - ref);
+                const uint32_t g0 = (uint32_t)(base_off + ref);
+                for (int64_t j = j0; j < j1; j++) {
+                    if (ql[q + j] >= minq) {
+                        if (po && n_out >= skip) {
+                            if (written == limit) return n_out;
+                            isx_obs &o = po[written];
+                            o.gpos = g0 + (uint32_t)j; o.mm = mm; o.base = CODE2IDX[sq[q + j]]; o.flags = 0;
+                            if (pp) pp[written] = pid[ri];
+                            written++;
+                        }
+                        n_out++;
+                    }
+                }
+                q += n; ref += n;
+            } else if (op == CI || op == CS) q += n;
+            else if (op == CD || op == CN) ref += n;
+        }
+        return n_out;
+    }
+
+    // observations [first, first + count) of the batch's stream (thread safe)
+    void emit_range(int64_t first, uint32_t count, isx_obs *po, uint32_t *pp) const
+    {
+        size_t ri = (size_t)(std::upper_bound(out_at.begin(), out_at.end(), (uint64_t)first) - out_at.begin()) - 1;
+        uint64_t skip = (uint64_t)first - out_at[ri];
+        uint32_t done = 0;
+        while (done < count) {
+            const uint64_t have = out_at[ri + 1] - out_at[ri];
+            if (have > skip) {
+                const uint32_t take = (uint32_t)std::min<uint64_t>(count - done, have - skip);
+                walk(ri, skip, take, po + done, pp ? pp + done : nullptr);
+                done += take;
+            }
+            skip = 0;
+            ri++;
+        }
+    }
+    int64_t n_obs() const { return (int64_t)out_at.back(); }
+};
+
+int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, BamBatch **out)
 {
-    if (!bam || !p || n_refs < 0 || (n_refs && !refs)) { isx_set_error("isx_bam_expand_refs: bad argument"); return ISX_ERR_ARG; }
+    *out = nullptr;
     isx_bam &B = *bam;
     if (!B.scanned || !B.filtered) { isx_set_error("isx_bam_expand_refs: scan and filter first"); return ISX_ERR_STATE; }
     const size_t n_ref_all = B.ref_name.size();
@@ -1060,8 +1138,12 @@ int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *re
         fprintf(stderr, "[isx_bam_expand_refs] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    // flat space of the batch: its references laid end to end in the order given
-    std::vector<int64_t> boff(n_ref_all, -1);
+    std::unique_ptr<BamBatch> Q(new BamBatch());
+    Q->B = bam; Q->prm = *p;
+    Q->minq = (uint8_t)std::min(255, std::max(0, p->min_base_quality));
+    // flat space of the batch: its references laid end to end (file order)
+    std::vector<int64_t> &boff = Q->boff;
+    boff.assign(n_ref_all, -1);
     int64_t n_pos = 0;
     std::vector<uint8_t> seg_wanted(B.segs.size(), 0);
     for (int32_t i = 0; i < n_refs; i++) {
@@ -1073,6 +1155,7 @@ int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *re
             for (uint32_t s = B.ref_seg0[(size_t)t]; s <= B.ref_seg1[(size_t)t]; s++) seg_wanted[s] = 1;
     }
     if (n_pos >= (int64_t)0xFFFF0000ll) { isx_set_error("isx_bam_expand_refs: the batch's flat space must be < 2^32 - 65536 positions"); return ISX_ERR_ARG; }
+    Q->n_pos = n_pos;
     std::vector<uint32_t> seg_list;
     for (uint32_t s = 0; s < B.segs.size(); s++) if (seg_wanted[s]) seg_list.push_back(s);
 
@@ -1101,7 +1184,7 @@ int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *re
     if (rc_any.load()) { for (auto &w : sw) if (!w.err.empty()) { isx_set_error(w.err); break; } return rc_any.load(); }
     std::vector<uint64_t> r_at(sw.size() + 1, 0), c_at(sw.size() + 1, 0), s_at(sw.size() + 1, 0);
     for (size_t k = 0; k < sw.size(); k++) { r_at[k + 1] = r_at[k] + sw[k].keep.size(); c_at[k + 1] = c_at[k] + sw[k].n_cig; s_at[k + 1] = s_at[k] + sw[k].n_seq; }
-    Batch S;
+    Batch &S = Q->S;
     S.reads.resize((size_t)r_at.back());
     S.cigars.resize((size_t)c_at.back()); S.seqs.resize((size_t)s_at.back()); S.quals.resize((size_t)s_at.back());
     pool.run((int)sw.size(), [&](int k) {
@@ -1158,15 +1241,14 @@ int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *re
     }
     stage("overlap resolution");
 
-    // ---- expansion: the visits on which get_base_counts_mm touches `table` ----
-    // dense pair ids in order of first appearance (serial, one word per read); then per read the number of
-    // visits it contributes (threads), a prefix sum, and the writes (threads) -- file order is kept
-    std::vector<uint8_t> emit(n_reads, 0);
+    // ---- which reads are piled up, dense pair ids in order of first appearance (serial, one word per read), and
+    //      where every read's observations start in the stream (count per read on the threads, prefix sum) ----
+    Q->emit.assign(n_reads, 0);
     std::vector<uint64_t> slot0(n_ref_all, 0);              // the batch's pair entries, reference after reference
     uint64_t n_slots = 0;
     for (int32_t i = 0; i < n_refs; i++) { slot0[(size_t)refs[i]] = n_slots; n_slots += B.ref_pair0[(size_t)refs[i] + 1] - B.ref_pair0[(size_t)refs[i]]; }
     std::vector<uint32_t> dense((size_t)n_slots, 0xFFFFFFFFu);
-    std::vector<uint32_t> pid(n_reads, 0);
+    Q->pid.assign(n_reads, 0);
     uint32_t next_pair = 0;
     for (size_t ri = 0; ri < n_reads; ri++) {
         const Read &r = S.reads[ri];
@@ -1176,63 +1258,22 @@ int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *re
         if (!pi.pass || pi.reads == 0) continue;
         uint32_t &d = dense[(size_t)(slot0[(size_t)r.tid] + (r.pair_idx - B.ref_pair0[(size_t)r.tid]))];
         if (d == 0xFFFFFFFFu) d = next_pair++;
-        pid[ri] = d;
-        emit[ri] = 1;
+        Q->pid[ri] = d;
+        Q->emit[ri] = 1;
     }
-    const uint8_t minq = (uint8_t)std::min(255, std::max(0, p->min_base_quality));
-    std::vector<uint64_t> out_at(n_reads + 1, 0);
-    auto walk = [&](size_t ri, bool write, isx_obs *po, uint32_t *pp) -> uint64_t {
-        const Read &r = S.reads[ri];
-        const PairInfo &pi = B.pairs[r.pair_idx];
-        const uint16_t mm = p->skip_mm ? 0 : (uint16_t)pi.mm;
-        const int64_t base_off = boff[(size_t)r.tid];
-        const int64_t ref_len = B.ref_len[(size_t)r.tid];
-        const uint8_t *ql = S.quals.data() + r.seq_off, *sq = S.seqs.data() + r.seq_off;
-        int64_t ref = r.pos, q = 0;
-        uint64_t n_out = 0;
-        for (int k = 0; k < r.n_cigar; k++) {
-            const uint32_t c = S.cigars[r.cigar_off + (uint64_t)k];
-            const int op = c & 15;
-            const int64_t n = c >> 4;
-            if (op == CM || op == CEQ || op == CX) {
-                // the reference's pileups are truncated to [0, scaffold length) (profile_utilities.py:150-153)
-                const int64_t j0 = std::max<int64_t>(0, -ref), j1 = std::min<int64_t>(n, ref_len - ref);
-                const uint32_t g0 = (uint32_t)(base_off + ref);
-                for (int64_t j = j0; j < j1; j++) {
-                    if (ql[q + j] >= minq) {
-                        if (write) {
-                            isx_obs &o = po[n_out];
-                            o.gpos = g0 + (uint32_t)j; o.mm = mm; o.base = CODE2IDX[sq[q + j]]; o.flags = 0;
-                            pp[n_out] = pid[ri];
-                        }
-                        n_out++;
-                    }
-                }
-                q += n; ref += n;
-            } else if (op == CI || op == CS) q += n;
-            else if (op == CD || op == CN) ref += n;
-        }
-        return n_out;
-    };
+    Q->next_pair = next_pair;
+    Q->out_at.assign(n_reads + 1, 0);
     const int n_tasks = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n_reads / 2048 + 1));
+    BamBatch *q = Q.get();
     pool.run(n_tasks, [&](int t) {
         for (size_t ri = n_reads * (size_t)t / (size_t)n_tasks; ri < n_reads * ((size_t)t + 1) / (size_t)n_tasks; ri++)
-            if (emit[ri]) out_at[ri + 1] = walk(ri, false, nullptr, nullptr);
+            if (q->emit[ri]) q->out_at[ri + 1] = q->walk(ri, 0, 0, nullptr, nullptr);
     });
-    for (size_t ri = 0; ri < n_reads; ri++) out_at[ri + 1] += out_at[ri];
-    const size_t n_out = (size_t)out_at[n_reads];
-    if (n_out >= 0xFFFFFFFFull) { isx_set_error("isx_bam_expand_refs: more than 2^32 observations in one batch (expand fewer references at a time)"); return ISX_ERR_ARG; }
-    B.obs.reset(new isx_obs[std::max<size_t>(n_out, 1)]);
-    B.pair.reset(new uint32_t[std::max<size_t>(n_out, 1)]);
-    B.n_obs = n_out;
-    pool.run(n_tasks, [&](int t) {
-        for (size_t ri = n_reads * (size_t)t / (size_t)n_tasks; ri < n_reads * ((size_t)t + 1) / (size_t)n_tasks; ri++)
-            if (emit[ri]) walk(ri, true, B.obs.get() + out_at[ri], B.pair.get() + out_at[ri]);
-    });
-    stage("expansion");
+    for (size_t ri = 0; ri < n_reads; ri++) Q->out_at[ri + 1] += Q->out_at[ri];
+    if (Q->out_at.back() >= 0xFFFFFFFFull) { isx_set_error("isx_bam_expand_refs: more than 2^32 observations in one batch (expand fewer references at a time)"); return ISX_ERR_ARG; }
+    stage("count");
 
     // ---- iterate_splits (fasta.py:56-73) on the batch's flat space ----
-    B.split_bounds.clear(); B.split_ref.clear();
     const int64_t W = p->window_length > 0 ? p->window_length : 10000;
     for (int32_t i = 0; i < n_refs; i++) {
         const size_t t = (size_t)refs[i];
@@ -1242,22 +1283,58 @@ int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *re
         const int64_t chunk = (int64_t)((double)sLen / (double)n_chunks);
         int64_t start = 0;
         for (int64_t c = 0; c < n_chunks; c++) {
-            B.split_bounds.push_back(boff[t] + start);
-            B.split_ref.push_back((int32_t)t);
+            Q->split_bounds.push_back(boff[t] + start);
+            Q->split_ref.push_back((int32_t)t);
             if (c + 1 < n_chunks) start += chunk;
         }
     }
-    B.split_bounds.push_back(n_pos);
+    Q->split_bounds.push_back(n_pos);
+    *out = Q.release();
+    return ISX_OK;
+}
+
+void bam_batch_free(BamBatch *q) { delete q; }
+int64_t bam_batch_n_obs(const BamBatch *q) { return q->n_obs(); }
+int64_t bam_batch_n_pos(const BamBatch *q) { return q->n_pos; }
+void bam_batch_emit(const BamBatch *q, int64_t first, uint32_t count, isx_obs *obs, uint32_t *pair) { q->emit_range(first, count, obs, pair); }
+void bam_batch_info(const BamBatch *q, int32_t n_refs, isx_bam_info *info)
+{
+    *info = q->B->totals;
+    info->n_refs = n_refs;
+    info->n_splits = (int32_t)q->split_ref.size();
+    info->n_pos = q->n_pos;
+    info->n_obs = q->n_obs();
+    info->n_pairs = q->next_pair;
+    info->max_mm = q->prm.skip_mm ? 0 : q->B->totals.max_mm;
+}
+const std::vector<int64_t> &bam_batch_bounds(const BamBatch *q) { return q->split_bounds; }
+
+extern "C" {
+
+int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info)
+{
+    if (!bam || !p || n_refs < 0 || (n_refs && !refs)) { isx_set_error("isx_bam_expand_refs: bad argument"); return ISX_ERR_ARG; }
+    isx_bam &B = *bam;
+    BamBatch *q = nullptr;
+    const int rc = bam_batch_prepare(bam, p, refs, n_refs, &q);
+    if (rc != ISX_OK) return rc;
+    std::unique_ptr<BamBatch> Q(q);
+    // the whole stream into the handle (threads over contiguous pieces; file order is kept)
+    const size_t n_out = (size_t)Q->n_obs();
+    B.obs.reset(new isx_obs[std::max<size_t>(n_out, 1)]);
+    B.pair.reset(new uint32_t[std::max<size_t>(n_out, 1)]);
+    B.n_obs = n_out;
+    isxenc::HostPool &pool = pool_of(B);
+    const size_t piece = 1 << 16;
+    const int n_tasks = (int)((n_out + piece - 1) / piece);
+    pool.run(n_tasks, [&](int t) {
+        const size_t a = (size_t)t * piece, e = std::min(n_out, a + piece);
+        q->emit_range((int64_t)a, (uint32_t)(e - a), B.obs.get() + a, B.pair.get() + a);
+    });
+    B.split_bounds = Q->split_bounds;
+    B.split_ref = Q->split_ref;
     B.expanded = true;
-    if (info) {
-        *info = B.totals;
-        info->n_refs = n_refs;
-        info->n_splits = (int32_t)B.split_ref.size();
-        info->n_pos = n_pos;
-        info->n_obs = (int64_t)B.n_obs;
-        info->n_pairs = next_pair;
-        info->max_mm = p->skip_mm ? 0 : B.totals.max_mm;
-    }
+    if (info) bam_batch_info(q, n_refs, info);
     return ISX_OK;
 }
 

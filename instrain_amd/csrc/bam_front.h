@@ -1,0 +1,17 @@
+// bam_front.h -- what isx_pipe.hip needs from the BAM front end: a prepared batch of references whose observation
+// stream can be pulled range by range (see bam_front.cpp BamBatch).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/instrain_amd.h"
+
+struct BamBatch;
+int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, BamBatch **out);
+void bam_batch_free(BamBatch *q);
+int64_t bam_batch_n_obs(const BamBatch *q);
+int64_t bam_batch_n_pos(const BamBatch *q);
+void bam_batch_emit(const BamBatch *q, int64_t first, uint32_t count, isx_obs *obs, uint32_t *pair);     // thread safe
+void bam_batch_info(const BamBatch *q, int32_t n_refs, isx_bam_info *info);
+const std::vector<int64_t> &bam_batch_bounds(const BamBatch *q);

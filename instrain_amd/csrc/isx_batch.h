@@ -43,6 +43,9 @@ struct isx_batch {
     uint32_t *d_rec32 = nullptr, *d_gbase = nullptr;    // compact stream (4-byte records + one position base per 256)
     uint16_t *d_rec16 = nullptr;                        // short stream (n_mm_bins == 1: 2-byte records, base per 512)
     uint32_t *d_pair = nullptr, *d_gpos = nullptr, *d_cbase = nullptr;
+    uint2 *d_pair_runs = nullptr;       // pipe slots: pair ids as runs (PileupArgs::pair_runs) instead of d_pair
+    uint32_t *d_run_index = nullptr;
+    uint32_t n_runs = 0;
     uint16_t *d_gpos16 = nullptr;
     int gpos16_shift = 7;
     uint8_t *d_ref = nullptr;

@@ -120,7 +120,10 @@ struct PileupArgs {
                                 //     position = gbase[record / 512] + delta; padding records are 0xFFFF
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK)
     const uint8_t *ref;
-    const uint32_t *pair;       // read-pair id per record (linkage only)
+    const uint32_t *pair;       // read-pair id per record (linkage only), or NULL and ...
+    const uint2 *pair_runs;     // ... runs of equal pair ids: (first device record, pair id), ascending; run_index[c] = the run
+    const uint32_t *run_index;  //     that holds device record 1024 c (pipe slots: ~0.06 B per record over PCIe instead of 4)
+    uint32_t n_runs;
     const uint32_t *gpos;       // positions alone, 4 B per record (linkage only): what the allele pass streams ...
     const uint16_t *gpos16;     // ... or, when every 1024-record chunk spans < 65535 positions, 2 B deltas to
     const uint32_t *chunk_base; //     the chunk's / group's lowest position (0xFFFF = padding record); gpos is NULL then

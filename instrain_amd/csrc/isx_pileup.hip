@@ -224,7 +224,13 @@ __device__ __forceinline__ void allele_drain(const PileupArgs &a, const uint32_t
         if (base < 4 && ((maskl[rel] >> base) & 1u)) {
             const uint32_t slot = atomicAdd(&slabc[rel], 1u);
             isx_ao o;
-            o.pair = a.pair[i]; o.site = w0 + rel; o.obs_idx = i;
+            if (a.pair) o.pair = a.pair[i];
+            else {                              // run table: a read's records are consecutive, a chunk holds a handful of runs
+                uint32_t r = a.run_index[i >> 10];
+                while (r + 1 < a.n_runs && a.pair_runs[r + 1].x <= i) r++;
+                o.pair = a.pair_runs[r].y;
+            }
+            o.site = w0 + rel; o.obs_idx = i;
             o.mm = (uint16_t)mm; o.base = (uint8_t)base; o.pad = 0;
             a.ao[ao_base + slot] = o;
         }

@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#include "bam_front.h"
 #include "isx_batch.h"
 #include "obs_encode.h"
 
@@ -39,7 +40,8 @@ struct Slot {
     isx_batch *b = nullptr;
     uint8_t *h_in = nullptr, *d_in = nullptr;
     size_t in_bytes = 0;
-    size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_rec = 0, off_pair = 0;
+    size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_rec = 0, off_runs = 0, off_ridx = 0;
+    std::vector<isxenc::PairRun> runs;      // pair-id runs of the batch being submitted
     uint8_t *h_out = nullptr;
     size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0, o_cov16 = 0, o_rare = 0;
     std::vector<isx_rare> rare_big;         // more clonTR entries than the pinned block holds / the device list overflowed
@@ -93,6 +95,7 @@ struct isx_pipe {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     int64_t next_ticket = 0;
     int64_t cap_rec = 0;
+    size_t cap_runs = 0;                    // pair-id runs a slot can take (linkage)
     int rb = 2;                             // record bytes
     uint32_t G = ISX_GROUP16;
     size_t snv_prefix = 0;                  // SNV rows copied out with the dense tables
@@ -111,6 +114,7 @@ static void pipe_free(isx_pipe *p)
         if (s.b) {
             isx_batch *b = s.b;             // the input arrays belong to the arena, not to the batch
             b->d_rec = nullptr; b->d_rec32 = nullptr; b->d_rec16 = nullptr; b->d_gbase = nullptr; b->d_pair = nullptr;
+            b->d_pair_runs = nullptr; b->d_run_index = nullptr;
             b->d_gpos = nullptr; b->d_gpos16 = nullptr; b->d_cbase = nullptr; b->d_ref = nullptr; b->d_win = nullptr;
             b->d_bounds = nullptr;
             isx_batch_destroy(b);
@@ -189,7 +193,8 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.off_ref = o; o = up(o + (size_t)cap_pos);
     s.off_gbase = o; o = up(o + (size_t)(p->cap_rec / p->G) * sizeof(uint32_t));
     s.off_rec = o; o = up(o + (size_t)p->cap_rec * p->rb);
-    s.off_pair = o; if (prm->enable_linkage) o = up(o + (size_t)p->cap_rec * sizeof(uint32_t));
+    s.off_runs = o; if (prm->enable_linkage) o = up(o + p->cap_runs * sizeof(isxenc::PairRun));
+    s.off_ridx = o; if (prm->enable_linkage) o = up(o + ((size_t)p->cap_rec / ISX_CHUNK + 2) * sizeof(uint32_t));
     s.in_bytes = o;
     HIP_TRY(hipHostMalloc(&s.h_in, s.in_bytes, hipHostMallocDefault));
     HIP_TRY(hipMalloc(&s.d_in, s.in_bytes));
@@ -238,6 +243,7 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     const uint64_t want = (uint64_t)((double)pp->max_obs * (1.0 + js)) + 4 * ISX_PAD;
     p->cap_rec = (int64_t)((want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
     if ((uint64_t)p->cap_rec >= 0xFFFFFFFFull) { delete p; isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
+    p->cap_runs = (size_t)p->cap_rec / 4 + 1024;      // a read pair's records are consecutive: runs of tens to hundreds of records
     p->snv_prefix = (size_t)std::min<int64_t>(std::max<int64_t>(pp->max_pos / 64, 1 << 16), 1 << 22);
     // clonTR list: the device list can hold every position; a sixteenth of that travels with every batch, the
     // rest only when a batch really has that many (deep samples)
@@ -267,18 +273,14 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
 
 void isx_pipe_destroy(isx_pipe *p) { pipe_free(p); }
 
-int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
-                    int64_t n_obs, const isx_obs *obs, const uint32_t *pair, int64_t *ticket)
+// the common part of a submit: `J` arrives with its input side set (arrays, or a producer), everything else happens here
+static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                         int64_t n_obs, isxenc::EncodeJob &J, int64_t *ticket)
 {
-    if (!p || !ref || !split_bounds || !ticket || n_pos <= 0 || n_splits <= 0 || n_obs < 0 || (n_obs && !obs)) {
-        isx_set_error("isx_pipe_submit: bad argument");
-        return ISX_ERR_ARG;
-    }
     if (n_pos > p->pp.max_pos || n_obs > p->pp.max_obs || n_splits > p->pp.max_splits) {
         isx_set_error("isx_pipe_submit: batch larger than the pipe was created for");
         return ISX_ERR_CAPACITY;
     }
-    if (p->prm.enable_linkage && n_obs && !pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
     if (split_bounds[0] != 0 || split_bounds[n_splits] != n_pos) { isx_set_error("split_bounds must span [0, n_pos]"); return ISX_ERR_ARG; }
     for (int i = 0; i < n_splits; i++)
         if (split_bounds[i + 1] <= split_bounds[i]) { isx_set_error("split_bounds must be strictly ascending"); return ISX_ERR_ARG; }
@@ -289,18 +291,32 @@ int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_sp
     HIP_TRY(hipSetDevice(c->device));
     const bool dense = b->M == 1, linkage = p->prm.enable_linkage != 0;
 
-    // ---- host threads: records + group bases (+ pair ids) into the pinned arena, reference codes, bounds ----
+    // ---- host threads: records + group bases (+ pair-id runs) into the pinned arena, reference codes, bounds ----
     const double t0 = now_ms();
-    isxenc::EncodeJob J;
-    J.obs = obs; J.pair = linkage ? pair : nullptr; J.n_obs = n_obs; J.n_pos = n_pos; J.record_bytes = p->rb;
+    J.n_obs = n_obs; J.n_pos = n_pos; J.record_bytes = p->rb;
     J.rec = s.h_in + s.off_rec; J.gbase = reinterpret_cast<uint32_t *>(s.h_in + s.off_gbase);
-    J.pair_out = linkage ? reinterpret_cast<uint32_t *>(s.h_in + s.off_pair) : nullptr;
+    J.pair_out = nullptr;
+    J.runs = linkage ? &s.runs : nullptr;
     J.cmin = s.cmin.data(); J.cmax = s.cmax.data(); J.cany = s.cany.data();
     J.cap_rec = p->cap_rec; J.slack = p->slack;
     const int erc = isxenc::encode_obs(*p->pool, J);
     if (erc == isxenc::ENC_CAPACITY) { isx_set_error("isx_pipe_submit: the stream jumps too often for the pipe's record capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
     if (erc == isxenc::ENC_MM_RANGE) { isx_set_error("an observation has mm >= 256"); return ISX_ERR_MM_RANGE; }
     if (erc == isxenc::ENC_BAD_POS) { isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
+    if (linkage) {          // pair-id runs + the run that holds the first record of every 1024-record chunk
+        if (s.runs.size() > p->cap_runs) { isx_set_error("isx_pipe_submit: pair ids change too often along the stream (a read pair's records must be consecutive)"); return ISX_ERR_CAPACITY; }
+        if (s.runs.empty()) s.runs.push_back(isxenc::PairRun{0u, 0u});
+        memcpy(s.h_in + s.off_runs, s.runs.data(), s.runs.size() * sizeof(isxenc::PairRun));
+        uint32_t *ridx = reinterpret_cast<uint32_t *>(s.h_in + s.off_ridx);
+        const uint64_t n_ch = (uint64_t)J.n_rec / ISX_CHUNK;
+        size_t r = 0;
+        for (uint64_t ch = 0; ch < n_ch; ch++) {
+            const uint32_t first = (uint32_t)(ch * ISX_CHUNK);
+            while (r + 1 < s.runs.size() && s.runs[r + 1].first <= first) r++;
+            ridx[ch] = (uint32_t)r;
+        }
+        b->n_runs = (uint32_t)s.runs.size();
+    }
     if (J.passes > 1 && J.n_groups_in > 0)            // remember how jumpy this stream is: the next batch gets its slack up front
         p->slack = std::max(p->slack, 1.25 * ((double)J.n_groups_real / (double)J.n_groups_in - 1.0) + 0.01);
     {
@@ -344,7 +360,9 @@ int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_sp
     b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
     b->d_rec16 = p->rb == 2 ? reinterpret_cast<uint16_t *>(s.d_in + s.off_rec) : nullptr;
     b->d_rec32 = p->rb == 4 ? reinterpret_cast<uint32_t *>(s.d_in + s.off_rec) : nullptr;
-    b->d_pair = linkage ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pair) : nullptr;
+    b->d_pair = nullptr;
+    b->d_pair_runs = linkage ? reinterpret_cast<uint2 *>(s.d_in + s.off_runs) : nullptr;
+    b->d_run_index = linkage ? reinterpret_cast<uint32_t *>(s.d_in + s.off_ridx) : nullptr;
     b->d_gpos16 = s.d_gpos16; b->gpos16_shift = 5;
     s.encode_ms = (float)(now_ms() - t0);
     s.encode_passes = J.passes;
@@ -359,8 +377,10 @@ int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_sp
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
     s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
     if (linkage) {
-        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pair, s.h_in + s.off_pair, (size_t)b->n_rec * 4, hipMemcpyHostToDevice, p->s_h2d));
-        s.h2d_bytes += (int64_t)b->n_rec * 4;
+        const size_t rb = s.runs.size() * sizeof(isxenc::PairRun), ib = (size_t)(b->n_rec / ISX_CHUNK) * sizeof(uint32_t);
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_runs, s.h_in + s.off_runs, rb, hipMemcpyHostToDevice, p->s_h2d));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ridx, s.h_in + s.off_ridx, ib, hipMemcpyHostToDevice, p->s_h2d));
+        s.h2d_bytes += (int64_t)(rb + ib);
     }
     HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
 
@@ -409,6 +429,45 @@ int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_sp
     s.state = 1;
     *ticket = s.ticket;
     return ISX_OK;
+}
+
+int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                    int64_t n_obs, const isx_obs *obs, const uint32_t *pair, int64_t *ticket)
+{
+    if (!p || !ref || !split_bounds || !ticket || n_pos <= 0 || n_splits <= 0 || n_obs < 0 || (n_obs && !obs)) {
+        isx_set_error("isx_pipe_submit: bad argument");
+        return ISX_ERR_ARG;
+    }
+    if (p->prm.enable_linkage && n_obs && !pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
+    isxenc::EncodeJob J;
+    J.obs = obs; J.pair = p->prm.enable_linkage ? pair : nullptr;
+    static const isx_obs none{};
+    if (!n_obs) J.obs = &none;
+    return submit_common(p, n_pos, ref, n_splits, split_bounds, n_obs, J, ticket);
+}
+
+// A batch straight from the BAM front end: the references `refs` (ascending) of a scanned + filtered file are
+// loaded, overlap-resolved and expanded INTO the slot's pinned staging -- the encoder pulls the observation stream
+// group by group from the front end, so neither the 8-byte records nor the per-record pair ids of the batch are ever
+// materialised (profile_utilities.py:150-153 + 268-286 feeding the device directly).
+int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s *bp, const int32_t *refs, int32_t n_refs,
+                        const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds, struct isx_bam_info_s *info, int64_t *ticket)
+{
+    if (!p || !bam || !bp || !refs || n_refs <= 0 || !ref || !ticket) { isx_set_error("isx_pipe_submit_bam: bad argument"); return ISX_ERR_ARG; }
+    BamBatch *q = nullptr;
+    int rc = bam_batch_prepare(bam, bp, refs, n_refs, &q);
+    if (rc != ISX_OK) return rc;
+    std::unique_ptr<BamBatch, void (*)(BamBatch *)> Q(q, bam_batch_free);
+    const int64_t n_pos = bam_batch_n_pos(q), n_obs = bam_batch_n_obs(q);
+    const std::vector<int64_t> &own = bam_batch_bounds(q);
+    if (!split_bounds) { split_bounds = own.data(); n_splits = (int32_t)own.size() - 1; }     // iterate_splits of the front end
+    if (n_splits <= 0) { isx_set_error("isx_pipe_submit_bam: no splits"); return ISX_ERR_ARG; }
+    if (info) bam_batch_info(q, n_refs, info);
+    isxenc::EncodeJob J;
+    J.obs = nullptr;
+    J.want_pairs = p->prm.enable_linkage != 0;
+    J.produce = [q](int64_t first, uint32_t count, isx_obs *o, uint32_t *pr) { bam_batch_emit(q, first, count, o, pr); };
+    return submit_common(p, n_pos, ref, n_splits, split_bounds, n_obs, J, ticket);
 }
 
 int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)

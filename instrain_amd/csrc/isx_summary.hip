@@ -68,11 +68,11 @@ __global__ void k_level_apply(const isx_entry *entries, const uint32_t *win_nent
         const isx_entry e = entries[i];
         if (e.mm != mm) continue;
         const uint32_t s = e.cnt[0] + e.cnt[1] + e.cnt[2] + e.cnt[3];
-        if (s) {
-            cov[e.gpos] += s;
-            Acc *a = &acc[find_seg(bounds, n_seg, e.gpos)];
-            if (!a->present) a->present = 1;        // covT has this level on this scaffold (shrink_basewise)
-        }
+        if (s) cov[e.gpos] += s;
+        // covT has this level on this scaffold as soon as one column created it -- also when its only read showed a
+        // non-ACGT base there (update_covT writes sum(count) = 0; shrink_basewise keeps the key with an empty Series)
+        Acc *a = &acc[find_seg(bounds, n_seg, e.gpos)];
+        if (!a->present) a->present = 1;
         if (e.clon == e.clon) cv[e.gpos] = e.clon;
         if (e.clon_rarefied == e.clon_rarefied) cr[e.gpos] = e.clon_rarefied;
     }

@@ -242,6 +242,7 @@ struct Task {
     int64_t need = 0;                   // device groups the task's input needs
     uint32_t max_pair = 0;
     int err = 0;
+    std::vector<PairRun> runs;          // pair-id runs of the task's region, ascending device records
 };
 
 }  // namespace
@@ -273,7 +274,9 @@ int encode_obs(HostPool &pool, EncodeJob &J)
         std::fill(J.gbase + g0, J.gbase + g1, 0u);
         if (J.pair_out) memset(J.pair_out + g0 * G, 0, (size_t)(g1 - g0) * G * 4);
     };
-    auto emit = [&](int64_t og, const isx_obs *src, const uint32_t *psrc, uint32_t n, uint32_t lo, uint32_t hi, uint32_t &maxp) {
+    const bool have_pairs = J.pair != nullptr || (J.obs == nullptr && J.want_pairs);
+    auto emit = [&](int64_t og, const isx_obs *src, const uint32_t *psrc, uint32_t n, uint32_t lo, uint32_t hi, uint32_t &maxp,
+                    std::vector<PairRun> &runs) {
         if (w16) {
             uint16_t *d = rec16 + og * G;
             if (fast) enc16_avx512(src, n, lo, d); else enc16_scalar(src, n, lo, d);
@@ -291,26 +294,46 @@ int encode_obs(HostPool &pool, EncodeJob &J)
             for (uint32_t i = n; i < G; i++) pd[i] = 0;
             maxp = m;
         }
+        if (J.runs && have_pairs) {
+            uint32_t last = runs.empty() ? 0xFFFFFFFFu : runs.back().pair;
+            uint32_t m = maxp;
+            const uint32_t r0 = (uint32_t)(og * G);
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t p = psrc[i];
+                if (p != last || runs.empty()) { runs.push_back(PairRun{r0 + i, p}); last = p; m = p > m ? p : m; }
+            }
+            maxp = m;
+        }
         const int64_t ch = og / gpc;
         J.cmin[ch] = std::min(J.cmin[ch], lo); J.cmax[ch] = std::max(J.cmax[ch], hi); J.cany[ch] = 1;
     };
     auto work = [&](int ti) {
         Task &T = tasks[(size_t)ti];
-        T.need = 0; T.max_pair = 0; T.err = 0;
+        T.need = 0; T.max_pair = 0; T.err = 0; T.runs.clear();
+        std::vector<isx_obs> tmp_obs;           // producer mode: one input group at a time
+        std::vector<uint32_t> tmp_pair;
+        if (!J.obs) { tmp_obs.resize(G); if (have_pairs) tmp_pair.resize(G); }
         bool writing = !overflow.load(std::memory_order_relaxed);
         if (writing)
             for (int64_t ch = T.out_a / gpc; ch < T.out_b / gpc; ch++) { J.cmin[ch] = 0xFFFFFFFFu; J.cmax[ch] = 0; J.cany[ch] = 0; }
         int64_t out = T.out_a;
+        const uint32_t *pair_src = nullptr;     // pair ids of the current input group (array or producer buffer)
+        int64_t pair_src0 = 0;
         auto put = [&](const isx_obs *src, int64_t first, uint32_t n, uint32_t lo, uint32_t hi) {
             T.need++;
             if (!writing) return;
             if (out == T.out_b || overflow.load(std::memory_order_relaxed)) { overflow.store(1); writing = false; return; }
-            emit(out++, src, J.pair ? J.pair + first : nullptr, n, lo, hi, T.max_pair);
+            emit(out++, src, pair_src ? pair_src + (first - pair_src0) : nullptr, n, lo, hi, T.max_pair, T.runs);
         };
         for (int64_t ig = T.in_a; ig < T.in_b; ig++) {
             const int64_t s0 = ig * (int64_t)G;
             const uint32_t n = (uint32_t)std::min<int64_t>(G, J.n_obs - s0);
-            const isx_obs *src = J.obs + s0;
+            const isx_obs *src;
+            if (J.obs) { src = J.obs + s0; pair_src = J.pair; pair_src0 = 0; }
+            else {
+                J.produce(s0, n, tmp_obs.data(), have_pairs ? tmp_pair.data() : nullptr);
+                src = tmp_obs.data(); pair_src = have_pairs ? tmp_pair.data() : nullptr; pair_src0 = s0;
+            }
             uint32_t lo, hi, mm;
             if (fast) stat_avx512(src, n, lo, hi, mm); else stat_scalar(src, n, lo, hi, mm);
             if (!w16 && mm >= 256u) { T.err = ENC_MM_RANGE; return; }
@@ -360,6 +383,15 @@ int encode_obs(HostPool &pool, EncodeJob &J)
             int64_t real = 0;
             uint32_t mp = 0;
             for (auto &T : tasks) { real += T.need; mp = std::max(mp, T.max_pair); }
+            if (J.runs) {                                   // tasks own ascending regions: concatenation stays sorted
+                J.runs->clear();
+                size_t nr = 0;
+                for (auto &T : tasks) nr += T.runs.size();
+                J.runs->reserve(nr + 1);
+                for (auto &T : tasks)
+                    for (const PairRun &r : T.runs)
+                        if (J.runs->empty() || J.runs->back().pair != r.pair) J.runs->push_back(r);
+            }
             J.n_groups_real = real; J.max_pair = mp;
             (void)gpp;
             return ENC_OK;

@@ -43,16 +43,23 @@ private:
     bool stop_ = false;
 };
 
+struct PairRun { uint32_t first, pair; };    // device records [first, next run's first) belong to read pair `pair`
+
 struct EncodeJob {
-    // input (BAM arrival order)
+    // input (BAM arrival order): arrays, or a producer that materialises any range of the input on demand
+    // (the BAM front end expands reads straight into the encoder: the 8-byte records never exist as a whole)
     const isx_obs *obs = nullptr;
     const uint32_t *pair = nullptr;     // may be NULL
+    std::function<void(int64_t first, uint32_t count, isx_obs *obs_out, uint32_t *pair_out)> produce;   // when obs == NULL
+    bool want_pairs = false;            // producer mode: ask the producer for pair ids too
     int64_t n_obs = 0, n_pos = 0;
     int record_bytes = 2;               // 2: short stream (one mm bin), 4: compact stream
     // output memory (pinned staging in the library; any host memory in tests)
     void *rec = nullptr;                // cap_rec records of record_bytes
     uint32_t *gbase = nullptr;          // cap_rec / group
-    uint32_t *pair_out = nullptr;       // cap_rec, NULL when pair is NULL
+    uint32_t *pair_out = nullptr;       // cap_rec pair ids per device record, or NULL ...
+    std::vector<PairRun> *runs = nullptr;   // ... and / or the same as runs of equal ids (what the pipe uploads: ~0.06 B per
+                                        // record instead of 4; padding records continue the run before them)
     uint32_t *cmin = nullptr, *cmax = nullptr;   // per ISX_CHUNK (1024) device records: position range ...
     uint8_t *cany = nullptr;            // ... and whether the chunk holds a real record
     int64_t cap_rec = 0;

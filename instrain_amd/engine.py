@@ -206,6 +206,23 @@ class Pipe:
                                        pair.ctypes.data if pair is not None and len(obs) else None, C.byref(t)))
         return t.value
 
+    def submit_bam(self, bamfile, refs, ref_codes, split_bounds=None, **kw):
+        """-> ticket.  The references `refs` (ascending indices) of a scanned + filtered BamFile go straight from the
+        front end into the slot's staging (isx_pipe_submit_bam); kw = the expansion flags of BamFile.expand_refs.
+        bamfile.info holds the batch's counts afterwards."""
+        refs = np.ascontiguousarray(refs, dtype=np.int32)
+        ref_codes = np.ascontiguousarray(ref_codes, dtype=np.uint8)
+        sb = None if split_bounds is None else np.ascontiguousarray(split_bounds, dtype=np.int64)
+        p = BamFile._params(**kw)
+        info = BamInfo()
+        t = C.c_int64(-1)
+        rc = self.lib.isx_pipe_submit_bam(self.h, bamfile.h, C.byref(p), refs.ctypes.data, len(refs), ref_codes.ctypes.data,
+                                          0 if sb is None else len(sb) - 1, None if sb is None else sb.ctypes.data,
+                                          C.byref(info), C.byref(t))
+        bamfile._info(info)                         # the batch's real size is known even when it did not fit the pipe
+        check(rc)
+        return t.value
+
     def collect(self, ticket, want_ld=True):
         """-> dict like Batch.fetch() (+ 'sizes', 'stats'); the dense arrays / snv rows are views of pinned memory."""
         r = _lib.PipeResult()

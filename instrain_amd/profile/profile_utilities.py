@@ -579,9 +579,9 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             """one batch through expand -> device -> SplitObjects; raises on failure"""
             nonlocal pipe
             tids = [plan[k][0] for k in items]
-            obs, pair, _, _ = bf.expand_refs(tids, copy=False, **ekw)
             bounds, s_scaff, s_num, s_off, s_len, seqs = [], [], [], [], [], []
             off = 0
+            est = 0
             for k in items:
                 tid, name, splits = plan[k]
                 for (num, s, e) in splits:
@@ -589,20 +589,33 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                     s_scaff.append(name); s_num.append(num); s_off.append(off); s_len.append(e - s + 1)
                 seqs.append(engine.encode_seq(str(s2s[name]).upper()))
                 off += refs[tid][1]
+                est += est_obs[k]
             bounds.append(off)
             ref = np.concatenate(seqs) if len(seqs) > 1 else seqs[0]
-            need = (off, len(obs), len(bounds))
-            if pipe is None or need[0] > pipe.cap[0] or need[1] > pipe.cap[1] or need[2] > pipe.cap[2]:
-                if pipe is not None:
+            need = (off, int(est * 1.1) + 4096, len(bounds))
+            t = None
+            for attempt in range(3):
+                if pipe is None or need[0] > pipe.cap[0] or need[1] > pipe.cap[1] or need[2] > pipe.cap[2]:
+                    if pipe is not None:
+                        pipe.close()
+                    cap = (max(need[0], 1 << 16), max(need[1], 1 << 16), max(need[2], 64))
+                    pipe = engine.Pipe(ctx, max_pos=cap[0], max_obs=cap[1], max_splits=cap[2], depth=1,
+                                       host_threads=int(kwargs.get('host_threads', 0)), pin_threads=False,
+                                       jump_slack=(0.1, 0.5, 2.0)[attempt],
+                                       min_cov=int(kwargs.get('min_cov', 5)), min_freq=min_freq, min_snp=int(kwargs.get('min_snp', 10)),
+                                       rarefied_coverage=int(kwargs.get('rarefied_coverage', 5)), n_mm_bins=n_mm,
+                                       enable_linkage=True, seed=int(kwargs.get('seed', 0)), want_counts=store_everything)
+                    pipe.cap = cap
+                try:
+                    t = pipe.submit_bam(bf, tids, ref, bounds, **ekw)
+                    break
+                except engine.IsxError as e:        # the estimate was short / the stream jumps a lot: a larger slot
+                    if e.code != -3 or attempt == 2:
+                        raise
+                    n_real = int(bf.info["n_obs"]) if bf.info and bf.info.get("n_obs") else need[1] * 2
+                    need = (need[0], max(int(n_real * 1.05) + 4096, need[1] + 1), need[2])
                     pipe.close()
-                cap = (max(need[0], min(max_pos, 1 << 16)), max(need[1], 1 << 16), max(need[2], 64))
-                pipe = engine.Pipe(ctx, max_pos=cap[0], max_obs=cap[1], max_splits=cap[2], depth=1,
-                                   host_threads=int(kwargs.get('host_threads', 0)), pin_threads=False, jump_slack=0.5,
-                                   min_cov=int(kwargs.get('min_cov', 5)), min_freq=min_freq, min_snp=int(kwargs.get('min_snp', 10)),
-                                   rarefied_coverage=int(kwargs.get('rarefied_coverage', 5)), n_mm_bins=n_mm,
-                                   enable_linkage=True, seed=int(kwargs.get('seed', 0)), want_counts=store_everything)
-                pipe.cap = cap
-            t = pipe.submit(ref, bounds, obs, pair)
+                    pipe = None
             try:
                 res = pipe.collect(t)
                 if res.get("n_saturated"):           # coverage beyond the 16-bit hand-back: take the exact counts

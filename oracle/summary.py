@@ -23,10 +23,11 @@ def estimate_breadth(coverage):
 
 
 def coverage_table(entries, snv, length, clon_r=None):
-    """-> list of dict rows, one per mm level present in covT (levels with any coverage > 0),
-    ascending, with the reference's column names."""
+    """-> list of dict rows, one per mm level that is a key of covT (every level some column created, also one whose
+    only read showed a non-ACGT base: update_covT stores 0 and shrink_basewise keeps the key), ascending, with the
+    reference's column names."""
     lvl_sum = entries["cnt"].sum(axis=1)
-    cov_levels = sorted(set(int(m) for m in entries["mm"][lvl_sum > 0]))     # covT keys after shrink_basewise
+    cov_levels = sorted(set(int(m) for m in entries["mm"]))                  # covT keys after shrink_basewise
     rows = []
     for mm in cov_levels:
         k = entries["mm"] <= mm

@@ -35,8 +35,12 @@ def build_inputs():
                                                   ref_ambig=3, self_pairs=0.1)
         seqs.append(seq)
         P.append(pos + off); B.append(base); M.append(mm); R.append(pair + npairs)
-        off += L
         npairs += int(pair.max()) + 1
+        if name == "single":        # a read pair at mm level 7 whose kept bases are all non-ACGT: the level exists, counts nothing
+            P.append(np.arange(700, 730) + off); B.append(np.full(30, 4, dtype=base.dtype)); M.append(np.full(30, 7, dtype=mm.dtype))
+            R.append(np.full(30, npairs, dtype=pair.dtype))
+            npairs += 1
+        off += L
     return seqs, np.concatenate(P), np.concatenate(B), np.concatenate(M), np.concatenate(R)
 
 

@@ -240,3 +240,43 @@ def test_pipe_errors(ctx):
     assert r["sizes"]["n_snv"] == 0 and (r["cov16"] == 0).all() and np.isnan(r["clon"]).all() and len(r["rare"]) == 0
     pipe.release(t)
     pipe.close()
+
+
+def test_submit_bam_equals_array_submit(ctx, tmp_path):
+    """the fused path (front end expanding straight into the slot's staging, pair ids as runs) gives exactly the tables of
+    expand_refs + array submit and of the one-shot path, for a messy multi-scaffold BAM, with and without mm profiling"""
+    from instrain_amd import engine
+    from tests import bamwriter
+    refs = [("scafA", 4000), ("scafB", 900), ("scafC", 12500), ("empty", 700)]
+    rng = np.random.Generator(np.random.PCG64(5))
+    seqs = ["".join(rng.choice(list("ACGT"), ln)) for _, ln in refs]
+    path = str(tmp_path / "m.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(21, refs[:3], 9000))
+    bam = engine.BamFile(path, threads=4)
+    bam.scan()
+    bam.filter(min_read_ani=0.9)
+    for skip_mm in (False, True):
+        n_mm = 1 if skip_mm else bam.info["max_mm"] + 1
+        kw = dict(min_cov=5, min_freq=0.05, min_snp=8, n_mm_bins=n_mm, enable_linkage=True, rarefied_coverage=10, seed=2)
+        for sel in ([0, 1, 2, 3], [2], [0, 3]):
+            ekw = dict(min_read_ani=0.9, skip_mm=skip_mm, window_length=1000)
+            obs, pair, bounds, sref = bam.expand_refs(sel, **ekw)
+            ref = np.concatenate([engine.encode_seq(seqs[t]) for t in sel])
+            b = engine.Batch(ctx, ref, bounds, obs, pair, **kw)
+            b.run()
+            exp, sizes = b.fetch(), b.sizes()
+            b.close()
+            pipe = engine.Pipe(ctx, max_pos=len(ref), max_obs=max(len(obs), 1), max_splits=len(bounds), depth=2, host_threads=3,
+                               jump_slack=1.0, want_counts=True, **kw)
+            t1 = pipe.submit(ref, bounds, obs, pair)
+            t2 = pipe.submit_bam(bam, sel, ref, None, **ekw)
+            assert bam.info["n_obs"] == len(obs) and bam.info["n_splits"] == len(bounds) - 1
+            for t in (t1, t2):
+                r = pipe.collect(t)
+                same_tables(r, exp, "bam %s %s" % (sel, skip_mm))
+                assert r["sizes"] == sizes
+                pipe.release(t)
+            pipe.close()
+            if sel == [2]:
+                assert sizes["n_ld"] > 0 and sizes["n_snv"] > 100
+    bam.close()
