@@ -297,6 +297,9 @@ struct isx_bam {
     std::vector<uint8_t> priority;                  // per pair: its name is a priority read
     std::vector<std::string> priority_names;
     isx_bam_info totals{};
+    // small files: the inflated segments and their record offsets stay (pass 2 neither inflates nor walks again)
+    std::vector<std::vector<uint8_t>> seg_cache;
+    std::vector<std::vector<uint64_t>> seg_cache_rec;
     std::vector<int64_t> ref_filtered_pairs, ref_reads;
     // ---- results of the last expand ----
     std::unique_ptr<isx_obs[]> obs;
@@ -454,6 +457,8 @@ bool is_long_cigar_placeholder(const RecView &r)
     return (c0 & 15) == CS && (int32_t)(c0 >> 4) == r.l_seq && (c1 & 15) == CN;
 }
 
+int n_threads_default();
+
 int open_file(const char *path, isx_bam &B)
 {
     B.fd = open(path, O_RDONLY);
@@ -525,8 +530,10 @@ int open_file(const char *path, isx_bam &B)
         o += 8 + (size_t)l_name;
     }
     B.first_rec = o;
-    // ---- segments: runs of blocks of ~32 MiB inflated ----
-    const uint64_t SEG = (uint64_t)32 << 20;
+    // ---- segments: runs of blocks, ~32 MiB inflated for big files, smaller ones when the file is small so that
+    //      every thread still gets a few (segments are the unit of parallel work in both passes) ----
+    const uint64_t want_segs = (uint64_t)4 * (uint64_t)(B.threads > 0 ? B.threads : n_threads_default());
+    const uint64_t SEG = std::min<uint64_t>((uint64_t)32 << 20, std::max<uint64_t>((uint64_t)1 << 20, total / std::max<uint64_t>(want_segs, 1)));
     Segment cur;
     cur.b0 = 0; cur.ioff0 = 0;
     for (uint32_t b = 0; b < B.blocks.size(); b++) {
@@ -682,7 +689,13 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
     if (B.scanned) { if (info) *info = B.totals; return ISX_OK; }
     isxenc::HostPool &pool = pool_of(B);
     const size_t n_ref = B.ref_name.size(), n_seg = B.segs.size();
+    const bool timing = getenv("ISX_BAM_TIMING") != nullptr;       // tuning aid: stage times on stderr (no effect on results)
+    double t_inflate = 0, t_hop = 0, t_extract = 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
     B.seg_reads.assign(n_seg, {}); B.seg_names.assign(n_seg, {});
+    const bool keep_inflated = B.total_inflated <= ((uint64_t)1 << 30);
+    if (keep_inflated) { B.seg_cache.assign(n_seg, {}); B.seg_cache_rec.assign(n_seg, {}); }
     // waves of segments: inflate (parallel) -> record boundaries (serial walk over block_size fields) -> field
     // extraction (parallel).  At most one wave of inflated data is alive.
     const size_t wave = (size_t)std::max(2, pool.size());
@@ -698,6 +711,7 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
             if (!seg_inflate(B, inf, B.segs[w0 + (size_t)i], bufs[(size_t)i])) bad.store(1);
         });
         if (bad.load()) { isx_set_error("BGZF inflate failed"); return ISX_ERR_IO; }
+        { const double t = now(); t_inflate += t - t_mark; t_mark = t; }
         Inflater inf;
         for (size_t si = w0; si < w1; si++) {
             Segment &s = B.segs[si];
@@ -710,12 +724,16 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
             read_ord += s.n_reads;
             first = next;
         }
+        { const double t = now(); t_hop += t - t_mark; t_mark = t; }
         std::atomic<int> rc_any{0};
         pool.run((int)(w1 - w0), [&](int i) {
             const int rc = scan_segment(B, (uint32_t)(w0 + (size_t)i), bufs[(size_t)i], recs[(size_t)i], errs[w0 + (size_t)i]);
             if (rc != ISX_OK) rc_any.store(rc);
         });
         if (rc_any.load()) { for (auto &e : errs) if (!e.empty()) { isx_set_error(e); break; } return rc_any.load(); }
+        if (keep_inflated)
+            for (size_t si = w0; si < w1; si++) { B.seg_cache[si].swap(bufs[si - w0].data); B.seg_cache_rec[si].swap(recs[si - w0]); }
+        { const double t = now(); t_extract += t - t_mark; t_mark = t; }
     }
     if (first != B.total_inflated) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
     B.n_reads = read_ord;
@@ -756,7 +774,7 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
     std::vector<Part> parts;
     for (size_t t = 0; t < n_ref; t++) {
         if (!B.ref_reads[t]) continue;
-        const uint32_t P = (uint32_t)std::min<int64_t>(64, B.ref_reads[t] / 262144 + 1);
+        const uint32_t P = (uint32_t)std::min<int64_t>(64, B.ref_reads[t] / 32768 + 1);
         for (uint32_t p = 0; p < P; p++) parts.push_back(Part{(uint32_t)t, p, P, {}, {}});
     }
     B.read_pair.assign((size_t)B.n_reads, 0xFFFFFFFFu);
@@ -849,6 +867,8 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
         }
         std::vector<PairInfo>().swap(pt.info);
     });
+    if (timing) fprintf(stderr, "[isx_bam_scan] %zu segments, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms\n",
+                        n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark);
     for (auto &v : B.seg_reads) std::vector<ReadLite>().swap(v);     // names stay until the filter has run (set_r2m / priority reads / cross-scaffold filters)
     B.totals = isx_bam_info{};
     B.totals.n_refs = (int32_t)n_ref;
@@ -1160,19 +1180,25 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     for (uint32_t s = 0; s < B.segs.size(); s++) if (seg_wanted[s]) seg_list.push_back(s);
 
     // ---- load the batch's reads: inflate + walk + count per segment, then fill ----
-    struct SegWork { SegBuf buf; std::vector<uint64_t> rec; std::vector<uint32_t> keep; uint64_t n_cig = 0, n_seq = 0; std::string err; };
+    struct SegWork { SegBuf buf; std::vector<uint64_t> rec; const uint8_t *data = nullptr; const std::vector<uint64_t> *recp = nullptr;
+                     std::vector<uint32_t> keep; uint64_t n_cig = 0, n_seq = 0; std::string err; };
     std::vector<SegWork> sw(seg_list.size());
     std::atomic<int> rc_any{0};
     pool.run((int)seg_list.size(), [&](int k) {
         const Segment &s = B.segs[seg_list[(size_t)k]];
         SegWork &w = sw[(size_t)k];
-        Inflater inf;
-        uint64_t next = 0;
-        if (!seg_inflate(B, inf, s, w.buf)) { w.err = "BGZF inflate failed"; rc_any.store(ISX_ERR_IO); return; }
+        const bool cached = !B.seg_cache.empty();
+        if (cached) { w.data = B.seg_cache[seg_list[(size_t)k]].data(); w.recp = &B.seg_cache_rec[seg_list[(size_t)k]]; }
+        else {
+            Inflater inf;
+            uint64_t next = 0;
+            if (!seg_inflate(B, inf, s, w.buf)) { w.err = "BGZF inflate failed"; rc_any.store(ISX_ERR_IO); return; }
+            if (s.n_reads && (seg_hop(B, inf, s, w.buf, s.first_rec, w.rec, next) != ISX_OK || w.rec.size() != s.n_reads)) { w.err = "BAM changed between scan and expand"; rc_any.store(ISX_ERR_IO); return; }
+            w.data = w.buf.data.data(); w.recp = &w.rec;
+        }
         if (s.n_reads == 0) return;
-        if (seg_hop(B, inf, s, w.buf, s.first_rec, w.rec, next) != ISX_OK || w.rec.size() != s.n_reads) { w.err = "BAM changed between scan and expand"; rc_any.store(ISX_ERR_IO); return; }
         for (uint32_t i = 0; i < s.n_reads; i++) {
-            const uint8_t *q = w.buf.data.data() + (w.rec[i] - s.ioff0);
+            const uint8_t *q = w.data + ((*w.recp)[i] - s.ioff0);
             const int32_t tid = rd32(q + 4);
             if (tid < 0 || (size_t)tid >= n_ref_all || boff[(size_t)tid] < 0) continue;
             if (rd16(q + 18) & DEF_MASK) continue;                     // htslib's pileup never sees these
@@ -1193,7 +1219,7 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
         uint64_t ci = c_at[(size_t)k], qi = s_at[(size_t)k];
         for (size_t j = 0; j < w.keep.size(); j++) {
             RecView r;
-            if (!rec_view(w.buf.data.data() + (w.rec[w.keep[j]] - s.ioff0), r)) { w.err = "corrupt BAM record"; rc_any.store(ISX_ERR_IO); return; }
+            if (!rec_view(w.data + ((*w.recp)[w.keep[j]] - s.ioff0), r)) { w.err = "corrupt BAM record"; rc_any.store(ISX_ERR_IO); return; }
             Read R{};
             R.tid = r.tid; R.pos = r.pos; R.isize = r.isize; R.l_seq = r.l_seq; R.flag = r.flag; R.n_cigar = r.n_cigar;
             R.pair_idx = B.read_pair[(size_t)(s.read0 + w.keep[j])];

@@ -562,6 +562,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                     bf.set_r2m(tid, list(r2m), None)
                 else:
                     bf.set_r2m(tid, list(r2m.keys()), [0 if skip_mm else int(v) for v in r2m.values()])
+            bf.scan()                                # refresh the totals (max_mm now comes from the controller's values)
         info = dict(bf.info) if bf.info else {}
         n_mm = 1 if skip_mm else int(bf.info["max_mm"]) + 1
         if 's2p' in kwargs and isinstance(kwargs['s2p'], dict):
