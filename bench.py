@@ -274,7 +274,7 @@ def resident_leg(ctx, w, window, steps=30):
             "note": "resident re-run of one batch (no hand-over, no fetch): kernel-only ceiling"}
 
 
-def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=3, with_cpu=True):
+def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=3, with_cpu=True, scale=1.0):
     """BASELINE.json configs[4]: 1000-genome database, 10 Gbp of reads, --database_mode (one mm
     bin; genomes below 1x dropped like fasta.py:110-136 does).  The kept genomes are LPT-sharded 8 ways on the
     reference's own cost estimate (read pairs, profile_controller.py:460-465); rank r streams shard r through its
@@ -282,7 +282,8 @@ def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=3, with_cpu
     N=1: the per-GPU shard (1/8 of C5); N=8: the whole configuration."""
     from instrain_amd import dist as idist
     from instrain_amd import engine, synth
-    meta = synth.Metagenome(1000, total_read_bp=10e9, seed=5, threads=max(2, host_threads))
+    n_genomes = max(16, int(round(1000 * scale)))            # scale < 1: debug runs only (reported in the workload string)
+    meta = synth.Metagenome(n_genomes, total_read_bp=10e9 * n_genomes / 1000.0, seed=5, threads=max(2, host_threads))
     kept = meta.kept_genomes()
     shards = idist.lpt_shards(meta.pairs[kept], 8)
     mine = kept[shards[rank % 8]]
@@ -310,10 +311,11 @@ def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=3, with_cpu
     n_pos = int(sum(w["n_pos"] for w in ws))
     abytes = pileup_algorithmic_bytes(n_obs, n_pos, 0, dense=True, record_bytes=2)
     k_ms = tot("kernel_ms")
-    out = {"workload": "C5 shard %d of 8 per GPU: %d of the %d kept genomes (of 1000; %.2f Gbp of positions, %.2f Gbp of reads on this rank), "
-                       "--database_mode, streamed in %d batches" % (rank % 8, len(mine), len(kept), n_pos / 1e9, bases / 1e9, len(ws)),
+    out = {"workload": "C5 shard %d of 8 per GPU: %d of the %d kept genomes (of the database; %.2f Gbp of positions, %.2f Gbp of reads on this rank), "
+                       "--database_mode, streamed in %d batches%s" % (rank % 8, len(mine), len(kept), n_pos / 1e9, bases / 1e9, len(ws),
+                                                                     "" if n_genomes == 1000 else " [DEBUG SCALE: %d genomes]" % n_genomes),
            "gbp_per_s": bases_all / dt_max / 1e9, "seconds": dt_max, "n_gpus": world,
-           "genomes_kept": int(len(kept)), "genomes_total": 1000, "positions": n_pos, "kept_observations": n_obs,
+           "genomes_kept": int(len(kept)), "genomes_total": n_genomes, "positions": n_pos, "kept_observations": n_obs,
            "mean_depth": n_obs / max(n_pos, 1), "snv_rows": int(sum(z["n_snv"] for _, z in stats)),
            "load_imbalance": float(max(meta.pairs[kept[s]].sum() for s in shards) / np.mean([meta.pairs[kept[s]].sum() for s in shards])),
            "generate_s": gen_s,
@@ -476,7 +478,7 @@ def main():
                 return float(t.item()), float(u.item()), g_ms
             return dt_c5, bases, g_ms
         pipe.close()
-        c5 = c5_leg(ctx, rank, world, host_threads, barrier, dist_info, with_cpu=(world == 1 and not args.no_cpu_baseline))
+        c5 = c5_leg(ctx, rank, world, host_threads, barrier, dist_info, with_cpu=(world == 1 and not args.no_cpu_baseline), scale=args.scale)
 
     if rank == 0:
         st = [s for s, _ in stats]

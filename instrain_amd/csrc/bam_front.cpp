@@ -394,6 +394,58 @@ int seg_hop(const isx_bam &B, Inflater &inf, const Segment &s, SegBuf &buf, uint
     return ISX_OK;
 }
 
+// Could a record start at inflated offset `off`?  (fixed fields in range, sizes consistent, a printable NUL-terminated
+// name, CIGAR operators < 9)  Used to find the first record of a segment without walking the file up to it.
+bool plausible_record(const isx_bam &B, const uint8_t *p, uint64_t avail, uint64_t &len)
+{
+    if (avail < 36) return false;
+    const int32_t bs = rd32(p);
+    if (bs < 32 || bs > (1 << 26)) return false;
+    const int32_t tid = rd32(p + 4), pos = rd32(p + 8), l_seq = rd32(p + 20), mtid = rd32(p + 24), mpos = rd32(p + 28);
+    const int n_ref = (int)B.ref_name.size();
+    if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1 || l_seq < 0) return false;
+    if (tid >= 0 && pos > B.ref_len[(size_t)tid]) return false;
+    const uint32_t l_name = p[12], n_cig = rd16(p + 16);
+    if (l_name == 0) return false;
+    const uint64_t need = 32 + (uint64_t)l_name + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+    if (need > (uint64_t)bs) return false;
+    if (avail >= 36 + (uint64_t)l_name) {
+        if (p[36 + l_name - 1] != 0) return false;
+        for (uint32_t i = 0; i + 1 < l_name; i++) if (p[36 + i] < 33 || p[36 + i] > 126) return false;
+    }
+    if (avail >= 36 + (uint64_t)l_name + 4ull * n_cig)
+        for (uint32_t k = 0; k < n_cig; k++) if ((p[36 + l_name + 4 * k] & 15) > 8) return false;
+    len = 4 + (uint64_t)bs;
+    return true;
+}
+
+// first offset >= s.ioff0 at which a chain of plausible records starts; ~0 when the segment seems to hold none.
+// The caller verifies the guess against the walk of the previous segment (and re-walks on a mismatch).
+uint64_t seg_guess(const isx_bam &B, Inflater &inf, const Segment &s, SegBuf &buf)
+{
+    const int CHAIN = 4;
+    for (uint64_t off = s.ioff0; off < s.ioff1; off++) {
+        uint64_t o = off;
+        int ok = 0;
+        for (; ok < CHAIN; ok++) {
+            if (o >= B.total_inflated) break;                       // the chain ran off the end of the file: fine
+            if (o + 36 > B.total_inflated) { ok = -1; break; }
+            if (!seg_need(B, inf, s, buf, o, 36)) { ok = -1; break; }
+            const uint64_t have = s.ioff0 + buf.data.size() - o;
+            uint64_t len = 0;
+            if (!plausible_record(B, buf.data.data() + (o - s.ioff0), std::min<uint64_t>(have, 36 + 256), len)) { ok = -1; break; }
+            if (have < 36 + 256 && o + 36 + 256 <= B.total_inflated) {    // name not fully in view yet: bring it in and look again
+                if (!seg_need(B, inf, s, buf, o, 36 + 256)) { ok = -1; break; }
+                if (!plausible_record(B, buf.data.data() + (o - s.ioff0), 36 + 256, len)) { ok = -1; break; }
+            }
+            if (o + len > B.total_inflated) { ok = -1; break; }
+            o += len;
+        }
+        if (ok >= 0) return off;
+    }
+    return ~0ull;
+}
+
 struct RecView {        // validated fixed part of a record
     const uint8_t *p;   // at block_size
     int32_t block, tid, pos, l_seq, isize;
@@ -706,21 +758,39 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
         std::vector<SegBuf> bufs(w1 - w0);
         std::vector<std::vector<uint64_t>> recs(w1 - w0);
         std::atomic<int> bad{0};
+        // every segment: inflate, guess where its first record starts, walk its records from there (all in parallel) ...
+        std::vector<uint64_t> guess(w1 - w0, ~0ull), nexts(w1 - w0, 0);
+        std::vector<int> hop_rc(w1 - w0, ISX_OK);
         pool.run((int)(w1 - w0), [&](int i) {
             Inflater inf;
-            if (!seg_inflate(B, inf, B.segs[w0 + (size_t)i], bufs[(size_t)i])) bad.store(1);
+            const Segment &s = B.segs[w0 + (size_t)i];
+            if (!seg_inflate(B, inf, s, bufs[(size_t)i])) { bad.store(1); return; }
+            uint64_t g = (w0 + (size_t)i == 0) ? std::max(B.first_rec, s.ioff0) : seg_guess(B, inf, s, bufs[(size_t)i]);
+            if (w0 + (size_t)i == 0 && B.first_rec > s.ioff1) g = ~0ull;
+            guess[(size_t)i] = g;
+            if (g != ~0ull) {
+                std::string keep_err = "";
+                hop_rc[(size_t)i] = seg_hop(B, inf, s, bufs[(size_t)i], g, recs[(size_t)i], nexts[(size_t)i]);
+            }
         });
         if (bad.load()) { isx_set_error("BGZF inflate failed"); return ISX_ERR_IO; }
         { const double t = now(); t_inflate += t - t_mark; t_mark = t; }
+        // ... then the chain is checked serially: a segment's first record must be where the previous segment's walk
+        // ended; where the guess was off (or there was none) that segment is walked again from the right place
         Inflater inf;
         for (size_t si = w0; si < w1; si++) {
             Segment &s = B.segs[si];
+            const size_t k = si - w0;
+            if (first > s.ioff1) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; recs[k].clear(); continue; }    // a record spans the whole segment
             s.first_rec = std::max(first, s.ioff0);
-            if (first > s.ioff1) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; continue; }    // a record spans the whole segment
             uint64_t next = first;
-            const int rc = seg_hop(B, inf, s, bufs[si - w0], s.first_rec, recs[si - w0], next);
-            if (rc != ISX_OK) return rc;
-            s.read0 = read_ord; s.n_reads = (uint32_t)recs[si - w0].size();
+            if (s.first_rec >= s.ioff1) { recs[k].clear(); next = first; }
+            else if (guess[k] == s.first_rec && hop_rc[k] == ISX_OK) next = nexts[k];
+            else {
+                const int rc = seg_hop(B, inf, s, bufs[k], s.first_rec, recs[k], next);
+                if (rc != ISX_OK) return rc;
+            }
+            s.read0 = read_ord; s.n_reads = (uint32_t)recs[k].size();
             read_ord += s.n_reads;
             first = next;
         }

@@ -45,8 +45,10 @@ def init_from_env(backend=None):
 
 
 def gather_tables(tables, dst=0, device=None):
-    """tables: {name: numpy structured array}. Rank `dst` gets {name: concatenation over ranks in
-    rank order}; other ranks get None.  One all_gather of sizes + one padded gather per table."""
+    """tables: {name: numpy structured array}. Rank `dst` gets {name: concatenation over ranks in rank order}; other
+    ranks get None.  The one collective of the path: an all_gather of the byte counts, then every rank sends
+    exactly its bytes to `dst` in one grouped round of point-to-point transfers (ncclSend / ncclRecv inside a group on
+    RCCL; all tables of a rank travel as ONE packed buffer) -- nothing is padded to the largest rank."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -59,19 +61,30 @@ def gather_tables(tables, dst=0, device=None):
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
     all_sizes = torch.stack(all_sizes).cpu().numpy()
-    out = {} if rank == dst else None
+    mine = np.concatenate([np.frombuffer(np.ascontiguousarray(tables[n]).tobytes(), dtype=np.uint8) for n in names]) \
+        if names else np.zeros(0, np.uint8)
+    ops, bufs = [], {}
+    if rank == dst:
+        for r in range(world):
+            if r == dst or all_sizes[r].sum() == 0:
+                continue
+            bufs[r] = torch.empty(int(all_sizes[r].sum()), dtype=torch.uint8, device=device)
+            ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+    elif len(mine):
+        ops.append(dist.P2POp(dist.isend, torch.from_numpy(mine.copy()).to(device), dst))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if rank != dst:
+        return None
+    out = {}
+    raw = {r: (bufs[r].cpu().numpy() if r in bufs else (mine if r == dst else np.zeros(0, np.uint8))) for r in range(world)}
     for j, n in enumerate(names):
-        mx = int(all_sizes[:, j].max())
-        buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=device)
-        raw = np.frombuffer(np.ascontiguousarray(tables[n]).tobytes(), dtype=np.uint8)
-        if len(raw):
-            buf[:len(raw)] = torch.from_numpy(raw.copy()).to(device)
-        recv = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
-        dist.gather(buf, recv, dst=dst)
-        if rank == dst:
-            parts = [np.frombuffer(recv[r].cpu().numpy().tobytes()[:int(all_sizes[r, j])], dtype=tables[n].dtype)
-                     for r in range(world)]
-            out[n] = np.concatenate(parts)
+        parts = []
+        for r in range(world):
+            o = int(all_sizes[r, :j].sum())
+            parts.append(np.frombuffer(raw[r][o:o + int(all_sizes[r, j])].tobytes(), dtype=tables[n].dtype))
+        out[n] = np.concatenate(parts)
     return out
 
 
@@ -91,3 +104,79 @@ def pack_batches(n_pos, n_obs, max_pos, max_obs):
     if cur:
         out.append(cur)
     return out
+
+
+# ---- one BAM profiled by several ranks (one process per GPU) ----
+def shard_scaffolds(filtered_pairs, lengths, world):
+    """LPT over the scaffolds that have reads, on the reference's own cost estimate: 0.0061 s x pairs + 0.2 s per
+    scaffold (profile_controller.py:460-465).  Every rank computes the same answer from the same scan."""
+    idx = [i for i in range(len(lengths)) if lengths[i] > 0]
+    cost = [0.0061401594694834305 * float(filtered_pairs[i]) + 0.2 for i in idx]
+    return [[idx[j] for j in sh] for sh in lpt_shards(cost, world)]
+
+
+def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=None, **kwargs):
+    """Scaffolds of ONE sorted BAM sharded over `world` ranks: every rank scans the file (so the read filter's
+    whole-file median insert is the same everywhere without a collective), takes the scaffolds LPT gives it, profiles
+    them through profile_bam, and the SNV / linkage / per-scaffold summary tables are gathered on rank 0
+    (gather_tables).  Returns (splits of this rank, gathered tables on rank 0 | None)."""
+    import pandas as pd
+    from . import engine
+    from ._lib import LD_DT, SCAFFOLD_LEVEL_DT, SNV_DT
+    from .profile import profile_utilities as pu
+    bf = engine.BamFile(bam, threads=int(kwargs.get('host_threads', 0)))
+    try:
+        refs = bf.refs()
+        bf.scan()
+        bf.filter(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
+                  max_insert_relative=kwargs.get('max_insert_relative', 3), min_insert=kwargs.get('min_insert', 50),
+                  pairing_filter=kwargs.get('pairing_filter', 'paired_only'))
+        _, pairs = bf.ref_counts()
+    finally:
+        bf.close()
+    usable = [i for i, (n, ln, _) in enumerate(refs) if n in s2s and len(s2s[n]) == ln]
+    shards = shard_scaffolds([pairs[i] for i in usable], [refs[i][1] for i in usable], world)
+    mine = [usable[j] for j in shards[rank]]
+    W = int(kwargs.get('window_length', 10000))
+    rows = [(refs[t][0], i, s, e) for t in mine for i, (s, e) in enumerate(pu.iterate_splits(refs[t][1], W))]
+    fdb = pd.DataFrame(rows, columns=["scaffold", "split_number", "start", "end"])
+    tabs = {}
+    splits = pu.profile_bam(bam, fdb, None, None, s2s=s2s, null_model=null_model, scaffold_tables=tabs, **kwargs) if len(rows) else {}
+    load = float(sum(pairs[t] for t in mine))
+    if not gather:
+        return splits, None, load
+    # packed tables with the scaffold's index in the BAM header as the key
+    tid_of = {refs[t][0]: t for t in mine}
+    snv_dt = np.dtype([("tid", "<i4")] + [(n, SNV_DT[n]) if SNV_DT[n].shape == () else (n, SNV_DT[n].base, SNV_DT[n].shape) for n in SNV_DT.names])
+    ld_dt = np.dtype([("tid", "<i4")] + [(n, LD_DT[n]) for n in LD_DT.names])
+    sm_dt = np.dtype([("tid", "<i4")] + [(n, SCAFFOLD_LEVEL_DT[n]) for n in SCAFFOLD_LEVEL_DT.names])
+    snv_parts, ld_parts = [], []
+    seen = set()
+    for S in splits.values():
+        tb, i = S.__dict__.get('_src', (None, None))
+        if tb is None or (id(tb), i) in seen:
+            continue
+        seen.add((id(tb), i))
+        for src, cut, dt, parts, keys in ((tb.snv, tb.s_cut, snv_dt, snv_parts, ("gpos",)), (tb.ld, tb.l_cut, ld_dt, ld_parts, ("gpos_a", "gpos_b"))):
+            rws = src[cut[i]:cut[i + 1]]
+            o = np.zeros(len(rws), dtype=dt)
+            for n in rws.dtype.names:
+                o[n] = rws[n]
+            for k in keys:
+                o[k] = rws[k] - tb.offset[i]            # scaffold coordinates
+            o["tid"] = tid_of[S.scaffold]
+            parts.append(o)
+    sm_parts = []
+    for name, t in tabs.items():
+        o = np.zeros(len(t), dtype=sm_dt)
+        o["tid"] = tid_of[name]
+        o["mm"] = t["mm"].values
+        o["nonzero"] = np.round(t["breadth"].values * t["length"].values).astype(np.int64)
+        o["counted"] = np.round(t["breadth_minCov"].values * t["length"].values).astype(np.int64)
+        o["sum_cov"] = np.round(t["coverage"].values * t["length"].values).astype(np.uint64)
+        o["median_cov"] = t["coverage_median"].values
+        sm_parts.append(o)
+    tables = {"snv": np.concatenate(snv_parts) if snv_parts else np.zeros(0, snv_dt),
+              "ld": np.concatenate(ld_parts) if ld_parts else np.zeros(0, ld_dt),
+              "summary": np.concatenate(sm_parts) if sm_parts else np.zeros(0, sm_dt)}
+    return splits, gather_tables(tables, dst=0, device=device), load

@@ -266,3 +266,37 @@ def test_corrupt_inputs_are_errors_not_crashes(tmp_path):
     with pytest.raises(engine.IsxError) as e:
         engine.BamFile(rewrite(bytes(data), "aux2.bam")).expand()
     assert e.value.code == -5
+
+
+def test_record_longer_than_a_segment(tmp_path):
+    """a 2.3 Mbp read (one BAM record spanning several 1 MiB segments of the scan) between ordinary pairs: the segments
+    inside it hold no record start -- whatever the first-record guesser finds in its bases is overruled by the chain check"""
+    from tests import bamwriter
+    refs = [("big", 4_000_000)]
+    rng = np.random.Generator(np.random.PCG64(3))
+    reads = bamwriter.random_reads(31, [("big", 100_000)], 400)
+    L = 2_300_000
+    long_read = dict(tid=0, pos=150_000, mapq=40, flag=0x1 | 0x40 | 0x2, name="longread", cigar=[("M", L)],
+                     seq="".join(rng.choice(list("ACGT"), L)), qual=np.full(L, 40), nm=3, isize=L + 500, extra_tags=False)
+    mate = dict(long_read, pos=150_000 + L + 100, flag=0x1 | 0x80 | 0x2, cigar=[("M", 100)], seq="A" * 100, qual=np.full(100, 40),
+                nm=0, isize=-(L + 500))
+    tail = bamwriter.random_reads(32, [("big", 100_000)], 300)
+    for r in tail:
+        r["pos"] += 3_000_000
+        r["name"] = "t" + r["name"]
+    reads = sorted(reads + [long_read, mate] + tail, key=lambda r: (r["tid"], r["pos"]))
+    path = str(tmp_path / "long.bam")
+    bamwriter.write_bam(path, refs, reads)
+    bam = engine.BamFile(path, threads=4)
+    info = bam.scan()
+    assert info["n_reads"] == len(reads)
+    bam.filter(min_read_ani=0.5, max_insert_relative=1e9)
+    assert bam.r2m(0).get("longread") == 3
+    obs, pair, bounds, sref = bam.expand_refs([0], min_read_ani=0.5, max_insert_relative=1e9)
+    k = obs[pair == pair[np.flatnonzero(obs["gpos"] == 150_000)[0]]]
+    assert len(k) == L + 100 and (np.diff(k["gpos"][:L].astype(np.int64)) == 1).all() and (k["mm"] == 3).all()
+    # the same file through one thread (serial chain) gives the same stream
+    b1 = engine.BamFile(path, threads=1)
+    o1, p1, _, _ = b1.expand(min_read_ani=0.5, max_insert_relative=1e9)
+    assert len(o1) == len(obs) and (o1 == obs).all() and (p1 == pair).all()
+    bam.close(); b1.close()

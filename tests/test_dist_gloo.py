@@ -48,3 +48,63 @@ def test_gather_world_size_2(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_OK" in r.stdout
+
+
+SHARD_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    from instrain_amd import dist as idist, engine
+    rank, local, world = idist.init_from_env(backend="gloo")
+    path = sys.argv[1]
+    bam = engine.BamFile(path, threads=2)
+    bam.scan(); info = bam.filter(min_read_ani=0.9)
+    refs = bam.refs()
+    _, pairs = bam.ref_counts()
+    shards = idist.shard_scaffolds(pairs, [r[1] for r in refs], world)
+    mine = shards[rank]
+    # this rank's part of the observation stream (host front end only: no GPU here), keyed by (tid, position)
+    obs, pair, bounds, sref = bam.expand_refs(sorted(mine), min_read_ani=0.9)
+    offs = np.r_[0, np.cumsum([refs[t][1] for t in sorted(mine)])]
+    which = np.searchsorted(offs, obs["gpos"], side="right") - 1
+    dt = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("base", "u1"), ("mm", "<u2")])
+    t = np.zeros(len(obs), dtype=dt)
+    t["tid"] = np.array(sorted(mine), dtype=np.int32)[which] if len(obs) else 0
+    t["pos"] = obs["gpos"] - offs[which]; t["base"] = obs["base"]; t["mm"] = obs["mm"]
+    med = np.array([info["median_insert"]])
+    out = idist.gather_tables({"obs": t, "median": med.view([("m", "<f8")])}, dst=0)
+    if rank == 0:
+        whole = engine.BamFile(path, threads=2)
+        o, p, b, s = whole.expand(min_read_ani=0.9)
+        woffs = np.r_[0, np.cumsum([r[1] for r in refs])]
+        ww = np.searchsorted(woffs, o["gpos"], side="right") - 1
+        exp = np.zeros(len(o), dtype=dt)
+        exp["tid"] = ww; exp["pos"] = o["gpos"] - woffs[ww]; exp["base"] = o["base"]; exp["mm"] = o["mm"]
+        got = np.sort(out["obs"], order=["tid", "pos", "base", "mm"])
+        exp = np.sort(exp, order=["tid", "pos", "base", "mm"])
+        assert len(got) == len(exp) and (got == exp).all()
+        assert (out["median"]["m"] == whole.info["median_insert"]).all() and len(out["median"]) == world
+        assert sorted(x for sh in shards for x in sh) == [i for i in range(len(refs)) if refs[i][1] > 0]
+        print("SHARD_OK", [len(sh) for sh in shards], len(got))
+    dist.barrier()
+    dist.destroy_process_group()
+""") % REPO
+
+
+def test_one_bam_sharded_over_two_ranks(tmp_path):
+    """both ranks scan the same BAM (same whole-file median insert without a collective), LPT gives each its
+    scaffolds, each expands only those; the gathered union equals the single-process expansion"""
+    sys.path.insert(0, REPO)
+    from tests import bamwriter
+    refs = [("s%d" % i, ln) for i, ln in enumerate([4000, 900, 12500, 700, 2600, 5100])]
+    path = str(tmp_path / "shard.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(41, refs[:5], 5000))
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29534", str(script), path],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "SHARD_OK" in r.stdout

@@ -431,3 +431,78 @@ def test_end_to_end_messy_bam_vs_oracle(tmp_path):
                 assert (ser.values == lv[k][np.argsort(exp["entries"]["pos"][k])]).all()
             n_rows += len(es); n_ld += len(el)
     assert n_rows > 50
+
+
+SHARDED_WORKER = '''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+torch.cuda.set_device(0)
+import torch.distributed as dist
+from instrain_amd import dist as idist
+from tests import util
+rank, local, world = idist.init_from_env(backend="gloo")
+path, out = sys.argv[1], sys.argv[2]
+z = np.load(sys.argv[3], allow_pickle=True)
+seqs = {str(k): str(v) for k, v in zip(z["names"], z["seqs"])}
+lut, fb = util.load_lut()
+model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+model[-1] = fb
+kw = dict(min_cov=5, min_freq=0.05, min_snp=10, min_read_ani=0.9, window_length=1000, device=0)
+splits, tables, load = idist.profile_bam_sharded(path, seqs, model, rank, world, **kw)
+loads = [None] * world
+dist.all_gather_object(loads, (load, len(splits)))
+if rank == 0:
+    np.savez(out, snv=tables["snv"], ld=tables["ld"], summary=tables["summary"], loads=np.array([l[0] for l in loads]),
+             n_splits=np.array([l[1] for l in loads]))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_one_bam_profiled_by_two_ranks_equals_one_rank(tmp_path):
+    """scaffolds of one BAM LPT-sharded over two ranks (both on GPU 0, gloo rendezvous): the SNV / linkage / summary
+    tables gathered on rank 0 equal the single-process profile"""
+    import subprocess
+    import sys
+    import instrain_amd.profile as prof
+    from instrain_amd import engine
+    from tests import bamwriter
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    refs = [("s%d" % i, ln) for i, ln in enumerate([4000, 900, 12500, 700, 2600, 5100])]
+    rng = np.random.Generator(np.random.PCG64(8))
+    seqs = {n: "".join(rng.choice(list("ACGT"), ln)) for n, ln in refs}
+    path = str(tmp_path / "shard.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(43, refs[:5], 7000))
+    np.savez(str(tmp_path / "seqs.npz"), names=np.array(list(seqs)), seqs=np.array(list(seqs.values())))
+    script = tmp_path / "w.py"
+    script.write_text(SHARDED_WORKER % repo)
+    out = str(tmp_path / "gathered.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29578", str(script), path, out, str(tmp_path / "seqs.npz")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    g = np.load(out)
+    assert (g["n_splits"] > 0).all() and g["n_splits"].sum() == sum(ln // 1000 + 1 for _, ln in refs[:5])
+    assert g["loads"].max() / g["loads"].mean() < 1.6                      # LPT balance on the reference's cost estimate
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    one = prof.profile_bam(path, s2s=seqs, null_model=model, min_cov=5, min_freq=0.05, min_snp=10, min_read_ani=0.9, window_length=1000)
+    tid = {n: i for i, (n, _) in enumerate(refs)}
+    rows = []
+    lrows = []
+    for S in one.values():
+        t = S.raw_snp_table
+        for r_ in t.itertuples():
+            rows.append((tid[r_.scaffold], r_.position, r_.mm, r_.A, r_.C, r_.T, r_.G, r_.allele_count))
+        for r_ in S.raw_linkage_table.itertuples():
+            lrows.append((tid[r_.scaffold], r_.position_A, r_.position_B, r_.mm, r_.total, r_.countAB))
+    got = sorted((int(x["tid"]), int(x["gpos"]), int(x["mm"]), int(x["cnt"][0]), int(x["cnt"][1]), int(x["cnt"][2]), int(x["cnt"][3]),
+                  int(x["allele_count"])) for x in g["snv"])
+    assert got == sorted(rows) and len(rows) > 100
+    gotl = sorted((int(x["tid"]), int(x["gpos_a"]), int(x["gpos_b"]), int(x["mm"]), int(x["total"]), int(x["countAB"])) for x in g["ld"])
+    assert gotl == sorted(lrows)
+    assert sorted(set(int(t) for t in g["summary"]["tid"])) == [0, 1, 2, 3, 4]
