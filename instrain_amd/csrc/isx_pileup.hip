@@ -399,6 +399,9 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         const uint32_t w0 = (uint32_t)w * (uint32_t)W;
         const uint32_t cur_lo = lo, cur_hi = hi;
         const uint32_t dummy = 4u * (uint32_t)W + (uint32_t)(tid & 63);     // see the stream loop
+#ifdef ISX_TUNING
+        uint32_t ablate_acc = 0;
+#endif
         {   // zero the window's counters
             uint4 *z = reinterpret_cast<uint4 *>(cnt);
             for (int i = tid; i < W; i += nthr) z[i] = make_uint4(0, 0, 0, 0);
@@ -430,6 +433,11 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
                     for (int h = 0; h < 8; h++) {
                         const uint32_t r = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1), 13) + bw;
                         const uint32_t bb = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1) + 13, 3);
+#ifdef ISX_TUNING       // ablations of the stream loop (tools/ablate_dense.py): what bounds it?
+                        if (dbg & 8) { ablate_acc += (r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy; continue; }     // decode, no LDS
+                        if (dbg & 16) { atomicAdd(&cnt[dummy], (r < (uint32_t)W && bb < 4) ? 1u : 0u); continue; }                         // lane-private word
+                        if (dbg & 32) { if (h == 0) atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u); continue; }   // 1 of 8 records
+#endif
                         atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u);
                     }
                 } else if (FMT == 4) {
@@ -451,6 +459,9 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
             const uint32_t nxt = i0 + 4 * nthr;
             if (nxt < hi) issue(nxt);
         }
+#ifdef ISX_TUNING
+        if (ablate_acc == 0xDEADBEEFu) cnt[dummy] = ablate_acc;             // keeps the ablated decode alive
+#endif
         __syncthreads();
 
         // first loads of the NEXT window go out before the epilogue (with linkage the registers
