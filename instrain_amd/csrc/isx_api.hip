@@ -173,7 +173,9 @@ struct ObsStream {
     template <class T>
     int upload_encoded(T **d_dst)
     {
-        HIP_TRY(hipMalloc(d_dst, b->n_rec * sizeof(T)));
+        HIP_TRY(hipMalloc(d_dst, b->n_rec * sizeof(T) + ISX_TAIL_BYTES));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<uint8_t *>(*d_dst) + b->n_rec * sizeof(T)),
+                                  (int)(sizeof(T) == 2 ? 0xFFFFFFFFu : ISX_PAD32), ISX_TAIL_BYTES / 4, c->stream));
         return staged_upload(c, *d_dst, b->n_rec, [&](T *dst, uint64_t first, uint64_t cnt) {
             if (too_wide.load() || has_jump.load()) return;
             fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
@@ -196,7 +198,8 @@ struct ObsStream {
             b->d_rec32 = nullptr; b->d_rec16 = nullptr;
             return 1;
         }
-        HIP_TRY(hipMalloc(&b->d_gbase, std::max<uint64_t>(n_groups, 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&b->d_gbase, (n_groups + ISX_TAIL_GROUPS) * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(b->d_gbase + n_groups, 0, ISX_TAIL_GROUPS * sizeof(uint32_t), c->stream));
         HIP_TRY(hipMemcpy(b->d_gbase, gbase.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
         return ISX_OK;
     }

@@ -12,6 +12,11 @@
 #define ISX_CHUNK 1024              // observation directory granule (records)
 #define ISX_PAD 2048                // the record stream is padded to a multiple of this (whole directory chunks, 16-byte loads)
 #define ISX_SENTINEL 0xFFFFFFFFu    // gpos of padding records (never inside a window)
+// The compact streams (2- / 4-byte records) are followed by this many bytes of padding records (and the group bases by
+// ISX_TAIL_GROUPS entries): k_pileup_dense streams them with unconditional 16-byte loads, a workgroup's last round may run
+// this far past its window's range -- what it reads there is either beyond the window (dropped) or padding.
+#define ISX_TAIL_BYTES 65536
+#define ISX_TAIL_GROUPS 256
 
 void isx_set_error(const std::string &msg);
 

@@ -373,24 +373,34 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
     u32x4 v[4];
     uint32_t gb[4] = {0, 0, 0, 0};              // COMPACT: position base of each load's group (wave-uniform)
     uint32_t lo = 0, hi = 0;
+    const uint32_t lane16 = (uint32_t)tid;      // lane offset in 16-byte units: the one address register of the stream loads
+    auto issue_one = [&](int u, uint32_t i0) {  // one coalesced 16-byte load per lane into slot u
+        const uint32_t j = i0 + tid + u * nthr;
+        // compact streams: unconditional (ISX_TAIL_BYTES of padding follow the stream; records past `hi` lie beyond the
+        // window and are dropped like any other) -- no per-lane branch, no select against a padding value
+        if (COMPACT || j < hi) {
+            // wave-uniform base in scalar registers + one 32-bit lane offset (saddr form): no 64-bit address pair per
+            // load in flight -- with four loads rotating the pairs were spilled and every reload drained vmcnt
+            const uint64_t ub = reinterpret_cast<uint64_t>(rec4 + (i0 + (uint32_t)(u * nthr)));
+            typedef __attribute__((address_space(1))) const u32x4 gvec;        // global, not flat: vmcnt only
+            const gvec *sb = reinterpret_cast<const gvec *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ub >> 32)) << 32) |
+                                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ub));
+            v[u] = __builtin_nontemporal_load(sb + lane16);
+            if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
+        } else if (FMT == 2) { v[u].x = v[u].y = v[u].z = v[u].w = 0xFFFFFFFFu; }
+        else if (FMT == 4) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
+        else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
+    };
     auto issue = [&](uint32_t i0) {             // 4 coalesced 16-byte loads per lane
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t j = i0 + tid + u * nthr;
-            if (j < hi) {
-                v[u] = __builtin_nontemporal_load(&rec4[j]);
-                if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
-            } else if (FMT == 2) { v[u].x = v[u].y = v[u].z = v[u].w = 0xFFFFFFFFu; }
-            else if (FMT == 4) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
-            else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
-        }
+        for (int u = 0; u < 4; u++) issue_one(u, i0);
     };
     auto prefetch_window = [&](int wn) {
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
             lo = rng.x >> RSH; hi = rng.y >> RSH;
-            if (lo < hi) issue(lo);
+            if (lo < hi) { issue_one(0, lo); issue_one(1, lo); }        // the first half-round; the stream loop issues the rest
         }
     };
     prefetch_window(slot);
@@ -420,44 +430,51 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         __syncthreads();
 
         // ---- get_base_counts_mm (profile_utilities.py:268-286) over the window's slice ----
-        for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                // Branch-free: a record outside the window / without an A,C,T,G base adds to a per-lane dummy word
-                // (the queue region, idle during the stream) -- no exec-mask juggling per record, and the
-                // counter index is a 24-bit mad (v_mul_lo_u32 is quarter rate).
-                if (FMT == 2) {
-                    const uint32_t bw = gb[u] - w0;
-                    const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                    for (int h = 0; h < 8; h++) {
-                        const uint32_t r = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1), 13) + bw;
-                        const uint32_t bb = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1) + 13, 3);
-#ifdef ISX_TUNING       // ablations of the stream loop (tools/ablate_dense.py): what bounds it?
-                        if (dbg & 8) { ablate_acc += (r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy; continue; }     // decode, no LDS
-                        if (dbg & 16) { atomicAdd(&cnt[dummy], (r < (uint32_t)W && bb < 4) ? 1u : 0u); continue; }                         // lane-private word
-                        if (dbg & 32) { if (h == 0) atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u); continue; }   // 1 of 8 records
+        // Branch-free: a record outside the window / without an A,C,T,G base adds to a per-lane dummy word (the queue
+        // region, idle during the stream) -- no exec-mask juggling per record, and the counter index is a 24-bit mad
+        // (v_mul_lo_u32 is quarter rate).
+        auto count_slot = [&](int u) {
+            if (FMT == 2) {
+                const uint32_t bw = gb[u] - w0;
+                const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#ifdef ISX_TUNING
+                if (dbg & 64) { ablate_acc += x[0] ^ x[1] ^ x[2] ^ x[3] ^ bw; return; }         // loads only
 #endif
-                        atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u);
-                    }
-                } else if (FMT == 4) {
-                    const uint32_t bw = gb[u] - w0;
-                    const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-                    for (int h = 0; h < 4; h++) {
-                        const uint32_t r = (x[h] & 0xFFFFu) + bw, bb = __builtin_amdgcn_ubfe(x[h], 24, 3);
-                        atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u);
-                    }
-                } else {
-                    const uint32_t g0 = v[u].x, a0 = v[u].y, g1 = v[u].z, a1 = v[u].w;
-                    const uint32_t r0 = g0 - w0, r1 = g1 - w0;
-                    const uint32_t b0 = (a0 >> 16) & 0xFFu, b1 = (a1 >> 16) & 0xFFu;
-                    if (r0 < (uint32_t)W && b0 < 4) atomicAdd(&cnt[b0 * W + r0], 1u);
-                    if (r1 < (uint32_t)W && b1 < 4) atomicAdd(&cnt[b1 * W + r1], 1u);
+                for (int h = 0; h < 8; h++) {
+                    const uint32_t r = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1), 13) + bw;
+                    const uint32_t bb = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1) + 13, 3);
+#ifdef ISX_TUNING       // ablations of the stream loop (tools/ablate_dense.py): what bounds it?
+                    if (dbg & 8) { ablate_acc += (r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy; continue; }     // decode, no LDS
+                    if (dbg & 16) { atomicAdd(&cnt[dummy], (r < (uint32_t)W && bb < 4) ? 1u : 0u); continue; }                         // lane-private word
+                    if (dbg & 32) { if (h == 0) atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u); continue; }   // 1 of 8 records
+#endif
+                    atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u);
                 }
+            } else if (FMT == 4) {
+                const uint32_t bw = gb[u] - w0;
+                const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t r = (x[h] & 0xFFFFu) + bw, bb = __builtin_amdgcn_ubfe(x[h], 24, 3);
+                    atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u);
+                }
+            } else {
+                const uint32_t g0 = v[u].x, a0 = v[u].y, g1 = v[u].z, a1 = v[u].w;
+                const uint32_t r0 = g0 - w0, r1 = g1 - w0;
+                const uint32_t b0 = (a0 >> 16) & 0xFFu, b1 = (a1 >> 16) & 0xFFu;
+                if (r0 < (uint32_t)W && b0 < 4) atomicAdd(&cnt[b0 * W + r0], 1u);
+                if (r1 < (uint32_t)W && b1 < 4) atomicAdd(&cnt[b1 * W + r1], 1u);
             }
-            const uint32_t nxt = i0 + 4 * nthr;
-            if (nxt < hi) issue(nxt);
+        };
+        // Two half-rounds in flight: slots 0,1 (loaded during the previous half / the previous window's epilogue) are
+        // counted while slots 2,3 load, and slots 0,1 of the NEXT round load while 2,3 are counted.  Every slot is
+        // loaded, then consumed, then reloaded in static program order: no register copies, the waits are vmcnt(2).
+        for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
+            issue_one(2, i0); issue_one(3, i0);
+            count_slot(0); count_slot(1);
+            if (i0 + 4 * nthr < hi) { issue_one(0, i0 + 4 * nthr); issue_one(1, i0 + 4 * nthr); }
+            count_slot(2); count_slot(3);
         }
 #ifdef ISX_TUNING
         if (ablate_acc == 0xDEADBEEFu) cnt[dummy] = ablate_acc;             // keeps the ablated decode alive

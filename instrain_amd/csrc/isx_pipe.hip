@@ -191,8 +191,8 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.off_bounds = o; o = up(o + (size_t)(p->pp.max_splits + 1) * sizeof(int64_t));
     s.off_win = o; o = up(o + ((size_t)cap_pos / 64 + 2) * sizeof(uint2));
     s.off_ref = o; o = up(o + (size_t)cap_pos);
-    s.off_gbase = o; o = up(o + (size_t)(p->cap_rec / p->G) * sizeof(uint32_t));
-    s.off_rec = o; o = up(o + (size_t)p->cap_rec * p->rb);
+    s.off_gbase = o; o = up(o + ((size_t)(p->cap_rec / p->G) + ISX_TAIL_GROUPS) * sizeof(uint32_t));
+    s.off_rec = o; o = up(o + (size_t)p->cap_rec * p->rb + ISX_TAIL_BYTES);
     s.off_runs = o; if (prm->enable_linkage) o = up(o + p->cap_runs * sizeof(isxenc::PairRun));
     s.off_ridx = o; if (prm->enable_linkage) o = up(o + ((size_t)p->cap_rec / ISX_CHUNK + 2) * sizeof(uint32_t));
     s.in_bytes = o;
@@ -371,7 +371,12 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     hipStream_t ps = c->pstream[b->ps];
     HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
     const size_t head = s.off_ref + (size_t)n_pos;                         // bounds | windows | reference codes
-    const size_t gb_bytes = (size_t)(b->n_rec / p->G) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * p->rb;
+    // the stream is followed by a tail of padding records / zero bases (see ISX_TAIL_BYTES): the slot's arena still
+    // holds the previous batch there
+    if (p->rb == 2) memset(s.h_in + s.off_rec + (size_t)b->n_rec * 2, 0xFF, ISX_TAIL_BYTES);
+    else std::fill_n(reinterpret_cast<uint32_t *>(s.h_in + s.off_rec + (size_t)b->n_rec * 4), ISX_TAIL_BYTES / 4, (uint32_t)ISX_PAD32);
+    memset(s.h_in + s.off_gbase + (size_t)(b->n_rec / p->G) * sizeof(uint32_t), 0, ISX_TAIL_GROUPS * sizeof(uint32_t));
+    const size_t gb_bytes = ((size_t)(b->n_rec / p->G) + ISX_TAIL_GROUPS) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * p->rb + ISX_TAIL_BYTES;
     HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, head, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));

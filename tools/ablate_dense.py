@@ -16,7 +16,7 @@ lut, fb = util.load_lut()
 ctx.set_null_model(lut, fb)
 w = bench.c2_workload(2)
 for dbg, what in ((0, "full kernel"), (2, "stream loop only (no epilogue)"), (2 | 8, "stream: loads + decode, no LDS atomics"),
-                  (2 | 16, "stream: atomics on lane-private words"), (2 | 32, "stream: 1 atomic per 8 records"), (8, "epilogue + loads + decode")):
+                  (2 | 16, "stream: atomics on lane-private words"), (2 | 32, "stream: 1 atomic per 8 records"), (2 | 64, "stream: loads only"), (8, "epilogue + loads + decode"), (64, "epilogue + loads only")):
     os.environ["ISX_DEBUG_MODE"] = str(dbg)
     b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], None, n_mm_bins=1, enable_linkage=False)
     for _ in range(3):
