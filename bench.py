@@ -178,8 +178,10 @@ def linkage_leg(ctx, seed=3):
     the sparse pair-increment path (default) and the dense int8-MFMA path (linkage_mode 2)."""
     from instrain_amd import engine, synth
     glen = int(os.environ.get("ISX_BENCH_C3_BP", 5_000_000))        # configs[2] in full; smaller = a slice of it (debug)
-    w = synth.make_workload(genome_len=glen, coverage=200, n_sites=glen // 100, seed=seed, skip_mm=True,
-                            af_lo=0.2, af_hi=0.5)
+    # the multi-threaded generator (same read / site model as synth.make_workload, seconds instead of minutes at 200x)
+    meta = synth.Metagenome(1, total_read_bp=200.0 * glen, seed=seed, contigs=1, len_lo=glen, len_hi=glen, abundance_sigma=0.0,
+                            min_genome_coverage=0.0, site_frac=0.01, af_lo=0.2, af_hi=0.5)
+    w = meta.generate([0])
     out = {"workload": "C3%s: %.1f Mbp genome, 200x, %d SNV sites (1 / 100 bp, two haplotype backgrounds), skip_mm, linkage on"
                        % ("" if glen == 5_000_000 else " slice", glen / 1e6, glen // 100),
            "kept_observations": int(w["n_obs"]), "read_pairs": int(w["n_pairs"])}
