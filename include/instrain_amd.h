@@ -412,6 +412,10 @@ int isx_bam_ref_counts(const isx_bam *bam, int64_t *reads, int64_t *filtered_pai
 /* overlap resolution + expansion of the given references (ascending ids = file order), laid end to end (the batch's
  * flat space); results stay in the handle until the next expand (isx_bam_copy / isx_bam_view) */
 int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info);
+/* the re-pileup of SNV pooling (polymorpher.py:287-293: samfile.pileup(scaffold, start, stop, truncate=True)): only the columns
+ * [start, stop) of one reference, from the reads overlapping them (only the BGZF blocks that can hold such reads are touched);
+ * gpos stays the position on the reference */
+int isx_bam_expand_region(isx_bam *bam, const isx_bam_params *p, int32_t ref, int64_t start, int64_t stop, isx_bam_info *info);
 /* scan + filter + expansion of every reference of the file */
 int isx_bam_expand(isx_bam *bam, const isx_bam_params *p, isx_bam_info *info);
 /* copy out: obs[n_obs], pair[n_obs], split_bounds[n_splits+1], split_ref[n_splits] */

@@ -114,7 +114,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_bam", "isx_pipe_collect", "isx_pipe_release", "isx_encode_obs",
            "isx_bam_open", "isx_bam_close", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan",
            "isx_bam_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_ref_counts",
-           "isx_bam_expand_refs", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
+           "isx_bam_expand_refs", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
 
 _lib = None
 
@@ -171,6 +171,7 @@ def load():
     lib.isx_bam_drop_names.argtypes = [vp]
     lib.isx_bam_r2m.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), vp, vp, vp]
     lib.isx_bam_ref_counts.argtypes = [vp, vp, vp]
+    lib.isx_bam_expand_region.argtypes = [vp, C.POINTER(BamParams), i32, i64, i64, C.POINTER(BamInfo)]
     lib.isx_bam_expand_refs.argtypes = [vp, C.POINTER(BamParams), vp, i32, C.POINTER(BamInfo)]
     lib.isx_bam_ref.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64)]
     lib.isx_bam_copy.argtypes = [vp, vp, vp, vp, vp]

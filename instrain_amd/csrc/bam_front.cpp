@@ -144,6 +144,7 @@ struct Segment {
     uint64_t first_rec = 0;         // inflated offset of the first record that STARTS in the segment (== ioff1: none)
     uint64_t read0 = 0;             // ordinal of that record
     uint32_t n_reads = 0;
+    int32_t tid_first = -1, pos_first = 0, tid_last = -1, pos_last = 0;   // first / last record (set by the scan)
 };
 
 // ---- inflate: libdeflate when the image has it (2-3x zlib), zlib otherwise ----
@@ -297,6 +298,7 @@ struct isx_bam {
     std::vector<uint8_t> priority;                  // per pair: its name is a priority read
     std::vector<std::string> priority_names;
     isx_bam_info totals{};
+    int64_t max_span = 0;                           // longest reference span of a read (region queries: how far back a read may start)
     // small files: the inflated segments and their record offsets stay (pass 2 neither inflates nor walks again)
     std::vector<std::vector<uint8_t>> seg_cache;
     std::vector<std::vector<uint64_t>> seg_cache_rec;
@@ -807,6 +809,13 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
     }
     if (first != B.total_inflated) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
     B.n_reads = read_ord;
+    for (size_t si = 0; si < n_seg; si++) {
+        const auto &rs = B.seg_reads[si];
+        if (rs.empty()) continue;
+        Segment &sg = B.segs[si];
+        sg.tid_first = rs.front().tid; sg.pos_first = rs.front().pos; sg.tid_last = rs.back().tid; sg.pos_last = rs.back().pos;
+        for (const ReadLite &L : rs) if (L.any) B.max_span = std::max<int64_t>(B.max_span, L.last - (int64_t)L.pos + 1);
+    }
 
     // ---- reference -> the run of reads that belongs to it (the file is sorted: a reference's reads are contiguous) ----
     struct Run { uint32_t seg; uint32_t i0, i1; };
@@ -1149,6 +1158,7 @@ struct BamBatch {
     std::vector<uint64_t> out_at;           // [n_reads + 1] first observation of every read
     std::vector<int64_t> boff;              // per reference of the file: offset in the batch's flat space, -1 = not in the batch
     int64_t n_pos = 0;
+    int64_t reg_lo = 0, reg_hi = -1;        // one-reference batches: only positions [reg_lo, reg_hi) are piled up (-1 = all)
     uint32_t next_pair = 0;
     uint8_t minq = 30;
     std::vector<int64_t> split_bounds;
@@ -1172,7 +1182,8 @@ struct BamBatch {
             const int64_t n = c >> 4;
             if (op == CM || op == CEQ || op == CX) {
                 // the reference's pileups are truncated to [0, scaffold length) (profile_utilities.py:150-153)
-                const int64_t j0 = std::max<int64_t>(0, -ref), j1 = std::min<int64_t>(n, ref_len - ref);
+                int64_t j0 = std::max<int64_t>(0, -ref), j1 = std::min<int64_t>(n, ref_len - ref);
+                if (reg_hi >= 0) { j0 = std::max<int64_t>(j0, reg_lo - ref); j1 = std::min<int64_t>(j1, reg_hi - ref); }
                 const uint32_t g0 = (uint32_t)(base_off + ref);
                 for (int64_t j = j0; j < j1; j++) {
                     if (ql[q + j] >= minq) {
@@ -1213,7 +1224,7 @@ struct BamBatch {
     int64_t n_obs() const { return (int64_t)out_at.back(); }
 };
 
-int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, BamBatch **out)
+int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, BamBatch **out, int64_t reg_lo, int64_t reg_hi)
 {
     *out = nullptr;
     isx_bam &B = *bam;
@@ -1246,6 +1257,19 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     }
     if (n_pos >= (int64_t)0xFFFF0000ll) { isx_set_error("isx_bam_expand_refs: the batch's flat space must be < 2^32 - 65536 positions"); return ISX_ERR_ARG; }
     Q->n_pos = n_pos;
+    const bool region = reg_hi >= 0;
+    if (region) {
+        if (n_refs != 1 || reg_lo < 0 || reg_hi <= reg_lo) { isx_set_error("isx_bam_expand_region: one reference and 0 <= start < stop"); return ISX_ERR_ARG; }
+        Q->reg_lo = reg_lo; Q->reg_hi = std::min<int64_t>(reg_hi, B.ref_len[(size_t)refs[0]]);
+        // the file is sorted: segments whose records all start at or after the region's end, or so far before its start that
+        // no read reaches it, cannot contribute
+        for (uint32_t s = 0; s < B.segs.size(); s++) {
+            if (!seg_wanted[s]) continue;
+            const Segment &sg = B.segs[s];
+            if (sg.tid_first == refs[0] && sg.pos_first >= Q->reg_hi) seg_wanted[s] = 0;
+            if (sg.tid_last == refs[0] && (int64_t)sg.pos_last + B.max_span <= Q->reg_lo) seg_wanted[s] = 0;
+        }
+    }
     std::vector<uint32_t> seg_list;
     for (uint32_t s = 0; s < B.segs.size(); s++) if (seg_wanted[s]) seg_list.push_back(s);
 
@@ -1272,6 +1296,10 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
             const int32_t tid = rd32(q + 4);
             if (tid < 0 || (size_t)tid >= n_ref_all || boff[(size_t)tid] < 0) continue;
             if (rd16(q + 18) & DEF_MASK) continue;                     // htslib's pileup never sees these
+            if (region) {                                               // the fetch of a region only yields reads that overlap it
+                const int32_t pos = rd32(q + 8);
+                if (pos >= Q->reg_hi || (int64_t)pos + B.max_span <= Q->reg_lo) continue;
+            }
             w.keep.push_back(i);
             w.n_cig += rd16(q + 16);
             w.n_seq += (uint64_t)std::max(rd32(q + 20), 0);
@@ -1407,12 +1435,12 @@ const std::vector<int64_t> &bam_batch_bounds(const BamBatch *q) { return q->spli
 
 extern "C" {
 
-int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info)
+static int expand_into_handle(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info, int64_t reg_lo, int64_t reg_hi)
 {
     if (!bam || !p || n_refs < 0 || (n_refs && !refs)) { isx_set_error("isx_bam_expand_refs: bad argument"); return ISX_ERR_ARG; }
     isx_bam &B = *bam;
     BamBatch *q = nullptr;
-    const int rc = bam_batch_prepare(bam, p, refs, n_refs, &q);
+    const int rc = bam_batch_prepare(bam, p, refs, n_refs, &q, reg_lo, reg_hi);
     if (rc != ISX_OK) return rc;
     std::unique_ptr<BamBatch> Q(q);
     // the whole stream into the handle (threads over contiguous pieces; file order is kept)
@@ -1432,6 +1460,19 @@ int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *re
     B.expanded = true;
     if (info) bam_batch_info(q, n_refs, info);
     return ISX_OK;
+}
+
+int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info)
+{
+    return expand_into_handle(bam, p, refs, n_refs, info, 0, -1);
+}
+
+// samfile.pileup(scaffold, start=..., stop=..., truncate=True) of the SNV-pooling re-pileup (polymorpher.py:287-293): only the
+// columns [start, stop) of ONE reference, from the reads that overlap them; positions stay those of the whole reference
+int isx_bam_expand_region(isx_bam *bam, const isx_bam_params *p, int32_t ref, int64_t start, int64_t stop, isx_bam_info *info)
+{
+    if (stop <= start || start < 0) { isx_set_error("isx_bam_expand_region: 0 <= start < stop"); return ISX_ERR_ARG; }
+    return expand_into_handle(bam, p, &ref, 1, info, start, stop);
 }
 
 // scan + filter + expansion of every reference of the file

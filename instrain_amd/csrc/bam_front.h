@@ -8,7 +8,9 @@
 #include "../../include/instrain_amd.h"
 
 struct BamBatch;
-int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, BamBatch **out);
+// reg_hi < 0: whole references; else n_refs == 1 and only positions [reg_lo, reg_hi) of it
+int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, BamBatch **out, int64_t reg_lo = 0,
+                      int64_t reg_hi = -1);
 void bam_batch_free(BamBatch *q);
 int64_t bam_batch_n_obs(const BamBatch *q);
 int64_t bam_batch_n_pos(const BamBatch *q);

@@ -378,7 +378,9 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         const uint32_t j = i0 + tid + u * nthr;
         // compact streams: unconditional (ISX_TAIL_BYTES of padding follow the stream; records past `hi` lie beyond the
         // window and are dropped like any other) -- no per-lane branch, no select against a padding value
-        if (COMPACT || j < hi) {
+        // (a wave whose 64 loads all lie past `hi` skips the load -- a uniform branch -- and counts padding instead)
+        const uint32_t jw = __builtin_amdgcn_readfirstlane(j);
+        if (COMPACT ? jw < hi : j < hi) {
             // wave-uniform base in scalar registers + one 32-bit lane offset (saddr form): no 64-bit address pair per
             // load in flight -- with four loads rotating the pairs were spilled and every reload drained vmcnt
             const uint64_t ub = reinterpret_cast<uint64_t>(rec4 + (i0 + (uint32_t)(u * nthr)));
@@ -390,10 +392,6 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         } else if (FMT == 2) { v[u].x = v[u].y = v[u].z = v[u].w = 0xFFFFFFFFu; }
         else if (FMT == 4) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
         else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
-    };
-    auto issue = [&](uint32_t i0) {             // 4 coalesced 16-byte loads per lane
-#pragma unroll
-        for (int u = 0; u < 4; u++) issue_one(u, i0);
     };
     auto prefetch_window = [&](int wn) {
         lo = hi = 0;

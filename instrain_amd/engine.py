@@ -426,6 +426,14 @@ class BamFile:
         self._info(info)
         return self._results(info, copy)
 
+    def expand_region(self, ref, start, stop, copy=True, **kw):
+        """pass 2 for the columns [start, stop) of reference index `ref` only (the re-pileup of SNV pooling)"""
+        info = BamInfo()
+        p = self._params(**kw)
+        check(self.lib.isx_bam_expand_region(self.h, C.byref(p), int(ref), int(start), int(stop), C.byref(info)))
+        self._info(info)
+        return self._results(info, copy)
+
     def expand(self, copy=True, **kw):
         """scan + filter + expansion of every reference -> (obs, pair, split_bounds, split_ref)"""
         info = BamInfo()

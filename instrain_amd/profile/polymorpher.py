@@ -6,7 +6,7 @@
 The reference opens a second pileup iterator with the same htslib arguments as profile_split and
 returns, for every requested position, mm_counts_to_counts(get_base_counts_mm(column, R2M)) = the
 A,C,T,G counts over ALL mm levels.  Here that is one dense (n_mm_bins == 1) pass of the same
-k_pileup_dense kernel over the whole BAM followed by a gather at the requested positions.
+k_pileup_dense kernel over the region the reference piles up, followed by a gather at the requested positions.
 """
 import numpy as np
 
@@ -16,9 +16,10 @@ from .. import engine
 def extract_SNVS_from_bam(bam_loc, R2M, positions, scaffold, ctx=None, null_model=None, **kwargs):
     """-> {position: np.array([A, C, T, G])} like the reference (zeros where nothing is piled up).
 
-    R2M is accepted for signature compatibility; the read-pair filter is recomputed by the C++ front
-    end from the same flags (min_read_ani, min_mapq, max_insert_relative, min_insert), which yields the
-    R2M the reference would have stored for this BAM."""
+    Like the reference (polymorpher.py:287-293) only the columns [min(positions) - 1, max(positions) + 1) of the scaffold
+    are piled up, from the reads that overlap them.  R2M: the scaffold's {pair: mm} (or a set of pair names) the way the
+    reference hands it over -- exactly those read pairs are counted; None = the built-in read filter with the flags in
+    kwargs (min_read_ani, min_mapq, max_insert_relative, min_insert, pairing_filter)."""
     positions = [int(p) for p in positions]
     if len(positions) == 0:
         return {}
@@ -30,26 +31,42 @@ def extract_SNVS_from_bam(bam_loc, R2M, positions, scaffold, ctx=None, null_mode
         ctx.set_null_model(*null_model_lut(null_model))
     bf = engine.BamFile(bam_loc)
     try:
-        obs, pair, bounds, sref = bf.expand(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
-                                            max_insert_relative=kwargs.get('max_insert_relative', 3),
-                                            min_insert=kwargs.get('min_insert', 50), skip_mm=True)
-        refs = {n: (ln, off) for n, ln, off in bf.refs()}
-        if scaffold not in refs:
+        names = [n for n, _, _ in bf.refs()]
+        if scaffold not in names:
             raise ValueError("scaffold {0} is not in the .bam file {1}!".format(scaffold, bam_loc))
-        n_pos = int(bf.info["n_pos"])
+        tid = names.index(scaffold)
+        ln = bf.refs()[tid][1]
+        lo, hi = max(min(positions) - 1, 0), min(max(positions) + 1, ln)
+        fkw = dict(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
+                   max_insert_relative=kwargs.get('max_insert_relative', 3), min_insert=kwargs.get('min_insert', 50),
+                   pairing_filter=kwargs.get('pairing_filter', 'paired_only'))
+        bf.scan()
+        if R2M is None:
+            bf.filter(**fkw)
+        else:
+            bf.set_r2m(tid, list(R2M), None)
+        if hi <= lo:
+            obs = np.zeros(0, dtype=engine.OBS_DT)
+        else:
+            obs, _, _, _ = bf.expand_region(tid, lo, hi, skip_mm=True, **fkw)
     finally:
         bf.close()
-    b = engine.Batch(ctx, np.zeros(n_pos, dtype=np.uint8), [0, n_pos], obs, None, n_mm_bins=1, enable_linkage=False,
-                     rarefied_coverage=0)
-    try:
-        b.run()
-        counts = b.fetch()["counts"]
-    finally:
-        b.close()
-        if own:
-            ctx.close()
-    ln, off = refs[scaffold]
     out = {}
+    n_pos = max(hi - lo, 1)
+    if len(obs):
+        obs = obs.copy()
+        obs["gpos"] -= lo                                   # the device batch covers the region only
+        b = engine.Batch(ctx, np.zeros(n_pos, dtype=np.uint8), [0, n_pos], obs, None, n_mm_bins=1, enable_linkage=False,
+                         rarefied_coverage=0)
+        try:
+            b.run()
+            counts = b.fetch()["counts"]
+        finally:
+            b.close()
+    else:
+        counts = np.zeros((n_pos, 4), dtype=np.uint32)
+    if own:
+        ctx.close()
     for p in positions:
-        out[p] = counts[off + p].astype(np.int64) if 0 <= p < ln else np.zeros(4, dtype=np.int64)
+        out[p] = counts[p - lo].astype(np.int64) if lo <= p < hi else np.zeros(4, dtype=np.int64)
     return out

@@ -300,3 +300,29 @@ def test_record_longer_than_a_segment(tmp_path):
     o1, p1, _, _ = b1.expand(min_read_ani=0.5, max_insert_relative=1e9)
     assert len(o1) == len(obs) and (o1 == obs).all() and (p1 == pair).all()
     bam.close(); b1.close()
+
+
+def test_expand_region_equals_the_cut_of_the_whole_reference(tmp_path):
+    """samfile.pileup(scaffold, start, stop, truncate=True): the region's columns from the reads that overlap them ==
+    the whole reference's stream restricted to those positions (an overlap tweak only ever concerns positions both mates
+    cover, so the reads outside the region cannot matter)"""
+    from tests import bamwriter
+    refs = [("scafA", 4000), ("scafB", 30000)]
+    path = str(tmp_path / "r.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(51, refs, 20000))
+    bam = engine.BamFile(path, threads=4)
+    bam.scan(); bam.filter(min_read_ani=0.9)
+    o, p, _, _ = bam.expand_refs([1], min_read_ani=0.9)
+    for lo, hi in ((0, 30000), (12000, 12001), (29990, 40000), (5000, 9000), (100, 260)):
+        ro, rp, rb, rs = bam.expand_region(1, lo, hi, min_read_ani=0.9)
+        k = (o["gpos"] >= lo) & (o["gpos"] < hi)
+        assert len(ro) == k.sum() and (ro == o[k]).all(), (lo, hi)
+        # pair ids are dense per expansion: same partition of the observations
+        _, a = np.unique(rp, return_inverse=True)
+        _, c = np.unique(p[k], return_inverse=True)
+        fa = np.zeros(a.max() + 1 if len(a) else 0, int); fc = np.zeros(c.max() + 1 if len(c) else 0, int)
+        fa[a[::-1]] = np.arange(len(a))[::-1]; fc[c[::-1]] = np.arange(len(c))[::-1]
+        assert (fa[a] == fc[c]).all()
+    with pytest.raises(engine.IsxError):
+        bam.expand_region(1, 10, 10)
+    bam.close()
