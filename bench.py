@@ -296,7 +296,7 @@ def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=3, with_cpu
     gen_s = time.perf_counter() - t0
     pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
                        max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
-                       pin_threads=False, n_mm_bins=1, enable_linkage=False, jump_slack=0.5)
+                       pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20, jump_slack=0.5)
     stream(pipe, ws, min(2, len(ws)), depth)                 # warm-up (also teaches the pipe this stream's jump slack)
     barrier()
     stats = []
@@ -314,11 +314,14 @@ def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=3, with_cpu
     abytes = pileup_algorithmic_bytes(n_obs, n_pos, 0, dense=True, record_bytes=2)
     k_ms = tot("kernel_ms")
     out = {"workload": "C5 shard %d of 8 per GPU: %d of the %d kept genomes (of the database; %.2f Gbp of positions, %.2f Gbp of reads on this rank), "
-                       "--database_mode, streamed in %d batches%s" % (rank % 8, len(mine), len(kept), n_pos / 1e9, bases / 1e9, len(ws),
+                       "--database_mode, pileup + SNV call + linkage, streamed in %d batches%s" % (rank % 8, len(mine), len(kept), n_pos / 1e9, bases / 1e9, len(ws),
                                                                      "" if n_genomes == 1000 else " [DEBUG SCALE: %d genomes]" % n_genomes),
            "gbp_per_s": bases_all / dt_max / 1e9, "seconds": dt_max, "n_gpus": world,
            "genomes_kept": int(len(kept)), "genomes_total": n_genomes, "positions": n_pos, "kept_observations": n_obs,
            "mean_depth": n_obs / max(n_pos, 1), "snv_rows": int(sum(z["n_snv"] for _, z in stats)),
+           "linkage": "on (sparse path; the reference links every profile, linkage.py:14-44)",
+           "snv_pairs_linked": int(sum(z["n_edges"] for _, z in stats)), "ld_rows": int(sum(z["n_ld"] for _, z in stats)),
+           "snv_pairs_linked_per_s": float(sum(z["n_edges"] for _, z in stats)) * world / dt_max,
            "load_imbalance": float(max(meta.pairs[kept[s]].sum() for s in shards) / np.mean([meta.pairs[kept[s]].sum() for s in shards])),
            "generate_s": gen_s,
            "stages_ms_total": {"host_encode": tot("encode_ms"), "copy_in": tot("h2d_ms"), "kernel": k_ms, "copy_out": tot("d2h_ms"),
@@ -351,9 +354,10 @@ def make_variants(w, n):
 def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False):
     """n_steps batches through the pipe, at most `depth` in flight; returns the last collected result"""
     tickets, done, last = [], 0, None
+    link = pipe.enable_linkage
     for i in range(n_steps):
         if len(tickets) - done == depth:
-            r = pipe.collect(tickets[done], want_ld=False)
+            r = pipe.collect(tickets[done], want_ld=link)
             if stats is not None:
                 stats.append((r["stats"], r["sizes"]))
             if keep_last and done == n_steps - 1:
@@ -361,9 +365,9 @@ def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False):
             pipe.release(tickets[done])
             done += 1
         v = variants[i % len(variants)]
-        tickets.append(pipe.submit(v["ref_codes"], v["split_bounds"], v["obs"], None))
+        tickets.append(pipe.submit(v["ref_codes"], v["split_bounds"], v["obs"], v["pair"] if link else None))
     while done < len(tickets):
-        r = pipe.collect(tickets[done], want_ld=False)
+        r = pipe.collect(tickets[done], want_ld=link)
         if stats is not None:
             stats.append((r["stats"], r["sizes"]))
         if keep_last and done == n_steps - 1:
