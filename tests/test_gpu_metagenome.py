@@ -129,3 +129,46 @@ def test_c5_per_gpu_shard_properties(ctx):
         sig.append(out)
     assert sig[0] == sig[1]
     pipe.close()
+
+
+def test_c4_per_gpu_shard_properties(ctx):
+    """configs[3]: 100 genomes U(2,6) Mbp x 50 contigs at 50x mean coverage (log-normal abundances), --database_mode; rank
+    0's LPT shard of 8 (~2.5 Gbp of reads) streamed through the pipe with linkage on.  Size-independent properties per
+    batch: the coverage table sums to the observations handed over, every SNV row's counts sum to the coverage at its
+    position and exceed min_cov, LD rows stay inside one scaffold with counts that add up, deep genomes produce clonTR
+    exactly where coverage >= 50."""
+    from instrain_amd import dist as idist
+    from instrain_amd import engine, synth
+    meta = synth.Metagenome(100, mean_coverage=50, seed=4)
+    kept = meta.kept_genomes()
+    assert len(kept) == 100 and abs(float((meta.coverage * meta.length).sum()) / float(meta.length.sum()) - 50) < 1e-6
+    shard = kept[idist.lpt_shards(meta.pairs[kept], 8)[0]]
+    est = (meta.pairs[shard] * 2 * meta.read_len * 0.92).astype(np.int64)
+    batches = idist.pack_batches(meta.length[shard], est, 40_000_000, 400_000_000)
+    ws_meta = [shard[b] for b in batches]
+    pipe = None
+    total = 0
+    for sel in ws_meta:                                       # one batch in memory at a time (a batch is up to 5 GB of records)
+        w = meta.generate(sel)
+        if pipe is None or w["n_obs"] > cap[1] or w["n_pos"] > cap[0] or len(w["split_bounds"]) > cap[2]:
+            if pipe is not None:
+                pipe.close()
+            cap = (max(w["n_pos"], 30_000_000), int(w["n_obs"] * 1.2), len(w["split_bounds"]) + 4096)
+            pipe = engine.Pipe(ctx, max_pos=cap[0], max_obs=cap[1], max_splits=cap[2], depth=1, n_mm_bins=1,
+                               enable_linkage=True, min_snp=20, jump_slack=0.3)
+        t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], w["pair"])
+        r = pipe.collect(t)
+        cov = r["cov16"].astype(np.int64)
+        assert r["n_saturated"] == 0 and int(cov.sum()) == w["n_obs"]
+        snv, ld = r["snv"], r["ld"]
+        assert len(snv) > 1000 and (snv["cnt"].sum(axis=1) == cov[snv["gpos"]]).all() and (snv["cnt"].sum(axis=1) >= 5).all()
+        sb = w["scaffold_bounds"]
+        assert len(ld) > 100
+        assert (np.searchsorted(sb, ld["gpos_a"], side="right") == np.searchsorted(sb, ld["gpos_b"], side="right")).all()
+        assert (ld["countAB"].astype(np.int64) + ld["countAb"] + ld["countaB"] + ld["countab"] == ld["total"]).all()
+        assert (r["rare"]["gpos"] == np.flatnonzero(cov >= 50)).all()
+        total += w["profiled_bases"]
+        pipe.release(t)
+        del w, r
+    pipe.close()
+    assert 1.5e9 < total < 4e9
