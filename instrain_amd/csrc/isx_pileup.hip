@@ -649,23 +649,26 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
     uint32_t gb[4] = {0, 0, 0, 0};
     uint32_t lo = 0, hi = 0;
     uint32_t my_entries = 0;                    // thread 0: entries of all windows of this workgroup
-    auto issue = [&](uint32_t i0) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t j = i0 + tid + u * nthr;
-            if (j < hi) {
-                v[u] = __builtin_nontemporal_load(&rec4[j]);
-                if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
-            } else if (COMPACT) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
-            else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
-        }
+    // same load scheme as k_pileup_dense: wave-uniform bound, scalar base + lane offset, two half-rounds in flight
+    auto issue_one = [&](int u, uint32_t i0) {
+        const uint32_t j = i0 + tid + u * nthr;
+        const uint32_t jw = __builtin_amdgcn_readfirstlane(j);
+        if (COMPACT ? jw < hi : j < hi) {
+            const uint64_t ub = reinterpret_cast<uint64_t>(rec4 + (i0 + (uint32_t)(u * nthr)));
+            typedef __attribute__((address_space(1))) const u32x4 gvec;
+            const gvec *sb = reinterpret_cast<const gvec *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ub >> 32)) << 32) |
+                                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ub));
+            v[u] = __builtin_nontemporal_load(sb + (uint32_t)tid);
+            if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
+        } else if (COMPACT) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
+        else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
     };
     auto prefetch_window = [&](int wn) {
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
             lo = rng.x >> RSH; hi = rng.y >> RSH;
-            if (lo < hi) issue(lo);
+            if (lo < hi) { issue_one(0, lo); issue_one(1, lo); }
         }
     };
     prefetch_window(slot);
@@ -687,27 +690,28 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 
         // ---- get_base_counts_mm over the window's slice of the stream ----
         uint32_t bad_mm = 0;
-        for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
+        auto count_slot = [&](int u) {
+            const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                for (int h = 0; h < (COMPACT ? 4 : 2); h++) {
-                    uint32_t rel, base, mm;
-                    if (COMPACT) { rel = (x[h] & 0xFFFFu) + (gb[u] - w0); base = (x[h] >> 24) & 7u; mm = (x[h] >> 16) & 0xFFu; }
-                    else { rel = x[2 * h] - w0; base = (x[2 * h + 1] >> 16) & 0xFFu; mm = x[2 * h + 1] & 0xFFFFu; }
-                    if (rel >= (uint32_t)W) continue;
-                    if (mm >= (uint32_t)M) { bad_mm = 1; continue; }
-                    if (base < 4) {
-                        if (PACKED) atomicAdd(&cnt[__umul24(mm * 2 + (base >> 1), (uint32_t)W) + rel], 1u << (16 * (base & 1)));
-                        else atomicAdd(&cnt[__umul24(mm * 4 + base, (uint32_t)W) + rel], 1u);
-                    } else if (!COMPACT || base != 7u) {            // 7 = padding record of the compact stream
-                        atomicOr(&pres[__umul24(mm >> 5, (uint32_t)W) + rel], 1u << (mm & 31));
-                    }
+            for (int h = 0; h < (COMPACT ? 4 : 2); h++) {
+                uint32_t rel, base, mm;
+                if (COMPACT) { rel = (x[h] & 0xFFFFu) + (gb[u] - w0); base = (x[h] >> 24) & 7u; mm = (x[h] >> 16) & 0xFFu; }
+                else { rel = x[2 * h] - w0; base = (x[2 * h + 1] >> 16) & 0xFFu; mm = x[2 * h + 1] & 0xFFFFu; }
+                if (rel >= (uint32_t)W) continue;
+                if (mm >= (uint32_t)M) { bad_mm = 1; continue; }
+                if (base < 4) {
+                    if (PACKED) atomicAdd(&cnt[__umul24(mm * 2 + (base >> 1), (uint32_t)W) + rel], 1u << (16 * (base & 1)));
+                    else atomicAdd(&cnt[__umul24(mm * 4 + base, (uint32_t)W) + rel], 1u);
+                } else if (!COMPACT || base != 7u) {            // 7 = padding record of the compact stream
+                    atomicOr(&pres[__umul24(mm >> 5, (uint32_t)W) + rel], 1u << (mm & 31));
                 }
             }
-            const uint32_t nxt = i0 + 4 * nthr;
-            if (nxt < hi) issue(nxt);
+        };
+        for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
+            issue_one(2, i0); issue_one(3, i0);
+            count_slot(0); count_slot(1);
+            if (i0 + 4 * nthr < hi) { issue_one(0, i0 + 4 * nthr); issue_one(1, i0 + 4 * nthr); }
+            count_slot(2); count_slot(3);
         }
         if (bad_mm) flag_or(a, ISX_FLAG_MM_RANGE);
         __syncthreads();

@@ -236,6 +236,34 @@ void enc32_avx512(const isx_obs *s, size_t n, uint32_t lo, uint32_t *d)
     enc32_scalar(s + i, n - i, lo, d + i);
 }
 
+// run starts of a group's pair ids: 16 ids per compare against their predecessors; a read's ~100 records share one id, so
+// almost every compare finds nothing
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+void pair_runs_avx512(const uint32_t *p, uint32_t n, uint32_t r0, std::vector<PairRun> &runs, uint32_t &maxp)
+{
+    if (!n) return;
+    uint32_t last = runs.empty() ? ~p[0] : runs.back().pair;
+    uint32_t m = maxp;
+    uint32_t i = 0;
+    if (p[0] != last || runs.empty()) { runs.push_back(PairRun{r0, p[0]}); m = p[0] > m ? p[0] : m; }
+    i = 1;
+    for (; i + 16 <= n; i += 16) {
+        const __m512i v = _mm512_loadu_si512(reinterpret_cast<const void *>(p + i));
+        const __m512i q = _mm512_loadu_si512(reinterpret_cast<const void *>(p + i - 1));
+        __mmask16 k = _mm512_cmpneq_epu32_mask(v, q);
+        while (k) {
+            const int b = __builtin_ctz((unsigned)k);
+            k = (__mmask16)(k & (k - 1));
+            const uint32_t x = p[i + (uint32_t)b];
+            runs.push_back(PairRun{r0 + i + (uint32_t)b, x});
+            m = x > m ? x : m;
+        }
+    }
+    for (; i < n; i++)
+        if (p[i] != p[i - 1]) { runs.push_back(PairRun{r0 + i, p[i]}); m = p[i] > m ? p[i] : m; }
+    maxp = m;
+}
+
 struct Task {
     int64_t in_a = 0, in_b = 0;         // input groups
     int64_t out_a = 0, out_b = 0;       // device groups of the task's region
@@ -295,14 +323,17 @@ int encode_obs(HostPool &pool, EncodeJob &J)
             maxp = m;
         }
         if (J.runs && have_pairs) {
-            uint32_t last = runs.empty() ? 0xFFFFFFFFu : runs.back().pair;
-            uint32_t m = maxp;
             const uint32_t r0 = (uint32_t)(og * G);
-            for (uint32_t i = 0; i < n; i++) {
-                const uint32_t p = psrc[i];
-                if (p != last || runs.empty()) { runs.push_back(PairRun{r0 + i, p}); last = p; m = p > m ? p : m; }
+            if (fast) pair_runs_avx512(psrc, n, r0, runs, maxp);
+            else {
+                uint32_t last = runs.empty() ? 0xFFFFFFFFu : runs.back().pair;
+                uint32_t m = maxp;
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t p = psrc[i];
+                    if (p != last || runs.empty()) { runs.push_back(PairRun{r0 + i, p}); last = p; m = p > m ? p : m; }
+                }
+                maxp = m;
             }
-            maxp = m;
         }
         const int64_t ch = og / gpc;
         J.cmin[ch] = std::min(J.cmin[ch], lo); J.cmax[ch] = std::max(J.cmax[ch], hi); J.cany[ch] = 1;
