@@ -41,7 +41,6 @@ struct Slot {
     uint8_t *h_in = nullptr, *d_in = nullptr;
     size_t in_bytes = 0;
     size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_rec = 0, off_runs = 0, off_ridx = 0;
-    std::vector<isxenc::PairRun> runs;      // pair-id runs of the batch being submitted
     uint8_t *h_out = nullptr;
     size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0, o_cov16 = 0, o_rare = 0;
     std::vector<isx_rare> rare_big;         // more clonTR entries than the pinned block holds / the device list overflowed
@@ -296,26 +295,19 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     J.n_obs = n_obs; J.n_pos = n_pos; J.record_bytes = p->rb;
     J.rec = s.h_in + s.off_rec; J.gbase = reinterpret_cast<uint32_t *>(s.h_in + s.off_gbase);
     J.pair_out = nullptr;
-    J.runs = linkage ? &s.runs : nullptr;
+    if (linkage) {
+        J.runs_out = reinterpret_cast<isxenc::PairRun *>(s.h_in + s.off_runs); J.cap_runs = p->cap_runs;
+        J.run_index_out = reinterpret_cast<uint32_t *>(s.h_in + s.off_ridx);
+    }
     J.cmin = s.cmin.data(); J.cmax = s.cmax.data(); J.cany = s.cany.data();
     J.cap_rec = p->cap_rec; J.slack = p->slack;
     const int erc = isxenc::encode_obs(*p->pool, J);
     if (erc == isxenc::ENC_CAPACITY) { isx_set_error("isx_pipe_submit: the stream jumps too often for the pipe's record capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
     if (erc == isxenc::ENC_MM_RANGE) { isx_set_error("an observation has mm >= 256"); return ISX_ERR_MM_RANGE; }
     if (erc == isxenc::ENC_BAD_POS) { isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
-    if (linkage) {          // pair-id runs + the run that holds the first record of every 1024-record chunk
-        if (s.runs.size() > p->cap_runs) { isx_set_error("isx_pipe_submit: pair ids change too often along the stream (a read pair's records must be consecutive)"); return ISX_ERR_CAPACITY; }
-        if (s.runs.empty()) s.runs.push_back(isxenc::PairRun{0u, 0u});
-        memcpy(s.h_in + s.off_runs, s.runs.data(), s.runs.size() * sizeof(isxenc::PairRun));
-        uint32_t *ridx = reinterpret_cast<uint32_t *>(s.h_in + s.off_ridx);
-        const uint64_t n_ch = (uint64_t)J.n_rec / ISX_CHUNK;
-        size_t r = 0;
-        for (uint64_t ch = 0; ch < n_ch; ch++) {
-            const uint32_t first = (uint32_t)(ch * ISX_CHUNK);
-            while (r + 1 < s.runs.size() && s.runs[r + 1].first <= first) r++;
-            ridx[ch] = (uint32_t)r;
-        }
-        b->n_runs = (uint32_t)s.runs.size();
+    if (linkage) {          // pair-id runs + run index were written into the arena by the encoder's threads
+        if (J.n_runs > p->cap_runs) { isx_set_error("isx_pipe_submit: pair ids change too often along the stream (a read pair's records must be consecutive)"); return ISX_ERR_CAPACITY; }
+        b->n_runs = (uint32_t)J.n_runs;
     }
     if (J.passes > 1 && J.n_groups_in > 0)            // remember how jumpy this stream is: the next batch gets its slack up front
         p->slack = std::max(p->slack, 1.25 * ((double)J.n_groups_real / (double)J.n_groups_in - 1.0) + 0.01);
@@ -382,7 +374,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
     s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
     if (linkage) {
-        const size_t rb = s.runs.size() * sizeof(isxenc::PairRun), ib = (size_t)(b->n_rec / ISX_CHUNK) * sizeof(uint32_t);
+        const size_t rb = (size_t)b->n_runs * sizeof(isxenc::PairRun), ib = (size_t)(b->n_rec / ISX_CHUNK) * sizeof(uint32_t);
         HIP_TRY(hipMemcpyAsync(s.d_in + s.off_runs, s.h_in + s.off_runs, rb, hipMemcpyHostToDevice, p->s_h2d));
         HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ridx, s.h_in + s.off_ridx, ib, hipMemcpyHostToDevice, p->s_h2d));
         s.h2d_bytes += (int64_t)(rb + ib);

@@ -322,7 +322,7 @@ int encode_obs(HostPool &pool, EncodeJob &J)
             for (uint32_t i = n; i < G; i++) pd[i] = 0;
             maxp = m;
         }
-        if (J.runs && have_pairs) {
+        if (J.runs_out && have_pairs) {
             const uint32_t r0 = (uint32_t)(og * G);
             if (fast) pair_runs_avx512(psrc, n, r0, runs, maxp);
             else {
@@ -414,14 +414,35 @@ int encode_obs(HostPool &pool, EncodeJob &J)
             int64_t real = 0;
             uint32_t mp = 0;
             for (auto &T : tasks) { real += T.need; mp = std::max(mp, T.max_pair); }
-            if (J.runs) {                                   // tasks own ascending regions: concatenation stays sorted
-                J.runs->clear();
-                size_t nr = 0;
-                for (auto &T : tasks) nr += T.runs.size();
-                J.runs->reserve(nr + 1);
-                for (auto &T : tasks)
-                    for (const PairRun &r : T.runs)
-                        if (J.runs->empty() || J.runs->back().pair != r.pair) J.runs->push_back(r);
+            if (J.runs_out) {                               // tasks own ascending regions: concatenation stays sorted
+                std::vector<size_t> at(tasks.size() + 1, 0);
+                for (size_t t = 0; t < tasks.size(); t++) at[t + 1] = at[t] + tasks[t].runs.size();
+                J.n_runs = at.back();
+                if (J.n_runs == 0) { J.n_runs = 1; if (J.cap_runs) J.runs_out[0] = PairRun{0u, 0u}; at.back() = 1; }
+                else if (J.n_runs <= J.cap_runs)
+                    pool.run((int)tasks.size(), [&](int t) {
+                        if (!tasks[(size_t)t].runs.empty())
+                            memcpy(J.runs_out + at[(size_t)t], tasks[(size_t)t].runs.data(), tasks[(size_t)t].runs.size() * sizeof(PairRun));
+                    });
+                if (J.n_runs <= J.cap_runs && J.run_index_out) {
+                    const int64_t n_ch = n_rec / CHUNK;
+                    const int pieces = (int)std::max<int64_t>(1, std::min<int64_t>(n_ch / 4096, (int64_t)4 * pool.size()));
+                    const PairRun *R = J.runs_out;
+                    const size_t nR = J.n_runs;
+                    pool.run(pieces, [&](int pc) {
+                        const int64_t c0 = n_ch * pc / pieces, c1 = n_ch * (pc + 1) / pieces;
+                        // last run with first <= c0 * CHUNK
+                        size_t lo = 0, hi = nR;
+                        const uint32_t f0 = (uint32_t)(c0 * CHUNK);
+                        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (R[mid].first <= f0) lo = mid; else hi = mid; }
+                        size_t r = lo;
+                        for (int64_t ch = c0; ch < c1; ch++) {
+                            const uint32_t first = (uint32_t)(ch * CHUNK);
+                            while (r + 1 < nR && R[r + 1].first <= first) r++;
+                            J.run_index_out[ch] = (uint32_t)r;
+                        }
+                    });
+                }
             }
             J.n_groups_real = real; J.max_pair = mp;
             (void)gpp;

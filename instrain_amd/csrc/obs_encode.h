@@ -58,8 +58,13 @@ struct EncodeJob {
     void *rec = nullptr;                // cap_rec records of record_bytes
     uint32_t *gbase = nullptr;          // cap_rec / group
     uint32_t *pair_out = nullptr;       // cap_rec pair ids per device record, or NULL ...
-    std::vector<PairRun> *runs = nullptr;   // ... and / or the same as runs of equal ids (what the pipe uploads: ~0.06 B per
-                                        // record instead of 4; padding records continue the run before them)
+    // ... and / or the same as runs of equal ids (what the pipe uploads: ~0.06 B per record instead of 4; padding records
+    // continue the run before them): runs_out[cap_runs] ascending by first record, run_index_out[n_rec / 1024] = the run that
+    // holds the first record of every 1024-record chunk.  Both are written by the pool's threads.
+    PairRun *runs_out = nullptr;
+    size_t cap_runs = 0;
+    uint32_t *run_index_out = nullptr;
+    size_t n_runs = 0;                  // result (> cap_runs: the table did not fit, nothing was written)
     uint32_t *cmin = nullptr, *cmax = nullptr;   // per ISX_CHUNK (1024) device records: position range ...
     uint8_t *cany = nullptr;            // ... and whether the chunk holds a real record
     int64_t cap_rec = 0;
