@@ -302,6 +302,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     J.cmin = s.cmin.data(); J.cmax = s.cmax.data(); J.cany = s.cany.data();
     J.cap_rec = p->cap_rec; J.slack = p->slack;
     const int erc = isxenc::encode_obs(*p->pool, J);
+    const double t_enc = now_ms();
     if (erc == isxenc::ENC_CAPACITY) { isx_set_error("isx_pipe_submit: the stream jumps too often for the pipe's record capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
     if (erc == isxenc::ENC_MM_RANGE) { isx_set_error("an observation has mm >= 256"); return ISX_ERR_MM_RANGE; }
     if (erc == isxenc::ENC_BAD_POS) { isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
@@ -358,6 +359,9 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     b->d_gpos16 = s.d_gpos16; b->gpos16_shift = 5;
     s.encode_ms = (float)(now_ms() - t0);
     s.encode_passes = J.passes;
+    if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
+        fprintf(stderr, "[isx_pipe_submit] records %.2f ms (%d pass), reference + bounds + windows %.2f ms; %lld obs, %lld runs\n",
+                t_enc - t0, J.passes, now_ms() - t_enc, (long long)n_obs, (long long)J.n_runs);
 
     // ---- copy-in queue ----
     hipStream_t ps = c->pstream[b->ps];
