@@ -297,7 +297,7 @@ def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=3, with_cpu
     pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
                        max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
                        pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20, jump_slack=0.5)
-    stream(pipe, ws, min(2, len(ws)), depth)                 # warm-up (also teaches the pipe this stream's jump slack)
+    stream(pipe, ws, len(ws), depth)                         # warm-up: one pass over the shard (every slot's tables and linkage buffers reach their steady size; the pipe learns the stream's jump slack)
     barrier()
     stats = []
     t0 = time.perf_counter()

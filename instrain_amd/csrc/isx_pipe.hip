@@ -485,6 +485,8 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
         const double t0 = now_ms();
         HIP_TRY(hipEventSynchronize(s.ev_d2h1));
         out->collect_wait_ms = (float)(now_ms() - t0);
+        const double t_c0 = now_ms();
+        double t_fin = 0, t_rare = 0;
         hipStream_t ps = c->pstream[b->ps];
         bool redo = false;
         for (int attempt = 0;; attempt++) {
@@ -501,6 +503,7 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
             if ((rc = launch_pass(b)) != ISX_OK) { s.state = 2; return rc; }
             redo = true;
         }
+        t_fin = now_ms();
         if (redo && dense) {                        // the copied-out tables predate the repeated pass
             HIP_TRY(hipMemcpy(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
@@ -527,6 +530,7 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
                 std::sort(rr, rr + n_rare, [](const isx_rare &x, const isx_rare &y) { return x.gpos < y.gpos; });
             }
         }
+        t_rare = now_ms();
         const size_t n_snv = (size_t)b->sizes.n_snv;
         isx_snv *rows = reinterpret_cast<isx_snv *>(s.h_out + s.o_snv);
         if (n_snv > p->snv_prefix || redo) {
@@ -534,6 +538,9 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
             if (n_snv) HIP_TRY(hipMemcpy(rows, b->d_snv, n_snv * sizeof(isx_snv), hipMemcpyDeviceToHost));
         }
         std::sort(rows, rows + n_snv, [](const isx_snv &x, const isx_snv &y) { return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm; });
+        if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
+            fprintf(stderr, "[isx_pipe_collect] wait %.2f ms, finish (sizes, linkage) %.2f ms, clonTR list (%u) %.2f ms, snv rows (%zu) %.2f ms\n",
+                    out->collect_wait_ms, t_fin - t_c0, b->n_rare, t_rare - t_fin, n_snv, now_ms() - t_rare);
         s.state = 2;
     }
     out->ticket = ticket;
