@@ -296,7 +296,10 @@ typedef struct {
     int32_t want_counts;        /* n_mm_bins == 1: 1 = also hand back the per-base count table and the dense clonTR array
                                  * (16 + 4 more bytes per position over PCIe: the reference keeps them only with
                                  * --store_everything, profile_utilities.py:205-211); 0 = the shrunk tables below */
-    int32_t reserved;
+    int32_t ring_kib;           /* pinned staging of a slot's records: 0 = automatic (the whole stream when it is at most
+                                 * 512 MiB -- 128 MiB with depth 1 --, otherwise a ring of 2 x 128 MiB -- 2 x 32 MiB --
+                                 * through which it leaves in waves while it is being encoded), > 0 = a ring of that
+                                 * many KiB (at least 32), < 0 = never a ring */
 } isx_pipe_params;
 
 /* one entry of the sparse clonTR table (positions whose coverage reaches rarefied_coverage) */
@@ -315,10 +318,11 @@ typedef struct {
     const uint16_t *coverage16; /* [n_pos] covT = min(sum of the four counts, 65535); n_saturated positions hold 65535
                                  * (their exact counts: isx_batch_fetch_dense on `batch`, or want_counts) */
     const float *clon;          /* [n_pos] clonT, NaN below min_cov */
-    const isx_rare *rare;       /* [n_rare] clonTR as a sparse table, ascending gpos */
+    const isx_rare *rare;       /* [n_rare] clonTR as a sparse table, ascending gpos; NULL when more than n_pos / 8
+                                 * positions have one (a deep sample): then clon_rarefied holds the dense array */
     int64_t n_rare, n_saturated;
     const uint32_t *counts;     /* [n_pos][4], NULL unless want_counts */
-    const float *clon_rarefied; /* [n_pos] dense clonTR, NULL unless want_counts */
+    const float *clon_rarefied; /* [n_pos] dense clonTR (NaN = none); NULL unless want_counts or rare == NULL */
     const isx_snv *snv;         /* [sizes.n_snv], canonical (gpos, mm) order; both modes */
     /* the slot itself: isx_batch_fetch_entries / isx_batch_fetch_ld / isx_batch_summarize / isx_compare_* may be
      * called on it until isx_pipe_release (n_mm_bins > 1: the entry table is fetched this way) */
@@ -355,6 +359,12 @@ int isx_pipe_release(isx_pipe *p, int64_t ticket);
 int isx_encode_obs(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int64_t n_pos, int32_t record_bytes,
                    int32_t host_threads, double slack, int64_t cap_rec, void *rec, uint32_t *gbase, uint32_t *pair_out,
                    int64_t *n_rec, int32_t *passes);
+/* The same through the pipe's staging ring (what a pipe does when a batch's records exceed its ring): the encoder
+ * writes waves of at most ring_records / 2 records (ring_records: a multiple of 4096; pair must be NULL) into a private
+ * ring and every finished wave is copied to its place in rec -- the copy standing in for the DMA engine. */
+int isx_encode_obs_ring(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int64_t n_pos, int32_t record_bytes,
+                        int32_t host_threads, double slack, int64_t cap_rec, int64_t ring_records, void *rec,
+                        uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec, int32_t *passes);
 
 /* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ----
  * Two passes over the (memory-mapped, compressed) file, like the reference, none of which holds the file's reads:

@@ -849,72 +849,105 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
     }
 
     // ---- pair tables: one task per (reference, name-hash partition) ----
-    struct Part { uint32_t ref, p, P; std::vector<PairInfo> info; std::string no_nm; };
+    // The reads are first bucketed by partition (two passes over the per-segment runs: count, then fill an index list in
+    // file order), so that a partition's task touches only its own reads -- not every read of the reference.
+    struct Part { uint32_t ref, p, P; uint64_t r0, r1; std::vector<PairInfo> info; std::string no_nm; };
+    struct ReadRef { uint32_t seg, i; };
     std::vector<Part> parts;
+    std::vector<size_t> first_part(n_ref + 1, 0);
     for (size_t t = 0; t < n_ref; t++) {
+        first_part[t] = parts.size();
         if (!B.ref_reads[t]) continue;
-        const uint32_t P = (uint32_t)std::min<int64_t>(64, B.ref_reads[t] / 32768 + 1);
-        for (uint32_t p = 0; p < P; p++) parts.push_back(Part{(uint32_t)t, p, P, {}, {}});
+        const uint32_t P = (uint32_t)std::min<int64_t>(4096, B.ref_reads[t] / 16384 + 1);
+        for (uint32_t p = 0; p < P; p++) parts.push_back(Part{(uint32_t)t, p, P, 0, 0, {}, {}});
     }
+    first_part[n_ref] = parts.size();
+    struct FlatRun { uint32_t ref, seg, i0, i1; size_t cur; };
+    std::vector<FlatRun> flat;
+    size_t n_cur = 0;
+    for (size_t t = 0; t < n_ref; t++)
+        for (const Run &r : runs[t]) { flat.push_back(FlatRun{(uint32_t)t, r.seg, r.i0, r.i1, n_cur}); n_cur += first_part[t + 1] - first_part[t]; }
+    std::vector<uint64_t> cur(n_cur, 0);
+    auto part_of = [](uint64_t h64, uint32_t P) -> uint32_t { return P == 1 ? 0u : (uint32_t)((h64 >> 40) % P); };
+    pool.run((int)flat.size(), [&](int k) {
+        const FlatRun &f = flat[(size_t)k];
+        const uint32_t P = (uint32_t)(first_part[f.ref + 1] - first_part[f.ref]);
+        const auto &rs = B.seg_reads[f.seg];
+        uint64_t *c = cur.data() + f.cur;
+        for (uint32_t i = f.i0; i < f.i1; i++) c[part_of(rs[i].h64, P)]++;
+    });
+    {   // counts -> write cursors: a partition's reads stay in file order (its runs in order, each run's reads in order)
+        uint64_t at = 0;
+        size_t k0 = 0;
+        for (size_t t = 0; t < n_ref; t++) {
+            const size_t nr = runs[t].size(), P = first_part[t + 1] - first_part[t];
+            for (size_t p = 0; p < P; p++) {
+                parts[first_part[t] + p].r0 = at;
+                for (size_t k = 0; k < nr; k++) { uint64_t &c = cur[flat[k0 + k].cur + p]; const uint64_t n = c; c = at; at += n; }
+                parts[first_part[t] + p].r1 = at;
+            }
+            k0 += nr;
+        }
+    }
+    std::vector<ReadRef> order((size_t)(parts.empty() ? 0 : parts.back().r1));
+    pool.run((int)flat.size(), [&](int k) {
+        const FlatRun &f = flat[(size_t)k];
+        const uint32_t P = (uint32_t)(first_part[f.ref + 1] - first_part[f.ref]);
+        const auto &rs = B.seg_reads[f.seg];
+        uint64_t *c = cur.data() + f.cur;
+        for (uint32_t i = f.i0; i < f.i1; i++) order[(size_t)c[part_of(rs[i].h64, P)]++] = ReadRef{f.seg, i};
+    });
+    std::vector<uint64_t>().swap(cur);
     B.read_pair.assign((size_t)B.n_reads, 0xFFFFFFFFu);
     pool.run((int)parts.size(), [&](int pi) {
         Part &pt = parts[(size_t)pi];
         NameTable tab;
-        size_t mine = 0;
-        for (const Run &r : runs[pt.ref]) {
-            const auto &rs = B.seg_reads[r.seg];
-            for (uint32_t i = r.i0; i < r.i1; i++) mine += (pt.P == 1 || (rs[i].h64 >> 40) % pt.P == pt.p);
-        }
-        tab.init(mine);
-        pt.info.reserve(mine / 2 + 8);
-        for (const Run &r : runs[pt.ref]) {
-            const auto &rs = B.seg_reads[r.seg];
-            const char *names = B.seg_names[r.seg].data();
-            const uint64_t ord0 = B.segs[r.seg].read0;
-            for (uint32_t i = r.i0; i < r.i1; i++) {
-                const ReadLite &L = rs[i];
-                if (pt.P > 1 && (L.h64 >> 40) % pt.P != pt.p) continue;
-                // get_paired_reads skips unmapped reads and reads without aligned bases (get_reference_positions() == []);
-                // the latter still take part in htslib's overlap bookkeeping by name, so they get an entry that counts nothing
-                const bool counted = !(L.flag & FUNMAP) && L.any;
-                if (L.flag & FUNMAP) continue;
-                if (counted && !L.has_nm) { if (pt.no_nm.empty()) pt.no_nm.assign(names + L.name_off, L.name_len); continue; }
-                uint64_t slot = L.h64 & tab.mask;
-                const uint64_t hk = L.h64 | 1;              // 0 marks an empty slot
-                uint32_t idx = 0xFFFFFFFFu;
-                for (;;) {
-                    if (tab.key[slot] == 0) break;
-                    if (tab.key[slot] == hk) {
-                        const PairInfo &e = pt.info[tab.val[slot]];
-                        if (e.name_len == L.name_len && memcmp(B.seg_names[e.name_seg].data() + e.name_off, names + L.name_off, L.name_len) == 0) { idx = tab.val[slot]; break; }
-                    }
-                    slot = (slot + 1) & tab.mask;
+        tab.init((size_t)(pt.r1 - pt.r0));
+        pt.info.reserve((size_t)(pt.r1 - pt.r0) / 2 + 8);
+        for (uint64_t q = pt.r0; q < pt.r1; q++) {
+            const ReadRef rr = order[(size_t)q];
+            const ReadLite &L = B.seg_reads[rr.seg][rr.i];
+            const char *names = B.seg_names[rr.seg].data();
+            // get_paired_reads skips unmapped reads and reads without aligned bases (get_reference_positions() == []);
+            // the latter still take part in htslib's overlap bookkeeping by name, so they get an entry that counts nothing
+            const bool counted = !(L.flag & FUNMAP) && L.any;
+            if (L.flag & FUNMAP) continue;
+            if (counted && !L.has_nm) { if (pt.no_nm.empty()) pt.no_nm.assign(names + L.name_off, L.name_len); continue; }
+            uint64_t slot = L.h64 & tab.mask;
+            const uint64_t hk = L.h64 | 1;              // 0 marks an empty slot
+            uint32_t idx = 0xFFFFFFFFu;
+            for (;;) {
+                if (tab.key[slot] == 0) break;
+                if (tab.key[slot] == hk) {
+                    const PairInfo &e = pt.info[tab.val[slot]];
+                    if (e.name_len == L.name_len && memcmp(B.seg_names[e.name_seg].data() + e.name_off, names + L.name_off, L.name_len) == 0) { idx = tab.val[slot]; break; }
                 }
-                if (idx == 0xFFFFFFFFu) {
-                    idx = (uint32_t)pt.info.size();
-                    tab.key[slot] = hk; tab.val[slot] = idx;
-                    PairInfo e{};
-                    e.name_seg = r.seg; e.name_off = L.name_off; e.name_len = L.name_len;
-                    e.insert = -1;
-                    if (counted) { e.nm = L.nm; e.mapq = L.mapq; e.length = L.qlen; e.reads = 1; e.start = L.first; e.stop = L.last; }
-                    pt.info.push_back(e);
-                } else if (counted) {
-                    PairInfo &e = pt.info[idx];
-                    if (e.reads == 0) { e.nm = L.nm; e.mapq = L.mapq; e.length = L.qlen; e.reads = 1; e.start = L.first; e.stop = L.last; e.insert = -1; }
-                    else {
-                        e.nm += L.nm;
-                        e.reads += 1;
-                        e.length += L.qlen;
-                        e.mapq = std::max<int64_t>(e.mapq, L.mapq);
-                        if (e.reads == 2) {
-                            if (L.last > e.start) e.insert = L.last - e.start;
-                            else e.insert = e.stop - L.first;
-                        } else e.insert = -1;
-                        e.start = 0; e.stop = 0;
-                    }
-                }
-                B.read_pair[(size_t)(ord0 + i)] = idx;       // local index for now
+                slot = (slot + 1) & tab.mask;
             }
+            if (idx == 0xFFFFFFFFu) {
+                idx = (uint32_t)pt.info.size();
+                tab.key[slot] = hk; tab.val[slot] = idx;
+                PairInfo e{};
+                e.name_seg = rr.seg; e.name_off = L.name_off; e.name_len = L.name_len;
+                e.insert = -1;
+                if (counted) { e.nm = L.nm; e.mapq = L.mapq; e.length = L.qlen; e.reads = 1; e.start = L.first; e.stop = L.last; }
+                pt.info.push_back(e);
+            } else if (counted) {
+                PairInfo &e = pt.info[idx];
+                if (e.reads == 0) { e.nm = L.nm; e.mapq = L.mapq; e.length = L.qlen; e.reads = 1; e.start = L.first; e.stop = L.last; e.insert = -1; }
+                else {
+                    e.nm += L.nm;
+                    e.reads += 1;
+                    e.length += L.qlen;
+                    e.mapq = std::max<int64_t>(e.mapq, L.mapq);
+                    if (e.reads == 2) {
+                        if (L.last > e.start) e.insert = L.last - e.start;
+                        else e.insert = e.stop - L.first;
+                    } else e.insert = -1;
+                    e.start = 0; e.stop = 0;
+                }
+            }
+            B.read_pair[(size_t)(B.segs[rr.seg].read0 + rr.i)] = idx;       // local index for now
         }
     });
     for (auto &pt : parts) if (!pt.no_nm.empty()) { isx_set_error("read without NM tag: " + pt.no_nm); return ISX_ERR_IO; }
@@ -924,25 +957,15 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
     if (part_base.back() >= 0xFFFFFFFFull) { isx_set_error("more than 2^32 read names"); return ISX_ERR_ARG; }
     B.pairs.resize((size_t)part_base.back());
     B.ref_pair0.assign(n_ref + 1, 0);
-    {
-        std::vector<size_t> first_part(n_ref + 1, parts.size());
-        for (size_t i = parts.size(); i-- > 0;) first_part[parts[i].ref] = i;
-        uint64_t run = part_base.back();
-        for (size_t t = n_ref; t-- > 0;) { if (first_part[t] < parts.size()) run = part_base[first_part[t]]; B.ref_pair0[t] = run; }
-        B.ref_pair0[n_ref] = part_base.back();
-    }
+    for (size_t t = 0; t <= n_ref; t++) B.ref_pair0[t] = part_base[first_part[t]];
     pool.run((int)parts.size(), [&](int pi) {
         Part &pt = parts[(size_t)pi];
         std::copy(pt.info.begin(), pt.info.end(), B.pairs.begin() + (ptrdiff_t)part_base[(size_t)pi]);
         const uint32_t base = (uint32_t)part_base[(size_t)pi];
-        for (const Run &r : runs[pt.ref]) {
-            const auto &rs = B.seg_reads[r.seg];
-            const uint64_t ord0 = B.segs[r.seg].read0;
-            for (uint32_t i = r.i0; i < r.i1; i++) {
-                if (pt.P > 1 && (rs[i].h64 >> 40) % pt.P != pt.p) continue;
-                uint32_t &v = B.read_pair[(size_t)(ord0 + i)];
-                if (v != 0xFFFFFFFFu) v += base;
-            }
+        for (uint64_t q = pt.r0; q < pt.r1; q++) {
+            const ReadRef rr = order[(size_t)q];
+            uint32_t &v = B.read_pair[(size_t)(B.segs[rr.seg].read0 + rr.i)];
+            if (v != 0xFFFFFFFFu) v += base;
         }
         std::vector<PairInfo>().swap(pt.info);
     });

@@ -5,9 +5,11 @@
 // spawn_profile_workers, :273-314 recieve_profile_results): splits go in, SplitObjects come back, every split
 // is profiled once.  Here the unit is a batch of splits and the three stages run on different engines:
 //
-//   host threads   isx_obs (8 B) -> resident records (2 / 4 B) straight into the slot's pinned input arena
-//   copy-in queue  ONE contiguous arena: split bounds | window directory | reference codes | group bases |
-//                  records | pair ids  -> the slot's device arena of the same layout (hipMemcpyAsync)
+//   host threads   isx_obs (8 B) -> resident records (2 / 4 B) straight into the slot's pinned staging
+//   copy-in queue  split bounds | window directory | reference codes | group bases | run index | records -> the slot's
+//                  device arena of the same layout (hipMemcpyAsync); a slot whose records exceed 512 MiB stages
+//                  them through a pinned ring of two 128 MiB halves instead (waves: one half is copied while the
+//                  threads fill the other), because pinning gigabytes costs more than profiling them
 //   pass queue     k_pileup_dense / k_pileup_mm (+ the cursor publication) once the copy-in event has fired
 //   copy-out queue counts | clonality | rarefied clonality | first SNV rows -> the slot's pinned result block
 //
@@ -39,10 +41,17 @@ double now_ms()
 struct Slot {
     isx_batch *b = nullptr;
     uint8_t *h_in = nullptr, *d_in = nullptr;
-    size_t in_bytes = 0;
-    size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_rec = 0, off_runs = 0, off_ridx = 0;
+    size_t in_bytes = 0;                    // of the device arena; the pinned one ends after the ring when the pipe stages through one
+    size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_ridx = 0, off_rec = 0;   // records last
+    // pair-id runs (linkage): their own pinned / device blocks, grown when a batch has more runs than any before it
+    isxenc::PairRun *h_runs = nullptr;
+    uint2 *d_runs = nullptr;
+    size_t cap_runs = 0;
+    hipEvent_t ev_ring[2] = {nullptr, nullptr};     // ring mode: the copy that last read each half
+    bool ring_busy[2] = {false, false};
     uint8_t *h_out = nullptr;
     size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0, o_cov16 = 0, o_rare = 0;
+    bool rare_dense = false;                // the clonTR table of the last batch went back as the dense array
     std::vector<isx_rare> rare_big;         // more clonTR entries than the pinned block holds / the device list overflowed
     std::vector<uint32_t> cmin, cmax;
     std::vector<uint8_t> cany;
@@ -94,7 +103,7 @@ struct isx_pipe {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     int64_t next_ticket = 0;
     int64_t cap_rec = 0;
-    size_t cap_runs = 0;                    // pair-id runs a slot can take (linkage)
+    int64_t ring_half = 0;                  // records per half of a slot's staging ring; 0 = the pinned arena holds the whole stream
     int rb = 2;                             // record bytes
     uint32_t G = ISX_GROUP16;
     size_t snv_prefix = 0;                  // SNV rows copied out with the dense tables
@@ -121,6 +130,9 @@ static void pipe_free(isx_pipe *p)
         if (s.d_gpos16) (void)hipFree(s.d_gpos16);
         if (s.d_in) (void)hipFree(s.d_in);
         if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.d_runs) (void)hipFree(s.d_runs);
+        if (s.h_runs) (void)hipHostFree(s.h_runs);
+        for (hipEvent_t e : s.ev_ring) if (e) (void)hipEventDestroy(e);
         if (s.h_out) (void)hipHostFree(s.h_out);
         for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_pass, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
     }
@@ -191,12 +203,19 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.off_win = o; o = up(o + ((size_t)cap_pos / 64 + 2) * sizeof(uint2));
     s.off_ref = o; o = up(o + (size_t)cap_pos);
     s.off_gbase = o; o = up(o + ((size_t)(p->cap_rec / p->G) + ISX_TAIL_GROUPS) * sizeof(uint32_t));
-    s.off_rec = o; o = up(o + (size_t)p->cap_rec * p->rb + ISX_TAIL_BYTES);
-    s.off_runs = o; if (prm->enable_linkage) o = up(o + p->cap_runs * sizeof(isxenc::PairRun));
     s.off_ridx = o; if (prm->enable_linkage) o = up(o + ((size_t)p->cap_rec / ISX_CHUNK + 2) * sizeof(uint32_t));
-    s.in_bytes = o;
-    HIP_TRY(hipHostMalloc(&s.h_in, s.in_bytes, hipHostMallocDefault));
+    s.off_rec = o;
+    s.in_bytes = up(o + (size_t)p->cap_rec * p->rb + ISX_TAIL_BYTES);
+    const size_t host_bytes = p->ring_half ? up(o + 2 * (size_t)p->ring_half * p->rb) : s.in_bytes;
+    HIP_TRY(hipHostMalloc(&s.h_in, host_bytes, hipHostMallocDefault));
     HIP_TRY(hipMalloc(&s.d_in, s.in_bytes));
+    if (prm->enable_linkage) {
+        // a read pair's records are consecutive: runs of tens to hundreds of records
+        s.cap_runs = (size_t)p->cap_rec / 48 + 4096;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_runs), s.cap_runs * sizeof(isxenc::PairRun), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&s.d_runs, s.cap_runs * sizeof(uint2)));
+    }
+    if (p->ring_half) for (hipEvent_t &e : s.ev_ring) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (prm->enable_linkage && p->rb == 4) HIP_TRY(hipMalloc(&s.d_gpos16, (size_t)p->cap_rec * sizeof(uint16_t)));
     // pinned result block
     o = 0;
@@ -205,10 +224,9 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
         s.o_cov16 = o; o = up(o + (size_t)cap_pos * 2);
         s.o_clon = o; o = up(o + (size_t)cap_pos * 4);
         s.o_rare = o; if (prm->rarefied_coverage > 0) o = up(o + p->rare_prefix * sizeof(isx_rare));
-        if (p->pp.want_counts) {
-            s.o_counts = o; o = up(o + (size_t)cap_pos * 16);
-            s.o_clonr = o; if (prm->rarefied_coverage > 0) o = up(o + (size_t)cap_pos * 4);
-        }
+        // the dense clonTR array: always with want_counts, otherwise only when the sparse list would not be sparse
+        s.o_clonr = o; if (prm->rarefied_coverage > 0) o = up(o + (size_t)cap_pos * 4);
+        if (p->pp.want_counts) { s.o_counts = o; o = up(o + (size_t)cap_pos * 16); }
     }
     s.out_bytes = o;
     HIP_TRY(hipHostMalloc(&s.h_out, s.out_bytes, hipHostMallocDefault));
@@ -242,7 +260,18 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     const uint64_t want = (uint64_t)((double)pp->max_obs * (1.0 + js)) + 4 * ISX_PAD;
     p->cap_rec = (int64_t)((want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
     if ((uint64_t)p->cap_rec >= 0xFFFFFFFFull) { delete p; isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
-    p->cap_runs = (size_t)p->cap_rec / 4 + 1024;      // a read pair's records are consecutive: runs of tens to hundreds of records
+    {   // staging: the whole stream in pinned memory, or -- pinning gigabytes costs about a second per 4 GB, more than
+        // profiling them -- waves through a ring of two halves that the copy engine drains while the threads fill
+        const size_t rec_bytes = (size_t)p->cap_rec * p->rb;
+        size_t ring = 0;
+        if (pp->ring_kib > 0) ring = (size_t)pp->ring_kib << 10;
+        else if (pp->ring_kib == 0 && pp->depth == 1 && rec_bytes > ((size_t)128 << 20)) ring = (size_t)64 << 20;   // no other batch to overlap with
+        else if (pp->ring_kib == 0 && rec_bytes > ((size_t)512 << 20)) ring = (size_t)256 << 20;
+        if (ring && ring < rec_bytes) {
+            p->ring_half = (int64_t)(ring / 2 / p->rb) / ISX_PAD * ISX_PAD;
+            if (p->ring_half < 2 * ISX_PAD) { delete p; isx_set_error("isx_pipe_create: ring_kib too small (at least 32)"); return ISX_ERR_ARG; }
+        }
+    }
     p->snv_prefix = (size_t)std::min<int64_t>(std::max<int64_t>(pp->max_pos / 64, 1 << 16), 1 << 22);
     // clonTR list: the device list can hold every position; a sixteenth of that travels with every batch, the
     // rest only when a batch really has that many (deep samples)
@@ -290,24 +319,61 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     HIP_TRY(hipSetDevice(c->device));
     const bool dense = b->M == 1, linkage = p->prm.enable_linkage != 0;
 
-    // ---- host threads: records + group bases (+ pair-id runs) into the pinned arena, reference codes, bounds ----
+    // ---- host threads: records + group bases (+ pair-id runs) into pinned staging, reference codes, bounds ----
     const double t0 = now_ms();
+    const bool ring = p->ring_half > 0;
+    uint8_t *d_rec = s.d_in + s.off_rec;
+    hipError_t ring_err = hipSuccess;
+    size_t ring_bytes = 0;
     J.n_obs = n_obs; J.n_pos = n_pos; J.record_bytes = p->rb;
     J.rec = s.h_in + s.off_rec; J.gbase = reinterpret_cast<uint32_t *>(s.h_in + s.off_gbase);
     J.pair_out = nullptr;
-    if (linkage) {
-        J.runs_out = reinterpret_cast<isxenc::PairRun *>(s.h_in + s.off_runs); J.cap_runs = p->cap_runs;
-        J.run_index_out = reinterpret_cast<uint32_t *>(s.h_in + s.off_ridx);
-    }
     J.cmin = s.cmin.data(); J.cmax = s.cmax.data(); J.cany = s.cany.data();
-    J.cap_rec = p->cap_rec; J.slack = p->slack;
-    const int erc = isxenc::encode_obs(*p->pool, J);
+    J.cap_rec = p->cap_rec;
+    if (ring) {
+        // the copy-in queue starts here: every finished wave leaves for its place in the device arena while the next
+        // one is being written into the other half
+        HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+        const size_t half_bytes = (size_t)p->ring_half * p->rb, grp_bytes = (size_t)p->G * p->rb;
+        J.ring_groups = p->ring_half / p->G;
+        J.wave_begin = [&](int h) {
+            if (s.ring_busy[h]) { const hipError_t e = hipEventSynchronize(s.ev_ring[h]); if (e != hipSuccess && ring_err == hipSuccess) ring_err = e; s.ring_busy[h] = false; }
+        };
+        J.wave_flush = [&](int h, int64_t g0, int64_t g1) {
+            const size_t n = (size_t)(g1 - g0) * grp_bytes;
+            if (g0 == 0) ring_bytes = 0;                    // a layout that overflowed is written again from the start
+            hipError_t e = hipMemcpyAsync(d_rec + (size_t)g0 * grp_bytes, s.h_in + s.off_rec + (size_t)h * half_bytes, n, hipMemcpyHostToDevice, p->s_h2d);
+            if (e == hipSuccess) e = hipEventRecord(s.ev_ring[h], p->s_h2d);
+            if (e != hipSuccess && ring_err == hipSuccess) ring_err = e;
+            s.ring_busy[h] = true;
+            ring_bytes += n;
+        };
+    }
+    int erc = 0;
+    for (int attempt = 0;; attempt++) {
+        if (linkage) {
+            J.runs_out = s.h_runs; J.cap_runs = s.cap_runs;
+            J.run_index_out = reinterpret_cast<uint32_t *>(s.h_in + s.off_ridx);
+        }
+        J.slack = p->slack;
+        ring_bytes = 0;
+        erc = isxenc::encode_obs(*p->pool, J);
+        if (erc != isxenc::ENC_OK || !linkage || J.n_runs <= s.cap_runs || attempt == 1) break;
+        // more pair-id runs than any batch of this slot had (short fragments): larger blocks, encode again
+        HIP_TRY(hipStreamSynchronize(p->s_h2d));
+        (void)hipHostFree(s.h_runs); s.h_runs = nullptr;
+        (void)hipFree(s.d_runs); s.d_runs = nullptr;
+        s.cap_runs = J.n_runs + J.n_runs / 4 + 4096;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_runs), s.cap_runs * sizeof(isxenc::PairRun), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&s.d_runs, s.cap_runs * sizeof(uint2)));
+    }
     const double t_enc = now_ms();
+    if (ring_err != hipSuccess) { isx_set_error(std::string("isx_pipe_submit: staging ring: ") + hipGetErrorString(ring_err)); return ISX_ERR_HIP; }
     if (erc == isxenc::ENC_CAPACITY) { isx_set_error("isx_pipe_submit: the stream jumps too often for the pipe's record capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
     if (erc == isxenc::ENC_MM_RANGE) { isx_set_error("an observation has mm >= 256"); return ISX_ERR_MM_RANGE; }
     if (erc == isxenc::ENC_BAD_POS) { isx_set_error("observation gpos >= n_pos"); return ISX_ERR_ARG; }
-    if (linkage) {          // pair-id runs + run index were written into the arena by the encoder's threads
-        if (J.n_runs > p->cap_runs) { isx_set_error("isx_pipe_submit: pair ids change too often along the stream (a read pair's records must be consecutive)"); return ISX_ERR_CAPACITY; }
+    if (linkage) {          // pair-id runs + run index were written into pinned staging by the encoder's threads
+        if (J.n_runs > s.cap_runs) { isx_set_error("isx_pipe_submit: internal: pair-id run table did not fit after growing it"); return ISX_ERR_STATE; }
         b->n_runs = (uint32_t)J.n_runs;
     }
     if (J.passes > 1 && J.n_groups_in > 0)            // remember how jumpy this stream is: the next batch gets its slack up front
@@ -354,7 +420,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     b->d_rec16 = p->rb == 2 ? reinterpret_cast<uint16_t *>(s.d_in + s.off_rec) : nullptr;
     b->d_rec32 = p->rb == 4 ? reinterpret_cast<uint32_t *>(s.d_in + s.off_rec) : nullptr;
     b->d_pair = nullptr;
-    b->d_pair_runs = linkage ? reinterpret_cast<uint2 *>(s.d_in + s.off_runs) : nullptr;
+    b->d_pair_runs = linkage ? s.d_runs : nullptr;
     b->d_run_index = linkage ? reinterpret_cast<uint32_t *>(s.d_in + s.off_ridx) : nullptr;
     b->d_gpos16 = s.d_gpos16; b->gpos16_shift = 5;
     s.encode_ms = (float)(now_ms() - t0);
@@ -365,21 +431,27 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
 
     // ---- copy-in queue ----
     hipStream_t ps = c->pstream[b->ps];
-    HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+    if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
     const size_t head = s.off_ref + (size_t)n_pos;                         // bounds | windows | reference codes
     // the stream is followed by a tail of padding records / zero bases (see ISX_TAIL_BYTES): the slot's arena still
     // holds the previous batch there
-    if (p->rb == 2) memset(s.h_in + s.off_rec + (size_t)b->n_rec * 2, 0xFF, ISX_TAIL_BYTES);
-    else std::fill_n(reinterpret_cast<uint32_t *>(s.h_in + s.off_rec + (size_t)b->n_rec * 4), ISX_TAIL_BYTES / 4, (uint32_t)ISX_PAD32);
     memset(s.h_in + s.off_gbase + (size_t)(b->n_rec / p->G) * sizeof(uint32_t), 0, ISX_TAIL_GROUPS * sizeof(uint32_t));
     const size_t gb_bytes = ((size_t)(b->n_rec / p->G) + ISX_TAIL_GROUPS) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * p->rb + ISX_TAIL_BYTES;
     HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, head, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    if (ring) {             // the records left wave by wave; the tail is written on the device
+        if (p->rb == 2) HIP_TRY(hipMemsetD8Async(reinterpret_cast<hipDeviceptr_t>(d_rec + (size_t)b->n_rec * 2), 0xFF, ISX_TAIL_BYTES, p->s_h2d));
+        else HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_rec + (size_t)b->n_rec * 4), (int)ISX_PAD32, ISX_TAIL_BYTES / 4, p->s_h2d));
+        if (ring_bytes != (size_t)b->n_rec * p->rb) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; }
+    } else {
+        if (p->rb == 2) memset(s.h_in + s.off_rec + (size_t)b->n_rec * 2, 0xFF, ISX_TAIL_BYTES);
+        else std::fill_n(reinterpret_cast<uint32_t *>(s.h_in + s.off_rec + (size_t)b->n_rec * 4), ISX_TAIL_BYTES / 4, (uint32_t)ISX_PAD32);
+        HIP_TRY(hipMemcpyAsync(d_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    }
     s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
     if (linkage) {
         const size_t rb = (size_t)b->n_runs * sizeof(isxenc::PairRun), ib = (size_t)(b->n_rec / ISX_CHUNK) * sizeof(uint32_t);
-        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_runs, s.h_in + s.off_runs, rb, hipMemcpyHostToDevice, p->s_h2d));
+        HIP_TRY(hipMemcpyAsync(s.d_runs, s.h_runs, rb, hipMemcpyHostToDevice, p->s_h2d));
         HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ridx, s.h_in + s.off_ridx, ib, hipMemcpyHostToDevice, p->s_h2d));
         s.h2d_bytes += (int64_t)(rb + ib);
     }
@@ -456,8 +528,10 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
 {
     if (!p || !bam || !bp || !refs || n_refs <= 0 || !ref || !ticket) { isx_set_error("isx_pipe_submit_bam: bad argument"); return ISX_ERR_ARG; }
     BamBatch *q = nullptr;
+    const double t_in = now_ms();
     int rc = bam_batch_prepare(bam, bp, refs, n_refs, &q);
     if (rc != ISX_OK) return rc;
+    const double t_prep = now_ms();
     std::unique_ptr<BamBatch, void (*)(BamBatch *)> Q(q, bam_batch_free);
     const int64_t n_pos = bam_batch_n_pos(q), n_obs = bam_batch_n_obs(q);
     const std::vector<int64_t> &own = bam_batch_bounds(q);
@@ -468,7 +542,12 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
     J.obs = nullptr;
     J.want_pairs = p->prm.enable_linkage != 0;
     J.produce = [q](int64_t first, uint32_t count, isx_obs *o, uint32_t *pr) { bam_batch_emit(q, first, count, o, pr); };
-    return submit_common(p, n_pos, ref, n_splits, split_bounds, n_obs, J, ticket);
+    rc = submit_common(p, n_pos, ref, n_splits, split_bounds, n_obs, J, ticket);
+    const double t_sub = now_ms();
+    Q.reset();
+    if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
+        fprintf(stderr, "[isx_pipe_submit_bam] prepare %.1f ms, encode + enqueue %.1f ms, free %.1f ms\n", t_prep - t_in, t_sub - t_prep, now_ms() - t_sub);
+    return rc;
 }
 
 int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
@@ -517,11 +596,13 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
             const size_t n_rare = b->n_rare;
             isx_rare *rr = reinterpret_cast<isx_rare *>(s.h_out + s.o_rare);
             s.rare_big.clear();
-            if (n_rare > p->cap_rare) {                     // the device list overflowed: rebuild it from the dense array
-                std::vector<float> dense_r((size_t)b->n_pos);
-                HIP_TRY(hipMemcpy(dense_r.data(), b->d_clon_r, dense_r.size() * 4, hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < dense_r.size(); i++)
-                    if (!std::isnan(dense_r[i])) s.rare_big.push_back(isx_rare{(uint32_t)i, dense_r[i]});
+            s.rare_dense = false;
+            if (n_rare > p->cap_rare || n_rare * 8 > (size_t)b->n_pos) {
+                // a deep sample: most positions reach the rarefied coverage, so the 8-byte list is no smaller than
+                // the 4-byte dense array (and would need sorting) -- or the device list overflowed: hand back the array
+                if (!p->pp.want_counts || redo)
+                    HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+                s.rare_dense = true;
             } else {
                 if (n_rare > p->rare_prefix || redo) {
                     if (n_rare > p->rare_prefix) { s.rare_big.resize(n_rare); rr = s.rare_big.data(); }
@@ -552,13 +633,11 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
         out->clon = reinterpret_cast<const float *>(s.h_out + s.o_clon);
         out->n_saturated = b->n_sat;
         if (p->prm.rarefied_coverage > 0) {
-            out->rare = s.rare_big.empty() ? reinterpret_cast<const isx_rare *>(s.h_out + s.o_rare) : s.rare_big.data();
-            out->n_rare = s.rare_big.empty() ? (int64_t)b->n_rare : (int64_t)s.rare_big.size();
+            out->n_rare = (int64_t)b->n_rare;
+            if (!s.rare_dense) out->rare = s.rare_big.empty() ? reinterpret_cast<const isx_rare *>(s.h_out + s.o_rare) : s.rare_big.data();
+            if (s.rare_dense || p->pp.want_counts) out->clon_rarefied = reinterpret_cast<const float *>(s.h_out + s.o_clonr);
         }
-        if (p->pp.want_counts) {
-            out->counts = reinterpret_cast<const uint32_t *>(s.h_out + s.o_counts);
-            out->clon_rarefied = p->prm.rarefied_coverage > 0 ? reinterpret_cast<const float *>(s.h_out + s.o_clonr) : nullptr;
-        }
+        if (p->pp.want_counts) out->counts = reinterpret_cast<const uint32_t *>(s.h_out + s.o_counts);
     }
     out->batch = b;
     out->encode_ms = s.encode_ms;
@@ -588,12 +667,13 @@ int isx_pipe_release(isx_pipe *p, int64_t ticket)
     return ISX_OK;
 }
 
-int isx_encode_obs(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int64_t n_pos, int32_t record_bytes,
-                   int32_t host_threads, double slack, int64_t cap_rec, void *rec, uint32_t *gbase, uint32_t *pair_out,
-                   int64_t *n_rec, int32_t *passes)
+int isx_encode_obs_ring(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int64_t n_pos, int32_t record_bytes,
+                        int32_t host_threads, double slack, int64_t cap_rec, int64_t ring_records, void *rec, uint32_t *gbase,
+                        uint32_t *pair_out, int64_t *n_rec, int32_t *passes)
 {
     if ((n_obs && !obs) || n_obs < 0 || n_pos <= 0 || (record_bytes != 2 && record_bytes != 4) || !rec || !gbase || !n_rec ||
-        cap_rec < ISX_PAD || (cap_rec % ISX_PAD) || (pair && !pair_out)) {
+        cap_rec < ISX_PAD || (cap_rec % ISX_PAD) || (pair && !pair_out) || ring_records < 0 || (ring_records % (2 * ISX_PAD)) ||
+        (ring_records && pair)) {
         isx_set_error("isx_encode_obs: bad argument");
         return ISX_ERR_ARG;
     }
@@ -606,6 +686,20 @@ int isx_encode_obs(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int6
     J.rec = rec; J.gbase = gbase; J.pair_out = pair ? pair_out : nullptr;
     J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data();
     J.cap_rec = cap_rec; J.slack = slack;
+    std::vector<uint8_t> ring;
+    if (ring_records) {         // the pipe's ring mode with a memcpy standing in for the DMA engine
+        const int64_t G = record_bytes == 2 ? ISX_GROUP16 : ISX_GROUP;
+        const int64_t half = ring_records / 2;
+        ring.assign((size_t)ring_records * record_bytes, 0xAB);
+        J.rec = ring.data();
+        J.ring_groups = half / G;
+        J.wave_begin = [](int) {};
+        J.wave_flush = [&](int h, int64_t g0, int64_t g1) {
+            memcpy(static_cast<uint8_t *>(rec) + (size_t)g0 * G * record_bytes, ring.data() + (size_t)h * half * record_bytes,
+                   (size_t)(g1 - g0) * G * record_bytes);
+            memset(ring.data() + (size_t)h * half * record_bytes, 0xAB, (size_t)half * record_bytes);    // stale data must never travel
+        };
+    }
     const int erc = isxenc::encode_obs(pool, J);
     if (erc == isxenc::ENC_CAPACITY) { isx_set_error("isx_encode_obs: cap_rec too small for this stream"); return ISX_ERR_CAPACITY; }
     if (erc == isxenc::ENC_MM_RANGE) { isx_set_error("an observation has mm >= 256"); return ISX_ERR_MM_RANGE; }
@@ -613,6 +707,13 @@ int isx_encode_obs(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int6
     *n_rec = J.n_rec;
     if (passes) *passes = J.passes;
     return ISX_OK;
+}
+
+int isx_encode_obs(const isx_obs *obs, const uint32_t *pair, int64_t n_obs, int64_t n_pos, int32_t record_bytes,
+                   int32_t host_threads, double slack, int64_t cap_rec, void *rec, uint32_t *gbase, uint32_t *pair_out,
+                   int64_t *n_rec, int32_t *passes)
+{
+    return isx_encode_obs_ring(obs, pair, n_obs, n_pos, record_bytes, host_threads, slack, cap_rec, 0, rec, gbase, pair_out, n_rec, passes);
 }
 
 }  // extern "C"

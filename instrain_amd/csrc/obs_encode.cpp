@@ -270,6 +270,7 @@ struct Task {
     int64_t need = 0;                   // device groups the task's input needs
     uint32_t max_pair = 0;
     int err = 0;
+    int ran = -1;                       // the pass that last ran this task
     std::vector<PairRun> runs;          // pair-id runs of the task's region, ascending device records
 };
 
@@ -288,17 +289,29 @@ int encode_obs(HostPool &pool, EncodeJob &J)
     uint16_t *rec16 = static_cast<uint16_t *>(J.rec);
     uint32_t *rec32 = static_cast<uint32_t *>(J.rec);
 
-    int n_tasks = (int)std::max<int64_t>(1, std::min<int64_t>(n_in / 64, (int64_t)8 * pool.size()));
-    const int64_t per = ((n_in + n_tasks - 1) / n_tasks + gpc - 1) / gpc * gpc;
-    n_tasks = per ? (int)((n_in + per - 1) / per) : 0;
-    std::vector<Task> tasks((size_t)n_tasks);
-    for (int t = 0; t < n_tasks; t++) { tasks[(size_t)t].in_a = per * t; tasks[(size_t)t].in_b = std::min<int64_t>(n_in, per * (t + 1)); }
+    const bool ring = J.ring_groups > 0;
+    const int64_t H = J.ring_groups;                        // device groups per ring half
+    if (ring && (H % gpp != 0 || H < 2 * gpp)) return ENC_CAPACITY;
+    int n_tasks = 0;
+    std::vector<Task> tasks;
+    auto build_tasks = [&](int64_t per_max) {
+        n_tasks = (int)std::max<int64_t>(1, std::min<int64_t>(n_in / 64, (int64_t)8 * pool.size()));
+        int64_t per = ((n_in + n_tasks - 1) / n_tasks + gpc - 1) / gpc * gpc;
+        if (per_max > 0) per = std::max<int64_t>(gpc, std::min<int64_t>(per, per_max / gpc * gpc));
+        n_tasks = per ? (int)((n_in + per - 1) / per) : 0;
+        if (ring && n_tasks == 0) n_tasks = 1;              // an empty batch still pads its first wave
+        tasks.assign((size_t)n_tasks, Task());
+        for (int t = 0; t < n_tasks; t++) { tasks[(size_t)t].in_a = std::min<int64_t>(n_in, per * t); tasks[(size_t)t].in_b = std::min<int64_t>(n_in, per * (t + 1)); }
+    };
+    // ring mode: a wave should hold a few tasks per thread, and a task's region must fit a half with room to spare
+    build_tasks(ring ? std::max<int64_t>(gpc, H / (2 * (int64_t)pool.size())) : 0);
+    int64_t rec_shift = 0;                                  // ring mode: device group g of the running wave lives at group g + rec_shift of `rec`
 
     std::atomic<int> overflow{0};
     auto pad_groups = [&](int64_t g0, int64_t g1) {             // whole padding groups [g0, g1)
         if (g1 <= g0) return;
-        if (w16) memset(rec16 + g0 * G, 0xFF, (size_t)(g1 - g0) * G * 2);
-        else std::fill(rec32 + g0 * G, rec32 + g1 * G, PAD32);
+        if (w16) memset(rec16 + (g0 + rec_shift) * G, 0xFF, (size_t)(g1 - g0) * G * 2);
+        else std::fill(rec32 + (g0 + rec_shift) * G, rec32 + (g1 + rec_shift) * G, PAD32);
         std::fill(J.gbase + g0, J.gbase + g1, 0u);
         if (J.pair_out) memset(J.pair_out + g0 * G, 0, (size_t)(g1 - g0) * G * 4);
     };
@@ -306,11 +319,11 @@ int encode_obs(HostPool &pool, EncodeJob &J)
     auto emit = [&](int64_t og, const isx_obs *src, const uint32_t *psrc, uint32_t n, uint32_t lo, uint32_t hi, uint32_t &maxp,
                     std::vector<PairRun> &runs) {
         if (w16) {
-            uint16_t *d = rec16 + og * G;
+            uint16_t *d = rec16 + (og + rec_shift) * G;
             if (fast) enc16_avx512(src, n, lo, d); else enc16_scalar(src, n, lo, d);
             if (n < G) memset(d + n, 0xFF, (size_t)(G - n) * 2);
         } else {
-            uint32_t *d = rec32 + og * G;
+            uint32_t *d = rec32 + (og + rec_shift) * G;
             if (fast) enc32_avx512(src, n, lo, d); else enc32_scalar(src, n, lo, d);
             for (uint32_t i = n; i < G; i++) d[i] = PAD32;
         }
@@ -340,7 +353,7 @@ int encode_obs(HostPool &pool, EncodeJob &J)
     };
     auto work = [&](int ti) {
         Task &T = tasks[(size_t)ti];
-        T.need = 0; T.max_pair = 0; T.err = 0; T.runs.clear();
+        T.need = 0; T.max_pair = 0; T.err = 0; T.runs.clear(); T.ran = J.passes;
         std::vector<isx_obs> tmp_obs;           // producer mode: one input group at a time
         std::vector<uint32_t> tmp_pair;
         if (!J.obs) { tmp_obs.resize(G); if (have_pairs) tmp_pair.resize(G); }
@@ -397,20 +410,63 @@ int encode_obs(HostPool &pool, EncodeJob &J)
     };
     int64_t total = layout(false);
     J.passes = 0;
-    for (int pass = 0; pass < 2; pass++) {
+    bool retasked = false;
+    for (int pass = 0; pass < 3; pass++) {
         const int64_t n_rec = std::max<int64_t>(PADREC, (total * G + PADREC - 1) / PADREC * PADREC);
-        if (n_rec > J.cap_rec) {
+        bool fits = n_rec <= J.cap_rec;
+        if (ring && fits) {
+            tasks.back().out_b = n_rec / G;                 // the last task pads up to n_rec: padding travels with the last wave
+            for (auto &T : tasks) if (T.out_b - T.out_a > H) fits = false;
+            if (!fits && pass > 0 && !retasked) {           // a region larger than a ring half (a stream that jumps all the time):
+                retasked = true;                            // tasks so small that even one record per device group fits
+                build_tasks(std::max<int64_t>(gpc, H / (int64_t)G));
+                total = layout(false);
+                overflow.store(1);
+                J.passes++;
+                pool.run(n_tasks, work);                    // count only
+                for (auto &T : tasks) if (T.err) return T.err;
+                overflow.store(0);
+                total = layout(true);
+                continue;
+            }
+        }
+        if (!fits) {
             if (pass == 0) overflow.store(1);               // the estimate does not fit: count only, then decide
             else return ENC_CAPACITY;
         }
         J.passes++;
-        pool.run(n_tasks, work);
+        if (!ring || overflow.load()) pool.run(n_tasks, work);
+        else {
+            int wave = 0;
+            for (int t0 = 0; t0 < n_tasks && !overflow.load();) {
+                int t1 = t0 + 1;
+                while (t1 < n_tasks && tasks[(size_t)t1].out_b - tasks[(size_t)t0].out_a <= H) t1++;
+                const int half = wave & 1;
+                const int64_t g0 = tasks[(size_t)t0].out_a, g1 = tasks[(size_t)t1 - 1].out_b;
+                J.wave_begin(half);
+                rec_shift = (int64_t)half * H - g0;
+                pool.run(t1 - t0, [&](int i) { work(t0 + i); });
+                bool bad = overflow.load() != 0;
+                for (int t = t0; t < t1; t++) if (tasks[(size_t)t].err) bad = true;
+                if (!bad) J.wave_flush(half, g0, g1);
+                else if (!overflow.load()) break;           // a task refused its input: reported below
+                t0 = t1; wave++;
+            }
+            rec_shift = 0;
+            if (overflow.load()) {                          // the waves after the overflow still have to be counted
+                std::vector<int> rest;
+                for (int t = 0; t < n_tasks; t++) if (tasks[(size_t)t].ran != J.passes) rest.push_back(t);
+                pool.run((int)rest.size(), [&](int i) { work(rest[(size_t)i]); });
+            }
+        }
         for (auto &T : tasks) if (T.err) return T.err;
         if (!overflow.load()) {
             J.n_rec = n_rec;
-            for (int64_t ch = total / gpc; ch < n_rec / CHUNK; ch++) { J.cmin[ch] = 0xFFFFFFFFu; J.cmax[ch] = 0; J.cany[ch] = 0; }
-            pad_groups(total, n_rec / G);
-            _mm_sfence();
+            if (!ring) {
+                for (int64_t ch = total / gpc; ch < n_rec / CHUNK; ch++) { J.cmin[ch] = 0xFFFFFFFFu; J.cmax[ch] = 0; J.cany[ch] = 0; }
+                pad_groups(total, n_rec / G);
+                _mm_sfence();
+            }
             int64_t real = 0;
             uint32_t mp = 0;
             for (auto &T : tasks) { real += T.need; mp = std::max(mp, T.max_pair); }

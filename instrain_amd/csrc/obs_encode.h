@@ -68,6 +68,13 @@ struct EncodeJob {
     uint32_t *cmin = nullptr, *cmax = nullptr;   // per ISX_CHUNK (1024) device records: position range ...
     uint8_t *cany = nullptr;            // ... and whether the chunk holds a real record
     int64_t cap_rec = 0;
+    // ring mode (ring_groups > 0): `rec` is not the whole stream but two halves of ring_groups device groups each.  The tasks
+    // run in waves whose regions fit one half; wave_begin(half) is called before a wave writes (the half's previous copy must
+    // have left the host), wave_flush(half, g0, g1) after it: device groups [g0, g1) sit at the start of that half.  The
+    // padding up to n_rec is part of the last wave.  Both are called from the thread that called encode_obs.
+    int64_t ring_groups = 0;
+    std::function<void(int half)> wave_begin;
+    std::function<void(int half, int64_t g0, int64_t g1)> wave_flush;
     double slack = 0.0;                 // expected extra device groups per input group (0 = none: a stream without jumps)
     // results
     int64_t n_rec = 0;                  // device records (multiple of 2048)

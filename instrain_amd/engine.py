@@ -179,7 +179,7 @@ class Pipe:
 
     def __init__(self, ctx, max_pos, max_obs, max_splits, depth=4, host_threads=0, pin_threads=True, jump_slack=0.0,
                  min_cov=5, min_freq=0.05, min_snp=20, rarefied_coverage=50, n_mm_bins=1, enable_linkage=False,
-                 linkage_mode=0, window=0, seed=0, layout=0, want_counts=False):
+                 linkage_mode=0, window=0, seed=0, layout=0, want_counts=False, ring_kib=0):
         self.ctx, self.lib = ctx, ctx.lib
         self.n_mm_bins = int(n_mm_bins)
         self.want_counts = bool(want_counts)
@@ -187,7 +187,7 @@ class Pipe:
         p = Params(int(min_cov), int(min_snp), float(min_freq), int(rarefied_coverage), int(n_mm_bins),
                    1 if enable_linkage else 0, int(linkage_mode), int(window), int(seed), int(layout), 0)
         pp = _lib.PipeParams(int(max_pos), int(max_obs), int(max_splits), int(depth), int(host_threads),
-                             1 if pin_threads else 0, float(jump_slack), 1 if want_counts else 0, 0)
+                             1 if pin_threads else 0, float(jump_slack), 1 if want_counts else 0, int(ring_kib))
         h = C.c_void_p()
         check(self.lib.isx_pipe_create(ctx.h, C.byref(p), C.byref(pp), C.byref(h)))
         self.h = h
@@ -243,11 +243,22 @@ class Pipe:
             # the shrunk tables (what shrink_basewise keeps): coverage, clonality, sparse rarefied clonality
             out["cov16"] = view(r.coverage16, np.uint16, n_pos)
             out["clon"] = view(r.clon, np.float32, n_pos)
-            out["rare"] = view(r.rare, _lib.RARE_DT, int(r.n_rare)) if r.rare else np.empty(0, dtype=_lib.RARE_DT)
+            if r.clon_rarefied:                     # want_counts, or a deep sample (the list would not be sparse)
+                out["clon_r"] = view(r.clon_rarefied, np.float32, n_pos)
+            if r.rare:
+                out["rare"] = view(r.rare, _lib.RARE_DT, int(r.n_rare))
+            elif r.clon_rarefied:                   # the library handed the dense array instead of the list
+                k = np.flatnonzero(~np.isnan(out["clon_r"]))
+                out["rare"] = np.empty(len(k), dtype=_lib.RARE_DT)
+                out["rare"]["gpos"] = k
+                out["rare"]["clon_rarefied"] = out["clon_r"][k]
+            else:
+                out["rare"] = np.empty(0, dtype=_lib.RARE_DT)
             out["n_saturated"] = int(r.n_saturated)
             if r.counts:                            # want_counts: the full tables as Batch.fetch() returns them
                 out["counts"] = view(r.counts, np.uint32, n_pos * 4).reshape(n_pos, 4)
-                out["clon_r"] = view(r.clon_rarefied, np.float32, n_pos) if r.clon_rarefied else np.full(n_pos, np.nan, np.float32)
+                if "clon_r" not in out:
+                    out["clon_r"] = np.full(n_pos, np.nan, np.float32)
         else:
             e = np.empty(max(1, sz["n_entries"]), dtype=ENTRY_DT)
             check(self.lib.isx_batch_fetch_entries(slot.h, e.ctypes.data))
@@ -278,8 +289,8 @@ class Pipe:
             pass
 
 
-def encode_obs(obs, pair=None, n_pos=None, record_bytes=2, threads=1, slack=0.0, cap_rec=None):
-    """isx_encode_obs (host only): -> (rec, gbase, pair_out | None, passes)"""
+def encode_obs(obs, pair=None, n_pos=None, record_bytes=2, threads=1, slack=0.0, cap_rec=None, ring_records=0):
+    """isx_encode_obs / isx_encode_obs_ring (host only): -> (rec, gbase, pair_out | None, passes)"""
     lib = _lib.load()
     obs = np.ascontiguousarray(obs, dtype=OBS_DT)
     G = 512 if record_bytes == 2 else 256
@@ -293,9 +304,10 @@ def encode_obs(obs, pair=None, n_pos=None, record_bytes=2, threads=1, slack=0.0,
     if pair is not None:
         pair = np.ascontiguousarray(pair, dtype=np.uint32)
     n_rec, passes = C.c_int64(0), C.c_int32(0)
-    check(lib.isx_encode_obs(obs.ctypes.data if len(obs) else None, pair.ctypes.data if pair is not None else None, len(obs),
-                             int(n_pos), int(record_bytes), int(threads), float(slack), int(cap_rec), rec.ctypes.data,
-                             gbase.ctypes.data, pout.ctypes.data if pout is not None else None, C.byref(n_rec), C.byref(passes)))
+    check(lib.isx_encode_obs_ring(obs.ctypes.data if len(obs) else None, pair.ctypes.data if pair is not None else None, len(obs),
+                                  int(n_pos), int(record_bytes), int(threads), float(slack), int(cap_rec), int(ring_records),
+                                  rec.ctypes.data, gbase.ctypes.data, pout.ctypes.data if pout is not None else None,
+                                  C.byref(n_rec), C.byref(passes)))
     n = n_rec.value
     return rec[:n], gbase[:n // G], (pout[:n] if pout is not None else None), passes.value
 

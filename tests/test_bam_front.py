@@ -326,3 +326,31 @@ def test_expand_region_equals_the_cut_of_the_whole_reference(tmp_path):
     with pytest.raises(engine.IsxError):
         bam.expand_region(1, 10, 10)
     bam.close()
+
+
+def test_pair_tables_over_several_name_partitions(tmp_path):
+    """a reference with more than 16384 reads builds its name -> pair table in several hash partitions (reads bucketed
+    by partition first, tables built in parallel, then laid end to end): same pairs, same R2M, same tallies as
+    the oracle's single dictionary, for any thread count"""
+    from oracle import bam_py
+    from tests import bamwriter
+    refs = [("small", 3000), ("big", 60_000)]
+    reads = bamwriter.random_reads(77, refs[1:], 17_500)
+    for r in reads:                                   # random_reads numbered the one reference it was given 0
+        r["tid"] = 1
+        r["name"] = "b" + r["name"]
+    reads = bamwriter.random_reads(78, refs[:1], 200) + reads
+    path = str(tmp_path / "parts.bam")
+    bamwriter.write_bam(path, refs, reads)
+    rrefs, rr = bam_py.read_bam(path)
+    p2i = {r[0]: bam_py.get_paired_reads(rr, t) for t, r in enumerate(rrefs)}
+    r2m, tallies = bam_py.filter_pairs(p2i, min_read_ani=0.9)
+    for threads in (1, 5):
+        bam = engine.BamFile(path, threads=threads)
+        bam.scan()
+        info = bam.filter(min_read_ani=0.9)
+        assert info["n_reads"] == len(reads) > 2 * 16384
+        assert info["unfiltered_pairs"] == sum(t["unfiltered_pairs"] for t in tallies.values())
+        assert info["filtered_pairs"] == sum(t["filtered_pairs"] for t in tallies.values()) > 5000
+        assert bam.r2m(1) == r2m["big"] and bam.r2m(0) == r2m["small"]
+        bam.close()

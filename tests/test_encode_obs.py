@@ -100,3 +100,34 @@ def test_errors():
     obs["gpos"] = np.arange(600) * 10_000                                 # every record its own group
     with pytest.raises(IsxError):
         engine.encode_obs(obs, None, n_pos=10_000_000, record_bytes=2, cap_rec=4096)
+
+
+@pytest.mark.parametrize("rb", [2, 4])
+@pytest.mark.parametrize("islands,gap", [(1, 0), (7, 70_000), (40, 200_000)])
+def test_ring_mode_matches_whole_arena(rb, islands, gap):
+    """the pipe's staging ring (waves of at most half a ring, each copied to its place once complete): the stream that
+    arrives is the one the whole-arena encoder writes for the same layout, whatever the ring size / thread count"""
+    rng = np.random.default_rng(70 + islands)
+    obs, _ = make_stream(rng, 6000, 100, islands, gap, 0 if rb == 2 else 200)
+    for threads, slack, ring in ((1, 0.0, 8192), (4, 0.3, 16384), (3, 0.0, 4 * 65536), (8, 0.05, 8192)):
+        rec, gbase, _, passes = engine.encode_obs(obs, None, record_bytes=rb, threads=threads, slack=slack, ring_records=ring)
+        assert len(rec) % 2048 == 0
+        assert not (rec == (0xABAB if rb == 2 else 0xABABABAB)).any()         # nothing stale / unwritten travelled
+        got, n_real = decode(rec, gbase, None, rb)
+        np.testing.assert_array_equal(got["gpos"], obs["gpos"])
+        np.testing.assert_array_equal(got["base"], np.minimum(obs["base"], 4))
+        if rb == 4:
+            np.testing.assert_array_equal(got["mm"], obs["mm"])
+
+
+def test_ring_mode_every_record_its_own_group():
+    """a stream that jumps at every record expands 512x: regions outgrow a ring half, the encoder re-cuts its tasks"""
+    obs = np.zeros(3000, dtype=OBS_DT)
+    obs["gpos"] = np.arange(3000) * 10_000
+    rec, gbase, _, passes = engine.encode_obs(obs, None, n_pos=30_000_000, record_bytes=2, threads=3,
+                                              cap_rec=3000 * 512 + 8192, ring_records=1 << 21)
+    got, n_real = decode(rec, gbase, None, 2)
+    np.testing.assert_array_equal(got["gpos"], obs["gpos"])
+    assert passes >= 2
+    rec, gbase, _, _ = engine.encode_obs(np.zeros(0, dtype=OBS_DT), None, n_pos=10, record_bytes=4, ring_records=8192)
+    assert len(rec) == 2048 and (rec == 0x0700FFFF).all()

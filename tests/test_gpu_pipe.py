@@ -66,13 +66,14 @@ def same_tables(got, exp, what):
             assert (a == e).all(), (what, k)
 
 
-@pytest.mark.parametrize("linkage", [False, True])
-def test_stream_of_distinct_batches_dense(ctx, linkage):
+@pytest.mark.parametrize("linkage,rarefied", [(False, 20), (True, 20), (False, 36)])
+def test_stream_of_distinct_batches_dense(ctx, linkage, rarefied):
     """one mm bin (2-byte records): 7 distinct batches of different sizes through 3 slots, collected in
-    order while later ones are in flight; bit-identical to the one-shot path"""
+    order while later ones are in flight; bit-identical to the one-shot path.  rarefied 20: most positions
+    have a clonTR value (it comes back as the dense array); 36: few do (the sparse list)"""
     from instrain_amd import engine
     ws = [small_workload(100 + i, 60_000 + 17_000 * (i % 3), 25 + 5 * (i % 2), True) for i in range(7)]
-    kw = dict(enable_linkage=linkage, min_snp=5, seed=11, rarefied_coverage=20)
+    kw = dict(enable_linkage=linkage, min_snp=5, seed=11, rarefied_coverage=rarefied)
     exp = [one_shot(ctx, w, **kw) for w in ws]
     pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
                        max_splits=max(len(w["split_bounds"]) for w in ws), depth=3, host_threads=4, n_mm_bins=1,
@@ -119,6 +120,34 @@ def test_stream_mm_profiling_with_linkage(ctx):
             assert r["stats"]["record_bytes"] == 4
             same_tables(r, exp[i][0], "mm batch %d" % i)
             assert r["sizes"] == exp[i][1] and r["sizes"]["n_entries"] > 0 and r["sizes"]["n_ld"] > 0
+            pipe.release(t)
+    pipe.close()
+
+
+@pytest.mark.parametrize("skip_mm", [True, False])
+def test_staging_ring(ctx, skip_mm):
+    """records staged through a small pinned ring (the mode a pipe picks by itself beyond 512 MiB of records): waves of
+    half a ring leave for the device while the next is encoded; tables identical to the one-shot path, slots reused,
+    and a batch with more pair-id runs than the slot was created for"""
+    from instrain_amd import engine
+    ws = [small_workload(400 + i, 40_000 + 11_000 * i, 30, skip_mm) for i in range(4)]
+    M = max(w["n_mm_bins"] for w in ws)
+    for w in ws:
+        w["n_mm_bins"] = M
+    # the last batch: every record its own pair (far more runs than cap_rec / 48)
+    w = ws[3]
+    w["pair"] = np.arange(len(w["obs"]), dtype=np.uint32)
+    kw = dict(enable_linkage=True, min_snp=5, seed=5, rarefied_coverage=20)
+    exp = [one_shot(ctx, w, **kw) for w in ws]
+    pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
+                       max_splits=max(len(w["split_bounds"]) for w in ws), depth=2, host_threads=3, n_mm_bins=M,
+                       ring_kib=64, **kw)
+    for rnd in range(2):
+        ts = [pipe.submit(ws[i]["ref_codes"], ws[i]["split_bounds"], ws[i]["obs"], ws[i]["pair"]) for i in (2 * rnd, 2 * rnd + 1)]
+        for t, i in zip(ts, (2 * rnd, 2 * rnd + 1)):
+            r = pipe.collect(t)
+            same_tables(r, exp[i][0], "ring batch %d" % i)
+            assert r["sizes"] == exp[i][1]
             pipe.release(t)
     pipe.close()
 
