@@ -64,9 +64,13 @@ struct Read {           // a read of the batch being expanded
     int32_t tid, pos, isize, l_seq;
     uint16_t flag, n_cigar;
     uint32_t pair_idx;          // index into isx_bam::pairs, 0xFFFFFFFF = not in any table
-    uint64_t cigar_off, seq_off;
+    uint64_t cigar_off;
+    const uint8_t *seq;         // 4-bit codes, two per byte, where the record lies in its inflated segment (never copied)
+    uint8_t *qual;              // its qualities, same place: overlap resolution rewrites them there
     int64_t ref_end;            // reference position after the last CIGAR op (bam_endpos)
 };
+
+inline uint8_t nib(const uint8_t *seq, int64_t i) { return (uint8_t)((seq[i >> 1] >> ((~i & 1) << 2)) & 15); }
 
 struct Cursor {     // htslib sam.c cigar_iref2iseq_* state
     const uint32_t *cig; int n; int k, icig, iseq, iref;
@@ -274,6 +278,37 @@ struct RawBuf {                 // sized once, written once: no value initialisa
     size_t size() const { return n; }
 };
 
+template <class T>
+struct NoInitAlloc : std::allocator<T> {      // vector::resize without the memset: the elements are written right after, in parallel
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+
+// stable bucketing of the indices [0, n) by key(i) in [0, P): order lists bucket 0's indices ascending, then bucket 1's, ...
+template <class Key>
+void bucket_indices(isxenc::HostPool &pool, size_t n, int P, Key key, std::vector<uint32_t> &order, std::vector<size_t> &start)
+{
+    const int C = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n / 65536 + 1));
+    std::vector<size_t> cnt((size_t)C * (size_t)P, 0);
+    pool.run(C, [&](int c) {
+        size_t *k = cnt.data() + (size_t)c * (size_t)P;
+        for (size_t i = n * (size_t)c / (size_t)C; i < n * ((size_t)c + 1) / (size_t)C; i++) { const int b = key(i); if (b >= 0) k[b]++; }
+    });
+    start.assign((size_t)P + 1, 0);
+    size_t at = 0;
+    for (int b = 0; b < P; b++) {
+        start[(size_t)b] = at;
+        for (int c = 0; c < C; c++) { size_t &k = cnt[(size_t)c * (size_t)P + (size_t)b]; const size_t m = k; k = at; at += m; }
+    }
+    start[(size_t)P] = at;
+    order.resize(at);
+    pool.run(C, [&](int c) {
+        size_t *k = cnt.data() + (size_t)c * (size_t)P;
+        for (size_t i = n * (size_t)c / (size_t)C; i < n * ((size_t)c + 1) / (size_t)C; i++) { const int b = key(i); if (b >= 0) order[k[b]++] = (uint32_t)i; }
+    });
+}
+
 struct isx_bam {
     int fd = -1;
     const uint8_t *map = nullptr;
@@ -289,8 +324,8 @@ struct isx_bam {
     bool scanned = false, filtered = false;
     uint64_t n_reads = 0;
     std::vector<uint32_t> read_pair;                // per read ordinal
-    std::vector<PairInfo> pairs;
-    std::vector<PairInfo> pairs_scan;               // what the scan found, kept once all_reads has rewritten entries (_merge_info)
+    std::vector<PairInfo, NoInitAlloc<PairInfo>> pairs;
+    std::vector<PairInfo, NoInitAlloc<PairInfo>> pairs_scan;               // what the scan found, kept once all_reads has rewritten entries (_merge_info)
     std::vector<uint64_t> ref_pair0;                // [n_ref + 1] pairs of a reference are contiguous
     std::vector<uint32_t> ref_seg0, ref_seg1;       // segments holding records of the reference: [seg0, seg1]
     std::vector<std::vector<char>> seg_names;       // name blobs, dropped after the filter (or kept for set_r2m)
@@ -603,18 +638,19 @@ int open_file(const char *path, isx_bam &B)
 }
 
 // htslib sam.c tweak_overlap_quality on two reads of the batch
+struct SegBuf;
 struct Batch {
     std::vector<Read> reads;
-    RawBuf<uint32_t> cigars;
-    RawBuf<uint8_t> seqs, quals;
+    RawBuf<uint32_t> cigars;                // copied (aligned); sequences and qualities stay in the inflated segments:
+    std::vector<std::vector<uint8_t>> seg_data;
 };
 
 void tweak_overlap(Batch &S, const Read &a, const Read &b)
 {
     Cursor ca{S.cigars.data() + a.cigar_off, a.n_cigar, 0, 0, 0, 0};
     Cursor cb{S.cigars.data() + b.cigar_off, b.n_cigar, 0, 0, 0, 0};
-    uint8_t *aq = S.quals.data() + a.seq_off, *bq = S.quals.data() + b.seq_off;
-    const uint8_t *as = S.seqs.data() + a.seq_off, *bs = S.seqs.data() + b.seq_off;
+    uint8_t *aq = a.qual, *bq = b.qual;
+    const uint8_t *as = a.seq, *bs = b.seq;
     int iref = b.pos;
     int a_ret = cur_set(ca, iref - a.pos);
     if (a_ret < 0) return;
@@ -630,7 +666,7 @@ void tweak_overlap(Batch &S, const Read &a, const Read &b)
         iref++;
         if (ca.iref + a.pos != cb.iref + b.pos) continue;
         const int qa = aq[ca.iseq], qb = bq[cb.iseq];
-        if (as[ca.iseq] == bs[cb.iseq]) {
+        if (nib(as, ca.iseq) == nib(bs, cb.iseq)) {
             const int q = qa + qb;
             aq[ca.iseq] = (uint8_t)(q > 200 ? 200 : q);
             bq[cb.iseq] = 0;
@@ -1187,18 +1223,15 @@ struct BamBatch {
     std::vector<int64_t> split_bounds;
     std::vector<int32_t> split_ref;
 
-    // observations [skip, skip + limit) of read ri -> po / pp (pp may be NULL); returns how many the read has in all when
-    // po == NULL (count only)
-    uint64_t walk(size_t ri, uint64_t skip, uint64_t limit, isx_obs *po, uint32_t *pp) const
+    // how many observations read ri contributes (bases of M/=/X blocks inside the scaffold / region with quality >= minq)
+    uint64_t count_read(size_t ri) const
     {
         const Read &r = S.reads[ri];
-        const PairInfo &pi = B->pairs[r.pair_idx];
-        const uint16_t mm = prm.skip_mm ? 0 : (uint16_t)pi.mm;
-        const int64_t base_off = boff[(size_t)r.tid];
         const int64_t ref_len = B->ref_len[(size_t)r.tid];
-        const uint8_t *ql = S.quals.data() + r.seq_off, *sq = S.seqs.data() + r.seq_off;
+        const uint8_t *ql = r.qual;
+        const uint8_t mq = minq;
         int64_t ref = r.pos, q = 0;
-        uint64_t n_out = 0, written = 0;
+        uint64_t n_out = 0;
         for (int k = 0; k < r.n_cigar; k++) {
             const uint32_t c = S.cigars[r.cigar_off + (uint64_t)k];
             const int op = c & 15;
@@ -1207,18 +1240,42 @@ struct BamBatch {
                 // the reference's pileups are truncated to [0, scaffold length) (profile_utilities.py:150-153)
                 int64_t j0 = std::max<int64_t>(0, -ref), j1 = std::min<int64_t>(n, ref_len - ref);
                 if (reg_hi >= 0) { j0 = std::max<int64_t>(j0, reg_lo - ref); j1 = std::min<int64_t>(j1, reg_hi - ref); }
-                const uint32_t g0 = (uint32_t)(base_off + ref);
+                uint32_t m = 0;
+                for (int64_t j = j0; j < j1; j++) m += ql[q + j] >= mq;
+                n_out += m;
+                q += n; ref += n;
+            } else if (op == CI || op == CS) q += n;
+            else if (op == CD || op == CN) ref += n;
+        }
+        return n_out;
+    }
+
+    // every observation of read ri -> out (room for l_seq + 1 records: the store is unconditional, the cursor advances only
+    // for a base that counts); returns how many
+    uint32_t walk_all(size_t ri, isx_obs *out) const
+    {
+        const Read &r = S.reads[ri];
+        const PairInfo &pi = B->pairs[r.pair_idx];
+        const uint64_t hi = (uint64_t)(prm.skip_mm ? 0 : (uint16_t)pi.mm) << 32;
+        const int64_t base_off = boff[(size_t)r.tid];
+        const int64_t ref_len = B->ref_len[(size_t)r.tid];
+        const uint8_t *ql = r.qual, *sq = r.seq;
+        const uint8_t mq = minq;
+        uint64_t *o64 = reinterpret_cast<uint64_t *>(out);
+        int64_t ref = r.pos, q = 0;
+        uint32_t n_out = 0;
+        for (int k = 0; k < r.n_cigar; k++) {
+            const uint32_t c = S.cigars[r.cigar_off + (uint64_t)k];
+            const int op = c & 15;
+            const int64_t n = c >> 4;
+            if (op == CM || op == CEQ || op == CX) {
+                int64_t j0 = std::max<int64_t>(0, -ref), j1 = std::min<int64_t>(n, ref_len - ref);
+                if (reg_hi >= 0) { j0 = std::max<int64_t>(j0, reg_lo - ref); j1 = std::min<int64_t>(j1, reg_hi - ref); }
+                const uint64_t g0 = (uint64_t)(uint32_t)(base_off + ref);
                 for (int64_t j = j0; j < j1; j++) {
-                    if (ql[q + j] >= minq) {
-                        if (po && n_out >= skip) {
-                            if (written == limit) return n_out;
-                            isx_obs &o = po[written];
-                            o.gpos = g0 + (uint32_t)j; o.mm = mm; o.base = CODE2IDX[sq[q + j]]; o.flags = 0;
-                            if (pp) pp[written] = pid[ri];
-                            written++;
-                        }
-                        n_out++;
-                    }
+                    const int64_t i = q + j;
+                    o64[n_out] = (g0 + (uint64_t)j) | hi | ((uint64_t)CODE2IDX[nib(sq, i)] << 48);    // gpos | mm << 32 | base << 48
+                    n_out += ql[i] >= mq;
                 }
                 q += n; ref += n;
             } else if (op == CI || op == CS) q += n;
@@ -1230,14 +1287,23 @@ struct BamBatch {
     // observations [first, first + count) of the batch's stream (thread safe)
     void emit_range(int64_t first, uint32_t count, isx_obs *po, uint32_t *pp) const
     {
+        static_assert(sizeof(isx_obs) == 8, "isx_obs is one 64-bit word");
         size_t ri = (size_t)(std::upper_bound(out_at.begin(), out_at.end(), (uint64_t)first) - out_at.begin()) - 1;
         uint64_t skip = (uint64_t)first - out_at[ri];
         uint32_t done = 0;
+        thread_local std::vector<isx_obs> tmp;
         while (done < count) {
             const uint64_t have = out_at[ri + 1] - out_at[ri];
             if (have > skip) {
                 const uint32_t take = (uint32_t)std::min<uint64_t>(count - done, have - skip);
-                walk(ri, skip, take, po + done, pp ? pp + done : nullptr);
+                if (skip == 0 && (uint64_t)(count - done) > have) walk_all(ri, po + done);      // whole read, room for the spare store
+                else {
+                    const size_t need = (size_t)std::max(S.reads[ri].l_seq, 0) + 1;
+                    if (tmp.size() < need) tmp.resize(need + 256);
+                    walk_all(ri, tmp.data());
+                    memcpy(po + done, tmp.data() + skip, (size_t)take * sizeof(isx_obs));
+                }
+                if (pp) std::fill(pp + done, pp + done + take, pid[ri]);
                 done += take;
             }
             skip = 0;
@@ -1333,30 +1399,31 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     for (size_t k = 0; k < sw.size(); k++) { r_at[k + 1] = r_at[k] + sw[k].keep.size(); c_at[k + 1] = c_at[k] + sw[k].n_cig; s_at[k + 1] = s_at[k] + sw[k].n_seq; }
     Batch &S = Q->S;
     S.reads.resize((size_t)r_at.back());
-    S.cigars.resize((size_t)c_at.back()); S.seqs.resize((size_t)s_at.back()); S.quals.resize((size_t)s_at.back());
+    S.cigars.resize((size_t)c_at.back());
+    S.seg_data.resize(sw.size());
     pool.run((int)sw.size(), [&](int k) {
         const Segment &s = B.segs[seg_list[(size_t)k]];
         SegWork &w = sw[(size_t)k];
-        uint64_t ci = c_at[(size_t)k], qi = s_at[(size_t)k];
+        uint64_t ci = c_at[(size_t)k];
+        if (w.keep.empty()) { SegBuf().data.swap(w.buf.data); return; }
+        // the batch owns the inflated segment from here on (a segment the handle keeps inflated is copied: overlap
+        // resolution writes qualities)
+        if (w.buf.data.empty()) w.buf.data = B.seg_cache[seg_list[(size_t)k]];
+        S.seg_data[(size_t)k].swap(w.buf.data);
+        uint8_t *own = S.seg_data[(size_t)k].data();
         for (size_t j = 0; j < w.keep.size(); j++) {
             RecView r;
-            if (!rec_view(w.data + ((*w.recp)[w.keep[j]] - s.ioff0), r)) { w.err = "corrupt BAM record"; rc_any.store(ISX_ERR_IO); return; }
+            if (!rec_view(own + ((*w.recp)[w.keep[j]] - s.ioff0), r)) { w.err = "corrupt BAM record"; rc_any.store(ISX_ERR_IO); return; }
             Read R{};
             R.tid = r.tid; R.pos = r.pos; R.isize = r.isize; R.l_seq = r.l_seq; R.flag = r.flag; R.n_cigar = r.n_cigar;
             R.pair_idx = B.read_pair[(size_t)(s.read0 + w.keep[j])];
-            R.cigar_off = ci; R.seq_off = qi;
+            R.cigar_off = ci;
             memcpy(S.cigars.data() + ci, r.cigar, (size_t)r.n_cigar * 4);
-            uint8_t *sq = S.seqs.data() + qi;
-            for (int32_t x = 0; x < r.l_seq; x++) {
-                const uint8_t byte = r.seq[x >> 1];
-                sq[x] = (x & 1) ? (byte & 15) : (byte >> 4);
-            }
-            memcpy(S.quals.data() + qi, r.qual, (size_t)r.l_seq);
+            R.seq = r.seq; R.qual = const_cast<uint8_t *>(r.qual);
             R.ref_end = span_of(r.cigar, r.n_cigar, r.pos).end;
             S.reads[(size_t)(r_at[(size_t)k] + j)] = R;
-            ci += r.n_cigar; qi += (uint64_t)r.l_seq;
+            ci += r.n_cigar;
         }
-        SegBuf().data.swap(w.buf.data);
     });
     if (rc_any.load()) { for (auto &w : sw) if (!w.err.empty()) { isx_set_error(w.err); break; } return rc_any.load(); }
     sw.clear();
@@ -1366,15 +1433,24 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     //      only ever touch each other's qualities ----
     const size_t n_reads = S.reads.size();
     {
-        const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 2, n_reads / 16384 + 1));
+        // candidates only (both mates mapped, proper pair, |isize| < 2 * l_qseq), bucketed by pair so that a task touches its
+        // own reads and not every read of the batch
+        const int P = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n_reads / 16384 + 1));
+        std::vector<uint32_t> order;
+        std::vector<size_t> start;
+        if (n_reads >= 0xFFFFFFFFull) { isx_set_error("isx_bam_expand_refs: more than 2^32 reads in one batch"); return ISX_ERR_ARG; }
+        bucket_indices(pool, n_reads, P, [&](size_t ri) -> int {
+            const Read &r = S.reads[ri];
+            if (r.pair_idx == 0xFFFFFFFFu || (r.flag & FMUNMAP) || !(r.flag & FPROPER)) return -1;
+            if (std::abs((int64_t)r.isize) >= 2 * (int64_t)r.l_seq) return -1;
+            return (int)(r.pair_idx % (uint32_t)P);
+        }, order, start);
         pool.run(P, [&](int part) {
             std::unordered_map<uint32_t, int64_t> pending;      // pair -> read waiting for its mate
-            pending.reserve(n_reads / (size_t)P / 4 + 16);
-            for (size_t ri = 0; ri < n_reads; ri++) {
+            pending.reserve((start[(size_t)part + 1] - start[(size_t)part]) / 2 + 16);
+            for (size_t q = start[(size_t)part]; q < start[(size_t)part + 1]; q++) {
+                const size_t ri = order[q];
                 const Read &r = S.reads[ri];
-                if (r.pair_idx == 0xFFFFFFFFu || (int)(r.pair_idx % (uint32_t)P) != part) continue;
-                if ((r.flag & FMUNMAP) || !(r.flag & FPROPER)) continue;
-                if (std::abs((int64_t)r.isize) >= 2 * (int64_t)r.l_seq) continue;
                 auto it = pending.find(r.pair_idx);
                 if (it != pending.end() && S.reads[(size_t)it->second].ref_end <= r.pos) { pending.erase(it); it = pending.end(); }   // earlier read already left the buffer
                 if (it == pending.end()) pending.emplace(r.pair_idx, (int64_t)ri);
@@ -1388,35 +1464,66 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     }
     stage("overlap resolution");
 
-    // ---- which reads are piled up, dense pair ids in order of first appearance (serial, one word per read), and
-    //      where every read's observations start in the stream (count per read on the threads, prefix sum) ----
+    // ---- which reads are piled up, dense pair ids in order of first appearance, and where every read's observations
+    //      start in the stream (count per read + prefix sums, all on the threads) ----
     Q->emit.assign(n_reads, 0);
     std::vector<uint64_t> slot0(n_ref_all, 0);              // the batch's pair entries, reference after reference
     uint64_t n_slots = 0;
     for (int32_t i = 0; i < n_refs; i++) { slot0[(size_t)refs[i]] = n_slots; n_slots += B.ref_pair0[(size_t)refs[i] + 1] - B.ref_pair0[(size_t)refs[i]]; }
-    std::vector<uint32_t> dense((size_t)n_slots, 0xFFFFFFFFu);
+    // dense id of a pair = rank of its first piled-up read: per pair the smallest read index (atomic min, threads over
+    // the reads), a prefix count of those first reads, then every read looks its pair's id up
+    std::vector<uint32_t> first((size_t)n_slots, 0xFFFFFFFFu), dense((size_t)n_slots, 0xFFFFFFFFu);
     Q->pid.assign(n_reads, 0);
-    uint32_t next_pair = 0;
-    for (size_t ri = 0; ri < n_reads; ri++) {
-        const Read &r = S.reads[ri];
-        // R2M membership is by NAME on this scaffold (get_base_counts_mm looks up query_name)
-        if (r.pair_idx == 0xFFFFFFFFu) continue;
-        const PairInfo &pi = B.pairs[r.pair_idx];
-        if (!pi.pass || pi.reads == 0) continue;
-        uint32_t &d = dense[(size_t)(slot0[(size_t)r.tid] + (r.pair_idx - B.ref_pair0[(size_t)r.tid]))];
-        if (d == 0xFFFFFFFFu) d = next_pair++;
-        Q->pid[ri] = d;
-        Q->emit[ri] = 1;
-    }
-    Q->next_pair = next_pair;
-    Q->out_at.assign(n_reads + 1, 0);
     const int n_tasks = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n_reads / 2048 + 1));
+    auto lo_of = [&](int t) { return n_reads * (size_t)t / (size_t)n_tasks; };
+    auto slot_of = [&](const Read &r) -> size_t { return (size_t)(slot0[(size_t)r.tid] + (r.pair_idx - B.ref_pair0[(size_t)r.tid])); };
     BamBatch *q = Q.get();
     pool.run(n_tasks, [&](int t) {
-        for (size_t ri = n_reads * (size_t)t / (size_t)n_tasks; ri < n_reads * ((size_t)t + 1) / (size_t)n_tasks; ri++)
-            if (q->emit[ri]) q->out_at[ri + 1] = q->walk(ri, 0, 0, nullptr, nullptr);
+        for (size_t ri = lo_of(t); ri < lo_of(t + 1); ri++) {
+            const Read &r = S.reads[ri];
+            // R2M membership is by NAME on this scaffold (get_base_counts_mm looks up query_name)
+            if (r.pair_idx == 0xFFFFFFFFu) continue;
+            const PairInfo &pi = B.pairs[r.pair_idx];
+            if (!pi.pass || pi.reads == 0) continue;
+            q->emit[ri] = 1;
+            uint32_t *f = &first[slot_of(r)];
+            uint32_t cur = __atomic_load_n(f, __ATOMIC_RELAXED);
+            while ((uint32_t)ri < cur && !__atomic_compare_exchange_n(f, &cur, (uint32_t)ri, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
     });
-    for (size_t ri = 0; ri < n_reads; ri++) Q->out_at[ri + 1] += Q->out_at[ri];
+    std::vector<uint32_t> firsts((size_t)n_tasks + 1, 0);
+    std::vector<uint64_t> outs((size_t)n_tasks + 1, 0);
+    Q->out_at.assign(n_reads + 1, 0);
+    pool.run(n_tasks, [&](int t) {
+        uint32_t nf = 0;
+        uint64_t no = 0;
+        for (size_t ri = lo_of(t); ri < lo_of(t + 1); ri++) {
+            if (!q->emit[ri]) continue;
+            nf += first[slot_of(S.reads[ri])] == (uint32_t)ri;
+            const uint64_t c = q->count_read(ri);
+            q->out_at[ri + 1] = c;
+            no += c;
+        }
+        firsts[(size_t)t + 1] = nf; outs[(size_t)t + 1] = no;
+    });
+    for (int t = 0; t < n_tasks; t++) { firsts[(size_t)t + 1] += firsts[(size_t)t]; outs[(size_t)t + 1] += outs[(size_t)t]; }
+    Q->next_pair = firsts[(size_t)n_tasks];
+    pool.run(n_tasks, [&](int t) {
+        uint32_t nf = firsts[(size_t)t];
+        uint64_t at = outs[(size_t)t];
+        for (size_t ri = lo_of(t); ri < lo_of(t + 1); ri++) {
+            if (q->emit[ri]) {
+                const size_t sl = slot_of(S.reads[ri]);
+                if (first[sl] == (uint32_t)ri) dense[sl] = nf++;
+            }
+            at += q->out_at[ri + 1];
+            q->out_at[ri + 1] = at;
+        }
+    });
+    pool.run(n_tasks, [&](int t) {
+        for (size_t ri = lo_of(t); ri < lo_of(t + 1); ri++)
+            if (q->emit[ri]) q->pid[ri] = dense[slot_of(S.reads[ri])];
+    });
     if (Q->out_at.back() >= 0xFFFFFFFFull) { isx_set_error("isx_bam_expand_refs: more than 2^32 observations in one batch (expand fewer references at a time)"); return ISX_ERR_ARG; }
     stage("count");
 

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bam_front.h"
@@ -544,7 +545,8 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
     J.produce = [q](int64_t first, uint32_t count, isx_obs *o, uint32_t *pr) { bam_batch_emit(q, first, count, o, pr); };
     rc = submit_common(p, n_pos, ref, n_splits, split_bounds, n_obs, J, ticket);
     const double t_sub = now_ms();
-    Q.reset();
+    // giving a gigabyte-sized batch back to the system takes as long as encoding it: not on the caller's time
+    std::thread([](BamBatch *dead) { bam_batch_free(dead); }, Q.release()).detach();
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_submit_bam] prepare %.1f ms, encode + enqueue %.1f ms, free %.1f ms\n", t_prep - t_in, t_sub - t_prep, now_ms() - t_sub);
     return rc;

@@ -49,6 +49,24 @@ def _own(a):
     return a if (a.flags.owndata or isinstance(a.base, np.ndarray) and a.base.flags.owndata) else np.array(a)
 
 
+def _cuts(col, bounds):
+    """np.searchsorted(col, bounds) for a column of a structured array: numpy would first copy the strided column
+    (hundreds of MB for an entry table), a bisection only touches len(bounds) * log2(len(col)) of its elements"""
+    n = len(col)
+    lo = np.zeros(len(bounds), dtype=np.int64)
+    hi = np.full(len(bounds), n, dtype=np.int64)
+    b = np.asarray(bounds, dtype=np.int64)
+    while True:
+        act = lo < hi
+        if not act.any():
+            return lo
+        mid = (lo + hi) >> 1
+        v = col[np.minimum(mid, max(n - 1, 0))].astype(np.int64) if n else b
+        right = act & (v < b)
+        lo = np.where(right, mid + 1, lo)
+        hi = np.where(act & ~right, mid, hi)
+
+
 class _BatchTables:
     """The tables of one device batch, cut per split on demand (shrink_basewise / generate_snp_table /
     calculate_ld outputs of every split of the batch).  Built once per batch from numpy arrays; the pandas
@@ -59,11 +77,11 @@ class _BatchTables:
         self.scaffold = split_scaffold
         self.offset = np.asarray(scaffold_offset, dtype=np.int64)
         self.snv, self.ld = _own(res["snv"]), _own(res["ld"])
-        self.s_cut = np.searchsorted(self.snv["gpos"], self.bounds)
-        self.l_cut = np.searchsorted(self.ld["gpos_a"], self.bounds)
+        self.s_cut = _cuts(self.snv["gpos"], self.bounds)
+        self.l_cut = _cuts(self.ld["gpos_a"], self.bounds)
         if "entries" in res:                        # mm profiling on: (position, mm) entries
             self.entries = res["entries"]
-            self.e_cut = np.searchsorted(self.entries["gpos"], self.bounds)
+            self.e_cut = _cuts(self.entries["gpos"], self.bounds)
         else:                                       # one mm bin: coverage per position, clonality, sparse clonTR
             self.entries = None
             if "cov16" in res and not res.get("n_saturated"):
