@@ -744,7 +744,13 @@ int isx_bam_open(const char *path, isx_bam **out)
     return ISX_OK;
 }
 
-void isx_bam_close(isx_bam *bam) { delete bam; }
+void isx_bam_close(isx_bam *bam)
+{
+    if (!bam) return;
+    // the tables of a large file (hundreds of MB of pair entries and names) take tens of ms to give back: not the caller's
+    if (bam->n_reads > (1u << 20)) std::thread([](isx_bam *dead) { delete dead; }, bam).detach();
+    else delete bam;
+}
 
 int isx_bam_set_threads(isx_bam *bam, int32_t threads)
 {
@@ -1049,17 +1055,27 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
     T.filtered_pairs = T.filtered_singletons = T.filtered_bases = 0;
     if (!B.pairs_scan.empty()) B.pairs = B.pairs_scan;          // an earlier all_reads run merged entries in place
     else if (p->pairing_filter == 2) B.pairs_scan = B.pairs;
-    for (PairInfo &e : B.pairs) { e.pass = false; e.in_filter = false; }
+    isxenc::HostPool &pool = pool_of(B);
+    const size_t n_pairs = B.pairs.size();
+    const int C = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n_pairs / 32768 + 1));
+    auto c_lo = [&](int c) { return n_pairs * (size_t)c / (size_t)C; };
+    struct Tally { int64_t reads = 0, pairs = 0, single = 0, f_pairs = 0, f_single = 0, f_bases = 0, max_mm = 0; std::vector<int64_t> ins; };
+    std::vector<Tally> tl((size_t)C);
     // paired_read_filter: scaffolds in header order, names in order of first appearance
-    std::vector<PairInfo> merged;       // all_reads: entries rewritten by _merge_info
     if (p->pairing_filter == 0) {
-        for (size_t i = 0; i < B.pairs.size(); i++) {
-            PairInfo &e = B.pairs[i];
-            if (e.reads == 0) continue;
-            T.unfiltered_reads += e.reads; T.unfiltered_pairs += e.reads == 2; T.unfiltered_singletons += e.reads == 1;
-            e.in_filter = e.reads == 2 || B.priority[i];
-        }
+        pool.run(C, [&](int c) {
+            Tally &t = tl[(size_t)c];
+            for (size_t i = c_lo(c); i < c_lo(c + 1); i++) {
+                PairInfo &e = B.pairs[i];
+                e.pass = false; e.in_filter = false;
+                if (e.reads == 0) continue;
+                t.reads += e.reads; t.pairs += e.reads == 2; t.single += e.reads == 1;
+                e.in_filter = e.reads == 2 || B.priority[i];
+            }
+        });
+        for (const Tally &t : tl) { T.unfiltered_reads += t.reads; T.unfiltered_pairs += t.pairs; T.unfiltered_singletons += t.single; }
     } else {
+        for (PairInfo &e : B.pairs) { e.pass = false; e.in_filter = false; }
         // names are looked up across scaffolds (pair2scaffold)
         std::unordered_map<std::string_view, uint32_t> seen;        // name -> index of the entry that holds it now
         seen.reserve(B.pairs.size());
@@ -1092,8 +1108,15 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
     // median insert of the pairs that went through (reads == 2)
     double median = median_insert;
     if (std::isnan(median)) {
+        pool.run(C, [&](int c) {
+            std::vector<int64_t> &v = tl[(size_t)c].ins;
+            for (size_t i = c_lo(c); i < c_lo(c + 1); i++) { const PairInfo &e = B.pairs[i]; if (e.in_filter && e.reads == 2) v.push_back(e.insert); }
+        });
         std::vector<int64_t> ins;
-        for (const PairInfo &e : B.pairs) if (e.in_filter && e.reads == 2) ins.push_back(e.insert);
+        size_t n_ins = 0;
+        for (const Tally &t : tl) n_ins += t.ins.size();
+        ins.reserve(n_ins);
+        for (Tally &t : tl) { ins.insert(ins.end(), t.ins.begin(), t.ins.end()); std::vector<int64_t>().swap(t.ins); }
         if (!ins.empty()) {                             // np.median (selection, not a full sort)
             const size_t n = ins.size();
             std::nth_element(ins.begin(), ins.begin() + (ptrdiff_t)(n / 2), ins.end());
@@ -1103,24 +1126,41 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
     }
     T.median_insert = median;
     const double max_insert = median * p->max_insert_relative;
-    int64_t max_mm = 0;
     B.ref_filtered_pairs.assign(n_ref, 0);
-    for (size_t t = 0; t < n_ref; t++) {
-        for (uint64_t i = B.ref_pair0[t]; i < B.ref_pair0[t + 1]; i++) {
-            PairInfo &e = B.pairs[(size_t)i];
-            if (!e.in_filter) continue;
-            const double pid = 1 - ((double)e.nm / (double)e.length);        // evaluate_pair :406
-            bool ok = pid > p->min_read_ani;
-            ok = ok && (e.mapq > p->min_mapq);
-            if (e.reads == 2 && e.insert != -1) ok = ok && ((double)e.insert > (double)p->min_insert) && ((double)e.insert < max_insert);
-            e.pass = ok;
-            if (ok) {
-                e.mm = (int32_t)e.nm;
-                T.filtered_pairs++; T.filtered_bases += e.length; T.filtered_singletons += e.reads == 1;
-                B.ref_filtered_pairs[t]++;
-                if (e.nm > max_mm) max_mm = e.nm;
+    std::vector<std::vector<std::pair<size_t, int64_t>>> per_ref((size_t)C);       // (reference, pairs that passed) per piece
+    pool.run(C, [&](int c) {
+        Tally &tc = tl[(size_t)c];
+        size_t i = c_lo(c);
+        const size_t end = c_lo(c + 1);
+        size_t t = (size_t)(std::upper_bound(B.ref_pair0.begin(), B.ref_pair0.end(), (uint64_t)i) - B.ref_pair0.begin()) - 1;
+        while (i < end) {
+            while (t + 1 < B.ref_pair0.size() && B.ref_pair0[t + 1] <= i) t++;
+            const size_t stop = std::min<size_t>(end, (size_t)B.ref_pair0[t + 1]);
+            int64_t passed = 0;
+            for (; i < stop; i++) {
+                PairInfo &e = B.pairs[i];
+                if (!e.in_filter) continue;
+                const double pid = 1 - ((double)e.nm / (double)e.length);        // evaluate_pair :406
+                bool ok = pid > p->min_read_ani;
+                ok = ok && (e.mapq > p->min_mapq);
+                if (e.reads == 2 && e.insert != -1) ok = ok && ((double)e.insert > (double)p->min_insert) && ((double)e.insert < max_insert);
+                e.pass = ok;
+                if (ok) {
+                    e.mm = (int32_t)e.nm;
+                    tc.f_pairs++; tc.f_bases += e.length; tc.f_single += e.reads == 1;
+                    passed++;
+                    if (e.nm > tc.max_mm) tc.max_mm = e.nm;
+                }
             }
+            if (passed) per_ref[(size_t)c].push_back({t, passed});
         }
+    });
+    int64_t max_mm = 0;
+    for (int c = 0; c < C; c++) {
+        const Tally &t = tl[(size_t)c];
+        T.filtered_pairs += t.f_pairs; T.filtered_bases += t.f_bases; T.filtered_singletons += t.f_single;
+        max_mm = std::max(max_mm, t.max_mm);
+        for (const auto &pr : per_ref[(size_t)c]) B.ref_filtered_pairs[pr.first] += pr.second;
     }
     if (max_mm > 65535) { isx_set_error("mm level > 65535"); return ISX_ERR_ARG; }
     T.max_mm = p->skip_mm ? 0 : (int32_t)max_mm;

@@ -53,6 +53,7 @@ struct Slot {
     uint8_t *h_out = nullptr;
     size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0, o_cov16 = 0, o_rare = 0;
     bool rare_dense = false;                // the clonTR table of the last batch went back as the dense array
+    std::vector<float> clonr_big;           // that array when the pipe has no pinned room for it (no want_counts)
     std::vector<isx_rare> rare_big;         // more clonTR entries than the pinned block holds / the device list overflowed
     std::vector<uint32_t> cmin, cmax;
     std::vector<uint8_t> cany;
@@ -119,7 +120,10 @@ static void pipe_free(isx_pipe *p)
     if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
     if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
     for (int i = 0; i < 2; i++) if (p->ctx->pstream[i]) (void)hipStreamSynchronize(p->ctx->pstream[i]);
+    const double t_f0 = now_ms();
+    double t_batch = 0, t_dev = 0, t_pin = 0;
     for (Slot &s : p->slots) {
+        double t_x = now_ms();
         if (s.b) {
             isx_batch *b = s.b;             // the input arrays belong to the arena, not to the batch
             b->d_rec = nullptr; b->d_rec32 = nullptr; b->d_rec16 = nullptr; b->d_gbase = nullptr; b->d_pair = nullptr;
@@ -128,15 +132,20 @@ static void pipe_free(isx_pipe *p)
             b->d_bounds = nullptr;
             isx_batch_destroy(b);
         }
+        t_batch += now_ms() - t_x; t_x = now_ms();
         if (s.d_gpos16) (void)hipFree(s.d_gpos16);
         if (s.d_in) (void)hipFree(s.d_in);
-        if (s.h_in) (void)hipHostFree(s.h_in);
         if (s.d_runs) (void)hipFree(s.d_runs);
+        t_dev += now_ms() - t_x; t_x = now_ms();
+        if (s.h_in) (void)hipHostFree(s.h_in);
         if (s.h_runs) (void)hipHostFree(s.h_runs);
         for (hipEvent_t e : s.ev_ring) if (e) (void)hipEventDestroy(e);
         if (s.h_out) (void)hipHostFree(s.h_out);
+        t_pin += now_ms() - t_x;
         for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_pass, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
     }
+    if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
+        fprintf(stderr, "[isx_pipe_destroy] device tables %.1f ms, device arena %.1f ms, pinned staging %.1f ms, total %.1f ms\n", t_batch, t_dev, t_pin, now_ms() - t_f0);
     if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
     if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     delete p;
@@ -147,6 +156,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
 {
     isx_ctx *c = p->ctx;
     const isx_params *prm = &p->prm;
+    const double t_s0 = now_ms();
     isx_batch *b = new isx_batch();
     s.b = b;
     b->ctx = c; b->prm = *prm; b->M = prm->n_mm_bins;
@@ -208,11 +218,16 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.off_rec = o;
     s.in_bytes = up(o + (size_t)p->cap_rec * p->rb + ISX_TAIL_BYTES);
     const size_t host_bytes = p->ring_half ? up(o + 2 * (size_t)p->ring_half * p->rb) : s.in_bytes;
+    const double t_a0 = now_ms();
     HIP_TRY(hipHostMalloc(&s.h_in, host_bytes, hipHostMallocDefault));
+    const double t_a1 = now_ms();
     HIP_TRY(hipMalloc(&s.d_in, s.in_bytes));
+    if (getenv("ISX_PIPE_TIMING"))
+        fprintf(stderr, "[isx_pipe_create] slot %d: device tables %.1f ms, pinned input %.1f MB %.1f ms, device arena %.1f MB %.1f ms\n", index,
+                t_a0 - t_s0, host_bytes / 1e6, t_a1 - t_a0, s.in_bytes / 1e6, now_ms() - t_a1);
     if (prm->enable_linkage) {
         // a read pair's records are consecutive: runs of tens to hundreds of records
-        s.cap_runs = (size_t)p->cap_rec / 48 + 4096;
+        s.cap_runs = (size_t)p->cap_rec / 64 + 4096;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_runs), s.cap_runs * sizeof(isxenc::PairRun), hipHostMallocDefault));
         HIP_TRY(hipMalloc(&s.d_runs, s.cap_runs * sizeof(uint2)));
     }
@@ -225,12 +240,15 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
         s.o_cov16 = o; o = up(o + (size_t)cap_pos * 2);
         s.o_clon = o; o = up(o + (size_t)cap_pos * 4);
         s.o_rare = o; if (prm->rarefied_coverage > 0) o = up(o + p->rare_prefix * sizeof(isx_rare));
-        // the dense clonTR array: always with want_counts, otherwise only when the sparse list would not be sparse
-        s.o_clonr = o; if (prm->rarefied_coverage > 0) o = up(o + (size_t)cap_pos * 4);
-        if (p->pp.want_counts) { s.o_counts = o; o = up(o + (size_t)cap_pos * 16); }
+        if (p->pp.want_counts) {
+            s.o_counts = o; o = up(o + (size_t)cap_pos * 16);
+            s.o_clonr = o; if (prm->rarefied_coverage > 0) o = up(o + (size_t)cap_pos * 4);
+        }
     }
     s.out_bytes = o;
+    const double t_o0 = now_ms();
     HIP_TRY(hipHostMalloc(&s.h_out, s.out_bytes, hipHostMallocDefault));
+    if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_create] slot %d: pinned results %.1f MB %.1f ms\n", index, s.out_bytes / 1e6, now_ms() - t_o0);
     for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_pass, &s.ev_d2h0, &s.ev_d2h1}) HIP_TRY(hipEventCreate(e));
     const size_t n_chunks = (size_t)(p->cap_rec / ISX_CHUNK) + 2;
     s.cmin.resize(n_chunks); s.cmax.resize(n_chunks); s.cany.resize(n_chunks);
@@ -284,7 +302,9 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
         nt = q > 0 ? q : (int)std::thread::hardware_concurrency();
         nt = std::max(1, std::min(nt, 32));
     }
+    const double t_c0 = now_ms();
     p->pool.reset(new isxenc::HostPool(nt, gpu_numa_node(c->device), pp->pin_threads != 0));
+    const double t_c1 = now_ms();
     int rc = ISX_OK;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking)) != hipSuccess ||
@@ -296,6 +316,8 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     p->slots.resize((size_t)pp->depth);
     for (int i = 0; i < pp->depth && rc == ISX_OK; i++) rc = slot_batch_create(p, p->slots[(size_t)i], i);
     if (rc != ISX_OK) { pipe_free(p); return rc; }
+    if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
+        fprintf(stderr, "[isx_pipe_create] thread pool %.1f ms, %d slot(s) %.1f ms\n", t_c1 - t_c0, pp->depth, now_ms() - t_c1);
     *out = p;
     return ISX_OK;
 }
@@ -602,7 +624,12 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
             if (n_rare > p->cap_rare || n_rare * 8 > (size_t)b->n_pos) {
                 // a deep sample: most positions reach the rarefied coverage, so the 8-byte list is no smaller than
                 // the 4-byte dense array (and would need sorting) -- or the device list overflowed: hand back the array
-                if (!p->pp.want_counts || redo)
+                // (without want_counts there is no pinned room for it: deep samples are the exception, pinning 4 more bytes per
+                // position for every pipe is not worth it)
+                if (!p->pp.want_counts) {
+                    if (s.clonr_big.size() < (size_t)b->n_pos) s.clonr_big.resize((size_t)b->n_pos);
+                    HIP_TRY(hipMemcpy(s.clonr_big.data(), b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+                } else if (redo)
                     HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
                 s.rare_dense = true;
             } else {
@@ -637,7 +664,8 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
         if (p->prm.rarefied_coverage > 0) {
             out->n_rare = (int64_t)b->n_rare;
             if (!s.rare_dense) out->rare = s.rare_big.empty() ? reinterpret_cast<const isx_rare *>(s.h_out + s.o_rare) : s.rare_big.data();
-            if (s.rare_dense || p->pp.want_counts) out->clon_rarefied = reinterpret_cast<const float *>(s.h_out + s.o_clonr);
+            if (p->pp.want_counts) out->clon_rarefied = reinterpret_cast<const float *>(s.h_out + s.o_clonr);
+            else if (s.rare_dense) out->clon_rarefied = s.clonr_big.data();
         }
         if (p->pp.want_counts) out->counts = reinterpret_cast<const uint32_t *>(s.h_out + s.o_counts);
     }

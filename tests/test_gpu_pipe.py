@@ -134,7 +134,7 @@ def test_staging_ring(ctx, skip_mm):
     M = max(w["n_mm_bins"] for w in ws)
     for w in ws:
         w["n_mm_bins"] = M
-    # the last batch: every record its own pair (far more runs than cap_rec / 48)
+    # the last batch: every record its own pair (far more runs than cap_rec / 64)
     w = ws[3]
     w["pair"] = np.arange(len(w["obs"]), dtype=np.uint32)
     kw = dict(enable_linkage=True, min_snp=5, seed=5, rarefied_coverage=20)

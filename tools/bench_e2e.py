@@ -31,4 +31,4 @@ for rep in range(2):
         dt = time.perf_counter() - t0
         print("skip_mm=%s: %d SplitObjects in %.2f s -> %.3f Gbp/s end to end" % (skip, len(out), dt, n_pairs * 300 / 1e9 / dt), flush=True)
         if rep == 1:
-            pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+            pstats.Stats(pr).sort_stats("tottime").print_stats(22)
