@@ -276,7 +276,7 @@ def resident_leg(ctx, w, window, steps=30):
             "note": "resident re-run of one batch (no hand-over, no fetch): kernel-only ceiling"}
 
 
-def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=3, with_cpu=True, scale=1.0):
+def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu=True, scale=1.0):
     """BASELINE.json configs[4]: 1000-genome database, 10 Gbp of reads, --database_mode (one mm
     bin; genomes below 1x dropped like fasta.py:110-136 does).  The kept genomes are LPT-sharded 8 ways on the
     reference's own cost estimate (read pairs, profile_controller.py:460-465); rank r streams shard r through its

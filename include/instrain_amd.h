@@ -279,8 +279,10 @@ int isx_compare_fetch_snps(isx_batch *a, isx_compare_snp *out);
  *     batch k   is copied in (hipMemcpyAsync) and profiled,
  *     batch k-1's tables are copied out (hipMemcpyAsync) / read by the caller.
  * isx_pipe_submit returns once the batch is encoded and everything else is enqueued (the caller's buffers may be
- * reused); isx_pipe_collect blocks until that batch's results are on the host; isx_pipe_release gives the slot
- * back.  Tickets count from 0 in submission order; at most `depth` batches may be submitted and not yet released
+ * reused); a thread of the pipe finishes every batch as soon as its copy-out has landed (table sizes, growth + a
+ * repeated pass when a table was too small, the linkage stages, row sorting) while the caller encodes the next one;
+ * isx_pipe_collect blocks until that is done for the batch and hands its tables over; isx_pipe_release gives the
+ * slot back.  Tickets count from 0 in submission order; at most `depth` batches may be submitted and not yet released
  * (isx_pipe_submit then returns ISX_ERR_STATE).  Not thread-safe: one caller thread per pipe. */
 typedef struct isx_pipe isx_pipe;
 
@@ -334,6 +336,8 @@ typedef struct {
     int32_t record_bytes;       /* 2 or 4 */
     int32_t encode_passes;      /* 1; 2 when the stream jumped more often than the slot's slack allowed */
     int64_t h2d_bytes, d2h_bytes;
+    const isx_ld *ld;           /* [sizes.n_ld] the LD rows when linkage is enabled (else NULL), reference order;
+                                 * valid until isx_pipe_release */
 } isx_pipe_result;
 
 int isx_pipe_create(isx_ctx *ctx, const isx_params *params, const isx_pipe_params *pp, isx_pipe **out);

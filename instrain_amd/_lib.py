@@ -65,7 +65,7 @@ class PipeResult(C.Structure):
                 ("batch", C.c_void_p),
                 ("encode_ms", C.c_float), ("h2d_ms", C.c_float), ("kernel_ms", C.c_float), ("d2h_ms", C.c_float),
                 ("collect_wait_ms", C.c_float), ("record_bytes", C.c_int32), ("encode_passes", C.c_int32),
-                ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64)]
+                ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64), ("ld", C.c_void_p)]
 
 
 class BamParams(C.Structure):

@@ -19,7 +19,10 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <thread>
@@ -59,9 +62,13 @@ struct Slot {
     std::vector<uint8_t> cany;
     std::vector<uint2> win;
     std::vector<isx_snv> snv_big;           // more SNV rows than the pinned block holds (rare)
+    std::vector<isx_ld> ld_rows;            // the batch's LD rows (linkage), fetched by the finisher
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_pass = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     int64_t ticket = -1;
-    int state = 0;                          // 0 free, 1 submitted, 2 collected
+    int state = 0;                          // 0 free, 1 submitted, 2 finished (tables on the host, linkage done)
+    int rc = 0;                             // of the finishing step
+    std::string err;
+    float finish_wait_ms = 0.f;
     float encode_ms = 0.f;
     int encode_passes = 0;
     int64_t h2d_bytes = 0, d2h_bytes = 0;
@@ -111,11 +118,24 @@ struct isx_pipe {
     size_t snv_prefix = 0;                  // SNV rows copied out with the dense tables
     size_t rare_prefix = 0, cap_rare = 0;   // clonTR entries copied out with them / the device list's capacity
     double slack = 0.0;                     // learned: extra device groups per input group of the last jumping batch
+    // the finisher: a thread that takes every submitted batch as soon as its copy-out has landed -- sizes, table growth +
+    // repeated pass, linkage stages, row sorting -- so that this work overlaps the caller encoding the next batch
+    std::thread finisher;
+    std::mutex mu;                          // slot states + the work queue
+    std::condition_variable cv_work, cv_done;
+    std::deque<int64_t> work;
+    bool stop = false;
+    std::mutex launch_mu;                   // pass-queue launches (submit vs. the finisher repeating a pass)
 };
 
 static void pipe_free(isx_pipe *p)
 {
     if (!p) return;
+    if (p->finisher.joinable()) {               // it finishes what was submitted, then leaves
+        { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
+        p->cv_work.notify_all();
+        p->finisher.join();
+    }
     (void)hipSetDevice(p->ctx->device);
     if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
     if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
@@ -255,6 +275,111 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     return ISX_OK;
 }
 
+// everything between "the batch's copy-out has landed" and "its tables can be handed to the caller"
+static int finish_slot(isx_pipe *p, Slot &s)
+{
+    isx_ctx *c = p->ctx;
+    isx_batch *b = s.b;
+    const bool dense = b->M == 1;
+    const double t0 = now_ms();
+    HIP_TRY(hipEventSynchronize(s.ev_d2h1));
+    s.finish_wait_ms = (float)(now_ms() - t0);
+    const double t_c0 = now_ms();
+    double t_fin = 0, t_rare = 0;
+    hipStream_t ps = c->pstream[b->ps];
+    bool redo = false;
+    for (int attempt = 0;; attempt++) {
+        uint32_t cf = 0;
+        int rc = finish_pass(b, &cf);           // sizes from the published cursors; linkage stages when enabled
+        if (rc != ISX_OK) return rc;
+        if (!cf) break;
+        if (attempt == 7) { isx_set_error("output tables still too small after 8 growth steps"); return ISX_ERR_CAPACITY; }
+        // a table was too small for this batch: grow it and repeat the pass (the slot still holds its input)
+        if ((rc = batch_grow_tables(b, cf)) != ISX_OK) return rc;
+        if (!dense) b->cap_ovf = b->cap_entries - (size_t)b->n_win * b->slab;
+        std::lock_guard<std::mutex> lk(p->launch_mu);
+        if (dense && p->prm.rarefied_coverage > 0)
+            HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)b->n_pos, ps));
+        if ((rc = launch_pass(b)) != ISX_OK) return rc;
+        redo = true;
+    }
+    t_fin = now_ms();
+    if (redo && dense) {                        // the copied-out tables predate the repeated pass
+        HIP_TRY(hipMemcpy(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+        if (p->pp.want_counts) {
+            HIP_TRY(hipMemcpy(s.h_out + s.o_counts, b->d_counts, (size_t)b->n_pos * 16, hipMemcpyDeviceToHost));
+            if (p->prm.rarefied_coverage > 0)
+                HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    if (dense && p->prm.rarefied_coverage > 0) {        // the sparse clonTR table, ascending positions
+        const size_t n_rare = b->n_rare;
+        isx_rare *rr = reinterpret_cast<isx_rare *>(s.h_out + s.o_rare);
+        s.rare_big.clear();
+        s.rare_dense = false;
+        if (n_rare > p->cap_rare || n_rare * 8 > (size_t)b->n_pos) {
+            // a deep sample: most positions reach the rarefied coverage, so the 8-byte list is no smaller than
+            // the 4-byte dense array (and would need sorting) -- or the device list overflowed: hand back the array
+            // (without want_counts there is no pinned room for it: deep samples are the exception, pinning 4 more bytes per
+            // position for every pipe is not worth it)
+            if (!p->pp.want_counts) {
+                if (s.clonr_big.size() < (size_t)b->n_pos) s.clonr_big.resize((size_t)b->n_pos);
+                HIP_TRY(hipMemcpy(s.clonr_big.data(), b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+            } else if (redo)
+                HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+            s.rare_dense = true;
+        } else {
+            if (n_rare > p->rare_prefix || redo) {
+                if (n_rare > p->rare_prefix) { s.rare_big.resize(n_rare); rr = s.rare_big.data(); }
+                if (n_rare) HIP_TRY(hipMemcpy(rr, b->d_rare, n_rare * sizeof(isx_rare), hipMemcpyDeviceToHost));
+            }
+            std::sort(rr, rr + n_rare, [](const isx_rare &x, const isx_rare &y) { return x.gpos < y.gpos; });
+        }
+    }
+    t_rare = now_ms();
+    const size_t n_snv = (size_t)b->sizes.n_snv;
+    isx_snv *rows = reinterpret_cast<isx_snv *>(s.h_out + s.o_snv);
+    if (n_snv > p->snv_prefix || redo) {
+        if (n_snv > p->snv_prefix) { s.snv_big.resize(n_snv); rows = s.snv_big.data(); }
+        if (n_snv) HIP_TRY(hipMemcpy(rows, b->d_snv, n_snv * sizeof(isx_snv), hipMemcpyDeviceToHost));
+    }
+    std::sort(rows, rows + n_snv, [](const isx_snv &x, const isx_snv &y) { return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm; });
+    if (p->prm.enable_linkage) {
+        // the LD rows too: a blocking copy issued by the caller would queue behind the next batches' large transfers
+        s.ld_rows.resize((size_t)b->sizes.n_ld);
+        if (!s.ld_rows.empty()) { const int rc = isx_batch_fetch_ld(b, s.ld_rows.data()); if (rc != ISX_OK) return rc; }
+    }
+    if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
+        fprintf(stderr, "[isx_pipe finisher] wait %.2f ms, finish (sizes, linkage) %.2f ms, clonTR list (%u) %.2f ms, snv rows (%zu) %.2f ms\n",
+                s.finish_wait_ms, t_fin - t_c0, b->n_rare, t_rare - t_fin, n_snv, now_ms() - t_rare);
+    return ISX_OK;
+}
+
+static void finisher_main(isx_pipe *p)
+{
+    (void)hipSetDevice(p->ctx->device);
+    for (;;) {
+        int64_t ticket;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_work.wait(lk, [&] { return p->stop || !p->work.empty(); });
+            if (p->work.empty()) return;        // stop, nothing left
+            ticket = p->work.front();
+            p->work.pop_front();
+        }
+        Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
+        const int rc = finish_slot(p, s);
+        std::string err = rc == ISX_OK ? std::string() : std::string(isx_last_error());
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            s.rc = rc; s.err.swap(err);
+            s.state = 2;
+        }
+        p->cv_done.notify_all();
+    }
+}
+
 extern "C" {
 
 int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp, isx_pipe **out)
@@ -316,6 +441,7 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     p->slots.resize((size_t)pp->depth);
     for (int i = 0; i < pp->depth && rc == ISX_OK; i++) rc = slot_batch_create(p, p->slots[(size_t)i], i);
     if (rc != ISX_OK) { pipe_free(p); return rc; }
+    p->finisher = std::thread(finisher_main, p);
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_create] thread pool %.1f ms, %d slot(s) %.1f ms\n", t_c1 - t_c0, pp->depth, now_ms() - t_c1);
     *out = p;
@@ -481,6 +607,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
 
     // ---- pass queue ----
+    std::unique_lock<std::mutex> launch_lk(p->launch_mu);
     HIP_TRY(hipStreamWaitEvent(ps, s.ev_h2d1, 0));
     if (dense && p->prm.rarefied_coverage > 0)
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)n_pos, ps));
@@ -521,9 +648,15 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         }
     }
     HIP_TRY(hipEventRecord(s.ev_d2h1, p->s_d2h));
-    s.ticket = p->next_ticket++;
-    s.state = 1;
-    *ticket = s.ticket;
+    launch_lk.unlock();
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        s.ticket = p->next_ticket++;
+        s.state = 1; s.rc = ISX_OK;
+        *ticket = s.ticket;
+        p->work.push_back(s.ticket);
+    }
+    p->cv_work.notify_one();
     return ISX_OK;
 }
 
@@ -578,81 +711,19 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
 {
     if (!p || !out || ticket < 0) { isx_set_error("isx_pipe_collect: bad argument"); return ISX_ERR_ARG; }
     Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
-    if (s.ticket != ticket || s.state == 0) { isx_set_error("isx_pipe_collect: unknown or already released ticket"); return ISX_ERR_STATE; }
     isx_ctx *c = p->ctx;
     isx_batch *b = s.b;
-    HIP_TRY(hipSetDevice(c->device));
     const bool dense = b->M == 1;
     *out = isx_pipe_result{};
-    if (s.state == 1) {
+    {
         const double t0 = now_ms();
-        HIP_TRY(hipEventSynchronize(s.ev_d2h1));
+        std::unique_lock<std::mutex> lk(p->mu);
+        if (s.ticket != ticket || s.state == 0) { isx_set_error("isx_pipe_collect: unknown or already released ticket"); return ISX_ERR_STATE; }
+        p->cv_done.wait(lk, [&] { return s.state == 2; });
         out->collect_wait_ms = (float)(now_ms() - t0);
-        const double t_c0 = now_ms();
-        double t_fin = 0, t_rare = 0;
-        hipStream_t ps = c->pstream[b->ps];
-        bool redo = false;
-        for (int attempt = 0;; attempt++) {
-            uint32_t cf = 0;
-            int rc = finish_pass(b, &cf);           // sizes from the published cursors; linkage stages when enabled
-            if (rc != ISX_OK) { s.state = 2; return rc; }
-            if (!cf) break;
-            if (attempt == 7) { isx_set_error("output tables still too small after 8 growth steps"); s.state = 2; return ISX_ERR_CAPACITY; }
-            // a table was too small for this batch: grow it and repeat the pass (the slot still holds its input)
-            if ((rc = batch_grow_tables(b, cf)) != ISX_OK) { s.state = 2; return rc; }
-            if (!dense) b->cap_ovf = b->cap_entries - (size_t)b->n_win * b->slab;
-            if (dense && p->prm.rarefied_coverage > 0)
-                HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)b->n_pos, ps));
-            if ((rc = launch_pass(b)) != ISX_OK) { s.state = 2; return rc; }
-            redo = true;
-        }
-        t_fin = now_ms();
-        if (redo && dense) {                        // the copied-out tables predate the repeated pass
-            HIP_TRY(hipMemcpy(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
-            if (p->pp.want_counts) {
-                HIP_TRY(hipMemcpy(s.h_out + s.o_counts, b->d_counts, (size_t)b->n_pos * 16, hipMemcpyDeviceToHost));
-                if (p->prm.rarefied_coverage > 0)
-                    HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
-            }
-        }
-        if (dense && p->prm.rarefied_coverage > 0) {        // the sparse clonTR table, ascending positions
-            const size_t n_rare = b->n_rare;
-            isx_rare *rr = reinterpret_cast<isx_rare *>(s.h_out + s.o_rare);
-            s.rare_big.clear();
-            s.rare_dense = false;
-            if (n_rare > p->cap_rare || n_rare * 8 > (size_t)b->n_pos) {
-                // a deep sample: most positions reach the rarefied coverage, so the 8-byte list is no smaller than
-                // the 4-byte dense array (and would need sorting) -- or the device list overflowed: hand back the array
-                // (without want_counts there is no pinned room for it: deep samples are the exception, pinning 4 more bytes per
-                // position for every pipe is not worth it)
-                if (!p->pp.want_counts) {
-                    if (s.clonr_big.size() < (size_t)b->n_pos) s.clonr_big.resize((size_t)b->n_pos);
-                    HIP_TRY(hipMemcpy(s.clonr_big.data(), b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
-                } else if (redo)
-                    HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
-                s.rare_dense = true;
-            } else {
-                if (n_rare > p->rare_prefix || redo) {
-                    if (n_rare > p->rare_prefix) { s.rare_big.resize(n_rare); rr = s.rare_big.data(); }
-                    if (n_rare) HIP_TRY(hipMemcpy(rr, b->d_rare, n_rare * sizeof(isx_rare), hipMemcpyDeviceToHost));
-                }
-                std::sort(rr, rr + n_rare, [](const isx_rare &x, const isx_rare &y) { return x.gpos < y.gpos; });
-            }
-        }
-        t_rare = now_ms();
-        const size_t n_snv = (size_t)b->sizes.n_snv;
-        isx_snv *rows = reinterpret_cast<isx_snv *>(s.h_out + s.o_snv);
-        if (n_snv > p->snv_prefix || redo) {
-            if (n_snv > p->snv_prefix) { s.snv_big.resize(n_snv); rows = s.snv_big.data(); }
-            if (n_snv) HIP_TRY(hipMemcpy(rows, b->d_snv, n_snv * sizeof(isx_snv), hipMemcpyDeviceToHost));
-        }
-        std::sort(rows, rows + n_snv, [](const isx_snv &x, const isx_snv &y) { return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm; });
-        if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
-            fprintf(stderr, "[isx_pipe_collect] wait %.2f ms, finish (sizes, linkage) %.2f ms, clonTR list (%u) %.2f ms, snv rows (%zu) %.2f ms\n",
-                    out->collect_wait_ms, t_fin - t_c0, b->n_rare, t_rare - t_fin, n_snv, now_ms() - t_rare);
-        s.state = 2;
+        if (s.rc != ISX_OK) { isx_set_error(s.err); return s.rc; }
     }
+    HIP_TRY(hipSetDevice(c->device));
     out->ticket = ticket;
     out->n_pos = b->n_pos; out->n_obs = b->n_obs;
     out->sizes = b->sizes;
@@ -674,6 +745,7 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
     out->encode_passes = s.encode_passes;
     out->record_bytes = p->rb;
     out->h2d_bytes = s.h2d_bytes; out->d2h_bytes = s.d2h_bytes;
+    out->ld = p->prm.enable_linkage ? s.ld_rows.data() : nullptr;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s.ev_h2d0, s.ev_h2d1) == hipSuccess) out->h2d_ms = ms;
     if (hipEventElapsedTime(&ms, s.ev_d2h0, s.ev_d2h1) == hipSuccess) out->d2h_ms = ms;
@@ -686,13 +758,9 @@ int isx_pipe_release(isx_pipe *p, int64_t ticket)
 {
     if (!p || ticket < 0) { isx_set_error("isx_pipe_release: bad argument"); return ISX_ERR_ARG; }
     Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
+    std::unique_lock<std::mutex> lk(p->mu);
     if (s.ticket != ticket || s.state == 0) { isx_set_error("isx_pipe_release: unknown or already released ticket"); return ISX_ERR_STATE; }
-    if (s.state == 1) {                             // never collected: let its queued work drain before the slot is reused
-        HIP_TRY(hipSetDevice(p->ctx->device));
-        HIP_TRY(hipEventSynchronize(s.ev_d2h1));
-        uint32_t cf = 0;
-        (void)finish_pass(s.b, &cf);
-    }
+    p->cv_done.wait(lk, [&] { return s.state == 2; });     // never collected: its queued work drains before the slot is reused
     s.state = 0;
     return ISX_OK;
 }

@@ -266,9 +266,7 @@ class Pipe:
             out["clon_r"] = out["entries"]["clon_rarefied"]
         out["snv"] = view(r.snv, SNV_DT, sz["n_snv"])
         if want_ld and self.enable_linkage:
-            l = np.empty(max(1, sz["n_ld"]), dtype=LD_DT)
-            check(self.lib.isx_batch_fetch_ld(slot.h, l.ctypes.data))
-            out["ld"] = l[:sz["n_ld"]]
+            out["ld"] = view(r.ld, LD_DT, sz["n_ld"]) if r.ld else np.empty(0, dtype=LD_DT)
         else:
             out["ld"] = np.empty(0, dtype=LD_DT)
         out["slot"] = slot

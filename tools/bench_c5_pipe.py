@@ -22,8 +22,28 @@ for link in (False, True, True):
                        depth=3, host_threads=int(os.environ.get("THREADS", 24)), n_mm_bins=1, enable_linkage=link, min_snp=20, jump_slack=0.5)
     bench.stream(pipe, ws, 2, 3)
     stats = []
+    t_sub, t_col, t_rel = [], [], []
     t0 = time.perf_counter()
-    bench.stream(pipe, ws, len(ws), 3, stats)
+    tickets = []
+    done = 0
+    def take():
+        global done
+        a = time.perf_counter()
+        r = pipe.collect(tickets[done], want_ld=link)
+        b = time.perf_counter()
+        stats.append((r["stats"], r["sizes"]))
+        pipe.release(tickets[done])
+        t_col.append((b - a) * 1e3); t_rel.append((time.perf_counter() - b) * 1e3)
+        done += 1
+    for i, v in enumerate(ws):
+        if len(tickets) - done == 3:
+            take()
+        a = time.perf_counter()
+        tickets.append(pipe.submit(v["ref_codes"], v["split_bounds"], v["obs"], v["pair"] if link else None))
+        t_sub.append((time.perf_counter() - a) * 1e3)
+    while done < len(tickets):
+        take()
     dt = time.perf_counter() - t0
+    print("caller: submit %.1f ms" % sum(t_sub), [round(x, 1) for x in t_sub], "collect %.1f ms" % sum(t_col), [round(x, 1) for x in t_col], "release %.1f" % sum(t_rel), flush=True)
     print("linkage", link, "wall %.1f ms" % (dt * 1e3), "encode", [round(s[0]["encode_ms"], 1) for s in stats], "collect_wait", [round(s[0]["collect_wait_ms"], 1) for s in stats], flush=True)
     pipe.close()
