@@ -271,6 +271,35 @@ def test_pipe_errors(ctx):
     pipe.close()
 
 
+def test_error_found_while_finishing_reaches_collect(ctx):
+    """an mm level the pipe has no bin for is only seen by the kernel; the pipe's finishing thread finds the flag, collect()
+    of THAT batch raises with its message, the batches around it are unaffected"""
+    from instrain_amd import engine
+    from instrain_amd._lib import IsxError
+    w = small_workload(700, 30_000, 15, False)
+    M = int(w["n_mm_bins"])
+    exp, sizes = one_shot(ctx, w, enable_linkage=False)
+    bad = w["obs"].copy()
+    bad["mm"][len(bad) // 2] = M + 3
+    pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=w["n_obs"], max_splits=len(w["split_bounds"]), depth=3, host_threads=2,
+                       n_mm_bins=M, enable_linkage=False)
+    t0 = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+    t1 = pipe.submit(w["ref_codes"], w["split_bounds"], bad)
+    t2 = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+    same_tables(pipe.collect(t0), exp, "before the bad batch")
+    with pytest.raises(IsxError) as e:
+        pipe.collect(t1)
+    assert "mm" in str(e.value)
+    same_tables(pipe.collect(t2), exp, "after the bad batch")
+    for t in (t0, t1, t2):
+        pipe.release(t)
+    t3 = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])          # the slot that held the bad batch
+    t4 = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+    same_tables(pipe.collect(t4), exp, "reused slot")
+    pipe.release(t3); pipe.release(t4)
+    pipe.close()
+
+
 def test_submit_bam_equals_array_submit(ctx, tmp_path):
     """the fused path (front end expanding straight into the slot's staging, pair ids as runs) gives exactly the tables of
     expand_refs + array submit and of the one-shot path, for a messy multi-scaffold BAM, with and without mm profiling"""
