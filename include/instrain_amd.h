@@ -354,6 +354,9 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
                         int64_t *ticket);
 int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out);
 int isx_pipe_release(isx_pipe *p, int64_t ticket);
+/* n_mm_bins > 1: the entry table of a collected batch ([sizes.n_entries], (gpos, mm) order) -- what
+ * isx_batch_fetch_entries(result.batch, out) returns, moved through the slot's pinned staging by the pipe's host threads */
+int isx_pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out);
 
 /* The pipe's host-side encoder on its own (no GPU needed): obs[n_obs] -> resident record stream.
  *   record_bytes 2: delta:13 | base:3, groups of 512 records; 4: delta:16 | mm:8 | base:3 (<< 24), groups of 256;

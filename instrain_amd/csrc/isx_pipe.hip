@@ -31,6 +31,7 @@
 #include "bam_front.h"
 #include "isx_batch.h"
 #include "obs_encode.h"
+#include "isx_summary.h"
 
 namespace {
 
@@ -752,6 +753,55 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
     isx_timings t{};
     if (isx_batch_timings(b, &t) == ISX_OK) out->kernel_ms = t.pileup_ms;
     return ISX_OK;
+}
+
+// The entry table of a collected mm batch (isx_batch_fetch_entries on the slot, but the 32 bytes per entry go through the
+// slot's idle pinned input staging in two alternating pieces and are moved into `out` by the pipe's host threads: a blocking
+// copy into pageable memory runs at a fifth of the link).
+int isx_pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out)
+{
+    if (!p || ticket < 0 || !out) { isx_set_error("isx_pipe_fetch_entries: bad argument"); return ISX_ERR_ARG; }
+    Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (s.ticket != ticket || s.state != 2 || s.rc != ISX_OK) { isx_set_error("isx_pipe_fetch_entries: collect the batch first"); return ISX_ERR_STATE; }
+    }
+    isx_batch *b = s.b;
+    if (b->M == 1) { isx_set_error("n_mm_bins == 1: the dense tables come with isx_pipe_collect"); return ISX_ERR_STATE; }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    const size_t n = (size_t)b->sizes.n_entries;
+    if (!n) return ISX_OK;
+    const size_t region = p->ring_half ? 2 * (size_t)p->ring_half * p->rb : (size_t)p->cap_rec * p->rb;
+    const size_t piece = std::min<size_t>((size_t)32 << 20, region / 2 / 4096 * 4096);
+    if (piece < ((size_t)1 << 20)) return isx_batch_fetch_entries(b, out);      // tiny pipe: not worth it
+    uint8_t *bounce[2] = {s.h_in + s.off_rec, s.h_in + s.off_rec + piece};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (hipEvent_t &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const EntryCopier copier = [&](const void *dsrc, void *hdst, size_t bytes, hipStream_t st) -> int {
+        const size_t n_pieces = (bytes + piece - 1) / piece;
+        auto issue = [&](size_t k) -> hipError_t {
+            const size_t off = k * piece, len = std::min(piece, bytes - off);
+            hipError_t e = hipMemcpyAsync(bounce[k & 1], static_cast<const uint8_t *>(dsrc) + off, len, hipMemcpyDeviceToHost, st);
+            return e == hipSuccess ? hipEventRecord(ev[k & 1], st) : e;
+        };
+        HIP_TRY(issue(0));
+        for (size_t k = 0; k < n_pieces; k++) {
+            if (k + 1 < n_pieces) HIP_TRY(issue(k + 1));        // its half was emptied by the threads one step ago
+            HIP_TRY(hipEventSynchronize(ev[k & 1]));
+            const size_t off = k * piece, len = std::min(piece, bytes - off);
+            const size_t sub = (size_t)1 << 20;
+            const uint8_t *src = bounce[k & 1];
+            uint8_t *dst = static_cast<uint8_t *>(hdst) + off;
+            p->pool->run((int)((len + sub - 1) / sub), [&](int t) {
+                const size_t a = (size_t)t * sub;
+                memcpy(dst + a, src + a, std::min(sub, len - a));
+            });
+        }
+        return ISX_OK;
+    };
+    const int rc = fetch_entries_sorted(p->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, (uint32_t)b->n_win, b->n_ovf, n, out, &copier);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 int isx_pipe_release(isx_pipe *p, int64_t ticket)

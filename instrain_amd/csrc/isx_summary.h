@@ -1,5 +1,7 @@
 // isx_summary.h -- host-side interface of the per-scaffold summary pass (isx_summary.hip)
 #pragma once
+#include <functional>
+
 #include "isx_internal.h"
 
 struct SummaryBuffers {
@@ -67,6 +69,9 @@ struct CompareSnpIn {                       // nullptr lut = coverage half only
 int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, const CompareSnpIn &snp, CompareBuffers &B,
                 isx_compare_level *host_out, float *ms);
 
-// the mm path's entry table (window slabs + overflow) compacted and ordered by (gpos, mm) on the device
+// the mm path's entry table (window slabs + overflow) compacted and ordered by (gpos, mm) on the device, then brought to
+// host_out: by one hipMemcpyAsync, or by `copier` (device source, host destination, bytes, stream) when the caller has a
+// faster way to pageable memory (a pipe's pinned staging + its host threads)
+typedef std::function<int(const void *, void *, size_t, hipStream_t)> EntryCopier;
 int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t *win_nent, uint32_t slab, uint32_t n_win,
-                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out);
+                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out, const EntryCopier *copier = nullptr);

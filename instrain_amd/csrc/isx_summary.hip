@@ -373,7 +373,7 @@ __global__ void k_gather_entries(const isx_entry *entries, const uint32_t *idx, 
 }  // namespace
 
 int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t *win_nent, uint32_t slab, uint32_t n_win,
-                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out)
+                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out, const EntryCopier *copier)
 {
     const uint64_t ovf0 = (uint64_t)n_win * slab;
     if (ovf0 + n_ovf >= 0xFFFFFFFFull || n_entries >= 0xFFFFFFFFull) { isx_set_error("entry table too large to fetch in one piece"); return ISX_ERR_CAPACITY; }
@@ -402,8 +402,14 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
     hipLaunchKernelGGL(k_gather_entries, dim3((n + 255) / 256), dim3(256), 0, s, entries, idx + n, n, out);
     uint32_t got = 0;
     FE_TRY(hipMemcpyAsync(&got, cursor, 4, hipMemcpyDeviceToHost, s));
-    FE_TRY(hipMemcpyAsync(host_out, out, (size_t)n * sizeof(isx_entry), hipMemcpyDeviceToHost, s));
-    FE_TRY(hipStreamSynchronize(s));
+    if (copier) {
+        FE_TRY(hipStreamSynchronize(s));
+        const int crc = (*copier)(out, host_out, (size_t)n * sizeof(isx_entry), s);
+        if (crc != ISX_OK) return done(crc);
+    } else {
+        FE_TRY(hipMemcpyAsync(host_out, out, (size_t)n * sizeof(isx_entry), hipMemcpyDeviceToHost, s));
+        FE_TRY(hipStreamSynchronize(s));
+    }
 #undef FE_TRY
     if (got != n) { isx_set_error("entry table inconsistent: " + std::to_string(got) + " gathered vs " + std::to_string(n)); rc = ISX_ERR_STATE; }
     return done(rc);

@@ -261,7 +261,7 @@ class Pipe:
                     out["clon_r"] = np.full(n_pos, np.nan, np.float32)
         else:
             e = np.empty(max(1, sz["n_entries"]), dtype=ENTRY_DT)
-            check(self.lib.isx_batch_fetch_entries(slot.h, e.ctypes.data))
+            check(self.lib.isx_pipe_fetch_entries(self.h, int(ticket), e.ctypes.data))
             out["entries"] = e[:sz["n_entries"]]
             out["clon_r"] = out["entries"]["clon_rarefied"]
         out["snv"] = view(r.snv, SNV_DT, sz["n_snv"])
