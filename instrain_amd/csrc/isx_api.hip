@@ -353,13 +353,13 @@ int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed)
         // small batches: every CU should still own >= 2 windows
         const int64_t wsmall = (n_pos / 1024 + 63) / 64 * 64;
         if (wsmall < 2048) return (int)std::max<int64_t>(512, wsmall);
-        // otherwise the multiple of 64 in [2048, 3904] (two 1024-lane workgroups per CU fit their LDS)
+        // otherwise the multiple of 64 in [2048, 3264] (two 1024-lane workgroups per CU fit their LDS)
         // that wastes least: whole rounds of the 512 persistent workgroups x stream over-scan of a
         // window (~ one read length + one directory chunk on each side)
         // (with linkage a position also carries slabc + maskl: 25 bytes, so two workgroups fit up to 3136)
         int best = 2560;
         double best_eff = 0.0;
-        const int wtop = prm->enable_linkage ? 3136 : 3904;
+        const int wtop = prm->enable_linkage ? 3136 : ISX_PK16_MAX_W;      // 3264: the packed decode of 2-byte records needs 16-bit byte offsets
         for (int w = 2048; w <= wtop; w += 64) {
             const double n_win = std::ceil((double)n_pos / w);
             const double rounds = n_win / 512.0;

@@ -10,6 +10,8 @@
 #define ISX_GROUP16 512              // short stream: records per position base (one wave-wide 16-byte load of 8 records per lane)
 #define ISX_GROUP 256                // compact stream: records per position base (one wave-wide 16-byte load)
 #define ISX_CHUNK 1024              // observation directory granule (records)
+#define ISX_DENSE_PAD 8             // k_pileup_dense: extra words per counter row (junk columns of the packed 16-bit decode)
+#define ISX_PK16_MAX_W 3264         // ... whose byte offsets (5 (W + 8) + 7) * 4 must stay below 65536
 #define ISX_PAD 2048                // the record stream is padded to a multiple of this (whole directory chunks, 16-byte loads)
 #define ISX_SENTINEL 0xFFFFFFFFu    // gpos of padding records (never inside a window)
 // The compact streams (2- / 4-byte records) are followed by this many bytes of padding records (and the group bases by

@@ -340,18 +340,21 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, uint32_t lo, ui
 // NEXT window's first loads, which are issued before the epilogue starts.  SNV rows / SNP sites /
 // allele-observation slabs are allocated with ONE global atomic each per window (LDS-aggregated);
 // clonality divisions and row emission run densely packed from an LDS queue.
-// LDS: cnt[4][W] | queue[W] | scratch[16] | thr_lds[THR_LDS] | (linkage) slabc[W] | maskl[W bytes]
+// LDS: cnt[4][S] | queue[S] | scratch[16] | thr_lds[THR_LDS] | (linkage) slabc[W] | maskl[W bytes], S = W + ISX_DENSE_PAD:
+// the 8 extra words of a row are the junk columns of the packed decode (records that belong to another window), and the
+// queue region -- idle during the stream -- is the junk row of records without an A/C/T/G base.
 // ---------------------------------------------------------------------------------------------
-template <bool LINKAGE, int FMT>          // FMT = bytes per resident record: 8 (isx_obs), 4 (compact), 2 (short)
-__global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
+template <bool LINKAGE, int FMT, bool PK16 = false>   // FMT = bytes per resident record: 8 (isx_obs), 4 (compact), 2 (short);
+__global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)     // PK16: short records decoded two at a time
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     publish_previous(a, tid);
     const int W = a.W;
+    const int S = W + ISX_DENSE_PAD;            // row stride of the counters
     uint32_t *cnt = lds;
-    uint32_t *queue = lds + 4 * W;
-    uint32_t *scratch = queue + W;
+    uint32_t *queue = lds + 4 * S;
+    uint32_t *scratch = queue + S;
     uint16_t *thr_lds = reinterpret_cast<uint16_t *>(scratch + S_N);
     uint32_t *slabc = scratch + S_N + THR_LDS / 2;
     uint8_t *maskl = reinterpret_cast<uint8_t *>(slabc + W);
@@ -372,6 +375,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
 
     u32x4 v[4];
     uint32_t gb[4] = {0, 0, 0, 0};              // COMPACT: position base of each load's group (wave-uniform)
+    bool live[4] = {false, false, false, false};   // COMPACT: the wave really loaded slot u (wave-uniform); a skipped slot holds nothing to count
     uint32_t lo = 0, hi = 0;
     const uint32_t lane16 = (uint32_t)tid;      // lane offset in 16-byte units: the one address register of the stream loads
     auto issue_one = [&](int u, uint32_t i0) {  // one coalesced 16-byte load per lane into slot u
@@ -380,6 +384,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         // window and are dropped like any other) -- no per-lane branch, no select against a padding value
         // (a wave whose 64 loads all lie past `hi` skips the load -- a uniform branch -- and counts padding instead)
         const uint32_t jw = __builtin_amdgcn_readfirstlane(j);
+        if (COMPACT) live[u] = jw < hi;
         if (COMPACT ? jw < hi : j < hi) {
             // wave-uniform base in scalar registers + one 32-bit lane offset (saddr form): no 64-bit address pair per
             // load in flight -- with four loads rotating the pairs were spilled and every reload drained vmcnt
@@ -406,13 +411,13 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
     for (int w = slot; w < a.n_win; w += grid) {
         const uint32_t w0 = (uint32_t)w * (uint32_t)W;
         const uint32_t cur_lo = lo, cur_hi = hi;
-        const uint32_t dummy = 4u * (uint32_t)W + (uint32_t)(tid & 63);     // see the stream loop
+        const uint32_t dummy = 4u * (uint32_t)S + (uint32_t)(tid & 63);     // see the stream loop
 #ifdef ISX_TUNING
         uint32_t ablate_acc = 0;
 #endif
         {   // zero the window's counters
             uint4 *z = reinterpret_cast<uint4 *>(cnt);
-            for (int i = tid; i < W; i += nthr) z[i] = make_uint4(0, 0, 0, 0);
+            for (int i = tid; i < S; i += nthr) z[i] = make_uint4(0, 0, 0, 0);     // 4 S words
             if (linkage) {
                 uint4 *zm = reinterpret_cast<uint4 *>(maskl);
                 for (int i = tid; i < (W >> 4); i += nthr) zm[i] = make_uint4(0, 0, 0, 0);
@@ -432,22 +437,58 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         // region, idle during the stream) -- no exec-mask juggling per record, and the counter index is a 24-bit mad
         // (v_mul_lo_u32 is quarter rate).
         auto count_slot = [&](int u) {
+            if (COMPACT && !live[u]) return;        // uniform: the last round of a window is half empty on average
             if (FMT == 2) {
                 const uint32_t bw = gb[u] - w0;
                 const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #ifdef ISX_TUNING
                 if (dbg & 64) { ablate_acc += x[0] ^ x[1] ^ x[2] ^ x[3] ^ bw; return; }         // loads only
 #endif
+                if (PK16
+#ifdef ISX_TUNING
+                    && !(dbg & (8 | 16 | 32))
+#endif
+                ) {
+                    // Two records per 32-bit word, decoded together with packed 16-bit ALU ops: the stream phase is VALU-bound
+                    // (SQ counters) and this is 5 VALU per record instead of 8 VALU + 1 SALU.
+                    //   rel  = delta + (group base - window start) mod 2^16; anything >= W (a later window; an earlier one
+                    //          wraps to >= 57345) is clamped into the lane's junk column W + (lane & 7)
+                    //   row  = min(base, 4): row 4 is the junk row (the idle queue region) for non-ACGT / padding records
+                    //   byte offset = (row * S + rel) * 4 < 65536 because W <= ISX_PK16_MAX_W (checked at launch)
+                    // The group's offset is wave-uniform; one that cannot belong to a group overlapping the window (a chunk of
+                    // the directory may drag in a group of another genome) would alias in 16 bits and is replaced by one that
+                    // sends every record of the load to the junk columns.
+                    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                    const uint32_t o16 = (bw + 8192u < 24576u) ? (bw & 0xFFFFu) : 0x7000u;
+                    const u16x2 bw2 = {(unsigned short)o16, (unsigned short)o16};
+                    const unsigned short wl = (unsigned short)(W + (tid & 7));
+                    const u16x2 wl2 = {wl, wl};
+                    const u16x2 sv = {(unsigned short)S, (unsigned short)S};
+                    const u16x2 m13 = {0x1FFF, 0x1FFF};
+                    const u16x2 four = {4, 4};
+                    char *lds_b = reinterpret_cast<char *>(lds);
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const u16x2 xx = __builtin_bit_cast(u16x2, x[h]);
+                        const u16x2 r = __builtin_elementwise_min((u16x2)((xx & m13) + bw2), wl2);
+                        const u16x2 row = __builtin_elementwise_min((u16x2)(xx >> 13), four);
+                        const u16x2 f = (u16x2)(row * sv + r) << 2;
+                        const uint32_t fa = __builtin_bit_cast(uint32_t, f);
+                        atomicAdd(reinterpret_cast<uint32_t *>(lds_b + (fa & 0xFFFFu)), 1u);
+                        atomicAdd(reinterpret_cast<uint32_t *>(lds_b + (fa >> 16)), 1u);
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int h = 0; h < 8; h++) {
                     const uint32_t r = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1), 13) + bw;
                     const uint32_t bb = __builtin_amdgcn_ubfe(x[h >> 1], 16 * (h & 1) + 13, 3);
 #ifdef ISX_TUNING       // ablations of the stream loop (tools/ablate_dense.py): what bounds it?
-                    if (dbg & 8) { ablate_acc += (r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy; continue; }     // decode, no LDS
+                    if (dbg & 8) { ablate_acc += (r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)S) + r : dummy; continue; }     // decode, no LDS
                     if (dbg & 16) { atomicAdd(&cnt[dummy], (r < (uint32_t)W && bb < 4) ? 1u : 0u); continue; }                         // lane-private word
-                    if (dbg & 32) { if (h == 0) atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u); continue; }   // 1 of 8 records
+                    if (dbg & 32) { if (h == 0) atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)S) + r : dummy], 1u); continue; }   // 1 of 8 records
 #endif
-                    atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u);
+                    atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)S) + r : dummy], 1u);
                 }
             } else if (FMT == 4) {
                 const uint32_t bw = gb[u] - w0;
@@ -455,14 +496,14 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
                     const uint32_t r = (x[h] & 0xFFFFu) + bw, bb = __builtin_amdgcn_ubfe(x[h], 24, 3);
-                    atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)W) + r : dummy], 1u);
+                    atomicAdd(&cnt[(r < (uint32_t)W && bb < 4) ? __umul24(bb, (uint32_t)S) + r : dummy], 1u);
                 }
             } else {
                 const uint32_t g0 = v[u].x, a0 = v[u].y, g1 = v[u].z, a1 = v[u].w;
                 const uint32_t r0 = g0 - w0, r1 = g1 - w0;
                 const uint32_t b0 = (a0 >> 16) & 0xFFu, b1 = (a1 >> 16) & 0xFFu;
-                if (r0 < (uint32_t)W && b0 < 4) atomicAdd(&cnt[b0 * W + r0], 1u);
-                if (r1 < (uint32_t)W && b1 < 4) atomicAdd(&cnt[b1 * W + r1], 1u);
+                if (r0 < (uint32_t)W && b0 < 4) atomicAdd(&cnt[b0 * S + r0], 1u);
+                if (r1 < (uint32_t)W && b1 < 4) atomicAdd(&cnt[b1 * S + r1], 1u);
             }
         };
         // Two half-rounds in flight: slots 0,1 (loaded during the previous half / the previous window's epilogue) are
@@ -488,7 +529,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
         for (int p = tid; p < ((dbg & 2) ? 0 : W); p += nthr, ep_it++) {
             const uint32_t gpos = w0 + p;
             if (gpos >= a.n_pos) break;
-            const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
+            const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
             const uint32_t total = c[0] + c[1] + c[2] + c[3];
             a.counts[gpos] = make_uint4(c[0], c[1], c[2], c[3]);
             if (a.cov16) {                      // shrunk hand-back of a pipe slot: coverage alone, 2 bytes per position
@@ -534,7 +575,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
             const uint32_t e = queue[q];
             if (!(e & (1u << 13))) continue;
             const int p = (int)(e & 0x1FFFu);
-            const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
+            const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
             a.clon[w0 + p] = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
         }
         if (nrows | nrare) __syncthreads();     // uniform: scratch bases from the atomics above
@@ -545,7 +586,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
                 const uint32_t e = queue[q];
                 if (!(e & (1u << 15))) continue;
                 const int p = (int)(e & 0x1FFFu);
-                const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
+                const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
                 const float v = rarefied_clonality(a, c, w0 + p, 0);
                 a.clon_r[w0 + p] = v;
                 if (list) a.rare[rare_base + atomicAdd(&scratch[S_RARE_RANK], 1u)] = make_uint2(w0 + p, __float_as_uint(v));
@@ -566,7 +607,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)
             const uint32_t my_row = atomicAdd(&scratch[S_ROW_RANK], 1u);
             const int p = (int)(e & 0x1FFFu);
             const uint32_t gpos = w0 + p;
-            const uint32_t c[4] = {cnt[p], cnt[W + p], cnt[2 * W + p], cnt[3 * W + p]};
+            const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
             const uint32_t total = c[0] + c[1] + c[2] + c[3];
             const int ref_base = a.ref[gpos];
             const SiteCall sc = call_level(a, nullptr, c, total, ref_base, true);
@@ -647,12 +688,14 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 
     u32x4 v[4];
     uint32_t gb[4] = {0, 0, 0, 0};
+    bool live[4] = {false, false, false, false};       // COMPACT: the wave really loaded slot u (see k_pileup_dense)
     uint32_t lo = 0, hi = 0;
     uint32_t my_entries = 0;                    // thread 0: entries of all windows of this workgroup
     // same load scheme as k_pileup_dense: wave-uniform bound, scalar base + lane offset, two half-rounds in flight
     auto issue_one = [&](int u, uint32_t i0) {
         const uint32_t j = i0 + tid + u * nthr;
         const uint32_t jw = __builtin_amdgcn_readfirstlane(j);
+        if (COMPACT) live[u] = jw < hi;
         if (COMPACT ? jw < hi : j < hi) {
             const uint64_t ub = reinterpret_cast<uint64_t>(rec4 + (i0 + (uint32_t)(u * nthr)));
             typedef __attribute__((address_space(1))) const u32x4 gvec;
@@ -691,6 +734,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         // ---- get_base_counts_mm over the window's slice of the stream ----
         uint32_t bad_mm = 0;
         auto count_slot = [&](int u) {
+            if (COMPACT && !live[u]) return;
             const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
             for (int h = 0; h < (COMPACT ? 4 : 2); h++) {
@@ -930,7 +974,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int *stage_off)
 {
     size_t words, cnt_words;
-    if (M == 1) { cnt_words = (size_t)4 * W; words = (size_t)5 * W + S_N + THR_LDS / 2; }
+    if (M == 1) { cnt_words = (size_t)4 * (W + ISX_DENSE_PAD); words = (size_t)5 * (W + ISX_DENSE_PAD) + S_N + THR_LDS / 2; }
     else {
         cnt_words = (size_t)M * (packed ? 2 : 4) * W;
         words = cnt_words + (size_t)((M + 31) / 32) * W + S_N + (size_t)qcap * 2 + (size_t)rqcap * 4 + THR_LDS / 2;
@@ -978,6 +1022,10 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
         }
     } else {
         const bool link = a.enable_linkage != 0;
+#ifndef ISX_NO_PK16
+        if (a.rec16 && a.W <= ISX_PK16_MAX_W) { if (link) launch_one(k_pileup_dense<true, 2, true>, a, l); else launch_one(k_pileup_dense<false, 2, true>, a, l); }
+        else
+#endif
         if (a.rec16) { if (link) launch_one(k_pileup_dense<true, 2>, a, l); else launch_one(k_pileup_dense<false, 2>, a, l); }
         else if (a.rec32) { if (link) launch_one(k_pileup_dense<true, 4>, a, l); else launch_one(k_pileup_dense<false, 4>, a, l); }
         else { if (link) launch_one(k_pileup_dense<true, 8>, a, l); else launch_one(k_pileup_dense<false, 8>, a, l); }

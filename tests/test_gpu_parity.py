@@ -59,6 +59,16 @@ def test_window_size_invariance(ctx, window):
     util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what="window%d" % window)
 
 
+@pytest.mark.parametrize("window", [3264, 3328, 4096])
+def test_short_record_decode_variants(ctx, window):
+    """one mm bin, 2-byte records: up to W = 3264 two records are decoded at a time with packed 16-bit ALU ops (byte
+    offsets of the counters must fit 16 bits), wider windows take the one-at-a-time decode; same tables either way"""
+    from tests import prod
+    g = util.load_case("synth_m1_ld")
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), window=window, **_params(g))
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what="window%d" % window)
+
+
 def test_stored_sars_golden_from_bam(ctx):
     """BAM -> C++ front end -> kernels -> tables == the reference's stored run (3 splits in one batch)."""
     from instrain_amd import engine
