@@ -688,14 +688,12 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 
     u32x4 v[4];
     uint32_t gb[4] = {0, 0, 0, 0};
-    bool live[4] = {false, false, false, false};       // COMPACT: the wave really loaded slot u (see k_pileup_dense)
     uint32_t lo = 0, hi = 0;
     uint32_t my_entries = 0;                    // thread 0: entries of all windows of this workgroup
     // same load scheme as k_pileup_dense: wave-uniform bound, scalar base + lane offset, two half-rounds in flight
     auto issue_one = [&](int u, uint32_t i0) {
         const uint32_t j = i0 + tid + u * nthr;
         const uint32_t jw = __builtin_amdgcn_readfirstlane(j);
-        if (COMPACT) live[u] = jw < hi;
         if (COMPACT ? jw < hi : j < hi) {
             const uint64_t ub = reinterpret_cast<uint64_t>(rec4 + (i0 + (uint32_t)(u * nthr)));
             typedef __attribute__((address_space(1))) const u32x4 gvec;
@@ -734,7 +732,6 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         // ---- get_base_counts_mm over the window's slice of the stream ----
         uint32_t bad_mm = 0;
         auto count_slot = [&](int u) {
-            if (COMPACT && !live[u]) return;
             const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
             for (int h = 0; h < (COMPACT ? 4 : 2); h++) {
