@@ -45,5 +45,5 @@ for link in (False, True, True):
         take()
     dt = time.perf_counter() - t0
     print("caller: submit %.1f ms" % sum(t_sub), [round(x, 1) for x in t_sub], "collect %.1f ms" % sum(t_col), [round(x, 1) for x in t_col], "release %.1f" % sum(t_rel), flush=True)
-    print("linkage", link, "wall %.1f ms" % (dt * 1e3), "encode", [round(s[0]["encode_ms"], 1) for s in stats], "collect_wait", [round(s[0]["collect_wait_ms"], 1) for s in stats], flush=True)
+    print("linkage", link, "wall %.1f ms" % (dt * 1e3), "encode", [round(s[0]["encode_ms"], 1) for s in stats], "collect_wait", [round(s[0]["collect_wait_ms"], 1) for s in stats], "passes", [s[0]["encode_passes"] for s in stats], flush=True)
     pipe.close()
