@@ -345,6 +345,17 @@ struct ObsStream {
 // chip (tools/tune_pileup.py), smaller for small batches so every CU still owns >= 2 windows; (mm) the
 // largest multiple of 64 whose counters fit half of the 160 KiB LDS (two resident workgroups per CU),
 // at most 2 positions per lane
+// mm kernel: two 512-lane workgroups per CU (78 KB of LDS each; their phases can overlap) while that leaves a window of at
+// least 1024 positions; with more mm bins one 1024-lane workgroup with the whole CU's LDS -- a window twice as wide halves the
+// over-scan and the per-window fixed costs (16 bins: W 384 -> 1024, 0.390 -> 0.343 ms on C2; 32 bins: 0.757 -> 0.622 ms)
+void batch_pick_block(isx_batch *b)
+{
+    if (b->M == 1) { b->block = 1024; return; }
+    b->block = 512;
+    if (b->prm.window > 0) { if (b->prm.window > 1024) b->block = 1024; return; }
+    if (batch_window_for(b, b->n_pos, true) < 1024) b->block = 1024;
+}
+
 int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed)
 {
     const isx_params *prm = &b->prm;
@@ -369,7 +380,8 @@ int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed)
         return best;
     }
     const int bytes_per_pos = b->M * (packed ? 8 : 16) + ((b->M + 31) / 32) * 4 + 5;
-    const int wmax = ((78 * 1024 - 8 * b->qcap - 8192 - 2048 - 256) / bytes_per_pos) / 64 * 64;
+    const int budget = (b->block >= 1024 ? 156 : 78) * 1024;       // one 1024-lane workgroup per CU, or two of 512
+    const int wmax = ((budget - 8 * b->qcap - 8192 - 2048 - 256) / bytes_per_pos) / 64 * 64;
     return std::min(std::max(wmax, 64), 2 * b->block);
 }
 
@@ -536,7 +548,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     b->ctx = c; b->prm = *prm; b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits;
     b->M = prm->n_mm_bins;
     const bool dense = b->M == 1;
-    b->block = dense ? 1024 : 512;       // mm kernel: > 64 VGPRs, two 512-lane workgroups per CU overlap their phases
+    batch_pick_block(b);
 #ifdef ISX_TUNING
     if (const char *e = getenv("ISX_BLOCK")) b->block = atoi(e);       // tuning builds only (make tuning)
 #endif

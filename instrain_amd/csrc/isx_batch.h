@@ -92,6 +92,7 @@ struct isx_batch {
 std::vector<uint16_t> build_thresholds(const std::vector<int32_t> &lut, int32_t fallback, double min_freq);
 
 // window size of a batch of n_pos positions (0 = params.window unset -> auto), see isx_batch_create
+void batch_pick_block(isx_batch *b);
 int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed);
 
 // window -> record range directory from the per-chunk position ranges (prefix-max / suffix-min); returns

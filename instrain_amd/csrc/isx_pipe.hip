@@ -185,7 +185,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true;
     b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
     const bool dense = b->M == 1;
-    b->block = dense ? 1024 : 512;
+    batch_pick_block(b);
     const int64_t cap_pos = p->pp.max_pos;
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
     for (auto &e : b->ev_sum) HIP_TRY(hipEventCreate(&e));
