@@ -620,6 +620,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                     cap = (max(need[0], 1 << 16), max(need[1], 1 << 16), max(need[2], 64))
                     pipe = engine.Pipe(ctx, max_pos=cap[0], max_obs=cap[1], max_splits=cap[2], depth=1,
                                        host_threads=int(kwargs.get('host_threads', 0)), pin_threads=False,
+                                       ring_kib=int(kwargs.get('staging_ring_kib', 0)),
                                        jump_slack=(0.1, 0.5, 2.0)[attempt],
                                        min_cov=int(kwargs.get('min_cov', 5)), min_freq=min_freq, min_snp=int(kwargs.get('min_snp', 10)),
                                        rarefied_coverage=int(kwargs.get('rarefied_coverage', 5)), n_mm_bins=n_mm,

@@ -55,6 +55,30 @@ def test_tables_equal_stored_golden(sars_profile):
         assert (np.isnan(a) == np.isnan(b)).all() and np.nanmax(np.abs(a - b)) <= 1e-6, c
 
 
+@pytest.mark.parametrize("skip_mm", [False, True])
+def test_profile_bam_through_the_staging_ring(sars_profile, skip_mm):
+    """the whole seam with the slot's records staged through a small pinned ring (what a pipe does by itself for batches of
+    hundreds of MB): same SplitObjects as with the whole stream pinned"""
+    import instrain_amd.profile as prof
+    from tests.test_oracle_golden import read_fasta
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    seq = read_fasta(os.path.join(util.GOLD, "sars_cov_2_MT039887.1.fasta"))
+    kw = dict(s2s={"MT039887.1": seq}, null_model=model, min_cov=5, min_freq=0.05, min_snp=20, min_read_ani=0.95,
+              skip_mm_profiling=skip_mm)
+    bam = os.path.join(util.GOLD, "sars_cov_2.sorted.bam")
+    a = sars_profile if not skip_mm else prof.profile_bam(bam, **kw)
+    b = prof.profile_bam(bam, staging_ring_kib=64, **kw)
+    assert sorted(a) == sorted(b)
+    for k in a:
+        A, B = a[k], b[k]
+        assert A.raw_snp_table.equals(B.raw_snp_table) and A.raw_linkage_table.equals(B.raw_linkage_table), k
+        assert sorted(A.covT) == sorted(B.covT)
+        for mm in A.covT:
+            assert A.covT[mm].equals(B.covT[mm]) and A.clonT[mm].equals(B.clonT[mm]), (k, mm)
+
+
 def test_covT_vs_snv_table_coverage(sars_profile):
     """the reference's test_profile_13 (test_profile.py:726-750): cumulative covT == position_coverage"""
     for S in sars_profile.values():
