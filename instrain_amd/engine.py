@@ -223,7 +223,7 @@ class Pipe:
         check(rc)
         return t.value
 
-    def collect(self, ticket, want_ld=True):
+    def collect(self, ticket, want_ld=True, rare_list=True):
         """-> dict like Batch.fetch() (+ 'sizes', 'stats'); the dense arrays / snv rows are views of pinned memory."""
         r = _lib.PipeResult()
         check(self.lib.isx_pipe_collect(self.h, int(ticket), C.byref(r)))
@@ -247,6 +247,8 @@ class Pipe:
                 out["clon_r"] = view(r.clon_rarefied, np.float32, n_pos)
             if r.rare:
                 out["rare"] = view(r.rare, _lib.RARE_DT, int(r.n_rare))
+            elif r.clon_rarefied and not rare_list:
+                pass                                # the caller cuts the dense array itself (profile_bam: per split, on demand)
             elif r.clon_rarefied:                   # the library handed the dense array instead of the list
                 k = np.flatnonzero(~np.isnan(out["clon_r"]))
                 out["rare"] = np.empty(len(k), dtype=_lib.RARE_DT)

@@ -89,13 +89,13 @@ class _BatchTables:
             else:
                 self.cov = res["counts"].sum(axis=1, dtype=np.int64)
             self.clon = _own(res["clon"])
+            self.clon_r = None
             if "rare" in res:
                 self.rare_pos = res["rare"]["gpos"].astype(np.int64)
                 self.rare_val = np.array(res["rare"]["clon_rarefied"])
-            else:
-                k = np.flatnonzero(~np.isnan(res["clon_r"]))
-                self.rare_pos, self.rare_val = k.astype(np.int64), np.array(res["clon_r"][k])
-            self.r_cut = np.searchsorted(self.rare_pos, self.bounds)
+                self.r_cut = np.searchsorted(self.rare_pos, self.bounds)
+            else:                                   # a deep sample: the dense array, cut per split when somebody asks
+                self.clon_r = _own(res["clon_r"])
         self.pileup_counts = _own(res["counts"]) if "counts" in res and self.entries is None else None
 
     # -- shrink_basewise (profile_utilities.py:337-350): dict mm -> sparse Series; a level that occurs in the split keeps
@@ -134,8 +134,13 @@ class _BatchTables:
         cl = self.clon[s:e]
         k = np.flatnonzero(~np.isnan(cl))
         clonT = {0: pd.Series(cl[k].astype("float32"), index=k + (s - off))}
-        r0, r1 = self.r_cut[i], self.r_cut[i + 1]
-        clonTR = {0: pd.Series(self.rare_val[r0:r1].astype("float32"), index=self.rare_pos[r0:r1] - off)}
+        if self.clon_r is not None:
+            cr = self.clon_r[s:e]
+            k = np.flatnonzero(~np.isnan(cr))
+            clonTR = {0: pd.Series(cr[k].astype("float32"), index=k + (s - off))}
+        else:
+            r0, r1 = self.r_cut[i], self.r_cut[i + 1]
+            clonTR = {0: pd.Series(self.rare_val[r0:r1].astype("float32"), index=self.rare_pos[r0:r1] - off)}
         return covT, clonT, clonTR
 
     def snp_table(self, i):
@@ -637,7 +642,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                     pipe.close()
                     pipe = None
             try:
-                res = pipe.collect(t)
+                res = pipe.collect(t, rare_list=False)
                 if res.get("n_saturated"):           # coverage beyond the 16-bit hand-back: take the exact counts
                     full = res["slot"].fetch()
                     res["counts"] = full["counts"]
