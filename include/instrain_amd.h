@@ -416,6 +416,11 @@ int isx_bam_ref(const isx_bam *bam, int32_t i, const char **name, int64_t *lengt
 /* names[offs[i] .. offs[i+1]) = i-th priority read (--priority_reads, filter_reads.py:428-469); used by the next isx_bam_filter */
 int isx_bam_set_priority_reads(isx_bam *bam, int64_t n, const char *names, const int64_t *offs);
 int isx_bam_scan(isx_bam *bam, isx_bam_info *info /* may be NULL */);
+/* Pass 1 over share `part` of `n_parts` of the file (one share per rank of a multi-GPU run): the handle owns the references
+ * whose first read lies in its share of the segments -- complete pair tables for those, every other reference looks empty
+ * (isx_bam_ref_counts).  paired_only only; the file-wide median insert is the caller's to combine: isx_bam_insert_sizes of
+ * every share (an all-gather) -> isx_bam_filter(median_insert).  isx_bam_scan == share 0 of 1. */
+int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info *info /* may be NULL */);
 /* insert sizes of the two-read pairs: out may be NULL to ask for *n only (a median across files / ranks) */
 int isx_bam_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n);
 int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert /* NaN = this file's own */, isx_bam_info *info);

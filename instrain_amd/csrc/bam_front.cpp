@@ -322,6 +322,7 @@ struct isx_bam {
     std::unique_ptr<isxenc::HostPool> pool;
     // ---- scan products ----
     bool scanned = false, filtered = false;
+    int32_t part = 0, n_parts = 1;                  // isx_bam_scan_part: which share of the file this handle scanned
     uint64_t n_reads = 0;
     std::vector<uint32_t> read_pair;                // per read ordinal
     std::vector<PairInfo, NoInitAlloc<PairInfo>> pairs;
@@ -778,11 +779,26 @@ int isx_bam_set_priority_reads(isx_bam *bam, int64_t n, const char *names, const
 }
 
 // ---- pass 1: get_paired_reads for every reference (filter_reads.py:885-956) ----
-int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
+int isx_bam_scan(isx_bam *bam, isx_bam_info *info) { return isx_bam_scan_part(bam, 0, 1, info); }
+
+// Pass 1 over ONE of n_parts shares of the file (ranks of a multi-GPU run: each scans its share, not the whole file).
+// The share is a range of segments of equal compressed size, [s0, s1); the handle OWNS the references whose first read lies in
+// it: their pair tables are complete (the scan runs on past s1 until the reference that straddles it has ended), every other
+// reference looks empty to this handle.  A share that does not start the file begins two segments early: the chain check
+// (a segment's first record must be where the previous segment's walk ended) then holds for its own first segment exactly
+// as in a whole-file scan, and the last read before s0 tells whether the reference at s0 began earlier (then it belongs to the
+// previous share).  What is global -- the median insert of the read filter -- is the caller's to combine
+// (isx_bam_insert_sizes of every share -> isx_bam_filter(median_insert)).
+int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info *info)
 {
-    if (!bam) { isx_set_error("isx_bam_scan: bad argument"); return ISX_ERR_ARG; }
+    if (!bam || n_parts < 1 || part < 0 || part >= n_parts) { isx_set_error("isx_bam_scan: bad argument"); return ISX_ERR_ARG; }
     isx_bam &B = *bam;
-    if (B.scanned) { if (info) *info = B.totals; return ISX_OK; }
+    if (B.scanned) {
+        if (B.part != part || B.n_parts != n_parts) { isx_set_error("isx_bam_scan: this handle already scanned another share of the file"); return ISX_ERR_STATE; }
+        if (info) *info = B.totals;
+        return ISX_OK;
+    }
+    B.part = part; B.n_parts = n_parts;
     isxenc::HostPool &pool = pool_of(B);
     const size_t n_ref = B.ref_name.size(), n_seg = B.segs.size();
     const bool timing = getenv("ISX_BAM_TIMING") != nullptr;       // tuning aid: stage times on stderr (no effect on results)
@@ -797,7 +813,12 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
     const size_t wave = (size_t)std::max(2, pool.size());
     uint64_t first = B.first_rec, read_ord = 0;
     std::vector<std::string> errs(n_seg);
-    for (size_t w0 = 0; w0 < n_seg; w0 += wave) {
+    const size_t s0 = n_seg * (size_t)part / (size_t)n_parts, s1 = n_seg * ((size_t)part + 1) / (size_t)n_parts;
+    size_t sv = s0 >= 2 ? s0 - 2 : 0;           // where the walk starts (verification run-in)
+    bool have_first = sv == 0;                  // the file's first record is known; any other start is a guess until the chain confirms it
+    size_t s_end = n_seg;                       // one past the last segment scanned
+    if (s0 == s1) { sv = 0; s_end = 0; }        // more shares than segments: this one is empty
+    for (size_t w0 = sv; w0 < s_end; w0 += wave) {
         const size_t w1 = std::min(n_seg, w0 + wave);
         std::vector<SegBuf> bufs(w1 - w0);
         std::vector<std::vector<uint64_t>> recs(w1 - w0);
@@ -825,6 +846,11 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
         for (size_t si = w0; si < w1; si++) {
             Segment &s = B.segs[si];
             const size_t k = si - w0;
+            if (!have_first) {                  // a share's run-in: start from the structural guess
+                if (guess[k] == ~0ull) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; recs[k].clear(); continue; }
+                first = guess[k];
+                have_first = true;
+            }
             if (first > s.ioff1) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; recs[k].clear(); continue; }    // a record spans the whole segment
             s.first_rec = std::max(first, s.ioff0);
             uint64_t next = first;
@@ -848,9 +874,28 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
         if (keep_inflated)
             for (size_t si = w0; si < w1; si++) { B.seg_cache[si].swap(bufs[si - w0].data); B.seg_cache_rec[si].swap(recs[si - w0]); }
         { const double t = now(); t_extract += t - t_mark; t_mark = t; }
+        if (n_parts > 1 && w1 >= s1 && w1 < n_seg) {
+            // past the share: stop once the reference that straddles s1 has ended (a read of another reference, or an
+            // unmapped one, was seen at or after s1)
+            int32_t t_end = -2;
+            for (size_t si = s1; si-- > sv;) if (!B.seg_reads[si].empty()) { t_end = B.seg_reads[si].back().tid; break; }
+            bool ended = t_end < 0;
+            for (size_t si = s1; si < w1 && !ended; si++)
+                if (!B.seg_reads[si].empty() && B.seg_reads[si].back().tid != t_end) ended = true;
+            if (ended) { s_end = w1; break; }
+        }
     }
-    if (first != B.total_inflated) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
+    if (s_end == n_seg && s0 != s1 && first != B.total_inflated) { isx_set_error("truncated BAM record"); return ISX_ERR_IO; }
     B.n_reads = read_ord;
+    // which references this share owns: those whose first read lies in [s0, s1)
+    std::vector<uint8_t> owned(n_ref, n_parts == 1 ? 1 : 0);
+    if (n_parts > 1 && s0 != s1) {
+        int32_t t_prev = -2;                    // reference of the last read before s0: its run began in an earlier share
+        for (size_t si = s0; si-- > sv;) if (!B.seg_reads[si].empty()) { t_prev = B.seg_reads[si].back().tid; break; }
+        if (s0 > 0 && t_prev == -2) { isx_set_error("isx_bam_scan_part: no record starts in the two segments before this share (a record longer than a segment): scan the whole file instead"); return ISX_ERR_ARG; }
+        for (size_t si = s0; si < s1; si++)
+            for (const ReadLite &L : B.seg_reads[si]) if (L.tid >= 0 && L.tid != t_prev) owned[(size_t)L.tid] = 1;
+    }
     for (size_t si = 0; si < n_seg; si++) {
         const auto &rs = B.seg_reads[si];
         if (rs.empty()) continue;
@@ -875,7 +920,7 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
                 const int32_t t = rs[i].tid;
                 size_t j = i;
                 while (j < rs.size() && rs[j].tid == t) j++;
-                if (t >= 0) {
+                if (t >= 0 && owned[(size_t)t]) {
                     if (t != last_tid && closed[(size_t)t]) unsorted = true;
                     runs[(size_t)t].push_back(Run{si, (uint32_t)i, (uint32_t)j});
                     B.ref_seg0[(size_t)t] = std::min(B.ref_seg0[(size_t)t], si);
@@ -1011,12 +1056,13 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info)
         }
         std::vector<PairInfo>().swap(pt.info);
     });
-    if (timing) fprintf(stderr, "[isx_bam_scan] %zu segments, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms\n",
-                        n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark);
+    if (timing) fprintf(stderr, "[isx_bam_scan] share %d/%d: segments [%zu, %zu) of %zu, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms\n",
+                        part, n_parts, sv, s_end, n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark);
     for (auto &v : B.seg_reads) std::vector<ReadLite>().swap(v);     // names stay until the filter has run (set_r2m / priority reads / cross-scaffold filters)
     B.totals = isx_bam_info{};
     B.totals.n_refs = (int32_t)n_ref;
     B.totals.n_reads = (int64_t)B.n_reads;
+    if (n_parts > 1) { B.totals.n_reads = 0; for (int64_t r : B.ref_reads) B.totals.n_reads += r; }     // the share's own references
     for (int64_t l : B.ref_len) B.totals.n_pos += l;
     B.scanned = true;
     if (info) *info = B.totals;
@@ -1039,6 +1085,8 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
     if (!bam || !p) { isx_set_error("isx_bam_filter: bad argument"); return ISX_ERR_ARG; }
     if (!bam->scanned) { isx_set_error("isx_bam_filter: scan first"); return ISX_ERR_STATE; }
     if (p->pairing_filter < 0 || p->pairing_filter > 2) { isx_set_error("pairing_filter must be 0 (paired_only), 1 (non_discordant) or 2 (all_reads)"); return ISX_ERR_ARG; }
+    if (bam->n_parts > 1 && p->pairing_filter != 0) { isx_set_error("isx_bam_filter: non_discordant / all_reads look read names up across all scaffolds: scan the whole file (isx_bam_scan), not a share of it"); return ISX_ERR_STATE; }
+    if (bam->n_parts > 1 && std::isnan(median_insert)) { isx_set_error("isx_bam_filter: a share of the file cannot know the file's median insert: combine isx_bam_insert_sizes of all shares and pass it"); return ISX_ERR_STATE; }
     isx_bam &B = *bam;
     const size_t n_ref = B.ref_name.size();
     auto name_of = [&](const PairInfo &e) { return std::string_view(B.seg_names[e.name_seg].data() + e.name_off, e.name_len); };

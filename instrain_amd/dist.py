@@ -88,6 +88,31 @@ def gather_tables(tables, dst=0, device=None):
     return out
 
 
+def all_gather_concat(arr, device=None):
+    """Every rank gets the concatenation (rank order) of every rank's 1-d array: an all_gather of the lengths, then one
+    all_gather of the arrays padded to the longest.  The exchange step of the sharded scan: the read filter's median insert
+    is a property of the whole file (filter_reads.py:216-219), each rank has only its share's insert sizes."""
+    import torch
+    import torch.distributed as dist
+    arr = np.ascontiguousarray(arr)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return arr
+    world = dist.get_world_size()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    n = torch.tensor([len(arr)], dtype=torch.int64, device=device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n)
+    ns = [int(x.item()) for x in ns]
+    m = max(max(ns), 1)
+    raw = np.zeros(m * arr.dtype.itemsize, dtype=np.uint8)
+    raw[:arr.nbytes] = np.frombuffer(arr.tobytes(), dtype=np.uint8)
+    mine = torch.from_numpy(raw).to(device)
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine)
+    return np.concatenate([np.frombuffer(b.cpu().numpy().tobytes()[:k * arr.dtype.itemsize], dtype=arr.dtype) for b, k in zip(bufs, ns)])
+
+
 def pack_batches(n_pos, n_obs, max_pos, max_obs):
     """Cut a rank's scaffolds / genomes (in the given order) into batches for one pipe: consecutive items are
     taken while the flat positions stay <= max_pos and the (estimated) observations <= max_obs.  The reference
@@ -116,33 +141,54 @@ def shard_scaffolds(filtered_pairs, lengths, world):
 
 
 def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=None, **kwargs):
-    """Scaffolds of ONE sorted BAM sharded over `world` ranks: every rank scans the file (so the read filter's
-    whole-file median insert is the same everywhere without a collective), takes the scaffolds LPT gives it, profiles
-    them through profile_bam, and the SNV / linkage / per-scaffold summary tables are gathered on rank 0
-    (gather_tables).  Returns (splits of this rank, gathered tables on rank 0 | None)."""
+    """Scaffolds of ONE sorted BAM over `world` ranks.
+    paired_only (the default): every rank scans only its SHARE of the file (isx_bam_scan_part) and owns the scaffolds whose
+    reads start there -- shares are equal in compressed bytes, i.e. in reads, which is the reference's own cost measure
+    (profile_controller.py:460-465); the one thing that is global, the read filter's median insert, comes from an
+    all_gather of the shares' insert sizes (all_gather_concat).  Other pairing filters look read names up across all
+    scaffolds: there every rank scans the whole file and the scaffolds are dealt by LPT (shard_scaffolds).
+    Each rank profiles its scaffolds through profile_bam; SNV / linkage / per-scaffold summary tables are gathered on rank 0
+    (gather_tables).  Returns (splits of this rank, gathered tables on rank 0 | None, this rank's load)."""
     import pandas as pd
     from . import engine
     from ._lib import LD_DT, SCAFFOLD_LEVEL_DT, SNV_DT
     from .profile import profile_utilities as pu
+    fkw = dict(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
+               max_insert_relative=kwargs.get('max_insert_relative', 3), min_insert=kwargs.get('min_insert', 50),
+               pairing_filter=kwargs.get('pairing_filter', 'paired_only'))
+    sharded_scan = world > 1 and fkw['pairing_filter'] == 'paired_only' and kwargs.get('scan', 'sharded') == 'sharded'
     bf = engine.BamFile(bam, threads=int(kwargs.get('host_threads', 0)))
     try:
         refs = bf.refs()
-        bf.scan()
-        bf.filter(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
-                  max_insert_relative=kwargs.get('max_insert_relative', 3), min_insert=kwargs.get('min_insert', 50),
-                  pairing_filter=kwargs.get('pairing_filter', 'paired_only'))
+        usable = [i for i, (n, ln, _) in enumerate(refs) if n in s2s and len(s2s[n]) == ln]
+        extra = {}
+        if sharded_scan:
+            part = (rank, world)
+            bf.scan(part=part)
+            ins = all_gather_concat(bf.insert_sizes(), device)
+            median = float(np.median(ins)) if len(ins) else 0.0
+            reads, _ = bf.ref_counts()
+            # a scaffold without reads starts in nobody's share: deal those round robin (they still get their empty profile)
+            owned = all_gather_concat((reads > 0).astype(np.uint8), device).reshape(world, -1).sum(axis=0)
+            mine = [t for t in usable if reads[t] > 0 or (owned[t] == 0 and t % world == rank)]
+            extra = dict(scan_part=part, median_insert=median)
+        else:
+            bf.scan()
+            bf.filter(**fkw)
+            _, pairs = bf.ref_counts()
+            shards = shard_scaffolds([pairs[i] for i in usable], [refs[i][1] for i in usable], world)
+            mine = [usable[j] for j in shards[rank]]
+        W = int(kwargs.get('window_length', 10000))
+        rows = [(refs[t][0], i, s, e) for t in mine for i, (s, e) in enumerate(pu.iterate_splits(refs[t][1], W))]
+        fdb = pd.DataFrame(rows, columns=["scaffold", "split_number", "start", "end"])
+        tabs = {}
+        kw = {k: v for k, v in kwargs.items() if k != 'scan'}
+        splits = pu.profile_bam(bam, fdb, None, None, s2s=s2s, null_model=null_model, scaffold_tables=tabs, bamfile=bf,
+                                **extra, **kw) if len(rows) else {}
         _, pairs = bf.ref_counts()
+        load = float(sum(pairs[t] for t in mine))
     finally:
         bf.close()
-    usable = [i for i, (n, ln, _) in enumerate(refs) if n in s2s and len(s2s[n]) == ln]
-    shards = shard_scaffolds([pairs[i] for i in usable], [refs[i][1] for i in usable], world)
-    mine = [usable[j] for j in shards[rank]]
-    W = int(kwargs.get('window_length', 10000))
-    rows = [(refs[t][0], i, s, e) for t in mine for i, (s, e) in enumerate(pu.iterate_splits(refs[t][1], W))]
-    fdb = pd.DataFrame(rows, columns=["scaffold", "split_number", "start", "end"])
-    tabs = {}
-    splits = pu.profile_bam(bam, fdb, None, None, s2s=s2s, null_model=null_model, scaffold_tables=tabs, **kwargs) if len(rows) else {}
-    load = float(sum(pairs[t] for t in mine))
     if not gather:
         return splits, None, load
     # packed tables with the scaffold's index in the BAM header as the key

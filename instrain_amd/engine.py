@@ -360,10 +360,14 @@ class BamFile:
         self.info = {n: getattr(info, n) for n, _ in BamInfo._fields_ if n != "pad"}
         return self.info
 
-    def scan(self):
-        """pass 1: pair tables of every reference (get_paired_reads)"""
+    def scan(self, part=None):
+        """pass 1: pair tables of every reference (get_paired_reads); part = (i, n): only share i of n of the file -- the
+        handle then owns the references whose first read lies in that share (ref_counts() is zero for the others)"""
         info = BamInfo()
-        check(self.lib.isx_bam_scan(self.h, C.byref(info)))
+        if part is None:
+            check(self.lib.isx_bam_scan(self.h, C.byref(info)))
+        else:
+            check(self.lib.isx_bam_scan_part(self.h, int(part[0]), int(part[1]), C.byref(info)))
         return self._info(info)
 
     def insert_sizes(self):

@@ -543,12 +543,13 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                 logs.append(line)
 
     own_ctx = kwargs.get('ctx') is None
+    own_bf = kwargs.get('bamfile') is None           # a caller's handle may already hold the scan (dist.profile_bam_sharded)
     ctx = bf = pipe = None
     try:
         ctx = kwargs.get('ctx') or engine.Context(int(kwargs.get('device', 0)))
         lut, fb = null_model_lut(null_model)
         ctx.set_null_model(lut, fb)
-        bf = engine.BamFile(bam, threads=int(kwargs.get('host_threads', 0)))
+        bf = kwargs.get('bamfile') or engine.BamFile(bam, threads=int(kwargs.get('host_threads', 0)))
         refs = bf.refs()
         tid_of = {n: i for i, (n, _, _) in enumerate(refs)}
         wanted = list(dict.fromkeys(fasta_db['scaffold'])) if fasta_db is not None else [n for n, _, _ in refs if n in s2s]
@@ -569,7 +570,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         if not plan:
             return out
         # ---- read pairs: the controller's R2M, or the built-in filter ----
-        bf.scan()
+        bf.scan(part=kwargs.get('scan_part'))
         fkw = dict(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
                    max_insert_relative=kwargs.get('max_insert_relative', 3), min_insert=kwargs.get('min_insert', 50),
                    pairing_filter=kwargs.get('pairing_filter', 'paired_only'))
@@ -577,7 +578,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         if sR2M is None:
             if kwargs.get('priority_reads'):
                 bf.set_priority_reads(kwargs['priority_reads'])
-            bf.filter(**fkw)
+            bf.filter(median_insert=kwargs.get('median_insert'), **fkw)
         else:
             for tid, name, _ in plan:
                 r2m = sR2M.get(name, {})
@@ -585,7 +586,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                     bf.set_r2m(tid, list(r2m), None)
                 else:
                     bf.set_r2m(tid, list(r2m.keys()), [0 if skip_mm else int(v) for v in r2m.values()])
-            bf.scan()                                # refresh the totals (max_mm now comes from the controller's values)
+            bf.scan(part=kwargs.get('scan_part'))    # refresh the totals (max_mm now comes from the controller's values)
         info = dict(bf.info) if bf.info else {}
         n_mm = 1 if skip_mm else int(bf.info["max_mm"]) + 1
         if 's2p' in kwargs and isinstance(kwargs['s2p'], dict):
@@ -688,7 +689,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
     finally:
         if pipe is not None:
             pipe.close()
-        if bf is not None:
+        if bf is not None and own_bf:
             bf.close()
         if own_ctx and ctx is not None:
             ctx.close()

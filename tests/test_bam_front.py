@@ -354,3 +354,62 @@ def test_pair_tables_over_several_name_partitions(tmp_path):
         assert info["filtered_pairs"] == sum(t["filtered_pairs"] for t in tallies.values()) > 5000
         assert bam.r2m(1) == r2m["big"] and bam.r2m(0) == r2m["small"]
         bam.close()
+
+
+@pytest.mark.parametrize("n_parts", [2, 3, 7])
+def test_scan_in_shares_equals_the_whole_file_scan(tmp_path, n_parts):
+    """isx_bam_scan_part: every share owns the references whose first read lies in its segments; over all shares
+    every reference with reads is owned exactly once, its pair table / R2M / expansion are those of the whole-file scan,
+    and the insert sizes of all shares together give the whole file's median (the one collective of a multi-rank run)"""
+    from tests import bamwriter
+    refs = [("s%d" % i, ln) for i, ln in enumerate([4000, 900, 12500, 700, 2600, 5100, 300, 8000])]
+    path = str(tmp_path / "shares.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(61, refs[:7], 9000))
+    whole = engine.BamFile(path, threads=3)
+    whole.scan()
+    w_ins = np.sort(whole.insert_sizes())
+    w_info = whole.filter(min_read_ani=0.9)
+    w_reads, w_pairs = whole.ref_counts()
+    o, p, b, s = whole.expand(min_read_ani=0.9)
+    offs = np.r_[0, np.cumsum([r[1] for r in refs])]
+    owners = np.zeros(len(refs), int)
+    all_ins = []
+    shares = []
+    for part in range(n_parts):
+        bam = engine.BamFile(path, threads=2)
+        bam.scan(part=(part, n_parts))
+        all_ins.append(bam.insert_sizes())
+        shares.append(bam)
+    all_ins = np.sort(np.concatenate(all_ins))
+    assert len(all_ins) == len(w_ins) and (all_ins == w_ins).all()
+    median = float(np.median(all_ins))
+    assert median == w_info["median_insert"]
+    n_pairs = 0
+    for part, bam in enumerate(shares):
+        with pytest.raises(engine.IsxError):
+            bam.filter(min_read_ani=0.9)                        # a share cannot know the file's median insert
+        with pytest.raises(engine.IsxError):
+            bam.filter(median_insert=median, min_read_ani=0.9, pairing_filter="all_reads")
+        info = bam.filter(median_insert=median, min_read_ani=0.9)
+        reads, pairs = bam.ref_counts()
+        mine = np.flatnonzero(reads)
+        owners[mine] += 1
+        assert (reads[mine] == w_reads[mine]).all() and (pairs[mine] == w_pairs[mine]).all(), part
+        n_pairs += int(pairs.sum())
+        for t in mine:
+            assert bam.r2m(int(t)) == whole.r2m(int(t)), (part, t)
+        if len(mine):
+            oo, pp, bb, ss = bam.expand_refs([int(t) for t in mine], min_read_ani=0.9)
+            exp, at = [], 0
+            for t in mine:
+                k = (o["gpos"] >= offs[t]) & (o["gpos"] < offs[t + 1])
+                e = o[k].copy()
+                e["gpos"] = e["gpos"] - offs[t] + at
+                exp.append(e)
+                at += refs[t][1]
+            exp = np.concatenate(exp)
+            assert len(oo) == len(exp) and (oo == exp).all(), part
+        bam.close()
+    assert (owners[w_reads > 0] == 1).all() and (owners[w_reads == 0] == 0).all(), owners
+    assert n_pairs == int(w_pairs.sum())
+    whole.close()

@@ -108,3 +108,67 @@ def test_one_bam_sharded_over_two_ranks(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "SHARD_OK" in r.stdout
+
+
+SCAN_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    from instrain_amd import dist as idist, engine
+    rank, local, world = idist.init_from_env(backend="gloo")
+    path = sys.argv[1]
+    bam = engine.BamFile(path, threads=2)
+    refs = bam.refs()
+    bam.scan(part=(rank, world))                       # this rank's share of the file only
+    ins = idist.all_gather_concat(bam.insert_sizes())  # the exchange: the filter's median insert is a whole-file property
+    median = float(np.median(ins))
+    info = bam.filter(median_insert=median, min_read_ani=0.9)
+    reads, pairs = bam.ref_counts()
+    mine = [int(t) for t in np.flatnonzero(reads)]
+    owned = idist.all_gather_concat((reads > 0).astype(np.uint8)).reshape(world, -1)
+    obs, pair, bounds, sref = bam.expand_refs(mine, min_read_ani=0.9) if mine else (np.zeros(0, engine.OBS_DT), None, None, None)
+    offs = np.r_[0, np.cumsum([refs[t][1] for t in mine])]
+    which = np.searchsorted(offs, obs["gpos"], side="right") - 1
+    dt = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("base", "u1"), ("mm", "<u2")])
+    t = np.zeros(len(obs), dtype=dt)
+    if len(obs):
+        t["tid"] = np.array(mine, dtype=np.int32)[which]
+        t["pos"] = obs["gpos"] - offs[which]; t["base"] = obs["base"]; t["mm"] = obs["mm"]
+    out = idist.gather_tables({"obs": t}, dst=0)
+    if rank == 0:
+        whole = engine.BamFile(path, threads=2)
+        o, p, b, s = whole.expand(min_read_ani=0.9)
+        assert whole.info["median_insert"] == median and len(ins) > 1000
+        w_reads, _ = whole.ref_counts()
+        assert ((owned.sum(axis=0) == 1) == (w_reads > 0)).all() and owned.sum(axis=0).max() == 1
+        assert owned.sum(axis=1).min() >= 1            # every rank got something to do
+        woffs = np.r_[0, np.cumsum([r[1] for r in refs])]
+        ww = np.searchsorted(woffs, o["gpos"], side="right") - 1
+        exp = np.zeros(len(o), dtype=dt)
+        exp["tid"] = ww; exp["pos"] = o["gpos"] - woffs[ww]; exp["base"] = o["base"]; exp["mm"] = o["mm"]
+        got = np.sort(out["obs"], order=["tid", "pos", "base", "mm"])
+        exp = np.sort(exp, order=["tid", "pos", "base", "mm"])
+        assert len(got) == len(exp) and (got == exp).all()
+        print("SCAN_OK", owned.sum(axis=1).tolist(), len(got))
+    dist.barrier()
+    dist.destroy_process_group()
+""") % REPO
+
+
+def test_sharded_scan_two_ranks(tmp_path):
+    """each rank scans HALF of the BAM (isx_bam_scan_part), the insert sizes are all-gathered for the whole-file median,
+    each rank filters and expands the scaffolds it owns; the union equals the single-process result"""
+    sys.path.insert(0, REPO)
+    from tests import bamwriter
+    refs = [("s%d" % i, 6000 + 500 * i) for i in range(12)]
+    path = str(tmp_path / "scan.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(43, refs[:11], 9000))
+    script = tmp_path / "scan_worker.py"
+    script.write_text(SCAN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29535", str(script), path],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "SCAN_OK" in r.stdout
