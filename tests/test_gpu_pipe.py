@@ -124,8 +124,8 @@ def test_stream_mm_profiling_with_linkage(ctx):
     pipe.close()
 
 
-@pytest.mark.parametrize("skip_mm", [True, False])
-def test_staging_ring(ctx, skip_mm):
+@pytest.mark.parametrize("skip_mm,ring_kib", [(True, 64), (False, 64), (False, 4096)])
+def test_staging_ring(ctx, skip_mm, ring_kib):
     """records staged through a small pinned ring (the mode a pipe picks by itself beyond 512 MiB of records): waves of
     half a ring leave for the device while the next is encoded; tables identical to the one-shot path, slots reused,
     and a batch with more pair-id runs than the slot was created for"""
@@ -141,7 +141,7 @@ def test_staging_ring(ctx, skip_mm):
     exp = [one_shot(ctx, w, **kw) for w in ws]
     pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws),
                        max_splits=max(len(w["split_bounds"]) for w in ws), depth=2, host_threads=3, n_mm_bins=M,
-                       ring_kib=64, **kw)
+                       ring_kib=ring_kib, **kw)          # 4096: the entry table also comes back through the ring's halves
     for rnd in range(2):
         ts = [pipe.submit(ws[i]["ref_codes"], ws[i]["split_bounds"], ws[i]["obs"], ws[i]["pair"]) for i in (2 * rnd, 2 * rnd + 1)]
         for t, i in zip(ts, (2 * rnd, 2 * rnd + 1)):
