@@ -818,8 +818,10 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     bool have_first = sv == 0;                  // the file's first record is known; any other start is a guess until the chain confirms it
     size_t s_end = n_seg;                       // one past the last segment scanned
     if (s0 == s1) { sv = 0; s_end = 0; }        // more shares than segments: this one is empty
-    for (size_t w0 = sv; w0 < s_end; w0 += wave) {
-        const size_t w1 = std::min(n_seg, w0 + wave);
+    for (size_t w0 = sv, w1 = 0; w0 < s_end; w0 = w1) {
+        // full waves while they start inside the share; past its end a quarter wave at a time (the scaffold that straddles
+        // s1 usually ends within a segment or two)
+        w1 = std::min(n_seg, w0 + ((n_parts > 1 && w0 >= s1) ? std::max<size_t>(1, wave / 4) : wave));
         std::vector<SegBuf> bufs(w1 - w0);
         std::vector<std::vector<uint64_t>> recs(w1 - w0);
         std::atomic<int> bad{0};

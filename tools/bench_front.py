@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def write_simple_bam(path, G, n_pairs, read_len=150, seed=1):
+def write_simple_bam(path, G, n_pairs, read_len=150, seed=1, n_refs=1):
     rng = np.random.Generator(np.random.PCG64(seed))
     ref = rng.integers(0, 4, G, dtype=np.uint8)
     ins = np.maximum(rng.normal(350, 30, n_pairs), 2 * read_len).astype(np.int64)
@@ -17,13 +17,21 @@ def write_simple_bam(path, G, n_pairs, read_len=150, seed=1):
     first = np.concatenate([np.ones(n_pairs, bool), np.zeros(n_pairs, bool)])
     o = np.argsort(starts, kind="stable")
     code4 = np.array([1, 2, 8, 4], dtype=np.uint8)          # A C T G in the ACTG order of `ref` -> BAM nibbles
-    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:scaf\tLN:%d\n" % G
-    out = [b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1) +
-           struct.pack("<i", 5) + b"scaf\0" + struct.pack("<i", G)]
+    L = G // n_refs                  # n_refs > 1: the genome cut into scaffolds scaf0, scaf1, ... (pairs across a cut are dropped)
+    names = ["scaf"] if n_refs == 1 else ["scaf%d" % i for i in range(n_refs)]
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, L if n_refs > 1 else G) for n in names)
+    out = [b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(names)) +
+           b"".join(struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", L if n_refs > 1 else G) for n in names)]
     qual = bytes([37]) * read_len
     cig = struct.pack("<I", (read_len << 4) | 0)
     for k in o:
         st = int(starts[k])
+        tid, mt = 0, int(mate[k])
+        if n_refs > 1:
+            tid = st // L
+            if tid >= n_refs or (st + read_len - 1) // L != tid or mt // L != tid or (mt + read_len - 1) // L != tid:
+                continue
+            mt -= tid * L
         b = ref[st:st + read_len].copy()
         e = rng.random(read_len) < 0.002
         b[e] = rng.integers(0, 4, int(e.sum()))
@@ -32,7 +40,7 @@ def write_simple_bam(path, G, n_pairs, read_len=150, seed=1):
         packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8).tobytes()
         name = b"p%d\0" % pid[k]
         flag = 0x1 | 0x2 | (0x40 if first[k] else 0x80) | (0x20 if first[k] else 0x10)
-        body = struct.pack("<iiBBHHHiiii", 0, st, len(name), 42, 4680, 1, flag, read_len, 0, int(mate[k]), int(isz[k])) + \
+        body = struct.pack("<iiBBHHHiiii", tid, st - tid * L if n_refs > 1 else st, len(name), 42, 4680, 1, flag, read_len, tid, mt, int(isz[k])) + \
             name + cig + packed + qual + b"NMC" + struct.pack("<B", nm)
         out.append(struct.pack("<i", len(body)) + body)
     blob = b"".join(out)
