@@ -413,3 +413,29 @@ def test_scan_in_shares_equals_the_whole_file_scan(tmp_path, n_parts):
     assert (owners[w_reads > 0] == 1).all() and (owners[w_reads == 0] == 0).all(), owners
     assert n_pairs == int(w_pairs.sum())
     whole.close()
+
+
+def test_share_scan_argument_and_state_errors(tmp_path):
+    from tests import bamwriter
+    refs = [("a", 3000), ("b", 2000)]
+    path = str(tmp_path / "e.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(3, refs, 400))
+    bam = engine.BamFile(path, threads=2)
+    for part in ((2, 2), (-1, 2), (0, 0)):
+        with pytest.raises(engine.IsxError):
+            bam.scan(part=part)
+    bam.scan(part=(0, 2))
+    bam.scan(part=(0, 2))                                # the same share again: a no-op
+    with pytest.raises(engine.IsxError):
+        bam.scan(part=(1, 2))                            # one handle, one share
+    with pytest.raises(engine.IsxError):
+        bam.scan()                                       # ... and not the whole file either
+    bam.close()
+    # more shares than the file has segments: the surplus shares own nothing, the others everything once
+    owned = np.zeros(2, int)
+    for part in range(40):
+        b = engine.BamFile(path, threads=1)
+        b.scan(part=(part, 40))
+        owned += (b.ref_counts()[0] > 0)
+        b.close()
+    assert (owned == 1).all()
