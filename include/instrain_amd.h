@@ -231,6 +231,23 @@ typedef struct {
 int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, isx_scaffold_level *out,
                         float *device_ms);
 
+/* ---- genome-level coverage roll-up (genomeUtilities.py:297-365 genomeLevel_coverage_info on
+ * generate_genome_coverage_array :932-981; iRep is not part of this) ----
+ * A genome = consecutive scaffolds of the batch.  One row per (genome, mm level): the coverage, cumulative over levels
+ * <= mm, of all its scaffolds laid end to end with mask_edges positions cut from both ends of every scaffold (a scaffold
+ * shorter than twice that drops out): how many positions are left, the exact sums over them and the median.
+ * coverage_median = int(median_cov); coverage_std = sqrt(sumsq / n - (sum / n)^2); coverage_SEM = sample std / sqrt(n). */
+typedef struct {
+    int64_t n;                      /* positions after masking (0: the reference then uses the single value 0) */
+    uint64_t sum_cov, sumsq_cov;
+    double median_cov;
+    int32_t mm, pad;
+} isx_genome_level;
+
+/* out[n_genomes][n_mm_bins]; genome_first_scaffold[n_genomes + 1] ascending scaffold indices, [0] = 0, [n_genomes] = n_scaffolds */
+int isx_batch_summarize_genomes(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, int32_t n_genomes,
+                                const int32_t *genome_first_scaffold, int32_t mask_edges, isx_genome_level *out, float *device_ms);
+
 /* ---- compare: two samples on the same scaffolds (readComparer.py:35-143 compare_scaffold, one pair) ----
  * Two batches over the SAME flat space (same scaffolds laid out identically, same ctx).  One row per
  * (scaffold, mm): positions where both / either sample reach min_cov in the coverage cumulated over

@@ -90,6 +90,8 @@ SCAFFOLD_LEVEL_DT = np.dtype([("nonzero", "<i8"), ("sum_cov", "<u8"), ("sumsq_co
                               ("counted_rarefied", "<i8"), ("sum_clon_rarefied", "<f8"),
                               ("median_clon_rarefied", "<f8"), ("mm", "<i4"), ("present", "<i4")])
 assert SCAFFOLD_LEVEL_DT.itemsize == 88
+GENOME_LEVEL_DT = np.dtype([("n", "<i8"), ("sum_cov", "<u8"), ("sumsq_cov", "<u8"), ("median_cov", "<f8"), ("mm", "<i4"), ("pad", "<i4")])
+assert GENOME_LEVEL_DT.itemsize == 40
 
 
 COMPARE_LEVEL_DT = np.dtype([("both", "<i8"), ("either", "<i8"), ("mm", "<i4"), ("present_a", "<i4"),
@@ -110,7 +112,7 @@ class IsxError(RuntimeError):
 SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destroy", "isx_set_null_model",
            "isx_batch_create", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
-           "isx_batch_summarize", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
+           "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
            "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_bam", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_encode_obs", "isx_encode_obs_ring",
            "isx_bam_open", "isx_bam_close", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
            "isx_bam_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_ref_counts",
@@ -147,6 +149,7 @@ def load():
         getattr(lib, f).argtypes = [vp, vp]
     lib.isx_batch_fetch_dense.argtypes = [vp, vp, vp, vp]
     lib.isx_batch_summarize.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_float)]
+    lib.isx_batch_summarize_genomes.argtypes = [vp, i32, vp, i32, vp, i32, vp, C.POINTER(C.c_float)]
     lib.isx_compare_coverage.argtypes = [vp, vp, i32, vp, i32, vp, C.POINTER(C.c_float)]
     lib.isx_compare_scaffolds.argtypes = [vp, vp, i32, vp, i32, C.c_double, vp, C.POINTER(i64), C.POINTER(C.c_float)]
     lib.isx_compare_fetch_snps.argtypes = [vp, vp]

@@ -924,6 +924,31 @@ int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffo
     return run_summary(in, b->S, out, device_ms);
 }
 
+int isx_batch_summarize_genomes(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, int32_t n_genomes,
+                                const int32_t *genome_first_scaffold, int32_t mask_edges, isx_genome_level *out, float *device_ms)
+{
+    NEED_RUN(b, out);
+    if (n_scaffolds <= 0 || !scaffold_bounds || scaffold_bounds[0] != 0 || scaffold_bounds[n_scaffolds] != b->n_pos) {
+        isx_set_error("isx_batch_summarize_genomes: scaffold_bounds must span [0, n_pos]");
+        return ISX_ERR_ARG;
+    }
+    for (int i = 0; i < n_scaffolds; i++)
+        if (scaffold_bounds[i + 1] <= scaffold_bounds[i]) { isx_set_error("scaffold_bounds must be strictly ascending"); return ISX_ERR_ARG; }
+    if (n_genomes <= 0 || !genome_first_scaffold || genome_first_scaffold[0] != 0 || genome_first_scaffold[n_genomes] != n_scaffolds || mask_edges < 0) {
+        isx_set_error("isx_batch_summarize_genomes: genome_first_scaffold must span [0, n_scaffolds], mask_edges >= 0");
+        return ISX_ERR_ARG;
+    }
+    for (int g = 0; g < n_genomes; g++)
+        if (genome_first_scaffold[g + 1] <= genome_first_scaffold[g]) { isx_set_error("genome_first_scaffold must be strictly ascending (a genome = consecutive scaffolds of the batch)"); return ISX_ERR_ARG; }
+    SummaryIn in{};
+    in.stream = b->ctx->stream; in.ev = b->ev_sum;
+    in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
+    in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
+    in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
+    in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
+    return run_genome_summary(in, b->S, n_genomes, genome_first_scaffold, mask_edges, out, device_ms);
+}
+
 static void fill_summary_in(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, SummaryIn &in)
 {
     in.stream = b->ctx->stream; in.ev = b->ev_sum;

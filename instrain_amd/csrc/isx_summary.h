@@ -37,6 +37,8 @@ struct SummaryIn {
 };
 
 int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host_out, float *ms);
+int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, const int32_t *genome_first, int mask_edges,
+                       isx_genome_level *host_out, float *ms);
 
 struct CompareBuffers {
     uint32_t *cov_a = nullptr, *cov_b = nullptr;

@@ -321,6 +321,55 @@ __global__ void __launch_bounds__(256) k_snp_apply(const SnpCand *cand, uint32_t
     rows[atomicAdd(&cursors[1], 1u)] = r;
 }
 
+// ---- genome level (genomeUtilities.py:297-365 on generate_genome_coverage_array :932-981) ----
+// covm[p] = cumulative coverage, or 0xFFFFFFFF when p lies in the `mask` positions at either end of its scaffold (or the
+// scaffold is shorter than twice that): masked positions sort behind every real one and are left out of the sums.
+struct GAcc { unsigned long long n, sum, sumsq; };
+
+__global__ void __launch_bounds__(256) k_genome_mask_reduce(const uint32_t *cov, uint32_t n_pos, const int64_t *sbounds, int n_scaf,
+                                                            const int64_t *gbounds, int n_gen, uint32_t mask, uint32_t *covm, GAcc *acc)
+{
+    const uint32_t TILE = 64;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p0 = t * TILE;
+    if (p0 >= n_pos) return;
+    const uint32_t p1 = (uint32_t)min((uint64_t)n_pos, p0 + TILE);
+    int sc = find_seg(sbounds, n_scaf, (uint32_t)p0), g = find_seg(gbounds, n_gen, (uint32_t)p0);
+    unsigned long long n = 0, sum = 0, sq = 0;
+    auto flush = [&]() {
+        if (n) { atomicAdd(&acc[g].n, n); atomicAdd(&acc[g].sum, sum); atomicAdd(&acc[g].sumsq, sq); }
+        n = sum = sq = 0;
+    };
+    for (uint32_t p = (uint32_t)p0; p < p1; p++) {
+        if ((int64_t)p >= sbounds[sc + 1]) sc = find_seg(sbounds, n_scaf, p);
+        if ((int64_t)p >= gbounds[g + 1]) { flush(); g = find_seg(gbounds, n_gen, p); }
+        const int64_t s0 = sbounds[sc], s1 = sbounds[sc + 1];
+        const bool valid = mask == 0 || (s1 - s0 >= 2 * (int64_t)mask && (int64_t)p - s0 >= (int64_t)mask && s1 - (int64_t)p > (int64_t)mask);
+        const unsigned long long c = cov[p];
+        covm[p] = valid ? (uint32_t)c : 0xFFFFFFFFu;
+        if (valid) { n++; sum += c; sq += c * c; }
+    }
+    flush();
+}
+
+__global__ void k_genome_rows(const uint32_t *sorted, const uint32_t *seg_off, const GAcc *acc, int n_gen, int mm, int M,
+                              isx_genome_level *out)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_gen) return;
+    const GAcc a = acc[g];
+    const uint32_t b = seg_off[g];
+    isx_genome_level r;
+    r.n = (int64_t)a.n; r.sum_cov = a.sum; r.sumsq_cov = a.sumsq;
+    r.median_cov = 0.0;                         // no position left: the reference takes the median of [0]
+    if (a.n) {
+        const uint64_t h = a.n >> 1;
+        r.median_cov = (a.n & 1) ? (double)sorted[b + h] : ((double)sorted[b + h - 1] + (double)sorted[b + h]) / 2.0;
+    }
+    r.mm = mm; r.pad = 0;
+    out[(size_t)g * M + mm] = r;
+}
+
 template <class T>
 int dev_alloc(T **p, size_t n)
 {
@@ -529,6 +578,96 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
     HIP_TRY(hipStreamSynchronize(s));
     if (ms) { float v = 0.f; (void)hipEventElapsedTime(&v, in.ev[0], in.ev[1]); *ms = v; }
     return ISX_OK;
+}
+
+// Genome-level coverage roll-up: a genome = consecutive scaffolds of the batch; per (genome, mm) the number of positions left
+// after cutting `mask_edges` from both ends of every scaffold, the exact sums of the cumulative coverage over them and its median.
+int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, const int32_t *genome_first, int mask_edges,
+                       isx_genome_level *host_out, float *ms)
+{
+    hipStream_t s = in.stream;
+    const uint32_t n_pos = in.n_pos;
+    const int n_scaf = in.n_scaffolds, M = in.M;
+    int rc;
+    if ((rc = dev_alloc(&B.cov, n_pos)) || (rc = dev_alloc(&B.cv, n_pos)) || (rc = dev_alloc(&B.cr, n_pos)) ||
+        (rc = dev_alloc(&B.k_u32, n_pos)) || (rc = dev_alloc(&B.k_f32, n_pos))) return rc;
+    // small per-call tables (this is a once-per-batch pass)
+    std::vector<int64_t> gb((size_t)n_genomes + 1);
+    for (int g = 0; g <= n_genomes; g++) gb[(size_t)g] = in.scaffold_bounds[genome_first[g]];
+    std::vector<uint32_t> off((size_t)n_genomes + 1);
+    for (int g = 0; g <= n_genomes; g++) off[(size_t)g] = (uint32_t)gb[(size_t)g];
+    int64_t *d_sb = nullptr, *d_gb = nullptr;
+    uint32_t *d_off = nullptr, *d_be = nullptr, *covm = reinterpret_cast<uint32_t *>(B.k_f32);     // k_f32 is free in this pass
+    GAcc *d_acc = nullptr;
+    Acc *d_sacc = nullptr;
+    isx_genome_level *d_rows = nullptr;
+    void *temp = nullptr;
+    auto done = [&](int code) {
+        void *ps[] = {d_sb, d_gb, d_off, d_be, d_acc, d_sacc, d_rows, temp};
+        for (void *p : ps) if (p) (void)hipFree(p);
+        return code;
+    };
+#define GS_TRY(expr) do { if ((expr) != hipSuccess) { isx_set_error(std::string("HIP error in the genome summary: ") + #expr); return done(ISX_ERR_HIP); } } while (0)
+    GS_TRY(hipMalloc(&d_sb, ((size_t)n_scaf + 1) * sizeof(int64_t)));
+    GS_TRY(hipMalloc(&d_gb, ((size_t)n_genomes + 1) * sizeof(int64_t)));
+    GS_TRY(hipMalloc(&d_off, ((size_t)n_genomes + 1) * sizeof(uint32_t)));
+    GS_TRY(hipMalloc(&d_be, (size_t)n_genomes * 2 * sizeof(uint32_t)));
+    GS_TRY(hipMalloc(&d_acc, (size_t)n_genomes * sizeof(GAcc)));
+    GS_TRY(hipMalloc(&d_sacc, (size_t)n_scaf * sizeof(Acc)));
+    GS_TRY(hipMalloc(&d_rows, (size_t)n_genomes * M * sizeof(isx_genome_level)));
+    GS_TRY(hipMemsetAsync(d_sacc, 0, (size_t)n_scaf * sizeof(Acc), s));
+    GS_TRY(hipMemcpyAsync(d_sb, in.scaffold_bounds, ((size_t)n_scaf + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    GS_TRY(hipMemcpyAsync(d_gb, gb.data(), gb.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    GS_TRY(hipMemcpyAsync(d_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    // medians from sorted copies, big genomes one by one with the device-wide sort (see run_summary)
+    constexpr uint32_t BIG_SEG = 1u << 17;
+    std::vector<uint32_t> seg_b((size_t)n_genomes), seg_e((size_t)n_genomes);
+    std::vector<int> big;
+    uint32_t longest = 1;
+    for (int g = 0; g < n_genomes; g++) {
+        seg_b[(size_t)g] = off[(size_t)g]; seg_e[(size_t)g] = off[(size_t)g + 1];
+        if (seg_e[(size_t)g] - seg_b[(size_t)g] > BIG_SEG) {
+            big.push_back(g);
+            longest = std::max(longest, seg_e[(size_t)g] - seg_b[(size_t)g]);
+            seg_e[(size_t)g] = seg_b[(size_t)g];
+        }
+    }
+    GS_TRY(hipMemcpyAsync(d_be, seg_b.data(), (size_t)n_genomes * 4, hipMemcpyHostToDevice, s));
+    GS_TRY(hipMemcpyAsync(d_be + n_genomes, seg_e.data(), (size_t)n_genomes * 4, hipMemcpyHostToDevice, s));
+    const bool any_small = (int)big.size() < n_genomes;
+    size_t tb = 0, tb2 = 0;
+    GS_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb, covm, B.k_u32, n_pos, (unsigned)n_genomes, d_be, d_be + n_genomes, 0, 32, s));
+    if (!big.empty()) { GS_TRY(rocprim::radix_sort_keys(nullptr, tb2, covm, B.k_u32, (size_t)longest, 0, 32, s)); tb = std::max(tb, tb2); }
+    GS_TRY(hipMalloc(&temp, tb + 256));
+    GS_TRY(hipEventRecord(in.ev[0], s));
+    const dim3 blk(256), gpos((n_pos + 255) / 256), ggen((n_genomes + 255) / 256);
+    if (M > 1) {
+        GS_TRY(hipMemsetAsync(B.cov, 0, (size_t)n_pos * 4, s));
+        GS_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(B.cv), 0x7FC00000, n_pos, s));
+        GS_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(B.cr), 0x7FC00000, n_pos, s));
+    }
+    for (int mm = 0; mm < M; mm++) {
+        if (M == 1) hipLaunchKernelGGL(k_level_dense, gpos, blk, 0, s, in.counts, in.clon, in.clon_r, n_pos, B.cov, B.cv, B.cr);
+        else hipLaunchKernelGGL(k_level_apply, dim3(2048), blk, 0, s, in.entries, in.win_nent, in.slab, in.n_win, in.ovf0, in.n_ovf,
+                                (uint32_t)mm, B.cov, B.cv, B.cr, d_sb, n_scaf, d_sacc);
+        GS_TRY(hipMemsetAsync(d_acc, 0, (size_t)n_genomes * sizeof(GAcc), s));
+        const uint32_t tiles = (n_pos + 63) / 64;
+        hipLaunchKernelGGL(k_genome_mask_reduce, dim3((tiles + 255) / 256), blk, 0, s, B.cov, n_pos, d_sb, n_scaf, d_gb, n_genomes,
+                           (uint32_t)std::max(mask_edges, 0), covm, d_acc);
+        size_t t = tb + 256;
+        if (any_small) GS_TRY(rocprim::segmented_radix_sort_keys(temp, t, covm, B.k_u32, n_pos, (unsigned)n_genomes, d_be, d_be + n_genomes, 0, 32, s));
+        for (int g : big) {
+            t = tb + 256;
+            GS_TRY(rocprim::radix_sort_keys(temp, t, covm + off[(size_t)g], B.k_u32 + off[(size_t)g], (size_t)(off[(size_t)g + 1] - off[(size_t)g]), 0, 32, s));
+        }
+        hipLaunchKernelGGL(k_genome_rows, ggen, blk, 0, s, B.k_u32, d_off, d_acc, n_genomes, mm, M, d_rows);
+    }
+    GS_TRY(hipEventRecord(in.ev[1], s));
+    GS_TRY(hipMemcpyAsync(host_out, d_rows, (size_t)n_genomes * M * sizeof(isx_genome_level), hipMemcpyDeviceToHost, s));
+    GS_TRY(hipStreamSynchronize(s));
+#undef GS_TRY
+    if (ms) { float v = 0.f; (void)hipEventElapsedTime(&v, in.ev[0], in.ev[1]); *ms = v; }
+    return done(ISX_OK);
 }
 
 void CompareBuffers::release()

@@ -147,6 +147,17 @@ class Batch:
         check(self.lib.isx_batch_summarize(self.h, len(sb) - 1, sb.ctypes.data, out.ctypes.data, C.byref(ms)))
         return out, ms.value
 
+    def summarize_genomes(self, scaffold_bounds, genome_first_scaffold, mask_edges=100):
+        """genome-level coverage roll-up (genomeUtilities.genomeLevel_coverage_info without iRep): a genome = consecutive
+        scaffolds of the batch -> (structured array [n_genomes, n_mm_bins], device ms)"""
+        sb = np.ascontiguousarray(scaffold_bounds, dtype=np.int64)
+        gf = np.ascontiguousarray(genome_first_scaffold, dtype=np.int32)
+        out = np.zeros((len(gf) - 1, self.n_mm_bins), dtype=_lib.GENOME_LEVEL_DT)
+        ms = C.c_float(0)
+        check(self.lib.isx_batch_summarize_genomes(self.h, len(sb) - 1, sb.ctypes.data, len(gf) - 1, gf.ctypes.data, int(mask_edges),
+                                                   out.ctypes.data, C.byref(ms)))
+        return out, ms.value
+
     def close(self):
         if self.h:
             self.lib.isx_batch_destroy(self.h)

@@ -85,3 +85,34 @@ def coverage_table(entries, snv, length, clon_r=None):
         row["mm"] = mm
         rows.append(row)
     return rows
+
+
+def genome_coverage_rows(covT, s2l, genome2scaffolds, mms, mask_edges=100):
+    """genomeLevel_coverage_info (/root/reference/inStrain/genomeUtilities.py:297-365) without iRep, on
+    generate_genome_coverage_array (:932-981): per genome and mm the coverage of all its scaffolds laid end to end with
+    `mask_edges` positions cut from both ends of every scaffold (a scaffold shorter than twice that drops out), cumulative
+    over levels <= mm -> median (int), SEM (ddof 1), std (ddof 0).
+    covT: scaffold -> {mm: (positions, values)} (the shrunk covT); s2l: scaffold -> length; rows in the reference's order
+    (genomes in dict order, mms ascending)."""
+    rows = []
+    for genome, scaffolds in genome2scaffolds.items():
+        scaffolds = [s for s in scaffolds if s in s2l]
+        for mm in mms:
+            arrs = []
+            for sc in scaffolds:
+                ln = int(s2l[sc])
+                cov = np.zeros(ln, dtype=np.float64)                # mm_counts_to_counts_shrunk(fill_zeros=slen); absent scaffold -> NaN -> fillna(0)
+                for m, (pos, val) in covT.get(sc, {}).items():
+                    if int(m) <= int(mm):
+                        np.add.at(cov, np.asarray(pos, dtype=np.int64), np.asarray(val, dtype=np.float64))
+                if mask_edges:
+                    cov = cov[mask_edges:ln - mask_edges] if ln >= 2 * mask_edges else cov[:0]
+                arrs.append(cov)
+            covs = np.concatenate(arrs) if arrs else np.zeros(0)
+            if len(covs) == 0:
+                covs = np.zeros(1)                                  # pd.Series([0]) in the reference
+            n = len(covs)
+            sem = float(np.std(covs, ddof=1) / np.sqrt(n)) if n > 1 else float("nan")       # scipy.stats.sem
+            rows.append({"mm": int(mm), "genome": genome, "coverage_median": int(np.median(covs)),
+                         "coverage_SEM": sem, "coverage_std": float(np.std(covs))})
+    return rows

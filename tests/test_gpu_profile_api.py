@@ -530,3 +530,54 @@ def test_one_bam_profiled_by_two_ranks_equals_one_rank(tmp_path):
     gotl = sorted((int(x["tid"]), int(x["gpos_a"]), int(x["gpos_b"]), int(x["mm"]), int(x["total"]), int(x["countAB"])) for x in g["ld"])
     assert gotl == sorted(lrows)
     assert sorted(set(int(t) for t in g["summary"]["tid"])) == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("mm_levels", [1, 4])
+def test_genome_level_rollup_vs_oracle(mm_levels):
+    """isx_batch_summarize_genomes + profile.genome_utilities against oracle/summary.genome_coverage_rows (itself pinned
+    by the reference's genomeLevel_coverage_info, tests/test_oracle_golden.py): three genomes of consecutive scaffolds, one
+    scaffold shorter than the 2 x 100 masked positions, one without reads, a genome of 300 kbp (device-wide sort path)"""
+    from instrain_amd import engine, synth
+    from instrain_amd.profile import genome_utilities as gu
+    from oracle import summary
+    lens = [5200, 150, 2600, 300_000, 900, 1301, 7000]
+    names = ["s%d" % i for i in range(len(lens))]
+    genome_first = [0, 3, 5, 7]                       # g0 = s0..s2, g1 = s3..s4, g2 = s5..s6
+    genomes = ["g0", "g1", "g2"]
+    sb = np.r_[0, np.cumsum(lens)].astype(np.int64)
+    n_pos = int(sb[-1])
+    rng = np.random.Generator(np.random.PCG64(7 + mm_levels))
+    # observations: coverage ~ 12 on every scaffold but s4 (no reads); mm levels random
+    pos = []
+    for i, ln in enumerate(lens):
+        if i == 4:
+            continue
+        pos.append(sb[i] + rng.integers(0, ln, size=12 * ln))
+    pos = np.sort(np.concatenate(pos)).astype(np.uint32)
+    base = rng.integers(0, 4, len(pos)).astype(np.uint8)
+    mm = rng.integers(0, mm_levels, len(pos))
+    ctx = engine.Context(0)
+    lut, fb = util.load_lut()
+    ctx.set_null_model(lut, fb)
+    ref = rng.integers(0, 4, n_pos).astype(np.uint8)
+    b = engine.Batch(ctx, ref, sb, engine.pack_obs(pos, base, mm), None, n_mm_bins=mm_levels, enable_linkage=False)
+    b.run()
+    lv, ms = b.summarize_genomes(sb, genome_first, mask_edges=100)
+    got = gu.genome_level_rows(lv, genomes, mms=[0, 1, 3, 9])
+    b.close(); ctx.close()
+    # the same from the observations with the oracle's restatement
+    covT = {}
+    for i, nme in enumerate(names):
+        k = (pos >= sb[i]) & (pos < sb[i + 1])
+        covT[nme] = {}
+        for m in range(mm_levels):
+            p, c = np.unique(pos[k & (mm == m)] - sb[i], return_counts=True)
+            covT[nme][m] = (p, c)
+    g2s = {g: names[genome_first[j]:genome_first[j + 1]] for j, g in enumerate(genomes)}
+    exp = summary.genome_coverage_rows(covT, dict(zip(names, lens)), g2s, [0, 1, 3, 9], mask_edges=100)
+    assert len(got) == len(exp) == 12
+    for (_, r), e in zip(got.iterrows(), exp):
+        assert r["mm"] == e["mm"] and r["genome"] == e["genome"] and r["coverage_median"] == e["coverage_median"], (dict(r), e)
+        for k in ("coverage_SEM", "coverage_std"):
+            assert (np.isnan(r[k]) and np.isnan(e[k])) or abs(r[k] - e[k]) <= 1e-9 * max(1.0, abs(e[k])), (k, dict(r), e)
+    assert lv["n"][0, 0] == (5200 - 200) + 0 + (2600 - 200) and lv["n"][1, 0] == (300_000 - 200) + (900 - 200)

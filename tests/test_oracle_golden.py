@@ -204,3 +204,32 @@ def test_oracle_compare_overlap_vs_reference_vectors(name):
     assert [r["population_SNPs"] for r in t] == list(g["t_population_SNPs"])
     for k in ("conANI", "popANI", "percent_genome_compared"):
         np.testing.assert_array_equal(np.array([r[k] for r in t], dtype=np.float64), g["t_" + k])
+
+
+def _genome_inputs():
+    g = np.load(os.path.join(util.GOLD, "genome_coverage_inputs.npz"))
+    scaffolds = [str(s) for s in g["scaffolds"]]
+    s2l = dict(zip(scaffolds, (int(x) for x in g["lengths"])))
+    covT = {}
+    for si, mm, pos, val in g["cov"]:
+        d = covT.setdefault(scaffolds[int(si)], {}).setdefault(int(mm), ([], []))
+        d[0].append(int(pos)); d[1].append(int(val))
+    g2s = {}
+    for genome, sc in g["genome_of"]:
+        g2s.setdefault(str(genome), []).append(str(sc))
+    return covT, s2l, g2s, [int(m) for m in g["mms"]]
+
+
+def test_genome_level_coverage_rollup_vs_reference():
+    """oracle/summary.genome_coverage_rows against the reference's genomeLevel_coverage_info (genomeUtilities.py:297-365)
+    on a synthetic covT: masked scaffold edges, a scaffold shorter than the mask, one without coverage, one absent"""
+    import pandas as pd
+    from oracle import summary
+    covT, s2l, g2s, mms = _genome_inputs()
+    rows = summary.genome_coverage_rows(covT, s2l, g2s, mms, mask_edges=100)
+    ref = pd.read_csv(os.path.join(util.GOLD, "genome_coverage.csv"))
+    assert len(rows) == len(ref) == 12
+    for r, (_, e) in zip(rows, ref.iterrows()):
+        assert r["mm"] == e["mm"] and r["genome"] == e["genome"] and r["coverage_median"] == e["coverage_median"], (r, dict(e))
+        for k in ("coverage_SEM", "coverage_std"):
+            assert (np.isnan(r[k]) and np.isnan(e[k])) or abs(r[k] - e[k]) <= 1e-9 * max(1.0, abs(e[k])), (k, r, dict(e))
