@@ -391,6 +391,30 @@ struct SegBuf {
     uint32_t b_end = 0;             // blocks inflated so far: [seg.b0, b_end)
 };
 
+// how many inflated bytes a handle may keep between its two passes: a quarter of the memory that is available to this
+// process (MemAvailable, the cgroup's limit when there is one), at most 16 GiB, at least 1 GiB
+uint64_t inflate_cache_limit()
+{
+    uint64_t avail = (uint64_t)4 << 30;
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            unsigned long long kb = 0;
+            if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = (uint64_t)kb << 10; break; }
+        }
+        fclose(f);
+    }
+    if (FILE *f = fopen("/sys/fs/cgroup/memory.max", "r")) {
+        unsigned long long mx = 0, cur = 0;
+        if (fscanf(f, "%llu", &mx) == 1) {
+            if (FILE *g = fopen("/sys/fs/cgroup/memory.current", "r")) { if (fscanf(g, "%llu", &cur) != 1) cur = 0; fclose(g); }
+            if (mx > cur) avail = std::min<uint64_t>(avail, mx - cur);
+        }
+        fclose(f);
+    }
+    return std::max<uint64_t>((uint64_t)1 << 30, std::min<uint64_t>(avail / 4, (uint64_t)16 << 30));
+}
+
 bool seg_inflate(const isx_bam &B, Inflater &inf, const Segment &s, SegBuf &out)
 {
     out.data.resize((size_t)(s.ioff1 - s.ioff0));
@@ -806,7 +830,8 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_mark = now();
     B.seg_reads.assign(n_seg, {}); B.seg_names.assign(n_seg, {});
-    const bool keep_inflated = B.total_inflated <= ((uint64_t)1 << 30);
+    // pass 2 needs the same bytes again: keep a file's inflated segments when they are a small part of what the host has free
+    const bool keep_inflated = B.total_inflated <= inflate_cache_limit();
     if (keep_inflated) { B.seg_cache.assign(n_seg, {}); B.seg_cache_rec.assign(n_seg, {}); }
     // waves of segments: inflate (parallel) -> record boundaries (serial walk over block_size fields) -> field
     // extraction (parallel).  At most one wave of inflated data is alive.
@@ -1460,7 +1485,7 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     pool.run((int)seg_list.size(), [&](int k) {
         const Segment &s = B.segs[seg_list[(size_t)k]];
         SegWork &w = sw[(size_t)k];
-        const bool cached = !B.seg_cache.empty();
+        const bool cached = !B.seg_cache.empty() && !B.seg_cache[seg_list[(size_t)k]].empty();
         if (cached) { w.data = B.seg_cache[seg_list[(size_t)k]].data(); w.recp = &B.seg_cache_rec[seg_list[(size_t)k]]; }
         else {
             Inflater inf;
@@ -1496,9 +1521,17 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
         SegWork &w = sw[(size_t)k];
         uint64_t ci = c_at[(size_t)k];
         if (w.keep.empty()) { SegBuf().data.swap(w.buf.data); return; }
-        // the batch owns the inflated segment from here on (a segment the handle keeps inflated is copied: overlap
-        // resolution writes qualities)
-        if (w.buf.data.empty()) w.buf.data = B.seg_cache[seg_list[(size_t)k]];
+        // the batch owns the inflated segment from here on (overlap resolution writes qualities).  A segment the handle kept
+        // inflated since the scan is handed over when no reference outside this batch has reads in it (nobody will ask
+        // for it again; if somebody does it is inflated anew), copied otherwise.
+        if (w.buf.data.empty()) {
+            std::vector<uint8_t> &kept = B.seg_cache[seg_list[(size_t)k]];
+            bool others = region;
+            for (int32_t t = std::max(s.tid_first, 0); t <= s.tid_last && !others; t++)
+                if (B.ref_reads[(size_t)t] > 0 && boff[(size_t)t] < 0) others = true;
+            if (others) w.buf.data = kept;
+            else w.buf.data.swap(kept);             // `kept` is now empty: a later request inflates the segment again
+        }
         S.seg_data[(size_t)k].swap(w.buf.data);
         uint8_t *own = S.seg_data[(size_t)k].data();
         for (size_t j = 0; j < w.keep.size(); j++) {
