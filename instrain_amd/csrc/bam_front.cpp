@@ -907,6 +907,14 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
             int32_t t_end = -2;
             for (size_t si = s1; si-- > sv;) if (!B.seg_reads[si].empty()) { t_end = B.seg_reads[si].back().tid; break; }
             bool ended = t_end < 0;
+            if (!ended && s0 > 0) {             // a share inside one long scaffold owns nothing: nothing to complete either
+                int32_t t_prev = -2;
+                for (size_t si = s0; si-- > sv;) if (!B.seg_reads[si].empty()) { t_prev = B.seg_reads[si].back().tid; break; }
+                bool owns_any = false;
+                for (size_t si = s0; si < s1 && !owns_any; si++)
+                    for (const ReadLite &L : B.seg_reads[si]) if (L.tid >= 0 && L.tid != t_prev) { owns_any = true; break; }
+                if (!owns_any) ended = true;
+            }
             for (size_t si = s1; si < w1 && !ended; si++)
                 if (!B.seg_reads[si].empty() && B.seg_reads[si].back().tid != t_end) ended = true;
             if (ended) { s_end = w1; break; }
