@@ -43,6 +43,22 @@ double now_ms()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// host staging that is pinned for a streaming pipe and plain for a single-slot one (nothing to overlap the copy with, and
+// pinning + unpinning costs several times the slower copy)
+int host_block_alloc(void **p, size_t bytes, bool pinned)
+{
+    *p = nullptr;
+    if (pinned) { HIP_TRY(hipHostMalloc(p, std::max<size_t>(bytes, 1), hipHostMallocDefault)); return ISX_OK; }
+    if (posix_memalign(p, 4096, std::max<size_t>(bytes, 4096)) != 0) { *p = nullptr; isx_set_error("out of host memory"); return ISX_ERR_ARG; }
+    return ISX_OK;
+}
+
+void host_block_free(void *p, bool pinned)
+{
+    if (!p) return;
+    if (pinned) (void)hipHostFree(p); else free(p);
+}
+
 struct Slot {
     isx_batch *b = nullptr;
     uint8_t *h_in = nullptr, *d_in = nullptr;
@@ -50,11 +66,13 @@ struct Slot {
     size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_ridx = 0, off_rec = 0;   // records last
     // pair-id runs (linkage): their own pinned / device blocks, grown when a batch has more runs than any before it
     isxenc::PairRun *h_runs = nullptr;
+    bool runs_pinned = true;
     uint2 *d_runs = nullptr;
     size_t cap_runs = 0;
     hipEvent_t ev_ring[2] = {nullptr, nullptr};     // ring mode: the copy that last read each half
     bool ring_busy[2] = {false, false};
     uint8_t *h_out = nullptr;
+    bool out_pinned = true;                 // false: plain memory (a single-slot pipe with a large result block, see slot_batch_create)
     size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0, o_cov16 = 0, o_rare = 0;
     bool rare_dense = false;                // the clonTR table of the last batch went back as the dense array
     std::vector<float> clonr_big;           // that array when the pipe has no pinned room for it (no want_counts)
@@ -159,9 +177,9 @@ static void pipe_free(isx_pipe *p)
         if (s.d_runs) (void)hipFree(s.d_runs);
         t_dev += now_ms() - t_x; t_x = now_ms();
         if (s.h_in) (void)hipHostFree(s.h_in);
-        if (s.h_runs) (void)hipHostFree(s.h_runs);
+        host_block_free(s.h_runs, s.runs_pinned);
         for (hipEvent_t e : s.ev_ring) if (e) (void)hipEventDestroy(e);
-        if (s.h_out) (void)hipHostFree(s.h_out);
+        host_block_free(s.h_out, s.out_pinned);
         t_pin += now_ms() - t_x;
         for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_pass, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
     }
@@ -249,7 +267,8 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     if (prm->enable_linkage) {
         // a read pair's records are consecutive: runs of tens to hundreds of records
         s.cap_runs = (size_t)p->cap_rec / 64 + 4096;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_runs), s.cap_runs * sizeof(isxenc::PairRun), hipHostMallocDefault));
+        s.runs_pinned = p->pp.depth > 1;
+        { const int hrc = host_block_alloc(reinterpret_cast<void **>(&s.h_runs), s.cap_runs * sizeof(isxenc::PairRun), s.runs_pinned); if (hrc != ISX_OK) return hrc; }
         HIP_TRY(hipMalloc(&s.d_runs, s.cap_runs * sizeof(uint2)));
     }
     if (p->ring_half) for (hipEvent_t &e : s.ev_ring) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -268,8 +287,12 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     }
     s.out_bytes = o;
     const double t_o0 = now_ms();
-    HIP_TRY(hipHostMalloc(&s.h_out, s.out_bytes, hipHostMallocDefault));
-    if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_create] slot %d: pinned results %.1f MB %.1f ms\n", index, s.out_bytes / 1e6, now_ms() - t_o0);
+    // A single-slot pipe has nothing to overlap its copy-out with, and pinning (then unpinning) a result block of hundreds of
+    // MB costs several times what the slower copy into plain memory does: 144 MB pinned = ~35 ms + ~30 ms to free, copied
+    // into pageable memory = ~15 ms.
+    s.out_pinned = !(p->pp.depth == 1 && s.out_bytes > ((size_t)64 << 20));
+    { const int hrc = host_block_alloc(reinterpret_cast<void **>(&s.h_out), s.out_bytes, s.out_pinned); if (hrc != ISX_OK) return hrc; }
+    if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_create] slot %d: %s results %.1f MB %.1f ms\n", index, s.out_pinned ? "pinned" : "pageable", s.out_bytes / 1e6, now_ms() - t_o0);
     for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_pass, &s.ev_d2h0, &s.ev_d2h1}) HIP_TRY(hipEventCreate(e));
     const size_t n_chunks = (size_t)(p->cap_rec / ISX_CHUNK) + 2;
     s.cmin.resize(n_chunks); s.cmax.resize(n_chunks); s.cany.resize(n_chunks);
@@ -511,10 +534,10 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         if (erc != isxenc::ENC_OK || !linkage || J.n_runs <= s.cap_runs || attempt == 1) break;
         // more pair-id runs than any batch of this slot had (short fragments): larger blocks, encode again
         HIP_TRY(hipStreamSynchronize(p->s_h2d));
-        (void)hipHostFree(s.h_runs); s.h_runs = nullptr;
+        host_block_free(s.h_runs, s.runs_pinned); s.h_runs = nullptr;
         (void)hipFree(s.d_runs); s.d_runs = nullptr;
         s.cap_runs = J.n_runs + J.n_runs / 4 + 4096;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_runs), s.cap_runs * sizeof(isxenc::PairRun), hipHostMallocDefault));
+        { const int hrc = host_block_alloc(reinterpret_cast<void **>(&s.h_runs), s.cap_runs * sizeof(isxenc::PairRun), s.runs_pinned); if (hrc != ISX_OK) return hrc; }
         HIP_TRY(hipMalloc(&s.d_runs, s.cap_runs * sizeof(uint2)));
     }
     const double t_enc = now_ms();

@@ -271,6 +271,22 @@ def test_pipe_errors(ctx):
     pipe.close()
 
 
+def test_single_slot_pipe_with_a_large_result_block(ctx):
+    """depth 1 and more than 64 MB of dense results: the block is plain (not pinned) memory; same tables"""
+    from instrain_amd import engine
+    w = small_workload(800, 50_000, 25, True)
+    exp, sizes = one_shot(ctx, w, enable_linkage=False, rarefied_coverage=20)
+    pipe = engine.Pipe(ctx, max_pos=12_000_000, max_obs=w["n_obs"], max_splits=len(w["split_bounds"]), depth=1, host_threads=2,
+                       n_mm_bins=1, enable_linkage=False, rarefied_coverage=20)
+    for _ in range(2):
+        t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"])
+        r = pipe.collect(t)
+        same_tables(r, exp, "pageable result block")
+        assert r["sizes"] == sizes
+        pipe.release(t)
+    pipe.close()
+
+
 def test_error_found_while_finishing_reaches_collect(ctx):
     """an mm level the pipe has no bin for is only seen by the kernel; the pipe's finishing thread finds the flag, collect()
     of THAT batch raises with its message, the batches around it are unaffected"""
