@@ -351,6 +351,36 @@ def make_variants(w, n):
         return list(ex.map(lambda k: synth.shifted_variant(w, k), range(n)))
 
 
+def profile_bam_leg(ctx):
+    """The whole seam on a BAM file: instrain_amd.profile.profile_bam (front end scan + filter + expansion fused into the
+    pipe's staging, device batch, table hand-back, SplitObjects) on a synthetic sorted BAM of 0.12 Gbp of reads (2 x 150 bp,
+    insert N(350,30)) over one 3 Mbp scaffold, mm profiling on (the reference's default).  Best of three runs; the BAM is
+    written once into /tmp by a slow Python writer that is not timed."""
+    import instrain_amd.profile as amd
+    from tests import util
+    from tools.bench_front import write_simple_bam
+    n_pairs, G = 400_000, 3_000_000
+    path = "/tmp/isx_bench_%d_%d.bam" % (n_pairs, G)
+    if not os.path.exists(path):
+        write_simple_bam(path, G, n_pairs)
+    rng = np.random.Generator(np.random.PCG64(1))                # the reference sequence write_simple_bam draws first
+    seq = "".join(np.array(list("ACTG"))[rng.integers(0, 4, G, dtype=np.uint8)])
+    lut, fb = util.load_lut()
+    nm = {i: int(v) for i, v in enumerate(lut) if v >= 0}
+    nm[-1] = fb
+    best, n_splits = None, 0
+    for rep in range(3):
+        t0 = time.perf_counter()
+        out = amd.profile_bam(path, None, None, None, s2s={"scaf": seq}, null_model=nm, ctx=ctx)
+        dt = time.perf_counter() - t0
+        n_splits = len(out)
+        best = dt if best is None else min(best, dt)
+    return {"workload": "profile_bam end to end: sorted BAM on disk (%.2f Gbp of reads, %d read pairs, one %.1f Mbp scaffold) -> SplitObjects, "
+                        "mm profiling + linkage on" % (n_pairs * 300 / 1e9, n_pairs, G / 1e6),
+            "seconds": best, "gbp_per_s": n_pairs * 300 / 1e9 / best, "split_objects": n_splits,
+            "note": "host-bound (BGZF inflate, read filter, per-base expansion on the box's CPUs); a 0.9 Gbp BAM takes 0.8-1.0 s (DESIGN.md section 5)"}
+
+
 def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False):
     """n_steps batches through the pipe, at most `depth` in flight; returns the last collected result"""
     tickets, done, last = [], 0, None
@@ -394,6 +424,7 @@ def main():
     ap.add_argument("--no-mm-leg", action="store_true")
     ap.add_argument("--no-resident-leg", action="store_true")
     ap.add_argument("--no-c5-leg", action="store_true")
+    ap.add_argument("--no-bam-leg", action="store_true", help="skip the profile_bam end-to-end leg")
     ap.add_argument("--only-c5", action="store_true", help="skip the C2 legs' extras (debug)")
     ap.add_argument("--window", type=int, default=0)
     args = ap.parse_args()
@@ -561,6 +592,11 @@ def main():
             out["linkage"] = linkage_leg(ctx)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
+        if world == 1 and not args.no_bam_leg and not args.only_c5:
+            try:
+                out["profile_bam"] = profile_bam_leg(ctx)
+            except Exception as e:                  # never lose the line over the extra leg
+                out["profile_bam"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     pipe.close()
     ctx.close()
