@@ -49,7 +49,7 @@ extern "C" {
 #define ISX_ERR_IO (-5)         /* BAM / file error */
 #define ISX_ERR_STATE (-6)      /* call out of order (e.g. fetch before run) */
 
-#define ISX_ABI_VERSION 2
+#define ISX_ABI_VERSION 3
 
 /* Base codes everywhere: 0=A 1=C 2=T 3=G (P2C order, profile_utilities.py:34), 4 = anything else. */
 
@@ -319,6 +319,10 @@ typedef struct {
                                  * 512 MiB -- 128 MiB with depth 1 --, otherwise a ring of 2 x 128 MiB -- 2 x 32 MiB --
                                  * through which it leaves in waves while it is being encoded), > 0 = a ring of that
                                  * many KiB (at least 32), < 0 = never a ring */
+    int32_t pad0;
+    int64_t max_segs;           /* > 0: a READ-LEVEL pipe (isx_pipe_submit_reads / isx_pipe_submit_bam hand over read segments,
+                                 * see isx_segs below; isx_pipe_submit is refused): the largest n_seg of a batch.  max_obs then
+                                 * only bounds the linkage tables (0 = 150 x max_segs) */
 } isx_pipe_params;
 
 /* one entry of the sparse clonTR table (positions whose coverage reaches rarefied_coverage) */
@@ -374,6 +378,63 @@ int isx_pipe_release(isx_pipe *p, int64_t ticket);
 /* n_mm_bins > 1: the entry table of a collected batch ([sizes.n_entries], (gpos, mm) order) -- what
  * isx_batch_fetch_entries(result.batch, out) returns, moved through the slot's pinned staging by the pipe's host threads */
 int isx_pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out);
+
+
+/* ---- read-level hand-over: the per-base expansion of the pileup happens on the device ----
+ * Instead of one 8-byte record per (pileup column, pileup read) visit the host ships READ SEGMENTS: a segment = up to
+ * ISX_SEG_BASES consecutive reference positions covered by one M / = / X run of a read's CIGAR (a longer run is cut into
+ * several segments; an insertion / deletion / skip ends a segment), with one 3-bit code per position:
+ *     0..3 = A, C, T, G observed with quality >= min_base_quality after htslib's overlap resolution
+ *     4    = nothing to count here (low quality, masked by the mate's overlap, position outside the scaffold, padding)
+ *     5    = a base that is not A/C/T/G but passes the quality filter (it makes its mm level "present" at the position,
+ *            profile_utilities.py:279-285, without being counted); 6, 7 = reserved, treated as 4
+ * packed ten per 32-bit word (base j of the segment: word j / 10, bits 3 (j % 10) .. + 2; the top two bits are 0; unused
+ * slots hold code 4).  ~0.43 bytes per base instead of 8 (isx_obs) on the host and 2 / 4 on the device, and the host never
+ * walks single bases into records.  Replaces exactly what isx_obs replaces: the visits of
+ * samfile.pileup(...) + get_base_counts_mm (profile_utilities.py:150-153, 268-286).
+ * Segments arrive in BAM order (ascending read start; a read's segments follow each other), i.e. position-clustered. */
+#define ISX_SEG_BASES 150
+#define ISX_SEG_WORDS 15
+#define ISX_SEG_SKIP_WORD 0x24924924u   /* ten codes 4 */
+
+typedef struct {
+    int64_t n_seg;
+    const uint32_t *gpos;       /* [n_seg] flat position of the segment's first base */
+    const uint8_t *len;         /* [n_seg] 1 .. ISX_SEG_BASES positions; gpos + len <= n_pos */
+    const uint8_t *mm;          /* [n_seg] R2M[read name] (< n_mm_bins); NULL = 0 (--skip_mm_profiling) */
+    const uint32_t *pair;       /* [n_seg] dense read-pair id (both mates share it); NULL unless linkage is enabled */
+    const uint32_t *bases;      /* [n_seg][ISX_SEG_WORDS] packed codes */
+} isx_segs;
+
+/* isx_batch_create / isx_pipe_submit with read segments instead of observations; results are identical to handing over
+ * the observations the segments stand for */
+int isx_batch_create_reads(isx_ctx *ctx, const isx_params *params, int64_t n_pos, const uint8_t *ref, int32_t n_splits,
+                           const int64_t *split_bounds, const isx_segs *segs, isx_batch **out);
+int isx_pipe_submit_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                          const isx_segs *segs, int64_t *ticket);
+
+/* Host helper for a caller that decodes the BAM itself (e.g. a pysam loop over samfile.fetch()): reads -> segments.
+ * Per read r: flat position of its reference start ref_start[r] (may be negative relative to the scaffold when the
+ * caller lays scaffolds end to end: [clip_lo[r], clip_hi[r]) is the scaffold's range in flat space -- columns outside
+ * are truncated like the reference's pileup does), its CIGAR cigar[cigar_off[r] .. cigar_off[r + 1]) in BAM encoding
+ * (len << 4 | op, op = MIDNSHP=X), its bases seq[seq_off[r] ..] as ASCII and qualities qual[seq_off[r] ..] (raw phred, after
+ * any overlap resolution), mm[r] (NULL = 0) and pair[r] (NULL = none).  Output arrays hold cap_seg segments (*n_seg is
+ * set; ISX_ERR_CAPACITY when they are too small -- isx_count_read_segs gives the exact number). */
+int isx_count_read_segs(int64_t n_reads, const uint32_t *cigar, const int64_t *cigar_off, const int64_t *ref_start,
+                        const int64_t *clip_lo, const int64_t *clip_hi, int64_t *n_seg);
+int isx_pack_reads(int64_t n_reads, const int64_t *ref_start, const int64_t *clip_lo, const int64_t *clip_hi,
+                   const uint32_t *cigar, const int64_t *cigar_off, const char *seq, const uint8_t *qual, const int64_t *seq_off,
+                   const uint8_t *mm, const uint32_t *pair, int32_t min_base_quality, int64_t cap_seg, uint32_t *seg_gpos,
+                   uint8_t *seg_len, uint8_t *seg_mm, uint32_t *seg_pair, uint32_t *seg_bases, int64_t *n_seg);
+
+/* The read-level pipe's host-side staging on its own (no GPU needed): segments -> device record stream.
+ *   device record = 16 words: delta:16 | len:8 | mm:8, then the 15 payload words; records come in groups of 16 (one
+ *   wave-wide 16-byte load) with one 32-bit position base per group, start = gbase[record / 16] + delta; a group is
+ *   closed early and padded with empty records (len 0, payload ISX_SEG_SKIP_WORD) where the stream jumps >= 65536
+ *   positions; *n_rec is a multiple of 16.  rec holds cap_rec records, gbase cap_rec / 16 bases, pair_out (NULL with
+ *   segs->pair == NULL) cap_rec ids. */
+int isx_encode_segs(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int64_t cap_rec, uint32_t *rec,
+                    uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec);
 
 /* The pipe's host-side encoder on its own (no GPU needed): obs[n_obs] -> resident record stream.
  *   record_bytes 2: delta:13 | base:3, groups of 512 records; 4: delta:16 | mm:8 | base:3 (<< 24), groups of 256;

@@ -39,7 +39,16 @@ LAYOUT_WIDE_RECORDS, LAYOUT_NO_SHORT_RECORDS, LAYOUT_NO_PACKED_COUNTERS = 1, 2, 
 class PipeParams(C.Structure):
     _fields_ = [("max_pos", C.c_int64), ("max_obs", C.c_int64), ("max_splits", C.c_int32), ("depth", C.c_int32),
                 ("host_threads", C.c_int32), ("pin_threads", C.c_int32), ("jump_slack", C.c_double),
-                ("want_counts", C.c_int32), ("ring_kib", C.c_int32)]
+                ("want_counts", C.c_int32), ("ring_kib", C.c_int32), ("pad0", C.c_int32), ("max_segs", C.c_int64)]
+
+
+SEG_BASES, SEG_WORDS, SEG_SKIP_WORD = 150, 15, 0x24924924
+
+
+class Segs(C.Structure):
+    """isx_segs: SoA view of a batch of read segments (pointers into numpy arrays the caller keeps alive)"""
+    _fields_ = [("n_seg", C.c_int64), ("gpos", C.c_void_p), ("len", C.c_void_p), ("mm", C.c_void_p), ("pair", C.c_void_p),
+                ("bases", C.c_void_p)]
 
 
 RARE_DT = np.dtype([("gpos", "<u4"), ("clon_rarefied", "<f4")])
@@ -110,10 +119,10 @@ class IsxError(RuntimeError):
 
 
 SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destroy", "isx_set_null_model",
-           "isx_batch_create", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
+           "isx_batch_create", "isx_batch_create_reads", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
            "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
-           "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_bam", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_encode_obs", "isx_encode_obs_ring",
+           "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_submit_bam", "isx_encode_segs", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_encode_obs", "isx_encode_obs_ring",
            "isx_bam_open", "isx_bam_close", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
            "isx_bam_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_ref_counts",
            "isx_bam_expand_refs", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
@@ -138,6 +147,11 @@ def load():
     lib.isx_ctx_destroy.restype = None
     lib.isx_set_null_model.argtypes = [vp, vp, i64, i32]
     lib.isx_batch_create.argtypes = [vp, C.POINTER(Params), i64, vp, i32, vp, i64, vp, vp, C.POINTER(vp)]
+    lib.isx_batch_create_reads.argtypes = [vp, C.POINTER(Params), i64, vp, i32, vp, C.POINTER(Segs), C.POINTER(vp)]
+    lib.isx_pipe_submit_reads.argtypes = [vp, i64, vp, i32, vp, C.POINTER(Segs), C.POINTER(i64)]
+    lib.isx_encode_segs.argtypes = [C.POINTER(Segs), i64, i32, i32, i64, vp, vp, vp, C.POINTER(i64)]
+    lib.isx_count_read_segs.argtypes = [i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    lib.isx_pack_reads.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
     lib.isx_batch_destroy.argtypes = [vp]
     lib.isx_batch_destroy.restype = None
     lib.isx_batch_run.argtypes = [vp]

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "isx_batch.h"
+#include "seg_encode.h"
 
 static thread_local std::string g_err;
 void isx_set_error(const std::string &msg) { g_err = msg; }
@@ -386,7 +387,7 @@ int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed)
 }
 
 uint64_t build_window_directory(const uint32_t *cmin, const uint32_t *cmax, const uint8_t *cany, uint64_t n_chunks, int W,
-                                int64_t n_pos, std::vector<uint2> &win)
+                                int64_t n_pos, std::vector<uint2> &win, uint32_t chunk)
 {
     std::vector<uint32_t> pmax(n_chunks), smin(n_chunks);
     uint32_t run = 0;
@@ -401,8 +402,8 @@ uint64_t build_window_directory(const uint32_t *cmin, const uint32_t *cmax, cons
         while (lo < n_chunks && (uint64_t)pmax[lo] < w0) lo++;       // chunks before lo: every gpos < w0
         if (hi < lo) hi = lo;
         while (hi < n_chunks && (uint64_t)smin[hi] < w1) hi++;       // chunks from hi on: every gpos >= w1
-        win[(size_t)w] = make_uint2((uint32_t)(lo * ISX_CHUNK), (uint32_t)(hi * ISX_CHUNK));
-        longest = std::max(longest, (hi - lo) * ISX_CHUNK);
+        win[(size_t)w] = make_uint2((uint32_t)(lo * chunk), (uint32_t)(hi * chunk));
+        longest = std::max(longest, (hi - lo) * chunk);
     }
     return longest;
 }
@@ -412,7 +413,7 @@ int batch_set_geometry(isx_batch *b)
     const bool dense = b->M == 1;
     if (!dense && b->W > 2 * b->block) { isx_set_error("mm path: window must be <= 2 x block"); return ISX_ERR_ARG; }
     b->rqcap = dense ? 0 : std::min(b->W, 512);     // positions with SNV rows per window (overflow: per-position atomics)
-    b->lds = pileup_lds_bytes(b->W, b->M, b->qcap, b->rqcap, b->prm.enable_linkage, b->packed, b->block, &b->stage_off);
+    b->lds = pileup_lds_bytes(b->W, b->M, b->qcap, b->rqcap, b->prm.enable_linkage, b->packed, b->block, b->segs ? 1 : 0, &b->stage_off);
     if (b->lds > 160 * 1024) { isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
     {   // persistent kernels: as many workgroups as stay resident on the 256 CUs
         const int per_cu = std::max(1, std::min((int)(160 * 1024 / b->lds), 2048 / b->block));
@@ -513,7 +514,7 @@ void isx_batch_destroy(isx_batch *b)
     }
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
+    void *ps[] = {b->d_seg, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) (void)hipFree(p);
@@ -525,17 +526,15 @@ void isx_batch_destroy(isx_batch *b)
     delete b;
 }
 
-int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uint8_t *ref, int32_t n_splits,
-                     const int64_t *split_bounds, int64_t n_obs, const isx_obs *obs, const uint32_t *pair,
-                     isx_batch **out)
+// isx_batch_create (observations) and isx_batch_create_reads (read segments: segs != NULL, n_obs = an upper bound of
+// the observations they stand for) share everything but the upload of the stream
+static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uint8_t *ref, int32_t n_splits,
+                             const int64_t *split_bounds, int64_t n_obs, const isx_obs *obs, const uint32_t *pair,
+                             const isx_segs *segs, isx_batch **out)
 {
-    if (!c || !prm || !out || !ref || !split_bounds || n_pos <= 0 || n_splits <= 0 || n_obs < 0 || (n_obs && !obs)) {
-        isx_set_error("isx_batch_create: bad argument");
-        return ISX_ERR_ARG;
-    }
     *out = nullptr;
     if (!c->d_lut) { isx_set_error("isx_batch_create: call isx_set_null_model first"); return ISX_ERR_STATE; }
-    if (prm->enable_linkage && n_obs && !pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
+    if (prm->enable_linkage && n_obs && !(segs ? segs->pair : pair)) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
     if (prm->n_mm_bins < 1 || prm->n_mm_bins > 128) { isx_set_error("n_mm_bins must be in [1, 128]"); return ISX_ERR_ARG; }
     if (n_pos >= (int64_t)0xFFFF0000ll) { isx_set_error("flat position space must be < 2^32 - 65536"); return ISX_ERR_ARG; }
     if (split_bounds[0] != 0 || split_bounds[n_splits] != n_pos) { isx_set_error("split_bounds must span [0, n_pos]"); return ISX_ERR_ARG; }
@@ -547,6 +546,7 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     b->ps = (int)(c->n_created++ & 1u);
     b->ctx = c; b->prm = *prm; b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits;
     b->M = prm->n_mm_bins;
+    b->segs = segs != nullptr;
     const bool dense = b->M == 1;
     batch_pick_block(b);
 #ifdef ISX_TUNING
@@ -592,9 +592,47 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     BH(hipMalloc(&b->d_sites, b->cap_sites * sizeof(isx_site)));
     if (prm->enable_linkage) BH(hipMalloc(&b->d_ao, b->cap_ao * sizeof(isx_ao)));
 
-    // ---- observation stream (+ pair ids / allele-pass positions with linkage): see ObsStream ----
-    ObsStream st(c, b, obs, pair, n_obs, n_pos);
-    {
+    // ---- observation stream (+ pair ids / allele-pass positions with linkage): see ObsStream; or the read segments ----
+    ObsStream st(c, b, obs, pair, segs ? 0 : n_obs, n_pos);
+    uint32_t dir_chunk = ISX_CHUNK;
+    if (segs) {
+        // read segments: encoded on the host (the pipe does the same into pinned staging, seg_encode.cpp), one upload
+        dir_chunk = ISX_SEG_GROUP;
+        int64_t jumps = 0;                          // a jump of >= 65536 positions closes a group early: at most 15 padding records each
+        for (int64_t i = 1; i < segs->n_seg; i++) jumps += (segs->gpos[i] > segs->gpos[i - 1] ? segs->gpos[i] - segs->gpos[i - 1] : segs->gpos[i - 1] - segs->gpos[i]) >= 32768u;
+        const int64_t cap_rec = ((segs->n_seg + ISX_SEG_GROUP - 1) / ISX_SEG_GROUP + jumps + (segs->n_seg + 4095) / 4096 + 1) * ISX_SEG_GROUP;
+        std::vector<uint32_t> h_rec((size_t)cap_rec * ISX_SEG_REC_WORDS), h_gbase((size_t)(cap_rec / ISX_SEG_GROUP)), h_pair;
+        if (prm->enable_linkage) h_pair.resize((size_t)cap_rec);
+        st.cmin.assign(h_gbase.size(), 0xFFFFFFFFu); st.cmax.assign(h_gbase.size(), 0u); st.cany.assign(h_gbase.size(), 0);
+        isxenc::HostPool pool((int)std::max<int64_t>(1, std::min<int64_t>(16, segs->n_seg / 65536 + 1)), -1, false);
+        isxenc::SegJob J;
+        J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = b->M;
+        if (!prm->enable_linkage) J.in.pair = nullptr;
+        J.rec = h_rec.data(); J.gbase = h_gbase.data(); J.pair_out = prm->enable_linkage ? h_pair.data() : nullptr;
+        J.cmin = st.cmin.data(); J.cmax = st.cmax.data(); J.cany = st.cany.data(); J.cap_rec = cap_rec;
+        const int erc = isxenc::encode_segs(pool, J);
+        if (erc != isxenc::SEG_OK) {
+            isx_batch_destroy(b);
+            if (erc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
+            isx_set_error(erc == isxenc::SEG_BAD_POS ? "a segment reaches beyond n_pos" : erc == isxenc::SEG_BAD_LEN ? "a segment's length is not in [1, 150]"
+                                                                                       : "internal: segment stream larger than estimated");
+            return erc == isxenc::SEG_CAPACITY ? ISX_ERR_STATE : ISX_ERR_ARG;
+        }
+        b->n_rec = (uint64_t)J.n_rec;
+        b->n_pairs = (uint64_t)J.max_pair + 1;
+        st.n_chunks = b->n_rec / ISX_SEG_GROUP;
+        BH(hipMalloc(&b->d_seg, (size_t)b->n_rec * 64 + ISX_TAIL_BYTES));
+        BH(hipMemcpyAsync(b->d_seg, h_rec.data(), (size_t)b->n_rec * 64, hipMemcpyHostToDevice, c->stream));
+        BH(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<uint8_t *>(b->d_seg) + (size_t)b->n_rec * 64), (int)ISX_SEG_SKIP_WORD, ISX_TAIL_BYTES / 4, c->stream));
+        BH(hipMalloc(&b->d_gbase, (st.n_chunks + ISX_TAIL_GROUPS) * sizeof(uint32_t)));
+        BH(hipMemsetAsync(b->d_gbase + st.n_chunks, 0, ISX_TAIL_GROUPS * sizeof(uint32_t), c->stream));
+        BH(hipMemcpyAsync(b->d_gbase, h_gbase.data(), st.n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (prm->enable_linkage) {
+            BH(hipMalloc(&b->d_pair, (size_t)b->n_rec * sizeof(uint32_t)));
+            BH(hipMemcpyAsync(b->d_pair, h_pair.data(), (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        }
+        BH(hipStreamSynchronize(c->stream));         // the host vectors are locals
+    } else {
         int rc = st.upload_records();
         if (rc == ISX_OK && prm->enable_linkage) rc = st.upload_linkage_arrays();
         if (rc != ISX_OK) { isx_batch_destroy(b); return rc; }
@@ -615,9 +653,9 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
             // u16-packed counters are legal when no window streams >= 65536 records
             const int Wp = batch_window_for(b, n_pos, true);
             if (!(prm->layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win) < 65536) { b->packed = 1; W = Wp; }
+                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, dir_chunk) < 65536) { b->packed = 1; W = Wp; }
         }
-        if (!b->packed) build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win);
+        if (!b->packed) build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win, dir_chunk);
         b->W = W;
         b->n_win = (int)win.size();
         BT(batch_set_geometry(b));
@@ -641,6 +679,32 @@ int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uin
     return ISX_OK;
 }
 
+int isx_batch_create(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uint8_t *ref, int32_t n_splits,
+                     const int64_t *split_bounds, int64_t n_obs, const isx_obs *obs, const uint32_t *pair,
+                     isx_batch **out)
+{
+    if (!c || !prm || !out || !ref || !split_bounds || n_pos <= 0 || n_splits <= 0 || n_obs < 0 || (n_obs && !obs)) {
+        isx_set_error("isx_batch_create: bad argument");
+        return ISX_ERR_ARG;
+    }
+    return batch_create_impl(c, prm, n_pos, ref, n_splits, split_bounds, n_obs, obs, pair, nullptr, out);
+}
+
+int isx_batch_create_reads(isx_ctx *c, const isx_params *prm, int64_t n_pos, const uint8_t *ref, int32_t n_splits,
+                           const int64_t *split_bounds, const isx_segs *segs, isx_batch **out)
+{
+    if (!c || !prm || !out || !ref || !split_bounds || n_pos <= 0 || n_splits <= 0 || !segs || segs->n_seg < 0 ||
+        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases))) {
+        isx_set_error("isx_batch_create_reads: bad argument");
+        return ISX_ERR_ARG;
+    }
+    if (prm->layout & (ISX_LAYOUT_WIDE_RECORDS | ISX_LAYOUT_NO_SHORT_RECORDS)) { isx_set_error("isx_batch_create_reads: the record layouts apply to observation batches only"); return ISX_ERR_ARG; }
+    if (prm->linkage_mode == 2) { isx_set_error("isx_batch_create_reads: the dense MFMA linkage path takes observation batches only"); return ISX_ERR_ARG; }
+    int64_t n_bases = 0;                            // upper bound of the observations: sizes the linkage tables
+    for (int64_t i = 0; i < segs->n_seg; i++) n_bases += segs->len[i];
+    return batch_create_impl(c, prm, n_pos, ref, n_splits, split_bounds, n_bases, nullptr, nullptr, segs, out);
+}
+
 static float ev_ms(hipEvent_t a, hipEvent_t b)
 {
     float ms = 0.f;
@@ -659,6 +723,7 @@ int launch_pass(isx_batch *b)
     // one-wave kernel k_publish_state copies them to mapped pinned memory right behind the pileup kernel
 
     PileupArgs a{};
+    a.seg = b->d_seg;
     a.rec = b->d_rec; a.rec32 = b->d_rec32; a.rec16 = b->d_rec16; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref;
     a.pair = b->d_pair; a.pair_runs = b->d_pair_runs; a.run_index = b->d_run_index; a.n_runs = b->n_runs; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_rec32 ? b->d_gbase : b->d_cbase; a.gpos16_shift = b->gpos16_shift; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
@@ -748,7 +813,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags)
     b->tim.pileup_threads = b->block;
     b->tim.pileup_lds_bytes = (int32_t)b->lds;
     b->tim.pileup_window = b->W;
-    b->tim.record_bytes = b->d_rec16 ? 2 : (b->d_rec32 ? 4 : 8);
+    b->tim.record_bytes = b->d_seg ? 64 : (b->d_rec16 ? 2 : (b->d_rec32 ? 4 : 8));
 
     if (b->prm.enable_linkage) {
         LinkageIn in{};

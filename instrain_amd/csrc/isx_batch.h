@@ -33,6 +33,7 @@ struct isx_batch {
     int64_t cap_pos = 0, cap_obs = 0;   // pipe slots: what the device buffers were sized for (0 = this batch's own n_pos / n_obs)
     size_t slab_region = 0;             // pipe slots, mm path: entries set aside for the window slabs (0 = n_win * slab)
     bool arena = false;                 // pipe slots: the input arrays live in the slot's arena, not in own allocations
+    bool segs = false;                  // the stream is read segments (d_seg), not observation records
     uint64_t n_rec = 0;         // padded
     uint64_t n_pairs = 0;
     int32_t n_splits = 0;
@@ -42,6 +43,7 @@ struct isx_batch {
     uint2 *d_rec = nullptr;             // wide stream (8-byte isx_obs) -- or:
     uint32_t *d_rec32 = nullptr, *d_gbase = nullptr;    // compact stream (4-byte records + one position base per 256)
     uint16_t *d_rec16 = nullptr;                        // short stream (n_mm_bins == 1: 2-byte records, base per 512)
+    uint4 *d_seg = nullptr;                             // read-segment stream (64-byte records, base per 16; d_pair per record)
     uint32_t *d_pair = nullptr, *d_gpos = nullptr, *d_cbase = nullptr;
     uint2 *d_pair_runs = nullptr;       // pipe slots: pair ids as runs (PileupArgs::pair_runs) instead of d_pair
     uint32_t *d_run_index = nullptr;
@@ -98,7 +100,7 @@ int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed);
 // window -> record range directory from the per-chunk position ranges (prefix-max / suffix-min); returns
 // the longest record range of a window
 uint64_t build_window_directory(const uint32_t *cmin, const uint32_t *cmax, const uint8_t *cany, uint64_t n_chunks, int W,
-                                int64_t n_pos, std::vector<uint2> &win);
+                                int64_t n_pos, std::vector<uint2> &win, uint32_t chunk = ISX_CHUNK);
 
 // derived launch geometry (LDS bytes, persistent grid, row-queue capacity, entry slab) once b->W / b->packed are set
 int batch_set_geometry(isx_batch *b);

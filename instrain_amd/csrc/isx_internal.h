@@ -11,6 +11,10 @@
 #define ISX_GROUP 256                // compact stream: records per position base (one wave-wide 16-byte load)
 #define ISX_CHUNK 1024              // observation directory granule (records)
 #define ISX_DENSE_PAD 8             // k_pileup_dense: extra words per counter row (junk columns of the packed 16-bit decode)
+// read-segment stream (include/instrain_amd.h isx_segs; seg_encode.h): 64-byte records, 16 per position base
+#define ISX_SEG_GROUP 16
+#define ISX_SEG_PAD 32              // k_pileup_dense on segments: extra words per counter row = ISX_SEG_LM columns before position 0 of
+#define ISX_SEG_LM 16               // the window + 16 after its last one: a 10-base word that straddles a window edge needs no per-base test
 #define ISX_PK16_MAX_W 3264         // ... whose byte offsets (5 (W + 8) + 7) * 4 must stay below 65536
 #define ISX_PAD 2048                // the record stream is padded to a multiple of this (whole directory chunks, 16-byte loads)
 #define ISX_SENTINEL 0xFFFFFFFFu    // gpos of padding records (never inside a window)
@@ -125,7 +129,10 @@ struct PileupArgs {
     const uint32_t *gbase;      //     gbase[record / 256] + delta; padding records are ISX_PAD32; or ...
     const uint16_t *rec16;      // ... short stream (n_mm_bins == 1 only; rec, rec32 == NULL): delta:13 | base:3 per record,
                                 //     position = gbase[record / 512] + delta; padding records are 0xFFFF
-    const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK)
+    const uint4 *seg;           // ... read-segment stream (rec, rec32, rec16 == NULL): 64-byte records as four 16-byte quarters, the
+                                //     first word of a record = delta:16 | len:8 | mm:8, start = gbase[record / 16] + delta, then 15 words of
+                                //     ten 3-bit base codes; `pair` (linkage) is indexed by RECORD
+    const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK; of ISX_SEG_GROUP for the segment stream)
     const uint8_t *ref;
     const uint32_t *pair;       // read-pair id per record (linkage only), or NULL and ...
     const uint2 *pair_runs;     // ... runs of equal pair ids: (first device record, pair id), ascending; run_index[c] = the run
@@ -145,6 +152,7 @@ struct PileupArgs {
     int32_t qcap;               // deferred-clonality queue capacity (entries)
     int32_t rqcap;              // mm path: row-queue capacity (positions with SNV rows per window)
     int32_t stage_off;          // allele pass: LDS word offset of the per-wave hit stage (0 = aliases the counters)
+    int32_t pad, lm;            // dense path: counter row stride = W + pad words, position 0 of the window at column lm
     double min_freq;
     // outputs
     uint4 *counts;              // dense path (M == 1): [n_pos]
@@ -185,6 +193,6 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s);
 void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
                          const uint32_t *base16, uint32_t base16_records, uint64_t n_rec, hipStream_t s);
-size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int *stage_off);
+size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int segs, int *stage_off);
 
 struct LinkageBuffers;      // defined in isx_linkage.hip

@@ -333,6 +333,92 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, uint32_t lo, ui
     if (nst) allele_drain(a, st, nst, w0, maskl, slabc, ao_base, lane);
 }
 
+// quad broadcast: every lane of a quad of four gets lane 0's value (the record header sits in the first 16-byte quarter)
+__device__ __forceinline__ uint32_t quad_first(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00 /* quad_perm [0,0,0,0] */, 0xF, 0xF, true);
+}
+
+#define SEG_SKIPW 0x24924924u       // ten codes 4: nothing to count in this word
+
+// update_linked_reads on the read-segment stream: the window's records are walked a second time, but a 10-base word is
+// only opened when the window's SNP-site bitmap has a bit under it (sites are ~1 % of the positions); a qualifying base
+// is staged and drained exactly like allele_pass does.  An allele observation's arrival order (obs_idx) is its RECORD:
+// two observations of one pair at one site come from its two mates, whose records keep the BAM order.
+// lo16, hi16: the window's range in 16-byte quarters (multiples of 64).
+__device__ __forceinline__ void allele_pass_segs(const PileupArgs &a, uint32_t lo16, uint32_t hi16, uint32_t w0, int W,
+                                                 const uint8_t *maskl, uint32_t *slabc, uint32_t ao_base, uint32_t *stage,
+                                                 int tid, int nthr)
+{
+    const int lane = tid & 63;
+    uint32_t *st = stage + (tid >> 6) * 128;
+    uint32_t *sitebits = stage + (nthr >> 6) * 128;         // [W / 32 + 2]
+    for (int p = tid; p < W; p += nthr) {                   // W and nthr are multiples of 64: whole waves
+        const uint64_t bal = __ballot(maskl[p] != 0);
+        if (lane == 0) { sitebits[p >> 5] = (uint32_t)bal; sitebits[(p >> 5) + 1] = (uint32_t)(bal >> 32); }
+    }
+    if (tid < 2) sitebits[(W >> 5) + tid] = 0;
+    __syncthreads();
+    uint32_t nst = 0;
+    auto drain = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < nst) {
+            const uint32_t rec = st[2 * lane], info = st[2 * lane + 1];
+            const uint32_t rel = info & 0xFFFFu;
+            const uint32_t slot = atomicAdd(&slabc[rel], 1u);
+            isx_ao o;
+            o.pair = a.pair[rec]; o.site = w0 + rel; o.obs_idx = rec;
+            o.mm = (uint16_t)(info >> 24); o.base = (uint8_t)((info >> 16) & 7u); o.pad = 0;
+            a.ao[ao_base + slot] = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const uint32_t q = (uint32_t)tid & 3u;
+    for (uint32_t i0 = lo16; i0 < hi16; i0 += (uint32_t)nthr) {
+        const uint32_t i = i0 + (uint32_t)tid;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane(i) >= hi16) break;         // wave-uniform
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.seg) + i);
+        const uint32_t gb = a.gbase[__builtin_amdgcn_readfirstlane(i >> 6)];
+        const uint32_t hdr = quad_first(v.x);
+        const uint32_t mm = a.M > 1 ? hdr >> 24 : 0u;
+        const int32_t r0 = (int32_t)(gb + (hdr & 0xFFFFu) - w0) + (int32_t)(q * 40u) - 10;
+        const uint32_t wd[4] = {q ? v.x : SEG_SKIPW, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int32_t r = r0 + 10 * k;
+            const uint32_t w = wd[k];
+            uint32_t bits = 0;
+            if (w != SEG_SKIPW && (uint32_t)(r + 9) < (uint32_t)(W + 9)) {
+                const int32_t base = r < 0 ? 0 : r;
+                const uint32_t wi = (uint32_t)base >> 5;
+                const uint64_t b64 = (uint64_t)sitebits[wi] | ((uint64_t)sitebits[wi + 1] << 32);
+                bits = ((uint32_t)(b64 >> (base & 31)) << (base - r)) & 0x3FFu;
+            }
+            while (__ballot(bits != 0)) {                                       // wave-uniform
+                const bool has = bits != 0;
+                const int j = has ? __ffs((int)bits) - 1 : 0;
+                bits &= bits - 1u;                                              // 0 stays 0
+                const uint32_t code = (w >> (3 * j)) & 7u;
+                const uint32_t rel = (uint32_t)(r + j);
+                const bool cand = has && code < 4u && ((maskl[has ? rel : 0u] >> code) & 1u);
+                const uint64_t bal = __ballot(cand);
+                if (bal == 0) continue;
+                const uint32_t n = (uint32_t)__popcll(bal);
+                if (nst + n > 64u) { drain(); nst = 0; }
+                if (cand) {
+                    const uint32_t at = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    st[2 * at] = i >> 2;
+                    st[2 * at + 1] = rel | (code << 16) | (mm << 24);
+                }
+                nst += n;
+            }
+        }
+    }
+    if (nst) drain();
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_pileup_dense: the n_mm_bins == 1 (--skip_mm_profiling / --database_mode) specialisation.
 // Persistent workgroups: each walks windows slot, slot + grid, ... so the per-window fixed costs
@@ -344,15 +430,16 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, uint32_t lo, ui
 // the 8 extra words of a row are the junk columns of the packed decode (records that belong to another window), and the
 // queue region -- idle during the stream -- is the junk row of records without an A/C/T/G base.
 // ---------------------------------------------------------------------------------------------
-template <bool LINKAGE, int FMT, bool PK16 = false>   // FMT = bytes per resident record: 8 (isx_obs), 4 (compact), 2 (short);
-__global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)     // PK16: short records decoded two at a time
+template <bool LINKAGE, int FMT, bool PK16 = false>   // FMT = bytes per resident record: 8 (isx_obs), 4 (compact), 2 (short), 64 (read
+__global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)     // segments); PK16: short records decoded two at a time
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     publish_previous(a, tid);
     const int W = a.W;
-    const int S = W + ISX_DENSE_PAD;            // row stride of the counters
-    uint32_t *cnt = lds;
+    constexpr bool SEGS = FMT == 64;
+    const int S = W + (SEGS ? ISX_SEG_PAD : ISX_DENSE_PAD);     // row stride of the counters
+    uint32_t *cnt = lds + (SEGS ? ISX_SEG_LM : 0);              // segments: ISX_SEG_LM margin columns on either side of the window
     uint32_t *queue = lds + 4 * S;
     uint32_t *scratch = queue + S;
     uint16_t *thr_lds = reinterpret_cast<uint16_t *>(scratch + S_N);
@@ -364,8 +451,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
     // COMPACT: 4-byte records (4 per 16-byte load); a wave-wide load covers exactly one ISX_GROUP of 256
     // records, so the group's position base is a scalar load.  Otherwise the 8-byte isx_obs (2 per load).
     constexpr bool COMPACT = FMT != 8;
-    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(FMT == 2 ? (const void *)a.rec16 : (FMT == 4 ? (const void *)a.rec32 : (const void *)a.rec));
-    constexpr int RSH = FMT == 2 ? 3 : (FMT == 4 ? 2 : 1);         // record index -> 16-byte load index
+    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(SEGS ? (const void *)a.seg : (FMT == 2 ? (const void *)a.rec16 : (FMT == 4 ? (const void *)a.rec32 : (const void *)a.rec)));
+    constexpr int RSH = FMT == 2 ? 3 : (FMT == 4 ? 2 : 1);         // record index -> 16-byte load index (segments: a record is FOUR loads)
     const int dbg = a.debug_mode;               // ablation switches (tools/), 0 in production
 
     {   // once per workgroup: folded thresholds of the low coverages
@@ -402,7 +489,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
-            lo = rng.x >> RSH; hi = rng.y >> RSH;
+            if (SEGS) { lo = rng.x << 2; hi = rng.y << 2; } else { lo = rng.x >> RSH; hi = rng.y >> RSH; }
             if (lo < hi) { issue_one(0, lo); issue_one(1, lo); }        // the first half-round; the stream loop issues the rest
         }
     };
@@ -438,6 +525,34 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         // (v_mul_lo_u32 is quarter rate).
         auto count_slot = [&](int u) {
             if (COMPACT && !live[u]) return;        // uniform: the last round of a window is half empty on average
+            if (SEGS) {
+                // Read segments: a quad of lanes holds one 64-byte record, lane q its quarter -- the header (lane 0's first
+                // word, broadcast inside the quad) and three words of ten bases, or four words: bases 40 q - 10 + 10 k ... of
+                // the segment.  A word lies at ten consecutive positions, so its counters are ten consecutive columns (rows
+                // = base code; row 4 -- the idle queue region -- swallows code 4) at one LDS address + immediate offsets:
+                // 2 VALU + one LDS atomic per base and no per-base window test (the margin columns absorb the edge words).
+                const uint32_t q = (uint32_t)tid & 3u;
+                const uint32_t hdr = quad_first(v[u].x);
+                const int32_t r0 = (int32_t)(gb[u] + (hdr & 0xFFFFu) - w0) + (int32_t)(q * 40u) - 10;
+                const uint32_t wd[4] = {q ? v[u].x : SEG_SKIPW, v[u].y, v[u].z, v[u].w};
+                char *lds_b = reinterpret_cast<char *>(lds);
+                const uint32_t S4 = (uint32_t)S * 4u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int32_t r = r0 + 10 * k;
+                    uint32_t w = wd[k];
+                    if (w == SEG_SKIPW || (uint32_t)(r + 9) >= (uint32_t)(W + 9)) continue;
+                    const uint32_t m = w & SEG_SKIPW;                   // codes 5..7 count like 4
+                    w &= ~((m >> 1) | (m >> 2));
+                    const uint32_t a0 = (uint32_t)(r + ISX_SEG_LM) << 2;
+#pragma unroll
+                    for (int j = 0; j < 10; j++) {
+                        const uint32_t code = __builtin_amdgcn_ubfe(w, 3 * j, 3);
+                        atomicAdd(reinterpret_cast<uint32_t *>(lds_b + (__umul24(code, S4) + a0 + 4u * (uint32_t)j)), 1u);
+                    }
+                }
+                return;
+            }
             if (FMT == 2) {
                 const uint32_t bw = gb[u] - w0;
                 const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -630,7 +745,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         if (linkage) {
             if (ok && nao) {
                 __syncthreads();                // every wave is done with cnt: it becomes the allele pass's stage
-                allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                if (SEGS) allele_pass_segs(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                else allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
             prefetch_window(w + grid);
         }
@@ -651,7 +767,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
 // pres = levels made present by a non-ACGT base only (profile_utilities.py:279-285 creates
 // table[mm] before the KeyError), a presence the SNV loop must see.
 // ---------------------------------------------------------------------------------------------
-template <bool PACKED, bool LINKAGE, bool COMPACT>
+template <bool PACKED, bool LINKAGE, bool COMPACT, bool SEGS = false>    // SEGS: the read-segment stream (COMPACT is true then)
 __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -671,7 +787,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
     constexpr bool linkage = LINKAGE;            // compile-time: the linkage-off kernels carry none of the allele pass
     const int grid = gridDim.x, per = grid >> 3;
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
-    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(COMPACT ? (const void *)a.rec32 : (const void *)a.rec);
+    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(SEGS ? (const void *)a.seg : (COMPACT ? (const void *)a.rec32 : (const void *)a.rec));
     constexpr int RSH = COMPACT ? 2 : 1;        // record index -> 16-byte load index (see k_pileup_dense)
     {   // once per workgroup: folded thresholds of the low coverages
         const int n = min(THR_LDS, a.lut_n);
@@ -708,7 +824,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
-            lo = rng.x >> RSH; hi = rng.y >> RSH;
+            if (SEGS) { lo = rng.x << 2; hi = rng.y << 2; } else { lo = rng.x >> RSH; hi = rng.y >> RSH; }
             if (lo < hi) { issue_one(0, lo); issue_one(1, lo); }
         }
     };
@@ -733,6 +849,36 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         uint32_t bad_mm = 0;
         auto count_slot = [&](int u) {
             const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (SEGS) {
+                // read segments (see k_pileup_dense): lane q of a quad walks the words of its quarter of the record; the mm
+                // level is the record's, so a word's ten counters are ten consecutive columns of the level's rows
+                const uint32_t q = (uint32_t)tid & 3u;
+                const uint32_t hdr = quad_first(x[0]);
+                const uint32_t mm = hdr >> 24;
+                if (((hdr >> 16) & 0xFFu) == 0) return;                 // padding record / a slot the wave did not load
+                if (mm >= (uint32_t)M) { bad_mm = 1; return; }
+                const int32_t r0 = (int32_t)(gb[u] + (hdr & 0xFFFFu) - w0) + (int32_t)(q * 40u) - 10;
+                const uint32_t rowb = __umul24(mm * (PACKED ? 2u : 4u), (uint32_t)W);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int32_t r = r0 + 10 * k;
+                    const uint32_t wv = (k == 0 && q == 0) ? SEG_SKIPW : x[k];
+                    if (wv == SEG_SKIPW || (uint32_t)(r + 9) >= (uint32_t)(W + 9)) continue;
+#pragma unroll
+                    for (int j = 0; j < 10; j++) {
+                        const uint32_t code = __builtin_amdgcn_ubfe(wv, 3 * j, 3);
+                        const uint32_t rel = (uint32_t)(r + j);
+                        if (rel >= (uint32_t)W) continue;
+                        if (code < 4u) {
+                            if (PACKED) atomicAdd(&cnt[rowb + __umul24(code >> 1, (uint32_t)W) + rel], 1u << (16 * (code & 1)));
+                            else atomicAdd(&cnt[rowb + __umul24(code, (uint32_t)W) + rel], 1u);
+                        } else if (code == 5u) {                        // a base that is not A/C/T/G: the level is present here
+                            atomicOr(&pres[__umul24(mm >> 5, (uint32_t)W) + rel], 1u << (mm & 31));
+                        }
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int h = 0; h < (COMPACT ? 4 : 2); h++) {
                 uint32_t rel, base, mm;
@@ -957,7 +1103,8 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         if (linkage) {
             if (ok && nao) {
                 __syncthreads();                // every wave is done with the counters: they become the stage
-                allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                if (SEGS) allele_pass_segs(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                else allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
             prefetch_window(w + grid);
         }
@@ -968,10 +1115,11 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 
 }  // namespace
 
-size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int *stage_off)
+size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int segs, int *stage_off)
 {
     size_t words, cnt_words;
-    if (M == 1) { cnt_words = (size_t)4 * (W + ISX_DENSE_PAD); words = (size_t)5 * (W + ISX_DENSE_PAD) + S_N + THR_LDS / 2; }
+    const int pad = segs ? ISX_SEG_PAD : ISX_DENSE_PAD;
+    if (M == 1) { cnt_words = (size_t)4 * (W + pad); words = (size_t)5 * (W + pad) + S_N + THR_LDS / 2; }
     else {
         cnt_words = (size_t)M * (packed ? 2 : 4) * W;
         words = cnt_words + (size_t)((M + 31) / 32) * W + S_N + (size_t)qcap * 2 + (size_t)rqcap * 4 + THR_LDS / 2;
@@ -980,7 +1128,7 @@ size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int pack
     if (stage_off) *stage_off = 0;
     if (linkage) {
         bytes += (size_t)W * 5;                 // slabc[W] + maskl[W]
-        const size_t stage_words = (size_t)(block / 64) * 128;      // allele pass: 64 two-word entries per wave
+        const size_t stage_words = (size_t)(block / 64) * 128 + (segs ? (size_t)W / 32 + 2 : 0);   // allele pass: 64 two-word entries per wave (+ the segment walk's site bitmap)
         if (cnt_words < stage_words) {          // small windows: the counters cannot host the stage
             bytes = (bytes + 15) & ~(size_t)15;
             if (stage_off) *stage_off = (int)(bytes / 4);
@@ -1006,7 +1154,14 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
 {
     const LaunchCfg l{block, lds, grid, s, ev_start, ev_stop};
     const int sel = (a.enable_linkage != 0 ? 1 : 0) | (a.rec32 ? 2 : 0) | (packed ? 4 : 0);
-    if (a.M > 1) {
+    if (a.M > 1 && a.seg) {
+        switch (sel & 5) {
+        case 0: launch_one(k_pileup_mm<false, false, true, true>, a, l); break;
+        case 1: launch_one(k_pileup_mm<false, true, true, true>, a, l); break;
+        case 4: launch_one(k_pileup_mm<true, false, true, true>, a, l); break;
+        default: launch_one(k_pileup_mm<true, true, true, true>, a, l); break;
+        }
+    } else if (a.M > 1) {
         switch (sel) {
         case 0: launch_one(k_pileup_mm<false, false, false>, a, l); break;
         case 1: launch_one(k_pileup_mm<false, true, false>, a, l); break;
@@ -1019,6 +1174,7 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
         }
     } else {
         const bool link = a.enable_linkage != 0;
+        if (a.seg) { if (link) launch_one(k_pileup_dense<true, 64>, a, l); else launch_one(k_pileup_dense<false, 64>, a, l); return; }
 #ifndef ISX_NO_PK16
         if (a.rec16 && a.W <= ISX_PK16_MAX_W) { if (link) launch_one(k_pileup_dense<true, 2, true>, a, l); else launch_one(k_pileup_dense<false, 2, true>, a, l); }
         else

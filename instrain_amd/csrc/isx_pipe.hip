@@ -31,6 +31,7 @@
 #include "bam_front.h"
 #include "isx_batch.h"
 #include "obs_encode.h"
+#include "seg_encode.h"
 #include "isx_summary.h"
 
 namespace {
@@ -64,6 +65,7 @@ struct Slot {
     uint8_t *h_in = nullptr, *d_in = nullptr;
     size_t in_bytes = 0;                    // of the device arena; the pinned one ends after the ring when the pipe stages through one
     size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_ridx = 0, off_rec = 0;   // records last
+    size_t off_pairs = 0;                   // read-level pipe + linkage: one pair id per record (between the group bases and the records)
     // pair-id runs (linkage): their own pinned / device blocks, grown when a batch has more runs than any before it
     isxenc::PairRun *h_runs = nullptr;
     bool runs_pinned = true;
@@ -133,6 +135,7 @@ struct isx_pipe {
     int64_t cap_rec = 0;
     int64_t ring_half = 0;                  // records per half of a slot's staging ring; 0 = the pinned arena holds the whole stream
     int rb = 2;                             // record bytes
+    bool segs = false;                      // a read-level pipe: 64-byte read-segment records (isx_pipe_params.max_segs > 0)
     uint32_t G = ISX_GROUP16;
     size_t snv_prefix = 0;                  // SNV rows copied out with the dense tables
     size_t rare_prefix = 0, cap_rare = 0;   // clonTR entries copied out with them / the device list's capacity
@@ -165,6 +168,7 @@ static void pipe_free(isx_pipe *p)
         double t_x = now_ms();
         if (s.b) {
             isx_batch *b = s.b;             // the input arrays belong to the arena, not to the batch
+            b->d_seg = nullptr;
             b->d_rec = nullptr; b->d_rec32 = nullptr; b->d_rec16 = nullptr; b->d_gbase = nullptr; b->d_pair = nullptr;
             b->d_pair_runs = nullptr; b->d_run_index = nullptr;
             b->d_gpos = nullptr; b->d_gpos16 = nullptr; b->d_cbase = nullptr; b->d_ref = nullptr; b->d_win = nullptr;
@@ -202,6 +206,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     b->ps = index & 1;
     b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true;
     b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
+    b->segs = p->segs;
     const bool dense = b->M == 1;
     batch_pick_block(b);
     const int64_t cap_pos = p->pp.max_pos;
@@ -253,7 +258,8 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.off_win = o; o = up(o + ((size_t)cap_pos / 64 + 2) * sizeof(uint2));
     s.off_ref = o; o = up(o + (size_t)cap_pos);
     s.off_gbase = o; o = up(o + ((size_t)(p->cap_rec / p->G) + ISX_TAIL_GROUPS) * sizeof(uint32_t));
-    s.off_ridx = o; if (prm->enable_linkage) o = up(o + ((size_t)p->cap_rec / ISX_CHUNK + 2) * sizeof(uint32_t));
+    s.off_ridx = o; if (prm->enable_linkage && !p->segs) o = up(o + ((size_t)p->cap_rec / ISX_CHUNK + 2) * sizeof(uint32_t));
+    s.off_pairs = o; if (prm->enable_linkage && p->segs) o = up(o + (size_t)p->cap_rec * sizeof(uint32_t));
     s.off_rec = o;
     s.in_bytes = up(o + (size_t)p->cap_rec * p->rb + ISX_TAIL_BYTES);
     const size_t host_bytes = p->ring_half ? up(o + 2 * (size_t)p->ring_half * p->rb) : s.in_bytes;
@@ -264,7 +270,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     if (getenv("ISX_PIPE_TIMING"))
         fprintf(stderr, "[isx_pipe_create] slot %d: device tables %.1f ms, pinned input %.1f MB %.1f ms, device arena %.1f MB %.1f ms\n", index,
                 t_a0 - t_s0, host_bytes / 1e6, t_a1 - t_a0, s.in_bytes / 1e6, now_ms() - t_a1);
-    if (prm->enable_linkage) {
+    if (prm->enable_linkage && !p->segs) {
         // a read pair's records are consecutive: runs of tens to hundreds of records
         s.cap_runs = (size_t)p->cap_rec / 64 + 4096;
         s.runs_pinned = p->pp.depth > 1;
@@ -294,7 +300,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     { const int hrc = host_block_alloc(reinterpret_cast<void **>(&s.h_out), s.out_bytes, s.out_pinned); if (hrc != ISX_OK) return hrc; }
     if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_create] slot %d: %s results %.1f MB %.1f ms\n", index, s.out_pinned ? "pinned" : "pageable", s.out_bytes / 1e6, now_ms() - t_o0);
     for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_pass, &s.ev_d2h0, &s.ev_d2h1}) HIP_TRY(hipEventCreate(e));
-    const size_t n_chunks = (size_t)(p->cap_rec / ISX_CHUNK) + 2;
+    const size_t n_chunks = (size_t)(p->cap_rec / (p->segs ? ISX_SEG_GROUP : ISX_CHUNK)) + 2;
     s.cmin.resize(n_chunks); s.cmax.resize(n_chunks); s.cany.resize(n_chunks);
     return ISX_OK;
 }
@@ -412,23 +418,35 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     *out = nullptr;
     if (!c->d_lut) { isx_set_error("isx_pipe_create: call isx_set_null_model first"); return ISX_ERR_STATE; }
     if (prm->n_mm_bins < 1 || prm->n_mm_bins > 128) { isx_set_error("n_mm_bins must be in [1, 128]"); return ISX_ERR_ARG; }
-    if (pp->max_pos <= 0 || pp->max_obs < 0 || pp->max_splits <= 0 || pp->depth < 1 || pp->depth > 64) {
-        isx_set_error("isx_pipe_create: max_pos > 0, max_obs >= 0, max_splits > 0, 1 <= depth <= 64");
+    if (pp->max_pos <= 0 || pp->max_obs < 0 || pp->max_splits <= 0 || pp->depth < 1 || pp->depth > 64 || pp->max_segs < 0) {
+        isx_set_error("isx_pipe_create: max_pos > 0, max_obs >= 0, max_segs >= 0, max_splits > 0, 1 <= depth <= 64");
         return ISX_ERR_ARG;
     }
+    if (pp->max_segs > 0 && prm->linkage_mode == 2) { isx_set_error("isx_pipe_create: the dense MFMA linkage path takes observation batches only"); return ISX_ERR_ARG; }
     if (pp->max_pos >= (int64_t)0xFFFF0000ll) { isx_set_error("flat position space must be < 2^32 - 65536"); return ISX_ERR_ARG; }
     if (prm->window && (prm->window < 64 || (prm->window & 63) || prm->window > 8192)) { isx_set_error("window must be a multiple of 64 in [64, 8192]"); return ISX_ERR_ARG; }
     if (prm->layout & ISX_LAYOUT_WIDE_RECORDS) { isx_set_error("a pipe streams 2- / 4-byte records only"); return ISX_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     isx_pipe *p = new isx_pipe();
     p->ctx = c; p->prm = *prm; p->pp = *pp;
-    p->rb = (prm->n_mm_bins == 1 && !(prm->layout & ISX_LAYOUT_NO_SHORT_RECORDS)) ? 2 : 4;
-    p->G = p->rb == 2 ? ISX_GROUP16 : ISX_GROUP;
+    p->segs = pp->max_segs > 0;
+    p->rb = p->segs ? 64 : ((prm->n_mm_bins == 1 && !(prm->layout & ISX_LAYOUT_NO_SHORT_RECORDS)) ? 2 : 4);
+    p->G = p->segs ? ISX_SEG_GROUP : (p->rb == 2 ? ISX_GROUP16 : ISX_GROUP);
     const double js = pp->jump_slack > 0 ? pp->jump_slack : 0.25;
-    const uint64_t want = (uint64_t)((double)pp->max_obs * (1.0 + js)) + 4 * ISX_PAD;
-    p->cap_rec = (int64_t)((want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
-    if ((uint64_t)p->cap_rec >= 0xFFFFFFFFull) { delete p; isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
-    {   // staging: the whole stream in pinned memory, or -- pinning gigabytes costs about a second per 4 GB, more than
+    if (p->segs) {
+        // groups of 16 records; a group is closed early where the stream jumps >= 65536 positions (at most once per 64 Ki
+        // positions and per scaffold in a position-sorted stream) and at the end of every encoder task
+        if (p->pp.max_obs == 0) p->pp.max_obs = pp->max_segs * ISX_SEG_BASES;
+        const uint64_t groups = (uint64_t)(pp->max_segs + ISX_SEG_GROUP - 1) / ISX_SEG_GROUP + (uint64_t)pp->max_segs / 4096 + (uint64_t)pp->max_pos / 65536 +
+                                (uint64_t)pp->max_splits + 64 + (uint64_t)((double)pp->max_segs / ISX_SEG_GROUP * js * 0.25);
+        p->cap_rec = (int64_t)groups * ISX_SEG_GROUP;
+        if ((uint64_t)p->cap_rec >= (1ull << 26)) { delete p; isx_set_error("more than 2^26 segment records in one batch (4 GiB of records)"); return ISX_ERR_ARG; }
+    } else {
+        const uint64_t want = (uint64_t)((double)pp->max_obs * (1.0 + js)) + 4 * ISX_PAD;
+        p->cap_rec = (int64_t)((want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
+        if ((uint64_t)p->cap_rec >= 0xFFFFFFFFull) { delete p; isx_set_error("more than 2^32 records in one batch"); return ISX_ERR_ARG; }
+    }
+    if (!p->segs) {   // staging: the whole stream in pinned memory, or -- pinning gigabytes costs about a second per 4 GB, more than
         // profiling them -- waves through a ring of two halves that the copy engine drains while the threads fill
         const size_t rec_bytes = (size_t)p->cap_rec * p->rb;
         size_t ring = 0;
@@ -474,6 +492,69 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
 
 void isx_pipe_destroy(isx_pipe *p) { pipe_free(p); }
 
+// the pass queue and the copy-out queue of a slot whose copy-in has been enqueued (s.ev_h2d1 recorded), then the
+// hand-over to the finisher
+static int enqueue_pass(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticket)
+{
+    isx_ctx *c = p->ctx;
+    isx_batch *b = s.b;
+    const bool dense = b->M == 1, linkage = p->prm.enable_linkage != 0;
+    hipStream_t ps = c->pstream[b->ps];
+    int rc = ISX_OK;
+    // ---- pass queue ----
+    std::unique_lock<std::mutex> launch_lk(p->launch_mu);
+    HIP_TRY(hipStreamWaitEvent(ps, s.ev_h2d1, 0));
+    if (dense && p->prm.rarefied_coverage > 0)
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)n_pos, ps));
+    if (linkage && p->rb == 4)
+        launch_extract_gpos(nullptr, b->d_rec32, b->d_gbase, nullptr, b->d_gpos16, b->d_gbase, ISX_GROUP, b->n_rec, ps);
+    if ((rc = launch_pass(b)) != ISX_OK) return rc;
+    {   // cursors -> mapped host state right behind the kernel: the copy-out below needs no host round trip
+        PileupArgs pa{};
+        pa.cursors = b->d_cursors; pa.host_state = b->d_host_state;
+        launch_publish_state(pa, b->epoch, ps);
+        b->publish_enqueued = true;
+        if (c->unpublished[b->ps] == b) c->unpublished[b->ps] = nullptr;
+    }
+    HIP_TRY(hipEventRecord(s.ev_pass, ps));
+
+    // ---- copy-out queue ----
+    HIP_TRY(hipStreamWaitEvent(p->s_d2h, s.ev_pass, 0));
+    HIP_TRY(hipEventRecord(s.ev_d2h0, p->s_d2h));
+    const size_t snv_rows = std::min(p->snv_prefix, b->cap_snv);
+    HIP_TRY(hipMemcpyAsync(s.h_out + s.o_snv, b->d_snv, snv_rows * sizeof(isx_snv), hipMemcpyDeviceToHost, p->s_d2h));
+    s.d2h_bytes = (int64_t)(snv_rows * sizeof(isx_snv));
+    if (dense) {
+        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_cov16, b->d_cov16, (size_t)n_pos * 2, hipMemcpyDeviceToHost, p->s_d2h));
+        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clon, b->d_clon, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
+        s.d2h_bytes += (int64_t)n_pos * 6;
+        if (p->prm.rarefied_coverage > 0) {
+            const size_t n = std::min(p->rare_prefix, std::min(p->cap_rare, (size_t)n_pos));
+            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_rare, b->d_rare, n * sizeof(isx_rare), hipMemcpyDeviceToHost, p->s_d2h));
+            s.d2h_bytes += (int64_t)(n * sizeof(isx_rare));
+        }
+        if (p->pp.want_counts) {
+            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_counts, b->d_counts, (size_t)n_pos * 16, hipMemcpyDeviceToHost, p->s_d2h));
+            s.d2h_bytes += (int64_t)n_pos * 16;
+            if (p->prm.rarefied_coverage > 0) {
+                HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clonr, b->d_clon_r, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
+                s.d2h_bytes += (int64_t)n_pos * 4;
+            }
+        }
+    }
+    HIP_TRY(hipEventRecord(s.ev_d2h1, p->s_d2h));
+    launch_lk.unlock();
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        s.ticket = p->next_ticket++;
+        s.state = 1; s.rc = ISX_OK;
+        *ticket = s.ticket;
+        p->work.push_back(s.ticket);
+    }
+    p->cv_work.notify_one();
+    return ISX_OK;
+}
+
 // the common part of a submit: `J` arrives with its input side set (arrays, or a producer), everything else happens here
 static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
                          int64_t n_obs, isxenc::EncodeJob &J, int64_t *ticket)
@@ -486,7 +567,10 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     for (int i = 0; i < n_splits; i++)
         if (split_bounds[i + 1] <= split_bounds[i]) { isx_set_error("split_bounds must be strictly ascending"); return ISX_ERR_ARG; }
     Slot &s = p->slots[(size_t)(p->next_ticket % (int64_t)p->slots.size())];
-    if (s.state != 0) { isx_set_error("isx_pipe_submit: every slot is in use (collect + release the oldest batch first)"); return ISX_ERR_STATE; }
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (s.state != 0) { isx_set_error("isx_pipe_submit: every slot is in use (collect + release the oldest batch first)"); return ISX_ERR_STATE; }
+    }
     isx_ctx *c = p->ctx;
     isx_batch *b = s.b;
     HIP_TRY(hipSetDevice(c->device));
@@ -603,7 +687,6 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
                 t_enc - t0, J.passes, now_ms() - t_enc, (long long)n_obs, (long long)J.n_runs);
 
     // ---- copy-in queue ----
-    hipStream_t ps = c->pstream[b->ps];
     if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
     const size_t head = s.off_ref + (size_t)n_pos;                         // bounds | windows | reference codes
     // the stream is followed by a tail of padding records / zero bases (see ISX_TAIL_BYTES): the slot's arena still
@@ -630,58 +713,124 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     }
     HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
 
-    // ---- pass queue ----
-    std::unique_lock<std::mutex> launch_lk(p->launch_mu);
-    HIP_TRY(hipStreamWaitEvent(ps, s.ev_h2d1, 0));
-    if (dense && p->prm.rarefied_coverage > 0)
-        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)n_pos, ps));
-    if (linkage && p->rb == 4)
-        launch_extract_gpos(nullptr, b->d_rec32, b->d_gbase, nullptr, b->d_gpos16, b->d_gbase, ISX_GROUP, b->n_rec, ps);
-    if ((rc = launch_pass(b)) != ISX_OK) return rc;
-    {   // cursors -> mapped host state right behind the kernel: the copy-out below needs no host round trip
-        PileupArgs pa{};
-        pa.cursors = b->d_cursors; pa.host_state = b->d_host_state;
-        launch_publish_state(pa, b->epoch, ps);
-        b->publish_enqueued = true;
-        if (c->unpublished[b->ps] == b) c->unpublished[b->ps] = nullptr;
-    }
-    HIP_TRY(hipEventRecord(s.ev_pass, ps));
+    return enqueue_pass(p, s, n_pos, ticket);
+}
 
-    // ---- copy-out queue ----
-    HIP_TRY(hipStreamWaitEvent(p->s_d2h, s.ev_pass, 0));
-    HIP_TRY(hipEventRecord(s.ev_d2h0, p->s_d2h));
-    const size_t snv_rows = std::min(p->snv_prefix, b->cap_snv);
-    HIP_TRY(hipMemcpyAsync(s.h_out + s.o_snv, b->d_snv, snv_rows * sizeof(isx_snv), hipMemcpyDeviceToHost, p->s_d2h));
-    s.d2h_bytes = (int64_t)(snv_rows * sizeof(isx_snv));
-    if (dense) {
-        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_cov16, b->d_cov16, (size_t)n_pos * 2, hipMemcpyDeviceToHost, p->s_d2h));
-        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clon, b->d_clon, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
-        s.d2h_bytes += (int64_t)n_pos * 6;
-        if (p->prm.rarefied_coverage > 0) {
-            const size_t n = std::min(p->rare_prefix, std::min(p->cap_rare, (size_t)n_pos));
-            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_rare, b->d_rare, n * sizeof(isx_rare), hipMemcpyDeviceToHost, p->s_d2h));
-            s.d2h_bytes += (int64_t)(n * sizeof(isx_rare));
-        }
-        if (p->pp.want_counts) {
-            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_counts, b->d_counts, (size_t)n_pos * 16, hipMemcpyDeviceToHost, p->s_d2h));
-            s.d2h_bytes += (int64_t)n_pos * 16;
-            if (p->prm.rarefied_coverage > 0) {
-                HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clonr, b->d_clon_r, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
-                s.d2h_bytes += (int64_t)n_pos * 4;
-            }
-        }
+// a read-level batch: `J` arrives with its input side set (isx_segs arrays, or a producer + the segment starts)
+static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                              isxenc::SegJob &J, int64_t *ticket)
+{
+    if (n_pos > p->pp.max_pos || J.n_seg > p->pp.max_segs || n_splits > p->pp.max_splits) {
+        isx_set_error("isx_pipe_submit_reads: batch larger than the pipe was created for");
+        return ISX_ERR_CAPACITY;
     }
-    HIP_TRY(hipEventRecord(s.ev_d2h1, p->s_d2h));
-    launch_lk.unlock();
+    if (split_bounds[0] != 0 || split_bounds[n_splits] != n_pos) { isx_set_error("split_bounds must span [0, n_pos]"); return ISX_ERR_ARG; }
+    for (int i = 0; i < n_splits; i++)
+        if (split_bounds[i + 1] <= split_bounds[i]) { isx_set_error("split_bounds must be strictly ascending"); return ISX_ERR_ARG; }
+    Slot &s = p->slots[(size_t)(p->next_ticket % (int64_t)p->slots.size())];
     {
         std::lock_guard<std::mutex> lk(p->mu);
-        s.ticket = p->next_ticket++;
-        s.state = 1; s.rc = ISX_OK;
-        *ticket = s.ticket;
-        p->work.push_back(s.ticket);
+        if (s.state != 0) { isx_set_error("isx_pipe_submit_reads: every slot is in use (collect + release the oldest batch first)"); return ISX_ERR_STATE; }
     }
-    p->cv_work.notify_one();
-    return ISX_OK;
+    isx_ctx *c = p->ctx;
+    isx_batch *b = s.b;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool dense = b->M == 1, linkage = p->prm.enable_linkage != 0;
+
+    // ---- host threads: records + group bases (+ pair ids) into pinned staging, reference codes, bounds ----
+    const double t0 = now_ms();
+    J.n_pos = n_pos; J.n_mm_bins = b->M;
+    J.rec = reinterpret_cast<uint32_t *>(s.h_in + s.off_rec);
+    J.gbase = reinterpret_cast<uint32_t *>(s.h_in + s.off_gbase);
+    J.pair_out = linkage ? reinterpret_cast<uint32_t *>(s.h_in + s.off_pairs) : nullptr;
+    J.cmin = s.cmin.data(); J.cmax = s.cmax.data(); J.cany = s.cany.data();
+    J.cap_rec = p->cap_rec;
+    const int erc = isxenc::encode_segs(*p->pool, J);
+    const double t_enc = now_ms();
+    if (erc == isxenc::SEG_CAPACITY) { isx_set_error("isx_pipe_submit_reads: the stream jumps too often for the pipe's record capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
+    if (erc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
+    if (erc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
+    if (erc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
+    if (J.n_bases > p->pp.max_obs) { isx_set_error("isx_pipe_submit_reads: more bases than the pipe's max_obs"); return ISX_ERR_CAPACITY; }
+    {
+        const int64_t piece = (int64_t)4 << 20;
+        const int n_tasks = (int)((n_pos + piece - 1) / piece);
+        uint8_t *dst = s.h_in + s.off_ref;
+        auto cp = [&](int t) {
+            const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
+            memcpy(dst + a, ref + a, (size_t)(e - a));
+        };
+        if (n_tasks > 1) p->pool->run(n_tasks, cp); else cp(0);
+    }
+    memcpy(s.h_in + s.off_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t));
+
+    // ---- this batch's geometry ----
+    b->n_pos = n_pos; b->n_obs = J.n_bases; b->n_splits = n_splits; b->n_rec = (uint64_t)J.n_rec;
+    b->n_pairs = (uint64_t)J.max_pair + 1;
+    const uint64_t n_chunks = b->n_rec / ISX_SEG_GROUP;
+    b->packed = 0;
+    int W = batch_window_for(b, n_pos, false);
+    if (!dense) {
+        const int Wp = batch_window_for(b, n_pos, true);
+        if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
+            build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win, ISX_SEG_GROUP) < 65536) { b->packed = 1; W = Wp; }
+    }
+    if (!b->packed) build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, W, n_pos, s.win, ISX_SEG_GROUP);
+    b->W = W;
+    b->n_win = (int)s.win.size();
+    if (s.win.size() > (size_t)p->pp.max_pos / 64 + 2) { isx_set_error("internal: window directory larger than the arena"); return ISX_ERR_STATE; }
+    int rc = batch_set_geometry(b);
+    if (rc != ISX_OK) return rc;
+    if (!dense) {
+        const size_t used = (size_t)b->n_win * b->slab;
+        if (used > b->slab_region) { isx_set_error("internal: entry slabs larger than the slot's region"); return ISX_ERR_STATE; }
+        b->cap_ovf = b->cap_entries - used;
+    }
+    memcpy(s.h_in + s.off_win, s.win.data(), s.win.size() * sizeof(uint2));
+    b->d_bounds = reinterpret_cast<int64_t *>(s.d_in + s.off_bounds);
+    b->d_win = reinterpret_cast<uint2 *>(s.d_in + s.off_win);
+    b->d_ref = s.d_in + s.off_ref;
+    b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
+    b->d_seg = reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
+    b->d_rec16 = nullptr; b->d_rec32 = nullptr;
+    b->d_pair = linkage ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pairs) : nullptr;
+    b->d_pair_runs = nullptr; b->d_run_index = nullptr; b->n_runs = 0;
+    s.encode_ms = (float)(now_ms() - t0);
+    s.encode_passes = 1;
+    if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
+        fprintf(stderr, "[isx_pipe_submit_reads] records %.2f ms, reference + bounds + windows %.2f ms; %lld segments, %lld records\n",
+                t_enc - t0, now_ms() - t_enc, (long long)J.n_seg, (long long)J.n_rec);
+
+    // ---- copy-in queue: bounds | windows | reference codes, then group bases (| pair ids) | records ----
+    HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+    const size_t head = s.off_ref + (size_t)n_pos;
+    const size_t gb_bytes = (size_t)(b->n_rec / ISX_SEG_GROUP) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * 64;
+    HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, head, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
+    if (linkage) {
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, s.h_in + s.off_pairs, (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, p->s_h2d));
+        s.h2d_bytes += (int64_t)b->n_rec * 4;
+    }
+    HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
+    return enqueue_pass(p, s, n_pos, ticket);
+}
+
+int isx_pipe_submit_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                          const isx_segs *segs, int64_t *ticket)
+{
+    if (!p || !ref || !split_bounds || !ticket || n_pos <= 0 || n_splits <= 0 || !segs || segs->n_seg < 0 ||
+        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases))) {
+        isx_set_error("isx_pipe_submit_reads: bad argument");
+        return ISX_ERR_ARG;
+    }
+    if (!p->segs) { isx_set_error("isx_pipe_submit_reads: not a read-level pipe (isx_pipe_params.max_segs == 0)"); return ISX_ERR_STATE; }
+    if (p->prm.enable_linkage && segs->n_seg && !segs->pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
+    isxenc::SegJob J;
+    J.in = *segs; J.n_seg = segs->n_seg;
+    if (!p->prm.enable_linkage) J.in.pair = nullptr;
+    return submit_segs_common(p, n_pos, ref, n_splits, split_bounds, J, ticket);
 }
 
 int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
@@ -692,6 +841,7 @@ int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_sp
         return ISX_ERR_ARG;
     }
     if (p->prm.enable_linkage && n_obs && !pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
+    if (p->segs) { isx_set_error("isx_pipe_submit: a read-level pipe takes isx_pipe_submit_reads / isx_pipe_submit_bam"); return ISX_ERR_STATE; }
     isxenc::EncodeJob J;
     J.obs = obs; J.pair = p->prm.enable_linkage ? pair : nullptr;
     static const isx_obs none{};

@@ -255,4 +255,60 @@ int isx_synth_generate(const isx_synth_params *p, const int32_t *genome_sel, int
     return 0;
 }
 
+
+// ---- observation stream -> read segments (include/instrain_amd.h isx_segs) ----
+// What the read-level hand-over ships for the same workload: consecutive observations of one read pair / mm level at
+// ascending positions less than 150 columns from the first become one segment (missing columns = code 4).  Any stream is
+// legal input (a segment only ever grows by the observation that follows it, so the segments keep the arrival order); a
+// read-major stream -- what the generator above and the BAM front end emit -- gives one segment per read.
+// Two calls: n_seg first (seg_gpos == NULL), then the arrays.  base >= 4 (a non-ACGT base) becomes code 5.
+int64_t isx_synth_obs_to_segs(const synth_obs *obs, const uint32_t *pair, int64_t n_obs, uint32_t *seg_gpos, uint8_t *seg_len,
+                              uint8_t *seg_mm, uint32_t *seg_pair, uint32_t *seg_bases, int32_t threads)
+{
+    auto starts_new = [&](int64_t i, uint32_t seg_start) {
+        if (i == 0) return true;
+        if (pair && pair[i] != pair[i - 1]) return true;
+        if (obs[i].mm != obs[i - 1].mm) return true;
+        if (obs[i].gpos <= obs[i - 1].gpos) return true;
+        return obs[i].gpos - seg_start >= 150u;
+    };
+    // pass 1 (sequential: a segment's start decides where the next one begins): first observation of every segment
+    std::vector<int64_t> first;
+    first.reserve((size_t)(n_obs / 100 + 16));
+    uint32_t st = 0;
+    for (int64_t i = 0; i < n_obs; i++)
+        if (starts_new(i, st)) { st = obs[i].gpos; first.push_back(i); }
+    const int64_t n_seg = (int64_t)first.size();
+    if (!seg_gpos) return n_seg;
+    first.push_back(n_obs);
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t s0 = next.fetch_add(4096);
+            if (s0 >= n_seg) break;
+            const int64_t s1 = std::min<int64_t>(n_seg, s0 + 4096);
+            for (int64_t sgi = s0; sgi < s1; sgi++) {
+                const int64_t a = first[(size_t)sgi], e = first[(size_t)sgi + 1];
+                const uint32_t g0 = obs[a].gpos;
+                uint32_t *w = seg_bases + (size_t)sgi * 15;
+                for (int k = 0; k < 15; k++) w[k] = 0x24924924u;
+                for (int64_t i = a; i < e; i++) {
+                    const uint32_t j = obs[i].gpos - g0, code = obs[i].base < 4 ? obs[i].base : 5u;
+                    w[j / 10] = (w[j / 10] & ~(7u << (3 * (j % 10)))) | (code << (3 * (j % 10)));
+                }
+                seg_gpos[sgi] = g0;
+                seg_len[sgi] = (uint8_t)(obs[e - 1].gpos - g0 + 1);
+                if (seg_mm) seg_mm[sgi] = (uint8_t)std::min<uint32_t>(255u, obs[a].mm);
+                if (seg_pair) seg_pair[sgi] = pair ? pair[a] : 0u;
+            }
+        }
+    };
+    const int nt = std::max(1, threads);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    return n_seg;
+}
+
 }  // extern "C"

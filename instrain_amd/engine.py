@@ -19,6 +19,46 @@ def pack_obs(gpos, base, mm):
     return o
 
 
+class SegBatch:
+    """Read segments of a batch (isx_segs): gpos u32 [n], len u8 [n], mm u8 [n] | None, pair u32 [n] | None,
+    bases u32 [n, 15] (ten 3-bit codes per word).  Keeps the arrays alive for the ctypes view."""
+
+    def __init__(self, gpos, length, bases, mm=None, pair=None):
+        self.gpos = np.ascontiguousarray(gpos, dtype=np.uint32)
+        self.len = np.ascontiguousarray(length, dtype=np.uint8)
+        self.bases = np.ascontiguousarray(bases, dtype=np.uint32).reshape(-1, _lib.SEG_WORDS)
+        self.mm = None if mm is None else np.ascontiguousarray(mm, dtype=np.uint8)
+        self.pair = None if pair is None else np.ascontiguousarray(pair, dtype=np.uint32)
+        n = len(self.gpos)
+        assert len(self.len) == n and len(self.bases) == n
+        assert self.mm is None or len(self.mm) == n
+        assert self.pair is None or len(self.pair) == n
+        self.n_seg = n
+
+    def c(self, with_pair=True):
+        ptr = lambda a: a.ctypes.data if a is not None and len(a) else None
+        return _lib.Segs(self.n_seg, ptr(self.gpos), ptr(self.len), ptr(self.mm), ptr(self.pair) if with_pair else None,
+                         ptr(self.bases))
+
+    @property
+    def n_bases(self):
+        return int(self.len.sum(dtype=np.int64))
+
+
+def pack_codes(codes):
+    """[n, 150] uint8 base codes (0..3 A C T G, 4 skip, 5 non-ACGT) -> [n, 15] uint32, ten codes per word"""
+    c = np.ascontiguousarray(codes, dtype=np.uint32).reshape(-1, _lib.SEG_WORDS, 10)
+    sh = (3 * np.arange(10, dtype=np.uint32))[None, None, :]
+    return (c << sh).sum(axis=2, dtype=np.uint32)
+
+
+def unpack_codes(bases):
+    """inverse of pack_codes: [n, 15] uint32 -> [n, 150] uint8"""
+    b = np.ascontiguousarray(bases, dtype=np.uint32).reshape(-1, _lib.SEG_WORDS, 1)
+    sh = (3 * np.arange(10, dtype=np.uint32))[None, None, :]
+    return ((b >> sh) & 7).astype(np.uint8).reshape(-1, _lib.SEG_BASES)
+
+
 SEQ_LUT = np.full(256, 4, dtype=np.uint8)
 for _i, _c in enumerate("ACTG"):
     SEQ_LUT[ord(_c)] = _i
@@ -72,6 +112,18 @@ class Batch:
         self.lib = ctx.lib
         ref_codes = np.ascontiguousarray(ref_codes, dtype=np.uint8)
         split_bounds = np.ascontiguousarray(split_bounds, dtype=np.int64)
+        if isinstance(obs, SegBatch):               # read-level batch (isx_batch_create_reads)
+            segs = obs
+            self.n_pos, self.n_obs, self.n_mm_bins = len(ref_codes), segs.n_bases, int(n_mm_bins)
+            p = Params(int(min_cov), int(min_snp), float(min_freq), int(rarefied_coverage), int(n_mm_bins),
+                       1 if enable_linkage else 0, int(linkage_mode), int(window), int(seed), int(layout), 0)
+            cs = segs.c(with_pair=bool(enable_linkage))
+            h = C.c_void_p()
+            check(self.lib.isx_batch_create_reads(ctx.h, C.byref(p), self.n_pos, ref_codes.ctypes.data, len(split_bounds) - 1,
+                                                  split_bounds.ctypes.data, C.byref(cs), C.byref(h)))
+            self.h = h
+            ctx._adopt(self)
+            return
         obs = np.ascontiguousarray(obs, dtype=OBS_DT)
         if pair is not None:
             pair = np.ascontiguousarray(pair, dtype=np.uint32)
@@ -190,7 +242,7 @@ class Pipe:
 
     def __init__(self, ctx, max_pos, max_obs, max_splits, depth=4, host_threads=0, pin_threads=True, jump_slack=0.0,
                  min_cov=5, min_freq=0.05, min_snp=20, rarefied_coverage=50, n_mm_bins=1, enable_linkage=False,
-                 linkage_mode=0, window=0, seed=0, layout=0, want_counts=False, ring_kib=0):
+                 linkage_mode=0, window=0, seed=0, layout=0, want_counts=False, ring_kib=0, max_segs=0):
         self.ctx, self.lib = ctx, ctx.lib
         self.n_mm_bins = int(n_mm_bins)
         self.want_counts = bool(want_counts)
@@ -198,7 +250,8 @@ class Pipe:
         p = Params(int(min_cov), int(min_snp), float(min_freq), int(rarefied_coverage), int(n_mm_bins),
                    1 if enable_linkage else 0, int(linkage_mode), int(window), int(seed), int(layout), 0)
         pp = _lib.PipeParams(int(max_pos), int(max_obs), int(max_splits), int(depth), int(host_threads),
-                             1 if pin_threads else 0, float(jump_slack), 1 if want_counts else 0, int(ring_kib))
+                             1 if pin_threads else 0, float(jump_slack), 1 if want_counts else 0, int(ring_kib), 0, int(max_segs))
+        self.read_level = max_segs > 0
         h = C.c_void_p()
         check(self.lib.isx_pipe_create(ctx.h, C.byref(p), C.byref(pp), C.byref(h)))
         self.h = h
@@ -215,6 +268,16 @@ class Pipe:
         check(self.lib.isx_pipe_submit(self.h, len(ref_codes), ref_codes.ctypes.data, len(split_bounds) - 1,
                                        split_bounds.ctypes.data, len(obs), obs.ctypes.data if len(obs) else None,
                                        pair.ctypes.data if pair is not None and len(obs) else None, C.byref(t)))
+        return t.value
+
+    def submit_reads(self, ref_codes, split_bounds, segs):
+        """-> ticket.  A read-level batch (SegBatch) through a pipe created with max_segs > 0 (isx_pipe_submit_reads)."""
+        ref_codes = np.ascontiguousarray(ref_codes, dtype=np.uint8)
+        split_bounds = np.ascontiguousarray(split_bounds, dtype=np.int64)
+        cs = segs.c(with_pair=self.enable_linkage)
+        t = C.c_int64(-1)
+        check(self.lib.isx_pipe_submit_reads(self.h, len(ref_codes), ref_codes.ctypes.data, len(split_bounds) - 1,
+                                             split_bounds.ctypes.data, C.byref(cs), C.byref(t)))
         return t.value
 
     def submit_bam(self, bamfile, refs, ref_codes, split_bounds=None, **kw):
@@ -321,6 +384,64 @@ def encode_obs(obs, pair=None, n_pos=None, record_bytes=2, threads=1, slack=0.0,
                                   C.byref(n_rec), C.byref(passes)))
     n = n_rec.value
     return rec[:n], gbase[:n // G], (pout[:n] if pout is not None else None), passes.value
+
+
+def encode_segs(segs, n_pos, n_mm_bins=1, threads=1, cap_rec=None):
+    """isx_encode_segs (host only): SegBatch -> (rec [n_rec, 16] uint32, gbase [n_rec / 16], pair_out | None)"""
+    lib = _lib.load()
+    if cap_rec is None:
+        cap_rec = ((segs.n_seg + 15) // 16 + segs.n_seg // 4096 + 64) * 16
+    rec = np.empty((cap_rec, 16), dtype=np.uint32)
+    gbase = np.empty(cap_rec // 16, dtype=np.uint32)
+    pout = np.empty(cap_rec, dtype=np.uint32) if segs.pair is not None else None
+    n_rec = C.c_int64(0)
+    cs = segs.c()
+    check(lib.isx_encode_segs(C.byref(cs), int(n_pos), int(n_mm_bins), int(threads), int(cap_rec), rec.ctypes.data, gbase.ctypes.data,
+                              pout.ctypes.data if pout is not None else None, C.byref(n_rec)))
+    n = n_rec.value
+    return rec[:n], gbase[:n // 16], (pout[:n] if pout is not None else None)
+
+
+def decode_segs(rec, gbase):
+    """device record stream -> (gpos, len, mm, codes [n, 150]) of its real records, in stream order (tests)"""
+    rec = np.asarray(rec, dtype=np.uint32).reshape(-1, 16)
+    hdr = rec[:, 0]
+    ln = (hdr >> 16) & 0xFF
+    real = ln > 0
+    start = np.repeat(np.asarray(gbase, dtype=np.uint32), 16)[:len(rec)] + (hdr & 0xFFFF)
+    return start[real], ln[real].astype(np.uint8), (hdr[real] >> 24).astype(np.uint8), unpack_codes(rec[real, 1:])
+
+
+def pack_reads(ref_start, clip_lo, clip_hi, cigars, seqs, quals, mm=None, pair=None, min_base_quality=30):
+    """isx_pack_reads (host only): per read its flat reference start, its scaffold's [clip_lo, clip_hi) in flat space, its CIGAR
+    (uint32 array, BAM encoding), bases (str / bytes) and qualities (uint8 array) -> SegBatch"""
+    lib = _lib.load()
+    n = len(ref_start)
+    rs = np.ascontiguousarray(ref_start, dtype=np.int64)
+    lo = np.ascontiguousarray(clip_lo, dtype=np.int64)
+    hi = np.ascontiguousarray(clip_hi, dtype=np.int64)
+    cig_off = np.zeros(n + 1, dtype=np.int64)
+    seq_off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        cig_off[1:] = np.cumsum([len(c) for c in cigars])
+        seq_off[1:] = np.cumsum([len(q) for q in quals])
+    cig = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint32) for c in cigars]) if n else np.zeros(0, np.uint32))
+    seq = b"".join(s.encode() if isinstance(s, str) else bytes(s) for s in seqs)
+    qual = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint8) for q in quals]) if n else np.zeros(0, np.uint8))
+    assert len(seq) == len(qual)
+    mmv = None if mm is None else np.ascontiguousarray(mm, dtype=np.uint8)
+    pv = None if pair is None else np.ascontiguousarray(pair, dtype=np.uint32)
+    ns = C.c_int64(0)
+    check(lib.isx_count_read_segs(n, cig.ctypes.data, cig_off.ctypes.data, rs.ctypes.data, lo.ctypes.data, hi.ctypes.data, C.byref(ns)))
+    cap = max(1, ns.value)
+    g = np.empty(cap, np.uint32); ln = np.empty(cap, np.uint8); sm = np.zeros(cap, np.uint8); sp = np.zeros(cap, np.uint32)
+    bs = np.empty((cap, _lib.SEG_WORDS), np.uint32)
+    check(lib.isx_pack_reads(n, rs.ctypes.data, lo.ctypes.data, hi.ctypes.data, cig.ctypes.data, cig_off.ctypes.data, seq,
+                             qual.ctypes.data, seq_off.ctypes.data, mmv.ctypes.data if mmv is not None else None,
+                             pv.ctypes.data if pv is not None else None, int(min_base_quality), cap, g.ctypes.data, ln.ctypes.data,
+                             sm.ctypes.data, sp.ctypes.data, bs.ctypes.data, C.byref(ns)))
+    k = ns.value
+    return SegBatch(g[:k], ln[:k], bs[:k], sm[:k] if mm is not None else None, sp[:k] if pair is not None else None)
 
 
 def dense_to_entries(counts, clon):

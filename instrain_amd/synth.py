@@ -179,8 +179,31 @@ def _synth():
                                            _C.POINTER(_SynthOut)]
         lib.isx_synth_free.argtypes = [_C.POINTER(_SynthOut)]
         lib.isx_synth_free.restype = None
+        lib.isx_synth_obs_to_segs.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int64, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_void_p,
+                                              _C.c_void_p, _C.c_int32]
+        lib.isx_synth_obs_to_segs.restype = _C.c_int64
         _synth_lib = lib
     return _synth_lib
+
+
+def segs_from_obs(obs, pair=None, threads=0):
+    """The read segments (engine.SegBatch) an observation stream stands for -- what the read-level hand-over ships for the
+    same workload: one segment per read for a read-major stream (the generators here, the BAM front end)."""
+    from . import engine
+    if threads <= 0:
+        threads = max(1, min(16, len(_os.sched_getaffinity(0))))
+    obs = np.ascontiguousarray(obs, dtype=OBS_DT)
+    pr = None if pair is None else np.ascontiguousarray(pair, dtype=np.uint32)
+    lib = _synth()
+    n = int(lib.isx_synth_obs_to_segs(obs.ctypes.data, pr.ctypes.data if pr is not None else None, len(obs), None, None, None, None, None, 1))
+    g = np.empty(n, np.uint32)
+    ln = np.empty(n, np.uint8)
+    mm = np.empty(n, np.uint8)
+    sp = np.empty(n, np.uint32) if pr is not None else None
+    bs = np.empty((n, 15), np.uint32)
+    lib.isx_synth_obs_to_segs(obs.ctypes.data, pr.ctypes.data if pr is not None else None, len(obs), g.ctypes.data, ln.ctypes.data,
+                              mm.ctypes.data, sp.ctypes.data if sp is not None else None, bs.ctypes.data, int(threads))
+    return engine.SegBatch(g, ln, bs, mm, sp)
 
 
 class _SynthOwner:

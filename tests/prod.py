@@ -31,16 +31,25 @@ def to_oracle_layout(res, gpos_to_pos):
     return {"entries": E, "snv": S, "ld": L}
 
 
-def run_split(ctx, pos, base, mm, pair, seq, start, n_mm_bins=None, **kw):
+def run_split(ctx, pos, base, mm, pair, seq, start, n_mm_bins=None, reads=None, **kw):
     """One split through the product. pos absolute; only observations inside the split are sent
-    (truncate=True of the pileup call, profile_utilities.py:150)."""
+    (truncate=True of the pileup call, profile_utilities.py:150).  reads = "stream": the same observations handed over as
+    read segments cut from the stream as it comes (synth.segs_from_obs); "reassembled": as segments rebuilt per read pair
+    (tests.util.reassemble_segs) -- the read-level hand-over instead of the observation records."""
     pos = np.asarray(pos, dtype=np.int64)
     sel = (pos >= start) & (pos < start + len(seq))
     mm = np.asarray(mm)
     if n_mm_bins is None:
         n_mm_bins = int(mm.max()) + 1 if len(mm) else 1
     obs = engine.pack_obs((pos[sel] - start).astype(np.uint32), np.asarray(base)[sel], mm[sel])
-    b = engine.Batch(ctx, engine.encode_seq(seq), [0, len(seq)], obs, np.asarray(pair)[sel].astype(np.uint32),
+    pr = np.asarray(pair)[sel].astype(np.uint32)
+    if reads == "stream":
+        from instrain_amd import synth
+        obs, pr = synth.segs_from_obs(obs, pr), None
+    elif reads == "reassembled":
+        from tests import util
+        obs, pr = util.reassemble_segs(obs["gpos"], obs["base"], obs["mm"], pr), None
+    b = engine.Batch(ctx, engine.encode_seq(seq), [0, len(seq)], obs, pr,
                      n_mm_bins=n_mm_bins, **kw)
     b.run()
     res = b.fetch()

@@ -1,0 +1,230 @@
+"""GPU parity of the READ-LEVEL hand-over (isx_batch_create_reads / isx_pipe_submit_reads): handing over read segments
+must give the tables that handing over the observations they stand for gives -- bit for bit -- and therefore the
+reference's (golden vectors, stored sars_cov_2 run)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(util.GOLD, "synth_*.npz")))
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from instrain_amd import engine
+    c = engine.Context(0)
+    lut, fb = util.load_lut()
+    c.set_null_model(lut, fb)
+    yield c
+    c.close()
+
+
+def _params(g):
+    return dict(min_cov=int(g["p_min_cov"]), min_freq=float(g["p_min_freq"]), min_snp=int(g["p_min_snp"]))
+
+
+@pytest.mark.parametrize("how", ["stream", "reassembled"])
+@pytest.mark.parametrize("name", CASES)
+def test_golden_vectors_as_read_segments(ctx, name, how):
+    from tests import prod
+    g = util.load_case(name)
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), reads=how, **_params(g))
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name + "/" + how)
+    assert res["n_edges"] == int(g["n_edges"])
+
+
+@pytest.mark.parametrize("window", [64, 128, 1024, 3136])
+@pytest.mark.parametrize("name", ["synth_dense", "synth_mm4_deep", "synth_m1_ld"])
+def test_window_size_invariance(ctx, name, window):
+    from tests import prod
+    g = util.load_case(name)
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), reads="reassembled", window=window, **_params(g))
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what="%s window%d" % (name, window))
+
+
+def _tables_equal(a, b, what):
+    for k in a:
+        if k in ("counts", "clon", "clon_r", "snv", "ld", "entries"):
+            x, y = a[k], b[k]
+            assert x.shape == y.shape, (what, k, x.shape, y.shape)
+            assert x.tobytes() == y.tobytes(), (what, k)
+
+
+def test_stored_sars_golden_as_read_segments(ctx):
+    """BAM -> front end -> observations -> read segments -> kernels == the reference's stored run, and == the observation path"""
+    from instrain_amd import engine, synth
+    from tests import prod
+    from tests.test_oracle_golden import check_against_sars_golden, read_fasta
+    bam = engine.BamFile(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"))
+    obs, pair, bounds, sref = bam.expand()
+    M = bam.info["max_mm"] + 1
+    bam.close()
+    seq = read_fasta(os.path.join(util.GOLD, "sars_cov_2_MT039887.1.fasta"))
+    segs = synth.segs_from_obs(obs, pair)
+    assert segs.n_bases >= len(obs)
+    kw = dict(n_mm_bins=M, min_cov=5, min_freq=0.05, min_snp=20)
+    b = engine.Batch(ctx, engine.encode_seq(seq), bounds, segs, **kw)
+    b.run()
+    got = b.fetch()
+    sizes = b.sizes()
+    assert b.timings()["record_bytes"] == 64
+    b.close()
+    res = prod.to_oracle_layout(got, lambda g: g.astype(np.int64))
+    check_against_sars_golden(res["snv"], res["ld"], float_tol=TOL)
+    assert sizes["n_edges"] == 963 and sizes["n_increments"] == 23319
+    b2 = engine.Batch(ctx, engine.encode_seq(seq), bounds, obs, pair, **kw)
+    b2.run()
+    _tables_equal(got, b2.fetch(), "sars")
+    b2.close()
+
+
+def _mg():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(util.GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)         # only its synthetic generator is used (no reference import)
+    return mg
+
+
+def test_randomized_sweep_reads_equal_observations(ctx):
+    """random small splits, thresholds, mm-level counts, non-ACGT rates, windows: both hand-overs give the same tables"""
+    from instrain_amd import engine, synth
+    mg = _mg()
+    rng = np.random.Generator(np.random.PCG64(77))
+    for it in range(24):
+        mLen = int(rng.integers(300, 6000))
+        mm_levels = int(rng.choice([1, 1, 2, 5, 17]))
+        seq, pos, base, mm, pair = mg.synth_case(seed=1000 + it, mLen=mLen, depth=int(rng.integers(3, 120)), mm_levels=mm_levels,
+                                                 n_sites=int(rng.integers(0, 80)), p_other=float(rng.choice([0.0, 0.03])), ref_ambig=int(rng.integers(0, 4)),
+                                                 self_pairs=float(rng.choice([0.0, 0.3])))
+        kw = dict(n_mm_bins=int(mm.max()) + 1 if len(mm) else 1, min_cov=int(rng.integers(1, 8)), min_freq=float(rng.choice([0.01, 0.05, 0.2])),
+                  min_snp=int(rng.integers(1, 25)), window=int(rng.choice([0, 64, 256, 1024])), rarefied_coverage=int(rng.choice([0, 5, 50])))
+        obs = engine.pack_obs(pos.astype(np.uint32), base, mm)
+        pr = pair.astype(np.uint32)
+        ref = engine.encode_seq(seq)
+        a = engine.Batch(ctx, ref, [0, mLen], obs, pr, **kw)
+        a.run()
+        ra = a.fetch()
+        sa = a.sizes()
+        a.close()
+        for segs in (synth.segs_from_obs(obs, pr), util.reassemble_segs(pos, base, mm, pair)):
+            b = engine.Batch(ctx, ref, [0, mLen], segs, **kw)
+            b.run()
+            _tables_equal(ra, b.fetch(), "iteration %d %r" % (it, kw))
+            assert b.sizes() == sa
+            b.close()
+
+
+def test_non_acgt_base_makes_its_level_present(ctx):
+    """code 5 (a base that is not A/C/T/G but passes the filter) creates the (position, mm) entry without a count
+    (profile_utilities.py:279-285); code 4 / 6 / 7 do nothing"""
+    from instrain_amd import engine
+    ref = np.zeros(500, np.uint8)
+    codes = np.full((3, 150), 4, np.uint8)
+    codes[0, :20] = 0                       # read 0, mm 0: twenty A
+    codes[1, 5] = 5                         # read 1, mm 2: one N over position 105
+    codes[1, 6] = 6; codes[1, 7] = 7
+    codes[2, :10] = 1                       # read 2, mm 1
+    segs = engine.SegBatch([100, 100, 300], [20, 8, 10], engine.pack_codes(codes), mm=[0, 2, 1], pair=[0, 1, 2])
+    b = engine.Batch(ctx, ref, [0, 500], segs, n_mm_bins=3, min_cov=1, enable_linkage=False)
+    b.run()
+    e = b.fetch()["entries"]
+    b.close()
+    key = {(int(r["gpos"]), int(r["mm"])): r["cnt"].tolist() for r in e}
+    assert key[(105, 2)] == [0, 0, 0, 0] and key[(105, 0)] == [1, 0, 0, 0]
+    assert (106, 2) not in key and (107, 2) not in key
+    assert len(e) == 20 + 1 + 10
+    # one mm bin: a non-ACGT base is simply not counted
+    d = engine.Batch(ctx, ref, [0, 500], engine.SegBatch(segs.gpos, segs.len, segs.bases, None, segs.pair), n_mm_bins=1, min_cov=1, enable_linkage=False)
+    d.run()
+    c = d.fetch()["counts"]
+    d.close()
+    assert c[100:120, 0].tolist() == [1] * 20 and c[300:310, 1].tolist() == [1] * 10 and int(c.sum()) == 30
+
+
+def test_segments_straddling_windows_and_far_jumps(ctx):
+    """segments that cross window edges at every offset, a jump of > 65535 positions between two segments (group cut) and
+    a segment ending at the last position of the batch"""
+    from instrain_amd import engine
+    n_pos = 300_000
+    rng = np.random.Generator(np.random.PCG64(5))
+    starts = np.sort(np.concatenate([rng.integers(0, 3000, 400), rng.integers(200_000, 203_000, 400), [n_pos - 150]])).astype(np.uint32)
+    n = len(starts)
+    codes = rng.integers(0, 6, (n, 150)).astype(np.uint8)
+    ln = np.full(n, 150, np.uint8)
+    segs = engine.SegBatch(starts, ln, engine.pack_codes(codes), mm=None, pair=np.arange(n, dtype=np.uint32))
+    exp = np.zeros((n_pos, 4), np.int64)
+    for b in range(4):
+        si, off = np.nonzero(codes == b)
+        np.add.at(exp[:, b], starts[si].astype(np.int64) + off, 1)
+    ref = rng.integers(0, 4, n_pos, dtype=np.uint8)
+    for window in (64, 192, 1024, 0):
+        bt = engine.Batch(ctx, ref, [0, 150_000, n_pos], segs, n_mm_bins=1, min_cov=5, enable_linkage=True, window=window)
+        bt.run()
+        c = bt.fetch()["counts"]
+        bt.close()
+        assert (c.astype(np.int64) == exp).all(), window
+
+
+def _c2(scale=1.0, seed=2, skip_mm=True):
+    from instrain_amd import synth
+    return synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale), seed=seed, skip_mm=skip_mm)
+
+
+@pytest.mark.parametrize("skip_mm,linkage", [(True, False), (True, True), (False, True)])
+def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage):
+    """a C2 slice through the read-level pipe == the same observations through a resident batch, every table"""
+    from instrain_amd import engine, synth
+    w = _c2(0.1, seed=4, skip_mm=skip_mm)
+    M = w["n_mm_bins"]
+    segs = synth.segs_from_obs(w["obs"], w["pair"])
+    kw = dict(n_mm_bins=M, enable_linkage=linkage, min_snp=20)
+    a = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"] if linkage else None, **kw)
+    a.run()
+    ra, sa = a.fetch(), a.sizes()
+    a.close()
+    pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=0, max_segs=segs.n_seg, max_splits=len(w["split_bounds"]), depth=2,
+                       host_threads=4, pin_threads=False, want_counts=True, **kw)
+    tickets = [pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs) for _ in range(2)]
+    for t in tickets:
+        r = pipe.collect(t)
+        assert r["stats"]["record_bytes"] == 64
+        assert r["sizes"] == sa
+        if M == 1:
+            assert (r["counts"] == ra["counts"]).all()
+            assert r["clon"].tobytes() == ra["clon"].tobytes()
+            assert (r["cov16"] == np.minimum(ra["counts"].sum(axis=1), 65535)).all()
+        else:
+            assert r["entries"].tobytes() == ra["entries"].tobytes()
+        assert r["snv"].tobytes() == ra["snv"].tobytes()
+        if linkage:
+            assert r["ld"].tobytes() == ra["ld"].tobytes()
+        pipe.release(t)
+    # an observation batch is refused by a read-level pipe
+    with pytest.raises(engine.IsxError, match="read-level"):
+        pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], w["pair"] if linkage else None)
+    pipe.close()
+
+
+def test_full_c2_reads_equal_observations(ctx):
+    """BASELINE configs[1] at full size: both hand-overs, all tables identical; the segments are 1 / 4.6 of the 2-byte records"""
+    from instrain_amd import engine, synth
+    w = _c2()
+    segs = synth.segs_from_obs(w["obs"], w["pair"])
+    assert segs.n_seg == 2 * w["n_pairs"]
+    a = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], None, n_mm_bins=1, enable_linkage=False)
+    a.run()
+    ra = a.fetch()
+    a.close()
+    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], segs, n_mm_bins=1, enable_linkage=False)
+    b.run()
+    rb = b.fetch()
+    b.close()
+    _tables_equal(ra, rb, "C2")
+    assert int(rb["counts"].sum()) == w["n_obs"]

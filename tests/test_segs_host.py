@@ -1,0 +1,143 @@
+"""Host side of the read-level hand-over (no GPU): observation stream <-> read segments, the staging encoder
+(isx_encode_segs) and the read packer (isx_pack_reads).  The segments must stand for exactly the observations the
+reference's pileup loop visits (profile_utilities.py:150-153, 268-286)."""
+import numpy as np
+import pytest
+
+from instrain_amd import engine, synth
+from tests import util
+
+
+def _workload(seed=7, G=60_000, cov=12, skip_mm=False):
+    return synth.make_workload(genome_len=G, coverage=cov, n_sites=200, seed=seed, skip_mm=skip_mm)
+
+
+def test_segments_of_a_read_major_stream_round_trip():
+    w = _workload()
+    segs = synth.segs_from_obs(w["obs"], w["pair"])
+    # one segment per read: 2 x 150 bp reads whose kept bases span at most 150 columns
+    assert segs.n_seg <= 2 * w["n_pairs"] and segs.n_seg >= 2 * w["n_pairs"] - 4
+    g, b, m, p = util.segs_to_obs(segs)
+    assert (g == w["obs"]["gpos"]).all() and (b == w["obs"]["base"]).all()
+    assert (m == w["obs"]["mm"]).all() and (p == w["pair"]).all()
+    assert int(segs.len.max()) <= 150 and int(segs.len.min()) >= 1
+    # unused slots hold code 4, the top two bits of every word are clear
+    assert (segs.bases >> 30 == 0).all()
+    cd = engine.unpack_codes(segs.bases)
+    tail = np.arange(150)[None, :] >= segs.len[:, None]
+    assert (cd[tail] == 4).all()
+
+
+def test_segments_of_a_column_major_stream_keep_arrival_order():
+    g = util.load_case("synth_selfpairs")
+    pos = g["pos"].astype(np.int64) - int(g["start"])
+    sel = (pos >= 0) & (pos < len(str(g["seq"])))
+    for make in (lambda: util.reassemble_segs(pos[sel], g["base"][sel], g["mm"][sel], g["pair"][sel]),
+                 lambda: synth.segs_from_obs(engine.pack_obs(pos[sel].astype(np.uint32), g["base"][sel], g["mm"][sel]), g["pair"][sel].astype(np.uint32))):
+        segs = make()
+        gg, bb, mm, pp = util.segs_to_obs(segs)
+        a = np.lexsort((bb, mm, pp, gg))
+        e = np.lexsort((np.minimum(g["base"][sel], 4), g["mm"][sel], g["pair"][sel], pos[sel]))
+        assert (gg[a] == pos[sel][e]).all() and (bb[a] == np.minimum(g["base"][sel], 4)[e]).all()
+        assert (mm[a] == g["mm"][sel][e]).all() and (pp[a] == g["pair"][sel][e]).all()
+        # two observations of one pair at one site: the segment created first holds the one that arrived first
+        first_seen = {}
+        order_ok = True
+        seg_of = np.repeat(np.arange(segs.n_seg), ((engine.unpack_codes(segs.bases) < 4) | (engine.unpack_codes(segs.bases) == 5)).sum(axis=1))
+        arrival = {}
+        for i, (q, pr, b) in enumerate(zip(pos[sel], g["pair"][sel], g["base"][sel])):
+            arrival.setdefault((int(q), int(pr)), []).append(min(int(b), 4))
+        got = {}
+        for q, pr, b, s in zip(gg, pp, bb, seg_of):
+            got.setdefault((int(q), int(pr)), []).append((int(s), int(b)))
+        for k, v in got.items():
+            assert [b for _, b in sorted(v)] == arrival[k], k
+
+
+def test_reassembled_segments_are_whole_reads():
+    w = _workload(seed=9, G=20_000, cov=8)
+    o = w["obs"]
+    # shuffle into column-major order (stable within a column = arrival order)
+    k = np.argsort(o["gpos"], kind="stable")
+    segs = util.reassemble_segs(o["gpos"][k], o["base"][k], o["mm"][k], w["pair"][k])
+    assert segs.n_seg <= 2 * w["n_pairs"]
+    gg, bb, mm, pp = util.segs_to_obs(segs)
+    a, e = np.lexsort((pp, gg)), np.lexsort((w["pair"], o["gpos"]))
+    assert (gg[a] == o["gpos"][e]).all() and (bb[a] == o["base"][e]).all() and (pp[a] == w["pair"][e]).all()
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_encode_segs_layout(threads):
+    w = _workload(seed=11, G=400_000, cov=6)
+    # a jump of > 65535 positions in the middle of the stream: the group there is closed early and padded
+    o = w["obs"].copy()
+    o["gpos"][o["gpos"] >= 200_000] += 300_000
+    segs = synth.segs_from_obs(o, w["pair"])
+    n_pos = 400_000 + 300_000
+    rec, gbase, pout = engine.encode_segs(segs, n_pos, n_mm_bins=int(o["mm"].max()) + 1, threads=threads)
+    assert len(rec) % 16 == 0 and len(gbase) == len(rec) // 16
+    g, ln, mm, cd = engine.decode_segs(rec, gbase)
+    assert (g == segs.gpos).all() and (ln == segs.len).all() and (mm == segs.mm).all()
+    assert (engine.pack_codes(cd) == segs.bases).all()
+    hdr = rec[:, 0]
+    real = ((hdr >> 16) & 0xFF) > 0
+    assert (pout[real] == segs.pair).all() and (pout[~real] == 0).all()
+    assert (rec[~real, 1:] == 0x24924924).all() and (hdr[~real] == 0).all()
+    # every group's deltas fit 16 bits by construction; the jump costs padding
+    assert real.sum() == segs.n_seg and (~real).sum() >= 1
+    # the number of groups does not depend on the thread count beyond the per-task rounding
+    assert len(rec) <= (segs.n_seg // 16 + segs.n_seg // 4096 + 64) * 16       # reads straddling the jump alternate between its sides
+
+
+def test_encode_segs_rejects_bad_input():
+    from instrain_amd._lib import IsxError
+    segs = engine.SegBatch([10, 20], [150, 150], np.full((2, 15), 0x24924924, np.uint32), mm=[0, 3])
+    with pytest.raises(IsxError, match="beyond n_pos"):
+        engine.encode_segs(segs, 100, n_mm_bins=4)
+    with pytest.raises(IsxError, match="mm >= n_mm_bins"):
+        engine.encode_segs(segs, 1000, n_mm_bins=2)
+    bad = engine.SegBatch([10], [0], np.full((1, 15), 0x24924924, np.uint32))
+    with pytest.raises(IsxError, match="length"):
+        engine.encode_segs(bad, 1000)
+    empty = engine.SegBatch(np.zeros(0, np.uint32), np.zeros(0, np.uint8), np.zeros((0, 15), np.uint32))
+    rec, gbase, _ = engine.encode_segs(empty, 1000)
+    assert len(rec) == 16 and (rec[:, 0] == 0).all()
+
+
+def _cig(*ops):
+    code = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}
+    return np.asarray([(n << 4) | code[o] for n, o in ops], dtype=np.uint32)
+
+
+def test_pack_reads_follows_the_cigar_and_the_quality_filter():
+    rng = np.random.Generator(np.random.PCG64(3))
+    L = 400
+    seq = "".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04], size=L))
+    qual = rng.choice([12, 25, 30, 37], size=L).astype(np.uint8)
+    # 5S 100M 3I 40= 7D 20X 2N 180M 50S: query = 5 + 100 + 3 + 40 + 20 + 180 + 50 = 398
+    cig = _cig((5, "S"), (100, "M"), (3, "I"), (40, "="), (7, "D"), (20, "X"), (2, "N"), (180, "M"), (50, "S"))
+    seq, qual = seq[:398], qual[:398]
+    start = 1000
+    segs = engine.pack_reads([start], [0], [10_000], [cig], [seq], [qual], mm=[2], pair=[7])
+    # expected observations by a plain walk
+    exp = []
+    ref, q = start, 0
+    for n, op in ((5, "S"), (100, "M"), (3, "I"), (40, "="), (7, "D"), (20, "X"), (2, "N"), (180, "M"), (50, "S")):
+        if op in "M=X":
+            for j in range(n):
+                if qual[q + j] >= 30:
+                    exp.append((ref + j, "ACTG".find(seq[q + j]) if seq[q + j] in "ACTG" else 4))
+            q += n; ref += n
+        elif op in "IS":
+            q += n
+        elif op in "DN":
+            ref += n
+    g, b, m, p = util.segs_to_obs(segs)
+    assert list(zip(g.tolist(), b.tolist())) == exp
+    assert (m == 2).all() and (p == 7).all()
+    # runs: 100 | 40 | 20 | 180 -> 150 + 30: five segments, none longer than 150
+    assert segs.n_seg == 5 and segs.len.tolist() == [100, 40, 20, 150, 30]
+    # truncation to the scaffold: columns outside [clip_lo, clip_hi) are dropped like the reference's truncate=True
+    clipped = engine.pack_reads([start], [1050], [1300], [cig], [seq], [qual])
+    gc, bc, _, _ = util.segs_to_obs(clipped)
+    assert list(zip(gc.tolist(), bc.tolist())) == [e for e in exp if 1050 <= e[0] < 1300]

@@ -102,3 +102,44 @@ def assert_same(got, exp, float_tol=1e-6, what=""):
         m = ~np.isnan(a)
         if m.any():
             assert np.max(np.abs(a[m] - b[m])) <= float_tol, (what, k, np.max(np.abs(a[m] - b[m])))
+
+
+def reassemble_segs(gpos, base, mm, pair):
+    """Any observation stream (e.g. the goldens' column-major one) -> read segments (engine.SegBatch) the way reads would
+    carry them: an observation extends the oldest open segment of its pair with the same mm whose last column lies before
+    it and whose start is less than 150 columns back, otherwise it opens a new segment; segments keep the order of their
+    first observation, so two observations of one pair at one site stay in arrival order (linkage's self pairs)."""
+    from instrain_amd import engine
+    open_of = {}
+    starts, mms, pairs, lasts, codes = [], [], [], [], []
+    for i in range(len(gpos)):
+        g, m, p, b = int(gpos[i]), int(mm[i]), int(pair[i]), int(base[i])
+        hit = None
+        for si in open_of.setdefault(p, []):
+            if mms[si] == m and g > lasts[si] and g - starts[si] < 150:
+                hit = si
+                break
+        if hit is None:
+            hit = len(starts)
+            starts.append(g); mms.append(m); pairs.append(p); lasts.append(g)
+            codes.append(np.full(150, 4, dtype=np.uint8))
+            open_of[p].append(hit)
+        codes[hit][g - starts[hit]] = b if b < 4 else 5
+        lasts[hit] = g
+    n = len(starts)
+    ln = np.asarray([lasts[i] - starts[i] + 1 for i in range(n)], dtype=np.uint8)
+    cd = np.stack(codes) if n else np.zeros((0, 150), np.uint8)
+    return engine.SegBatch(np.asarray(starts, np.uint32), ln, engine.pack_codes(cd), np.asarray(mms, np.uint8), np.asarray(pairs, np.uint32))
+
+
+def segs_to_obs(segs):
+    """engine.SegBatch -> (gpos, base, mm, pair) of the observations it stands for, segment after segment (base 4 = a
+    non-ACGT base that passes the filter)"""
+    from instrain_amd import engine
+    cd = engine.unpack_codes(segs.bases)
+    si, off = np.nonzero((cd < 4) | (cd == 5))
+    g = segs.gpos[si].astype(np.int64) + off
+    b = np.where(cd[si, off] < 4, cd[si, off], 4).astype(np.uint8)
+    m = segs.mm[si] if segs.mm is not None else np.zeros(len(si), np.uint8)
+    p = segs.pair[si] if segs.pair is not None else np.zeros(len(si), np.uint32)
+    return g, b, m, p
