@@ -485,6 +485,7 @@ typedef struct isx_bam_info_s {
     int32_t max_mm;
     int32_t pad;
     int64_t unfiltered_reads, unfiltered_singletons, filtered_singletons;   /* read_report tallies (filter_reads.py:487-495, 372-377) */
+    int64_t n_segs;             /* read segments of the batch (isx_bam_segment_refs / isx_pipe_submit_bam on a read-level pipe), else 0 */
 } isx_bam_info;
 
 int isx_bam_open(const char *path, isx_bam **out);     /* header + BGZF block index; nothing else is inflated */
@@ -512,6 +513,13 @@ int isx_bam_ref_counts(const isx_bam *bam, int64_t *reads, int64_t *filtered_pai
 /* overlap resolution + expansion of the given references (ascending ids = file order), laid end to end (the batch's
  * flat space); results stay in the handle until the next expand (isx_bam_copy / isx_bam_view) */
 int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info);
+/* the same batch as READ SEGMENTS (isx_segs above) instead of observations -- what isx_pipe_submit_bam hands a read-level
+ * pipe: no per-base walk on the host.  info->n_obs = the columns the segments cover (an upper bound of the observations);
+ * isx_bam_copy_segs copies them out (any pointer may be NULL): gpos / len / mm / pair [n_seg], bases [n_seg][15],
+ * split_bounds[n_splits + 1], split_ref[n_splits] */
+int isx_bam_segment_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info, int64_t *n_seg);
+int isx_bam_copy_segs(const isx_bam *bam, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint32_t *bases,
+                      int64_t *split_bounds, int32_t *split_ref);
 /* the re-pileup of SNV pooling (polymorpher.py:287-293: samfile.pileup(scaffold, start, stop, truncate=True)): only the columns
  * [start, stop) of one reference, from the reads overlapping them (only the BGZF blocks that can hold such reads are touched);
  * gpos stays the position on the reference */

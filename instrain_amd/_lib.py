@@ -91,7 +91,7 @@ class BamInfo(C.Structure):
                 ("n_obs", C.c_int64), ("n_pairs", C.c_int64), ("unfiltered_pairs", C.c_int64),
                 ("filtered_pairs", C.c_int64), ("filtered_bases", C.c_int64), ("median_insert", C.c_double),
                 ("max_mm", C.c_int32), ("pad", C.c_int32), ("unfiltered_reads", C.c_int64),
-                ("unfiltered_singletons", C.c_int64), ("filtered_singletons", C.c_int64)]
+                ("unfiltered_singletons", C.c_int64), ("filtered_singletons", C.c_int64), ("n_segs", C.c_int64)]
 
 
 SCAFFOLD_LEVEL_DT = np.dtype([("nonzero", "<i8"), ("sum_cov", "<u8"), ("sumsq_cov", "<u8"), ("median_cov", "<f8"),
@@ -125,7 +125,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_submit_bam", "isx_encode_segs", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_encode_obs", "isx_encode_obs_ring",
            "isx_bam_open", "isx_bam_close", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
            "isx_bam_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_ref_counts",
-           "isx_bam_expand_refs", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
+           "isx_bam_expand_refs", "isx_bam_segment_refs", "isx_bam_copy_segs", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
 
 _lib = None
 
@@ -193,6 +193,8 @@ def load():
     lib.isx_bam_ref_counts.argtypes = [vp, vp, vp]
     lib.isx_bam_expand_region.argtypes = [vp, C.POINTER(BamParams), i32, i64, i64, C.POINTER(BamInfo)]
     lib.isx_bam_expand_refs.argtypes = [vp, C.POINTER(BamParams), vp, i32, C.POINTER(BamInfo)]
+    lib.isx_bam_segment_refs.argtypes = [vp, C.POINTER(BamParams), vp, i32, C.POINTER(BamInfo), C.POINTER(i64)]
+    lib.isx_bam_copy_segs.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.isx_bam_ref.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64)]
     lib.isx_bam_copy.argtypes = [vp, vp, vp, vp, vp]
     lib.isx_bam_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

@@ -26,6 +26,7 @@
 //                                 holding them are inflated again; overlap resolution and expansion run on that
 //                                 batch's reads alone.
 // No device code here; it is linked into libinstrain_amd.so so that the whole path sits behind one C ABI.
+#include <immintrin.h>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -59,6 +60,67 @@ constexpr uint16_t DEF_MASK = FUNMAP | FSECONDARY | FQCFAIL | FDUP;
 
 // 4-bit BAM code -> inStrain base index (A,C,T,G = 0..3; everything else 4)
 const uint8_t CODE2IDX[16] = {4, 0, 1, 4, 3, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4};
+
+// 4-bit BAM code -> read-segment code (include/instrain_amd.h isx_segs): A,C,T,G = 0..3; anything else 5 (a base that only
+// makes its mm level present, profile_utilities.py:279-285)
+const uint8_t CODE2SEG[16] = {5, 0, 1, 5, 3, 5, 5, 5, 2, 5, 5, 5, 5, 5, 5, 5};
+
+// codes of `n` (<= 150) consecutive query bases starting at query offset q0 -> out[n] (code 4 where the quality is below minq)
+inline void seg_codes_scalar(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint8_t *out)
+{
+    for (int j = 0; j < n; j++) {
+        const int64_t i = q0 + j;
+        out[j] = qual[i] >= minq ? CODE2SEG[(seq[i >> 1] >> ((~i & 1) << 2)) & 15] : (uint8_t)4;
+    }
+}
+
+__attribute__((target("avx2")))
+inline void seg_codes_avx2(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint8_t *out)
+{
+    // local, padded copies: the vector loads below may run up to 31 bytes past the bases asked for
+    alignas(32) uint8_t sq[96], ql[192], cd[192];
+    const int64_t e0 = q0 & ~(int64_t)1;                    // even base the copy starts at
+    const int lead = (int)(q0 - e0), m = n + lead;
+    memcpy(sq, seq + (e0 >> 1), (size_t)((m + 1) >> 1));
+    memcpy(ql, qual + e0, (size_t)m);
+    const __m128i nmask = _mm_set1_epi8(0x0F);
+    const __m256i lut = _mm256_broadcastsi128_si256(_mm_loadu_si128(reinterpret_cast<const __m128i *>(CODE2SEG)));
+    const __m256i mq = _mm256_set1_epi8((char)minq), four = _mm256_set1_epi8(4);
+    for (int j = 0; j < m; j += 32) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(sq + (j >> 1)));
+        const __m128i hi = _mm_and_si128(_mm_srli_epi16(v, 4), nmask), lo = _mm_and_si128(v, nmask);
+        const __m256i nib = _mm256_set_m128i(_mm_unpackhi_epi8(hi, lo), _mm_unpacklo_epi8(hi, lo));     // base order
+        const __m256i code = _mm256_shuffle_epi8(lut, nib);
+        const __m256i q = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(ql + j));
+        const __m256i ok = _mm256_cmpeq_epi8(_mm256_max_epu8(q, mq), q);                                // q >= minq, unsigned
+        _mm256_store_si256(reinterpret_cast<__m256i *>(cd + j), _mm256_blendv_epi8(four, code, ok));
+    }
+    memcpy(out, cd + lead, (size_t)n);
+}
+
+inline bool cpu_has_avx2_bmi2()
+{
+    static const bool v = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+    return v;
+}
+
+// ten codes per word (base j: word j / 10, bits 3 (j % 10)); slots from n on hold code 4
+inline void seg_pack_scalar(const uint8_t *cd, int n, uint32_t *w)
+{
+    for (int k = 0; k < ISX_SEG_WORDS; k++) w[k] = ISX_SEG_SKIP_WORD;
+    for (int j = 0; j < n; j++) w[j / 10] = (w[j / 10] & ~(7u << (3 * (j % 10)))) | ((uint32_t)cd[j] << (3 * (j % 10)));
+}
+
+__attribute__((target("bmi2")))
+inline void seg_pack_bmi2(uint8_t *cd /* [160], writable: padded with code 4 */, int n, uint32_t *w)
+{
+    memset(cd + n, 4, (size_t)(160 - n));
+    for (int k = 0; k < ISX_SEG_WORDS; k++) {
+        uint64_t x;
+        memcpy(&x, cd + 10 * k, 8);
+        w[k] = (uint32_t)_pext_u64(x, 0x0707070707070707ull) | ((uint32_t)cd[10 * k + 8] << 24) | ((uint32_t)cd[10 * k + 9] << 27);
+    }
+}
 
 struct Read {           // a read of the batch being expanded
     int32_t tid, pos, isize, l_seq;
@@ -342,6 +404,8 @@ struct isx_bam {
     // ---- results of the last expand ----
     std::unique_ptr<isx_obs[]> obs;
     std::unique_ptr<uint32_t[]> pair;
+    std::vector<uint32_t> seg_gpos, seg_pair, seg_bases;    // isx_bam_segment_refs: the batch as read segments
+    std::vector<uint8_t> seg_len, seg_mm;
     size_t n_obs = 0;
     std::vector<int64_t> split_bounds;
     std::vector<int32_t> split_ref;
@@ -1407,6 +1471,61 @@ struct BamBatch {
         return n_out;
     }
 
+    // ---- read-level hand-over: the batch as read segments (isx_segs) instead of observations ----
+    std::vector<uint64_t> seg_at;           // [n_reads + 1] first segment of every read
+    std::vector<uint32_t> seg_gpos;         // [n_segs] flat start of every segment (the staging encoder's layout pass wants them up front)
+    int64_t n_seg_bases = 0;                // columns covered by the segments (>= the observations)
+
+    // calls f(flat start, query offset, columns) for every segment of read ri: the M / = / X runs of its CIGAR, truncated to
+    // the scaffold / region like the reference's pileup (profile_utilities.py:150-153), cut every ISX_SEG_BASES columns
+    template <class F>
+    void for_segments(size_t ri, F &&f) const
+    {
+        const Read &r = S.reads[ri];
+        const int64_t base_off = boff[(size_t)r.tid];
+        const int64_t ref_len = B->ref_len[(size_t)r.tid];
+        int64_t ref = r.pos, q = 0;
+        for (int k = 0; k < r.n_cigar; k++) {
+            const uint32_t c = S.cigars[r.cigar_off + (uint64_t)k];
+            const int op = c & 15;
+            const int64_t n = c >> 4;
+            if (op == CM || op == CEQ || op == CX) {
+                int64_t j0 = std::max<int64_t>(0, -ref), j1 = std::min<int64_t>(n, ref_len - ref);
+                if (reg_hi >= 0) { j0 = std::max<int64_t>(j0, reg_lo - ref); j1 = std::min<int64_t>(j1, reg_hi - ref); }
+                for (int64_t c0 = j0; c0 < j1; c0 += ISX_SEG_BASES)
+                    f(base_off + ref + c0, q + c0, std::min<int64_t>(ISX_SEG_BASES, j1 - c0));
+                q += n; ref += n;
+            } else if (op == CI || op == CS) q += n;
+            else if (op == CD || op == CN) ref += n;
+        }
+    }
+
+    // segments [first, first + count) of the batch's stream (thread safe); pair may be NULL
+    void emit_segs(int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint32_t *bases) const
+    {
+        size_t ri = (size_t)(std::upper_bound(seg_at.begin(), seg_at.end(), (uint64_t)first) - seg_at.begin()) - 1;
+        int64_t skip = first - (int64_t)seg_at[ri], done = 0;
+        const bool fast = cpu_has_avx2_bmi2();
+        const uint8_t mq = minq;
+        alignas(32) uint8_t cd[192];
+        for (; done < count; ri++) {
+            if (seg_at[ri + 1] == seg_at[ri]) continue;
+            const Read &r = S.reads[ri];
+            const uint8_t m = prm.skip_mm ? (uint8_t)0 : (uint8_t)std::min<int32_t>(255, B->pairs[r.pair_idx].mm);
+            const uint32_t id = pid[ri];
+            for_segments(ri, [&](int64_t g, int64_t q0, int64_t cols) {
+                if (skip > 0) { skip--; return; }
+                if (done >= count) return;
+                if (fast) { seg_codes_avx2(r.seq, r.qual, q0, (int)cols, mq, cd); seg_pack_bmi2(cd, (int)cols, bases + (size_t)done * ISX_SEG_WORDS); }
+                else { seg_codes_scalar(r.seq, r.qual, q0, (int)cols, mq, cd); seg_pack_scalar(cd, (int)cols, bases + (size_t)done * ISX_SEG_WORDS); }
+                gpos[done] = (uint32_t)g; len[done] = (uint8_t)cols; mm[done] = m;
+                if (pair) pair[done] = id;
+                done++;
+            });
+            skip = 0;
+        }
+    }
+
     // observations [first, first + count) of the batch's stream (thread safe)
     void emit_range(int64_t first, uint32_t count, isx_obs *po, uint32_t *pp) const
     {
@@ -1436,7 +1555,8 @@ struct BamBatch {
     int64_t n_obs() const { return (int64_t)out_at.back(); }
 };
 
-int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, BamBatch **out, int64_t reg_lo, int64_t reg_hi)
+int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, BamBatch **out, int64_t reg_lo, int64_t reg_hi,
+                      bool as_segments)
 {
     *out = nullptr;
     isx_bam &B = *bam;
@@ -1623,20 +1743,41 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
         }
     });
     std::vector<uint32_t> firsts((size_t)n_tasks + 1, 0);
-    std::vector<uint64_t> outs((size_t)n_tasks + 1, 0);
+    std::vector<uint64_t> outs((size_t)n_tasks + 1, 0), segs_of((size_t)n_tasks + 1, 0), cols_of((size_t)n_tasks + 1, 0);
     Q->out_at.assign(n_reads + 1, 0);
+    std::vector<uint32_t> seg_cnt;                  // segments of every read
+    if (as_segments) { Q->seg_at.assign(n_reads + 1, 0); seg_cnt.assign(n_reads, 0); }
     pool.run(n_tasks, [&](int t) {
         uint32_t nf = 0;
-        uint64_t no = 0;
+        uint64_t no = 0, ns = 0, nc = 0;
         for (size_t ri = lo_of(t); ri < lo_of(t + 1); ri++) {
             if (!q->emit[ri]) continue;
             nf += first[slot_of(S.reads[ri])] == (uint32_t)ri;
+            if (as_segments) {                      // segments come from the CIGAR alone: no per-base pass
+                uint64_t k = 0;
+                q->for_segments(ri, [&](int64_t, int64_t, int64_t cols) { k++; nc += (uint64_t)cols; });
+                seg_cnt[ri] = (uint32_t)k;
+                ns += k;
+                continue;
+            }
             const uint64_t c = q->count_read(ri);
             q->out_at[ri + 1] = c;
             no += c;
         }
-        firsts[(size_t)t + 1] = nf; outs[(size_t)t + 1] = no;
+        firsts[(size_t)t + 1] = nf; outs[(size_t)t + 1] = no; segs_of[(size_t)t + 1] = ns; cols_of[(size_t)t + 1] = nc;
     });
+    for (int t = 0; t < n_tasks; t++) { segs_of[(size_t)t + 1] += segs_of[(size_t)t]; Q->n_seg_bases += (int64_t)cols_of[(size_t)t + 1]; }
+    if (as_segments) {
+        Q->seg_gpos.resize((size_t)segs_of[(size_t)n_tasks]);
+        pool.run(n_tasks, [&](int t) {
+            uint64_t at = segs_of[(size_t)t];
+            for (size_t ri = lo_of(t); ri < lo_of(t + 1); ri++) {
+                q->seg_at[ri] = at;
+                if (seg_cnt[ri]) q->for_segments(ri, [&](int64_t g, int64_t, int64_t) { q->seg_gpos[(size_t)at++] = (uint32_t)g; });
+            }
+        });
+        q->seg_at[n_reads] = segs_of[(size_t)n_tasks];
+    }
     for (int t = 0; t < n_tasks; t++) { firsts[(size_t)t + 1] += firsts[(size_t)t]; outs[(size_t)t + 1] += outs[(size_t)t]; }
     Q->next_pair = firsts[(size_t)n_tasks];
     pool.run(n_tasks, [&](int t) {
@@ -1679,6 +1820,13 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
 }
 
 void bam_batch_free(BamBatch *q) { delete q; }
+int64_t bam_batch_n_segs(const BamBatch *q) { return (int64_t)q->seg_gpos.size(); }
+int64_t bam_batch_seg_bases(const BamBatch *q) { return q->n_seg_bases; }
+const uint32_t *bam_batch_seg_gpos(const BamBatch *q) { return q->seg_gpos.data(); }
+void bam_batch_emit_segs(const BamBatch *q, int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint32_t *bases)
+{
+    q->emit_segs(first, count, gpos, len, mm, pair, bases);
+}
 int64_t bam_batch_n_obs(const BamBatch *q) { return q->n_obs(); }
 int64_t bam_batch_n_pos(const BamBatch *q) { return q->n_pos; }
 void bam_batch_emit(const BamBatch *q, int64_t first, uint32_t count, isx_obs *obs, uint32_t *pair) { q->emit_range(first, count, obs, pair); }
@@ -1688,7 +1836,8 @@ void bam_batch_info(const BamBatch *q, int32_t n_refs, isx_bam_info *info)
     info->n_refs = n_refs;
     info->n_splits = (int32_t)q->split_ref.size();
     info->n_pos = q->n_pos;
-    info->n_obs = q->n_obs();
+    info->n_obs = q->seg_at.empty() ? q->n_obs() : q->n_seg_bases;
+    info->n_segs = (int64_t)q->seg_gpos.size();
     info->n_pairs = q->next_pair;
     info->max_mm = q->prm.skip_mm ? 0 : q->B->totals.max_mm;
 }
@@ -1701,7 +1850,7 @@ static int expand_into_handle(isx_bam *bam, const isx_bam_params *p, const int32
     if (!bam || !p || n_refs < 0 || (n_refs && !refs)) { isx_set_error("isx_bam_expand_refs: bad argument"); return ISX_ERR_ARG; }
     isx_bam &B = *bam;
     BamBatch *q = nullptr;
-    const int rc = bam_batch_prepare(bam, p, refs, n_refs, &q, reg_lo, reg_hi);
+    const int rc = bam_batch_prepare(bam, p, refs, n_refs, &q, reg_lo, reg_hi, false);
     if (rc != ISX_OK) return rc;
     std::unique_ptr<BamBatch> Q(q);
     // the whole stream into the handle (threads over contiguous pieces; file order is kept)
@@ -1726,6 +1875,51 @@ static int expand_into_handle(isx_bam *bam, const isx_bam_params *p, const int32
 int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info)
 {
     return expand_into_handle(bam, p, refs, n_refs, info, 0, -1);
+}
+
+// the same batch as READ SEGMENTS (isx_segs): what isx_pipe_submit_bam hands a read-level pipe; info->n_obs = the columns
+// the segments cover (an upper bound of the observations), *n_seg = how many isx_bam_copy_segs will deliver
+int isx_bam_segment_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info, int64_t *n_seg)
+{
+    if (!bam || !p || n_refs < 0 || (n_refs && !refs) || !n_seg) { isx_set_error("isx_bam_segment_refs: bad argument"); return ISX_ERR_ARG; }
+    isx_bam &B = *bam;
+    BamBatch *q = nullptr;
+    const int rc = bam_batch_prepare(bam, p, refs, n_refs, &q, 0, -1, true);
+    if (rc != ISX_OK) return rc;
+    std::unique_ptr<BamBatch> Q(q);
+    const size_t n = Q->seg_gpos.size();
+    B.seg_gpos.assign(Q->seg_gpos.begin(), Q->seg_gpos.end());
+    B.seg_len.resize(n); B.seg_mm.resize(n); B.seg_pair.resize(n); B.seg_bases.resize(n * ISX_SEG_WORDS);
+    isxenc::HostPool &pool = pool_of(B);
+    const size_t piece = 4096;
+    std::vector<uint32_t> tmp_gpos(n);
+    pool.run((int)((n + piece - 1) / piece), [&](int t) {
+        const size_t a = (size_t)t * piece, e = std::min(n, a + piece);
+        q->emit_segs((int64_t)a, (int64_t)(e - a), tmp_gpos.data() + a, B.seg_len.data() + a, B.seg_mm.data() + a, B.seg_pair.data() + a,
+                     B.seg_bases.data() + a * ISX_SEG_WORDS);
+    });
+    if (tmp_gpos != B.seg_gpos) { isx_set_error("internal: segment starts of the layout pass and of the emission differ"); return ISX_ERR_STATE; }
+    B.split_bounds = Q->split_bounds;
+    B.split_ref = Q->split_ref;
+    B.expanded = false;
+    if (info) bam_batch_info(q, n_refs, info);
+    *n_seg = (int64_t)n;
+    return ISX_OK;
+}
+
+int isx_bam_copy_segs(const isx_bam *bam, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint32_t *bases, int64_t *split_bounds,
+                      int32_t *split_ref)
+{
+    if (!bam) { isx_set_error("isx_bam_copy_segs: NULL handle"); return ISX_ERR_ARG; }
+    const size_t n = bam->seg_gpos.size();
+    if (gpos && n) memcpy(gpos, bam->seg_gpos.data(), n * 4);
+    if (len && n) memcpy(len, bam->seg_len.data(), n);
+    if (mm && n) memcpy(mm, bam->seg_mm.data(), n);
+    if (pair && n) memcpy(pair, bam->seg_pair.data(), n * 4);
+    if (bases && n) memcpy(bases, bam->seg_bases.data(), n * ISX_SEG_WORDS * 4);
+    if (split_bounds) memcpy(split_bounds, bam->split_bounds.data(), bam->split_bounds.size() * sizeof(int64_t));
+    if (split_ref && !bam->split_ref.empty()) memcpy(split_ref, bam->split_ref.data(), bam->split_ref.size() * sizeof(int32_t));
+    return ISX_OK;
 }
 
 // samfile.pileup(scaffold, start=..., stop=..., truncate=True) of the SNV-pooling re-pileup (polymorpher.py:287-293): only the

@@ -859,20 +859,31 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
     if (!p || !bam || !bp || !refs || n_refs <= 0 || !ref || !ticket) { isx_set_error("isx_pipe_submit_bam: bad argument"); return ISX_ERR_ARG; }
     BamBatch *q = nullptr;
     const double t_in = now_ms();
-    int rc = bam_batch_prepare(bam, bp, refs, n_refs, &q);
+    int rc = bam_batch_prepare(bam, bp, refs, n_refs, &q, 0, -1, p->segs);
     if (rc != ISX_OK) return rc;
     const double t_prep = now_ms();
     std::unique_ptr<BamBatch, void (*)(BamBatch *)> Q(q, bam_batch_free);
-    const int64_t n_pos = bam_batch_n_pos(q), n_obs = bam_batch_n_obs(q);
+    const int64_t n_pos = bam_batch_n_pos(q), n_obs = p->segs ? bam_batch_seg_bases(q) : bam_batch_n_obs(q);
     const std::vector<int64_t> &own = bam_batch_bounds(q);
     if (!split_bounds) { split_bounds = own.data(); n_splits = (int32_t)own.size() - 1; }     // iterate_splits of the front end
     if (n_splits <= 0) { isx_set_error("isx_pipe_submit_bam: no splits"); return ISX_ERR_ARG; }
     if (info) bam_batch_info(q, n_refs, info);
-    isxenc::EncodeJob J;
-    J.obs = nullptr;
-    J.want_pairs = p->prm.enable_linkage != 0;
-    J.produce = [q](int64_t first, uint32_t count, isx_obs *o, uint32_t *pr) { bam_batch_emit(q, first, count, o, pr); };
-    rc = submit_common(p, n_pos, ref, n_splits, split_bounds, n_obs, J, ticket);
+    if (p->segs) {
+        // read-level pipe: the reads' segments are packed (3-bit codes, quality filter applied) straight into the encoder's
+        // per-task scratch and from there into pinned staging -- no per-base records on the host at all
+        isxenc::SegJob J;
+        J.n_seg = bam_batch_n_segs(q);
+        J.gpos_all = bam_batch_seg_gpos(q);
+        J.want_pairs = p->prm.enable_linkage != 0;
+        J.produce = [q](int64_t first, int64_t count, uint32_t *g, uint8_t *l, uint8_t *m, uint32_t *pr, uint32_t *b) { bam_batch_emit_segs(q, first, count, g, l, m, pr, b); };
+        rc = submit_segs_common(p, n_pos, ref, n_splits, split_bounds, J, ticket);
+    } else {
+        isxenc::EncodeJob J;
+        J.obs = nullptr;
+        J.want_pairs = p->prm.enable_linkage != 0;
+        J.produce = [q](int64_t first, uint32_t count, isx_obs *o, uint32_t *pr) { bam_batch_emit(q, first, count, o, pr); };
+        rc = submit_common(p, n_pos, ref, n_splits, split_bounds, n_obs, J, ticket);
+    }
     const double t_sub = now_ms();
     // giving a gigabyte-sized batch back to the system takes as long as encoding it: not on the caller's time
     std::thread([](BamBatch *dead) { bam_batch_free(dead); }, Q.release()).detach();

@@ -15,12 +15,15 @@
 // below min_genome_coverage are dropped like the reference's filter_fasta does in --database_mode
 // (/root/reference/inStrain/profile/fasta.py:110-136, controller.py:211-214).
 #include <stdint.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -100,17 +103,20 @@ void isx_synth_free(isx_synth_out *o)
     memset(o, 0, sizeof *o);
 }
 
-// generate the genomes genome_sel[0..n_sel) (indices of the plan), laid end to end in that order
-int isx_synth_generate(const isx_synth_params *p, const int32_t *genome_sel, int32_t n_sel, const int64_t *length,
-                       const double *coverage, isx_synth_out *out)
+}  // extern "C" (the generator core below is C++)
+
+namespace {
+
+struct Contig { int64_t off, len, n_pairs, obs_off, obs_cap, obs_n, pair0; int genome, contig, plan_genome; uint64_t seed; };
+
+// the contigs of the genomes genome_sel[0..n_sel), laid end to end in that order
+int64_t plan_contigs(const isx_synth_params *p, const int32_t *genome_sel, int32_t n_sel, const int64_t *length, const double *coverage,
+                     std::vector<Contig> &cs, int64_t &obs_cap, int64_t &pair0)
 {
-    if (!p || !genome_sel || n_sel <= 0 || !out) return -1;
-    memset(out, 0, sizeof *out);
     const int RL = p->read_len, C = p->contigs;
-    const int64_t n_sc = (int64_t)n_sel * C;
-    struct Contig { int64_t off, len, n_pairs, obs_off, obs_cap, obs_n, pair0; int genome; uint64_t seed; };
-    std::vector<Contig> cs((size_t)n_sc);
-    int64_t off = 0, obs_cap = 0, pair0 = 0;
+    cs.assign((size_t)n_sel * C, Contig{});
+    int64_t off = 0;
+    obs_cap = 0; pair0 = 0;
     const int64_t min_ins = 2 * (int64_t)RL;
     for (int i = 0; i < n_sel; i++) {
         const int g = genome_sel[i];
@@ -126,13 +132,156 @@ int isx_synth_generate(const isx_synth_params *p, const int32_t *genome_sel, int
             if (c == C - 1) len = std::max<int64_t>(1, L - used);
             used += len;
             Contig &k = cs[(size_t)i * C + c];
-            k.off = off; k.len = len; k.genome = i; k.seed = mix(p->seed, (uint64_t)g, 100 + (uint64_t)c);
+            k.off = off; k.len = len; k.genome = i; k.contig = c; k.plan_genome = g; k.seed = mix(p->seed, (uint64_t)g, 100 + (uint64_t)c);
             const double want = coverage[g] * (double)len / (2.0 * RL);
             k.n_pairs = len >= min_ins + 8 ? (int64_t)(want + r.uni()) : 0;
             k.obs_off = obs_cap; k.obs_cap = k.n_pairs * 2 * RL; k.pair0 = pair0;
             obs_cap += k.obs_cap; pair0 += k.n_pairs; off += len;
         }
     }
+    return off;
+}
+
+// One contig's reference and reads, deterministic in its seed.  emit(read id i (mates 2j, 2j + 1 of pair j), start, bases[RL],
+// keep[RL] (1 = quality >= 30), mismatches of the pair, mismatches of this read) is called read by read in BAM order.
+struct ContigGen {
+    std::vector<int32_t> site_of;
+    std::vector<uint8_t> alt, bases, hap, keep;
+    std::vector<float> af;
+    std::vector<int64_t> rstart;
+    std::vector<uint32_t> order;
+    std::vector<uint16_t> mmv, mmr;
+    int64_t n_sites = 0;
+
+    template <class Emit>
+    void run(const isx_synth_params *p, const Contig &k, uint8_t *ref, Emit &&emit)
+    {
+        const int RL = p->read_len;
+        const int64_t min_ins = 2 * (int64_t)RL;
+        const uint32_t keep_thr = (uint32_t)std::min(65535.0, std::max(0.0, p->p_keep * 65536.0));
+        Rng r(k.seed);
+        for (int64_t i = 0; i < k.len; i += 32) {                  // 2 bits per base
+            uint64_t x = r.next();
+            const int64_t e = std::min<int64_t>(k.len, i + 32);
+            for (int64_t j = i; j < e; j++, x >>= 2) ref[j] = (uint8_t)(x & 3);
+        }
+        n_sites = 0;
+        if (!k.n_pairs) return;
+        // variable sites
+        site_of.assign((size_t)k.len, -1);
+        const int64_t ns = (int64_t)((double)k.len * p->site_frac + r.uni());
+        alt.clear(); af.clear();
+        for (int64_t s = 0; s < ns; s++) {
+            const int64_t pos = (int64_t)r.below((uint64_t)k.len);
+            if (site_of[(size_t)pos] >= 0) continue;
+            site_of[(size_t)pos] = (int32_t)alt.size();
+            alt.push_back((uint8_t)((ref[pos] + 1 + r.below(3)) & 3));
+            af.push_back((float)(p->af_lo + (p->af_hi - p->af_lo) * r.uni()));
+        }
+        n_sites = (int64_t)alt.size();
+        // read starts (pair j: mates 2j, 2j+1), BAM order = by start
+        const int64_t np = k.n_pairs, nr = 2 * np;
+        rstart.resize((size_t)nr); hap.resize((size_t)np); mmv.assign((size_t)np, 0); mmr.assign((size_t)nr, 0);
+        for (int64_t j = 0; j < np; j++) {
+            int64_t ins = (int64_t)(p->insert_mean + p->insert_sd * r.normal());
+            ins = std::min<int64_t>(std::max<int64_t>(ins, min_ins), k.len - 1);
+            const int64_t s1 = (int64_t)r.below((uint64_t)(k.len - ins));
+            rstart[(size_t)(2 * j)] = s1; rstart[(size_t)(2 * j + 1)] = s1 + ins - RL;
+            hap[(size_t)j] = (uint8_t)(r.next() & 1);
+        }
+        order.resize((size_t)nr);
+        for (int64_t i = 0; i < nr; i++) order[(size_t)i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rstart[a] < rstart[b]; });
+        // read bases (in read-id order so mm is known before anything is emitted)
+        bases.resize((size_t)nr * RL);
+        int64_t next_err = p->err > 0 ? (int64_t)(std::log(1.0 - r.uni()) / std::log(1.0 - p->err)) : (int64_t)1 << 62;
+        for (int64_t i = 0; i < nr; i++) {
+            const int64_t st = rstart[(size_t)i];
+            uint8_t *b = bases.data() + (size_t)i * RL;
+            int mm = 0;
+            for (int q = 0; q < RL; q++) {
+                uint8_t v = ref[st + q];
+                const int32_t si = site_of[(size_t)(st + q)];
+                if (si >= 0 && r.uni() < (double)af[(size_t)si] * (hap[(size_t)(i >> 1)] ? 1.6 : 0.4)) v = alt[(size_t)si];
+                if (next_err-- == 0) {
+                    v = (uint8_t)r.below(4);
+                    next_err = (int64_t)(std::log(1.0 - r.uni()) / std::log(1.0 - p->err));
+                }
+                mm += v != ref[st + q];
+                b[q] = v;
+            }
+            mmr[(size_t)i] = (uint16_t)std::min(65535, mm);
+            mmv[(size_t)(i >> 1)] = (uint16_t)std::min<int>(65535, mmv[(size_t)(i >> 1)] + mm);
+        }
+        // BAM order; a base is kept with probability p_keep (16 random bits each)
+        keep.resize((size_t)RL);
+        for (int64_t oi = 0; oi < nr; oi++) {
+            const uint32_t i = order[(size_t)oi];
+            uint64_t bits = 0;
+            for (int q = 0; q < RL; q++) {
+                if ((q & 3) == 0) bits = r.next();
+                keep[(size_t)q] = (uint32_t)(bits & 0xFFFF) < keep_thr;
+                bits >>= 16;
+            }
+            emit(i, rstart[i], bases.data() + (size_t)i * RL, keep.data(), mmv[i >> 1], mmr[i]);
+        }
+    }
+};
+
+// ---- BGZF / BAM output of the same reads (what the front end of the product then decodes) ----
+void bgzf_append(std::string &out, const uint8_t *data, size_t n)
+{
+    for (size_t a = 0; a < n || (n == 0 && a == 0); a += 0xFF00) {
+        const size_t len = std::min<size_t>(0xFF00, n - a);
+        uint8_t comp[0x10000 + 64];
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = const_cast<Bytef *>(data + a); zs.avail_in = (uInt)len;
+        zs.next_out = comp; zs.avail_out = sizeof comp;
+        deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data + a, (uInt)len);
+        const uint16_t bsize = (uint16_t)(clen + 25);
+        const uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 0xFF), (uint8_t)(bsize >> 8)};
+        out.append(reinterpret_cast<const char *>(hdr), 18);
+        out.append(reinterpret_cast<const char *>(comp), clen);
+        const uint32_t isize = (uint32_t)len;
+        out.append(reinterpret_cast<const char *>(&crc), 4);
+        out.append(reinterpret_cast<const char *>(&isize), 4);
+        if (n == 0) break;
+    }
+}
+
+inline int reg2bin(int64_t beg, int64_t end)
+{
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+template <class T> inline void put(std::string &s, T v) { s.append(reinterpret_cast<const char *>(&v), sizeof v); }
+
+}  // namespace
+
+extern "C" {
+
+// generate the genomes genome_sel[0..n_sel) (indices of the plan), laid end to end in that order
+int isx_synth_generate(const isx_synth_params *p, const int32_t *genome_sel, int32_t n_sel, const int64_t *length,
+                       const double *coverage, isx_synth_out *out)
+{
+    if (!p || !genome_sel || n_sel <= 0 || !out) return -1;
+    memset(out, 0, sizeof *out);
+    const int RL = p->read_len, C = p->contigs;
+    const int64_t n_sc = (int64_t)n_sel * C;
+    std::vector<Contig> cs;
+    int64_t obs_cap = 0, pair0 = 0;
+    const int64_t off = plan_contigs(p, genome_sel, n_sel, length, coverage, cs, obs_cap, pair0);
     if (off >= (int64_t)0xFFFF0000ll || pair0 >= (int64_t)0xFFFFFFFFll) return -2;
     out->n_pos = off; out->n_pairs = pair0; out->n_scaffolds = n_sc;
     out->profiled_bases = pair0 * 2 * RL;
@@ -146,94 +295,27 @@ int isx_synth_generate(const isx_synth_params *p, const int32_t *genome_sel, int
     out->scaffold_bounds[n_sc] = off;
 
     std::atomic<int64_t> next{0}, n_sites{0};
-    const uint32_t keep_thr = (uint32_t)std::min(65535.0, std::max(0.0, p->p_keep * 65536.0));
     auto work = [&]() {
-        std::vector<int32_t> site_of;
-        std::vector<uint8_t> alt, bases, hap;
-        std::vector<float> af;
-        std::vector<int64_t> rstart;
-        std::vector<uint32_t> order;
-        std::vector<uint16_t> mmv;
+        ContigGen G;
         for (;;) {
             const int64_t ci = next.fetch_add(1);
             if (ci >= n_sc) break;
             Contig &k = cs[(size_t)ci];
-            Rng r(k.seed);
-            uint8_t *ref = out->ref + k.off;
-            for (int64_t i = 0; i < k.len; i += 32) {                  // 2 bits per base
-                uint64_t x = r.next();
-                const int64_t e = std::min<int64_t>(k.len, i + 32);
-                for (int64_t j = i; j < e; j++, x >>= 2) ref[j] = (uint8_t)(x & 3);
-            }
-            k.obs_n = 0;
-            if (!k.n_pairs) continue;
-            // variable sites
-            site_of.assign((size_t)k.len, -1);
-            const int64_t ns = (int64_t)((double)k.len * p->site_frac + r.uni());
-            alt.clear(); af.clear();
-            for (int64_t s = 0; s < ns; s++) {
-                const int64_t pos = (int64_t)r.below((uint64_t)k.len);
-                if (site_of[(size_t)pos] >= 0) continue;
-                site_of[(size_t)pos] = (int32_t)alt.size();
-                alt.push_back((uint8_t)((ref[pos] + 1 + r.below(3)) & 3));
-                af.push_back((float)(p->af_lo + (p->af_hi - p->af_lo) * r.uni()));
-            }
-            n_sites.fetch_add((int64_t)alt.size());
-            // read starts (pair j: mates 2j, 2j+1), BAM order = by start
-            const int64_t np = k.n_pairs, nr = 2 * np;
-            rstart.resize((size_t)nr); hap.resize((size_t)np); mmv.assign((size_t)np, 0);
-            for (int64_t j = 0; j < np; j++) {
-                int64_t ins = (int64_t)(p->insert_mean + p->insert_sd * r.normal());
-                ins = std::min<int64_t>(std::max<int64_t>(ins, min_ins), k.len - 1);
-                const int64_t s1 = (int64_t)r.below((uint64_t)(k.len - ins));
-                rstart[(size_t)(2 * j)] = s1; rstart[(size_t)(2 * j + 1)] = s1 + ins - RL;
-                hap[(size_t)j] = (uint8_t)(r.next() & 1);
-            }
-            order.resize((size_t)nr);
-            for (int64_t i = 0; i < nr; i++) order[(size_t)i] = (uint32_t)i;
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rstart[a] < rstart[b]; });
-            // read bases (in read-id order so mm is known before anything is emitted)
-            bases.resize((size_t)nr * RL);
-            int64_t next_err = p->err > 0 ? (int64_t)(std::log(1.0 - r.uni()) / std::log(1.0 - p->err)) : (int64_t)1 << 62;
-            for (int64_t i = 0; i < nr; i++) {
-                const int64_t st = rstart[(size_t)i];
-                uint8_t *b = bases.data() + (size_t)i * RL;
-                int mm = 0;
-                for (int q = 0; q < RL; q++) {
-                    uint8_t v = ref[st + q];
-                    const int32_t si = site_of[(size_t)(st + q)];
-                    if (si >= 0 && r.uni() < (double)af[(size_t)si] * (hap[(size_t)(i >> 1)] ? 1.6 : 0.4)) v = alt[(size_t)si];
-                    if (next_err-- == 0) {
-                        v = (uint8_t)r.below(4);
-                        next_err = (int64_t)(std::log(1.0 - r.uni()) / std::log(1.0 - p->err));
-                    }
-                    mm += v != ref[st + q];
-                    b[q] = v;
-                }
-                mmv[(size_t)(i >> 1)] = (uint16_t)std::min<int>(65535, mmv[(size_t)(i >> 1)] + mm);
-            }
-            // emit in BAM order; a base is kept with probability p_keep (16 random bits each)
             synth_obs *o = out->obs + k.obs_off;
             uint32_t *pr = out->pair + k.obs_off;
             int64_t n = 0;
-            for (int64_t oi = 0; oi < nr; oi++) {
-                const uint32_t i = order[(size_t)oi];
-                const int64_t st = rstart[i];
-                const uint8_t *b = bases.data() + (size_t)i * RL;
-                const uint16_t mm = p->with_mm ? (uint16_t)std::min<int>(p->max_mm, mmv[i >> 1]) : (uint16_t)0;
+            G.run(p, k, out->ref + k.off, [&](uint32_t i, int64_t st, const uint8_t *b, const uint8_t *keep, uint16_t mm_pair, uint16_t) {
+                const uint16_t mm = p->with_mm ? (uint16_t)std::min<int>(p->max_mm, mm_pair) : (uint16_t)0;
                 const uint32_t pid = (uint32_t)(k.pair0 + (i >> 1));
-                uint64_t bits = 0;
                 for (int q = 0; q < RL; q++) {
-                    if ((q & 3) == 0) bits = r.next();
-                    const uint32_t u = (uint32_t)(bits & 0xFFFF);
-                    bits >>= 16;
-                    if (u >= keep_thr) continue;
+                    if (!keep[q]) continue;
                     o[n].gpos = (uint32_t)(k.off + st + q); o[n].mm = mm; o[n].base = b[q]; o[n].flags = 0;
                     pr[n] = pid;
                     n++;
                 }
-            }
+            });
             k.obs_n = n;
+            n_sites.fetch_add(G.n_sites);
         }
     };
     const int nt = std::max(1, p->threads);
@@ -255,6 +337,98 @@ int isx_synth_generate(const isx_synth_params *p, const int32_t *genome_sel, int
     return 0;
 }
 
+// The same genomes as a coordinate-sorted BAM: one @SQ per contig ("g<genome>_c<contig>", genome = index of the plan), the
+// reads of isx_synth_generate record for record (2 x read_len, <read_len>M, proper pairs, quality 37 where the generator keeps a
+// base and 12 where it drops it, NM = the read's mismatches), contig after contig.  Returns the number of reads written, < 0 on error.
+// ref_out (may be NULL): [sum of contig lengths] base codes, the FASTA of the file.
+int64_t isx_synth_write_bam(const isx_synth_params *p, const int32_t *genome_sel, int32_t n_sel, const int64_t *length,
+                            const double *coverage, const char *path, uint8_t *ref_out, int64_t *n_pos_out, int64_t *n_pairs_out)
+{
+    if (!p || !genome_sel || n_sel <= 0 || !path) return -1;
+    const int RL = p->read_len, C = p->contigs;
+    const int64_t n_sc = (int64_t)n_sel * C;
+    std::vector<Contig> cs;
+    int64_t obs_cap = 0, pair0 = 0;
+    const int64_t off = plan_contigs(p, genome_sel, n_sel, length, coverage, cs, obs_cap, pair0);
+    if (n_pos_out) *n_pos_out = off;
+    if (n_pairs_out) *n_pairs_out = pair0;
+    std::vector<uint8_t> own_ref;
+    if (!ref_out) { own_ref.resize((size_t)std::max<int64_t>(off, 1)); ref_out = own_ref.data(); }
+    // header
+    std::string head, text = "@HD\tVN:1.6\tSO:coordinate\n";
+    char name[64];
+    for (auto &k : cs) { snprintf(name, sizeof name, "g%05d_c%03d", k.plan_genome, k.contig); text += std::string("@SQ\tSN:") + name + "\tLN:" + std::to_string(k.len) + "\n"; }
+    head.append("BAM\1", 4);
+    put<int32_t>(head, (int32_t)text.size());
+    head += text;
+    put<int32_t>(head, (int32_t)n_sc);
+    for (auto &k : cs) {
+        snprintf(name, sizeof name, "g%05d_c%03d", k.plan_genome, k.contig);
+        put<int32_t>(head, (int32_t)strlen(name) + 1);
+        head.append(name, strlen(name) + 1);
+        put<int32_t>(head, (int32_t)k.len);
+    }
+    std::vector<std::string> part((size_t)n_sc);
+    std::atomic<int64_t> next{0}, n_reads{0};
+    static const uint8_t NIB[4] = {1, 2, 8, 4};         // A C T G (P2C order) -> BAM 4-bit codes
+    auto work = [&]() {
+        ContigGen G;
+        std::string raw;
+        for (;;) {
+            const int64_t ci = next.fetch_add(1);
+            if (ci >= n_sc) break;
+            const Contig &k = cs[(size_t)ci];
+            raw.clear();
+            raw.reserve((size_t)k.n_pairs * 2 * (size_t)(60 + RL + RL / 2));
+            int64_t nr = 0;
+            G.run(p, k, ref_out + k.off, [&](uint32_t i, int64_t st, const uint8_t *b, const uint8_t *keep, uint16_t, uint16_t mm_read) {
+                const bool first = (i & 1) == 0;
+                const int64_t mate = G.rstart[i ^ 1];
+                const int64_t lo = std::min(st, mate), hi = std::max(st, mate) + RL;
+                const int32_t tlen = (int32_t)(st <= mate ? hi - lo : -(hi - lo));
+                char rn[48];
+                const int l_name = snprintf(rn, sizeof rn, "g%dc%dp%lld", k.plan_genome, k.contig, (long long)(i >> 1)) + 1;
+                const int32_t block = 32 + l_name + 4 + (RL + 1) / 2 + RL + 4;
+                put<int32_t>(raw, block);
+                put<int32_t>(raw, (int32_t)ci);
+                put<int32_t>(raw, (int32_t)st);
+                put<uint8_t>(raw, (uint8_t)l_name);
+                put<uint8_t>(raw, 42);
+                put<uint16_t>(raw, (uint16_t)reg2bin(st, st + RL));
+                put<uint16_t>(raw, 1);
+                put<uint16_t>(raw, (uint16_t)(0x1 | 0x2 | (first ? 0x40 | 0x20 : 0x80 | 0x10)));
+                put<int32_t>(raw, RL);
+                put<int32_t>(raw, (int32_t)ci);
+                put<int32_t>(raw, (int32_t)mate);
+                put<int32_t>(raw, tlen);
+                raw.append(rn, (size_t)l_name);
+                put<uint32_t>(raw, ((uint32_t)RL << 4) | 0u);
+                for (int q = 0; q < RL; q += 2) put<uint8_t>(raw, (uint8_t)((NIB[b[q]] << 4) | (q + 1 < RL ? NIB[b[q + 1]] : 0)));
+                for (int q = 0; q < RL; q++) put<uint8_t>(raw, keep[q] ? 37 : 12);
+                raw.append("NMC", 3);
+                put<uint8_t>(raw, (uint8_t)std::min<int>(255, mm_read));
+                nr++;
+            });
+            if (!raw.empty()) bgzf_append(part[(size_t)ci], reinterpret_cast<const uint8_t *>(raw.data()), raw.size());
+            n_reads.fetch_add(nr);
+        }
+    };
+    const int nt = std::max(1, p->threads);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    FILE *f = fopen(path, "wb");
+    if (!f) return -4;
+    std::string hz;
+    bgzf_append(hz, reinterpret_cast<const uint8_t *>(head.data()), head.size());
+    bool ok = fwrite(hz.data(), 1, hz.size(), f) == hz.size();
+    for (auto &s : part) if (ok && !s.empty()) ok = fwrite(s.data(), 1, s.size(), f) == s.size();
+    static const uint8_t eof_block[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(eof_block, 1, 28, f) == 28;
+    ok = fclose(f) == 0 && ok;
+    return ok ? n_reads.load() : -5;
+}
 
 // ---- observation stream -> read segments (include/instrain_amd.h isx_segs) ----
 // What the read-level hand-over ships for the same workload: consecutive observations of one read pair / mm level at

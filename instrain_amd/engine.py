@@ -574,6 +574,24 @@ class BamFile:
         self._info(info)
         return self._results(info, copy)
 
+    def segment_refs(self, refs, **kw):
+        """pass 2 for the reference indices `refs` as READ SEGMENTS (what a read-level pipe is handed): -> (SegBatch,
+        split_bounds, split_ref); info["n_obs"] = the columns the segments cover"""
+        refs = np.ascontiguousarray(refs, dtype=np.int32)
+        info = BamInfo()
+        p = self._params(**kw)
+        n = C.c_int64(0)
+        check(self.lib.isx_bam_segment_refs(self.h, C.byref(p), refs.ctypes.data, len(refs), C.byref(info), C.byref(n)))
+        self._info(info)
+        k = n.value
+        g, ln, mm, pr = np.empty(k, np.uint32), np.empty(k, np.uint8), np.empty(k, np.uint8), np.empty(k, np.uint32)
+        bs = np.empty((k, _lib.SEG_WORDS), np.uint32)
+        bounds = np.empty(info.n_splits + 1, dtype=np.int64)
+        sref = np.empty(info.n_splits, dtype=np.int32)
+        check(self.lib.isx_bam_copy_segs(self.h, g.ctypes.data, ln.ctypes.data, mm.ctypes.data, pr.ctypes.data, bs.ctypes.data,
+                                         bounds.ctypes.data, sref.ctypes.data))
+        return SegBatch(g, ln, bs, mm, pr), bounds, sref
+
     def expand_region(self, ref, start, stop, copy=True, **kw):
         """pass 2 for the columns [start, stop) of reference index `ref` only (the re-pileup of SNV pooling)"""
         info = BamInfo()

@@ -143,8 +143,9 @@ class _BatchTables:
             clonTR = {0: pd.Series(self.rare_val[r0:r1].astype("float32"), index=self.rare_pos[r0:r1] - off)}
         return covT, clonT, clonTR
 
-    def snp_table(self, i):
-        snv = self.snv[self.s_cut[i]:self.s_cut[i + 1]]
+    def snp_table(self, i, i_end=None):
+        """raw_snp_table of split i, or of the consecutive splits [i, i_end) of ONE scaffold"""
+        snv = self.snv[self.s_cut[i]:self.s_cut[i + 1 if i_end is None else i_end]]
         if not len(snv):
             return pd.DataFrame()
         cnt = snv["cnt"].astype(np.int64)
@@ -198,42 +199,52 @@ class SplitObject():
         return self.__dict__[name]
 
     def materialize(self):
+        """cut this split's tables out of the batch and let go of the batch"""
         for a in ('covT', 'raw_snp_table', 'raw_linkage_table'):
             getattr(self, a)
+        src = self.__dict__.get('_src')
+        if src is not None and src[0].pileup_counts is not None:
+            getattr(self, 'pileup_counts')
         self.__dict__.pop('_src', None)
         return self
 
-    def merge_single_profile(self, ScaffoldSplitObject):
-        '''Convert self into a scaffold_profile object (profile_utilities.py:831-858)'''
-        Sprofile = _scaffold_profile_class()()
-        Sprofile.scaffold = self.scaffold
+    def __getstate__(self):
+        # The reference puts split objects on multiprocessing queues (profile_controller.py:273-314): a pickled split
+        # carries its OWN tables, not the arrays of the whole device batch it was cut from
+        self.materialize()
+        return dict(self.__dict__)
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    # what the merge step copies from a split / from the ScaffoldSplitObject (profile_utilities.py:831-858)
+    _OWN_FIELDS = ('scaffold', 'bam', 'length', 'raw_snp_table', 'raw_linkage_table', 'covT', 'clonT', 'clonTR', 'min_freq')
+    _OPTIONAL_FIELDS = ('read_to_snvs', 'mm_to_position_graph', 'pileup_counts', 'profile_genes', 'gene_database', 'gene2sequence')
+    _PARENT_FIELDS = ('profile_genes', 'gene_database', 'gene2sequence')
+
+    def merge_single_profile(self, ScaffoldSplitObject, profile_class=None):
+        """A scaffold of one split becomes its scaffold_profile (profile_utilities.py:831-858).  profile_class: the class to
+        instantiate -- inside the reference's process the caller passes inStrain's own scaffold_profile (what its merge
+        worker and everything downstream expect); default: the mirror below."""
+        Sprofile = (profile_class or SCAFFOLD_PROFILE_CLASS or scaffold_profile)()
+        for att in SplitObject._OWN_FIELDS:
+            setattr(Sprofile, att, getattr(self, att))
         Sprofile.null_model = ScaffoldSplitObject.null_model
-        Sprofile.bam = self.bam
-        Sprofile.length = self.length
-        Sprofile.raw_snp_table = self.raw_snp_table
-        Sprofile.raw_linkage_table = self.raw_linkage_table
-        Sprofile.covT = self.covT
-        Sprofile.clonT = self.clonT
-        Sprofile.clonTR = self.clonTR
-        Sprofile.min_freq = self.min_freq
-        for att in ['read_to_snvs', 'mm_to_position_graph', 'pileup_counts'] + ['profile_genes', 'gene_database', 'gene2sequence']:
+        for att in SplitObject._OPTIONAL_FIELDS:
             if att in self.__dict__ or (att == 'pileup_counts' and hasattr(self, att)):
                 setattr(Sprofile, att, getattr(self, att))
-        for att in ['profile_genes', 'gene_database', 'gene2sequence']:
+        for att in SplitObject._PARENT_FIELDS:
             if hasattr(ScaffoldSplitObject, att):
                 setattr(Sprofile, att, getattr(ScaffoldSplitObject, att))
         Sprofile.make_cumulative_tables()
         return Sprofile
 
 
-def _scaffold_profile_class():
-    """inside the reference's process its own scaffold_profile is used (the merge worker and everything after it
-    expect that class); standalone, the mirror below"""
-    try:
-        from inStrain.profile.profile_utilities import scaffold_profile as ref_cls
-        return ref_cls
-    except Exception:
-        return scaffold_profile
+# The class SplitObject.merge_single_profile instantiates when the caller names none.  The reference's merge worker calls
+# split.merge_single_profile(self) with one argument and expects ITS scaffold_profile back: an integration sets this once
+# (INTEGRATION.md: instrain_amd.profile.profile_utilities.SCAFFOLD_PROFILE_CLASS = inStrain...scaffold_profile); product
+# code never imports the reference itself.
+SCAFFOLD_PROFILE_CLASS = None
 
 
 def merge_basewise(mm2array_list):
@@ -287,17 +298,10 @@ class scaffold_profile():
 
 
 def _make_snp_table(Stable):
-    """profile_utilities.py:576-596"""
-    if Stable is not False:
-        try:
-            Sdb = pd.DataFrame(Stable)
-            Sdb['scaffold'] = Sdb['scaffold'].astype('category')
-            Sdb['con_base'] = Sdb['con_base'].astype('category')
-        except KeyError:
-            Sdb = pd.DataFrame()
-    else:
-        Sdb = pd.DataFrame()
-    return Sdb
+    """profile_utilities.py:576-596: the raw table with its two string columns as categories; no rows / no table -> empty"""
+    if Stable is False or Stable is None or 'scaffold' not in getattr(Stable, 'columns', ()):
+        return pd.DataFrame()
+    return pd.DataFrame(Stable).astype({'scaffold': 'category', 'con_base': 'category'})
 
 
 def _parse_Sdb(sdb):
@@ -501,16 +505,44 @@ def _failure_log(scaffold, split_number):
     return "\n{1} DEBUG FAILURE SplitException {0} {2}\n".format(scaffold, t, split_number)   # profile_utilities.py:108-110
 
 
-def _scaffold_splits(fasta_db, name, length, window_length):
-    """(split_number, start, end) of a scaffold: fasta_db's rows when given (fasta.py:33-40), else iterate_splits"""
-    if fasta_db is not None:
-        db = fasta_db[fasta_db['scaffold'] == name].sort_values('start')
-        rows = [(int(r.split_number), int(r.start), int(r.end)) for r in db.itertuples()]
-        # _validate_splits (fasta.py:75-85): 0-based, double inclusive, covering the scaffold
-        if not rows or rows[0][1] != 0 or rows[-1][2] != length - 1 or any(a[2] + 1 != b[1] for a, b in zip(rows, rows[1:])):
-            raise ValueError("fasta_db splits of {0} do not tile [0, {1})".format(name, length))
-        return rows
-    return [(i, s, e) for i, (s, e) in enumerate(iterate_splits(length, window_length))]
+def plan_scaffolds(fasta_db, wanted_lengths, window_length):
+    """{scaffold: [(split_number, start, end), ...]} for every scaffold of `wanted_lengths` (name -> length), and
+    {scaffold: exception} for those whose splits are unusable.  With a fasta_db its rows decide (fasta.py:33-40,
+    profile_controller.py:415-433) -- ONE pass over the table (factorize + one sort), like the reference's single groupby
+    (:420), not one filter of the whole table per scaffold; without it iterate_splits (fasta.py:56-73).
+    _validate_splits (fasta.py:75-85): 0-based, double inclusive, tiling the scaffold."""
+    plan, bad = {}, {}
+    if fasta_db is None:
+        for name, ln in wanted_lengths.items():
+            plan[name] = [(i, s, e) for i, (s, e) in enumerate(iterate_splits(ln, window_length))]
+        return plan, bad
+    codes, names = pd.factorize(fasta_db['scaffold'].values, sort=False)
+    start = fasta_db['start'].values.astype(np.int64)
+    end = fasta_db['end'].values.astype(np.int64)
+    num = fasta_db['split_number'].values.astype(np.int64)
+    order = np.lexsort((start, codes))
+    codes_o, start_o, end_o, num_o = codes[order], start[order], end[order], num[order]
+    first = np.r_[0, np.flatnonzero(np.diff(codes_o)) + 1, len(codes_o)] if len(codes_o) else np.zeros(1, np.int64)
+    tiles = np.ones(len(codes_o), dtype=bool)
+    if len(codes_o) > 1:
+        tiles[1:] = (end_o[:-1] + 1 == start_o[1:]) | (codes_o[1:] != codes_o[:-1])
+    bad_rows = np.add.reduceat(~tiles, first[:-1]) if len(codes_o) else np.zeros(0, np.int64)
+    for g in range(len(first) - 1):
+        a, e = int(first[g]), int(first[g + 1])
+        name = names[codes_o[a]]
+        if name not in wanted_lengths:
+            continue
+        ln = wanted_lengths[name]
+        if start_o[a] != 0 or end_o[e - 1] != ln - 1 or bad_rows[g]:
+            bad[name] = ValueError("fasta_db splits of {0} do not tile [0, {1})".format(name, ln))
+            continue
+        plan[name] = list(zip(num_o[a:e].tolist(), start_o[a:e].tolist(), end_o[a:e].tolist()))
+    return plan, bad
+
+
+class _Group:
+    """one device batch of whole scaffolds: its flat layout"""
+    __slots__ = ("items", "tids", "bounds", "s_scaff", "s_num", "s_off", "s_len", "ref", "n_pos", "first_split", "ticket", "est_segs")
 
 
 def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
@@ -521,16 +553,29 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
     plus `s2s` (scaffold -> upper-cased sequence, controller.py:337), `null_model` (dict, snv_utilities.py:14-38),
     optionally `ctx` (an engine.Context to reuse), `device`, `scaffold_tables` (dict that receives every scaffold's
     cumulative_scaffold_table from the device summaries), `logs` (list that receives the failure lines),
-    `batch_positions` / `batch_observations` (size of a device batch).
+    `batch_positions` / `batch_reads` (size of a device batch; `batch_observations` is accepted as 150 x batch_reads), `pipe_depth` (device batches in flight: the front end
+    prepares batch k + 1 while batch k is profiled and its tables are cut), `stats` (dict that receives stage times).
+    The BAM's reads go to the device as read segments (isx_pipe_submit_bam on a read-level pipe): the host never expands a
+    read into per-base records.
     Returns {"scaffold.split": SplitObject} = Sprofile_dict (profile_utilities.py:85)."""
     s2s = kwargs['s2s']
     null_model = kwargs['null_model']
     logs = kwargs.get('logs')
+    stats = kwargs.get('stats')
     W = int(kwargs.get('window_length', 10000))
     skip_mm = bool(kwargs.get('skip_mm_profiling', False))
     min_freq = float(kwargs.get('min_freq', .05))
     store_everything = bool(kwargs.get('store_everything', False))
+    # the CLI always passes its own default of 50 (argumentParser.py:170); profile_split's fallback of 5 (:143) is never reached from it
+    rarefied = int(kwargs.get('rarefied_coverage', 50))
     out = {}
+    t_stage = [time.perf_counter()]
+
+    def stage(name):
+        if stats is not None:
+            now = time.perf_counter()
+            stats[name] = stats.get(name, 0.0) + (now - t_stage[0]) * 1e3
+            t_stage[0] = now
 
     def fail(scaffold, split_numbers, exc=None):
         if exc is not None:
@@ -552,25 +597,32 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         bf = kwargs.get('bamfile') or engine.BamFile(bam, threads=int(kwargs.get('host_threads', 0)))
         refs = bf.refs()
         tid_of = {n: i for i, (n, _, _) in enumerate(refs)}
-        wanted = list(dict.fromkeys(fasta_db['scaffold'])) if fasta_db is not None else [n for n, _, _ in refs if n in s2s]
+        if fasta_db is not None:
+            wanted = list(dict.fromkeys(fasta_db['scaffold'].values.tolist()))
+            rows_of = fasta_db['scaffold'].value_counts(sort=False).to_dict()
+        else:
+            wanted = [n for n, _, _ in refs if n in s2s]
+            rows_of = {}
         # ---- which scaffolds can be profiled at all ----
-        plan = []                                    # (tid, name, [(split_number, start, end)])
+        usable, failed = {}, {}
         for name in wanted:
-            try:
-                if name not in tid_of:               # samfile.pileup raises ValueError -> (None, log) (profile_utilities.py:154-156)
-                    raise ValueError("scaffold {0} is not in the .bam file {1}!".format(name, bam))
-                ln = refs[tid_of[name]][1]
-                if name not in s2s or len(s2s[name]) != ln:
-                    raise ValueError("scaffold {0} has no sequence / its length differs from the .bam header".format(name))
-                plan.append((tid_of[name], name, _scaffold_splits(fasta_db, name, ln, W)))
-            except Exception as e:
-                n_splits = len(fasta_db[fasta_db['scaffold'] == name]) if fasta_db is not None else 1
-                fail(name, range(n_splits), e)
-        plan.sort()                                  # file order: the record stream stays position-clustered
+            if name not in tid_of:                   # samfile.pileup raises ValueError -> (None, log) (profile_utilities.py:154-156)
+                failed[name] = ValueError("scaffold {0} is not in the .bam file {1}!".format(name, bam))
+            elif name not in s2s or len(s2s[name]) != refs[tid_of[name]][1]:
+                failed[name] = ValueError("scaffold {0} has no sequence / its length differs from the .bam header".format(name))
+            else:
+                usable[name] = refs[tid_of[name]][1]
+        splits_of, bad = plan_scaffolds(fasta_db, usable, W)
+        failed.update(bad)
+        for name, e in failed.items():
+            fail(name, range(int(rows_of.get(name, 1))), e)
+        plan = sorted((tid_of[name], name, sp) for name, sp in splits_of.items())     # file order: the stream stays position-clustered
+        stage("plan_ms")
         if not plan:
             return out
         # ---- read pairs: the controller's R2M, or the built-in filter ----
         bf.scan(part=kwargs.get('scan_part'))
+        stage("scan_ms")
         fkw = dict(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
                    max_insert_relative=kwargs.get('max_insert_relative', 3), min_insert=kwargs.get('min_insert', 50),
                    pairing_filter=kwargs.get('pairing_filter', 'paired_only'))
@@ -587,95 +639,154 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                 else:
                     bf.set_r2m(tid, list(r2m.keys()), [0 if skip_mm else int(v) for v in r2m.values()])
             bf.scan(part=kwargs.get('scan_part'))    # refresh the totals (max_mm now comes from the controller's values)
-        info = dict(bf.info) if bf.info else {}
         n_mm = 1 if skip_mm else int(bf.info["max_mm"]) + 1
-        if 's2p' in kwargs and isinstance(kwargs['s2p'], dict):
-            pass
+        if n_mm > 128:
+            raise ValueError("a read pair with {0} mismatches: more than the 128 mm levels a device batch holds "
+                             "(profile with --skip_mm_profiling or a higher --min_read_ani)".format(n_mm - 1))
         reads_per_ref, pairs_per_ref = bf.ref_counts()
         bf.drop_names()
-        # ---- batches of whole scaffolds under a position / observation budget ----
-        mean_pair = (info.get("filtered_bases", 0) / info["filtered_pairs"]) if info.get("filtered_pairs") else 300.0
-        est_obs = [int(pairs_per_ref[tid] * mean_pair) + 1024 for tid, _, _ in plan]
+        stage("filter_ms")
+        # ---- batches of whole scaffolds under a position / read budget; the reference groups its commands by estimated
+        #      cost the same way (profile_controller.py:436-457) ----
+        est_segs = [int(reads_per_ref[tid] * 1.25) + 64 for tid, _, _ in plan]     # a read = 1 segment + 1 per indel
         max_pos = int(kwargs.get('batch_positions', 64_000_000))
-        max_obs = int(kwargs.get('batch_observations', 256_000_000))
-        groups = idist.pack_batches([refs[tid][1] for tid, _, _ in plan], est_obs, max_pos, max_obs)
+        max_segs = int(kwargs.get('batch_reads', max(64, int(kwargs['batch_observations']) // 150) if 'batch_observations' in kwargs else 4_000_000))
+        item_groups = idist.pack_batches([refs[tid][1] for tid, _, _ in plan], est_segs, max_pos, max_segs)
 
-        def run_group(items, depth_hint):
-            """one batch through expand -> device -> SplitObjects; raises on failure"""
-            nonlocal pipe
-            tids = [plan[k][0] for k in items]
-            bounds, s_scaff, s_num, s_off, s_len, seqs = [], [], [], [], [], []
+        def layout(items):
+            g = _Group()
+            g.items, g.tids = items, [plan[k][0] for k in items]
+            bounds, s_scaff, s_num, s_off, s_len, seqs, first_split = [], [], [], [], [], [], []
             off = 0
-            est = 0
             for k in items:
                 tid, name, splits = plan[k]
+                first_split.append(len(bounds))
                 for (num, s, e) in splits:
                     bounds.append(off + s)
                     s_scaff.append(name); s_num.append(num); s_off.append(off); s_len.append(e - s + 1)
                 seqs.append(engine.encode_seq(str(s2s[name]).upper()))
                 off += refs[tid][1]
-                est += est_obs[k]
+            first_split.append(len(bounds))
             bounds.append(off)
-            ref = np.concatenate(seqs) if len(seqs) > 1 else seqs[0]
-            need = (off, int(est * 1.1) + 4096, len(bounds))
-            t = None
-            for attempt in range(3):
-                if pipe is None or need[0] > pipe.cap[0] or need[1] > pipe.cap[1] or need[2] > pipe.cap[2]:
-                    if pipe is not None:
-                        pipe.close()
-                    cap = (max(need[0], 1 << 16), max(need[1], 1 << 16), max(need[2], 64))
-                    pipe = engine.Pipe(ctx, max_pos=cap[0], max_obs=cap[1], max_splits=cap[2], depth=1,
-                                       host_threads=int(kwargs.get('host_threads', 0)), pin_threads=False,
-                                       ring_kib=int(kwargs.get('staging_ring_kib', 0)),
-                                       jump_slack=(0.1, 0.5, 2.0)[attempt],
-                                       min_cov=int(kwargs.get('min_cov', 5)), min_freq=min_freq, min_snp=int(kwargs.get('min_snp', 10)),
-                                       rarefied_coverage=int(kwargs.get('rarefied_coverage', 5)), n_mm_bins=n_mm,
-                                       enable_linkage=True, seed=int(kwargs.get('seed', 0)), want_counts=store_everything)
-                    pipe.cap = cap
-                try:
-                    t = pipe.submit_bam(bf, tids, ref, bounds, **ekw)
-                    break
-                except engine.IsxError as e:        # the estimate was short / the stream jumps a lot: a larger slot
-                    if e.code != -3 or attempt == 2:
-                        raise
-                    n_real = int(bf.info["n_obs"]) if bf.info and bf.info.get("n_obs") else need[1] * 2
-                    need = (need[0], max(int(n_real * 1.05) + 4096, need[1] + 1), need[2])
-                    pipe.close()
-                    pipe = None
+            g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len = np.asarray(bounds, np.int64), s_scaff, s_num, s_off, s_len
+            g.ref = np.concatenate(seqs) if len(seqs) > 1 else seqs[0]
+            g.n_pos, g.first_split = off, first_split
+            g.est_segs = sum(est_segs[k] for k in items)
+            g.ticket = None
+            return g
+
+        depth = max(1, int(kwargs.get('pipe_depth', 2 if len(item_groups) > 1 else 1)))
+
+        def make_pipe(need):
+            cap = (max(need[0], 1 << 16), max(need[1], 1 << 12), max(need[2], 64))
+            pp = engine.Pipe(ctx, max_pos=cap[0], max_obs=0, max_segs=cap[1], max_splits=cap[2], depth=depth,
+                             host_threads=int(kwargs.get('host_threads', 0)), pin_threads=False,
+                             min_cov=int(kwargs.get('min_cov', 5)), min_freq=min_freq, min_snp=int(kwargs.get('min_snp', 10)),
+                             rarefied_coverage=rarefied, n_mm_bins=n_mm,
+                             enable_linkage=True, seed=int(kwargs.get('seed', 0)), want_counts=store_everything)
+            pp.cap = cap
+            return pp
+
+        def submit(g):
+            """the front end's pass 2 for the group's scaffolds + hand-over; returns False when the pipe is too small"""
+            try:
+                g.ticket = pipe.submit_bam(bf, g.tids, g.ref, g.bounds, **ekw)
+                return True
+            except engine.IsxError as e:
+                if e.code != -3:
+                    raise
+                return False
+
+        def collect(g):
+            """tables of a submitted group -> SplitObjects"""
+            t = g.ticket
             try:
                 res = pipe.collect(t, rare_list=False)
                 if res.get("n_saturated"):           # coverage beyond the 16-bit hand-back: take the exact counts
                     full = res["slot"].fetch()
                     res["counts"] = full["counts"]
-                splits = tables_to_splits(res, np.asarray(bounds), s_scaff, s_num, s_off, s_len, min_freq, bam)
+                splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam)
                 if kwargs.get('scaffold_tables') is not None:
-                    sb = np.r_[0, np.cumsum([refs[plan[k][0]][1] for k in items])]
+                    sb = np.r_[0, np.cumsum([refs[tid][1] for tid in g.tids])]
                     levels, _ = res["slot"].summarize(sb)
-                    for j, k in enumerate(items):
+                    tables = splits[0]._src[0] if splits else None
+                    for j, k in enumerate(g.items):
                         name = plan[k][1]
-                        snp = [S.raw_snp_table for S in splits if S.scaffold == name and len(S.raw_snp_table)]
-                        snp = pd.concat(snp) if snp else pd.DataFrame()
+                        snp = tables.snp_table(g.first_split[j], g.first_split[j + 1])     # the scaffold's rows in one cut
                         kwargs['scaffold_tables'][name] = make_coverage_table(levels[j], refs[plan[k][0]][1], name, snp)
             finally:
                 pipe.release(t)
+                g.ticket = None
             return splits
 
-        for items in groups:
+        def take(splits):
+            for S in splits:
+                out["{0}.{1}".format(S.scaffold, S.split_number)] = S
+
+        def run_alone(items):
+            """a group whose batch failed: scaffold by scaffold, so that only the offender is dropped"""
+            nonlocal pipe
+            for k in items:
+                try:
+                    g = layout([k])
+                    if not submit(g):
+                        need = (g.n_pos, max(int(bf.info.get("n_segs", 0)) + 4096, 2 * g.est_segs), len(g.bounds))
+                        pipe.close()
+                        pipe = make_pipe(need)
+                        if not submit(g):
+                            raise RuntimeError("scaffold does not fit a device batch")
+                    take(collect(g))
+                except Exception as e2:
+                    fail(plan[k][1], [sp[0] for sp in plan[k][2]], e2)
+
+        groups = [layout(items) for items in item_groups]
+        need = (max(g.n_pos for g in groups), max(g.est_segs for g in groups), max(len(g.bounds) for g in groups))
+        pipe = make_pipe(need)
+        stage("setup_ms")
+        in_flight = []                               # submitted, not yet collected (at most `depth`)
+
+        def drain_one():
+            g = in_flight.pop(0)
             try:
-                for S in run_group(items, len(groups)):
-                    out["{0}.{1}".format(S.scaffold, S.split_number)] = S
+                sp = collect(g)
+                stage("collect_ms")
+                take(sp)
             except Exception as e:
-                if len(items) == 1:
-                    fail(plan[items[0]][1], [s[0] for s in plan[items[0]][2]], e)
-                    continue
                 print(e)
                 traceback.print_exc()
-                for k in items:                      # find the scaffold that breaks the batch: the others still count
+                for h in in_flight:                  # the pipe may be rebuilt below: bring the others home first
                     try:
-                        for S in run_group([k], 1):
-                            out["{0}.{1}".format(S.scaffold, S.split_number)] = S
-                    except Exception as e2:
-                        fail(plan[k][1], [s[0] for s in plan[k][2]], e2)
+                        take(collect(h))
+                    except Exception:
+                        run_alone(h.items)
+                del in_flight[:]
+                run_alone(g.items)
+
+        for g in groups:
+            while len(in_flight) >= depth:
+                drain_one()
+            try:
+                ok = submit(g)
+                stage("submit_ms")
+                if not ok:
+                    # the estimate was short (many indels / long reads): a larger pipe once the batches in flight are home
+                    while in_flight:
+                        drain_one()
+                    n_real = int(bf.info.get("n_segs", 0)) if bf.info else 0
+                    need = (max(need[0], g.n_pos), max(2 * need[1], n_real + 4096), max(need[2], len(g.bounds)))
+                    pipe.close()
+                    pipe = make_pipe(need)
+                    if not submit(g):
+                        raise RuntimeError("batch does not fit the device pipe")
+                in_flight.append(g)
+            except Exception as e:
+                print(e)
+                traceback.print_exc()
+                while in_flight:
+                    drain_one()
+                run_alone(g.items)
+        while in_flight:
+            drain_one()
         return out
     except Exception as e:
         print(e)
@@ -693,3 +804,4 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             bf.close()
         if own_ctx and ctx is not None:
             ctx.close()
+        stage("teardown_ms")

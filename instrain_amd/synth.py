@@ -179,6 +179,9 @@ def _synth():
                                            _C.POINTER(_SynthOut)]
         lib.isx_synth_free.argtypes = [_C.POINTER(_SynthOut)]
         lib.isx_synth_free.restype = None
+        lib.isx_synth_write_bam.argtypes = [_C.POINTER(_SynthParams), _C.c_void_p, _C.c_int32, _C.c_void_p, _C.c_void_p, _C.c_char_p,
+                                            _C.c_void_p, _C.POINTER(_C.c_int64), _C.POINTER(_C.c_int64)]
+        lib.isx_synth_write_bam.restype = _C.c_int64
         lib.isx_synth_obs_to_segs.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int64, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_void_p,
                                               _C.c_void_p, _C.c_int32]
         lib.isx_synth_obs_to_segs.restype = _C.c_int64
@@ -255,6 +258,41 @@ class Metagenome:
 
     def kept_genomes(self):
         return np.flatnonzero(self.kept)
+
+    def contig_names(self, genome_sel):
+        """@SQ names of write_bam's file, contig after contig"""
+        return ["g%05d_c%03d" % (int(g), c) for g in genome_sel for c in range(self.contigs)]
+
+    def write_bam(self, genome_sel, path):
+        """The genomes `genome_sel` as a coordinate-sorted BAM, read for read what generate() turns into observations (quality 37
+        where a base is kept, 12 where it is dropped; one @SQ per contig) -> dict(n_reads, n_pairs, n_pos, ref_codes, names,
+        lengths, profiled_bases)"""
+        sel = np.ascontiguousarray(genome_sel, dtype=np.int32)
+        n_pos = int(self.length[sel].sum())
+        ref = np.empty(n_pos, dtype=np.uint8)
+        npos, npairs = _C.c_int64(0), _C.c_int64(0)
+        n = _synth().isx_synth_write_bam(_C.byref(self.p), sel.ctypes.data, len(sel), self.length.ctypes.data, self.coverage.ctypes.data,
+                                         path.encode(), ref.ctypes.data, _C.byref(npos), _C.byref(npairs))
+        if n < 0:
+            raise ValueError("isx_synth_write_bam failed (%d)" % n)
+        assert npos.value == n_pos
+        w = self.generate_layout(sel)
+        return {"n_reads": int(n), "n_pairs": int(npairs.value), "n_pos": n_pos, "ref_codes": ref, "names": self.contig_names(sel),
+                "scaffold_bounds": w, "profiled_bases": int(npairs.value) * 2 * self.read_len}
+
+    def generate_layout(self, genome_sel):
+        """flat scaffold bounds of generate(genome_sel) / write_bam(genome_sel) without generating the reads: contig lengths
+        come from the file header the writer produced -- here recomputed by a dry generate of zero-coverage genomes"""
+        sel = np.ascontiguousarray(genome_sel, dtype=np.int32)
+        cov = np.zeros_like(self.coverage)
+        out = _SynthOut()
+        rc = _synth().isx_synth_generate(_C.byref(self.p), sel.ctypes.data, len(sel), self.length.ctypes.data, cov.ctypes.data, _C.byref(out))
+        if rc != 0:
+            raise ValueError("isx_synth_generate failed (%d)" % rc)
+        n = int(out.n_scaffolds) + 1
+        sb = np.frombuffer((_C.c_uint8 * (n * 8)).from_address(out.scaffold_bounds), dtype=np.int64).copy()
+        _synth().isx_synth_free(_C.byref(out))
+        return sb
 
     def generate(self, genome_sel, window_length=10000):
         """-> workload dict like make_workload's (+ scaffold_bounds, scaffold_genome, genomes)"""

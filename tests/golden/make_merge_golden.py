@@ -85,6 +85,7 @@ def main():
     pu, su, lk, fa = mods
     from instrain_amd.profile import profile_utilities as ours
     from tests import util
+    ours.SCAFFOLD_PROFILE_CLASS = pu.scaffold_profile       # what an integration does once
     lut, fb = util.load_lut()
     nm = su.generate_snp_model(mg.REF + "/inStrain/helper_files/NullModel.txt", fdr=1e-6)
     seqs, pos, base, mm, pair = build_inputs()

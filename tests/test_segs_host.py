@@ -141,3 +141,44 @@ def test_pack_reads_follows_the_cigar_and_the_quality_filter():
     clipped = engine.pack_reads([start], [1050], [1300], [cig], [seq], [qual])
     gc, bc, _, _ = util.segs_to_obs(clipped)
     assert list(zip(gc.tolist(), bc.tolist())) == [e for e in exp if 1050 <= e[0] < 1300]
+
+
+def _same_stream(segs, obs, pair):
+    g, b, m, p = util.segs_to_obs(segs)
+    assert len(g) == len(obs)
+    assert (g == obs["gpos"]).all() and (b == np.minimum(obs["base"], 4)).all() and (m == obs["mm"]).all() and (p == pair).all()
+
+
+def test_bam_segments_stand_for_the_bam_observations():
+    """the front end's read segments (what a read-level pipe is handed) decode to exactly the observation stream the same
+    front end expands -- and that stream is pinned against the reference's stored sars_cov_2 run (test_bam_front)"""
+    import os
+    path = os.path.join(util.GOLD, "sars_cov_2.sorted.bam")
+    bam = engine.BamFile(path)
+    obs, pair, bounds, sref = bam.expand()
+    segs, b2, s2 = bam.segment_refs([0])
+    assert bam.info["n_obs"] >= len(obs) and (b2 == bounds).all() and (s2 == sref).all()
+    bam.close()
+    _same_stream(segs, obs, pair)
+    # reads are 2 x ~100-150 bp with indels: a handful of segments per read, all <= 150 columns, most of them full reads
+    assert segs.len.max() <= 150 and segs.n_seg < 2.5 * 2 * 13124
+
+
+@pytest.mark.parametrize("seed,skip_mm", [(1, False), (2, True), (3, False)])
+def test_messy_bam_segments_equal_observations(tmp_path, seed, skip_mm):
+    """clips, indels, ref skips, = / X, N bases, overlapping mates (qualities rewritten by the overlap resolution before they
+    are packed), reads hanging over scaffold ends, several references, subsets of them"""
+    from tests import bamwriter
+    refs = [("sA", 4000), ("sB", 1500), ("sC", 9000)]
+    reads = bamwriter.random_reads(seed, refs, 900)
+    path = str(tmp_path / "m.bam")
+    bamwriter.write_bam(path, refs, reads)
+    for sel in ([0, 1, 2], [1], [0, 2]):
+        bam = engine.BamFile(path, threads=3)
+        bam.scan()
+        bam.filter(min_read_ani=0.8, skip_mm=skip_mm)
+        obs, pair, bounds, sref = bam.expand_refs(sel, skip_mm=skip_mm, min_read_ani=0.8)
+        segs, b2, s2 = bam.segment_refs(sel, skip_mm=skip_mm, min_read_ani=0.8)
+        assert (b2 == bounds).all() and (s2 == sref).all()
+        bam.close()
+        _same_stream(segs, obs, pair)
