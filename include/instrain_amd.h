@@ -435,6 +435,11 @@ int isx_pack_reads(int64_t n_reads, const int64_t *ref_start, const int64_t *cli
  *   segs->pair == NULL) cap_rec ids. */
 int isx_encode_segs(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int64_t cap_rec, uint32_t *rec,
                     uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec);
+/* the same through the pipe's staging ring (what a read-level pipe does when a batch's records exceed 96 / 256 MiB): waves of at
+ * most ring_records / 2 records (ring_records: a multiple of 32, 0 = no ring) are written into a private ring and every finished
+ * wave is copied to its place in rec -- the copy standing in for the DMA engine */
+int isx_encode_segs_ring(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int64_t cap_rec, int64_t ring_records,
+                         uint32_t *rec, uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec);
 
 /* The pipe's host-side encoder on its own (no GPU needed): obs[n_obs] -> resident record stream.
  *   record_bytes 2: delta:13 | base:3, groups of 512 records; 4: delta:16 | mm:8 | base:3 (<< 24), groups of 256;

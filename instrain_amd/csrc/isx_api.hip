@@ -6,7 +6,10 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -16,6 +19,81 @@
 
 static thread_local std::string g_err;
 void isx_set_error(const std::string &msg) { g_err = msg; }
+
+// ---- caching device allocator (see isx_internal.h) ----
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;          // class size -> block
+    std::unordered_map<void *, size_t> live;            // block -> class size
+    size_t cached = 0;
+    static constexpr size_t LIMIT = (size_t)48 << 30;   // of 288 GB HBM
+    static size_t class_of(size_t bytes)
+    {
+        size_t v = std::max<size_t>(bytes, 4096);
+        int e = 0;
+        while ((v >> e) > 15) e++;                      // mantissa of 4 bits: classes 12.5 % apart at most
+        const size_t m = (v + (((size_t)1 << e) - 1)) >> e;
+        return m << e;
+    }
+};
+DevCache &dev_cache() { static DevCache c; return c; }
+}  // namespace
+
+hipError_t isx_dev_malloc(void **p, size_t bytes)
+{
+    DevCache &c = dev_cache();
+    const size_t cls = DevCache::class_of(bytes);
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.free_blocks.find(cls);
+        if (it != c.free_blocks.end()) {
+            *p = it->second;
+            c.free_blocks.erase(it);
+            c.cached -= cls;
+            c.live[*p] = cls;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess) {              // give the cache back and try once more
+        isx_dev_trim();
+        e = hipMalloc(p, cls);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.live[*p] = cls;
+    return hipSuccess;
+}
+
+void isx_dev_free(void *p)
+{
+    if (!p) return;
+    DevCache &c = dev_cache();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const size_t cls = it->second;
+            c.live.erase(it);
+            if (c.cached + cls <= DevCache::LIMIT) { c.free_blocks.emplace(cls, p); c.cached += cls; return; }
+        }
+    }
+    (void)hipFree(p);
+}
+
+void isx_dev_trim()
+{
+    DevCache &c = dev_cache();
+    std::vector<void *> dead;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (auto &kv : c.free_blocks) dead.push_back(kv.second);
+        c.free_blocks.clear();
+        c.cached = 0;
+    }
+    for (void *p : dead) (void)hipFree(p);
+}
 
 // host -> device through the two pinned staging buffers (hipMemcpyAsync, double-buffered);
 // `fill(dst, first, count)` writes `count` elements starting at element `first` into dst.
@@ -59,7 +137,7 @@ static int regrow(T **p, size_t *cap, size_t hard_max, size_t elem_pad = 0)
 {
     if (*cap >= hard_max) { isx_set_error("output table is at its hard bound and still too small"); return ISX_ERR_CAPACITY; }
     const size_t want = std::min(hard_max, std::max<size_t>(*cap * 4, 1024));
-    if (*p) (void)hipFree(*p);
+    if (*p) isx_dev_free(*p);
     *p = nullptr;
     HIP_TRY(hipMalloc(p, (want + elem_pad) * sizeof(T)));
     *cap = want;
@@ -194,8 +272,8 @@ struct ObsStream {
         if (rc != ISX_OK) return rc;
         if (too_wide.load() || has_jump.load()) {
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (b->d_rec32) (void)hipFree(b->d_rec32);
-            if (b->d_rec16) (void)hipFree(b->d_rec16);
+            if (b->d_rec32) isx_dev_free(b->d_rec32);
+            if (b->d_rec16) isx_dev_free(b->d_rec16);
             b->d_rec32 = nullptr; b->d_rec16 = nullptr;
             return 1;
         }
@@ -475,13 +553,14 @@ void isx_ctx_destroy(isx_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_lut) isx_dev_free(c->d_lut);
     for (int i = 0; i < 2; i++) {
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 2; i++) if (c->pstream[i]) (void)hipStreamDestroy(c->pstream[i]);
+    isx_dev_trim();
     delete c;
 }
 
@@ -496,7 +575,7 @@ int isx_set_null_model(isx_ctx *c, const int32_t *lut, int64_t n, int32_t fallba
         h[(size_t)i] = lut[i] < 0 ? 255 : (uint8_t)lut[i];
     }
     HIP_TRY(hipSetDevice(c->device));
-    if (c->d_lut) { (void)hipFree(c->d_lut); c->d_lut = nullptr; }
+    if (c->d_lut) { isx_dev_free(c->d_lut); c->d_lut = nullptr; }
     HIP_TRY(hipMalloc(&c->d_lut, (size_t)n));
     HIP_TRY(hipMemcpy(c->d_lut, h.data(), (size_t)n, hipMemcpyHostToDevice));
     c->lut_n = (int32_t)n;
@@ -517,7 +596,7 @@ void isx_batch_destroy(isx_batch *b)
     void *ps[] = {b->d_seg, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
-    for (void *p : ps) if (p) (void)hipFree(p);
+    for (void *p : ps) if (p) isx_dev_free(p);          // (falls through to hipFree for blocks that did not come from the cache)
     b->L.release();
     b->S.release();
     b->C.release();
@@ -866,7 +945,7 @@ int batch_grow_tables(isx_batch *b, uint32_t cap_flags)
             if ((rc = regrow(&b->d_sites, &b->cap_sites, (size_t)pos_bound))) return rc;
         }
         if (b->M > 1) {
-            if (b->d_slev) (void)hipFree(b->d_slev);
+            if (b->d_slev) isx_dev_free(b->d_slev);
             b->d_slev = nullptr;
             b->cap_slev = b->cap_sites * (size_t)b->M;
             HIP_TRY(hipMalloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
@@ -879,9 +958,9 @@ int batch_grow_tables(isx_batch *b, uint32_t cap_flags)
         size_t cap = b->cap_entries - slabs;
         isx_entry *dummy = nullptr;
         if ((rc = regrow(&dummy, &cap, (size_t)npm))) return rc;      // size check only
-        (void)hipFree(dummy);
+        isx_dev_free(dummy);
         if (slabs + cap >= 0xFFFFFFFFull) { isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_CAPACITY; }
-        if (b->d_entries) (void)hipFree(b->d_entries);
+        if (b->d_entries) isx_dev_free(b->d_entries);
         b->d_entries = nullptr;
         HIP_TRY(hipMalloc(&b->d_entries, (slabs + cap) * sizeof(isx_entry)));
         b->cap_entries = slabs + cap;

@@ -26,6 +26,14 @@
 
 void isx_set_error(const std::string &msg);
 
+// Device memory for buffers that are created and dropped again and again with similar sizes (the linkage stages' scratch,
+// the tables of a pipe's slots): freed blocks are kept per size class and handed out again, so a hipMalloc -- which takes
+// the process' address-space lock and stalls for as long as another thread is giving gigabytes back to the system -- only
+// happens the first time.  isx_dev_trim() (isx_ctx_destroy) really frees what is cached.
+hipError_t isx_dev_malloc(void **p, size_t bytes);
+void isx_dev_free(void *p);
+void isx_dev_trim();
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \

@@ -21,6 +21,9 @@
 //   5 radix sort + run-length encode of the keys                      -> mm2combo2counts
 //   6 k_ld_rows      one lane per edge: ascending mm on the edge, cumulative combo counts,
 //                    site counts <= mm, gates, r2 / D' in fp64 in the reference's order.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <vector>
 #include <cstring>
@@ -459,10 +462,10 @@ template <class T>
 int ensure(DevBuf<T> &b, size_t n)
 {
     if (b.cap >= n && b.p) return ISX_OK;
-    if (b.p) (void)hipFree(b.p);
+    if (b.p) isx_dev_free(b.p);
     b.p = nullptr; b.cap = 0;
     const size_t want = n + n / 4 + 256;
-    HIP_TRY(hipMalloc(&b.p, want * sizeof(T)));
+    HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b.p), want * sizeof(T)));
     b.cap = want;
     return ISX_OK;
 }
@@ -484,7 +487,7 @@ void LinkageBuffers::release()
                   ao_key2.p, incr_cnt.p, incr_off.p, keys.p, keys2.p, ukeys.p, ucnt.p, n_runs.p, rows_per.p,
                   row_off.p, ld.p, temp.p, key64.p, key64b.p, head.p, row_id.p, first_row.p, first_site.p,
                   split_slot.p, tile_cnt.p, tile_off.p, vals.p, vals2.p, dsplits.p, dtiles.p, xt.p};
-    for (void *p : ps) if (p) (void)hipFree(p);
+    for (void *p : ps) if (p) isx_dev_free(p);
     *this = LinkageBuffers();
 }
 
@@ -663,6 +666,11 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     out = LinkageOut();
     const uint32_t n_sites = in.n_sites;
     int rc;
+    const bool lt = getenv("ISX_LINK_TIMING") != nullptr;          // tuning aid: host time stamps on stderr
+    const auto lt0 = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what) {
+        if (lt) fprintf(stderr, "[run_linkage] %-22s +%.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lt0).count());
+    };
     EV(0);
     HIP_TRY(hipEventRecord(in.ev_mfma[0], s));
     HIP_TRY(hipEventRecord(in.ev_mfma[1], s));
@@ -675,11 +683,13 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     if ((rc = ensure(B.site_keys, n_sites)) || (rc = ensure(B.site_keys2, n_sites)) ||
         (rc = ensure(B.sites_sorted, n_sites)) || (rc = ensure(B.site_gpos, n_sites)) ||
         (rc = ensure(B.site_split, n_sites))) return rc;
+    tick("site buffers");
     hipLaunchKernelGGL(k_site_keys, dim3((n_sites + 255) / 256), dim3(256), 0, s, in.sites, n_sites, B.site_keys.p);
     RP(rocprim::radix_sort_pairs(tp, tb, B.site_keys.p, B.site_keys2.p, const_cast<isx_site *>(in.sites),
                                  B.sites_sorted.p, n_sites, 0, 32, s));
     hipLaunchKernelGGL(k_site_split, dim3((n_sites + 255) / 256), dim3(256), 0, s, B.sites_sorted.p, n_sites,
                        in.split_bounds, in.n_splits, B.site_gpos.p, B.site_split.p);
+    tick("site sort enqueued");
     EV(1);
 
     // ---- 2. allele observations (produced by the pileup kernel): position -> site rank ----
@@ -687,6 +697,7 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     out.n_ao = n_ao;
     if (n_ao == 0) { EV(2); EV(3); EV(4); EV(5); return ISX_OK; }
     if ((rc = ensure(B.ao_key, n_ao)) || (rc = ensure(B.ao2, n_ao)) || (rc = ensure(B.ao_key2, n_ao))) return rc;
+    tick("ao buffers");
     hipLaunchKernelGGL(k_ao_rank, dim3((n_ao + 255) / 256), dim3(256), 0, s, in.ao, n_ao, B.site_gpos.p, n_sites,
                        B.ao_key.p);
     EV(2);
@@ -696,6 +707,7 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     if (in.mode == 2) rc = dense_path(in, B, out, n_ao, n_sites, n_u);
     else rc = sparse_path(in, B, out, n_ao, n_u);
     if (rc != ISX_OK) return rc;
+    tick("pair counts");
     if (n_u == 0) { if (out.n_increments == 0) { /* EV(3)/EV(4) recorded by the path */ } EV(5); return ISX_OK; }
 
     // ---- 6. LD rows ----
@@ -718,5 +730,6 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
                            in.min_snp, nullptr, B.row_off.p, B.ld.p, nullptr, in.philox, sb);
     }
     EV(5);
+    tick("ld rows enqueued");
     return ISX_OK;
 }

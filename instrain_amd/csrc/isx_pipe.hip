@@ -74,7 +74,9 @@ struct Slot {
     hipEvent_t ev_ring[2] = {nullptr, nullptr};     // ring mode: the copy that last read each half
     bool ring_busy[2] = {false, false};
     uint8_t *h_out = nullptr;
-    bool out_pinned = true;                 // false: plain memory (a single-slot pipe with a large result block, see slot_batch_create)
+    uint8_t *h_small = nullptr;             // always pinned: the first SNV rows and clonTR entries (o_snv, o_rare are offsets into it)
+    size_t small_bytes = 0;
+    bool out_pinned = true;                 // false: the dense arrays go to plain memory through the pipe's bounce buffers (see slot_batch_create)
     size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0, o_cov16 = 0, o_rare = 0;
     bool rare_dense = false;                // the clonTR table of the last batch went back as the dense array
     std::vector<float> clonr_big;           // that array when the pipe has no pinned room for it (no want_counts)
@@ -148,7 +150,40 @@ struct isx_pipe {
     std::deque<int64_t> work;
     bool stop = false;
     std::mutex launch_mu;                   // pass-queue launches (submit vs. the finisher repeating a pass)
+    // position-sized result arrays of slots whose result block is plain memory travel through these (finisher thread only)
+    uint8_t *bounce[2] = {nullptr, nullptr};
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+    size_t bounce_bytes = 0;
+    std::unique_ptr<isxenc::HostPool> fin_pool;      // the finisher's own few threads (the encoder pool belongs to the caller's thread)
 };
+
+// device -> plain host memory at link speed: pieces through the two pinned bounce buffers, emptied by the finisher's threads
+static int bounce_d2h(isx_pipe *p, void *hdst, const void *dsrc, size_t bytes)
+{
+    if (!bytes) return ISX_OK;
+    const size_t piece = p->bounce_bytes;
+    const size_t n_pieces = (bytes + piece - 1) / piece;
+    hipStream_t st = p->s_d2h;
+    auto issue = [&](size_t k) -> hipError_t {
+        const size_t off = k * piece, len = std::min(piece, bytes - off);
+        hipError_t e = hipMemcpyAsync(p->bounce[k & 1], static_cast<const uint8_t *>(dsrc) + off, len, hipMemcpyDeviceToHost, st);
+        return e == hipSuccess ? hipEventRecord(p->bounce_ev[k & 1], st) : e;
+    };
+    HIP_TRY(issue(0));
+    for (size_t k = 0; k < n_pieces; k++) {
+        if (k + 1 < n_pieces) HIP_TRY(issue(k + 1));            // its buffer was emptied one step ago
+        HIP_TRY(hipEventSynchronize(p->bounce_ev[k & 1]));
+        const size_t off = k * piece, len = std::min(piece, bytes - off);
+        const size_t sub = (size_t)1 << 20;
+        const uint8_t *src = p->bounce[k & 1];
+        uint8_t *dst = static_cast<uint8_t *>(hdst) + off;
+        p->fin_pool->run((int)((len + sub - 1) / sub), [&](int t) {
+            const size_t a = (size_t)t * sub;
+            memcpy(dst + a, src + a, std::min(sub, len - a));
+        });
+    }
+    return ISX_OK;
+}
 
 static void pipe_free(isx_pipe *p)
 {
@@ -176,19 +211,24 @@ static void pipe_free(isx_pipe *p)
             isx_batch_destroy(b);
         }
         t_batch += now_ms() - t_x; t_x = now_ms();
-        if (s.d_gpos16) (void)hipFree(s.d_gpos16);
-        if (s.d_in) (void)hipFree(s.d_in);
-        if (s.d_runs) (void)hipFree(s.d_runs);
+        if (s.d_gpos16) isx_dev_free(s.d_gpos16);
+        if (s.d_in) isx_dev_free(s.d_in);
+        if (s.d_runs) isx_dev_free(s.d_runs);
         t_dev += now_ms() - t_x; t_x = now_ms();
         if (s.h_in) (void)hipHostFree(s.h_in);
         host_block_free(s.h_runs, s.runs_pinned);
         for (hipEvent_t e : s.ev_ring) if (e) (void)hipEventDestroy(e);
         host_block_free(s.h_out, s.out_pinned);
+        if (s.h_small) (void)hipHostFree(s.h_small);
         t_pin += now_ms() - t_x;
         for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_pass, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
     }
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_destroy] device tables %.1f ms, device arena %.1f ms, pinned staging %.1f ms, total %.1f ms\n", t_batch, t_dev, t_pin, now_ms() - t_f0);
+    for (int i = 0; i < 2; i++) {
+        if (p->bounce[i]) (void)hipHostFree(p->bounce[i]);
+        if (p->bounce_ev[i]) (void)hipEventDestroy(p->bounce_ev[i]);
+    }
     if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
     if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     delete p;
@@ -212,7 +252,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     const int64_t cap_pos = p->pp.max_pos;
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
     for (auto &e : b->ev_sum) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipMalloc(&b->d_cursors, (CUR_N + 4) * sizeof(uint32_t)));
+    HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_cursors), (CUR_N + 4) * sizeof(uint32_t)));
     b->d_flags = b->d_cursors + CUR_N;
     HIP_TRY(hipHostMalloc(&b->h_state, (CUR_N + 8) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     memset(b->h_state, 0, (CUR_N + 8) * sizeof(uint32_t));
@@ -220,37 +260,37 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     HIP_TRY(hipMemset(b->d_cursors, 0, (CUR_N + 4) * sizeof(uint32_t)));
     {
         std::vector<uint16_t> thr = build_thresholds(c->h_lut, c->fallback, prm->min_freq);
-        HIP_TRY(hipMalloc(&b->d_thr, thr.size() * sizeof(uint16_t)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_thr), thr.size() * sizeof(uint16_t)));
         HIP_TRY(hipMemcpy(b->d_thr, thr.data(), thr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     const uint64_t npm = (uint64_t)cap_pos * b->M;
     const uint64_t cap_obs = (uint64_t)std::max<int64_t>(p->pp.max_obs, 1);
     if (dense) {
-        HIP_TRY(hipMalloc(&b->d_counts, (size_t)cap_pos * sizeof(uint4)));
-        HIP_TRY(hipMalloc(&b->d_clon, (size_t)cap_pos * sizeof(float)));
-        HIP_TRY(hipMalloc(&b->d_clon_r, (size_t)cap_pos * sizeof(float)));
-        HIP_TRY(hipMalloc(&b->d_cov16, (size_t)cap_pos * sizeof(uint16_t)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_counts), (size_t)cap_pos * sizeof(uint4)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon), (size_t)cap_pos * sizeof(float)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon_r), (size_t)cap_pos * sizeof(float)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_cov16), (size_t)cap_pos * sizeof(uint16_t)));
         if (prm->rarefied_coverage > 0) {
             b->cap_rare = p->cap_rare;
-            HIP_TRY(hipMalloc(&b->d_rare, b->cap_rare * sizeof(uint2)));
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_rare), b->cap_rare * sizeof(uint2)));
         }
     } else {
         b->slab_region = (size_t)(cap_pos + 2 * b->block) * (size_t)std::min(b->M, 4);
         const size_t ovf = b->M <= 4 ? 16 : (size_t)std::max<uint64_t>(1u << 20, std::min<uint64_t>(cap_obs, npm) / 4);
         if (b->slab_region + ovf >= 0xFFFFFFFFull) { isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_ARG; }
         b->cap_entries = b->slab_region + ovf;
-        HIP_TRY(hipMalloc(&b->d_entries, b->cap_entries * sizeof(isx_entry)));
-        HIP_TRY(hipMalloc(&b->d_win_nent, ((size_t)cap_pos / 64 + 2) * sizeof(uint32_t)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_entries), b->cap_entries * sizeof(isx_entry)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_win_nent), ((size_t)cap_pos / 64 + 2) * sizeof(uint32_t)));
     }
     b->cap_snv = (size_t)std::min<uint64_t>(npm, std::max<uint64_t>((uint64_t)cap_pos / 2, 1u << 20));
     b->cap_sites = (size_t)std::min<uint64_t>((uint64_t)cap_pos, std::max<uint64_t>((uint64_t)cap_pos / 4, 1u << 20));
     b->cap_ao = (size_t)std::max<uint64_t>(1, std::min<uint64_t>(cap_obs, std::max<uint64_t>(cap_obs / 4, 1u << 20)));
-    HIP_TRY(hipMalloc(&b->d_snv, b->cap_snv * sizeof(isx_snv)));
-    HIP_TRY(hipMalloc(&b->d_sites, b->cap_sites * sizeof(isx_site)));
-    if (prm->enable_linkage) HIP_TRY(hipMalloc(&b->d_ao, b->cap_ao * sizeof(isx_ao)));
+    HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_snv), b->cap_snv * sizeof(isx_snv)));
+    HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_sites), b->cap_sites * sizeof(isx_site)));
+    if (prm->enable_linkage) HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_ao), b->cap_ao * sizeof(isx_ao)));
     if (!dense) {
         b->cap_slev = b->cap_sites * (size_t)std::min(b->M, 8);
-        HIP_TRY(hipMalloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_slev), b->cap_slev * sizeof(isx_slev)));
     }
     // input arena: one layout for the pinned staging block and its device twin
     size_t o = 0;
@@ -266,7 +306,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     const double t_a0 = now_ms();
     HIP_TRY(hipHostMalloc(&s.h_in, host_bytes, hipHostMallocDefault));
     const double t_a1 = now_ms();
-    HIP_TRY(hipMalloc(&s.d_in, s.in_bytes));
+    HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&s.d_in), s.in_bytes));
     if (getenv("ISX_PIPE_TIMING"))
         fprintf(stderr, "[isx_pipe_create] slot %d: device tables %.1f ms, pinned input %.1f MB %.1f ms, device arena %.1f MB %.1f ms\n", index,
                 t_a0 - t_s0, host_bytes / 1e6, t_a1 - t_a0, s.in_bytes / 1e6, now_ms() - t_a1);
@@ -275,17 +315,20 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
         s.cap_runs = (size_t)p->cap_rec / 64 + 4096;
         s.runs_pinned = p->pp.depth > 1;
         { const int hrc = host_block_alloc(reinterpret_cast<void **>(&s.h_runs), s.cap_runs * sizeof(isxenc::PairRun), s.runs_pinned); if (hrc != ISX_OK) return hrc; }
-        HIP_TRY(hipMalloc(&s.d_runs, s.cap_runs * sizeof(uint2)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&s.d_runs), s.cap_runs * sizeof(uint2)));
     }
     if (p->ring_half) for (hipEvent_t &e : s.ev_ring) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (prm->enable_linkage && p->rb == 4) HIP_TRY(hipMalloc(&s.d_gpos16, (size_t)p->cap_rec * sizeof(uint16_t)));
-    // pinned result block
+    if (prm->enable_linkage && p->rb == 4) HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&s.d_gpos16), (size_t)p->cap_rec * sizeof(uint16_t)));
+    // result blocks: a small pinned one (first SNV rows, first clonTR entries) and the position-sized arrays
     o = 0;
     s.o_snv = o; o = up(o + p->snv_prefix * sizeof(isx_snv));
+    s.o_rare = o; if (dense && prm->rarefied_coverage > 0) o = up(o + p->rare_prefix * sizeof(isx_rare));
+    s.small_bytes = o;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_small), std::max<size_t>(s.small_bytes, 1), hipHostMallocDefault));
+    o = 0;
     if (dense) {
         s.o_cov16 = o; o = up(o + (size_t)cap_pos * 2);
         s.o_clon = o; o = up(o + (size_t)cap_pos * 4);
-        s.o_rare = o; if (prm->rarefied_coverage > 0) o = up(o + p->rare_prefix * sizeof(isx_rare));
         if (p->pp.want_counts) {
             s.o_counts = o; o = up(o + (size_t)cap_pos * 16);
             s.o_clonr = o; if (prm->rarefied_coverage > 0) o = up(o + (size_t)cap_pos * 4);
@@ -293,10 +336,11 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     }
     s.out_bytes = o;
     const double t_o0 = now_ms();
-    // A single-slot pipe has nothing to overlap its copy-out with, and pinning (then unpinning) a result block of hundreds of
-    // MB costs several times what the slower copy into plain memory does: 144 MB pinned = ~35 ms + ~30 ms to free, copied
-    // into pageable memory = ~15 ms.
-    s.out_pinned = !(p->pp.depth == 1 && s.out_bytes > ((size_t)64 << 20));
+    // Pinning (then unpinning) hundreds of MB costs more than moving them: 144 MB pinned = ~35 ms + ~30 ms to free.  A large
+    // block lives in plain memory and the finisher moves the arrays there in pieces through two small pinned bounce buffers
+    // (a hipMemcpyAsync straight into pageable memory crawls at < 2 GB/s and holds up every hipMalloc issued meanwhile).
+    // A deep pipe (a long stream of batches) amortises the pinning and keeps its copy-out fully asynchronous.
+    s.out_pinned = s.out_bytes <= ((size_t)64 << 20) || p->pp.depth > 2;
     { const int hrc = host_block_alloc(reinterpret_cast<void **>(&s.h_out), s.out_bytes, s.out_pinned); if (hrc != ISX_OK) return hrc; }
     if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_create] slot %d: %s results %.1f MB %.1f ms\n", index, s.out_pinned ? "pinned" : "pageable", s.out_bytes / 1e6, now_ms() - t_o0);
     for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_pass, &s.ev_d2h0, &s.ev_d2h1}) HIP_TRY(hipEventCreate(e));
@@ -334,7 +378,16 @@ static int finish_slot(isx_pipe *p, Slot &s)
         redo = true;
     }
     t_fin = now_ms();
-    if (redo && dense) {                        // the copied-out tables predate the repeated pass
+    if (dense && !s.out_pinned) {               // a plain result block: the arrays come through the bounce buffers, now
+        int rc;
+        if (redo) HIP_TRY(hipStreamSynchronize(ps));
+        if ((rc = bounce_d2h(p, s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2)) != ISX_OK) return rc;
+        if ((rc = bounce_d2h(p, s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4)) != ISX_OK) return rc;
+        if (p->pp.want_counts) {
+            if ((rc = bounce_d2h(p, s.h_out + s.o_counts, b->d_counts, (size_t)b->n_pos * 16)) != ISX_OK) return rc;
+            if (p->prm.rarefied_coverage > 0 && (rc = bounce_d2h(p, s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4)) != ISX_OK) return rc;
+        }
+    } else if (redo && dense) {                 // the copied-out tables predate the repeated pass
         HIP_TRY(hipMemcpy(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
         if (p->pp.want_counts) {
@@ -345,7 +398,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
     }
     if (dense && p->prm.rarefied_coverage > 0) {        // the sparse clonTR table, ascending positions
         const size_t n_rare = b->n_rare;
-        isx_rare *rr = reinterpret_cast<isx_rare *>(s.h_out + s.o_rare);
+        isx_rare *rr = reinterpret_cast<isx_rare *>(s.h_small + s.o_rare);
         s.rare_big.clear();
         s.rare_dense = false;
         if (n_rare > p->cap_rare || n_rare * 8 > (size_t)b->n_pos) {
@@ -355,8 +408,9 @@ static int finish_slot(isx_pipe *p, Slot &s)
             // position for every pipe is not worth it)
             if (!p->pp.want_counts) {
                 if (s.clonr_big.size() < (size_t)b->n_pos) s.clonr_big.resize((size_t)b->n_pos);
-                HIP_TRY(hipMemcpy(s.clonr_big.data(), b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
-            } else if (redo)
+                if (p->bounce[0]) { const int rc = bounce_d2h(p, s.clonr_big.data(), b->d_clon_r, (size_t)b->n_pos * 4); if (rc != ISX_OK) return rc; }
+                else HIP_TRY(hipMemcpy(s.clonr_big.data(), b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
+            } else if (redo && s.out_pinned)
                 HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
             s.rare_dense = true;
         } else {
@@ -369,7 +423,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
     }
     t_rare = now_ms();
     const size_t n_snv = (size_t)b->sizes.n_snv;
-    isx_snv *rows = reinterpret_cast<isx_snv *>(s.h_out + s.o_snv);
+    isx_snv *rows = reinterpret_cast<isx_snv *>(s.h_small + s.o_snv);
     if (n_snv > p->snv_prefix || redo) {
         if (n_snv > p->snv_prefix) { s.snv_big.resize(n_snv); rows = s.snv_big.data(); }
         if (n_snv) HIP_TRY(hipMemcpy(rows, b->d_snv, n_snv * sizeof(isx_snv), hipMemcpyDeviceToHost));
@@ -381,8 +435,9 @@ static int finish_slot(isx_pipe *p, Slot &s)
         if (!s.ld_rows.empty()) { const int rc = isx_batch_fetch_ld(b, s.ld_rows.data()); if (rc != ISX_OK) return rc; }
     }
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
-        fprintf(stderr, "[isx_pipe finisher] wait %.2f ms, finish (sizes, linkage) %.2f ms, clonTR list (%u) %.2f ms, snv rows (%zu) %.2f ms\n",
-                s.finish_wait_ms, t_fin - t_c0, b->n_rare, t_rare - t_fin, n_snv, now_ms() - t_rare);
+        fprintf(stderr, "[isx_pipe finisher] wait %.2f ms, finish (sizes, linkage) %.2f ms [device: sites %.2f allele %.2f group %.2f incr %.2f ld %.2f; %lld ao, %lld incr, %lld ld], clonTR list (%u) %.2f ms, snv rows (%zu) %.2f ms\n",
+                s.finish_wait_ms, t_fin - t_c0, b->tim.sites_ms, b->tim.allele_ms, b->tim.group_ms, b->tim.incr_ms, b->tim.ld_ms,
+                (long long)b->sizes.n_allele_obs, (long long)b->sizes.n_increments, (long long)b->sizes.n_ld, b->n_rare, t_rare - t_fin, n_snv, now_ms() - t_rare);
     return ISX_OK;
 }
 
@@ -441,6 +496,16 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
                                 (uint64_t)pp->max_splits + 64 + (uint64_t)((double)pp->max_segs / ISX_SEG_GROUP * js * 0.25);
         p->cap_rec = (int64_t)groups * ISX_SEG_GROUP;
         if ((uint64_t)p->cap_rec >= (1ull << 26)) { delete p; isx_set_error("more than 2^26 segment records in one batch (4 GiB of records)"); return ISX_ERR_ARG; }
+        // staging: the whole stream pinned while that is cheap (a C2 batch is 43 MB), otherwise waves through a ring of two
+        // halves -- pinning costs ~0.2 s per GB and as much again to unpin, more than encoding and copying the records
+        const size_t rec_bytes = (size_t)p->cap_rec * 64;
+        size_t ring = 0;
+        if (pp->ring_kib > 0) ring = (size_t)pp->ring_kib << 10;
+        else if (pp->ring_kib == 0 && rec_bytes > ((size_t)(pp->depth == 1 ? 96 : 256) << 20)) ring = (size_t)64 << 20;
+        if (ring && ring < rec_bytes) {
+            p->ring_half = (int64_t)(ring / 2 / 64) / ISX_SEG_GROUP * ISX_SEG_GROUP;
+            if (p->ring_half < 4096 + 16 * ISX_SEG_GROUP) { delete p; isx_set_error("isx_pipe_create: ring_kib too small for a read-level pipe (at least 1024)"); return ISX_ERR_ARG; }
+        }
     } else {
         const uint64_t want = (uint64_t)((double)pp->max_obs * (1.0 + js)) + 4 * ISX_PAD;
         p->cap_rec = (int64_t)((want + ISX_PAD - 1) / ISX_PAD * ISX_PAD);
@@ -483,6 +548,15 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     p->slots.resize((size_t)pp->depth);
     for (int i = 0; i < pp->depth && rc == ISX_OK; i++) rc = slot_batch_create(p, p->slots[(size_t)i], i);
     if (rc != ISX_OK) { pipe_free(p); return rc; }
+    if (!p->slots[0].out_pinned) {
+        p->bounce_bytes = (size_t)16 << 20;
+        for (int i = 0; i < 2 && rc == ISX_OK; i++) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&p->bounce[i]), p->bounce_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&p->bounce_ev[i], hipEventDisableTiming) != hipSuccess) rc = ISX_ERR_HIP;
+        }
+        if (rc != ISX_OK) { isx_set_error("isx_pipe_create: bounce buffers"); pipe_free(p); return rc; }
+        p->fin_pool.reset(new isxenc::HostPool(std::max(1, std::min(nt, 6)), -1, false));
+    }
     p->finisher = std::thread(finisher_main, p);
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_create] thread pool %.1f ms, %d slot(s) %.1f ms\n", t_c1 - t_c0, pp->depth, now_ms() - t_c1);
@@ -522,17 +596,19 @@ static int enqueue_pass(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticket)
     HIP_TRY(hipStreamWaitEvent(p->s_d2h, s.ev_pass, 0));
     HIP_TRY(hipEventRecord(s.ev_d2h0, p->s_d2h));
     const size_t snv_rows = std::min(p->snv_prefix, b->cap_snv);
-    HIP_TRY(hipMemcpyAsync(s.h_out + s.o_snv, b->d_snv, snv_rows * sizeof(isx_snv), hipMemcpyDeviceToHost, p->s_d2h));
+    HIP_TRY(hipMemcpyAsync(s.h_small + s.o_snv, b->d_snv, snv_rows * sizeof(isx_snv), hipMemcpyDeviceToHost, p->s_d2h));
     s.d2h_bytes = (int64_t)(snv_rows * sizeof(isx_snv));
     if (dense) {
-        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_cov16, b->d_cov16, (size_t)n_pos * 2, hipMemcpyDeviceToHost, p->s_d2h));
-        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clon, b->d_clon, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
-        s.d2h_bytes += (int64_t)n_pos * 6;
         if (p->prm.rarefied_coverage > 0) {
             const size_t n = std::min(p->rare_prefix, std::min(p->cap_rare, (size_t)n_pos));
-            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_rare, b->d_rare, n * sizeof(isx_rare), hipMemcpyDeviceToHost, p->s_d2h));
+            HIP_TRY(hipMemcpyAsync(s.h_small + s.o_rare, b->d_rare, n * sizeof(isx_rare), hipMemcpyDeviceToHost, p->s_d2h));
             s.d2h_bytes += (int64_t)(n * sizeof(isx_rare));
         }
+        s.d2h_bytes += (int64_t)n_pos * 6;
+    }
+    if (dense && s.out_pinned) {           // (a plain result block is filled by the finisher, bounce_d2h)
+        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_cov16, b->d_cov16, (size_t)n_pos * 2, hipMemcpyDeviceToHost, p->s_d2h));
+        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clon, b->d_clon, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
         if (p->pp.want_counts) {
             HIP_TRY(hipMemcpyAsync(s.h_out + s.o_counts, b->d_counts, (size_t)n_pos * 16, hipMemcpyDeviceToHost, p->s_d2h));
             s.d2h_bytes += (int64_t)n_pos * 16;
@@ -619,10 +695,10 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         // more pair-id runs than any batch of this slot had (short fragments): larger blocks, encode again
         HIP_TRY(hipStreamSynchronize(p->s_h2d));
         host_block_free(s.h_runs, s.runs_pinned); s.h_runs = nullptr;
-        (void)hipFree(s.d_runs); s.d_runs = nullptr;
+        isx_dev_free(s.d_runs); s.d_runs = nullptr;
         s.cap_runs = J.n_runs + J.n_runs / 4 + 4096;
         { const int hrc = host_block_alloc(reinterpret_cast<void **>(&s.h_runs), s.cap_runs * sizeof(isxenc::PairRun), s.runs_pinned); if (hrc != ISX_OK) return hrc; }
-        HIP_TRY(hipMalloc(&s.d_runs, s.cap_runs * sizeof(uint2)));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&s.d_runs), s.cap_runs * sizeof(uint2)));
     }
     const double t_enc = now_ms();
     if (ring_err != hipSuccess) { isx_set_error(std::string("isx_pipe_submit: staging ring: ") + hipGetErrorString(ring_err)); return ISX_ERR_HIP; }
@@ -745,8 +821,32 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     J.pair_out = linkage ? reinterpret_cast<uint32_t *>(s.h_in + s.off_pairs) : nullptr;
     J.cmin = s.cmin.data(); J.cmax = s.cmax.data(); J.cany = s.cany.data();
     J.cap_rec = p->cap_rec;
+    const bool ring = p->ring_half > 0;
+    hipError_t ring_err = hipSuccess;
+    size_t ring_bytes = 0;
+    if (ring) {
+        // the copy-in queue starts here: every finished wave leaves for its place in the device arena while the next one is
+        // being written into the other half
+        HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+        const size_t half_bytes = (size_t)p->ring_half * 64;
+        constexpr size_t grp_bytes = (size_t)ISX_SEG_GROUP * 64;
+        uint8_t *d_rec = s.d_in + s.off_rec;
+        J.ring_groups = p->ring_half / ISX_SEG_GROUP;
+        J.wave_begin = [&s, &ring_err](int h) {
+            if (s.ring_busy[h]) { const hipError_t e = hipEventSynchronize(s.ev_ring[h]); if (e != hipSuccess && ring_err == hipSuccess) ring_err = e; s.ring_busy[h] = false; }
+        };
+        J.wave_flush = [&s, p, &ring_err, &ring_bytes, half_bytes, d_rec](int h, int64_t g0, int64_t g1) {
+            const size_t nb = (size_t)(g1 - g0) * grp_bytes;
+            hipError_t e = hipMemcpyAsync(d_rec + (size_t)g0 * grp_bytes, s.h_in + s.off_rec + (size_t)h * half_bytes, nb, hipMemcpyHostToDevice, p->s_h2d);
+            if (e == hipSuccess) e = hipEventRecord(s.ev_ring[h], p->s_h2d);
+            if (e != hipSuccess && ring_err == hipSuccess) ring_err = e;
+            s.ring_busy[h] = true;
+            ring_bytes += nb;
+        };
+    }
     const int erc = isxenc::encode_segs(*p->pool, J);
     const double t_enc = now_ms();
+    if (ring_err != hipSuccess) { isx_set_error(std::string("isx_pipe_submit_reads: staging ring: ") + hipGetErrorString(ring_err)); return ISX_ERR_HIP; }
     if (erc == isxenc::SEG_CAPACITY) { isx_set_error("isx_pipe_submit_reads: the stream jumps too often for the pipe's record capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
     if (erc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
     if (erc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
@@ -802,12 +902,13 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
                 t_enc - t0, now_ms() - t_enc, (long long)J.n_seg, (long long)J.n_rec);
 
     // ---- copy-in queue: bounds | windows | reference codes, then group bases (| pair ids) | records ----
-    HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+    if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
     const size_t head = s.off_ref + (size_t)n_pos;
     const size_t gb_bytes = (size_t)(b->n_rec / ISX_SEG_GROUP) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * 64;
     HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, head, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    if (ring) { if (ring_bytes != rec_bytes) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; } }
+    else HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
     s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
     if (linkage) {
         HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, s.h_in + s.off_pairs, (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, p->s_h2d));
@@ -912,14 +1013,14 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
     out->ticket = ticket;
     out->n_pos = b->n_pos; out->n_obs = b->n_obs;
     out->sizes = b->sizes;
-    out->snv = (size_t)b->sizes.n_snv > p->snv_prefix ? s.snv_big.data() : reinterpret_cast<const isx_snv *>(s.h_out + s.o_snv);
+    out->snv = (size_t)b->sizes.n_snv > p->snv_prefix ? s.snv_big.data() : reinterpret_cast<const isx_snv *>(s.h_small + s.o_snv);
     if (dense) {
         out->coverage16 = reinterpret_cast<const uint16_t *>(s.h_out + s.o_cov16);
         out->clon = reinterpret_cast<const float *>(s.h_out + s.o_clon);
         out->n_saturated = b->n_sat;
         if (p->prm.rarefied_coverage > 0) {
             out->n_rare = (int64_t)b->n_rare;
-            if (!s.rare_dense) out->rare = s.rare_big.empty() ? reinterpret_cast<const isx_rare *>(s.h_out + s.o_rare) : s.rare_big.data();
+            if (!s.rare_dense) out->rare = s.rare_big.empty() ? reinterpret_cast<const isx_rare *>(s.h_small + s.o_rare) : s.rare_big.data();
             if (p->pp.want_counts) out->clon_rarefied = reinterpret_cast<const float *>(s.h_out + s.o_clonr);
             else if (s.rare_dense) out->clon_rarefied = s.clonr_big.data();
         }

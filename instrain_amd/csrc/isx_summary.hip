@@ -434,7 +434,7 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
     int rc = ISX_OK;
     auto done = [&](int code) {
         void *ps[] = {keys, idx, cursor, out, temp};
-        for (void *p : ps) if (p) (void)hipFree(p);
+        for (void *p : ps) if (p) isx_dev_free(p);
         return code;
     };
 #define FE_TRY(expr) do { if ((expr) != hipSuccess) { isx_set_error(std::string("HIP error in fetch_entries: ") + #expr); return done(ISX_ERR_HIP); } } while (0)
@@ -467,7 +467,7 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
 void SummaryBuffers::release()
 {
     void *ps[] = {cov, cv, cr, k_u32, k_f32, seg_off, seg_be, bounds, acc, med, rows, temp};
-    for (void *p : ps) if (p) (void)hipFree(p);
+    for (void *p : ps) if (p) isx_dev_free(p);
     *this = SummaryBuffers();
 }
 
@@ -481,7 +481,7 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
         (rc = dev_alloc(&B.k_u32, n_pos)) || (rc = dev_alloc(&B.k_f32, n_pos))) return rc;
     if (B.n_seg != n_seg) {
         void *ps[] = {B.seg_off, B.seg_be, B.bounds, B.acc, B.med, B.rows};
-        for (void *p : ps) if (p) (void)hipFree(p);
+        for (void *p : ps) if (p) isx_dev_free(p);
         B.seg_off = nullptr; B.seg_be = nullptr; B.bounds = nullptr; B.acc = nullptr; B.med = nullptr; B.rows = nullptr;
         B.n_seg = n_seg;
     }
@@ -531,7 +531,7 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
         tb = std::max(tb, tb2);
     }
     if (B.temp_bytes < tb) {
-        if (B.temp) (void)hipFree(B.temp);
+        if (B.temp) isx_dev_free(B.temp);
         B.temp = nullptr;
         HIP_TRY(hipMalloc(&B.temp, tb + 256));
         B.temp_bytes = tb + 256;
@@ -604,7 +604,7 @@ int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, co
     void *temp = nullptr;
     auto done = [&](int code) {
         void *ps[] = {d_sb, d_gb, d_off, d_be, d_acc, d_sacc, d_rows, temp};
-        for (void *p : ps) if (p) (void)hipFree(p);
+        for (void *p : ps) if (p) isx_dev_free(p);
         return code;
     };
 #define GS_TRY(expr) do { if ((expr) != hipSuccess) { isx_set_error(std::string("HIP error in the genome summary: ") + #expr); return done(ISX_ERR_HIP); } } while (0)
@@ -673,7 +673,7 @@ int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, co
 void CompareBuffers::release()
 {
     void *ps[] = {cov_a, cov_b, scratch_f, bounds, acc_a, acc_b, both, rows, keys, idx, cand, snp_rows, cursors, temp};
-    for (void *p : ps) if (p) (void)hipFree(p);
+    for (void *p : ps) if (p) isx_dev_free(p);
     *this = CompareBuffers();
 }
 
@@ -681,7 +681,7 @@ template <class T>
 static int ensure(T **p, size_t have, size_t want)
 {
     if (*p && have >= want) return ISX_OK;
-    if (*p) (void)hipFree(*p);
+    if (*p) isx_dev_free(*p);
     *p = nullptr;
     HIP_TRY(hipMalloc(p, std::max<size_t>(want, 1) * sizeof(T)));
     return ISX_OK;
@@ -716,7 +716,7 @@ int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, const 
         size_t tb = 0;
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, B.keys, B.keys, B.idx, B.idx, std::max<size_t>(n_snv, 1), 0, 48, s));
         if (B.temp_bytes < tb) {
-            if (B.temp) (void)hipFree(B.temp);
+            if (B.temp) isx_dev_free(B.temp);
             B.temp = nullptr;
             HIP_TRY(hipMalloc(&B.temp, tb + 256));
             B.temp_bytes = tb + 256;

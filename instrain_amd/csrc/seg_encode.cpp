@@ -66,7 +66,10 @@ int encode_segs(HostPool &pool, SegJob &J)
     std::vector<int64_t> bases_of((size_t)std::max(n_tasks, 1), 0);
     std::vector<uint32_t> maxp_of((size_t)std::max(n_tasks, 1), 0);
     const bool pairs = J.pair_out != nullptr && (producer ? J.want_pairs : J.in.pair != nullptr);
+    const int64_t RG = J.ring_groups;
+    const size_t group_words = (size_t)ISX_SEG_GROUP * ISX_SEG_REC_WORDS;
     if (n == 0) {                                   // one empty group: the kernels want a stream
+        if (RG) J.wave_begin(0);
         for (int r = 0; r < ISX_SEG_GROUP; r++) {
             uint32_t *o = J.rec + (size_t)r * ISX_SEG_REC_WORDS;
             o[0] = 0;
@@ -75,17 +78,17 @@ int encode_segs(HostPool &pool, SegJob &J)
         }
         J.gbase[0] = 0; J.cmin[0] = 0xFFFFFFFFu; J.cmax[0] = 0; J.cany[0] = 0;
         J.n_bases = 0; J.max_pair = 0;
+        if (RG) J.wave_flush(0, 0, 1);
         return SEG_OK;
     }
-    pool.run(n_tasks, [&](int t) {
+    auto run_task = [&](int t, int64_t wave_g0, int half) {
         if (err.load(std::memory_order_relaxed) != SEG_OK) return;
         const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
         const uint32_t *gp, *pr, *bs;
         const uint8_t *ln, *mm;
         if (producer) {
             thread_local Scratch S;
-            const size_t c = (size_t)(e - a);
-            if (S.gpos.size() < c) { S.gpos.resize((size_t)TASK); S.pair.resize((size_t)TASK); S.bases.resize((size_t)TASK * ISX_SEG_WORDS); S.len.resize((size_t)TASK); S.mm.resize((size_t)TASK); }
+            if (S.gpos.size() < (size_t)TASK) { S.gpos.resize((size_t)TASK); S.pair.resize((size_t)TASK); S.bases.resize((size_t)TASK * ISX_SEG_WORDS); S.len.resize((size_t)TASK); S.mm.resize((size_t)TASK); }
             J.produce(a, e - a, S.gpos.data(), S.len.data(), S.mm.data(), pairs ? S.pair.data() : nullptr, S.bases.data());
             gp = S.gpos.data() - a; ln = S.len.data() - a; mm = S.mm.data() - a; pr = pairs ? S.pair.data() - a : nullptr;
             bs = S.bases.data() - (size_t)a * ISX_SEG_WORDS;
@@ -103,7 +106,7 @@ int encode_segs(HostPool &pool, SegJob &J)
                 if (nhi - nlo > SPAN) break;
                 lo = nlo; hi = nhi;
             }
-            uint32_t *o = J.rec + (size_t)g * ISX_SEG_GROUP * ISX_SEG_REC_WORDS;
+            uint32_t *o = J.rec + (RG ? (size_t)(g - wave_g0 + (int64_t)half * RG) : (size_t)g) * group_words;
             uint32_t last = 0;
             for (int64_t s = i; s < j; s++, o += ISX_SEG_REC_WORDS) {
                 const uint32_t L = ln[s], m = mm ? mm[s] : 0u, p = gp[s];
@@ -128,7 +131,22 @@ int encode_segs(HostPool &pool, SegJob &J)
             i = j; g++;
         }
         bases_of[(size_t)t] = nb; maxp_of[(size_t)t] = maxp;
-    });
+    };
+    if (!RG) pool.run(n_tasks, [&](int t) { run_task(t, 0, 0); });
+    else {
+        // waves of consecutive tasks whose groups fit one half of the ring
+        int half = 0;
+        for (int t0 = 0; t0 < n_tasks && err.load() == SEG_OK;) {
+            int t1 = t0 + 1;
+            while (t1 < n_tasks && g_at[(size_t)t1 + 1] - g_at[(size_t)t0] <= RG) t1++;
+            if (g_at[(size_t)t1] - g_at[(size_t)t0] > RG) return SEG_CAPACITY;         // one task alone outgrows a half (ring far too small)
+            J.wave_begin(half);
+            const int64_t wg0 = g_at[(size_t)t0];
+            pool.run(t1 - t0, [&](int k) { run_task(t0 + k, wg0, half); });
+            if (err.load() == SEG_OK) J.wave_flush(half, wg0, g_at[(size_t)t1]);
+            t0 = t1; half ^= 1;
+        }
+    }
     if (err.load() != SEG_OK) return err.load();
     J.n_bases = 0; J.max_pair = 0;
     for (int t = 0; t < n_tasks; t++) { J.n_bases += bases_of[(size_t)t]; J.max_pair = std::max(J.max_pair, maxp_of[(size_t)t]); }
@@ -178,11 +196,19 @@ extern "C" {
 int isx_encode_segs(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int64_t cap_rec, uint32_t *rec,
                     uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec)
 {
+    return isx_encode_segs_ring(segs, n_pos, n_mm_bins, host_threads, cap_rec, 0, rec, gbase, pair_out, n_rec);
+}
+
+int isx_encode_segs_ring(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int64_t cap_rec, int64_t ring_records,
+                         uint32_t *rec, uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec)
+{
     if (!segs || !rec || !gbase || !n_rec || segs->n_seg < 0 || cap_rec < ISX_SEG_GROUP || (cap_rec % ISX_SEG_GROUP) ||
-        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases)) || (segs->pair && !pair_out)) {
+        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases)) || (segs->pair && !pair_out) || ring_records < 0 ||
+        (ring_records % (2 * ISX_SEG_GROUP))) {
         isx_set_error("isx_encode_segs: bad argument");
         return ISX_ERR_ARG;
     }
+    std::vector<uint32_t> ring;
     isxenc::HostPool pool(std::max(1, host_threads), -1, false);
     std::vector<uint32_t> cmin((size_t)(cap_rec / ISX_SEG_GROUP)), cmax(cmin.size());
     std::vector<uint8_t> cany(cmin.size());
@@ -190,6 +216,18 @@ int isx_encode_segs(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins, int3
     J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = std::max(1, n_mm_bins);
     J.rec = rec; J.gbase = gbase; J.pair_out = segs->pair ? pair_out : nullptr;
     J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data(); J.cap_rec = cap_rec;
+    if (ring_records) {         // the pipe's ring mode with a memcpy standing in for the DMA engine
+        const int64_t half = ring_records / 2;
+        ring.assign((size_t)ring_records * ISX_SEG_REC_WORDS, 0xABABABABu);
+        J.rec = ring.data();
+        J.ring_groups = half / ISX_SEG_GROUP;
+        J.wave_begin = [](int) {};
+        J.wave_flush = [&](int h, int64_t g0, int64_t g1) {
+            const size_t gw = (size_t)ISX_SEG_GROUP * ISX_SEG_REC_WORDS;
+            memcpy(rec + (size_t)g0 * gw, ring.data() + (size_t)h * half * ISX_SEG_REC_WORDS, (size_t)(g1 - g0) * gw * 4);
+            std::fill_n(ring.begin() + (ptrdiff_t)((size_t)h * half * ISX_SEG_REC_WORDS), (size_t)half * ISX_SEG_REC_WORDS, 0xABABABABu);   // stale data must never travel
+        };
+    }
     const int rc = isxenc::encode_segs(pool, J);
     if (rc == isxenc::SEG_CAPACITY) { isx_set_error("isx_encode_segs: the stream does not fit cap_rec records"); return ISX_ERR_CAPACITY; }
     if (rc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }

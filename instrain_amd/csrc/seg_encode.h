@@ -34,6 +34,13 @@ struct SegJob {
     uint32_t *cmin = nullptr, *cmax = nullptr;  // per group: lowest start / highest last position of its real records
     uint8_t *cany = nullptr;
     int64_t cap_rec = 0;
+    // ring mode (ring_groups > 0): `rec` is not the whole stream but two halves of ring_groups groups each.  The tasks run in
+    // waves whose groups fit one half; wave_begin(half) is called before a wave writes (the half's previous copy must have left
+    // the host), wave_flush(half, g0, g1) after it: device groups [g0, g1) sit at the start of that half.  Both are called from
+    // the thread that called encode_segs.  gbase / pair_out / the directory are never ringed (4 + 4 bytes per 64-byte record).
+    int64_t ring_groups = 0;
+    std::function<void(int half)> wave_begin;
+    std::function<void(int half, int64_t g0, int64_t g1)> wave_flush;
     // results
     int64_t n_rec = 0;                          // device records, a multiple of ISX_SEG_GROUP
     int64_t n_bases = 0;                        // sum of the segment lengths (an upper bound of the observations)

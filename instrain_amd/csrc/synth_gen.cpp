@@ -232,7 +232,7 @@ struct ContigGen {
 void bgzf_append(std::string &out, const uint8_t *data, size_t n)
 {
     for (size_t a = 0; a < n || (n == 0 && a == 0); a += 0xFF00) {
-        const size_t len = std::min<size_t>(0xFF00, n - a);
+        const size_t len = n ? std::min<size_t>(0xFF00, n - a) : 0;
         uint8_t comp[0x10000 + 64];
         z_stream zs;
         memset(&zs, 0, sizeof zs);
@@ -409,8 +409,96 @@ int64_t isx_synth_write_bam(const isx_synth_params *p, const int32_t *genome_sel
                 put<uint8_t>(raw, (uint8_t)std::min<int>(255, mm_read));
                 nr++;
             });
-            if (!raw.empty()) bgzf_append(part[(size_t)ci], reinterpret_cast<const uint8_t *>(raw.data()), raw.size());
+            part[(size_t)ci].swap(raw);            // uncompressed for now: the blocks of ALL contigs are compressed in parallel below
             n_reads.fetch_add(nr);
+        }
+    };
+    const int nt = std::max(1, p->threads);
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+    }
+    // BGZF: pieces of <= 8 blocks of one contig, compressed by all threads, written in file order
+    struct Piece { size_t contig, off, len; };
+    std::vector<Piece> pieces;
+    const size_t PIECE = 8 * 0xFF00;
+    for (size_t ci = 0; ci < part.size(); ci++)
+        for (size_t a = 0; a < part[ci].size(); a += PIECE) pieces.push_back({ci, a, std::min(PIECE, part[ci].size() - a)});
+    std::vector<std::string> comp(pieces.size());
+    std::atomic<size_t> nextp{0};
+    auto squeeze = [&]() {
+        for (;;) {
+            const size_t k = nextp.fetch_add(1);
+            if (k >= pieces.size()) break;
+            bgzf_append(comp[k], reinterpret_cast<const uint8_t *>(part[pieces[k].contig].data()) + pieces[k].off, pieces[k].len);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(squeeze);
+        squeeze();
+        for (auto &t : th) t.join();
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) return -4;
+    std::string hz;
+    bgzf_append(hz, reinterpret_cast<const uint8_t *>(head.data()), head.size());
+    bool ok = fwrite(hz.data(), 1, hz.size(), f) == hz.size();
+    for (auto &s : comp) if (ok && !s.empty()) ok = fwrite(s.data(), 1, s.size(), f) == s.size();
+    static const uint8_t eof_block[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(eof_block, 1, 28, f) == 28;
+    ok = fclose(f) == 0 && ok;
+    return ok ? n_reads.load() : -5;
+}
+
+// The same genomes as READ SEGMENTS (include/instrain_amd.h isx_segs): one segment per read (read_len <= 150 columns, code 4
+// where the generator drops a base), what the read-level hand-over ships -- no observation stream in between.
+// Two calls: with seg_gpos == NULL only the sizes (out->n_obs = kept bases, return value = segments), then the arrays.
+int64_t isx_synth_generate_segs(const isx_synth_params *p, const int32_t *genome_sel, int32_t n_sel, const int64_t *length,
+                                const double *coverage, isx_synth_out *out, uint32_t *seg_gpos, uint8_t *seg_len, uint8_t *seg_mm,
+                                uint32_t *seg_pair, uint32_t *seg_bases)
+{
+    if (!p || !genome_sel || n_sel <= 0 || !out || p->read_len > 150) return -1;
+    memset(out, 0, sizeof *out);
+    const int RL = p->read_len, C = p->contigs;
+    const int64_t n_sc = (int64_t)n_sel * C;
+    std::vector<Contig> cs;
+    int64_t obs_cap = 0, pair0 = 0;
+    const int64_t off = plan_contigs(p, genome_sel, n_sel, length, coverage, cs, obs_cap, pair0);
+    if (off >= (int64_t)0xFFFF0000ll || pair0 >= (int64_t)0xFFFFFFFFll) return -2;
+    out->n_pos = off; out->n_pairs = pair0; out->n_scaffolds = n_sc;
+    out->profiled_bases = pair0 * 2 * RL;
+    if (!seg_gpos) return 2 * pair0;
+    out->ref = (uint8_t *)malloc((size_t)std::max<int64_t>(off, 1));
+    out->scaffold_bounds = (int64_t *)malloc((size_t)(n_sc + 1) * sizeof(int64_t));
+    out->scaffold_genome = (int32_t *)malloc((size_t)n_sc * sizeof(int32_t));
+    if (!out->ref || !out->scaffold_bounds || !out->scaffold_genome) { isx_synth_free(out); return -3; }
+    for (int64_t i = 0; i < n_sc; i++) { out->scaffold_bounds[i] = cs[(size_t)i].off; out->scaffold_genome[i] = cs[(size_t)i].genome; }
+    out->scaffold_bounds[n_sc] = off;
+    std::atomic<int64_t> next{0}, n_sites{0}, n_kept{0};
+    auto work = [&]() {
+        ContigGen G;
+        for (;;) {
+            const int64_t ci = next.fetch_add(1);
+            if (ci >= n_sc) break;
+            const Contig &k = cs[(size_t)ci];
+            int64_t at = 2 * k.pair0, kept = 0;             // a contig's reads are consecutive segments
+            G.run(p, k, out->ref + k.off, [&](uint32_t i, int64_t st, const uint8_t *b, const uint8_t *keep, uint16_t mm_pair, uint16_t) {
+                uint32_t *w = seg_bases + (size_t)at * 15;
+                for (int q = 0; q < 15; q++) w[q] = 0x24924924u;
+                for (int q = 0; q < RL; q++) {
+                    if (!keep[q]) continue;
+                    w[q / 10] = (w[q / 10] & ~(7u << (3 * (q % 10)))) | ((uint32_t)b[q] << (3 * (q % 10)));
+                    kept++;
+                }
+                seg_gpos[at] = (uint32_t)(k.off + st); seg_len[at] = (uint8_t)RL;
+                if (seg_mm) seg_mm[at] = p->with_mm ? (uint8_t)std::min<int>(std::min(255, p->max_mm), mm_pair) : (uint8_t)0;
+                if (seg_pair) seg_pair[at] = (uint32_t)(k.pair0 + (i >> 1));
+                at++;
+            });
+            n_sites.fetch_add(G.n_sites); n_kept.fetch_add(kept);
         }
     };
     const int nt = std::max(1, p->threads);
@@ -418,16 +506,39 @@ int64_t isx_synth_write_bam(const isx_synth_params *p, const int32_t *genome_sel
     for (int t = 1; t < nt; t++) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
-    FILE *f = fopen(path, "wb");
-    if (!f) return -4;
-    std::string hz;
-    bgzf_append(hz, reinterpret_cast<const uint8_t *>(head.data()), head.size());
-    bool ok = fwrite(hz.data(), 1, hz.size(), f) == hz.size();
-    for (auto &s : part) if (ok && !s.empty()) ok = fwrite(s.data(), 1, s.size(), f) == s.size();
-    static const uint8_t eof_block[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    ok = ok && fwrite(eof_block, 1, 28, f) == 28;
-    ok = fclose(f) == 0 && ok;
-    return ok ? n_reads.load() : -5;
+    out->n_obs = n_kept.load();
+    out->n_sites = n_sites.load();
+    return 2 * pair0;
+}
+
+// a distinct batch of the same shape from a batch of segments: every start moves up by `shift`, every A/C/T/G code is
+// rotated by `rot` (reference and reads alike) -- what synth.shifted_variant does to observation records
+void isx_synth_shift_segs(const uint32_t *gpos_in, const uint32_t *bases_in, int64_t n_seg, uint32_t shift, int32_t rot, uint32_t *gpos_out,
+                          uint32_t *bases_out, int32_t threads)
+{
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t a = next.fetch_add(8192);
+            if (a >= n_seg) break;
+            const int64_t e = std::min<int64_t>(n_seg, a + 8192);
+            for (int64_t i = a; i < e; i++) gpos_out[i] = gpos_in[i] + shift;
+            for (int64_t i = a * 15; i < e * 15; i++) {
+                const uint32_t w = bases_in[i];
+                // codes < 4 (bit 2 clear): (c + rot) & 3 on the low two bits of every 3-bit field, no carry into bit 2
+                const uint32_t acgt = ~w & 0x24924924u;                     // bit 2 of every field set where the code is A/C/T/G
+                const uint32_t sel = (acgt >> 2) * 3u;                      // 0b011 in those fields
+                const uint32_t lo = w & 0x1B6DB6DBu;                        // low two bits of every field
+                const uint32_t sum = (lo + (uint32_t)rot * 0x09249249u) & 0x1B6DB6DBu;   // per-field add; a carry lands in bit 2 and is masked off
+                bases_out[i] = (w & ~sel) | (sum & sel);
+            }
+        }
+    };
+    const int nt = std::max(1, threads);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
 }
 
 // ---- observation stream -> read segments (include/instrain_amd.h isx_segs) ----

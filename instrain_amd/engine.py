@@ -386,8 +386,8 @@ def encode_obs(obs, pair=None, n_pos=None, record_bytes=2, threads=1, slack=0.0,
     return rec[:n], gbase[:n // G], (pout[:n] if pout is not None else None), passes.value
 
 
-def encode_segs(segs, n_pos, n_mm_bins=1, threads=1, cap_rec=None):
-    """isx_encode_segs (host only): SegBatch -> (rec [n_rec, 16] uint32, gbase [n_rec / 16], pair_out | None)"""
+def encode_segs(segs, n_pos, n_mm_bins=1, threads=1, cap_rec=None, ring_records=0):
+    """isx_encode_segs / isx_encode_segs_ring (host only): SegBatch -> (rec [n_rec, 16] uint32, gbase [n_rec / 16], pair_out | None)"""
     lib = _lib.load()
     if cap_rec is None:
         cap_rec = ((segs.n_seg + 15) // 16 + segs.n_seg // 4096 + 64) * 16
@@ -396,8 +396,8 @@ def encode_segs(segs, n_pos, n_mm_bins=1, threads=1, cap_rec=None):
     pout = np.empty(cap_rec, dtype=np.uint32) if segs.pair is not None else None
     n_rec = C.c_int64(0)
     cs = segs.c()
-    check(lib.isx_encode_segs(C.byref(cs), int(n_pos), int(n_mm_bins), int(threads), int(cap_rec), rec.ctypes.data, gbase.ctypes.data,
-                              pout.ctypes.data if pout is not None else None, C.byref(n_rec)))
+    check(lib.isx_encode_segs_ring(C.byref(cs), int(n_pos), int(n_mm_bins), int(threads), int(cap_rec), int(ring_records), rec.ctypes.data,
+                                   gbase.ctypes.data, pout.ctypes.data if pout is not None else None, C.byref(n_rec)))
     n = n_rec.value
     return rec[:n], gbase[:n // 16], (pout[:n] if pout is not None else None)
 

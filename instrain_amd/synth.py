@@ -182,6 +182,11 @@ def _synth():
         lib.isx_synth_write_bam.argtypes = [_C.POINTER(_SynthParams), _C.c_void_p, _C.c_int32, _C.c_void_p, _C.c_void_p, _C.c_char_p,
                                             _C.c_void_p, _C.POINTER(_C.c_int64), _C.POINTER(_C.c_int64)]
         lib.isx_synth_write_bam.restype = _C.c_int64
+        lib.isx_synth_generate_segs.argtypes = [_C.POINTER(_SynthParams), _C.c_void_p, _C.c_int32, _C.c_void_p, _C.c_void_p, _C.POINTER(_SynthOut),
+                                                _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_void_p]
+        lib.isx_synth_generate_segs.restype = _C.c_int64
+        lib.isx_synth_shift_segs.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int64, _C.c_uint32, _C.c_int32, _C.c_void_p, _C.c_void_p, _C.c_int32]
+        lib.isx_synth_shift_segs.restype = None
         lib.isx_synth_obs_to_segs.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int64, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_void_p,
                                               _C.c_void_p, _C.c_int32]
         lib.isx_synth_obs_to_segs.restype = _C.c_int64
@@ -207,6 +212,28 @@ def segs_from_obs(obs, pair=None, threads=0):
     lib.isx_synth_obs_to_segs(obs.ctypes.data, pr.ctypes.data if pr is not None else None, len(obs), g.ctypes.data, ln.ctypes.data,
                               mm.ctypes.data, sp.ctypes.data if sp is not None else None, bs.ctypes.data, int(threads))
     return engine.SegBatch(g, ln, bs, mm, sp)
+
+
+def shifted_variant_segs(w, k, max_shift=65536, threads=4):
+    """shifted_variant for a read-level workload (w["segs"]: engine.SegBatch): the same shift of every position and the same
+    rotation of the base alphabet, applied to the segment starts, the packed codes and the reference"""
+    from . import engine
+    rng = np.random.Generator(np.random.PCG64(1000 + k))
+    s = int(rng.integers(0, max_shift)) if k else 0
+    r = k & 3
+    sg = w["segs"]
+    g = np.empty_like(sg.gpos)
+    b = np.empty_like(sg.bases)
+    _synth().isx_synth_shift_segs(sg.gpos.ctypes.data, sg.bases.ctypes.data, sg.n_seg, s, r, g.ctypes.data, b.ctypes.data, int(threads))
+    G = int(w["n_pos"])
+    n_pos = G + max_shift
+    ref = np.zeros(n_pos, dtype=np.uint8)
+    rc = w["ref_codes"]
+    ref[s:s + G] = np.where(rc < 4, (rc + r) & 3, rc)
+    out = {kk: v for kk, v in w.items() if kk not in ("obs", "pair")}
+    out.update({"segs": engine.SegBatch(g, sg.len, b, sg.mm, sg.pair), "ref_codes": ref, "n_pos": n_pos,
+                "split_bounds": split_bounds_for([n_pos], 10000), "variant": k, "shift": s, "rotation": r})
+    return out
 
 
 class _SynthOwner:
@@ -276,13 +303,12 @@ class Metagenome:
         if n < 0:
             raise ValueError("isx_synth_write_bam failed (%d)" % n)
         assert npos.value == n_pos
-        w = self.generate_layout(sel)
         return {"n_reads": int(n), "n_pairs": int(npairs.value), "n_pos": n_pos, "ref_codes": ref, "names": self.contig_names(sel),
-                "scaffold_bounds": w, "profiled_bases": int(npairs.value) * 2 * self.read_len}
+                "scaffold_bounds": self.layout(sel)["scaffold_bounds"], "profiled_bases": int(npairs.value) * 2 * self.read_len}
 
-    def generate_layout(self, genome_sel):
-        """flat scaffold bounds of generate(genome_sel) / write_bam(genome_sel) without generating the reads: contig lengths
-        come from the file header the writer produced -- here recomputed by a dry generate of zero-coverage genomes"""
+    def layout(self, genome_sel):
+        """The FASTA side of generate(genome_sel) / write_bam(genome_sel) without any read: contig names, flat scaffold bounds and
+        reference codes (a generate of the same genomes at zero coverage)"""
         sel = np.ascontiguousarray(genome_sel, dtype=np.int32)
         cov = np.zeros_like(self.coverage)
         out = _SynthOut()
@@ -291,8 +317,39 @@ class Metagenome:
             raise ValueError("isx_synth_generate failed (%d)" % rc)
         n = int(out.n_scaffolds) + 1
         sb = np.frombuffer((_C.c_uint8 * (n * 8)).from_address(out.scaffold_bounds), dtype=np.int64).copy()
+        ref = np.frombuffer((_C.c_uint8 * max(1, int(out.n_pos))).from_address(out.ref), dtype=np.uint8)[:int(out.n_pos)].copy()
         _synth().isx_synth_free(_C.byref(out))
-        return sb
+        return {"scaffold_bounds": sb, "ref_codes": ref, "names": self.contig_names(sel), "n_pos": int(sb[-1])}
+
+    def generate_segs(self, genome_sel, window_length=10000, with_pairs=True):
+        """-> workload dict like generate()'s, but with the reads as segments (w["segs"]: engine.SegBatch, one per read) and
+        no observation stream: what the read-level hand-over ships"""
+        from . import engine
+        sel = np.ascontiguousarray(genome_sel, dtype=np.int32)
+        out = _SynthOut()
+        lib = _synth()
+        n = int(lib.isx_synth_generate_segs(_C.byref(self.p), sel.ctypes.data, len(sel), self.length.ctypes.data, self.coverage.ctypes.data,
+                                            _C.byref(out), None, None, None, None, None))
+        if n < 0:
+            raise ValueError("isx_synth_generate_segs failed (%d)" % n)
+        g, ln, mm = np.empty(n, np.uint32), np.empty(n, np.uint8), np.empty(n, np.uint8)
+        pr = np.empty(n, np.uint32) if with_pairs else None
+        bs = np.empty((n, 15), np.uint32)
+        n2 = int(lib.isx_synth_generate_segs(_C.byref(self.p), sel.ctypes.data, len(sel), self.length.ctypes.data, self.coverage.ctypes.data,
+                                             _C.byref(out), g.ctypes.data, ln.ctypes.data, mm.ctypes.data,
+                                             pr.ctypes.data if pr is not None else None, bs.ctypes.data))
+        assert n2 == n
+        owner = _SynthOwner(out)
+        ref = np.frombuffer((_C.c_uint8 * max(1, out.n_pos)).from_address(out.ref), dtype=np.uint8)[:out.n_pos].copy()
+        sb = np.frombuffer((_C.c_uint8 * ((out.n_scaffolds + 1) * 8)).from_address(out.scaffold_bounds), dtype=np.int64).copy()
+        sg = np.frombuffer((_C.c_uint8 * (max(1, out.n_scaffolds) * 4)).from_address(out.scaffold_genome), dtype=np.int32)[:out.n_scaffolds].copy()
+        w = {"ref_codes": ref, "segs": engine.SegBatch(g, ln, bs, mm, pr), "scaffold_bounds": sb, "scaffold_genome": sel[sg],
+             "genomes": sel.copy(), "n_pairs": int(out.n_pairs), "n_obs": int(out.n_obs), "n_pos": int(out.n_pos),
+             "n_sites_planted": int(out.n_sites), "profiled_bases": int(out.profiled_bases),
+             "n_mm_bins": int(mm.max()) + 1 if (self.p.with_mm and n) else 1}
+        w["split_bounds"] = split_bounds_for(np.diff(sb), window_length)
+        del owner
+        return w
 
     def generate(self, genome_sel, window_length=10000):
         """-> workload dict like make_workload's (+ scaffold_bounds, scaffold_genome, genomes)"""

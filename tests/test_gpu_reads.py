@@ -106,7 +106,8 @@ def test_randomized_sweep_reads_equal_observations(ctx):
                                                  n_sites=int(rng.integers(0, 80)), p_other=float(rng.choice([0.0, 0.03])), ref_ambig=int(rng.integers(0, 4)),
                                                  self_pairs=float(rng.choice([0.0, 0.3])))
         kw = dict(n_mm_bins=int(mm.max()) + 1 if len(mm) else 1, min_cov=int(rng.integers(1, 8)), min_freq=float(rng.choice([0.01, 0.05, 0.2])),
-                  min_snp=int(rng.integers(1, 25)), window=int(rng.choice([0, 64, 256, 1024])), rarefied_coverage=int(rng.choice([0, 5, 50])))
+                  min_snp=int(rng.integers(1, 25)), window=int(rng.choice([0, 64, 256, 1024] if mm_levels <= 5 else [0, 64, 256])),
+                  rarefied_coverage=int(rng.choice([0, 5, 50])))
         obs = engine.pack_obs(pos.astype(np.uint32), base, mm)
         pr = pair.astype(np.uint32)
         ref = engine.encode_seq(seq)

@@ -33,6 +33,23 @@ def test_cases_exist():
     assert len(CASES) >= 8
 
 
+@pytest.mark.parametrize("name", ["synth_mm4", "synth_selfpairs", "synth_ambig", "synth_skipmm_ld", "synth_lowcov"])
+def test_python_column_restatement_matches_reference_vectors(name):
+    """oracle/py_columns.py (the per-column Python loop bench.py times as the reference-like CPU baseline) gives the
+    reference's tables too -- a second restatement, independent of the C port"""
+    from oracle import py_columns
+    lut, fb = util.load_lut()
+    nm = {i: int(v) for i, v in enumerate(lut) if v >= 0}
+    nm[-1] = fb
+    g = util.load_case(name)
+    res = py_columns.profile_split(g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), nm,
+                                   min_cov=int(g["p_min_cov"]), min_freq=float(g["p_min_freq"]), min_snp=int(g["p_min_snp"]))
+    util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=0.0, what=name)
+    assert res["n_edges"] == int(g["n_edges"])
+    c = run_oracle_case(g, lut, fb)
+    assert res["n_increments"] == c["n_increments"]
+
+
 # ---------------------------------------------------------------------------------------
 # The reference's stored golden run (sars_cov_2 .IS folder, inStrain 1.2.4 + real pysam)
 # ---------------------------------------------------------------------------------------

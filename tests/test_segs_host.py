@@ -89,6 +89,21 @@ def test_encode_segs_layout(threads):
     assert len(rec) <= (segs.n_seg // 16 + segs.n_seg // 4096 + 64) * 16       # reads straddling the jump alternate between its sides
 
 
+@pytest.mark.parametrize("ring_records", [2 * 4096 + 64, 3 * 4096, 1 << 14])
+def test_encode_segs_through_the_staging_ring(ring_records):
+    """waves through a ring of two halves give the stream the whole-arena layout gives, whatever the half size"""
+    w = _workload(seed=13, G=300_000, cov=10)
+    segs = synth.segs_from_obs(w["obs"], w["pair"])
+    a = engine.encode_segs(segs, w["n_pos"], n_mm_bins=int(w["obs"]["mm"].max()) + 1, threads=3)
+    b = engine.encode_segs(segs, w["n_pos"], n_mm_bins=int(w["obs"]["mm"].max()) + 1, threads=3, ring_records=ring_records)
+    assert len(a[0]) == len(b[0]) > ring_records // 2
+    for x, y in zip(a, b):
+        assert (x == y).all()
+    from instrain_amd._lib import IsxError
+    with pytest.raises(IsxError):                       # a half that cannot hold one task of 4096 segments
+        engine.encode_segs(segs, w["n_pos"], n_mm_bins=16, ring_records=2 * 2048)
+
+
 def test_encode_segs_rejects_bad_input():
     from instrain_amd._lib import IsxError
     segs = engine.SegBatch([10, 20], [150, 150], np.full((2, 15), 0x24924924, np.uint32), mm=[0, 3])
