@@ -152,6 +152,7 @@ def cpu_baseline(w, budget_s=25.0, min_s=10.0):
     like profile_split, on the splits of the SAME workload (wrapped around) for >= min_s of wall time:
     first on one core, then on T host threads (the C call releases the GIL; the reference parallelises
     over splits the same way, profile_controller.py:243-271).  `value` / `cores` = the T-thread run."""
+    _trace("cpu_baseline")
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     from tests import util
@@ -210,6 +211,7 @@ def cpu_baseline_python(w, n_splits=200, budget_s=18.0):
     (position, mm), per-read SNV lists, dict-of-dicts linkage network) with multiprocessing over splits exactly like the
     reference's worker pool (profile_controller.py:243-271), P = the cpus this process may use, on a subsample of the SAME
     workload's splits (evenly spaced), stopped after budget_s; the rate is extrapolated linearly (cost is per split)."""
+    _trace("cpu_baseline_python")
     import multiprocessing as mp
     from tests import util
     lut, fb = util.load_lut()
@@ -241,6 +243,15 @@ def cpu_baseline_python(w, n_splits=200, budget_s=18.0):
 INT8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA peak (spec, no sparsity; MI355X_MICROARCH.md: >= 4404 measured)
 
 
+def _trace(msg):
+    """progress on stderr (ISX_BENCH_TRACE=1): which leg a long run is in"""
+    if os.environ.get("ISX_BENCH_TRACE"):
+        print("[bench %.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def _time_batch(b, warm=2, steps=5):
     for _ in range(warm):
         b.run()
@@ -256,6 +267,7 @@ def _time_batch(b, warm=2, steps=5):
 def linkage_leg(ctx, seed=3):
     """Secondary metric: SNV pairs linked / s on BASELINE configs[2] (C3: 5 Mbp, 200x, 50 000 SNV sites): the read-level
     batch (sparse pair-increment path) and the observation batch with the sparse and the dense int8-MFMA path."""
+    _trace("linkage_leg")
     from instrain_amd import engine, synth
     glen = int(os.environ.get("ISX_BENCH_C3_BP", 5_000_000))        # configs[2] in full; smaller = a slice of it (debug)
     meta = synth.Metagenome(1, total_read_bp=200.0 * glen, seed=seed, contigs=1, len_lo=glen, len_hi=glen, abundance_sigma=0.0,
@@ -304,6 +316,7 @@ def _roofline(kernel, ab, k_ms, t, traffic=None, **extra):
 def mm_leg(ctx, w, steps=10):
     """C2 again with mm profiling ON (the reference's default): k_pileup_mm, sparse (pos, mm) entries; read-level batch and
     observation batch."""
+    _trace("mm_leg")
     from instrain_amd import engine
     out = {"workload": "C2 with mm profiling on (%d mm bins)" % w["n_mm_bins_mm"]}
     for name, src in (("reads", w["segs_mm"]), ("observations", w["obs_mm"])):
@@ -326,6 +339,7 @@ def resident_leg(ctx, w, window, steps=30):
     reports): k_pileup_dense on the read segments (the kernel of the timed step) and on the 2-byte observation records.
     Plus the old kernel-only ceiling: two resident read-level batches passed over alternately, nothing handed over or
     fetched -- NOT what production does."""
+    _trace("resident_leg")
     from instrain_amd import engine
     out = {}
     for name, src in (("reads", w["segs"]), ("observations", w["obs"])):
@@ -372,6 +386,7 @@ def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu
     (read pairs, profile_controller.py:460-465); rank r streams the shards r, r + N, ... through its read-level pipe in
     batches of a few genomes, every batch handed over, profiled once (pileup + SNV call + linkage), tables copied back.
     N = 1: the WHOLE kept database through one GPU; N = 8: one shard per GPU (strong scaling of the configuration)."""
+    _trace("c5_leg")
     from instrain_amd import dist as idist
     from instrain_amd import engine
     meta, kept, shards, n_genomes = _c5_plan(scale, host_threads)
@@ -460,6 +475,7 @@ def c5_bam_leg(ctx, host_threads, scale=1.0):
     """The north-star shape through the ENTRY POINT: shard 0 of C5 (1/8 of the kept database: ~85 genomes, ~4 200 contigs) written
     as a coordinate-sorted BAM by the generator, profiled by instrain_amd.profile.profile_bam with a fasta_db of every
     contig's splits (what the controller hands over, profile_controller.py:415-433) in --database_mode."""
+    _trace("c5_bam_leg")
     import pandas as pd
     import instrain_amd.profile as amd
     from instrain_amd.profile.profile_utilities import iterate_splits
@@ -498,6 +514,7 @@ def profile_bam_leg(ctx, host_threads):
     pipe's staging, device batch, table hand-back, SplitObjects) on the 0.9 Gbp probe: a synthetic sorted BAM of 3 M pairs
     2 x 150 bp over one 24 Mbp scaffold, --skip_mm_profiling, and with mm profiling on (the reference's default).  Best of three
     runs each with a warm context; the BAM is written once into /tmp by the generator and is not timed."""
+    _trace("profile_bam_leg")
     import instrain_amd.profile as amd
     from instrain_amd import synth
     n_pairs, G = int(os.environ.get("ISX_BENCH_BAM_PAIRS", 3_000_000)), int(os.environ.get("ISX_BENCH_BAM_BP", 24_000_000))
@@ -537,6 +554,7 @@ def bam_sharded_leg(ctx, rank, world, local, host_threads, barrier, device):
     mean coverage, log-normal abundances) as one sorted BAM, profiled by dist.profile_bam_sharded -- every rank scans its share
     of the file, the shares' insert sizes are all-gathered for the file-wide median, every rank profiles the scaffolds it owns
     and rank 0 gathers the SNV / linkage / summary tables (grouped point-to-point on RCCL)."""
+    _trace("bam_sharded_leg")
     import torch.distributed as tdist
     from instrain_amd import dist as idist
     from instrain_amd import synth
@@ -674,6 +692,7 @@ def main():
 
     # Every step hands one batch of read segments over from host memory, profiles it once and brings its tables back;
     # consecutive batches overlap in the pipe's three queues.
+    _trace("C2 stream")
     stream(pipe, variants, args.warmup, args.depth)
     barrier()
     torch.cuda.synchronize()

@@ -17,7 +17,9 @@ struct SummaryBuffers {
     void *temp = nullptr;
     size_t temp_bytes = 0;
     int n_seg = -1;
+    size_t cap_pos = 0;             // positions the position-sized arrays hold (a pipe slot sees batches of different sizes)
     void release();
+    void fit_positions(size_t n_pos);
 };
 
 struct SummaryIn {

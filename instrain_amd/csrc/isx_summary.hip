@@ -464,6 +464,16 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
     return done(rc);
 }
 
+// the position-sized arrays are kept between calls; a batch with more positions than any before it gets new ones
+void SummaryBuffers::fit_positions(size_t n_pos)
+{
+    if (n_pos <= cap_pos) return;
+    void *ps[] = {cov, cv, cr, k_u32, k_f32};
+    for (void *p : ps) if (p) isx_dev_free(p);
+    cov = nullptr; cv = nullptr; cr = nullptr; k_u32 = nullptr; k_f32 = nullptr;
+    cap_pos = n_pos;
+}
+
 void SummaryBuffers::release()
 {
     void *ps[] = {cov, cv, cr, k_u32, k_f32, seg_off, seg_be, bounds, acc, med, rows, temp};
@@ -477,8 +487,9 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
     const uint32_t n_pos = in.n_pos;
     const int n_seg = in.n_scaffolds, M = in.M;
     int rc;
-    if ((rc = dev_alloc(&B.cov, n_pos)) || (rc = dev_alloc(&B.cv, n_pos)) || (rc = dev_alloc(&B.cr, n_pos)) ||
-        (rc = dev_alloc(&B.k_u32, n_pos)) || (rc = dev_alloc(&B.k_f32, n_pos))) return rc;
+    B.fit_positions(n_pos);
+    if ((rc = dev_alloc(&B.cov, B.cap_pos)) || (rc = dev_alloc(&B.cv, B.cap_pos)) || (rc = dev_alloc(&B.cr, B.cap_pos)) ||
+        (rc = dev_alloc(&B.k_u32, B.cap_pos)) || (rc = dev_alloc(&B.k_f32, B.cap_pos))) return rc;
     if (B.n_seg != n_seg) {
         void *ps[] = {B.seg_off, B.seg_be, B.bounds, B.acc, B.med, B.rows};
         for (void *p : ps) if (p) isx_dev_free(p);
@@ -589,8 +600,9 @@ int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, co
     const uint32_t n_pos = in.n_pos;
     const int n_scaf = in.n_scaffolds, M = in.M;
     int rc;
-    if ((rc = dev_alloc(&B.cov, n_pos)) || (rc = dev_alloc(&B.cv, n_pos)) || (rc = dev_alloc(&B.cr, n_pos)) ||
-        (rc = dev_alloc(&B.k_u32, n_pos)) || (rc = dev_alloc(&B.k_f32, n_pos))) return rc;
+    B.fit_positions(n_pos);
+    if ((rc = dev_alloc(&B.cov, B.cap_pos)) || (rc = dev_alloc(&B.cv, B.cap_pos)) || (rc = dev_alloc(&B.cr, B.cap_pos)) ||
+        (rc = dev_alloc(&B.k_u32, B.cap_pos)) || (rc = dev_alloc(&B.k_f32, B.cap_pos))) return rc;
     // small per-call tables (this is a once-per-batch pass)
     std::vector<int64_t> gb((size_t)n_genomes + 1);
     for (int g = 0; g <= n_genomes; g++) gb[(size_t)g] = in.scaffold_bounds[genome_first[g]];

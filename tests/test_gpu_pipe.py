@@ -354,3 +354,22 @@ def test_submit_bam_equals_array_submit(ctx, tmp_path):
             if sel == [2]:
                 assert sizes["n_ld"] > 0 and sizes["n_snv"] > 100
     bam.close()
+
+
+def test_summaries_on_a_reused_slot_with_growing_batches(ctx):
+    """a slot's summary buffers follow the batch: a small batch first, then a larger one through the same slot (the
+    position-sized scratch of isx_batch_summarize used to keep the first batch's size)"""
+    from instrain_amd import engine, synth
+    ws = [synth.make_workload(genome_len=g, coverage=12, n_sites=40, seed=31 + i) for i, g in enumerate((30_000, 400_000, 90_000))]
+    pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=max(w["n_obs"] for w in ws), max_splits=64, depth=1,
+                       host_threads=2, pin_threads=False, n_mm_bins=1, enable_linkage=False, want_counts=True)
+    for w in ws:
+        t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], None)
+        r = pipe.collect(t)
+        lv, _ = r["slot"].summarize([0, w["n_pos"] // 3, w["n_pos"]])
+        cov = r["counts"].sum(axis=1)
+        for j, (a, e) in enumerate(((0, w["n_pos"] // 3), (w["n_pos"] // 3, w["n_pos"]))):
+            assert int(lv[j, 0]["sum_cov"]) == int(cov[a:e].sum()) and int(lv[j, 0]["nonzero"]) == int((cov[a:e] > 0).sum())
+            assert float(lv[j, 0]["median_cov"]) == float(np.median(cov[a:e]))
+        pipe.release(t)
+    pipe.close()
