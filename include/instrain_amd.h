@@ -331,6 +331,12 @@ typedef struct {
     float clon_rarefied;
 } isx_rare;
 
+/* exact coverage of a position whose 16- / 8-bit hand-back entry saturated */
+typedef struct {
+    uint32_t gpos;
+    uint32_t coverage;
+} isx_sat;
+
 typedef struct {
     int64_t ticket;
     int64_t n_pos, n_obs;
@@ -359,6 +365,13 @@ typedef struct {
     int64_t h2d_bytes, d2h_bytes;
     const isx_ld *ld;           /* [sizes.n_ld] the LD rows when linkage is enabled (else NULL), reference order;
                                  * valid until isx_pipe_release */
+    /* n_mm_bins == 1, a SHALLOW batch (mean depth below min_cov; the pipe decides per batch, never with want_counts): the
+     * position-sized tables shrink further.  coverage16 == NULL -> coverage8; clon == NULL -> clon_sparse. */
+    const uint8_t *coverage8;   /* [n_pos] min(covT, 255); exact values of the positions at 255 or beyond: `saturated` */
+    const isx_rare *clon_sparse;/* [n_clon] (gpos, clonT) of the positions that have a clonality, ascending gpos */
+    int64_t n_clon;
+    const isx_sat *saturated;   /* [n_saturated] (gpos, exact coverage) of the positions whose coverage16 / coverage8 entry
+                                 * saturated, unordered; NULL when the list outgrew the pipe's room (isx_batch_fetch_dense then) */
 } isx_pipe_result;
 
 int isx_pipe_create(isx_ctx *ctx, const isx_params *params, const isx_pipe_params *pp, isx_pipe **out);

@@ -52,6 +52,8 @@ class Segs(C.Structure):
 
 
 RARE_DT = np.dtype([("gpos", "<u4"), ("clon_rarefied", "<f4")])
+CLON_DT = np.dtype([("gpos", "<u4"), ("clon", "<f4")])          # isx_pipe_result.clon_sparse (isx_rare's layout)
+SAT_DT = np.dtype([("gpos", "<u4"), ("coverage", "<u4")])
 
 
 class Sizes(C.Structure):
@@ -74,7 +76,8 @@ class PipeResult(C.Structure):
                 ("batch", C.c_void_p),
                 ("encode_ms", C.c_float), ("h2d_ms", C.c_float), ("kernel_ms", C.c_float), ("d2h_ms", C.c_float),
                 ("collect_wait_ms", C.c_float), ("record_bytes", C.c_int32), ("encode_passes", C.c_int32),
-                ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64), ("ld", C.c_void_p)]
+                ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64), ("ld", C.c_void_p),
+                ("coverage8", C.c_void_p), ("clon_sparse", C.c_void_p), ("n_clon", C.c_int64), ("saturated", C.c_void_p)]
 
 
 class BamParams(C.Structure):

@@ -593,7 +593,7 @@ void isx_batch_destroy(isx_batch *b)
     }
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_seg, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
+    void *ps[] = {b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) isx_dev_free(p);          // (falls through to hipFree for blocks that did not come from the cache)
@@ -813,6 +813,9 @@ int launch_pass(isx_batch *b)
     a.counts = b->d_counts; a.clon = b->d_clon; a.clon_r = b->d_clon_r;
     a.min_cov_r = b->prm.rarefied_coverage;
     a.cov16 = b->d_cov16; a.rare = b->d_rare; a.cap_rare = (uint32_t)std::min<size_t>(b->cap_rare, 0xFFFFFFFFu);
+    a.cov8 = b->sparse_out && b->cov8_out ? b->d_cov8 : nullptr;
+    a.sat = b->d_sat; a.cap_sat = (uint32_t)std::min<size_t>(b->cap_sat, 0xFFFFFFFFu); a.sat_thr = a.cov8 ? 255u : 65535u;
+    a.clon_list = b->sparse_out ? b->d_clon_list : nullptr; a.cap_clon = (uint32_t)std::min<size_t>(b->cap_clon, 0xFFFFFFFFu);
     a.seed_lo = (uint32_t)b->prm.seed; a.seed_hi = (uint32_t)(b->prm.seed >> 32);
     a.entries = b->d_entries; a.slab = b->slab; a.cap_ovf = (uint32_t)b->cap_ovf;
     a.ovf0 = (uint64_t)b->n_win * b->slab; a.win_nent = b->d_win_nent;
@@ -885,7 +888,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags)
     b->n_ovf = cur[CUR_ENTRIES];
     b->sizes.n_snv = cur[CUR_SNV];
     b->sizes.n_sites = cur[CUR_SITES];
-    b->n_rare = cur[CUR_RARE]; b->n_sat = cur[CUR_SAT];
+    b->n_rare = cur[CUR_RARE]; b->n_sat = cur[CUR_SAT]; b->n_clon = cur[CUR_CLON];
     b->tim = isx_timings{};
     b->tim_pending = true;                  // the kernel's own time stamps are read when somebody asks (isx_batch_timings)
     b->tim.pileup_blocks = b->grid;
@@ -901,7 +904,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags)
         in.philox = Philox{(uint32_t)b->prm.seed, (uint32_t)(b->prm.seed >> 32)};
         in.n_pairs = b->n_pairs; in.ao = b->d_ao; in.n_ao = cur[CUR_AO];
         in.sites = b->d_sites; in.n_sites = cur[CUR_SITES];
-        in.slev = b->d_slev; in.counts = b->d_counts;
+        in.slev = b->d_slev; in.snv = b->d_snv;
         in.split_bounds = b->d_bounds; in.n_splits = b->n_splits; in.M = b->M; in.min_snp = b->prm.min_snp;
         LinkageOut lo;
         int rc = run_linkage(in, b->L, lo);
@@ -1043,6 +1046,7 @@ int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts, float *clon, float *cl
 {
     NEED_RUN(b, counts);
     if (b->M != 1) { isx_set_error("n_mm_bins > 1: use isx_batch_fetch_entries"); return ISX_ERR_STATE; }
+    if (!b->d_counts) { isx_set_error("this pipe slot keeps no per-base count table (create the pipe with want_counts)"); return ISX_ERR_STATE; }
     HIP_TRY(hipMemcpy(counts, b->d_counts, (size_t)b->n_pos * sizeof(uint4), hipMemcpyDeviceToHost));
     if (clon) HIP_TRY(hipMemcpy(clon, b->d_clon, (size_t)b->n_pos * sizeof(float), hipMemcpyDeviceToHost));
     if (clon_rarefied) HIP_TRY(hipMemcpy(clon_rarefied, b->d_clon_r, (size_t)b->n_pos * sizeof(float), hipMemcpyDeviceToHost));
@@ -1063,6 +1067,7 @@ int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffo
     in.stream = b->ctx->stream; in.ev = b->ev_sum;
     in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
     in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
+    in.cov16 = b->d_cov16; in.sat = b->d_sat; in.n_sat = (uint32_t)std::min<size_t>(b->n_sat, b->cap_sat);
     in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
     in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
     return run_summary(in, b->S, out, device_ms);
@@ -1088,6 +1093,7 @@ int isx_batch_summarize_genomes(isx_batch *b, int32_t n_scaffolds, const int64_t
     in.stream = b->ctx->stream; in.ev = b->ev_sum;
     in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
     in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
+    in.cov16 = b->d_cov16; in.sat = b->d_sat; in.n_sat = (uint32_t)std::min<size_t>(b->n_sat, b->cap_sat);
     in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
     in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
     return run_genome_summary(in, b->S, n_genomes, genome_first_scaffold, mask_edges, out, device_ms);
@@ -1098,6 +1104,7 @@ static void fill_summary_in(isx_batch *b, int32_t n_scaffolds, const int64_t *sc
     in.stream = b->ctx->stream; in.ev = b->ev_sum;
     in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
     in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
+    in.cov16 = b->d_cov16; in.sat = b->d_sat; in.n_sat = (uint32_t)std::min<size_t>(b->n_sat, b->cap_sat);
     in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
     in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
 }

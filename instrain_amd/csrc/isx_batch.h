@@ -64,6 +64,13 @@ struct isx_batch {
     uint2 *d_rare = nullptr;         // pipe slots (dense path): sparse clonTR list
     size_t cap_rare = 0;
     uint32_t n_rare = 0, n_sat = 0;  // of the last pass: list entries (may exceed cap_rare: list unusable), saturated positions
+    // pipe slots (dense path), the hand-back of a shallow batch: 1-byte coverage, exact (gpos, coverage) of the positions beyond
+    // 255 / 65535, clonality as a sparse (gpos, value) list -- sorted by position on the device before it leaves
+    uint8_t *d_cov8 = nullptr;
+    uint2 *d_sat = nullptr, *d_clon_list = nullptr, *d_clon_sorted = nullptr;
+    size_t cap_sat = 0, cap_clon = 0;
+    uint32_t n_clon = 0;
+    bool sparse_out = false, cov8_out = false;   // this pass: write the sparse clonality list / the 1-byte coverage
     isx_entry *d_entries = nullptr;  // mm path: [n_win][slab] slabs, then cap_ovf overflow entries
     uint32_t *d_win_nent = nullptr;
     isx_slev *d_slev = nullptr;

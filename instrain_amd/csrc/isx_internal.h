@@ -55,13 +55,14 @@ void isx_dev_trim();
 // cursors (dev_cursors[i], uint32)
 enum { CUR_ENTRIES = 0 /* mm path: overflow entries */, CUR_SNV = 1, CUR_SITES = 2, CUR_AO = 3, CUR_SLEV = 4,
        CUR_ENT_TOTAL = 5, CUR_RARE = 6 /* dense path: entries of the sparse clonTR list */,
-       CUR_SAT = 7 /* dense path: positions whose coverage saturates the 16-bit hand-back */, CUR_N = 8 };
+       CUR_SAT = 7 /* dense path: positions whose coverage reaches sat_thr (entries of the exact-coverage list) */,
+       CUR_CLON = 8 /* dense path: entries of the sparse clonality list */, CUR_N = 9 };
 
 // SNP site record: a position where update_snp_table returned anySNP (snv_utilities.py:129-133).
 // Holds what linkage needs later: the `bases` set and where the per-level counts live.
 struct isx_site {
     uint32_t gpos;
-    uint32_t entry_off;     // mm path: index of the site's first isx_slev row; dense path: unused
+    uint32_t entry_off;     // mm path: index of the site's first isx_slev row; dense path: index of the site's SNV row (its counts)
     uint16_t n_levels;      // mm path: number of levels present
     uint8_t mask;           // `bases` set, bit b = base b
     uint8_t pad;
@@ -163,10 +164,15 @@ struct PileupArgs {
     int32_t pad, lm;            // dense path: counter row stride = W + pad words, position 0 of the window at column lm
     double min_freq;
     // outputs
-    uint4 *counts;              // dense path (M == 1): [n_pos]
+    uint4 *counts;              // dense path (M == 1): [n_pos]; NULL = not kept (a pipe slot without want_counts: 16 B/pos less to write)
     float *clon;                // dense path: [n_pos]
     float *clon_r;              // rarefied clonality: dense [n_pos] / mm path [cap_entries]; pre-filled with NaN
     uint16_t *cov16;            // dense path, pipe slots: min(coverage, 65535) per position (NULL = not wanted)
+    uint8_t *cov8;              // ... and min(coverage, 255) for the 1-byte hand-back of a shallow batch (NULL = not wanted)
+    uint2 *sat;                 // ... exact (gpos, coverage) of the positions whose coverage reaches sat_thr (255 with cov8, else 65535)
+    uint32_t cap_sat, sat_thr;
+    uint2 *clon_list;           // dense path, pipe slots, shallow batches: (gpos, float bits of clonT) of the positions that have one, unordered
+    uint32_t cap_clon;
     uint2 *rare;                // dense path, pipe slots: (gpos, float bits of clonTR) of the positions that have one, unordered
     uint32_t cap_rare;
     int32_t min_cov_r;          // rarefied_coverage; <= 0 disables the rarefied output

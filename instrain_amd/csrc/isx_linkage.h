@@ -46,7 +46,7 @@ struct LinkageIn {
     const isx_site *sites;      // unsorted, from k_pileup_call
     uint32_t n_sites;
     const isx_slev *slev;       // mm path: per-level counts of the SNP sites
-    const uint4 *counts;        // dense path
+    const isx_snv *snv;         // dense path: the SNV rows (isx_site::entry_off indexes them)
     const int64_t *split_bounds;
     int n_splits;
     int M;

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) k_pair_incr(const isx_ao *ao, uint32_t n,
 struct SiteView {
     const isx_site *sites;
     const isx_slev *slev;       // mm path: per-level counts of the sites
-    const uint4 *counts;        // dense path
+    const isx_snv *snv;         // dense path: a site's entry_off is the index of its SNV row, whose counts are the site's
     int dense;
 };
 
@@ -126,8 +126,8 @@ __device__ __forceinline__ void site_cum(const SiteView &v, uint32_t s, uint32_t
 {
     const isx_site st = v.sites[s];
     if (v.dense) {
-        const uint4 c = v.counts[st.gpos];
-        out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+        const isx_snv r = v.snv[st.entry_off];
+        out[0] = r.cnt[0]; out[1] = r.cnt[1]; out[2] = r.cnt[2]; out[3] = r.cnt[3];
         has_mm = (mm == 0);
         return;
     }
@@ -714,7 +714,7 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     const int sb = bits_for(n_sites);
     if ((rc = ensure(B.rows_per, n_u)) || (rc = ensure(B.row_off, (size_t)n_u + 1))) return rc;
     HIP_TRY(hipMemsetAsync(B.n_runs.p + 1, 0, 4, s));
-    SiteView v{B.sites_sorted.p, in.slev, in.counts, in.M == 1 ? 1 : 0};
+    SiteView v{B.sites_sorted.p, in.slev, in.snv, in.M == 1 ? 1 : 0};
     hipLaunchKernelGGL(k_ld_rows<false>, dim3((n_u + 255) / 256), dim3(256), 0, s, B.ukeys.p, B.ucnt.p, n_u, v,
                        in.min_snp, B.rows_per.p, nullptr, nullptr, B.n_runs.p + 1, in.philox, sb);
     uint64_t n_ld = 0;

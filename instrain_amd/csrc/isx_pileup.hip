@@ -47,7 +47,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define THR_LDS 1024        // coverages below this read their folded threshold from LDS
 
 // scratch words (LDS)
-enum { S_NQ = 0, S_ROWS, S_SITES, S_ROW_BASE, S_SITE_BASE, S_ROW_RANK, S_NAO, S_AO_BASE, S_ENT_TOT, S_ENT_BASE, S_SLEV, S_SLEV_BASE, S_NRARE, S_RARE_BASE, S_RARE_RANK, S_N = 16 };
+enum { S_NQ = 0, S_ROWS, S_SITES, S_ROW_BASE, S_SITE_BASE, S_ROW_RANK, S_NAO, S_AO_BASE, S_ENT_TOT, S_ENT_BASE, S_SLEV, S_SLEV_BASE, S_NRARE, S_RARE_BASE, S_RARE_RANK,
+       S_NCLON, S_CLON_BASE, S_CLON_RANK, S_N = 20 };
 
 // table cursors run on across launches; a run's slots are relative to the values it started from
 __device__ __forceinline__ uint32_t cur_add(const PileupArgs &a, int which, uint32_t n)
@@ -646,10 +647,14 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             if (gpos >= a.n_pos) break;
             const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
             const uint32_t total = c[0] + c[1] + c[2] + c[3];
-            a.counts[gpos] = make_uint4(c[0], c[1], c[2], c[3]);
-            if (a.cov16) {                      // shrunk hand-back of a pipe slot: coverage alone, 2 bytes per position
-                a.cov16[gpos] = (uint16_t)min(total, 65535u);
-                if (total >= 65535u) cur_add(a, CUR_SAT, 1u);
+            if (a.counts) a.counts[gpos] = make_uint4(c[0], c[1], c[2], c[3]);
+            if (a.cov16) {                      // shrunk hand-back of a pipe slot: coverage alone, 2 (or 1) bytes per position,
+                a.cov16[gpos] = (uint16_t)min(total, 65535u);       // exact values of the few positions beyond that in a list
+                if (a.cov8) a.cov8[gpos] = (uint8_t)min(total, 255u);
+                if (total >= a.sat_thr) {
+                    const uint32_t k = cur_add(a, CUR_SAT, 1u);
+                    if (k < a.cap_sat) a.sat[k] = make_uint2(gpos, total);
+                }
             }
             float cl = __builtin_nanf("");
             bool defer = false;
@@ -660,12 +665,13 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 const uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
                 if (mx == total) cl = 1.0f; else defer = true;
                 if (defer) entry |= 1u << 13;
+                if (a.clon_list) { atomicAdd(&scratch[S_NCLON], 1u); if (!defer) entry |= 1u << 16; }    // sparse clonality list: written below, once the window has its slots
                 if (sc.snp != -1) {
                     entry |= 1u << 14;
                     atomicAdd(&scratch[S_ROWS], 1u);
                     if (sc.morphia >= 2) {
                         const uint32_t mask = (1u << sc.snp) | (1u << sc.var);
-                        entry |= (atomicAdd(&scratch[S_SITES], 1u) + 1u) << 16;
+                        entry |= (atomicAdd(&scratch[S_SITES], 1u) + 1u) << 17;
                         if (linkage) {
                             maskl[p] = (uint8_t)mask;
                             slabc[p] = atomicAdd(&scratch[S_NAO], masked_sum(c, mask));
@@ -685,13 +691,25 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         if (tid == 128 && nao) scratch[S_AO_BASE] = cur_add(a, CUR_AO, nao);
         const uint32_t nrare = a.rare ? scratch[S_NRARE] : 0u;
         if (tid == 192 && nrare) scratch[S_RARE_BASE] = cur_add(a, CUR_RARE, nrare);
-        // ---- deferred clonalities (snv_utilities.py:225-231), densely packed ----
-        for (uint32_t q = tid; q < nq; q += nthr) {
-            const uint32_t e = queue[q];
-            if (!(e & (1u << 13))) continue;
-            const int p = (int)(e & 0x1FFFu);
-            const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
-            a.clon[w0 + p] = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+        const uint32_t nclon = a.clon_list ? scratch[S_NCLON] : 0u;
+        if (tid == 256 % nthr && nclon) scratch[S_CLON_BASE] = cur_add(a, CUR_CLON, nclon);
+        if (nclon) __syncthreads();             // uniform: the list entries below need the window's base
+        // ---- deferred clonalities (snv_utilities.py:225-231), densely packed; the sparse clonality list ----
+        {
+            const uint32_t clon_base = scratch[S_CLON_BASE];
+            const bool list = nclon && clon_base + nclon <= a.cap_clon;      // else the host reads the dense array
+            for (uint32_t q = tid; q < nq; q += nthr) {
+                const uint32_t e = queue[q];
+                if (!(e & ((1u << 13) | (1u << 16)))) continue;
+                const int p = (int)(e & 0x1FFFu);
+                float v = 1.0f;
+                if (e & (1u << 13)) {
+                    const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
+                    v = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+                    a.clon[w0 + p] = v;
+                }
+                if (list) a.clon_list[clon_base + atomicAdd(&scratch[S_CLON_RANK], 1u)] = make_uint2(w0 + p, __float_as_uint(v));
+            }
         }
         if (nrows | nrare) __syncthreads();     // uniform: scratch bases from the atomics above
         if (a.min_cov_r > 0) {                  // rarefied clonality (snv_utilities.py:233-247), own loop: fewer live registers
@@ -734,10 +752,10 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             r.ref_base = (uint8_t)ref_base;
             r.cnt[0] = c[0]; r.cnt[1] = c[1]; r.cnt[2] = c[2]; r.cnt[3] = c[3];
             a.snv[row_base + my_row] = r;
-            const uint32_t ss = e >> 16;
+            const uint32_t ss = e >> 17;
             if (ss) {
                 isx_site st;
-                st.gpos = gpos; st.entry_off = 0; st.n_levels = 1;
+                st.gpos = gpos; st.entry_off = row_base + my_row; st.n_levels = 1;      // linkage reads the site's counts from its SNV row
                 st.mask = (uint8_t)((1u << sc.snp) | (1u << sc.var)); st.pad = 0;
                 a.sites[site_base + ss - 1] = st;
             }

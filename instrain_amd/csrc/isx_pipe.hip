@@ -79,6 +79,11 @@ struct Slot {
     bool out_pinned = true;                 // false: the dense arrays go to plain memory through the pipe's bounce buffers (see slot_batch_create)
     size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0, o_cov16 = 0, o_rare = 0;
     bool rare_dense = false;                // the clonTR table of the last batch went back as the dense array
+    bool cov8 = false, clon_sparse = false; // how the last (shallow) batch's coverage / clonality went back
+    std::vector<isx_sat> sat_rows;          // exact coverage of its saturated positions
+    bool sat_complete = true;
+    void *sort_temp = nullptr;              // device scratch of the clonality list's sort
+    size_t sort_temp_bytes = 0;
     std::vector<float> clonr_big;           // that array when the pipe has no pinned room for it (no want_counts)
     std::vector<isx_rare> rare_big;         // more clonTR entries than the pinned block holds / the device list overflowed
     std::vector<uint32_t> cmin, cmax;
@@ -211,6 +216,7 @@ static void pipe_free(isx_pipe *p)
             isx_batch_destroy(b);
         }
         t_batch += now_ms() - t_x; t_x = now_ms();
+        if (s.sort_temp) isx_dev_free(s.sort_temp);
         if (s.d_gpos16) isx_dev_free(s.d_gpos16);
         if (s.d_in) isx_dev_free(s.d_in);
         if (s.d_runs) isx_dev_free(s.d_runs);
@@ -266,7 +272,17 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     const uint64_t npm = (uint64_t)cap_pos * b->M;
     const uint64_t cap_obs = (uint64_t)std::max<int64_t>(p->pp.max_obs, 1);
     if (dense) {
-        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_counts), (size_t)cap_pos * sizeof(uint4)));
+        // the per-base count table is only kept when the caller wants it back (--store_everything): otherwise 16 B/pos less to write
+        if (p->pp.want_counts) HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_counts), (size_t)cap_pos * sizeof(uint4)));
+        else {
+            // shallow batches go back as 1-byte coverage + sparse clonality list (see submit: sparse_out)
+            b->cap_clon = (size_t)cap_pos / 2 + 65536;
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_cov8), (size_t)cap_pos));
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon_list), b->cap_clon * sizeof(uint2)));
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon_sorted), b->cap_clon * sizeof(uint2)));
+        }
+        b->cap_sat = (size_t)cap_pos / 16 + 65536;
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_sat), b->cap_sat * sizeof(uint2)));
         HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon), (size_t)cap_pos * sizeof(float)));
         HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon_r), (size_t)cap_pos * sizeof(float)));
         HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_cov16), (size_t)cap_pos * sizeof(uint16_t)));
@@ -366,10 +382,13 @@ static int finish_slot(isx_pipe *p, Slot &s)
         uint32_t cf = 0;
         int rc = finish_pass(b, &cf);           // sizes from the published cursors; linkage stages when enabled
         if (rc != ISX_OK) return rc;
-        if (!cf) break;
+        // a batch taken for shallow that has more positions beyond 255 than the exact-coverage list holds: again with 16 bits
+        const bool cov8_overflow = !cf && dense && b->sparse_out && b->cov8_out && (size_t)b->n_sat > b->cap_sat;
+        if (!cf && !cov8_overflow) break;
         if (attempt == 7) { isx_set_error("output tables still too small after 8 growth steps"); return ISX_ERR_CAPACITY; }
         // a table was too small for this batch: grow it and repeat the pass (the slot still holds its input)
-        if ((rc = batch_grow_tables(b, cf)) != ISX_OK) return rc;
+        if (cov8_overflow) b->cov8_out = false;
+        else if ((rc = batch_grow_tables(b, cf)) != ISX_OK) return rc;
         if (!dense) b->cap_ovf = b->cap_entries - (size_t)b->n_win * b->slab;
         std::lock_guard<std::mutex> lk(p->launch_mu);
         if (dense && p->prm.rarefied_coverage > 0)
@@ -378,23 +397,47 @@ static int finish_slot(isx_pipe *p, Slot &s)
         redo = true;
     }
     t_fin = now_ms();
-    if (dense && !s.out_pinned) {               // a plain result block: the arrays come through the bounce buffers, now
-        int rc;
+    // device -> the slot's result block: through the bounce buffers into a plain block, a blocking copy into a pinned one
+    auto fetch = [&](void *hdst, const void *dsrc, size_t bytes) -> int {
+        if (!bytes) return ISX_OK;
+        if (!s.out_pinned) return bounce_d2h(p, hdst, dsrc, bytes);
+        HIP_TRY(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, p->s_d2h));
+        return ISX_OK;
+    };
+    if (dense) {
+        int rc = ISX_OK;
         if (redo) HIP_TRY(hipStreamSynchronize(ps));
-        if ((rc = bounce_d2h(p, s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2)) != ISX_OK) return rc;
-        if ((rc = bounce_d2h(p, s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4)) != ISX_OK) return rc;
-        if (p->pp.want_counts) {
-            if ((rc = bounce_d2h(p, s.h_out + s.o_counts, b->d_counts, (size_t)b->n_pos * 16)) != ISX_OK) return rc;
-            if (p->prm.rarefied_coverage > 0 && (rc = bounce_d2h(p, s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4)) != ISX_OK) return rc;
+        s.cov8 = false; s.clon_sparse = false; s.sat_complete = (size_t)b->n_sat <= b->cap_sat;
+        if (b->sparse_out) {
+            // a shallow batch: 1-byte coverage (exact values of the few positions at 255 or beyond in the list below) and the
+            // clonality of the positions that have one as a (position, value) list, sorted by position on the device
+            s.cov8 = b->cov8_out;
+            if (s.cov8) rc = fetch(s.h_out + s.o_cov16, b->d_cov8, (size_t)b->n_pos);
+            else rc = fetch(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2);
+            if (rc != ISX_OK) return rc;
+            s.d2h_bytes += (int64_t)b->n_pos * (s.cov8 ? 1 : 2);
+            const size_t n_clon = b->n_clon;
+            if (n_clon <= b->cap_clon && n_clon * 2 <= (size_t)b->n_pos) {
+                if ((rc = sort_pairs_by_position(p->s_d2h, b->d_clon_list, b->d_clon_sorted, n_clon, &s.sort_temp, &s.sort_temp_bytes)) != ISX_OK) return rc;
+                if ((rc = fetch(s.h_out + s.o_clon, b->d_clon_sorted, n_clon * sizeof(isx_rare))) != ISX_OK) return rc;
+                s.clon_sparse = true;
+                s.d2h_bytes += (int64_t)(n_clon * sizeof(isx_rare));
+            } else {
+                if ((rc = fetch(s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4)) != ISX_OK) return rc;
+                s.d2h_bytes += (int64_t)b->n_pos * 4;
+            }
+        } else if (!s.out_pinned || redo) {     // a plain result block, or tables that predate the repeated pass
+            if ((rc = fetch(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2)) != ISX_OK) return rc;
+            if ((rc = fetch(s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4)) != ISX_OK) return rc;
+            if (p->pp.want_counts) {
+                if ((rc = fetch(s.h_out + s.o_counts, b->d_counts, (size_t)b->n_pos * 16)) != ISX_OK) return rc;
+                if (p->prm.rarefied_coverage > 0 && (rc = fetch(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4)) != ISX_OK) return rc;
+            }
         }
-    } else if (redo && dense) {                 // the copied-out tables predate the repeated pass
-        HIP_TRY(hipMemcpy(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(s.h_out + s.o_clon, b->d_clon, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
-        if (p->pp.want_counts) {
-            HIP_TRY(hipMemcpy(s.h_out + s.o_counts, b->d_counts, (size_t)b->n_pos * 16, hipMemcpyDeviceToHost));
-            if (p->prm.rarefied_coverage > 0)
-                HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
-        }
+        // exact coverage of the saturated positions (a handful; none at all for most batches)
+        s.sat_rows.resize(s.sat_complete ? (size_t)b->n_sat : 0);
+        if (!s.sat_rows.empty()) HIP_TRY(hipMemcpyAsync(s.sat_rows.data(), b->d_sat, s.sat_rows.size() * sizeof(isx_sat), hipMemcpyDeviceToHost, p->s_d2h));
+        HIP_TRY(hipStreamSynchronize(p->s_d2h));
     }
     if (dense && p->prm.rarefied_coverage > 0) {        // the sparse clonTR table, ascending positions
         const size_t n_rare = b->n_rare;
@@ -604,9 +647,9 @@ static int enqueue_pass(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticket)
             HIP_TRY(hipMemcpyAsync(s.h_small + s.o_rare, b->d_rare, n * sizeof(isx_rare), hipMemcpyDeviceToHost, p->s_d2h));
             s.d2h_bytes += (int64_t)(n * sizeof(isx_rare));
         }
-        s.d2h_bytes += (int64_t)n_pos * 6;
+        if (!b->sparse_out) s.d2h_bytes += (int64_t)n_pos * 6;
     }
-    if (dense && s.out_pinned) {           // (a plain result block is filled by the finisher, bounce_d2h)
+    if (dense && s.out_pinned && !b->sparse_out) {     // (a plain result block / a shallow batch's tables are brought in by the finisher)
         HIP_TRY(hipMemcpyAsync(s.h_out + s.o_cov16, b->d_cov16, (size_t)n_pos * 2, hipMemcpyDeviceToHost, p->s_d2h));
         HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clon, b->d_clon, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
         if (p->pp.want_counts) {
@@ -725,6 +768,9 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
 
     // ---- this batch's geometry ----
     b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits; b->n_rec = (uint64_t)J.n_rec;
+    // a shallow batch (mean depth below min_cov: most positions have no clonality) hands its tables back sparse, see finish_slot
+    b->sparse_out = dense && b->d_clon_list != nullptr && p->prm.min_cov > 0 && (double)b->n_obs < 0.9 * (double)p->prm.min_cov * (double)n_pos;
+    b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
     b->packed = 0;
@@ -866,6 +912,9 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
 
     // ---- this batch's geometry ----
     b->n_pos = n_pos; b->n_obs = J.n_bases; b->n_splits = n_splits; b->n_rec = (uint64_t)J.n_rec;
+    // a shallow batch (mean depth below min_cov: most positions have no clonality) hands its tables back sparse, see finish_slot
+    b->sparse_out = dense && b->d_clon_list != nullptr && p->prm.min_cov > 0 && (double)b->n_obs < 0.9 * (double)p->prm.min_cov * (double)n_pos;
+    b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / ISX_SEG_GROUP;
     b->packed = 0;
@@ -1015,9 +1064,12 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
     out->sizes = b->sizes;
     out->snv = (size_t)b->sizes.n_snv > p->snv_prefix ? s.snv_big.data() : reinterpret_cast<const isx_snv *>(s.h_small + s.o_snv);
     if (dense) {
-        out->coverage16 = reinterpret_cast<const uint16_t *>(s.h_out + s.o_cov16);
-        out->clon = reinterpret_cast<const float *>(s.h_out + s.o_clon);
+        if (s.cov8) out->coverage8 = s.h_out + s.o_cov16;
+        else out->coverage16 = reinterpret_cast<const uint16_t *>(s.h_out + s.o_cov16);
+        if (s.clon_sparse) { out->clon_sparse = reinterpret_cast<const isx_rare *>(s.h_out + s.o_clon); out->n_clon = (int64_t)b->n_clon; }
+        else out->clon = reinterpret_cast<const float *>(s.h_out + s.o_clon);
         out->n_saturated = b->n_sat;
+        out->saturated = s.sat_complete ? s.sat_rows.data() : nullptr;
         if (p->prm.rarefied_coverage > 0) {
             out->n_rare = (int64_t)b->n_rare;
             if (!s.rare_dense) out->rare = s.rare_big.empty() ? reinterpret_cast<const isx_rare *>(s.h_small + s.o_rare) : s.rare_big.data();

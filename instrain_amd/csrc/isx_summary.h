@@ -29,7 +29,10 @@ struct SummaryIn {
     int n_scaffolds, M;
     const int64_t *scaffold_bounds; // host, [n_scaffolds + 1]
     // dense path
-    const uint4 *counts;
+    const uint4 *counts;            // NULL: a pipe slot without a count table -> cov16 + the exact values of saturated positions
+    const uint16_t *cov16;
+    const uint2 *sat;
+    uint32_t n_sat;
     const float *clon, *clon_r;
     // mm path
     const isx_entry *entries;
@@ -37,6 +40,9 @@ struct SummaryIn {
     uint32_t slab, n_win, n_ovf;
     uint64_t ovf0;
 };
+
+// (position, value) pairs ordered by position: a 32-bit radix sort of the 8-byte entries on their low word; *temp grows on demand
+int sort_pairs_by_position(hipStream_t s, const uint2 *in, uint2 *out, size_t n, void **temp, size_t *temp_bytes);
 
 int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host_out, float *ms);
 int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, const int32_t *genome_first, int mask_edges,

@@ -40,16 +40,29 @@ __device__ __forceinline__ int find_seg(const int64_t *bounds, int n_seg, uint32
     return lo;
 }
 
-// dense path (one level): counts / clonalities are already per position
-__global__ void k_level_dense(const uint4 *counts, const float *clon, const float *clon_r, uint32_t n_pos,
+// dense path (one level): counts / clonalities are already per position.  A pipe slot that keeps no count table has the
+// coverage itself (16 bits, saturating) and the exact values of the few saturated positions in a list.
+__global__ void k_level_dense(const uint4 *counts, const uint16_t *cov16, const float *clon, const float *clon_r, uint32_t n_pos,
                               uint32_t *cov, float *cv, float *cr)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pos) return;
-    const uint4 c = counts[i];
-    cov[i] = c.x + c.y + c.z + c.w;
+    if (counts) { const uint4 c = counts[i]; cov[i] = c.x + c.y + c.z + c.w; }
+    else cov[i] = cov16[i];
     cv[i] = clon[i];
     cr[i] = clon_r[i];
+}
+
+__global__ void k_patch_saturated(const uint2 *sat, uint32_t n_sat, uint32_t *cov)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_sat && sat[i].y >= 65535u) cov[sat[i].x] = sat[i].y;
+}
+
+static void launch_level_dense(const SummaryIn &in, dim3 grid, dim3 blk, hipStream_t s, uint32_t n_pos, uint32_t *cov, float *cv, float *cr)
+{
+    hipLaunchKernelGGL(k_level_dense, grid, blk, 0, s, in.counts, in.cov16, in.clon, in.clon_r, n_pos, cov, cv, cr);
+    if (!in.counts && in.n_sat) hipLaunchKernelGGL(k_patch_saturated, dim3((in.n_sat + 255) / 256), blk, 0, s, in.sat, in.n_sat, cov);
 }
 
 // mm path: add level `mm` of the entry table (window slabs + overflow) onto the running arrays.
@@ -464,6 +477,25 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
     return done(rc);
 }
 
+int sort_pairs_by_position(hipStream_t s, const uint2 *in, uint2 *out, size_t n, void **temp, size_t *temp_bytes)
+{
+    if (!n) return ISX_OK;
+    static_assert(sizeof(uint2) == sizeof(uint64_t), "an entry is one 64-bit key, position in its low word");
+    const uint64_t *ki = reinterpret_cast<const uint64_t *>(in);
+    uint64_t *ko = reinterpret_cast<uint64_t *>(out);
+    size_t tb = 0;
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, ki, ko, n, 0, 32, s));
+    if (tb > *temp_bytes || !*temp) {
+        if (*temp) isx_dev_free(*temp);
+        *temp = nullptr; *temp_bytes = 0;
+        HIP_TRY(isx_dev_malloc(temp, tb + 256));
+        *temp_bytes = tb + 256;
+    }
+    size_t t = *temp_bytes;
+    HIP_TRY(rocprim::radix_sort_keys(*temp, t, ki, ko, n, 0, 32, s));
+    return ISX_OK;
+}
+
 // the position-sized arrays are kept between calls; a batch with more positions than any before it gets new ones
 void SummaryBuffers::fit_positions(size_t n_pos)
 {
@@ -568,7 +600,7 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
     for (int mm = 0; mm < M; mm++) {
         hipLaunchKernelGGL(k_reset_acc, gseg, blk, 0, s, acc, n_seg);
         if (M == 1) {
-            hipLaunchKernelGGL(k_level_dense, gpos, blk, 0, s, in.counts, in.clon, in.clon_r, n_pos, B.cov, B.cv, B.cr);
+            launch_level_dense(in, gpos, blk, s, n_pos, B.cov, B.cv, B.cr);
         } else {
             hipLaunchKernelGGL(k_level_apply, dim3(2048), blk, 0, s, in.entries, in.win_nent, in.slab, in.n_win, in.ovf0,
                                in.n_ovf, (uint32_t)mm, B.cov, B.cv, B.cr, B.bounds, n_seg, acc);
@@ -659,7 +691,7 @@ int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, co
         GS_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(B.cr), 0x7FC00000, n_pos, s));
     }
     for (int mm = 0; mm < M; mm++) {
-        if (M == 1) hipLaunchKernelGGL(k_level_dense, gpos, blk, 0, s, in.counts, in.clon, in.clon_r, n_pos, B.cov, B.cv, B.cr);
+        if (M == 1) launch_level_dense(in, gpos, blk, s, n_pos, B.cov, B.cv, B.cr);
         else hipLaunchKernelGGL(k_level_apply, dim3(2048), blk, 0, s, in.entries, in.win_nent, in.slab, in.n_win, in.ovf0, in.n_ovf,
                                 (uint32_t)mm, B.cov, B.cv, B.cr, d_sb, n_scaf, d_sacc);
         GS_TRY(hipMemsetAsync(d_acc, 0, (size_t)n_genomes * sizeof(GAcc), s));
@@ -763,7 +795,7 @@ int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, const 
         hipLaunchKernelGGL(k_reset_acc, gseg, blk, 0, s, acc, n_seg);
         if (mm >= in.M) return;                 // no such level in this sample: coverage carries over
         if (in.M == 1) {
-            hipLaunchKernelGGL(k_level_dense, gpos, blk, 0, s, in.counts, in.clon, in.clon_r, n_pos, cov, f0, f1);
+            launch_level_dense(in, gpos, blk, s, n_pos, cov, f0, f1);
             hipLaunchKernelGGL(k_present_dense, gpos, blk, 0, s, cov, n_pos, B.bounds, n_seg, acc);
         } else {
             hipLaunchKernelGGL(k_level_apply, dim3(2048), blk, 0, s, in.entries, in.win_nent, in.slab, in.n_win, in.ovf0, in.n_ovf,

@@ -297,8 +297,10 @@ class Pipe:
         check(rc)
         return t.value
 
-    def collect(self, ticket, want_ld=True, rare_list=True):
-        """-> dict like Batch.fetch() (+ 'sizes', 'stats'); the dense arrays / snv rows are views of pinned memory."""
+    def collect(self, ticket, want_ld=True, rare_list=True, densify=True):
+        """-> dict like Batch.fetch() (+ 'sizes', 'stats'); the dense arrays / snv rows are views of pinned memory.
+        A shallow batch (one mm bin, mean depth below min_cov) comes back as 'cov8' + 'clon_sparse' (+ 'saturated'); densify
+        rebuilds the 'cov16' / 'clon' arrays every other batch has from them (False: the caller reads the sparse forms)."""
         r = _lib.PipeResult()
         check(self.lib.isx_pipe_collect(self.h, int(ticket), C.byref(r)))
         sz = {n: getattr(r.sizes, n) for n, _ in Sizes._fields_}
@@ -315,8 +317,25 @@ class Pipe:
         slot = _SlotBatch(self.ctx, r.batch, n_pos, r.n_obs, self.n_mm_bins)
         if self.n_mm_bins == 1:
             # the shrunk tables (what shrink_basewise keeps): coverage, clonality, sparse rarefied clonality
-            out["cov16"] = view(r.coverage16, np.uint16, n_pos)
-            out["clon"] = view(r.clon, np.float32, n_pos)
+            # (a shallow batch comes back smaller still: 1-byte coverage, clonality as a sorted (position, value) list)
+            if r.coverage16:
+                out["cov16"] = view(r.coverage16, np.uint16, n_pos)
+            else:
+                out["cov8"] = view(r.coverage8, np.uint8, n_pos)
+            if r.clon:
+                out["clon"] = view(r.clon, np.float32, n_pos)
+            else:
+                out["clon_sparse"] = view(r.clon_sparse, _lib.CLON_DT, int(r.n_clon))
+            if r.n_saturated and r.saturated:
+                out["saturated"] = view(r.saturated, _lib.SAT_DT, int(r.n_saturated)).copy()
+            if densify and "cov8" in out:
+                out["cov16"] = out.pop("cov8").astype(np.uint16)
+                if "saturated" in out:
+                    out["cov16"][out["saturated"]["gpos"]] = np.minimum(out["saturated"]["coverage"], 65535)
+            if densify and "clon_sparse" in out:
+                cs = out.pop("clon_sparse")
+                out["clon"] = np.full(n_pos, np.nan, np.float32)
+                out["clon"][cs["gpos"]] = cs["clon"]
             if r.clon_rarefied:                     # want_counts, or a deep sample (the list would not be sparse)
                 out["clon_r"] = view(r.clon_rarefied, np.float32, n_pos)
             if r.rare:

@@ -84,11 +84,22 @@ class _BatchTables:
             self.e_cut = _cuts(self.entries["gpos"], self.bounds)
         else:                                       # one mm bin: coverage per position, clonality, sparse clonTR
             self.entries = None
-            if "cov16" in res and not res.get("n_saturated"):
-                self.cov = _own(res["cov16"])
-            else:
+            if "counts" in res:
                 self.cov = res["counts"].sum(axis=1, dtype=np.int64)
-            self.clon = _own(res["clon"])
+            else:                                   # the shrunk hand-back: 16- or 8-bit coverage + the exact values beyond
+                self.cov = _own(res["cov16"] if "cov16" in res else res["cov8"])
+                if res.get("n_saturated"):
+                    if "saturated" not in res:
+                        raise ValueError("coverage beyond the hand-back's range at too many positions: profile with store_everything")
+                    self.cov = self.cov.astype(np.int64)
+                    self.cov[res["saturated"]["gpos"]] = res["saturated"]["coverage"]
+            if "clon_sparse" in res:                # a shallow batch: clonality as a sorted (position, value) list
+                self.clon = None
+                self.clon_pos = res["clon_sparse"]["gpos"].astype(np.int64)
+                self.clon_val = np.array(res["clon_sparse"]["clon"])
+                self.c_cut = np.searchsorted(self.clon_pos, self.bounds)
+            else:
+                self.clon = _own(res["clon"])
             self.clon_r = None
             if "rare" in res:
                 self.rare_pos = res["rare"]["gpos"].astype(np.int64)
@@ -131,9 +142,13 @@ class _BatchTables:
         if len(k) == 0:
             return {}, {}, {}                       # no read reached the split: no mm level was ever created
         covT = {0: pd.Series(cov[k].astype("int32"), index=k + (s - off))}
-        cl = self.clon[s:e]
-        k = np.flatnonzero(~np.isnan(cl))
-        clonT = {0: pd.Series(cl[k].astype("float32"), index=k + (s - off))}
+        if self.clon is None:
+            c0, c1 = self.c_cut[i], self.c_cut[i + 1]
+            clonT = {0: pd.Series(self.clon_val[c0:c1].astype("float32"), index=self.clon_pos[c0:c1] - off)}
+        else:
+            cl = self.clon[s:e]
+            k = np.flatnonzero(~np.isnan(cl))
+            clonT = {0: pd.Series(cl[k].astype("float32"), index=k + (s - off))}
         if self.clon_r is not None:
             cr = self.clon_r[s:e]
             k = np.flatnonzero(~np.isnan(cr))
@@ -701,10 +716,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             """tables of a submitted group -> SplitObjects"""
             t = g.ticket
             try:
-                res = pipe.collect(t, rare_list=False)
-                if res.get("n_saturated"):           # coverage beyond the 16-bit hand-back: take the exact counts
-                    full = res["slot"].fetch()
-                    res["counts"] = full["counts"]
+                res = pipe.collect(t, rare_list=False, densify=False)
                 splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam)
                 if kwargs.get('scaffold_tables') is not None:
                     sb = np.r_[0, np.cumsum([refs[tid][1] for tid in g.tids])]

@@ -373,3 +373,85 @@ def test_summaries_on_a_reused_slot_with_growing_batches(ctx):
             assert float(lv[j, 0]["median_cov"]) == float(np.median(cov[a:e]))
         pipe.release(t)
     pipe.close()
+
+
+@pytest.mark.parametrize("reads", [False, True])
+@pytest.mark.parametrize("linkage", [False, True])
+def test_shallow_batch_comes_back_sparse(ctx, reads, linkage):
+    """mean depth below min_cov: the slot keeps no count table and hands back 1-byte coverage + the clonality of the few
+    positions that have one as a sorted list (+ exact coverage of positions at 255 or beyond); densified, every table
+    equals the resident batch's"""
+    from instrain_amd import engine, synth
+    w = synth.make_workload(genome_len=600_000, coverage=3, n_sites=900, seed=41)
+    o = w["obs"].copy()
+    # a pile of 400 reads over one spot: coverage far beyond 255 inside a shallow batch
+    extra = np.zeros(400 * 50, dtype=o.dtype)
+    extra["gpos"] = np.tile(np.arange(300_000, 300_050, dtype=np.uint32), 400)
+    extra["base"] = np.repeat(np.arange(400) % 4, 50)
+    obs = np.concatenate([o, extra])
+    pair = np.concatenate([w["pair"], np.repeat(np.arange(400, dtype=np.uint32) + w["n_pairs"], 50)])
+    kw = dict(n_mm_bins=1, enable_linkage=linkage, min_snp=5, min_cov=5, rarefied_coverage=4)
+    a = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], obs, pair if linkage else None, **kw)
+    a.run()
+    exp, sizes = a.fetch(), a.sizes()
+    a.close()
+    segs = synth.segs_from_obs(obs, pair)
+    pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=len(obs) if not reads else 0, max_segs=segs.n_seg if reads else 0,
+                       max_splits=len(w["split_bounds"]), depth=2, host_threads=2, pin_threads=False, **kw)
+    for rep in range(2):
+        t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs) if reads else pipe.submit(w["ref_codes"], w["split_bounds"], obs, pair if linkage else None)
+        raw = pipe.collect(t, densify=False)
+        assert "cov8" in raw and "clon_sparse" in raw and "cov16" not in raw and "clon" not in raw
+        cov = exp["counts"].sum(axis=1, dtype=np.int64)
+        assert (raw["cov8"] == np.minimum(cov, 255)).all()
+        sat = raw["saturated"]
+        k = np.flatnonzero(cov >= 255)
+        assert raw["n_saturated"] == len(k) == 50 and (np.sort(sat["gpos"]) == k).all()
+        assert (sat["coverage"][np.argsort(sat["gpos"])] == cov[k]).all()
+        cs = raw["clon_sparse"]
+        has = np.flatnonzero(~np.isnan(exp["clon"]))
+        assert (cs["gpos"] == has).all() and cs["clon"].tobytes() == exp["clon"][has].tobytes()
+        assert len(has) * 2 < w["n_pos"]
+        assert raw["sizes"] == sizes
+        assert raw["snv"].tobytes() == exp["snv"].tobytes()
+        if linkage:
+            assert raw["ld"].tobytes() == exp["ld"].tobytes()
+        # the rarefied clonality list and the device summaries work without the count table
+        r = exp["clon_r"]
+        hr = np.flatnonzero(~np.isnan(r))
+        assert (raw["rare"]["gpos"] == hr).all()
+        lv, _ = raw["slot"].summarize([0, w["n_pos"]])
+        assert int(lv[0, 0]["sum_cov"]) == int(cov.sum()) and int(lv[0, 0]["nonzero"]) == int((cov > 0).sum())
+        assert int(lv[0, 0]["counted"]) == len(has)
+        with pytest.raises(engine.IsxError, match="count table"):
+            raw["slot"].fetch()
+        pipe.release(t)
+        # the default collect() rebuilds the arrays every other batch has
+        t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs) if reads else pipe.submit(w["ref_codes"], w["split_bounds"], obs, pair if linkage else None)
+        d = pipe.collect(t)
+        assert (d["cov16"] == np.minimum(cov, 65535)).all() and d["clon"].tobytes() == exp["clon"].tobytes()
+        pipe.release(t)
+    pipe.close()
+
+
+def test_deep_batch_after_shallow_on_one_slot(ctx):
+    """the hand-back follows the batch: shallow, deep, shallow through the same slot"""
+    from instrain_amd import engine, synth
+    ws = [synth.make_workload(genome_len=200_000, coverage=c, n_sites=200, seed=51 + i) for i, c in enumerate((2, 30, 3))]
+    pipe = engine.Pipe(ctx, max_pos=200_000, max_obs=max(w["n_obs"] for w in ws), max_splits=64, depth=1, host_threads=2, pin_threads=False,
+                       n_mm_bins=1, enable_linkage=False)
+    for w, shallow in zip(ws, (True, False, True)):
+        a = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], None, n_mm_bins=1, enable_linkage=False)
+        a.run()
+        exp = a.fetch()
+        a.close()
+        t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], None)
+        raw = pipe.collect(t, densify=False)
+        assert ("clon_sparse" in raw) == shallow and ("cov8" in raw) == shallow
+        pipe.release(t)
+        t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], None)
+        d = pipe.collect(t)
+        assert (d["cov16"] == exp["counts"].sum(axis=1)).all() and d["clon"].tobytes() == exp["clon"].tobytes()
+        assert d["snv"].tobytes() == exp["snv"].tobytes()
+        pipe.release(t)
+    pipe.close()
