@@ -613,7 +613,7 @@ def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False):
 
     def take():
         nonlocal done, last
-        r = pipe.collect(tickets[done], want_ld=link)
+        r = pipe.collect(tickets[done], want_ld=link, densify=False)      # the tables as they come (views of the slot)
         if stats is not None:
             stats.append((r["stats"], r["sizes"]))
         if keep_last and done == n_steps - 1:

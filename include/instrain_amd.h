@@ -365,10 +365,13 @@ typedef struct {
     int64_t h2d_bytes, d2h_bytes;
     const isx_ld *ld;           /* [sizes.n_ld] the LD rows when linkage is enabled (else NULL), reference order;
                                  * valid until isx_pipe_release */
-    /* n_mm_bins == 1, a SHALLOW batch (mean depth below min_cov; the pipe decides per batch, never with want_counts): the
-     * position-sized tables shrink further.  coverage16 == NULL -> coverage8; clon == NULL -> clon_sparse. */
+    /* n_mm_bins == 1 without want_counts: the position-sized tables shrink further.
+     * coverage16 == NULL -> coverage8 (a shallow batch: mean depth below 16).
+     * clon == NULL -> clon_sparse: clonT[p] is exactly 1.0 at every position whose coverage reaches min_cov, EXCEPT the listed
+     * positions (more than one base observed there); below min_cov there is none (NaN).  clon (the dense array) comes instead
+     * when more than half of the positions would be listed. */
     const uint8_t *coverage8;   /* [n_pos] min(covT, 255); exact values of the positions at 255 or beyond: `saturated` */
-    const isx_rare *clon_sparse;/* [n_clon] (gpos, clonT) of the positions that have a clonality, ascending gpos */
+    const isx_rare *clon_sparse;/* [n_clon] (gpos, clonT != 1.0), ascending gpos */
     int64_t n_clon;
     const isx_sat *saturated;   /* [n_saturated] (gpos, exact coverage) of the positions whose coverage16 / coverage8 entry
                                  * saturated, unordered; NULL when the list outgrew the pipe's room (isx_batch_fetch_dense then) */

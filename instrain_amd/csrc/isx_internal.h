@@ -171,7 +171,8 @@ struct PileupArgs {
     uint8_t *cov8;              // ... and min(coverage, 255) for the 1-byte hand-back of a shallow batch (NULL = not wanted)
     uint2 *sat;                 // ... exact (gpos, coverage) of the positions whose coverage reaches sat_thr (255 with cov8, else 65535)
     uint32_t cap_sat, sat_thr;
-    uint2 *clon_list;           // dense path, pipe slots, shallow batches: (gpos, float bits of clonT) of the positions that have one, unordered
+    uint2 *clon_list;           // dense path, pipe slots: (gpos, float bits of clonT) of the positions whose clonality is NOT 1.0 (more than
+                                // one base observed), unordered: every other position that reaches min_cov has exactly 1.0
     uint32_t cap_clon;
     uint2 *rare;                // dense path, pipe slots: (gpos, float bits of clonTR) of the positions that have one, unordered
     uint32_t cap_rare;

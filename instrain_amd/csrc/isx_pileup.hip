@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 const uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
                 if (mx == total) cl = 1.0f; else defer = true;
                 if (defer) entry |= 1u << 13;
-                if (a.clon_list) { atomicAdd(&scratch[S_NCLON], 1u); if (!defer) entry |= 1u << 16; }    // sparse clonality list: written below, once the window has its slots
+                if (a.clon_list && defer) atomicAdd(&scratch[S_NCLON], 1u);     // the list of clonalities other than 1.0: written below, once the window has its slots
                 if (sc.snp != -1) {
                     entry |= 1u << 14;
                     atomicAdd(&scratch[S_ROWS], 1u);
@@ -700,14 +700,11 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             const bool list = nclon && clon_base + nclon <= a.cap_clon;      // else the host reads the dense array
             for (uint32_t q = tid; q < nq; q += nthr) {
                 const uint32_t e = queue[q];
-                if (!(e & ((1u << 13) | (1u << 16)))) continue;
+                if (!(e & (1u << 13))) continue;
                 const int p = (int)(e & 0x1FFFu);
-                float v = 1.0f;
-                if (e & (1u << 13)) {
-                    const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
-                    v = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
-                    a.clon[w0 + p] = v;
-                }
+                const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
+                const float v = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+                a.clon[w0 + p] = v;
                 if (list) a.clon_list[clon_base + atomicAdd(&scratch[S_CLON_RANK], 1u)] = make_uint2(w0 + p, __float_as_uint(v));
             }
         }

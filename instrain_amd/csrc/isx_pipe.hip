@@ -138,6 +138,7 @@ struct isx_pipe {
     std::unique_ptr<isxenc::HostPool> pool;
     std::vector<Slot> slots;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipStream_t s_fin = nullptr;            // the finisher's own queue: what it fetches must not wait behind the copy-outs of later batches
     int64_t next_ticket = 0;
     int64_t cap_rec = 0;
     int64_t ring_half = 0;                  // records per half of a slot's staging ring; 0 = the pinned arena holds the whole stream
@@ -168,7 +169,7 @@ static int bounce_d2h(isx_pipe *p, void *hdst, const void *dsrc, size_t bytes)
     if (!bytes) return ISX_OK;
     const size_t piece = p->bounce_bytes;
     const size_t n_pieces = (bytes + piece - 1) / piece;
-    hipStream_t st = p->s_d2h;
+    hipStream_t st = p->s_fin;
     auto issue = [&](size_t k) -> hipError_t {
         const size_t off = k * piece, len = std::min(piece, bytes - off);
         hipError_t e = hipMemcpyAsync(p->bounce[k & 1], static_cast<const uint8_t *>(dsrc) + off, len, hipMemcpyDeviceToHost, st);
@@ -201,6 +202,7 @@ static void pipe_free(isx_pipe *p)
     (void)hipSetDevice(p->ctx->device);
     if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
     if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
+    if (p->s_fin) (void)hipStreamSynchronize(p->s_fin);
     for (int i = 0; i < 2; i++) if (p->ctx->pstream[i]) (void)hipStreamSynchronize(p->ctx->pstream[i]);
     const double t_f0 = now_ms();
     double t_batch = 0, t_dev = 0, t_pin = 0;
@@ -237,6 +239,7 @@ static void pipe_free(isx_pipe *p)
     }
     if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
     if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
+    if (p->s_fin) (void)hipStreamDestroy(p->s_fin);
     delete p;
 }
 
@@ -401,7 +404,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
     auto fetch = [&](void *hdst, const void *dsrc, size_t bytes) -> int {
         if (!bytes) return ISX_OK;
         if (!s.out_pinned) return bounce_d2h(p, hdst, dsrc, bytes);
-        HIP_TRY(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, p->s_d2h));
+        HIP_TRY(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, p->s_fin));
         return ISX_OK;
     };
     if (dense) {
@@ -409,8 +412,9 @@ static int finish_slot(isx_pipe *p, Slot &s)
         if (redo) HIP_TRY(hipStreamSynchronize(ps));
         s.cov8 = false; s.clon_sparse = false; s.sat_complete = (size_t)b->n_sat <= b->cap_sat;
         if (b->sparse_out) {
-            // a shallow batch: 1-byte coverage (exact values of the few positions at 255 or beyond in the list below) and the
-            // clonality of the positions that have one as a (position, value) list, sorted by position on the device
+            // coverage in 2 bytes, or 1 for a shallow batch (exact values of the few positions at 255 / 65535 or beyond in the
+            // list below); clonality: a position that reaches min_cov has exactly 1.0 unless more than one base was observed there
+            // -- only those exceptions travel, as a (position, value) list sorted by position on the device
             s.cov8 = b->cov8_out;
             if (s.cov8) rc = fetch(s.h_out + s.o_cov16, b->d_cov8, (size_t)b->n_pos);
             else rc = fetch(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2);
@@ -418,7 +422,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
             s.d2h_bytes += (int64_t)b->n_pos * (s.cov8 ? 1 : 2);
             const size_t n_clon = b->n_clon;
             if (n_clon <= b->cap_clon && n_clon * 2 <= (size_t)b->n_pos) {
-                if ((rc = sort_pairs_by_position(p->s_d2h, b->d_clon_list, b->d_clon_sorted, n_clon, &s.sort_temp, &s.sort_temp_bytes)) != ISX_OK) return rc;
+                if ((rc = sort_pairs_by_position(p->s_fin, b->d_clon_list, b->d_clon_sorted, n_clon, &s.sort_temp, &s.sort_temp_bytes)) != ISX_OK) return rc;
                 if ((rc = fetch(s.h_out + s.o_clon, b->d_clon_sorted, n_clon * sizeof(isx_rare))) != ISX_OK) return rc;
                 s.clon_sparse = true;
                 s.d2h_bytes += (int64_t)(n_clon * sizeof(isx_rare));
@@ -436,8 +440,8 @@ static int finish_slot(isx_pipe *p, Slot &s)
         }
         // exact coverage of the saturated positions (a handful; none at all for most batches)
         s.sat_rows.resize(s.sat_complete ? (size_t)b->n_sat : 0);
-        if (!s.sat_rows.empty()) HIP_TRY(hipMemcpyAsync(s.sat_rows.data(), b->d_sat, s.sat_rows.size() * sizeof(isx_sat), hipMemcpyDeviceToHost, p->s_d2h));
-        HIP_TRY(hipStreamSynchronize(p->s_d2h));
+        if (!s.sat_rows.empty()) HIP_TRY(hipMemcpyAsync(s.sat_rows.data(), b->d_sat, s.sat_rows.size() * sizeof(isx_sat), hipMemcpyDeviceToHost, p->s_fin));
+        HIP_TRY(hipStreamSynchronize(p->s_fin));
     }
     if (dense && p->prm.rarefied_coverage > 0) {        // the sparse clonTR table, ascending positions
         const size_t n_rare = b->n_rare;
@@ -583,6 +587,7 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     int rc = ISX_OK;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&p->s_fin, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking)) != hipSuccess) {
         isx_set_error(std::string("isx_pipe_create: ") + hipGetErrorString(e));
         pipe_free(p);
@@ -768,8 +773,9 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
 
     // ---- this batch's geometry ----
     b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits; b->n_rec = (uint64_t)J.n_rec;
-    // a shallow batch (mean depth below min_cov: most positions have no clonality) hands its tables back sparse, see finish_slot
-    b->sparse_out = dense && b->d_clon_list != nullptr && p->prm.min_cov > 0 && (double)b->n_obs < 0.9 * (double)p->prm.min_cov * (double)n_pos;
+    // without a count table to hand back, the position-sized tables travel shrunk (see finish_slot): clonality as the list of
+    // values other than 1.0, coverage in one byte for a shallow batch
+    b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
@@ -912,8 +918,9 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
 
     // ---- this batch's geometry ----
     b->n_pos = n_pos; b->n_obs = J.n_bases; b->n_splits = n_splits; b->n_rec = (uint64_t)J.n_rec;
-    // a shallow batch (mean depth below min_cov: most positions have no clonality) hands its tables back sparse, see finish_slot
-    b->sparse_out = dense && b->d_clon_list != nullptr && p->prm.min_cov > 0 && (double)b->n_obs < 0.9 * (double)p->prm.min_cov * (double)n_pos;
+    // without a count table to hand back, the position-sized tables travel shrunk (see finish_slot): clonality as the list of
+    // values other than 1.0, coverage in one byte for a shallow batch
+    b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / ISX_SEG_GROUP;

@@ -245,6 +245,7 @@ class Pipe:
                  linkage_mode=0, window=0, seed=0, layout=0, want_counts=False, ring_kib=0, max_segs=0):
         self.ctx, self.lib = ctx, ctx.lib
         self.n_mm_bins = int(n_mm_bins)
+        self.min_cov = int(min_cov)
         self.want_counts = bool(want_counts)
         self.enable_linkage = bool(enable_linkage)
         p = Params(int(min_cov), int(min_snp), float(min_freq), int(rarefied_coverage), int(n_mm_bins),
@@ -299,8 +300,10 @@ class Pipe:
 
     def collect(self, ticket, want_ld=True, rare_list=True, densify=True):
         """-> dict like Batch.fetch() (+ 'sizes', 'stats'); the dense arrays / snv rows are views of pinned memory.
-        A shallow batch (one mm bin, mean depth below min_cov) comes back as 'cov8' + 'clon_sparse' (+ 'saturated'); densify
-        rebuilds the 'cov16' / 'clon' arrays every other batch has from them (False: the caller reads the sparse forms)."""
+        One mm bin without want_counts: the tables come back shrunk -- 'cov16' or (a shallow batch) 'cov8', 'saturated' =
+        exact coverage of the positions beyond that range, and 'clon_sparse' = the clonalities other than 1.0 (every other
+        position with coverage >= min_cov has exactly 1.0); densify rebuilds the 'cov16' / 'clon' arrays from them
+        (False: the caller reads the shrunk forms, see dense_clon)."""
         r = _lib.PipeResult()
         check(self.lib.isx_pipe_collect(self.h, int(ticket), C.byref(r)))
         sz = {n: getattr(r.sizes, n) for n, _ in Sizes._fields_}
@@ -333,9 +336,7 @@ class Pipe:
                 if "saturated" in out:
                     out["cov16"][out["saturated"]["gpos"]] = np.minimum(out["saturated"]["coverage"], 65535)
             if densify and "clon_sparse" in out:
-                cs = out.pop("clon_sparse")
-                out["clon"] = np.full(n_pos, np.nan, np.float32)
-                out["clon"][cs["gpos"]] = cs["clon"]
+                out["clon"] = dense_clon(out["cov16"] if "cov16" in out else out["cov8"], out.pop("clon_sparse"), self.min_cov)
             if r.clon_rarefied:                     # want_counts, or a deep sample (the list would not be sparse)
                 out["clon_r"] = view(r.clon_rarefied, np.float32, n_pos)
             if r.rare:
@@ -403,6 +404,14 @@ def encode_obs(obs, pair=None, n_pos=None, record_bytes=2, threads=1, slack=0.0,
                                   C.byref(n_rec), C.byref(passes)))
     n = n_rec.value
     return rec[:n], gbase[:n // G], (pout[:n] if pout is not None else None), passes.value
+
+
+def dense_clon(cov, clon_sparse, min_cov):
+    """clonT of a one-mm-bin batch from its shrunk hand-back: 1.0 where the coverage reaches min_cov, the listed values at the
+    listed positions, NaN elsewhere (a saturated 8- / 16-bit coverage entry is >= any sensible min_cov)"""
+    out = np.where(np.asarray(cov) >= min_cov, np.float32(1.0), np.float32(np.nan)).astype(np.float32)
+    out[clon_sparse["gpos"]] = clon_sparse["clon"]
+    return out
 
 
 def encode_segs(segs, n_pos, n_mm_bins=1, threads=1, cap_rec=None, ring_records=0):

@@ -72,7 +72,8 @@ class _BatchTables:
     calculate_ld outputs of every split of the batch).  Built once per batch from numpy arrays; the pandas
     objects of a split are only made when somebody reads them."""
 
-    def __init__(self, res, split_bounds, split_scaffold, scaffold_offset):
+    def __init__(self, res, split_bounds, split_scaffold, scaffold_offset, min_cov=5):
+        self.min_cov = int(min_cov)
         self.bounds = np.asarray(split_bounds, dtype=np.int64)
         self.scaffold = split_scaffold
         self.offset = np.asarray(scaffold_offset, dtype=np.int64)
@@ -93,7 +94,7 @@ class _BatchTables:
                         raise ValueError("coverage beyond the hand-back's range at too many positions: profile with store_everything")
                     self.cov = self.cov.astype(np.int64)
                     self.cov[res["saturated"]["gpos"]] = res["saturated"]["coverage"]
-            if "clon_sparse" in res:                # a shallow batch: clonality as a sorted (position, value) list
+            if "clon_sparse" in res:                # clonality shrunk: 1.0 wherever the coverage reaches min_cov, except the listed positions
                 self.clon = None
                 self.clon_pos = res["clon_sparse"]["gpos"].astype(np.int64)
                 self.clon_val = np.array(res["clon_sparse"]["clon"])
@@ -143,8 +144,12 @@ class _BatchTables:
             return {}, {}, {}                       # no read reached the split: no mm level was ever created
         covT = {0: pd.Series(cov[k].astype("int32"), index=k + (s - off))}
         if self.clon is None:
+            kc = np.flatnonzero(cov >= self.min_cov)
+            vals = np.ones(len(kc), dtype="float32")
             c0, c1 = self.c_cut[i], self.c_cut[i + 1]
-            clonT = {0: pd.Series(self.clon_val[c0:c1].astype("float32"), index=self.clon_pos[c0:c1] - off)}
+            if c1 > c0:
+                vals[np.searchsorted(kc, self.clon_pos[c0:c1] - s)] = self.clon_val[c0:c1]
+            clonT = {0: pd.Series(vals, index=kc + (s - off))}
         else:
             cl = self.clon[s:e]
             k = np.flatnonzero(~np.isnan(cl))
@@ -453,9 +458,9 @@ def make_coverage_table(levels, lengt, scaff, SNPTable):
 
 
 def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_offset, split_seq_len, min_freq,
-                     bam_name=None):
+                     bam_name=None, min_cov=5):
     """Batch result (engine.Batch.fetch() / Pipe.collect()) -> list of SplitObject, one per split, in split order."""
-    tables = _BatchTables(res, split_bounds, split_scaffold, scaffold_offset)
+    tables = _BatchTables(res, split_bounds, split_scaffold, scaffold_offset, min_cov)
     out = []
     for i in range(len(split_bounds) - 1):
         S = SplitObject()
@@ -717,7 +722,8 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             t = g.ticket
             try:
                 res = pipe.collect(t, rare_list=False, densify=False)
-                splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam)
+                splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam,
+                                          min_cov=int(kwargs.get('min_cov', 5)))
                 if kwargs.get('scaffold_tables') is not None:
                     sb = np.r_[0, np.cumsum([refs[tid][1] for tid in g.tids])]
                     levels, _ = res["slot"].summarize(sb)

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.isx_abi_version() == 2
+    assert lib.isx_abi_version() == 3
     assert isinstance(lib.isx_last_error(), bytes)
 
 

@@ -378,9 +378,8 @@ def test_summaries_on_a_reused_slot_with_growing_batches(ctx):
 @pytest.mark.parametrize("reads", [False, True])
 @pytest.mark.parametrize("linkage", [False, True])
 def test_shallow_batch_comes_back_sparse(ctx, reads, linkage):
-    """mean depth below min_cov: the slot keeps no count table and hands back 1-byte coverage + the clonality of the few
-    positions that have one as a sorted list (+ exact coverage of positions at 255 or beyond); densified, every table
-    equals the resident batch's"""
+    """a slot that keeps no count table hands back 1-byte coverage for a shallow batch (+ exact coverage of positions at 255
+    or beyond) and the clonalities other than 1.0 as a sorted list; densified, every table equals the resident batch's"""
     from instrain_amd import engine, synth
     w = synth.make_workload(genome_len=600_000, coverage=3, n_sites=900, seed=41)
     o = w["obs"].copy()
@@ -410,8 +409,10 @@ def test_shallow_batch_comes_back_sparse(ctx, reads, linkage):
         assert (sat["coverage"][np.argsort(sat["gpos"])] == cov[k]).all()
         cs = raw["clon_sparse"]
         has = np.flatnonzero(~np.isnan(exp["clon"]))
-        assert (cs["gpos"] == has).all() and cs["clon"].tobytes() == exp["clon"][has].tobytes()
-        assert len(has) * 2 < w["n_pos"]
+        other = np.flatnonzero(~np.isnan(exp["clon"]) & (exp["clon"] != 1.0))
+        assert (cs["gpos"] == other).all() and cs["clon"].tobytes() == exp["clon"][other].tobytes() and 0 < len(other) < len(has)
+        assert (np.flatnonzero(cov >= 5) == has).all()          # ... and every other position with coverage >= min_cov has 1.0
+        assert engine.dense_clon(raw["cov8"], cs, 5).tobytes() == exp["clon"].tobytes()
         assert raw["sizes"] == sizes
         assert raw["snv"].tobytes() == exp["snv"].tobytes()
         if linkage:
@@ -447,7 +448,7 @@ def test_deep_batch_after_shallow_on_one_slot(ctx):
         a.close()
         t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], None)
         raw = pipe.collect(t, densify=False)
-        assert ("clon_sparse" in raw) == shallow and ("cov8" in raw) == shallow
+        assert "clon_sparse" in raw and ("cov8" in raw) == shallow and ("cov16" in raw) != shallow
         pipe.release(t)
         t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], None)
         d = pipe.collect(t)
