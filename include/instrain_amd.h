@@ -399,31 +399,27 @@ int isx_pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out);
 /* ---- read-level hand-over: the per-base expansion of the pileup happens on the device ----
  * Instead of one 8-byte record per (pileup column, pileup read) visit the host ships READ SEGMENTS: a segment = up to
  * ISX_SEG_BASES consecutive reference positions covered by one M / = / X run of a read's CIGAR (a longer run is cut into
- * several segments; an insertion / deletion / skip ends a segment), with one 3-bit code per position
+ * several segments; an insertion / deletion / skip ends a segment), with one 3-bit code per position:
  *     0..3 = A, C, T, G observed with quality >= min_base_quality after htslib's overlap resolution
  *     4    = nothing to count here (low quality, masked by the mate's overlap, position outside the scaffold, padding)
  *     5    = a base that is not A/C/T/G but passes the quality filter (it makes its mm level "present" at the position,
  *            profile_utilities.py:279-285, without being counted); 6, 7 = reserved, treated as 4
- * as BIT PLANES, so that a wave of 64 lanes can walk a segment with lane l = base l: the 15 payload words hold
- *     words  0.. 5  chunk A, bases   0.. 63: three 64-bit planes (low word first); bit l of plane b = bit b of base l's code
- *     words  6..11  chunk B, bases  64..127: likewise
- *     words 12..14  chunk C, bases 128..159: three 32-bit planes
- * unused slots hold code 4 (plane 2 set, planes 0 and 1 clear).  64 bytes per 150-base read, ~0.43 bytes per base instead
- * of 8 (isx_obs) on the host and 2 / 4 on the device, and the host never walks single bases into records.  Replaces
- * exactly what isx_obs replaces: the visits of samfile.pileup(...) + get_base_counts_mm (profile_utilities.py:150-153, 268-286).
+ * packed ten per 32-bit word (base j of the segment: word j / 10, bits 3 (j % 10) .. + 2; the top two bits are 0; unused
+ * slots hold code 4).  ~0.43 bytes per base instead of 8 (isx_obs) on the host and 2 / 4 on the device, and the host never
+ * walks single bases into records.  Replaces exactly what isx_obs replaces: the visits of
+ * samfile.pileup(...) + get_base_counts_mm (profile_utilities.py:150-153, 268-286).
  * Segments arrive in BAM order (ascending read start; a read's segments follow each other), i.e. position-clustered. */
-#define ISX_SEG_BASES 160
+#define ISX_SEG_BASES 150
 #define ISX_SEG_WORDS 15
-/* payload of a segment without a single base (what padding records hold) */
-#define ISX_SEG_EMPTY_PAYLOAD {0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0xFFFFFFFFu}
+#define ISX_SEG_SKIP_WORD 0x24924924u   /* ten codes 4 */
 
 typedef struct {
     int64_t n_seg;
     const uint32_t *gpos;       /* [n_seg] flat position of the segment's first base */
-    const uint8_t *len;         /* [n_seg] 1 .. ISX_SEG_BASES (160) positions; gpos + len <= n_pos */
+    const uint8_t *len;         /* [n_seg] 1 .. ISX_SEG_BASES positions; gpos + len <= n_pos */
     const uint8_t *mm;          /* [n_seg] R2M[read name] (< n_mm_bins); NULL = 0 (--skip_mm_profiling) */
     const uint32_t *pair;       /* [n_seg] dense read-pair id (both mates share it); NULL unless linkage is enabled */
-    const uint32_t *bases;      /* [n_seg][ISX_SEG_WORDS] the codes' bit planes */
+    const uint32_t *bases;      /* [n_seg][ISX_SEG_WORDS] packed codes */
 } isx_segs;
 
 /* isx_batch_create / isx_pipe_submit with read segments instead of observations; results are identical to handing over
@@ -450,7 +446,7 @@ int isx_pack_reads(int64_t n_reads, const int64_t *ref_start, const int64_t *cli
 /* The read-level pipe's host-side staging on its own (no GPU needed): segments -> device record stream.
  *   device record = 16 words: delta:16 | len:8 | mm:8, then the 15 payload words; records come in groups of 16 (one
  *   wave-wide 16-byte load) with one 32-bit position base per group, start = gbase[record / 16] + delta; a group is
- *   closed early and padded with empty records (len 0, payload ISX_SEG_EMPTY_PAYLOAD) where the stream jumps >= 65536
+ *   closed early and padded with empty records (len 0, payload ISX_SEG_SKIP_WORD) where the stream jumps >= 65536
  *   positions; *n_rec is a multiple of 16.  rec holds cap_rec records, gbase cap_rec / 16 bases, pair_out (NULL with
  *   segs->pair == NULL) cap_rec ids. */
 int isx_encode_segs(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int64_t cap_rec, uint32_t *rec,

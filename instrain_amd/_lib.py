@@ -42,8 +42,7 @@ class PipeParams(C.Structure):
                 ("want_counts", C.c_int32), ("ring_kib", C.c_int32), ("pad0", C.c_int32), ("max_segs", C.c_int64)]
 
 
-SEG_BASES, SEG_WORDS = 160, 15
-SEG_EMPTY_PAYLOAD = (0, 0, 0, 0, 0xFFFFFFFF, 0xFFFFFFFF, 0, 0, 0, 0, 0xFFFFFFFF, 0xFFFFFFFF, 0, 0, 0xFFFFFFFF)
+SEG_BASES, SEG_WORDS, SEG_SKIP_WORD = 150, 15, 0x24924924
 
 
 class Segs(C.Structure):

@@ -49,7 +49,6 @@
 
 #include "../../include/instrain_amd.h"
 #include "obs_encode.h"
-#include "seg_encode.h"
 
 void isx_set_error(const std::string &msg);
 
@@ -66,7 +65,7 @@ const uint8_t CODE2IDX[16] = {4, 0, 1, 4, 3, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4};
 // makes its mm level present, profile_utilities.py:279-285)
 const uint8_t CODE2SEG[16] = {5, 0, 1, 5, 3, 5, 5, 5, 2, 5, 5, 5, 5, 5, 5, 5};
 
-// codes of `n` (<= 160) consecutive query bases starting at query offset q0 -> out[n] (code 4 where the quality is below minq)
+// codes of `n` (<= 150) consecutive query bases starting at query offset q0 -> out[n] (code 4 where the quality is below minq)
 inline void seg_codes_scalar(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint8_t *out)
 {
     for (int j = 0; j < n; j++) {
@@ -79,7 +78,7 @@ __attribute__((target("avx2")))
 inline void seg_codes_avx2(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint8_t *out)
 {
     // local, padded copies: the vector loads below may run up to 31 bytes past the bases asked for
-    alignas(32) uint8_t sq[112], ql[224], cd[224];
+    alignas(32) uint8_t sq[96], ql[192], cd[192];
     const int64_t e0 = q0 & ~(int64_t)1;                    // even base the copy starts at
     const int lead = (int)(q0 - e0), m = n + lead;
     memcpy(sq, seq + (e0 >> 1), (size_t)((m + 1) >> 1));
@@ -99,27 +98,28 @@ inline void seg_codes_avx2(const uint8_t *seq, const uint8_t *qual, int64_t q0, 
     memcpy(out, cd + lead, (size_t)n);
 }
 
-inline bool cpu_has_avx2()
+inline bool cpu_has_avx2_bmi2()
 {
-    static const bool v = __builtin_cpu_supports("avx2");
+    static const bool v = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
     return v;
 }
 
-// codes -> the segment's payload (bit planes, include/instrain_amd.h); slots from n on hold code 4
-__attribute__((target("avx2")))
-inline void seg_pack_avx2(uint8_t *cd /* [160], writable: padded with code 4 */, int n, uint32_t *w)
+// ten codes per word (base j: word j / 10, bits 3 (j % 10)); slots from n on hold code 4
+inline void seg_pack_scalar(const uint8_t *cd, int n, uint32_t *w)
 {
-    memset(cd + n, 4, (size_t)(ISX_SEG_BASES - n));
-    uint32_t m[5][3];
-    for (int k = 0; k < 5; k++) {
-        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(cd + 32 * k));
-        m[k][0] = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(v, 7));
-        m[k][1] = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(v, 6));
-        m[k][2] = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(v, 5));
+    for (int k = 0; k < ISX_SEG_WORDS; k++) w[k] = ISX_SEG_SKIP_WORD;
+    for (int j = 0; j < n; j++) w[j / 10] = (w[j / 10] & ~(7u << (3 * (j % 10)))) | ((uint32_t)cd[j] << (3 * (j % 10)));
+}
+
+__attribute__((target("bmi2")))
+inline void seg_pack_bmi2(uint8_t *cd /* [160], writable: padded with code 4 */, int n, uint32_t *w)
+{
+    memset(cd + n, 4, (size_t)(160 - n));
+    for (int k = 0; k < ISX_SEG_WORDS; k++) {
+        uint64_t x;
+        memcpy(&x, cd + 10 * k, 8);
+        w[k] = (uint32_t)_pext_u64(x, 0x0707070707070707ull) | ((uint32_t)cd[10 * k + 8] << 24) | ((uint32_t)cd[10 * k + 9] << 27);
     }
-    for (int c = 0; c < 2; c++)
-        for (int b = 0; b < 3; b++) { w[6 * c + 2 * b] = m[2 * c][b]; w[6 * c + 2 * b + 1] = m[2 * c + 1][b]; }
-    for (int b = 0; b < 3; b++) w[12 + b] = m[4][b];
 }
 
 struct Read {           // a read of the batch being expanded
@@ -1505,9 +1505,9 @@ struct BamBatch {
     {
         size_t ri = (size_t)(std::upper_bound(seg_at.begin(), seg_at.end(), (uint64_t)first) - seg_at.begin()) - 1;
         int64_t skip = first - (int64_t)seg_at[ri], done = 0;
-        const bool fast = cpu_has_avx2();
+        const bool fast = cpu_has_avx2_bmi2();
         const uint8_t mq = minq;
-        alignas(32) uint8_t cd[224];
+        alignas(32) uint8_t cd[192];
         for (; done < count; ri++) {
             if (seg_at[ri + 1] == seg_at[ri]) continue;
             const Read &r = S.reads[ri];
@@ -1516,8 +1516,8 @@ struct BamBatch {
             for_segments(ri, [&](int64_t g, int64_t q0, int64_t cols) {
                 if (skip > 0) { skip--; return; }
                 if (done >= count) return;
-                if (fast) { seg_codes_avx2(r.seq, r.qual, q0, (int)cols, mq, cd); seg_pack_avx2(cd, (int)cols, bases + (size_t)done * ISX_SEG_WORDS); }
-                else { seg_codes_scalar(r.seq, r.qual, q0, (int)cols, mq, cd); isxenc::seg_planes_from_codes(cd, (int)cols, bases + (size_t)done * ISX_SEG_WORDS); }
+                if (fast) { seg_codes_avx2(r.seq, r.qual, q0, (int)cols, mq, cd); seg_pack_bmi2(cd, (int)cols, bases + (size_t)done * ISX_SEG_WORDS); }
+                else { seg_codes_scalar(r.seq, r.qual, q0, (int)cols, mq, cd); seg_pack_scalar(cd, (int)cols, bases + (size_t)done * ISX_SEG_WORDS); }
                 gpos[done] = (uint32_t)g; len[done] = (uint8_t)cols; mm[done] = m;
                 if (pair) pair[done] = id;
                 done++;

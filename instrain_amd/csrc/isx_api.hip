@@ -693,7 +693,7 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
         if (erc != isxenc::SEG_OK) {
             isx_batch_destroy(b);
             if (erc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
-            isx_set_error(erc == isxenc::SEG_BAD_POS ? "a segment reaches beyond n_pos" : erc == isxenc::SEG_BAD_LEN ? "a segment's length is not in [1, 160]"
+            isx_set_error(erc == isxenc::SEG_BAD_POS ? "a segment reaches beyond n_pos" : erc == isxenc::SEG_BAD_LEN ? "a segment's length is not in [1, 150]"
                                                                                        : "internal: segment stream larger than estimated");
             return erc == isxenc::SEG_CAPACITY ? ISX_ERR_STATE : ISX_ERR_ARG;
         }
@@ -702,7 +702,7 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
         st.n_chunks = b->n_rec / ISX_SEG_GROUP;
         BH(hipMalloc(&b->d_seg, (size_t)b->n_rec * 64 + ISX_TAIL_BYTES));
         BH(hipMemcpyAsync(b->d_seg, h_rec.data(), (size_t)b->n_rec * 64, hipMemcpyHostToDevice, c->stream));
-        BH(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<uint8_t *>(b->d_seg) + (size_t)b->n_rec * 64), 0, ISX_TAIL_BYTES / 4, c->stream));
+        BH(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<uint8_t *>(b->d_seg) + (size_t)b->n_rec * 64), (int)ISX_SEG_SKIP_WORD, ISX_TAIL_BYTES / 4, c->stream));
         BH(hipMalloc(&b->d_gbase, (st.n_chunks + ISX_TAIL_GROUPS) * sizeof(uint32_t)));
         BH(hipMemsetAsync(b->d_gbase + st.n_chunks, 0, ISX_TAIL_GROUPS * sizeof(uint32_t), c->stream));
         BH(hipMemcpyAsync(b->d_gbase, h_gbase.data(), st.n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -803,7 +803,7 @@ int launch_pass(isx_batch *b)
 
     PileupArgs a{};
     a.seg = b->d_seg;
-    a.rec = b->d_rec; a.rec32 = b->d_rec32; a.rec16 = b->d_rec16; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref; a.ref_packed = b->ref_packed ? 1 : 0;
+    a.rec = b->d_rec; a.rec32 = b->d_rec32; a.rec16 = b->d_rec16; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref;
     a.pair = b->d_pair; a.pair_runs = b->d_pair_runs; a.run_index = b->d_run_index; a.n_runs = b->n_runs; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_rec32 ? b->d_gbase : b->d_cbase; a.gpos16_shift = b->gpos16_shift; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;

@@ -13,8 +13,8 @@
 #define ISX_DENSE_PAD 8             // k_pileup_dense: extra words per counter row (junk columns of the packed 16-bit decode)
 // read-segment stream (include/instrain_amd.h isx_segs; seg_encode.h): 64-byte records, 16 per position base
 #define ISX_SEG_GROUP 16
-#define ISX_SEG_PAD 128             // k_pileup_dense on segments: extra words per counter row = ISX_SEG_LM columns before position 0 of
-#define ISX_SEG_LM 64               // the window + 64 after its last one: a 64-base chunk that straddles a window edge needs no per-lane test
+#define ISX_SEG_PAD 32              // k_pileup_dense on segments: extra words per counter row = ISX_SEG_LM columns before position 0 of
+#define ISX_SEG_LM 16               // the window + 16 after its last one: a 10-base word that straddles a window edge needs no per-base test
 #define ISX_PK16_MAX_W 3264         // ... whose byte offsets (5 (W + 8) + 7) * 4 must stay below 65536
 #define ISX_PAD 2048                // the record stream is padded to a multiple of this (whole directory chunks, 16-byte loads)
 #define ISX_SENTINEL 0xFFFFFFFFu    // gpos of padding records (never inside a window)
@@ -138,12 +138,11 @@ struct PileupArgs {
     const uint32_t *gbase;      //     gbase[record / 256] + delta; padding records are ISX_PAD32; or ...
     const uint16_t *rec16;      // ... short stream (n_mm_bins == 1 only; rec, rec32 == NULL): delta:13 | base:3 per record,
                                 //     position = gbase[record / 512] + delta; padding records are 0xFFFF
-    const uint4 *seg;           // ... read-segment stream (rec, rec32, rec16 == NULL): 64-byte records, the first word of a record =
-                                //     delta:16 | len:8 | mm:8, start = gbase[record / 16] + delta, then 15 words of base-code bit planes
-                                //     (see isx_pileup.hip walk_segs); `pair` (linkage) is indexed by RECORD
+    const uint4 *seg;           // ... read-segment stream (rec, rec32, rec16 == NULL): 64-byte records as four 16-byte quarters, the
+                                //     first word of a record = delta:16 | len:8 | mm:8, start = gbase[record / 16] + delta, then 15 words of
+                                //     ten 3-bit base codes; `pair` (linkage) is indexed by RECORD
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK; of ISX_SEG_GROUP for the segment stream)
-    const uint8_t *ref;         // reference base code per flat position -- or, ref_packed (pipe slots: half the bytes over PCIe), two per
-    int32_t ref_packed;         // byte: position 2 i in the low nibble of byte i, 2 i + 1 in the high one
+    const uint8_t *ref;
     const uint32_t *pair;       // read-pair id per record (linkage only), or NULL and ...
     const uint2 *pair_runs;     // ... runs of equal pair ids: (first device record, pair id), ascending; run_index[c] = the run
     const uint32_t *run_index;  //     that holds device record 1024 c (pipe slots: ~0.06 B per record over PCIe instead of 4)

@@ -87,13 +87,6 @@ __device__ __forceinline__ void publish_previous(const PileupArgs &a, int tid)
     if (tid == 0) __hip_atomic_store(&a.pub_host_state[CUR_N + 4], a.pub_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// reference base code of a flat position (see PileupArgs::ref_packed)
-__device__ __forceinline__ uint8_t ref_at(const PileupArgs &a, uint32_t gpos)
-{
-    if (a.ref_packed) return (uint8_t)((a.ref[gpos >> 1] >> ((gpos & 1u) << 2)) & 0xFu);
-    return a.ref[gpos];
-}
-
 __device__ __forceinline__ int argmax4(const uint32_t *c)
 {
     int b = 0;
@@ -341,81 +334,32 @@ __device__ __forceinline__ void allele_pass(const PileupArgs &a, uint32_t lo, ui
     if (nst) allele_drain(a, st, nst, w0, maskl, slabc, ao_base, lane);
 }
 
-// ---- the read-segment stream (include/instrain_amd.h isx_segs; seg_encode.h) ----
-// A 64-byte record = header word (delta:16 | len:8 | mm:8) + 15 payload words holding up to 160 base codes as BIT PLANES:
-// chunk A (bases 0..63) = three 64-bit planes (bit l of plane b = bit b of base l's 3-bit code), chunk B (64..127) likewise,
-// chunk C (128..159) three 32-bit planes.  ONE WAVE walks one record: the record arrives through the scalar cache
-// (s_load into SGPRs, wave-uniform), lane l takes base l of a chunk -- its code comes out of the planes with three
-// v_cndmask on SGPR-pair masks -- and the wave's 64 lanes touch 64 CONSECUTIVE columns of the window's counters: no LDS
-// bank conflict by construction (lane-per-read walks hit ~3.5 lanes per bank), one LDS atomic + ~6 VALU per base.
-typedef __attribute__((address_space(4))) const uint32_t cu32;
-
-// lane l: bit l of `mask` ? b : a (v_cndmask_b32 with an SGPR pair as the condition)
-__device__ __forceinline__ uint32_t sel_bit(uint32_t a, uint32_t b, uint64_t mask)
+// quad broadcast: every lane of a quad of four gets lane 0's value (the record header sits in the first 16-byte quarter)
+__device__ __forceinline__ uint32_t quad_first(uint32_t x)
 {
-    uint32_t r;
-    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
-    return r;
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00 /* quad_perm [0,0,0,0] */, 0xF, 0xF, true);
 }
 
-// chunk(hdr, rel, p0, p1, p2, rec) is called wave-uniformly for every chunk of every record of [rec_lo, rec_hi) that can touch
-// the window [w0, w0 + W): rel = window-relative position of the chunk's lane 0 (-63 .. W - 1), p0..p2 its planes (lanes
-// beyond the chunk have p2 set = "nothing here").  The next record of the wave is fetched while the current one is walked.
-template <class F>
-__device__ __forceinline__ void walk_segs(const PileupArgs &a, uint32_t rec_lo, uint32_t rec_hi, uint32_t w0, int W, int tid, int nthr, F &&chunk)
-{
-    const uint32_t nw = (uint32_t)nthr >> 6;
-    cu32 *segc = reinterpret_cast<cu32 *>(reinterpret_cast<uintptr_t>(a.seg));
-    cu32 *gbc = reinterpret_cast<cu32 *>(reinterpret_cast<uintptr_t>(a.gbase));
-    uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rec_lo + ((uint32_t)tid >> 6)));
-    if (r >= rec_hi) return;
-    uint32_t cur[16], nxt[16], gb_cur, gb_nxt = 0;
-    {
-        cu32 *rp = segc + (size_t)r * 16;
-#pragma unroll
-        for (int k = 0; k < 16; k++) cur[k] = rp[k];
-        gb_cur = gbc[r >> 4];
-    }
-    for (;;) {
-        const uint32_t rn = r + nw;
-        const bool more = rn < rec_hi;
-        if (more) {
-            cu32 *rp = segc + (size_t)rn * 16;
-#pragma unroll
-            for (int k = 0; k < 16; k++) nxt[k] = rp[k];
-            gb_nxt = gbc[rn >> 4];
-        }
-        const uint32_t hdr = cur[0];
-        const int32_t len = (int32_t)((hdr >> 16) & 0xFFu);
-        const int32_t rel0 = (int32_t)(gb_cur + (hdr & 0xFFFFu) - w0);
-        if (len != 0 && rel0 < W && rel0 > -160) {
-            if (rel0 > -64)
-                chunk(hdr, rel0, (uint64_t)cur[1] | ((uint64_t)cur[2] << 32), (uint64_t)cur[3] | ((uint64_t)cur[4] << 32),
-                      (uint64_t)cur[5] | ((uint64_t)cur[6] << 32), r);
-            if (len > 64 && rel0 + 64 < W && rel0 + 64 > -64)
-                chunk(hdr, rel0 + 64, (uint64_t)cur[7] | ((uint64_t)cur[8] << 32), (uint64_t)cur[9] | ((uint64_t)cur[10] << 32),
-                      (uint64_t)cur[11] | ((uint64_t)cur[12] << 32), r);
-            if (len > 128 && rel0 + 128 < W)
-                chunk(hdr, rel0 + 128, (uint64_t)cur[13], (uint64_t)cur[14], (uint64_t)cur[15] | 0xFFFFFFFF00000000ull, r);
-        }
-        if (!more) break;
-#pragma unroll
-        for (int k = 0; k < 16; k++) cur[k] = nxt[k];
-        gb_cur = gb_nxt;
-        r = rn;
-    }
-}
+#define SEG_SKIPW 0x24924924u       // ten codes 4: nothing to count in this word
 
-// update_linked_reads on the read-segment stream: the window's records are walked a second time; a lane whose column is a
-// SNP site (maskl) and whose base belongs to the site's `bases` set is staged and drained exactly like allele_pass does.
-// An allele observation's arrival order (obs_idx) is its RECORD: two observations of one pair at one site come from its two
-// mates, whose records keep the BAM order.  rec_lo, rec_hi: the window's range in records.
-__device__ __forceinline__ void allele_pass_segs(const PileupArgs &a, uint32_t rec_lo, uint32_t rec_hi, uint32_t w0, int W,
+// update_linked_reads on the read-segment stream: the window's records are walked a second time, but a 10-base word is
+// only opened when the window's SNP-site bitmap has a bit under it (sites are ~1 % of the positions); a qualifying base
+// is staged and drained exactly like allele_pass does.  An allele observation's arrival order (obs_idx) is its RECORD:
+// two observations of one pair at one site come from its two mates, whose records keep the BAM order.
+// lo16, hi16: the window's range in 16-byte quarters (multiples of 64).
+__device__ __forceinline__ void allele_pass_segs(const PileupArgs &a, uint32_t lo16, uint32_t hi16, uint32_t w0, int W,
                                                  const uint8_t *maskl, uint32_t *slabc, uint32_t ao_base, uint32_t *stage,
                                                  int tid, int nthr)
 {
     const int lane = tid & 63;
     uint32_t *st = stage + (tid >> 6) * 128;
+    uint32_t *sitebits = stage + (nthr >> 6) * 128;         // [W / 32 + 2]
+    for (int p = tid; p < W; p += nthr) {                   // W and nthr are multiples of 64: whole waves
+        const uint64_t bal = __ballot(maskl[p] != 0);
+        if (lane == 0) { sitebits[p >> 5] = (uint32_t)bal; sitebits[(p >> 5) + 1] = (uint32_t)(bal >> 32); }
+    }
+    if (tid < 2) sitebits[(W >> 5) + tid] = 0;
+    __syncthreads();
     uint32_t nst = 0;
     auto drain = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -432,23 +376,47 @@ __device__ __forceinline__ void allele_pass_segs(const PileupArgs &a, uint32_t r
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    walk_segs(a, rec_lo, rec_hi, w0, W, tid, nthr, [&](uint32_t hdr, int32_t rel, uint64_t p0, uint64_t p1, uint64_t p2, uint32_t rec) {
-        const int32_t rl = rel + lane;
-        const uint32_t m = (uint32_t)rl < (uint32_t)W ? (uint32_t)maskl[rl] : 0u;
-        if (__ballot(m != 0) == 0) return;                                      // wave-uniform: no SNP site under this chunk
-        const uint32_t code = sel_bit(sel_bit(0u, 1u, p0), sel_bit(2u, 3u, p0), p1);
-        const bool cand = sel_bit(1u, 0u, p2) && ((m >> code) & 1u);
-        const uint64_t bal = __ballot(cand);
-        if (bal == 0) return;
-        const uint32_t n = (uint32_t)__popcll(bal);
-        if (nst + n > 64u) { drain(); nst = 0; }
-        if (cand) {
-            const uint32_t at = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            st[2 * at] = rec;
-            st[2 * at + 1] = (uint32_t)rl | (code << 16) | ((a.M > 1 ? hdr >> 24 : 0u) << 24);
+    const uint32_t q = (uint32_t)tid & 3u;
+    for (uint32_t i0 = lo16; i0 < hi16; i0 += (uint32_t)nthr) {
+        const uint32_t i = i0 + (uint32_t)tid;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane(i) >= hi16) break;         // wave-uniform
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.seg) + i);
+        const uint32_t gb = a.gbase[__builtin_amdgcn_readfirstlane(i >> 6)];
+        const uint32_t hdr = quad_first(v.x);
+        const uint32_t mm = a.M > 1 ? hdr >> 24 : 0u;
+        const int32_t r0 = (int32_t)(gb + (hdr & 0xFFFFu) - w0) + (int32_t)(q * 40u) - 10;
+        const uint32_t wd[4] = {q ? v.x : SEG_SKIPW, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int32_t r = r0 + 10 * k;
+            const uint32_t w = wd[k];
+            uint32_t bits = 0;
+            if (w != SEG_SKIPW && (uint32_t)(r + 9) < (uint32_t)(W + 9)) {
+                const int32_t base = r < 0 ? 0 : r;
+                const uint32_t wi = (uint32_t)base >> 5;
+                const uint64_t b64 = (uint64_t)sitebits[wi] | ((uint64_t)sitebits[wi + 1] << 32);
+                bits = ((uint32_t)(b64 >> (base & 31)) << (base - r)) & 0x3FFu;
+            }
+            while (__ballot(bits != 0)) {                                       // wave-uniform
+                const bool has = bits != 0;
+                const int j = has ? __ffs((int)bits) - 1 : 0;
+                bits &= bits - 1u;                                              // 0 stays 0
+                const uint32_t code = (w >> (3 * j)) & 7u;
+                const uint32_t rel = (uint32_t)(r + j);
+                const bool cand = has && code < 4u && ((maskl[has ? rel : 0u] >> code) & 1u);
+                const uint64_t bal = __ballot(cand);
+                if (bal == 0) continue;
+                const uint32_t n = (uint32_t)__popcll(bal);
+                if (nst + n > 64u) { drain(); nst = 0; }
+                if (cand) {
+                    const uint32_t at = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    st[2 * at] = i >> 2;
+                    st[2 * at + 1] = rel | (code << 16) | (mm << 24);
+                }
+                nst += n;
+            }
         }
-        nst += n;
-    });
+    }
     if (nst) drain();
 }
 
@@ -522,8 +490,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
-            if (SEGS) { lo = rng.x; hi = rng.y; return; }               // records; walk_segs fetches them through the scalar cache
-            lo = rng.x >> RSH; hi = rng.y >> RSH;
+            if (SEGS) { lo = rng.x << 2; hi = rng.y << 2; } else { lo = rng.x >> RSH; hi = rng.y >> RSH; }
             if (lo < hi) { issue_one(0, lo); issue_one(1, lo); }        // the first half-round; the stream loop issues the rest
         }
     };
@@ -549,7 +516,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const uint32_t gp = w0 + tid + it * nthr;
-            ref_raw[it] = (tid + it * nthr < W && gp < a.n_pos) ? ref_at(a, gp) : (uint8_t)4;
+            ref_raw[it] = (tid + it * nthr < W && gp < a.n_pos) ? a.ref[gp] : (uint8_t)4;
         }
         __syncthreads();
 
@@ -559,6 +526,34 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         // (v_mul_lo_u32 is quarter rate).
         auto count_slot = [&](int u) {
             if (COMPACT && !live[u]) return;        // uniform: the last round of a window is half empty on average
+            if (SEGS) {
+                // Read segments: a quad of lanes holds one 64-byte record, lane q its quarter -- the header (lane 0's first
+                // word, broadcast inside the quad) and three words of ten bases, or four words: bases 40 q - 10 + 10 k ... of
+                // the segment.  A word lies at ten consecutive positions, so its counters are ten consecutive columns (rows
+                // = base code; row 4 -- the idle queue region -- swallows code 4) at one LDS address + immediate offsets:
+                // 2 VALU + one LDS atomic per base and no per-base window test (the margin columns absorb the edge words).
+                const uint32_t q = (uint32_t)tid & 3u;
+                const uint32_t hdr = quad_first(v[u].x);
+                const int32_t r0 = (int32_t)(gb[u] + (hdr & 0xFFFFu) - w0) + (int32_t)(q * 40u) - 10;
+                const uint32_t wd[4] = {q ? v[u].x : SEG_SKIPW, v[u].y, v[u].z, v[u].w};
+                char *lds_b = reinterpret_cast<char *>(lds);
+                const uint32_t S4 = (uint32_t)S * 4u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int32_t r = r0 + 10 * k;
+                    uint32_t w = wd[k];
+                    if (w == SEG_SKIPW || (uint32_t)(r + 9) >= (uint32_t)(W + 9)) continue;
+                    const uint32_t m = w & SEG_SKIPW;                   // codes 5..7 count like 4
+                    w &= ~((m >> 1) | (m >> 2));
+                    const uint32_t a0 = (uint32_t)(r + ISX_SEG_LM) << 2;
+#pragma unroll
+                    for (int j = 0; j < 10; j++) {
+                        const uint32_t code = __builtin_amdgcn_ubfe(w, 3 * j, 3);
+                        atomicAdd(reinterpret_cast<uint32_t *>(lds_b + (__umul24(code, S4) + a0 + 4u * (uint32_t)j)), 1u);
+                    }
+                }
+                return;
+            }
             if (FMT == 2) {
                 const uint32_t bw = gb[u] - w0;
                 const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -630,24 +625,6 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         // Two half-rounds in flight: slots 0,1 (loaded during the previous half / the previous window's epilogue) are
         // counted while slots 2,3 load, and slots 0,1 of the NEXT round load while 2,3 are counted.  Every slot is
         // loaded, then consumed, then reloaded in static program order: no register copies, the waits are vmcnt(2).
-        if (SEGS) {
-            // read segments: one wave per record, lane l = base l of a chunk; rows = base code (row 4 -- the idle queue region --
-            // swallows "nothing here"), 64 consecutive columns per wave-wide atomic, the margin columns absorb the window's edges
-            char *lds_b = reinterpret_cast<char *>(lds);
-            const uint32_t S4 = (uint32_t)S * 4u;
-            const uint32_t lane4 = ((uint32_t)(tid & 63) + ISX_SEG_LM) * 4u;
-            walk_segs(a, lo, hi, w0, W, tid, nthr, [&](uint32_t, int32_t rel, uint64_t p0, uint64_t p1, uint64_t p2, uint32_t) {
-#ifdef ISX_TUNING
-                if (dbg & 64) { ablate_acc += (uint32_t)p0 ^ (uint32_t)p1 ^ (uint32_t)p2; return; }       // loads only
-#endif
-                const uint32_t c01 = sel_bit(sel_bit(0u, 1u, p0), sel_bit(2u, 3u, p0), p1);
-                const uint32_t row = sel_bit(c01, 4u, p2);
-#ifdef ISX_TUNING
-                if (dbg & 8) { ablate_acc += row; return; }                                            // decode, no LDS
-#endif
-                atomicAdd(reinterpret_cast<uint32_t *>(lds_b + (__umul24(row, S4) + (uint32_t)(rel * 4) + lane4)), 1u);
-            });
-        } else
         for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
             issue_one(2, i0); issue_one(3, i0);
             count_slot(0); count_slot(1);
@@ -683,7 +660,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             bool defer = false;
             uint32_t entry = (uint32_t)p;
             if ((int64_t)total >= (int64_t)a.min_cov) {
-                const int ref_base = ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : ref_at(a, gpos));
+                const int ref_base = ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : a.ref[gpos]);
                 const SiteCall sc = call_level(a, thr_lds, c, total, ref_base, false);
                 const uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
                 if (mx == total) cl = 1.0f; else defer = true;
@@ -762,7 +739,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             const uint32_t gpos = w0 + p;
             const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
             const uint32_t total = c[0] + c[1] + c[2] + c[3];
-            const int ref_base = ref_at(a, gpos);
+            const int ref_base = a.ref[gpos];
             const SiteCall sc = call_level(a, nullptr, c, total, ref_base, true);
             isx_snv r;
             r.gpos = gpos; r.mm = 0;
@@ -862,8 +839,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
-            if (SEGS) { lo = rng.x; hi = rng.y; return; }               // records (see k_pileup_dense)
-            lo = rng.x >> RSH; hi = rng.y >> RSH;
+            if (SEGS) { lo = rng.x << 2; hi = rng.y << 2; } else { lo = rng.x >> RSH; hi = rng.y >> RSH; }
             if (lo < hi) { issue_one(0, lo); issue_one(1, lo); }
         }
     };
@@ -888,6 +864,36 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         uint32_t bad_mm = 0;
         auto count_slot = [&](int u) {
             const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (SEGS) {
+                // read segments (see k_pileup_dense): lane q of a quad walks the words of its quarter of the record; the mm
+                // level is the record's, so a word's ten counters are ten consecutive columns of the level's rows
+                const uint32_t q = (uint32_t)tid & 3u;
+                const uint32_t hdr = quad_first(x[0]);
+                const uint32_t mm = hdr >> 24;
+                if (((hdr >> 16) & 0xFFu) == 0) return;                 // padding record / a slot the wave did not load
+                if (mm >= (uint32_t)M) { bad_mm = 1; return; }
+                const int32_t r0 = (int32_t)(gb[u] + (hdr & 0xFFFFu) - w0) + (int32_t)(q * 40u) - 10;
+                const uint32_t rowb = __umul24(mm * (PACKED ? 2u : 4u), (uint32_t)W);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int32_t r = r0 + 10 * k;
+                    const uint32_t wv = (k == 0 && q == 0) ? SEG_SKIPW : x[k];
+                    if (wv == SEG_SKIPW || (uint32_t)(r + 9) >= (uint32_t)(W + 9)) continue;
+#pragma unroll
+                    for (int j = 0; j < 10; j++) {
+                        const uint32_t code = __builtin_amdgcn_ubfe(wv, 3 * j, 3);
+                        const uint32_t rel = (uint32_t)(r + j);
+                        if (rel >= (uint32_t)W) continue;
+                        if (code < 4u) {
+                            if (PACKED) atomicAdd(&cnt[rowb + __umul24(code >> 1, (uint32_t)W) + rel], 1u << (16 * (code & 1)));
+                            else atomicAdd(&cnt[rowb + __umul24(code, (uint32_t)W) + rel], 1u);
+                        } else if (code == 5u) {                        // a base that is not A/C/T/G: the level is present here
+                            atomicOr(&pres[__umul24(mm >> 5, (uint32_t)W) + rel], 1u << (mm & 31));
+                        }
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int h = 0; h < (COMPACT ? 4 : 2); h++) {
                 uint32_t rel, base, mm;
@@ -903,23 +909,6 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
                 }
             }
         };
-        if (SEGS) {
-            // read segments (see k_pileup_dense): one wave per record, lane l = base l of a chunk; the mm level is the record's
-            const int lane_i = tid & 63;
-            walk_segs(a, lo, hi, w0, W, tid, nthr, [&](uint32_t hdr, int32_t rel, uint64_t p0, uint64_t p1, uint64_t p2, uint32_t) {
-                const uint32_t mm = hdr >> 24;
-                if (mm >= (uint32_t)M) { bad_mm = 1; return; }
-                const uint32_t rl = (uint32_t)(rel + lane_i);
-                if (rl >= (uint32_t)W) return;
-                const uint32_t b0 = sel_bit(0u, 1u, p0), b1 = sel_bit(0u, 1u, p1), skip = sel_bit(0u, 1u, p2);
-                if (!skip) {
-                    if (PACKED) atomicAdd(&cnt[__umul24(mm * 2 + b1, (uint32_t)W) + rl], 1u << (16 * b0));
-                    else atomicAdd(&cnt[__umul24(mm * 4 + (b0 | (b1 << 1)), (uint32_t)W) + rl], 1u);
-                } else if (b0 && !b1) {                                 // code 5: a base that is not A/C/T/G -- the level is present here
-                    atomicOr(&pres[__umul24(mm >> 5, (uint32_t)W) + rl], 1u << (mm & 31));
-                }
-            });
-        } else
         for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
             issue_one(2, i0); issue_one(3, i0);
             count_slot(0); count_slot(1);
@@ -942,7 +931,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         uint32_t *rowq = queue + 2 * QCAP;      // [rqcap][4]: p | any<<16 | cry<<17 | mask<<20, row off, site off | nlev<<24, slev off
         // mode 1 (rare, queued positions only): write the SNV rows and the site's level rows
         auto emit_rows = [&](int p, uint32_t gpos, uint32_t row_at, uint32_t cry_in, uint32_t slev_at) {
-            const int ref_base = ref_at(a, gpos);
+            const int ref_base = a.ref[gpos];
             uint32_t cum[4] = {0, 0, 0, 0};
             uint32_t rows = 0, nl = 0;
             for (int m = 0; m < M; m++) {
@@ -979,7 +968,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
             const int p = tid + j * nthr;
             const uint32_t gpos = w0 + p;
             const bool valid = p < W && gpos < a.n_pos && !(dbg & 2);
-            const int ref_base = valid ? (int)ref_at(a, gpos) : 4;
+            const int ref_base = valid ? (int)a.ref[gpos] : 4;
             uint32_t cum[4] = {0, 0, 0, 0};
             uint32_t any = 0, cry = 0, rows = 0, nlev = 0, mask = 0;
             for (int m = 0; m < M; m++) {
@@ -1154,7 +1143,7 @@ size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int pack
     if (stage_off) *stage_off = 0;
     if (linkage) {
         bytes += (size_t)W * 5;                 // slabc[W] + maskl[W]
-        const size_t stage_words = (size_t)(block / 64) * 128;      // allele pass: 64 two-word entries per wave
+        const size_t stage_words = (size_t)(block / 64) * 128 + (segs ? (size_t)W / 32 + 2 : 0);   // allele pass: 64 two-word entries per wave (+ the segment walk's site bitmap)
         if (cnt_words < stage_words) {          // small windows: the counters cannot host the stage
             bytes = (bytes + 15) & ~(size_t)15;
             if (stage_off) *stage_off = (int)(bytes / 4);

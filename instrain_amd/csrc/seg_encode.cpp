@@ -21,7 +21,6 @@ namespace isxenc {
 
 namespace {
 
-constexpr uint32_t EMPTY_PAYLOAD[ISX_SEG_WORDS] = ISX_SEG_EMPTY_PAYLOAD;
 constexpr int64_t TASK = 4096;          // segments per task (a multiple of ISX_SEG_GROUP): 256 KiB of payload
 constexpr uint32_t SPAN = 65535u;       // largest delta a header can carry
 
@@ -69,8 +68,8 @@ inline void put_record_avx512(uint32_t *o, uint32_t header, const uint32_t *payl
 __attribute__((target("avx512f,avx512bw,avx512vl")))
 inline void put_padding_avx512(uint32_t *o)
 {
-    alignas(64) static const uint32_t empty[16] = {0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0xFFFFFFFFu};
-    _mm512_stream_si512(reinterpret_cast<__m512i *>(o), _mm512_load_si512(reinterpret_cast<const __m512i *>(empty)));
+    const __m512i v = _mm512_mask_set1_epi32(_mm512_set1_epi32((int)ISX_SEG_SKIP_WORD), (__mmask16)0x0001, 0);
+    _mm512_stream_si512(reinterpret_cast<__m512i *>(o), v);
 }
 
 }  // namespace
@@ -101,7 +100,7 @@ int encode_segs(HostPool &pool, SegJob &J)
         for (int r = 0; r < ISX_SEG_GROUP; r++) {
             uint32_t *o = J.rec + (size_t)r * ISX_SEG_REC_WORDS;
             o[0] = 0;
-            for (int k = 1; k < ISX_SEG_REC_WORDS; k++) o[k] = EMPTY_PAYLOAD[k - 1];
+            for (int k = 1; k < ISX_SEG_REC_WORDS; k++) o[k] = ISX_SEG_SKIP_WORD;
             if (J.pair_out) J.pair_out[r] = 0;
         }
         J.gbase[0] = 0; J.cmin[0] = 0xFFFFFFFFu; J.cmax[0] = 0; J.cany[0] = 0;
@@ -153,7 +152,7 @@ int encode_segs(HostPool &pool, SegJob &J)
             for (int64_t s = j - i; s < ISX_SEG_GROUP; s++, o += ISX_SEG_REC_WORDS) {
                 if (fast) { put_padding_avx512(o); continue; }
                 o[0] = 0;
-                for (int k = 1; k < ISX_SEG_REC_WORDS; k++) o[k] = EMPTY_PAYLOAD[k - 1];
+                for (int k = 1; k < ISX_SEG_REC_WORDS; k++) o[k] = ISX_SEG_SKIP_WORD;
             }
             if (J.pair_out) {
                 uint32_t *po = J.pair_out + (size_t)g * ISX_SEG_GROUP;
@@ -266,7 +265,7 @@ int isx_encode_segs_ring(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins,
     if (rc == isxenc::SEG_CAPACITY) { isx_set_error("isx_encode_segs: the stream does not fit cap_rec records"); return ISX_ERR_CAPACITY; }
     if (rc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
     if (rc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
-    if (rc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 160]"); return ISX_ERR_ARG; }
+    if (rc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
     *n_rec = J.n_rec;
     return ISX_OK;
 }
@@ -310,12 +309,13 @@ int isx_pack_reads(int64_t n_reads, const int64_t *ref_start, const int64_t *cli
             for (int64_t c0 = 0; c0 < cols && !full; c0 += ISX_SEG_BASES) {
                 const int L = (int)std::min<int64_t>(ISX_SEG_BASES, cols - c0);
                 if (n >= cap_seg) { full = true; return; }
-                uint8_t cd[ISX_SEG_BASES];
+                uint32_t *w = seg_bases + (size_t)n * ISX_SEG_WORDS;
+                for (int k = 0; k < ISX_SEG_WORDS; k++) w[k] = ISX_SEG_SKIP_WORD;
                 for (int j = 0; j < L; j++) {
                     const int64_t qi = q0 + c0 + j;
-                    cd[j] = (uint8_t)((int)ql[qi] >= min_base_quality ? ascii_code(sq[qi]) : 4u);
+                    const uint32_t code = (int)ql[qi] >= min_base_quality ? ascii_code(sq[qi]) : 4u;
+                    w[j / 10] = (w[j / 10] & ~(7u << (3 * (j % 10)))) | (code << (3 * (j % 10)));
                 }
-                isxenc::seg_planes_from_codes(cd, L, seg_bases + (size_t)n * ISX_SEG_WORDS);
                 seg_gpos[n] = (uint32_t)(pos + c0); seg_len[n] = (uint8_t)L;
                 if (seg_mm) seg_mm[n] = mm ? mm[r] : (uint8_t)0;
                 if (seg_pair) seg_pair[n] = pair ? pair[r] : 0u;

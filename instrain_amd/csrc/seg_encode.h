@@ -18,36 +18,6 @@
 
 namespace isxenc {
 
-// base codes cd[0 .. n) (n <= ISX_SEG_BASES; 0..3 A C T G, 4 nothing, 5 non-ACGT) -> the 15 payload words of a segment (bit planes,
-// include/instrain_amd.h); slots from n on hold code 4
-inline void seg_planes_from_codes(const uint8_t *cd, int n, uint32_t *w)
-{
-    uint64_t pl[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};          // [chunk][plane]
-    for (int j = 0; j < n; j++) {
-        const int c = j >> 6, l = j & 63;
-        const uint64_t v = cd[j];
-        pl[c][0] |= (v & 1u) << l; pl[c][1] |= ((v >> 1) & 1u) << l; pl[c][2] |= ((v >> 2) & 1u) << l;
-    }
-    for (int j = n; j < ISX_SEG_BASES; j++) pl[j >> 6][2] |= 1ull << (j & 63);
-    for (int c = 0; c < 2; c++)
-        for (int b = 0; b < 3; b++) { w[6 * c + 2 * b] = (uint32_t)pl[c][b]; w[6 * c + 2 * b + 1] = (uint32_t)(pl[c][b] >> 32); }
-    for (int b = 0; b < 3; b++) w[12 + b] = (uint32_t)pl[2][b];
-}
-
-// the inverse (tests, tools): payload -> cd[ISX_SEG_BASES]
-inline void seg_codes_from_planes(const uint32_t *w, uint8_t *cd)
-{
-    for (int j = 0; j < ISX_SEG_BASES; j++) {
-        const int c = j >> 6, l = j & 63;
-        uint32_t v = 0;
-        for (int b = 0; b < 3; b++) {
-            const uint64_t p = c < 2 ? ((uint64_t)w[6 * c + 2 * b] | ((uint64_t)w[6 * c + 2 * b + 1] << 32)) : (uint64_t)w[12 + b];
-            v |= (uint32_t)((p >> l) & 1u) << b;
-        }
-        cd[j] = (uint8_t)v;
-    }
-}
-
 struct SegJob {
     // input: arrays (isx_segs), or a producer that writes any range of the segment stream on demand (the BAM front end
     // emits segments straight into the encoder's per-task scratch: the batch's segments never exist as a whole)

@@ -265,21 +265,6 @@ inline int reg2bin(int64_t beg, int64_t end)
     return 0;
 }
 
-// base codes cd[0 .. n) (n <= 160) -> the 15 payload words of a read segment (bit planes, include/instrain_amd.h isx_segs)
-void planes_from_codes(const uint8_t *cd, int n, uint32_t *w)
-{
-    uint64_t pl[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (int j = 0; j < n; j++) {
-        const int c = j >> 6, l = j & 63;
-        const uint64_t v = cd[j];
-        pl[c][0] |= (v & 1u) << l; pl[c][1] |= ((v >> 1) & 1u) << l; pl[c][2] |= ((v >> 2) & 1u) << l;
-    }
-    for (int j = n; j < 160; j++) pl[j >> 6][2] |= 1ull << (j & 63);
-    for (int c = 0; c < 2; c++)
-        for (int b = 0; b < 3; b++) { w[6 * c + 2 * b] = (uint32_t)pl[c][b]; w[6 * c + 2 * b + 1] = (uint32_t)(pl[c][b] >> 32); }
-    for (int b = 0; b < 3; b++) w[12 + b] = (uint32_t)pl[2][b];
-}
-
 template <class T> inline void put(std::string &s, T v) { s.append(reinterpret_cast<const char *>(&v), sizeof v); }
 
 }  // namespace
@@ -475,7 +460,7 @@ int64_t isx_synth_generate_segs(const isx_synth_params *p, const int32_t *genome
                                 const double *coverage, isx_synth_out *out, uint32_t *seg_gpos, uint8_t *seg_len, uint8_t *seg_mm,
                                 uint32_t *seg_pair, uint32_t *seg_bases)
 {
-    if (!p || !genome_sel || n_sel <= 0 || !out || p->read_len > 160) return -1;
+    if (!p || !genome_sel || n_sel <= 0 || !out || p->read_len > 150) return -1;
     memset(out, 0, sizeof *out);
     const int RL = p->read_len, C = p->contigs;
     const int64_t n_sc = (int64_t)n_sel * C;
@@ -501,9 +486,13 @@ int64_t isx_synth_generate_segs(const isx_synth_params *p, const int32_t *genome
             const Contig &k = cs[(size_t)ci];
             int64_t at = 2 * k.pair0, kept = 0;             // a contig's reads are consecutive segments
             G.run(p, k, out->ref + k.off, [&](uint32_t i, int64_t st, const uint8_t *b, const uint8_t *keep, uint16_t mm_pair, uint16_t) {
-                uint8_t cd[160];
-                for (int q = 0; q < RL; q++) { cd[q] = keep[q] ? b[q] : (uint8_t)4; kept += keep[q]; }
-                planes_from_codes(cd, RL, seg_bases + (size_t)at * 15);
+                uint32_t *w = seg_bases + (size_t)at * 15;
+                for (int q = 0; q < 15; q++) w[q] = 0x24924924u;
+                for (int q = 0; q < RL; q++) {
+                    if (!keep[q]) continue;
+                    w[q / 10] = (w[q / 10] & ~(7u << (3 * (q % 10)))) | ((uint32_t)b[q] << (3 * (q % 10)));
+                    kept++;
+                }
                 seg_gpos[at] = (uint32_t)(k.off + st); seg_len[at] = (uint8_t)RL;
                 if (seg_mm) seg_mm[at] = p->with_mm ? (uint8_t)std::min<int>(std::min(255, p->max_mm), mm_pair) : (uint8_t)0;
                 if (seg_pair) seg_pair[at] = (uint32_t)(k.pair0 + (i >> 1));
@@ -534,22 +523,14 @@ void isx_synth_shift_segs(const uint32_t *gpos_in, const uint32_t *bases_in, int
             if (a >= n_seg) break;
             const int64_t e = std::min<int64_t>(n_seg, a + 8192);
             for (int64_t i = a; i < e; i++) gpos_out[i] = gpos_in[i] + shift;
-            for (int64_t i = a; i < e; i++) {
-                // (c + rot) & 3 on the low two planes of the A/C/T/G codes (plane 2 clear), plane by plane
-                const uint32_t *wi = bases_in + i * 15;
-                uint32_t *wo = bases_out + i * 15;
-                auto rotate = [&](int o0, int o1, int o2, int words) {
-                    for (int k = 0; k < words; k++) {
-                        const uint32_t b0 = wi[o0 + k], b1 = wi[o1 + k], sk = wi[o2 + k];
-                        uint32_t n0 = b0, n1 = b1;
-                        if (rot & 1) { n1 ^= n0; n0 = ~n0; }          // + 1
-                        if (rot & 2) n1 = ~n1;                        // + 2
-                        wo[o0 + k] = (b0 & sk) | (n0 & ~sk);
-                        wo[o1 + k] = (b1 & sk) | (n1 & ~sk);
-                        wo[o2 + k] = sk;
-                    }
-                };
-                rotate(0, 2, 4, 2); rotate(6, 8, 10, 2); rotate(12, 13, 14, 1);
+            for (int64_t i = a * 15; i < e * 15; i++) {
+                const uint32_t w = bases_in[i];
+                // codes < 4 (bit 2 clear): (c + rot) & 3 on the low two bits of every 3-bit field, no carry into bit 2
+                const uint32_t acgt = ~w & 0x24924924u;                     // bit 2 of every field set where the code is A/C/T/G
+                const uint32_t sel = (acgt >> 2) * 3u;                      // 0b011 in those fields
+                const uint32_t lo = w & 0x1B6DB6DBu;                        // low two bits of every field
+                const uint32_t sum = (lo + (uint32_t)rot * 0x09249249u) & 0x1B6DB6DBu;   // per-field add; a carry lands in bit 2 and is masked off
+                bases_out[i] = (w & ~sel) | (sum & sel);
             }
         }
     };
@@ -562,7 +543,7 @@ void isx_synth_shift_segs(const uint32_t *gpos_in, const uint32_t *bases_in, int
 
 // ---- observation stream -> read segments (include/instrain_amd.h isx_segs) ----
 // What the read-level hand-over ships for the same workload: consecutive observations of one read pair / mm level at
-// ascending positions less than 160 columns from the first become one segment (missing columns = code 4).  Any stream is
+// ascending positions less than 150 columns from the first become one segment (missing columns = code 4).  Any stream is
 // legal input (a segment only ever grows by the observation that follows it, so the segments keep the arrival order); a
 // read-major stream -- what the generator above and the BAM front end emit -- gives one segment per read.
 // Two calls: n_seg first (seg_gpos == NULL), then the arrays.  base >= 4 (a non-ACGT base) becomes code 5.
@@ -574,7 +555,7 @@ int64_t isx_synth_obs_to_segs(const synth_obs *obs, const uint32_t *pair, int64_
         if (pair && pair[i] != pair[i - 1]) return true;
         if (obs[i].mm != obs[i - 1].mm) return true;
         if (obs[i].gpos <= obs[i - 1].gpos) return true;
-        return obs[i].gpos - seg_start >= 160u;
+        return obs[i].gpos - seg_start >= 150u;
     };
     // pass 1 (sequential: a segment's start decides where the next one begins): first observation of every segment
     std::vector<int64_t> first;
@@ -594,11 +575,12 @@ int64_t isx_synth_obs_to_segs(const synth_obs *obs, const uint32_t *pair, int64_
             for (int64_t sgi = s0; sgi < s1; sgi++) {
                 const int64_t a = first[(size_t)sgi], e = first[(size_t)sgi + 1];
                 const uint32_t g0 = obs[a].gpos;
-                uint8_t cd[160];
-                const int L = (int)(obs[e - 1].gpos - g0 + 1);
-                memset(cd, 4, (size_t)L);
-                for (int64_t i = a; i < e; i++) cd[obs[i].gpos - g0] = (uint8_t)(obs[i].base < 4 ? obs[i].base : 5u);
-                planes_from_codes(cd, L, seg_bases + (size_t)sgi * 15);
+                uint32_t *w = seg_bases + (size_t)sgi * 15;
+                for (int k = 0; k < 15; k++) w[k] = 0x24924924u;
+                for (int64_t i = a; i < e; i++) {
+                    const uint32_t j = obs[i].gpos - g0, code = obs[i].base < 4 ? obs[i].base : 5u;
+                    w[j / 10] = (w[j / 10] & ~(7u << (3 * (j % 10)))) | (code << (3 * (j % 10)));
+                }
                 seg_gpos[sgi] = g0;
                 seg_len[sgi] = (uint8_t)(obs[e - 1].gpos - g0 + 1);
                 if (seg_mm) seg_mm[sgi] = (uint8_t)std::min<uint32_t>(255u, obs[a].mm);

@@ -46,37 +46,17 @@ class SegBatch:
 
 
 def pack_codes(codes):
-    """[n, <= 160] uint8 base codes (0..3 A C T G, 4 nothing, 5 non-ACGT; missing columns = 4) -> [n, 15] uint32 payload:
-    the codes' bit planes (include/instrain_amd.h isx_segs: chunk A = bases 0..63 as three 64-bit planes, B = 64..127, C =
-    128..159 as three 32-bit planes)"""
-    c = np.asarray(codes, dtype=np.uint8)
-    c = c.reshape(-1, c.shape[-1]) if c.ndim > 1 else c.reshape(1, -1)
-    n = len(c)
-    full = np.full((n, _lib.SEG_BASES), 4, dtype=np.uint8)
-    full[:, :c.shape[1]] = c
-    out = np.zeros((n, _lib.SEG_WORDS), dtype=np.uint32)
-    w32 = (np.uint64(1) << np.arange(32, dtype=np.uint64))[None, :]
-    for b in range(3):
-        bits = ((full >> b) & 1).astype(np.uint64)
-        for k in range(5):                              # 32 bases per output word
-            word = (bits[:, 32 * k:32 * k + 32] * w32).sum(axis=1).astype(np.uint32)
-            chunk, half = divmod(k, 2)
-            out[:, (6 * chunk + 2 * b + half) if chunk < 2 else (12 + b)] = word
-    return out
+    """[n, 150] uint8 base codes (0..3 A C T G, 4 skip, 5 non-ACGT) -> [n, 15] uint32, ten codes per word"""
+    c = np.ascontiguousarray(codes, dtype=np.uint32).reshape(-1, _lib.SEG_WORDS, 10)
+    sh = (3 * np.arange(10, dtype=np.uint32))[None, None, :]
+    return (c << sh).sum(axis=2, dtype=np.uint32)
 
 
 def unpack_codes(bases):
-    """inverse of pack_codes: [n, 15] uint32 -> [n, 160] uint8"""
-    w = np.ascontiguousarray(bases, dtype=np.uint32).reshape(-1, _lib.SEG_WORDS)
-    n = len(w)
-    out = np.zeros((n, _lib.SEG_BASES), dtype=np.uint8)
-    sh = np.arange(32, dtype=np.uint32)[None, :]
-    for b in range(3):
-        for k in range(5):
-            chunk, half = divmod(k, 2)
-            word = w[:, (6 * chunk + 2 * b + half) if chunk < 2 else (12 + b)]
-            out[:, 32 * k:32 * k + 32] |= (((word[:, None] >> sh) & 1) << b).astype(np.uint8)
-    return out
+    """inverse of pack_codes: [n, 15] uint32 -> [n, 150] uint8"""
+    b = np.ascontiguousarray(bases, dtype=np.uint32).reshape(-1, _lib.SEG_WORDS, 1)
+    sh = (3 * np.arange(10, dtype=np.uint32))[None, None, :]
+    return ((b >> sh) & 7).astype(np.uint8).reshape(-1, _lib.SEG_BASES)
 
 
 SEQ_LUT = np.full(256, 4, dtype=np.uint8)

@@ -129,7 +129,7 @@ def test_non_acgt_base_makes_its_level_present(ctx):
     (profile_utilities.py:279-285); code 4 / 6 / 7 do nothing"""
     from instrain_amd import engine
     ref = np.zeros(500, np.uint8)
-    codes = np.full((3, 160), 4, np.uint8)
+    codes = np.full((3, 150), 4, np.uint8)
     codes[0, :20] = 0                       # read 0, mm 0: twenty A
     codes[1, 5] = 5                         # read 1, mm 2: one N over position 105
     codes[1, 6] = 6; codes[1, 7] = 7
@@ -157,10 +157,10 @@ def test_segments_straddling_windows_and_far_jumps(ctx):
     from instrain_amd import engine
     n_pos = 300_000
     rng = np.random.Generator(np.random.PCG64(5))
-    starts = np.sort(np.concatenate([rng.integers(0, 3000, 400), rng.integers(200_000, 203_000, 400), [n_pos - 160]])).astype(np.uint32)
+    starts = np.sort(np.concatenate([rng.integers(0, 3000, 400), rng.integers(200_000, 203_000, 400), [n_pos - 150]])).astype(np.uint32)
     n = len(starts)
-    codes = rng.integers(0, 6, (n, 160)).astype(np.uint8)
-    ln = np.full(n, 160, np.uint8)
+    codes = rng.integers(0, 6, (n, 150)).astype(np.uint8)
+    ln = np.full(n, 150, np.uint8)
     segs = engine.SegBatch(starts, ln, engine.pack_codes(codes), mm=None, pair=np.arange(n, dtype=np.uint32))
     exp = np.zeros((n_pos, 4), np.int64)
     for b in range(4):

@@ -21,9 +21,10 @@ def test_segments_of_a_read_major_stream_round_trip():
     assert (g == w["obs"]["gpos"]).all() and (b == w["obs"]["base"]).all()
     assert (m == w["obs"]["mm"]).all() and (p == w["pair"]).all()
     assert int(segs.len.max()) <= 150 and int(segs.len.min()) >= 1
-    # unused slots hold code 4
+    # unused slots hold code 4, the top two bits of every word are clear
+    assert (segs.bases >> 30 == 0).all()
     cd = engine.unpack_codes(segs.bases)
-    tail = np.arange(160)[None, :] >= segs.len[:, None]
+    tail = np.arange(150)[None, :] >= segs.len[:, None]
     assert (cd[tail] == 4).all()
 
 
@@ -81,7 +82,7 @@ def test_encode_segs_layout(threads):
     hdr = rec[:, 0]
     real = ((hdr >> 16) & 0xFF) > 0
     assert (pout[real] == segs.pair).all() and (pout[~real] == 0).all()
-    assert (rec[~real, 1:] == np.asarray(engine._lib.SEG_EMPTY_PAYLOAD, np.uint32)[None, :]).all() and (hdr[~real] == 0).all()
+    assert (rec[~real, 1:] == 0x24924924).all() and (hdr[~real] == 0).all()
     # every group's deltas fit 16 bits by construction; the jump costs padding
     assert real.sum() == segs.n_seg and (~real).sum() >= 1
     # the number of groups does not depend on the thread count beyond the per-task rounding
@@ -105,18 +106,16 @@ def test_encode_segs_through_the_staging_ring(ring_records):
 
 def test_encode_segs_rejects_bad_input():
     from instrain_amd._lib import IsxError
-    empty = np.asarray(engine._lib.SEG_EMPTY_PAYLOAD, np.uint32)
-    segs = engine.SegBatch([10, 20], [150, 150], np.tile(empty, (2, 1)), mm=[0, 3])
+    segs = engine.SegBatch([10, 20], [150, 150], np.full((2, 15), 0x24924924, np.uint32), mm=[0, 3])
     with pytest.raises(IsxError, match="beyond n_pos"):
         engine.encode_segs(segs, 100, n_mm_bins=4)
     with pytest.raises(IsxError, match="mm >= n_mm_bins"):
         engine.encode_segs(segs, 1000, n_mm_bins=2)
-    for ln in (0, 161):
-        bad = engine.SegBatch([10], [ln], empty[None, :])
-        with pytest.raises(IsxError, match="length"):
-            engine.encode_segs(bad, 1000)
-    none = engine.SegBatch(np.zeros(0, np.uint32), np.zeros(0, np.uint8), np.zeros((0, 15), np.uint32))
-    rec, gbase, _ = engine.encode_segs(none, 1000)
+    bad = engine.SegBatch([10], [0], np.full((1, 15), 0x24924924, np.uint32))
+    with pytest.raises(IsxError, match="length"):
+        engine.encode_segs(bad, 1000)
+    empty = engine.SegBatch(np.zeros(0, np.uint32), np.zeros(0, np.uint8), np.zeros((0, 15), np.uint32))
+    rec, gbase, _ = engine.encode_segs(empty, 1000)
     assert len(rec) == 16 and (rec[:, 0] == 0).all()
 
 
@@ -151,8 +150,8 @@ def test_pack_reads_follows_the_cigar_and_the_quality_filter():
     g, b, m, p = util.segs_to_obs(segs)
     assert list(zip(g.tolist(), b.tolist())) == exp
     assert (m == 2).all() and (p == 7).all()
-    # runs: 100 | 40 | 20 | 180 -> 160 + 20: five segments, none longer than 160
-    assert segs.n_seg == 5 and segs.len.tolist() == [100, 40, 20, 160, 20]
+    # runs: 100 | 40 | 20 | 180 -> 150 + 30: five segments, none longer than 150
+    assert segs.n_seg == 5 and segs.len.tolist() == [100, 40, 20, 150, 30]
     # truncation to the scaffold: columns outside [clip_lo, clip_hi) are dropped like the reference's truncate=True
     clipped = engine.pack_reads([start], [1050], [1300], [cig], [seq], [qual])
     gc, bc, _, _ = util.segs_to_obs(clipped)
@@ -176,8 +175,8 @@ def test_bam_segments_stand_for_the_bam_observations():
     assert bam.info["n_obs"] >= len(obs) and (b2 == bounds).all() and (s2 == sref).all()
     bam.close()
     _same_stream(segs, obs, pair)
-    # reads are 2 x ~100-150 bp with indels: a handful of segments per read, all <= 160 columns, most of them full reads
-    assert segs.len.max() <= 160 and segs.n_seg < 2.5 * 2 * 13124
+    # reads are 2 x ~100-150 bp with indels: a handful of segments per read, all <= 150 columns, most of them full reads
+    assert segs.len.max() <= 150 and segs.n_seg < 2.5 * 2 * 13124
 
 
 @pytest.mark.parametrize("seed,skip_mm", [(1, False), (2, True), (3, False)])

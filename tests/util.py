@@ -107,7 +107,7 @@ def assert_same(got, exp, float_tol=1e-6, what=""):
 def reassemble_segs(gpos, base, mm, pair):
     """Any observation stream (e.g. the goldens' column-major one) -> read segments (engine.SegBatch) the way reads would
     carry them: an observation extends the oldest open segment of its pair with the same mm whose last column lies before
-    it and whose start is less than 160 columns back, otherwise it opens a new segment; segments keep the order of their
+    it and whose start is less than 150 columns back, otherwise it opens a new segment; segments keep the order of their
     first observation, so two observations of one pair at one site stay in arrival order (linkage's self pairs)."""
     from instrain_amd import engine
     open_of = {}
@@ -116,19 +116,19 @@ def reassemble_segs(gpos, base, mm, pair):
         g, m, p, b = int(gpos[i]), int(mm[i]), int(pair[i]), int(base[i])
         hit = None
         for si in open_of.setdefault(p, []):
-            if mms[si] == m and g > lasts[si] and g - starts[si] < 160:
+            if mms[si] == m and g > lasts[si] and g - starts[si] < 150:
                 hit = si
                 break
         if hit is None:
             hit = len(starts)
             starts.append(g); mms.append(m); pairs.append(p); lasts.append(g)
-            codes.append(np.full(160, 4, dtype=np.uint8))
+            codes.append(np.full(150, 4, dtype=np.uint8))
             open_of[p].append(hit)
         codes[hit][g - starts[hit]] = b if b < 4 else 5
         lasts[hit] = g
     n = len(starts)
     ln = np.asarray([lasts[i] - starts[i] + 1 for i in range(n)], dtype=np.uint8)
-    cd = np.stack(codes) if n else np.zeros((0, 160), np.uint8)
+    cd = np.stack(codes) if n else np.zeros((0, 150), np.uint8)
     return engine.SegBatch(np.asarray(starts, np.uint32), ln, engine.pack_codes(cd), np.asarray(mms, np.uint8), np.asarray(pairs, np.uint32))
 
 
