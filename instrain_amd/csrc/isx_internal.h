@@ -142,7 +142,8 @@ struct PileupArgs {
                                 //     first word of a record = delta:16 | len:8 | mm:8, start = gbase[record / 16] + delta, then 15 words of
                                 //     ten 3-bit base codes; `pair` (linkage) is indexed by RECORD
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK; of ISX_SEG_GROUP for the segment stream)
-    const uint8_t *ref;
+    const uint8_t *ref;         // reference base code per flat position -- or, ref_packed (pipe slots: half the bytes over PCIe), two per
+    int32_t ref_packed;         // byte: position 2 i in the low nibble of byte i, 2 i + 1 in the high one
     const uint32_t *pair;       // read-pair id per record (linkage only), or NULL and ...
     const uint2 *pair_runs;     // ... runs of equal pair ids: (first device record, pair id), ascending; run_index[c] = the run
     const uint32_t *run_index;  //     that holds device record 1024 c (pipe slots: ~0.06 B per record over PCIe instead of 4)

@@ -87,6 +87,13 @@ __device__ __forceinline__ void publish_previous(const PileupArgs &a, int tid)
     if (tid == 0) __hip_atomic_store(&a.pub_host_state[CUR_N + 4], a.pub_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// reference base code of a flat position (see PileupArgs::ref_packed)
+__device__ __forceinline__ uint8_t ref_at(const PileupArgs &a, uint32_t gpos)
+{
+    if (a.ref_packed) return (uint8_t)((a.ref[gpos >> 1] >> ((gpos & 1u) << 2)) & 0xFu);
+    return a.ref[gpos];
+}
+
 __device__ __forceinline__ int argmax4(const uint32_t *c)
 {
     int b = 0;
@@ -516,7 +523,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const uint32_t gp = w0 + tid + it * nthr;
-            ref_raw[it] = (tid + it * nthr < W && gp < a.n_pos) ? a.ref[gp] : (uint8_t)4;
+            ref_raw[it] = (tid + it * nthr < W && gp < a.n_pos) ? ref_at(a, gp) : (uint8_t)4;
         }
         __syncthreads();
 
@@ -660,7 +667,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             bool defer = false;
             uint32_t entry = (uint32_t)p;
             if ((int64_t)total >= (int64_t)a.min_cov) {
-                const int ref_base = ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : a.ref[gpos]);
+                const int ref_base = ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : ref_at(a, gpos));
                 const SiteCall sc = call_level(a, thr_lds, c, total, ref_base, false);
                 const uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
                 if (mx == total) cl = 1.0f; else defer = true;
@@ -739,7 +746,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             const uint32_t gpos = w0 + p;
             const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
             const uint32_t total = c[0] + c[1] + c[2] + c[3];
-            const int ref_base = a.ref[gpos];
+            const int ref_base = ref_at(a, gpos);
             const SiteCall sc = call_level(a, nullptr, c, total, ref_base, true);
             isx_snv r;
             r.gpos = gpos; r.mm = 0;
@@ -931,7 +938,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         uint32_t *rowq = queue + 2 * QCAP;      // [rqcap][4]: p | any<<16 | cry<<17 | mask<<20, row off, site off | nlev<<24, slev off
         // mode 1 (rare, queued positions only): write the SNV rows and the site's level rows
         auto emit_rows = [&](int p, uint32_t gpos, uint32_t row_at, uint32_t cry_in, uint32_t slev_at) {
-            const int ref_base = a.ref[gpos];
+            const int ref_base = ref_at(a, gpos);
             uint32_t cum[4] = {0, 0, 0, 0};
             uint32_t rows = 0, nl = 0;
             for (int m = 0; m < M; m++) {
@@ -968,7 +975,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
             const int p = tid + j * nthr;
             const uint32_t gpos = w0 + p;
             const bool valid = p < W && gpos < a.n_pos && !(dbg & 2);
-            const int ref_base = valid ? (int)a.ref[gpos] : 4;
+            const int ref_base = valid ? (int)ref_at(a, gpos) : 4;
             uint32_t cum[4] = {0, 0, 0, 0};
             uint32_t any = 0, cry = 0, rows = 0, nlev = 0, mask = 0;
             for (int m = 0; m < M; m++) {

@@ -253,7 +253,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.b = b;
     b->ctx = c; b->prm = *prm; b->M = prm->n_mm_bins;
     b->ps = index & 1;
-    b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true;
+    b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true; b->ref_packed = true;
     b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
     b->segs = p->segs;
     const bool dense = b->M == 1;
@@ -763,9 +763,13 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         const int64_t piece = (int64_t)4 << 20;
         const int n_tasks = (int)((n_pos + piece - 1) / piece);
         uint8_t *dst = s.h_in + s.off_ref;
-        auto cp = [&](int t) {
+        auto cp = [&](int t) {      // two codes per byte (piece is even): half the reference bytes cross PCIe
             const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
-            memcpy(dst + a, ref + a, (size_t)(e - a));
+            uint8_t *o = dst + (a >> 1);
+            const uint8_t *r = ref + a;
+            const int64_t n2 = (e - a) >> 1;
+            for (int64_t i = 0; i < n2; i++) o[i] = (uint8_t)((r[2 * i] & 0xF) | (r[2 * i + 1] << 4));
+            if ((e - a) & 1) o[n2] = (uint8_t)(r[e - a - 1] & 0xF);
         };
         if (n_tasks > 1) p->pool->run(n_tasks, cp); else cp(0);
     }
@@ -816,7 +820,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
 
     // ---- copy-in queue ----
     if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
-    const size_t head = s.off_ref + (size_t)n_pos;                         // bounds | windows | reference codes
+    const size_t head = s.off_ref + ((size_t)n_pos + 1) / 2;               // bounds | windows | reference codes (two per byte)
     // the stream is followed by a tail of padding records / zero bases (see ISX_TAIL_BYTES): the slot's arena still
     // holds the previous batch there
     memset(s.h_in + s.off_gbase + (size_t)(b->n_rec / p->G) * sizeof(uint32_t), 0, ISX_TAIL_GROUPS * sizeof(uint32_t));
@@ -908,9 +912,13 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         const int64_t piece = (int64_t)4 << 20;
         const int n_tasks = (int)((n_pos + piece - 1) / piece);
         uint8_t *dst = s.h_in + s.off_ref;
-        auto cp = [&](int t) {
+        auto cp = [&](int t) {      // two codes per byte (piece is even): half the reference bytes cross PCIe
             const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
-            memcpy(dst + a, ref + a, (size_t)(e - a));
+            uint8_t *o = dst + (a >> 1);
+            const uint8_t *r = ref + a;
+            const int64_t n2 = (e - a) >> 1;
+            for (int64_t i = 0; i < n2; i++) o[i] = (uint8_t)((r[2 * i] & 0xF) | (r[2 * i + 1] << 4));
+            if ((e - a) & 1) o[n2] = (uint8_t)(r[e - a - 1] & 0xF);
         };
         if (n_tasks > 1) p->pool->run(n_tasks, cp); else cp(0);
     }
@@ -959,7 +967,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
 
     // ---- copy-in queue: bounds | windows | reference codes, then group bases (| pair ids) | records ----
     if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
-    const size_t head = s.off_ref + (size_t)n_pos;
+    const size_t head = s.off_ref + ((size_t)n_pos + 1) / 2;              // (reference codes two per byte)
     const size_t gb_bytes = (size_t)(b->n_rec / ISX_SEG_GROUP) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * 64;
     HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, head, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
