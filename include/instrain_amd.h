@@ -521,6 +521,11 @@ int isx_bam_scan(isx_bam *bam, isx_bam_info *info /* may be NULL */);
  * (isx_bam_ref_counts).  paired_only only; the file-wide median insert is the caller's to combine: isx_bam_insert_sizes of
  * every share (an all-gather) -> isx_bam_filter(median_insert).  isx_bam_scan == share 0 of 1. */
 int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info *info /* may be NULL */);
+/* The scaffolds that exist for the read filter: the reference builds its pair table from the scaffolds of the fasta only
+ * (filter_reads.py:63-77, 157-178), so the median insert (:213-217), the read_report tallies and the cross-scaffold name
+ * look-ups of non_discordant / all_reads ignore every other reference of the BAM.  refs[n] reference ids; n == 0 = all
+ * (a BAM mapped to exactly the fasta).  Applies to isx_bam_insert_sizes and isx_bam_filter. */
+int isx_bam_set_wanted_refs(isx_bam *bam, const int32_t *refs, int32_t n);
 /* insert sizes of the two-read pairs: out may be NULL to ask for *n only (a median across files / ranks) */
 int isx_bam_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n);
 int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert /* NaN = this file's own */, isx_bam_info *info);

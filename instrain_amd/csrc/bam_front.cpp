@@ -404,6 +404,7 @@ struct isx_bam {
     // ---- results of the last expand ----
     std::unique_ptr<isx_obs[]> obs;
     std::unique_ptr<uint32_t[]> pair;
+    std::vector<uint8_t> ref_wanted;                        // isx_bam_set_wanted_refs: empty = every reference counts
     std::vector<uint32_t> seg_gpos, seg_pair, seg_bases;    // isx_bam_segment_refs: the batch as read segments
     std::vector<uint8_t> seg_len, seg_mm;
     size_t n_obs = 0;
@@ -905,6 +906,7 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     const size_t s0 = n_seg * (size_t)part / (size_t)n_parts, s1 = n_seg * ((size_t)part + 1) / (size_t)n_parts;
     size_t sv = s0 >= 2 ? s0 - 2 : 0;           // where the walk starts (verification run-in)
     bool have_first = sv == 0;                  // the file's first record is known; any other start is a guess until the chain confirms it
+    bool verified = sv == 0;                    // a guessed start counts once a later segment's own guess falls on the chain walked from it
     size_t s_end = n_seg;                       // one past the last segment scanned
     if (s0 == s1) { sv = 0; s_end = 0; }        // more shares than segments: this one is empty
     for (size_t w0 = sv, w1 = 0; w0 < s_end; w0 = w1) {
@@ -944,6 +946,19 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
             }
             if (first > s.ioff1) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; recs[k].clear(); continue; }    // a record spans the whole segment
             s.first_rec = std::max(first, s.ioff0);
+            if (!verified && s.first_rec < s.ioff1 && guess[k] != ~0ull && si > sv) {
+                // the run-in of a share: the chain started from a structural guess.  The next segment's own, independent guess
+                // either falls on the chain -- both are right -- or one of them is wrong and nothing here can tell which
+                if (guess[k] != s.first_rec) {
+                    isx_set_error("isx_bam_scan_part: the record chain walked from a guessed start disagrees with the next segment's own guess: scan the whole file instead");
+                    return ISX_ERR_IO;
+                }
+                verified = true;
+            }
+            if (!verified && si >= s0 && n_parts > 1) {
+                isx_set_error("isx_bam_scan_part: no second record start confirmed the guessed one in the two segments before this share: scan the whole file instead");
+                return ISX_ERR_IO;
+            }
             uint64_t next = first;
             if (s.first_rec >= s.ioff1) { recs[k].clear(); next = first; }
             else if (guess[k] == s.first_rec && hop_rc[k] == ISX_OK) next = nexts[k];
@@ -1173,8 +1188,32 @@ int isx_bam_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n)
     if (!bam || !n) { isx_set_error("isx_bam_insert_sizes: bad argument"); return ISX_ERR_ARG; }
     if (!bam->scanned) { isx_set_error("isx_bam_insert_sizes: scan first"); return ISX_ERR_STATE; }
     int64_t k = 0;
-    for (const PairInfo &i : bam->pairs) if (i.reads == 2) { if (out && k < cap) out[k] = i.insert; k++; }
+    const size_t n_ref = bam->ref_name.size();
+    for (size_t t = 0; t < n_ref; t++) {
+        if (!bam->ref_wanted.empty() && !bam->ref_wanted[t]) continue;      // the reference only loads the scaffolds of the fasta
+        for (uint64_t j = bam->ref_pair0[t]; j < bam->ref_pair0[t + 1]; j++) {
+            const PairInfo &i = bam->pairs[(size_t)j];
+            if (i.reads == 2) { if (out && k < cap) out[k] = i.insert; k++; }
+        }
+    }
     *n = k;
+    return ISX_OK;
+}
+
+// The scaffolds that count for the read filter: the reference builds its pair table only from the scaffolds of the fasta
+// (filter_reads.py:63-77, 157-178) -- the median insert (:213-217), the tallies and the cross-scaffold name look-ups of
+// non_discordant / all_reads never see a read of another scaffold of the BAM.  n == 0: every reference of the file.
+int isx_bam_set_wanted_refs(isx_bam *bam, const int32_t *refs, int32_t n)
+{
+    if (!bam || n < 0 || (n && !refs)) { isx_set_error("isx_bam_set_wanted_refs: bad argument"); return ISX_ERR_ARG; }
+    const size_t n_ref = bam->ref_name.size();
+    bam->ref_wanted.clear();
+    if (n == 0) return ISX_OK;
+    bam->ref_wanted.assign(n_ref, 0);
+    for (int32_t i = 0; i < n; i++) {
+        if (refs[i] < 0 || (size_t)refs[i] >= n_ref) { bam->ref_wanted.clear(); isx_set_error("isx_bam_set_wanted_refs: reference id out of range"); return ISX_ERR_ARG; }
+        bam->ref_wanted[(size_t)refs[i]] = 1;
+    }
     return ISX_OK;
 }
 
@@ -1197,6 +1236,14 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
         for (const std::string &s : B.priority_names) pr.emplace(std::string_view(s), 1);
         for (size_t i = 0; i < B.pairs.size(); i++) if (pr.count(name_of(B.pairs[i]))) B.priority[i] = 1;
     }
+    // entries of scaffolds outside the wanted set do not exist for the filter
+    std::vector<uint8_t> skip;
+    if (!B.ref_wanted.empty()) {
+        skip.assign(B.pairs.size(), 0);
+        for (size_t t = 0; t < n_ref; t++)
+            if (!B.ref_wanted[t]) std::fill(skip.begin() + (ptrdiff_t)B.ref_pair0[t], skip.begin() + (ptrdiff_t)B.ref_pair0[t + 1], (uint8_t)1);
+    }
+    auto absent = [&](size_t i) { return !skip.empty() && skip[i]; };
     isx_bam_info T = B.totals;
     T.unfiltered_pairs = T.unfiltered_singletons = T.unfiltered_reads = 0;
     T.filtered_pairs = T.filtered_singletons = T.filtered_bases = 0;
@@ -1215,7 +1262,7 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
             for (size_t i = c_lo(c); i < c_lo(c + 1); i++) {
                 PairInfo &e = B.pairs[i];
                 e.pass = false; e.in_filter = false;
-                if (e.reads == 0) continue;
+                if (e.reads == 0 || absent(i)) continue;
                 t.reads += e.reads; t.pairs += e.reads == 2; t.single += e.reads == 1;
                 e.in_filter = e.reads == 2 || B.priority[i];
             }
@@ -1228,7 +1275,7 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
         seen.reserve(B.pairs.size());
         for (size_t i = 0; i < B.pairs.size(); i++) {
             PairInfo &e = B.pairs[i];
-            if (e.reads == 0) continue;
+            if (e.reads == 0 || absent(i)) continue;
             T.unfiltered_reads += e.reads; T.unfiltered_pairs += e.reads == 2; T.unfiltered_singletons += e.reads == 1;
             auto it = seen.find(name_of(e));
             if (p->pairing_filter == 1) {               // non_discordant

@@ -140,6 +140,24 @@ def shard_scaffolds(filtered_pairs, lengths, world):
     return [[idx[j] for j in sh] for sh in lpt_shards(cost, world)]
 
 
+def scan_share(bf, rank, world, device=None):
+    """Every rank scans its share of the BAM (isx_bam_scan_part).  A share scan can fail on one rank alone (no record start
+    near its share's beginning, a truncated block): the ranks exchange a status word BEFORE the first data collective, so
+    that nobody is left waiting in an all_gather for a rank that raised.  -> True when every share was scanned; False when
+    any failed -- the caller then lets every rank scan the whole file with a fresh handle (a handle scans one share only)."""
+    from . import engine
+    ok, why = 1, ""
+    try:
+        bf.scan(part=(rank, world))
+    except engine.IsxError as e:
+        ok, why = 0, str(e)
+    if int(all_gather_concat(np.asarray([ok], dtype=np.int32), device).min()) == 0:
+        import logging
+        logging.warning("share scan failed on a rank (%s): every rank scans the whole file", why or "another rank")
+        return False
+    return True
+
+
 def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=None, **kwargs):
     """Scaffolds of ONE sorted BAM over `world` ranks.
     paired_only (the default): every rank scans only its SHARE of the file (isx_bam_scan_part) and owns the scaffolds whose
@@ -161,10 +179,19 @@ def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=N
     try:
         refs = bf.refs()
         usable = [i for i, (n, ln, _) in enumerate(refs) if n in s2s and len(s2s[n]) == ln]
+        # the read filter only ever sees the scaffolds of the fasta (filter_reads.py:63-77): every rank restricts the insert
+        # sizes it contributes, and its own filter run, to the same set
+        filter_refs = usable if len(usable) < len(refs) else []
+        bf.set_wanted_refs(filter_refs)
         extra = {}
         if sharded_scan:
             part = (rank, world)
-            bf.scan(part=part)
+            sharded_scan = scan_share(bf, rank, world, device)      # False: a share failed somewhere, everybody falls back together
+            if not sharded_scan:                                    # a handle scans one share only: a fresh one for the whole file
+                bf.close()
+                bf = engine.BamFile(bam, threads=int(kwargs.get('host_threads', 0)))
+                bf.set_wanted_refs(filter_refs)
+        if sharded_scan:
             ins = all_gather_concat(bf.insert_sizes(), device)
             median = float(np.median(ins)) if len(ins) else 0.0
             reads, _ = bf.ref_counts()
@@ -184,7 +211,7 @@ def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=N
         tabs = {}
         kw = {k: v for k, v in kwargs.items() if k != 'scan'}
         splits = pu.profile_bam(bam, fdb, None, None, s2s=s2s, null_model=null_model, scaffold_tables=tabs, bamfile=bf,
-                                **extra, **kw) if len(rows) else {}
+                                filter_refs=filter_refs, **extra, **kw) if len(rows) else {}
         _, pairs = bf.ref_counts()
         load = float(sum(pairs[t] for t in mine))
     finally:

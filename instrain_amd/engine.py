@@ -530,6 +530,12 @@ class BamFile:
             check(self.lib.isx_bam_scan_part(self.h, int(part[0]), int(part[1]), C.byref(info)))
         return self._info(info)
 
+    def set_wanted_refs(self, refs=None):
+        """the scaffolds that exist for the read filter (the reference loads only the scaffolds of the fasta,
+        filter_reads.py:63-77): reference indices, None / empty = every reference of the file"""
+        r = np.ascontiguousarray(refs if refs is not None else [], dtype=np.int32)
+        check(self.lib.isx_bam_set_wanted_refs(self.h, r.ctypes.data if len(r) else None, len(r)))
+
     def insert_sizes(self):
         n = C.c_int64(0)
         check(self.lib.isx_bam_insert_sizes(self.h, None, 0, C.byref(n)))

@@ -650,6 +650,12 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         if sR2M is None:
             if kwargs.get('priority_reads'):
                 bf.set_priority_reads(kwargs['priority_reads'])
+            # the reference's filter only ever sees the scaffolds of the fasta (filter_reads.py:63-77): a BAM mapped to a larger
+            # database must not let the other references into the median insert / the cross-scaffold look-ups
+            wanted_tids = kwargs.get('filter_refs')
+            if wanted_tids is None:
+                wanted_tids = [t for t, _, _ in plan] if len(plan) < len(refs) else []
+            bf.set_wanted_refs(wanted_tids)
             bf.filter(median_insert=kwargs.get('median_insert'), **fkw)
         else:
             for tid, name, _ in plan:

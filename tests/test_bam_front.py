@@ -439,3 +439,45 @@ def test_share_scan_argument_and_state_errors(tmp_path):
         owned += (b.ref_counts()[0] > 0)
         b.close()
     assert (owned == 1).all()
+
+
+@pytest.mark.parametrize("mode", ["paired_only", "non_discordant", "all_reads"])
+def test_filter_sees_only_the_scaffolds_of_the_fasta(tmp_path, mode):
+    """a BAM mapped to a larger database than the fasta: the reference builds its pair table from the fasta's scaffolds only
+    (filter_reads.py:63-77, 157-178), so the median insert, the tallies and the cross-scaffold name look-ups ignore the
+    other references (isx_bam_set_wanted_refs): the filter's decisions equal those on a BAM that holds only the wanted
+    scaffolds' reads -- and, for paired_only, the oracle's restatement of the reference's filter on those scaffolds"""
+    from oracle import bam_py
+    from tests import bamwriter
+    refs = [("in1", 5000), ("out", 6000), ("in2", 3000)]
+    reads = bamwriter.random_reads(5, refs, 2500)
+    path, path_sub = str(tmp_path / "db.bam"), str(tmp_path / "sub.bam")
+    bamwriter.write_bam(path, refs, reads)
+    wanted = [0, 2]
+    rrefs, rr = bam_py.read_bam(path)
+    bamwriter.write_bam(path_sub, refs, [r for r in reads if r["tid"] in wanted])
+    a = engine.BamFile(path, threads=2)
+    a.scan()
+    a.set_wanted_refs(wanted)
+    ia = a.filter(min_read_ani=0.9, pairing_filter=mode)
+    b = engine.BamFile(path_sub, threads=2)
+    b.scan()
+    ib = b.filter(min_read_ani=0.9, pairing_filter=mode)
+    for k in ("filtered_pairs", "unfiltered_pairs", "unfiltered_reads", "unfiltered_singletons", "filtered_singletons", "median_insert", "filtered_bases"):
+        assert ia[k] == ib[k], k
+    assert ia["filtered_pairs"] > 100
+    for t in range(3):
+        assert a.r2m(t) == b.r2m(t)
+    assert a.r2m(1) == {}
+    assert (np.sort(a.insert_sizes()) == np.sort(b.insert_sizes())).all()
+    # without the restriction the other scaffold's pairs count: the restriction matters
+    a.set_wanted_refs(None)
+    assert len(a.insert_sizes()) > len(b.insert_sizes())
+    if mode == "paired_only":
+        p2i = {refs[t][0]: bam_py.get_paired_reads(rr, t) for t in wanted}
+        r2m, tallies = bam_py.filter_pairs(p2i, min_read_ani=0.9)
+        assert ib["filtered_pairs"] == sum(t["filtered_pairs"] for t in tallies.values())
+        for t in wanted:
+            assert b.r2m(t) == r2m[refs[t][0]]
+    a.close()
+    b.close()

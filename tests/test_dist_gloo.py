@@ -172,3 +172,91 @@ def test_sharded_scan_two_ranks(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "SCAN_OK" in r.stdout
+
+
+def _run_workers(tmp_path, script_text, nproc, port, *args, env_extra=None):
+    script = tmp_path / ("worker_%d.py" % port)
+    script.write_text(script_text)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(env_extra or {}))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)] + list(args),
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+SCAN4_WORKER = SCAN_WORKER.replace("assert owned.sum(axis=1).min() >= 1            # every rank got something to do",
+                                   "assert (owned.sum(axis=1).min() == 0) == (os.environ.get('EXPECT_EMPTY') == '1'), owned.sum(axis=1)")
+
+
+def test_sharded_scan_four_ranks_uneven_shares(tmp_path):
+    """world 4, scaffolds of very different sizes: the shares own 1 .. many scaffolds each, the union is still the file"""
+    sys.path.insert(0, REPO)
+    from tests import bamwriter
+    refs = [("s%d" % i, ln) for i, ln in enumerate([30000, 800, 900, 15000, 700, 650, 9000, 12000, 600, 5000])]
+    path = str(tmp_path / "scan4.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(47, refs, 14000))
+    out = _run_workers(tmp_path, SCAN4_WORKER, 4, 29541, path, env_extra={"EXPECT_EMPTY": "0"})
+    assert "SCAN_OK" in out
+
+
+def test_sharded_scan_four_ranks_one_owns_nothing(tmp_path):
+    """world 4 over a BAM dominated by one long scaffold: a share that lies inside it owns no scaffold at all (its rank
+    contributes empty tables to the gather), the others still cover the file"""
+    sys.path.insert(0, REPO)
+    from tests import bamwriter
+    refs = [("big", 60000), ("small1", 2000), ("small2", 2500)]
+    path = str(tmp_path / "scan4e.bam")
+    reads = bamwriter.random_reads(48, refs[:1], 12000) + bamwriter.random_reads(49, refs[1:], 900)
+    for r in reads[12000 * 2:]:
+        pass
+    # reads of the second call carry tids relative to refs[1:]: shift them
+    n_big = sum(1 for _ in bamwriter.random_reads(48, refs[:1], 12000))
+    for r in reads[n_big:]:
+        r["tid"] += 1
+        if "mtid" in r:
+            r["mtid"] += 1
+    reads.sort(key=lambda r: (r["tid"], r["pos"]))
+    bamwriter.write_bam(path, refs, reads)
+    out = _run_workers(tmp_path, SCAN4_WORKER, 4, 29542, path, env_extra={"EXPECT_EMPTY": "1"})
+    assert "SCAN_OK" in out
+
+
+FALLBACK_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    from instrain_amd import dist as idist, engine
+    rank, local, world = idist.init_from_env(backend="gloo")
+    path = sys.argv[1]
+    bam = engine.BamFile(path, threads=2)
+    if rank == 1:                                       # this rank's share scan fails (what a share without a record start does)
+        real = bam.scan
+        def failing(part=None):
+            if part is not None:
+                raise engine.IsxError(-5, "no record starts in the two segments before this share")
+            return real(part)
+        bam.scan = failing
+    sharded = idist.scan_share(bam, rank, world)
+    assert sharded is False                            # EVERY rank learns of it, nobody hangs in the next collective
+    bam.close()
+    bam = engine.BamFile(path, threads=2)              # a handle scans one share only: a fresh one for the whole file
+    bam.scan()
+    info = bam.filter(min_read_ani=0.9)
+    med = idist.all_gather_concat(np.asarray([info["median_insert"]]))
+    assert len(med) == world and (med == med[0]).all()
+    if rank == 0:
+        print("FALLBACK_OK")
+    dist.barrier()
+    dist.destroy_process_group()
+""") % REPO
+
+
+def test_failed_share_scan_falls_back_on_every_rank(tmp_path):
+    sys.path.insert(0, REPO)
+    from tests import bamwriter
+    refs = [("s%d" % i, 5000) for i in range(6)]
+    path = str(tmp_path / "fb.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(50, refs, 3000))
+    assert "FALLBACK_OK" in _run_workers(tmp_path, FALLBACK_WORKER, 2, 29543, path)
