@@ -124,7 +124,8 @@ inline void seg_pack_bmi2(uint8_t *cd /* [160], writable: padded with code 4 */,
 
 struct Read {           // a read of the batch being expanded
     int32_t tid, pos, isize, l_seq;
-    uint16_t flag, n_cigar;
+    uint16_t flag;
+    uint32_t n_cigar;           // real operation count (a CIGAR kept in the CG tag has more than 65535)
     uint32_t pair_idx;          // index into isx_bam::pairs, 0xFFFFFFFF = not in any table
     uint64_t cigar_off;
     const uint8_t *seq;         // 4-bit codes, two per byte, where the record lies in its inflated segment (never copied)
@@ -310,6 +311,43 @@ int parse_nm(const uint8_t *p, const uint8_t *end, bool &has, int32_t &nm)
         }
         }
         if (is_nm && num) { has = true; nm = (int32_t)v; }
+    }
+    return p == end ? 0 : -1;
+}
+
+// the CG:B,I tag of a record: 1 and the operations when present, 0 when absent, -1 on a malformed aux block
+int find_long_cigar(const uint8_t *p, const uint8_t *end, const uint8_t *&ops, uint32_t &n_ops)
+{
+    while (p + 3 <= end) {
+        const bool is_cg = (p[0] == 'C' && p[1] == 'G');
+        const char t = (char)p[2];
+        p += 3;
+        size_t step = 0;
+        switch (t) {
+        case 'A': case 'c': case 'C': step = 1; break;
+        case 's': case 'S': step = 2; break;
+        case 'i': case 'I': case 'f': step = 4; break;
+        case 'Z': case 'H': {
+            const uint8_t *q = p;
+            while (q < end && *q) q++;
+            if (q >= end) return -1;
+            step = (size_t)(q - p) + 1;
+            break;
+        }
+        case 'B': {
+            if (end - p < 5) return -1;
+            const char sub = (char)p[0];
+            const int32_t cnt = rd32(p + 1);
+            const int sz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
+            if (!sz || cnt < 0 || (uint64_t)cnt * sz > (uint64_t)(end - p - 5)) return -1;
+            if (is_cg && sub == 'I') { ops = p + 5; n_ops = (uint32_t)cnt; return 1; }
+            step = 5 + (size_t)cnt * sz;
+            break;
+        }
+        default: return -1;
+        }
+        if ((size_t)(end - p) < step) return -1;
+        p += step;
     }
     return p == end ? 0 : -1;
 }
@@ -576,10 +614,13 @@ uint64_t seg_guess(const isx_bam &B, Inflater &inf, const Segment &s, SegBuf &bu
 struct RecView {        // validated fixed part of a record
     const uint8_t *p;   // at block_size
     int32_t block, tid, pos, l_seq, isize;
-    uint16_t n_cigar, flag;
+    uint32_t n_cigar;   // operations at `cigar`: the record's own, or the CG tag's when the record holds the placeholder
+    uint16_t flag;
     uint8_t l_name, mapq;
     const uint8_t *name, *cigar, *seq, *qual, *aux, *end;
 };
+
+int find_long_cigar(const uint8_t *p, const uint8_t *end, const uint8_t *&ops, uint32_t &n_ops);
 
 bool rec_view(const uint8_t *p, RecView &r)
 {
@@ -599,6 +640,20 @@ bool rec_view(const uint8_t *p, RecView &r)
     r.qual = r.seq + ((size_t)r.l_seq + 1) / 2;
     r.aux = r.qual + r.l_seq;
     r.end = p + 4 + r.block;
+    // a CIGAR of more than 65535 operations: the record holds the placeholder <l_seq>S<ref_len>N and the operations are the
+    // CG:B,I tag (SAM spec 4.2.2).  htslib moves them back when it reads the record (bam_tag2cigar, sam.c), so pysam -- and the
+    // reference with it -- never sees the placeholder; nor does anything behind this view.
+    if (r.n_cigar == 2 && r.tid >= 0) {
+        uint32_t c0, c1;
+        memcpy(&c0, r.cigar, 4); memcpy(&c1, r.cigar + 4, 4);
+        if ((c0 & 15) == CS && (int32_t)(c0 >> 4) == r.l_seq && (c1 & 15) == CN) {
+            const uint8_t *ops = nullptr;
+            uint32_t n_ops = 0;
+            const int rc = find_long_cigar(r.aux, r.end, ops, n_ops);
+            if (rc < 0) return false;
+            if (rc > 0) { r.cigar = ops; r.n_cigar = n_ops; }
+        }
+    }
     return true;
 }
 
@@ -624,16 +679,6 @@ RefSpan span_of(const uint8_t *cigar, int n_cigar, int32_t pos)
     }
     s.end = ref;
     return s;
-}
-
-// a record whose real CIGAR sits in the CG tag (> 65535 operations) is not supported: say so instead of piling
-// up the placeholder
-bool is_long_cigar_placeholder(const RecView &r)
-{
-    if (r.n_cigar != 2) return false;
-    uint32_t c0, c1;
-    memcpy(&c0, r.cigar, 4); memcpy(&c1, r.cigar + 4, 4);
-    return (c0 & 15) == CS && (int32_t)(c0 >> 4) == r.l_seq && (c1 & 15) == CN;
 }
 
 int n_threads_default();
@@ -737,8 +782,8 @@ struct Batch {
 
 void tweak_overlap(Batch &S, const Read &a, const Read &b)
 {
-    Cursor ca{S.cigars.data() + a.cigar_off, a.n_cigar, 0, 0, 0, 0};
-    Cursor cb{S.cigars.data() + b.cigar_off, b.n_cigar, 0, 0, 0, 0};
+    Cursor ca{S.cigars.data() + a.cigar_off, (int)a.n_cigar, 0, 0, 0, 0};
+    Cursor cb{S.cigars.data() + b.cigar_off, (int)b.n_cigar, 0, 0, 0, 0};
     uint8_t *aq = a.qual, *bq = b.qual;
     const uint8_t *as = a.seq, *bs = b.seq;
     int iref = b.pos;
@@ -796,7 +841,6 @@ int scan_segment(isx_bam &B, uint32_t si, const SegBuf &buf, const std::vector<u
         int32_t nm = 0;
         if (parse_nm(r.aux, r.end, has, nm) != 0) { err = "bad aux field"; return ISX_ERR_IO; }
         L.has_nm = has; L.nm = nm;
-        if (r.tid >= 0 && is_long_cigar_placeholder(r)) { err = "record with its CIGAR in the CG tag (> 65535 operations) is not supported"; return ISX_ERR_IO; }
         const RefSpan sp = span_of(r.cigar, r.n_cigar, r.pos);
         L.first = sp.first; L.last = sp.last; L.qlen = (int32_t)sp.qlen; L.any = sp.any;
         out[i] = L;
@@ -1466,7 +1510,7 @@ struct BamBatch {
         const uint8_t mq = minq;
         int64_t ref = r.pos, q = 0;
         uint64_t n_out = 0;
-        for (int k = 0; k < r.n_cigar; k++) {
+        for (uint32_t k = 0; k < r.n_cigar; k++) {
             const uint32_t c = S.cigars[r.cigar_off + (uint64_t)k];
             const int op = c & 15;
             const int64_t n = c >> 4;
@@ -1498,7 +1542,7 @@ struct BamBatch {
         uint64_t *o64 = reinterpret_cast<uint64_t *>(out);
         int64_t ref = r.pos, q = 0;
         uint32_t n_out = 0;
-        for (int k = 0; k < r.n_cigar; k++) {
+        for (uint32_t k = 0; k < r.n_cigar; k++) {
             const uint32_t c = S.cigars[r.cigar_off + (uint64_t)k];
             const int op = c & 15;
             const int64_t n = c >> 4;
@@ -1532,7 +1576,7 @@ struct BamBatch {
         const int64_t base_off = boff[(size_t)r.tid];
         const int64_t ref_len = B->ref_len[(size_t)r.tid];
         int64_t ref = r.pos, q = 0;
-        for (int k = 0; k < r.n_cigar; k++) {
+        for (uint32_t k = 0; k < r.n_cigar; k++) {
             const uint32_t c = S.cigars[r.cigar_off + (uint64_t)k];
             const int op = c & 15;
             const int64_t n = c >> 4;
@@ -1680,7 +1724,11 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
                 if (pos >= Q->reg_hi || (int64_t)pos + B.max_span <= Q->reg_lo) continue;
             }
             w.keep.push_back(i);
-            w.n_cig += rd16(q + 16);
+            if (rd16(q + 16) == 2) {                                    // maybe the placeholder of a CIGAR kept in the CG tag
+                RecView r;
+                if (!rec_view(q, r)) { w.err = "corrupt BAM record"; rc_any.store(ISX_ERR_IO); return; }
+                w.n_cig += r.n_cigar;
+            } else w.n_cig += rd16(q + 16);
             w.n_seq += (uint64_t)std::max(rd32(q + 20), 0);
         }
     });

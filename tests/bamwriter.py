@@ -18,17 +18,25 @@ def _bgzf_block(data):
     return hdr + comp + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
 
 
-def write_bam(path, refs, reads):
+def write_bam(path, refs, reads, cg_every=0):
     """refs: [(name, length)]; reads: dicts with tid,pos,mapq,flag,isize,name,cigar[(op char,len)],seq(str),qual(array),nm
-    -- must already be sorted by (tid, pos)."""
+    -- must already be sorted by (tid, pos).  cg_every = k > 0: every k-th mapped read is written the way a CIGAR of more
+    than 65535 operations is (SAM spec 4.2.2): the placeholder <l_seq>S<ref_len>N in the record, the operations in CG:B,I."""
     out = bytearray()
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
     out += b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
     for name, ln in refs:
         out += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln)
-    for r in reads:
+    for i_read, r in enumerate(reads):
         name = r["name"].encode() + b"\0"
         cig = b"".join(struct.pack("<I", (n << 4) | CIG_OP[op]) for op, n in r["cigar"])
+        n_cig = len(r["cigar"])
+        cg = b""
+        if cg_every and i_read % cg_every == 0 and r["tid"] >= 0 and n_cig:
+            ref_len = sum(n for op, n in r["cigar"] if op in "MDN=X")
+            cg = b"CGBI" + struct.pack("<i", n_cig) + cig
+            cig = struct.pack("<II", (len(r["seq"]) << 4) | CIG_OP["S"], (ref_len << 4) | CIG_OP["N"])
+            n_cig = 2
         seq = r["seq"]
         codes = [SEQ_CODE[c] for c in seq] + ([0] if len(seq) % 2 else [])
         packed = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
@@ -36,7 +44,8 @@ def write_bam(path, refs, reads):
         tags = b"" if r.get("nm") is None else b"NMC" + struct.pack("<B", r["nm"])
         if r.get("extra_tags"):
             tags = b"XSZ" + b"hello\0" + tags + b"ASi" + struct.pack("<i", -7) + b"ZBBS" + struct.pack("<iHH", 2, 1, 2)
-        body = struct.pack("<iiBBHHHiiii", r["tid"], r["pos"], len(name), r["mapq"], 4680, len(r["cigar"]), r["flag"],
+        tags = tags + cg if i_read % 2 else cg + tags
+        body = struct.pack("<iiBBHHHiiii", r["tid"], r["pos"], len(name), r["mapq"], 4680, n_cig, r["flag"],
                            len(seq), r.get("mtid", r["tid"]), r.get("mpos", 0), r["isize"]) + name + cig + packed + qual + tags
         out += struct.pack("<i", len(body)) + body
     with open(path, "wb") as f:

@@ -481,3 +481,29 @@ def test_filter_sees_only_the_scaffolds_of_the_fasta(tmp_path, mode):
             assert b.r2m(t) == r2m[refs[t][0]]
     a.close()
     b.close()
+
+
+def test_cigar_in_the_cg_tag_reads_like_the_cigar_itself(tmp_path):
+    """a CIGAR of more than 65535 operations is stored as <l_seq>S<ref_len>N + CG:B,I (SAM spec 4.2.2); htslib puts it
+    back when it reads the record (bam_tag2cigar), so pysam and the reference never see the placeholder: the same reads
+    written both ways must scan, filter and expand identically -- as observations and as read segments"""
+    from tests import bamwriter
+    refs = [("scafA", 4000), ("scafB", 900), ("scafC", 12500)]
+    reads = bamwriter.random_reads(5, refs, 5000)
+    plain, tagged = str(tmp_path / "plain.bam"), str(tmp_path / "tagged.bam")
+    bamwriter.write_bam(plain, refs, reads)
+    bamwriter.write_bam(tagged, refs, reads, cg_every=3)
+    out = []
+    for path in (plain, tagged):
+        bam = engine.BamFile(path)
+        obs, pair, bounds, sref = bam.expand(min_read_ani=0.9, window_length=1000)
+        info = dict(bam.info)
+        seg = bam.segment_refs(np.arange(3), window_length=1000, min_read_ani=0.9)
+        out.append((obs, pair, info, seg))
+        bam.close()
+    (o0, p0, i0, s0), (o1, p1, i1, s1) = out
+    assert len(o0) > 20000 and (o0 == o1).all() and (p0 == p1).all()
+    assert i0["filtered_pairs"] == i1["filtered_pairs"] > 300 and i0["n_reads"] == i1["n_reads"]
+    assert s0[0].n_seg == s1[0].n_seg > 1000
+    for f in ("gpos", "len", "mm", "pair", "bases"):
+        assert (getattr(s0[0], f) == getattr(s1[0], f)).all(), f
