@@ -380,7 +380,7 @@ def _c5_plan(scale, host_threads):
     return meta, kept, shards, n_genomes
 
 
-def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu=True, scale=1.0):
+def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu=True, scale=1.0, stage_async=True):
     """BASELINE.json configs[4]: 1000-genome database, 10 Gbp of reads, --database_mode (one mm bin; genomes
     below 1x dropped like fasta.py:110-136 does).  The kept genomes are LPT-sharded 8 ways on the reference's own cost estimate
     (read pairs, profile_controller.py:460-465); rank r streams the shards r, r + N, ... through its read-level pipe in
@@ -401,7 +401,7 @@ def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu
     gen_s = time.perf_counter() - t0
     pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["segs"].n_seg for w in ws),
                        max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
-                       pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20)
+                       pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20, stage_async=stage_async)
     stream(pipe, ws[:min(len(ws), 2 * depth)], min(len(ws), 2 * depth), depth)      # warm-up: every slot's tables and linkage buffers reach their steady size
     barrier()
     stats = []
@@ -643,6 +643,7 @@ def main():
     ap.add_argument("--variants", type=int, default=32, help="distinct batches cycled through the timed steps")
     ap.add_argument("--depth", type=int, default=4, help="pipe slots")
     ap.add_argument("--host-threads", type=int, default=0, help="staging threads of the pipe (0 = the cpus this rank may use)")
+    ap.add_argument("--sync-submit", action="store_true", help="submit_reads encodes on the caller's thread (isx_pipe_params.stage_async = 0)")
     ap.add_argument("--pin", action="store_true", help="bind the staging threads to the L3 domains of the GPU's NUMA node")
     ap.add_argument("--no-bind", action="store_true", help="do not bind the process to the GPU's NUMA node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -681,7 +682,7 @@ def main():
     host_threads = args.host_threads or max(2, min(48, host_cpus() // world))
     pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=0, max_segs=int(w["segs"].n_seg),
                        max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
-                       pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window)
+                       pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=not args.sync_submit)
 
     def barrier():
         if world > 1:
@@ -743,7 +744,7 @@ def main():
                 return float(t.item()), float(u.item()), g_ms
             return dt_c5, bases, g_ms
         c5 = c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=args.depth,
-                    with_cpu=(world == 1 and not args.no_cpu_baseline), scale=args.scale)
+                    with_cpu=(world == 1 and not args.no_cpu_baseline), scale=args.scale, stage_async=not args.sync_submit)
 
     # one BAM sharded over the ranks (every rank takes part; rank 0 reports)
     sharded = None

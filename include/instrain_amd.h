@@ -319,7 +319,11 @@ typedef struct {
                                  * 512 MiB -- 128 MiB with depth 1 --, otherwise a ring of 2 x 128 MiB -- 2 x 32 MiB --
                                  * through which it leaves in waves while it is being encoded), > 0 = a ring of that
                                  * many KiB (at least 32), < 0 = never a ring */
-    int32_t pad0;
+    int32_t stage_async;        /* read-level pipe: 1 = isx_pipe_submit_reads only queues the batch and returns its ticket; a
+                                 * thread of the pipe encodes it into staging and enqueues it (in ticket order) while the caller
+                                 * goes on.  `ref` and the isx_segs arrays must then stay valid and unchanged until
+                                 * isx_pipe_collect / isx_pipe_release of that ticket; what the encoder finds wrong with
+                                 * them (mm range, capacity ...) is reported by isx_pipe_collect */
     int64_t max_segs;           /* > 0: a READ-LEVEL pipe (isx_pipe_submit_reads / isx_pipe_submit_bam hand over read segments,
                                  * see isx_segs below; isx_pipe_submit is refused): the largest n_seg of a batch.  max_obs then
                                  * only bounds the linkage tables (0 = 150 x max_segs) */

@@ -366,24 +366,78 @@ uint64_t hash_name(const uint8_t *s, size_t n)
 
 }  // namespace
 
+// The front end's large arrays (inflated segments, per-read tables: hundreds of MB to GB per file) are written once by
+// many threads right after they are allocated.  From malloc that is one page fault per 4 KiB under the process's mm lock --
+// with 32 threads faulting at once the lock, not the memory, sets the pace -- and as many PTEs to tear down on free.
+// Blocks of 4 MiB and more are therefore mapped 2 MiB-aligned and advised MADV_HUGEPAGE (transparent huge pages in
+// "madvise" or "always" mode: one fault per 2 MiB; elsewhere the advice is a no-op).
+constexpr size_t BIG_BLOCK = (size_t)4 << 20, HUGE_PAGE = (size_t)2 << 20;
+inline size_t big_len(size_t bytes) { return (bytes + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE; }
+
+void *block_alloc(size_t bytes)
+{
+    if (bytes < BIG_BLOCK) { void *p = malloc(std::max<size_t>(bytes, 1)); if (!p) throw std::bad_alloc(); return p; }
+    const size_t len = big_len(bytes);
+    uint8_t *m = static_cast<uint8_t *>(mmap(nullptr, len + HUGE_PAGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (m == MAP_FAILED) throw std::bad_alloc();
+    uint8_t *a = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(m) + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE);
+    if (a > m) (void)munmap(m, (size_t)(a - m));
+    const size_t tail = (size_t)(m + len + HUGE_PAGE - (a + len));
+    if (tail) (void)munmap(a + len, tail);
+    (void)madvise(a, len, MADV_HUGEPAGE);
+    return a;
+}
+
+void block_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes < BIG_BLOCK) free(p);
+    else (void)munmap(p, big_len(bytes));
+}
+
 template <class T>
 struct RawBuf {                 // sized once, written once: no value initialisation (vector::resize would memset)
-    std::unique_ptr<T[]> p;
+    T *p = nullptr;
     size_t n = 0;
-    void resize(size_t m) { p.reset(new T[std::max<size_t>(m, 1)]); n = m; }
-    T *data() { return p.get(); }
-    const T *data() const { return p.get(); }
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { block_free(p, n * sizeof(T)); }
+    void resize(size_t m) { block_free(p, n * sizeof(T)); p = nullptr; n = 0; p = static_cast<T *>(block_alloc(m * sizeof(T))); n = m; }
+    T *data() { return p; }
+    const T *data() const { return p; }
     const T &operator[](size_t i) const { return p[i]; }
     T &operator[](size_t i) { return p[i]; }
     size_t size() const { return n; }
 };
 
 template <class T>
-struct NoInitAlloc : std::allocator<T> {      // vector::resize without the memset: the elements are written right after, in parallel
+struct NoInitAlloc {            // vector::resize without the memset: the elements are written right after, in parallel
+    using value_type = T;
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) noexcept {}
     template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    T *allocate(size_t n) { return static_cast<T *>(block_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t n) noexcept { block_free(p, n * sizeof(T)); }
     template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const NoInitAlloc<U> &) const noexcept { return true; }
+    template <class U> bool operator!=(const NoInitAlloc<U> &) const noexcept { return false; }
 };
+
+template <class T> using uvec = std::vector<T, NoInitAlloc<T>>;
+
+// v = n copies of x, written (and first touched) by the pool's threads
+template <class T>
+void par_assign(isxenc::HostPool &pool, uvec<T> &v, size_t n, T x)
+{
+    v.resize(n);
+    const size_t piece = (size_t)1 << 20;
+    const int n_tasks = (int)((n + piece - 1) / piece);
+    T *d = v.data();
+    auto body = [&](int t) { std::fill(d + (size_t)t * piece, d + std::min(n, ((size_t)t + 1) * piece), x); };
+    if (n_tasks > 1) pool.run(n_tasks, body); else if (n_tasks == 1) body(0);
+}
 
 // stable bucketing of the indices [0, n) by key(i) in [0, P): order lists bucket 0's indices ascending, then bucket 1's, ...
 template <class Key>
@@ -424,7 +478,7 @@ struct isx_bam {
     bool scanned = false, filtered = false;
     int32_t part = 0, n_parts = 1;                  // isx_bam_scan_part: which share of the file this handle scanned
     uint64_t n_reads = 0;
-    std::vector<uint32_t> read_pair;                // per read ordinal
+    uvec<uint32_t> read_pair;                       // per read ordinal
     std::vector<PairInfo, NoInitAlloc<PairInfo>> pairs;
     std::vector<PairInfo, NoInitAlloc<PairInfo>> pairs_scan;               // what the scan found, kept once all_reads has rewritten entries (_merge_info)
     std::vector<uint64_t> ref_pair0;                // [n_ref + 1] pairs of a reference are contiguous
@@ -436,7 +490,7 @@ struct isx_bam {
     isx_bam_info totals{};
     int64_t max_span = 0;                           // longest reference span of a read (region queries: how far back a read may start)
     // small files: the inflated segments and their record offsets stay (pass 2 neither inflates nor walks again)
-    std::vector<std::vector<uint8_t>> seg_cache;
+    std::vector<uvec<uint8_t>> seg_cache;
     std::vector<std::vector<uint64_t>> seg_cache_rec;
     std::vector<int64_t> ref_filtered_pairs, ref_reads;
     // ---- results of the last expand ----
@@ -490,7 +544,7 @@ bool inflate_range(const isx_bam &B, Inflater &inf, uint32_t b0, uint32_t b1, ui
 
 // A segment's inflated bytes plus as much of the following blocks as its last record needs.
 struct SegBuf {
-    std::vector<uint8_t> data;      // data[0] = inflated offset seg.ioff0
+    uvec<uint8_t> data;             // data[0] = inflated offset seg.ioff0 (no memset before the inflater writes it)
     uint32_t b_end = 0;             // blocks inflated so far: [seg.b0, b_end)
 };
 
@@ -775,9 +829,9 @@ int open_file(const char *path, isx_bam &B)
 // htslib sam.c tweak_overlap_quality on two reads of the batch
 struct SegBuf;
 struct Batch {
-    std::vector<Read> reads;
+    uvec<Read> reads;
     RawBuf<uint32_t> cigars;                // copied (aligned); sequences and qualities stay in the inflated segments:
-    std::vector<std::vector<uint8_t>> seg_data;
+    std::vector<uvec<uint8_t>> seg_data;
 };
 
 void tweak_overlap(Batch &S, const Read &a, const Read &b)
@@ -1054,13 +1108,27 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
         for (size_t si = s0; si < s1; si++)
             for (const ReadLite &L : B.seg_reads[si]) if (L.tid >= 0 && L.tid != t_prev) owned[(size_t)L.tid] = 1;
     }
-    for (size_t si = 0; si < n_seg; si++) {
+    // per segment on the threads: the longest reference span of a read, and the runs of reads of one reference
+    struct TidRun { int32_t tid; uint32_t i0, i1; };
+    std::vector<std::vector<TidRun>> seg_runs(n_seg);
+    std::vector<int64_t> seg_span(n_seg, 0);
+    pool.run((int)n_seg, [&](int k) {
+        const size_t si = (size_t)k;
         const auto &rs = B.seg_reads[si];
-        if (rs.empty()) continue;
+        if (rs.empty()) return;
         Segment &sg = B.segs[si];
         sg.tid_first = rs.front().tid; sg.pos_first = rs.front().pos; sg.tid_last = rs.back().tid; sg.pos_last = rs.back().pos;
-        for (const ReadLite &L : rs) if (L.any) B.max_span = std::max<int64_t>(B.max_span, L.last - (int64_t)L.pos + 1);
-    }
+        int64_t span = 0;
+        size_t i0 = 0;
+        for (size_t i = 0; i < rs.size(); i++) {
+            const ReadLite &L = rs[i];
+            if (L.any) span = std::max<int64_t>(span, L.last - (int64_t)L.pos + 1);
+            if (L.tid != rs[i0].tid) { seg_runs[si].push_back(TidRun{rs[i0].tid, (uint32_t)i0, (uint32_t)i}); i0 = i; }
+        }
+        seg_runs[si].push_back(TidRun{rs[i0].tid, (uint32_t)i0, (uint32_t)rs.size()});
+        seg_span[si] = span;
+    });
+    for (size_t si = 0; si < n_seg; si++) B.max_span = std::max(B.max_span, seg_span[si]);
 
     // ---- reference -> the run of reads that belongs to it (the file is sorted: a reference's reads are contiguous) ----
     struct Run { uint32_t seg; uint32_t i0, i1; };
@@ -1072,12 +1140,9 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
         bool unsorted = false;
         std::vector<uint8_t> closed(n_ref, 0);
         for (uint32_t si = 0; si < n_seg; si++) {
-            const auto &rs = B.seg_reads[si];
-            size_t i = 0;
-            while (i < rs.size()) {
-                const int32_t t = rs[i].tid;
-                size_t j = i;
-                while (j < rs.size() && rs[j].tid == t) j++;
+            for (const TidRun &tr : seg_runs[si]) {
+                const int32_t t = tr.tid;
+                const size_t i = tr.i0, j = tr.i1;
                 if (t >= 0 && owned[(size_t)t]) {
                     if (t != last_tid && closed[(size_t)t]) unsorted = true;
                     runs[(size_t)t].push_back(Run{si, (uint32_t)i, (uint32_t)j});
@@ -1087,7 +1152,6 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
                 }
                 if (last_tid >= 0 && t != last_tid) closed[(size_t)last_tid] = 1;
                 last_tid = t;
-                i = j;
             }
         }
         if (unsorted) { isx_set_error("BAM is not sorted by reference: the reads of a reference must be contiguous"); return ISX_ERR_IO; }
@@ -1134,7 +1198,7 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
             k0 += nr;
         }
     }
-    std::vector<ReadRef> order((size_t)(parts.empty() ? 0 : parts.back().r1));
+    uvec<ReadRef> order((size_t)(parts.empty() ? 0 : parts.back().r1));
     pool.run((int)flat.size(), [&](int k) {
         const FlatRun &f = flat[(size_t)k];
         const uint32_t P = (uint32_t)(first_part[f.ref + 1] - first_part[f.ref]);
@@ -1143,13 +1207,23 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
         for (uint32_t i = f.i0; i < f.i1; i++) order[(size_t)c[part_of(rs[i].h64, P)]++] = ReadRef{f.seg, i};
     });
     std::vector<uint64_t>().swap(cur);
-    B.read_pair.assign((size_t)B.n_reads, 0xFFFFFFFFu);
+    const double t_bucket = now();
+    par_assign(pool, B.read_pair, (size_t)B.n_reads, 0xFFFFFFFFu);
     pool.run((int)parts.size(), [&](int pi) {
         Part &pt = parts[(size_t)pi];
         NameTable tab;
         tab.init((size_t)(pt.r1 - pt.r0));
         pt.info.reserve((size_t)(pt.r1 - pt.r0) / 2 + 8);
         for (uint64_t q = pt.r0; q < pt.r1; q++) {
+            // a partition's reads lie scattered over the file: what the next ones will touch is asked for ahead of time
+            if (q + 16 < pt.r1) { const ReadRef r2 = order[(size_t)q + 16]; __builtin_prefetch(&B.seg_reads[r2.seg][r2.i]); }
+            if (q + 8 < pt.r1) {
+                const ReadRef r3 = order[(size_t)q + 8];
+                const ReadLite &L3 = B.seg_reads[r3.seg][r3.i];
+                __builtin_prefetch(B.seg_names[r3.seg].data() + L3.name_off);
+                __builtin_prefetch(&tab.key[L3.h64 & tab.mask]);
+                __builtin_prefetch(&B.read_pair[(size_t)(B.segs[r3.seg].read0 + r3.i)], 1);
+            }
             const ReadRef rr = order[(size_t)q];
             const ReadLite &L = B.seg_reads[rr.seg][rr.i];
             const char *names = B.seg_names[rr.seg].data();
@@ -1195,6 +1269,7 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
             B.read_pair[(size_t)(B.segs[rr.seg].read0 + rr.i)] = idx;       // local index for now
         }
     });
+    const double t_tables = now();
     for (auto &pt : parts) if (!pt.no_nm.empty()) { isx_set_error("read without NM tag: " + pt.no_nm); return ISX_ERR_IO; }
     // one table: a reference's partitions follow each other
     std::vector<uint64_t> part_base(parts.size() + 1, 0);
@@ -1206,16 +1281,20 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     pool.run((int)parts.size(), [&](int pi) {
         Part &pt = parts[(size_t)pi];
         std::copy(pt.info.begin(), pt.info.end(), B.pairs.begin() + (ptrdiff_t)part_base[(size_t)pi]);
-        const uint32_t base = (uint32_t)part_base[(size_t)pi];
-        for (uint64_t q = pt.r0; q < pt.r1; q++) {
-            const ReadRef rr = order[(size_t)q];
-            uint32_t &v = B.read_pair[(size_t)(B.segs[rr.seg].read0 + rr.i)];
-            if (v != 0xFFFFFFFFu) v += base;
-        }
         std::vector<PairInfo>().swap(pt.info);
     });
-    if (timing) fprintf(stderr, "[isx_bam_scan] share %d/%d: segments [%zu, %zu) of %zu, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms\n",
-                        part, n_parts, sv, s_end, n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark);
+    // local pair index -> index into the one table, read by read in file order (a read's partition follows from its hash again)
+    pool.run((int)flat.size(), [&](int k) {
+        const FlatRun &f = flat[(size_t)k];
+        const uint32_t P = (uint32_t)(first_part[f.ref + 1] - first_part[f.ref]);
+        const auto &rs = B.seg_reads[f.seg];
+        const uint64_t *pb = part_base.data() + first_part[f.ref];
+        uint32_t *v = B.read_pair.data() + B.segs[f.seg].read0;
+        for (uint32_t i = f.i0; i < f.i1; i++)
+            if (v[i] != 0xFFFFFFFFu) v[i] += (uint32_t)pb[part_of(rs[i].h64, P)];
+    });
+    if (timing) fprintf(stderr, "[isx_bam_scan] share %d/%d: segments [%zu, %zu) of %zu, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms (bucketing %.1f, tables %.1f, merge %.1f)\n",
+                        part, n_parts, sv, s_end, n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark, t_bucket - t_mark, t_tables - t_bucket, now() - t_tables);
     for (auto &v : B.seg_reads) std::vector<ReadLite>().swap(v);     // names stay until the filter has run (set_r2m / priority reads / cross-scaffold filters)
     B.totals = isx_bam_info{};
     B.totals.n_refs = (int32_t)n_ref;
@@ -1490,9 +1569,9 @@ struct BamBatch {
     isx_bam *B = nullptr;
     isx_bam_params prm{};
     Batch S;
-    std::vector<uint8_t> emit;
-    std::vector<uint32_t> pid;              // dense pair id per read
-    std::vector<uint64_t> out_at;           // [n_reads + 1] first observation of every read
+    uvec<uint8_t> emit;
+    uvec<uint32_t> pid;              // dense pair id per read
+    uvec<uint64_t> out_at;           // [n_reads + 1] first observation of every read
     std::vector<int64_t> boff;              // per reference of the file: offset in the batch's flat space, -1 = not in the batch
     int64_t n_pos = 0;
     int64_t reg_lo = 0, reg_hi = -1;        // one-reference batches: only positions [reg_lo, reg_hi) are piled up (-1 = all)
@@ -1563,8 +1642,8 @@ struct BamBatch {
     }
 
     // ---- read-level hand-over: the batch as read segments (isx_segs) instead of observations ----
-    std::vector<uint64_t> seg_at;           // [n_reads + 1] first segment of every read
-    std::vector<uint32_t> seg_gpos;         // [n_segs] flat start of every segment (the staging encoder's layout pass wants them up front)
+    uvec<uint64_t> seg_at;           // [n_reads + 1] first segment of every read
+    uvec<uint32_t> seg_gpos;                // [n_segs] flat start of every segment (the staging encoder's layout pass wants them up front)
     int64_t n_seg_bases = 0;                // columns covered by the segments (>= the observations)
 
     // calls f(flat start, query offset, columns) for every segment of read ri: the M / = / X runs of its CIGAR, truncated to
@@ -1748,7 +1827,7 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
         // inflated since the scan is handed over when no reference outside this batch has reads in it (nobody will ask
         // for it again; if somebody does it is inflated anew), copied otherwise.
         if (w.buf.data.empty()) {
-            std::vector<uint8_t> &kept = B.seg_cache[seg_list[(size_t)k]];
+            uvec<uint8_t> &kept = B.seg_cache[seg_list[(size_t)k]];
             bool others = region;
             for (int32_t t = std::max(s.tid_first, 0); t <= s.tid_last && !others; t++)
                 if (B.ref_reads[(size_t)t] > 0 && boff[(size_t)t] < 0) others = true;
@@ -1812,14 +1891,16 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
 
     // ---- which reads are piled up, dense pair ids in order of first appearance, and where every read's observations
     //      start in the stream (count per read + prefix sums, all on the threads) ----
-    Q->emit.assign(n_reads, 0);
+    par_assign(pool, Q->emit, n_reads, (uint8_t)0);
     std::vector<uint64_t> slot0(n_ref_all, 0);              // the batch's pair entries, reference after reference
     uint64_t n_slots = 0;
     for (int32_t i = 0; i < n_refs; i++) { slot0[(size_t)refs[i]] = n_slots; n_slots += B.ref_pair0[(size_t)refs[i] + 1] - B.ref_pair0[(size_t)refs[i]]; }
     // dense id of a pair = rank of its first piled-up read: per pair the smallest read index (atomic min, threads over
     // the reads), a prefix count of those first reads, then every read looks its pair's id up
-    std::vector<uint32_t> first((size_t)n_slots, 0xFFFFFFFFu), dense((size_t)n_slots, 0xFFFFFFFFu);
-    Q->pid.assign(n_reads, 0);
+    uvec<uint32_t> first, dense;
+    par_assign(pool, first, (size_t)n_slots, 0xFFFFFFFFu);
+    par_assign(pool, dense, (size_t)n_slots, 0xFFFFFFFFu);
+    par_assign(pool, Q->pid, n_reads, 0u);
     const int n_tasks = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n_reads / 2048 + 1));
     auto lo_of = [&](int t) { return n_reads * (size_t)t / (size_t)n_tasks; };
     auto slot_of = [&](const Read &r) -> size_t { return (size_t)(slot0[(size_t)r.tid] + (r.pair_idx - B.ref_pair0[(size_t)r.tid])); };
@@ -1839,9 +1920,9 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     });
     std::vector<uint32_t> firsts((size_t)n_tasks + 1, 0);
     std::vector<uint64_t> outs((size_t)n_tasks + 1, 0), segs_of((size_t)n_tasks + 1, 0), cols_of((size_t)n_tasks + 1, 0);
-    Q->out_at.assign(n_reads + 1, 0);
-    std::vector<uint32_t> seg_cnt;                  // segments of every read
-    if (as_segments) { Q->seg_at.assign(n_reads + 1, 0); seg_cnt.assign(n_reads, 0); }
+    par_assign(pool, Q->out_at, n_reads + 1, (uint64_t)0);
+    uvec<uint32_t> seg_cnt;                         // segments of every read
+    if (as_segments) { Q->seg_at.resize(n_reads + 1); par_assign(pool, seg_cnt, n_reads, 0u); }      // (seg_at: every entry is written below)
     pool.run(n_tasks, [&](int t) {
         uint32_t nf = 0;
         uint64_t no = 0, ns = 0, nc = 0;

@@ -20,14 +20,17 @@
 static thread_local std::string g_err;
 void isx_set_error(const std::string &msg) { g_err = msg; }
 
-// ---- caching device allocator (see isx_internal.h) ----
+// ---- caching allocators (see isx_internal.h): device memory, and pinned host memory ----
 namespace {
-struct DevCache {
+struct BlockCache {
     std::mutex mu;
     std::multimap<size_t, void *> free_blocks;          // class size -> block
     std::unordered_map<void *, size_t> live;            // block -> class size
     size_t cached = 0;
-    static constexpr size_t LIMIT = (size_t)48 << 30;   // of 288 GB HBM
+    const size_t limit;
+    hipError_t (*const raw_alloc)(void **, size_t);
+    hipError_t (*const raw_free)(void *);
+    BlockCache(size_t lim, hipError_t (*a)(void **, size_t), hipError_t (*f)(void *)) : limit(lim), raw_alloc(a), raw_free(f) {}
     static size_t class_of(size_t bytes)
     {
         size_t v = std::max<size_t>(bytes, 4096);
@@ -36,64 +39,69 @@ struct DevCache {
         const size_t m = (v + (((size_t)1 << e) - 1)) >> e;
         return m << e;
     }
+    void trim()
+    {
+        std::vector<void *> dead;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto &kv : free_blocks) dead.push_back(kv.second);
+            free_blocks.clear();
+            cached = 0;
+        }
+        for (void *p : dead) (void)raw_free(p);
+    }
+    hipError_t get(void **p, size_t bytes)
+    {
+        const size_t cls = class_of(bytes);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_blocks.find(cls);
+            if (it != free_blocks.end()) {
+                *p = it->second;
+                free_blocks.erase(it);
+                cached -= cls;
+                live[*p] = cls;
+                return hipSuccess;
+            }
+        }
+        hipError_t e = raw_alloc(p, cls);
+        if (e != hipSuccess) {              // give the cache back and try once more
+            trim();
+            e = raw_alloc(p, cls);
+            if (e != hipSuccess) return e;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        live[*p] = cls;
+        return hipSuccess;
+    }
+    void put(void *p)
+    {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = live.find(p);
+            if (it != live.end()) {
+                const size_t cls = it->second;
+                live.erase(it);
+                if (cached + cls <= limit) { free_blocks.emplace(cls, p); cached += cls; return; }
+            }
+        }
+        (void)raw_free(p);
+    }
 };
-DevCache &dev_cache() { static DevCache c; return c; }
+hipError_t raw_dev_alloc(void **p, size_t n) { return hipMalloc(p, n); }
+hipError_t raw_dev_free(void *p) { return hipFree(p); }
+hipError_t raw_pin_alloc(void **p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault); }
+hipError_t raw_pin_free(void *p) { return hipHostFree(p); }
+BlockCache &dev_cache() { static BlockCache c((size_t)48 << 30, raw_dev_alloc, raw_dev_free); return c; }      // of 288 GB HBM
+BlockCache &pin_cache() { static BlockCache c((size_t)8 << 30, raw_pin_alloc, raw_pin_free); return c; }
 }  // namespace
 
-hipError_t isx_dev_malloc(void **p, size_t bytes)
-{
-    DevCache &c = dev_cache();
-    const size_t cls = DevCache::class_of(bytes);
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        auto it = c.free_blocks.find(cls);
-        if (it != c.free_blocks.end()) {
-            *p = it->second;
-            c.free_blocks.erase(it);
-            c.cached -= cls;
-            c.live[*p] = cls;
-            return hipSuccess;
-        }
-    }
-    hipError_t e = hipMalloc(p, cls);
-    if (e != hipSuccess) {              // give the cache back and try once more
-        isx_dev_trim();
-        e = hipMalloc(p, cls);
-        if (e != hipSuccess) return e;
-    }
-    std::lock_guard<std::mutex> lk(c.mu);
-    c.live[*p] = cls;
-    return hipSuccess;
-}
-
-void isx_dev_free(void *p)
-{
-    if (!p) return;
-    DevCache &c = dev_cache();
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        auto it = c.live.find(p);
-        if (it != c.live.end()) {
-            const size_t cls = it->second;
-            c.live.erase(it);
-            if (c.cached + cls <= DevCache::LIMIT) { c.free_blocks.emplace(cls, p); c.cached += cls; return; }
-        }
-    }
-    (void)hipFree(p);
-}
-
-void isx_dev_trim()
-{
-    DevCache &c = dev_cache();
-    std::vector<void *> dead;
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        for (auto &kv : c.free_blocks) dead.push_back(kv.second);
-        c.free_blocks.clear();
-        c.cached = 0;
-    }
-    for (void *p : dead) (void)hipFree(p);
-}
+hipError_t isx_dev_malloc(void **p, size_t bytes) { return dev_cache().get(p, bytes); }
+void isx_dev_free(void *p) { dev_cache().put(p); }
+hipError_t isx_pin_malloc(void **p, size_t bytes) { return pin_cache().get(p, bytes); }
+void isx_pin_free(void *p) { pin_cache().put(p); }
+void isx_dev_trim() { dev_cache().trim(); pin_cache().trim(); }
 
 // host -> device through the two pinned staging buffers (hipMemcpyAsync, double-buffered);
 // `fill(dst, first, count)` writes `count` elements starting at element `first` into dst.

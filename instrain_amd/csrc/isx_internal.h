@@ -32,7 +32,11 @@ void isx_set_error(const std::string &msg);
 // happens the first time.  isx_dev_trim() (isx_ctx_destroy) really frees what is cached.
 hipError_t isx_dev_malloc(void **p, size_t bytes);
 void isx_dev_free(void *p);
-void isx_dev_trim();
+// the same for pinned host memory (a pipe's staging arenas: pinning and unpinning a few hundred MB takes tens of ms each
+// way, more than a small job's device work), at most 8 GiB kept
+hipError_t isx_pin_malloc(void **p, size_t bytes);
+void isx_pin_free(void *p);
+void isx_dev_trim();        // both caches
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \

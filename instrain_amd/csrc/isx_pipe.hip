@@ -49,7 +49,7 @@ double now_ms()
 int host_block_alloc(void **p, size_t bytes, bool pinned)
 {
     *p = nullptr;
-    if (pinned) { HIP_TRY(hipHostMalloc(p, std::max<size_t>(bytes, 1), hipHostMallocDefault)); return ISX_OK; }
+    if (pinned) { HIP_TRY(isx_pin_malloc(p, std::max<size_t>(bytes, 1))); return ISX_OK; }
     if (posix_memalign(p, 4096, std::max<size_t>(bytes, 4096)) != 0) { *p = nullptr; isx_set_error("out of host memory"); return ISX_ERR_ARG; }
     return ISX_OK;
 }
@@ -57,7 +57,7 @@ int host_block_alloc(void **p, size_t bytes, bool pinned)
 void host_block_free(void *p, bool pinned)
 {
     if (!p) return;
-    if (pinned) (void)hipHostFree(p); else free(p);
+    if (pinned) isx_pin_free(p); else free(p);
 }
 
 struct Slot {
@@ -161,6 +161,20 @@ struct isx_pipe {
     hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     size_t bounce_bytes = 0;
     std::unique_ptr<isxenc::HostPool> fin_pool;      // the finisher's own few threads (the encoder pool belongs to the caller's thread)
+    // the stager (isx_pipe_params.stage_async): isx_pipe_submit_reads only queues the batch; this thread encodes it into the
+    // slot's staging and enqueues its copies and kernels, so the caller's own per-batch work overlaps the encoding of the
+    // batch before.  Jobs are staged in ticket order; next_ticket counts the staged ones, next_promise the handed-out ones.
+    struct StageJob {
+        int64_t ticket, n_pos;
+        const uint8_t *ref;
+        std::vector<int64_t> bounds;
+        isx_segs segs;
+    };
+    std::thread stager;
+    std::deque<StageJob> stage_q;
+    std::condition_variable cv_stage;
+    int64_t next_promise = 0;
+    bool stage_stop = false;
 };
 
 // device -> plain host memory at link speed: pieces through the two pinned bounce buffers, emptied by the finisher's threads
@@ -194,6 +208,11 @@ static int bounce_d2h(isx_pipe *p, void *hdst, const void *dsrc, size_t bytes)
 static void pipe_free(isx_pipe *p)
 {
     if (!p) return;
+    if (p->stager.joinable()) {                 // it stages what was queued, then leaves
+        { std::lock_guard<std::mutex> lk(p->mu); p->stage_stop = true; }
+        p->cv_stage.notify_all();
+        p->stager.join();
+    }
     if (p->finisher.joinable()) {               // it finishes what was submitted, then leaves
         { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
         p->cv_work.notify_all();
@@ -223,18 +242,18 @@ static void pipe_free(isx_pipe *p)
         if (s.d_in) isx_dev_free(s.d_in);
         if (s.d_runs) isx_dev_free(s.d_runs);
         t_dev += now_ms() - t_x; t_x = now_ms();
-        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_in) isx_pin_free(s.h_in);
         host_block_free(s.h_runs, s.runs_pinned);
         for (hipEvent_t e : s.ev_ring) if (e) (void)hipEventDestroy(e);
         host_block_free(s.h_out, s.out_pinned);
-        if (s.h_small) (void)hipHostFree(s.h_small);
+        if (s.h_small) isx_pin_free(s.h_small);
         t_pin += now_ms() - t_x;
         for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_pass, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
     }
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_destroy] device tables %.1f ms, device arena %.1f ms, pinned staging %.1f ms, total %.1f ms\n", t_batch, t_dev, t_pin, now_ms() - t_f0);
     for (int i = 0; i < 2; i++) {
-        if (p->bounce[i]) (void)hipHostFree(p->bounce[i]);
+        if (p->bounce[i]) isx_pin_free(p->bounce[i]);
         if (p->bounce_ev[i]) (void)hipEventDestroy(p->bounce_ev[i]);
     }
     if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
@@ -323,7 +342,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.in_bytes = up(o + (size_t)p->cap_rec * p->rb + ISX_TAIL_BYTES);
     const size_t host_bytes = p->ring_half ? up(o + 2 * (size_t)p->ring_half * p->rb) : s.in_bytes;
     const double t_a0 = now_ms();
-    HIP_TRY(hipHostMalloc(&s.h_in, host_bytes, hipHostMallocDefault));
+    HIP_TRY(isx_pin_malloc(reinterpret_cast<void **>(&s.h_in), host_bytes));
     const double t_a1 = now_ms();
     HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&s.d_in), s.in_bytes));
     if (getenv("ISX_PIPE_TIMING"))
@@ -343,7 +362,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.o_snv = o; o = up(o + p->snv_prefix * sizeof(isx_snv));
     s.o_rare = o; if (dense && prm->rarefied_coverage > 0) o = up(o + p->rare_prefix * sizeof(isx_rare));
     s.small_bytes = o;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_small), std::max<size_t>(s.small_bytes, 1), hipHostMallocDefault));
+    HIP_TRY(isx_pin_malloc(reinterpret_cast<void **>(&s.h_small), std::max<size_t>(s.small_bytes, 1)));
     o = 0;
     if (dense) {
         s.o_cov16 = o; o = up(o + (size_t)cap_pos * 2);
@@ -512,6 +531,43 @@ static void finisher_main(isx_pipe *p)
     }
 }
 
+static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                              isxenc::SegJob &J, int64_t *ticket);
+
+static void stager_main(isx_pipe *p)
+{
+    for (;;) {
+        isx_pipe::StageJob job;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_stage.wait(lk, [&] { return p->stage_stop || !p->stage_q.empty(); });
+            if (p->stage_q.empty()) return;
+            job = std::move(p->stage_q.front());        // it stays "queued" (next_ticket == its ticket) until it is staged
+            p->stage_q.pop_front();
+        }
+        isxenc::SegJob J;
+        J.in = job.segs; J.n_seg = job.segs.n_seg;
+        int64_t got = -1;
+        const int rc = submit_segs_common(p, job.n_pos, job.ref, (int32_t)job.bounds.size() - 1, job.bounds.data(), J, &got);
+        if (rc != ISX_OK) {                              // the batch's ticket carries the error to isx_pipe_collect
+            Slot &s = p->slots[(size_t)(job.ticket % (int64_t)p->slots.size())];
+            std::string err(isx_last_error());
+            std::lock_guard<std::mutex> lk(p->mu);
+            s.ticket = job.ticket; s.rc = rc; s.err.swap(err); s.state = 2;
+            p->next_ticket = job.ticket + 1;
+        }
+        p->cv_done.notify_all();
+    }
+}
+
+// a synchronous submit on a pipe with a stager: what was queued before goes first
+static void drain_stager(isx_pipe *p)
+{
+    if (!p->stager.joinable()) return;
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_done.wait(lk, [&] { return p->next_ticket == p->next_promise; });
+}
+
 extern "C" {
 
 int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp, isx_pipe **out)
@@ -599,7 +655,7 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     if (!p->slots[0].out_pinned) {
         p->bounce_bytes = (size_t)16 << 20;
         for (int i = 0; i < 2 && rc == ISX_OK; i++) {
-            if (hipHostMalloc(reinterpret_cast<void **>(&p->bounce[i]), p->bounce_bytes, hipHostMallocDefault) != hipSuccess ||
+            if (isx_pin_malloc(reinterpret_cast<void **>(&p->bounce[i]), p->bounce_bytes) != hipSuccess ||
                 hipEventCreateWithFlags(&p->bounce_ev[i], hipEventDisableTiming) != hipSuccess) rc = ISX_ERR_HIP;
         }
         if (rc != ISX_OK) { isx_set_error("isx_pipe_create: bounce buffers"); pipe_free(p); return rc; }
@@ -608,6 +664,7 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     p->finisher = std::thread(finisher_main, p);
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_create] thread pool %.1f ms, %d slot(s) %.1f ms\n", t_c1 - t_c0, pp->depth, now_ms() - t_c1);
+    if (pp->stage_async && p->segs) p->stager = std::thread(stager_main, p);
     *out = p;
     return ISX_OK;
 }
@@ -671,6 +728,7 @@ static int enqueue_pass(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticket)
     {
         std::lock_guard<std::mutex> lk(p->mu);
         s.ticket = p->next_ticket++;
+        if (p->next_promise < p->next_ticket) p->next_promise = p->next_ticket;
         s.state = 1; s.rc = ISX_OK;
         *ticket = s.ticket;
         p->work.push_back(s.ticket);
@@ -760,7 +818,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     if (J.passes > 1 && J.n_groups_in > 0)            // remember how jumpy this stream is: the next batch gets its slack up front
         p->slack = std::max(p->slack, 1.25 * ((double)J.n_groups_real / (double)J.n_groups_in - 1.0) + 0.01);
     {
-        const int64_t piece = (int64_t)4 << 20;
+        const int64_t piece = (int64_t)256 << 10;
         const int n_tasks = (int)((n_pos + piece - 1) / piece);
         uint8_t *dst = s.h_in + s.off_ref;
         auto cp = [&](int t) {      // two codes per byte (piece is even): half the reference bytes cross PCIe
@@ -909,7 +967,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (erc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
     if (J.n_bases > p->pp.max_obs) { isx_set_error("isx_pipe_submit_reads: more bases than the pipe's max_obs"); return ISX_ERR_CAPACITY; }
     {
-        const int64_t piece = (int64_t)4 << 20;
+        const int64_t piece = (int64_t)256 << 10;
         const int n_tasks = (int)((n_pos + piece - 1) / piece);
         uint8_t *dst = s.h_in + s.off_ref;
         auto cp = [&](int t) {      // two codes per byte (piece is even): half the reference bytes cross PCIe
@@ -922,6 +980,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         };
         if (n_tasks > 1) p->pool->run(n_tasks, cp); else cp(0);
     }
+    const double t_ref = now_ms();
     memcpy(s.h_in + s.off_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t));
 
     // ---- this batch's geometry ----
@@ -962,8 +1021,9 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     s.encode_ms = (float)(now_ms() - t0);
     s.encode_passes = 1;
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
-        fprintf(stderr, "[isx_pipe_submit_reads] records %.2f ms, reference + bounds + windows %.2f ms; %lld segments, %lld records\n",
-                t_enc - t0, now_ms() - t_enc, (long long)J.n_seg, (long long)J.n_rec);
+        fprintf(stderr, "[isx_pipe_submit_reads] records %.2f ms, reference %.2f ms, bounds + windows %.2f ms; %lld segments, %lld records\n",
+                t_enc - t0, t_ref - t_enc, now_ms() - t_ref, (long long)J.n_seg, (long long)J.n_rec);
+    const double t_q0 = now_ms();
 
     // ---- copy-in queue: bounds | windows | reference codes, then group bases (| pair ids) | records ----
     if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
@@ -979,7 +1039,10 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         s.h2d_bytes += (int64_t)b->n_rec * 4;
     }
     HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
-    return enqueue_pass(p, s, n_pos, ticket);
+    const double t_q1 = now_ms();
+    rc = enqueue_pass(p, s, n_pos, ticket);
+    if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_submit_reads] copy-in queue %.2f ms, pass + copy-out queue %.2f ms\n", t_q1 - t_q0, now_ms() - t_q1);
+    return rc;
 }
 
 int isx_pipe_submit_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
@@ -992,6 +1055,31 @@ int isx_pipe_submit_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_
     }
     if (!p->segs) { isx_set_error("isx_pipe_submit_reads: not a read-level pipe (isx_pipe_params.max_segs == 0)"); return ISX_ERR_STATE; }
     if (p->prm.enable_linkage && segs->n_seg && !segs->pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
+    if (p->stager.joinable()) {
+        // queued for the stager: only what can be said without touching the segments is checked here, the rest comes back
+        // through isx_pipe_collect.  The caller's arrays stay its own and unchanged until that call (or isx_pipe_release).
+        if (n_pos > p->pp.max_pos || segs->n_seg > p->pp.max_segs || n_splits > p->pp.max_splits) {
+            isx_set_error("isx_pipe_submit_reads: batch larger than the pipe was created for");
+            return ISX_ERR_CAPACITY;
+        }
+        isx_pipe::StageJob job;
+        job.n_pos = n_pos; job.ref = ref; job.segs = *segs;
+        if (!p->prm.enable_linkage) job.segs.pair = nullptr;
+        job.bounds.assign(split_bounds, split_bounds + n_splits + 1);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            const int64_t t = p->next_promise, n = (int64_t)p->slots.size();
+            const Slot &s = p->slots[(size_t)(t % n)];
+            // the slot is free when the batch that had it last (ticket t - n) was staged, finished and released
+            if (t - n >= p->next_ticket || s.state != 0) { isx_set_error("isx_pipe_submit_reads: every slot is in use (collect + release the oldest batch first)"); return ISX_ERR_STATE; }
+            job.ticket = t;
+            p->next_promise = t + 1;
+            *ticket = t;
+            p->stage_q.push_back(std::move(job));
+        }
+        p->cv_stage.notify_one();
+        return ISX_OK;
+    }
     isxenc::SegJob J;
     J.in = *segs; J.n_seg = segs->n_seg;
     if (!p->prm.enable_linkage) J.in.pair = nullptr;
@@ -1024,6 +1112,7 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
     if (!p || !bam || !bp || !refs || n_refs <= 0 || !ref || !ticket) { isx_set_error("isx_pipe_submit_bam: bad argument"); return ISX_ERR_ARG; }
     BamBatch *q = nullptr;
     const double t_in = now_ms();
+    drain_stager(p);
     int rc = bam_batch_prepare(bam, bp, refs, n_refs, &q, 0, -1, p->segs);
     if (rc != ISX_OK) return rc;
     const double t_prep = now_ms();
@@ -1068,6 +1157,7 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
     {
         const double t0 = now_ms();
         std::unique_lock<std::mutex> lk(p->mu);
+        if (ticket < p->next_promise) p->cv_done.wait(lk, [&] { return p->next_ticket > ticket; });     // queued for the stager: staged first
         if (s.ticket != ticket || s.state == 0) { isx_set_error("isx_pipe_collect: unknown or already released ticket"); return ISX_ERR_STATE; }
         p->cv_done.wait(lk, [&] { return s.state == 2; });
         out->collect_wait_ms = (float)(now_ms() - t0);
@@ -1161,6 +1251,7 @@ int isx_pipe_release(isx_pipe *p, int64_t ticket)
     if (!p || ticket < 0) { isx_set_error("isx_pipe_release: bad argument"); return ISX_ERR_ARG; }
     Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
     std::unique_lock<std::mutex> lk(p->mu);
+    if (ticket < p->next_promise) p->cv_done.wait(lk, [&] { return p->next_ticket > ticket; });
     if (s.ticket != ticket || s.state == 0) { isx_set_error("isx_pipe_release: unknown or already released ticket"); return ISX_ERR_STATE; }
     p->cv_done.wait(lk, [&] { return s.state == 2; });     // never collected: its queued work drains before the slot is reused
     s.state = 0;

@@ -77,16 +77,35 @@ class Context:
         self.h = h
         self.device = device
         self._children = []         # weak references to live Batch / Pipe objects: closed before the context
+        self._closers = []          # threads closing objects handed to close_later
 
     def _adopt(self, obj):
         import weakref
         self._children.append(weakref.ref(obj))
+
+    def close_later(self, *objs):
+        """close() the objects (pipes, BAM handles), in order, on a helper thread; the context waits for it before it goes"""
+        import threading
+
+        def run():
+            for o in objs:
+                try:
+                    o.close()
+                except Exception:
+                    pass
+        self._closers = [t for t in self._closers if t.is_alive()]
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        self._closers.append(t)
 
     def set_null_model(self, lut, fallback):
         lut = np.ascontiguousarray(lut, dtype=np.int32)
         check(self.lib.isx_set_null_model(self.h, lut.ctypes.data, len(lut), int(fallback)))
 
     def close(self):
+        for t in self._closers:
+            t.join()
+        self._closers = []
         if self.h:
             for r in self._children:
                 o = r()
@@ -242,8 +261,10 @@ class Pipe:
 
     def __init__(self, ctx, max_pos, max_obs, max_splits, depth=4, host_threads=0, pin_threads=True, jump_slack=0.0,
                  min_cov=5, min_freq=0.05, min_snp=20, rarefied_coverage=50, n_mm_bins=1, enable_linkage=False,
-                 linkage_mode=0, window=0, seed=0, layout=0, want_counts=False, ring_kib=0, max_segs=0):
+                 linkage_mode=0, window=0, seed=0, layout=0, want_counts=False, ring_kib=0, max_segs=0, stage_async=False):
         self.ctx, self.lib = ctx, ctx.lib
+        self._held = {}                             # stage_async: what a queued batch still reads, by ticket
+        self.stage_async = bool(stage_async) and max_segs > 0
         self.n_mm_bins = int(n_mm_bins)
         self.min_cov = int(min_cov)
         self.want_counts = bool(want_counts)
@@ -251,7 +272,8 @@ class Pipe:
         p = Params(int(min_cov), int(min_snp), float(min_freq), int(rarefied_coverage), int(n_mm_bins),
                    1 if enable_linkage else 0, int(linkage_mode), int(window), int(seed), int(layout), 0)
         pp = _lib.PipeParams(int(max_pos), int(max_obs), int(max_splits), int(depth), int(host_threads),
-                             1 if pin_threads else 0, float(jump_slack), 1 if want_counts else 0, int(ring_kib), 0, int(max_segs))
+                             1 if pin_threads else 0, float(jump_slack), 1 if want_counts else 0, int(ring_kib),
+                             1 if self.stage_async else 0, int(max_segs))
         self.read_level = max_segs > 0
         h = C.c_void_p()
         check(self.lib.isx_pipe_create(ctx.h, C.byref(p), C.byref(pp), C.byref(h)))
@@ -279,6 +301,8 @@ class Pipe:
         t = C.c_int64(-1)
         check(self.lib.isx_pipe_submit_reads(self.h, len(ref_codes), ref_codes.ctypes.data, len(split_bounds) - 1,
                                              split_bounds.ctypes.data, C.byref(cs), C.byref(t)))
+        if self.stage_async:                        # the stager reads these until the batch is collected / released
+            self._held[t.value] = (ref_codes, segs, cs)
         return t.value
 
     def submit_bam(self, bamfile, refs, ref_codes, split_bounds=None, **kw):
@@ -369,12 +393,16 @@ class Pipe:
         return out
 
     def release(self, ticket):
-        check(self.lib.isx_pipe_release(self.h, int(ticket)))
+        try:
+            check(self.lib.isx_pipe_release(self.h, int(ticket)))
+        finally:
+            self._held.pop(int(ticket), None)
 
     def close(self):
-        if self.h:
-            self.lib.isx_pipe_destroy(self.h)
-            self.h = None
+        h, self.h = self.h, None                    # (a second close, from another thread, finds nothing to do)
+        if h:
+            self.lib.isx_pipe_destroy(h)            # (stages and finishes what is still queued)
+        self._held.clear()
 
     def __del__(self):
         try:
@@ -656,9 +684,9 @@ class BamFile:
         return self._refs
 
     def close(self):
-        if self.h:
-            self.lib.isx_bam_close(self.h)
-            self.h = None
+        h, self.h = self.h, None
+        if h:
+            self.lib.isx_bam_close(h)
 
     def __del__(self):
         try:

@@ -609,7 +609,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
 
     own_ctx = kwargs.get('ctx') is None
     own_bf = kwargs.get('bamfile') is None           # a caller's handle may already hold the scan (dist.profile_bam_sharded)
-    ctx = bf = pipe = None
+    ctx = bf = pipe = helpers = None
     try:
         ctx = kwargs.get('ctx') or engine.Context(int(kwargs.get('device', 0)))
         lut, fb = null_model_lut(null_model)
@@ -763,9 +763,17 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                 except Exception as e2:
                     fail(plan[k][1], [sp[0] for sp in plan[k][2]], e2)
 
-        groups = [layout(items) for items in item_groups]
-        need = (max(g.n_pos for g in groups), max(g.est_segs for g in groups), max(len(g.bounds) for g in groups))
-        pipe = make_pipe(need)
+        # what the largest group needs follows from the plan alone; the pipe (pinned staging, device arena: tens of ms) is set
+        # up by one helper thread while another lays the groups out (sequence codes, split tables: Python + numpy) -- a group's
+        # layout is then ready when the group before it is being handed over (isx_pipe_submit_bam runs without the GIL)
+        need = (max(sum(refs[plan[k][0]][1] for k in items) for items in item_groups),
+                max(sum(est_segs[k] for k in items) for items in item_groups),
+                max(sum(len(plan[k][2]) for k in items) + 1 for items in item_groups))
+        from concurrent.futures import ThreadPoolExecutor
+        helpers = ThreadPoolExecutor(2)
+        pipe_f = helpers.submit(make_pipe, need)
+        layouts = [helpers.submit(layout, items) for items in item_groups]
+        pipe = pipe_f.result()
         stage("setup_ms")
         in_flight = []                               # submitted, not yet collected (at most `depth`)
 
@@ -786,10 +794,14 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                 del in_flight[:]
                 run_alone(g.items)
 
-        for g in groups:
+        for gi, items in enumerate(item_groups):
             while len(in_flight) >= depth:
                 drain_one()
+            g = None
             try:
+                g = layouts[gi].result()
+                layouts[gi] = None
+                stage("layout_wait_ms")
                 ok = submit(g)
                 stage("submit_ms")
                 if not ok:
@@ -808,7 +820,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                 traceback.print_exc()
                 while in_flight:
                     drain_one()
-                run_alone(g.items)
+                run_alone(items)
         while in_flight:
             drain_one()
         return out
@@ -822,10 +834,13 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             logs.append(line)
         return out
     finally:
-        if pipe is not None:
-            pipe.close()
-        if bf is not None and own_bf:
-            bf.close()
+        if helpers is not None:
+            helpers.shutdown(wait=True)
+        dead = [o for o in (pipe, bf if own_bf else None) if o is not None]
         if own_ctx and ctx is not None:
+            for o in dead:
+                o.close()
             ctx.close()
+        elif dead:
+            ctx.close_later(*dead)                   # a caller's context: unpinning / unmapping GBs is not on the caller's time
         stage("teardown_ms")

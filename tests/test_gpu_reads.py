@@ -215,6 +215,65 @@ def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage):
     pipe.close()
 
 
+@pytest.mark.parametrize("linkage", [False, True])
+def test_queued_submits_equal_blocking_submits(ctx, linkage):
+    """isx_pipe_params.stage_async: submit_reads only queues; the pipe's stager encodes and enqueues in ticket order.  Same
+    tables as the blocking submit, slot reuse over more batches than slots, slot exhaustion refused at submit, what the
+    encoder rejects reported by collect (and the pipe goes on after it), a synchronous submit_bam-style drain at close."""
+    from instrain_amd import engine, synth
+    ws = [_c2(0.05, seed=11 + i, skip_mm=True) for i in range(3)]
+    segs = [synth.segs_from_obs(w["obs"], w["pair"]) for w in ws]
+    kw = dict(n_mm_bins=1, enable_linkage=linkage, min_snp=20)
+    cap = dict(max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(s.n_seg for s in segs),
+               max_splits=max(len(w["split_bounds"]) for w in ws), depth=2, host_threads=4, pin_threads=False)
+    want = []
+    plain = engine.Pipe(ctx, **cap, **kw)
+    for w, sg in zip(ws, segs):
+        t = plain.submit_reads(w["ref_codes"], w["split_bounds"], sg)
+        r = plain.collect(t, want_ld=linkage)
+        want.append((r["sizes"], r["snv"].copy(), r["cov16"].copy(), r["clon"].copy(), r["ld"].copy() if linkage else None))
+        plain.release(t)
+    plain.close()
+    pipe = engine.Pipe(ctx, stage_async=True, **cap, **kw)
+    order = [0, 1, 2, 1, 0, 2, 2]
+    tickets, done = [], 0
+
+    def take():
+        nonlocal done
+        r = pipe.collect(tickets[done], want_ld=linkage)
+        sz, snv, cov, clon, ld = want[order[done]]
+        assert r["sizes"] == sz and r["snv"].tobytes() == snv.tobytes()
+        assert (r["cov16"] == cov).all() and r["clon"].tobytes() == clon.tobytes()
+        if linkage:
+            assert r["ld"].tobytes() == ld.tobytes()
+        pipe.release(tickets[done])
+        done += 1
+
+    for k in order:
+        if len(tickets) - done == 2:
+            take()
+        tickets.append(pipe.submit_reads(ws[k]["ref_codes"], ws[k]["split_bounds"], segs[k]))
+    assert tickets == list(range(len(order)))
+    with pytest.raises(engine.IsxError, match="every slot is in use"):
+        pipe.submit_reads(ws[0]["ref_codes"], ws[0]["split_bounds"], segs[0])
+    while done < len(tickets):
+        take()
+    # a batch the encoder rejects: the ticket is handed out, collect reports it, the next batch is fine
+    bad = engine.SegBatch(segs[0].gpos, segs[0].len, segs[0].bases, np.full(segs[0].n_seg, 3, np.uint8), segs[0].pair)
+    tb = pipe.submit_reads(ws[0]["ref_codes"], ws[0]["split_bounds"], bad)
+    tg = pipe.submit_reads(ws[1]["ref_codes"], ws[1]["split_bounds"], segs[1])
+    assert (tb, tg) == (len(order), len(order) + 1)
+    with pytest.raises(engine.IsxError, match="mm >= n_mm_bins"):
+        pipe.collect(tb)
+    pipe.release(tb)
+    r = pipe.collect(tg, want_ld=linkage)
+    assert r["sizes"] == want[1][0] and r["snv"].tobytes() == want[1][1].tobytes()
+    pipe.release(tg)
+    # queued and never collected: close() stages and finishes it
+    pipe.submit_reads(ws[2]["ref_codes"], ws[2]["split_bounds"], segs[2])
+    pipe.close()
+
+
 def test_full_c2_reads_equal_observations(ctx):
     """BASELINE configs[1] at full size: both hand-overs, all tables identical; the segments are 1 / 4.6 of the 2-byte records"""
     from instrain_amd import engine, synth

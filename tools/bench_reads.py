@@ -44,9 +44,11 @@ def main():
         print("%-5s resident: kernel %.4f ms (min %.4f), window %d, %d x %d lanes, lds %d, record bytes %d" %
               (name, float(np.mean(ks)), float(np.min(ks)), t["pileup_window"], t["pileup_blocks"], t["pileup_threads"], t["pileup_lds_bytes"], t["record_bytes"]))
         b.close()
-    for name in ("obs", "reads"):
+    for name in ("obs", "reads", "reads queued"):
+        queued = name.endswith("queued")
+        name = name.split()[0]
         pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=w["n_obs"] if name == "obs" else 0, max_segs=segs.n_seg if name == "reads" else 0,
-                           max_splits=len(w["split_bounds"]), depth=a.depth, host_threads=a.threads, pin_threads=False, **kw)
+                           max_splits=len(w["split_bounds"]), depth=a.depth, host_threads=a.threads, pin_threads=False, stage_async=queued, **kw)
         sub = (lambda: pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], w["pair"] if a.linkage else None)) if name == "obs" else \
               (lambda: pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs))
         for phase in range(2):
@@ -54,14 +56,14 @@ def main():
             t0 = time.perf_counter()
             for i in range(a.steps):
                 if len(tickets) - done == a.depth:
-                    stats.append(pipe.collect(tickets[done], want_ld=a.linkage)["stats"]); pipe.release(tickets[done]); done += 1
+                    stats.append(pipe.collect(tickets[done], want_ld=a.linkage, densify=False)["stats"]); pipe.release(tickets[done]); done += 1
                 tickets.append(sub())
             while done < len(tickets):
-                stats.append(pipe.collect(tickets[done], want_ld=a.linkage)["stats"]); pipe.release(tickets[done]); done += 1
+                stats.append(pipe.collect(tickets[done], want_ld=a.linkage, densify=False)["stats"]); pipe.release(tickets[done]); done += 1
             dt = time.perf_counter() - t0
         mean = lambda k: float(np.mean([s[k] for s in stats]))
-        print("%-5s streamed: %.2f Gbp/s, step %.3f ms (encode %.3f, h2d %.3f [%.1f MB], kernel %.4f, d2h %.3f [%.1f MB])" %
-              (name, w["profiled_bases"] * a.steps / dt / 1e9, dt / a.steps * 1e3, mean("encode_ms"), mean("h2d_ms"), mean("h2d_bytes") / 1e6,
+        print("%-5s streamed%s: %.2f Gbp/s, step %.3f ms (encode %.3f, h2d %.3f [%.1f MB], kernel %.4f, d2h %.3f [%.1f MB])" %
+              (name, " (queued submits)" if queued else "", w["profiled_bases"] * a.steps / dt / 1e9, dt / a.steps * 1e3, mean("encode_ms"), mean("h2d_ms"), mean("h2d_bytes") / 1e6,
                mean("kernel_ms"), mean("d2h_ms"), mean("d2h_bytes") / 1e6))
         pipe.close()
     ctx.close()
