@@ -533,6 +533,18 @@ int isx_bam_set_wanted_refs(isx_bam *bam, const int32_t *refs, int32_t n);
 /* insert sizes of the two-read pairs: out may be NULL to ask for *n only (a median across files / ranks) */
 int isx_bam_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n);
 int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert /* NaN = this file's own */, isx_bam_info *info);
+/* non_discordant / all_reads over SHARES of a file (filter_reads.py:497-532 look every read name up across all scaffolds):
+ * isx_bam_pair_keys hands out, per pair entry of this handle in table order, two independent 64-bit hashes of the name,
+ * the reference it sits on and info4 = (nm, mapq, length, reads) as the scan found them (reads == 0: not an entry for
+ * the filter); h1 == NULL asks for *n only.  The caller finds the names held by more than one scaffold over all shares and
+ * tells every share about its own entries among them with isx_bam_set_cross_names: entry[i] = index into the table,
+ * occurrences[i] = how many scaffolds of the file hold the name (>= 2), info4[4 i ..] = the entry's merged info after
+ * _merge_info in header order (used by all_reads only).  isx_bam_filter then accepts those modes on a share.
+ * isx_bam_filter_insert_sizes: the inserts of what went through paired_read_filter (the values the median is taken over)
+ * after a first isx_bam_filter run -- gathered over the shares they give the file's median for the final run. */
+int isx_bam_pair_keys(isx_bam *bam, uint64_t *h1, uint64_t *h2, int32_t *tid, int64_t *info4, int64_t cap, int64_t *n);
+int isx_bam_set_cross_names(isx_bam *bam, int64_t n, const int64_t *entry, const int64_t *occurrences, const int64_t *info4);
+int isx_bam_filter_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n);
 int isx_bam_set_r2m(isx_bam *bam, int32_t ref, int64_t n, const char *names, const int64_t *offs, const int32_t *mm /* NULL = 0 */);
 /* the reference's Rdic[scaffold] as the filter left it (read pair -> mm, controller.py:274-281): sizes first (names NULL),
  * then names[name_bytes], offs[n + 1], mm[n] */

@@ -483,8 +483,8 @@ struct isx_bam {
     std::vector<PairInfo, NoInitAlloc<PairInfo>> pairs_scan;               // what the scan found, kept once all_reads has rewritten entries (_merge_info)
     std::vector<uint64_t> ref_pair0;                // [n_ref + 1] pairs of a reference are contiguous
     std::vector<uint32_t> ref_seg0, ref_seg1;       // segments holding records of the reference: [seg0, seg1]
-    std::vector<std::vector<char>> seg_names;       // name blobs, dropped after the filter (or kept for set_r2m)
-    std::vector<std::vector<ReadLite>> seg_reads;   // dropped after the pair tables are built
+    std::vector<uvec<char>> seg_names;              // name blobs, dropped after the filter (or kept for set_r2m)
+    std::vector<uvec<ReadLite>> seg_reads;          // dropped after the pair tables are built
     std::vector<uint8_t> priority;                  // per pair: its name is a priority read
     std::vector<std::string> priority_names;
     isx_bam_info totals{};
@@ -497,6 +497,10 @@ struct isx_bam {
     std::unique_ptr<isx_obs[]> obs;
     std::unique_ptr<uint32_t[]> pair;
     std::vector<uint8_t> ref_wanted;                        // isx_bam_set_wanted_refs: empty = every reference counts
+    // isx_bam_set_cross_names: what the other scaffolds of the FILE (other shares included) hold under the names of this
+    // handle's pair entries -- the one thing non_discordant / all_reads need from beyond a share
+    bool cross_set = false;
+    std::vector<int64_t> cross_idx, cross_occ, cross_info;  // entry, occurrences file-wide, merged (nm, mapq, length, reads)
     std::vector<uint32_t> seg_gpos, seg_pair, seg_bases;    // isx_bam_segment_refs: the batch as read segments
     std::vector<uint8_t> seg_len, seg_mm;
     size_t n_obs = 0;
@@ -873,8 +877,8 @@ void tweak_overlap(Batch &S, const Read &a, const Read &b)
 int scan_segment(isx_bam &B, uint32_t si, const SegBuf &buf, const std::vector<uint64_t> &rec_off, std::string &err)
 {
     const Segment &s = B.segs[si];
-    std::vector<ReadLite> &out = B.seg_reads[si];
-    std::vector<char> &names = B.seg_names[si];
+    uvec<ReadLite> &out = B.seg_reads[si];
+    uvec<char> &names = B.seg_names[si];
     out.resize(rec_off.size());
     size_t name_bytes = 0;
     const int n_ref = (int)B.ref_name.size();
@@ -1295,7 +1299,7 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     });
     if (timing) fprintf(stderr, "[isx_bam_scan] share %d/%d: segments [%zu, %zu) of %zu, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms (bucketing %.1f, tables %.1f, merge %.1f)\n",
                         part, n_parts, sv, s_end, n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark, t_bucket - t_mark, t_tables - t_bucket, now() - t_tables);
-    for (auto &v : B.seg_reads) std::vector<ReadLite>().swap(v);     // names stay until the filter has run (set_r2m / priority reads / cross-scaffold filters)
+    pool.run((int)B.seg_reads.size(), [&](int k) { uvec<ReadLite>().swap(B.seg_reads[(size_t)k]); });     // names stay until the filter has run (set_r2m / priority reads / cross-scaffold filters)
     B.totals = isx_bam_info{};
     B.totals.n_refs = (int32_t)n_ref;
     B.totals.n_reads = (int64_t)B.n_reads;
@@ -1323,6 +1327,66 @@ int isx_bam_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n)
     return ISX_OK;
 }
 
+// a second, independent hash of a name: with hash_name a 128-bit identity for names compared across shares
+static uint64_t hash_name2(const uint8_t *s, size_t n)
+{
+    uint64_t h = 0x84222325cbf29ce4ull + n * 0xC2B2AE3D27D4EB4Full;
+    for (size_t i = 0; i < n; i++) { h ^= s[i]; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 31; }
+    h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33;
+    return h;
+}
+
+int isx_bam_pair_keys(isx_bam *bam, uint64_t *h1, uint64_t *h2, int32_t *tid, int64_t *info4, int64_t cap, int64_t *n)
+{
+    if (!bam || !n) { isx_set_error("isx_bam_pair_keys: bad argument"); return ISX_ERR_ARG; }
+    isx_bam &B = *bam;
+    if (!B.scanned) { isx_set_error("isx_bam_pair_keys: scan first"); return ISX_ERR_STATE; }
+    if (B.seg_names.empty() && !B.pairs.empty()) { isx_set_error("isx_bam_pair_keys: the read names were already dropped"); return ISX_ERR_STATE; }
+    const std::vector<PairInfo, NoInitAlloc<PairInfo>> &tab = B.pairs_scan.empty() ? B.pairs : B.pairs_scan;     // what the scan found
+    *n = (int64_t)tab.size();
+    if (!h1) return ISX_OK;
+    if (!h2 || !tid || !info4 || cap < *n) { isx_set_error("isx_bam_pair_keys: arrays too small"); return ISX_ERR_ARG; }
+    const size_t n_ref = B.ref_name.size();
+    isxenc::HostPool &pool = pool_of(B);
+    pool.run((int)n_ref, [&](int t) {
+        const bool gone = !B.ref_wanted.empty() && !B.ref_wanted[(size_t)t];
+        for (uint64_t j = B.ref_pair0[(size_t)t]; j < B.ref_pair0[(size_t)t + 1]; j++) {
+            const PairInfo &e = tab[(size_t)j];
+            const uint8_t *nm = reinterpret_cast<const uint8_t *>(B.seg_names[e.name_seg].data() + e.name_off);
+            h1[j] = hash_name(nm, e.name_len); h2[j] = hash_name2(nm, e.name_len);
+            tid[j] = t;
+            info4[4 * j] = e.nm; info4[4 * j + 1] = e.mapq; info4[4 * j + 2] = e.length;
+            info4[4 * j + 3] = gone ? 0 : e.reads;          // reads == 0: the entry does not exist for the filter
+        }
+    });
+    return ISX_OK;
+}
+
+int isx_bam_set_cross_names(isx_bam *bam, int64_t n, const int64_t *entry, const int64_t *occurrences, const int64_t *info4)
+{
+    if (!bam || n < 0 || (n && (!entry || !occurrences || !info4))) { isx_set_error("isx_bam_set_cross_names: bad argument"); return ISX_ERR_ARG; }
+    isx_bam &B = *bam;
+    if (!B.scanned) { isx_set_error("isx_bam_set_cross_names: scan first"); return ISX_ERR_STATE; }
+    for (int64_t i = 0; i < n; i++)
+        if (entry[i] < 0 || (size_t)entry[i] >= B.pairs.size() || occurrences[i] < 2) { isx_set_error("isx_bam_set_cross_names: entry out of range / fewer than two occurrences"); return ISX_ERR_ARG; }
+    B.cross_idx.assign(entry, entry + n);
+    B.cross_occ.assign(occurrences, occurrences + n);
+    B.cross_info.assign(info4, info4 + 4 * n);
+    B.cross_set = true;
+    return ISX_OK;
+}
+
+int isx_bam_filter_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n)
+{
+    if (!bam || !n) { isx_set_error("isx_bam_filter_insert_sizes: bad argument"); return ISX_ERR_ARG; }
+    if (!bam->filtered) { isx_set_error("isx_bam_filter_insert_sizes: filter first"); return ISX_ERR_STATE; }
+    int64_t k = 0;
+    for (const PairInfo &e : bam->pairs)
+        if (e.in_filter && e.reads == 2) { if (out && k < cap) out[k] = e.insert; k++; }
+    *n = k;
+    return ISX_OK;
+}
+
 // The scaffolds that count for the read filter: the reference builds its pair table only from the scaffolds of the fasta
 // (filter_reads.py:63-77, 157-178) -- the median insert (:213-217), the tallies and the cross-scaffold name look-ups of
 // non_discordant / all_reads never see a read of another scaffold of the BAM.  n == 0: every reference of the file.
@@ -1346,7 +1410,7 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
     if (!bam || !p) { isx_set_error("isx_bam_filter: bad argument"); return ISX_ERR_ARG; }
     if (!bam->scanned) { isx_set_error("isx_bam_filter: scan first"); return ISX_ERR_STATE; }
     if (p->pairing_filter < 0 || p->pairing_filter > 2) { isx_set_error("pairing_filter must be 0 (paired_only), 1 (non_discordant) or 2 (all_reads)"); return ISX_ERR_ARG; }
-    if (bam->n_parts > 1 && p->pairing_filter != 0) { isx_set_error("isx_bam_filter: non_discordant / all_reads look read names up across all scaffolds: scan the whole file (isx_bam_scan), not a share of it"); return ISX_ERR_STATE; }
+    if (bam->n_parts > 1 && p->pairing_filter != 0 && !bam->cross_set) { isx_set_error("isx_bam_filter: non_discordant / all_reads look read names up across all scaffolds: scan the whole file (isx_bam_scan), or tell this share what the others hold (isx_bam_pair_keys of every share -> isx_bam_set_cross_names)"); return ISX_ERR_STATE; }
     if (bam->n_parts > 1 && std::isnan(median_insert)) { isx_set_error("isx_bam_filter: a share of the file cannot know the file's median insert: combine isx_bam_insert_sizes of all shares and pass it"); return ISX_ERR_STATE; }
     isx_bam &B = *bam;
     const size_t n_ref = B.ref_name.size();
@@ -1391,6 +1455,35 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
             }
         });
         for (const Tally &t : tl) { T.unfiltered_reads += t.reads; T.unfiltered_pairs += t.pairs; T.unfiltered_singletons += t.single; }
+    } else if (B.cross_set) {
+        // the cross-scaffold look-ups were resolved by the caller over ALL shares (isx_bam_set_cross_names): a name met k times
+        // in header order is, for non_discordant, kept when k == 1 or it is a priority read, dropped from both scaffolds when
+        // k == 2 and a KeyError of the reference when k > 2 (paired_read_filter :497-512); for all_reads every occurrence
+        // carries the merged info the caller summed (_merge_info, :514-532)
+        pool.run(C, [&](int c) {
+            Tally &t = tl[(size_t)c];
+            for (size_t i = c_lo(c); i < c_lo(c + 1); i++) {
+                PairInfo &e = B.pairs[i];
+                e.pass = false; e.in_filter = false;
+                if (e.reads == 0 || absent(i)) continue;
+                t.reads += e.reads; t.pairs += e.reads == 2; t.single += e.reads == 1;
+                e.in_filter = true;
+            }
+        });
+        for (const Tally &t : tl) { T.unfiltered_reads += t.reads; T.unfiltered_pairs += t.pairs; T.unfiltered_singletons += t.single; }
+        for (size_t j = 0; j < B.cross_idx.size(); j++) {
+            const size_t i = (size_t)B.cross_idx[j];
+            PairInfo &e = B.pairs[i];
+            if (e.reads == 0 || absent(i)) continue;
+            if (p->pairing_filter == 1) {
+                if (B.priority[i]) continue;
+                if (B.cross_occ[j] > 2) { isx_set_error("non_discordant: a read name occurs on three scaffolds (the reference fails with KeyError here)"); return ISX_ERR_ARG; }
+                e.in_filter = false;
+            } else {
+                e.nm = B.cross_info[4 * j]; e.mapq = B.cross_info[4 * j + 1]; e.length = B.cross_info[4 * j + 2]; e.reads = B.cross_info[4 * j + 3];
+                e.insert = -2; e.start = -1; e.stop = -1;
+            }
+        }
     } else {
         for (PairInfo &e : B.pairs) { e.pass = false; e.in_filter = false; }
         // names are looked up across scaffolds (pair2scaffold)
@@ -1425,20 +1518,56 @@ int isx_bam_filter(isx_bam *bam, const isx_bam_params *p, double median_insert, 
     // median insert of the pairs that went through (reads == 2)
     double median = median_insert;
     if (std::isnan(median)) {
+        // np.median of the inserts: a counting selection (inserts are a few hundred, the table covers [0, 65536)) on the threads;
+        // only a file with inserts outside the table takes the general route (gather + nth_element)
+        constexpr int64_t HB = 65536;
+        std::vector<std::vector<uint32_t>> hist((size_t)C);
+        std::vector<uint8_t> odd((size_t)C, 0);
         pool.run(C, [&](int c) {
-            std::vector<int64_t> &v = tl[(size_t)c].ins;
-            for (size_t i = c_lo(c); i < c_lo(c + 1); i++) { const PairInfo &e = B.pairs[i]; if (e.in_filter && e.reads == 2) v.push_back(e.insert); }
+            std::vector<uint32_t> &h = hist[(size_t)c];
+            h.assign((size_t)HB, 0);
+            for (size_t i = c_lo(c); i < c_lo(c + 1); i++) {
+                const PairInfo &e = B.pairs[i];
+                if (!e.in_filter || e.reads != 2) continue;
+                if (e.insert >= 0 && e.insert < HB) h[(size_t)e.insert]++; else odd[(size_t)c] = 1;
+            }
         });
-        std::vector<int64_t> ins;
-        size_t n_ins = 0;
-        for (const Tally &t : tl) n_ins += t.ins.size();
-        ins.reserve(n_ins);
-        for (Tally &t : tl) { ins.insert(ins.end(), t.ins.begin(), t.ins.end()); std::vector<int64_t>().swap(t.ins); }
-        if (!ins.empty()) {                             // np.median (selection, not a full sort)
-            const size_t n = ins.size();
-            std::nth_element(ins.begin(), ins.begin() + (ptrdiff_t)(n / 2), ins.end());
-            const double hi = (double)ins[n / 2];
-            median = (n & 1) ? hi : ((double)*std::max_element(ins.begin(), ins.begin() + (ptrdiff_t)(n / 2)) + hi) / 2.0;
+        bool any_odd = false;
+        for (uint8_t o : odd) any_odd = any_odd || o;
+        if (!any_odd) {
+            std::vector<uint64_t> tot((size_t)HB, 0);
+            const int HT = std::min(C, 16);
+            pool.run(HT, [&](int k) {
+                for (size_t v = (size_t)HB * (size_t)k / (size_t)HT; v < (size_t)HB * ((size_t)k + 1) / (size_t)HT; v++) {
+                    uint64_t a = 0;
+                    for (int c = 0; c < C; c++) a += hist[(size_t)c][v];
+                    tot[v] = a;
+                }
+            });
+            uint64_t n = 0;
+            for (uint64_t a : tot) n += a;
+            if (n) {
+                auto at_rank = [&](uint64_t r) -> int64_t { uint64_t a = 0; for (int64_t v = 0; v < HB; v++) { a += tot[(size_t)v]; if (a > r) return v; } return HB - 1; };
+                const double hi = (double)at_rank(n / 2);
+                median = (n & 1) ? hi : ((double)at_rank(n / 2 - 1) + hi) / 2.0;
+            }
+        } else {
+            std::vector<std::vector<uint32_t>>().swap(hist);
+            pool.run(C, [&](int c) {
+                std::vector<int64_t> &v = tl[(size_t)c].ins;
+                for (size_t i = c_lo(c); i < c_lo(c + 1); i++) { const PairInfo &e = B.pairs[i]; if (e.in_filter && e.reads == 2) v.push_back(e.insert); }
+            });
+            std::vector<int64_t> ins;
+            size_t n_ins = 0;
+            for (const Tally &t : tl) n_ins += t.ins.size();
+            ins.reserve(n_ins);
+            for (Tally &t : tl) { ins.insert(ins.end(), t.ins.begin(), t.ins.end()); std::vector<int64_t>().swap(t.ins); }
+            if (!ins.empty()) {                             // np.median (selection, not a full sort)
+                const size_t n = ins.size();
+                std::nth_element(ins.begin(), ins.begin() + (ptrdiff_t)(n / 2), ins.end());
+                const double hi = (double)ins[n / 2];
+                median = (n & 1) ? hi : ((double)*std::max_element(ins.begin(), ins.begin() + (ptrdiff_t)(n / 2)) + hi) / 2.0;
+            }
         }
     }
     T.median_insert = median;
@@ -1544,7 +1673,7 @@ int isx_bam_r2m(const isx_bam *bam, int32_t ref, int64_t *n, int64_t *name_bytes
 int isx_bam_drop_names(isx_bam *bam)
 {
     if (!bam) { isx_set_error("isx_bam_drop_names: bad argument"); return ISX_ERR_ARG; }
-    std::vector<std::vector<char>>().swap(bam->seg_names);
+    std::vector<uvec<char>>().swap(bam->seg_names);
     return ISX_OK;
 }
 

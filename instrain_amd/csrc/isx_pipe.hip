@@ -93,6 +93,7 @@ struct Slot {
     std::vector<isx_ld> ld_rows;            // the batch's LD rows (linkage), fetched by the finisher
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_pass = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     int64_t ticket = -1;
+    BamBatch *dead_batch = nullptr;         // isx_pipe_submit_bam: the front end's batch, freed by the finisher after the slot's work
     int state = 0;                          // 0 free, 1 submitted, 2 finished (tables on the host, linkage done)
     int rc = 0;                             // of the finishing step
     std::string err;
@@ -522,12 +523,15 @@ static void finisher_main(isx_pipe *p)
         Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
         const int rc = finish_slot(p, s);
         std::string err = rc == ISX_OK ? std::string() : std::string(isx_last_error());
+        BamBatch *dead = nullptr;
         {
             std::lock_guard<std::mutex> lk(p->mu);
             s.rc = rc; s.err.swap(err);
             s.state = 2;
+            dead = s.dead_batch; s.dead_batch = nullptr;
         }
         p->cv_done.notify_all();
+        if (dead) bam_batch_free(dead);
     }
 }
 
@@ -1139,8 +1143,15 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
         rc = submit_common(p, n_pos, ref, n_splits, split_bounds, n_obs, J, ticket);
     }
     const double t_sub = now_ms();
-    // giving a gigabyte-sized batch back to the system takes as long as encoding it: not on the caller's time
-    std::thread([](BamBatch *dead) { bam_batch_free(dead); }, Q.release()).detach();
+    // giving a gigabyte-sized batch back to the system takes as long as encoding it: not on the caller's time -- and not while
+    // the finisher works on this batch either (unmapping holds the process' address-space lock: every HIP call that maps or
+    // allocates waits for it).  The finisher drops it once the batch's tables are home.
+    if (rc == ISX_OK) {
+        std::lock_guard<std::mutex> lk(p->mu);
+        Slot &s = p->slots[(size_t)(*ticket % (int64_t)p->slots.size())];
+        if (s.ticket == *ticket && s.state == 1) s.dead_batch = Q.release();
+    }
+    if (Q) std::thread([](BamBatch *dead) { bam_batch_free(dead); }, Q.release()).detach();
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_submit_bam] prepare %.1f ms, encode + enqueue %.1f ms, free %.1f ms\n", t_prep - t_in, t_sub - t_prep, now_ms() - t_sub);
     return rc;

@@ -158,6 +158,44 @@ def scan_share(bf, rank, world, device=None):
     return True
 
 
+CROSS_DT = np.dtype([("h1", "<u8"), ("h2", "<u8"), ("tid", "<i4"), ("rank", "<i4"), ("entry", "<i8"), ("info", "<i8", (4,))])
+
+
+def resolve_cross_names(bf, rank, world, device=None):
+    """non_discordant / all_reads on a file scanned in shares: the reference looks every read name up across ALL scaffolds
+    (paired_read_filter, filter_reads.py:497-532).  Every rank hands out the 64-bit hashes of its shares' pair names (8 bytes
+    a pair -- an all_gather, not a second scan of the file by every rank), the names held more than once anywhere are found
+    from those, and only for them the full records (128-bit key, scaffold, nm / mapq / length / reads) are exchanged; each
+    rank then tells its handle how often each of its names occurs in the file and what _merge_info leaves in its entry
+    (isx_bam_set_cross_names).  Collective: every rank must call it."""
+    h1, h2, tid, info = bf.pair_keys()
+    live = np.flatnonzero(info[:, 3] > 0)
+    sh = np.sort(all_gather_concat(h1[live], device))
+    dup = np.unique(sh[1:][sh[1:] == sh[:-1]])                   # hashes met more than once in the file
+    m = live[np.isin(h1[live], dup)]
+    rec = np.zeros(len(m), dtype=CROSS_DT)
+    rec["h1"], rec["h2"], rec["tid"], rec["rank"], rec["entry"], rec["info"] = h1[m], h2[m], tid[m], rank, m, info[m]
+    r = all_gather_concat(rec, device)
+    if len(r) == 0:
+        bf.set_cross_names([], [], np.zeros((0, 4), np.int64))
+        return 0
+    # groups of one name (both hashes equal), its scaffolds in header order: a scaffold's table holds a name once
+    r = r[np.lexsort((r["tid"], r["h2"], r["h1"]))]
+    first = np.r_[True, (r["h1"][1:] != r["h1"][:-1]) | (r["h2"][1:] != r["h2"][:-1])]
+    gid = np.cumsum(first) - 1
+    start = np.flatnonzero(first)
+    occ = np.bincount(gid)[gid]
+    # _merge_info in header order: the j-th occurrence ends up with the sum of the first j, the FIRST one with the sum of all
+    # (every later scaffold merges into the entry the name was first seen in)
+    cs = np.cumsum(r["info"], axis=0)
+    pref = cs - (cs[start] - r["info"][start])[gid]
+    total = pref[np.r_[start[1:], len(r)] - 1][gid]
+    merged = np.where(first[:, None], total, pref)
+    mine = (r["rank"] == rank) & (occ >= 2)
+    bf.set_cross_names(r["entry"][mine], occ[mine], merged[mine])
+    return int(mine.sum())
+
+
 def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=None, **kwargs):
     """Scaffolds of ONE sorted BAM over `world` ranks.
     paired_only (the default): every rank scans only its SHARE of the file (isx_bam_scan_part) and owns the scaffolds whose
@@ -174,7 +212,7 @@ def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=N
     fkw = dict(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
                max_insert_relative=kwargs.get('max_insert_relative', 3), min_insert=kwargs.get('min_insert', 50),
                pairing_filter=kwargs.get('pairing_filter', 'paired_only'))
-    sharded_scan = world > 1 and fkw['pairing_filter'] == 'paired_only' and kwargs.get('scan', 'sharded') == 'sharded'
+    sharded_scan = world > 1 and kwargs.get('scan', 'sharded') == 'sharded'
     bf = engine.BamFile(bam, threads=int(kwargs.get('host_threads', 0)))
     try:
         refs = bf.refs()
@@ -192,7 +230,23 @@ def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=N
                 bf = engine.BamFile(bam, threads=int(kwargs.get('host_threads', 0)))
                 bf.set_wanted_refs(filter_refs)
         if sharded_scan:
-            ins = all_gather_concat(bf.insert_sizes(), device)
+            if fkw['pairing_filter'] == 'paired_only':
+                ins = all_gather_concat(bf.insert_sizes(), device)
+            else:
+                # names are looked up across the whole file: exchange them, run the filter's first half to see who goes through
+                # paired_read_filter (the median is taken over exactly those), and agree on failure before the next collective
+                # (a name on three scaffolds is the reference's KeyError -- on one rank only)
+                resolve_cross_names(bf, rank, world, device)
+                if kwargs.get('priority_reads'):
+                    bf.set_priority_reads(kwargs['priority_reads'])
+                ok, why = 1, ""
+                try:
+                    bf.filter(median_insert=0.0, **fkw)
+                except engine.IsxError as e:
+                    ok, why = 0, str(e)
+                if int(all_gather_concat(np.asarray([ok], dtype=np.int32), device).min()) == 0:
+                    raise engine.IsxError(-1, why or "the read filter failed on another rank")
+                ins = all_gather_concat(bf.filter_insert_sizes(), device)
             median = float(np.median(ins)) if len(ins) else 0.0
             reads, _ = bf.ref_counts()
             # a scaffold without reads starts in nobody's share: deal those round robin (they still get their empty profile)

@@ -571,6 +571,33 @@ class BamFile:
         check(self.lib.isx_bam_insert_sizes(self.h, out.ctypes.data, n.value, C.byref(n)))
         return out[:n.value]
 
+    def filter_insert_sizes(self):
+        """inserts of the pairs that went through paired_read_filter in the last filter() (what the median is taken over)"""
+        n = C.c_int64(0)
+        check(self.lib.isx_bam_filter_insert_sizes(self.h, None, 0, C.byref(n)))
+        out = np.empty(max(1, n.value), dtype=np.int64)
+        check(self.lib.isx_bam_filter_insert_sizes(self.h, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def pair_keys(self):
+        """-> (h1 u64 [n], h2 u64 [n], tid i32 [n], info i64 [n, 4] = nm, mapq, length, reads) per pair entry of this handle
+        (isx_bam_pair_keys): the names as 128-bit keys, for the cross-scaffold look-ups of a file scanned in shares"""
+        n = C.c_int64(0)
+        check(self.lib.isx_bam_pair_keys(self.h, None, None, None, None, 0, C.byref(n)))
+        k = n.value
+        h1, h2 = np.empty(k, np.uint64), np.empty(k, np.uint64)
+        tid, info = np.empty(k, np.int32), np.empty((k, 4), np.int64)
+        if k:
+            check(self.lib.isx_bam_pair_keys(self.h, h1.ctypes.data, h2.ctypes.data, tid.ctypes.data, info.ctypes.data, k, C.byref(n)))
+        return h1, h2, tid, info
+
+    def set_cross_names(self, entry, occurrences, info):
+        entry = np.ascontiguousarray(entry, dtype=np.int64)
+        occurrences = np.ascontiguousarray(occurrences, dtype=np.int64)
+        info = np.ascontiguousarray(info, dtype=np.int64).reshape(-1, 4)
+        assert len(entry) == len(occurrences) == len(info)
+        check(self.lib.isx_bam_set_cross_names(self.h, len(entry), entry.ctypes.data, occurrences.ctypes.data, info.ctypes.data))
+
     def set_priority_reads(self, names):
         blob, offs = _name_blob(list(names))
         check(self.lib.isx_bam_set_priority_reads(self.h, len(offs) - 1, blob, offs.ctypes.data))

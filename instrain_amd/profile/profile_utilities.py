@@ -640,6 +640,11 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         stage("plan_ms")
         if not plan:
             return out
+        # the scaffolds' sequence codes are made by helper threads while the front end scans the file (its passes run without
+        # the GIL); the same helpers later set the pipe up and lay the groups out
+        from concurrent.futures import ThreadPoolExecutor
+        helpers = ThreadPoolExecutor(2)
+        codes_of = [helpers.submit(lambda nm=name: engine.encode_seq(str(s2s[nm]).upper())) for _, name, _ in plan]
         # ---- read pairs: the controller's R2M, or the built-in filter ----
         bf.scan(part=kwargs.get('scan_part'))
         stage("scan_ms")
@@ -690,7 +695,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                 for (num, s, e) in splits:
                     bounds.append(off + s)
                     s_scaff.append(name); s_num.append(num); s_off.append(off); s_len.append(e - s + 1)
-                seqs.append(engine.encode_seq(str(s2s[name]).upper()))
+                seqs.append(codes_of[k].result())
                 off += refs[tid][1]
             first_split.append(len(bounds))
             bounds.append(off)
@@ -728,6 +733,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             t = g.ticket
             try:
                 res = pipe.collect(t, rare_list=False, densify=False)
+                stage("collect_wait_ms")
                 splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam,
                                           min_cov=int(kwargs.get('min_cov', 5)))
                 if kwargs.get('scaffold_tables') is not None:
@@ -769,8 +775,6 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         need = (max(sum(refs[plan[k][0]][1] for k in items) for items in item_groups),
                 max(sum(est_segs[k] for k in items) for items in item_groups),
                 max(sum(len(plan[k][2]) for k in items) + 1 for items in item_groups))
-        from concurrent.futures import ThreadPoolExecutor
-        helpers = ThreadPoolExecutor(2)
         pipe_f = helpers.submit(make_pipe, need)
         layouts = [helpers.submit(layout, items) for items in item_groups]
         pipe = pipe_f.result()

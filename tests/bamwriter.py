@@ -111,3 +111,30 @@ def random_reads(seed, refs, n_pairs, read_len=60):
     # a same-name mate pair whose second read starts at the same position (order = file order)
     reads.sort(key=lambda r: (r["tid"], r["pos"]))
     return reads
+
+
+def cross_scaffold_bam(path, seed, triple):
+    """pairs whose mates sit on two scaffolds (a twentieth of them), singletons of one name on two scaffolds, and -- `triple` --
+    names on three scaffolds (the reference's KeyError under non_discordant; merged twice under all_reads)"""
+    refs = [("s%d" % i, ln) for i, ln in enumerate([9000, 7000, 12000, 800, 6000, 5000, 11000, 4000])]
+    reads = random_reads(seed, refs, 9000)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    by_name = {}
+    for r in reads:
+        by_name.setdefault(r["name"], []).append(r)
+    extra = []
+    for name, rs in by_name.items():
+        u = rng.random()
+        if u < 0.05 and len(rs) == 2:               # second mate moves to another scaffold
+            t2 = (rs[0]["tid"] + 1 + int(rng.integers(0, len(refs) - 1))) % len(refs)
+            rs[1]["tid"] = t2
+            rs[1]["pos"] = int(rng.integers(0, refs[t2][1] - 200))
+        elif triple and u < 0.06:                   # a copy of the first read on two more scaffolds
+            for k in (1, 2):
+                c = dict(rs[0])
+                c["tid"] = (rs[0]["tid"] + k) % len(refs)
+                c["pos"] = int(rng.integers(0, refs[c["tid"]][1] - 200))
+                extra.append(c)
+    reads = sorted(reads + extra, key=lambda r: (r["tid"], r["pos"]))
+    write_bam(path, refs, reads)
+    return refs

@@ -260,3 +260,87 @@ def test_failed_share_scan_falls_back_on_every_rank(tmp_path):
     path = str(tmp_path / "fb.bam")
     bamwriter.write_bam(path, refs, bamwriter.random_reads(50, refs, 3000))
     assert "FALLBACK_OK" in _run_workers(tmp_path, FALLBACK_WORKER, 2, 29543, path)
+
+
+CROSS_WORKER = textwrap.dedent("""
+    import os, sys, zlib
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    from instrain_amd import dist as idist, engine
+    rank, local, world = idist.init_from_env(backend="gloo")
+    path, mode, expect = sys.argv[1], sys.argv[2], sys.argv[3]
+    prio = ["p7", "p13", "p21", "p40", "p55"] if len(sys.argv) > 4 else []
+    fkw = dict(pairing_filter=mode, min_read_ani=0.9)
+    bam = engine.BamFile(path, threads=2)
+    refs = bam.refs()
+    bam.scan(part=(rank, world))
+    n_cross = idist.resolve_cross_names(bam, rank, world)
+    if prio:
+        bam.set_priority_reads(prio)
+    ok, why = 1, ""
+    try:
+        bam.filter(median_insert=0.0, **fkw)
+    except engine.IsxError as e:
+        ok, why = 0, str(e)
+    oks = idist.all_gather_concat(np.asarray([ok], dtype=np.int32))
+    if expect == "keyerror":
+        assert oks.min() == 0 and (ok == 1 or "three scaffolds" in why)
+        if rank == 0:
+            print("CROSS_OK keyerror", oks.tolist())
+        dist.barrier(); dist.destroy_process_group(); sys.exit(0)
+    assert oks.min() == 1, why
+    ins = idist.all_gather_concat(bam.filter_insert_sizes())
+    median = float(np.median(ins))
+    info = bam.filter(median_insert=median, **fkw)
+    reads, pairs = bam.ref_counts()
+    dt = np.dtype([("tid", "<i4"), ("name", "<u4"), ("len", "<i4"), ("mm", "<i4")])
+    rows = []
+    for t in np.flatnonzero(reads):
+        for name, mm in bam.r2m(int(t)).items():
+            rows.append((int(t), zlib.crc32(name.encode()), len(name), int(mm)))
+    mine = np.array(rows, dtype=dt) if rows else np.zeros(0, dtype=dt)
+    tal = np.asarray([info[k] for k in ("unfiltered_reads", "unfiltered_pairs", "unfiltered_singletons", "filtered_pairs", "filtered_singletons", "filtered_bases")], dtype=np.int64)
+    tals = idist.all_gather_concat(tal).reshape(world, -1)
+    crosses = idist.all_gather_concat(np.asarray([n_cross], dtype=np.int64))
+    out = idist.gather_tables({"r2m": mine}, dst=0)
+    if rank == 0:
+        whole = engine.BamFile(path, threads=2)
+        whole.scan()
+        if prio:
+            whole.set_priority_reads(prio)
+        winfo = whole.filter(**fkw)
+        assert winfo["median_insert"] == median, (winfo["median_insert"], median)
+        exp = []
+        for t in range(len(refs)):
+            for name, mm in whole.r2m(t).items():
+                exp.append((t, zlib.crc32(name.encode()), len(name), int(mm)))
+        exp = np.sort(np.array(exp, dtype=dt), order=["tid", "name", "len"])
+        got = np.sort(out["r2m"], order=["tid", "name", "len"])
+        assert len(got) == len(exp) > 1000 and (got == exp).all(), (len(got), len(exp))
+        for i, k in enumerate(("unfiltered_reads", "unfiltered_pairs", "unfiltered_singletons", "filtered_pairs", "filtered_singletons", "filtered_bases")):
+            assert tals[:, i].sum() == winfo[k], (k, tals[:, i].tolist(), winfo[k])
+        assert crosses.sum() > 100 and (crosses > 0).sum() >= 2      # the names really straddle shares
+        print("CROSS_OK", mode, crosses.tolist(), len(got))
+    dist.barrier()
+    dist.destroy_process_group()
+""") % REPO
+
+
+def test_non_discordant_and_all_reads_over_share_scans(tmp_path):
+    """the cross-scaffold name look-ups of non_discordant / all_reads with every rank scanning only its share: name hashes
+    all-gathered, repeated names resolved, isx_bam_set_cross_names -- R2M, tallies and median equal the whole-file filter's"""
+    sys.path.insert(0, REPO)
+    from tests import bamwriter
+    p2 = str(tmp_path / "cross2.bam")
+    bamwriter.cross_scaffold_bam(p2, 71, triple=False)
+    out = _run_workers(tmp_path, CROSS_WORKER, 3, 29551, p2, "non_discordant", "ok")
+    assert "CROSS_OK non_discordant" in out
+    out = _run_workers(tmp_path, CROSS_WORKER, 3, 29552, p2, "non_discordant", "ok", "prio")
+    assert "CROSS_OK non_discordant" in out
+    p3 = str(tmp_path / "cross3.bam")
+    bamwriter.cross_scaffold_bam(p3, 73, triple=True)
+    out = _run_workers(tmp_path, CROSS_WORKER, 4, 29553, p3, "all_reads", "ok")
+    assert "CROSS_OK all_reads" in out
+    out = _run_workers(tmp_path, CROSS_WORKER, 2, 29554, p3, "non_discordant", "keyerror")
+    assert "CROSS_OK keyerror" in out

@@ -474,6 +474,8 @@ lut, fb = util.load_lut()
 model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
 model[-1] = fb
 kw = dict(min_cov=5, min_freq=0.05, min_snp=10, min_read_ani=0.9, window_length=1000, device=0)
+if len(sys.argv) > 4:
+    kw["pairing_filter"] = sys.argv[4]
 splits, tables, load = idist.profile_bam_sharded(path, seqs, model, rank, world, **kw)
 loads = [None] * world
 dist.all_gather_object(loads, (load, len(splits)))
@@ -530,6 +532,49 @@ def test_one_bam_profiled_by_two_ranks_equals_one_rank(tmp_path):
     gotl = sorted((int(x["tid"]), int(x["gpos_a"]), int(x["gpos_b"]), int(x["mm"]), int(x["total"]), int(x["countAB"])) for x in g["ld"])
     assert gotl == sorted(lrows)
     assert sorted(set(int(t) for t in g["summary"]["tid"])) == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("mode", ["all_reads", "non_discordant"])
+def test_sharded_profile_with_cross_scaffold_filters(tmp_path, mode):
+    """non_discordant / all_reads with every rank scanning only its share (dist.resolve_cross_names: read-name hashes
+    all-gathered, repeated names resolved): the gathered SNV / linkage tables equal the single-process profile of the file"""
+    import subprocess
+    import sys
+    import instrain_amd.profile as prof
+    from tests import bamwriter
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "cross.bam")
+    refs = bamwriter.cross_scaffold_bam(path, 91, triple=(mode == "all_reads"))
+    rng = np.random.Generator(np.random.PCG64(9))
+    seqs = {n: "".join(rng.choice(list("ACGT"), ln)) for n, ln in refs}
+    np.savez(str(tmp_path / "seqs.npz"), names=np.array(list(seqs)), seqs=np.array(list(seqs.values())))
+    script = tmp_path / "w.py"
+    script.write_text(SHARDED_WORKER % repo)
+    out = str(tmp_path / "gathered.npz")
+    port = "29581" if mode == "all_reads" else "29582"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), path, out, str(tmp_path / "seqs.npz"), mode],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    g = np.load(out)
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    one = prof.profile_bam(path, s2s=seqs, null_model=model, min_cov=5, min_freq=0.05, min_snp=10, min_read_ani=0.9, window_length=1000,
+                           pairing_filter=mode)
+    tid = {n: i for i, (n, _) in enumerate(refs)}
+    rows, lrows = [], []
+    for S in one.values():
+        for r_ in S.raw_snp_table.itertuples():
+            rows.append((tid[r_.scaffold], r_.position, r_.mm, r_.A, r_.C, r_.T, r_.G, r_.allele_count))
+        for r_ in S.raw_linkage_table.itertuples():
+            lrows.append((tid[r_.scaffold], r_.position_A, r_.position_B, r_.mm, r_.total, r_.countAB))
+    got = sorted((int(x["tid"]), int(x["gpos"]), int(x["mm"]), int(x["cnt"][0]), int(x["cnt"][1]), int(x["cnt"][2]), int(x["cnt"][3]),
+                  int(x["allele_count"])) for x in g["snv"])
+    assert got == sorted(rows) and len(rows) > 100
+    gotl = sorted((int(x["tid"]), int(x["gpos_a"]), int(x["gpos_b"]), int(x["mm"]), int(x["total"]), int(x["countAB"])) for x in g["ld"])
+    assert gotl == sorted(lrows)
 
 
 @pytest.mark.parametrize("mm_levels", [1, 4])
