@@ -623,6 +623,7 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
     if (!c->d_lut) { isx_set_error("isx_batch_create: call isx_set_null_model first"); return ISX_ERR_STATE; }
     if (prm->enable_linkage && n_obs && !(segs ? segs->pair : pair)) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
     if (prm->n_mm_bins < 1 || prm->n_mm_bins > 128) { isx_set_error("n_mm_bins must be in [1, 128]"); return ISX_ERR_ARG; }
+    if (prm->enable_linkage && prm->linkage_mode == 2 && prm->n_mm_bins != 1) { isx_set_error("the dense MFMA linkage path needs n_mm_bins == 1"); return ISX_ERR_ARG; }
     if (n_pos >= (int64_t)0xFFFF0000ll) { isx_set_error("flat position space must be < 2^32 - 65536"); return ISX_ERR_ARG; }
     if (split_bounds[0] != 0 || split_bounds[n_splits] != n_pos) { isx_set_error("split_bounds must span [0, n_pos]"); return ISX_ERR_ARG; }
     for (int i = 0; i < n_splits; i++)

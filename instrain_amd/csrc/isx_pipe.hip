@@ -417,6 +417,13 @@ static int finish_slot(isx_pipe *p, Slot &s)
         if (dense && p->prm.rarefied_coverage > 0)
             HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)b->n_pos, ps));
         if ((rc = launch_pass(b)) != ISX_OK) return rc;
+        {   // published here, under the launch lock like a submit's pass: finish_pass must not touch the stream's publication state
+            PileupArgs pa{};
+            pa.cursors = b->d_cursors; pa.host_state = b->d_host_state;
+            launch_publish_state(pa, b->epoch, ps);
+            b->publish_enqueued = true;
+            if (c->unpublished[b->ps] == b) c->unpublished[b->ps] = nullptr;
+        }
         redo = true;
     }
     t_fin = now_ms();
@@ -677,7 +684,24 @@ void isx_pipe_destroy(isx_pipe *p) { pipe_free(p); }
 
 // the pass queue and the copy-out queue of a slot whose copy-in has been enqueued (s.ev_h2d1 recorded), then the
 // hand-over to the finisher
+static int enqueue_pass_impl(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticket);
+
+// the copy-in queue already holds this batch: when the pass cannot be enqueued behind it the slot stays free, so nothing of
+// the batch may still be in flight on its arena when the error is returned
 static int enqueue_pass(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticket)
+{
+    const int rc = enqueue_pass_impl(p, s, n_pos, ticket);
+    if (rc != ISX_OK) {
+        const std::string why(isx_last_error());
+        (void)hipStreamSynchronize(p->s_h2d);
+        (void)hipStreamSynchronize(p->ctx->pstream[s.b->ps]);
+        (void)hipStreamSynchronize(p->s_d2h);
+        isx_set_error(why);
+    }
+    return rc;
+}
+
+static int enqueue_pass_impl(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticket)
 {
     isx_ctx *c = p->ctx;
     isx_batch *b = s.b;

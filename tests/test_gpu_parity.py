@@ -576,11 +576,13 @@ def test_dense_mfma_linkage_vs_sparse_and_oracle(ctx, seed, mLen, depth, n_sites
 
 
 def test_dense_mode_needs_single_mm_bin(ctx):
+    """linkage_mode 2 (the MFMA co-occurrence path) with more than one mm bin is refused when the batch is created"""
     from instrain_amd import engine
     obs = engine.pack_obs(np.arange(8, dtype=np.uint32), np.zeros(8, np.uint8), np.zeros(8, int))
-    b = engine.Batch(ctx, engine.encode_seq("ACGTACGT"), [0, 8], obs, np.arange(8, dtype=np.uint32), n_mm_bins=2,
-                     linkage_mode=2)
-    b.run()          # no SNP sites -> nothing to refuse yet; the mode check sits behind the first site
+    with pytest.raises(engine.IsxError, match="needs n_mm_bins == 1"):
+        engine.Batch(ctx, engine.encode_seq("ACGTACGT"), [0, 8], obs, np.arange(8, dtype=np.uint32), n_mm_bins=2, linkage_mode=2)
+    b = engine.Batch(ctx, engine.encode_seq("ACGTACGT"), [0, 8], obs, np.arange(8, dtype=np.uint32), n_mm_bins=1, linkage_mode=2)
+    b.run()
     b.close()
 
 
