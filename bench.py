@@ -58,16 +58,23 @@ def c2_workload(seed, scale=1.0, with_mm=False):
     return w
 
 
-def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense, record_bytes=8, n_rec=0, out_bytes_per_pos=20):
+def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense, record_bytes=8, n_rec=0, out_bytes_per_pos=20, ref_bytes_per_pos=1.0):
     """Bytes one launch has to move.  In: the resident stream -- record_bytes per observation (2 / 4 for
     the streams the library builds from isx_obs, 8 = isx_obs as is, SURVEY 8(d)'s figure), or for read segments
     (record_bytes 64) 64 B per record + 4 B per 16 records of position bases -- and 1 B/position of reference.  Out, dense
     (M == 1): 16 B counts + 4 B clonality per position (+ 2 B coverage in a pipe slot); mm path: 32 B per present
     (position, mm) entry."""
     b = (n_rec * 64 + n_rec // 16 * 4) if record_bytes == 64 else n_obs * record_bytes
-    b += n_pos * 1
+    b += int(n_pos * ref_bytes_per_pos)         # (a pipe slot holds the reference two codes per byte)
     b += n_pos * out_bytes_per_pos if dense else n_entries * 32
     return b
+
+
+def slot_out_bytes_per_pos(n_obs, n_pos):
+    """What k_pileup_dense writes per position in a pipe slot without want_counts (the shrunk hand-back): 16-bit coverage + fp32
+    clonality, + the 8-bit coverage a shallow batch (mean depth < 16) sends home instead -- the count table is not written at
+    all; the lists (clonalities other than 1.0, saturated coverages, SNV rows) are a few bytes per thousand positions."""
+    return 7 if n_obs < 16 * n_pos else 6
 
 
 def split_obs_ranges(obs_gpos, bounds, chunk=1024):
@@ -380,7 +387,7 @@ def _c5_plan(scale, host_threads):
     return meta, kept, shards, n_genomes
 
 
-def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu=True, scale=1.0, stage_async=True):
+def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu=True, scale=1.0, stage_async=False):
     """BASELINE.json configs[4]: 1000-genome database, 10 Gbp of reads, --database_mode (one mm bin; genomes
     below 1x dropped like fasta.py:110-136 does).  The kept genomes are LPT-sharded 8 ways on the reference's own cost estimate
     (read pairs, profile_controller.py:460-465); rank r streams the shards r, r + N, ... through its read-level pipe in
@@ -417,7 +424,7 @@ def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu
     n_obs = int(sum(w["n_obs"] for w in ws))
     n_pos = int(sum(w["n_pos"] for w in ws))
     n_rec = int(sum((w["segs"].n_seg + 15) // 16 * 16 for w in ws))
-    abytes = pileup_algorithmic_bytes(n_obs, n_pos, 0, dense=True, record_bytes=64, n_rec=n_rec, out_bytes_per_pos=22)
+    abytes = pileup_algorithmic_bytes(n_obs, n_pos, 0, dense=True, record_bytes=64, n_rec=n_rec, out_bytes_per_pos=slot_out_bytes_per_pos(n_obs, n_pos), ref_bytes_per_pos=0.5)
     k_ms = tot("kernel_ms")
     out = {"workload": "C5%s: the %d kept genomes of the 1000-genome database (%.2f Gbp of positions, %.2f Gbp of reads in all), --database_mode, "
                        "pileup + SNV call + linkage; this rank: shards %s of 8 (%.2f Gbp of reads) streamed as read segments in %d batches%s"
@@ -643,7 +650,7 @@ def main():
     ap.add_argument("--variants", type=int, default=32, help="distinct batches cycled through the timed steps")
     ap.add_argument("--depth", type=int, default=4, help="pipe slots")
     ap.add_argument("--host-threads", type=int, default=0, help="staging threads of the pipe (0 = the cpus this rank may use)")
-    ap.add_argument("--sync-submit", action="store_true", help="submit_reads encodes on the caller's thread (isx_pipe_params.stage_async = 0)")
+    ap.add_argument("--queued-submit", action="store_true", help="submit_reads only queues the batch, the pipe's stager thread encodes it (isx_pipe_params.stage_async = 1; same-box A/B in profiles/r03_stream_ab.md: no gain on a 16-cpu cgroup, the stager competes with the encoder's own threads)")
     ap.add_argument("--pin", action="store_true", help="bind the staging threads to the L3 domains of the GPU's NUMA node")
     ap.add_argument("--no-bind", action="store_true", help="do not bind the process to the GPU's NUMA node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -682,7 +689,7 @@ def main():
     host_threads = args.host_threads or max(2, min(48, host_cpus() // world))
     pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=0, max_segs=int(w["segs"].n_seg),
                        max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
-                       pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=not args.sync_submit)
+                       pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=args.queued_submit)
 
     def barrier():
         if world > 1:
@@ -744,7 +751,7 @@ def main():
                 return float(t.item()), float(u.item()), g_ms
             return dt_c5, bases, g_ms
         c5 = c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=args.depth,
-                    with_cpu=(world == 1 and not args.no_cpu_baseline), scale=args.scale, stage_async=not args.sync_submit)
+                    with_cpu=(world == 1 and not args.no_cpu_baseline), scale=args.scale, stage_async=args.queued_submit)
 
     # one BAM sharded over the ranks (every rank takes part; rank 0 reports)
     sharded = None
@@ -762,7 +769,8 @@ def main():
         k_ms = mean("kernel_ms")                 # dispatch time stamps of every pass of the timed region
         n_pos_v = int(np.mean([v["n_pos"] for v in variants]))
         n_rec = (int(w["segs"].n_seg) + 15) // 16 * 16
-        abytes = pileup_algorithmic_bytes(w["n_obs"], n_pos_v, 0, dense=True, record_bytes=64, n_rec=n_rec, out_bytes_per_pos=22)
+        abytes = pileup_algorithmic_bytes(w["n_obs"], n_pos_v, 0, dense=True, record_bytes=64, n_rec=n_rec,
+                                          out_bytes_per_pos=slot_out_bytes_per_pos(w["n_obs"], n_pos_v), ref_bytes_per_pos=0.5)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         ms_step = dt / args.steps * 1e3
         h2d_b, d2h_b = mean("h2d_bytes"), mean("d2h_bytes")
@@ -785,7 +793,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc("c2_reads_bytes_per_launch") if args.scale == 1.0 else None,
                          "algorithmic_bytes_per_launch": abytes, "record_bytes": 64,
                          "kernel_ms_avg": k_ms, "launches": len(st),
-                         "note": "durations = the dispatches' own time stamps inside the timed (streamed) region"},
+                         "note": "durations = the dispatches' own time stamps inside the timed (streamed) region; a pipe slot's kernel "
+                                 "writes 6 B/pos (16-bit coverage + clonality; no count table)"},
             "roofline_pcie": {"bound": "pcie", "direction": "host->device", "achieved": h2d_b / (ms_step * 1e-3) / 1e9,
                               "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": h2d_b / (ms_step * 1e-3) / 1e9 / PCIE_PEAK_GBS,
                               "bytes_per_step": h2d_b, "bytes_per_profiled_base": h2d_b / float(w["profiled_bases"]), "copy_ms_avg": mean("h2d_ms"),

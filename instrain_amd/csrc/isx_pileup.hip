@@ -545,6 +545,9 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 const uint32_t wd[4] = {q ? v[u].x : SEG_SKIPW, v[u].y, v[u].z, v[u].w};
                 char *lds_b = reinterpret_cast<char *>(lds);
                 const uint32_t S4 = (uint32_t)S * 4u;
+#ifdef ISX_TUNING       // ablations of the stream loop (tools/tune_reads.py): what bounds it?
+                if (dbg & 64) { ablate_acc += wd[0] ^ wd[1] ^ wd[2] ^ wd[3] ^ hdr; return; }            // loads only
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int32_t r = r0 + 10 * k;
@@ -556,6 +559,10 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
 #pragma unroll
                     for (int j = 0; j < 10; j++) {
                         const uint32_t code = __builtin_amdgcn_ubfe(w, 3 * j, 3);
+#ifdef ISX_TUNING
+                        if (dbg & 8) { ablate_acc += __umul24(code, S4) + a0 + 4u * (uint32_t)j; continue; }                          // decode, no LDS
+                        if (dbg & 16) { atomicAdd(reinterpret_cast<uint32_t *>(lds_b + ((dummy + (code & 0u)) << 2)), 1u); continue; }  // lane-private word: no conflicts
+#endif
                         atomicAdd(reinterpret_cast<uint32_t *>(lds_b + (__umul24(code, S4) + a0 + 4u * (uint32_t)j)), 1u);
                     }
                 }
@@ -654,8 +661,14 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             if (gpos >= a.n_pos) break;
             const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
             const uint32_t total = c[0] + c[1] + c[2] + c[3];
-            if (a.counts) a.counts[gpos] = make_uint4(c[0], c[1], c[2], c[3]);
-            if (a.cov16) {                      // shrunk hand-back of a pipe slot: coverage alone, 2 (or 1) bytes per position,
+#ifdef ISX_TUNING       // ablations of the epilogue (tools/tune_reads.py)
+            const bool st_ok = !(dbg & 128);    // 128: no global stores of the position-sized tables
+            const bool call_ok = !(dbg & 256);  // 256: no SNV call / clonality (as if below min_cov)
+#else
+            constexpr bool st_ok = true, call_ok = true;
+#endif
+            if (a.counts && st_ok) a.counts[gpos] = make_uint4(c[0], c[1], c[2], c[3]);
+            if (a.cov16 && st_ok) {             // shrunk hand-back of a pipe slot: coverage alone, 2 (or 1) bytes per position,
                 a.cov16[gpos] = (uint16_t)min(total, 65535u);       // exact values of the few positions beyond that in a list
                 if (a.cov8) a.cov8[gpos] = (uint8_t)min(total, 255u);
                 if (total >= a.sat_thr) {
@@ -666,10 +679,15 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             float cl = __builtin_nanf("");
             bool defer = false;
             uint32_t entry = (uint32_t)p;
-            if ((int64_t)total >= (int64_t)a.min_cov) {
+            if ((int64_t)total >= (int64_t)a.min_cov && call_ok) {
                 const int ref_base = ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : ref_at(a, gpos));
+#ifdef ISX_TUNING
+                const SiteCall sc = (dbg & 1024) ? SiteCall{-1, 1, 0, 0} : call_level(a, thr_lds, c, total, ref_base, false);    // 1024: no SNV call
+                const uint32_t mx = (dbg & 2048) ? total : max(max(c[0], c[1]), max(c[2], c[3]));                               // 2048: every clonality 1.0
+#else
                 const SiteCall sc = call_level(a, thr_lds, c, total, ref_base, false);
                 const uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
+#endif
                 if (mx == total) cl = 1.0f; else defer = true;
                 if (defer) entry |= 1u << 13;
                 if (a.clon_list && defer) atomicAdd(&scratch[S_NCLON], 1u);     // the list of clonalities other than 1.0: written below, once the window has its slots
@@ -689,9 +707,12 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             // clonTR is gated on rarefied_coverage alone (snv_utilities.py:100-102), also below min_cov
             if (a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r) { entry |= 1u << 15; if (a.rare) atomicAdd(&scratch[S_NRARE], 1u); }
             if (entry != (uint32_t)p) queue[atomicAdd(&scratch[S_NQ], 1u)] = entry;
-            if (!defer) a.clon[gpos] = cl;
+            if (!defer && st_ok) a.clon[gpos] = cl;
         }
         __syncthreads();
+#ifdef ISX_TUNING
+        if (dbg & 512) { __syncthreads(); continue; }       // 512: nothing after the first epilogue pass (no table slots, no rows)
+#endif
         const uint32_t nq = scratch[S_NQ], nrows = scratch[S_ROWS], nsites = scratch[S_SITES], nao = scratch[S_NAO];
         if (tid == 0 && nrows) scratch[S_ROW_BASE] = cur_add(a, CUR_SNV, nrows);
         if (tid == 64 && nsites) scratch[S_SITE_BASE] = cur_add(a, CUR_SITES, nsites);
