@@ -103,6 +103,32 @@ hipError_t isx_pin_malloc(void **p, size_t bytes) { return pin_cache().get(p, by
 void isx_pin_free(void *p) { pin_cache().put(p); }
 void isx_dev_trim() { dev_cache().trim(); pin_cache().trim(); }
 
+namespace {
+__global__ void __launch_bounds__(256) k_copy_out(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + i);
+        reinterpret_cast<u32x4 *>(dst)[i] = v;
+    }
+}
+}  // namespace
+
+hipError_t isx_copy_to_host(void *hdst, const void *dsrc, size_t bytes, hipStream_t stream)
+{
+    if (!bytes) return hipSuccess;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(hdst) | reinterpret_cast<uintptr_t>(dsrc)) & 15) == 0;
+    if (!aligned || bytes < ((size_t)64 << 10)) return hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
+    const size_t n16 = bytes / 16, tail = bytes - n16 * 16;
+    const int blocks = (int)std::min<size_t>(128, (n16 + 1023) / 1024);
+    hipLaunchKernelGGL(k_copy_out, dim3(blocks), dim3(256), 0, stream, static_cast<uint4 *>(hdst), static_cast<const uint4 *>(dsrc), n16);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && tail)
+        e = hipMemcpyAsync(static_cast<uint8_t *>(hdst) + n16 * 16, static_cast<const uint8_t *>(dsrc) + n16 * 16, tail, hipMemcpyDeviceToHost, stream);
+    return e;
+}
+
 // host -> device through the two pinned staging buffers (hipMemcpyAsync, double-buffered);
 // `fill(dst, first, count)` writes `count` elements starting at element `first` into dst.
 template <class T, class F>

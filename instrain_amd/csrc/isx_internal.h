@@ -38,6 +38,13 @@ hipError_t isx_pin_malloc(void **p, size_t bytes);
 void isx_pin_free(void *p);
 void isx_dev_trim();        // both caches
 
+// Device -> PINNED host memory by a copy kernel instead of the DMA engine.  hipMemcpyAsync serves both directions of this
+// stack's copies from one SDMA queue: a pipe's copy-out waited behind the next batch's copy-in and a streamed step took the SUM
+// of the two (profiles/r03_stream_ab.md).  Pinned host memory is mapped into the device's address space, so the tables leave
+// through the CUs' own store path (a few dozen workgroups keep the link's upstream direction full) while the DMA engine brings
+// the next batch in.  Falls back to hipMemcpyAsync for small or unaligned copies.
+hipError_t isx_copy_to_host(void *hdst_pinned, const void *dsrc, size_t bytes, hipStream_t stream);
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \

@@ -187,7 +187,7 @@ static int bounce_d2h(isx_pipe *p, void *hdst, const void *dsrc, size_t bytes)
     hipStream_t st = p->s_fin;
     auto issue = [&](size_t k) -> hipError_t {
         const size_t off = k * piece, len = std::min(piece, bytes - off);
-        hipError_t e = hipMemcpyAsync(p->bounce[k & 1], static_cast<const uint8_t *>(dsrc) + off, len, hipMemcpyDeviceToHost, st);
+        hipError_t e = isx_copy_to_host(p->bounce[k & 1], static_cast<const uint8_t *>(dsrc) + off, len, st);
         return e == hipSuccess ? hipEventRecord(p->bounce_ev[k & 1], st) : e;
     };
     HIP_TRY(issue(0));
@@ -431,7 +431,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
     auto fetch = [&](void *hdst, const void *dsrc, size_t bytes) -> int {
         if (!bytes) return ISX_OK;
         if (!s.out_pinned) return bounce_d2h(p, hdst, dsrc, bytes);
-        HIP_TRY(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, p->s_fin));
+        HIP_TRY(isx_copy_to_host(hdst, dsrc, bytes, p->s_fin));
         return ISX_OK;
     };
     if (dense) {
@@ -729,24 +729,24 @@ static int enqueue_pass_impl(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticke
     HIP_TRY(hipStreamWaitEvent(p->s_d2h, s.ev_pass, 0));
     HIP_TRY(hipEventRecord(s.ev_d2h0, p->s_d2h));
     const size_t snv_rows = std::min(p->snv_prefix, b->cap_snv);
-    HIP_TRY(hipMemcpyAsync(s.h_small + s.o_snv, b->d_snv, snv_rows * sizeof(isx_snv), hipMemcpyDeviceToHost, p->s_d2h));
+    HIP_TRY(isx_copy_to_host(s.h_small + s.o_snv, b->d_snv, snv_rows * sizeof(isx_snv), p->s_d2h));
     s.d2h_bytes = (int64_t)(snv_rows * sizeof(isx_snv));
     if (dense) {
         if (p->prm.rarefied_coverage > 0) {
             const size_t n = std::min(p->rare_prefix, std::min(p->cap_rare, (size_t)n_pos));
-            HIP_TRY(hipMemcpyAsync(s.h_small + s.o_rare, b->d_rare, n * sizeof(isx_rare), hipMemcpyDeviceToHost, p->s_d2h));
+            HIP_TRY(isx_copy_to_host(s.h_small + s.o_rare, b->d_rare, n * sizeof(isx_rare), p->s_d2h));
             s.d2h_bytes += (int64_t)(n * sizeof(isx_rare));
         }
         if (!b->sparse_out) s.d2h_bytes += (int64_t)n_pos * 6;
     }
     if (dense && s.out_pinned && !b->sparse_out) {     // (a plain result block / a shallow batch's tables are brought in by the finisher)
-        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_cov16, b->d_cov16, (size_t)n_pos * 2, hipMemcpyDeviceToHost, p->s_d2h));
-        HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clon, b->d_clon, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
+        HIP_TRY(isx_copy_to_host(s.h_out + s.o_cov16, b->d_cov16, (size_t)n_pos * 2, p->s_d2h));
+        HIP_TRY(isx_copy_to_host(s.h_out + s.o_clon, b->d_clon, (size_t)n_pos * 4, p->s_d2h));
         if (p->pp.want_counts) {
-            HIP_TRY(hipMemcpyAsync(s.h_out + s.o_counts, b->d_counts, (size_t)n_pos * 16, hipMemcpyDeviceToHost, p->s_d2h));
+            HIP_TRY(isx_copy_to_host(s.h_out + s.o_counts, b->d_counts, (size_t)n_pos * 16, p->s_d2h));
             s.d2h_bytes += (int64_t)n_pos * 16;
             if (p->prm.rarefied_coverage > 0) {
-                HIP_TRY(hipMemcpyAsync(s.h_out + s.o_clonr, b->d_clon_r, (size_t)n_pos * 4, hipMemcpyDeviceToHost, p->s_d2h));
+                HIP_TRY(isx_copy_to_host(s.h_out + s.o_clonr, b->d_clon_r, (size_t)n_pos * 4, p->s_d2h));
                 s.d2h_bytes += (int64_t)n_pos * 4;
             }
         }
