@@ -264,7 +264,7 @@ def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=N
         fdb = pd.DataFrame(rows, columns=["scaffold", "split_number", "start", "end"])
         tabs = {}
         kw = {k: v for k, v in kwargs.items() if k != 'scan'}
-        splits = pu.profile_bam(bam, fdb, None, None, s2s=s2s, null_model=null_model, scaffold_tables=tabs, bamfile=bf,
+        splits = pu.profile_bam(bam, fdb, None, None, s2s=s2s, null_model=null_model, scaffold_levels=tabs, bamfile=bf,
                                 filter_refs=filter_refs, **extra, **kw) if len(rows) else {}
         _, pairs = bf.ref_counts()
         load = float(sum(pairs[t] for t in mine))
@@ -294,14 +294,11 @@ def profile_bam_sharded(bam, s2s, null_model, rank, world, gather=True, device=N
             o["tid"] = tid_of[S.scaffold]
             parts.append(o)
     sm_parts = []
-    for name, t in tabs.items():
-        o = np.zeros(len(t), dtype=sm_dt)
+    for name, lv in tabs.items():                   # the device's per-(scaffold, mm) aggregates, as they came (no pandas round trip)
+        o = np.zeros(len(lv), dtype=sm_dt)
+        for n in SCAFFOLD_LEVEL_DT.names:
+            o[n] = lv[n]
         o["tid"] = tid_of[name]
-        o["mm"] = t["mm"].values
-        o["nonzero"] = np.round(t["breadth"].values * t["length"].values).astype(np.int64)
-        o["counted"] = np.round(t["breadth_minCov"].values * t["length"].values).astype(np.int64)
-        o["sum_cov"] = np.round(t["coverage"].values * t["length"].values).astype(np.uint64)
-        o["median_cov"] = t["coverage_median"].values
         sm_parts.append(o)
     tables = {"snv": np.concatenate(snv_parts) if snv_parts else np.zeros(0, snv_dt),
               "ld": np.concatenate(ld_parts) if ld_parts else np.zeros(0, ld_dt),

@@ -736,14 +736,17 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                 stage("collect_wait_ms")
                 splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam,
                                           min_cov=int(kwargs.get('min_cov', 5)))
-                if kwargs.get('scaffold_tables') is not None:
+                if kwargs.get('scaffold_tables') is not None or kwargs.get('scaffold_levels') is not None:
                     sb = np.r_[0, np.cumsum([refs[tid][1] for tid in g.tids])]
                     levels, _ = res["slot"].summarize(sb)
                     tables = splits[0]._src[0] if splits else None
                     for j, k in enumerate(g.items):
                         name = plan[k][1]
-                        snp = tables.snp_table(g.first_split[j], g.first_split[j + 1])     # the scaffold's rows in one cut
-                        kwargs['scaffold_tables'][name] = make_coverage_table(levels[j], refs[plan[k][0]][1], name, snp)
+                        if kwargs.get('scaffold_levels') is not None:       # the device's per-(scaffold, mm) aggregates as they are
+                            kwargs['scaffold_levels'][name] = levels[j][levels[j]['present'] != 0].copy()
+                        if kwargs.get('scaffold_tables') is not None:
+                            snp = tables.snp_table(g.first_split[j], g.first_split[j + 1])     # the scaffold's rows in one cut
+                            kwargs['scaffold_tables'][name] = make_coverage_table(levels[j], refs[plan[k][0]][1], name, snp)
             finally:
                 pipe.release(t)
                 g.ticket = None

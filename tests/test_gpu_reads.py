@@ -290,3 +290,35 @@ def test_full_c2_reads_equal_observations(ctx):
     b.close()
     _tables_equal(ra, rb, "C2")
     assert int(rb["counts"].sum()) == w["n_obs"]
+
+
+@pytest.mark.parametrize("linkage", [False, True])
+def test_empty_and_single_segment_batches(ctx, linkage):
+    """no read at all (a scaffold nobody mapped to), then one 1-base and one 150-base segment: a resident batch and a pipe slot
+    (first batch of a slot, then reused after a full one) hand back all-zero coverage / the one column, no SNV, no LD rows"""
+    from instrain_amd import engine
+    n_pos = 5000
+    ref = np.zeros(n_pos, np.uint8)
+    bounds = [0, 2500, n_pos]
+    empty = engine.SegBatch(np.zeros(0, np.uint32), np.zeros(0, np.uint8), np.zeros((0, 15), np.uint32), np.zeros(0, np.uint8), np.zeros(0, np.uint32))
+    b = engine.Batch(ctx, ref, bounds, empty, n_mm_bins=1, enable_linkage=linkage)
+    b.run()
+    r = b.fetch()
+    assert r["counts"].sum() == 0 and len(r["snv"]) == 0 and len(r["ld"]) == 0 and np.isnan(r["clon"]).all()
+    b.close()
+    codes = np.full(150, 1, np.uint8)           # 150 x 'C' against a reference of 'A': below min_cov, so no SNV rows
+    one = np.full(150, 4, np.uint8)             # unused slots hold code 4
+    one[0] = 1
+    two = engine.SegBatch(np.array([7, 2400], np.uint32), np.array([1, 150], np.uint8),
+                          engine.pack_codes(np.stack([one, codes])), np.zeros(2, np.uint8), np.array([0, 1], np.uint32))
+    pipe = engine.Pipe(ctx, max_pos=n_pos, max_obs=0, max_segs=4096, max_splits=4, depth=1, host_threads=2, pin_threads=False,
+                       n_mm_bins=1, enable_linkage=linkage, want_counts=True)
+    for segs, cols in ((empty, 0), (two, 151), (empty, 0)):
+        t = pipe.submit_reads(ref, bounds, segs)
+        r = pipe.collect(t)
+        assert int(r["counts"].sum()) == cols and len(r["snv"]) == 0
+        if cols:
+            assert r["counts"][7, 1] == 1 and (r["counts"][2400:2550, 1] == 1).all() and r["counts"][:, [0, 2, 3]].sum() == 0
+            assert (r["cov16"][2400:2550] == 1).all() and r["cov16"].sum() == 151
+        pipe.release(t)
+    pipe.close()
