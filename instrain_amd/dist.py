@@ -51,7 +51,7 @@ def gather_tables(tables, dst=0, device=None):
     RCCL; all tables of a rank travel as ONE packed buffer) -- nothing is padded to the largest rank."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("ISX_DIST_FORCE")):
         return tables
     world, rank = dist.get_world_size(), dist.get_rank()
     if device is None:
@@ -95,8 +95,8 @@ def all_gather_concat(arr, device=None):
     import torch
     import torch.distributed as dist
     arr = np.ascontiguousarray(arr)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return arr
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not os.environ.get("ISX_DIST_FORCE")):
+        return arr                                  # (ISX_DIST_FORCE: a world of one still goes through the collectives -- tests)
     world = dist.get_world_size()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")

@@ -534,6 +534,43 @@ def test_one_bam_profiled_by_two_ranks_equals_one_rank(tmp_path):
     assert sorted(set(int(t) for t in g["summary"]["tid"])) == [0, 1, 2, 3, 4]
 
 
+RCCL_WORKER = '''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from instrain_amd import dist as idist
+from instrain_amd._lib import SNV_DT
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)          # "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl"
+a = np.arange(100003, dtype=np.int64) * 7
+got = idist.all_gather_concat(a)                                       # lengths + padded payload through ncclAllGather on device tensors
+assert got.dtype == a.dtype and (got == a).all()
+assert len(idist.all_gather_concat(np.zeros(0, np.uint8))) == 0
+snv = np.zeros(1234, dtype=SNV_DT); snv["gpos"] = np.arange(1234)
+out = idist.gather_tables({"snv": snv, "ld": np.zeros(0, np.int32)}, dst=0)
+assert (out["snv"]["gpos"] == snv["gpos"]).all() and len(out["ld"]) == 0
+dist.barrier(device_ids=[0])
+dist.destroy_process_group()
+print("RCCL_OK")
+'''
+
+
+def test_collectives_over_rccl_world_of_one(tmp_path):
+    """the exchange steps of the multi-GPU path through the RCCL backend itself (one GPU here, so a world of one: RCCL refuses two
+    ranks on one device; ISX_DIST_FORCE makes the world of one take the collective route instead of the short cut)"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % repo)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29585", ISX_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("mode", ["all_reads", "non_discordant"])
 def test_sharded_profile_with_cross_scaffold_filters(tmp_path, mode):
     """non_discordant / all_reads with every rank scanning only its share (dist.resolve_cross_names: read-name hashes
