@@ -347,7 +347,8 @@ typedef struct {
     isx_sizes sizes;
     /* n_mm_bins == 1: tables in pinned host memory, valid until isx_pipe_release.  What shrink_basewise keeps
      * (profile_utilities.py:337-350) is coverage, clonality and the few rarefied clonalities, so that is what
-     * crosses PCIe: 6 bytes per position instead of 24. */
+     * crosses PCIe: 6 bytes per position instead of 24 (round 3: 1-2 bytes + short lists, see coverage8 / clon_sparse below).
+     * The tables leave the device through a copy kernel into the pinned block, not through the DMA engine. */
     const uint16_t *coverage16; /* [n_pos] covT = min(sum of the four counts, 65535); n_saturated positions hold 65535
                                  * (their exact counts: isx_batch_fetch_dense on `batch`, or want_counts) */
     const float *clon;          /* [n_pos] clonT, NaN below min_cov */
@@ -361,10 +362,10 @@ typedef struct {
      * called on it until isx_pipe_release (n_mm_bins > 1: the entry table is fetched this way) */
     isx_batch *batch;
     /* where the time of this batch went, milliseconds */
-    float encode_ms;            /* host threads: isx_obs -> records in pinned staging */
+    float encode_ms;            /* host threads: isx_obs / isx_segs -> records in pinned staging */
     float h2d_ms, kernel_ms, d2h_ms;    /* device-side durations (HIP events) */
     float collect_wait_ms;      /* host time isx_pipe_collect spent waiting */
-    int32_t record_bytes;       /* 2 or 4 */
+    int32_t record_bytes;       /* 2 or 4 (observation records), 64 (read segments) */
     int32_t encode_passes;      /* 1; 2 when the stream jumped more often than the slot's slack allowed */
     int64_t h2d_bytes, d2h_bytes;
     const isx_ld *ld;           /* [sizes.n_ld] the LD rows when linkage is enabled (else NULL), reference order;
@@ -387,8 +388,8 @@ void isx_pipe_destroy(isx_pipe *p);
 int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
                     int64_t n_obs, const isx_obs *obs, const uint32_t *pair, int64_t *ticket);
 /* The same, fed by the BAM front end (isx_bam_* below; the file must be scanned and filtered): references `refs`
- * (ascending ids) are expanded straight into the slot's pinned staging -- the 8-byte records of the batch never
- * exist as a whole.  split_bounds == NULL: the front end's own iterate_splits geometry.  ref[n_pos] = base codes of
+ * (ascending ids) are expanded straight into the slot's pinned staging -- neither the 8-byte records nor (read-level
+ * pipe) the read segments of the batch ever exist as a whole.  split_bounds == NULL: the front end's own iterate_splits geometry.  ref[n_pos] = base codes of
  * the batch's references laid end to end.  info (may be NULL) receives the batch's counts. */
 int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s *bp, const int32_t *refs, int32_t n_refs,
                         const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds, struct isx_bam_info_s *info,
@@ -522,8 +523,9 @@ int isx_bam_set_priority_reads(isx_bam *bam, int64_t n, const char *names, const
 int isx_bam_scan(isx_bam *bam, isx_bam_info *info /* may be NULL */);
 /* Pass 1 over share `part` of `n_parts` of the file (one share per rank of a multi-GPU run): the handle owns the references
  * whose first read lies in its share of the segments -- complete pair tables for those, every other reference looks empty
- * (isx_bam_ref_counts).  paired_only only; the file-wide median insert is the caller's to combine: isx_bam_insert_sizes of
- * every share (an all-gather) -> isx_bam_filter(median_insert).  isx_bam_scan == share 0 of 1. */
+ * (isx_bam_ref_counts).  The file-wide median insert is the caller's to combine: isx_bam_insert_sizes of every share (an
+ * all-gather) -> isx_bam_filter(median_insert); non_discordant / all_reads additionally need isx_bam_set_cross_names (below).
+ * isx_bam_scan == share 0 of 1. */
 int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info *info /* may be NULL */);
 /* The scaffolds that exist for the read filter: the reference builds its pair table from the scaffolds of the fasta only
  * (filter_reads.py:63-77, 157-178), so the median insert (:213-217), the read_report tallies and the cross-scaffold name
