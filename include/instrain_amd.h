@@ -399,6 +399,11 @@ int isx_pipe_release(isx_pipe *p, int64_t ticket);
 /* n_mm_bins > 1: the entry table of a collected batch ([sizes.n_entries], (gpos, mm) order) -- what
  * isx_batch_fetch_entries(result.batch, out) returns, moved through the slot's pinned staging by the pipe's host threads */
 int isx_pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out);
+/* The same table shrunk to what shrink_basewise keeps of a (position, mm) level (profile_utilities.py:337-350): covT is the
+ * level's coverage, not its four counts.  Four columns of sizes.n_entries values in (gpos, mm) order: gpos; mm_cov = mm << 24 |
+ * sum of the level's four counts; clon; clon_rarefied (NaN = none) -- 16 bytes an entry over PCIe instead of 32.
+ * ISX_ERR_CAPACITY when a level's coverage reaches 2^24 or an mm level 256 (fetch the full entries then). */
+int isx_pipe_fetch_entries_shrunk(isx_pipe *p, int64_t ticket, uint32_t *gpos, uint32_t *mm_cov, float *clon, float *clon_rarefied);
 
 
 /* ---- read-level hand-over: the per-base expansion of the pileup happens on the device ----

@@ -115,6 +115,9 @@ COMPARE_SNP_DT = np.dtype([("gpos", "<u4"), ("mm", "<u2"), ("consensus_snp", "u1
 assert COMPARE_SNP_DT.itemsize == 48
 
 
+ERR_CAPACITY = -3          # ISX_ERR_CAPACITY (include/instrain_amd.h)
+
+
 class IsxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libinstrain_amd error %d: %s" % (code, msg))
@@ -125,7 +128,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_batch_create", "isx_batch_create_reads", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
            "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
-           "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_submit_bam", "isx_encode_segs", "isx_encode_segs_ring", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_encode_obs", "isx_encode_obs_ring",
+           "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_submit_bam", "isx_encode_segs", "isx_encode_segs_ring", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_pipe_fetch_entries_shrunk", "isx_encode_obs", "isx_encode_obs_ring",
            "isx_bam_open", "isx_bam_close", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
            "isx_bam_insert_sizes", "isx_bam_set_wanted_refs", "isx_bam_pair_keys", "isx_bam_set_cross_names", "isx_bam_filter_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_ref_counts",
            "isx_bam_expand_refs", "isx_bam_segment_refs", "isx_bam_copy_segs", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
@@ -179,6 +182,7 @@ def load():
     lib.isx_pipe_collect.argtypes = [vp, i64, C.POINTER(PipeResult)]
     lib.isx_pipe_release.argtypes = [vp, i64]
     lib.isx_pipe_fetch_entries.argtypes = [vp, i64, vp]
+    lib.isx_pipe_fetch_entries_shrunk.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.isx_encode_obs.argtypes = [vp, vp, i64, i64, i32, i32, C.c_double, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
     lib.isx_encode_obs_ring.argtypes = [vp, vp, i64, i64, i32, i32, C.c_double, i64, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
     lib.isx_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]

@@ -1235,9 +1235,24 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
 // The entry table of a collected mm batch (isx_batch_fetch_entries on the slot, but the 32 bytes per entry go through the
 // slot's idle pinned input staging in two alternating pieces and are moved into `out` by the pipe's host threads: a blocking
 // copy into pageable memory runs at a fifth of the link).
+static int pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out, const EntrySoa *soa);
+
 int isx_pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out)
 {
-    if (!p || ticket < 0 || !out) { isx_set_error("isx_pipe_fetch_entries: bad argument"); return ISX_ERR_ARG; }
+    if (!out) { isx_set_error("isx_pipe_fetch_entries: bad argument"); return ISX_ERR_ARG; }
+    return pipe_fetch_entries(p, ticket, out, nullptr);
+}
+
+int isx_pipe_fetch_entries_shrunk(isx_pipe *p, int64_t ticket, uint32_t *gpos, uint32_t *mm_cov, float *clon, float *clon_rarefied)
+{
+    if (!gpos || !mm_cov || !clon || !clon_rarefied) { isx_set_error("isx_pipe_fetch_entries_shrunk: bad argument"); return ISX_ERR_ARG; }
+    const EntrySoa soa{gpos, mm_cov, clon, clon_rarefied};
+    return pipe_fetch_entries(p, ticket, nullptr, &soa);
+}
+
+static int pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out, const EntrySoa *soa)
+{
+    if (!p || ticket < 0) { isx_set_error("isx_pipe_fetch_entries: bad argument"); return ISX_ERR_ARG; }
     Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
     {
         std::lock_guard<std::mutex> lk(p->mu);
@@ -1250,7 +1265,8 @@ int isx_pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out)
     if (!n) return ISX_OK;
     const size_t region = p->ring_half ? 2 * (size_t)p->ring_half * p->rb : (size_t)p->cap_rec * p->rb;
     const size_t piece = std::min<size_t>((size_t)32 << 20, region / 2 / 4096 * 4096);
-    if (piece < ((size_t)1 << 20)) return isx_batch_fetch_entries(b, out);      // tiny pipe: not worth it
+    if (piece < ((size_t)1 << 20))              // tiny pipe: the staging detour is not worth it
+        return fetch_entries_sorted(p->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, (uint32_t)b->n_win, b->n_ovf, n, out, nullptr, soa);
     uint8_t *bounce[2] = {s.h_in + s.off_rec, s.h_in + s.off_rec + piece};
     hipEvent_t ev[2] = {nullptr, nullptr};
     for (hipEvent_t &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1258,7 +1274,7 @@ int isx_pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out)
         const size_t n_pieces = (bytes + piece - 1) / piece;
         auto issue = [&](size_t k) -> hipError_t {
             const size_t off = k * piece, len = std::min(piece, bytes - off);
-            hipError_t e = hipMemcpyAsync(bounce[k & 1], static_cast<const uint8_t *>(dsrc) + off, len, hipMemcpyDeviceToHost, st);
+            hipError_t e = isx_copy_to_host(bounce[k & 1], static_cast<const uint8_t *>(dsrc) + off, len, st);
             return e == hipSuccess ? hipEventRecord(ev[k & 1], st) : e;
         };
         HIP_TRY(issue(0));
@@ -1276,7 +1292,7 @@ int isx_pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out)
         }
         return ISX_OK;
     };
-    const int rc = fetch_entries_sorted(p->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, (uint32_t)b->n_win, b->n_ovf, n, out, &copier);
+    const int rc = fetch_entries_sorted(p->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, (uint32_t)b->n_win, b->n_ovf, n, out, &copier, soa);
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     return rc;
 }

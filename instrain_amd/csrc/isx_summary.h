@@ -83,5 +83,8 @@ int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, const 
 // host_out: by one hipMemcpyAsync, or by `copier` (device source, host destination, bytes, stream) when the caller has a
 // faster way to pageable memory (a pipe's pinned staging + its host threads)
 typedef std::function<int(const void *, void *, size_t, hipStream_t)> EntryCopier;
+// soa != NULL: the shrunk hand-back instead (isx_pipe_fetch_entries_shrunk): four host columns of n_entries 4-byte values
+struct EntrySoa { uint32_t *gpos, *mm_cov; float *clon, *clon_rarefied; };
 int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t *win_nent, uint32_t slab, uint32_t n_win,
-                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out, const EntryCopier *copier = nullptr);
+                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out, const EntryCopier *copier = nullptr,
+                         const EntrySoa *soa = nullptr);

@@ -432,17 +432,34 @@ __global__ void k_gather_entries(const isx_entry *entries, const uint32_t *idx, 
     uint4 *dst = reinterpret_cast<uint4 *>(&out[k]);
     dst[0] = src[0]; dst[1] = src[1];
 }
+
+// the same gather, shrunk to what shrink_basewise keeps of a (position, mm) level: its coverage, not its four counts --
+// four 4-byte columns (position | mm:8 cov:24 | clonality | rarefied clonality), 16 bytes an entry instead of 32
+__global__ void k_gather_entries_soa(const isx_entry *entries, const uint32_t *idx, uint32_t n, uint32_t *gpos, uint32_t *mm_cov,
+                                     float *clon, float *clon_r, uint32_t *too_deep)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(&entries[idx[k]]);
+    const uint4 a = src[0], b = src[1];             // gpos | mm, flags | cnt[0] | cnt[1]  ;  cnt[2] | cnt[3] | clon | clon_rarefied
+    const uint32_t cov = a.z + a.w + b.x + b.y, mm = a.y & 0xFFFFu;
+    if (cov >= (1u << 24) || mm >= 256u) atomicOr(too_deep, 1u);
+    gpos[k] = a.x;
+    mm_cov[k] = (mm << 24) | (cov & 0xFFFFFFu);
+    clon[k] = __uint_as_float(b.z);
+    clon_r[k] = __uint_as_float(b.w);
+}
 }  // namespace
 
 int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t *win_nent, uint32_t slab, uint32_t n_win,
-                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out, const EntryCopier *copier)
+                         uint32_t n_ovf, uint64_t n_entries, isx_entry *host_out, const EntryCopier *copier, const EntrySoa *soa)
 {
     const uint64_t ovf0 = (uint64_t)n_win * slab;
     if (ovf0 + n_ovf >= 0xFFFFFFFFull || n_entries >= 0xFFFFFFFFull) { isx_set_error("entry table too large to fetch in one piece"); return ISX_ERR_CAPACITY; }
     const uint32_t n = (uint32_t)n_entries;
     uint64_t *keys = nullptr;
     uint32_t *idx = nullptr, *cursor = nullptr;
-    isx_entry *out = nullptr;
+    uint8_t *out = nullptr;
     void *temp = nullptr;
     int rc = ISX_OK;
     auto done = [&](int code) {
@@ -450,30 +467,44 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
         for (void *p : ps) if (p) isx_dev_free(p);
         return code;
     };
+    const size_t out_bytes = (size_t)n * (soa ? 16 : sizeof(isx_entry));
 #define FE_TRY(expr) do { if ((expr) != hipSuccess) { isx_set_error(std::string("HIP error in fetch_entries: ") + #expr); return done(ISX_ERR_HIP); } } while (0)
-    FE_TRY(hipMalloc(&keys, (size_t)n * 2 * sizeof(uint64_t)));
-    FE_TRY(hipMalloc(&idx, (size_t)n * 2 * sizeof(uint32_t)));
-    FE_TRY(hipMalloc(&cursor, 4));
-    FE_TRY(hipMalloc(&out, (size_t)n * sizeof(isx_entry)));
-    FE_TRY(hipMemsetAsync(cursor, 0, 4, s));
+    // (cached blocks: a profile fetches a table of this size per batch)
+    FE_TRY(isx_dev_malloc(reinterpret_cast<void **>(&keys), (size_t)n * 2 * sizeof(uint64_t)));
+    FE_TRY(isx_dev_malloc(reinterpret_cast<void **>(&idx), (size_t)n * 2 * sizeof(uint32_t)));
+    FE_TRY(isx_dev_malloc(reinterpret_cast<void **>(&cursor), 8));
+    FE_TRY(isx_dev_malloc(reinterpret_cast<void **>(&out), out_bytes));
+    FE_TRY(hipMemsetAsync(cursor, 0, 8, s));
     hipLaunchKernelGGL(k_entry_keys, dim3(2048), dim3(256), 0, s, entries, win_nent, slab, ovf0, n_ovf, keys, idx, cursor, n);
     size_t tb = 0;
     FE_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys, keys + n, idx, idx + n, (size_t)n, 0, 48, s));
-    FE_TRY(hipMalloc(&temp, tb + 256));
+    FE_TRY(isx_dev_malloc(&temp, tb + 256));
     FE_TRY(rocprim::radix_sort_pairs(temp, tb, keys, keys + n, idx, idx + n, (size_t)n, 0, 48, s));
-    hipLaunchKernelGGL(k_gather_entries, dim3((n + 255) / 256), dim3(256), 0, s, entries, idx + n, n, out);
-    uint32_t got = 0;
-    FE_TRY(hipMemcpyAsync(&got, cursor, 4, hipMemcpyDeviceToHost, s));
-    if (copier) {
-        FE_TRY(hipStreamSynchronize(s));
-        const int crc = (*copier)(out, host_out, (size_t)n * sizeof(isx_entry), s);
-        if (crc != ISX_OK) return done(crc);
-    } else {
-        FE_TRY(hipMemcpyAsync(host_out, out, (size_t)n * sizeof(isx_entry), hipMemcpyDeviceToHost, s));
-        FE_TRY(hipStreamSynchronize(s));
+    uint32_t *col = reinterpret_cast<uint32_t *>(out);
+    if (soa)
+        hipLaunchKernelGGL(k_gather_entries_soa, dim3((n + 255) / 256), dim3(256), 0, s, entries, idx + n, n, col, col + n,
+                           reinterpret_cast<float *>(col + 2 * (size_t)n), reinterpret_cast<float *>(col + 3 * (size_t)n), cursor + 1);
+    else
+        hipLaunchKernelGGL(k_gather_entries, dim3((n + 255) / 256), dim3(256), 0, s, entries, idx + n, n, reinterpret_cast<isx_entry *>(out));
+    uint32_t got[2] = {0, 0};
+    FE_TRY(hipMemcpyAsync(got, cursor, 8, hipMemcpyDeviceToHost, s));
+    FE_TRY(hipStreamSynchronize(s));
+    if (got[0] != n) { isx_set_error("entry table inconsistent: " + std::to_string(got[0]) + " gathered vs " + std::to_string(n)); return done(ISX_ERR_STATE); }
+    if (soa && got[1]) { isx_set_error("a (position, mm) level with coverage >= 2^24 or mm >= 256: fetch the full entries (isx_pipe_fetch_entries)"); return done(ISX_ERR_CAPACITY); }
+    void *dsts[4] = {host_out, nullptr, nullptr, nullptr};
+    const int n_parts = soa ? 4 : 1;
+    if (soa) { dsts[0] = soa->gpos; dsts[1] = soa->mm_cov; dsts[2] = soa->clon; dsts[3] = soa->clon_rarefied; }
+    const size_t part_bytes = out_bytes / (size_t)n_parts;
+    for (int k = 0; k < n_parts; k++) {
+        if (copier) {
+            const int crc = (*copier)(out + (size_t)k * part_bytes, dsts[k], part_bytes, s);
+            if (crc != ISX_OK) return done(crc);
+        } else {
+            FE_TRY(hipMemcpyAsync(dsts[k], out + (size_t)k * part_bytes, part_bytes, hipMemcpyDeviceToHost, s));
+        }
     }
+    FE_TRY(hipStreamSynchronize(s));
 #undef FE_TRY
-    if (got != n) { isx_set_error("entry table inconsistent: " + std::to_string(got) + " gathered vs " + std::to_string(n)); rc = ISX_ERR_STATE; }
     return done(rc);
 }
 

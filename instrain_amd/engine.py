@@ -322,7 +322,7 @@ class Pipe:
         check(rc)
         return t.value
 
-    def collect(self, ticket, want_ld=True, rare_list=True, densify=True):
+    def collect(self, ticket, want_ld=True, rare_list=True, densify=True, shrunk_entries=False):
         """-> dict like Batch.fetch() (+ 'sizes', 'stats'); the dense arrays / snv rows are views of pinned memory.
         One mm bin without want_counts: the tables come back shrunk -- 'cov16' or (a shallow batch) 'cov8', 'saturated' =
         exact coverage of the positions beyond that range, and 'clon_sparse' = the clonalities other than 1.0 (every other
@@ -380,10 +380,23 @@ class Pipe:
                 if "clon_r" not in out:
                     out["clon_r"] = np.full(n_pos, np.nan, np.float32)
         else:
-            e = np.empty(max(1, sz["n_entries"]), dtype=ENTRY_DT)
-            check(self.lib.isx_pipe_fetch_entries(self.h, int(ticket), e.ctypes.data))
-            out["entries"] = e[:sz["n_entries"]]
-            out["clon_r"] = out["entries"]["clon_rarefied"]
+            n_e = sz["n_entries"]
+            got = False
+            if shrunk_entries:
+                # what shrink_basewise keeps of a (position, mm) level is its coverage, not its four counts: four 4-byte columns
+                # (isx_pipe_fetch_entries_shrunk) instead of 32-byte entries; a level deeper than 2^24 -> the full entries
+                cols = (np.empty(max(1, n_e), np.uint32), np.empty(max(1, n_e), np.uint32), np.empty(max(1, n_e), np.float32), np.empty(max(1, n_e), np.float32))
+                rc = self.lib.isx_pipe_fetch_entries_shrunk(self.h, int(ticket), *(c.ctypes.data for c in cols))
+                if rc == 0:
+                    out["entries_soa"] = tuple(c[:n_e] for c in cols)
+                    got = True
+                elif rc != _lib.ERR_CAPACITY:
+                    check(rc)
+            if not got:
+                e = np.empty(max(1, n_e), dtype=ENTRY_DT)
+                check(self.lib.isx_pipe_fetch_entries(self.h, int(ticket), e.ctypes.data))
+                out["entries"] = e[:n_e]
+                out["clon_r"] = out["entries"]["clon_rarefied"]
         out["snv"] = view(r.snv, SNV_DT, sz["n_snv"])
         if want_ld and self.enable_linkage:
             out["ld"] = view(r.ld, LD_DT, sz["n_ld"]) if r.ld else np.empty(0, dtype=LD_DT)

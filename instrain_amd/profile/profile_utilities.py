@@ -80,11 +80,14 @@ class _BatchTables:
         self.snv, self.ld = _own(res["snv"]), _own(res["ld"])
         self.s_cut = _cuts(self.snv["gpos"], self.bounds)
         self.l_cut = _cuts(self.ld["gpos_a"], self.bounds)
-        if "entries" in res:                        # mm profiling on: (position, mm) entries
+        self.soa = self.entries = None
+        if "entries_soa" in res:                    # mm profiling on, shrunk hand-back: columns gpos | mm << 24 | cov | clon | clon_rarefied
+            self.soa = res["entries_soa"]
+            self.e_cut = _cuts(self.soa[0], self.bounds)
+        elif "entries" in res:                      # mm profiling on: (position, mm) entries
             self.entries = res["entries"]
             self.e_cut = _cuts(self.entries["gpos"], self.bounds)
-        else:                                       # one mm bin: coverage per position, clonality, sparse clonTR
-            self.entries = None
+        if self.soa is None and self.entries is None:       # one mm bin: coverage per position, clonality, sparse clonTR
             if "counts" in res:
                 self.cov = res["counts"].sum(axis=1, dtype=np.int64)
             else:                                   # the shrunk hand-back: 16- or 8-bit coverage + the exact values beyond
@@ -108,7 +111,7 @@ class _BatchTables:
                 self.r_cut = np.searchsorted(self.rare_pos, self.bounds)
             else:                                   # a deep sample: the dense array, cut per split when somebody asks
                 self.clon_r = _own(res["clon_r"])
-        self.pileup_counts = _own(res["counts"]) if "counts" in res and self.entries is None else None
+        self.pileup_counts = _own(res["counts"]) if "counts" in res and self.entries is None and self.soa is None else None
 
     # -- shrink_basewise (profile_utilities.py:337-350): dict mm -> sparse Series; a level that occurs in the split keeps
     #    its key even when its Series is empty (the reference deletes nothing but zeros / NaNs) --
@@ -125,6 +128,19 @@ class _BatchTables:
     def basewise(self, i):
         """-> covT, clonT, clonTR of split i"""
         off = self.offset[i]
+        if self.soa is not None:
+            a, b = self.e_cut[i], self.e_cut[i + 1]
+            g, mc, cl, cr = (x[a:b] for x in self.soa)
+            pos = g.astype(np.int64) - off
+            mm, lvl = (mc >> 24).astype(np.uint16), (mc & 0xFFFFFF).astype(np.int64)
+            all_mm = np.unique(mm)
+            k = lvl > 0
+            covT = self._by_mm(pos[k], mm[k], lvl[k], "int32", all_mm)
+            k = ~np.isnan(cl)
+            clonT = self._by_mm(pos[k], mm[k], cl[k], "float32", all_mm)
+            k = ~np.isnan(cr)
+            clonTR = self._by_mm(pos[k], mm[k], cr[k], "float32", all_mm)
+            return covT, clonT, clonTR
         if self.entries is not None:
             ee = self.entries[self.e_cut[i]:self.e_cut[i + 1]]
             pos = ee["gpos"].astype(np.int64) - off
@@ -732,7 +748,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             """tables of a submitted group -> SplitObjects"""
             t = g.ticket
             try:
-                res = pipe.collect(t, rare_list=False, densify=False)
+                res = pipe.collect(t, rare_list=False, densify=False, shrunk_entries=not store_everything)
                 stage("collect_wait_ms")
                 splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam,
                                           min_cov=int(kwargs.get('min_cov', 5)))

@@ -124,6 +124,34 @@ def test_stream_mm_profiling_with_linkage(ctx):
     pipe.close()
 
 
+@pytest.mark.parametrize("reads", [False, True])
+def test_shrunk_entry_hand_back_equals_the_entries(ctx, reads):
+    """isx_pipe_fetch_entries_shrunk (four 4-byte columns: position | mm << 24 | coverage of the level | clonality | rarefied
+    clonality) == the 32-byte entries of the same collected batch, column by column and bit by bit; big enough for the staging
+    detour of the copy (> 1 MiB pieces) and small enough for the direct one"""
+    from instrain_amd import engine, synth
+    for genome, cov in ((60_000, 30), (1_500_000, 40)):
+        w = small_workload(300 + genome % 7, genome, cov, False)
+        M = w["n_mm_bins"]
+        kw = dict(enable_linkage=False, rarefied_coverage=20, seed=9, n_mm_bins=M)
+        if reads:
+            segs = synth.segs_from_obs(w["obs"], w["pair"])
+            pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=0, max_segs=segs.n_seg, max_splits=len(w["split_bounds"]), depth=1, host_threads=3, **kw)
+            t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs)
+        else:
+            pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=w["n_obs"], max_splits=len(w["split_bounds"]), depth=1, host_threads=3, **kw)
+            t = pipe.submit(w["ref_codes"], w["split_bounds"], w["obs"], None)
+        full = pipe.collect(t)["entries"].copy()
+        g, mc, cl, cr = pipe.collect(t, shrunk_entries=True)["entries_soa"]
+        assert len(full) == len(g) > 50_000
+        assert (g == full["gpos"]).all() and ((mc >> 24) == full["mm"]).all()
+        assert ((mc & 0xFFFFFF) == full["cnt"].sum(axis=1)).all()
+        assert cl.tobytes() == full["clon"].tobytes() and cr.tobytes() == full["clon_rarefied"].tobytes()
+        assert np.isfinite(cr).sum() > 100
+        pipe.release(t)
+        pipe.close()
+
+
 @pytest.mark.parametrize("skip_mm,ring_kib", [(True, 64), (False, 64), (False, 4096)])
 def test_staging_ring(ctx, skip_mm, ring_kib):
     """records staged through a small pinned ring (the mode a pipe picks by itself beyond 512 MiB of records): waves of
