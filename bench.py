@@ -499,6 +499,7 @@ def c5_bam_leg(ctx, host_threads, scale=1.0):
     best, st_best, n_out = None, None, 0
     for rep in range(2):
         st = {}
+        ctx.wait_closers()
         t0 = time.perf_counter()
         out = amd.profile_bam(path, fdb, None, None, s2s=s2s, null_model=_null_model_dict(), ctx=ctx, skip_mm_profiling=True,
                               min_snp=20, stats=st, host_threads=host_threads)
@@ -539,6 +540,7 @@ def profile_bam_leg(ctx, host_threads):
         best, st_best, n_splits = None, None, 0
         for rep in range(3):
             st = {}
+            ctx.wait_closers()                      # the previous call's pipe and BAM handle go on a helper thread: not into this call's time
             t0 = time.perf_counter()
             res = amd.profile_bam(path, None, None, None, s2s=s2s, null_model=nm, ctx=ctx, skip_mm_profiling=skip, stats=st,
                                   host_threads=host_threads)

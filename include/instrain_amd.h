@@ -520,7 +520,8 @@ typedef struct isx_bam_info_s {
 } isx_bam_info;
 
 int isx_bam_open(const char *path, isx_bam **out);     /* header + BGZF block index; nothing else is inflated */
-void isx_bam_close(isx_bam *bam);
+void isx_bam_close(isx_bam *bam);           /* a large handle is given back to the system on a thread of its own */
+void isx_bam_close_wait(isx_bam *bam);      /* ... or before this returns (a caller that closes on its own helper thread) */
 int isx_bam_set_threads(isx_bam *bam, int32_t threads); /* 0 = automatic (2 x the container's cpu quota, at most 64) */
 int isx_bam_ref(const isx_bam *bam, int32_t i, const char **name, int64_t *length, int64_t *flat_offset);
 /* names[offs[i] .. offs[i+1]) = i-th priority read (--priority_reads, filter_reads.py:428-469); used by the next isx_bam_filter */

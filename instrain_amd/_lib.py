@@ -129,7 +129,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
            "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
            "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_submit_bam", "isx_encode_segs", "isx_encode_segs_ring", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_pipe_fetch_entries_shrunk", "isx_encode_obs", "isx_encode_obs_ring",
-           "isx_bam_open", "isx_bam_close", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
+           "isx_bam_open", "isx_bam_close", "isx_bam_close_wait", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
            "isx_bam_insert_sizes", "isx_bam_set_wanted_refs", "isx_bam_pair_keys", "isx_bam_set_cross_names", "isx_bam_filter_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_ref_counts",
            "isx_bam_expand_refs", "isx_bam_segment_refs", "isx_bam_copy_segs", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
 
@@ -188,6 +188,8 @@ def load():
     lib.isx_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.isx_bam_close.argtypes = [vp]
     lib.isx_bam_close.restype = None
+    lib.isx_bam_close_wait.argtypes = [vp]
+    lib.isx_bam_close_wait.restype = None
     lib.isx_bam_expand.argtypes = [vp, C.POINTER(BamParams), C.POINTER(BamInfo)]
     lib.isx_bam_set_threads.argtypes = [vp, i32]
     lib.isx_bam_set_priority_reads.argtypes = [vp, i64, C.c_char_p, vp]

@@ -41,6 +41,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -463,6 +464,8 @@ void bucket_indices(isxenc::HostPool &pool, size_t n, int P, Key key, std::vecto
     });
 }
 
+struct BamBatch;
+
 struct isx_bam {
     int fd = -1;
     const uint8_t *map = nullptr;
@@ -508,11 +511,15 @@ struct isx_bam {
     std::vector<int32_t> split_ref;
     bool expanded = false;
 
-    ~isx_bam()
-    {
-        if (map) munmap(const_cast<uint8_t *>(map), map_len);
-        if (fd >= 0) close(fd);
-    }
+    // batches a pipe is done with (bam_batch_retire): giving a gigabyte back to the system takes 100+ ms of the process' address-space
+    // lock -- page faults and device calls of every other thread wait for it -- so it happens when the handle goes (isx_bam_close
+    // does that on a thread of its own), or earlier only when more than RETIRE_LIMIT bytes have piled up
+    std::mutex retire_mu;
+    std::vector<std::pair<BamBatch *, size_t>> retired;
+    size_t retired_bytes = 0;
+    static constexpr size_t RETIRE_LIMIT = (size_t)6 << 30;
+
+    ~isx_bam();
 };
 
 namespace {
@@ -943,6 +950,8 @@ void isx_bam_close(isx_bam *bam)
     if (bam->n_reads > (1u << 20)) std::thread([](isx_bam *dead) { delete dead; }, bam).detach();
     else delete bam;
 }
+
+void isx_bam_close_wait(isx_bam *bam) { delete bam; }
 
 int isx_bam_set_threads(isx_bam *bam, int32_t threads)
 {
@@ -2125,6 +2134,34 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
 }
 
 void bam_batch_free(BamBatch *q) { delete q; }
+
+isx_bam::~isx_bam()
+{
+    for (auto &r : retired) delete r.first;
+    if (map) munmap(const_cast<uint8_t *>(map), map_len);
+    if (fd >= 0) close(fd);
+}
+
+void bam_batch_retire(BamBatch *q)
+{
+    if (!q) return;
+    isx_bam *B = q->B;
+    size_t bytes = q->S.reads.size() * sizeof(Read) + q->S.cigars.size() * 4 + q->emit.size() + q->pid.size() * 4 + q->out_at.size() * 8 +
+                   q->seg_at.size() * 8 + q->seg_gpos.size() * 4;
+    for (const auto &d : q->S.seg_data) bytes += d.size();
+    std::vector<BamBatch *> dead;
+    {
+        std::lock_guard<std::mutex> lk(B->retire_mu);
+        B->retired.emplace_back(q, bytes);
+        B->retired_bytes += bytes;
+        while (B->retired_bytes > isx_bam::RETIRE_LIMIT && !B->retired.empty()) {
+            dead.push_back(B->retired.front().first);
+            B->retired_bytes -= B->retired.front().second;
+            B->retired.erase(B->retired.begin());
+        }
+    }
+    for (BamBatch *d : dead) delete d;
+}
 int64_t bam_batch_n_segs(const BamBatch *q) { return (int64_t)q->seg_gpos.size(); }
 int64_t bam_batch_seg_bases(const BamBatch *q) { return q->n_seg_bases; }
 const uint32_t *bam_batch_seg_gpos(const BamBatch *q) { return q->seg_gpos.data(); }

@@ -18,6 +18,8 @@ const uint32_t *bam_batch_seg_gpos(const BamBatch *q);  // [n_segs] flat start o
 void bam_batch_emit_segs(const BamBatch *q, int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair,
                          uint32_t *bases);               // thread safe
 void bam_batch_free(BamBatch *q);
+// done with, but not freed now: the batch goes with its handle (isx_bam_close), see isx_bam::retired
+void bam_batch_retire(BamBatch *q);
 int64_t bam_batch_n_obs(const BamBatch *q);
 int64_t bam_batch_n_pos(const BamBatch *q);
 void bam_batch_emit(const BamBatch *q, int64_t first, uint32_t count, isx_obs *obs, uint32_t *pair);     // thread safe

@@ -538,7 +538,7 @@ static void finisher_main(isx_pipe *p)
             dead = s.dead_batch; s.dead_batch = nullptr;
         }
         p->cv_done.notify_all();
-        if (dead) bam_batch_free(dead);
+        if (dead) bam_batch_retire(dead);          // (freed with its handle: unmapping a gigabyte now would stall the caller's next steps)
     }
 }
 
@@ -1175,7 +1175,7 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
         Slot &s = p->slots[(size_t)(*ticket % (int64_t)p->slots.size())];
         if (s.ticket == *ticket && s.state == 1) s.dead_batch = Q.release();
     }
-    if (Q) std::thread([](BamBatch *dead) { bam_batch_free(dead); }, Q.release()).detach();
+    if (Q) bam_batch_retire(Q.release());
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_submit_bam] prepare %.1f ms, encode + enqueue %.1f ms, free %.1f ms\n", t_prep - t_in, t_sub - t_prep, now_ms() - t_sub);
     return rc;

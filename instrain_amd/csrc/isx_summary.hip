@@ -13,6 +13,7 @@
 // Levels are applied in ascending order onto three flat per-position arrays that stay on the
 // device; per level one pass of segmented reductions (register partials, one set of atomics per
 // lane) and three rocPRIM segmented radix sorts for the medians.
+#include <chrono>
 #include <algorithm>
 #include <vector>
 #include <cstring>
@@ -457,6 +458,9 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
     const uint64_t ovf0 = (uint64_t)n_win * slab;
     if (ovf0 + n_ovf >= 0xFFFFFFFFull || n_entries >= 0xFFFFFFFFull) { isx_set_error("entry table too large to fetch in one piece"); return ISX_ERR_CAPACITY; }
     const uint32_t n = (uint32_t)n_entries;
+    const bool timing = getenv("ISX_PIPE_TIMING") != nullptr;      // tuning aid (stderr only)
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = now_ms();
     uint64_t *keys = nullptr;
     uint32_t *idx = nullptr, *cursor = nullptr;
     uint8_t *out = nullptr;
@@ -491,6 +495,7 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
     FE_TRY(hipStreamSynchronize(s));
     if (got[0] != n) { isx_set_error("entry table inconsistent: " + std::to_string(got[0]) + " gathered vs " + std::to_string(n)); return done(ISX_ERR_STATE); }
     if (soa && got[1]) { isx_set_error("a (position, mm) level with coverage >= 2^24 or mm >= 256: fetch the full entries (isx_pipe_fetch_entries)"); return done(ISX_ERR_CAPACITY); }
+    const double t_dev = now_ms();
     void *dsts[4] = {host_out, nullptr, nullptr, nullptr};
     const int n_parts = soa ? 4 : 1;
     if (soa) { dsts[0] = soa->gpos; dsts[1] = soa->mm_cov; dsts[2] = soa->clon; dsts[3] = soa->clon_rarefied; }
@@ -505,6 +510,7 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
     }
     FE_TRY(hipStreamSynchronize(s));
 #undef FE_TRY
+    if (timing) fprintf(stderr, "[fetch_entries] %u entries: keys + sort + gather %.1f ms, copy of %.1f MB %.1f ms (from %.1f)\n", n, t_dev - t_0, out_bytes / 1e6, now_ms() - t_dev, t_0);
     return done(rc);
 }
 

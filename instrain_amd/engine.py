@@ -90,7 +90,10 @@ class Context:
         def run():
             for o in objs:
                 try:
-                    o.close()
+                    if isinstance(o, BamFile):
+                        o.close(wait=True)          # (wait_closers() then really waits for the memory)
+                    else:
+                        o.close()
                 except Exception:
                     pass
         self._closers = [t for t in self._closers if t.is_alive()]
@@ -102,10 +105,14 @@ class Context:
         lut = np.ascontiguousarray(lut, dtype=np.int32)
         check(self.lib.isx_set_null_model(self.h, lut.ctypes.data, len(lut), int(fallback)))
 
-    def close(self):
+    def wait_closers(self):
+        """block until what close_later was handed is gone (a benchmark that times call after call does this in between)"""
         for t in self._closers:
             t.join()
         self._closers = []
+
+    def close(self):
+        self.wait_closers()
         if self.h:
             for r in self._children:
                 o = r()
@@ -723,10 +730,12 @@ class BamFile:
             self._refs = out
         return self._refs
 
-    def close(self):
+    def close(self, wait=False):
+        """wait: the handle's memory is back with the system when this returns (close_later: the caller's helper thread is the
+        place for that); otherwise a large handle is freed on a thread of the library's"""
         h, self.h = self.h, None
         if h:
-            self.lib.isx_bam_close(h)
+            (self.lib.isx_bam_close_wait if wait else self.lib.isx_bam_close)(h)
 
     def __del__(self):
         try:

@@ -38,6 +38,7 @@ for rep in range(3):
     for skip in modes:
         st = {}
         pr = cProfile.Profile()
+        ctx.wait_closers()
         t0 = time.perf_counter()
         if "--prof" in sys.argv and rep == 2:
             pr.enable()
