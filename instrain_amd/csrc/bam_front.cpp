@@ -514,6 +514,11 @@ struct isx_bam {
     // batches a pipe is done with (bam_batch_retire): giving a gigabyte back to the system takes 100+ ms of the process' address-space
     // lock -- page faults and device calls of every other thread wait for it -- so it happens when the handle goes (isx_bam_close
     // does that on a thread of its own), or earlier only when more than RETIRE_LIMIT bytes have piled up
+    // the scan's per-read records and the name blobs (dropped after the pair tables / the filter) wait here too when they are small
+    // enough to keep (<= KEEP_DEAD bytes each): freed with the handle, not in the middle of the caller's run
+    std::vector<uvec<ReadLite>> dead_reads;
+    std::vector<uvec<char>> dead_names;
+    static constexpr size_t KEEP_DEAD = (size_t)2 << 30;
     std::mutex retire_mu;
     std::vector<std::pair<BamBatch *, size_t>> retired;
     size_t retired_bytes = 0;
@@ -1004,7 +1009,8 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     const bool timing = getenv("ISX_BAM_TIMING") != nullptr;       // tuning aid: stage times on stderr (no effect on results)
     double t_inflate = 0, t_hop = 0, t_extract = 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_mark = now();
+    const double t_begin = now();
+    double t_mark = t_begin;
     B.seg_reads.assign(n_seg, {}); B.seg_names.assign(n_seg, {});
     // pass 2 needs the same bytes again: keep a file's inflated segments when they are a small part of what the host has free
     const bool keep_inflated = B.total_inflated <= inflate_cache_limit();
@@ -1306,9 +1312,16 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
         for (uint32_t i = f.i0; i < f.i1; i++)
             if (v[i] != 0xFFFFFFFFu) v[i] += (uint32_t)pb[part_of(rs[i].h64, P)];
     });
-    if (timing) fprintf(stderr, "[isx_bam_scan] share %d/%d: segments [%zu, %zu) of %zu, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms (bucketing %.1f, tables %.1f, merge %.1f)\n",
-                        part, n_parts, sv, s_end, n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark, t_bucket - t_mark, t_tables - t_bucket, now() - t_tables);
-    pool.run((int)B.seg_reads.size(), [&](int k) { uvec<ReadLite>().swap(B.seg_reads[(size_t)k]); });     // names stay until the filter has run (set_r2m / priority reads / cross-scaffold filters)
+    if (timing) fprintf(stderr, "[isx_bam_scan] share %d/%d: segments [%zu, %zu) of %zu, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms (bucketing %.1f, tables %.1f, merge %.1f); %.1f ms since the scan began\n",
+                        part, n_parts, sv, s_end, n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark, t_bucket - t_mark, t_tables - t_bucket, now() - t_tables, now() - t_begin);
+    {
+        size_t bytes = 0;
+        for (const auto &v : B.seg_reads) bytes += v.size() * sizeof(ReadLite);
+        if (bytes <= isx_bam::KEEP_DEAD && B.dead_reads.empty()) B.dead_reads.swap(B.seg_reads);       // unmapped with the handle (see isx_bam::retired)
+        else pool.run((int)B.seg_reads.size(), [&](int k) { uvec<ReadLite>().swap(B.seg_reads[(size_t)k]); });
+        B.seg_reads.clear();
+    }
+    // names stay until the filter has run (set_r2m / priority reads / cross-scaffold filters)
     B.totals = isx_bam_info{};
     B.totals.n_refs = (int32_t)n_ref;
     B.totals.n_reads = (int64_t)B.n_reads;
@@ -1682,6 +1695,9 @@ int isx_bam_r2m(const isx_bam *bam, int32_t ref, int64_t *n, int64_t *name_bytes
 int isx_bam_drop_names(isx_bam *bam)
 {
     if (!bam) { isx_set_error("isx_bam_drop_names: bad argument"); return ISX_ERR_ARG; }
+    size_t bytes = 0;
+    for (const auto &v : bam->seg_names) bytes += v.size();
+    if (bytes <= isx_bam::KEEP_DEAD && bam->dead_names.empty()) bam->dead_names.swap(bam->seg_names);
     std::vector<uvec<char>>().swap(bam->seg_names);
     return ISX_OK;
 }

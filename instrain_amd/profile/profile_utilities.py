@@ -859,6 +859,12 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
     finally:
         if helpers is not None:
             helpers.shutdown(wait=True)
+        # this call's own large arrays (sequence codes, group layouts) go before the helper thread below starts unmapping the pipe's
+        # and the handle's gigabytes: both want the process' address-space lock
+        try:
+            del codes_of[:], layouts[:]
+        except NameError:
+            pass
         dead = [o for o in (pipe, bf if own_bf else None) if o is not None]
         if own_ctx and ctx is not None:
             for o in dead:
