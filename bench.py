@@ -440,7 +440,7 @@ def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu
            "load_imbalance": float(max(meta.pairs[kept[s]].sum() for s in shards) / np.mean([meta.pairs[kept[s]].sum() for s in shards])),
            "generate_s": gen_s,
            "stages_ms_total": {"host_stage": tot("encode_ms"), "copy_in": tot("h2d_ms"), "kernel": k_ms, "copy_out": tot("d2h_ms"),
-                               "wall": dt * 1e3},
+                               "collect_wait": tot("collect_wait_ms"), "wall": dt * 1e3},
            "roofline": {"bound": "hbm", "kernel": "k_pileup_dense (read segments)", "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
                         "algorithmic_bytes": abytes, "bytes_per_position": abytes / max(n_pos, 1), "kernel_ms_total": k_ms, "launches": len(st),

@@ -115,17 +115,95 @@ __global__ void __launch_bounds__(256) k_copy_out(uint4 *__restrict__ dst, const
 }
 }  // namespace
 
+namespace {
+template <class T>
+__global__ void __launch_bounds__(256) k_copy_small(T *__restrict__ dst, const T *__restrict__ src, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
 hipError_t isx_copy_to_host(void *hdst, const void *dsrc, size_t bytes, hipStream_t stream)
 {
     if (!bytes) return hipSuccess;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(hdst) | reinterpret_cast<uintptr_t>(dsrc)) & 15) == 0;
-    if (!aligned || bytes < ((size_t)64 << 10)) return hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
-    const size_t n16 = bytes / 16, tail = bytes - n16 * 16;
-    const int blocks = (int)std::min<size_t>(128, (n16 + 1023) / 1024);
-    hipLaunchKernelGGL(k_copy_out, dim3(blocks), dim3(256), 0, stream, static_cast<uint4 *>(hdst), static_cast<const uint4 *>(dsrc), n16);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess && tail)
-        e = hipMemcpyAsync(static_cast<uint8_t *>(hdst) + n16 * 16, static_cast<const uint8_t *>(dsrc) + n16 * 16, tail, hipMemcpyDeviceToHost, stream);
+    const uintptr_t both = reinterpret_cast<uintptr_t>(hdst) | reinterpret_cast<uintptr_t>(dsrc);
+    size_t done = 0;
+    if ((both & 15) == 0 && bytes >= 4096) {
+        const size_t n16 = bytes / 16;
+        const int blocks = (int)std::min<size_t>(128, (n16 + 1023) / 1024);
+        hipLaunchKernelGGL(k_copy_out, dim3(blocks), dim3(256), 0, stream, static_cast<uint4 *>(hdst), static_cast<const uint4 *>(dsrc), n16);
+        done = n16 * 16;
+    }
+    if (done < bytes) {                     // small pieces and tails: words when they line up, bytes otherwise -- never the DMA engine
+        const size_t rest = bytes - done;
+        uint8_t *d = static_cast<uint8_t *>(hdst) + done;
+        const uint8_t *s = static_cast<const uint8_t *>(dsrc) + done;
+        const bool words = (((both | rest) & 3) == 0);
+        const size_t n = words ? rest / 4 : rest;
+        const int blocks = (int)std::min<size_t>(64, (n + 255) / 256);
+        if (words) hipLaunchKernelGGL(k_copy_small<uint32_t>, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(d), reinterpret_cast<const uint32_t *>(s), n);
+        else hipLaunchKernelGGL(k_copy_small<uint8_t>, dim3(blocks), dim3(256), 0, stream, d, s, n);
+    }
+    return hipGetLastError();
+}
+
+namespace {
+__global__ void __launch_bounds__(256) k_copy_counted(uint4 *__restrict__ dst, const uint4 *__restrict__ src, const uint32_t *cursor,
+                                                      uint32_t base, uint32_t row_bytes, uint64_t cap_rows)
+{
+    const uint64_t rows = min((uint64_t)(*cursor - base), cap_rows);
+    const uint64_t n16 = (rows * row_bytes + 15) / 16;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+hipError_t isx_copy_rows_to_host(void *hdst, const void *dsrc, const uint32_t *d_cursor, uint32_t base, uint32_t row_bytes,
+                                 size_t cap_rows, hipStream_t stream)
+{
+    if (!cap_rows) return hipSuccess;
+    if (((reinterpret_cast<uintptr_t>(hdst) | reinterpret_cast<uintptr_t>(dsrc)) & 15) != 0) return hipErrorInvalidValue;
+    const size_t n16 = (cap_rows * row_bytes + 15) / 16;
+    const int blocks = (int)std::min<size_t>(64, (n16 + 1023) / 1024);
+    hipLaunchKernelGGL(k_copy_counted, dim3(std::max(blocks, 1)), dim3(256), 0, stream, static_cast<uint4 *>(hdst), static_cast<const uint4 *>(dsrc),
+                       d_cursor, base, row_bytes, (uint64_t)cap_rows);
+    return hipGetLastError();
+}
+
+namespace {
+struct ReadBack {
+    uint8_t *pin = nullptr;
+    size_t used = 0;
+    struct Item { void *dst; size_t off, bytes; };
+    std::vector<Item> items;
+    static constexpr size_t CAP = (size_t)1 << 20;
+    ~ReadBack() { if (pin) isx_pin_free(pin); }
+};
+thread_local ReadBack g_rb;
+}  // namespace
+
+hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStream_t stream)
+{
+    if (!bytes) return hipSuccess;
+    ReadBack &rb = g_rb;
+    if (!rb.pin && isx_pin_malloc(reinterpret_cast<void **>(&rb.pin), ReadBack::CAP) != hipSuccess) rb.pin = nullptr;
+    const size_t off = (rb.used + 15) & ~(size_t)15;
+    if (!rb.pin || off + bytes > ReadBack::CAP) return hipMemcpyAsync(host_dst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
+    const hipError_t e = isx_copy_to_host(rb.pin + off, dsrc, bytes, stream);
+    if (e != hipSuccess) return e;
+    rb.items.push_back({host_dst, off, bytes});
+    rb.used = off + bytes;
+    return hipSuccess;
+}
+
+hipError_t isx_read_sync(hipStream_t stream)
+{
+    const hipError_t e = hipStreamSynchronize(stream);
+    ReadBack &rb = g_rb;
+    if (e == hipSuccess) for (const auto &it : rb.items) memcpy(it.dst, rb.pin + it.off, it.bytes);
+    rb.items.clear();
+    rb.used = 0;
     return e;
 }
 
@@ -881,12 +959,12 @@ int launch_pass(isx_batch *b)
 
 // wait for the pass enqueued by launch_pass and collect it (linkage stages run here: they need the
 // table sizes on the host); *cap_flags receives the ISX_FLAG_CAP_* bits of tables that were too small
-int finish_pass(isx_batch *b, uint32_t *cap_flags)
+int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
 {
     *cap_flags = 0;
     isx_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
+    hipStream_t s = link_stream ? link_stream : c->stream;      // (a pipe's finishers each bring their own: two batches are finished side by side)
     b->in_flight = false;
     if (!b->publish_enqueued) {
         PileupArgs pa{};

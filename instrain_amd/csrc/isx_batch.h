@@ -115,7 +115,7 @@ int batch_set_geometry(isx_batch *b);
 
 extern "C" {
 int launch_pass(isx_batch *b);
-int finish_pass(isx_batch *b, uint32_t *cap_flags);
+int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream = nullptr);
 // grow the tables named by cap_flags (x4 up to their hard bounds); the pass must then be repeated
 int batch_grow_tables(isx_batch *b, uint32_t cap_flags);
 }

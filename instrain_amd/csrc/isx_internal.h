@@ -44,6 +44,17 @@ void isx_dev_trim();        // both caches
 // through the CUs' own store path (a few dozen workgroups keep the link's upstream direction full) while the DMA engine brings
 // the next batch in.  Falls back to hipMemcpyAsync for small or unaligned copies.
 hipError_t isx_copy_to_host(void *hdst_pinned, const void *dsrc, size_t bytes, hipStream_t stream);
+// Small read-backs into ANY host memory (table sizes, the last element of a scan, a few hundred rows): the same kernel route
+// through a pinned scratch of the calling thread (1 MiB) -- a 4-byte hipMemcpyAsync queues behind whatever 100 MB copy-in the DMA
+// engine is busy with (up to ~2 ms each, several per batch).  isx_read_back enqueues, isx_read_sync waits for the stream and
+// delivers the values; larger requests than the scratch has room for go to hipMemcpyAsync.
+// rows [0, min(*cursor - base, cap_rows)) of a device table into pinned host memory: the count is read on the device, so the
+// copy can be enqueued behind the kernel that produces the rows without the host knowing how many there will be -- and without
+// copying a fixed-size prefix of mostly unused rows (up to 15 bytes beyond the last row are copied: both tables are larger)
+hipError_t isx_copy_rows_to_host(void *hdst_pinned, const void *dsrc, const uint32_t *d_cursor, uint32_t base, uint32_t row_bytes,
+                                 size_t cap_rows, hipStream_t stream);
+hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStream_t stream);
+hipError_t isx_read_sync(hipStream_t stream);
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \

@@ -509,9 +509,9 @@ int scan_total(LinkageBuffers &B, hipStream_t s, uint32_t *cnt, uint32_t *off, u
     int rc;
     RP(rocprim::exclusive_scan(tp, tb, cnt, off, 0u, n, rocprim::plus<uint32_t>(), s));
     uint32_t last_off = 0, last_cnt = 0;
-    HIP_TRY(hipMemcpyAsync(&last_off, off + (n - 1), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&last_cnt, cnt + (n - 1), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(isx_read_back(&last_off, off + (n - 1), 4, s));
+    HIP_TRY(isx_read_back(&last_cnt, cnt + (n - 1), 4, s));
+    HIP_TRY(isx_read_sync(s));
     total = (uint64_t)last_off + last_cnt;
     return ISX_OK;
 }
@@ -540,9 +540,9 @@ int sparse_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_
                        B.site_split.p, nullptr, B.incr_off.p, B.keys.p, sb);
     RP(rocprim::radix_sort_keys(tp, tb, B.keys.p, B.keys2.p, (size_t)n_inc, 0, 2 * sb + 12, s));
     RP(rocprim::run_length_encode(tp, tb, B.keys2.p, (size_t)n_inc, B.ukeys.p, B.ucnt.p, B.n_runs.p, s));
-    HIP_TRY(hipMemcpyAsync(&n_u, B.n_runs.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(isx_read_back(&n_u, B.n_runs.p, 4, s));
     EV(4);
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(isx_read_sync(s));
     return ISX_OK;
 }
 
@@ -571,9 +571,9 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
     hipLaunchKernelGGL(k_split_first_row, ga, blk, 0, s, B.key64b.p, B.row_id.p, n_ao, B.first_row.p);
     hipLaunchKernelGGL(k_split_first_site, dim3((n_sites + 255) / 256), blk, 0, s, B.site_split.p, n_sites, B.first_site.p);
     std::vector<uint32_t> frow((size_t)nsp + 1), fsite((size_t)nsp + 1);
-    HIP_TRY(hipMemcpyAsync(frow.data(), B.first_row.p, frow.size() * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(fsite.data(), B.first_site.p, fsite.size() * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(isx_read_back(frow.data(), B.first_row.p, frow.size() * 4, s));
+    HIP_TRY(isx_read_back(fsite.data(), B.first_site.p, fsite.size() * 4, s));
+    HIP_TRY(isx_read_sync(s));
     frow[nsp] = (uint32_t)n_rows; fsite[nsp] = n_sites;
     for (uint32_t i = nsp; i-- > 0;) {
         if (frow[i] == 0xFFFFFFFFu) frow[i] = frow[i + 1];
@@ -650,9 +650,9 @@ int dense_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_t
                               rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s));
     RP(rocprim::reduce(tp, tb, B.vals2.p, B.n_runs.p + 1, 0u, (size_t)n_k, rocprim::plus<uint32_t>(), s));
     uint32_t h2[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h2, B.n_runs.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(isx_read_back(h2, B.n_runs.p, 8, s));
     EV(4);
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(isx_read_sync(s));
     n_u = h2[0];
     out.n_increments = h2[1];
     return ISX_OK;
@@ -720,8 +720,8 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     uint64_t n_ld = 0;
     if ((rc = scan_total(B, s, B.rows_per.p, B.row_off.p, n_u, n_ld))) return rc;
     uint32_t n_edges = 0;
-    HIP_TRY(hipMemcpyAsync(&n_edges, B.n_runs.p + 1, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(isx_read_back(&n_edges, B.n_runs.p + 1, 4, s));
+    HIP_TRY(isx_read_sync(s));
     out.n_edges = n_edges;
     out.n_ld = n_ld;
     if (n_ld) {

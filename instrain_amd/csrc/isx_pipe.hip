@@ -139,7 +139,8 @@ struct isx_pipe {
     std::unique_ptr<isxenc::HostPool> pool;
     std::vector<Slot> slots;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
-    hipStream_t s_fin = nullptr;            // the finisher's own queue: what it fetches must not wait behind the copy-outs of later batches
+    hipStream_t s_fin = nullptr;            // the finishers' own queues: what they fetch must not wait behind the copy-outs of later batches
+    hipStream_t s_fin2 = nullptr;           // (one per finisher thread: a sync of one must not wait for the other's 30 MB table)
     int64_t next_ticket = 0;
     int64_t cap_rec = 0;
     int64_t ring_half = 0;                  // records per half of a slot's staging ring; 0 = the pinned arena holds the whole stream
@@ -152,6 +153,8 @@ struct isx_pipe {
     // the finisher: a thread that takes every submitted batch as soon as its copy-out has landed -- sizes, table growth +
     // repeated pass, linkage stages, row sorting -- so that this work overlaps the caller encoding the next batch
     std::thread finisher;
+    std::thread finisher2;                  // depth >= 2: two batches are finished side by side (the work is host latency: syncs, small sorts)
+    std::mutex bounce_mu;                   // the bounce buffers and fin_pool belong to one finisher at a time
     std::mutex mu;                          // slot states + the work queue
     std::condition_variable cv_work, cv_done;
     std::deque<int64_t> work;
@@ -179,12 +182,12 @@ struct isx_pipe {
 };
 
 // device -> plain host memory at link speed: pieces through the two pinned bounce buffers, emptied by the finisher's threads
-static int bounce_d2h(isx_pipe *p, void *hdst, const void *dsrc, size_t bytes)
+static int bounce_d2h(isx_pipe *p, void *hdst, const void *dsrc, size_t bytes, hipStream_t st)
 {
     if (!bytes) return ISX_OK;
+    std::lock_guard<std::mutex> bounce_lk(p->bounce_mu);
     const size_t piece = p->bounce_bytes;
     const size_t n_pieces = (bytes + piece - 1) / piece;
-    hipStream_t st = p->s_fin;
     auto issue = [&](size_t k) -> hipError_t {
         const size_t off = k * piece, len = std::min(piece, bytes - off);
         hipError_t e = isx_copy_to_host(p->bounce[k & 1], static_cast<const uint8_t *>(dsrc) + off, len, st);
@@ -218,11 +221,13 @@ static void pipe_free(isx_pipe *p)
         { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
         p->cv_work.notify_all();
         p->finisher.join();
+        if (p->finisher2.joinable()) p->finisher2.join();
     }
     (void)hipSetDevice(p->ctx->device);
     if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
     if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
     if (p->s_fin) (void)hipStreamSynchronize(p->s_fin);
+    if (p->s_fin2) (void)hipStreamSynchronize(p->s_fin2);
     for (int i = 0; i < 2; i++) if (p->ctx->pstream[i]) (void)hipStreamSynchronize(p->ctx->pstream[i]);
     const double t_f0 = now_ms();
     double t_batch = 0, t_dev = 0, t_pin = 0;
@@ -260,6 +265,7 @@ static void pipe_free(isx_pipe *p)
     if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
     if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     if (p->s_fin) (void)hipStreamDestroy(p->s_fin);
+    if (p->s_fin2) (void)hipStreamDestroy(p->s_fin2);
     delete p;
 }
 
@@ -389,7 +395,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
 }
 
 // everything between "the batch's copy-out has landed" and "its tables can be handed to the caller"
-static int finish_slot(isx_pipe *p, Slot &s)
+static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
 {
     isx_ctx *c = p->ctx;
     isx_batch *b = s.b;
@@ -403,7 +409,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
     bool redo = false;
     for (int attempt = 0;; attempt++) {
         uint32_t cf = 0;
-        int rc = finish_pass(b, &cf);           // sizes from the published cursors; linkage stages when enabled
+        int rc = finish_pass(b, &cf, sfin);     // sizes from the published cursors; linkage stages when enabled (on this finisher's queue)
         if (rc != ISX_OK) return rc;
         // a batch taken for shallow that has more positions beyond 255 than the exact-coverage list holds: again with 16 bits
         const bool cov8_overflow = !cf && dense && b->sparse_out && b->cov8_out && (size_t)b->n_sat > b->cap_sat;
@@ -427,11 +433,20 @@ static int finish_slot(isx_pipe *p, Slot &s)
         redo = true;
     }
     t_fin = now_ms();
+    s.d2h_bytes += (int64_t)(std::min((size_t)b->sizes.n_snv, p->snv_prefix) * sizeof(isx_snv));
+    if (dense && p->prm.rarefied_coverage > 0) s.d2h_bytes += (int64_t)(std::min((size_t)b->n_rare, p->rare_prefix) * sizeof(isx_rare));
     // device -> the slot's result block: through the bounce buffers into a plain block, a blocking copy into a pinned one
+    // small tables into any host memory, waited for: through the calling thread's pinned scratch (isx_read_back), not the DMA queue
+    auto pull = [&](void *hdst, const void *dsrc, size_t bytes) -> int {
+        if (!bytes) return ISX_OK;
+        HIP_TRY(isx_read_back(hdst, dsrc, bytes, sfin));
+        HIP_TRY(isx_read_sync(sfin));
+        return ISX_OK;
+    };
     auto fetch = [&](void *hdst, const void *dsrc, size_t bytes) -> int {
         if (!bytes) return ISX_OK;
-        if (!s.out_pinned) return bounce_d2h(p, hdst, dsrc, bytes);
-        HIP_TRY(isx_copy_to_host(hdst, dsrc, bytes, p->s_fin));
+        if (!s.out_pinned) return bounce_d2h(p, hdst, dsrc, bytes, sfin);
+        HIP_TRY(isx_copy_to_host(hdst, dsrc, bytes, sfin));
         return ISX_OK;
     };
     if (dense) {
@@ -449,7 +464,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
             s.d2h_bytes += (int64_t)b->n_pos * (s.cov8 ? 1 : 2);
             const size_t n_clon = b->n_clon;
             if (n_clon <= b->cap_clon && n_clon * 2 <= (size_t)b->n_pos) {
-                if ((rc = sort_pairs_by_position(p->s_fin, b->d_clon_list, b->d_clon_sorted, n_clon, &s.sort_temp, &s.sort_temp_bytes)) != ISX_OK) return rc;
+                if ((rc = sort_pairs_by_position(sfin, b->d_clon_list, b->d_clon_sorted, n_clon, &s.sort_temp, &s.sort_temp_bytes)) != ISX_OK) return rc;
                 if ((rc = fetch(s.h_out + s.o_clon, b->d_clon_sorted, n_clon * sizeof(isx_rare))) != ISX_OK) return rc;
                 s.clon_sparse = true;
                 s.d2h_bytes += (int64_t)(n_clon * sizeof(isx_rare));
@@ -467,8 +482,8 @@ static int finish_slot(isx_pipe *p, Slot &s)
         }
         // exact coverage of the saturated positions (a handful; none at all for most batches)
         s.sat_rows.resize(s.sat_complete ? (size_t)b->n_sat : 0);
-        if (!s.sat_rows.empty()) HIP_TRY(hipMemcpyAsync(s.sat_rows.data(), b->d_sat, s.sat_rows.size() * sizeof(isx_sat), hipMemcpyDeviceToHost, p->s_fin));
-        HIP_TRY(hipStreamSynchronize(p->s_fin));
+        if (!s.sat_rows.empty()) HIP_TRY(isx_read_back(s.sat_rows.data(), b->d_sat, s.sat_rows.size() * sizeof(isx_sat), sfin));
+        HIP_TRY(isx_read_sync(sfin));
     }
     if (dense && p->prm.rarefied_coverage > 0) {        // the sparse clonTR table, ascending positions
         const size_t n_rare = b->n_rare;
@@ -482,7 +497,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
             // position for every pipe is not worth it)
             if (!p->pp.want_counts) {
                 if (s.clonr_big.size() < (size_t)b->n_pos) s.clonr_big.resize((size_t)b->n_pos);
-                if (p->bounce[0]) { const int rc = bounce_d2h(p, s.clonr_big.data(), b->d_clon_r, (size_t)b->n_pos * 4); if (rc != ISX_OK) return rc; }
+                if (p->bounce[0]) { const int rc = bounce_d2h(p, s.clonr_big.data(), b->d_clon_r, (size_t)b->n_pos * 4, sfin); if (rc != ISX_OK) return rc; }
                 else HIP_TRY(hipMemcpy(s.clonr_big.data(), b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
             } else if (redo && s.out_pinned)
                 HIP_TRY(hipMemcpy(s.h_out + s.o_clonr, b->d_clon_r, (size_t)b->n_pos * 4, hipMemcpyDeviceToHost));
@@ -490,7 +505,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
         } else {
             if (n_rare > p->rare_prefix || redo) {
                 if (n_rare > p->rare_prefix) { s.rare_big.resize(n_rare); rr = s.rare_big.data(); }
-                if (n_rare) HIP_TRY(hipMemcpy(rr, b->d_rare, n_rare * sizeof(isx_rare), hipMemcpyDeviceToHost));
+                { const int prc = pull(rr, b->d_rare, n_rare * sizeof(isx_rare)); if (prc != ISX_OK) return prc; }
             }
             std::sort(rr, rr + n_rare, [](const isx_rare &x, const isx_rare &y) { return x.gpos < y.gpos; });
         }
@@ -500,13 +515,13 @@ static int finish_slot(isx_pipe *p, Slot &s)
     isx_snv *rows = reinterpret_cast<isx_snv *>(s.h_small + s.o_snv);
     if (n_snv > p->snv_prefix || redo) {
         if (n_snv > p->snv_prefix) { s.snv_big.resize(n_snv); rows = s.snv_big.data(); }
-        if (n_snv) HIP_TRY(hipMemcpy(rows, b->d_snv, n_snv * sizeof(isx_snv), hipMemcpyDeviceToHost));
+        { const int prc = pull(rows, b->d_snv, n_snv * sizeof(isx_snv)); if (prc != ISX_OK) return prc; }
     }
     std::sort(rows, rows + n_snv, [](const isx_snv &x, const isx_snv &y) { return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm; });
     if (p->prm.enable_linkage) {
         // the LD rows too: a blocking copy issued by the caller would queue behind the next batches' large transfers
         s.ld_rows.resize((size_t)b->sizes.n_ld);
-        if (!s.ld_rows.empty()) { const int rc = isx_batch_fetch_ld(b, s.ld_rows.data()); if (rc != ISX_OK) return rc; }
+        if (!s.ld_rows.empty()) { const int rc = pull(s.ld_rows.data(), b->L.ld.p, s.ld_rows.size() * sizeof(isx_ld)); if (rc != ISX_OK) return rc; }
     }
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe finisher] wait %.2f ms, finish (sizes, linkage) %.2f ms [device: sites %.2f allele %.2f group %.2f incr %.2f ld %.2f; %lld ao, %lld incr, %lld ld], clonTR list (%u) %.2f ms, snv rows (%zu) %.2f ms\n",
@@ -515,7 +530,7 @@ static int finish_slot(isx_pipe *p, Slot &s)
     return ISX_OK;
 }
 
-static void finisher_main(isx_pipe *p)
+static void finisher_main(isx_pipe *p, hipStream_t sfin)
 {
     (void)hipSetDevice(p->ctx->device);
     for (;;) {
@@ -528,7 +543,7 @@ static void finisher_main(isx_pipe *p)
             p->work.pop_front();
         }
         Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
-        const int rc = finish_slot(p, s);
+        const int rc = finish_slot(p, s, sfin);
         std::string err = rc == ISX_OK ? std::string() : std::string(isx_last_error());
         BamBatch *dead = nullptr;
         {
@@ -655,6 +670,7 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&p->s_fin, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&p->s_fin2, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking)) != hipSuccess) {
         isx_set_error(std::string("isx_pipe_create: ") + hipGetErrorString(e));
         pipe_free(p);
@@ -672,7 +688,8 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
         if (rc != ISX_OK) { isx_set_error("isx_pipe_create: bounce buffers"); pipe_free(p); return rc; }
         p->fin_pool.reset(new isxenc::HostPool(std::max(1, std::min(nt, 6)), -1, false));
     }
-    p->finisher = std::thread(finisher_main, p);
+    p->finisher = std::thread(finisher_main, p, p->s_fin);
+    if (pp->depth >= 2) p->finisher2 = std::thread(finisher_main, p, p->s_fin2);
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_create] thread pool %.1f ms, %d slot(s) %.1f ms\n", t_c1 - t_c0, pp->depth, now_ms() - t_c1);
     if (pp->stage_async && p->segs) p->stager = std::thread(stager_main, p);
@@ -729,13 +746,13 @@ static int enqueue_pass_impl(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticke
     HIP_TRY(hipStreamWaitEvent(p->s_d2h, s.ev_pass, 0));
     HIP_TRY(hipEventRecord(s.ev_d2h0, p->s_d2h));
     const size_t snv_rows = std::min(p->snv_prefix, b->cap_snv);
-    HIP_TRY(isx_copy_to_host(s.h_small + s.o_snv, b->d_snv, snv_rows * sizeof(isx_snv), p->s_d2h));
-    s.d2h_bytes = (int64_t)(snv_rows * sizeof(isx_snv));
+    // the SNV rows (and clonTR entries) this pass will have produced: counted on the device, no fixed-size prefix
+    HIP_TRY(isx_copy_rows_to_host(s.h_small + s.o_snv, b->d_snv, b->d_cursors + CUR_SNV, b->base[CUR_SNV], (uint32_t)sizeof(isx_snv), snv_rows, p->s_d2h));
+    s.d2h_bytes = 0;                        // (finish_slot adds what really travelled)
     if (dense) {
         if (p->prm.rarefied_coverage > 0) {
             const size_t n = std::min(p->rare_prefix, std::min(p->cap_rare, (size_t)n_pos));
-            HIP_TRY(isx_copy_to_host(s.h_small + s.o_rare, b->d_rare, n * sizeof(isx_rare), p->s_d2h));
-            s.d2h_bytes += (int64_t)(n * sizeof(isx_rare));
+            HIP_TRY(isx_copy_rows_to_host(s.h_small + s.o_rare, b->d_rare, b->d_cursors + CUR_RARE, b->base[CUR_RARE], (uint32_t)sizeof(isx_rare), n, p->s_d2h));
         }
         if (!b->sparse_out) s.d2h_bytes += (int64_t)n_pos * 6;
     }
