@@ -390,7 +390,8 @@ int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_sp
 /* The same, fed by the BAM front end (isx_bam_* below; the file must be scanned and filtered): references `refs`
  * (ascending ids) are expanded straight into the slot's pinned staging -- neither the 8-byte records nor (read-level
  * pipe) the read segments of the batch ever exist as a whole.  split_bounds == NULL: the front end's own iterate_splits geometry.  ref[n_pos] = base codes of
- * the batch's references laid end to end.  info (may be NULL) receives the batch's counts. */
+ * the batch's references laid end to end.  info (may be NULL) receives the batch's counts.  `bam` must stay open until the
+ * batch has been collected (its reads go back to the handle then and are freed with it). */
 int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s *bp, const int32_t *refs, int32_t n_refs,
                         const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds, struct isx_bam_info_s *info,
                         int64_t *ticket);

@@ -191,7 +191,7 @@ hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStre
     const size_t off = (rb.used + 15) & ~(size_t)15;
     if (!rb.pin || off + bytes > ReadBack::CAP) return hipMemcpyAsync(host_dst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
     const hipError_t e = isx_copy_to_host(rb.pin + off, dsrc, bytes, stream);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) { rb.items.clear(); rb.used = 0; return e; }      // (the caller returns without a sync: nothing may stay pending)
     rb.items.push_back({host_dst, off, bytes});
     rb.used = off + bytes;
     return hipSuccess;

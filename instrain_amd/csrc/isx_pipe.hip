@@ -545,15 +545,15 @@ static void finisher_main(isx_pipe *p, hipStream_t sfin)
         Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
         const int rc = finish_slot(p, s, sfin);
         std::string err = rc == ISX_OK ? std::string() : std::string(isx_last_error());
-        BamBatch *dead = nullptr;
         {
             std::lock_guard<std::mutex> lk(p->mu);
             s.rc = rc; s.err.swap(err);
+            // the front end's batch goes back to its handle BEFORE the slot is published as finished: once the caller has
+            // collected its last batch it may close the handle (freed with it: unmapping a gigabyte now would stall the caller)
+            if (s.dead_batch) { bam_batch_retire(s.dead_batch); s.dead_batch = nullptr; }
             s.state = 2;
-            dead = s.dead_batch; s.dead_batch = nullptr;
         }
         p->cv_done.notify_all();
-        if (dead) bam_batch_retire(dead);          // (freed with its handle: unmapping a gigabyte now would stall the caller's next steps)
     }
 }
 
