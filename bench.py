@@ -1,23 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline measurement of the `inStrain profile` hot path on MI355X.
 
-A "step" = one batch of synthetic reads profiled ONCE, the way production does it: the batch is handed over from
-host memory as READ SEGMENTS (isx_pipe_submit_reads: 64-byte records staged into pinned memory by the pipe's host
-threads, hipMemcpyAsync in), expanded and profiled on the device (k_pileup_dense walks the segments into its LDS
-window histograms, SNV call epilogue) and its tables copied back to pinned host memory (isx_pipe_collect).  The K
-timed steps stream K batches through the pipe with copy-in / pass / copy-out of consecutive batches overlapping; the
-batches are distinct (up to 32 variants of the workload, synth.shifted_variant_segs; cycled beyond that).  At N=1 the
-workload is BASELINE.json configs[1] (C2: one 5 Mbp genome, 20x, 2x150 bp, --skip_mm_profiling, linkage off).  For
-N>1 every rank streams its own C2 genomes (scaffolds shard embarrassingly; weak scaling; no data-path collective;
-one final RCCL gather of the SNV tables after the timed region, reported separately).
+The headline is BASELINE.json configs[4], the configuration north_star quotes its target on: the
+1000-genome database with 10 Gbp of reads, --database_mode, pileup + SNV call + linkage.  A STEP = one pass over the
+rank's share of the kept database (N = 1: all of it, ~80 batches of a few genomes), every batch handed over from host
+memory as READ SEGMENTS (isx_pipe_submit_reads: 64-byte records staged into pinned memory by the pipe's host threads,
+hipMemcpyAsync in), profiled ONCE on the device (k_pileup_dense walks the segments into its LDS window histograms, SNV
+call epilogue, linkage chain) and its tables copied back to pinned host memory (isx_pipe_collect); copy-in / pass /
+copy-out of consecutive batches overlap in the pipe.  Before the timed steps ONE untimed pass checks every batch's
+tables on the host (C5Run.verify_pass); every timed batch's row counts must equal that pass's.  N > 1: the 8 LPT shards
+of the database are dealt over the ranks (strong scaling; no data-path collective; one final RCCL gather of the SNV
+tables after the timed region, reported separately).  `python bench.py --gpus N` without a launcher starts its N ranks
+itself (torch.distributed.run on 127.0.0.1).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects `roofline` (dominant kernel
-vs the HBM roof, the kernel alone over a resident batch), `roofline_lds` (the same kernel vs the LDS atomic rate, its
-real bound), `roofline_observation_kernel` (the 2-byte-record kernel of the observation hand-over), `roofline_pcie`,
-`resident`, `mm_on`, `linkage` (C3), `c5` (configs[4]: the whole kept database through one GPU at N=1, with
-`cpu_baseline` = the C port and `cpu_baseline_python` = the reference-like Python restatement on the same
-configuration), `bam_sharded` (one BAM over the ranks), `profile_bam` / `c5_bam` (BAM on disk -> SplitObjects) and
-`cpu_baseline` / `cpu_baseline_python` (C2; rank 0, N=1 only).
+Prints ONE short JSON line on rank 0 (contract in the task statement: metric / value / ... / config / roofline /
+cpu_baseline + cpu_baseline_python on the same configuration) and writes the full record -- every leg's detail -- to
+bench_detail.json (--detail): `c5` (the headline in full), `c2_stream` (configs[1] streamed, the round-3 headline),
+`roofline_c2_resident` / `roofline_lds` / `roofline_observation_kernel` (the kernels alone over resident C2 batches),
+`mm_on`, `linkage` (C3), `bam_sharded` (one BAM over the ranks), `profile_bam` / `c5_bam` (BAM on disk -> SplitObjects),
+`cpu_baseline_c2` / `cpu_baseline_python_c2`.
 """
 import argparse
 import json
@@ -304,11 +305,38 @@ def linkage_leg(ctx, seed=3):
     return out
 
 
-def _pmc(key):
+def _kernel_source_sha():
+    """identity of the kernels the PMC passes were collected on: sha1 over the pileup kernel source"""
+    import hashlib
     try:
-        return json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get(key)
-    except Exception:
+        return hashlib.sha1(open(os.path.join(REPO, "instrain_amd", "csrc", "isx_pileup.hip"), "rb").read()).hexdigest()[:16]
+    except OSError:
         return None
+
+
+def _pmc_file():
+    try:
+        return json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return {}
+
+
+def _pmc(key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/make_profiles.sh) -- None when the kernel source
+    changed since the passes were collected (a stale figure is not a measurement)."""
+    j = _pmc_file()
+    if j.get("kernel_source_sha") != _kernel_source_sha():
+        return None
+    return j.get(key)
+
+
+def _pmc_source(key):
+    j = _pmc_file()
+    if key not in j:
+        return None
+    stale = j.get("kernel_source_sha") != _kernel_source_sha()
+    return "profiles/pmc_traffic.json: rocprofv3 --pmc passes of tag %s at commit %s%s" % (
+        j.get("tag"), j.get("commit"), " -- STALE (isx_pileup.hip changed since), traffic withheld" if stale else "")
 
 
 def _roofline(kernel, ab, k_ms, t, traffic=None, **extra):
@@ -387,81 +415,137 @@ def _c5_plan(scale, host_threads):
     return meta, kept, shards, n_genomes
 
 
-def c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=4, with_cpu=True, scale=1.0, stage_async=False):
-    """BASELINE.json configs[4]: 1000-genome database, 10 Gbp of reads, --database_mode (one mm bin; genomes
-    below 1x dropped like fasta.py:110-136 does).  The kept genomes are LPT-sharded 8 ways on the reference's own cost estimate
-    (read pairs, profile_controller.py:460-465); rank r streams the shards r, r + N, ... through its read-level pipe in
-    batches of a few genomes, every batch handed over, profiled once (pileup + SNV call + linkage), tables copied back.
-    N = 1: the WHOLE kept database through one GPU; N = 8: one shard per GPU (strong scaling of the configuration)."""
-    _trace("c5_leg")
-    from instrain_amd import dist as idist
-    from instrain_amd import engine
-    meta, kept, shards, n_genomes = _c5_plan(scale, host_threads)
-    my_shards = [s for s in range(8) if s % world == rank % world]
-    t0 = time.perf_counter()
-    ws = []
-    for sh in my_shards:
-        mine = kept[shards[sh]]
-        est = (meta.pairs[mine] * 2).astype(np.int64)          # segments: one per read
-        for b in idist.pack_batches(meta.length[mine], est, 40_000_000, 1_000_000):
-            ws.append(meta.generate_segs(mine[b]))
-    gen_s = time.perf_counter() - t0
-    pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["segs"].n_seg for w in ws),
-                       max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
-                       pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20, stage_async=stage_async)
-    stream(pipe, ws[:min(len(ws), 2 * depth)], min(len(ws), 2 * depth), depth)      # warm-up: every slot's tables and linkage buffers reach their steady size
-    barrier()
-    stats = []
-    t0 = time.perf_counter()
-    last = stream(pipe, ws, len(ws), depth, stats, keep_last=True)
-    barrier()
-    dt = time.perf_counter() - t0
-    pipe.close()
-    bases = float(sum(w["profiled_bases"] for w in ws))
-    dt_max, bases_all, gather_ms = dist_info(dt, bases, last)
-    st = [s for s, _ in stats]
-    tot = lambda k: float(np.sum([s[k] for s in st]))
-    n_obs = int(sum(w["n_obs"] for w in ws))
-    n_pos = int(sum(w["n_pos"] for w in ws))
-    n_rec = int(sum((w["segs"].n_seg + 15) // 16 * 16 for w in ws))
-    abytes = pileup_algorithmic_bytes(n_obs, n_pos, 0, dense=True, record_bytes=64, n_rec=n_rec, out_bytes_per_pos=slot_out_bytes_per_pos(n_obs, n_pos), ref_bytes_per_pos=0.5)
-    k_ms = tot("kernel_ms")
-    out = {"workload": "C5%s: the %d kept genomes of the 1000-genome database (%.2f Gbp of positions, %.2f Gbp of reads in all), --database_mode, "
-                       "pileup + SNV call + linkage; this rank: shards %s of 8 (%.2f Gbp of reads) streamed as read segments in %d batches%s"
-                       % (" whole configuration through ONE GPU" if world == 1 else " over %d GPUs" % world, len(kept),
-                          float(meta.length[kept].sum()) / 1e9, float(meta.pairs[kept].sum()) * 2 * meta.read_len / 1e9, my_shards,
-                          bases / 1e9, len(ws), "" if n_genomes == 1000 else " [DEBUG SCALE: %d genomes]" % n_genomes),
-           "gbp_per_s": bases_all / dt_max / 1e9, "seconds": dt_max, "n_gpus": world, "scaling": "strong",
-           "genomes_kept": int(len(kept)), "genomes_total": n_genomes, "positions": n_pos, "kept_observations": n_obs, "read_segments": n_rec,
-           "mean_depth": n_obs / max(n_pos, 1), "snv_rows": int(sum(z["n_snv"] for _, z in stats)),
-           "linkage": "on (sparse path; the reference links every profile, linkage.py:14-44)",
-           "snv_pairs_linked": int(sum(z["n_edges"] for _, z in stats)), "ld_rows": int(sum(z["n_ld"] for _, z in stats)),
-           "snv_pairs_linked_per_s": float(sum(z["n_edges"] for _, z in stats)) * world / dt_max,
-           "load_imbalance": float(max(meta.pairs[kept[s]].sum() for s in shards) / np.mean([meta.pairs[kept[s]].sum() for s in shards])),
-           "generate_s": gen_s,
-           "stages_ms_total": {"host_stage": tot("encode_ms"), "copy_in": tot("h2d_ms"), "kernel": k_ms, "copy_out": tot("d2h_ms"),
-                               "collect_wait": tot("collect_wait_ms"), "wall": dt * 1e3},
-           "roofline": {"bound": "hbm", "kernel": "k_pileup_dense (read segments)", "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
-                        "algorithmic_bytes": abytes, "bytes_per_position": abytes / max(n_pos, 1), "kernel_ms_total": k_ms, "launches": len(st),
-                        "traffic": None},
-           "roofline_pcie": {"bound": "pcie", "direction": "device->host", "achieved": tot("d2h_bytes") / dt / 1e9, "peak": PCIE_PEAK_GBS,
-                             "unit": "GB/s", "frac": tot("d2h_bytes") / dt / 1e9 / PCIE_PEAK_GBS, "bytes": tot("d2h_bytes"),
-                             "bytes_per_position": tot("d2h_bytes") / max(n_pos, 1), "host_to_device_bytes": tot("h2d_bytes")}}
-    if gather_ms is not None:
-        out["final_gather_ms"] = gather_ms
-    if with_cpu:
-        # the CPU baselines on the same configuration: the observation stream of one batch of median size
-        order = np.argsort([w["n_obs"] for w in ws])
-        sel = ws[int(order[len(order) // 2])]["genomes"]
-        wo = meta.generate(sel)
+class C5Run:
+    """BASELINE.json configs[4] (the configuration north_star quotes its target on): 1000-genome database,
+    10 Gbp of reads, --database_mode (one mm bin; genomes below 1x dropped like fasta.py:110-136 does).  The kept genomes are
+    LPT-sharded 8 ways on the reference's own cost estimate (read pairs, profile_controller.py:460-465); rank r takes the
+    shards r, r + N, ... and streams them through its read-level pipe in batches of a few genomes, every batch handed over
+    from host memory, profiled once (pileup + SNV call + linkage), tables copied back.  N = 1: the WHOLE kept database
+    through one GPU; N = 8: one shard per GPU (strong scaling of the configuration).  One STEP = one pass over all of the
+    rank's batches."""
+
+    def __init__(self, ctx, rank, world, host_threads, depth=4, scale=1.0, stage_async=False):
+        from instrain_amd import dist as idist
+        from instrain_amd import engine
+        self.ctx, self.rank, self.world, self.depth = ctx, rank, world, depth
+        self.meta, self.kept, self.shards, self.n_genomes = _c5_plan(scale, host_threads)
+        meta, kept = self.meta, self.kept
+        self.my_shards = [s for s in range(8) if s % world == rank % world]
+        t0 = time.perf_counter()
+        self.ws = []
+        for sh in self.my_shards:
+            mine = kept[self.shards[sh]]
+            est = (meta.pairs[mine] * 2).astype(np.int64)          # segments: one per read
+            for b in idist.pack_batches(meta.length[mine], est, 40_000_000, 1_000_000):
+                self.ws.append(meta.generate_segs(mine[b]))
+        self.gen_s = time.perf_counter() - t0
+        ws = self.ws
+        self.pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["segs"].n_seg for w in ws),
+                                max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
+                                pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20, stage_async=stage_async)
+        self.bases = float(sum(w["profiled_bases"] for w in ws))
+        self.signature = None
+
+    def verify_pass(self):
+        """One untimed pass in which every batch's tables are CHECKED on the host (size-independent properties): the coverage
+        table sums to the kept observations handed over, SNV rows are strictly ordered by position with counts that sum to
+        the coverage at their position and reach min_cov, LD rows' four counts add up to their total.  Returns and remembers
+        the per-batch signature (n_snv, n_ld, n_edges) the timed passes are compared with."""
+        sig = []
+
+        def check(i, r):
+            w = self.ws[i]
+            cov = (r["cov16"] if "cov16" in r else r["cov8"]).astype(np.int64)
+            lim = 65535 if "cov16" in r else 255
+            total = int(cov.sum())
+            if "saturated" in r:
+                s = r["saturated"]
+                total += int((s["coverage"].astype(np.int64) - lim).sum())
+                cov[s["gpos"]] = s["coverage"]
+            if total != w["n_obs"]:
+                raise AssertionError("C5 batch %d: coverage table sums to %d, %d observations were handed over" % (i, total, w["n_obs"]))
+            snv = r["snv"]
+            g = snv["gpos"].astype(np.int64)
+            if len(g) != r["sizes"]["n_snv"] or (np.diff(g) <= 0).any():
+                raise AssertionError("C5 batch %d: SNV rows not strictly ordered by position" % i)
+            c = snv["cnt"].sum(axis=1).astype(np.int64)
+            if (c != cov[g]).any() or (c < 5).any():
+                raise AssertionError("C5 batch %d: SNV row counts do not sum to the coverage at their position" % i)
+            ld = r["ld"]
+            if len(ld) and (ld["countAB"].astype(np.int64) + ld["countAb"] + ld["countaB"] + ld["countab"] != ld["total"]).any():
+                raise AssertionError("C5 batch %d: LD row counts do not add up" % i)
+            sig.append((int(r["sizes"]["n_snv"]), int(r["sizes"]["n_ld"]), int(r["sizes"]["n_edges"])))
+
+        stream(self.pipe, self.ws, len(self.ws), self.depth, check=check)
+        self.signature = sig
+        return sig
+
+    def run(self, passes, stats=None, keep_last=False):
+        n = len(self.ws)
+        return stream(self.pipe, self.ws, n * passes, self.depth, stats, keep_last=keep_last)
+
+    def check_timed(self, stats):
+        """every timed batch produced the tables of the verified pass (row counts; the stream is deterministic)"""
+        n = len(self.ws)
+        for i, (_, z) in enumerate(stats):
+            if (int(z["n_snv"]), int(z["n_ld"]), int(z["n_edges"])) != self.signature[i % n]:
+                raise AssertionError("C5 timed batch %d differs from the verified pass: %r vs %r"
+                                     % (i, (z["n_snv"], z["n_ld"], z["n_edges"]), self.signature[i % n]))
+
+    def close(self):
+        self.pipe.close()
+
+    def report(self, dt_max, bases_all, stats, passes, gather_ms=None):
+        meta, kept, ws, world = self.meta, self.kept, self.ws, self.world
+        st = [s for s, _ in stats]
+        tot = lambda k: float(np.sum([s[k] for s in st])) / passes          # per pass
+        n_obs = int(sum(w["n_obs"] for w in ws))
+        n_pos = int(sum(w["n_pos"] for w in ws))
+        n_rec = int(sum((w["segs"].n_seg + 15) // 16 * 16 for w in ws))
+        abytes = pileup_algorithmic_bytes(n_obs, n_pos, 0, dense=True, record_bytes=64, n_rec=n_rec,
+                                          out_bytes_per_pos=slot_out_bytes_per_pos(n_obs, n_pos), ref_bytes_per_pos=0.5)
+        k_ms = tot("kernel_ms")
+        one = stats[:len(ws)]
+        out = {"workload": "C5%s: the %d kept genomes of the 1000-genome database (%.2f Gbp of positions, %.2f Gbp of reads in all), --database_mode, "
+                           "pileup + SNV call + linkage; this rank: shards %s of 8 (%.2f Gbp of reads) streamed as read segments in %d batches%s"
+                           % (" whole configuration through ONE GPU" if world == 1 else " over %d GPUs" % world, len(kept),
+                              float(meta.length[kept].sum()) / 1e9, float(meta.pairs[kept].sum()) * 2 * meta.read_len / 1e9, self.my_shards,
+                              self.bases / 1e9, len(ws), "" if self.n_genomes == 1000 else " [DEBUG SCALE: %d genomes]" % self.n_genomes),
+               "gbp_per_s": bases_all * passes / dt_max / 1e9, "seconds_per_pass": dt_max / passes, "n_gpus": world, "scaling": "strong",
+               "genomes_kept": int(len(kept)), "genomes_total": self.n_genomes, "positions": n_pos, "kept_observations": n_obs, "read_segments": n_rec,
+               "batches": len(ws), "mean_depth": n_obs / max(n_pos, 1), "snv_rows": int(sum(z["n_snv"] for _, z in one)),
+               "linkage": "on (sparse path; the reference links every profile, linkage.py:14-44)",
+               "snv_pairs_linked": int(sum(z["n_edges"] for _, z in one)), "ld_rows": int(sum(z["n_ld"] for _, z in one)),
+               "snv_pairs_linked_per_s": float(sum(z["n_edges"] for _, z in one)) * world * passes / dt_max,
+               "load_imbalance": float(max(meta.pairs[kept[s]].sum() for s in self.shards) / np.mean([meta.pairs[kept[s]].sum() for s in self.shards])),
+               "generate_s": self.gen_s,
+               "verified": "every batch checked in an untimed pass (coverage sum == observations handed over, SNV rows ordered and consistent with "
+                           "the coverage, LD counts add up); every timed batch's row counts equal that pass's",
+               "stages_ms_per_pass": {"host_stage": tot("encode_ms"), "copy_in": tot("h2d_ms"), "kernel": k_ms, "copy_out": tot("d2h_ms"),
+                                      "collect_wait": tot("collect_wait_ms"), "wall": dt_max / passes * 1e3},
+               "roofline": {"bound": "hbm", "kernel": "k_pileup_dense<linkage, read segments> (pipe slot output)",
+                            "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
+                            "algorithmic_bytes_per_launch": abytes / max(len(ws), 1), "bytes_per_position": abytes / max(n_pos, 1),
+                            "kernel_ms_avg": k_ms / max(len(ws), 1), "kernel_ms_per_pass": k_ms, "launches": len(st),
+                            "traffic": _pmc("c5_dense_linkage_bytes_per_launch") if self.n_genomes == 1000 else None,
+                            "traffic_source": _pmc_source("c5_dense_linkage_bytes_per_launch")},
+               "roofline_pcie": {"bound": "pcie", "direction": "host->device", "achieved": tot("h2d_bytes") / (dt_max / passes) / 1e9, "peak": PCIE_PEAK_GBS,
+                                 "unit": "GB/s", "frac": tot("h2d_bytes") / (dt_max / passes) / 1e9 / PCIE_PEAK_GBS, "bytes_per_pass": tot("h2d_bytes"),
+                                 "bytes_per_profiled_base": tot("h2d_bytes") / max(self.bases, 1.0),
+                                 "device_to_host_bytes_per_pass": tot("d2h_bytes"), "device_to_host_bytes_per_position": tot("d2h_bytes") / max(n_pos, 1)}}
+        if gather_ms is not None:
+            out["final_gather_ms"] = gather_ms
+        return out
+
+    def cpu_baselines(self):
+        """the CPU baselines on the same configuration: the observation stream of one batch of median size"""
+        order = np.argsort([w["n_obs"] for w in self.ws])
+        sel = self.ws[int(order[len(order) // 2])]["genomes"]
+        wo = self.meta.generate(sel)
         cb = cpu_baseline(wo, budget_s=12.0, min_s=6.0)
-        out["cpu_baseline"] = cb
-        out["speedup_vs_cpu_port"] = out["gbp_per_s"] / cb["value"] if cb["value"] else None
         cp = cpu_baseline_python(wo, n_splits=200, budget_s=15.0)
-        out["cpu_baseline_python"] = cp
-        out["speedup_vs_python_restatement"] = out["gbp_per_s"] / cp["value"] if cp["value"] else None
-    return out
+        return cb, cp
 
 
 def _s2s(info):
@@ -615,8 +699,9 @@ def make_variants(w, n):
         return list(ex.map(lambda k: synth.shifted_variant_segs(w, k), range(n)))
 
 
-def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False):
-    """n_steps batches through the pipe, at most `depth` in flight; returns the last collected result"""
+def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False, check=None):
+    """n_steps batches through the pipe, at most `depth` in flight; returns the last collected result.  check(i, result) is
+    called on every collected batch (untimed verification passes only)."""
     tickets, done, last = [], 0, None
     link = pipe.enable_linkage
 
@@ -625,6 +710,8 @@ def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False):
         r = pipe.collect(tickets[done], want_ld=link, densify=False)      # the tables as they come (views of the slot)
         if stats is not None:
             stats.append((r["stats"], r["sizes"]))
+        if check is not None:
+            check(done % len(variants), r)
         if keep_last and done == n_steps - 1:
             last = {"snv": r["snv"].copy()}
         pipe.release(tickets[done])
@@ -643,27 +730,95 @@ def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False):
     return last
 
 
+def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
+    """The round-3 headline as a leg: BASELINE configs[1] (C2: one 5 Mbp genome, 20x, --skip_mm_profiling, linkage off), one
+    batch per step streamed through a read-level pipe (N = 1 only)."""
+    _trace("C2 stream")
+    from instrain_amd import engine
+    n_var = max(1, min(args.variants, steps))
+    variants = make_variants(w, n_var)
+    pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=0, max_segs=int(w["segs"].n_seg),
+                       max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
+                       pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=args.queued_submit)
+    stream(pipe, variants, warmup, args.depth)
+    stats = []
+    t0 = time.perf_counter()
+    stream(pipe, variants[warmup % n_var:] + variants[:warmup % n_var], steps, args.depth, stats)
+    dt = time.perf_counter() - t0
+    pipe.close()
+    st = [s for s, _ in stats]
+    mean = lambda k: float(np.mean([s[k] for s in st])) if st else 0.0
+    k_ms = mean("kernel_ms")
+    n_pos_v = int(np.mean([v["n_pos"] for v in variants]))
+    n_rec = (int(w["segs"].n_seg) + 15) // 16 * 16
+    abytes = pileup_algorithmic_bytes(w["n_obs"], n_pos_v, 0, dense=True, record_bytes=64, n_rec=n_rec,
+                                      out_bytes_per_pos=slot_out_bytes_per_pos(w["n_obs"], n_pos_v), ref_bytes_per_pos=0.5)
+    ms_step = dt / steps * 1e3
+    h2d_b, d2h_b = mean("h2d_bytes"), mean("d2h_bytes")
+    return {"workload": "C2 streamed: one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, 2x150 bp, --skip_mm_profiling, linkage off; read "
+                        "segments handed over from host memory, profiled once, tables copied back; %d distinct batches" % n_var,
+            "gbp_per_s": float(w["profiled_bases"]) * steps / dt / 1e9, "ms_per_step": ms_step, "steps": steps, "warmup": warmup,
+            "kept_observations": int(w["n_obs"]), "read_segments": int(w["segs"].n_seg), "pipe_depth": args.depth, "host_threads": host_threads,
+            "roofline_in_stream": {"bound": "hbm", "kernel": "k_pileup_dense (read segments, slot output)",
+                                   "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
+                                   "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": k_ms, "launches": len(st)},
+            "roofline_pcie": {"bound": "pcie", "direction": "host->device", "achieved": h2d_b / (ms_step * 1e-3) / 1e9,
+                              "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": h2d_b / (ms_step * 1e-3) / 1e9 / PCIE_PEAK_GBS,
+                              "bytes_per_step": h2d_b, "bytes_per_profiled_base": h2d_b / float(w["profiled_bases"]), "copy_ms_avg": mean("h2d_ms"),
+                              "device_to_host_bytes_per_step": d2h_b},
+            "stages_ms": {"host_stage": mean("encode_ms"), "copy_in": mean("h2d_ms"), "kernel": k_ms, "copy_out": mean("d2h_ms"),
+                          "collect_wait": mean("collect_wait_ms"), "step": ms_step},
+            "snv_rows": int(stats[-1][1]["n_snv"]) if stats else 0}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) under
+    torch.distributed.run on this node and hand their output through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, ISX_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def _short(s, n=118):
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--scale", type=float, default=1.0, help="shrink the C2 genome / the C5 database (debug only; reported in config)")
-    ap.add_argument("--variants", type=int, default=32, help="distinct batches cycled through the timed steps")
+    ap.add_argument("--steps", type=int, default=10, help="timed steps; a step = one pass over the rank's share of the C5 database")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the C5 database / the C2 genome (debug only; reported in config)")
+    ap.add_argument("--variants", type=int, default=32, help="distinct batches cycled through the C2 leg")
     ap.add_argument("--depth", type=int, default=4, help="pipe slots")
     ap.add_argument("--host-threads", type=int, default=0, help="staging threads of the pipe (0 = the cpus this rank may use)")
-    ap.add_argument("--queued-submit", action="store_true", help="submit_reads only queues the batch, the pipe's stager thread encodes it (isx_pipe_params.stage_async = 1; same-box A/B in profiles/r03_stream_ab.md: no gain on a 16-cpu cgroup, the stager competes with the encoder's own threads)")
+    ap.add_argument("--queued-submit", action="store_true", help="submit_reads only queues the batch, the pipe's stager thread encodes it (isx_pipe_params.stage_async = 1; same-box A/B in profiles/r03_stream_ab.md: no gain on a 16-cpu cgroup)")
     ap.add_argument("--pin", action="store_true", help="bind the staging threads to the L3 domains of the GPU's NUMA node")
     ap.add_argument("--no-bind", action="store_true", help="do not bind the process to the GPU's NUMA node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-linkage-leg", action="store_true")
     ap.add_argument("--no-mm-leg", action="store_true")
     ap.add_argument("--no-resident-leg", action="store_true")
-    ap.add_argument("--no-c5-leg", action="store_true")
+    ap.add_argument("--no-c2-leg", action="store_true")
     ap.add_argument("--no-bam-leg", action="store_true", help="skip the BAM end-to-end legs (profile_bam, c5_bam, bam_sharded)")
-    ap.add_argument("--only-c5", action="store_true", help="skip the C2 legs' extras (debug)")
+    ap.add_argument("--only-c5", action="store_true", help="the headline alone: no C2 legs, no BAM legs, no CPU baselines (debug)")
+    ap.add_argument("--detail", default=os.path.join(REPO, "bench_detail.json"), help="where the full record goes (the printed line is a digest)")
     ap.add_argument("--window", type=int, default=0)
     args = ap.parse_args()
+    if args.only_c5:
+        args.no_c2_leg = args.no_resident_leg = args.no_mm_leg = args.no_linkage_leg = args.no_cpu_baseline = args.no_bam_leg = True
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -671,11 +826,18 @@ def main():
     from instrain_amd import engine
     from tests import util        # only for the committed null-model LUT fixture (data, not oracle code)
 
-    # ISX_DIST_BACKEND=gloo + ISX_DEVICE=0 let the N>1 control flow be exercised on a 1-GPU box (tests only)
-    rank, local, world = idist.init_from_env(backend=os.environ.get("ISX_DIST_BACKEND"))
-    assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
+    # More ranks than visible GPUs (a 1-GPU box exercising the N > 1 control flow): gloo, ranks share the devices round robin.
+    want_world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get("ISX_DIST_BACKEND") or ("gloo" if want_world > max(n_dev, 1) else None)
+    rank, local, world = idist.init_from_env(backend=backend)
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    shared = n_dev > 0 and world > n_dev
     if "ISX_DEVICE" in os.environ:
         local = int(os.environ["ISX_DEVICE"])
+    elif shared:
+        local = local % n_dev
     use_nccl = world > 1 and dist.get_backend() == "nccl"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local) if (world == 1 or use_nccl) else torch.device("cpu")
@@ -683,15 +845,7 @@ def main():
     ctx = engine.Context(local)
     lut, fb = util.load_lut()
     ctx.set_null_model(lut, fb)
-
-    want_mm = world == 1 and not args.no_mm_leg and not args.only_c5
-    w = c2_workload(seed=2 + rank, scale=args.scale, with_mm=want_mm)
-    n_var = max(1, min(args.variants, args.steps))
-    variants = make_variants(w, n_var)
     host_threads = args.host_threads or max(2, min(48, host_cpus() // world))
-    pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=0, max_segs=int(w["segs"].n_seg),
-                       max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
-                       pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=args.queued_submit)
 
     def barrier():
         if world > 1:
@@ -700,27 +854,30 @@ def main():
             else:
                 dist.barrier()
 
-    # Every step hands one batch of read segments over from host memory, profiles it once and brings its tables back;
-    # consecutive batches overlap in the pipe's three queues.
-    _trace("C2 stream")
-    stream(pipe, variants, args.warmup, args.depth)
+    # ---- the headline: configs[4] (C5), the configuration north_star quotes its target on ----
+    _trace("C5 generate")
+    c5 = C5Run(ctx, rank, world, host_threads, depth=args.depth, scale=args.scale, stage_async=args.queued_submit)
+    _trace("C5 verify pass")
+    c5.verify_pass()                            # untimed: every batch's tables checked on the host; also warms every slot
+    if args.warmup:
+        c5.run(args.warmup)
     barrier()
     torch.cuda.synchronize()
     stats = []
     t0 = time.perf_counter()
-    last = stream(pipe, variants[args.warmup % n_var:] + variants[:args.warmup % n_var], args.steps, args.depth, stats, keep_last=world > 1)
+    last = c5.run(args.steps, stats, keep_last=world > 1)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    c5.check_timed(stats)
+    bases_all = c5.bases
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        u = torch.tensor([float(w["profiled_bases"])], dtype=torch.float64, device=dev)
+        u = torch.tensor([c5.bases], dtype=torch.float64, device=dev)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        units = float(u.item())
-    else:
-        units = float(w["profiled_bases"])
+        bases_all = float(u.item())
 
     # the one collective of the path: final gather of the SNV tables to rank 0 (outside the timed steps)
     gather_ms = None
@@ -732,32 +889,17 @@ def main():
         torch.cuda.synchronize()
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
-    pipe.close()
-
-    # configs[4] (C5): N = 1 streams the whole kept database through the one GPU, N = 8 one shard per GPU; rank 0 reports
-    c5 = None
-    if not args.no_c5_leg:
-        def dist_info(dt_c5, bases, last_c5):
-            g_ms = None
-            if world > 1:
-                t = torch.tensor([dt_c5], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                u = torch.tensor([bases], dtype=torch.float64, device=dev)
-                dist.all_reduce(u, op=dist.ReduceOp.SUM)
-                barrier()
-                g0 = time.perf_counter()
-                idist.gather_tables({"snv": last_c5["snv"]}, dst=0, device=dev)
-                torch.cuda.synchronize()
-                barrier()
-                g_ms = (time.perf_counter() - g0) * 1e3
-                return float(t.item()), float(u.item()), g_ms
-            return dt_c5, bases, g_ms
-        c5 = c5_leg(ctx, rank, world, host_threads, barrier, dist_info, depth=args.depth,
-                    with_cpu=(world == 1 and not args.no_cpu_baseline), scale=args.scale, stage_async=args.queued_submit)
+    head = c5.report(dt, bases_all, stats, args.steps, gather_ms)
+    cb = cp = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, cp = c5.cpu_baselines()
+    n_batches = len(c5.ws)
+    c5.close()
+    del c5
 
     # one BAM sharded over the ranks (every rank takes part; rank 0 reports)
     sharded = None
-    if not args.no_bam_leg and not args.only_c5:
+    if not args.no_bam_leg:
         try:
             sharded = bam_sharded_leg(ctx, rank, world, local, host_threads, barrier, dev)
         except Exception as e:                      # never lose the line over an extra leg
@@ -766,99 +908,94 @@ def main():
                 raise
 
     if rank == 0:
-        st = [s for s, _ in stats]
-        mean = lambda k: float(np.mean([s[k] for s in st])) if st else 0.0
-        k_ms = mean("kernel_ms")                 # dispatch time stamps of every pass of the timed region
-        n_pos_v = int(np.mean([v["n_pos"] for v in variants]))
-        n_rec = (int(w["segs"].n_seg) + 15) // 16 * 16
-        abytes = pileup_algorithmic_bytes(w["n_obs"], n_pos_v, 0, dense=True, record_bytes=64, n_rec=n_rec,
-                                          out_bytes_per_pos=slot_out_bytes_per_pos(w["n_obs"], n_pos_v), ref_bytes_per_pos=0.5)
-        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        ms_step = dt / args.steps * 1e3
-        h2d_b, d2h_b = mean("h2d_bytes"), mean("d2h_bytes")
+        detail = {"c5": head}
         out = {
-            "metric": "Gbp profiled/s", "value": units * args.steps / dt / 1e9, "unit": "Gbp/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": "C2 streamed: one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, 2x150 bp pairs, insert N(350,30), "
-                                   "--skip_mm_profiling (1 mm bin), linkage off; every batch handed over from host memory as READ SEGMENTS "
-                                   "(64-byte records: start, length, 150 x 3-bit base codes with the quality filter applied -> pinned "
-                                   "hipMemcpyAsync), expanded + profiled once on the device (pileup + SNV call), tables copied back; "
-                                   "%d distinct batches" % n_var,
-                       "genome_bp": int(w["n_pos"]), "kept_observations": int(w["n_obs"]), "read_segments": int(w["segs"].n_seg),
-                       "profiled_bases_per_batch": int(w["profiled_bases"]), "splits": int(len(variants[0]["split_bounds"]) - 1),
-                       "distinct_batches": n_var, "pipe_depth": args.depth, "host_threads": host_threads,
-                       "process_bound_to_numa_node": numa_node,
-                       "parallelism": "scaffold-sharded x%d" % world, "scale": args.scale},
-            "roofline": {"bound": "hbm", "kernel": "k_pileup_dense (read segments)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc("c2_reads_bytes_per_launch") if args.scale == 1.0 else None,
-                         "algorithmic_bytes_per_launch": abytes, "record_bytes": 64,
-                         "kernel_ms_avg": k_ms, "launches": len(st),
-                         "note": "durations = the dispatches' own time stamps inside the timed (streamed) region; a pipe slot's kernel "
-                                 "writes 6 B/pos (16-bit coverage + clonality; no count table)"},
-            "roofline_pcie": {"bound": "pcie", "direction": "host->device", "achieved": h2d_b / (ms_step * 1e-3) / 1e9,
-                              "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": h2d_b / (ms_step * 1e-3) / 1e9 / PCIE_PEAK_GBS,
-                              "bytes_per_step": h2d_b, "bytes_per_profiled_base": h2d_b / float(w["profiled_bases"]), "copy_ms_avg": mean("h2d_ms"),
-                              "during_copy_gbs": h2d_b / (mean("h2d_ms") * 1e-3) / 1e9 if mean("h2d_ms") > 0 else 0.0,
-                              "device_to_host": {"bytes_per_step": d2h_b, "copy_ms_avg": mean("d2h_ms"),
-                                                 "achieved": d2h_b / (ms_step * 1e-3) / 1e9}},
-            "stages_ms": {"host_stage": mean("encode_ms"), "copy_in": mean("h2d_ms"), "kernel": k_ms, "copy_out": mean("d2h_ms"),
-                          "collect_wait": mean("collect_wait_ms"), "step": ms_step,
-                          "host_bytes_read_per_step": int(w["segs"].n_seg) * 65 + n_pos_v},
-            "snv_rows": int(stats[-1][1]["n_snv"]) if stats else 0, "snp_sites": int(stats[-1][1]["n_sites"]) if stats else 0,
+            "metric": "Gbp profiled/s", "value": head["gbp_per_s"], "unit": "Gbp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "world_size_seen": world, "backend": (dist.get_backend() if world > 1 else None),
+            "config": {"workload": _short("C5: 1000-genome database, 10 Gbp reads, --database_mode, pileup+SNV call+linkage; step = whole pass%s"
+                                          % ("" if args.scale == 1.0 else " [DEBUG scale %g]" % args.scale)),
+                       "genomes_kept": head["genomes_kept"], "positions": head["positions"], "read_gbp_per_step": bases_all / 1e9,
+                       "batches_per_step": n_batches if world == 1 else None, "hand_over": "read segments from host memory (pinned hipMemcpyAsync)",
+                       "pipe_depth": args.depth, "host_threads_per_rank": host_threads, "cgroup_cpus": cgroup_cpus(),
+                       "numa_node": numa_node, "parallelism": "genome-sharded x%d%s" % (world, " (ranks share %d GPU)" % n_dev if shared else ""),
+                       "verified": "per-batch checks in an untimed pass; timed row counts equal"},
+            "roofline": {k: head["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                            "algorithmic_bytes_per_launch", "kernel_ms_avg", "launches")},
+            "h2d_bytes_per_base": head["roofline_pcie"]["bytes_per_profiled_base"], "pcie_frac": head["roofline_pcie"]["frac"],
+            "snv_pairs_linked_per_s": head["snv_pairs_linked_per_s"],
+            "stages_ms": {k: round(v, 2) for k, v in head["stages_ms_per_pass"].items()},
         }
+        out["roofline"]["kernel"] = _short(out["roofline"]["kernel"], 80)
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
-        if c5 is not None:
-            out["c5"] = c5
+        if cb is not None:
+            detail["cpu_baseline"], detail["cpu_baseline_python"] = cb, cp
+            out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                   "sample": _short("median C5 batch: " + cb["sample"])}
+            out["cpu_baseline_python"] = {"value": cp["value"], "unit": cp["unit"], "cores": cp["cores"], "kind": cp["kind"],
+                                          "sample": _short("median C5 batch: " + cp["sample"])}
+            out["speedup_vs_cpu_port"] = out["value"] / cb["value"] if cb["value"] else None
+            out["speedup_vs_python_restatement"] = out["value"] / cp["value"] if cp["value"] else None
         if sharded is not None:
-            out["bam_sharded"] = sharded
-        if args.only_c5:
-            args.no_resident_leg = args.no_mm_leg = args.no_linkage_leg = args.no_cpu_baseline = True
-            want_mm = False
-        if world == 1 and not args.no_resident_leg:
-            res = resident_leg(ctx, w, args.window)
-            out["resident"] = res
-            # The roofline of the dominant kernel is priced on the kernel having the GPU to itself (10 blocking runs over a
-            # resident read-level C2 batch, the dispatch's own time stamps = what rocprofv3 reports): in the streamed region a
-            # launch is a few % of a PCIe-bound step, the GPU idles between launches and its clocks sag (kernel_ms_in_stream).
-            r = out["roofline"]
-            k_alone = res["reads"]["kernel_ms_alone"]
-            tr = res["reads"]["timings"]
-            ab = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], 0, dense=True, record_bytes=64, n_rec=n_rec, out_bytes_per_pos=20)
-            r.update({"kernel_ms_in_stream": r["kernel_ms_avg"], "frac_in_stream": r["frac"], "kernel_ms_avg": k_alone,
-                      "kernel_ms_min": res["reads"]["kernel_ms_min"],
-                      "algorithmic_bytes_per_launch": ab, "achieved": ab / (k_alone * 1e-3) / 1e9,
-                      "frac": ab / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "blocks": tr["pileup_blocks"], "threads": tr["pileup_threads"], "lds_bytes": tr["pileup_lds_bytes"], "window": tr["pileup_window"],
-                      "gbs_at_8_bytes_per_observation": pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], 0, True, 8) / (k_alone * 1e-3) / 1e9,
-                      "note": "kernel alone over a resident read-level C2 batch (dispatch time stamps, 10 blocking runs): 64 B per read segment + "
-                              "4 B per 16 of them + 1 B/pos in, 20 B/pos out; kernel_ms_in_stream = the same kernel inside the PCIe-bound "
-                              "streamed region.  With ~0.43 B per base in, the kernel is no longer bound by the stream but by its "
-                              "LDS read-modify-writes (one per kept base, see roofline_lds) and by the 20 B/pos it writes"})
-            out["roofline_lds"] = {"bound": "lds-atomic", "kernel": r["kernel"], "achieved": w["n_obs"] / (k_alone * 1e-3) / 1e12,
-                                   "peak": LDS_ATOMIC_PEAK / 1e12, "unit": "T atomics/s", "frac": w["n_obs"] / (k_alone * 1e-3) / LDS_ATOMIC_PEAK,
-                                   "atomics_per_launch": int(w["n_obs"]),
-                                   "note": "one ds_add_u32 lane per kept base; peak = 256 CUs x 16 lanes/clk x 2.4 GHz (conflict-free)"}
-            ko = res["observations"]["kernel_ms_alone"]
-            to = res["observations"]["timings"]
-            abo = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], 0, dense=True, record_bytes=to["record_bytes"])
-            out["roofline_observation_kernel"] = _roofline("k_pileup_dense (2-byte observation records; isx_pipe_submit / isx_batch_create)", abo, ko, to,
-                                                           _pmc("c2_pileup_bytes_per_launch"), kernel_ms_min=res["observations"]["kernel_ms_min"])
-        if want_mm:
-            out["mm_on"] = mm_leg(ctx, w)
-        if world == 1 and not args.no_linkage_leg:
-            out["linkage"] = linkage_leg(ctx)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
-            out["cpu_baseline_python"] = cpu_baseline_python(w)
-        if world == 1 and not args.no_bam_leg and not args.only_c5:
+            detail["bam_sharded"] = sharded
+            out["bam_sharded_gbp_per_s"] = sharded.get("gbp_per_s")
+        legs = {}
+        if world == 1 and not (args.no_c2_leg and args.no_resident_leg and args.no_mm_leg and args.no_linkage_leg):
+            want_mm = not args.no_mm_leg
+            w = c2_workload(seed=2, scale=args.scale, with_mm=want_mm)
+            if not args.no_c2_leg:
+                legs["c2_stream"] = c2_stream_leg(ctx, w, args, host_threads, 32, 4)
+                out["c2_stream_gbp_per_s"] = legs["c2_stream"]["gbp_per_s"]
+            if not args.no_resident_leg:
+                res = resident_leg(ctx, w, args.window)
+                legs["resident"] = res
+                # The dominant kernel with the GPU to itself: 10 blocking runs over a resident read-level C2 batch with its full
+                # count table (20 B/pos out), the dispatch's own time stamps = what rocprofv3 reports.
+                n_rec = (int(w["segs"].n_seg) + 15) // 16 * 16
+                k_alone = res["reads"]["kernel_ms_alone"]
+                tr = res["reads"]["timings"]
+                ab = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], 0, dense=True, record_bytes=64, n_rec=n_rec, out_bytes_per_pos=20)
+                legs["roofline_c2_resident"] = _roofline("k_pileup_dense (read segments, resident C2 batch with count table)", ab, k_alone, tr,
+                                                         _pmc("c2_reads_bytes_per_launch") if args.scale == 1.0 else None,
+                                                         kernel_ms_min=res["reads"]["kernel_ms_min"], traffic_source=_pmc_source("c2_reads_bytes_per_launch"))
+                legs["roofline_lds"] = {"bound": "lds-atomic", "achieved": res["reads"]["timings"].get("lds_atomics", w["n_obs"]) / (k_alone * 1e-3) / 1e12,
+                                        "peak": LDS_ATOMIC_PEAK / 1e12, "unit": "T atomics/s",
+                                        "note": "peak = 256 CUs x 16 lanes/clk x 2.4 GHz (conflict-free)"}
+                ko = res["observations"]["kernel_ms_alone"]
+                to = res["observations"]["timings"]
+                abo = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], 0, dense=True, record_bytes=to["record_bytes"])
+                legs["roofline_observation_kernel"] = _roofline("k_pileup_dense (2-byte observation records; isx_pipe_submit / isx_batch_create)", abo, ko, to,
+                                                                _pmc("c2_pileup_bytes_per_launch"), kernel_ms_min=res["observations"]["kernel_ms_min"])
+                out["roofline_c2_resident"] = {k: legs["roofline_c2_resident"][k] for k in ("achieved", "frac", "traffic", "kernel_ms_avg", "algorithmic_bytes_per_launch")}
+            if want_mm:
+                legs["mm_on"] = mm_leg(ctx, w)
+                out["mm_on_roofline_frac"] = legs["mm_on"]["roofline"]["frac"]
+            if not args.no_linkage_leg:
+                legs["linkage"] = linkage_leg(ctx)
+                out["c3_snv_pairs_linked_per_s"] = legs["linkage"]["snv_pairs_linked_per_s"]
+            if not args.no_cpu_baseline:
+                legs["cpu_baseline_c2"] = cpu_baseline(w)
+                legs["cpu_baseline_python_c2"] = cpu_baseline_python(w)
+            del w
+        if world == 1 and not args.no_bam_leg:
             for key, fn in (("profile_bam", lambda: profile_bam_leg(ctx, host_threads)), ("c5_bam", lambda: c5_bam_leg(ctx, host_threads, args.scale))):
                 try:
-                    out[key] = fn()
+                    legs[key] = fn()
+                    out[key + "_gbp_per_s"] = legs[key].get("gbp_per_s")
                 except Exception as e:                  # never lose the line over an extra leg
-                    out[key] = {"error": repr(e)}
+                    legs[key] = {"error": repr(e)}
+        detail.update(legs)
+        detail["line"] = dict(out)
+        try:
+            with open(args.detail, "w") as f:
+                json.dump(detail, f, indent=1)
+            out["detail_file"] = os.path.relpath(args.detail, REPO)
+        except OSError as e:
+            out["detail_file"] = "not written: %r" % (e,)
+        if os.environ.get("ISX_BENCH_DETAIL_STDERR"):
+            print(json.dumps(detail), file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

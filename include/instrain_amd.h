@@ -462,6 +462,10 @@ int isx_pack_reads(int64_t n_reads, const int64_t *ref_start, const int64_t *cli
  *   segs->pair == NULL) cap_rec ids. */
 int isx_encode_segs(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int64_t cap_rec, uint32_t *rec,
                     uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec);
+/* records (a multiple of 16) the segment starts gpos[n_seg] need in the device stream: the encoder's own counting pass -- a group
+ * closes after 16 segments or where its starts would span more than 65 535 positions, i.e. every few segments on a sparse
+ * (low-coverage) stream.  What cap_rec of isx_encode_segs must be at least; < 0 on a bad argument. */
+int64_t isx_seg_records_needed(const uint32_t *gpos, int64_t n_seg, int32_t host_threads);
 /* the same through the pipe's staging ring (what a read-level pipe does when a batch's records exceed 96 / 256 MiB): waves of at
  * most ring_records / 2 records (ring_records: a multiple of 32, 0 = no ring) are written into a private ring and every finished
  * wave is copied to its place in rec -- the copy standing in for the DMA engine */

@@ -13,6 +13,7 @@
 #include <thread>
 #include <type_traits>
 #include <vector>
+#include <unistd.h>
 
 #include "isx_batch.h"
 #include "seg_encode.h"
@@ -23,14 +24,20 @@ void isx_set_error(const std::string &msg) { g_err = msg; }
 // ---- caching allocators (see isx_internal.h): device memory, and pinned host memory ----
 namespace {
 struct BlockCache {
+    struct Key {
+        int dev; size_t cls;
+        bool operator<(const Key &o) const { return dev != o.dev ? dev < o.dev : cls < o.cls; }
+    };
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;          // class size -> block
-    std::unordered_map<void *, size_t> live;            // block -> class size
-    size_t cached = 0;
-    const size_t limit;
+    std::multimap<Key, void *> free_blocks;             // (device, class size) -> block: a block only goes back to a context on ITS device
+    std::unordered_map<void *, Key> live;               // block -> where it came from
+    std::map<int, size_t> cached;                       // bytes kept per device
+    const bool per_device;                              // device memory: keyed by the current device; pinned memory: one pool
+    size_t (*const limit_of)(int dev);
     hipError_t (*const raw_alloc)(void **, size_t);
     hipError_t (*const raw_free)(void *);
-    BlockCache(size_t lim, hipError_t (*a)(void **, size_t), hipError_t (*f)(void *)) : limit(lim), raw_alloc(a), raw_free(f) {}
+    BlockCache(bool per_dev, size_t (*lim)(int), hipError_t (*a)(void **, size_t), hipError_t (*f)(void *))
+        : per_device(per_dev), limit_of(lim), raw_alloc(a), raw_free(f) {}
     static size_t class_of(size_t bytes)
     {
         size_t v = std::max<size_t>(bytes, 4096);
@@ -39,39 +46,57 @@ struct BlockCache {
         const size_t m = (v + (((size_t)1 << e) - 1)) >> e;
         return m << e;
     }
-    void trim()
+    int current() const
     {
-        std::vector<void *> dead;
+        int d = -1;
+        if (per_device && hipGetDevice(&d) != hipSuccess) d = -1;
+        return d;
+    }
+    // blocks of `dev` only (dev < -1: every device)
+    void trim(int dev = -2)
+    {
+        std::vector<std::pair<int, void *>> dead;
         {
             std::lock_guard<std::mutex> lk(mu);
-            for (auto &kv : free_blocks) dead.push_back(kv.second);
-            free_blocks.clear();
-            cached = 0;
+            for (auto it = free_blocks.begin(); it != free_blocks.end();) {
+                if (dev < -1 || it->first.dev == dev) {
+                    dead.emplace_back(it->first.dev, it->second);
+                    cached[it->first.dev] -= it->first.cls;
+                    it = free_blocks.erase(it);
+                } else ++it;
+            }
         }
-        for (void *p : dead) (void)raw_free(p);
+        int keep = -1;
+        const bool sw = per_device && hipGetDevice(&keep) == hipSuccess;
+        for (auto &d : dead) {
+            if (sw && d.first >= 0) (void)hipSetDevice(d.first);
+            (void)raw_free(d.second);
+        }
+        if (sw && keep >= 0) (void)hipSetDevice(keep);
     }
     hipError_t get(void **p, size_t bytes)
     {
-        const size_t cls = class_of(bytes);
+        const Key k{current(), class_of(bytes)};
         {
             std::lock_guard<std::mutex> lk(mu);
-            auto it = free_blocks.find(cls);
+            auto it = free_blocks.find(k);
             if (it != free_blocks.end()) {
                 *p = it->second;
                 free_blocks.erase(it);
-                cached -= cls;
-                live[*p] = cls;
+                cached[k.dev] -= k.cls;
+                live[*p] = k;
                 return hipSuccess;
             }
         }
-        hipError_t e = raw_alloc(p, cls);
+        hipError_t e = raw_alloc(p, k.cls);
         if (e != hipSuccess) {              // give the cache back and try once more
+            (void)hipGetLastError();
             trim();
-            e = raw_alloc(p, cls);
+            e = raw_alloc(p, k.cls);
             if (e != hipSuccess) return e;
         }
         std::lock_guard<std::mutex> lk(mu);
-        live[*p] = cls;
+        live[*p] = k;
         return hipSuccess;
     }
     void put(void *p)
@@ -81,9 +106,9 @@ struct BlockCache {
             std::lock_guard<std::mutex> lk(mu);
             auto it = live.find(p);
             if (it != live.end()) {
-                const size_t cls = it->second;
+                const Key k = it->second;
                 live.erase(it);
-                if (cached + cls <= limit) { free_blocks.emplace(cls, p); cached += cls; return; }
+                if (cached[k.dev] + k.cls <= limit_of(k.dev)) { free_blocks.emplace(k, p); cached[k.dev] += k.cls; return; }
             }
         }
         (void)raw_free(p);
@@ -93,8 +118,33 @@ hipError_t raw_dev_alloc(void **p, size_t n) { return hipMalloc(p, n); }
 hipError_t raw_dev_free(void *p) { return hipFree(p); }
 hipError_t raw_pin_alloc(void **p, size_t n) { return hipHostMalloc(p, n, hipHostMallocDefault); }
 hipError_t raw_pin_free(void *p) { return hipHostFree(p); }
-BlockCache &dev_cache() { static BlockCache c((size_t)48 << 30, raw_dev_alloc, raw_dev_free); return c; }      // of 288 GB HBM
-BlockCache &pin_cache() { static BlockCache c((size_t)8 << 30, raw_pin_alloc, raw_pin_free); return c; }
+// What may stay cached: a sixth of the device's memory (48 GiB of a 288 GB MI355X; less on a smaller part), an eighth of the
+// host's RAM up to 8 GiB pinned.  Asked once per device.
+size_t dev_limit(int dev)
+{
+    static std::mutex mu;
+    static std::map<int, size_t> lim;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = lim.find(dev);
+    if (it != lim.end()) return it->second;
+    size_t v = (size_t)8 << 30;
+    hipDeviceProp_t pr;
+    if (dev >= 0 && hipGetDeviceProperties(&pr, dev) == hipSuccess) v = pr.totalGlobalMem / 6;
+    else (void)hipGetLastError();
+    lim[dev] = v;
+    return v;
+}
+size_t pin_limit(int)
+{
+    static const size_t v = [] {
+        const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+        const size_t ram = pages > 0 && psz > 0 ? (size_t)pages * (size_t)psz : (size_t)64 << 30;
+        return std::min<size_t>((size_t)8 << 30, ram / 8);
+    }();
+    return v;
+}
+BlockCache &dev_cache() { static BlockCache c(true, dev_limit, raw_dev_alloc, raw_dev_free); return c; }
+BlockCache &pin_cache() { static BlockCache c(false, pin_limit, raw_pin_alloc, raw_pin_free); return c; }
 }  // namespace
 
 hipError_t isx_dev_malloc(void **p, size_t bytes) { return dev_cache().get(p, bytes); }
@@ -102,6 +152,18 @@ void isx_dev_free(void *p) { dev_cache().put(p); }
 hipError_t isx_pin_malloc(void **p, size_t bytes) { return pin_cache().get(p, bytes); }
 void isx_pin_free(void *p) { pin_cache().put(p); }
 void isx_dev_trim() { dev_cache().trim(); pin_cache().trim(); }
+// An allocation that does not go through the cache (one-shot batches, tables that only grow): when the device is full because
+// of what the cache keeps, give that back and try once more.
+hipError_t isx_raw_dev_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dev_cache().trim();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
 
 namespace {
 __global__ void __launch_bounds__(256) k_copy_out(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
@@ -189,12 +251,22 @@ hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStre
     ReadBack &rb = g_rb;
     if (!rb.pin && isx_pin_malloc(reinterpret_cast<void **>(&rb.pin), ReadBack::CAP) != hipSuccess) rb.pin = nullptr;
     const size_t off = (rb.used + 15) & ~(size_t)15;
-    if (!rb.pin || off + bytes > ReadBack::CAP) return hipMemcpyAsync(host_dst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
+    if (!rb.pin || off + bytes > ReadBack::CAP) {
+        const hipError_t e = hipMemcpyAsync(host_dst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) { rb.items.clear(); rb.used = 0; }             // nothing may stay pending on a failing exit
+        return e;
+    }
     const hipError_t e = isx_copy_to_host(rb.pin + off, dsrc, bytes, stream);
     if (e != hipSuccess) { rb.items.clear(); rb.used = 0; return e; }      // (the caller returns without a sync: nothing may stay pending)
     rb.items.push_back({host_dst, off, bytes});
     rb.used = off + bytes;
     return hipSuccess;
+}
+
+void isx_read_drop()
+{
+    g_rb.items.clear();
+    g_rb.used = 0;
 }
 
 hipError_t isx_read_sync(hipStream_t stream)
@@ -251,7 +323,7 @@ static int regrow(T **p, size_t *cap, size_t hard_max, size_t elem_pad = 0)
     const size_t want = std::min(hard_max, std::max<size_t>(*cap * 4, 1024));
     if (*p) isx_dev_free(*p);
     *p = nullptr;
-    HIP_TRY(hipMalloc(p, (want + elem_pad) * sizeof(T)));
+    HIP_TRY(isx_raw_dev_malloc(p, (want + elem_pad) * sizeof(T)));
     *cap = want;
     return ISX_OK;
 }
@@ -364,7 +436,7 @@ struct ObsStream {
     template <class T>
     int upload_encoded(T **d_dst)
     {
-        HIP_TRY(hipMalloc(d_dst, b->n_rec * sizeof(T) + ISX_TAIL_BYTES));
+        HIP_TRY(isx_raw_dev_malloc(d_dst, b->n_rec * sizeof(T) + ISX_TAIL_BYTES));
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<uint8_t *>(*d_dst) + b->n_rec * sizeof(T)),
                                   (int)(sizeof(T) == 2 ? 0xFFFFFFFFu : ISX_PAD32), ISX_TAIL_BYTES / 4, c->stream));
         return staged_upload(c, *d_dst, b->n_rec, [&](T *dst, uint64_t first, uint64_t cnt) {
@@ -389,7 +461,7 @@ struct ObsStream {
             b->d_rec32 = nullptr; b->d_rec16 = nullptr;
             return 1;
         }
-        HIP_TRY(hipMalloc(&b->d_gbase, (n_groups + ISX_TAIL_GROUPS) * sizeof(uint32_t)));
+        HIP_TRY(isx_raw_dev_malloc(&b->d_gbase, (n_groups + ISX_TAIL_GROUPS) * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(b->d_gbase + n_groups, 0, ISX_TAIL_GROUPS * sizeof(uint32_t), c->stream));
         HIP_TRY(hipMemcpy(b->d_gbase, gbase.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice));
         return ISX_OK;
@@ -437,7 +509,7 @@ struct ObsStream {
     // copy into the pinned buffer, then one vectorisable sweep per chunk for the min/max directory
     int upload_wide()
     {
-        HIP_TRY(hipMalloc(&b->d_rec, b->n_rec * sizeof(uint2)));
+        HIP_TRY(isx_raw_dev_malloc(&b->d_rec, b->n_rec * sizeof(uint2)));
         return staged_upload(c, b->d_rec, b->n_rec, [&](uint2 *dst, uint64_t first, uint64_t cnt) {
             fill_threads(cnt, [&](uint64_t a0, uint64_t a1, int &bad) {
                 for (uint64_t i0 = a0; i0 < a1; i0 += ISX_CHUNK) {
@@ -487,23 +559,23 @@ struct ObsStream {
     // when every chunk spans < 65535 positions, else the 4-byte positions; the short stream is read itself
     int upload_linkage_arrays()
     {
-        HIP_TRY(hipMalloc(&b->d_pair, b->n_rec * sizeof(uint32_t)));
+        HIP_TRY(isx_raw_dev_malloc(&b->d_pair, b->n_rec * sizeof(uint32_t)));
         if (!b->d_rec16) {
             bool narrow = true;
             if (!b->d_rec32) for (uint64_t i = 0; i < n_chunks; i++) if (cany[i] && cmax[i] - cmin[i] >= 65535u) { narrow = false; break; }
             std::vector<uint32_t> cb;
             if (narrow) {
-                HIP_TRY(hipMalloc(&b->d_gpos16, b->n_rec * sizeof(uint16_t)));
+                HIP_TRY(isx_raw_dev_malloc(&b->d_gpos16, b->n_rec * sizeof(uint16_t)));
                 if (b->d_rec32) { b->gpos16_shift = 5; }                 // base per ISX_GROUP = 32 loads of 8 records
                 else {
                     cb.assign(cmin.begin(), cmin.end());
                     for (uint64_t i = 0; i < n_chunks; i++) if (!cany[i]) cb[i] = 0;
-                    HIP_TRY(hipMalloc(&b->d_cbase, std::max<uint64_t>(n_chunks, 1) * sizeof(uint32_t)));
+                    HIP_TRY(isx_raw_dev_malloc(&b->d_cbase, std::max<uint64_t>(n_chunks, 1) * sizeof(uint32_t)));
                     HIP_TRY(hipMemcpyAsync(b->d_cbase, cb.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                     b->gpos16_shift = 7;                                 // base per ISX_CHUNK = 128 loads
                 }
             } else {
-                HIP_TRY(hipMalloc(&b->d_gpos, b->n_rec * sizeof(uint32_t)));
+                HIP_TRY(isx_raw_dev_malloc(&b->d_gpos, b->n_rec * sizeof(uint32_t)));
             }
             launch_extract_gpos(b->d_rec, b->d_rec32, b->d_gbase, b->d_gpos, b->d_gpos16, b->d_rec32 ? b->d_gbase : b->d_cbase,
                                 b->d_rec32 ? ISX_GROUP : ISX_CHUNK, b->n_rec, c->stream);
@@ -688,7 +760,7 @@ int isx_set_null_model(isx_ctx *c, const int32_t *lut, int64_t n, int32_t fallba
     }
     HIP_TRY(hipSetDevice(c->device));
     if (c->d_lut) { isx_dev_free(c->d_lut); c->d_lut = nullptr; }
-    HIP_TRY(hipMalloc(&c->d_lut, (size_t)n));
+    HIP_TRY(isx_raw_dev_malloc(&c->d_lut, (size_t)n));
     HIP_TRY(hipMemcpy(c->d_lut, h.data(), (size_t)n, hipMemcpyHostToDevice));
     c->lut_n = (int32_t)n;
     c->fallback = fallback;
@@ -753,9 +825,9 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
 #define BH(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { isx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); isx_batch_destroy(b); return ISX_ERR_HIP; } } while (0)
     for (auto &e : b->ev) BH(hipEventCreate(&e));
     for (auto &e : b->ev_sum) BH(hipEventCreate(&e));
-    BH(hipMalloc(&b->d_ref, (size_t)n_pos));
-    BH(hipMalloc(&b->d_bounds, (size_t)(n_splits + 1) * sizeof(int64_t)));
-    BH(hipMalloc(&b->d_cursors, (CUR_N + 4) * sizeof(uint32_t)));
+    BH(isx_raw_dev_malloc(&b->d_ref, (size_t)n_pos));
+    BH(isx_raw_dev_malloc(&b->d_bounds, (size_t)(n_splits + 1) * sizeof(int64_t)));
+    BH(isx_raw_dev_malloc(&b->d_cursors, (CUR_N + 4) * sizeof(uint32_t)));
     b->d_flags = b->d_cursors + CUR_N;
     BH(hipHostMalloc(&b->h_state, (CUR_N + 8) * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     memset(b->h_state, 0, (CUR_N + 8) * sizeof(uint32_t));
@@ -763,26 +835,26 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
     BH(hipMemsetAsync(b->d_cursors, 0, (CUR_N + 4) * sizeof(uint32_t), c->stream));
     {   // folded presence threshold per coverage (see build_thresholds)
         std::vector<uint16_t> thr = build_thresholds(c->h_lut, c->fallback, prm->min_freq);
-        BH(hipMalloc(&b->d_thr, thr.size() * sizeof(uint16_t)));
+        BH(isx_raw_dev_malloc(&b->d_thr, thr.size() * sizeof(uint16_t)));
         BH(hipMemcpy(b->d_thr, thr.data(), thr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     const uint64_t npm = (uint64_t)n_pos * b->M;
     if (b->M == 1) {
-        BH(hipMalloc(&b->d_counts, (size_t)n_pos * sizeof(uint4)));
-        BH(hipMalloc(&b->d_clon, (size_t)n_pos * sizeof(float)));
+        BH(isx_raw_dev_malloc(&b->d_counts, (size_t)n_pos * sizeof(uint4)));
+        BH(isx_raw_dev_malloc(&b->d_clon, (size_t)n_pos * sizeof(float)));
     } else {
         // entries / site-level tables are sized once the window geometry is known (below)
     }
     if (b->M == 1) {   // rarefied clonality: NaN where not produced (the positions are the same every run)
-        BH(hipMalloc(&b->d_clon_r, (size_t)n_pos * sizeof(float)));
+        BH(isx_raw_dev_malloc(&b->d_clon_r, (size_t)n_pos * sizeof(float)));
         BH(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)n_pos, c->stream));
     }
     b->cap_snv = (size_t)std::min<uint64_t>(npm, std::max<uint64_t>((uint64_t)n_pos / 2, 1u << 20));
     b->cap_sites = (size_t)std::min<uint64_t>((uint64_t)n_pos, std::max<uint64_t>((uint64_t)n_pos / 4, 1u << 20));
     b->cap_ao = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_obs, std::max<uint64_t>((uint64_t)n_obs / 4, 1u << 20)));
-    BH(hipMalloc(&b->d_snv, b->cap_snv * sizeof(isx_snv)));
-    BH(hipMalloc(&b->d_sites, b->cap_sites * sizeof(isx_site)));
-    if (prm->enable_linkage) BH(hipMalloc(&b->d_ao, b->cap_ao * sizeof(isx_ao)));
+    BH(isx_raw_dev_malloc(&b->d_snv, b->cap_snv * sizeof(isx_snv)));
+    BH(isx_raw_dev_malloc(&b->d_sites, b->cap_sites * sizeof(isx_site)));
+    if (prm->enable_linkage) BH(isx_raw_dev_malloc(&b->d_ao, b->cap_ao * sizeof(isx_ao)));
 
     // ---- observation stream (+ pair ids / allele-pass positions with linkage): see ObsStream; or the read segments ----
     ObsStream st(c, b, obs, pair, segs ? 0 : n_obs, n_pos);
@@ -790,13 +862,13 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
     if (segs) {
         // read segments: encoded on the host (the pipe does the same into pinned staging, seg_encode.cpp), one upload
         dir_chunk = ISX_SEG_GROUP;
-        int64_t jumps = 0;                          // a jump of >= 65536 positions closes a group early: at most 15 padding records each
-        for (int64_t i = 1; i < segs->n_seg; i++) jumps += (segs->gpos[i] > segs->gpos[i - 1] ? segs->gpos[i] - segs->gpos[i - 1] : segs->gpos[i - 1] - segs->gpos[i]) >= 32768u;
-        const int64_t cap_rec = ((segs->n_seg + ISX_SEG_GROUP - 1) / ISX_SEG_GROUP + jumps + (segs->n_seg + 4095) / 4096 + 1) * ISX_SEG_GROUP;
+        isxenc::HostPool pool((int)std::max<int64_t>(1, std::min<int64_t>(16, segs->n_seg / 65536 + 1)), -1, false);
+        // exactly the groups the encoder will cut (the same counting pass: a group closes after 16 segments or where its starts
+        // would span more than 65 535 positions -- every few segments on a sparse stream, not only at jumps)
+        const int64_t cap_rec = isxenc::seg_groups_needed(pool, segs->gpos, segs->n_seg) * ISX_SEG_GROUP;
         std::vector<uint32_t> h_rec((size_t)cap_rec * ISX_SEG_REC_WORDS), h_gbase((size_t)(cap_rec / ISX_SEG_GROUP)), h_pair;
         if (prm->enable_linkage) h_pair.resize((size_t)cap_rec);
         st.cmin.assign(h_gbase.size(), 0xFFFFFFFFu); st.cmax.assign(h_gbase.size(), 0u); st.cany.assign(h_gbase.size(), 0);
-        isxenc::HostPool pool((int)std::max<int64_t>(1, std::min<int64_t>(16, segs->n_seg / 65536 + 1)), -1, false);
         isxenc::SegJob J;
         J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = b->M;
         if (!prm->enable_linkage) J.in.pair = nullptr;
@@ -813,14 +885,14 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
         b->n_rec = (uint64_t)J.n_rec;
         b->n_pairs = (uint64_t)J.max_pair + 1;
         st.n_chunks = b->n_rec / ISX_SEG_GROUP;
-        BH(hipMalloc(&b->d_seg, (size_t)b->n_rec * 64 + ISX_TAIL_BYTES));
+        BH(isx_raw_dev_malloc(&b->d_seg, (size_t)b->n_rec * 64 + ISX_TAIL_BYTES));
         BH(hipMemcpyAsync(b->d_seg, h_rec.data(), (size_t)b->n_rec * 64, hipMemcpyHostToDevice, c->stream));
         BH(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<uint8_t *>(b->d_seg) + (size_t)b->n_rec * 64), (int)ISX_SEG_SKIP_WORD, ISX_TAIL_BYTES / 4, c->stream));
-        BH(hipMalloc(&b->d_gbase, (st.n_chunks + ISX_TAIL_GROUPS) * sizeof(uint32_t)));
+        BH(isx_raw_dev_malloc(&b->d_gbase, (st.n_chunks + ISX_TAIL_GROUPS) * sizeof(uint32_t)));
         BH(hipMemsetAsync(b->d_gbase + st.n_chunks, 0, ISX_TAIL_GROUPS * sizeof(uint32_t), c->stream));
         BH(hipMemcpyAsync(b->d_gbase, h_gbase.data(), st.n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         if (prm->enable_linkage) {
-            BH(hipMalloc(&b->d_pair, (size_t)b->n_rec * sizeof(uint32_t)));
+            BH(isx_raw_dev_malloc(&b->d_pair, (size_t)b->n_rec * sizeof(uint32_t)));
             BH(hipMemcpyAsync(b->d_pair, h_pair.data(), (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         }
         BH(hipStreamSynchronize(c->stream));         // the host vectors are locals
@@ -855,12 +927,12 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
             const uint64_t tot = (uint64_t)b->n_win * b->slab + b->cap_ovf;
             if (tot >= 0xFFFFFFFFull) { isx_batch_destroy(b); isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_ARG; }
             b->cap_entries = (size_t)tot;
-            BH(hipMalloc(&b->d_entries, b->cap_entries * sizeof(isx_entry)));
-            BH(hipMalloc(&b->d_win_nent, (size_t)b->n_win * sizeof(uint32_t)));
+            BH(isx_raw_dev_malloc(&b->d_entries, b->cap_entries * sizeof(isx_entry)));
+            BH(isx_raw_dev_malloc(&b->d_win_nent, (size_t)b->n_win * sizeof(uint32_t)));
             b->cap_slev = b->cap_sites * (size_t)std::min(b->M, 8);
-            BH(hipMalloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
+            BH(isx_raw_dev_malloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
         }
-        BH(hipMalloc(&b->d_win, win.size() * sizeof(uint2)));
+        BH(isx_raw_dev_malloc(&b->d_win, win.size() * sizeof(uint2)));
         BH(hipMemcpyAsync(b->d_win, win.data(), win.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
         BH(hipMemcpyAsync(b->d_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
         BH(hipStreamSynchronize(c->stream));
@@ -1064,7 +1136,7 @@ int batch_grow_tables(isx_batch *b, uint32_t cap_flags)
             if (b->d_slev) isx_dev_free(b->d_slev);
             b->d_slev = nullptr;
             b->cap_slev = b->cap_sites * (size_t)b->M;
-            HIP_TRY(hipMalloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
+            HIP_TRY(isx_raw_dev_malloc(&b->d_slev, b->cap_slev * sizeof(isx_slev)));
         }
     }
     if (cap_flags & ISX_FLAG_CAP_AO) { if ((rc = regrow(&b->d_ao, &b->cap_ao, (size_t)obs_bound))) return rc; }
@@ -1078,7 +1150,7 @@ int batch_grow_tables(isx_batch *b, uint32_t cap_flags)
         if (slabs + cap >= 0xFFFFFFFFull) { isx_set_error("mm path: more than 2^32 entry slots in one batch"); return ISX_ERR_CAPACITY; }
         if (b->d_entries) isx_dev_free(b->d_entries);
         b->d_entries = nullptr;
-        HIP_TRY(hipMalloc(&b->d_entries, (slabs + cap) * sizeof(isx_entry)));
+        HIP_TRY(isx_raw_dev_malloc(&b->d_entries, (slabs + cap) * sizeof(isx_entry)));
         b->cap_entries = slabs + cap;
         b->cap_ovf = b->cap_entries - used_slabs;
     }

@@ -33,7 +33,7 @@ void isx_set_error(const std::string &msg);
 hipError_t isx_dev_malloc(void **p, size_t bytes);
 void isx_dev_free(void *p);
 // the same for pinned host memory (a pipe's staging arenas: pinning and unpinning a few hundred MB takes tens of ms each
-// way, more than a small job's device work), at most 8 GiB kept
+// way, more than a small job's device work), at most 8 GiB (an eighth of the host's RAM) kept; device blocks: a sixth of the device's memory, per device
 hipError_t isx_pin_malloc(void **p, size_t bytes);
 void isx_pin_free(void *p);
 void isx_dev_trim();        // both caches
@@ -55,12 +55,18 @@ hipError_t isx_copy_rows_to_host(void *hdst_pinned, const void *dsrc, const uint
                                  size_t cap_rows, hipStream_t stream);
 hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStream_t stream);
 hipError_t isx_read_sync(hipStream_t stream);
+void isx_read_drop();       // forget the calling thread's pending read-backs (every failing HIP_TRY does: their destinations may be
+                            // stack variables of the function that is about to return)
+// hipMalloc outside the caches, with the trim-and-retry of isx_dev_malloc when the device is full of cached blocks
+hipError_t isx_raw_dev_malloc(void **p, size_t bytes);
+template <class T> static inline hipError_t isx_raw_dev_malloc(T **p, size_t bytes) { return isx_raw_dev_malloc(reinterpret_cast<void **>(p), bytes); }
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
         if (_e != hipSuccess) {                                                                \
             isx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+            isx_read_drop();                                                                   \
             return ISX_ERR_HIP;                                                                \
         }                                                                                      \
     } while (0)

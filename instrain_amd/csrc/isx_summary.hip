@@ -388,7 +388,7 @@ template <class T>
 int dev_alloc(T **p, size_t n)
 {
     if (*p) return ISX_OK;
-    HIP_TRY(hipMalloc(p, std::max<size_t>(n, 1) * sizeof(T)));
+    HIP_TRY(isx_raw_dev_malloc(p, std::max<size_t>(n, 1) * sizeof(T)));
     return ISX_OK;
 }
 
@@ -613,7 +613,7 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
     if (B.temp_bytes < tb) {
         if (B.temp) isx_dev_free(B.temp);
         B.temp = nullptr;
-        HIP_TRY(hipMalloc(&B.temp, tb + 256));
+        HIP_TRY(isx_raw_dev_malloc(&B.temp, tb + 256));
         B.temp_bytes = tb + 256;
     }
     auto sort_u32 = [&](const uint32_t *src, uint32_t *dst) -> int {
@@ -689,13 +689,13 @@ int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, co
         return code;
     };
 #define GS_TRY(expr) do { if ((expr) != hipSuccess) { isx_set_error(std::string("HIP error in the genome summary: ") + #expr); return done(ISX_ERR_HIP); } } while (0)
-    GS_TRY(hipMalloc(&d_sb, ((size_t)n_scaf + 1) * sizeof(int64_t)));
-    GS_TRY(hipMalloc(&d_gb, ((size_t)n_genomes + 1) * sizeof(int64_t)));
-    GS_TRY(hipMalloc(&d_off, ((size_t)n_genomes + 1) * sizeof(uint32_t)));
-    GS_TRY(hipMalloc(&d_be, (size_t)n_genomes * 2 * sizeof(uint32_t)));
-    GS_TRY(hipMalloc(&d_acc, (size_t)n_genomes * sizeof(GAcc)));
-    GS_TRY(hipMalloc(&d_sacc, (size_t)n_scaf * sizeof(Acc)));
-    GS_TRY(hipMalloc(&d_rows, (size_t)n_genomes * M * sizeof(isx_genome_level)));
+    GS_TRY(isx_raw_dev_malloc(&d_sb, ((size_t)n_scaf + 1) * sizeof(int64_t)));
+    GS_TRY(isx_raw_dev_malloc(&d_gb, ((size_t)n_genomes + 1) * sizeof(int64_t)));
+    GS_TRY(isx_raw_dev_malloc(&d_off, ((size_t)n_genomes + 1) * sizeof(uint32_t)));
+    GS_TRY(isx_raw_dev_malloc(&d_be, (size_t)n_genomes * 2 * sizeof(uint32_t)));
+    GS_TRY(isx_raw_dev_malloc(&d_acc, (size_t)n_genomes * sizeof(GAcc)));
+    GS_TRY(isx_raw_dev_malloc(&d_sacc, (size_t)n_scaf * sizeof(Acc)));
+    GS_TRY(isx_raw_dev_malloc(&d_rows, (size_t)n_genomes * M * sizeof(isx_genome_level)));
     GS_TRY(hipMemsetAsync(d_sacc, 0, (size_t)n_scaf * sizeof(Acc), s));
     GS_TRY(hipMemcpyAsync(d_sb, in.scaffold_bounds, ((size_t)n_scaf + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     GS_TRY(hipMemcpyAsync(d_gb, gb.data(), gb.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
@@ -719,7 +719,7 @@ int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, co
     size_t tb = 0, tb2 = 0;
     GS_TRY(rocprim::segmented_radix_sort_keys(nullptr, tb, covm, B.k_u32, n_pos, (unsigned)n_genomes, d_be, d_be + n_genomes, 0, 32, s));
     if (!big.empty()) { GS_TRY(rocprim::radix_sort_keys(nullptr, tb2, covm, B.k_u32, (size_t)longest, 0, 32, s)); tb = std::max(tb, tb2); }
-    GS_TRY(hipMalloc(&temp, tb + 256));
+    GS_TRY(isx_raw_dev_malloc(&temp, tb + 256));
     GS_TRY(hipEventRecord(in.ev[0], s));
     const dim3 blk(256), gpos((n_pos + 255) / 256), ggen((n_genomes + 255) / 256);
     if (M > 1) {
@@ -764,7 +764,7 @@ static int ensure(T **p, size_t have, size_t want)
     if (*p && have >= want) return ISX_OK;
     if (*p) isx_dev_free(*p);
     *p = nullptr;
-    HIP_TRY(hipMalloc(p, std::max<size_t>(want, 1) * sizeof(T)));
+    HIP_TRY(isx_raw_dev_malloc(p, std::max<size_t>(want, 1) * sizeof(T)));
     return ISX_OK;
 }
 
@@ -799,7 +799,7 @@ int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, const 
         if (B.temp_bytes < tb) {
             if (B.temp) isx_dev_free(B.temp);
             B.temp = nullptr;
-            HIP_TRY(hipMalloc(&B.temp, tb + 256));
+            HIP_TRY(isx_raw_dev_malloc(&B.temp, tb + 256));
             B.temp_bytes = tb + 256;
         }
     }

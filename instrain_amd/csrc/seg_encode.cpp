@@ -74,6 +74,22 @@ inline void put_padding_avx512(uint32_t *o)
 
 }  // namespace
 
+// device groups the segment starts need, with encode_segs' own task cut (a task never shares a group with its neighbour):
+// what a caller must size cap_rec by -- a sparse stream (starts thousands of positions apart) closes a group every few
+// segments because of the 65 535 span, not only at jumps
+int64_t seg_groups_needed(HostPool &pool, const uint32_t *gpos, int64_t n)
+{
+    const int n_tasks = (int)((n + TASK - 1) / TASK);
+    std::vector<int64_t> g((size_t)std::max(n_tasks, 1), 0);
+    pool.run(n_tasks, [&](int t) {
+        const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
+        g[(size_t)t] = count_groups(gpos, a, e);
+    });
+    int64_t tot = 0;
+    for (int64_t v : g) tot += v;
+    return std::max<int64_t>(tot, 1);
+}
+
 int encode_segs(HostPool &pool, SegJob &J)
 {
     const int64_t n = J.n_seg;
@@ -268,6 +284,13 @@ int isx_encode_segs_ring(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins,
     if (rc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
     *n_rec = J.n_rec;
     return ISX_OK;
+}
+
+int64_t isx_seg_records_needed(const uint32_t *gpos, int64_t n_seg, int32_t host_threads)
+{
+    if (n_seg < 0 || (n_seg && !gpos)) return -1;
+    isxenc::HostPool pool(std::max(1, host_threads), -1, false);
+    return isxenc::seg_groups_needed(pool, gpos, n_seg) * ISX_SEG_GROUP;
 }
 
 int isx_count_read_segs(int64_t n_reads, const uint32_t *cigar, const int64_t *cigar_off, const int64_t *ref_start,

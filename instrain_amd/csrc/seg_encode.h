@@ -50,5 +50,6 @@ struct SegJob {
 enum { SEG_OK = 0, SEG_CAPACITY = 1, SEG_MM_RANGE = 2, SEG_BAD_POS = 3, SEG_BAD_LEN = 4 };
 
 int encode_segs(HostPool &pool, SegJob &job);
+int64_t seg_groups_needed(HostPool &pool, const uint32_t *gpos, int64_t n);
 
 }  // namespace isxenc

@@ -465,8 +465,8 @@ def dense_clon(cov, clon_sparse, min_cov):
 def encode_segs(segs, n_pos, n_mm_bins=1, threads=1, cap_rec=None, ring_records=0):
     """isx_encode_segs / isx_encode_segs_ring (host only): SegBatch -> (rec [n_rec, 16] uint32, gbase [n_rec / 16], pair_out | None)"""
     lib = _lib.load()
-    if cap_rec is None:
-        cap_rec = ((segs.n_seg + 15) // 16 + segs.n_seg // 4096 + 64) * 16
+    if cap_rec is None:                     # exactly what the encoder will cut (a sparse stream closes a group every few segments)
+        cap_rec = int(lib.isx_seg_records_needed(segs.gpos.ctypes.data if segs.n_seg else None, segs.n_seg, int(threads)))
     rec = np.empty((cap_rec, 16), dtype=np.uint32)
     gbase = np.empty(cap_rec // 16, dtype=np.uint32)
     pout = np.empty(cap_rec, dtype=np.uint32) if segs.pair is not None else None

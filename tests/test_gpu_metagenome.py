@@ -172,3 +172,242 @@ def test_c4_per_gpu_shard_properties(ctx):
         del w, r
     pipe.close()
     assert 1.5e9 < total < 4e9
+
+
+# ---- the same configurations through the READ-LEVEL hand-over: the path bench.py times since round 3 ----
+
+def _expected_coverage(w, per_base_at=None):
+    """exact per-position coverage of a read-level workload, from the segments on the host (numpy, in chunks: segment starts
+    +1 / ends -1, prefix sum, minus the bases a segment does not observe); per_base_at = sorted positions -> also the (A,C,T,G)
+    counts at those positions"""
+    from instrain_amd import engine
+    sg = w["segs"]
+    n_pos = w["n_pos"]
+    diff = np.zeros(n_pos + 1, np.int64)
+    np.add.at(diff, sg.gpos.astype(np.int64), 1)
+    np.add.at(diff, sg.gpos.astype(np.int64) + sg.len, -1)
+    cov = np.cumsum(diff[:-1])
+    per_base = np.zeros((len(per_base_at), 4), np.int64) if per_base_at is not None else None
+    j = np.arange(150, dtype=np.int64)[None, :]
+    for c0 in range(0, sg.n_seg, 200_000):
+        cd = engine.unpack_codes(sg.bases[c0:c0 + 200_000])
+        inside = j < sg.len[c0:c0 + 200_000, None]
+        g = sg.gpos[c0:c0 + 200_000, None].astype(np.int64) + j
+        miss = inside & (cd >= 4)
+        cov -= np.bincount(g[miss], minlength=n_pos)
+        if per_base is not None:
+            ok = inside & (cd < 4)
+            gg, bb = g[ok], cd[ok]
+            k = np.searchsorted(per_base_at, gg)
+            hit = (k < len(per_base_at)) & (per_base_at[np.minimum(k, len(per_base_at) - 1)] == gg)
+            np.add.at(per_base, (k[hit], bb[hit]), 1)
+    return cov, per_base
+
+
+def _slot_coverage(r):
+    cov = (r["cov16"] if "cov16" in r else r["cov8"]).astype(np.int64)
+    if "saturated" in r:
+        cov[r["saturated"]["gpos"]] = r["saturated"]["coverage"]
+    return cov
+
+
+def _same_tables(a, b, keys, what):
+    for k in keys:
+        x, y = a[k], b[k]
+        assert x.shape == y.shape, (what, k, x.shape, y.shape)
+        assert x.tobytes() == y.tobytes(), (what, k)
+
+
+def test_metagenome_slice_vs_oracle_as_segments(ctx):
+    """the slice of test_metagenome_slice_vs_oracle, handed over as read segments (generate_segs: the reads whole, as the
+    bench's C4 / C5 legs ship them) through the one-shot path and through Pipe.submit_reads, against the C oracle"""
+    from instrain_amd import engine, synth
+    from oracle import oracle
+    from tests import prod
+    lut, fb = util.load_lut()
+    meta = synth.Metagenome(14, mean_coverage=5, seed=44, contigs=4, len_lo=30_000, len_hi=70_000, threads=4)
+    kept = meta.kept_genomes()
+    w = meta.generate_segs(kept)
+    kw = dict(min_cov=5, min_freq=0.05, min_snp=10)
+    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["segs"], n_mm_bins=1, enable_linkage=True, **kw)
+    b.run()
+    res = b.fetch()
+    assert b.timings()["record_bytes"] == 64
+    got = prod.to_oracle_layout(res, lambda g: g.astype(np.int64))
+    b.close()
+    gpos, base, mm, pair = util.segs_to_obs(w["segs"])
+    assert len(gpos) == w["n_obs"]
+    letters = np.array(list("ACTGN"))
+    exp = {"entries": [], "snv": [], "ld": []}
+    sb = w["split_bounds"]
+    for s, e in zip(sb[:-1], sb[1:]):
+        o = oracle.profile_split(gpos, base, mm.astype(np.int64), pair.astype(np.int64), "".join(letters[w["ref_codes"][s:e]]), int(s), lut, fb, **kw)
+        for k in exp:
+            exp[k].append(o[k])
+    exp = {k: np.concatenate(v) for k, v in exp.items()}
+    assert len(exp["snv"]) > 100 and len(exp["ld"]) > 20
+    util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=1e-6, what="metagenome slice as segments")
+    # the pipe: full tables (want_counts) == the one-shot batch; the default shrunk slot == what they shrink to
+    for want_counts in (True, False):
+        pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=0, max_segs=w["segs"].n_seg, max_splits=len(sb), depth=2, host_threads=4,
+                           n_mm_bins=1, enable_linkage=True, want_counts=want_counts, **kw)
+        t = pipe.submit_reads(w["ref_codes"], sb, w["segs"])
+        r = pipe.collect(t)
+        if want_counts:
+            _same_tables(r, res, ("counts", "clon", "snv", "ld"), "pipe/want_counts")
+        else:
+            cov = res["counts"].sum(axis=1)
+            assert (_slot_coverage(r) == cov).all()
+            assert (r["clon"].view(np.uint32) == res["clon"].view(np.uint32)).all()
+            _same_tables(r, res, ("snv", "ld"), "pipe/shrunk")
+        pipe.release(t)
+        pipe.close()
+    # a sub-slice again as segments REBUILT from the observation stream pair by pair (different cuts of the same reads)
+    sub = meta.generate(kept[:2])
+    segs2 = util.reassemble_segs(sub["obs"]["gpos"], sub["obs"]["base"], sub["obs"]["mm"], sub["pair"])
+    outs = []
+    for src, pr in ((sub["obs"], sub["pair"]), (segs2, None)):
+        b = engine.Batch(ctx, sub["ref_codes"], sub["split_bounds"], src, pr, n_mm_bins=1, enable_linkage=True, **kw)
+        b.run()
+        outs.append(b.fetch())
+        b.close()
+    _same_tables(outs[0], outs[1], ("counts", "clon", "snv", "ld"), "reassembled")
+
+
+def _stream_reads(pipe, ws, depth, check):
+    tickets, done = [None] * len(ws), 0
+    out = []
+    for i, w in enumerate(ws):
+        if i - done == depth:
+            out.append(check(done, pipe.collect(tickets[done], densify=False)))
+            pipe.release(tickets[done])
+            done += 1
+        tickets[i] = pipe.submit_reads(w["ref_codes"], w["split_bounds"], w["segs"])
+    while done < len(ws):
+        out.append(check(done, pipe.collect(tickets[done], densify=False)))
+        pipe.release(tickets[done])
+        done += 1
+    return out
+
+
+def test_c5_per_gpu_shard_read_segments(ctx):
+    """configs[4] exactly as bench.py's headline streams it: rank 0's LPT shard of 8, ~4 150 contigs a batch, read segments through a
+    read-level pipe with linkage on and the default (shrunk) slot output.  Per batch: the coverage table equals the exact
+    per-position coverage computed on the host from the segments; SNV rows are strictly ordered, their counts sum to the
+    coverage and follow the segments base by base; LD rows stay inside a scaffold and add up; the stream is idempotent.
+    One whole batch is also handed over as observation records: byte-identical tables."""
+    from instrain_amd import dist as idist
+    from instrain_amd import engine, synth
+    meta = synth.Metagenome(1000, total_read_bp=10e9, seed=5)
+    kept = meta.kept_genomes()
+    shard = kept[idist.lpt_shards(meta.pairs[kept], 8)[0]]
+    est = (meta.pairs[shard] * 2).astype(np.int64)
+    batches = idist.pack_batches(meta.length[shard], est, 40_000_000, 1_000_000)         # bench.py's cut
+    assert len(batches) >= 8
+    ws = [meta.generate_segs(shard[b]) for b in batches]
+    assert max(len(w["scaffold_bounds"]) - 1 for w in ws) >= 300                          # hundreds of contigs in one flat space
+    total_bases = sum(w["profiled_bases"] for w in ws)
+    assert 0.9e9 < total_bases < 1.4e9
+    pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["segs"].n_seg for w in ws),
+                       max_splits=max(len(w["split_bounds"]) for w in ws), depth=4, n_mm_bins=1, enable_linkage=True, min_snp=20)
+    exp_cov = {}
+
+    def check(i, r):
+        w = ws[i]
+        if i not in exp_cov:
+            exp_cov[i] = _expected_coverage(w)[0]
+        cov = _slot_coverage(r)
+        assert int(cov.sum()) == w["n_obs"]
+        assert (cov == exp_cov[i]).all()
+        snv, ld = r["snv"], r["ld"]
+        g = snv["gpos"].astype(np.int64)
+        assert len(snv) == r["sizes"]["n_snv"] > 0 and (np.diff(g) > 0).all()
+        assert (snv["cnt"].sum(axis=1) == cov[g]).all() and (cov[g] >= 5).all()
+        assert (snv["ref_base"] == w["ref_codes"][g]).all()
+        sb = w["scaffold_bounds"]
+        if len(ld):
+            assert (np.searchsorted(sb, ld["gpos_a"], side="right") == np.searchsorted(sb, ld["gpos_b"], side="right")).all()
+            assert (ld["countAB"].astype(np.int64) + ld["countAb"] + ld["countaB"] + ld["countab"] == ld["total"]).all()
+        cl = engine.dense_clon(cov, r["clon_sparse"], 5) if "clon_sparse" in r else r["clon"]
+        assert np.isnan(cl[cov < 5]).all() and not np.isnan(cl[cov >= 5]).any()
+        return (int((cov * (np.arange(len(cov)) % 65521)).sum()), len(snv), int(g.sum()), len(ld), snv["cnt"].tobytes())
+
+    sig = [_stream_reads(pipe, ws, 4, check) for _ in range(2)]
+    assert sig[0] == sig[1]
+    # SNV row counts follow the segments base by base (one batch: per-base counts at the SNV positions from the host decode)
+    i = int(np.argmax([w["n_obs"] for w in ws]))
+    w = ws[i]
+    t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], w["segs"])
+    r = pipe.collect(t, densify=False)
+    _, per_base = _expected_coverage(w, per_base_at=r["snv"]["gpos"].astype(np.int64))
+    assert (per_base == r["snv"]["cnt"]).all()
+    keep = {k: r[k].copy() for k in ("snv", "ld")}
+    cov_segs = _slot_coverage(r)
+    clon_segs = engine.dense_clon(cov_segs, r["clon_sparse"], 5) if "clon_sparse" in r else r["clon"].copy()
+    pipe.release(t)
+    pipe.close()
+    # the same batch as observation records (isx_pipe_submit): byte-identical tables
+    wo = meta.generate(w["genomes"])
+    assert wo["n_obs"] == w["n_obs"]
+    po = engine.Pipe(ctx, max_pos=wo["n_pos"], max_obs=wo["n_obs"], max_splits=len(wo["split_bounds"]), depth=1, n_mm_bins=1,
+                     enable_linkage=True, min_snp=20, jump_slack=0.5)
+    t = po.submit(wo["ref_codes"], wo["split_bounds"], wo["obs"], wo["pair"])
+    ro = po.collect(t, densify=False)
+    assert (_slot_coverage(ro) == cov_segs).all()
+    clon_obs = engine.dense_clon(cov_segs, ro["clon_sparse"], 5) if "clon_sparse" in ro else ro["clon"]
+    assert (clon_obs.view(np.uint32) == clon_segs.view(np.uint32)).all()
+    _same_tables(ro, keep, ("snv", "ld"), "C5 batch: observations vs segments")
+    po.release(t)
+    po.close()
+
+
+def test_c4_per_gpu_shard_read_segments(ctx):
+    """configs[3] as read segments: rank 0's LPT shard of 8 (100 genomes x 50 contigs, 50x mean, log-normal abundances), linkage
+    on, depth-2 pipe.  Per batch the properties of test_c4_per_gpu_shard_properties + the exact coverage from the host; the
+    deepest batch also goes through the observation hand-over: byte-identical SNV and LD tables."""
+    from instrain_amd import dist as idist
+    from instrain_amd import engine, synth
+    meta = synth.Metagenome(100, mean_coverage=50, seed=4)
+    kept = meta.kept_genomes()
+    shard = kept[idist.lpt_shards(meta.pairs[kept], 8)[0]]
+    est = (meta.pairs[shard] * 2).astype(np.int64)
+    batches = idist.pack_batches(meta.length[shard], est, 40_000_000, 3_000_000)
+    pipe, cap, total, deepest = None, None, 0, None
+    for b in batches:
+        w = meta.generate_segs(shard[b])
+        if pipe is None or w["segs"].n_seg > cap[1] or w["n_pos"] > cap[0] or len(w["split_bounds"]) > cap[2]:
+            if pipe is not None:
+                pipe.close()
+            cap = (max(w["n_pos"], 30_000_000), int(w["segs"].n_seg * 1.2), len(w["split_bounds"]) + 4096)
+            pipe = engine.Pipe(ctx, max_pos=cap[0], max_obs=0, max_segs=cap[1], max_splits=cap[2], depth=2, n_mm_bins=1,
+                               enable_linkage=True, min_snp=20)
+        t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], w["segs"])
+        r = pipe.collect(t, densify=False)
+        cov = _slot_coverage(r)
+        exp, _ = _expected_coverage(w)
+        assert (cov == exp).all() and int(cov.sum()) == w["n_obs"]
+        snv, ld = r["snv"], r["ld"]
+        g = snv["gpos"].astype(np.int64)
+        assert len(snv) > 1000 and (np.diff(g) > 0).all() and (snv["cnt"].sum(axis=1) == cov[g]).all() and (cov[g] >= 5).all()
+        sb = w["scaffold_bounds"]
+        assert len(ld) > 100
+        assert (np.searchsorted(sb, ld["gpos_a"], side="right") == np.searchsorted(sb, ld["gpos_b"], side="right")).all()
+        assert (ld["countAB"].astype(np.int64) + ld["countAb"] + ld["countaB"] + ld["countab"] == ld["total"]).all()
+        rare = r["rare"]["gpos"] if "rare" in r else np.flatnonzero(~np.isnan(r["clon_r"]))
+        assert (rare == np.flatnonzero(cov >= 50)).all()
+        total += w["profiled_bases"]
+        if deepest is None or w["n_obs"] / w["n_pos"] > deepest[0]:
+            deepest = (w["n_obs"] / w["n_pos"], w["genomes"].copy(), {k: r[k].copy() for k in ("snv", "ld")}, cov)
+        pipe.release(t)
+        del w, r
+    pipe.close()
+    assert 1.5e9 < total < 4e9
+    wo = meta.generate(deepest[1])
+    po = engine.Pipe(ctx, max_pos=wo["n_pos"], max_obs=wo["n_obs"], max_splits=len(wo["split_bounds"]), depth=1, n_mm_bins=1,
+                     enable_linkage=True, min_snp=20, jump_slack=0.3)
+    t = po.submit(wo["ref_codes"], wo["split_bounds"], wo["obs"], wo["pair"])
+    ro = po.collect(t, densify=False)
+    assert (_slot_coverage(ro) == deepest[3]).all()
+    _same_tables(ro, deepest[2], ("snv", "ld"), "C4 batch: observations vs segments")
+    po.release(t)
+    po.close()

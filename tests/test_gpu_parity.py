@@ -427,25 +427,53 @@ def test_full_size_properties(ctx):
     assert (r1["snv"]["cnt"].sum(axis=1) == cov[r1["snv"]["gpos"]]).all()
 
 
+def _bench_line(r):
+    import json
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    assert len(lines[0]) < 4000                 # the printed line is a digest: the driver's record keeps all of it
+    return json.loads(lines[0])
+
+
 def test_bench_two_ranks_control_flow(tmp_path):
     """bench.py under torch.distributed.run with 2 ranks (both on GPU 0, gloo) -- the N>1 code path
-    (per-rank workload, barrier, MAX-reduce of the time, SUM of units, final gather) runs and prints
-    one JSON line whose value is the whole-job aggregate."""
-    import json
+    (per-rank shards of C5, verification pass, barrier, MAX-reduce of the time, SUM of units, final gather) runs and
+    prints one JSON line whose value is the whole-job aggregate."""
     import subprocess
     import sys
     repo = os.path.dirname(util.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
     env = dict(os.environ, ISX_DIST_BACKEND="gloo", ISX_DEVICE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(repo, "bench.py"),
-                        "--gpus", "2", "--steps", "5", "--warmup", "1", "--scale", "0.05"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and "final_gather_ms" in j
-    assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05", "--detail", str(tmp_path / "d.json")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    j = _bench_line(r)
+    assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["backend"] == "gloo"
+    assert j["scaling"] == "strong" and j["value"] > 0 and "final_gather_ms" in j
+    assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j and j["bam_sharded_gbp_per_s"] > 0
+    assert "C5" in j["config"]["workload"]
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts the two ranks itself; on a box with one
+    GPU they share it over gloo (the line says so)"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(util.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ISX_DIST_BACKEND", "ISX_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--scale", "0.05",
+                        "--only-c5", "--detail", str(tmp_path / "d.json")], env=env, capture_output=True, text=True, timeout=900)
+    j = _bench_line(r)
+    assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["value"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert j["backend"] == "gloo" and "share" in j["config"]["parallelism"]
+    # a launcher that started the wrong number of ranks is an error, not a silent 1-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--scale", "0.05", "--only-c5"],
+                        env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)
 
 
 @pytest.mark.parametrize("name", ["synth_m1", "synth_skipmm", "synth_m1_ld", "synth_skipmm_ld", "c3_split"])

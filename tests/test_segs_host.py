@@ -104,6 +104,24 @@ def test_encode_segs_through_the_staging_ring(ring_records):
         engine.encode_segs(segs, w["n_pos"], n_mm_bins=16, ring_records=2 * 2048)
 
 
+def test_encode_segs_sparse_stream_is_sized_exactly():
+    """low coverage: starts 5 000 positions apart close a group every 14 segments (the 65 535 span), without any jump of >= 32 768
+    -- the default capacity comes from the encoder's own counting pass (the old estimate gave ISX_ERR_CAPACITY)"""
+    n = 8192
+    gpos = (np.arange(n, dtype=np.uint32) * 5000).astype(np.uint32)
+    segs = engine.SegBatch(gpos, np.full(n, 150, np.uint8), np.zeros((n, 15), np.uint32))
+    n_pos = int(gpos[-1]) + 150
+    need = engine._lib.load().isx_seg_records_needed(segs.gpos.ctypes.data, n, 2)
+    assert need > (n // 16 + n // 4096 + 1) * 16            # more than the old estimate
+    rec, gbase, _ = engine.encode_segs(segs, n_pos)
+    assert len(rec) == need
+    g, ln, _, _ = engine.decode_segs(rec, gbase)
+    assert (g == gpos).all() and (ln == 150).all()
+    from instrain_amd._lib import IsxError
+    with pytest.raises(IsxError):
+        engine.encode_segs(segs, n_pos, cap_rec=need - 16)
+
+
 def test_encode_segs_rejects_bad_input():
     from instrain_amd._lib import IsxError
     segs = engine.SegBatch([10, 20], [150, 150], np.full((2, 15), 0x24924924, np.uint32), mm=[0, 3])
