@@ -41,6 +41,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <string_view>
@@ -520,6 +521,10 @@ struct isx_bam {
     std::vector<uvec<char>> dead_names;
     static constexpr size_t KEEP_DEAD = (size_t)2 << 30;
     std::mutex retire_mu;
+    std::condition_variable retire_cv;
+    int batches_out = 0;            // batches bam_batch_prepare handed out that were neither retired nor freed yet (a pipe's finisher
+                                    // may still hold them): isx_bam_close waits for them (closing the handle under an
+                                    // uncollected isx_pipe_submit_bam ticket was a use-after-free)
     std::vector<std::pair<BamBatch *, size_t>> retired;
     size_t retired_bytes = 0;
     static constexpr size_t RETIRE_LIMIT = (size_t)6 << 30;
@@ -948,15 +953,32 @@ int isx_bam_open(const char *path, isx_bam **out)
     return ISX_OK;
 }
 
+static void await_batches(isx_bam *B)
+{
+    std::unique_lock<std::mutex> lk(B->retire_mu);
+    B->retire_cv.wait(lk, [&] { return B->batches_out <= 0; });
+}
+
 void isx_bam_close(isx_bam *bam)
 {
     if (!bam) return;
     // the tables of a large file (hundreds of MB of pair entries and names) take tens of ms to give back: not the caller's
-    if (bam->n_reads > (1u << 20)) std::thread([](isx_bam *dead) { delete dead; }, bam).detach();
+    // ... and a handle with batches still out (an uncollected isx_pipe_submit_bam ticket) goes when the last of them is back
+    bool out;
+    {
+        std::lock_guard<std::mutex> lk(bam->retire_mu);
+        out = bam->batches_out > 0;
+    }
+    if (out || bam->n_reads > (1u << 20)) std::thread([](isx_bam *dead) { await_batches(dead); delete dead; }, bam).detach();
     else delete bam;
 }
 
-void isx_bam_close_wait(isx_bam *bam) { delete bam; }
+void isx_bam_close_wait(isx_bam *bam)
+{
+    if (!bam) return;
+    await_batches(bam);
+    delete bam;
+}
 
 int isx_bam_set_threads(isx_bam *bam, int32_t threads)
 {
@@ -2145,11 +2167,28 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
         }
     }
     Q->split_bounds.push_back(n_pos);
+    {
+        std::lock_guard<std::mutex> lk(bam->retire_mu);
+        bam->batches_out++;
+    }
     *out = Q.release();
     return ISX_OK;
 }
 
-void bam_batch_free(BamBatch *q) { delete q; }
+static void batch_is_back(isx_bam *B)
+{
+    std::lock_guard<std::mutex> lk(B->retire_mu);
+    if (--B->batches_out == 0) B->retire_cv.notify_all();
+}
+
+void bam_batch_free(BamBatch *q)
+{
+    if (!q) return;
+    isx_bam *B = q->B;
+    delete q;
+    batch_is_back(B);
+}
+
 
 isx_bam::~isx_bam()
 {
@@ -2177,6 +2216,7 @@ void bam_batch_retire(BamBatch *q)
         }
     }
     for (BamBatch *d : dead) delete d;
+    batch_is_back(B);
 }
 int64_t bam_batch_n_segs(const BamBatch *q) { return (int64_t)q->seg_gpos.size(); }
 int64_t bam_batch_seg_bases(const BamBatch *q) { return q->n_seg_bases; }
@@ -2210,7 +2250,7 @@ static int expand_into_handle(isx_bam *bam, const isx_bam_params *p, const int32
     BamBatch *q = nullptr;
     const int rc = bam_batch_prepare(bam, p, refs, n_refs, &q, reg_lo, reg_hi, false);
     if (rc != ISX_OK) return rc;
-    std::unique_ptr<BamBatch> Q(q);
+    std::unique_ptr<BamBatch, void (*)(BamBatch *)> Q(q, bam_batch_free);
     // the whole stream into the handle (threads over contiguous pieces; file order is kept)
     const size_t n_out = (size_t)Q->n_obs();
     B.obs.reset(new isx_obs[std::max<size_t>(n_out, 1)]);
@@ -2244,7 +2284,7 @@ int isx_bam_segment_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *r
     BamBatch *q = nullptr;
     const int rc = bam_batch_prepare(bam, p, refs, n_refs, &q, 0, -1, true);
     if (rc != ISX_OK) return rc;
-    std::unique_ptr<BamBatch> Q(q);
+    std::unique_ptr<BamBatch, void (*)(BamBatch *)> Q(q, bam_batch_free);
     const size_t n = Q->seg_gpos.size();
     B.seg_gpos.assign(Q->seg_gpos.begin(), Q->seg_gpos.end());
     B.seg_len.resize(n); B.seg_mm.resize(n); B.seg_pair.resize(n); B.seg_bases.resize(n * ISX_SEG_WORDS);

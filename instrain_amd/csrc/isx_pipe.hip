@@ -545,15 +545,17 @@ static void finisher_main(isx_pipe *p, hipStream_t sfin)
         Slot &s = p->slots[(size_t)(ticket % (int64_t)p->slots.size())];
         const int rc = finish_slot(p, s, sfin);
         std::string err = rc == ISX_OK ? std::string() : std::string(isx_last_error());
+        BamBatch *dead = nullptr;
         {
             std::lock_guard<std::mutex> lk(p->mu);
             s.rc = rc; s.err.swap(err);
-            // the front end's batch goes back to its handle BEFORE the slot is published as finished: once the caller has
-            // collected its last batch it may close the handle (freed with it: unmapping a gigabyte now would stall the caller)
-            if (s.dead_batch) { bam_batch_retire(s.dead_batch); s.dead_batch = nullptr; }
+            dead = s.dead_batch; s.dead_batch = nullptr;
             s.state = 2;
         }
         p->cv_done.notify_all();
+        // the front end's batch goes back to its handle outside the pipe's lock (retiring may free older batches: gigabytes);
+        // the handle itself waits for its batches before it goes (isx_bam_close), so the caller may close it right after collect
+        if (dead) bam_batch_retire(dead);
     }
 }
 

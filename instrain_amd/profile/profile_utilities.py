@@ -695,7 +695,12 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         stage("filter_ms")
         # ---- batches of whole scaffolds under a position / read budget; the reference groups its commands by estimated
         #      cost the same way (profile_controller.py:436-457) ----
-        est_segs = [int(reads_per_ref[tid] * 1.25) + 64 for tid, _, _ in plan]     # a read = 1 segment + 1 per indel
+        # a read = one segment per 150 aligned columns (2 x 250 / 2 x 300 libraries: two or more) + one per indel; the mean read
+        # length comes from the filter's tallies (sum of the kept pairs' query lengths, controller.py:309-310)
+        fp, fb = int(bf.info.get("filtered_pairs", 0) or 0), int(bf.info.get("filtered_bases", 0) or 0)
+        mean_len = fb / (2.0 * fp) if fp > 0 and fb > 0 else 150.0
+        per_read = float(-(-int(np.ceil(mean_len)) // 150)) + 0.25
+        est_segs = [int(reads_per_ref[tid] * per_read) + 64 for tid, _, _ in plan]
         max_pos = int(kwargs.get('batch_positions', 64_000_000))
         max_segs = int(kwargs.get('batch_reads', max(64, int(kwargs['batch_observations']) // 150) if 'batch_observations' in kwargs else 4_000_000))
         item_groups = idist.pack_batches([refs[tid][1] for tid, _, _ in plan], est_segs, max_pos, max_segs)
