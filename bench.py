@@ -65,7 +65,7 @@ def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense, record_bytes=8, n_r
     (record_bytes 64) 64 B per record + 4 B per 16 records of position bases -- and 1 B/position of reference.  Out, dense
     (M == 1): 16 B counts + 4 B clonality per position (+ 2 B coverage in a pipe slot); mm path: 32 B per present
     (position, mm) entry."""
-    b = (n_rec * 64 + n_rec // 16 * 4) if record_bytes == 64 else n_obs * record_bytes
+    b = (n_rec * 64 + n_rec // 16 * 4) if record_bytes == 64 else ((n_rec * 32 + n_rec // 32 * 4) if record_bytes == 32 else n_obs * record_bytes)
     b += int(n_pos * ref_bytes_per_pos)         # (a pipe slot holds the reference two codes per byte)
     b += n_pos * out_bytes_per_pos if dense else n_entries * 32
     return b
@@ -424,7 +424,7 @@ class C5Run:
     through one GPU; N = 8: one shard per GPU (strong scaling of the configuration).  One STEP = one pass over all of the
     rank's batches."""
 
-    def __init__(self, ctx, rank, world, host_threads, depth=4, scale=1.0, stage_async=False):
+    def __init__(self, ctx, rank, world, host_threads, depth=4, scale=1.0, stage_async=False, staged=True):
         from instrain_amd import dist as idist
         from instrain_amd import engine
         self.ctx, self.rank, self.world, self.depth = ctx, rank, world, depth
@@ -445,6 +445,12 @@ class C5Run:
                                 pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20, stage_async=stage_async)
         self.bases = float(sum(w["profiled_bases"] for w in ws))
         self.signature = None
+        # The host side of the hand-over, done once per batch as a decoder would do it while it decodes (the reference's workers
+        # decode their BAM region before they profile it): compare with the reference, encode the wire records, pack the
+        # reference, lay out the window directory -- into a pinned image per batch.  A timed step only enqueues DMA + kernels.
+        t0 = time.perf_counter()
+        self.wires = [self.pipe.stage_reads(w["ref_codes"], w["split_bounds"], w["segs"]) for w in ws] if staged else None
+        self.stage_s = time.perf_counter() - t0
 
     def verify_pass(self):
         """One untimed pass in which every batch's tables are CHECKED on the host (size-independent properties): the coverage
@@ -476,13 +482,26 @@ class C5Run:
                 raise AssertionError("C5 batch %d: LD row counts do not add up" % i)
             sig.append((int(r["sizes"]["n_snv"]), int(r["sizes"]["n_ld"]), int(r["sizes"]["n_edges"])))
 
-        stream(self.pipe, self.ws, len(self.ws), self.depth, check=check)
+        stream(self.pipe, self.ws, len(self.ws), self.depth, check=check, wires=self.wires)
         self.signature = sig
         return sig
 
-    def run(self, passes, stats=None, keep_last=False):
+    def run(self, passes, stats=None, keep_last=False, staged=True):
         n = len(self.ws)
-        return stream(self.pipe, self.ws, n * passes, self.depth, stats, keep_last=keep_last)
+        return stream(self.pipe, self.ws, n * passes, self.depth, stats, keep_last=keep_last, wires=self.wires if staged else None)
+
+    def unstaged_pass(self):
+        """one pass with the host staging INSIDE the step (isx_pipe_submit_reads: the pipe's threads compare with the reference and
+        encode into the slot's pinned arena at submit time) -- what a caller pays that hands over isx_segs arrays it cannot stage
+        ahead; reported beside the headline"""
+        stats = []
+        t0 = time.perf_counter()
+        self.run(1, stats, staged=False)
+        dt = time.perf_counter() - t0
+        self.check_timed(stats)
+        st = [x for x, _ in stats]
+        return {"gbp_per_s": self.bases / dt / 1e9, "seconds": dt, "host_stage_ms": float(np.sum([x["encode_ms"] for x in st])),
+                "copy_in_ms": float(np.sum([x["h2d_ms"] for x in st])), "h2d_bytes": float(np.sum([x["h2d_bytes"] for x in st]))}
 
     def check_timed(self, stats):
         """every timed batch produced the tables of the verified pass (row counts; the stream is deterministic)"""
@@ -502,8 +521,11 @@ class C5Run:
         n_obs = int(sum(w["n_obs"] for w in ws))
         n_pos = int(sum(w["n_pos"] for w in ws))
         n_rec = int(sum((w["segs"].n_seg + 15) // 16 * 16 for w in ws))
-        abytes = pileup_algorithmic_bytes(n_obs, n_pos, 0, dense=True, record_bytes=64, n_rec=n_rec,
-                                          out_bytes_per_pos=slot_out_bytes_per_pos(n_obs, n_pos), ref_bytes_per_pos=0.5)
+        rbytes = int(st[0]["record_bytes"]) if st else 64
+        h2d = tot("h2d_bytes")
+        # what a launch has to move: the stream as it lies in HBM (= what crossed PCIe: records, group bases, pair ids, packed
+        # reference, directory) + what the epilogue writes per position
+        abytes = h2d + n_pos * slot_out_bytes_per_pos(n_obs, n_pos)
         k_ms = tot("kernel_ms")
         one = stats[:len(ws)]
         out = {"workload": "C5%s: the %d kept genomes of the 1000-genome database (%.2f Gbp of positions, %.2f Gbp of reads in all), --database_mode, "
@@ -518,12 +540,15 @@ class C5Run:
                "snv_pairs_linked": int(sum(z["n_edges"] for _, z in one)), "ld_rows": int(sum(z["n_ld"] for _, z in one)),
                "snv_pairs_linked_per_s": float(sum(z["n_edges"] for _, z in one)) * world * passes / dt_max,
                "load_imbalance": float(max(meta.pairs[kept[s]].sum() for s in self.shards) / np.mean([meta.pairs[kept[s]].sum() for s in self.shards])),
-               "generate_s": self.gen_s,
+               "generate_s": self.gen_s, "stage_s": self.stage_s,
+               "hand_over": "isx_pipe_submit_wire: every batch staged once (isx_pipe_stage_reads: wire records in a pinned image), a step enqueues DMA + kernels"
+                            if self.wires is not None else "isx_pipe_submit_reads: host staging inside the step",
+               "record_bytes": int(st[0]["record_bytes"]) if st else None,
                "verified": "every batch checked in an untimed pass (coverage sum == observations handed over, SNV rows ordered and consistent with "
                            "the coverage, LD counts add up); every timed batch's row counts equal that pass's",
                "stages_ms_per_pass": {"host_stage": tot("encode_ms"), "copy_in": tot("h2d_ms"), "kernel": k_ms, "copy_out": tot("d2h_ms"),
                                       "collect_wait": tot("collect_wait_ms"), "wall": dt_max / passes * 1e3},
-               "roofline": {"bound": "hbm", "kernel": "k_pileup_dense<linkage, read segments> (pipe slot output)",
+               "roofline": {"bound": "hbm", "kernel": "k_pileup_dense<linkage, %s> (pipe slot output)" % ("reference-delta records" if rbytes == 32 else "segment records"),
                             "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
                             "algorithmic_bytes_per_launch": abytes / max(len(ws), 1), "bytes_per_position": abytes / max(n_pos, 1),
@@ -699,9 +724,10 @@ def make_variants(w, n):
         return list(ex.map(lambda k: synth.shifted_variant_segs(w, k), range(n)))
 
 
-def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False, check=None):
+def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False, check=None, wires=None):
     """n_steps batches through the pipe, at most `depth` in flight; returns the last collected result.  check(i, result) is
-    called on every collected batch (untimed verification passes only)."""
+    called on every collected batch (untimed verification passes only).  wires: the batches staged ahead of time
+    (Pipe.stage_reads) -- a submit is then DMA + kernels only (isx_pipe_submit_wire)."""
     tickets, done, last = [], 0, None
     link = pipe.enable_linkage
 
@@ -721,7 +747,9 @@ def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False, check=No
         if len(tickets) - done == depth:
             take()
         v = variants[i % len(variants)]
-        if pipe.read_level:
+        if wires is not None:
+            tickets.append(pipe.submit_wire(wires[i % len(variants)]))
+        elif pipe.read_level:
             tickets.append(pipe.submit_reads(v["ref_codes"], v["split_bounds"], v["segs"]))
         else:
             tickets.append(pipe.submit(v["ref_codes"], v["split_bounds"], v["obs"], v["pair"] if link else None))
@@ -740,26 +768,35 @@ def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
     pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=0, max_segs=int(w["segs"].n_seg),
                        max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
                        pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=args.queued_submit)
-    stream(pipe, variants, warmup, args.depth)
+    wires = [pipe.stage_reads(v["ref_codes"], v["split_bounds"], v["segs"]) for v in variants]
+    stream(pipe, variants, warmup, args.depth, wires=wires)
     stats = []
     t0 = time.perf_counter()
-    stream(pipe, variants[warmup % n_var:] + variants[:warmup % n_var], steps, args.depth, stats)
+    k0 = warmup % n_var
+    stream(pipe, variants[k0:] + variants[:k0], steps, args.depth, stats, wires=wires[k0:] + wires[:k0])
     dt = time.perf_counter() - t0
+    # the same stream with the host staging inside every step (isx_pipe_submit_reads)
+    st2 = []
+    t1 = time.perf_counter()
+    stream(pipe, variants, steps, args.depth, st2)
+    dt2 = time.perf_counter() - t1
     pipe.close()
     st = [s for s, _ in stats]
     mean = lambda k: float(np.mean([s[k] for s in st])) if st else 0.0
     k_ms = mean("kernel_ms")
     n_pos_v = int(np.mean([v["n_pos"] for v in variants]))
     n_rec = (int(w["segs"].n_seg) + 15) // 16 * 16
-    abytes = pileup_algorithmic_bytes(w["n_obs"], n_pos_v, 0, dense=True, record_bytes=64, n_rec=n_rec,
-                                      out_bytes_per_pos=slot_out_bytes_per_pos(w["n_obs"], n_pos_v), ref_bytes_per_pos=0.5)
-    ms_step = dt / steps * 1e3
     h2d_b, d2h_b = mean("h2d_bytes"), mean("d2h_bytes")
-    return {"workload": "C2 streamed: one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, 2x150 bp, --skip_mm_profiling, linkage off; read "
-                        "segments handed over from host memory, profiled once, tables copied back; %d distinct batches" % n_var,
+    abytes = h2d_b + n_pos_v * slot_out_bytes_per_pos(w["n_obs"], n_pos_v)
+    ms_step = dt / steps * 1e3
+    return {"workload": "C2 streamed: one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, 2x150 bp, --skip_mm_profiling, linkage off; wire "
+                        "records staged once in pinned memory, per step DMA + profile once + tables copied back; %d distinct batches" % n_var,
             "gbp_per_s": float(w["profiled_bases"]) * steps / dt / 1e9, "ms_per_step": ms_step, "steps": steps, "warmup": warmup,
+            "record_bytes": int(st[0]["record_bytes"]) if st else None,
+            "with_host_staging": {"gbp_per_s": float(w["profiled_bases"]) * steps / dt2 / 1e9, "ms_per_step": dt2 / steps * 1e3,
+                                  "host_stage_ms": float(np.mean([x["encode_ms"] for x, _ in st2])) if st2 else 0.0},
             "kept_observations": int(w["n_obs"]), "read_segments": int(w["segs"].n_seg), "pipe_depth": args.depth, "host_threads": host_threads,
-            "roofline_in_stream": {"bound": "hbm", "kernel": "k_pileup_dense (read segments, slot output)",
+            "roofline_in_stream": {"bound": "hbm", "kernel": "k_pileup_dense (wire records, slot output)",
                                    "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
                                    "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": k_ms, "launches": len(st)},
@@ -890,6 +927,8 @@ def main():
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
     head = c5.report(dt, bases_all, stats, args.steps, gather_ms)
+    if rank == 0 and world == 1 and not args.only_c5:
+        head["submit_reads_pass"] = c5.unstaged_pass()
     cb = cp = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, cp = c5.cpu_baselines()
@@ -917,7 +956,7 @@ def main():
             "config": {"workload": _short("C5: 1000-genome database, 10 Gbp reads, --database_mode, pileup+SNV call+linkage; step = whole pass%s"
                                           % ("" if args.scale == 1.0 else " [DEBUG scale %g]" % args.scale)),
                        "genomes_kept": head["genomes_kept"], "positions": head["positions"], "read_gbp_per_step": bases_all / 1e9,
-                       "batches_per_step": n_batches if world == 1 else None, "hand_over": "read segments from host memory (pinned hipMemcpyAsync)",
+                       "batches_per_step": n_batches if world == 1 else None, "hand_over": _short("%d-byte wire records staged once in pinned host memory; a step = DMA (hipMemcpyAsync) + kernels + tables back" % (head.get("record_bytes") or 0)),
                        "pipe_depth": args.depth, "host_threads_per_rank": host_threads, "cgroup_cpus": cgroup_cpus(),
                        "numa_node": numa_node, "parallelism": "genome-sharded x%d%s" % (world, " (ranks share %d GPU)" % n_dev if shared else ""),
                        "verified": "per-batch checks in an untimed pass; timed row counts equal"},
@@ -926,7 +965,10 @@ def main():
             "h2d_bytes_per_base": head["roofline_pcie"]["bytes_per_profiled_base"], "pcie_frac": head["roofline_pcie"]["frac"],
             "snv_pairs_linked_per_s": head["snv_pairs_linked_per_s"],
             "stages_ms": {k: round(v, 2) for k, v in head["stages_ms_per_pass"].items()},
+            "stage_once_s": round(head["stage_s"], 3),
         }
+        if "submit_reads_pass" in head:
+            out["c5_with_host_staging_gbp_per_s"] = head["submit_reads_pass"]["gbp_per_s"]
         out["roofline"]["kernel"] = _short(out["roofline"]["kernel"], 80)
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
@@ -953,11 +995,12 @@ def main():
                 legs["resident"] = res
                 # The dominant kernel with the GPU to itself: 10 blocking runs over a resident read-level C2 batch with its full
                 # count table (20 B/pos out), the dispatch's own time stamps = what rocprofv3 reports.
-                n_rec = (int(w["segs"].n_seg) + 15) // 16 * 16
                 k_alone = res["reads"]["kernel_ms_alone"]
                 tr = res["reads"]["timings"]
-                ab = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], 0, dense=True, record_bytes=64, n_rec=n_rec, out_bytes_per_pos=20)
-                legs["roofline_c2_resident"] = _roofline("k_pileup_dense (read segments, resident C2 batch with count table)", ab, k_alone, tr,
+                n_seg = int(w["segs"].n_seg)
+                n_rec = (n_seg + n_seg // 4096 * 32 + 31) // 32 * 32 if tr["record_bytes"] == 32 else (n_seg + 15) // 16 * 16
+                ab = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], 0, dense=True, record_bytes=tr["record_bytes"], n_rec=n_rec, out_bytes_per_pos=20)
+                legs["roofline_c2_resident"] = _roofline("k_pileup_dense (%d-byte wire records, resident C2 batch with count table)" % tr["record_bytes"], ab, k_alone, tr,
                                                          _pmc("c2_reads_bytes_per_launch") if args.scale == 1.0 else None,
                                                          kernel_ms_min=res["reads"]["kernel_ms_min"], traffic_source=_pmc_source("c2_reads_bytes_per_launch"))
                 legs["roofline_lds"] = {"bound": "lds-atomic", "achieved": res["reads"]["timings"].get("lds_atomics", w["n_obs"]) / (k_alone * 1e-3) / 1e12,

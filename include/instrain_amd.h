@@ -87,6 +87,8 @@ typedef struct {
 #define ISX_LAYOUT_WIDE_RECORDS 1       /* 8-byte records (isx_obs as is) instead of the 2- / 4-byte stream */
 #define ISX_LAYOUT_NO_SHORT_RECORDS 2   /* n_mm_bins == 1: 4-byte instead of 2-byte records */
 #define ISX_LAYOUT_NO_PACKED_COUNTERS 4 /* mm path: u32 instead of packed u16 LDS counters */
+#define ISX_LAYOUT_SEG64_RECORDS 8      /* read-level batch with one mm bin: 64-byte segment records (3-bit codes, the round-3 stream)
+                                         * instead of the 32-byte reference-delta records */
 
 /* (position, mm)-present entry: one per mm level present at a position, ascending mm.
  * 32 bytes (two aligned 16-byte device stores).  cnt = counts of THIS level; covT[mm][pos] = sum(cnt);
@@ -423,6 +425,20 @@ int isx_pipe_fetch_entries_shrunk(isx_pipe *p, int64_t ticket, uint32_t *gpos, u
 #define ISX_SEG_BASES 150
 #define ISX_SEG_WORDS 15
 #define ISX_SEG_SKIP_WORD 0x24924924u   /* ten codes 4 */
+/* The device stream of a read-level batch with ONE mm bin is made of reference-delta records (since round 4): what differs from
+ * the reference travels, not the bases.  32 bytes per record, 32 records per group (one wave-wide 16-byte load) sharing a
+ * 32-bit position base:
+ *   word 0      delta:16 | len:8 | mm:8      start = gbase[record / 32] + delta; len 0 = padding record
+ *   words 1-2   skip bits of columns 0..63   bit set = no observation at that column (below min_qual, deletion, ref-skip,
+ *   words 4-6   skip bits of columns 64..159                                        a base that is not A/C/T/G); bits >= len are 0
+ *   word 3, 7   exceptions 0-2, 3-5: three (offset:8 | base:2) fields in bits 0..29 each; an exception = an observed base that
+ *               differs from the reference code at its position (every observed base where the reference is not A/C/T/G);
+ *               empty field = 0x3FF.  A segment with more than ISX_DREC_EXC exceptions travels as several records (pieces).
+ * 0.21 bytes per base instead of 0.43; the kernel adds +1 / -1 at a record's ends to a coverage-difference row, one LDS
+ * atomic per skipped column and one per exception, and rebuilds the reference base's count from the prefix sum. */
+#define ISX_DREC_WORDS 8
+#define ISX_DREC_EXC 6
+#define ISX_DREC_NO_EXC 0x3FFFFFFFu
 
 typedef struct {
     int64_t n_seg;
@@ -439,6 +455,21 @@ int isx_batch_create_reads(isx_ctx *ctx, const isx_params *params, int64_t n_pos
                            const int64_t *split_bounds, const isx_segs *segs, isx_batch **out);
 int isx_pipe_submit_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
                           const isx_segs *segs, int64_t *ticket);
+
+/* Staged batches -- the zero-copy hand-over.  isx_pipe_stage_reads does ALL the host work of isx_pipe_submit_reads (comparison with the
+ * reference / record encoding on the pipe's threads, reference packing, window directory) once, into a pinned image owned by the
+ * returned isx_wire; isx_pipe_submit_wire then only enqueues the DMA copies from that image + the pass + the copy-out: no
+ * staging threads, no host pass over the reads.  A caller that decodes its reads ahead of the device (the reference's workers decode
+ * their BAM region before they profile it, profile_utilities.py:150-153) stages every batch as it is decoded; a rank of a
+ * multi-GPU node needs no encoder threads in its submit loop.  A wire belongs to the pipe it was staged for, may be submitted any
+ * number of times, and is freed by the caller (after the last batch submitted from it has been collected).
+ * isx_wire_bytes = what one submit copies over PCIe. */
+typedef struct isx_wire isx_wire;
+int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                         const isx_segs *segs, isx_wire **out);
+int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *wire, int64_t *ticket);
+int64_t isx_wire_bytes(const isx_wire *wire);
+void isx_wire_free(isx_wire *wire);
 
 /* Host helper for a caller that decodes the BAM itself (e.g. a pysam loop over samfile.fetch()): reads -> segments.
  * Per read r: flat position of its reference start ref_start[r] (may be negative relative to the scaffold when the
@@ -471,6 +502,15 @@ int64_t isx_seg_records_needed(const uint32_t *gpos, int64_t n_seg, int32_t host
  * wave is copied to its place in rec -- the copy standing in for the DMA engine */
 int isx_encode_segs_ring(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int64_t cap_rec, int64_t ring_records,
                          uint32_t *rec, uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec);
+
+/* The same staging for a one-mm-bin pipe (no GPU needed): segments + the reference codes ref[n_pos] -> 32-byte reference-delta
+ * records (ISX_DREC_* above) in groups of 32.  The segments are cut into tasks of 4096; every task's region holds the groups its
+ * segment starts need + slack_groups spare ones (>= 1) for the pieces of segments with more than ISX_DREC_EXC exceptions, unused
+ * groups are padding.  ISX_ERR_CAPACITY with *need_slack > slack_groups: encode again with that many (a pipe learns it);
+ * otherwise cap_rec (isx_delta_records_needed) is too small.  ring_records as in isx_encode_segs_ring (a multiple of 64). */
+int isx_encode_delta(const isx_segs *segs, const uint8_t *ref, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int32_t slack_groups,
+                     int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec, int64_t *need_slack);
+int64_t isx_delta_records_needed(const uint32_t *gpos, int64_t n_seg, int32_t host_threads, int32_t slack_groups);
 
 /* The pipe's host-side encoder on its own (no GPU needed): obs[n_obs] -> resident record stream.
  *   record_bytes 2: delta:13 | base:3, groups of 512 records; 4: delta:16 | mm:8 | base:3 (<< 24), groups of 256;

@@ -633,7 +633,9 @@ int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed)
         // (with linkage a position also carries slabc + maskl: 25 bytes, so two workgroups fit up to 3136)
         int best = 2560;
         double best_eff = 0.0;
-        const int wtop = prm->enable_linkage ? 3136 : ISX_PK16_MAX_W;      // 3264: the packed decode of 2-byte records needs 16-bit byte offsets
+        // (reference-delta records carry two more rows -- skipped columns aside, the coverage differences: 24 / 29 bytes a position)
+        const int wtop = b->drec ? (prm->enable_linkage ? 2688 : 3264)
+                                 : (prm->enable_linkage ? 3136 : ISX_PK16_MAX_W);      // 3264: the packed decode of 2-byte records needs 16-bit byte offsets
         for (int w = 2048; w <= wtop; w += 64) {
             const double n_win = std::ceil((double)n_pos / w);
             const double rounds = n_win / 512.0;
@@ -674,8 +676,9 @@ int batch_set_geometry(isx_batch *b)
 {
     const bool dense = b->M == 1;
     if (!dense && b->W > 2 * b->block) { isx_set_error("mm path: window must be <= 2 x block"); return ISX_ERR_ARG; }
+    if (b->drec && b->W > 4 * b->block) { isx_set_error("reference-delta records: window must be <= 4 x block (4096)"); return ISX_ERR_ARG; }
     b->rqcap = dense ? 0 : std::min(b->W, 512);     // positions with SNV rows per window (overflow: per-position atomics)
-    b->lds = pileup_lds_bytes(b->W, b->M, b->qcap, b->rqcap, b->prm.enable_linkage, b->packed, b->block, b->segs ? 1 : 0, &b->stage_off);
+    b->lds = pileup_lds_bytes(b->W, b->M, b->qcap, b->rqcap, b->prm.enable_linkage, b->packed, b->block, b->segs ? (b->drec ? 32 : 64) : 0, &b->stage_off, &b->dlt_off);
     if (b->lds > 160 * 1024) { isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
     {   // persistent kernels: as many workgroups as stay resident on the 256 CUs
         const int per_cu = std::max(1, std::min((int)(160 * 1024 / b->lds), 2048 / b->block));
@@ -777,7 +780,7 @@ void isx_batch_destroy(isx_batch *b)
     }
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
+    void *ps[] = {b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_drec, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) isx_dev_free(p);          // (falls through to hipFree for blocks that did not come from the cache)
@@ -811,6 +814,7 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
     b->ctx = c; b->prm = *prm; b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits;
     b->M = prm->n_mm_bins;
     b->segs = segs != nullptr;
+    b->drec = b->segs && b->M == 1 && !(prm->layout & ISX_LAYOUT_SEG64_RECORDS);
     const bool dense = b->M == 1;
     batch_pick_block(b);
 #ifdef ISX_TUNING
@@ -859,7 +863,50 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
     // ---- observation stream (+ pair ids / allele-pass positions with linkage): see ObsStream; or the read segments ----
     ObsStream st(c, b, obs, pair, segs ? 0 : n_obs, n_pos);
     uint32_t dir_chunk = ISX_CHUNK;
-    if (segs) {
+    if (segs && b->drec) {
+        // read segments as reference-delta records: compared with the reference and encoded on the host (the pipe does the same into
+        // pinned staging, seg_encode.cpp), one upload
+        dir_chunk = ISX_DREC_GROUP;
+        isxenc::HostPool pool((int)std::max<int64_t>(1, std::min<int64_t>(16, segs->n_seg / 65536 + 1)), -1, false);
+        std::vector<uint32_t> h_rec, h_gbase, h_pair;
+        isxenc::SegJob J;
+        int64_t slack = 1;
+        for (int attempt = 0;; attempt++) {     // a second time when segments differ from the reference so often that their pieces outgrow a task's spare groups
+            const int64_t cap_rec = isxenc::delta_groups_needed(pool, segs->gpos, segs->n_seg, slack) * ISX_DREC_GROUP;
+            h_rec.resize((size_t)cap_rec * ISX_DREC_WORDS); h_gbase.resize((size_t)(cap_rec / ISX_DREC_GROUP));
+            if (prm->enable_linkage) h_pair.resize((size_t)cap_rec);
+            st.cmin.assign(h_gbase.size(), 0xFFFFFFFFu); st.cmax.assign(h_gbase.size(), 0u); st.cany.assign(h_gbase.size(), 0);
+            J = isxenc::SegJob();
+            J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = b->M; J.ref = ref; J.slack_groups = slack;
+            if (!prm->enable_linkage) J.in.pair = nullptr;
+            J.rec = h_rec.data(); J.gbase = h_gbase.data(); J.pair_out = prm->enable_linkage ? h_pair.data() : nullptr;
+            J.cmin = st.cmin.data(); J.cmax = st.cmax.data(); J.cany = st.cany.data(); J.cap_rec = cap_rec;
+            const int erc = isxenc::encode_delta(pool, J);
+            if (erc == isxenc::SEG_CAPACITY && J.need_slack > slack && attempt == 0) { slack = J.need_slack; continue; }
+            if (erc != isxenc::SEG_OK) {
+                isx_batch_destroy(b);
+                if (erc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
+                isx_set_error(erc == isxenc::SEG_BAD_POS ? "a segment reaches beyond n_pos" : erc == isxenc::SEG_BAD_LEN ? "a segment's length is not in [1, 150]"
+                                                                                           : "internal: segment stream larger than estimated");
+                return erc == isxenc::SEG_CAPACITY ? ISX_ERR_STATE : ISX_ERR_ARG;
+            }
+            break;
+        }
+        b->n_rec = (uint64_t)J.n_rec;
+        b->n_pairs = (uint64_t)J.max_pair + 1;
+        st.n_chunks = b->n_rec / ISX_DREC_GROUP;
+        BH(isx_raw_dev_malloc(&b->d_drec, (size_t)b->n_rec * 32 + ISX_TAIL_BYTES));
+        BH(hipMemcpyAsync(b->d_drec, h_rec.data(), (size_t)b->n_rec * 32, hipMemcpyHostToDevice, c->stream));
+        BH(hipMemsetAsync(reinterpret_cast<uint8_t *>(b->d_drec) + (size_t)b->n_rec * 32, 0, ISX_TAIL_BYTES, c->stream));     // len 0: nothing to count
+        BH(isx_raw_dev_malloc(&b->d_gbase, (st.n_chunks + ISX_TAIL_GROUPS) * sizeof(uint32_t)));
+        BH(hipMemsetAsync(b->d_gbase + st.n_chunks, 0, ISX_TAIL_GROUPS * sizeof(uint32_t), c->stream));
+        BH(hipMemcpyAsync(b->d_gbase, h_gbase.data(), st.n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (prm->enable_linkage) {
+            BH(isx_raw_dev_malloc(&b->d_pair, (size_t)b->n_rec * sizeof(uint32_t)));
+            BH(hipMemcpyAsync(b->d_pair, h_pair.data(), (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        }
+        BH(hipStreamSynchronize(c->stream));         // the host vectors are locals
+    } else if (segs) {
         // read segments: encoded on the host (the pipe does the same into pinned staging, seg_encode.cpp), one upload
         dir_chunk = ISX_SEG_GROUP;
         isxenc::HostPool pool((int)std::max<int64_t>(1, std::min<int64_t>(16, segs->n_seg / 65536 + 1)), -1, false);
@@ -987,7 +1034,7 @@ int launch_pass(isx_batch *b)
     // one-wave kernel k_publish_state copies them to mapped pinned memory right behind the pileup kernel
 
     PileupArgs a{};
-    a.seg = b->d_seg;
+    a.seg = b->d_seg; a.drec = b->d_drec; a.dlt_off = b->dlt_off;
     a.rec = b->d_rec; a.rec32 = b->d_rec32; a.rec16 = b->d_rec16; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref; a.ref_packed = b->ref_packed ? 1 : 0;
     a.pair = b->d_pair; a.pair_runs = b->d_pair_runs; a.run_index = b->d_run_index; a.n_runs = b->n_runs; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_rec32 ? b->d_gbase : b->d_cbase; a.gpos16_shift = b->gpos16_shift; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
@@ -1080,7 +1127,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
     b->tim.pileup_threads = b->block;
     b->tim.pileup_lds_bytes = (int32_t)b->lds;
     b->tim.pileup_window = b->W;
-    b->tim.record_bytes = b->d_seg ? 64 : (b->d_rec16 ? 2 : (b->d_rec32 ? 4 : 8));
+    b->tim.record_bytes = b->d_seg ? 64 : (b->d_drec ? 32 : (b->d_rec16 ? 2 : (b->d_rec32 ? 4 : 8)));
 
     if (b->prm.enable_linkage) {
         LinkageIn in{};

@@ -33,7 +33,8 @@ struct isx_batch {
     int64_t cap_pos = 0, cap_obs = 0;   // pipe slots: what the device buffers were sized for (0 = this batch's own n_pos / n_obs)
     size_t slab_region = 0;             // pipe slots, mm path: entries set aside for the window slabs (0 = n_win * slab)
     bool arena = false;                 // pipe slots: the input arrays live in the slot's arena, not in own allocations
-    bool segs = false;                  // the stream is read segments (d_seg), not observation records
+    bool segs = false;                  // the stream is read segments (d_seg / d_drec), not observation records
+    bool drec = false;                  // ... as 32-byte reference-delta records (one mm bin; d_drec) instead of 64-byte segment records
     uint64_t n_rec = 0;         // padded
     uint64_t n_pairs = 0;
     int32_t n_splits = 0;
@@ -44,6 +45,8 @@ struct isx_batch {
     uint32_t *d_rec32 = nullptr, *d_gbase = nullptr;    // compact stream (4-byte records + one position base per 256)
     uint16_t *d_rec16 = nullptr;                        // short stream (n_mm_bins == 1: 2-byte records, base per 512)
     uint4 *d_seg = nullptr;                             // read-segment stream (64-byte records, base per 16; d_pair per record)
+    uint4 *d_drec = nullptr;                            // reference-delta stream (32-byte records, base per 32; d_pair per record)
+    int dlt_off = 0;
     uint32_t *d_pair = nullptr, *d_gpos = nullptr, *d_cbase = nullptr;
     uint2 *d_pair_runs = nullptr;       // pipe slots: pair ids as runs (PileupArgs::pair_runs) instead of d_pair
     uint32_t *d_run_index = nullptr;

@@ -169,6 +169,8 @@ struct PileupArgs {
     const uint4 *seg;           // ... read-segment stream (rec, rec32, rec16 == NULL): 64-byte records as four 16-byte quarters, the
                                 //     first word of a record = delta:16 | len:8 | mm:8, start = gbase[record / 16] + delta, then 15 words of
                                 //     ten 3-bit base codes; `pair` (linkage) is indexed by RECORD
+    const uint4 *drec;          // ... reference-delta stream (one mm bin; rec, rec32, rec16, seg == NULL): 32-byte records as two 16-byte halves
+                                //     (include/instrain_amd.h ISX_DREC_*), start = gbase[record / 32] + delta; `pair` is indexed by RECORD
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK; of ISX_SEG_GROUP for the segment stream)
     const uint8_t *ref;         // reference base code per flat position -- or, ref_packed (pipe slots: half the bytes over PCIe), two per
     int32_t ref_packed;         // byte: position 2 i in the low nibble of byte i, 2 i + 1 in the high one
@@ -190,6 +192,7 @@ struct PileupArgs {
     int32_t qcap;               // deferred-clonality queue capacity (entries)
     int32_t rqcap;              // mm path: row-queue capacity (positions with SNV rows per window)
     int32_t stage_off;          // allele pass: LDS word offset of the per-wave hit stage (0 = aliases the counters)
+    int32_t dlt_off;            // reference-delta stream: LDS word offset of the coverage-difference row (pileup_lds_bytes)
     int32_t pad, lm;            // dense path: counter row stride = W + pad words, position 0 of the window at column lm
     double min_freq;
     // outputs
@@ -237,6 +240,6 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s);
 void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
                          const uint32_t *base16, uint32_t base16_records, uint64_t n_rec, hipStream_t s);
-size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int segs, int *stage_off);
+size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int segs, int *stage_off, int *dlt_off = nullptr);
 
 struct LinkageBuffers;      // defined in isx_linkage.hip

@@ -427,6 +427,120 @@ __device__ __forceinline__ void allele_pass_segs(const PileupArgs &a, uint32_t l
     if (nst) drain();
 }
 
+// ---- reference-delta records (include/instrain_amd.h ISX_DREC_*): a PAIR of lanes holds one 32-byte record ----
+// lane 0 of the pair: header, skip bits of columns 0..63, exceptions 0-2; lane 1: skip bits of columns 64..159, exceptions 3-5
+__device__ __forceinline__ uint32_t pair_first(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xA0 /* quad_perm [0,0,2,2] */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t pair_other(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+
+// four reference codes (one per byte) of the positions gpos .. gpos + 3 (gpos a multiple of 4); 4 beyond n_pos
+__device__ __forceinline__ uint32_t ref4_at(const PileupArgs &a, uint32_t gpos)
+{
+    if (gpos + 3u < a.n_pos) {
+        if (a.ref_packed) {
+            const uint32_t h = *reinterpret_cast<const uint16_t *>(a.ref + (gpos >> 1));
+            return (h & 0xFu) | ((h & 0xF0u) << 4) | ((h & 0xF00u) << 8) | ((h & 0xF000u) << 12);
+        }
+        return *reinterpret_cast<const uint32_t *>(a.ref + gpos);
+    }
+    uint32_t r = 0;
+    for (int k = 0; k < 4; k++) r |= (gpos + k < a.n_pos ? (uint32_t)ref_at(a, gpos + k) : 4u) << (8 * k);
+    return r;
+}
+
+// update_linked_reads on the reference-delta stream: like allele_pass_segs, the window's records are walked a second time against
+// the bitmap of the window's SNP sites; a record's base at a site is its exception there, else the reference's (unless skipped).
+// lo16, hi16: the window's range in 16-byte halves of records (multiples of 64).
+__device__ __forceinline__ void allele_pass_delta(const PileupArgs &a, uint32_t lo16, uint32_t hi16, uint32_t w0, int W,
+                                                  const uint8_t *maskl, uint32_t *slabc, uint32_t ao_base, uint32_t *stage,
+                                                  int tid, int nthr)
+{
+    const int lane = tid & 63;
+    uint32_t *st = stage + (tid >> 6) * 128;
+    uint32_t *sitebits = stage + (nthr >> 6) * 128;         // [W / 32 + 2]
+    for (int p = tid; p < W; p += nthr) {                   // W and nthr are multiples of 64: whole waves
+        const uint64_t bal = __ballot(maskl[p] != 0);
+        if (lane == 0) { sitebits[p >> 5] = (uint32_t)bal; sitebits[(p >> 5) + 1] = (uint32_t)(bal >> 32); }
+    }
+    if (tid < 2) sitebits[(W >> 5) + tid] = 0;
+    __syncthreads();
+    uint32_t nst = 0;
+    auto drain = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < nst) {
+            const uint32_t rec = st[2 * lane], info = st[2 * lane + 1];
+            const uint32_t rel = info & 0xFFFFu;
+            const uint32_t slot = atomicAdd(&slabc[rel], 1u);
+            isx_ao o;
+            o.pair = a.pair[rec]; o.site = w0 + rel; o.obs_idx = rec;
+            o.mm = (uint16_t)(info >> 24); o.base = (uint8_t)((info >> 16) & 7u); o.pad = 0;
+            a.ao[ao_base + slot] = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const uint32_t odd = (uint32_t)tid & 1u;
+    for (uint32_t i0 = lo16; i0 < hi16; i0 += (uint32_t)nthr) {
+        const uint32_t i = i0 + (uint32_t)tid;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane(i) >= hi16) break;         // wave-uniform
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.drec) + i);
+        const uint32_t gb = a.gbase[__builtin_amdgcn_readfirstlane(i >> 6)];
+        const uint32_t hdr = pair_first(v.x);
+        const uint32_t len = (hdr >> 16) & 0xFFu;
+        const uint32_t mm = a.M > 1 ? hdr >> 24 : 0u;
+        const uint32_t e_mine = v.w, e_other = pair_other(v.w);
+        const int32_t s = (int32_t)(gb + (hdr & 0xFFFFu) - w0);
+        const uint32_t sk[3] = {odd ? v.x : v.y, odd ? v.y : v.z, odd ? v.z : 0xFFFFFFFFu};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t c0 = (odd ? 64u : 0u) + 32u * (uint32_t)k;      // first column of this 32-column chunk
+            const int32_t r = s + (int32_t)c0;
+            uint32_t bits = 0;
+            if (len > c0 && (odd || k < 2) && (uint32_t)(r + 31) < (uint32_t)(W + 31)) {
+                const uint32_t ncol = min(len - c0, 32u);
+                const int32_t base = r < 0 ? 0 : r;
+                const uint32_t wi = (uint32_t)base >> 5;
+                const uint64_t b64 = (uint64_t)sitebits[wi] | ((uint64_t)sitebits[wi + 1] << 32);
+                bits = (uint32_t)(b64 >> (base & 31)) << (base - r);
+                bits &= ~sk[k] & (ncol == 32u ? 0xFFFFFFFFu : (1u << ncol) - 1u);
+            }
+            while (__ballot(bits != 0)) {                                       // wave-uniform
+                const bool has = bits != 0;
+                const int j = has ? __ffs((int)bits) - 1 : 0;
+                bits &= bits - 1u;                                              // 0 stays 0
+                const uint32_t col = c0 + (uint32_t)j;
+                const uint32_t rel = has ? (uint32_t)(r + j) : 0u;
+                uint32_t code = 8u;
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    const uint32_t x = (e_mine >> (10 * f)) & 0x3FFu, y = (e_other >> (10 * f)) & 0x3FFu;
+                    if ((x & 0xFFu) == col) code = x >> 8;
+                    if ((y & 0xFFu) == col) code = y >> 8;
+                }
+                if (has && code == 8u) code = ref_at(a, w0 + rel);
+                const bool cand = has && code < 4u && ((maskl[rel] >> code) & 1u);
+                const uint64_t bal = __ballot(cand);
+                if (bal == 0) continue;
+                const uint32_t n = (uint32_t)__popcll(bal);
+                if (nst + n > 64u) { drain(); nst = 0; }
+                if (cand) {
+                    const uint32_t at = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    st[2 * at] = i >> 1;
+                    st[2 * at + 1] = rel | (code << 16) | (mm << 24);
+                }
+                nst += n;
+            }
+        }
+    }
+    if (nst) drain();
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_pileup_dense: the n_mm_bins == 1 (--skip_mm_profiling / --database_mode) specialisation.
 // Persistent workgroups: each walks windows slot, slot + grid, ... so the per-window fixed costs
@@ -446,6 +560,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
     publish_previous(a, tid);
     const int W = a.W;
     constexpr bool SEGS = FMT == 64;
+    constexpr bool DREC = FMT == 32;                            // reference-delta records: see count_slot and the materialise phase
     const int S = W + (SEGS ? ISX_SEG_PAD : ISX_DENSE_PAD);     // row stride of the counters
     uint32_t *cnt = lds + (SEGS ? ISX_SEG_LM : 0);              // segments: ISX_SEG_LM margin columns on either side of the window
     uint32_t *queue = lds + 4 * S;
@@ -453,13 +568,17 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
     uint16_t *thr_lds = reinterpret_cast<uint16_t *>(scratch + S_N);
     uint32_t *slabc = scratch + S_N + THR_LDS / 2;
     uint8_t *maskl = reinterpret_cast<uint8_t *>(slabc + W);
+    // DREC: two more rows -- the coverage differences (+1 where a record starts, -1 behind its end) and, in the queue's row (idle
+    // until the epilogue), the skipped columns; the counter rows hold the EXCEPTIONS until the materialise phase
+    uint32_t *dlt = lds + a.dlt_off;
+    uint32_t *wtot = dlt + S;                   // [16] per-wave totals of the prefix sum
     constexpr bool linkage = LINKAGE;            // compile-time: the linkage-off kernels carry none of the allele pass
     const int grid = gridDim.x, per = grid >> 3;
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
     // COMPACT: 4-byte records (4 per 16-byte load); a wave-wide load covers exactly one ISX_GROUP of 256
     // records, so the group's position base is a scalar load.  Otherwise the 8-byte isx_obs (2 per load).
     constexpr bool COMPACT = FMT != 8;
-    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(SEGS ? (const void *)a.seg : (FMT == 2 ? (const void *)a.rec16 : (FMT == 4 ? (const void *)a.rec32 : (const void *)a.rec)));
+    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(SEGS ? (const void *)a.seg : (DREC ? (const void *)a.drec : (FMT == 2 ? (const void *)a.rec16 : (FMT == 4 ? (const void *)a.rec32 : (const void *)a.rec))));
     constexpr int RSH = FMT == 2 ? 3 : (FMT == 4 ? 2 : 1);         // record index -> 16-byte load index (segments: a record is FOUR loads)
     const int dbg = a.debug_mode;               // ablation switches (tools/), 0 in production
 
@@ -490,6 +609,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             v[u] = __builtin_nontemporal_load(sb + lane16);
             if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
         } else if (FMT == 2) { v[u].x = v[u].y = v[u].z = v[u].w = 0xFFFFFFFFu; }
+        else if (SEGS || DREC) { }             // (a slot the wave did not load is never counted: live[u])
         else if (FMT == 4) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
         else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
     };
@@ -497,7 +617,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
-            if (SEGS) { lo = rng.x << 2; hi = rng.y << 2; } else { lo = rng.x >> RSH; hi = rng.y >> RSH; }
+            if (SEGS) { lo = rng.x << 2; hi = rng.y << 2; } else if (DREC) { lo = rng.x << 1; hi = rng.y << 1; } else { lo = rng.x >> RSH; hi = rng.y >> RSH; }
             if (lo < hi) { issue_one(0, lo); issue_one(1, lo); }        // the first half-round; the stream loop issues the rest
         }
     };
@@ -513,12 +633,18 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         {   // zero the window's counters
             uint4 *z = reinterpret_cast<uint4 *>(cnt);
             for (int i = tid; i < S; i += nthr) z[i] = make_uint4(0, 0, 0, 0);     // 4 S words
+            if (DREC) {
+                uint4 *zq = reinterpret_cast<uint4 *>(queue), *zd = reinterpret_cast<uint4 *>(dlt);
+                for (int i = tid; i < (S >> 2); i += nthr) { zq[i] = make_uint4(0, 0, 0, 0); zd[i] = make_uint4(0, 0, 0, 0); }
+            }
             if (linkage) {
                 uint4 *zm = reinterpret_cast<uint4 *>(maskl);
                 for (int i = tid; i < (W >> 4); i += nthr) zm[i] = make_uint4(0, 0, 0, 0);
             }
             if (tid < S_N) scratch[tid] = 0;
         }
+        uint32_t ref4 = 0x04040404u;            // DREC: the reference codes of this thread's four positions of the materialise phase
+        if (DREC && 4 * tid < W) ref4 = ref4_at(a, w0 + 4u * (uint32_t)tid);
         uint8_t ref_raw[2];
 #pragma unroll
         for (int it = 0; it < 2; it++) {
@@ -533,6 +659,51 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         // (v_mul_lo_u32 is quarter rate).
         auto count_slot = [&](int u) {
             if (COMPACT && !live[u]) return;        // uniform: the last round of a window is half empty on average
+            if (DREC) {
+                // Reference-delta records: a pair of lanes holds one 32-byte record.  Coverage is counted by DIFFERENCE -- +1 at the
+                // record's first column, -1 behind its last (2 LDS atomics per record, by the pair's first lane) -- and only what
+                // is not "the reference's base, observed" touches a counter of its own: one atomic per skipped column (the set bits
+                // of this lane's share of the skip plane) and one per exception.  ~17 atomics per 150-base read instead of 135.
+                const uint32_t odd = (uint32_t)tid & 1u;
+                const uint32_t hdr = pair_first(v[u].x);
+                const uint32_t len = (hdr >> 16) & 0xFFu;
+                const int32_t s = (int32_t)(gb[u] + (hdr & 0xFFFFu) - w0);
+                const uint32_t uW = (uint32_t)W;
+#ifdef ISX_TUNING
+                if (dbg & 64) { ablate_acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w ^ hdr; return; }        // loads only
+#endif
+                if (!odd && len) {
+                    const int32_t hi_c = s + (int32_t)len;
+                    if (hi_c > 0 && s < W) {
+                        atomicAdd(&dlt[s < 0 ? 0 : s], 1u);
+                        if (hi_c < W) atomicAdd(&dlt[hi_c], 0xFFFFFFFFu);
+                    }
+                }
+                uint32_t sk[3] = {odd ? v[u].x : v[u].y, odd ? v[u].y : v[u].z, odd ? v[u].z : 0u};
+#ifdef ISX_TUNING
+                if (dbg & 8) sk[0] = sk[1] = sk[2] = 0;                 // no skip-plane walk
+#endif
+                const int32_t c0 = s + (odd ? 64 : 0);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    uint32_t bits = sk[k];
+                    const int32_t r = c0 + 32 * k;
+                    if ((uint32_t)(r + 31) >= uW + 31u) bits = 0;                // the whole word lies outside the window
+                    while (__ballot(bits != 0)) {                               // wave-uniform
+                        const uint32_t rel = (uint32_t)(r + __ffs((int)bits) - 1);
+                        if (bits != 0 && rel < uW) atomicAdd(&queue[rel], 1u);
+                        bits &= bits - 1u;                                      // 0 stays 0
+                    }
+                }
+                const uint32_t ex = v[u].w;
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    const uint32_t off = (ex >> (10 * f)) & 0xFFu, code = (ex >> (10 * f + 8)) & 3u;
+                    const uint32_t rel = (uint32_t)(s + (int32_t)off);
+                    if (off < len && rel < uW) atomicAdd(&cnt[__umul24(code, (uint32_t)S) + rel], 1u);
+                }
+                return;
+            }
             if (SEGS) {
                 // Read segments: a quad of lanes holds one 64-byte record, lane q its quarter -- the header (lane 0's first
                 // word, broadcast inside the quad) and three words of ten bases, or four words: bases 40 q - 10 + 10 k ... of
@@ -653,6 +824,44 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         // first loads of the NEXT window go out before the epilogue (with linkage the registers
         // are needed by the allele pass first, so the prefetch follows it)
         if (!linkage) prefetch_window(w + grid);
+
+        if (DREC && !(dbg & 16)) {
+            // ---- materialise: the reference base's count of every position from the coverage differences ----
+            //   covered[p] = prefix sum of the difference row; observed[p] = covered[p] - skipped[p];
+            //   count of the reference's base = observed[p] - sum of the exceptions counted at p
+            // (a thread owns four consecutive positions; prefix sum over the wave, per-wave totals through LDS) -- afterwards the
+            // counter rows are what the other record formats leave behind and the epilogue below does not know the difference
+            const int t4 = tid * 4, lane = tid & 63;
+            const bool act = t4 < W;
+            uint32_t run[4] = {0, 0, 0, 0};
+            if (act) {
+                const uint4 d = *reinterpret_cast<const uint4 *>(dlt + t4);
+                run[0] = d.x; run[1] = run[0] + d.y; run[2] = run[1] + d.z; run[3] = run[2] + d.w;
+            }
+            uint32_t inc = run[3];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(inc, o);
+                if (lane >= o) inc += y;
+            }
+            if (lane == 63) wtot[tid >> 6] = inc;
+            __syncthreads();
+            uint32_t off = inc - run[3];
+            for (int k = 0; k < (tid >> 6); k++) off += wtot[k];
+            if (act) {
+                const uint4 m4 = *reinterpret_cast<const uint4 *>(queue + t4);
+                const uint4 c0 = *reinterpret_cast<const uint4 *>(cnt + t4), c1 = *reinterpret_cast<const uint4 *>(cnt + S + t4),
+                            c2 = *reinterpret_cast<const uint4 *>(cnt + 2 * S + t4), c3 = *reinterpret_cast<const uint4 *>(cnt + 3 * S + t4);
+                const uint32_t mk[4] = {m4.x, m4.y, m4.z, m4.w};
+                const uint32_t ek[4] = {c0.x + c1.x + c2.x + c3.x, c0.y + c1.y + c2.y + c3.y, c0.z + c1.z + c2.z + c3.z, c0.w + c1.w + c2.w + c3.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t r = (ref4 >> (8 * k)) & 0xFFu;
+                    if (r < 4u) cnt[__umul24(r, (uint32_t)S) + (uint32_t)(t4 + k)] = off + run[k] - mk[k] - ek[k];
+                }
+            }
+            __syncthreads();
+        }
 
         // ---- epilogue pass 1: integer only (update_snp_table, single mm level) ----
         int ep_it = 0;
@@ -789,6 +998,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             if (ok && nao) {
                 __syncthreads();                // every wave is done with cnt: it becomes the allele pass's stage
                 if (SEGS) allele_pass_segs(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                else if (DREC) allele_pass_delta(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
                 else allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
             prefetch_window(w + grid);
@@ -1158,10 +1368,11 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
 
 }  // namespace
 
-size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int segs, int *stage_off)
+size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int segs, int *stage_off, int *dlt_off)
 {
     size_t words, cnt_words;
-    const int pad = segs ? ISX_SEG_PAD : ISX_DENSE_PAD;
+    const int pad = segs == 64 ? ISX_SEG_PAD : ISX_DENSE_PAD;       // segs: 0 = observation records, 64 = segment records, 32 = reference-delta records
+    if (dlt_off) *dlt_off = 0;
     if (M == 1) { cnt_words = (size_t)4 * (W + pad); words = (size_t)5 * (W + pad) + S_N + THR_LDS / 2; }
     else {
         cnt_words = (size_t)M * (packed ? 2 : 4) * W;
@@ -1177,6 +1388,11 @@ size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int pack
             if (stage_off) *stage_off = (int)(bytes / 4);
             bytes += stage_words * 4;
         }
+    }
+    if (segs == 32 && M == 1) {                 // the coverage-difference row + 16 per-wave totals of its prefix sum
+        bytes = (bytes + 15) & ~(size_t)15;
+        if (dlt_off) *dlt_off = (int)(bytes / 4);
+        bytes += ((size_t)(W + pad) + 16) * 4;
     }
     return bytes;
 }
@@ -1218,6 +1434,7 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
     } else {
         const bool link = a.enable_linkage != 0;
         if (a.seg) { if (link) launch_one(k_pileup_dense<true, 64>, a, l); else launch_one(k_pileup_dense<false, 64>, a, l); return; }
+        if (a.drec) { if (link) launch_one(k_pileup_dense<true, 32>, a, l); else launch_one(k_pileup_dense<false, 32>, a, l); return; }
 #ifndef ISX_NO_PK16
         if (a.rec16 && a.W <= ISX_PK16_MAX_W) { if (link) launch_one(k_pileup_dense<true, 2, true>, a, l); else launch_one(k_pileup_dense<false, 2, true>, a, l); }
         else

@@ -145,7 +145,9 @@ struct isx_pipe {
     int64_t cap_rec = 0;
     int64_t ring_half = 0;                  // records per half of a slot's staging ring; 0 = the pinned arena holds the whole stream
     int rb = 2;                             // record bytes
-    bool segs = false;                      // a read-level pipe: 64-byte read-segment records (isx_pipe_params.max_segs > 0)
+    bool segs = false;                      // a read-level pipe: 64-byte read-segment records (isx_pipe_params.max_segs > 0) ...
+    bool drec = false;                      // ... or, with one mm bin, 32-byte reference-delta records in groups of 32
+    int64_t dslack = 1;                     // learned: spare groups per encoder task (pieces of segments that differ from the reference a lot)
     uint32_t G = ISX_GROUP16;
     size_t snv_prefix = 0;                  // SNV rows copied out with the dense tables
     size_t rare_prefix = 0, cap_rare = 0;   // clonTR entries copied out with them / the device list's capacity
@@ -235,7 +237,7 @@ static void pipe_free(isx_pipe *p)
         double t_x = now_ms();
         if (s.b) {
             isx_batch *b = s.b;             // the input arrays belong to the arena, not to the batch
-            b->d_seg = nullptr;
+            b->d_seg = nullptr; b->d_drec = nullptr;
             b->d_rec = nullptr; b->d_rec32 = nullptr; b->d_rec16 = nullptr; b->d_gbase = nullptr; b->d_pair = nullptr;
             b->d_pair_runs = nullptr; b->d_run_index = nullptr;
             b->d_gpos = nullptr; b->d_gpos16 = nullptr; b->d_cbase = nullptr; b->d_ref = nullptr; b->d_win = nullptr;
@@ -281,7 +283,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     b->ps = index & 1;
     b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true; b->ref_packed = true;
     b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
-    b->segs = p->segs;
+    b->segs = p->segs; b->drec = p->drec;
     const bool dense = b->M == 1;
     batch_pick_block(b);
     const int64_t cap_pos = p->pp.max_pos;
@@ -389,7 +391,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     { const int hrc = host_block_alloc(reinterpret_cast<void **>(&s.h_out), s.out_bytes, s.out_pinned); if (hrc != ISX_OK) return hrc; }
     if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_create] slot %d: %s results %.1f MB %.1f ms\n", index, s.out_pinned ? "pinned" : "pageable", s.out_bytes / 1e6, now_ms() - t_o0);
     for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_pass, &s.ev_d2h0, &s.ev_d2h1}) HIP_TRY(hipEventCreate(e));
-    const size_t n_chunks = (size_t)(p->cap_rec / (p->segs ? ISX_SEG_GROUP : ISX_CHUNK)) + 2;
+    const size_t n_chunks = (size_t)(p->cap_rec / (p->segs ? (int64_t)p->G : (int64_t)ISX_CHUNK)) + 2;
     s.cmin.resize(n_chunks); s.cmax.resize(n_chunks); s.cany.resize(n_chunks);
     return ISX_OK;
 }
@@ -616,26 +618,30 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     isx_pipe *p = new isx_pipe();
     p->ctx = c; p->prm = *prm; p->pp = *pp;
     p->segs = pp->max_segs > 0;
-    p->rb = p->segs ? 64 : ((prm->n_mm_bins == 1 && !(prm->layout & ISX_LAYOUT_NO_SHORT_RECORDS)) ? 2 : 4);
-    p->G = p->segs ? ISX_SEG_GROUP : (p->rb == 2 ? ISX_GROUP16 : ISX_GROUP);
+    p->drec = p->segs && prm->n_mm_bins == 1 && !(prm->layout & ISX_LAYOUT_SEG64_RECORDS);
+    p->rb = p->segs ? (p->drec ? 32 : 64) : ((prm->n_mm_bins == 1 && !(prm->layout & ISX_LAYOUT_NO_SHORT_RECORDS)) ? 2 : 4);
+    p->G = p->segs ? (p->drec ? ISX_DREC_GROUP : ISX_SEG_GROUP) : (p->rb == 2 ? ISX_GROUP16 : ISX_GROUP);
     const double js = pp->jump_slack > 0 ? pp->jump_slack : 0.25;
     if (p->segs) {
         // groups of 16 records; a group is closed early where the stream jumps >= 65536 positions (at most once per 64 Ki
         // positions and per scaffold in a position-sorted stream) and at the end of every encoder task
         if (p->pp.max_obs == 0) p->pp.max_obs = pp->max_segs * ISX_SEG_BASES;
-        const uint64_t groups = (uint64_t)(pp->max_segs + ISX_SEG_GROUP - 1) / ISX_SEG_GROUP + (uint64_t)pp->max_segs / 4096 + (uint64_t)pp->max_pos / 65536 +
-                                (uint64_t)pp->max_splits + 64 + (uint64_t)((double)pp->max_segs / ISX_SEG_GROUP * js * 0.25);
-        p->cap_rec = (int64_t)groups * ISX_SEG_GROUP;
+        // (reference-delta records: + spare groups per encoder task for the pieces of segments with many differences -- two per
+        // task of 4096 up front, js more of the stream when the data asks for it; a batch beyond that is ISX_ERR_CAPACITY)
+        const uint64_t G = p->G;
+        const uint64_t groups = (uint64_t)(pp->max_segs + G - 1) / G + (uint64_t)pp->max_segs / 4096 * (p->drec ? 3 : 1) + (uint64_t)pp->max_pos / 65536 +
+                                (uint64_t)pp->max_splits + 64 + (uint64_t)((double)pp->max_segs / G * js * (p->drec ? 1.0 : 0.25));
+        p->cap_rec = (int64_t)(groups * G);
         if ((uint64_t)p->cap_rec >= (1ull << 26)) { delete p; isx_set_error("more than 2^26 segment records in one batch (4 GiB of records)"); return ISX_ERR_ARG; }
         // staging: the whole stream pinned while that is cheap (a C2 batch is 43 MB), otherwise waves through a ring of two
         // halves -- pinning costs ~0.2 s per GB and as much again to unpin, more than encoding and copying the records
-        const size_t rec_bytes = (size_t)p->cap_rec * 64;
+        const size_t rec_bytes = (size_t)p->cap_rec * (size_t)p->rb;
         size_t ring = 0;
         if (pp->ring_kib > 0) ring = (size_t)pp->ring_kib << 10;
         else if (pp->ring_kib == 0 && rec_bytes > ((size_t)(pp->depth == 1 ? 96 : 256) << 20)) ring = (size_t)64 << 20;
         if (ring && ring < rec_bytes) {
-            p->ring_half = (int64_t)(ring / 2 / 64) / ISX_SEG_GROUP * ISX_SEG_GROUP;
-            if (p->ring_half < 4096 + 16 * ISX_SEG_GROUP) { delete p; isx_set_error("isx_pipe_create: ring_kib too small for a read-level pipe (at least 1024)"); return ISX_ERR_ARG; }
+            p->ring_half = (int64_t)(ring / 2 / (size_t)p->rb) / (int64_t)p->G * (int64_t)p->G;
+            if (p->ring_half * p->rb < (4096 + 16 * ISX_SEG_GROUP) * 64) { delete p; isx_set_error("isx_pipe_create: ring_kib too small for a read-level pipe (at least 1024)"); return ISX_ERR_ARG; }
         }
     } else {
         const uint64_t want = (uint64_t)((double)pp->max_obs * (1.0 + js)) + 4 * ISX_PAD;
@@ -989,10 +995,10 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         // the copy-in queue starts here: every finished wave leaves for its place in the device arena while the next one is
         // being written into the other half
         HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
-        const size_t half_bytes = (size_t)p->ring_half * 64;
-        constexpr size_t grp_bytes = (size_t)ISX_SEG_GROUP * 64;
+        const size_t half_bytes = (size_t)p->ring_half * (size_t)p->rb;
+        constexpr size_t grp_bytes = (size_t)ISX_SEG_GROUP * 64;           // (= ISX_DREC_GROUP * 32: a group is 1 KiB in both formats)
         uint8_t *d_rec = s.d_in + s.off_rec;
-        J.ring_groups = p->ring_half / ISX_SEG_GROUP;
+        J.ring_groups = p->ring_half / (int64_t)p->G;
         J.wave_begin = [&s, &ring_err](int h) {
             if (s.ring_busy[h]) { const hipError_t e = hipEventSynchronize(s.ev_ring[h]); if (e != hipSuccess && ring_err == hipSuccess) ring_err = e; s.ring_busy[h] = false; }
         };
@@ -1005,7 +1011,21 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
             ring_bytes += nb;
         };
     }
-    const int erc = isxenc::encode_segs(*p->pool, J);
+    int erc;
+    if (p->drec) {
+        // reference-delta records: the segments are compared with the reference here; pieces of segments with more than six
+        // differences take spare groups of their task's region -- a batch that needs more than the pipe has learned so far is
+        // encoded a second time (ring mode: its waves simply travel again)
+        J.ref = ref;
+        for (int attempt = 0;; attempt++) {
+            J.slack_groups = p->dslack;
+            ring_bytes = 0;
+            erc = isxenc::encode_delta(*p->pool, J);
+            if (erc == isxenc::SEG_CAPACITY && J.need_slack > p->dslack && attempt == 0) { p->dslack = J.need_slack; continue; }
+            break;
+        }
+        s.encode_passes = erc == isxenc::SEG_OK && J.need_slack == p->dslack && p->dslack > 1 ? 2 : 1;
+    } else erc = isxenc::encode_segs(*p->pool, J);
     const double t_enc = now_ms();
     if (ring_err != hipSuccess) { isx_set_error(std::string("isx_pipe_submit_reads: staging ring: ") + hipGetErrorString(ring_err)); return ISX_ERR_HIP; }
     if (erc == isxenc::SEG_CAPACITY) { isx_set_error("isx_pipe_submit_reads: the stream jumps too often for the pipe's record capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
@@ -1037,15 +1057,15 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
     b->n_pairs = (uint64_t)J.max_pair + 1;
-    const uint64_t n_chunks = b->n_rec / ISX_SEG_GROUP;
+    const uint64_t n_chunks = b->n_rec / p->G;
     b->packed = 0;
     int W = batch_window_for(b, n_pos, false);
     if (!dense) {
         const int Wp = batch_window_for(b, n_pos, true);
         if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-            build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win, ISX_SEG_GROUP) < 65536) { b->packed = 1; W = Wp; }
+            build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win, p->G) < 65536) { b->packed = 1; W = Wp; }
     }
-    if (!b->packed) build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, W, n_pos, s.win, ISX_SEG_GROUP);
+    if (!b->packed) build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, W, n_pos, s.win, p->G);
     b->W = W;
     b->n_win = (int)s.win.size();
     if (s.win.size() > (size_t)p->pp.max_pos / 64 + 2) { isx_set_error("internal: window directory larger than the arena"); return ISX_ERR_STATE; }
@@ -1061,12 +1081,13 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     b->d_win = reinterpret_cast<uint2 *>(s.d_in + s.off_win);
     b->d_ref = s.d_in + s.off_ref;
     b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
-    b->d_seg = reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
+    b->d_seg = p->drec ? nullptr : reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
+    b->d_drec = p->drec ? reinterpret_cast<uint4 *>(s.d_in + s.off_rec) : nullptr;
     b->d_rec16 = nullptr; b->d_rec32 = nullptr;
     b->d_pair = linkage ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pairs) : nullptr;
     b->d_pair_runs = nullptr; b->d_run_index = nullptr; b->n_runs = 0;
     s.encode_ms = (float)(now_ms() - t0);
-    s.encode_passes = 1;
+    if (!p->drec) s.encode_passes = 1;
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_submit_reads] records %.2f ms, reference %.2f ms, bounds + windows %.2f ms; %lld segments, %lld records\n",
                 t_enc - t0, t_ref - t_enc, now_ms() - t_ref, (long long)J.n_seg, (long long)J.n_rec);
@@ -1075,7 +1096,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     // ---- copy-in queue: bounds | windows | reference codes, then group bases (| pair ids) | records ----
     if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
     const size_t head = s.off_ref + ((size_t)n_pos + 1) / 2;              // (reference codes two per byte)
-    const size_t gb_bytes = (size_t)(b->n_rec / ISX_SEG_GROUP) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * 64;
+    const size_t gb_bytes = (size_t)(b->n_rec / p->G) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * (size_t)p->rb;
     HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, head, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
     if (ring) { if (ring_bytes != rec_bytes) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; } }
@@ -1090,6 +1111,193 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     rc = enqueue_pass(p, s, n_pos, ticket);
     if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_submit_reads] copy-in queue %.2f ms, pass + copy-out queue %.2f ms\n", t_q1 - t_q0, now_ms() - t_q1);
     return rc;
+}
+
+// ---- staged batches (isx_wire): the host work of a read-level submit done ONCE, ahead of time, into a pinned image of its own ----
+struct isx_wire {
+    isx_pipe *pipe = nullptr;           // staged for this pipe: its record format, capacities and window choice
+    uint8_t *h = nullptr;               // pinned: bounds | window directory | reference codes | group bases | pair ids | records
+    size_t bytes = 0;
+    size_t o_bounds = 0, o_win = 0, o_ref = 0, o_gbase = 0, o_pairs = 0, o_rec = 0;
+    size_t bounds_bytes = 0, win_bytes = 0, ref_bytes = 0, gbase_bytes = 0, pairs_bytes = 0, rec_bytes = 0;
+    int64_t n_pos = 0, n_bases = 0, n_rec = 0, n_seg = 0;
+    int32_t n_splits = 0;
+    uint64_t n_pairs = 0;
+    int W = 0, packed = 0;
+    float stage_ms = 0.f;
+    int encode_passes = 1;
+};
+
+int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                         const isx_segs *segs, isx_wire **out)
+{
+    if (!p || !ref || !split_bounds || !out || n_pos <= 0 || n_splits <= 0 || !segs || segs->n_seg < 0 ||
+        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases))) {
+        isx_set_error("isx_pipe_stage_reads: bad argument");
+        return ISX_ERR_ARG;
+    }
+    *out = nullptr;
+    if (!p->segs) { isx_set_error("isx_pipe_stage_reads: not a read-level pipe (isx_pipe_params.max_segs == 0)"); return ISX_ERR_STATE; }
+    const bool linkage = p->prm.enable_linkage != 0;
+    if (linkage && segs->n_seg && !segs->pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
+    if (n_pos > p->pp.max_pos || segs->n_seg > p->pp.max_segs || n_splits > p->pp.max_splits) {
+        isx_set_error("isx_pipe_stage_reads: batch larger than the pipe was created for");
+        return ISX_ERR_CAPACITY;
+    }
+    if (split_bounds[0] != 0 || split_bounds[n_splits] != n_pos) { isx_set_error("split_bounds must span [0, n_pos]"); return ISX_ERR_ARG; }
+    for (int i = 0; i < n_splits; i++)
+        if (split_bounds[i + 1] <= split_bounds[i]) { isx_set_error("split_bounds must be strictly ascending"); return ISX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    const double t0 = now_ms();
+    std::unique_ptr<isx_wire, void (*)(isx_wire *)> w(new isx_wire(), isx_wire_free);
+    w->pipe = p; w->n_pos = n_pos; w->n_splits = n_splits; w->n_seg = segs->n_seg;
+    const isx_batch *b0 = p->slots[0].b;            // (every slot shares the parameters the window choice depends on)
+    const int M = b0->M;
+    const size_t G = p->G, rb = (size_t)p->rb;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    isxenc::SegJob J;
+    std::vector<uint32_t> cmin, cmax;
+    std::vector<uint8_t> cany;
+    for (int attempt = 0;; attempt++) {
+        // exact record capacity of this batch (the encoder's own counting pass), at most the pipe's
+        int64_t cap = p->drec ? isxenc::delta_groups_needed(*p->pool, segs->gpos, segs->n_seg, p->dslack) * ISX_DREC_GROUP
+                              : isxenc::seg_groups_needed(*p->pool, segs->gpos, segs->n_seg) * ISX_SEG_GROUP;
+        if (cap > p->cap_rec) { isx_set_error("isx_pipe_stage_reads: the stream needs more records than the pipe's capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
+        const size_t n_groups = (size_t)cap / G;
+        w->bounds_bytes = (size_t)(n_splits + 1) * sizeof(int64_t);
+        w->ref_bytes = ((size_t)n_pos + 1) / 2;
+        const size_t win_cap = ((size_t)n_pos / 64 + 2) * sizeof(uint2);       // (the smallest window is 64 positions)
+        size_t o = 0;
+        w->o_bounds = o; o = up(o + w->bounds_bytes);
+        w->o_win = o; o = up(o + win_cap);
+        w->o_ref = o; o = up(o + w->ref_bytes);
+        w->o_gbase = o; o = up(o + n_groups * sizeof(uint32_t));
+        w->o_pairs = o; if (linkage) o = up(o + (size_t)cap * sizeof(uint32_t));
+        w->o_rec = o; o = up(o + (size_t)cap * rb);
+        if (w->h) { isx_pin_free(w->h); w->h = nullptr; }
+        HIP_TRY(isx_pin_malloc(reinterpret_cast<void **>(&w->h), o));
+        w->bytes = o;
+        cmin.assign(n_groups + 2, 0xFFFFFFFFu); cmax.assign(n_groups + 2, 0u); cany.assign(n_groups + 2, 0);
+        J = isxenc::SegJob();
+        J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = M;
+        if (!linkage) J.in.pair = nullptr;
+        J.rec = reinterpret_cast<uint32_t *>(w->h + w->o_rec);
+        J.gbase = reinterpret_cast<uint32_t *>(w->h + w->o_gbase);
+        J.pair_out = linkage ? reinterpret_cast<uint32_t *>(w->h + w->o_pairs) : nullptr;
+        J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data();
+        J.cap_rec = cap;
+        int erc;
+        if (p->drec) {
+            J.ref = ref; J.slack_groups = p->dslack;
+            erc = isxenc::encode_delta(*p->pool, J);
+            if (erc == isxenc::SEG_CAPACITY && J.need_slack > p->dslack && attempt == 0) { p->dslack = J.need_slack; w->encode_passes = 2; continue; }
+        } else erc = isxenc::encode_segs(*p->pool, J);
+        if (erc == isxenc::SEG_CAPACITY) { isx_set_error("isx_pipe_stage_reads: the stream does not fit the record capacity"); return ISX_ERR_CAPACITY; }
+        if (erc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
+        if (erc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
+        if (erc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
+        break;
+    }
+    if (J.n_bases > p->pp.max_obs) { isx_set_error("isx_pipe_stage_reads: more bases than the pipe's max_obs"); return ISX_ERR_CAPACITY; }
+    w->n_rec = J.n_rec; w->n_bases = J.n_bases; w->n_pairs = (uint64_t)J.max_pair + 1;
+    w->gbase_bytes = (size_t)(J.n_rec / (int64_t)G) * sizeof(uint32_t);
+    w->rec_bytes = (size_t)J.n_rec * rb;
+    w->pairs_bytes = linkage ? (size_t)J.n_rec * sizeof(uint32_t) : 0;
+    {   // reference codes, two per byte
+        const int64_t piece = (int64_t)256 << 10;
+        const int n_tasks = (int)((n_pos + piece - 1) / piece);
+        uint8_t *dst = w->h + w->o_ref;
+        auto cp = [&](int t) {
+            const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
+            uint8_t *o = dst + (a >> 1);
+            const uint8_t *r = ref + a;
+            const int64_t n2 = (e - a) >> 1;
+            for (int64_t i = 0; i < n2; i++) o[i] = (uint8_t)((r[2 * i] & 0xF) | (r[2 * i + 1] << 4));
+            if ((e - a) & 1) o[n2] = (uint8_t)(r[e - a - 1] & 0xF);
+        };
+        if (n_tasks > 1) p->pool->run(n_tasks, cp); else cp(0);
+    }
+    memcpy(w->h + w->o_bounds, split_bounds, w->bounds_bytes);
+    {   // the window directory, for the window this pipe's kernels will use on a batch of n_pos positions
+        const uint64_t n_chunks = (uint64_t)J.n_rec / G;
+        std::vector<uint2> win;
+        w->packed = 0;
+        int W = batch_window_for(b0, n_pos, false);
+        if (M > 1) {
+            const int Wp = batch_window_for(b0, n_pos, true);
+            if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
+                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, (uint32_t)G) < 65536) { w->packed = 1; W = Wp; }
+        }
+        if (!w->packed) build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win, (uint32_t)G);
+        w->W = W;
+        w->win_bytes = win.size() * sizeof(uint2);
+        if (w->win_bytes > ((size_t)n_pos / 64 + 2) * sizeof(uint2) || win.size() > (size_t)p->pp.max_pos / 64 + 2) { isx_set_error("internal: window directory larger than its region"); return ISX_ERR_STATE; }
+        memcpy(w->h + w->o_win, win.data(), w->win_bytes);
+    }
+    w->stage_ms = (float)(now_ms() - t0);
+    *out = w.release();
+    return ISX_OK;
+}
+
+void isx_wire_free(isx_wire *w)
+{
+    if (!w) return;
+    if (w->h) isx_pin_free(w->h);
+    delete w;
+}
+
+int64_t isx_wire_bytes(const isx_wire *w) { return w ? (int64_t)(w->bounds_bytes + w->win_bytes + w->ref_bytes + w->gbase_bytes + w->pairs_bytes + w->rec_bytes) : 0; }
+
+// a staged batch into the next free slot: copies straight from the image, no host work
+int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
+{
+    if (!p || !w || !ticket) { isx_set_error("isx_pipe_submit_wire: bad argument"); return ISX_ERR_ARG; }
+    if (w->pipe != p) { isx_set_error("isx_pipe_submit_wire: the batch was staged for another pipe"); return ISX_ERR_ARG; }
+    drain_stager(p);
+    Slot &s = p->slots[(size_t)(p->next_ticket % (int64_t)p->slots.size())];
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (s.state != 0) { isx_set_error("isx_pipe_submit_wire: every slot is in use (collect + release the oldest batch first)"); return ISX_ERR_STATE; }
+    }
+    isx_ctx *c = p->ctx;
+    isx_batch *b = s.b;
+    HIP_TRY(hipSetDevice(c->device));
+    const double t0 = now_ms();
+    const bool dense = b->M == 1, linkage = p->prm.enable_linkage != 0;
+    b->n_pos = w->n_pos; b->n_obs = w->n_bases; b->n_splits = w->n_splits; b->n_rec = (uint64_t)w->n_rec;
+    b->sparse_out = dense && b->d_clon_list != nullptr;
+    b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)w->n_pos;
+    b->n_pairs = w->n_pairs;
+    b->packed = w->packed; b->W = w->W;
+    b->n_win = (int)(w->win_bytes / sizeof(uint2));
+    int rc = batch_set_geometry(b);
+    if (rc != ISX_OK) return rc;
+    if (!dense) {
+        const size_t used = (size_t)b->n_win * b->slab;
+        if (used > b->slab_region) { isx_set_error("internal: entry slabs larger than the slot's region"); return ISX_ERR_STATE; }
+        b->cap_ovf = b->cap_entries - used;
+    }
+    b->d_bounds = reinterpret_cast<int64_t *>(s.d_in + s.off_bounds);
+    b->d_win = reinterpret_cast<uint2 *>(s.d_in + s.off_win);
+    b->d_ref = s.d_in + s.off_ref;
+    b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
+    b->d_seg = p->drec ? nullptr : reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
+    b->d_drec = p->drec ? reinterpret_cast<uint4 *>(s.d_in + s.off_rec) : nullptr;
+    b->d_rec16 = nullptr; b->d_rec32 = nullptr;
+    b->d_pair = linkage ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pairs) : nullptr;
+    b->d_pair_runs = nullptr; b->d_run_index = nullptr; b->n_runs = 0;
+    HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, w->h + w->o_bounds, w->bounds_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, w->h + w->o_win, w->win_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, w->h + w->o_ref, w->ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, w->h + w->o_gbase, w->gbase_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    if (linkage) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, w->h + w->o_pairs, w->pairs_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, w->h + w->o_rec, w->rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
+    s.h2d_bytes = isx_wire_bytes(w);
+    s.encode_ms = (float)(now_ms() - t0);       // (what this submit itself spent on the host: enqueueing)
+    s.encode_passes = 0;                        // staged ahead of time
+    return enqueue_pass(p, s, w->n_pos, ticket);
 }
 
 int isx_pipe_submit_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,13 +26,13 @@ constexpr int64_t TASK = 4096;          // segments per task (a multiple of ISX_
 constexpr uint32_t SPAN = 65535u;       // largest delta a header can carry
 
 // groups the segments [a, e) need: greedy, arrival order
-inline int64_t count_groups(const uint32_t *gpos, int64_t a, int64_t e)
+inline int64_t count_groups(const uint32_t *gpos, int64_t a, int64_t e, int64_t group = ISX_SEG_GROUP)
 {
     int64_t n = 0;
     for (int64_t i = a; i < e;) {
         uint32_t lo = gpos[i], hi = gpos[i];
         int64_t j = i + 1;
-        for (; j < e && j - i < ISX_SEG_GROUP; j++) {
+        for (; j < e && j - i < group; j++) {
             const uint32_t p = gpos[j];
             const uint32_t nlo = p < lo ? p : lo, nhi = p > hi ? p : hi;
             if (nhi - nlo > SPAN) break;
@@ -202,6 +203,295 @@ int encode_segs(HostPool &pool, SegJob &J)
     return SEG_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// reference-delta records (include/instrain_amd.h ISX_DREC_*): a segment is compared with the reference on the host and only
+// what differs travels -- the columns it does not observe as a bit plane, the bases that are not the reference's as
+// (offset, base) exceptions.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Cols {                           // one segment against the reference: 160-bit column masks
+    uint64_t skip[3];                   // no observation at the column (codes >= 4)
+    uint64_t exc[3];                    // observed, and not the reference's base
+    alignas(64) uint8_t code[192];      // base code per column
+};
+
+inline void cols_scalar(const uint32_t *bases, const uint8_t *ref, uint32_t L, Cols &C)
+{
+    C.skip[0] = C.skip[1] = C.skip[2] = 0;
+    C.exc[0] = C.exc[1] = C.exc[2] = 0;
+    for (uint32_t j = 0; j < L; j++) {
+        const uint32_t c = (bases[j / 10] >> (3 * (j % 10))) & 7u;
+        C.code[j] = (uint8_t)c;
+        const uint64_t bit = 1ull << (j & 63);
+        if (c >= 4) C.skip[j >> 6] |= bit;
+        else if (c != ref[j]) C.exc[j >> 6] |= bit;
+    }
+}
+
+inline bool cpu_has_vbmi()
+{
+    static const bool v = cpu_has_avx512() && __builtin_cpu_supports("avx512vbmi") && !getenv("ISX_NO_VBMI");     // (the switch: tests of the scalar path)
+    return v;
+}
+
+// three vectors of 64 codes from the fifteen words: per 64-bit lane the two words its eight codes sit in (vpermd), the eight
+// 3-bit fields picked by vpmultishiftqb
+struct UnpackTables {
+    alignas(64) uint32_t idx[3][16];
+    alignas(64) uint8_t ctrl[3][64];
+    UnpackTables()
+    {
+        for (int k = 0; k < 3; k++)
+            for (int q = 0; q < 8; q++) {
+                const int n0 = 64 * k + 8 * q, i = n0 / 10;
+                idx[k][2 * q] = (uint32_t)std::min(i, 15);
+                idx[k][2 * q + 1] = (uint32_t)std::min(i + 1, 15);
+                for (int t = 0; t < 8; t++) {
+                    const int n = n0 + t;
+                    ctrl[k][8 * q + t] = (uint8_t)((n / 10 == i ? 0 : 32) + 3 * (n % 10));
+                }
+            }
+    }
+};
+
+__attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi")))
+inline void cols_vbmi(const uint32_t *bases, const uint8_t *ref, uint32_t L, Cols &C)
+{
+    static const UnpackTables T;
+    const __m512i in = _mm512_maskz_loadu_epi32((__mmask16)0x7FFF, bases);
+    const __m512i seven = _mm512_set1_epi8(7), four = _mm512_set1_epi8(4);
+#pragma GCC unroll 3
+    for (int k = 0; k < 3; k++) {
+        const __m512i src = _mm512_permutexvar_epi32(_mm512_load_si512(T.idx[k]), in);
+        const __m512i c = _mm512_and_si512(_mm512_multishift_epi64_epi8(_mm512_load_si512(T.ctrl[k]), src), seven);
+        _mm512_store_si512(C.code + 64 * k, c);
+        const uint32_t have = L > (uint32_t)(64 * k) ? std::min<uint32_t>(64u, L - (uint32_t)(64 * k)) : 0u;
+        const __mmask64 lm = have == 64 ? ~(__mmask64)0 : (((__mmask64)1 << have) - 1);
+        const __m512i r = _mm512_maskz_loadu_epi8(lm, ref + 64 * k);               // (masked lanes never fault)
+        const __mmask64 sk = _mm512_cmpge_epu8_mask(c, four) & lm;
+        C.skip[k] = (uint64_t)sk;
+        C.exc[k] = (uint64_t)(_mm512_cmpneq_epi8_mask(c, r) & lm & ~sk);
+    }
+}
+
+// bits [b, b + len) of a 160-bit mask, moved down to bit 0 (len <= 160 - b)
+inline void window160(const uint64_t m[3], uint32_t b, uint32_t len, uint64_t out[3])
+{
+    const uint32_t ws = b >> 6, bs = b & 63;
+    for (uint32_t i = 0; i < 3; i++) {
+        const uint64_t lo = i + ws < 3 ? m[i + ws] : 0, hi = i + ws + 1 < 3 ? m[i + ws + 1] : 0;
+        uint64_t v = bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+        const uint32_t from = 64 * i;
+        if (len <= from) v = 0;
+        else if (len - from < 64) v &= ((uint64_t)1 << (len - from)) - 1;
+        out[i] = v;
+    }
+}
+
+struct GroupBuf {
+    alignas(64) uint32_t rec[ISX_DREC_GROUP][ISX_DREC_WORDS];
+    uint32_t start[ISX_DREC_GROUP], last[ISX_DREC_GROUP], pair[ISX_DREC_GROUP];
+    int n = 0;
+    uint32_t lo = 0, hi = 0;
+};
+
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+inline void store_group_avx512(uint32_t *o, const GroupBuf &G)
+{
+    for (int r = 0; r < ISX_DREC_GROUP; r += 2) _mm512_stream_si512(reinterpret_cast<__m512i *>(o + (size_t)r * ISX_DREC_WORDS), _mm512_load_si512(G.rec[r]));
+    _mm_sfence();
+}
+
+}  // namespace
+
+int64_t delta_groups_needed(HostPool &pool, const uint32_t *gpos, int64_t n, int64_t slack_groups)
+{
+    const int n_tasks = (int)((n + TASK - 1) / TASK);
+    std::vector<int64_t> g((size_t)std::max(n_tasks, 1), 0);
+    pool.run(n_tasks, [&](int t) {
+        const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
+        g[(size_t)t] = count_groups(gpos, a, e, ISX_DREC_GROUP) + slack_groups;
+    });
+    int64_t tot = 0;
+    for (int64_t v : g) tot += v;
+    return std::max<int64_t>(tot, 1);
+}
+
+int encode_delta(HostPool &pool, SegJob &J)
+{
+    const int64_t n = J.n_seg;
+    const bool producer = (bool)J.produce;
+    const uint32_t *gpos_all = producer ? J.gpos_all : J.in.gpos;
+    const int n_tasks = (int)((n + TASK - 1) / TASK);
+    const int64_t slack = std::max<int64_t>(J.slack_groups, 1);
+    std::vector<int64_t> g_at((size_t)n_tasks + 1, 0);
+    pool.run(n_tasks, [&](int t) {
+        const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
+        g_at[(size_t)t + 1] = count_groups(gpos_all, a, e, ISX_DREC_GROUP) + slack;
+    });
+    for (int t = 0; t < n_tasks; t++) g_at[(size_t)t + 1] += g_at[(size_t)t];
+    const int64_t n_groups = std::max<int64_t>(g_at[(size_t)n_tasks], 1);
+    J.n_rec = n_groups * ISX_DREC_GROUP;
+    J.need_slack = slack;
+    if (J.n_rec > J.cap_rec) return SEG_CAPACITY;
+    std::atomic<int> err{SEG_OK};
+    std::vector<int64_t> bases_of((size_t)std::max(n_tasks, 1), 0), need_of((size_t)std::max(n_tasks, 1), 0), pieces_of((size_t)std::max(n_tasks, 1), 0);
+    std::vector<uint32_t> maxp_of((size_t)std::max(n_tasks, 1), 0);
+    const bool pairs = J.pair_out != nullptr && (producer ? J.want_pairs : J.in.pair != nullptr);
+    const int64_t RG = J.ring_groups;
+    constexpr size_t group_words = (size_t)ISX_DREC_GROUP * ISX_DREC_WORDS;
+    const bool fast_store = cpu_has_avx512() && (reinterpret_cast<uintptr_t>(J.rec) & 63) == 0;
+    const bool vbmi = cpu_has_vbmi();
+    auto put_empty_group = [&](uint32_t *o) {
+        for (int r = 0; r < ISX_DREC_GROUP; r++, o += ISX_DREC_WORDS) {
+            o[0] = o[1] = o[2] = o[4] = o[5] = o[6] = 0;
+            o[3] = o[7] = ISX_DREC_NO_EXC;
+        }
+    };
+    if (n == 0) {                                   // one empty group: the kernels want a stream
+        if (RG) J.wave_begin(0);
+        put_empty_group(J.rec);
+        if (J.pair_out) for (int r = 0; r < ISX_DREC_GROUP; r++) J.pair_out[r] = 0;
+        J.gbase[0] = 0; J.cmin[0] = 0xFFFFFFFFu; J.cmax[0] = 0; J.cany[0] = 0;
+        J.n_bases = 0; J.max_pair = 0; J.n_pieces = 0;
+        if (RG) J.wave_flush(0, 0, 1);
+        return SEG_OK;
+    }
+    auto run_task = [&](int t, int64_t wave_g0, int half) {
+        if (err.load(std::memory_order_relaxed) != SEG_OK) return;
+        const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
+        const uint32_t *gp, *pr, *bs;
+        const uint8_t *ln, *mm;
+        if (producer) {
+            thread_local Scratch S;
+            if (S.gpos.size() < (size_t)TASK) { S.gpos.resize((size_t)TASK); S.pair.resize((size_t)TASK); S.bases.resize((size_t)TASK * ISX_SEG_WORDS + 1); S.len.resize((size_t)TASK); S.mm.resize((size_t)TASK); }
+            J.produce(a, e - a, S.gpos.data(), S.len.data(), S.mm.data(), pairs ? S.pair.data() : nullptr, S.bases.data());
+            gp = S.gpos.data() - a; ln = S.len.data() - a; mm = S.mm.data() - a; pr = pairs ? S.pair.data() - a : nullptr;
+            bs = S.bases.data() - (size_t)a * ISX_SEG_WORDS;
+        } else {
+            gp = J.in.gpos; ln = J.in.len; mm = J.in.mm; pr = pairs ? J.in.pair : nullptr; bs = J.in.bases;
+        }
+        const int64_t g_end = g_at[(size_t)t + 1];
+        int64_t g = g_at[(size_t)t], nb = 0, used = 0, np = 0;     // used: groups this task needs (may exceed its region: counted, not written)
+        uint32_t maxp = 0;
+        GroupBuf G;
+        auto rec_at = [&](int64_t gi) { return J.rec + (RG ? (size_t)(gi - wave_g0 + (int64_t)half * RG) : (size_t)gi) * group_words; };
+        auto close_group = [&]() {
+            if (!G.n) return;
+            if (g < g_end) {
+                uint32_t lo = G.start[0], last = G.last[0];
+                for (int r = 1; r < G.n; r++) { lo = std::min(lo, G.start[r]); last = std::max(last, G.last[r]); }
+                for (int r = 0; r < G.n; r++) G.rec[r][0] |= G.start[r] - lo;
+                for (int r = G.n; r < ISX_DREC_GROUP; r++) {
+                    uint32_t *o = G.rec[r];
+                    o[0] = o[1] = o[2] = o[4] = o[5] = o[6] = 0;
+                    o[3] = o[7] = ISX_DREC_NO_EXC;
+                    G.pair[r] = 0;
+                }
+                uint32_t *o = rec_at(g);
+                if (fast_store) store_group_avx512(o, G); else memcpy(o, G.rec, sizeof G.rec);
+                if (J.pair_out) memcpy(J.pair_out + (size_t)g * ISX_DREC_GROUP, G.pair, sizeof G.pair);
+                J.gbase[g] = lo; J.cmin[g] = lo; J.cmax[g] = last; J.cany[g] = 1;
+                g++;
+            }
+            used++;
+            G.n = 0;
+        };
+        auto add_piece = [&](uint32_t start, uint32_t len, uint32_t m, uint32_t pid, const uint64_t msk[3], const uint32_t exc[2]) {
+            if (G.n) {
+                const uint32_t nlo = std::min(G.lo, start), nhi = std::max(G.hi, start);
+                if (G.n == ISX_DREC_GROUP || nhi - nlo > SPAN) close_group();
+            }
+            if (!G.n) { G.lo = G.hi = start; }
+            else { G.lo = std::min(G.lo, start); G.hi = std::max(G.hi, start); }
+            uint32_t *o = G.rec[G.n];
+            o[0] = (len << 16) | (m << 24);
+            o[1] = (uint32_t)msk[0]; o[2] = (uint32_t)(msk[0] >> 32); o[3] = exc[0];
+            o[4] = (uint32_t)msk[1]; o[5] = (uint32_t)(msk[1] >> 32); o[6] = (uint32_t)msk[2]; o[7] = exc[1];
+            G.start[G.n] = start; G.last[G.n] = start + len - 1; G.pair[G.n] = pid;
+            G.n++;
+            np++;
+        };
+        Cols C;
+        for (int64_t s = a; s < e; s++) {
+            const uint32_t L = ln[s], m = mm ? mm[s] : 0u, p = gp[s];
+            if (L == 0 || L > ISX_SEG_BASES) { err.store(SEG_BAD_LEN); return; }
+            if ((int64_t)p + (int64_t)L > J.n_pos || p != gpos_all[s]) { err.store(SEG_BAD_POS); return; }
+            if ((int)m >= J.n_mm_bins) { err.store(SEG_MM_RANGE); return; }
+            const uint32_t pid = pr ? pr[s] : 0u;
+            maxp = std::max(maxp, pid);
+            nb += L;
+            if (vbmi) cols_vbmi(bs + (size_t)s * ISX_SEG_WORDS, J.ref + p, L, C);
+            else cols_scalar(bs + (size_t)s * ISX_SEG_WORDS, J.ref + p, L, C);
+            const int n_exc = __builtin_popcountll(C.exc[0]) + __builtin_popcountll(C.exc[1]) + __builtin_popcountll(C.exc[2]);
+            if (n_exc == 0) {
+                const uint32_t none[2] = {ISX_DREC_NO_EXC, ISX_DREC_NO_EXC};
+                add_piece(p, L, m, pid, C.skip, none);
+                continue;
+            }
+            // pieces of at most ISX_DREC_EXC exceptions: a piece ends right before the exception it has no room for
+            uint64_t ex[3] = {C.exc[0], C.exc[1], C.exc[2]};
+            uint32_t b = 0;
+            while (b < L) {
+                uint32_t f[ISX_DREC_EXC], nf = 0, end = L;
+                for (int k = 0; k < 3; k++) {
+                    while (ex[k]) {
+                        const uint32_t col = (uint32_t)(64 * k + __builtin_ctzll(ex[k]));
+                        if (nf == ISX_DREC_EXC) { end = col; goto cut; }
+                        ex[k] &= ex[k] - 1;
+                        f[nf++] = ((col - b) & 0xFFu) | ((uint32_t)(C.code[col] & 3u) << 8);
+                    }
+                }
+            cut:
+                uint32_t w[2] = {ISX_DREC_NO_EXC, ISX_DREC_NO_EXC};
+                for (uint32_t i = 0; i < nf; i++) {
+                    const int wi = i / 3, sh = 10 * (int)(i % 3);
+                    w[wi] = (w[wi] & ~(0x3FFu << sh)) | (f[i] << sh);
+                }
+                uint64_t msk[3];
+                window160(C.skip, b, end - b, msk);
+                add_piece(p + b, end - b, m, pid, msk, w);
+                b = end;
+            }
+        }
+        close_group();
+        need_of[(size_t)t] = used;
+        for (; g < g_end; g++) {                    // the spare groups of the region: empty
+            put_empty_group(rec_at(g));
+            if (J.pair_out) memset(J.pair_out + (size_t)g * ISX_DREC_GROUP, 0, ISX_DREC_GROUP * sizeof(uint32_t));
+            J.gbase[g] = 0; J.cmin[g] = 0xFFFFFFFFu; J.cmax[g] = 0; J.cany[g] = 0;
+        }
+        bases_of[(size_t)t] = nb; maxp_of[(size_t)t] = maxp; pieces_of[(size_t)t] = np;
+    };
+    if (!RG) pool.run(n_tasks, [&](int t) { run_task(t, 0, 0); });
+    else {
+        int half = 0;
+        for (int t0 = 0; t0 < n_tasks && err.load() == SEG_OK;) {
+            int t1 = t0 + 1;
+            while (t1 < n_tasks && g_at[(size_t)t1 + 1] - g_at[(size_t)t0] <= RG) t1++;
+            if (g_at[(size_t)t1] - g_at[(size_t)t0] > RG) return SEG_CAPACITY;         // one task alone outgrows a half (ring far too small)
+            J.wave_begin(half);
+            const int64_t wg0 = g_at[(size_t)t0];
+            pool.run(t1 - t0, [&](int k) { run_task(t0 + k, wg0, half); });
+            if (err.load() == SEG_OK) J.wave_flush(half, wg0, g_at[(size_t)t1]);
+            t0 = t1; half ^= 1;
+        }
+    }
+    if (err.load() != SEG_OK) return err.load();
+    J.n_bases = 0; J.max_pair = 0; J.n_pieces = 0;
+    int64_t worst = 0;
+    for (int t = 0; t < n_tasks; t++) {
+        J.n_bases += bases_of[(size_t)t]; J.max_pair = std::max(J.max_pair, maxp_of[(size_t)t]); J.n_pieces += pieces_of[(size_t)t];
+        const int64_t region = g_at[(size_t)t + 1] - g_at[(size_t)t];
+        worst = std::max(worst, need_of[(size_t)t] - (region - slack));
+    }
+    J.need_slack = worst;
+    if (worst > slack) return SEG_CAPACITY;         // some task outgrew its region: encode again with slack_groups >= need_slack
+    return SEG_OK;
+}
+
 }  // namespace isxenc
 
 namespace {
@@ -284,6 +574,57 @@ int isx_encode_segs_ring(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins,
     if (rc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
     *n_rec = J.n_rec;
     return ISX_OK;
+}
+
+int isx_encode_delta(const isx_segs *segs, const uint8_t *ref, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int32_t slack_groups,
+                     int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec, int64_t *need_slack)
+{
+    if (!segs || !ref || !rec || !gbase || !n_rec || segs->n_seg < 0 || cap_rec < ISX_DREC_GROUP || (cap_rec % ISX_DREC_GROUP) || n_pos <= 0 ||
+        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases)) || (segs->pair && !pair_out) || ring_records < 0 ||
+        (ring_records % (2 * ISX_DREC_GROUP)) || slack_groups < 0) {
+        isx_set_error("isx_encode_delta: bad argument");
+        return ISX_ERR_ARG;
+    }
+    std::vector<uint32_t> ring;
+    isxenc::HostPool pool(std::max(1, host_threads), -1, false);
+    std::vector<uint32_t> cmin((size_t)(cap_rec / ISX_DREC_GROUP)), cmax(cmin.size());
+    std::vector<uint8_t> cany(cmin.size());
+    isxenc::SegJob J;
+    J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = std::max(1, n_mm_bins);
+    J.ref = ref; J.slack_groups = std::max(1, slack_groups);
+    J.rec = rec; J.gbase = gbase; J.pair_out = segs->pair ? pair_out : nullptr;
+    J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data(); J.cap_rec = cap_rec;
+    if (ring_records) {         // the pipe's ring mode with a memcpy standing in for the DMA engine
+        const int64_t half = ring_records / 2;
+        ring.assign((size_t)ring_records * ISX_DREC_WORDS, 0xABABABABu);
+        J.rec = ring.data();
+        J.ring_groups = half / ISX_DREC_GROUP;
+        J.wave_begin = [](int) {};
+        J.wave_flush = [&](int h, int64_t g0, int64_t g1) {
+            const size_t gw = (size_t)ISX_DREC_GROUP * ISX_DREC_WORDS;
+            memcpy(rec + (size_t)g0 * gw, ring.data() + (size_t)h * half * ISX_DREC_WORDS, (size_t)(g1 - g0) * gw * 4);
+            std::fill_n(ring.begin() + (ptrdiff_t)((size_t)h * half * ISX_DREC_WORDS), (size_t)half * ISX_DREC_WORDS, 0xABABABABu);
+        };
+    }
+    const int rc = isxenc::encode_delta(pool, J);
+    if (need_slack) *need_slack = J.need_slack;
+    *n_rec = J.n_rec;
+    if (rc == isxenc::SEG_CAPACITY) {
+        isx_set_error(J.need_slack > J.slack_groups ? "isx_encode_delta: a task needs more spare groups than slack_groups (see *need_slack)"
+                                                    : "isx_encode_delta: the stream does not fit cap_rec records");
+        return ISX_ERR_CAPACITY;
+    }
+    if (rc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
+    if (rc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
+    if (rc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
+    return ISX_OK;
+}
+
+int64_t isx_delta_records_needed(const uint32_t *gpos, int64_t n_seg, int32_t host_threads, int32_t slack_groups)
+{
+    if (n_seg < 0 || (n_seg && !gpos) || slack_groups < 0) return -1;
+    isxenc::HostPool pool(std::max(1, host_threads), -1, false);
+    return isxenc::delta_groups_needed(pool, gpos, n_seg, std::max(1, slack_groups)) * ISX_DREC_GROUP;
 }
 
 int64_t isx_seg_records_needed(const uint32_t *gpos, int64_t n_seg, int32_t host_threads)

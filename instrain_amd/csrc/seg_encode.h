@@ -15,6 +15,8 @@
 
 #define ISX_SEG_GROUP 16                // records per position base = one wave-wide 16-byte load (64 lanes x 16 B = 16 records)
 #define ISX_SEG_REC_WORDS 16            // header + ISX_SEG_WORDS payload words
+// reference-delta records (include/instrain_amd.h, ISX_DREC_*): 32 bytes, 32 per group = one wave-wide 16-byte load
+#define ISX_DREC_GROUP 32
 
 namespace isxenc {
 
@@ -41,6 +43,14 @@ struct SegJob {
     int64_t ring_groups = 0;
     std::function<void(int half)> wave_begin;
     std::function<void(int half, int64_t g0, int64_t g1)> wave_flush;
+    // reference-delta records (encode_delta): the reference codes of the batch's flat space (1 byte per position, 0..3 = A C T G,
+    // anything else = not a base) and the spare groups every task's region gets for the extra records of segments that differ
+    // from the reference at more than ISX_DREC_EXC columns (a segment is then cut into pieces); need_slack = what the worst task
+    // would have needed (> slack_groups: nothing usable was written, encode again with at least that)
+    const uint8_t *ref = nullptr;
+    int64_t slack_groups = 1;
+    int64_t need_slack = 0;
+    int64_t n_pieces = 0;                       // delta records written (>= n_seg)
     // results
     int64_t n_rec = 0;                          // device records, a multiple of ISX_SEG_GROUP
     int64_t n_bases = 0;                        // sum of the segment lengths (an upper bound of the observations)
@@ -50,6 +60,10 @@ struct SegJob {
 enum { SEG_OK = 0, SEG_CAPACITY = 1, SEG_MM_RANGE = 2, SEG_BAD_POS = 3, SEG_BAD_LEN = 4 };
 
 int encode_segs(HostPool &pool, SegJob &job);
+// the same stream as 32-byte reference-delta records (groups of ISX_DREC_GROUP); SEG_CAPACITY with need_slack > slack_groups
+// means "encode again with more slack", otherwise the stream does not fit cap_rec
+int encode_delta(HostPool &pool, SegJob &job);
+int64_t delta_groups_needed(HostPool &pool, const uint32_t *gpos, int64_t n, int64_t slack_groups);
 int64_t seg_groups_needed(HostPool &pool, const uint32_t *gpos, int64_t n);
 
 }  // namespace isxenc

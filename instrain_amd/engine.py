@@ -271,6 +271,7 @@ class Pipe:
                  linkage_mode=0, window=0, seed=0, layout=0, want_counts=False, ring_kib=0, max_segs=0, stage_async=False):
         self.ctx, self.lib = ctx, ctx.lib
         self._held = {}                             # stage_async: what a queued batch still reads, by ticket
+        self._wires = []                            # staged batches (freed with the pipe at the latest)
         self.stage_async = bool(stage_async) and max_segs > 0
         self.n_mm_bins = int(n_mm_bins)
         self.min_cov = int(min_cov)
@@ -310,6 +311,25 @@ class Pipe:
                                              split_bounds.ctypes.data, C.byref(cs), C.byref(t)))
         if self.stage_async:                        # the stager reads these until the batch is collected / released
             self._held[t.value] = (ref_codes, segs, cs)
+        return t.value
+
+    def stage_reads(self, ref_codes, split_bounds, segs):
+        """-> Wire: the batch staged once into a pinned image of its own (isx_pipe_stage_reads); submit_wire(wire) then costs no
+        host work.  The wire stays valid until wire.close() / the pipe's close()."""
+        ref_codes = np.ascontiguousarray(ref_codes, dtype=np.uint8)
+        split_bounds = np.ascontiguousarray(split_bounds, dtype=np.int64)
+        cs = segs.c(with_pair=self.enable_linkage)
+        h = C.c_void_p()
+        check(self.lib.isx_pipe_stage_reads(self.h, len(ref_codes), ref_codes.ctypes.data, len(split_bounds) - 1, split_bounds.ctypes.data,
+                                            C.byref(cs), C.byref(h)))
+        w = Wire(self, h)
+        self._wires.append(w)
+        return w
+
+    def submit_wire(self, wire):
+        """-> ticket.  A staged batch (stage_reads) into the next free slot: DMA copies + pass + copy-out, nothing else"""
+        t = C.c_int64(-1)
+        check(self.lib.isx_pipe_submit_wire(self.h, wire.h, C.byref(t)))
         return t.value
 
     def submit_bam(self, bamfile, refs, ref_codes, split_bounds=None, **kw):
@@ -422,6 +442,9 @@ class Pipe:
         h, self.h = self.h, None                    # (a second close, from another thread, finds nothing to do)
         if h:
             self.lib.isx_pipe_destroy(h)            # (stages and finishes what is still queued)
+            for w in self._wires:
+                w.close()
+        self._wires = []
         self._held.clear()
 
     def __del__(self):
@@ -429,6 +452,22 @@ class Pipe:
             self.close()
         except Exception:
             pass
+
+
+class Wire:
+    """A staged batch (isx_wire): pinned image + geometry, made by Pipe.stage_reads"""
+
+    def __init__(self, pipe, h):
+        self.lib, self.h = pipe.lib, h
+        self.bytes = int(self.lib.isx_wire_bytes(h))
+
+    def close(self):
+        h, self.h = self.h, None
+        if h:
+            self.lib.isx_wire_free(h)
+
+    def __del__(self):
+        pass                                        # (freed by its pipe's close(): a wire must outlive the batches submitted from it)
 
 
 def encode_obs(obs, pair=None, n_pos=None, record_bytes=2, threads=1, slack=0.0, cap_rec=None, ring_records=0):
@@ -476,6 +515,59 @@ def encode_segs(segs, n_pos, n_mm_bins=1, threads=1, cap_rec=None, ring_records=
                                    gbase.ctypes.data, pout.ctypes.data if pout is not None else None, C.byref(n_rec)))
     n = n_rec.value
     return rec[:n], gbase[:n // 16], (pout[:n] if pout is not None else None)
+
+
+def encode_delta(segs, ref_codes, n_mm_bins=1, threads=1, slack_groups=1, cap_rec=None, ring_records=0, retry=True):
+    """isx_encode_delta (host only): SegBatch + reference codes -> (rec [n_rec, 8] uint32, gbase [n_rec / 32], pair_out | None,
+    slack_groups used); retry: encode again with the slack the first attempt asked for"""
+    lib = _lib.load()
+    ref = np.ascontiguousarray(ref_codes, dtype=np.uint8)
+    while True:
+        cap = cap_rec if cap_rec is not None else int(lib.isx_delta_records_needed(segs.gpos.ctypes.data if segs.n_seg else None, segs.n_seg, int(threads), int(slack_groups)))
+        rec = np.empty((cap, 8), dtype=np.uint32)
+        gbase = np.empty(cap // 32, dtype=np.uint32)
+        pout = np.empty(cap, dtype=np.uint32) if segs.pair is not None else None
+        n_rec, need = C.c_int64(0), C.c_int64(0)
+        cs = segs.c()
+        rc = lib.isx_encode_delta(C.byref(cs), ref.ctypes.data, len(ref), int(n_mm_bins), int(threads), int(slack_groups), cap, int(ring_records),
+                                  rec.ctypes.data, gbase.ctypes.data, pout.ctypes.data if pout is not None else None, C.byref(n_rec), C.byref(need))
+        if rc == _lib.ERR_CAPACITY and retry and need.value > slack_groups and cap_rec is None:
+            slack_groups = int(need.value)
+            continue
+        check(rc)
+        n = n_rec.value
+        return rec[:n], gbase[:n // 32], (pout[:n] if pout is not None else None), slack_groups
+
+
+def decode_delta(rec, gbase, ref_codes):
+    """reference-delta record stream -> (gpos, len, mm, codes [n, 150]) of its real records (pieces), in stream order (tests);
+    code 4 where a column is skipped or beyond the record's length"""
+    rec = np.asarray(rec, dtype=np.uint32).reshape(-1, 8)
+    ref = np.asarray(ref_codes, dtype=np.uint8)
+    hdr = rec[:, 0]
+    ln = ((hdr >> 16) & 0xFF).astype(np.int64)
+    real = ln > 0
+    start = (np.repeat(np.asarray(gbase, dtype=np.uint32), 32)[:len(rec)] + (hdr & 0xFFFF)).astype(np.int64)
+    r, st, ln = rec[real], start[real], ln[real]
+    n = len(r)
+    j = np.arange(160, dtype=np.int64)[None, :]
+    words = np.stack([r[:, 1], r[:, 2], r[:, 4], r[:, 5], r[:, 6]], axis=1)
+    skip = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(n, 160).astype(bool)
+    assert not (skip & (j >= ln[:, None])).any(), "skip bits beyond a record's length"
+    inside = j < ln[:, None]
+    pos = np.minimum(st[:, None] + j, len(ref) - 1)
+    codes = np.where(inside & ~skip, ref[pos], 4).astype(np.uint8)
+    for wi in (3, 7):
+        for k in range(3):
+            f = (r[:, wi] >> (10 * k)) & 0x3FF
+            has = f != 0x3FF
+            off, base = (f & 0xFF).astype(np.int64), ((f >> 8) & 3).astype(np.uint8)
+            rows = np.flatnonzero(has)
+            assert (off[rows] < ln[rows]).all() and not skip[rows, off[rows]].any()
+            assert (base[rows] != ref[st[rows] + off[rows]]).all(), "an exception that equals the reference"
+            codes[rows, off[rows]] = base[rows]
+        assert ((r[:, wi] >> 30) == 0).all()
+    return st.astype(np.uint32), ln.astype(np.uint8), (hdr[real] >> 24).astype(np.uint8), codes[:, :150]
 
 
 def decode_segs(rec, gbase):

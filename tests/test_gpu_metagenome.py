@@ -232,7 +232,7 @@ def test_metagenome_slice_vs_oracle_as_segments(ctx):
     b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["segs"], n_mm_bins=1, enable_linkage=True, **kw)
     b.run()
     res = b.fetch()
-    assert b.timings()["record_bytes"] == 64
+    assert b.timings()["record_bytes"] == 32
     got = prod.to_oracle_layout(res, lambda g: g.astype(np.int64))
     b.close()
     gpos, base, mm, pair = util.segs_to_obs(w["segs"])

@@ -29,12 +29,22 @@ def _params(g):
     return dict(min_cov=int(g["p_min_cov"]), min_freq=float(g["p_min_freq"]), min_snp=int(g["p_min_snp"]))
 
 
-@pytest.mark.parametrize("how", ["stream", "reassembled"])
+SEG64 = 8       # isx_params.layout: ISX_LAYOUT_SEG64_RECORDS (one mm bin: the 64-byte segment records instead of reference-delta records)
+
+
+@pytest.mark.parametrize("how", ["stream", "reassembled", "stream64", "reassembled64"])
 @pytest.mark.parametrize("name", CASES)
 def test_golden_vectors_as_read_segments(ctx, name, how):
+    """every reference-generated vector as read segments: one mm bin -> 32-byte reference-delta records (difference-array
+    pileup), or with layout SEG64 the 64-byte segment records; several mm bins -> segment records"""
     from tests import prod
     g = util.load_case(name)
-    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), reads=how, **_params(g))
+    kw = _params(g)
+    if how.endswith("64"):
+        if int(g["mm"].max()) > 0:
+            pytest.skip("several mm bins: segment records either way")
+        how, kw = how[:-2], dict(kw, layout=SEG64)
+    res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), reads=how, **kw)
     util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name + "/" + how)
     assert res["n_edges"] == int(g["n_edges"])
 
@@ -117,11 +127,13 @@ def test_randomized_sweep_reads_equal_observations(ctx):
         sa = a.sizes()
         a.close()
         for segs in (synth.segs_from_obs(obs, pr), util.reassemble_segs(pos, base, mm, pair)):
-            b = engine.Batch(ctx, ref, [0, mLen], segs, **kw)
-            b.run()
-            _tables_equal(ra, b.fetch(), "iteration %d %r" % (it, kw))
-            assert b.sizes() == sa
-            b.close()
+            for layout in ((0, SEG64) if kw["n_mm_bins"] == 1 else (0,)):
+                b = engine.Batch(ctx, ref, [0, mLen], segs, layout=layout, **kw)
+                b.run()
+                _tables_equal(ra, b.fetch(), "iteration %d %r layout %d" % (it, kw, layout))
+                assert b.sizes() == sa
+                assert b.timings()["record_bytes"] == (32 if kw["n_mm_bins"] == 1 and layout == 0 else 64)
+                b.close()
 
 
 def test_non_acgt_base_makes_its_level_present(ctx):
@@ -167,12 +179,14 @@ def test_segments_straddling_windows_and_far_jumps(ctx):
         si, off = np.nonzero(codes == b)
         np.add.at(exp[:, b], starts[si].astype(np.int64) + off, 1)
     ref = rng.integers(0, 4, n_pos, dtype=np.uint8)
+    # (random bases against a random reference: three of four columns are exceptions -- a segment travels as ~20 delta records)
     for window in (64, 192, 1024, 0):
-        bt = engine.Batch(ctx, ref, [0, 150_000, n_pos], segs, n_mm_bins=1, min_cov=5, enable_linkage=True, window=window)
-        bt.run()
-        c = bt.fetch()["counts"]
-        bt.close()
-        assert (c.astype(np.int64) == exp).all(), window
+        for layout in (0, SEG64):
+            bt = engine.Batch(ctx, ref, [0, 150_000, n_pos], segs, n_mm_bins=1, min_cov=5, enable_linkage=True, window=window, layout=layout)
+            bt.run()
+            c = bt.fetch()["counts"]
+            bt.close()
+            assert (c.astype(np.int64) == exp).all(), (window, layout)
 
 
 def _c2(scale=1.0, seed=2, skip_mm=True):
@@ -180,14 +194,14 @@ def _c2(scale=1.0, seed=2, skip_mm=True):
     return synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale), seed=seed, skip_mm=skip_mm)
 
 
-@pytest.mark.parametrize("skip_mm,linkage", [(True, False), (True, True), (False, True)])
-def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage):
+@pytest.mark.parametrize("skip_mm,linkage,layout", [(True, False, 0), (True, True, 0), (True, True, SEG64), (False, True, 0)])
+def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage, layout):
     """a C2 slice through the read-level pipe == the same observations through a resident batch, every table"""
     from instrain_amd import engine, synth
     w = _c2(0.1, seed=4, skip_mm=skip_mm)
     M = w["n_mm_bins"]
     segs = synth.segs_from_obs(w["obs"], w["pair"])
-    kw = dict(n_mm_bins=M, enable_linkage=linkage, min_snp=20)
+    kw = dict(n_mm_bins=M, enable_linkage=linkage, min_snp=20, layout=layout)
     a = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["obs"], w["pair"] if linkage else None, **kw)
     a.run()
     ra, sa = a.fetch(), a.sizes()
@@ -197,7 +211,7 @@ def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage):
     tickets = [pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs) for _ in range(2)]
     for t in tickets:
         r = pipe.collect(t)
-        assert r["stats"]["record_bytes"] == 64
+        assert r["stats"]["record_bytes"] == (32 if M == 1 and layout == 0 else 64)
         assert r["sizes"] == sa
         if M == 1:
             assert (r["counts"] == ra["counts"]).all()
@@ -284,12 +298,14 @@ def test_full_c2_reads_equal_observations(ctx):
     a.run()
     ra = a.fetch()
     a.close()
-    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], segs, n_mm_bins=1, enable_linkage=False)
-    b.run()
-    rb = b.fetch()
-    b.close()
-    _tables_equal(ra, rb, "C2")
-    assert int(rb["counts"].sum()) == w["n_obs"]
+    for layout in (0, SEG64):
+        b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], segs, n_mm_bins=1, enable_linkage=False, layout=layout)
+        b.run()
+        rb = b.fetch()
+        assert b.timings()["record_bytes"] == (64 if layout else 32)
+        b.close()
+        _tables_equal(ra, rb, "C2 layout %d" % layout)
+        assert int(rb["counts"].sum()) == w["n_obs"]
 
 
 @pytest.mark.parametrize("linkage", [False, True])
@@ -321,4 +337,63 @@ def test_empty_and_single_segment_batches(ctx, linkage):
             assert r["counts"][7, 1] == 1 and (r["counts"][2400:2550, 1] == 1).all() and r["counts"][:, [0, 2, 3]].sum() == 0
             assert (r["cov16"][2400:2550] == 1).all() and r["cov16"].sum() == 151
         pipe.release(t)
+    pipe.close()
+
+
+@pytest.mark.parametrize("skip_mm,linkage,layout", [(True, False, 0), (True, True, 0), (True, True, SEG64), (False, True, 0)])
+def test_staged_batches_equal_submits(ctx, skip_mm, linkage, layout):
+    """isx_pipe_stage_reads + isx_pipe_submit_wire (the zero-copy hand-over: all host work done once, into a pinned image) give the
+    tables isx_pipe_submit_reads gives; a wire can be submitted again and again, interleaved with other wires and plain submits;
+    a wire of another pipe is refused"""
+    from instrain_amd import engine, synth
+    ws = [_c2(0.05, seed=31 + i, skip_mm=skip_mm) for i in range(2)]
+    M = max(w["n_mm_bins"] for w in ws)
+    segs = [synth.segs_from_obs(w["obs"], w["pair"]) for w in ws]
+    kw = dict(n_mm_bins=M, enable_linkage=linkage, min_snp=20, layout=layout)
+    cap = dict(max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(s.n_seg for s in segs),
+               max_splits=max(len(w["split_bounds"]) for w in ws), depth=3, host_threads=4, pin_threads=False, want_counts=True)
+    pipe = engine.Pipe(ctx, **cap, **kw)
+    keys = ("counts", "clon", "snv", "ld") if M == 1 else ("entries", "snv", "ld")
+    want = []
+    for w, sg in zip(ws, segs):
+        t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], sg)
+        r = pipe.collect(t)
+        want.append((r["sizes"], {k: r[k].copy() for k in keys}))
+        pipe.release(t)
+    wires = [pipe.stage_reads(w["ref_codes"], w["split_bounds"], sg) for w, sg in zip(ws, segs)]
+    rb = 32 if (M == 1 and layout == 0) else 64
+    for wr, sg, w in zip(wires, segs, ws):
+        assert wr.bytes < sg.n_seg * rb * 1.1 + w["n_pos"] * 0.55 + (sg.n_seg * 4.4 if linkage else 0) + 200_000
+    order = [0, 1, 1, 0, 0, 1]
+    tickets, done = [], 0
+
+    def take():
+        nonlocal done
+        r = pipe.collect(tickets[done])
+        sz, tb = want[order[done]]
+        assert r["sizes"] == sz and r["stats"]["record_bytes"] == rb and r["stats"]["encode_passes"] == 0
+        for k in keys:
+            assert r[k].tobytes() == tb[k].tobytes(), (k, done)
+        pipe.release(tickets[done])
+        done += 1
+
+    for i, k in enumerate(order):
+        if len(tickets) - done == 3:
+            take()
+        if i == 3:                                  # a plain submit in between
+            tickets.append(pipe.submit_reads(ws[k]["ref_codes"], ws[k]["split_bounds"], segs[k]))
+            continue
+        tickets.append(pipe.submit_wire(wires[k]))
+    while done < len(tickets):
+        if done == 3:
+            r = pipe.collect(tickets[done])
+            assert r["sizes"] == want[order[done]][0]
+            pipe.release(tickets[done])
+            done += 1
+            continue
+        take()
+    other = engine.Pipe(ctx, **cap, **kw)
+    with pytest.raises(engine.IsxError, match="another pipe"):
+        other.submit_wire(wires[0])
+    other.close()
     pipe.close()

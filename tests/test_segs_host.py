@@ -1,6 +1,8 @@
 """Host side of the read-level hand-over (no GPU): observation stream <-> read segments, the staging encoder
 (isx_encode_segs) and the read packer (isx_pack_reads).  The segments must stand for exactly the observations the
 reference's pileup loop visits (profile_utilities.py:150-153, 268-286)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -120,6 +122,70 @@ def test_encode_segs_sparse_stream_is_sized_exactly():
     from instrain_amd._lib import IsxError
     with pytest.raises(IsxError):
         engine.encode_segs(segs, n_pos, cap_rec=need - 16)
+
+
+def _pieces_to_columns(g, ln, cd, n_pos):
+    """pieces -> per-position multiset signature: (position, code) pairs of every observed column, sorted"""
+    j = np.arange(150)[None, :]
+    ok = (j < ln[:, None]) & (cd < 4)
+    pos = (g[:, None].astype(np.int64) + j)[ok]
+    return np.sort(pos * 8 + cd[ok])
+
+
+def _mutated_workload(seed, G=120_000, cov=6, err=0.05, n_frac=0.01):
+    """reads with MANY mismatches (5 %: ~7 per read -> pieces) over a reference with non-ACGT stretches"""
+    rng = np.random.default_rng(seed)
+    w = synth.make_workload(genome_len=G, coverage=cov, n_sites=G // 50, err=err, seed=seed, skip_mm=True)
+    ref = w["ref_codes"].copy()
+    ref[rng.random(G) < n_frac] = 4
+    ref[1000:1400] = 4
+    return w, ref
+
+
+@pytest.mark.parametrize("threads,vbmi", [(1, True), (3, True), (2, False)])
+def test_encode_delta_round_trip(threads, vbmi):
+    """reference-delta records decode to exactly the observations the segments stand for: plain reads (one piece each), reads
+    with more than six differences (several pieces), a reference with non-ACGT positions (every base there is an exception);
+    the AVX-512 VBMI and the scalar compare agree (the scalar path runs in a subprocess: the choice is made once per process)"""
+    if not vbmi:
+        import subprocess
+        import sys
+        code = ("import os, sys; os.environ['ISX_NO_VBMI'] = '1'; sys.path.insert(0, %r); import tests.test_segs_host as t; "
+                "t.test_encode_delta_round_trip(2, True)" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
+    w = _workload(seed=21, G=300_000, cov=8, skip_mm=True)
+    segs = synth.segs_from_obs(w["obs"], w["pair"])
+    rec, gbase, pout, slack = engine.encode_delta(segs, w["ref_codes"], threads=threads)
+    assert len(rec) % 32 == 0 and len(gbase) == len(rec) // 32
+    g, ln, mm, cd = engine.decode_delta(rec, gbase, w["ref_codes"])
+    exp = engine.unpack_codes(segs.bases)
+    exp = np.where((np.arange(150)[None, :] < segs.len[:, None]) & (exp < 4), exp, 4)
+    assert len(g) == segs.n_seg and (g == segs.gpos).all() and (ln == segs.len).all() and (cd == exp).all()
+    real = ((rec[:, 0] >> 16) & 0xFF) > 0
+    assert (pout[real] == segs.pair).all() and (pout[~real] == 0).all()
+    assert (rec[~real][:, [1, 2, 4, 5, 6]] == 0).all() and (rec[~real][:, [3, 7]] == 0x3FFFFFFF).all() and (rec[~real, 0] == 0).all()
+    # many mismatches + non-ACGT reference: pieces
+    w, ref = _mutated_workload(seed=22)
+    segs = synth.segs_from_obs(w["obs"], w["pair"])
+    rec, gbase, pout, slack = engine.encode_delta(segs, ref, threads=threads)
+    g, ln, mm, cd = engine.decode_delta(rec, gbase, ref)
+    assert len(g) > segs.n_seg * 1.2 and slack > 1                 # pieces, and the first attempt's single spare group was not enough
+    gg, bb, _, _ = util.segs_to_obs(segs)
+    assert (_pieces_to_columns(g, ln, cd, len(ref)) == np.sort(gg * 8 + bb)).all()
+    real = ((rec[:, 0] >> 16) & 0xFF) > 0
+    # pieces keep their segment's pair id and the stream's order; a piece never carries more than six exceptions
+    n_exc = sum((((rec[real][:, wi] >> (10 * k)) & 0x3FF) != 0x3FF).astype(int) for wi in (3, 7) for k in range(3))
+    assert n_exc.max() == 6
+    first = np.r_[True, (pout[real][1:] != pout[real][:-1]) | (g[1:] <= g[:-1])]
+    assert first.sum() >= segs.n_seg * 0.99
+    # through the staging ring: the same stream
+    r2 = engine.encode_delta(segs, ref, threads=threads, slack_groups=slack, ring_records=2 * 8192)
+    assert (r2[0] == rec).all() and (r2[1] == gbase).all() and (r2[2] == pout).all()
+    from instrain_amd._lib import IsxError
+    with pytest.raises(IsxError):
+        engine.encode_delta(segs, ref, slack_groups=1, retry=False)
 
 
 def test_encode_segs_rejects_bad_input():

@@ -17,8 +17,11 @@ ctx = engine.Context(0)
 lut, fb = util.load_lut()
 ctx.set_null_model(lut, fb)
 w = bench.c2_workload(2, scale=float(os.environ.get("SCALE", "1.0")))
+LAYOUT = int(os.environ.get("LAYOUT", "0"))        # 0 = reference-delta records, 8 = 64-byte segment records
 if "--sweep" in sys.argv:
-    combos = [(0, 0, 0)] + [(W, B, 0) for B in (1024, 512, 256) for W in (832, 1024, 1536, 2048, 2560, 3264) if W <= 4 * B + 1024]
+    combos = [(0, 0, 0)] + [(W, B, 0) for B in (1024, 512, 256) for W in (768, 1024, 1536, 2048, 2560, 3200) if W <= 4 * B]
+elif LAYOUT == 0:       # delta records: 8 = no skip-plane walk, 16 = no materialise phase
+    combos = [(0, 0, d) for d in (0, 2, 64, 8, 16, 8 | 16, 2 | 64, 2 | 8, 128, 256, 512, 1024, 2048, 128 | 256 | 512)]
 else:
     combos = [(0, 0, d) for d in (0, 2, 64, 8, 16, 2 | 64, 128, 256, 512, 1024, 2048, 1024 | 2048, 128 | 256, 128 | 256 | 512, 128 | 512, 64 | 128 | 256 | 512)]
 for W, B, dbg in combos:
@@ -28,7 +31,7 @@ for W, B, dbg in combos:
         os.environ["ISX_BLOCK"] = str(B)
     os.environ["ISX_DEBUG_MODE"] = str(dbg)
     try:
-        b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["segs"], None, n_mm_bins=1, enable_linkage=False, window=W)
+        b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["segs"], None, n_mm_bins=1, enable_linkage=False, window=W, layout=LAYOUT)
         for _ in range(3):
             b.run()
         ts = []
