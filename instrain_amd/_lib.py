@@ -33,7 +33,7 @@ class Params(C.Structure):
                 ("reserved", C.c_int32)]
 
 
-LAYOUT_WIDE_RECORDS, LAYOUT_NO_SHORT_RECORDS, LAYOUT_NO_PACKED_COUNTERS, LAYOUT_SEG64_RECORDS = 1, 2, 4, 8
+LAYOUT_WIDE_RECORDS, LAYOUT_NO_SHORT_RECORDS, LAYOUT_NO_PACKED_COUNTERS, LAYOUT_SEG64_RECORDS = 1, 2, 4, 8          # NO_PACKED_COUNTERS also keeps reference-delta batches on 32-bit LDS counters
 
 
 class PipeParams(C.Structure):

@@ -634,7 +634,8 @@ int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed)
         int best = 2560;
         double best_eff = 0.0;
         // (reference-delta records carry two more rows -- skipped columns aside, the coverage differences: 24 / 29 bytes a position)
-        const int wtop = b->drec ? (prm->enable_linkage ? 2688 : 3264)
+        const int wtop = (b->drec && packed) ? (prm->enable_linkage ? 4352 : 6080)        // 16-bit counters: 12 (+ 6 with linkage) bytes a position
+                       : b->drec ? (prm->enable_linkage ? 2688 : 3264)
                                  : (prm->enable_linkage ? 3136 : ISX_PK16_MAX_W);      // 3264: the packed decode of 2-byte records needs 16-bit byte offsets
         for (int w = 2048; w <= wtop; w += 64) {
             const double n_win = std::ceil((double)n_pos / w);
@@ -676,7 +677,7 @@ int batch_set_geometry(isx_batch *b)
 {
     const bool dense = b->M == 1;
     if (!dense && b->W > 2 * b->block) { isx_set_error("mm path: window must be <= 2 x block"); return ISX_ERR_ARG; }
-    if (b->drec && b->W > 4 * b->block) { isx_set_error("reference-delta records: window must be <= 4 x block (4096)"); return ISX_ERR_ARG; }
+    if (b->drec && b->W > (b->packed ? 8 : 4) * b->block) { isx_set_error("reference-delta records: window must be <= 4 x block (8 x with 16-bit counters)"); return ISX_ERR_ARG; }
     b->rqcap = dense ? 0 : std::min(b->W, 512);     // positions with SNV rows per window (overflow: per-position atomics)
     b->lds = pileup_lds_bytes(b->W, b->M, b->qcap, b->rqcap, b->prm.enable_linkage, b->packed, b->block, b->segs ? (b->drec ? 32 : 64) : 0, &b->stage_off, &b->dlt_off);
     if (b->lds > 160 * 1024) { isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
@@ -960,11 +961,12 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
         std::vector<uint2> win;
         b->packed = 0;
         int W = batch_window_for(b, n_pos, false);
-        if (!dense) {
-            // u16-packed counters are legal when no window streams >= 65536 records
+        if (!dense || b->drec) {
+            // u16-packed counters are legal when no window streams >= 65536 records (reference-delta records: 32768 -- a
+            // coverage difference is signed)
             const int Wp = batch_window_for(b, n_pos, true);
             if (!(prm->layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, dir_chunk) < 65536) { b->packed = 1; W = Wp; }
+                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, dir_chunk) < (dense ? 32768u : 65536u)) { b->packed = 1; W = Wp; }
         }
         if (!b->packed) build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win, dir_chunk);
         b->W = W;

@@ -561,17 +561,31 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
     const int W = a.W;
     constexpr bool SEGS = FMT == 64;
     constexpr bool DREC = FMT == 32;                            // reference-delta records: see count_slot and the materialise phase
+    // PKL (reference-delta records of a batch none of whose windows streams 32768 records): 16-bit counters, two per LDS word --
+    // rows (A | C) and (T | G), and ONE row for skipped columns (low half) and coverage differences (high half, wrapping) that
+    // becomes the queue after the materialise phase: 12 instead of 24 bytes a position, so a window is twice as wide and the
+    // per-window fixed costs (barriers, dependent global latencies, cursor round trips) are paid half as often
+    constexpr bool PKL = DREC && PK16;
+    constexpr int NR = PKL ? 2 : 4;                             // counter rows
     const int S = W + (SEGS ? ISX_SEG_PAD : ISX_DENSE_PAD);     // row stride of the counters
     uint32_t *cnt = lds + (SEGS ? ISX_SEG_LM : 0);              // segments: ISX_SEG_LM margin columns on either side of the window
-    uint32_t *queue = lds + 4 * S;
+    uint32_t *queue = lds + NR * S;
     uint32_t *scratch = queue + S;
     uint16_t *thr_lds = reinterpret_cast<uint16_t *>(scratch + S_N);
     uint32_t *slabc = scratch + S_N + THR_LDS / 2;
     uint8_t *maskl = reinterpret_cast<uint8_t *>(slabc + W);
     // DREC: two more rows -- the coverage differences (+1 where a record starts, -1 behind its end) and, in the queue's row (idle
     // until the epilogue), the skipped columns; the counter rows hold the EXCEPTIONS until the materialise phase
-    uint32_t *dlt = lds + a.dlt_off;
-    uint32_t *wtot = dlt + S;                   // [16] per-wave totals of the prefix sum
+    uint32_t *dlt = PKL ? queue : lds + a.dlt_off;
+    uint32_t *wtot = lds + a.dlt_off + (PKL ? 0 : S);           // [16] per-wave totals of the prefix sum
+    uint8_t *refl = reinterpret_cast<uint8_t *>(wtot + 16);     // PKL: the window's reference codes [W], stashed by the materialise phase
+    // the four counts of window position p
+    auto ld4 = [&](int p, uint32_t *c) {
+        if (PKL) {
+            const uint32_t x = cnt[p], y = cnt[S + p];
+            c[0] = x & 0xFFFFu; c[1] = x >> 16; c[2] = y & 0xFFFFu; c[3] = y >> 16;
+        } else { c[0] = cnt[p]; c[1] = cnt[S + p]; c[2] = cnt[2 * S + p]; c[3] = cnt[3 * S + p]; }
+    };
     constexpr bool linkage = LINKAGE;            // compile-time: the linkage-off kernels carry none of the allele pass
     const int grid = gridDim.x, per = grid >> 3;
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
@@ -613,29 +627,35 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         else if (FMT == 4) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
         else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
     };
+    // a window's record range is loaded one window AHEAD of its first record loads (at the top of the window before): the loads
+    // that depend on it are then issued without waiting for a global round trip
+    uint2 rng_next = make_uint2(0, 0);
     auto prefetch_window = [&](int wn) {
         lo = hi = 0;
         if (wn < a.n_win) {
-            const uint2 rng = a.win_range[wn];
+            const uint2 rng = rng_next;
             if (SEGS) { lo = rng.x << 2; hi = rng.y << 2; } else if (DREC) { lo = rng.x << 1; hi = rng.y << 1; } else { lo = rng.x >> RSH; hi = rng.y >> RSH; }
             if (lo < hi) { issue_one(0, lo); issue_one(1, lo); }        // the first half-round; the stream loop issues the rest
         }
     };
+    if (slot < a.n_win) rng_next = a.win_range[slot];
     prefetch_window(slot);
 
     for (int w = slot; w < a.n_win; w += grid) {
         const uint32_t w0 = (uint32_t)w * (uint32_t)W;
         const uint32_t cur_lo = lo, cur_hi = hi;
+        if (w + grid < a.n_win) rng_next = a.win_range[w + grid];
         const uint32_t dummy = 4u * (uint32_t)S + (uint32_t)(tid & 63);     // see the stream loop
 #ifdef ISX_TUNING
         uint32_t ablate_acc = 0;
 #endif
         {   // zero the window's counters
             uint4 *z = reinterpret_cast<uint4 *>(cnt);
-            for (int i = tid; i < S; i += nthr) z[i] = make_uint4(0, 0, 0, 0);     // 4 S words
-            if (DREC) {
-                uint4 *zq = reinterpret_cast<uint4 *>(queue), *zd = reinterpret_cast<uint4 *>(dlt);
-                for (int i = tid; i < (S >> 2); i += nthr) { zq[i] = make_uint4(0, 0, 0, 0); zd[i] = make_uint4(0, 0, 0, 0); }
+            const int nz = ((NR + (DREC ? 1 : 0)) * S) >> 2;        // the counter rows (+ the skipped-columns row behind them)
+            for (int i = tid; i < nz; i += nthr) z[i] = make_uint4(0, 0, 0, 0);
+            if (DREC && !PKL) {
+                uint4 *zd = reinterpret_cast<uint4 *>(dlt);
+                for (int i = tid; i < (S >> 2); i += nthr) zd[i] = make_uint4(0, 0, 0, 0);
             }
             if (linkage) {
                 uint4 *zm = reinterpret_cast<uint4 *>(maskl);
@@ -643,13 +663,18 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             }
             if (tid < S_N) scratch[tid] = 0;
         }
-        uint32_t ref4 = 0x04040404u;            // DREC: the reference codes of this thread's four positions of the materialise phase
-        if (DREC && 4 * tid < W) ref4 = ref4_at(a, w0 + 4u * (uint32_t)tid);
+        // DREC: the reference codes of this thread's four positions of the materialise phase (ref4); with packed rows the window's
+        // codes go to LDS here (coalesced word loads; read back after the stream's barrier by whichever thread owns a position)
+        uint32_t ref4 = 0x04040404u, ref4b = 0x04040404u;      // (loaded here, stored behind the stream loop: the latency hides there)
+        if (PKL) {
+            if (4 * tid < W) ref4 = ref4_at(a, w0 + 4u * (uint32_t)tid);
+            if (4 * (tid + nthr) < W) ref4b = ref4_at(a, w0 + 4u * (uint32_t)(tid + nthr));
+        } else if (DREC && 4 * tid < W) ref4 = ref4_at(a, w0 + 4u * (uint32_t)tid);
         uint8_t ref_raw[2];
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const uint32_t gp = w0 + tid + it * nthr;
-            ref_raw[it] = (tid + it * nthr < W && gp < a.n_pos) ? ref_at(a, gp) : (uint8_t)4;
+            ref_raw[it] = (!PKL && tid + it * nthr < W && gp < a.n_pos) ? ref_at(a, gp) : (uint8_t)4;
         }
         __syncthreads();
 
@@ -675,8 +700,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 if (!odd && len) {
                     const int32_t hi_c = s + (int32_t)len;
                     if (hi_c > 0 && s < W) {
-                        atomicAdd(&dlt[s < 0 ? 0 : s], 1u);
-                        if (hi_c < W) atomicAdd(&dlt[hi_c], 0xFFFFFFFFu);
+                        atomicAdd(&dlt[s < 0 ? 0 : s], PKL ? 0x00010000u : 1u);
+                        if (hi_c < W) atomicAdd(&dlt[hi_c], PKL ? 0xFFFF0000u : 0xFFFFFFFFu);
                     }
                 }
                 uint32_t sk[3] = {odd ? v[u].x : v[u].y, odd ? v[u].y : v[u].z, odd ? v[u].z : 0u};
@@ -700,7 +725,10 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 for (int f = 0; f < 3; f++) {
                     const uint32_t off = (ex >> (10 * f)) & 0xFFu, code = (ex >> (10 * f + 8)) & 3u;
                     const uint32_t rel = (uint32_t)(s + (int32_t)off);
-                    if (off < len && rel < uW) atomicAdd(&cnt[__umul24(code, (uint32_t)S) + rel], 1u);
+                    if (off < len && rel < uW) {
+                        if (PKL) atomicAdd(&cnt[__umul24(code >> 1, (uint32_t)S) + rel], 1u << (16 * (code & 1u)));
+                        else atomicAdd(&cnt[__umul24(code, (uint32_t)S) + rel], 1u);
+                    }
                 }
                 return;
             }
@@ -810,6 +838,14 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         // Two half-rounds in flight: slots 0,1 (loaded during the previous half / the previous window's epilogue) are
         // counted while slots 2,3 load, and slots 0,1 of the NEXT round load while 2,3 are counted.  Every slot is
         // loaded, then consumed, then reloaded in static program order: no register copies, the waits are vmcnt(2).
+        if (DREC) {
+            // reference-delta records: the stream is a fifth of the observation records' -- one half-round (two slots) in flight is
+            // enough, and the eight registers of the other one keep the kernel out of scratch memory
+            for (uint32_t i0 = lo; i0 < hi; i0 += 2 * nthr) {
+                count_slot(0); count_slot(1);
+                if (i0 + 2 * nthr < hi) { issue_one(0, i0 + 2 * nthr); issue_one(1, i0 + 2 * nthr); }
+            }
+        } else
         for (uint32_t i0 = lo; i0 < hi; i0 += 4 * nthr) {
             issue_one(2, i0); issue_one(3, i0);
             count_slot(0); count_slot(1);
@@ -819,13 +855,47 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
 #ifdef ISX_TUNING
         if (ablate_acc == 0xDEADBEEFu) cnt[dummy] = ablate_acc;             // keeps the ablated decode alive
 #endif
+        if (PKL) {                              // the window's reference codes, for whichever thread owns a position afterwards
+            if (4 * tid < W) reinterpret_cast<uint32_t *>(refl)[tid] = ref4;
+            if (4 * (tid + nthr) < W) reinterpret_cast<uint32_t *>(refl)[tid + nthr] = ref4b;
+        }
         __syncthreads();
 
         // first loads of the NEXT window go out before the epilogue (with linkage the registers
         // are needed by the allele pass first, so the prefetch follows it)
         if (!linkage) prefetch_window(w + grid);
 
-        if (DREC && !(dbg & 16)) {
+        if (PKL && !(dbg & 16)) {
+            // ---- materialise, packed rows: a thread owns PT consecutive positions (PT odd: a wave's 64 lanes then hit 64 different
+            //      LDS banks at every step) ----
+            const int lane = tid & 63;
+            const int PT = ((W + nthr - 1) / nthr) | 1, p0 = tid * PT;
+            int32_t sum = 0;
+            for (int k = 0; k < PT; k++) if (p0 + k < W) sum += (int32_t)dlt[p0 + k] >> 16;
+            int32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int32_t y = __shfl_up(inc, o);
+                if (lane >= o) inc += y;
+            }
+            if (lane == 63) wtot[tid >> 6] = (uint32_t)inc;
+            __syncthreads();
+            int32_t run = inc - sum;
+            for (int k = 0; k < (tid >> 6); k++) run += (int32_t)wtot[k];
+            for (int k = 0; k < PT; k++) {
+                const int p = p0 + k;
+                if (p >= W) break;
+                const uint32_t x = dlt[p], a01 = cnt[p], a23 = cnt[S + p];
+                run += (int32_t)x >> 16;
+                const uint32_t r = refl[p];
+                if (r < 4u) {
+                    const uint32_t v = (uint32_t)run - (x & 0xFFFFu) - ((a01 & 0xFFFFu) + (a01 >> 16) + (a23 & 0xFFFFu) + (a23 >> 16));
+                    cnt[(r >> 1) * S + p] = ((r >> 1) ? a23 : a01) + (v << (16 * (r & 1u)));
+                }
+            }
+            __syncthreads();
+        }
+        if (DREC && !PKL && !(dbg & 16)) {
             // ---- materialise: the reference base's count of every position from the coverage differences ----
             //   covered[p] = prefix sum of the difference row; observed[p] = covered[p] - skipped[p];
             //   count of the reference's base = observed[p] - sum of the exceptions counted at p
@@ -868,7 +938,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         for (int p = tid; p < ((dbg & 2) ? 0 : W); p += nthr, ep_it++) {
             const uint32_t gpos = w0 + p;
             if (gpos >= a.n_pos) break;
-            const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
+            uint32_t c[4];
+            ld4(p, c);
             const uint32_t total = c[0] + c[1] + c[2] + c[3];
 #ifdef ISX_TUNING       // ablations of the epilogue (tools/tune_reads.py)
             const bool st_ok = !(dbg & 128);    // 128: no global stores of the position-sized tables
@@ -889,7 +960,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             bool defer = false;
             uint32_t entry = (uint32_t)p;
             if ((int64_t)total >= (int64_t)a.min_cov && call_ok) {
-                const int ref_base = ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : ref_at(a, gpos));
+                const int ref_base = PKL ? (int)refl[p] : (ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : ref_at(a, gpos)));
 #ifdef ISX_TUNING
                 const SiteCall sc = (dbg & 1024) ? SiteCall{-1, 1, 0, 0} : call_level(a, thr_lds, c, total, ref_base, false);    // 1024: no SNV call
                 const uint32_t mx = (dbg & 2048) ? total : max(max(c[0], c[1]), max(c[2], c[3]));                               // 2048: every clonality 1.0
@@ -939,7 +1010,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 const uint32_t e = queue[q];
                 if (!(e & (1u << 13))) continue;
                 const int p = (int)(e & 0x1FFFu);
-                const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
+                uint32_t c[4];
+            ld4(p, c);
                 const float v = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
                 a.clon[w0 + p] = v;
                 if (list) a.clon_list[clon_base + atomicAdd(&scratch[S_CLON_RANK], 1u)] = make_uint2(w0 + p, __float_as_uint(v));
@@ -953,7 +1025,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 const uint32_t e = queue[q];
                 if (!(e & (1u << 15))) continue;
                 const int p = (int)(e & 0x1FFFu);
-                const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
+                uint32_t c[4];
+            ld4(p, c);
                 const float v = rarefied_clonality(a, c, w0 + p, 0);
                 a.clon_r[w0 + p] = v;
                 if (list) a.rare[rare_base + atomicAdd(&scratch[S_RARE_RANK], 1u)] = make_uint2(w0 + p, __float_as_uint(v));
@@ -974,9 +1047,10 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             const uint32_t my_row = atomicAdd(&scratch[S_ROW_RANK], 1u);
             const int p = (int)(e & 0x1FFFu);
             const uint32_t gpos = w0 + p;
-            const uint32_t c[4] = {cnt[p], cnt[S + p], cnt[2 * S + p], cnt[3 * S + p]};
+            uint32_t c[4];
+            ld4(p, c);
             const uint32_t total = c[0] + c[1] + c[2] + c[3];
-            const int ref_base = ref_at(a, gpos);
+            const int ref_base = PKL ? (int)refl[p] : (int)ref_at(a, gpos);
             const SiteCall sc = call_level(a, nullptr, c, total, ref_base, true);
             isx_snv r;
             r.gpos = gpos; r.mm = 0;
@@ -1373,7 +1447,8 @@ size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int pack
     size_t words, cnt_words;
     const int pad = segs == 64 ? ISX_SEG_PAD : ISX_DENSE_PAD;       // segs: 0 = observation records, 64 = segment records, 32 = reference-delta records
     if (dlt_off) *dlt_off = 0;
-    if (M == 1) { cnt_words = (size_t)4 * (W + pad); words = (size_t)5 * (W + pad) + S_N + THR_LDS / 2; }
+    const bool pkl = M == 1 && segs == 32 && packed;    // reference-delta records with 16-bit counters: two counter rows + the queue row
+    if (M == 1) { cnt_words = (size_t)(pkl ? 2 : 4) * (W + pad); words = cnt_words + (size_t)(W + pad) + S_N + THR_LDS / 2; }
     else {
         cnt_words = (size_t)M * (packed ? 2 : 4) * W;
         words = cnt_words + (size_t)((M + 31) / 32) * W + S_N + (size_t)qcap * 2 + (size_t)rqcap * 4 + THR_LDS / 2;
@@ -1390,9 +1465,9 @@ size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int pack
         }
     }
     if (segs == 32 && M == 1) {                 // the coverage-difference row + 16 per-wave totals of its prefix sum
-        bytes = (bytes + 15) & ~(size_t)15;
+        bytes = (bytes + 15) & ~(size_t)15;     // (packed: the differences live in the queue row; the totals + one reference code per position)
         if (dlt_off) *dlt_off = (int)(bytes / 4);
-        bytes += ((size_t)(W + pad) + 16) * 4;
+        bytes += pkl ? 16 * 4 + (((size_t)W + 15) & ~(size_t)15) : ((size_t)(W + pad) + 16) * 4;
     }
     return bytes;
 }
@@ -1434,6 +1509,7 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
     } else {
         const bool link = a.enable_linkage != 0;
         if (a.seg) { if (link) launch_one(k_pileup_dense<true, 64>, a, l); else launch_one(k_pileup_dense<false, 64>, a, l); return; }
+        if (a.drec && packed) { if (link) launch_one(k_pileup_dense<true, 32, true>, a, l); else launch_one(k_pileup_dense<false, 32, true>, a, l); return; }
         if (a.drec) { if (link) launch_one(k_pileup_dense<true, 32>, a, l); else launch_one(k_pileup_dense<false, 32>, a, l); return; }
 #ifndef ISX_NO_PK16
         if (a.rec16 && a.W <= ISX_PK16_MAX_W) { if (link) launch_one(k_pileup_dense<true, 2, true>, a, l); else launch_one(k_pileup_dense<false, 2, true>, a, l); }

@@ -156,6 +156,8 @@ struct isx_pipe {
     // repeated pass, linkage stages, row sorting -- so that this work overlaps the caller encoding the next batch
     std::thread finisher;
     std::thread finisher2;                  // depth >= 2: two batches are finished side by side (the work is host latency: syncs, small sorts)
+    std::vector<std::thread> more_finishers;    // depth >= 4: further ones, each with a queue of its own (extra_fin)
+    std::vector<hipStream_t> extra_fin;
     std::mutex bounce_mu;                   // the bounce buffers and fin_pool belong to one finisher at a time
     std::mutex mu;                          // slot states + the work queue
     std::condition_variable cv_work, cv_done;
@@ -224,12 +226,14 @@ static void pipe_free(isx_pipe *p)
         p->cv_work.notify_all();
         p->finisher.join();
         if (p->finisher2.joinable()) p->finisher2.join();
+        for (auto &t : p->more_finishers) if (t.joinable()) t.join();
     }
     (void)hipSetDevice(p->ctx->device);
     if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
     if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
     if (p->s_fin) (void)hipStreamSynchronize(p->s_fin);
     if (p->s_fin2) (void)hipStreamSynchronize(p->s_fin2);
+    for (hipStream_t st : p->extra_fin) (void)hipStreamSynchronize(st);
     for (int i = 0; i < 2; i++) if (p->ctx->pstream[i]) (void)hipStreamSynchronize(p->ctx->pstream[i]);
     const double t_f0 = now_ms();
     double t_batch = 0, t_dev = 0, t_pin = 0;
@@ -268,6 +272,7 @@ static void pipe_free(isx_pipe *p)
     if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     if (p->s_fin) (void)hipStreamDestroy(p->s_fin);
     if (p->s_fin2) (void)hipStreamDestroy(p->s_fin2);
+    for (hipStream_t st : p->extra_fin) (void)hipStreamDestroy(st);
     delete p;
 }
 
@@ -698,6 +703,19 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     }
     p->finisher = std::thread(finisher_main, p, p->s_fin);
     if (pp->depth >= 2) p->finisher2 = std::thread(finisher_main, p, p->s_fin2);
+    {
+        // a deep pipe whose copy-in no longer bounds the stream (reference-delta records halved it) is paced by how many batches
+        // are being finished at a time -- sizes, linkage chain, small sorts: chains of short kernels and host syncs
+        int want = pp->depth >= 4 ? 4 : 2;
+        if (const char *e = getenv("ISX_PIPE_FINISHERS")) want = std::max(1, atoi(e));
+        want = std::min(want, pp->depth);
+        for (int i = 2; i < want; i++) {
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+            p->extra_fin.push_back(st);
+            p->more_finishers.emplace_back(finisher_main, p, st);
+        }
+    }
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_create] thread pool %.1f ms, %d slot(s) %.1f ms\n", t_c1 - t_c0, pp->depth, now_ms() - t_c1);
     if (pp->stage_async && p->segs) p->stager = std::thread(stager_main, p);
@@ -1060,10 +1078,10 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     const uint64_t n_chunks = b->n_rec / p->G;
     b->packed = 0;
     int W = batch_window_for(b, n_pos, false);
-    if (!dense) {
+    if (!dense || p->drec) {
         const int Wp = batch_window_for(b, n_pos, true);
         if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-            build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win, p->G) < 65536) { b->packed = 1; W = Wp; }
+            build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win, p->G) < (dense ? 32768u : 65536u)) { b->packed = 1; W = Wp; }
     }
     if (!b->packed) build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, W, n_pos, s.win, p->G);
     b->W = W;
@@ -1223,10 +1241,10 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         std::vector<uint2> win;
         w->packed = 0;
         int W = batch_window_for(b0, n_pos, false);
-        if (M > 1) {
+        if (M > 1 || p->drec) {
             const int Wp = batch_window_for(b0, n_pos, true);
             if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, (uint32_t)G) < 65536) { w->packed = 1; W = Wp; }
+                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, (uint32_t)G) < (M == 1 ? 32768u : 65536u)) { w->packed = 1; W = Wp; }
         }
         if (!w->packed) build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win, (uint32_t)G);
         w->W = W;

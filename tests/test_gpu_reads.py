@@ -30,9 +30,10 @@ def _params(g):
 
 
 SEG64 = 8       # isx_params.layout: ISX_LAYOUT_SEG64_RECORDS (one mm bin: the 64-byte segment records instead of reference-delta records)
+NOPACK = 4      # ISX_LAYOUT_NO_PACKED_COUNTERS: reference-delta records with 32-bit LDS counters (the path of very deep batches)
 
 
-@pytest.mark.parametrize("how", ["stream", "reassembled", "stream64", "reassembled64"])
+@pytest.mark.parametrize("how", ["stream", "reassembled", "stream64", "reassembled64", "stream32u", "reassembled32u"])
 @pytest.mark.parametrize("name", CASES)
 def test_golden_vectors_as_read_segments(ctx, name, how):
     """every reference-generated vector as read segments: one mm bin -> 32-byte reference-delta records (difference-array
@@ -40,10 +41,10 @@ def test_golden_vectors_as_read_segments(ctx, name, how):
     from tests import prod
     g = util.load_case(name)
     kw = _params(g)
-    if how.endswith("64"):
+    if how.endswith("64") or how.endswith("32u"):
         if int(g["mm"].max()) > 0:
             pytest.skip("several mm bins: segment records either way")
-        how, kw = how[:-2], dict(kw, layout=SEG64)
+        how, kw = (how[:-2], dict(kw, layout=SEG64)) if how.endswith("64") else (how[:-3], dict(kw, layout=NOPACK))
     res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), reads=how, **kw)
     util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name + "/" + how)
     assert res["n_edges"] == int(g["n_edges"])
@@ -127,12 +128,12 @@ def test_randomized_sweep_reads_equal_observations(ctx):
         sa = a.sizes()
         a.close()
         for segs in (synth.segs_from_obs(obs, pr), util.reassemble_segs(pos, base, mm, pair)):
-            for layout in ((0, SEG64) if kw["n_mm_bins"] == 1 else (0,)):
+            for layout in ((0, NOPACK, SEG64) if kw["n_mm_bins"] == 1 else (0,)):
                 b = engine.Batch(ctx, ref, [0, mLen], segs, layout=layout, **kw)
                 b.run()
                 _tables_equal(ra, b.fetch(), "iteration %d %r layout %d" % (it, kw, layout))
                 assert b.sizes() == sa
-                assert b.timings()["record_bytes"] == (32 if kw["n_mm_bins"] == 1 and layout == 0 else 64)
+                assert b.timings()["record_bytes"] == (32 if kw["n_mm_bins"] == 1 and layout != SEG64 else 64)
                 b.close()
 
 
@@ -181,7 +182,7 @@ def test_segments_straddling_windows_and_far_jumps(ctx):
     ref = rng.integers(0, 4, n_pos, dtype=np.uint8)
     # (random bases against a random reference: three of four columns are exceptions -- a segment travels as ~20 delta records)
     for window in (64, 192, 1024, 0):
-        for layout in (0, SEG64):
+        for layout in (0, NOPACK, SEG64):
             bt = engine.Batch(ctx, ref, [0, 150_000, n_pos], segs, n_mm_bins=1, min_cov=5, enable_linkage=True, window=window, layout=layout)
             bt.run()
             c = bt.fetch()["counts"]
@@ -194,7 +195,7 @@ def _c2(scale=1.0, seed=2, skip_mm=True):
     return synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale), seed=seed, skip_mm=skip_mm)
 
 
-@pytest.mark.parametrize("skip_mm,linkage,layout", [(True, False, 0), (True, True, 0), (True, True, SEG64), (False, True, 0)])
+@pytest.mark.parametrize("skip_mm,linkage,layout", [(True, False, 0), (True, True, 0), (True, True, NOPACK), (True, True, SEG64), (False, True, 0)])
 def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage, layout):
     """a C2 slice through the read-level pipe == the same observations through a resident batch, every table"""
     from instrain_amd import engine, synth
@@ -211,7 +212,7 @@ def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage, layout):
     tickets = [pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs) for _ in range(2)]
     for t in tickets:
         r = pipe.collect(t)
-        assert r["stats"]["record_bytes"] == (32 if M == 1 and layout == 0 else 64)
+        assert r["stats"]["record_bytes"] == (32 if M == 1 and layout != SEG64 else 64)
         assert r["sizes"] == sa
         if M == 1:
             assert (r["counts"] == ra["counts"]).all()
@@ -298,11 +299,12 @@ def test_full_c2_reads_equal_observations(ctx):
     a.run()
     ra = a.fetch()
     a.close()
-    for layout in (0, SEG64):
+    for layout in (0, NOPACK, SEG64):
         b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], segs, n_mm_bins=1, enable_linkage=False, layout=layout)
         b.run()
         rb = b.fetch()
-        assert b.timings()["record_bytes"] == (64 if layout else 32)
+        assert b.timings()["record_bytes"] == (64 if layout == SEG64 else 32)
+        assert (b.timings()["pileup_window"] > 4096) == (layout == 0)          # 16-bit LDS counters: the wide window
         b.close()
         _tables_equal(ra, rb, "C2 layout %d" % layout)
         assert int(rb["counts"].sum()) == w["n_obs"]
