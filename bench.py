@@ -405,6 +405,13 @@ def resident_leg(ctx, w, window, steps=30):
     return out
 
 
+# C5 batches: genomes are packed into device batches under these budgets (the reference groups its profile commands by estimated
+# cost the same way, profile_controller.py:397-457).  A batch pays ~100 short kernel launches and a handful of host syncs in its
+# linkage / hand-back chain whatever its size, so batches are made as large as the pipe's slots comfortably hold.
+C5_BATCH_POS = int(os.environ.get("ISX_BENCH_C5_BATCH_POS", 80_000_000))
+C5_BATCH_SEGS = int(os.environ.get("ISX_BENCH_C5_BATCH_SEGS", 2_000_000))
+
+
 def _c5_plan(scale, host_threads):
     from instrain_amd import dist as idist
     from instrain_amd import synth
@@ -436,7 +443,7 @@ class C5Run:
         for sh in self.my_shards:
             mine = kept[self.shards[sh]]
             est = (meta.pairs[mine] * 2).astype(np.int64)          # segments: one per read
-            for b in idist.pack_batches(meta.length[mine], est, 40_000_000, 1_000_000):
+            for b in idist.pack_batches(meta.length[mine], est, C5_BATCH_POS, C5_BATCH_SEGS):
                 self.ws.append(meta.generate_segs(mine[b]))
         self.gen_s = time.perf_counter() - t0
         ws = self.ws
@@ -836,7 +843,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the C5 database / the C2 genome (debug only; reported in config)")
     ap.add_argument("--variants", type=int, default=32, help="distinct batches cycled through the C2 leg")
-    ap.add_argument("--depth", type=int, default=4, help="pipe slots")
+    ap.add_argument("--depth", type=int, default=8, help="pipe slots (batches in flight: copy-in, pass, copy-out and up to four finishing)")
     ap.add_argument("--host-threads", type=int, default=0, help="staging threads of the pipe (0 = the cpus this rank may use)")
     ap.add_argument("--queued-submit", action="store_true", help="submit_reads only queues the batch, the pipe's stager thread encodes it (isx_pipe_params.stage_async = 1; same-box A/B in profiles/r03_stream_ab.md: no gain on a 16-cpu cgroup)")
     ap.add_argument("--pin", action="store_true", help="bind the staging threads to the L3 domains of the GPU's NUMA node")
@@ -857,6 +864,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    import instrain_amd           # (sets GPU_MAX_HW_QUEUES before the HIP runtime comes up, see instrain_amd/__init__.py)
     import torch
     import torch.distributed as dist
     from instrain_amd import dist as idist

@@ -711,6 +711,9 @@ int isx_ctx_create(int device_id, isx_ctx **out)
 {
     if (!out) { isx_set_error("isx_ctx_create: out is NULL"); return ISX_ERR_ARG; }
     *out = nullptr;
+    // (a pipe drives a dozen streams at once; the runtime's default of 4 hardware queues serialises them -- see instrain_amd/__init__.py.
+    //  Honoured only when this is the process' first HIP call and the user has set nothing.)
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         isx_set_error("no HIP device visible: libinstrain_amd has no CPU fallback");
