@@ -211,6 +211,20 @@ int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts /* [n_pos][4] */, float
                           float *clon_rarefied /* [n_pos] */);
 int isx_batch_fetch_snv(isx_batch *b, isx_snv *out);
 int isx_batch_fetch_ld(isx_batch *b, isx_ld *out);
+/* The appends of update_linked_reads (linkage.py:254-283), isx_sizes.n_allele_obs rows in no particular order: read pair `pair`
+ * showed base `base` (in the site's `bases` set) at the SNP site at flat position gpos; `order` ranks the appends of one pair at one
+ * site (both mates visible at a column: the self pairs of linkage.py:26-30).  read_to_snvs[mm][read] of the reference is a pair's
+ * rows of level mm sorted by (gpos, order); mm_to_position_graph its itertools.combinations (profile_utilities.py:205-211: kept
+ * with --store_everything).  Needs enable_linkage; valid after isx_batch_run / isx_pipe_collect. */
+typedef struct {
+    uint32_t pair;
+    uint32_t gpos;
+    uint32_t order;
+    uint16_t mm;
+    uint8_t base;
+    uint8_t pad;
+} isx_allele_obs;
+int isx_batch_fetch_allele_obs(isx_batch *b, isx_allele_obs *out);
 
 /* ---- per-scaffold merge summaries (make_coverage_table, profile_utilities.py:425-506) ----
  * One row per (scaffold, mm level): the position-sized aggregates of the cumulative coverage over
@@ -599,6 +613,13 @@ int isx_bam_pair_keys(isx_bam *bam, uint64_t *h1, uint64_t *h2, int32_t *tid, in
 int isx_bam_set_cross_names(isx_bam *bam, int64_t n, const int64_t *entry, const int64_t *occurrences, const int64_t *info4);
 int isx_bam_filter_insert_sizes(isx_bam *bam, int64_t *out, int64_t cap, int64_t *n);
 int isx_bam_set_r2m(isx_bam *bam, int32_t ref, int64_t n, const char *names, const int64_t *offs, const int32_t *mm /* NULL = 0 */);
+/* pairs with more than `cap` mismatches are piled up at mm level `cap` from now on (the device bins 128 levels: a caller that meets a
+ * pair beyond that clamps and warns instead of failing the call); isx_bam_r2m still reports the true values */
+int isx_bam_set_mm_cap(isx_bam *bam, int32_t cap);
+/* names of the read pairs of the batch prepared last (isx_bam_expand_refs / isx_bam_segment_refs / isx_pipe_submit_bam) by dense pair
+ * id, i.e. by the ids isx_allele_obs.pair carries: names[offs[i] .. offs[i + 1]) (names / offs may be NULL to ask for the sizes).
+ * Only while the handle still has the names (no isx_bam_drop_names before the batch was prepared): --store_everything. */
+int isx_bam_batch_pair_names(const isx_bam *bam, int64_t *n, int64_t *name_bytes, char *names, int64_t *offs);
 /* the reference's Rdic[scaffold] as the filter left it (read pair -> mm, controller.py:274-281): sizes first (names NULL),
  * then names[name_bytes], offs[n + 1], mm[n] */
 int isx_bam_r2m(const isx_bam *bam, int32_t ref, int64_t *n, int64_t *name_bytes, char *names, int64_t *offs, int32_t *mm);

@@ -23,6 +23,8 @@ LD_DT = np.dtype([("gpos_a", "<u4"), ("gpos_b", "<u4"), ("mm", "<u2"), ("allele_
                   ("allele_B", "u1"), ("allele_b", "u1"), ("pad", "<u2"), ("total", "<u4"), ("countAB", "<u4"),
                   ("countAb", "<u4"), ("countaB", "<u4"), ("countab", "<u4"), ("pad2", "<u4"),
                   ("r2", "<f8"), ("d_prime", "<f8"), ("r2_normalized", "<f8"), ("d_prime_normalized", "<f8")])
+AO_DT = np.dtype([("pair", "<u4"), ("gpos", "<u4"), ("order", "<u4"), ("mm", "<u2"), ("base", "u1"), ("pad", "u1")])
+assert AO_DT.itemsize == 16
 assert OBS_DT.itemsize == 8 and ENTRY_DT.itemsize == 32 and SNV_DT.itemsize == 28 and LD_DT.itemsize == 72
 
 
@@ -126,11 +128,11 @@ class IsxError(RuntimeError):
 
 SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destroy", "isx_set_null_model",
            "isx_batch_create", "isx_batch_create_reads", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
-           "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld",
+           "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld", "isx_batch_fetch_allele_obs",
            "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
            "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_stage_reads", "isx_pipe_submit_wire", "isx_wire_bytes", "isx_wire_free", "isx_pipe_submit_bam", "isx_encode_segs", "isx_encode_segs_ring", "isx_seg_records_needed", "isx_encode_delta", "isx_delta_records_needed", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_pipe_fetch_entries_shrunk", "isx_encode_obs", "isx_encode_obs_ring",
            "isx_bam_open", "isx_bam_close", "isx_bam_close_wait", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
-           "isx_bam_insert_sizes", "isx_bam_set_wanted_refs", "isx_bam_pair_keys", "isx_bam_set_cross_names", "isx_bam_filter_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_ref_counts",
+           "isx_bam_insert_sizes", "isx_bam_set_wanted_refs", "isx_bam_pair_keys", "isx_bam_set_cross_names", "isx_bam_filter_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_batch_pair_names", "isx_bam_set_mm_cap", "isx_bam_ref_counts",
            "isx_bam_expand_refs", "isx_bam_segment_refs", "isx_bam_copy_segs", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
 
 _lib = None
@@ -177,7 +179,7 @@ def load():
     lib.isx_batch_wait.argtypes = [vp]
     lib.isx_batch_sizes.argtypes = [vp, C.POINTER(Sizes)]
     lib.isx_batch_timings.argtypes = [vp, C.POINTER(Timings)]
-    for f in ("isx_batch_fetch_entries", "isx_batch_fetch_snv", "isx_batch_fetch_ld"):
+    for f in ("isx_batch_fetch_entries", "isx_batch_fetch_snv", "isx_batch_fetch_ld", "isx_batch_fetch_allele_obs"):
         getattr(lib, f).argtypes = [vp, vp]
     lib.isx_batch_fetch_dense.argtypes = [vp, vp, vp, vp]
     lib.isx_batch_summarize.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_float)]
@@ -215,6 +217,8 @@ def load():
     lib.isx_bam_set_r2m.argtypes = [vp, i32, i64, C.c_char_p, vp, vp]
     lib.isx_bam_drop_names.argtypes = [vp]
     lib.isx_bam_r2m.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), vp, vp, vp]
+    lib.isx_bam_batch_pair_names.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), vp, vp]
+    lib.isx_bam_set_mm_cap.argtypes = [vp, i32]
     lib.isx_bam_ref_counts.argtypes = [vp, vp, vp]
     lib.isx_bam_expand_region.argtypes = [vp, C.POINTER(BamParams), i32, i64, i64, C.POINTER(BamInfo)]
     lib.isx_bam_expand_refs.argtypes = [vp, C.POINTER(BamParams), vp, i32, C.POINTER(BamInfo)]

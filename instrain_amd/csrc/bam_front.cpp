@@ -43,6 +43,7 @@
 #include <memory>
 #include <condition_variable>
 #include <mutex>
+#include <queue>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -520,6 +521,9 @@ struct isx_bam {
     std::vector<uvec<ReadLite>> dead_reads;
     std::vector<uvec<char>> dead_names;
     static constexpr size_t KEEP_DEAD = (size_t)2 << 30;
+    int32_t mm_cap = 0x7FFFFFFF;            // isx_bam_set_mm_cap: pairs with more mismatches are piled up at this level
+    std::vector<uint32_t> last_dense_pair;  // of the batch prepared last: dense pair id -> index into `pairs` (kept while the names are:
+                                            // isx_bam_batch_pair_names, the read_to_snvs keys of --store_everything)
     std::mutex retire_mu;
     std::condition_variable retire_cv;
     int batches_out = 0;            // batches bam_batch_prepare handed out that were neither retired nor freed yet (a pipe's finisher
@@ -1713,6 +1717,37 @@ int isx_bam_r2m(const isx_bam *bam, int32_t ref, int64_t *n, int64_t *name_bytes
     return ISX_OK;
 }
 
+// Pairs with more than `cap` mismatches are piled up at level `cap` (a device batch holds 128 mm levels; the reference bins any
+// mm, profile_utilities.py:268-286): the caller warns -- the alternative is to fail the whole call.  isx_bam_r2m keeps the true values.
+int isx_bam_set_mm_cap(isx_bam *bam, int32_t cap)
+{
+    if (!bam || cap < 0) { isx_set_error("isx_bam_set_mm_cap: bad argument"); return ISX_ERR_ARG; }
+    bam->mm_cap = cap;
+    return ISX_OK;
+}
+
+// names of the read pairs of the batch prepared LAST (isx_bam_expand_refs / isx_bam_segment_refs / isx_pipe_submit_bam), by dense pair
+// id -- the ids the device's tables (isx_ao.pair) carry.  Needs the names (no isx_bam_drop_names before the batch was prepared).
+int isx_bam_batch_pair_names(const isx_bam *bam, int64_t *n, int64_t *name_bytes, char *names, int64_t *offs)
+{
+    if (!bam || !n || !name_bytes) { isx_set_error("isx_bam_batch_pair_names: bad argument"); return ISX_ERR_ARG; }
+    const isx_bam &B = *bam;
+    if (B.seg_names.empty() && !B.last_dense_pair.empty()) { isx_set_error("isx_bam_batch_pair_names: the read names were dropped"); return ISX_ERR_STATE; }
+    int64_t nb = 0;
+    const int64_t k = (int64_t)B.last_dense_pair.size();
+    for (int64_t i = 0; i < k; i++) {
+        const PairInfo &e = B.pairs[B.last_dense_pair[(size_t)i]];
+        if (names && offs) {
+            offs[i] = nb;
+            memcpy(names + nb, B.seg_names[e.name_seg].data() + e.name_off, e.name_len);
+        }
+        nb += e.name_len;
+    }
+    if (names && offs) offs[k] = nb;
+    *n = k; *name_bytes = nb;
+    return ISX_OK;
+}
+
 // free the read names once no isx_bam_set_r2m / isx_bam_filter call will follow (they are the bulk of what the scan keeps)
 int isx_bam_drop_names(isx_bam *bam)
 {
@@ -1789,7 +1824,7 @@ struct BamBatch {
     {
         const Read &r = S.reads[ri];
         const PairInfo &pi = B->pairs[r.pair_idx];
-        const uint64_t hi = (uint64_t)(prm.skip_mm ? 0 : (uint16_t)pi.mm) << 32;
+        const uint64_t hi = (uint64_t)(prm.skip_mm ? 0 : (uint16_t)std::min<int32_t>(pi.mm, B->mm_cap)) << 32;
         const int64_t base_off = boff[(size_t)r.tid];
         const int64_t ref_len = B->ref_len[(size_t)r.tid];
         const uint8_t *ql = r.qual, *sq = r.seq;
@@ -1857,7 +1892,7 @@ struct BamBatch {
         for (; done < count; ri++) {
             if (seg_at[ri + 1] == seg_at[ri]) continue;
             const Read &r = S.reads[ri];
-            const uint8_t m = prm.skip_mm ? (uint8_t)0 : (uint8_t)std::min<int32_t>(255, B->pairs[r.pair_idx].mm);
+            const uint8_t m = prm.skip_mm ? (uint8_t)0 : (uint8_t)std::min<int32_t>(std::min<int32_t>(255, B->mm_cap), B->pairs[r.pair_idx].mm);
             const uint32_t id = pid[ri];
             for_segments(ri, [&](int64_t g, int64_t q0, int64_t cols) {
                 if (skip > 0) { skip--; return; }
@@ -2030,6 +2065,53 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     sw.clear();
     stage("load reads");
 
+    // ---- max_depth = 100000 of the pileup call (profile_utilities.py:150, polymorpher.py:290) as htslib 1.9 applies it
+    //      (bam_plp_push, sam.c): a read that starts exactly at the column the iterator stands on -- i.e. any read but the first
+    //      of a run of equal starts -- is not pushed while the buffer's node pool holds more than max_depth nodes (the buffered
+    //      reads, whose end lies at or beyond that start, + the list's sentinel).  Dropped reads take no part in the overlap
+    //      resolution and reach no column.  Only a position with >= 100000 reads over it can drop anything: a parallel screen
+    //      (reads starting within the longest read span of each start) decides whether the serial replay runs at all.
+    //      PARITY UNPINNED (no reference fixture is that deep; restated from the htslib-1.9 source, like oracle/bam_py.py).
+    {
+        constexpr int64_t MAX_DEPTH = 100000;
+        const size_t n_all = S.reads.size();
+        if (n_all > (size_t)MAX_DEPTH) {
+            const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n_all / 65536 + 1));
+            std::vector<int64_t> span_max((size_t)nt, 0);
+            pool.run(nt, [&](int t) {
+                int64_t m = 0;
+                for (size_t i = n_all * (size_t)t / (size_t)nt; i < n_all * (size_t)(t + 1) / (size_t)nt; i++) m = std::max(m, S.reads[i].ref_end - (int64_t)S.reads[i].pos);
+                span_max[(size_t)t] = m;
+            });
+            const int64_t L = std::max<int64_t>(1, *std::max_element(span_max.begin(), span_max.end()));
+            std::atomic<int> deep{0};
+            pool.run(nt, [&](int t) {           // reads of the same reference that start in (pos - L, pos]: an upper bound of the buffer there
+                const size_t a = n_all * (size_t)t / (size_t)nt, e = n_all * (size_t)(t + 1) / (size_t)nt;
+                size_t lo = a;
+                while (lo > 0 && S.reads[lo - 1].tid == S.reads[a].tid && (int64_t)S.reads[lo - 1].pos > (int64_t)S.reads[a].pos - L) lo--;
+                for (size_t i = a; i < e; i++) {
+                    while (S.reads[lo].tid != S.reads[i].tid || (int64_t)S.reads[lo].pos <= (int64_t)S.reads[i].pos - L) lo++;
+                    if ((int64_t)(i - lo + 1) >= MAX_DEPTH) { deep.store(1); return; }
+                }
+            });
+            if (deep.load()) {
+                std::priority_queue<int64_t, std::vector<int64_t>, std::greater<int64_t>> ends;
+                int32_t cur_tid = -1, prev_pos = -1;
+                int64_t n_drop = 0;
+                for (size_t i = 0; i < n_all; i++) {
+                    Read &r = S.reads[i];
+                    if (r.tid != cur_tid) { cur_tid = r.tid; prev_pos = -1; ends = decltype(ends)(); }
+                    while (!ends.empty() && ends.top() < (int64_t)r.pos) ends.pop();
+                    if (prev_pos == r.pos && (int64_t)ends.size() + 1 > MAX_DEPTH) { r.pair_idx = 0xFFFFFFFFu; r.flag |= FUNMAP; n_drop++; continue; }
+                    prev_pos = r.pos;
+                    ends.push(r.ref_end);
+                }
+                (void)n_drop;
+            }
+            stage("max_depth");
+        }
+    }
+
     // ---- overlap_push in file order (htslib-1.9 rule |isize| < 2*l_qseq), partitioned by pair: a pair's two reads
     //      only ever touch each other's qualities ----
     const size_t n_reads = S.reads.size();
@@ -2132,13 +2214,16 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     }
     for (int t = 0; t < n_tasks; t++) { firsts[(size_t)t + 1] += firsts[(size_t)t]; outs[(size_t)t + 1] += outs[(size_t)t]; }
     Q->next_pair = firsts[(size_t)n_tasks];
+    const bool keep_names = !B.seg_names.empty();           // (isx_bam_drop_names not called: somebody wants the names of the pair ids)
+    bam->last_dense_pair.assign(keep_names ? (size_t)Q->next_pair : 0, 0u);
+    uint32_t *dpair = bam->last_dense_pair.data();
     pool.run(n_tasks, [&](int t) {
         uint32_t nf = firsts[(size_t)t];
         uint64_t at = outs[(size_t)t];
         for (size_t ri = lo_of(t); ri < lo_of(t + 1); ri++) {
             if (q->emit[ri]) {
                 const size_t sl = slot_of(S.reads[ri]);
-                if (first[sl] == (uint32_t)ri) dense[sl] = nf++;
+                if (first[sl] == (uint32_t)ri) { if (keep_names) dpair[nf] = S.reads[ri].pair_idx; dense[sl] = nf++; }
             }
             at += q->out_at[ri + 1];
             q->out_at[ri + 1] = at;

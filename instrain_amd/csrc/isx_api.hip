@@ -1409,6 +1409,25 @@ int isx_batch_fetch_snv(isx_batch *b, isx_snv *out)
     return ISX_OK;
 }
 
+// update_linked_reads' appends (linkage.py:254-283) as the device holds them after the linkage stages: one row per (read pair,
+// SNP site, base in the site's `bases` set) -- what read_to_snvs / mm_to_position_graph of --store_everything are made of
+int isx_batch_fetch_allele_obs(isx_batch *b, isx_allele_obs *out)
+{
+    NEED_RUN(b, out);
+    const size_t n = (size_t)b->sizes.n_allele_obs, n_sites = (size_t)b->sizes.n_sites;
+    if (!n) return ISX_OK;
+    if (!b->prm.enable_linkage || !b->d_ao || !b->L.site_gpos.p) { isx_set_error("isx_batch_fetch_allele_obs: the batch was profiled without linkage"); return ISX_ERR_STATE; }
+    static_assert(sizeof(isx_allele_obs) == sizeof(isx_ao), "isx_allele_obs mirrors isx_ao");
+    std::vector<uint32_t> gpos(n_sites);
+    HIP_TRY(hipMemcpy(out, b->d_ao, n * sizeof(isx_ao), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(gpos.data(), b->L.site_gpos.p, n_sites * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {                // the linkage stages left the site's RANK in the row (k_ao_rank): back to its position
+        if (out[i].gpos >= n_sites) { isx_set_error("internal: allele observation with a site rank beyond the site table"); return ISX_ERR_STATE; }
+        out[i].gpos = gpos[out[i].gpos];
+    }
+    return ISX_OK;
+}
+
 int isx_batch_fetch_ld(isx_batch *b, isx_ld *out)
 {
     NEED_RUN(b, out);

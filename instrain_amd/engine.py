@@ -217,6 +217,13 @@ class Batch:
         out["ld"] = l[:s["n_ld"]]
         return out
 
+    def fetch_allele_obs(self):
+        """update_linked_reads' appends (isx_batch_fetch_allele_obs) -> structured array (pair, gpos, order, mm, base)"""
+        n = int(self.sizes()["n_allele_obs"])
+        out = np.empty(max(1, n), dtype=_lib.AO_DT)
+        check(self.lib.isx_batch_fetch_allele_obs(self.h, out.ctypes.data))
+        return out[:n]
+
     def summarize(self, scaffold_bounds):
         """per-(scaffold, mm) aggregates of make_coverage_table -> (structured array [n_scaffolds, n_mm_bins], device ms)"""
         sb = np.ascontiguousarray(scaffold_bounds, dtype=np.int64)
@@ -739,6 +746,21 @@ class BamFile:
         check(self.lib.isx_bam_r2m(self.h, int(ref), C.byref(n), C.byref(nb), names, offs.ctypes.data, mm.ctypes.data))
         raw = names.raw
         return {raw[offs[i]:offs[i + 1]].decode(): int(mm[i]) for i in range(n.value)}
+
+    def set_mm_cap(self, cap):
+        """pairs with more than `cap` mismatches are piled up at level `cap` (isx_bam_set_mm_cap)"""
+        check(self.lib.isx_bam_set_mm_cap(self.h, int(cap)))
+
+    def batch_pair_names(self):
+        """names of the read pairs of the batch prepared last (expand_refs / segment_refs / Pipe.submit_bam), indexed by the dense
+        pair id the device's tables carry (isx_bam_batch_pair_names); needs the names (no drop_names() before)"""
+        n, nb = C.c_int64(0), C.c_int64(0)
+        check(self.lib.isx_bam_batch_pair_names(self.h, C.byref(n), C.byref(nb), None, None))
+        names = C.create_string_buffer(max(1, nb.value))
+        offs = np.zeros(n.value + 1, dtype=np.int64)
+        check(self.lib.isx_bam_batch_pair_names(self.h, C.byref(n), C.byref(nb), names, offs.ctypes.data))
+        raw = names.raw
+        return [raw[offs[i]:offs[i + 1]].decode() for i in range(n.value)]
 
     def drop_names(self):
         check(self.lib.isx_bam_drop_names(self.h))

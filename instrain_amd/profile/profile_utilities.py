@@ -12,6 +12,7 @@ profile_bam keeps the reference's contract (profile/__init__.py:7-18):
     reference's "SplitException" line and dropped -- the others go on (profile_utilities.py:100-111, 154-156).
 """
 import logging
+import os
 import time
 import traceback
 
@@ -112,6 +113,15 @@ class _BatchTables:
             else:                                   # a deep sample: the dense array, cut per split when somebody asks
                 self.clon_r = _own(res["clon_r"])
         self.pileup_counts = _own(res["counts"]) if "counts" in res and self.entries is None and self.soa is None else None
+        if self.pileup_counts is None and self.entries is not None and res.get("allele_obs") is not None:
+            # --store_everything with mm profiling on: pileup_counts[pos] = the counts over ALL mm levels (profile_utilities.py:257-259)
+            pc = np.zeros((int(self.bounds[-1]), 4), dtype=np.int64)
+            np.add.at(pc, self.entries["gpos"].astype(np.int64), self.entries["cnt"].astype(np.int64))
+            self.pileup_counts = pc
+        # --store_everything: update_linked_reads' appends as the device holds them (read_to_snvs / mm_to_position_graph are
+        # made from them per split, profile/linkage.py); pair_names: the batch's dense pair id -> read-pair name
+        self.ao = res.get("allele_obs")
+        self.pair_names = res.get("pair_names")
 
     # -- shrink_basewise (profile_utilities.py:337-350): dict mm -> sparse Series; a level that occurs in the split keeps
     #    its key even when its Series is empty (the reference deletes nothing but zeros / NaNs) --
@@ -212,7 +222,7 @@ class SplitObject():
     '''Holds the profile of an individual split (same attributes as the reference's SplitObject,
     profile_utilities.py:823-858).  covT / clonT / clonTR / raw_snp_table / raw_linkage_table are cut out of the
     batch's tables the first time they are read.'''
-    _LAZY = ('covT', 'clonT', 'clonTR', 'raw_snp_table', 'raw_linkage_table', 'pileup_counts')
+    _LAZY = ('covT', 'clonT', 'clonTR', 'raw_snp_table', 'raw_linkage_table', 'pileup_counts', 'read_to_snvs', 'mm_to_position_graph')
 
     def __init__(self):
         pass
@@ -232,6 +242,12 @@ class SplitObject():
             if tables.pileup_counts is None:
                 raise AttributeError(name)
             self.pileup_counts = tables.pileup_counts[int(tables.bounds[i]):int(tables.bounds[i + 1])].astype(np.int64)
+        elif name in ('read_to_snvs', 'mm_to_position_graph'):      # --store_everything (profile_utilities.py:205-211)
+            if tables.ao is None:
+                raise AttributeError(name)
+            from . import linkage
+            self.read_to_snvs = linkage.read_to_snvs_of_split(tables.ao, int(tables.bounds[i]), int(tables.bounds[i + 1]), tables.pair_names)
+            self.mm_to_position_graph = linkage.calc_mm_SNV_linkage_network(self.read_to_snvs, scaff=self.scaffold)
         return self.__dict__[name]
 
     def materialize(self):
@@ -241,6 +257,8 @@ class SplitObject():
         src = self.__dict__.get('_src')
         if src is not None and src[0].pileup_counts is not None:
             getattr(self, 'pileup_counts')
+        if src is not None and src[0].ao is not None:
+            getattr(self, 'read_to_snvs')
         self.__dict__.pop('_src', None)
         return self
 
@@ -267,7 +285,7 @@ class SplitObject():
             setattr(Sprofile, att, getattr(self, att))
         Sprofile.null_model = ScaffoldSplitObject.null_model
         for att in SplitObject._OPTIONAL_FIELDS:
-            if att in self.__dict__ or (att == 'pileup_counts' and hasattr(self, att)):
+            if att in self.__dict__ or (att in ('pileup_counts', 'read_to_snvs', 'mm_to_position_graph') and hasattr(self, att)):
                 setattr(Sprofile, att, getattr(self, att))
         for att in SplitObject._PARENT_FIELDS:
             if hasattr(ScaffoldSplitObject, att):
@@ -473,11 +491,35 @@ def make_coverage_table(levels, lengt, scaff, SNPTable):
     return pd.DataFrame(table, columns=COVERAGE_COLUMNS)
 
 
+def get_worker_log(worker_type, unit, status, when=None, mem=None):
+    """logUtils.get_worker_log (logUtils.py:939-975): "\nWorkerLog worker_type unit status RAM time PID" -- the line
+    profile_controller.py:288-289 collects from SplitObject.log and the log parser reads (linewords[0..6]).  `when`: the time
+    stamp to report (a device batch profiles all its splits at once: they share the batch's start / end)."""
+    assert status in ['start', 'end'], status
+    if mem is None:
+        mem = _rss()
+    return "\nWorkerLog {0} {1} {2} {3} {4} {5}".format(worker_type, unit, status, mem, time.time() if when is None else when, os.getpid())
+
+
+def _rss():
+    try:
+        import psutil
+        return psutil.Process(os.getpid()).memory_info().rss
+    except Exception:
+        try:
+            return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+        except Exception:
+            return 0
+
+
 def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_offset, split_seq_len, min_freq,
-                     bam_name=None, min_cov=5):
-    """Batch result (engine.Batch.fetch() / Pipe.collect()) -> list of SplitObject, one per split, in split order."""
+                     bam_name=None, min_cov=5, started=None):
+    """Batch result (engine.Batch.fetch() / Pipe.collect()) -> list of SplitObject, one per split, in split order.
+    started: time.time() when the batch's profiling began (the start stamp of every split's worker log)."""
     tables = _BatchTables(res, split_bounds, split_scaffold, scaffold_offset, min_cov)
     out = []
+    t_end, mem = time.time(), _rss()
+    t_start = t_end if started is None else started
     for i in range(len(split_bounds) - 1):
         S = SplitObject()
         S.scaffold = split_scaffold[i]
@@ -485,7 +527,8 @@ def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_o
         S.bam = bam_name
         S.length = int(split_seq_len[i])
         S.min_freq = min_freq
-        S.log = ""
+        unit = "{0}.{1}".format(S.scaffold, S.split_number)    # profile_utilities.py:133-134, 212-214
+        S.log = get_worker_log('SplitProfile', unit, 'start', t_start, mem) + get_worker_log('SplitProfile', unit, 'end', t_end, mem)
         S._src = (tables, i)
         out.append(S)
     return out
@@ -517,16 +560,20 @@ def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, 
     b = engine.Batch(ctx, ref, bounds, obs, pair, min_cov=min_cov, min_freq=min_freq, min_snp=min_snp,
                      rarefied_coverage=int(kwargs.get('rarefied_coverage', 5)), n_mm_bins=n_mm_bins,
                      enable_linkage=True, seed=int(kwargs.get('seed', 0)))
+    t_started = time.time()
     try:
         b.run()
         res = b.fetch()
+        if kwargs.get('store_everything'):          # read_to_snvs / mm_to_position_graph are made from these (profile/linkage.py)
+            res["allele_obs"] = b.fetch_allele_obs()
+            res["pair_names"] = kwargs.get('pair_names')
         levels = None
         if kwargs.get('scaffold_tables') is not None:   # only the merge step's cumulative tables need the device summaries
             scaff_bounds = np.r_[0, np.cumsum([len(q) for q in sequences])]
             levels, _ = b.summarize(scaff_bounds)
     finally:
         b.close()
-    splits = tables_to_splits(res, np.asarray(bounds), s_scaff, s_num, s_off, s_len, min_freq, bam_name)
+    splits = tables_to_splits(res, np.asarray(bounds), s_scaff, s_num, s_off, s_len, min_freq, bam_name, started=t_started)
     out = {"{0}.{1}".format(S.scaffold, S.split_number): S for S in splits}
     if kwargs.get('scaffold_tables') is not None:       # cumulative_scaffold_table per scaffold (merge step)
         for i, name in enumerate(scaffolds):
@@ -578,7 +625,7 @@ def plan_scaffolds(fasta_db, wanted_lengths, window_length):
 
 class _Group:
     """one device batch of whole scaffolds: its flat layout"""
-    __slots__ = ("items", "tids", "bounds", "s_scaff", "s_num", "s_off", "s_len", "ref", "n_pos", "first_split", "ticket", "est_segs")
+    __slots__ = ("items", "tids", "bounds", "s_scaff", "s_num", "s_off", "s_len", "ref", "n_pos", "first_split", "ticket", "est_segs", "t_submit", "pair_names")
 
 
 def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
@@ -688,10 +735,16 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             bf.scan(part=kwargs.get('scan_part'))    # refresh the totals (max_mm now comes from the controller's values)
         n_mm = 1 if skip_mm else int(bf.info["max_mm"]) + 1
         if n_mm > 128:
-            raise ValueError("a read pair with {0} mismatches: more than the 128 mm levels a device batch holds "
-                             "(profile with --skip_mm_profiling or a higher --min_read_ani)".format(n_mm - 1))
+            # the reference bins any mm (profile_utilities.py:268-286); a device batch holds 128 levels.  Rather than failing the
+            # whole call, pairs beyond level 127 are piled up AT level 127 (their bases then appear one level early in the
+            # cumulative tables of the levels >= 127 only) -- loudly
+            logging.warning("a read pair with {0} mismatches: the device bins mm levels 0..127, pairs beyond are counted at level 127 "
+                            "(--skip_mm_profiling or a higher --min_read_ani avoids this)".format(n_mm - 1))
+            bf.set_mm_cap(127)
+            n_mm = 128
         reads_per_ref, pairs_per_ref = bf.ref_counts()
-        bf.drop_names()
+        if not store_everything:                    # (--store_everything keys read_to_snvs by read name: the names stay)
+            bf.drop_names()
         stage("filter_ms")
         # ---- batches of whole scaffolds under a position / read budget; the reference groups its commands by estimated
         #      cost the same way (profile_controller.py:436-457) ----
@@ -743,6 +796,9 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             """the front end's pass 2 for the group's scaffolds + hand-over; returns False when the pipe is too small"""
             try:
                 g.ticket = pipe.submit_bam(bf, g.tids, g.ref, g.bounds, **ekw)
+                g.t_submit = time.time()
+                if store_everything:
+                    g.pair_names = bf.batch_pair_names()
                 return True
             except engine.IsxError as e:
                 if e.code != -3:
@@ -755,8 +811,11 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             try:
                 res = pipe.collect(t, rare_list=False, densify=False, shrunk_entries=not store_everything)
                 stage("collect_wait_ms")
+                if store_everything:                # read_to_snvs / mm_to_position_graph of the splits are made from these
+                    res["allele_obs"] = res["slot"].fetch_allele_obs()
+                    res["pair_names"] = getattr(g, 'pair_names', None)
                 splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam,
-                                          min_cov=int(kwargs.get('min_cov', 5)))
+                                          min_cov=int(kwargs.get('min_cov', 5)), started=getattr(g, 't_submit', None))
                 if kwargs.get('scaffold_tables') is not None or kwargs.get('scaffold_levels') is not None:
                     sb = np.r_[0, np.cumsum([refs[tid][1] for tid in g.tids])]
                     levels, _ = res["slot"].summarize(sb)
@@ -853,6 +912,11 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             drain_one()
         return out
     except Exception as e:
+        # a failure of the call as a whole (unreadable BAM, a pair beyond the 128 mm levels a device batch holds, a device fault):
+        # the reference's convention is per split (profile_utilities.py:104-111) -- with strict=True the caller gets the exception
+        # itself instead of a partial dict and one log line, so "the call failed" cannot be mistaken for "no reads"
+        if kwargs.get('strict'):
+            raise
         print(e)
         traceback.print_exc()
         t = time.strftime('%m-%d %H:%M')

@@ -44,7 +44,7 @@ CM, CI, CD, CN, CS, CH, CP, CEQ, CX = range(9)
 
 class Read:
     __slots__ = ("name", "tid", "pos", "mapq", "flag", "isize", "cigar", "seq", "qual",
-                 "nm", "l_qseq")
+                 "nm", "l_qseq", "dropped")
 
     def ref_positions(self):
         """pysam get_reference_positions(): ref positions of M/=/X bases."""
@@ -333,13 +333,51 @@ def tweak_overlap_quality(a, b):
             aq[ca.iseq] = 0
 
 
+def apply_max_depth(reads, tid, max_depth=100000):
+    """max_depth of the pileup call (profile_utilities.py:150; polymorpher.py:290), as htslib 1.9 applies it in bam_plp_push
+    (sam.c): a read is NOT pushed into the pileup buffer when
+        iter->tid == b->core.tid && iter->pos == b->core.pos && iter->mp->cnt > iter->maxcnt
+    i.e. when it starts exactly at the column the iterator stands on while the buffer's node pool holds more than max_depth
+    nodes (the buffered reads + the list's sentinel tail).  The iterator stands on a read's start only once an EARLIER read with
+    the same start has been pushed (bam_plp_auto emits every column before that start first), so the first read of a
+    same-start run is always taken; the buffer then holds the accepted reads whose end lies beyond the last emitted column
+    (end >= start; bam_plp_next frees a node at column p when end <= p).  Dropped reads never reach overlap_push
+    (overlap_remove) nor any column.  Reads the flag mask removes are never pushed and do not count.
+    PARITY UNPINNED: no fixture of the reference exercises a column deeper than 100 000 (pysam is not in this image); this follows
+    the published htslib-1.9 source.  Marks r.dropped on the reads of `tid`; returns how many were dropped."""
+    import heapq
+    ends = []                       # min-heap of the end positions of the buffered reads
+    n_drop = 0
+    prev_pos = None
+    for r in reads:
+        if r.tid != tid or (r.flag & DEF_MASK):
+            continue
+        r.dropped = False
+        while ends and ends[0] < r.pos:         # columns up to pos - 1 have been emitted: nodes with end <= pos - 1 are gone
+            heapq.heappop(ends)
+        if prev_pos == r.pos and len(ends) + 1 > max_depth:
+            r.dropped = True
+            n_drop += 1
+            continue
+        prev_pos = r.pos
+        heapq.heappush(ends, r.end_pos())
+    return n_drop
+
+
+def _is_dropped(r):
+    try:
+        return r.dropped
+    except AttributeError:
+        return False
+
+
 def resolve_overlaps(reads, tid):
     """Apply overlap_push in file order to the reads of one reference (mutates qual).
     The hash entry of a read that has left the pileup buffer before its mate arrives is
     dropped (overlap_remove); then the mate is entered as a fresh first-seen read."""
     H = {}
     for r in reads:
-        if r.tid != tid or (r.flag & DEF_MASK):
+        if r.tid != tid or (r.flag & DEF_MASK) or _is_dropped(r):
             continue
         if (r.flag & FMUNMAP) or not (r.flag & FPROPER_PAIR):
             continue
@@ -363,7 +401,7 @@ def expand_observations(reads, tid, r2m, min_base_quality=30, skip_mm=False, ref
     name2id = {}
     P, B, M, R = [], [], [], []
     for r in reads:
-        if r.tid != tid or (r.flag & DEF_MASK):
+        if r.tid != tid or (r.flag & DEF_MASK) or _is_dropped(r):
             continue
         if r.name not in r2m:
             continue

@@ -108,7 +108,7 @@ def columns_from_obs(pos, base, pair_names):
 
 
 def run_reference_split(mods, scaffold, seq, start, pos, base, mm, pair, nm, skip_mm=False,
-                        min_cov=5, min_freq=0.05, min_snp=20, rarefied_coverage=50):
+                        min_cov=5, min_freq=0.05, min_snp=20, rarefied_coverage=50, extras=None):
     """The body of profile_split (profile_utilities.py:158-192) on duck-typed columns."""
     pu, su, lk, fa = mods
     names = ["r%d" % p for p in pair]
@@ -134,6 +134,8 @@ def run_reference_split(mods, scaffold, seq, start, pos, base, mm, pair, nm, ski
     if len(S) > 0:
         S["position"] = S["position"] + start
     G = lk.calc_mm_SNV_linkage_network(read_to_snvs, scaff=scaffold)
+    if extras is not None:          # the --store_everything extras (profile_utilities.py:205-211) as the reference built them
+        extras["read_to_snvs"], extras["mm_to_position_graph"] = read_to_snvs, G
     L = lk.calculate_ld(G, min_snp, snv2mm2counts=snv2mm2counts, scaffold=scaffold)
     if len(L) > 0:
         for p in ["position_A", "position_B"]:
@@ -266,6 +268,9 @@ SYNTH = {
 }
 
 
+EXTRAS = ("synth_mm4", "synth_m1", "synth_skipmm", "synth_selfpairs", "synth_offset", "synth_ambig")
+
+
 def main():
     mods = import_reference()
     pu, su, lk, fa = mods
@@ -288,19 +293,29 @@ def main():
     np.save(os.path.join(HERE, "iterate_splits.npy"), np.array(rows, dtype=np.int64))
 
     # synthetic splits through the reference's own functions
+    from instrain_amd.profile import linkage as our_linkage      # (only its flatten(): the canonical array form of the two objects)
+    extras_out = {}
     for name, kw in SYNTH.items():
         kw = dict(kw)
         skip_mm = kw.pop("skip_mm", False)
         params = dict(min_cov=kw.pop("min_cov", 5), min_freq=kw.pop("min_freq", 0.05), min_snp=kw.pop("min_snp", 20))
         start = kw.get("start", 0)
         seq, pos, base, mm, pair = synth_case(**kw)
+        ex = {} if name in EXTRAS else None
         covT, clonT, S, L, ne = run_reference_split(mods, "scaf", seq, start, pos, base, mm, pair, nm,
-                                                    skip_mm=skip_mm, **params)
+                                                    skip_mm=skip_mm, extras=ex, **params)
+        if ex is not None:
+            rts, gr = our_linkage.flatten(ex["read_to_snvs"], ex["mm_to_position_graph"], name_to_id=lambda n: int(n[1:]))
+            extras_out[name + "_rts"], extras_out[name + "_graph"] = rts, gr
+            print(name, "read_to_snvs entries", len(rts), "graph combos", len(gr))
         exp = pack_expected(covT, clonT, S, L, ne)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), seq=np.array(seq), start=np.array(start),
                             pos=pos.astype(np.int32), base=base, mm=(mm * (0 if skip_mm else 1)).astype(np.int32),
                             pair=pair.astype(np.int32), **{"p_" + k: np.array(v) for k, v in params.items()}, **exp)
         print(name, "obs", len(pos), "snv rows", len(S), "ld rows", len(L), "edges", ne)
+
+    # read_to_snvs / mm_to_position_graph of a few cases, flattened (store_everything extras)
+    np.savez_compressed(os.path.join(HERE, "linkage_extras.npz"), **extras_out)
 
     # ---- one split of the bench's C3 generator (configs[2]: 200x, 1 SNV site / 100 bp, one mm bin) ----
     if "--skip-c3" not in sys.argv:

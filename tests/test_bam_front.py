@@ -507,3 +507,49 @@ def test_cigar_in_the_cg_tag_reads_like_the_cigar_itself(tmp_path):
     assert s0[0].n_seg == s1[0].n_seg > 1000
     for f in ("gpos", "len", "mm", "pair", "bases"):
         assert (getattr(s0[0], f) == getattr(s1[0], f)).all(), f
+
+
+def test_max_depth_of_the_pileup_call(tmp_path):
+    """max_depth=100000 (profile_utilities.py:150) as htslib 1.9 applies it: of a run of reads with the SAME start, those pushed
+    while the pileup buffer already holds 100 000 reads are dropped -- here a pile of 100 050 reads starting at one position over 5
+    older reads that still cover it: 99 995 of the pile are taken, the column is exactly 100 000 deep.  PARITY UNPINNED: the
+    reference holds no fixture this deep (and pysam is not in this image); the C++ front end is checked against the oracle's
+    restatement of the published htslib rule and against the arithmetic above."""
+    from oracle import bam_py
+    from tests import bamwriter
+    refs = [("deep", 2000)]
+    L = 20
+    q = np.full(L, 37, np.uint8)
+    reads = []
+
+    def pair(name, s1, s2):
+        for mate, (s, ms) in enumerate(((s1, s2), (s2, s1))):
+            reads.append(dict(tid=0, pos=s, mapq=40, flag=0x1 | 0x2 | (0x40 if mate == 0 else 0x80) | (0x20 if mate == 0 else 0x10),
+                              isize=(s2 + L - s1) * (1 if mate == 0 else -1), name=name, cigar=[("M", L)], seq="ACGT" * (L // 4), qual=q, nm=0,
+                              mtid=0, mpos=ms))
+    for i in range(5):
+        pair("old%d" % i, 485 + i, 1100 + i)                    # cover 485 .. 508: still buffered when the pile arrives
+    N = 100_050
+    for i in range(N):
+        pair("pile%d" % i, 500, 1200)
+    for i in range(20):
+        pair("next%d" % i, 501, 1300 + i)
+    reads.sort(key=lambda r: r["pos"])                          # stable: file order inside a start = creation order
+    path = str(tmp_path / "deep.bam")
+    bamwriter.write_bam(path, refs, reads)
+    bam = engine.BamFile(path)
+    obs, pair_id, bounds, sref = bam.expand(min_read_ani=0.9, window_length=10000)
+    bam.close()
+    cov = np.bincount(obs["gpos"], minlength=2000)
+    assert cov[500] == 100_000 and cov[499] == 5 and cov[484] == 0           # 5 older + 99 995 of the pile
+    # the 20 reads starting at 501 arrive while the pile is still buffered: the first of the run is always pushed (the iterator
+    # does not stand on 501 yet), the other 19 meet a full buffer
+    assert cov[519] == 99_995 + 1 and cov[520] == 1
+    assert cov[1200] == 100_000 and cov[1219] == 100_000                     # the mates: a run of 100 050 over an empty buffer
+    # the oracle's restatement, observation for observation
+    rrefs, rr = bam_py.read_bam(path)
+    r2m, _ = bam_py.filter_pairs({"deep": bam_py.get_paired_reads(rr, 0)}, min_read_ani=0.9)
+    assert bam_py.apply_max_depth(rr, 0) == (N - 99_995) + 19 + (N - 100_000)
+    bam_py.resolve_overlaps(rr, 0)
+    pos, base, mm, pr, _ = bam_py.expand_observations(rr, 0, r2m["deep"], ref_len=2000)
+    assert len(pos) == len(obs) and (obs["gpos"] == pos).all() and (obs["base"] == base).all() and (pair_id == pr).all()

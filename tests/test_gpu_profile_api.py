@@ -663,3 +663,115 @@ def test_genome_level_rollup_vs_oracle(mm_levels):
         for k in ("coverage_SEM", "coverage_std"):
             assert (np.isnan(r[k]) and np.isnan(e[k])) or abs(r[k] - e[k]) <= 1e-9 * max(1.0, abs(e[k])), (k, dict(r), e)
     assert lv["n"][0, 0] == (5200 - 200) + 0 + (2600 - 200) and lv["n"][1, 0] == (300_000 - 200) + (900 - 200)
+
+
+EXTRA_CASES = ["synth_mm4", "synth_m1", "synth_skipmm", "synth_selfpairs", "synth_offset", "synth_ambig"]
+
+
+@pytest.mark.parametrize("reads", [None, "reassembled"])
+@pytest.mark.parametrize("name", EXTRA_CASES)
+def test_store_everything_extras_equal_the_references(name, reads):
+    """read_to_snvs (update_linked_reads, linkage.py:254-283) and mm_to_position_graph (calc_mm_SNV_linkage_network, :14-44) rebuilt
+    from the device's allele observations == the objects the reference itself built on the same split
+    (tests/golden/linkage_extras.npz, written by make_golden.py from the imported reference): every read's list entry for entry,
+    every edge's mm / allele-combination count"""
+    from instrain_amd import engine
+    from instrain_amd.profile import linkage
+    g = util.load_case(name)
+    gold = np.load(os.path.join(util.GOLD, "linkage_extras.npz"))
+    seq, start = str(g["seq"]), int(g["start"])
+    pos = g["pos"].astype(np.int64)
+    sel = (pos >= start) & (pos < start + len(seq))
+    mm = g["mm"][sel]
+    obs = engine.pack_obs((pos[sel] - start).astype(np.uint32), g["base"][sel], mm)
+    pair = g["pair"][sel].astype(np.uint32)
+    ctx = engine.Context(0)
+    lut, fb = util.load_lut()
+    ctx.set_null_model(lut, fb)
+    src, pr = (obs, pair) if reads is None else (util.reassemble_segs(obs["gpos"], obs["base"], obs["mm"], pair), None)
+    b = engine.Batch(ctx, engine.encode_seq(seq), [0, len(seq)], src, pr, n_mm_bins=int(mm.max()) + 1 if len(mm) else 1,
+                     min_cov=int(g["p_min_cov"]), min_freq=float(g["p_min_freq"]), min_snp=int(g["p_min_snp"]))
+    b.run()
+    ao = b.fetch_allele_obs()
+    assert len(ao) == b.sizes()["n_allele_obs"]
+    n_edges = b.sizes()["n_edges"]
+    b.close()
+    ctx.close()
+    rts = linkage.read_to_snvs_of_split(ao, 0, len(seq))
+    G = linkage.calc_mm_SNV_linkage_network(rts)
+    got_rts, got_gr = linkage.flatten(rts, G)
+    assert (got_rts == gold[name + "_rts"]).all() and got_rts.shape == gold[name + "_rts"].shape
+    assert (got_gr == gold[name + "_graph"]).all() and got_gr.shape == gold[name + "_graph"].shape
+    assert G.number_of_edges() == n_edges == int(g["n_edges"])
+
+
+def test_store_everything_on_a_bam_names_the_reads(tmp_path):
+    """profile_bam(store_everything=True): SplitObjects carry read_to_snvs keyed by READ NAME, mm_to_position_graph and
+    pileup_counts (profile_utilities.py:205-211), and their log is the reference's WorkerLog pair (:133-134, 212-214)"""
+    import instrain_amd.profile as prof
+    from instrain_amd import engine
+    from tests.test_oracle_golden import read_fasta
+    lut, fb = util.load_lut()
+    model = {int(i): int(v) for i, v in enumerate(lut) if v >= 0}
+    model[-1] = fb
+    seq = read_fasta(os.path.join(util.GOLD, "sars_cov_2_MT039887.1.fasta"))
+    bam = os.path.join(util.GOLD, "sars_cov_2.sorted.bam")
+    st = {}
+    splits = prof.profile_bam(bam, s2s={"MT039887.1": seq}, null_model=model, min_cov=5, min_freq=0.05, min_snp=20,
+                              min_read_ani=0.95, store_everything=True, stats=st)
+    bf = engine.BamFile(bam)
+    bf.scan()
+    bf.filter(min_read_ani=0.95)
+    r2m = bf.r2m(0)
+    bf.close()
+    n_entries = n_edges = 0
+    for key, S in splits.items():
+        rts, G = S.read_to_snvs, S.mm_to_position_graph
+        assert S.pileup_counts.shape == (S.length, 4)
+        for mm, reads in rts.items():
+            for name, lst in reads.items():
+                assert r2m[name] == mm                              # the key is the pair's name, its level the filter's mm
+                p = [int(e.split(":")[0]) for e in lst]
+                assert p == sorted(p) and 0 <= p[0] and p[-1] < S.length
+                n_entries += len(lst)
+        n_edges += G.number_of_edges()
+        words = S.log.split()
+        assert words[0] == "WorkerLog" and words[1] == "SplitProfile" and words[2] == key and words[3] == "start"
+        assert words[7] == "WorkerLog" and words[10] == "end" and float(words[12]) >= float(words[5]) and int(words[13]) == os.getpid()
+    assert n_entries > 1000
+    assert n_edges == 963                                           # the stored run's linkage network (SURVEY 8a, a14)
+
+
+def test_pairs_beyond_128_mm_levels_are_clamped_not_fatal(tmp_path, caplog):
+    """a controller's R2M with pairs of 200 mismatches (long reads, a low --min_read_ani): the device bins levels 0..127, such
+    pairs are piled up AT level 127 with a warning -- the same profile as an R2M that says 127 -- instead of an empty result;
+    strict=True turns a failing call into its exception"""
+    import logging
+    import instrain_amd.profile as prof
+    from instrain_amd import engine
+    refs, seqs, path, model = _messy(tmp_path, seed=14, n_pairs=2500)
+    kw = dict(null_model=model, min_cov=5, min_freq=0.05, min_snp=10, window_length=1000, s2s=seqs)
+    bam = engine.BamFile(path)
+    bam.scan(); bam.filter(min_read_ani=0.9)
+    r2m = {name: bam.r2m(t) for t, (name, _, _) in enumerate(bam.refs())}
+    bam.close()
+    far = {s: dict(d) for s, d in r2m.items()}
+    at127 = {s: dict(d) for s, d in r2m.items()}
+    k = 0
+    for s in far:
+        for name in list(far[s])[::7]:
+            far[s][name], at127[s][name] = 200 + (k % 50), 127
+            k += 1
+    assert k > 50
+    with caplog.at_level(logging.WARNING):
+        a = prof.profile_bam(path, None, far, None, strict=True, **kw)
+    assert any("counted at level 127" in r.message for r in caplog.records)
+    b = prof.profile_bam(path, None, at127, None, strict=True, **kw)
+    assert sorted(a) == sorted(b) and len(a) > 5
+    for key in a:
+        _same_split(a[key], b[key])
+    assert max(max(S.covT) for S in a.values() if len(S.covT)) == 127
+    # a call that fails as a whole: the exception itself with strict, a logged failure and a partial dict without
+    with pytest.raises(Exception):
+        prof.profile_bam(str(tmp_path / "no_such.bam"), None, None, None, strict=True, **kw)
+    assert prof.profile_bam(str(tmp_path / "no_such.bam"), None, None, None, **kw) == {}
