@@ -2071,7 +2071,7 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     //      reads, whose end lies at or beyond that start, + the list's sentinel).  Dropped reads take no part in the overlap
     //      resolution and reach no column.  Only a position with >= 100000 reads over it can drop anything: a parallel screen
     //      (reads starting within the longest read span of each start) decides whether the serial replay runs at all.
-    //      PARITY UNPINNED (no reference fixture is that deep; restated from the htslib-1.9 source, like oracle/bam_py.py).
+    //      PARITY UNPINNED (no reference fixture is that deep; restated from the htslib-1.9 source; the tests hold a second, pure-Python restatement).
     {
         constexpr int64_t MAX_DEPTH = 100000;
         const size_t n_all = S.reads.size();

@@ -785,7 +785,7 @@ void isx_batch_destroy(isx_batch *b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     void *ps[] = {b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_drec, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
-                  b->d_snv, b->d_sites, b->d_ao, b->d_cursors};
+                  b->d_snv, b->d_sites, b->d_ao, b->d_cursors, b->d_snv_raw, b->d_sites_raw, b->d_rare_raw, b->d_win_rec, b->d_win_out};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) isx_dev_free(p);          // (falls through to hipFree for blocks that did not come from the cache)
     b->L.release();
@@ -1072,7 +1072,39 @@ int launch_pass(isx_batch *b)
         u->publish_enqueued = true;
         c->unpublished[b->ps] = nullptr;
     }
+    b->ordered = false;
+    if (b->M == 1) {
+        // position order by gather (isx_pileup.hip k_win_gather): the kernel writes scratch tables + one (slot, count) record per window
+        auto grow = [&](auto **p, size_t *cap, size_t want, size_t elem) -> hipError_t {
+            if (*cap >= want && *p) return hipSuccess;
+            if (*p) isx_dev_free(*p);
+            *p = nullptr; *cap = 0;
+            const hipError_t e = isx_dev_malloc(reinterpret_cast<void **>(p), std::max<size_t>(want, 1) * elem);
+            if (e == hipSuccess) *cap = want;
+            return e;
+        };
+        HIP_TRY(grow(&b->d_snv_raw, &b->cap_snv_raw, b->cap_snv, sizeof(isx_snv)));
+        HIP_TRY(grow(&b->d_sites_raw, &b->cap_sites_raw, b->cap_sites, sizeof(isx_site)));
+        if (b->d_rare) HIP_TRY(grow(&b->d_rare_raw, &b->cap_rare_raw, b->cap_rare, sizeof(uint2)));
+        if ((size_t)b->n_win > b->cap_win || !b->d_win_rec) {
+            if (b->d_win_rec) isx_dev_free(b->d_win_rec);
+            if (b->d_win_out) isx_dev_free(b->d_win_out);
+            b->d_win_rec = b->d_win_out = nullptr;
+            const size_t want = (size_t)b->n_win + (size_t)b->n_win / 4 + 64;
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_win_rec), want * 8 * sizeof(uint32_t)));
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_win_out), want * 4 * sizeof(uint32_t)));
+            b->cap_win = want;
+        }
+        a.snv = b->d_snv_raw; a.sites = b->d_sites_raw;
+        if (b->d_rare) a.rare = b->d_rare_raw;
+        a.win_rec = b->d_win_rec;
+    }
     launch_pileup(a, b->block, b->lds, b->grid, b->packed, s, b->ev[0], b->ev[1]);
+    if (b->M == 1) {
+        launch_win_order(b->d_win_rec, b->d_win_out, b->n_win, b->W, b->d_snv_raw, b->d_snv, b->d_sites_raw, b->d_sites,
+                         a.clon_list, b->d_clon_sorted, b->d_rare ? b->d_rare_raw : nullptr, b->d_rare, s);
+        b->ordered = true;
+    }
     HIP_TRY(hipGetLastError());
     ++b->epoch;
     b->publish_enqueued = false;
@@ -1140,7 +1172,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
         in.mode = b->prm.linkage_mode == 2 ? 2 : 1;
         in.philox = Philox{(uint32_t)b->prm.seed, (uint32_t)(b->prm.seed >> 32)};
         in.n_pairs = b->n_pairs; in.ao = b->d_ao; in.n_ao = cur[CUR_AO];
-        in.sites = b->d_sites; in.n_sites = cur[CUR_SITES];
+        in.sites = b->d_sites; in.n_sites = cur[CUR_SITES]; in.sites_ordered = b->ordered;
         in.slev = b->d_slev; in.snv = b->d_snv;
         in.split_bounds = b->d_bounds; in.n_splits = b->n_splits; in.M = b->M; in.min_snp = b->prm.min_snp;
         LinkageOut lo;

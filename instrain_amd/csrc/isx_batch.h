@@ -82,6 +82,14 @@ struct isx_batch {
     size_t cap_ovf = 0, cap_slev = 0;
     isx_snv *d_snv = nullptr;
     isx_site *d_sites = nullptr;
+    // dense path: the kernel fills these in the order the windows reach the cursors; k_win_gather then writes d_snv / d_sites /
+    // d_rare / d_clon_sorted in position order (launch_pass) -- everything downstream reads ordered tables and sorts nothing
+    isx_snv *d_snv_raw = nullptr;
+    isx_site *d_sites_raw = nullptr;
+    uint2 *d_rare_raw = nullptr;
+    uint32_t *d_win_rec = nullptr, *d_win_out = nullptr;
+    size_t cap_snv_raw = 0, cap_sites_raw = 0, cap_rare_raw = 0, cap_win = 0;
+    bool ordered = false;            // the last pass left its tables ordered
     isx_ao *d_ao = nullptr;
     uint32_t *d_cursors = nullptr, *d_flags = nullptr;   // one allocation: cursors[CUR_N] | flags[4]
     uint32_t *h_state = nullptr;                          // mapped pinned mirror, written by k_publish_state

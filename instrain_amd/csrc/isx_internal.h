@@ -224,6 +224,8 @@ struct PileupArgs {
     isx_ao *ao;                 // allele observations, exactly sized slabs per SNP site
     uint32_t cap_ao;
     int32_t enable_linkage;
+    uint32_t *win_rec;          // dense path: [n_win][8] = (first slot, count) of the window's SNV rows | SNP sites | clonality list | clonTR list
+                                // entries (NULL = not wanted): what k_win_gather orders the tables by
     uint32_t *cursors;          // monotonic across runs: slot = atomicAdd(...) - base[...] (no per-run memset)
     uint32_t *flags;
     uint32_t base[CUR_N];       // cursor values when this run started (host copy of the last read-back)
@@ -238,6 +240,9 @@ struct PileupArgs {
 void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s, hipEvent_t ev_start,
                    hipEvent_t ev_stop);        // record format from a.rec16 / a.rec32 / a.rec; the events bracket the dispatch
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s);
+// position order of the dense path's tables by window-ordered gather instead of sorting (isx_pileup.hip: k_win_scan, k_win_gather)
+void launch_win_order(const uint32_t *win_rec, uint32_t *win_out, int n_win, int W, const isx_snv *snv_raw, isx_snv *snv, const isx_site *sites_raw,
+                      isx_site *sites, const uint2 *clon_raw, uint2 *clon, const uint2 *rare_raw, uint2 *rare, hipStream_t s);
 void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
                          const uint32_t *base16, uint32_t base16_records, uint64_t n_rec, hipStream_t s);
 size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int segs, int *stage_off, int *dlt_off = nullptr);

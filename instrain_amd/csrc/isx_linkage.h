@@ -43,8 +43,9 @@ struct LinkageIn {
     uint64_t n_pairs;           // 0 = unknown
     isx_ao *ao;                 // written by the pileup kernel (site field = flat position)
     uint32_t n_ao;
-    const isx_site *sites;      // unsorted, from k_pileup_call
+    const isx_site *sites;      // from the pileup kernel: unsorted, or ...
     uint32_t n_sites;
+    bool sites_ordered = false; // ... already in position order (dense path: k_win_gather) -- the site sort is skipped
     const isx_slev *slev;       // mm path: per-level counts of the SNP sites
     const isx_snv *snv;         // dense path: the SNV rows (isx_site::entry_off indexes them)
     const int64_t *split_bounds;

@@ -684,10 +684,14 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
         (rc = ensure(B.sites_sorted, n_sites)) || (rc = ensure(B.site_gpos, n_sites)) ||
         (rc = ensure(B.site_split, n_sites))) return rc;
     tick("site buffers");
-    hipLaunchKernelGGL(k_site_keys, dim3((n_sites + 255) / 256), dim3(256), 0, s, in.sites, n_sites, B.site_keys.p);
-    RP(rocprim::radix_sort_pairs(tp, tb, B.site_keys.p, B.site_keys2.p, const_cast<isx_site *>(in.sites),
-                                 B.sites_sorted.p, n_sites, 0, 32, s));
-    hipLaunchKernelGGL(k_site_split, dim3((n_sites + 255) / 256), dim3(256), 0, s, B.sites_sorted.p, n_sites,
+    const isx_site *sites_sorted = in.sites;
+    if (!in.sites_ordered) {
+        hipLaunchKernelGGL(k_site_keys, dim3((n_sites + 255) / 256), dim3(256), 0, s, in.sites, n_sites, B.site_keys.p);
+        RP(rocprim::radix_sort_pairs(tp, tb, B.site_keys.p, B.site_keys2.p, const_cast<isx_site *>(in.sites),
+                                     B.sites_sorted.p, n_sites, 0, 32, s));
+        sites_sorted = B.sites_sorted.p;
+    }
+    hipLaunchKernelGGL(k_site_split, dim3((n_sites + 255) / 256), dim3(256), 0, s, sites_sorted, n_sites,
                        in.split_bounds, in.n_splits, B.site_gpos.p, B.site_split.p);
     tick("site sort enqueued");
     EV(1);
@@ -714,7 +718,7 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     const int sb = bits_for(n_sites);
     if ((rc = ensure(B.rows_per, n_u)) || (rc = ensure(B.row_off, (size_t)n_u + 1))) return rc;
     HIP_TRY(hipMemsetAsync(B.n_runs.p + 1, 0, 4, s));
-    SiteView v{B.sites_sorted.p, in.slev, in.snv, in.M == 1 ? 1 : 0};
+    SiteView v{sites_sorted, in.slev, in.snv, in.M == 1 ? 1 : 0};
     hipLaunchKernelGGL(k_ld_rows<false>, dim3((n_u + 255) / 256), dim3(256), 0, s, B.ukeys.p, B.ucnt.p, n_u, v,
                        in.min_snp, B.rows_per.p, nullptr, nullptr, B.n_runs.p + 1, in.philox, sb);
     uint64_t n_ld = 0;

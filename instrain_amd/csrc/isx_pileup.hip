@@ -1040,6 +1040,17 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                                             : (site_base + nsites > a.cap_sites ? ISX_FLAG_CAP_SITES : ISX_FLAG_CAP_AO));
             ok = false;
         }
+        if (a.win_rec && tid == 0) {
+            // where this window's rows / sites / list entries went and how many there are: the tables are filled in the order the
+            // windows reach their cursors, k_win_gather puts them into position order afterwards (windows are position ranges, a
+            // window's entries lie together) -- instead of sorting the tables
+            uint32_t *wr = a.win_rec + 8 * (size_t)w;
+            const uint32_t cb = scratch[S_CLON_BASE], rb = scratch[S_RARE_BASE];
+            wr[0] = row_base; wr[1] = ok ? nrows : 0u;
+            wr[2] = site_base; wr[3] = ok ? nsites : 0u;
+            wr[4] = cb; wr[5] = (nclon && cb + nclon <= a.cap_clon) ? nclon : 0u;
+            wr[6] = rb; wr[7] = (nrare && rb + nrare <= a.cap_rare) ? nrare : 0u;
+        }
         for (uint32_t q0 = 0; q0 < (ok ? nq : 0u); q0 += nthr) {
             const uint32_t q = q0 + tid;
             const uint32_t e = q < nq ? queue[q] : 0u;
@@ -1440,6 +1451,133 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
     if (tid == 0 && my_entries) cur_add(a, CUR_ENT_TOTAL, my_entries);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Position order without sorting.  k_pileup_dense hands out table slots window by window as the windows reach the cursors, so the
+// SNV rows, SNP sites, the clonality list and the clonTR list come out grouped by window but with the windows (and the entries
+// inside one) in no particular order.  A window is a range of positions and every entry of these tables has its own position
+// (one mm bin: one row per position), so the ordered tables are a GATHER: k_win_scan = exclusive prefix of the per-window counts
+// in window order; k_win_gather = one workgroup per window, rank of an entry = set bits below its position in the window's
+// occupancy bitmap.  Replaces four sorts per batch (rocprim's radix sort of a few 10^5 keys is 5-8 kernel launches each).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_win_scan(const uint32_t *__restrict__ win_rec, uint32_t *__restrict__ win_out, int n_win)
+{
+    __shared__ uint32_t wsum[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n_win + 1023) / 1024, a0 = tid * per, a1 = min(n_win, a0 + per);
+    uint32_t s[4] = {0, 0, 0, 0};
+    for (int w = a0; w < a1; w++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[k] += win_rec[8 * (size_t)w + 2 * k + 1];
+    }
+    uint32_t inc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = s[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(v, o);
+            if (lane >= o) v += y;
+        }
+        inc[k] = v;
+        if (lane == 63) wsum[k][wave] = v;
+    }
+    __syncthreads();
+    uint32_t run[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t off = inc[k] - s[k];
+        for (int j = 0; j < wave; j++) off += wsum[k][j];
+        run[k] = off;
+    }
+    for (int w = a0; w < a1; w++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            win_out[4 * (size_t)w + k] = run[k];
+            run[k] += win_rec[8 * (size_t)w + 2 * k + 1];
+        }
+    }
+}
+
+struct GatherArgs {
+    const uint32_t *win_rec, *win_out;
+    const isx_snv *snv_raw; isx_snv *snv;
+    const isx_site *sites_raw; isx_site *sites;
+    const uint2 *clon_raw; uint2 *clon;
+    const uint2 *rare_raw; uint2 *rare;
+    int W;
+};
+
+// exclusive prefix of the set bits of a window's occupancy bitmap (256 words = 8192 positions), per word
+__device__ __forceinline__ void bitmap_prefix(const uint32_t *bm, uint32_t *pre, uint32_t *tmp4, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = (uint32_t)__popc(bm[tid]);
+    uint32_t v = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(v, o);
+        if (lane >= o) v += y;
+    }
+    if (lane == 63) tmp4[wave] = v;
+    __syncthreads();
+    uint32_t off = v - c;
+    for (int j = 0; j < wave; j++) off += tmp4[j];
+    pre[tid] = off;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_win_gather(const GatherArgs g)
+{
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const uint32_t *wr = g.win_rec + 8 * (size_t)w, *wo = g.win_out + 4 * (size_t)w;
+    const uint32_t n_rows = wr[1], n_sites = wr[3], n_clon = wr[5], n_rare = wr[7];
+    if (!(n_rows | n_sites | n_clon | n_rare)) return;
+    __shared__ uint32_t bm_rows[256], pre_rows[256], bm[256], pre[256], tmp4[4];
+    const uint32_t w0 = (uint32_t)w * (uint32_t)g.W;
+    auto rank_of = [](const uint32_t *bmx, const uint32_t *prex, uint32_t p) {
+        return prex[p >> 5] + (uint32_t)__popc(bmx[p >> 5] & ((1u << (p & 31u)) - 1u));
+    };
+    bm_rows[tid] = 0;
+    __syncthreads();
+    if (n_rows | n_sites) {                     // rows first: a site's entry_off is the index of ITS row in the ordered table
+        for (uint32_t i = tid; i < n_rows; i += 256) { const uint32_t p = g.snv_raw[wr[0] + i].gpos - w0; atomicOr(&bm_rows[p >> 5], 1u << (p & 31u)); }
+        __syncthreads();
+        bitmap_prefix(bm_rows, pre_rows, tmp4, tid);
+        for (uint32_t i = tid; i < n_rows; i += 256) {
+            const isx_snv r = g.snv_raw[wr[0] + i];
+            g.snv[wo[0] + rank_of(bm_rows, pre_rows, r.gpos - w0)] = r;
+        }
+    }
+    if (n_sites) {
+        bm[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n_sites; i += 256) { const uint32_t p = g.sites_raw[wr[2] + i].gpos - w0; atomicOr(&bm[p >> 5], 1u << (p & 31u)); }
+        __syncthreads();
+        bitmap_prefix(bm, pre, tmp4, tid);
+        for (uint32_t i = tid; i < n_sites; i += 256) {
+            isx_site st = g.sites_raw[wr[2] + i];
+            const uint32_t p = st.gpos - w0;
+            st.entry_off = wo[0] + rank_of(bm_rows, pre_rows, p);
+            g.sites[wo[1] + rank_of(bm, pre, p)] = st;
+        }
+    }
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+        const uint32_t n = which ? n_rare : n_clon;
+        if (!n) continue;                       // (uniform)
+        const uint2 *src = (which ? g.rare_raw : g.clon_raw) + wr[which ? 6 : 4];
+        uint2 *dst = (which ? g.rare : g.clon) + wo[which ? 3 : 2];
+        __syncthreads();
+        bm[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 256) { const uint32_t p = src[i].x - w0; atomicOr(&bm[p >> 5], 1u << (p & 31u)); }
+        __syncthreads();
+        bitmap_prefix(bm, pre, tmp4, tid);
+        for (uint32_t i = tid; i < n; i += 256) { const uint2 e = src[i]; dst[rank_of(bm, pre, e.x - w0)] = e; }
+    }
+}
+
 }  // namespace
 
 size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int segs, int *stage_off, int *dlt_off)
@@ -1538,6 +1676,15 @@ void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t
 {
     hipLaunchKernelGGL(k_extract_gpos, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, s, rec, rec32, gbase, gpos, gpos16,
                        base16, base16_records, n_rec);
+}
+
+void launch_win_order(const uint32_t *win_rec, uint32_t *win_out, int n_win, int W, const isx_snv *snv_raw, isx_snv *snv, const isx_site *sites_raw,
+                      isx_site *sites, const uint2 *clon_raw, uint2 *clon, const uint2 *rare_raw, uint2 *rare, hipStream_t s)
+{
+    if (n_win <= 0) return;
+    hipLaunchKernelGGL(k_win_scan, dim3(1), dim3(1024), 0, s, win_rec, win_out, n_win);
+    GatherArgs g{win_rec, win_out, snv_raw, snv, sites_raw, sites, clon_raw, clon, rare_raw, rare, W};
+    hipLaunchKernelGGL(k_win_gather, dim3(n_win), dim3(256), 0, s, g);
 }
 
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s)

@@ -471,7 +471,8 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
             s.d2h_bytes += (int64_t)b->n_pos * (s.cov8 ? 1 : 2);
             const size_t n_clon = b->n_clon;
             if (n_clon <= b->cap_clon && n_clon * 2 <= (size_t)b->n_pos) {
-                if ((rc = sort_pairs_by_position(sfin, b->d_clon_list, b->d_clon_sorted, n_clon, &s.sort_temp, &s.sort_temp_bytes)) != ISX_OK) return rc;
+                // (b->ordered: k_win_gather already wrote the list in position order behind the pileup kernel)
+                if (!b->ordered && (rc = sort_pairs_by_position(sfin, b->d_clon_list, b->d_clon_sorted, n_clon, &s.sort_temp, &s.sort_temp_bytes)) != ISX_OK) return rc;
                 if ((rc = fetch(s.h_out + s.o_clon, b->d_clon_sorted, n_clon * sizeof(isx_rare))) != ISX_OK) return rc;
                 s.clon_sparse = true;
                 s.d2h_bytes += (int64_t)(n_clon * sizeof(isx_rare));
@@ -514,7 +515,7 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
                 if (n_rare > p->rare_prefix) { s.rare_big.resize(n_rare); rr = s.rare_big.data(); }
                 { const int prc = pull(rr, b->d_rare, n_rare * sizeof(isx_rare)); if (prc != ISX_OK) return prc; }
             }
-            std::sort(rr, rr + n_rare, [](const isx_rare &x, const isx_rare &y) { return x.gpos < y.gpos; });
+            if (!b->ordered) std::sort(rr, rr + n_rare, [](const isx_rare &x, const isx_rare &y) { return x.gpos < y.gpos; });
         }
     }
     t_rare = now_ms();
@@ -524,7 +525,7 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         if (n_snv > p->snv_prefix) { s.snv_big.resize(n_snv); rows = s.snv_big.data(); }
         { const int prc = pull(rows, b->d_snv, n_snv * sizeof(isx_snv)); if (prc != ISX_OK) return prc; }
     }
-    std::sort(rows, rows + n_snv, [](const isx_snv &x, const isx_snv &y) { return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm; });
+    if (!b->ordered) std::sort(rows, rows + n_snv, [](const isx_snv &x, const isx_snv &y) { return x.gpos != y.gpos ? x.gpos < y.gpos : x.mm < y.mm; });
     if (p->prm.enable_linkage) {
         // the LD rows too: a blocking copy issued by the caller would queue behind the next batches' large transfers
         s.ld_rows.resize((size_t)b->sizes.n_ld);

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""gpurun_out/<tag>/ (made by tools/make_profiles.sh on the GPU box) -> profiles/<tag>_*.md, <tag>_bench_n1.json,
-pmc_traffic.json.  usage: python tools/write_profiles.py <tag>"""
+"""gpurun_out/<tag>/ (made by tools/make_profiles.sh on the GPU box) -> profiles/<tag>_*.md, <tag>_bench_n1.json, pmc_traffic.json.
+usage: python tools/write_profiles.py <tag>"""
+import hashlib
 import json
+import os
 import subprocess
 import sys
 
@@ -10,10 +12,21 @@ import pandas as pd
 tag = sys.argv[1]
 R = 'gpurun_out/' + tag
 rnd = int(tag[1:])
-j = json.load(open(R + '/bench_n1.json'))
-json.dump(j, open('profiles/%s_bench_n1.json' % tag, 'w'), indent=1)
-READS, OBS = r'k_pileup_dense<false, 64', r'k_pileup_dense<false, 2'
-MM_READS, MM_OBS = r'k_pileup_mm<\w+, \w+, \w+, true>', r'k_pileup_mm<\w+, \w+, \w+, false>'
+line = json.loads([l for l in open(R + '/bench.json') if l.startswith('{')][-1])
+detail = json.load(open(R + '/bench_detail.json'))
+json.dump({"line": line, "detail": detail}, open('profiles/%s_bench_n1.json' % tag, 'w'), indent=1)
+commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD']).decode().strip()
+sha = hashlib.sha1(open('instrain_amd/csrc/isx_pileup.hip', 'rb').read()).hexdigest()[:16]
+
+K = {"delta": r'k_pileup_dense<false, 32, true>', "delta_u32": r'k_pileup_dense<false, 32, false>', "seg64": r'k_pileup_dense<false, 64, false>',
+     "obs": r'k_pileup_dense<false, 2, true>', "mm_reads": r'k_pileup_mm<\w+, \w+, \w+, true>', "mm_obs": r'k_pileup_mm<\w+, \w+, \w+, false>',
+     "c5": r'k_pileup_dense<true, 32, true>'}
+LABEL = {"delta": "k_pileup_dense<false, 32, true> -- C2 as 32-byte reference-delta records, 16-bit LDS rows (production)",
+         "delta_u32": "k_pileup_dense<false, 32, false> -- the same records, 32-bit LDS rows (very deep batches)",
+         "seg64": "k_pileup_dense<false, 64, false> -- C2 as 64-byte segment records (round 3)",
+         "obs": "k_pileup_dense<false, 2, true> -- C2 as 2-byte observation records (round 2)",
+         "mm_reads": "k_pileup_mm<..., SEGS> -- C2 as segment records, mm profiling on", "mm_obs": "k_pileup_mm -- C2 as 4-byte observation records, mm on",
+         "c5": "k_pileup_dense<true, 32, true> -- one C5 batch (80 Mbp, linkage on) in a pipe slot (shrunk output)"}
 
 
 def summ(*dirs):
@@ -28,122 +41,104 @@ def stat_row(ks, pat):
     return int(r['Calls']), r['TotalDurationNs'] / r['Calls'] / 1e3, r['MinNs'] / 1e3, r['MaxNs'] / 1e3
 
 
-ks = pd.read_csv(R + '/trace_c2/%s_kernel_stats.csv' % tag)
-rd, ob = stat_row(ks, READS), stat_row(ks, OBS)
-ro = j["roofline"]
-ev, evs = ro["kernel_ms_avg"] * 1e3, ro.get("kernel_ms_in_stream", 0) * 1e3
-obs_ev = j["roofline_observation_kernel"]["kernel_ms_avg"] * 1e3
-open('profiles/%s_c2_kernel_stats.md' % tag, 'w').write(f'''# Round {rnd} — rocprofv3 --kernel-trace --stats, C2 workload (final kernels of the round)
-
-Command (tools/make_profiles.sh): `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python bench.py --steps 30 --warmup 4 --no-cpu-baseline --no-linkage-leg --no-mm-leg --no-c5-leg --no-bam-leg`
-
-**k_pileup_dense<false, 64, false>** (read-segment records, linkage off -- the kernel of the timed step): {rd[0]} calls, average {rd[1]:.1f} us,
-min {rd[2]:.1f} us, max {rd[3]:.1f} us under rocprof.  The calls are of two kinds: 34 launches inside the streamed pipe (4 warm-up + 30 timed
-batches; a launch is a few % of a PCIe-bound step, the GPU idles in between and its clocks sag; un-profiled bench: {evs:.1f} us each =
-roofline.kernel_ms_in_stream) and 4 + 10 + 1 + 30 launches of the resident leg (un-profiled bench: {ev:.1f} us = roofline.kernel_ms_avg, the figure
-the roofline is priced on; MinNs above is the same kernel at full clocks).
-**k_pileup_dense<false, 2, true>** (2-byte observation records, the round-2 kernel, resident leg only): {ob[0]} calls, average {ob[1]:.1f} us
-(bench: {obs_ev:.1f} us).
-
-''' + summ(R + '/trace_c2'))
-
-cf = pd.read_csv(R + '/pmc_fetch/%s_counter_collection.csv' % tag)
-cw = pd.read_csv(R + '/pmc_write/%s_counter_collection.csv' % tag)
-
-
-def mean(c, pat, name=None):
+def counter_mean(c, pat, name=None):
     r = c[c['Kernel_Name'].str.contains(pat, regex=True)]
     if name is not None:
         r = r[r['Counter_Name'] == name]
-    return float(r['Counter_Value'].mean())
+    return float(r['Counter_Value'].mean()) if len(r) else float('nan')
 
 
-def traffic(pat):
-    f, w = mean(cf, pat), mean(cw, pat)
-    return f * 1024 * 2, w * 1024, f, w          # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
+def traffic(cf, cw, pat):
+    f, w = counter_mean(cf, pat), counter_mean(cw, pat)
+    return f * 1024 * 2, w * 1024, f, w          # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section)
 
 
-tr = {k: traffic(p) for k, p in (("reads", READS), ("obs", OBS), ("mm_reads", MM_READS), ("mm_obs", MM_OBS))}
-alg = {"reads": ro["algorithmic_bytes_per_launch"], "obs": j["roofline_observation_kernel"]["algorithmic_bytes_per_launch"],
-       "mm_reads": j["mm_on"]["reads"]["roofline"]["algorithmic_bytes_per_launch"],
-       "mm_obs": j["mm_on"]["observations"]["roofline"]["algorithmic_bytes_per_launch"]}
-label = {"reads": "k_pileup_dense<false, 64> (C2 as read segments, skip-mm; resident batch: counts + clonality out)",
-         "obs": "k_pileup_dense<false, 2, true> (C2 as 2-byte observation records)",
-         "mm_reads": "k_pileup_mm<..., SEGS> (C2 as read segments, mm profiling on, W = %d)" % j["mm_on"]["reads"]["roofline"]["window"],
-         "mm_obs": "k_pileup_mm (C2 as 4-byte observation records, mm on)"}
-lines = []
-for k in ("reads", "obs", "mm_reads", "mm_obs"):
-    r_, w_, _, _ = tr[k]
-    lines.append(f"* {label[k]}: read {r_/1e6:.1f} MB + written {w_/1e6:.1f} MB = **{(r_+w_)/1e6:.1f} MB per launch** vs {alg[k]/1e6:.1f} MB algorithmic = {(r_+w_)/alg[k]:.2f}x.")
-open('profiles/%s_c2_pmc.md' % tag, 'w').write(f'''# Round {rnd} — HBM traffic of the pileup kernels on C2 (separate --pmc passes over tools/pmc_target.py)
+# ---- kernel stats ----
+ks2 = pd.read_csv(R + '/trace_c2/%s_kernel_stats.csv' % tag)
+ks5 = pd.read_csv(R + '/trace_c5b/%s_kernel_stats.csv' % tag)
+rows = {k: stat_row(ks2, p) for k, p in K.items() if k != "c5"}
+rows["c5"] = stat_row(ks5, K["c5"])
+res = detail.get("resident", {})
+rc2 = detail.get("roofline_c2_resident", {})
+body = "\n".join("* **%s**: %d calls, average %.1f us, min %.1f us, max %.1f us" % ((LABEL[k],) + rows[k]) for k in K if rows.get(k))
+open('profiles/%s_c2_kernel_stats.md' % tag, 'w').write(f'''# Round {rnd} -- rocprofv3 --kernel-trace --stats over the resident launches (tools/pmc_target.py)
 
-`rocprofv3 --pmc FETCH_SIZE -- python tools/pmc_target.py` and the same with WRITE_SIZE: only resident C2 batches, 8 launches per kernel, every
-launch of a kernel name the same work (the launches bench.py's roofline objects are priced on).  FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950
-correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced streaming reads, so
-read bytes = FETCH_SIZE x 1024 x 2.  Algorithmic bytes as in DESIGN.md section 3 (64 B per read-segment record + 4 B per 16 of them, or
-2 / 4 B per observation; 1 B/pos reference; 20 B/pos out, or 32 B per (position, mm) entry).
+Commands (tools/make_profiles.sh): `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python tools/pmc_target.py` and
+the same with `--c5`: only resident / re-submitted batches, 8 launches per kernel, every launch of a kernel name the same work -- the launches bench.py's roofline
+objects are priced on (its `resident` leg times the same kernels with the dispatches' own time stamps: un-profiled {rc2.get("kernel_ms_avg", 0) * 1e3:.1f} us for the
+reference-delta kernel).
 
-''' + "\n".join(lines) + "\n\n" + summ(R + '/pmc_fetch', R + '/pmc_write'))
-json.dump({"c2_reads_bytes_per_launch": int(tr["reads"][0] + tr["reads"][1]), "c2_pileup_bytes_per_launch": int(tr["obs"][0] + tr["obs"][1]),
-           "c2_mm_reads_bytes_per_launch": int(tr["mm_reads"][0] + tr["mm_reads"][1]),
-           "c2_mm_pileup_bytes_per_launch": int(tr["mm_obs"][0] + tr["mm_obs"][1]),
-           "fetch_size_kib": {k: v[2] for k, v in tr.items()}, "write_size_kib": {k: v[3] for k, v in tr.items()},
-           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/pmc_target.py (profiles/%s_c2_pmc.md); FETCH_SIZE doubled per the gfx950 correction" % tag,
-           "round": rnd}, open('profiles/pmc_traffic.json', 'w'), indent=1)
+{body}
 
-# ---- SQ counters of the two one-bin kernels ----
-sq = pd.concat([pd.read_csv(R + '/sq1/%s_counter_collection.csv' % tag), pd.read_csv(R + '/sq2/%s_counter_collection.csv' % tag)])
-names = sorted(sq['Counter_Name'].unique())
-rows = []
-for n in names:
-    a, b = mean(sq, READS, n), mean(sq, OBS, n)
-    rows.append((n, a, b))
-wc = {k: dict((n, v) for n, *_ in [] ) for k in ()}
-wr = dict((n, a) for n, a, _ in rows)
-wo = dict((n, b) for n, _, b in rows)
-tab = "| counter | reads kernel | % of wave cycles | observation kernel | % of wave cycles |\n|:--|--:|--:|--:|--:|\n"
-for n, a, b in rows:
-    tab += "| %s | %.4g | %.1f | %.4g | %.1f |\n" % (n, a, 100 * a / wr["SQ_WAVE_CYCLES"], b, 100 * b / wo["SQ_WAVE_CYCLES"])
-n_obs = j["config"]["kept_observations"]
-open('profiles/%s_sq_counters.md' % tag, 'w').write(f'''# Round {rnd} — SQ counters of k_pileup_dense on C2: read-segment records vs 2-byte observation records
+''' + summ(R + '/trace_c2') + "\n" + summ(R + '/trace_c5b'))
 
-Two `rocprofv3 --pmc` passes of 8 counters over `tools/pmc_target.py --no-mm` (resident C2 batch, 8 launches per kernel; mean per launch; the
-cycle counters are in quad-cycles summed over all waves, MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES).
+c5 = detail["c5"]
+open('profiles/%s_c5_kernel_stats.md' % tag, 'w').write(f'''# Round {rnd} -- rocprofv3 --kernel-trace --stats, bench.py headline (configs[4]: the whole 1000-genome database through one GPU)
 
-{tab}
-Reading (reads kernel, {ev:.1f} us alone; {n_obs/1e6:.0f} M kept bases = {n_obs/1e6:.0f} M LDS read-modify-writes per launch):
-* LDS instructions: {wr["SQ_INSTS_LDS"]/1e6:.2f} M wave-level = {wr["SQ_INSTS_LDS"]*64/n_obs:.2f} lane slots per kept base (the skip slots of a record's last word and the
-  lanes of short records are masked off); `SQ_LDS_BANK_CONFLICT` = {wr["SQ_LDS_BANK_CONFLICT"]/1e6:.1f} M cycles against `SQ_LDS_IDX_ACTIVE` = {wr["SQ_LDS_IDX_ACTIVE"]/1e6:.1f} M:
-  **{100*wr["SQ_LDS_BANK_CONFLICT"]/wr["SQ_LDS_IDX_ACTIVE"]:.0f} % of the LDS pipe's busy cycles are bank-conflict replays** (observation kernel: {100*wo["SQ_LDS_BANK_CONFLICT"]/wo["SQ_LDS_IDX_ACTIVE"]:.0f} %).
-  A wave's 64 atomics go to 16 records x 4 quarters at unrelated columns: the expected deepest bank is 3-4 of 64 lanes.
-* VALU: {wr["SQ_INSTS_VALU"]/1e6:.1f} M wave-level instructions ({wr["SQ_INSTS_VALU"]*64/n_obs:.1f} lane-instructions per kept base) vs {wo["SQ_INSTS_VALU"]/1e6:.1f} M for the observation
-  records; waves parked (`SQ_WAIT_ANY`) {100*wr["SQ_WAIT_ANY"]/wr["SQ_WAVE_CYCLES"]:.0f} % of their life vs {100*wo["SQ_WAIT_ANY"]/wo["SQ_WAVE_CYCLES"]:.0f} %: with 1 / 4.6 of the bytes to stream the loads no longer
-  set the pace; issue stalls (`SQ_WAIT_INST_ANY`, {100*wr["SQ_WAIT_INST_ANY"]/wr["SQ_WAVE_CYCLES"]:.0f} %) and the LDS queue do.
-* Consequence for the roofline: the kernel moves {ro["algorithmic_bytes_per_launch"]/1e6:.0f} MB in {ev:.1f} us = {ro["frac"]*100:.0f} % of the HBM roof -- not because it wastes traffic
-  (measured traffic = {(tr["reads"][0]+tr["reads"][1])/ro["algorithmic_bytes_per_launch"]:.2f}x algorithmic) but because its bound moved from the stream to the LDS atomics:
-  {j["roofline_lds"]["frac"]*100:.0f} % of the conflict-free ds_add rate (bench.py roofline_lds), ~3.3x conflict replays on top.
-''')
-
-l = j['linkage']
-open('profiles/%s_linkage_kernel_stats.md' % tag, 'w').write(f'''# Round {rnd} — rocprofv3 --kernel-trace --stats, bench.py with the linkage leg (BASELINE configs[2]: 5 Mbp, 200x, 50 000 SNV sites)
-
-Command (tools/make_profiles.sh): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-mm-leg --no-c5-leg --no-bam-leg`
-(7 runs each of: the read-level batch through the sparse chain, the observation batch through the sparse chain, the observation batch through
-the dense MFMA path; k_pileup_dense<true, ...> is the linkage-on pileup with the allele pass, <false, ...> the C2 steps of the same command.)
-
-Un-profiled bench line of the same box: read-level {l["reads"]["snv_pairs_linked_per_s"]/1e6:.1f} M SNV pairs/s ({l["reads"]["ms_per_step"]:.2f} ms per step: {l["reads"]["kernel_ms"]}),
-observations {l["sparse"]["snv_pairs_linked_per_s"]/1e6:.1f} M SNV pairs/s ({l["sparse"]["ms_per_step"]:.2f} ms); dense MFMA pass {l["dense_mfma"]["mfma"]["pass_ms"]:.3f} ms =
-{l["dense_mfma"]["mfma"]["achieved_tops"]:.0f} int8 TOPS = {l["dense_mfma"]["mfma"]["utilisation"]*100:.1f} % of the 5 POPS dense peak (useful tiles only); see r03_mfma_crossover.md.
-
-''' + summ(R + '/trace_linkage'))
-c5 = j.get('c5', {})
-open('profiles/%s_c5_kernel_stats.md' % tag, 'w').write(f'''# Round {rnd} — rocprofv3 --kernel-trace --stats, bench.py with the C5 leg (configs[4]: the whole 1000-genome database through one GPU)
-
-Command (tools/make_profiles.sh): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-linkage-leg --no-mm-leg --no-resident-leg --no-bam-leg`
-The k_pileup_dense<true, 64> rows are the C5 batches (8 warm-up + {c5.get("roofline", {}).get("launches", "?")} timed; 25-40 Mbp of positions, ~0.75 M read segments each).
-Un-profiled bench line of the same box: {c5.get("gbp_per_s", 0):.1f} Gbp/s for all 8 shards on one GPU ({c5.get("seconds", 0)*1e3:.0f} ms; stage totals {c5.get("stages_ms_total")}),
-kernel total {c5.get("roofline", {}).get("kernel_ms_total", 0):.2f} ms = {c5.get("roofline", {}).get("frac", 0)*100:.0f} % of the HBM roof on {c5.get("roofline", {}).get("bytes_per_position", 0):.1f} algorithmic bytes per
-position; the leg is bound by the copy-in queue ({c5.get("roofline_pcie", {}).get("host_to_device_bytes", 0)/1e9:.2f} GB over PCIe).
+Command (tools/make_profiles.sh): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python bench.py --only-c5 --steps 3 --warmup 1`
+(verification pass + 1 warm-up + 3 timed passes of {c5["batches"]} batches each; the k_pileup_dense<true, 32, true> rows are those batches).
+Un-profiled bench line of the same box: **{line["value"]:.1f} Gbp/s** ({line["ms_per_step"]:.1f} ms per pass; per pass: {c5["stages_ms_per_pass"]});
+pileup kernel {c5["roofline"]["kernel_ms_per_pass"]:.1f} ms per pass on {c5["roofline"]["bytes_per_position"]:.2f} algorithmic bytes per position;
+{c5["roofline_pcie"]["bytes_per_pass"] / 1e9:.2f} GB over PCIe per pass = {c5["roofline_pcie"]["bytes_per_profiled_base"]:.3f} B per profiled base.
 
 ''' + summ(R + '/trace_c5'))
-print(j["value"], j["ms_per_step"], ro["frac"], j["cpu_baseline"]["value"], c5.get("gbp_per_s"))
+
+# ---- PMC traffic ----
+cf, cw = pd.read_csv(R + '/pmc_fetch/%s_counter_collection.csv' % tag), pd.read_csv(R + '/pmc_write/%s_counter_collection.csv' % tag)
+cf5, cw5 = pd.read_csv(R + '/pmc_fetch_c5/%s_counter_collection.csv' % tag), pd.read_csv(R + '/pmc_write_c5/%s_counter_collection.csv' % tag)
+tr = {k: traffic(cf, cw, p) for k, p in K.items() if k != "c5"}
+tr["c5"] = traffic(cf5, cw5, K["c5"])
+w = None
+alg = {"delta": rc2.get("algorithmic_bytes_per_launch"), "obs": detail.get("roofline_observation_kernel", {}).get("algorithmic_bytes_per_launch"),
+       "mm_reads": detail.get("mm_on", {}).get("reads", {}).get("roofline", {}).get("algorithmic_bytes_per_launch"),
+       "mm_obs": detail.get("mm_on", {}).get("observations", {}).get("roofline", {}).get("algorithmic_bytes_per_launch")}
+c5log = open(R + '/pmc_fetch_c5.log').read()
+lines = []
+for k in K:
+    r_, w_, _, _ = tr[k]
+    if r_ != r_:
+        continue
+    a = alg.get(k)
+    lines.append(f"* {LABEL[k]}: read {r_/1e6:.1f} MB + written {w_/1e6:.1f} MB = **{(r_+w_)/1e6:.1f} MB per launch**" +
+                 (f" vs {a/1e6:.1f} MB algorithmic = {(r_+w_)/a:.2f}x." if a else "."))
+open('profiles/%s_c2_pmc.md' % tag, 'w').write(f'''# Round {rnd} -- HBM traffic of the pileup kernels (separate --pmc passes over tools/pmc_target.py)
+
+`rocprofv3 --pmc FETCH_SIZE -- python tools/pmc_target.py [--c5]` and the same with WRITE_SIZE (separate passes, no tracing): 8 launches per kernel, every
+launch of a kernel name the same work.  FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B
+requests at 64 B for wide coalesced streaming reads, so read bytes = FETCH_SIZE x 1024 x 2.  Algorithmic bytes as in DESIGN.md section 3.
+The C5 batch of the `--c5` pass: {[l for l in c5log.splitlines() if l.startswith("c5 batch")][-1] if "c5 batch" in c5log else "?"}
+
+''' + "\n".join(lines) + "\n\n" + summ(R + '/pmc_fetch', R + '/pmc_write') + "\n" + summ(R + '/pmc_fetch_c5', R + '/pmc_write_c5'))
+tot = lambda k: int(tr[k][0] + tr[k][1]) if tr[k][0] == tr[k][0] else None
+json.dump({"c2_reads_bytes_per_launch": tot("delta"), "c2_delta_u32_bytes_per_launch": tot("delta_u32"), "c2_seg64_bytes_per_launch": tot("seg64"),
+           "c2_pileup_bytes_per_launch": tot("obs"), "c2_mm_reads_bytes_per_launch": tot("mm_reads"), "c2_mm_pileup_bytes_per_launch": tot("mm_obs"),
+           "c5_dense_linkage_bytes_per_launch": tot("c5"),
+           "fetch_size_kib": {k: v[2] for k, v in tr.items()}, "write_size_kib": {k: v[3] for k, v in tr.items()},
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/pmc_target.py [--c5] (profiles/%s_c2_pmc.md); FETCH_SIZE doubled per the "
+                   "gfx950 correction.  bench.py withholds these figures when instrain_amd/csrc/isx_pileup.hip no longer hashes to kernel_source_sha" % tag,
+           "round": rnd, "tag": tag, "commit": commit, "kernel_source_sha": sha}, open('profiles/pmc_traffic.json', 'w'), indent=1)
+
+# ---- SQ counters: the reference-delta kernel next to the round-3 segment kernel ----
+sq = pd.concat([pd.read_csv(R + '/sq1/%s_counter_collection.csv' % tag), pd.read_csv(R + '/sq2/%s_counter_collection.csv' % tag)])
+names = sorted(sq['Counter_Name'].unique())
+cols = ["delta", "seg64", "obs"]
+val = {k: {n: counter_mean(sq, K[k], n) for n in names} for k in cols}
+tab = "| counter | " + " | ".join("%s | %% of wave cycles" % k for k in cols) + " |\n|:--|" + "--:|--:|" * len(cols) + "\n"
+for n in names:
+    tab += "| %s | " % n + " | ".join("%.4g | %.1f" % (val[k][n], 100 * val[k][n] / val[k]["SQ_WAVE_CYCLES"]) for k in cols) + " |\n"
+d, s6 = val["delta"], val["seg64"]
+n_obs = detail.get("c2_stream", {}).get("kept_observations", 0)
+open('profiles/%s_sq_counters.md' % tag, 'w').write(f'''# Round {rnd} -- SQ counters of k_pileup_dense on C2: reference-delta records (16-bit LDS rows) vs segment records vs observation records
+
+Two `rocprofv3 --pmc` passes of 8 counters over `tools/pmc_target.py --no-mm` (resident C2 batch, 8 launches per kernel; mean per launch; the cycle counters
+are in quad-cycles summed over all waves, MI355X_MICROARCH.md).  delta = k_pileup_dense<false, 32, true>, seg64 = <false, 64, false>, obs = <false, 2, true>.
+
+{tab}
+Reading:
+* LDS instructions per launch: {d["SQ_INSTS_LDS"]/1e6:.2f} M (delta) vs {s6["SQ_INSTS_LDS"]/1e6:.2f} M (segments): the difference array replaces one `ds_add_u32` per kept base
+  ({n_obs/1e6:.0f} M per launch) by +1 / -1 at a record's ends, one per skipped column and one per exception.
+* `SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE` = {100*d["SQ_LDS_BANK_CONFLICT"]/d["SQ_LDS_IDX_ACTIVE"]:.0f} % (delta) vs {100*s6["SQ_LDS_BANK_CONFLICT"]/s6["SQ_LDS_IDX_ACTIVE"]:.0f} % (segments);
+  LDS pipe busy cycles {d["SQ_LDS_IDX_ACTIVE"]/1e6:.1f} M vs {s6["SQ_LDS_IDX_ACTIVE"]/1e6:.1f} M.
+* waves parked (`SQ_WAIT_ANY`) {100*d["SQ_WAIT_ANY"]/d["SQ_WAVE_CYCLES"]:.0f} % of their life (segments: {100*s6["SQ_WAIT_ANY"]/s6["SQ_WAVE_CYCLES"]:.0f} %); VALU instructions {d["SQ_INSTS_VALU"]/1e6:.1f} M vs {s6["SQ_INSTS_VALU"]/1e6:.1f} M.
+''')
+print(line["value"], line["ms_per_step"], line["roofline"], tot("delta"), tot("c5"))
