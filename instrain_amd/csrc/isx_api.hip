@@ -875,18 +875,21 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
         std::vector<uint32_t> h_rec, h_gbase, h_pair;
         isxenc::SegJob J;
         int64_t slack = 1;
+        std::vector<int64_t> exact;             // second attempt: every task's region is what the first one found it needs
         for (int attempt = 0;; attempt++) {     // a second time when segments differ from the reference so often that their pieces outgrow a task's spare groups
-            const int64_t cap_rec = isxenc::delta_groups_needed(pool, segs->gpos, segs->n_seg, slack) * ISX_DREC_GROUP;
+            int64_t cap_rec = isxenc::delta_groups_needed(pool, segs->gpos, segs->n_seg, slack) * ISX_DREC_GROUP;
+            if (!exact.empty()) { cap_rec = 0; for (int64_t v : exact) cap_rec += std::max<int64_t>(v, 1) * ISX_DREC_GROUP; }
             h_rec.resize((size_t)cap_rec * ISX_DREC_WORDS); h_gbase.resize((size_t)(cap_rec / ISX_DREC_GROUP));
             if (prm->enable_linkage) h_pair.resize((size_t)cap_rec);
             st.cmin.assign(h_gbase.size(), 0xFFFFFFFFu); st.cmax.assign(h_gbase.size(), 0u); st.cany.assign(h_gbase.size(), 0);
             J = isxenc::SegJob();
             J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = b->M; J.ref = ref; J.slack_groups = slack;
+            J.task_groups = exact.empty() ? nullptr : exact.data();
             if (!prm->enable_linkage) J.in.pair = nullptr;
             J.rec = h_rec.data(); J.gbase = h_gbase.data(); J.pair_out = prm->enable_linkage ? h_pair.data() : nullptr;
             J.cmin = st.cmin.data(); J.cmax = st.cmax.data(); J.cany = st.cany.data(); J.cap_rec = cap_rec;
             const int erc = isxenc::encode_delta(pool, J);
-            if (erc == isxenc::SEG_CAPACITY && J.need_slack > slack && attempt == 0) { slack = J.need_slack; continue; }
+            if (erc == isxenc::SEG_CAPACITY && J.need_slack > slack && attempt == 0) { exact = J.task_need; continue; }
             if (erc != isxenc::SEG_OK) {
                 isx_batch_destroy(b);
                 if (erc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
@@ -1040,7 +1043,7 @@ int launch_pass(isx_batch *b)
 
     PileupArgs a{};
     a.seg = b->d_seg; a.drec = b->d_drec; a.dlt_off = b->dlt_off;
-    a.rec = b->d_rec; a.rec32 = b->d_rec32; a.rec16 = b->d_rec16; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref; a.ref_packed = b->ref_packed ? 1 : 0;
+    a.rec = b->d_rec; a.rec32 = b->d_rec32; a.rec16 = b->d_rec16; a.gbase = b->d_gbase; a.win_range = b->d_win; a.ref = b->d_ref; a.ref_packed = b->ref_packed; a.ref_n = b->d_ref_n;
     a.pair = b->d_pair; a.pair_runs = b->d_pair_runs; a.run_index = b->d_run_index; a.n_runs = b->n_runs; a.gpos = b->d_gpos; a.gpos16 = b->d_gpos16; a.chunk_base = b->d_rec32 ? b->d_gbase : b->d_cbase; a.gpos16_shift = b->gpos16_shift; a.thr = b->d_thr; a.lut_n = c->lut_n; a.fallback = c->fallback; a.qcap = b->qcap; a.rqcap = b->rqcap; a.stage_off = b->stage_off;
     a.n_pos = (uint32_t)b->n_pos; a.W = b->W; a.logW = b->logW; a.M = b->M; a.n_win = b->n_win;
     a.min_cov = b->prm.min_cov; a.min_freq = b->prm.min_freq;

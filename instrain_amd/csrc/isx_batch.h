@@ -54,7 +54,8 @@ struct isx_batch {
     uint16_t *d_gpos16 = nullptr;
     int gpos16_shift = 7;
     uint8_t *d_ref = nullptr;
-    bool ref_packed = false;            // pipe slots: two reference codes per byte (PileupArgs::ref_packed)
+    int ref_packed = 0;                 // pipe slots: 2 = a 2-bit plane (+ d_ref_n: bit plane of the positions that are not A/C/T/G), see PileupArgs
+    uint8_t *d_ref_n = nullptr;
     uint2 *d_win = nullptr;
     uint16_t *d_thr = nullptr;
     int qcap = 1024, rqcap = 0, stage_off = 0;

@@ -172,8 +172,9 @@ struct PileupArgs {
     const uint4 *drec;          // ... reference-delta stream (one mm bin; rec, rec32, rec16, seg == NULL): 32-byte records as two 16-byte halves
                                 //     (include/instrain_amd.h ISX_DREC_*), start = gbase[record / 32] + delta; `pair` is indexed by RECORD
     const uint2 *win_range;     // per window: [lo, hi) in records (multiples of ISX_CHUNK; of ISX_SEG_GROUP for the segment stream)
-    const uint8_t *ref;         // reference base code per flat position -- or, ref_packed (pipe slots: half the bytes over PCIe), two per
-    int32_t ref_packed;         // byte: position 2 i in the low nibble of byte i, 2 i + 1 in the high one
+    const uint8_t *ref;         // reference base code per flat position (ref_packed 0) -- or, in a pipe slot, packed: 1 = two codes per byte
+    int32_t ref_packed;         // (round 3: position 2 i in the low nibble of byte i), 2 = a 2-bit plane, four positions a byte (A C T G), with
+    const uint8_t *ref_n;       // ref_n = bit plane of the positions that are NOT A/C/T/G (NULL: the batch has none): 0.25 / 0.375 B a position
     const uint32_t *pair;       // read-pair id per record (linkage only), or NULL and ...
     const uint2 *pair_runs;     // ... runs of equal pair ids: (first device record, pair id), ascending; run_index[c] = the run
     const uint32_t *run_index;  //     that holds device record 1024 c (pipe slots: ~0.06 B per record over PCIe instead of 4)

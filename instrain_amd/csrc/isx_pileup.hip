@@ -90,6 +90,10 @@ __device__ __forceinline__ void publish_previous(const PileupArgs &a, int tid)
 // reference base code of a flat position (see PileupArgs::ref_packed)
 __device__ __forceinline__ uint8_t ref_at(const PileupArgs &a, uint32_t gpos)
 {
+    if (a.ref_packed == 2) {
+        if (a.ref_n && ((a.ref_n[gpos >> 3] >> (gpos & 7u)) & 1u)) return 4;
+        return (uint8_t)((a.ref[gpos >> 2] >> ((gpos & 3u) << 1)) & 3u);
+    }
     if (a.ref_packed) return (uint8_t)((a.ref[gpos >> 1] >> ((gpos & 1u) << 2)) & 0xFu);
     return a.ref[gpos];
 }
@@ -442,6 +446,18 @@ __device__ __forceinline__ uint32_t pair_other(uint32_t x)
 __device__ __forceinline__ uint32_t ref4_at(const PileupArgs &a, uint32_t gpos)
 {
     if (gpos + 3u < a.n_pos) {
+        if (a.ref_packed == 2) {
+            const uint32_t h = a.ref[gpos >> 2];
+            uint32_t r = (h & 3u) | ((h & 0xCu) << 6) | ((h & 0x30u) << 12) | ((h & 0xC0u) << 18);
+            if (a.ref_n) {
+                const uint32_t nb = ((uint32_t)a.ref_n[gpos >> 3] >> (gpos & 4u)) & 0xFu;
+                if (nb) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if ((nb >> k) & 1u) r = (r & ~(0xFFu << (8 * k))) | (4u << (8 * k));
+                }
+            }
+            return r;
+        }
         if (a.ref_packed) {
             const uint32_t h = *reinterpret_cast<const uint16_t *>(a.ref + (gpos >> 1));
             return (h & 0xFu) | ((h & 0xF0u) << 4) | ((h & 0xF00u) << 8) | ((h & 0xF000u) << 12);

@@ -16,6 +16,7 @@
 // A slot is a complete isx_batch whose device tables are sized once for the pipe's largest batch, so a
 // submit allocates nothing and everything isx_batch_* offers (linkage stages, entry fetch, summaries,
 // compare) works on a collected slot unchanged.
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -94,6 +95,7 @@ struct Slot {
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_pass = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     int64_t ticket = -1;
     BamBatch *dead_batch = nullptr;         // isx_pipe_submit_bam: the front end's batch, freed by the finisher after the slot's work
+    bool ref_has_n = false;                 // the batch's reference holds positions that are not A/C/T/G: their bit plane travels too
     int state = 0;                          // 0 free, 1 submitted, 2 finished (tables on the host, linkage done)
     int rc = 0;                             // of the finishing step
     std::string err;
@@ -103,6 +105,44 @@ struct Slot {
     int64_t h2d_bytes = 0, d2h_bytes = 0;
     uint16_t *d_gpos16 = nullptr;           // compact stream + linkage: positions alone for the allele pass
 };
+
+// The reference codes of a batch as they travel and lie in a slot: a 2-bit plane (A C T G; anything else as 0), four positions a
+// byte, and -- only when the batch holds a position that is not A/C/T/G -- a bit plane marking those (PileupArgs::ref_packed == 2,
+// ref_n).  0.25 (0.375) bytes a position over PCIe instead of 0.5 (round 3's nibbles) or 1.  plane2 holds (n_pos + 3) / 4 bytes,
+// nplane (n_pos + 7) / 8; returns whether the N plane is needed (it is always written).
+static inline size_t ref2_bytes(int64_t n_pos) { return (((size_t)n_pos + 3) / 4 + 15) & ~(size_t)15; }
+static inline size_t refn_bytes(int64_t n_pos) { return (((size_t)n_pos + 7) / 8 + 15) & ~(size_t)15; }
+static bool pack_ref2(isxenc::HostPool &pool, const uint8_t *ref, int64_t n_pos, uint8_t *plane2, uint8_t *nplane)
+{
+    const int64_t piece = (int64_t)256 << 10;               // a multiple of 8
+    const int n_tasks = (int)((n_pos + piece - 1) / piece);
+    std::atomic<int> any{0};
+    auto cp = [&](int t) {
+        const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
+        uint8_t *o2 = plane2 + (a >> 2), *on = nplane + (a >> 3);
+        const uint8_t *r = ref + a;
+        const int64_t n = e - a;
+        bool seen = false;
+        for (int64_t i = 0; i < n; i += 8) {
+            uint32_t lo = 0, hi = 0, nb = 0;
+            const int64_t m = std::min<int64_t>(8, n - i);
+            for (int64_t k = 0; k < m; k++) {
+                const uint32_t c = r[i + k];
+                const uint32_t bad = c > 3u;
+                nb |= bad << k;
+                const uint32_t v = bad ? 0u : c;
+                if (k < 4) lo |= v << (2 * k); else hi |= v << (2 * (k - 4));
+            }
+            o2[i >> 2] = (uint8_t)lo;
+            if (m > 4) o2[(i >> 2) + 1] = (uint8_t)hi;
+            on[i >> 3] = (uint8_t)nb;
+            seen |= nb != 0;
+        }
+        if (seen) any.store(1, std::memory_order_relaxed);
+    };
+    if (n_tasks > 1) pool.run(n_tasks, cp); else if (n_tasks == 1) cp(0);
+    return any.load() != 0;
+}
 
 int cgroup_cpus()
 {
@@ -286,7 +326,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.b = b;
     b->ctx = c; b->prm = *prm; b->M = prm->n_mm_bins;
     b->ps = index & 1;
-    b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true; b->ref_packed = true;
+    b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true; b->ref_packed = 2;
     b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
     b->segs = p->segs; b->drec = p->drec;
     const bool dense = b->M == 1;
@@ -348,7 +388,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     size_t o = 0;
     s.off_bounds = o; o = up(o + (size_t)(p->pp.max_splits + 1) * sizeof(int64_t));
     s.off_win = o; o = up(o + ((size_t)cap_pos / 64 + 2) * sizeof(uint2));
-    s.off_ref = o; o = up(o + (size_t)cap_pos);
+    s.off_ref = o; o = up(o + ref2_bytes(cap_pos) + refn_bytes(cap_pos));        // 2-bit plane | non-ACGT bit plane
     s.off_gbase = o; o = up(o + ((size_t)(p->cap_rec / p->G) + ISX_TAIL_GROUPS) * sizeof(uint32_t));
     s.off_ridx = o; if (prm->enable_linkage && !p->segs) o = up(o + ((size_t)p->cap_rec / ISX_CHUNK + 2) * sizeof(uint32_t));
     s.off_pairs = o; if (prm->enable_linkage && p->segs) o = up(o + (size_t)p->cap_rec * sizeof(uint32_t));
@@ -889,20 +929,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     }
     if (J.passes > 1 && J.n_groups_in > 0)            // remember how jumpy this stream is: the next batch gets its slack up front
         p->slack = std::max(p->slack, 1.25 * ((double)J.n_groups_real / (double)J.n_groups_in - 1.0) + 0.01);
-    {
-        const int64_t piece = (int64_t)256 << 10;
-        const int n_tasks = (int)((n_pos + piece - 1) / piece);
-        uint8_t *dst = s.h_in + s.off_ref;
-        auto cp = [&](int t) {      // two codes per byte (piece is even): half the reference bytes cross PCIe
-            const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
-            uint8_t *o = dst + (a >> 1);
-            const uint8_t *r = ref + a;
-            const int64_t n2 = (e - a) >> 1;
-            for (int64_t i = 0; i < n2; i++) o[i] = (uint8_t)((r[2 * i] & 0xF) | (r[2 * i + 1] << 4));
-            if ((e - a) & 1) o[n2] = (uint8_t)(r[e - a - 1] & 0xF);
-        };
-        if (n_tasks > 1) p->pool->run(n_tasks, cp); else cp(0);
-    }
+    s.ref_has_n = pack_ref2(*p->pool, ref, n_pos, s.h_in + s.off_ref, s.h_in + s.off_ref + ref2_bytes(n_pos));
     memcpy(s.h_in + s.off_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t));
 
     // ---- this batch's geometry ----
@@ -935,6 +962,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     b->d_bounds = reinterpret_cast<int64_t *>(s.d_in + s.off_bounds);
     b->d_win = reinterpret_cast<uint2 *>(s.d_in + s.off_win);
     b->d_ref = s.d_in + s.off_ref;
+    b->d_ref_n = s.ref_has_n ? s.d_in + s.off_ref + ref2_bytes(b->n_pos) : nullptr;
     b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
     b->d_rec16 = p->rb == 2 ? reinterpret_cast<uint16_t *>(s.d_in + s.off_rec) : nullptr;
     b->d_rec32 = p->rb == 4 ? reinterpret_cast<uint32_t *>(s.d_in + s.off_rec) : nullptr;
@@ -950,12 +978,16 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
 
     // ---- copy-in queue ----
     if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
-    const size_t head = s.off_ref + ((size_t)n_pos + 1) / 2;               // bounds | windows | reference codes (two per byte)
+    const size_t ref_bytes = ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0);   // 2-bit plane (+ the non-ACGT bit plane)
+    const size_t head = (size_t)(n_splits + 1) * sizeof(int64_t) + s.win.size() * sizeof(uint2) + ref_bytes;
     // the stream is followed by a tail of padding records / zero bases (see ISX_TAIL_BYTES): the slot's arena still
     // holds the previous batch there
     memset(s.h_in + s.off_gbase + (size_t)(b->n_rec / p->G) * sizeof(uint32_t), 0, ISX_TAIL_GROUPS * sizeof(uint32_t));
     const size_t gb_bytes = ((size_t)(b->n_rec / p->G) + ISX_TAIL_GROUPS) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * p->rb + ISX_TAIL_BYTES;
-    HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, head, hipMemcpyHostToDevice, p->s_h2d));
+    // bounds | windows | reference planes: what is used of each region, not the regions (a slot is sized for the largest batch)
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, s.h_in + s.off_win, s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, s.h_in + s.off_ref, ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
     if (ring) {             // the records left wave by wave; the tail is written on the device
         if (p->rb == 2) HIP_TRY(hipMemsetD8Async(reinterpret_cast<hipDeviceptr_t>(d_rec + (size_t)b->n_rec * 2), 0xFF, ISX_TAIL_BYTES, p->s_h2d));
@@ -1036,14 +1068,27 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         // differences take spare groups of their task's region -- a batch that needs more than the pipe has learned so far is
         // encoded a second time (ring mode: its waves simply travel again)
         J.ref = ref;
+        std::vector<int64_t> exact;
+        s.encode_passes = 1;
         for (int attempt = 0;; attempt++) {
             J.slack_groups = p->dslack;
+            J.task_groups = exact.empty() ? nullptr : exact.data();
             ring_bytes = 0;
             erc = isxenc::encode_delta(*p->pool, J);
-            if (erc == isxenc::SEG_CAPACITY && J.need_slack > p->dslack && attempt == 0) { p->dslack = J.need_slack; continue; }
+            if (erc == isxenc::SEG_CAPACITY && J.need_slack > p->dslack && attempt == 0) {
+                // the second attempt gives every task exactly what the first one found it needs; the pipe remembers the AVERAGE
+                // surplus (data that differs from the reference everywhere then fits at once; one task over a stretch where the
+                // reference is not A/C/T/G does not inflate the others)
+                exact = J.task_need;
+                int64_t tot = 0;
+                for (int64_t v : exact) tot += v;
+                const int64_t n_t = (int64_t)exact.size(), base_tot = J.n_rec / ISX_DREC_GROUP - n_t * p->dslack;
+                p->dslack = std::max<int64_t>(p->dslack, 1 + (tot - base_tot + n_t - 1) / std::max<int64_t>(n_t, 1));
+                s.encode_passes = 2;
+                continue;
+            }
             break;
         }
-        s.encode_passes = erc == isxenc::SEG_OK && J.need_slack == p->dslack && p->dslack > 1 ? 2 : 1;
     } else erc = isxenc::encode_segs(*p->pool, J);
     const double t_enc = now_ms();
     if (ring_err != hipSuccess) { isx_set_error(std::string("isx_pipe_submit_reads: staging ring: ") + hipGetErrorString(ring_err)); return ISX_ERR_HIP; }
@@ -1052,20 +1097,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (erc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
     if (erc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
     if (J.n_bases > p->pp.max_obs) { isx_set_error("isx_pipe_submit_reads: more bases than the pipe's max_obs"); return ISX_ERR_CAPACITY; }
-    {
-        const int64_t piece = (int64_t)256 << 10;
-        const int n_tasks = (int)((n_pos + piece - 1) / piece);
-        uint8_t *dst = s.h_in + s.off_ref;
-        auto cp = [&](int t) {      // two codes per byte (piece is even): half the reference bytes cross PCIe
-            const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
-            uint8_t *o = dst + (a >> 1);
-            const uint8_t *r = ref + a;
-            const int64_t n2 = (e - a) >> 1;
-            for (int64_t i = 0; i < n2; i++) o[i] = (uint8_t)((r[2 * i] & 0xF) | (r[2 * i + 1] << 4));
-            if ((e - a) & 1) o[n2] = (uint8_t)(r[e - a - 1] & 0xF);
-        };
-        if (n_tasks > 1) p->pool->run(n_tasks, cp); else cp(0);
-    }
+    s.ref_has_n = pack_ref2(*p->pool, ref, n_pos, s.h_in + s.off_ref, s.h_in + s.off_ref + ref2_bytes(n_pos));
     const double t_ref = now_ms();
     memcpy(s.h_in + s.off_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t));
 
@@ -1099,6 +1131,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     b->d_bounds = reinterpret_cast<int64_t *>(s.d_in + s.off_bounds);
     b->d_win = reinterpret_cast<uint2 *>(s.d_in + s.off_win);
     b->d_ref = s.d_in + s.off_ref;
+    b->d_ref_n = s.ref_has_n ? s.d_in + s.off_ref + ref2_bytes(b->n_pos) : nullptr;
     b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
     b->d_seg = p->drec ? nullptr : reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
     b->d_drec = p->drec ? reinterpret_cast<uint4 *>(s.d_in + s.off_rec) : nullptr;
@@ -1114,9 +1147,13 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
 
     // ---- copy-in queue: bounds | windows | reference codes, then group bases (| pair ids) | records ----
     if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
-    const size_t head = s.off_ref + ((size_t)n_pos + 1) / 2;              // (reference codes two per byte)
+    const size_t ref_bytes = ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0);   // 2-bit plane (+ the non-ACGT bit plane)
+    const size_t head = (size_t)(n_splits + 1) * sizeof(int64_t) + s.win.size() * sizeof(uint2) + ref_bytes;
     const size_t gb_bytes = (size_t)(b->n_rec / p->G) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * (size_t)p->rb;
-    HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, head, hipMemcpyHostToDevice, p->s_h2d));
+    // bounds | windows | reference planes: what is used of each region, not the regions (a slot is sized for the largest batch)
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, s.h_in + s.off_win, s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, s.h_in + s.off_ref, ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
     if (ring) { if (ring_bytes != rec_bytes) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; } }
     else HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
@@ -1143,6 +1180,7 @@ struct isx_wire {
     int32_t n_splits = 0;
     uint64_t n_pairs = 0;
     int W = 0, packed = 0;
+    bool ref_has_n = false;
     float stage_ms = 0.f;
     int encode_passes = 1;
 };
@@ -1177,14 +1215,16 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     isxenc::SegJob J;
     std::vector<uint32_t> cmin, cmax;
     std::vector<uint8_t> cany;
+    std::vector<int64_t> exact;                 // second attempt: every encoder task's region is what the first one found it needs
     for (int attempt = 0;; attempt++) {
         // exact record capacity of this batch (the encoder's own counting pass), at most the pipe's
         int64_t cap = p->drec ? isxenc::delta_groups_needed(*p->pool, segs->gpos, segs->n_seg, p->dslack) * ISX_DREC_GROUP
                               : isxenc::seg_groups_needed(*p->pool, segs->gpos, segs->n_seg) * ISX_SEG_GROUP;
+        if (!exact.empty()) { cap = 0; for (int64_t v : exact) cap += std::max<int64_t>(v, 1) * ISX_DREC_GROUP; }
         if (cap > p->cap_rec) { isx_set_error("isx_pipe_stage_reads: the stream needs more records than the pipe's capacity (raise jump_slack)"); return ISX_ERR_CAPACITY; }
         const size_t n_groups = (size_t)cap / G;
         w->bounds_bytes = (size_t)(n_splits + 1) * sizeof(int64_t);
-        w->ref_bytes = ((size_t)n_pos + 1) / 2;
+        w->ref_bytes = ref2_bytes(n_pos) + refn_bytes(n_pos);       // (the non-ACGT plane only travels when the batch has such a position)
         const size_t win_cap = ((size_t)n_pos / 64 + 2) * sizeof(uint2);       // (the smallest window is 64 positions)
         size_t o = 0;
         w->o_bounds = o; o = up(o + w->bounds_bytes);
@@ -1208,8 +1248,9 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         int erc;
         if (p->drec) {
             J.ref = ref; J.slack_groups = p->dslack;
+            J.task_groups = exact.empty() ? nullptr : exact.data();
             erc = isxenc::encode_delta(*p->pool, J);
-            if (erc == isxenc::SEG_CAPACITY && J.need_slack > p->dslack && attempt == 0) { p->dslack = J.need_slack; w->encode_passes = 2; continue; }
+            if (erc == isxenc::SEG_CAPACITY && J.need_slack > p->dslack && attempt == 0) { exact = J.task_need; w->encode_passes = 2; continue; }
         } else erc = isxenc::encode_segs(*p->pool, J);
         if (erc == isxenc::SEG_CAPACITY) { isx_set_error("isx_pipe_stage_reads: the stream does not fit the record capacity"); return ISX_ERR_CAPACITY; }
         if (erc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
@@ -1222,20 +1263,8 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     w->gbase_bytes = (size_t)(J.n_rec / (int64_t)G) * sizeof(uint32_t);
     w->rec_bytes = (size_t)J.n_rec * rb;
     w->pairs_bytes = linkage ? (size_t)J.n_rec * sizeof(uint32_t) : 0;
-    {   // reference codes, two per byte
-        const int64_t piece = (int64_t)256 << 10;
-        const int n_tasks = (int)((n_pos + piece - 1) / piece);
-        uint8_t *dst = w->h + w->o_ref;
-        auto cp = [&](int t) {
-            const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
-            uint8_t *o = dst + (a >> 1);
-            const uint8_t *r = ref + a;
-            const int64_t n2 = (e - a) >> 1;
-            for (int64_t i = 0; i < n2; i++) o[i] = (uint8_t)((r[2 * i] & 0xF) | (r[2 * i + 1] << 4));
-            if ((e - a) & 1) o[n2] = (uint8_t)(r[e - a - 1] & 0xF);
-        };
-        if (n_tasks > 1) p->pool->run(n_tasks, cp); else cp(0);
-    }
+    w->ref_has_n = pack_ref2(*p->pool, ref, n_pos, w->h + w->o_ref, w->h + w->o_ref + ref2_bytes(n_pos));
+    if (!w->ref_has_n) w->ref_bytes = ref2_bytes(n_pos);
     memcpy(w->h + w->o_bounds, split_bounds, w->bounds_bytes);
     {   // the window directory, for the window this pipe's kernels will use on a batch of n_pos positions
         const uint64_t n_chunks = (uint64_t)J.n_rec / G;
@@ -1284,6 +1313,7 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     const double t0 = now_ms();
     const bool dense = b->M == 1, linkage = p->prm.enable_linkage != 0;
     b->n_pos = w->n_pos; b->n_obs = w->n_bases; b->n_splits = w->n_splits; b->n_rec = (uint64_t)w->n_rec;
+    s.ref_has_n = w->ref_has_n;
     b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)w->n_pos;
     b->n_pairs = w->n_pairs;
@@ -1299,6 +1329,7 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     b->d_bounds = reinterpret_cast<int64_t *>(s.d_in + s.off_bounds);
     b->d_win = reinterpret_cast<uint2 *>(s.d_in + s.off_win);
     b->d_ref = s.d_in + s.off_ref;
+    b->d_ref_n = s.ref_has_n ? s.d_in + s.off_ref + ref2_bytes(b->n_pos) : nullptr;
     b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
     b->d_seg = p->drec ? nullptr : reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
     b->d_drec = p->drec ? reinterpret_cast<uint4 *>(s.d_in + s.off_rec) : nullptr;

@@ -327,7 +327,8 @@ int encode_delta(HostPool &pool, SegJob &J)
     const int n_tasks = (int)((n + TASK - 1) / TASK);
     const int64_t slack = std::max<int64_t>(J.slack_groups, 1);
     std::vector<int64_t> g_at((size_t)n_tasks + 1, 0);
-    pool.run(n_tasks, [&](int t) {
+    if (J.task_groups) for (int t = 0; t < n_tasks; t++) g_at[(size_t)t + 1] = std::max<int64_t>(J.task_groups[t], 1);
+    else pool.run(n_tasks, [&](int t) {
         const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
         g_at[(size_t)t + 1] = count_groups(gpos_all, a, e, ISX_DREC_GROUP) + slack;
     });
@@ -482,13 +483,16 @@ int encode_delta(HostPool &pool, SegJob &J)
     if (err.load() != SEG_OK) return err.load();
     J.n_bases = 0; J.max_pair = 0; J.n_pieces = 0;
     int64_t worst = 0;
+    bool fits = true;
+    J.task_need.assign(need_of.begin(), need_of.begin() + n_tasks);
     for (int t = 0; t < n_tasks; t++) {
         J.n_bases += bases_of[(size_t)t]; J.max_pair = std::max(J.max_pair, maxp_of[(size_t)t]); J.n_pieces += pieces_of[(size_t)t];
         const int64_t region = g_at[(size_t)t + 1] - g_at[(size_t)t];
-        worst = std::max(worst, need_of[(size_t)t] - (region - slack));
+        if (need_of[(size_t)t] > region) fits = false;
+        worst = std::max(worst, need_of[(size_t)t] - (region - (J.task_groups ? 0 : slack)));
     }
-    J.need_slack = worst;
-    if (worst > slack) return SEG_CAPACITY;         // some task outgrew its region: encode again with slack_groups >= need_slack
+    J.need_slack = fits ? slack : std::max<int64_t>(worst, slack + 1);
+    if (!fits) return SEG_CAPACITY;                 // some task outgrew its region: encode again with task_groups = task_need
     return SEG_OK;
 }
 

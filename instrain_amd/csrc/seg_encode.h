@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include <functional>
+#include <vector>
 
 #include "../../include/instrain_amd.h"
 #include "obs_encode.h"
@@ -50,6 +51,11 @@ struct SegJob {
     const uint8_t *ref = nullptr;
     int64_t slack_groups = 1;
     int64_t need_slack = 0;
+    // every run reports the groups each task of 4096 segments really needs (task_need); a second run may be given exactly those
+    // (task_groups, one entry per task) instead of "starts + slack_groups": one task over a stretch where the reference is not
+    // A/C/T/G (every base there is an exception) then does not inflate the regions of all the others
+    std::vector<int64_t> task_need;
+    const int64_t *task_groups = nullptr;
     int64_t n_pieces = 0;                       // delta records written (>= n_seg)
     // results
     int64_t n_rec = 0;                          // device records, a multiple of ISX_SEG_GROUP

@@ -21,8 +21,15 @@ def ctx():
 
 def small_workload(seed, genome_len, coverage, skip_mm, n_sites=None):
     from instrain_amd import synth
-    return synth.make_workload(genome_len=genome_len, coverage=coverage, n_sites=n_sites or genome_len // 200, seed=seed,
-                               skip_mm=skip_mm, af_lo=0.2, af_hi=0.5)
+    w = synth.make_workload(genome_len=genome_len, coverage=coverage, n_sites=n_sites or genome_len // 200, seed=seed,
+                            skip_mm=skip_mm, af_lo=0.2, af_hi=0.5)
+    if seed % 2:            # every other workload: a reference with positions that are not A/C/T/G (a slot's 2-bit plane + its bit plane)
+        rng = np.random.Generator(np.random.PCG64(seed + 500))
+        ref = w["ref_codes"].copy()
+        ref[rng.random(len(ref)) < 0.003] = 4
+        ref[len(ref) // 2:len(ref) // 2 + 300] = 4
+        w["ref_codes"] = ref
+    return w
 
 
 def one_shot(ctx, w, **kw):

@@ -190,16 +190,25 @@ def test_segments_straddling_windows_and_far_jumps(ctx):
             assert (c.astype(np.int64) == exp).all(), (window, layout)
 
 
-def _c2(scale=1.0, seed=2, skip_mm=True):
+def _c2(scale=1.0, seed=2, skip_mm=True, with_n=False):
+    """with_n: positions that are not A/C/T/G in the reference (isolated ones and a run): a pipe slot then carries the bit plane
+    that marks them beside its 2-bit reference plane"""
     from instrain_amd import synth
-    return synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale), seed=seed, skip_mm=skip_mm)
+    w = synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale), seed=seed, skip_mm=skip_mm)
+    if with_n:
+        rng = np.random.Generator(np.random.PCG64(seed + 99))
+        ref = w["ref_codes"].copy()
+        ref[rng.random(len(ref)) < 0.004] = 4
+        ref[len(ref) // 3:len(ref) // 3 + 700] = 4
+        w["ref_codes"] = ref
+    return w
 
 
 @pytest.mark.parametrize("skip_mm,linkage,layout", [(True, False, 0), (True, True, 0), (True, True, NOPACK), (True, True, SEG64), (False, True, 0)])
 def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage, layout):
     """a C2 slice through the read-level pipe == the same observations through a resident batch, every table"""
     from instrain_amd import engine, synth
-    w = _c2(0.1, seed=4, skip_mm=skip_mm)
+    w = _c2(0.1, seed=4, skip_mm=skip_mm, with_n=linkage)
     M = w["n_mm_bins"]
     segs = synth.segs_from_obs(w["obs"], w["pair"])
     kw = dict(n_mm_bins=M, enable_linkage=linkage, min_snp=20, layout=layout)
@@ -348,7 +357,7 @@ def test_staged_batches_equal_submits(ctx, skip_mm, linkage, layout):
     tables isx_pipe_submit_reads gives; a wire can be submitted again and again, interleaved with other wires and plain submits;
     a wire of another pipe is refused"""
     from instrain_amd import engine, synth
-    ws = [_c2(0.05, seed=31 + i, skip_mm=skip_mm) for i in range(2)]
+    ws = [_c2(0.05, seed=31 + i, skip_mm=skip_mm, with_n=(i == 1)) for i in range(2)]
     M = max(w["n_mm_bins"] for w in ws)
     segs = [synth.segs_from_obs(w["obs"], w["pair"]) for w in ws]
     kw = dict(n_mm_bins=M, enable_linkage=linkage, min_snp=20, layout=layout)
