@@ -730,7 +730,13 @@ int isx_ctx_create(int device_id, isx_ctx **out)
     isx_ctx *c = new isx_ctx();
     c->device = device_id;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&c->pstream[i], hipStreamNonBlocking));
+    {   // the pass queues get the highest stream priority: a pileup kernel is a persistent grid sized for the whole device -- when the
+        // copy kernels and the linkage chains of other batches hold some of the wave slots, its late workgroups delay the whole pass
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+        const int prio = getenv("ISX_NO_STREAM_PRIORITY") ? least : greatest;
+        for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithPriority(&c->pstream[i], hipStreamNonBlocking, prio));
+    }
     c->pin_bytes = (size_t)64 << 20;
     for (int i = 0; i < 2; i++) {
         HIP_TRY(hipHostMalloc(&c->pin[i], c->pin_bytes, hipHostMallocDefault));
