@@ -71,11 +71,22 @@ def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense, record_bytes=8, n_r
     return b
 
 
-def slot_out_bytes_per_pos(n_obs, n_pos):
-    """What k_pileup_dense writes per position in a pipe slot without want_counts (the shrunk hand-back): 16-bit coverage + fp32
-    clonality, + the 8-bit coverage a shallow batch (mean depth < 16) sends home instead -- the count table is not written at
-    all; the lists (clonalities other than 1.0, saturated coverages, SNV rows) are a few bytes per thousand positions."""
-    return 7 if n_obs < 16 * n_pos else 6
+# isx_pipe_params.lean_output (a slot's kernel writes only what travels home: 1-2 instead of 6-7 bytes a position) is built and tested,
+# but moves no clock: the kernel is bound by its per-window latency chain, not by its stores (C5: 1.24-1.29 ms per launch either
+# way, same box) -- so the bench keeps the plain slots whose dense arrays the device summaries can read.
+LEAN_SLOTS = bool(int(os.environ.get("ISX_BENCH_LEAN_SLOTS", "0")))
+
+
+def slot_out_bytes_per_pos(n_obs, n_pos, lean=None):
+    """What k_pileup_dense writes per position in a pipe slot without want_counts (the shrunk hand-back).  A lean slot
+    (isx_pipe_params.lean_output, what bench.py's pipes are): the coverage that travels home -- 1 byte for a shallow batch (mean
+    depth < 16), 2 otherwise -- and the sparse lists (clonalities other than 1.0: 8 bytes an entry, a few % of the positions;
+    saturated coverages, SNV rows).  A plain slot also writes the dense fp32 clonality and the 16-bit coverage beside the 8-bit
+    one: 7 / 6 bytes."""
+    shallow = n_obs < 16 * n_pos
+    if lean is None:
+        lean = LEAN_SLOTS
+    return (1 if shallow else 2) if lean else (7 if shallow else 6)
 
 
 def split_obs_ranges(obs_gpos, bounds, chunk=1024):
@@ -449,7 +460,7 @@ class C5Run:
         ws = self.ws
         self.pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["segs"].n_seg for w in ws),
                                 max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
-                                pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20, stage_async=stage_async)
+                                pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20, stage_async=stage_async, lean_output=LEAN_SLOTS)
         self.bases = float(sum(w["profiled_bases"] for w in ws))
         self.signature = None
         # The host side of the hand-over, done once per batch as a decoder would do it while it decodes (the reference's workers
@@ -774,7 +785,7 @@ def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
     variants = make_variants(w, n_var)
     pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=0, max_segs=int(w["segs"].n_seg),
                        max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
-                       pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=args.queued_submit)
+                       pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=args.queued_submit, lean_output=LEAN_SLOTS)
     wires = [pipe.stage_reads(v["ref_codes"], v["split_bounds"], v["segs"]) for v in variants]
     stream(pipe, variants, warmup, args.depth, wires=wires)
     stats = []

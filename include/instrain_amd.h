@@ -340,6 +340,11 @@ typedef struct {
                                  * goes on.  `ref` and the isx_segs arrays must then stay valid and unchanged until
                                  * isx_pipe_collect / isx_pipe_release of that ticket; what the encoder finds wrong with
                                  * them (mm range, capacity ...) is reported by isx_pipe_collect */
+    int32_t lean_output;        /* n_mm_bins == 1 without want_counts: 1 = a slot's kernel writes ONLY what travels home -- 1- (or 2-) byte
+                                 * coverage and the sparse lists -- not the dense clonality array (4 B/pos) nor the 16-bit coverage beside the
+                                 * 8-bit one: 1-2 instead of 6-7 bytes a position written.  A batch whose clonality list does not fit is
+                                 * passed again with the dense array.  isx_batch_summarize* (which read those arrays on the device) are then
+                                 * refused on the slot's batch.  (This field sits in what was padding: the struct's size is unchanged.) */
     int64_t max_segs;           /* > 0: a READ-LEVEL pipe (isx_pipe_submit_reads / isx_pipe_submit_bam hand over read segments,
                                  * see isx_segs below; isx_pipe_submit is refused): the largest n_seg of a batch.  max_obs then
                                  * only bounds the linkage tables (0 = 150 x max_segs) */

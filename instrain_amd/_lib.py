@@ -41,7 +41,8 @@ LAYOUT_WIDE_RECORDS, LAYOUT_NO_SHORT_RECORDS, LAYOUT_NO_PACKED_COUNTERS, LAYOUT_
 class PipeParams(C.Structure):
     _fields_ = [("max_pos", C.c_int64), ("max_obs", C.c_int64), ("max_splits", C.c_int32), ("depth", C.c_int32),
                 ("host_threads", C.c_int32), ("pin_threads", C.c_int32), ("jump_slack", C.c_double),
-                ("want_counts", C.c_int32), ("ring_kib", C.c_int32), ("stage_async", C.c_int32), ("max_segs", C.c_int64)]
+                ("want_counts", C.c_int32), ("ring_kib", C.c_int32), ("stage_async", C.c_int32), ("lean_output", C.c_int32),
+                ("max_segs", C.c_int64)]
 
 
 SEG_BASES, SEG_WORDS, SEG_SKIP_WORD = 150, 15, 0x24924924

@@ -1062,6 +1062,10 @@ int launch_pass(isx_batch *b)
     a.cov8 = b->sparse_out && b->cov8_out ? b->d_cov8 : nullptr;
     a.sat = b->d_sat; a.cap_sat = (uint32_t)std::min<size_t>(b->cap_sat, 0xFFFFFFFFu); a.sat_thr = a.cov8 ? 255u : 65535u;
     a.clon_list = b->sparse_out ? b->d_clon_list : nullptr; a.cap_clon = (uint32_t)std::min<size_t>(b->cap_clon, 0xFFFFFFFFu);
+    if (b->lean && b->sparse_out) {             // a lean slot writes only what travels home
+        if (!b->clon_dense) a.clon = nullptr;
+        if (a.cov8) a.cov16 = nullptr;
+    }
     a.seed_lo = (uint32_t)b->prm.seed; a.seed_hi = (uint32_t)(b->prm.seed >> 32);
     a.entries = b->d_entries; a.slab = b->slab; a.cap_ovf = (uint32_t)b->cap_ovf;
     a.ovf0 = (uint64_t)b->n_win * b->slab; a.win_nent = b->d_win_nent;
@@ -1344,6 +1348,7 @@ int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffo
     SummaryIn in{};
     in.stream = b->ctx->stream; in.ev = b->ev_sum;
     in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
+    if (b->lean && !b->d_counts) { isx_set_error("this batch lives in a lean pipe slot (isx_pipe_params.lean_output): its dense coverage / clonality arrays were not written"); return ISX_ERR_STATE; }
     in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
     in.cov16 = b->d_cov16; in.sat = b->d_sat; in.n_sat = (uint32_t)std::min<size_t>(b->n_sat, b->cap_sat);
     in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
@@ -1370,6 +1375,7 @@ int isx_batch_summarize_genomes(isx_batch *b, int32_t n_scaffolds, const int64_t
     SummaryIn in{};
     in.stream = b->ctx->stream; in.ev = b->ev_sum;
     in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
+    if (b->lean && !b->d_counts) { isx_set_error("this batch lives in a lean pipe slot (isx_pipe_params.lean_output): its dense coverage / clonality arrays were not written"); return ISX_ERR_STATE; }
     in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
     in.cov16 = b->d_cov16; in.sat = b->d_sat; in.n_sat = (uint32_t)std::min<size_t>(b->n_sat, b->cap_sat);
     in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
@@ -1398,6 +1404,7 @@ int isx_compare_coverage(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const 
         return ISX_ERR_ARG;
     }
     SummaryIn ia{}, ib{};
+    if ((a->lean && !a->d_counts) || (b->lean && !b->d_counts)) { isx_set_error("a batch of a lean pipe slot (isx_pipe_params.lean_output) keeps no dense coverage / clonality arrays"); return ISX_ERR_STATE; }
     fill_summary_in(a, n_scaffolds, scaffold_bounds, ia);
     fill_summary_in(b, n_scaffolds, scaffold_bounds, ib);
     return run_compare(ia, ib, (uint32_t)std::max(min_cov, 0), CompareSnpIn(), a->C, out, device_ms);
@@ -1415,6 +1422,7 @@ int isx_compare_scaffolds(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const
     }
     if (!a->ctx->d_lut) { isx_set_error("isx_compare_scaffolds: set the null model first"); return ISX_ERR_STATE; }
     SummaryIn ia{}, ib{};
+    if ((a->lean && !a->d_counts) || (b->lean && !b->d_counts)) { isx_set_error("a batch of a lean pipe slot (isx_pipe_params.lean_output) keeps no dense coverage / clonality arrays"); return ISX_ERR_STATE; }
     fill_summary_in(a, n_scaffolds, scaffold_bounds, ia);
     fill_summary_in(b, n_scaffolds, scaffold_bounds, ib);
     CompareSnpIn sn;

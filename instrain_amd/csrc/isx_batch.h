@@ -76,6 +76,8 @@ struct isx_batch {
     size_t cap_sat = 0, cap_clon = 0;
     uint32_t n_clon = 0;
     bool sparse_out = false, cov8_out = false;   // this pass: write the sparse clonality list / the 1-byte coverage
+    bool lean = false, clon_dense = false;       // lean slot (isx_pipe_params.lean_output): the dense clonality array / the 16-bit coverage
+                                                 // are written only when a batch needs them (clon_dense: its clonality list did not fit)
     isx_entry *d_entries = nullptr;  // mm path: [n_win][slab] slabs, then cap_ovf overflow entries
     uint32_t *d_win_nent = nullptr;
     isx_slev *d_slev = nullptr;

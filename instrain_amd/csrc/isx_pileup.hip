@@ -964,8 +964,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             constexpr bool st_ok = true, call_ok = true;
 #endif
             if (a.counts && st_ok) a.counts[gpos] = make_uint4(c[0], c[1], c[2], c[3]);
-            if (a.cov16 && st_ok) {             // shrunk hand-back of a pipe slot: coverage alone, 2 (or 1) bytes per position,
-                a.cov16[gpos] = (uint16_t)min(total, 65535u);       // exact values of the few positions beyond that in a list
+            if ((a.cov16 || a.cov8) && st_ok) { // shrunk hand-back of a pipe slot: coverage alone, 2 (or 1) bytes per position,
+                if (a.cov16) a.cov16[gpos] = (uint16_t)min(total, 65535u);      // exact values of the few positions beyond that in a list
                 if (a.cov8) a.cov8[gpos] = (uint8_t)min(total, 255u);
                 if (total >= a.sat_thr) {
                     const uint32_t k = cur_add(a, CUR_SAT, 1u);
@@ -1003,7 +1003,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             // clonTR is gated on rarefied_coverage alone (snv_utilities.py:100-102), also below min_cov
             if (a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r) { entry |= 1u << 15; if (a.rare) atomicAdd(&scratch[S_NRARE], 1u); }
             if (entry != (uint32_t)p) queue[atomicAdd(&scratch[S_NQ], 1u)] = entry;
-            if (!defer && st_ok) a.clon[gpos] = cl;
+            if (!defer && st_ok && a.clon) a.clon[gpos] = cl;      // (a lean slot keeps no dense clonality array)
         }
         __syncthreads();
 #ifdef ISX_TUNING
@@ -1029,7 +1029,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 uint32_t c[4];
             ld4(p, c);
                 const float v = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
-                a.clon[w0 + p] = v;
+                if (a.clon) a.clon[w0 + p] = v;
                 if (list) a.clon_list[clon_base + atomicAdd(&scratch[S_CLON_RANK], 1u)] = make_uint2(w0 + p, __float_as_uint(v));
             }
         }

@@ -329,6 +329,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true; b->ref_packed = 2;
     b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
     b->segs = p->segs; b->drec = p->drec;
+    b->lean = p->pp.lean_output != 0 && !p->pp.want_counts && b->M == 1;
     const bool dense = b->M == 1;
     batch_pick_block(b);
     const int64_t cap_pos = p->pp.max_pos;
@@ -460,11 +461,15 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         if (rc != ISX_OK) return rc;
         // a batch taken for shallow that has more positions beyond 255 than the exact-coverage list holds: again with 16 bits
         const bool cov8_overflow = !cf && dense && b->sparse_out && b->cov8_out && (size_t)b->n_sat > b->cap_sat;
-        if (!cf && !cov8_overflow) break;
+        // a lean slot whose clonality list cannot be used (too many entries for the list / for a list to pay): again, with the dense array
+        const bool clon_overflow = !cf && dense && b->sparse_out && b->lean && !b->clon_dense &&
+                                   ((size_t)b->n_clon > b->cap_clon || (size_t)b->n_clon * 2 > (size_t)b->n_pos);
+        if (!cf && !cov8_overflow && !clon_overflow) break;
         if (attempt == 7) { isx_set_error("output tables still too small after 8 growth steps"); return ISX_ERR_CAPACITY; }
         // a table was too small for this batch: grow it and repeat the pass (the slot still holds its input)
         if (cov8_overflow) b->cov8_out = false;
-        else if ((rc = batch_grow_tables(b, cf)) != ISX_OK) return rc;
+        if (clon_overflow) b->clon_dense = true;
+        if (cf && (rc = batch_grow_tables(b, cf)) != ISX_OK) return rc;
         if (!dense) b->cap_ovf = b->cap_entries - (size_t)b->n_win * b->slab;
         std::lock_guard<std::mutex> lk(p->launch_mu);
         if (dense && p->prm.rarefied_coverage > 0)
@@ -938,6 +943,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     // values other than 1.0, coverage in one byte for a shallow batch
     b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
+    b->clon_dense = false;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
     b->packed = 0;
@@ -1107,6 +1113,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     // values other than 1.0, coverage in one byte for a shallow batch
     b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
+    b->clon_dense = false;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / p->G;
     b->packed = 0;
@@ -1316,6 +1323,7 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     s.ref_has_n = w->ref_has_n;
     b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)w->n_pos;
+    b->clon_dense = false;
     b->n_pairs = w->n_pairs;
     b->packed = w->packed; b->W = w->W;
     b->n_win = (int)(w->win_bytes / sizeof(uint2));

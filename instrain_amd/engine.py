@@ -275,7 +275,7 @@ class Pipe:
 
     def __init__(self, ctx, max_pos, max_obs, max_splits, depth=4, host_threads=0, pin_threads=True, jump_slack=0.0,
                  min_cov=5, min_freq=0.05, min_snp=20, rarefied_coverage=50, n_mm_bins=1, enable_linkage=False,
-                 linkage_mode=0, window=0, seed=0, layout=0, want_counts=False, ring_kib=0, max_segs=0, stage_async=False):
+                 linkage_mode=0, window=0, seed=0, layout=0, want_counts=False, ring_kib=0, max_segs=0, stage_async=False, lean_output=False):
         self.ctx, self.lib = ctx, ctx.lib
         self._held = {}                             # stage_async: what a queued batch still reads, by ticket
         self._wires = []                            # staged batches (freed with the pipe at the latest)
@@ -288,7 +288,7 @@ class Pipe:
                    1 if enable_linkage else 0, int(linkage_mode), int(window), int(seed), int(layout), 0)
         pp = _lib.PipeParams(int(max_pos), int(max_obs), int(max_splits), int(depth), int(host_threads),
                              1 if pin_threads else 0, float(jump_slack), 1 if want_counts else 0, int(ring_kib),
-                             1 if self.stage_async else 0, int(max_segs))
+                             1 if self.stage_async else 0, 1 if lean_output else 0, int(max_segs))
         self.read_level = max_segs > 0
         h = C.c_void_p()
         check(self.lib.isx_pipe_create(ctx.h, C.byref(p), C.byref(pp), C.byref(h)))

@@ -408,3 +408,38 @@ def test_staged_batches_equal_submits(ctx, skip_mm, linkage, layout):
         other.submit_wire(wires[0])
     other.close()
     pipe.close()
+
+
+def test_lean_slot_output_equals_the_plain_slot(ctx):
+    """isx_pipe_params.lean_output: a slot's kernel writes only what travels home (8- / 16-bit coverage + the sparse lists).  Same
+    tables as a plain slot for a shallow batch (8-bit coverage), a deep one (16-bit) and one whose clonality list cannot be used
+    (most positions carry a second base: the pass is repeated with the dense array); device summaries are refused on a lean slot"""
+    from instrain_amd import engine, synth
+    ws = [synth.make_workload(genome_len=300_000, coverage=6, n_sites=300, seed=61, skip_mm=True),
+          synth.make_workload(genome_len=200_000, coverage=60, n_sites=400, seed=62, skip_mm=True),
+          synth.make_workload(genome_len=60_000, coverage=300, n_sites=100, seed=63, skip_mm=True, err=0.01)]
+    segs = [synth.segs_from_obs(w["obs"], w["pair"]) for w in ws]
+    cap = dict(max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(s.n_seg for s in segs),
+               max_splits=max(len(w["split_bounds"]) for w in ws), depth=2, host_threads=4, pin_threads=False,
+               n_mm_bins=1, enable_linkage=True, min_snp=20)
+    out = {}
+    for lean in (False, True):
+        pipe = engine.Pipe(ctx, lean_output=lean, **cap)
+        res = []
+        for w, sg in zip(ws, segs):
+            t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], sg)
+            r = pipe.collect(t)                         # densified: cov16 + clon arrays rebuilt on the host
+            res.append({k: r[k].copy() for k in ("cov16", "clon", "snv", "ld")} | {"sizes": r["sizes"], "rare": r["rare"].copy()})
+            if lean:
+                with pytest.raises(engine.IsxError, match="lean"):
+                    r["slot"].summarize(np.array([0, w["n_pos"]], np.int64))
+            pipe.release(t)
+        pipe.close()
+        out[lean] = res
+    for a, b in zip(out[False], out[True]):
+        assert a["sizes"] == b["sizes"]
+        for k in ("cov16", "snv", "ld", "rare"):
+            assert a[k].tobytes() == b[k].tobytes(), k
+        assert a["clon"].view(np.uint32).tobytes() == b["clon"].view(np.uint32).tobytes()
+    n2 = out[True][2]
+    assert (~np.isnan(n2["clon"]) & (n2["clon"] != 1.0)).sum() * 2 > len(n2["clon"])        # the case that needs the dense array
