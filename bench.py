@@ -75,6 +75,8 @@ def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense, record_bytes=8, n_r
 # but moves no clock: the kernel is bound by its per-window latency chain, not by its stores (C5: 1.24-1.29 ms per launch either
 # way, same box) -- so the bench keeps the plain slots whose dense arrays the device summaries can read.
 LEAN_SLOTS = bool(int(os.environ.get("ISX_BENCH_LEAN_SLOTS", "0")))
+C5_RESERVE_CUS = int(os.environ.get("ISX_BENCH_C5_RESERVE_CUS", "4"))
+C5_LINKAGE = bool(int(os.environ.get("ISX_BENCH_C5_LINKAGE", "1")))      # 0: diagnostic only (what the linkage chain costs the stream); not the workload
 
 
 def slot_out_bytes_per_pos(n_obs, n_pos, lean=None):
@@ -419,8 +421,8 @@ def resident_leg(ctx, w, window, steps=30):
 # C5 batches: genomes are packed into device batches under these budgets (the reference groups its profile commands by estimated
 # cost the same way, profile_controller.py:397-457).  A batch pays ~100 short kernel launches and a handful of host syncs in its
 # linkage / hand-back chain whatever its size, so batches are made as large as the pipe's slots comfortably hold.
-C5_BATCH_POS = int(os.environ.get("ISX_BENCH_C5_BATCH_POS", 80_000_000))
-C5_BATCH_SEGS = int(os.environ.get("ISX_BENCH_C5_BATCH_SEGS", 2_000_000))
+C5_BATCH_POS = int(os.environ.get("ISX_BENCH_C5_BATCH_POS", 120_000_000))
+C5_BATCH_SEGS = int(os.environ.get("ISX_BENCH_C5_BATCH_SEGS", 3_000_000))
 
 
 def _c5_plan(scale, host_threads):
@@ -460,7 +462,7 @@ class C5Run:
         ws = self.ws
         self.pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["segs"].n_seg for w in ws),
                                 max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
-                                pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20, stage_async=stage_async, lean_output=LEAN_SLOTS)
+                                pin_threads=False, n_mm_bins=1, enable_linkage=C5_LINKAGE, min_snp=20, stage_async=stage_async, lean_output=LEAN_SLOTS)
         self.bases = float(sum(w["profiled_bases"] for w in ws))
         self.signature = None
         # The host side of the hand-over, done once per batch as a decoder would do it while it decodes (the reference's workers
@@ -813,7 +815,7 @@ def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
             "record_bytes": int(st[0]["record_bytes"]) if st else None,
             "with_host_staging": {"gbp_per_s": float(w["profiled_bases"]) * steps / dt2 / 1e9, "ms_per_step": dt2 / steps * 1e3,
                                   "host_stage_ms": float(np.mean([x["encode_ms"] for x, _ in st2])) if st2 else 0.0},
-            "kept_observations": int(w["n_obs"]), "read_segments": int(w["segs"].n_seg), "pipe_depth": args.depth, "host_threads": host_threads,
+            "kept_observations": int(w["n_obs"]), "read_segments": int(w["segs"].n_seg), "pipe_depth": args.depth, "pileup_cus": 256 - 8 * C5_RESERVE_CUS, "host_threads": host_threads,
             "roofline_in_stream": {"bound": "hbm", "kernel": "k_pileup_dense (wire records, slot output)",
                                    "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
@@ -912,7 +914,11 @@ def main():
 
     # ---- the headline: configs[4] (C5), the configuration north_star quotes its target on ----
     _trace("C5 generate")
-    c5 = C5Run(ctx, rank, world, host_threads, depth=args.depth, scale=args.scale, stage_async=args.queued_submit)
+    # (its own context: 4 CUs of every XCD kept free of pileup kernels for the finishers' linkage chains -- isx_ctx_reserve_cus;
+    # the resident-batch legs below keep the whole device)
+    ctx5 = engine.Context(local, reserve_cus=C5_RESERVE_CUS)
+    ctx5.set_null_model(lut, fb)
+    c5 = C5Run(ctx5, rank, world, host_threads, depth=args.depth, scale=args.scale, stage_async=args.queued_submit)
     _trace("C5 verify pass")
     c5.verify_pass()                            # untimed: every batch's tables checked on the host; also warms every slot
     if args.warmup:
@@ -954,6 +960,7 @@ def main():
     n_batches = len(c5.ws)
     c5.close()
     del c5
+    ctx5.close()
 
     # one BAM sharded over the ranks (every rank takes part; rank 0 reports)
     sharded = None

@@ -165,6 +165,13 @@ int isx_abi_version(void);
 
 int isx_ctx_create(int device_id, isx_ctx **out);
 void isx_ctx_destroy(isx_ctx *ctx);
+/* Keep `cus_per_xcd` (0..8) compute units of each of the 8 XCDs free of pileup kernels: the context's two pass queues are masked off them
+ * and every side queue of its pipes (copy-in, finishers' linkage chains, copy-out) onto them.  A pileup kernel is a persistent grid that
+ * fills every CU it may use for its whole run, so without a reserve each short launch of a finisher's chain waits for one to end; with 4
+ * (32 of 256 CUs) the whole-database stream of bench.py gains ~8 %, a resident batch loses the CUs' share.  0 (the default; the
+ * environment's ISX_PASS_CU_RESERVE overrides the default) = no reserve, pass queues at the highest stream priority instead.  Call it
+ * before the context's first batch or pipe.  No counterpart in the reference (its workers are processes: profile/profile_utilities.py). */
+int isx_ctx_reserve_cus(isx_ctx *ctx, int cus_per_xcd);
 
 /* lut[c] = minimum count for a base to be "present" at coverage c, or < 0 when the
  * coverage is missing from the model; fallback = model[-1]. */

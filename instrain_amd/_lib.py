@@ -127,7 +127,7 @@ class IsxError(RuntimeError):
         self.code = code
 
 
-SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destroy", "isx_set_null_model",
+SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destroy", "isx_ctx_reserve_cus", "isx_set_null_model",
            "isx_batch_create", "isx_batch_create_reads", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld", "isx_batch_fetch_allele_obs",
            "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
@@ -153,6 +153,7 @@ def load():
     lib.isx_abi_version.restype = C.c_int
     lib.isx_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.isx_ctx_destroy.argtypes = [vp]
+    lib.isx_ctx_reserve_cus.argtypes = [vp, C.c_int]
     lib.isx_ctx_destroy.restype = None
     lib.isx_set_null_model.argtypes = [vp, vp, i64, i32]
     lib.isx_batch_create.argtypes = [vp, C.POINTER(Params), i64, vp, i32, vp, i64, vp, vp, C.POINTER(vp)]

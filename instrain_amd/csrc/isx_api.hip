@@ -189,6 +189,12 @@ __global__ void __launch_bounds__(256) k_copy_small(T *__restrict__ dst, const T
 hipError_t isx_copy_to_host(void *hdst, const void *dsrc, size_t bytes, hipStream_t stream)
 {
     if (!bytes) return hipSuccess;
+    {   // position-sized tables: the DMA engine.  A copy KERNEL that streams megabytes into host memory keeps the memory system's queues
+        // full of PCIe writes: every other kernel's HBM traffic waits behind them and the copy-in DMA loses a fifth of its rate
+        // (whole-database stream: 82 -> 55 ms a pass without the coverage rows' copy kernel, rate of the copy-in 43 -> 54 GB/s)
+        static const size_t dma_min = [] { const char *e = getenv("ISX_D2H_DMA_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
+        if (bytes >= dma_min) return hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
+    }
     const uintptr_t both = reinterpret_cast<uintptr_t>(hdst) | reinterpret_cast<uintptr_t>(dsrc);
     size_t done = 0;
     if ((both & 15) == 0 && bytes >= 4096) {
@@ -639,7 +645,7 @@ int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed)
                                  : (prm->enable_linkage ? 3136 : ISX_PK16_MAX_W);      // 3264: the packed decode of 2-byte records needs 16-bit byte offsets
         for (int w = 2048; w <= wtop; w += 64) {
             const double n_win = std::ceil((double)n_pos / w);
-            const double rounds = n_win / 512.0;
+            const double rounds = n_win / (2.0 * b->ctx->pass_cus);
             const double eff = rounds / std::ceil(rounds) * (w / (w + 200.0));
             if (eff > best_eff + 1e-9) { best_eff = eff; best = w; }
         }
@@ -683,7 +689,7 @@ int batch_set_geometry(isx_batch *b)
     if (b->lds > 160 * 1024) { isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
     {   // persistent kernels: as many workgroups as stay resident on the 256 CUs
         const int per_cu = std::max(1, std::min((int)(160 * 1024 / b->lds), 2048 / b->block));
-        int g = 256 * per_cu;
+        int g = b->ctx->pass_cus * per_cu;
 #ifdef ISX_TUNING
         if (const char *e = getenv("ISX_GRID")) g = std::max(8, atoi(e));       // tuning builds only
 #endif
@@ -706,6 +712,39 @@ extern "C" {
 
 const char *isx_last_error(void) { return g_err.c_str(); }
 int isx_abi_version(void) { return ISX_ABI_VERSION; }
+
+// The two pass queues of a context.  r = 0: plain queues at the highest stream priority -- a pileup kernel is a persistent grid sized for the
+// whole device; when copy kernels and the linkage chains of other batches hold some of the wave slots, its late workgroups delay the whole
+// pass.  r > 0: queues masked off r CUs of every XCD instead (hipExtStreamCreateWithCUMask: a masked queue carries no priority), and every
+// side queue of the context (copy-in, finishers, copy-out: isx_side_stream_create) masked ONTO them.  A persistent pileup grid fills every CU
+// it may use (LDS and wave slots) for its whole run; without the reserve each of the ~60 short launches of a finisher's chain (linkage sorts,
+// gathers, copy kernels) waits for a pileup kernel to END.
+static int make_pass_queues(isx_ctx *c, int r, int n_cu)
+{
+    r = std::max(0, std::min(r, 8));
+    if (n_cu != 256) r = 0;
+    for (int i = 0; i < 2; i++) if (c->pstream[i]) { HIP_TRY(hipStreamSynchronize(c->pstream[i])); HIP_TRY(hipStreamDestroy(c->pstream[i])); c->pstream[i] = nullptr; }
+    for (int k = 0; k < 8; k++) c->side_mask[k] = 0;
+    c->pass_cus = 256;
+    if (r > 0) {
+        // bit layouts differ between driver versions (the CUs of an XCD contiguous, or interleaved across the 8 XCDs): clear bits that are
+        // r per XCD under BOTH readings -- in block k of 32 bits the bits whose index is k (beyond 4 of them: k + 1) modulo 8
+        uint32_t mask[8];
+        for (int k = 0; k < 8; k++) {
+            mask[k] = 0xFFFFFFFFu;
+            for (int j = 0; j < r; j++) mask[k] &= ~(1u << (((k + (j >> 2)) & 7) + 8 * (j & 3)));
+        }
+        for (int i = 0; i < 2; i++) HIP_TRY(hipExtStreamCreateWithCUMask(&c->pstream[i], 8, mask));
+        c->pass_cus = 256 - 8 * r;
+        if (!getenv("ISX_SIDE_UNMASKED")) for (int k = 0; k < 8; k++) c->side_mask[k] = ~mask[k];
+    } else {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+        const int prio = getenv("ISX_NO_STREAM_PRIORITY") ? least : greatest;
+        for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithPriority(&c->pstream[i], hipStreamNonBlocking, prio));
+    }
+    return ISX_OK;
+}
 
 int isx_ctx_create(int device_id, isx_ctx **out)
 {
@@ -730,12 +769,10 @@ int isx_ctx_create(int device_id, isx_ctx **out)
     isx_ctx *c = new isx_ctx();
     c->device = device_id;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    {   // the pass queues get the highest stream priority: a pileup kernel is a persistent grid sized for the whole device -- when the
-        // copy kernels and the linkage chains of other batches hold some of the wave slots, its late workgroups delay the whole pass
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
-        const int prio = getenv("ISX_NO_STREAM_PRIORITY") ? least : greatest;
-        for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithPriority(&c->pstream[i], hipStreamNonBlocking, prio));
+    {
+        const char *e = getenv("ISX_PASS_CU_RESERVE");       // default of every context of this process (isx_ctx_reserve_cus sets one context's)
+        const int rc = make_pass_queues(c, e ? atoi(e) : 0, prop.multiProcessorCount);
+        if (rc != ISX_OK) return rc;
     }
     c->pin_bytes = (size_t)64 << 20;
     for (int i = 0; i < 2; i++) {
@@ -744,6 +781,24 @@ int isx_ctx_create(int device_id, isx_ctx **out)
     }
     *out = c;
     return ISX_OK;
+}
+
+extern "C++" hipError_t isx_side_stream_create(isx_ctx *c, hipStream_t *s)
+{
+    bool any = false;
+    for (int k = 0; k < 8; k++) any = any || c->side_mask[k] != 0;
+    if (any) return hipExtStreamCreateWithCUMask(s, 8, c->side_mask);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
+int isx_ctx_reserve_cus(isx_ctx *c, int cus_per_xcd)
+{
+    if (!c) { isx_set_error("isx_ctx_reserve_cus: null context"); return ISX_ERR_ARG; }
+    if (c->n_created || c->n_pipes) { isx_set_error("isx_ctx_reserve_cus: call it before the context's first batch or pipe (their launch shapes and queues follow it)"); return ISX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    return make_pass_queues(c, cus_per_xcd, prop.multiProcessorCount);
 }
 
 void isx_ctx_destroy(isx_ctx *c)

@@ -16,8 +16,11 @@ struct isx_ctx {
     // batches' kernels are in different queues, so the next one's workgroups move in as the current one's retire
     // (no kernel-boundary gap); everything else of a batch runs on `stream` after its pass is known to be complete
     hipStream_t pstream[2] = {nullptr, nullptr};
+    uint32_t side_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... and those CUs as a queue mask (all zero: no reserve)
+    int pass_cus = 256;                 // CUs the pass queues may use (256 minus what ISX_PASS_CU_RESERVE keeps free for the finishers' short kernels)
     struct isx_batch *unpublished[2] = {nullptr, nullptr};   // per pass stream: batch whose last pass has no publication enqueued yet
     unsigned n_created = 0;
+    unsigned n_pipes = 0;               // pipes ever created on this context
     uint8_t *d_lut = nullptr;
     std::vector<int32_t> h_lut;
     int32_t lut_n = 0, fallback = 0;
@@ -25,6 +28,9 @@ struct isx_ctx {
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     size_t pin_bytes = 0;
 };
+
+// a queue for what is NOT a pass (copy-in, finishers' chains, copy-out): on the reserved CUs when the context keeps some (isx_api.hip)
+hipError_t isx_side_stream_create(isx_ctx *c, hipStream_t *s);
 
 struct isx_batch {
     isx_ctx *ctx = nullptr;

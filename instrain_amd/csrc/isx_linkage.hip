@@ -491,6 +491,11 @@ void LinkageBuffers::release()
     *this = LinkageBuffers();
 }
 
+// rocPRIM sorts fewer than 2^20 items by block sort + ~log2(n / block) merge passes (two dozen launches for the 10^5 .. 10^6 allele
+// observations / pair increments of a batch); in a stream of batches every launch of a finisher's chain queues behind other batches'
+// kernels, so the chain's length in LAUNCHES is what it costs.  Onesweep: one histogram + one pass per 8 bits (ISX_SORT_MERGE=1: rocPRIM's choice)
+using isx_sort_onesweep = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+static const bool g_sort_merge = getenv("ISX_SORT_MERGE") != nullptr;
 #define EV(i) HIP_TRY(hipEventRecord(in.ev[i], s))
 #define RP(call_with_temp)                                                                       \
     do {                                                                                         \
@@ -524,7 +529,8 @@ int sparse_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_
     const int sb = bits_for(in.n_sites);
     n_u = 0;
     const int pair_bits = bits_for(in.n_pairs ? in.n_pairs : 0xFFFFFFFFull);
-    RP(rocprim::radix_sort_pairs(tp, tb, B.ao_key.p, B.ao_key2.p, in.ao, B.ao2.p, n_ao, 0, pair_bits, s));
+    if (g_sort_merge) RP(rocprim::radix_sort_pairs(tp, tb, B.ao_key.p, B.ao_key2.p, in.ao, B.ao2.p, n_ao, 0, pair_bits, s));
+    else RP(rocprim::radix_sort_pairs<isx_sort_onesweep>(tp, tb, B.ao_key.p, B.ao_key2.p, in.ao, B.ao2.p, n_ao, 0, pair_bits, s));
     EV(3);
     if ((rc = ensure(B.incr_cnt, n_ao)) || (rc = ensure(B.incr_off, (size_t)n_ao + 1))) return rc;
     hipLaunchKernelGGL((k_pair_incr<false, false>), dim3((n_ao + 255) / 256), dim3(256), 0, s, B.ao2.p, n_ao,
@@ -538,7 +544,8 @@ int sparse_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_
         (rc = ensure(B.ucnt, n_inc)) || (rc = ensure(B.n_runs, 2))) return rc;
     hipLaunchKernelGGL((k_pair_incr<true, false>), dim3((n_ao + 255) / 256), dim3(256), 0, s, B.ao2.p, n_ao,
                        B.site_split.p, nullptr, B.incr_off.p, B.keys.p, sb);
-    RP(rocprim::radix_sort_keys(tp, tb, B.keys.p, B.keys2.p, (size_t)n_inc, 0, 2 * sb + 12, s));
+    if (g_sort_merge) RP(rocprim::radix_sort_keys(tp, tb, B.keys.p, B.keys2.p, (size_t)n_inc, 0, 2 * sb + 12, s));
+    else RP(rocprim::radix_sort_keys<isx_sort_onesweep>(tp, tb, B.keys.p, B.keys2.p, (size_t)n_inc, 0, 2 * sb + 12, s));
     RP(rocprim::run_length_encode(tp, tb, B.keys2.p, (size_t)n_inc, B.ukeys.p, B.ucnt.p, B.n_runs.p, s));
     HIP_TRY(isx_read_back(&n_u, B.n_runs.p, 4, s));
     EV(4);

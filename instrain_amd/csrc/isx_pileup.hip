@@ -162,7 +162,11 @@ __device__ __forceinline__ SiteCall call_level(const PileupArgs &a, const uint16
     const bool fast = total < (uint32_t)a.lut_n;
     uint32_t thr = 0;
     if (fast) {
-        thr = (thr_lds && total < THR_LDS) ? (uint32_t)thr_lds[total] : (uint32_t)a.thr[total];
+        if (thr_lds) {          // two typed loads (a select of the LDS and the global pointer would be ONE flat load, which also counts as an LDS access)
+            thr = thr_lds[min(total, (uint32_t)THR_LDS - 1u)];
+            asm volatile("" : "+v"(thr));
+            if (total >= THR_LDS) thr = a.thr[total];
+        } else thr = a.thr[total];
 #pragma unroll
         for (int k = 0; k < 4; k++) r.morphia += (c[k] >= thr) ? 1 : 0;
         const int am = argmax4(c);
@@ -568,10 +572,28 @@ __device__ __forceinline__ void allele_pass_delta(const PileupArgs &a, uint32_t 
 // the 8 extra words of a row are the junk columns of the packed decode (records that belong to another window), and the
 // queue region -- idle during the stream -- is the junk row of records without an A/C/T/G base.
 // ---------------------------------------------------------------------------------------------
+#ifndef ISX_LB_WAVES
+#define ISX_LB_WAVES 8
+#endif
+#ifdef ISX_TUNING
+// timeline of workgroup 0 (debug bit 4096): 16 stamps a window, first 32 windows; read back with isx_debug_read_ts (tools/timeline.py)
+__device__ unsigned long long g_isx_ts[32 * 16];
+extern "C" int isx_debug_read_ts(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_isx_ts), sizeof(g_isx_ts)); }
+#define ISX_TS(k) do { if ((dbg & 4096) && blockIdx.x == 0 && tid == 0 && ts_w < 32) g_isx_ts[ts_w * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define ISX_TS(k) do { } while (0)
+#endif
 template <bool LINKAGE, int FMT, bool PK16 = false>   // FMT = bytes per resident record: 8 (isx_obs), 4 (compact), 2 (short), 64 (read
-__global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)     // segments); PK16: short records decoded two at a time
+__global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const PileupArgs a_kernarg)     // segments); PK16: short records decoded two at a time
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // The ~150 dwords of arguments stay in the kernarg segment and every phase of a window reads the few it needs from there again
+    // (scalar loads, cache hits): held in SGPRs across the whole window loop they were spilled to VGPR lanes, and a third of the VALU
+    // instructions issued were v_readlane / v_writelane.  ISX_ARGS_FRESH() makes the compiler forget what it has loaded so far.
+    typedef const __attribute__((address_space(4))) PileupArgs KernArgs;
+    KernArgs *kargs = (KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+#define a (*(const PileupArgs *)kargs)
+#define ISX_ARGS_FRESH() asm volatile("" : "+s"(kargs))
     const int tid = threadIdx.x, nthr = blockDim.x;
     publish_previous(a, tid);
     const int W = a.W;
@@ -657,9 +679,17 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
     if (slot < a.n_win) rng_next = a.win_range[slot];
     prefetch_window(slot);
 
+#ifdef ISX_TUNING
+    int ts_w = -1;
+#endif
     for (int w = slot; w < a.n_win; w += grid) {
         const uint32_t w0 = (uint32_t)w * (uint32_t)W;
         const uint32_t cur_lo = lo, cur_hi = hi;
+#ifdef ISX_TUNING
+        ++ts_w;
+#endif
+        ISX_TS(0);
+        ISX_ARGS_FRESH();
         if (w + grid < a.n_win) rng_next = a.win_range[w + grid];
         const uint32_t dummy = 4u * (uint32_t)S + (uint32_t)(tid & 63);     // see the stream loop
 #ifdef ISX_TUNING
@@ -693,6 +723,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             ref_raw[it] = (!PKL && tid + it * nthr < W && gp < a.n_pos) ? ref_at(a, gp) : (uint8_t)4;
         }
         __syncthreads();
+        ISX_TS(1);
+        ISX_ARGS_FRESH();
 
         // ---- get_base_counts_mm (profile_utilities.py:268-286) over the window's slice ----
         // Branch-free: a record outside the window / without an A,C,T,G base adds to a per-lane dummy word (the queue
@@ -876,6 +908,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             if (4 * (tid + nthr) < W) reinterpret_cast<uint32_t *>(refl)[tid + nthr] = ref4b;
         }
         __syncthreads();
+        ISX_TS(2);
+        ISX_ARGS_FRESH();
 
         // first loads of the NEXT window go out before the epilogue (with linkage the registers
         // are needed by the allele pass first, so the prefetch follows it)
@@ -896,6 +930,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             }
             if (lane == 63) wtot[tid >> 6] = (uint32_t)inc;
             __syncthreads();
+            ISX_TS(3);
             int32_t run = inc - sum;
             for (int k = 0; k < (tid >> 6); k++) run += (int32_t)wtot[k];
             for (int k = 0; k < PT; k++) {
@@ -910,6 +945,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 }
             }
             __syncthreads();
+            ISX_TS(4);
+            ISX_ARGS_FRESH();
         }
         if (DREC && !PKL && !(dbg & 16)) {
             // ---- materialise: the reference base's count of every position from the coverage differences ----
@@ -932,6 +969,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             }
             if (lane == 63) wtot[tid >> 6] = inc;
             __syncthreads();
+            ISX_TS(3);
             uint32_t off = inc - run[3];
             for (int k = 0; k < (tid >> 6); k++) off += wtot[k];
             if (act) {
@@ -947,6 +985,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 }
             }
             __syncthreads();
+            ISX_TS(4);
+            ISX_ARGS_FRESH();
         }
 
         // ---- epilogue pass 1: integer only (update_snp_table, single mm level) ----
@@ -1006,6 +1046,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             if (!defer && st_ok && a.clon) a.clon[gpos] = cl;      // (a lean slot keeps no dense clonality array)
         }
         __syncthreads();
+        ISX_TS(5);
+        ISX_ARGS_FRESH();
 #ifdef ISX_TUNING
         if (dbg & 512) { __syncthreads(); continue; }       // 512: nothing after the first epilogue pass (no table slots, no rows)
 #endif
@@ -1018,6 +1060,7 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
         const uint32_t nclon = a.clon_list ? scratch[S_NCLON] : 0u;
         if (tid == 256 % nthr && nclon) scratch[S_CLON_BASE] = cur_add(a, CUR_CLON, nclon);
         if (nclon) __syncthreads();             // uniform: the list entries below need the window's base
+        ISX_TS(6);
         // ---- deferred clonalities (snv_utilities.py:225-231), densely packed; the sparse clonality list ----
         {
             const uint32_t clon_base = scratch[S_CLON_BASE];
@@ -1034,6 +1077,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
             }
         }
         if (nrows | nrare) __syncthreads();     // uniform: scratch bases from the atomics above
+        ISX_TS(7);
+        ISX_ARGS_FRESH();
         if (a.min_cov_r > 0) {                  // rarefied clonality (snv_utilities.py:233-247), own loop: fewer live registers
             const uint32_t rare_base = scratch[S_RARE_BASE];
             const bool list = nrare && rare_base + nrare <= a.cap_rare;      // else the host reads the dense array
@@ -1095,6 +1140,8 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 a.sites[site_base + ss - 1] = st;
             }
         }
+        ISX_TS(8);
+        ISX_ARGS_FRESH();
         if (linkage) {
             if (ok && nao) {
                 __syncthreads();                // every wave is done with cnt: it becomes the allele pass's stage
@@ -1102,12 +1149,16 @@ __global__ void __launch_bounds__(1024, 8) k_pileup_dense(const PileupArgs a)   
                 else if (DREC) allele_pass_delta(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
                 else allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
+            ISX_TS(9);
             prefetch_window(w + grid);
         }
         // the zeroing + barrier at the top of the next window protect cnt / queue / scratch
         __syncthreads();
+        ISX_TS(10);
     }
 }
+#undef a
+#undef ISX_ARGS_FRESH
 
 // ---------------------------------------------------------------------------------------------
 // k_pileup_mm: n_mm_bins > 1 (mm profiling on, the reference's default).  Persistent workgroups

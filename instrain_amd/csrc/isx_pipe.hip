@@ -325,7 +325,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     isx_batch *b = new isx_batch();
     s.b = b;
     b->ctx = c; b->prm = *prm; b->M = prm->n_mm_bins;
-    b->ps = index & 1;
+    b->ps = getenv("ISX_ONE_PASS_QUEUE") ? 0 : (index & 1);
     b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true; b->ref_packed = 2;
     b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
     b->segs = p->segs; b->drec = p->drec;
@@ -722,15 +722,16 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
         nt = q > 0 ? q : (int)std::thread::hardware_concurrency();
         nt = std::max(1, std::min(nt, 32));
     }
+    c->n_pipes++;
     const double t_c0 = now_ms();
     p->pool.reset(new isxenc::HostPool(nt, gpu_numa_node(c->device), pp->pin_threads != 0));
     const double t_c1 = now_ms();
     int rc = ISX_OK;
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&p->s_fin, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&p->s_fin2, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking)) != hipSuccess) {
+    if ((e = isx_side_stream_create(c, &p->s_h2d)) != hipSuccess ||
+        (e = isx_side_stream_create(c, &p->s_fin)) != hipSuccess ||
+        (e = isx_side_stream_create(c, &p->s_fin2)) != hipSuccess ||
+        (e = isx_side_stream_create(c, &p->s_d2h)) != hipSuccess) {
         isx_set_error(std::string("isx_pipe_create: ") + hipGetErrorString(e));
         pipe_free(p);
         return ISX_ERR_HIP;
@@ -757,7 +758,7 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
         want = std::min(want, pp->depth);
         for (int i = 2; i < want; i++) {
             hipStream_t st = nullptr;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+            if (isx_side_stream_create(c, &st) != hipSuccess) break;
             p->extra_fin.push_back(st);
             p->more_finishers.emplace_back(finisher_main, p, st);
         }

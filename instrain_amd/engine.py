@@ -70,11 +70,15 @@ def encode_seq(seq):
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, reserve_cus=None):
+        """reserve_cus: CUs of each XCD kept free of pileup kernels for the pipes' side queues (isx_ctx_reserve_cus; None = the
+        library's default) -- for contexts that stream batches with linkage through a Pipe"""
         self.lib = _lib.load()
         h = C.c_void_p()
         check(self.lib.isx_ctx_create(int(device), C.byref(h)))
         self.h = h
+        if reserve_cus is not None:
+            check(self.lib.isx_ctx_reserve_cus(self.h, int(reserve_cus)))
         self.device = device
         self._children = []         # weak references to live Batch / Pipe objects: closed before the context
         self._closers = []          # threads closing objects handed to close_later

@@ -27,6 +27,8 @@ if "DBG" in os.environ:
     combos = [(0, 0, int(d)) for d in os.environ["DBG"].split(",")]
 else:
     combos = [(0, 0, 0)] + [(W, B, 0) for B in (1024, 512, 256) for W in (512, 768, 1024, 1536, 2048, 2688) if W <= 4 * B]
+if "COMBOS" in os.environ:       # COMBOS=W:block[:dbg],...
+    combos = [tuple((list(map(int, c.split(":"))) + [0])[:3]) for c in os.environ["COMBOS"].split(",")]
 for W, B, dbg in combos:
     for k in ("ISX_GRID", "ISX_BLOCK"):
         os.environ.pop(k, None)

@@ -24,6 +24,8 @@ elif LAYOUT == 0:       # delta records: 8 = no skip-plane walk, 16 = no materia
     combos = [(0, 0, d) for d in (0, 2, 64, 8, 16, 8 | 16, 2 | 64, 2 | 8, 128, 256, 512, 1024, 2048, 128 | 256 | 512)]
 else:
     combos = [(0, 0, d) for d in (0, 2, 64, 8, 16, 2 | 64, 128, 256, 512, 1024, 2048, 1024 | 2048, 128 | 256, 128 | 256 | 512, 128 | 512, 64 | 128 | 256 | 512)]
+if "COMBOS" in os.environ:       # COMBOS=W:block[:dbg],...
+    combos = [tuple((list(map(int, c.split(":"))) + [0])[:3]) for c in os.environ["COMBOS"].split(",")]
 for W, B, dbg in combos:
     for k in ("ISX_GRID", "ISX_BLOCK"):
         os.environ.pop(k, None)
