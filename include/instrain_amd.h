@@ -453,17 +453,29 @@ int isx_pipe_fetch_entries_shrunk(isx_pipe *p, int64_t ticket, uint32_t *gpos, u
 #define ISX_SEG_SKIP_WORD 0x24924924u   /* ten codes 4 */
 /* The device stream of a read-level batch with ONE mm bin is made of reference-delta records (since round 4): what differs from
  * the reference travels, not the bases.  32 bytes per record, 32 records per group (one wave-wide 16-byte load) sharing a
- * 32-bit position base:
- *   word 0      delta:16 | len:8 | mm:8      start = gbase[record / 32] + delta; len 0 = padding record
- *   words 1-2   skip bits of columns 0..63   bit set = no observation at that column (below min_qual, deletion, ref-skip,
- *   words 4-6   skip bits of columns 64..159                                        a base that is not A/C/T/G); bits >= len are 0
- *   word 3, 7   exceptions 0-2, 3-5: three (offset:8 | base:2) fields in bits 0..29 each; an exception = an observed base that
- *               differs from the reference code at its position (every observed base where the reference is not A/C/T/G);
- *               empty field = 0x3FF.  A segment with more than ISX_DREC_EXC exceptions travels as several records (pieces).
- * 0.21 bytes per base instead of 0.43; the kernel adds +1 / -1 at a record's ends to a coverage-difference row, one LDS
- * atomic per skipped column and one per exception, and rebuilds the reference base's count from the prefix sum. */
+ * 32-bit position base.  A record is one of two kinds, told apart by bit 31 of its word 0 (ISX_DREC_DUAL):
+ *  - a DUAL record: two segments that have no skipped column, 16 bytes each (the common case: a read that aligns without
+ *    deletion / low-quality base / N is one such segment) --
+ *      word 0      delta:16 | len:8 | 0x80      start = gbase[record / 32] + delta; len 0 = this half is empty
+ *      word 1      dense read-pair id (0 without linkage)
+ *      words 2, 3  exceptions 0-2, 3-5: three (offset:8 | base:2) fields in bits 0..29 each; an exception = an observed base
+ *                  that differs from the reference code at its position (every observed base where the reference is not
+ *                  A/C/T/G); empty field = 0x3FF
+ *    (the second half, words 4-7, alike; a half filled later never precedes, in the segments' order, the record's first);
+ *  - a FULL record: one segment with its plane of skipped columns --
+ *      word 0      delta:16 | len:8 | 0         len 0 = padding record
+ *      words 1-2   skip bits of columns 0..63   bit set = no observation at that column (below min_qual, deletion, ref-skip,
+ *      words 4-6   skip bits of columns 64..159                                        a base that is not A/C/T/G); bits >= len are 0
+ *      word 3      exceptions 0-2
+ *      word 7      dense read-pair id
+ * A segment with more exceptions than its kind holds (ISX_DREC_EXC / ISX_DREC_EXC_FULL) travels as several pieces.  16 bytes per
+ * 150-base read that matches the reference's alignment columns -- 0.11 bytes per base instead of 0.43, pair id included; the kernel
+ * adds +1 / -1 at a segment's ends to a coverage-difference row, one LDS atomic per skipped column and one per exception, and
+ * rebuilds the reference base's count from the prefix sum. */
 #define ISX_DREC_WORDS 8
-#define ISX_DREC_EXC 6
+#define ISX_DREC_EXC 6          /* exceptions of a dual record's half */
+#define ISX_DREC_EXC_FULL 3     /* ... of a full record */
+#define ISX_DREC_DUAL 0x80000000u
 #define ISX_DREC_NO_EXC 0x3FFFFFFFu
 
 typedef struct {
@@ -531,9 +543,11 @@ int isx_encode_segs_ring(const isx_segs *segs, int64_t n_pos, int32_t n_mm_bins,
 
 /* The same staging for a one-mm-bin pipe (no GPU needed): segments + the reference codes ref[n_pos] -> 32-byte reference-delta
  * records (ISX_DREC_* above) in groups of 32.  The segments are cut into tasks of 4096; every task's region holds the groups its
- * segment starts need + slack_groups spare ones (>= 1) for the pieces of segments with more than ISX_DREC_EXC exceptions, unused
- * groups are padding.  ISX_ERR_CAPACITY with *need_slack > slack_groups: encode again with that many (a pipe learns it);
- * otherwise cap_rec (isx_delta_records_needed) is too small.  ring_records as in isx_encode_segs_ring (a multiple of 64). */
+ * segments need if none of them has a skipped column (64 to a group) + slack_groups spare ones (>= 1) for full records and the pieces
+ * of segments with many exceptions, unused groups are padding.  ISX_ERR_CAPACITY with *need_slack > slack_groups: encode again with
+ * that many (a pipe sizes every task's region exactly on its second attempt); otherwise cap_rec (isx_delta_records_needed) is too
+ * small.  pair_out is not written (the read-pair ids, segs->pair, travel inside the records) and may be NULL.  ring_records as in
+ * isx_encode_segs_ring (a multiple of 64). */
 int isx_encode_delta(const isx_segs *segs, const uint8_t *ref, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int32_t slack_groups,
                      int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec, int64_t *need_slack);
 int64_t isx_delta_records_needed(const uint32_t *gpos, int64_t n_seg, int32_t host_threads, int32_t slack_groups);

@@ -941,13 +941,12 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
             int64_t cap_rec = isxenc::delta_groups_needed(pool, segs->gpos, segs->n_seg, slack) * ISX_DREC_GROUP;
             if (!exact.empty()) { cap_rec = 0; for (int64_t v : exact) cap_rec += std::max<int64_t>(v, 1) * ISX_DREC_GROUP; }
             h_rec.resize((size_t)cap_rec * ISX_DREC_WORDS); h_gbase.resize((size_t)(cap_rec / ISX_DREC_GROUP));
-            if (prm->enable_linkage) h_pair.resize((size_t)cap_rec);
             st.cmin.assign(h_gbase.size(), 0xFFFFFFFFu); st.cmax.assign(h_gbase.size(), 0u); st.cany.assign(h_gbase.size(), 0);
             J = isxenc::SegJob();
             J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = b->M; J.ref = ref; J.slack_groups = slack;
             J.task_groups = exact.empty() ? nullptr : exact.data();
             if (!prm->enable_linkage) J.in.pair = nullptr;
-            J.rec = h_rec.data(); J.gbase = h_gbase.data(); J.pair_out = prm->enable_linkage ? h_pair.data() : nullptr;
+            J.rec = h_rec.data(); J.gbase = h_gbase.data(); J.pair_out = nullptr;
             J.cmin = st.cmin.data(); J.cmax = st.cmax.data(); J.cany = st.cany.data(); J.cap_rec = cap_rec;
             const int erc = isxenc::encode_delta(pool, J);
             if (erc == isxenc::SEG_CAPACITY && J.need_slack > slack && attempt == 0) { exact = J.task_need; continue; }
@@ -969,10 +968,7 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
         BH(isx_raw_dev_malloc(&b->d_gbase, (st.n_chunks + ISX_TAIL_GROUPS) * sizeof(uint32_t)));
         BH(hipMemsetAsync(b->d_gbase + st.n_chunks, 0, ISX_TAIL_GROUPS * sizeof(uint32_t), c->stream));
         BH(hipMemcpyAsync(b->d_gbase, h_gbase.data(), st.n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        if (prm->enable_linkage) {
-            BH(isx_raw_dev_malloc(&b->d_pair, (size_t)b->n_rec * sizeof(uint32_t)));
-            BH(hipMemcpyAsync(b->d_pair, h_pair.data(), (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        }
+        // (no pair table: the records carry the read-pair ids)
         BH(hipStreamSynchronize(c->stream));         // the host vectors are locals
     } else if (segs) {
         // read segments: encoded on the host (the pipe does the same into pinned staging, seg_encode.cpp), one upload

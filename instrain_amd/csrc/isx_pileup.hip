@@ -494,11 +494,13 @@ __device__ __forceinline__ void allele_pass_delta(const PileupArgs &a, uint32_t 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if ((uint32_t)lane < nst) {
-            const uint32_t rec = st[2 * lane], info = st[2 * lane + 1];
+            const uint32_t half = st[2 * lane], info = st[2 * lane + 1];     // half: index of the segment's 16-byte half (a full record: its first)
             const uint32_t rel = info & 0xFFFFu;
             const uint32_t slot = atomicAdd(&slabc[rel], 1u);
             isx_ao o;
-            o.pair = a.pair[rec]; o.site = w0 + rel; o.obs_idx = rec;
+            // the read-pair id travels inside the record: word 1 of a dual half, word 7 of a full record
+            o.pair = reinterpret_cast<const uint32_t *>(a.drec)[(info >> 20) & 1u ? ((half | 1u) << 2) + 3u : (half << 2) + 1u];
+            o.site = w0 + rel; o.obs_idx = half;
             o.mm = (uint16_t)(info >> 24); o.base = (uint8_t)((info >> 16) & 7u); o.pad = 0;
             a.ao[ao_base + slot] = o;
         }
@@ -511,24 +513,29 @@ __device__ __forceinline__ void allele_pass_delta(const PileupArgs &a, uint32_t 
         if ((uint32_t)__builtin_amdgcn_readfirstlane(i) >= hi16) break;         // wave-uniform
         const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.drec) + i);
         const uint32_t gb = a.gbase[__builtin_amdgcn_readfirstlane(i >> 6)];
-        const uint32_t hdr = pair_first(v.x);
+        const uint32_t hdr0 = pair_first(v.x);
+        const bool dual = (hdr0 >> 31) != 0u;                   // two segments without skipped columns, a lane each; else one with its skip plane
+        const uint32_t hdr = dual ? v.x : hdr0;
         const uint32_t len = (hdr >> 16) & 0xFFu;
-        const uint32_t mm = a.M > 1 ? hdr >> 24 : 0u;
-        const uint32_t e_mine = v.w, e_other = pair_other(v.w);
+        const uint32_t w3 = pair_first(v.w);                    // a full record's exceptions (its word 3)
+        const uint32_t e_a = dual ? v.z : w3, e_b = dual ? v.w : ISX_DREC_NO_EXC;
         const int32_t s = (int32_t)(gb + (hdr & 0xFFFFu) - w0);
-        const uint32_t sk[3] = {odd ? v.x : v.y, odd ? v.y : v.z, odd ? v.z : 0xFFFFFFFFu};
+        // the five 32-column chunks of a segment: a dual half walks all of its own; of a full record the first lane walks chunks 0, 1 (skip
+        // words 1, 2), the second 2, 3, 4 (words 4, 5, 6)
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t c0 = (odd ? 64u : 0u) + 32u * (uint32_t)k;      // first column of this 32-column chunk
+        for (int k = 0; k < 5; k++) {
+            const uint32_t c0 = 32u * (uint32_t)k;                 // first column of this 32-column chunk
             const int32_t r = s + (int32_t)c0;
+            const uint32_t skw = dual ? 0u : (k == 0 ? v.y : (k == 1 ? v.z : (k == 2 ? v.x : (k == 3 ? v.y : v.z))));
+            const bool mine = dual || (odd != 0u) == (k >= 2);
             uint32_t bits = 0;
-            if (len > c0 && (odd || k < 2) && (uint32_t)(r + 31) < (uint32_t)(W + 31)) {
+            if (len > c0 && mine && (uint32_t)(r + 31) < (uint32_t)(W + 31)) {
                 const uint32_t ncol = min(len - c0, 32u);
                 const int32_t base = r < 0 ? 0 : r;
                 const uint32_t wi = (uint32_t)base >> 5;
                 const uint64_t b64 = (uint64_t)sitebits[wi] | ((uint64_t)sitebits[wi + 1] << 32);
                 bits = (uint32_t)(b64 >> (base & 31)) << (base - r);
-                bits &= ~sk[k] & (ncol == 32u ? 0xFFFFFFFFu : (1u << ncol) - 1u);
+                bits &= ~skw & (ncol == 32u ? 0xFFFFFFFFu : (1u << ncol) - 1u);
             }
             while (__ballot(bits != 0)) {                                       // wave-uniform
                 const bool has = bits != 0;
@@ -539,7 +546,7 @@ __device__ __forceinline__ void allele_pass_delta(const PileupArgs &a, uint32_t 
                 uint32_t code = 8u;
 #pragma unroll
                 for (int f = 0; f < 3; f++) {
-                    const uint32_t x = (e_mine >> (10 * f)) & 0x3FFu, y = (e_other >> (10 * f)) & 0x3FFu;
+                    const uint32_t x = (e_a >> (10 * f)) & 0x3FFu, y = (e_b >> (10 * f)) & 0x3FFu;
                     if ((x & 0xFFu) == col) code = x >> 8;
                     if ((y & 0xFFu) == col) code = y >> 8;
                 }
@@ -551,8 +558,8 @@ __device__ __forceinline__ void allele_pass_delta(const PileupArgs &a, uint32_t 
                 if (nst + n > 64u) { drain(); nst = 0; }
                 if (cand) {
                     const uint32_t at = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    st[2 * at] = i >> 1;
-                    st[2 * at + 1] = rel | (code << 16) | (mm << 24);
+                    st[2 * at] = dual ? i : (i & ~1u);
+                    st[2 * at + 1] = rel | (code << 16) | (dual ? 0u : 1u << 20);
                 }
                 nst += n;
             }
@@ -733,19 +740,22 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
         auto count_slot = [&](int u) {
             if (COMPACT && !live[u]) return;        // uniform: the last round of a window is half empty on average
             if (DREC) {
-                // Reference-delta records: a pair of lanes holds one 32-byte record.  Coverage is counted by DIFFERENCE -- +1 at the
-                // record's first column, -1 behind its last (2 LDS atomics per record, by the pair's first lane) -- and only what
-                // is not "the reference's base, observed" touches a counter of its own: one atomic per skipped column (the set bits
-                // of this lane's share of the skip plane) and one per exception.  ~17 atomics per 150-base read instead of 135.
+                // Reference-delta records: a pair of lanes holds one 32-byte record -- ONE segment with its plane of skipped columns (a full
+                // record), or TWO segments without skipped columns, a lane each (a dual record: include/instrain_amd.h ISX_DREC_*).  Coverage
+                // is counted by DIFFERENCE -- +1 at a segment's first column, -1 behind its last (2 LDS atomics per segment) -- and only what
+                // is not "the reference's base, observed" touches a counter of its own: one atomic per skipped column (the set bits of this
+                // lane's share of the skip plane) and one per exception.  ~17 atomics per 150-base read instead of 135.
                 const uint32_t odd = (uint32_t)tid & 1u;
-                const uint32_t hdr = pair_first(v[u].x);
+                const uint32_t hdr0 = pair_first(v[u].x);
+                const bool dual = (hdr0 >> 31) != 0u;
+                const uint32_t hdr = dual ? v[u].x : hdr0;
                 const uint32_t len = (hdr >> 16) & 0xFFu;
                 const int32_t s = (int32_t)(gb[u] + (hdr & 0xFFFFu) - w0);
                 const uint32_t uW = (uint32_t)W;
 #ifdef ISX_TUNING
                 if (dbg & 64) { ablate_acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w ^ hdr; return; }        // loads only
 #endif
-                if (!odd && len) {
+                if ((dual || !odd) && len) {
                     const int32_t hi_c = s + (int32_t)len;
                     if (hi_c > 0 && s < W) {
                         atomicAdd(&dlt[s < 0 ? 0 : s], PKL ? 0x00010000u : 1u);
@@ -753,6 +763,7 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
                     }
                 }
                 uint32_t sk[3] = {odd ? v[u].x : v[u].y, odd ? v[u].y : v[u].z, odd ? v[u].z : 0u};
+                if (dual) sk[0] = sk[1] = sk[2] = 0;                    // (a dual record's segments have no skipped columns)
 #ifdef ISX_TUNING
                 if (dbg & 8) sk[0] = sk[1] = sk[2] = 0;                 // no skip-plane walk
 #endif
@@ -768,12 +779,15 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
                         bits &= bits - 1u;                                      // 0 stays 0
                     }
                 }
-                const uint32_t ex = v[u].w;
+                // exceptions: a dual half carries six (its words 2, 3); a full record three (word 3 = the first lane's fourth word; its
+                // word 7 is the read-pair id)
+                const uint32_t exw[2] = {dual ? v[u].z : (odd ? ISX_DREC_NO_EXC : v[u].w), dual ? v[u].w : ISX_DREC_NO_EXC};
 #pragma unroll
-                for (int f = 0; f < 3; f++) {
-                    const uint32_t off = (ex >> (10 * f)) & 0xFFu, code = (ex >> (10 * f + 8)) & 3u;
+                for (int f = 0; f < 6; f++) {
+                    const uint32_t ex = exw[f / 3];
+                    const uint32_t off = (ex >> (10 * (f % 3))) & 0xFFu, code = (ex >> (10 * (f % 3) + 8)) & 3u;
                     const uint32_t rel = (uint32_t)(s + (int32_t)off);
-                    if (off < len && rel < uW) {
+                    if (off < len && rel < uW) {                 // (an empty field has offset 255)
                         if (PKL) atomicAdd(&cnt[__umul24(code >> 1, (uint32_t)S) + rel], 1u << (16 * (code & 1u)));
                         else atomicAdd(&cnt[__umul24(code, (uint32_t)S) + rel], 1u);
                     }

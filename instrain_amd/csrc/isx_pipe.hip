@@ -392,7 +392,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.off_ref = o; o = up(o + ref2_bytes(cap_pos) + refn_bytes(cap_pos));        // 2-bit plane | non-ACGT bit plane
     s.off_gbase = o; o = up(o + ((size_t)(p->cap_rec / p->G) + ISX_TAIL_GROUPS) * sizeof(uint32_t));
     s.off_ridx = o; if (prm->enable_linkage && !p->segs) o = up(o + ((size_t)p->cap_rec / ISX_CHUNK + 2) * sizeof(uint32_t));
-    s.off_pairs = o; if (prm->enable_linkage && p->segs) o = up(o + (size_t)p->cap_rec * sizeof(uint32_t));
+    s.off_pairs = o; if (prm->enable_linkage && p->segs && !p->drec) o = up(o + (size_t)p->cap_rec * sizeof(uint32_t));     // (reference-delta records carry the ids themselves)
     s.off_rec = o;
     s.in_bytes = up(o + (size_t)p->cap_rec * p->rb + ISX_TAIL_BYTES);
     const size_t host_bytes = p->ring_half ? up(o + 2 * (size_t)p->ring_half * p->rb) : s.in_bytes;
@@ -1043,7 +1043,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     J.n_pos = n_pos; J.n_mm_bins = b->M;
     J.rec = reinterpret_cast<uint32_t *>(s.h_in + s.off_rec);
     J.gbase = reinterpret_cast<uint32_t *>(s.h_in + s.off_gbase);
-    J.pair_out = linkage ? reinterpret_cast<uint32_t *>(s.h_in + s.off_pairs) : nullptr;
+    J.pair_out = linkage && !p->drec ? reinterpret_cast<uint32_t *>(s.h_in + s.off_pairs) : nullptr;
     J.cmin = s.cmin.data(); J.cmax = s.cmax.data(); J.cany = s.cany.data();
     J.cap_rec = p->cap_rec;
     const bool ring = p->ring_half > 0;
@@ -1144,7 +1144,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     b->d_seg = p->drec ? nullptr : reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
     b->d_drec = p->drec ? reinterpret_cast<uint4 *>(s.d_in + s.off_rec) : nullptr;
     b->d_rec16 = nullptr; b->d_rec32 = nullptr;
-    b->d_pair = linkage ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pairs) : nullptr;
+    b->d_pair = linkage && !p->drec ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pairs) : nullptr;
     b->d_pair_runs = nullptr; b->d_run_index = nullptr; b->n_runs = 0;
     s.encode_ms = (float)(now_ms() - t0);
     if (!p->drec) s.encode_passes = 1;
@@ -1166,7 +1166,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (ring) { if (ring_bytes != rec_bytes) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; } }
     else HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
     s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
-    if (linkage) {
+    if (linkage && !p->drec) {
         HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, s.h_in + s.off_pairs, (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, p->s_h2d));
         s.h2d_bytes += (int64_t)b->n_rec * 4;
     }
@@ -1239,7 +1239,7 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         w->o_win = o; o = up(o + win_cap);
         w->o_ref = o; o = up(o + w->ref_bytes);
         w->o_gbase = o; o = up(o + n_groups * sizeof(uint32_t));
-        w->o_pairs = o; if (linkage) o = up(o + (size_t)cap * sizeof(uint32_t));
+        w->o_pairs = o; if (linkage && !p->drec) o = up(o + (size_t)cap * sizeof(uint32_t));
         w->o_rec = o; o = up(o + (size_t)cap * rb);
         if (w->h) { isx_pin_free(w->h); w->h = nullptr; }
         HIP_TRY(isx_pin_malloc(reinterpret_cast<void **>(&w->h), o));
@@ -1250,7 +1250,7 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         if (!linkage) J.in.pair = nullptr;
         J.rec = reinterpret_cast<uint32_t *>(w->h + w->o_rec);
         J.gbase = reinterpret_cast<uint32_t *>(w->h + w->o_gbase);
-        J.pair_out = linkage ? reinterpret_cast<uint32_t *>(w->h + w->o_pairs) : nullptr;
+        J.pair_out = linkage && !p->drec ? reinterpret_cast<uint32_t *>(w->h + w->o_pairs) : nullptr;
         J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data();
         J.cap_rec = cap;
         int erc;
@@ -1270,7 +1270,7 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     w->n_rec = J.n_rec; w->n_bases = J.n_bases; w->n_pairs = (uint64_t)J.max_pair + 1;
     w->gbase_bytes = (size_t)(J.n_rec / (int64_t)G) * sizeof(uint32_t);
     w->rec_bytes = (size_t)J.n_rec * rb;
-    w->pairs_bytes = linkage ? (size_t)J.n_rec * sizeof(uint32_t) : 0;
+    w->pairs_bytes = linkage && !p->drec ? (size_t)J.n_rec * sizeof(uint32_t) : 0;
     w->ref_has_n = pack_ref2(*p->pool, ref, n_pos, w->h + w->o_ref, w->h + w->o_ref + ref2_bytes(n_pos));
     if (!w->ref_has_n) w->ref_bytes = ref2_bytes(n_pos);
     memcpy(w->h + w->o_bounds, split_bounds, w->bounds_bytes);
@@ -1343,14 +1343,14 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     b->d_seg = p->drec ? nullptr : reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
     b->d_drec = p->drec ? reinterpret_cast<uint4 *>(s.d_in + s.off_rec) : nullptr;
     b->d_rec16 = nullptr; b->d_rec32 = nullptr;
-    b->d_pair = linkage ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pairs) : nullptr;
+    b->d_pair = linkage && !p->drec ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pairs) : nullptr;
     b->d_pair_runs = nullptr; b->d_run_index = nullptr; b->n_runs = 0;
     HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, w->h + w->o_bounds, w->bounds_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, w->h + w->o_win, w->win_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, w->h + w->o_ref, w->ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, w->h + w->o_gbase, w->gbase_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    if (linkage) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, w->h + w->o_pairs, w->pairs_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    if (w->pairs_bytes) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, w->h + w->o_pairs, w->pairs_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, w->h + w->o_rec, w->rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
     s.h2d_bytes = isx_wire_bytes(w);

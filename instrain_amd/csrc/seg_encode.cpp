@@ -292,8 +292,10 @@ inline void window160(const uint64_t m[3], uint32_t b, uint32_t len, uint64_t ou
 
 struct GroupBuf {
     alignas(64) uint32_t rec[ISX_DREC_GROUP][ISX_DREC_WORDS];
-    uint32_t start[ISX_DREC_GROUP], last[ISX_DREC_GROUP], pair[ISX_DREC_GROUP];
-    int n = 0;
+    uint32_t start[2 * ISX_DREC_GROUP], last[2 * ISX_DREC_GROUP];      // per 16-byte half (a full record: its first)
+    bool used[2 * ISX_DREC_GROUP];
+    int n = 0;                  // records
+    int open = -1;              // the dual record whose second half is still free (-1: none)
     uint32_t lo = 0, hi = 0;
 };
 
@@ -312,7 +314,7 @@ int64_t delta_groups_needed(HostPool &pool, const uint32_t *gpos, int64_t n, int
     std::vector<int64_t> g((size_t)std::max(n_tasks, 1), 0);
     pool.run(n_tasks, [&](int t) {
         const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
-        g[(size_t)t] = count_groups(gpos, a, e, ISX_DREC_GROUP) + slack_groups;
+        g[(size_t)t] = count_groups(gpos, a, e, 2 * ISX_DREC_GROUP) + slack_groups;      // (a group holds up to 64 segments without skipped columns)
     });
     int64_t tot = 0;
     for (int64_t v : g) tot += v;
@@ -330,7 +332,7 @@ int encode_delta(HostPool &pool, SegJob &J)
     if (J.task_groups) for (int t = 0; t < n_tasks; t++) g_at[(size_t)t + 1] = std::max<int64_t>(J.task_groups[t], 1);
     else pool.run(n_tasks, [&](int t) {
         const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
-        g_at[(size_t)t + 1] = count_groups(gpos_all, a, e, ISX_DREC_GROUP) + slack;
+        g_at[(size_t)t + 1] = count_groups(gpos_all, a, e, 2 * ISX_DREC_GROUP) + slack;
     });
     for (int t = 0; t < n_tasks; t++) g_at[(size_t)t + 1] += g_at[(size_t)t];
     const int64_t n_groups = std::max<int64_t>(g_at[(size_t)n_tasks], 1);
@@ -340,21 +342,20 @@ int encode_delta(HostPool &pool, SegJob &J)
     std::atomic<int> err{SEG_OK};
     std::vector<int64_t> bases_of((size_t)std::max(n_tasks, 1), 0), need_of((size_t)std::max(n_tasks, 1), 0), pieces_of((size_t)std::max(n_tasks, 1), 0);
     std::vector<uint32_t> maxp_of((size_t)std::max(n_tasks, 1), 0);
-    const bool pairs = J.pair_out != nullptr && (producer ? J.want_pairs : J.in.pair != nullptr);
+    const bool pairs = producer ? J.want_pairs : J.in.pair != nullptr;          // (the ids travel inside the records: pair_out is not written)
     const int64_t RG = J.ring_groups;
     constexpr size_t group_words = (size_t)ISX_DREC_GROUP * ISX_DREC_WORDS;
     const bool fast_store = cpu_has_avx512() && (reinterpret_cast<uintptr_t>(J.rec) & 63) == 0;
     const bool vbmi = cpu_has_vbmi();
-    auto put_empty_group = [&](uint32_t *o) {
+    auto put_empty_group = [&](uint32_t *o) {     // full records of length 0
         for (int r = 0; r < ISX_DREC_GROUP; r++, o += ISX_DREC_WORDS) {
-            o[0] = o[1] = o[2] = o[4] = o[5] = o[6] = 0;
-            o[3] = o[7] = ISX_DREC_NO_EXC;
+            o[0] = o[1] = o[2] = o[4] = o[5] = o[6] = o[7] = 0;
+            o[3] = ISX_DREC_NO_EXC;
         }
     };
     if (n == 0) {                                   // one empty group: the kernels want a stream
         if (RG) J.wave_begin(0);
         put_empty_group(J.rec);
-        if (J.pair_out) for (int r = 0; r < ISX_DREC_GROUP; r++) J.pair_out[r] = 0;
         J.gbase[0] = 0; J.cmin[0] = 0xFFFFFFFFu; J.cmax[0] = 0; J.cany[0] = 0;
         J.n_bases = 0; J.max_pair = 0; J.n_pieces = 0;
         if (RG) J.wave_flush(0, 0, 1);
@@ -382,37 +383,56 @@ int encode_delta(HostPool &pool, SegJob &J)
         auto close_group = [&]() {
             if (!G.n) return;
             if (g < g_end) {
-                uint32_t lo = G.start[0], last = G.last[0];
-                for (int r = 1; r < G.n; r++) { lo = std::min(lo, G.start[r]); last = std::max(last, G.last[r]); }
-                for (int r = 0; r < G.n; r++) G.rec[r][0] |= G.start[r] - lo;
+                uint32_t lo = 0xFFFFFFFFu, last = 0;
+                for (int h = 0; h < 2 * G.n; h++) if (G.used[h]) { lo = std::min(lo, G.start[h]); last = std::max(last, G.last[h]); }
+                for (int h = 0; h < 2 * G.n; h++) if (G.used[h]) G.rec[h >> 1][4 * (h & 1)] |= G.start[h] - lo;
                 for (int r = G.n; r < ISX_DREC_GROUP; r++) {
                     uint32_t *o = G.rec[r];
-                    o[0] = o[1] = o[2] = o[4] = o[5] = o[6] = 0;
-                    o[3] = o[7] = ISX_DREC_NO_EXC;
-                    G.pair[r] = 0;
+                    o[0] = o[1] = o[2] = o[4] = o[5] = o[6] = o[7] = 0;
+                    o[3] = ISX_DREC_NO_EXC;
                 }
                 uint32_t *o = rec_at(g);
                 if (fast_store) store_group_avx512(o, G); else memcpy(o, G.rec, sizeof G.rec);
-                if (J.pair_out) memcpy(J.pair_out + (size_t)g * ISX_DREC_GROUP, G.pair, sizeof G.pair);
                 J.gbase[g] = lo; J.cmin[g] = lo; J.cmax[g] = last; J.cany[g] = 1;
                 g++;
             }
             used++;
-            G.n = 0;
+            G.n = 0; G.open = -1;
         };
-        auto add_piece = [&](uint32_t start, uint32_t len, uint32_t m, uint32_t pid, const uint64_t msk[3], const uint32_t exc[2]) {
+        // one piece of a segment -> a 16-byte half of a dual record when the segment has no skipped columns (`plain`: exc holds up to
+        // ISX_DREC_EXC exceptions), else a full record (msk + exc[0]: up to ISX_DREC_EXC_FULL exceptions).  A plain piece fills the free
+        // half of the record before it only while no full record has come in between: the stream keeps the segments' order.
+        auto add_piece = [&](uint32_t start, uint32_t len, uint32_t pid, const uint64_t msk[3], const uint32_t exc[2], bool plain) {
+            bool fill = plain && G.open >= 0;
             if (G.n) {
                 const uint32_t nlo = std::min(G.lo, start), nhi = std::max(G.hi, start);
-                if (G.n == ISX_DREC_GROUP || nhi - nlo > SPAN) close_group();
+                if (nhi - nlo > SPAN || (!fill && G.n == ISX_DREC_GROUP)) { close_group(); fill = false; }
             }
             if (!G.n) { G.lo = G.hi = start; }
             else { G.lo = std::min(G.lo, start); G.hi = std::max(G.hi, start); }
-            uint32_t *o = G.rec[G.n];
-            o[0] = (len << 16) | (m << 24);
-            o[1] = (uint32_t)msk[0]; o[2] = (uint32_t)(msk[0] >> 32); o[3] = exc[0];
-            o[4] = (uint32_t)msk[1]; o[5] = (uint32_t)(msk[1] >> 32); o[6] = (uint32_t)msk[2]; o[7] = exc[1];
-            G.start[G.n] = start; G.last[G.n] = start + len - 1; G.pair[G.n] = pid;
-            G.n++;
+            int h;
+            if (fill) {
+                h = 2 * G.open + 1;
+                uint32_t *o = G.rec[G.open] + 4;
+                o[0] = (len << 16) | ISX_DREC_DUAL; o[1] = pid; o[2] = exc[0]; o[3] = exc[1];
+                G.open = -1;
+            } else {
+                h = 2 * G.n;
+                uint32_t *o = G.rec[G.n];
+                if (plain) {
+                    o[0] = (len << 16) | ISX_DREC_DUAL; o[1] = pid; o[2] = exc[0]; o[3] = exc[1];
+                    o[4] = ISX_DREC_DUAL; o[5] = 0; o[6] = o[7] = ISX_DREC_NO_EXC;         // second half: length 0 until a piece moves in
+                    G.open = G.n;
+                } else {
+                    o[0] = len << 16;
+                    o[1] = (uint32_t)msk[0]; o[2] = (uint32_t)(msk[0] >> 32); o[3] = exc[0];
+                    o[4] = (uint32_t)msk[1]; o[5] = (uint32_t)(msk[1] >> 32); o[6] = (uint32_t)msk[2]; o[7] = pid;
+                    G.open = -1;
+                }
+                G.used[h + 1] = false;
+                G.n++;
+            }
+            G.used[h] = true; G.start[h] = start; G.last[h] = start + len - 1;
             np++;
         };
         Cols C;
@@ -427,12 +447,14 @@ int encode_delta(HostPool &pool, SegJob &J)
             if (vbmi) cols_vbmi(bs + (size_t)s * ISX_SEG_WORDS, J.ref + p, L, C);
             else cols_scalar(bs + (size_t)s * ISX_SEG_WORDS, J.ref + p, L, C);
             const int n_exc = __builtin_popcountll(C.exc[0]) + __builtin_popcountll(C.exc[1]) + __builtin_popcountll(C.exc[2]);
+            const bool plain = (C.skip[0] | C.skip[1] | C.skip[2]) == 0;           // no skipped column in the whole segment: its pieces are dual halves
             if (n_exc == 0) {
                 const uint32_t none[2] = {ISX_DREC_NO_EXC, ISX_DREC_NO_EXC};
-                add_piece(p, L, m, pid, C.skip, none);
+                add_piece(p, L, pid, C.skip, none, plain);
                 continue;
             }
-            // pieces of at most ISX_DREC_EXC exceptions: a piece ends right before the exception it has no room for
+            // pieces of at most ISX_DREC_EXC (plain) / ISX_DREC_EXC_FULL exceptions: a piece ends right before the exception it has no room for
+            const uint32_t max_exc = plain ? ISX_DREC_EXC : ISX_DREC_EXC_FULL;
             uint64_t ex[3] = {C.exc[0], C.exc[1], C.exc[2]};
             uint32_t b = 0;
             while (b < L) {
@@ -440,7 +462,7 @@ int encode_delta(HostPool &pool, SegJob &J)
                 for (int k = 0; k < 3; k++) {
                     while (ex[k]) {
                         const uint32_t col = (uint32_t)(64 * k + __builtin_ctzll(ex[k]));
-                        if (nf == ISX_DREC_EXC) { end = col; goto cut; }
+                        if (nf == max_exc) { end = col; goto cut; }
                         ex[k] &= ex[k] - 1;
                         f[nf++] = ((col - b) & 0xFFu) | ((uint32_t)(C.code[col] & 3u) << 8);
                     }
@@ -453,7 +475,7 @@ int encode_delta(HostPool &pool, SegJob &J)
                 }
                 uint64_t msk[3];
                 window160(C.skip, b, end - b, msk);
-                add_piece(p + b, end - b, m, pid, msk, w);
+                add_piece(p + b, end - b, pid, msk, w, plain);
                 b = end;
             }
         }
@@ -461,7 +483,6 @@ int encode_delta(HostPool &pool, SegJob &J)
         need_of[(size_t)t] = used;
         for (; g < g_end; g++) {                    // the spare groups of the region: empty
             put_empty_group(rec_at(g));
-            if (J.pair_out) memset(J.pair_out + (size_t)g * ISX_DREC_GROUP, 0, ISX_DREC_GROUP * sizeof(uint32_t));
             J.gbase[g] = 0; J.cmin[g] = 0xFFFFFFFFu; J.cmax[g] = 0; J.cany[g] = 0;
         }
         bases_of[(size_t)t] = nb; maxp_of[(size_t)t] = maxp; pieces_of[(size_t)t] = np;
@@ -584,7 +605,7 @@ int isx_encode_delta(const isx_segs *segs, const uint8_t *ref, int64_t n_pos, in
                      int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec, int64_t *need_slack)
 {
     if (!segs || !ref || !rec || !gbase || !n_rec || segs->n_seg < 0 || cap_rec < ISX_DREC_GROUP || (cap_rec % ISX_DREC_GROUP) || n_pos <= 0 ||
-        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases)) || (segs->pair && !pair_out) || ring_records < 0 ||
+        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases)) || ring_records < 0 ||
         (ring_records % (2 * ISX_DREC_GROUP)) || slack_groups < 0) {
         isx_set_error("isx_encode_delta: bad argument");
         return ISX_ERR_ARG;
@@ -596,7 +617,8 @@ int isx_encode_delta(const isx_segs *segs, const uint8_t *ref, int64_t n_pos, in
     isxenc::SegJob J;
     J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = std::max(1, n_mm_bins);
     J.ref = ref; J.slack_groups = std::max(1, slack_groups);
-    J.rec = rec; J.gbase = gbase; J.pair_out = segs->pair ? pair_out : nullptr;
+    (void)pair_out;             // (the read-pair ids travel inside the records)
+    J.rec = rec; J.gbase = gbase; J.pair_out = nullptr;
     J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data(); J.cap_rec = cap_rec;
     if (ring_records) {         // the pipe's ring mode with a memcpy standing in for the DMA engine
         const int64_t half = ring_records / 2;

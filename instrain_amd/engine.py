@@ -529,56 +529,75 @@ def encode_segs(segs, n_pos, n_mm_bins=1, threads=1, cap_rec=None, ring_records=
 
 
 def encode_delta(segs, ref_codes, n_mm_bins=1, threads=1, slack_groups=1, cap_rec=None, ring_records=0, retry=True):
-    """isx_encode_delta (host only): SegBatch + reference codes -> (rec [n_rec, 8] uint32, gbase [n_rec / 32], pair_out | None,
-    slack_groups used); retry: encode again with the slack the first attempt asked for"""
+    """isx_encode_delta (host only): SegBatch + reference codes -> (rec [n_rec, 8] uint32, gbase [n_rec / 32], None, slack_groups used);
+    the read-pair ids travel inside the records (decode_delta returns them).  retry: encode again with the slack the first attempt
+    asked for"""
     lib = _lib.load()
     ref = np.ascontiguousarray(ref_codes, dtype=np.uint8)
     while True:
         cap = cap_rec if cap_rec is not None else int(lib.isx_delta_records_needed(segs.gpos.ctypes.data if segs.n_seg else None, segs.n_seg, int(threads), int(slack_groups)))
         rec = np.empty((cap, 8), dtype=np.uint32)
         gbase = np.empty(cap // 32, dtype=np.uint32)
-        pout = np.empty(cap, dtype=np.uint32) if segs.pair is not None else None
         n_rec, need = C.c_int64(0), C.c_int64(0)
         cs = segs.c()
         rc = lib.isx_encode_delta(C.byref(cs), ref.ctypes.data, len(ref), int(n_mm_bins), int(threads), int(slack_groups), cap, int(ring_records),
-                                  rec.ctypes.data, gbase.ctypes.data, pout.ctypes.data if pout is not None else None, C.byref(n_rec), C.byref(need))
+                                  rec.ctypes.data, gbase.ctypes.data, None, C.byref(n_rec), C.byref(need))
         if rc == _lib.ERR_CAPACITY and retry and need.value > slack_groups and cap_rec is None:
             slack_groups = int(need.value)
             continue
         check(rc)
         n = n_rec.value
-        return rec[:n], gbase[:n // 32], (pout[:n] if pout is not None else None), slack_groups
+        return rec[:n], gbase[:n // 32], None, slack_groups
+
+
+DREC_DUAL = 0x80000000
+DREC_NO_EXC = 0x3FFFFFFF
 
 
 def decode_delta(rec, gbase, ref_codes):
-    """reference-delta record stream -> (gpos, len, mm, codes [n, 150]) of its real records (pieces), in stream order (tests);
-    code 4 where a column is skipped or beyond the record's length"""
+    """reference-delta record stream -> (gpos, len, mm, codes [n, 150], pair, full) of its pieces in stream order (a dual record's first
+    half before its second) -- tests; code 4 where a column is skipped or beyond the piece's length; full: the piece is a full record"""
     rec = np.asarray(rec, dtype=np.uint32).reshape(-1, 8)
     ref = np.asarray(ref_codes, dtype=np.uint8)
-    hdr = rec[:, 0]
+    n = len(rec)
+    dual = (rec[:, 0] >> 31) == 1
+    assert ((rec[dual, 4] >> 31) == 1).all(), "a dual record's second half carries the flag too"
+    assert ((rec[:, 0] >> 24) & 0x7F == 0).all() and ((rec[dual, 4] >> 24) & 0x7F == 0).all()
+    zero = np.zeros(n, dtype=np.uint32)
+    none = np.full(n, DREC_NO_EXC, dtype=np.uint32)
+    # per half: header, pair id, two exception words, five skip words
+    hdr = np.stack([rec[:, 0], np.where(dual, rec[:, 4], zero)], axis=1)
+    pair = np.stack([np.where(dual, rec[:, 1], rec[:, 7]), np.where(dual, rec[:, 5], zero)], axis=1)
+    e0 = np.stack([np.where(dual, rec[:, 2], rec[:, 3]), np.where(dual, rec[:, 6], none)], axis=1)
+    e1 = np.stack([np.where(dual, rec[:, 3], none), np.where(dual, rec[:, 7], none)], axis=1)
+    skw = [np.stack([np.where(dual, zero, rec[:, k]), zero], axis=1) for k in (1, 2, 4, 5, 6)]
+    gb = np.repeat(np.asarray(gbase, dtype=np.uint32), 32)[:n]
+    start = (gb[:, None] + (hdr & 0xFFFF)).astype(np.int64)
     ln = ((hdr >> 16) & 0xFF).astype(np.int64)
-    real = ln > 0
-    start = (np.repeat(np.asarray(gbase, dtype=np.uint32), 32)[:len(rec)] + (hdr & 0xFFFF)).astype(np.int64)
-    r, st, ln = rec[real], start[real], ln[real]
-    n = len(r)
+    full = np.stack([~dual, np.zeros(n, dtype=bool)], axis=1)
+    real = (ln > 0).reshape(-1)
+    flat = lambda x: x.reshape(-1)[real]
+    st, ln, pr, e0, e1, fl = flat(start), flat(ln), flat(pair), flat(e0), flat(e1), flat(full)
+    words = np.stack([flat(w) for w in skw], axis=1)
+    m = len(st)
     j = np.arange(160, dtype=np.int64)[None, :]
-    words = np.stack([r[:, 1], r[:, 2], r[:, 4], r[:, 5], r[:, 6]], axis=1)
-    skip = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(n, 160).astype(bool)
-    assert not (skip & (j >= ln[:, None])).any(), "skip bits beyond a record's length"
+    skip = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(m, 160).astype(bool)
+    assert not (skip & (j >= ln[:, None])).any(), "skip bits beyond a piece's length"
+    assert skip[fl].any(axis=1).all() or True
     inside = j < ln[:, None]
     pos = np.minimum(st[:, None] + j, len(ref) - 1)
     codes = np.where(inside & ~skip, ref[pos], 4).astype(np.uint8)
-    for wi in (3, 7):
+    for e in (e0, e1):
         for k in range(3):
-            f = (r[:, wi] >> (10 * k)) & 0x3FF
+            f = (e >> (10 * k)) & 0x3FF
             has = f != 0x3FF
             off, base = (f & 0xFF).astype(np.int64), ((f >> 8) & 3).astype(np.uint8)
             rows = np.flatnonzero(has)
             assert (off[rows] < ln[rows]).all() and not skip[rows, off[rows]].any()
             assert (base[rows] != ref[st[rows] + off[rows]]).all(), "an exception that equals the reference"
             codes[rows, off[rows]] = base[rows]
-        assert ((r[:, wi] >> 30) == 0).all()
-    return st.astype(np.uint32), ln.astype(np.uint8), (hdr[real] >> 24).astype(np.uint8), codes[:, :150]
+        assert ((e >> 30) == 0).all()
+    return st.astype(np.uint32), ln.astype(np.uint8), np.zeros(m, dtype=np.uint8), codes[:, :150], pr, fl
 
 
 def decode_segs(rec, gbase):

@@ -190,11 +190,11 @@ def test_segments_straddling_windows_and_far_jumps(ctx):
             assert (c.astype(np.int64) == exp).all(), (window, layout)
 
 
-def _c2(scale=1.0, seed=2, skip_mm=True, with_n=False):
+def _c2(scale=1.0, seed=2, skip_mm=True, with_n=False, p_keep=0.90):
     """with_n: positions that are not A/C/T/G in the reference (isolated ones and a run): a pipe slot then carries the bit plane
     that marks them beside its 2-bit reference plane"""
     from instrain_amd import synth
-    w = synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale), seed=seed, skip_mm=skip_mm)
+    w = synth.make_workload(genome_len=int(5_000_000 * scale), coverage=20, n_sites=int(5000 * scale), seed=seed, skip_mm=skip_mm, p_keep=p_keep)
     if with_n:
         rng = np.random.Generator(np.random.PCG64(seed + 99))
         ref = w["ref_codes"].copy()
@@ -204,11 +204,14 @@ def _c2(scale=1.0, seed=2, skip_mm=True, with_n=False):
     return w
 
 
-@pytest.mark.parametrize("skip_mm,linkage,layout", [(True, False, 0), (True, True, 0), (True, True, NOPACK), (True, True, SEG64), (False, True, 0)])
-def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage, layout):
-    """a C2 slice through the read-level pipe == the same observations through a resident batch, every table"""
+@pytest.mark.parametrize("skip_mm,linkage,layout,p_keep", [(True, False, 0, 0.9), (True, True, 0, 0.9), (True, True, NOPACK, 0.9), (True, True, SEG64, 0.9), (False, True, 0, 0.9),
+                                                           (True, True, 0, 0.995), (True, False, 0, 1.0), (True, True, NOPACK, 0.995)])
+def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage, layout, p_keep):
+    """a C2 slice through the read-level pipe == the same observations through a resident batch, every table
+    (p_keep 0.9: every read has bases below the quality bar = full reference-delta records; 0.995: about half of them have none = halves
+    of dual records, mixed with full ones; 1.0: dual records only)"""
     from instrain_amd import engine, synth
-    w = _c2(0.1, seed=4, skip_mm=skip_mm, with_n=linkage)
+    w = _c2(0.1, seed=4, skip_mm=skip_mm, with_n=linkage, p_keep=p_keep)
     M = w["n_mm_bins"]
     segs = synth.segs_from_obs(w["obs"], w["pair"])
     kw = dict(n_mm_bins=M, enable_linkage=linkage, min_snp=20, layout=layout)

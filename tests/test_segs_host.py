@@ -10,8 +10,8 @@ from instrain_amd import engine, synth
 from tests import util
 
 
-def _workload(seed=7, G=60_000, cov=12, skip_mm=False):
-    return synth.make_workload(genome_len=G, coverage=cov, n_sites=200, seed=seed, skip_mm=skip_mm)
+def _workload(seed=7, G=60_000, cov=12, skip_mm=False, **kw):
+    return synth.make_workload(genome_len=G, coverage=cov, n_sites=200, seed=seed, skip_mm=skip_mm, **kw)
 
 
 def test_segments_of_a_read_major_stream_round_trip():
@@ -135,7 +135,7 @@ def _pieces_to_columns(g, ln, cd, n_pos):
 def _mutated_workload(seed, G=120_000, cov=6, err=0.05, n_frac=0.01):
     """reads with MANY mismatches (5 %: ~7 per read -> pieces) over a reference with non-ACGT stretches"""
     rng = np.random.default_rng(seed)
-    w = synth.make_workload(genome_len=G, coverage=cov, n_sites=G // 50, err=err, seed=seed, skip_mm=True)
+    w = synth.make_workload(genome_len=G, coverage=cov, n_sites=G // 50, err=err, seed=seed, skip_mm=True, p_keep=0.995)
     ref = w["ref_codes"].copy()
     ref[rng.random(G) < n_frac] = 4
     ref[1000:1400] = 4
@@ -155,34 +155,40 @@ def test_encode_delta_round_trip(threads, vbmi):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         return
-    w = _workload(seed=21, G=300_000, cov=8, skip_mm=True)
+    w = _workload(seed=21, G=300_000, cov=8, skip_mm=True, p_keep=0.995)      # about half of the reads have no base below the quality bar
     segs = synth.segs_from_obs(w["obs"], w["pair"])
-    rec, gbase, pout, slack = engine.encode_delta(segs, w["ref_codes"], threads=threads)
+    rec, gbase, _, slack = engine.encode_delta(segs, w["ref_codes"], threads=threads)
     assert len(rec) % 32 == 0 and len(gbase) == len(rec) // 32
-    g, ln, mm, cd = engine.decode_delta(rec, gbase, w["ref_codes"])
+    g, ln, mm, cd, pr, full = engine.decode_delta(rec, gbase, w["ref_codes"])
     exp = engine.unpack_codes(segs.bases)
     exp = np.where((np.arange(150)[None, :] < segs.len[:, None]) & (exp < 4), exp, 4)
-    assert len(g) == segs.n_seg and (g == segs.gpos).all() and (ln == segs.len).all() and (cd == exp).all()
-    real = ((rec[:, 0] >> 16) & 0xFF) > 0
-    assert (pout[real] == segs.pair).all() and (pout[~real] == 0).all()
-    assert (rec[~real][:, [1, 2, 4, 5, 6]] == 0).all() and (rec[~real][:, [3, 7]] == 0x3FFFFFFF).all() and (rec[~real, 0] == 0).all()
+    assert len(g) == segs.n_seg and (g == segs.gpos).all() and (ln == segs.len).all() and (cd == exp).all() and (pr == segs.pair).all()
+    # a segment without a skipped column is half of a dual record (16 bytes a read), one with skipped columns a full record
+    has_skip = ((exp == 4) & (np.arange(150)[None, :] < segs.len[:, None])).any(axis=1)
+    assert (full == has_skip).all() and 0.2 < has_skip.mean() < 0.8
+    n_dual = int((rec[:, 0] >> 31).sum())
+    assert n_dual <= ((~has_skip).sum() + 1) // 2 + int(has_skip.sum()) + len(gbase)        # halves are filled wherever the order allows
+    pad = (((rec[:, 0] >> 16) & 0xFF) == 0) & ((rec[:, 0] >> 31) == 0)
+    assert (rec[pad][:, [0, 1, 2, 4, 5, 6, 7]] == 0).all() and (rec[pad][:, 3] == 0x3FFFFFFF).all()
     # many mismatches + non-ACGT reference: pieces
     w, ref = _mutated_workload(seed=22)
     segs = synth.segs_from_obs(w["obs"], w["pair"])
-    rec, gbase, pout, slack = engine.encode_delta(segs, ref, threads=threads)
-    g, ln, mm, cd = engine.decode_delta(rec, gbase, ref)
+    rec, gbase, _, slack = engine.encode_delta(segs, ref, threads=threads)
+    g, ln, mm, cd, pr, full = engine.decode_delta(rec, gbase, ref)
     assert len(g) > segs.n_seg * 1.2 and slack > 1                 # pieces, and the first attempt's single spare group was not enough
     gg, bb, _, _ = util.segs_to_obs(segs)
     assert (_pieces_to_columns(g, ln, cd, len(ref)) == np.sort(gg * 8 + bb)).all()
-    real = ((rec[:, 0] >> 16) & 0xFF) > 0
-    # pieces keep their segment's pair id and the stream's order; a piece never carries more than six exceptions
-    n_exc = sum((((rec[real][:, wi] >> (10 * k)) & 0x3FF) != 0x3FF).astype(int) for wi in (3, 7) for k in range(3))
-    assert n_exc.max() == 6
-    first = np.r_[True, (pout[real][1:] != pout[real][:-1]) | (g[1:] <= g[:-1])]
-    assert first.sum() >= segs.n_seg * 0.99
+    # a piece never carries more exceptions than its kind holds: six in a dual half, three in a full record
+    ref_at = ref[np.minimum(g[:, None].astype(np.int64) + np.arange(150)[None, :], len(ref) - 1)]
+    n_exc = ((cd < 4) & (cd != ref_at) & (np.arange(150)[None, :] < ln[:, None])).sum(axis=1)
+    assert n_exc[~full].max() == 6 and n_exc[full].max() == 3
+    # pieces keep their segment's pair id and the stream's order
+    first = np.r_[True, (pr[1:] != pr[:-1]) | (g[1:].astype(np.int64) != g[:-1].astype(np.int64) + ln[:-1])]        # a piece continues where the one before it ends
+    starts = g[first]
+    assert len(starts) == segs.n_seg and (starts == segs.gpos).all() and (pr[first] == segs.pair).all()
     # through the staging ring: the same stream
-    r2 = engine.encode_delta(segs, ref, threads=threads, slack_groups=slack, ring_records=2 * 8192)
-    assert (r2[0] == rec).all() and (r2[1] == gbase).all() and (r2[2] == pout).all()
+    r2 = engine.encode_delta(segs, ref, threads=threads, slack_groups=slack, ring_records=2 * 32768)
+    assert (r2[0] == rec).all() and (r2[1] == gbase).all()
     from instrain_amd._lib import IsxError
     with pytest.raises(IsxError):
         engine.encode_delta(segs, ref, slack_groups=1, retry=False)
