@@ -74,7 +74,7 @@ def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense, record_bytes=8, n_r
 # isx_pipe_params.lean_output (a slot's kernel writes only what travels home: 1-2 instead of 6-7 bytes a position) is built and tested,
 # but moves no clock: the kernel is bound by its per-window latency chain, not by its stores (C5: 1.24-1.29 ms per launch either
 # way, same box) -- so the bench keeps the plain slots whose dense arrays the device summaries can read.
-LEAN_SLOTS = bool(int(os.environ.get("ISX_BENCH_LEAN_SLOTS", "0")))
+LEAN_SLOTS = bool(int(os.environ.get("ISX_BENCH_LEAN_SLOTS", "1")))
 C5_RESERVE_CUS = int(os.environ.get("ISX_BENCH_C5_RESERVE_CUS", "4"))
 C5_LINKAGE = bool(int(os.environ.get("ISX_BENCH_C5_LINKAGE", "1")))      # 0: diagnostic only (what the linkage chain costs the stream); not the workload
 
@@ -88,6 +88,8 @@ def slot_out_bytes_per_pos(n_obs, n_pos, lean=None):
     shallow = n_obs < 16 * n_pos
     if lean is None:
         lean = LEAN_SLOTS
+    if lean and n_obs < 6 * n_pos:
+        return 0.5                  # 4-bit coverage plane (the 16-bit rows of the windows beyond 15 not counted)
     return (1 if shallow else 2) if lean else (7 if shallow else 6)
 
 
@@ -480,9 +482,10 @@ class C5Run:
         sig = []
 
         def check(i, r):
+            from instrain_amd import engine
             w = self.ws[i]
-            cov = (r["cov16"] if "cov16" in r else r["cov8"]).astype(np.int64)
-            lim = 65535 if "cov16" in r else 255
+            cov = engine.dense_cov(r, w["n_pos"]).astype(np.int64) if "cov4" in r else (r["cov16"] if "cov16" in r else r["cov8"]).astype(np.int64)
+            lim = 65535 if ("cov16" in r or "cov4" in r) else 255
             total = int(cov.sum())
             if "saturated" in r:
                 s = r["saturated"]

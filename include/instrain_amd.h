@@ -408,6 +408,16 @@ typedef struct {
     int64_t n_clon;
     const isx_sat *saturated;   /* [n_saturated] (gpos, exact coverage) of the positions whose coverage16 / coverage8 entry
                                  * saturated, unordered; NULL when the list outgrew the pipe's room (isx_batch_fetch_dense then) */
+    /* lean slots (isx_pipe_params.lean_output), a batch of mean depth below 6 in reference-delta records: coverage16 == coverage8 == NULL ->
+     * coverage4: min(covT, 15) of two positions a byte (low nibble = the even position), and every window of cov_window positions
+     * (window w = positions [w * cov_window, (w + 1) * cov_window)) that holds a position beyond 15 ALSO as a whole row of 16-bit
+     * values: row k of cov_rows is window cov_row_window[k] (rows in no particular order; a position beyond 65534: `saturated`).
+     * Half a byte per position over PCIe for a metagenome at depth 3 instead of one. */
+    const uint8_t *coverage4;   /* [(n_pos + 1) / 2] */
+    const uint16_t *cov_rows;   /* [n_cov_rows][cov_window] (the last window's row: entries beyond n_pos are 0) */
+    const uint32_t *cov_row_window; /* [n_cov_rows] */
+    int64_t n_cov_rows;
+    int32_t cov_window, pad_cov;
 } isx_pipe_result;
 
 int isx_pipe_create(isx_ctx *ctx, const isx_params *params, const isx_pipe_params *pp, isx_pipe **out);

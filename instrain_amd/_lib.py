@@ -80,7 +80,9 @@ class PipeResult(C.Structure):
                 ("encode_ms", C.c_float), ("h2d_ms", C.c_float), ("kernel_ms", C.c_float), ("d2h_ms", C.c_float),
                 ("collect_wait_ms", C.c_float), ("record_bytes", C.c_int32), ("encode_passes", C.c_int32),
                 ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64), ("ld", C.c_void_p),
-                ("coverage8", C.c_void_p), ("clon_sparse", C.c_void_p), ("n_clon", C.c_int64), ("saturated", C.c_void_p)]
+                ("coverage8", C.c_void_p), ("clon_sparse", C.c_void_p), ("n_clon", C.c_int64), ("saturated", C.c_void_p),
+                ("coverage4", C.c_void_p), ("cov_rows", C.c_void_p), ("cov_row_window", C.c_void_p), ("n_cov_rows", C.c_int64),
+                ("cov_window", C.c_int32), ("pad_cov", C.c_int32)]
 
 
 class BamParams(C.Structure):

@@ -845,7 +845,7 @@ void isx_batch_destroy(isx_batch *b)
     }
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ps[] = {b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_drec, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
+    void *ps[] = {b->d_cov_row_win, b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_drec, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors, b->d_snv_raw, b->d_sites_raw, b->d_rare_raw, b->d_win_rec, b->d_win_out};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) isx_dev_free(p);          // (falls through to hipFree for blocks that did not come from the cache)
@@ -1112,6 +1112,14 @@ int launch_pass(isx_batch *b)
     a.cov16 = b->d_cov16; a.rare = b->d_rare; a.cap_rare = (uint32_t)std::min<size_t>(b->cap_rare, 0xFFFFFFFFu);
     a.cov8 = b->sparse_out && b->cov8_out ? b->d_cov8 : nullptr;
     a.sat = b->d_sat; a.cap_sat = (uint32_t)std::min<size_t>(b->cap_sat, 0xFFFFFFFFu); a.sat_thr = a.cov8 ? 255u : 65535u;
+    b->nib_pass = false;
+    if (b->sparse_out && b->nib_out && b->lean && b->drec && b->packed && b->M == 1 && b->d_cov_row_win && b->d_cov8 &&
+        (size_t)b->n_win <= b->cap_cov_row_win) {      // 4-bit plane + rows: the two coverage buffers change their roles
+        b->nib_pass = true;
+        a.cov4 = b->d_cov8; a.cov_rows = b->d_cov16; a.cov_row_win = b->d_cov_row_win;
+        a.cap_cov_rows = (uint32_t)std::min<uint64_t>((uint64_t)(b->cap_pos ? b->cap_pos : b->n_pos), 0xFFFFFFFFu);
+        a.cov8 = nullptr; a.cov16 = nullptr; a.sat_thr = 65535u;
+    }
     a.clon_list = b->sparse_out ? b->d_clon_list : nullptr; a.cap_clon = (uint32_t)std::min<size_t>(b->cap_clon, 0xFFFFFFFFu);
     if (b->lean && b->sparse_out) {             // a lean slot writes only what travels home
         if (!b->clon_dense) a.clon = nullptr;
@@ -1221,7 +1229,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
     b->n_ovf = cur[CUR_ENTRIES];
     b->sizes.n_snv = cur[CUR_SNV];
     b->sizes.n_sites = cur[CUR_SITES];
-    b->n_rare = cur[CUR_RARE]; b->n_sat = cur[CUR_SAT]; b->n_clon = cur[CUR_CLON];
+    b->n_rare = cur[CUR_RARE]; b->n_sat = cur[CUR_SAT]; b->n_clon = cur[CUR_CLON]; b->n_cov_rows = cur[CUR_COVX];
     b->tim = isx_timings{};
     b->tim_pending = true;                  // the kernel's own time stamps are read when somebody asks (isx_batch_timings)
     b->tim.pileup_blocks = b->grid;

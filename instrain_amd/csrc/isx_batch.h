@@ -81,6 +81,11 @@ struct isx_batch {
     uint2 *d_sat = nullptr, *d_clon_list = nullptr, *d_clon_sorted = nullptr;
     size_t cap_sat = 0, cap_clon = 0;
     uint32_t n_clon = 0;
+    bool nib_pass = false;              // the last pass really wrote the 4-bit plane (nib_out asked for, and the kernel is the packed reference-delta one)
+    bool nib_out = false;               // this pass: coverage as the 4-bit plane (in d_cov8) + 16-bit rows of the windows beyond 15 (in d_cov16): lean slots
+    uint32_t *d_cov_row_win = nullptr;  // ... and the window of every such row
+    size_t cap_cov_row_win = 0;
+    uint32_t n_cov_rows = 0;
     bool sparse_out = false, cov8_out = false;   // this pass: write the sparse clonality list / the 1-byte coverage
     bool lean = false, clon_dense = false;       // lean slot (isx_pipe_params.lean_output): the dense clonality array / the 16-bit coverage
                                                  // are written only when a batch needs them (clon_dense: its clonality list did not fit)

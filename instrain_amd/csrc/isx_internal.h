@@ -84,7 +84,8 @@ template <class T> static inline hipError_t isx_raw_dev_malloc(T **p, size_t byt
 enum { CUR_ENTRIES = 0 /* mm path: overflow entries */, CUR_SNV = 1, CUR_SITES = 2, CUR_AO = 3, CUR_SLEV = 4,
        CUR_ENT_TOTAL = 5, CUR_RARE = 6 /* dense path: entries of the sparse clonTR list */,
        CUR_SAT = 7 /* dense path: positions whose coverage reaches sat_thr (entries of the exact-coverage list) */,
-       CUR_CLON = 8 /* dense path: entries of the sparse clonality list */, CUR_N = 9 };
+       CUR_CLON = 8 /* dense path: entries of the sparse clonality list */,
+       CUR_COVX = 9 /* dense path, 4-bit coverage plane: windows that also wrote a 16-bit row */, CUR_N = 10 };
 
 // SNP site record: a position where update_snp_table returned anySNP (snv_utilities.py:129-133).
 // Holds what linkage needs later: the `bases` set and where the per-level counts live.
@@ -202,6 +203,13 @@ struct PileupArgs {
     float *clon_r;              // rarefied clonality: dense [n_pos] / mm path [cap_entries]; pre-filled with NaN
     uint16_t *cov16;            // dense path, pipe slots: min(coverage, 65535) per position (NULL = not wanted)
     uint8_t *cov8;              // ... and min(coverage, 255) for the 1-byte hand-back of a shallow batch (NULL = not wanted)
+    // ... or, a lean slot's shallow batch (reference-delta records, 16-bit LDS rows): min(coverage, 15), two positions a byte (cov4, low nibble
+    // = the even position) -- and, of every window that holds a position beyond 15, the whole window as a 16-bit row: row k of cov_rows
+    // (k from CUR_COVX) with cov_row_win[k] = the window.  0.5 B a position home for a metagenome at depth 3 instead of 1
+    uint8_t *cov4;
+    uint16_t *cov_rows;
+    uint32_t *cov_row_win;
+    uint32_t cap_cov_rows;      // entries of cov_rows (rows that would reach beyond are not written; the host repeats such a batch with cov8)
     uint2 *sat;                 // ... exact (gpos, coverage) of the positions whose coverage reaches sat_thr (255 with cov8, else 65535)
     uint32_t cap_sat, sat_thr;
     uint2 *clon_list;           // dense path, pipe slots: (gpos, float bits of clonT) of the positions whose clonality is NOT 1.0 (more than

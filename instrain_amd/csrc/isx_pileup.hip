@@ -48,7 +48,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // scratch words (LDS)
 enum { S_NQ = 0, S_ROWS, S_SITES, S_ROW_BASE, S_SITE_BASE, S_ROW_RANK, S_NAO, S_AO_BASE, S_ENT_TOT, S_ENT_BASE, S_SLEV, S_SLEV_BASE, S_NRARE, S_RARE_BASE, S_RARE_RANK,
-       S_NCLON, S_CLON_BASE, S_CLON_RANK, S_N = 20 };
+       S_NCLON, S_CLON_BASE, S_CLON_RANK, S_COVX, S_COVX_BASE, S_N = 20 };
 
 // table cursors run on across launches; a run's slots are relative to the values it started from
 __device__ __forceinline__ uint32_t cur_add(const PileupArgs &a, int which, uint32_t n)
@@ -947,17 +947,20 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
             ISX_TS(3);
             int32_t run = inc - sum;
             for (int k = 0; k < (tid >> 6); k++) run += (int32_t)wtot[k];
-            for (int k = 0; k < PT; k++) {
+            bool beyond15 = false;                  // (4-bit coverage plane: does the window need its 16-bit row?  reads covering a position
+            for (int k = 0; k < PT; k++) {          //  bound its coverage from above)
                 const int p = p0 + k;
                 if (p >= W) break;
                 const uint32_t x = dlt[p], a01 = cnt[p], a23 = cnt[S + p];
                 run += (int32_t)x >> 16;
+                beyond15 |= run > 15;
                 const uint32_t r = refl[p];
                 if (r < 4u) {
                     const uint32_t v = (uint32_t)run - (x & 0xFFFFu) - ((a01 & 0xFFFFu) + (a01 >> 16) + (a23 & 0xFFFFu) + (a23 >> 16));
                     cnt[(r >> 1) * S + p] = ((r >> 1) ? a23 : a01) + (v << (16 * (r & 1u)));
                 }
             }
+            if (a.cov4 && __ballot(beyond15) && lane == 0) scratch[S_COVX] = 1u;       // (every writer writes the same 1)
             __syncthreads();
             ISX_TS(4);
             ISX_ARGS_FRESH();
@@ -1018,7 +1021,11 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
             constexpr bool st_ok = true, call_ok = true;
 #endif
             if (a.counts && st_ok) a.counts[gpos] = make_uint4(c[0], c[1], c[2], c[3]);
-            if ((a.cov16 || a.cov8) && st_ok) { // shrunk hand-back of a pipe slot: coverage alone, 2 (or 1) bytes per position,
+            if (PKL && a.cov4 && st_ok) {       // 4-bit plane: a pair of lanes holds the two positions of a byte
+                const uint32_t nib = min(total, 15u), other = pair_other(nib);          // (a lane beyond n_pos has left the loop: it reads as 0)
+                if (!(tid & 1)) a.cov4[gpos >> 1] = (uint8_t)(nib | (other << 4));
+            }
+            if ((a.cov16 || a.cov8 || (PKL && a.cov4)) && st_ok) { // shrunk hand-back of a pipe slot: coverage alone, 2 (or 1) bytes per position,
                 if (a.cov16) a.cov16[gpos] = (uint16_t)min(total, 65535u);      // exact values of the few positions beyond that in a list
                 if (a.cov8) a.cov8[gpos] = (uint8_t)min(total, 255u);
                 if (total >= a.sat_thr) {
@@ -1073,6 +1080,8 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
         if (tid == 192 && nrare) scratch[S_RARE_BASE] = cur_add(a, CUR_RARE, nrare);
         const uint32_t nclon = a.clon_list ? scratch[S_NCLON] : 0u;
         if (tid == 256 % nthr && nclon) scratch[S_CLON_BASE] = cur_add(a, CUR_CLON, nclon);
+        const uint32_t covx = PKL ? scratch[S_COVX] : 0u;                   // 4-bit coverage plane: this window also writes its 16-bit row
+        if (PKL && tid == 320 % nthr && covx) scratch[S_COVX_BASE] = cur_add(a, CUR_COVX, 1u);
         if (nclon) __syncthreads();             // uniform: the list entries below need the window's base
         ISX_TS(6);
         // ---- deferred clonalities (snv_utilities.py:225-231), densely packed; the sparse clonality list ----
@@ -1090,7 +1099,19 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
                 if (list) a.clon_list[clon_base + atomicAdd(&scratch[S_CLON_RANK], 1u)] = make_uint2(w0 + p, __float_as_uint(v));
             }
         }
-        if (nrows | nrare) __syncthreads();     // uniform: scratch bases from the atomics above
+        if (nrows | nrare | covx) __syncthreads();     // uniform: scratch bases from the atomics above
+        if (PKL && covx) {
+            const uint32_t k = scratch[S_COVX_BASE];
+            const uint32_t at = k * (uint32_t)W;
+            if (at + (uint32_t)W <= a.cap_cov_rows) {
+                for (int p = tid; p < W; p += nthr) {
+                    uint32_t c[4];
+                    ld4(p, c);
+                    a.cov_rows[at + (uint32_t)p] = (uint16_t)min(c[0] + c[1] + c[2] + c[3], 65535u);
+                }
+            }
+            if (tid == 0) a.cov_row_win[k] = (uint32_t)w;
+        }
         ISX_TS(7);
         ISX_ARGS_FRESH();
         if (a.min_cov_r > 0) {                  // rarefied clonality (snv_utilities.py:233-247), own loop: fewer live registers

@@ -81,6 +81,10 @@ struct Slot {
     size_t out_bytes = 0, o_counts = 0, o_clon = 0, o_clonr = 0, o_snv = 0, o_cov16 = 0, o_rare = 0;
     bool rare_dense = false;                // the clonTR table of the last batch went back as the dense array
     bool cov8 = false, clon_sparse = false; // how the last (shallow) batch's coverage / clonality went back
+    bool cov4 = false;                      // ... coverage as the 4-bit plane + 16-bit rows (lean slots): rows at h_out + o_cov16 + cov_rows_off
+    size_t cov_rows_off = 0;
+    int cov_window = 0;
+    std::vector<uint32_t> cov_row_win;
     std::vector<isx_sat> sat_rows;          // exact coverage of its saturated positions
     bool sat_complete = true;
     void *sort_temp = nullptr;              // device scratch of the clonality list's sort
@@ -355,6 +359,10 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
             // shallow batches go back as 1-byte coverage + sparse clonality list (see submit: sparse_out)
             b->cap_clon = (size_t)cap_pos / 2 + 65536;
             HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_cov8), (size_t)cap_pos));
+            if (p->pp.lean_output) {        // 4-bit coverage plane of shallow batches: the window of every 16-bit row (finish_slot)
+                b->cap_cov_row_win = (size_t)cap_pos / 64 + 2;
+                HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_cov_row_win), b->cap_cov_row_win * sizeof(uint32_t)));
+            }
             HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon_list), b->cap_clon * sizeof(uint2)));
             HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon_sorted), b->cap_clon * sizeof(uint2)));
         }
@@ -460,14 +468,19 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         int rc = finish_pass(b, &cf, sfin);     // sizes from the published cursors; linkage stages when enabled (on this finisher's queue)
         if (rc != ISX_OK) return rc;
         // a batch taken for shallow that has more positions beyond 255 than the exact-coverage list holds: again with 16 bits
-        const bool cov8_overflow = !cf && dense && b->sparse_out && b->cov8_out && (size_t)b->n_sat > b->cap_sat;
+        const bool cov8_overflow = !cf && dense && b->sparse_out && b->cov8_out && !b->nib_pass && (size_t)b->n_sat > b->cap_sat;
+        // a 4-bit plane whose 16-bit rows would not fit the slot's coverage block (most windows beyond 15: not a shallow batch after all)
+        const bool nib_overflow = !cf && dense && b->nib_pass &&
+                                  ((size_t)b->n_pos / 2 + 128 + (size_t)b->n_cov_rows * (size_t)b->W * 2 > (size_t)b->n_pos * 2 ||
+                                   ((size_t)b->n_cov_rows + 1) * (size_t)b->W > (size_t)(b->cap_pos ? b->cap_pos : b->n_pos));
         // a lean slot whose clonality list cannot be used (too many entries for the list / for a list to pay): again, with the dense array
         const bool clon_overflow = !cf && dense && b->sparse_out && b->lean && !b->clon_dense &&
                                    ((size_t)b->n_clon > b->cap_clon || (size_t)b->n_clon * 2 > (size_t)b->n_pos);
-        if (!cf && !cov8_overflow && !clon_overflow) break;
+        if (!cf && !cov8_overflow && !clon_overflow && !nib_overflow) break;
         if (attempt == 7) { isx_set_error("output tables still too small after 8 growth steps"); return ISX_ERR_CAPACITY; }
         // a table was too small for this batch: grow it and repeat the pass (the slot still holds its input)
         if (cov8_overflow) b->cov8_out = false;
+        if (nib_overflow) b->nib_out = false;
         if (clon_overflow) b->clon_dense = true;
         if (cf && (rc = batch_grow_tables(b, cf)) != ISX_OK) return rc;
         if (!dense) b->cap_ovf = b->cap_entries - (size_t)b->n_win * b->slab;
@@ -504,16 +517,26 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
     if (dense) {
         int rc = ISX_OK;
         if (redo) HIP_TRY(hipStreamSynchronize(ps));
-        s.cov8 = false; s.clon_sparse = false; s.sat_complete = (size_t)b->n_sat <= b->cap_sat;
+        s.cov8 = false; s.cov4 = false; s.clon_sparse = false; s.sat_complete = (size_t)b->n_sat <= b->cap_sat;
         if (b->sparse_out) {
             // coverage in 2 bytes, or 1 for a shallow batch (exact values of the few positions at 255 / 65535 or beyond in the
             // list below); clonality: a position that reaches min_cov has exactly 1.0 unless more than one base was observed there
             // -- only those exceptions travel, as a (position, value) list sorted by position on the device
-            s.cov8 = b->cov8_out;
-            if (s.cov8) rc = fetch(s.h_out + s.o_cov16, b->d_cov8, (size_t)b->n_pos);
+            s.cov8 = b->cov8_out && !b->nib_pass;
+            if (b->nib_pass) {
+                // min(coverage, 15) of two positions a byte + the windows that hold anything beyond 15 as whole 16-bit rows
+                const size_t nib_bytes = ((size_t)b->n_pos + 1) / 2, rows_bytes = (size_t)b->n_cov_rows * (size_t)b->W * 2;
+                s.cov4 = true; s.cov_window = b->W;
+                s.cov_rows_off = (nib_bytes + 63) & ~(size_t)63;
+                rc = fetch(s.h_out + s.o_cov16, b->d_cov8, nib_bytes);
+                if (rc == ISX_OK) rc = fetch(s.h_out + s.o_cov16 + s.cov_rows_off, b->d_cov16, rows_bytes);
+                s.cov_row_win.resize(b->n_cov_rows);
+                if (rc == ISX_OK && b->n_cov_rows) rc = pull(s.cov_row_win.data(), b->d_cov_row_win, (size_t)b->n_cov_rows * sizeof(uint32_t));
+                s.d2h_bytes += (int64_t)(nib_bytes + rows_bytes + (size_t)b->n_cov_rows * 4);
+            } else if (s.cov8) rc = fetch(s.h_out + s.o_cov16, b->d_cov8, (size_t)b->n_pos);
             else rc = fetch(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2);
             if (rc != ISX_OK) return rc;
-            s.d2h_bytes += (int64_t)b->n_pos * (s.cov8 ? 1 : 2);
+            if (!s.cov4) s.d2h_bytes += (int64_t)b->n_pos * (s.cov8 ? 1 : 2);
             const size_t n_clon = b->n_clon;
             if (n_clon <= b->cap_clon && n_clon * 2 <= (size_t)b->n_pos) {
                 // (b->ordered: k_win_gather already wrote the list in position order behind the pileup kernel)
@@ -944,6 +967,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     // values other than 1.0, coverage in one byte for a shallow batch
     b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
+    b->nib_out = b->cov8_out && b->lean && (double)b->n_obs < 6.0 * (double)n_pos;      // (mean depth below 6: most windows stay within 4 bits)
     b->clon_dense = false;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
@@ -1114,6 +1138,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     // values other than 1.0, coverage in one byte for a shallow batch
     b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
+    b->nib_out = b->cov8_out && b->lean && (double)b->n_obs < 6.0 * (double)n_pos;      // (mean depth below 6: most windows stay within 4 bits)
     b->clon_dense = false;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / p->G;
@@ -1324,6 +1349,7 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     s.ref_has_n = w->ref_has_n;
     b->sparse_out = dense && b->d_clon_list != nullptr;
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)w->n_pos;
+    b->nib_out = b->cov8_out && b->lean && (double)b->n_obs < 6.0 * (double)w->n_pos;
     b->clon_dense = false;
     b->n_pairs = w->n_pairs;
     b->packed = w->packed; b->W = w->W;
@@ -1490,7 +1516,13 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
     out->sizes = b->sizes;
     out->snv = (size_t)b->sizes.n_snv > p->snv_prefix ? s.snv_big.data() : reinterpret_cast<const isx_snv *>(s.h_small + s.o_snv);
     if (dense) {
-        if (s.cov8) out->coverage8 = s.h_out + s.o_cov16;
+        if (s.cov4) {
+            out->coverage4 = s.h_out + s.o_cov16;
+            out->cov_rows = reinterpret_cast<const uint16_t *>(s.h_out + s.o_cov16 + s.cov_rows_off);
+            out->cov_row_window = s.cov_row_win.data();
+            out->n_cov_rows = (int64_t)s.cov_row_win.size();
+            out->cov_window = s.cov_window;
+        } else if (s.cov8) out->coverage8 = s.h_out + s.o_cov16;
         else out->coverage16 = reinterpret_cast<const uint16_t *>(s.h_out + s.o_cov16);
         if (s.clon_sparse) { out->clon_sparse = reinterpret_cast<const isx_rare *>(s.h_out + s.o_clon); out->n_clon = (int64_t)b->n_clon; }
         else out->clon = reinterpret_cast<const float *>(s.h_out + s.o_clon);

@@ -385,6 +385,11 @@ class Pipe:
             # (a shallow batch comes back smaller still: 1-byte coverage, clonality as a sorted (position, value) list)
             if r.coverage16:
                 out["cov16"] = view(r.coverage16, np.uint16, n_pos)
+            elif r.coverage4:                       # a lean slot's shallow batch: 4-bit plane + 16-bit rows of the windows beyond 15 (dense_cov)
+                out["cov4"] = view(r.coverage4, np.uint8, (n_pos + 1) // 2)
+                out["cov_window"] = int(r.cov_window)
+                out["cov_row_win"] = view(r.cov_row_window, np.uint32, int(r.n_cov_rows)).copy()
+                out["cov_rows"] = view(r.cov_rows, np.uint16, int(r.n_cov_rows) * int(r.cov_window)).reshape(-1, int(r.cov_window))
             else:
                 out["cov8"] = view(r.coverage8, np.uint8, n_pos)
             if r.clon:
@@ -393,12 +398,12 @@ class Pipe:
                 out["clon_sparse"] = view(r.clon_sparse, _lib.CLON_DT, int(r.n_clon))
             if r.n_saturated and r.saturated:
                 out["saturated"] = view(r.saturated, _lib.SAT_DT, int(r.n_saturated)).copy()
-            if densify and "cov8" in out:
-                out["cov16"] = out.pop("cov8").astype(np.uint16)
-                if "saturated" in out:
-                    out["cov16"][out["saturated"]["gpos"]] = np.minimum(out["saturated"]["coverage"], 65535)
+            if densify and ("cov8" in out or "cov4" in out):
+                out["cov16"] = dense_cov(out, n_pos)
+                for k in ("cov8", "cov4", "cov_rows", "cov_row_win", "cov_window"):
+                    out.pop(k, None)
             if densify and "clon_sparse" in out:
-                out["clon"] = dense_clon(out["cov16"] if "cov16" in out else out["cov8"], out.pop("clon_sparse"), self.min_cov)
+                out["clon"] = dense_clon(out["cov16"], out.pop("clon_sparse"), self.min_cov)
             if r.clon_rarefied:                     # want_counts, or a deep sample (the list would not be sparse)
                 out["clon_r"] = view(r.clon_rarefied, np.float32, n_pos)
             if r.rare:
@@ -548,6 +553,30 @@ def encode_delta(segs, ref_codes, n_mm_bins=1, threads=1, slack_groups=1, cap_re
         check(rc)
         n = n_rec.value
         return rec[:n], gbase[:n // 32], None, slack_groups
+
+
+def dense_cov(res, n_pos=None):
+    """coverage per position (uint16, capped at 65535) of a collected batch in whichever shrunk form it came home: 'cov16', 'cov8'
+    (+ 'saturated'), or the lean slots' 'cov4' plane + 'cov_rows' / 'cov_row_win' / 'cov_window' (isx_pipe_result.coverage4)"""
+    if "cov16" in res:
+        return res["cov16"]
+    if "cov8" in res:
+        cov = res["cov8"].astype(np.uint16)
+    else:
+        nib = res["cov4"]
+        n_pos = 2 * len(nib) if n_pos is None else int(n_pos)
+        cov = np.empty(2 * len(nib), dtype=np.uint16)
+        cov[0::2] = nib & 15
+        cov[1::2] = nib >> 4
+        cov = cov[:n_pos]
+        W = int(res["cov_window"])
+        for k, w in enumerate(res["cov_row_win"].tolist()):
+            lo = w * W
+            hi = min(lo + W, n_pos)
+            cov[lo:hi] = res["cov_rows"][k, :hi - lo]
+    if "saturated" in res:
+        cov[res["saturated"]["gpos"]] = np.minimum(res["saturated"]["coverage"], 65535)
+    return cov
 
 
 DREC_DUAL = 0x80000000

@@ -92,7 +92,7 @@ class _BatchTables:
             if "counts" in res:
                 self.cov = res["counts"].sum(axis=1, dtype=np.int64)
             else:                                   # the shrunk hand-back: 16- or 8-bit coverage + the exact values beyond
-                self.cov = _own(res["cov16"] if "cov16" in res else res["cov8"])
+                self.cov = engine.dense_cov(res) if "cov4" in res else _own(res["cov16"] if "cov16" in res else res["cov8"])
                 if res.get("n_saturated"):
                     if "saturated" not in res:
                         raise ValueError("coverage beyond the hand-back's range at too many positions: profile with store_everything")

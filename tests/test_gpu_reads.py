@@ -418,7 +418,9 @@ def test_lean_slot_output_equals_the_plain_slot(ctx):
     tables as a plain slot for a shallow batch (8-bit coverage), a deep one (16-bit) and one whose clonality list cannot be used
     (most positions carry a second base: the pass is repeated with the dense array); device summaries are refused on a lean slot"""
     from instrain_amd import engine, synth
-    ws = [synth.make_workload(genome_len=300_000, coverage=6, n_sites=300, seed=61, skip_mm=True),
+    ws = [synth.make_workload(genome_len=400_000, coverage=3, n_sites=300, seed=59, skip_mm=True),      # 4-bit coverage plane, hardly a window beyond 15
+          synth.make_workload(genome_len=400_000, coverage=5, n_sites=300, seed=60, skip_mm=True),      # ... with 16-bit rows for many windows
+          synth.make_workload(genome_len=300_000, coverage=6, n_sites=300, seed=61, skip_mm=True),
           synth.make_workload(genome_len=200_000, coverage=60, n_sites=400, seed=62, skip_mm=True),
           synth.make_workload(genome_len=60_000, coverage=300, n_sites=100, seed=63, skip_mm=True, err=0.01)]
     segs = [synth.segs_from_obs(w["obs"], w["pair"]) for w in ws]
@@ -426,11 +428,22 @@ def test_lean_slot_output_equals_the_plain_slot(ctx):
                max_splits=max(len(w["split_bounds"]) for w in ws), depth=2, host_threads=4, pin_threads=False,
                n_mm_bins=1, enable_linkage=True, min_snp=20)
     out = {}
+    n_rows = []
     for lean in (False, True):
         pipe = engine.Pipe(ctx, lean_output=lean, **cap)
         res = []
         for w, sg in zip(ws, segs):
             t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], sg)
+            raw = pipe.collect(t, densify=False)
+            assert ("cov4" in raw) == (lean and w["n_obs"] < 6 * w["n_pos"]), (lean, w["n_obs"] / w["n_pos"])
+            if "cov4" in raw:
+                n_rows.append(len(raw["cov_row_win"]))
+                assert raw["cov_rows"].shape == (len(raw["cov_row_win"]), raw["cov_window"]) and len(set(raw["cov_row_win"].tolist())) == len(raw["cov_row_win"])
+                exp_cov = np.bincount(w["obs"]["gpos"], minlength=w["n_pos"])
+                W = raw["cov_window"]
+                beyond = np.unique(np.flatnonzero(exp_cov > 15) // W)
+                assert set(beyond.tolist()) <= set(raw["cov_row_win"].tolist())          # every window beyond 15 has its row (a few more may: the bound is reads covering)
+                assert (engine.dense_cov(raw, w["n_pos"]) == np.minimum(exp_cov, 65535)).all()
             r = pipe.collect(t)                         # densified: cov16 + clon arrays rebuilt on the host
             res.append({k: r[k].copy() for k in ("cov16", "clon", "snv", "ld")} | {"sizes": r["sizes"], "rare": r["rare"].copy()})
             if lean:
@@ -444,5 +457,6 @@ def test_lean_slot_output_equals_the_plain_slot(ctx):
         for k in ("cov16", "snv", "ld", "rare"):
             assert a[k].tobytes() == b[k].tobytes(), k
         assert a["clon"].view(np.uint32).tobytes() == b["clon"].view(np.uint32).tobytes()
-    n2 = out[True][2]
+    assert len(n_rows) == 3 and n_rows[2] >= 10 and n_rows[0] <= n_rows[1] <= n_rows[2]        # (the depth-6 batch keeps 5.4 of 6 bases: 4-bit plane too)
+    n2 = out[True][4]
     assert (~np.isnan(n2["clon"]) & (n2["clon"] != 1.0)).sum() * 2 > len(n2["clon"])        # the case that needs the dense array
