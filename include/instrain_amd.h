@@ -577,6 +577,27 @@ int isx_encode_obs_ring(const isx_obs *obs, const uint32_t *pair, int64_t n_obs,
                         int32_t host_threads, double slack, int64_t cap_rec, int64_t ring_records, void *rec,
                         uint32_t *gbase, uint32_t *pair_out, int64_t *n_rec, int32_t *passes);
 
+/* ---- BGZF blocks inflated on the device ----
+ * The reference reads its BAM through pysam / htslib (filter_reads.py:885-956, profile_utilities.py:150-153): bgzf.c hands every
+ * block of at most 64 KiB to zlib's inflate.  The blocks are independent raw deflate streams (RFC 1951), so the device decodes one
+ * per lane, all blocks of a file side by side (csrc/isx_inflate.hip).
+ *   isx_bgzf_index            walks the block headers of a BGZF image (nothing is inflated): where each block's deflate stream lies,
+ *                             how long it and its inflated bytes are (ISIZE), where those go in the inflated stream
+ *   isx_bgzf_inflate_device   copies the compressed span to the device, inflates, copies the inflated bytes to `out` (host memory);
+ *                             *kernel_ms = the kernel alone.  ISX_ERR_IO names the first block that is not a valid deflate stream of
+ *                             ISIZE bytes (the CRC32 of a block is not checked)
+ *   isx_bgzf_inflate_host     the same decoder on the calling thread (no GPU: what the CPU tests pin against zlib) */
+typedef struct {
+    int64_t in_off;             /* offset of the block's deflate stream in the image */
+    int32_t in_len;             /* its length in bytes */
+    int32_t out_len;            /* ISIZE: inflated bytes (0 .. 65536) */
+    int64_t out_off;            /* where they go: the sum of the ISIZEs before this block */
+} isx_bgzf_block;
+int isx_bgzf_index(const uint8_t *image, int64_t n_bytes, int64_t cap_blocks, isx_bgzf_block *blocks, int64_t *n_blocks, int64_t *out_bytes);
+int isx_bgzf_inflate_device(isx_ctx *ctx, const uint8_t *image, int64_t n_bytes, const isx_bgzf_block *blocks, int64_t n_blocks,
+                            uint8_t *out, int64_t out_bytes, float *kernel_ms);
+int isx_bgzf_inflate_host(const uint8_t *image, int64_t n_bytes, const isx_bgzf_block *blocks, int64_t n_blocks, uint8_t *out, int64_t out_bytes);
+
 /* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ----
  * Two passes over the (memory-mapped, compressed) file, like the reference, none of which holds the file's reads:
  *   isx_bam_scan         filter_reads.get_paired_reads for every reference (filter_reads.py:885-956): per

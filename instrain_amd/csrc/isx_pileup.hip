@@ -665,7 +665,9 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
             typedef __attribute__((address_space(1))) const u32x4 gvec;        // global, not flat: vmcnt only
             const gvec *sb = reinterpret_cast<const gvec *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ub >> 32)) << 32) |
                                                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ub));
-            v[u] = __builtin_nontemporal_load(sb + lane16);
+            // (with linkage the allele pass walks the window's records a second time: the first walk leaves them in the L2, the second --
+            // non-temporal -- is their last use)
+            v[u] = linkage ? *(sb + lane16) : __builtin_nontemporal_load(sb + lane16);
             if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
         } else if (FMT == 2) { v[u].x = v[u].y = v[u].z = v[u].w = 0xFFFFFFFFu; }
         else if (SEGS || DREC) { }             // (a slot the wave did not load is never counted: live[u])
@@ -1208,9 +1210,14 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
 // table[mm] before the KeyError), a presence the SNV loop must see.
 // ---------------------------------------------------------------------------------------------
 template <bool PACKED, bool LINKAGE, bool COMPACT, bool SEGS = false>    // SEGS: the read-segment stream (COMPACT is true then)
-__global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
+__global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // (arguments read from the kernarg segment phase by phase, as in k_pileup_dense)
+    typedef const __attribute__((address_space(4))) PileupArgs KernArgs;
+    KernArgs *kargs = (KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+#define a (*(const PileupArgs *)kargs)
+#define ISX_ARGS_FRESH() asm volatile("" : "+s"(kargs))
     const int tid = threadIdx.x, nthr = blockDim.x;
     publish_previous(a, tid);
     const int W = a.W, M = a.M;
@@ -1284,6 +1291,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
             if (tid < S_N) scratch[tid] = 0;
         }
         __syncthreads();
+        ISX_ARGS_FRESH();
 
         // ---- get_base_counts_mm over the window's slice of the stream ----
         uint32_t bad_mm = 0;
@@ -1342,6 +1350,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
         }
         if (bad_mm) flag_or(a, ISX_FLAG_MM_RANGE);
         __syncthreads();
+        ISX_ARGS_FRESH();
         if (!linkage) prefetch_window(w + grid);
         const int dbg = a.debug_mode;           // ablation switches (tools/ablate_mm.py), 0 in production
         const uint32_t CW = (uint32_t)a.slab;   // entry slab of this window: [w * CW, (w + 1) * CW)
@@ -1492,6 +1501,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
             }
         }
         __syncthreads();
+        ISX_ARGS_FRESH();
         const uint32_t n_ent = scratch[S_ENT_TOT], nrows = scratch[S_ROWS], nsites = scratch[S_SITES], nao = scratch[S_NAO],
                        nslev = scratch[S_SLEV], nrq = min(scratch[S_ROW_RANK], (uint32_t)a.rqcap);
         if (tid == 0) {
@@ -1549,9 +1559,12 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a)
             prefetch_window(w + grid);
         }
         __syncthreads();
+        ISX_ARGS_FRESH();
     }
     if (tid == 0 && my_entries) cur_add(a, CUR_ENT_TOTAL, my_entries);
 }
+#undef a
+#undef ISX_ARGS_FRESH
 
 
 // ---------------------------------------------------------------------------------------------

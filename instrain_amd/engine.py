@@ -908,3 +908,34 @@ class BamFile:
             self.close()
         except Exception:
             pass
+
+
+def bgzf_index(image):
+    """isx_bgzf_index: the blocks of a BGZF image (bytes / uint8 array) -> (blocks [n] of _lib.BGZF_BLOCK_DT, inflated bytes)"""
+    lib = _lib.load()
+    img = np.frombuffer(image, dtype=np.uint8) if not isinstance(image, np.ndarray) else np.ascontiguousarray(image, dtype=np.uint8)
+    n, tot = C.c_int64(0), C.c_int64(0)
+    check(lib.isx_bgzf_index(img.ctypes.data if len(img) else None, len(img), 0, None, C.byref(n), C.byref(tot)) if len(img) else 0)
+    blocks = np.zeros(n.value, dtype=_lib.BGZF_BLOCK_DT)
+    if n.value:
+        check(lib.isx_bgzf_index(img.ctypes.data, len(img), n.value, blocks.ctypes.data, C.byref(n), C.byref(tot)))
+    return blocks, int(tot.value)
+
+
+def bgzf_inflate(image, blocks=None, ctx=None):
+    """The inflated bytes of a BGZF image's blocks (all of them, or the given rows of bgzf_index re-based to their own output) --
+    on the device of `ctx` (isx_bgzf_inflate_device; returns (bytes array, kernel ms)) or, ctx None, by the same decoder on the host"""
+    lib = _lib.load()
+    img = np.frombuffer(image, dtype=np.uint8) if not isinstance(image, np.ndarray) else np.ascontiguousarray(image, dtype=np.uint8)
+    if blocks is None:
+        blocks, _ = bgzf_index(img)
+    blocks = np.ascontiguousarray(blocks, dtype=_lib.BGZF_BLOCK_DT).copy()
+    blocks["out_off"] = np.cumsum(blocks["out_len"], dtype=np.int64) - blocks["out_len"]
+    total = int(blocks["out_len"].sum())
+    out = np.empty(total, dtype=np.uint8)
+    if ctx is None:
+        check(lib.isx_bgzf_inflate_host(img.ctypes.data, len(img), blocks.ctypes.data, len(blocks), out.ctypes.data, total))
+        return out, None
+    ms = C.c_float(0)
+    check(lib.isx_bgzf_inflate_device(ctx.h, img.ctypes.data, len(img), blocks.ctypes.data, len(blocks), out.ctypes.data, total, C.byref(ms)))
+    return out, float(ms.value)
