@@ -818,7 +818,7 @@ def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
             "record_bytes": int(st[0]["record_bytes"]) if st else None,
             "with_host_staging": {"gbp_per_s": float(w["profiled_bases"]) * steps / dt2 / 1e9, "ms_per_step": dt2 / steps * 1e3,
                                   "host_stage_ms": float(np.mean([x["encode_ms"] for x, _ in st2])) if st2 else 0.0},
-            "kept_observations": int(w["n_obs"]), "read_segments": int(w["segs"].n_seg), "pipe_depth": args.depth, "pileup_cus": 256 - 8 * C5_RESERVE_CUS, "host_threads": host_threads,
+            "kept_observations": int(w["n_obs"]), "read_segments": int(w["segs"].n_seg), "pipe_depth": args.depth, "host_threads": host_threads,
             "roofline_in_stream": {"bound": "hbm", "kernel": "k_pileup_dense (wire records, slot output)",
                                    "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
@@ -986,7 +986,7 @@ def main():
                                           % ("" if args.scale == 1.0 else " [DEBUG scale %g]" % args.scale)),
                        "genomes_kept": head["genomes_kept"], "positions": head["positions"], "read_gbp_per_step": bases_all / 1e9,
                        "batches_per_step": n_batches if world == 1 else None, "hand_over": _short("%d-byte wire records staged once in pinned host memory; a step = DMA (hipMemcpyAsync) + kernels + tables back" % (head.get("record_bytes") or 0)),
-                       "pipe_depth": args.depth, "host_threads_per_rank": host_threads, "cgroup_cpus": cgroup_cpus(),
+                       "pipe_depth": args.depth, "pileup_cus": 256 - 8 * C5_RESERVE_CUS, "lean_slots": LEAN_SLOTS, "host_threads_per_rank": host_threads, "cgroup_cpus": cgroup_cpus(),
                        "numa_node": numa_node, "parallelism": "genome-sharded x%d%s" % (world, " (ranks share %d GPU)" % n_dev if shared else ""),
                        "verified": "per-batch checks in an untimed pass; timed row counts equal"},
             "roofline": {k: head["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",

@@ -22,6 +22,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c5 -o $TAG -- $
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c5 -o $TAG -- $T --c5 > $OUT/pmc_write_c5.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq1 -o $TAG -- $T --no-mm > $OUT/sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d $OUT/sq2 -o $TAG -- $T --no-mm > $OUT/sq2.log 2>&1
+# the device inflate prototype next to zlib (tools/inflate_rate.py), and its lanes-per-wave sweep
+python $REPO/tools/inflate_rate.py > $OUT/inflate_rate.log 2>&1
+for l in 64 16 8; do ISX_INFLATE_LPW=$l DEVICE_ONLY=1 python $REPO/tools/inflate_rate.py 2>&1 | tail -1 | sed "s/^/LPW $l: /" >> $OUT/inflate_rate.log; done
+rm -f /tmp/isx_inflate_probe.bam
 cd $REPO
 # keep only the small CSVs (kernel stats / counter collection); traces are large
 find $OUT -name "*kernel_trace.csv" -size +2M -delete
