@@ -38,11 +38,11 @@ hipError_t isx_pin_malloc(void **p, size_t bytes);
 void isx_pin_free(void *p);
 void isx_dev_trim();        // both caches
 
-// Device -> PINNED host memory by a copy kernel instead of the DMA engine.  hipMemcpyAsync serves both directions of this
-// stack's copies from one SDMA queue: a pipe's copy-out waited behind the next batch's copy-in and a streamed step took the SUM
-// of the two (profiles/r03_stream_ab.md).  Pinned host memory is mapped into the device's address space, so the tables leave
-// through the CUs' own store path (a few dozen workgroups keep the link's upstream direction full) while the DMA engine brings
-// the next batch in.  Falls back to hipMemcpyAsync for small or unaligned copies.
+// Device -> PINNED host memory.  Pieces below 1 MiB (ISX_D2H_DMA_MIN) leave by a copy kernel: hipMemcpyAsync serves both directions of
+// this stack's copies from one queue, so a small copy-out waited behind the next batch's 100 MB copy-in (profiles/r03_stream_ab.md), and
+// pinned host memory is mapped into the device's address space.  Position-sized tables go by hipMemcpyAsync: a kernel that streams
+// megabytes into host memory fills the memory system's queues with PCIe writes, and every other kernel's HBM traffic and the copy-in
+// DMA wait behind them (round 4: whole-database pass 100 -> 66 ms).
 hipError_t isx_copy_to_host(void *hdst_pinned, const void *dsrc, size_t bytes, hipStream_t stream);
 // Small read-backs into ANY host memory (table sizes, the last element of a scan, a few hundred rows): the same kernel route
 // through a pinned scratch of the calling thread (1 MiB) -- a 4-byte hipMemcpyAsync queues behind whatever 100 MB copy-in the DMA
