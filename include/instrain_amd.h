@@ -597,6 +597,9 @@ int isx_bgzf_index(const uint8_t *image, int64_t n_bytes, int64_t cap_blocks, is
 int isx_bgzf_inflate_device(isx_ctx *ctx, const uint8_t *image, int64_t n_bytes, const isx_bgzf_block *blocks, int64_t n_blocks,
                             uint8_t *out, int64_t out_bytes, float *kernel_ms);
 int isx_bgzf_inflate_host(const uint8_t *image, int64_t n_bytes, const isx_bgzf_block *blocks, int64_t n_blocks, uint8_t *out, int64_t out_bytes);
+/* The BAM front end's host decoder on the calling thread (csrc/fast_inflate.h: table driven, about twice zlib's inflate on BAM blocks;
+ * inside the front end zlib decodes whatever this one refuses) -- here without the fallback, for tests and tools/inflate_rate.py. */
+int isx_bgzf_inflate_fast(const uint8_t *image, int64_t n_bytes, const isx_bgzf_block *blocks, int64_t n_blocks, uint8_t *out, int64_t out_bytes);
 
 /* ---- host-side BAM front end (BGZF/BAM decode, read-pair filter, htslib-1.9 pileup rules) ----
  * Two passes over the (memory-mapped, compressed) file, like the reference, none of which holds the file's reads:

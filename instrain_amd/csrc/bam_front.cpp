@@ -34,6 +34,8 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "fast_inflate.h"
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -238,9 +240,17 @@ struct Deflate {
 };
 const Deflate &deflate_lib() { static Deflate d; return d; }
 
+// ---- inflate: libdeflate when the image has it, else the table-driven decoder of fast_inflate.h (2x zlib's inflate on BAM blocks;
+// ISX_BAM_ZLIB=1: zlib only), zlib for whatever that one does not decode ----
 struct Inflater {       // one per thread
     void *ld = nullptr;
-    Inflater() { if (deflate_lib().alloc) ld = deflate_lib().alloc(); }
+    std::unique_ptr<isxinf::FastInflater> fast;
+    Inflater()
+    {
+        if (deflate_lib().alloc) ld = deflate_lib().alloc();
+        static const bool zlib_only = getenv("ISX_BAM_ZLIB") != nullptr;
+        if (!ld && !zlib_only) fast.reset(new isxinf::FastInflater());
+    }
     ~Inflater() { if (ld) deflate_lib().release(ld); }
     bool run(const uint8_t *src, size_t n_src, uint8_t *dst, size_t n_dst)
     {
@@ -249,6 +259,7 @@ struct Inflater {       // one per thread
             size_t got = 0;
             return deflate_lib().decomp(ld, src, n_src, dst, n_dst, &got) == 0 && got == n_dst;
         }
+        if (fast && fast->run(src, n_src, dst, n_dst)) return true;
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
         if (inflateInit2(&zs, -15) != Z_OK) return false;
@@ -2445,3 +2456,24 @@ int isx_bam_view(const isx_bam *bam, const isx_obs **obs, const uint32_t **pair)
 }
 
 }  // extern "C"
+
+
+// the front end's own block decoder on the calling thread (tests, tools/inflate_rate.py): fast_inflate.h with NO fallback -- ISX_ERR_IO names
+// the first block it does not decode
+int isx_bgzf_inflate_fast(const uint8_t *file, int64_t n_bytes, const isx_bgzf_block *blocks, int64_t n_blocks, uint8_t *out, int64_t out_bytes)
+{
+    if (!file || !blocks || n_blocks < 0 || (!out && out_bytes) || out_bytes < 0) { isx_set_error("isx_bgzf_inflate_fast: bad argument"); return ISX_ERR_ARG; }
+    std::unique_ptr<isxinf::FastInflater> f(new isxinf::FastInflater());
+    for (int64_t i = 0; i < n_blocks; i++) {
+        const isx_bgzf_block &b = blocks[i];
+        if (b.in_off < 0 || b.in_len < 0 || b.in_off + b.in_len > n_bytes || b.out_len < 0 || b.out_off < 0 || b.out_off + b.out_len > out_bytes) {
+            isx_set_error("isx_bgzf_inflate_fast: a block reaches outside its buffer");
+            return ISX_ERR_ARG;
+        }
+        if (b.out_len && !f->run(file + b.in_off, (size_t)b.in_len, out + b.out_off, (size_t)b.out_len)) {
+            isx_set_error("BGZF block " + std::to_string(i) + ": not decoded by the fast decoder");
+            return ISX_ERR_IO;
+        }
+    }
+    return ISX_OK;
+}

@@ -734,10 +734,18 @@ static int make_pass_queues(isx_ctx *c, int r, int n_cu)
             mask[k] = 0xFFFFFFFFu;
             for (int j = 0; j < r; j++) mask[k] &= ~(1u << (((k + (j >> 2)) & 7) + 8 * (j & 3)));
         }
-        for (int i = 0; i < 2; i++) HIP_TRY(hipExtStreamCreateWithCUMask(&c->pstream[i], 8, mask));
-        c->pass_cus = 256 - 8 * r;
-        if (!getenv("ISX_SIDE_UNMASKED")) for (int k = 0; k < 8; k++) c->side_mask[k] = ~mask[k];
-    } else {
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; i++) ok = hipExtStreamCreateWithCUMask(&c->pstream[i], 8, mask) == hipSuccess;
+        if (ok) {
+            c->pass_cus = 256 - 8 * r;
+            if (!getenv("ISX_SIDE_UNMASKED")) for (int k = 0; k < 8; k++) c->side_mask[k] = ~mask[k];
+        } else {            // a stack that refuses masked queues: go on without a reserve (the request is a performance hint, not a contract)
+            (void)hipGetLastError();
+            for (int i = 0; i < 2; i++) if (c->pstream[i]) { (void)hipStreamDestroy(c->pstream[i]); c->pstream[i] = nullptr; }
+            r = 0;
+        }
+    }
+    if (r == 0) {
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
         const int prio = getenv("ISX_NO_STREAM_PRIORITY") ? least : greatest;
@@ -787,7 +795,10 @@ extern "C++" hipError_t isx_side_stream_create(isx_ctx *c, hipStream_t *s)
 {
     bool any = false;
     for (int k = 0; k < 8; k++) any = any || c->side_mask[k] != 0;
-    if (any) return hipExtStreamCreateWithCUMask(s, 8, c->side_mask);
+    if (any) {
+        if (hipExtStreamCreateWithCUMask(s, 8, c->side_mask) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();            // (as above: without the mask rather than not at all)
+    }
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 

@@ -922,9 +922,10 @@ def bgzf_index(image):
     return blocks, int(tot.value)
 
 
-def bgzf_inflate(image, blocks=None, ctx=None):
+def bgzf_inflate(image, blocks=None, ctx=None, fast=False):
     """The inflated bytes of a BGZF image's blocks (all of them, or the given rows of bgzf_index re-based to their own output) --
-    on the device of `ctx` (isx_bgzf_inflate_device; returns (bytes array, kernel ms)) or, ctx None, by the same decoder on the host"""
+    on the device of `ctx` (isx_bgzf_inflate_device; returns (bytes array, kernel ms)) or, ctx None, by the same decoder on the host;
+    fast=True: the BAM front end's table-driven host decoder instead (isx_bgzf_inflate_fast)"""
     lib = _lib.load()
     img = np.frombuffer(image, dtype=np.uint8) if not isinstance(image, np.ndarray) else np.ascontiguousarray(image, dtype=np.uint8)
     if blocks is None:
@@ -934,7 +935,8 @@ def bgzf_inflate(image, blocks=None, ctx=None):
     total = int(blocks["out_len"].sum())
     out = np.empty(total, dtype=np.uint8)
     if ctx is None:
-        check(lib.isx_bgzf_inflate_host(img.ctypes.data, len(img), blocks.ctypes.data, len(blocks), out.ctypes.data, total))
+        fn = lib.isx_bgzf_inflate_fast if fast else lib.isx_bgzf_inflate_host
+        check(fn(img.ctypes.data, len(img), blocks.ctypes.data, len(blocks), out.ctypes.data, total))
         return out, None
     ms = C.c_float(0)
     check(lib.isx_bgzf_inflate_device(ctx.h, img.ctypes.data, len(img), blocks.ctypes.data, len(blocks), out.ctypes.data, total, C.byref(ms)))

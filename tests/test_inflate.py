@@ -60,6 +60,8 @@ def test_index_and_host_decoder_against_zlib():
     assert (blocks["out_off"] == np.cumsum(blocks["out_len"]) - blocks["out_len"]).all()
     out, _ = engine.bgzf_inflate(img)
     assert out.tobytes() == plain
+    out, _ = engine.bgzf_inflate(img, fast=True)        # the front end's table-driven decoder (fast_inflate.h), no zlib fallback
+    assert out.tobytes() == plain
     # a subset of the blocks, re-based
     sel = blocks[5:17]
     out, _ = engine.bgzf_inflate(img, sel)
@@ -71,6 +73,8 @@ def test_index_and_host_decoder_against_zlib():
 def test_host_decoder_on_the_golden_bams(name):
     raw = open(os.path.join(util.GOLD, name), "rb").read()
     out, _ = engine.bgzf_inflate(raw)
+    fast, _ = engine.bgzf_inflate(raw, fast=True)
+    assert fast.tobytes() == out.tobytes()
     d = zlib.decompressobj(31)
     exp = b""
     data = raw
@@ -119,3 +123,33 @@ def test_device_inflate_equals_zlib():
     except IsxError as e:
         assert "BGZF block" in str(e)
     ctx.close()
+
+
+def test_fast_decoder_long_codes_and_random_streams():
+    """skewed symbol statistics give codes of 12-15 bits (the second-level tables), many small blocks exercise every table rebuild;
+    truncated or flipped streams must be refused or at least never write beyond their block"""
+    rng = np.random.Generator(np.random.PCG64(11))
+    blocks, plain = [], []
+    for k in range(60):
+        n = int(rng.integers(1, 60000))
+        p = rng.geometric(0.02 + 0.3 * rng.random(), n).clip(0, 255).astype(np.uint8)       # a long tail of rare byte values
+        if k % 3 == 0:
+            p[rng.integers(0, n, n // 50)] = rng.integers(0, 256, n // 50, dtype=np.uint8)
+        if k % 4 == 1:                                                                      # far matches: distances up to 32 K
+            p = np.concatenate([p[:20000], p[:20000], p[:5000]])[:65000]
+        blocks.append(bgzf_block(p.tobytes(), int(rng.choice([1, 4, 6, 9]))))
+        plain.append(p.tobytes())
+    img, plain = b"".join(blocks), b"".join(plain)
+    for fast in (False, True):
+        out, _ = engine.bgzf_inflate(img, fast=fast)
+        assert out.tobytes() == plain, fast
+    idx, _ = engine.bgzf_index(img)
+    guard = np.full(len(plain) + 64, 0xA5, np.uint8)
+    for k in (3, 17, 40):
+        bad = bytearray(img)
+        bad[int(idx["in_off"][k]) + int(idx["in_len"][k]) // 2] ^= 0x10
+        try:
+            out, _ = engine.bgzf_inflate(bytes(bad), fast=True)
+            assert out.tobytes() != plain
+        except IsxError:
+            pass
