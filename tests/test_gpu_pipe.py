@@ -491,3 +491,46 @@ def test_deep_batch_after_shallow_on_one_slot(ctx):
         assert d["snv"].tobytes() == exp["snv"].tobytes()
         pipe.release(t)
     pipe.close()
+
+
+def test_context_with_a_cu_reserve_gives_the_same_tables(ctx):
+    """isx_ctx_reserve_cus: pass queues masked off 4 CUs of every XCD, side queues onto them, the persistent grid sized for 224 CUs --
+    a stream of read-level batches with linkage (lean slots, staged wires, large tables home by DMA) comes back byte for byte as from a
+    context that keeps the whole device; the call is refused once the context has made a batch"""
+    from instrain_amd import engine, synth
+    from instrain_amd._lib import IsxError, check
+    ws = [synth.make_workload(genome_len=600_000, coverage=c, n_sites=800, seed=s, skip_mm=True) for c, s in ((4, 91), (12, 92), (40, 93))]
+    segs = [synth.segs_from_obs(w["obs"], w["pair"]) for w in ws]
+    cap = dict(max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(s.n_seg for s in segs),
+               max_splits=max(len(w["split_bounds"]) for w in ws), depth=4, host_threads=4, pin_threads=False,
+               n_mm_bins=1, enable_linkage=True, min_snp=20, lean_output=True)
+    lut, fb = util.load_lut()
+    out = []
+    for reserve in (None, 4):
+        c = ctx if reserve is None else engine.Context(0, reserve_cus=reserve)
+        if reserve is not None:
+            c.set_null_model(lut, fb)
+        pipe = engine.Pipe(c, **cap)
+        wires = [pipe.stage_reads(w["ref_codes"], w["split_bounds"], sg) for w, sg in zip(ws, segs)]
+        tickets = [pipe.submit_wire(x) for x in wires] + [pipe.submit_wire(wires[0])]
+        res = []
+        for t in tickets:
+            r = pipe.collect(t)
+            res.append({k: r[k].copy() for k in ("cov16", "clon", "snv", "ld", "rare")} | {"sizes": r["sizes"]})
+            pipe.release(t)
+        if reserve is not None:
+            with pytest.raises(IsxError, match="before the context's first"):
+                check(c.lib.isx_ctx_reserve_cus(c.h, 2))
+        for x in wires:
+            x.close()
+        pipe.close()
+        if reserve is not None:
+            c.close()
+        out.append(res)
+    for a, b in zip(*out):
+        assert a["sizes"] == b["sizes"]
+        for k in ("cov16", "snv", "ld", "rare"):
+            assert a[k].tobytes() == b[k].tobytes(), k
+        assert a["clon"].view(np.uint32).tobytes() == b["clon"].view(np.uint32).tobytes()
+    cov = np.bincount(ws[0]["obs"]["gpos"], minlength=ws[0]["n_pos"])
+    assert (out[1][0]["cov16"] == cov).all() and out[1][3]["snv"].tobytes() == out[1][0]["snv"].tobytes()
