@@ -446,7 +446,7 @@ class C5Run:
     through one GPU; N = 8: one shard per GPU (strong scaling of the configuration).  One STEP = one pass over all of the
     rank's batches."""
 
-    def __init__(self, ctx, rank, world, host_threads, depth=4, scale=1.0, stage_async=False, staged=True):
+    def __init__(self, ctx, rank, world, host_threads, depth=4, scale=1.0, stage_async=False, staged=True, min_batches=8):
         from instrain_amd import dist as idist
         from instrain_amd import engine
         self.ctx, self.rank, self.world, self.depth = ctx, rank, world, depth
@@ -455,11 +455,17 @@ class C5Run:
         self.my_shards = [s for s in range(8) if s % world == rank % world]
         t0 = time.perf_counter()
         self.ws = []
+        # batch budget: 120 Mbp / 3 M segments at N = 1; a rank of a larger job keeps at least ~8 batches a pass (a pass ends with the
+        # last batch's kernel + linkage chain + copy-out, which nothing overlaps: the shorter the pass, the smaller that batch should be)
+        my_pos = int(sum(meta.length[kept[self.shards[sh]]].sum() for sh in self.my_shards))
+        shrink = min(1.0, max(0.25, my_pos / float(min_batches) / C5_BATCH_POS)) if min_batches else 1.0
+        batch_pos, batch_segs = int(C5_BATCH_POS * shrink), int(C5_BATCH_SEGS * shrink)
         for sh in self.my_shards:
             mine = kept[self.shards[sh]]
             est = (meta.pairs[mine] * 2).astype(np.int64)          # segments: one per read
-            for b in idist.pack_batches(meta.length[mine], est, C5_BATCH_POS, C5_BATCH_SEGS):
+            for b in idist.pack_batches(meta.length[mine], est, batch_pos, batch_segs):
                 self.ws.append(meta.generate_segs(mine[b]))
+        self.ws.sort(key=lambda w: -w["n_pos"])                     # largest first: the pass drains behind its smallest batch
         self.gen_s = time.perf_counter() - t0
         ws = self.ws
         self.pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["segs"].n_seg for w in ws),

@@ -25,7 +25,7 @@ ctx = engine.Context(0)
 lut, fb = util.load_lut()
 ctx.set_null_model(lut, fb)
 if "--c5" in sys.argv:
-    run = bench.C5Run(ctx, 0, 8, 4, depth=1, staged=True)        # rank 0 of 8: one shard is enough to find a batch
+    run = bench.C5Run(ctx, 0, 8, 4, depth=1, staged=True, min_batches=0)        # rank 0 of 8: one shard is enough to find a batch (of the N = 1 size)
     sizes = [w["n_pos"] for w in run.ws]
     k = int(np.argsort(sizes)[len(sizes) // 2])
     w, wire = run.ws[k], run.wires[k]
