@@ -446,7 +446,7 @@ class C5Run:
     through one GPU; N = 8: one shard per GPU (strong scaling of the configuration).  One STEP = one pass over all of the
     rank's batches."""
 
-    def __init__(self, ctx, rank, world, host_threads, depth=4, scale=1.0, stage_async=False, staged=True, min_batches=8):
+    def __init__(self, ctx, rank, world, host_threads, depth=4, scale=1.0, stage_async=False, staged=True, min_batches=0):
         from instrain_amd import dist as idist
         from instrain_amd import engine
         self.ctx, self.rank, self.world, self.depth = ctx, rank, world, depth
@@ -455,8 +455,9 @@ class C5Run:
         self.my_shards = [s for s in range(8) if s % world == rank % world]
         t0 = time.perf_counter()
         self.ws = []
-        # batch budget: 120 Mbp / 3 M segments at N = 1; a rank of a larger job keeps at least ~8 batches a pass (a pass ends with the
-        # last batch's kernel + linkage chain + copy-out, which nothing overlaps: the shorter the pass, the smaller that batch should be)
+        # batch budget: 120 Mbp / 3 M segments whatever the job's size.  (min_batches > 0 shrinks it so that a rank of an N-GPU job keeps
+        # that many batches a pass: measured as a LOSS -- one shard of 8 in 4 batches 7.3 ms a pass, in 11 batches 10.0 ms,
+        # tools/c5_rank_probe.py -- a batch's ~60 short launches cost more than a shorter drain saves)
         my_pos = int(sum(meta.length[kept[self.shards[sh]]].sum() for sh in self.my_shards))
         shrink = min(1.0, max(0.25, my_pos / float(min_batches) / C5_BATCH_POS)) if min_batches else 1.0
         batch_pos, batch_segs = int(C5_BATCH_POS * shrink), int(C5_BATCH_SEGS * shrink)
