@@ -7,8 +7,9 @@
 //   * literal / length codes through an 11-bit first-level table whose entries already carry the symbol's meaning (literal byte,
 //     length base + number of extra bits, end of block) -- codes longer than 11 bits go through 16-entry second-level tables;
 //     distance codes through an 8-bit first-level table (+ 128-entry second level);
-//   * up to three literals per refill; matches copied eight bytes a step (runs with a period below 8 from a pattern word);
-//   * a careful byte-wise loop only for the last ~270 bytes of a block, where a wide store could reach beyond the block.
+//   * up to three literals per refill; the next symbol's table entry is looked up before a match is copied; matches copied sixteen
+//     bytes at once and eight a step beyond (runs with a period below 8 from a pattern word);
+//   * a careful byte-wise loop only for the last ~290 bytes of a block, where a wide store could reach beyond the block.
 // Anything irregular (a code it cannot place, sizes that do not come out) makes it return false and the caller falls back to zlib:
 // it never has to be the judge of a corrupt file.  Pinned against zlib by tests/test_inflate.py (isx_bgzf_inflate_fast).
 #pragma once
@@ -223,24 +224,18 @@ private:
     bool codes(uint8_t *out, size_t &o_io, size_t n_out)
     {
         size_t o = o_io;
-        const size_t wide_end = n_out >= 272 ? n_out - 272 : 0;     // below this a copy may write up to 8 bytes beyond its match
-        {
+        const size_t wide_end = n_out >= 288 ? n_out - 288 : 0;     // below this a copy may write up to 24 bytes beyond its match
+        if (end_ - in_ >= 16) {
             uint64_t buf = buf_;
             int cnt = cnt_;
             const uint8_t *in = in_;
-            const uint8_t *const in_fast = end_ - 8;
+            const uint8_t *const in_fast = end_ - 16;              // two refills of 8 bytes are safe from here
             const uint32_t *const lit = lit_, *const dst = dst_;
             bool done = false, bad = false;
+#define ISXINF_REFILL() do { uint64_t w_; memcpy(&w_, in, 8); buf |= w_ << cnt; const int k_ = (63 - cnt) >> 3; in += k_; cnt += 8 * k_; } while (0)
+            ISXINF_REFILL();
+            uint32_t e = lit[buf & ((1u << LB) - 1u)];             // the entry of the symbol about to be decoded (nothing consumed yet)
             while (in <= in_fast && o < wide_end) {
-                {   // refill: cnt >= 56 afterwards
-                    uint64_t w;
-                    memcpy(&w, in, 8);
-                    buf |= w << cnt;
-                    const int k = (63 - cnt) >> 3;
-                    in += k;
-                    cnt += 8 * k;
-                }
-                uint32_t e = lit[buf & ((1u << LB) - 1u)];
                 if (__builtin_expect(((e >> 8) & 3u) == K_SUB, 0)) {
                     if (!(e & 15u)) { bad = true; break; }
                     buf >>= LB; cnt -= LB;
@@ -262,6 +257,8 @@ private:
                             out[o++] = (uint8_t)(f >> 16);
                         }
                     }
+                    ISXINF_REFILL();
+                    e = lit[buf & ((1u << LB) - 1u)];
                     continue;
                 }
                 if (kind == K_EOB) { if (e & (1u << 12)) bad = true; else done = true; break; }
@@ -280,11 +277,18 @@ private:
                 const uint32_t dist = (d >> 16) + (uint32_t)(buf & (((uint64_t)1 << xd) - 1));
                 buf >>= xd; cnt -= xd;
                 if (__builtin_expect(dist > o, 0)) { bad = true; break; }
+                // the next symbol's entry is looked up BEFORE this match is copied: the table read's latency passes under the copy
+                ISXINF_REFILL();
+                e = lit[buf & ((1u << LB) - 1u)];
                 uint8_t *dp = out + o;
                 const uint8_t *sp = dp - dist;
-                if (dist >= 8) {
-                    uint32_t k = 0;
-                    do { uint64_t w; memcpy(&w, sp + k, 8); memcpy(dp + k, &w, 8); k += 8; } while (k < len);
+                o += len;
+                if (__builtin_expect(dist >= 8, 1)) {
+                    // sixteen bytes whatever the length (most matches are shorter), more in steps of eight
+                    uint64_t w;
+                    memcpy(&w, sp, 8); memcpy(dp, &w, 8);
+                    memcpy(&w, sp + 8, 8); memcpy(dp + 8, &w, 8);
+                    for (uint32_t k = 16; k < len; k += 8) { memcpy(&w, sp + k, 8); memcpy(dp + k, &w, 8); }
                 } else if (dist == 1) {
                     const uint64_t pat = 0x0101010101010101ull * sp[0];
                     for (uint32_t k = 0; k < len; k += 8) memcpy(dp + k, &pat, 8);
@@ -294,8 +298,8 @@ private:
                     const uint32_t step = (8u / dist) * dist;
                     for (uint32_t k = 0; k < len; k += step) memcpy(dp + k, &pat, 8);
                 }
-                o += len;
             }
+#undef ISXINF_REFILL
             buf_ = buf; cnt_ = cnt; in_ = in;
             if (bad || cnt < 0) return false;
             if (done) { o_io = o; return true; }

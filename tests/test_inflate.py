@@ -153,3 +153,38 @@ def test_fast_decoder_long_codes_and_random_streams():
             assert out.tobytes() != plain
         except IsxError:
             pass
+
+
+def test_fast_decoder_never_writes_outside_its_block_on_corrupt_input():
+    """300 random corruptions (bit flips, truncations, wrong ISIZE) of real blocks: the decoder refuses or decodes something, and the bytes
+    before and behind the block's output stay untouched either way"""
+    import ctypes as C
+    from instrain_amd import _lib
+    lib = _lib.load()
+    rng = np.random.Generator(np.random.PCG64(23))
+    raw = open(os.path.join(util.GOLD, "sars_cov_2.sorted.bam"), "rb").read()
+    blocks, _ = engine.bgzf_index(raw)
+    blocks = blocks[blocks["out_len"] > 4000]
+    assert len(blocks) >= 4
+    GUARD = 4096
+    n_refused = 0
+    for it in range(300):
+        b = blocks[int(rng.integers(0, len(blocks)))].copy()
+        img = np.frombuffer(raw, dtype=np.uint8).copy()
+        lo, n = int(b["in_off"]), int(b["in_len"])
+        kind = it % 3
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                img[lo + int(rng.integers(0, n))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        elif kind == 1:
+            b["in_len"] = int(rng.integers(1, n))                       # truncated stream
+        else:
+            b["out_len"] = int(rng.integers(1, 65536))                  # a wrong ISIZE
+        one = np.zeros(1, dtype=_lib.BGZF_BLOCK_DT)
+        one[0] = b
+        one["out_off"] = GUARD
+        out = np.full(GUARD + int(b["out_len"]) + GUARD, 0xA5, dtype=np.uint8)
+        rc = lib.isx_bgzf_inflate_fast(img.ctypes.data, len(img), one.ctypes.data, 1, out.ctypes.data, len(out))
+        n_refused += rc != 0
+        assert (out[:GUARD] == 0xA5).all() and (out[GUARD + int(b["out_len"]):] == 0xA5).all(), (it, kind)
+    assert n_refused > 150
