@@ -1045,6 +1045,7 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     const size_t n_ref = B.ref_name.size(), n_seg = B.segs.size();
     const bool timing = getenv("ISX_BAM_TIMING") != nullptr;       // tuning aid: stage times on stderr (no effect on results)
     double t_inflate = 0, t_hop = 0, t_extract = 0;
+    std::atomic<uint64_t> thr_inflate_us{0}, thr_hop_us{0};        // (timing only) summed over the pool's threads: block decode / guess + record walk
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     double t_mark = t_begin;
@@ -1076,7 +1077,9 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
         pool.run((int)(w1 - w0), [&](int i) {
             Inflater inf;
             const Segment &s = B.segs[w0 + (size_t)i];
+            const double ta = timing ? now() : 0.0;
             if (!seg_inflate(B, inf, s, bufs[(size_t)i])) { bad.store(1); return; }
+            const double tb = timing ? now() : 0.0;
             uint64_t g = (w0 + (size_t)i == 0) ? std::max(B.first_rec, s.ioff0) : seg_guess(B, inf, s, bufs[(size_t)i]);
             if (w0 + (size_t)i == 0 && B.first_rec > s.ioff1) g = ~0ull;
             guess[(size_t)i] = g;
@@ -1084,6 +1087,7 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
                 std::string keep_err = "";
                 hop_rc[(size_t)i] = seg_hop(B, inf, s, bufs[(size_t)i], g, recs[(size_t)i], nexts[(size_t)i]);
             }
+            if (timing) { const double tc = now(); thr_inflate_us.fetch_add((uint64_t)((tb - ta) * 1e3)); thr_hop_us.fetch_add((uint64_t)((tc - tb) * 1e3)); }
         });
         if (bad.load()) { isx_set_error("BGZF inflate failed"); return ISX_ERR_IO; }
         { const double t = now(); t_inflate += t - t_mark; t_mark = t; }
@@ -1351,6 +1355,8 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     });
     if (timing) fprintf(stderr, "[isx_bam_scan] share %d/%d: segments [%zu, %zu) of %zu, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms (bucketing %.1f, tables %.1f, merge %.1f); %.1f ms since the scan began\n",
                         part, n_parts, sv, s_end, n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark, t_bucket - t_mark, t_tables - t_bucket, now() - t_tables, now() - t_begin);
+    if (timing) fprintf(stderr, "[isx_bam_scan]   inside 'inflate', summed over the threads: block decode + buffers %.1f ms, start guess + record walk %.1f ms\n",
+                        thr_inflate_us.load() / 1e3, thr_hop_us.load() / 1e3);
     {
         size_t bytes = 0;
         for (const auto &v : B.seg_reads) bytes += v.size() * sizeof(ReadLite);
