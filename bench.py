@@ -487,6 +487,7 @@ class C5Run:
         the coverage at their position and reach min_cov, LD rows' four counts add up to their total.  Returns and remembers
         the per-batch signature (n_snv, n_ld, n_edges) the timed passes are compared with."""
         sig = []
+        covered = {}
 
         def check(i, r):
             from instrain_amd import engine
@@ -500,6 +501,7 @@ class C5Run:
                 cov[s["gpos"]] = s["coverage"]
             if total != w["n_obs"]:
                 raise AssertionError("C5 batch %d: coverage table sums to %d, %d observations were handed over" % (i, total, w["n_obs"]))
+            covered[i] = int(np.count_nonzero(cov))
             snv = r["snv"]
             g = snv["gpos"].astype(np.int64)
             if len(g) != r["sizes"]["n_snv"] or (np.diff(g) <= 0).any():
@@ -584,7 +586,13 @@ class C5Run:
                             "algorithmic_bytes_per_launch": abytes / max(len(ws), 1), "bytes_per_position": abytes / max(n_pos, 1),
                             "kernel_ms_avg": k_ms / max(len(ws), 1), "kernel_ms_per_pass": k_ms, "launches": len(st),
                             "traffic": _pmc("c5_dense_linkage_bytes_per_launch") if self.n_genomes == 1000 else None,
-                            "traffic_source": _pmc_source("c5_dense_linkage_bytes_per_launch")},
+                            "traffic_source": _pmc_source("c5_dense_linkage_bytes_per_launch"),
+                            # the same kernel time priced on SURVEY 8(d)'s byte model of the naive formulation (12 B per kept observation
+                            # with linkage + 1 B per position of reference + 28 B per covered position out) instead of this build's format
+                            # bytes -- for comparison only: `frac` above is the stricter figure
+                            "survey_8d_model": {"bytes_per_pass": n_obs * 12 + n_pos + int(getattr(self, "covered", 0) or n_pos) * 28,
+                                                "frac": ((n_obs * 12 + n_pos + int(getattr(self, "covered", 0) or n_pos) * 28) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else 0.0},
+                            "bound_of_the_pass": "pcie (copy-in %.1f of %.1f ms)" % (tot("h2d_ms"), dt_max / passes * 1e3)},
                "roofline_pcie": {"bound": "pcie", "direction": "host->device", "achieved": tot("h2d_bytes") / (dt_max / passes) / 1e9, "peak": PCIE_PEAK_GBS,
                                  "unit": "GB/s", "frac": tot("h2d_bytes") / (dt_max / passes) / 1e9 / PCIE_PEAK_GBS, "bytes_per_pass": tot("h2d_bytes"),
                                  "bytes_per_profiled_base": tot("h2d_bytes") / max(self.bases, 1.0),
@@ -997,7 +1005,7 @@ def main():
                        "numa_node": numa_node, "parallelism": "genome-sharded x%d%s" % (world, " (ranks share %d GPU)" % n_dev if shared else ""),
                        "verified": "per-batch checks in an untimed pass; timed row counts equal"},
             "roofline": {k: head["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
-                                                            "algorithmic_bytes_per_launch", "kernel_ms_avg", "launches")},
+                                                            "algorithmic_bytes_per_launch", "kernel_ms_avg", "launches", "survey_8d_model", "bound_of_the_pass")},
             "h2d_bytes_per_base": head["roofline_pcie"]["bytes_per_profiled_base"], "pcie_frac": head["roofline_pcie"]["frac"],
             "snv_pairs_linked_per_s": head["snv_pairs_linked_per_s"],
             "stages_ms": {k: round(v, 2) for k, v in head["stages_ms_per_pass"].items()},
