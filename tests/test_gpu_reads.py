@@ -460,3 +460,41 @@ def test_lean_slot_output_equals_the_plain_slot(ctx):
     assert len(n_rows) == 3 and n_rows[2] >= 10 and n_rows[0] <= n_rows[1] <= n_rows[2]        # (the depth-6 batch keeps 5.4 of 6 bases: 4-bit plane too)
     n2 = out[True][4]
     assert (~np.isnan(n2["clon"]) & (n2["clon"] != 1.0)).sum() * 2 > len(n2["clon"])        # the case that needs the dense array
+
+
+def test_lean_slot_with_a_pile_in_every_window_repeats_the_pass_without_the_4bit_plane(ctx):
+    """a shallow batch (mean depth 4.8) with 24 reads stacked every 800 positions (amplicon-like): every window holds positions beyond 15,
+    the 16-bit rows would outgrow the slot's coverage block -> the pass is repeated with the 8-bit plane; tables equal the plain slot's"""
+    from instrain_amd import engine, synth
+    w = synth.make_workload(genome_len=900_000, coverage=2, n_sites=400, seed=77, skip_mm=True)
+    base = synth.segs_from_obs(w["obs"], w["pair"])
+    starts = np.arange(300, w["n_pos"] - 200, 800, dtype=np.uint32)
+    sg = np.repeat(starts, 24)
+    codes = np.full((len(sg), 150), 4, dtype=np.uint8)
+    codes[:, :100] = w["ref_codes"][sg[:, None].astype(np.int64) + np.arange(100)[None, :]]
+    spike_pair = (int(base.pair.max()) + 1 + np.arange(len(sg))).astype(np.uint32)
+    g = np.concatenate([base.gpos, sg])
+    order = np.argsort(g, kind="stable")
+    segs = engine.SegBatch(g[order], np.concatenate([base.len, np.full(len(sg), 100, np.uint8)])[order],
+                           np.concatenate([base.bases, engine.pack_codes(codes)])[order], None, np.concatenate([base.pair, spike_pair])[order])
+    exp_cov = np.bincount(w["obs"]["gpos"], minlength=w["n_pos"])
+    for s in starts:
+        exp_cov[int(s):int(s) + 100] += 24
+    assert exp_cov.sum() < 6 * w["n_pos"]
+    cap = dict(max_pos=w["n_pos"], max_obs=0, max_segs=segs.n_seg, max_splits=len(w["split_bounds"]), depth=2, host_threads=4, pin_threads=False,
+               n_mm_bins=1, enable_linkage=True, min_snp=20)
+    got = {}
+    for lean in (False, True):
+        pipe = engine.Pipe(ctx, lean_output=lean, **cap)
+        t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs)
+        raw = pipe.collect(t, densify=False)
+        assert "cov8" in raw and "cov4" not in raw, lean                # the lean slot fell back: rows for every window do not fit
+        assert (engine.dense_cov(raw, w["n_pos"]) == exp_cov).all()
+        r = pipe.collect(t)
+        got[lean] = {k: r[k].copy() for k in ("cov16", "clon", "snv", "ld")} | {"sizes": r["sizes"]}
+        pipe.release(t)
+        pipe.close()
+    assert got[False]["sizes"] == got[True]["sizes"]
+    for k in ("cov16", "snv", "ld"):
+        assert got[False][k].tobytes() == got[True][k].tobytes(), k
+    assert got[False]["clon"].view(np.uint32).tobytes() == got[True]["clon"].view(np.uint32).tobytes()
