@@ -1218,7 +1218,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
         bool seen = false;
         for (;;) {
             if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == b->epoch) { seen = true; break; }
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(b->spin_us)) break;
         }
         if (!seen) HIP_TRY(hipStreamSynchronize(c->pstream[b->ps]));
     }

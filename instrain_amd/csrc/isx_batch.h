@@ -81,6 +81,8 @@ struct isx_batch {
     uint2 *d_sat = nullptr, *d_clon_list = nullptr, *d_clon_sorted = nullptr;
     size_t cap_sat = 0, cap_clon = 0;
     uint32_t n_clon = 0;
+    int spin_us = 2000;                 // finish_pass: how long the finisher polls the epoch word before it falls back to a stream wait (a pipe
+                                        // whose caller gave it few host threads -- a rank of a multi-GPU job on a shared CPU quota -- polls briefly)
     bool nib_pass = false;              // the last pass really wrote the 4-bit plane (nib_out asked for, and the kernel is the packed reference-delta one)
     bool nib_out = false;               // this pass: coverage as the 4-bit plane (in d_cov8) + 16-bit rows of the windows beyond 15 (in d_cov16): lean slots
     uint32_t *d_cov_row_win = nullptr;  // ... and the window of every such row

@@ -334,6 +334,8 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
     b->segs = p->segs; b->drec = p->drec;
     b->lean = p->pp.lean_output != 0 && !p->pp.want_counts && b->M == 1;
+    // four finishers polling for 2 ms each would take the whole CPU share of a rank that has 2-4 host threads to itself
+    b->spin_us = (p->pp.host_threads > 0 && p->pp.host_threads < 8) ? 200 : 2000;
     const bool dense = b->M == 1;
     batch_pick_block(b);
     const int64_t cap_pos = p->pp.max_pos;
