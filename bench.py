@@ -535,6 +535,23 @@ class C5Run:
         return {"gbp_per_s": self.bases / dt / 1e9, "seconds": dt, "host_stage_ms": float(np.sum([x["encode_ms"] for x in st])),
                 "copy_in_ms": float(np.sum([x["h2d_ms"] for x in st])), "h2d_bytes": float(np.sum([x["h2d_bytes"] for x in st]))}
 
+    def resident_reference_passes(self, passes=4):
+        """the same passes with every batch's reference planes kept on the device (isx_wire_keep_reference): what a service that profiles
+        sample after sample against ONE database would run -- the reference is the same for every sample, only the reads are new.
+        An extra of the line, not its value: the headline hands every batch over whole"""
+        for x in self.wires:
+            x.keep_reference()
+        self.run(1)
+        stats = []
+        t0 = time.perf_counter()
+        self.run(passes, stats)
+        dt = (time.perf_counter() - t0) / passes
+        self.check_timed(stats)
+        st = [x for x, _ in stats]
+        return {"gbp_per_s": self.bases / dt / 1e9, "ms_per_pass": dt * 1e3, "passes": passes,
+                "h2d_bytes_per_pass": float(np.sum([x["h2d_bytes"] for x in st])) / passes,
+                "h2d_bytes_per_base": float(np.sum([x["h2d_bytes"] for x in st])) / passes / max(self.bases, 1.0)}
+
     def check_timed(self, stats):
         """every timed batch produced the tables of the verified pass (row counts; the stream is deterministic)"""
         n = len(self.ws)
@@ -972,6 +989,8 @@ def main():
     head = c5.report(dt, bases_all, stats, args.steps, gather_ms)
     if rank == 0 and world == 1 and not args.only_c5:
         head["submit_reads_pass"] = c5.unstaged_pass()
+    if rank == 0 and world == 1 and (not args.only_c5 or os.environ.get("ISX_BENCH_RESIDENT_REF")):
+        head["resident_reference"] = c5.resident_reference_passes()         # (last: the wires keep their device copies from here on)
     cb = cp = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, cp = c5.cpu_baselines()
@@ -1013,6 +1032,9 @@ def main():
         }
         if "submit_reads_pass" in head:
             out["c5_with_host_staging_gbp_per_s"] = head["submit_reads_pass"]["gbp_per_s"]
+        if "resident_reference" in head:
+            out["c5_resident_reference_gbp_per_s"] = head["resident_reference"]["gbp_per_s"]
+            out["c5_resident_reference_h2d_bytes_per_base"] = head["resident_reference"]["h2d_bytes_per_base"]
         out["roofline"]["kernel"] = _short(out["roofline"]["kernel"], 80)
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms

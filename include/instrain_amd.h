@@ -518,6 +518,11 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
 int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *wire, int64_t *ticket);
 int64_t isx_wire_bytes(const isx_wire *wire);
 void isx_wire_free(isx_wire *wire);
+/* Keep a staged batch's reference planes in device memory: later submits of the wire bring in only what belongs to the sample (records,
+ * directory, bounds).  The reference of a database is the same for every sample profiled against it -- the reference program holds its
+ * fasta in memory for the whole run (profile_controller.py:415-433) -- and is a quarter of a shallow metagenome batch's copy-in.  The
+ * device copy lives until isx_wire_free. */
+int isx_wire_keep_reference(isx_pipe *p, isx_wire *wire);
 
 /* Host helper for a caller that decodes the BAM itself (e.g. a pysam loop over samfile.fetch()): reads -> segments.
  * Per read r: flat position of its reference start ref_start[r] (may be negative relative to the scaffold when the

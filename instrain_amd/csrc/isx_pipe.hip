@@ -1218,6 +1218,8 @@ struct isx_wire {
     bool ref_has_n = false;
     float stage_ms = 0.f;
     int encode_passes = 1;
+    uint8_t *d_ref = nullptr;           // isx_wire_keep_reference: the reference planes stay on the device between submits
+    int device = 0;
 };
 
 int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
@@ -1326,10 +1328,28 @@ void isx_wire_free(isx_wire *w)
 {
     if (!w) return;
     if (w->h) isx_pin_free(w->h);
+    if (w->d_ref) { (void)hipSetDevice(w->device); isx_dev_free(w->d_ref); }
     delete w;
 }
 
-int64_t isx_wire_bytes(const isx_wire *w) { return w ? (int64_t)(w->bounds_bytes + w->win_bytes + w->ref_bytes + w->gbase_bytes + w->pairs_bytes + w->rec_bytes) : 0; }
+// The reference planes of a staged batch stay in HBM from now on: later submits of the wire copy everything BUT them.  The reference of a
+// database is the same for every sample profiled against it (the reference program holds its fasta in host memory for the whole run,
+// profile_controller.py:415-433); a quarter of a shallow metagenome batch's copy-in is its 2-bit plane.
+int isx_wire_keep_reference(isx_pipe *p, isx_wire *w)
+{
+    if (!p || !w || w->pipe != p) { isx_set_error("isx_wire_keep_reference: bad argument"); return ISX_ERR_ARG; }
+    if (w->d_ref || !w->ref_bytes) return ISX_OK;
+    isx_ctx *c = p->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t *d = nullptr;
+    HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&d), w->ref_bytes + 64));
+    const hipError_t e = hipMemcpy(d, w->h + w->o_ref, w->ref_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { isx_dev_free(d); isx_set_error(std::string("isx_wire_keep_reference: ") + hipGetErrorString(e)); return ISX_ERR_HIP; }
+    w->d_ref = d; w->device = c->device;
+    return ISX_OK;
+}
+
+int64_t isx_wire_bytes(const isx_wire *w) { return w ? (int64_t)(w->bounds_bytes + w->win_bytes + (w->d_ref ? 0 : w->ref_bytes) + w->gbase_bytes + w->pairs_bytes + w->rec_bytes) : 0; }
 
 // a staged batch into the next free slot: copies straight from the image, no host work
 int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
@@ -1365,8 +1385,9 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     }
     b->d_bounds = reinterpret_cast<int64_t *>(s.d_in + s.off_bounds);
     b->d_win = reinterpret_cast<uint2 *>(s.d_in + s.off_win);
-    b->d_ref = s.d_in + s.off_ref;
-    b->d_ref_n = s.ref_has_n ? s.d_in + s.off_ref + ref2_bytes(b->n_pos) : nullptr;
+    uint8_t *const dref = w->d_ref ? w->d_ref : s.d_in + s.off_ref;         // (a kept reference: the wire's own device copy, nothing to bring in)
+    b->d_ref = dref;
+    b->d_ref_n = s.ref_has_n ? dref + ref2_bytes(b->n_pos) : nullptr;
     b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
     b->d_seg = p->drec ? nullptr : reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
     b->d_drec = p->drec ? reinterpret_cast<uint4 *>(s.d_in + s.off_rec) : nullptr;
@@ -1376,7 +1397,7 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, w->h + w->o_bounds, w->bounds_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, w->h + w->o_win, w->win_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, w->h + w->o_ref, w->ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    if (!w->d_ref) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, w->h + w->o_ref, w->ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, w->h + w->o_gbase, w->gbase_bytes, hipMemcpyHostToDevice, p->s_h2d));
     if (w->pairs_bytes) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, w->h + w->o_pairs, w->pairs_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, w->h + w->o_rec, w->rec_bytes, hipMemcpyHostToDevice, p->s_h2d));

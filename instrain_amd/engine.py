@@ -474,8 +474,13 @@ class Wire:
     """A staged batch (isx_wire): pinned image + geometry, made by Pipe.stage_reads"""
 
     def __init__(self, pipe, h):
-        self.lib, self.h = pipe.lib, h
+        self.lib, self.h, self.pipe_h = pipe.lib, h, pipe.h
         self.bytes = int(self.lib.isx_wire_bytes(h))
+
+    def keep_reference(self):
+        """isx_wire_keep_reference: the batch's reference planes stay on the device; later submits copy only the sample's part"""
+        check(self.lib.isx_wire_keep_reference(self.pipe_h, self.h))
+        self.bytes = int(self.lib.isx_wire_bytes(self.h))
 
     def close(self):
         h, self.h = self.h, None

@@ -406,6 +406,19 @@ def test_staged_batches_equal_submits(ctx, skip_mm, linkage, layout):
             done += 1
             continue
         take()
+    # the reference planes kept on the device (isx_wire_keep_reference): later submits bring in less and give the same tables -- also when
+    # the slot has meanwhile held another batch's reference
+    before = [wr.bytes for wr in wires]
+    for wr in wires:
+        wr.keep_reference()
+    assert all(wr.bytes < b0 - w["n_pos"] // 4 + 64 for wr, b0, w in zip(wires, before, ws))
+    for k in (1, 0, 1, 1, 0):
+        t = pipe.submit_wire(wires[k])
+        r = pipe.collect(t)
+        assert r["sizes"] == want[k][0] and r["stats"]["h2d_bytes"] == wires[k].bytes
+        for kk in keys:
+            assert r[kk].tobytes() == want[k][1][kk].tobytes(), (kk, k)
+        pipe.release(t)
     other = engine.Pipe(ctx, **cap, **kw)
     with pytest.raises(engine.IsxError, match="another pipe"):
         other.submit_wire(wires[0])
