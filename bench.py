@@ -3,11 +3,13 @@
 
 The headline is BASELINE.json configs[4], the configuration north_star quotes its target on: the
 1000-genome database with 10 Gbp of reads, --database_mode, pileup + SNV call + linkage.  A STEP = one pass over the
-rank's share of the kept database (N = 1: all of it, ~80 batches of a few genomes), every batch handed over from host
-memory as READ SEGMENTS (isx_pipe_submit_reads: 64-byte records staged into pinned memory by the pipe's host threads,
-hipMemcpyAsync in), profiled ONCE on the device (k_pileup_dense walks the segments into its LDS window histograms, SNV
-call epilogue, linkage chain) and its tables copied back to pinned host memory (isx_pipe_collect); copy-in / pass /
-copy-out of consecutive batches overlap in the pipe.  Before the timed steps ONE untimed pass checks every batch's
+rank's share of the kept database (N = 1: all of it, 25 batches of <= 120 Mbp), every batch handed over INSIDE the step from
+the caller's own (pageable) arrays -- its reads as bit planes (isx_read_planes: one 64-byte line a read), the reference as
+its 2-bit plane -- through isx_pipe_submit_planes: the pipe's host threads copy the reference planes into pinned staging and
+make the 32-byte reference-delta wire records by XOR against them, hipMemcpyAsync brings them in, the batch is profiled ONCE
+on the device (k_pileup_dense: difference-array pileup in LDS, SNV call epilogue, linkage chain) and its tables are copied
+back to pinned host memory (isx_pipe_collect); staging / copy-in / pass / copy-out of consecutive batches overlap in the
+pipe.  (Round 4's headline replayed pre-staged pinned images: that is the extra `c5_staged_replay_gbp_per_s` now.)  Before the timed steps ONE untimed pass checks every batch's
 tables on the host (C5Run.verify_pass); every timed batch's row counts must equal that pass's.  N > 1: the 8 LPT shards
 of the database are dealt over the ranks (strong scaling; no data-path collective; one final RCCL gather of the SNV
 tables after the timed region, reported separately).  `python bench.py --gpus N` without a launcher starts its N ranks
@@ -446,7 +448,7 @@ class C5Run:
     through one GPU; N = 8: one shard per GPU (strong scaling of the configuration).  One STEP = one pass over all of the
     rank's batches."""
 
-    def __init__(self, ctx, rank, world, host_threads, depth=4, scale=1.0, stage_async=False, staged=True, min_batches=0):
+    def __init__(self, ctx, rank, world, host_threads, depth=4, scale=1.0, stage_async=False, min_batches=0):
         from instrain_amd import dist as idist
         from instrain_amd import engine
         self.ctx, self.rank, self.world, self.depth = ctx, rank, world, depth
@@ -465,20 +467,32 @@ class C5Run:
             mine = kept[self.shards[sh]]
             est = (meta.pairs[mine] * 2).astype(np.int64)          # segments: one per read
             for b in idist.pack_batches(meta.length[mine], est, batch_pos, batch_segs):
-                self.ws.append(meta.generate_segs(mine[b]))
+                w = meta.generate_segs(mine[b])
+                # What the caller holds and hands over (include/instrain_amd.h isx_read_planes / isx_ref_planes): its reads as bit planes
+                # -- one 64-byte line a read: 2-bit base codes + the plane of columns that are not observed -- and the database's
+                # reference as the 2-bit plane it travels as.  Plain (pageable) memory of this process, written before the timed region,
+                # exactly where round 4 generated its isx_segs arrays.
+                w["planes"] = engine.PlaneBatch.from_segs(w["segs"], threads=host_threads)
+                w["ref_planes"] = engine.RefPlanes.from_codes(w["ref_codes"], threads=host_threads)
+                w["n_seg"] = int(w["segs"].n_seg)
+                del w["segs"], w["ref_codes"]
+                self.ws.append(w)
         self.ws.sort(key=lambda w: -w["n_pos"])                     # largest first: the pass drains behind its smallest batch
         self.gen_s = time.perf_counter() - t0
         ws = self.ws
-        self.pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["segs"].n_seg for w in ws),
+        self.pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["n_seg"] for w in ws),
                                 max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
                                 pin_threads=False, n_mm_bins=1, enable_linkage=C5_LINKAGE, min_snp=20, stage_async=stage_async, lean_output=LEAN_SLOTS)
         self.bases = float(sum(w["profiled_bases"] for w in ws))
         self.signature = None
-        # The host side of the hand-over, done once per batch as a decoder would do it while it decodes (the reference's workers
-        # decode their BAM region before they profile it): compare with the reference, encode the wire records, pack the
-        # reference, lay out the window directory -- into a pinned image per batch.  A timed step only enqueues DMA + kernels.
+        self.wires = None
+        self.stage_s = None
+
+    def stage_all(self):
+        """every batch staged once into a pinned image (isx_pipe_stage_planes): what round 4's headline replayed.  An extra of the line
+        now -- the headline's steps do this work inside the step"""
         t0 = time.perf_counter()
-        self.wires = [self.pipe.stage_reads(w["ref_codes"], w["split_bounds"], w["segs"]) for w in ws] if staged else None
+        self.wires = [self.pipe.stage_planes(w["ref_planes"], w["split_bounds"], w["planes"]) for w in self.ws]
         self.stage_s = time.perf_counter() - t0
 
     def verify_pass(self):
@@ -514,37 +528,43 @@ class C5Run:
                 raise AssertionError("C5 batch %d: LD row counts do not add up" % i)
             sig.append((int(r["sizes"]["n_snv"]), int(r["sizes"]["n_ld"]), int(r["sizes"]["n_edges"])))
 
-        stream(self.pipe, self.ws, len(self.ws), self.depth, check=check, wires=self.wires)
+        stream(self.pipe, self.ws, len(self.ws), self.depth, check=check)
         self.signature = sig
         return sig
 
-    def run(self, passes, stats=None, keep_last=False, staged=True):
+    def run(self, passes, stats=None, keep_last=False, staged=False):
+        """passes over the rank's batches.  staged False (the headline): every batch handed over from the caller's arrays --
+        isx_pipe_submit_planes: reference planes copied into pinned staging, records made by the XOR pass, DMA, kernels, tables back, all
+        inside the step.  staged True: the pinned images of stage_all() replayed (DMA + kernels + tables back)."""
         n = len(self.ws)
         return stream(self.pipe, self.ws, n * passes, self.depth, stats, keep_last=keep_last, wires=self.wires if staged else None)
 
-    def unstaged_pass(self):
-        """one pass with the host staging INSIDE the step (isx_pipe_submit_reads: the pipe's threads compare with the reference and
-        encode into the slot's pinned arena at submit time) -- what a caller pays that hands over isx_segs arrays it cannot stage
-        ahead; reported beside the headline"""
+    def staged_replay(self, passes=4):
+        """round 4's headline as an extra: batches staged once (untimed), a pass = DMA + kernels + tables back"""
+        if self.wires is None:
+            self.stage_all()
+        self.run(1, staged=True)
         stats = []
         t0 = time.perf_counter()
-        self.run(1, stats, staged=False)
-        dt = time.perf_counter() - t0
+        self.run(passes, stats, staged=True)
+        dt = (time.perf_counter() - t0) / passes
         self.check_timed(stats)
         st = [x for x, _ in stats]
-        return {"gbp_per_s": self.bases / dt / 1e9, "seconds": dt, "host_stage_ms": float(np.sum([x["encode_ms"] for x in st])),
-                "copy_in_ms": float(np.sum([x["h2d_ms"] for x in st])), "h2d_bytes": float(np.sum([x["h2d_bytes"] for x in st]))}
+        return {"gbp_per_s": self.bases / dt / 1e9, "ms_per_pass": dt * 1e3, "passes": passes, "stage_once_s": self.stage_s,
+                "copy_in_ms_per_pass": float(np.sum([x["h2d_ms"] for x in st])) / passes, "kernel_ms_per_pass": float(np.sum([x["kernel_ms"] for x in st])) / passes}
 
     def resident_reference_passes(self, passes=4):
         """the same passes with every batch's reference planes kept on the device (isx_wire_keep_reference): what a service that profiles
         sample after sample against ONE database would run -- the reference is the same for every sample, only the reads are new.
         An extra of the line, not its value: the headline hands every batch over whole"""
+        if self.wires is None:
+            self.stage_all()
         for x in self.wires:
             x.keep_reference()
-        self.run(1)
+        self.run(1, staged=True)
         stats = []
         t0 = time.perf_counter()
-        self.run(passes, stats)
+        self.run(passes, stats, staged=True)
         dt = (time.perf_counter() - t0) / passes
         self.check_timed(stats)
         st = [x for x, _ in stats]
@@ -569,7 +589,7 @@ class C5Run:
         tot = lambda k: float(np.sum([s[k] for s in st])) / passes          # per pass
         n_obs = int(sum(w["n_obs"] for w in ws))
         n_pos = int(sum(w["n_pos"] for w in ws))
-        n_rec = int(sum((w["segs"].n_seg + 15) // 16 * 16 for w in ws))
+        n_rec = int(sum(w["n_seg"] for w in ws))
         rbytes = int(st[0]["record_bytes"]) if st else 64
         h2d = tot("h2d_bytes")
         # what a launch has to move: the stream as it lies in HBM (= what crossed PCIe: records, group bases, pair ids, packed
@@ -589,9 +609,10 @@ class C5Run:
                "snv_pairs_linked": int(sum(z["n_edges"] for _, z in one)), "ld_rows": int(sum(z["n_ld"] for _, z in one)),
                "snv_pairs_linked_per_s": float(sum(z["n_edges"] for _, z in one)) * world * passes / dt_max,
                "load_imbalance": float(max(meta.pairs[kept[s]].sum() for s in self.shards) / np.mean([meta.pairs[kept[s]].sum() for s in self.shards])),
-               "generate_s": self.gen_s, "stage_s": self.stage_s,
-               "hand_over": "isx_pipe_submit_wire: every batch staged once (isx_pipe_stage_reads: wire records in a pinned image), a step enqueues DMA + kernels"
-                            if self.wires is not None else "isx_pipe_submit_reads: host staging inside the step",
+               "generate_s": self.gen_s,
+               "hand_over": "isx_pipe_submit_planes: every batch handed over from the caller's (pageable) arrays inside the step -- reads as bit planes "
+                            "(64 B a read), the reference as its 2-bit plane; the pipe's threads copy the reference planes into pinned staging and make the "
+                            "32-byte wire records by XOR against them while the previous batches' DMA and kernels run",
                "record_bytes": int(st[0]["record_bytes"]) if st else None,
                "verified": "every batch checked in an untimed pass (coverage sum == observations handed over, SNV rows ordered and consistent with "
                            "the coverage, LD counts add up); every timed batch's row counts equal that pass's",
@@ -804,6 +825,8 @@ def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False, check=No
         v = variants[i % len(variants)]
         if wires is not None:
             tickets.append(pipe.submit_wire(wires[i % len(variants)]))
+        elif "planes" in v:
+            tickets.append(pipe.submit_planes(v["ref_planes"], v["split_bounds"], v["planes"]))
         elif pipe.read_level:
             tickets.append(pipe.submit_reads(v["ref_codes"], v["split_bounds"], v["segs"]))
         else:
@@ -987,8 +1010,8 @@ def main():
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
     head = c5.report(dt, bases_all, stats, args.steps, gather_ms)
-    if rank == 0 and world == 1 and not args.only_c5:
-        head["submit_reads_pass"] = c5.unstaged_pass()
+    if rank == 0 and world == 1 and (not args.only_c5 or os.environ.get("ISX_BENCH_STAGED")):
+        head["staged_replay"] = c5.staged_replay()
     if rank == 0 and world == 1 and (not args.only_c5 or os.environ.get("ISX_BENCH_RESIDENT_REF")):
         head["resident_reference"] = c5.resident_reference_passes()         # (last: the wires keep their device copies from here on)
     cb = cp = None
@@ -1019,7 +1042,7 @@ def main():
             "config": {"workload": _short("C5: 1000-genome database, 10 Gbp reads, --database_mode, pileup+SNV call+linkage; step = whole pass%s"
                                           % ("" if args.scale == 1.0 else " [DEBUG scale %g]" % args.scale)),
                        "genomes_kept": head["genomes_kept"], "positions": head["positions"], "read_gbp_per_step": bases_all / 1e9,
-                       "batches_per_step": n_batches if world == 1 else None, "hand_over": _short("%d-byte wire records staged once in pinned host memory; a step = DMA (hipMemcpyAsync) + kernels + tables back" % (head.get("record_bytes") or 0)),
+                       "batches_per_step": n_batches if world == 1 else None, "hand_over": _short("isx_pipe_submit_planes per batch INSIDE the step: caller's bit planes (pageable) -> XOR stager -> %d-byte wire records in pinned staging -> hipMemcpyAsync -> kernels -> tables back" % (head.get("record_bytes") or 0), 220),
                        "pipe_depth": args.depth, "pileup_cus": 256 - 8 * C5_RESERVE_CUS, "lean_slots": LEAN_SLOTS, "host_threads_per_rank": host_threads, "cgroup_cpus": cgroup_cpus(),
                        "numa_node": numa_node, "parallelism": "genome-sharded x%d%s" % (world, " (ranks share %d GPU)" % n_dev if shared else ""),
                        "verified": "per-batch checks in an untimed pass; timed row counts equal"},
@@ -1028,10 +1051,10 @@ def main():
             "h2d_bytes_per_base": head["roofline_pcie"]["bytes_per_profiled_base"], "pcie_frac": head["roofline_pcie"]["frac"],
             "snv_pairs_linked_per_s": head["snv_pairs_linked_per_s"],
             "stages_ms": {k: round(v, 2) for k, v in head["stages_ms_per_pass"].items()},
-            "stage_once_s": round(head["stage_s"], 3),
         }
-        if "submit_reads_pass" in head:
-            out["c5_with_host_staging_gbp_per_s"] = head["submit_reads_pass"]["gbp_per_s"]
+        if "staged_replay" in head:                 # round 4's headline (pre-staged pinned images replayed): an extra now
+            out["c5_staged_replay_gbp_per_s"] = head["staged_replay"]["gbp_per_s"]
+            out["c5_stage_once_s"] = round(head["staged_replay"]["stage_once_s"], 3)
         if "resident_reference" in head:
             out["c5_resident_reference_gbp_per_s"] = head["resident_reference"]["gbp_per_s"]
             out["c5_resident_reference_h2d_bytes_per_base"] = head["resident_reference"]["h2d_bytes_per_base"]

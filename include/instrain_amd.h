@@ -49,7 +49,10 @@ extern "C" {
 #define ISX_ERR_IO (-5)         /* BAM / file error */
 #define ISX_ERR_STATE (-6)      /* call out of order (e.g. fetch before run) */
 
-#define ISX_ABI_VERSION 3
+/* 4 (round 5): isx_pipe_result grew (coverage4 / cov_rows ...), isx_pipe_params.lean_output reads what was padding, one-mm-bin read
+ * batches travel as 32-byte reference-delta records, bit-plane hand-over (isx_read_planes).  A caller compiled against another version
+ * must not call in: compare isx_abi_version() with this constant first (instrain_amd/_lib.py does and refuses to load). */
+#define ISX_ABI_VERSION 4
 
 /* Base codes everywhere: 0=A 1=C 2=T 3=G (P2C order, profile_utilities.py:34), 4 = anything else. */
 
@@ -524,6 +527,56 @@ void isx_wire_free(isx_wire *wire);
  * device copy lives until isx_wire_free. */
 int isx_wire_keep_reference(isx_pipe *p, isx_wire *wire);
 
+/* ---- read-level hand-over as BIT PLANES (round 5): what a decoder holds anyway, and what the host stager wants ----
+ * The same read segments as isx_segs, one 64-byte line per segment instead of fifteen words of 3-bit codes:
+ *     words 0-4 (uint64)  the 2-bit base code (A C T G = 0 1 2 3, P2C order) of column j at bits 2 (j % 32) of word j / 32
+ *                         (a BAM's 4-bit seq nibbles map straight onto it); columns that are not observed may hold anything
+ *     words 5-7           bit j % 64 of word 5 + j / 64 set = column j is NOT observed: base quality below min_base_quality after
+ *                         htslib's overlap resolution, a base that is not A/C/T/G, padding (codes 4 / 5 of isx_segs.  With one mm
+ *                         bin a non-ACGT base has no effect on any table: profile_utilities.py:279-285 only makes its mm level
+ *                         "present", snv_utilities.py:85-104 then sees zero counts); bits from column len on are ignored
+ * and the reference as it travels to the device: a 2-bit plane, four positions a byte (position p at bits 2 (p % 4) of byte p / 4,
+ * anything that is not A/C/T/G as 0) + a bit plane marking the positions that are not A/C/T/G (NULL = there are none).
+ * Why: the stager of isx_pipe_submit_reads unpacks 150 codes to bytes and compares them with reference bytes; from planes the
+ * observed-and-different columns are one XOR of five words against the funnel-shifted reference plane (32 columns a step), the skip
+ * plane is copied into the record as it is, and the reference plane is copied, not packed.  One-mm-bin pipes only
+ * (--database_mode / --skip_mm_profiling; n_mm_bins > 1: ISX_ERR_STATE -- hand isx_segs over).  Replaces the same reference code as
+ * isx_segs: the visits of samfile.pileup(...) + get_base_counts_mm (profile_utilities.py:150-153, 268-286).  Tables are
+ * byte-identical to those of the isx_segs the planes stand for (tests/test_gpu_planes.py). */
+#define ISX_PLANE_WORDS 8
+typedef struct {
+    int64_t n_seg;
+    const uint32_t *gpos;       /* [n_seg] flat position of the segment's first column, BAM order */
+    const uint8_t *len;         /* [n_seg] 1 .. ISX_SEG_BASES columns; gpos + len <= n_pos */
+    const uint32_t *pair;       /* [n_seg] dense read-pair id; NULL unless linkage is enabled */
+    const uint64_t *planes;     /* [n_seg][ISX_PLANE_WORDS] */
+} isx_read_planes;
+
+typedef struct {
+    const uint8_t *plane2;      /* [(n_pos + 3) / 4] */
+    const uint8_t *nplane;      /* [(n_pos + 7) / 8] or NULL */
+} isx_ref_planes;
+
+/* host helpers (no GPU needed).  isx_pack_ref_planes: reference codes (0..3 = A C T G, anything else = not a base) -> the two planes
+ * (plane2 [(n_pos + 3) / 4], nplane [(n_pos + 7) / 8], both always written); *has_n = whether nplane marks any position.
+ * isx_planes_from_segs: isx_segs -> planes[n_seg][8] (gpos / len / pair are shared with the input as they are). */
+int isx_pack_ref_planes(const uint8_t *ref, int64_t n_pos, int32_t host_threads, uint8_t *plane2, uint8_t *nplane, int32_t *has_n);
+int isx_planes_from_segs(const isx_segs *segs, int32_t host_threads, uint64_t *planes);
+/* isx_pack_reads with planes as output (same arguments otherwise; seg_planes [cap_seg][8]) */
+int isx_pack_read_planes(int64_t n_reads, const int64_t *ref_start, const int64_t *clip_lo, const int64_t *clip_hi,
+                         const uint32_t *cigar, const int64_t *cigar_off, const char *seq, const uint8_t *qual, const int64_t *seq_off,
+                         const uint32_t *pair, int32_t min_base_quality, int64_t cap_seg, uint32_t *seg_gpos,
+                         uint8_t *seg_len, uint32_t *seg_pair, uint64_t *seg_planes, int64_t *n_seg);
+/* isx_pipe_submit_reads / isx_pipe_stage_reads from planes.  The stager's work per batch is the XOR pass + a copy of the reference
+ * planes into pinned staging; with isx_pipe_params.stage_async the pipe's own stager thread does it while the previous batch's DMA runs. */
+int isx_pipe_submit_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref, int32_t n_splits, const int64_t *split_bounds,
+                           const isx_read_planes *reads, int64_t *ticket);
+int isx_pipe_stage_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref, int32_t n_splits, const int64_t *split_bounds,
+                          const isx_read_planes *reads, isx_wire **out);
+/* the stager on its own (no GPU needed), like isx_encode_delta: planes + reference planes -> 32-byte reference-delta records */
+int isx_encode_planes(const isx_read_planes *reads, const isx_ref_planes *ref, int64_t n_pos, int32_t host_threads, int32_t slack_groups,
+                      int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, int64_t *n_rec, int64_t *need_slack);
+
 /* Host helper for a caller that decodes the BAM itself (e.g. a pysam loop over samfile.fetch()): reads -> segments.
  * Per read r: flat position of its reference start ref_start[r] (may be negative relative to the scaffold when the
  * caller lays scaffolds end to end: [clip_lo[r], clip_hi[r]) is the scaffold's range in flat space -- columns outside
@@ -701,6 +754,9 @@ int isx_bam_expand_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *re
 int isx_bam_segment_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *refs, int32_t n_refs, isx_bam_info *info, int64_t *n_seg);
 int isx_bam_copy_segs(const isx_bam *bam, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint32_t *bases,
                       int64_t *split_bounds, int32_t *split_ref);
+/* the segments of isx_bam_segment_refs as bit planes (isx_read_planes.planes: [n_seg][ISX_PLANE_WORDS]) -- what isx_pipe_submit_bam
+ * hands a one-mm-bin pipe's stager, straight from the records' 4-bit seq */
+int isx_bam_copy_read_planes(const isx_bam *bam, uint64_t *planes);
 /* the re-pileup of SNV pooling (polymorpher.py:287-293: samfile.pileup(scaffold, start, stop, truncate=True)): only the columns
  * [start, stop) of one reference, from the reads overlapping them (only the BGZF blocks that can hold such reads are touched);
  * gpos stays the position on the reference */

@@ -55,6 +55,20 @@ class Segs(C.Structure):
                 ("bases", C.c_void_p)]
 
 
+PLANE_WORDS = 8
+ABI_VERSION = 4             # ISX_ABI_VERSION of include/instrain_amd.h this binding was written against
+
+
+class ReadPlanes(C.Structure):
+    """isx_read_planes: the same segments as bit planes, one 64-byte line each"""
+    _fields_ = [("n_seg", C.c_int64), ("gpos", C.c_void_p), ("len", C.c_void_p), ("pair", C.c_void_p), ("planes", C.c_void_p)]
+
+
+class RefPlanes(C.Structure):
+    """isx_ref_planes: the reference as it travels (2-bit plane + bit plane of the positions that are not A/C/T/G, or NULL)"""
+    _fields_ = [("plane2", C.c_void_p), ("nplane", C.c_void_p)]
+
+
 RARE_DT = np.dtype([("gpos", "<u4"), ("clon_rarefied", "<f4")])
 CLON_DT = np.dtype([("gpos", "<u4"), ("clon", "<f4")])          # isx_pipe_result.clon_sparse (isx_rare's layout)
 SAT_DT = np.dtype([("gpos", "<u4"), ("coverage", "<u4")])
@@ -135,10 +149,11 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld", "isx_batch_fetch_allele_obs",
            "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
            "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_stage_reads", "isx_pipe_submit_wire", "isx_wire_bytes", "isx_wire_free", "isx_wire_keep_reference", "isx_pipe_submit_bam", "isx_encode_segs", "isx_encode_segs_ring", "isx_seg_records_needed", "isx_encode_delta", "isx_delta_records_needed", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_pipe_fetch_entries_shrunk", "isx_encode_obs", "isx_encode_obs_ring",
+           "isx_pack_ref_planes", "isx_planes_from_segs", "isx_pack_read_planes", "isx_pipe_submit_planes", "isx_pipe_stage_planes", "isx_encode_planes",
            "isx_bgzf_index", "isx_bgzf_inflate_device", "isx_bgzf_inflate_host", "isx_bgzf_inflate_fast",
            "isx_bam_open", "isx_bam_close", "isx_bam_close_wait", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
            "isx_bam_insert_sizes", "isx_bam_set_wanted_refs", "isx_bam_pair_keys", "isx_bam_set_cross_names", "isx_bam_filter_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_batch_pair_names", "isx_bam_set_mm_cap", "isx_bam_ref_counts",
-           "isx_bam_expand_refs", "isx_bam_segment_refs", "isx_bam_copy_segs", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
+           "isx_bam_expand_refs", "isx_bam_segment_refs", "isx_bam_copy_segs", "isx_bam_copy_read_planes", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
 
 _lib = None
 
@@ -155,6 +170,9 @@ def load():
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.isx_last_error.restype = C.c_char_p
     lib.isx_abi_version.restype = C.c_int
+    if lib.isx_abi_version() != ABI_VERSION:        # structs and record formats changed between versions: never call into another one
+        raise IsxError(-6, "%s has ABI version %d, this package binds version %d: rebuild it (python -c 'import __graft_entry__ as g; g.build()')"
+                       % (LIB_PATH, lib.isx_abi_version(), ABI_VERSION))
     lib.isx_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.isx_ctx_destroy.argtypes = [vp]
     lib.isx_ctx_reserve_cus.argtypes = [vp, C.c_int]
@@ -235,6 +253,13 @@ def load():
     lib.isx_bam_expand_refs.argtypes = [vp, C.POINTER(BamParams), vp, i32, C.POINTER(BamInfo)]
     lib.isx_bam_segment_refs.argtypes = [vp, C.POINTER(BamParams), vp, i32, C.POINTER(BamInfo), C.POINTER(i64)]
     lib.isx_bam_copy_segs.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.isx_bam_copy_read_planes.argtypes = [vp, vp]
+    lib.isx_pack_ref_planes.argtypes = [vp, i64, i32, vp, vp, C.POINTER(i32)]
+    lib.isx_planes_from_segs.argtypes = [C.POINTER(Segs), i32, vp]
+    lib.isx_pack_read_planes.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, C.POINTER(i64)]
+    lib.isx_pipe_submit_planes.argtypes = [vp, i64, C.POINTER(RefPlanes), i32, vp, C.POINTER(ReadPlanes), C.POINTER(i64)]
+    lib.isx_pipe_stage_planes.argtypes = [vp, i64, C.POINTER(RefPlanes), i32, vp, C.POINTER(ReadPlanes), C.POINTER(vp)]
+    lib.isx_encode_planes.argtypes = [C.POINTER(ReadPlanes), C.POINTER(RefPlanes), i64, i32, i32, i64, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]
     lib.isx_bam_ref.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64)]
     lib.isx_bam_copy.argtypes = [vp, vp, vp, vp, vp]
     lib.isx_bam_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

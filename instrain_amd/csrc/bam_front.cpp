@@ -127,6 +127,69 @@ inline void seg_pack_bmi2(uint8_t *cd /* [160], writable: padded with code 4 */,
     }
 }
 
+// ---- the same segment as BIT PLANES (include/instrain_amd.h isx_read_planes): words 0-4 the 2-bit codes, words 5-7 the columns
+// that are not observed (quality below minq, or a base that is not A/C/T/G) ----
+inline void seg_planes_scalar(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint64_t *P)
+{
+    uint64_t b[5] = {0, 0, 0, 0, 0}, sk[3] = {0, 0, 0};
+    for (int j = 0; j < n; j++) {
+        const int64_t i = q0 + j;
+        const uint32_t c = CODE2IDX[(seq[i >> 1] >> ((~i & 1) << 2)) & 15];
+        if (c > 3 || qual[i] < minq) sk[j >> 6] |= (uint64_t)1 << (j & 63);
+        else b[j >> 5] |= (uint64_t)c << (2 * (j & 31));
+    }
+    for (int k = 0; k < 5; k++) P[k] = b[k];
+    for (int k = 0; k < 3; k++) P[5 + k] = sk[k];
+}
+
+inline bool cpu_has_avx512bw()
+{
+    static const bool v = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && !getenv("ISX_NO_AVX512");
+    return v;
+}
+
+// 64 bases a step straight from the record's 4-bit seq and its qualities (masked loads: nothing beyond the read is touched):
+// nibbles into base order, a 16-entry look-up gives the 2-bit code or flags "not a base", the quality compare gives the observed
+// columns as a mask register; four codes are folded into a byte by two shift-or steps and a narrowing move.  The conversion starts
+// at the even base below q0; a leading odd base is shifted out at the end.
+__attribute__((target("avx512f,avx512bw,avx512vl,bmi2")))
+inline void seg_planes_avx512(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint64_t *P)
+{
+    const int64_t e0 = q0 & ~(int64_t)1;
+    const int lead = (int)(q0 - e0), m = n + lead;                                 // m <= 151 columns from the even base e0
+    const uint8_t *sq = seq + (e0 >> 1), *ql = qual + e0;
+    const __m512i lut = _mm512_broadcast_i32x4(_mm_setr_epi8((char)0x80, 0, 1, (char)0x80, 3, (char)0x80, (char)0x80, (char)0x80, 2, (char)0x80, (char)0x80,
+                                                            (char)0x80, (char)0x80, (char)0x80, (char)0x80, (char)0x80));
+    const __m512i mq = _mm512_set1_epi8((char)minq);
+    alignas(64) uint64_t b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t sk[3];
+    for (int k = 0; k < 3; k++) {
+        const int have = m - 64 * k;                                               // columns of this step
+        if (have <= 0) { sk[k] = 0; continue; }
+        const int nb = have >= 64 ? 64 : have;
+        const __mmask64 cm = nb == 64 ? ~(__mmask64)0 : (((__mmask64)1 << nb) - 1);
+        const __mmask32 bm = (__mmask32)((((uint64_t)1 << ((nb + 1) >> 1)) - 1));          // (nb 63 / 64: all 32 bytes)
+        const __m512i w = _mm512_cvtepu8_epi16(_mm256_maskz_loadu_epi8(bm, sq + 32 * k));
+        // word = byte: low byte <- high nibble (the even base), high byte <- low nibble
+        const __m512i nib = _mm512_or_si512(_mm512_srli_epi16(w, 4), _mm512_slli_epi16(_mm512_and_si512(w, _mm512_set1_epi16(0x0F)), 8));
+        const __m512i code = _mm512_shuffle_epi8(lut, nib);
+        const __m512i q = _mm512_maskz_loadu_epi8(cm, ql + 64 * k);
+        const __mmask64 ok = _mm512_mask_cmpge_epu8_mask(cm, q, mq) & ~_mm512_movepi8_mask(code);
+        sk[k] = (uint64_t)(cm & ~ok);
+        // four 2-bit codes a byte: c0 | c1 << 2 within 16 bits, then the two nibbles of a dword, then dword -> byte
+        const __m512i c2 = _mm512_and_si512(code, _mm512_set1_epi8(3));
+        const __m512i t = _mm512_and_si512(_mm512_or_si512(c2, _mm512_srli_epi16(c2, 6)), _mm512_set1_epi16(0x000F));
+        const __m512i u = _mm512_or_si512(t, _mm512_srli_epi32(t, 12));
+        _mm_store_si128(reinterpret_cast<__m128i *>(b + 2 * k), _mm512_cvtepi32_epi8(u));
+    }
+    if (lead) {                                                                     // drop the odd leading column
+        for (int k = 0; k < 5; k++) b[k] = (b[k] >> 2) | (b[k + 1] << 62);
+        sk[0] = (sk[0] >> 1) | (sk[1] << 63); sk[1] = (sk[1] >> 1) | (sk[2] << 63); sk[2] >>= 1;
+    }
+    for (int k = 0; k < 5; k++) P[k] = b[k];
+    P[5] = sk[0]; P[6] = sk[1]; P[7] = sk[2];
+}
+
 struct Read {           // a read of the batch being expanded
     int32_t tid, pos, isize, l_seq;
     uint16_t flag;
@@ -518,6 +581,7 @@ struct isx_bam {
     bool cross_set = false;
     std::vector<int64_t> cross_idx, cross_occ, cross_info;  // entry, occurrences file-wide, merged (nm, mapq, length, reads)
     std::vector<uint32_t> seg_gpos, seg_pair, seg_bases;    // isx_bam_segment_refs: the batch as read segments
+    std::vector<uint64_t> seg_planes;                       // ... and as bit planes
     std::vector<uint8_t> seg_len, seg_mm;
     size_t n_obs = 0;
     std::vector<int64_t> split_bounds;
@@ -1924,6 +1988,31 @@ struct BamBatch {
         }
     }
 
+    // the same segments as bit planes (isx_read_planes: one 64-byte line each); one mm bin only -- the pair's mm does not travel
+    void emit_planes(int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint32_t *pair, uint64_t *planes) const
+    {
+        size_t ri = (size_t)(std::upper_bound(seg_at.begin(), seg_at.end(), (uint64_t)first) - seg_at.begin()) - 1;
+        int64_t skip = first - (int64_t)seg_at[ri], done = 0;
+        const bool fast = cpu_has_avx512bw();
+        const uint8_t mq = minq;
+        for (; done < count; ri++) {
+            if (seg_at[ri + 1] == seg_at[ri]) continue;
+            const Read &r = S.reads[ri];
+            const uint32_t id = pid[ri];
+            for_segments(ri, [&](int64_t g, int64_t q0, int64_t cols) {
+                if (skip > 0) { skip--; return; }
+                if (done >= count) return;
+                uint64_t *P = planes + (size_t)done * ISX_PLANE_WORDS;
+                if (fast) seg_planes_avx512(r.seq, r.qual, q0, (int)cols, mq, P);
+                else seg_planes_scalar(r.seq, r.qual, q0, (int)cols, mq, P);
+                gpos[done] = (uint32_t)g; len[done] = (uint8_t)cols;
+                if (pair) pair[done] = id;
+                done++;
+            });
+            skip = 0;
+        }
+    }
+
     // observations [first, first + count) of the batch's stream (thread safe)
     void emit_range(int64_t first, uint32_t count, isx_obs *po, uint32_t *pp) const
     {
@@ -2327,6 +2416,10 @@ void bam_batch_emit_segs(const BamBatch *q, int64_t first, int64_t count, uint32
 {
     q->emit_segs(first, count, gpos, len, mm, pair, bases);
 }
+void bam_batch_emit_planes(const BamBatch *q, int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint32_t *pair, uint64_t *planes)
+{
+    q->emit_planes(first, count, gpos, len, pair, planes);
+}
 int64_t bam_batch_n_obs(const BamBatch *q) { return q->n_obs(); }
 int64_t bam_batch_n_pos(const BamBatch *q) { return q->n_pos; }
 void bam_batch_emit(const BamBatch *q, int64_t first, uint32_t count, isx_obs *obs, uint32_t *pair) { q->emit_range(first, count, obs, pair); }
@@ -2390,14 +2483,21 @@ int isx_bam_segment_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *r
     const size_t n = Q->seg_gpos.size();
     B.seg_gpos.assign(Q->seg_gpos.begin(), Q->seg_gpos.end());
     B.seg_len.resize(n); B.seg_mm.resize(n); B.seg_pair.resize(n); B.seg_bases.resize(n * ISX_SEG_WORDS);
+    B.seg_planes.resize(n * ISX_PLANE_WORDS);               // the same segments as bit planes (isx_bam_copy_read_planes)
     isxenc::HostPool &pool = pool_of(B);
     const size_t piece = 4096;
-    std::vector<uint32_t> tmp_gpos(n);
+    std::vector<uint32_t> tmp_gpos(n), g2(n), p2(n);
+    std::vector<uint8_t> l2(n);
     pool.run((int)((n + piece - 1) / piece), [&](int t) {
         const size_t a = (size_t)t * piece, e = std::min(n, a + piece);
         q->emit_segs((int64_t)a, (int64_t)(e - a), tmp_gpos.data() + a, B.seg_len.data() + a, B.seg_mm.data() + a, B.seg_pair.data() + a,
                      B.seg_bases.data() + a * ISX_SEG_WORDS);
+        q->emit_planes((int64_t)a, (int64_t)(e - a), g2.data() + a, l2.data() + a, p2.data() + a, B.seg_planes.data() + a * ISX_PLANE_WORDS);
     });
+    if (g2 != tmp_gpos || memcmp(l2.data(), B.seg_len.data(), n) != 0 || memcmp(p2.data(), B.seg_pair.data(), n * 4) != 0) {
+        isx_set_error("internal: the segment and the bit-plane emission differ");
+        return ISX_ERR_STATE;
+    }
     if (tmp_gpos != B.seg_gpos) { isx_set_error("internal: segment starts of the layout pass and of the emission differ"); return ISX_ERR_STATE; }
     B.split_bounds = Q->split_bounds;
     B.split_ref = Q->split_ref;
@@ -2419,6 +2519,13 @@ int isx_bam_copy_segs(const isx_bam *bam, uint32_t *gpos, uint8_t *len, uint8_t 
     if (bases && n) memcpy(bases, bam->seg_bases.data(), n * ISX_SEG_WORDS * 4);
     if (split_bounds) memcpy(split_bounds, bam->split_bounds.data(), bam->split_bounds.size() * sizeof(int64_t));
     if (split_ref && !bam->split_ref.empty()) memcpy(split_ref, bam->split_ref.data(), bam->split_ref.size() * sizeof(int32_t));
+    return ISX_OK;
+}
+
+int isx_bam_copy_read_planes(const isx_bam *bam, uint64_t *planes)
+{
+    if (!bam || !planes) { isx_set_error("isx_bam_copy_read_planes: bad argument"); return ISX_ERR_ARG; }
+    if (!bam->seg_planes.empty()) memcpy(planes, bam->seg_planes.data(), bam->seg_planes.size() * sizeof(uint64_t));
     return ISX_OK;
 }
 

@@ -118,33 +118,26 @@ static inline size_t ref2_bytes(int64_t n_pos) { return (((size_t)n_pos + 3) / 4
 static inline size_t refn_bytes(int64_t n_pos) { return (((size_t)n_pos + 7) / 8 + 15) & ~(size_t)15; }
 static bool pack_ref2(isxenc::HostPool &pool, const uint8_t *ref, int64_t n_pos, uint8_t *plane2, uint8_t *nplane)
 {
-    const int64_t piece = (int64_t)256 << 10;               // a multiple of 8
-    const int n_tasks = (int)((n_pos + piece - 1) / piece);
+    return isxenc::pack_ref_planes(pool, ref, n_pos, plane2, nplane);
+}
+
+// the caller's own planes into staging (isx_ref_planes): a copy on the pool's threads; returns whether the N plane marks a position
+static bool copy_ref_planes(isxenc::HostPool &pool, const isx_ref_planes *rp, int64_t n_pos, uint8_t *plane2, uint8_t *nplane)
+{
+    const size_t b2 = ((size_t)n_pos + 3) / 4, bn = ((size_t)n_pos + 7) / 8;
+    const size_t piece = (size_t)1 << 20;
+    const int t2 = (int)((b2 + piece - 1) / piece), tn = rp->nplane ? (int)((bn + piece - 1) / piece) : 0;
     std::atomic<int> any{0};
-    auto cp = [&](int t) {
-        const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
-        uint8_t *o2 = plane2 + (a >> 2), *on = nplane + (a >> 3);
-        const uint8_t *r = ref + a;
-        const int64_t n = e - a;
-        bool seen = false;
-        for (int64_t i = 0; i < n; i += 8) {
-            uint32_t lo = 0, hi = 0, nb = 0;
-            const int64_t m = std::min<int64_t>(8, n - i);
-            for (int64_t k = 0; k < m; k++) {
-                const uint32_t c = r[i + k];
-                const uint32_t bad = c > 3u;
-                nb |= bad << k;
-                const uint32_t v = bad ? 0u : c;
-                if (k < 4) lo |= v << (2 * k); else hi |= v << (2 * (k - 4));
-            }
-            o2[i >> 2] = (uint8_t)lo;
-            if (m > 4) o2[(i >> 2) + 1] = (uint8_t)hi;
-            on[i >> 3] = (uint8_t)nb;
-            seen |= nb != 0;
-        }
-        if (seen) any.store(1, std::memory_order_relaxed);
-    };
-    if (n_tasks > 1) pool.run(n_tasks, cp); else if (n_tasks == 1) cp(0);
+    pool.run(t2 + tn, [&](int t) {
+        if (t < t2) { const size_t a = (size_t)t * piece; memcpy(plane2 + a, rp->plane2 + a, std::min(piece, b2 - a)); return; }
+        const size_t a = (size_t)(t - t2) * piece, n = std::min(piece, bn - a);
+        const uint8_t *src = rp->nplane + a;
+        uint8_t acc = 0;
+        for (size_t i = 0; i < n; i++) acc |= src[i];
+        memcpy(nplane + a, src, n);
+        if (acc) any.store(1, std::memory_order_relaxed);
+    });
+    // (bits of the last bytes beyond n_pos are the caller's padding: the kernels never look at positions >= n_pos)
     return any.load() != 0;
 }
 
@@ -221,6 +214,9 @@ struct isx_pipe {
         const uint8_t *ref;
         std::vector<int64_t> bounds;
         isx_segs segs;
+        bool planes = false;            // isx_pipe_submit_planes: reads / rp instead of segs / ref
+        isx_read_planes reads{};
+        isx_ref_planes rp{};
     };
     std::thread stager;
     std::deque<StageJob> stage_q;
@@ -638,7 +634,7 @@ static void finisher_main(isx_pipe *p, hipStream_t sfin)
 }
 
 static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
-                              isxenc::SegJob &J, int64_t *ticket);
+                              isxenc::SegJob &J, int64_t *ticket, const isx_ref_planes *rp = nullptr);
 
 static void stager_main(isx_pipe *p)
 {
@@ -652,9 +648,10 @@ static void stager_main(isx_pipe *p)
             p->stage_q.pop_front();
         }
         isxenc::SegJob J;
-        J.in = job.segs; J.n_seg = job.segs.n_seg;
+        if (job.planes) { J.in2 = job.reads; J.n_seg = job.reads.n_seg; }
+        else { J.in = job.segs; J.n_seg = job.segs.n_seg; }
         int64_t got = -1;
-        const int rc = submit_segs_common(p, job.n_pos, job.ref, (int32_t)job.bounds.size() - 1, job.bounds.data(), J, &got);
+        const int rc = submit_segs_common(p, job.n_pos, job.ref, (int32_t)job.bounds.size() - 1, job.bounds.data(), J, &got, job.planes ? &job.rp : nullptr);
         if (rc != ISX_OK) {                              // the batch's ticket carries the error to isx_pipe_collect
             Slot &s = p->slots[(size_t)(job.ticket % (int64_t)p->slots.size())];
             std::string err(isx_last_error());
@@ -1044,9 +1041,11 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
 }
 
 // a read-level batch: `J` arrives with its input side set (isx_segs arrays, or a producer + the segment starts)
+// (bit-plane input -- J.in2 / J.produce_planes -- goes through encode_planes; its reference arrives as planes (`rp`) or as codes)
 static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
-                              isxenc::SegJob &J, int64_t *ticket)
+                              isxenc::SegJob &J, int64_t *ticket, const isx_ref_planes *rp)
 {
+    const bool planes_in = J.in2.planes != nullptr || (bool)J.produce_planes || (J.n_seg == 0 && rp != nullptr);
     if (n_pos > p->pp.max_pos || J.n_seg > p->pp.max_segs || n_splits > p->pp.max_splits) {
         isx_set_error("isx_pipe_submit_reads: batch larger than the pipe was created for");
         return ISX_ERR_CAPACITY;
@@ -1096,6 +1095,16 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         };
     }
     int erc;
+    double t_ref0 = 0.0;
+    if (planes_in) {
+        // the reference planes first, into staging: the record pass compares against that copy
+        if (!p->drec) { isx_set_error("bit-plane reads need a one-mm-bin pipe (reference-delta records)"); return ISX_ERR_STATE; }
+        const double t_r = now_ms();
+        uint8_t *h2 = s.h_in + s.off_ref, *hn = h2 + ref2_bytes(n_pos);
+        s.ref_has_n = rp ? copy_ref_planes(*p->pool, rp, n_pos, h2, hn) : pack_ref2(*p->pool, ref, n_pos, h2, hn);
+        J.ref2 = h2; J.refn = s.ref_has_n ? hn : nullptr;
+        t_ref0 = now_ms() - t_r;
+    }
     if (p->drec) {
         // reference-delta records: the segments are compared with the reference here; pieces of segments with more than six
         // differences take spare groups of their task's region -- a batch that needs more than the pipe has learned so far is
@@ -1107,7 +1116,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
             J.slack_groups = p->dslack;
             J.task_groups = exact.empty() ? nullptr : exact.data();
             ring_bytes = 0;
-            erc = isxenc::encode_delta(*p->pool, J);
+            erc = planes_in ? isxenc::encode_planes(*p->pool, J) : isxenc::encode_delta(*p->pool, J);
             if (erc == isxenc::SEG_CAPACITY && J.need_slack > p->dslack && attempt == 0) {
                 // the second attempt gives every task exactly what the first one found it needs; the pipe remembers the AVERAGE
                 // surplus (data that differs from the reference everywhere then fits at once; one task over a stretch where the
@@ -1130,7 +1139,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (erc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
     if (erc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
     if (J.n_bases > p->pp.max_obs) { isx_set_error("isx_pipe_submit_reads: more bases than the pipe's max_obs"); return ISX_ERR_CAPACITY; }
-    s.ref_has_n = pack_ref2(*p->pool, ref, n_pos, s.h_in + s.off_ref, s.h_in + s.off_ref + ref2_bytes(n_pos));
+    if (!planes_in) s.ref_has_n = pack_ref2(*p->pool, ref, n_pos, s.h_in + s.off_ref, s.h_in + s.off_ref + ref2_bytes(n_pos));
     const double t_ref = now_ms();
     memcpy(s.h_in + s.off_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t));
 
@@ -1176,8 +1185,8 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     s.encode_ms = (float)(now_ms() - t0);
     if (!p->drec) s.encode_passes = 1;
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
-        fprintf(stderr, "[isx_pipe_submit_reads] records %.2f ms, reference %.2f ms, bounds + windows %.2f ms; %lld segments, %lld records\n",
-                t_enc - t0, t_ref - t_enc, now_ms() - t_ref, (long long)J.n_seg, (long long)J.n_rec);
+        fprintf(stderr, "[isx_pipe_submit_reads] records %.2f ms, reference %.2f ms, bounds + windows %.2f ms; %lld segments, %lld records%s\n",
+                t_enc - t0 - t_ref0, t_ref - t_enc + t_ref0, now_ms() - t_ref, (long long)J.n_seg, (long long)J.n_rec, planes_in ? " (bit planes)" : "");
     const double t_q0 = now_ms();
 
     // ---- copy-in queue: bounds | windows | reference codes, then group bases (| pair ids) | records ----
@@ -1222,14 +1231,12 @@ struct isx_wire {
     int device = 0;
 };
 
-int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
-                         const isx_segs *segs, isx_wire **out)
+// isx_pipe_stage_reads / isx_pipe_stage_planes: `segs` + `ref`, or `reads` + `rp`
+static int stage_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, const isx_ref_planes *rp, int32_t n_splits, const int64_t *split_bounds,
+                        const isx_segs *segs, const isx_read_planes *reads, isx_wire **out)
 {
-    if (!p || !ref || !split_bounds || !out || n_pos <= 0 || n_splits <= 0 || !segs || segs->n_seg < 0 ||
-        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases))) {
-        isx_set_error("isx_pipe_stage_reads: bad argument");
-        return ISX_ERR_ARG;
-    }
+    isx_segs as_segs{};
+    if (reads) { as_segs.n_seg = reads->n_seg; as_segs.gpos = reads->gpos; as_segs.len = reads->len; as_segs.pair = reads->pair; segs = &as_segs; }
     *out = nullptr;
     if (!p->segs) { isx_set_error("isx_pipe_stage_reads: not a read-level pipe (isx_pipe_params.max_segs == 0)"); return ISX_ERR_STATE; }
     const bool linkage = p->prm.enable_linkage != 0;
@@ -1275,18 +1282,24 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         w->bytes = o;
         cmin.assign(n_groups + 2, 0xFFFFFFFFu); cmax.assign(n_groups + 2, 0u); cany.assign(n_groups + 2, 0);
         J = isxenc::SegJob();
-        J.in = *segs; J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = M;
-        if (!linkage) J.in.pair = nullptr;
+        J.n_seg = segs->n_seg; J.n_pos = n_pos; J.n_mm_bins = M;
+        if (reads) { J.in2 = *reads; if (!linkage) J.in2.pair = nullptr; }
+        else { J.in = *segs; if (!linkage) J.in.pair = nullptr; }
         J.rec = reinterpret_cast<uint32_t *>(w->h + w->o_rec);
         J.gbase = reinterpret_cast<uint32_t *>(w->h + w->o_gbase);
         J.pair_out = linkage && !p->drec ? reinterpret_cast<uint32_t *>(w->h + w->o_pairs) : nullptr;
         J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data();
         J.cap_rec = cap;
         int erc;
+        if (reads) {                     // the reference planes first (the record pass compares against the image's copy)
+            uint8_t *h2 = w->h + w->o_ref, *hn = h2 + ref2_bytes(n_pos);
+            w->ref_has_n = rp ? copy_ref_planes(*p->pool, rp, n_pos, h2, hn) : pack_ref2(*p->pool, ref, n_pos, h2, hn);
+            J.ref2 = h2; J.refn = w->ref_has_n ? hn : nullptr;
+        }
         if (p->drec) {
             J.ref = ref; J.slack_groups = p->dslack;
             J.task_groups = exact.empty() ? nullptr : exact.data();
-            erc = isxenc::encode_delta(*p->pool, J);
+            erc = reads ? isxenc::encode_planes(*p->pool, J) : isxenc::encode_delta(*p->pool, J);
             if (erc == isxenc::SEG_CAPACITY && J.need_slack > p->dslack && attempt == 0) { exact = J.task_need; w->encode_passes = 2; continue; }
         } else erc = isxenc::encode_segs(*p->pool, J);
         if (erc == isxenc::SEG_CAPACITY) { isx_set_error("isx_pipe_stage_reads: the stream does not fit the record capacity"); return ISX_ERR_CAPACITY; }
@@ -1300,7 +1313,7 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     w->gbase_bytes = (size_t)(J.n_rec / (int64_t)G) * sizeof(uint32_t);
     w->rec_bytes = (size_t)J.n_rec * rb;
     w->pairs_bytes = linkage && !p->drec ? (size_t)J.n_rec * sizeof(uint32_t) : 0;
-    w->ref_has_n = pack_ref2(*p->pool, ref, n_pos, w->h + w->o_ref, w->h + w->o_ref + ref2_bytes(n_pos));
+    if (!reads) w->ref_has_n = pack_ref2(*p->pool, ref, n_pos, w->h + w->o_ref, w->h + w->o_ref + ref2_bytes(n_pos));
     if (!w->ref_has_n) w->ref_bytes = ref2_bytes(n_pos);
     memcpy(w->h + w->o_bounds, split_bounds, w->bounds_bytes);
     {   // the window directory, for the window this pipe's kernels will use on a batch of n_pos positions
@@ -1322,6 +1335,29 @@ int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     w->stage_ms = (float)(now_ms() - t0);
     *out = w.release();
     return ISX_OK;
+}
+
+int isx_pipe_stage_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
+                         const isx_segs *segs, isx_wire **out)
+{
+    if (!p || !ref || !split_bounds || !out || n_pos <= 0 || n_splits <= 0 || !segs || segs->n_seg < 0 ||
+        (segs->n_seg && (!segs->gpos || !segs->len || !segs->bases))) {
+        isx_set_error("isx_pipe_stage_reads: bad argument");
+        return ISX_ERR_ARG;
+    }
+    return stage_common(p, n_pos, ref, nullptr, n_splits, split_bounds, segs, nullptr, out);
+}
+
+int isx_pipe_stage_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref, int32_t n_splits, const int64_t *split_bounds,
+                          const isx_read_planes *reads, isx_wire **out)
+{
+    if (!p || !ref || !ref->plane2 || !split_bounds || !out || n_pos <= 0 || n_splits <= 0 || !reads || reads->n_seg < 0 ||
+        (reads->n_seg && (!reads->gpos || !reads->len || !reads->planes))) {
+        isx_set_error("isx_pipe_stage_planes: bad argument");
+        return ISX_ERR_ARG;
+    }
+    if (!p->drec) { isx_set_error("isx_pipe_stage_planes: bit-plane reads need a one-mm-bin read-level pipe"); return ISX_ERR_STATE; }
+    return stage_common(p, n_pos, nullptr, ref, n_splits, split_bounds, nullptr, reads, out);
 }
 
 void isx_wire_free(isx_wire *w)
@@ -1449,6 +1485,44 @@ int isx_pipe_submit_reads(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_
     return submit_segs_common(p, n_pos, ref, n_splits, split_bounds, J, ticket);
 }
 
+int isx_pipe_submit_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref, int32_t n_splits, const int64_t *split_bounds,
+                           const isx_read_planes *reads, int64_t *ticket)
+{
+    if (!p || !ref || !ref->plane2 || !split_bounds || !ticket || n_pos <= 0 || n_splits <= 0 || !reads || reads->n_seg < 0 ||
+        (reads->n_seg && (!reads->gpos || !reads->len || !reads->planes))) {
+        isx_set_error("isx_pipe_submit_planes: bad argument");
+        return ISX_ERR_ARG;
+    }
+    if (!p->segs || !p->drec) { isx_set_error("isx_pipe_submit_planes: bit-plane reads need a one-mm-bin read-level pipe (max_segs > 0, n_mm_bins == 1)"); return ISX_ERR_STATE; }
+    if (p->prm.enable_linkage && reads->n_seg && !reads->pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
+    if (p->stager.joinable()) {         // queued for the stager (see isx_pipe_submit_reads): the caller's arrays stay valid and unchanged until collect / release
+        if (n_pos > p->pp.max_pos || reads->n_seg > p->pp.max_segs || n_splits > p->pp.max_splits) {
+            isx_set_error("isx_pipe_submit_planes: batch larger than the pipe was created for");
+            return ISX_ERR_CAPACITY;
+        }
+        isx_pipe::StageJob job;
+        job.n_pos = n_pos; job.ref = nullptr; job.planes = true; job.reads = *reads; job.rp = *ref;
+        if (!p->prm.enable_linkage) job.reads.pair = nullptr;
+        job.bounds.assign(split_bounds, split_bounds + n_splits + 1);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            const int64_t t = p->next_promise, n = (int64_t)p->slots.size();
+            const Slot &s = p->slots[(size_t)(t % n)];
+            if (t - n >= p->next_ticket || s.state != 0) { isx_set_error("isx_pipe_submit_planes: every slot is in use (collect + release the oldest batch first)"); return ISX_ERR_STATE; }
+            job.ticket = t;
+            p->next_promise = t + 1;
+            *ticket = t;
+            p->stage_q.push_back(std::move(job));
+        }
+        p->cv_stage.notify_one();
+        return ISX_OK;
+    }
+    isxenc::SegJob J;
+    J.in2 = *reads; J.n_seg = reads->n_seg;
+    if (!p->prm.enable_linkage) J.in2.pair = nullptr;
+    return submit_segs_common(p, n_pos, nullptr, n_splits, split_bounds, J, ticket, ref);
+}
+
 int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,
                     int64_t n_obs, const isx_obs *obs, const uint32_t *pair, int64_t *ticket)
 {
@@ -1492,7 +1566,9 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
         J.n_seg = bam_batch_n_segs(q);
         J.gpos_all = bam_batch_seg_gpos(q);
         J.want_pairs = p->prm.enable_linkage != 0;
-        J.produce = [q](int64_t first, int64_t count, uint32_t *g, uint8_t *l, uint8_t *m, uint32_t *pr, uint32_t *b) { bam_batch_emit_segs(q, first, count, g, l, m, pr, b); };
+        // (one mm bin: as bit planes -- the 4-bit seq maps straight onto the 2-bit plane and the stager XORs instead of unpacking)
+        if (p->drec && !getenv("ISX_BAM_SEG_WORDS")) J.produce_planes = [q](int64_t first, int64_t count, uint32_t *g, uint8_t *l, uint32_t *pr, uint64_t *pl) { bam_batch_emit_planes(q, first, count, g, l, pr, pl); };
+        else J.produce = [q](int64_t first, int64_t count, uint32_t *g, uint8_t *l, uint8_t *m, uint32_t *pr, uint32_t *b) { bam_batch_emit_segs(q, first, count, g, l, m, pr, b); };
         rc = submit_segs_common(p, n_pos, ref, n_splits, split_bounds, J, ticket);
     } else {
         isxenc::EncodeJob J;

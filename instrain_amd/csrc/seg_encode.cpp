@@ -517,6 +517,341 @@ int encode_delta(HostPool &pool, SegJob &J)
     return SEG_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// bit-plane input (include/instrain_amd.h isx_read_planes) -> the same reference-delta records.  Nothing is unpacked: the five
+// words of 2-bit codes are XORed with the reference plane funnel-shifted to the segment's start (32 columns a step), the two
+// bits of a column are folded and gathered with pext into the 160-bit "differs" mask, the skip plane is the input's own.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct LenMasks {                       // bits [0, L) of a 256-bit field (rows are loaded as one vector)
+    alignas(32) uint64_t m[ISX_SEG_BASES + 1][4];
+    LenMasks()
+    {
+        for (uint32_t L = 0; L <= ISX_SEG_BASES; L++)
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t from = 64 * k;
+                m[L][k] = L <= from ? 0 : (L - from >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << (L - from)) - 1));
+            }
+    }
+};
+
+inline bool cpu_has_bmi2()
+{
+    static const bool v = __builtin_cpu_supports("bmi2") && !getenv("ISX_NO_BMI2");     // (the switch: tests of the portable path)
+    return v;
+}
+
+inline uint64_t even_bits_portable(uint64_t x)       // bits 0, 2, 4 ... 62 -> bits 0 .. 31
+{
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return x;
+}
+
+// bits [p, p + 160) of a bit plane; `q` = plane + p / 8 with at least 32 readable bytes
+inline void bits160(const uint8_t *q, uint32_t sh, uint64_t d[3])
+{
+    uint64_t w[4];
+    memcpy(w, q, 32);
+    for (int i = 0; i < 3; i++) d[i] = (w[i] >> sh) | ((w[i + 1] << 1) << (63 - sh));
+}
+
+struct PlaneTask {                       // one task of encode_planes: segments [a, e) into device groups [ga, ge)
+    int64_t a, e;
+    const uint32_t *gp, *pr, *gpos_all;
+    const uint8_t *ln;
+    const uint64_t *pl;
+    uint32_t *rec0;                     // where device group g0 lies
+    int64_t g0, ga, ge;
+    bool fast_store;
+    int64_t used = 0, np = 0, nb = 0;   // results: groups needed (may exceed the region: counted, not written), pieces, columns
+    uint32_t maxp = 0;
+};
+
+inline void put_empty_drec(uint32_t *o)
+{
+    o[0] = o[1] = o[2] = o[4] = o[5] = o[6] = o[7] = 0;
+    o[3] = ISX_DREC_NO_EXC;
+}
+
+#ifndef ISX_PLANES_PREFETCH
+#define ISX_PLANES_PREFETCH 16
+#endif
+constexpr int64_t PLANES_PREFETCH = ISX_PLANES_PREFETCH;     // segments ahead of the one being encoded
+struct PlaneGroup {                     // the group being filled (layout rules: encode_delta's add_piece / close_group)
+    alignas(64) uint32_t rec[ISX_DREC_GROUP][ISX_DREC_WORDS];
+    int n = 0, open = -1;               // records / the dual record whose second half is still free (-1: none)
+    uint32_t lo = 0, hi = 0, last = 0;  // lowest / highest start, highest last position
+    int64_t g = 0, used = 0;            // next device group to write / groups the task needs (may exceed its region: counted, not written)
+};
+// a start below the group's base (input that is not sorted by start): the deltas written so far move up
+__attribute__((noinline)) void rebase_drecs(PlaneGroup &G, uint32_t new_lo)
+{
+    const uint32_t up = G.lo - new_lo;
+    for (int r = 0; r < G.n; r++) {
+        uint32_t *o = G.rec[r];
+        if ((o[0] >> 16) & 0xFFu) o[0] += up;
+        if ((o[0] & ISX_DREC_DUAL) && ((o[4] >> 16) & 0xFFu)) o[4] += up;
+    }
+    G.lo = new_lo;
+}
+
+struct PlaneScratch {
+    std::vector<uint32_t> gpos, pair;
+    std::vector<uint8_t> len;
+    std::vector<uint64_t> planes;       // (64-byte aligned inside)
+    uint64_t *pl = nullptr;
+};
+
+// the per-segment pass, compiled three times: portable (shift-and-mask), BMI2 (pext gathers the "differs" bits), AVX-512 VBMI2 + GFNI
+// (one funnel shift for the five words, one GF(2) affine transform instead of the gathers)
+#define ISX_PLANES_FN planes_task_portable
+#define ISX_CLOSE_FN close_group_portable
+#define ISX_DIFFERS_FN differs160_portable
+#define ISX_PLANES_VARIANT 0
+#include "seg_planes.inc"
+#undef ISX_PLANES_FN
+#undef ISX_CLOSE_FN
+#undef ISX_DIFFERS_FN
+#undef ISX_PLANES_VARIANT
+#pragma GCC push_options
+#pragma GCC target("bmi,bmi2,popcnt,lzcnt")
+#define ISX_PLANES_FN planes_task_bmi2
+#define ISX_CLOSE_FN close_group_bmi2
+#define ISX_DIFFERS_FN differs160_bmi2
+#define ISX_PLANES_VARIANT 1
+#include "seg_planes.inc"
+#undef ISX_PLANES_FN
+#undef ISX_CLOSE_FN
+#undef ISX_DIFFERS_FN
+#undef ISX_PLANES_VARIANT
+#pragma GCC pop_options
+#pragma GCC push_options
+#pragma GCC target("bmi,bmi2,popcnt,lzcnt,avx512f,avx512bw,avx512vl,avx512vbmi2,gfni")
+#define ISX_PLANES_FN planes_task_avx512
+#define ISX_CLOSE_FN close_group_avx512
+#define ISX_DIFFERS_FN differs160_avx512
+#define ISX_PLANES_VARIANT 2
+#include "seg_planes.inc"
+#undef ISX_PLANES_FN
+#undef ISX_CLOSE_FN
+#undef ISX_DIFFERS_FN
+#undef ISX_PLANES_VARIANT
+#pragma GCC pop_options
+
+inline int planes_variant()
+{
+    static const int v = [] {
+        if (const char *e = getenv("ISX_PLANES_VARIANT")) return std::max(0, std::min(2, atoi(e)));     // (the switch: tests of every path)
+        if (!cpu_has_bmi2()) return 0;
+        return cpu_has_avx512() && __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("gfni") ? 2 : 1;
+    }();
+    if (v == 2 && !(cpu_has_avx512() && __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("gfni") && __builtin_cpu_supports("bmi2"))) return __builtin_cpu_supports("bmi2") ? 1 : 0;
+    if (v == 1 && !__builtin_cpu_supports("bmi2")) return 0;
+    return v;
+}
+
+}  // namespace
+
+int encode_planes(HostPool &pool, SegJob &J)
+{
+    const int64_t n = J.n_seg;
+    const bool producer = (bool)J.produce_planes;
+    const uint32_t *gpos_all = producer ? J.gpos_all : J.in2.gpos;
+    const int n_tasks = (int)((n + TASK - 1) / TASK);
+    const int64_t slack = std::max<int64_t>(J.slack_groups, 1);
+    std::vector<int64_t> g_at((size_t)n_tasks + 1, 0);
+    if (J.task_groups) for (int t = 0; t < n_tasks; t++) g_at[(size_t)t + 1] = std::max<int64_t>(J.task_groups[t], 1);
+    else pool.run(n_tasks, [&](int t) {
+        const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
+        g_at[(size_t)t + 1] = count_groups(gpos_all, a, e, 2 * ISX_DREC_GROUP) + slack;
+    });
+    for (int t = 0; t < n_tasks; t++) g_at[(size_t)t + 1] += g_at[(size_t)t];
+    const int64_t n_groups = std::max<int64_t>(g_at[(size_t)n_tasks], 1);
+    J.n_rec = n_groups * ISX_DREC_GROUP;
+    J.need_slack = slack;
+    if (J.n_rec > J.cap_rec) return SEG_CAPACITY;
+    std::atomic<int> err{SEG_OK};
+    std::vector<int64_t> bases_of((size_t)std::max(n_tasks, 1), 0), need_of((size_t)std::max(n_tasks, 1), 0), pieces_of((size_t)std::max(n_tasks, 1), 0);
+    std::vector<uint32_t> maxp_of((size_t)std::max(n_tasks, 1), 0);
+    const bool pairs = producer ? J.want_pairs : J.in2.pair != nullptr;
+    const int64_t RG = J.ring_groups;
+    constexpr size_t group_words = (size_t)ISX_DREC_GROUP * ISX_DREC_WORDS;
+    const bool fast_store = cpu_has_avx512() && (reinterpret_cast<uintptr_t>(J.rec) & 63) == 0;
+    const int variant = planes_variant();
+    if (n == 0) {                                   // one empty group: the kernels want a stream
+        if (RG) J.wave_begin(0);
+        for (int r = 0; r < ISX_DREC_GROUP; r++) put_empty_drec(J.rec + (size_t)r * ISX_DREC_WORDS);
+        J.gbase[0] = 0; J.cmin[0] = 0xFFFFFFFFu; J.cmax[0] = 0; J.cany[0] = 0;
+        J.n_bases = 0; J.max_pair = 0; J.n_pieces = 0;
+        if (RG) J.wave_flush(0, 0, 1);
+        return SEG_OK;
+    }
+    auto run_task = [&](int t, int64_t wave_g0, int half) {
+        if (err.load(std::memory_order_relaxed) != SEG_OK) return;
+        const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
+        const uint32_t *gp, *pr;
+        const uint8_t *ln;
+        const uint64_t *pl;
+        if (producer) {
+            thread_local PlaneScratch S;
+            if (S.gpos.size() < (size_t)TASK) {
+                S.gpos.resize((size_t)TASK); S.pair.resize((size_t)TASK); S.len.resize((size_t)TASK);
+                S.planes.resize((size_t)TASK * ISX_PLANE_WORDS + 8);
+                S.pl = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(S.planes.data()) + 63) & ~(uintptr_t)63);
+            }
+            J.produce_planes(a, e - a, S.gpos.data(), S.len.data(), pairs ? S.pair.data() : nullptr, S.pl);
+            gp = S.gpos.data() - a; ln = S.len.data() - a; pr = pairs ? S.pair.data() - a : nullptr;
+            pl = S.pl - (size_t)a * ISX_PLANE_WORDS;
+        } else {
+            gp = J.in2.gpos; ln = J.in2.len; pr = pairs ? J.in2.pair : nullptr; pl = J.in2.planes;
+        }
+        // (ring mode: device group gi of this wave lies at slot gi - wave_g0 of the wave's half)
+        PlaneTask K;
+        K.a = a; K.e = e; K.gp = gp; K.ln = ln; K.pr = pr; K.pl = pl; K.gpos_all = gpos_all;
+        K.rec0 = RG ? J.rec + (size_t)((int64_t)half * RG) * group_words : J.rec;
+        K.g0 = RG ? wave_g0 : 0; K.ga = g_at[(size_t)t]; K.ge = g_at[(size_t)t + 1]; K.fast_store = fast_store;
+        if (variant == 2) planes_task_avx512(J, err, K);
+        else if (variant == 1) planes_task_bmi2(J, err, K);
+        else planes_task_portable(J, err, K);
+        if (err.load(std::memory_order_relaxed) != SEG_OK) return;
+        need_of[(size_t)t] = K.used;
+        bases_of[(size_t)t] = K.nb; maxp_of[(size_t)t] = K.maxp; pieces_of[(size_t)t] = K.np;
+    };
+    if (!RG) pool.run(n_tasks, [&](int t) { run_task(t, 0, 0); });
+    else {
+        int half = 0;
+        for (int t0 = 0; t0 < n_tasks && err.load() == SEG_OK;) {
+            int t1 = t0 + 1;
+            while (t1 < n_tasks && g_at[(size_t)t1 + 1] - g_at[(size_t)t0] <= RG) t1++;
+            if (g_at[(size_t)t1] - g_at[(size_t)t0] > RG) return SEG_CAPACITY;         // one task alone outgrows a half (ring far too small)
+            J.wave_begin(half);
+            const int64_t wg0 = g_at[(size_t)t0];
+            pool.run(t1 - t0, [&](int k) { run_task(t0 + k, wg0, half); });
+            if (err.load() == SEG_OK) J.wave_flush(half, wg0, g_at[(size_t)t1]);
+            t0 = t1; half ^= 1;
+        }
+    }
+    if (err.load() != SEG_OK) return err.load();
+    J.n_bases = 0; J.max_pair = 0; J.n_pieces = 0;
+    int64_t worst = 0;
+    bool fits = true;
+    J.task_need.assign(need_of.begin(), need_of.begin() + n_tasks);
+    for (int t = 0; t < n_tasks; t++) {
+        J.n_bases += bases_of[(size_t)t]; J.max_pair = std::max(J.max_pair, maxp_of[(size_t)t]); J.n_pieces += pieces_of[(size_t)t];
+        const int64_t region = g_at[(size_t)t + 1] - g_at[(size_t)t];
+        if (need_of[(size_t)t] > region) fits = false;
+        worst = std::max(worst, need_of[(size_t)t] - (region - (J.task_groups ? 0 : slack)));
+    }
+    J.need_slack = fits ? slack : std::max<int64_t>(worst, slack + 1);
+    if (!fits) return SEG_CAPACITY;                 // some task outgrew its region: encode again with task_groups = task_need
+    return SEG_OK;
+}
+
+
+// The reference codes of a batch as they travel and lie in a slot: a 2-bit plane (A C T G; anything else as 0), four positions a
+// byte, and a bit plane marking the positions that are not A/C/T/G.  plane2 holds (n_pos + 3) / 4 bytes, nplane (n_pos + 7) / 8;
+// returns whether the N plane marks any position (it is always written).
+namespace {
+__attribute__((target("bmi2")))
+inline void pack_ref_piece_bmi2(const uint8_t *r, int64_t n, uint8_t *o2, uint8_t *on, bool &seen)
+{
+    int64_t i = 0;
+    uint64_t any = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x;
+        memcpy(&x, r + i, 8);
+        const uint64_t bad = x & 0xFCFCFCFCFCFCFCFCull;                        // a code above 3 has one of these bits
+        if (__builtin_expect(bad == 0, 1)) {
+            const uint16_t v = (uint16_t)_pext_u64(x, 0x0303030303030303ull);
+            memcpy(o2 + (i >> 2), &v, 2);
+            on[i >> 3] = 0;
+            continue;
+        }
+        uint64_t t = bad | (bad >> 4);
+        t |= t >> 2; t |= t >> 1;                                               // bit 0 of every byte: the byte is not a base
+        const uint64_t nb = t & 0x0101010101010101ull;
+        const uint64_t keep = ~(nb * 0xFFull);                                  // bytes that are bases
+        const uint16_t v = (uint16_t)_pext_u64(x & keep, 0x0303030303030303ull);
+        memcpy(o2 + (i >> 2), &v, 2);
+        on[i >> 3] = (uint8_t)_pext_u64(nb, 0x0101010101010101ull);
+        any |= nb;
+    }
+    for (; i < n; i += 8) {                                                      // the last, partial byte group
+        uint32_t lo = 0, hi = 0, nbits = 0;
+        const int64_t m = std::min<int64_t>(8, n - i);
+        for (int64_t k = 0; k < m; k++) {
+            const uint32_t c = r[i + k];
+            const uint32_t b = c > 3u;
+            nbits |= b << k;
+            const uint32_t v = b ? 0u : c;
+            if (k < 4) lo |= v << (2 * k); else hi |= v << (2 * (k - 4));
+        }
+        o2[i >> 2] = (uint8_t)lo;
+        if (m > 4) o2[(i >> 2) + 1] = (uint8_t)hi;
+        on[i >> 3] = (uint8_t)nbits;
+        any |= nbits;
+    }
+    seen = any != 0;
+}
+
+inline void pack_ref_piece_scalar(const uint8_t *r, int64_t n, uint8_t *o2, uint8_t *on, bool &seen)
+{
+    seen = false;
+    for (int64_t i = 0; i < n; i += 8) {
+        uint32_t lo = 0, hi = 0, nb = 0;
+        const int64_t m = std::min<int64_t>(8, n - i);
+        for (int64_t k = 0; k < m; k++) {
+            const uint32_t c = r[i + k];
+            const uint32_t bad = c > 3u;
+            nb |= bad << k;
+            const uint32_t v = bad ? 0u : c;
+            if (k < 4) lo |= v << (2 * k); else hi |= v << (2 * (k - 4));
+        }
+        o2[i >> 2] = (uint8_t)lo;
+        if (m > 4) o2[(i >> 2) + 1] = (uint8_t)hi;
+        on[i >> 3] = (uint8_t)nb;
+        seen |= nb != 0;
+    }
+}
+}  // namespace
+
+bool pack_ref_planes(HostPool &pool, const uint8_t *ref, int64_t n_pos, uint8_t *plane2, uint8_t *nplane)
+{
+    const int64_t piece = (int64_t)256 << 10;               // a multiple of 8
+    const int n_tasks = (int)((n_pos + piece - 1) / piece);
+    std::atomic<int> any{0};
+    const bool bmi2 = cpu_has_bmi2();
+    auto cp = [&](int t) {
+        const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n_pos, a + piece);
+        bool seen = false;
+        if (bmi2) pack_ref_piece_bmi2(ref + a, e - a, plane2 + (a >> 2), nplane + (a >> 3), seen);
+        else pack_ref_piece_scalar(ref + a, e - a, plane2 + (a >> 2), nplane + (a >> 3), seen);
+        if (seen) any.store(1, std::memory_order_relaxed);
+    };
+    if (n_tasks > 1) pool.run(n_tasks, cp); else if (n_tasks == 1) cp(0);
+    return any.load() != 0;
+}
+
+// fifteen words of ten 3-bit codes -> one line of planes (codes >= 4: skipped column, base bits 0)
+void planes_from_words(const uint32_t *w, uint32_t L, uint64_t *P)
+{
+    uint64_t b[5] = {0, 0, 0, 0, 0}, sk[3] = {0, 0, 0};
+    for (uint32_t j = 0; j < L; j++) {
+        const uint32_t c = (w[j / 10] >> (3 * (j % 10))) & 7u;
+        if (c >= 4) sk[j >> 6] |= (uint64_t)1 << (j & 63);
+        else b[j >> 5] |= (uint64_t)c << (2 * (j & 31));
+    }
+    for (int i = 0; i < 5; i++) P[i] = b[i];
+    for (int i = 0; i < 3; i++) P[5 + i] = sk[i];
+}
+
 }  // namespace isxenc
 
 namespace {
@@ -716,6 +1051,120 @@ int isx_pack_reads(int64_t n_reads, const int64_t *ref_start, const int64_t *cli
     }
     if (bad) { isx_set_error("isx_pack_reads: a CIGAR reaches beyond its read's bases or the flat space"); return ISX_ERR_ARG; }
     if (full) { isx_set_error("isx_pack_reads: more segments than cap_seg (isx_count_read_segs gives the number)"); return ISX_ERR_CAPACITY; }
+    *n_seg = n;
+    return ISX_OK;
+}
+
+int isx_pack_ref_planes(const uint8_t *ref, int64_t n_pos, int32_t host_threads, uint8_t *plane2, uint8_t *nplane, int32_t *has_n)
+{
+    if (!ref || n_pos <= 0 || !plane2 || !nplane) { isx_set_error("isx_pack_ref_planes: bad argument"); return ISX_ERR_ARG; }
+    isxenc::HostPool pool(std::max(1, host_threads), -1, false);
+    const bool any = isxenc::pack_ref_planes(pool, ref, n_pos, plane2, nplane);
+    if (has_n) *has_n = any ? 1 : 0;
+    return ISX_OK;
+}
+
+int isx_planes_from_segs(const isx_segs *segs, int32_t host_threads, uint64_t *planes)
+{
+    if (!segs || segs->n_seg < 0 || (segs->n_seg && (!segs->len || !segs->bases || !planes))) { isx_set_error("isx_planes_from_segs: bad argument"); return ISX_ERR_ARG; }
+    const int64_t n = segs->n_seg, piece = 8192;
+    std::atomic<bool> bad{false};
+    isxenc::HostPool pool(std::max(1, host_threads), -1, false);
+    pool.run((int)((n + piece - 1) / piece), [&](int t) {
+        const int64_t a = (int64_t)t * piece, e = std::min<int64_t>(n, a + piece);
+        for (int64_t i = a; i < e; i++) {
+            const uint32_t L = segs->len[i];
+            if (L == 0 || L > ISX_SEG_BASES) { bad.store(true); return; }
+            isxenc::planes_from_words(segs->bases + (size_t)i * ISX_SEG_WORDS, L, planes + (size_t)i * ISX_PLANE_WORDS);
+        }
+    });
+    if (bad.load()) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
+    return ISX_OK;
+}
+
+int isx_encode_planes(const isx_read_planes *reads, const isx_ref_planes *ref, int64_t n_pos, int32_t host_threads, int32_t slack_groups,
+                      int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, int64_t *n_rec, int64_t *need_slack)
+{
+    if (!reads || !ref || !ref->plane2 || !rec || !gbase || !n_rec || reads->n_seg < 0 || cap_rec < ISX_DREC_GROUP || (cap_rec % ISX_DREC_GROUP) || n_pos <= 0 ||
+        (reads->n_seg && (!reads->gpos || !reads->len || !reads->planes)) || ring_records < 0 ||
+        (ring_records % (2 * ISX_DREC_GROUP)) || slack_groups < 0) {
+        isx_set_error("isx_encode_planes: bad argument");
+        return ISX_ERR_ARG;
+    }
+    std::vector<uint32_t> ring;
+    isxenc::HostPool pool(std::max(1, host_threads), -1, false);
+    std::vector<uint32_t> cmin((size_t)(cap_rec / ISX_DREC_GROUP)), cmax(cmin.size());
+    std::vector<uint8_t> cany(cmin.size());
+    isxenc::SegJob J;
+    J.in2 = *reads; J.n_seg = reads->n_seg; J.n_pos = n_pos; J.n_mm_bins = 1;
+    J.ref2 = ref->plane2; J.refn = ref->nplane; J.slack_groups = std::max(1, slack_groups);
+    J.rec = rec; J.gbase = gbase; J.pair_out = nullptr;
+    J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data(); J.cap_rec = cap_rec;
+    if (ring_records) {         // the pipe's ring mode with a memcpy standing in for the DMA engine
+        const int64_t half = ring_records / 2;
+        ring.assign((size_t)ring_records * ISX_DREC_WORDS + 16, 0xABABABABu);
+        uint32_t *r0 = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(ring.data()) + 63) & ~(uintptr_t)63);
+        J.rec = r0;
+        J.ring_groups = half / ISX_DREC_GROUP;
+        J.wave_begin = [](int) {};
+        J.wave_flush = [&, r0](int h, int64_t g0, int64_t g1) {
+            const size_t gw = (size_t)ISX_DREC_GROUP * ISX_DREC_WORDS;
+            memcpy(rec + (size_t)g0 * gw, r0 + (size_t)h * half * ISX_DREC_WORDS, (size_t)(g1 - g0) * gw * 4);
+            std::fill_n(r0 + (size_t)h * half * ISX_DREC_WORDS, (size_t)half * ISX_DREC_WORDS, 0xABABABABu);
+        };
+    }
+    const int rc = isxenc::encode_planes(pool, J);
+    if (need_slack) *need_slack = J.need_slack;
+    *n_rec = J.n_rec;
+    if (rc == isxenc::SEG_CAPACITY) {
+        isx_set_error(J.need_slack > J.slack_groups ? "isx_encode_planes: a task needs more spare groups than slack_groups (see *need_slack)"
+                                                    : "isx_encode_planes: the stream does not fit cap_rec records");
+        return ISX_ERR_CAPACITY;
+    }
+    if (rc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
+    if (rc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
+    return ISX_OK;
+}
+
+int isx_pack_read_planes(int64_t n_reads, const int64_t *ref_start, const int64_t *clip_lo, const int64_t *clip_hi,
+                         const uint32_t *cigar, const int64_t *cigar_off, const char *seq, const uint8_t *qual, const int64_t *seq_off,
+                         const uint32_t *pair, int32_t min_base_quality, int64_t cap_seg, uint32_t *seg_gpos,
+                         uint8_t *seg_len, uint32_t *seg_pair, uint64_t *seg_planes, int64_t *n_seg)
+{
+    if (n_reads < 0 || !n_seg || cap_seg < 0 || (n_reads && (!ref_start || !clip_lo || !clip_hi || !cigar || !cigar_off || !seq || !qual || !seq_off)) ||
+        (cap_seg && (!seg_gpos || !seg_len || !seg_planes)) || (pair && cap_seg && !seg_pair)) {
+        isx_set_error("isx_pack_read_planes: bad argument");
+        return ISX_ERR_ARG;
+    }
+    int64_t n = 0;
+    bool full = false, bad = false;
+    for (int64_t r = 0; r < n_reads && !full && !bad; r++) {
+        const char *sq = seq + seq_off[r];
+        const uint8_t *ql = qual + seq_off[r];
+        const int64_t q_len = seq_off[r + 1] - seq_off[r];
+        const bool ok = for_runs(cigar + cigar_off[r], cigar_off[r + 1] - cigar_off[r], ref_start[r], clip_lo[r], clip_hi[r],
+                                 [&](int64_t pos, int64_t q0, int64_t cols) {
+            if (q0 + cols > q_len || pos < 0 || pos + cols > (int64_t)0xFFFFFFFFll) { bad = true; return; }
+            for (int64_t c0 = 0; c0 < cols && !full; c0 += ISX_SEG_BASES) {
+                const int L = (int)std::min<int64_t>(ISX_SEG_BASES, cols - c0);
+                if (n >= cap_seg) { full = true; return; }
+                uint64_t *P = seg_planes + (size_t)n * ISX_PLANE_WORDS;
+                for (int k = 0; k < ISX_PLANE_WORDS; k++) P[k] = 0;
+                for (int j = 0; j < L; j++) {
+                    const int64_t qi = q0 + c0 + j;
+                    const uint32_t code = (int)ql[qi] >= min_base_quality ? ascii_code(sq[qi]) : 4u;
+                    if (code >= 4) P[5 + (j >> 6)] |= (uint64_t)1 << (j & 63);
+                    else P[j >> 5] |= (uint64_t)code << (2 * (j & 31));
+                }
+                seg_gpos[n] = (uint32_t)(pos + c0); seg_len[n] = (uint8_t)L;
+                if (seg_pair) seg_pair[n] = pair ? pair[r] : 0u;
+                n++;
+            }
+        });
+        if (!ok) { isx_set_error("isx_pack_read_planes: unknown CIGAR operator"); return ISX_ERR_ARG; }
+    }
+    if (bad) { isx_set_error("isx_pack_read_planes: a CIGAR reaches beyond its read's bases or the flat space"); return ISX_ERR_ARG; }
+    if (full) { isx_set_error("isx_pack_read_planes: more segments than cap_seg (isx_count_read_segs gives the number)"); return ISX_ERR_CAPACITY; }
     *n_seg = n;
     return ISX_OK;
 }

@@ -27,6 +27,13 @@ struct SegJob {
     isx_segs in{};
     std::function<void(int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint32_t *bases)> produce;
     const uint32_t *gpos_all = nullptr;         // producer mode: the segment starts alone (the layout pass needs them up front)
+    // bit-plane input (include/instrain_amd.h isx_read_planes; encode_planes): arrays, or a producer that writes any range of the
+    // stream -- gpos / len / pair [count] and planes [count][ISX_PLANE_WORDS] -- into the task's scratch
+    isx_read_planes in2{};
+    std::function<void(int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint32_t *pair, uint64_t *planes)> produce_planes;
+    // ... compared with the reference as it travels: the 2-bit plane (four positions a byte, anything that is not A/C/T/G as 0)
+    // and the bit plane of those positions (NULL = the batch has none)
+    const uint8_t *ref2 = nullptr, *refn = nullptr;
     int64_t n_seg = 0, n_pos = 0;
     int n_mm_bins = 1;
     bool want_pairs = false;
@@ -69,7 +76,16 @@ int encode_segs(HostPool &pool, SegJob &job);
 // the same stream as 32-byte reference-delta records (groups of ISX_DREC_GROUP); SEG_CAPACITY with need_slack > slack_groups
 // means "encode again with more slack", otherwise the stream does not fit cap_rec
 int encode_delta(HostPool &pool, SegJob &job);
+// the same records from bit-plane input (SegJob::in2 / produce_planes, ref2 / refn): exceptions are found by XOR against the funnel-
+// shifted 2-bit reference plane, 32 columns a step, the skip plane is copied.  Same layout rules, same result codes, and the same
+// bytes as encode_delta gives for the segments the planes stand for.
+int encode_planes(HostPool &pool, SegJob &job);
 int64_t delta_groups_needed(HostPool &pool, const uint32_t *gpos, int64_t n, int64_t slack_groups);
 int64_t seg_groups_needed(HostPool &pool, const uint32_t *gpos, int64_t n);
+// reference codes (1 byte a position) -> the planes that travel (see include/instrain_amd.h isx_ref_planes); returns whether any
+// position is not A/C/T/G
+bool pack_ref_planes(HostPool &pool, const uint8_t *ref, int64_t n_pos, uint8_t *plane2, uint8_t *nplane);
+// one segment's fifteen words of 3-bit codes -> its line of planes
+void planes_from_words(const uint32_t *words, uint32_t len, uint64_t *planes);
 
 }  // namespace isxenc

@@ -45,6 +45,72 @@ class SegBatch:
         return int(self.len.sum(dtype=np.int64))
 
 
+def _aligned(shape, dtype, align=64):
+    """uninitialised C-contiguous array whose data pointer is `align`-byte aligned"""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.empty(n + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
+class PlaneBatch:
+    """Read segments of a batch as bit planes (isx_read_planes): gpos u32 [n], len u8 [n], pair u32 [n] | None, planes u64 [n, 8] --
+    words 0-4 the 2-bit base codes of the columns (A C T G = 0 1 2 3), words 5-7 the columns that are not observed.  One 64-byte line a
+    segment; one mm bin only.  from_segs(SegBatch) converts (isx_planes_from_segs)."""
+
+    def __init__(self, gpos, length, planes, pair=None):
+        self.gpos = np.ascontiguousarray(gpos, dtype=np.uint32)
+        self.len = np.ascontiguousarray(length, dtype=np.uint8)
+        planes = np.asarray(planes, dtype=np.uint64).reshape(-1, _lib.PLANE_WORDS)
+        if not planes.flags.c_contiguous or planes.ctypes.data % 64:
+            a = _aligned(planes.shape, np.uint64)
+            a[...] = planes
+            planes = a
+        self.planes = planes
+        self.pair = None if pair is None else np.ascontiguousarray(pair, dtype=np.uint32)
+        n = len(self.gpos)
+        assert len(self.len) == n and len(self.planes) == n and (self.pair is None or len(self.pair) == n)
+        self.n_seg = n
+
+    @classmethod
+    def from_segs(cls, segs, threads=1):
+        planes = _aligned((segs.n_seg, _lib.PLANE_WORDS), np.uint64)
+        cs = segs.c()
+        check(_lib.load().isx_planes_from_segs(C.byref(cs), int(threads), planes.ctypes.data if segs.n_seg else None))
+        return cls(segs.gpos, segs.len, planes, segs.pair)
+
+    def c(self, with_pair=True):
+        ptr = lambda a: a.ctypes.data if a is not None and len(a) else None
+        return _lib.ReadPlanes(self.n_seg, ptr(self.gpos), ptr(self.len), ptr(self.pair) if with_pair else None, ptr(self.planes))
+
+    @property
+    def n_bases(self):
+        return int(self.len.sum(dtype=np.int64))
+
+
+class RefPlanes:
+    """The reference of a batch as it travels (isx_ref_planes): plane2 u8 [(n_pos + 3) // 4] (2 bits a position, anything that is not
+    A/C/T/G as 0) and nplane u8 [(n_pos + 7) // 8] | None (the positions that are not A/C/T/G).  from_codes packs reference codes."""
+
+    def __init__(self, plane2, nplane, n_pos):
+        self.plane2 = np.ascontiguousarray(plane2, dtype=np.uint8)
+        self.nplane = None if nplane is None else np.ascontiguousarray(nplane, dtype=np.uint8)
+        self.n_pos = int(n_pos)
+        assert len(self.plane2) >= (self.n_pos + 3) // 4 and (self.nplane is None or len(self.nplane) >= (self.n_pos + 7) // 8)
+
+    @classmethod
+    def from_codes(cls, ref_codes, threads=1):
+        ref = np.ascontiguousarray(ref_codes, dtype=np.uint8)
+        n = len(ref)
+        p2, pn = np.empty((n + 3) // 4, dtype=np.uint8), np.empty((n + 7) // 8, dtype=np.uint8)
+        has = C.c_int32(0)
+        check(_lib.load().isx_pack_ref_planes(ref.ctypes.data, n, int(threads), p2.ctypes.data, pn.ctypes.data, C.byref(has)))
+        return cls(p2, pn if has.value else None, n)
+
+    def c(self):
+        return _lib.RefPlanes(self.plane2.ctypes.data, None if self.nplane is None else self.nplane.ctypes.data)
+
+
 def pack_codes(codes):
     """[n, 150] uint8 base codes (0..3 A C T G, 4 skip, 5 non-ACGT) -> [n, 15] uint32, ten codes per word"""
     c = np.ascontiguousarray(codes, dtype=np.uint32).reshape(-1, _lib.SEG_WORDS, 10)
@@ -337,6 +403,28 @@ class Pipe:
         self._wires.append(w)
         return w
 
+    def submit_planes(self, ref_planes, split_bounds, reads):
+        """-> ticket.  A read-level batch as bit planes (PlaneBatch) against the reference planes (RefPlanes): isx_pipe_submit_planes"""
+        split_bounds = np.ascontiguousarray(split_bounds, dtype=np.int64)
+        cr, cf = reads.c(with_pair=self.enable_linkage), ref_planes.c()
+        t = C.c_int64(-1)
+        check(self.lib.isx_pipe_submit_planes(self.h, ref_planes.n_pos, C.byref(cf), len(split_bounds) - 1, split_bounds.ctypes.data,
+                                              C.byref(cr), C.byref(t)))
+        if self.stage_async:                        # the stager reads these until the batch is collected / released
+            self._held[t.value] = (ref_planes, reads, cr, cf)
+        return t.value
+
+    def stage_planes(self, ref_planes, split_bounds, reads):
+        """-> Wire, like stage_reads, from bit planes (isx_pipe_stage_planes)"""
+        split_bounds = np.ascontiguousarray(split_bounds, dtype=np.int64)
+        cr, cf = reads.c(with_pair=self.enable_linkage), ref_planes.c()
+        h = C.c_void_p()
+        check(self.lib.isx_pipe_stage_planes(self.h, ref_planes.n_pos, C.byref(cf), len(split_bounds) - 1, split_bounds.ctypes.data,
+                                             C.byref(cr), C.byref(h)))
+        w = Wire(self, h)
+        self._wires.append(w)
+        return w
+
     def submit_wire(self, wire):
         """-> ticket.  A staged batch (stage_reads) into the next free slot: DMA copies + pass + copy-out, nothing else"""
         t = C.c_int64(-1)
@@ -560,6 +648,26 @@ def encode_delta(segs, ref_codes, n_mm_bins=1, threads=1, slack_groups=1, cap_re
         return rec[:n], gbase[:n // 32], None, slack_groups
 
 
+def encode_planes(reads, ref_planes, threads=1, slack_groups=1, cap_rec=None, ring_records=0, retry=True):
+    """isx_encode_planes (host only): PlaneBatch + RefPlanes -> (rec [n_rec, 8] uint32, gbase [n_rec / 32], None, slack_groups used) --
+    the same records encode_delta gives for the segments the planes stand for"""
+    lib = _lib.load()
+    while True:
+        cap = cap_rec if cap_rec is not None else int(lib.isx_delta_records_needed(reads.gpos.ctypes.data if reads.n_seg else None, reads.n_seg, int(threads), int(slack_groups)))
+        rec = _aligned((cap, 8), np.uint32)
+        gbase = np.empty(cap // 32, dtype=np.uint32)
+        n_rec, need = C.c_int64(0), C.c_int64(0)
+        cr, cf = reads.c(), ref_planes.c()
+        rc = lib.isx_encode_planes(C.byref(cr), C.byref(cf), ref_planes.n_pos, int(threads), int(slack_groups), cap, int(ring_records),
+                                   rec.ctypes.data, gbase.ctypes.data, C.byref(n_rec), C.byref(need))
+        if rc == _lib.ERR_CAPACITY and retry and need.value > slack_groups and cap_rec is None:
+            slack_groups = int(need.value)
+            continue
+        check(rc)
+        n = n_rec.value
+        return rec[:n], gbase[:n // 32], None, slack_groups
+
+
 def dense_cov(res, n_pos=None):
     """coverage per position (uint16, capped at 65535) of a collected batch in whichever shrunk form it came home: 'cov16', 'cov8'
     (+ 'saturated'), or the lean slots' 'cov4' plane + 'cov_rows' / 'cov_row_win' / 'cov_window' (isx_pipe_result.coverage4)"""
@@ -674,6 +782,35 @@ def pack_reads(ref_start, clip_lo, clip_hi, cigars, seqs, quals, mm=None, pair=N
                              sm.ctypes.data, sp.ctypes.data, bs.ctypes.data, C.byref(ns)))
     k = ns.value
     return SegBatch(g[:k], ln[:k], bs[:k], sm[:k] if mm is not None else None, sp[:k] if pair is not None else None)
+
+
+def pack_read_planes(ref_start, clip_lo, clip_hi, cigars, seqs, quals, pair=None, min_base_quality=30):
+    """isx_pack_read_planes (host only): pack_reads with bit planes as output -> PlaneBatch"""
+    lib = _lib.load()
+    n = len(ref_start)
+    rs = np.ascontiguousarray(ref_start, dtype=np.int64)
+    lo = np.ascontiguousarray(clip_lo, dtype=np.int64)
+    hi = np.ascontiguousarray(clip_hi, dtype=np.int64)
+    cig_off = np.zeros(n + 1, dtype=np.int64)
+    seq_off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        cig_off[1:] = np.cumsum([len(c) for c in cigars])
+        seq_off[1:] = np.cumsum([len(q) for q in quals])
+    cig = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint32) for c in cigars]) if n else np.zeros(0, np.uint32))
+    seq = b"".join(s.encode() if isinstance(s, str) else bytes(s) for s in seqs)
+    qual = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint8) for q in quals]) if n else np.zeros(0, np.uint8))
+    assert len(seq) == len(qual)
+    pv = None if pair is None else np.ascontiguousarray(pair, dtype=np.uint32)
+    ns = C.c_int64(0)
+    check(lib.isx_count_read_segs(n, cig.ctypes.data, cig_off.ctypes.data, rs.ctypes.data, lo.ctypes.data, hi.ctypes.data, C.byref(ns)))
+    cap = max(1, ns.value)
+    g = np.empty(cap, np.uint32); ln = np.empty(cap, np.uint8); sp = np.zeros(cap, np.uint32)
+    pl = _aligned((cap, _lib.PLANE_WORDS), np.uint64)
+    check(lib.isx_pack_read_planes(n, rs.ctypes.data, lo.ctypes.data, hi.ctypes.data, cig.ctypes.data, cig_off.ctypes.data, seq,
+                                   qual.ctypes.data, seq_off.ctypes.data, pv.ctypes.data if pv is not None else None, int(min_base_quality), cap,
+                                   g.ctypes.data, ln.ctypes.data, sp.ctypes.data, pl.ctypes.data, C.byref(ns)))
+    k = ns.value
+    return PlaneBatch(g[:k], ln[:k], pl[:k], sp[:k] if pair is not None else None)
 
 
 def dense_to_entries(counts, clon):
@@ -870,7 +1007,15 @@ class BamFile:
         sref = np.empty(info.n_splits, dtype=np.int32)
         check(self.lib.isx_bam_copy_segs(self.h, g.ctypes.data, ln.ctypes.data, mm.ctypes.data, pr.ctypes.data, bs.ctypes.data,
                                          bounds.ctypes.data, sref.ctypes.data))
+        self._n_segs = k
         return SegBatch(g, ln, bs, mm, pr), bounds, sref
+
+    def read_planes(self):
+        """the segments of the last segment_refs() as bit planes [n_seg, 8] uint64 (isx_bam_copy_read_planes): what submit_bam hands a
+        one-mm-bin pipe's stager"""
+        pl = _aligned((self._n_segs, _lib.PLANE_WORDS), np.uint64)
+        check(self.lib.isx_bam_copy_read_planes(self.h, pl.ctypes.data if self._n_segs else None))
+        return pl
 
     def expand_region(self, ref, start, stop, copy=True, **kw):
         """pass 2 for the columns [start, stop) of reference index `ref` only (the re-pileup of SNV pooling)"""

@@ -31,7 +31,7 @@ def to_oracle_layout(res, gpos_to_pos):
     return {"entries": E, "snv": S, "ld": L}
 
 
-def run_split(ctx, pos, base, mm, pair, seq, start, n_mm_bins=None, reads=None, **kw):
+def run_split(ctx, pos, base, mm, pair, seq, start, n_mm_bins=None, reads=None, planes=False, **kw):
     """One split through the product. pos absolute; only observations inside the split are sent
     (truncate=True of the pileup call, profile_utilities.py:150).  reads = "stream": the same observations handed over as
     read segments cut from the stream as it comes (synth.segs_from_obs); "reassembled": as segments rebuilt per read pair
@@ -49,6 +49,22 @@ def run_split(ctx, pos, base, mm, pair, seq, start, n_mm_bins=None, reads=None, 
     elif reads == "reassembled":
         from tests import util
         obs, pr = util.reassemble_segs(obs["gpos"], obs["base"], obs["mm"], pr), None
+    if planes:
+        # the same segments as bit planes through a one-slot pipe (isx_pipe_submit_planes; one mm bin): full tables back (want_counts)
+        assert reads in ("stream", "reassembled") and n_mm_bins == 1
+        ref = engine.encode_seq(seq)
+        pipe = engine.Pipe(ctx, max_pos=len(ref), max_obs=0, max_segs=max(1, obs.n_seg), max_splits=1, depth=1, host_threads=2, pin_threads=False,
+                           n_mm_bins=1, enable_linkage=True, want_counts=True, **kw)
+        t = pipe.submit_planes(engine.RefPlanes.from_codes(ref), [0, len(ref)], engine.PlaneBatch.from_segs(obs))
+        r = pipe.collect(t)
+        res = {k: r[k].copy() for k in ("counts", "clon", "clon_r", "snv", "ld")}
+        sizes = r["sizes"]
+        pipe.release(t)
+        pipe.close()
+        out = to_oracle_layout(res, lambda g: g.astype(np.int64) + start)
+        out["n_edges"] = sizes["n_edges"]
+        out["sizes"] = sizes
+        return out
     b = engine.Batch(ctx, engine.encode_seq(seq), [0, len(seq)], obs, pr,
                      n_mm_bins=n_mm_bins, **kw)
     b.run()

@@ -26,24 +26,42 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.isx_abi_version() == 3
+    hdr = open(os.path.join(REPO, "include", "instrain_amd.h")).read()
+    declared = int(re.search(r"#define\s+ISX_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.isx_abi_version() == declared == _lib.ABI_VERSION == 4
     assert isinstance(lib.isx_last_error(), bytes)
+
+
+def test_loader_refuses_another_abi_version(tmp_path):
+    """a library of another ABI version is never called into (isx_pipe_result / isx_pipe_params changed size and meaning between versions)"""
+    import subprocess
+    import sys
+    src = tmp_path / "old.c"
+    src.write_text("int isx_abi_version(void) { return 3; }\nconst char *isx_last_error(void) { return \"\"; }\n")
+    so = tmp_path / "libold.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)])
+    code = ("import os, sys; os.environ['ISX_LIB'] = %r; sys.path.insert(0, %r)\nfrom instrain_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.IsxError as e:\n    assert 'ABI version 3' in str(e), str(e); print('refused')\n" % (str(so), REPO))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "refused" in r.stdout, r.stderr[-1500:]
 
 
 def test_struct_sizes_match_header(tmp_path):
     """sizeof() of every ABI struct as the C compiler sees the header == the ctypes / numpy mirror."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "instrain_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "instrain_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(isx_params),sizeof(isx_sizes),sizeof(isx_timings),sizeof(isx_bam_params),sizeof(isx_bam_info),'
-                   'sizeof(isx_obs),sizeof(isx_entry),sizeof(isx_snv),sizeof(isx_ld),sizeof(isx_scaffold_level),sizeof(isx_compare_level),sizeof(isx_compare_snp),sizeof(isx_pipe_params),sizeof(isx_pipe_result));return 0;}\n')
+                   'sizeof(isx_obs),sizeof(isx_entry),sizeof(isx_snv),sizeof(isx_ld),sizeof(isx_scaffold_level),sizeof(isx_compare_level),sizeof(isx_compare_snp),sizeof(isx_pipe_params),sizeof(isx_pipe_result),'
+                   'sizeof(isx_read_planes),sizeof(isx_ref_planes),sizeof(isx_segs));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
     c_sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     py_sizes = [C.sizeof(_lib.Params), C.sizeof(_lib.Sizes), C.sizeof(_lib.Timings), C.sizeof(_lib.BamParams),
                 C.sizeof(_lib.BamInfo), _lib.OBS_DT.itemsize, _lib.ENTRY_DT.itemsize, _lib.SNV_DT.itemsize,
                 _lib.LD_DT.itemsize, _lib.SCAFFOLD_LEVEL_DT.itemsize, _lib.COMPARE_LEVEL_DT.itemsize,
-                _lib.COMPARE_SNP_DT.itemsize, C.sizeof(_lib.PipeParams), C.sizeof(_lib.PipeResult)]
+                _lib.COMPARE_SNP_DT.itemsize, C.sizeof(_lib.PipeParams), C.sizeof(_lib.PipeResult),
+                C.sizeof(_lib.ReadPlanes), C.sizeof(_lib.RefPlanes), C.sizeof(_lib.Segs)]
     assert c_sizes == py_sizes, (c_sizes, py_sizes)
 
 

@@ -25,7 +25,8 @@ ctx = engine.Context(0)
 lut, fb = util.load_lut()
 ctx.set_null_model(lut, fb)
 if "--c5" in sys.argv:
-    run = bench.C5Run(ctx, 0, 8, 4, depth=1, staged=True, min_batches=0)        # rank 0 of 8: one shard is enough to find a batch (of the N = 1 size)
+    run = bench.C5Run(ctx, 0, 8, 4, depth=1, min_batches=0)        # rank 0 of 8: one shard is enough to find a batch (of the N = 1 size)
+    run.stage_all()
     sizes = [w["n_pos"] for w in run.ws]
     k = int(np.argsort(sizes)[len(sizes) // 2])
     w, wire = run.ws[k], run.wires[k]
@@ -35,7 +36,7 @@ if "--c5" in sys.argv:
         st = r["stats"]
         run.pipe.release(t)
     print("c5 batch %d: %d positions, %d segments, %d kept observations, kernel %.4f ms, h2d %d bytes, record_bytes %d"
-          % (k, w["n_pos"], w["segs"].n_seg, w["n_obs"], st["kernel_ms"], st["h2d_bytes"], st["record_bytes"]), flush=True)
+          % (k, w["n_pos"], w["n_seg"], w["n_obs"], st["kernel_ms"], st["h2d_bytes"], st["record_bytes"]), flush=True)
     run.close()
 else:
     with_mm = "--no-mm" not in sys.argv
