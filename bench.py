@@ -439,6 +439,34 @@ def _c5_plan(scale, host_threads):
     return meta, kept, shards, n_genomes
 
 
+def planes_coverage(w, per_base_at=None, chunk=200_000):
+    """exact per-position coverage of a bit-plane workload, on the host (numpy, in chunks): segment starts +1 / ends -1, prefix sum,
+    minus the columns a segment does not observe; per_base_at = sorted positions -> also the (A, C, T, G) counts at those positions.
+    The check of the tables, independent of the library: only the format's definition (include/instrain_amd.h isx_read_planes)."""
+    pb, n_pos = w["planes"], int(w["n_pos"])
+    g0 = pb.gpos.astype(np.int64)
+    ln = pb.len.astype(np.int64)
+    diff = np.bincount(g0, minlength=n_pos + 1).astype(np.int64) - np.bincount(g0 + ln, minlength=n_pos + 1).astype(np.int64)
+    cov = np.cumsum(diff[:-1])
+    per_base = np.zeros((len(per_base_at), 4), np.int64) if per_base_at is not None else None
+    j = np.arange(150, dtype=np.int64)[None, :]
+    for c0 in range(0, pb.n_seg, chunk):
+        pl = pb.planes[c0:c0 + chunk]
+        skip = np.unpackbits(np.ascontiguousarray(pl[:, 5:8]).view(np.uint8), axis=1, bitorder="little")[:, :150].astype(bool)
+        inside = j < ln[c0:c0 + chunk, None]
+        g = g0[c0:c0 + chunk, None] + j
+        cov -= np.bincount(g[inside & skip], minlength=n_pos)
+        if per_base is not None:
+            ok = inside & ~skip
+            two = np.unpackbits(np.ascontiguousarray(pl[:, 0:5]).view(np.uint8), axis=1, bitorder="little")[:, :300].reshape(len(pl), 150, 2)
+            code = two[:, :, 0] | (two[:, :, 1] << 1)
+            gg, bb = g[ok], code[ok]
+            k = np.searchsorted(per_base_at, gg)
+            hit = (k < len(per_base_at)) & (per_base_at[np.minimum(k, len(per_base_at) - 1)] == gg)
+            np.add.at(per_base, (k[hit], bb[hit]), 1)
+    return cov, per_base
+
+
 class C5Run:
     """BASELINE.json configs[4] (the configuration north_star quotes its target on): 1000-genome database,
     10 Gbp of reads, --database_mode (one mm bin; genomes below 1x dropped like fasta.py:110-136 does).  The kept genomes are
@@ -502,6 +530,7 @@ class C5Run:
         the per-batch signature (n_snv, n_ld, n_edges) the timed passes are compared with."""
         sig = []
         covered = {}
+        exact_i = int(np.argmax([w["n_pos"] for w in self.ws]))
 
         def check(i, r):
             from instrain_amd import engine
@@ -516,6 +545,15 @@ class C5Run:
             if total != w["n_obs"]:
                 raise AssertionError("C5 batch %d: coverage table sums to %d, %d observations were handed over" % (i, total, w["n_obs"]))
             covered[i] = int(np.count_nonzero(cov))
+            if i == exact_i:
+                # the largest batch: EXACT per-position coverage and the SNV rows' counts base by base, recomputed on the host from
+                # the planes that were handed over (planes_coverage: numpy on the format's definition, nothing of the library)
+                exp, per_base = planes_coverage(w, per_base_at=r["snv"]["gpos"].astype(np.int64))
+                if not (cov == exp).all():
+                    raise AssertionError("C5 batch %d: coverage differs from the host's at %d positions" % (i, int((cov != exp).sum())))
+                if not (per_base == r["snv"]["cnt"]).all():
+                    raise AssertionError("C5 batch %d: SNV row counts differ from the host's per-base counts" % i)
+                self.exact_checked = {"batch": int(i), "positions": int(len(cov)), "snv_rows": int(len(per_base))}
             snv = r["snv"]
             g = snv["gpos"].astype(np.int64)
             if len(g) != r["sizes"]["n_snv"] or (np.diff(g) <= 0).any():
@@ -531,6 +569,13 @@ class C5Run:
         stream(self.pipe, self.ws, len(self.ws), self.depth, check=check)
         self.signature = sig
         return sig
+
+    def checked_pass(self, check, staged=False):
+        """one pass with check(i, result) called on every collected batch (tests/test_gpu_metagenome.py drives the headline's exact
+        configuration through this)"""
+        if staged and self.wires is None:
+            self.stage_all()
+        stream(self.pipe, self.ws, len(self.ws), self.depth, check=check, wires=self.wires if staged else None)
 
     def run(self, passes, stats=None, keep_last=False, staged=False):
         """passes over the rank's batches.  staged False (the headline): every batch handed over from the caller's arrays --
@@ -614,8 +659,10 @@ class C5Run:
                             "(64 B a read), the reference as its 2-bit plane; the pipe's threads copy the reference planes into pinned staging and make the "
                             "32-byte wire records by XOR against them while the previous batches' DMA and kernels run",
                "record_bytes": int(st[0]["record_bytes"]) if st else None,
-               "verified": "every batch checked in an untimed pass (coverage sum == observations handed over, SNV rows ordered and consistent with "
-                           "the coverage, LD counts add up); every timed batch's row counts equal that pass's",
+               "verified": "every batch checked in an untimed pass through the SAME hand-over (coverage sum == observations handed over, SNV rows ordered "
+                           "and consistent with the coverage, LD counts add up; the largest batch: exact per-position coverage and per-base SNV counts "
+                           "recomputed on the host); every timed batch's row counts equal that pass's",
+               "exact_check": getattr(self, "exact_checked", None),
                "stages_ms_per_pass": {"host_stage": tot("encode_ms"), "copy_in": tot("h2d_ms"), "kernel": k_ms, "copy_out": tot("d2h_ms"),
                                       "collect_wait": tot("collect_wait_ms"), "wall": dt_max / passes * 1e3},
                "roofline": {"bound": "hbm", "kernel": "k_pileup_dense<linkage, %s> (pipe slot output)" % ("reference-delta records" if rbytes == 32 else "segment records"),
@@ -1045,7 +1092,7 @@ def main():
                        "batches_per_step": n_batches if world == 1 else None, "hand_over": _short("isx_pipe_submit_planes per batch INSIDE the step: caller's bit planes (pageable) -> XOR stager -> %d-byte wire records in pinned staging -> hipMemcpyAsync -> kernels -> tables back" % (head.get("record_bytes") or 0), 220),
                        "pipe_depth": args.depth, "pileup_cus": 256 - 8 * C5_RESERVE_CUS, "lean_slots": LEAN_SLOTS, "host_threads_per_rank": host_threads, "cgroup_cpus": cgroup_cpus(),
                        "numa_node": numa_node, "parallelism": "genome-sharded x%d%s" % (world, " (ranks share %d GPU)" % n_dev if shared else ""),
-                       "verified": "per-batch checks in an untimed pass; timed row counts equal"},
+                       "verified": "per-batch checks in an untimed pass (largest batch: exact coverage + per-base SNV counts from the host); timed row counts equal"},
             "roofline": {k: head["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                             "algorithmic_bytes_per_launch", "kernel_ms_avg", "launches", "survey_8d_model", "bound_of_the_pass")},
             "h2d_bytes_per_base": head["roofline_pcie"]["bytes_per_profiled_base"], "pcie_frac": head["roofline_pcie"]["frac"],

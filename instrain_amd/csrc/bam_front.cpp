@@ -911,7 +911,8 @@ int open_file(const char *path, isx_bam &B)
     // ---- segments: runs of blocks, ~32 MiB inflated for big files, smaller ones when the file is small so that
     //      every thread still gets a few (segments are the unit of parallel work in both passes) ----
     const uint64_t want_segs = (uint64_t)4 * (uint64_t)(B.threads > 0 ? B.threads : n_threads_default());
-    const uint64_t SEG = std::min<uint64_t>((uint64_t)32 << 20, std::max<uint64_t>((uint64_t)1 << 20, total / std::max<uint64_t>(want_segs, 1)));
+    uint64_t SEG = std::min<uint64_t>((uint64_t)32 << 20, std::max<uint64_t>((uint64_t)1 << 20, total / std::max<uint64_t>(want_segs, 1)));
+    if (const char *e = getenv("ISX_BAM_SEG_KIB")) SEG = std::max<uint64_t>((uint64_t)64 << 10, (uint64_t)atoll(e) << 10);        // tuning aid
     Segment cur;
     cur.b0 = 0; cur.ioff0 = 0;
     for (uint32_t b = 0; b < B.blocks.size(); b++) {
@@ -970,6 +971,28 @@ void tweak_overlap(Batch &S, const Read &a, const Read &b)
 }
 
 // ---- scan: one segment's records -> ReadLite + names ----
+// what pass 1 keeps of one record: fixed fields, name (appended to `names`) + its hash, NM, reference span
+inline int extract_record(const uint8_t *p, int n_ref, uvec<char> &names, ReadLite &L, const char *&err)
+{
+    RecView r;
+    if (!rec_view(p, r)) { err = "corrupt BAM record"; return ISX_ERR_IO; }
+    if (r.tid >= n_ref) { err = "corrupt BAM record (reference id)"; return ISX_ERR_IO; }
+    L = ReadLite{};
+    L.tid = r.tid; L.pos = r.pos; L.isize = r.isize; L.l_seq = r.l_seq; L.flag = r.flag; L.mapq = r.mapq;
+    const size_t at = names.size(), nl = (size_t)r.l_name - 1;
+    L.name_off = (uint32_t)at; L.name_len = (uint16_t)nl;
+    names.resize(at + nl);
+    memcpy(names.data() + at, r.name, nl);
+    L.h64 = hash_name(r.name, nl);
+    bool has = false;
+    int32_t nm = 0;
+    if (parse_nm(r.aux, r.end, has, nm) != 0) { err = "bad aux field"; return ISX_ERR_IO; }
+    L.has_nm = has; L.nm = nm;
+    const RefSpan sp = span_of(r.cigar, r.n_cigar, r.pos);
+    L.first = sp.first; L.last = sp.last; L.qlen = (int32_t)sp.qlen; L.any = sp.any;
+    return ISX_OK;
+}
+
 int scan_segment(isx_bam &B, uint32_t si, const SegBuf &buf, const std::vector<uint64_t> &rec_off, std::string &err)
 {
     const Segment &s = B.segs[si];
@@ -979,28 +1002,100 @@ int scan_segment(isx_bam &B, uint32_t si, const SegBuf &buf, const std::vector<u
     size_t name_bytes = 0;
     const int n_ref = (int)B.ref_name.size();
     for (size_t i = 0; i < rec_off.size(); i++) name_bytes += buf.data[(size_t)(rec_off[i] - s.ioff0) + 12];
-    names.resize(name_bytes);
-    size_t at = 0;
+    names.resize(0);
+    names.reserve(name_bytes);
     for (size_t i = 0; i < rec_off.size(); i++) {
-        RecView r;
-        if (!rec_view(buf.data.data() + (rec_off[i] - s.ioff0), r)) { err = "corrupt BAM record"; return ISX_ERR_IO; }
-        if (r.tid >= n_ref) { err = "corrupt BAM record (reference id)"; return ISX_ERR_IO; }
-        ReadLite L{};
-        L.tid = r.tid; L.pos = r.pos; L.isize = r.isize; L.l_seq = r.l_seq; L.flag = r.flag; L.mapq = r.mapq;
-        L.name_off = (uint32_t)at; L.name_len = (uint16_t)(r.l_name - 1);
-        memcpy(names.data() + at, r.name, (size_t)r.l_name - 1);
-        at += (size_t)r.l_name - 1;
-        L.h64 = hash_name(r.name, (size_t)r.l_name - 1);
-        bool has = false;
-        int32_t nm = 0;
-        if (parse_nm(r.aux, r.end, has, nm) != 0) { err = "bad aux field"; return ISX_ERR_IO; }
-        L.has_nm = has; L.nm = nm;
-        const RefSpan sp = span_of(r.cigar, r.n_cigar, r.pos);
-        L.first = sp.first; L.last = sp.last; L.qlen = (int32_t)sp.qlen; L.any = sp.any;
-        out[i] = L;
+        const char *e = nullptr;
+        const int rc = extract_record(buf.data.data() + (rec_off[i] - s.ioff0), n_ref, names, out[i], e);
+        if (rc != ISX_OK) { err = e; return rc; }
     }
-    names.resize(at);
     return ISX_OK;
+}
+
+// Pass 1's per-segment work in one sweep: the segment's blocks are inflated one after the other and the record chain is walked
+// through every block right after it was written (while it still sits in the core's cache -- walked afterwards, over a 10-30 MiB
+// buffer, every hop of the chain is a miss: 110 ns a record, as much as decoding it), from `first`, or, when that is ~0, from a
+// structural guess made on the segment's first blocks (*guess_out; ~0 = the segment seems to hold no record start).  The buffer
+// is reserved with room for the record that straddles the segment's end, so bringing that one in does not move 30 MiB.
+// Returns false when a block does not inflate; *hop_rc = seg_hop's result for the walk (ISX_ERR_IO: the chain ran into something
+// that is not a record -- the guess was wrong, or the file is corrupt: the caller's serial pass decides).
+// lite / names (may be NULL): the records' fields are extracted in the same sweep (extract_record), as soon as a record lies whole in
+// the inflated part; *lite_rc = ISX_OK when every record of rec_off was extracted (else the caller runs scan_segment).
+bool seg_inflate_hop(const isx_bam &B, Inflater &inf, const Segment &s, SegBuf &buf, uint64_t first, bool guess, uint64_t *guess_out,
+                     std::vector<uint64_t> &rec_off, uint64_t &next_first, int *hop_rc, uvec<ReadLite> *lite, uvec<char> *names, int *lite_rc)
+{
+    const size_t seg_bytes = (size_t)(s.ioff1 - s.ioff0);
+    buf.data.reserve(seg_bytes + (size_t)4 * 65536);
+    buf.data.resize(0);
+    buf.b_end = s.b0;
+    rec_off.clear();
+    rec_off.reserve(seg_bytes / 192 + 16);
+    *hop_rc = ISX_OK;
+    auto inflate_next = [&]() -> bool {
+        const Block &k = B.blocks[buf.b_end];
+        const size_t old = buf.data.size();
+        buf.data.resize(old + k.isize);
+        if (!inf.run(B.map + k.coff + k.hdr, k.csize - k.hdr - 8, buf.data.data() + old, k.isize)) return false;
+        buf.b_end++;
+        return true;
+    };
+    size_t n_lite = 0;                                  // records extracted so far
+    bool lite_ok = lite != nullptr;
+    const int n_ref = (int)B.ref_name.size();
+    if (lite) { lite->resize(0); lite->reserve(seg_bytes / 192 + 16); names->resize(0); names->reserve(seg_bytes / 12); }
+    auto extract_upto = [&](uint64_t have) {            // every record that ends at or before `have`
+        while (lite_ok && n_lite < rec_off.size()) {
+            const uint64_t a = rec_off[n_lite], e = n_lite + 1 < rec_off.size() ? rec_off[n_lite + 1] : next_first;
+            if (e > have || e == 0) break;
+            ReadLite L;
+            const char *msg = nullptr;
+            if (extract_record(buf.data.data() + (a - s.ioff0), n_ref, *names, L, msg) != ISX_OK) { lite_ok = false; break; }
+            lite->push_back(L);
+            n_lite++;
+        }
+    };
+    next_first = 0;                                     // (the end of the last record in rec_off while the walk runs: kept in `off`)
+    uint64_t off = first;
+    if (guess) {
+        for (int k = 0; k < 4 && buf.b_end < s.b1; k++) if (!inflate_next()) return false;
+        off = seg_guess(B, inf, s, buf);                // (brings further blocks in itself when a candidate chain needs them)
+        *guess_out = off;
+    }
+    bool walking = off != ~0ull;
+    for (;;) {
+        if (walking) {
+            const uint64_t have = s.ioff0 + buf.data.size();
+            const uint8_t *d = buf.data.data();
+            while (off < s.ioff1 && off + 4 <= have) {
+                const int32_t block = rd32(d + (off - s.ioff0));
+                if (block < 32 || off + 4 + (uint64_t)block > B.total_inflated) { walking = false; *hop_rc = ISX_ERR_IO; break; }
+                rec_off.push_back(off);
+                off += 4 + (uint64_t)block;
+            }
+            next_first = off;
+            extract_upto(have);
+        }
+        if (buf.b_end >= s.b1) break;
+        if (!inflate_next()) return false;
+    }
+    if (walking) {
+        // what is left: a record whose size field straddles the segment's end, and the bytes of the last record beyond it
+        while (off < s.ioff1) {
+            if (off + 4 > B.total_inflated) { *hop_rc = ISX_ERR_IO; break; }
+            if (!seg_need(B, inf, s, buf, off, 4)) return false;
+            const int32_t block = rd32(buf.data.data() + (off - s.ioff0));
+            if (block < 32 || off + 4 + (uint64_t)block > B.total_inflated) { *hop_rc = ISX_ERR_IO; break; }
+            rec_off.push_back(off);
+            off += 4 + (uint64_t)block;
+        }
+        if (*hop_rc == ISX_OK && !rec_off.empty() && !seg_need(B, inf, s, buf, rec_off.back(), off - rec_off.back())) return false;
+        if (*hop_rc != ISX_OK) isx_set_error("truncated BAM record");
+        next_first = off;
+        if (*hop_rc == ISX_OK) extract_upto(s.ioff0 + buf.data.size());
+    }
+    next_first = off;
+    if (lite_rc) *lite_rc = (lite_ok && *hop_rc == ISX_OK && n_lite == rec_off.size()) ? ISX_OK : ISX_ERR_STATE;
+    return true;
 }
 
 // open-addressing (hash of name) -> local pair index
@@ -1109,6 +1204,7 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     const size_t n_ref = B.ref_name.size(), n_seg = B.segs.size();
     const bool timing = getenv("ISX_BAM_TIMING") != nullptr;       // tuning aid: stage times on stderr (no effect on results)
     double t_inflate = 0, t_hop = 0, t_extract = 0;
+    std::atomic<uint64_t> thr_guess_us{0};
     std::atomic<uint64_t> thr_inflate_us{0}, thr_hop_us{0};        // (timing only) summed over the pool's threads: block decode / guess + record walk
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
@@ -1137,21 +1233,20 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
         std::atomic<int> bad{0};
         // every segment: inflate, guess where its first record starts, walk its records from there (all in parallel) ...
         std::vector<uint64_t> guess(w1 - w0, ~0ull), nexts(w1 - w0, 0);
-        std::vector<int> hop_rc(w1 - w0, ISX_OK);
+        std::vector<int> hop_rc(w1 - w0, ISX_OK), lite_rc(w1 - w0, ISX_ERR_STATE);      // lite_rc OK: the sweep extracted every record of its walk
         pool.run((int)(w1 - w0), [&](int i) {
             Inflater inf;
             const Segment &s = B.segs[w0 + (size_t)i];
             const double ta = timing ? now() : 0.0;
-            if (!seg_inflate(B, inf, s, bufs[(size_t)i])) { bad.store(1); return; }
-            const double tb = timing ? now() : 0.0;
-            uint64_t g = (w0 + (size_t)i == 0) ? std::max(B.first_rec, s.ioff0) : seg_guess(B, inf, s, bufs[(size_t)i]);
-            if (w0 + (size_t)i == 0 && B.first_rec > s.ioff1) g = ~0ull;
+            const bool is_first = w0 + (size_t)i == 0;
+            uint64_t g = is_first ? std::max(B.first_rec, s.ioff0) : ~0ull;
+            if (is_first && B.first_rec > s.ioff1) g = ~0ull;
+            const bool do_guess = !is_first;
+            if (!seg_inflate_hop(B, inf, s, bufs[(size_t)i], g, do_guess, &g, recs[(size_t)i], nexts[(size_t)i], &hop_rc[(size_t)i],
+                                 &B.seg_reads[w0 + (size_t)i], &B.seg_names[w0 + (size_t)i], &lite_rc[(size_t)i])) { bad.store(1); return; }
             guess[(size_t)i] = g;
-            if (g != ~0ull) {
-                std::string keep_err = "";
-                hop_rc[(size_t)i] = seg_hop(B, inf, s, bufs[(size_t)i], g, recs[(size_t)i], nexts[(size_t)i]);
-            }
-            if (timing) { const double tc = now(); thr_inflate_us.fetch_add((uint64_t)((tb - ta) * 1e3)); thr_hop_us.fetch_add((uint64_t)((tc - tb) * 1e3)); }
+            const double tb = timing ? now() : 0.0, tg = tb;
+            if (timing) { const double tc = now(); thr_inflate_us.fetch_add((uint64_t)((tb - ta) * 1e3)); thr_hop_us.fetch_add((uint64_t)((tc - tb) * 1e3)); thr_guess_us.fetch_add((uint64_t)((tg - tb) * 1e3)); }
         });
         if (bad.load()) { isx_set_error("BGZF inflate failed"); return ISX_ERR_IO; }
         { const double t = now(); t_inflate += t - t_mark; t_mark = t; }
@@ -1162,11 +1257,11 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
             Segment &s = B.segs[si];
             const size_t k = si - w0;
             if (!have_first) {                  // a share's run-in: start from the structural guess
-                if (guess[k] == ~0ull) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; recs[k].clear(); continue; }
+                if (guess[k] == ~0ull) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; recs[k].clear(); lite_rc[k] = ISX_ERR_STATE; continue; }
                 first = guess[k];
                 have_first = true;
             }
-            if (first > s.ioff1) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; recs[k].clear(); continue; }    // a record spans the whole segment
+            if (first > s.ioff1) { s.first_rec = s.ioff1; s.read0 = read_ord; s.n_reads = 0; recs[k].clear(); lite_rc[k] = ISX_ERR_STATE; continue; }    // a record spans the whole segment
             s.first_rec = std::max(first, s.ioff0);
             if (!verified && s.first_rec < s.ioff1 && guess[k] != ~0ull && si > sv) {
                 // the run-in of a share: the chain started from a structural guess.  The next segment's own, independent guess
@@ -1182,9 +1277,10 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
                 return ISX_ERR_IO;
             }
             uint64_t next = first;
-            if (s.first_rec >= s.ioff1) { recs[k].clear(); next = first; }
+            if (s.first_rec >= s.ioff1) { recs[k].clear(); lite_rc[k] = ISX_ERR_STATE; next = first; }
             else if (guess[k] == s.first_rec && hop_rc[k] == ISX_OK) next = nexts[k];
             else {
+                lite_rc[k] = ISX_ERR_STATE;         // (the sweep walked -- and extracted -- from a wrong start)
                 const int rc = seg_hop(B, inf, s, bufs[k], s.first_rec, recs[k], next);
                 if (rc != ISX_OK) return rc;
             }
@@ -1195,6 +1291,7 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
         { const double t = now(); t_hop += t - t_mark; t_mark = t; }
         std::atomic<int> rc_any{0};
         pool.run((int)(w1 - w0), [&](int i) {
+            if (lite_rc[(size_t)i] == ISX_OK && B.seg_reads[w0 + (size_t)i].size() == recs[(size_t)i].size() && !getenv("ISX_BAM_NO_FUSED_EXTRACT")) return;   // done in the sweep
             const int rc = scan_segment(B, (uint32_t)(w0 + (size_t)i), bufs[(size_t)i], recs[(size_t)i], errs[w0 + (size_t)i]);
             if (rc != ISX_OK) rc_any.store(rc);
         });
@@ -1419,8 +1516,8 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     });
     if (timing) fprintf(stderr, "[isx_bam_scan] share %d/%d: segments [%zu, %zu) of %zu, %d threads: inflate %.1f ms, record walk %.1f ms, field extraction %.1f ms, pair tables %.1f ms (bucketing %.1f, tables %.1f, merge %.1f); %.1f ms since the scan began\n",
                         part, n_parts, sv, s_end, n_seg, pool.size(), t_inflate, t_hop, t_extract, now() - t_mark, t_bucket - t_mark, t_tables - t_bucket, now() - t_tables, now() - t_begin);
-    if (timing) fprintf(stderr, "[isx_bam_scan]   inside 'inflate', summed over the threads: block decode + buffers %.1f ms, start guess + record walk %.1f ms\n",
-                        thr_inflate_us.load() / 1e3, thr_hop_us.load() / 1e3);
+    if (timing) fprintf(stderr, "[isx_bam_scan]   inside 'inflate', summed over the threads: block decode + buffers %.1f ms, start guess + record walk %.1f ms (guess %.1f)\n",
+                        thr_inflate_us.load() / 1e3, thr_hop_us.load() / 1e3, thr_guess_us.load() / 1e3);
     {
         size_t bytes = 0;
         for (const auto &v : B.seg_reads) bytes += v.size() * sizeof(ReadLite);

@@ -223,15 +223,35 @@ class SplitObject():
     profile_utilities.py:823-858).  covT / clonT / clonTR / raw_snp_table / raw_linkage_table are cut out of the
     batch's tables the first time they are read.'''
     _LAZY = ('covT', 'clonT', 'clonTR', 'raw_snp_table', 'raw_linkage_table', 'pileup_counts', 'read_to_snvs', 'mm_to_position_graph')
+    # the plain fields too are read off the batch's split table on first access: a 1000-genome database is tens of thousands of
+    # splits a batch, and building every object's strings eagerly was a fifth of profile_bam's time on it
+    _META = ('scaffold', 'split_number', 'bam', 'length', 'min_freq', 'log')
 
     def __init__(self):
         pass
 
+    @classmethod
+    def _of_batch(cls, tables, i):
+        S = cls.__new__(cls)
+        S.__dict__['_src'] = (tables, i)
+        return S
+
     def __getattr__(self, name):                    # only reached when the attribute is not set yet
         src = self.__dict__.get('_src')
-        if src is None or name not in SplitObject._LAZY:
+        if src is None or (name not in SplitObject._LAZY and name not in SplitObject._META):
             raise AttributeError(name)
         tables, i = src
+        if name in SplitObject._META:
+            m = tables.meta
+            d = self.__dict__
+            d['scaffold'] = m['scaffold'][i]
+            d['split_number'] = int(m['number'][i])
+            d['bam'] = m['bam']
+            d['length'] = int(m['length'][i])
+            d['min_freq'] = m['min_freq']
+            unit = "{0}.{1}".format(d['scaffold'], d['split_number'])    # profile_utilities.py:133-134, 212-214
+            d['log'] = get_worker_log('SplitProfile', unit, 'start', m['t_start'], m['mem']) + get_worker_log('SplitProfile', unit, 'end', m['t_end'], m['mem'])
+            return d[name]
         if name in ('covT', 'clonT', 'clonTR'):
             self.covT, self.clonT, self.clonTR = tables.basewise(i)
         elif name == 'raw_snp_table':
@@ -252,7 +272,7 @@ class SplitObject():
 
     def materialize(self):
         """cut this split's tables out of the batch and let go of the batch"""
-        for a in ('covT', 'raw_snp_table', 'raw_linkage_table'):
+        for a in ('scaffold', 'covT', 'raw_snp_table', 'raw_linkage_table'):
             getattr(self, a)
         src = self.__dict__.get('_src')
         if src is not None and src[0].pileup_counts is not None:
@@ -517,21 +537,10 @@ def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_o
     """Batch result (engine.Batch.fetch() / Pipe.collect()) -> list of SplitObject, one per split, in split order.
     started: time.time() when the batch's profiling began (the start stamp of every split's worker log)."""
     tables = _BatchTables(res, split_bounds, split_scaffold, scaffold_offset, min_cov)
-    out = []
     t_end, mem = time.time(), _rss()
-    t_start = t_end if started is None else started
-    for i in range(len(split_bounds) - 1):
-        S = SplitObject()
-        S.scaffold = split_scaffold[i]
-        S.split_number = int(split_number[i])
-        S.bam = bam_name
-        S.length = int(split_seq_len[i])
-        S.min_freq = min_freq
-        unit = "{0}.{1}".format(S.scaffold, S.split_number)    # profile_utilities.py:133-134, 212-214
-        S.log = get_worker_log('SplitProfile', unit, 'start', t_start, mem) + get_worker_log('SplitProfile', unit, 'end', t_end, mem)
-        S._src = (tables, i)
-        out.append(S)
-    return out
+    tables.meta = {'scaffold': split_scaffold, 'number': split_number, 'length': split_seq_len, 'bam': bam_name, 'min_freq': min_freq,
+                   't_start': t_end if started is None else started, 't_end': t_end, 'mem': mem}
+    return [SplitObject._of_batch(tables, i) for i in range(len(split_bounds) - 1)]
 
 
 def profile_splits(ctx, scaffolds, sequences, obs, pair, null_model, n_mm_bins, window_length=10000, bam_name=None,
@@ -833,8 +842,10 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             return splits
 
         def take(splits):
-            for S in splits:
-                out["{0}.{1}".format(S.scaffold, S.split_number)] = S
+            if not splits:
+                return
+            m = splits[0]._src[0].meta              # (the keys straight from the batch's split table: no per-object field is realised)
+            out.update(zip(map("{0}.{1}".format, m['scaffold'], m['number']), splits))
 
         def run_alone(items):
             """a group whose batch failed: scaffold by scaffold, so that only the offender is dropped"""

@@ -302,7 +302,7 @@ def test_c5_per_gpu_shard_read_segments(ctx):
     kept = meta.kept_genomes()
     shard = kept[idist.lpt_shards(meta.pairs[kept], 8)[0]]
     est = (meta.pairs[shard] * 2).astype(np.int64)
-    batches = idist.pack_batches(meta.length[shard], est, 40_000_000, 1_000_000)         # bench.py's cut
+    batches = idist.pack_batches(meta.length[shard], est, 40_000_000, 1_000_000)         # (a finer cut than the bench's: 8+ batches)
     assert len(batches) >= 8
     ws = [meta.generate_segs(shard[b]) for b in batches]
     assert max(len(w["scaffold_bounds"]) - 1 for w in ws) >= 300                          # hundreds of contigs in one flat space
@@ -411,3 +411,95 @@ def test_c4_per_gpu_shard_read_segments(ctx):
     _same_tables(ro, deepest[2], ("snv", "ld"), "C4 batch: observations vs segments")
     po.release(t)
     po.close()
+
+
+def test_c5_headline_configuration_exactly():
+    """bench.py's headline, as it is timed: rank 0's C5 shard cut by bench.C5_BATCH_POS / C5_BATCH_SEGS (nothing restated), lean slots,
+    a context with bench.C5_RESERVE_CUS compute units reserved, pipe depth 8, every batch handed over by isx_pipe_submit_planes (bit
+    planes from the caller's arrays, staged inside the submit) -- and the same batches as pre-staged wires (the round-4 way, an extra
+    of the line).  Every batch: exact per-position coverage from the host, SNV rows ordered / consistent / on the reference, LD rows
+    inside a scaffold and adding up, clonality exactly where coverage reaches min_cov; the largest batch: SNV counts base by base;
+    one batch byte-equal to a plain pipe (plain slots, isx_segs hand-over, no reserve, depth 1)."""
+    import bench
+    from instrain_amd import engine, synth
+    lut, fb = util.load_lut()
+    ctx5 = engine.Context(0, reserve_cus=bench.C5_RESERVE_CUS)
+    ctx5.set_null_model(lut, fb)
+    run = bench.C5Run(ctx5, 0, 8, 8, depth=8)
+    assert run.pipe.read_level and bench.LEAN_SLOTS and bench.C5_LINKAGE
+    assert max(w["n_pos"] for w in run.ws) <= bench.C5_BATCH_POS and max(w["n_seg"] for w in run.ws) <= bench.C5_BATCH_SEGS + 2 * 10 ** 5
+    assert 2 <= len(run.ws) <= 8 and 0.9e9 < run.bases < 1.5e9
+    exp = {}
+    big = int(np.argmax([w["n_pos"] for w in run.ws]))
+    seen = {False: [], True: []}
+
+    def make_check(staged):
+        def check(i, r):
+            w = run.ws[i]
+            if i not in exp:
+                exp[i] = bench.planes_coverage(w)[0]
+            assert ("cov4" in r) == (w["n_obs"] < 6 * w["n_pos"])                # lean slot: the 4-bit plane for a shallow batch
+            cov = engine.dense_cov(r, w["n_pos"]).astype(np.int64)
+            if "saturated" in r:
+                cov[r["saturated"]["gpos"]] = r["saturated"]["coverage"]
+            assert (cov == exp[i]).all() and int(cov.sum()) == w["n_obs"]
+            snv, ld = r["snv"], r["ld"]
+            g = snv["gpos"].astype(np.int64)
+            assert len(snv) == r["sizes"]["n_snv"] > 0 and (np.diff(g) > 0).all()
+            assert (snv["cnt"].sum(axis=1) == cov[g]).all() and (cov[g] >= 5).all()
+            ref2 = w["ref_planes"].plane2
+            assert (snv["ref_base"] == ((ref2[g >> 2] >> (2 * (g & 3)).astype(np.uint8)) & 3)).all()
+            sb = w["scaffold_bounds"]
+            if len(ld):
+                assert (np.searchsorted(sb, ld["gpos_a"], side="right") == np.searchsorted(sb, ld["gpos_b"], side="right")).all()
+                assert (ld["countAB"].astype(np.int64) + ld["countAb"] + ld["countaB"] + ld["countab"] == ld["total"]).all()
+            cl = engine.dense_clon(cov, r["clon_sparse"], 5) if "clon_sparse" in r else r["clon"]
+            assert np.isnan(cl[cov < 5]).all() and not np.isnan(cl[cov >= 5]).any()
+            assert r["stats"]["record_bytes"] == 32 and r["stats"]["encode_passes"] == (0 if staged else r["stats"]["encode_passes"])
+            if i == big:
+                _, per_base = bench.planes_coverage(w, per_base_at=g)
+                assert (per_base == snv["cnt"]).all()
+            seen[staged].append((i, snv.tobytes(), ld.tobytes(), cl.view(np.uint32).tobytes(), r["sizes"]))
+        return check
+
+    sig = run.verify_pass()                                # bench.py's own untimed pass (incl. its exact check of the largest batch)
+    assert len(sig) == len(run.ws) and run.exact_checked["batch"] == big
+    run.checked_pass(make_check(False), staged=False)
+    run.checked_pass(make_check(True), staged=True)
+    assert len(seen[False]) == len(run.ws) and sorted(x[0] for x in seen[True]) == list(range(len(run.ws)))
+    by_i = {x[0]: x for x in seen[False]}
+    for x in seen[True]:                                    # staged wires == planes handed over inside the step
+        assert x[1:] == by_i[x[0]][1:]
+    # the timed configuration's passes are deterministic
+    stats = []
+    run.run(2, stats)
+    run.check_timed(stats)
+    # one batch through a PLAIN pipe: plain slots, segments (3-bit words) rebuilt from the planes, no reserve, depth 1
+    k = int(np.argmin([w["n_pos"] for w in run.ws]))
+    w = run.ws[k]
+    pb = w["planes"]
+    two = np.unpackbits(np.ascontiguousarray(pb.planes[:, 0:5]).view(np.uint8), axis=1, bitorder="little")[:, :300].reshape(pb.n_seg, 150, 2)
+    code = (two[:, :, 0] | (two[:, :, 1] << 1)).astype(np.uint8)
+    skip = np.unpackbits(np.ascontiguousarray(pb.planes[:, 5:8]).view(np.uint8), axis=1, bitorder="little")[:, :150].astype(bool)
+    code[skip | (np.arange(150)[None, :] >= pb.len[:, None])] = 4
+    segs = engine.SegBatch(pb.gpos, pb.len, engine.pack_codes(code), None, pb.pair)
+    del two, skip, code
+    rp = w["ref_planes"]
+    refc = ((rp.plane2[np.arange(w["n_pos"]) >> 2] >> (2 * (np.arange(w["n_pos"]) & 3)).astype(np.uint8)) & 3).astype(np.uint8)
+    if rp.nplane is not None:
+        refc[np.unpackbits(rp.nplane, bitorder="little")[:w["n_pos"]].astype(bool)] = 4
+    run.close()
+    ctx5.close()
+    ctx = engine.Context(0)
+    ctx.set_null_model(lut, fb)
+    plain = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=0, max_segs=segs.n_seg, max_splits=len(w["split_bounds"]), depth=1, host_threads=8,
+                        pin_threads=False, n_mm_bins=1, enable_linkage=True, min_snp=20)
+    t = plain.submit_reads(refc, w["split_bounds"], segs)
+    r = plain.collect(t)
+    cl = r["clon"]
+    assert (r["cov16"].astype(np.int64) == exp[k]).all()
+    assert r["snv"].tobytes() == by_i[k][1] and r["ld"].tobytes() == by_i[k][2] and cl.view(np.uint32).tobytes() == by_i[k][3]
+    assert r["sizes"] == by_i[k][4]
+    plain.release(t)
+    plain.close()
+    ctx.close()

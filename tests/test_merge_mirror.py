@@ -79,6 +79,31 @@ def test_mirror_merge_of_oracle_tables_equals_reference_merge():
     check_profile(P, "single", z)
 
 
+def test_split_objects_realise_their_fields_on_demand():
+    """tables_to_splits makes one cheap object per split (a 1000-genome database is tens of thousands a batch): the plain fields and
+    the WorkerLog lines (logUtils.py:939-975 format) appear on first access, pickling carries the split's own tables"""
+    import pickle
+    from instrain_amd.profile import profile_utilities as ours
+    m = _golden_module()
+    lut, fb = util.load_lut()
+    z, seqs, pos, base, mm, pair = _inputs()
+    res, bounds, s_scaff, s_num, s_off, s_len = m.oracle_batch_tables(seqs, pos, base, mm, pair, lut, fb)
+    splits = ours.tables_to_splits(res, bounds, s_scaff, s_num, s_off, s_len, 0.05, "x.bam", started=123.5)
+    assert len(splits) == len(s_scaff) and all(list(vars(S)) == ["_src"] for S in splits)          # nothing realised yet
+    for i, S in enumerate(splits):
+        assert hasattr(S, "log") and not hasattr(S, "no_such_field")
+        assert (S.scaffold, S.split_number, S.bam, S.length, S.min_freq) == (s_scaff[i], int(s_num[i]), "x.bam", int(s_len[i]), 0.05)
+        lines = S.log.split("\n")
+        assert lines[0] == "" and len(lines) == 3
+        for ln, status in zip(lines[1:], ("start", "end")):
+            w = ln.split()
+            assert w[:4] == ["WorkerLog", "SplitProfile", "%s.%d" % (s_scaff[i], int(s_num[i])), status] and len(w) == 7
+        assert float(lines[1].split()[5]) == 123.5
+    T = pickle.loads(pickle.dumps(splits[1]))
+    assert "_src" not in vars(T) and T.scaffold == splits[1].scaffold and T.log == splits[1].log
+    assert T.raw_snp_table.equals(splits[1].raw_snp_table) and sorted(T.covT) == sorted(splits[1].covT)
+
+
 @pytest.mark.gpu
 def test_device_tables_through_the_mirror_merge_equal_reference_merge():
     from instrain_amd import engine
