@@ -584,6 +584,40 @@ class C5Run:
         n = len(self.ws)
         return stream(self.pipe, self.ws, n * passes, self.depth, stats, keep_last=keep_last, wires=self.wires if staged else None)
 
+    def gather_pass(self):
+        """one untimed pass whose tables are KEPT: what this rank contributes to the path's one collective (the final gather of the
+        profile on rank 0, SURVEY 8e / profile_controller.py:195-233): every batch's SNV rows and LD rows (flat positions made unique
+        over the rank by the batch's offset in the rank's own flat space) and a per-scaffold coverage summary (covered positions, summed
+        coverage: what the merge step's cumulative tables start from)"""
+        from instrain_amd import engine
+        snv, ld, summ = [], [], []
+        off = np.r_[0, np.cumsum([w["n_pos"] for w in self.ws])].astype(np.int64)
+        summ_dt = np.dtype([("genome", "<i4"), ("scaffold", "<i4"), ("length", "<i8"), ("covered", "<i8"), ("sum_cov", "<i8")])
+
+        def keep(i, r):
+            w = self.ws[i]
+            a = np.zeros(len(r["snv"]), dtype=[("rank_pos", "<i8")] + r["snv"].dtype.descr)
+            for k in r["snv"].dtype.names:
+                a[k] = r["snv"][k]
+            a["rank_pos"] = r["snv"]["gpos"].astype(np.int64) + off[i]
+            snv.append(a)
+            b = np.zeros(len(r["ld"]), dtype=[("rank_pos_a", "<i8")] + r["ld"].dtype.descr)
+            for k in r["ld"].dtype.names:
+                b[k] = r["ld"][k]
+            b["rank_pos_a"] = r["ld"]["gpos_a"].astype(np.int64) + off[i]
+            ld.append(b)
+            cov = engine.dense_cov(r, w["n_pos"]).astype(np.int64)
+            sb = w["scaffold_bounds"]
+            t = np.zeros(len(sb) - 1, dtype=summ_dt)
+            t["genome"], t["scaffold"], t["length"] = w["scaffold_genome"], np.arange(len(sb) - 1), np.diff(sb)
+            t["sum_cov"] = np.add.reduceat(cov, sb[:-1])
+            t["covered"] = np.add.reduceat((cov > 0).astype(np.int64), sb[:-1])
+            summ.append(t)
+
+        stream(self.pipe, self.ws, len(self.ws), self.depth, check=keep)
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
+        return {"snv": cat(snv, snv[0].dtype if snv else np.dtype("u1")), "ld": cat(ld, ld[0].dtype if ld else np.dtype("u1")), "summary": cat(summ, summ_dt)}
+
     def staged_replay(self, passes=4):
         """round 4's headline as an extra: batches staged once (untimed), a pass = DMA + kernels + tables back"""
         if self.wires is None:
@@ -1026,18 +1060,23 @@ def main():
     c5 = C5Run(ctx5, rank, world, host_threads, depth=args.depth, scale=args.scale, stage_async=args.queued_submit)
     _trace("C5 verify pass")
     c5.verify_pass()                            # untimed: every batch's tables checked on the host; also warms every slot
+    # N > 1: the job is the same whole database (strong scaling), so a rank's pass shrinks to a few ms -- a STEP is then PPS passes
+    # back to back (the rate is what is reported; the timed region must be long against a barrier's jitter)
+    PPS = 1 if world == 1 else int(os.environ.get("ISX_BENCH_PASSES_PER_STEP", 2 * world))
     if args.warmup:
-        c5.run(args.warmup)
+        c5.run(args.warmup * PPS)
     barrier()
     torch.cuda.synchronize()
     stats = []
     t0 = time.perf_counter()
-    last = c5.run(args.steps, stats, keep_last=world > 1)
+    c5.run(args.steps * PPS, stats)
     torch.cuda.synchronize()
+    dt_mine = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     c5.check_timed(stats)
     bases_all = c5.bases
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1045,20 +1084,45 @@ def main():
         u = torch.tensor([c5.bases], dtype=torch.float64, device=dev)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         bases_all = float(u.item())
+        mine = torch.tensor([dt_mine, c5.bases, float(len(c5.ws))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+        pass_ms = allr[:, 0] / (args.steps * PPS) * 1e3
+        per_rank = {"pass_ms": [round(float(x), 3) for x in pass_ms], "pass_ms_min": float(pass_ms.min()), "pass_ms_max": float(pass_ms.max()),
+                    "gbp_per_pass": [round(float(x) / 1e9, 4) for x in allr[:, 1]], "batches": [int(x) for x in allr[:, 2]],
+                    "time_imbalance": float(pass_ms.max() / pass_ms.mean()), "passes_per_step": PPS}
 
-    # the one collective of the path: final gather of the SNV tables to rank 0 (outside the timed steps)
-    gather_ms = None
+    # the one collective of the path: the final gather of ONE pass's whole profile to rank 0 -- every batch's SNV rows and LD rows and
+    # the per-scaffold summaries -- outside the timed steps, timed on its own
+    gather_ms = gathered = None
     if world > 1:
+        mine_tables = c5.gather_pass()
         torch.cuda.synchronize()
         barrier()
         g0 = time.perf_counter()
-        idist.gather_tables({"snv": last["snv"]}, dst=0, device=dev)
+        got = idist.gather_tables(mine_tables, dst=0, device=dev)
         torch.cuda.synchronize()
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
-    head = c5.report(dt, bases_all, stats, args.steps, gather_ms)
-    if rank == 0 and world == 1 and (not args.only_c5 or os.environ.get("ISX_BENCH_STAGED")):
-        head["staged_replay"] = c5.staged_replay()
+        if rank == 0:
+            gathered = {"rows": {k: int(len(v)) for k, v in got.items()}, "bytes": int(sum(v.nbytes for v in got.values())),
+                        "my_bytes": int(sum(v.nbytes for v in mine_tables.values()))}
+        del mine_tables, got
+    head = c5.report(dt, bases_all, stats, args.steps * PPS, gather_ms)
+    if per_rank is not None:
+        head["per_rank"] = per_rank
+        head["final_gather"] = gathered
+    if (world == 1 and rank == 0 and (not args.only_c5 or os.environ.get("ISX_BENCH_STAGED"))) or world > 1:
+        # (N > 1: every rank replays its own staged images -- the device side of the scaling curve, free of the host stager's share of
+        # the node's cpus; aggregated below)
+        rep = c5.staged_replay(passes=4 * PPS)
+        if world > 1:
+            barrier()
+            u = torch.tensor([rep["ms_per_pass"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(u, op=dist.ReduceOp.MAX)
+            rep = dict(rep, ms_per_pass=float(u.item()), gbp_per_s=bases_all / (float(u.item()) * 1e-3) / 1e9, note="max over ranks of a rank's own replay time")
+        head["staged_replay"] = rep
     if rank == 0 and world == 1 and (not args.only_c5 or os.environ.get("ISX_BENCH_RESIDENT_REF")):
         head["resident_reference"] = c5.resident_reference_passes()         # (last: the wires keep their device copies from here on)
     cb = cp = None
@@ -1083,7 +1147,7 @@ def main():
         detail = {"c5": head}
         out = {
             "metric": "Gbp profiled/s", "value": head["gbp_per_s"], "unit": "Gbp/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "passes_per_step": PPS,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "world_size_seen": world, "backend": (dist.get_backend() if world > 1 else None),
             "config": {"workload": _short("C5: 1000-genome database, 10 Gbp reads, --database_mode, pileup+SNV call+linkage; step = whole pass%s"
@@ -1108,6 +1172,9 @@ def main():
         out["roofline"]["kernel"] = _short(out["roofline"]["kernel"], 80)
         if gather_ms is not None:
             out["final_gather_ms"] = gather_ms
+            out["final_gather"] = gathered
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if cb is not None:
             detail["cpu_baseline"], detail["cpu_baseline_python"] = cb, cp
             out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],

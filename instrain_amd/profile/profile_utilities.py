@@ -45,9 +45,25 @@ def iterate_splits(sLen, window_length=10000):
 # ---------------------------------------------------------------------------------------------------------
 # result carriers
 # ---------------------------------------------------------------------------------------------------------
+_COPIERS = None
+
+
 def _own(a):
-    """a numpy array that stays valid after the pipe slot it may point into is released"""
-    return a if (a.flags.owndata or isinstance(a.base, np.ndarray) and a.base.flags.owndata) else np.array(a)
+    """a numpy array that stays valid after the pipe slot it may point into is released (a position-sized table of a metagenome batch
+    is hundreds of MB: pieces are copied side by side -- numpy's copy loop runs without the GIL)"""
+    if a.flags.owndata or isinstance(a.base, np.ndarray) and a.base.flags.owndata:
+        return a
+    if a.nbytes < (16 << 20) or not a.flags.c_contiguous:
+        return np.array(a)
+    global _COPIERS
+    if _COPIERS is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPIERS = ThreadPoolExecutor(6)
+    out = np.empty_like(a)
+    n = len(a)
+    step = -(-n // 12)
+    list(_COPIERS.map(lambda k: np.copyto(out[k:k + step], a[k:k + step]), range(0, n, step)))
+    return out
 
 
 def _cuts(col, bounds):

@@ -453,6 +453,26 @@ def test_bench_two_ranks_control_flow(tmp_path):
     assert j["scaling"] == "strong" and j["value"] > 0 and "final_gather_ms" in j
     assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j and j["bam_sharded_gbp_per_s"] > 0
     assert "C5" in j["config"]["workload"]
+    # the gather is the whole profile of one pass (every batch's SNV + LD rows + per-scaffold summaries), the ranks' own times are in the line
+    fg, pr = j["final_gather"], j["per_rank"]
+    assert fg["rows"]["snv"] > 0 and fg["rows"]["summary"] > 0 and fg["bytes"] > fg["my_bytes"] > 0
+    assert pr["passes_per_step"] == 4 == j["passes_per_step"] and len(pr["pass_ms"]) == 2 and pr["pass_ms_max"] >= pr["pass_ms_min"] > 0
+    assert j["c5_staged_replay_gbp_per_s"] > 0
+
+
+def test_bench_eight_ranks_control_flow(tmp_path):
+    """the N = 8 control flow on one GPU (gloo, the ranks share the device): one LPT shard of the database per rank, 16 passes a step,
+    per-rank pass times, the final gather of all eight ranks' tables on rank 0"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(util.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ISX_DIST_BACKEND", "ISX_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--scale", "0.04", "--depth", "2",
+                        "--host-threads", "2", "--only-c5", "--detail", str(tmp_path / "d.json")], env=env, capture_output=True, text=True, timeout=1500)
+    j = _bench_line(r)
+    assert j["n_gpus"] == 8 and j["world_size_seen"] == 8 and j["value"] > 0 and j["passes_per_step"] == 16
+    assert len(j["per_rank"]["pass_ms"]) == 8 and min(j["per_rank"]["batches"]) >= 1
+    assert j["final_gather"]["rows"]["snv"] > 0 and j["final_gather_ms"] > 0
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
