@@ -19,17 +19,34 @@ def _dlist():
     return defaultdict(list)
 
 
+class SortedAlleleObs:
+    """A batch's allele observations sorted ONCE by position: every split then cuts its rows with two bisections instead of masking the
+    whole batch's array (a 64 Mbp batch has thousands of splits and millions of rows: O(splits x rows) otherwise)."""
+
+    def __init__(self, ao):
+        order = np.argsort(ao["gpos"], kind="stable")
+        self.rows = ao[order]
+        self.gpos = np.ascontiguousarray(self.rows["gpos"]).astype(np.int64)
+
+    def cut(self, lo, hi):
+        a, b = np.searchsorted(self.gpos, [int(lo), int(hi)])
+        return self.rows[a:b]
+
+
 def read_to_snvs_of_split(ao, lo, hi, pair_names=None):
     """Allele observations of one split -> read_to_snvs: mm -> read name -> ["position:base", ...] with positions relative to
     the split's start (RelPosition, profile_utilities.py:244, 263-265), a read's entries in column order and, inside a column,
-    in the order the pileup visited the mates.  ao: the batch's rows (engine.Batch.fetch_allele_obs); [lo, hi): the split's range
-    of flat positions; pair_names: dense pair id -> read-pair name (None: the id itself, as "r<id>" has no meaning here)."""
+    in the order the pileup visited the mates.  ao: the batch's rows (engine.Batch.fetch_allele_obs) or a SortedAlleleObs of them;
+    [lo, hi): the split's range of flat positions; pair_names: dense pair id -> read-pair name (None: the id itself, as "r<id>" has
+    no meaning here)."""
     out = defaultdict(_dlist)
-    g = ao["gpos"].astype(np.int64)
-    sel = np.flatnonzero((g >= lo) & (g < hi))
-    if not len(sel):
+    if isinstance(ao, SortedAlleleObs):
+        a = ao.cut(lo, hi)
+    else:
+        g = ao["gpos"].astype(np.int64)
+        a = ao[np.flatnonzero((g >= lo) & (g < hi))]
+    if not len(a):
         return out
-    a = ao[sel]
     order = np.lexsort((a["order"], a["gpos"], a["pair"], a["mm"]))
     a = a[order]
     rel = a["gpos"].astype(np.int64) - int(lo)

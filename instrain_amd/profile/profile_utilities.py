@@ -137,6 +137,9 @@ class _BatchTables:
         # --store_everything: update_linked_reads' appends as the device holds them (read_to_snvs / mm_to_position_graph are
         # made from them per split, profile/linkage.py); pair_names: the batch's dense pair id -> read-pair name
         self.ao = res.get("allele_obs")
+        if self.ao is not None:                     # sorted by position once: a split cuts its rows by bisection (profile/linkage.py)
+            from . import linkage
+            self.ao = linkage.SortedAlleleObs(self.ao)
         self.pair_names = res.get("pair_names")
 
     # -- shrink_basewise (profile_utilities.py:337-350): dict mm -> sparse Series; a level that occurs in the split keeps
@@ -241,7 +244,7 @@ class SplitObject():
     _LAZY = ('covT', 'clonT', 'clonTR', 'raw_snp_table', 'raw_linkage_table', 'pileup_counts', 'read_to_snvs', 'mm_to_position_graph')
     # the plain fields too are read off the batch's split table on first access: a 1000-genome database is tens of thousands of
     # splits a batch, and building every object's strings eagerly was a fifth of profile_bam's time on it
-    _META = ('scaffold', 'split_number', 'bam', 'length', 'min_freq', 'log')
+    _META = ('scaffold', 'split_number', 'bam', 'length', 'min_freq', 'log', 'mm_clamped')   # mm_clamped: None, or the level pairs beyond it were merged into
 
     def __init__(self):
         pass
@@ -265,6 +268,7 @@ class SplitObject():
             d['bam'] = m['bam']
             d['length'] = int(m['length'][i])
             d['min_freq'] = m['min_freq']
+            d['mm_clamped'] = m.get('mm_clamped')
             unit = "{0}.{1}".format(d['scaffold'], d['split_number'])    # profile_utilities.py:133-134, 212-214
             d['log'] = get_worker_log('SplitProfile', unit, 'start', m['t_start'], m['mem']) + get_worker_log('SplitProfile', unit, 'end', m['t_end'], m['mem'])
             return d[name]
@@ -549,13 +553,13 @@ def _rss():
 
 
 def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_offset, split_seq_len, min_freq,
-                     bam_name=None, min_cov=5, started=None):
+                     bam_name=None, min_cov=5, started=None, mm_clamped=None):
     """Batch result (engine.Batch.fetch() / Pipe.collect()) -> list of SplitObject, one per split, in split order.
     started: time.time() when the batch's profiling began (the start stamp of every split's worker log)."""
     tables = _BatchTables(res, split_bounds, split_scaffold, scaffold_offset, min_cov)
     t_end, mem = time.time(), _rss()
     tables.meta = {'scaffold': split_scaffold, 'number': split_number, 'length': split_seq_len, 'bam': bam_name, 'min_freq': min_freq,
-                   't_start': t_end if started is None else started, 't_end': t_end, 'mem': mem}
+                   't_start': t_end if started is None else started, 't_end': t_end, 'mem': mem, 'mm_clamped': mm_clamped}
     return [SplitObject._of_batch(tables, i) for i in range(len(split_bounds) - 1)]
 
 
@@ -759,10 +763,16 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                     bf.set_r2m(tid, list(r2m.keys()), [0 if skip_mm else int(v) for v in r2m.values()])
             bf.scan(part=kwargs.get('scan_part'))    # refresh the totals (max_mm now comes from the controller's values)
         n_mm = 1 if skip_mm else int(bf.info["max_mm"]) + 1
+        mm_clamped = None
         if n_mm > 128:
             # the reference bins any mm (profile_utilities.py:268-286); a device batch holds 128 levels.  Rather than failing the
             # whole call, pairs beyond level 127 are piled up AT level 127 (their bases then appear one level early in the
-            # cumulative tables of the levels >= 127 only) -- loudly
+            # cumulative tables of the levels >= 127 only) -- loudly, on every SplitObject (S.mm_clamped = 127), and never under
+            # strict=True: a caller that asked for exactness gets the error instead of merged levels
+            if kwargs.get('strict'):
+                raise ValueError("a read pair with {0} mismatches: the device bins mm levels 0..127 (strict=True refuses to merge the levels "
+                                 "beyond; --skip_mm_profiling or a higher --min_read_ani avoids this)".format(n_mm - 1))
+            mm_clamped = 127
             logging.warning("a read pair with {0} mismatches: the device bins mm levels 0..127, pairs beyond are counted at level 127 "
                             "(--skip_mm_profiling or a higher --min_read_ani avoids this)".format(n_mm - 1))
             bf.set_mm_cap(127)
@@ -840,7 +850,7 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                     res["allele_obs"] = res["slot"].fetch_allele_obs()
                     res["pair_names"] = getattr(g, 'pair_names', None)
                 splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam,
-                                          min_cov=int(kwargs.get('min_cov', 5)), started=getattr(g, 't_submit', None))
+                                          min_cov=int(kwargs.get('min_cov', 5)), started=getattr(g, 't_submit', None), mm_clamped=mm_clamped)
                 if kwargs.get('scaffold_tables') is not None or kwargs.get('scaffold_levels') is not None:
                     sb = np.r_[0, np.cumsum([refs[tid][1] for tid in g.tids])]
                     levels, _ = res["slot"].summarize(sb)

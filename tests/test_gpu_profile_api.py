@@ -744,8 +744,8 @@ def test_store_everything_on_a_bam_names_the_reads(tmp_path):
 
 def test_pairs_beyond_128_mm_levels_are_clamped_not_fatal(tmp_path, caplog):
     """a controller's R2M with pairs of 200 mismatches (long reads, a low --min_read_ani): the device bins levels 0..127, such
-    pairs are piled up AT level 127 with a warning -- the same profile as an R2M that says 127 -- instead of an empty result;
-    strict=True turns a failing call into its exception"""
+    pairs are piled up AT level 127 with a warning -- the same profile as an R2M that says 127 -- instead of an empty result, and every
+    SplitObject says so (mm_clamped == 127); strict=True refuses to merge levels (ValueError) and turns any failing call into its exception"""
     import logging
     import instrain_amd.profile as prof
     from instrain_amd import engine
@@ -764,12 +764,15 @@ def test_pairs_beyond_128_mm_levels_are_clamped_not_fatal(tmp_path, caplog):
             k += 1
     assert k > 50
     with caplog.at_level(logging.WARNING):
-        a = prof.profile_bam(path, None, far, None, strict=True, **kw)
+        a = prof.profile_bam(path, None, far, None, **kw)
     assert any("counted at level 127" in r.message for r in caplog.records)
+    with pytest.raises(ValueError, match="strict=True refuses"):
+        prof.profile_bam(path, None, far, None, strict=True, **kw)
     b = prof.profile_bam(path, None, at127, None, strict=True, **kw)
     assert sorted(a) == sorted(b) and len(a) > 5
     for key in a:
         _same_split(a[key], b[key])
+        assert a[key].mm_clamped == 127 and b[key].mm_clamped is None
     assert max(max(S.covT) for S in a.values() if len(S.covT)) == 127
     # a call that fails as a whole: the exception itself with strict, a logged failure and a partial dict without
     with pytest.raises(Exception):
