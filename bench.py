@@ -919,7 +919,9 @@ def stream(pipe, variants, n_steps, depth, stats=None, keep_last=False, check=No
 
 def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
     """The round-3 headline as a leg: BASELINE configs[1] (C2: one 5 Mbp genome, 20x, --skip_mm_profiling, linkage off), one
-    batch per step streamed through a read-level pipe (N = 1 only)."""
+    batch per step streamed through a read-level pipe (N = 1 only).  Like the headline the leg's value is the INCLUSIVE hand-over:
+    every batch goes in from the caller's bit planes (isx_pipe_submit_planes, staged inside the step); beside it the same stream as
+    pre-staged pinned images (round 4's way) and with the isx_segs hand-over (round 3's: 3-bit words, byte compare)."""
     _trace("C2 stream")
     from instrain_amd import engine
     n_var = max(1, min(args.variants, steps))
@@ -927,33 +929,45 @@ def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
     pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=0, max_segs=int(w["segs"].n_seg),
                        max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
                        pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=args.queued_submit, lean_output=LEAN_SLOTS)
-    wires = [pipe.stage_reads(v["ref_codes"], v["split_bounds"], v["segs"]) for v in variants]
-    stream(pipe, variants, warmup, args.depth, wires=wires)
+    as_planes = [dict(v, planes=engine.PlaneBatch.from_segs(v["segs"], threads=host_threads), ref_planes=engine.RefPlanes.from_codes(v["ref_codes"], threads=host_threads))
+                 for v in variants]
+    k0 = warmup % n_var
+    rot = lambda xs: xs[k0:] + xs[:k0]
+    # (1) the leg's value: planes handed over inside the step
+    stream(pipe, as_planes, warmup, args.depth)
     stats = []
     t0 = time.perf_counter()
-    k0 = warmup % n_var
-    stream(pipe, variants[k0:] + variants[:k0], steps, args.depth, stats, wires=wires[k0:] + wires[:k0])
+    stream(pipe, rot(as_planes), steps, args.depth, stats)
     dt = time.perf_counter() - t0
-    # the same stream with the host staging inside every step (isx_pipe_submit_reads)
+    # (2) pre-staged pinned images replayed: DMA + kernels + tables back
+    wires = [pipe.stage_planes(v["ref_planes"], v["split_bounds"], v["planes"]) for v in as_planes]
+    stream(pipe, variants, warmup, args.depth, wires=wires)
+    st_w = []
+    t1 = time.perf_counter()
+    stream(pipe, rot(variants), steps, args.depth, st_w, wires=rot(wires))
+    dt_w = time.perf_counter() - t1
+    # (3) the isx_segs hand-over (isx_pipe_submit_reads)
     st2 = []
     t1 = time.perf_counter()
     stream(pipe, variants, steps, args.depth, st2)
     dt2 = time.perf_counter() - t1
     pipe.close()
     st = [s for s, _ in stats]
-    mean = lambda k: float(np.mean([s[k] for s in st])) if st else 0.0
+    mean = lambda k, xs=None: float(np.mean([s[k] for s in (st if xs is None else xs)])) if (st if xs is None else xs) else 0.0
     k_ms = mean("kernel_ms")
     n_pos_v = int(np.mean([v["n_pos"] for v in variants]))
-    n_rec = (int(w["segs"].n_seg) + 15) // 16 * 16
     h2d_b, d2h_b = mean("h2d_bytes"), mean("d2h_bytes")
     abytes = h2d_b + n_pos_v * slot_out_bytes_per_pos(w["n_obs"], n_pos_v)
     ms_step = dt / steps * 1e3
-    return {"workload": "C2 streamed: one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, 2x150 bp, --skip_mm_profiling, linkage off; wire "
-                        "records staged once in pinned memory, per step DMA + profile once + tables copied back; %d distinct batches" % n_var,
+    stw = [s for s, _ in st_w]
+    return {"workload": "C2 streamed: one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, 2x150 bp, --skip_mm_profiling, linkage off; every batch handed "
+                        "over from the caller's bit planes inside the step (isx_pipe_submit_planes), profiled once, tables copied back; %d distinct batches" % n_var,
             "gbp_per_s": float(w["profiled_bases"]) * steps / dt / 1e9, "ms_per_step": ms_step, "steps": steps, "warmup": warmup,
             "record_bytes": int(st[0]["record_bytes"]) if st else None,
-            "with_host_staging": {"gbp_per_s": float(w["profiled_bases"]) * steps / dt2 / 1e9, "ms_per_step": dt2 / steps * 1e3,
-                                  "host_stage_ms": float(np.mean([x["encode_ms"] for x, _ in st2])) if st2 else 0.0},
+            "staged_replay": {"gbp_per_s": float(w["profiled_bases"]) * steps / dt_w / 1e9, "ms_per_step": dt_w / steps * 1e3,
+                              "copy_in_ms": mean("h2d_ms", stw), "kernel_ms": mean("kernel_ms", stw)},
+            "segs_hand_over": {"gbp_per_s": float(w["profiled_bases"]) * steps / dt2 / 1e9, "ms_per_step": dt2 / steps * 1e3,
+                               "host_stage_ms": float(np.mean([x["encode_ms"] for x, _ in st2])) if st2 else 0.0},
             "kept_observations": int(w["n_obs"]), "read_segments": int(w["segs"].n_seg), "pipe_depth": args.depth, "host_threads": host_threads,
             "roofline_in_stream": {"bound": "hbm", "kernel": "k_pileup_dense (wire records, slot output)",
                                    "achieved": abytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1193,6 +1207,7 @@ def main():
             if not args.no_c2_leg:
                 legs["c2_stream"] = c2_stream_leg(ctx, w, args, host_threads, 32, 4)
                 out["c2_stream_gbp_per_s"] = legs["c2_stream"]["gbp_per_s"]
+                out["c2_staged_replay_gbp_per_s"] = legs["c2_stream"]["staged_replay"]["gbp_per_s"]
             if not args.no_resident_leg:
                 res = resident_leg(ctx, w, args.window)
                 legs["resident"] = res

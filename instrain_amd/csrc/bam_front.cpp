@@ -2366,13 +2366,31 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     auto lo_of = [&](int t) { return n_reads * (size_t)t / (size_t)n_tasks; };
     auto slot_of = [&](const Read &r) -> size_t { return (size_t)(slot0[(size_t)r.tid] + (r.pair_idx - B.ref_pair0[(size_t)r.tid])); };
     BamBatch *q = Q.get();
+    // "is this read's pair in R2M" as ONE BIT per pair entry: the reads come in position order, their pair entries in hash order --
+    // a look-up into the 72-byte entries is a DRAM miss per read (6 M reads: 20-40 ms of the hand-over), the bit plane stays in the L2
+    // (only the words between the first and the last pair entry of the batch's references are made: a reference's entries are contiguous)
+    const size_t n_pair_all = B.pairs.size();
+    uvec<uint64_t> pass_bits((n_pair_all + 63) / 64);
+    {
+        size_t p_lo = n_pair_all, p_hi = 0;
+        for (int32_t i = 0; i < n_refs; i++) { p_lo = std::min<size_t>(p_lo, (size_t)B.ref_pair0[(size_t)refs[i]]); p_hi = std::max<size_t>(p_hi, (size_t)B.ref_pair0[(size_t)refs[i] + 1]); }
+        const size_t w_lo = p_lo >> 6, n_words = p_hi > p_lo ? ((p_hi + 63) >> 6) - w_lo : 0;
+        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n_words / 4096 + 1));
+        pool.run(nt, [&](int t) {
+            for (size_t wd = w_lo + n_words * (size_t)t / (size_t)nt; wd < w_lo + n_words * (size_t)(t + 1) / (size_t)nt; wd++) {
+                uint64_t m = 0;
+                const size_t i0 = wd * 64, i1 = std::min(n_pair_all, i0 + 64);
+                for (size_t i = i0; i < i1; i++) m |= (uint64_t)(B.pairs[i].pass && B.pairs[i].reads != 0) << (i - i0);
+                pass_bits[wd] = m;
+            }
+        });
+    }
     pool.run(n_tasks, [&](int t) {
         for (size_t ri = lo_of(t); ri < lo_of(t + 1); ri++) {
             const Read &r = S.reads[ri];
             // R2M membership is by NAME on this scaffold (get_base_counts_mm looks up query_name)
             if (r.pair_idx == 0xFFFFFFFFu) continue;
-            const PairInfo &pi = B.pairs[r.pair_idx];
-            if (!pi.pass || pi.reads == 0) continue;
+            if (!((pass_bits[r.pair_idx >> 6] >> (r.pair_idx & 63u)) & 1u)) continue;
             q->emit[ri] = 1;
             uint32_t *f = &first[slot_of(r)];
             uint32_t cur = __atomic_load_n(f, __ATOMIC_RELAXED);
