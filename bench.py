@@ -704,6 +704,7 @@ class C5Run:
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
                             "algorithmic_bytes_per_launch": abytes / max(len(ws), 1), "bytes_per_position": abytes / max(n_pos, 1),
                             "kernel_ms_avg": k_ms / max(len(ws), 1), "kernel_ms_per_pass": k_ms, "launches": len(st),
+                            "positions_per_s": n_pos / (k_ms * 1e-3) if k_ms else 0.0,
                             "traffic": _pmc("c5_dense_linkage_bytes_per_launch") if self.n_genomes == 1000 else None,
                             "traffic_source": _pmc_source("c5_dense_linkage_bytes_per_launch"),
                             # the same kernel time priced on SURVEY 8(d)'s byte model of the naive formulation (12 B per kept observation
@@ -1172,7 +1173,7 @@ def main():
                        "numa_node": numa_node, "parallelism": "genome-sharded x%d%s" % (world, " (ranks share %d GPU)" % n_dev if shared else ""),
                        "verified": "per-batch checks in an untimed pass (largest batch: exact coverage + per-base SNV counts from the host); timed row counts equal"},
             "roofline": {k: head["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
-                                                            "algorithmic_bytes_per_launch", "kernel_ms_avg", "launches", "survey_8d_model", "bound_of_the_pass")},
+                                                            "algorithmic_bytes_per_launch", "kernel_ms_avg", "launches", "positions_per_s", "survey_8d_model", "bound_of_the_pass")},
             "h2d_bytes_per_base": head["roofline_pcie"]["bytes_per_profiled_base"], "pcie_frac": head["roofline_pcie"]["frac"],
             "snv_pairs_linked_per_s": head["snv_pairs_linked_per_s"],
             "stages_ms": {k: round(v, 2) for k, v in head["stages_ms_per_pass"].items()},
@@ -1229,7 +1230,19 @@ def main():
                 abo = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], 0, dense=True, record_bytes=to["record_bytes"])
                 legs["roofline_observation_kernel"] = _roofline("k_pileup_dense (2-byte observation records; isx_pipe_submit / isx_batch_create)", abo, ko, to,
                                                                 _pmc("c2_pileup_bytes_per_launch"), kernel_ms_min=res["observations"]["kernel_ms_min"])
-                out["roofline_c2_resident"] = {k: legs["roofline_c2_resident"][k] for k in ("achieved", "frac", "traffic", "kernel_ms_avg", "algorithmic_bytes_per_launch")}
+                # the yardstick that describes this kernel ("positions per second and VALU issue do"): positions per second, and the
+                # share of all SIMD issue slots in which a wave issued a VALU instruction (SQ_ACTIVE_INST_VALU of the committed PMC pass, in
+                # quad-cycles, over SIMDs x launch time x 2.4 GHz / 4)
+                sq = _pmc("c2_delta_sq") if args.scale == 1.0 else None
+                legs["roofline_c2_resident"]["positions_per_s"] = w["n_pos"] / (k_alone * 1e-3)
+                if sq and k_alone:
+                    simd_quads = 256 * 4 * (k_alone * 1e-3) * 2.4e9 / 4.0
+                    legs["roofline_c2_resident"]["valu_issue"] = {"bound": "valu-issue", "achieved": sq["SQ_ACTIVE_INST_VALU"], "peak": simd_quads, "unit": "SIMD quad-cycles per launch",
+                                                                  "frac": sq["SQ_ACTIVE_INST_VALU"] / simd_quads, "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"),
+                                                                  "valu_insts_per_position": (sq.get("SQ_INSTS_VALU") or 0) * 64.0 / w["n_pos"]}
+                out["roofline_c2_resident"] = {k: legs["roofline_c2_resident"][k] for k in ("achieved", "frac", "traffic", "kernel_ms_avg", "algorithmic_bytes_per_launch", "positions_per_s")}
+                if "valu_issue" in legs["roofline_c2_resident"]:
+                    out["roofline_c2_resident"]["valu_issue_frac"] = legs["roofline_c2_resident"]["valu_issue"]["frac"]
             if want_mm:
                 legs["mm_on"] = mm_leg(ctx, w)
                 out["mm_on_roofline_frac"] = legs["mm_on"]["roofline"]["frac"]

@@ -97,6 +97,8 @@ struct Slot {
     std::vector<isx_snv> snv_big;           // more SNV rows than the pinned block holds (rare)
     std::vector<isx_ld> ld_rows;            // the batch's LD rows (linkage), fetched by the finisher
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_pass = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
+    hipEvent_t ev_h2da = nullptr, ev_h2db = nullptr;   // a copy-in in two parts (the reference leaves before the records exist): end of the first, start of the second
+    bool h2d_split = false;
     int64_t ticket = -1;
     BamBatch *dead_batch = nullptr;         // isx_pipe_submit_bam: the front end's batch, freed by the finisher after the slot's work
     bool ref_has_n = false;                 // the batch's reference holds positions that are not A/C/T/G: their bit plane travels too
@@ -300,7 +302,7 @@ static void pipe_free(isx_pipe *p)
         host_block_free(s.h_out, s.out_pinned);
         if (s.h_small) isx_pin_free(s.h_small);
         t_pin += now_ms() - t_x;
-        for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_pass, s.ev_d2h0, s.ev_d2h1}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {s.ev_h2d0, s.ev_h2d1, s.ev_pass, s.ev_d2h0, s.ev_d2h1, s.ev_h2da, s.ev_h2db}) if (e) (void)hipEventDestroy(e);
     }
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_destroy] device tables %.1f ms, device arena %.1f ms, pinned staging %.1f ms, total %.1f ms\n", t_batch, t_dev, t_pin, now_ms() - t_f0);
@@ -442,7 +444,7 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     s.out_pinned = s.out_bytes <= ((size_t)64 << 20) || p->pp.depth > 2;
     { const int hrc = host_block_alloc(reinterpret_cast<void **>(&s.h_out), s.out_bytes, s.out_pinned); if (hrc != ISX_OK) return hrc; }
     if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_create] slot %d: %s results %.1f MB %.1f ms\n", index, s.out_pinned ? "pinned" : "pageable", s.out_bytes / 1e6, now_ms() - t_o0);
-    for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_pass, &s.ev_d2h0, &s.ev_d2h1}) HIP_TRY(hipEventCreate(e));
+    for (hipEvent_t *e : {&s.ev_h2d0, &s.ev_h2d1, &s.ev_pass, &s.ev_d2h0, &s.ev_d2h1, &s.ev_h2da, &s.ev_h2db}) HIP_TRY(hipEventCreate(e));
     const size_t n_chunks = (size_t)(p->cap_rec / (p->segs ? (int64_t)p->G : (int64_t)ISX_CHUNK)) + 2;
     s.cmin.resize(n_chunks); s.cmax.resize(n_chunks); s.cany.resize(n_chunks);
     return ISX_OK;
@@ -1036,6 +1038,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         s.h2d_bytes += (int64_t)(rb + ib);
     }
     HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
+    s.h2d_split = false;
 
     return enqueue_pass(p, s, n_pos, ticket);
 }
@@ -1096,6 +1099,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     }
     int erc;
     double t_ref0 = 0.0;
+    bool early_ref = false, early_rec = false;
     if (planes_in) {
         // the reference planes first, into staging: the record pass compares against that copy
         if (!p->drec) { isx_set_error("bit-plane reads need a one-mm-bin pipe (reference-delta records)"); return ISX_ERR_STATE; }
@@ -1104,6 +1108,15 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         s.ref_has_n = rp ? copy_ref_planes(*p->pool, rp, n_pos, h2, hn) : pack_ref2(*p->pool, ref, n_pos, h2, hn);
         J.ref2 = h2; J.refn = s.ref_has_n ? hn : nullptr;
         t_ref0 = now_ms() - t_r;
+        // ... and leave at once: the DMA engine brings the reference in while the threads make the records
+        // (ISX_PIPE_LATE_DMA=1: every copy after the host pass, as before round 5 -- same-box A/B)
+        static const bool late_dma = getenv("ISX_PIPE_LATE_DMA") != nullptr;
+        if (late_dma) goto ref_staged;
+        if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, h2, ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0), hipMemcpyHostToDevice, p->s_h2d));
+        if (!ring) HIP_TRY(hipEventRecord(s.ev_h2da, p->s_h2d));
+        early_ref = true;
+    ref_staged:;
     }
     if (p->drec) {
         // reference-delta records: the segments are compared with the reference here; pieces of segments with more than six
@@ -1139,6 +1152,14 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (erc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
     if (erc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
     if (J.n_bases > p->pp.max_obs) { isx_set_error("isx_pipe_submit_reads: more bases than the pipe's max_obs"); return ISX_ERR_CAPACITY; }
+    if (early_ref && !ring) {
+        // the records leave as soon as they exist; the window directory below is made while they travel
+        const size_t gb_bytes0 = (size_t)(J.n_rec / (int64_t)p->G) * sizeof(uint32_t), rec_bytes0 = (size_t)J.n_rec * (size_t)p->rb;
+        HIP_TRY(hipEventRecord(s.ev_h2db, p->s_h2d));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes0, hipMemcpyHostToDevice, p->s_h2d));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes0, hipMemcpyHostToDevice, p->s_h2d));
+        early_rec = true;
+    }
     if (!planes_in) s.ref_has_n = pack_ref2(*p->pool, ref, n_pos, s.h_in + s.off_ref, s.h_in + s.off_ref + ref2_bytes(n_pos));
     const double t_ref = now_ms();
     memcpy(s.h_in + s.off_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t));
@@ -1190,23 +1211,24 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     const double t_q0 = now_ms();
 
     // ---- copy-in queue: bounds | windows | reference codes, then group bases (| pair ids) | records ----
-    if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+    if (!ring && !early_ref) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
     const size_t ref_bytes = ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0);   // 2-bit plane (+ the non-ACGT bit plane)
     const size_t head = (size_t)(n_splits + 1) * sizeof(int64_t) + s.win.size() * sizeof(uint2) + ref_bytes;
     const size_t gb_bytes = (size_t)(b->n_rec / p->G) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * (size_t)p->rb;
     // bounds | windows | reference planes: what is used of each region, not the regions (a slot is sized for the largest batch)
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, s.h_in + s.off_win, s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, s.h_in + s.off_ref, ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    if (!early_ref) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, s.h_in + s.off_ref, ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    if (!early_rec) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
     if (ring) { if (ring_bytes != rec_bytes) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; } }
-    else HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    else if (!early_rec) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
     s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
     if (linkage && !p->drec) {
         HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, s.h_in + s.off_pairs, (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, p->s_h2d));
         s.h2d_bytes += (int64_t)b->n_rec * 4;
     }
     HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
+    s.h2d_split = early_rec;
     const double t_q1 = now_ms();
     rc = enqueue_pass(p, s, n_pos, ticket);
     if (getenv("ISX_PIPE_TIMING")) fprintf(stderr, "[isx_pipe_submit_reads] copy-in queue %.2f ms, pass + copy-out queue %.2f ms\n", t_q1 - t_q0, now_ms() - t_q1);
@@ -1438,6 +1460,7 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     if (w->pairs_bytes) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, w->h + w->o_pairs, w->pairs_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, w->h + w->o_rec, w->rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
     HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
+    s.h2d_split = false;
     s.h2d_bytes = isx_wire_bytes(w);
     s.encode_ms = (float)(now_ms() - t0);       // (what this submit itself spent on the host: enqueueing)
     s.encode_passes = 0;                        // staged ahead of time
@@ -1642,7 +1665,10 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
     out->h2d_bytes = s.h2d_bytes; out->d2h_bytes = s.d2h_bytes;
     out->ld = p->prm.enable_linkage ? s.ld_rows.data() : nullptr;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s.ev_h2d0, s.ev_h2d1) == hipSuccess) out->h2d_ms = ms;
+    if (s.h2d_split) {                          // the time the DMA engine worked for this batch, not the stager's time between its two parts
+        float m1 = 0.f, m2 = 0.f;
+        if (hipEventElapsedTime(&m1, s.ev_h2d0, s.ev_h2da) == hipSuccess && hipEventElapsedTime(&m2, s.ev_h2db, s.ev_h2d1) == hipSuccess) out->h2d_ms = m1 + m2;
+    } else if (hipEventElapsedTime(&ms, s.ev_h2d0, s.ev_h2d1) == hipSuccess) out->h2d_ms = ms;
     if (hipEventElapsedTime(&ms, s.ev_d2h0, s.ev_d2h1) == hipSuccess) out->d2h_ms = ms;
     isx_timings t{};
     if (isx_batch_timings(b, &t) == ISX_OK) out->kernel_ms = t.pileup_ms;

@@ -141,4 +141,9 @@ Reading:
   LDS pipe busy cycles {d["SQ_LDS_IDX_ACTIVE"]/1e6:.1f} M vs {s6["SQ_LDS_IDX_ACTIVE"]/1e6:.1f} M.
 * waves parked (`SQ_WAIT_ANY`) {100*d["SQ_WAIT_ANY"]/d["SQ_WAVE_CYCLES"]:.0f} % of their life (segments: {100*s6["SQ_WAIT_ANY"]/s6["SQ_WAVE_CYCLES"]:.0f} %); VALU instructions {d["SQ_INSTS_VALU"]/1e6:.1f} M vs {s6["SQ_INSTS_VALU"]/1e6:.1f} M.
 ''')
+# the VALU-issue yardstick of the resident C2 launch (bench.py roofline_c2_resident.valu_issue): quad-cycles in which a wave issued a VALU
+# instruction, and the instruction count, per launch
+pj = json.load(open('profiles/pmc_traffic.json'))
+pj["c2_delta_sq"] = {n: d[n] for n in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY") if n in d}
+json.dump(pj, open('profiles/pmc_traffic.json', 'w'), indent=1)
 print(line["value"], line["ms_per_step"], line["roofline"], tot("delta"), tot("c5"))
