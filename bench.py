@@ -712,7 +712,7 @@ class C5Run:
                             # bytes -- for comparison only: `frac` above is the stricter figure
                             "survey_8d_model": {"bytes_per_pass": n_obs * 12 + n_pos + int(getattr(self, "covered", 0) or n_pos) * 28,
                                                 "frac": ((n_obs * 12 + n_pos + int(getattr(self, "covered", 0) or n_pos) * 28) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else 0.0},
-                            "bound_of_the_pass": "pcie (copy-in %.1f of %.1f ms)" % (tot("h2d_ms"), dt_max / passes * 1e3)},
+                            "bound_of_the_pass": "host stager %.1f ms + pcie copy-in %.1f ms, overlapped, of %.1f ms" % (tot("encode_ms"), tot("h2d_ms"), dt_max / passes * 1e3)},
                "roofline_pcie": {"bound": "pcie", "direction": "host->device", "achieved": tot("h2d_bytes") / (dt_max / passes) / 1e9, "peak": PCIE_PEAK_GBS,
                                  "unit": "GB/s", "frac": tot("h2d_bytes") / (dt_max / passes) / 1e9 / PCIE_PEAK_GBS, "bytes_per_pass": tot("h2d_bytes"),
                                  "bytes_per_profiled_base": tot("h2d_bytes") / max(self.bases, 1.0),
