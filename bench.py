@@ -510,7 +510,7 @@ class C5Run:
         ws = self.ws
         self.pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["n_seg"] for w in ws),
                                 max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
-                                pin_threads=False, n_mm_bins=1, enable_linkage=C5_LINKAGE, min_snp=20, stage_async=stage_async, lean_output=LEAN_SLOTS)
+                                pin_threads=bool(os.environ.get("ISX_BENCH_PIN")), n_mm_bins=1, enable_linkage=C5_LINKAGE, min_snp=20, stage_async=stage_async, lean_output=LEAN_SLOTS)
         self.bases = float(sum(w["profiled_bases"] for w in ws))
         self.signature = None
         self.wires = None

@@ -1,7 +1,7 @@
 // enc_bench.cpp -- host-only timing of the read-level stagers: encode_delta (3-bit words, compare with reference bytes) against
 // encode_planes (bit planes, XOR with the 2-bit reference plane), same synthetic batch, outputs compared byte for byte.
 // build: g++ -O3 -std=c++17 -I include tools/src/enc_bench.cpp instrain_amd/csrc/seg_encode.o instrain_amd/csrc/obs_encode.o -lpthread -o tools/bin/enc_bench
-// usage: enc_bench [threads] [n_pos] [depth] [p_skip] [p_mismatch] [p_N]
+// usage: enc_bench [threads] [n_pos] [depth] [p_skip] [p_mismatch] [p_N]      (ISX_ENC_PIN=<numa node>: spread the threads over the L3 domains of that node)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -61,7 +61,9 @@ int main(int argc, char **argv)
     }
     isx_read_planes rp{n_seg, gpos.data(), len.data(), pair.data(), planes};
     isx_ref_planes rf{p2.data(), has_n ? pn.data() : nullptr};
-    isxenc::HostPool pool(T, -1, false);
+    const char *pin_env = getenv("ISX_ENC_PIN");
+    isxenc::HostPool pool(T, pin_env ? atoi(pin_env) : -1, pin_env != nullptr);
+    if (pin_env) printf("threads pinned over the L3 domains of NUMA node %s\n", pin_env);
     int64_t slack = 8;
     const int64_t cap = isxenc::delta_groups_needed(pool, gpos.data(), n_seg, 64) * ISX_DREC_GROUP;
     std::vector<uint32_t> recA_raw((size_t)cap * 8 + 16), recB_raw((size_t)cap * 8 + 16), gbA((size_t)cap / 32), gbB((size_t)cap / 32);
