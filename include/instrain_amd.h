@@ -555,6 +555,11 @@ typedef struct {
 typedef struct {
     const uint8_t *plane2;      /* [(n_pos + 3) / 4] */
     const uint8_t *nplane;      /* [(n_pos + 7) / 8] or NULL */
+    uint64_t key;               /* 0, or the caller's name for THIS reference content (a batch of a database: the same scaffolds in the same
+                                 * order): the pipe keeps the planes of a key on the device after their first trip (isx_pipe_submit_planes)
+                                 * and later batches that carry the key -- of any sample -- bring in only their reads.  The reference program
+                                 * holds its fasta in memory for the whole run the same way (profile_controller.py:415-433).  The planes
+                                 * must still be passed (the stager compares against them on the host) and must be the key's content */
 } isx_ref_planes;
 
 /* host helpers (no GPU needed).  isx_pack_ref_planes: reference codes (0..3 = A C T G, anything else = not a base) -> the two planes
@@ -573,6 +578,9 @@ int isx_pipe_submit_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref
                            const isx_read_planes *reads, int64_t *ticket);
 int isx_pipe_stage_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref, int32_t n_splits, const int64_t *split_bounds,
                           const isx_read_planes *reads, isx_wire **out);
+/* device memory a pipe may spend on resident references (isx_ref_planes.key), in MiB; 0 = the default (4096), < 0 = keep nothing.  Keys
+ * beyond the budget travel every time.  Entries live until isx_pipe_destroy. */
+int isx_pipe_set_reference_budget(isx_pipe *p, int64_t mib);
 /* the stager on its own (no GPU needed), like isx_encode_delta: planes + reference planes -> 32-byte reference-delta records */
 int isx_encode_planes(const isx_read_planes *reads, const isx_ref_planes *ref, int64_t n_pos, int32_t host_threads, int32_t slack_groups,
                       int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, int64_t *n_rec, int64_t *need_slack);

@@ -66,7 +66,7 @@ class ReadPlanes(C.Structure):
 
 class RefPlanes(C.Structure):
     """isx_ref_planes: the reference as it travels (2-bit plane + bit plane of the positions that are not A/C/T/G, or NULL)"""
-    _fields_ = [("plane2", C.c_void_p), ("nplane", C.c_void_p)]
+    _fields_ = [("plane2", C.c_void_p), ("nplane", C.c_void_p), ("key", C.c_uint64)]
 
 
 RARE_DT = np.dtype([("gpos", "<u4"), ("clon_rarefied", "<f4")])
@@ -149,7 +149,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld", "isx_batch_fetch_allele_obs",
            "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
            "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_stage_reads", "isx_pipe_submit_wire", "isx_wire_bytes", "isx_wire_free", "isx_wire_keep_reference", "isx_pipe_submit_bam", "isx_encode_segs", "isx_encode_segs_ring", "isx_seg_records_needed", "isx_encode_delta", "isx_delta_records_needed", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_pipe_fetch_entries_shrunk", "isx_encode_obs", "isx_encode_obs_ring",
-           "isx_pack_ref_planes", "isx_planes_from_segs", "isx_pack_read_planes", "isx_pipe_submit_planes", "isx_pipe_stage_planes", "isx_encode_planes",
+           "isx_pack_ref_planes", "isx_planes_from_segs", "isx_pack_read_planes", "isx_pipe_submit_planes", "isx_pipe_stage_planes", "isx_encode_planes", "isx_pipe_set_reference_budget",
            "isx_bgzf_index", "isx_bgzf_inflate_device", "isx_bgzf_inflate_host", "isx_bgzf_inflate_fast",
            "isx_bam_open", "isx_bam_close", "isx_bam_close_wait", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
            "isx_bam_insert_sizes", "isx_bam_set_wanted_refs", "isx_bam_pair_keys", "isx_bam_set_cross_names", "isx_bam_filter_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_batch_pair_names", "isx_bam_set_mm_cap", "isx_bam_ref_counts",
@@ -258,6 +258,7 @@ def load():
     lib.isx_planes_from_segs.argtypes = [C.POINTER(Segs), i32, vp]
     lib.isx_pack_read_planes.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, C.POINTER(i64)]
     lib.isx_pipe_submit_planes.argtypes = [vp, i64, C.POINTER(RefPlanes), i32, vp, C.POINTER(ReadPlanes), C.POINTER(i64)]
+    lib.isx_pipe_set_reference_budget.argtypes = [vp, i64]
     lib.isx_pipe_stage_planes.argtypes = [vp, i64, C.POINTER(RefPlanes), i32, vp, C.POINTER(ReadPlanes), C.POINTER(vp)]
     lib.isx_encode_planes.argtypes = [C.POINTER(ReadPlanes), C.POINTER(RefPlanes), i64, i32, i32, i64, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]
     lib.isx_bam_ref.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64)]

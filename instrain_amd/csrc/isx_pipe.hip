@@ -34,6 +34,7 @@
 #include "obs_encode.h"
 #include "seg_encode.h"
 #include "isx_summary.h"
+#include <unordered_map>
 
 namespace {
 
@@ -220,6 +221,10 @@ struct isx_pipe {
         isx_read_planes reads{};
         isx_ref_planes rp{};
     };
+    // resident references (isx_ref_planes.key): device copies of a batch's reference planes, kept after their first trip
+    struct RefEntry { uint8_t *d = nullptr; size_t bytes = 0; int64_t n_pos = 0; bool has_n = false; hipEvent_t ready = nullptr; };
+    std::unordered_map<uint64_t, RefEntry> ref_cache;
+    size_t ref_cache_bytes = 0, ref_cache_budget = (size_t)4096 << 20;
     std::thread stager;
     std::deque<StageJob> stage_q;
     std::condition_variable cv_stage;
@@ -306,6 +311,7 @@ static void pipe_free(isx_pipe *p)
     }
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe_destroy] device tables %.1f ms, device arena %.1f ms, pinned staging %.1f ms, total %.1f ms\n", t_batch, t_dev, t_pin, now_ms() - t_f0);
+    for (auto &kv : p->ref_cache) { if (kv.second.d) isx_dev_free(kv.second.d); if (kv.second.ready) (void)hipEventDestroy(kv.second.ready); }
     for (int i = 0; i < 2; i++) {
         if (p->bounce[i]) isx_pin_free(p->bounce[i]);
         if (p->bounce_ev[i]) (void)hipEventDestroy(p->bounce_ev[i]);
@@ -1100,11 +1106,30 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     int erc;
     double t_ref0 = 0.0;
     bool early_ref = false, early_rec = false;
+    uint8_t *resident_ref = nullptr;            // the batch's reference planes already on the device (isx_ref_planes.key)
     if (planes_in) {
         // the reference planes first, into staging: the record pass compares against that copy
         if (!p->drec) { isx_set_error("bit-plane reads need a one-mm-bin pipe (reference-delta records)"); return ISX_ERR_STATE; }
         const double t_r = now_ms();
         uint8_t *h2 = s.h_in + s.off_ref, *hn = h2 + ref2_bytes(n_pos);
+        if (rp && rp->key) {
+            auto it = p->ref_cache.find(rp->key);
+            if (it != p->ref_cache.end()) {
+                // the device already holds this reference: nothing is staged, nothing travels; the record pass compares against the
+                // caller's own planes
+                const isx_pipe::RefEntry &e = it->second;
+                if (e.n_pos != n_pos || e.has_n != (rp->nplane != nullptr && e.has_n)) { isx_set_error("isx_pipe_submit_planes: the reference key stands for other planes (positions / non-ACGT plane differ)"); return ISX_ERR_ARG; }
+                s.ref_has_n = e.has_n;
+                J.ref2 = rp->plane2; J.refn = e.has_n ? rp->nplane : nullptr;
+                resident_ref = e.d;
+                HIP_TRY(hipStreamWaitEvent(p->s_h2d, e.ready, 0));         // (the entry's own copy, enqueued by an earlier submit)
+                if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+                HIP_TRY(hipEventRecord(s.ev_h2da, p->s_h2d));
+                early_ref = true;
+                t_ref0 = now_ms() - t_r;
+                goto ref_staged;
+            }
+        }
         s.ref_has_n = rp ? copy_ref_planes(*p->pool, rp, n_pos, h2, hn) : pack_ref2(*p->pool, ref, n_pos, h2, hn);
         J.ref2 = h2; J.refn = s.ref_has_n ? hn : nullptr;
         t_ref0 = now_ms() - t_r;
@@ -1116,6 +1141,20 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, h2, ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0), hipMemcpyHostToDevice, p->s_h2d));
         if (!ring) HIP_TRY(hipEventRecord(s.ev_h2da, p->s_h2d));
         early_ref = true;
+        if (rp && rp->key && !resident_ref) {
+            // first trip of this key: a device-side copy of what just arrived stays with the pipe (while its budget lasts)
+            const size_t rb_all = ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0);
+            if (p->ref_cache_bytes + rb_all <= p->ref_cache_budget) {
+                isx_pipe::RefEntry e;
+                if (isx_dev_malloc(reinterpret_cast<void **>(&e.d), rb_all + 64) == hipSuccess && hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) == hipSuccess) {
+                    HIP_TRY(hipMemcpyAsync(e.d, s.d_in + s.off_ref, rb_all, hipMemcpyDeviceToDevice, p->s_h2d));
+                    HIP_TRY(hipEventRecord(e.ready, p->s_h2d));
+                    e.bytes = rb_all; e.n_pos = n_pos; e.has_n = s.ref_has_n;
+                    p->ref_cache_bytes += rb_all;
+                    p->ref_cache.emplace(rp->key, e);
+                } else { if (e.d) isx_dev_free(e.d); (void)hipGetLastError(); }
+            }
+        }
     ref_staged:;
     }
     if (p->drec) {
@@ -1195,8 +1234,8 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     memcpy(s.h_in + s.off_win, s.win.data(), s.win.size() * sizeof(uint2));
     b->d_bounds = reinterpret_cast<int64_t *>(s.d_in + s.off_bounds);
     b->d_win = reinterpret_cast<uint2 *>(s.d_in + s.off_win);
-    b->d_ref = s.d_in + s.off_ref;
-    b->d_ref_n = s.ref_has_n ? s.d_in + s.off_ref + ref2_bytes(b->n_pos) : nullptr;
+    b->d_ref = resident_ref ? resident_ref : s.d_in + s.off_ref;
+    b->d_ref_n = s.ref_has_n ? b->d_ref + ref2_bytes(b->n_pos) : nullptr;
     b->d_gbase = reinterpret_cast<uint32_t *>(s.d_in + s.off_gbase);
     b->d_seg = p->drec ? nullptr : reinterpret_cast<uint4 *>(s.d_in + s.off_rec);
     b->d_drec = p->drec ? reinterpret_cast<uint4 *>(s.d_in + s.off_rec) : nullptr;
@@ -1222,7 +1261,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (!early_rec) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
     if (ring) { if (ring_bytes != rec_bytes) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; } }
     else if (!early_rec) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
+    s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes) - (resident_ref ? (int64_t)ref_bytes : 0);
     if (linkage && !p->drec) {
         HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, s.h_in + s.off_pairs, (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, p->s_h2d));
         s.h2d_bytes += (int64_t)b->n_rec * 4;
@@ -1544,6 +1583,13 @@ int isx_pipe_submit_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref
     J.in2 = *reads; J.n_seg = reads->n_seg;
     if (!p->prm.enable_linkage) J.in2.pair = nullptr;
     return submit_segs_common(p, n_pos, nullptr, n_splits, split_bounds, J, ticket, ref);
+}
+
+int isx_pipe_set_reference_budget(isx_pipe *p, int64_t mib)
+{
+    if (!p) { isx_set_error("isx_pipe_set_reference_budget: bad argument"); return ISX_ERR_ARG; }
+    p->ref_cache_budget = mib < 0 ? 0 : (size_t)(mib ? mib : 4096) << 20;
+    return ISX_OK;
 }
 
 int isx_pipe_submit(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t n_splits, const int64_t *split_bounds,

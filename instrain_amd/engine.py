@@ -92,23 +92,24 @@ class RefPlanes:
     """The reference of a batch as it travels (isx_ref_planes): plane2 u8 [(n_pos + 3) // 4] (2 bits a position, anything that is not
     A/C/T/G as 0) and nplane u8 [(n_pos + 7) // 8] | None (the positions that are not A/C/T/G).  from_codes packs reference codes."""
 
-    def __init__(self, plane2, nplane, n_pos):
+    def __init__(self, plane2, nplane, n_pos, key=0):
         self.plane2 = np.ascontiguousarray(plane2, dtype=np.uint8)
         self.nplane = None if nplane is None else np.ascontiguousarray(nplane, dtype=np.uint8)
         self.n_pos = int(n_pos)
+        self.key = int(key)         # != 0: the caller's name for this content -- a pipe keeps the planes of a key on the device after their first trip
         assert len(self.plane2) >= (self.n_pos + 3) // 4 and (self.nplane is None or len(self.nplane) >= (self.n_pos + 7) // 8)
 
     @classmethod
-    def from_codes(cls, ref_codes, threads=1):
+    def from_codes(cls, ref_codes, threads=1, key=0):
         ref = np.ascontiguousarray(ref_codes, dtype=np.uint8)
         n = len(ref)
         p2, pn = np.empty((n + 3) // 4, dtype=np.uint8), np.empty((n + 7) // 8, dtype=np.uint8)
         has = C.c_int32(0)
         check(_lib.load().isx_pack_ref_planes(ref.ctypes.data, n, int(threads), p2.ctypes.data, pn.ctypes.data, C.byref(has)))
-        return cls(p2, pn if has.value else None, n)
+        return cls(p2, pn if has.value else None, n, key)
 
-    def c(self):
-        return _lib.RefPlanes(self.plane2.ctypes.data, None if self.nplane is None else self.nplane.ctypes.data)
+    def c(self, keyed=True):
+        return _lib.RefPlanes(self.plane2.ctypes.data, None if self.nplane is None else self.nplane.ctypes.data, self.key if keyed else 0)
 
 
 def pack_codes(codes):
@@ -403,16 +404,21 @@ class Pipe:
         self._wires.append(w)
         return w
 
-    def submit_planes(self, ref_planes, split_bounds, reads):
-        """-> ticket.  A read-level batch as bit planes (PlaneBatch) against the reference planes (RefPlanes): isx_pipe_submit_planes"""
+    def submit_planes(self, ref_planes, split_bounds, reads, keyed=True):
+        """-> ticket.  A read-level batch as bit planes (PlaneBatch) against the reference planes (RefPlanes): isx_pipe_submit_planes.
+        keyed=False ignores ref_planes.key (the reference travels like any other)"""
         split_bounds = np.ascontiguousarray(split_bounds, dtype=np.int64)
-        cr, cf = reads.c(with_pair=self.enable_linkage), ref_planes.c()
+        cr, cf = reads.c(with_pair=self.enable_linkage), ref_planes.c(keyed)
         t = C.c_int64(-1)
         check(self.lib.isx_pipe_submit_planes(self.h, ref_planes.n_pos, C.byref(cf), len(split_bounds) - 1, split_bounds.ctypes.data,
                                               C.byref(cr), C.byref(t)))
         if self.stage_async:                        # the stager reads these until the batch is collected / released
             self._held[t.value] = (ref_planes, reads, cr, cf)
         return t.value
+
+    def set_reference_budget(self, mib):
+        """device memory this pipe may spend on resident references (RefPlanes.key), MiB"""
+        check(self.lib.isx_pipe_set_reference_budget(self.h, int(mib)))
 
     def stage_planes(self, ref_planes, split_bounds, reads):
         """-> Wire, like stage_reads, from bit planes (isx_pipe_stage_planes)"""
