@@ -1134,6 +1134,7 @@ int launch_pass(isx_batch *b)
     a.clon_list = b->sparse_out ? b->d_clon_list : nullptr; a.cap_clon = (uint32_t)std::min<size_t>(b->cap_clon, 0xFFFFFFFFu);
     if (b->lean && b->sparse_out) {             // a lean slot writes only what travels home
         if (!b->clon_dense) a.clon = nullptr;
+        if (!b->rare_dense && a.rare) a.clon_r = nullptr;
         if (a.cov8) a.cov16 = nullptr;
     }
     a.seed_lo = (uint32_t)b->prm.seed; a.seed_hi = (uint32_t)(b->prm.seed >> 32);

@@ -89,6 +89,7 @@ struct isx_batch {
     size_t cap_cov_row_win = 0;
     uint32_t n_cov_rows = 0;
     bool sparse_out = false, cov8_out = false;   // this pass: write the sparse clonality list / the 1-byte coverage
+    bool rare_dense = true;             // this pass writes the dense clonTR array (a lean slot's shallow batch: the list alone; finish_slot repeats the pass otherwise)
     bool lean = false, clon_dense = false;       // lean slot (isx_pipe_params.lean_output): the dense clonality array / the 16-bit coverage
                                                  // are written only when a batch needs them (clon_dense: its clonality list did not fit)
     isx_entry *d_entries = nullptr;  // mm path: [n_win][slab] slabs, then cap_ovf overflow entries

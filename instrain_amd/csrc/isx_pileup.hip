@@ -1131,7 +1131,7 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
                 uint32_t c[4];
             ld4(p, c);
                 const float v = rarefied_clonality(a, c, w0 + p, 0);
-                a.clon_r[w0 + p] = v;
+                if (a.clon_r) a.clon_r[w0 + p] = v;
                 if (list) a.rare[rare_base + atomicAdd(&scratch[S_RARE_RANK], 1u)] = make_uint2(w0 + p, __float_as_uint(v));
             }
         }

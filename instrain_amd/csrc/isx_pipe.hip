@@ -482,16 +482,20 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         // a lean slot whose clonality list cannot be used (too many entries for the list / for a list to pay): again, with the dense array
         const bool clon_overflow = !cf && dense && b->sparse_out && b->lean && !b->clon_dense &&
                                    ((size_t)b->n_clon > b->cap_clon || (size_t)b->n_clon * 2 > (size_t)b->n_pos);
-        if (!cf && !cov8_overflow && !clon_overflow && !nib_overflow) break;
+        // a lean slot's batch taken for shallow whose clonTR list cannot be used (deep after all): again, with the dense array
+        const bool rare_overflow = !cf && dense && p->prm.rarefied_coverage > 0 && !b->rare_dense &&
+                                   ((size_t)b->n_rare > p->cap_rare || (size_t)b->n_rare * 8 > (size_t)b->n_pos);
+        if (!cf && !cov8_overflow && !clon_overflow && !nib_overflow && !rare_overflow) break;
         if (attempt == 7) { isx_set_error("output tables still too small after 8 growth steps"); return ISX_ERR_CAPACITY; }
         // a table was too small for this batch: grow it and repeat the pass (the slot still holds its input)
         if (cov8_overflow) b->cov8_out = false;
         if (nib_overflow) b->nib_out = false;
         if (clon_overflow) b->clon_dense = true;
+        if (rare_overflow) b->rare_dense = true;
         if (cf && (rc = batch_grow_tables(b, cf)) != ISX_OK) return rc;
         if (!dense) b->cap_ovf = b->cap_entries - (size_t)b->n_win * b->slab;
         std::lock_guard<std::mutex> lk(p->launch_mu);
-        if (dense && p->prm.rarefied_coverage > 0)
+        if (dense && p->prm.rarefied_coverage > 0 && b->rare_dense)
             HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)b->n_pos, ps));
         if ((rc = launch_pass(b)) != ISX_OK) return rc;
         {   // published here, under the launch lock like a submit's pass: finish_pass must not touch the stream's publication state
@@ -831,7 +835,7 @@ static int enqueue_pass_impl(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticke
     // ---- pass queue ----
     std::unique_lock<std::mutex> launch_lk(p->launch_mu);
     HIP_TRY(hipStreamWaitEvent(ps, s.ev_h2d1, 0));
-    if (dense && p->prm.rarefied_coverage > 0)
+    if (dense && p->prm.rarefied_coverage > 0 && b->rare_dense)     // (a lean slot's shallow batch hands back the clonTR list alone)
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)n_pos, ps));
     if (linkage && p->rb == 4)
         launch_extract_gpos(nullptr, b->d_rec32, b->d_gbase, nullptr, b->d_gpos16, b->d_gbase, ISX_GROUP, b->n_rec, ps);
@@ -976,6 +980,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
     b->nib_out = b->cov8_out && b->lean && (double)b->n_obs < 6.0 * (double)n_pos;      // (mean depth below 6: most windows stay within 4 bits)
     b->clon_dense = false;
+    b->rare_dense = !(b->lean && b->sparse_out) || (double)b->n_obs * 4.0 >= (double)p->prm.rarefied_coverage * (double)b->n_pos;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
     b->packed = 0;
@@ -1211,6 +1216,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)n_pos;
     b->nib_out = b->cov8_out && b->lean && (double)b->n_obs < 6.0 * (double)n_pos;      // (mean depth below 6: most windows stay within 4 bits)
     b->clon_dense = false;
+    b->rare_dense = !(b->lean && b->sparse_out) || (double)b->n_obs * 4.0 >= (double)p->prm.rarefied_coverage * (double)b->n_pos;
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / p->G;
     b->packed = 0;
@@ -1470,6 +1476,7 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     b->cov8_out = b->sparse_out && (double)b->n_obs < 16.0 * (double)w->n_pos;
     b->nib_out = b->cov8_out && b->lean && (double)b->n_obs < 6.0 * (double)w->n_pos;
     b->clon_dense = false;
+    b->rare_dense = !(b->lean && b->sparse_out) || (double)b->n_obs * 4.0 >= (double)p->prm.rarefied_coverage * (double)b->n_pos;
     b->n_pairs = w->n_pairs;
     b->packed = w->packed; b->W = w->W;
     b->n_win = (int)(w->win_bytes / sizeof(uint2));

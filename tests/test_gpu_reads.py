@@ -475,13 +475,16 @@ def test_lean_slot_output_equals_the_plain_slot(ctx):
     assert (~np.isnan(n2["clon"]) & (n2["clon"] != 1.0)).sum() * 2 > len(n2["clon"])        # the case that needs the dense array
 
 
-def test_lean_slot_with_a_pile_in_every_window_repeats_the_pass_without_the_4bit_plane(ctx):
+@pytest.mark.parametrize("every,rarefied", [(800, 50), (700, 24)])
+def test_lean_slot_with_a_pile_in_every_window_repeats_the_pass_without_the_4bit_plane(ctx, every, rarefied):
     """a shallow batch (mean depth 4.8) with 24 reads stacked every 800 positions (amplicon-like): every window holds positions beyond 15,
-    the 16-bit rows would outgrow the slot's coverage block -> the pass is repeated with the 8-bit plane; tables equal the plain slot's"""
+    the 16-bit rows would outgrow the slot's coverage block -> the pass is repeated with the 8-bit plane; tables equal the plain slot's.
+    (700, 24): a lean slot takes a batch of mean depth below rarefied_coverage / 4 for shallow and writes the clonTR list alone; here one
+    position in seven reaches the rarefied coverage, the list is no shorter than the array -> the pass is repeated with the dense array"""
     from instrain_amd import engine, synth
     w = synth.make_workload(genome_len=900_000, coverage=2, n_sites=400, seed=77, skip_mm=True)
     base = synth.segs_from_obs(w["obs"], w["pair"])
-    starts = np.arange(300, w["n_pos"] - 200, 800, dtype=np.uint32)
+    starts = np.arange(300, w["n_pos"] - 200, every, dtype=np.uint32)
     sg = np.repeat(starts, 24)
     codes = np.full((len(sg), 150), 4, dtype=np.uint8)
     codes[:, :100] = w["ref_codes"][sg[:, None].astype(np.int64) + np.arange(100)[None, :]]
@@ -495,7 +498,7 @@ def test_lean_slot_with_a_pile_in_every_window_repeats_the_pass_without_the_4bit
         exp_cov[int(s):int(s) + 100] += 24
     assert exp_cov.sum() < 6 * w["n_pos"]
     cap = dict(max_pos=w["n_pos"], max_obs=0, max_segs=segs.n_seg, max_splits=len(w["split_bounds"]), depth=2, host_threads=4, pin_threads=False,
-               n_mm_bins=1, enable_linkage=True, min_snp=20)
+               n_mm_bins=1, enable_linkage=True, min_snp=20, rarefied_coverage=rarefied)
     got = {}
     for lean in (False, True):
         pipe = engine.Pipe(ctx, lean_output=lean, **cap)
@@ -504,10 +507,12 @@ def test_lean_slot_with_a_pile_in_every_window_repeats_the_pass_without_the_4bit
         assert "cov8" in raw and "cov4" not in raw, lean                # the lean slot fell back: rows for every window do not fit
         assert (engine.dense_cov(raw, w["n_pos"]) == exp_cov).all()
         r = pipe.collect(t)
-        got[lean] = {k: r[k].copy() for k in ("cov16", "clon", "snv", "ld")} | {"sizes": r["sizes"]}
+        got[lean] = {k: r[k].copy() for k in ("cov16", "clon", "snv", "ld")} | {"sizes": r["sizes"], "rare": r["rare"].copy()}
         pipe.release(t)
         pipe.close()
     assert got[False]["sizes"] == got[True]["sizes"]
-    for k in ("cov16", "snv", "ld"):
+    n_reach = int((exp_cov >= rarefied).sum())
+    assert len(got[True]["rare"]) == n_reach and (n_reach * 8 > w["n_pos"]) == (rarefied == 24)
+    for k in ("cov16", "snv", "ld", "rare"):
         assert got[False][k].tobytes() == got[True][k].tobytes(), k
     assert got[False]["clon"].view(np.uint32).tobytes() == got[True]["clon"].view(np.uint32).tobytes()
