@@ -109,6 +109,21 @@ def split_obs_ranges(obs_gpos, bounds, chunk=1024):
     return np.minimum(lo, n), np.minimum(hi, n)
 
 
+def cgroup_throttled_ms():
+    """time the cgroup's cpu quota has held this container's threads back so far (cpu.stat throttled_usec), None when not readable"""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            for line in open(path):
+                k, v = line.split()
+                if k == "throttled_usec":
+                    return int(v) / 1e3
+                if k == "throttled_time":
+                    return int(v) / 1e6
+        except Exception:
+            pass
+    return None
+
+
 def cgroup_cpus():
     """cpus this container may use on average (cgroup v2 cpu.max), None when unlimited"""
     try:
@@ -1052,6 +1067,9 @@ def main():
     elif shared:
         local = local % n_dev
     use_nccl = world > 1 and dist.get_backend() == "nccl"
+    if os.environ.get("ISX_BENCH_SCHEDULE"):    # tuning aid: how the runtime's host threads wait (1 spin, 2 yield, 4 blocking sync)
+        import ctypes
+        ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(int(os.environ["ISX_BENCH_SCHEDULE"]))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local) if (world == 1 or use_nccl) else torch.device("cpu")
     numa_node = None if args.no_bind else bind_to_gpu_numa_node(torch, local)
@@ -1084,10 +1102,15 @@ def main():
     barrier()
     torch.cuda.synchronize()
     stats = []
+    cpu0, thr0 = time.process_time(), cgroup_throttled_ms()
     t0 = time.perf_counter()
     c5.run(args.steps * PPS, stats)
     torch.cuda.synchronize()
     dt_mine = time.perf_counter() - t0
+    # what the timed passes cost the HOST: cpu time of all threads of this process per wall second (stager threads, finishers, the DMA's
+    # submitters, waits that spin) beside the cpus the cgroup grants, and how long the cgroup held the process back meanwhile
+    host_cpu = {"cpus_busy": (time.process_time() - cpu0) / dt_mine, "cpus_granted": cgroup_cpus(),
+                "throttled_ms_per_pass": None if thr0 is None else (cgroup_throttled_ms() - thr0) / (args.steps * PPS)}
     barrier()
     dt = time.perf_counter() - t0
     c5.check_timed(stats)
@@ -1178,6 +1201,7 @@ def main():
             "h2d_bytes_per_base": head["roofline_pcie"]["bytes_per_profiled_base"], "pcie_frac": head["roofline_pcie"]["frac"],
             "snv_pairs_linked_per_s": head["snv_pairs_linked_per_s"],
             "stages_ms": {k: round(v, 2) for k, v in head["stages_ms_per_pass"].items()},
+            "host_cpu": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in host_cpu.items()},
         }
         if "staged_replay" in head:                 # round 4's headline (pre-staged pinned images replayed): an extra now
             out["c5_staged_replay_gbp_per_s"] = head["staged_replay"]["gbp_per_s"]

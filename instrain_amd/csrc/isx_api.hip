@@ -679,6 +679,65 @@ uint64_t build_window_directory(const uint32_t *cmin, const uint32_t *cmax, cons
     return longest;
 }
 
+// The same directory on a pool's threads (a pipe's submit runs it between a batch's record pass and the batch's copy-in: 0.25 ms on the
+// calling thread while the stager's threads wait, once per batch).  Two steps: running max / min per block of chunks with the blocks'
+// carries applied on access, then every thread its run of windows (binary search for the first window, two pointers after).
+uint64_t build_window_directory_mt(isxenc::HostPool &pool, const uint32_t *cmin, const uint32_t *cmax, const uint8_t *cany, uint64_t n_chunks, int W,
+                                   int64_t n_pos, std::vector<uint2> &win, uint32_t chunk, std::vector<uint32_t> &pmax, std::vector<uint32_t> &smin)
+{
+    const int n_win = (int)((n_pos + W - 1) / W);
+    const int T = std::min(pool.size(), 16);
+    if (T < 2 || n_chunks < 4096 || n_win < 1024) return build_window_directory(cmin, cmax, cany, n_chunks, W, n_pos, win, chunk);
+    if (pmax.size() < n_chunks) { pmax.resize(n_chunks); smin.resize(n_chunks); }
+    const uint64_t B = (n_chunks + (uint64_t)T - 1) / (uint64_t)T;         // chunks a block
+    uint32_t bmax[16], bmin[16], cmax_in[16], cmin_in[16];
+    pool.run(T, [&](int t) {
+        const uint64_t a = std::min(n_chunks, B * (uint64_t)t), e = std::min(n_chunks, a + B);
+        uint32_t run = 0;
+        for (uint64_t i = a; i < e; i++) { if (cany[i]) run = std::max(run, cmax[i]); pmax[i] = run; }
+        bmax[t] = run;
+        run = 0xFFFFFFFFu;
+        for (uint64_t i = e; i-- > a;) { if (cany[i]) run = std::min(run, cmin[i]); smin[i] = run; }
+        bmin[t] = run;
+    });
+    { uint32_t run = 0; for (int t = 0; t < T; t++) { cmax_in[t] = run; run = std::max(run, bmax[t]); } }          // what lies before / behind a block
+    { uint32_t run = 0xFFFFFFFFu; for (int t = T; t-- > 0;) { cmin_in[t] = run; run = std::min(run, bmin[t]); } }
+    auto PM = [&](uint64_t i) { return std::max(pmax[i], cmax_in[i / B]); };
+    auto SM = [&](uint64_t i) { return std::min(smin[i], cmin_in[i / B]); };
+    win.resize((size_t)n_win);
+    uint64_t longest_t[16];
+    pool.run(T, [&](int t) {
+        const int wa = (int)((int64_t)n_win * t / T), we = (int)((int64_t)n_win * (t + 1) / T);
+        uint64_t longest = 0, lo = 0, hi = 0;
+        if (wa < we) {
+            const uint64_t w0 = (uint64_t)wa * (uint64_t)W;
+            uint64_t l = 0, r = n_chunks;                    // first chunk with PM >= w0
+            while (l < r) { const uint64_t m = (l + r) >> 1; if ((uint64_t)PM(m) < w0) l = m + 1; else r = m; }
+            lo = hi = l;
+        }
+        for (int w = wa; w < we; w++) {
+            const uint64_t w0 = (uint64_t)w * (uint64_t)W, w1 = w0 + (uint64_t)W;
+            while (lo < n_chunks && (uint64_t)PM(lo) < w0) lo++;
+            if (hi < lo) hi = lo;
+            while (hi < n_chunks && (uint64_t)SM(hi) < w1) hi++;
+            win[(size_t)w] = make_uint2((uint32_t)(lo * chunk), (uint32_t)(hi * chunk));
+            longest = std::max(longest, (hi - lo) * chunk);
+        }
+        longest_t[t] = longest;
+    });
+    uint64_t longest = 0;
+    for (int t = 0; t < T; t++) longest = std::max(longest, longest_t[t]);
+    if (getenv("ISX_DIR_CHECK")) {          // tests: the threads' directory against the plain one
+        std::vector<uint2> ref;
+        const uint64_t l2 = build_window_directory(cmin, cmax, cany, n_chunks, W, n_pos, ref, chunk);
+        if (l2 != longest || ref.size() != win.size() || memcmp(ref.data(), win.data(), ref.size() * sizeof(uint2)) != 0) {
+            fprintf(stderr, "build_window_directory_mt differs from build_window_directory (%llu chunks, %d windows)\n", (unsigned long long)n_chunks, n_win);
+            abort();
+        }
+    }
+    return longest;
+}
+
 int batch_set_geometry(isx_batch *b)
 {
     const bool dense = b->M == 1;
@@ -768,6 +827,11 @@ int isx_ctx_create(int device_id, isx_ctx **out)
     }
     if (device_id < 0 || device_id >= n) { isx_set_error("bad device id"); return ISX_ERR_ARG; }
     HIP_TRY(hipSetDevice(device_id));
+    // Host threads that wait for the device (a pipe's finishers between the stages of a linkage chain, its copy-out waits) SLEEP instead
+    // of spinning: the runtime's default spins, which on a cpu-limited lease (a cgroup quota) takes the cpus the pipe's stager threads need
+    // -- measured on a 16-cpu lease: ~1.5 cpus of spinning, the cgroup throttling the process 25-35 ms of every 64 ms pass, 144 -> 159 Gbp/s
+    // with the waits blocking.  A device-wide setting of this process; ISX_ACTIVE_WAIT=1 leaves the runtime's default alone.
+    if (!getenv("ISX_ACTIVE_WAIT")) { if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError(); }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {

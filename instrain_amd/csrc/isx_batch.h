@@ -137,6 +137,8 @@ int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed);
 // the longest record range of a window
 uint64_t build_window_directory(const uint32_t *cmin, const uint32_t *cmax, const uint8_t *cany, uint64_t n_chunks, int W,
                                 int64_t n_pos, std::vector<uint2> &win, uint32_t chunk = ISX_CHUNK);
+uint64_t build_window_directory_mt(isxenc::HostPool &pool, const uint32_t *cmin, const uint32_t *cmax, const uint8_t *cany, uint64_t n_chunks, int W,
+                                   int64_t n_pos, std::vector<uint2> &win, uint32_t chunk, std::vector<uint32_t> &pmax, std::vector<uint32_t> &smin);
 
 // derived launch geometry (LDS bytes, persistent grid, row-queue capacity, entry slab) once b->W / b->packed are set
 int batch_set_geometry(isx_batch *b);

@@ -92,7 +92,7 @@ struct Slot {
     size_t sort_temp_bytes = 0;
     std::vector<float> clonr_big;           // that array when the pipe has no pinned room for it (no want_counts)
     std::vector<isx_rare> rare_big;         // more clonTR entries than the pinned block holds / the device list overflowed
-    std::vector<uint32_t> cmin, cmax;
+    std::vector<uint32_t> cmin, cmax, dir_pmax, dir_smin;     // (dir_*: scratch of the window directory)
     std::vector<uint8_t> cany;
     std::vector<uint2> win;
     std::vector<isx_snv> snv_big;           // more SNV rows than the pinned block holds (rare)
@@ -1224,9 +1224,9 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (!dense || p->drec) {
         const int Wp = batch_window_for(b, n_pos, true);
         if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-            build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win, p->G) < (dense ? 32768u : 65536u)) { b->packed = 1; W = Wp; }
+            build_window_directory_mt(*p->pool, s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win, p->G, s.dir_pmax, s.dir_smin) < (dense ? 32768u : 65536u)) { b->packed = 1; W = Wp; }
     }
-    if (!b->packed) build_window_directory(s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, W, n_pos, s.win, p->G);
+    if (!b->packed) build_window_directory_mt(*p->pool, s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, W, n_pos, s.win, p->G, s.dir_pmax, s.dir_smin);
     b->W = W;
     b->n_win = (int)s.win.size();
     if (s.win.size() > (size_t)p->pp.max_pos / 64 + 2) { isx_set_error("internal: window directory larger than the arena"); return ISX_ERR_STATE; }
@@ -1386,14 +1386,15 @@ static int stage_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, const is
     {   // the window directory, for the window this pipe's kernels will use on a batch of n_pos positions
         const uint64_t n_chunks = (uint64_t)J.n_rec / G;
         std::vector<uint2> win;
+        std::vector<uint32_t> dir_pmax, dir_smin;
         w->packed = 0;
         int W = batch_window_for(b0, n_pos, false);
         if (M > 1 || p->drec) {
             const int Wp = batch_window_for(b0, n_pos, true);
             if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, (uint32_t)G) < (M == 1 ? 32768u : 65536u)) { w->packed = 1; W = Wp; }
+                build_window_directory_mt(*p->pool, cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, (uint32_t)G, dir_pmax, dir_smin) < (M == 1 ? 32768u : 65536u)) { w->packed = 1; W = Wp; }
         }
-        if (!w->packed) build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win, (uint32_t)G);
+        if (!w->packed) build_window_directory_mt(*p->pool, cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win, (uint32_t)G, dir_pmax, dir_smin);
         w->W = W;
         w->win_bytes = win.size() * sizeof(uint2);
         if (w->win_bytes > ((size_t)n_pos / 64 + 2) * sizeof(uint2) || win.size() > (size_t)p->pp.max_pos / 64 + 2) { isx_set_error("internal: window directory larger than its region"); return ISX_ERR_STATE; }

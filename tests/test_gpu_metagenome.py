@@ -413,7 +413,7 @@ def test_c4_per_gpu_shard_read_segments(ctx):
     po.close()
 
 
-def test_c5_headline_configuration_exactly():
+def test_c5_headline_configuration_exactly(monkeypatch):
     """bench.py's headline, as it is timed: rank 0's C5 shard cut by bench.C5_BATCH_POS / C5_BATCH_SEGS (nothing restated), lean slots,
     a context with bench.C5_RESERVE_CUS compute units reserved, pipe depth 8, every batch handed over by isx_pipe_submit_planes (bit
     planes from the caller's arrays, staged inside the submit) -- and the same batches as pre-staged wires (the round-4 way, an extra
@@ -422,6 +422,7 @@ def test_c5_headline_configuration_exactly():
     one batch byte-equal to a plain pipe (plain slots, isx_segs hand-over, no reserve, depth 1)."""
     import bench
     from instrain_amd import engine, synth
+    monkeypatch.setenv("ISX_DIR_CHECK", "1")       # every window directory made on the stager's threads is compared with the plain one (aborts)
     lut, fb = util.load_lut()
     ctx5 = engine.Context(0, reserve_cus=bench.C5_RESERVE_CUS)
     ctx5.set_null_model(lut, fb)
