@@ -14,6 +14,8 @@
 #include <type_traits>
 #include <vector>
 #include <unistd.h>
+#include <sys/prctl.h>
+#include <time.h>
 
 #include "isx_batch.h"
 #include "seg_encode.h"
@@ -275,9 +277,45 @@ void isx_read_drop()
     g_rb.used = 0;
 }
 
+// Host threads that wait for the device (a pipe's finishers between the stages of a linkage chain and in front of the copy-out, the
+// bounce copies) SLEEP between polls instead of calling the runtime's own waits: those spin by default, which on a cpu-limited lease (a
+// cgroup quota) takes the cpus the pipe's stager threads need -- measured on a 16-cpu lease: ~1.5 cpus of spinning, the cgroup throttling the
+// whole process 25-35 ms of every 64 ms pass.  (hipDeviceScheduleBlockingSync would do the same through the completion interrupt, but it is a
+// device-wide setting of the host process and a three-rank job sharing one GPU hung under it.)  A few polls back to back for the short waits,
+// then naps that grow to 200 us; ISX_ACTIVE_WAIT=1 calls the runtime's waits as before.
+static bool isx_active_wait()
+{
+    static const bool a = getenv("ISX_ACTIVE_WAIT") != nullptr;
+    return a;
+}
+template <class Ready>
+static hipError_t isx_nap_until(Ready ready)
+{
+    static thread_local bool slack_set = false;
+    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }      // this thread's naps end on time (default slack: 50 us)
+    for (int i = 0;; i++) {
+        const hipError_t r = ready();
+        if (r != hipErrorNotReady) return r;
+        if (i < 4) continue;
+        const long us = i < 40 ? 20 : (i < 100 ? 50 : 200);
+        struct timespec ts = {0, us * 1000L};
+        nanosleep(&ts, nullptr);
+    }
+}
+hipError_t isx_wait_event(hipEvent_t e)
+{
+    if (isx_active_wait()) return hipEventSynchronize(e);
+    return isx_nap_until([&] { return hipEventQuery(e); });
+}
+hipError_t isx_wait_stream(hipStream_t s)
+{
+    if (isx_active_wait()) return hipStreamSynchronize(s);
+    return isx_nap_until([&] { return hipStreamQuery(s); });
+}
+
 hipError_t isx_read_sync(hipStream_t stream)
 {
-    const hipError_t e = hipStreamSynchronize(stream);
+    const hipError_t e = isx_wait_stream(stream);
     ReadBack &rb = g_rb;
     if (e == hipSuccess) for (const auto &it : rb.items) memcpy(it.dst, rb.pin + it.off, it.bytes);
     rb.items.clear();
@@ -294,7 +332,7 @@ static int staged_upload(isx_ctx *c, T *d_dst, uint64_t n, F fill)
     int k = 0;
     for (uint64_t off = 0; off < n; off += per, k ^= 1) {
         const uint64_t cnt = std::min<uint64_t>(per, n - off);
-        HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        HIP_TRY(isx_wait_event(c->pin_ev[k]));
         fill(reinterpret_cast<T *>(c->pin[k]), off, cnt);
         HIP_TRY(hipMemcpyAsync(d_dst + off, c->pin[k], cnt * sizeof(T), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream));
@@ -461,7 +499,7 @@ struct ObsStream {
         const int rc = want16 ? upload_encoded(&b->d_rec16) : upload_encoded(&b->d_rec32);
         if (rc != ISX_OK) return rc;
         if (too_wide.load() || has_jump.load()) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(isx_wait_stream(c->stream));
             if (b->d_rec32) isx_dev_free(b->d_rec32);
             if (b->d_rec16) isx_dev_free(b->d_rec16);
             b->d_rec32 = nullptr; b->d_rec16 = nullptr;
@@ -585,7 +623,7 @@ struct ObsStream {
             }
             launch_extract_gpos(b->d_rec, b->d_rec32, b->d_gbase, b->d_gpos, b->d_gpos16, b->d_rec32 ? b->d_gbase : b->d_cbase,
                                 b->d_rec32 ? ISX_GROUP : ISX_CHUNK, b->n_rec, c->stream);
-            HIP_TRY(hipStreamSynchronize(c->stream));                     // cb is a local
+            HIP_TRY(isx_wait_stream(c->stream));                     // cb is a local
         }
         uint32_t maxp = 0;
         const int rc = staged_upload(c, b->d_pair, b->n_rec, [&](uint32_t *dst, uint64_t first, uint64_t cnt) {
@@ -782,7 +820,7 @@ static int make_pass_queues(isx_ctx *c, int r, int n_cu)
 {
     r = std::max(0, std::min(r, 8));
     if (n_cu != 256) r = 0;
-    for (int i = 0; i < 2; i++) if (c->pstream[i]) { HIP_TRY(hipStreamSynchronize(c->pstream[i])); HIP_TRY(hipStreamDestroy(c->pstream[i])); c->pstream[i] = nullptr; }
+    for (int i = 0; i < 2; i++) if (c->pstream[i]) { HIP_TRY(isx_wait_stream(c->pstream[i])); HIP_TRY(hipStreamDestroy(c->pstream[i])); c->pstream[i] = nullptr; }
     for (int k = 0; k < 8; k++) c->side_mask[k] = 0;
     c->pass_cus = 256;
     if (r > 0) {
@@ -827,11 +865,6 @@ int isx_ctx_create(int device_id, isx_ctx **out)
     }
     if (device_id < 0 || device_id >= n) { isx_set_error("bad device id"); return ISX_ERR_ARG; }
     HIP_TRY(hipSetDevice(device_id));
-    // Host threads that wait for the device (a pipe's finishers between the stages of a linkage chain, its copy-out waits) SLEEP instead
-    // of spinning: the runtime's default spins, which on a cpu-limited lease (a cgroup quota) takes the cpus the pipe's stager threads need
-    // -- measured on a 16-cpu lease: ~1.5 cpus of spinning, the cgroup throttling the process 25-35 ms of every 64 ms pass, 144 -> 159 Gbp/s
-    // with the waits blocking.  A device-wide setting of this process; ISX_ACTIVE_WAIT=1 leaves the runtime's default alone.
-    if (!getenv("ISX_ACTIVE_WAIT")) { if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError(); }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
@@ -916,10 +949,10 @@ void isx_batch_destroy(isx_batch *b)
     if (!b) return;
     for (int i = 0; i < 2; i++) {
         if (b->ctx->unpublished[i] == b) b->ctx->unpublished[i] = nullptr;
-        if (b->ctx->pstream[i]) (void)hipStreamSynchronize(b->ctx->pstream[i]);
+        if (b->ctx->pstream[i]) (void)isx_wait_stream(b->ctx->pstream[i]);
     }
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)isx_wait_stream(b->ctx->stream);
     void *ps[] = {b->d_cov_row_win, b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_drec, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors, b->d_snv_raw, b->d_sites_raw, b->d_rare_raw, b->d_win_rec, b->d_win_out};
     if (b->h_state) (void)hipHostFree(b->h_state);
@@ -1044,7 +1077,7 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
         BH(hipMemsetAsync(b->d_gbase + st.n_chunks, 0, ISX_TAIL_GROUPS * sizeof(uint32_t), c->stream));
         BH(hipMemcpyAsync(b->d_gbase, h_gbase.data(), st.n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         // (no pair table: the records carry the read-pair ids)
-        BH(hipStreamSynchronize(c->stream));         // the host vectors are locals
+        BH(isx_wait_stream(c->stream));         // the host vectors are locals
     } else if (segs) {
         // read segments: encoded on the host (the pipe does the same into pinned staging, seg_encode.cpp), one upload
         dir_chunk = ISX_SEG_GROUP;
@@ -1081,7 +1114,7 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
             BH(isx_raw_dev_malloc(&b->d_pair, (size_t)b->n_rec * sizeof(uint32_t)));
             BH(hipMemcpyAsync(b->d_pair, h_pair.data(), (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         }
-        BH(hipStreamSynchronize(c->stream));         // the host vectors are locals
+        BH(isx_wait_stream(c->stream));         // the host vectors are locals
     } else {
         int rc = st.upload_records();
         if (rc == ISX_OK && prm->enable_linkage) rc = st.upload_linkage_arrays();
@@ -1122,7 +1155,7 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
         BH(isx_raw_dev_malloc(&b->d_win, win.size() * sizeof(uint2)));
         BH(hipMemcpyAsync(b->d_win, win.data(), win.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
         BH(hipMemcpyAsync(b->d_bounds, split_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        BH(hipStreamSynchronize(c->stream));
+        BH(isx_wait_stream(c->stream));
     }
 #undef BT
 #undef BH
@@ -1285,14 +1318,14 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
             if (__atomic_load_n(ep, __ATOMIC_ACQUIRE) == b->epoch) { seen = true; break; }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(b->spin_us)) break;
         }
-        if (!seen) HIP_TRY(hipStreamSynchronize(c->pstream[b->ps]));
+        if (!seen) HIP_TRY(isx_wait_stream(c->pstream[b->ps]));
     }
     uint32_t cur[CUR_N];
     for (int i = 0; i < CUR_N; i++) { cur[i] = b->h_state[i] - b->base[i]; b->base[i] = b->h_state[i]; }
     const uint32_t flags = b->h_state[CUR_N];
     if (flags) {        // error path: start the next run from a clean slate
         HIP_TRY(hipMemsetAsync(b->d_cursors, 0, (CUR_N + 4) * sizeof(uint32_t), s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(isx_wait_stream(s));
         memset(b->base, 0, sizeof(b->base));
     }
     if (flags & ISX_FLAG_MM_RANGE) { isx_set_error("an observation has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
@@ -1326,7 +1359,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
         LinkageOut lo;
         int rc = run_linkage(in, b->L, lo);
         if (rc != ISX_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(isx_wait_stream(s));
         b->sizes.n_allele_obs = (int64_t)lo.n_ao;
         b->sizes.n_increments = (int64_t)lo.n_increments;
         b->sizes.n_edges = (int64_t)lo.n_edges;
@@ -1435,7 +1468,7 @@ int isx_batch_timings(const isx_batch *b, isx_timings *out)
     if (!b->ran) { isx_set_error("isx_batch_timings: run the batch first"); return ISX_ERR_STATE; }
     if (b->tim_pending) {
         isx_batch *m = const_cast<isx_batch *>(b);
-        HIP_TRY(hipEventSynchronize(b->ev[1]));
+        HIP_TRY(isx_wait_event(b->ev[1]));
         m->tim.pileup_ms = ev_ms(b->ev[0], b->ev[1]);
         if (!b->prm.enable_linkage) m->tim.total_ms = m->tim.pileup_ms;
         m->tim_pending = false;

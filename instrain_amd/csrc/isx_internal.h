@@ -55,6 +55,9 @@ hipError_t isx_copy_rows_to_host(void *hdst_pinned, const void *dsrc, const uint
                                  size_t cap_rows, hipStream_t stream);
 hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStream_t stream);
 hipError_t isx_read_sync(hipStream_t stream);
+// waits that sleep between polls (isx_api.hip): what every host thread of the library waits for the device with
+hipError_t isx_wait_event(hipEvent_t e);
+hipError_t isx_wait_stream(hipStream_t s);
 void isx_read_drop();       // forget the calling thread's pending read-backs (every failing HIP_TRY does: their destinations may be
                             // stack variables of the function that is about to return)
 // hipMalloc outside the caches, with the trim-and-retry of isx_dev_malloc when the device is full of cached blocks

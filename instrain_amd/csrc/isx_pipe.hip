@@ -247,7 +247,7 @@ static int bounce_d2h(isx_pipe *p, void *hdst, const void *dsrc, size_t bytes, h
     HIP_TRY(issue(0));
     for (size_t k = 0; k < n_pieces; k++) {
         if (k + 1 < n_pieces) HIP_TRY(issue(k + 1));            // its buffer was emptied one step ago
-        HIP_TRY(hipEventSynchronize(p->bounce_ev[k & 1]));
+        HIP_TRY(isx_wait_event(p->bounce_ev[k & 1]));
         const size_t off = k * piece, len = std::min(piece, bytes - off);
         const size_t sub = (size_t)1 << 20;
         const uint8_t *src = p->bounce[k & 1];
@@ -276,12 +276,12 @@ static void pipe_free(isx_pipe *p)
         for (auto &t : p->more_finishers) if (t.joinable()) t.join();
     }
     (void)hipSetDevice(p->ctx->device);
-    if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
-    if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
-    if (p->s_fin) (void)hipStreamSynchronize(p->s_fin);
-    if (p->s_fin2) (void)hipStreamSynchronize(p->s_fin2);
-    for (hipStream_t st : p->extra_fin) (void)hipStreamSynchronize(st);
-    for (int i = 0; i < 2; i++) if (p->ctx->pstream[i]) (void)hipStreamSynchronize(p->ctx->pstream[i]);
+    if (p->s_h2d) (void)isx_wait_stream(p->s_h2d);
+    if (p->s_d2h) (void)isx_wait_stream(p->s_d2h);
+    if (p->s_fin) (void)isx_wait_stream(p->s_fin);
+    if (p->s_fin2) (void)isx_wait_stream(p->s_fin2);
+    for (hipStream_t st : p->extra_fin) (void)isx_wait_stream(st);
+    for (int i = 0; i < 2; i++) if (p->ctx->pstream[i]) (void)isx_wait_stream(p->ctx->pstream[i]);
     const double t_f0 = now_ms();
     double t_batch = 0, t_dev = 0, t_pin = 0;
     for (Slot &s : p->slots) {
@@ -463,7 +463,7 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
     isx_batch *b = s.b;
     const bool dense = b->M == 1;
     const double t0 = now_ms();
-    HIP_TRY(hipEventSynchronize(s.ev_d2h1));
+    HIP_TRY(isx_wait_event(s.ev_d2h1));
     s.finish_wait_ms = (float)(now_ms() - t0);
     const double t_c0 = now_ms();
     double t_fin = 0, t_rare = 0;
@@ -526,7 +526,7 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
     };
     if (dense) {
         int rc = ISX_OK;
-        if (redo) HIP_TRY(hipStreamSynchronize(ps));
+        if (redo) HIP_TRY(isx_wait_stream(ps));
         s.cov8 = false; s.cov4 = false; s.clon_sparse = false; s.sat_complete = (size_t)b->n_sat <= b->cap_sat;
         if (b->sparse_out) {
             // coverage in 2 bytes, or 1 for a shallow batch (exact values of the few positions at 255 / 65535 or beyond in the
@@ -817,9 +817,9 @@ static int enqueue_pass(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticket)
     const int rc = enqueue_pass_impl(p, s, n_pos, ticket);
     if (rc != ISX_OK) {
         const std::string why(isx_last_error());
-        (void)hipStreamSynchronize(p->s_h2d);
-        (void)hipStreamSynchronize(p->ctx->pstream[s.b->ps]);
-        (void)hipStreamSynchronize(p->s_d2h);
+        (void)isx_wait_stream(p->s_h2d);
+        (void)isx_wait_stream(p->ctx->pstream[s.b->ps]);
+        (void)isx_wait_stream(p->s_d2h);
         isx_set_error(why);
     }
     return rc;
@@ -928,7 +928,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         const size_t half_bytes = (size_t)p->ring_half * p->rb, grp_bytes = (size_t)p->G * p->rb;
         J.ring_groups = p->ring_half / p->G;
         J.wave_begin = [&](int h) {
-            if (s.ring_busy[h]) { const hipError_t e = hipEventSynchronize(s.ev_ring[h]); if (e != hipSuccess && ring_err == hipSuccess) ring_err = e; s.ring_busy[h] = false; }
+            if (s.ring_busy[h]) { const hipError_t e = isx_wait_event(s.ev_ring[h]); if (e != hipSuccess && ring_err == hipSuccess) ring_err = e; s.ring_busy[h] = false; }
         };
         J.wave_flush = [&](int h, int64_t g0, int64_t g1) {
             const size_t n = (size_t)(g1 - g0) * grp_bytes;
@@ -951,7 +951,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         erc = isxenc::encode_obs(*p->pool, J);
         if (erc != isxenc::ENC_OK || !linkage || J.n_runs <= s.cap_runs || attempt == 1) break;
         // more pair-id runs than any batch of this slot had (short fragments): larger blocks, encode again
-        HIP_TRY(hipStreamSynchronize(p->s_h2d));
+        HIP_TRY(isx_wait_stream(p->s_h2d));
         host_block_free(s.h_runs, s.runs_pinned); s.h_runs = nullptr;
         isx_dev_free(s.d_runs); s.d_runs = nullptr;
         s.cap_runs = J.n_runs + J.n_runs / 4 + 4096;
@@ -1097,7 +1097,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         uint8_t *d_rec = s.d_in + s.off_rec;
         J.ring_groups = p->ring_half / (int64_t)p->G;
         J.wave_begin = [&s, &ring_err](int h) {
-            if (s.ring_busy[h]) { const hipError_t e = hipEventSynchronize(s.ev_ring[h]); if (e != hipSuccess && ring_err == hipSuccess) ring_err = e; s.ring_busy[h] = false; }
+            if (s.ring_busy[h]) { const hipError_t e = isx_wait_event(s.ev_ring[h]); if (e != hipSuccess && ring_err == hipSuccess) ring_err = e; s.ring_busy[h] = false; }
         };
         J.wave_flush = [&s, p, &ring_err, &ring_bytes, half_bytes, d_rec](int h, int64_t g0, int64_t g1) {
             const size_t nb = (size_t)(g1 - g0) * grp_bytes;
@@ -1777,7 +1777,7 @@ static int pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out, const
         HIP_TRY(issue(0));
         for (size_t k = 0; k < n_pieces; k++) {
             if (k + 1 < n_pieces) HIP_TRY(issue(k + 1));        // its half was emptied by the threads one step ago
-            HIP_TRY(hipEventSynchronize(ev[k & 1]));
+            HIP_TRY(isx_wait_event(ev[k & 1]));
             const size_t off = k * piece, len = std::min(piece, bytes - off);
             const size_t sub = (size_t)1 << 20;
             const uint8_t *src = bounce[k & 1];

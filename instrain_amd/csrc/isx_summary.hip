@@ -492,7 +492,7 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
         hipLaunchKernelGGL(k_gather_entries, dim3((n + 255) / 256), dim3(256), 0, s, entries, idx + n, n, reinterpret_cast<isx_entry *>(out));
     uint32_t got[2] = {0, 0};
     FE_TRY(hipMemcpyAsync(got, cursor, 8, hipMemcpyDeviceToHost, s));
-    FE_TRY(hipStreamSynchronize(s));
+    FE_TRY(isx_wait_stream(s));
     if (got[0] != n) { isx_set_error("entry table inconsistent: " + std::to_string(got[0]) + " gathered vs " + std::to_string(n)); return done(ISX_ERR_STATE); }
     if (soa && got[1]) { isx_set_error("a (position, mm) level with coverage >= 2^24 or mm >= 256: fetch the full entries (isx_pipe_fetch_entries)"); return done(ISX_ERR_CAPACITY); }
     const double t_dev = now_ms();
@@ -508,7 +508,7 @@ int fetch_entries_sorted(hipStream_t s, const isx_entry *entries, const uint32_t
             FE_TRY(hipMemcpyAsync(dsts[k], out + (size_t)k * part_bytes, part_bytes, hipMemcpyDeviceToHost, s));
         }
     }
-    FE_TRY(hipStreamSynchronize(s));
+    FE_TRY(isx_wait_stream(s));
 #undef FE_TRY
     if (timing) fprintf(stderr, "[fetch_entries] %u entries: keys + sort + gather %.1f ms, copy of %.1f MB %.1f ms (from %.1f)\n", n, t_dev - t_0, out_bytes / 1e6, now_ms() - t_dev, t_0);
     return done(rc);
@@ -655,7 +655,7 @@ int run_summary(const SummaryIn &in, SummaryBuffers &B, isx_scaffold_level *host
     }
     HIP_TRY(hipEventRecord(in.ev[1], s));
     HIP_TRY(hipMemcpyAsync(host_out, B.rows, (size_t)n_seg * M * sizeof(isx_scaffold_level), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(isx_wait_stream(s));
     if (ms) { float v = 0.f; (void)hipEventElapsedTime(&v, in.ev[0], in.ev[1]); *ms = v; }
     return ISX_OK;
 }
@@ -745,7 +745,7 @@ int run_genome_summary(const SummaryIn &in, SummaryBuffers &B, int n_genomes, co
     }
     GS_TRY(hipEventRecord(in.ev[1], s));
     GS_TRY(hipMemcpyAsync(host_out, d_rows, (size_t)n_genomes * M * sizeof(isx_genome_level), hipMemcpyDeviceToHost, s));
-    GS_TRY(hipStreamSynchronize(s));
+    GS_TRY(isx_wait_stream(s));
 #undef GS_TRY
     if (ms) { float v = 0.f; (void)hipEventElapsedTime(&v, in.ev[0], in.ev[1]); *ms = v; }
     return done(ISX_OK);
@@ -857,7 +857,7 @@ int run_compare(const SummaryIn &a, const SummaryIn &b, uint32_t min_cov, const 
     HIP_TRY(hipMemcpyAsync(host_out, B.rows, (size_t)n_seg * M * sizeof(isx_compare_level), hipMemcpyDeviceToHost, s));
     uint32_t cur[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(cur, B.cursors, sizeof(cur), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(isx_wait_stream(s));
     B.n_snp_rows = cur[1];
     if (ms) { float v = 0.f; (void)hipEventElapsedTime(&v, a.ev[0], a.ev[1]); *ms = v; }
     return ISX_OK;

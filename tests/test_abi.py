@@ -85,3 +85,10 @@ def test_product_never_imports_oracle():
     for f in glob.glob(os.path.join(REPO, "instrain_amd", "csrc", "*")):
         if f.endswith((".hip", ".cpp", ".h")):
             assert "oracle" not in open(f).read(), f
+
+
+def test_graft_entry_build_passes():
+    """the driver's "does it build" check: __graft_entry__.build() (make is up to date here: seconds) with its own assertions --
+    every declared symbol present, the ABI version the loader and the header agree on"""
+    import __graft_entry__
+    __graft_entry__.build()

@@ -444,10 +444,10 @@ def test_bench_two_ranks_control_flow(tmp_path):
     import sys
     repo = os.path.dirname(util.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
     env = dict(os.environ, ISX_DIST_BACKEND="gloo", ISX_DEVICE="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r = util.run_group([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(repo, "bench.py"),
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05", "--detail", str(tmp_path / "d.json")],
-                       env=env, capture_output=True, text=True, timeout=900)
+                       env=env, timeout=420)
     j = _bench_line(r)
     assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["backend"] == "gloo"
     assert j["scaling"] == "strong" and j["value"] > 0 and "final_gather_ms" in j
@@ -467,8 +467,8 @@ def test_bench_eight_ranks_control_flow(tmp_path):
     import sys
     repo = os.path.dirname(util.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ISX_DIST_BACKEND", "ISX_DEVICE")}
-    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--scale", "0.04", "--depth", "2",
-                        "--host-threads", "2", "--only-c5", "--detail", str(tmp_path / "d.json")], env=env, capture_output=True, text=True, timeout=1500)
+    r = util.run_group([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--scale", "0.04", "--depth", "2",
+                        "--host-threads", "2", "--only-c5", "--detail", str(tmp_path / "d.json")], env=env, timeout=600)
     j = _bench_line(r)
     assert j["n_gpus"] == 8 and j["world_size_seen"] == 8 and j["value"] > 0 and j["passes_per_step"] == 16
     assert len(j["per_rank"]["pass_ms"]) == 8 and min(j["per_rank"]["batches"]) >= 1
@@ -482,8 +482,8 @@ def test_bench_starts_its_own_ranks(tmp_path):
     import sys
     repo = os.path.dirname(util.GOLD.rstrip("/")).rsplit("/tests", 1)[0]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ISX_DIST_BACKEND", "ISX_DEVICE")}
-    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--scale", "0.05",
-                        "--only-c5", "--detail", str(tmp_path / "d.json")], env=env, capture_output=True, text=True, timeout=900)
+    r = util.run_group([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--scale", "0.05",
+                        "--only-c5", "--detail", str(tmp_path / "d.json")], env=env, timeout=420)
     j = _bench_line(r)
     assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["value"] > 0
     import torch

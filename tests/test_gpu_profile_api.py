@@ -506,9 +506,9 @@ def test_one_bam_profiled_by_two_ranks_equals_one_rank(tmp_path):
     script.write_text(SHARDED_WORKER % repo)
     out = str(tmp_path / "gathered.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r = util.run_group([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29578", str(script), path, out, str(tmp_path / "seqs.npz")],
-                       env=env, capture_output=True, text=True, timeout=600)
+                       env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     g = np.load(out)
     assert (g["n_splits"] > 0).all() and g["n_splits"].sum() == sum(ln // 1000 + 1 for _, ln in refs)
@@ -590,9 +590,9 @@ def test_sharded_profile_with_cross_scaffold_filters(tmp_path, mode):
     out = str(tmp_path / "gathered.npz")
     port = "29581" if mode == "all_reads" else "29582"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+    r = util.run_group([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script), path, out, str(tmp_path / "seqs.npz"), mode],
-                       env=env, capture_output=True, text=True, timeout=600)
+                       env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     g = np.load(out)
     lut, fb = util.load_lut()

@@ -143,3 +143,22 @@ def segs_to_obs(segs):
     m = segs.mm[si] if segs.mm is not None else np.zeros(len(si), np.uint8)
     p = segs.pair[si] if segs.pair is not None else np.zeros(len(si), np.uint32)
     return g, b, m, p
+
+
+def run_group(cmd, env=None, timeout=300):
+    """subprocess.run(cmd, capture_output=True, text=True) in a process group of its own; a command that outlives `timeout` is killed WITH
+    its children (a launcher killed alone leaves its ranks behind, holding the GPU for every test after it)."""
+    import os
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = p.communicate()
+        raise AssertionError("timed out after %d s: %s\n%s\n%s" % (timeout, " ".join(map(str, cmd)), (out or "")[-1500:], (err or "")[-3000:]))
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
