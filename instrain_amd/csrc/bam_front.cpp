@@ -1247,7 +1247,11 @@ int isx_bam_scan_part(isx_bam *bam, int32_t part, int32_t n_parts, isx_bam_info 
     if (keep_inflated) { B.seg_cache.assign(n_seg, {}); B.seg_cache_rec.assign(n_seg, {}); }
     // waves of segments: inflate (parallel) -> record boundaries (serial walk over block_size fields) -> field
     // extraction (parallel).  At most one wave of inflated data is alive.
-    const size_t wave = (size_t)std::max(2, pool.size());
+    // (ISX_BAM_WAVE / ISX_BAM_SEG_KIB: tuning aids.  Round 5 tried several small segments per thread and wave, handed out one at a time --
+    //  256 segments in waves of 64 instead of 128 in waves of 16 -- against the 15 % a wave loses to its slowest decode: 249-276 ms
+    //  against 193-307 for the scan of the probe on one (noisy) box and a slower pass 2; not kept)
+    size_t wave = (size_t)std::max(2, pool.size());
+    if (const char *e = getenv("ISX_BAM_WAVE")) wave = (size_t)std::max(2, atoi(e));
     uint64_t first = B.first_rec, read_ord = 0;
     std::vector<std::string> errs(n_seg);
     const size_t s0 = n_seg * (size_t)part / (size_t)n_parts, s1 = n_seg * ((size_t)part + 1) / (size_t)n_parts;
