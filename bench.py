@@ -999,6 +999,64 @@ def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
             "snv_rows": int(stats[-1][1]["n_snv"]) if stats else 0}
 
 
+def c2_mm_stream_leg(ctx, w, args, host_threads, steps, warmup):
+    """SURVEY 8(d) C2 "second run with mm on": the reference's DEFAULT mode (mm profiling on, argumentParser.py:131, controller.py:274-281)
+    streamed like c2_stream_leg -- every batch handed over inside the step (isx_pipe_submit_reads: the segments carry the pairs' mm), profiled
+    once, and what shrink_basewise keeps of the (position, mm) levels (profile_utilities.py:337-350) handed back inside the step too."""
+    _trace("C2 mm stream")
+    from instrain_amd import engine
+    M = int(w["n_mm_bins_mm"])
+    n_var = max(1, min(args.variants, steps, 16))
+    variants = make_variants(dict(w, segs=w["segs_mm"]), n_var)
+    pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=0, max_segs=int(w["segs_mm"].n_seg),
+                       max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
+                       pin_threads=args.pin, n_mm_bins=M, enable_linkage=False, window=args.window, lean_output=LEAN_SLOTS)
+    out = {"workload": "C2 streamed with mm profiling ON (%d mm bins): one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, linkage off; every batch handed over "
+                       "inside the step (isx_pipe_submit_reads), profiled once, the per-level tables handed back inside the step; %d distinct batches" % (M, n_var),
+           "mm_bins": M}
+
+    def run(n, stats=None):
+        tickets, done = [], 0
+        fetch_s = 0.0
+        n_ent = 0
+
+        def take():
+            nonlocal done, fetch_s, n_ent
+            t0 = time.perf_counter()
+            r = pipe.collect(tickets[done], want_ld=False, densify=False, shrunk_entries=True)
+            fetch_s += time.perf_counter() - t0
+            n_ent = r["sizes"]["n_entries"]
+            if stats is not None:
+                stats.append((r["stats"], r["sizes"]))
+            pipe.release(tickets[done])
+            done += 1
+
+        for i in range(n):
+            if len(tickets) - done == args.depth:
+                take()
+            v = variants[i % n_var]
+            tickets.append(pipe.submit_reads(v["ref_codes"], v["split_bounds"], v["segs"]))
+        while done < len(tickets):
+            take()
+        return fetch_s, n_ent
+
+    run(warmup)
+    stats = []
+    t0 = time.perf_counter()
+    fetch_s, n_ent = run(steps, stats)
+    dt = time.perf_counter() - t0
+    pipe.close()
+    st = [s for s, _ in stats]
+    mean = lambda k: float(np.mean([s[k] for s in st])) if st else 0.0
+    ms_step = dt / steps * 1e3
+    out.update({"gbp_per_s": float(w["profiled_bases"]) * steps / dt / 1e9, "ms_per_step": ms_step, "steps": steps, "warmup": warmup,
+                "entries": int(n_ent), "record_bytes": int(st[0]["record_bytes"]) if st else None,
+                "h2d_bytes_per_step": mean("h2d_bytes"), "d2h_bytes_per_step": mean("d2h_bytes"),
+                "stages_ms": {"host_stage": mean("encode_ms"), "copy_in": mean("h2d_ms"), "kernel": mean("kernel_ms"), "copy_out": mean("d2h_ms"),
+                              "collect_wait": mean("collect_wait_ms"), "collect_and_fetch": fetch_s / steps * 1e3, "step": ms_step}})
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) under
     torch.distributed.run on this node and hand their output through."""
@@ -1037,6 +1095,7 @@ def main():
     ap.add_argument("--no-resident-leg", action="store_true")
     ap.add_argument("--no-c2-leg", action="store_true")
     ap.add_argument("--no-bam-leg", action="store_true", help="skip the BAM end-to-end legs (profile_bam, c5_bam, bam_sharded)")
+    ap.add_argument("--only-mm", action="store_true", help="the mm-on legs alone (debug)")
     ap.add_argument("--only-c5", action="store_true", help="the headline alone: no C2 legs, no BAM legs, no CPU baselines (debug)")
     ap.add_argument("--detail", default=os.path.join(REPO, "bench_detail.json"), help="where the full record goes (the printed line is a digest)")
     ap.add_argument("--window", type=int, default=0)
@@ -1271,6 +1330,8 @@ def main():
             if want_mm:
                 legs["mm_on"] = mm_leg(ctx, w)
                 out["mm_on_roofline_frac"] = legs["mm_on"]["roofline"]["frac"]
+                legs["c2_mm_stream"] = c2_mm_stream_leg(ctx, w, args, host_threads, 32, 4)
+                out["c2_mm_stream_gbp_per_s"] = legs["c2_mm_stream"]["gbp_per_s"]
             if not args.no_linkage_leg:
                 legs["linkage"] = linkage_leg(ctx)
                 out["c3_snv_pairs_linked_per_s"] = legs["linkage"]["snv_pairs_linked_per_s"]
