@@ -1015,7 +1015,9 @@ def c2_mm_stream_leg(ctx, w, args, host_threads, steps, warmup):
                        "inside the step (isx_pipe_submit_reads), profiled once, the per-level tables handed back inside the step; %d distinct batches" % (M, n_var),
            "mm_bins": M}
 
-    def run(n, stats=None):
+    pipe_levels = [False]
+
+    def run(n, stats=None, check=None):
         tickets, done = [], 0
         fetch_s = 0.0
         n_ent = 0
@@ -1023,11 +1025,15 @@ def c2_mm_stream_leg(ctx, w, args, host_threads, steps, warmup):
         def take():
             nonlocal done, fetch_s, n_ent
             t0 = time.perf_counter()
+            # the level tables as they come home (views of the slot's pinned block: level mask, coverage bytes, lists)
             r = pipe.collect(tickets[done], want_ld=False, densify=False, shrunk_entries=True)
             fetch_s += time.perf_counter() - t0
             n_ent = r["sizes"]["n_entries"]
             if stats is not None:
                 stats.append((r["stats"], r["sizes"]))
+            if check is not None:
+                check(done % n_var, r)
+            pipe_levels[0] = "levels" in r
             pipe.release(tickets[done])
             done += 1
 
@@ -1040,11 +1046,34 @@ def c2_mm_stream_leg(ctx, w, args, host_threads, steps, warmup):
             take()
         return fetch_s, n_ent
 
+    # untimed: every distinct batch's level tables expanded on the host -- the levels' coverages must add up to the observations handed
+    # over, batch 0 must equal the one-shot batch's entries column by column
+    seen = {}
+
+    def check(k, r):
+        g, mc, cl, cr = pipe.expand_levels(r) if "levels" in r else r["entries_soa"]
+        cov = (mc & 0xFFFFFF).astype(np.int64)
+        assert int(cov.sum()) == int(w["n_obs"]), ("mm stream: coverage does not add up", k, int(cov.sum()), int(w["n_obs"]))
+        assert (np.diff(g.astype(np.int64) * 256 + (mc >> 24)) > 0).all(), ("mm stream: levels out of order", k)
+        seen[k] = (len(g), int(np.isfinite(cl).sum()), int(r["sizes"]["n_snv"]))
+        if k == 0:
+            b = engine.Batch(ctx, variants[0]["ref_codes"], variants[0]["split_bounds"], variants[0]["segs"], None, n_mm_bins=M, enable_linkage=False)
+            b.run()
+            e = b.fetch()["entries"]
+            b.close()
+            assert g.tobytes() == e["gpos"].tobytes() and ((mc >> 24) == e["mm"]).all() and (cov == e["cnt"].sum(axis=1)).all(), "mm stream: levels != one-shot entries"
+            assert cl.tobytes() == e["clon"].tobytes() and cr.tobytes() == e["clon_rarefied"].tobytes(), "mm stream: clonalities != one-shot entries"
+
+    run(n_var, check=check)
     run(warmup)
     stats = []
     t0 = time.perf_counter()
     fetch_s, n_ent = run(steps, stats)
     dt = time.perf_counter() - t0
+    for i, (_, sz) in enumerate(stats):
+        assert (int(sz["n_entries"]), int(sz["n_snv"])) == (seen[i % n_var][0], seen[i % n_var][2]), ("mm stream: a timed batch differs from its verified pass", i)
+    out["verified"] = "untimed pass: every batch's levels expanded on the host (coverage adds up to the observations, (position, mm) order), batch 0 == one-shot entries bit by bit; timed batches: level / SNV row counts equal"
+    out["hand_back"] = "level-sparse (isx_pipe_result.lev_*)" if pipe_levels[0] else "32-byte entries -> isx_pipe_fetch_entries_shrunk"
     pipe.close()
     st = [s for s, _ in stats]
     mean = lambda k: float(np.mean([s[k] for s in st])) if st else 0.0

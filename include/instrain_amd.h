@@ -52,7 +52,8 @@ extern "C" {
 /* 4 (round 5): isx_pipe_result grew (coverage4 / cov_rows ...), isx_pipe_params.lean_output reads what was padding, one-mm-bin read
  * batches travel as 32-byte reference-delta records, bit-plane hand-over (isx_read_planes).  A caller compiled against another version
  * must not call in: compare isx_abi_version() with this constant first (instrain_amd/_lib.py does and refuses to load). */
-#define ISX_ABI_VERSION 4
+/* 5 (round 6): isx_pipe_result grew again (lev_*: the level-sparse hand-back of mm profiling), isx_levels_expand, ISX_LAYOUT_MM_ENTRIES. */
+#define ISX_ABI_VERSION 5
 
 /* Base codes everywhere: 0=A 1=C 2=T 3=G (P2C order, profile_utilities.py:34), 4 = anything else. */
 
@@ -92,6 +93,9 @@ typedef struct {
 #define ISX_LAYOUT_NO_PACKED_COUNTERS 4 /* mm path: u32 instead of packed u16 LDS counters */
 #define ISX_LAYOUT_SEG64_RECORDS 8      /* read-level batch with one mm bin: 64-byte segment records (3-bit codes, the round-3 stream)
                                          * instead of the 32-byte reference-delta records */
+
+#define ISX_LAYOUT_MM_ENTRIES 16        /* read-level pipe with mm profiling on: hand the levels back as 32-byte entries in window slabs (the
+                                         * round-2 way: isx_pipe_fetch_entries) instead of the level-sparse tables (isx_pipe_result.lev_*) */
 
 /* (position, mm)-present entry: one per mm level present at a position, ascending mm.
  * 32 bytes (two aligned 16-byte device stores).  cnt = counts of THIS level; covT[mm][pos] = sum(cnt);
@@ -421,7 +425,35 @@ typedef struct {
     const uint32_t *cov_row_window; /* [n_cov_rows] */
     int64_t n_cov_rows;
     int32_t cov_window, pad_cov;
+    /* n_mm_bins in 2..32 (mm profiling on, the reference's default: argumentParser.py:131) in a read-level pipe without want_counts: what
+     * shrink_basewise keeps of the (position, mm) levels (profile_utilities.py:337-350; covT = the level's own coverage, :288-295; clonT /
+     * clonTR of the counts up to the level, snv_utilities.py:85-104) comes home LEVEL-SPARSE instead of as 32-byte entries --
+     *   lev_mask     [n_pos] elements of lev_mask_bytes (1, 2, 4): bit m = level m is present at the position (also a level made present
+     *                by a base that is not A/C/T/G: coverage 0, profile_utilities.py:279-285)
+     *   lev_cov      [n_lev] elements of lev_cov_bytes (1, or 2 for a deep batch): the level's coverage, saturating at 255 / 65535 -- the
+     *                levels of window w (positions [w * lev_window, (w + 1) * lev_window)) are the elements from lev_win_off[w] on, in
+     *                (position, mm) order; the windows' ranges are disjoint but in no particular order
+     *   lev_sat      [n_lev_sat] (index into lev_cov, exact coverage) of the saturated elements
+     *   lev_clon     [n_lev_clon] (index, clonT): every level whose cumulative coverage reaches min_cov has clonT exactly 1.0 EXCEPT the
+     *                listed ones (more than one base observed up to that level); below min_cov there is none (NaN)
+     *   lev_rare     [n_lev_rare] (index, clonTR) of the levels that have one (cumulative coverage >= rarefied_coverage)
+     * 1-3 bytes per level over PCIe instead of 32 (16 with isx_pipe_fetch_entries_shrunk).  isx_levels_expand makes the four columns of
+     * isx_pipe_fetch_entries_shrunk from them on the host.  A lean slot (isx_pipe_params.lean_output) writes nothing else; a plain
+     * slot also keeps the 32-byte entries on the device (isx_batch_summarize, isx_pipe_fetch_entries).  NULL / 0 otherwise. */
+    const void *lev_mask;
+    const void *lev_cov;
+    const uint32_t *lev_win_off;
+    const isx_rare *lev_clon, *lev_rare;    /* .gpos = the level's index into lev_cov */
+    const isx_sat *lev_sat;                 /* .gpos = the level's index into lev_cov */
+    int64_t n_lev, n_lev_clon, n_lev_rare, n_lev_sat;
+    int32_t lev_mask_bytes, lev_cov_bytes, lev_window, n_lev_windows, lev_min_cov, pad_lev;
 } isx_pipe_result;
+
+/* The level-sparse tables of a collected batch (isx_pipe_result.lev_*) as the four columns of isx_pipe_fetch_entries_shrunk: n_lev values
+ * each in (gpos, mm) order -- gpos; mm_cov = mm << 24 | the level's coverage; clon; clon_rarefied (NaN = none).  Host work only (no GPU
+ * call), on host_threads threads.  ISX_ERR_CAPACITY when a level's coverage reaches 2^24; ISX_ERR_STATE when the result holds no such
+ * tables or they are inconsistent. */
+int isx_levels_expand(const isx_pipe_result *r, int32_t host_threads, uint32_t *gpos, uint32_t *mm_cov, float *clon, float *clon_rarefied);
 
 int isx_pipe_create(isx_ctx *ctx, const isx_params *params, const isx_pipe_params *pp, isx_pipe **out);
 void isx_pipe_destroy(isx_pipe *p);

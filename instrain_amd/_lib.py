@@ -56,7 +56,7 @@ class Segs(C.Structure):
 
 
 PLANE_WORDS = 8
-ABI_VERSION = 4             # ISX_ABI_VERSION of include/instrain_amd.h this binding was written against
+ABI_VERSION = 5             # ISX_ABI_VERSION of include/instrain_amd.h this binding was written against
 
 
 class ReadPlanes(C.Structure):
@@ -97,7 +97,12 @@ class PipeResult(C.Structure):
                 ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64), ("ld", C.c_void_p),
                 ("coverage8", C.c_void_p), ("clon_sparse", C.c_void_p), ("n_clon", C.c_int64), ("saturated", C.c_void_p),
                 ("coverage4", C.c_void_p), ("cov_rows", C.c_void_p), ("cov_row_window", C.c_void_p), ("n_cov_rows", C.c_int64),
-                ("cov_window", C.c_int32), ("pad_cov", C.c_int32)]
+                ("cov_window", C.c_int32), ("pad_cov", C.c_int32),
+                # mm profiling on, level-sparse hand-back (include/instrain_amd.h isx_pipe_result.lev_*)
+                ("lev_mask", C.c_void_p), ("lev_cov", C.c_void_p), ("lev_win_off", C.c_void_p), ("lev_clon", C.c_void_p), ("lev_rare", C.c_void_p),
+                ("lev_sat", C.c_void_p), ("n_lev", C.c_int64), ("n_lev_clon", C.c_int64), ("n_lev_rare", C.c_int64), ("n_lev_sat", C.c_int64),
+                ("lev_mask_bytes", C.c_int32), ("lev_cov_bytes", C.c_int32), ("lev_window", C.c_int32), ("n_lev_windows", C.c_int32),
+                ("lev_min_cov", C.c_int32), ("pad_lev", C.c_int32)]
 
 
 class BamParams(C.Structure):
@@ -148,7 +153,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_batch_create", "isx_batch_create_reads", "isx_batch_destroy", "isx_batch_run", "isx_batch_launch", "isx_batch_wait", "isx_batch_sizes", "isx_batch_timings",
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld", "isx_batch_fetch_allele_obs",
            "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
-           "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_stage_reads", "isx_pipe_submit_wire", "isx_wire_bytes", "isx_wire_free", "isx_wire_keep_reference", "isx_pipe_submit_bam", "isx_encode_segs", "isx_encode_segs_ring", "isx_seg_records_needed", "isx_encode_delta", "isx_delta_records_needed", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_pipe_fetch_entries_shrunk", "isx_encode_obs", "isx_encode_obs_ring",
+           "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_stage_reads", "isx_pipe_submit_wire", "isx_wire_bytes", "isx_wire_free", "isx_wire_keep_reference", "isx_pipe_submit_bam", "isx_encode_segs", "isx_encode_segs_ring", "isx_seg_records_needed", "isx_encode_delta", "isx_delta_records_needed", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_pipe_fetch_entries_shrunk", "isx_levels_expand", "isx_encode_obs", "isx_encode_obs_ring",
            "isx_pack_ref_planes", "isx_planes_from_segs", "isx_pack_read_planes", "isx_pipe_submit_planes", "isx_pipe_stage_planes", "isx_encode_planes", "isx_pipe_set_reference_budget",
            "isx_bgzf_index", "isx_bgzf_inflate_device", "isx_bgzf_inflate_host", "isx_bgzf_inflate_fast",
            "isx_bam_open", "isx_bam_close", "isx_bam_close_wait", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
@@ -225,6 +230,7 @@ def load():
     lib.isx_pipe_release.argtypes = [vp, i64]
     lib.isx_pipe_fetch_entries.argtypes = [vp, i64, vp]
     lib.isx_pipe_fetch_entries_shrunk.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.isx_levels_expand.argtypes = [C.POINTER(PipeResult), i32, vp, vp, vp, vp]
     lib.isx_encode_obs.argtypes = [vp, vp, i64, i64, i32, i32, C.c_double, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
     lib.isx_encode_obs_ring.argtypes = [vp, vp, i64, i64, i32, i32, C.c_double, i64, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
     lib.isx_bam_open.argtypes = [C.c_char_p, C.POINTER(vp)]

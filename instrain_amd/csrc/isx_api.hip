@@ -953,7 +953,7 @@ void isx_batch_destroy(isx_batch *b)
     }
     (void)hipSetDevice(b->ctx->device);
     (void)isx_wait_stream(b->ctx->stream);
-    void *ps[] = {b->d_cov_row_win, b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_drec, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_slev,
+    void *ps[] = {b->d_cov_row_win, b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_drec, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_lev_mask, b->d_lev_cov, b->d_lev_win_off, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors, b->d_snv_raw, b->d_sites_raw, b->d_rare_raw, b->d_win_rec, b->d_win_out};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) isx_dev_free(p);          // (falls through to hipFree for blocks that did not come from the cache)
@@ -1237,6 +1237,14 @@ int launch_pass(isx_batch *b)
     a.seed_lo = (uint32_t)b->prm.seed; a.seed_hi = (uint32_t)(b->prm.seed >> 32);
     a.entries = b->d_entries; a.slab = b->slab; a.cap_ovf = (uint32_t)b->cap_ovf;
     a.ovf0 = (uint64_t)b->n_win * b->slab; a.win_nent = b->d_win_nent;
+    if (b->lev_sparse) {                        // mm path of a pipe slot: the levels go home as mask + coverage bytes + lists (PileupArgs::lev_*)
+        a.lev_mask = b->d_lev_mask; a.lev_cov = b->d_lev_cov; a.lev_win_off = b->d_lev_win_off;
+        a.lev_mask_bytes = b->lev_mask_bytes; a.lev_cov_bytes = b->lev_cov_bytes;
+        a.cap_lev = (uint32_t)std::min<size_t>(b->cap_lev, 0xFFFFFFFEu);
+        a.sat_thr = b->lev_cov_bytes == 1 ? 255u : 65535u;
+        a.clon_list = b->d_clon_list; a.cap_clon = (uint32_t)std::min<size_t>(b->cap_clon, 0xFFFFFFFFu);
+        a.cov16 = nullptr; a.cov8 = nullptr; a.clon = nullptr; a.clon_r = nullptr;
+    }
     a.slev = b->d_slev; a.cap_slev = (uint32_t)std::min<size_t>(b->cap_slev, 0xFFFFFFFFu);
     a.snv = b->d_snv; a.cap_snv = (uint32_t)std::min<size_t>(b->cap_snv, 0xFFFFFFFFu);
     a.sites = b->d_sites; a.cap_sites = (uint32_t)std::min<size_t>(b->cap_sites, 0xFFFFFFFFu);
@@ -1335,7 +1343,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
     }
     b->sizes = isx_sizes{};
     b->sizes.n_entries = cur[CUR_ENT_TOTAL];
-    b->n_ovf = cur[CUR_ENTRIES];
+    b->n_ovf = b->lev_sparse ? cur[CUR_ENT_TOTAL] : cur[CUR_ENTRIES];        // (a flat table = no slabs, every entry an "overflow" entry)
     b->sizes.n_snv = cur[CUR_SNV];
     b->sizes.n_sites = cur[CUR_SITES];
     b->n_rare = cur[CUR_RARE]; b->n_sat = cur[CUR_SAT]; b->n_clon = cur[CUR_CLON]; b->n_cov_rows = cur[CUR_COVX];
@@ -1405,7 +1413,22 @@ int batch_grow_tables(isx_batch *b, uint32_t cap_flags)
         }
     }
     if (cap_flags & ISX_FLAG_CAP_AO) { if ((rc = regrow(&b->d_ao, &b->cap_ao, (size_t)obs_bound))) return rc; }
-    if (cap_flags & ISX_FLAG_CAP_ENTRIES) {
+    if ((cap_flags & ISX_FLAG_CAP_ENTRIES) && b->lev_sparse) {
+        // level-sparse slot: the coverage stream (and the flat entry table, when kept) x4 up to one level per (position, mm bin)
+        const size_t bound = (size_t)std::min<uint64_t>(npm, 0xFFFFFFF0ull);
+        if (b->cap_lev >= bound) { isx_set_error("output table is at its hard bound and still too small"); return ISX_ERR_CAPACITY; }
+        const size_t cap = std::min(bound, std::max<size_t>(b->cap_lev * 4, 1024));
+        if (b->d_lev_cov) isx_dev_free(b->d_lev_cov);
+        b->d_lev_cov = nullptr;
+        HIP_TRY(isx_raw_dev_malloc(reinterpret_cast<uint8_t **>(&b->d_lev_cov), cap * 2 + 64));
+        if (b->d_entries) {
+            isx_dev_free(b->d_entries);
+            b->d_entries = nullptr;
+            HIP_TRY(isx_raw_dev_malloc(&b->d_entries, cap * sizeof(isx_entry)));
+            b->cap_entries = cap;
+        }
+        b->cap_lev = cap;
+    } else if (cap_flags & ISX_FLAG_CAP_ENTRIES) {
         const size_t used_slabs = (size_t)b->n_win * b->slab;
         const size_t slabs = b->slab_region ? b->slab_region : used_slabs;      // entries set aside for the window slabs
         size_t cap = b->cap_entries - slabs;
@@ -1489,7 +1512,8 @@ int isx_batch_fetch_entries(isx_batch *b, isx_entry *out)
     const size_t n = (size_t)b->sizes.n_entries;
     if (!n) return ISX_OK;
     // the device table is one slab per window (used prefix = win_nent[w]) + the overflow region
-    return fetch_entries_sorted(b->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, (uint32_t)b->n_win, b->n_ovf, n, out);
+    if (!b->d_entries) { isx_set_error("this batch lives in a lean pipe slot (isx_pipe_params.lean_output): its 32-byte entries were not written -- the levels come with isx_pipe_collect (isx_pipe_result.lev_*)"); return ISX_ERR_STATE; }
+    return fetch_entries_sorted(b->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, entry_wins(b), b->n_ovf, n, out);
 }
 
 int isx_batch_fetch_dense(isx_batch *b, uint32_t *counts, float *clon, float *clon_rarefied)
@@ -1516,11 +1540,11 @@ int isx_batch_summarize(isx_batch *b, int32_t n_scaffolds, const int64_t *scaffo
     SummaryIn in{};
     in.stream = b->ctx->stream; in.ev = b->ev_sum;
     in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
-    if (b->lean && !b->d_counts) { isx_set_error("this batch lives in a lean pipe slot (isx_pipe_params.lean_output): its dense coverage / clonality arrays were not written"); return ISX_ERR_STATE; }
+    if (b->lean && !b->d_counts && !b->d_entries) { isx_set_error("this batch lives in a lean pipe slot (isx_pipe_params.lean_output): its dense coverage / clonality arrays were not written"); return ISX_ERR_STATE; }
     in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
     in.cov16 = b->d_cov16; in.sat = b->d_sat; in.n_sat = (uint32_t)std::min<size_t>(b->n_sat, b->cap_sat);
-    in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
-    in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
+    in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = entry_wins(b);
+    in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)entry_wins(b) * b->slab;
     return run_summary(in, b->S, out, device_ms);
 }
 
@@ -1543,11 +1567,11 @@ int isx_batch_summarize_genomes(isx_batch *b, int32_t n_scaffolds, const int64_t
     SummaryIn in{};
     in.stream = b->ctx->stream; in.ev = b->ev_sum;
     in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
-    if (b->lean && !b->d_counts) { isx_set_error("this batch lives in a lean pipe slot (isx_pipe_params.lean_output): its dense coverage / clonality arrays were not written"); return ISX_ERR_STATE; }
+    if (b->lean && !b->d_counts && !b->d_entries) { isx_set_error("this batch lives in a lean pipe slot (isx_pipe_params.lean_output): its dense coverage / clonality arrays were not written"); return ISX_ERR_STATE; }
     in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
     in.cov16 = b->d_cov16; in.sat = b->d_sat; in.n_sat = (uint32_t)std::min<size_t>(b->n_sat, b->cap_sat);
-    in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
-    in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
+    in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = entry_wins(b);
+    in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)entry_wins(b) * b->slab;
     return run_genome_summary(in, b->S, n_genomes, genome_first_scaffold, mask_edges, out, device_ms);
 }
 
@@ -1557,8 +1581,8 @@ static void fill_summary_in(isx_batch *b, int32_t n_scaffolds, const int64_t *sc
     in.n_pos = (uint32_t)b->n_pos; in.n_scaffolds = n_scaffolds; in.M = b->M; in.scaffold_bounds = scaffold_bounds;
     in.counts = b->d_counts; in.clon = b->d_clon; in.clon_r = b->d_clon_r;
     in.cov16 = b->d_cov16; in.sat = b->d_sat; in.n_sat = (uint32_t)std::min<size_t>(b->n_sat, b->cap_sat);
-    in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = (uint32_t)b->n_win;
-    in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)b->n_win * b->slab;
+    in.entries = b->d_entries; in.win_nent = b->d_win_nent; in.slab = b->slab; in.n_win = entry_wins(b);
+    in.n_ovf = b->n_ovf; in.ovf0 = (uint64_t)entry_wins(b) * b->slab;
 }
 
 int isx_compare_coverage(isx_batch *a, isx_batch *b, int32_t n_scaffolds, const int64_t *scaffold_bounds, int32_t min_cov,

@@ -92,6 +92,15 @@ struct isx_batch {
     bool rare_dense = true;             // this pass writes the dense clonTR array (a lean slot's shallow batch: the list alone; finish_slot repeats the pass otherwise)
     bool lean = false, clon_dense = false;       // lean slot (isx_pipe_params.lean_output): the dense clonality array / the 16-bit coverage
                                                  // are written only when a batch needs them (clon_dense: its clonality list did not fit)
+    // mm path, level-sparse hand-back (pipe slots with n_mm_bins <= 32 and no want_counts; PileupArgs::lev_*): per position the mask of its
+    // levels, per present level its coverage in lev_cov_bytes (1 for a batch shallower than 64x, else 2), the window's first level index;
+    // d_clon_list / d_rare / d_sat then hold (level index, value).  d_entries is a FLAT table indexed by level (handed to the consumers of
+    // the slab layout as "no slabs + n_entries overflow entries": entry_wins / n_ovf) -- and absent in a lean slot.
+    bool lev_sparse = false;
+    void *d_lev_mask = nullptr, *d_lev_cov = nullptr;
+    uint32_t *d_lev_win_off = nullptr;
+    size_t cap_lev = 0;
+    int lev_mask_bytes = 0, lev_cov_bytes = 1;
     isx_entry *d_entries = nullptr;  // mm path: [n_win][slab] slabs, then cap_ovf overflow entries
     uint32_t *d_win_nent = nullptr;
     isx_slev *d_slev = nullptr;
@@ -125,6 +134,10 @@ struct isx_batch {
     isx_timings tim{};
 };
 
+
+// windows of the entry table's slab region as its consumers see it (fetch_entries_sorted, the summaries): a level-sparse slot keeps a flat
+// table, i.e. no slabs and sizes.n_entries "overflow" entries
+static inline uint32_t entry_wins(const isx_batch *b) { return b->lev_sparse ? 0u : (uint32_t)b->n_win; }
 
 // ---- shared between isx_api.hip and isx_pipe.hip ----
 std::vector<uint16_t> build_thresholds(const std::vector<int32_t> &lut, int32_t fallback, double min_freq);

@@ -247,6 +247,17 @@ struct PileupArgs {
     const uint32_t *pub_cursors;
     uint32_t *pub_host_state;
     uint32_t pub_epoch;
+    // mm path, level-sparse hand-back (pipe slots with n_mm_bins <= 32 and no want_counts; k_pileup_mm<..., SPARSE>): what
+    // shrink_basewise keeps of the (position, mm) levels (profile_utilities.py:337-350) in 1-3 bytes a level instead of a 32-byte entry --
+    // which levels a position has, every present level's coverage, and the few clonalities that are not 1.0
+    void *lev_mask;             // [n_pos] bit m = level m is present at the position; element width lev_mask_bytes (1, 2 or 4)
+    void *lev_cov;              // one element (lev_cov_bytes: 1 or 2) per present (position, level): min(the level's coverage, sat_thr); a window's
+                                // levels lie together, position-major (ascending position, then ascending level), from lev_win_off[window] on
+    uint32_t *lev_win_off;      // [n_win] index of the window's first level (slots come from CUR_ENT_TOTAL, in the order the windows get there)
+    uint32_t cap_lev;           // levels lev_cov (and, when kept, the flat entry table) have room for
+    int32_t lev_mask_bytes, lev_cov_bytes;
+    // clon_list / rare / sat hold (level index, value) here: the clonT values other than 1.0, every clonTR value, the exact coverage of
+    // the levels at or beyond sat_thr; `entries` (NULL in a lean slot) is then the flat table entries[level index]
 };
 
 void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int packed, hipStream_t s, hipEvent_t ev_start,

@@ -1214,7 +1214,11 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
 // pres = levels made present by a non-ACGT base only (profile_utilities.py:279-285 creates
 // table[mm] before the KeyError), a presence the SNV loop must see.
 // ---------------------------------------------------------------------------------------------
-template <bool PACKED, bool LINKAGE, bool COMPACT, bool SEGS = false>    // SEGS: the read-segment stream (COMPACT is true then)
+// SPARSE (pipe slots, M <= 32): the levels also go home as a per-position level mask + one coverage byte (or two) per present level
+// + the list of clonalities other than 1.0 (PileupArgs::lev_*); level indices are position-major inside a window (a block-wide
+// prefix sum of the positions' level counts), the window's first index comes from one global atomic.  The 32-byte entries are then a
+// flat table indexed by level (a.entries; NULL in a lean slot: nothing but what travels home is written).
+template <bool PACKED, bool LINKAGE, bool COMPACT, bool SEGS = false, bool SPARSE = false>    // SEGS: the read-segment stream (COMPACT is true then)
 __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1402,6 +1406,60 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
                 rows++;
             }
         };
+        // SPARSE, pass A: which levels every position has -> level indices.  A lane's two positions p = tid, tid + nthr; position order
+        // is (j, tid) order, so the prefix sum runs over j = 0 first.  One global atomic hands the window its range of level slots.
+        uint32_t lmask[2] = {0, 0}, loff[2] = {0, 0};
+        uint32_t lev_base = 0;
+        bool lev_ok = true;
+        if (SPARSE) {
+            uint32_t *wtot2 = rowq;                                 // [2][16] per-wave totals (the row queue is idle until the level loop)
+            uint32_t nl2[2], inc2[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int p = tid + j * nthr;
+                const uint32_t gpos = w0 + p;
+                uint32_t mk = 0;
+                if (p < W && gpos < a.n_pos && !(dbg & 2)) {
+                    mk = pres[p];                                   // (M <= 32: one presence word)
+                    for (int m = 0; m < M; m++) {
+                        uint32_t any4;
+                        if (PACKED) any4 = cnt[(m * 2) * W + p] | cnt[(m * 2 + 1) * W + p];
+                        else any4 = cnt[(m * 4) * W + p] | cnt[(m * 4 + 1) * W + p] | cnt[(m * 4 + 2) * W + p] | cnt[(m * 4 + 3) * W + p];
+                        mk |= (any4 ? 1u : 0u) << m;
+                    }
+                    if (a.lev_mask_bytes == 1) reinterpret_cast<uint8_t *>(a.lev_mask)[gpos] = (uint8_t)mk;
+                    else if (a.lev_mask_bytes == 2) reinterpret_cast<uint16_t *>(a.lev_mask)[gpos] = (uint16_t)mk;
+                    else reinterpret_cast<uint32_t *>(a.lev_mask)[gpos] = mk;
+                }
+                lmask[j] = mk;
+                nl2[j] = (uint32_t)__popc(mk);
+                inc2[j] = wave_scan_incl(nl2[j]);
+                if (lane == 63) wtot2[j * 16 + (tid >> 6)] = inc2[j];
+            }
+            __syncthreads();
+            uint32_t tot0 = 0, before0 = 0, tot1 = 0, before1 = 0;
+            const int nwv = nthr >> 6, wv = tid >> 6;
+            for (int k = 0; k < nwv; k++) {
+                const uint32_t x0 = wtot2[k], x1 = wtot2[16 + k];
+                tot0 += x0; tot1 += x1;
+                if (k < wv) { before0 += x0; before1 += x1; }
+            }
+            loff[0] = before0 + inc2[0] - nl2[0];
+            loff[1] = tot0 + before1 + inc2[1] - nl2[1];
+            if (tid == 0) {
+                const uint32_t nw = tot0 + tot1;
+                const uint32_t at = nw ? cur_add(a, CUR_ENT_TOTAL, nw) : 0u;
+                a.lev_win_off[w] = at;
+                bool fits = at + nw <= a.cap_lev;
+                if (!fits) flag_or(a, ISX_FLAG_CAP_ENTRIES);
+                scratch[S_ENT_BASE] = at;
+                scratch[S_ENT_TOT] = fits ? 1u : 0u;
+            }
+            __syncthreads();
+            lev_base = scratch[S_ENT_BASE];
+            lev_ok = scratch[S_ENT_TOT] != 0u;
+        }
+        uint32_t n_cl = 0, n_rr = 0;                                // SPARSE: this lane's queued clonT / clonTR values (list slots are sized from them)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int p = tid + j * nthr;
@@ -1413,25 +1471,43 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
             for (int m = 0; m < M; m++) {
                 uint32_t l[4] = {0, 0, 0, 0};
                 bool present = false;
-                if (valid) {
+                if (SPARSE) {
+                    present = ((lmask[j] >> m) & 1u) != 0 && lev_ok;
+                    if (present) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) l[k] = rd(m, k, p);
+                    }
+                } else if (valid) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) l[k] = rd(m, k, p);
                     present = (l[0] | l[1] | l[2] | l[3] | ((pres[(m >> 5) * W + p] >> (m & 31)) & 1u)) != 0;
                 }
                 const unsigned long long bal = __ballot(present);
                 if (bal == 0) continue;                             // wave-uniform
-                uint32_t wbase = 0;
-                const int first = __ffsll((long long)bal) - 1;
-                if (lane == first) wbase = atomicAdd(&scratch[S_ENT_TOT], (uint32_t)__popcll(bal));
-                wbase = __shfl(wbase, first);
-                if (!present) continue;
-                const uint32_t slot_w = wbase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                 uint64_t ei;
-                if (slot_w < CW) ei = slab0 + slot_w;
-                else {                                              // slab full (more than CW / W levels per position on average)
-                    const uint32_t o = cur_add(a, CUR_ENTRIES, 1u);
-                    if (o >= a.cap_ovf) { flag_or(a, ISX_FLAG_CAP_ENTRIES); continue; }
-                    ei = a.ovf0 + o;
+                if (SPARSE) {
+                    if (!present) continue;
+                    ei = (uint64_t)(lev_base + loff[j] + (uint32_t)__popc(lmask[j] & ((1u << m) - 1u)));
+                    const uint32_t cov_m = l[0] + l[1] + l[2] + l[3];
+                    if (a.lev_cov_bytes == 1) reinterpret_cast<uint8_t *>(a.lev_cov)[ei] = (uint8_t)min(cov_m, 255u);
+                    else reinterpret_cast<uint16_t *>(a.lev_cov)[ei] = (uint16_t)min(cov_m, 65535u);
+                    if (cov_m >= a.sat_thr) {
+                        const uint32_t k = cur_add(a, CUR_SAT, 1u);
+                        if (k < a.cap_sat) a.sat[k] = make_uint2((uint32_t)ei, cov_m);
+                    }
+                } else {
+                    uint32_t wbase = 0;
+                    const int first = __ffsll((long long)bal) - 1;
+                    if (lane == first) wbase = atomicAdd(&scratch[S_ENT_TOT], (uint32_t)__popcll(bal));
+                    wbase = __shfl(wbase, first);
+                    if (!present) continue;
+                    const uint32_t slot_w = wbase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (slot_w < CW) ei = slab0 + slot_w;
+                    else {                                              // slab full (more than CW / W levels per position on average)
+                        const uint32_t o = cur_add(a, CUR_ENTRIES, 1u);
+                        if (o >= a.cap_ovf) { flag_or(a, ISX_FLAG_CAP_ENTRIES); continue; }
+                        ei = a.ovf0 + o;
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) cum[k] += l[k];         // mm_counts_to_counts(MMcounts, mm)
@@ -1451,12 +1527,17 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
                     if (qs < QCAP && ei < 0xFFFFFFFFull) {
                         queue[qs * 2 + 0] = (uint32_t)ei;
                         queue[qs * 2 + 1] = ((uint32_t)m << 16) | (uint32_t)p | (want_c ? 1u << 30 : 0u) | (want_r ? 1u << 31 : 0u);
+                        if (SPARSE) { n_cl += want_c ? 1u : 0u; n_rr += want_r ? 1u : 0u; }
                     } else {                                        // queue full: inline
                         if (want_c) cl = (float)clonality(cum, total);
                         if (want_r) clr = rarefied_clonality(a, cum, gpos, (uint32_t)m);
+                        if (SPARSE) {                               // (its own list slots: rare)
+                            if (want_c) { const uint32_t k = cur_add(a, CUR_CLON, 1u); if (k < a.cap_clon) a.clon_list[k] = make_uint2((uint32_t)ei, __float_as_uint(cl)); }
+                            if (want_r) { const uint32_t k = cur_add(a, CUR_RARE, 1u); if (k < a.cap_rare) a.rare[k] = make_uint2((uint32_t)ei, __float_as_uint(clr)); }
+                        }
                     }
                 }
-                if (!(dbg & 64)) {
+                if (!(dbg & 64) && (!SPARSE || a.entries)) {
                     uint4 *dst = reinterpret_cast<uint4 *>(&a.entries[ei]);
                     dst[0] = make_uint4(gpos, (uint32_t)m, l[0], l[1]);                     // gpos | mm,flags | cnt[0..1]
                     dst[1] = make_uint4(l[2], l[3], __float_as_uint(cl), __float_as_uint(clr));
@@ -1509,7 +1590,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
         ISX_ARGS_FRESH();
         const uint32_t n_ent = scratch[S_ENT_TOT], nrows = scratch[S_ROWS], nsites = scratch[S_SITES], nao = scratch[S_NAO],
                        nslev = scratch[S_SLEV], nrq = min(scratch[S_ROW_RANK], (uint32_t)a.rqcap);
-        if (tid == 0) {
+        if (!SPARSE && tid == 0) {
             a.win_nent[w] = min(n_ent, CW);
             my_entries += n_ent;                                    // per-workgroup total, published once at the end
         }
@@ -1519,6 +1600,19 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
         if (tid == 256 % nthr && nslev) scratch[S_SLEV_BASE] = cur_add(a, CUR_SLEV, nslev);
         // ---- deferred clonalities: calculate_clonality (snv_utilities.py:225-231) in fp64, densely packed ----
         const uint32_t nq = min(scratch[S_NQ], QCAP);
+        bool clon_fit = true, rare_fit = true;
+        if (SPARSE) {
+            // list slots of the window's queued values: the lanes' counts summed per wave, one LDS atomic a wave, one global atomic a list
+            const uint32_t wc = wave_scan_incl(n_cl), wr = wave_scan_incl(n_rr);
+            if (lane == 63) { if (wc) atomicAdd(&scratch[S_NCLON], wc); if (wr) atomicAdd(&scratch[S_NRARE], wr); }
+            __syncthreads();
+            const uint32_t nclon = scratch[S_NCLON], nrare = scratch[S_NRARE];
+            if (tid == 320 % nthr && nclon) scratch[S_CLON_BASE] = cur_add(a, CUR_CLON, nclon);
+            if (tid == 384 % nthr && nrare) scratch[S_RARE_BASE] = cur_add(a, CUR_RARE, nrare);
+            if (nclon | nrare) __syncthreads();                     // (uniform)
+            clon_fit = scratch[S_CLON_BASE] + nclon <= a.cap_clon;  // a list that outgrew its table: the host sees the cursor and repeats the pass
+            rare_fit = scratch[S_RARE_BASE] + nrare <= a.cap_rare;
+        }
         for (uint32_t q = tid; q < nq; q += nthr) {
             const uint32_t pm = queue[q * 2 + 1];
             const int p = (int)(pm & 0xFFFFu), mq = (int)((pm >> 16) & 0x3FFFu);
@@ -1527,8 +1621,16 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
 #pragma unroll
                 for (int k = 0; k < 4; k++) c[k] += rd(m, k, p);
             }
-            if (pm & (1u << 30)) a.entries[queue[q * 2]].clon = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
-            if (pm & (1u << 31)) a.entries[queue[q * 2]].clon_rarefied = rarefied_clonality(a, c, w0 + p, (uint32_t)mq);
+            if (pm & (1u << 30)) {
+                const float v = (float)clonality(c, c[0] + c[1] + c[2] + c[3]);
+                if (!SPARSE || a.entries) a.entries[queue[q * 2]].clon = v;
+                if (SPARSE && clon_fit) a.clon_list[scratch[S_CLON_BASE] + atomicAdd(&scratch[S_CLON_RANK], 1u)] = make_uint2(queue[q * 2], __float_as_uint(v));
+            }
+            if (pm & (1u << 31)) {
+                const float v = rarefied_clonality(a, c, w0 + p, (uint32_t)mq);
+                if (!SPARSE || a.entries) a.entries[queue[q * 2]].clon_rarefied = v;
+                if (SPARSE && rare_fit) a.rare[scratch[S_RARE_BASE] + atomicAdd(&scratch[S_RARE_RANK], 1u)] = make_uint2(queue[q * 2], __float_as_uint(v));
+            }
         }
         if (nrows) __syncthreads();             // uniform: bases from the atomics above
         const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE], ao_base = scratch[S_AO_BASE],
@@ -1566,7 +1668,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
         __syncthreads();
         ISX_ARGS_FRESH();
     }
-    if (tid == 0 && my_entries) cur_add(a, CUR_ENT_TOTAL, my_entries);
+    if (!SPARSE && tid == 0 && my_entries) cur_add(a, CUR_ENT_TOTAL, my_entries);
 }
 #undef a
 #undef ISX_ARGS_FRESH
@@ -1741,7 +1843,14 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
 {
     const LaunchCfg l{block, lds, grid, s, ev_start, ev_stop};
     const int sel = (a.enable_linkage != 0 ? 1 : 0) | (a.rec32 ? 2 : 0) | (packed ? 4 : 0);
-    if (a.M > 1 && a.seg) {
+    if (a.M > 1 && a.seg && a.lev_cov) {
+        switch (sel & 5) {
+        case 0: launch_one(k_pileup_mm<false, false, true, true, true>, a, l); break;
+        case 1: launch_one(k_pileup_mm<false, true, true, true, true>, a, l); break;
+        case 4: launch_one(k_pileup_mm<true, false, true, true, true>, a, l); break;
+        default: launch_one(k_pileup_mm<true, true, true, true, true>, a, l); break;
+        }
+    } else if (a.M > 1 && a.seg) {
         switch (sel & 5) {
         case 0: launch_one(k_pileup_mm<false, false, true, true>, a, l); break;
         case 1: launch_one(k_pileup_mm<false, true, true, true>, a, l); break;

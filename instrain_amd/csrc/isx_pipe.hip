@@ -95,6 +95,11 @@ struct Slot {
     std::vector<uint32_t> cmin, cmax, dir_pmax, dir_smin;     // (dir_*: scratch of the window directory)
     std::vector<uint8_t> cany;
     std::vector<uint2> win;
+    // mm path, level-sparse hand-back (isx_batch::lev_sparse): offsets into h_out and how much of each region the last batch used
+    size_t o_lmask = 0, o_lwin = 0, o_lcov = 0, o_lclon = 0, o_lrare = 0;
+    size_t lcov_room = 0, lclon_room = 0, lrare_room = 0;          // bytes
+    std::vector<uint8_t> lcov_big;          // a batch whose coverage stream / lists outgrow the pinned rooms (a deep sample)
+    std::vector<isx_rare> lclon_big, lrare_big;
     std::vector<isx_snv> snv_big;           // more SNV rows than the pinned block holds (rare)
     std::vector<isx_ld> ld_rows;            // the batch's LD rows (linkage), fetched by the finisher
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_pass = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
@@ -337,7 +342,10 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
     b->cap_pos = p->pp.max_pos; b->cap_obs = p->pp.max_obs; b->arena = true; b->ref_packed = 2;
     b->n_pos = p->pp.max_pos; b->n_obs = p->pp.max_obs;
     b->segs = p->segs; b->drec = p->drec;
-    b->lean = p->pp.lean_output != 0 && !p->pp.want_counts && b->M == 1;
+    b->lean = p->pp.lean_output != 0 && !p->pp.want_counts;
+    // mm profiling on in a read-level pipe: the levels go home sparse (mask + coverage bytes + lists) instead of as 32-byte entries;
+    // a lean slot does not even write the entries
+    b->lev_sparse = b->M > 1 && b->M <= 32 && p->segs && !p->pp.want_counts && !(prm->layout & ISX_LAYOUT_MM_ENTRIES);
     // four finishers polling for 2 ms each would take the whole CPU share of a rank that has 2-4 host threads to itself
     b->spin_us = (p->pp.host_threads > 0 && p->pp.host_threads < 8) ? 200 : 2000;
     const bool dense = b->M == 1;
@@ -377,6 +385,24 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
         HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon), (size_t)cap_pos * sizeof(float)));
         HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon_r), (size_t)cap_pos * sizeof(float)));
         HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_cov16), (size_t)cap_pos * sizeof(uint16_t)));
+        if (prm->rarefied_coverage > 0) {
+            b->cap_rare = p->cap_rare;
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_rare), b->cap_rare * sizeof(uint2)));
+        }
+    } else if (b->lev_sparse) {
+        b->lev_mask_bytes = b->M <= 8 ? 1 : (b->M <= 16 ? 2 : 4);
+        b->cap_lev = (size_t)std::min<uint64_t>(std::min<uint64_t>(npm, 0xFFFFFFF0ull), std::max<uint64_t>((uint64_t)cap_pos * (uint64_t)std::min(b->M, 4), 1u << 20));
+        HIP_TRY(isx_dev_malloc(&b->d_lev_mask, (size_t)cap_pos * b->lev_mask_bytes + 64));
+        HIP_TRY(isx_dev_malloc(&b->d_lev_cov, b->cap_lev * 2 + 64));
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_lev_win_off), ((size_t)cap_pos / 64 + 2) * sizeof(uint32_t)));
+        if (!b->lean) {                     // a plain slot keeps the entries too (flat, indexed by level): device summaries, isx_batch_fetch_entries
+            b->cap_entries = b->cap_lev;
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_entries), b->cap_entries * sizeof(isx_entry)));
+        }
+        b->cap_clon = (size_t)cap_pos / 4 + 65536;
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_clon_list), b->cap_clon * sizeof(uint2)));
+        b->cap_sat = (size_t)cap_pos / 16 + 65536;
+        HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_sat), b->cap_sat * sizeof(uint2)));
         if (prm->rarefied_coverage > 0) {
             b->cap_rare = p->cap_rare;
             HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_rare), b->cap_rare * sizeof(uint2)));
@@ -441,6 +467,16 @@ static int slot_batch_create(isx_pipe *p, Slot &s, int index)
             s.o_clonr = o; if (prm->rarefied_coverage > 0) o = up(o + (size_t)cap_pos * 4);
         }
     }
+    if (b->lev_sparse) {
+        s.o_lmask = o; o = up(o + (size_t)cap_pos * b->lev_mask_bytes);
+        s.o_lwin = o; o = up(o + ((size_t)cap_pos / 64 + 2) * sizeof(uint32_t));
+        s.lcov_room = (size_t)cap_pos * (size_t)std::min(b->M, 4);
+        s.o_lcov = o; o = up(o + s.lcov_room);
+        s.lclon_room = (size_t)cap_pos;                                 // (cap_pos / 8 list entries)
+        s.o_lclon = o; o = up(o + s.lclon_room);
+        s.lrare_room = prm->rarefied_coverage > 0 ? (size_t)cap_pos / 2 : 0;
+        s.o_lrare = o; o = up(o + s.lrare_room);
+    }
     s.out_bytes = o;
     const double t_o0 = now_ms();
     // Pinning (then unpinning) hundreds of MB costs more than moving them: 144 MB pinned = ~35 ms + ~30 ms to free.  A large
@@ -485,7 +521,10 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         // a lean slot's batch taken for shallow whose clonTR list cannot be used (deep after all): again, with the dense array
         const bool rare_overflow = !cf && dense && p->prm.rarefied_coverage > 0 && !b->rare_dense &&
                                    ((size_t)b->n_rare > p->cap_rare || (size_t)b->n_rare * 8 > (size_t)b->n_pos);
-        if (!cf && !cov8_overflow && !clon_overflow && !nib_overflow && !rare_overflow) break;
+        // level-sparse mm slot: a list that outgrew its table (the kernel wrote what fitted; the cursors say what there was)
+        const bool lev_overflow = !cf && b->lev_sparse && ((size_t)b->n_clon > b->cap_clon || (size_t)b->n_sat > b->cap_sat ||
+                                                           (p->prm.rarefied_coverage > 0 && (size_t)b->n_rare > b->cap_rare));
+        if (!cf && !cov8_overflow && !clon_overflow && !nib_overflow && !rare_overflow && !lev_overflow) break;
         if (attempt == 7) { isx_set_error("output tables still too small after 8 growth steps"); return ISX_ERR_CAPACITY; }
         // a table was too small for this batch: grow it and repeat the pass (the slot still holds its input)
         if (cov8_overflow) b->cov8_out = false;
@@ -493,7 +532,22 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         if (clon_overflow) b->clon_dense = true;
         if (rare_overflow) b->rare_dense = true;
         if (cf && (rc = batch_grow_tables(b, cf)) != ISX_OK) return rc;
-        if (!dense) b->cap_ovf = b->cap_entries - (size_t)b->n_win * b->slab;
+        if (lev_overflow) {
+            auto regrow_list = [&](uint2 **lp, size_t *cap, size_t need) -> int {
+                if (need <= *cap) return ISX_OK;
+                HIP_TRY(isx_wait_stream(ps));
+                if (*lp) isx_dev_free(*lp);
+                *lp = nullptr;
+                const size_t want = need + need / 4 + 65536;
+                HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(lp), want * sizeof(uint2)));
+                *cap = want;
+                return ISX_OK;
+            };
+            if ((rc = regrow_list(&b->d_clon_list, &b->cap_clon, b->n_clon)) != ISX_OK) return rc;
+            if ((rc = regrow_list(&b->d_sat, &b->cap_sat, b->n_sat)) != ISX_OK) return rc;
+            if (p->prm.rarefied_coverage > 0 && (rc = regrow_list(&b->d_rare, &b->cap_rare, b->n_rare)) != ISX_OK) return rc;
+        }
+        if (!dense && !b->lev_sparse) b->cap_ovf = b->cap_entries - (size_t)b->n_win * b->slab;
         std::lock_guard<std::mutex> lk(p->launch_mu);
         if (dense && p->prm.rarefied_coverage > 0 && b->rare_dense)
             HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_clon_r), 0x7FC00000, (size_t)b->n_pos, ps));
@@ -570,6 +624,32 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         s.sat_rows.resize(s.sat_complete ? (size_t)b->n_sat : 0);
         if (!s.sat_rows.empty()) HIP_TRY(isx_read_back(s.sat_rows.data(), b->d_sat, s.sat_rows.size() * sizeof(isx_sat), sfin));
         HIP_TRY(isx_read_sync(sfin));
+    }
+    if (b->lev_sparse) {
+        // mm profiling on: the level mask, the windows' first level indices, one coverage byte (or two) per present level, the lists
+        if (redo) HIP_TRY(isx_wait_stream(ps));
+        int rc = ISX_OK;
+        const size_t n_lev = (size_t)b->sizes.n_entries, cov_bytes = n_lev * (size_t)b->lev_cov_bytes;
+        const size_t clon_bytes = (size_t)b->n_clon * sizeof(isx_rare), rare_bytes = p->prm.rarefied_coverage > 0 ? (size_t)b->n_rare * sizeof(isx_rare) : 0;
+        if ((rc = fetch(s.h_out + s.o_lmask, b->d_lev_mask, (size_t)b->n_pos * b->lev_mask_bytes)) != ISX_OK) return rc;
+        if ((rc = fetch(s.h_out + s.o_lwin, b->d_lev_win_off, (size_t)b->n_win * sizeof(uint32_t))) != ISX_OK) return rc;
+        // what outgrows its pinned room (a deep sample's clonTR list, a coverage stream of more than four levels a position): plain vectors
+        auto fetch_or_big = [&](size_t off, size_t room, auto &big, const void *dsrc, size_t bytes) -> int {
+            big.clear();
+            if (bytes <= room) return fetch(s.h_out + off, dsrc, bytes);
+            big.resize((bytes + sizeof(big[0]) - 1) / sizeof(big[0]));
+            if (p->bounce[0]) return bounce_d2h(p, big.data(), dsrc, bytes, sfin);
+            HIP_TRY(hipMemcpy(big.data(), dsrc, bytes, hipMemcpyDeviceToHost));
+            return ISX_OK;
+        };
+        if ((rc = fetch_or_big(s.o_lcov, s.lcov_room, s.lcov_big, b->d_lev_cov, cov_bytes)) != ISX_OK) return rc;
+        if ((rc = fetch_or_big(s.o_lclon, s.lclon_room, s.lclon_big, b->d_clon_list, clon_bytes)) != ISX_OK) return rc;
+        if (rare_bytes && (rc = fetch_or_big(s.o_lrare, s.lrare_room, s.lrare_big, b->d_rare, rare_bytes)) != ISX_OK) return rc;
+        s.sat_rows.resize((size_t)b->n_sat);
+        if (!s.sat_rows.empty()) HIP_TRY(isx_read_back(s.sat_rows.data(), b->d_sat, s.sat_rows.size() * sizeof(isx_sat), sfin));
+        HIP_TRY(isx_read_sync(sfin));
+        HIP_TRY(isx_wait_stream(sfin));
+        s.d2h_bytes += (int64_t)((size_t)b->n_pos * b->lev_mask_bytes + (size_t)b->n_win * 4 + cov_bytes + clon_bytes + rare_bytes + s.sat_rows.size() * sizeof(isx_sat));
     }
     if (dense && p->prm.rarefied_coverage > 0) {        // the sparse clonTR table, ascending positions
         const size_t n_rare = b->n_rare;
@@ -981,6 +1061,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     b->nib_out = b->cov8_out && b->lean && (double)b->n_obs < 6.0 * (double)n_pos;      // (mean depth below 6: most windows stay within 4 bits)
     b->clon_dense = false;
     b->rare_dense = !(b->lean && b->sparse_out) || (double)b->n_obs * 4.0 >= (double)p->prm.rarefied_coverage * (double)b->n_pos;
+    if (b->lev_sparse) b->lev_cov_bytes = (double)b->n_obs < 64.0 * (double)b->n_pos ? 1 : 2;      // (a level of a batch this shallow rarely reaches 255: the exact values of those that do travel in a list)
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / ISX_CHUNK;
     b->packed = 0;
@@ -996,7 +1077,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     if (s.win.size() > (size_t)p->pp.max_pos / 64 + 2) { isx_set_error("internal: window directory larger than the arena"); return ISX_ERR_STATE; }
     int rc = batch_set_geometry(b);
     if (rc != ISX_OK) return rc;
-    if (!dense) {
+    if (!dense && !b->lev_sparse) {
         const size_t used = (size_t)b->n_win * b->slab;
         if (used > b->slab_region) { isx_set_error("internal: entry slabs larger than the slot's region"); return ISX_ERR_STATE; }
         b->cap_ovf = b->cap_entries - used;
@@ -1217,6 +1298,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     b->nib_out = b->cov8_out && b->lean && (double)b->n_obs < 6.0 * (double)n_pos;      // (mean depth below 6: most windows stay within 4 bits)
     b->clon_dense = false;
     b->rare_dense = !(b->lean && b->sparse_out) || (double)b->n_obs * 4.0 >= (double)p->prm.rarefied_coverage * (double)b->n_pos;
+    if (b->lev_sparse) b->lev_cov_bytes = (double)b->n_obs < 64.0 * (double)b->n_pos ? 1 : 2;      // (a level of a batch this shallow rarely reaches 255: the exact values of those that do travel in a list)
     b->n_pairs = (uint64_t)J.max_pair + 1;
     const uint64_t n_chunks = b->n_rec / p->G;
     b->packed = 0;
@@ -1232,7 +1314,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (s.win.size() > (size_t)p->pp.max_pos / 64 + 2) { isx_set_error("internal: window directory larger than the arena"); return ISX_ERR_STATE; }
     int rc = batch_set_geometry(b);
     if (rc != ISX_OK) return rc;
-    if (!dense) {
+    if (!dense && !b->lev_sparse) {
         const size_t used = (size_t)b->n_win * b->slab;
         if (used > b->slab_region) { isx_set_error("internal: entry slabs larger than the slot's region"); return ISX_ERR_STATE; }
         b->cap_ovf = b->cap_entries - used;
@@ -1478,12 +1560,13 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     b->nib_out = b->cov8_out && b->lean && (double)b->n_obs < 6.0 * (double)w->n_pos;
     b->clon_dense = false;
     b->rare_dense = !(b->lean && b->sparse_out) || (double)b->n_obs * 4.0 >= (double)p->prm.rarefied_coverage * (double)b->n_pos;
+    if (b->lev_sparse) b->lev_cov_bytes = (double)b->n_obs < 64.0 * (double)b->n_pos ? 1 : 2;      // (a level of a batch this shallow rarely reaches 255: the exact values of those that do travel in a list)
     b->n_pairs = w->n_pairs;
     b->packed = w->packed; b->W = w->W;
     b->n_win = (int)(w->win_bytes / sizeof(uint2));
     int rc = batch_set_geometry(b);
     if (rc != ISX_OK) return rc;
-    if (!dense) {
+    if (!dense && !b->lev_sparse) {
         const size_t used = (size_t)b->n_win * b->slab;
         if (used > b->slab_region) { isx_set_error("internal: entry slabs larger than the slot's region"); return ISX_ERR_STATE; }
         b->cap_ovf = b->cap_entries - used;
@@ -1712,6 +1795,18 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
         }
         if (p->pp.want_counts) out->counts = reinterpret_cast<const uint32_t *>(s.h_out + s.o_counts);
     }
+    if (b->lev_sparse) {
+        out->lev_mask = s.h_out + s.o_lmask;
+        out->lev_win_off = reinterpret_cast<const uint32_t *>(s.h_out + s.o_lwin);
+        out->lev_cov = s.lcov_big.empty() ? s.h_out + s.o_lcov : s.lcov_big.data();
+        out->lev_clon = s.lclon_big.empty() ? reinterpret_cast<const isx_rare *>(s.h_out + s.o_lclon) : s.lclon_big.data();
+        out->lev_rare = s.lrare_big.empty() ? reinterpret_cast<const isx_rare *>(s.h_out + s.o_lrare) : s.lrare_big.data();
+        out->lev_sat = s.sat_rows.data();
+        out->n_lev = b->sizes.n_entries; out->n_lev_clon = (int64_t)b->n_clon; out->n_lev_sat = (int64_t)b->n_sat;
+        out->n_lev_rare = p->prm.rarefied_coverage > 0 ? (int64_t)b->n_rare : 0;
+        out->lev_mask_bytes = b->lev_mask_bytes; out->lev_cov_bytes = b->lev_cov_bytes;
+        out->lev_window = b->W; out->n_lev_windows = b->n_win; out->lev_min_cov = p->prm.min_cov;
+    }
     out->batch = b;
     out->encode_ms = s.encode_ms;
     out->encode_passes = s.encode_passes;
@@ -1760,10 +1855,20 @@ static int pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out, const
     HIP_TRY(hipSetDevice(p->ctx->device));
     const size_t n = (size_t)b->sizes.n_entries;
     if (!n) return ISX_OK;
+    if (b->lev_sparse && soa) {             // the four columns are made on the host from what already came home with the batch
+        isx_pipe_result r;
+        const int rc = isx_pipe_collect(p, ticket, &r);
+        if (rc != ISX_OK) return rc;
+        return isx_levels_expand(&r, std::max(1, std::min(p->pool ? p->pool->size() : 1, 16)), soa->gpos, soa->mm_cov, soa->clon, soa->clon_rarefied);
+    }
+    if (b->lev_sparse && !b->d_entries) {
+        isx_set_error("isx_pipe_fetch_entries: a lean slot keeps no 32-byte entries (the levels come with isx_pipe_collect: isx_pipe_result.lev_*, isx_levels_expand)");
+        return ISX_ERR_STATE;
+    }
     const size_t region = p->ring_half ? 2 * (size_t)p->ring_half * p->rb : (size_t)p->cap_rec * p->rb;
     const size_t piece = std::min<size_t>((size_t)32 << 20, region / 2 / 4096 * 4096);
     if (piece < ((size_t)1 << 20))              // tiny pipe: the staging detour is not worth it
-        return fetch_entries_sorted(p->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, (uint32_t)b->n_win, b->n_ovf, n, out, nullptr, soa);
+        return fetch_entries_sorted(p->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, entry_wins(b), b->n_ovf, n, out, nullptr, soa);
     uint8_t *bounce[2] = {s.h_in + s.off_rec, s.h_in + s.off_rec + piece};
     hipEvent_t ev[2] = {nullptr, nullptr};
     for (hipEvent_t &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1789,7 +1894,7 @@ static int pipe_fetch_entries(isx_pipe *p, int64_t ticket, isx_entry *out, const
         }
         return ISX_OK;
     };
-    const int rc = fetch_entries_sorted(p->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, (uint32_t)b->n_win, b->n_ovf, n, out, &copier, soa);
+    const int rc = fetch_entries_sorted(p->ctx->stream, b->d_entries, b->d_win_nent, (uint32_t)b->slab, entry_wins(b), b->n_ovf, n, out, &copier, soa);
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     return rc;
 }

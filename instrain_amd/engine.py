@@ -1,6 +1,7 @@
 """Thin object layer over the C ABI: Context (one per GPU), Batch (resident set of splits),
 BamFile (host BAM front end).  All compute happens in libinstrain_amd.so."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -519,7 +520,21 @@ class Pipe:
         else:
             n_e = sz["n_entries"]
             got = False
-            if shrunk_entries:
+            if r.lev_mask:
+                # level-sparse hand-back (isx_pipe_result.lev_*): the level mask per position, one coverage element per present level,
+                # the lists; views of the slot's result block like the dense tables
+                out["levels"] = {"mask": view(r.lev_mask, {1: np.uint8, 2: np.uint16, 4: np.uint32}[int(r.lev_mask_bytes)], n_pos),
+                                 "cov": view(r.lev_cov, np.uint8 if r.lev_cov_bytes == 1 else np.uint16, int(r.n_lev)),
+                                 "win_off": view(r.lev_win_off, np.uint32, int(r.n_lev_windows)), "window": int(r.lev_window),
+                                 "clon": view(r.lev_clon, _lib.RARE_DT, int(r.n_lev_clon)), "rare": view(r.lev_rare, _lib.RARE_DT, int(r.n_lev_rare)),
+                                 "sat": view(r.lev_sat, _lib.SAT_DT, int(r.n_lev_sat)), "n": int(r.n_lev)}
+                if shrunk_entries and densify:      # the four columns shrink_basewise's inputs are cut from, made on the host (isx_levels_expand)
+                    out["entries_soa"] = self.expand_levels(r)
+                    got = True
+                elif shrunk_entries:
+                    got = True                      # the caller reads the level tables as they came (expand_levels(result) later)
+                    out["_result"] = r
+            if shrunk_entries and not got:
                 # what shrink_basewise keeps of a (position, mm) level is its coverage, not its four counts: four 4-byte columns
                 # (isx_pipe_fetch_entries_shrunk) instead of 32-byte entries; a level deeper than 2^24 -> the full entries
                 cols = (np.empty(max(1, n_e), np.uint32), np.empty(max(1, n_e), np.uint32), np.empty(max(1, n_e), np.float32), np.empty(max(1, n_e), np.float32))
@@ -541,6 +556,16 @@ class Pipe:
             out["ld"] = np.empty(0, dtype=LD_DT)
         out["slot"] = slot
         return out
+
+    def expand_levels(self, r, threads=0):
+        """The level-sparse tables of a collected batch (the isx_pipe_result `r`, or collect()'s dict with densify=False) as the four
+        columns gpos | mm << 24 | coverage | clon | clon_rarefied in (gpos, mm) order: isx_levels_expand, host work only."""
+        if isinstance(r, dict):
+            r = r["_result"]
+        n = max(1, int(r.n_lev))
+        cols = (np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.float32), np.empty(n, np.float32))
+        check(self.lib.isx_levels_expand(C.byref(r), int(threads) or min(16, len(os.sched_getaffinity(0))), *(c.ctypes.data for c in cols)))
+        return tuple(c[:int(r.n_lev)] for c in cols)
 
     def release(self, ticket):
         try:

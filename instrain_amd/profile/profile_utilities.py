@@ -846,6 +846,8 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             try:
                 res = pipe.collect(t, rare_list=False, densify=False, shrunk_entries=not store_everything)
                 stage("collect_wait_ms")
+                if "_result" in res:                # mm profiling on: the level-sparse tables -> the columns the splits' covT / clonT / clonTR are cut from
+                    res["entries_soa"] = pipe.expand_levels(res)
                 if store_everything:                # read_to_snvs / mm_to_position_graph of the splits are made from these
                     res["allele_obs"] = res["slot"].fetch_allele_obs()
                     res["pair_names"] = getattr(g, 'pair_names', None)

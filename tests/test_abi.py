@@ -28,7 +28,7 @@ def test_abi_version_and_error_string():
     lib = _lib.load()
     hdr = open(os.path.join(REPO, "include", "instrain_amd.h")).read()
     declared = int(re.search(r"#define\s+ISX_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert lib.isx_abi_version() == declared == _lib.ABI_VERSION == 4
+    assert lib.isx_abi_version() == declared == _lib.ABI_VERSION == 5
     assert isinstance(lib.isx_last_error(), bytes)
 
 
