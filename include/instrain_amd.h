@@ -97,6 +97,12 @@ typedef struct {
 #define ISX_LAYOUT_MM_ENTRIES 16        /* read-level pipe with mm profiling on: hand the levels back as 32-byte entries in window slabs (the
                                          * round-2 way: isx_pipe_fetch_entries) instead of the level-sparse tables (isx_pipe_result.lev_*) */
 
+#define ISX_LAYOUT_MM_DELTA_RECORDS 32  /* read-level batch with mm profiling on: 32-byte reference-delta records with the pair's mm level in bits
+                                         * 24..30 of a segment's header (k_pileup_mm materialises every level's coverage-difference row) instead of
+                                         * the 64-byte segment records.  Half the bytes over PCIe; measured (round 6) the kernel is
+                                         * no faster -- the per-level prefix sums and the wider LDS rows eat what the shorter stream saves -- and
+                                         * the host stager of isx_segs input costs twice the segment records': opt-in, not the default */
+
 /* (position, mm)-present entry: one per mm level present at a position, ascending mm.
  * 32 bytes (two aligned 16-byte device stores).  cnt = counts of THIS level; covT[mm][pos] = sum(cnt);
  * clon = clonT[mm][pos] (float32 of the cumulative-<=mm clonality) or NaN when cumulative coverage

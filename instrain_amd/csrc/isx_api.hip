@@ -689,7 +689,8 @@ int batch_window_for(const isx_batch *b, int64_t n_pos, bool packed)
         }
         return best;
     }
-    const int bytes_per_pos = b->M * (packed ? 8 : 16) + ((b->M + 31) / 32) * 4 + 5;
+    // (reference-delta records: per level also the skipped-columns / coverage-difference row(s), 4 / 8 bytes)
+    const int bytes_per_pos = b->M * ((packed ? 8 : 16) + (b->drec ? (packed ? 4 : 8) : 0)) + ((b->M + 31) / 32) * 4 + 5;
     const int budget = (b->block >= 1024 ? 156 : 78) * 1024;       // one 1024-lane workgroup per CU, or two of 512
     const int wmax = ((budget - 8 * b->qcap - 8192 - 2048 - 256) / bytes_per_pos) / 64 * 64;
     return std::min(std::max(wmax, 64), 2 * b->block);
@@ -780,7 +781,7 @@ int batch_set_geometry(isx_batch *b)
 {
     const bool dense = b->M == 1;
     if (!dense && b->W > 2 * b->block) { isx_set_error("mm path: window must be <= 2 x block"); return ISX_ERR_ARG; }
-    if (b->drec && b->W > (b->packed ? 8 : 4) * b->block) { isx_set_error("reference-delta records: window must be <= 4 x block (8 x with 16-bit counters)"); return ISX_ERR_ARG; }
+    if (b->drec && dense && b->W > (b->packed ? 8 : 4) * b->block) { isx_set_error("reference-delta records: window must be <= 4 x block (8 x with 16-bit counters)"); return ISX_ERR_ARG; }
     b->rqcap = dense ? 0 : std::min(b->W, 512);     // positions with SNV rows per window (overflow: per-position atomics)
     b->lds = pileup_lds_bytes(b->W, b->M, b->qcap, b->rqcap, b->prm.enable_linkage, b->packed, b->block, b->segs ? (b->drec ? 32 : 64) : 0, &b->stage_off, &b->dlt_off);
     if (b->lds > 160 * 1024) { isx_set_error("window * n_mm_bins does not fit the 160 KiB LDS"); return ISX_ERR_ARG; }
@@ -987,7 +988,8 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
     b->ctx = c; b->prm = *prm; b->n_pos = n_pos; b->n_obs = n_obs; b->n_splits = n_splits;
     b->M = prm->n_mm_bins;
     b->segs = segs != nullptr;
-    b->drec = b->segs && b->M == 1 && !(prm->layout & ISX_LAYOUT_SEG64_RECORDS);
+    // (round 6: reference-delta records can carry the pair's mm level in the header -- opt-in with mm profiling on, see ISX_LAYOUT_MM_DELTA_RECORDS)
+    b->drec = b->segs && !(prm->layout & ISX_LAYOUT_SEG64_RECORDS) && (b->M == 1 || (prm->layout & ISX_LAYOUT_MM_DELTA_RECORDS));
     const bool dense = b->M == 1;
     batch_pick_block(b);
 #ifdef ISX_TUNING
@@ -1137,7 +1139,7 @@ static int batch_create_impl(isx_ctx *c, const isx_params *prm, int64_t n_pos, c
             // coverage difference is signed)
             const int Wp = batch_window_for(b, n_pos, true);
             if (!(prm->layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, dir_chunk) < (dense ? 32768u : 65536u)) { b->packed = 1; W = Wp; }
+                build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, dir_chunk) < (b->drec ? 32768u : 65536u)) { b->packed = 1; W = Wp; }
         }
         if (!b->packed) build_window_directory(cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win, dir_chunk);
         b->W = W;

@@ -574,7 +574,7 @@ __device__ __forceinline__ void allele_pass_delta(const PileupArgs &a, uint32_t 
                 if (cand) {
                     const uint32_t at = nst + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     st[2 * at] = dual ? i : (i & ~1u);
-                    st[2 * at + 1] = rel | (code << 16) | (dual ? 0u : 1u << 20);
+                    st[2 * at + 1] = rel | (code << 16) | (dual ? 0u : 1u << 20) | (((hdr >> 24) & 0x7Fu) << 24);     // (the pair's mm level: bits 24..30 of the header)
                 }
                 nst += n;
             }
@@ -1218,7 +1218,14 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
 // + the list of clonalities other than 1.0 (PileupArgs::lev_*); level indices are position-major inside a window (a block-wide
 // prefix sum of the positions' level counts), the window's first index comes from one global atomic.  The 32-byte entries are then a
 // flat table indexed by level (a.entries; NULL in a lean slot: nothing but what travels home is written).
-template <bool PACKED, bool LINKAGE, bool COMPACT, bool SEGS = false, bool SPARSE = false>    // SEGS: the read-segment stream (COMPACT is true then)
+// DREC (round 6): the stream is reference-delta records with the pair's mm level in bits 24..30 of a segment's header.  As in
+// k_pileup_dense a level's coverage is counted by DIFFERENCE (+1 at a segment's first column, -1 behind its last, into the level's
+// difference row), one atomic per skipped column and one per exception; a materialise phase -- a thread owns PT consecutive
+// positions, per level a wave prefix sum of the differences -- then rebuilds the reference base's count of every (position, level)
+// and the position's level mask, after which the counters are what the other record formats leave behind.  ~17 LDS atomics per
+// 150-base read instead of 135.  LDS: cnt | aux[M][W] (PACKED: skipped columns in the low half, coverage differences in the
+// wrapping high half; else two rows a level) | pres | ...
+template <bool PACKED, bool LINKAGE, bool COMPACT, bool SEGS = false, bool SPARSE = false, bool DREC = false>    // SEGS: the read-segment stream (COMPACT is true then)
 __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1230,9 +1237,13 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
     const int tid = threadIdx.x, nthr = blockDim.x;
     publish_previous(a, tid);
     const int W = a.W, M = a.M;
-    const int n_cnt = M * (PACKED ? 2 : 4) * W;
+#ifdef ISX_TUNING
+    int ts_w = -1;                              // timeline of workgroup 0 (debug bit 4096, tools/timeline_mm.py)
+#endif
+    const int n_cnt = M * (PACKED ? 2 : 4) * W + (DREC ? M * (PACKED ? 1 : 2) * W : 0);
     const int pres_words = (M + 31) >> 5;
     uint32_t *cnt = lds;
+    uint32_t *aux = lds + M * (PACKED ? 2 : 4) * W;      // DREC: per level the skipped-columns / coverage-difference row(s)
     uint32_t *pres = lds + n_cnt;
     uint32_t *scratch = pres + pres_words * W;
     uint32_t *queue = scratch + S_N;                    // [QCAP][2]: entry index, flags | (mm << 16) | p
@@ -1243,7 +1254,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
     constexpr bool linkage = LINKAGE;            // compile-time: the linkage-off kernels carry none of the allele pass
     const int grid = gridDim.x, per = grid >> 3;
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // consecutive windows share an XCD's L2
-    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(SEGS ? (const void *)a.seg : (COMPACT ? (const void *)a.rec32 : (const void *)a.rec));
+    const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(DREC ? (const void *)a.drec : (SEGS ? (const void *)a.seg : (COMPACT ? (const void *)a.rec32 : (const void *)a.rec)));
     constexpr int RSH = COMPACT ? 2 : 1;        // record index -> 16-byte load index (see k_pileup_dense)
     {   // once per workgroup: folded thresholds of the low coverages
         const int n = min(THR_LDS, a.lut_n);
@@ -1273,14 +1284,15 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
                                                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ub));
             v[u] = __builtin_nontemporal_load(sb + (uint32_t)tid);
             if (COMPACT) gb[u] = a.gbase[__builtin_amdgcn_readfirstlane(j >> 6)];
-        } else if (COMPACT) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
+        } else if (DREC) { v[u].x = v[u].y = v[u].z = v[u].w = 0u; }       // (length 0: nothing to count)
+        else if (COMPACT) { v[u].x = v[u].y = v[u].z = v[u].w = ISX_PAD32; }
         else { v[u].x = ISX_SENTINEL; v[u].y = 0; v[u].z = ISX_SENTINEL; v[u].w = 0; }
     };
     auto prefetch_window = [&](int wn) {
         lo = hi = 0;
         if (wn < a.n_win) {
             const uint2 rng = a.win_range[wn];
-            if (SEGS) { lo = rng.x << 2; hi = rng.y << 2; } else { lo = rng.x >> RSH; hi = rng.y >> RSH; }
+            if (DREC) { lo = rng.x << 1; hi = rng.y << 1; } else if (SEGS) { lo = rng.x << 2; hi = rng.y << 2; } else { lo = rng.x >> RSH; hi = rng.y >> RSH; }
             if (lo < hi) { issue_one(0, lo); issue_one(1, lo); }
         }
     };
@@ -1289,6 +1301,11 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
     for (int w = slot; w < a.n_win; w += grid) {
         const uint32_t w0 = (uint32_t)w * (uint32_t)W;
         const uint32_t cur_lo = lo, cur_hi = hi;
+        const int dbg = a.debug_mode;           // ablation switches (tools/ablate_mm.py), 0 in production
+#ifdef ISX_TUNING
+        ++ts_w;
+#endif
+        ISX_TS(0);
         {   // zero the window
             uint4 *z = reinterpret_cast<uint4 *>(lds);
             const int n4 = (n_cnt + pres_words * W) >> 2;   // W is a multiple of 64
@@ -1300,12 +1317,83 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
             if (tid < S_N) scratch[tid] = 0;
         }
         __syncthreads();
+        ISX_TS(1);
         ISX_ARGS_FRESH();
 
+        // DREC: the reference codes of the materialise phase's positions (a lane's position of chunk wave / wave + waves), loaded
+        // here so that their latency hides behind the stream
+        uint32_t rcode[2] = {4u, 4u};
+        if (DREC) {
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                const int p = 64 * ((tid >> 6) + sl * (nthr >> 6)) + (tid & 63);
+                const uint32_t gp = w0 + (uint32_t)p;
+                if (p < W && gp < a.n_pos) rcode[sl] = (uint32_t)ref_at(a, gp);
+            }
+        }
         // ---- get_base_counts_mm over the window's slice of the stream ----
         uint32_t bad_mm = 0;
         auto count_slot = [&](int u) {
             const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (DREC) {
+                // reference-delta records (k_pileup_dense's count_slot, with the level's rows): a pair of lanes holds one 32-byte record --
+                // ONE segment with its plane of skipped columns (full), or TWO segments without skipped columns, a lane each (dual)
+                const uint32_t odd = (uint32_t)tid & 1u;
+                const uint32_t hdr0 = pair_first(x[0]);
+                const bool dual = (hdr0 >> 31) != 0u;
+                const uint32_t hdr = dual ? x[0] : hdr0;
+                const uint32_t len = (hdr >> 16) & 0xFFu, mm = (hdr >> 24) & 0x7Fu;
+                if (len == 0) return;
+                if (mm >= (uint32_t)M) { bad_mm = 1; return; }
+                const int32_t s = (int32_t)(gb[u] + (hdr & 0xFFFFu) - w0);
+                const uint32_t uW = (uint32_t)W;
+                uint32_t *dlt = aux + __umul24(PACKED ? mm : 2u * mm + 1u, uW);          // coverage differences (PACKED: high half of the level's aux word)
+                uint32_t *skp = aux + __umul24(PACKED ? mm : 2u * mm, uW);               // skipped columns (PACKED: low half)
+                if (dual || !odd) {
+                    const int32_t hi_c = s + (int32_t)len;
+                    if (hi_c > 0 && s < W) {
+                        atomicAdd(&dlt[s < 0 ? 0 : s], PACKED ? 0x00010000u : 1u);
+                        if (hi_c < W) atomicAdd(&dlt[hi_c], PACKED ? 0xFFFF0000u : 0xFFFFFFFFu);
+                    }
+                }
+                // a full record's skip plane: the first lane holds columns 0..63 (words 1, 2), the second 64..159 (words 4..6)
+                uint32_t sk[3] = {odd ? x[0] : x[1], odd ? x[1] : x[2], odd ? x[2] : 0u};
+                if (dual) sk[0] = sk[1] = sk[2] = 0;
+                const int32_t c0 = s + (odd ? 64 : 0);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    uint32_t bits = sk[k];
+                    const int32_t r = c0 + 32 * k;
+                    if ((uint32_t)(r + 31) >= uW + 31u) bits = 0;                // the whole word lies outside the window
+                    while (__ballot(bits != 0)) {                               // wave-uniform
+                        const uint32_t rel = (uint32_t)(r + __ffs((int)bits) - 1);
+                        if (bits != 0 && rel < uW) atomicAdd(&skp[rel], 1u);
+                        bits &= bits - 1u;                                      // 0 stays 0
+                    }
+                }
+                // exceptions (the first lane of a full record: word 3; a dual half: words 2, 3).  An exception at a SKIPPED column of a full
+                // record is a base that is not A/C/T/G: nothing to count, the level is present there (profile_utilities.py:279-285)
+                const uint32_t o4 = pair_other(x[0]), o5 = pair_other(x[1]), o6 = pair_other(x[2]);      // (the second lane's skip words)
+                const uint32_t exw[2] = {dual ? x[2] : (odd ? ISX_DREC_NO_EXC : x[3]), dual ? x[3] : ISX_DREC_NO_EXC};
+#pragma unroll
+                for (int f = 0; f < 6; f++) {
+                    const uint32_t ex = exw[f / 3];
+                    const uint32_t off = (ex >> (10 * (f % 3))) & 0xFFu, code = (ex >> (10 * (f % 3) + 8)) & 3u;
+                    const uint32_t rel = (uint32_t)(s + (int32_t)off);
+                    if (off < len && rel < uW) {                 // (an empty field has offset 255)
+                        bool marker = false;
+                        if (!dual) {
+                            const uint32_t wsel = off >> 5;
+                            const uint32_t skw = wsel == 0 ? x[1] : (wsel == 1 ? x[2] : (wsel == 2 ? o4 : (wsel == 3 ? o5 : o6)));
+                            marker = ((skw >> (off & 31u)) & 1u) != 0u;
+                        }
+                        if (marker) atomicOr(&pres[__umul24(mm >> 5, uW) + rel], 1u << (mm & 31));
+                        else if (PACKED) atomicAdd(&cnt[__umul24(mm * 2u + (code >> 1), uW) + rel], 1u << (16 * (code & 1u)));
+                        else atomicAdd(&cnt[__umul24(mm * 4u + code, uW) + rel], 1u);
+                    }
+                }
+                return;
+            }
             if (SEGS) {
                 // read segments (see k_pileup_dense): lane q of a quad walks the words of its quarter of the record; the mm
                 // level is the record's, so a word's ten counters are ten consecutive columns of the level's rows
@@ -1359,9 +1447,85 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
         }
         if (bad_mm) flag_or(a, ISX_FLAG_MM_RANGE);
         __syncthreads();
+        ISX_TS(2);
         ISX_ARGS_FRESH();
         if (!linkage) prefetch_window(w + grid);
-        const int dbg = a.debug_mode;           // ablation switches (tools/ablate_mm.py), 0 in production
+        if (DREC) {
+            // ---- materialise: per level  covered = prefix sum of the difference row; observed = covered - skipped; count of the
+            //      reference's base = observed - the exceptions counted at the position.  A wave owns chunks of 64 consecutive positions
+            //      (chunk = wave, wave + waves: W <= 2 x block, so two at most), a lane ONE position of a chunk: the prefix inside a chunk is
+            //      one DPP scan, the chunks' totals go through LDS (ctot, in the deferred queue: idle until the level loop) and are scanned
+            //      by every wave for itself.  Levels in groups of 8: their loads and scans are independent chains.
+            uint32_t *ctot = queue;             // [8][32]
+            const int lane_m = tid & 63;
+            const int nwv = nthr >> 6, NCH = (W + 63) >> 6;
+            const uint32_t uW = (uint32_t)W;
+            int cc[2], pp[2];
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                cc[sl] = __builtin_amdgcn_readfirstlane((tid >> 6) + sl * nwv);
+                pp[sl] = 64 * cc[sl] + lane_m;
+            }
+            for (int m0 = 0; m0 < M; m0 += 8) {
+                const int mc = min(8, M - m0);
+                uint32_t x[2][8];
+                int32_t inc[2][8];
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    if (cc[sl] >= NCH) continue;            // (uniform)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        x[sl][i] = 0;
+                        if (i < mc && pp[sl] < W) x[sl][i] = aux[__umul24((uint32_t)(PACKED ? m0 + i : 2 * (m0 + i) + 1), uW) + (uint32_t)pp[sl]];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        if (i >= mc) continue;              // (uniform)
+                        inc[sl][i] = (int32_t)wave_scan_incl(PACKED ? (uint32_t)((int32_t)x[sl][i] >> 16) : x[sl][i]);
+                        if (lane_m == 63) ctot[32 * i + cc[sl]] = (uint32_t)inc[sl][i];
+                    }
+                }
+                __syncthreads();
+                uint32_t lbits[2] = {0, 0};     // levels of this group present at the lane's positions
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (i >= mc) continue;                  // (uniform)
+                    const int m = m0 + i;
+                    const uint32_t t = lane_m < NCH ? ctot[32 * i + lane_m] : 0u;
+                    const uint32_t before = wave_scan_incl(t) - t;          // lane c: sum of the totals of the chunks before chunk c
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) {
+                        if (cc[sl] >= NCH) continue;        // (uniform)
+                        const int32_t run = (int32_t)__builtin_amdgcn_readlane((int)before, cc[sl]) + inc[sl][i];
+                        const int p = pp[sl];
+                        if (p >= W || run == 0) continue;                   // no read of this level covers the position
+                        const uint32_t nskip = PACKED ? (x[sl][i] & 0xFFFFu) : aux[__umul24((uint32_t)(2 * m), uW) + (uint32_t)p];
+                        const uint32_t observed = (uint32_t)run - nskip;
+                        if (!observed) continue;
+                        lbits[sl] |= 1u << i;
+                        const uint32_t r = rcode[sl];
+                        if (r < 4u) {
+                            if (PACKED) {
+                                const uint32_t a01 = cnt[(m * 2) * W + p], a23 = cnt[(m * 2 + 1) * W + p];
+                                const uint32_t vref = observed - ((a01 & 0xFFFFu) + (a01 >> 16) + (a23 & 0xFFFFu) + (a23 >> 16));
+                                if (vref) cnt[(m * 2 + (int)(r >> 1)) * W + p] = ((r >> 1) ? a23 : a01) + (vref << (16 * (r & 1u)));
+                            } else {
+                                const uint32_t e4 = cnt[(m * 4) * W + p] + cnt[(m * 4 + 1) * W + p] + cnt[(m * 4 + 2) * W + p] + cnt[(m * 4 + 3) * W + p];
+                                if (observed != e4) cnt[(m * 4 + (int)r) * W + p] += observed - e4;
+                            }
+                        }
+                    }
+                }
+                // the group's levels into the positions' presence words (beside the bits the non-ACGT markers set during the stream)
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++)
+                    if (lbits[sl]) pres[(m0 >> 5) * W + pp[sl]] |= lbits[sl] << (m0 & 31);
+                if (m0 + 8 < M) __syncthreads();            // (uniform) the next group's totals overwrite ctot
+            }
+            __syncthreads();
+            ISX_ARGS_FRESH();
+        }
+        ISX_TS(3);
         const uint32_t CW = (uint32_t)a.slab;   // entry slab of this window: [w * CW, (w + 1) * CW)
         const uint64_t slab0 = (uint64_t)w * CW;
         const int lane = tid & 63;
@@ -1421,6 +1585,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
                 uint32_t mk = 0;
                 if (p < W && gpos < a.n_pos && !(dbg & 2)) {
                     mk = pres[p];                                   // (M <= 32: one presence word)
+                    if (!DREC)                                      // (DREC: the materialise phase left the complete mask there)
                     for (int m = 0; m < M; m++) {
                         uint32_t any4;
                         if (PACKED) any4 = cnt[(m * 2) * W + p] | cnt[(m * 2 + 1) * W + p];
@@ -1459,6 +1624,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
             lev_base = scratch[S_ENT_BASE];
             lev_ok = scratch[S_ENT_TOT] != 0u;
         }
+        ISX_TS(4);
         uint32_t n_cl = 0, n_rr = 0;                                // SPARSE: this lane's queued clonT / clonTR values (list slots are sized from them)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -1587,6 +1753,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
             }
         }
         __syncthreads();
+        ISX_TS(5);
         ISX_ARGS_FRESH();
         const uint32_t n_ent = scratch[S_ENT_TOT], nrows = scratch[S_ROWS], nsites = scratch[S_SITES], nao = scratch[S_NAO],
                        nslev = scratch[S_SLEV], nrq = min(scratch[S_ROW_RANK], (uint32_t)a.rqcap);
@@ -1633,6 +1800,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
             }
         }
         if (nrows) __syncthreads();             // uniform: bases from the atomics above
+        ISX_TS(6);
         const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE], ao_base = scratch[S_AO_BASE],
                        slev_base = scratch[S_SLEV_BASE];
         bool ok = true;
@@ -1657,15 +1825,19 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
                 a.sites[site_base + (rowq[q * 4 + 2] & 0xFFFFFFu)] = ss;
             }
         }
+        ISX_TS(7);
         if (linkage) {
             if (ok && nao) {
                 __syncthreads();                // every wave is done with the counters: they become the stage
-                if (SEGS) allele_pass_segs(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                if (DREC) allele_pass_delta(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
+                else if (SEGS) allele_pass_segs(a, cur_lo, cur_hi, w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
                 else allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
             prefetch_window(w + grid);
         }
+        ISX_TS(8);
         __syncthreads();
+        ISX_TS(9);
         ISX_ARGS_FRESH();
     }
     if (!SPARSE && tid == 0 && my_entries) cur_add(a, CUR_ENT_TOTAL, my_entries);
@@ -1806,6 +1978,7 @@ size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int pack
     if (M == 1) { cnt_words = (size_t)(pkl ? 2 : 4) * (W + pad); words = cnt_words + (size_t)(W + pad) + S_N + THR_LDS / 2; }
     else {
         cnt_words = (size_t)M * (packed ? 2 : 4) * W;
+        if (segs == 32) cnt_words += (size_t)M * (packed ? 1 : 2) * W;      // reference-delta records: the levels' skipped-columns / coverage-difference rows
         words = cnt_words + (size_t)((M + 31) / 32) * W + S_N + (size_t)qcap * 2 + (size_t)rqcap * 4 + THR_LDS / 2;
     }
     size_t bytes = words * sizeof(uint32_t);
@@ -1843,7 +2016,18 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
 {
     const LaunchCfg l{block, lds, grid, s, ev_start, ev_stop};
     const int sel = (a.enable_linkage != 0 ? 1 : 0) | (a.rec32 ? 2 : 0) | (packed ? 4 : 0);
-    if (a.M > 1 && a.seg && a.lev_cov) {
+    if (a.M > 1 && a.drec) {
+        switch ((sel & 5) | (a.lev_cov ? 2 : 0)) {
+        case 0: launch_one(k_pileup_mm<false, false, true, true, false, true>, a, l); break;
+        case 1: launch_one(k_pileup_mm<false, true, true, true, false, true>, a, l); break;
+        case 2: launch_one(k_pileup_mm<false, false, true, true, true, true>, a, l); break;
+        case 3: launch_one(k_pileup_mm<false, true, true, true, true, true>, a, l); break;
+        case 4: launch_one(k_pileup_mm<true, false, true, true, false, true>, a, l); break;
+        case 5: launch_one(k_pileup_mm<true, true, true, true, false, true>, a, l); break;
+        case 6: launch_one(k_pileup_mm<true, false, true, true, true, true>, a, l); break;
+        default: launch_one(k_pileup_mm<true, true, true, true, true, true>, a, l); break;
+        }
+    } else if (a.M > 1 && a.seg && a.lev_cov) {
         switch (sel & 5) {
         case 0: launch_one(k_pileup_mm<false, false, true, true, true>, a, l); break;
         case 1: launch_one(k_pileup_mm<false, true, true, true, true>, a, l); break;

@@ -783,7 +783,7 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
     isx_pipe *p = new isx_pipe();
     p->ctx = c; p->prm = *prm; p->pp = *pp;
     p->segs = pp->max_segs > 0;
-    p->drec = p->segs && prm->n_mm_bins == 1 && !(prm->layout & ISX_LAYOUT_SEG64_RECORDS);
+    p->drec = p->segs && !(prm->layout & ISX_LAYOUT_SEG64_RECORDS) && (prm->n_mm_bins == 1 || (prm->layout & ISX_LAYOUT_MM_DELTA_RECORDS));     // (mm profiling on: opt-in)
     p->rb = p->segs ? (p->drec ? 32 : 64) : ((prm->n_mm_bins == 1 && !(prm->layout & ISX_LAYOUT_NO_SHORT_RECORDS)) ? 2 : 4);
     p->G = p->segs ? (p->drec ? ISX_DREC_GROUP : ISX_SEG_GROUP) : (p->rb == 2 ? ISX_GROUP16 : ISX_GROUP);
     const double js = pp->jump_slack > 0 ? pp->jump_slack : 0.25;
@@ -1306,7 +1306,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (!dense || p->drec) {
         const int Wp = batch_window_for(b, n_pos, true);
         if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-            build_window_directory_mt(*p->pool, s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win, p->G, s.dir_pmax, s.dir_smin) < (dense ? 32768u : 65536u)) { b->packed = 1; W = Wp; }
+            build_window_directory_mt(*p->pool, s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, Wp, n_pos, s.win, p->G, s.dir_pmax, s.dir_smin) < (p->drec ? 32768u : 65536u)) { b->packed = 1; W = Wp; }
     }
     if (!b->packed) build_window_directory_mt(*p->pool, s.cmin.data(), s.cmax.data(), s.cany.data(), n_chunks, W, n_pos, s.win, p->G, s.dir_pmax, s.dir_smin);
     b->W = W;
@@ -1474,7 +1474,7 @@ static int stage_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, const is
         if (M > 1 || p->drec) {
             const int Wp = batch_window_for(b0, n_pos, true);
             if (!(p->prm.layout & ISX_LAYOUT_NO_PACKED_COUNTERS) &&
-                build_window_directory_mt(*p->pool, cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, (uint32_t)G, dir_pmax, dir_smin) < (M == 1 ? 32768u : 65536u)) { w->packed = 1; W = Wp; }
+                build_window_directory_mt(*p->pool, cmin.data(), cmax.data(), cany.data(), n_chunks, Wp, n_pos, win, (uint32_t)G, dir_pmax, dir_smin) < (p->drec ? 32768u : 65536u)) { w->packed = 1; W = Wp; }
         }
         if (!w->packed) build_window_directory_mt(*p->pool, cmin.data(), cmax.data(), cany.data(), n_chunks, W, n_pos, win, (uint32_t)G, dir_pmax, dir_smin);
         w->W = W;

@@ -214,6 +214,7 @@ namespace {
 struct Cols {                           // one segment against the reference: 160-bit column masks
     uint64_t skip[3];                   // no observation at the column (codes >= 4)
     uint64_t exc[3];                    // observed, and not the reference's base
+    uint64_t nbase[3];                  // code 5: a base that is not A/C/T/G (mm profiling on: it makes its level present, profile_utilities.py:279-285)
     alignas(64) uint8_t code[192];      // base code per column
 };
 
@@ -221,11 +222,12 @@ inline void cols_scalar(const uint32_t *bases, const uint8_t *ref, uint32_t L, C
 {
     C.skip[0] = C.skip[1] = C.skip[2] = 0;
     C.exc[0] = C.exc[1] = C.exc[2] = 0;
+    C.nbase[0] = C.nbase[1] = C.nbase[2] = 0;
     for (uint32_t j = 0; j < L; j++) {
         const uint32_t c = (bases[j / 10] >> (3 * (j % 10))) & 7u;
         C.code[j] = (uint8_t)c;
         const uint64_t bit = 1ull << (j & 63);
-        if (c >= 4) C.skip[j >> 6] |= bit;
+        if (c >= 4) { C.skip[j >> 6] |= bit; if (c == 5) C.nbase[j >> 6] |= bit; }
         else if (c != ref[j]) C.exc[j >> 6] |= bit;
     }
 }
@@ -261,7 +263,7 @@ inline void cols_vbmi(const uint32_t *bases, const uint8_t *ref, uint32_t L, Col
 {
     static const UnpackTables T;
     const __m512i in = _mm512_maskz_loadu_epi32((__mmask16)0x7FFF, bases);
-    const __m512i seven = _mm512_set1_epi8(7), four = _mm512_set1_epi8(4);
+    const __m512i seven = _mm512_set1_epi8(7), four = _mm512_set1_epi8(4), five = _mm512_set1_epi8(5);
 #pragma GCC unroll 3
     for (int k = 0; k < 3; k++) {
         const __m512i src = _mm512_permutexvar_epi32(_mm512_load_si512(T.idx[k]), in);
@@ -272,6 +274,7 @@ inline void cols_vbmi(const uint32_t *bases, const uint8_t *ref, uint32_t L, Col
         const __m512i r = _mm512_maskz_loadu_epi8(lm, ref + 64 * k);               // (masked lanes never fault)
         const __mmask64 sk = _mm512_cmpge_epu8_mask(c, four) & lm;
         C.skip[k] = (uint64_t)sk;
+        C.nbase[k] = (uint64_t)(_mm512_cmpeq_epi8_mask(c, five) & lm);
         C.exc[k] = (uint64_t)(_mm512_cmpneq_epi8_mask(c, r) & lm & ~sk);
     }
 }
@@ -402,7 +405,8 @@ int encode_delta(HostPool &pool, SegJob &J)
         // one piece of a segment -> a 16-byte half of a dual record when the segment has no skipped columns (`plain`: exc holds up to
         // ISX_DREC_EXC exceptions), else a full record (msk + exc[0]: up to ISX_DREC_EXC_FULL exceptions).  A plain piece fills the free
         // half of the record before it only while no full record has come in between: the stream keeps the segments' order.
-        auto add_piece = [&](uint32_t start, uint32_t len, uint32_t pid, const uint64_t msk[3], const uint32_t exc[2], bool plain) {
+        auto add_piece = [&](uint32_t start, uint32_t len, uint32_t pid, const uint64_t msk[3], const uint32_t exc[2], bool plain, uint32_t mmv) {
+            len |= mmv << 8;                    // the pair's mm level rides in bits 24..30 of the header (0 with one mm bin)
             bool fill = plain && G.open >= 0;
             if (G.n) {
                 const uint32_t nlo = std::min(G.lo, start), nhi = std::max(G.hi, start);
@@ -432,7 +436,7 @@ int encode_delta(HostPool &pool, SegJob &J)
                 G.used[h + 1] = false;
                 G.n++;
             }
-            G.used[h] = true; G.start[h] = start; G.last[h] = start + len - 1;
+            G.used[h] = true; G.start[h] = start; G.last[h] = start + (len & 0xFFu) - 1;
             np++;
         };
         Cols C;
@@ -446,11 +450,16 @@ int encode_delta(HostPool &pool, SegJob &J)
             nb += L;
             if (vbmi) cols_vbmi(bs + (size_t)s * ISX_SEG_WORDS, J.ref + p, L, C);
             else cols_scalar(bs + (size_t)s * ISX_SEG_WORDS, J.ref + p, L, C);
+            if (J.n_mm_bins > 1) {
+                // mm profiling on: a base that is not A/C/T/G travels as an "exception" at a SKIPPED column (the kernel tells it from a
+                // counted one by the column's skip bit): nothing is counted there, the pair's level becomes present
+                C.exc[0] |= C.nbase[0]; C.exc[1] |= C.nbase[1]; C.exc[2] |= C.nbase[2];
+            }
             const int n_exc = __builtin_popcountll(C.exc[0]) + __builtin_popcountll(C.exc[1]) + __builtin_popcountll(C.exc[2]);
             const bool plain = (C.skip[0] | C.skip[1] | C.skip[2]) == 0;           // no skipped column in the whole segment: its pieces are dual halves
             if (n_exc == 0) {
                 const uint32_t none[2] = {ISX_DREC_NO_EXC, ISX_DREC_NO_EXC};
-                add_piece(p, L, pid, C.skip, none, plain);
+                add_piece(p, L, pid, C.skip, none, plain, m);
                 continue;
             }
             // pieces of at most ISX_DREC_EXC (plain) / ISX_DREC_EXC_FULL exceptions: a piece ends right before the exception it has no room for
@@ -475,7 +484,7 @@ int encode_delta(HostPool &pool, SegJob &J)
                 }
                 uint64_t msk[3];
                 window160(C.skip, b, end - b, msk);
-                add_piece(p + b, end - b, pid, msk, w, plain);
+                add_piece(p + b, end - b, pid, msk, w, plain, m);
                 b = end;
             }
         }

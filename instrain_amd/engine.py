@@ -735,7 +735,6 @@ def decode_delta(rec, gbase, ref_codes):
     n = len(rec)
     dual = (rec[:, 0] >> 31) == 1
     assert ((rec[dual, 4] >> 31) == 1).all(), "a dual record's second half carries the flag too"
-    assert ((rec[:, 0] >> 24) & 0x7F == 0).all() and ((rec[dual, 4] >> 24) & 0x7F == 0).all()
     zero = np.zeros(n, dtype=np.uint32)
     none = np.full(n, DREC_NO_EXC, dtype=np.uint32)
     # per half: header, pair id, two exception words, five skip words
@@ -747,10 +746,11 @@ def decode_delta(rec, gbase, ref_codes):
     gb = np.repeat(np.asarray(gbase, dtype=np.uint32), 32)[:n]
     start = (gb[:, None] + (hdr & 0xFFFF)).astype(np.int64)
     ln = ((hdr >> 16) & 0xFF).astype(np.int64)
+    lvl = ((hdr >> 24) & 0x7F).astype(np.uint8)            # the pair's mm level (0 with one mm bin)
     full = np.stack([~dual, np.zeros(n, dtype=bool)], axis=1)
     real = (ln > 0).reshape(-1)
     flat = lambda x: x.reshape(-1)[real]
-    st, ln, pr, e0, e1, fl = flat(start), flat(ln), flat(pair), flat(e0), flat(e1), flat(full)
+    st, ln, pr, e0, e1, fl, lvl = flat(start), flat(ln), flat(pair), flat(e0), flat(e1), flat(full), flat(lvl)
     words = np.stack([flat(w) for w in skw], axis=1)
     m = len(st)
     j = np.arange(160, dtype=np.int64)[None, :]
@@ -766,11 +766,16 @@ def decode_delta(rec, gbase, ref_codes):
             has = f != 0x3FF
             off, base = (f & 0xFF).astype(np.int64), ((f >> 8) & 3).astype(np.uint8)
             rows = np.flatnonzero(has)
-            assert (off[rows] < ln[rows]).all() and not skip[rows, off[rows]].any()
+            assert (off[rows] < ln[rows]).all()
+            # an exception at a SKIPPED column (mm profiling on, full records only): a base that is not A/C/T/G -- code 5
+            mark = skip[rows, off[rows]]
+            assert fl[rows[mark]].all(), "a non-ACGT marker in a dual half"
+            codes[rows[mark], off[rows[mark]]] = 5
+            rows = rows[~mark]
             assert (base[rows] != ref[st[rows] + off[rows]]).all(), "an exception that equals the reference"
             codes[rows, off[rows]] = base[rows]
         assert ((e >> 30) == 0).all()
-    return st.astype(np.uint32), ln.astype(np.uint8), np.zeros(m, dtype=np.uint8), codes[:, :150], pr, fl
+    return st.astype(np.uint32), ln.astype(np.uint8), lvl, codes[:, :150], pr, fl
 
 
 def decode_segs(rec, gbase):

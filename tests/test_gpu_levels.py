@@ -17,6 +17,8 @@ pytestmark = pytest.mark.gpu
 MM_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(util.GOLD, "synth_*.npz"))
                   if int(np.load(p)["mm"].max()) > 0)
 MM_ENTRIES = 16     # isx_params.layout: ISX_LAYOUT_MM_ENTRIES
+MMDELTA = 32        # ISX_LAYOUT_MM_DELTA_RECORDS: reference-delta records with the mm level in the header instead of segment records
+NOPACK = 4          # ISX_LAYOUT_NO_PACKED_COUNTERS
 
 
 @pytest.fixture(scope="module")
@@ -43,8 +45,9 @@ def same_soa(got, exp, what):
 def through_pipe(ctx, ref, bounds, segs, M, lean=False, layout=0, depth=1, **kw):
     """-> (the four columns, the result dict's level tables or None, the full entries or None, snv rows, ld rows)"""
     from instrain_amd import engine
+    # (delta records: a segment over a non-ACGT stretch of the reference is many pieces -- room for them, as a caller with such data would give)
     pipe = engine.Pipe(ctx, max_pos=len(ref), max_obs=0, max_segs=max(1, segs.n_seg), max_splits=len(bounds), depth=depth, host_threads=3,
-                       pin_threads=False, n_mm_bins=M, lean_output=lean, layout=layout, **kw)
+                       pin_threads=False, n_mm_bins=M, lean_output=lean, layout=layout, jump_slack=8.0 if layout & MMDELTA else 0.0, **kw)
     t = pipe.submit_reads(ref, bounds, segs)
     r = pipe.collect(t, shrunk_entries=True)
     soa = tuple(c.copy() for c in r["entries_soa"])
@@ -81,10 +84,11 @@ def test_golden_vectors_level_sparse(ctx, name):
     b.close()
     want = soa_of_entries(exp["entries"])
     assert np.isfinite(want[3]).any() or int(exp["entries"]["cnt"].sum(axis=1).max()) < 8
-    for how, lean, layout in (("plain", False, 0), ("lean", True, 0), ("slabs", False, MM_ENTRIES)):
+    for how, lean, layout in (("plain", False, 0), ("lean", True, 0), ("slabs", False, MM_ENTRIES), ("plain delta records", False, MMDELTA), ("lean delta records", True, MMDELTA),
+                              ("lean 32-bit counters", True, NOPACK), ("lean delta records 32-bit counters", True, MMDELTA | NOPACK), ("slabs delta records", False, MM_ENTRIES | MMDELTA)):
         soa, lev, full, snv, ld = through_pipe(ctx, ref, [0, len(ref)], segs, M, lean=lean, layout=layout, **kw)
         same_soa(soa, want, name + "/" + how)
-        assert (lev is None) == (layout == MM_ENTRIES or M > 32), (name, how)
+        assert (lev is None) == (bool(layout & MM_ENTRIES) or M > 32), (name, how)
         if full is not None:
             assert full.tobytes() == exp["entries"].tobytes(), (name, how, "entries")
         assert snv.tobytes() == exp["snv"].tobytes() and ld.tobytes() == exp["ld"].tobytes(), (name, how, "rows")

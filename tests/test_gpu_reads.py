@@ -30,20 +30,26 @@ def _params(g):
 
 
 SEG64 = 8       # isx_params.layout: ISX_LAYOUT_SEG64_RECORDS (one mm bin: the 64-byte segment records instead of reference-delta records)
+MMDELTA = 32    # ISX_LAYOUT_MM_DELTA_RECORDS (mm profiling on: reference-delta records with the level in the header instead of segment records)
 NOPACK = 4      # ISX_LAYOUT_NO_PACKED_COUNTERS: reference-delta records with 32-bit LDS counters (the path of very deep batches)
 
 
-@pytest.mark.parametrize("how", ["stream", "reassembled", "stream64", "reassembled64", "stream32u", "reassembled32u"])
+@pytest.mark.parametrize("how", ["stream", "reassembled", "stream64", "reassembled64", "stream32u", "reassembled32u", "streamD", "reassembledD", "reassembledDu"])
 @pytest.mark.parametrize("name", CASES)
 def test_golden_vectors_as_read_segments(ctx, name, how):
-    """every reference-generated vector as read segments: one mm bin -> 32-byte reference-delta records (difference-array
-    pileup), or with layout SEG64 the 64-byte segment records; several mm bins -> segment records"""
+    """every reference-generated vector as read segments: 32-byte reference-delta records (difference-array pileup; with several mm bins
+    the pair's level rides in the header and k_pileup_mm materialises every level's difference row), with layout SEG64 the 64-byte
+    segment records, with NOPACK 32-bit LDS counters"""
     from tests import prod
     g = util.load_case(name)
     kw = _params(g)
-    if how.endswith("64") or how.endswith("32u"):
+    if how.endswith("D") or how.endswith("Du"):         # several mm bins as reference-delta records (round 6), 16-bit and 32-bit LDS counters
+        if int(g["mm"].max()) == 0:
+            pytest.skip("one mm bin: reference-delta records anyway")
+        how, kw = (how[:-1], dict(kw, layout=MMDELTA)) if how.endswith("D") else (how[:-2], dict(kw, layout=MMDELTA | NOPACK))
+    elif how.endswith("64") or how.endswith("32u"):
         if int(g["mm"].max()) > 0:
-            pytest.skip("several mm bins: segment records either way")
+            pytest.skip("several mm bins: segment records by default")
         how, kw = (how[:-2], dict(kw, layout=SEG64)) if how.endswith("64") else (how[:-3], dict(kw, layout=NOPACK))
     res = prod.run_split(ctx, g["pos"], g["base"], g["mm"], g["pair"], str(g["seq"]), int(g["start"]), reads=how, **kw)
     util.assert_same(util.canon_from_struct(res), util.canon_from_golden(g), float_tol=TOL, what=name + "/" + how)
@@ -88,6 +94,11 @@ def test_stored_sars_golden_as_read_segments(ctx):
     sizes = b.sizes()
     assert b.timings()["record_bytes"] == 64
     b.close()
+    bd = engine.Batch(ctx, engine.encode_seq(seq), bounds, segs, layout=MMDELTA, **kw)       # 26 mm levels as reference-delta records (round 6): the same tables
+    bd.run()
+    assert bd.timings()["record_bytes"] == 32
+    _tables_equal(got, bd.fetch(), "sars mm delta records")
+    bd.close()
     res = prod.to_oracle_layout(got, lambda g: g.astype(np.int64))
     check_against_sars_golden(res["snv"], res["ld"], float_tol=TOL)
     assert sizes["n_edges"] == 963 and sizes["n_increments"] == 23319
@@ -128,12 +139,12 @@ def test_randomized_sweep_reads_equal_observations(ctx):
         sa = a.sizes()
         a.close()
         for segs in (synth.segs_from_obs(obs, pr), util.reassemble_segs(pos, base, mm, pair)):
-            for layout in ((0, NOPACK, SEG64) if kw["n_mm_bins"] == 1 else (0,)):
+            for layout in ((0, NOPACK, SEG64) if kw["n_mm_bins"] == 1 else (0, MMDELTA, MMDELTA | NOPACK)):
                 b = engine.Batch(ctx, ref, [0, mLen], segs, layout=layout, **kw)
                 b.run()
                 _tables_equal(ra, b.fetch(), "iteration %d %r layout %d" % (it, kw, layout))
                 assert b.sizes() == sa
-                assert b.timings()["record_bytes"] == (32 if kw["n_mm_bins"] == 1 and layout != SEG64 else 64)
+                assert b.timings()["record_bytes"] == (32 if (kw["n_mm_bins"] == 1 and layout != SEG64) or (layout & MMDELTA) else 64)
                 b.close()
 
 
@@ -205,7 +216,7 @@ def _c2(scale=1.0, seed=2, skip_mm=True, with_n=False, p_keep=0.90):
 
 
 @pytest.mark.parametrize("skip_mm,linkage,layout,p_keep", [(True, False, 0, 0.9), (True, True, 0, 0.9), (True, True, NOPACK, 0.9), (True, True, SEG64, 0.9), (False, True, 0, 0.9),
-                                                           (True, True, 0, 0.995), (True, False, 0, 1.0), (True, True, NOPACK, 0.995)])
+                                                           (True, True, 0, 0.995), (True, False, 0, 1.0), (True, True, NOPACK, 0.995), (False, True, MMDELTA, 0.9), (False, False, MMDELTA, 0.995)])
 def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage, layout, p_keep):
     """a C2 slice through the read-level pipe == the same observations through a resident batch, every table
     (p_keep 0.9: every read has bases below the quality bar = full reference-delta records; 0.995: about half of them have none = halves
@@ -224,7 +235,7 @@ def test_pipe_reads_equal_observation_batch(ctx, skip_mm, linkage, layout, p_kee
     tickets = [pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs) for _ in range(2)]
     for t in tickets:
         r = pipe.collect(t)
-        assert r["stats"]["record_bytes"] == (32 if M == 1 and layout != SEG64 else 64)
+        assert r["stats"]["record_bytes"] == (32 if (M == 1 and layout != SEG64) or (layout & MMDELTA) else 64)
         assert r["sizes"] == sa
         if M == 1:
             assert (r["counts"] == ra["counts"]).all()

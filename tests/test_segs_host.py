@@ -194,6 +194,43 @@ def test_encode_delta_round_trip(threads, vbmi):
         engine.encode_delta(segs, ref, slack_groups=1, retry=False)
 
 
+def test_encode_delta_carries_the_mm_level_and_non_acgt_bases():
+    """mm profiling on (round 6): a segment's header carries its pair's mm level (bits 24..30), and a base that is not A/C/T/G but
+    passes the quality filter (code 5: it makes its level present, profile_utilities.py:279-285) travels as an exception at a skipped
+    column -- the records decode to the segments' codes, 5 included, levels included; with one mm bin code 5 is only a skipped column"""
+    rng = np.random.default_rng(5)
+    w, ref = _mutated_workload(seed=31, G=60_000, cov=10, err=0.01)
+    segs = synth.segs_from_obs(w["obs"], w["pair"])
+    codes = engine.unpack_codes(segs.bases)
+    inside = np.arange(150)[None, :] < segs.len[:, None]
+    n5 = inside & (rng.random(codes.shape) < 0.004)                 # sprinkle non-ACGT bases, also over skipped columns and mismatches
+    codes = np.where(n5, 5, np.where(inside, codes, 4)).astype(np.uint8)
+    lvl = rng.integers(0, 23, segs.n_seg).astype(np.uint8)
+    segs = engine.SegBatch(segs.gpos, segs.len, engine.pack_codes(codes), lvl, segs.pair)
+    for M, threads in ((23, 1), (23, 3), (1, 2)):
+        sg = segs if M > 1 else engine.SegBatch(segs.gpos, segs.len, segs.bases, np.zeros(segs.n_seg, np.uint8), segs.pair)
+        rec, gbase, _, slack = engine.encode_delta(sg, ref, n_mm_bins=M, threads=threads)
+        g, ln, mm, cd, pr, full = engine.decode_delta(rec, gbase, ref)
+        first = np.r_[True, (pr[1:] != pr[:-1]) | (g[1:].astype(np.int64) != g[:-1].astype(np.int64) + ln[:-1])]
+        seg_of = np.cumsum(first) - 1
+        assert seg_of[-1] + 1 == segs.n_seg and (g[first] == segs.gpos).all()
+        assert (mm == (lvl[seg_of] if M > 1 else 0)).all()                                        # every piece carries its segment's level
+        # piece columns -> segment columns
+        off = (g.astype(np.int64) - segs.gpos[seg_of].astype(np.int64))
+        got = np.full(codes.shape, 4, np.uint8)
+        j = np.arange(150)[None, :]
+        ok = j < ln[:, None]
+        rows = np.broadcast_to(seg_of[:, None], ok.shape)[ok]
+        cols = (off[:, None] + j)[ok]
+        got[rows, cols] = cd[ok]
+        want = codes if M > 1 else np.where(codes == 5, 4, codes)
+        assert (got == want).all()
+        assert (M > 1) == bool((cd == 5).any())
+        assert full[(cd == 5).any(axis=1)].all()                                                # a marker needs the skip plane: a full record
+    with pytest.raises(engine.IsxError, match="mm >= n_mm_bins"):
+        engine.encode_delta(segs, ref, n_mm_bins=22)
+
+
 def test_encode_segs_rejects_bad_input():
     from instrain_amd._lib import IsxError
     segs = engine.SegBatch([10, 20], [150, 150], np.full((2, 15), 0x24924924, np.uint32), mm=[0, 3])
