@@ -453,6 +453,10 @@ typedef struct {
     const isx_sat *lev_sat;                 /* .gpos = the level's index into lev_cov */
     int64_t n_lev, n_lev_clon, n_lev_rare, n_lev_sat;
     int32_t lev_mask_bytes, lev_cov_bytes, lev_window, n_lev_windows, lev_min_cov, pad_lev;
+    /* a 64-bit checksum over the bytes of the SNV rows and the LD rows of this batch as they lie in `snv` / `ld`, made by the pipe's finisher
+     * thread when the rows have landed (order-sensitive; the same rows give the same value): a caller that streams many batches can compare
+     * every batch's tables with a verified pass without reading them (bench.py check_timed) */
+    uint64_t rows_checksum;
 } isx_pipe_result;
 
 /* The level-sparse tables of a collected batch (isx_pipe_result.lev_*) as the four columns of isx_pipe_fetch_entries_shrunk: n_lev values

@@ -102,7 +102,7 @@ class PipeResult(C.Structure):
                 ("lev_mask", C.c_void_p), ("lev_cov", C.c_void_p), ("lev_win_off", C.c_void_p), ("lev_clon", C.c_void_p), ("lev_rare", C.c_void_p),
                 ("lev_sat", C.c_void_p), ("n_lev", C.c_int64), ("n_lev_clon", C.c_int64), ("n_lev_rare", C.c_int64), ("n_lev_sat", C.c_int64),
                 ("lev_mask_bytes", C.c_int32), ("lev_cov_bytes", C.c_int32), ("lev_window", C.c_int32), ("n_lev_windows", C.c_int32),
-                ("lev_min_cov", C.c_int32), ("pad_lev", C.c_int32)]
+                ("lev_min_cov", C.c_int32), ("pad_lev", C.c_int32), ("rows_checksum", C.c_uint64)]
 
 
 class BamParams(C.Structure):

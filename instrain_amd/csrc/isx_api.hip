@@ -291,12 +291,20 @@ static bool isx_active_wait()
 template <class Ready>
 static hipError_t isx_nap_until(Ready ready)
 {
-    static thread_local bool slack_set = false;
-    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }      // this thread's naps end on time (default slack: 50 us)
+    // The naps must end on time (default timer slack: 50 us).  The slack is a property of the calling THREAD, and that may be the embedding
+    // application's (the Python main thread in collect / fetch): it is lowered for the duration of this wait only and put back.
+    long old_slack = -1;
     for (int i = 0;; i++) {
         const hipError_t r = ready();
-        if (r != hipErrorNotReady) return r;
+        if (r != hipErrorNotReady) {
+            if (old_slack > 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old_slack, 0, 0, 0);
+            return r;
+        }
         if (i < 4) continue;
+        if (old_slack < 0) {
+            old_slack = (long)prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+            if (old_slack > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); else old_slack = 0;
+        }
         const long us = i < 40 ? 20 : (i < 100 ? 50 : 200);
         struct timespec ts = {0, us * 1000L};
         nanosleep(&ts, nullptr);
@@ -307,10 +315,24 @@ hipError_t isx_wait_event(hipEvent_t e)
     if (isx_active_wait()) return hipEventSynchronize(e);
     return isx_nap_until([&] { return hipEventQuery(e); });
 }
+// hipStreamSynchronize waits for the work queued BEFORE the call; polling hipStreamQuery would wait until the stream has drained, also of
+// what other threads enqueue meanwhile (a pass queue shared by the slots of a deep pipe: more latency, starvation in principle -- ADVICE r5).
+// So: an event recorded at the call, polled.  The events are the calling thread's own (created on first use, one per device).
 hipError_t isx_wait_stream(hipStream_t s)
 {
     if (isx_active_wait()) return hipStreamSynchronize(s);
-    return isx_nap_until([&] { return hipStreamQuery(s); });
+    struct Ev { hipEvent_t e = nullptr; int dev = -1; ~Ev() { if (e) (void)hipEventDestroy(e); } };
+    static thread_local Ev ev;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (ev.e && ev.dev != dev) { (void)hipEventDestroy(ev.e); ev.e = nullptr; }
+    if (!ev.e) {
+        if (hipEventCreateWithFlags(&ev.e, hipEventDisableTiming) != hipSuccess) { ev.e = nullptr; (void)hipGetLastError(); return isx_nap_until([&] { return hipStreamQuery(s); }); }
+        ev.dev = dev;
+    }
+    const hipError_t r = hipEventRecord(ev.e, s);
+    if (r != hipSuccess) return r;
+    return isx_nap_until([&] { return hipEventQuery(ev.e); });
 }
 
 hipError_t isx_read_sync(hipStream_t stream)
@@ -1283,7 +1305,10 @@ int launch_pass(isx_batch *b)
             b->d_win_rec = b->d_win_out = nullptr;
             const size_t want = (size_t)b->n_win + (size_t)b->n_win / 4 + 64;
             HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_win_rec), want * 8 * sizeof(uint32_t)));
-            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_win_out), want * 4 * sizeof(uint32_t)));
+            // (+ k_win_scan's chunk states behind the window offsets: 8 words per 1024 windows, zero = "no launch has written here")
+            const size_t n_state = (want / 1024 + 2) * 8;
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_win_out), (want * 4 + n_state) * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(b->d_win_out + want * 4, 0, n_state * sizeof(uint32_t), s));
             b->cap_win = want;
         }
         a.snv = b->d_snv_raw; a.sites = b->d_sites_raw;
@@ -1293,7 +1318,7 @@ int launch_pass(isx_batch *b)
     launch_pileup(a, b->block, b->lds, b->grid, b->packed, s, b->ev[0], b->ev[1]);
     if (b->M == 1) {
         launch_win_order(b->d_win_rec, b->d_win_out, b->n_win, b->W, b->d_snv_raw, b->d_snv, b->d_sites_raw, b->d_sites,
-                         a.clon_list, b->d_clon_sorted, b->d_rare ? b->d_rare_raw : nullptr, b->d_rare, s);
+                         a.clon_list, b->d_clon_sorted, b->d_rare ? b->d_rare_raw : nullptr, b->d_rare, b->d_win_out + b->cap_win * 4, b->epoch + 1, s);
         b->ordered = true;
     }
     HIP_TRY(hipGetLastError());

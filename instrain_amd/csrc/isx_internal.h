@@ -265,7 +265,8 @@ void launch_pileup(const PileupArgs &a, int block, size_t lds, int grid, int pac
 void launch_publish_state(const PileupArgs &a, uint32_t epoch, hipStream_t s);
 // position order of the dense path's tables by window-ordered gather instead of sorting (isx_pileup.hip: k_win_scan, k_win_gather)
 void launch_win_order(const uint32_t *win_rec, uint32_t *win_out, int n_win, int W, const isx_snv *snv_raw, isx_snv *snv, const isx_site *sites_raw,
-                      isx_site *sites, const uint2 *clon_raw, uint2 *clon, const uint2 *rare_raw, uint2 *rare, hipStream_t s);
+                      isx_site *sites, const uint2 *clon_raw, uint2 *clon, const uint2 *rare_raw, uint2 *rare, uint32_t *scan_state, uint32_t epoch, hipStream_t s);
+// scan_state: 8 words per chunk of 1024 windows, zeroed once when allocated; epoch: a value no earlier launch on this state used (not 0)
 void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t *gbase, uint32_t *gpos, uint16_t *gpos16,
                          const uint32_t *base16, uint32_t base16_records, uint64_t n_rec, hipStream_t s);
 size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int packed, int block, int segs, int *stage_off, int *dlt_off = nullptr);

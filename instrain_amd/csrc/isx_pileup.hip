@@ -1854,43 +1854,58 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
 // in window order; k_win_gather = one workgroup per window, rank of an entry = set bits below its position in the window's
 // occupancy bitmap.  Replaces four sorts per batch (rocprim's radix sort of a few 10^5 keys is 5-8 kernel launches each).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_win_scan(const uint32_t *__restrict__ win_rec, uint32_t *__restrict__ win_out, int n_win)
+__global__ void __launch_bounds__(1024) k_win_scan(const uint32_t *__restrict__ win_rec, uint32_t *__restrict__ win_out, int n_win,
+                                                   uint32_t *state, uint32_t epoch)
 {
-    // One workgroup, chunks of 1024 windows: a thread loads ONE window's record (two 16-byte loads, coalesced over the wave) and the four
-    // counts are scanned over the chunk -- DPP inside a wave, per-wave totals through LDS -- on top of the totals carried from the chunks
-    // before.  (A thread walking its own run of ~30 windows, 32 bytes apart, took 116 us on a 120 Mbp batch.)
-    __shared__ uint32_t wsum[2][4][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t carry[4] = {0, 0, 0, 0};
+    // One workgroup per chunk of 1024 windows (round 6; one workgroup walking all chunks took 73 us on a 117 Mbp batch): a thread loads ONE
+    // window's record (two 16-byte loads, coalesced over the wave), the four counts are scanned over the chunk -- DPP inside a wave, per-wave
+    // totals through LDS --, the chunk's totals are published in `state` (8 words a chunk: totals | epoch) and every workgroup adds up the
+    // totals of the chunks before it once they carry this launch's epoch (workgroups are dispatched in index order: the ones waited for run).
+    __shared__ uint32_t wsum[4][16], pre[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
     const uint4 *rec4 = reinterpret_cast<const uint4 *>(win_rec);
     uint4 *out4 = reinterpret_cast<uint4 *>(win_out);
-    int buf = 0;
-    for (int w0 = 0; w0 < n_win; w0 += 1024, buf ^= 1) {
-        const int w = w0 + tid;
-        uint32_t c[4] = {0, 0, 0, 0};
-        if (w < n_win) {
-            const uint4 lo = rec4[2 * (size_t)w], hi = rec4[2 * (size_t)w + 1];
-            c[0] = lo.y; c[1] = lo.w; c[2] = hi.y; c[3] = hi.w;
-        }
-        uint32_t inc[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            inc[k] = wave_scan_incl(c[k]);
-            if (lane == 63) wsum[buf][k][wave] = inc[k];
-        }
-        __syncthreads();                        // (two buffers: the next chunk's totals do not overwrite what a slower wave still reads)
-        uint32_t tot[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t off = carry[k] + inc[k] - c[k], t = 0;
-            for (int j = 0; j < 16; j++) { const uint32_t x = wsum[buf][k][j]; if (j < wave) off += x; t += x; }
-            tot[k] = t;
-            inc[k] = off;
-        }
-        if (w < n_win) out4[w] = make_uint4(inc[0], inc[1], inc[2], inc[3]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) carry[k] += tot[k];
+    const int w = g * 1024 + tid;
+    uint32_t c[4] = {0, 0, 0, 0};
+    if (w < n_win) {
+        const uint4 lo = rec4[2 * (size_t)w], hi = rec4[2 * (size_t)w + 1];
+        c[0] = lo.y; c[1] = lo.w; c[2] = hi.y; c[3] = hi.w;
     }
+    uint32_t inc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        inc[k] = wave_scan_incl(c[k]);
+        if (lane == 63) wsum[k][wave] = inc[k];
+    }
+    if (tid < 4) pre[tid] = 0;
+    __syncthreads();
+    uint32_t tot[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t off = inc[k] - c[k], t = 0;
+        for (int j = 0; j < 16; j++) { const uint32_t x = wsum[k][j]; if (j < wave) off += x; t += x; }
+        tot[k] = t;
+        inc[k] = off;
+    }
+    if (tid == 0) {
+        uint32_t *st = state + 8 * (size_t)g;
+#pragma unroll
+        for (int k = 0; k < 4; k++) __hip_atomic_store(&st[k], tot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st[4], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t add[4] = {0, 0, 0, 0};
+    for (int cpre = tid; cpre < g; cpre += 1024) {
+        uint32_t *sp = state + 8 * (size_t)cpre;
+        while (__hip_atomic_load(&sp[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+        for (int k = 0; k < 4; k++) add[k] += __hip_atomic_load(&sp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < g) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (add[k]) atomicAdd(&pre[k], add[k]);
+    }
+    __syncthreads();
+    if (w < n_win) out4[w] = make_uint4(pre[0] + inc[0], pre[1] + inc[1], pre[2] + inc[2], pre[3] + inc[3]);
 }
 
 struct GatherArgs {
@@ -2087,10 +2102,10 @@ void launch_extract_gpos(const uint2 *rec, const uint32_t *rec32, const uint32_t
 }
 
 void launch_win_order(const uint32_t *win_rec, uint32_t *win_out, int n_win, int W, const isx_snv *snv_raw, isx_snv *snv, const isx_site *sites_raw,
-                      isx_site *sites, const uint2 *clon_raw, uint2 *clon, const uint2 *rare_raw, uint2 *rare, hipStream_t s)
+                      isx_site *sites, const uint2 *clon_raw, uint2 *clon, const uint2 *rare_raw, uint2 *rare, uint32_t *scan_state, uint32_t epoch, hipStream_t s)
 {
     if (n_win <= 0) return;
-    hipLaunchKernelGGL(k_win_scan, dim3(1), dim3(1024), 0, s, win_rec, win_out, n_win);
+    hipLaunchKernelGGL(k_win_scan, dim3((n_win + 1023) / 1024), dim3(1024), 0, s, win_rec, win_out, n_win, scan_state, epoch);
     GatherArgs g{win_rec, win_out, snv_raw, snv, sites_raw, sites, clon_raw, clon, rare_raw, rare, W};
     hipLaunchKernelGGL(k_win_gather, dim3(n_win), dim3(256), 0, s, g);
 }

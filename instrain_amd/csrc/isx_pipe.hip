@@ -102,6 +102,7 @@ struct Slot {
     std::vector<isx_rare> lclon_big, lrare_big;
     std::vector<isx_snv> snv_big;           // more SNV rows than the pinned block holds (rare)
     std::vector<isx_ld> ld_rows;            // the batch's LD rows (linkage), fetched by the finisher
+    uint64_t rows_checksum = 0;             // over the SNV + LD rows' bytes (isx_pipe_result.rows_checksum)
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_pass = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     hipEvent_t ev_h2da = nullptr, ev_h2db = nullptr;   // a copy-in in two parts (the reference leaves before the records exist): end of the first, start of the second
     bool h2d_split = false;
@@ -117,6 +118,25 @@ struct Slot {
     int64_t h2d_bytes = 0, d2h_bytes = 0;
     uint16_t *d_gpos16 = nullptr;           // compact stream + linkage: positions alone for the allele pass
 };
+
+// order-sensitive 64-bit checksum of a table's bytes (four multiply-add lanes over its 64-bit words: ~20 GB/s on one core)
+static uint64_t bytes_checksum(const void *p, size_t bytes, uint64_t seed)
+{
+    const uint8_t *b = static_cast<const uint8_t *>(p);
+    uint64_t a[4] = {seed ^ 0x9E3779B97F4A7C15ull, seed + 0xC2B2AE3D27D4EB4Full, seed ^ 0x165667B19E3779F9ull, seed + 0x27D4EB2F165667C5ull};
+    const size_t n8 = bytes / 8;
+    size_t i = 0;
+    for (; i + 4 <= n8; i += 4) {
+        uint64_t w[4];
+        memcpy(w, b + 8 * i, 32);
+        for (int k = 0; k < 4; k++) a[k] = a[k] * 0x100000001B3ull + w[k];
+    }
+    uint64_t h = (uint64_t)bytes;
+    for (; i < n8; i++) { uint64_t w; memcpy(&w, b + 8 * i, 8); h = h * 0x100000001B3ull + w; }
+    for (size_t j = n8 * 8; j < bytes; j++) h = h * 0x100000001B3ull + b[j];
+    for (int k = 0; k < 4; k++) { h ^= a[k]; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; }
+    return h;
+}
 
 // The reference codes of a batch as they travel and lie in a slot: a 2-bit plane (A C T G; anything else as 0), four positions a
 // byte, and -- only when the batch holds a position that is not A/C/T/G -- a bit plane marking those (PileupArgs::ref_packed == 2,
@@ -147,6 +167,23 @@ static bool copy_ref_planes(isxenc::HostPool &pool, const isx_ref_planes *rp, in
     });
     // (bits of the last bytes beyond n_pos are the caller's padding: the kernels never look at positions >= n_pos)
     return any.load() != 0;
+}
+
+// a cheap content check of a reference's 2-bit plane (a resident reference is found by the caller's KEY: a key reused for other planes would
+// otherwise compare on the host against planes the device does not hold): 64-bit words sampled at 4096 spread places + the length
+static uint64_t ref_plane_checksum(const uint8_t *plane2, int64_t n_pos)
+{
+    const size_t words = (((size_t)n_pos + 3) / 4) / 8;
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n_pos;
+    if (!words) { for (size_t i = 0; i < ((size_t)n_pos + 3) / 4; i++) h = (h ^ plane2[i]) * 0x100000001B3ull; return h; }
+    const size_t n_s = std::min<size_t>(words, 4096), step = words / n_s;
+    for (size_t k = 0; k < n_s; k++) {
+        uint64_t w;
+        memcpy(&w, plane2 + 8 * (k * step), 8);
+        h = (h ^ w) * 0x100000001B3ull;
+        h ^= h >> 29;
+    }
+    return h;
 }
 
 int cgroup_cpus()
@@ -227,9 +264,10 @@ struct isx_pipe {
         isx_ref_planes rp{};
     };
     // resident references (isx_ref_planes.key): device copies of a batch's reference planes, kept after their first trip
-    struct RefEntry { uint8_t *d = nullptr; size_t bytes = 0; int64_t n_pos = 0; bool has_n = false; hipEvent_t ready = nullptr; };
+    struct RefEntry { uint8_t *d = nullptr; size_t bytes = 0; int64_t n_pos = 0; bool has_n = false; hipEvent_t ready = nullptr; uint64_t sum = 0; };
     std::unordered_map<uint64_t, RefEntry> ref_cache;
-    size_t ref_cache_bytes = 0, ref_cache_budget = (size_t)4096 << 20;
+    size_t ref_cache_bytes = 0;
+    std::atomic<size_t> ref_cache_budget{(size_t)4096 << 20};      // (isx_pipe_set_reference_budget may be called while the stager thread submits)
     std::thread stager;
     std::deque<StageJob> stage_q;
     std::condition_variable cv_stage;
@@ -689,6 +727,7 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         s.ld_rows.resize((size_t)b->sizes.n_ld);
         if (!s.ld_rows.empty()) { const int rc = pull(s.ld_rows.data(), b->L.ld.p, s.ld_rows.size() * sizeof(isx_ld)); if (rc != ISX_OK) return rc; }
     }
+    s.rows_checksum = bytes_checksum(s.ld_rows.data(), p->prm.enable_linkage ? s.ld_rows.size() * sizeof(isx_ld) : 0, bytes_checksum(rows, n_snv * sizeof(isx_snv), 0));
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
         fprintf(stderr, "[isx_pipe finisher] wait %.2f ms, finish (sizes, linkage) %.2f ms [device: sites %.2f allele %.2f group %.2f incr %.2f ld %.2f; %lld ao, %lld incr, %lld ld], clonTR list (%u) %.2f ms, snv rows (%zu) %.2f ms\n",
                 s.finish_wait_ms, t_fin - t_c0, b->tim.sites_ms, b->tim.allele_ms, b->tim.group_ms, b->tim.incr_ms, b->tim.ld_ms,
@@ -1204,7 +1243,10 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
                 // the device already holds this reference: nothing is staged, nothing travels; the record pass compares against the
                 // caller's own planes
                 const isx_pipe::RefEntry &e = it->second;
-                if (e.n_pos != n_pos || e.has_n != (rp->nplane != nullptr && e.has_n)) { isx_set_error("isx_pipe_submit_planes: the reference key stands for other planes (positions / non-ACGT plane differ)"); return ISX_ERR_ARG; }
+                if (e.n_pos != n_pos || e.has_n != (rp->nplane != nullptr && e.has_n) || e.sum != ref_plane_checksum(rp->plane2, n_pos)) {
+                    isx_set_error("isx_pipe_submit_planes: the reference key stands for other planes (positions / non-ACGT plane / content differ)");
+                    return ISX_ERR_ARG;
+                }
                 s.ref_has_n = e.has_n;
                 J.ref2 = rp->plane2; J.refn = e.has_n ? rp->nplane : nullptr;
                 resident_ref = e.d;
@@ -1230,15 +1272,19 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         if (rp && rp->key && !resident_ref) {
             // first trip of this key: a device-side copy of what just arrived stays with the pipe (while its budget lasts)
             const size_t rb_all = ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0);
-            if (p->ref_cache_bytes + rb_all <= p->ref_cache_budget) {
+            if (p->ref_cache_bytes + rb_all <= p->ref_cache_budget.load(std::memory_order_relaxed)) {
                 isx_pipe::RefEntry e;
-                if (isx_dev_malloc(reinterpret_cast<void **>(&e.d), rb_all + 64) == hipSuccess && hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) == hipSuccess) {
-                    HIP_TRY(hipMemcpyAsync(e.d, s.d_in + s.off_ref, rb_all, hipMemcpyDeviceToDevice, p->s_h2d));
-                    HIP_TRY(hipEventRecord(e.ready, p->s_h2d));
-                    e.bytes = rb_all; e.n_pos = n_pos; e.has_n = s.ref_has_n;
+                bool ok = isx_dev_malloc(reinterpret_cast<void **>(&e.d), rb_all + 64) == hipSuccess && hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) == hipSuccess;
+                ok = ok && hipMemcpyAsync(e.d, s.d_in + s.off_ref, rb_all, hipMemcpyDeviceToDevice, p->s_h2d) == hipSuccess && hipEventRecord(e.ready, p->s_h2d) == hipSuccess;
+                if (ok) {
+                    e.bytes = rb_all; e.n_pos = n_pos; e.has_n = s.ref_has_n; e.sum = ref_plane_checksum(rp->plane2, n_pos);
                     p->ref_cache_bytes += rb_all;
                     p->ref_cache.emplace(rp->key, e);
-                } else { if (e.d) isx_dev_free(e.d); (void)hipGetLastError(); }
+                } else {                            // (no entry: the batch goes on with the planes that just travelled; nothing leaks)
+                    if (e.d) isx_dev_free(e.d);
+                    if (e.ready) (void)hipEventDestroy(e.ready);
+                    (void)hipGetLastError();
+                }
             }
         }
     ref_staged:;
@@ -1679,7 +1725,7 @@ int isx_pipe_submit_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref
 int isx_pipe_set_reference_budget(isx_pipe *p, int64_t mib)
 {
     if (!p) { isx_set_error("isx_pipe_set_reference_budget: bad argument"); return ISX_ERR_ARG; }
-    p->ref_cache_budget = mib < 0 ? 0 : (size_t)(mib ? mib : 4096) << 20;
+    p->ref_cache_budget.store(mib < 0 ? 0 : (size_t)(mib ? mib : 4096) << 20, std::memory_order_relaxed);
     return ISX_OK;
 }
 
@@ -1813,6 +1859,7 @@ int isx_pipe_collect(isx_pipe *p, int64_t ticket, isx_pipe_result *out)
     out->record_bytes = p->rb;
     out->h2d_bytes = s.h2d_bytes; out->d2h_bytes = s.d2h_bytes;
     out->ld = p->prm.enable_linkage ? s.ld_rows.data() : nullptr;
+    out->rows_checksum = s.rows_checksum;
     float ms = 0.f;
     if (s.h2d_split) {                          // the time the DMA engine worked for this batch, not the stager's time between its two parts
         float m1 = 0.f, m2 = 0.f;

@@ -464,7 +464,7 @@ class Pipe:
         r = _lib.PipeResult()
         check(self.lib.isx_pipe_collect(self.h, int(ticket), C.byref(r)))
         sz = {n: getattr(r.sizes, n) for n, _ in Sizes._fields_}
-        out = {"sizes": sz, "ticket": r.ticket,
+        out = {"sizes": sz, "ticket": r.ticket, "rows_checksum": int(r.rows_checksum),
                "stats": {k: getattr(r, k) for k in ("encode_ms", "h2d_ms", "kernel_ms", "d2h_ms", "collect_wait_ms",
                                                     "record_bytes", "encode_passes", "h2d_bytes", "d2h_bytes")}}
         n_pos = int(r.n_pos)
@@ -885,6 +885,10 @@ class BamFile:
         self._refs = None
         if threads:
             check(self.lib.isx_bam_set_threads(self.h, int(threads)))
+
+    def set_threads(self, threads):
+        """host threads of the handle's passes from now on (0 = automatic: 2 x the container's cpu quota)"""
+        check(self.lib.isx_bam_set_threads(self.h, int(threads)))
 
     @staticmethod
     def _params(min_read_ani=0.95, min_mapq=-1, max_insert_relative=3, min_insert=50, min_base_quality=30,

@@ -738,6 +738,12 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         helpers = ThreadPoolExecutor(2)
         codes_of = [helpers.submit(lambda nm=name: engine.encode_seq(str(s2s[nm]).upper())) for _, name, _ in plan]
         # ---- read pairs: the controller's R2M, or the built-in filter ----
+        # pass 1 (inflate + record walk) waits on page faults of the mapped file and of its buffers: it runs on twice the threads the
+        # hand-over gets (measured r5: scan 180 -> 137 ms with 32 threads on a 16-cpu quota, the hand-over 85 -> 112 ms)
+        n_thr = int(kwargs.get('host_threads', 0))
+        scan_thr = int(kwargs.get('scan_threads', 2 * n_thr))
+        if own_bf and n_thr > 0 and scan_thr != n_thr:
+            bf.set_threads(scan_thr)
         bf.scan(part=kwargs.get('scan_part'))
         stage("scan_ms")
         fkw = dict(min_read_ani=kwargs.get('min_read_ani', 0.95), min_mapq=kwargs.get('min_mapq', -1),
@@ -780,6 +786,8 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         reads_per_ref, pairs_per_ref = bf.ref_counts()
         if not store_everything:                    # (--store_everything keys read_to_snvs by read name: the names stay)
             bf.drop_names()
+        if own_bf and n_thr > 0 and scan_thr != n_thr:
+            bf.set_threads(n_thr)
         stage("filter_ms")
         # ---- batches of whole scaffolds under a position / read budget; the reference groups its commands by estimated
         #      cost the same way (profile_controller.py:436-457) ----
@@ -872,8 +880,12 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         def take(splits):
             if not splits:
                 return
-            m = splits[0]._src[0].meta              # (the keys straight from the batch's split table: no per-object field is realised)
-            out.update(zip(map("{0}.{1}".format, m['scaffold'], m['number']), splits))
+            src = splits[0].__dict__.get('_src')
+            if src is not None and all(S.__dict__.get('_src') is not None and S.__dict__['_src'][0] is src[0] for S in (splits[0], splits[-1])):
+                m = src[0].meta                     # (the keys straight from the batch's split table: no per-object field is realised)
+                out.update(zip(map("{0}.{1}".format, m['scaffold'], m['number']), splits))
+            else:                                   # materialised / unpickled objects: their own fields
+                out.update(("{0}.{1}".format(S.scaffold, S.split_number), S) for S in splits)
 
         def run_alone(items):
             """a group whose batch failed: scaffold by scaffold, so that only the offender is dropped"""

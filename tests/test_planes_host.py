@@ -224,3 +224,56 @@ def test_pack_read_planes_equals_pack_reads():
     pb = engine.pack_read_planes(**args)
     assert pb.n_seg == segs.n_seg and (pb.gpos == segs.gpos).all() and (pb.len == segs.len).all() and (pb.pair == segs.pair).all()
     assert (pb.planes == _planes_numpy(segs)).all()
+
+
+def _guarded(data):
+    """a copy of `data` (uint8) that ENDS at a page boundary followed by an inaccessible page: a read past the end faults"""
+    import ctypes
+    import mmap
+    page = mmap.PAGESIZE
+    n = len(data)
+    size = (n + page - 1) // page * page + page
+    m = mmap.mmap(-1, size)
+    buf = np.frombuffer(m, dtype=np.uint8)
+    start = size - page - n
+    buf[start:start + n] = data
+    libc = ctypes.CDLL(None, use_errno=True)
+    addr = buf.ctypes.data + size - page
+    assert libc.mprotect(ctypes.c_void_p(addr), ctypes.c_size_t(page), 0) == 0        # PROT_NONE
+    return buf[start:start + n], m
+
+
+def _guard_page_body():
+    rng = np.random.default_rng(9)
+    for n_pos in (4096 * 8, 4096 * 8 + 5, 50_003):
+        ref = rng.integers(0, 4, n_pos).astype(np.uint8)
+        ref[rng.random(n_pos) < 0.05] = 4
+        ref[-300:][rng.random(300) < 0.3] = 4
+        starts = np.r_[np.arange(max(0, n_pos - 520), n_pos - 1, 1), [0, 10, n_pos - 1]].astype(np.uint32)
+        starts.sort()
+        ln = np.minimum(150, n_pos - starts.astype(np.int64)).astype(np.uint8)
+        codes = np.full((len(starts), 150), 4, np.uint8)
+        for i, (s, l) in enumerate(zip(starts.tolist(), ln.tolist())):
+            c = ref[s:s + l].copy()
+            c[c > 3] = rng.integers(0, 4, int((c > 3).sum()))
+            flip = rng.random(l) < 0.03
+            c[flip] = (c[flip] + 1) & 3
+            c[rng.random(l) < 0.05] = 4
+            codes[i, :l] = c
+        segs = engine.SegBatch(starts, ln, engine.pack_codes(codes), None, np.arange(len(starts), dtype=np.uint32))
+        want = engine.encode_delta(segs, ref, threads=2)
+        rp = engine.RefPlanes.from_codes(ref, threads=1)
+        p2, keep2 = _guarded(rp.plane2[:(n_pos + 3) // 4])
+        pn, keepn = _guarded(rp.nplane[:(n_pos + 7) // 8])
+        got = engine.encode_planes(engine.PlaneBatch.from_segs(segs), engine.RefPlanes(p2, pn, n_pos), threads=2)
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_planes_stager_never_reads_past_the_caller_planes(variant):
+    """isx_encode_planes read up to 7 bytes past the caller's non-ACGT bit plane for segments starting in the last ~250 positions.
+    Both reference planes end at an inaccessible page here (a stray read is a segfault: the body runs in a subprocess), segments start at
+    every one of the last 520 positions, through every compiled variant of the per-segment pass; records == the byte-compare stager's"""
+    code = ("import os, sys; os.environ['ISX_PLANES_VARIANT'] = '%d'; sys.path.insert(0, %r); import tests.test_planes_host as t; t._guard_page_body()" % (variant, REPO))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
