@@ -1018,11 +1018,19 @@ def c2_mm_stream_leg(ctx, w, args, host_threads, steps, warmup):
     M = int(w["n_mm_bins_mm"])
     n_var = max(1, min(args.variants, steps, 16))
     variants = make_variants(dict(w, segs=w["segs_mm"]), n_var)
+    # the hand-over: the reads as bit planes + the pairs' mm levels (isx_read_planes.mm), the batches as 32-byte reference-delta records with
+    # the level in the header (ISX_LAYOUT_MM_DELTA_RECORDS, round 6); ISX_BENCH_MM_SEGS=1: isx_segs -> 64-byte segment records (round 3's way)
+    as_segs = bool(int(os.environ.get("ISX_BENCH_MM_SEGS", "0")))
     pipe = engine.Pipe(ctx, max_pos=max(v["n_pos"] for v in variants), max_obs=0, max_segs=int(w["segs_mm"].n_seg),
                        max_splits=max(len(v["split_bounds"]) for v in variants), depth=args.depth, host_threads=host_threads,
-                       pin_threads=args.pin, n_mm_bins=M, enable_linkage=False, window=args.window, lean_output=LEAN_SLOTS)
+                       pin_threads=args.pin, n_mm_bins=M, enable_linkage=False, window=args.window, lean_output=LEAN_SLOTS,
+                       layout=0 if as_segs else 32)
+    if not as_segs:
+        variants = [dict(v, planes=engine.PlaneBatch.from_segs(v["segs"], threads=host_threads), ref_planes=engine.RefPlanes.from_codes(v["ref_codes"], threads=host_threads))
+                    for v in variants]
     out = {"workload": "C2 streamed with mm profiling ON (%d mm bins): one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, linkage off; every batch handed over "
-                       "inside the step (isx_pipe_submit_reads), profiled once, the per-level tables handed back inside the step; %d distinct batches" % (M, n_var),
+                       "inside the step (%s), profiled once, the per-level tables handed back inside the step; %d distinct batches"
+                       % (M, "isx_pipe_submit_reads: isx_segs" if as_segs else "isx_pipe_submit_planes: bit planes + the pairs' mm levels -> reference-delta records", n_var),
            "mm_bins": M}
 
     pipe_levels = [False]
@@ -1051,7 +1059,10 @@ def c2_mm_stream_leg(ctx, w, args, host_threads, steps, warmup):
             if len(tickets) - done == args.depth:
                 take()
             v = variants[i % n_var]
-            tickets.append(pipe.submit_reads(v["ref_codes"], v["split_bounds"], v["segs"]))
+            if "planes" in v:
+                tickets.append(pipe.submit_planes(v["ref_planes"], v["split_bounds"], v["planes"], keyed=False))
+            else:
+                tickets.append(pipe.submit_reads(v["ref_codes"], v["split_bounds"], v["segs"]))
         while done < len(tickets):
             take()
         return fetch_s, n_ent

@@ -581,8 +581,9 @@ int isx_wire_keep_reference(isx_pipe *p, isx_wire *wire);
  * anything that is not A/C/T/G as 0) + a bit plane marking the positions that are not A/C/T/G (NULL = there are none).
  * Why: the stager of isx_pipe_submit_reads unpacks 150 codes to bytes and compares them with reference bytes; from planes the
  * observed-and-different columns are one XOR of five words against the funnel-shifted reference plane (32 columns a step), the skip
- * plane is copied into the record as it is, and the reference plane is copied, not packed.  One-mm-bin pipes only
- * (--database_mode / --skip_mm_profiling; n_mm_bins > 1: ISX_ERR_STATE -- hand isx_segs over).  Replaces the same reference code as
+ * plane is copied into the record as it is, and the reference plane is copied, not packed.  Pipes whose batches travel as
+ * reference-delta records: one mm bin (--database_mode / --skip_mm_profiling), or -- round 6 -- n_mm_bins > 1 with ISX_LAYOUT_MM_DELTA_RECORDS
+ * (isx_read_planes.mm; otherwise ISX_ERR_STATE -- hand isx_segs over).  Replaces the same reference code as
  * isx_segs: the visits of samfile.pileup(...) + get_base_counts_mm (profile_utilities.py:150-153, 268-286).  Tables are
  * byte-identical to those of the isx_segs the planes stand for (tests/test_gpu_planes.py). */
 #define ISX_PLANE_WORDS 8
@@ -592,6 +593,12 @@ typedef struct {
     const uint8_t *len;         /* [n_seg] 1 .. ISX_SEG_BASES columns; gpos + len <= n_pos */
     const uint32_t *pair;       /* [n_seg] dense read-pair id; NULL unless linkage is enabled */
     const uint64_t *planes;     /* [n_seg][ISX_PLANE_WORDS] */
+    /* round 6 (ABI 5) -- mm profiling on (a pipe with n_mm_bins > 1 and ISX_LAYOUT_MM_DELTA_RECORDS): */
+    const uint8_t *mm;          /* [n_seg] R2M[read name] (< n_mm_bins, <= 127); NULL = 0.  A base that is not A/C/T/G but passes the quality
+                                 * filter makes its pair's level present at the column (profile_utilities.py:279-285): its column is marked NOT
+                                 * observed like any other, its 2-bit code is 1 (0 at every other column that is not observed), and bit 63 of the
+                                 * line's word 7 is set when the line holds such a column (the stager's common path tests that bit alone).  With
+                                 * one mm bin all of this is ignored, as before. */
 } isx_read_planes;
 
 typedef struct {
@@ -626,6 +633,10 @@ int isx_pipe_set_reference_budget(isx_pipe *p, int64_t mib);
 /* the stager on its own (no GPU needed), like isx_encode_delta: planes + reference planes -> 32-byte reference-delta records */
 int isx_encode_planes(const isx_read_planes *reads, const isx_ref_planes *ref, int64_t n_pos, int32_t host_threads, int32_t slack_groups,
                       int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, int64_t *n_rec, int64_t *need_slack);
+/* the same with mm profiling on: reads->mm rides in the records' headers, marked non-ACGT columns become exceptions at skipped columns --
+ * the records isx_encode_delta makes of the segments (and their mm) the planes stand for */
+int isx_encode_planes_mm(const isx_read_planes *reads, const isx_ref_planes *ref, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int32_t slack_groups,
+                         int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, int64_t *n_rec, int64_t *need_slack);
 
 /* Host helper for a caller that decodes the BAM itself (e.g. a pysam loop over samfile.fetch()): reads -> segments.
  * Per read r: flat position of its reference start ref_start[r] (may be negative relative to the scaffold when the

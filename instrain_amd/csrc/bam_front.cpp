@@ -129,14 +129,29 @@ inline void seg_pack_bmi2(uint8_t *cd /* [160], writable: padded with code 4 */,
 
 // ---- the same segment as BIT PLANES (include/instrain_amd.h isx_read_planes): words 0-4 the 2-bit codes, words 5-7 the columns
 // that are not observed (quality below minq, or a base that is not A/C/T/G) ----
-inline void seg_planes_scalar(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint64_t *P)
+inline uint64_t even_bits_of(uint64_t x)         // bits 0, 2, 4 ... 62 -> bits 0 .. 31
+{
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return x;
+}
+
+// mark_n (mm profiling on, isx_read_planes.mm): a base that is not A/C/T/G but passes the quality filter gets code 1 at its (not observed)
+// column and sets the line's marker flag, bit 63 of word 7; every other column that is not observed has code 0
+inline void seg_planes_scalar(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint64_t *P, bool mark_n = false)
 {
     uint64_t b[5] = {0, 0, 0, 0, 0}, sk[3] = {0, 0, 0};
     for (int j = 0; j < n; j++) {
         const int64_t i = q0 + j;
         const uint32_t c = CODE2IDX[(seq[i >> 1] >> ((~i & 1) << 2)) & 15];
-        if (c > 3 || qual[i] < minq) sk[j >> 6] |= (uint64_t)1 << (j & 63);
-        else b[j >> 5] |= (uint64_t)c << (2 * (j & 31));
+        if (c > 3 || qual[i] < minq) {
+            sk[j >> 6] |= (uint64_t)1 << (j & 63);
+            if (mark_n && c > 3 && qual[i] >= minq) { b[j >> 5] |= (uint64_t)1 << (2 * (j & 31)); sk[2] |= (uint64_t)1 << 63; }
+        } else b[j >> 5] |= (uint64_t)c << (2 * (j & 31));
     }
     for (int k = 0; k < 5; k++) P[k] = b[k];
     for (int k = 0; k < 3; k++) P[5 + k] = sk[k];
@@ -153,7 +168,7 @@ inline bool cpu_has_avx512bw()
 // columns as a mask register; four codes are folded into a byte by two shift-or steps and a narrowing move.  The conversion starts
 // at the even base below q0; a leading odd base is shifted out at the end.
 __attribute__((target("avx512f,avx512bw,avx512vl,bmi2")))
-inline void seg_planes_avx512(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint64_t *P)
+inline void seg_planes_avx512(const uint8_t *seq, const uint8_t *qual, int64_t q0, int n, uint8_t minq, uint64_t *P, bool mark_n = false)
 {
     const int64_t e0 = q0 & ~(int64_t)1;
     const int lead = (int)(q0 - e0), m = n + lead;                                 // m <= 151 columns from the even base e0
@@ -163,6 +178,7 @@ inline void seg_planes_avx512(const uint8_t *seq, const uint8_t *qual, int64_t q
     const __m512i mq = _mm512_set1_epi8((char)minq);
     alignas(64) uint64_t b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t sk[3];
+    uint64_t any_n = 0;
     for (int k = 0; k < 3; k++) {
         const int have = m - 64 * k;                                               // columns of this step
         if (have <= 0) { sk[k] = 0; continue; }
@@ -174,10 +190,16 @@ inline void seg_planes_avx512(const uint8_t *seq, const uint8_t *qual, int64_t q
         const __m512i nib = _mm512_or_si512(_mm512_srli_epi16(w, 4), _mm512_slli_epi16(_mm512_and_si512(w, _mm512_set1_epi16(0x0F)), 8));
         const __m512i code = _mm512_shuffle_epi8(lut, nib);
         const __m512i q = _mm512_maskz_loadu_epi8(cm, ql + 64 * k);
-        const __mmask64 ok = _mm512_mask_cmpge_epu8_mask(cm, q, mq) & ~_mm512_movepi8_mask(code);
+        const __mmask64 qok = _mm512_mask_cmpge_epu8_mask(cm, q, mq);
+        const __mmask64 ok = qok & ~_mm512_movepi8_mask(code);
         sk[k] = (uint64_t)(cm & ~ok);
         // four 2-bit codes a byte: c0 | c1 << 2 within 16 bits, then the two nibbles of a dword, then dword -> byte
-        const __m512i c2 = _mm512_and_si512(code, _mm512_set1_epi8(3));
+        __m512i c2 = _mm512_and_si512(code, _mm512_set1_epi8(3));
+        if (mark_n) {                               // codes only at observed columns, 1 at the marked ones
+            const __mmask64 nm = qok & _mm512_movepi8_mask(code);
+            c2 = _mm512_mask_mov_epi8(_mm512_maskz_mov_epi8(ok, c2), nm, _mm512_set1_epi8(1));
+            any_n |= (uint64_t)nm;
+        }
         const __m512i t = _mm512_and_si512(_mm512_or_si512(c2, _mm512_srli_epi16(c2, 6)), _mm512_set1_epi16(0x000F));
         const __m512i u = _mm512_or_si512(t, _mm512_srli_epi32(t, 12));
         _mm_store_si128(reinterpret_cast<__m128i *>(b + 2 * k), _mm512_cvtepi32_epi8(u));
@@ -186,8 +208,12 @@ inline void seg_planes_avx512(const uint8_t *seq, const uint8_t *qual, int64_t q
         for (int k = 0; k < 5; k++) b[k] = (b[k] >> 2) | (b[k + 1] << 62);
         sk[0] = (sk[0] >> 1) | (sk[1] << 63); sk[1] = (sk[1] >> 1) | (sk[2] << 63); sk[2] >>= 1;
     }
+    if (lead && any_n) {                            // (a marked column that was the dropped leading one does not count)
+        const uint64_t m0 = (even_bits_of(b[0]) | (even_bits_of(b[1]) << 32)) & sk[0], m1 = (even_bits_of(b[2]) | (even_bits_of(b[3]) << 32)) & sk[1], m2 = even_bits_of(b[4]) & sk[2];
+        any_n = m0 | m1 | m2;
+    }
     for (int k = 0; k < 5; k++) P[k] = b[k];
-    P[5] = sk[0]; P[6] = sk[1]; P[7] = sk[2];
+    P[5] = sk[0]; P[6] = sk[1]; P[7] = sk[2] | (any_n ? (uint64_t)1 << 63 : 0);
 }
 
 struct Read {           // a read of the batch being expanded
@@ -2121,8 +2147,9 @@ struct BamBatch {
         }
     }
 
-    // the same segments as bit planes (isx_read_planes: one 64-byte line each); one mm bin only -- the pair's mm does not travel
-    void emit_planes(int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint32_t *pair, uint64_t *planes) const
+    // the same segments as bit planes (isx_read_planes: one 64-byte line each); mm != NULL (mm profiling on): the pairs' levels too, and
+    // the non-ACGT bases that pass the filter are marked in the lines
+    void emit_planes(int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint64_t *planes) const
     {
         size_t ri = (size_t)(std::upper_bound(seg_at.begin(), seg_at.end(), (uint64_t)first) - seg_at.begin()) - 1;
         int64_t skip = first - (int64_t)seg_at[ri], done = 0;
@@ -2132,13 +2159,16 @@ struct BamBatch {
             if (seg_at[ri + 1] == seg_at[ri]) continue;
             const Read &r = S.reads[ri];
             const uint32_t id = pid[ri];
+            const bool mark = mm != nullptr && !prm.skip_mm;
+            const uint8_t m = mark ? (uint8_t)std::min<int32_t>(std::min<int32_t>(127, B->mm_cap), B->pairs[r.pair_idx].mm) : (uint8_t)0;
             for_segments(ri, [&](int64_t g, int64_t q0, int64_t cols) {
                 if (skip > 0) { skip--; return; }
                 if (done >= count) return;
                 uint64_t *P = planes + (size_t)done * ISX_PLANE_WORDS;
-                if (fast) seg_planes_avx512(r.seq, r.qual, q0, (int)cols, mq, P);
-                else seg_planes_scalar(r.seq, r.qual, q0, (int)cols, mq, P);
+                if (fast) seg_planes_avx512(r.seq, r.qual, q0, (int)cols, mq, P, mark);
+                else seg_planes_scalar(r.seq, r.qual, q0, (int)cols, mq, P, mark);
                 gpos[done] = (uint32_t)g; len[done] = (uint8_t)cols;
+                if (mm) mm[done] = m;
                 if (pair) pair[done] = id;
                 done++;
             });
@@ -2567,9 +2597,9 @@ void bam_batch_emit_segs(const BamBatch *q, int64_t first, int64_t count, uint32
 {
     q->emit_segs(first, count, gpos, len, mm, pair, bases);
 }
-void bam_batch_emit_planes(const BamBatch *q, int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint32_t *pair, uint64_t *planes)
+void bam_batch_emit_planes(const BamBatch *q, int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint64_t *planes)
 {
-    q->emit_planes(first, count, gpos, len, pair, planes);
+    q->emit_planes(first, count, gpos, len, mm, pair, planes);
 }
 int64_t bam_batch_n_obs(const BamBatch *q) { return q->n_obs(); }
 int64_t bam_batch_n_pos(const BamBatch *q) { return q->n_pos; }
@@ -2638,14 +2668,16 @@ int isx_bam_segment_refs(isx_bam *bam, const isx_bam_params *p, const int32_t *r
     isxenc::HostPool &pool = pool_of(B);
     const size_t piece = 4096;
     std::vector<uint32_t> tmp_gpos(n), g2(n), p2(n);
-    std::vector<uint8_t> l2(n);
+    std::vector<uint8_t> l2(n), m2(n);
     pool.run((int)((n + piece - 1) / piece), [&](int t) {
         const size_t a = (size_t)t * piece, e = std::min(n, a + piece);
         q->emit_segs((int64_t)a, (int64_t)(e - a), tmp_gpos.data() + a, B.seg_len.data() + a, B.seg_mm.data() + a, B.seg_pair.data() + a,
                      B.seg_bases.data() + a * ISX_SEG_WORDS);
-        q->emit_planes((int64_t)a, (int64_t)(e - a), g2.data() + a, l2.data() + a, p2.data() + a, B.seg_planes.data() + a * ISX_PLANE_WORDS);
+        q->emit_planes((int64_t)a, (int64_t)(e - a), g2.data() + a, l2.data() + a, m2.data() + a, p2.data() + a, B.seg_planes.data() + a * ISX_PLANE_WORDS);
     });
-    if (g2 != tmp_gpos || memcmp(l2.data(), B.seg_len.data(), n) != 0 || memcmp(p2.data(), B.seg_pair.data(), n * 4) != 0) {
+    bool mm_same = true;
+    for (size_t i = 0; i < n && mm_same; i++) mm_same = m2[i] == (uint8_t)std::min<int>(B.seg_mm[i], 127);
+    if (g2 != tmp_gpos || memcmp(l2.data(), B.seg_len.data(), n) != 0 || memcmp(p2.data(), B.seg_pair.data(), n * 4) != 0 || !mm_same) {
         isx_set_error("internal: the segment and the bit-plane emission differ");
         return ISX_ERR_STATE;
     }

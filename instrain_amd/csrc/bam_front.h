@@ -18,7 +18,7 @@ const uint32_t *bam_batch_seg_gpos(const BamBatch *q);  // [n_segs] flat start o
 void bam_batch_emit_segs(const BamBatch *q, int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair,
                          uint32_t *bases);               // thread safe
 // the same segments as bit planes (isx_read_planes): gpos / len / pair [count], planes [count][ISX_PLANE_WORDS]; thread safe
-void bam_batch_emit_planes(const BamBatch *q, int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint32_t *pair, uint64_t *planes);
+void bam_batch_emit_planes(const BamBatch *q, int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint64_t *planes);  // mm: NULL with one mm bin
 void bam_batch_free(BamBatch *q);
 // done with, but not freed now: the batch goes with its handle (isx_bam_close), see isx_bam::retired
 void bam_batch_retire(BamBatch *q);

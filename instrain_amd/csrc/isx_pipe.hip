@@ -1234,7 +1234,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     uint8_t *resident_ref = nullptr;            // the batch's reference planes already on the device (isx_ref_planes.key)
     if (planes_in) {
         // the reference planes first, into staging: the record pass compares against that copy
-        if (!p->drec) { isx_set_error("bit-plane reads need a one-mm-bin pipe (reference-delta records)"); return ISX_ERR_STATE; }
+        if (!p->drec) { isx_set_error("bit-plane reads need a pipe whose batches travel as reference-delta records (one mm bin, or ISX_LAYOUT_MM_DELTA_RECORDS)"); return ISX_ERR_STATE; }
         const double t_r = now_ms();
         uint8_t *h2 = s.h_in + s.off_ref, *hn = h2 + ref2_bytes(n_pos);
         if (rp && rp->key) {
@@ -1552,7 +1552,7 @@ int isx_pipe_stage_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref,
         isx_set_error("isx_pipe_stage_planes: bad argument");
         return ISX_ERR_ARG;
     }
-    if (!p->drec) { isx_set_error("isx_pipe_stage_planes: bit-plane reads need a one-mm-bin read-level pipe"); return ISX_ERR_STATE; }
+    if (!p->drec) { isx_set_error("isx_pipe_stage_planes: bit-plane reads need a read-level pipe with one mm bin or ISX_LAYOUT_MM_DELTA_RECORDS"); return ISX_ERR_STATE; }
     return stage_common(p, n_pos, nullptr, ref, n_splits, split_bounds, nullptr, reads, out);
 }
 
@@ -1692,7 +1692,7 @@ int isx_pipe_submit_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref
         isx_set_error("isx_pipe_submit_planes: bad argument");
         return ISX_ERR_ARG;
     }
-    if (!p->segs || !p->drec) { isx_set_error("isx_pipe_submit_planes: bit-plane reads need a one-mm-bin read-level pipe (max_segs > 0, n_mm_bins == 1)"); return ISX_ERR_STATE; }
+    if (!p->segs || !p->drec) { isx_set_error("isx_pipe_submit_planes: bit-plane reads need a read-level pipe (max_segs > 0) with one mm bin (n_mm_bins == 1) or ISX_LAYOUT_MM_DELTA_RECORDS"); return ISX_ERR_STATE; }
     if (p->prm.enable_linkage && reads->n_seg && !reads->pair) { isx_set_error("linkage needs the pair array"); return ISX_ERR_ARG; }
     if (p->stager.joinable()) {         // queued for the stager (see isx_pipe_submit_reads): the caller's arrays stay valid and unchanged until collect / release
         if (n_pos > p->pp.max_pos || reads->n_seg > p->pp.max_segs || n_splits > p->pp.max_splits) {
@@ -1773,7 +1773,7 @@ int isx_pipe_submit_bam(isx_pipe *p, isx_bam *bam, const struct isx_bam_params_s
         J.gpos_all = bam_batch_seg_gpos(q);
         J.want_pairs = p->prm.enable_linkage != 0;
         // (one mm bin: as bit planes -- the 4-bit seq maps straight onto the 2-bit plane and the stager XORs instead of unpacking)
-        if (p->drec && !getenv("ISX_BAM_SEG_WORDS")) J.produce_planes = [q](int64_t first, int64_t count, uint32_t *g, uint8_t *l, uint32_t *pr, uint64_t *pl) { bam_batch_emit_planes(q, first, count, g, l, pr, pl); };
+        if (p->drec && !getenv("ISX_BAM_SEG_WORDS")) J.produce_planes = [q](int64_t first, int64_t count, uint32_t *g, uint8_t *l, uint8_t *m, uint32_t *pr, uint64_t *pl) { bam_batch_emit_planes(q, first, count, g, l, m, pr, pl); };
         else J.produce = [q](int64_t first, int64_t count, uint32_t *g, uint8_t *l, uint8_t *m, uint32_t *pr, uint32_t *b) { bam_batch_emit_segs(q, first, count, g, l, m, pr, b); };
         rc = submit_segs_common(p, n_pos, ref, n_splits, split_bounds, J, ticket);
     } else {

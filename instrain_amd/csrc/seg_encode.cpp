@@ -575,6 +575,7 @@ struct PlaneTask {                       // one task of encode_planes: segments 
     int64_t a, e;
     const uint32_t *gp, *pr, *gpos_all;
     const uint8_t *ln;
+    const uint8_t *mm = nullptr;        // the segments' mm levels (n_mm_bins > 1), NULL = 0
     const uint64_t *pl;
     uint32_t *rec0;                     // where device group g0 lies
     int64_t g0, ga, ge;
@@ -613,7 +614,7 @@ __attribute__((noinline)) void rebase_drecs(PlaneGroup &G, uint32_t new_lo)
 
 struct PlaneScratch {
     std::vector<uint32_t> gpos, pair;
-    std::vector<uint8_t> len;
+    std::vector<uint8_t> len, mm;
     std::vector<uint64_t> planes;       // (64-byte aligned inside)
     uint64_t *pl = nullptr;
 };
@@ -706,24 +707,26 @@ int encode_planes(HostPool &pool, SegJob &J)
         if (err.load(std::memory_order_relaxed) != SEG_OK) return;
         const int64_t a = (int64_t)t * TASK, e = std::min<int64_t>(n, a + TASK);
         const uint32_t *gp, *pr;
-        const uint8_t *ln;
+        const uint8_t *ln, *mmv = nullptr;
         const uint64_t *pl;
         if (producer) {
             thread_local PlaneScratch S;
             if (S.gpos.size() < (size_t)TASK) {
-                S.gpos.resize((size_t)TASK); S.pair.resize((size_t)TASK); S.len.resize((size_t)TASK);
+                S.gpos.resize((size_t)TASK); S.pair.resize((size_t)TASK); S.len.resize((size_t)TASK); S.mm.resize((size_t)TASK);
                 S.planes.resize((size_t)TASK * ISX_PLANE_WORDS + 8);
                 S.pl = reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(S.planes.data()) + 63) & ~(uintptr_t)63);
             }
-            J.produce_planes(a, e - a, S.gpos.data(), S.len.data(), pairs ? S.pair.data() : nullptr, S.pl);
+            J.produce_planes(a, e - a, S.gpos.data(), S.len.data(), J.n_mm_bins > 1 ? S.mm.data() : nullptr, pairs ? S.pair.data() : nullptr, S.pl);
             gp = S.gpos.data() - a; ln = S.len.data() - a; pr = pairs ? S.pair.data() - a : nullptr;
+            if (J.n_mm_bins > 1) mmv = S.mm.data() - a;
             pl = S.pl - (size_t)a * ISX_PLANE_WORDS;
         } else {
             gp = J.in2.gpos; ln = J.in2.len; pr = pairs ? J.in2.pair : nullptr; pl = J.in2.planes;
+            if (J.n_mm_bins > 1) mmv = J.in2.mm;
         }
         // (ring mode: device group gi of this wave lies at slot gi - wave_g0 of the wave's half)
         PlaneTask K;
-        K.a = a; K.e = e; K.gp = gp; K.ln = ln; K.pr = pr; K.pl = pl; K.gpos_all = gpos_all;
+        K.a = a; K.e = e; K.gp = gp; K.ln = ln; K.mm = mmv; K.pr = pr; K.pl = pl; K.gpos_all = gpos_all;
         K.rec0 = RG ? J.rec + (size_t)((int64_t)half * RG) * group_words : J.rec;
         K.g0 = RG ? wave_g0 : 0; K.ga = g_at[(size_t)t]; K.ge = g_at[(size_t)t + 1]; K.fast_store = fast_store;
         if (variant == 2) planes_task_avx512(J, err, K);
@@ -848,14 +851,17 @@ bool pack_ref_planes(HostPool &pool, const uint8_t *ref, int64_t n_pos, uint8_t 
     return any.load() != 0;
 }
 
-// fifteen words of ten 3-bit codes -> one line of planes (codes >= 4: skipped column, base bits 0)
+// fifteen words of ten 3-bit codes -> one line of planes (codes >= 4: skipped column, base bits 0 -- except code 5, a base that is not
+// A/C/T/G but passed the filter: base bits 1 and the line's marker flag, bit 63 of word 7; isx_read_planes.mm in include/instrain_amd.h)
 void planes_from_words(const uint32_t *w, uint32_t L, uint64_t *P)
 {
     uint64_t b[5] = {0, 0, 0, 0, 0}, sk[3] = {0, 0, 0};
     for (uint32_t j = 0; j < L; j++) {
         const uint32_t c = (w[j / 10] >> (3 * (j % 10))) & 7u;
-        if (c >= 4) sk[j >> 6] |= (uint64_t)1 << (j & 63);
-        else b[j >> 5] |= (uint64_t)c << (2 * (j & 31));
+        if (c >= 4) {
+            sk[j >> 6] |= (uint64_t)1 << (j & 63);
+            if (c == 5) { b[j >> 5] |= (uint64_t)1 << (2 * (j & 31)); sk[2] |= (uint64_t)1 << 63; }
+        } else b[j >> 5] |= (uint64_t)c << (2 * (j & 31));
     }
     for (int i = 0; i < 5; i++) P[i] = b[i];
     for (int i = 0; i < 3; i++) P[5 + i] = sk[i];
@@ -1094,6 +1100,13 @@ int isx_planes_from_segs(const isx_segs *segs, int32_t host_threads, uint64_t *p
 int isx_encode_planes(const isx_read_planes *reads, const isx_ref_planes *ref, int64_t n_pos, int32_t host_threads, int32_t slack_groups,
                       int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, int64_t *n_rec, int64_t *need_slack)
 {
+    return isx_encode_planes_mm(reads, ref, n_pos, 1, host_threads, slack_groups, cap_rec, ring_records, rec, gbase, n_rec, need_slack);
+}
+
+int isx_encode_planes_mm(const isx_read_planes *reads, const isx_ref_planes *ref, int64_t n_pos, int32_t n_mm_bins, int32_t host_threads, int32_t slack_groups,
+                         int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, int64_t *n_rec, int64_t *need_slack)
+{
+    if (n_mm_bins < 1 || n_mm_bins > 128) { isx_set_error("isx_encode_planes: n_mm_bins must be in [1, 128]"); return ISX_ERR_ARG; }
     if (!reads || !ref || !ref->plane2 || !rec || !gbase || !n_rec || reads->n_seg < 0 || cap_rec < ISX_DREC_GROUP || (cap_rec % ISX_DREC_GROUP) || n_pos <= 0 ||
         (reads->n_seg && (!reads->gpos || !reads->len || !reads->planes)) || ring_records < 0 ||
         (ring_records % (2 * ISX_DREC_GROUP)) || slack_groups < 0) {
@@ -1105,7 +1118,7 @@ int isx_encode_planes(const isx_read_planes *reads, const isx_ref_planes *ref, i
     std::vector<uint32_t> cmin((size_t)(cap_rec / ISX_DREC_GROUP)), cmax(cmin.size());
     std::vector<uint8_t> cany(cmin.size());
     isxenc::SegJob J;
-    J.in2 = *reads; J.n_seg = reads->n_seg; J.n_pos = n_pos; J.n_mm_bins = 1;
+    J.in2 = *reads; J.n_seg = reads->n_seg; J.n_pos = n_pos; J.n_mm_bins = n_mm_bins;
     J.ref2 = ref->plane2; J.refn = ref->nplane; J.slack_groups = std::max(1, slack_groups);
     J.rec = rec; J.gbase = gbase; J.pair_out = nullptr;
     J.cmin = cmin.data(); J.cmax = cmax.data(); J.cany = cany.data(); J.cap_rec = cap_rec;
@@ -1132,6 +1145,7 @@ int isx_encode_planes(const isx_read_planes *reads, const isx_ref_planes *ref, i
     }
     if (rc == isxenc::SEG_BAD_POS) { isx_set_error("a segment reaches beyond n_pos"); return ISX_ERR_ARG; }
     if (rc == isxenc::SEG_BAD_LEN) { isx_set_error("a segment's length is not in [1, 150]"); return ISX_ERR_ARG; }
+    if (rc == isxenc::SEG_MM_RANGE) { isx_set_error("a segment has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
     return ISX_OK;
 }
 
@@ -1162,8 +1176,10 @@ int isx_pack_read_planes(int64_t n_reads, const int64_t *ref_start, const int64_
                 for (int j = 0; j < L; j++) {
                     const int64_t qi = q0 + c0 + j;
                     const uint32_t code = (int)ql[qi] >= min_base_quality ? ascii_code(sq[qi]) : 4u;
-                    if (code >= 4) P[5 + (j >> 6)] |= (uint64_t)1 << (j & 63);
-                    else P[j >> 5] |= (uint64_t)code << (2 * (j & 31));
+                    if (code >= 4) {
+                        P[5 + (j >> 6)] |= (uint64_t)1 << (j & 63);
+                        if (code == 5) { P[j >> 5] |= (uint64_t)1 << (2 * (j & 31)); P[7] |= (uint64_t)1 << 63; }     // a non-ACGT base that passed the filter: marked (isx_read_planes.mm)
+                    } else P[j >> 5] |= (uint64_t)code << (2 * (j & 31));
                 }
                 seg_gpos[n] = (uint32_t)(pos + c0); seg_len[n] = (uint8_t)L;
                 if (seg_pair) seg_pair[n] = pair ? pair[r] : 0u;

@@ -30,7 +30,7 @@ struct SegJob {
     // bit-plane input (include/instrain_amd.h isx_read_planes; encode_planes): arrays, or a producer that writes any range of the
     // stream -- gpos / len / pair [count] and planes [count][ISX_PLANE_WORDS] -- into the task's scratch
     isx_read_planes in2{};
-    std::function<void(int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint32_t *pair, uint64_t *planes)> produce_planes;
+    std::function<void(int64_t first, int64_t count, uint32_t *gpos, uint8_t *len, uint8_t *mm, uint32_t *pair, uint64_t *planes)> produce_planes;   // (mm: written when n_mm_bins > 1)
     // ... compared with the reference as it travels: the 2-bit plane (four positions a byte, anything that is not A/C/T/G as 0)
     // and the bit plane of those positions (NULL = the batch has none)
     const uint8_t *ref2 = nullptr, *refn = nullptr;

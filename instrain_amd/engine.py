@@ -59,9 +59,10 @@ class PlaneBatch:
     words 0-4 the 2-bit base codes of the columns (A C T G = 0 1 2 3), words 5-7 the columns that are not observed.  One 64-byte line a
     segment; one mm bin only.  from_segs(SegBatch) converts (isx_planes_from_segs)."""
 
-    def __init__(self, gpos, length, planes, pair=None):
+    def __init__(self, gpos, length, planes, pair=None, mm=None):
         self.gpos = np.ascontiguousarray(gpos, dtype=np.uint32)
         self.len = np.ascontiguousarray(length, dtype=np.uint8)
+        self.mm = None if mm is None else np.ascontiguousarray(mm, dtype=np.uint8)      # the pairs' mm levels (mm profiling on), see isx_read_planes.mm
         planes = np.asarray(planes, dtype=np.uint64).reshape(-1, _lib.PLANE_WORDS)
         if not planes.flags.c_contiguous or planes.ctypes.data % 64:
             a = _aligned(planes.shape, np.uint64)
@@ -70,7 +71,7 @@ class PlaneBatch:
         self.planes = planes
         self.pair = None if pair is None else np.ascontiguousarray(pair, dtype=np.uint32)
         n = len(self.gpos)
-        assert len(self.len) == n and len(self.planes) == n and (self.pair is None or len(self.pair) == n)
+        assert len(self.len) == n and len(self.planes) == n and (self.pair is None or len(self.pair) == n) and (self.mm is None or len(self.mm) == n)
         self.n_seg = n
 
     @classmethod
@@ -78,11 +79,11 @@ class PlaneBatch:
         planes = _aligned((segs.n_seg, _lib.PLANE_WORDS), np.uint64)
         cs = segs.c()
         check(_lib.load().isx_planes_from_segs(C.byref(cs), int(threads), planes.ctypes.data if segs.n_seg else None))
-        return cls(segs.gpos, segs.len, planes, segs.pair)
+        return cls(segs.gpos, segs.len, planes, segs.pair, segs.mm)
 
     def c(self, with_pair=True):
         ptr = lambda a: a.ctypes.data if a is not None and len(a) else None
-        return _lib.ReadPlanes(self.n_seg, ptr(self.gpos), ptr(self.len), ptr(self.pair) if with_pair else None, ptr(self.planes))
+        return _lib.ReadPlanes(self.n_seg, ptr(self.gpos), ptr(self.len), ptr(self.pair) if with_pair else None, ptr(self.planes), ptr(self.mm))
 
     @property
     def n_bases(self):
@@ -679,7 +680,7 @@ def encode_delta(segs, ref_codes, n_mm_bins=1, threads=1, slack_groups=1, cap_re
         return rec[:n], gbase[:n // 32], None, slack_groups
 
 
-def encode_planes(reads, ref_planes, threads=1, slack_groups=1, cap_rec=None, ring_records=0, retry=True):
+def encode_planes(reads, ref_planes, threads=1, slack_groups=1, cap_rec=None, ring_records=0, retry=True, n_mm_bins=1):
     """isx_encode_planes (host only): PlaneBatch + RefPlanes -> (rec [n_rec, 8] uint32, gbase [n_rec / 32], None, slack_groups used) --
     the same records encode_delta gives for the segments the planes stand for"""
     lib = _lib.load()
@@ -689,8 +690,8 @@ def encode_planes(reads, ref_planes, threads=1, slack_groups=1, cap_rec=None, ri
         gbase = np.empty(cap // 32, dtype=np.uint32)
         n_rec, need = C.c_int64(0), C.c_int64(0)
         cr, cf = reads.c(), ref_planes.c()
-        rc = lib.isx_encode_planes(C.byref(cr), C.byref(cf), ref_planes.n_pos, int(threads), int(slack_groups), cap, int(ring_records),
-                                   rec.ctypes.data, gbase.ctypes.data, C.byref(n_rec), C.byref(need))
+        rc = lib.isx_encode_planes_mm(C.byref(cr), C.byref(cf), ref_planes.n_pos, int(n_mm_bins), int(threads), int(slack_groups), cap, int(ring_records),
+                                      rec.ctypes.data, gbase.ctypes.data, C.byref(n_rec), C.byref(need))
         if rc == _lib.ERR_CAPACITY and retry and need.value > slack_groups and cap_rec is None:
             slack_groups = int(need.value)
             continue

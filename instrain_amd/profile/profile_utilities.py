@@ -20,7 +20,7 @@ import numpy as np
 import pandas as pd
 
 from .. import dist as idist
-from .. import engine
+from .. import _lib, engine
 from .snv_utilities import CLASSES, null_model_lut
 
 BASES = np.array(["A", "C", "T", "G", "N"])
@@ -738,10 +738,9 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
         helpers = ThreadPoolExecutor(2)
         codes_of = [helpers.submit(lambda nm=name: engine.encode_seq(str(s2s[nm]).upper())) for _, name, _ in plan]
         # ---- read pairs: the controller's R2M, or the built-in filter ----
-        # pass 1 (inflate + record walk) waits on page faults of the mapped file and of its buffers: it runs on twice the threads the
-        # hand-over gets (measured r5: scan 180 -> 137 ms with 32 threads on a 16-cpu quota, the hand-over 85 -> 112 ms)
+        # pass 1 (inflate + record walk) may run on another number of threads than the hand-over (scan_threads)
         n_thr = int(kwargs.get('host_threads', 0))
-        scan_thr = int(kwargs.get('scan_threads', 2 * n_thr))
+        scan_thr = int(kwargs.get('scan_threads', n_thr))       # (2 x n_thr measured both ways box to box in round 6: 180 -> 137 ms once, 155 -> 180 ms another time; the caller may choose)
         if own_bf and n_thr > 0 and scan_thr != n_thr:
             bf.set_threads(scan_thr)
         bf.scan(part=kwargs.get('scan_part'))
@@ -831,7 +830,13 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                              host_threads=int(kwargs.get('host_threads', 0)), pin_threads=False,
                              min_cov=int(kwargs.get('min_cov', 5)), min_freq=min_freq, min_snp=int(kwargs.get('min_snp', 10)),
                              rarefied_coverage=rarefied, n_mm_bins=n_mm,
-                             enable_linkage=True, seed=int(kwargs.get('seed', 0)), want_counts=store_everything)
+                             enable_linkage=True, seed=int(kwargs.get('seed', 0)), want_counts=store_everything,
+                             # mm profiling on: the front end emits bit planes + the pairs' levels, the batches travel as 32-byte
+                             # reference-delta records with the level in the header (round 6) -- half the bytes, the 14-ns stager
+                             layout=int(kwargs.get('layout', _lib.LAYOUT_MM_DELTA_RECORDS if n_mm > 1 else 0)),
+                             # (a read that differs from the reference at more than three columns is several delta records: pairs kept at
+                             # 95 % identity carry up to 15 mismatches -- room for their pieces)
+                             jump_slack=float(kwargs.get('jump_slack', 1.0 if n_mm > 1 else 0.0)))
             pp.cap = cap
             return pp
 
@@ -846,6 +851,8 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             except engine.IsxError as e:
                 if e.code != -3:
                     raise
+                if os.environ.get("ISX_PROFILE_DEBUG"):
+                    print("submit_bam:", e)
                 return False
 
         def collect(g):
@@ -894,10 +901,15 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                 try:
                     g = layout([k])
                     if not submit(g):
-                        need = (g.n_pos, max(int(bf.info.get("n_segs", 0)) + 4096, 2 * g.est_segs), len(g.bounds))
-                        pipe.close()
-                        pipe = make_pipe(need)
-                        if not submit(g):
+                        ok = False
+                        for grow in (2, 8, 32):
+                            need = (g.n_pos, max(int(bf.info.get("n_segs", 0)) + 4096, grow * g.est_segs), len(g.bounds))
+                            pipe.close()
+                            pipe = make_pipe(need)
+                            ok = submit(g)
+                            if ok:
+                                break
+                        if not ok:
                             raise RuntimeError("scaffold does not fit a device batch")
                     take(collect(g))
                 except Exception as e2:
@@ -947,10 +959,14 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                     while in_flight:
                         drain_one()
                     n_real = int(bf.info.get("n_segs", 0)) if bf.info else 0
-                    need = (max(need[0], g.n_pos), max(2 * need[1], n_real + 4096), max(need[2], len(g.bounds)))
-                    pipe.close()
-                    pipe = make_pipe(need)
-                    if not submit(g):
+                    for grow in (2, 4, 8):              # (reads that are many records each: a few more tries before giving up)
+                        need = (max(need[0], g.n_pos), max(grow * need[1], n_real + 4096), max(need[2], len(g.bounds)))
+                        pipe.close()
+                        pipe = make_pipe(need)
+                        ok = submit(g)
+                        if ok:
+                            break
+                    if not ok:
                         raise RuntimeError("batch does not fit the device pipe")
                 in_flight.append(g)
             except Exception as e:

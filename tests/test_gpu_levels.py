@@ -42,13 +42,16 @@ def same_soa(got, exp, what):
         assert got[k].tobytes() == exp[k].tobytes(), (what, name, np.flatnonzero(got[k].view(np.uint32) != exp[k].view(np.uint32))[:5])
 
 
-def through_pipe(ctx, ref, bounds, segs, M, lean=False, layout=0, depth=1, **kw):
+def through_pipe(ctx, ref, bounds, segs, M, lean=False, layout=0, depth=1, planes=False, **kw):
     """-> (the four columns, the result dict's level tables or None, the full entries or None, snv rows, ld rows)"""
     from instrain_amd import engine
     # (delta records: a segment over a non-ACGT stretch of the reference is many pieces -- room for them, as a caller with such data would give)
     pipe = engine.Pipe(ctx, max_pos=len(ref), max_obs=0, max_segs=max(1, segs.n_seg), max_splits=len(bounds), depth=depth, host_threads=3,
                        pin_threads=False, n_mm_bins=M, lean_output=lean, layout=layout, jump_slack=8.0 if layout & MMDELTA else 0.0, **kw)
-    t = pipe.submit_reads(ref, bounds, segs)
+    if planes:          # the same reads as bit planes + their mm levels (isx_read_planes.mm): the XOR stager
+        t = pipe.submit_planes(engine.RefPlanes.from_codes(ref), bounds, engine.PlaneBatch.from_segs(segs))
+    else:
+        t = pipe.submit_reads(ref, bounds, segs)
     r = pipe.collect(t, shrunk_entries=True)
     soa = tuple(c.copy() for c in r["entries_soa"])
     lev = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in r["levels"].items()} if "levels" in r else None
@@ -86,7 +89,7 @@ def test_golden_vectors_level_sparse(ctx, name):
     assert np.isfinite(want[3]).any() or int(exp["entries"]["cnt"].sum(axis=1).max()) < 8
     for how, lean, layout in (("plain", False, 0), ("lean", True, 0), ("slabs", False, MM_ENTRIES), ("plain delta records", False, MMDELTA), ("lean delta records", True, MMDELTA),
                               ("lean 32-bit counters", True, NOPACK), ("lean delta records 32-bit counters", True, MMDELTA | NOPACK), ("slabs delta records", False, MM_ENTRIES | MMDELTA)):
-        soa, lev, full, snv, ld = through_pipe(ctx, ref, [0, len(ref)], segs, M, lean=lean, layout=layout, **kw)
+        soa, lev, full, snv, ld = through_pipe(ctx, ref, [0, len(ref)], segs, M, lean=lean, layout=layout, planes="delta records" in how and "slabs" not in how, **kw)
         same_soa(soa, want, name + "/" + how)
         assert (lev is None) == (bool(layout & MM_ENTRIES) or M > 32), (name, how)
         if full is not None:

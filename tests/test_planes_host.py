@@ -22,9 +22,11 @@ def _planes_numpy(segs):
     live = np.arange(150)[None, :] < segs.len[:, None]
     obs = live & (cd < 4)
     out = np.zeros((segs.n_seg, 8), dtype=np.uint64)
+    mark = live & (cd == 5)         # a base that is not A/C/T/G but passed the filter: code 1 at its (not observed) column + the line's flag
     for j in range(150):
-        out[:, j // 32] |= np.where(obs[:, j], cd[:, j], 0).astype(np.uint64) << np.uint64(2 * (j % 32))
+        out[:, j // 32] |= np.where(obs[:, j], cd[:, j], np.where(mark[:, j], 1, 0)).astype(np.uint64) << np.uint64(2 * (j % 32))
         out[:, 5 + j // 64] |= (live[:, j] & ~obs[:, j]).astype(np.uint64) << np.uint64(j % 64)
+    out[:, 7] |= mark.any(axis=1).astype(np.uint64) << np.uint64(63)
     return out
 
 
@@ -182,7 +184,7 @@ def test_bam_front_end_emits_the_planes_of_its_segments(avx512):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         return
-    n_checked = 0
+    n_checked = n_marked = 0
     for name in ("sars_cov_2.sorted.bam", "SmallScaffold.fa.sorted.bam", "filter_modes.bam"):
         path = os.path.join(REPO, "tests", "golden", name)
         bam = engine.BamFile(path)
@@ -192,10 +194,17 @@ def test_bam_front_end_emits_the_planes_of_its_segments(avx512):
         segs, _, _ = bam.segment_refs(refs, skip_mm=True)
         planes = bam.read_planes()
         assert planes.shape == (segs.n_seg, 8)
-        assert (_masked(planes, segs.len) == _planes_numpy(segs)).all(), name
+        assert (_masked(planes, segs.len) == _masked(_planes_numpy(segs), segs.len)).all(), name
         n_checked += segs.n_seg
+        # mm profiling on (round 6): the non-ACGT bases that pass the filter are MARKED (code 1 at their column, the line's flag), every
+        # other column that is not observed has code 0 -- the planes are the definition's, bit for bit
+        bam.filter(skip_mm=False)
+        segs, _, _ = bam.segment_refs(refs, skip_mm=False)
+        planes = bam.read_planes()
+        assert (planes == _planes_numpy(segs)).all(), name
+        n_marked += int((planes[:, 7] >> np.uint64(63)).sum())
         bam.close()
-    assert n_checked > 20000
+    assert n_checked > 20000 and n_marked > 0
 
 
 def test_pack_read_planes_equals_pack_reads():
@@ -277,3 +286,45 @@ def test_planes_stager_never_reads_past_the_caller_planes(variant):
     code = ("import os, sys; os.environ['ISX_PLANES_VARIANT'] = '%d'; sys.path.insert(0, %r); import tests.test_planes_host as t; t._guard_page_body()" % (variant, REPO))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("variant", [None, 0, 1, 2])
+def test_planes_with_mm_levels_equal_encode_delta(variant):
+    """mm profiling on (round 6): the pairs' levels (isx_read_planes.mm) ride in the records' headers and the marked non-ACGT columns become
+    exceptions at skipped columns -- the XOR stager writes exactly the records the byte-compare stager makes of the segments (with their mm
+    and their code-5 columns), through every compiled variant; with one mm bin the marks are ignored; a level beyond the bins is refused"""
+    if variant is not None:
+        code = ("import os, sys; os.environ['ISX_PLANES_VARIANT'] = '%d'; sys.path.insert(0, %r); import tests.test_planes_host as t; "
+                "t.test_planes_with_mm_levels_equal_encode_delta(None)" % (variant, REPO))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
+    rng = np.random.default_rng(17)
+    w, ref = _mutated_workload(seed=41, G=90_000, cov=9, err=0.012)
+    segs = synth.segs_from_obs(w["obs"], w["pair"])
+    codes = engine.unpack_codes(segs.bases)
+    inside = np.arange(150)[None, :] < segs.len[:, None]
+    n5 = inside & (rng.random(codes.shape) < 0.003)
+    n5[rng.random(segs.n_seg) < 0.8] = False                         # most lines carry no mark (the stager's common path)
+    codes = np.where(n5, 5, np.where(inside, codes, 4)).astype(np.uint8)
+    lvl = rng.integers(0, 19, segs.n_seg).astype(np.uint8)
+    segs = engine.SegBatch(segs.gpos, segs.len, engine.pack_codes(codes), lvl, segs.pair)
+    rp = engine.RefPlanes.from_codes(ref, threads=2)
+    pb = engine.PlaneBatch.from_segs(segs, threads=2)
+    assert pb.mm is not None and ((pb.planes[:, 7] >> np.uint64(63)) == n5.any(axis=1)).all() and 0 < n5.any(axis=1).mean() < 0.5
+    for threads in (1, 3):
+        a = engine.encode_delta(segs, ref, n_mm_bins=19, threads=threads)
+        b = engine.encode_planes(pb, rp, threads=threads, n_mm_bins=19)
+        assert a[0].shape == b[0].shape and (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3] == b[3]
+    g, ln, mm, cd, pr, full = engine.decode_delta(b[0], b[1], ref)
+    assert (cd == 5).sum() == n5.sum() and mm.max() == 18
+    # through the staging ring
+    r2 = engine.encode_planes(pb, rp, threads=2, n_mm_bins=19, slack_groups=b[3], ring_records=2 * 32768)
+    assert (r2[0] == b[0]).all() and (r2[1] == b[1]).all()
+    # one mm bin: the marks and the levels are ignored -- the records of the same segments with code 5 read as "not observed", level 0
+    plain = engine.SegBatch(segs.gpos, segs.len, engine.pack_codes(np.where(codes == 5, 4, codes)), None, segs.pair)
+    a1 = engine.encode_delta(plain, ref, threads=2)
+    b1 = engine.encode_planes(engine.PlaneBatch(pb.gpos, pb.len, pb.planes, pb.pair), rp, threads=2)
+    assert (a1[0] == b1[0]).all() and (a1[1] == b1[1]).all()
+    with pytest.raises(IsxError, match="mm >= n_mm_bins"):
+        engine.encode_planes(pb, rp, threads=2, n_mm_bins=18)
