@@ -393,15 +393,18 @@ def mm_leg(ctx, w, steps=10):
     _trace("mm_leg")
     from instrain_amd import engine
     out = {"workload": "C2 with mm profiling on (%d mm bins)" % w["n_mm_bins_mm"]}
-    for name, src in (("reads", w["segs_mm"]), ("observations", w["obs_mm"])):
-        b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], src, None, n_mm_bins=w["n_mm_bins_mm"], enable_linkage=False)
+    # reads: 64-byte segment records (the default with mm profiling on); reads_delta_records: 32-byte reference-delta records with the level in
+    # the header (ISX_LAYOUT_MM_DELTA_RECORDS, round 6: per-level difference rows + a materialise phase); observations: 4-byte records
+    for name, src, layout in (("reads", w["segs_mm"], 0), ("reads_delta_records", w["segs_mm"], 32), ("observations", w["obs_mm"], 0)):
+        b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], src, None, n_mm_bins=w["n_mm_bins_mm"], enable_linkage=False, layout=layout)
         dt, k, kmin = _time_batch(b, warm=3, steps=steps)
         s, t = b.sizes(), b.timings()
         b.close()
-        n_rec = (w["segs_mm"].n_seg + 15) // 16 * 16
+        n_seg = int(w["segs_mm"].n_seg)
+        n_rec = (n_seg + n_seg // 4096 * 32 + 31) // 32 * 32 if t["record_bytes"] == 32 else (n_seg + 15) // 16 * 16
         ab = pileup_algorithmic_bytes(w["n_obs"], w["n_pos"], s["n_entries"], dense=False, record_bytes=t["record_bytes"], n_rec=n_rec)
         out[name] = {"gbp_per_s": w["profiled_bases"] / 1e9 / dt, "ms_per_step": dt * 1e3, "entries": s["n_entries"], "snv_rows": s["n_snv"],
-                     "roofline": _roofline("k_pileup_mm", ab, k, t, _pmc("c2_mm_reads_bytes_per_launch" if name == "reads" else "c2_mm_pileup_bytes_per_launch"),
+                     "roofline": _roofline("k_pileup_mm", ab, k, t, _pmc({"reads": "c2_mm_reads_bytes_per_launch", "observations": "c2_mm_pileup_bytes_per_launch", "reads_delta_records": "c2_mm_delta_bytes_per_launch"}[name]),
                                            kernel_ms_min=kmin)}
     out["gbp_per_s"] = out["reads"]["gbp_per_s"]
     out["roofline"] = out["reads"]["roofline"]
@@ -530,13 +533,19 @@ class C5Run:
         self.ws.sort(key=lambda w: -w["n_pos"])                     # largest first: the pass drains behind its smallest batch
         self.gen_s = time.perf_counter() - t0
         ws = self.ws
-        self.pipe = engine.Pipe(ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["n_seg"] for w in ws),
-                                max_splits=max(len(w["split_bounds"]) for w in ws), depth=depth, host_threads=host_threads,
-                                pin_threads=bool(os.environ.get("ISX_BENCH_PIN")), n_mm_bins=1, enable_linkage=C5_LINKAGE, min_snp=20, stage_async=stage_async, lean_output=LEAN_SLOTS)
+        self.stage_async = stage_async
+        self.pipe = self.make_pipe(host_threads)
         self.bases = float(sum(w["profiled_bases"] for w in ws))
         self.signature = None
         self.wires = None
         self.stage_s = None
+
+    def make_pipe(self, host_threads):
+        from instrain_amd import engine
+        ws = self.ws
+        return engine.Pipe(self.ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["n_seg"] for w in ws),
+                           max_splits=max(len(w["split_bounds"]) for w in ws), depth=self.depth, host_threads=host_threads,
+                           pin_threads=bool(os.environ.get("ISX_BENCH_PIN")), n_mm_bins=1, enable_linkage=C5_LINKAGE, min_snp=20, stage_async=self.stage_async, lean_output=LEAN_SLOTS)
 
     def stage_all(self):
         """every batch staged once into a pinned image (isx_pipe_stage_planes): what round 4's headline replayed.  An extra of the line
@@ -755,6 +764,48 @@ class C5Run:
         cb = cpu_baseline(wo, budget_s=14.0, min_s=8.0)
         cp = cpu_baseline_python(wo, n_splits=200, budget_s=22.0, min_s=12.0)
         return cb, cp
+
+
+def rank_threads_sweep(local, lut, fb, depth, scale=1.0, threads=(2, 4, 8, 16), passes=6):
+    """What one rank of an 8-GPU job can do with T stager threads: shard 0 of 8 of the C5 database (the N = 8 job's
+    per-rank share) through one GPU with the hand-over inside the step, for T = 2, 4, 8, 16 host threads -- the figure the first hardware
+    scaling run is to be read against: on a node whose cpu quota does not grow with its GPUs a rank gets quota / 8 threads, and the
+    curve is then the stager's, not the device's.  The pre-staged replay beside it is the device side (no stager)."""
+    _trace("rank threads sweep")
+    import torch
+    from instrain_amd import engine
+    out = {"workload": "C5 shard 0 of 8 (one rank's share of the N = 8 job) through one GPU, hand-over inside the step, by stager threads", "by_threads": {}}
+    top = max(2, host_cpus())
+    ctx = engine.Context(local, reserve_cus=C5_RESERVE_CUS)
+    ctx.set_null_model(lut, fb)
+    run = C5Run(ctx, 0, 8, min(top, max(threads)), depth=depth, scale=scale)
+    run.verify_pass()
+    out["gbp_per_pass"], out["batches"] = run.bases / 1e9, len(run.ws)
+    for T in threads:
+        if T > top:
+            continue
+        run.pipe.close()
+        run.pipe = run.make_pipe(T)
+        run.run(2)
+        torch.cuda.synchronize()
+        cpu0 = time.process_time()
+        t0 = time.perf_counter()
+        stats = []
+        run.run(passes, stats)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / passes
+        run.check_timed(stats)
+        st = [x for x, _ in stats]
+        out["by_threads"][str(T)] = {"ms_per_pass": dt * 1e3, "gbp_per_s": run.bases / dt / 1e9, "x8": 8 * run.bases / dt / 1e9,
+                                     "cpus_busy": (time.process_time() - cpu0) / (dt * passes),
+                                     "host_stage_ms_per_pass": float(np.sum([x["encode_ms"] for x in st])) / passes,
+                                     "copy_in_ms_per_pass": float(np.sum([x["h2d_ms"] for x in st])) / passes}
+    rep = run.staged_replay(passes=passes)
+    out["staged_replay_ms_per_pass"] = rep["ms_per_pass"]
+    out["note"] = "x8 = what eight such ranks add up to when every rank has its own PCIe link AND its own T threads"
+    run.close()
+    ctx.close()
+    return out
 
 
 def _s2s(info):
@@ -1144,6 +1195,7 @@ def main():
     ap.add_argument("--no-mm-leg", action="store_true")
     ap.add_argument("--no-resident-leg", action="store_true")
     ap.add_argument("--no-c2-leg", action="store_true")
+    ap.add_argument("--no-rank-sweep", action="store_true", help="skip the threads-per-rank sweep (one shard of 8 with 2 / 4 / 8 / 16 stager threads)")
     ap.add_argument("--no-bam-leg", action="store_true", help="skip the BAM end-to-end legs (profile_bam, c5_bam, bam_sharded)")
     ap.add_argument("--only-mm", action="store_true", help="the mm-on legs alone (debug)")
     ap.add_argument("--only-c5", action="store_true", help="the headline alone: no C2 legs, no BAM legs, no CPU baselines (debug)")
@@ -1389,6 +1441,12 @@ def main():
                 legs["cpu_baseline_c2"] = cpu_baseline(w)
                 legs["cpu_baseline_python_c2"] = cpu_baseline_python(w)
             del w
+        if world == 1 and not args.only_c5 and not args.no_rank_sweep:
+            try:
+                legs["rank_threads_sweep"] = rank_threads_sweep(local, lut, fb, args.depth, args.scale)
+                out["rank_of_8_gbp_per_s_by_threads"] = {k: round(v["gbp_per_s"], 1) for k, v in legs["rank_threads_sweep"]["by_threads"].items()}
+            except Exception as e:                  # never lose the line over an extra leg
+                legs["rank_threads_sweep"] = {"error": repr(e)}
         if world == 1 and not args.no_bam_leg:
             for key, fn in (("profile_bam", lambda: profile_bam_leg(ctx, host_threads)), ("c5_bam", lambda: c5_bam_leg(ctx, host_threads, args.scale))):
                 try:

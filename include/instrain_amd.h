@@ -460,7 +460,7 @@ typedef struct {
 } isx_pipe_result;
 
 /* The level-sparse tables of a collected batch (isx_pipe_result.lev_*) as the four columns of isx_pipe_fetch_entries_shrunk: n_lev values
- * each in (gpos, mm) order -- gpos; mm_cov = mm << 24 | the level's coverage; clon; clon_rarefied (NaN = none).  Host work only (no GPU
+ * each in (gpos, mm) order -- gpos; mm_cov = mm << 24 | the level's coverage; clon; clon_rarefied (NaN = none; may be NULL when n_lev_rare == 0).  Host work only (no GPU
  * call), on host_threads threads.  ISX_ERR_CAPACITY when a level's coverage reaches 2^24; ISX_ERR_STATE when the result holds no such
  * tables or they are inconsistent. */
 int isx_levels_expand(const isx_pipe_result *r, int32_t host_threads, uint32_t *gpos, uint32_t *mm_cov, float *clon, float *clon_rarefied);

@@ -2022,6 +2022,8 @@ struct BamBatch {
     Batch S;
     uvec<uint8_t> emit;
     uvec<uint32_t> pid;              // dense pair id per read
+    uvec<uint8_t> pair_mm;           // mm profiling on: min(mm, 255) of the pairs [pair_mm_lo, ...) of the batch's references -- a 1-byte table the
+    size_t pair_mm_lo = 0;           // emission looks a read's level up in (the PairInfo table is 30 x larger: a cache miss a read)
     uvec<uint64_t> out_at;           // [n_reads + 1] first observation of every read
     std::vector<int64_t> boff;              // per reference of the file: offset in the batch's flat space, -1 = not in the batch
     int64_t n_pos = 0;
@@ -2132,7 +2134,7 @@ struct BamBatch {
         for (; done < count; ri++) {
             if (seg_at[ri + 1] == seg_at[ri]) continue;
             const Read &r = S.reads[ri];
-            const uint8_t m = prm.skip_mm ? (uint8_t)0 : (uint8_t)std::min<int32_t>(std::min<int32_t>(255, B->mm_cap), B->pairs[r.pair_idx].mm);
+            const uint8_t m = prm.skip_mm ? (uint8_t)0 : (uint8_t)std::min<int32_t>(std::min<int32_t>(255, B->mm_cap), (int32_t)pair_mm[(size_t)r.pair_idx - pair_mm_lo]);
             const uint32_t id = pid[ri];
             for_segments(ri, [&](int64_t g, int64_t q0, int64_t cols) {
                 if (skip > 0) { skip--; return; }
@@ -2160,7 +2162,7 @@ struct BamBatch {
             const Read &r = S.reads[ri];
             const uint32_t id = pid[ri];
             const bool mark = mm != nullptr && !prm.skip_mm;
-            const uint8_t m = mark ? (uint8_t)std::min<int32_t>(std::min<int32_t>(127, B->mm_cap), B->pairs[r.pair_idx].mm) : (uint8_t)0;
+            const uint8_t m = mark ? (uint8_t)std::min<int32_t>(std::min<int32_t>(127, B->mm_cap), (int32_t)pair_mm[(size_t)r.pair_idx - pair_mm_lo]) : (uint8_t)0;
             for_segments(ri, [&](int64_t g, int64_t q0, int64_t cols) {
                 if (skip > 0) { skip--; return; }
                 if (done >= count) return;
@@ -2442,11 +2444,17 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
         for (int32_t i = 0; i < n_refs; i++) { p_lo = std::min<size_t>(p_lo, (size_t)B.ref_pair0[(size_t)refs[i]]); p_hi = std::max<size_t>(p_hi, (size_t)B.ref_pair0[(size_t)refs[i] + 1]); }
         const size_t w_lo = p_lo >> 6, n_words = p_hi > p_lo ? ((p_hi + 63) >> 6) - w_lo : 0;
         const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() * 4, n_words / 4096 + 1));
+        const bool want_mm = !p->skip_mm;
+        if (want_mm) { Q->pair_mm_lo = w_lo * 64; Q->pair_mm.resize(n_words * 64 + 64); }
+        uint8_t *pmm = want_mm ? Q->pair_mm.data() : nullptr;
         pool.run(nt, [&](int t) {
             for (size_t wd = w_lo + n_words * (size_t)t / (size_t)nt; wd < w_lo + n_words * (size_t)(t + 1) / (size_t)nt; wd++) {
                 uint64_t m = 0;
                 const size_t i0 = wd * 64, i1 = std::min(n_pair_all, i0 + 64);
-                for (size_t i = i0; i < i1; i++) m |= (uint64_t)(B.pairs[i].pass && B.pairs[i].reads != 0) << (i - i0);
+                for (size_t i = i0; i < i1; i++) {
+                    m |= (uint64_t)(B.pairs[i].pass && B.pairs[i].reads != 0) << (i - i0);
+                    if (pmm) pmm[i - w_lo * 64] = (uint8_t)std::min<int32_t>(255, std::max<int32_t>(0, B.pairs[i].mm));
+                }
                 pass_bits[wd] = m;
             }
         });

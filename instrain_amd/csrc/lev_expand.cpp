@@ -42,7 +42,8 @@ void run_threads(int n_threads, int n_tasks, const F &fn)
 
 extern "C" int isx_levels_expand(const isx_pipe_result *r, int32_t host_threads, uint32_t *gpos, uint32_t *mm_cov, float *clon, float *clon_rarefied)
 {
-    if (!r || !gpos || !mm_cov || !clon || !clon_rarefied) { isx_set_error("isx_levels_expand: bad argument"); return ISX_ERR_ARG; }
+    // (clon_rarefied may be NULL when the result holds no rarefied clonality at all, n_lev_rare == 0: a column of NaNs less to write)
+    if (!r || !gpos || !mm_cov || !clon || (!clon_rarefied && r->n_lev_rare)) { isx_set_error("isx_levels_expand: bad argument"); return ISX_ERR_ARG; }
     if (!r->lev_mask || r->lev_window <= 0 || (r->n_lev && (!r->lev_cov || !r->lev_win_off))) {
         isx_set_error("isx_levels_expand: the result holds no level-sparse tables (n_mm_bins in 2..32, read-level pipe without want_counts)");
         return ISX_ERR_STATE;
@@ -105,7 +106,7 @@ extern "C" int isx_levels_expand(const isx_pipe_result *r, int32_t host_threads,
                     gpos[o] = (uint32_t)p;
                     mm_cov[o] = ((uint32_t)lvl << 24) | (cov & 0xFFFFFFu);
                     clon[o] = (int64_t)cum >= min_cov ? 1.0f : nanf_;
-                    clon_rarefied[o] = nanf_;
+                    if (clon_rarefied) clon_rarefied[o] = nanf_;
                     o++; d++;
                 }
             }

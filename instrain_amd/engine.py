@@ -564,8 +564,10 @@ class Pipe:
         if isinstance(r, dict):
             r = r["_result"]
         n = max(1, int(r.n_lev))
-        cols = (np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.float32), np.empty(n, np.float32))
-        check(self.lib.isx_levels_expand(C.byref(r), int(threads) or min(16, len(os.sched_getaffinity(0))), *(c.ctypes.data for c in cols)))
+        cols = [np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.float32), np.empty(n, np.float32) if r.n_lev_rare else None]
+        check(self.lib.isx_levels_expand(C.byref(r), int(threads) or min(16, len(os.sched_getaffinity(0))), *(c.ctypes.data if c is not None else None for c in cols)))
+        if cols[3] is None:                     # no level reaches the rarefied coverage: one NaN, broadcast (read-only; nobody writes the columns)
+            cols[3] = np.broadcast_to(np.float32(np.nan), (n,))
         return tuple(c[:int(r.n_lev)] for c in cols)
 
     def release(self, ticket):

@@ -3,7 +3,7 @@
 #   tools/make_profiles.sh <tag>      -> gpurun_out/<tag>/{bench.json, bench_detail.json, trace_*, pmc_*, sq*}
 # Summaries are made afterwards with tools/write_profiles.py <tag> and committed under profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT

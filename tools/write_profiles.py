@@ -19,14 +19,16 @@ commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD']).decode
 sha = hashlib.sha1(open('instrain_amd/csrc/isx_pileup.hip', 'rb').read()).hexdigest()[:16]
 
 K = {"delta": r'k_pileup_dense<false, 32, true>', "delta_u32": r'k_pileup_dense<false, 32, false>', "seg64": r'k_pileup_dense<false, 64, false>',
-     "obs": r'k_pileup_dense<false, 2, true>', "mm_reads": r'k_pileup_mm<\w+, \w+, \w+, true>', "mm_obs": r'k_pileup_mm<\w+, \w+, \w+, false>',
+     "obs": r'k_pileup_dense<false, 2, true>', "mm_reads": r'k_pileup_mm<\w+, \w+, \w+, true, \w+, false>', "mm_delta": r'k_pileup_mm<\w+, \w+, \w+, true, \w+, true>',
+     "mm_obs": r'k_pileup_mm<\w+, \w+, \w+, false',
      "c5": r'k_pileup_dense<true, 32, true>'}
 LABEL = {"delta": "k_pileup_dense<false, 32, true> -- C2 as 32-byte reference-delta records, 16-bit LDS rows (production)",
          "delta_u32": "k_pileup_dense<false, 32, false> -- the same records, 32-bit LDS rows (very deep batches)",
          "seg64": "k_pileup_dense<false, 64, false> -- C2 as 64-byte segment records (round 3)",
          "obs": "k_pileup_dense<false, 2, true> -- C2 as 2-byte observation records (round 2)",
          "mm_reads": "k_pileup_mm<..., SEGS> -- C2 as segment records, mm profiling on", "mm_obs": "k_pileup_mm -- C2 as 4-byte observation records, mm on",
-         "c5": "k_pileup_dense<true, 32, true> -- one C5 batch (80 Mbp, linkage on) in a pipe slot (shrunk output)"}
+         "mm_delta": "k_pileup_mm<..., SEGS, ., DREC> -- C2 as reference-delta records with the mm level in the header (round 6), mm profiling on",
+         "c5": "k_pileup_dense<true, 32, true> -- one C5 batch of the headline's average size (linkage on) in a pipe slot (shrunk output)"}
 
 
 def summ(*dirs):
@@ -91,7 +93,8 @@ tr["c5"] = traffic(cf5, cw5, K["c5"])
 w = None
 alg = {"delta": rc2.get("algorithmic_bytes_per_launch"), "obs": detail.get("roofline_observation_kernel", {}).get("algorithmic_bytes_per_launch"),
        "mm_reads": detail.get("mm_on", {}).get("reads", {}).get("roofline", {}).get("algorithmic_bytes_per_launch"),
-       "mm_obs": detail.get("mm_on", {}).get("observations", {}).get("roofline", {}).get("algorithmic_bytes_per_launch")}
+       "mm_obs": detail.get("mm_on", {}).get("observations", {}).get("roofline", {}).get("algorithmic_bytes_per_launch"),
+       "mm_delta": detail.get("mm_on", {}).get("reads_delta_records", {}).get("roofline", {}).get("algorithmic_bytes_per_launch")}
 c5log = open(R + '/pmc_fetch_c5.log').read()
 lines = []
 for k in K:
@@ -111,7 +114,7 @@ The C5 batch of the `--c5` pass: {[l for l in c5log.splitlines() if l.startswith
 ''' + "\n".join(lines) + "\n\n" + summ(R + '/pmc_fetch', R + '/pmc_write') + "\n" + summ(R + '/pmc_fetch_c5', R + '/pmc_write_c5'))
 tot = lambda k: int(tr[k][0] + tr[k][1]) if tr[k][0] == tr[k][0] else None
 json.dump({"c2_reads_bytes_per_launch": tot("delta"), "c2_delta_u32_bytes_per_launch": tot("delta_u32"), "c2_seg64_bytes_per_launch": tot("seg64"),
-           "c2_pileup_bytes_per_launch": tot("obs"), "c2_mm_reads_bytes_per_launch": tot("mm_reads"), "c2_mm_pileup_bytes_per_launch": tot("mm_obs"),
+           "c2_pileup_bytes_per_launch": tot("obs"), "c2_mm_reads_bytes_per_launch": tot("mm_reads"), "c2_mm_pileup_bytes_per_launch": tot("mm_obs"), "c2_mm_delta_bytes_per_launch": tot("mm_delta"),
            "c5_dense_linkage_bytes_per_launch": tot("c5"),
            "fetch_size_kib": {k: v[2] for k, v in tr.items()}, "write_size_kib": {k: v[3] for k, v in tr.items()},
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/pmc_target.py [--c5] (profiles/%s_c2_pmc.md); FETCH_SIZE doubled per the "
