@@ -570,6 +570,11 @@ class Pipe:
             cols[3] = np.broadcast_to(np.float32(np.nan), (n,))
         return tuple(c[:int(r.n_lev)] for c in cols)
 
+    def levels_copy(self, r):
+        """The level-sparse tables of a collected batch (collect()'s dict with densify=False) copied out of the slot's result block:
+        a LevelTables that outlives release() and makes the four columns when somebody asks (LevelTables.columns())."""
+        return LevelTables(self.lib, r["_result"] if isinstance(r, dict) else r)
+
     def release(self, ticket):
         try:
             check(self.lib.isx_pipe_release(self.h, int(ticket)))
@@ -590,6 +595,65 @@ class Pipe:
             self.close()
         except Exception:
             pass
+
+
+_COPY_POOL = None
+
+
+def _par_copy(a):
+    """a.copy() on a few threads for the large ones (numpy's copy releases the GIL; one thread moves ~6 GB/s out of pinned memory)"""
+    global _COPY_POOL
+    if a.nbytes < (8 << 20):
+        return a.copy()
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(6)
+    out = np.empty_like(a)
+    n = len(a)
+    step = -(-n // 12)
+    list(_COPY_POOL.map(lambda k: np.copyto(out[k:k + step], a[k:k + step]), range(0, n, step)))
+    return out
+
+
+class LevelTables:
+    """Own copies of a batch's level-sparse tables (isx_pipe_result.lev_*: mask per position, one coverage element per present level, the
+    windows' first level indices, the lists) -- 1-3 bytes a level.  columns() expands them to gpos | mm << 24 | coverage | clon |
+    clon_rarefied in (gpos, mm) order (isx_levels_expand, host work) the first time it is called and keeps the result."""
+
+    def __init__(self, lib, r):
+        self.lib = lib
+        n_pos, n_lev, n_win = int(r.n_pos), int(r.n_lev), int(r.n_lev_windows)
+
+        def own(addr, dtype, n):
+            if not n or not addr:
+                return np.empty(0, dtype=dtype)
+            return _par_copy(np.frombuffer((C.c_uint8 * (n * np.dtype(dtype).itemsize)).from_address(addr), dtype=dtype))
+
+        self.mask = own(r.lev_mask, {1: np.uint8, 2: np.uint16, 4: np.uint32}[int(r.lev_mask_bytes)], n_pos)
+        self.cov = own(r.lev_cov, np.uint8 if r.lev_cov_bytes == 1 else np.uint16, n_lev)
+        self.win_off = own(r.lev_win_off, np.uint32, n_win)
+        self.clon = own(r.lev_clon, _lib.RARE_DT, int(r.n_lev_clon))
+        self.rare = own(r.lev_rare, _lib.RARE_DT, int(r.n_lev_rare))
+        self.sat = own(r.lev_sat, _lib.SAT_DT, int(r.n_lev_sat))
+        q = _lib.PipeResult()
+        q.n_pos, q.n_lev, q.n_lev_clon, q.n_lev_rare, q.n_lev_sat = n_pos, n_lev, len(self.clon), len(self.rare), len(self.sat)
+        q.lev_mask_bytes, q.lev_cov_bytes, q.lev_window, q.n_lev_windows, q.lev_min_cov = r.lev_mask_bytes, r.lev_cov_bytes, r.lev_window, r.n_lev_windows, r.lev_min_cov
+        ptr = lambda a: a.ctypes.data if len(a) else None
+        q.lev_mask, q.lev_cov, q.lev_win_off = ptr(self.mask), ptr(self.cov) or ptr(self.win_off), ptr(self.win_off)
+        q.lev_clon, q.lev_rare, q.lev_sat = ptr(self.clon), ptr(self.rare), ptr(self.sat)
+        self._r = q
+        self._cols = None
+        self.n = n_lev
+
+    def columns(self, threads=0):
+        if self._cols is None:
+            n = max(1, self.n)
+            cols = [np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.float32), np.empty(n, np.float32) if len(self.rare) else None]
+            check(self.lib.isx_levels_expand(C.byref(self._r), int(threads) or min(16, len(os.sched_getaffinity(0))), *(c.ctypes.data if c is not None else None for c in cols)))
+            if cols[3] is None:
+                cols[3] = np.broadcast_to(np.float32(np.nan), (n,))
+            self._cols = tuple(c[:self.n] for c in cols)
+        return self._cols
 
 
 class Wire:

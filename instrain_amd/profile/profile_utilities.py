@@ -97,14 +97,15 @@ class _BatchTables:
         self.snv, self.ld = _own(res["snv"]), _own(res["ld"])
         self.s_cut = _cuts(self.snv["gpos"], self.bounds)
         self.l_cut = _cuts(self.ld["gpos_a"], self.bounds)
-        self.soa = self.entries = None
-        if "entries_soa" in res:                    # mm profiling on, shrunk hand-back: columns gpos | mm << 24 | cov | clon | clon_rarefied
-            self.soa = res["entries_soa"]
-            self.e_cut = _cuts(self.soa[0], self.bounds)
+        self._soa = self.entries = self._lev = self._e_cut = None
+        if "level_tables" in res:                   # mm profiling on, level-sparse hand-back (round 6): own copies of the level tables, 1-3 bytes a
+            self._lev = res["level_tables"]         # level; the columns below are made from them the first time a split's tables are read
+        elif "entries_soa" in res:                  # mm profiling on, shrunk hand-back: columns gpos | mm << 24 | cov | clon | clon_rarefied
+            self._soa = res["entries_soa"]
         elif "entries" in res:                      # mm profiling on: (position, mm) entries
             self.entries = res["entries"]
-            self.e_cut = _cuts(self.entries["gpos"], self.bounds)
-        if self.soa is None and self.entries is None:       # one mm bin: coverage per position, clonality, sparse clonTR
+            self._e_cut = _cuts(self.entries["gpos"], self.bounds)
+        if self._soa is None and self._lev is None and self.entries is None:       # one mm bin: coverage per position, clonality, sparse clonTR
             if "counts" in res:
                 self.cov = res["counts"].sum(axis=1, dtype=np.int64)
             else:                                   # the shrunk hand-back: 16- or 8-bit coverage + the exact values beyond
@@ -128,7 +129,7 @@ class _BatchTables:
                 self.r_cut = np.searchsorted(self.rare_pos, self.bounds)
             else:                                   # a deep sample: the dense array, cut per split when somebody asks
                 self.clon_r = _own(res["clon_r"])
-        self.pileup_counts = _own(res["counts"]) if "counts" in res and self.entries is None and self.soa is None else None
+        self.pileup_counts = _own(res["counts"]) if "counts" in res and self.entries is None and self._soa is None and self._lev is None else None
         if self.pileup_counts is None and self.entries is not None and res.get("allele_obs") is not None:
             # --store_everything with mm profiling on: pileup_counts[pos] = the counts over ALL mm levels (profile_utilities.py:257-259)
             pc = np.zeros((int(self.bounds[-1]), 4), dtype=np.int64)
@@ -141,6 +142,19 @@ class _BatchTables:
             from . import linkage
             self.ao = linkage.SortedAlleleObs(self.ao)
         self.pair_names = res.get("pair_names")
+
+    @property
+    def soa(self):
+        if self._soa is None and self._lev is not None:
+            self._soa = self._lev.columns()
+            self._lev = None
+        return self._soa
+
+    @property
+    def e_cut(self):
+        if self._e_cut is None:
+            self._e_cut = _cuts(self.soa[0], self.bounds)
+        return self._e_cut
 
     # -- shrink_basewise (profile_utilities.py:337-350): dict mm -> sparse Series; a level that occurs in the split keeps
     #    its key even when its Series is empty (the reference deletes nothing but zeros / NaNs) --
@@ -861,8 +875,8 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             try:
                 res = pipe.collect(t, rare_list=False, densify=False, shrunk_entries=not store_everything)
                 stage("collect_wait_ms")
-                if "_result" in res:                # mm profiling on: the level-sparse tables -> the columns the splits' covT / clonT / clonTR are cut from
-                    res["entries_soa"] = pipe.expand_levels(res)
+                if "_result" in res:                # mm profiling on: own copies of the level-sparse tables (1-3 bytes a level); the columns the
+                    res["level_tables"] = pipe.levels_copy(res)      # splits' covT / clonT / clonTR are cut from are made on first access
                 if store_everything:                # read_to_snvs / mm_to_position_graph of the splits are made from these
                     res["allele_obs"] = res["slot"].fetch_allele_obs()
                     res["pair_names"] = getattr(g, 'pair_names', None)

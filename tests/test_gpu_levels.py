@@ -134,7 +134,7 @@ def test_level_tables_of_a_stream(ctx):
             expect.append(b.fetch()["entries"])
             b.close()
         order = list(range(len(use))) + list(range(len(use)))[::-1]          # every batch twice, the slots reused with other batches
-        tickets, done = [], 0
+        tickets, done, kept = [], 0, []
 
         def take():
             nonlocal done
@@ -147,7 +147,9 @@ def test_level_tables_of_a_stream(ctx):
             if use[k] is ws[1]:
                 assert int(expect[k]["cnt"].sum(axis=1).max()) > 400 and len(lev["sat"]) > 10 and lev["cov"].dtype == np.uint8
             assert 50 < len(lev["clon"]) < len(soa[0]) // 4
+            own = pipe.levels_copy(r)               # own copies of the level tables (what profile_bam keeps of a batch) ...
             pipe.release(tickets[done])
+            kept.append((k, own))                   # ... expanded after the slot has been given back and reused
             done += 1
 
         for k in order:
@@ -157,6 +159,9 @@ def test_level_tables_of_a_stream(ctx):
         while done < len(tickets):
             take()
         pipe.close()
+        for k, own in kept:
+            same_soa(own.columns(threads=2), soa_of_entries(expect[k]), "kept level tables M=%d batch %d" % (M, k))
+            assert own.columns() is own.columns()
 
 
 def test_deep_batch_two_byte_coverage(ctx):

@@ -15,7 +15,7 @@ lut, fb = util.load_lut()
 ctx.set_null_model(lut, fb)
 w = bench.c2_workload(2, with_mm=True)
 M = w["n_mm_bins_mm"]
-for layout in (0, 8):
+for layout in (0, 32):
     for window in [int(x) for x in os.environ.get("WINDOWS", "0,256,384,448,512,640,704,1024,1408,1728,2048").split(",")]:
         try:
             b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["segs_mm"], None, n_mm_bins=M, enable_linkage=False, layout=layout, window=window)

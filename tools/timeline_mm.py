@@ -2,7 +2,7 @@
 """Per-phase timeline of ONE workgroup of k_pileup_mm on the C2 batch with mm profiling on (tuning build, debug bit 4096: wall_clock64
 stamps of workgroup 0 after each barrier of its first 32 windows).
     tools/build_tuning.sh && ISX_LIB=instrain_amd/libinstrain_amd_tuning.so python tools/timeline_mm.py
-LAYOUT=8: the 64-byte segment records instead of reference-delta records; SPARSE=1: through a pipe slot (level-sparse tables)."""
+LAYOUT=32: reference-delta records with the mm level in the header (ISX_LAYOUT_MM_DELTA_RECORDS) instead of the 64-byte segment records; SPARSE=1: through a pipe slot (level-sparse tables), LEAN=0: a plain slot (entries kept)."""
 import ctypes
 import os
 import sys
