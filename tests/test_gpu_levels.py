@@ -182,3 +182,31 @@ def test_deep_batch_two_byte_coverage(ctx):
         same_soa(soa, soa_of_entries(exp["entries"]), "deep lean=%s" % lean)
         assert np.isfinite(soa[3]).sum() > len(soa[0]) // 2            # most levels carry a rarefied clonality here: the list outgrows its pinned room
         assert snv.tobytes() == exp["snv"].tobytes() and ld.tobytes() == exp["ld"].tobytes()
+
+
+def test_lists_that_outgrow_their_tables_repeat_the_pass(ctx):
+    """a small deep batch whose reads disagree with the reference at 3 % of their bases: nearly every level above the first sees more than
+    one base, so the list of clonalities that are not 1.0 (and, at rarefied_coverage 20, the clonTR list) is longer than the slot's device
+    table was sized for (cap_pos / 4 + 65 536) -- the finisher sees it from the cursors, grows the tables and repeats the pass; the level
+    tables still equal the one-shot batch's entries, in the slot's next batch too"""
+    from instrain_amd import engine, synth
+    w = synth.make_workload(genome_len=40_000, coverage=400, n_sites=200, err=0.03, seed=91, skip_mm=False, max_mm=30)
+    segs = synth.segs_from_obs(w["obs"], w["pair"])
+    M = w["n_mm_bins"]
+    kw = dict(enable_linkage=False, rarefied_coverage=20, seed=4)
+    b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], segs, None, n_mm_bins=M, **kw)
+    b.run()
+    exp = b.fetch()["entries"]
+    b.close()
+    want = soa_of_entries(exp)
+    n_mixed = int((np.isfinite(exp["clon"]) & (exp["clon"] != 1.0)).sum())
+    assert n_mixed > 40_000 // 4 + 65_536 + 10_000, n_mixed            # more than the slot's first table holds
+    pipe = engine.Pipe(ctx, max_pos=w["n_pos"], max_obs=0, max_segs=segs.n_seg, max_splits=len(w["split_bounds"]), depth=1, host_threads=3,
+                       pin_threads=False, n_mm_bins=M, lean_output=True, **kw)
+    for rnd in range(2):
+        t = pipe.submit_reads(w["ref_codes"], w["split_bounds"], segs)
+        r = pipe.collect(t, shrunk_entries=True, densify=False)
+        assert len(r["levels"]["clon"]) == n_mixed
+        same_soa(pipe.expand_levels(r), want, "overflowing lists, round %d" % rnd)
+        pipe.release(t)
+    pipe.close()
