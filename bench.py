@@ -545,7 +545,8 @@ class C5Run:
         ws = self.ws
         return engine.Pipe(self.ctx, max_pos=max(w["n_pos"] for w in ws), max_obs=0, max_segs=max(w["n_seg"] for w in ws),
                            max_splits=max(len(w["split_bounds"]) for w in ws), depth=self.depth, host_threads=host_threads,
-                           pin_threads=bool(os.environ.get("ISX_BENCH_PIN")), n_mm_bins=1, enable_linkage=C5_LINKAGE, min_snp=20, stage_async=self.stage_async, lean_output=LEAN_SLOTS)
+                           pin_threads=bool(os.environ.get("ISX_BENCH_PIN")), n_mm_bins=1, enable_linkage=C5_LINKAGE, min_snp=20, stage_async=self.stage_async, lean_output=LEAN_SLOTS,
+                           layout=int(os.environ.get("ISX_BENCH_LAYOUT", "0")))     # (A/B: 64 = ISX_LAYOUT_NO_STRIPES)
 
     def stage_all(self):
         """every batch staged once into a pinned image (isx_pipe_stage_planes): what round 4's headline replayed.  An extra of the line

@@ -103,6 +103,10 @@ typedef struct {
                                          * no faster -- the per-level prefix sums and the wider LDS rows eat what the shorter stream saves -- and
                                          * the host stager of isx_segs input costs twice the segment records': opt-in, not the default */
 
+#define ISX_LAYOUT_NO_STRIPES 64         /* one-mm-bin reference-delta batches without a count table (pipe slots): the round-4 epilogue -- every position
+                                         * gets the reference base's count and walks the first epilogue pass -- instead of the stripe path (a thread owns
+                                         * eight positions, coverage straight from the difference row, only positions at min_cov go on) */
+
 /* (position, mm)-present entry: one per mm level present at a position, ascending mm.
  * 32 bytes (two aligned 16-byte device stores).  cnt = counts of THIS level; covT[mm][pos] = sum(cnt);
  * clon = clonT[mm][pos] (float32 of the cumulative-<=mm clonality) or NaN when cumulative coverage

@@ -1258,6 +1258,10 @@ int launch_pass(isx_batch *b)
         if (!b->rare_dense && a.rare) a.clon_r = nullptr;
         if (a.cov8) a.cov16 = nullptr;
     }
+#ifdef ISX_TUNING
+    if (getenv("ISX_NO_COUNTS")) { a.counts = nullptr; if (atoi(getenv("ISX_NO_COUNTS")) > 1) a.clon = nullptr; }      // tuning builds only (tools/timeline.py): a resident batch run like a pipe slot
+#endif
+    a.stripe = (b->drec && b->packed && b->M == 1 && !a.counts && !(b->prm.layout & ISX_LAYOUT_NO_STRIPES)) ? 1 : 0;
     a.seed_lo = (uint32_t)b->prm.seed; a.seed_hi = (uint32_t)(b->prm.seed >> 32);
     a.entries = b->d_entries; a.slab = b->slab; a.cap_ovf = (uint32_t)b->cap_ovf;
     a.ovf0 = (uint64_t)b->n_win * b->slab; a.win_nent = b->d_win_nent;

@@ -198,6 +198,7 @@ struct PileupArgs {
     int32_t rqcap;              // mm path: row-queue capacity (positions with SNV rows per window)
     int32_t stage_off;          // allele pass: LDS word offset of the per-wave hit stage (0 = aliases the counters)
     int32_t dlt_off;            // reference-delta stream: LDS word offset of the coverage-difference row (pileup_lds_bytes)
+    int32_t stripe;             // reference-delta stream, packed rows, no count table: the stripe path of k_pileup_dense (ISX_LAYOUT_NO_STRIPES switches it off)
     int32_t pad, lm;            // dense path: counter row stride = W + pad words, position 0 of the window at column lm
     double min_freq;
     // outputs

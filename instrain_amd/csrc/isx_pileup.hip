@@ -49,6 +49,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // scratch words (LDS)
 enum { S_NQ = 0, S_ROWS, S_SITES, S_ROW_BASE, S_SITE_BASE, S_ROW_RANK, S_NAO, S_AO_BASE, S_ENT_TOT, S_ENT_BASE, S_SLEV, S_SLEV_BASE, S_NRARE, S_RARE_BASE, S_RARE_RANK,
        S_NCLON, S_CLON_BASE, S_CLON_RANK, S_COVX, S_COVX_BASE, S_N = 20 };
+#define S_RNG 128           // k_pileup_dense: behind the scratch words, the record ranges of the workgroup's next 64 windows (64 x uint2)
 
 // table cursors run on across launches; a run's slots are relative to the values it started from
 __device__ __forceinline__ uint32_t cur_add(const PileupArgs &a, int which, uint32_t n)
@@ -631,8 +632,9 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
     uint32_t *cnt = lds + (SEGS ? ISX_SEG_LM : 0);              // segments: ISX_SEG_LM margin columns on either side of the window
     uint32_t *queue = lds + NR * S;
     uint32_t *scratch = queue + S;
-    uint16_t *thr_lds = reinterpret_cast<uint16_t *>(scratch + S_N);
-    uint32_t *slabc = scratch + S_N + THR_LDS / 2;
+    uint2 *rngl = reinterpret_cast<uint2 *>(scratch + S_N);
+    uint16_t *thr_lds = reinterpret_cast<uint16_t *>(scratch + S_N + S_RNG);
+    uint32_t *slabc = scratch + S_N + S_RNG + THR_LDS / 2;
     uint8_t *maskl = reinterpret_cast<uint8_t *>(slabc + W);
     // DREC: two more rows -- the coverage differences (+1 where a record starts, -1 behind its end) and, in the queue's row (idle
     // until the epilogue), the skipped columns; the counter rows hold the EXCEPTIONS until the materialise phase
@@ -655,6 +657,7 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
     const u32x4 *rec4 = reinterpret_cast<const u32x4 *>(SEGS ? (const void *)a.seg : (DREC ? (const void *)a.drec : (FMT == 2 ? (const void *)a.rec16 : (FMT == 4 ? (const void *)a.rec32 : (const void *)a.rec))));
     constexpr int RSH = FMT == 2 ? 3 : (FMT == 4 ? 2 : 1);         // record index -> 16-byte load index (segments: a record is FOUR loads)
     const int dbg = a.debug_mode;               // ablation switches (tools/), 0 in production
+    const bool stripe_k = PKL && a.stripe != 0; // packed rows without a count table: materialise + first epilogue pass by stripes (below), window by window
 
     {   // once per workgroup: folded thresholds of the low coverages
         const int n = min(THR_LDS, a.lut_n);
@@ -702,6 +705,7 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
     };
     if (slot < a.n_win) rng_next = a.win_range[slot];
     prefetch_window(slot);
+    int win_it = 0;                             // this workgroup's windows so far
 
 #ifdef ISX_TUNING
     int ts_w = -1;
@@ -709,12 +713,22 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
     for (int w = slot; w < a.n_win; w += grid) {
         const uint32_t w0 = (uint32_t)w * (uint32_t)W;
         const uint32_t cur_lo = lo, cur_hi = hi;
+        // the stripe path pays where many positions stay below min_cov; in a deep window every position goes on, the compaction is wasted and
+        // the loops behind it walk a full queue for its few flagged entries (resident C2, depth 18: 68 us against 59).  A window that streams
+        // more than W / 16 records (mean depth beyond ~8 at 135 kept bases a record) takes the per-position epilogue
+        const bool stripe = stripe_k && (cur_hi - cur_lo) * 8u <= (uint32_t)W;
 #ifdef ISX_TUNING
         ++ts_w;
 #endif
         ISX_TS(0);
         ISX_ARGS_FRESH();
-        if (w + grid < a.n_win) rng_next = a.win_range[w + grid];
+        // the record ranges of the workgroup's next 64 windows wait in LDS (filled here every 64th window; visible behind the barrier
+        // below, read at the window's end): loaded window by window, the value -- wanted in scalar registers, which the compiler has none
+        // to spare for -- was waited for on the spot, a memory round trip at the top of every window
+        if ((win_it & 63) == 0 && tid < 64) {
+            const int wn = w + (tid + 1) * grid;
+            rngl[tid] = wn < a.n_win ? a.win_range[wn] : make_uint2(0, 0);
+        }
         const uint32_t dummy = 4u * (uint32_t)S + (uint32_t)(tid & 63);     // see the stream loop
 #ifdef ISX_TUNING
         uint32_t ablate_acc = 0;
@@ -944,9 +958,9 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
 
         // first loads of the NEXT window go out before the epilogue (with linkage the registers
         // are needed by the allele pass first, so the prefetch follows it)
-        if (!linkage) prefetch_window(w + grid);
+        if (!linkage) { rng_next = rngl[win_it & 63]; prefetch_window(w + grid); }
 
-        if (PKL && !(dbg & 16)) {
+        if (PKL && !stripe && !(dbg & 16)) {
             // ---- materialise, packed rows: a thread owns PT consecutive positions (PT odd: a wave's 64 lanes then hit 64 different
             //      LDS banks at every step) ----
             const int lane = tid & 63;
@@ -959,13 +973,13 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
             ISX_TS(3);
             int32_t run = inc - sum;
             for (int k = 0; k < (tid >> 6); k++) run += (int32_t)wtot[k];
-            bool beyond15 = false;                  // (4-bit coverage plane: does the window need its 16-bit row?  reads covering a position
-            for (int k = 0; k < PT; k++) {          //  bound its coverage from above)
+            bool beyond15 = false;                  // (4-bit coverage plane: does the window need its 16-bit row?)
+            for (int k = 0; k < PT; k++) {
                 const int p = p0 + k;
                 if (p >= W) break;
                 const uint32_t x = dlt[p], a01 = cnt[p], a23 = cnt[S + p];
                 run += (int32_t)x >> 16;
-                beyond15 |= run > 15;
+                beyond15 |= run - (int32_t)(x & 0xFFFFu) > 15;        // (what is observed: covered minus skipped)
                 const uint32_t r = refl[p];
                 if (r < 4u) {
                     const uint32_t v = (uint32_t)run - (x & 0xFFFFu) - ((a01 & 0xFFFFu) + (a01 >> 16) + (a23 & 0xFFFFu) + (a23 >> 16));
@@ -1014,6 +1028,204 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
         }
 
         // ---- epilogue pass 1: integer only (update_snp_table, single mm level) ----
+        // what a position that reaches min_cov (or rarefied_coverage) needs: the SNV call, its clonality class, its table slots.  `qi` < 0: the
+        // position joins the queue if anything is left to do for it; else it IS queue entry qi (the stripe path) and its entry is rewritten in place
+        // stripe path: its queue holds EVERY position that reaches min_cov, and few of them have anything left to do after the first pass
+        // (a clonality to divide, a row, a clonTR value).  Their queue indices are listed in the free top of the queue row (a shallow
+        // window's queue is short: room for 1024 two-byte indices) so that the loops below run over them densely instead of having every
+        // wave walk the whole queue for a lane or two; a deep window -- no room, or more than 1024 -- walks the queue as before
+        uint16_t *const flist = reinterpret_cast<uint16_t *>(queue + S - 512);
+        bool use_fl = false;
+        auto site_pass1 = [&](int p, uint32_t gpos, const uint32_t *c, uint32_t total, int ref_base, int qi, bool st_ok, bool call_ok) {
+            float cl = __builtin_nanf("");
+            bool defer = false;
+            uint32_t entry = (uint32_t)p;
+            if ((int64_t)total >= (int64_t)a.min_cov && call_ok) {
+#ifdef ISX_TUNING
+                const SiteCall sc = (dbg & 1024) ? SiteCall{-1, 1, 0, 0} : call_level(a, thr_lds, c, total, ref_base, false);    // 1024: no SNV call
+                const uint32_t mx = (dbg & 2048) ? total : max(max(c[0], c[1]), max(c[2], c[3]));                               // 2048: every clonality 1.0
+#else
+                const SiteCall sc = call_level(a, thr_lds, c, total, ref_base, false);
+                const uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
+#endif
+                if (mx == total) cl = 1.0f; else defer = true;
+                if (defer) entry |= 1u << 13;
+                if (a.clon_list && defer) atomicAdd(&scratch[S_NCLON], 1u);     // the list of clonalities other than 1.0: written below, once the window has its slots
+                if (sc.snp != -1) {
+                    entry |= 1u << 14;
+                    atomicAdd(&scratch[S_ROWS], 1u);
+                    if (sc.morphia >= 2) {
+                        const uint32_t mask = (1u << sc.snp) | (1u << sc.var);
+                        entry |= (atomicAdd(&scratch[S_SITES], 1u) + 1u) << 17;
+                        if (linkage) {
+                            maskl[p] = (uint8_t)mask;
+                            slabc[p] = atomicAdd(&scratch[S_NAO], masked_sum(c, mask));
+                        }
+                    }
+                }
+            }
+            // clonTR is gated on rarefied_coverage alone (snv_utilities.py:100-102), also below min_cov
+            if (a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r) { entry |= 1u << 15; if (a.rare) atomicAdd(&scratch[S_NRARE], 1u); }
+            if (qi >= 0) {
+                queue[qi] = entry;
+                if (use_fl && entry != (uint32_t)p) {
+                    const uint32_t k = atomicAdd(&scratch[S_ENT_TOT], 1u);      // (S_ENT_TOT: a word of the mm kernel, free here)
+                    if (k < 1024u) flist[k] = (uint16_t)qi;
+                }
+            }
+            else if (entry != (uint32_t)p) queue[atomicAdd(&scratch[S_NQ], 1u)] = entry;
+            if (!defer && st_ok && a.clon) a.clon[gpos] = cl;      // (a lean slot keeps no dense clonality array)
+        };
+        uint32_t tot_pk[4] = {0, 0, 0, 0};      // stripe path: this thread's eight coverages, 16 bits each (kept for the window's 16-bit row)
+        if (PKL && stripe) {
+            // ---- stripe path (round 6; packed rows, no count table wanted): materialise and first epilogue pass in one ----
+            // A thread owns EIGHT consecutive positions.  Their coverage is the prefix sum of the difference row minus the skipped columns -- it
+            // needs neither the exception counters nor the reference -- and coverage is all a position below min_cov (and rarefied_coverage)
+            // hands back: the 4-bit plane leaves as one 32-bit word a thread (cov16: one 16-byte store, cov8: 8 bytes), and only the positions
+            // that do reach min_cov are COMPACTED into the queue (wave prefix sum of their number, one LDS atomic a wave) and get the reference
+            // base's count, the SNV call and the rest from a second pass with every lane busy.  At metagenome depth (70 % of a C5 batch's
+            // positions lie below min_cov) that pass runs over a third of the window.  (profile_utilities.py:288-295, snv_utilities.py:85-104)
+            const int lane = tid & 63;
+            const int p0 = tid * 8;
+            const bool act = p0 < W;
+            uint32_t x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int32_t sum = 0;
+            if (act) {
+                const uint4 xa = *reinterpret_cast<const uint4 *>(dlt + p0), xb = *reinterpret_cast<const uint4 *>(dlt + p0 + 4);
+                x[0] = xa.x; x[1] = xa.y; x[2] = xa.z; x[3] = xa.w; x[4] = xb.x; x[5] = xb.y; x[6] = xb.z; x[7] = xb.w;
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum += (int32_t)x[k] >> 16;
+            }
+            const int32_t inc = (int32_t)wave_scan_incl((uint32_t)sum);
+            if (lane == 63) wtot[tid >> 6] = (uint32_t)inc;
+            __syncthreads();                    // (from here on nobody reads the difference row: it becomes the queue)
+            ISX_TS(3);
+            // (branch-free on purpose: written with a test per position the compiler made sixteen branches of it, each re-reading n_pos from
+            //  the kernarg segment.  The arguments this phase needs are read once.)
+            const uint32_t n_pos = a.n_pos, sat_thr = a.sat_thr;
+            const int32_t need = a.min_cov_r > 0 ? min(a.min_cov, a.min_cov_r) : a.min_cov;
+            // what the waves before this one add up to: every lane reads one of the sixteen totals, a prefix sum inside each row of 16 lanes
+            uint32_t wv = wtot[lane & 15];
+            wv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wv, 0x111, 0xF, 0xF, false);      // row_shr:1
+            wv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wv, 0x112, 0xF, 0xF, false);      // row_shr:2
+            wv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wv, 0x114, 0xF, 0xF, false);      // row_shr:4
+            wv += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wv, 0x118, 0xF, 0xF, false);      // row_shr:8
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            int32_t run = inc - sum + (wave ? __builtin_amdgcn_readlane((int)wv, wave - 1) : 0);
+            const uint32_t g0 = w0 + (uint32_t)p0;
+            const uint32_t nv = (act && g0 < n_pos) ? min(n_pos - g0, 8u) : 0u;        // positions of this stripe that exist (8 but for the batch's last stripe and the lanes beyond the window)
+            uint32_t tot[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                run += (int32_t)x[k] >> 16;
+                tot[k] = (uint32_t)run - (x[k] & 0xFFFFu);
+            }
+            if (nv < 8u) {                      // (a position that does not exist never goes on, whatever min_cov is)
+#pragma unroll
+                for (int k = 0; k < 8; k++) if ((uint32_t)k >= nv) tot[k] = 0x80000000u;
+            }
+            bool go[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) go[k] = (int32_t)tot[k] >= need;
+            if (nv < 8u) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) if ((uint32_t)k >= nv) tot[k] = 0u;
+            }
+            uint32_t nib = 0, tmax = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                tmax = max(tmax, tot[k]);
+                nib |= min(tot[k], 15u) << (4 * k);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) tot_pk[k] = tot[2 * k] | (tot[2 * k + 1] << 16);
+            if (nv) {
+                const bool whole = nv == 8u;    // (the batch's last stripe is stored position by position: the tables end at n_pos)
+                // (every loop over the eight is unrolled: an index that is not a constant would send the array to scratch memory)
+                uint8_t *const cov4 = a.cov4, *const cov8 = a.cov8;
+                uint16_t *const cov16 = a.cov16;
+                float *const clon = a.clon;
+                if (cov4) {
+                    if (whole) *reinterpret_cast<uint32_t *>(cov4 + (g0 >> 1)) = nib;
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 8; k += 2) if ((uint32_t)k < nv) cov4[(g0 + (uint32_t)k) >> 1] = (uint8_t)(nib >> (4 * k));
+                    }
+                }
+                if (cov16) {
+                    if (whole) *reinterpret_cast<uint4 *>(cov16 + g0) = make_uint4(tot_pk[0], tot_pk[1], tot_pk[2], tot_pk[3]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) if ((uint32_t)k < nv) cov16[g0 + (uint32_t)k] = (uint16_t)tot[k];
+                    }
+                }
+                if (cov8) {
+                    uint32_t b0 = 0, b1 = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { b0 |= min(tot[k], 255u) << (8 * k); b1 |= min(tot[4 + k], 255u) << (8 * k); }
+                    if (whole) *reinterpret_cast<uint2 *>(cov8 + g0) = make_uint2(b0, b1);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) if ((uint32_t)k < nv) cov8[g0 + (uint32_t)k] = (uint8_t)min(tot[k], 255u);
+                    }
+                }
+                if ((cov16 || cov8 || cov4) && tmax >= sat_thr) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (tot[k] >= sat_thr) {
+                            const uint32_t at = cur_add(a, CUR_SAT, 1u);
+                            if (at < a.cap_sat) a.sat[at] = make_uint2(g0 + (uint32_t)k, tot[k]);
+                        }
+                    }
+                }
+                if (clon) {                     // dense clonality array: NaN below min_cov; the positions of the queue are written again by the second pass
+                    const float qn = __builtin_nanf("");
+                    if (whole) {
+                        reinterpret_cast<float4 *>(clon + g0)[0] = make_float4(qn, qn, qn, qn);
+                        reinterpret_cast<float4 *>(clon + g0)[1] = make_float4(qn, qn, qn, qn);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) if ((uint32_t)k < nv) clon[g0 + (uint32_t)k] = qn;
+                    }
+                }
+                if (cov4 && tmax > 15u) scratch[S_COVX] = 1u;       // (every writer writes the same 1)
+            }
+            // compaction of the positions that go on: the lanes whose position k does are one ballot; a lane's slot is the wave's base (one
+            // LDS atomic a wave) + the ballots before k + the lanes below it in ballot k.  (The queue is then column-major inside a wave's
+            // 512 positions; nothing downstream depends on the order of the queue.)
+            uint64_t bal[8];
+            uint32_t wn = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { bal[k] = __ballot(go[k]); wn += (uint32_t)__popcll(bal[k]); }
+            if (wn) {                           // wave-uniform
+                uint32_t qb = 0;
+                if (lane == 0) qb = atomicAdd(&scratch[S_NQ], wn);
+                qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (go[k]) queue[__builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], qb))] = (uint32_t)(p0 + k) | (tot[k] << 16);
+                    qb += (uint32_t)__popcll(bal[k]);
+                }
+            }
+            __syncthreads();
+            ISX_TS(4);
+            ISX_ARGS_FRESH();
+            const uint32_t nq1 = scratch[S_NQ];
+            use_fl = nq1 + 512u <= (uint32_t)S;
+            for (uint32_t q = tid; q < nq1; q += nthr) {
+                const uint32_t e = queue[q];
+                const int p = (int)(e & 0x1FFFu);
+                uint32_t a01 = cnt[p], a23 = cnt[S + p];
+                const uint32_t r = refl[p];
+                if (r < 4u) {                   // the reference base's count: what was observed and is no exception
+                    const uint32_t v = (e >> 16) - ((a01 & 0xFFFFu) + (a01 >> 16) + (a23 & 0xFFFFu) + (a23 >> 16));
+                    if (r >> 1) { a23 += v << (16 * (r & 1u)); cnt[S + p] = a23; }
+                    else { a01 += v << (16 * (r & 1u)); cnt[p] = a01; }
+                }
+                const uint32_t c[4] = {a01 & 0xFFFFu, a01 >> 16, a23 & 0xFFFFu, a23 >> 16};
+                site_pass1(p, w0 + (uint32_t)p, c, c[0] + c[1] + c[2] + c[3], (int)r, (int)q, true, true);
+            }
+        } else {
         int ep_it = 0;
         for (int p = tid; p < ((dbg & 2) ? 0 : W); p += nthr, ep_it++) {
             const uint32_t gpos = w0 + p;
@@ -1040,46 +1252,20 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
                     if (k < a.cap_sat) a.sat[k] = make_uint2(gpos, total);
                 }
             }
-            float cl = __builtin_nanf("");
-            bool defer = false;
-            uint32_t entry = (uint32_t)p;
-            if ((int64_t)total >= (int64_t)a.min_cov && call_ok) {
-                const int ref_base = PKL ? (int)refl[p] : (ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : ref_at(a, gpos)));
-#ifdef ISX_TUNING
-                const SiteCall sc = (dbg & 1024) ? SiteCall{-1, 1, 0, 0} : call_level(a, thr_lds, c, total, ref_base, false);    // 1024: no SNV call
-                const uint32_t mx = (dbg & 2048) ? total : max(max(c[0], c[1]), max(c[2], c[3]));                               // 2048: every clonality 1.0
-#else
-                const SiteCall sc = call_level(a, thr_lds, c, total, ref_base, false);
-                const uint32_t mx = max(max(c[0], c[1]), max(c[2], c[3]));
-#endif
-                if (mx == total) cl = 1.0f; else defer = true;
-                if (defer) entry |= 1u << 13;
-                if (a.clon_list && defer) atomicAdd(&scratch[S_NCLON], 1u);     // the list of clonalities other than 1.0: written below, once the window has its slots
-                if (sc.snp != -1) {
-                    entry |= 1u << 14;
-                    atomicAdd(&scratch[S_ROWS], 1u);
-                    if (sc.morphia >= 2) {
-                        const uint32_t mask = (1u << sc.snp) | (1u << sc.var);
-                        entry |= (atomicAdd(&scratch[S_SITES], 1u) + 1u) << 17;
-                        if (linkage) {
-                            maskl[p] = (uint8_t)mask;
-                            slabc[p] = atomicAdd(&scratch[S_NAO], masked_sum(c, mask));
-                        }
-                    }
-                }
-            }
-            // clonTR is gated on rarefied_coverage alone (snv_utilities.py:100-102), also below min_cov
-            if (a.min_cov_r > 0 && (int64_t)total >= (int64_t)a.min_cov_r) { entry |= 1u << 15; if (a.rare) atomicAdd(&scratch[S_NRARE], 1u); }
-            if (entry != (uint32_t)p) queue[atomicAdd(&scratch[S_NQ], 1u)] = entry;
-            if (!defer && st_ok && a.clon) a.clon[gpos] = cl;      // (a lean slot keeps no dense clonality array)
+            const int ref_base = PKL ? (int)refl[p] : (ep_it == 0 ? ref_raw[0] : (ep_it == 1 ? ref_raw[1] : ref_at(a, gpos)));
+            site_pass1(p, gpos, c, total, ref_base, -1, st_ok, call_ok);
+        }
         }
         __syncthreads();
         ISX_TS(5);
         ISX_ARGS_FRESH();
 #ifdef ISX_TUNING
-        if (dbg & 512) { __syncthreads(); continue; }       // 512: nothing after the first epilogue pass (no table slots, no rows)
+        if (dbg & 512) { win_it++; __syncthreads(); continue; }       // 512: nothing after the first epilogue pass (no table slots, no rows)
 #endif
         const uint32_t nq = scratch[S_NQ], nrows = scratch[S_ROWS], nsites = scratch[S_SITES], nao = scratch[S_NAO];
+        const uint32_t nfl = scratch[S_ENT_TOT];
+        const bool fl = PKL && use_fl && nfl <= 1024u;       // (uniform) the loops below walk the listed queue entries only
+        const uint32_t nit = fl ? nfl : nq;
         if (tid == 0 && nrows) scratch[S_ROW_BASE] = cur_add(a, CUR_SNV, nrows);
         if (tid == 64 && nsites) scratch[S_SITE_BASE] = cur_add(a, CUR_SITES, nsites);
         if (tid == 128 && nao) scratch[S_AO_BASE] = cur_add(a, CUR_AO, nao);
@@ -1095,8 +1281,8 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
         {
             const uint32_t clon_base = scratch[S_CLON_BASE];
             const bool list = nclon && clon_base + nclon <= a.cap_clon;      // else the host reads the dense array
-            for (uint32_t q = tid; q < nq; q += nthr) {
-                const uint32_t e = queue[q];
+            for (uint32_t q = tid; q < nit; q += nthr) {
+                const uint32_t e = queue[fl ? (uint32_t)flist[q] : q];
                 if (!(e & (1u << 13))) continue;
                 const int p = (int)(e & 0x1FFFu);
                 uint32_t c[4];
@@ -1111,6 +1297,9 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
             const uint32_t k = scratch[S_COVX_BASE];
             const uint32_t at = k * (uint32_t)W;
             if (at + (uint32_t)W <= a.cap_cov_rows) {
+                if (stripe) {                   // the stripe path still holds its eight coverages
+                    if (8 * tid < W) *reinterpret_cast<uint4 *>(a.cov_rows + at + 8u * (uint32_t)tid) = make_uint4(tot_pk[0], tot_pk[1], tot_pk[2], tot_pk[3]);
+                } else
                 for (int p = tid; p < W; p += nthr) {
                     uint32_t c[4];
                     ld4(p, c);
@@ -1124,8 +1313,8 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
         if (a.min_cov_r > 0) {                  // rarefied clonality (snv_utilities.py:233-247), own loop: fewer live registers
             const uint32_t rare_base = scratch[S_RARE_BASE];
             const bool list = nrare && rare_base + nrare <= a.cap_rare;      // else the host reads the dense array
-            for (uint32_t q = tid; q < nq; q += nthr) {
-                const uint32_t e = queue[q];
+            for (uint32_t q = tid; q < nit; q += nthr) {
+                const uint32_t e = queue[fl ? (uint32_t)flist[q] : q];
                 if (!(e & (1u << 15))) continue;
                 const int p = (int)(e & 0x1FFFu);
                 uint32_t c[4];
@@ -1154,9 +1343,9 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
             wr[4] = cb; wr[5] = (nclon && cb + nclon <= a.cap_clon) ? nclon : 0u;
             wr[6] = rb; wr[7] = (nrare && rb + nrare <= a.cap_rare) ? nrare : 0u;
         }
-        for (uint32_t q0 = 0; q0 < (ok ? nq : 0u); q0 += nthr) {
+        for (uint32_t q0 = 0; q0 < (ok ? nit : 0u); q0 += nthr) {
             const uint32_t q = q0 + tid;
-            const uint32_t e = q < nq ? queue[q] : 0u;
+            const uint32_t e = q < nit ? queue[fl ? (uint32_t)flist[q] : q] : 0u;
             if (!((e >> 14) & 1u)) continue;
             const uint32_t my_row = atomicAdd(&scratch[S_ROW_RANK], 1u);
             const int p = (int)(e & 0x1FFFu);
@@ -1192,8 +1381,10 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
                 else allele_pass(a, cur_lo << (RSH - 1), cur_hi << (RSH - 1), w0, W, maskl, slabc, ao_base, lds + a.stage_off, tid, nthr);
             }
             ISX_TS(9);
+            rng_next = rngl[win_it & 63];
             prefetch_window(w + grid);
         }
+        win_it++;
         // the zeroing + barrier at the top of the next window protect cnt / queue / scratch
         __syncthreads();
         ISX_TS(10);
@@ -1990,7 +2181,7 @@ size_t pileup_lds_bytes(int W, int M, int qcap, int rqcap, int linkage, int pack
     const int pad = segs == 64 ? ISX_SEG_PAD : ISX_DENSE_PAD;       // segs: 0 = observation records, 64 = segment records, 32 = reference-delta records
     if (dlt_off) *dlt_off = 0;
     const bool pkl = M == 1 && segs == 32 && packed;    // reference-delta records with 16-bit counters: two counter rows + the queue row
-    if (M == 1) { cnt_words = (size_t)(pkl ? 2 : 4) * (W + pad); words = cnt_words + (size_t)(W + pad) + S_N + THR_LDS / 2; }
+    if (M == 1) { cnt_words = (size_t)(pkl ? 2 : 4) * (W + pad); words = cnt_words + (size_t)(W + pad) + S_N + S_RNG + THR_LDS / 2; }
     else {
         cnt_words = (size_t)M * (packed ? 2 : 4) * W;
         if (segs == 32) cnt_words += (size_t)M * (packed ? 1 : 2) * W;      // reference-delta records: the levels' skipped-columns / coverage-difference rows

@@ -466,7 +466,7 @@ def test_lean_slot_output_equals_the_plain_slot(ctx):
                 exp_cov = np.bincount(w["obs"]["gpos"], minlength=w["n_pos"])
                 W = raw["cov_window"]
                 beyond = np.unique(np.flatnonzero(exp_cov > 15) // W)
-                assert set(beyond.tolist()) <= set(raw["cov_row_win"].tolist())          # every window beyond 15 has its row (a few more may: the bound is reads covering)
+                assert set(beyond.tolist()) == set(raw["cov_row_win"].tolist())          # exactly the windows beyond 15 have a row (the stripe path knows the coverage itself)
                 assert (engine.dense_cov(raw, w["n_pos"]) == np.minimum(exp_cov, 65535)).all()
             r = pipe.collect(t)                         # densified: cov16 + clon arrays rebuilt on the host
             res.append({k: r[k].copy() for k in ("cov16", "clon", "snv", "ld")} | {"sizes": r["sizes"], "rare": r["rare"].copy()})
@@ -481,7 +481,7 @@ def test_lean_slot_output_equals_the_plain_slot(ctx):
         for k in ("cov16", "snv", "ld", "rare"):
             assert a[k].tobytes() == b[k].tobytes(), k
         assert a["clon"].view(np.uint32).tobytes() == b["clon"].view(np.uint32).tobytes()
-    assert len(n_rows) == 3 and n_rows[2] >= 10 and n_rows[0] <= n_rows[1] <= n_rows[2]        # (the depth-6 batch keeps 5.4 of 6 bases: 4-bit plane too)
+    assert len(n_rows) == 3 and n_rows[2] >= 3 and n_rows[0] <= n_rows[1] <= n_rows[2]         # (the depth-6 batch keeps 5.4 of 6 bases: 4-bit plane too)
     n2 = out[True][4]
     assert (~np.isnan(n2["clon"]) & (n2["clon"] != 1.0)).sum() * 2 > len(n2["clon"])        # the case that needs the dense array
 

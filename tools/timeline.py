@@ -34,7 +34,7 @@ else:
     link = os.environ.get("LINK", "1") == "1"
     kw = {"min_snp": 20}
 os.environ["ISX_DEBUG_MODE"] = str(4096 | int(os.environ.get("DBG", "0")))
-b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["segs"], None, n_mm_bins=1, enable_linkage=link, window=0, layout=0, **kw)
+b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], w["segs"], None, n_mm_bins=1, enable_linkage=link, window=int(os.environ.get("WINDOW", "0")), layout=int(os.environ.get("LAYOUT", "0")), **kw)
 for _ in range(4):
     b.run()
 t = b.timings()
