@@ -2342,7 +2342,8 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
     //      reads, whose end lies at or beyond that start, + the list's sentinel).  Dropped reads take no part in the overlap
     //      resolution and reach no column.  Only a position with >= 100000 reads over it can drop anything: a parallel screen
     //      (reads starting within the longest read span of each start) decides whether the serial replay runs at all.
-    //      PARITY UNPINNED (no reference fixture is that deep; restated from the htslib-1.9 source; the tests hold a second, pure-Python restatement).
+    //      PARITY UNPINNED (no reference fixture is that deep; restated from the htslib-1.9 source; the tests hold a second, pure-Python restatement,
+    //      which replays every split literally: its own reads, its own buffer, its own columns).
     {
         constexpr int64_t MAX_DEPTH = 100000;
         const size_t n_all = S.reads.size();
@@ -2366,18 +2367,90 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
                 }
             });
             if (deep.load()) {
+                // Round 6: the replay is restarted PER SPLIT, as the reference's iterator is (profile_utilities.py:150-153: one
+                // samfile.pileup(..., max_depth=100000, start=start, stop=end+1) per split, fasta.py:56-73 iterate_splits): a split's
+                // iterator is fed the reads that overlap [start, end] (pos <= end, bam_endpos > start) and starts with an empty buffer.
+                // A read that overlaps two splits is replayed in both and can be dropped in one and taken in the other (a pile
+                // within a read's length before a split bound: the buffer of the later split's iterator never saw the reads that
+                // end before the bound).  Such a read keeps its place in the stream; its CIGAR is rewritten so that it covers no
+                // column of the splits that dropped it -- M/=/X there become I + N, D becomes N -- and everything downstream
+                // (overlap resolution, expansion) sees a read that is absent exactly there.  Dropped everywhere: removed as before.
+                const int64_t WL = p->window_length > 0 ? p->window_length : 10000;
                 std::priority_queue<int64_t, std::vector<int64_t>, std::greater<int64_t>> ends;
-                int32_t cur_tid = -1, prev_pos = -1;
-                int64_t n_drop = 0;
-                for (size_t i = 0; i < n_all; i++) {
-                    Read &r = S.reads[i];
-                    if (r.tid != cur_tid) { cur_tid = r.tid; prev_pos = -1; ends = decltype(ends)(); }
-                    while (!ends.empty() && ends.top() < (int64_t)r.pos) ends.pop();
-                    if (prev_pos == r.pos && (int64_t)ends.size() + 1 > MAX_DEPTH) { r.pair_idx = 0xFFFFFFFFu; r.flag |= FUNMAP; n_drop++; continue; }
-                    prev_pos = r.pos;
-                    ends.push(r.ref_end);
+                std::vector<uint16_t> n_seen(n_all, 0), n_drop(n_all, 0);
+                std::vector<std::pair<uint32_t, int32_t>> drops;        // (read, split ordinal on its reference)
+                size_t i0 = 0;
+                while (i0 < n_all) {
+                    const int32_t tid = S.reads[i0].tid;
+                    size_t i1 = i0;
+                    while (i1 < n_all && S.reads[i1].tid == tid) i1++;
+                    const int64_t sLen = tid >= 0 ? B.ref_len[(size_t)tid] : 0;
+                    if (sLen > 0) {
+                        const int64_t nC = sLen / WL + 1, chunk = (int64_t)((double)sLen / (double)nC);
+                        size_t lo = i0;
+                        for (int64_t c = 0; c < nC; c++) {
+                            const int64_t s0 = c * chunk, e0 = c + 1 == nC ? sLen - 1 : (c + 1) * chunk - 1;
+                            while (lo < i1 && (int64_t)S.reads[lo].pos + L <= s0) lo++;      // (cannot reach the split: ref_end <= pos + L)
+                            ends = decltype(ends)();
+                            int32_t prev_pos = -1;
+                            for (size_t i = lo; i < i1 && (int64_t)S.reads[i].pos <= e0; i++) {
+                                const Read &r = S.reads[i];
+                                if (std::max<int64_t>(r.ref_end, (int64_t)r.pos + 1) <= s0) continue;       // not fetched for this split
+                                while (!ends.empty() && ends.top() < (int64_t)r.pos) ends.pop();
+                                if (n_seen[i] < 0xFFFF) n_seen[i]++;
+                                if (prev_pos == r.pos && (int64_t)ends.size() + 1 > MAX_DEPTH) { if (n_drop[i] < 0xFFFF) n_drop[i]++; drops.emplace_back((uint32_t)i, (int32_t)c); continue; }
+                                prev_pos = r.pos;
+                                ends.push(r.ref_end);
+                            }
+                        }
+                    }
+                    i0 = i1;
                 }
-                (void)n_drop;
+                // what the drops mean for each read
+                std::vector<uint32_t> extra;                            // rewritten CIGARs, appended to S.cigars below
+                const size_t old_n = S.cigars.size();
+                std::sort(drops.begin(), drops.end());
+                for (size_t d = 0; d < drops.size();) {
+                    const uint32_t ri = drops[d].first;
+                    size_t d1 = d;
+                    while (d1 < drops.size() && drops[d1].first == ri) d1++;
+                    Read &r = S.reads[ri];
+                    if (n_drop[ri] >= n_seen[ri]) { r.pair_idx = 0xFFFFFFFFu; r.flag |= FUNMAP; d = d1; continue; }     // no iterator took it
+                    const int64_t sLen = B.ref_len[(size_t)r.tid];
+                    const int64_t nC = sLen / WL + 1, chunk = (int64_t)((double)sLen / (double)nC);
+                    auto split_of = [&](int64_t rp) { return chunk > 0 ? std::min<int64_t>(rp / chunk, nC - 1) : 0; };
+                    auto split_end = [&](int64_t c) { return c + 1 == nC ? sLen - 1 : (c + 1) * chunk - 1; };
+                    auto is_dropped = [&](int64_t c) { for (size_t k = d; k < d1; k++) if (drops[k].second == (int32_t)c) return true; return false; };
+                    const uint64_t new_off = (uint64_t)old_n + extra.size();
+                    int64_t rp = r.pos;
+                    for (uint32_t k = 0; k < r.n_cigar; k++) {
+                        const uint32_t cg = S.cigars[r.cigar_off + (uint64_t)k];
+                        const uint32_t op = cg & 15u;
+                        int64_t n = (int64_t)(cg >> 4);
+                        const bool m_like = op == CM || op == CEQ || op == CX, d_like = op == CD || op == CN;
+                        if (!m_like && !d_like) { extra.push_back(cg); continue; }           // consumes no reference: as it is
+                        while (n > 0) {             // the operation cut at the split bounds it crosses
+                            const int64_t c = rp >= 0 && rp < sLen ? split_of(rp) : -1;
+                            const int64_t run = c < 0 ? n : std::min<int64_t>(n, split_end(c) - rp + 1);
+                            if (c >= 0 && is_dropped(c)) {
+                                if (m_like) extra.push_back((uint32_t)(run << 4) | CI);
+                                extra.push_back((uint32_t)(run << 4) | CN);
+                            } else extra.push_back((uint32_t)(run << 4) | op);
+                            rp += run; n -= run;
+                        }
+                    }
+                    r.cigar_off = new_off;
+                    r.n_cigar = (uint32_t)((uint64_t)old_n + extra.size() - new_off);
+                    d = d1;
+                }
+                if (!extra.empty()) {
+                    RawBuf<uint32_t> nb;
+                    nb.resize(old_n + extra.size());
+                    memcpy(nb.p, S.cigars.p, old_n * sizeof(uint32_t));
+                    memcpy(nb.p + old_n, extra.data(), extra.size() * sizeof(uint32_t));
+                    std::swap(nb.p, S.cigars.p);
+                    std::swap(nb.n, S.cigars.n);
+                }
             }
             stage("max_depth");
         }

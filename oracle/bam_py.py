@@ -364,6 +364,54 @@ def apply_max_depth(reads, tid, max_depth=100000):
     return n_drop
 
 
+def iterate_splits(s_len, window_len=10000):
+    """fasta.py:56-73: 0-based, double-inclusive (start, end) of a scaffold's splits"""
+    n_chunks = s_len // window_len + 1
+    chunk = int(s_len / n_chunks)
+    out, start, end = [], 0, 0
+    for i in range(n_chunks):
+        if i + 1 == n_chunks:
+            out.append((start, s_len - 1))
+        else:
+            end += chunk
+            out.append((start, end - 1))
+            start += chunk
+    return out
+
+
+def expand_observations_per_split(reads, tid, r2m, splits, **kw):
+    """The reference's own structure, literally (profile_utilities.py:150-153): ONE pileup iterator per split -- fed the reads that
+    overlap [start, end] (pos <= end and bam_endpos > start, the region fetch of samfile.pileup(..., start=start, stop=end+1)), with
+    its own max_depth buffer (apply_max_depth on that subset alone) and its own overlap resolution on its own copies of the records,
+    truncated to the split's columns.  Returns (pos, base, mm, pair) over all splits, pair = ids of the read names in order of first
+    appearance; differs from the whole-scaffold replay only where >= 100 000 reads pile up within a read's length of a split bound.
+    PARITY UNPINNED like apply_max_depth (no fixture of the reference is that deep, pysam is not in this image)."""
+    import copy
+    gid = {}
+    P, B, M, R = [], [], [], []
+    for (s, e) in splits:
+        sub = []
+        for r in reads:
+            if r.tid != tid or (r.flag & DEF_MASK):
+                continue
+            if r.pos <= e and max(r.end_pos(), r.pos + 1) > s:
+                c = copy.copy(r)
+                c.qual = r.qual.copy()
+                sub.append(c)
+        apply_max_depth(sub, tid)
+        resolve_overlaps(sub, tid)
+        pos, base, mm, pr, name2id = expand_observations(sub, tid, r2m, **kw)
+        keep = (pos >= s) & (pos <= e)
+        local = np.zeros(max(len(name2id), 1), dtype=np.int64)
+        for name, i in name2id.items():
+            local[i] = gid.setdefault(name, len(gid))
+        P.append(pos[keep]); B.append(base[keep]); M.append(mm[keep]); R.append(local[pr[keep]] if len(pr) else pr)
+    if not P:
+        z = np.zeros(0, dtype=np.int64)
+        return z, z.astype(np.uint8), z, z
+    return np.concatenate(P), np.concatenate(B).astype(np.uint8), np.concatenate(M), np.concatenate(R)
+
+
 def _is_dropped(r):
     try:
         return r.dropped

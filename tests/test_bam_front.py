@@ -553,3 +553,62 @@ def test_max_depth_of_the_pileup_call(tmp_path):
     bam_py.resolve_overlaps(rr, 0)
     pos, base, mm, pr, _ = bam_py.expand_observations(rr, 0, r2m["deep"], ref_len=2000)
     assert len(pos) == len(obs) and (obs["gpos"] == pos).all() and (obs["base"] == base).all() and (pair_id == pr).all()
+
+
+def test_max_depth_is_replayed_per_split(tmp_path):
+    """The reference opens ONE pileup iterator per split (profile_utilities.py:150-153; splits from fasta.py:56-73), each with its own
+    max_depth buffer fed by the reads that overlap the split.  A 25 000-base scaffold at window_length 10 000 has splits [0, 8332],
+    [8333, 16665], [16666, 24999].  50 000 reads cover 8310..8329 (split 0 only) and 60 000 more cover 8320..8339 (both splits): split
+    0's iterator takes 50 000 of the second pile (its buffer holds the first), split 1's iterator never sees the first pile and takes
+    all 60 000 -- the last 10 000 reads of the second pile are present from column 8333 on and absent before it.  (A replay over the
+    whole scaffold -- what rounds 4-5 did -- leaves 50 000 at 8333..8339.)  Checked against the arithmetic and against the oracle's
+    literal per-split restatement, position by position and base by base.  PARITY UNPINNED (no fixture this deep; no pysam here)."""
+    from oracle import bam_py
+    from tests import bamwriter
+    refs = [("deep", 25000)]
+    assert bam_py.iterate_splits(25000, 10000) == [(0, 8332), (8333, 16665), (16666, 24999)]
+    L = 20
+    q = np.full(L, 37, np.uint8)
+    reads = []
+
+    def pair(name, s1, s2, seq="ACGT" * (L // 4)):
+        for mate, (s, ms) in enumerate(((s1, s2), (s2, s1))):
+            reads.append(dict(tid=0, pos=s, mapq=40, flag=0x1 | 0x2 | (0x40 if mate == 0 else 0x80) | (0x20 if mate == 0 else 0x10),
+                              isize=(s2 + L - s1) * (1 if mate == 0 else -1), name=name, cigar=[("M", L)], seq=seq, qual=q, nm=0,
+                              mtid=0, mpos=ms))
+    for i in range(50_000):
+        pair("first%d" % i, 8310, 20000)
+    for i in range(60_000):
+        pair("second%d" % i, 8320, 20100, seq="TTGCA" * (L // 5))
+    for i in range(7):
+        pair("plain%d" % i, 8328 + i, 21000 + i)                # arrive while both piles are buffered; some straddle the bound
+    reads.sort(key=lambda r: r["pos"])
+    path = str(tmp_path / "deep_split.bam")
+    bamwriter.write_bam(path, refs, reads)
+    bam = engine.BamFile(path)
+    obs, pair_id, bounds, sref = bam.expand(min_read_ani=0.9, window_length=10000)
+    bam.close()
+    assert list(bounds) == [0, 8333, 16666, 25000]
+    cov = np.bincount(obs["gpos"], minlength=25000)
+    plain = np.zeros(25000, np.int64)
+    for i in range(7):
+        plain[8328 + i:8328 + i + L] += 1
+    assert (cov[8310:8320] == 50_000).all()
+    assert (cov[8320:8328] == 100_000).all()                                # 50 000 + the 50 000 of the second pile split 0 takes
+    # the plain reads start at 8328..8334 on columns the iterator does not stand on yet (each start is a new run): all taken
+    assert (cov[8328:8330] == 100_000 + plain[8328:8330]).all()
+    assert (cov[8330:8333] == 50_000 + plain[8330:8333]).all()              # the first pile has ended; split 0 still lacks 10 000 of the second
+    assert (cov[8333:8340] == 60_000 + plain[8333:8340]).all()              # split 1's iterator took the whole second pile
+    assert (cov[20000:20020] == 50_000).all() and (cov[20100:20120] == 60_000).all()        # the mates: nothing else buffered there
+    # the oracle's literal per-split replay
+    rrefs, rr = bam_py.read_bam(path)
+    r2m, _ = bam_py.filter_pairs({"deep": bam_py.get_paired_reads(rr, 0)}, min_read_ani=0.9)
+    pos, base, mm, pr = bam_py.expand_observations_per_split(rr, 0, r2m["deep"], bam_py.iterate_splits(25000, 10000), ref_len=25000)
+    assert len(pos) == len(obs)
+    want = np.zeros((25000, 5), np.int64)
+    np.add.at(want, (pos, base), 1)
+    got = np.zeros((25000, 5), np.int64)
+    np.add.at(got, (obs["gpos"].astype(np.int64), obs["base"].astype(np.int64)), 1)
+    assert (want == got).all()
+    # a read pair's observations: the same multiset of per-pair counts
+    assert sorted(np.bincount(pr).tolist()) == sorted(np.bincount(pair_id).tolist())
