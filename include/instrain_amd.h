@@ -799,6 +799,13 @@ int isx_bam_set_r2m(isx_bam *bam, int32_t ref, int64_t n, const char *names, con
 /* pairs with more than `cap` mismatches are piled up at mm level `cap` from now on (the device bins 128 levels: a caller that meets a
  * pair beyond that clamps and warns instead of failing the call); isx_bam_r2m still reports the true values */
 int isx_bam_set_mm_cap(isx_bam *bam, int32_t cap);
+/* Round 6: mm levels of any size, exactly (the reference bins any mm, profile_utilities.py:268-286; its tables depend on the ORDER of the
+ * levels alone -- counts are cumulated over the levels <= mm, :297-312).  isx_bam_mm_levels: the distinct mm values of the kept pairs,
+ * ascending (*n = how many there are; the first min(*n, cap) are written).  isx_bam_set_mm_levels: from now on a pair travels with the RANK
+ * of its mm in `levels` (n_mm_bins = n; the caller maps the ranks in the tables back to the values); n = 0 switches the ranks off.  With
+ * more than 128 distinct values isx_bam_set_mm_cap(127) still merges the ranks beyond. */
+int isx_bam_mm_levels(const isx_bam *bam, int32_t *levels, int32_t cap, int32_t *n);
+int isx_bam_set_mm_levels(isx_bam *bam, const int32_t *levels, int32_t n);
 /* names of the read pairs of the batch prepared last (isx_bam_expand_refs / isx_bam_segment_refs / isx_pipe_submit_bam) by dense pair
  * id, i.e. by the ids isx_allele_obs.pair carries: names[offs[i] .. offs[i + 1]) (names / offs may be NULL to ask for the sizes).
  * Only while the handle still has the names (no isx_bam_drop_names before the batch was prepared): --store_everything. */

@@ -159,7 +159,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_pack_ref_planes", "isx_planes_from_segs", "isx_pack_read_planes", "isx_pipe_submit_planes", "isx_pipe_stage_planes", "isx_encode_planes", "isx_encode_planes_mm", "isx_pipe_set_reference_budget",
            "isx_bgzf_index", "isx_bgzf_inflate_device", "isx_bgzf_inflate_host", "isx_bgzf_inflate_fast",
            "isx_bam_open", "isx_bam_close", "isx_bam_close_wait", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
-           "isx_bam_insert_sizes", "isx_bam_set_wanted_refs", "isx_bam_pair_keys", "isx_bam_set_cross_names", "isx_bam_filter_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_batch_pair_names", "isx_bam_set_mm_cap", "isx_bam_ref_counts",
+           "isx_bam_insert_sizes", "isx_bam_set_wanted_refs", "isx_bam_pair_keys", "isx_bam_set_cross_names", "isx_bam_filter_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_batch_pair_names", "isx_bam_set_mm_cap", "isx_bam_mm_levels", "isx_bam_set_mm_levels", "isx_bam_ref_counts",
            "isx_bam_expand_refs", "isx_bam_segment_refs", "isx_bam_copy_segs", "isx_bam_copy_read_planes", "isx_bam_expand_region", "isx_bam_expand", "isx_bam_copy", "isx_bam_view"]
 
 _lib = None
@@ -256,6 +256,8 @@ def load():
     lib.isx_bam_r2m.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), vp, vp, vp]
     lib.isx_bam_batch_pair_names.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), vp, vp]
     lib.isx_bam_set_mm_cap.argtypes = [vp, i32]
+    lib.isx_bam_mm_levels.argtypes = [vp, vp, i32, vp]
+    lib.isx_bam_set_mm_levels.argtypes = [vp, vp, i32]
     lib.isx_bam_ref_counts.argtypes = [vp, vp, vp]
     lib.isx_bam_expand_region.argtypes = [vp, C.POINTER(BamParams), i32, i64, i64, C.POINTER(BamInfo)]
     lib.isx_bam_expand_refs.argtypes = [vp, C.POINTER(BamParams), vp, i32, C.POINTER(BamInfo)]

@@ -623,6 +623,16 @@ struct isx_bam {
     std::vector<uvec<char>> dead_names;
     static constexpr size_t KEEP_DEAD = (size_t)2 << 30;
     int32_t mm_cap = 0x7FFFFFFF;            // isx_bam_set_mm_cap: pairs with more mismatches are piled up at this level
+    // isx_bam_set_mm_levels: the mm VALUES that occur among the kept pairs, ascending; a pair then travels with the RANK of its value
+    // (the device only needs the levels' order: counts are cumulated over the levels <= mm, profile_utilities.py:297-312; the caller
+    // maps ranks back to values).  Empty: a pair travels with its mm itself.
+    std::vector<int32_t> mm_levels;
+    int32_t level_of(int32_t mm) const
+    {
+        if (mm_levels.empty()) return std::min<int32_t>(mm, mm_cap);
+        const int32_t k = (int32_t)(std::lower_bound(mm_levels.begin(), mm_levels.end(), mm) - mm_levels.begin());
+        return std::min<int32_t>(k, mm_cap);
+    }
     std::vector<uint32_t> last_dense_pair;  // of the batch prepared last: dense pair id -> index into `pairs` (kept while the names are:
                                             // isx_bam_batch_pair_names, the read_to_snvs keys of --store_everything)
     std::mutex retire_mu;
@@ -1966,6 +1976,30 @@ int isx_bam_set_mm_cap(isx_bam *bam, int32_t cap)
     return ISX_OK;
 }
 
+// Round 6: mm levels beyond 127 binned exactly.  The reference bins any mm (profile_utilities.py:268-286) and every table it makes
+// depends on the levels' ORDER alone (cumulative counts over the levels <= mm); a device batch holds 128 levels.  isx_bam_mm_levels
+// lists the distinct mm values of the kept pairs, isx_bam_set_mm_levels makes the pairs travel with the rank of their value in that
+// list -- exact whenever no more than 128 DIFFERENT values occur, whatever their size (isx_bam_set_mm_cap then merges the ranks beyond).
+int isx_bam_mm_levels(const isx_bam *bam, int32_t *levels, int32_t cap, int32_t *n)
+{
+    if (!bam || !n || cap < 0 || (cap && !levels)) { isx_set_error("isx_bam_mm_levels: bad argument"); return ISX_ERR_ARG; }
+    std::vector<int32_t> v;
+    for (const PairInfo &e : bam->pairs) if (e.pass && e.reads != 0) v.push_back(e.mm);
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    *n = (int32_t)std::min<size_t>(v.size(), 0x7FFFFFFF);
+    for (int32_t i = 0; i < std::min<int32_t>(*n, cap); i++) levels[i] = v[(size_t)i];
+    return ISX_OK;
+}
+
+int isx_bam_set_mm_levels(isx_bam *bam, const int32_t *levels, int32_t n)
+{
+    if (!bam || n < 0 || (n && !levels)) { isx_set_error("isx_bam_set_mm_levels: bad argument"); return ISX_ERR_ARG; }
+    for (int32_t i = 1; i < n; i++) if (levels[i] <= levels[i - 1]) { isx_set_error("isx_bam_set_mm_levels: the values must ascend"); return ISX_ERR_ARG; }
+    bam->mm_levels.assign(levels, levels + n);
+    return ISX_OK;
+}
+
 // names of the read pairs of the batch prepared LAST (isx_bam_expand_refs / isx_bam_segment_refs / isx_pipe_submit_bam), by dense pair
 // id -- the ids the device's tables (isx_ao.pair) carry.  Needs the names (no isx_bam_drop_names before the batch was prepared).
 int isx_bam_batch_pair_names(const isx_bam *bam, int64_t *n, int64_t *name_bytes, char *names, int64_t *offs)
@@ -2066,7 +2100,7 @@ struct BamBatch {
     {
         const Read &r = S.reads[ri];
         const PairInfo &pi = B->pairs[r.pair_idx];
-        const uint64_t hi = (uint64_t)(prm.skip_mm ? 0 : (uint16_t)std::min<int32_t>(pi.mm, B->mm_cap)) << 32;
+        const uint64_t hi = (uint64_t)(prm.skip_mm ? 0 : (uint16_t)B->level_of(pi.mm)) << 32;
         const int64_t base_off = boff[(size_t)r.tid];
         const int64_t ref_len = B->ref_len[(size_t)r.tid];
         const uint8_t *ql = r.qual, *sq = r.seq;
@@ -2526,7 +2560,7 @@ int bam_batch_prepare(isx_bam *bam, const isx_bam_params *p, const int32_t *refs
                 const size_t i0 = wd * 64, i1 = std::min(n_pair_all, i0 + 64);
                 for (size_t i = i0; i < i1; i++) {
                     m |= (uint64_t)(B.pairs[i].pass && B.pairs[i].reads != 0) << (i - i0);
-                    if (pmm) pmm[i - w_lo * 64] = (uint8_t)std::min<int32_t>(255, std::max<int32_t>(0, B.pairs[i].mm));
+                    if (pmm) pmm[i - w_lo * 64] = (uint8_t)std::min<int32_t>(255, std::max<int32_t>(0, B.level_of(B.pairs[i].mm)));
                 }
                 pass_bits[wd] = m;
             }

@@ -1048,6 +1048,19 @@ class BamFile:
         raw = names.raw
         return {raw[offs[i]:offs[i + 1]].decode(): int(mm[i]) for i in range(n.value)}
 
+    def mm_levels(self):
+        """the distinct mm values of the kept read pairs, ascending (isx_bam_mm_levels)"""
+        n = C.c_int32(0)
+        check(self.lib.isx_bam_mm_levels(self.h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        check(self.lib.isx_bam_mm_levels(self.h, out.ctypes.data, int(n.value), C.byref(n)))
+        return out[:n.value]
+
+    def set_mm_levels(self, levels):
+        """pairs travel with the rank of their mm in `levels` (ascending values; isx_bam_set_mm_levels); empty: with the mm itself"""
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        check(self.lib.isx_bam_set_mm_levels(self.h, lv.ctypes.data if len(lv) else None, int(len(lv))))
+
     def set_mm_cap(self, cap):
         """pairs with more than `cap` mismatches are piled up at level `cap` (isx_bam_set_mm_cap)"""
         check(self.lib.isx_bam_set_mm_cap(self.h, int(cap)))

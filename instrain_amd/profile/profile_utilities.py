@@ -89,8 +89,11 @@ class _BatchTables:
     calculate_ld outputs of every split of the batch).  Built once per batch from numpy arrays; the pandas
     objects of a split are only made when somebody reads them."""
 
-    def __init__(self, res, split_bounds, split_scaffold, scaffold_offset, min_cov=5):
+    def __init__(self, res, split_bounds, split_scaffold, scaffold_offset, min_cov=5, mm_values=None):
         self.min_cov = int(min_cov)
+        # mm levels beyond what a device batch indexes directly: the device's levels are RANKS, mm_values[rank] the pairs' real mm
+        # (profile_bam, isx_bam_set_mm_levels); every mm that leaves this object goes through _mm()
+        self.mm_values = None if mm_values is None else np.asarray(mm_values, dtype=np.int64)
         self.bounds = np.asarray(split_bounds, dtype=np.int64)
         self.scaffold = split_scaffold
         self.offset = np.asarray(scaffold_offset, dtype=np.int64)
@@ -138,10 +141,18 @@ class _BatchTables:
         # --store_everything: update_linked_reads' appends as the device holds them (read_to_snvs / mm_to_position_graph are
         # made from them per split, profile/linkage.py); pair_names: the batch's dense pair id -> read-pair name
         self.ao = res.get("allele_obs")
+        if self.ao is not None and self.mm_values is not None:
+            self.ao = self.ao.copy()
+            self.ao["mm"] = self._mm(self.ao["mm"])
         if self.ao is not None:                     # sorted by position once: a split cuts its rows by bisection (profile/linkage.py)
             from . import linkage
             self.ao = linkage.SortedAlleleObs(self.ao)
         self.pair_names = res.get("pair_names")
+
+    def _mm(self, levels):
+        """device level -> the pairs' mm"""
+        levels = np.asarray(levels)
+        return levels if self.mm_values is None else self.mm_values[levels.astype(np.int64)]
 
     @property
     def soa(self):
@@ -175,7 +186,7 @@ class _BatchTables:
             a, b = self.e_cut[i], self.e_cut[i + 1]
             g, mc, cl, cr = (x[a:b] for x in self.soa)
             pos = g.astype(np.int64) - off
-            mm, lvl = (mc >> 24).astype(np.uint16), (mc & 0xFFFFFF).astype(np.int64)
+            mm, lvl = self._mm((mc >> 24).astype(np.uint16)), (mc & 0xFFFFFF).astype(np.int64)
             all_mm = np.unique(mm)
             k = lvl > 0
             covT = self._by_mm(pos[k], mm[k], lvl[k], "int32", all_mm)
@@ -187,14 +198,15 @@ class _BatchTables:
         if self.entries is not None:
             ee = self.entries[self.e_cut[i]:self.e_cut[i + 1]]
             pos = ee["gpos"].astype(np.int64) - off
-            all_mm = np.unique(ee["mm"])
+            emm = self._mm(ee["mm"])
+            all_mm = np.unique(emm)
             lvl = ee["cnt"].sum(axis=1)
             k = lvl > 0
-            covT = self._by_mm(pos[k], ee["mm"][k], lvl[k], "int32", all_mm)
+            covT = self._by_mm(pos[k], emm[k], lvl[k], "int32", all_mm)
             k = ~np.isnan(ee["clon"])
-            clonT = self._by_mm(pos[k], ee["mm"][k], ee["clon"][k], "float32", all_mm)
+            clonT = self._by_mm(pos[k], emm[k], ee["clon"][k], "float32", all_mm)
             k = ~np.isnan(ee["clon_rarefied"])
-            clonTR = self._by_mm(pos[k], ee["mm"][k], ee["clon_rarefied"][k], "float32", all_mm)
+            clonTR = self._by_mm(pos[k], emm[k], ee["clon_rarefied"][k], "float32", all_mm)
             return covT, clonT, clonTR
         s, e = int(self.bounds[i]), int(self.bounds[i + 1])
         cov = self.cov[s:e]
@@ -231,7 +243,7 @@ class _BatchTables:
         return pd.DataFrame({
             'scaffold': self.scaffold[i], 'position': snv["gpos"].astype(np.int64) - self.offset[i],
             'ref_base': BASES[snv["ref_base"]], 'A': cnt[:, 0], 'C': cnt[:, 1], 'T': cnt[:, 2], 'G': cnt[:, 3],
-            'con_base': BASES[snv["con_base"]], 'var_base': BASES[snv["var_base"]], 'mm': snv["mm"].astype(np.int64),
+            'con_base': BASES[snv["con_base"]], 'var_base': BASES[snv["var_base"]], 'mm': self._mm(snv["mm"]).astype(np.int64),
             'allele_count': snv["allele_count"].astype(np.int64), 'class': np.array(CLASSES)[snv["cls"]],
             'cryptic': snv["cryptic"].astype(bool), 'position_coverage': cnt.sum(axis=1)}, columns=SNP_COLUMNS)
 
@@ -248,7 +260,7 @@ class _BatchTables:
             'countaB': ld["countaB"].astype(np.int64), 'countab': ld["countab"].astype(np.int64),
             'allele_A': BASES[ld["allele_A"]], 'allele_a': BASES[ld["allele_a"]], 'allele_B': BASES[ld["allele_B"]],
             'allele_b': BASES[ld["allele_b"]], 'distance': np.abs(pb - pa), 'position_A': pa, 'position_B': pb,
-            'mm': ld["mm"].astype(np.int64), 'scaffold': self.scaffold[i]}, columns=LD_COLUMNS)
+            'mm': self._mm(ld["mm"]).astype(np.int64), 'scaffold': self.scaffold[i]}, columns=LD_COLUMNS)
 
 
 class SplitObject():
@@ -567,10 +579,10 @@ def _rss():
 
 
 def tables_to_splits(res, split_bounds, split_scaffold, split_number, scaffold_offset, split_seq_len, min_freq,
-                     bam_name=None, min_cov=5, started=None, mm_clamped=None):
+                     bam_name=None, min_cov=5, started=None, mm_clamped=None, mm_values=None):
     """Batch result (engine.Batch.fetch() / Pipe.collect()) -> list of SplitObject, one per split, in split order.
     started: time.time() when the batch's profiling began (the start stamp of every split's worker log)."""
-    tables = _BatchTables(res, split_bounds, split_scaffold, scaffold_offset, min_cov)
+    tables = _BatchTables(res, split_bounds, split_scaffold, scaffold_offset, min_cov, mm_values=mm_values)
     t_end, mem = time.time(), _rss()
     tables.meta = {'scaffold': split_scaffold, 'number': split_number, 'length': split_seq_len, 'bam': bam_name, 'min_freq': min_freq,
                    't_start': t_end if started is None else started, 't_end': t_end, 'mem': mem, 'mm_clamped': mm_clamped}
@@ -783,19 +795,32 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
             bf.scan(part=kwargs.get('scan_part'))    # refresh the totals (max_mm now comes from the controller's values)
         n_mm = 1 if skip_mm else int(bf.info["max_mm"]) + 1
         mm_clamped = None
+        mm_values = None
+        bf.set_mm_levels([])
+        bf.set_mm_cap(0x7FFFFFFF)
         if n_mm > 128:
-            # the reference bins any mm (profile_utilities.py:268-286); a device batch holds 128 levels.  Rather than failing the
-            # whole call, pairs beyond level 127 are piled up AT level 127 (their bases then appear one level early in the
-            # cumulative tables of the levels >= 127 only) -- loudly, on every SplitObject (S.mm_clamped = 127), and never under
-            # strict=True: a caller that asked for exactness gets the error instead of merged levels
-            if kwargs.get('strict'):
-                raise ValueError("a read pair with {0} mismatches: the device bins mm levels 0..127 (strict=True refuses to merge the levels "
-                                 "beyond; --skip_mm_profiling or a higher --min_read_ani avoids this)".format(n_mm - 1))
-            mm_clamped = 127
-            logging.warning("a read pair with {0} mismatches: the device bins mm levels 0..127, pairs beyond are counted at level 127 "
-                            "(--skip_mm_profiling or a higher --min_read_ani avoids this)".format(n_mm - 1))
-            bf.set_mm_cap(127)
-            n_mm = 128
+            # the reference bins any mm (profile_utilities.py:268-286); a device batch indexes 128 levels.  Every table depends on the
+            # ORDER of the levels alone (counts are cumulated over the levels <= mm, :297-312), so the pairs travel with the RANK of
+            # their mm among the values that occur and the tables' levels are mapped back (round 6: exact for any mm as long as no
+            # more than 128 DIFFERENT values occur among the kept pairs)
+            mm_values = np.asarray(bf.mm_levels(), dtype=np.int64)
+            bf.set_mm_levels(mm_values)
+            n_mm = len(mm_values)
+            if n_mm > 128:
+                # more than 128 different values: the pairs beyond the 128th are piled up AT it (their bases then appear early in the
+                # cumulative tables of the levels from there on) -- loudly, on every SplitObject (S.mm_clamped = that value), and never
+                # under strict=True: a caller that asked for exactness gets the error instead of merged levels
+                if kwargs.get('strict'):
+                    raise ValueError("read pairs with {0} different numbers of mismatches (up to {1}): the device bins 128 mm levels "
+                                     "(strict=True refuses to merge the levels beyond; --skip_mm_profiling or a higher --min_read_ani "
+                                     "avoids this)".format(n_mm, int(mm_values[-1])))
+                mm_clamped = int(mm_values[127])
+                logging.warning("read pairs with {0} different numbers of mismatches: the device bins 128 mm levels, pairs beyond {1} "
+                                "mismatches are counted at that level (--skip_mm_profiling or a higher --min_read_ani avoids "
+                                "this)".format(n_mm, mm_clamped))
+                bf.set_mm_cap(127)
+                mm_values = mm_values[:128]
+                n_mm = 128
         reads_per_ref, pairs_per_ref = bf.ref_counts()
         if not store_everything:                    # (--store_everything keys read_to_snvs by read name: the names stay)
             bf.drop_names()
@@ -881,10 +906,13 @@ def profile_bam(bam, fasta_db=None, sR2M=None, ISP_loc=None, **kwargs):
                     res["allele_obs"] = res["slot"].fetch_allele_obs()
                     res["pair_names"] = getattr(g, 'pair_names', None)
                 splits = tables_to_splits(res, g.bounds, g.s_scaff, g.s_num, g.s_off, g.s_len, min_freq, bam,
-                                          min_cov=int(kwargs.get('min_cov', 5)), started=getattr(g, 't_submit', None), mm_clamped=mm_clamped)
+                                          min_cov=int(kwargs.get('min_cov', 5)), started=getattr(g, 't_submit', None), mm_clamped=mm_clamped, mm_values=mm_values)
                 if kwargs.get('scaffold_tables') is not None or kwargs.get('scaffold_levels') is not None:
                     sb = np.r_[0, np.cumsum([refs[tid][1] for tid in g.tids])]
                     levels, _ = res["slot"].summarize(sb)
+                    if mm_values is not None:               # the device's levels are ranks: back to the pairs' mm
+                        for lv in levels:
+                            lv['mm'] = mm_values[lv['mm'].astype(np.int64)]
                     tables = splits[0]._src[0] if splits else None
                     for j, k in enumerate(g.items):
                         name = plan[k][1]

@@ -742,10 +742,32 @@ def test_store_everything_on_a_bam_names_the_reads(tmp_path):
     assert n_edges == 963                                           # the stored run's linkage network
 
 
-def test_pairs_beyond_128_mm_levels_are_clamped_not_fatal(tmp_path, caplog):
-    """a controller's R2M with pairs of 200 mismatches (long reads, a low --min_read_ani): the device bins levels 0..127, such
-    pairs are piled up AT level 127 with a warning -- the same profile as an R2M that says 127 -- instead of an empty result, and every
-    SplitObject says so (mm_clamped == 127); strict=True refuses to merge levels (ValueError) and turns any failing call into its exception"""
+def _same_split_mm(a, b, to_a):
+    """_same_split with b's mm levels renamed by to_a (b was profiled with order-preserving stand-ins for a's mm values)"""
+    for att in ("scaffold", "split_number", "length"):
+        assert getattr(a, att) == getattr(b, att)
+    for att in ("raw_snp_table", "raw_linkage_table"):
+        x, y = getattr(a, att), getattr(b, att)
+        assert len(x) == len(y)
+        if len(x):
+            y = y.copy()
+            y["mm"] = [to_a[int(m)] for m in y["mm"]]
+            cols = [c for c in x.columns if not c.endswith("_normalized")]
+            pd.testing.assert_frame_equal(x[cols].reset_index(drop=True), y[cols].reset_index(drop=True))
+    for att in ("covT", "clonT"):
+        x, y = getattr(a, att), getattr(b, att)
+        assert sorted(x) == sorted(to_a[int(m)] for m in y), att
+        for m in y:
+            pd.testing.assert_series_equal(x[to_a[int(m)]], y[m])
+
+
+def test_pairs_beyond_128_mm_levels_are_binned_exactly(tmp_path, caplog):
+    """a controller's R2M with pairs of 200..249 mismatches (long reads, a low --min_read_ani).  The reference bins any mm
+    (profile_utilities.py:268-286) and its tables depend on the ORDER of the levels alone (:297-312): the pairs travel with the rank of
+    their mm among the values that occur (isx_bam_set_mm_levels) and the tables come back under the real values -- the same profile as an
+    R2M whose values are small order-preserving stand-ins, level for level, with no warning and under strict=True.  More than 128
+    DIFFERENT values: the pairs beyond the 128th are counted at it, with a warning, every SplitObject says so (mm_clamped = that value) --
+    the same profile as an R2M that says that value -- and strict=True refuses (ValueError)"""
     import logging
     import instrain_amd.profile as prof
     from instrain_amd import engine
@@ -756,24 +778,48 @@ def test_pairs_beyond_128_mm_levels_are_clamped_not_fatal(tmp_path, caplog):
     r2m = {name: bam.r2m(t) for t, (name, _, _) in enumerate(bam.refs())}
     bam.close()
     far = {s: dict(d) for s, d in r2m.items()}
-    at127 = {s: dict(d) for s, d in r2m.items()}
     k = 0
     for s in far:
         for name in list(far[s])[::7]:
-            far[s][name], at127[s][name] = 200 + (k % 50), 127
+            far[s][name] = 200 + (k % 50)
             k += 1
     assert k > 50
+    values = sorted({v for d in far.values() for v in d.values()})
+    assert 50 < len(values) <= 128 and values[-1] == 249
+    rank = {v: i for i, v in enumerate(values)}
+    small = {s: {n: rank[v] for n, v in d.items()} for s, d in far.items()}            # order-preserving stand-ins below 128
     with caplog.at_level(logging.WARNING):
-        a = prof.profile_bam(path, None, far, None, **kw)
-    assert any("counted at level 127" in r.message for r in caplog.records)
+        a = prof.profile_bam(path, None, far, None, strict=True, **kw)
+    assert not any("mismatches" in r.message for r in caplog.records)
+    b = prof.profile_bam(path, None, small, None, strict=True, **kw)
+    assert sorted(a) == sorted(b) and len(a) > 5
+    for key in a:
+        _same_split_mm(a[key], b[key], values)
+        assert a[key].mm_clamped is None
+    assert max(max(S.covT) for S in a.values() if len(S.covT)) == 249
+    # more than 128 different values
+    wide = {s: dict(d) for s, d in r2m.items()}
+    k = 0
+    for s in wide:
+        for name in list(wide[s])[::5]:
+            wide[s][name] = 300 + 2 * (k % 150)
+            k += 1
+    values = sorted({v for d in wide.values() for v in d.values()})
+    assert len(values) > 128
+    cap = values[127]
+    at_cap = {s: {n: min(v, cap) for n, v in d.items()} for s, d in wide.items()}
+    caplog.clear()
+    with caplog.at_level(logging.WARNING):
+        a = prof.profile_bam(path, None, wide, None, **kw)
+    assert any("are counted at that level" in r.message for r in caplog.records)
     with pytest.raises(ValueError, match="strict=True refuses"):
-        prof.profile_bam(path, None, far, None, strict=True, **kw)
-    b = prof.profile_bam(path, None, at127, None, strict=True, **kw)
+        prof.profile_bam(path, None, wide, None, strict=True, **kw)
+    b = prof.profile_bam(path, None, at_cap, None, strict=True, **kw)
     assert sorted(a) == sorted(b) and len(a) > 5
     for key in a:
         _same_split(a[key], b[key])
-        assert a[key].mm_clamped == 127 and b[key].mm_clamped is None
-    assert max(max(S.covT) for S in a.values() if len(S.covT)) == 127
+        assert a[key].mm_clamped == cap and b[key].mm_clamped is None
+    assert max(max(S.covT) for S in a.values() if len(S.covT)) == cap
     # a call that fails as a whole: the exception itself with strict, a logged failure and a partial dict without
     with pytest.raises(Exception):
         prof.profile_bam(str(tmp_path / "no_such.bam"), None, None, None, strict=True, **kw)
