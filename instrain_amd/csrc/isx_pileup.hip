@@ -489,6 +489,35 @@ __device__ __forceinline__ uint32_t ref4_at(const PileupArgs &a, uint32_t gpos)
     return r;
 }
 
+// The same in two steps, so that the global loads can be issued at a window's top and their values first touched behind the stream loop:
+// ref4_at uses what it loads at once (a branch on the non-ACGT bits, the unpacking arithmetic), and the compiler put the wait -- a
+// vmcnt(0), which also waits for the records prefetched during the window before -- right behind each load: up to four serialized
+// memory round trips at the top of every window of a pipe slot.  ref4_raw only loads (the batch's last positions: the codes themselves)
+__device__ __forceinline__ void ref4_raw(const PileupArgs &a, uint32_t gpos, uint32_t &raw, uint32_t &rawn)
+{
+    rawn = 0;
+    if (gpos + 3u < a.n_pos) {
+        if (a.ref_packed == 2) {
+            raw = a.ref[gpos >> 2];
+            if (a.ref_n) rawn = a.ref_n[gpos >> 3];
+        } else if (a.ref_packed) raw = *reinterpret_cast<const uint16_t *>(a.ref + (gpos >> 1));
+        else raw = *reinterpret_cast<const uint32_t *>(a.ref + gpos);
+    } else raw = ref4_at(a, gpos);
+}
+__device__ __forceinline__ uint32_t ref4_expand(const PileupArgs &a, uint32_t gpos, uint32_t raw, uint32_t rawn)
+{
+    if (gpos + 3u >= a.n_pos) return raw;
+    if (a.ref_packed == 2) {
+        uint32_t r = (raw & 3u) | ((raw & 0xCu) << 6) | ((raw & 0x30u) << 12) | ((raw & 0xC0u) << 18);
+        const uint32_t nb = (rawn >> (gpos & 4u)) & 0xFu;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r = ((nb >> k) & 1u) ? ((r & ~(0xFFu << (8 * k))) | (4u << (8 * k))) : r;
+        return r;
+    }
+    if (a.ref_packed) return (raw & 0xFu) | ((raw & 0xF0u) << 4) | ((raw & 0xF00u) << 8) | ((raw & 0xF000u) << 12);
+    return raw;
+}
+
 // update_linked_reads on the reference-delta stream: like allele_pass_segs, the window's records are walked a second time against
 // the bitmap of the window's SNP sites; a record's base at a site is its exception there, else the reference's (unless skipped).
 // lo16, hi16: the window's range in 16-byte halves of records (multiples of 64).
@@ -616,8 +645,13 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
     typedef const __attribute__((address_space(4))) PileupArgs KernArgs;
     KernArgs *kargs = (KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
 #define a (*(const PileupArgs *)kargs)
-#define ISX_ARGS_FRESH() asm volatile("" : "+s"(kargs))
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    // The same for what derives from the thread index: the compiler hoists every tid-based address and predicate out of the window loop
+    // and then has no registers to keep them in -- they went to scratch memory, and a scratch reload at a window's top is a vector memory
+    // operation: its s_waitcnt vmcnt(0) also waited for the record loads prefetched during the window before (the whole point of the
+    // prefetch).  At every phase boundary the thread index is an unknown again; what a phase needs of it is recomputed in a few VALU.
+    int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+#define ISX_ARGS_FRESH() asm volatile("" : "+s"(kargs), "+v"(tid))
     publish_previous(a, tid);
     const int W = a.W;
     constexpr bool SEGS = FMT == 64;
@@ -750,9 +784,10 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
         // DREC: the reference codes of this thread's four positions of the materialise phase (ref4); with packed rows the window's
         // codes go to LDS here (coalesced word loads; read back after the stream's barrier by whichever thread owns a position)
         uint32_t ref4 = 0x04040404u, ref4b = 0x04040404u;      // (loaded here, stored behind the stream loop: the latency hides there)
-        if (PKL) {
-            if (4 * tid < W) ref4 = ref4_at(a, w0 + 4u * (uint32_t)tid);
-            if (4 * (tid + nthr) < W) ref4b = ref4_at(a, w0 + 4u * (uint32_t)(tid + nthr));
+        uint32_t ref4n = 0, ref4bn = 0;
+        if (PKL) {                              // (raw: unpacked where they are stored)
+            if (4 * tid < W) ref4_raw(a, w0 + 4u * (uint32_t)tid, ref4, ref4n);
+            if (4 * (tid + nthr) < W) ref4_raw(a, w0 + 4u * (uint32_t)(tid + nthr), ref4b, ref4bn);
         } else if (DREC && 4 * tid < W) ref4 = ref4_at(a, w0 + 4u * (uint32_t)tid);
         uint8_t ref_raw[2];
 #pragma unroll
@@ -949,8 +984,8 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
         if (ablate_acc == 0xDEADBEEFu) cnt[dummy] = ablate_acc;             // keeps the ablated decode alive
 #endif
         if (PKL) {                              // the window's reference codes, for whichever thread owns a position afterwards
-            if (4 * tid < W) reinterpret_cast<uint32_t *>(refl)[tid] = ref4;
-            if (4 * (tid + nthr) < W) reinterpret_cast<uint32_t *>(refl)[tid + nthr] = ref4b;
+            if (4 * tid < W) reinterpret_cast<uint32_t *>(refl)[tid] = ref4_expand(a, w0 + 4u * (uint32_t)tid, ref4, ref4n);
+            if (4 * (tid + nthr) < W) reinterpret_cast<uint32_t *>(refl)[tid + nthr] = ref4_expand(a, w0 + 4u * (uint32_t)(tid + nthr), ref4b, ref4bn);
         }
         __syncthreads();
         ISX_TS(2);
@@ -1424,8 +1459,9 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
     typedef const __attribute__((address_space(4))) PileupArgs KernArgs;
     KernArgs *kargs = (KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
 #define a (*(const PileupArgs *)kargs)
-#define ISX_ARGS_FRESH() asm volatile("" : "+s"(kargs))
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    int tid = threadIdx.x;                      // (an unknown again at every phase boundary, like the arguments: see k_pileup_dense)
+    const int nthr = blockDim.x;
+#define ISX_ARGS_FRESH() asm volatile("" : "+s"(kargs), "+v"(tid))
     publish_previous(a, tid);
     const int W = a.W, M = a.M;
 #ifdef ISX_TUNING
