@@ -1301,15 +1301,112 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
         const uint32_t nfl = scratch[S_ENT_TOT];
         const bool fl = PKL && use_fl && nfl <= 1024u;       // (uniform) the loops below walk the listed queue entries only
         const uint32_t nit = fl ? nfl : nq;
-        if (tid == 0 && nrows) scratch[S_ROW_BASE] = cur_add(a, CUR_SNV, nrows);
-        if (tid == 64 && nsites) scratch[S_SITE_BASE] = cur_add(a, CUR_SITES, nsites);
-        if (tid == 128 && nao) scratch[S_AO_BASE] = cur_add(a, CUR_AO, nao);
         const uint32_t nrare = a.rare ? scratch[S_NRARE] : 0u;
-        if (tid == 192 && nrare) scratch[S_RARE_BASE] = cur_add(a, CUR_RARE, nrare);
         const uint32_t nclon = a.clon_list ? scratch[S_NCLON] : 0u;
-        if (tid == 256 % nthr && nclon) scratch[S_CLON_BASE] = cur_add(a, CUR_CLON, nclon);
         const uint32_t covx = PKL ? scratch[S_COVX] : 0u;                   // 4-bit coverage plane: this window also writes its 16-bit row
-        if (PKL && tid == 320 % nthr && covx) scratch[S_COVX_BASE] = cur_add(a, CUR_COVX, 1u);
+        {   // the window's table slots: six lanes of the LAST wave (the one least likely to hold queue entries), one atomic instruction --
+            // that wave waits for the round trip, the others go on with what needs no slot yet
+            const int k = tid - (nthr - 64);
+            if (k >= 0 && k < 6) {
+                const uint32_t n = k == 0 ? nrows : (k == 1 ? nsites : (k == 2 ? nao : (k == 3 ? nrare : (k == 4 ? nclon : (covx ? 1u : 0u)))));
+                const int which = k == 0 ? CUR_SNV : (k == 1 ? CUR_SITES : (k == 2 ? CUR_AO : (k == 3 ? CUR_RARE : (k == 4 ? CUR_CLON : CUR_COVX))));
+                const int slot_w = k == 0 ? S_ROW_BASE : (k == 1 ? S_SITE_BASE : (k == 2 ? S_AO_BASE : (k == 3 ? S_RARE_BASE : (k == 4 ? S_CLON_BASE : S_COVX_BASE))));
+                if (n) scratch[slot_w] = atomicAdd(&a.cursors[which], n) - a.base[which];
+            }
+        }
+        bool ok = nrows != 0;
+        uint32_t ao_base = 0;
+        auto slots_ok = [&](uint32_t row_base, uint32_t site_base) {    // (after the barrier that makes the slots visible)
+            ao_base = scratch[S_AO_BASE];
+            if (ok && (row_base + nrows > a.cap_snv || site_base + nsites > a.cap_sites || ao_base + nao > a.cap_ao)) {
+                if (tid == 0) flag_or(a, row_base + nrows > a.cap_snv ? ISX_FLAG_CAP_SNV
+                                                : (site_base + nsites > a.cap_sites ? ISX_FLAG_CAP_SITES : ISX_FLAG_CAP_AO));
+                ok = false;
+            }
+            if (a.win_rec && tid == 0) {
+                // where this window's rows / sites / list entries went and how many there are: the tables are filled in the order the
+                // windows reach their cursors, k_win_gather puts them into position order afterwards (windows are position ranges, a
+                // window's entries lie together) -- instead of sorting the tables
+                uint32_t *wr = a.win_rec + 8 * (size_t)w;
+                const uint32_t cb = scratch[S_CLON_BASE], rb = scratch[S_RARE_BASE];
+                wr[0] = row_base; wr[1] = ok ? nrows : 0u;
+                wr[2] = site_base; wr[3] = ok ? nsites : 0u;
+                wr[4] = cb; wr[5] = (nclon && cb + nclon <= a.cap_clon) ? nclon : 0u;
+                wr[6] = rb; wr[7] = (nrare && rb + nrare <= a.cap_rare) ? nrare : 0u;
+            }
+        };
+        auto covx_row = [&]() {
+            if (PKL && covx) {
+                const uint32_t k = scratch[S_COVX_BASE];
+                const uint32_t at = k * (uint32_t)W;
+                if (at + (uint32_t)W <= a.cap_cov_rows) {
+                    if (stripe) {                   // the stripe path still holds its eight coverages
+                        if (8 * tid < W) *reinterpret_cast<uint4 *>(a.cov_rows + at + 8u * (uint32_t)tid) = make_uint4(tot_pk[0], tot_pk[1], tot_pk[2], tot_pk[3]);
+                    } else
+                    for (int p = tid; p < W; p += nthr) {
+                        uint32_t c[4];
+                        ld4(p, c);
+                        a.cov_rows[at + (uint32_t)p] = (uint16_t)min(c[0] + c[1] + c[2] + c[3], 65535u);
+                    }
+                }
+                if (tid == 0) a.cov_row_win[k] = (uint32_t)w;
+            }
+        };
+        if (fl && nit <= (uint32_t)nthr) {
+            // ---- a shallow window's tail in one step: a thread has at most ONE listed queue entry.  What needs no table slot -- the fp64
+            //      clonality (snv_utilities.py:225-231), the rarefied one (:233-247), the SNV row's call and class (:107-133) -- is computed
+            //      while the slot atomics are under way; ONE barrier; then the stores.  (The loops below pay the atomics' round trip and
+            //      two barriers before they start.) ----
+            const bool have = (uint32_t)tid < nit;
+            const uint32_t e = have ? queue[(uint32_t)flist[tid]] : 0u;
+            const int p = (int)(e & 0x1FFFu);
+            const uint32_t gpos = w0 + (uint32_t)p;
+            uint32_t c[4] = {0, 0, 0, 0};
+            if (have) ld4(p, c);
+            const uint32_t total = c[0] + c[1] + c[2] + c[3];
+            const bool f_clon = (e >> 13) & 1u, f_row = (e >> 14) & 1u, f_rare = a.min_cov_r > 0 && ((e >> 15) & 1u);
+            float v_clon = 0.f, v_rare = 0.f;
+            if (f_clon) v_clon = (float)clonality(c, total);
+            if (f_rare) v_rare = rarefied_clonality(a, c, gpos, 0);
+            const int ref_base = f_row ? (int)refl[p] : 4;
+            SiteCall sc{-2, 0, 0, 0};
+            if (f_row) sc = call_level(a, nullptr, c, total, ref_base, true);
+            __syncthreads();                    // the slots are there
+            ISX_TS(6);
+            ISX_ARGS_FRESH();
+            const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE];
+            slots_ok(row_base, site_base);
+            covx_row();
+            if (f_clon) {
+                const uint32_t clon_base = scratch[S_CLON_BASE];
+                if (a.clon) a.clon[gpos] = v_clon;
+                if (nclon && clon_base + nclon <= a.cap_clon) a.clon_list[clon_base + atomicAdd(&scratch[S_CLON_RANK], 1u)] = make_uint2(gpos, __float_as_uint(v_clon));
+            }
+            if (f_rare) {
+                const uint32_t rare_base = scratch[S_RARE_BASE];
+                if (a.clon_r) a.clon_r[gpos] = v_rare;
+                if (nrare && rare_base + nrare <= a.cap_rare) a.rare[rare_base + atomicAdd(&scratch[S_RARE_RANK], 1u)] = make_uint2(gpos, __float_as_uint(v_rare));
+            }
+            if (f_row && ok) {
+                const uint32_t my_row = atomicAdd(&scratch[S_ROW_RANK], 1u);
+                isx_snv r;
+                r.gpos = gpos; r.mm = 0;
+                r.con_base = (uint8_t)sc.snp; r.var_base = (uint8_t)sc.var;
+                r.allele_count = (uint8_t)sc.morphia; r.cls = (uint8_t)sc.cls;
+                r.cryptic = 0;
+                r.ref_base = (uint8_t)ref_base;
+                r.cnt[0] = c[0]; r.cnt[1] = c[1]; r.cnt[2] = c[2]; r.cnt[3] = c[3];
+                a.snv[row_base + my_row] = r;
+                const uint32_t ss = e >> 17;
+                if (ss) {
+                    isx_site st;
+                    st.gpos = gpos; st.entry_off = row_base + my_row; st.n_levels = 1;
+                    st.mask = (uint8_t)((1u << sc.snp) | (1u << sc.var)); st.pad = 0;
+                    a.sites[site_base + ss - 1] = st;
+                }
+            }
+            ISX_TS(7);
+        } else {
         if (nclon) __syncthreads();             // uniform: the list entries below need the window's base
         ISX_TS(6);
         // ---- deferred clonalities (snv_utilities.py:225-231), densely packed; the sparse clonality list ----
@@ -1328,21 +1425,7 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
             }
         }
         if (nrows | nrare | covx) __syncthreads();     // uniform: scratch bases from the atomics above
-        if (PKL && covx) {
-            const uint32_t k = scratch[S_COVX_BASE];
-            const uint32_t at = k * (uint32_t)W;
-            if (at + (uint32_t)W <= a.cap_cov_rows) {
-                if (stripe) {                   // the stripe path still holds its eight coverages
-                    if (8 * tid < W) *reinterpret_cast<uint4 *>(a.cov_rows + at + 8u * (uint32_t)tid) = make_uint4(tot_pk[0], tot_pk[1], tot_pk[2], tot_pk[3]);
-                } else
-                for (int p = tid; p < W; p += nthr) {
-                    uint32_t c[4];
-                    ld4(p, c);
-                    a.cov_rows[at + (uint32_t)p] = (uint16_t)min(c[0] + c[1] + c[2] + c[3], 65535u);
-                }
-            }
-            if (tid == 0) a.cov_row_win[k] = (uint32_t)w;
-        }
+        covx_row();
         ISX_TS(7);
         ISX_ARGS_FRESH();
         if (a.min_cov_r > 0) {                  // rarefied clonality (snv_utilities.py:233-247), own loop: fewer live registers
@@ -1360,24 +1443,8 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
             }
         }
         // ---- SNV rows / SNP sites (snv_utilities.py:107-133) ----
-        const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE], ao_base = scratch[S_AO_BASE];
-        bool ok = nrows != 0;
-        if (ok && (row_base + nrows > a.cap_snv || site_base + nsites > a.cap_sites || ao_base + nao > a.cap_ao)) {
-            if (tid == 0) flag_or(a, row_base + nrows > a.cap_snv ? ISX_FLAG_CAP_SNV
-                                            : (site_base + nsites > a.cap_sites ? ISX_FLAG_CAP_SITES : ISX_FLAG_CAP_AO));
-            ok = false;
-        }
-        if (a.win_rec && tid == 0) {
-            // where this window's rows / sites / list entries went and how many there are: the tables are filled in the order the
-            // windows reach their cursors, k_win_gather puts them into position order afterwards (windows are position ranges, a
-            // window's entries lie together) -- instead of sorting the tables
-            uint32_t *wr = a.win_rec + 8 * (size_t)w;
-            const uint32_t cb = scratch[S_CLON_BASE], rb = scratch[S_RARE_BASE];
-            wr[0] = row_base; wr[1] = ok ? nrows : 0u;
-            wr[2] = site_base; wr[3] = ok ? nsites : 0u;
-            wr[4] = cb; wr[5] = (nclon && cb + nclon <= a.cap_clon) ? nclon : 0u;
-            wr[6] = rb; wr[7] = (nrare && rb + nrare <= a.cap_rare) ? nrare : 0u;
-        }
+        const uint32_t row_base = scratch[S_ROW_BASE], site_base = scratch[S_SITE_BASE];
+        slots_ok(row_base, site_base);
         for (uint32_t q0 = 0; q0 < (ok ? nit : 0u); q0 += nthr) {
             const uint32_t q = q0 + tid;
             const uint32_t e = q < nit ? queue[fl ? (uint32_t)flist[q] : q] : 0u;
@@ -1405,6 +1472,7 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
                 st.mask = (uint8_t)((1u << sc.snp) | (1u << sc.var)); st.pad = 0;
                 a.sites[site_base + ss - 1] = st;
             }
+        }
         }
         ISX_TS(8);
         ISX_ARGS_FRESH();
