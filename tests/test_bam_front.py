@@ -224,6 +224,51 @@ def test_expand_refs_subsets_and_controller_r2m(tmp_path):
     whole.close(); bam.close()
 
 
+def test_mm_levels_of_any_size_travel_as_ranks(tmp_path):
+    """isx_bam_mm_levels / isx_bam_set_mm_levels (round 6): the reference bins any mm (profile_utilities.py:268-286) and only the ORDER
+    of the levels enters its tables (:297-312).  A controller's R2M with values in the hundreds: the distinct values come back
+    ascending, and with them set every observation carries the rank of its pair's value -- the very stream of an R2M that holds the
+    ranks themselves; switched off again, the values themselves; a cap still merges the ranks beyond it; values that do not ascend
+    are refused"""
+    from oracle import bam_py
+    from tests import bamwriter
+    refs = [("scafA", 4000), ("scafC", 9000)]
+    path = str(tmp_path / "lv.bam")
+    bamwriter.write_bam(path, refs, bamwriter.random_reads(23, refs, 4000))
+    bam = engine.BamFile(path, threads=3)
+    bam.scan()
+    bam.filter(min_read_ani=0.9)
+    r2m = bam.r2m(1)
+    names = list(r2m)
+    big = {n: (700 + 3 * (i % 40) if i % 3 == 0 else int(r2m[n])) for i, n in enumerate(names)}
+    bam.set_r2m(1, names, [big[n] for n in names])
+    bam.set_r2m(0, [], [])
+    bam.scan()
+    levels = bam.mm_levels()
+    assert list(levels) == sorted(set(big.values())) and levels[-1] == 817 and len(levels) < 128
+    rank = {int(v): i for i, v in enumerate(levels)}
+    o_val, p_val, _, _ = bam.expand_refs([1], min_read_ani=0.9)
+    assert int(o_val["mm"].max()) == 817
+    bam.set_mm_levels(levels)
+    o_rank, p_rank, _, _ = bam.expand_refs([1], min_read_ani=0.9)
+    assert (o_rank["gpos"] == o_val["gpos"]).all() and (o_rank["base"] == o_val["base"]).all() and (p_rank == p_val).all()
+    assert (levels[o_rank["mm"].astype(np.int64)] == o_val["mm"]).all() and int(o_rank["mm"].max()) == len(levels) - 1
+    # the stream of an R2M that says the ranks
+    bam.set_mm_levels([])
+    bam.set_r2m(1, names, [rank[big[n]] for n in names])
+    o_small, _, _, _ = bam.expand_refs([1], min_read_ani=0.9)
+    assert (o_small == o_rank).all()
+    # a cap merges the ranks beyond it
+    bam.set_r2m(1, names, [big[n] for n in names])
+    bam.set_mm_levels(levels)
+    bam.set_mm_cap(10)
+    o_cap, _, _, _ = bam.expand_refs([1], min_read_ani=0.9)
+    assert (o_cap["mm"] == np.minimum(o_rank["mm"], 10)).all()
+    with pytest.raises(engine.IsxError, match="ascend"):
+        bam.set_mm_levels([3, 3, 9])
+    bam.close()
+
+
 def test_corrupt_inputs_are_errors_not_crashes(tmp_path):
     """truncated / corrupted inflated streams: bounds-checked, reported as ISX_ERR_IO"""
     import struct, zlib
