@@ -451,6 +451,18 @@ __device__ __forceinline__ void allele_pass_segs(const PileupArgs &a, uint32_t l
     if (nst) drain();
 }
 
+// the skip bits of a 32-column word whose first column is window position r, cut to the columns that lie inside [0, W): the walk below
+// then needs no per-bit window test (a word wholly inside the window -- nearly every one -- costs one compare)
+__device__ __forceinline__ uint32_t skip_bits_in_window(uint32_t bits, int32_t r, uint32_t uW)
+{
+    if ((uint32_t)r > uW - 32u) {               // crosses an edge of the window or lies outside (a negative r wraps around)
+        const int32_t lo = r < 0 ? -r : 0, hi = (int32_t)uW - r < 32 ? (int32_t)uW - r : 32;
+        if (hi <= lo) bits = 0;
+        else bits &= (hi >= 32 ? 0xFFFFFFFFu : (1u << hi) - 1u) & ~((1u << lo) - 1u);
+    }
+    return bits;
+}
+
 // ---- reference-delta records (include/instrain_amd.h ISX_DREC_*): a PAIR of lanes holds one 32-byte record ----
 // lane 0 of the pair: header, skip bits of columns 0..63, exceptions 0-2; lane 1: skip bits of columns 64..159, exceptions 3-5
 __device__ __forceinline__ uint32_t pair_first(uint32_t x)
@@ -836,12 +848,10 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
                 const int32_t c0 = s + (odd ? 64 : 0);
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    uint32_t bits = sk[k];
                     const int32_t r = c0 + 32 * k;
-                    if ((uint32_t)(r + 31) >= uW + 31u) bits = 0;                // the whole word lies outside the window
+                    uint32_t bits = skip_bits_in_window(sk[k], r, uW);
                     while (__ballot(bits != 0)) {                               // wave-uniform
-                        const uint32_t rel = (uint32_t)(r + __ffs((int)bits) - 1);
-                        if (bits != 0 && rel < uW) atomicAdd(&queue[rel], 1u);
+                        if (bits != 0) atomicAdd(&queue[r + (int32_t)__builtin_ctz(bits)], 1u);
                         bits &= bits - 1u;                                      // 0 stays 0
                     }
                 }
@@ -1657,12 +1667,10 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
                 const int32_t c0 = s + (odd ? 64 : 0);
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    uint32_t bits = sk[k];
                     const int32_t r = c0 + 32 * k;
-                    if ((uint32_t)(r + 31) >= uW + 31u) bits = 0;                // the whole word lies outside the window
+                    uint32_t bits = skip_bits_in_window(sk[k], r, uW);
                     while (__ballot(bits != 0)) {                               // wave-uniform
-                        const uint32_t rel = (uint32_t)(r + __ffs((int)bits) - 1);
-                        if (bits != 0 && rel < uW) atomicAdd(&skp[rel], 1u);
+                        if (bits != 0) atomicAdd(&skp[r + (int32_t)__builtin_ctz(bits)], 1u);
                         bits &= bits - 1u;                                      // 0 stays 0
                     }
                 }

@@ -22,6 +22,12 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c5 -o $TAG -- $
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c5 -o $TAG -- $T --c5 > $OUT/pmc_write_c5.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq1 -o $TAG -- $T --no-mm > $OUT/sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d $OUT/sq2 -o $TAG -- $T --no-mm > $OUT/sq2.log 2>&1
+# ... and on the headline's average-size C5 batch in a lean pipe slot: the stripe path (round 6) and the per-position epilogue (ISX_LAYOUT_NO_STRIPES)
+for L in 0 64; do
+  ISX_BENCH_LAYOUT=$L rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/sq1_c5_$L -o $TAG -- $T --c5 > $OUT/sq1_c5_$L.log 2>&1
+  ISX_BENCH_LAYOUT=$L rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $OUT/sq2_c5_$L -o $TAG -- $T --c5 > $OUT/sq2_c5_$L.log 2>&1
+  ISX_BENCH_LAYOUT=$L $T --c5 > $OUT/c5_batch_layout$L.log 2>&1
+done
 # the device inflate prototype next to zlib (tools/inflate_rate.py), and its lanes-per-wave sweep
 python $REPO/tools/inflate_rate.py > $OUT/inflate_rate.log 2>&1
 for l in 64 16 8; do ISX_INFLATE_LPW=$l DEVICE_ONLY=1 python $REPO/tools/inflate_rate.py 2>&1 | tail -1 | sed "s/^/LPW $l: /" >> $OUT/inflate_rate.log; done

@@ -144,6 +144,39 @@ Reading:
   LDS pipe busy cycles {d["SQ_LDS_IDX_ACTIVE"]/1e6:.1f} M vs {s6["SQ_LDS_IDX_ACTIVE"]/1e6:.1f} M.
 * waves parked (`SQ_WAIT_ANY`) {100*d["SQ_WAIT_ANY"]/d["SQ_WAVE_CYCLES"]:.0f} % of their life (segments: {100*s6["SQ_WAIT_ANY"]/s6["SQ_WAVE_CYCLES"]:.0f} %); VALU instructions {d["SQ_INSTS_VALU"]/1e6:.1f} M vs {s6["SQ_INSTS_VALU"]/1e6:.1f} M.
 ''')
+# ---- SQ counters on the C5 batch: the stripe path against the per-position epilogue ----
+import re
+c5sq = {}
+for L in (0, 64):
+    try:
+        c = pd.concat([pd.read_csv(R + '/sq1_c5_%d/%s_counter_collection.csv' % (L, tag)), pd.read_csv(R + '/sq2_c5_%d/%s_counter_collection.csv' % (L, tag))])
+    except FileNotFoundError:
+        continue
+    c5sq[L] = {n: counter_mean(c, K["c5"], n) for n in sorted(c['Counter_Name'].unique())}
+    lg = open(R + '/c5_batch_layout%d.log' % L).read()
+    m = re.search(r"c5 batch \d+: (\d+) positions, (\d+) segments, (\d+) kept observations, kernel ([0-9.]+) ms", lg)
+    if m:
+        c5sq[L]["positions"], c5sq[L]["kernel_ms"] = int(m.group(1)), float(m.group(4))
+if 0 in c5sq and 64 in c5sq:
+    a_, b_ = c5sq[0], c5sq[64]
+    names5 = [n for n in sorted(a_) if n.startswith("SQ_")]
+    tab5 = "| counter | stripe path | per position | per-position epilogue (ISX_LAYOUT_NO_STRIPES) | per position |\n|:--|--:|--:|--:|--:|\n"
+    for n in names5:
+        tab5 += "| %s | %.4g | %.3g | %.4g | %.3g |\n" % (n, a_[n], a_[n] / a_["positions"], b_[n], b_[n] / b_["positions"])
+    open('profiles/%s_sq_counters.md' % tag, 'a').write(f"""
+## The headline's average-size C5 batch in a lean pipe slot (`tools/pmc_target.py --c5`): k_pileup_dense<true, 32, true>
+
+{a_["positions"] / 1e6:.1f} M positions, linkage on; un-profiled kernel time of the same submit: **{a_["kernel_ms"]:.3f} ms with the stripe path**
+(round 6: coverage straight from the difference row, a thread owns eight positions, only positions at min_cov go on) against {b_["kernel_ms"]:.3f} ms with the
+per-position epilogue (`ISX_BENCH_LAYOUT=64` = `ISX_LAYOUT_NO_STRIPES`), same build.  Instruction counters are WAVE instructions per launch
+(x 64 lanes for lane-instructions); "per position" divides by the batch's positions.
+
+{tab5}
+* VALU: **{a_["SQ_INSTS_VALU"] / a_["positions"]:.2f} wave instructions = {64 * a_["SQ_INSTS_VALU"] / a_["positions"]:.0f} lane-instructions per position** (per-position epilogue:
+  {b_["SQ_INSTS_VALU"] / b_["positions"]:.2f} = {64 * b_["SQ_INSTS_VALU"] / b_["positions"]:.0f}); scalar {a_["SQ_INSTS_SALU"] / a_["positions"]:.2f} vs {b_["SQ_INSTS_SALU"] / b_["positions"]:.2f}; LDS {a_["SQ_INSTS_LDS"] / a_["positions"]:.3f} vs {b_["SQ_INSTS_LDS"] / b_["positions"]:.3f}.
+* `SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES` x 8 waves a SIMD = {800 * a_["SQ_ACTIVE_INST_VALU"] / a_["SQ_WAVE_CYCLES"]:.0f} % of the SIMDs' VALU issue time (was {800 * b_["SQ_ACTIVE_INST_VALU"] / b_["SQ_WAVE_CYCLES"]:.0f} %);
+  waves parked (`SQ_WAIT_ANY`) {100 * a_["SQ_WAIT_ANY"] / a_["SQ_WAVE_CYCLES"]:.0f} % of their life.
+""")
 # the VALU-issue yardstick of the resident C2 launch (bench.py roofline_c2_resident.valu_issue): quad-cycles in which a wave issued a VALU
 # instruction, and the instruction count, per launch
 pj = json.load(open('profiles/pmc_traffic.json'))
