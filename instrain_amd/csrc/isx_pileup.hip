@@ -858,8 +858,11 @@ __global__ void __launch_bounds__(1024, ISX_LB_WAVES) k_pileup_dense(const Pileu
                 // exceptions: a dual half carries six (its words 2, 3); a full record three (word 3 = the first lane's fourth word; its
                 // word 7 is the read-pair id)
                 const uint32_t exw[2] = {dual ? v[u].z : (odd ? ISX_DREC_NO_EXC : v[u].w), dual ? v[u].w : ISX_DREC_NO_EXC};
+                // (fields fill up in order; the second word -- a dual half's exceptions four to six -- is empty in nearly every wave)
+                const int nf = __ballot(exw[1] != ISX_DREC_NO_EXC) ? 6 : 3;
 #pragma unroll
                 for (int f = 0; f < 6; f++) {
+                    if (f == 3 && nf == 3) break;               // wave-uniform
                     const uint32_t ex = exw[f / 3];
                     const uint32_t off = (ex >> (10 * (f % 3))) & 0xFFu, code = (ex >> (10 * (f % 3) + 8)) & 3u;
                     const uint32_t rel = (uint32_t)(s + (int32_t)off);
@@ -1678,8 +1681,10 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
                 // record is a base that is not A/C/T/G: nothing to count, the level is present there (profile_utilities.py:279-285)
                 const uint32_t o4 = pair_other(x[0]), o5 = pair_other(x[1]), o6 = pair_other(x[2]);      // (the second lane's skip words)
                 const uint32_t exw[2] = {dual ? x[2] : (odd ? ISX_DREC_NO_EXC : x[3]), dual ? x[3] : ISX_DREC_NO_EXC};
+                const int nf = __ballot(exw[1] != ISX_DREC_NO_EXC) ? 6 : 3;       // (the second word is empty in nearly every wave)
 #pragma unroll
                 for (int f = 0; f < 6; f++) {
+                    if (f == 3 && nf == 3) break;               // wave-uniform
                     const uint32_t ex = exw[f / 3];
                     const uint32_t off = (ex >> (10 * (f % 3))) & 0xFFu, code = (ex >> (10 * (f % 3) + 8)) & 3u;
                     const uint32_t rel = (uint32_t)(s + (int32_t)off);
