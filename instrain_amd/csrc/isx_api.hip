@@ -1373,6 +1373,7 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
         return ISX_OK;
     }
     b->sizes = isx_sizes{};
+    b->ld_host = nullptr; b->n_ld_host = 0; b->link_chain = 0;
     b->sizes.n_entries = cur[CUR_ENT_TOTAL];
     b->n_ovf = b->lev_sparse ? cur[CUR_ENT_TOTAL] : cur[CUR_ENTRIES];        // (a flat table = no slabs, every entry an "overflow" entry)
     b->sizes.n_snv = cur[CUR_SNV];
@@ -1398,7 +1399,8 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
         LinkageOut lo;
         int rc = run_linkage(in, b->L, lo);
         if (rc != ISX_OK) return rc;
-        HIP_TRY(isx_wait_stream(s));
+        if (lo.chain != 3) HIP_TRY(isx_wait_stream(s));     // (the bucket chain ends with its one read-back: waited for already)
+        b->ld_host = lo.ld_host; b->n_ld_host = (size_t)lo.n_ld_host; b->link_chain = lo.chain;
         b->sizes.n_allele_obs = (int64_t)lo.n_ao;
         b->sizes.n_increments = (int64_t)lo.n_increments;
         b->sizes.n_edges = (int64_t)lo.n_edges;

@@ -124,6 +124,9 @@ struct isx_batch {
     uint32_t epoch = 0;                                   // run counter, echoed by k_publish_state
     size_t cap_entries = 0, cap_snv = 0, cap_sites = 0, cap_ao = 0;
     LinkageBuffers L;
+    const isx_ld *ld_host = nullptr;    // bucket chain: the first n_ld_host LD rows, already on the host (L.h_ld)
+    size_t n_ld_host = 0;
+    int link_chain = 0;                 // which chain the last pass took (LinkageOut::chain)
     SummaryBuffers S;
     CompareBuffers C;
     hipEvent_t ev_sum[2] = {};

@@ -1,5 +1,6 @@
 // isx_linkage.h -- host-side interface of the linkage pipeline (isx_linkage.hip)
 #pragma once
+#include <vector>
 #include "isx_internal.h"
 
 template <class T>
@@ -7,6 +8,9 @@ struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;     // elements
 };
+
+constexpr size_t LD_HEAD = 1;               // rows of ld_block in front of the LD rows (>= 64 bytes of state words)
+constexpr size_t LD_PREFIX_ROWS = 2048;     // rows that come home with the state words
 
 struct DenseSplit {         // one split of the dense MFMA path
     uint64_t xt_off;        // byte offset of its column-major X^T block
@@ -25,8 +29,14 @@ struct LinkageBuffers {
     DevBuf<uint32_t> incr_cnt, incr_off;
     DevBuf<uint64_t> keys, keys2, ukeys;
     DevBuf<uint32_t> ucnt, n_runs, rows_per, row_off;
-    DevBuf<isx_ld> ld;
+    DevBuf<isx_ld> ld_block;     // [LD_HEAD rows: the bucket chain's state words][the LD rows]
+    DevBuf<isx_ld> ld;           // a view of ld_block behind its head (cap = rows it can hold; ld_block owns the memory)
     DevBuf<uint8_t> temp;
+    // bucket chain (isx_linkage.hip): per-pair chains of the allele observations, a bucket of pair increments per first site
+    DevBuf<uint64_t> chain_head;
+    DevBuf<uint32_t> next, site_cnt, site_off, site_cur, site_nu, site_rows, site_row_off;
+    uint32_t chain_epoch = 0;
+    std::vector<isx_ld> h_ld;    // what the chain's one read-back brought: state words + the first rows
     // dense path
     DevBuf<uint64_t> key64, key64b;
     DevBuf<uint32_t> head, row_id, first_row, first_site, split_slot, tile_cnt, tile_off, vals, vals2;
@@ -58,6 +68,9 @@ struct LinkageIn {
 
 struct LinkageOut {
     uint64_t n_ao = 0, n_increments = 0, n_edges = 0, n_ld = 0;
+    const isx_ld *ld_host = nullptr;    // bucket chain: the first n_ld_host rows are on the host already (valid until the buffers' next run)
+    uint64_t n_ld_host = 0;
+    int chain = 0;                      // 1 sorted chain (rocPRIM sorts), 2 dense MFMA, 3 bucket chain
     uint64_t dense_tiles = 0, dense_bytes = 0, dense_macs = 0;   // dense path only
 };
 

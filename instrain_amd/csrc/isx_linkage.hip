@@ -154,26 +154,18 @@ __device__ __forceinline__ void major_minor(const uint32_t *c, int &maj, int &mn
     maj = order[0]; mnr = order[1];
 }
 
-// One lane per unique key; the lane holding the first key of an edge (site1, site2) walks the
-// edge's keys (ascending mm, then combo).  EMIT=false: count rows per edge.  EMIT=true: write.
+// The keys of one edge (site1, site2) from its first key `u` on: ascending mm, then combo; key >> 12 identifies the edge, bits 4..11
+// are the mm level, bits 0..3 the combo (b1, b2).  _iterator_ld_sites / _calc_ld_single (linkage.py:93-196) per mm level that both
+// sites hold.  EMIT = false counts the rows, EMIT = true writes them from out[0] on.  Returns the number of rows.
 template <bool EMIT>
-__global__ void __launch_bounds__(256) k_ld_rows(const uint64_t *ukeys, const uint32_t *ucnt, uint32_t n_u,
-                                                 SiteView v, int min_snp, uint32_t *rows_per, const uint32_t *row_off,
-                                                 isx_ld *out, uint32_t *n_edges, Philox ph, int sb)
+__device__ __forceinline__ uint32_t ld_edge_rows(const uint64_t *ukeys, const uint32_t *ucnt, uint32_t u, uint32_t n_u, uint32_t s1, uint32_t s2,
+                                                 const SiteView &v, int min_snp, isx_ld *out, const Philox &ph)
 {
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n_u) return;
-    const uint64_t k0 = ukeys[u];
-    const uint64_t edge = k0 >> 12;
-    const bool head = (u == 0) || ((ukeys[u - 1] >> 12) != edge);
-    if (!head) { if (!EMIT) rows_per[u] = 0; return; }
-    if (!EMIT) atomicAdd(n_edges, 1u);
-    const uint32_t s1 = (uint32_t)(k0 >> (12 + sb)), s2 = (uint32_t)((k0 >> 12) & ((1u << sb) - 1u));
+    const uint64_t edge = ukeys[u] >> 12;
     uint32_t combo[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) combo[i] = 0;
     uint32_t rows = 0;
-    uint32_t o = EMIT ? row_off[u] : 0;
     uint32_t i = u;
     while (i < n_u && (ukeys[i] >> 12) == edge) {
         const uint32_t mm = (uint32_t)((ukeys[i] >> 4) & 0xFFu);
@@ -267,11 +259,271 @@ __global__ void __launch_bounds__(256) k_ld_rows(const uint64_t *ukeys, const ui
                     r.d_prime_normalized = ln / (d2 < d1 ? d2 : d1);
                 }
             }
-            out[o + rows] = r;
+            out[rows] = r;
         }
         rows++;
     }
+    return rows;
+}
+
+// One lane per unique key; the lane holding the first key of an edge (site1, site2) walks the
+// edge's keys (ascending mm, then combo).  EMIT=false: count rows per edge.  EMIT=true: write.
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_ld_rows(const uint64_t *ukeys, const uint32_t *ucnt, uint32_t n_u,
+                                                 SiteView v, int min_snp, uint32_t *rows_per, const uint32_t *row_off,
+                                                 isx_ld *out, uint32_t *n_edges, Philox ph, int sb)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_u) return;
+    const uint64_t k0 = ukeys[u];
+    const uint64_t edge = k0 >> 12;
+    const bool head = (u == 0) || ((ukeys[u - 1] >> 12) != edge);
+    if (!head) { if (!EMIT) rows_per[u] = 0; return; }
+    if (!EMIT) atomicAdd(n_edges, 1u);
+    const uint32_t s1 = (uint32_t)(k0 >> (12 + sb)), s2 = (uint32_t)((k0 >> 12) & ((1u << sb) - 1u));
+    const uint32_t rows = ld_edge_rows<EMIT>(ukeys, ucnt, u, n_u, s1, s2, v, min_snp, EMIT ? out + row_off[u] : nullptr, ph);
     if (!EMIT) rows_per[u] = rows;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Bucket chain (round 6): steps 3-6 without a sort library, eight launches and one host sync a batch whatever its size.
+//   k_link_prep     split id + position of every site, the per-site counters and the chain's state words cleared
+//   k_ao_chain      k_ao_rank + every allele observation pushed onto the chain of its read pair's hash slot (an atomic exchange
+//                   on a table of (epoch, index) words: entries of an earlier batch read as "empty", so the table is never cleared)
+//   k_pair_walk<0>  every observation walks the OLDER entries of its chain: each unordered combination inside a pair is met exactly
+//                   once (itertools.combinations, linkage.py:30); counted at the site that comes first in the pair's list
+//   k_scan_u32      exclusive scan of the per-site counts -> a bucket per first site
+//   k_pair_walk<1>  the same walk writes (site2, mm, b1, b2) into the first site's bucket
+//   k_site_edges    one wave per first site: its bucket aggregated in an LDS hash table (mm2combo2counts of every edge of the
+//                   site), the unique keys sorted by (site2, mm, combo), written back over the bucket; the LD rows of its edges counted
+//   k_scan_u32      rows per site -> first row of every site
+//   k_site_ld_emit  one wave per site with rows: the rows written in (site1, site2, mm) order -- the order the sorted chain gave
+// What the host learns (increments, unique keys, edges, rows, three overflow flags) is one 64-byte read-back at the end; a table that
+// was too small is grown and the chain continues from the kernel that needed it; a site with more unique keys than the LDS table
+// holds sends the batch through the sorted chain (sparse_path) instead.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t LK_NIL = 0xFFFFFFFFu;
+constexpr int LK_SLOTS = 1024;          // LDS hash slots of a site's wave
+constexpr int LK_MAXU = 768;            // unique keys of one first site beyond which the batch takes the sorted chain
+constexpr uint64_t LK_EMPTY = ~0ull;
+enum { LS_NINC = 0, LS_NU = 1, LS_NEDGES = 2, LS_NLD = 3, LS_FLAGS = 4, LS_WORDS = 16 };
+constexpr uint32_t LKF_KEYS = 1u, LKF_BUCKET = 2u, LKF_LD = 4u;
+
+__global__ void __launch_bounds__(256) k_link_prep(const isx_site *sites, uint32_t n, const int64_t *bounds, int n_splits,
+                                                   uint32_t *site_gpos, uint32_t *site_split, uint32_t *site_cnt, uint32_t *state)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < LS_WORDS) state[i] = 0;
+    if (i >= n) return;
+    const uint32_t g = sites[i].gpos;
+    int lo = 0, hi = n_splits;          // bounds[lo] <= g < bounds[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bounds[mid] <= (int64_t)g) lo = mid; else hi = mid;
+    }
+    site_gpos[i] = g;
+    site_split[i] = (uint32_t)lo;
+    site_cnt[i] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_ao_chain(isx_ao *ao, uint32_t n, const uint32_t *site_gpos, uint32_t n_sites,
+                                                  unsigned long long *head, int hshift, uint32_t epoch, uint32_t *next)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = ao[i].site;
+    uint32_t lo = 0, hi = n_sites;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (site_gpos[mid] < g) lo = mid + 1; else hi = mid;
+    }
+    ao[i].site = lo;
+    const uint32_t h = (ao[i].pair * 0x9E3779B1u) >> hshift;
+    const unsigned long long old = atomicExch(&head[h], ((unsigned long long)epoch << 32) | i);
+    next[i] = (uint32_t)(old >> 32) == epoch ? (uint32_t)old : LK_NIL;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_pair_walk(const isx_ao *ao, uint32_t n, const uint32_t *next, const uint32_t *site_split,
+                                                   uint32_t *site_cnt, const uint32_t *site_off, uint64_t *keys, uint64_t cap_keys,
+                                                   uint32_t *state)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (EMIT && (uint64_t)state[LS_NINC] > cap_keys) {       // the buckets do not fit: the host grows them and comes back
+        if (i == 0) atomicOr(&state[LS_FLAGS], LKF_KEYS);
+        return;
+    }
+    if (i >= n) return;
+    const isx_ao a = ao[i];
+    const uint32_t sa = site_split[a.site];
+    for (uint32_t j = next[i]; j != LK_NIL; j = next[j]) {
+        const isx_ao b = ao[j];
+        if (b.pair != a.pair) continue;                      // another pair on the same hash slot
+        if (site_split[b.site] != sa) continue;              // read_to_snvs is per profile_split call
+        // list order = (column, arrival order inside the column)
+        const bool a_first = (a.site < b.site) || (a.site == b.site && a.obs_idx < b.obs_idx);
+        const uint32_t s1 = a_first ? a.site : b.site;
+        const uint32_t slot = atomicAdd(&site_cnt[s1], 1u);
+        if (EMIT) keys[site_off[s1] + slot] = a_first ? make_key(0, 0, b.site, a.mm, a.base, b.base) : make_key(0, 0, a.site, a.mm, b.base, a.base);
+    }
+}
+
+// exclusive scan of in[0, n) into out[0, n] (out[n] = the total, also stored to *total) by ONE workgroup; `zero` (optional) is cleared
+// along the way -- the cursors the next kernel fills the buckets with
+__global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, uint32_t *zero)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    __shared__ unsigned long long total_s;      // (the offsets are 32-bit: a total that is not is reported as 0xFFFFFFFF)
+    const uint32_t t = threadIdx.x, l = t & 63, w = t >> 6;
+    if (t == 0) { carry_s = 0; total_s = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t i0 = base + 4 * t;
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { v[q] = i0 + q < n ? in[i0 + q] : 0u; if (zero && i0 + q < n) zero[i0 + q] = 0; }
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if ((int)l >= d) inc += o; }
+        if (l == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (uint32_t q = 0; q < w; q++) before += wsum[q];
+        uint32_t run = before + inc - mine;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { if (i0 + q < n) out[i0 + q] = run; run += v[q]; }
+        __syncthreads();
+        if (t == 1023) { total_s += (unsigned long long)(run - carry_s); carry_s = run; }
+        __syncthreads();
+    }
+    if (t == 0) { const uint32_t tot = total_s > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)total_s; out[n] = tot; *total = tot; }
+}
+
+__device__ __forceinline__ uint32_t lk_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 40); }
+
+// one wave per first site
+__global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucnt, uint32_t *rows_per, const uint32_t *site_off, uint32_t n_sites,
+                                                   SiteView v, int min_snp, uint32_t *site_nu, uint32_t *site_rows, uint32_t *state, Philox ph,
+                                                   uint32_t max_u)
+{
+    __shared__ unsigned long long tk[LK_SLOTS];
+    __shared__ uint32_t tc[LK_SLOTS];
+    const uint32_t s1 = blockIdx.x, l = threadIdx.x;
+    if (state[LS_FLAGS] & LKF_KEYS) return;
+    const uint32_t off = site_off[s1], n_b = site_off[s1 + 1] - off;
+    if (n_b == 0) { if (l == 0) { site_nu[s1] = 0; site_rows[s1] = 0; } return; }
+    for (uint32_t q = l; q < LK_SLOTS; q += 64) { tk[q] = LK_EMPTY; tc[q] = 0; }
+    __syncthreads();
+    // mm2combo2counts of every edge of this site: key -> count
+    uint32_t nu = 0;
+    bool full = false;
+    for (uint32_t c = 0; c < n_b && !full; c += 64) {
+        const bool have = c + l < n_b;
+        const uint64_t k = have ? keys[off + c + l] : 0;
+        bool fresh = false;
+        if (have) {
+            uint32_t slot = lk_hash(k) & (LK_SLOTS - 1);
+            for (;;) {
+                const unsigned long long old = atomicCAS(&tk[slot], LK_EMPTY, (unsigned long long)k);
+                if (old == LK_EMPTY || old == k) { fresh = old == LK_EMPTY; atomicAdd(&tc[slot], 1u); break; }
+                slot = (slot + 1) & (LK_SLOTS - 1);
+            }
+        }
+        nu += (uint32_t)__popcll(__ballot(fresh));
+        full = nu > max_u;                                    // (wave-uniform; the table can take 64 more than LK_MAXU before it is full)
+    }
+    if (full) {                                                 // too many different keys for the table: the sorted chain takes the batch
+        if (l == 0) { atomicOr(&state[LS_FLAGS], LKF_BUCKET); site_nu[s1] = 0; site_rows[s1] = 0; }
+        return;
+    }
+    __syncthreads();
+    // compact in place (the write cursor never passes the slots being read), pad to a power of two, bitonic sort by key
+    uint32_t base = 0;
+    for (uint32_t r = 0; r < LK_SLOTS; r += 64) {
+        const unsigned long long k = tk[r + l];
+        const uint32_t c = tc[r + l];
+        const bool valid = k != LK_EMPTY;
+        const unsigned long long bal = __ballot(valid);
+        const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << l) - 1ull));
+        __syncthreads();
+        if (valid) { tk[base + rank] = k; tc[base + rank] = c; }
+        base += (uint32_t)__popcll(bal);
+        __syncthreads();
+    }
+    uint32_t n_pad = 64;
+    while (n_pad < nu) n_pad <<= 1;
+    for (uint32_t q = nu + l; q < n_pad; q += 64) { tk[q] = LK_EMPTY; tc[q] = 0; }
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= n_pad; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = l; t < n_pad / 2; t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                const bool up = (i & kk) == 0;
+                const unsigned long long x = tk[i], y = tk[p];
+                if ((x > y) == up) {
+                    const uint32_t cx = tc[i], cy = tc[p];
+                    tk[i] = y; tk[p] = x; tc[i] = cy; tc[p] = cx;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // the unique keys back over the bucket (k_site_ld_emit reads them), rows per edge
+    uint32_t rows_sum = 0, heads = 0;
+    for (uint32_t u = l; u < nu; u += 64) {
+        const uint64_t k = tk[u];
+        keys[off + u] = k;
+        ucnt[off + u] = tc[u];
+        const bool head = u == 0 || (tk[u - 1] >> 12) != (k >> 12);
+        uint32_t rows = 0;
+        if (head) {
+            rows = ld_edge_rows<false>(reinterpret_cast<const uint64_t *>(tk), tc, u, nu, s1, (uint32_t)(k >> 12), v, min_snp, nullptr, ph);
+            heads++;
+        }
+        rows_per[off + u] = rows;
+        rows_sum += rows;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { rows_sum += __shfl_xor(rows_sum, d); heads += __shfl_xor(heads, d); }
+    if (l == 0) {
+        site_nu[s1] = nu; site_rows[s1] = rows_sum;
+        atomicAdd(&state[LS_NU], nu);
+        atomicAdd(&state[LS_NEDGES], heads);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_site_ld_emit(const uint64_t *keys, const uint32_t *ucnt, const uint32_t *rows_per, const uint32_t *site_off,
+                                                     const uint32_t *site_nu, const uint32_t *site_rows, const uint32_t *site_row_off,
+                                                     SiteView v, int min_snp, isx_ld *out, uint64_t cap_ld, uint32_t *state, Philox ph)
+{
+    __shared__ unsigned long long tk[LK_SLOTS];
+    __shared__ uint32_t tc[LK_SLOTS];
+    const uint32_t s1 = blockIdx.x, l = threadIdx.x;
+    if (state[LS_FLAGS] & (LKF_KEYS | LKF_BUCKET)) return;
+    if ((uint64_t)state[LS_NLD] > cap_ld) { if (s1 == 0 && l == 0) atomicOr(&state[LS_FLAGS], LKF_LD); return; }
+    if (site_rows[s1] == 0) return;
+    const uint32_t off = site_off[s1], nu = site_nu[s1];
+    for (uint32_t u = l; u < nu; u += 64) { tk[u] = keys[off + u]; tc[u] = ucnt[off + u]; }
+    __syncthreads();
+    uint32_t carry = site_row_off[s1];
+    for (uint32_t c = 0; c < nu; c += 64) {
+        const uint32_t u = c + l;
+        const uint32_t r = u < nu ? rows_per[off + u] : 0u;
+        uint32_t inc = r;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if ((int)l >= d) inc += o; }
+        if (r) (void)ld_edge_rows<true>(reinterpret_cast<const uint64_t *>(tk), tc, u, nu, s1, (uint32_t)(tk[u] >> 12), v, min_snp, out + carry + inc - r, ph);
+        carry += __shfl(inc, 63);
+    }
+}
+
+__global__ void k_ao_pair_keys(const isx_ao *ao, uint32_t n, uint32_t *ao_key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ao_key[i] = ao[i].pair;
 }
 
 
@@ -472,6 +724,16 @@ int ensure(DevBuf<T> &b, size_t n)
 
 int ensure_temp(DevBuf<uint8_t> &b, size_t bytes) { return ensure(b, bytes); }
 
+// room for n LD rows behind the head of ld_block
+int ensure_ld(LinkageBuffers &B, size_t n)
+{
+    const int rc = ensure(B.ld_block, n + LD_HEAD);
+    if (rc) return rc;
+    B.ld.p = B.ld_block.p + LD_HEAD;
+    B.ld.cap = B.ld_block.cap - LD_HEAD;
+    return ISX_OK;
+}
+
 inline int bits_for(uint64_t n)
 {
     int b = 1;
@@ -485,7 +747,7 @@ void LinkageBuffers::release()
 {
     void *ps[] = {site_keys.p, site_keys2.p, sites_sorted.p, site_gpos.p, site_split.p, ao_key.p, ao2.p,
                   ao_key2.p, incr_cnt.p, incr_off.p, keys.p, keys2.p, ukeys.p, ucnt.p, n_runs.p, rows_per.p,
-                  row_off.p, ld.p, temp.p, key64.p, key64b.p, head.p, row_id.p, first_row.p, first_site.p,
+                  row_off.p, ld_block.p, temp.p, chain_head.p, next.p, site_cnt.p, site_off.p, site_cur.p, site_nu.p, site_rows.p, site_row_off.p, key64.p, key64b.p, head.p, row_id.p, first_row.p, first_site.p,
                   split_slot.p, tile_cnt.p, tile_off.p, vals.p, vals2.p, dsplits.p, dtiles.p, xt.p};
     for (void *p : ps) if (p) isx_dev_free(p);
     *this = LinkageBuffers();
@@ -550,6 +812,116 @@ int sparse_path(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, uint32_
     HIP_TRY(isx_read_back(&n_u, B.n_runs.p, 4, s));
     EV(4);
     HIP_TRY(isx_read_sync(s));
+    return ISX_OK;
+}
+
+// steps 3-6 as the bucket chain (kernels above); *fell_back: a site's keys did not fit the LDS table, nothing of the chain's output is valid
+int bucket_chain(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, const isx_site *sites_sorted, bool *fell_back)
+{
+    hipStream_t s = in.stream;
+    int rc;
+    *fell_back = false;
+    const uint32_t n_ao = in.n_ao, n_sites = in.n_sites;
+    int logH = 12;
+    while (logH < 31 && (1ull << logH) < 2ull * n_ao) logH++;
+    const size_t H = (size_t)1 << logH;
+    if (B.chain_head.cap < H || !B.chain_head.p) {
+        if ((rc = ensure(B.chain_head, H))) return rc;
+        HIP_TRY(hipMemsetAsync(B.chain_head.p, 0, B.chain_head.cap * sizeof(uint64_t), s));
+        B.chain_epoch = 0;
+    }
+    if (++B.chain_epoch == 0) {                                 // 2^32 batches later: the tags start over
+        HIP_TRY(hipMemsetAsync(B.chain_head.p, 0, B.chain_head.cap * sizeof(uint64_t), s));
+        B.chain_epoch = 1;
+    }
+    size_t cap_keys = std::max<size_t>(B.keys.cap, std::max<size_t>((size_t)n_ao * 2, 65536));
+    size_t cap_ld = std::max<size_t>(B.ld_block.cap > LD_HEAD ? B.ld_block.cap - LD_HEAD : 0, 4096);
+    static_assert(sizeof(isx_ld) * LD_HEAD >= LS_WORDS * sizeof(uint32_t), "the state words fit the head of ld_block");
+    // test aids: ISX_LINK_MAXU = unique keys a site may have before the batch falls back (<= LK_MAXU); ISX_LINK_TEST_CAPS = "keys,rows":
+    // what the first attempt tells the kernels the tables hold (the growth steps without a batch that needs them)
+    uint32_t max_u = LK_MAXU;
+    if (const char *e = getenv("ISX_LINK_MAXU")) max_u = (uint32_t)std::min<long>(std::max<long>(atol(e), 1), LK_MAXU);
+    size_t test_keys = 0, test_ld = 0;
+    if (const char *e = getenv("ISX_LINK_TEST_CAPS")) { unsigned long a = 0, b = 0; if (sscanf(e, "%lu,%lu", &a, &b) == 2) { test_keys = a; test_ld = b; } }
+    auto size_tables = [&]() -> int {
+        int r;
+        if ((r = ensure(B.keys, cap_keys)) || (r = ensure(B.ucnt, cap_keys)) || (r = ensure(B.rows_per, cap_keys))) return r;
+        cap_keys = std::min(std::min(B.keys.cap, B.ucnt.cap), B.rows_per.cap);
+        return ISX_OK;
+    };
+    auto size_ld = [&]() -> int {
+        const int r = ensure_ld(B, cap_ld);
+        if (r) return r;
+        cap_ld = B.ld.cap;
+        return ISX_OK;
+    };
+    if ((rc = ensure(B.next, n_ao)) || (rc = ensure(B.site_cnt, (size_t)n_sites + 1)) || (rc = ensure(B.site_off, (size_t)n_sites + 1)) ||
+        (rc = ensure(B.site_cur, (size_t)n_sites + 1)) || (rc = ensure(B.site_nu, n_sites)) || (rc = ensure(B.site_rows, (size_t)n_sites + 1)) ||
+        (rc = ensure(B.site_row_off, (size_t)n_sites + 1)) || (rc = size_tables()) || (rc = size_ld())) return rc;
+    uint32_t *state = reinterpret_cast<uint32_t *>(B.ld_block.p);           // the chain's state words live in front of the rows: one read-back
+    const dim3 blk(256), g_sites((n_sites + 255) / 256), g_ao((n_ao + 255) / 256);
+    SiteView v{sites_sorted, in.slev, in.snv, in.M == 1 ? 1 : 0};
+    hipLaunchKernelGGL(k_link_prep, g_sites, blk, 0, s, sites_sorted, n_sites, in.split_bounds, in.n_splits, B.site_gpos.p, B.site_split.p,
+                       B.site_cnt.p, state);
+    EV(1);
+    hipLaunchKernelGGL(k_ao_chain, g_ao, blk, 0, s, in.ao, n_ao, B.site_gpos.p, n_sites, reinterpret_cast<unsigned long long *>(B.chain_head.p),
+                       32 - logH, B.chain_epoch, B.next.p);
+    EV(2);
+    hipLaunchKernelGGL((k_pair_walk<false>), g_ao, blk, 0, s, in.ao, n_ao, B.next.p, B.site_split.p, B.site_cnt.p, nullptr, nullptr, (uint64_t)0, state);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, B.site_cnt.p, B.site_off.p, n_sites, state + LS_NINC, B.site_cur.p);
+    uint32_t h[LS_WORDS] = {0};
+    for (int stage = 0, attempt = 0;; attempt++) {               // stage 0: from the buckets on; 1: the rows only (after a table grew)
+        if (attempt == 4) { isx_set_error("linkage tables still too small after three growth steps"); return ISX_ERR_CAPACITY; }
+        if (stage == 0) {
+            hipLaunchKernelGGL((k_pair_walk<true>), g_ao, blk, 0, s, in.ao, n_ao, B.next.p, B.site_split.p, B.site_cur.p, B.site_off.p, B.keys.p,
+                               (uint64_t)(attempt == 0 && test_keys ? std::min(test_keys, cap_keys) : cap_keys), state);
+            EV(3);
+            hipLaunchKernelGGL(k_site_edges, dim3(n_sites), dim3(64), 0, s, B.keys.p, B.ucnt.p, B.rows_per.p, B.site_off.p, n_sites, v, in.min_snp,
+                               B.site_nu.p, B.site_rows.p, state, in.philox, max_u);
+            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, B.site_rows.p, B.site_row_off.p, n_sites, state + LS_NLD, (uint32_t *)nullptr);
+            EV(4);
+        }
+        hipLaunchKernelGGL(k_site_ld_emit, dim3(n_sites), dim3(64), 0, s, B.keys.p, B.ucnt.p, B.rows_per.p, B.site_off.p, B.site_nu.p, B.site_rows.p,
+                           B.site_row_off.p, v, in.min_snp, B.ld.p, (uint64_t)(attempt == 0 && test_ld ? std::min(test_ld, cap_ld) : cap_ld), state, in.philox);
+        HIP_TRY(hipGetLastError());
+        // the state words and, with them, the first rows (most batches of a metagenome have a few hundred): one copy, one wait
+        const size_t n_pre = std::min<size_t>(cap_ld, LD_PREFIX_ROWS);
+        B.h_ld.resize(LD_HEAD + n_pre);
+        HIP_TRY(isx_read_back(B.h_ld.data(), B.ld_block.p, (LD_HEAD + n_pre) * sizeof(isx_ld), s));
+        EV(5);
+        HIP_TRY(isx_read_sync(s));
+        memcpy(h, B.h_ld.data(), sizeof(h));
+        if (h[LS_FLAGS] & LKF_KEYS) {
+            if (h[LS_NINC] == 0xFFFFFFFFu) { isx_set_error("more than 2^32 pair increments in one batch"); return ISX_ERR_CAPACITY; }
+            cap_keys = (size_t)h[LS_NINC] + h[LS_NINC] / 4 + 4096;
+            B.keys.cap = B.ucnt.cap = B.rows_per.cap = 0;        // (ensure() frees and reallocates: nothing in them is needed)
+            if ((rc = size_tables())) return rc;
+            HIP_TRY(hipMemsetAsync(state + LS_NU, 0, (LS_WORDS - LS_NU) * sizeof(uint32_t), s));
+            HIP_TRY(hipMemsetAsync(B.site_cur.p, 0, ((size_t)n_sites + 1) * sizeof(uint32_t), s));
+            stage = 0;
+            continue;
+        }
+        if (h[LS_FLAGS] & LKF_BUCKET) { *fell_back = true; return ISX_OK; }
+        if (h[LS_FLAGS] & LKF_LD) {
+            if (h[LS_NLD] == 0xFFFFFFFFu) { isx_set_error("more than 2^32 LD rows in one batch"); return ISX_ERR_CAPACITY; }
+            // (the state words sit in the block that is about to move: they are put back in front of the new rows)
+            cap_ld = (size_t)h[LS_NLD] + h[LS_NLD] / 4 + 4096;
+            B.ld_block.cap = 0;
+            if ((rc = size_ld())) return rc;
+            state = reinterpret_cast<uint32_t *>(B.ld_block.p);
+            h[LS_FLAGS] &= ~LKF_LD;
+            HIP_TRY(hipMemcpyAsync(state, h, sizeof(h), hipMemcpyHostToDevice, s));
+            HIP_TRY(isx_wait_stream(s));
+            stage = 1;
+            continue;
+        }
+        break;
+    }
+    out.n_increments = h[LS_NINC];
+    out.n_edges = h[LS_NEDGES];
+    out.n_ld = h[LS_NLD];
+    out.ld_host = B.h_ld.data() + LD_HEAD;
+    out.n_ld_host = std::min<uint64_t>(out.n_ld, B.h_ld.size() - LD_HEAD);
     return ISX_OK;
 }
 
@@ -698,20 +1070,32 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
                                      B.sites_sorted.p, n_sites, 0, 32, s));
         sites_sorted = B.sites_sorted.p;
     }
-    hipLaunchKernelGGL(k_site_split, dim3((n_sites + 255) / 256), dim3(256), 0, s, sites_sorted, n_sites,
-                       in.split_bounds, in.n_splits, B.site_gpos.p, B.site_split.p);
-    tick("site sort enqueued");
-    EV(1);
-
     // ---- 2. allele observations (produced by the pileup kernel): position -> site rank ----
     const uint32_t n_ao = in.n_ao;
     out.n_ao = n_ao;
+    // ISX_LINK_CHAIN=sorted: steps 3-6 through the device-wide sorts (the round-2 chain, kept as the bucket chain's fallback and its check)
+    const char *chain_env = getenv("ISX_LINK_CHAIN");
+    const bool bucket = in.mode != 2 && n_ao != 0 && !(chain_env && !strcmp(chain_env, "sorted"));
+    bool ranked = false;
+    if (bucket) {
+        bool fell_back = false;
+        if ((rc = bucket_chain(in, B, out, sites_sorted, &fell_back)) != ISX_OK) return rc;
+        tick("bucket chain");
+        if (!fell_back) { out.chain = 3; return ISX_OK; }
+        ranked = true;                                      // (k_link_prep / k_ao_chain have run: sites split, observations ranked)
+    } else {
+        hipLaunchKernelGGL(k_site_split, dim3((n_sites + 255) / 256), dim3(256), 0, s, sites_sorted, n_sites,
+                           in.split_bounds, in.n_splits, B.site_gpos.p, B.site_split.p);
+        tick("site sort enqueued");
+        EV(1);
+    }
     if (n_ao == 0) { EV(2); EV(3); EV(4); EV(5); return ISX_OK; }
     if ((rc = ensure(B.ao_key, n_ao)) || (rc = ensure(B.ao2, n_ao)) || (rc = ensure(B.ao_key2, n_ao))) return rc;
     tick("ao buffers");
-    hipLaunchKernelGGL(k_ao_rank, dim3((n_ao + 255) / 256), dim3(256), 0, s, in.ao, n_ao, B.site_gpos.p, n_sites,
-                       B.ao_key.p);
+    if (ranked) hipLaunchKernelGGL(k_ao_pair_keys, dim3((n_ao + 255) / 256), dim3(256), 0, s, in.ao, n_ao, B.ao_key.p);
+    else hipLaunchKernelGGL(k_ao_rank, dim3((n_ao + 255) / 256), dim3(256), 0, s, in.ao, n_ao, B.site_gpos.p, n_sites, B.ao_key.p);
     EV(2);
+    out.chain = in.mode == 2 ? 2 : 1;
 
     // ---- 3-5. co-occurrence counts as sorted unique keys ----
     uint32_t n_u = 0;
@@ -736,7 +1120,7 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
     out.n_edges = n_edges;
     out.n_ld = n_ld;
     if (n_ld) {
-        if ((rc = ensure(B.ld, n_ld))) return rc;
+        if ((rc = ensure_ld(B, n_ld))) return rc;
         hipLaunchKernelGGL(k_ld_rows<true>, dim3((n_u + 255) / 256), dim3(256), 0, s, B.ukeys.p, B.ucnt.p, n_u, v,
                            in.min_snp, nullptr, B.row_off.p, B.ld.p, nullptr, in.philox, sb);
     }

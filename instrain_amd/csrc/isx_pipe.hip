@@ -725,7 +725,8 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
     if (p->prm.enable_linkage) {
         // the LD rows too: a blocking copy issued by the caller would queue behind the next batches' large transfers
         s.ld_rows.resize((size_t)b->sizes.n_ld);
-        if (!s.ld_rows.empty()) { const int rc = pull(s.ld_rows.data(), b->L.ld.p, s.ld_rows.size() * sizeof(isx_ld)); if (rc != ISX_OK) return rc; }
+        if (!s.ld_rows.empty() && b->ld_host && s.ld_rows.size() <= b->n_ld_host) memcpy(s.ld_rows.data(), b->ld_host, s.ld_rows.size() * sizeof(isx_ld));   // came home with the chain's state words
+        else if (!s.ld_rows.empty()) { const int rc = pull(s.ld_rows.data(), b->L.ld.p, s.ld_rows.size() * sizeof(isx_ld)); if (rc != ISX_OK) return rc; }
     }
     s.rows_checksum = bytes_checksum(s.ld_rows.data(), p->prm.enable_linkage ? s.ld_rows.size() * sizeof(isx_ld) : 0, bytes_checksum(rows, n_snv * sizeof(isx_snv), 0));
     if (getenv("ISX_PIPE_TIMING"))      // tuning aid (stderr only)
