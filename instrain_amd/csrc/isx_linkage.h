@@ -34,7 +34,8 @@ struct LinkageBuffers {
     DevBuf<uint8_t> temp;
     // bucket chain (isx_linkage.hip): per-pair chains of the allele observations, a bucket of pair increments per first site
     DevBuf<uint64_t> chain_head;
-    DevBuf<uint32_t> next, site_cnt, site_off, site_cur, site_nu, site_rows, site_row_off;
+    DevBuf<uint32_t> next, site_cnt, site_off, site_cur, site_nu, site_rows, site_row_off, site_list1, site_list2;
+    DevBuf<uint64_t> edge_list;  // (site1, index of the edge's first key in the site's bucket) as uint2
     uint32_t chain_epoch = 0;
     std::vector<isx_ld> h_ld;    // what the chain's one read-back brought: state words + the first rows
     // dense path

@@ -287,31 +287,33 @@ __global__ void __launch_bounds__(256) k_ld_rows(const uint64_t *ukeys, const ui
 
 
 // ------------------------------------------------------------------------------------------
-// Bucket chain (round 6): steps 3-6 without a sort library, eight launches and one host sync a batch whatever its size.
+// Bucket chain (round 6): steps 3-6 without a sort library, nine launches and one host sync a batch whatever its size.
 //   k_link_prep     split id + position of every site, the per-site counters and the chain's state words cleared
-//   k_ao_chain      k_ao_rank + every allele observation pushed onto the chain of its read pair's hash slot (an atomic exchange
-//                   on a table of (epoch, index) words: entries of an earlier batch read as "empty", so the table is never cleared)
+//   k_ao_chain      k_ao_rank + every allele observation pushed onto the chain of its read pair (an atomic exchange on a table of
+//                   (epoch, index) words: entries of an earlier batch read as "empty", so the table is never cleared)
 //   k_pair_walk<0>  every observation walks the OLDER entries of its chain: each unordered combination inside a pair is met exactly
 //                   once (itertools.combinations, linkage.py:30); counted at the site that comes first in the pair's list
-//   k_scan_u32      exclusive scan of the per-site counts -> a bucket per first site
+//   k_scan_u32      exclusive scan of the per-site counts -> a bucket per first site, the list of sites that have one
 //   k_pair_walk<1>  the same walk writes (site2, mm, b1, b2) into the first site's bucket
 //   k_site_edges    one wave per first site: its bucket aggregated in an LDS hash table (mm2combo2counts of every edge of the
-//                   site), the unique keys sorted by (site2, mm, combo), written back over the bucket; the LD rows of its edges counted
+//                   site), the unique keys sorted by (site2, mm, combo) and written back over the bucket; its edges on the edge list
+//   k_edge_rows<0>  one lane per edge: its LD rows counted
 //   k_scan_u32      rows per site -> first row of every site
-//   k_site_ld_emit  one wave per site with rows: the rows written in (site1, site2, mm) order -- the order the sorted chain gave
-// What the host learns (increments, unique keys, edges, rows, three overflow flags) is one 64-byte read-back at the end; a table that
-// was too small is grown and the chain continues from the kernel that needed it; a site with more unique keys than the LDS table
-// holds sends the batch through the sorted chain (sparse_path) instead.
+//   k_edge_rows<1>  one lane per edge: the rows written behind those of the site's earlier edges -- (site1, site2, mm) order, as the sorted chain
+// What the host learns (increments, unique keys, edges, rows, three overflow flags) comes with the first 2048 rows in one read-back at the
+// end; a table that was too small is grown and the chain continues from the kernel that needed it; a site with more unique keys than the
+// LDS table holds sends the batch through the sorted chain (sparse_path) instead.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t LK_NIL = 0xFFFFFFFFu;
 constexpr int LK_SLOTS = 1024;          // LDS hash slots of a site's wave
 constexpr int LK_MAXU = 768;            // unique keys of one first site beyond which the batch takes the sorted chain
 constexpr uint64_t LK_EMPTY = ~0ull;
-enum { LS_NINC = 0, LS_NU = 1, LS_NEDGES = 2, LS_NLD = 3, LS_FLAGS = 4, LS_WORDS = 16 };
+constexpr uint32_t LK_STAGE = 256;
+enum { LS_NINC = 0, LS_NU = 1, LS_NEDGES = 2, LS_NLD = 3, LS_FLAGS = 4, LS_NLIST1 = 5 /* sites with increments */, LS_NLIST2 = 6 /* sites with rows */, LS_WORDS = 16 };
 constexpr uint32_t LKF_KEYS = 1u, LKF_BUCKET = 2u, LKF_LD = 4u;
 
 __global__ void __launch_bounds__(256) k_link_prep(const isx_site *sites, uint32_t n, const int64_t *bounds, int n_splits,
-                                                   uint32_t *site_gpos, uint32_t *site_split, uint32_t *site_cnt, uint32_t *state)
+                                                   uint32_t *site_gpos, uint32_t *site_split, uint32_t *site_cnt, uint32_t *site_rows, uint32_t *state)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < LS_WORDS) state[i] = 0;
@@ -325,10 +327,11 @@ __global__ void __launch_bounds__(256) k_link_prep(const isx_site *sites, uint32
     site_gpos[i] = g;
     site_split[i] = (uint32_t)lo;
     site_cnt[i] = 0;
+    site_rows[i] = 0;
 }
 
 __global__ void __launch_bounds__(256) k_ao_chain(isx_ao *ao, uint32_t n, const uint32_t *site_gpos, uint32_t n_sites,
-                                                  unsigned long long *head, int hshift, uint32_t epoch, uint32_t *next)
+                                                  unsigned long long *head, int hshift, uint32_t direct, uint32_t epoch, uint32_t *next)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -339,7 +342,10 @@ __global__ void __launch_bounds__(256) k_ao_chain(isx_ao *ao, uint32_t n, const 
         if (site_gpos[mid] < g) lo = mid + 1; else hi = mid;
     }
     ao[i].site = lo;
-    const uint32_t h = (ao[i].pair * 0x9E3779B1u) >> hshift;
+    // the slot of the pair: its id when the table has one per pair (`direct` = its size: the observations of a site come from reads
+    // with neighbouring ids, so do their slots; no two pairs share a chain), a multiplicative hash otherwise
+    const uint32_t pr = ao[i].pair;
+    const uint32_t h = pr < direct ? pr : (pr * 0x9E3779B1u) >> hshift;
     const unsigned long long old = atomicExch(&head[h], ((unsigned long long)epoch << 32) | i);
     next[i] = (uint32_t)(old >> 32) == epoch ? (uint32_t)old : LK_NIL;
 }
@@ -349,174 +355,248 @@ __global__ void __launch_bounds__(256) k_pair_walk(const isx_ao *ao, uint32_t n,
                                                    uint32_t *site_cnt, const uint32_t *site_off, uint64_t *keys, uint64_t cap_keys,
                                                    uint32_t *state)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, l = threadIdx.x & 63;
     if (EMIT && (uint64_t)state[LS_NINC] > cap_keys) {       // the buckets do not fit: the host grows them and comes back
         if (i == 0) atomicOr(&state[LS_FLAGS], LKF_KEYS);
         return;
     }
-    if (i >= n) return;
-    const isx_ao a = ao[i];
-    const uint32_t sa = site_split[a.site];
-    for (uint32_t j = next[i]; j != LK_NIL; j = next[j]) {
-        const isx_ao b = ao[j];
-        if (b.pair != a.pair) continue;                      // another pair on the same hash slot
-        if (site_split[b.site] != sa) continue;              // read_to_snvs is per profile_split call
-        // list order = (column, arrival order inside the column)
-        const bool a_first = (a.site < b.site) || (a.site == b.site && a.obs_idx < b.obs_idx);
-        const uint32_t s1 = a_first ? a.site : b.site;
-        const uint32_t slot = atomicAdd(&site_cnt[s1], 1u);
-        if (EMIT) keys[site_off[s1] + slot] = a_first ? make_key(0, 0, b.site, a.mm, a.base, b.base) : make_key(0, 0, a.site, a.mm, b.base, a.base);
+    isx_ao a{};
+    uint32_t sa = 0, j = LK_NIL;
+    if (i < n) { a = ao[i]; sa = site_split[a.site]; j = next[i]; }
+    while (__ballot(j != LK_NIL)) {                          // (wave-uniform: the lanes' slots are taken together below)
+        bool hit = false;
+        uint32_t s1 = 0;
+        uint64_t key = 0;
+        if (j != LK_NIL) {
+            const isx_ao b = ao[j];
+            const uint32_t nj = next[j];
+            if (b.pair == a.pair && site_split[b.site] == sa) {      // (another pair on the same hash slot; read_to_snvs is per profile_split call)
+                hit = true;
+                // list order = (column, arrival order inside the column)
+                const bool a_first = (a.site < b.site) || (a.site == b.site && a.obs_idx < b.obs_idx);
+                s1 = a_first ? a.site : b.site;
+                if (EMIT) key = a_first ? make_key(0, 0, b.site, a.mm, a.base, b.base) : make_key(0, 0, a.site, a.mm, b.base, a.base);
+            }
+            j = nj;
+        }
+        // one atomic per first site and wave step: the observations of a site sit side by side, so most lanes of a wave ask for the same counter
+        unsigned long long m = __ballot(hit);
+        uint32_t slot = 0;
+        while (m) {
+            const int leader = __builtin_ctzll(m);
+            const uint32_t ls1 = __shfl(s1, leader);
+            const bool mine = hit && s1 == ls1;
+            const unsigned long long same = __ballot(mine);
+            uint32_t base = 0;
+            if ((int)l == leader) base = atomicAdd(&site_cnt[ls1], (uint32_t)__popcll(same));
+            if (EMIT) {
+                base = __shfl(base, leader);
+                if (mine) slot = base + (uint32_t)__popcll(same & ((1ull << l) - 1ull));
+            }
+            m &= ~same;
+        }
+        if (EMIT && hit) keys[site_off[s1] + slot] = key;
     }
 }
 
 // exclusive scan of in[0, n) into out[0, n] (out[n] = the total, also stored to *total) by ONE workgroup; `zero` (optional) is cleared
-// along the way -- the cursors the next kernel fills the buckets with
-__global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, uint32_t *zero)
+// along the way -- the cursors the next kernel fills the buckets with; `list` receives the indices with in[i] != 0, ascending, *n_list
+// their number (the next kernel's waves walk that list: a metagenome batch has increments at a tenth of its sites)
+__global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, uint32_t *zero,
+                                                   uint32_t *list, uint32_t *n_list)
 {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
+    // a thread owns four consecutive elements of a 4096-element tile (one 16-byte load, 16-byte stores: whole lines per wave instruction --
+    // sixteen elements a thread made every store touch 64 lines); the next tile's load is in flight while this one is scanned
+    __shared__ uint32_t wsum[16], wnz[16];
+    __shared__ uint32_t carry_s, carry_nz;
     __shared__ unsigned long long total_s;      // (the offsets are 32-bit: a total that is not is reported as 0xFFFFFFFF)
     const uint32_t t = threadIdx.x, l = t & 63, w = t >> 6;
-    if (t == 0) { carry_s = 0; total_s = 0; }
+    if (t == 0) { carry_s = 0; carry_nz = 0; total_s = 0; }
     __syncthreads();
+    auto load4 = [&](uint32_t i0) -> uint4 {
+        if (i0 + 4 <= n) return *reinterpret_cast<const uint4 *>(in + i0);       // (hipMalloc'ed arrays: 16-byte aligned)
+        uint4 x;
+        x.x = i0 < n ? in[i0] : 0u; x.y = i0 + 1 < n ? in[i0 + 1] : 0u; x.z = i0 + 2 < n ? in[i0 + 2] : 0u; x.w = 0u;
+        return x;
+    };
+    uint4 nxt = load4(4 * t);
     for (uint32_t base = 0; base < n; base += 4096) {
         const uint32_t i0 = base + 4 * t;
-        uint32_t v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) { v[q] = i0 + q < n ? in[i0 + q] : 0u; if (zero && i0 + q < n) zero[i0 + q] = 0; }
+        const uint4 x = nxt;
+        if (base + 4096 < n) nxt = load4(i0 + 4096);
+        const uint32_t v[4] = {x.x, x.y, x.z, x.w};
         const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-        uint32_t inc = mine;
+        const uint32_t mine_nz = (v[0] != 0) + (v[1] != 0) + (v[2] != 0) + (v[3] != 0);
+        uint32_t inc = mine, inz = mine_nz;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if ((int)l >= d) inc += o; }
-        if (l == 63) wsum[w] = inc;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d), oz = __shfl_up(inz, d);
+            if ((int)l >= d) { inc += o; inz += oz; }
+        }
+        if (l == 63) { wsum[w] = inc; wnz[w] = inz; }
         __syncthreads();
-        uint32_t before = carry_s;
-        for (uint32_t q = 0; q < w; q++) before += wsum[q];
-        uint32_t run = before + inc - mine;
+        uint32_t before = carry_s, before_nz = carry_nz;
+        for (uint32_t q = 0; q < w; q++) { before += wsum[q]; before_nz += wnz[q]; }
+        uint32_t run = before + inc - mine, rnz = before_nz + inz - mine_nz;
+        uint4 o;
+        o.x = run; o.y = run + v[0]; o.z = o.y + v[1]; o.w = o.z + v[2];
+        run = o.w + v[3];
+        if (i0 + 4 <= n) {
+            *reinterpret_cast<uint4 *>(out + i0) = o;
+            if (zero) *reinterpret_cast<uint4 *>(zero + i0) = make_uint4(0, 0, 0, 0);
+        } else {
+            if (i0 < n) { out[i0] = o.x; if (zero) zero[i0] = 0; }
+            if (i0 + 1 < n) { out[i0 + 1] = o.y; if (zero) zero[i0 + 1] = 0; }
+            if (i0 + 2 < n) { out[i0 + 2] = o.z; if (zero) zero[i0 + 2] = 0; }
+        }
 #pragma unroll
-        for (int q = 0; q < 4; q++) { if (i0 + q < n) out[i0 + q] = run; run += v[q]; }
+        for (int q = 0; q < 4; q++) if (v[q] != 0) list[rnz++] = i0 + q;
         __syncthreads();
-        if (t == 1023) { total_s += (unsigned long long)(run - carry_s); carry_s = run; }
+        if (t == 1023) { total_s += (unsigned long long)(run - carry_s); carry_s = run; carry_nz = rnz; }
         __syncthreads();
     }
-    if (t == 0) { const uint32_t tot = total_s > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)total_s; out[n] = tot; *total = tot; }
+    if (t == 0) { const uint32_t tot = total_s > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)total_s; out[n] = tot; *total = tot; *n_list = carry_nz; }
 }
 
 __device__ __forceinline__ uint32_t lk_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 40); }
 
-// one wave per first site
-__global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucnt, uint32_t *rows_per, const uint32_t *site_off, uint32_t n_sites,
-                                                   SiteView v, int min_snp, uint32_t *site_nu, uint32_t *site_rows, uint32_t *state, Philox ph,
-                                                   uint32_t max_u)
+// one wave per first site with increments (the list of k_scan_u32), taken in turns by a fixed grid
+__global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucnt, uint32_t *rows_per, const uint32_t *site_off,
+                                                   uint32_t *site_nu, uint2 *edge_list, uint32_t *state, uint32_t max_u, const uint32_t *site_list)
 {
     __shared__ unsigned long long tk[LK_SLOTS];
     __shared__ uint32_t tc[LK_SLOTS];
-    const uint32_t s1 = blockIdx.x, l = threadIdx.x;
+    __shared__ uint2 stage[LK_STAGE];                           // edges of this wave's sites on their way to the list: one atomic per LK_STAGE edges
+    const uint32_t l = threadIdx.x;                             // (a counter every site's wave adds to takes ~9 ns a time: 1 ms for the 10^5 sites of a C3 batch)
     if (state[LS_FLAGS] & LKF_KEYS) return;
-    const uint32_t off = site_off[s1], n_b = site_off[s1 + 1] - off;
-    if (n_b == 0) { if (l == 0) { site_nu[s1] = 0; site_rows[s1] = 0; } return; }
-    for (uint32_t q = l; q < LK_SLOTS; q += 64) { tk[q] = LK_EMPTY; tc[q] = 0; }
-    __syncthreads();
-    // mm2combo2counts of every edge of this site: key -> count
-    uint32_t nu = 0;
-    bool full = false;
-    for (uint32_t c = 0; c < n_b && !full; c += 64) {
-        const bool have = c + l < n_b;
-        const uint64_t k = have ? keys[off + c + l] : 0;
-        bool fresh = false;
-        if (have) {
-            uint32_t slot = lk_hash(k) & (LK_SLOTS - 1);
-            for (;;) {
-                const unsigned long long old = atomicCAS(&tk[slot], LK_EMPTY, (unsigned long long)k);
-                if (old == LK_EMPTY || old == k) { fresh = old == LK_EMPTY; atomicAdd(&tc[slot], 1u); break; }
-                slot = (slot + 1) & (LK_SLOTS - 1);
-            }
+    const uint32_t n_list = state[LS_NLIST1];
+    uint32_t n_stage = 0, nu_sum = 0;
+    auto flush = [&]() {
+        uint32_t eb = 0;
+        if (l == 0) eb = atomicAdd(&state[LS_NEDGES], n_stage);
+        eb = __shfl(eb, 0);
+        __syncthreads();
+        for (uint32_t q = l; q < n_stage; q += 64) edge_list[eb + q] = stage[q];
+        __syncthreads();
+        n_stage = 0;
+    };
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const uint32_t s1 = site_list[li];
+        const uint32_t off = site_off[s1], n_b = site_off[s1 + 1] - off;
+        if (n_b == 1) {                                         // a single increment (most sites of a shallow metagenome batch): its own edge
+            if (l == 0) { ucnt[off] = 1; rows_per[off] = 0; site_nu[s1] = 1; }
+            if (n_stage + 1 > LK_STAGE) flush();
+            if (l == 0) stage[n_stage] = make_uint2(s1, 0);
+            n_stage++; nu_sum++;
+            continue;
         }
-        nu += (uint32_t)__popcll(__ballot(fresh));
-        full = nu > max_u;                                    // (wave-uniform; the table can take 64 more than LK_MAXU before it is full)
-    }
-    if (full) {                                                 // too many different keys for the table: the sorted chain takes the batch
-        if (l == 0) { atomicOr(&state[LS_FLAGS], LKF_BUCKET); site_nu[s1] = 0; site_rows[s1] = 0; }
-        return;
-    }
-    __syncthreads();
-    // compact in place (the write cursor never passes the slots being read), pad to a power of two, bitonic sort by key
-    uint32_t base = 0;
-    for (uint32_t r = 0; r < LK_SLOTS; r += 64) {
-        const unsigned long long k = tk[r + l];
-        const uint32_t c = tc[r + l];
-        const bool valid = k != LK_EMPTY;
-        const unsigned long long bal = __ballot(valid);
-        const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << l) - 1ull));
+        // a table of at least twice the bucket's increments (more unique keys than increments there are not), 64 .. LK_SLOTS slots
+        uint32_t slots = 64;
+        while (slots < LK_SLOTS && slots < 2 * n_b) slots <<= 1;
+        const uint32_t lim = min(max_u, slots - slots / 4);
+        __syncthreads();                                        // (the table of the wave's previous site has been read)
+        for (uint32_t q = l; q < slots; q += 64) { tk[q] = LK_EMPTY; tc[q] = 0; }
         __syncthreads();
-        if (valid) { tk[base + rank] = k; tc[base + rank] = c; }
-        base += (uint32_t)__popcll(bal);
-        __syncthreads();
-    }
-    uint32_t n_pad = 64;
-    while (n_pad < nu) n_pad <<= 1;
-    for (uint32_t q = nu + l; q < n_pad; q += 64) { tk[q] = LK_EMPTY; tc[q] = 0; }
-    __syncthreads();
-    for (uint32_t kk = 2; kk <= n_pad; kk <<= 1) {
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = l; t < n_pad / 2; t += 64) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
-                const bool up = (i & kk) == 0;
-                const unsigned long long x = tk[i], y = tk[p];
-                if ((x > y) == up) {
-                    const uint32_t cx = tc[i], cy = tc[p];
-                    tk[i] = y; tk[p] = x; tc[i] = cy; tc[p] = cx;
+        // mm2combo2counts of every edge of this site: key -> count
+        uint32_t nu = 0;
+        bool full = false;
+        for (uint32_t c = 0; c < n_b && !full; c += 64) {
+            const bool have = c + l < n_b;
+            const uint64_t k = have ? keys[off + c + l] : 0;
+            bool fresh = false;
+            if (have) {
+                uint32_t slot = lk_hash(k) & (slots - 1);
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&tk[slot], LK_EMPTY, (unsigned long long)k);
+                    if (old == LK_EMPTY || old == k) { fresh = old == LK_EMPTY; atomicAdd(&tc[slot], 1u); break; }
+                    slot = (slot + 1) & (slots - 1);
                 }
             }
+            nu += (uint32_t)__popcll(__ballot(fresh));
+            full = nu > lim;                                    // (wave-uniform; a 1024-slot table takes 64 more than `lim` before it is full,
+        }                                                       //  a smaller one never gets there: it has two slots per increment)
+        if (full) {                                             // too many different keys for the table: the sorted chain takes the batch
+            if (l == 0) atomicOr(&state[LS_FLAGS], LKF_BUCKET);
+            return;
+        }
+        __syncthreads();
+        // compact in place (the write cursor never passes the slots being read), pad to a power of two, bitonic sort by key
+        uint32_t base = 0;
+        for (uint32_t r = 0; r < slots; r += 64) {
+            const unsigned long long k = tk[r + l];
+            const uint32_t c = tc[r + l];
+            const bool valid = k != LK_EMPTY;
+            const unsigned long long bal = __ballot(valid);
+            const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << l) - 1ull));
+            __syncthreads();
+            if (valid) { tk[base + rank] = k; tc[base + rank] = c; }
+            base += (uint32_t)__popcll(bal);
             __syncthreads();
         }
-    }
-    // the unique keys back over the bucket (k_site_ld_emit reads them), rows per edge
-    uint32_t rows_sum = 0, heads = 0;
-    for (uint32_t u = l; u < nu; u += 64) {
-        const uint64_t k = tk[u];
-        keys[off + u] = k;
-        ucnt[off + u] = tc[u];
-        const bool head = u == 0 || (tk[u - 1] >> 12) != (k >> 12);
-        uint32_t rows = 0;
-        if (head) {
-            rows = ld_edge_rows<false>(reinterpret_cast<const uint64_t *>(tk), tc, u, nu, s1, (uint32_t)(k >> 12), v, min_snp, nullptr, ph);
-            heads++;
+        uint32_t n_pad = 2;
+        while (n_pad < nu) n_pad <<= 1;
+        for (uint32_t q = nu + l; q < n_pad; q += 64) { tk[q] = LK_EMPTY; tc[q] = 0; }
+        __syncthreads();
+        for (uint32_t kk = 2; kk <= n_pad; kk <<= 1) {
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = l; t < n_pad / 2; t += 64) {
+                    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                    const bool up = (i & kk) == 0;
+                    const unsigned long long x = tk[i], y = tk[p];
+                    if ((x > y) == up) {
+                        const uint32_t cx = tc[i], cy = tc[p];
+                        tk[i] = y; tk[p] = x; tc[i] = cy; tc[p] = cx;
+                    }
+                }
+                __syncthreads();
+            }
         }
-        rows_per[off + u] = rows;
-        rows_sum += rows;
+        // the unique keys back over the bucket; the first key of every edge (site1, site2) goes on the edge list: the LD kernels take a lane per edge
+        for (uint32_t c = 0; c < nu; c += 64) {
+            const uint32_t u = c + l;
+            bool head = false;
+            if (u < nu) {
+                const uint64_t k = tk[u];
+                keys[off + u] = k;
+                ucnt[off + u] = tc[u];
+                rows_per[off + u] = 0;
+                head = u == 0 || (tk[u - 1] >> 12) != (k >> 12);
+            }
+            const unsigned long long hb = __ballot(head);
+            if (n_stage + (uint32_t)__popcll(hb) > LK_STAGE) flush();
+            if (head) stage[n_stage + (uint32_t)__popcll(hb & ((1ull << l) - 1ull))] = make_uint2(s1, u);
+            n_stage += (uint32_t)__popcll(hb);
+        }
+        if (l == 0) site_nu[s1] = nu;
+        nu_sum += nu;
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { rows_sum += __shfl_xor(rows_sum, d); heads += __shfl_xor(heads, d); }
-    if (l == 0) {
-        site_nu[s1] = nu; site_rows[s1] = rows_sum;
-        atomicAdd(&state[LS_NU], nu);
-        atomicAdd(&state[LS_NEDGES], heads);
-    }
+    if (n_stage) flush();
+    if (l == 0 && nu_sum) atomicAdd(&state[LS_NU], nu_sum);
 }
 
-__global__ void __launch_bounds__(64) k_site_ld_emit(const uint64_t *keys, const uint32_t *ucnt, const uint32_t *rows_per, const uint32_t *site_off,
-                                                     const uint32_t *site_nu, const uint32_t *site_rows, const uint32_t *site_row_off,
-                                                     SiteView v, int min_snp, isx_ld *out, uint64_t cap_ld, uint32_t *state, Philox ph)
+// one lane per edge (site1, site2): EMIT = false counts its LD rows (rows_per at the edge's first key, summed per site), EMIT = true
+// writes them behind the rows of the site's earlier edges -- (site1, site2, mm) order, the order the sorted chain gave
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_edge_rows(const uint64_t *keys, const uint32_t *ucnt, uint32_t *rows_per, const uint32_t *site_off,
+                                                   const uint32_t *site_nu, uint32_t *site_rows, const uint32_t *site_row_off, const uint2 *edge_list,
+                                                   SiteView v, int min_snp, isx_ld *out, uint64_t cap_ld, uint32_t *state, Philox ph)
 {
-    __shared__ unsigned long long tk[LK_SLOTS];
-    __shared__ uint32_t tc[LK_SLOTS];
-    const uint32_t s1 = blockIdx.x, l = threadIdx.x;
     if (state[LS_FLAGS] & (LKF_KEYS | LKF_BUCKET)) return;
-    if ((uint64_t)state[LS_NLD] > cap_ld) { if (s1 == 0 && l == 0) atomicOr(&state[LS_FLAGS], LKF_LD); return; }
-    if (site_rows[s1] == 0) return;
-    const uint32_t off = site_off[s1], nu = site_nu[s1];
-    for (uint32_t u = l; u < nu; u += 64) { tk[u] = keys[off + u]; tc[u] = ucnt[off + u]; }
-    __syncthreads();
-    uint32_t carry = site_row_off[s1];
-    for (uint32_t c = 0; c < nu; c += 64) {
-        const uint32_t u = c + l;
-        const uint32_t r = u < nu ? rows_per[off + u] : 0u;
-        uint32_t inc = r;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if ((int)l >= d) inc += o; }
-        if (r) (void)ld_edge_rows<true>(reinterpret_cast<const uint64_t *>(tk), tc, u, nu, s1, (uint32_t)(tk[u] >> 12), v, min_snp, out + carry + inc - r, ph);
-        carry += __shfl(inc, 63);
+    if (EMIT && (uint64_t)state[LS_NLD] > cap_ld) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&state[LS_FLAGS], LKF_LD); return; }
+    const uint32_t n_edges = state[LS_NEDGES];
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += gridDim.x * blockDim.x) {
+        const uint2 ed = edge_list[e];
+        const uint32_t s1 = ed.x, u = ed.y, off = site_off[s1], nu = site_nu[s1];
+        const uint32_t s2 = (uint32_t)(keys[off + u] >> 12);
+        if (!EMIT) {
+            const uint32_t rows = ld_edge_rows<false>(keys + off, ucnt + off, u, nu, s1, s2, v, min_snp, nullptr, ph);
+            if (rows) { rows_per[off + u] = rows; atomicAdd(&site_rows[s1], rows); }
+        } else {
+            if (rows_per[off + u] == 0) continue;
+            uint32_t before = site_row_off[s1];
+            for (uint32_t q = 0; q < u; q++) before += rows_per[off + q];
+            (void)ld_edge_rows<true>(keys + off, ucnt + off, u, nu, s1, s2, v, min_snp, out + before, ph);
+        }
     }
 }
 
@@ -747,7 +827,7 @@ void LinkageBuffers::release()
 {
     void *ps[] = {site_keys.p, site_keys2.p, sites_sorted.p, site_gpos.p, site_split.p, ao_key.p, ao2.p,
                   ao_key2.p, incr_cnt.p, incr_off.p, keys.p, keys2.p, ukeys.p, ucnt.p, n_runs.p, rows_per.p,
-                  row_off.p, ld_block.p, temp.p, chain_head.p, next.p, site_cnt.p, site_off.p, site_cur.p, site_nu.p, site_rows.p, site_row_off.p, key64.p, key64b.p, head.p, row_id.p, first_row.p, first_site.p,
+                  row_off.p, ld_block.p, temp.p, chain_head.p, next.p, site_cnt.p, site_off.p, site_cur.p, site_nu.p, site_rows.p, site_row_off.p, site_list1.p, site_list2.p, edge_list.p, key64.p, key64b.p, head.p, row_id.p, first_row.p, first_site.p,
                   split_slot.p, tile_cnt.p, tile_off.p, vals.p, vals2.p, dsplits.p, dtiles.p, xt.p};
     for (void *p : ps) if (p) isx_dev_free(p);
     *this = LinkageBuffers();
@@ -822,8 +902,11 @@ int bucket_chain(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, const 
     int rc;
     *fell_back = false;
     const uint32_t n_ao = in.n_ao, n_sites = in.n_sites;
+    // the chains' heads: a slot per read pair when the ids are dense enough (no shared chains, neighbouring slots for the observations of a
+    // site), twice as many slots as observations behind a hash otherwise
+    const bool direct = in.n_pairs && in.n_pairs <= 8ull * n_ao + (1ull << 20) && in.n_pairs <= (1ull << 31);
     int logH = 12;
-    while (logH < 31 && (1ull << logH) < 2ull * n_ao) logH++;
+    while (logH < 31 && (1ull << logH) < (direct ? in.n_pairs : 2ull * n_ao)) logH++;
     const size_t H = (size_t)1 << logH;
     if (B.chain_head.cap < H || !B.chain_head.p) {
         if ((rc = ensure(B.chain_head, H))) return rc;
@@ -845,8 +928,8 @@ int bucket_chain(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, const 
     if (const char *e = getenv("ISX_LINK_TEST_CAPS")) { unsigned long a = 0, b = 0; if (sscanf(e, "%lu,%lu", &a, &b) == 2) { test_keys = a; test_ld = b; } }
     auto size_tables = [&]() -> int {
         int r;
-        if ((r = ensure(B.keys, cap_keys)) || (r = ensure(B.ucnt, cap_keys)) || (r = ensure(B.rows_per, cap_keys))) return r;
-        cap_keys = std::min(std::min(B.keys.cap, B.ucnt.cap), B.rows_per.cap);
+        if ((r = ensure(B.keys, cap_keys)) || (r = ensure(B.ucnt, cap_keys)) || (r = ensure(B.rows_per, cap_keys)) || (r = ensure(B.edge_list, cap_keys))) return r;
+        cap_keys = std::min(std::min(B.keys.cap, B.ucnt.cap), std::min(B.rows_per.cap, B.edge_list.cap));
         return ISX_OK;
     };
     auto size_ld = [&]() -> int {
@@ -857,18 +940,19 @@ int bucket_chain(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, const 
     };
     if ((rc = ensure(B.next, n_ao)) || (rc = ensure(B.site_cnt, (size_t)n_sites + 1)) || (rc = ensure(B.site_off, (size_t)n_sites + 1)) ||
         (rc = ensure(B.site_cur, (size_t)n_sites + 1)) || (rc = ensure(B.site_nu, n_sites)) || (rc = ensure(B.site_rows, (size_t)n_sites + 1)) ||
-        (rc = ensure(B.site_row_off, (size_t)n_sites + 1)) || (rc = size_tables()) || (rc = size_ld())) return rc;
+        (rc = ensure(B.site_row_off, (size_t)n_sites + 1)) || (rc = ensure(B.site_list1, n_sites)) || (rc = ensure(B.site_list2, n_sites)) || (rc = size_tables()) || (rc = size_ld())) return rc;
     uint32_t *state = reinterpret_cast<uint32_t *>(B.ld_block.p);           // the chain's state words live in front of the rows: one read-back
     const dim3 blk(256), g_sites((n_sites + 255) / 256), g_ao((n_ao + 255) / 256);
     SiteView v{sites_sorted, in.slev, in.snv, in.M == 1 ? 1 : 0};
     hipLaunchKernelGGL(k_link_prep, g_sites, blk, 0, s, sites_sorted, n_sites, in.split_bounds, in.n_splits, B.site_gpos.p, B.site_split.p,
-                       B.site_cnt.p, state);
+                       B.site_cnt.p, B.site_rows.p, state);
     EV(1);
     hipLaunchKernelGGL(k_ao_chain, g_ao, blk, 0, s, in.ao, n_ao, B.site_gpos.p, n_sites, reinterpret_cast<unsigned long long *>(B.chain_head.p),
-                       32 - logH, B.chain_epoch, B.next.p);
+                       32 - logH, direct ? (uint32_t)H : 0u, B.chain_epoch, B.next.p);
     EV(2);
     hipLaunchKernelGGL((k_pair_walk<false>), g_ao, blk, 0, s, in.ao, n_ao, B.next.p, B.site_split.p, B.site_cnt.p, nullptr, nullptr, (uint64_t)0, state);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, B.site_cnt.p, B.site_off.p, n_sites, state + LS_NINC, B.site_cur.p);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, B.site_cnt.p, B.site_off.p, n_sites, state + LS_NINC, B.site_cur.p, B.site_list1.p, state + LS_NLIST1);
+    const dim3 g_waves(std::min<uint32_t>(n_sites, 4096)), g_edges(std::min<uint32_t>((uint32_t)std::min<size_t>((cap_keys + 255) / 256, 0x7FFFFFFF), 2048));
     uint32_t h[LS_WORDS] = {0};
     for (int stage = 0, attempt = 0;; attempt++) {               // stage 0: from the buckets on; 1: the rows only (after a table grew)
         if (attempt == 4) { isx_set_error("linkage tables still too small after three growth steps"); return ISX_ERR_CAPACITY; }
@@ -876,13 +960,16 @@ int bucket_chain(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, const 
             hipLaunchKernelGGL((k_pair_walk<true>), g_ao, blk, 0, s, in.ao, n_ao, B.next.p, B.site_split.p, B.site_cur.p, B.site_off.p, B.keys.p,
                                (uint64_t)(attempt == 0 && test_keys ? std::min(test_keys, cap_keys) : cap_keys), state);
             EV(3);
-            hipLaunchKernelGGL(k_site_edges, dim3(n_sites), dim3(64), 0, s, B.keys.p, B.ucnt.p, B.rows_per.p, B.site_off.p, n_sites, v, in.min_snp,
-                               B.site_nu.p, B.site_rows.p, state, in.philox, max_u);
-            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, B.site_rows.p, B.site_row_off.p, n_sites, state + LS_NLD, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(k_site_edges, g_waves, dim3(64), 0, s, B.keys.p, B.ucnt.p, B.rows_per.p, B.site_off.p, B.site_nu.p,
+                               reinterpret_cast<uint2 *>(B.edge_list.p), state, max_u, B.site_list1.p);
+            hipLaunchKernelGGL((k_edge_rows<false>), g_edges, blk, 0, s, B.keys.p, B.ucnt.p, B.rows_per.p, B.site_off.p, B.site_nu.p, B.site_rows.p,
+                               (const uint32_t *)nullptr, reinterpret_cast<const uint2 *>(B.edge_list.p), v, in.min_snp, (isx_ld *)nullptr, (uint64_t)0, state, in.philox);
+            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, B.site_rows.p, B.site_row_off.p, n_sites, state + LS_NLD, (uint32_t *)nullptr, B.site_list2.p, state + LS_NLIST2);
             EV(4);
         }
-        hipLaunchKernelGGL(k_site_ld_emit, dim3(n_sites), dim3(64), 0, s, B.keys.p, B.ucnt.p, B.rows_per.p, B.site_off.p, B.site_nu.p, B.site_rows.p,
-                           B.site_row_off.p, v, in.min_snp, B.ld.p, (uint64_t)(attempt == 0 && test_ld ? std::min(test_ld, cap_ld) : cap_ld), state, in.philox);
+        hipLaunchKernelGGL((k_edge_rows<true>), g_edges, blk, 0, s, B.keys.p, B.ucnt.p, B.rows_per.p, B.site_off.p, B.site_nu.p, B.site_rows.p,
+                           B.site_row_off.p, reinterpret_cast<const uint2 *>(B.edge_list.p), v, in.min_snp, B.ld.p,
+                           (uint64_t)(attempt == 0 && test_ld ? std::min(test_ld, cap_ld) : cap_ld), state, in.philox);
         HIP_TRY(hipGetLastError());
         // the state words and, with them, the first rows (most batches of a metagenome have a few hundred): one copy, one wait
         const size_t n_pre = std::min<size_t>(cap_ld, LD_PREFIX_ROWS);
@@ -894,9 +981,9 @@ int bucket_chain(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, const 
         if (h[LS_FLAGS] & LKF_KEYS) {
             if (h[LS_NINC] == 0xFFFFFFFFu) { isx_set_error("more than 2^32 pair increments in one batch"); return ISX_ERR_CAPACITY; }
             cap_keys = (size_t)h[LS_NINC] + h[LS_NINC] / 4 + 4096;
-            B.keys.cap = B.ucnt.cap = B.rows_per.cap = 0;        // (ensure() frees and reallocates: nothing in them is needed)
+            B.keys.cap = B.ucnt.cap = B.rows_per.cap = B.edge_list.cap = 0;        // (ensure() frees and reallocates: nothing in them is needed)
             if ((rc = size_tables())) return rc;
-            HIP_TRY(hipMemsetAsync(state + LS_NU, 0, (LS_WORDS - LS_NU) * sizeof(uint32_t), s));
+            HIP_TRY(hipMemsetAsync(state + LS_NU, 0, (LS_FLAGS + 1 - LS_NU) * sizeof(uint32_t), s));      // (the total and the site list stay)
             HIP_TRY(hipMemsetAsync(B.site_cur.p, 0, ((size_t)n_sites + 1) * sizeof(uint32_t), s));
             stage = 0;
             continue;
