@@ -1337,6 +1337,14 @@ int launch_pass(isx_batch *b)
 // table sizes on the host); *cap_flags receives the ISX_FLAG_CAP_* bits of tables that were too small
 int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
 {
+    const int rc = finish_pass_sizes(b, cap_flags, link_stream);
+    if (rc != ISX_OK || *cap_flags) return rc;
+    return finish_pass_link(b, link_stream);
+}
+
+// the first half: the pass has run, its table sizes are on the host (no linkage stages yet; b->ran stays false until finish_pass_link)
+int finish_pass_sizes(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
+{
     *cap_flags = 0;
     isx_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
@@ -1386,14 +1394,23 @@ int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream)
     b->tim.pileup_lds_bytes = (int32_t)b->lds;
     b->tim.pileup_window = b->W;
     b->tim.record_bytes = b->d_seg ? 64 : (b->d_drec ? 32 : (b->d_rec16 ? 2 : (b->d_rec32 ? 4 : 8)));
+    b->n_ao_pass = cur[CUR_AO];
+    return ISX_OK;
+}
 
+// the second half: the linkage stages (they end with one wait for `link_stream`, which also delivers what the caller has queued with
+// isx_read_back on that stream meanwhile -- a pipe's finisher enqueues its fetches first and waits once)
+int finish_pass_link(isx_batch *b, hipStream_t link_stream)
+{
+    isx_ctx *c = b->ctx;
+    hipStream_t s = link_stream ? link_stream : c->stream;
     if (b->prm.enable_linkage) {
         LinkageIn in{};
         in.stream = s; in.ev = &b->ev[2]; in.ev_mfma = &b->ev[8];
         in.mode = b->prm.linkage_mode == 2 ? 2 : 1;
         in.philox = Philox{(uint32_t)b->prm.seed, (uint32_t)(b->prm.seed >> 32)};
-        in.n_pairs = b->n_pairs; in.ao = b->d_ao; in.n_ao = cur[CUR_AO];
-        in.sites = b->d_sites; in.n_sites = cur[CUR_SITES]; in.sites_ordered = b->ordered;
+        in.n_pairs = b->n_pairs; in.ao = b->d_ao; in.n_ao = b->n_ao_pass;
+        in.sites = b->d_sites; in.n_sites = (uint32_t)b->sizes.n_sites; in.sites_ordered = b->ordered;
         in.slev = b->d_slev; in.snv = b->d_snv;
         in.split_bounds = b->d_bounds; in.n_splits = b->n_splits; in.M = b->M; in.min_snp = b->prm.min_snp;
         LinkageOut lo;

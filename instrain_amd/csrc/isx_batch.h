@@ -126,6 +126,7 @@ struct isx_batch {
     LinkageBuffers L;
     const isx_ld *ld_host = nullptr;    // bucket chain: the first n_ld_host LD rows, already on the host (L.h_ld)
     size_t n_ld_host = 0;
+    uint32_t n_ao_pass = 0;             // allele observations of the last pass (finish_pass_sizes -> finish_pass_link)
     int link_chain = 0;                 // which chain the last pass took (LinkageOut::chain)
     SummaryBuffers S;
     CompareBuffers C;
@@ -162,6 +163,8 @@ int batch_set_geometry(isx_batch *b);
 extern "C" {
 int launch_pass(isx_batch *b);
 int finish_pass(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream = nullptr);
+int finish_pass_sizes(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream = nullptr);
+int finish_pass_link(isx_batch *b, hipStream_t link_stream = nullptr);
 // grow the tables named by cap_flags (x4 up to their hard bounds); the pass must then be repeated
 int batch_grow_tables(isx_batch *b, uint32_t cap_flags);
 }

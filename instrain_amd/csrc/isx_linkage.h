@@ -10,7 +10,7 @@ struct DevBuf {
 };
 
 constexpr size_t LD_HEAD = 1;               // rows of ld_block in front of the LD rows (>= 64 bytes of state words)
-constexpr size_t LD_PREFIX_ROWS = 2048;     // rows that come home with the state words
+constexpr size_t LD_PREFIX_ROWS = 2047;     // rows that come home with the state words ((LD_HEAD + rows) * 72 bytes: a multiple of 16, one copy kernel)
 
 struct DenseSplit {         // one split of the dense MFMA path
     uint64_t xt_off;        // byte offset of its column-major X^T block

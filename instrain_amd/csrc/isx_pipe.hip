@@ -545,7 +545,7 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
     bool redo = false;
     for (int attempt = 0;; attempt++) {
         uint32_t cf = 0;
-        int rc = finish_pass(b, &cf, sfin);     // sizes from the published cursors; linkage stages when enabled (on this finisher's queue)
+        int rc = finish_pass_sizes(b, &cf, sfin);     // sizes from the published cursors (the linkage stages follow the fetches below: one wait for both)
         if (rc != ISX_OK) return rc;
         // a batch taken for shallow that has more positions beyond 255 than the exact-coverage list holds: again with 16 bits
         const bool cov8_overflow = !cf && dense && b->sparse_out && b->cov8_out && !b->nib_pass && (size_t)b->n_sat > b->cap_sat;
@@ -599,7 +599,6 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         }
         redo = true;
     }
-    t_fin = now_ms();
     s.d2h_bytes += (int64_t)(std::min((size_t)b->sizes.n_snv, p->snv_prefix) * sizeof(isx_snv));
     if (dense && p->prm.rarefied_coverage > 0) s.d2h_bytes += (int64_t)(std::min((size_t)b->n_rare, p->rare_prefix) * sizeof(isx_rare));
     // device -> the slot's result block: through the bounce buffers into a plain block, a blocking copy into a pinned one
@@ -633,7 +632,9 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
                 rc = fetch(s.h_out + s.o_cov16, b->d_cov8, nib_bytes);
                 if (rc == ISX_OK) rc = fetch(s.h_out + s.o_cov16 + s.cov_rows_off, b->d_cov16, rows_bytes);
                 s.cov_row_win.resize(b->n_cov_rows);
-                if (rc == ISX_OK && b->n_cov_rows) rc = pull(s.cov_row_win.data(), b->d_cov_row_win, (size_t)b->n_cov_rows * sizeof(uint32_t));
+                if (rc == ISX_OK && b->n_cov_rows && isx_read_back(s.cov_row_win.data(), b->d_cov_row_win, (size_t)b->n_cov_rows * sizeof(uint32_t), sfin) != hipSuccess) {
+                    isx_set_error("isx_pipe finisher: read-back of the coverage rows' windows"); isx_read_drop(); rc = ISX_ERR_HIP;
+                }
                 s.d2h_bytes += (int64_t)(nib_bytes + rows_bytes + (size_t)b->n_cov_rows * 4);
             } else if (s.cov8) rc = fetch(s.h_out + s.o_cov16, b->d_cov8, (size_t)b->n_pos);
             else rc = fetch(s.h_out + s.o_cov16, b->d_cov16, (size_t)b->n_pos * 2);
@@ -661,7 +662,7 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         // exact coverage of the saturated positions (a handful; none at all for most batches)
         s.sat_rows.resize(s.sat_complete ? (size_t)b->n_sat : 0);
         if (!s.sat_rows.empty()) HIP_TRY(isx_read_back(s.sat_rows.data(), b->d_sat, s.sat_rows.size() * sizeof(isx_sat), sfin));
-        HIP_TRY(isx_read_sync(sfin));
+        // (no wait here: the linkage stages below end with the one wait that also covers these copies)
     }
     if (b->lev_sparse) {
         // mm profiling on: the level mask, the windows' first level indices, one coverage byte (or two) per present level, the lists
@@ -689,6 +690,13 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         HIP_TRY(isx_wait_stream(sfin));
         s.d2h_bytes += (int64_t)((size_t)b->n_pos * b->lev_mask_bytes + (size_t)b->n_win * 4 + cov_bytes + clon_bytes + rare_bytes + s.sat_rows.size() * sizeof(isx_sat));
     }
+    // the linkage stages, on this finisher's queue behind the copies above; the bucket chain's one read-back is the wait for all of it
+    {
+        const int lrc = finish_pass_link(b, sfin);
+        if (lrc != ISX_OK) return lrc;
+        if (!(p->prm.enable_linkage && b->link_chain == 3)) HIP_TRY(isx_read_sync(sfin));
+    }
+    t_fin = now_ms();
     if (dense && p->prm.rarefied_coverage > 0) {        // the sparse clonTR table, ascending positions
         const size_t n_rare = b->n_rare;
         isx_rare *rr = reinterpret_cast<isx_rare *>(s.h_small + s.o_rare);
