@@ -19,12 +19,13 @@ from tests import util
 ap = argparse.ArgumentParser()
 ap.add_argument("--c3-bp", type=int, default=5_000_000)
 ap.add_argument("--no-c5", action="store_true")
+ap.add_argument("--reverse", action="store_true", help="the sorted chain first")
 ap.add_argument("--c5-only", default=None, help="bucket | sorted: that chain's C5 shard alone (for a profiler)")
 args = ap.parse_args()
 os.environ["ISX_BENCH_C3_BP"] = str(args.c3_bp)
 lut, fb = util.load_lut()
 out = {}
-for chain in ((args.c5_only,) if args.c5_only else ("bucket", "sorted")):
+for chain in ((args.c5_only,) if args.c5_only else (("sorted", "bucket") if args.reverse else ("bucket", "sorted"))):
     if chain == "sorted":
         os.environ["ISX_LINK_CHAIN"] = "sorted"
     else:
