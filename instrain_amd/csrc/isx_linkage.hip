@@ -309,6 +309,7 @@ constexpr int LK_SLOTS = 1024;          // LDS hash slots of a site's wave
 constexpr int LK_MAXU = 768;            // unique keys of one first site beyond which the batch takes the sorted chain
 constexpr uint64_t LK_EMPTY = ~0ull;
 constexpr uint32_t LK_STAGE = 256;
+constexpr uint32_t LK_ROUND = 16;          // sites a wave of k_site_edges takes at a time
 enum { LS_NINC = 0, LS_NU = 1, LS_NEDGES = 2, LS_NLD = 3, LS_FLAGS = 4, LS_NLIST1 = 5 /* sites with increments */, LS_NLIST2 = 6 /* sites with rows */, LS_WORDS = 16 };
 constexpr uint32_t LKF_KEYS = 1u, LKF_BUCKET = 2u, LKF_LD = 4u;
 
@@ -480,16 +481,27 @@ __global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucn
         __syncthreads();
         n_stage = 0;
     };
-    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
-        const uint32_t s1 = site_list[li];
-        const uint32_t off = site_off[s1], n_b = site_off[s1 + 1] - off;
-        if (n_b == 1) {                                         // a single increment (most sites of a shallow metagenome batch): its own edge
-            if (l == 0) { ucnt[off] = 1; rows_per[off] = 0; site_nu[s1] = 1; }
-            if (n_stage + 1 > LK_STAGE) flush();
-            if (l == 0) stage[n_stage] = make_uint2(s1, 0);
-            n_stage++; nu_sum++;
-            continue;
+    // a wave takes LK_ROUND sites of the list at a time: their buckets' bounds are loaded side by side (a site at a time the wave waited
+    // for three dependent loads per site), the sites with a single increment -- most sites of a shallow metagenome batch -- are done by
+    // their lanes on the spot, the others go through the wave one after the other
+    for (uint32_t lb = blockIdx.x * LK_ROUND; lb < n_list; lb += gridDim.x * LK_ROUND) {
+    uint32_t my_s1 = 0, my_off = 0, my_nb = 0;
+    if (l < LK_ROUND && lb + l < n_list) { my_s1 = site_list[lb + l]; my_off = site_off[my_s1]; my_nb = site_off[my_s1 + 1] - my_off; }
+    {
+        const bool single = my_nb == 1;                         // its own edge, counted once
+        const unsigned long long sb = __ballot(single);
+        if (sb) {
+            if (n_stage + (uint32_t)__popcll(sb) > LK_STAGE) flush();
+            if (single) {
+                ucnt[my_off] = 1; rows_per[my_off] = 0; site_nu[my_s1] = 1;
+                stage[n_stage + (uint32_t)__popcll(sb & ((1ull << l) - 1ull))] = make_uint2(my_s1, 0);
+            }
+            n_stage += (uint32_t)__popcll(sb); nu_sum += (uint32_t)__popcll(sb);
         }
+    }
+    for (unsigned long long rest = __ballot(my_nb > 1); rest; rest &= rest - 1) {
+        const int src = __builtin_ctzll(rest);
+        const uint32_t s1 = __shfl(my_s1, src), off = __shfl(my_off, src), n_b = __shfl(my_nb, src);
         // a table of at least twice the bucket's increments (more unique keys than increments there are not), 64 .. LK_SLOTS slots
         uint32_t slots = 64;
         while (slots < LK_SLOTS && slots < 2 * n_b) slots <<= 1;
@@ -569,6 +581,7 @@ __global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucn
         }
         if (l == 0) site_nu[s1] = nu;
         nu_sum += nu;
+    }
     }
     if (n_stage) flush();
     if (l == 0 && nu_sum) atomicAdd(&state[LS_NU], nu_sum);
@@ -952,7 +965,7 @@ int bucket_chain(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out, const 
     EV(2);
     hipLaunchKernelGGL((k_pair_walk<false>), g_ao, blk, 0, s, in.ao, n_ao, B.next.p, B.site_split.p, B.site_cnt.p, nullptr, nullptr, (uint64_t)0, state);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, B.site_cnt.p, B.site_off.p, n_sites, state + LS_NINC, B.site_cur.p, B.site_list1.p, state + LS_NLIST1);
-    const dim3 g_waves(std::min<uint32_t>(n_sites, 4096)), g_edges(std::min<uint32_t>((uint32_t)std::min<size_t>((cap_keys + 255) / 256, 0x7FFFFFFF), 2048));
+    const dim3 g_waves(std::min<uint32_t>((n_sites + LK_ROUND - 1) / LK_ROUND, 4096)), g_edges(std::min<uint32_t>((uint32_t)std::min<size_t>((cap_keys + 255) / 256, 0x7FFFFFFF), 2048));
     uint32_t h[LS_WORDS] = {0};
     for (int stage = 0, attempt = 0;; attempt++) {               // stage 0: from the buckets on; 1: the rows only (after a table grew)
         if (attempt == 4) { isx_set_error("linkage tables still too small after three growth steps"); return ISX_ERR_CAPACITY; }
