@@ -105,3 +105,28 @@ def test_bucket_chain_vs_oracle_multi_split(ctx):
     exp = {k: np.concatenate(v) for k, v in exp.items()}
     util.assert_same(util.canon_from_struct(got), util.canon_from_struct(exp), float_tol=1e-6, what="multi-split")
     assert s["n_ld"] > 100
+
+
+def test_sparse_pair_ids_take_the_hashed_chains(ctx, monkeypatch):
+    """pair ids spread over 2^28 (a caller's own numbering): the chains' heads are a hash table instead of a slot per pair"""
+    from instrain_amd import synth
+    w = synth.make_workload(genome_len=60_000, coverage=80, n_sites=600, seed=7, skip_mm=True, af_lo=0.2, af_hi=0.5)
+    w = dict(w)
+    w["pair"] = (w["pair"].astype(np.uint64) * 4099 % (1 << 28)).astype(np.uint32)
+    assert len(np.unique(w["pair"])) > 0.99 * (int(w["pair"].shape[0]) // 150 // 2)          # (still one id per pair, give or take a collision)
+    got = _run(ctx, w, 1)
+    monkeypatch.setenv("ISX_LINK_CHAIN", "sorted")
+    exp = _run(ctx, w, 1)
+    _same(got, exp, "hashed chains")
+    assert exp[1]["n_ld"] > 100
+
+
+def test_batch_without_sites_or_pairs(ctx):
+    """no SNP site at all (the chain is not entered), and sites whose reads never see two of them (no increment)"""
+    from instrain_amd import synth
+    w = synth.make_workload(genome_len=30_000, coverage=30, n_sites=0, err=0.0, seed=8, skip_mm=True)
+    f, s = _run(ctx, w, 1)
+    assert s["n_ld"] == 0 and s["n_edges"] == 0 and len(f["ld"]) == 0
+    w = synth.make_workload(genome_len=200_000, coverage=40, n_sites=20, err=0.0, seed=8, skip_mm=True, af_lo=0.3, af_hi=0.5)
+    f, s = _run(ctx, w, 1)
+    assert s["n_sites"] >= 15 and s["n_ld"] <= 2
