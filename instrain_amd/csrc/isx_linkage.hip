@@ -461,29 +461,94 @@ __global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t *in, uint32_t 
 
 __device__ __forceinline__ uint32_t lk_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 40); }
 
-// one wave per first site with increments (the list of k_scan_u32), taken in turns by a fixed grid
+// bitonic sort of one 64-bit key a lane inside groups of G lanes (G a power of two <= 64), ascending, by shuffles: no LDS, no barrier
+template <int G>
+__device__ __forceinline__ uint64_t lk_sort_in_groups(uint64_t k, uint32_t l)
+{
+#pragma unroll
+    for (int kk = 2; kk <= G; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), j) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)k, j);
+            const bool up = ((l & (uint32_t)(G - 1)) & (uint32_t)kk) == 0, lower = (l & (uint32_t)j) == 0;
+            k = (lower == up) ? (k < o ? k : o) : (k > o ? k : o);
+        }
+    }
+    return k;
+}
+
+// edges of a wave's sites on their way to the list: one atomic per LK_STAGE edges (a counter every site's wave adds to takes ~9 ns a
+// time: 1 ms for the 10^5 sites of a C3 batch)
+__device__ __forceinline__ void lk_flush(uint2 *stage, uint32_t &n_stage, uint2 *edge_list, uint32_t *state, uint32_t l)
+{
+    uint32_t eb = 0;
+    if (l == 0) eb = atomicAdd(&state[LS_NEDGES], n_stage);
+    eb = __shfl(eb, 0);
+    __syncthreads();
+    for (uint32_t q = l; q < n_stage; q += 64) edge_list[eb + q] = stage[q];
+    __syncthreads();
+    n_stage = 0;
+}
+
+// Buckets of at most G increments, 64 / G of them side by side (`todo`: the lanes of the round that hold such a site): a lane holds one
+// increment, a group's keys are sorted by shuffles, equal neighbours are one unique key with their number as its count -- registers only.
+template <int G>
+__device__ __forceinline__ void lk_small_buckets(unsigned long long todo, uint32_t my_s1, uint32_t my_off, uint32_t my_nb, uint32_t l,
+                                                 uint64_t *keys, uint32_t *ucnt, uint32_t *rows_per, uint32_t *site_nu, uint2 *stage,
+                                                 uint32_t &n_stage, uint32_t &nu_sum, uint2 *edge_list, uint32_t *state)
+{
+    constexpr int NG = 64 / G;
+    const uint32_t g = l / G, t = l % G;
+    while (todo) {
+        int src = -1;
+#pragma unroll
+        for (int q = 0; q < NG; q++) {                          // the q-th group takes the q-th site that is left
+            const int sq = todo ? __builtin_ctzll(todo) : -1;
+            if (todo) todo &= todo - 1;
+            if ((int)g == q) src = sq;
+        }
+        const bool has = src >= 0;
+        const int sl = has ? src : 0;
+        const uint32_t s1 = __shfl(my_s1, sl), off = __shfl(my_off, sl), n_b = has ? __shfl(my_nb, sl) : 0u;
+        uint64_t k = t < n_b ? keys[off + t] : LK_EMPTY;
+        k = lk_sort_in_groups<G>(k, l);
+        const bool valid = k != LK_EMPTY;
+        const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(k >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)k, 1);
+        const bool uhead = valid && (t == 0 || k != prev);                              // first of its key
+        const bool ehead = uhead && (t == 0 || (k >> 12) != (prev >> 12));              // first key of its edge (site1, site2)
+        const unsigned long long ub = __ballot(uhead), eb = __ballot(ehead);
+        const unsigned long long gb = G == 64 ? ub : (ub >> (g * G)) & ((1ull << (G & 63)) - 1ull);
+        const uint32_t rank = (uint32_t)__popcll(gb & ((1ull << t) - 1ull));
+        if (uhead) {
+            const unsigned long long above = t == G - 1 ? 0ull : gb >> (t + 1);
+            const uint32_t next = above ? t + 1 + (uint32_t)__builtin_ctzll(above) : n_b;
+            keys[off + rank] = k;
+            ucnt[off + rank] = next - t;
+            rows_per[off + rank] = 0;
+        }
+        if (has && t == 0) site_nu[s1] = (uint32_t)__popcll(gb);
+        if (n_stage + (uint32_t)__popcll(eb) > LK_STAGE) lk_flush(stage, n_stage, edge_list, state, l);
+        if (ehead) stage[n_stage + (uint32_t)__popcll(eb & ((1ull << l) - 1ull))] = make_uint2(s1, rank);
+        n_stage += (uint32_t)__popcll(eb);
+        nu_sum += (uint32_t)__popcll(ub);
+    }
+}
+
+// one wave per LK_ROUND first sites with increments (the list of k_scan_u32), taken in turns by a fixed grid
 __global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucnt, uint32_t *rows_per, const uint32_t *site_off,
                                                    uint32_t *site_nu, uint2 *edge_list, uint32_t *state, uint32_t max_u, const uint32_t *site_list)
 {
     __shared__ unsigned long long tk[LK_SLOTS];
     __shared__ uint32_t tc[LK_SLOTS];
-    __shared__ uint2 stage[LK_STAGE];                           // edges of this wave's sites on their way to the list: one atomic per LK_STAGE edges
-    const uint32_t l = threadIdx.x;                             // (a counter every site's wave adds to takes ~9 ns a time: 1 ms for the 10^5 sites of a C3 batch)
+    __shared__ uint2 stage[LK_STAGE];
+    const uint32_t l = threadIdx.x;
     if (state[LS_FLAGS] & LKF_KEYS) return;
     const uint32_t n_list = state[LS_NLIST1];
     uint32_t n_stage = 0, nu_sum = 0;
-    auto flush = [&]() {
-        uint32_t eb = 0;
-        if (l == 0) eb = atomicAdd(&state[LS_NEDGES], n_stage);
-        eb = __shfl(eb, 0);
-        __syncthreads();
-        for (uint32_t q = l; q < n_stage; q += 64) edge_list[eb + q] = stage[q];
-        __syncthreads();
-        n_stage = 0;
-    };
     // a wave takes LK_ROUND sites of the list at a time: their buckets' bounds are loaded side by side (a site at a time the wave waited
-    // for three dependent loads per site), the sites with a single increment -- most sites of a shallow metagenome batch -- are done by
-    // their lanes on the spot, the others go through the wave one after the other
+    // for three dependent loads per site).  A site with a single increment -- most sites of a shallow metagenome batch -- is done by its lane
+    // on the spot; buckets of up to 16 increments go four at a time, up to 64 one at a time, through the register path above; the deep ones
+    // through an LDS hash table, one after the other
     for (uint32_t lb = blockIdx.x * LK_ROUND; lb < n_list; lb += gridDim.x * LK_ROUND) {
     uint32_t my_s1 = 0, my_off = 0, my_nb = 0;
     if (l < LK_ROUND && lb + l < n_list) { my_s1 = site_list[lb + l]; my_off = site_off[my_s1]; my_nb = site_off[my_s1 + 1] - my_off; }
@@ -491,7 +556,7 @@ __global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucn
         const bool single = my_nb == 1;                         // its own edge, counted once
         const unsigned long long sb = __ballot(single);
         if (sb) {
-            if (n_stage + (uint32_t)__popcll(sb) > LK_STAGE) flush();
+            if (n_stage + (uint32_t)__popcll(sb) > LK_STAGE) lk_flush(stage, n_stage, edge_list, state, l);
             if (single) {
                 ucnt[my_off] = 1; rows_per[my_off] = 0; site_nu[my_s1] = 1;
                 stage[n_stage + (uint32_t)__popcll(sb & ((1ull << l) - 1ull))] = make_uint2(my_s1, 0);
@@ -499,7 +564,10 @@ __global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucn
             n_stage += (uint32_t)__popcll(sb); nu_sum += (uint32_t)__popcll(sb);
         }
     }
-    for (unsigned long long rest = __ballot(my_nb > 1); rest; rest &= rest - 1) {
+    const uint32_t reg_max = max_u >= 64 ? 64u : 1u;            // (ISX_LINK_MAXU below 64, a test's setting: everything through the table, which knows the limit)
+    lk_small_buckets<16>(__ballot(my_nb >= 2 && my_nb <= min(16u, reg_max)), my_s1, my_off, my_nb, l, keys, ucnt, rows_per, site_nu, stage, n_stage, nu_sum, edge_list, state);
+    lk_small_buckets<64>(__ballot(my_nb > 16 && my_nb <= reg_max), my_s1, my_off, my_nb, l, keys, ucnt, rows_per, site_nu, stage, n_stage, nu_sum, edge_list, state);
+    for (unsigned long long rest = __ballot(my_nb > reg_max); rest; rest &= rest - 1) {
         const int src = __builtin_ctzll(rest);
         const uint32_t s1 = __shfl(my_s1, src), off = __shfl(my_off, src), n_b = __shfl(my_nb, src);
         // a table of at least twice the bucket's increments (more unique keys than increments there are not), 64 .. LK_SLOTS slots
@@ -575,7 +643,7 @@ __global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucn
                 head = u == 0 || (tk[u - 1] >> 12) != (k >> 12);
             }
             const unsigned long long hb = __ballot(head);
-            if (n_stage + (uint32_t)__popcll(hb) > LK_STAGE) flush();
+            if (n_stage + (uint32_t)__popcll(hb) > LK_STAGE) lk_flush(stage, n_stage, edge_list, state, l);
             if (head) stage[n_stage + (uint32_t)__popcll(hb & ((1ull << l) - 1ull))] = make_uint2(s1, u);
             n_stage += (uint32_t)__popcll(hb);
         }
@@ -583,7 +651,7 @@ __global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucn
         nu_sum += nu;
     }
     }
-    if (n_stage) flush();
+    if (n_stage) lk_flush(stage, n_stage, edge_list, state, l);
     if (l == 0 && nu_sum) atomicAdd(&state[LS_NU], nu_sum);
 }
 
