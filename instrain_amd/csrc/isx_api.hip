@@ -190,13 +190,21 @@ __global__ void __launch_bounds__(256) k_copy_small(T *__restrict__ dst, const T
 
 hipError_t isx_copy_to_host(void *hdst, const void *dsrc, size_t bytes, hipStream_t stream)
 {
+    // position-sized tables: the DMA engine.  A copy KERNEL that streams megabytes into host memory keeps the memory system's queues
+    // full of PCIe writes: every other kernel's HBM traffic waits behind them and the copy-in DMA loses a fifth of its rate
+    // (whole-database stream: 82 -> 55 ms a pass without the coverage rows' copy kernel, rate of the copy-in 43 -> 54 GB/s; a 16 MiB
+    // threshold, tried in round 6: headline 156-161 -> 153 Gbp/s, collect_wait 0.4 -> 4 ms)
+    static const size_t dma_min = [] { const char *e = getenv("ISX_D2H_DMA_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
+    return isx_copy_to_host_route(hdst, dsrc, bytes, stream, bytes < dma_min);
+}
+
+// by_kernel: the copy kernels whatever the size.  What a SMALL batch hands back (the level tables of a C2 batch with mm profiling on: 5 + 12 MB)
+// leaves by kernel although its pieces are megabytes: hipMemcpyAsync serves both directions of this stack's copies from one queue, and those
+// tables going home by DMA halved the rate of the next batches' copy-in (0.94 -> 0.69 ms a batch; C2 mm-on stream 93.5 -> 124 Gbp/s, round 6)
+hipError_t isx_copy_to_host_route(void *hdst, const void *dsrc, size_t bytes, hipStream_t stream, bool by_kernel)
+{
     if (!bytes) return hipSuccess;
-    {   // position-sized tables: the DMA engine.  A copy KERNEL that streams megabytes into host memory keeps the memory system's queues
-        // full of PCIe writes: every other kernel's HBM traffic waits behind them and the copy-in DMA loses a fifth of its rate
-        // (whole-database stream: 82 -> 55 ms a pass without the coverage rows' copy kernel, rate of the copy-in 43 -> 54 GB/s)
-        static const size_t dma_min = [] { const char *e = getenv("ISX_D2H_DMA_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
-        if (bytes >= dma_min) return hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
-    }
+    if (!by_kernel) return hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
     const uintptr_t both = reinterpret_cast<uintptr_t>(hdst) | reinterpret_cast<uintptr_t>(dsrc);
     size_t done = 0;
     if ((both & 15) == 0 && bytes >= 4096) {

@@ -44,6 +44,8 @@ void isx_dev_trim();        // both caches
 // megabytes into host memory fills the memory system's queues with PCIe writes, and every other kernel's HBM traffic and the copy-in
 // DMA wait behind them (round 4: whole-database pass 100 -> 66 ms).
 hipError_t isx_copy_to_host(void *hdst_pinned, const void *dsrc, size_t bytes, hipStream_t stream);
+// the same with the route given: by_kernel = the copy kernels whatever the size (what a small batch hands back, isx_pipe.hip's level tables)
+hipError_t isx_copy_to_host_route(void *hdst_pinned, const void *dsrc, size_t bytes, hipStream_t stream, bool by_kernel);
 // Small read-backs into ANY host memory (table sizes, the last element of a scan, a few hundred rows): the same kernel route
 // through a pinned scratch of the calling thread (1 MiB) -- a 4-byte hipMemcpyAsync queues behind whatever 100 MB copy-in the DMA
 // engine is busy with (up to ~2 ms each, several per batch).  isx_read_back enqueues, isx_read_sync waits for the stream and

@@ -670,12 +670,20 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         int rc = ISX_OK;
         const size_t n_lev = (size_t)b->sizes.n_entries, cov_bytes = n_lev * (size_t)b->lev_cov_bytes;
         const size_t clon_bytes = (size_t)b->n_clon * sizeof(isx_rare), rare_bytes = p->prm.rarefied_coverage > 0 ? (size_t)b->n_rare * sizeof(isx_rare) : 0;
-        if ((rc = fetch(s.h_out + s.o_lmask, b->d_lev_mask, (size_t)b->n_pos * b->lev_mask_bytes)) != ISX_OK) return rc;
+        // a small batch's tables (a C2 batch: 5 + 12 MB) leave by copy kernel, not by DMA: see isx_copy_to_host_route
+        static const size_t lev_kernel_max = [] { const char *e = getenv("ISX_LEV_KERNEL_MAX"); return e ? (size_t)atoll(e) : (size_t)32 << 20; }();
+        const bool lev_by_kernel = s.out_pinned && (size_t)b->n_pos * b->lev_mask_bytes + cov_bytes + clon_bytes + rare_bytes <= lev_kernel_max;
+        auto fetch_lev = [&](void *hdst, const void *dsrc, size_t bytes) -> int {
+            if (!lev_by_kernel) return fetch(hdst, dsrc, bytes);
+            HIP_TRY(isx_copy_to_host_route(hdst, dsrc, bytes, sfin, true));
+            return ISX_OK;
+        };
+        if ((rc = fetch_lev(s.h_out + s.o_lmask, b->d_lev_mask, (size_t)b->n_pos * b->lev_mask_bytes)) != ISX_OK) return rc;
         if ((rc = fetch(s.h_out + s.o_lwin, b->d_lev_win_off, (size_t)b->n_win * sizeof(uint32_t))) != ISX_OK) return rc;
         // what outgrows its pinned room (a deep sample's clonTR list, a coverage stream of more than four levels a position): plain vectors
         auto fetch_or_big = [&](size_t off, size_t room, auto &big, const void *dsrc, size_t bytes) -> int {
             big.clear();
-            if (bytes <= room) return fetch(s.h_out + off, dsrc, bytes);
+            if (bytes <= room) return fetch_lev(s.h_out + off, dsrc, bytes);
             big.resize((bytes + sizeof(big[0]) - 1) / sizeof(big[0]));
             if (p->bounce[0]) return bounce_d2h(p, big.data(), dsrc, bytes, sfin);
             HIP_TRY(hipMemcpy(big.data(), dsrc, bytes, hipMemcpyDeviceToHost));
