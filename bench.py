@@ -324,9 +324,19 @@ def linkage_leg(ctx, seed=3):
     out = {"workload": "C3%s: %.1f Mbp genome, 200x, %d SNV sites (1 / 100 bp, two haplotype backgrounds), skip_mm, linkage on"
                        % ("" if glen == 5_000_000 else " slice", glen / 1e6, glen // 100),
            "kept_observations": int(w["n_obs"]), "read_pairs": int(w["n_pairs"]), "read_segments": int(segs.n_seg)}
-    for name, src, pr, mode in (("reads", segs, None, 1), ("sparse", w["obs"], w["pair"], 1), ("dense_mfma", w["obs"], w["pair"], 2)):
+    # "reads": the read-level batch through the bucket chain (round 6: per-pair chains, a bucket of increments per first site, no sort library);
+    # "reads_sorted_chain": the same batch through the device-wide sorts of rounds 2-5 (ISX_LINK_CHAIN=sorted, read at every call) -- the A/B of the line
+    for name, src, pr, mode in (("reads", segs, None, 1), ("reads_sorted_chain", segs, None, 1), ("sparse", w["obs"], w["pair"], 1), ("dense_mfma", w["obs"], w["pair"], 2)):
+        if name == "reads_sorted_chain":
+            if os.environ.get("ISX_LINK_CHAIN"):
+                continue                    # (the caller chose a chain for the whole run: nothing to compare)
+            os.environ["ISX_LINK_CHAIN"] = "sorted"
         b = engine.Batch(ctx, w["ref_codes"], w["split_bounds"], src, pr, n_mm_bins=1, enable_linkage=True, linkage_mode=mode)
-        dt, _, _ = _time_batch(b)
+        try:
+            dt, _, _ = _time_batch(b)
+        finally:
+            if name == "reads_sorted_chain":
+                del os.environ["ISX_LINK_CHAIN"]
         mf = b.timings()["mfma_ms"]
         s, t = b.sizes(), b.timings()
         b.close()
@@ -1438,6 +1448,8 @@ def main():
             if not args.no_linkage_leg:
                 legs["linkage"] = linkage_leg(ctx)
                 out["c3_snv_pairs_linked_per_s"] = legs["linkage"]["snv_pairs_linked_per_s"]
+                if "reads_sorted_chain" in legs["linkage"]:
+                    out["c3_snv_pairs_linked_per_s_sorted_chain"] = legs["linkage"]["reads_sorted_chain"]["snv_pairs_linked_per_s"]
             if not args.no_cpu_baseline:
                 legs["cpu_baseline_c2"] = cpu_baseline(w)
                 legs["cpu_baseline_python_c2"] = cpu_baseline_python(w)
