@@ -161,10 +161,10 @@ typedef struct {
 /* per-kernel device time of the last isx_batch_run, milliseconds (HIP events on the ctx stream) */
 typedef struct {
     float pileup_ms;        /* k_pileup_dense / k_pileup_mm: window histogram + SNV call epilogue (+ allele pass with linkage) */
-    float sites_ms;         /* site table sort / rank */
-    float allele_ms;        /* k_ao_rank: allele observations -> site ranks */
-    float group_ms;         /* group allele observations by pair */
-    float incr_ms;          /* pair increments -> keys, sort, run-length */
+    float sites_ms;         /* site table sort / rank (bucket chain, round 6: k_link_prep) */
+    float allele_ms;        /* k_ao_rank: allele observations -> site ranks (bucket chain: + their read pairs' chains, k_ao_chain) */
+    float group_ms;         /* group allele observations by pair (bucket chain: both walks of the pairs' chains + the scan between them) */
+    float incr_ms;          /* pair increments -> keys, sort, run-length (bucket chain: per-site aggregation + the rows' count and scan) */
     float ld_ms;            /* LD rows */
     float total_ms;
     int32_t pileup_blocks, pileup_threads, pileup_lds_bytes, pileup_window;
