@@ -542,6 +542,22 @@ class C5Run:
                 self.ws.append(w)
         self.ws.sort(key=lambda w: -w["n_pos"])                     # largest first: the pass drains behind its smallest batch
         self.gen_s = time.perf_counter() - t0
+        # The database's reference planes are what a caller keeps for the whole run (profile_controller.py:415-433 holds the fasta the same
+        # way): registered once for the copy engine (isx_host_register), they are copied to the device from where they lie -- they still travel
+        # with every batch of every pass, the pipe's threads just do not copy them into staging first.  The reads stay plain pageable memory.
+        # ISX_BENCH_REGISTER_REF=0: as before round 6's last part (the A/B of the line).
+        self.ref_registered = False
+        if int(os.environ.get("ISX_BENCH_REGISTER_REF", "1")):
+            t_r = time.perf_counter()
+            try:
+                for w in self.ws:
+                    w["ref_planes"].register()
+                self.ref_registered = True
+            except Exception as e:                                  # (a lease that may not pin that much: the planes go through staging)
+                print("bench: reference planes not registered (%s)" % e, file=sys.stderr)
+                for w in self.ws:
+                    w["ref_planes"].unregister()
+            self.register_s = time.perf_counter() - t_r
         ws = self.ws
         self.stage_async = stage_async
         self.pipe = self.make_pipe(host_threads)
@@ -707,6 +723,10 @@ class C5Run:
 
     def close(self):
         self.pipe.close()
+        if getattr(self, "ref_registered", False):
+            for w in self.ws:
+                w["ref_planes"].unregister()
+            self.ref_registered = False
 
     def report(self, dt_max, bases_all, stats, passes, gather_ms=None):
         meta, kept, ws, world = self.meta, self.kept, self.ws, self.world
@@ -1264,6 +1284,7 @@ def main():
     ctx5 = engine.Context(local, reserve_cus=C5_RESERVE_CUS)
     ctx5.set_null_model(lut, fb)
     c5 = C5Run(ctx5, rank, world, host_threads, depth=args.depth, scale=args.scale, stage_async=args.queued_submit)
+    c5_ref_registered = bool(c5.ref_registered)
     _trace("C5 verify pass")
     c5.verify_pass()                            # untimed: every batch's tables checked on the host; also warms every slot
     # N > 1: the job is the same whole database (strong scaling), so a rank's pass shrinks to a few ms -- a STEP is then PPS passes
@@ -1364,7 +1385,8 @@ def main():
             "config": {"workload": _short("C5: 1000-genome database, 10 Gbp reads, --database_mode, pileup+SNV call+linkage; step = whole pass%s"
                                           % ("" if args.scale == 1.0 else " [DEBUG scale %g]" % args.scale)),
                        "genomes_kept": head["genomes_kept"], "positions": head["positions"], "read_gbp_per_step": bases_all / 1e9,
-                       "batches_per_step": n_batches if world == 1 else None, "hand_over": _short("isx_pipe_submit_planes per batch INSIDE the step: caller's bit planes (pageable) -> XOR stager -> %d-byte wire records in pinned staging -> hipMemcpyAsync -> kernels -> tables back" % (head.get("record_bytes") or 0), 220),
+                       "batches_per_step": n_batches if world == 1 else None, "hand_over": _short("isx_pipe_submit_planes per batch INSIDE the step: caller's bit planes (pageable) -> XOR stager -> %d-byte wire records in pinned staging -> hipMemcpyAsync -> kernels -> tables back; reference planes %s" % (head.get("record_bytes") or 0, "copied from the caller's registered arrays (isx_host_register, once, untimed) with every batch" if c5_ref_registered else "through staging"), 330),
+                       "reference_registered": c5_ref_registered,
                        "pipe_depth": args.depth, "pileup_cus": 256 - 8 * C5_RESERVE_CUS, "lean_slots": LEAN_SLOTS, "host_threads_per_rank": host_threads, "cgroup_cpus": cgroup_cpus(),
                        "numa_node": numa_node, "parallelism": "genome-sharded x%d%s" % (world, " (ranks share %d GPU)" % n_dev if shared else ""),
                        "verified": "per-batch checks in an untimed pass (largest batch: exact coverage + per-base SNV counts from the host); timed batches: row counts + checksum of the SNV / LD bytes equal"},

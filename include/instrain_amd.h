@@ -634,6 +634,15 @@ int isx_pipe_stage_planes(isx_pipe *p, int64_t n_pos, const isx_ref_planes *ref,
 /* device memory a pipe may spend on resident references (isx_ref_planes.key), in MiB; 0 = the default (4096), < 0 = keep nothing.  Keys
  * beyond the budget travel every time.  Entries live until isx_pipe_destroy. */
 int isx_pipe_set_reference_budget(isx_pipe *p, int64_t mib);
+/* A caller's long-lived host arrays registered for the copy engine (round 6): what profile_controller.py keeps in memory for the whole run -- the
+ * fasta, here its 2-bit / non-ACGT planes -- can be pinned ONCE (hipHostRegister; like loading the fasta, outside any batch) and is then copied to
+ * the device straight from where it lies: isx_pipe_submit_planes skips the copy of the reference planes into its pinned staging (a tenth of the
+ * stager's time on a whole-database pass) whenever ref->plane2 (and ref->nplane, if given) lie inside a registered range.  The planes still travel
+ * with every batch (unlike isx_ref_planes.key, which keeps them on the device).  The memory must stay valid and registered until every batch that
+ * was submitted with it has been collected; isx_host_unregister before freeing it.  ISX_ERR_HIP when the range cannot be pinned (RLIMIT_MEMLOCK),
+ * ISX_ERR_ARG for a range that overlaps a registered one / was never registered.  Thread-safe. */
+int isx_host_register(const void *ptr, int64_t bytes);
+int isx_host_unregister(const void *ptr);
 /* the stager on its own (no GPU needed), like isx_encode_delta: planes + reference planes -> 32-byte reference-delta records */
 int isx_encode_planes(const isx_read_planes *reads, const isx_ref_planes *ref, int64_t n_pos, int32_t host_threads, int32_t slack_groups,
                       int64_t cap_rec, int64_t ring_records, uint32_t *rec, uint32_t *gbase, int64_t *n_rec, int64_t *need_slack);

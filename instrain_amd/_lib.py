@@ -156,7 +156,7 @@ SYMBOLS = ["isx_last_error", "isx_abi_version", "isx_ctx_create", "isx_ctx_destr
            "isx_batch_fetch_entries", "isx_batch_fetch_dense", "isx_batch_fetch_snv", "isx_batch_fetch_ld", "isx_batch_fetch_allele_obs",
            "isx_batch_summarize", "isx_batch_summarize_genomes", "isx_compare_coverage", "isx_compare_scaffolds", "isx_compare_fetch_snps",
            "isx_pipe_create", "isx_pipe_destroy", "isx_pipe_submit", "isx_pipe_submit_reads", "isx_pipe_stage_reads", "isx_pipe_submit_wire", "isx_wire_bytes", "isx_wire_free", "isx_wire_keep_reference", "isx_pipe_submit_bam", "isx_encode_segs", "isx_encode_segs_ring", "isx_seg_records_needed", "isx_encode_delta", "isx_delta_records_needed", "isx_count_read_segs", "isx_pack_reads", "isx_pipe_collect", "isx_pipe_release", "isx_pipe_fetch_entries", "isx_pipe_fetch_entries_shrunk", "isx_levels_expand", "isx_encode_obs", "isx_encode_obs_ring",
-           "isx_pack_ref_planes", "isx_planes_from_segs", "isx_pack_read_planes", "isx_pipe_submit_planes", "isx_pipe_stage_planes", "isx_encode_planes", "isx_encode_planes_mm", "isx_pipe_set_reference_budget",
+           "isx_pack_ref_planes", "isx_planes_from_segs", "isx_pack_read_planes", "isx_pipe_submit_planes", "isx_pipe_stage_planes", "isx_encode_planes", "isx_encode_planes_mm", "isx_pipe_set_reference_budget", "isx_host_register", "isx_host_unregister",
            "isx_bgzf_index", "isx_bgzf_inflate_device", "isx_bgzf_inflate_host", "isx_bgzf_inflate_fast",
            "isx_bam_open", "isx_bam_close", "isx_bam_close_wait", "isx_bam_set_threads", "isx_bam_ref", "isx_bam_set_priority_reads", "isx_bam_scan", "isx_bam_scan_part",
            "isx_bam_insert_sizes", "isx_bam_set_wanted_refs", "isx_bam_pair_keys", "isx_bam_set_cross_names", "isx_bam_filter_insert_sizes", "isx_bam_filter", "isx_bam_set_r2m", "isx_bam_r2m", "isx_bam_drop_names", "isx_bam_batch_pair_names", "isx_bam_set_mm_cap", "isx_bam_mm_levels", "isx_bam_set_mm_levels", "isx_bam_ref_counts",
@@ -269,6 +269,8 @@ def load():
     lib.isx_pack_read_planes.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, C.POINTER(i64)]
     lib.isx_pipe_submit_planes.argtypes = [vp, i64, C.POINTER(RefPlanes), i32, vp, C.POINTER(ReadPlanes), C.POINTER(i64)]
     lib.isx_pipe_set_reference_budget.argtypes = [vp, i64]
+    lib.isx_host_register.argtypes = [vp, i64]
+    lib.isx_host_unregister.argtypes = [vp]
     lib.isx_pipe_stage_planes.argtypes = [vp, i64, C.POINTER(RefPlanes), i32, vp, C.POINTER(ReadPlanes), C.POINTER(vp)]
     lib.isx_encode_planes.argtypes = [C.POINTER(ReadPlanes), C.POINTER(RefPlanes), i64, i32, i32, i64, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]
     lib.isx_encode_planes_mm.argtypes = [C.POINTER(ReadPlanes), C.POINTER(RefPlanes), i64, i32, i32, i32, i64, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]

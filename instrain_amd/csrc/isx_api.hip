@@ -167,6 +167,48 @@ hipError_t isx_raw_dev_malloc(void **p, size_t bytes)
     return e;
 }
 
+// ---- host ranges registered for the copy engine (isx_host_register) ----
+namespace {
+struct HostRange { uintptr_t a; size_t n; };
+std::mutex g_hreg_mu;
+std::vector<HostRange> g_hreg;
+}  // namespace
+
+bool isx_host_is_registered(const void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    std::lock_guard<std::mutex> lk(g_hreg_mu);
+    for (const HostRange &r : g_hreg) if (a >= r.a && a + bytes <= r.a + r.n) return true;
+    return false;
+}
+
+extern "C" int isx_host_register(const void *ptr, int64_t bytes)
+{
+    if (!ptr || bytes <= 0) { isx_set_error("isx_host_register: bad argument"); return ISX_ERR_ARG; }
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    std::lock_guard<std::mutex> lk(g_hreg_mu);
+    for (const HostRange &r : g_hreg)
+        if (a < r.a + r.n && r.a < a + (size_t)bytes) { isx_set_error("isx_host_register: the range overlaps a registered one"); return ISX_ERR_ARG; }
+    HIP_TRY(hipHostRegister(const_cast<void *>(ptr), (size_t)bytes, hipHostRegisterDefault));
+    g_hreg.push_back(HostRange{a, (size_t)bytes});
+    return ISX_OK;
+}
+
+extern "C" int isx_host_unregister(const void *ptr)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    std::lock_guard<std::mutex> lk(g_hreg_mu);
+    for (size_t i = 0; i < g_hreg.size(); i++)
+        if (g_hreg[i].a == a) {
+            g_hreg.erase(g_hreg.begin() + (long)i);
+            HIP_TRY(hipHostUnregister(const_cast<void *>(ptr)));
+            return ISX_OK;
+        }
+    isx_set_error("isx_host_unregister: not a registered range");
+    return ISX_ERR_ARG;
+}
+
 namespace {
 __global__ void __launch_bounds__(256) k_copy_out(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
 {

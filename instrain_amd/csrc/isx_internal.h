@@ -55,6 +55,8 @@ hipError_t isx_copy_to_host_route(void *hdst_pinned, const void *dsrc, size_t by
 // copying a fixed-size prefix of mostly unused rows (up to 15 bytes beyond the last row are copied: both tables are larger)
 hipError_t isx_copy_rows_to_host(void *hdst_pinned, const void *dsrc, const uint32_t *d_cursor, uint32_t base, uint32_t row_bytes,
                                  size_t cap_rows, hipStream_t stream);
+// inside a range the caller registered with isx_host_register (pinned: the copy engine reads it where it lies)
+bool isx_host_is_registered(const void *ptr, size_t bytes);
 hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStream_t stream);
 hipError_t isx_read_sync(hipStream_t stream);
 // waits that sleep between polls (isx_api.hip): what every host thread of the library waits for the device with

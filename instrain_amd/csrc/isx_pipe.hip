@@ -169,6 +169,23 @@ static bool copy_ref_planes(isxenc::HostPool &pool, const isx_ref_planes *rp, in
     return any.load() != 0;
 }
 
+// does a bit plane hold a set bit (the non-ACGT plane of a registered reference: the kernels take the plain path when it is empty)
+static bool plane_any(isxenc::HostPool &pool, const uint8_t *pl, size_t bytes)
+{
+    const size_t piece = (size_t)1 << 20;
+    const int nt = (int)((bytes + piece - 1) / piece);
+    std::atomic<int> any{0};
+    pool.run(nt, [&](int t) {
+        const size_t a = (size_t)t * piece, n = std::min(piece, bytes - a);
+        uint64_t acc = 0;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t v; memcpy(&v, pl + a + i, 8); acc |= v; }
+        for (; i < n; i++) acc |= pl[a + i];
+        if (acc) any.store(1, std::memory_order_relaxed);
+    });
+    return any.load() != 0;
+}
+
 // a cheap content check of a reference's 2-bit plane (a resident reference is found by the caller's KEY: a key reused for other planes would
 // otherwise compare on the host against planes the device does not hold): 64-bit words sampled at 4096 spread places + the length
 static uint64_t ref_plane_checksum(const uint8_t *plane2, int64_t n_pos)
@@ -1274,6 +1291,23 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
                 t_ref0 = now_ms() - t_r;
                 goto ref_staged;
             }
+        }
+        if (rp && !(rp->key && !p->ref_cache.count(rp->key) && p->ref_cache_budget.load(std::memory_order_relaxed) > 0) &&
+            isx_host_is_registered(rp->plane2, ((size_t)n_pos + 3) / 4) &&
+            (!rp->nplane || isx_host_is_registered(rp->nplane, ((size_t)n_pos + 7) / 8))) {
+            // the caller's planes are registered for the copy engine (isx_host_register): they leave from where they lie, nothing is
+            // staged, the record pass compares against them (a key's FIRST trip still goes through staging: its device copy is made of that)
+            bool any_n = false;
+            if (rp->nplane) any_n = plane_any(*p->pool, rp->nplane, ((size_t)n_pos + 7) / 8);
+            s.ref_has_n = any_n;
+            J.ref2 = rp->plane2; J.refn = any_n ? rp->nplane : nullptr;
+            t_ref0 = now_ms() - t_r;
+            if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+            HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, rp->plane2, ((size_t)n_pos + 3) / 4, hipMemcpyHostToDevice, p->s_h2d));
+            if (any_n) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref + ref2_bytes(n_pos), rp->nplane, ((size_t)n_pos + 7) / 8, hipMemcpyHostToDevice, p->s_h2d));
+            if (!ring) HIP_TRY(hipEventRecord(s.ev_h2da, p->s_h2d));
+            early_ref = true;
+            goto ref_staged;
         }
         s.ref_has_n = rp ? copy_ref_planes(*p->pool, rp, n_pos, h2, hn) : pack_ref2(*p->pool, ref, n_pos, h2, hn);
         J.ref2 = h2; J.refn = s.ref_has_n ? hn : nullptr;

@@ -113,6 +113,31 @@ class RefPlanes:
     def c(self, keyed=True):
         return _lib.RefPlanes(self.plane2.ctypes.data, None if self.nplane is None else self.nplane.ctypes.data, self.key if keyed else 0)
 
+    def register(self):
+        """pin the planes for the copy engine (isx_host_register): a pipe then copies them to the device from where they lie instead of
+        through its staging.  Once per reference, like loading the fasta; unregister() before the arrays go."""
+        if getattr(self, "_registered", False):
+            return self
+        lib = _lib.load()
+        check(lib.isx_host_register(C.c_void_p(self.plane2.ctypes.data), C.c_int64(self.plane2.nbytes)))
+        if self.nplane is not None:
+            try:
+                check(lib.isx_host_register(C.c_void_p(self.nplane.ctypes.data), C.c_int64(self.nplane.nbytes)))
+            except Exception:
+                lib.isx_host_unregister(C.c_void_p(self.plane2.ctypes.data))
+                raise
+        self._registered = True
+        return self
+
+    def unregister(self):
+        if not getattr(self, "_registered", False):
+            return
+        lib = _lib.load()
+        lib.isx_host_unregister(C.c_void_p(self.plane2.ctypes.data))
+        if self.nplane is not None:
+            lib.isx_host_unregister(C.c_void_p(self.nplane.ctypes.data))
+        self._registered = False
+
 
 def pack_codes(codes):
     """[n, 150] uint8 base codes (0..3 A C T G, 4 skip, 5 non-ACGT) -> [n, 15] uint32, ten codes per word"""
