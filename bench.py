@@ -78,6 +78,7 @@ def pileup_algorithmic_bytes(n_obs, n_pos, n_entries, dense, record_bytes=8, n_r
 # way, same box) -- so the bench keeps the plain slots whose dense arrays the device summaries can read.
 LEAN_SLOTS = bool(int(os.environ.get("ISX_BENCH_LEAN_SLOTS", "1")))
 C5_RESERVE_CUS = int(os.environ.get("ISX_BENCH_C5_RESERVE_CUS", "4"))
+REGISTER_REF = bool(int(os.environ.get("ISX_BENCH_REGISTER_REF", "1")))    # the workloads' reference planes registered once for the copy engine (isx_host_register); 0 = through staging
 C5_LINKAGE = bool(int(os.environ.get("ISX_BENCH_C5_LINKAGE", "1")))      # 0: diagnostic only (what the linkage chain costs the stream); not the workload
 
 
@@ -309,6 +310,21 @@ def _time_batch(b, warm=2, steps=5):
         ts.append(time.perf_counter() - t0)
         ks.append(b.pileup_ms())
     return float(np.median(ts)), float(np.mean(ks)), float(np.min(ks))
+
+
+def _register_refs(vs):
+    try:
+        for v in vs:
+            v["ref_planes"].register()
+    except Exception as e:                      # (a lease that may not pin: through staging)
+        print("bench: reference planes not registered (%s)" % e, file=sys.stderr)
+        _unregister_refs(vs)
+
+
+def _unregister_refs(vs):
+    for v in vs:
+        if "ref_planes" in v:
+            v["ref_planes"].unregister()
 
 
 def linkage_leg(ctx, seed=3):
@@ -547,7 +563,7 @@ class C5Run:
         # with every batch of every pass, the pipe's threads just do not copy them into staging first.  The reads stay plain pageable memory.
         # ISX_BENCH_REGISTER_REF=0: as before round 6's last part (the A/B of the line).
         self.ref_registered = False
-        if int(os.environ.get("ISX_BENCH_REGISTER_REF", "1")):
+        if REGISTER_REF:
             t_r = time.perf_counter()
             try:
                 for w in self.ws:
@@ -1040,6 +1056,8 @@ def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
                        pin_threads=args.pin, n_mm_bins=1, enable_linkage=False, window=args.window, stage_async=args.queued_submit, lean_output=LEAN_SLOTS)
     as_planes = [dict(v, planes=engine.PlaneBatch.from_segs(v["segs"], threads=host_threads), ref_planes=engine.RefPlanes.from_codes(v["ref_codes"], threads=host_threads))
                  for v in variants]
+    if REGISTER_REF:                            # (the genomes' planes, like the headline's: registered once, copied from where they lie)
+        _register_refs(as_planes)
     k0 = warmup % n_var
     rot = lambda xs: xs[k0:] + xs[:k0]
     # (1) the leg's value: planes handed over inside the step
@@ -1061,6 +1079,7 @@ def c2_stream_leg(ctx, w, args, host_threads, steps, warmup):
     stream(pipe, variants, steps, args.depth, st2)
     dt2 = time.perf_counter() - t1
     pipe.close()
+    _unregister_refs(as_planes)
     st = [s for s, _ in stats]
     mean = lambda k, xs=None: float(np.mean([s[k] for s in (st if xs is None else xs)])) if (st if xs is None else xs) else 0.0
     k_ms = mean("kernel_ms")
@@ -1110,6 +1129,8 @@ def c2_mm_stream_leg(ctx, w, args, host_threads, steps, warmup):
     if not as_segs:
         variants = [dict(v, planes=engine.PlaneBatch.from_segs(v["segs"], threads=host_threads), ref_planes=engine.RefPlanes.from_codes(v["ref_codes"], threads=host_threads))
                     for v in variants]
+        if REGISTER_REF:
+            _register_refs(variants)
     out = {"workload": "C2 streamed with mm profiling ON (%d mm bins): one 5 Mbp genome (0.1 Gbp of reads) per batch, 20x, linkage off; every batch handed over "
                        "inside the step (%s), profiled once, the per-level tables handed back inside the step; %d distinct batches"
                        % (M, "isx_pipe_submit_reads: isx_segs" if as_segs else "isx_pipe_submit_planes: bit planes + the pairs' mm levels -> reference-delta records", n_var),
@@ -1178,6 +1199,7 @@ def c2_mm_stream_leg(ctx, w, args, host_threads, steps, warmup):
     out["verified"] = "untimed pass: every batch's levels expanded on the host (coverage adds up to the observations, (position, mm) order), batch 0 == one-shot entries bit by bit; timed batches: level / SNV row counts equal"
     out["hand_back"] = "level-sparse (isx_pipe_result.lev_*)" if pipe_levels[0] else "32-byte entries -> isx_pipe_fetch_entries_shrunk"
     pipe.close()
+    _unregister_refs(variants)
     st = [s for s, _ in stats]
     mean = lambda k: float(np.mean([s[k] for s in st])) if st else 0.0
     ms_step = dt / steps * 1e3

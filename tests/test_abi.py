@@ -77,6 +77,20 @@ def test_no_gpu_is_a_loud_error_not_a_fallback():
     assert b"device" in lib.isx_last_error().lower() or b"hip" in lib.isx_last_error().lower()
 
 
+def test_host_register_arguments_and_no_gpu():
+    """isx_host_register (round 6): bad arguments and unknown ranges are errors; without a device nothing can be pinned for its copy engine
+    and the call says so (the pipe then stages the planes as before: registration is an optimisation a caller asks for, never a silent no-op)"""
+    import numpy as np
+    import torch
+    lib = _lib.load()
+    buf = np.zeros(1 << 16, np.uint8)
+    assert lib.isx_host_register(None, 16) != 0 and lib.isx_host_register(buf.ctypes.data, 0) != 0
+    assert lib.isx_host_unregister(buf.ctypes.data) != 0 and b"not a registered range" in lib.isx_last_error()
+    if not torch.cuda.is_available():
+        assert lib.isx_host_register(buf.ctypes.data, buf.nbytes) != 0
+        assert lib.isx_host_unregister(buf.ctypes.data) != 0
+
+
 def test_product_never_imports_oracle():
     import glob
     for f in glob.glob(os.path.join(REPO, "instrain_amd", "**", "*.py"), recursive=True):
