@@ -62,8 +62,10 @@ void host_block_free(void *p, bool pinned)
     if (pinned) isx_pin_free(p); else free(p);
 }
 
+#define H2D(p, s) ((s).h2d ? (s).h2d : (p)->s_h2d)
 struct Slot {
     isx_batch *b = nullptr;
+    hipStream_t h2d = nullptr;              // this slot's copy-in queue when the pipe has two (else the pipe's)
     uint8_t *h_in = nullptr, *d_in = nullptr;
     size_t in_bytes = 0;                    // of the device arena; the pinned one ends after the ring when the pipe stages through one
     size_t off_bounds = 0, off_win = 0, off_ref = 0, off_gbase = 0, off_ridx = 0, off_rec = 0;   // records last
@@ -238,6 +240,7 @@ struct isx_pipe {
     std::unique_ptr<isxenc::HostPool> pool;
     std::vector<Slot> slots;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipStream_t s_h2d2 = nullptr;           // ISX_PIPE_H2D_STREAMS=2: the odd slots' copy-in queue (a second copy engine)
     hipStream_t s_fin = nullptr;            // the finishers' own queues: what they fetch must not wait behind the copy-outs of later batches
     hipStream_t s_fin2 = nullptr;           // (one per finisher thread: a sync of one must not wait for the other's 30 MB table)
     int64_t next_ticket = 0;
@@ -337,6 +340,7 @@ static void pipe_free(isx_pipe *p)
     }
     (void)hipSetDevice(p->ctx->device);
     if (p->s_h2d) (void)isx_wait_stream(p->s_h2d);
+    if (p->s_h2d2) (void)isx_wait_stream(p->s_h2d2);
     if (p->s_d2h) (void)isx_wait_stream(p->s_d2h);
     if (p->s_fin) (void)isx_wait_stream(p->s_fin);
     if (p->s_fin2) (void)isx_wait_stream(p->s_fin2);
@@ -377,6 +381,7 @@ static void pipe_free(isx_pipe *p)
         if (p->bounce_ev[i]) (void)hipEventDestroy(p->bounce_ev[i]);
     }
     if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
+    if (p->s_h2d2) (void)hipStreamDestroy(p->s_h2d2);
     if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     if (p->s_fin) (void)hipStreamDestroy(p->s_fin);
     if (p->s_fin2) (void)hipStreamDestroy(p->s_fin2);
@@ -924,7 +929,14 @@ int isx_pipe_create(isx_ctx *c, const isx_params *prm, const isx_pipe_params *pp
         return ISX_ERR_HIP;
     }
     p->slots.resize((size_t)pp->depth);
-    for (int i = 0; i < pp->depth && rc == ISX_OK; i++) rc = slot_batch_create(p, p->slots[(size_t)i], i);
+    {   // ISX_PIPE_H2D_STREAMS=2 (tuning aid): the odd slots copy in through a queue of their own
+        const char *e2 = getenv("ISX_PIPE_H2D_STREAMS");
+        if (e2 && atoi(e2) >= 2 && pp->depth >= 2 && isx_side_stream_create(c, &p->s_h2d2) != hipSuccess) { p->s_h2d2 = nullptr; (void)hipGetLastError(); }
+    }
+    for (int i = 0; i < pp->depth && rc == ISX_OK; i++) {
+        rc = slot_batch_create(p, p->slots[(size_t)i], i);
+        if ((i & 1) && p->s_h2d2) p->slots[(size_t)i].h2d = p->s_h2d2;
+    }
     if (rc != ISX_OK) { pipe_free(p); return rc; }
     if (!p->slots[0].out_pinned) {
         p->bounce_bytes = (size_t)16 << 20;
@@ -970,7 +982,7 @@ static int enqueue_pass(isx_pipe *p, Slot &s, int64_t n_pos, int64_t *ticket)
     const int rc = enqueue_pass_impl(p, s, n_pos, ticket);
     if (rc != ISX_OK) {
         const std::string why(isx_last_error());
-        (void)isx_wait_stream(p->s_h2d);
+        (void)isx_wait_stream(H2D(p, s));
         (void)isx_wait_stream(p->ctx->pstream[s.b->ps]);
         (void)isx_wait_stream(p->s_d2h);
         isx_set_error(why);
@@ -1077,7 +1089,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     if (ring) {
         // the copy-in queue starts here: every finished wave leaves for its place in the device arena while the next
         // one is being written into the other half
-        HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+        HIP_TRY(hipEventRecord(s.ev_h2d0, H2D(p, s)));
         const size_t half_bytes = (size_t)p->ring_half * p->rb, grp_bytes = (size_t)p->G * p->rb;
         J.ring_groups = p->ring_half / p->G;
         J.wave_begin = [&](int h) {
@@ -1086,8 +1098,8 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         J.wave_flush = [&](int h, int64_t g0, int64_t g1) {
             const size_t n = (size_t)(g1 - g0) * grp_bytes;
             if (g0 == 0) ring_bytes = 0;                    // a layout that overflowed is written again from the start
-            hipError_t e = hipMemcpyAsync(d_rec + (size_t)g0 * grp_bytes, s.h_in + s.off_rec + (size_t)h * half_bytes, n, hipMemcpyHostToDevice, p->s_h2d);
-            if (e == hipSuccess) e = hipEventRecord(s.ev_ring[h], p->s_h2d);
+            hipError_t e = hipMemcpyAsync(d_rec + (size_t)g0 * grp_bytes, s.h_in + s.off_rec + (size_t)h * half_bytes, n, hipMemcpyHostToDevice, H2D(p, s));
+            if (e == hipSuccess) e = hipEventRecord(s.ev_ring[h], H2D(p, s));
             if (e != hipSuccess && ring_err == hipSuccess) ring_err = e;
             s.ring_busy[h] = true;
             ring_bytes += n;
@@ -1104,7 +1116,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
         erc = isxenc::encode_obs(*p->pool, J);
         if (erc != isxenc::ENC_OK || !linkage || J.n_runs <= s.cap_runs || attempt == 1) break;
         // more pair-id runs than any batch of this slot had (short fragments): larger blocks, encode again
-        HIP_TRY(isx_wait_stream(p->s_h2d));
+        HIP_TRY(isx_wait_stream(H2D(p, s)));
         host_block_free(s.h_runs, s.runs_pinned); s.h_runs = nullptr;
         isx_dev_free(s.d_runs); s.d_runs = nullptr;
         s.cap_runs = J.n_runs + J.n_runs / 4 + 4096;
@@ -1174,7 +1186,7 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
                 t_enc - t0, J.passes, now_ms() - t_enc, (long long)n_obs, (long long)J.n_runs);
 
     // ---- copy-in queue ----
-    if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+    if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, H2D(p, s)));
     const size_t ref_bytes = ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0);   // 2-bit plane (+ the non-ACGT bit plane)
     const size_t head = (size_t)(n_splits + 1) * sizeof(int64_t) + s.win.size() * sizeof(uint2) + ref_bytes;
     // the stream is followed by a tail of padding records / zero bases (see ISX_TAIL_BYTES): the slot's arena still
@@ -1182,27 +1194,27 @@ static int submit_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, int32_t
     memset(s.h_in + s.off_gbase + (size_t)(b->n_rec / p->G) * sizeof(uint32_t), 0, ISX_TAIL_GROUPS * sizeof(uint32_t));
     const size_t gb_bytes = ((size_t)(b->n_rec / p->G) + ISX_TAIL_GROUPS) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * p->rb + ISX_TAIL_BYTES;
     // bounds | windows | reference planes: what is used of each region, not the regions (a slot is sized for the largest batch)
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, s.h_in + s.off_win, s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, s.h_in + s.off_ref, ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, H2D(p, s)));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, s.h_in + s.off_win, s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, H2D(p, s)));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, s.h_in + s.off_ref, ref_bytes, hipMemcpyHostToDevice, H2D(p, s)));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, H2D(p, s)));
     if (ring) {             // the records left wave by wave; the tail is written on the device
-        if (p->rb == 2) HIP_TRY(hipMemsetD8Async(reinterpret_cast<hipDeviceptr_t>(d_rec + (size_t)b->n_rec * 2), 0xFF, ISX_TAIL_BYTES, p->s_h2d));
-        else HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_rec + (size_t)b->n_rec * 4), (int)ISX_PAD32, ISX_TAIL_BYTES / 4, p->s_h2d));
+        if (p->rb == 2) HIP_TRY(hipMemsetD8Async(reinterpret_cast<hipDeviceptr_t>(d_rec + (size_t)b->n_rec * 2), 0xFF, ISX_TAIL_BYTES, H2D(p, s)));
+        else HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_rec + (size_t)b->n_rec * 4), (int)ISX_PAD32, ISX_TAIL_BYTES / 4, H2D(p, s)));
         if (ring_bytes != (size_t)b->n_rec * p->rb) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; }
     } else {
         if (p->rb == 2) memset(s.h_in + s.off_rec + (size_t)b->n_rec * 2, 0xFF, ISX_TAIL_BYTES);
         else std::fill_n(reinterpret_cast<uint32_t *>(s.h_in + s.off_rec + (size_t)b->n_rec * 4), ISX_TAIL_BYTES / 4, (uint32_t)ISX_PAD32);
-        HIP_TRY(hipMemcpyAsync(d_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
+        HIP_TRY(hipMemcpyAsync(d_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, H2D(p, s)));
     }
     s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes);
     if (linkage) {
         const size_t rb = (size_t)b->n_runs * sizeof(isxenc::PairRun), ib = (size_t)(b->n_rec / ISX_CHUNK) * sizeof(uint32_t);
-        HIP_TRY(hipMemcpyAsync(s.d_runs, s.h_runs, rb, hipMemcpyHostToDevice, p->s_h2d));
-        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ridx, s.h_in + s.off_ridx, ib, hipMemcpyHostToDevice, p->s_h2d));
+        HIP_TRY(hipMemcpyAsync(s.d_runs, s.h_runs, rb, hipMemcpyHostToDevice, H2D(p, s)));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ridx, s.h_in + s.off_ridx, ib, hipMemcpyHostToDevice, H2D(p, s)));
         s.h2d_bytes += (int64_t)(rb + ib);
     }
-    HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
+    HIP_TRY(hipEventRecord(s.ev_h2d1, H2D(p, s)));
     s.h2d_split = false;
 
     return enqueue_pass(p, s, n_pos, ticket);
@@ -1245,7 +1257,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (ring) {
         // the copy-in queue starts here: every finished wave leaves for its place in the device arena while the next one is
         // being written into the other half
-        HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+        HIP_TRY(hipEventRecord(s.ev_h2d0, H2D(p, s)));
         const size_t half_bytes = (size_t)p->ring_half * (size_t)p->rb;
         constexpr size_t grp_bytes = (size_t)ISX_SEG_GROUP * 64;           // (= ISX_DREC_GROUP * 32: a group is 1 KiB in both formats)
         uint8_t *d_rec = s.d_in + s.off_rec;
@@ -1255,8 +1267,8 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         };
         J.wave_flush = [&s, p, &ring_err, &ring_bytes, half_bytes, d_rec](int h, int64_t g0, int64_t g1) {
             const size_t nb = (size_t)(g1 - g0) * grp_bytes;
-            hipError_t e = hipMemcpyAsync(d_rec + (size_t)g0 * grp_bytes, s.h_in + s.off_rec + (size_t)h * half_bytes, nb, hipMemcpyHostToDevice, p->s_h2d);
-            if (e == hipSuccess) e = hipEventRecord(s.ev_ring[h], p->s_h2d);
+            hipError_t e = hipMemcpyAsync(d_rec + (size_t)g0 * grp_bytes, s.h_in + s.off_rec + (size_t)h * half_bytes, nb, hipMemcpyHostToDevice, H2D(p, s));
+            if (e == hipSuccess) e = hipEventRecord(s.ev_ring[h], H2D(p, s));
             if (e != hipSuccess && ring_err == hipSuccess) ring_err = e;
             s.ring_busy[h] = true;
             ring_bytes += nb;
@@ -1284,9 +1296,9 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
                 s.ref_has_n = e.has_n;
                 J.ref2 = rp->plane2; J.refn = e.has_n ? rp->nplane : nullptr;
                 resident_ref = e.d;
-                HIP_TRY(hipStreamWaitEvent(p->s_h2d, e.ready, 0));         // (the entry's own copy, enqueued by an earlier submit)
-                if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
-                HIP_TRY(hipEventRecord(s.ev_h2da, p->s_h2d));
+                HIP_TRY(hipStreamWaitEvent(H2D(p, s), e.ready, 0));         // (the entry's own copy, enqueued by an earlier submit)
+                if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, H2D(p, s)));
+                HIP_TRY(hipEventRecord(s.ev_h2da, H2D(p, s)));
                 early_ref = true;
                 t_ref0 = now_ms() - t_r;
                 goto ref_staged;
@@ -1302,10 +1314,10 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
             s.ref_has_n = any_n;
             J.ref2 = rp->plane2; J.refn = any_n ? rp->nplane : nullptr;
             t_ref0 = now_ms() - t_r;
-            if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
-            HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, rp->plane2, ((size_t)n_pos + 3) / 4, hipMemcpyHostToDevice, p->s_h2d));
-            if (any_n) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref + ref2_bytes(n_pos), rp->nplane, ((size_t)n_pos + 7) / 8, hipMemcpyHostToDevice, p->s_h2d));
-            if (!ring) HIP_TRY(hipEventRecord(s.ev_h2da, p->s_h2d));
+            if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, H2D(p, s)));
+            HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, rp->plane2, ((size_t)n_pos + 3) / 4, hipMemcpyHostToDevice, H2D(p, s)));
+            if (any_n) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref + ref2_bytes(n_pos), rp->nplane, ((size_t)n_pos + 7) / 8, hipMemcpyHostToDevice, H2D(p, s)));
+            if (!ring) HIP_TRY(hipEventRecord(s.ev_h2da, H2D(p, s)));
             early_ref = true;
             goto ref_staged;
         }
@@ -1316,9 +1328,9 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         // (ISX_PIPE_LATE_DMA=1: every copy after the host pass, as before round 5 -- same-box A/B)
         static const bool late_dma = getenv("ISX_PIPE_LATE_DMA") != nullptr;
         if (late_dma) goto ref_staged;
-        if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
-        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, h2, ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0), hipMemcpyHostToDevice, p->s_h2d));
-        if (!ring) HIP_TRY(hipEventRecord(s.ev_h2da, p->s_h2d));
+        if (!ring) HIP_TRY(hipEventRecord(s.ev_h2d0, H2D(p, s)));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, h2, ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0), hipMemcpyHostToDevice, H2D(p, s)));
+        if (!ring) HIP_TRY(hipEventRecord(s.ev_h2da, H2D(p, s)));
         early_ref = true;
         if (rp && rp->key && !resident_ref) {
             // first trip of this key: a device-side copy of what just arrived stays with the pipe (while its budget lasts)
@@ -1326,7 +1338,7 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
             if (p->ref_cache_bytes + rb_all <= p->ref_cache_budget.load(std::memory_order_relaxed)) {
                 isx_pipe::RefEntry e;
                 bool ok = isx_dev_malloc(reinterpret_cast<void **>(&e.d), rb_all + 64) == hipSuccess && hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) == hipSuccess;
-                ok = ok && hipMemcpyAsync(e.d, s.d_in + s.off_ref, rb_all, hipMemcpyDeviceToDevice, p->s_h2d) == hipSuccess && hipEventRecord(e.ready, p->s_h2d) == hipSuccess;
+                ok = ok && hipMemcpyAsync(e.d, s.d_in + s.off_ref, rb_all, hipMemcpyDeviceToDevice, H2D(p, s)) == hipSuccess && hipEventRecord(e.ready, H2D(p, s)) == hipSuccess;
                 if (ok) {
                     e.bytes = rb_all; e.n_pos = n_pos; e.has_n = s.ref_has_n; e.sum = ref_plane_checksum(rp->plane2, n_pos);
                     p->ref_cache_bytes += rb_all;
@@ -1377,9 +1389,9 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     if (early_ref && !ring) {
         // the records leave as soon as they exist; the window directory below is made while they travel
         const size_t gb_bytes0 = (size_t)(J.n_rec / (int64_t)p->G) * sizeof(uint32_t), rec_bytes0 = (size_t)J.n_rec * (size_t)p->rb;
-        HIP_TRY(hipEventRecord(s.ev_h2db, p->s_h2d));
-        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes0, hipMemcpyHostToDevice, p->s_h2d));
-        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes0, hipMemcpyHostToDevice, p->s_h2d));
+        HIP_TRY(hipEventRecord(s.ev_h2db, H2D(p, s)));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes0, hipMemcpyHostToDevice, H2D(p, s)));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes0, hipMemcpyHostToDevice, H2D(p, s)));
         early_rec = true;
     }
     if (!planes_in) s.ref_has_n = pack_ref2(*p->pool, ref, n_pos, s.h_in + s.off_ref, s.h_in + s.off_ref + ref2_bytes(n_pos));
@@ -1435,23 +1447,23 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     const double t_q0 = now_ms();
 
     // ---- copy-in queue: bounds | windows | reference codes, then group bases (| pair ids) | records ----
-    if (!ring && !early_ref) HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
+    if (!ring && !early_ref) HIP_TRY(hipEventRecord(s.ev_h2d0, H2D(p, s)));
     const size_t ref_bytes = ref2_bytes(n_pos) + (s.ref_has_n ? refn_bytes(n_pos) : 0);   // 2-bit plane (+ the non-ACGT bit plane)
     const size_t head = (size_t)(n_splits + 1) * sizeof(int64_t) + s.win.size() * sizeof(uint2) + ref_bytes;
     const size_t gb_bytes = (size_t)(b->n_rec / p->G) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * (size_t)p->rb;
     // bounds | windows | reference planes: what is used of each region, not the regions (a slot is sized for the largest batch)
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, s.h_in + s.off_win, s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, p->s_h2d));
-    if (!early_ref) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, s.h_in + s.off_ref, ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    if (!early_rec) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, H2D(p, s)));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, s.h_in + s.off_win, s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, H2D(p, s)));
+    if (!early_ref) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, s.h_in + s.off_ref, ref_bytes, hipMemcpyHostToDevice, H2D(p, s)));
+    if (!early_rec) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, H2D(p, s)));
     if (ring) { if (ring_bytes != rec_bytes) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; } }
-    else if (!early_rec) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
+    else if (!early_rec) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes, hipMemcpyHostToDevice, H2D(p, s)));
     s.h2d_bytes = (int64_t)(head + gb_bytes + rec_bytes) - (resident_ref ? (int64_t)ref_bytes : 0);
     if (linkage && !p->drec) {
-        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, s.h_in + s.off_pairs, (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, p->s_h2d));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, s.h_in + s.off_pairs, (size_t)b->n_rec * sizeof(uint32_t), hipMemcpyHostToDevice, H2D(p, s)));
         s.h2d_bytes += (int64_t)b->n_rec * 4;
     }
-    HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
+    HIP_TRY(hipEventRecord(s.ev_h2d1, H2D(p, s)));
     s.h2d_split = early_rec;
     const double t_q1 = now_ms();
     rc = enqueue_pass(p, s, n_pos, ticket);
@@ -1679,14 +1691,14 @@ int isx_pipe_submit_wire(isx_pipe *p, const isx_wire *w, int64_t *ticket)
     b->d_rec16 = nullptr; b->d_rec32 = nullptr;
     b->d_pair = linkage && !p->drec ? reinterpret_cast<uint32_t *>(s.d_in + s.off_pairs) : nullptr;
     b->d_pair_runs = nullptr; b->d_run_index = nullptr; b->n_runs = 0;
-    HIP_TRY(hipEventRecord(s.ev_h2d0, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, w->h + w->o_bounds, w->bounds_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, w->h + w->o_win, w->win_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    if (!w->d_ref) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, w->h + w->o_ref, w->ref_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, w->h + w->o_gbase, w->gbase_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    if (w->pairs_bytes) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, w->h + w->o_pairs, w->pairs_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, w->h + w->o_rec, w->rec_bytes, hipMemcpyHostToDevice, p->s_h2d));
-    HIP_TRY(hipEventRecord(s.ev_h2d1, p->s_h2d));
+    HIP_TRY(hipEventRecord(s.ev_h2d0, H2D(p, s)));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, w->h + w->o_bounds, w->bounds_bytes, hipMemcpyHostToDevice, H2D(p, s)));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, w->h + w->o_win, w->win_bytes, hipMemcpyHostToDevice, H2D(p, s)));
+    if (!w->d_ref) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, w->h + w->o_ref, w->ref_bytes, hipMemcpyHostToDevice, H2D(p, s)));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, w->h + w->o_gbase, w->gbase_bytes, hipMemcpyHostToDevice, H2D(p, s)));
+    if (w->pairs_bytes) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_pairs, w->h + w->o_pairs, w->pairs_bytes, hipMemcpyHostToDevice, H2D(p, s)));
+    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, w->h + w->o_rec, w->rec_bytes, hipMemcpyHostToDevice, H2D(p, s)));
+    HIP_TRY(hipEventRecord(s.ev_h2d1, H2D(p, s)));
     s.h2d_split = false;
     s.h2d_bytes = isx_wire_bytes(w);
     s.encode_ms = (float)(now_ms() - t0);       // (what this submit itself spent on the host: enqueueing)
