@@ -59,4 +59,18 @@ with open('profiles/%s_link_chain.md' % tag, 'w') as o:
     o.write('### bucket chain, C5 shard (all kernels)\n\n' + table(c5b) + '\n\n')
     o.write('### sorted chain, C5 shard (top 30)\n\n' + table(c5s, top=30) + '\n\n')
     o.write('## C3 resident batch: the chains\' kernels (one process ran both chains; 14 launches each)\n\n' + table(c3, keep=lambda n: any(k in n for k in link), top=60) + '\n')
+# the reference's default mode (mm on + linkage on) as a stream: tools/mm_launch_prof.sh
+mm = glob.glob('gpurun_out/mmcount/trace/**/mm_kernel_stats.csv', recursive=True)
+if mm:
+    rows = list(csv.DictReader(open(mm[0])))
+    nb = 20
+    for l in open('gpurun_out/mmcount/run.log'):
+        if l.startswith('BATCHES'):
+            nb = int(l.split()[1])
+    head = [l.rstrip() for l in open('gpurun_out/mmcount/run.log') if l.startswith('default mode')]
+    tot = sum(int(r['Calls']) for r in rows)
+    with open('profiles/%s_link_chain.md' % tag, 'a') as o:
+        o.write('\n## The default mode (mm profiling on, linkage on) as a stream: launches per batch\n\n`tools/mm_launch_prof.sh` (`rocprofv3 --kernel-trace --stats -- python tools/mm_launch_count.py %d`).\n' % nb)
+        o.write('%s\n\n**%d launches / %d batches = %.1f a batch** (the site table of `k_pileup_mm` still goes through a device-wide sort in front of the chain: `k_site_keys` + the rocprim rows; four copy kernels take the level tables home).\n\n' % ('\n'.join(head), tot, nb, tot / nb))
+        o.write(table(rows, top=30) + '\n')
 print('profiles/%s_link_chain.md' % tag)
