@@ -1026,7 +1026,7 @@ void isx_batch_destroy(isx_batch *b)
     }
     (void)hipSetDevice(b->ctx->device);
     (void)isx_wait_stream(b->ctx->stream);
-    void *ps[] = {b->d_cov_row_win, b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_drec, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_lev_mask, b->d_lev_cov, b->d_lev_win_off, b->d_slev,
+    void *ps[] = {b->d_cov_row_win, b->d_cov8, b->d_sat, b->d_clon_list, b->d_clon_sorted, b->d_seg, b->d_drec, b->d_rec, b->d_rec32, b->d_rec16, b->d_gbase, b->d_pair, b->d_gpos, b->d_gpos16, b->d_cbase, b->d_ref, b->d_win, b->d_thr, b->d_bounds, b->d_counts, b->d_clon, b->d_clon_r, b->d_cov16, b->d_rare, b->d_entries, b->d_win_nent, b->d_win_site_base, b->d_win_site_cnt, b->d_lev_mask, b->d_lev_cov, b->d_lev_win_off, b->d_slev,
                   b->d_snv, b->d_sites, b->d_ao, b->d_cursors, b->d_snv_raw, b->d_sites_raw, b->d_rare_raw, b->d_win_rec, b->d_win_out};
     if (b->h_state) (void)hipHostFree(b->h_state);
     for (void *p : ps) if (p) isx_dev_free(p);          // (falls through to hipFree for blocks that did not come from the cache)
@@ -1369,6 +1369,20 @@ int launch_pass(isx_batch *b)
         if (b->d_rare) a.rare = b->d_rare_raw;
         a.win_rec = b->d_win_rec;
     }
+    if (b->M > 1 && b->prm.enable_linkage && b->prm.linkage_mode != 2) {
+        // mm profiling on: a window's SNP sites lie side by side in the site table; (first, count) per window lets the linkage stages put
+        // the table in position order window by window instead of sorting it (k_site_order)
+        if ((size_t)b->n_win > b->cap_win_sites || !b->d_win_site_cnt) {
+            if (b->d_win_site_base) isx_dev_free(b->d_win_site_base);
+            if (b->d_win_site_cnt) isx_dev_free(b->d_win_site_cnt);
+            b->d_win_site_base = b->d_win_site_cnt = nullptr; b->cap_win_sites = 0;
+            const size_t want = (size_t)b->n_win + (size_t)b->n_win / 4 + 64;
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_win_site_base), want * sizeof(uint32_t)));
+            HIP_TRY(isx_dev_malloc(reinterpret_cast<void **>(&b->d_win_site_cnt), want * sizeof(uint32_t)));
+            b->cap_win_sites = want;
+        }
+        a.win_site_base = b->d_win_site_base; a.win_site_cnt = b->d_win_site_cnt;
+    }
     launch_pileup(a, b->block, b->lds, b->grid, b->packed, s, b->ev[0], b->ev[1]);
     if (b->M == 1) {
         launch_win_order(b->d_win_rec, b->d_win_out, b->n_win, b->W, b->d_snv_raw, b->d_snv, b->d_sites_raw, b->d_sites,
@@ -1425,6 +1439,7 @@ int finish_pass_sizes(isx_batch *b, uint32_t *cap_flags, hipStream_t link_stream
         HIP_TRY(isx_wait_stream(s));
         memset(b->base, 0, sizeof(b->base));
     }
+    b->sites_loose = (flags & ISX_FLAG_SITES_LOOSE) != 0;
     if (flags & ISX_FLAG_MM_RANGE) { isx_set_error("an observation has mm >= n_mm_bins"); return ISX_ERR_MM_RANGE; }
     if (flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES | ISX_FLAG_CAP_AO)) {
         *cap_flags = flags & (ISX_FLAG_CAP_ENTRIES | ISX_FLAG_CAP_SNV | ISX_FLAG_CAP_SITES | ISX_FLAG_CAP_AO);
@@ -1462,6 +1477,7 @@ int finish_pass_link(isx_batch *b, hipStream_t link_stream)
         in.n_pairs = b->n_pairs; in.ao = b->d_ao; in.n_ao = b->n_ao_pass;
         in.sites = b->d_sites; in.n_sites = (uint32_t)b->sizes.n_sites; in.sites_ordered = b->ordered;
         in.slev = b->d_slev; in.snv = b->d_snv;
+        if (b->M > 1 && b->d_win_site_cnt && !b->sites_loose) { in.win_site_base = b->d_win_site_base; in.win_site_cnt = b->d_win_site_cnt; in.n_win = b->n_win; }
         in.split_bounds = b->d_bounds; in.n_splits = b->n_splits; in.M = b->M; in.min_snp = b->prm.min_snp;
         LinkageOut lo;
         int rc = run_linkage(in, b->L, lo);

@@ -103,6 +103,9 @@ struct isx_batch {
     int lev_mask_bytes = 0, lev_cov_bytes = 1;
     isx_entry *d_entries = nullptr;  // mm path: [n_win][slab] slabs, then cap_ovf overflow entries
     uint32_t *d_win_nent = nullptr;
+    uint32_t *d_win_site_base = nullptr, *d_win_site_cnt = nullptr;    // k_pileup_mm with linkage: a window's range in the site table
+    size_t cap_win_sites = 0;
+    bool sites_loose = false;           // the last pass allocated a site outside its window's range (ISX_FLAG_SITES_LOOSE)
     isx_slev *d_slev = nullptr;
     uint32_t slab = 0;
     size_t cap_ovf = 0, cap_slev = 0;

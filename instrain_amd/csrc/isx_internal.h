@@ -86,6 +86,7 @@ template <class T> static inline hipError_t isx_raw_dev_malloc(T **p, size_t byt
 #define ISX_FLAG_CAP_AO 16u
 #define ISX_FLAG_CAP_INCR 32u
 #define ISX_FLAG_CAP_LD 64u
+#define ISX_FLAG_SITES_LOOSE 128u      // k_pileup_mm: a site was allocated outside its window's range (row queue full): the window site table does not cover the batch
 
 // cursors (dev_cursors[i], uint32)
 enum { CUR_ENTRIES = 0 /* mm path: overflow entries */, CUR_SNV = 1, CUR_SITES = 2, CUR_AO = 3, CUR_SLEV = 4,
@@ -232,6 +233,7 @@ struct PileupArgs {
     uint32_t cap_ovf;           // overflow capacity
     uint64_t ovf0;              // index of the overflow region = n_win * slab
     uint32_t *win_nent;         // [n_win] entries used in each slab
+    uint32_t *win_site_base, *win_site_cnt;     // [n_win] k_pileup_mm with linkage: where a window's SNP sites lie in `sites` and how many (round 6: position order without a sort)
     isx_slev *slev;             // per-level counts of the SNP sites
     uint32_t cap_slev;
     isx_snv *snv;

@@ -34,7 +34,7 @@ struct LinkageBuffers {
     DevBuf<uint8_t> temp;
     // bucket chain (isx_linkage.hip): per-pair chains of the allele observations, a bucket of pair increments per first site
     DevBuf<uint64_t> chain_head;
-    DevBuf<uint32_t> next, site_cnt, site_off, site_cur, site_nu, site_rows, site_row_off, site_list1, site_list2;
+    DevBuf<uint32_t> next, site_cnt, site_off, site_cur, site_nu, site_rows, site_row_off, site_list1, site_list2, win_off, win_list;
     DevBuf<uint64_t> edge_list;  // (site1, index of the edge's first key in the site's bucket) as uint2
     uint32_t chain_epoch = 0;
     std::vector<isx_ld> h_ld;    // what the chain's one read-back brought: state words + the first rows
@@ -57,6 +57,8 @@ struct LinkageIn {
     const isx_site *sites;      // from the pileup kernel: unsorted, or ...
     uint32_t n_sites;
     bool sites_ordered = false; // ... already in position order (dense path: k_win_gather) -- the site sort is skipped
+    const uint32_t *win_site_base = nullptr, *win_site_cnt = nullptr;   // ... or (mm path) window by window: [n_win] first site / sites of every window
+    int n_win = 0;              //     (k_site_order puts the table in position order without a device-wide sort)
     const isx_slev *slev;       // mm path: per-level counts of the SNP sites
     const isx_snv *snv;         // dense path: the SNV rows (isx_site::entry_off indexes them)
     const int64_t *split_bounds;

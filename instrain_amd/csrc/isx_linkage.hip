@@ -681,6 +681,25 @@ __global__ void __launch_bounds__(256) k_edge_rows(const uint64_t *keys, const u
     }
 }
 
+// mm path: the site table in position order without a device-wide sort.  k_pileup_mm writes a window's sites side by side (one allocation a
+// window) and records (first, count) per window; k_scan_u32 over the counts gives every window's place in position order and the list of
+// windows that have sites; here one wave per listed window ranks its few sites by position (a count of the smaller ones) and copies them there.
+__global__ void __launch_bounds__(64) k_site_order(const isx_site *sites, const uint32_t *win_base, const uint32_t *win_off, const uint32_t *win_list,
+                                                   const uint32_t *n_list_p, isx_site *sorted)
+{
+    const uint32_t l = threadIdx.x, n_list = *n_list_p;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const uint32_t w = win_list[li], off = win_off[w], n = win_off[w + 1] - off;
+        const isx_site *src = sites + win_base[w];
+        for (uint32_t e = l; e < n; e += 64) {
+            const isx_site me = src[e];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) rank += src[j].gpos < me.gpos ? 1u : 0u;     // (a position is a site once)
+            sorted[off + rank] = me;
+        }
+    }
+}
+
 __global__ void k_ao_pair_keys(const isx_ao *ao, uint32_t n, uint32_t *ao_key)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -908,7 +927,7 @@ void LinkageBuffers::release()
 {
     void *ps[] = {site_keys.p, site_keys2.p, sites_sorted.p, site_gpos.p, site_split.p, ao_key.p, ao2.p,
                   ao_key2.p, incr_cnt.p, incr_off.p, keys.p, keys2.p, ukeys.p, ucnt.p, n_runs.p, rows_per.p,
-                  row_off.p, ld_block.p, temp.p, chain_head.p, next.p, site_cnt.p, site_off.p, site_cur.p, site_nu.p, site_rows.p, site_row_off.p, site_list1.p, site_list2.p, edge_list.p, key64.p, key64b.p, head.p, row_id.p, first_row.p, first_site.p,
+                  row_off.p, ld_block.p, temp.p, chain_head.p, next.p, site_cnt.p, site_off.p, site_cur.p, site_nu.p, site_rows.p, site_row_off.p, site_list1.p, site_list2.p, edge_list.p, win_off.p, win_list.p, key64.p, key64b.p, head.p, row_id.p, first_row.p, first_site.p,
                   split_slot.p, tile_cnt.p, tile_off.p, vals.p, vals2.p, dsplits.p, dtiles.p, xt.p};
     for (void *p : ps) if (p) isx_dev_free(p);
     *this = LinkageBuffers();
@@ -1232,7 +1251,14 @@ int run_linkage(const LinkageIn &in, LinkageBuffers &B, LinkageOut &out)
         (rc = ensure(B.site_split, n_sites))) return rc;
     tick("site buffers");
     const isx_site *sites_sorted = in.sites;
-    if (!in.sites_ordered) {
+    const char *site_env = getenv("ISX_LINK_SITE_SORT");            // "rocprim": the device-wide sort also where the window table would do (check / A/B)
+    if (!in.sites_ordered && in.win_site_cnt && in.n_win > 0 && !(site_env && !strcmp(site_env, "rocprim"))) {
+        if ((rc = ensure(B.win_off, (size_t)in.n_win + 1)) || (rc = ensure(B.win_list, (size_t)in.n_win)) || (rc = ensure(B.n_runs, 2))) return rc;
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, in.win_site_cnt, B.win_off.p, (uint32_t)in.n_win, B.n_runs.p, (uint32_t *)nullptr, B.win_list.p, B.n_runs.p + 1);
+        hipLaunchKernelGGL(k_site_order, dim3(std::min<uint32_t>((uint32_t)in.n_win, 4096)), dim3(64), 0, s, in.sites, in.win_site_base, B.win_off.p, B.win_list.p,
+                           B.n_runs.p + 1, B.sites_sorted.p);
+        sites_sorted = B.sites_sorted.p;
+    } else if (!in.sites_ordered) {
         hipLaunchKernelGGL(k_site_keys, dim3((n_sites + 255) / 256), dim3(256), 0, s, in.sites, n_sites, B.site_keys.p);
         RP(rocprim::radix_sort_pairs(tp, tb, B.site_keys.p, B.site_keys2.p, const_cast<isx_site *>(in.sites),
                                      B.sites_sorted.p, n_sites, 0, 32, s));

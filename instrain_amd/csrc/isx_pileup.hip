@@ -2047,6 +2047,7 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
                     if (!fine) flag_or(a, ISX_FLAG_CAP_SNV);
                     if (any && fine) {
                         const uint32_t sa = cur_add(a, CUR_SITES, 1u);
+                        flag_or(a, ISX_FLAG_SITES_LOOSE);            // (outside the window's own range: the site table takes the device-wide sort)
                         slev_at = cur_add(a, CUR_SLEV, nlev);
                         if (sa >= a.cap_sites || slev_at + nlev > a.cap_slev) { flag_or(a, ISX_FLAG_CAP_SITES); fine = false; }
                         else {
@@ -2070,8 +2071,12 @@ __global__ void __launch_bounds__(1024) k_pileup_mm(const PileupArgs a_kernarg)
             my_entries += n_ent;                                    // per-workgroup total, published once at the end
         }
         if (tid == 64 && nrows) scratch[S_ROW_BASE] = cur_add(a, CUR_SNV, nrows);
-        if (tid == 128 && nsites) scratch[S_SITE_BASE] = cur_add(a, CUR_SITES, nsites);
-        if (tid == 192 && nao) scratch[S_AO_BASE] = cur_add(a, CUR_AO, nao);
+        if (tid == 128 % nthr) {
+            uint32_t sb = 0;
+            if (nsites) { sb = cur_add(a, CUR_SITES, nsites); scratch[S_SITE_BASE] = sb; }
+            if (a.win_site_cnt) { a.win_site_base[w] = sb; a.win_site_cnt[w] = nsites; }       // the window's sites lie side by side: k_site_order sorts window by window
+        }
+        if (tid == 192 % nthr && nao) scratch[S_AO_BASE] = cur_add(a, CUR_AO, nao);
         if (tid == 256 % nthr && nslev) scratch[S_SLEV_BASE] = cur_add(a, CUR_SLEV, nslev);
         // ---- deferred clonalities: calculate_clonality (snv_utilities.py:225-231) in fp64, densely packed ----
         const uint32_t nq = min(scratch[S_NQ], QCAP);

@@ -130,3 +130,21 @@ def test_batch_without_sites_or_pairs(ctx):
     w = synth.make_workload(genome_len=200_000, coverage=40, n_sites=20, err=0.0, seed=8, skip_mm=True, af_lo=0.3, af_hi=0.5)
     f, s = _run(ctx, w, 1)
     assert s["n_sites"] >= 15 and s["n_ld"] <= 2
+
+
+@pytest.mark.parametrize("cov,sites,glen", [(60, 1500, 200_000), (150, 2600, 4096)])
+def test_mm_site_table_in_position_order_without_a_sort(ctx, monkeypatch, cov, sites, glen):
+    """mm profiling on: k_pileup_mm records every window's range in the site table and k_site_order puts the table in position order window by
+    window (round 6) -- same rows as through the device-wide sort (ISX_LINK_SITE_SORT=rocprim).  Second case: SNP sites at more than half of the
+    positions of a window -- beyond the kernel's row queue, some sites are allocated outside their window's range and the batch takes the sort
+    by itself (ISX_FLAG_SITES_LOOSE)"""
+    from instrain_amd import synth
+    w = synth.make_workload(genome_len=glen, coverage=cov, n_sites=sites, seed=13, skip_mm=False, af_lo=0.3, af_hi=0.5)
+    M = int(w["obs"]["mm"].max()) + 1
+    got = _run(ctx, w, M)
+    monkeypatch.setenv("ISX_LINK_SITE_SORT", "rocprim")
+    exp = _run(ctx, w, M)
+    _same(got, exp, "window table vs sort")
+    assert exp[1]["n_ld"] > 500 and exp[1]["n_sites"] > 0.5 * sites
+    e = got[0]["entries"] if "entries" in got[0] else None
+    assert e is None or e.tobytes() == exp[0]["entries"].tobytes()
