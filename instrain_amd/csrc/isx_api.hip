@@ -291,6 +291,37 @@ hipError_t isx_copy_rows_to_host(void *hdst, const void *dsrc, const uint32_t *d
     return hipGetLastError();
 }
 
+// several tables of one batch to pinned host memory in ONE launch (a small batch's level tables: mask, window offsets, coverage bytes, lists)
+namespace {
+struct CopyJobs { uint4 *dst[ISX_COPY_JOBS]; const uint4 *src[ISX_COPY_JOBS]; uint32_t n16[ISX_COPY_JOBS]; uint32_t first[ISX_COPY_JOBS + 1]; int n; };
+__global__ void __launch_bounds__(256) k_copy_multi(const CopyJobs J)
+{
+    int j = 0;
+    while (j + 1 < J.n && blockIdx.x >= J.first[j + 1]) j++;
+    const uint32_t nb = J.first[j + 1] - J.first[j], lb = blockIdx.x - J.first[j];
+    for (uint32_t i = lb * 256u + threadIdx.x; i < J.n16[j]; i += nb * 256u) J.dst[j][i] = J.src[j][i];
+}
+}  // namespace
+
+hipError_t isx_copy_multi_to_host(const isx_copy_job *jobs, int n, hipStream_t stream)
+{
+    CopyJobs J{};
+    uint32_t blocks = 0;
+    for (int i = 0; i < n && J.n < ISX_COPY_JOBS; i++) {
+        if (!jobs[i].bytes) continue;
+        if (((reinterpret_cast<uintptr_t>(jobs[i].dst) | reinterpret_cast<uintptr_t>(jobs[i].src)) & 15) != 0 || jobs[i].bytes > ((size_t)1 << 35)) return hipErrorInvalidValue;
+        const uint32_t n16 = (uint32_t)((jobs[i].bytes + 15) / 16);         // (whole 16-byte pieces: both ends have the room)
+        J.dst[J.n] = static_cast<uint4 *>(jobs[i].dst); J.src[J.n] = static_cast<const uint4 *>(jobs[i].src); J.n16[J.n] = n16;
+        J.first[J.n] = blocks;
+        blocks += std::max<uint32_t>(1, std::min<uint32_t>(64, (n16 + 1023) / 1024));
+        J.n++;
+    }
+    if (!J.n) return hipSuccess;
+    J.first[J.n] = blocks;
+    hipLaunchKernelGGL(k_copy_multi, dim3(blocks), dim3(256), 0, stream, J);
+    return hipGetLastError();
+}
+
 namespace {
 struct ReadBack {
     uint8_t *pin = nullptr;

@@ -44,6 +44,10 @@ void isx_dev_trim();        // both caches
 // megabytes into host memory fills the memory system's queues with PCIe writes, and every other kernel's HBM traffic and the copy-in
 // DMA wait behind them (round 4: whole-database pass 100 -> 66 ms).
 hipError_t isx_copy_to_host(void *hdst_pinned, const void *dsrc, size_t bytes, hipStream_t stream);
+// up to ISX_COPY_JOBS tables to pinned host memory in one launch (16-byte aligned both ends; the last piece is copied whole: both sides have the room)
+#define ISX_COPY_JOBS 8
+struct isx_copy_job { void *dst; const void *src; size_t bytes; };
+hipError_t isx_copy_multi_to_host(const isx_copy_job *jobs, int n, hipStream_t stream);
 // the same with the route given: by_kernel = the copy kernels whatever the size (what a small batch hands back, isx_pipe.hip's level tables)
 hipError_t isx_copy_to_host_route(void *hdst_pinned, const void *dsrc, size_t bytes, hipStream_t stream, bool by_kernel);
 // Small read-backs into ANY host memory (table sizes, the last element of a scan, a few hundred rows): the same kernel route

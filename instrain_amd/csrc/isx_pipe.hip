@@ -695,13 +695,14 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         // a small batch's tables (a C2 batch: 5 + 12 MB) leave by copy kernel, not by DMA: see isx_copy_to_host_route
         static const size_t lev_kernel_max = [] { const char *e = getenv("ISX_LEV_KERNEL_MAX"); return e ? (size_t)atoll(e) : (size_t)32 << 20; }();
         const bool lev_by_kernel = s.out_pinned && (size_t)b->n_pos * b->lev_mask_bytes + cov_bytes + clon_bytes + rare_bytes <= lev_kernel_max;
+        std::vector<isx_copy_job> jobs;                             // (lev_by_kernel: all of the batch's tables in one launch)
         auto fetch_lev = [&](void *hdst, const void *dsrc, size_t bytes) -> int {
-            if (!lev_by_kernel) return fetch(hdst, dsrc, bytes);
-            HIP_TRY(isx_copy_to_host_route(hdst, dsrc, bytes, sfin, true));
+            if (!lev_by_kernel || ((reinterpret_cast<uintptr_t>(hdst) | reinterpret_cast<uintptr_t>(dsrc)) & 15)) return fetch(hdst, dsrc, bytes);
+            jobs.push_back(isx_copy_job{hdst, dsrc, bytes});
             return ISX_OK;
         };
         if ((rc = fetch_lev(s.h_out + s.o_lmask, b->d_lev_mask, (size_t)b->n_pos * b->lev_mask_bytes)) != ISX_OK) return rc;
-        if ((rc = fetch(s.h_out + s.o_lwin, b->d_lev_win_off, (size_t)b->n_win * sizeof(uint32_t))) != ISX_OK) return rc;
+        if ((rc = fetch_lev(s.h_out + s.o_lwin, b->d_lev_win_off, (size_t)b->n_win * sizeof(uint32_t))) != ISX_OK) return rc;
         // what outgrows its pinned room (a deep sample's clonTR list, a coverage stream of more than four levels a position): plain vectors
         auto fetch_or_big = [&](size_t off, size_t room, auto &big, const void *dsrc, size_t bytes) -> int {
             big.clear();
@@ -714,10 +715,10 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         if ((rc = fetch_or_big(s.o_lcov, s.lcov_room, s.lcov_big, b->d_lev_cov, cov_bytes)) != ISX_OK) return rc;
         if ((rc = fetch_or_big(s.o_lclon, s.lclon_room, s.lclon_big, b->d_clon_list, clon_bytes)) != ISX_OK) return rc;
         if (rare_bytes && (rc = fetch_or_big(s.o_lrare, s.lrare_room, s.lrare_big, b->d_rare, rare_bytes)) != ISX_OK) return rc;
+        if (!jobs.empty()) HIP_TRY(isx_copy_multi_to_host(jobs.data(), (int)jobs.size(), sfin));
         s.sat_rows.resize((size_t)b->n_sat);
         if (!s.sat_rows.empty()) HIP_TRY(isx_read_back(s.sat_rows.data(), b->d_sat, s.sat_rows.size() * sizeof(isx_sat), sfin));
-        HIP_TRY(isx_read_sync(sfin));
-        HIP_TRY(isx_wait_stream(sfin));
+        // (no wait here: the linkage stages below end with the one wait that also covers these copies)
         s.d2h_bytes += (int64_t)((size_t)b->n_pos * b->lev_mask_bytes + (size_t)b->n_win * 4 + cov_bytes + clon_bytes + rare_bytes + s.sat_rows.size() * sizeof(isx_sat));
     }
     // the linkage stages, on this finisher's queue behind the copies above; the bucket chain's one read-back is the wait for all of it
