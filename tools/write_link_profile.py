@@ -71,6 +71,6 @@ if mm:
     tot = sum(int(r['Calls']) for r in rows)
     with open('profiles/%s_link_chain.md' % tag, 'a') as o:
         o.write('\n## The default mode (mm profiling on, linkage on) as a stream: launches per batch\n\n`tools/mm_launch_prof.sh` (`rocprofv3 --kernel-trace --stats -- python tools/mm_launch_count.py %d`).\n' % nb)
-        o.write('%s\n\n**%d launches / %d batches = %.1f a batch** (29.4 while the site table of `k_pileup_mm` went through a device-wide sort in front of the chain; `k_site_order` puts it in position order window by window now -- 22.4 -- and one copy launch takes a small batch's level tables home).\n\n' % ('\n'.join(head), tot, nb, tot / nb))
+        o.write('%s\n\n**%d launches / %d batches = %.1f a batch** (29.4 while the site table of `k_pileup_mm` went through a device-wide sort in front of the chain; `k_site_order` puts it in position order window by window now -- 22.4 -- and one copy launch takes the level tables of a small batch home).\n\n' % ('\n'.join(head), tot, nb, tot / nb))
         o.write(table(rows, top=30) + '\n')
 print('profiles/%s_link_chain.md' % tag)
