@@ -1391,8 +1391,14 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
         // the records leave as soon as they exist; the window directory below is made while they travel
         const size_t gb_bytes0 = (size_t)(J.n_rec / (int64_t)p->G) * sizeof(uint32_t), rec_bytes0 = (size_t)J.n_rec * (size_t)p->rb;
         HIP_TRY(hipEventRecord(s.ev_h2db, H2D(p, s)));
-        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes0, hipMemcpyHostToDevice, H2D(p, s)));
-        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes0, hipMemcpyHostToDevice, H2D(p, s)));
+        if (s.off_pairs == s.off_rec && s.off_ridx == s.off_rec && s.off_rec - s.off_gbase < ((size_t)2 << 20)) {
+            // group bases | records lie side by side in both arenas (nothing between them in a pipe of reference-delta records): ONE copy --
+            // a small copy of its own is a blit kernel and a queue entry; the unused tail of the group bases' region (< 2 MB) travels along
+            HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, (s.off_rec - s.off_gbase) + rec_bytes0, hipMemcpyHostToDevice, H2D(p, s)));
+        } else {
+            HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes0, hipMemcpyHostToDevice, H2D(p, s)));
+            HIP_TRY(hipMemcpyAsync(s.d_in + s.off_rec, s.h_in + s.off_rec, rec_bytes0, hipMemcpyHostToDevice, H2D(p, s)));
+        }
         early_rec = true;
     }
     if (!planes_in) s.ref_has_n = pack_ref2(*p->pool, ref, n_pos, s.h_in + s.off_ref, s.h_in + s.off_ref + ref2_bytes(n_pos));
@@ -1453,8 +1459,12 @@ static int submit_segs_common(isx_pipe *p, int64_t n_pos, const uint8_t *ref, in
     const size_t head = (size_t)(n_splits + 1) * sizeof(int64_t) + s.win.size() * sizeof(uint2) + ref_bytes;
     const size_t gb_bytes = (size_t)(b->n_rec / p->G) * sizeof(uint32_t), rec_bytes = (size_t)b->n_rec * (size_t)p->rb;
     // bounds | windows | reference planes: what is used of each region, not the regions (a slot is sized for the largest batch)
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, H2D(p, s)));
-    HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, s.h_in + s.off_win, s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, H2D(p, s)));
+    if (s.off_win - s.off_bounds < ((size_t)1 << 20)) {          // bounds | windows in one copy (the bounds' region is a slot's max_splits: small)
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (s.off_win - s.off_bounds) + s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, H2D(p, s)));
+    } else {
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_bounds, s.h_in + s.off_bounds, (size_t)(n_splits + 1) * sizeof(int64_t), hipMemcpyHostToDevice, H2D(p, s)));
+        HIP_TRY(hipMemcpyAsync(s.d_in + s.off_win, s.h_in + s.off_win, s.win.size() * sizeof(uint2), hipMemcpyHostToDevice, H2D(p, s)));
+    }
     if (!early_ref) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_ref, s.h_in + s.off_ref, ref_bytes, hipMemcpyHostToDevice, H2D(p, s)));
     if (!early_rec) HIP_TRY(hipMemcpyAsync(s.d_in + s.off_gbase, s.h_in + s.off_gbase, gb_bytes, hipMemcpyHostToDevice, H2D(p, s)));
     if (ring) { if (ring_bytes != rec_bytes) { isx_set_error("internal: the staging ring did not carry the whole stream"); return ISX_ERR_STATE; } }
