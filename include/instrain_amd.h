@@ -640,7 +640,8 @@ int isx_pipe_set_reference_budget(isx_pipe *p, int64_t mib);
  * stager's time on a whole-database pass) whenever ref->plane2 (and ref->nplane, if given) lie inside a registered range.  The planes still travel
  * with every batch (unlike isx_ref_planes.key, which keeps them on the device).  The memory must stay valid and registered until every batch that
  * was submitted with it has been collected; isx_host_unregister before freeing it.  ISX_ERR_HIP when the range cannot be pinned (RLIMIT_MEMLOCK),
- * ISX_ERR_ARG for a range that overlaps a registered one / was never registered.  Thread-safe. */
+ * ISX_ERR_ARG for a range that shares a page with a registered one (pinning works on pages: give every registered array pages of its own) / was
+ * never registered.  Thread-safe. */
 int isx_host_register(const void *ptr, int64_t bytes);
 int isx_host_unregister(const void *ptr);
 /* the stager on its own (no GPU needed), like isx_encode_delta: planes + reference planes -> 32-byte reference-delta records */

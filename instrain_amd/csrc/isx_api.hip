@@ -187,9 +187,13 @@ extern "C" int isx_host_register(const void *ptr, int64_t bytes)
 {
     if (!ptr || bytes <= 0) { isx_set_error("isx_host_register: bad argument"); return ISX_ERR_ARG; }
     const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    // pinning works on pages: two registrations must not share one (the runtime's answer to that is not an error code one can rely on)
+    const uintptr_t pa = a & ~(uintptr_t)4095, pe = (a + (size_t)bytes + 4095) & ~(uintptr_t)4095;
     std::lock_guard<std::mutex> lk(g_hreg_mu);
-    for (const HostRange &r : g_hreg)
-        if (a < r.a + r.n && r.a < a + (size_t)bytes) { isx_set_error("isx_host_register: the range overlaps a registered one"); return ISX_ERR_ARG; }
+    for (const HostRange &r : g_hreg) {
+        const uintptr_t ra = r.a & ~(uintptr_t)4095, re = (r.a + r.n + 4095) & ~(uintptr_t)4095;
+        if (pa < re && ra < pe) { isx_set_error("isx_host_register: the range shares a page with a registered one"); return ISX_ERR_ARG; }
+    }
     HIP_TRY(hipHostRegister(const_cast<void *>(ptr), (size_t)bytes, hipHostRegisterDefault));
     g_hreg.push_back(HostRange{a, (size_t)bytes});
     return ISX_OK;
@@ -328,11 +332,16 @@ struct ReadBack {
     size_t used = 0;
     struct Item { void *dst; size_t off, bytes; };
     std::vector<Item> items;
+    // batching (isx_read_batch): the copies of the pending items are launched together by isx_read_sync -- one kernel instead of one each
+    bool batching = false;
+    std::vector<isx_copy_job> jobs;
     static constexpr size_t CAP = (size_t)1 << 20;
     ~ReadBack() { if (pin) isx_pin_free(pin); }
 };
 thread_local ReadBack g_rb;
 }  // namespace
+
+void isx_read_batch(bool on) { g_rb.batching = on; }
 
 hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStream_t stream)
 {
@@ -340,13 +349,18 @@ hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStre
     ReadBack &rb = g_rb;
     if (!rb.pin && isx_pin_malloc(reinterpret_cast<void **>(&rb.pin), ReadBack::CAP) != hipSuccess) rb.pin = nullptr;
     const size_t off = (rb.used + 15) & ~(size_t)15;
-    if (!rb.pin || off + bytes > ReadBack::CAP) {
+    if (!rb.pin || off + ((bytes + 15) & ~(size_t)15) > ReadBack::CAP) {
         const hipError_t e = hipMemcpyAsync(host_dst, dsrc, bytes, hipMemcpyDeviceToHost, stream);
-        if (e != hipSuccess) { rb.items.clear(); rb.used = 0; }             // nothing may stay pending on a failing exit
+        if (e != hipSuccess) { rb.items.clear(); rb.jobs.clear(); rb.used = 0; }             // nothing may stay pending on a failing exit
         return e;
     }
-    const hipError_t e = isx_copy_to_host(rb.pin + off, dsrc, bytes, stream);
-    if (e != hipSuccess) { rb.items.clear(); rb.used = 0; return e; }      // (the caller returns without a sync: nothing may stay pending)
+    if (rb.batching && (reinterpret_cast<uintptr_t>(dsrc) & 15) == 0 && rb.jobs.size() < ISX_COPY_JOBS) {
+        // (the source must not change before isx_read_sync: the caller's promise when it turns batching on)
+        rb.jobs.push_back(isx_copy_job{rb.pin + off, dsrc, bytes});
+    } else {
+        const hipError_t e = isx_copy_to_host(rb.pin + off, dsrc, bytes, stream);
+        if (e != hipSuccess) { rb.items.clear(); rb.jobs.clear(); rb.used = 0; return e; }      // (the caller returns without a sync: nothing may stay pending)
+    }
     rb.items.push_back({host_dst, off, bytes});
     rb.used = off + bytes;
     return hipSuccess;
@@ -355,6 +369,8 @@ hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStre
 void isx_read_drop()
 {
     g_rb.items.clear();
+    g_rb.jobs.clear();
+    g_rb.batching = false;
     g_rb.used = 0;
 }
 
@@ -418,8 +434,10 @@ hipError_t isx_wait_stream(hipStream_t s)
 
 hipError_t isx_read_sync(hipStream_t stream)
 {
-    const hipError_t e = isx_wait_stream(stream);
     ReadBack &rb = g_rb;
+    hipError_t e = hipSuccess;
+    if (!rb.jobs.empty()) { e = isx_copy_multi_to_host(rb.jobs.data(), (int)rb.jobs.size(), stream); rb.jobs.clear(); }
+    if (e == hipSuccess) e = isx_wait_stream(stream);
     if (e == hipSuccess) for (const auto &it : rb.items) memcpy(it.dst, rb.pin + it.off, it.bytes);
     rb.items.clear();
     rb.used = 0;

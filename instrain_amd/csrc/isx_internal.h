@@ -63,6 +63,10 @@ hipError_t isx_copy_rows_to_host(void *hdst_pinned, const void *dsrc, const uint
 bool isx_host_is_registered(const void *ptr, size_t bytes);
 hipError_t isx_read_back(void *host_dst, const void *dsrc, size_t bytes, hipStream_t stream);
 hipError_t isx_read_sync(hipStream_t stream);
+// batching: between isx_read_batch(true) and the calling thread's next isx_read_sync the copies of isx_read_back are not launched one by one but
+// together, by that isx_read_sync (one kernel) -- for sources that do not change in between (a pipe's finisher: window lists, exact-coverage rows, the
+// linkage stages' state words + rows).  isx_read_batch(false) / isx_read_drop end it.
+void isx_read_batch(bool on);
 // waits that sleep between polls (isx_api.hip): what every host thread of the library waits for the device with
 hipError_t isx_wait_event(hipEvent_t e);
 hipError_t isx_wait_stream(hipStream_t s);

@@ -631,6 +631,10 @@ static int finish_slot(isx_pipe *p, Slot &s, hipStream_t sfin)
         HIP_TRY(isx_read_sync(sfin));
         return ISX_OK;
     };
+    // the small read-backs from here on (window lists, exact-coverage rows, the linkage stages' state words + rows) leave in ONE copy launch, made
+    // by the wait that delivers them: nothing writes their sources in between
+    // (an exit with read-backs still pending -- an error between a read-back and its wait -- forgets them: their destinations may not outlive this call)
+    struct ReadBatch { ReadBatch() { isx_read_batch(true); } ~ReadBatch() { isx_read_drop(); } } read_batch;
     auto fetch = [&](void *hdst, const void *dsrc, size_t bytes) -> int {
         if (!bytes) return ISX_OK;
         if (!s.out_pinned) return bounce_d2h(p, hdst, dsrc, bytes, sfin);

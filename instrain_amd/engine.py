@@ -54,6 +54,13 @@ def _aligned(shape, dtype, align=64):
     return raw[off:off + n].view(dtype).reshape(shape)
 
 
+def _own_pages(n_bytes):
+    """uninitialised uint8 array of n_bytes that starts on a page and shares its last page with nothing"""
+    raw = np.empty(((int(n_bytes) + 4095) // 4096 + 1) * 4096, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    return raw[off:off + int(n_bytes)]
+
+
 class PlaneBatch:
     """Read segments of a batch as bit planes (isx_read_planes): gpos u32 [n], len u8 [n], pair u32 [n] | None, planes u64 [n, 8] --
     words 0-4 the 2-bit base codes of the columns (A C T G = 0 1 2 3), words 5-7 the columns that are not observed.  One 64-byte line a
@@ -105,7 +112,8 @@ class RefPlanes:
     def from_codes(cls, ref_codes, threads=1, key=0):
         ref = np.ascontiguousarray(ref_codes, dtype=np.uint8)
         n = len(ref)
-        p2, pn = np.empty((n + 3) // 4, dtype=np.uint8), np.empty((n + 7) // 8, dtype=np.uint8)
+        # (whole pages of their own: the planes can be registered for the copy engine -- register() -- without sharing a page with anything else)
+        p2, pn = _own_pages((n + 3) // 4), _own_pages((n + 7) // 8)
         has = C.c_int32(0)
         check(_lib.load().isx_pack_ref_planes(ref.ctypes.data, n, int(threads), p2.ctypes.data, pn.ctypes.data, C.byref(has)))
         return cls(p2, pn if has.value else None, n, key)
