@@ -504,3 +504,46 @@ def test_c5_headline_configuration_exactly(monkeypatch):
     plain.release(t)
     plain.close()
     ctx.close()
+
+
+def test_c5_headline_whole_database_at_n1():
+    """The headline as the driver runs it at N = 1: ALL of the kept database through one GPU -- bench.C5Run(rank 0 of 1): its 25 batches, the
+    reference planes registered (isx_host_register), lean slots, reserve, depth 8.  bench.py's own untimed verify pass (every batch: coverage
+    sums to the observations handed over, SNV rows ordered and consistent, LD counts add up; the largest batch exact), then exact per-position
+    coverage from the host for five batches spread over the pass, then two passes exactly as they are timed, every batch compared with the
+    verified pass by row counts and the checksum of its SNV + LD bytes (the shard test above is one rank of eight)."""
+    import bench
+    from instrain_amd import engine
+    lut, fb = util.load_lut()
+    ctx5 = engine.Context(0, reserve_cus=bench.C5_RESERVE_CUS)
+    ctx5.set_null_model(lut, fb)
+    run = bench.C5Run(ctx5, 0, 1, 16, depth=8)
+    try:
+        assert 20 <= len(run.ws) <= 30 and 8.5e9 < run.bases < 10.5e9 and run.ref_registered == bench.REGISTER_REF
+        sig = run.verify_pass()
+        assert len(sig) == len(run.ws) and all(s[0] > 0 for s in sig)
+        pick = set(np.linspace(0, len(run.ws) - 1, 5).astype(int).tolist())
+        seen = []
+
+        def check(i, r):
+            if i not in pick:
+                return
+            w = run.ws[i]
+            exp = bench.planes_coverage(w)[0]
+            cov = engine.dense_cov(r, w["n_pos"]).astype(np.int64)
+            if "saturated" in r:
+                cov[r["saturated"]["gpos"]] = r["saturated"]["coverage"]
+            assert (cov == exp).all() and int(cov.sum()) == w["n_obs"]
+            g = r["snv"]["gpos"].astype(np.int64)
+            assert (np.diff(g) > 0).all() and (r["snv"]["cnt"].sum(axis=1) == cov[g]).all()
+            seen.append(i)
+
+        run.checked_pass(check, staged=False)
+        assert sorted(seen) == sorted(pick)
+        stats = []
+        run.run(2, stats)
+        assert len(stats) == 2 * len(run.ws)
+        run.check_timed(stats)
+    finally:
+        run.close()
+        ctx5.close()
