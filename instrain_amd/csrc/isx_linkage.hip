@@ -541,6 +541,7 @@ __global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucn
     __shared__ unsigned long long tk[LK_SLOTS];
     __shared__ uint32_t tc[LK_SLOTS];
     __shared__ uint2 stage[LK_STAGE];
+    __shared__ unsigned long long cmp[64];
     const uint32_t l = threadIdx.x;
     if (state[LS_FLAGS] & LKF_KEYS) return;
     const uint32_t n_list = state[LS_NLIST1];
@@ -600,6 +601,33 @@ __global__ void __launch_bounds__(64) k_site_edges(uint64_t *keys, uint32_t *ucn
             return;
         }
         __syncthreads();
+        if (nu <= 64 && n_b < (1u << 26)) {
+            // the few unique keys of a deep bucket (a C3 site: ~240 increments, ~40 keys): gathered from the table one to a lane as
+            // key << 26 | count, sorted in registers -- no barrier per sorting step, no in-place compaction
+            uint32_t cb = 0;
+            for (uint32_t r = 0; r < slots; r += 64) {
+                const unsigned long long k = tk[r + l];
+                const bool valid = k != LK_EMPTY;
+                const unsigned long long bal = __ballot(valid);
+                if (valid) cmp[cb + (uint32_t)__popcll(bal & ((1ull << l) - 1ull))] = (k << 26) | tc[r + l];
+                cb += (uint32_t)__popcll(bal);
+            }
+            __syncthreads();
+            uint64_t v = l < nu ? cmp[l] : LK_EMPTY;
+            v = lk_sort_in_groups<64>(v, l);
+            const bool valid = l < nu;                              // (the padding sorts behind every key)
+            const uint64_t k = v >> 26;
+            const uint64_t pk = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(k >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)k, 1);
+            const bool head = valid && (l == 0 || (pk >> 12) != (k >> 12));
+            if (valid) { keys[off + l] = k; ucnt[off + l] = (uint32_t)(v & ((1u << 26) - 1u)); rows_per[off + l] = 0; }
+            const unsigned long long hb = __ballot(head);
+            if (n_stage + (uint32_t)__popcll(hb) > LK_STAGE) lk_flush(stage, n_stage, edge_list, state, l);
+            if (head) stage[n_stage + (uint32_t)__popcll(hb & ((1ull << l) - 1ull))] = make_uint2(s1, l);
+            n_stage += (uint32_t)__popcll(hb);
+            if (l == 0) site_nu[s1] = nu;
+            nu_sum += nu;
+            continue;
+        }
         // compact in place (the write cursor never passes the slots being read), pad to a power of two, bitonic sort by key
         uint32_t base = 0;
         for (uint32_t r = 0; r < slots; r += 64) {
